@@ -1,0 +1,337 @@
+/*
+ * vvr.h — C ABI of the MI355X-native VVC reconstruction back-end ("vvr" = VVC reconstruction).
+ *
+ * This is the drop-in boundary for the reconstruction stage of VVdeC.  It replaces the inner seam
+ *     DecLibRecon::create / destroy / decompressPicture / waitForPrevDecompressedPic / getCurrPic
+ *     (reference: source/Lib/DecoderLib/DecLibRecon.h:143-200, called only from DecLib::reconPicture and
+ *      DecLib::blockAndFinishPictures, source/Lib/DecoderLib/DecLib.cpp:612-655)
+ * with plain-C entry points: plain pointers and sizes, status codes instead of exceptions, no C++/torch types.
+ *
+ * Contract on entry of vvr_submit (mirrors the contract on entry of decompressPicture):
+ *   - the host parser has produced, for one picture, the per-CTU / per-CU / per-TU mode records, the quantised
+ *     coefficient levels (reference: written by CABACReader.cpp:2457-2478 into the reco plane; here: a packed
+ *     int16 stream, only the [0..maxScanPosX] x [0..maxScanPosY] corner of every coded transform block),
+ *     the final motion field after MV derivation ("MIDER", DecCu.cpp:62/720 — stays on the host), and the
+ *     deblocking edge parameters (LoopFilter::calcFilterStrengthsCTU, LoopFilter.cpp:360/495 — stays on the host);
+ *   - reference pictures are identified by DPB slot numbers owned by this context.
+ * Contract on exit of vvr_wait: the three planes of the output slot hold the final (post deblock/SAO/ALF) samples,
+ *   identical to the reference decoder's output for the same records (VVC is an integer specification).
+ *
+ * All structs are little-endian PODs with fixed layout; arrays are struct-of-arrays per picture.
+ * Coordinates are in LUMA samples unless a field says otherwise.  Only 4:2:0 and 4:0:0 are accepted in this version.
+ */
+#ifndef VVR_H
+#define VVR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define VVR_API __attribute__((visibility("default")))
+#else
+#define VVR_API
+#endif
+
+#define VVR_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * status codes (negative = error; mirrors the style of vvdecErrorCodes, include/vvdec/vvdec.h.in:91-105)
+ * ---------------------------------------------------------------------------------------------------------------- */
+enum {
+  VVR_OK               = 0,
+  VVR_ERR_UNSPECIFIED  = -1,
+  VVR_ERR_PARAMETER    = -2,   /* inconsistent picture description                                  */
+  VVR_ERR_UNSUPPORTED  = -3,   /* a coding tool / format this build does not reconstruct            */
+  VVR_ERR_DEVICE       = -4,   /* HIP runtime error (message via vvr_last_error)                    */
+  VVR_ERR_NO_DEVICE    = -5,   /* no usable gfx950 device: the back-end never falls back to the CPU */
+  VVR_ERR_BUSY         = -6,   /* DPB slot still in use / too many pictures in flight               */
+};
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * picture-level description
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define VVR_MAX_REFS      16
+#define VVR_MAX_ALF_APS    8
+#define VVR_ALF_CLASSES   25
+#define VVR_ALF_LUMA_TAPS 13   /* 12 symmetric taps + centre (centre entry unused)   */
+#define VVR_ALF_CHR_TAPS   7   /*  6 symmetric taps + centre                         */
+#define VVR_ALF_MAX_CHR_ALT 8
+#define VVR_CCALF_FILTERS  4
+#define VVR_CCALF_TAPS     7   /* MAX_NUM_CC_ALF_CHROMA_COEFF - 1 signalled taps + pad */
+
+/* tool_flags */
+enum {
+  VVR_TOOL_SAO_LUMA     = 1u << 0,   /* slice_sao_luma_flag                                        */
+  VVR_TOOL_SAO_CHROMA   = 1u << 1,
+  VVR_TOOL_ALF          = 1u << 2,   /* sps ALF on and at least one component enabled in the slice */
+  VVR_TOOL_CCALF        = 1u << 3,
+  VVR_TOOL_LMCS         = 1u << 4,   /* slice LMCS enabled (luma mapping)                          */
+  VVR_TOOL_LMCS_CSCALE  = 1u << 5,   /* chroma residual scaling                                    */
+  VVR_TOOL_DEBLOCK_OFF  = 1u << 6,   /* deblocking disabled for the picture                        */
+  VVR_TOOL_DEP_QUANT    = 1u << 7,
+  VVR_TOOL_BDOF         = 1u << 8,   /* sps BDOF on and not disabled in the picture header         */
+  VVR_TOOL_DMVR         = 1u << 9,
+  VVR_TOOL_PROF         = 1u << 10,
+  VVR_TOOL_JCCR_SIGN    = 1u << 11,  /* ph_joint_cbcr_sign_flag                                    */
+  VVR_TOOL_STILL_REF    = 1u << 12,  /* picture is still referenced: DMVR refined MVs are returned */
+  VVR_TOOL_LFNST        = 1u << 13,  /* sps LFNST on (TrQuant.cpp:301)                              */
+  VVR_TOOL_MTS          = 1u << 14,  /* sps MTS on (explicit+implicit selection resolved per TU)    */
+};
+
+typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::reconstructCoeff (AdaptiveLoopFilter.cpp:888) stays on the host */
+  int16_t luma_coeff[VVR_MAX_ALF_APS][VVR_ALF_CLASSES][VVR_ALF_LUMA_TAPS];   /* un-transposed, per class                 */
+  int16_t luma_clip [VVR_MAX_ALF_APS][VVR_ALF_CLASSES][VVR_ALF_LUMA_TAPS];   /* clipping VALUES (m_alfClippVls resolved)  */
+  int16_t chroma_coeff[VVR_ALF_MAX_CHR_ALT][VVR_ALF_CHR_TAPS];               /* per alternative (shared by Cb and Cr)     */
+  int16_t chroma_clip [VVR_ALF_MAX_CHR_ALT][VVR_ALF_CHR_TAPS];
+  int16_t ccalf_coeff[2][VVR_CCALF_FILTERS][VVR_CCALF_TAPS + 1];
+  uint8_t num_luma_aps;             /* alfCtbFilterIndex >= 16 selects luma_coeff[idx-16]                                  */
+  uint8_t pad[7];
+} vvr_alf_params;
+
+typedef struct vvr_lmcs_params {    /* Reshape::constructReshaper (Reshape.cpp:318) stays on the host */
+  int16_t fwd_lut[1024 * 4];        /* forward map, 1 << bit_depth entries used  */
+  int16_t inv_lut[1024 * 4];        /* inverse map                               */
+  int16_t chroma_scale[16];         /* m_chromaAdjHelpLUT                         */
+  int16_t pivot[17];                /* m_reshapePivot (input pivots of inverse)   */
+  int16_t pad[7];
+} vvr_lmcs_params;
+
+typedef struct vvr_pic_header {
+  uint32_t abi_version;             /* VVR_ABI_VERSION                                                  */
+  uint32_t tool_flags;              /* VVR_TOOL_*                                                       */
+  uint16_t width, height;           /* luma samples                                                     */
+  uint8_t  chroma_format;           /* 0 = 4:0:0, 1 = 4:2:0                                             */
+  uint8_t  bit_depth;               /* 8..12                                                            */
+  uint8_t  log2_ctu;                /* 5..7                                                             */
+  uint8_t  slice_type;              /* 0 B, 1 P, 2 I  (SliceType, CommonDef.h)                          */
+  int32_t  poc;
+  int16_t  out_slot;                /* DPB slot that receives the reconstruction                        */
+  int8_t   num_ref[2];
+  int16_t  ref_slot[2][VVR_MAX_REFS];
+  int32_t  ref_poc [2][VVR_MAX_REFS];
+  int8_t   deblock_beta_offset_div2[3];   /* Y, Cb, Cr (LoopFilter.cpp:1473,1637)                       */
+  int8_t   deblock_tc_offset_div2[3];
+  uint8_t  log2_sao_offset_scale[2];      /* luma, chroma                                               */
+  int8_t   min_qp_ts;               /* 4 + 6*internalMinusInputBitDepth (Quant.cpp:104)                  */
+  uint8_t  pad[7];
+} vvr_pic_header;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * coding unit  (source of each field: CodingUnit, source/Lib/CommonLib/Unit.h:314-420)
+ * ---------------------------------------------------------------------------------------------------------------- */
+enum { VVR_PRED_INTER = 0, VVR_PRED_INTRA = 1, VVR_PRED_IBC = 2 };
+enum { VVR_TREE_JOINT = 0, VVR_TREE_LUMA = 1, VVR_TREE_CHROMA = 2 };   /* which components the CU carries */
+
+/* cu.flags */
+enum {
+  VVR_CU_ROOT_CBF   = 1u << 0,
+  VVR_CU_SKIP       = 1u << 1,
+  VVR_CU_MERGE      = 1u << 2,
+  VVR_CU_AFFINE     = 1u << 3,
+  VVR_CU_AFFINE_6P  = 1u << 4,
+  VVR_CU_CIIP       = 1u << 5,
+  VVR_CU_GEO        = 1u << 6,
+  VVR_CU_SBTMVP     = 1u << 7,   /* mergeType == MRG_TYPE_SUBPU_ATMVP                                       */
+  VVR_CU_MIP        = 1u << 8,
+  VVR_CU_MIP_TRANSP = 1u << 9,
+  VVR_CU_SMVD       = 1u << 10,
+  VVR_CU_MMVD       = 1u << 11,
+};
+
+/* cu.mc_mode: the branch InterPrediction::motionCompensation (InterPrediction.cpp:1372-1459) takes for this CU.
+ * Resolving it needs POCs/flags only and is done once per CU by the host glue (vvr_resolve_mc_mode below). */
+enum {
+  VVR_MC_NONE = 0,
+  VVR_MC_UNI,          /* one list, or identical-motion shortcut (xCheckIdenticalMotion, :404)          */
+  VVR_MC_BI,           /* xPredInterBi: two lists + addAvg / BCW                                        */
+  VVR_MC_BDOF,         /* xSubPuBio (:551)                                                              */
+  VVR_MC_DMVR,         /* xProcessDMVR (:1847), BDOF decided per sub-block                              */
+  VVR_MC_DMVR_BDOF,
+  VVR_MC_AFFINE,       /* xPredAffineBlk (:934) (+PROF)                                                 */
+  VVR_MC_SBTMVP,       /* xSubPuMC (:438)                                                               */
+  VVR_MC_GEO,          /* motionCompensationGeo (:1461)                                                 */
+};
+
+typedef struct vvr_cu {
+  uint16_t x, y;                 /* luma position                                                            */
+  uint8_t  w, h;                 /* luma size (chroma-tree CU: luma-equivalent area)                         */
+  uint8_t  tree;                 /* VVR_TREE_*                                                               */
+  uint8_t  pred_mode;            /* VVR_PRED_*                                                               */
+  uint16_t flags;                /* VVR_CU_*                                                                 */
+  int8_t   qp;                   /* cu.qp (luma QP without QpBdOffset)                                       */
+  uint8_t  mc_mode;              /* VVR_MC_*                                                                 */
+  /* intra */
+  uint8_t  intra_dir[2];         /* FINAL modes (PU::getFinalIntraMode, UnitTools.cpp:587): 0 planar, 1 DC, 2..66, 67..69 LM/MDLM_L/MDLM_T; MIP: mode id */
+  uint8_t  multi_ref_idx;        /* 0..2                                                                     */
+  uint8_t  isp_mode;             /* 0 none, 1 HOR_INTRA_SUBPARTITIONS, 2 VER                                  */
+  uint8_t  bdpcm[2];             /* luma, chroma: 0 off, 1 hor, 2 ver                                        */
+  uint8_t  lfnst_idx;            /* 0..2                                                                     */
+  uint8_t  sbt_info;             /* CodingUnit::_sbtInfo                                                     */
+  /* inter */
+  uint8_t  inter_dir;            /* 1 L0, 2 L1, 3 bi                                                         */
+  int8_t   ref_idx[2];           /* -1 = unused                                                              */
+  uint8_t  bcw_idx;              /* 0..4, BCW_DEFAULT = 2                                                    */
+  uint8_t  imv;                  /* 3 = IMV_HPEL selects the alternative half-pel filter                     */
+  uint8_t  geo_split_dir;
+  uint8_t  geo_dir_ref[2];       /* interDirrefIdxGeo0/1 packing is resolved: [i] = (list << 4) | refIdx     */
+  uint8_t  ciip_neigh_intra;     /* bit0: above neighbour intra, bit1: left neighbour intra (IntraPrediction.cpp:917-927) */
+  uint8_t  lfnst_intra_mode;     /* intra mode used for LFNST set selection before wide-angle remap (TrQuant.cpp:213-221) */
+  uint8_t  pad0[2];
+  int32_t  mv[2][3][2];          /* [list][cpmv idx][hor,ver], 1/16 luma sample; [l][0] for translational     */
+  int32_t  geo_mv[2][2];         /* GPM: the two uni-prediction MVs                                           */
+  uint32_t first_tu, num_tu;     /* range in the TU array (decode order)                                     */
+  uint32_t dmvr_off;             /* first entry of this CU in the DMVR delta-MV output array                 */
+  uint32_t pad1;
+} vvr_cu;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * transform unit  (TransformUnit, Unit.h:285-304)
+ * ---------------------------------------------------------------------------------------------------------------- */
+enum { VVR_MTS_DCT2 = 0, VVR_MTS_SKIP = 1, VVR_MTS_DST7_DST7 = 2, VVR_MTS_DCT8_DST7 = 3, VVR_MTS_DST7_DCT8 = 4, VVR_MTS_DCT8_DCT8 = 5 };
+
+typedef struct vvr_tu {
+  uint16_t x, y;                 /* luma position                                                            */
+  uint8_t  w, h;                 /* luma size (chroma block = w/2 x h/2 for 4:2:0)                            */
+  uint8_t  comp_mask;            /* bit c set: block of component c exists in this TU (dual tree / ISP)       */
+  uint8_t  cbf;                  /* bit c: coded block flag of component c                                    */
+  uint8_t  joint_cbcr;           /* 0 or jointCbCr mask (1,2,3)                                               */
+  uint8_t  mts_idx[3];           /* VVR_MTS_* per component                                                   */
+  uint8_t  max_scan_x[3];        /* last significant column per component (TransformUnit::maxScanPosX)       */
+  uint8_t  max_scan_y[3];
+  int8_t   qp[3];                /* QpParam::Qps[0] per component incl. QpBdOffset (Quant.cpp:65-101);        */
+                                 /* for a joint-CbCr TU qp[1]/qp[2] hold the joint QP where ICT mode == 2     */
+  uint8_t  tr_type[3];           /* (trTypeVer << 2) | trTypeHor with 0 DCT2, 1 DCT8, 2 DST7                   */
+                                 /* = TrQuant::getTrTypes (TrQuant.cpp:330-407), resolved by the host glue     */
+  uint8_t  pad0;
+  uint32_t coef_off[3];          /* offset (int16 units) of this block's level corner in the coefficient stream */
+  uint32_t cu;                   /* owning CU                                                                  */
+} vvr_tu;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * per-4x4 side tables (picture raster order, stride = ceil(width/4))
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct vvr_motion {      /* MotionInfo, MotionInfo.h:122 */
+  int32_t mv[2][2];              /* [list][hor,ver]                                                            */
+  int8_t  ref_idx[2];            /* -1 unused (MI_NOT_VALID for intra)                                         */
+  uint8_t pad[2];
+} vvr_motion;
+
+typedef struct vvr_lfp {         /* LoopFilterParam, TypeDef.h:694-707; semantics SURVEY.md Appendix D         */
+  int8_t  qp[3];
+  uint8_t bs;                    /* 2 bits per component                                                       */
+  uint8_t side_max_filt_length;  /* [6:4] P, [2:0] Q, bit 7 transform edge                                     */
+  uint8_t flags;                 /* bit0 filterEdge luma, bit1 filterEdge chroma, bit5 chroma large block      */
+  uint8_t pad[2];
+} vvr_lfp;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * per-CTU loop filter controls
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct vvr_sao_ctu {     /* SAOBlkParam after reconstructBlkSAOParam (merge resolved, offsets scaled)   */
+  uint8_t mode[3];               /* 0 off, 1 on                                                                */
+  uint8_t type[3];               /* 0 EO_0, 1 EO_90, 2 EO_135, 3 EO_45, 4 BO                                    */
+  uint8_t band_pos[3];           /* BO: first band                                                             */
+  int8_t  offset[3][4];          /* EO: classes {valley, half-valley, half-peak, peak}; BO: 4 consecutive bands */
+  uint8_t pad[3];
+} vvr_sao_ctu;
+
+typedef struct vvr_alf_ctu {     /* CtuAlfData, CodingStructure.h:75 */
+  uint8_t cc_idc[2];             /* 0 off, else filter index + 1                                               */
+  uint8_t enable[3];
+  uint8_t alt[2];                /* chroma alternative                                                         */
+  uint8_t pad;
+  int16_t luma_filter_idx;       /* < 16: fixed set, else APS idx - 16                                         */
+  uint8_t pad2[2];
+} vvr_alf_ctu;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * one picture to reconstruct
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct vvr_picture {
+  vvr_pic_header        hdr;
+  uint32_t              num_cu, num_tu;
+  const vvr_cu*         cu;            /* decode order (CTU raster, z-scan inside the CTU)                      */
+  const vvr_tu*         tu;
+  const uint32_t*       ctu_first_cu;  /* [num_ctu + 1] first CU of every CTU                                    */
+  const int16_t*        coef;          /* packed quantised levels                                               */
+  uint64_t              num_coef;
+  const vvr_motion*     motion;        /* [h4][w4], may be NULL for intra pictures                               */
+  const vvr_lfp*        lfp[2];        /* [EDGE_VER, EDGE_HOR][h4][w4]                                           */
+  const vvr_sao_ctu*    sao;           /* [num_ctu] or NULL                                                      */
+  const vvr_alf_ctu*    alf;           /* [num_ctu] or NULL                                                      */
+  const vvr_alf_params* alf_params;    /* NULL when ALF is off                                                   */
+  const vvr_lmcs_params* lmcs;         /* NULL when LMCS is off                                                  */
+  int                   resident;      /* 0: all array pointers are host memory (copied H2D by vvr_submit);      */
+                                       /* 1: all array pointers are DEVICE memory already resident in HBM        */
+} vvr_picture;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * context  (replaces DecLibRecon instances + the DPB picture buffers they write)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct vvr_config {
+  uint32_t abi_version;
+  int32_t  device;               /* HIP device ordinal                                                          */
+  uint16_t max_width, max_height;
+  uint8_t  chroma_format, bit_depth, log2_ctu;
+  uint8_t  num_slots;            /* DPB slots (pictures resident in HBM)                                        */
+  uint8_t  num_streams;          /* pictures reconstructing concurrently (reference: 2, DecLib.h:70)            */
+  uint8_t  pad[3];
+  void*    ext_planes;           /* optional: caller-owned device memory for the DPB, num_slots * vvr_slot_bytes */
+                                 /* (mirrors vvdec_decoder_open_with_allocator, vvdec.h.in:576)                 */
+} vvr_config;
+
+typedef struct vvr_context vvr_context;
+
+/* DecLibRecon::create (DecLibRecon.cpp:132): HIP streams/events, constant tables, DPB planes. */
+VVR_API int          vvr_create(const vvr_config* cfg, vvr_context** out);
+/* DecLibRecon::destroy */
+VVR_API void         vvr_destroy(vvr_context* ctx);
+/* DecLibRecon::decompressPicture (DecLibRecon.cpp:429): asynchronous; returns a job id >= 0 or an error code. */
+VVR_API int          vvr_submit(vvr_context* ctx, const vvr_picture* pic);
+/* DecLibRecon::waitForPrevDecompressedPic (DecLibRecon.cpp:684): blocks until job `job` is reconstructed. */
+VVR_API int          vvr_wait(vvr_context* ctx, int job);
+/* wait for everything in flight */
+VVR_API int          vvr_sync(vvr_context* ctx);
+/* geometry of a DPB slot: byte size, and per-plane offset / stride (bytes) / rows */
+VVR_API size_t       vvr_slot_bytes(const vvr_config* cfg);
+VVR_API int          vvr_plane_layout(const vvr_context* ctx, int comp, size_t* offset, size_t* stride_bytes, int* width, int* height);
+/* device address of plane `comp` of `slot` (for zero-copy consumers, RCCL broadcast of reference pictures) */
+VVR_API void*        vvr_plane_ptr(vvr_context* ctx, int slot, int comp);
+/* vvdecFrame-style export (vvdecimpl.cpp:957 xAddPicture): copies plane `comp` of `slot` into a host buffer of 16-bit samples */
+VVR_API int          vvr_read_plane(vvr_context* ctx, int slot, int comp, uint16_t* dst, size_t dst_stride_samples);
+/* upload a reference picture produced elsewhere (another GPU / a test) into a slot */
+VVR_API int          vvr_write_plane(vvr_context* ctx, int slot, int comp, const uint16_t* src, size_t src_stride_samples);
+/* DMVR refined delta MVs of job (TaskFinishMotionInfo, DecCu.cpp:161): copies num_entries * 2 int32 */
+VVR_API int          vvr_read_dmvr(vvr_context* ctx, int job, int32_t* dst, size_t num_entries);
+/* upload the arrays of a picture description into HBM once; returns a description whose pointers are device
+ * pointers (resident = 1).  Used by the synthetic pre-parsed stream benchmark and by pipelined hosts. */
+VVR_API int          vvr_upload(vvr_context* ctx, const vvr_picture* host_pic, vvr_picture* dev_pic);
+VVR_API void         vvr_free_uploaded(vvr_context* ctx, vvr_picture* dev_pic);
+/* the HIP stream (hipStream_t) job `job` runs on, and the per-kernel timing of the last waited job (bench/profiling) */
+VVR_API void*        vvr_job_stream(vvr_context* ctx, int job);
+VVR_API const char*  vvr_last_error(const vvr_context* ctx);
+VVR_API const char*  vvr_version(void);
+
+/* kernel statistics accumulated with HIP events on the launch streams when enabled */
+typedef struct vvr_kernel_stat {
+  char     name[32];
+  uint64_t launches;
+  double   total_ms;
+  double   algo_bytes;           /* algorithmic bytes moved by these launches (SURVEY.md §8(d) model) */
+} vvr_kernel_stat;
+VVR_API int          vvr_enable_stats(vvr_context* ctx, int on);
+VVR_API int          vvr_get_stats(vvr_context* ctx, vvr_kernel_stat* out, int max_entries);
+
+/* Host glue helpers (pure functions, no device): what the reference computes per CU/TU on the CPU before the
+ * arithmetic starts.  They are part of the ABI so that the parser-side integration and the tests use one definition. */
+/* TrQuant::getTrTypes (TrQuant.cpp:330) -> (ver<<2)|hor */
+VVR_API uint8_t      vvr_resolve_tr_type(const vvr_pic_header* hdr, const vvr_cu* cu, const vvr_tu* tu, int comp, int implicit_mts, int explicit_mts_intra, int explicit_mts_inter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VVR_H */

@@ -1,0 +1,623 @@
+// oracle/ref_harness.cpp — TEST INFRASTRUCTURE.  Drives the *unmodified reference decoder classes* (compiled from
+// /root/reference by oracle/Makefile into oracle/_ref/) with a synthetic, pre-parsed picture description
+// (include/vvr.h).  It is the strongest parity pin available offline: no conformance bitstreams exist in this
+// container, but every reconstruction stage of the reference is callable on a hand-built
+// CodingStructure, exactly like DecLibRecon::ctuTask does (source/Lib/DecoderLib/DecLibRecon.cpp:732-1110):
+//
+//   TaskTrafoCtu -> TaskInterCtu -> TaskCriticalIntraKernel -> rspCtuBcw -> loopFilterCTU(VER) -> loopFilterCTU(HOR)
+//   -> SAOPrepareCTULine/SAOProcessCTU -> ALF prepareCTU/processCTU -> buffer swap
+//
+// run here as whole-picture passes in CTU raster order, which satisfies all neighbour-state preconditions of that
+// state machine.  The host-only stages (MIDER = MV derivation, and optionally LF_INIT = boundary-strength derivation)
+// are replaced by the motion field / edge-parameter tables carried in the description, because they are *inputs* of
+// the reconstruction stage.
+//
+// Nothing in the product (vvdec_amd/) links or loads this file.
+#include <sstream>
+#include <string>
+#include <vector>
+#include <memory>
+#include <mutex>
+#include <condition_variable>
+#include <thread>
+#include <atomic>
+#include <array>
+#include <list>
+#include <map>
+#include <functional>
+#include <iostream>
+#include <algorithm>
+#include <chrono>
+#include <exception>
+#include <unordered_map>
+#include <deque>
+#include <set>
+#include <iterator>
+#include <cstring>
+#include <cmath>
+#include <numeric>
+#include <limits>
+#define private public
+#define protected public
+#include "CommonLib/CommonDef.h"
+#include "CommonLib/Rom.h"
+#include "CommonLib/Slice.h"
+#include "CommonLib/Picture.h"
+#include "CommonLib/CodingStructure.h"
+#include "CommonLib/Unit.h"
+#include "CommonLib/UnitTools.h"
+#include "CommonLib/TrQuant.h"
+#include "CommonLib/InterPrediction.h"
+#include "CommonLib/IntraPrediction.h"
+#include "CommonLib/Reshape.h"
+#include "CommonLib/LoopFilter.h"
+#include "CommonLib/SampleAdaptiveOffset.h"
+#include "CommonLib/AdaptiveLoopFilter.h"
+#include "CommonLib/RdCost.h"
+#include "DecoderLib/DecCu.h"
+#include "CommonLib/TrQuant_EMT.h"
+#include "CommonLib/x86/CommonDefX86.h"
+#undef private
+#undef protected
+
+#include "../include/vvr.h"
+
+using namespace vvdec;
+
+extern "C" {
+
+// flags for vvref_reconstruct
+enum {
+  VVREF_SIMD            = 1,   // let the reference use its SSE4.1/AVX2 kernels (default: scalar "Core" = the specification)
+  VVREF_DERIVE_LFP      = 2,   // run LoopFilter::calcFilterStrengthsCTU and export its table instead of consuming pic->lfp
+  VVREF_STOP_AFTER_RECO = 4,   // output after INTRA stage (no in-loop filters)
+  VVREF_STOP_AFTER_DBK  = 8,
+  VVREF_STOP_AFTER_SAO  = 16,
+};
+
+static std::string g_err;
+__attribute__((visibility("default"))) const char* vvref_last_error() { return g_err.c_str(); }
+
+struct RefPicHolder { std::unique_ptr<Picture> pic; };
+
+static void fillPlane( PelBuf dst, const uint16_t* src, int w, int h )
+{
+  for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) dst.at( x, y ) = Pel( src[(size_t)y * w + x] );
+}
+
+// Builds everything and reconstructs one picture.
+//   ref_planes[slot*3+c]  : tightly packed (stride = plane width) 16-bit planes of the DPB slots the picture references
+//   out_planes[c]         : tightly packed output
+//   lfp_out[2]            : optional, receives the reference's own LoopFilterParam tables (picture raster 4x4 grid) when VVREF_DERIVE_LFP
+//   dmvr_out              : optional, receives m_dmvrMvCache entries (hor,ver) in CU order (cu.dmvr_off)
+//   stage_ms[8]           : optional wall time per stage {trafo+inter, intra, rsp, lf_v, lf_h, sao, alf, total}
+__attribute__((visibility("default")))
+int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes, uint16_t* const* out_planes,
+                       vvr_lfp* const* lfp_out, int32_t* dmvr_out, int flags, double* stage_ms )
+{
+  try
+  {
+    static bool romInit = false;
+    if( !romInit ) { initROM(); romInit = true; }
+
+    const vvr_pic_header& H = vp->hdr;
+    const bool enableOpt  = !!( flags & VVREF_SIMD );
+    // same switch as vvdecParams::simd (vvdecimpl.cpp:92-100): SCALAR keeps every function pointer on its "Core" version
+    read_x86_extension_flags( enableOpt ? x86_simd::UNDEFINED : x86_simd::SCALAR );
+    g_tCoeffOps = TCoeffOps();
+    const int  W = H.width, Hh = H.height;
+    const ChromaFormat cf = H.chroma_format == 0 ? CHROMA_400 : CHROMA_420;
+    const int  ctuSize = 1 << H.log2_ctu;
+    const int  bd = H.bit_depth;
+
+    // ------------------------------------------------------------------ parameter sets
+    auto spsP = std::make_shared<SPS>(); SPS& sps = *spsP;   // BasePS: shared_from_this needs shared ownership
+    sps.setSPSId( 0 );
+    sps.setChromaFormatIdc( cf );
+    sps.setMaxPicWidthInLumaSamples( W );
+    sps.setMaxPicHeightInLumaSamples( Hh );
+    sps.setBitDepth( bd );
+    sps.setQpBDOffset( 6 * ( bd - 8 ) );
+    sps.setInternalMinusInputBitDepth( ( H.min_qp_ts - 4 ) / 6 );
+    sps.setCTUSize( ctuSize );
+    sps.setMaxCUWidth( ctuSize );
+    sps.setMaxCUHeight( ctuSize );
+    sps.setLog2MinCodingBlockSize( 2 );
+    sps.setLog2MaxTbSize( 6 );
+    sps.setUseSAO( !!( H.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) );
+    sps.setUseALF( !!( H.tool_flags & VVR_TOOL_ALF ) );
+    sps.setUseCCALF( !!( H.tool_flags & VVR_TOOL_CCALF ) );
+    sps.setUseReshaper( !!( H.tool_flags & VVR_TOOL_LMCS ) );
+    sps.setUseLFNST( !!( H.tool_flags & VVR_TOOL_LFNST ) );
+    sps.setUseMTS( true );            // the per-TU transform types are forced below through mtsIdx/implicit rules, see tu setup
+    sps.setUseIntraMTS( true );
+    sps.setUseInterMTS( true );
+    sps.setUseSBT( true );
+    sps.setUseISP( true );
+    sps.setUseMIP( true );
+    sps.setUseLMChroma( true );
+    sps.setUseMRL( true );
+    sps.setBDPCMEnabledFlag( true );
+    sps.setTransformSkipEnabledFlag( true );
+    sps.setLog2MaxTransformSkipBlockSize( 5 );
+    sps.setJointCbCrEnabledFlag( true );
+    sps.setUseBIO( !!( H.tool_flags & VVR_TOOL_BDOF ) );
+    sps.setUseDMVR( !!( H.tool_flags & VVR_TOOL_DMVR ) );
+    sps.setUsePROF( !!( H.tool_flags & VVR_TOOL_PROF ) );
+    sps.setUseAffine( true );
+    sps.setUseAffineType( true );
+    sps.setUseBcw( true );
+    sps.setUseCiip( true );
+    sps.setUseGeo( true );
+    sps.setUseMMVD( true );
+    sps.setUseSMVD( true );
+    sps.setAMVREnabledFlag( true );
+    sps.setSBTMVPEnabledFlag( true );
+    sps.setDepQuantEnabledFlag( !!( H.tool_flags & VVR_TOOL_DEP_QUANT ) );
+    sps.setMaxTLayers( 1 );
+    {
+      ChromaQpMappingTable& t = sps.m_chromaQpMappingTable;
+      t.m_qpBdOffset = sps.getQpBDOffset();
+      t.m_sameCQPTableForAllChromaFlag = true;
+      for( int i = 0; i < MAX_NUM_CQP_MAPPING_TABLES; i++ )
+      {
+        t.m_chromaQpMappingTables[i].resize( MAX_QP + t.m_qpBdOffset + 1 );
+        for( int q = -t.m_qpBdOffset; q <= MAX_QP; q++ ) t.m_chromaQpMappingTables[i][q + t.m_qpBdOffset] = q;   // identity
+      }
+    }
+
+    auto ppsP = std::make_shared<PPS>(); PPS& pps = *ppsP;
+    pps.setPPSId( 0 );
+    pps.setSPSId( 0 );
+    pps.setPicWidthInLumaSamples( W );
+    pps.setPicHeightInLumaSamples( Hh );
+    pps.setLog2CtuSize( H.log2_ctu );
+    pps.setNumExpTileColumns( 1 );
+    pps.setNumExpTileRows( 1 );
+    pps.addTileColumnWidth( ( W + ctuSize - 1 ) / ctuSize );
+    pps.addTileRowHeight( ( Hh + ctuSize - 1 ) / ctuSize );
+    pps.initTiles();
+    pps.setLoopFilterAcrossTilesEnabledFlag( true );
+    pps.setLoopFilterAcrossSlicesEnabledFlag( true );
+    pps.setNumSubPics( 1 );
+    pps.pcv = std::make_unique<PreCalcValues>( sps, pps );
+
+    auto ph = std::make_shared<PicHeader>();
+    ph->setValid();
+    ph->setSPSId( 0 );
+    ph->setPPSId( 0 );
+    ph->setDisBdofFlag( !( H.tool_flags & VVR_TOOL_BDOF ) );
+    ph->setDisDmvrFlag( !( H.tool_flags & VVR_TOOL_DMVR ) );
+    ph->setDisProfFlag( !( H.tool_flags & VVR_TOOL_PROF ) );
+    ph->setJointCbCrSignFlag( !!( H.tool_flags & VVR_TOOL_JCCR_SIGN ) );
+    ph->setLmcsEnabledFlag( !!( H.tool_flags & VVR_TOOL_LMCS ) );
+    ph->setLmcsChromaResidualScaleFlag( !!( H.tool_flags & VVR_TOOL_LMCS_CSCALE ) );
+    ph->setVirtualBoundariesPresentFlag( false );
+
+    // ------------------------------------------------------------------ pictures
+    CUChunkCache cuCache; TUChunkCache tuCache;
+    const unsigned margin = 16 + ctuSize;
+
+    std::map<int, std::unique_ptr<Picture>> refPics;
+    auto getRefPic = [&]( int slot, int poc ) -> Picture*
+    {
+      auto it = refPics.find( slot );
+      if( it != refPics.end() ) return it->second.get();
+      std::unique_ptr<Picture> p( new Picture( enableOpt ) );
+      p->create( cf, Size( W, Hh ), ctuSize, margin, 0, nullptr );
+      p->poc = poc;
+      const int nc = cf == CHROMA_400 ? 1 : 3;
+      for( int c = 0; c < nc; c++ )
+      {
+        const int cw = c ? W >> 1 : W, chh = c ? Hh >> 1 : Hh;
+        CHECK( !ref_planes || !ref_planes[slot * 3 + c], "missing reference plane" );
+        fillPlane( p->getRecoBuf( ComponentID( c ) ), ref_planes[slot * 3 + c], cw, chh );
+      }
+      p->extendPicBorder( true, true, true, true );   // DecLibRecon::borderExtPic (DecLibRecon.cpp:236) does the same through 6 tasks
+      p->borderExtStarted = true;
+      p->progress = Picture::reconstructed;
+      p->dpbReferenceMark = Picture::ShortTerm;
+      p->reconDone.unlock();
+      Picture* r = p.get();
+      refPics[slot] = std::move( p );
+      return r;
+    };
+
+    Picture pic( enableOpt );
+    pic.create( cf, Size( W, Hh ), ctuSize, margin, 0, nullptr );
+    pic.poc = H.poc;
+    const APS* nullAps[ALF_CTB_MAX_NUM_APS] = { nullptr };
+
+    // ALF APSs
+    std::vector<std::shared_ptr<APS>> alfApsStore;
+    const APS* alfApss[ALF_CTB_MAX_NUM_APS] = { nullptr };
+    const bool useAlf = !!( H.tool_flags & VVR_TOOL_ALF ) && vp->alf && vp->alf_params;
+    if( useAlf )
+    {
+      const vvr_alf_params& A = *vp->alf_params;
+      auto clipIdx = [&]( int v ) { for( int i = 0; i < 4; i++ ) if( AdaptiveLoopFilter::m_alfClippVls[bd - 8][i] == v ) return i; THROW_FATAL( "bad ALF clip value " << v ); return 0; };
+      for( int a = 0; a < ALF_CTB_MAX_NUM_APS; a++ )
+      {
+        auto aps = std::make_shared<APS>();
+        aps->setAPSId( a );
+        aps->setAPSType( ALF_APS );
+        AlfSliceParam& p = aps->getMutableAlfAPSParam();
+        p.reset();
+        // syntax-level parameters chosen such that the reference's own host step reconstructCoeff (AdaptiveLoopFilter.cpp:888)
+        // reproduces exactly the final filters of the description
+        p.nonLinearFlagLuma = p.nonLinearFlagChroma = true;
+        p.numLumaFilters = MAX_NUM_ALF_CLASSES;
+        for( int c = 0; c < MAX_NUM_ALF_CLASSES; c++ )
+        {
+          p.filterCoeffDeltaIdx[c] = c;
+          for( int k = 0; k < MAX_NUM_ALF_LUMA_COEFF - 1; k++ )
+          {
+            p.lumaCoeff[c * MAX_NUM_ALF_LUMA_COEFF + k] = A.luma_coeff[a][c][k];
+            p.lumaClipp[c * MAX_NUM_ALF_LUMA_COEFF + k] = clipIdx( A.luma_clip[a][c][k] );
+          }
+        }
+        p.numAlternativesChroma = VVR_ALF_MAX_CHR_ALT;
+        for( int alt = 0; alt < VVR_ALF_MAX_CHR_ALT; alt++ ) for( int k = 0; k < MAX_NUM_ALF_CHROMA_COEFF - 1; k++ )
+        {
+          p.chromaCoeff[alt * MAX_NUM_ALF_CHROMA_COEFF + k] = A.chroma_coeff[alt][k];
+          p.chromaClipp[alt * MAX_NUM_ALF_CHROMA_COEFF + k] = clipIdx( A.chroma_clip[alt][k] );
+        }
+        aps->releaseMutableAlfAPSParam( p );
+        CcAlfFilterParam& cc = aps->getCcAlfAPSParam();
+        for( int c = 0; c < 2; c++ )
+        {
+          cc.ccAlfFilterEnabled[c] = true; cc.ccAlfFilterCount[c] = MAX_NUM_CC_ALF_FILTERS;
+          for( int f = 0; f < MAX_NUM_CC_ALF_FILTERS; f++ ) { cc.ccAlfFilterIdxEnabled[c][f] = true; for( int k = 0; k < MAX_NUM_CC_ALF_CHROMA_COEFF; k++ ) cc.ccAlfCoeff[c][f][k] = A.ccalf_coeff[c][f][k]; }
+        }
+        alfApsStore.push_back( aps );
+        alfApss[a] = aps.get();
+      }
+    }
+    pic.finalInit( &cuCache, &tuCache, &sps, &pps, ph, useAlf ? alfApss : nullAps, nullptr, nullptr );
+    CodingStructure& cs = *pic.cs;
+
+    Slice* slice = pic.allocateNewSlice();
+    slice->setPicHeader( ph.get() );
+    slice->setSliceType( SliceType( H.slice_type ) );
+    slice->setPOC( H.poc );
+    slice->setSliceQp( 32 );
+    slice->setDefaultClpRng( sps );
+    slice->setDepQuantEnabledFlag( !!( H.tool_flags & VVR_TOOL_DEP_QUANT ) );
+    slice->setDeblockingFilterDisable( !!( H.tool_flags & VVR_TOOL_DEBLOCK_OFF ) );
+    slice->setDeblockingFilterBetaOffsetDiv2( H.deblock_beta_offset_div2[0] );
+    slice->setDeblockingFilterTcOffsetDiv2( H.deblock_tc_offset_div2[0] );
+    slice->setDeblockingFilterCbBetaOffsetDiv2( H.deblock_beta_offset_div2[1] );
+    slice->setDeblockingFilterCbTcOffsetDiv2( H.deblock_tc_offset_div2[1] );
+    slice->setDeblockingFilterCrBetaOffsetDiv2( H.deblock_beta_offset_div2[2] );
+    slice->setDeblockingFilterCrTcOffsetDiv2( H.deblock_tc_offset_div2[2] );
+    slice->setSaoEnabledFlag( CHANNEL_TYPE_LUMA, !!( H.tool_flags & VVR_TOOL_SAO_LUMA ) );
+    slice->setSaoEnabledFlag( CHANNEL_TYPE_CHROMA, !!( H.tool_flags & VVR_TOOL_SAO_CHROMA ) );
+    slice->setLmcsEnabledFlag( !!( H.tool_flags & VVR_TOOL_LMCS ) );
+    slice->setExplicitScalingListUsed( false );
+    slice->setIndependentSliceIdx( 0 );
+    slice->resetSliceMap();
+    slice->addCtusToSlice( 0, pps.pcv->widthInCtus, 0, pps.pcv->heightInCtus, pps.pcv->widthInCtus );
+    for( int l = 0; l < 2; l++ )
+    {
+      slice->setNumRefIdx( RefPicList( l ), H.slice_type == 2 ? 0 : H.num_ref[l] );
+      for( int i = 0; i < H.num_ref[l] && H.slice_type != 2; i++ )
+      {
+        Picture* rp = getRefPic( H.ref_slot[l][i], H.ref_poc[l][i] );
+        slice->m_apcRefPicList[l][i]     = rp;
+        slice->m_aiRefPOCList[l][i]      = H.ref_poc[l][i];
+        slice->m_bIsUsedAsLongTerm[l][i] = false;
+      }
+    }
+    pic.stillReferenced = !!( H.tool_flags & VVR_TOOL_STILL_REF );
+    if( useAlf )
+    {
+      slice->setAlfEnabledFlag( COMPONENT_Y, true ); slice->setAlfEnabledFlag( COMPONENT_Cb, cf != CHROMA_400 ); slice->setAlfEnabledFlag( COMPONENT_Cr, cf != CHROMA_400 );
+      slice->setNumAlfAps( vp->alf_params->num_luma_aps );
+      AlfApsIdVec ids; for( int a = 0; a < vp->alf_params->num_luma_aps; a++ ) ids.push_back( a );
+      slice->setAlfApsIdsLuma( ids );
+      slice->setAlfApsIdChroma( 0 );
+      const bool cc = !!( H.tool_flags & VVR_TOOL_CCALF );
+      slice->setCcAlfCbEnabledFlag( cc ); slice->setCcAlfCrEnabledFlag( cc ); slice->setCcAlfCbApsId( 0 ); slice->setCcAlfCrApsId( 0 );
+      AdaptiveLoopFilter::reconstructCoeffAPSs( *slice );
+    }
+
+    // ------------------------------------------------------------------ CTU data, CUs, TUs
+    const PreCalcValues& pcv = *cs.pcv;
+    const int numCtu = pcv.sizeInCtus;
+    const int w4 = ( W + 3 ) >> 2, h4 = ( Hh + 3 ) >> 2;
+    const int ctu4 = ctuSize >> 2;
+    std::vector<LoopFilterParam> lfpStore( (size_t) pcv.num4x4CtuBlks * numCtu * 2 );
+    std::vector<MotionInfo>      miStore ( (size_t) pcv.num4x4CtuBlks * numCtu );
+    memset( (void*) lfpStore.data(), 0, lfpStore.size() * sizeof( LoopFilterParam ) );
+    memset( (void*) miStore.data(), MI_NOT_VALID, miStore.size() * sizeof( MotionInfo ) );
+
+    for( int a = 0; a < numCtu; a++ )
+    {
+      CtuData& cd = cs.getCtuData( a );
+      cd.slice = slice; cd.pps = &pps; cd.sps = &sps; cd.ph = ph.get();
+      cd.motion     = &miStore[(size_t) pcv.num4x4CtuBlks * a];
+      cd.lfParam[0] = &lfpStore[(size_t) pcv.num4x4CtuBlks * ( 2 * a + 0 )];
+      cd.lfParam[1] = &lfpStore[(size_t) pcv.num4x4CtuBlks * ( 2 * a + 1 )];
+      cd.saoParam.reset();
+      if( vp->sao )
+      {
+        const vvr_sao_ctu& s = vp->sao[a];
+        for( int c = 0; c < 3; c++ )
+        {
+          SAOOffset& o = cd.saoParam[c];
+          o.reset();
+          if( !s.mode[c] ) continue;
+          o.modeIdc = SAO_MODE_NEW;
+          o.typeIdc = s.type[c];
+          o.typeAuxInfo = s.type[c] == SAO_TYPE_BO ? s.band_pos[c] : 0;
+          // SAOPrepareCTULine -> reconstructBlkSAOParam -> invertQuantOffsets re-scales "coded" offsets; we give it coded offsets
+          // = final offsets >> log2OffsetScale so that its output equals the description (scale is 0 for bitDepth <= 10).
+          const int sc = H.log2_sao_offset_scale[c ? 1 : 0];
+          if( s.type[c] == SAO_TYPE_BO )
+            for( int i = 0; i < 4; i++ ) o.offset[( s.band_pos[c] + i ) % NUM_SAO_BO_CLASSES] = s.offset[c][i] >> sc;
+          else
+          {
+            o.offset[SAO_CLASS_EO_FULL_VALLEY] = s.offset[c][0] >> sc;
+            o.offset[SAO_CLASS_EO_HALF_VALLEY] = s.offset[c][1] >> sc;
+            o.offset[SAO_CLASS_EO_PLAIN]       = 0;
+            o.offset[SAO_CLASS_EO_HALF_PEAK]   = s.offset[c][2] >> sc;
+            o.offset[SAO_CLASS_EO_FULL_PEAK]   = s.offset[c][3] >> sc;
+          }
+        }
+      }
+      if( vp->alf )
+      {
+        const vvr_alf_ctu& f = vp->alf[a];
+        for( int c = 0; c < 3; c++ ) cd.alfParam.alfCtuEnableFlag[c] = f.enable[c];
+        for( int c = 0; c < 2; c++ ) { cd.alfParam.alfCtuAlternative[c] = f.alt[c]; cd.alfParam.ccAlfFilterControl[c] = f.cc_idc[c]; }
+        cd.alfParam.alfCtbFilterIndex = f.luma_filter_idx;
+      }
+    }
+
+    // motion field (the output of MIDER)
+    if( vp->motion )
+    {
+      for( int y = 0; y < h4; y++ ) for( int x = 0; x < w4; x++ )
+      {
+        const vvr_motion& m = vp->motion[(size_t) y * w4 + x];
+        const int ctuA = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 );
+        MotionInfo& mi = miStore[(size_t) pcv.num4x4CtuBlks * ctuA + ( y % ctu4 ) * ctu4 + ( x % ctu4 )];
+        mi.mv[0] = Mv( m.mv[0][0], m.mv[0][1] );
+        mi.mv[1] = Mv( m.mv[1][0], m.mv[1][1] );
+        mi.miRefIdx[0] = m.ref_idx[0] < 0 ? MI_NOT_VALID : m.ref_idx[0];
+        mi.miRefIdx[1] = m.ref_idx[1] < 0 ? MI_NOT_VALID : m.ref_idx[1];
+      }
+    }
+
+    PelUnitBuf reco = cs.getRecoBuf();
+    std::vector<CodingUnit*> cuPtrs( vp->num_cu );
+    for( uint32_t i = 0; i < vp->num_cu; i++ )
+    {
+      const vvr_cu& c = vp->cu[i];
+      UnitArea ua( cf, Area( c.x, c.y, c.w, c.h ) );
+      ChannelType chType = CHANNEL_TYPE_LUMA; TreeType tt = TREE_D;
+      if( c.tree == VVR_TREE_LUMA )   { ua.blocks[1] = CompArea(); ua.blocks[2] = CompArea(); tt = TREE_L; if( cf == CHROMA_400 ) tt = TREE_D; }
+      if( c.tree == VVR_TREE_CHROMA ) { ua.blocks[0] = CompArea(); tt = TREE_C; chType = CHANNEL_TYPE_CHROMA; }
+      if( cf == CHROMA_400 ) ua.blocks.resize( 1 );
+      const Position p0 = ua.blocks[chType].pos();
+      const CodingUnit* cuL = cs.getCURestricted( p0.offset( -1, 0 ), p0, 0, 0, chType );
+      const CodingUnit* cuA = cs.getCURestricted( p0.offset( 0, -1 ), p0, 0, 0, chType );
+      CodingUnit& cu = cs.addCU( ua, chType, tt, MODE_TYPE_ALL, cuL, cuA );
+      cuPtrs[i] = &cu;
+      cu.slice = slice; cu.pps = &pps; cu.sps = &sps; cu.tileIdx = 0;
+      cu.qp = c.qp; cu.chromaQpAdj = 0;
+      cu.setPredMode( c.pred_mode == VVR_PRED_INTRA ? MODE_INTRA : c.pred_mode == VVR_PRED_IBC ? MODE_IBC : MODE_INTER );
+      cu.setRootCbf( !!( c.flags & VVR_CU_ROOT_CBF ) );
+      cu.setSkip( !!( c.flags & VVR_CU_SKIP ) );
+      cu.setMergeFlag( !!( c.flags & VVR_CU_MERGE ) );
+      cu.setAffineFlag( !!( c.flags & VVR_CU_AFFINE ) );
+      cu.setAffineType( ( c.flags & VVR_CU_AFFINE_6P ) ? AFFINEMODEL_6PARAM : AFFINEMODEL_4PARAM );
+      cu.setCiipFlag( !!( c.flags & VVR_CU_CIIP ) );
+      cu.setGeoFlag( !!( c.flags & VVR_CU_GEO ) );
+      cu.setMergeType( ( c.flags & VVR_CU_SBTMVP ) ? MRG_TYPE_SUBPU_ATMVP : MRG_TYPE_DEFAULT_N );
+      cu.setMipFlag( !!( c.flags & VVR_CU_MIP ) );
+      cu.setMipTransposedFlag( !!( c.flags & VVR_CU_MIP_TRANSP ) );
+      cu.setSmvdMode( ( c.flags & VVR_CU_SMVD ) ? 1 : 0 );
+      cu.setMmvdFlag( !!( c.flags & VVR_CU_MMVD ) );
+      cu.intraDir[0] = c.intra_dir[0]; cu.intraDir[1] = c.intra_dir[1];
+      cu.setMultiRefIdx( c.multi_ref_idx );
+      cu.setIspMode( c.isp_mode );
+      cu.setBdpcmMode( c.bdpcm[0] ); cu.setBdpcmModeChroma( c.bdpcm[1] );
+      cu.setLfnstIdx( c.lfnst_idx );
+      cu.setSbtInfo( c.sbt_info );
+      cu.setInterDir( c.inter_dir );
+      cu.refIdx[0] = c.ref_idx[0]; cu.refIdx[1] = c.ref_idx[1];
+      cu.setBcwIdx( c.pred_mode == VVR_PRED_INTER ? c.bcw_idx : BCW_DEFAULT );
+      cu.setImv( c.imv );
+      cu.geoSplitDir = c.geo_split_dir;
+      cu.setInterDirrefIdxGeo0( c.geo_dir_ref[0] ); cu.setInterDirrefIdxGeo1( c.geo_dir_ref[1] );
+      for( int l = 0; l < 2; l++ ) for( int k = 0; k < 3; k++ ) cu.mv[l][k] = Mv( c.mv[l][k][0], c.mv[l][k][1] );
+      cu.setPlaneCbf( 0, false ); cu.setPlaneCbf( 1, false ); cu.setPlaneCbf( 2, false );
+
+      for( uint32_t t = c.first_tu; t < c.first_tu + c.num_tu; t++ )
+      {
+        const vvr_tu& vt = vp->tu[t];
+        UnitArea ta( cf, Area( vt.x, vt.y, vt.w, vt.h ) );
+        if( cf == CHROMA_400 ) ta.blocks.resize( 1 );
+        for( int k = 0; k < (int) ta.blocks.size(); k++ ) if( !( vt.comp_mask & ( 1 << k ) ) ) ta.blocks[k] = CompArea();
+        // ISP luma sub-partitions narrower than 4 share one chroma block placed in the last TU: comp_mask carries that
+        if( ( vt.comp_mask & 6 ) && ( c.isp_mode ) ) { ta.blocks[1] = cu.blocks[1]; ta.blocks[2] = cu.blocks[2]; }
+        TransformUnit& tu = cs.addTU( ta, chType, cu );
+        tu.cbf = vt.cbf;
+        tu.jointCbCr = vt.joint_cbcr;
+        for( int k = 0; k < 3; k++ )
+        {
+          tu.setMtsIdx( k, vt.mts_idx[k] );
+          tu.maxScanPosX[k] = vt.max_scan_x[k];
+          tu.maxScanPosY[k] = vt.max_scan_y[k];
+          if( vt.cbf & ( 1 << k ) ) cu.setPlaneCbf( k, true );
+          if( k && vt.joint_cbcr ) cu.setPlaneCbf( k, true );
+        }
+        // levels: scatter the packed corner into the reco plane at the TU position (CABACReader.cpp:2457-2478)
+        for( int k = 0; k < (int) ta.blocks.size(); k++ )
+        {
+          if( !ta.blocks[k].valid() ) continue;
+          const bool coded = ( vt.cbf >> k ) & 1;
+          if( !coded ) continue;
+          const CompArea& blk = tu.blocks[k];
+          PelBuf dst = reco.bufs[k].subBuf( blk.pos(), blk.size() );
+          const int16_t* src = vp->coef + vt.coef_off[k];
+          const bool fullBlk = ( k == 0 ? c.bdpcm[0] : c.bdpcm[1] ) != 0;
+          const int cw = fullBlk ? blk.width : vt.max_scan_x[k] + 1, chh = fullBlk ? blk.height : vt.max_scan_y[k] + 1;
+          for( int y = 0; y < chh; y++ ) for( int x = 0; x < cw; x++ ) dst.at( x, y ) = src[y * cw + x];
+        }
+      }
+    }
+
+    // LoopFilterParam tables from the description (unless we let the reference derive them)
+    if( !( flags & VVREF_DERIVE_LFP ) && vp->lfp[0] && vp->lfp[1] )
+    {
+      for( int d = 0; d < 2; d++ ) for( int y = 0; y < h4; y++ ) for( int x = 0; x < w4; x++ )
+      {
+        const vvr_lfp& s = vp->lfp[d][(size_t) y * w4 + x];
+        const int ctuA = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 );
+        LoopFilterParam& l = lfpStore[(size_t) pcv.num4x4CtuBlks * ( 2 * ctuA + d ) + ( y % ctu4 ) * ctu4 + ( x % ctu4 )];
+        l.qp[0] = s.qp[0]; l.qp[1] = s.qp[1]; l.qp[2] = s.qp[2];
+        l.bs = s.bs; l.sideMaxFiltLength = s.side_max_filt_length; l.flags = s.flags;
+      }
+    }
+
+    // ------------------------------------------------------------------ tools (DecLibRecon::create / decompressPicture set-up)
+    RdCost rdCost( enableOpt );
+    LoopFilter lf( enableOpt );
+    SampleAdaptiveOffset sao( enableOpt );
+    AdaptiveLoopFilter alf( enableOpt );
+    std::unique_ptr<IntraPrediction> intraPred( new IntraPrediction() );
+    std::unique_ptr<InterPrediction> interPred( new InterPrediction() );
+    std::unique_ptr<Reshape>         reshaper( new Reshape() );
+    std::unique_ptr<TrQuant>         trQuant( new TrQuant( interPred.get() ) );
+    DecCu decCu;
+    intraPred->init( cf, bd );
+    interPred->init( &rdCost, cf, ctuSize, enableOpt );
+    trQuant->init( &pic );
+    decCu.init( intraPred.get(), interPred.get(), reshaper.get(), trQuant.get() );
+
+    PelStorage fltBuf;
+    fltBuf.create( cf, Size( W, Hh ), ctuSize, margin, MEMORY_ALIGN_DEF_SIZE, true, nullptr );
+    const uint32_t log2SaoOffsetScale = (uint32_t) std::max( 0, bd - MAX_SAO_TRUNCATED_BITDEPTH );
+    sao.create( W, Hh, cf, ctuSize, ctuSize, H.log2_ctu - pcv.minCUWidthLog2, log2SaoOffsetScale, fltBuf );
+    if( useAlf ) alf.create( ph.get(), &sps, &pps, 1, fltBuf );
+
+    const ptrdiff_t ctuSampleSizeL = ctuSize * ctuSize;
+    const ptrdiff_t ctuSampleSize  = ctuSampleSizeL + ( cf == CHROMA_400 ? 0 : 2 * ( ctuSampleSizeL >> 2 ) );
+    std::vector<Pel> predBuf( (size_t) ctuSampleSize * numCtu + 64 );
+    cs.m_predBuf = predBuf.data();
+    std::vector<Mv> dmvrCache( (size_t) pcv.num8x8CtuBlks * numCtu );
+    cs.m_dmvrMvCache = dmvrCache.data();
+
+    auto now = []{ return std::chrono::steady_clock::now(); };
+    auto ms  = []( std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b ){ return std::chrono::duration<double, std::milli>( b - a ).count(); };
+    double st[8] = { 0 };
+    auto t0 = now();
+
+    // ------------------------------------------------------------------ stages (DecLibRecon::ctuTask)
+    if( flags & VVREF_DERIVE_LFP )
+      for( int a = 0; a < numCtu; a++ ) lf.calcFilterStrengthsCTU( cs, a );
+
+    auto tA = now();
+    for( int a = 0; a < numCtu; a++ )                                    // INTER
+    {
+      const int col = a % pcv.widthInCtus, line = a / pcv.widthInCtus;
+      const UnitArea ctuArea = getCtuArea( cs, col, line, true );
+      if( !cs.getCtuData( a ).firstCU ) continue;
+      decCu.TaskTrafoCtu( cs, a, ctuArea );
+      if( !slice->isIntra() ) decCu.TaskInterCtu( cs, a, ctuArea );
+    }
+    auto tB = now(); st[0] = ms( tA, tB );
+    for( int a = 0; a < numCtu; a++ )                                    // INTRA (raster order satisfies the wavefront dependencies)
+    {
+      const int col = a % pcv.widthInCtus, line = a / pcv.widthInCtus;
+      if( !cs.getCtuData( a ).firstCU ) continue;
+      decCu.TaskCriticalIntraKernel( cs, a, getCtuArea( cs, col, line, true ) );
+    }
+    auto tC = now(); st[1] = ms( tB, tC );
+
+    bool stop = !!( flags & VVREF_STOP_AFTER_RECO );
+    if( !stop )
+    {
+      for( int line = 0; line < (int) pcv.heightInCtus; line++ ) for( int col = 0; col < (int) pcv.widthInCtus; col++ )
+        lf.loopFilterCTU( cs, MAX_NUM_CHANNEL_TYPE, col, line, EDGE_VER );
+      auto tD = now(); st[3] = ms( tC, tD );
+      for( int line = 0; line < (int) pcv.heightInCtus; line++ ) for( int col = 0; col < (int) pcv.widthInCtus; col++ )
+        lf.loopFilterCTU( cs, MAX_NUM_CHANNEL_TYPE, col, line, EDGE_HOR );
+      auto tE = now(); st[4] = ms( tD, tE );
+      stop = !!( flags & VVREF_STOP_AFTER_DBK );
+      if( !stop )
+      {
+        if( sps.getUseSAO() )
+        {
+          for( int line = 0; line < (int) pcv.heightInCtus; line++ ) sao.SAOPrepareCTULine( cs, getLineArea( cs, line, true ) );
+          for( int line = 0; line < (int) pcv.heightInCtus; line++ ) for( int col = 0; col < (int) pcv.widthInCtus; col++ )
+            sao.SAOProcessCTU( cs, getCtuArea( cs, col, line, true ) );
+        }
+        auto tF = now(); st[5] = ms( tE, tF );
+        stop = !!( flags & VVREF_STOP_AFTER_SAO );
+        if( !stop && useAlf )
+        {
+          for( int line = 0; line < (int) pcv.heightInCtus; line++ ) for( int col = 0; col < (int) pcv.widthInCtus; col++ )
+            AdaptiveLoopFilter::prepareCTU( cs, col, line );
+          for( int line = 0; line < (int) pcv.heightInCtus; line++ ) for( int col = 0; col < (int) pcv.widthInCtus; col++ )
+            alf.processCTU( cs, col, line, 0 );
+          // DecLibRecon::swapBufs (DecLibRecon.cpp:423)
+          pic.m_bufs[PIC_RECONSTRUCTION].swap( fltBuf );
+          cs.rebindPicBufs();
+          st[6] = ms( tF, now() );
+        }
+      }
+    }
+    st[7] = ms( t0, now() );
+    if( stage_ms ) memcpy( stage_ms, st, sizeof( st ) );
+
+    // ------------------------------------------------------------------ outputs
+    {
+      PelUnitBuf out = pic.getRecoBuf();
+      const int nc = cf == CHROMA_400 ? 1 : 3;
+      for( int c = 0; c < nc; c++ )
+      {
+        const int cw = c ? W >> 1 : W, chh = c ? Hh >> 1 : Hh;
+        if( !out_planes[c] ) continue;
+        for( int y = 0; y < chh; y++ ) for( int x = 0; x < cw; x++ ) out_planes[c][(size_t) y * cw + x] = (uint16_t) out.bufs[c].at( x, y );
+      }
+    }
+    if( lfp_out && ( flags & VVREF_DERIVE_LFP ) )
+    {
+      for( int d = 0; d < 2; d++ ) if( lfp_out[d] ) for( int y = 0; y < h4; y++ ) for( int x = 0; x < w4; x++ )
+      {
+        const int ctuA = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 );
+        const LoopFilterParam& l = lfpStore[(size_t) pcv.num4x4CtuBlks * ( 2 * ctuA + d ) + ( y % ctu4 ) * ctu4 + ( x % ctu4 )];
+        vvr_lfp& o = lfp_out[d][(size_t) y * w4 + x];
+        o.qp[0] = l.qp[0]; o.qp[1] = l.qp[1]; o.qp[2] = l.qp[2]; o.bs = l.bs; o.side_max_filt_length = l.sideMaxFiltLength; o.flags = l.flags; o.pad[0] = o.pad[1] = 0;
+      }
+    }
+    if( dmvr_out )
+    {
+      for( uint32_t i = 0; i < vp->num_cu; i++ )
+      {
+        const vvr_cu& c = vp->cu[i];
+        if( c.mc_mode != VVR_MC_DMVR && c.mc_mode != VVR_MC_DMVR_BDOF ) continue;
+        const int n = std::max( 1, c.w >> 4 ) * std::max( 1, c.h >> 4 );
+        for( int k = 0; k < n; k++ )
+        {
+          const Mv& m = cs.m_dmvrMvCache[cuPtrs[i]->mvdL0SubPuOff + k];
+          dmvr_out[2 * ( c.dmvr_off + k ) + 0] = m.hor; dmvr_out[2 * ( c.dmvr_off + k ) + 1] = m.ver;
+        }
+      }
+    }
+    cs.m_predBuf = nullptr; cs.m_dmvrMvCache = nullptr;
+    for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
+    fltBuf.destroy();
+    return 0;
+  }
+  catch( std::exception& e )
+  {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+} // extern "C"

@@ -1,0 +1,57 @@
+"""ctypes wrapper of oracle/_ref/libvvref.so (the unmodified reference classes driven by oracle/ref_harness.cpp).
+
+TEST INFRASTRUCTURE ONLY.  Available only where oracle/_ref has been built (needs /root/reference at build time);
+tests that use it skip otherwise and rely on the committed golden fixtures it produced (tests/golden/)."""
+import ctypes as C
+import os
+import numpy as np
+from vvdec_amd import abi
+
+_LIB = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libvvref.so")
+SIMD, DERIVE_LFP, STOP_AFTER_RECO, STOP_AFTER_DBK, STOP_AFTER_SAO = 1, 2, 4, 8, 16
+_lib = None
+
+
+def available():
+    return os.path.exists(_LIB)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_LIB)
+        _lib.vvref_reconstruct.restype = C.c_int
+        _lib.vvref_last_error.restype = C.c_char_p
+    return _lib
+
+
+def reconstruct(desc, refs=None, flags=0, want_lfp=False, want_dmvr=0):
+    """desc: PictureDesc; refs: {slot: [Y, Cb, Cr] uint16 arrays}. Returns dict(planes=[...], ms=..., lfp=..., dmvr=...)."""
+    L = lib()
+    p = desc.c()
+    nslots = (max(refs.keys()) + 1) if refs else 0
+    ref_ptrs = (C.POINTER(C.c_uint16) * max(1, nslots * 3))()
+    keep = []
+    for slot, planes in (refs or {}).items():
+        for c, pl in enumerate(planes):
+            a = np.ascontiguousarray(pl, dtype=np.uint16)
+            keep.append(a)
+            ref_ptrs[slot * 3 + c] = a.ctypes.data_as(C.POINTER(C.c_uint16))
+    ncomp = 3 if desc.hdr.chroma_format else 1
+    outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
+    out_ptrs = (C.POINTER(C.c_uint16) * 3)()
+    for c in range(ncomp):
+        out_ptrs[c] = outs[c].ctypes.data_as(C.POINTER(C.c_uint16))
+    lfp_ptrs = (C.POINTER(abi.Lfp) * 2)()
+    lfps = None
+    if want_lfp:
+        lfps = [np.zeros(desc.w4 * desc.h4, np.dtype(abi.Lfp)) for _ in range(2)]
+        for d in range(2):
+            lfp_ptrs[d] = lfps[d].ctypes.data_as(C.POINTER(abi.Lfp))
+    dmvr = np.zeros((max(1, want_dmvr), 2), np.int32)
+    ms = (C.c_double * 8)()
+    rc = L.vvref_reconstruct(C.byref(p), ref_ptrs, out_ptrs, lfp_ptrs if want_lfp else None,
+                             dmvr.ctypes.data_as(C.POINTER(C.c_int32)) if want_dmvr else None, flags, ms)
+    if rc != 0:
+        raise RuntimeError("vvref_reconstruct failed: " + L.vvref_last_error().decode())
+    return dict(planes=outs, ms=list(ms), lfp=lfps, dmvr=dmvr)

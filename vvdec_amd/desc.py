@@ -1,0 +1,82 @@
+"""Host-side container for one pre-parsed picture (numpy arrays <-> the C `vvr_picture`).
+
+Mirrors what the reference hands to DecLibRecon::decompressPicture (a parsed `Picture` with its CodingStructure,
+DecLibRecon.cpp:429): CU/TU records, packed levels, motion field, deblocking edge parameters, SAO/ALF controls.
+"""
+import ctypes as C
+import numpy as np
+from . import abi
+
+CU_DT = np.dtype(abi.Cu)
+TU_DT = np.dtype(abi.Tu)
+MOTION_DT = np.dtype(abi.Motion)
+LFP_DT = np.dtype(abi.Lfp)
+SAO_DT = np.dtype(abi.SaoCtu)
+ALF_DT = np.dtype(abi.AlfCtu)
+
+
+class PictureDesc:
+    """Owns the arrays of one picture description; `.c()` returns a ctypes Picture that points into them."""
+
+    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, slice_type=abi.SLICE_I, poc=0, out_slot=0, tool_flags=0):
+        h = abi.PicHeader()
+        h.abi_version = abi.VVR_ABI_VERSION
+        h.width, h.height, h.bit_depth, h.log2_ctu, h.chroma_format = width, height, bit_depth, log2_ctu, chroma_format
+        h.slice_type, h.poc, h.out_slot, h.tool_flags = slice_type, poc, out_slot, tool_flags
+        h.min_qp_ts = 4
+        self.hdr = h
+        self.w4, self.h4 = (width + 3) // 4, (height + 3) // 4
+        ctu = 1 << log2_ctu
+        self.ctus_x, self.ctus_y = (width + ctu - 1) // ctu, (height + ctu - 1) // ctu
+        self.num_ctu = self.ctus_x * self.ctus_y
+        self.cu = np.zeros(0, CU_DT)
+        self.tu = np.zeros(0, TU_DT)
+        self.ctu_first_cu = np.zeros(self.num_ctu + 1, np.uint32)
+        self.coef = np.zeros(0, np.int16)
+        self.motion = None
+        self.lfp = [np.zeros(self.w4 * self.h4, LFP_DT), np.zeros(self.w4 * self.h4, LFP_DT)]
+        self.sao = None
+        self.alf = None
+        self.alf_params = None
+        self.lmcs = None
+
+    def set_refs(self, l0, l1=()):
+        """l0/l1: lists of (slot, poc)."""
+        for l, lst in enumerate((l0, l1)):
+            self.hdr.num_ref[l] = len(lst)
+            for i, (slot, poc) in enumerate(lst):
+                self.hdr.ref_slot[l][i] = slot
+                self.hdr.ref_poc[l][i] = poc
+
+    def c(self):
+        p = abi.Picture()
+        p.hdr = self.hdr
+        p.num_cu, p.num_tu = len(self.cu), len(self.tu)
+        self.cu = np.ascontiguousarray(self.cu)
+        self.tu = np.ascontiguousarray(self.tu)
+        self.coef = np.ascontiguousarray(self.coef, dtype=np.int16)
+        if len(self.coef) == 0:
+            self.coef = np.zeros(1, np.int16)
+        p.cu = self.cu.ctypes.data_as(C.POINTER(abi.Cu))
+        p.tu = self.tu.ctypes.data_as(C.POINTER(abi.Tu))
+        p.ctu_first_cu = self.ctu_first_cu.ctypes.data_as(C.POINTER(abi.u32))
+        p.coef = self.coef.ctypes.data_as(C.POINTER(abi.i16))
+        p.num_coef = len(self.coef)
+        if self.motion is not None:
+            p.motion = self.motion.ctypes.data_as(C.POINTER(abi.Motion))
+        for d in range(2):
+            p.lfp[d] = self.lfp[d].ctypes.data_as(C.POINTER(abi.Lfp))
+        if self.sao is not None:
+            p.sao = self.sao.ctypes.data_as(C.POINTER(abi.SaoCtu))
+        if self.alf is not None:
+            p.alf = self.alf.ctypes.data_as(C.POINTER(abi.AlfCtu))
+        if self.alf_params is not None:
+            p.alf_params = C.pointer(self.alf_params)
+        if self.lmcs is not None:
+            p.lmcs = C.pointer(self.lmcs)
+        p.resident = 0
+        self._keep = p
+        return p
+
+    def plane_shape(self, comp):
+        return (self.hdr.height >> (1 if comp else 0), self.hdr.width >> (1 if comp else 0))
