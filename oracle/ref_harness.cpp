@@ -76,6 +76,8 @@ enum {
 };
 
 static std::string g_err;
+static bool g_trace = getenv("VVREF_TRACE") != nullptr;
+#define TR(...) do { if( g_trace ) { fprintf( stderr, __VA_ARGS__ ); fflush( stderr ); } } while(0)
 __attribute__((visibility("default"))) const char* vvref_last_error() { return g_err.c_str(); }
 
 struct RefPicHolder { std::unique_ptr<Picture> pic; };
@@ -194,6 +196,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     ph->setLmcsChromaResidualScaleFlag( !!( H.tool_flags & VVR_TOOL_LMCS_CSCALE ) );
     ph->setVirtualBoundariesPresentFlag( false );
 
+    TR("ps done\n");
     // ------------------------------------------------------------------ pictures
     CUChunkCache cuCache; TUChunkCache tuCache;
     const unsigned margin = 16 + ctuSize;
@@ -213,6 +216,11 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
         CHECK( !ref_planes || !ref_planes[slot * 3 + c], "missing reference plane" );
         fillPlane( p->getRecoBuf( ComponentID( c ) ), ref_planes[slot * 3 + c], cw, chh );
       }
+      {
+        const APS* noAps[ALF_CTB_MAX_NUM_APS] = { nullptr };
+        p->finalInit( &cuCache, &tuCache, &sps, &pps, ph, noAps, nullptr, nullptr, false );   // gives the picture a CodingStructure (pps/sps/pcv) like a decoded one has
+      }
+      { Slice* rs = p->allocateNewSlice(); rs->setPOC( poc ); rs->setPicHeader( ph.get() ); rs->setSliceType( I_SLICE ); }
       p->extendPicBorder( true, true, true, true );   // DecLibRecon::borderExtPic (DecLibRecon.cpp:236) does the same through 6 tasks
       p->borderExtStarted = true;
       p->progress = Picture::reconstructed;
@@ -275,6 +283,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     }
     pic.finalInit( &cuCache, &tuCache, &sps, &pps, ph, useAlf ? alfApss : nullAps, nullptr, nullptr );
     CodingStructure& cs = *pic.cs;
+    TR("finalInit done\n");
 
     Slice* slice = pic.allocateNewSlice();
     slice->setPicHeader( ph.get() );
@@ -321,6 +330,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       AdaptiveLoopFilter::reconstructCoeffAPSs( *slice );
     }
 
+    TR("slice done\n");
     // ------------------------------------------------------------------ CTU data, CUs, TUs
     const PreCalcValues& pcv = *cs.pcv;
     const int numCtu = pcv.sizeInCtus;
@@ -389,6 +399,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       }
     }
 
+    TR("ctu data done\n");
     PelUnitBuf reco = cs.getRecoBuf();
     std::vector<CodingUnit*> cuPtrs( vp->num_cu );
     for( uint32_t i = 0; i < vp->num_cu; i++ )
@@ -445,6 +456,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
         TransformUnit& tu = cs.addTU( ta, chType, cu );
         tu.cbf = vt.cbf;
         tu.jointCbCr = vt.joint_cbcr;
+        tu.chromaQp[0] = vt.qp[1]; tu.chromaQp[1] = vt.qp[2];   // CABACReader.cpp:612-618: QpParam( tu, Cb/Cr ).Qp( false )
         for( int k = 0; k < 3; k++ )
         {
           tu.setMtsIdx( k, vt.mts_idx[k] );
@@ -469,6 +481,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       }
     }
 
+    TR("cus done\n");
     // LoopFilterParam tables from the description (unless we let the reference derive them)
     if( !( flags & VVREF_DERIVE_LFP ) && vp->lfp[0] && vp->lfp[1] )
     {
@@ -510,6 +523,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     std::vector<Mv> dmvrCache( (size_t) pcv.num8x8CtuBlks * numCtu );
     cs.m_dmvrMvCache = dmvrCache.data();
 
+    TR("tools done\n");
     auto now = []{ return std::chrono::steady_clock::now(); };
     auto ms  = []( std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b ){ return std::chrono::duration<double, std::milli>( b - a ).count(); };
     double st[8] = { 0 };
@@ -525,7 +539,9 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       const int col = a % pcv.widthInCtus, line = a / pcv.widthInCtus;
       const UnitArea ctuArea = getCtuArea( cs, col, line, true );
       if( !cs.getCtuData( a ).firstCU ) continue;
+      TR("trafo ctu %d\n", a);
       decCu.TaskTrafoCtu( cs, a, ctuArea );
+      TR("inter ctu %d\n", a);
       if( !slice->isIntra() ) decCu.TaskInterCtu( cs, a, ctuArea );
     }
     auto tB = now(); st[0] = ms( tA, tB );
@@ -536,6 +552,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       decCu.TaskCriticalIntraKernel( cs, a, getCtuArea( cs, col, line, true ) );
     }
     auto tC = now(); st[1] = ms( tB, tC );
+    TR("intra done\n");
 
     bool stop = !!( flags & VVREF_STOP_AFTER_RECO );
     if( !stop )

@@ -1,0 +1,423 @@
+// tools/synth.cpp — synthetic PRE-PARSED picture generator (measurement / test infrastructure, not the product).
+//
+// Emits what the host side of a decoder (CABAC parse + MV derivation + boundary-strength derivation) would hand to the
+// reconstruction stage for one picture: vvr_cu / vvr_tu records, packed levels, the motion field, deblocking edge
+// parameters, SAO / ALF controls (include/vvr.h).  Content statistics follow SURVEY.md §8(d) "configs as concrete
+// synthetic inputs".  Everything is drawn from a counter-based RNG seeded per picture, so a (seed, parameters) pair
+// fully determines the picture — the GPU box regenerates the same pictures the CPU oracle saw.
+//
+// All values are "conformant-stream-like": partitions are legal power-of-two CUs inside the picture, MVs obey
+// clipMv (Mv.cpp:64-82), deblocking filter lengths obey the non-overlap rules of LoopFilter.cpp:910-922, so that the
+// reference's sequential edge loop and a parallel edge filter are equivalent.
+#include "../include/vvr.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Rng {   // splitmix64
+  uint64_t s;
+  explicit Rng( uint64_t seed ) : s( seed * 0x9E3779B97F4A7C15ull + 0x1234567ull ) {}
+  uint64_t next() { uint64_t z = ( s += 0x9E3779B97F4A7C15ull ); z = ( z ^ ( z >> 30 ) ) * 0xBF58476D1CE4E5B9ull; z = ( z ^ ( z >> 27 ) ) * 0x94D049BB133111EBull; return z ^ ( z >> 31 ); }
+  uint32_t u( uint32_t n ) { return (uint32_t) ( next() % n ); }                 // [0,n)
+  double   f() { return ( next() >> 11 ) * ( 1.0 / 9007199254740992.0 ); }       // [0,1)
+  bool     p( double prob ) { return f() < prob; }
+  int      laplace( double b ) { double x = f() - 0.5; double v = -b * ( x < 0 ? -1 : 1 ) * std::log( 1 - 2 * std::fabs( x ) + 1e-12 ); return (int) std::lround( v ); }
+};
+
+} // namespace
+
+extern "C" {
+
+typedef struct vvs_params {
+  uint64_t seed;
+  uint16_t width, height;
+  uint8_t  bit_depth, log2_ctu, chroma_format, slice_type;
+  uint32_t tool_flags;          // VVR_TOOL_* to put in the header (and to draw tools from)
+  int8_t   num_ref[2];
+  int32_t  poc;
+  int32_t  ref_poc[2][VVR_MAX_REFS];
+  int16_t  ref_slot[2][VVR_MAX_REFS];
+  int16_t  out_slot;
+  int8_t   base_qp;             // 32 for the RA QP32 config
+  uint8_t  min_cu_log2;         // 3: min CU 8x8
+  float    p_intra;             // fraction of CUs coded intra (I slices: 1)
+  float    p_bi;                // of inter CUs
+  float    p_coded;             // fraction of TUs with a coded luma block
+  float    p_coded_chroma;
+  float    p_small_corner;      // fraction of coded blocks whose levels sit in a <= 8x8 corner
+  float    p_mts;               // explicit MTS (luma, size <= 32)
+  float    p_ts;                // transform skip
+  float    p_lfnst;             // of intra CUs
+  float    p_split_scale;       // scales the split probabilities (1 = mean CU ~32x32)
+  float    mv_sigma;            // luma samples
+  float    p_sao, p_alf_luma, p_alf_chroma, p_ccalf;
+  float    p_imv_hpel;
+  float    p_jccr;
+} vvs_params;
+
+typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
+  vvr_cu*      cu;      uint32_t max_cu;
+  vvr_tu*      tu;      uint32_t max_tu;
+  int16_t*     coef;    uint64_t max_coef;
+  uint32_t*    ctu_first_cu;
+  vvr_motion*  motion;
+  vvr_lfp*     lfp[2];
+  vvr_sao_ctu* sao;
+  vvr_alf_ctu* alf;
+  vvr_alf_params* alf_params;
+  // outputs
+  uint32_t     num_cu, num_tu; uint64_t num_coef; uint32_t num_dmvr;
+  vvr_pic_header hdr;
+} vvs_buffers;
+
+__attribute__((visibility("default")))
+void vvs_bounds( const vvs_params* P, uint32_t* max_cu, uint32_t* max_tu, uint64_t* max_coef )
+{
+  const uint32_t m = 1u << P->min_cu_log2;
+  const uint32_t n = ( ( P->width + m - 1 ) / m ) * ( ( P->height + m - 1 ) / m );
+  *max_cu = n; *max_tu = n + n / 4 + 16;
+  *max_coef = (uint64_t) P->width * P->height * 3 / 2 + 4096;
+}
+
+__attribute__((visibility("default")))
+void vvs_default_params( vvs_params* P )
+{
+  memset( P, 0, sizeof( *P ) );
+  P->seed = 1234; P->width = 3840; P->height = 2160; P->bit_depth = 10; P->log2_ctu = 7; P->chroma_format = 1; P->slice_type = 0;
+  P->base_qp = 32; P->min_cu_log2 = 3;
+  P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
+  P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f;
+}
+
+namespace {
+
+struct Gen {
+  const vvs_params& P; vvs_buffers& B; Rng rng;
+  int W, H, w4, h4, ctu, bd;
+  std::vector<int32_t> cuOf4;      // per 4x4: CU index
+  std::vector<int32_t> tuOf4;      // per 4x4: TU index
+  Gen( const vvs_params& p, vvs_buffers& b ) : P( p ), B( b ), rng( p.seed ) {}
+
+  void clipMv( int32_t mv[2], int x, int y ) const   // clipMvInPic, Mv.cpp:64
+  {
+    const int off = 8;
+    const int horMax = ( W + off - x - 1 ) * 16, horMin = ( -ctu - off - x + 1 ) * 16;
+    const int verMax = ( H + off - y - 1 ) * 16, verMin = ( -ctu - off - y + 1 ) * 16;
+    mv[0] = std::min( horMax, std::max( horMin, mv[0] ) );
+    mv[1] = std::min( verMax, std::max( verMin, mv[1] ) );
+  }
+
+  void genLevels( vvr_tu& tu, int c, int bw, int bh, bool ts )
+  {
+    // corner extents
+    int mx, my;
+    const int capW = std::min( bw, 32 ), capH = std::min( bh, 32 );
+    if( ts ) { mx = bw - 1; my = bh - 1; }
+    else if( rng.p( P.p_small_corner ) ) { mx = rng.u( std::min( capW, 8 ) ); my = rng.u( std::min( capH, 8 ) ); if( rng.p( 0.15 ) ) mx = my = 0; }
+    else { mx = rng.u( capW ); my = rng.u( capH ); }
+    const int mts = tu.mts_idx[c];
+    if( mts > 1 ) { mx = std::min( mx, 15 ); my = std::min( my, 15 ); }   // MTS zero-out: only the 16x16 corner can be non-zero
+    tu.max_scan_x[c] = (uint8_t) mx; tu.max_scan_y[c] = (uint8_t) my;
+    tu.coef_off[c] = (uint32_t) B.num_coef;
+    const int cw = mx + 1, ch = my + 1;
+    int16_t* dst = B.coef + B.num_coef;
+    bool any = false;
+    for( int y = 0; y < ch; y++ ) for( int x = 0; x < cw; x++ )
+    {
+      int v = 0;
+      const double dens = ( x == mx && y == my ) ? 1.0 : 0.6 / ( 1.0 + 0.15 * ( x + y ) );
+      if( rng.p( dens ) ) { v = rng.laplace( 1.5 ); if( x == 0 && y == 0 ) v *= 4; if( v == 0 ) v = rng.p( 0.5 ) ? 1 : -1; }
+      dst[y * cw + x] = (int16_t) v; any |= v != 0;
+    }
+    if( !any ) dst[my * cw + mx] = 1;
+    B.num_coef += (uint64_t) cw * ch;
+  }
+
+  void addCu( int x, int y, int w, int h )
+  {
+    vvr_cu& cu = B.cu[B.num_cu]; memset( &cu, 0, sizeof( cu ) );
+    const uint32_t cuIdx = B.num_cu++;
+    cu.x = x; cu.y = y; cu.w = w; cu.h = h; cu.tree = VVR_TREE_JOINT;
+    cu.qp = (int8_t) std::min( 63, std::max( 0, P.base_qp + (int) rng.u( 7 ) - 3 ) );
+    cu.bcw_idx = 2; cu.ref_idx[0] = cu.ref_idx[1] = -1;
+    const bool isI = P.slice_type == 2;
+    const bool intra = isI || ( std::max( w, h ) <= 64 && rng.p( P.p_intra ) );
+    cu.pred_mode = intra ? VVR_PRED_INTRA : VVR_PRED_INTER;
+    if( intra )
+    {
+      const int r = rng.u( 100 );
+      cu.intra_dir[0] = r < 20 ? 0 : r < 35 ? 1 : 2 + rng.u( 65 );
+      const int rc = rng.u( 100 );
+      cu.intra_dir[1] = rc < 40 ? cu.intra_dir[0] : rc < 55 ? 0 : rc < 65 ? 1 : rc < 75 ? 18 : rc < 85 ? 50 : 2 + rng.u( 65 );
+      cu.lfnst_intra_mode = cu.intra_dir[0];
+    }
+    else
+    {
+      const bool canBi = P.slice_type == 0 && P.num_ref[1] > 0 && ( w + h > 12 );
+      const bool bi = canBi && rng.p( P.p_bi );
+      const int list = bi ? 2 : ( P.slice_type == 0 && P.num_ref[1] > 0 && rng.p( 0.5 ) ) ? 1 : 0;
+      cu.inter_dir = bi ? 3 : ( list + 1 );
+      for( int l = 0; l < 2; l++ )
+      {
+        if( !( cu.inter_dir & ( 1 << l ) ) ) continue;
+        cu.ref_idx[l] = (int8_t) rng.u( P.num_ref[l] );
+        int32_t mv[2] = { rng.laplace( P.mv_sigma * 16 / 1.414 ), rng.laplace( P.mv_sigma * 16 / 1.414 ) };
+        const int r = rng.u( 100 );
+        if( r < 15 ) { mv[0] &= ~15; mv[1] &= ~15; }          // integer-pel
+        else if( r < 25 ) mv[0] &= ~15;
+        else if( r < 35 ) mv[1] &= ~15;
+        if( rng.p( P.p_imv_hpel ) ) { cu.imv = 3; mv[0] &= ~7; mv[1] &= ~7; }
+        clipMv( mv, x, y );
+        cu.mv[l][0][0] = mv[0]; cu.mv[l][0][1] = mv[1];
+      }
+      if( cu.imv == 3 ) for( int l = 0; l < 2; l++ ) { cu.mv[l][0][0] &= ~7; cu.mv[l][0][1] &= ~7; }
+      cu.flags |= rng.p( 0.5 ) ? VVR_CU_MERGE : 0;
+      // branch taken by InterPrediction::motionCompensation (InterPrediction.cpp:1372): BDOF/DMVR are off in this generator version
+      bool identical = false;
+      if( bi && P.ref_poc[0][cu.ref_idx[0]] == P.ref_poc[1][cu.ref_idx[1]] && cu.mv[0][0][0] == cu.mv[1][0][0] && cu.mv[0][0][1] == cu.mv[1][0][1] ) identical = true;
+      cu.mc_mode = ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
+    }
+    // transform units: split at 64 (max TB size), cbf per block
+    cu.first_tu = B.num_tu;
+    bool rootCbf = false;
+    const int tw = std::min( w, 64 ), th = std::min( h, 64 );
+    for( int ty = 0; ty < h; ty += th ) for( int tx = 0; tx < w; tx += tw )
+    {
+      vvr_tu& tu = B.tu[B.num_tu]; memset( &tu, 0, sizeof( tu ) );
+      const uint32_t tuIdx = B.num_tu++;
+      tu.x = x + tx; tu.y = y + ty; tu.w = tw; tu.h = th; tu.cu = cuIdx;
+      tu.comp_mask = P.chroma_format ? 7 : 1;
+      const int qpBd = 6 * ( bd - 8 );
+      tu.qp[0] = (int8_t) ( cu.qp + qpBd );
+      tu.qp[1] = tu.qp[2] = (int8_t) ( std::min( 63, std::max( -qpBd, (int) cu.qp ) ) + qpBd );   // identity chroma QP mapping, zero offsets
+      for( int c = 0; c < ( P.chroma_format ? 3 : 1 ); c++ )
+      {
+        const int bw = c ? tw >> 1 : tw, bh = c ? th >> 1 : th;
+        if( !rng.p( c ? P.p_coded_chroma : P.p_coded ) ) continue;
+        tu.cbf |= 1 << c;
+        bool ts = bw <= 32 && bh <= 32 && rng.p( P.p_ts );
+        tu.mts_idx[c] = ts ? VVR_MTS_SKIP : VVR_MTS_DCT2;
+        if( !ts && c == 0 && bw <= 32 && bh <= 32 && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
+        // getTrTypes (TrQuant.cpp:330): explicit MTS -> hor = (idx-2)&1 ? DCT8 : DST7 ; ver = (idx-2)>>1 ? DCT8 : DST7
+        int hor = 0, ver = 0;
+        if( tu.mts_idx[c] > 1 ) { hor = ( ( tu.mts_idx[c] - 2 ) & 1 ) ? 1 : 2; ver = ( ( tu.mts_idx[c] - 2 ) >> 1 ) ? 1 : 2; }
+        tu.tr_type[c] = (uint8_t) ( ( ver << 2 ) | hor );
+        genLevels( tu, c, bw, bh, ts );
+        rootCbf = true;
+      }
+      for( int yy = 0; yy < th; yy += 4 ) for( int xx = 0; xx < tw; xx += 4 )
+        if( tu.x + xx < W && tu.y + yy < H ) tuOf4[( ( tu.y + yy ) >> 2 ) * w4 + ( ( tu.x + xx ) >> 2 )] = (int32_t) tuIdx;
+    }
+    cu.num_tu = B.num_tu - cu.first_tu;
+    if( rootCbf ) cu.flags |= VVR_CU_ROOT_CBF;
+    if( !intra && !rootCbf && ( cu.flags & VVR_CU_MERGE ) ) cu.flags |= VVR_CU_SKIP;
+    // motion field + CU map
+    for( int yy = 0; yy < h; yy += 4 ) for( int xx = 0; xx < w; xx += 4 )
+    {
+      const int i4 = ( ( y + yy ) >> 2 ) * w4 + ( ( x + xx ) >> 2 );
+      cuOf4[i4] = (int32_t) cuIdx;
+      vvr_motion& m = B.motion[i4];
+      m.ref_idx[0] = cu.ref_idx[0]; m.ref_idx[1] = cu.ref_idx[1];
+      for( int l = 0; l < 2; l++ ) { m.mv[l][0] = cu.ref_idx[l] >= 0 ? cu.mv[l][0][0] : 0; m.mv[l][1] = cu.ref_idx[l] >= 0 ? cu.mv[l][0][1] : 0; }
+    }
+  }
+
+  void split( int x, int y, int w, int h )
+  {
+    if( x >= W || y >= H ) return;
+    const int minS = 1 << P.min_cu_log2;
+    const bool crossX = x + w > W, crossY = y + h > H;
+    if( crossX || crossY )
+    {
+      // implicit boundary split: quad when possible, else binary in the crossing direction
+      if( w > minS && h > minS && ( ( crossX && crossY ) || w == h ) ) { const int hw = w >> 1, hh = h >> 1; split( x, y, hw, hh ); split( x + hw, y, hw, hh ); split( x, y + hh, hw, hh ); split( x + hw, y + hh, hw, hh ); }
+      else if( crossX && w > minS ) { split( x, y, w >> 1, h ); split( x + ( w >> 1 ), y, w >> 1, h ); }
+      else if( crossY && h > minS ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); }
+      return;
+    }
+    const int s = std::max( w, h );
+    double ps = s >= 128 ? 0.92 : s >= 64 ? 0.70 : s >= 32 ? 0.45 : s >= 16 ? 0.25 : 0.0;
+    ps = std::min( 0.98, ps * P.p_split_scale );
+    if( w != h && std::min( w, h ) <= minS ) ps *= 0.5;
+    if( P.slice_type == 2 && s > 64 ) ps = 1.0;   // intra pictures: CUs <= 64
+    if( rng.p( ps ) )
+    {
+      const int r = rng.u( 100 );
+      const bool canQ = w == h && w > minS, canH = h > minS, canV = w > minS;
+      const bool canTH = h >= 4 * minS && h <= 64, canTV = w >= 4 * minS && w <= 64;
+      if( canQ && r < 50 ) { const int hw = w >> 1; split( x, y, hw, hw ); split( x + hw, y, hw, hw ); split( x, y + hw, hw, hw ); split( x + hw, y + hw, hw, hw ); return; }
+      if( canV && ( r < 68 || !canH ) ) { split( x, y, w >> 1, h ); split( x + ( w >> 1 ), y, w >> 1, h ); return; }
+      if( canH && r < 86 ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); return; }
+      if( canTV && r < 93 ) { split( x, y, w >> 2, h ); split( x + ( w >> 2 ), y, w >> 1, h ); split( x + 3 * ( w >> 2 ), y, w >> 2, h ); return; }
+      if( canTH ) { split( x, y, w, h >> 2 ); split( x, y + ( h >> 2 ), w, h >> 1 ); split( x, y + 3 * ( h >> 2 ), w, h >> 2 ); return; }
+      if( canH ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); return; }
+    }
+    addCu( x, y, w, h );
+  }
+
+  // ---------------------------------------------------------------------------------------------------------------
+  // deblocking edge parameters: the table LoopFilter::calcFilterStrengthsCTU (LoopFilter.cpp:495-1360) fills.
+  // This generator version has no sub-block (affine/SbTMVP) edges, no ISP/SBT, single tree.
+  // ---------------------------------------------------------------------------------------------------------------
+  void deriveLfp()
+  {
+    const int qpBd = 6 * ( bd - 8 );
+    for( int d = 0; d < 2; d++ )
+    {
+      memset( B.lfp[d], 0, sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+      for( int y4 = 0; y4 < h4; y4++ ) for( int x4 = 0; x4 < w4; x4++ )
+      {
+        const int px4 = d == 0 ? x4 - 1 : x4, py4 = d == 0 ? y4 : y4 - 1;
+        if( px4 < 0 || py4 < 0 ) continue;                    // picture boundary: never filtered
+        const int iq = y4 * w4 + x4, ip = py4 * w4 + px4;
+        const int tq = tuOf4[iq], tp = tuOf4[ip];
+        if( tq == tp ) continue;                               // not a transform (or CU) edge
+        const vvr_tu& TQ = B.tu[tq]; const vvr_tu& TP = B.tu[tp];
+        const vvr_cu& CQ = B.cu[TQ.cu]; const vvr_cu& CP = B.cu[TP.cu];
+        vvr_lfp& L = B.lfp[d][iq];
+        // maximum filter lengths from the transform sizes orthogonal to the edge (LoopFilter.cpp:910-922)
+        const int sizeQ = d == 0 ? TQ.w : TQ.h, sizeP = d == 0 ? TP.w : TP.h;
+        int lenP, lenQ;
+        if( sizeP <= 4 || sizeQ <= 4 ) lenP = lenQ = 1;
+        else { lenP = sizeP >= 32 ? 7 : 3; lenQ = sizeQ >= 32 ? 7 : 3; }
+        L.side_max_filt_length = (uint8_t) ( 0x80 | ( lenP << 4 ) | lenQ );
+        L.flags = 1;                                           // filterEdge luma
+        // chroma edges live on the 8x8 chroma-sample grid = 16 luma samples
+        const int posAlong = d == 0 ? ( x4 << 2 ) : ( y4 << 2 );
+        const bool chromaEdge = P.chroma_format && ( posAlong % 16 == 0 );
+        if( chromaEdge )
+        {
+          if( ( sizeP >> 1 ) >= 8 && ( sizeQ >> 1 ) >= 8 ) L.flags |= 0x20;   // both sides >= 8 chroma samples: long chroma filter allowed
+        }
+        // boundary strength (LoopFilter.cpp:1094-1360)
+        int bsY = 0, bsCb = 0, bsCr = 0;
+        const bool intra = CQ.pred_mode == VVR_PRED_INTRA || CP.pred_mode == VVR_PRED_INTRA;
+        if( intra ) { bsY = 2; bsCb = bsCr = chromaEdge ? 2 : 0; }
+        else
+        {
+          if( ( TQ.cbf & 1 ) || ( TP.cbf & 1 ) ) bsY = 1;
+          if( chromaEdge ) { if( ( TQ.cbf & 2 ) || ( TP.cbf & 2 ) ) bsCb = 1; if( ( TQ.cbf & 4 ) || ( TP.cbf & 4 ) ) bsCr = 1; }
+          if( !bsY && &CQ != &CP )
+          {
+            // motion-based rule
+            const vvr_motion& mq = B.motion[iq]; const vvr_motion& mp = B.motion[ip];
+            auto refPoc = [&]( const vvr_motion& m, int l ) { return m.ref_idx[l] >= 0 ? P.ref_poc[l][m.ref_idx[l]] : INT32_MIN; };
+            const int nq = ( mq.ref_idx[0] >= 0 ) + ( mq.ref_idx[1] >= 0 ), np = ( mp.ref_idx[0] >= 0 ) + ( mp.ref_idx[1] >= 0 );
+            auto far = [&]( const int32_t a[2], const int32_t b[2] ) { return std::abs( a[0] - b[0] ) >= 8 || std::abs( a[1] - b[1] ) >= 8; };
+            if( nq != np ) bsY = 1;
+            else if( nq == 1 )
+            {
+              const int lq = mq.ref_idx[0] >= 0 ? 0 : 1, lp = mp.ref_idx[0] >= 0 ? 0 : 1;
+              bsY = ( refPoc( mq, lq ) != refPoc( mp, lp ) || far( mq.mv[lq], mp.mv[lp] ) ) ? 1 : 0;
+            }
+            else
+            {
+              const int q0 = refPoc( mq, 0 ), q1 = refPoc( mq, 1 ), p0 = refPoc( mp, 0 ), p1 = refPoc( mp, 1 );
+              if( !( ( q0 == p0 && q1 == p1 ) || ( q0 == p1 && q1 == p0 ) ) ) bsY = 1;
+              else if( p0 != p1 )
+              {
+                if( q0 == p0 ) bsY = ( far( mq.mv[0], mp.mv[0] ) || far( mq.mv[1], mp.mv[1] ) ) ? 1 : 0;
+                else           bsY = ( far( mq.mv[0], mp.mv[1] ) || far( mq.mv[1], mp.mv[0] ) ) ? 1 : 0;
+              }
+              else
+                bsY = ( ( far( mq.mv[0], mp.mv[0] ) || far( mq.mv[1], mp.mv[1] ) ) && ( far( mq.mv[0], mp.mv[1] ) || far( mq.mv[1], mp.mv[0] ) ) ) ? 1 : 0;
+            }
+          }
+        }
+        L.bs = (uint8_t) ( bsY | ( bsCb << 2 ) | ( bsCr << 4 ) );
+        L.qp[0] = (int8_t) ( ( CQ.qp + CP.qp + 1 ) >> 1 );
+        L.qp[1] = (int8_t) ( ( TQ.qp[1] + TP.qp[1] - 2 * qpBd + 1 ) >> 1 );
+        L.qp[2] = (int8_t) ( ( TQ.qp[2] + TP.qp[2] - 2 * qpBd + 1 ) >> 1 );
+        if( !L.bs ) { /* edge without any filtering keeps its length info, like the reference table */ }
+      }
+    }
+  }
+
+  void genLoopFilterParams()
+  {
+    const int numCtu = ( ( W + ctu - 1 ) / ctu ) * ( ( H + ctu - 1 ) / ctu );
+    const int maxOff = 7;   // (1 << (min(bd,10) - 5)) - 1
+    for( int a = 0; a < numCtu; a++ )
+    {
+      vvr_sao_ctu& s = B.sao[a]; memset( &s, 0, sizeof( s ) );
+      for( int c = 0; c < ( P.chroma_format ? 3 : 1 ); c++ )
+      {
+        const bool en = ( P.tool_flags & ( c ? VVR_TOOL_SAO_CHROMA : VVR_TOOL_SAO_LUMA ) ) && rng.p( P.p_sao );
+        if( !en ) continue;
+        s.mode[c] = 1;
+        if( c == 2 ) { s.type[2] = s.type[1]; if( !s.mode[1] ) s.type[2] = (uint8_t) rng.u( 5 ); }   // Cb and Cr share the type when both are on
+        else s.type[c] = (uint8_t) ( rng.p( 0.75 ) ? rng.u( 4 ) : 4 );
+        if( s.type[c] == 4 ) { s.band_pos[c] = (uint8_t) rng.u( 32 ); for( int i = 0; i < 4; i++ ) s.offset[c][i] = (int8_t) ( (int) rng.u( 2 * maxOff + 1 ) - maxOff ); }
+        else { s.offset[c][0] = (int8_t) rng.u( maxOff + 1 ); s.offset[c][1] = (int8_t) rng.u( maxOff + 1 ); s.offset[c][2] = (int8_t) -(int) rng.u( maxOff + 1 ); s.offset[c][3] = (int8_t) -(int) rng.u( maxOff + 1 ); }
+      }
+      vvr_alf_ctu& f = B.alf[a]; memset( &f, 0, sizeof( f ) );
+      if( P.tool_flags & VVR_TOOL_ALF )
+      {
+        f.enable[0] = rng.p( P.p_alf_luma );
+        f.luma_filter_idx = (int16_t) ( rng.p( 0.5 ) ? rng.u( 16 ) : 16 + rng.u( B.alf_params->num_luma_aps ) );
+        if( P.chroma_format ) { f.enable[1] = rng.p( P.p_alf_chroma ); f.enable[2] = rng.p( P.p_alf_chroma ); f.alt[0] = (uint8_t) rng.u( VVR_ALF_MAX_CHR_ALT ); f.alt[1] = (uint8_t) rng.u( VVR_ALF_MAX_CHR_ALT ); }
+        if( ( P.tool_flags & VVR_TOOL_CCALF ) && P.chroma_format ) { f.cc_idc[0] = rng.p( P.p_ccalf ) ? 1 + rng.u( VVR_CCALF_FILTERS ) : 0; f.cc_idc[1] = rng.p( P.p_ccalf ) ? 1 + rng.u( VVR_CCALF_FILTERS ) : 0; }
+      }
+    }
+  }
+
+  void genAlfParams()
+  {
+    vvr_alf_params& A = *B.alf_params; memset( &A, 0, sizeof( A ) );
+    static const int clipVals[3][4] = { { 256, 32, 8, 2 }, { 512, 64, 16, 4 }, { 1024, 128, 32, 8 } };   // AdaptiveLoopFilter.cpp:382
+    const int* cv = clipVals[bd - 8];
+    A.num_luma_aps = 2;
+    for( int a = 0; a < VVR_MAX_ALF_APS; a++ ) for( int c = 0; c < VVR_ALF_CLASSES; c++ ) for( int k = 0; k < 12; k++ )
+    {
+      A.luma_coeff[a][c][k] = (int16_t) std::max( -128, std::min( 127, rng.laplace( k >= 9 ? 12.0 : 5.0 ) ) );
+      A.luma_clip[a][c][k]  = (int16_t) cv[rng.u( 4 )];
+    }
+    for( int alt = 0; alt < VVR_ALF_MAX_CHR_ALT; alt++ ) for( int k = 0; k < 6; k++ )
+    {
+      A.chroma_coeff[alt][k] = (int16_t) std::max( -128, std::min( 127, rng.laplace( k >= 4 ? 12.0 : 5.0 ) ) );
+      A.chroma_clip[alt][k]  = (int16_t) cv[rng.u( 4 )];
+    }
+    for( int c = 0; c < 2; c++ ) for( int f = 0; f < VVR_CCALF_FILTERS; f++ ) for( int k = 0; k < 7; k++ )
+    {
+      const int e = rng.u( 8 );          // CC-ALF coefficients are signed powers of two (or zero)
+      A.ccalf_coeff[c][f][k] = (int16_t) ( e == 0 ? 0 : ( rng.p( 0.5 ) ? 1 : -1 ) * ( 1 << ( e - 1 ) ) );
+    }
+  }
+
+  int run()
+  {
+    W = P.width; H = P.height; w4 = ( W + 3 ) >> 2; h4 = ( H + 3 ) >> 2; ctu = 1 << P.log2_ctu; bd = P.bit_depth;
+    cuOf4.assign( (size_t) w4 * h4, -1 ); tuOf4.assign( (size_t) w4 * h4, -1 );
+    B.num_cu = B.num_tu = 0; B.num_coef = 0; B.num_dmvr = 0;
+    for( size_t i = 0; i < (size_t) w4 * h4; i++ ) { memset( &B.motion[i], 0, sizeof( vvr_motion ) ); B.motion[i].ref_idx[0] = B.motion[i].ref_idx[1] = -1; }
+    vvr_pic_header& h = B.hdr; memset( &h, 0, sizeof( h ) );
+    h.abi_version = VVR_ABI_VERSION; h.tool_flags = P.tool_flags; h.width = W; h.height = H; h.chroma_format = P.chroma_format; h.bit_depth = bd;
+    h.log2_ctu = P.log2_ctu; h.slice_type = P.slice_type; h.poc = P.poc; h.out_slot = P.out_slot; h.min_qp_ts = 4;
+    for( int l = 0; l < 2; l++ ) { h.num_ref[l] = P.slice_type == 2 ? 0 : P.num_ref[l]; for( int i = 0; i < VVR_MAX_REFS; i++ ) { h.ref_slot[l][i] = P.ref_slot[l][i]; h.ref_poc[l][i] = P.ref_poc[l][i]; } }
+    for( int c = 0; c < 3; c++ ) { h.deblock_beta_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); h.deblock_tc_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); }
+    int a = 0;
+    for( int y = 0; y < H; y += ctu ) for( int x = 0; x < W; x += ctu, a++ ) { B.ctu_first_cu[a] = B.num_cu; split( x, y, ctu, ctu ); }
+    B.ctu_first_cu[a] = B.num_cu;
+    deriveLfp();
+    genAlfParams();
+    genLoopFilterParams();
+    return 0;
+  }
+};
+
+} // namespace
+
+__attribute__((visibility("default")))
+int vvs_generate( const vvs_params* P, vvs_buffers* B )
+{
+  if( P->min_cu_log2 < 3 || P->chroma_format > 1 || P->bit_depth < 8 || P->bit_depth > 10 ) return -1;
+  Gen g( *P, *B );
+  return g.run();
+}
+
+} // extern "C"

@@ -1,0 +1,101 @@
+"""Synthetic pre-parsed VVC picture stream (measurement/test infrastructure; wraps tools/synth.cpp).
+
+`generate(params)` returns a PictureDesc; `ra_gop(...)` yields the pictures of a hierarchical-B random-access stream
+ with DPB slot assignment, in decode order.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+from . import abi, desc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SRC = os.path.join(_ROOT, "tools", "synth.cpp")
+_LIB = os.path.join(_ROOT, "tools", "libvvrsynth.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-Wall", _SRC, "-o", _LIB])
+    return _LIB
+
+
+class Params(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("width", C.c_uint16), ("height", C.c_uint16),
+                ("bit_depth", C.c_uint8), ("log2_ctu", C.c_uint8), ("chroma_format", C.c_uint8), ("slice_type", C.c_uint8),
+                ("tool_flags", C.c_uint32), ("num_ref", C.c_int8 * 2), ("poc", C.c_int32),
+                ("ref_poc", C.c_int32 * abi.VVR_MAX_REFS * 2), ("ref_slot", C.c_int16 * abi.VVR_MAX_REFS * 2), ("out_slot", C.c_int16),
+                ("base_qp", C.c_int8), ("min_cu_log2", C.c_uint8),
+                ("p_intra", C.c_float), ("p_bi", C.c_float), ("p_coded", C.c_float), ("p_coded_chroma", C.c_float),
+                ("p_small_corner", C.c_float), ("p_mts", C.c_float), ("p_ts", C.c_float), ("p_lfnst", C.c_float),
+                ("p_split_scale", C.c_float), ("mv_sigma", C.c_float),
+                ("p_sao", C.c_float), ("p_alf_luma", C.c_float), ("p_alf_chroma", C.c_float), ("p_ccalf", C.c_float),
+                ("p_imv_hpel", C.c_float), ("p_jccr", C.c_float)]
+
+
+class Buffers(C.Structure):
+    _fields_ = [("cu", C.c_void_p), ("max_cu", C.c_uint32), ("tu", C.c_void_p), ("max_tu", C.c_uint32),
+                ("coef", C.c_void_p), ("max_coef", C.c_uint64), ("ctu_first_cu", C.c_void_p),
+                ("motion", C.c_void_p), ("lfp", C.c_void_p * 2), ("sao", C.c_void_p), ("alf", C.c_void_p), ("alf_params", C.c_void_p),
+                ("num_cu", C.c_uint32), ("num_tu", C.c_uint32), ("num_coef", C.c_uint64), ("num_dmvr", C.c_uint32),
+                ("hdr", abi.PicHeader)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.vvs_generate.restype = C.c_int
+    return _lib
+
+
+def default_params(**kw):
+    p = Params()
+    lib().vvs_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def set_refs(p, l0, l1=()):
+    for l, lst in enumerate((l0, l1)):
+        p.num_ref[l] = len(lst)
+        for i, (slot, poc) in enumerate(lst):
+            p.ref_slot[l][i] = slot
+            p.ref_poc[l][i] = poc
+
+
+def generate(p):
+    """Run the generator; returns a desc.PictureDesc owning compact copies of all arrays."""
+    L = lib()
+    mcu, mtu, mcoef = C.c_uint32(), C.c_uint32(), C.c_uint64()
+    L.vvs_bounds(C.byref(p), C.byref(mcu), C.byref(mtu), C.byref(mcoef))
+    d = desc.PictureDesc(p.width, p.height, p.bit_depth, p.log2_ctu, p.chroma_format, p.slice_type, p.poc, p.out_slot, p.tool_flags)
+    cu = np.zeros(mcu.value, desc.CU_DT)
+    tu = np.zeros(mtu.value, desc.TU_DT)
+    coef = np.zeros(mcoef.value, np.int16)
+    d.motion = np.zeros(d.w4 * d.h4, desc.MOTION_DT)
+    d.sao = np.zeros(d.num_ctu, desc.SAO_DT)
+    d.alf = np.zeros(d.num_ctu, desc.ALF_DT)
+    d.alf_params = abi.AlfParams()
+    b = Buffers()
+    b.cu, b.max_cu, b.tu, b.max_tu = cu.ctypes.data, mcu.value, tu.ctypes.data, mtu.value
+    b.coef, b.max_coef = coef.ctypes.data, mcoef.value
+    b.ctu_first_cu = d.ctu_first_cu.ctypes.data
+    b.motion = d.motion.ctypes.data
+    b.lfp[0], b.lfp[1] = d.lfp[0].ctypes.data, d.lfp[1].ctypes.data
+    b.sao, b.alf = d.sao.ctypes.data, d.alf.ctypes.data
+    b.alf_params = C.addressof(d.alf_params)
+    rc = L.vvs_generate(C.byref(p), C.byref(b))
+    if rc != 0:
+        raise RuntimeError("vvs_generate failed (%d)" % rc)
+    d.hdr = abi.PicHeader.from_buffer_copy(b.hdr)
+    d.cu = cu[:b.num_cu].copy()
+    d.tu = tu[:b.num_tu].copy()
+    d.coef = coef[:max(1, b.num_coef)].copy()
+    d.num_dmvr = b.num_dmvr
+    return d
