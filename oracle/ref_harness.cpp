@@ -438,7 +438,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       cu.setSbtInfo( c.sbt_info );
       cu.setInterDir( c.inter_dir );
       cu.refIdx[0] = c.ref_idx[0]; cu.refIdx[1] = c.ref_idx[1];
-      cu.setBcwIdx( c.pred_mode == VVR_PRED_INTER ? c.bcw_idx : BCW_DEFAULT );
+      cu.setBcwIdx( c.pred_mode == VVR_PRED_INTER ? g_BcwInternFwd[c.bcw_idx] : BCW_DEFAULT );   // description uses the weight-table index (2 = default), the reference its "internal domain"
       cu.setImv( c.imv );
       cu.geoSplitDir = c.geo_split_dir;
       cu.setInterDirrefIdxGeo0( c.geo_dir_ref[0] ); cu.setInterDirrefIdxGeo1( c.geo_dir_ref[1] );

@@ -1,0 +1,183 @@
+/* oracle/vvc_oracle.c — CPU restatement (TEST INFRASTRUCTURE): picture-level driver.
+ *
+ * Order of operations = the stage order of DecLibRecon::ctuTask (DecoderLib/DecLibRecon.cpp:732-1110) run as whole-picture
+ * passes, and inside a CU the order of DecCu::predAndReco / finishLMCSAndReco / reconstructResi
+ * (DecoderLib/DecCu.cpp:271-481, :483-534, :536-583). */
+#include "vvc_oracle_common.h"
+#include <stdio.h>
+
+static char g_err[256];
+void vvo_set_error( const char* msg ) { snprintf( g_err, sizeof( g_err ), "%s", msg ); }
+const char* vvo_last_error( void ) { return g_err; }
+
+int vvo_planes_alloc( vvo_planes* pl, int width, int height, int chroma_format )
+{
+  memset( pl, 0, sizeof( *pl ) );
+  pl->ncomp = chroma_format ? 3 : 1;
+  for( int c = 0; c < pl->ncomp; c++ )
+  {
+    pl->w[c] = c ? width >> 1 : width; pl->h[c] = c ? height >> 1 : height; pl->stride[c] = pl->w[c];
+    pl->p[c] = (pel*) calloc( (size_t) pl->w[c] * pl->h[c], sizeof( pel ) );
+    if( !pl->p[c] ) return -1;
+  }
+  return 0;
+}
+void vvo_planes_free( vvo_planes* pl ) { for( int c = 0; c < 3; c++ ) { free( pl->p[c] ); pl->p[c] = 0; } }
+
+/* residuals of one TU into tight per-component buffers (DecCu::reconstructResi, DecCu.cpp:536); returns mask of components that carry a residual */
+static int tu_residuals( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, int16_t* resi[3], int bw[3], int bh[3] )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int ncomp = H->chroma_format ? 3 : 1;
+  int mask = 0;
+  for( int c = 0; c < ncomp; c++ )
+  {
+    bw[c] = ( c && cu->isp_mode ) ? cu->w >> 1 : tu->w >> ( c ? 1 : 0 );
+    bh[c] = ( c && cu->isp_mode ) ? cu->h >> 1 : tu->h >> ( c ? 1 : 0 );
+    if( !( tu->comp_mask & ( 1 << c ) ) ) continue;
+    if( c && tu->joint_cbcr )
+    {
+      if( c != 1 ) continue;
+      /* joint Cb-Cr: one coded block, the other derived (TrQuant::invTransformICT, TrQuant.cpp:108-126,320) */
+      const int codedC = ( tu->joint_cbcr >> 1 ) ? 1 : 2;
+      if( vvo_residual_block( H, cu, tu, codedC, pic->coef, resi[codedC], bw[codedC] ) ) return -1;
+      static const int ict[2][4] = { { 0, 3, 1, 2 }, { 0, -3, -1, -2 } };               /* g_ictModes (Rom.cpp:409) */
+      const int mode = ict[( H->tool_flags & VVR_TOOL_JCCR_SIGN ) ? 1 : 0][tu->joint_cbcr];
+      int16_t *cb = resi[1], *cr = resi[2];
+      for( int i = 0; i < bw[1] * bh[1]; i++ )
+      {
+        if(      mode ==  1 ) cr[i] = (int16_t) (  cb[i] >> 1 );
+        else if( mode == -1 ) cr[i] = (int16_t) ( -cb[i] >> 1 );
+        else if( mode ==  2 ) cr[i] = cb[i];
+        else if( mode == -2 ) cr[i] = (int16_t) -cb[i];
+        else if( mode ==  3 ) cb[i] = (int16_t) (  cr[i] >> 1 );
+        else if( mode == -3 ) cb[i] = (int16_t) ( -cr[i] >> 1 );
+      }
+      bw[2] = bw[1]; bh[2] = bh[1];
+      mask |= 6;
+    }
+    else if( tu->cbf & ( 1 << c ) )
+    {
+      if( vvo_residual_block( H, cu, tu, c, pic->coef, resi[c], bw[c] ) ) return -1;
+      mask |= 1 << c;
+    }
+  }
+  return mask;
+}
+
+int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, uint16_t* const* out_planes, int flags )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int W = H->width, Hh = H->height, ncomp = H->chroma_format ? 3 : 1;
+  int rc = -1;
+  g_err[0] = 0;
+  /* reference pictures */
+  int numSlots = 0;
+  for( int l = 0; l < 2; l++ ) for( int i = 0; i < H->num_ref[l]; i++ ) if( H->ref_slot[l][i] + 1 > numSlots ) numSlots = H->ref_slot[l][i] + 1;
+  vvo_planes* refs = (vvo_planes*) calloc( (size_t) ( numSlots + 1 ), sizeof( vvo_planes ) );
+  vvo_planes reco, flt;
+  memset( &reco, 0, sizeof( reco ) ); memset( &flt, 0, sizeof( flt ) );
+  int16_t* resi[3] = { 0, 0, 0 };
+  int32_t* order = 0;
+  if( H->slice_type != 2 )
+    for( int l = 0; l < 2; l++ ) for( int i = 0; i < H->num_ref[l]; i++ )
+    {
+      const int s = H->ref_slot[l][i];
+      if( refs[s].p[0] ) continue;
+      if( vvo_planes_alloc( &refs[s], W, Hh, H->chroma_format ) ) goto done;
+      for( int c = 0; c < ncomp; c++ )
+      {
+        if( !ref_planes || !ref_planes[s * 3 + c] ) { vvo_set_error( "missing reference plane" ); goto done; }
+        for( size_t k = 0; k < (size_t) refs[s].w[c] * refs[s].h[c]; k++ ) refs[s].p[c][k] = (pel) ref_planes[s * 3 + c][k];
+      }
+    }
+  if( vvo_planes_alloc( &reco, W, Hh, H->chroma_format ) || vvo_planes_alloc( &flt, W, Hh, H->chroma_format ) ) goto done;
+  for( int c = 0; c < 3; c++ ) resi[c] = (int16_t*) malloc( sizeof( int16_t ) * 128 * 128 );
+
+  /* decode-order index of the transform block covering each 4x4 (luma tree / chroma tree): intra reference availability */
+  const int w4 = ( W + 3 ) >> 2, h4 = ( Hh + 3 ) >> 2;
+  order = (int32_t*) malloc( sizeof( int32_t ) * (size_t) w4 * h4 * 2 );
+  for( size_t k = 0; k < (size_t) w4 * h4 * 2; k++ ) order[k] = 0x7fffffff;
+  for( uint32_t i = 0; i < pic->num_cu; i++ )
+  {
+    const vvr_cu* cu = &pic->cu[i];
+    for( uint32_t t = cu->first_tu; t < cu->first_tu + cu->num_tu; t++ )
+    {
+      const vvr_tu* tu = &pic->tu[t];
+      for( int ch = 0; ch < 2; ch++ )
+      {
+        if( ch == 0 && !( tu->comp_mask & 1 ) ) continue;
+        if( ch == 1 && !( tu->comp_mask & 6 ) ) continue;
+        int x0 = tu->x, y0 = tu->y, ww = tu->w, hh = tu->h;
+        if( ch == 1 && cu->isp_mode ) { x0 = cu->x; y0 = cu->y; ww = cu->w; hh = cu->h; }
+        for( int y = y0; y < y0 + hh && y < Hh; y += 4 ) for( int x = x0; x < x0 + ww && x < W; x += 4 )
+          order[(size_t) ch * w4 * h4 + ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) t;
+      }
+    }
+  }
+
+  /* ---- INTER + INTRA stages */
+  for( uint32_t i = 0; i < pic->num_cu; i++ )
+  {
+    const vvr_cu* cu = &pic->cu[i];
+    if( cu->pred_mode == VVR_PRED_INTER )
+    {
+      if( vvo_inter_cu( pic, cu, refs, numSlots, &reco ) ) goto done;
+      if( cu->flags & VVR_CU_ROOT_CBF )
+        for( uint32_t t = cu->first_tu; t < cu->first_tu + cu->num_tu; t++ )
+        {
+          const vvr_tu* tu = &pic->tu[t];
+          int bw[3], bh[3];
+          const int mask = tu_residuals( pic, cu, tu, resi, bw, bh );
+          if( mask < 0 ) goto done;
+          for( int c = 0; c < ncomp; c++ )
+          {
+            if( !( mask & ( 1 << c ) ) ) continue;
+            /* AreaBuf::reconstruct (Buffer.cpp:482): reco = clip( pred + resi ) */
+            const int bx = tu->x >> ( c ? 1 : 0 ), by = tu->y >> ( c ? 1 : 0 );
+            for( int y = 0; y < bh[c]; y++ ) for( int x = 0; x < bw[c]; x++ )
+            {
+              pel* d = &reco.p[c][(size_t) ( by + y ) * reco.stride[c] + bx + x];
+              *d = (pel) vvo_clip_pel( *d + resi[c][y * bw[c] + x], H->bit_depth );
+            }
+          }
+        }
+    }
+    else if( cu->pred_mode == VVR_PRED_INTRA )
+    {
+      for( uint32_t t = cu->first_tu; t < cu->first_tu + cu->num_tu; t++ )
+      {
+        const vvr_tu* tu = &pic->tu[t];
+        int bw[3], bh[3];
+        const int mask = tu_residuals( pic, cu, tu, resi, bw, bh );
+        if( mask < 0 ) goto done;
+        for( int c = 0; c < ncomp; c++ )
+        {
+          if( !( tu->comp_mask & ( 1 << c ) ) ) continue;
+          if( vvo_intra_tu( pic, cu, tu, t, c, &reco, order, resi[c], ( mask >> c ) & 1 ) ) goto done;
+        }
+      }
+    }
+    else { vvo_set_error( "IBC is not restated" ); goto done; }
+  }
+
+  if( !( flags & VVO_STOP_AFTER_RECO ) )
+  {
+    vvo_deblock( pic, &reco, 0 );
+    vvo_deblock( pic, &reco, 1 );
+    if( !( flags & VVO_STOP_AFTER_DBK ) )
+    {
+      if( H->tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) { vvo_sao( pic, &reco, &flt ); vvo_planes tmp = reco; reco = flt; flt = tmp; }
+      if( !( flags & VVO_STOP_AFTER_SAO ) && ( H->tool_flags & VVR_TOOL_ALF ) && pic->alf && pic->alf_params ) { vvo_alf( pic, &reco, &flt ); vvo_planes tmp = reco; reco = flt; flt = tmp; }
+    }
+  }
+  for( int c = 0; c < ncomp; c++ ) if( out_planes[c] )
+    for( size_t k = 0; k < (size_t) reco.w[c] * reco.h[c]; k++ ) out_planes[c][k] = (uint16_t) reco.p[c][k];
+  rc = 0;
+done:
+  for( int s = 0; s < numSlots; s++ ) vvo_planes_free( &refs[s] );
+  free( refs ); vvo_planes_free( &reco ); vvo_planes_free( &flt );
+  for( int c = 0; c < 3; c++ ) free( resi[c] );
+  free( order );
+  return rc;
+}

@@ -1,0 +1,48 @@
+/* oracle/vvc_oracle_common.h — shared declarations of the CPU restatement (test infrastructure). */
+#ifndef VVC_ORACLE_COMMON_H
+#define VVC_ORACLE_COMMON_H
+#include "vvc_oracle.h"
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int16_t pel;
+
+typedef struct {
+  pel* p[3];
+  int  w[3], h[3], stride[3];
+  int  ncomp;
+} vvo_planes;
+
+static inline int vvo_clip3( int lo, int hi, int v ) { return v < lo ? lo : v > hi ? hi : v; }
+static inline int vvo_clip_pel( int v, int bd ) { return vvo_clip3( 0, ( 1 << bd ) - 1, v ); }
+static inline int vvo_log2( int v ) { int l = 0; while( ( 1 << l ) < v ) l++; return l; }
+static inline int vvo_abs( int v ) { return v < 0 ? -v : v; }
+static inline int vvo_min( int a, int b ) { return a < b ? a : b; }
+static inline int vvo_max( int a, int b ) { return a > b ? a : b; }
+static inline int vvo_sgn( int v ) { return ( v > 0 ) - ( v < 0 ); }
+
+/* clamped read of a reference plane = reading the border-extended picture (Picture::extendPicBorder, Picture.cpp:400) */
+static inline int vvo_ref_at( const vvo_planes* r, int c, int x, int y )
+{
+  x = vvo_clip3( 0, r->w[c] - 1, x ); y = vvo_clip3( 0, r->h[c] - 1, y );
+  return r->p[c][(size_t) y * r->stride[c] + x];
+}
+
+int  vvo_planes_alloc( vvo_planes* pl, int width, int height, int chroma_format );
+void vvo_planes_free( vvo_planes* pl );
+
+/* vvc_oracle_trafo.c */
+int  vvo_residual_block( const vvr_pic_header* hdr, const vvr_cu* cu, const vvr_tu* tu, int comp, const int16_t* coef, int16_t* resi, int rstride );
+/* vvc_oracle_inter.c */
+int  vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* refs /* [slot] */, int num_slots, vvo_planes* reco );
+/* vvc_oracle_intra.c */
+int  vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, vvo_planes* reco,
+                   const int32_t* tu_order_map /* per 4x4 luma units, per channel type */, const int16_t* resi, int has_resi );
+/* vvc_oracle_loopfilter.c */
+void vvo_deblock( const vvr_picture* pic, vvo_planes* reco, int dir );
+void vvo_sao( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst );
+void vvo_alf( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst );
+
+void vvo_set_error( const char* msg );
+#endif

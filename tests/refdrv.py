@@ -55,3 +55,44 @@ def reconstruct(desc, refs=None, flags=0, want_lfp=False, want_dmvr=0):
     if rc != 0:
         raise RuntimeError("vvref_reconstruct failed: " + L.vvref_last_error().decode())
     return dict(planes=outs, ms=list(ms), lfp=lfps, dmvr=dmvr)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the plain-C restatement (oracle/libvvoracle.so) through the same calling convention
+# ---------------------------------------------------------------------------------------------------------------------
+_OLIB = os.path.join(os.path.dirname(__file__), "..", "oracle", "libvvoracle.so")
+_olib = None
+
+
+def oracle_lib():
+    global _olib
+    if _olib is None:
+        if not os.path.exists(_OLIB):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.dirname(_OLIB), "oracle"], stdout=subprocess.DEVNULL)
+        _olib = C.CDLL(_OLIB)
+        _olib.vvo_reconstruct.restype = C.c_int
+        _olib.vvo_last_error.restype = C.c_char_p
+    return _olib
+
+
+def oracle_reconstruct(desc, refs=None, flags=0):
+    L = oracle_lib()
+    p = desc.c()
+    nslots = (max(refs.keys()) + 1) if refs else 0
+    ref_ptrs = (C.POINTER(C.c_uint16) * max(1, nslots * 3))()
+    keep = []
+    for slot, planes in (refs or {}).items():
+        for c, pl in enumerate(planes):
+            a = np.ascontiguousarray(pl, dtype=np.uint16)
+            keep.append(a)
+            ref_ptrs[slot * 3 + c] = a.ctypes.data_as(C.POINTER(C.c_uint16))
+    ncomp = 3 if desc.hdr.chroma_format else 1
+    outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
+    out_ptrs = (C.POINTER(C.c_uint16) * 3)()
+    for c in range(ncomp):
+        out_ptrs[c] = outs[c].ctypes.data_as(C.POINTER(C.c_uint16))
+    rc = L.vvo_reconstruct(C.byref(p), ref_ptrs, out_ptrs, flags)
+    if rc != 0:
+        raise RuntimeError("vvo_reconstruct failed: " + L.vvo_last_error().decode())
+    return outs
