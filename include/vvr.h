@@ -307,10 +307,14 @@ VVR_API int          vvr_read_plane(vvr_context* ctx, int slot, int comp, uint16
 VVR_API int          vvr_write_plane(vvr_context* ctx, int slot, int comp, const uint16_t* src, size_t src_stride_samples);
 /* DMVR refined delta MVs of job (TaskFinishMotionInfo, DecCu.cpp:161): copies num_entries * 2 int32 */
 VVR_API int          vvr_read_dmvr(vvr_context* ctx, int job, int32_t* dst, size_t num_entries);
-/* upload the arrays of a picture description into HBM once; returns a description whose pointers are device
- * pointers (resident = 1).  Used by the synthetic pre-parsed stream benchmark and by pipelined hosts. */
-VVR_API int          vvr_upload(vvr_context* ctx, const vvr_picture* host_pic, vvr_picture* dev_pic);
-VVR_API void         vvr_free_uploaded(vvr_context* ctx, vvr_picture* dev_pic);
+/* Two-step submission for pipelined hosts and for the synthetic pre-parsed stream benchmark:
+ * vvr_prepare validates the description, runs the host glue (builds the device work lists the reference iterates over
+ * in DecCu::TaskTrafoCtu / TaskInterCtu, DecCu.cpp:106-134) and makes everything resident in HBM;
+ * vvr_submit_prepared only enqueues kernels.  vvr_submit == prepare + submit_prepared + free after completion. */
+typedef struct vvr_prepared vvr_prepared;
+VVR_API int          vvr_prepare(vvr_context* ctx, const vvr_picture* host_pic, vvr_prepared** out);
+VVR_API int          vvr_submit_prepared(vvr_context* ctx, vvr_prepared* prepared);
+VVR_API void         vvr_free_prepared(vvr_context* ctx, vvr_prepared* prepared);
 /* the HIP stream (hipStream_t) job `job` runs on, and the per-kernel timing of the last waited job (bench/profiling) */
 VVR_API void*        vvr_job_stream(vvr_context* ctx, int job);
 VVR_API const char*  vvr_last_error(const vvr_context* ctx);

@@ -1,0 +1,175 @@
+"""vvdec_amd — MI355X-native VVC (H.266) reconstruction back-end.
+
+Python is only plumbing here (ctypes binding of the C ABI in include/vvr.h, used by tests, bench.py and the multi-GPU
+launcher).  The product is `libvvdec_amd.so`: hand-written HIP kernels for gfx950 + the C++ host scheduler in
+vvdec_amd/csrc/.  There is no CPU fallback: if the library is missing or no gfx950 device is present, creating a
+`Reconstructor` raises.
+
+`Reconstructor` mirrors the reference's DecLibRecon (source/Lib/DecoderLib/DecLibRecon.h:143-200):
+    create / destroy               -> Reconstructor(...) / close()
+    decompressPicture(Picture*)    -> decompress_picture(desc)        (asynchronous, returns a job id)
+    waitForPrevDecompressedPic()   -> wait(job)
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+from . import abi
+from .desc import PictureDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libvvdec_amd.so")
+_lib = None
+
+
+class VvrError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(_LIBPATH):
+        os.remove(_LIBPATH)
+    subprocess.check_call(["make", "-C", src], stdout=subprocess.DEVNULL)
+    return _LIBPATH
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built (never falls back to a CPU path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise VvrError("libvvdec_amd.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        L = C.CDLL(_LIBPATH)
+        L.vvr_version.restype = C.c_char_p
+        L.vvr_last_error.restype = C.c_char_p
+        L.vvr_last_error.argtypes = [C.c_void_p]
+        L.vvr_slot_bytes.restype = C.c_size_t
+        L.vvr_plane_ptr.restype = C.c_void_p
+        L.vvr_plane_ptr.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.vvr_job_stream.restype = C.c_void_p
+        L.vvr_job_stream.argtypes = [C.c_void_p, C.c_int]
+        for f in ("vvr_create", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_read_plane", "vvr_write_plane", "vvr_prepare",
+                  "vvr_submit_prepared", "vvr_enable_stats", "vvr_get_stats", "vvr_plane_layout"):
+            getattr(L, f).restype = C.c_int
+        L.vvr_destroy.argtypes = [C.c_void_p]
+        L.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+        L.vvr_sync.argtypes = [C.c_void_p]
+        L.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+        L.vvr_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vvr_submit_prepared.argtypes = [C.c_void_p, C.c_void_p]
+        L.vvr_free_prepared.argtypes = [C.c_void_p, C.c_void_p]
+        L.vvr_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.vvr_write_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.vvr_enable_stats.argtypes = [C.c_void_p, C.c_int]
+        L.vvr_get_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.vvr_plane_layout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
+                    "vvr_plane_ptr", "vvr_read_plane", "vvr_write_plane", "vvr_read_dmvr", "vvr_prepare", "vvr_submit_prepared",
+                    "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type"]
+
+
+class Reconstructor:
+    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, num_slots=8, num_streams=2, device=0, ext_planes=None):
+        self.L = lib()
+        cfg = abi.Config()
+        cfg.abi_version = abi.VVR_ABI_VERSION
+        cfg.device, cfg.max_width, cfg.max_height = device, width, height
+        cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = chroma_format, bit_depth, log2_ctu
+        cfg.num_slots, cfg.num_streams = num_slots, num_streams
+        cfg.ext_planes = ext_planes
+        self.cfg = cfg
+        self.ctx = C.c_void_p()
+        rc = self.L.vvr_create(C.byref(cfg), C.byref(self.ctx))
+        if rc != abi.VVR_OK:
+            raise VvrError("vvr_create failed with %d (%s)" % (rc, {abi.VVR_ERR_NO_DEVICE: "no gfx950 device; there is no CPU fallback"}.get(rc, "see include/vvr.h")))
+        self.width, self.height, self.chroma_format = width, height, chroma_format
+        self._keep = {}
+
+    # -- lifetime
+    def close(self):
+        if self.ctx:
+            self.L.vvr_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise VvrError("vvr error %d: %s" % (rc, self.L.vvr_last_error(self.ctx).decode()))
+        return rc
+
+    # -- DecLibRecon interface
+    def decompress_picture(self, d: PictureDesc):
+        p = d.c()
+        job = self._check(self.L.vvr_submit(self.ctx, C.byref(p)))
+        self._keep[job] = (d, p)
+        return job
+
+    def wait(self, job):
+        self._check(self.L.vvr_wait(self.ctx, job))
+        self._keep.pop(job, None)
+
+    def sync(self):
+        self._check(self.L.vvr_sync(self.ctx))
+        self._keep.clear()
+
+    # -- resident pictures (pre-parsed stream already in HBM)
+    def prepare(self, d: PictureDesc):
+        p = d.c()
+        h = C.c_void_p()
+        self._check(self.L.vvr_prepare(self.ctx, C.byref(p), C.byref(h)))
+        return h
+
+    def submit_prepared(self, handle):
+        return self._check(self.L.vvr_submit_prepared(self.ctx, handle))
+
+    def free_prepared(self, handle):
+        self.L.vvr_free_prepared(self.ctx, handle)
+
+    # -- planes
+    def plane_shape(self, comp):
+        return (self.height >> (1 if comp else 0), self.width >> (1 if comp else 0))
+
+    def read_picture(self, slot):
+        out = []
+        for c in range(3 if self.chroma_format else 1):
+            a = np.zeros(self.plane_shape(c), np.uint16)
+            self._check(self.L.vvr_read_plane(self.ctx, slot, c, a.ctypes.data, a.shape[1]))
+            out.append(a)
+        return out
+
+    def write_picture(self, slot, planes):
+        for c, pl in enumerate(planes):
+            a = np.ascontiguousarray(pl, dtype=np.uint16)
+            assert a.shape == self.plane_shape(c)
+            self._check(self.L.vvr_write_plane(self.ctx, slot, c, a.ctypes.data, a.shape[1]))
+
+    def plane_ptr(self, slot, comp):
+        return self.L.vvr_plane_ptr(self.ctx, slot, comp)
+
+    def slot_bytes(self):
+        return self.L.vvr_slot_bytes(C.byref(self.cfg))
+
+    def plane_layout(self, comp):
+        off, st, w, h = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int()
+        self._check(self.L.vvr_plane_layout(self.ctx, comp, C.byref(off), C.byref(st), C.byref(w), C.byref(h)))
+        return off.value, st.value, w.value, h.value
+
+    # -- statistics (HIP events around every kernel launch, on the launch stream)
+    def enable_stats(self, on=True):
+        self._check(self.L.vvr_enable_stats(self.ctx, 1 if on else 0))
+
+    def stats(self):
+        arr = (abi.KernelStat * 16)()
+        n = self._check(self.L.vvr_get_stats(self.ctx, arr, 16))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, algo_bytes=arr[i].algo_bytes) for i in range(n)]

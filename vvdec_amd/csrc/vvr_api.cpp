@@ -1,0 +1,508 @@
+// vvdec_amd/csrc/vvr_api.cpp — host side of the reconstruction back-end: the C ABI of include/vvr.h.
+//
+// Mirrors DecLibRecon (reference: source/Lib/DecoderLib/DecLibRecon.cpp): create() owns the per-instance resources
+// (there: per-thread tool objects + scratch, :132-168; here: HIP streams, DPB planes, scratch planes, constant tables),
+// vvr_submit() is decompressPicture() (:429) — it turns the parsed picture into device work lists and enqueues the
+// kernels in the stage order of the CTU state machine (:732-1110) — and vvr_wait() is waitForPrevDecompressedPic() (:684).
+// Several pictures are in flight on separate HIP streams; inter-picture dependencies (reference pictures, :544-581
+// "refPicExtDepBarriers") are whole-picture HIP events.  There is NO CPU fallback: without a gfx950 device every entry
+// point fails with VVR_ERR_NO_DEVICE.
+#include "vvr_device.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+int vvr_upload_tables();
+
+#define HIPCHK( ctx, call ) do { hipError_t e_ = ( call ); if( e_ != hipSuccess ) { ( ctx )->setError( std::string( #call ) + ": " + hipGetErrorString( e_ ) ); return VVR_ERR_DEVICE; } } while( 0 )
+
+namespace {
+
+struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
+
+struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
+
+enum { K_MC, K_ITRANS, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_NUM };
+const char* const kKernelNames[K_NUM] = { "k_mc", "k_itrans", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy" };
+
+struct DevBuf {
+  void* p = nullptr; size_t n = 0;
+};
+
+}   // namespace
+
+struct vvr_prepared {        // a picture description resident in HBM together with its device work lists
+  vvr_pic_header hdr;
+  PicDev   pic;
+  DevBuf   blob;             // one allocation holding every array
+  McItem*  mcItems = nullptr; int numMc = 0;
+  TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64
+  double   bytes[K_NUM] = { 0 };
+  bool     owned = false;
+};
+
+struct vvr_context {
+  vvr_config cfg;
+  int        device = 0;
+  std::string err;
+  std::vector<hipStream_t> streams;
+  std::vector<DevPlanes>   slots;       // DPB
+  std::vector<DevPlanes>   scratchB;    // per stream: second picture (SAO output)
+  std::vector<DevPlanes>   scratchR;    // per stream: residual planes (intra)
+  void*      planeMem = nullptr; bool planeMemOwned = false;
+  void*      scratchMem = nullptr;
+  size_t     planeBytes[3] = { 0, 0, 0 }, slotBytes = 0;
+  int        stride[3] = { 0, 0, 0 };
+  // jobs
+  struct Job { int id; int stream; hipEvent_t done; bool waited; vvr_prepared* autoFree; std::vector<PendingTiming> timings; };
+  std::vector<Job> jobs;
+  int        nextJob = 0, nextStream = 0;
+  std::vector<std::vector<int>> slotUsers;   // job ids that touched a slot since it was last written
+  bool       statsOn = false;
+  Stat       stats[K_NUM];
+  void setError( const std::string& e ) { err = e; }
+};
+
+static size_t alignUp( size_t v, size_t a ) { return ( v + a - 1 ) / a * a; }
+
+static void planeGeometry( const vvr_config* cfg, int stride[3], size_t bytes[3], size_t* total )
+{
+  const int ncomp = cfg->chroma_format ? 3 : 1;
+  size_t t = 0;
+  for( int c = 0; c < 3; c++ )
+  {
+    if( c >= ncomp ) { stride[c] = 0; bytes[c] = 0; continue; }
+    const int w = c ? cfg->max_width >> 1 : cfg->max_width, h = c ? cfg->max_height >> 1 : cfg->max_height;
+    stride[c] = (int) alignUp( (size_t) w, 64 );                  // 128-byte rows
+    bytes[c]  = alignUp( (size_t) stride[c] * h * sizeof( pel_t ), 256 );
+    t += bytes[c];
+  }
+  *total = t;
+}
+
+static DevPlanes carve( char* base, const vvr_config* cfg, const int stride[3], const size_t bytes[3] )
+{
+  DevPlanes d; memset( &d, 0, sizeof( d ) );
+  const int ncomp = cfg->chroma_format ? 3 : 1;
+  size_t off = 0;
+  for( int c = 0; c < ncomp; c++ )
+  {
+    d.p[c] = (pel_t*) ( base + off ); off += bytes[c];
+    d.stride[c] = stride[c];
+    d.w[c] = c ? cfg->max_width >> 1 : cfg->max_width; d.h[c] = c ? cfg->max_height >> 1 : cfg->max_height;
+  }
+  return d;
+}
+
+extern "C" {
+
+VVR_API const char* vvr_version( void ) { return "vvdec_amd 0.1 (gfx950, ABI 1)"; }
+
+VVR_API size_t vvr_slot_bytes( const vvr_config* cfg )
+{
+  int st[3]; size_t b[3], t; planeGeometry( cfg, st, b, &t ); return t;
+}
+
+VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
+{
+  if( !cfg || !out || cfg->abi_version != VVR_ABI_VERSION ) return VVR_ERR_PARAMETER;
+  if( cfg->chroma_format > 1 || cfg->bit_depth < 8 || cfg->bit_depth > 12 || cfg->log2_ctu < 5 || cfg->log2_ctu > 7 || !cfg->num_slots ) return VVR_ERR_UNSUPPORTED;
+  int ndev = 0;
+  if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0 || cfg->device >= ndev ) return VVR_ERR_NO_DEVICE;
+  vvr_context* c = new vvr_context();
+  c->cfg = *cfg; c->device = cfg->device;
+  if( hipSetDevice( cfg->device ) != hipSuccess ) { delete c; return VVR_ERR_NO_DEVICE; }
+  {
+    hipDeviceProp_t prop;
+    if( hipGetDeviceProperties( &prop, cfg->device ) != hipSuccess ) { delete c; return VVR_ERR_NO_DEVICE; }
+    if( strncmp( prop.gcnArchName, "gfx950", 6 ) != 0 ) { fprintf( stderr, "vvdec_amd: device %d is %s, this library is built for gfx950 only\n", cfg->device, prop.gcnArchName ); delete c; return VVR_ERR_NO_DEVICE; }
+  }
+  if( vvr_upload_tables() != 0 ) { delete c; return VVR_ERR_DEVICE; }
+  const int ns = std::max<int>( 1, cfg->num_streams );
+  c->streams.resize( ns );
+  for( int i = 0; i < ns; i++ ) if( hipStreamCreateWithFlags( &c->streams[i], hipStreamNonBlocking ) != hipSuccess ) { delete c; return VVR_ERR_DEVICE; }
+  planeGeometry( cfg, c->stride, c->planeBytes, &c->slotBytes );
+  if( cfg->ext_planes ) c->planeMem = cfg->ext_planes;
+  else { if( hipMalloc( &c->planeMem, c->slotBytes * cfg->num_slots ) != hipSuccess ) { delete c; return VVR_ERR_DEVICE; } c->planeMemOwned = true; hipMemset( c->planeMem, 0, c->slotBytes * cfg->num_slots ); }
+  if( hipMalloc( &c->scratchMem, c->slotBytes * 2 * ns ) != hipSuccess ) { delete c; return VVR_ERR_DEVICE; }
+  for( int s = 0; s < cfg->num_slots; s++ ) c->slots.push_back( carve( (char*) c->planeMem + c->slotBytes * s, cfg, c->stride, c->planeBytes ) );
+  for( int s = 0; s < ns; s++ )
+  {
+    c->scratchB.push_back( carve( (char*) c->scratchMem + c->slotBytes * ( 2 * s ), cfg, c->stride, c->planeBytes ) );
+    c->scratchR.push_back( carve( (char*) c->scratchMem + c->slotBytes * ( 2 * s + 1 ), cfg, c->stride, c->planeBytes ) );
+  }
+  c->slotUsers.resize( cfg->num_slots );
+  *out = c;
+  return VVR_OK;
+}
+
+VVR_API int vvr_sync( vvr_context* c );
+
+VVR_API void vvr_destroy( vvr_context* c )
+{
+  if( !c ) return;
+  hipSetDevice( c->device );
+  vvr_sync( c );
+  for( auto& j : c->jobs ) if( j.done ) hipEventDestroy( j.done );
+  for( auto s : c->streams ) hipStreamDestroy( s );
+  if( c->planeMemOwned && c->planeMem ) hipFree( c->planeMem );
+  if( c->scratchMem ) hipFree( c->scratchMem );
+  delete c;
+}
+
+VVR_API const char* vvr_last_error( const vvr_context* c ) { return c ? c->err.c_str() : "no context"; }
+
+VVR_API int vvr_plane_layout( const vvr_context* c, int comp, size_t* offset, size_t* stride_bytes, int* width, int* height )
+{
+  if( !c || comp < 0 || comp > 2 ) return VVR_ERR_PARAMETER;
+  size_t off = 0; for( int k = 0; k < comp; k++ ) off += c->planeBytes[k];
+  if( offset ) *offset = off;
+  if( stride_bytes ) *stride_bytes = (size_t) c->stride[comp] * sizeof( pel_t );
+  if( width ) *width = comp ? c->cfg.max_width >> 1 : c->cfg.max_width;
+  if( height ) *height = comp ? c->cfg.max_height >> 1 : c->cfg.max_height;
+  return VVR_OK;
+}
+
+VVR_API void* vvr_plane_ptr( vvr_context* c, int slot, int comp )
+{
+  if( !c || slot < 0 || slot >= (int) c->slots.size() || comp < 0 || comp > 2 ) return nullptr;
+  return c->slots[slot].p[comp];
+}
+
+VVR_API int vvr_read_plane( vvr_context* c, int slot, int comp, uint16_t* dst, size_t dstStride )
+{
+  if( !c || slot < 0 || slot >= (int) c->slots.size() || comp < 0 || comp > 2 || !c->slots[slot].p[comp] ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  vvr_sync( c );
+  const DevPlanes& d = c->slots[slot];
+  HIPCHK( c, hipMemcpy2D( dst, dstStride * 2, d.p[comp], (size_t) d.stride[comp] * 2, (size_t) d.w[comp] * 2, d.h[comp], hipMemcpyDeviceToHost ) );
+  return VVR_OK;
+}
+
+VVR_API int vvr_write_plane( vvr_context* c, int slot, int comp, const uint16_t* src, size_t srcStride )
+{
+  if( !c || slot < 0 || slot >= (int) c->slots.size() || comp < 0 || comp > 2 || !c->slots[slot].p[comp] ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  vvr_sync( c );
+  const DevPlanes& d = c->slots[slot];
+  HIPCHK( c, hipMemcpy2D( d.p[comp], (size_t) d.stride[comp] * 2, src, srcStride * 2, (size_t) d.w[comp] * 2, d.h[comp], hipMemcpyHostToDevice ) );
+  return VVR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// vvr_prepare: validation + host glue (work lists) + upload.  This is the only place that touches host arrays.
+// ---------------------------------------------------------------------------------------------------------------------
+static int validate( vvr_context* c, const vvr_picture* p )
+{
+  const vvr_pic_header& h = p->hdr;
+  if( h.abi_version != VVR_ABI_VERSION ) { c->setError( "abi_version mismatch" ); return VVR_ERR_PARAMETER; }
+  if( h.width != c->cfg.max_width || h.height != c->cfg.max_height || h.chroma_format != c->cfg.chroma_format || h.bit_depth != c->cfg.bit_depth || h.log2_ctu != c->cfg.log2_ctu )
+  { c->setError( "picture geometry differs from the context configuration" ); return VVR_ERR_PARAMETER; }
+  if( ( h.width & 7 ) || ( h.height & 7 ) ) { c->setError( "picture size must be a multiple of 8 (minimum CU size)" ); return VVR_ERR_PARAMETER; }
+  if( h.out_slot < 0 || h.out_slot >= c->cfg.num_slots ) { c->setError( "out_slot out of range" ); return VVR_ERR_PARAMETER; }
+  if( h.tool_flags & ( VVR_TOOL_LMCS | VVR_TOOL_LMCS_CSCALE ) ) { c->setError( "LMCS is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+  if( !p->cu || !p->tu || !p->coef || !p->lfp[0] || !p->lfp[1] ) { c->setError( "missing arrays" ); return VVR_ERR_PARAMETER; }
+  if( ( h.tool_flags & VVR_TOOL_ALF ) && ( !p->alf || !p->alf_params ) ) { c->setError( "ALF enabled without parameters" ); return VVR_ERR_PARAMETER; }
+  if( ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) && !p->sao ) { c->setError( "SAO enabled without parameters" ); return VVR_ERR_PARAMETER; }
+  if( h.slice_type != 2 )
+    for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
+      if( h.ref_slot[l][i] < 0 || h.ref_slot[l][i] >= c->cfg.num_slots || h.ref_slot[l][i] == h.out_slot ) { c->setError( "bad reference slot" ); return VVR_ERR_PARAMETER; }
+  for( uint32_t i = 0; i < p->num_cu; i++ )
+  {
+    const vvr_cu& cu = p->cu[i];
+    if( cu.x + cu.w > h.width || cu.y + cu.h > h.height || cu.first_tu + cu.num_tu > p->num_tu ) { c->setError( "CU outside the picture / bad TU range" ); return VVR_ERR_PARAMETER; }
+    if( cu.pred_mode == VVR_PRED_INTER )
+    {
+      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI ) { c->setError( "inter mode (BDOF/DMVR/affine/GPM/SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.flags & ( VVR_CU_AFFINE | VVR_CU_CIIP | VVR_CU_GEO | VVR_CU_SBTMVP ) ) { c->setError( "affine / CIIP / GPM / SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) { c->setError( "ref_idx out of range" ); return VVR_ERR_PARAMETER; }
+      if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
+      if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) { c->setError( "inter CU must be single tree" ); return VVR_ERR_PARAMETER; }
+    }
+    else { c->setError( "intra / IBC CUs are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+  }
+  return VVR_OK;
+}
+
+VVR_API void vvr_free_prepared( vvr_context* c, vvr_prepared* q )
+{
+  if( !q ) return;
+  if( c ) hipSetDevice( c->device );
+  if( q->blob.p ) hipFree( q->blob.p );
+  delete q;
+}
+
+VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** out )
+{
+  if( !c || !p || !out ) return VVR_ERR_PARAMETER;
+  if( p->resident ) { c->setError( "vvr_prepare needs host arrays" ); return VVR_ERR_PARAMETER; }
+  int rc = validate( c, p );
+  if( rc != VVR_OK ) return rc;
+  hipSetDevice( c->device );
+  const vvr_pic_header& h = p->hdr;
+  const int ncomp = h.chroma_format ? 3 : 1;
+  const int w4 = ( h.width + 3 ) >> 2, h4 = ( h.height + 3 ) >> 2, ctu = 1 << h.log2_ctu;
+  const int ctusX = ( h.width + ctu - 1 ) / ctu, ctusY = ( h.height + ctu - 1 ) / ctu, numCtu = ctusX * ctusY;
+
+  // ---- host glue: work lists (what DecCu::TaskTrafoCtu / TaskInterCtu iterate over, DecCu.cpp:106-134)
+  std::vector<McItem> mc;
+  std::vector<TbItem> tb[3];
+  double bytes[K_NUM] = { 0 };
+  for( uint32_t i = 0; i < p->num_cu; i++ )
+  {
+    const vvr_cu& cu = p->cu[i];
+    if( cu.pred_mode == VVR_PRED_INTER )
+    {
+      const int nl = cu.mc_mode == VVR_MC_BI ? 2 : 1;
+      for( int y = 0; y < cu.h; y += 16 ) for( int x = 0; x < cu.w; x += 16 )
+      {
+        McItem it; it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( 16, cu.w - x ); it.h = (uint8_t) std::min( 16, cu.h - y ); it.pad = 0; it.cu = i;
+        mc.push_back( it );
+        const double smp = (double) it.w * it.h * ( ncomp == 3 ? 1.5 : 1.0 );
+        bytes[K_MC] += smp * 2 * nl + smp * 2 + sizeof( McItem );
+      }
+      bytes[K_MC] += sizeof( vvr_cu );
+    }
+    if( !( cu.flags & VVR_CU_ROOT_CBF ) ) continue;
+    for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+    {
+      const vvr_tu& tu = p->tu[t];
+      for( int comp = 0; comp < ncomp; comp++ )
+      {
+        if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
+        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.mode = cu.pred_mode == VVR_PRED_INTER ? TB_ADD : TB_STORE; it.ict = 0; it.pad = 0;
+        if( comp && tu.joint_cbcr )
+        {
+          if( comp != 1 ) continue;
+          static const int ict[2][4] = { { 0, 3, 1, 2 }, { 0, -3, -1, -2 } };           // g_ictModes (Rom.cpp:409)
+          it.comp = (uint8_t) ( ( tu.joint_cbcr >> 1 ) ? 1 : 2 );
+          it.ict = (uint8_t) ( 4 + ict[( h.tool_flags & VVR_TOOL_JCCR_SIGN ) ? 1 : 0][tu.joint_cbcr] );
+        }
+        else if( !( tu.cbf & ( 1 << comp ) ) ) continue;
+        const int bw = tu.w >> ( it.comp ? 1 : 0 ), bh = tu.h >> ( it.comp ? 1 : 0 );
+        if( bw < 2 || bh < 2 ) { c->setError( "1-D transform blocks are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+        const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
+        tb[cls].push_back( it );
+        const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];
+        const double ncoef = bdp ? (double) bw * bh : (double) ( tu.max_scan_x[it.comp] + 1 ) * ( tu.max_scan_y[it.comp] + 1 );
+        bytes[K_ITRANS] += ncoef * 2 + (double) bw * bh * 4 * ( it.ict ? 2 : 1 ) + sizeof( TbItem ) + sizeof( vvr_tu ) / 3.0;
+      }
+    }
+  }
+  const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
+  bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
+  bytes[K_SAO] = samples * 4; bytes[K_ALF] = samples * 4; bytes[K_COPY] = samples * 4;
+
+  // ---- one device allocation for everything
+  struct Part { const void* src; size_t n; size_t off; };
+  std::vector<Part> parts;
+  size_t total = 0;
+  auto add = [&]( const void* src, size_t n ) { Part q{ src, n, total }; parts.push_back( q ); total += alignUp( std::max<size_t>( n, 16 ), 256 ); return (int) parts.size() - 1; };
+  const int iCu = add( p->cu, sizeof( vvr_cu ) * p->num_cu );
+  const int iTu = add( p->tu, sizeof( vvr_tu ) * p->num_tu );
+  const int iCoef = add( p->coef, sizeof( int16_t ) * (size_t) p->num_coef );
+  const int iMot = p->motion ? add( p->motion, sizeof( vvr_motion ) * (size_t) w4 * h4 ) : -1;
+  const int iL0 = add( p->lfp[0], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+  const int iL1 = add( p->lfp[1], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+  const int iSao = p->sao ? add( p->sao, sizeof( vvr_sao_ctu ) * numCtu ) : -1;
+  const int iAlf = p->alf ? add( p->alf, sizeof( vvr_alf_ctu ) * numCtu ) : -1;
+  const int iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
+  const int iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
+  int iTb[3]; for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
+
+  vvr_prepared* q = new vvr_prepared();
+  q->hdr = h;
+  if( hipMalloc( &q->blob.p, total ) != hipSuccess ) { delete q; c->setError( "hipMalloc failed" ); return VVR_ERR_DEVICE; }
+  q->blob.n = total;
+  // stage through one pinned buffer -> a single H2D copy
+  char* staging = nullptr;
+  if( hipHostMalloc( (void**) &staging, total, hipHostMallocDefault ) != hipSuccess ) { hipFree( q->blob.p ); delete q; c->setError( "hipHostMalloc failed" ); return VVR_ERR_DEVICE; }
+  for( auto& pt : parts ) if( pt.n ) memcpy( staging + pt.off, pt.src, pt.n );
+  hipError_t e = hipMemcpy( q->blob.p, staging, total, hipMemcpyHostToDevice );
+  hipHostFree( staging );
+  if( e != hipSuccess ) { hipFree( q->blob.p ); delete q; c->setError( "H2D copy failed" ); return VVR_ERR_DEVICE; }
+  char* base = (char*) q->blob.p;
+  PicDev& d = q->pic; memset( &d, 0, sizeof( d ) );
+  d.hdr = h; d.w4 = w4; d.h4 = h4; d.ctus_x = ctusX; d.ctus_y = ctusY;
+  d.cu = (const vvr_cu*) ( base + parts[iCu].off ); d.tu = (const vvr_tu*) ( base + parts[iTu].off ); d.coef = (const int16_t*) ( base + parts[iCoef].off );
+  d.motion = iMot >= 0 ? (const vvr_motion*) ( base + parts[iMot].off ) : nullptr;
+  d.lfp[0] = (const vvr_lfp*) ( base + parts[iL0].off ); d.lfp[1] = (const vvr_lfp*) ( base + parts[iL1].off );
+  d.sao = iSao >= 0 ? (const vvr_sao_ctu*) ( base + parts[iSao].off ) : nullptr;
+  d.alf = iAlf >= 0 ? (const vvr_alf_ctu*) ( base + parts[iAlf].off ) : nullptr;
+  d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
+  q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();
+  for( int k = 0; k < 3; k++ ) { q->tbItems[k] = (TbItem*) ( base + parts[iTb[k]].off ); q->numTb[k] = (int) tb[k].size(); }
+  memcpy( q->bytes, bytes, sizeof( bytes ) );
+  *out = q;
+  return VVR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// enqueue one prepared picture
+// ---------------------------------------------------------------------------------------------------------------------
+static vvr_context::Job* findJob( vvr_context* c, int id ) { for( auto& j : c->jobs ) if( j.id == id ) return &j; return nullptr; }
+
+static int finishJob( vvr_context* c, vvr_context::Job& j )
+{
+  if( j.waited ) return VVR_OK;
+  HIPCHK( c, hipEventSynchronize( j.done ) );
+  for( auto& t : j.timings )
+  {
+    float ms = 0; hipEventElapsedTime( &ms, t.a, t.b );
+    c->stats[t.kernel].launches++; c->stats[t.kernel].ms += ms; c->stats[t.kernel].bytes += t.bytes;
+    hipEventDestroy( t.a ); hipEventDestroy( t.b );
+  }
+  j.timings.clear();
+  if( j.autoFree ) { vvr_free_prepared( c, j.autoFree ); j.autoFree = nullptr; }
+  j.waited = true;
+  return VVR_OK;
+}
+
+VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
+{
+  if( !c || !q ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  const vvr_pic_header& h = q->hdr;
+  const int lane = c->nextStream; c->nextStream = ( c->nextStream + 1 ) % (int) c->streams.size();
+  hipStream_t s = c->streams[lane];
+  // a lane's scratch planes are reused: the previous job of this lane is ordered before us by the stream itself
+  // ---- dependencies: every job that read or wrote one of our slots
+  auto waitUsers = [&]( int slot ) { for( int id : c->slotUsers[slot] ) { vvr_context::Job* j = findJob( c, id ); if( j && !j->waited && j->stream != lane ) hipStreamWaitEvent( s, j->done, 0 ); } };
+  waitUsers( h.out_slot );
+  RefSet refs; memset( &refs, 0, sizeof( refs ) );
+  if( h.slice_type != 2 )
+    for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
+    {
+      const int slot = h.ref_slot[l][i];
+      // wait for the writer of the reference (it is the first entry since the slot was last written)
+      if( !c->slotUsers[slot].empty() ) { vvr_context::Job* j = findJob( c, c->slotUsers[slot][0] ); if( j && !j->waited && j->stream != lane ) hipStreamWaitEvent( s, j->done, 0 ); }
+      for( int k = 0; k < 3; k++ ) refs.p[l * VVR_MAX_REFS + i][k] = c->slots[slot].p[k];
+    }
+  vvr_context::Job job; job.id = c->nextJob++; job.stream = lane; job.waited = false; job.autoFree = nullptr;
+  HIPCHK( c, hipEventCreateWithFlags( &job.done, c->statsOn ? hipEventDefault : hipEventDisableTiming ) );
+
+  DevPlanes A = c->slots[h.out_slot], B = c->scratchB[lane], R = c->scratchR[lane];
+  auto timed = [&]( int k, auto&& fn )
+  {
+    if( c->statsOn ) { PendingTiming t; hipEventCreate( &t.a ); hipEventCreate( &t.b ); t.kernel = k; t.bytes = q->bytes[k]; hipEventRecord( t.a, s ); fn(); hipEventRecord( t.b, s ); job.timings.push_back( t ); }
+    else fn();
+  };
+  // INTER stage: prediction of every inter CU, then residual add (DecLibRecon.cpp:831-874)
+  if( q->numMc ) timed( K_MC, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc ); } );
+  if( q->numTb[0] + q->numTb[1] + q->numTb[2] )
+    timed( K_ITRANS, [&]{ launch_itrans( s, q->pic, A, R, q->tbItems[0], q->numTb[0], 16 ); launch_itrans( s, q->pic, A, R, q->tbItems[1], q->numTb[1], 32 ); launch_itrans( s, q->pic, A, R, q->tbItems[2], q->numTb[2], 64 ); } );
+  // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
+  if( !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF ) )
+  {
+    timed( K_DEBLOCK_V, [&]{ launch_deblock( s, q->pic, A, 0 ); } );
+    timed( K_DEBLOCK_H, [&]{ launch_deblock( s, q->pic, A, 1 ); } );
+  }
+  const bool sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) != 0, alf = ( h.tool_flags & VVR_TOOL_ALF ) != 0;
+  if( sao && alf ) { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
+  else if( sao )   { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_COPY, [&]{ launch_copy_planes( s, B, A ); } ); }
+  else if( alf )   { timed( K_COPY, [&]{ launch_copy_planes( s, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
+  HIPCHK( c, hipGetLastError() );
+  HIPCHK( c, hipEventRecord( job.done, s ) );
+  // bookkeeping
+  c->slotUsers[h.out_slot].clear(); c->slotUsers[h.out_slot].push_back( job.id );
+  if( h.slice_type != 2 ) for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ ) c->slotUsers[h.ref_slot[l][i]].push_back( job.id );
+  // retire old finished jobs to keep the table small
+  if( c->jobs.size() > 256 )
+  {
+    std::vector<vvr_context::Job> keep;
+    for( auto& j : c->jobs ) { if( j.waited ) { hipEventDestroy( j.done ); } else keep.push_back( j ); }
+    c->jobs.swap( keep );
+  }
+  c->jobs.push_back( job );
+  return job.id;
+}
+
+VVR_API int vvr_submit( vvr_context* c, const vvr_picture* p )
+{
+  vvr_prepared* q = nullptr;
+  int rc = vvr_prepare( c, p, &q );
+  if( rc != VVR_OK ) return rc;
+  const int id = vvr_submit_prepared( c, q );
+  if( id < 0 ) { vvr_free_prepared( c, q ); return id; }
+  findJob( c, id )->autoFree = q;
+  return id;
+}
+
+VVR_API int vvr_wait( vvr_context* c, int job )
+{
+  if( !c ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  vvr_context::Job* j = findJob( c, job );
+  if( !j ) return VVR_OK;       // already retired
+  return finishJob( c, *j );
+}
+
+VVR_API int vvr_sync( vvr_context* c )
+{
+  if( !c ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  for( auto& j : c->jobs ) { int rc = finishJob( c, j ); if( rc != VVR_OK ) return rc; }
+  for( auto s : c->streams ) HIPCHK( c, hipStreamSynchronize( s ) );
+  return VVR_OK;
+}
+
+VVR_API void* vvr_job_stream( vvr_context* c, int job ) { vvr_context::Job* j = c ? findJob( c, job ) : nullptr; return j ? (void*) c->streams[j->stream] : nullptr; }
+
+VVR_API int vvr_read_dmvr( vvr_context*, int, int32_t*, size_t ) { return VVR_ERR_UNSUPPORTED; }
+
+VVR_API int vvr_enable_stats( vvr_context* c, int on ) { if( !c ) return VVR_ERR_PARAMETER; vvr_sync( c ); c->statsOn = on != 0; for( auto& s : c->stats ) s = Stat(); return VVR_OK; }
+
+VVR_API int vvr_get_stats( vvr_context* c, vvr_kernel_stat* out, int maxEntries )
+{
+  if( !c ) return VVR_ERR_PARAMETER;
+  vvr_sync( c );
+  int n = 0;
+  for( int k = 0; k < K_NUM && n < maxEntries; k++ )
+  {
+    if( !c->stats[k].launches ) continue;
+    memset( &out[n], 0, sizeof( out[n] ) );
+    snprintf( out[n].name, sizeof( out[n].name ), "%s", kKernelNames[k] );
+    out[n].launches = c->stats[k].launches; out[n].total_ms = c->stats[k].ms; out[n].algo_bytes = c->stats[k].bytes;
+    n++;
+  }
+  return n;
+}
+
+VVR_API uint8_t vvr_resolve_tr_type( const vvr_pic_header*, const vvr_cu* cu, const vvr_tu* tu, int comp, int implicit_mts, int explicit_intra, int explicit_inter )
+{
+  // TrQuant::getTrTypes (TrQuant.cpp:330-407).  0 DCT2, 1 DCT8, 2 DST7; returns (ver << 2) | hor
+  int hor = 0, ver = 0;
+  const bool intra = cu->pred_mode == VVR_PRED_INTRA, luma = comp == 0;
+  const bool isImplicit = intra && luma && implicit_mts && cu->lfnst_idx == 0 && !( cu->flags & VVR_CU_MIP );
+  const bool isISP = intra && luma && cu->isp_mode;
+  if( isISP && cu->lfnst_idx ) return 0;
+  const int lw = tu->w, lh = tu->h;
+  if( isImplicit || isISP )
+  {
+    if( lw >= 4 && lw <= 16 ) hor = 2;
+    if( lh >= 4 && lh <= 16 ) ver = 2;
+    return (uint8_t) ( ( ver << 2 ) | hor );
+  }
+  const bool isInterLuma = cu->pred_mode == VVR_PRED_INTER && luma;
+  const bool isExplicit = intra ? ( explicit_intra && luma ) : ( explicit_inter && isInterLuma );
+  if( isInterLuma && cu->sbt_info )
+  {
+    const int sbtIdx = cu->sbt_info & 0xf, sbtPos = ( cu->sbt_info >> 4 ) & 0x3;      // CU::getSbtIdx / getSbtPos
+    if( sbtIdx == 1 || sbtIdx == 3 )   // SBT_VER_HALF, SBT_VER_QUAD
+    { if( lh > 32 ) hor = ver = 0; else if( sbtPos == 0 ) { hor = 1; ver = 2; } else { hor = 2; ver = 2; } }
+    else
+    { if( lw > 32 ) hor = ver = 0; else if( sbtPos == 0 ) { hor = 2; ver = 1; } else { hor = 2; ver = 2; } }
+    return (uint8_t) ( ( ver << 2 ) | hor );
+  }
+  if( isExplicit && tu->mts_idx[comp] > VVR_MTS_SKIP )
+  {
+    hor = ( ( tu->mts_idx[comp] - 2 ) & 1 ) ? 1 : 2;
+    ver = ( ( tu->mts_idx[comp] - 2 ) >> 1 ) ? 1 : 2;
+  }
+  return (uint8_t) ( ( ver << 2 ) | hor );
+}
+
+}   // extern "C"

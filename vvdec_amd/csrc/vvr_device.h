@@ -1,0 +1,60 @@
+// vvdec_amd/csrc/vvr_device.h — device-side view shared by the HIP kernels and the host scheduler (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vvr.h"
+
+typedef int16_t pel_t;
+
+// One picture's planes in HBM.  Rows are 128-byte aligned (stride in samples is a multiple of 64) so that a wavefront
+// reading 64 consecutive samples touches exactly one or two 128-B lines.  No border margins: reference reads clamp
+// their coordinates, which equals reading the reference decoder's border-extended picture (Picture.cpp:400-518).
+struct DevPlanes {
+  pel_t* p[3];
+  int    stride[3];
+  int    w[3], h[3];
+};
+
+// Work items built by the host glue (vvr_prepare) from the CU/TU records ---------------------------------------------
+
+// One motion-compensation tile: at most 16x16 luma samples (+ the co-located 8x8 chroma samples) of one inter CU.
+// 16x16 is the unit VVC itself uses for DMVR/BDOF processing (DMVR_SUBCU 16x16, MAX_BDOF_APPLICATION_REGION 16).
+struct McItem {
+  uint16_t x, y;       // luma position
+  uint8_t  w, h;       // luma size: 4, 8 or 16
+  uint16_t pad;
+  uint32_t cu;         // index into the CU array
+};
+
+// One transform block that carries a residual.
+struct TbItem {
+  uint32_t tu;         // index into the TU array
+  uint8_t  comp;       // component the coded levels belong to
+  uint8_t  mode;       // TB_ADD: reco += residual (inter CU, prediction already in the picture); TB_STORE: write residual plane
+  uint8_t  ict;        // 0, or 4 + ICT mode (-3..3 -> 1..7): joint Cb-Cr, the item writes both chroma blocks
+  uint8_t  pad;
+};
+enum { TB_ADD = 0, TB_STORE = 1 };
+
+struct PicDev {         // everything a kernel needs about one picture (passed by value)
+  vvr_pic_header     hdr;
+  const vvr_cu*      cu;
+  const vvr_tu*      tu;
+  const int16_t*     coef;
+  const vvr_motion*  motion;
+  const vvr_lfp*     lfp[2];
+  const vvr_sao_ctu* sao;
+  const vvr_alf_ctu* alf;
+  const vvr_alf_params* alf_params;
+  int                w4, h4, ctus_x, ctus_y;
+};
+
+struct RefSet { const pel_t* p[2 * VVR_MAX_REFS][3]; };   // reference planes indexed [list * 16 + refIdx][comp]; geometry = the current picture's
+
+// kernel launchers (vvr_kernels.hip) ----------------------------------------------------------------------------------
+void launch_mc     ( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
+void launch_itrans ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const TbItem* items, int numItems, int sizeClass );
+void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir );
+void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
+void launch_alf    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
+void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst );

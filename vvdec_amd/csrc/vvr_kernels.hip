@@ -1,0 +1,933 @@
+// vvdec_amd/csrc/vvr_kernels.hip — hand-written HIP kernels of the VVC reconstruction back-end for gfx950 (CDNA4).
+//
+// These are integer stencil / filter kernels bounded by HBM bandwidth; there is no MFMA anywhere (the only contraction,
+// the inverse transform, has N <= 64 and integer rounding semantics).  Design rules followed (cdna_hip_programming.md §2, §6):
+// 64-wide wavefronts, 256-thread workgroups, reference / coefficient tiles staged through LDS, coalesced row-wise
+// plane accesses (rows are 128-B aligned), constant tables read through the scalar/L1 path.
+//
+// Each kernel cites the reference function whose arithmetic it reproduces (paths relative to source/Lib of VVdeC);
+// bit-exactness is checked against the CPU restatement in oracle/ and the reference-driven golden fixtures.
+#include "vvr_device.h"
+
+namespace tbl {
+#include "../../tables/vvc_tables.inc"
+}
+
+namespace {
+
+__device__ __forceinline__ int clip3( int lo, int hi, int v ) { return v < lo ? lo : ( v > hi ? hi : v ); }
+__device__ __forceinline__ int clip_pel( int v, int bd ) { return clip3( 0, ( 1 << bd ) - 1, v ); }
+__device__ __forceinline__ int iabs( int v ) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int ilog2( int v ) { return 31 - __clz( v ); }
+__device__ __forceinline__ int sgn( int v ) { return ( v > 0 ) - ( v < 0 ); }
+
+} // namespace
+
+// ---- device copies of the constant tables (initialised from the generated include at load time) ----------------------
+__device__ int16_t d_dct2_2[4], d_dct2_4[16], d_dct2_8[64], d_dct2_16[256], d_dct2_32[1024], d_dct2_64[4096];
+__device__ int16_t d_dct8_4[16], d_dct8_8[64], d_dct8_16[256], d_dct8_32[1024];
+__device__ int16_t d_dst7_4[16], d_dst7_8[64], d_dst7_16[256], d_dst7_32[1024];
+__device__ int8_t  d_lfnst8x8[4][2][48][16], d_lfnst4x4[4][2][16][16];
+__device__ uint8_t d_lfnst_lut[97], d_lfnst_scan8x8_xy[16][2], d_lfnst_scan4x4_xy[16][2];
+__device__ int32_t d_inv_quant_scales[2][6];
+__device__ int16_t d_luma_filter[16][8], d_luma_filter_4x4[16][8], d_luma_alt_hpel[8], d_chroma_filter[32][4];
+__device__ int8_t  d_bcw_weights[5];
+__device__ uint16_t d_db_tc_table[66];
+__device__ uint8_t d_db_beta_table[64];
+__device__ int16_t d_alf_fixed_coeff[64][13];
+__device__ uint8_t d_alf_class_to_filter[16][25];
+
+#define UPLOAD( name ) do { hipError_t e = hipMemcpyToSymbol( HIP_SYMBOL( d_##name ), tbl::vvc_##name, sizeof( tbl::vvc_##name ) ); if( e != hipSuccess ) return (int) e; } while( 0 )
+int vvr_upload_tables()
+{
+  UPLOAD( dct2_2 ); UPLOAD( dct2_4 ); UPLOAD( dct2_8 ); UPLOAD( dct2_16 ); UPLOAD( dct2_32 ); UPLOAD( dct2_64 );
+  UPLOAD( dct8_4 ); UPLOAD( dct8_8 ); UPLOAD( dct8_16 ); UPLOAD( dct8_32 );
+  UPLOAD( dst7_4 ); UPLOAD( dst7_8 ); UPLOAD( dst7_16 ); UPLOAD( dst7_32 );
+  UPLOAD( lfnst8x8 ); UPLOAD( lfnst4x4 ); UPLOAD( lfnst_lut ); UPLOAD( lfnst_scan8x8_xy ); UPLOAD( lfnst_scan4x4_xy );
+  UPLOAD( inv_quant_scales ); UPLOAD( luma_filter ); UPLOAD( luma_filter_4x4 ); UPLOAD( luma_alt_hpel ); UPLOAD( chroma_filter );
+  UPLOAD( bcw_weights ); UPLOAD( db_tc_table ); UPLOAD( db_beta_table ); UPLOAD( alf_fixed_coeff ); UPLOAD( alf_class_to_filter );
+  return 0;
+}
+
+// =====================================================================================================================
+// k_mc — motion compensation of one <=16x16 luma tile (+ chroma) per workgroup.
+//   InterPrediction::xPredInterBlk (InterPrediction.cpp:751) + InterpolationFilter::filter<N> (InterpolationFilter.cpp:556)
+//   + filterCopy (:424) + AreaBuf::addAvg / addWeightedAvg (Buffer.cpp:441,372) + clipMvInPic (Mv.cpp:64).
+// The (w+7)x(h+7) reference window is staged once in LDS with clamped coordinates (= border-extended reference), the
+// horizontal pass writes its 16-bit intermediates to LDS, the vertical pass reads them back column-wise.
+// =====================================================================================================================
+#define IF_INTERNAL_OFFS 8192
+
+struct McShared {
+  pel_t win[23 * 24];     // reference window, row stride 24
+  pel_t tmp[23 * 16];     // horizontal-pass output
+};
+
+// predicts one component block of one list into `out` (one sample per thread, tid < w*h); bi = keep 14-bit precision
+__device__ __forceinline__ int mc_pred_component( McShared& sh, const pel_t* __restrict__ ref, int stride, int pw, int ph,
+                                                  int bx, int by, int w, int h, int mvx, int mvy, int comp, bool bi, bool altHpel, int bd,
+                                                  int tid, int nthreads, int lane )
+{
+  const int shf   = comp ? 5 : 4;
+  const int xFrac = mvx & ( ( 1 << shf ) - 1 ), yFrac = mvy & ( ( 1 << shf ) - 1 );
+  const int x0 = bx + ( mvx >> shf ), y0 = by + ( mvy >> shf );
+  const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const bool doH = xFrac != 0, doV = yFrac != 0;
+  const int ww = w + ( doH ? ntaps - 1 : 0 ), wh = h + ( doV ? ntaps - 1 : 0 );
+  const int wx0 = x0 - ( doH ? half : 0 ), wy0 = y0 - ( doV ? half : 0 );
+  __syncthreads();                                     // previous users of the LDS buffers are done
+  for( int i = tid; i < ww * wh; i += nthreads )
+  {
+    const int yy = i / ww, xx = i - yy * ww;
+    const int sx = clip3( 0, pw - 1, wx0 + xx ), sy = clip3( 0, ph - 1, wy0 + yy );
+    sh.win[yy * 24 + xx] = ref[(size_t) sy * stride + sx];
+  }
+  __syncthreads();
+  const int16_t* ch; const int16_t* cv;
+  if( comp ) { ch = d_chroma_filter[xFrac]; cv = d_chroma_filter[yFrac]; }
+  else
+  {
+    const bool f4 = ( w == 4 && h == 4 );
+    ch = ( xFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[xFrac] : d_luma_filter[xFrac];
+    cv = ( yFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[yFrac] : d_luma_filter[yFrac];
+  }
+  const int px = lane % w, py = lane / w;              // lane < w*h guaranteed by the caller for active threads
+  int val = 0;
+  if( !doH && !doV )
+  {
+    if( lane < w * h ) { const int s = sh.win[py * 24 + px]; val = bi ? (int16_t) ( (int16_t) ( s << headroom ) - (int16_t) IF_INTERNAL_OFFS ) : s; }
+    return val;
+  }
+  if( doH != doV )
+  {
+    int shift, offset;
+    if( !bi ) { shift = 6; offset = 32; } else { shift = 6 - headroom; offset = -IF_INTERNAL_OFFS * ( 1 << shift ); }
+    if( lane < w * h )
+    {
+      int sum = 0;
+      if( doH ) { for( int t = 0; t < ntaps; t++ ) sum += sh.win[py * 24 + px + t] * ch[t]; }
+      else      { for( int t = 0; t < ntaps; t++ ) sum += sh.win[( py + t ) * 24 + px] * cv[t]; }
+      val = (int16_t) ( ( sum + offset ) >> shift );
+      if( !bi ) val = clip_pel( val, bd );
+    }
+    return val;
+  }
+  {
+    const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+    for( int i = tid; i < w * wh; i += nthreads )
+    {
+      const int yy = i / w, xx = i - yy * w;
+      int sum = 0;
+      for( int t = 0; t < ntaps; t++ ) sum += sh.win[yy * 24 + xx + t] * ch[t];
+      sh.tmp[yy * 16 + xx] = (int16_t) ( ( sum + offset1 ) >> shift1 );
+    }
+    __syncthreads();
+    if( lane < w * h )
+    {
+      int shift2, offset2;
+      if( !bi ) { shift2 = 6 + headroom; offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 ); } else { shift2 = 6; offset2 = 0; }
+      int sum = 0;
+      for( int t = 0; t < ntaps; t++ ) sum += sh.tmp[( py + t ) * 16 + px] * cv[t];
+      val = (int16_t) ( ( sum + offset2 ) >> shift2 );
+      if( !bi ) val = clip_pel( val, bd );
+    }
+  }
+  return val;
+}
+
+__global__ __launch_bounds__( 256 ) void k_mc( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
+{
+  __shared__ McShared sh;
+  const int item = blockIdx.x;
+  if( item >= numItems ) return;
+  const McItem it = items[item];
+  const vvr_cu& cu = pic.cu[it.cu];
+  const int bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu;
+  const int tid = threadIdx.x;
+  const bool altHpel = cu.imv == 3;
+  const bool biPred = cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0;
+  const bool uni = cu.mc_mode == VVR_MC_UNI;
+  // clipMvInPic with the CU position (InterPrediction.cpp:657: m_currCuArea)
+  int mv[2][2];
+  {
+    const int horMax = ( pic.hdr.width + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - cu.x + 1 ) * 16;
+    const int verMax = ( pic.hdr.height + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - cu.y + 1 ) * 16;
+    for( int l = 0; l < 2; l++ ) { mv[l][0] = min( horMax, max( horMin, cu.mv[l][0][0] ) ); mv[l][1] = min( verMax, max( verMin, cu.mv[l][0][1] ) ); }
+  }
+  const int ncomp = pic.hdr.chroma_format ? 3 : 1;
+  for( int c = 0; c < ncomp; c++ )
+  {
+    const int cs = c ? 1 : 0;
+    const int bx = it.x >> cs, by = it.y >> cs, w = it.w >> cs, h = it.h >> cs;
+    const int lane = tid;
+    int out;
+    if( uni )
+    {
+      const int l = ( biPred || cu.ref_idx[0] >= 0 ) ? 0 : 1;
+      out = mc_pred_component( sh, refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c], reco.stride[c], reco.w[c], reco.h[c], bx, by, w, h, mv[l][0], mv[l][1], c, false, altHpel, bd, tid, 256, lane );
+    }
+    else
+    {
+      const int p0 = mc_pred_component( sh, refs.p[cu.ref_idx[0]][c], reco.stride[c], reco.w[c], reco.h[c], bx, by, w, h, mv[0][0], mv[0][1], c, true, altHpel, bd, tid, 256, lane );
+      const int p1 = mc_pred_component( sh, refs.p[VVR_MAX_REFS + cu.ref_idx[1]][c], reco.stride[c], reco.w[c], reco.h[c], bx, by, w, h, mv[1][0], mv[1][1], c, true, altHpel, bd, tid, 256, lane );
+      const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+      if( cu.bcw_idx != 2 )
+      {
+        const int w1 = d_bcw_weights[cu.bcw_idx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+        out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
+      }
+      else
+      {
+        const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+        out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
+      }
+    }
+    if( lane < w * h ) reco.p[c][(size_t) ( by + lane / w ) * reco.stride[c] + bx + lane % w] = (pel_t) out;
+  }
+}
+
+void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
+{
+  if( numItems ) hipLaunchKernelGGL( k_mc, dim3( numItems ), dim3( 256 ), 0, s, pic, refs, reco, items, numItems );
+}
+
+// =====================================================================================================================
+// k_itrans — dequantisation + LFNST + 2-D inverse transform + residual add / store, one transform block per workgroup.
+//   Quant::dequant (Quant.cpp:295), invLfnstNxNCore/xInvLfnst (TrQuant.cpp:79,201), TrQuant::xIT (:410),
+//   fastInvCore_ (TrQuant_EMT.cpp:389), cpyResiClip (:366), xITransformSkip (TrQuant.cpp:489), invTransformICT (:320),
+//   AreaBuf::reconstruct (Buffer.cpp:482).
+// Coefficients are dequantised straight into LDS; both 1-D passes run out of LDS.
+// =====================================================================================================================
+__device__ __forceinline__ const int16_t* tr_matrix( int type, int n )
+{
+  if( type == 0 ) { switch( n ) { case 2: return d_dct2_2; case 4: return d_dct2_4; case 8: return d_dct2_8; case 16: return d_dct2_16; case 32: return d_dct2_32; default: return d_dct2_64; } }
+  if( type == 1 ) { switch( n ) { case 4: return d_dct8_4; case 8: return d_dct8_8; case 16: return d_dct8_16; default: return d_dct8_32; } }
+  switch( n ) { case 4: return d_dst7_4; case 8: return d_dst7_8; case 16: return d_dst7_16; default: return d_dst7_32; }
+}
+
+__device__ __forceinline__ int wide_angle_mode( int w, int h, int mode )   // PU::getWideAngIntraMode (UnitTools.cpp:617)
+{
+  const int modeShift[6] = { 0, 6, 10, 12, 14, 15 };
+  if( mode < 2 ) return mode;
+  const int d = iabs( ilog2( w ) - ilog2( h ) );
+  if( w > h && mode < 2 + modeShift[d] ) mode += 65;
+  else if( h > w && mode > 66 - modeShift[d] ) mode -= 67;
+  return mode;
+}
+
+template<int MAXN>
+__global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, DevPlanes resi, const TbItem* __restrict__ items, int numItems )
+{
+  __shared__ int32_t dq[MAXN * MAXN];
+  __shared__ int32_t tmp[MAXN * MAXN];
+  __shared__ int32_t lf_in[16], lf_out[48];
+  const int item = blockIdx.x;
+  if( item >= numItems ) return;
+  const TbItem it = items[item];
+  const vvr_tu& tu = pic.tu[it.tu];
+  const vvr_cu& cu = pic.cu[tu.cu];
+  const int comp = it.comp, bd = pic.hdr.bit_depth, tid = threadIdx.x;
+  const int csh = comp ? 1 : 0;
+  int bw = tu.w >> csh, bh = tu.h >> csh, bx = tu.x >> csh, by = tu.y >> csh;
+  if( comp && cu.isp_mode ) { bw = cu.w >> 1; bh = cu.h >> 1; bx = cu.x >> 1; by = cu.y >> 1; }
+  const int lw = ilog2( bw ), lh = ilog2( bh );
+  const bool isTS = tu.mts_idx[comp] == VVR_MTS_SKIP;
+  const int bdpcm = comp ? cu.bdpcm[1] : cu.bdpcm[0];
+  int maxX = tu.max_scan_x[comp], maxY = tu.max_scan_y[comp];
+  const int16_t* __restrict__ lev = pic.coef + tu.coef_off[comp];
+  const int n = bw * bh;
+  for( int i = tid; i < n; i += 256 ) dq[i] = 0;
+  __syncthreads();
+  // ---- dequantisation
+  {
+    const bool depQuant = ( pic.hdr.tool_flags & VVR_TOOL_DEP_QUANT ) && !isTS;
+    int qp = tu.qp[comp];
+    if( isTS ) qp = max( qp, (int) pic.hdr.min_qp_ts );
+    const int per = depQuant ? ( qp + 1 ) / 6 : qp / 6;
+    const int rem = depQuant ? ( qp + 1 - 6 * per ) : qp - 6 * per;
+    const bool needSqrt = !isTS && ( ( lw + lh ) & 1 );
+    const int trShift = 15 - bd - ( ( lw + lh ) >> 1 ) - ( needSqrt ? 1 : 0 );
+    const int rightShift = 6 + ( depQuant ? 1 : 0 ) - ( ( isTS ? 0 : trShift ) + per );
+    const int scale = d_inv_quant_scales[needSqrt ? 1 : 0][rem];
+    int targetBits = 32 + rightShift - 7; if( targetBits > 16 ) targetBits = 16;
+    const int inMax = ( 1 << ( targetBits - 1 ) ) - 1, inMin = -inMax - 1;
+    if( bdpcm )
+    {
+      // invResDPCM (Quant.cpp:239): running sums along rows (mode 1) / columns (mode 2); one thread per line
+      const int lines = bdpcm == 1 ? bh : bw, len = bdpcm == 1 ? bw : bh;
+      for( int l = tid; l < lines; l += 256 )
+      {
+        int acc = 0;
+        for( int k = 0; k < len; k++ )
+        {
+          const int idx = bdpcm == 1 ? l * bw + k : k * bw + l;
+          const int v = lev[idx];
+          acc = k == 0 ? v : clip3( -32768, 32767, acc + v );
+          dq[idx] = acc;
+        }
+      }
+      __syncthreads();
+      maxX = bw - 1; maxY = bh - 1;
+      for( int i = tid; i < n; i += 256 )
+      {
+        const int level = dq[i];
+        if( level )
+        {
+          const long long c = clip3( inMin, inMax, level );
+          const long long v = rightShift > 0 ? ( c * scale + ( 1ll << ( rightShift - 1 ) ) ) >> rightShift : ( c * scale ) * ( 1ll << -rightShift );
+          dq[i] = clip3( -32768, 32767, (int) v );
+        }
+      }
+    }
+    else
+    {
+      const int cw = maxX + 1, cn = cw * ( maxY + 1 );
+      for( int i = tid; i < cn; i += 256 )
+      {
+        const int y = i / cw, x = i - y * cw;
+        const int level = lev[i];
+        if( level )
+        {
+          const long long c = clip3( inMin, inMax, level );
+          const long long v = rightShift > 0 ? ( c * scale + ( 1ll << ( rightShift - 1 ) ) ) >> rightShift : ( c * scale ) * ( 1ll << -rightShift );
+          dq[y * bw + x] = clip3( -32768, 32767, (int) v );
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- LFNST
+  if( ( pic.hdr.tool_flags & VVR_TOOL_LFNST ) && cu.lfnst_idx && !isTS && ( cu.tree != VVR_TREE_JOINT || comp == 0 ) )
+  {
+    const bool whge3 = bw >= 8 && bh >= 8;
+    int mode;
+    if( ( cu.flags & VVR_CU_MIP ) && comp == 0 ) mode = 0;
+    else if( comp && cu.intra_dir[1] >= 67 ) mode = cu.lfnst_intra_mode;
+    else mode = cu.intra_dir[comp ? 1 : 0];
+    mode = wide_angle_mode( ( cu.isp_mode && !comp ) ? cu.w : bw, ( cu.isp_mode && !comp ) ? cu.h : bh, mode );
+    const int lm = mode < 0 ? mode + 14 + 67 : mode >= 67 ? mode + 14 : mode;
+    const bool transpose = ( lm >= 67 && lm >= 67 + 14 ) || ( lm < 67 && lm > 34 );
+    const int sb = whge3 ? 8 : 4;
+    const int zeroOut = ( ( bw == 4 && bh == 4 ) || ( bw == 8 && bh == 8 ) ) ? 8 : 16;
+    if( tid < 16 ) { const uint8_t* xy = whge3 ? d_lfnst_scan8x8_xy[tid] : d_lfnst_scan4x4_xy[tid]; lf_in[tid] = dq[xy[1] * bw + xy[0]]; }
+    __syncthreads();
+    const int set = d_lfnst_lut[lm], idx = cu.lfnst_idx - 1, trSize = sb == 8 ? 48 : 16;
+    if( tid < trSize )
+    {
+      int r = 0;
+      for( int i = 0; i < zeroOut; i++ ) r += lf_in[i] * ( sb == 8 ? d_lfnst8x8[set][idx][tid][i] : d_lfnst4x4[set][idx][tid][i] );
+      lf_out[tid] = clip3( -32768, 32767, ( r + 64 ) >> 7 );
+    }
+    __syncthreads();
+    if( tid < sb * sb )
+    {
+      const int y = tid / sb, x = tid % sb;
+      if( sb == 4 ) dq[y * bw + x] = transpose ? lf_out[x * 4 + y] : lf_out[y * 4 + x];
+      else if( transpose )
+      {
+        if( x < 4 ) dq[y * bw + x] = lf_out[x * 8 + y];
+        else if( y < 4 ) dq[y * bw + x] = lf_out[32 + ( x - 4 ) * 4 + y];
+      }
+      else
+      {
+        if( y < 4 ) dq[y * bw + x] = lf_out[y * 8 + x];
+        else if( x < 4 ) dq[y * bw + x] = lf_out[32 + ( y - 4 ) * 4 + x];
+      }
+    }
+    maxX = max( maxX, min( bw - 1, 7 ) );
+    maxY = max( maxY, min( bh - 1, 7 ) );
+    __syncthreads();
+  }
+  // ---- inverse transform into tmp[] as final residual (row-major bw x bh)
+  const int trHor = tu.tr_type[comp] & 3, trVer = tu.tr_type[comp] >> 2;
+  const int shift1 = 7, shift2 = 20 - bd;
+  if( isTS )
+  {
+    for( int i = tid; i < n; i += 256 ) tmp[i] = (int16_t) dq[i];
+  }
+  else if( maxX == 0 && maxY == 0 && trHor == 0 && trVer == 0 )
+  {
+    int dc = ( dq[0] * 64 + ( 1 << ( shift1 - 1 ) ) ) >> shift1;
+    dc = ( dc * 64 + ( 1 << ( shift2 - 1 ) ) ) >> shift2;
+    for( int i = tid; i < n; i += 256 ) tmp[i] = (int16_t) dc;
+  }
+  else
+  {
+    const int skipW = max( ( trHor != 0 && bw == 32 ) ? 16 : bw > 32 ? bw - 32 : 0, bw - maxX - 1 );
+    const int skipH = max( ( trVer != 0 && bh == 32 ) ? 16 : bh > 32 ? bh - 32 : 0, bh - maxY - 1 );
+    const int redW = bw - skipW, cutH = bh - skipH;
+    const int16_t* __restrict__ Mv = tr_matrix( trVer, bh );
+    const int16_t* __restrict__ Mh = tr_matrix( trHor, bw );
+    // pass 1 (vertical): tmp[x*bh + y] = clip16( ( sum_k dq[k*bw + x] * Mv[k*bh + y] + 64 ) >> 7 ), x < redW
+    for( int i = tid; i < redW * bh; i += 256 )
+    {
+      const int x = i / bh, y = i - x * bh;
+      int sum = 0;
+      for( int k = 0; k < cutH; k++ ) sum += dq[k * bw + x] * Mv[k * bh + y];
+      tmp[x * bh + y] = clip3( -32768, 32767, ( sum + ( 1 << ( shift1 - 1 ) ) ) >> shift1 );
+    }
+    __syncthreads();
+    // pass 2 (horizontal): out[y*bw + x] = clip16( ( sum_{k<redW} tmp[k*bh + y] * Mh[k*bw + x] + rnd ) >> shift2 )
+    for( int i = tid; i < n; i += 256 )
+    {
+      const int y = i / bw, x = i - y * bw;
+      int sum = 0;
+      for( int k = 0; k < redW; k++ ) sum += tmp[k * bh + y] * Mh[k * bw + x];
+      dq[i] = clip3( -32768, 32767, ( sum + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
+    }
+    __syncthreads();
+    for( int i = tid; i < n; i += 256 ) tmp[i] = dq[i];
+  }
+  __syncthreads();
+  // ---- output
+  const int ict = it.ict ? (int) it.ict - 4 : 0;
+  for( int i = tid; i < n; i += 256 )
+  {
+    const int y = i / bw, x = i - y * bw;
+    int r = tmp[i], rOther = 0, cOther = 0;
+    int cSelf = comp;
+    if( ict )
+    {
+      // invTransformCbCr<mode> (TrQuant.cpp:108): derive the second chroma residual
+      if(      ict ==  1 ) { rOther =  r >> 1; cOther = 2; }
+      else if( ict == -1 ) { rOther = -r >> 1; cOther = 2; }
+      else if( ict ==  2 ) { rOther =  r;      cOther = 2; }
+      else if( ict == -2 ) { rOther = -r;      cOther = 2; }
+      else if( ict ==  3 ) { rOther =  r >> 1; cOther = 1; }
+      else                 { rOther = -r >> 1; cOther = 1; }
+      rOther = (int16_t) rOther;
+    }
+    if( it.mode == TB_ADD )
+    {
+      pel_t* d = &reco.p[cSelf][(size_t) ( by + y ) * reco.stride[cSelf] + bx + x];
+      *d = (pel_t) clip_pel( *d + r, bd );
+      if( ict ) { pel_t* e = &reco.p[cOther][(size_t) ( by + y ) * reco.stride[cOther] + bx + x]; *e = (pel_t) clip_pel( *e + rOther, bd ); }
+    }
+    else
+    {
+      resi.p[cSelf][(size_t) ( by + y ) * resi.stride[cSelf] + bx + x] = (pel_t) r;
+      if( ict ) resi.p[cOther][(size_t) ( by + y ) * resi.stride[cOther] + bx + x] = (pel_t) rOther;
+    }
+  }
+}
+
+void launch_itrans( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const TbItem* items, int numItems, int sizeClass )
+{
+  if( !numItems ) return;
+  if( sizeClass <= 16 )      hipLaunchKernelGGL( k_itrans<16>, dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
+  else if( sizeClass <= 32 ) hipLaunchKernelGGL( k_itrans<32>, dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
+  else                       hipLaunchKernelGGL( k_itrans<64>, dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
+}
+
+// =====================================================================================================================
+// k_deblock — one thread per 4x4 luma unit (= one 4-sample edge segment) and direction.
+//   LoopFilter::xDeblockCtuArea (LoopFilter.cpp:419), xEdgeFilterLuma (:1464), xEdgeFilterChroma (:1620) and the
+//   filters :106-335.  All edges of one direction are independent for a valid edge-parameter table (maximum filter
+//   lengths never overlap, :910-922), so the whole picture is one launch per direction.
+// =====================================================================================================================
+#define BS_GET( v, c ) ( ( ( v ) >> ( ( c ) << 1 ) ) & 3 )
+
+__device__ __forceinline__ int calc_dp( const pel_t* s, int o ) { return iabs( s[-o * 3] - 2 * s[-o * 2] + s[-o] ); }
+__device__ __forceinline__ int calc_dp_ctb( const pel_t* s, int o ) { return iabs( s[-o * 2] - 2 * s[-o * 2] + s[-o] ); }
+__device__ __forceinline__ int calc_dq( const pel_t* s, int o ) { return iabs( s[0] - 2 * s[o] + s[o * 2] ); }
+
+__device__ bool use_strong( const pel_t* s, int o, int d, int beta, int tc, bool pLarge, bool qLarge, int lenP, int lenQ, bool chromaCtb )
+{
+  const int m3 = s[-o], m4 = s[0];
+  if( !( d < ( beta >> 2 ) && iabs( m3 - m4 ) < ( ( tc * 5 + 1 ) >> 1 ) ) ) return false;
+  const int m0 = s[-4 * o], m7 = s[3 * o], m2 = s[-2 * o];
+  int sp3 = iabs( m0 - m3 );
+  if( chromaCtb ) sp3 = iabs( m2 - m3 );
+  int sq3 = iabs( m7 - m4 );
+  const int d_strong = sp3 + sq3;
+  if( pLarge || qLarge )
+  {
+    if( pLarge )
+    {
+      const int mP4 = s[-o * lenP - o];
+      if( lenP == 7 ) sp3 = sp3 + iabs( s[-o * 5] - s[-o * 6] - s[-o * 7] + mP4 );
+      sp3 = ( sp3 + iabs( m0 - mP4 ) + 1 ) >> 1;
+    }
+    if( qLarge )
+    {
+      const int m11 = s[o * lenQ];
+      if( lenQ == 7 ) sq3 = sq3 + iabs( s[o * 4] - s[o * 5] - s[o * 6] + m11 );
+      sq3 = ( sq3 + iabs( m11 - m7 ) + 1 ) >> 1;
+    }
+    return ( ( sp3 + sq3 ) < ( beta * 3 >> 5 ) ) && ( d < ( beta >> 4 ) ) && ( iabs( m3 - m4 ) < ( ( tc * 5 + 1 ) >> 1 ) );
+  }
+  return d_strong < ( beta >> 3 );
+}
+
+__device__ void filter_long( pel_t* src, int step, int o, int nP, int nQ, int tc )
+{
+  const int c7[7] = { 59, 50, 41, 32, 23, 14, 5 }, c5[5] = { 58, 45, 32, 19, 6 }, c3[3] = { 53, 32, 11 };
+  const int tc7[7] = { 6, 5, 4, 3, 2, 1, 1 }, tc3[3] = { 6, 4, 2 };
+  for( int i = 0; i < 4; i++ )
+  {
+    pel_t* sP = src + step * i - o; pel_t* sQ = src + step * i;
+    const int refP = ( sP[-( nP - 1 ) * o] + sP[-nP * o] + 1 ) >> 1;
+    const int refQ = ( sQ[( nQ - 1 ) * o] + sQ[nQ * o] + 1 ) >> 1;
+    int refM;
+    if( nP == nQ )
+    {
+      if( nP == 5 ) refM = ( 2 * ( sP[0] + sQ[0] + sP[-o] + sQ[o] + sP[-2 * o] + sQ[2 * o] ) + sP[-3 * o] + sQ[3 * o] + sP[-4 * o] + sQ[4 * o] + 8 ) >> 4;
+      else          refM = ( 2 * ( sP[0] + sQ[0] ) + sP[-o] + sQ[o] + sP[-2 * o] + sQ[2 * o] + sP[-3 * o] + sQ[3 * o] + sP[-4 * o] + sQ[4 * o] + sP[-5 * o] + sQ[5 * o] + sP[-6 * o] + sQ[6 * o] + 8 ) >> 4;
+    }
+    else
+    {
+      pel_t *pt = sP, *qt = sQ; int oP = -o, oQ = o; int nnP = nP, nnQ = nQ;
+      if( nQ > nP ) { pel_t* t = pt; pt = qt; qt = t; oP = o; oQ = -o; nnQ = nP; nnP = nQ; }
+      if( nnP == 7 && nnQ == 5 ) refM = ( 2 * ( sP[0] + sQ[0] + sP[-o] + sQ[o] ) + sP[-2 * o] + sQ[2 * o] + sP[-3 * o] + sQ[3 * o] + sP[-4 * o] + sQ[4 * o] + sP[-5 * o] + sQ[5 * o] + 8 ) >> 4;
+      else if( nnP == 7 && nnQ == 3 ) refM = ( 2 * ( pt[0] + qt[0] ) + qt[0] + 2 * ( qt[oQ] + qt[2 * oQ] ) + pt[oP] + qt[oQ] + pt[2 * oP] + pt[3 * oP] + pt[4 * oP] + pt[5 * oP] + pt[6 * oP] + 8 ) >> 4;
+      else refM = ( sP[0] + sQ[0] + sP[-o] + sQ[o] + sP[-2 * o] + sQ[2 * o] + sP[-3 * o] + sQ[3 * o] + 4 ) >> 3;
+    }
+    for( int p = 0; p < nP; p++ )
+    {
+      const int cf = nP == 7 ? c7[p] : nP == 5 ? c5[p] : c3[p], tcf = nP == 3 ? tc3[p] : tc7[p];
+      const int v = sP[-o * p], cv = ( tc * tcf ) >> 1;
+      sP[-o * p] = (pel_t) clip3( v - cv, v + cv, ( refM * cf + refP * ( 64 - cf ) + 32 ) >> 6 );
+    }
+    for( int p = 0; p < nQ; p++ )
+    {
+      const int cf = nQ == 7 ? c7[p] : nQ == 5 ? c5[p] : c3[p], tcf = nQ == 3 ? tc3[p] : tc7[p];
+      const int v = sQ[o * p], cv = ( tc * tcf ) >> 1;
+      sQ[o * p] = (pel_t) clip3( v - cv, v + cv, ( refM * cf + refQ * ( 64 - cf ) + 32 ) >> 6 );
+    }
+  }
+}
+
+__device__ __forceinline__ void filter_luma_pel( pel_t* s, int o, int tc, bool sw, int thrCut, bool fP, bool fQ, int bd )
+{
+  const int m1 = s[-3 * o], m2 = s[-2 * o], m3 = s[-o], m4 = s[0], m5 = s[o], m6 = s[2 * o];
+  if( sw )
+  {
+    const int m0 = s[-4 * o], m7 = s[3 * o];
+    s[-3 * o] = (pel_t) clip3( m1 - 1 * tc, m1 + 1 * tc, ( 2 * m0 + 3 * m1 + m2 + m3 + m4 + 4 ) >> 3 );
+    s[-2 * o] = (pel_t) clip3( m2 - 2 * tc, m2 + 2 * tc, ( m1 + m2 + m3 + m4 + 2 ) >> 2 );
+    s[-1 * o] = (pel_t) clip3( m3 - 3 * tc, m3 + 3 * tc, ( m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4 ) >> 3 );
+    s[0]      = (pel_t) clip3( m4 - 3 * tc, m4 + 3 * tc, ( m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4 ) >> 3 );
+    s[o]      = (pel_t) clip3( m5 - 2 * tc, m5 + 2 * tc, ( m3 + m4 + m5 + m6 + 2 ) >> 2 );
+    s[2 * o]  = (pel_t) clip3( m6 - 1 * tc, m6 + 1 * tc, ( m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4 ) >> 3 );
+  }
+  else
+  {
+    int delta = ( 9 * ( m4 - m3 ) - 3 * ( m5 - m2 ) + 8 ) >> 4;
+    if( iabs( delta ) < thrCut )
+    {
+      delta = clip3( -tc, tc, delta );
+      const int tc2 = tc >> 1;
+      s[-o] = (pel_t) clip_pel( m3 + delta, bd );
+      if( fP ) s[-2 * o] = (pel_t) clip_pel( m2 + clip3( -tc2, tc2, ( ( ( m1 + m3 + 1 ) >> 1 ) - m2 + delta ) >> 1 ), bd );
+      s[0] = (pel_t) clip_pel( m4 - delta, bd );
+      if( fQ ) s[o] = (pel_t) clip_pel( m5 + clip3( -tc2, tc2, ( ( ( m6 + m4 + 1 ) >> 1 ) - m5 - delta ) >> 1 ), bd );
+    }
+  }
+}
+
+__device__ __forceinline__ void filter_chroma_pel( pel_t* s, int o, int tc, bool sw, int bd, bool ctb )
+{
+  const int m2 = s[-2 * o], m3 = s[-o], m4 = s[0], m5 = s[o];
+  if( sw )
+  {
+    const int m6 = s[2 * o], m7 = s[3 * o];
+    if( ctb )
+    {
+      s[-o]    = (pel_t) clip3( m3 - tc, m3 + tc, ( 3 * m2 + 2 * m3 + m4 + m5 + m6 + 4 ) >> 3 );
+      s[0]     = (pel_t) clip3( m4 - tc, m4 + tc, ( 2 * m2 + m3 + 2 * m4 + m5 + m6 + m7 + 4 ) >> 3 );
+      s[o]     = (pel_t) clip3( m5 - tc, m5 + tc, ( m2 + m3 + m4 + 2 * m5 + m6 + 2 * m7 + 4 ) >> 3 );
+      s[2 * o] = (pel_t) clip3( m6 - tc, m6 + tc, ( m3 + m4 + m5 + 2 * m6 + 3 * m7 + 4 ) >> 3 );
+    }
+    else
+    {
+      const int m0 = s[-4 * o], m1 = s[-3 * o];
+      s[-3 * o] = (pel_t) clip3( m1 - tc, m1 + tc, ( 3 * m0 + 2 * m1 + m2 + m3 + m4 + 4 ) >> 3 );
+      s[-2 * o] = (pel_t) clip3( m2 - tc, m2 + tc, ( 2 * m0 + m1 + 2 * m2 + m3 + m4 + m5 + 4 ) >> 3 );
+      s[-o]     = (pel_t) clip3( m3 - tc, m3 + tc, ( m0 + m1 + m2 + 2 * m3 + m4 + m5 + m6 + 4 ) >> 3 );
+      s[0]      = (pel_t) clip3( m4 - tc, m4 + tc, ( m1 + m2 + m3 + 2 * m4 + m5 + m6 + m7 + 4 ) >> 3 );
+      s[o]      = (pel_t) clip3( m5 - tc, m5 + tc, ( m2 + m3 + m4 + 2 * m5 + m6 + 2 * m7 + 4 ) >> 3 );
+      s[2 * o]  = (pel_t) clip3( m6 - tc, m6 + tc, ( m3 + m4 + m5 + 2 * m6 + 3 * m7 + 4 ) >> 3 );
+    }
+  }
+  else
+  {
+    const int delta = clip3( -tc, tc, ( ( ( m4 - m3 ) * 4 ) + m2 - m5 + 4 ) >> 3 );
+    s[-o] = (pel_t) clip_pel( m3 + delta, bd );
+    s[0]  = (pel_t) clip_pel( m4 - delta, bd );
+  }
+}
+
+__device__ __forceinline__ int tc_value( int idx, int bd ) { const int t = d_db_tc_table[idx]; return bd < 10 ? ( t + ( 1 << ( 9 - bd ) ) ) >> ( 10 - bd ) : t << ( bd - 10 ); }
+
+__global__ __launch_bounds__( 256 ) void k_deblock( PicDev pic, DevPlanes r, int dir )
+{
+  // thread -> 4x4 unit; along the edge direction neighbouring threads handle neighbouring segments of the same edge line
+  const int x4 = blockIdx.x * 16 + ( dir == 0 ? threadIdx.x / 16 : threadIdx.x % 16 );
+  const int y4 = blockIdx.y * 16 + ( dir == 0 ? threadIdx.x % 16 : threadIdx.x / 16 );
+  if( x4 >= pic.w4 || y4 >= pic.h4 ) return;
+  const vvr_lfp l = pic.lfp[dir][(size_t) y4 * pic.w4 + x4];
+  if( !l.bs ) return;
+  const vvr_pic_header& H = pic.hdr;
+  const int bd = H.bit_depth;
+  // ---- luma
+  const int bsY = BS_GET( l.bs, 0 );
+  if( bsY )
+  {
+    const int stride = r.stride[0], x = x4 * 4, y = y4 * 4;
+    pel_t* src = r.p[0] + (size_t) y * stride + x;
+    const int o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
+    const int qp = l.qp[0];
+    const int lenP = ( l.side_max_filt_length >> 4 ) & 7, lenQ = l.side_max_filt_length & 7;
+    bool pLarge = lenP > 3, qLarge = lenQ > 3;
+    if( dir == 1 && ( y & ( ( 1 << H.log2_ctu ) - 1 ) ) == 0 ) pLarge = false;
+    const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * H.deblock_tc_offset_div2[0] );
+    const int idxB  = clip3( 0, 63, qp + 2 * H.deblock_beta_offset_div2[0] );
+    const int tc = tc_value( idxTC, bd ), beta = d_db_beta_table[idxB] << ( bd - 8 );
+    const int sideThr = ( beta + ( beta >> 1 ) ) >> 3, thrCut = tc * 10;
+    const pel_t* s0 = src; const pel_t* s3 = src + 3 * step;
+    const int dp0 = calc_dp( s0, o ), dq0 = calc_dq( s0, o ), dp3 = calc_dp( s3, o ), dq3 = calc_dq( s3, o );
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    bool done = false;
+    if( pLarge || qLarge )
+    {
+      const int o3 = 3 * o;
+      const int dp0L = pLarge ? ( dp0 + calc_dp( s0 - o3, o ) + 1 ) >> 1 : dp0;
+      const int dq0L = qLarge ? ( dq0 + calc_dq( s0 + o3, o ) + 1 ) >> 1 : dq0;
+      const int dp3L = pLarge ? ( dp3 + calc_dp( s3 - o3, o ) + 1 ) >> 1 : dp3;
+      const int dq3L = qLarge ? ( dq3 + calc_dq( s3 + o3, o ) + 1 ) >> 1 : dq3;
+      const int d0L = dp0L + dq0L, d3L = dp3L + dq3L, dL = d0L + d3L;
+      if( dL < beta )
+      {
+        const bool swL = use_strong( s0, o, 2 * d0L, beta, tc, pLarge, qLarge, lenP, lenQ, false ) && use_strong( s3, o, 2 * d3L, beta, tc, pLarge, qLarge, lenP, lenQ, false );
+        if( swL ) { filter_long( src, step, o, pLarge ? lenP : 3, qLarge ? lenQ : 3, tc ); done = true; }
+      }
+    }
+    if( !done )
+    {
+      const int dp = dp0 + dp3, dq = dq0 + dq3, d = d0 + d3;
+      if( d < beta )
+      {
+        bool fP = false, fQ = false, sw = false;
+        if( lenP > 1 && lenQ > 1 ) { fP = dp < sideThr; fQ = dq < sideThr; }
+        if( lenP > 2 && lenQ > 2 ) sw = use_strong( s0, o, 2 * d0, beta, tc, false, false, 7, 7, false ) && use_strong( s3, o, 2 * d3, beta, tc, false, false, 7, 7, false );
+        for( int i = 0; i < 4; i++ ) filter_luma_pel( src + step * i, o, tc, sw, thrCut, fP, fQ, bd );
+      }
+    }
+  }
+  // ---- chroma (4:2:0): edges on the 8-chroma-sample grid, two chroma lines per 4x4 luma unit
+  if( !H.chroma_format ) return;
+  if( dir == 0 ? ( x4 & 3 ) : ( y4 & 3 ) ) return;
+  const int bS[2] = { BS_GET( l.bs, 1 ), BS_GET( l.bs, 2 ) };
+  if( !bS[0] && !bS[1] ) return;
+  const int stride = r.stride[1], cx = x4 * 2, cy = y4 * 2;
+  const int o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
+  const bool large = ( l.flags >> 5 ) & 1;
+  const bool ctb = dir == 1 && ( cy & ( ( ( 1 << H.log2_ctu ) - 1 ) >> 1 ) ) == 0;
+  for( int c = 0; c < 2; c++ )
+  {
+    if( !( bS[c] == 2 || ( large && bS[c] == 1 ) ) ) continue;
+    pel_t* src = r.p[c + 1] + (size_t) cy * stride + cx;
+    const int qp = l.qp[c + 1];
+    const int idxTC = clip3( 0, 65, qp + 2 * ( bS[c] - 1 ) + 2 * H.deblock_tc_offset_div2[c + 1] );
+    const int tc = tc_value( idxTC, bd );
+    bool sw = false;
+    if( large )
+    {
+      const int idxB = clip3( 0, 63, qp + 2 * H.deblock_beta_offset_div2[c + 1] );
+      const int beta = d_db_beta_table[idxB] * ( 1 << ( bd - 8 ) );
+      const int dp0 = ctb ? calc_dp_ctb( src, o ) : calc_dp( src, o ), dq0 = calc_dq( src, o );
+      const int dp3 = ctb ? calc_dp_ctb( src + step, o ) : calc_dp( src + step, o ), dq3 = calc_dq( src + step, o );
+      const int d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
+      if( d < beta ) sw = use_strong( src, o, 2 * d0, beta, tc, false, false, 7, 7, ctb ) && use_strong( src + step, o, 2 * d3, beta, tc, false, false, 7, 7, ctb );
+    }
+    for( int i = 0; i < 2; i++ ) filter_chroma_pel( src + step * i, o, tc, sw, bd, ctb );
+  }
+}
+
+void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )
+{
+  if( pic.hdr.tool_flags & VVR_TOOL_DEBLOCK_OFF ) return;
+  hipLaunchKernelGGL( k_deblock, dim3( ( pic.w4 + 15 ) / 16, ( pic.h4 + 15 ) / 16 ), dim3( 256 ), 0, s, pic, reco, dir );
+}
+
+// =====================================================================================================================
+// k_sao — SampleAdaptiveOffset::offsetBlock_core (SampleAdaptiveOffset.cpp:64) per sample; reads the deblocked picture,
+// writes a second picture, so neighbour reads always see pre-SAO samples (the reference needs a line copy for that, :400).
+// =====================================================================================================================
+__global__ __launch_bounds__( 256 ) void k_sao( PicDev pic, DevPlanes src, DevPlanes dst )
+{
+  const int c = blockIdx.z;
+  const int cs = c ? 1 : 0;
+  const int cw = src.w[c], chh = src.h[c];
+  const int x = blockIdx.x * 64 + ( threadIdx.x & 63 );    // one sample per thread, a wavefront covers 64 consecutive samples of a row
+  const int y = blockIdx.y * 4 + ( threadIdx.x >> 6 );
+  if( x >= cw || y >= chh ) return;
+  const int bd = pic.hdr.bit_depth, ctuC = ( 1 << pic.hdr.log2_ctu ) >> cs;
+  const pel_t* __restrict__ S = src.p[c];
+  const int st = src.stride[c];
+  const int v = S[(size_t) y * st + x];
+  int out = v;
+  const bool enabled = pic.sao && ( pic.hdr.tool_flags & ( c ? VVR_TOOL_SAO_CHROMA : VVR_TOOL_SAO_LUMA ) );
+  if( enabled )
+  {
+    const vvr_sao_ctu& s = pic.sao[( y / ctuC ) * pic.ctus_x + ( x / ctuC )];
+    if( s.mode[c] )
+    {
+      const int type = s.type[c];
+      if( type == 4 )
+      {
+        const int k = ( ( v >> ( bd - 5 ) ) - s.band_pos[c] ) & 31;
+        if( k < 4 ) out = clip_pel( v + s.offset[c][k], bd );
+      }
+      else
+      {
+        const int dx = type == 1 ? 0 : ( type == 3 ? -1 : 1 ), dy = type == 0 ? 0 : 1;
+        const int ax = x - dx, ay = y - dy, bx = x + dx, by = y + dy;
+        if( ax >= 0 && ax < cw && ay >= 0 && ay < chh && bx >= 0 && bx < cw && by >= 0 && by < chh )
+        {
+          const int a = S[(size_t) ay * st + ax], b = S[(size_t) by * st + bx];
+          const int e = sgn( v - a ) + sgn( v - b );
+          if( e ) out = clip_pel( v + s.offset[c][e < 0 ? e + 2 : e + 1], bd );
+        }
+      }
+    }
+  }
+  dst.p[c][(size_t) y * dst.stride[c] + x] = (pel_t) out;
+}
+
+void launch_sao( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst )
+{
+  const int ncomp = pic.hdr.chroma_format ? 3 : 1;
+  hipLaunchKernelGGL( k_sao, dim3( ( src.w[0] + 63 ) / 64, ( src.h[0] + 3 ) / 4, ncomp ), dim3( 256 ), 0, s, pic, src, dst );
+}
+
+// =====================================================================================================================
+// k_alf — AdaptiveLoopFilter::filterCTU (AdaptiveLoopFilter.cpp:664) for the no-virtual-boundary / single-slice case:
+//   deriveClassificationBlk (:969), filterBlk<ALF_FILTER_7/5> (:1176), filterBlkCcAlf (:1348), prepareCTU (:453, border
+//   replication = clamped reads).  One workgroup filters a 32x32 luma tile (or 32x32 chroma tile): the tile plus a
+//   3-sample halo is staged in LDS; each thread first classifies one 4x4 block (luma), results are exchanged through LDS,
+//   then every thread filters 4 samples.
+// =====================================================================================================================
+#define ALF_T   32
+#define ALF_HALO 3
+#define ALF_LW  ( ALF_T + 2 * ALF_HALO + 2 )     // LDS row stride (40)
+
+__device__ __forceinline__ int clip_alf( int clip, int ref, int v0, int v1 ) { return clip3( -clip, clip, v0 - ref ) + clip3( -clip, clip, v1 - ref ); }
+
+__constant__ int8_t c_alf_perm[4][12] = {
+  { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 },
+  { 9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6 },
+  { 0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11 },
+  { 9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6 } };
+
+__global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, DevPlanes dst )
+{
+  __shared__ pel_t tile[( ALF_T + 2 * ALF_HALO ) * ALF_LW];
+  __shared__ uint8_t cls[64], trp[64];
+  const int tx0 = blockIdx.x * ALF_T, ty0 = blockIdx.y * ALF_T;
+  const int W = src.w[0], H = src.h[0], st = src.stride[0];
+  const int tid = threadIdx.x, bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu;
+  const pel_t* __restrict__ S = src.p[0];
+  // the whole tile lies in one CTU (ALF_T divides the CTU size)
+  const vvr_alf_ctu f = pic.alf[( ty0 >> pic.hdr.log2_ctu ) * pic.ctus_x + ( tx0 >> pic.hdr.log2_ctu )];
+  if( !f.enable[0] )
+  {
+    for( int i = tid; i < ALF_T * ALF_T; i += 256 )
+    {
+      const int y = ty0 + i / ALF_T, x = tx0 + i % ALF_T;
+      if( x < W && y < H ) dst.p[0][(size_t) y * dst.stride[0] + x] = S[(size_t) y * st + x];
+    }
+    return;
+  }
+  const int TW = ALF_T + 2 * ALF_HALO;
+  for( int i = tid; i < TW * TW; i += 256 )
+  {
+    const int yy = i / TW, xx = i - yy * TW;
+    const int sx = clip3( 0, W - 1, tx0 - ALF_HALO + xx ), sy = clip3( 0, H - 1, ty0 - ALF_HALO + yy );
+    tile[yy * ALF_LW + xx] = S[(size_t) sy * st + sx];
+  }
+  __syncthreads();
+#define T( x, y ) tile[( ( y ) + ALF_HALO ) * ALF_LW + ( x ) + ALF_HALO]      // tile-relative sample
+  const int vbPos = ctu - 4;
+  if( tid < 64 )
+  {
+    // ---- classification of the 4x4 block (bx,by) (tile-relative)
+    const int bx = ( tid & 7 ) * 4, by = ( tid >> 3 ) * 4;
+    const int yInCtu = ( ty0 + by ) & ( ctu - 1 );
+    int sumV = 0, sumH = 0, sumD0 = 0, sumD1 = 0;
+    for( int i = 0; i < 8; i += 2 )
+    {
+      if( yInCtu == vbPos - 4 && i == 6 ) continue;
+      if( yInCtu == vbPos && i == 0 ) continue;
+      const int r = by - 2 + i, rel = yInCtu - 2 + i;
+      int rm1 = r - 1, rp2 = r + 2;
+      if( rel > 0 && ( rel % ctu ) == vbPos - 2 ) rp2 = r + 1;
+      else if( rel > 0 && ( rel % ctu ) == vbPos ) rm1 = r;
+      for( int j = 0; j < 8; j += 2 )
+      {
+        const int cX = bx - 2 + j;
+        const int y0 = T( cX, r ) << 1, yup1 = T( cX + 1, r + 1 ) << 1;
+        sumV  += iabs( y0 - T( cX, rm1 ) - T( cX, r + 1 ) )         + iabs( yup1 - T( cX + 1, r ) - T( cX + 1, rp2 ) );
+        sumH  += iabs( y0 - T( cX + 1, r ) - T( cX - 1, r ) )       + iabs( yup1 - T( cX + 2, r + 1 ) - T( cX, r + 1 ) );
+        sumD0 += iabs( y0 - T( cX - 1, rm1 ) - T( cX + 1, r + 1 ) ) + iabs( yup1 - T( cX, r ) - T( cX + 2, rp2 ) );
+        sumD1 += iabs( y0 - T( cX - 1, r + 1 ) - T( cX + 1, rm1 ) ) + iabs( yup1 - T( cX, rp2 ) - T( cX + 2, r ) );
+      }
+    }
+    const int th[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
+    const int act = clip3( 0, 15, ( ( sumV + sumH ) * ( ( yInCtu == vbPos - 4 || yInCtu == vbPos ) ? 96 : 64 ) ) >> ( bd + 4 ) );
+    int cl = th[act];
+    int hv1, hv0, d1, d0, dirHV, dirD, hvd1, hvd0, mainDir, secDir;
+    if( sumV > sumH ) { hv1 = sumV; hv0 = sumH; dirHV = 1; } else { hv1 = sumH; hv0 = sumV; dirHV = 3; }
+    if( sumD0 > sumD1 ) { d1 = sumD0; d0 = sumD1; dirD = 0; } else { d1 = sumD1; d0 = sumD0; dirD = 2; }
+    if( (uint32_t) d1 * (uint32_t) hv0 > (uint32_t) hv1 * (uint32_t) d0 ) { hvd1 = d1; hvd0 = d0; mainDir = dirD; secDir = dirHV; }
+    else { hvd1 = hv1; hvd0 = hv0; mainDir = dirHV; secDir = dirD; }
+    int strength = 0;
+    if( hvd1 > 2 * hvd0 ) strength = 1;
+    if( hvd1 * 2 > 9 * hvd0 ) strength = 2;
+    if( strength ) cl += ( ( ( mainDir & 1 ) << 1 ) + strength ) * 5;
+    const int tt[8] = { 0, 1, 0, 2, 2, 3, 1, 3 };
+    cls[tid] = (uint8_t) cl; trp[tid] = (uint8_t) tt[mainDir * 2 + ( secDir >> 1 )];
+  }
+  __syncthreads();
+  // ---- filtering: thread -> (row, 4 consecutive columns)
+  const vvr_alf_params* __restrict__ A = pic.alf_params;
+  const int clipDef = 1 << ( bd );      // m_alfClippVls[bd-8][0] = 256 << (bd - 8)
+  for( int q = tid; q < ALF_T * ALF_T / 4; q += 256 )
+  {
+    const int y = q / ( ALF_T / 4 ), x4 = ( q % ( ALF_T / 4 ) ) * 4;
+    const int gy = ty0 + y;
+    if( gy >= H || tx0 + x4 >= W ) continue;
+    const int b = ( y >> 2 ) * 8 + ( x4 >> 2 );
+    const int cl = cls[b], tr = trp[b];
+    int cf[12], cp[12];
+    for( int k = 0; k < 12; k++ )
+    {
+      const int sk = c_alf_perm[tr][k];
+      if( f.luma_filter_idx < 16 ) { cf[k] = d_alf_fixed_coeff[d_alf_class_to_filter[f.luma_filter_idx][cl]][sk]; cp[k] = clipDef; }
+      else { cf[k] = A->luma_coeff[f.luma_filter_idx - 16][cl][sk]; cp[k] = A->luma_clip[f.luma_filter_idx - 16][cl][sk]; }
+    }
+    const int yVb = gy & ( ctu - 1 );
+    int r1 = y + 1, r2 = y - 1, r3 = y + 2, r4 = y - 2, r5 = y + 3, r6 = y - 3;
+    if( yVb < vbPos && yVb >= vbPos - 4 )
+    {
+      r1 = ( yVb == vbPos - 1 ) ? y : r1;  r3 = ( yVb >= vbPos - 2 ) ? r1 : r3;  r5 = ( yVb >= vbPos - 3 ) ? r3 : r5;
+      r2 = ( yVb == vbPos - 1 ) ? y : r2;  r4 = ( yVb >= vbPos - 2 ) ? r2 : r4;  r6 = ( yVb >= vbPos - 3 ) ? r4 : r6;
+    }
+    else if( yVb >= vbPos && yVb <= vbPos + 3 )
+    {
+      r2 = ( yVb == vbPos ) ? y : r2;  r4 = ( yVb <= vbPos + 1 ) ? r2 : r4;  r6 = ( yVb <= vbPos + 2 ) ? r4 : r6;
+      r1 = ( yVb == vbPos ) ? y : r1;  r3 = ( yVb <= vbPos + 1 ) ? r1 : r3;  r5 = ( yVb <= vbPos + 2 ) ? r3 : r5;
+    }
+    const bool nearVb = ( yVb == vbPos - 1 ) || ( yVb == vbPos );
+    for( int xx = x4; xx < x4 + 4 && tx0 + xx < W; xx++ )
+    {
+      const int cur = T( xx, y );
+      int sum = 0;
+      sum += cf[0]  * clip_alf( cp[0],  cur, T( xx, r5 ),     T( xx, r6 ) );
+      sum += cf[1]  * clip_alf( cp[1],  cur, T( xx + 1, r3 ), T( xx - 1, r4 ) );
+      sum += cf[2]  * clip_alf( cp[2],  cur, T( xx, r3 ),     T( xx, r4 ) );
+      sum += cf[3]  * clip_alf( cp[3],  cur, T( xx - 1, r3 ), T( xx + 1, r4 ) );
+      sum += cf[4]  * clip_alf( cp[4],  cur, T( xx + 2, r1 ), T( xx - 2, r2 ) );
+      sum += cf[5]  * clip_alf( cp[5],  cur, T( xx + 1, r1 ), T( xx - 1, r2 ) );
+      sum += cf[6]  * clip_alf( cp[6],  cur, T( xx, r1 ),     T( xx, r2 ) );
+      sum += cf[7]  * clip_alf( cp[7],  cur, T( xx - 1, r1 ), T( xx + 1, r2 ) );
+      sum += cf[8]  * clip_alf( cp[8],  cur, T( xx - 2, r1 ), T( xx + 2, r2 ) );
+      sum += cf[9]  * clip_alf( cp[9],  cur, T( xx + 3, y ),  T( xx - 3, y ) );
+      sum += cf[10] * clip_alf( cp[10], cur, T( xx + 2, y ),  T( xx - 2, y ) );
+      sum += cf[11] * clip_alf( cp[11], cur, T( xx + 1, y ),  T( xx - 1, y ) );
+      sum = nearVb ? ( sum + 512 ) >> 10 : ( sum + 64 ) >> 7;
+      dst.p[0][(size_t) gy * dst.stride[0] + tx0 + xx] = (pel_t) clip_pel( sum + cur, bd );
+    }
+  }
+#undef T
+}
+
+// chroma 5x5 diamond + CC-ALF: one thread per chroma sample, straight from global memory (L1/L2 serve the 13 + 8 taps)
+__global__ __launch_bounds__( 256 ) void k_alf_chroma( PicDev pic, DevPlanes src, DevPlanes dst )
+{
+  const int c = 1 + blockIdx.z;
+  const int x = blockIdx.x * 64 + ( threadIdx.x & 63 ), y = blockIdx.y * 4 + ( threadIdx.x >> 6 );
+  const int W = src.w[c], H = src.h[c];
+  if( x >= W || y >= H ) return;
+  const int bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu, ctuC = ctu >> 1;
+  const vvr_alf_ctu& f = pic.alf[( y / ctuC ) * pic.ctus_x + ( x / ctuC )];
+  const pel_t* __restrict__ S = src.p[c];
+  const int st = src.stride[c];
+#define C( xx, yy ) S[(size_t) clip3( 0, H - 1, ( yy ) ) * st + clip3( 0, W - 1, ( xx ) )]
+  const int cur = S[(size_t) y * st + x];
+  int v = cur;
+  const vvr_alf_params* __restrict__ A = pic.alf_params;
+  if( f.enable[c] )
+  {
+    const int16_t* cf = A->chroma_coeff[f.alt[c - 1]]; const int16_t* cp = A->chroma_clip[f.alt[c - 1]];
+    const int vbPos = ctuC - 2, yVb = y & ( ctuC - 1 );
+    int r1 = y + 1, r2 = y - 1, r3 = y + 2, r4 = y - 2;
+    if( yVb < vbPos && yVb >= vbPos - 2 )
+    {
+      r1 = ( yVb == vbPos - 1 ) ? y : r1;  r3 = ( yVb >= vbPos - 2 ) ? r1 : r3;
+      r2 = ( yVb == vbPos - 1 ) ? y : r2;  r4 = ( yVb >= vbPos - 2 ) ? r2 : r4;
+    }
+    else if( yVb >= vbPos && yVb <= vbPos + 1 )
+    {
+      r2 = ( yVb == vbPos ) ? y : r2;  r4 = ( yVb <= vbPos + 1 ) ? r2 : r4;
+      r1 = ( yVb == vbPos ) ? y : r1;  r3 = ( yVb <= vbPos + 1 ) ? r1 : r3;
+    }
+    const bool nearVb = ( yVb == vbPos - 1 ) || ( yVb == vbPos );
+    int sum = 0;
+    sum += cf[0] * clip_alf( cp[0], cur, C( x, r3 ),     C( x, r4 ) );
+    sum += cf[1] * clip_alf( cp[1], cur, C( x + 1, r1 ), C( x - 1, r2 ) );
+    sum += cf[2] * clip_alf( cp[2], cur, C( x, r1 ),     C( x, r2 ) );
+    sum += cf[3] * clip_alf( cp[3], cur, C( x - 1, r1 ), C( x + 1, r2 ) );
+    sum += cf[4] * clip_alf( cp[4], cur, C( x + 2, y ),  C( x - 2, y ) );
+    sum += cf[5] * clip_alf( cp[5], cur, C( x + 1, y ),  C( x - 1, y ) );
+    sum = nearVb ? ( sum + 512 ) >> 10 : ( sum + 64 ) >> 7;
+    v = clip_pel( sum + cur, bd );
+  }
+#undef C
+  if( ( pic.hdr.tool_flags & VVR_TOOL_CCALF ) && f.cc_idc[c - 1] )
+  {
+    const int16_t* cf = A->ccalf_coeff[c - 1][f.cc_idc[c - 1] - 1];
+    const pel_t* __restrict__ L = src.p[0];
+    const int ls = src.stride[0], LW = src.w[0], LH = src.h[0];
+#define Y( xx, yy ) L[(size_t) clip3( 0, LH - 1, ( yy ) ) * ls + clip3( 0, LW - 1, ( xx ) )]
+    const int vbPos = ctu - 4, lx = x << 1, ly = y << 1, pos = ly & ( ctu - 1 );
+    int o1 = 1, o2 = -1, o3 = 2;
+    if( pos == vbPos - 2 || pos == vbPos + 1 ) o3 = o1;
+    else if( pos == vbPos - 1 || pos == vbPos ) { o1 = 0; o2 = 0; o3 = 0; }
+    const int cc = Y( lx, ly );
+    int sum = 0;
+    sum += cf[0] * ( Y( lx,     ly + o2 ) - cc );
+    sum += cf[1] * ( Y( lx - 1, ly      ) - cc );
+    sum += cf[2] * ( Y( lx + 1, ly      ) - cc );
+    sum += cf[3] * ( Y( lx - 1, ly + o1 ) - cc );
+    sum += cf[4] * ( Y( lx,     ly + o1 ) - cc );
+    sum += cf[5] * ( Y( lx + 1, ly + o1 ) - cc );
+    sum += cf[6] * ( Y( lx,     ly + o3 ) - cc );
+#undef Y
+    sum = ( sum + 64 ) >> 7;
+    const int off = 1 << bd >> 1;
+    sum = clip_pel( sum + off, bd ) - off;
+    v = clip_pel( v + sum, bd );
+  }
+  dst.p[c][(size_t) y * dst.stride[c] + x] = (pel_t) v;
+}
+
+void launch_alf( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst )
+{
+  hipLaunchKernelGGL( k_alf_luma, dim3( ( src.w[0] + ALF_T - 1 ) / ALF_T, ( src.h[0] + ALF_T - 1 ) / ALF_T ), dim3( 256 ), 0, s, pic, src, dst );
+  if( pic.hdr.chroma_format )
+    hipLaunchKernelGGL( k_alf_chroma, dim3( ( src.w[1] + 63 ) / 64, ( src.h[1] + 3 ) / 4, 2 ), dim3( 256 ), 0, s, pic, src, dst );
+}
+
+// plain plane copy (used when a stage is disabled for a picture)
+__global__ void k_copy( DevPlanes src, DevPlanes dst )
+{
+  const int c = blockIdx.z, x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if( x < src.w[c] && y < src.h[c] ) dst.p[c][(size_t) y * dst.stride[c] + x] = src.p[c][(size_t) y * src.stride[c] + x];
+}
+void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst )
+{
+  const int ncomp = src.p[1] ? 3 : 1;
+  hipLaunchKernelGGL( k_copy, dim3( ( src.w[0] + 255 ) / 256, src.h[0], ncomp ), dim3( 256 ), 0, s, src, dst );
+}

@@ -99,3 +99,26 @@ def generate(p):
     d.coef = coef[:max(1, b.num_coef)].copy()
     d.num_dmvr = b.num_dmvr
     return d
+
+
+def picture_for_plan(plan, width, height, seed=1234, tool_flags=0, **kw):
+    """PictureDesc of one stream.PicPlan (generator seed = base seed + POC)."""
+    p = default_params(width=width, height=height, seed=seed + plan.poc, tool_flags=tool_flags, slice_type=plan.slice_type, **kw)
+    p.poc = plan.poc
+    p.out_slot = plan.slot
+    if plan.slice_type != abi.SLICE_I:
+        set_refs(p, plan.ref_slots[0], plan.ref_slots[1])
+    return generate(p)
+
+
+def natural_picture(width, height, seed, bit_depth=10):
+    """A smooth-plus-texture test picture (stands in for an IRAP picture until intra reconstruction is enabled)."""
+    rng = np.random.default_rng(seed)
+    mx = (1 << bit_depth) - 1
+    gy, gx = np.mgrid[0:height, 0:width]
+    base = (np.sin(gx / 37.0 + seed) + np.cos(gy / 23.0 - seed) + np.sin((gx + gy) / 61.0)) * (mx / 8.0) + mx / 2.0
+    blocks = rng.integers(-mx // 10, mx // 10, (height // 16 + 1, width // 16 + 1)).repeat(16, 0).repeat(16, 1)[:height, :width]
+    y = np.clip(base + blocks + rng.integers(-12, 13, (height, width)), 0, mx).astype(np.uint16)
+    cb = np.clip(y[::2, ::2].astype(np.int32) // 2 + mx // 4 + rng.integers(-6, 7, (height // 2, width // 2)), 0, mx).astype(np.uint16)
+    cr = np.clip(mx - y[::2, ::2].astype(np.int32) // 2 - mx // 4 + rng.integers(-6, 7, (height // 2, width // 2)), 0, mx).astype(np.uint16)
+    return [y, cb, cr]
