@@ -395,12 +395,16 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
   if( q->numTb[0] + q->numTb[1] + q->numTb[2] )
     timed( K_ITRANS, [&]{ launch_itrans( s, q->pic, A, R, q->tbItems[0], q->numTb[0], 16 ); launch_itrans( s, q->pic, A, R, q->tbItems[1], q->numTb[1], 32 ); launch_itrans( s, q->pic, A, R, q->tbItems[2], q->numTb[2], 64 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
-  if( !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF ) )
+  // debugging aid (like the reference's per-stage CRC traces, LoopFilter.cpp:399-406): VVR_STOP_AFTER=reco|dbk|sao
+  const char* stopEnv = getenv( "VVR_STOP_AFTER" );
+  const int stopAfter = !stopEnv ? 0 : !strcmp( stopEnv, "reco" ) ? 1 : !strcmp( stopEnv, "dbk" ) ? 2 : !strcmp( stopEnv, "sao" ) ? 3 : 0;
+  if( !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF ) && stopAfter != 1 )
   {
     timed( K_DEBLOCK_V, [&]{ launch_deblock( s, q->pic, A, 0 ); } );
     timed( K_DEBLOCK_H, [&]{ launch_deblock( s, q->pic, A, 1 ); } );
   }
-  const bool sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) != 0, alf = ( h.tool_flags & VVR_TOOL_ALF ) != 0;
+  const bool sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) != 0 && stopAfter != 1 && stopAfter != 2;
+  const bool alf = ( h.tool_flags & VVR_TOOL_ALF ) != 0 && stopAfter == 0;
   if( sao && alf ) { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
   else if( sao )   { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_COPY, [&]{ launch_copy_planes( s, B, A ); } ); }
   else if( alf )   { timed( K_COPY, [&]{ launch_copy_planes( s, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }

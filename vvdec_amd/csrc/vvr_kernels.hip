@@ -236,6 +236,7 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
   const int bdpcm = comp ? cu.bdpcm[1] : cu.bdpcm[0];
   int maxX = tu.max_scan_x[comp], maxY = tu.max_scan_y[comp];
   const int16_t* __restrict__ lev = pic.coef + tu.coef_off[comp];
+
   const int n = bw * bh;
   for( int i = tid; i < n; i += 256 ) dq[i] = 0;
   __syncthreads();
