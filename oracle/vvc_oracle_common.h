@@ -18,6 +18,7 @@ static inline int vvo_clip3( int lo, int hi, int v ) { return v < lo ? lo : v > 
 static inline int vvo_clip_pel( int v, int bd ) { return vvo_clip3( 0, ( 1 << bd ) - 1, v ); }
 static inline int vvo_log2( int v ) { int l = 0; while( ( 1 << l ) < v ) l++; return l; }
 static inline int vvo_abs( int v ) { return v < 0 ? -v : v; }
+static inline int vvo_floor_log2( int v ) { int l = 0; while( ( 2 << l ) <= v ) l++; return l; }   /* getLog2 (CommonDef.h:620) */
 static inline int vvo_min( int a, int b ) { return a < b ? a : b; }
 static inline int vvo_max( int a, int b ) { return a > b ? a : b; }
 static inline int vvo_sgn( int v ) { return ( v > 0 ) - ( v < 0 ); }

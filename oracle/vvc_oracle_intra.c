@@ -1,9 +1,329 @@
-/* oracle/vvc_oracle_intra.c — CPU restatement (TEST INFRASTRUCTURE): intra prediction.  (filled in below) */
+/* oracle/vvc_oracle_intra.c — CPU restatement (TEST INFRASTRUCTURE): intra prediction + reconstruction of one transform block.
+ *
+ * Follows  DecoderLib/DecCu.cpp:271-401 (predAndReco, intra branch),
+ *          CommonLib/IntraPrediction.cpp:947-964 (initIntraPatternChType), :1072-1249 (xFillReferenceSamples),
+ *          :1251-1288 (xFilterReferenceSamples), :1301-1330 (useFilteredIntraRefSamples), :1343-1400 (is{Above,Left}Available),
+ *          :412-441 (xGetPredValDc), :154-210 (xPredIntraPlanarCore), :212-233 (IntraPredSampleFilterCore, PDPC planar/DC),
+ *          :443-458 (getWideAngle), :474-517 (predIntraAng), :592-848 (xPredIntraAng), :850-885 (xPredIntraBDPCM),
+ *          CommonLib/CodingStructure.cpp:464-500 (getCURestricted),  CommonLib/Buffer.cpp:482 (reconstruct).
+ *
+ * Not restated in this version (the description is rejected): ISP, MIP, CCLM/MDLM. */
 #include "vvc_oracle_common.h"
+#include "../tables/vvc_tables.inc"
+
+#define MAXREF ( 2 * 64 + 8 )
+
+static const uint8_t intraFilterThr[2][8] = { { 24, 24, 24, 14, 2, 0, 0, 0 }, { 40, 40, 40, 28, 4, 0, 0, 0 } };   /* m_aucIntraFilter (:72) */
+static const int angTable[32]    = { 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 39, 45, 51, 57, 64, 73, 86, 102, 128, 171, 256, 341, 512, 1024 };
+static const int invAngTable[32] = { 0, 16384, 8192, 5461, 4096, 2731, 2048, 1638, 1365, 1170, 1024, 910, 819, 712, 630, 565, 512, 468, 420, 364, 321, 287, 256, 224, 191, 161, 128, 96, 64, 48, 32, 16 };
+static const int8_t gauss[32][4] = {   /* g_intraGaussFilter (:96) */
+  { 16, 32, 16, 0 }, { 16, 32, 16, 0 }, { 15, 31, 17, 1 }, { 15, 31, 17, 1 }, { 14, 30, 18, 2 }, { 14, 30, 18, 2 }, { 13, 29, 19, 3 }, { 13, 29, 19, 3 },
+  { 12, 28, 20, 4 }, { 12, 28, 20, 4 }, { 11, 27, 21, 5 }, { 11, 27, 21, 5 }, { 10, 26, 22, 6 }, { 10, 26, 22, 6 }, { 9, 25, 23, 7 }, { 9, 25, 23, 7 },
+  { 8, 24, 24, 8 }, { 8, 24, 24, 8 }, { 7, 23, 25, 9 }, { 7, 23, 25, 9 }, { 6, 22, 26, 10 }, { 6, 22, 26, 10 }, { 5, 21, 27, 11 }, { 5, 21, 27, 11 },
+  { 4, 20, 28, 12 }, { 4, 20, 28, 12 }, { 3, 19, 29, 13 }, { 3, 19, 29, 13 }, { 2, 18, 30, 14 }, { 2, 18, 30, 14 }, { 1, 17, 31, 15 }, { 1, 17, 31, 15 } };
+
+static int wide_angle( int w, int h, int mode )   /* IntraPrediction::getWideAngle (:443) */
+{
+  static const int modeShift[] = { 0, 6, 10, 12, 14, 15 };
+  if( mode > 1 && mode <= 66 )
+  {
+    const int d = vvo_abs( vvo_log2( w ) - vvo_log2( h ) );
+    if( w > h && mode < 2 + modeShift[d] ) mode += 65;
+    else if( h > w && mode > 66 - modeShift[d] ) mode -= 65;
+  }
+  return mode;
+}
+
+/* reference availability of the 4x4 luma-grid unit that contains channel position (x,y): the unit must lie inside the picture and
+ * its transform block must precede the current one in decoding order (getCURestricted + the TU index test of is*Available). */
+static int unit_avail( const vvr_pic_header* H, const int32_t* order, int ch, int x, int y, int32_t cur )
+{
+  const int cs = ch ? 1 : 0;
+  const int lx = x << cs, ly = y << cs;
+  if( x < 0 || y < 0 || lx >= H->width || ly >= H->height ) return 0;
+  const int w4 = ( H->width + 3 ) >> 2, h4 = ( H->height + 3 ) >> 2;
+  return order[(size_t) ch * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
+}
+
 int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, vvo_planes* reco,
                   const int32_t* order, const int16_t* resi, int has_resi )
 {
-  (void) pic; (void) cu; (void) tu; (void) tu_idx; (void) comp; (void) reco; (void) order; (void) resi; (void) has_resi;
-  vvo_set_error( "intra prediction not restated yet" );
-  return -1;
+  const vvr_pic_header* H = &pic->hdr;
+  const int bd = H->bit_depth, cs = comp ? 1 : 0, ch = comp ? 1 : 0;
+  const int x0 = tu->x >> cs, y0 = tu->y >> cs, w = tu->w >> cs, h = tu->h >> cs;
+  pel* plane = reco->p[comp]; const int stride = reco->stride[comp];
+  if( cu->isp_mode || ( ( cu->flags & VVR_CU_MIP ) && !comp ) || ( comp && cu->intra_dir[1] >= 67 ) ) { vvo_set_error( "ISP / MIP / CCLM are not restated" ); return -1; }
+  if( w < 4 || h < 4 ) { vvo_set_error( "intra blocks narrower than 4 are not restated" ); return -1; }
+  const int mrl = comp ? 0 : cu->multi_ref_idx;
+  const int bdpcm = comp ? cu->bdpcm[1] : cu->bdpcm[0];
+  const int dirMode = cu->intra_dir[ch];
+  const int topLen = 2 * w, leftLen = 2 * h;                 /* setReferenceArrayLengths (:460) */
+  pel top[MAXREF + 8], left[MAXREF + 8], ftop[MAXREF + 8], fleft[MAXREF + 8];
+
+  /* ---- xFillReferenceSamples (:1072): availability in units of 4 luma samples */
+  const int unit = 4 >> cs;
+  const int totalAbove = ( topLen + unit - 1 ) / unit, totalLeft = ( leftLen + unit - 1 ) / unit;
+  const int numAbove = w / unit, numLeft = h / unit;
+  const int32_t cur = (int32_t) tu_idx;
+  int nTL = unit_avail( H, order, ch, x0 - 1, y0 - 1, cur );
+  int nA = 0, nL = 0;
+  if( unit_avail( H, order, ch, x0, y0 - 1, cur ) )
+  {
+    nA = numAbove;
+    for( int k = 0; k < totalAbove - numAbove; k++ ) { if( !unit_avail( H, order, ch, x0 + w + k * unit, y0 - 1, cur ) ) break; nA++; }
+  }
+  if( unit_avail( H, order, ch, x0 - 1, y0, cur ) )
+  {
+    nL = numLeft;
+    for( int k = 0; k < totalLeft - numLeft; k++ ) { if( !unit_avail( H, order, ch, x0 - 1, y0 + h + k * unit, cur ) ) break; nL++; }
+  }
+  const int total = totalAbove + totalLeft + 1, nAll = nTL + nA + nL;
+  const int dcv = 1 << ( bd - 1 );
+#define R( xx, yy ) plane[(size_t) ( yy ) * stride + ( xx )]
+  if( nAll == 0 )
+  {
+    for( int j = 0; j <= topLen + mrl; j++ ) top[j] = (pel) dcv;
+    for( int i = 0; i <= leftLen + mrl; i++ ) left[i] = (pel) dcv;
+  }
+  else if( nAll == total )
+  {
+    for( int j = 0; j <= topLen + mrl; j++ ) top[j] = R( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) );
+    left[0] = top[0];
+    for( int i = 1; i <= leftLen + mrl; i++ ) left[i] = R( x0 - ( 1 + mrl ), y0 - mrl + ( i - 1 ) );
+  }
+  else if( nL > 0 )
+  {
+    /* left & below-left (downwards), padded */
+    int sz = vvo_min( nL * unit, leftLen );
+    for( int i = 0; i < sz; i++ ) left[1 + mrl + i] = R( x0 - ( 1 + mrl ), y0 + i );
+    for( int i = sz; i < leftLen; i++ ) left[1 + mrl + i] = left[1 + mrl + sz - 1];
+    /* top-left sample(s) */
+    if( nTL )
+    {
+      for( int j = 0; j <= mrl; j++ ) top[j] = R( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) );
+      for( int i = 1; i <= mrl; i++ ) left[i] = R( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) + i );
+    }
+    else
+    {
+      const pel t = R( x0 - ( 1 + mrl ), y0 );
+      top[0] = t;
+      for( int i = 1; i <= mrl; i++ ) { top[i] = t; left[i] = t; }
+    }
+    left[0] = top[0];
+    /* above & above-right */
+    if( nA )
+    {
+      sz = vvo_min( nA * unit, topLen );
+      for( int j = 0; j < sz; j++ ) top[1 + mrl + j] = R( x0 + j, y0 - ( 1 + mrl ) );
+      for( int j = sz; j < topLen; j++ ) top[1 + mrl + j] = top[1 + mrl + sz - 1];
+    }
+    else
+      for( int j = 0; j < topLen; j++ ) top[1 + mrl + j] = top[mrl];
+  }
+  else
+  {
+    /* left missing, top present */
+    const int sz = vvo_min( nA * unit, topLen );
+    for( int j = 0; j < sz; j++ ) top[1 + mrl + j] = R( x0 + j, y0 - ( 1 + mrl ) );
+    for( int j = sz; j < topLen; j++ ) top[1 + mrl + j] = top[1 + mrl + sz - 1];
+    const pel t = R( x0, y0 - ( 1 + mrl ) );
+    top[0] = t; left[0] = t;
+    for( int i = 1; i <= mrl; i++ ) { top[i] = t; left[i] = t; }
+    for( int i = 0; i < leftLen; i++ ) left[1 + mrl + i] = t;
+  }
+#undef R
+
+  /* ---- reference smoothing decision (DecCu.cpp:337 + useFilteredIntraRefSamples :1301) */
+  int useFilt = 0;
+  if( !comp && !mrl && !bdpcm && dirMode != 1 )
+  {
+    if( dirMode == 0 ) useFilt = w * h > 32;
+    else
+    {
+      const int pm = wide_angle( w, h, dirMode );
+      const int diff = vvo_min( vvo_abs( pm - 18 ), vvo_abs( pm - 50 ) );
+      const int l2 = ( vvo_log2( w ) + vvo_log2( h ) ) >> 1;
+      const int am = pm >= 34 ? pm - 50 : -( pm - 18 );
+      useFilt = diff > intraFilterThr[0][l2] && ( ( angTable[vvo_abs( am )] & 0x1F ) == 0 );
+    }
+  }
+  const pel *T = top, *L = left;
+  if( useFilt )
+  {   /* xFilterReferenceSamples (:1251), multiRefIdx is 0 here */
+    ftop[0] = fleft[0] = (pel) ( ( left[1] + 2 * top[0] + top[1] + 2 ) >> 2 );
+    for( int j = 1; j < topLen; j++ ) ftop[j] = (pel) ( ( top[j + 1] + 2 * top[j] + top[j - 1] + 2 ) >> 2 );
+    ftop[topLen] = top[topLen];
+    for( int i = 1; i < leftLen; i++ ) fleft[i] = (pel) ( ( left[i + 1] + 2 * left[i] + left[i - 1] + 2 ) >> 2 );
+    fleft[leftLen] = left[leftLen];
+    T = ftop; L = fleft;
+  }
+
+  /* ---- prediction (predIntraAng :474) */
+  pel pred[64 * 64];
+  int doPDPC = ( w >= 4 && h >= 4 ) && mrl == 0;
+  if( bdpcm )
+  {   /* xPredIntraBDPCM (:850) */
+    for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) pred[y * w + x] = bdpcm == 1 ? L[y + 1] : T[x + 1];
+  }
+  else if( dirMode == 0 )
+  {   /* xPredIntraPlanarCore (:154) */
+    const int l2w = vvo_log2( w ), l2h = vvo_log2( h );
+    const int bl = L[h + 1], tr = T[w + 1];
+    for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+    {
+      const int hor = ( L[y + 1] << l2w ) + ( x + 1 ) * ( tr - L[y + 1] );
+      const int ver = ( T[x + 1] << l2h ) + ( y + 1 ) * ( bl - T[x + 1] );
+      pred[y * w + x] = (pel) ( ( ( hor << l2h ) + ( ver << l2w ) + ( 1 << ( l2w + l2h ) ) ) >> ( 1 + l2w + l2h ) );
+    }
+  }
+  else if( dirMode == 1 )
+  {   /* xGetPredValDc (:412) */
+    int sum = 0;
+    const int denom = w == h ? w << 1 : vvo_max( w, h );
+    if( w >= h ) for( int i = 0; i < w; i++ ) sum += T[mrl + 1 + i];
+    if( w <= h ) for( int i = 0; i < h; i++ ) sum += L[mrl + 1 + i];
+    const pel dc = (pel) ( ( sum + ( denom >> 1 ) ) >> vvo_log2( denom ) );
+    for( int i = 0; i < w * h; i++ ) pred[i] = dc;
+  }
+  else
+  {   /* xPredIntraAng (:592) */
+    const int predMode = wide_angle( w, h, dirMode );
+    const int isVer = predMode >= 34;
+    const int am = isVer ? predMode - 50 : -( predMode - 18 );
+    const int absAm = vvo_abs( am ), sign = am < 0 ? -1 : 1;
+    const int invAngle = invAngTable[absAm], absAng = angTable[absAm], angle = sign * absAng;
+    pel refAboveBuf[2 * 64 + 3 + 33 * 3 + 64], refLeftBuf[2 * 64 + 3 + 33 * 3 + 64];
+    pel *refMain, *refSide;
+    int bw = w, bh = h;
+    if( angle < 0 )
+    {
+      pel* ra = refAboveBuf + h; pel* rl = refLeftBuf + w;
+      for( int x = 0; x <= w + 1 + mrl; x++ ) ra[x] = T[x];
+      for( int y = 0; y <= h + 1 + mrl; y++ ) rl[y] = L[y];
+      refMain = isVer ? ra : rl; refSide = isVer ? rl : ra;
+      const int sizeSide = isVer ? h : w;
+      for( int k = -sizeSide; k <= -1; k++ ) refMain[k] = refSide[vvo_min( ( -k * invAngle + 256 ) >> 9, sizeSide )];
+    }
+    else
+    {
+      for( int x = 0; x <= topLen + mrl; x++ ) refAboveBuf[x] = T[x];
+      for( int y = 0; y <= leftLen + mrl; y++ ) refLeftBuf[y] = L[y];
+      refMain = isVer ? refAboveBuf : refLeftBuf; refSide = isVer ? refLeftBuf : refAboveBuf;
+      const int l2r = vvo_log2( w ) - vvo_log2( h );
+      const int s = vvo_max( 0, isVer ? l2r : -l2r );
+      const int maxIndex = ( mrl << s ) + 2;
+      const int refLength = isVer ? topLen : leftLen;
+      const pel val = refMain[refLength + mrl];
+      for( int z = 1; z <= maxIndex; z++ ) refMain[refLength + mrl + z] = val;
+    }
+    if( !isVer ) { bw = h; bh = w; }                           /* predict the transposed block */
+    pel tmp[64 * 64];
+    pel* dst = isVer ? pred : tmp;
+    refMain += mrl; refSide += mrl;
+    if( angle == 0 )
+    {
+      if( doPDPC )
+      {
+        const int scale = ( vvo_log2( bw ) - 2 + vvo_log2( bh ) - 2 + 2 ) >> 2;
+        static const int levT[4] = { 3, 6, 12, 24 };
+        const int lev = vvo_min( levT[scale], bw );
+        const int topLeft = T[0];
+        for( int y = 0; y < bh; y++ )
+        {
+          const int lf = refSide[y + 1];
+          for( int x = 0; x < lev; x++ ) { const int wL = 32 >> vvo_min( 31, ( x << 1 ) >> scale ); dst[y * bw + x] = (pel) vvo_clip_pel( ( wL * ( lf - topLeft ) + ( refMain[x + 1] << 6 ) + 32 ) >> 6, bd ); }
+          for( int x = lev; x < bw; x++ ) dst[y * bw + x] = refMain[x + 1];
+        }
+      }
+      else
+        for( int y = 0; y < bh; y++ ) for( int x = 0; x < bw; x++ ) dst[y * bw + x] = refMain[x + 1];
+    }
+    else
+    {
+      if( absAng & 0x1F )
+      {
+        if( !comp )
+        {
+          const int diff = vvo_min( vvo_abs( predMode - 18 ), vvo_abs( predMode - 50 ) );
+          const int l2 = ( vvo_log2( bw ) + vvo_log2( bh ) ) >> 1;
+          const int filterFlag = diff > intraFilterThr[0][l2];
+          const int useCubic = !filterFlag || mrl > 0;
+          int deltaPos = angle * ( 1 + mrl );
+          for( int y = 0; y < bh; y++, deltaPos += angle )
+          {
+            const int di = deltaPos >> 5, df = deltaPos & 31;
+            for( int x = 0; x < bw; x++ )
+            {
+              const int i = di + 1 + x;
+              int v;
+              if( useCubic ) { const int16_t* f = vvc_chroma_filter[df]; v = ( f[0] * refMain[i - 1] + f[1] * refMain[i] + f[2] * refMain[i + 1] + f[3] * refMain[i + 2] + 32 ) >> 6; v = vvo_clip_pel( (pel) v, bd ); }
+              else           { const int8_t* f = gauss[df];              v = ( f[0] * refMain[i - 1] + f[1] * refMain[i] + f[2] * refMain[i + 1] + f[3] * refMain[i + 2] + 32 ) >> 6; }
+              dst[y * bw + x] = (pel) v;
+            }
+          }
+        }
+        else
+        {   /* IntraPredAngleChroma (:334): 2-tap */
+          int deltaPos = angle * ( 1 + mrl );
+          for( int y = 0; y < bh; y++, deltaPos += angle )
+          {
+            const int di = deltaPos >> 5, df = deltaPos & 31;
+            for( int x = 0; x < bw; x++ ) dst[y * bw + x] = (pel) ( ( ( 32 - df ) * refMain[x + di + 1] + df * refMain[x + di + 2] + 16 ) >> 5 );
+          }
+        }
+      }
+      else
+      {
+        int deltaPos = angle * ( 1 + mrl );
+        for( int y = 0; y < bh; y++, deltaPos += angle ) for( int x = 0; x < bw; x++ ) dst[y * bw + x] = refMain[( deltaPos >> 5 ) + 1 + x];
+      }
+      /* angular PDPC (:810-841) */
+      {
+        int angularScale = 0;
+        if( angle < 0 ) doPDPC = 0;
+        else
+        {
+          const int sideSize = predMode >= 34 ? h : w;
+          angularScale = vvo_min( 2, vvo_log2( sideSize ) - ( vvo_floor_log2( 3 * invAngle - 2 ) - 8 ) );
+          doPDPC = doPDPC && angularScale >= 0;
+        }
+        if( doPDPC )
+          for( int y = 0; y < bh; y++ )
+          {
+            int invAngleSum = 256;
+            for( int x = 0; x < vvo_min( 3 << angularScale, bw ); x++ )
+            {
+              invAngleSum += invAngle;
+              const int wL = 32 >> ( 2 * x >> angularScale );
+              const int lf = refSide[y + ( invAngleSum >> 9 ) + 1];
+              dst[y * bw + x] = (pel) ( dst[y * bw + x] + ( ( wL * ( lf - dst[y * bw + x] ) + 32 ) >> 6 ) );
+            }
+          }
+      }
+    }
+    if( !isVer ) for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) pred[y * w + x] = tmp[x * bw + y];
+    doPDPC = 0;   /* planar/DC PDPC below must not run for angular modes */
+  }
+  if( !bdpcm && doPDPC && ( dirMode == 0 || dirMode == 1 ) )
+  {   /* IntraPredSampleFilterCore (:212) — applied on the (possibly filtered) reference the prediction used */
+    const int scale = ( vvo_log2( w ) - 2 + vvo_log2( h ) - 2 + 2 ) >> 2;
+    for( int y = 0; y < h; y++ )
+    {
+      const int wT = 32 >> vvo_min( 31, ( y << 1 ) >> scale );
+      const int lf = L[y + 1];
+      for( int x = 0; x < w; x++ )
+      {
+        const int wL = 32 >> vvo_min( 31, ( x << 1 ) >> scale );
+        const int tp = T[x + 1], val = pred[y * w + x];
+        pred[y * w + x] = (pel) ( val + ( ( wL * ( lf - val ) + wT * ( tp - val ) + 32 ) >> 6 ) );
+      }
+    }
+  }
+  /* ---- reconstruction (DecCu.cpp:396-403) */
+  for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+  {
+    const int v = has_resi ? vvo_clip_pel( pred[y * w + x] + resi[y * w + x], bd ) : pred[y * w + x];
+    plane[(size_t) ( y0 + y ) * stride + x0 + x] = (pel) v;
+  }
+  return 0;
 }

@@ -58,6 +58,7 @@ typedef struct vvs_params {
   float    p_sao, p_alf_luma, p_alf_chroma, p_ccalf;
   float    p_imv_hpel;
   float    p_jccr;
+  float    p_mrl, p_bdpcm;
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -91,7 +92,7 @@ void vvs_default_params( vvs_params* P )
   P->seed = 1234; P->width = 3840; P->height = 2160; P->bit_depth = 10; P->log2_ctu = 7; P->chroma_format = 1; P->slice_type = 0;
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
-  P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f;
+  P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
 }
 
 namespace {
@@ -112,8 +113,32 @@ struct Gen {
     mv[1] = std::min( verMax, std::max( verMin, mv[1] ) );
   }
 
-  void genLevels( vvr_tu& tu, int c, int bw, int bh, bool ts )
+  void genLevels( vvr_tu& tu, int c, int bw, int bh, bool ts, bool bdpcm, bool lfnst )
   {
+    tu.coef_off[c] = (uint32_t) B.num_coef;
+    int16_t* dst = B.coef + B.num_coef;
+    if( bdpcm )
+    {   // BDPCM: the full block of (DPCM-coded) levels is transmitted (Quant.cpp:239); keep them sparse and small
+      tu.max_scan_x[c] = (uint8_t) ( bw - 1 ); tu.max_scan_y[c] = (uint8_t) ( bh - 1 );
+      for( int i = 0; i < bw * bh; i++ ) dst[i] = (int16_t) ( rng.p( 0.12 ) ? rng.laplace( 1.0 ) : 0 );
+      dst[0] = dst[0] ? dst[0] : 1;
+      B.num_coef += (uint64_t) bw * bh;
+      return;
+    }
+    if( lfnst )
+    {   // LFNST: only the first 8 (4x4 / 8x8 blocks) or 16 positions of the top-left 4x4 diagonal scan may be non-zero
+      static const uint8_t scanXY[16][2] = { {0,0},{0,1},{1,0},{0,2},{1,1},{2,0},{0,3},{1,2},{2,1},{3,0},{1,3},{2,2},{3,1},{2,3},{3,2},{3,3} };
+      const int maxNz = ( ( bw == 4 && bh == 4 ) || ( bw == 8 && bh == 8 ) ) ? 8 : 16;
+      const int nz = 1 + rng.u( maxNz );
+      int mx = 0, my = 0;
+      for( int i = 0; i < nz; i++ ) { mx = std::max<int>( mx, scanXY[i][0] ); my = std::max<int>( my, scanXY[i][1] ); }
+      tu.max_scan_x[c] = (uint8_t) mx; tu.max_scan_y[c] = (uint8_t) my;
+      const int cw = mx + 1, ch = my + 1;
+      for( int i = 0; i < cw * ch; i++ ) dst[i] = 0;
+      for( int i = 0; i < nz; i++ ) { int v = rng.laplace( 2.0 ); if( i == 0 ) v *= 3; if( i == nz - 1 && v == 0 ) v = 1; dst[scanXY[i][1] * cw + scanXY[i][0]] = (int16_t) v; }
+      B.num_coef += (uint64_t) cw * ch;
+      return;
+    }
     // corner extents
     int mx, my;
     const int capW = std::min( bw, 32 ), capH = std::min( bh, 32 );
@@ -123,9 +148,7 @@ struct Gen {
     const int mts = tu.mts_idx[c];
     if( mts > 1 ) { mx = std::min( mx, 15 ); my = std::min( my, 15 ); }   // MTS zero-out: only the 16x16 corner can be non-zero
     tu.max_scan_x[c] = (uint8_t) mx; tu.max_scan_y[c] = (uint8_t) my;
-    tu.coef_off[c] = (uint32_t) B.num_coef;
     const int cw = mx + 1, ch = my + 1;
-    int16_t* dst = B.coef + B.num_coef;
     bool any = false;
     for( int y = 0; y < ch; y++ ) for( int x = 0; x < cw; x++ )
     {
@@ -153,8 +176,14 @@ struct Gen {
       const int r = rng.u( 100 );
       cu.intra_dir[0] = r < 20 ? 0 : r < 35 ? 1 : 2 + rng.u( 65 );
       const int rc = rng.u( 100 );
-      cu.intra_dir[1] = rc < 40 ? cu.intra_dir[0] : rc < 55 ? 0 : rc < 65 ? 1 : rc < 75 ? 18 : rc < 85 ? 50 : 2 + rng.u( 65 );
+      cu.intra_dir[1] = rc < 40 ? cu.intra_dir[0] : rc < 55 ? 0 : rc < 65 ? 1 : rc < 75 ? 18 : rc < 85 ? 50 : 2 + rng.u( 65 );   // DM / planar / DC / hor / ver / any (CCLM: not generated yet)
       cu.lfnst_intra_mode = cu.intra_dir[0];
+      // multiple reference lines: luma only, never on the first row of a CTU, not with planar (intra_luma_ref_idx semantics)
+      if( ( y & ( ctu - 1 ) ) != 0 && cu.intra_dir[0] != 0 && rng.p( P.p_mrl ) ) cu.multi_ref_idx = (uint8_t) ( 1 + rng.u( 2 ) );
+      // BDPCM (implies transform skip of the luma block)
+      if( w <= 32 && h <= 32 && !cu.multi_ref_idx && rng.p( P.p_bdpcm ) ) { cu.bdpcm[0] = (uint8_t) ( 1 + rng.u( 2 ) ); cu.intra_dir[0] = cu.bdpcm[0] == 1 ? 18 : 50; cu.lfnst_intra_mode = cu.intra_dir[0]; }
+      // LFNST index (luma of single-tree CUs): needs DCT2 and a residual confined to the first 8/16 scan positions, see genLevels
+      if( ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
     }
     else
     {
@@ -198,16 +227,19 @@ struct Gen {
       for( int c = 0; c < ( P.chroma_format ? 3 : 1 ); c++ )
       {
         const int bw = c ? tw >> 1 : tw, bh = c ? th >> 1 : th;
-        if( !rng.p( c ? P.p_coded_chroma : P.p_coded ) ) continue;
+        const bool force = c == 0 && intra && ( cu.bdpcm[0] || cu.lfnst_idx );     // these modes are only signalled with a coded luma block
+        if( !force && !rng.p( c ? P.p_coded_chroma : P.p_coded ) ) continue;
         tu.cbf |= 1 << c;
         bool ts = bw <= 32 && bh <= 32 && rng.p( P.p_ts );
+        if( c == 0 && intra && cu.bdpcm[0] ) ts = true;
+        if( c == 0 && intra && cu.lfnst_idx ) ts = false;
         tu.mts_idx[c] = ts ? VVR_MTS_SKIP : VVR_MTS_DCT2;
         if( !ts && c == 0 && bw <= 32 && bh <= 32 && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
         // getTrTypes (TrQuant.cpp:330): explicit MTS -> hor = (idx-2)&1 ? DCT8 : DST7 ; ver = (idx-2)>>1 ? DCT8 : DST7
         int hor = 0, ver = 0;
         if( tu.mts_idx[c] > 1 ) { hor = ( ( tu.mts_idx[c] - 2 ) & 1 ) ? 1 : 2; ver = ( ( tu.mts_idx[c] - 2 ) >> 1 ) ? 1 : 2; }
         tu.tr_type[c] = (uint8_t) ( ( ver << 2 ) | hor );
-        genLevels( tu, c, bw, bh, ts );
+        genLevels( tu, c, bw, bh, ts, c == 0 && intra && cu.bdpcm[0], c == 0 && intra && cu.lfnst_idx );
         rootCbf = true;
       }
       for( int yy = 0; yy < th; yy += 4 ) for( int xx = 0; xx < tw; xx += 4 )

@@ -58,138 +58,204 @@ int vvr_upload_tables()
 // =====================================================================================================================
 #define IF_INTERNAL_OFFS 8192
 
-struct McShared {
-  pel_t win[23 * 24];     // reference window, row stride 24
-  pel_t tmp[23 * 16];     // horizontal-pass output
+// One (list, component) prediction segment of a tile.
+struct McSeg {
+  int x0, y0;            // top-left of the window in the reference plane (may be outside: reads are clamped)
+  int ww, wh;            // window size
+  int xFrac, yFrac;
+  int w, h;              // block size
+  int winOff, tmpOff;    // offsets (in samples) into the LDS arrays
 };
 
-// predicts one component block of one list into `out` (one sample per thread, tid < w*h); bi = keep 14-bit precision
-__device__ __forceinline__ int mc_pred_component( McShared& sh, const pel_t* __restrict__ ref, int stride, int pw, int ph,
-                                                  int bx, int by, int w, int h, int mvx, int mvy, int comp, bool bi, bool altHpel, int bd,
-                                                  int tid, int nthreads, int lane )
+#define MC_WIN_L   ( 23 * 24 )
+#define MC_WIN_C   ( 11 * 12 )
+#define MC_TMP_L   ( 23 * 16 )
+#define MC_TMP_C   ( 11 * 8 )
+
+// final sample of one segment at block position (px,py): all four (xFrac, yFrac) cases of xPredInterBlk
+__device__ __forceinline__ int mc_final( const pel_t* win, int wstride, const pel_t* tmp, int tstride, const McSeg& g, const int16_t* ch, const int16_t* cv,
+                                         int comp, bool bi, int bd, int px, int py )
 {
-  const int shf   = comp ? 5 : 4;
-  const int xFrac = mvx & ( ( 1 << shf ) - 1 ), yFrac = mvy & ( ( 1 << shf ) - 1 );
-  const int x0 = bx + ( mvx >> shf ), y0 = by + ( mvy >> shf );
-  const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
+  const int ntaps = comp ? 4 : 8;
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  const bool doH = xFrac != 0, doV = yFrac != 0;
-  const int ww = w + ( doH ? ntaps - 1 : 0 ), wh = h + ( doV ? ntaps - 1 : 0 );
-  const int wx0 = x0 - ( doH ? half : 0 ), wy0 = y0 - ( doV ? half : 0 );
-  __syncthreads();                                     // previous users of the LDS buffers are done
-  for( int i = tid; i < ww * wh; i += nthreads )
-  {
-    const int yy = i / ww, xx = i - yy * ww;
-    const int sx = clip3( 0, pw - 1, wx0 + xx ), sy = clip3( 0, ph - 1, wy0 + yy );
-    sh.win[yy * 24 + xx] = ref[(size_t) sy * stride + sx];
-  }
-  __syncthreads();
-  const int16_t* ch; const int16_t* cv;
-  if( comp ) { ch = d_chroma_filter[xFrac]; cv = d_chroma_filter[yFrac]; }
-  else
-  {
-    const bool f4 = ( w == 4 && h == 4 );
-    ch = ( xFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[xFrac] : d_luma_filter[xFrac];
-    cv = ( yFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[yFrac] : d_luma_filter[yFrac];
-  }
-  const int px = lane % w, py = lane / w;              // lane < w*h guaranteed by the caller for active threads
-  int val = 0;
+  const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
   if( !doH && !doV )
   {
-    if( lane < w * h ) { const int s = sh.win[py * 24 + px]; val = bi ? (int16_t) ( (int16_t) ( s << headroom ) - (int16_t) IF_INTERNAL_OFFS ) : s; }
-    return val;
+    const int s = win[py * wstride + px];
+    return bi ? (int16_t) ( (int16_t) ( s << headroom ) - (int16_t) IF_INTERNAL_OFFS ) : s;
   }
   if( doH != doV )
   {
     int shift, offset;
     if( !bi ) { shift = 6; offset = 32; } else { shift = 6 - headroom; offset = -IF_INTERNAL_OFFS * ( 1 << shift ); }
-    if( lane < w * h )
-    {
-      int sum = 0;
-      if( doH ) { for( int t = 0; t < ntaps; t++ ) sum += sh.win[py * 24 + px + t] * ch[t]; }
-      else      { for( int t = 0; t < ntaps; t++ ) sum += sh.win[( py + t ) * 24 + px] * cv[t]; }
-      val = (int16_t) ( ( sum + offset ) >> shift );
-      if( !bi ) val = clip_pel( val, bd );
-    }
-    return val;
+    int sum = 0;
+    if( doH ) { for( int t = 0; t < ntaps; t++ ) sum += win[py * wstride + px + t] * ch[t]; }
+    else      { for( int t = 0; t < ntaps; t++ ) sum += win[( py + t ) * wstride + px] * cv[t]; }
+    int val = (int16_t) ( ( sum + offset ) >> shift );
+    return bi ? val : clip_pel( val, bd );
   }
-  {
-    const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
-    for( int i = tid; i < w * wh; i += nthreads )
-    {
-      const int yy = i / w, xx = i - yy * w;
-      int sum = 0;
-      for( int t = 0; t < ntaps; t++ ) sum += sh.win[yy * 24 + xx + t] * ch[t];
-      sh.tmp[yy * 16 + xx] = (int16_t) ( ( sum + offset1 ) >> shift1 );
-    }
-    __syncthreads();
-    if( lane < w * h )
-    {
-      int shift2, offset2;
-      if( !bi ) { shift2 = 6 + headroom; offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 ); } else { shift2 = 6; offset2 = 0; }
-      int sum = 0;
-      for( int t = 0; t < ntaps; t++ ) sum += sh.tmp[( py + t ) * 16 + px] * cv[t];
-      val = (int16_t) ( ( sum + offset2 ) >> shift2 );
-      if( !bi ) val = clip_pel( val, bd );
-    }
-  }
-  return val;
+  int shift2, offset2;
+  if( !bi ) { shift2 = 6 + headroom; offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 ); } else { shift2 = 6; offset2 = 0; }
+  int sum = 0;
+  for( int t = 0; t < ntaps; t++ ) sum += tmp[( py + t ) * tstride + px] * cv[t];
+  int val = (int16_t) ( ( sum + offset2 ) >> shift2 );
+  return bi ? val : clip_pel( val, bd );
 }
 
-__global__ __launch_bounds__( 256 ) void k_mc( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
+// NT threads per tile.  With NT = 64 a tile is one wavefront: 32 tiles resident per CU, barriers are free, and the
+// single exposure to global-memory latency (phase A) is hidden by the other resident tiles.
+template<int NT>
+__global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
 {
-  __shared__ McShared sh;
-  const int item = blockIdx.x;
+  __shared__ pel_t winL[2][MC_WIN_L];
+  __shared__ pel_t winC[2][2][MC_WIN_C];
+  __shared__ pel_t tmpL[2][MC_TMP_L];
+  __shared__ pel_t tmpC[2][2][MC_TMP_C];
+  __shared__ McSeg seg[2][3];
+  __shared__ const pel_t* refp[2][3];
+  __shared__ int16_t coefH[2][3][8], coefV[2][3][8];
+  // XCD-aware mapping (cdna_hip_programming.md T1): consecutive workgroups are dealt round-robin to the 8 XCDs; give each XCD
+  // a contiguous run of tiles so that the halo rows shared by neighbouring tiles hit the same L2.
+  int item;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    item = ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + ( bid >> 3 );
+  }
   if( item >= numItems ) return;
   const McItem it = items[item];
   const vvr_cu& cu = pic.cu[it.cu];
   const int bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu;
   const int tid = threadIdx.x;
-  const bool altHpel = cu.imv == 3;
   const bool biPred = cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0;
   const bool uni = cu.mc_mode == VVR_MC_UNI;
-  // clipMvInPic with the CU position (InterPrediction.cpp:657: m_currCuArea)
-  int mv[2][2];
-  {
-    const int horMax = ( pic.hdr.width + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - cu.x + 1 ) * 16;
-    const int verMax = ( pic.hdr.height + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - cu.y + 1 ) * 16;
-    for( int l = 0; l < 2; l++ ) { mv[l][0] = min( horMax, max( horMin, cu.mv[l][0][0] ) ); mv[l][1] = min( verMax, max( verMin, cu.mv[l][0][1] ) ); }
-  }
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
+  const int l0 = uni ? ( ( biPred || cu.ref_idx[0] >= 0 ) ? 0 : 1 ) : 0;
+  const int nl = uni ? 1 : 2;
+  // ---- segment geometry + filter taps: computed once by six lanes, shared through LDS
+  if( tid < 6 )
+  {
+    const int k = tid / 3, c = tid - 3 * k;
+    if( k < nl && c < ncomp )
+    {
+      const int l = uni ? l0 : k;
+      // clipMvInPic with the CU position (Mv.cpp:64; InterPrediction.cpp:657 uses m_currCuArea)
+      const int horMax = ( pic.hdr.width + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - cu.x + 1 ) * 16;
+      const int verMax = ( pic.hdr.height + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - cu.y + 1 ) * 16;
+      const int mvx = min( horMax, max( horMin, cu.mv[l][0][0] ) ), mvy = min( verMax, max( verMin, cu.mv[l][0][1] ) );
+      McSeg g;
+      const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
+      g.w = it.w >> cs; g.h = it.h >> cs;
+      g.xFrac = mvx & ( ( 1 << shf ) - 1 ); g.yFrac = mvy & ( ( 1 << shf ) - 1 );
+      const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
+      g.ww = g.w + ( doH ? ntaps - 1 : 0 ); g.wh = g.h + ( doV ? ntaps - 1 : 0 );
+      g.x0 = ( it.x >> cs ) + ( mvx >> shf ) - ( doH ? half : 0 );
+      g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - ( doV ? half : 0 );
+      g.winOff = 0; g.tmpOff = 0;
+      seg[k][c] = g;
+      refp[k][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
+      // InterpolationFilter.cpp:1078-1085 / 669-676 (luma 4x4 blocks use the 6-tap table), :105 (alternative half-pel filter)
+      const bool altHpel = cu.imv == 3, f4 = g.w == 4 && g.h == 4;
+      const int16_t* ch = c ? d_chroma_filter[g.xFrac] : ( g.xFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[g.xFrac] : d_luma_filter[g.xFrac];
+      const int16_t* cv = c ? d_chroma_filter[g.yFrac] : ( g.yFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[g.yFrac] : d_luma_filter[g.yFrac];
+      for( int t = 0; t < ntaps; t++ ) { coefH[k][c][t] = ch[t]; coefV[k][c][t] = cv[t]; }
+    }
+  }
+  __syncthreads();
+  // ---- phase A: all reference windows of the tile into LDS, one exposure to HBM/L2 latency.
+  // lanes map to (row, column) with 32 columns per row group: no integer division, rows are contiguous 2-byte runs
+  {
+    const int col = tid & 31, row0 = tid >> 5;
+    for( int k = 0; k < nl; k++ )
+    {
+      for( int c = 0; c < ncomp; c++ )
+      {
+        const McSeg g = seg[k][c];
+        pel_t* win = c ? winC[k][c - 1] : winL[k];
+        const int wst = c ? 12 : 24;
+        const pel_t* __restrict__ ref = refp[k][c];
+        const int stride = reco.stride[c], pw = reco.w[c], ph = reco.h[c];
+        if( col < g.ww )
+        {
+          const int sx = clip3( 0, pw - 1, g.x0 + col );
+          for( int yy = row0; yy < g.wh; yy += NT / 32 )
+          {
+            const int sy = clip3( 0, ph - 1, g.y0 + yy );
+            win[yy * wst + col] = ref[(size_t) sy * stride + sx];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase B: horizontal pass of the 2-D segments (16-bit intermediates, InterpolationFilter.cpp:902-915)
+  {
+    const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+    const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+    const int col = tid & 15, row0 = tid >> 4;
+    for( int k = 0; k < nl; k++ )
+    {
+      for( int c = 0; c < ncomp; c++ )
+      {
+        const McSeg g = seg[k][c];
+        if( !( g.xFrac && g.yFrac ) || col >= g.w ) continue;
+        const pel_t* win = c ? winC[k][c - 1] : winL[k];
+        pel_t* tmp = c ? tmpC[k][c - 1] : tmpL[k];
+        const int wst = c ? 12 : 24, tst = c ? 8 : 16, ntaps = c ? 4 : 8;
+        int cf[8];
+        for( int t = 0; t < 8; t++ ) cf[t] = coefH[k][c][t];
+        for( int yy = row0; yy < g.wh; yy += NT / 16 )
+        {
+          int sum = 0;
+          for( int t = 0; t < ntaps; t++ ) sum += win[yy * wst + col + t] * cf[t];
+          tmp[yy * tst + col] = (int16_t) ( ( sum + offset1 ) >> shift1 );
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase C: final samples
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   for( int c = 0; c < ncomp; c++ )
   {
     const int cs = c ? 1 : 0;
-    const int bx = it.x >> cs, by = it.y >> cs, w = it.w >> cs, h = it.h >> cs;
-    const int lane = tid;
-    int out;
-    if( uni )
+    const int w = it.w >> cs, h = it.h >> cs;
+    const pel_t* win0 = c ? winC[0][c - 1] : winL[0]; const pel_t* tmp0 = c ? tmpC[0][c - 1] : tmpL[0];
+    const pel_t* win1 = c ? winC[1][c - 1] : winL[1]; const pel_t* tmp1 = c ? tmpC[1][c - 1] : tmpL[1];
+    const int wst = c ? 12 : 24, tst = c ? 8 : 16;
+    const int lw = w == 16 ? 4 : w == 8 ? 3 : w == 4 ? 2 : 1;       // log2 of the tile width
+    for( int i = tid; i < w * h; i += NT )
     {
-      const int l = ( biPred || cu.ref_idx[0] >= 0 ) ? 0 : 1;
-      out = mc_pred_component( sh, refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c], reco.stride[c], reco.w[c], reco.h[c], bx, by, w, h, mv[l][0], mv[l][1], c, false, altHpel, bd, tid, 256, lane );
-    }
-    else
-    {
-      const int p0 = mc_pred_component( sh, refs.p[cu.ref_idx[0]][c], reco.stride[c], reco.w[c], reco.h[c], bx, by, w, h, mv[0][0], mv[0][1], c, true, altHpel, bd, tid, 256, lane );
-      const int p1 = mc_pred_component( sh, refs.p[VVR_MAX_REFS + cu.ref_idx[1]][c], reco.stride[c], reco.w[c], reco.h[c], bx, by, w, h, mv[1][0], mv[1][1], c, true, altHpel, bd, tid, 256, lane );
-      const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-      if( cu.bcw_idx != 2 )
-      {
-        const int w1 = d_bcw_weights[cu.bcw_idx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
-        out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
-      }
+      const int px = i & ( w - 1 ), py = i >> lw;
+      int out;
+      if( uni ) out = mc_final( win0, wst, tmp0, tst, seg[0][c], coefH[0][c], coefV[0][c], c, false, bd, px, py );
       else
       {
-        const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
-        out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
+        const int p0 = mc_final( win0, wst, tmp0, tst, seg[0][c], coefH[0][c], coefV[0][c], c, true, bd, px, py );
+        const int p1 = mc_final( win1, wst, tmp1, tst, seg[1][c], coefH[1][c], coefV[1][c], c, true, bd, px, py );
+        if( cu.bcw_idx != 2 )
+        {
+          const int w1 = d_bcw_weights[cu.bcw_idx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+          out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
+        }
+        else
+        {
+          const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+          out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
+        }
       }
+      reco.p[c][(size_t) ( ( it.y >> cs ) + py ) * reco.stride[c] + ( it.x >> cs ) + px] = (pel_t) out;
     }
-    if( lane < w * h ) reco.p[c][(size_t) ( by + lane / w ) * reco.stride[c] + bx + lane % w] = (pel_t) out;
   }
 }
 
+static int g_mcThreads = 0;
 void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
 {
-  if( numItems ) hipLaunchKernelGGL( k_mc, dim3( numItems ), dim3( 256 ), 0, s, pic, refs, reco, items, numItems );
+  if( !numItems ) return;
+  if( !g_mcThreads ) { const char* e = getenv( "VVR_MC_THREADS" ); g_mcThreads = e ? atoi( e ) : 64; }
+  if( g_mcThreads == 256 )      hipLaunchKernelGGL( k_mc<256>, dim3( numItems ), dim3( 256 ), 0, s, pic, refs, reco, items, numItems );
+  else if( g_mcThreads == 128 ) hipLaunchKernelGGL( k_mc<128>, dim3( numItems ), dim3( 128 ), 0, s, pic, refs, reco, items, numItems );
+  else                          hipLaunchKernelGGL( k_mc<64>,  dim3( numItems ), dim3( 64 ),  0, s, pic, refs, reco, items, numItems );
 }
 
 // =====================================================================================================================
@@ -221,6 +287,7 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
 {
   __shared__ int32_t dq[MAXN * MAXN];
   __shared__ int32_t tmp[MAXN * MAXN];
+  __shared__ int16_t mvS[MAXN * MAXN], mhS[MAXN * MAXN];
   __shared__ int32_t lf_in[16], lf_out[48];
   const int item = blockIdx.x;
   if( item >= numItems ) return;
@@ -340,53 +407,55 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
     maxY = max( maxY, min( bh - 1, 7 ) );
     __syncthreads();
   }
-  // ---- inverse transform into tmp[] as final residual (row-major bw x bh)
+  // ---- inverse transform; every thread produces the final residual of its samples and emits it right away
   const int trHor = tu.tr_type[comp] & 3, trVer = tu.tr_type[comp] >> 2;
   const int shift1 = 7, shift2 = 20 - bd;
-  if( isTS )
+  const bool dcOnly = !isTS && maxX == 0 && maxY == 0 && trHor == 0 && trVer == 0;
+  int redW = 0;
+  int dcVal = 0;
+  if( dcOnly )
   {
-    for( int i = tid; i < n; i += 256 ) tmp[i] = (int16_t) dq[i];
+    dcVal = ( dq[0] * 64 + ( 1 << ( shift1 - 1 ) ) ) >> shift1;
+    dcVal = (int16_t) ( ( dcVal * 64 + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
   }
-  else if( maxX == 0 && maxY == 0 && trHor == 0 && trVer == 0 )
-  {
-    int dc = ( dq[0] * 64 + ( 1 << ( shift1 - 1 ) ) ) >> shift1;
-    dc = ( dc * 64 + ( 1 << ( shift2 - 1 ) ) ) >> shift2;
-    for( int i = tid; i < n; i += 256 ) tmp[i] = (int16_t) dc;
-  }
-  else
+  else if( !isTS )
   {
     const int skipW = max( ( trHor != 0 && bw == 32 ) ? 16 : bw > 32 ? bw - 32 : 0, bw - maxX - 1 );
     const int skipH = max( ( trVer != 0 && bh == 32 ) ? 16 : bh > 32 ? bh - 32 : 0, bh - maxY - 1 );
-    const int redW = bw - skipW, cutH = bh - skipH;
+    const int cutH = bh - skipH;
+    redW = bw - skipW;
+    // the basis rows both passes touch, staged in LDS (the tables themselves stay L2-resident)
     const int16_t* __restrict__ Mv = tr_matrix( trVer, bh );
     const int16_t* __restrict__ Mh = tr_matrix( trHor, bw );
+    for( int i = tid; i < cutH * bh; i += 256 ) mvS[i] = Mv[i];
+    for( int i = tid; i < redW * bw; i += 256 ) mhS[i] = Mh[i];
+    __syncthreads();
     // pass 1 (vertical): tmp[x*bh + y] = clip16( ( sum_k dq[k*bw + x] * Mv[k*bh + y] + 64 ) >> 7 ), x < redW
     for( int i = tid; i < redW * bh; i += 256 )
     {
       const int x = i / bh, y = i - x * bh;
       int sum = 0;
-      for( int k = 0; k < cutH; k++ ) sum += dq[k * bw + x] * Mv[k * bh + y];
+      for( int k = 0; k < cutH; k++ ) sum += dq[k * bw + x] * mvS[k * bh + y];
       tmp[x * bh + y] = clip3( -32768, 32767, ( sum + ( 1 << ( shift1 - 1 ) ) ) >> shift1 );
     }
     __syncthreads();
-    // pass 2 (horizontal): out[y*bw + x] = clip16( ( sum_{k<redW} tmp[k*bh + y] * Mh[k*bw + x] + rnd ) >> shift2 )
-    for( int i = tid; i < n; i += 256 )
-    {
-      const int y = i / bw, x = i - y * bw;
-      int sum = 0;
-      for( int k = 0; k < redW; k++ ) sum += tmp[k * bh + y] * Mh[k * bw + x];
-      dq[i] = clip3( -32768, 32767, ( sum + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
-    }
-    __syncthreads();
-    for( int i = tid; i < n; i += 256 ) tmp[i] = dq[i];
   }
-  __syncthreads();
-  // ---- output
+  // ---- pass 2 (horizontal) + output
   const int ict = it.ict ? (int) it.ict - 4 : 0;
   for( int i = tid; i < n; i += 256 )
   {
     const int y = i / bw, x = i - y * bw;
-    int r = tmp[i], rOther = 0, cOther = 0;
+    int r;
+    if( isTS ) r = (int16_t) dq[i];
+    else if( dcOnly ) r = dcVal;
+    else
+    {
+      // out[y*bw + x] = clip16( ( sum_{k<redW} tmp[k*bh + y] * Mh[k*bw + x] + rnd ) >> shift2 )
+      int sum = 0;
+      for( int k = 0; k < redW; k++ ) sum += tmp[k * bh + y] * mhS[k * bw + x];
+      r = clip3( -32768, 32767, ( sum + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
+    }
+    int rOther = 0, cOther = 0;
     int cSelf = comp;
     if( ict )
     {
@@ -725,6 +794,7 @@ __constant__ int8_t c_alf_perm[4][12] = {
 __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, DevPlanes dst )
 {
   __shared__ pel_t tile[( ALF_T + 2 * ALF_HALO ) * ALF_LW];
+  __shared__ int16_t fCoef[25 * 12], fClip[25 * 12];      // the CTU's filter set: per class, un-transposed
   __shared__ uint8_t cls[64], trp[64];
   const int tx0 = blockIdx.x * ALF_T, ty0 = blockIdx.y * ALF_T;
   const int W = src.w[0], H = src.h[0], st = src.stride[0];
@@ -748,19 +818,27 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
     const int sx = clip3( 0, W - 1, tx0 - ALF_HALO + xx ), sy = clip3( 0, H - 1, ty0 - ALF_HALO + yy );
     tile[yy * ALF_LW + xx] = S[(size_t) sy * st + sx];
   }
+  {
+    const vvr_alf_params* __restrict__ A = pic.alf_params;
+    const int clipDef = 1 << bd;      // m_alfClippVls[bd-8][0] = 256 << (bd - 8)
+    for( int i = tid; i < 25 * 12; i += 256 )
+    {
+      const int cl = i / 12, k = i - cl * 12;
+      if( f.luma_filter_idx < 16 ) { fCoef[i] = d_alf_fixed_coeff[d_alf_class_to_filter[f.luma_filter_idx][cl]][k]; fClip[i] = (int16_t) clipDef; }
+      else { fCoef[i] = A->luma_coeff[f.luma_filter_idx - 16][cl][k]; fClip[i] = A->luma_clip[f.luma_filter_idx - 16][cl][k]; }
+    }
+  }
   __syncthreads();
 #define T( x, y ) tile[( ( y ) + ALF_HALO ) * ALF_LW + ( x ) + ALF_HALO]      // tile-relative sample
   const int vbPos = ctu - 4;
-  if( tid < 64 )
   {
-    // ---- classification of the 4x4 block (bx,by) (tile-relative)
-    const int bx = ( tid & 7 ) * 4, by = ( tid >> 3 ) * 4;
+    // ---- classification: 4 lanes per 4x4 block, one Laplacian cell-row each, reduced with lane shuffles
+    const int blk = tid >> 2, i = ( tid & 3 ) * 2;
+    const int bx = ( blk & 7 ) * 4, by = ( blk >> 3 ) * 4;
     const int yInCtu = ( ty0 + by ) & ( ctu - 1 );
     int sumV = 0, sumH = 0, sumD0 = 0, sumD1 = 0;
-    for( int i = 0; i < 8; i += 2 )
+    if( !( ( yInCtu == vbPos - 4 && i == 6 ) || ( yInCtu == vbPos && i == 0 ) ) )
     {
-      if( yInCtu == vbPos - 4 && i == 6 ) continue;
-      if( yInCtu == vbPos && i == 0 ) continue;
       const int r = by - 2 + i, rel = yInCtu - 2 + i;
       int rm1 = r - 1, rp2 = r + 2;
       if( rel > 0 && ( rel % ctu ) == vbPos - 2 ) rp2 = r + 1;
@@ -775,70 +853,74 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
         sumD1 += iabs( y0 - T( cX - 1, r + 1 ) - T( cX + 1, rm1 ) ) + iabs( yup1 - T( cX, rp2 ) - T( cX + 2, r ) );
       }
     }
-    const int th[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
-    const int act = clip3( 0, 15, ( ( sumV + sumH ) * ( ( yInCtu == vbPos - 4 || yInCtu == vbPos ) ? 96 : 64 ) ) >> ( bd + 4 ) );
-    int cl = th[act];
-    int hv1, hv0, d1, d0, dirHV, dirD, hvd1, hvd0, mainDir, secDir;
-    if( sumV > sumH ) { hv1 = sumV; hv0 = sumH; dirHV = 1; } else { hv1 = sumH; hv0 = sumV; dirHV = 3; }
-    if( sumD0 > sumD1 ) { d1 = sumD0; d0 = sumD1; dirD = 0; } else { d1 = sumD1; d0 = sumD0; dirD = 2; }
-    if( (uint32_t) d1 * (uint32_t) hv0 > (uint32_t) hv1 * (uint32_t) d0 ) { hvd1 = d1; hvd0 = d0; mainDir = dirD; secDir = dirHV; }
-    else { hvd1 = hv1; hvd0 = hv0; mainDir = dirHV; secDir = dirD; }
-    int strength = 0;
-    if( hvd1 > 2 * hvd0 ) strength = 1;
-    if( hvd1 * 2 > 9 * hvd0 ) strength = 2;
-    if( strength ) cl += ( ( ( mainDir & 1 ) << 1 ) + strength ) * 5;
-    const int tt[8] = { 0, 1, 0, 2, 2, 3, 1, 3 };
-    cls[tid] = (uint8_t) cl; trp[tid] = (uint8_t) tt[mainDir * 2 + ( secDir >> 1 )];
+    sumV  += __shfl_xor( sumV, 1 );  sumV  += __shfl_xor( sumV, 2 );
+    sumH  += __shfl_xor( sumH, 1 );  sumH  += __shfl_xor( sumH, 2 );
+    sumD0 += __shfl_xor( sumD0, 1 ); sumD0 += __shfl_xor( sumD0, 2 );
+    sumD1 += __shfl_xor( sumD1, 1 ); sumD1 += __shfl_xor( sumD1, 2 );
+    if( ( tid & 3 ) == 0 )
+    {
+      const int th[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
+      const int act = clip3( 0, 15, ( ( sumV + sumH ) * ( ( yInCtu == vbPos - 4 || yInCtu == vbPos ) ? 96 : 64 ) ) >> ( bd + 4 ) );
+      int cl = th[act];
+      int hv1, hv0, d1, d0, dirHV, dirD, hvd1, hvd0, mainDir, secDir;
+      if( sumV > sumH ) { hv1 = sumV; hv0 = sumH; dirHV = 1; } else { hv1 = sumH; hv0 = sumV; dirHV = 3; }
+      if( sumD0 > sumD1 ) { d1 = sumD0; d0 = sumD1; dirD = 0; } else { d1 = sumD1; d0 = sumD0; dirD = 2; }
+      if( (uint32_t) d1 * (uint32_t) hv0 > (uint32_t) hv1 * (uint32_t) d0 ) { hvd1 = d1; hvd0 = d0; mainDir = dirD; secDir = dirHV; }
+      else { hvd1 = hv1; hvd0 = hv0; mainDir = dirHV; secDir = dirD; }
+      int strength = 0;
+      if( hvd1 > 2 * hvd0 ) strength = 1;
+      if( hvd1 * 2 > 9 * hvd0 ) strength = 2;
+      if( strength ) cl += ( ( ( mainDir & 1 ) << 1 ) + strength ) * 5;
+      const int tt[8] = { 0, 1, 0, 2, 2, 3, 1, 3 };
+      cls[blk] = (uint8_t) cl; trp[blk] = (uint8_t) tt[mainDir * 2 + ( secDir >> 1 )];
+    }
   }
   __syncthreads();
-  // ---- filtering: thread -> (row, 4 consecutive columns)
-  const vvr_alf_params* __restrict__ A = pic.alf_params;
-  const int clipDef = 1 << ( bd );      // m_alfClippVls[bd-8][0] = 256 << (bd - 8)
-  for( int q = tid; q < ALF_T * ALF_T / 4; q += 256 )
+  // ---- filtering: thread -> (row, 4 consecutive columns) = one row of one 4x4 block
   {
-    const int y = q / ( ALF_T / 4 ), x4 = ( q % ( ALF_T / 4 ) ) * 4;
+    const int y = tid >> 3, x4 = ( tid & 7 ) * 4;
     const int gy = ty0 + y;
-    if( gy >= H || tx0 + x4 >= W ) continue;
-    const int b = ( y >> 2 ) * 8 + ( x4 >> 2 );
-    const int cl = cls[b], tr = trp[b];
-    int cf[12], cp[12];
-    for( int k = 0; k < 12; k++ )
+    if( gy < H && tx0 + x4 < W )
     {
-      const int sk = c_alf_perm[tr][k];
-      if( f.luma_filter_idx < 16 ) { cf[k] = d_alf_fixed_coeff[d_alf_class_to_filter[f.luma_filter_idx][cl]][sk]; cp[k] = clipDef; }
-      else { cf[k] = A->luma_coeff[f.luma_filter_idx - 16][cl][sk]; cp[k] = A->luma_clip[f.luma_filter_idx - 16][cl][sk]; }
-    }
-    const int yVb = gy & ( ctu - 1 );
-    int r1 = y + 1, r2 = y - 1, r3 = y + 2, r4 = y - 2, r5 = y + 3, r6 = y - 3;
-    if( yVb < vbPos && yVb >= vbPos - 4 )
-    {
-      r1 = ( yVb == vbPos - 1 ) ? y : r1;  r3 = ( yVb >= vbPos - 2 ) ? r1 : r3;  r5 = ( yVb >= vbPos - 3 ) ? r3 : r5;
-      r2 = ( yVb == vbPos - 1 ) ? y : r2;  r4 = ( yVb >= vbPos - 2 ) ? r2 : r4;  r6 = ( yVb >= vbPos - 3 ) ? r4 : r6;
-    }
-    else if( yVb >= vbPos && yVb <= vbPos + 3 )
-    {
-      r2 = ( yVb == vbPos ) ? y : r2;  r4 = ( yVb <= vbPos + 1 ) ? r2 : r4;  r6 = ( yVb <= vbPos + 2 ) ? r4 : r6;
-      r1 = ( yVb == vbPos ) ? y : r1;  r3 = ( yVb <= vbPos + 1 ) ? r1 : r3;  r5 = ( yVb <= vbPos + 2 ) ? r3 : r5;
-    }
-    const bool nearVb = ( yVb == vbPos - 1 ) || ( yVb == vbPos );
-    for( int xx = x4; xx < x4 + 4 && tx0 + xx < W; xx++ )
-    {
-      const int cur = T( xx, y );
-      int sum = 0;
-      sum += cf[0]  * clip_alf( cp[0],  cur, T( xx, r5 ),     T( xx, r6 ) );
-      sum += cf[1]  * clip_alf( cp[1],  cur, T( xx + 1, r3 ), T( xx - 1, r4 ) );
-      sum += cf[2]  * clip_alf( cp[2],  cur, T( xx, r3 ),     T( xx, r4 ) );
-      sum += cf[3]  * clip_alf( cp[3],  cur, T( xx - 1, r3 ), T( xx + 1, r4 ) );
-      sum += cf[4]  * clip_alf( cp[4],  cur, T( xx + 2, r1 ), T( xx - 2, r2 ) );
-      sum += cf[5]  * clip_alf( cp[5],  cur, T( xx + 1, r1 ), T( xx - 1, r2 ) );
-      sum += cf[6]  * clip_alf( cp[6],  cur, T( xx, r1 ),     T( xx, r2 ) );
-      sum += cf[7]  * clip_alf( cp[7],  cur, T( xx - 1, r1 ), T( xx + 1, r2 ) );
-      sum += cf[8]  * clip_alf( cp[8],  cur, T( xx - 2, r1 ), T( xx + 2, r2 ) );
-      sum += cf[9]  * clip_alf( cp[9],  cur, T( xx + 3, y ),  T( xx - 3, y ) );
-      sum += cf[10] * clip_alf( cp[10], cur, T( xx + 2, y ),  T( xx - 2, y ) );
-      sum += cf[11] * clip_alf( cp[11], cur, T( xx + 1, y ),  T( xx - 1, y ) );
-      sum = nearVb ? ( sum + 512 ) >> 10 : ( sum + 64 ) >> 7;
-      dst.p[0][(size_t) gy * dst.stride[0] + tx0 + xx] = (pel_t) clip_pel( sum + cur, bd );
+      const int b = ( y >> 2 ) * 8 + ( x4 >> 2 );
+      const int cl = cls[b], tr = trp[b];
+      int cf[12], cp[12];
+#pragma unroll
+      for( int k = 0; k < 12; k++ ) { const int sk = c_alf_perm[tr][k]; cf[k] = fCoef[cl * 12 + sk]; cp[k] = fClip[cl * 12 + sk]; }
+      const int yVb = gy & ( ctu - 1 );
+      int r1 = y + 1, r2 = y - 1, r3 = y + 2, r4 = y - 2, r5 = y + 3, r6 = y - 3;
+      if( yVb < vbPos && yVb >= vbPos - 4 )
+      {
+        r1 = ( yVb == vbPos - 1 ) ? y : r1;  r3 = ( yVb >= vbPos - 2 ) ? r1 : r3;  r5 = ( yVb >= vbPos - 3 ) ? r3 : r5;
+        r2 = ( yVb == vbPos - 1 ) ? y : r2;  r4 = ( yVb >= vbPos - 2 ) ? r2 : r4;  r6 = ( yVb >= vbPos - 3 ) ? r4 : r6;
+      }
+      else if( yVb >= vbPos && yVb <= vbPos + 3 )
+      {
+        r2 = ( yVb == vbPos ) ? y : r2;  r4 = ( yVb <= vbPos + 1 ) ? r2 : r4;  r6 = ( yVb <= vbPos + 2 ) ? r4 : r6;
+        r1 = ( yVb == vbPos ) ? y : r1;  r3 = ( yVb <= vbPos + 1 ) ? r1 : r3;  r5 = ( yVb <= vbPos + 2 ) ? r3 : r5;
+      }
+      const bool nearVb = ( yVb == vbPos - 1 ) || ( yVb == vbPos );
+#pragma unroll
+      for( int xx = x4; xx < x4 + 4; xx++ )
+      {
+        if( tx0 + xx >= W ) break;
+        const int cur = T( xx, y );
+        int sum = 0;
+        sum += cf[0]  * clip_alf( cp[0],  cur, T( xx, r5 ),     T( xx, r6 ) );
+        sum += cf[1]  * clip_alf( cp[1],  cur, T( xx + 1, r3 ), T( xx - 1, r4 ) );
+        sum += cf[2]  * clip_alf( cp[2],  cur, T( xx, r3 ),     T( xx, r4 ) );
+        sum += cf[3]  * clip_alf( cp[3],  cur, T( xx - 1, r3 ), T( xx + 1, r4 ) );
+        sum += cf[4]  * clip_alf( cp[4],  cur, T( xx + 2, r1 ), T( xx - 2, r2 ) );
+        sum += cf[5]  * clip_alf( cp[5],  cur, T( xx + 1, r1 ), T( xx - 1, r2 ) );
+        sum += cf[6]  * clip_alf( cp[6],  cur, T( xx, r1 ),     T( xx, r2 ) );
+        sum += cf[7]  * clip_alf( cp[7],  cur, T( xx - 1, r1 ), T( xx + 1, r2 ) );
+        sum += cf[8]  * clip_alf( cp[8],  cur, T( xx - 2, r1 ), T( xx + 2, r2 ) );
+        sum += cf[9]  * clip_alf( cp[9],  cur, T( xx + 3, y ),  T( xx - 3, y ) );
+        sum += cf[10] * clip_alf( cp[10], cur, T( xx + 2, y ),  T( xx - 2, y ) );
+        sum += cf[11] * clip_alf( cp[11], cur, T( xx + 1, y ),  T( xx - 1, y ) );
+        sum = nearVb ? ( sum + 512 ) >> 10 : ( sum + 64 ) >> 7;
+        dst.p[0][(size_t) gy * dst.stride[0] + tx0 + xx] = (pel_t) clip_pel( sum + cur, bd );
+      }
     }
   }
 #undef T
