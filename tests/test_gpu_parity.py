@@ -14,21 +14,27 @@ pytestmark = pytest.mark.gpu
 TOOLS = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS
 
 
-def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=True, **kw):
+def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=True, intra=False, **kw):
+    """intra=False: POC 0 is an uploaded picture and all CUs are inter; intra=True: POC 0 is an I picture reconstructed by the
+    back-end and the B pictures contain intra CUs (p_intra)."""
     import vvdec_amd
-    plans, nslots = stream.ra_plan(frames, gop=gop)
+    plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=not intra)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=streams, log2_ctu=log2_ctu)
     seed_pic = synth.natural_picture(W, H, seed)
-    rec.write_picture(0, seed_pic)
-    cpu = {0: seed_pic}
+    cpu = {}
+    if not intra:
+        rec.write_picture(0, seed_pic)
+        cpu = {0: seed_pic}
+        kw.setdefault("p_intra", 0.0)
     hashes = []
-    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, p_intra=0.0, log2_ctu=log2_ctu, **kw) for pl in plans]
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=log2_ctu, **kw) for pl in plans]
     jobs = [rec.decompress_picture(d) for d in descs]          # everything in flight: the back-end orders the dependencies
     rec.sync()
     # verify in decode order; the CPU oracle consumes its own previous outputs as references.  A slot is overwritten
     # later in the stream, so pictures are read back in a second, serial pass.
     rec2 = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, log2_ctu=log2_ctu)
-    rec2.write_picture(0, seed_pic)
+    if not intra:
+        rec2.write_picture(0, seed_pic)
     for pl, d in zip(plans, descs):
         rec2.wait(rec2.decompress_picture(d))
         got = rec2.read_picture(pl.slot)
@@ -83,6 +89,26 @@ def test_4k_determinism_and_oracle(built):
     h1 = _run_stream(3840, 2160, 3, 2, 41, TOOLS, streams=4, check=True)
     h2 = _run_stream(3840, 2160, 3, 2, 41, TOOLS, streams=1, check=False)
     assert h1 == h2
+
+
+TOOLS_I = TOOLS | abi.TOOL_LFNST
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_intra_stream_bit_exact(built, seed):
+    """I picture + B pictures with intra CUs: planar/DC/angular (+wide angle), PDPC, MRL, reference smoothing, BDPCM, LFNST."""
+    _run_stream(256, 128, 9, 4, seed, TOOLS_I, intra=True)
+
+
+def test_intra_heavy(built):
+    _run_stream(416, 240, 5, 4, 61, TOOLS_I, intra=True, p_intra=0.5, p_coded=0.7, p_coded_chroma=0.6, p_small_corner=0.3, p_lfnst=0.6, p_mrl=0.4, p_bdpcm=0.1)
+    _run_stream(128, 128, 3, 2, 62, TOOLS_I, intra=True, p_intra=1.0, p_coded=0.9, p_coded_chroma=0.9, p_lfnst=0.7, p_split_scale=1.5)
+    _run_stream(256, 192, 3, 2, 63, TOOLS_I, intra=True, log2_ctu=6)
+    _run_stream(128, 96, 3, 2, 64, TOOLS_I, intra=True, log2_ctu=5)
+
+
+def test_1080p_intra_stream(built):
+    _run_stream(1920, 1080, 3, 2, 71, TOOLS_I, intra=True, streams=3)
 
 
 def test_unsupported_tools_fail_loudly(built):

@@ -25,8 +25,8 @@ struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 
 struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
 
-enum { K_MC, K_ITRANS, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_NUM };
-const char* const kKernelNames[K_NUM] = { "k_mc", "k_itrans", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy" };
+enum { K_MC, K_ITRANS, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_NUM };
+const char* const kKernelNames[K_NUM] = { "k_mc", "k_itrans", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy" };
 
 struct DevBuf {
   void* p = nullptr; size_t n = 0;
@@ -39,7 +39,9 @@ struct vvr_prepared {        // a picture description resident in HBM together w
   PicDev   pic;
   DevBuf   blob;             // one allocation holding every array
   McItem*  mcItems = nullptr; int numMc = 0;
-  TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64
+  TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64 (TB_ADD: after MC)
+  TbItem*  tbStore[3] = { nullptr, nullptr, nullptr }; int numTbStore[3] = { 0, 0, 0 };   // residuals of intra blocks (TB_STORE)
+  IntraItem* intraItems = nullptr; uint32_t* ctuStart = nullptr; uint32_t* active = nullptr; int numActive = 0, numIntra = 0;
   double   bytes[K_NUM] = { 0 };
   bool     owned = false;
 };
@@ -54,6 +56,7 @@ struct vvr_context {
   std::vector<DevPlanes>   scratchR;    // per stream: residual planes (intra)
   void*      planeMem = nullptr; bool planeMemOwned = false;
   void*      scratchMem = nullptr;
+  std::vector<int*> syncBuf;            // per stream: ticket + per-(component, CTU) flags of the intra wavefront
   size_t     planeBytes[3] = { 0, 0, 0 }, slotBytes = 0;
   int        stride[3] = { 0, 0, 0 };
   // jobs
@@ -134,6 +137,11 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
     c->scratchB.push_back( carve( (char*) c->scratchMem + c->slotBytes * ( 2 * s ), cfg, c->stride, c->planeBytes ) );
     c->scratchR.push_back( carve( (char*) c->scratchMem + c->slotBytes * ( 2 * s + 1 ), cfg, c->stride, c->planeBytes ) );
   }
+  {
+    const int ctu = 1 << cfg->log2_ctu;
+    const size_t numCtu = (size_t) ( ( cfg->max_width + ctu - 1 ) / ctu ) * ( ( cfg->max_height + ctu - 1 ) / ctu );
+    for( int s = 0; s < ns; s++ ) { int* p = nullptr; if( hipMalloc( (void**) &p, sizeof( int ) * ( 1 + 3 * numCtu ) ) != hipSuccess ) { delete c; return VVR_ERR_DEVICE; } c->syncBuf.push_back( p ); }
+  }
   c->slotUsers.resize( cfg->num_slots );
   *out = c;
   return VVR_OK;
@@ -150,6 +158,7 @@ VVR_API void vvr_destroy( vvr_context* c )
   for( auto s : c->streams ) hipStreamDestroy( s );
   if( c->planeMemOwned && c->planeMem ) hipFree( c->planeMem );
   if( c->scratchMem ) hipFree( c->scratchMem );
+  for( auto p : c->syncBuf ) hipFree( p );
   delete c;
 }
 
@@ -222,7 +231,14 @@ static int validate( vvr_context* c, const vvr_picture* p )
       if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
       if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) { c->setError( "inter CU must be single tree" ); return VVR_ERR_PARAMETER; }
     }
-    else { c->setError( "intra / IBC CUs are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+    else if( cu.pred_mode == VVR_PRED_INTRA )
+    {
+      if( cu.isp_mode || ( cu.flags & VVR_CU_MIP ) || ( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] >= 67 ) ) { c->setError( "ISP / MIP / CCLM are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.w > 64 || cu.h > 64 || cu.w < 8 || cu.h < 8 ) { c->setError( "intra CU size outside 8..64 is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.tree != VVR_TREE_JOINT ) { c->setError( "dual-tree intra is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.intra_dir[0] > 66 || cu.multi_ref_idx > 2 || cu.bdpcm[1] ) { c->setError( "bad intra mode / chroma BDPCM not implemented" ); return VVR_ERR_UNSUPPORTED; }
+    }
+    else { c->setError( "IBC CUs are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
   }
   return VVR_OK;
 }
@@ -249,11 +265,73 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
 
   // ---- host glue: work lists (what DecCu::TaskTrafoCtu / TaskInterCtu iterate over, DecCu.cpp:106-134)
   std::vector<McItem> mc;
-  std::vector<TbItem> tb[3];
+  std::vector<TbItem> tb[3], tbS[3];
+  std::vector<IntraItem> intra[3];
+  std::vector<uint32_t> ctuStartV( 3 * (size_t) ( numCtu + 1 ), 0 );
   double bytes[K_NUM] = { 0 };
+  // decode-order index of the transform block covering every 4x4 luma unit (both channel types): reference availability
+  // = "inside the picture and reconstructed before me" (CodingStructure::getCURestricted, CodingStructure.cpp:464, and the
+  // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
+  std::vector<int32_t> order;
+  bool anyIntra = false;
+  for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA;
+  if( anyIntra )
+  {
+    order.assign( (size_t) w4 * h4 * 2, 0x7fffffff );
+    for( uint32_t i = 0; i < p->num_cu; i++ )
+    {
+      const vvr_cu& cu = p->cu[i];
+      for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+      {
+        const vvr_tu& tu = p->tu[t];
+        for( int chn = 0; chn < 2; chn++ )
+        {
+          if( chn == 0 && !( tu.comp_mask & 1 ) ) continue;
+          if( chn == 1 && !( tu.comp_mask & 6 ) ) continue;
+          for( int y = tu.y; y < tu.y + tu.h && y < h.height; y += 4 ) for( int x = tu.x; x < tu.x + tu.w && x < h.width; x += 4 )
+            order[(size_t) chn * w4 * h4 + ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) t;
+        }
+      }
+    }
+  }
+  auto unitAvail = [&]( int chn, int x, int y, int32_t cur ) -> int
+  {
+    const int cs = chn ? 1 : 0, lx = x << cs, ly = y << cs;
+    if( x < 0 || y < 0 || lx >= h.width || ly >= h.height ) return 0;
+    return order[(size_t) chn * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
+  };
+  uint32_t curCtu = 0;
   for( uint32_t i = 0; i < p->num_cu; i++ )
   {
     const vvr_cu& cu = p->cu[i];
+    {
+      // CTU bookkeeping for the per-CTU intra lists (CUs arrive in CTU raster order)
+      const uint32_t ctuOfCu = (uint32_t) ( ( cu.y >> h.log2_ctu ) * ctusX + ( cu.x >> h.log2_ctu ) );
+      if( ctuOfCu < curCtu ) { c->setError( "CUs are not in CTU raster order" ); return VVR_ERR_PARAMETER; }
+      while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
+    }
+    if( cu.pred_mode == VVR_PRED_INTRA )
+    {
+      for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+      {
+        const vvr_tu& tu = p->tu[t];
+        for( int comp = 0; comp < ncomp; comp++ )
+        {
+          if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
+          const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
+          const int x0 = tu.x >> cs, y0 = tu.y >> cs, w = tu.w >> cs, hh = tu.h >> cs;
+          const int totalAbove = ( 2 * w + unit - 1 ) / unit, totalLeft = ( 2 * hh + unit - 1 ) / unit;
+          IntraItem it; memset( &it, 0, sizeof( it ) );
+          it.tu = t; it.comp = (uint8_t) comp;
+          it.hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
+          it.nTL = (uint8_t) unitAvail( chn, x0 - 1, y0 - 1, (int32_t) t );
+          if( unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
+          if( unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }
+          intra[comp].push_back( it );
+          bytes[K_INTRA] += (double) w * hh * ( it.hasResi ? 4 : 2 ) + sizeof( IntraItem );
+        }
+      }
+    }
     if( cu.pred_mode == VVR_PRED_INTER )
     {
       const int nl = cu.mc_mode == VVR_MC_BI ? 2 : 1;
@@ -285,13 +363,25 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         const int bw = tu.w >> ( it.comp ? 1 : 0 ), bh = tu.h >> ( it.comp ? 1 : 0 );
         if( bw < 2 || bh < 2 ) { c->setError( "1-D transform blocks are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
         const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
-        tb[cls].push_back( it );
+        ( it.mode == TB_ADD ? tb[cls] : tbS[cls] ).push_back( it );
         const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];
         const double ncoef = bdp ? (double) bw * bh : (double) ( tu.max_scan_x[it.comp] + 1 ) * ( tu.max_scan_y[it.comp] + 1 );
         bytes[K_ITRANS] += ncoef * 2 + (double) bw * bh * 4 * ( it.ict ? 2 : 1 ) + sizeof( TbItem ) + sizeof( vvr_tu ) / 3.0;
       }
     }
   }
+  while( curCtu < (uint32_t) numCtu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
+  // one item array for the three components; ctuStart holds offsets into it; active (component, CTU) pairs in raster order
+  std::vector<IntraItem> intraAll;
+  std::vector<uint32_t> activeV;
+  for( int k = 0; k < 3; k++ )
+  {
+    const uint32_t base = (uint32_t) intraAll.size();
+    intraAll.insert( intraAll.end(), intra[k].begin(), intra[k].end() );
+    for( int a = 0; a <= numCtu; a++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + a] += base;
+  }
+  for( int a = 0; a < numCtu; a++ ) for( int k = 0; k < 3; k++ )
+    if( ctuStartV[(size_t) k * ( numCtu + 1 ) + a + 1] > ctuStartV[(size_t) k * ( numCtu + 1 ) + a] ) activeV.push_back( ( (uint32_t) k << 24 ) | (uint32_t) a );
   const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
   bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
   bytes[K_SAO] = samples * 4; bytes[K_ALF] = samples * 4; bytes[K_COPY] = samples * 4;
@@ -312,6 +402,10 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   const int iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
   const int iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
   int iTb[3]; for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
+  int iTbS[3]; for( int k = 0; k < 3; k++ ) iTbS[k] = add( tbS[k].data(), sizeof( TbItem ) * tbS[k].size() );
+  const int iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
+  const int iCtuStart = add( ctuStartV.data(), sizeof( uint32_t ) * ctuStartV.size() );
+  const int iActive = add( activeV.data(), sizeof( uint32_t ) * activeV.size() );
 
   vvr_prepared* q = new vvr_prepared();
   q->hdr = h;
@@ -335,6 +429,10 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
   q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();
   for( int k = 0; k < 3; k++ ) { q->tbItems[k] = (TbItem*) ( base + parts[iTb[k]].off ); q->numTb[k] = (int) tb[k].size(); }
+  for( int k = 0; k < 3; k++ ) { q->tbStore[k] = (TbItem*) ( base + parts[iTbS[k]].off ); q->numTbStore[k] = (int) tbS[k].size(); }
+  q->intraItems = (IntraItem*) ( base + parts[iIntra].off ); q->numIntra = (int) intraAll.size();
+  q->ctuStart = (uint32_t*) ( base + parts[iCtuStart].off );
+  q->active = (uint32_t*) ( base + parts[iActive].off ); q->numActive = (int) activeV.size();
   memcpy( q->bytes, bytes, sizeof( bytes ) );
   *out = q;
   return VVR_OK;
@@ -392,8 +490,10 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
   };
   // INTER stage: prediction of every inter CU, then residual add (DecLibRecon.cpp:831-874)
   if( q->numMc ) timed( K_MC, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc ); } );
-  if( q->numTb[0] + q->numTb[1] + q->numTb[2] )
-    timed( K_ITRANS, [&]{ launch_itrans( s, q->pic, A, R, q->tbItems[0], q->numTb[0], 16 ); launch_itrans( s, q->pic, A, R, q->tbItems[1], q->numTb[1], 32 ); launch_itrans( s, q->pic, A, R, q->tbItems[2], q->numTb[2], 64 ); } );
+  if( q->numTb[0] + q->numTb[1] + q->numTb[2] + q->numTbStore[0] + q->numTbStore[1] + q->numTbStore[2] )
+    timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) { launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); launch_itrans( s, q->pic, A, R, q->tbStore[k], q->numTbStore[k], 16 << k ); } } );
+  // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)
+  if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->ctuStart, q->active, q->numActive, c->syncBuf[lane] ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
   // debugging aid (like the reference's per-stage CRC traces, LoopFilter.cpp:399-406): VVR_STOP_AFTER=reco|dbk|sao
   const char* stopEnv = getenv( "VVR_STOP_AFTER" );

@@ -36,6 +36,17 @@ struct TbItem {
 };
 enum { TB_ADD = 0, TB_STORE = 1 };
 
+// One intra-predicted transform block (decode order inside its CTU).  The reference-sample availability counts are the
+// m_neighborSize[] values IntraPrediction::xFillReferenceSamples derives by walking the CU/TU tree (IntraPrediction.cpp:1104-1139);
+// that walk is host glue here (vvr_prepare), the kernel only consumes the counts.
+struct IntraItem {
+  uint32_t tu;
+  uint8_t  comp;
+  uint8_t  nTL, nA, nL;   // available units (4 luma samples): top-left (0/1), above incl. above-right, left incl. below-left
+  uint8_t  hasResi;
+  uint8_t  pad[3];
+};
+
 struct PicDev {         // everything a kernel needs about one picture (passed by value)
   vvr_pic_header     hdr;
   const vvr_cu*      cu;
@@ -58,3 +69,4 @@ void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )
 void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 void launch_alf    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst );
+void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const uint32_t* ctuStart, const uint32_t* active, int numActive, int* sync );

@@ -1014,3 +1014,331 @@ void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst )
   const int ncomp = src.p[1] ? 3 : 1;
   hipLaunchKernelGGL( k_copy, dim3( ( src.w[0] + 255 ) / 256, src.h[0], ncomp ), dim3( 256 ), 0, s, src, dst );
 }
+
+// =====================================================================================================================
+// k_intra — intra prediction + reconstruction, one workgroup per (CTU, colour component).
+//   DecCu::predAndReco intra branch (DecCu.cpp:271-401), IntraPrediction::xFillReferenceSamples (IntraPrediction.cpp:1072),
+//   xFilterReferenceSamples (:1251), useFilteredIntraRefSamples (:1301), xPredIntraPlanarCore (:154), xGetPredValDc (:412),
+//   xPredIntraAng (:592), IntraPredSampleFilterCore (:212), xPredIntraBDPCM (:850), AreaBuf::reconstruct (Buffer.cpp:482).
+//
+// Intra blocks depend on their already reconstructed neighbours, so the blocks of one CTU are processed in decoding
+// order by one workgroup, and CTUs run as a wavefront (reference: INTRA state of DecLibRecon::ctuTask, DecLibRecon.cpp:876).
+// MI355X mapping: the CTU (plus 3 reference lines above / left and 64 samples above-right) lives in LDS for the whole
+// lifetime of the workgroup, so the serial block-to-block dependency never leaves the CU; the CTU-to-CTU dependency is a
+// per-(component, CTU) flag in HBM published with an agent-scope release and consumed with one relaxed poll + one
+// agent-scope acquire (cdna_hip_programming.md §6 Guideline 16).  Work is handed out through an atomic ticket in raster
+// order, so a workgroup only ever waits for CTUs whose workgroups have already started: no residency assumption.
+// =====================================================================================================================
+#define IT_PAD    3
+#define IT_RIGHT 64
+#define IT_MAXREF ( 2 * 64 + 8 )
+
+struct IntraShared {
+  pel_t tile[( 128 + IT_PAD ) * ( 128 + IT_PAD + IT_RIGHT + 5 )];   // row stride = S + IT_PAD + IT_RIGHT + 5 (odd multiple of dwords breaks bank alignment)
+  pel_t top[IT_MAXREF + 8], left[IT_MAXREF + 8], ftop[IT_MAXREF + 8], fleft[IT_MAXREF + 8];
+  pel_t refA[2 * 64 + 3 + 99 + 64], refL[2 * 64 + 3 + 99 + 64];
+  int   ticket;
+  int   dcSum;
+};
+
+__constant__ uint8_t c_intraFilterThr[8] = { 24, 24, 24, 14, 2, 0, 0, 0 };
+__constant__ int16_t c_angTable[32]    = { 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 39, 45, 51, 57, 64, 73, 86, 102, 128, 171, 256, 341, 512, 1024 };
+__constant__ int16_t c_invAngTable[32] = { 0, 16384, 8192, 5461, 4096, 2731, 2048, 1638, 1365, 1170, 1024, 910, 819, 712, 630, 565, 512, 468, 420, 364, 321, 287, 256, 224, 191, 161, 128, 96, 64, 48, 32, 16 };
+
+__device__ __forceinline__ int intra_wide_angle( int w, int h, int mode )   // IntraPrediction::getWideAngle (:443)
+{
+  const int modeShift[6] = { 0, 6, 10, 12, 14, 15 };
+  if( mode > 1 && mode <= 66 )
+  {
+    const int d = iabs( ilog2( w ) - ilog2( h ) );
+    if( w > h && mode < 2 + modeShift[d] ) mode += 65;
+    else if( h > w && mode > 66 - modeShift[d] ) mode -= 65;
+  }
+  return mode;
+}
+
+__global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, DevPlanes resi, const IntraItem* __restrict__ items,
+                                                  const uint32_t* __restrict__ ctuStart /* [3][numCtu+1] */, const uint32_t* __restrict__ active, int numActive,
+                                                  int* __restrict__ sync /* [0]: ticket, [1 + comp*numCtu + ctu]: done flags */ )
+{
+  __shared__ IntraShared sh;
+  const int tid = threadIdx.x;
+  const int numCtu = pic.ctus_x * pic.ctus_y;
+  if( tid == 0 ) sh.ticket = atomicAdd( &sync[0], 1 );
+  __syncthreads();
+  const int ticket = sh.ticket;
+  if( ticket >= numActive ) return;
+  const uint32_t ent = active[ticket];
+  const int comp = ent >> 24, ctu = ent & 0xffffff;
+  const int cxI = ctu % pic.ctus_x, cyI = ctu / pic.ctus_x;
+  const int cs = comp ? 1 : 0, ch = comp ? 1 : 0;
+  const int S = ( 1 << pic.hdr.log2_ctu ) >> cs;
+  const int ox = cxI * S, oy = cyI * S;
+  const int bd = pic.hdr.bit_depth;
+  const int PW = reco.w[comp], PH = reco.h[comp], pstride = reco.stride[comp];
+  pel_t* __restrict__ plane = reco.p[comp];
+  const int TS = 128 + IT_PAD + IT_RIGHT + 5;
+#define TILE( x, y ) sh.tile[( ( y ) - oy + IT_PAD ) * TS + ( ( x ) - ox + IT_PAD )]
+  // ---- wait for the CTUs this one reads from: left, above-left, above, above-right (only those that have intra blocks of this component)
+  if( tid == 0 )
+  {
+    const uint32_t* cst = ctuStart + comp * ( numCtu + 1 );
+    const int nb[4][2] = { { -1, 0 }, { -1, -1 }, { 0, -1 }, { 1, -1 } };
+    for( int k = 0; k < 4; k++ )
+    {
+      const int nx = cxI + nb[k][0], ny = cyI + nb[k][1];
+      if( nx < 0 || ny < 0 || nx >= pic.ctus_x ) continue;
+      const int n = ny * pic.ctus_x + nx;
+      if( cst[n + 1] == cst[n] ) continue;
+      int* flag = &sync[1 + comp * numCtu + n];
+      while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 2 );
+    }
+    __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );
+  }
+  __syncthreads();
+  // ---- stage the CTU and its reference border in LDS
+  {
+    const int x0 = max( 0, ox - IT_PAD ), x1 = min( PW, ox + S + IT_RIGHT );
+    const int y0 = max( 0, oy - IT_PAD ), y1 = min( PH, oy + S );
+    const int tw = x1 - x0;
+    for( int y = y0 + ( tid >> 6 ); y < y1; y += 4 )
+      for( int x = x0 + ( tid & 63 ); x < x1; x += 64 )
+        TILE( x, y ) = plane[(size_t) y * pstride + x];
+    (void) tw;
+  }
+  __syncthreads();
+  const uint32_t i0 = ctuStart[comp * ( numCtu + 1 ) + ctu], i1 = ctuStart[comp * ( numCtu + 1 ) + ctu + 1];
+  for( uint32_t ii = i0; ii < i1; ii++ )
+  {
+    const IntraItem it = items[ii];
+    const vvr_tu& tu = pic.tu[it.tu];
+    const vvr_cu& cu = pic.cu[tu.cu];
+    const int x0 = tu.x >> cs, y0 = tu.y >> cs, w = tu.w >> cs, h = tu.h >> cs;
+    const int mrl = comp ? 0 : cu.multi_ref_idx;
+    const int bdpcm = comp ? cu.bdpcm[1] : cu.bdpcm[0];
+    const int dirMode = cu.intra_dir[ch];
+    const int topLen = 2 * w, leftLen = 2 * h;
+    const int unit = 4 >> cs;
+    const int totalAbove = ( topLen + unit - 1 ) / unit, totalLeft = ( leftLen + unit - 1 ) / unit;
+    const int nTL = it.nTL, nA = it.nA, nL = it.nL;
+    const int nAll = nTL + nA + nL, total = totalAbove + totalLeft + 1;
+    // ---- xFillReferenceSamples: one lane per reference position
+    {
+      const int dcv = 1 << ( bd - 1 );
+      const int n = max( topLen, leftLen ) + mrl + 1;
+      for( int j = tid; j < n; j += 256 )
+      {
+        int tv = dcv, lv = dcv;
+        if( nAll == 0 ) {}
+        else if( nAll == total )
+        {
+          if( j <= topLen + mrl ) tv = TILE( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) );
+          if( j <= leftLen + mrl ) lv = j == 0 ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) ) : TILE( x0 - ( 1 + mrl ), y0 - mrl + ( j - 1 ) );
+        }
+        else if( nL > 0 )
+        {
+          const int szL = min( nL * unit, leftLen ), szA = min( nA * unit, topLen );
+          const int tpad = TILE( x0 - ( 1 + mrl ), y0 );
+          // left line
+          if( j == 0 ) lv = nTL ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) ) : tpad;
+          else if( j <= mrl ) lv = nTL ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) + j ) : tpad;
+          else if( j <= leftLen + mrl ) { const int i = j - 1 - mrl; lv = TILE( x0 - ( 1 + mrl ), y0 + min( i, szL - 1 ) ); }
+          // top line
+          if( j <= mrl ) tv = nTL ? TILE( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) ) : tpad;
+          else if( j <= topLen + mrl )
+          {
+            const int i = j - 1 - mrl;
+            if( nA ) tv = TILE( x0 + min( i, szA - 1 ), y0 - ( 1 + mrl ) );
+            else     tv = nTL ? TILE( x0 - 1, y0 - ( 1 + mrl ) ) : tpad;      // = top[mrl]
+          }
+        }
+        else
+        {
+          const int szA = min( nA * unit, topLen );
+          const int t = TILE( x0, y0 - ( 1 + mrl ) );
+          lv = t;
+          if( j <= mrl ) tv = t;
+          else if( j <= topLen + mrl ) tv = TILE( x0 + min( j - 1 - mrl, szA - 1 ), y0 - ( 1 + mrl ) );
+        }
+        if( j <= topLen + mrl ) sh.top[j] = (pel_t) tv;
+        if( j <= leftLen + mrl ) sh.left[j] = (pel_t) lv;
+      }
+    }
+    __syncthreads();
+    // ---- reference smoothing
+    bool useFilt = false;
+    if( !comp && !mrl && !cu.bdpcm[0] && dirMode != 1 )
+    {
+      if( dirMode == 0 ) useFilt = w * h > 32;
+      else
+      {
+        const int pm = intra_wide_angle( w, h, dirMode );
+        const int diff = min( iabs( pm - 18 ), iabs( pm - 50 ) );
+        const int l2 = ( ilog2( w ) + ilog2( h ) ) >> 1;
+        const int am = pm >= 34 ? pm - 50 : -( pm - 18 );
+        useFilt = diff > c_intraFilterThr[l2] && ( ( c_angTable[iabs( am )] & 0x1F ) == 0 );
+      }
+    }
+    if( useFilt )
+    {
+      for( int j = tid; j <= max( topLen, leftLen ); j += 256 )
+      {
+        if( j == 0 ) { const int v = ( sh.left[1] + 2 * sh.top[0] + sh.top[1] + 2 ) >> 2; sh.ftop[0] = sh.fleft[0] = (pel_t) v; }
+        else
+        {
+          if( j < topLen ) sh.ftop[j] = (pel_t) ( ( sh.top[j + 1] + 2 * sh.top[j] + sh.top[j - 1] + 2 ) >> 2 ); else if( j == topLen ) sh.ftop[j] = sh.top[j];
+          if( j < leftLen ) sh.fleft[j] = (pel_t) ( ( sh.left[j + 1] + 2 * sh.left[j] + sh.left[j - 1] + 2 ) >> 2 ); else if( j == leftLen ) sh.fleft[j] = sh.left[j];
+        }
+      }
+      __syncthreads();
+    }
+    const pel_t* T = useFilt ? sh.ftop : sh.top;
+    const pel_t* L = useFilt ? sh.fleft : sh.left;
+    const bool pdpcOK = ( w >= 4 && h >= 4 ) && mrl == 0;
+    const pel_t* __restrict__ rs = resi.p[comp];
+    const int rstride = resi.stride[comp];
+    const int lw = ilog2( w ), lh = ilog2( h );
+    // ---- mode-specific set-up
+    int predMode = 0, angle = 0, invAngle = 0, absAng = 0; bool isVer = true;
+    pel_t* refMain = nullptr; pel_t* refSide = nullptr;
+    int dcVal = 0;
+    const bool angular = !bdpcm && dirMode > 1;
+    if( !bdpcm && dirMode == 1 )
+    {
+      if( tid == 0 ) sh.dcSum = 0;
+      __syncthreads();
+      int part = 0;
+      if( w >= h ) for( int i = tid; i < w; i += 256 ) part += T[mrl + 1 + i];
+      if( w <= h ) for( int i = tid; i < h; i += 256 ) part += L[mrl + 1 + i];
+      if( part ) atomicAdd( &sh.dcSum, part );
+      __syncthreads();
+      const int denom = w == h ? w << 1 : max( w, h );
+      dcVal = ( sh.dcSum + ( denom >> 1 ) ) >> ilog2( denom );
+    }
+    else if( angular )
+    {
+      predMode = intra_wide_angle( w, h, dirMode );
+      isVer = predMode >= 34;
+      const int am = isVer ? predMode - 50 : -( predMode - 18 );
+      invAngle = c_invAngTable[iabs( am )]; absAng = c_angTable[iabs( am )]; angle = am < 0 ? -absAng : absAng;
+      if( angle < 0 )
+      {
+        pel_t* ra = sh.refA + 64; pel_t* rl = sh.refL + 64;       // room for the projected samples at negative indices
+        for( int j = tid; j <= max( w, h ) + 1 + mrl; j += 256 ) { if( j <= w + 1 + mrl ) ra[j] = T[j]; if( j <= h + 1 + mrl ) rl[j] = L[j]; }
+        __syncthreads();
+        refMain = isVer ? ra : rl; refSide = isVer ? rl : ra;
+        const int sizeSide = isVer ? h : w;
+        for( int k = tid + 1; k <= sizeSide; k += 256 ) refMain[-k] = refSide[min( ( k * invAngle + 256 ) >> 9, sizeSide )];
+      }
+      else
+      {
+        const int l2r = lw - lh;
+        const int s = max( 0, isVer ? l2r : -l2r );
+        const int maxIndex = ( mrl << s ) + 2;
+        const int refLength = isVer ? topLen : leftLen;
+        for( int j = tid; j <= max( topLen, leftLen ) + mrl; j += 256 ) { if( j <= topLen + mrl ) sh.refA[j] = T[j]; if( j <= leftLen + mrl ) sh.refL[j] = L[j]; }
+        __syncthreads();
+        refMain = isVer ? sh.refA : sh.refL; refSide = isVer ? sh.refL : sh.refA;
+        if( tid < maxIndex ) refMain[refLength + mrl + 1 + tid] = ( isVer ? T : L )[refLength + mrl];
+      }
+      __syncthreads();
+      refMain += mrl; refSide += mrl;
+    }
+    // ---- prediction + reconstruction, one sample per lane-iteration
+    const int bw = isVer ? w : h, bh = isVer ? h : w;       // angular modes predict in the transposed domain for horizontal modes
+    bool cubic = false, doAngPdpc = false; int angScale = 0;
+    if( angular )
+    {
+      if( !comp )
+      {
+        const int diff = min( iabs( predMode - 18 ), iabs( predMode - 50 ) );
+        const int l2 = ( ilog2( bw ) + ilog2( bh ) ) >> 1;
+        cubic = !( diff > c_intraFilterThr[l2] ) || mrl > 0;
+      }
+      if( angle > 0 )
+      {
+        const int sideSize = predMode >= 34 ? h : w;
+        angScale = min( 2, ilog2( sideSize ) - ( ilog2( 3 * invAngle - 2 ) - 8 ) );
+        doAngPdpc = pdpcOK && angScale >= 0;
+      }
+    }
+    const int pscale = ( lw - 2 + lh - 2 + 2 ) >> 2;
+    for( int i = tid; i < w * h; i += 256 )
+    {
+      const int x = i & ( w - 1 ), y = i >> lw;
+      int v;
+      if( bdpcm ) v = bdpcm == 1 ? L[y + 1] : T[x + 1];
+      else if( dirMode == 0 )
+      {
+        const int hor = ( L[y + 1] << lw ) + ( x + 1 ) * ( T[w + 1] - L[y + 1] );
+        const int ver = ( T[x + 1] << lh ) + ( y + 1 ) * ( L[h + 1] - T[x + 1] );
+        v = (int16_t) ( ( ( hor << lh ) + ( ver << lw ) + ( 1 << ( lw + lh ) ) ) >> ( 1 + lw + lh ) );
+      }
+      else if( dirMode == 1 ) v = dcVal;
+      else
+      {
+        const int xx = isVer ? x : y, yy = isVer ? y : x;      // position in the (possibly transposed) prediction block
+        if( angle == 0 )
+        {
+          if( pdpcOK )
+          {
+            const int lev = min( pscale == 0 ? 3 : pscale == 1 ? 6 : pscale == 2 ? 12 : 24, bw );
+            if( xx < lev ) { const int wL = 32 >> min( 31, ( xx << 1 ) >> pscale ); v = clip_pel( ( wL * ( refSide[yy + 1] - T[0] ) + ( refMain[xx + 1] << 6 ) + 32 ) >> 6, bd ); }
+            else v = refMain[xx + 1];
+          }
+          else v = refMain[xx + 1];
+        }
+        else
+        {
+          const int deltaPos = angle * ( 1 + mrl ) + yy * angle;
+          const int di = deltaPos >> 5, df = deltaPos & 31;
+          if( absAng & 0x1F )
+          {
+            if( !comp )
+            {
+              const int k = di + 1 + xx;
+              if( cubic ) { const int16_t* f = d_chroma_filter[df]; v = (int16_t) ( ( f[0] * refMain[k - 1] + f[1] * refMain[k] + f[2] * refMain[k + 1] + f[3] * refMain[k + 2] + 32 ) >> 6 ); v = clip_pel( v, bd ); }
+              else { const int g0 = 16 - ( df >> 1 ), g1 = 32 - ( df >> 1 ), g2 = 16 + ( df >> 1 ), g3 = df >> 1;     // g_intraGaussFilter (:96)
+                     v = (int16_t) ( ( g0 * refMain[k - 1] + g1 * refMain[k] + g2 * refMain[k + 1] + g3 * refMain[k + 2] + 32 ) >> 6 ); }
+            }
+            else v = (int16_t) ( ( ( 32 - df ) * refMain[xx + di + 1] + df * refMain[xx + di + 2] + 16 ) >> 5 );
+          }
+          else v = refMain[di + 1 + xx];
+          if( doAngPdpc && xx < min( 3 << angScale, bw ) )
+          {
+            const int invAngleSum = 256 + ( xx + 1 ) * invAngle;
+            const int wL = 32 >> ( 2 * xx >> angScale );
+            v = (int16_t) ( v + ( ( wL * ( refSide[yy + ( invAngleSum >> 9 ) + 1] - v ) + 32 ) >> 6 ) );
+          }
+        }
+      }
+      if( !bdpcm && pdpcOK && dirMode <= 1 )
+      {
+        const int wT = 32 >> min( 31, ( y << 1 ) >> pscale ), wL = 32 >> min( 31, ( x << 1 ) >> pscale );
+        v = (int16_t) ( v + ( ( wL * ( L[y + 1] - v ) + wT * ( T[x + 1] - v ) + 32 ) >> 6 ) );
+      }
+      if( it.hasResi ) v = clip_pel( v + rs[(size_t) ( y0 + y ) * rstride + x0 + x], bd );
+      TILE( x0 + x, y0 + y ) = (pel_t) v;
+      plane[(size_t) ( y0 + y ) * pstride + x0 + x] = (pel_t) v;
+    }
+    __syncthreads();
+  }
+#undef TILE
+  // ---- publish: all stores of the workgroup drained, one agent-scope release, then the flag
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+  __syncthreads();
+  if( tid == 0 )
+  {
+    __builtin_amdgcn_fence( __ATOMIC_RELEASE, "agent" );
+    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+    __hip_atomic_store( &sync[1 + comp * numCtu + ctu], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  }
+}
+
+void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const uint32_t* ctuStart, const uint32_t* active, int numActive, int* sync )
+{
+  if( !numActive ) return;
+  const int numCtu = pic.ctus_x * pic.ctus_y;
+  hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + 3 * (size_t) numCtu ), s );
+  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, ctuStart, active, numActive, sync );
+}
