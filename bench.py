@@ -33,9 +33,9 @@ def _cpu_worker(args):
     kind, W, H, seed, tools, gop, idx = args
     import refdrv
     from vvdec_amd import synth, stream
-    plans, _ = stream.ra_plan(gop + 1, gop=gop)
+    plans, _ = stream.ra_plan(gop + 1, gop=gop, seed_poc0_is_external=False)
     pl = plans[idx % len(plans)]
-    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, p_intra=0.0)
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools)
     refs = {}
     for lst in pl.ref_slots:
         for (slot, poc) in lst:
@@ -81,9 +81,9 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--gop", type=int, default=16)
-    ap.add_argument("--streams", type=int, default=4, help="pictures in flight per GPU")
+    ap.add_argument("--streams", type=int, default=8, help="pictures in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", type=int, default=1, help="number of pictures re-checked against the CPU oracle after the run")
+    ap.add_argument("--verify", type=int, default=2, help="number of pictures re-checked against the CPU oracle after the run")
     a = ap.parse_args()
 
     import torch
@@ -101,18 +101,16 @@ def main():
     from vvdec_amd import abi, synth, stream
     vvdec_amd.lib()
     W, H = a.width, a.height
-    tools = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS
+    tools = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST
     K, Wm = a.steps, a.warmup
-    nframes = ((max(K, Wm) + a.gop - 1) // a.gop) * a.gop + 1
-    plans, nslots = stream.ra_plan(nframes, gop=a.gop)
+    nframes = ((max(K, Wm) - 1 + a.gop - 1) // a.gop) * a.gop + 1
+    plans, nslots = stream.ra_plan(nframes, gop=a.gop, seed_poc0_is_external=False)   # POC 0 is an I picture
     seed = 1234 + 100000 * rank                       # every rank reconstructs its own closed-GOP segment
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank)
-    seed_pic = synth.natural_picture(W, H, seed + 100)
-    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, p_intra=0.0) for pl in plans[:max(K, Wm)]]
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools) for pl in plans[:max(K, Wm)]]
     prepared = [rec.prepare(d) for d in descs]        # everything resident in HBM from here on
 
     def one_pass(n):
-        rec.write_picture(0, seed_pic)
         rec.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -141,9 +139,8 @@ def main():
         verified = 0
         if a.verify:
             import refdrv
-            cpu = {0: seed_pic}
+            cpu = {}
             rec2 = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, device=local_rank)
-            rec2.write_picture(0, seed_pic)
             for pl, d in list(zip(plans, descs))[:a.verify]:
                 rec2.wait(rec2.decompress_picture(d))
                 got = rec2.read_picture(pl.slot)
@@ -171,8 +168,8 @@ def main():
                "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int16", "data": "synthetic",
                "config": {"workload": "%dx%d 10-bit 4:2:0 random-access QP32 (hierarchical-B GOP %d), CTU 128, pre-parsed records resident in HBM" % (W, H, a.gop),
-                          "tools": "inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), dequant+dep-quant, DCT2/DST7/DCT8 + transform skip + joint-CbCr, deblocking, SAO, ALF + CC-ALF",
-                          "not_yet": "intra CUs, BDOF/DMVR/affine/GPM/CIIP, LMCS (rejected with VVR_ERR_UNSUPPORTED)",
+                          "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel), dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, deblocking, SAO, ALF + CC-ALF",
+                          "not_yet": "CCLM/MIP/ISP, BDOF/DMVR/affine/GPM/CIIP, LMCS (rejected with VVR_ERR_UNSUPPORTED)",
                           "pictures_in_flight": a.streams, "sharding": "closed-GOP segment per GPU, no data-path collective",
                           "verified_pictures_vs_oracle": verified},
                "roofline": roof}

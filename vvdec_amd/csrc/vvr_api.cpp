@@ -273,14 +273,19 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   // = "inside the picture and reconstructed before me" (CodingStructure::getCURestricted, CodingStructure.cpp:464, and the
   // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
   std::vector<int32_t> order;
+  std::vector<uint8_t> intraAt;          // per 4x4 luma unit: covered by an intra CU
+  std::vector<uint8_t> depMaskV( 3 * (size_t) numCtu, 0 );   // per (component, CTU): bit k set = must wait for neighbour k (L, AL, A, AR)
   bool anyIntra = false;
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA;
   if( anyIntra )
   {
     order.assign( (size_t) w4 * h4 * 2, 0x7fffffff );
+    intraAt.assign( (size_t) w4 * h4, 0 );
     for( uint32_t i = 0; i < p->num_cu; i++ )
     {
       const vvr_cu& cu = p->cu[i];
+      if( cu.pred_mode == VVR_PRED_INTRA )
+        for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) intraAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = 1;
       for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
       {
         const vvr_tu& tu = p->tu[t];
@@ -304,9 +309,9 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   for( uint32_t i = 0; i < p->num_cu; i++ )
   {
     const vvr_cu& cu = p->cu[i];
+    // CTU bookkeeping for the per-CTU intra lists (CUs arrive in CTU raster order)
+    const uint32_t ctuOfCu = (uint32_t) ( ( cu.y >> h.log2_ctu ) * ctusX + ( cu.x >> h.log2_ctu ) );
     {
-      // CTU bookkeeping for the per-CTU intra lists (CUs arrive in CTU raster order)
-      const uint32_t ctuOfCu = (uint32_t) ( ( cu.y >> h.log2_ctu ) * ctusX + ( cu.x >> h.log2_ctu ) );
       if( ctuOfCu < curCtu ) { c->setError( "CUs are not in CTU raster order" ); return VVR_ERR_PARAMETER; }
       while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
     }
@@ -328,6 +333,23 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           if( unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
           if( unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }
           intra[comp].push_back( it );
+          {
+            // which neighbouring CTUs hold INTRA samples this block reads (inter samples are final before the intra stage starts)
+            const int ctuX = cu.x >> h.log2_ctu, ctuY = cu.y >> h.log2_ctu;
+            const int mrl = comp ? 0 : cu.multi_ref_idx;
+            auto touch = [&]( int xc, int yc )   // component coordinates of a reference sample
+            {
+              const int lx = xc << cs, ly = yc << cs;
+              if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
+              if( !intraAt[(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )] ) return;
+              const int dx = ( lx >> h.log2_ctu ) - ctuX, dy = ( ly >> h.log2_ctu ) - ctuY;
+              uint8_t& m = depMaskV[(size_t) comp * numCtu + ctuOfCu];
+              if( dx == -1 && dy == 0 ) m |= 1; else if( dx == -1 && dy == -1 ) m |= 2; else if( dx == 0 && dy == -1 ) m |= 4; else if( dx == 1 && dy == -1 ) m |= 8;
+            };
+            if( it.nTL ) touch( x0 - 1 - mrl, y0 - 1 - mrl );
+            for( int k = 0; k < it.nA * unit; k += unit ) touch( x0 + k, y0 - 1 - mrl );
+            for( int k = 0; k < it.nL * unit; k += unit ) touch( x0 - 1 - mrl, y0 + k );
+          }
           bytes[K_INTRA] += (double) w * hh * ( it.hasResi ? 4 : 2 ) + sizeof( IntraItem );
         }
       }
@@ -382,6 +404,10 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   }
   for( int a = 0; a < numCtu; a++ ) for( int k = 0; k < 3; k++ )
     if( ctuStartV[(size_t) k * ( numCtu + 1 ) + a + 1] > ctuStartV[(size_t) k * ( numCtu + 1 ) + a] ) activeV.push_back( ( (uint32_t) k << 24 ) | (uint32_t) a );
+  {
+    const size_t na = activeV.size();
+    for( size_t t = 0; t < na; t++ ) activeV.push_back( depMaskV[(size_t) ( activeV[t] >> 24 ) * numCtu + ( activeV[t] & 0xffffff )] );
+  }
   const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
   bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
   bytes[K_SAO] = samples * 4; bytes[K_ALF] = samples * 4; bytes[K_COPY] = samples * 4;
@@ -432,7 +458,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   for( int k = 0; k < 3; k++ ) { q->tbStore[k] = (TbItem*) ( base + parts[iTbS[k]].off ); q->numTbStore[k] = (int) tbS[k].size(); }
   q->intraItems = (IntraItem*) ( base + parts[iIntra].off ); q->numIntra = (int) intraAll.size();
   q->ctuStart = (uint32_t*) ( base + parts[iCtuStart].off );
-  q->active = (uint32_t*) ( base + parts[iActive].off ); q->numActive = (int) activeV.size();
+  q->active = (uint32_t*) ( base + parts[iActive].off ); q->numActive = (int) activeV.size() / 2;
   memcpy( q->bytes, bytes, sizeof( bytes ) );
   *out = q;
   return VVR_OK;

@@ -1029,12 +1029,14 @@ void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst )
 // agent-scope acquire (cdna_hip_programming.md §6 Guideline 16).  Work is handed out through an atomic ticket in raster
 // order, so a workgroup only ever waits for CTUs whose workgroups have already started: no residency assumption.
 // =====================================================================================================================
-#define IT_PAD    3
+#define IT_PAD    3      // reference lines above the CTU (multiRefIdx <= 2)
+#define IT_PADX   8      // columns left of the CTU kept in LDS: 8 samples = 16 bytes, so that every tile row starts 16-byte aligned in HBM
 #define IT_RIGHT 64
+#define IT_TS   ( IT_PADX + 128 + IT_RIGHT + 8 )     // LDS row stride in samples (16-byte multiple)
 #define IT_MAXREF ( 2 * 64 + 8 )
 
 struct IntraShared {
-  pel_t tile[( 128 + IT_PAD ) * ( 128 + IT_PAD + IT_RIGHT + 5 )];   // row stride = S + IT_PAD + IT_RIGHT + 5 (odd multiple of dwords breaks bank alignment)
+  pel_t tile[( 128 + IT_PAD ) * IT_TS];
   pel_t top[IT_MAXREF + 8], left[IT_MAXREF + 8], ftop[IT_MAXREF + 8], fleft[IT_MAXREF + 8];
   pel_t refA[2 * 64 + 3 + 99 + 64], refL[2 * 64 + 3 + 99 + 64];
   int   ticket;
@@ -1058,7 +1060,7 @@ __device__ __forceinline__ int intra_wide_angle( int w, int h, int mode )   // I
 }
 
 __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, DevPlanes resi, const IntraItem* __restrict__ items,
-                                                  const uint32_t* __restrict__ ctuStart /* [3][numCtu+1] */, const uint32_t* __restrict__ active, int numActive,
+                                                  const uint32_t* __restrict__ ctuStart /* [3][numCtu+1] */, const uint32_t* __restrict__ active /* [numActive] entries, then [numActive] dependency masks */, int numActive,
                                                   int* __restrict__ sync /* [0]: ticket, [1 + comp*numCtu + ctu]: done flags */ )
 {
   __shared__ IntraShared sh;
@@ -1077,19 +1079,18 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   const int bd = pic.hdr.bit_depth;
   const int PW = reco.w[comp], PH = reco.h[comp], pstride = reco.stride[comp];
   pel_t* __restrict__ plane = reco.p[comp];
-  const int TS = 128 + IT_PAD + IT_RIGHT + 5;
-#define TILE( x, y ) sh.tile[( ( y ) - oy + IT_PAD ) * TS + ( ( x ) - ox + IT_PAD )]
+#define TILE( x, y ) sh.tile[( ( y ) - oy + IT_PAD ) * IT_TS + ( ( x ) - ox + IT_PADX )]
   // ---- wait for the CTUs this one reads from: left, above-left, above, above-right (only those that have intra blocks of this component)
   if( tid == 0 )
   {
-    const uint32_t* cst = ctuStart + comp * ( numCtu + 1 );
+    // the host glue marks which of the four neighbours actually contain intra samples this CTU's blocks read
+    const uint32_t depMask = active[numActive + ticket];
     const int nb[4][2] = { { -1, 0 }, { -1, -1 }, { 0, -1 }, { 1, -1 } };
     for( int k = 0; k < 4; k++ )
     {
+      if( !( depMask & ( 1u << k ) ) ) continue;
       const int nx = cxI + nb[k][0], ny = cyI + nb[k][1];
-      if( nx < 0 || ny < 0 || nx >= pic.ctus_x ) continue;
       const int n = ny * pic.ctus_x + nx;
-      if( cst[n + 1] == cst[n] ) continue;
       int* flag = &sync[1 + comp * numCtu + n];
       while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 2 );
     }
@@ -1098,13 +1099,19 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   __syncthreads();
   // ---- stage the CTU and its reference border in LDS
   {
-    const int x0 = max( 0, ox - IT_PAD ), x1 = min( PW, ox + S + IT_RIGHT );
+    // 16-byte chunks (8 samples); plane rows are 128-byte aligned and padded to a multiple of 64 samples, so a chunk that
+    // straddles the picture's right edge stays inside the row allocation (those samples are never used)
     const int y0 = max( 0, oy - IT_PAD ), y1 = min( PH, oy + S );
-    const int tw = x1 - x0;
-    for( int y = y0 + ( tid >> 6 ); y < y1; y += 4 )
-      for( int x = x0 + ( tid & 63 ); x < x1; x += 64 )
-        TILE( x, y ) = plane[(size_t) y * pstride + x];
-    (void) tw;
+    const int c0 = ox >= IT_PADX ? -1 : 0;                                  // first chunk relative to ox / 8
+    const int c1 = ( min( PW, ox + S + IT_RIGHT ) - ox + 7 ) >> 3;           // one past the last chunk
+    const int nch = c1 - c0;
+    for( int i = tid; i < nch * ( y1 - y0 ); i += 256 )
+    {
+      const int r = i / nch, cidx = c0 + ( i - r * nch );
+      const int y = y0 + r, x = ox + cidx * 8;
+      const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
+      *reinterpret_cast<uint4*>( &TILE( x, y ) ) = v;
+    }
   }
   __syncthreads();
   const uint32_t i0 = ctuStart[comp * ( numCtu + 1 ) + ctu], i1 = ctuStart[comp * ( numCtu + 1 ) + ctu + 1];
