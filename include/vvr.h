@@ -319,6 +319,10 @@ VVR_API void         vvr_free_prepared(vvr_context* ctx, vvr_prepared* prepared)
 VVR_API void*        vvr_job_stream(vvr_context* ctx, int job);
 VVR_API const char*  vvr_last_error(const vvr_context* ctx);
 VVR_API const char*  vvr_version(void);
+/* sizeof() of ABI struct number `which` as this library was compiled (0 vvr_pic_header, 1 vvr_cu, 2 vvr_tu, 3 vvr_motion,
+ * 4 vvr_lfp, 5 vvr_sao_ctu, 6 vvr_alf_ctu, 7 vvr_alf_params, 8 vvr_lmcs_params, 9 vvr_picture, 10 vvr_config,
+ * 11 vvr_kernel_stat; anything else 0): lets a binding written in another language verify its struct mirror at load time */
+VVR_API size_t       vvr_abi_sizeof(int which);
 
 /* kernel statistics accumulated with HIP events on the launch streams when enabled */
 typedef struct vvr_kernel_stat {

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz with the REAL reference decoder classes (oracle/_ref/libvvref.so).
+
+Run in the build container (needs /root/reference for `make -C oracle harness`):   python tests/golden/make_golden.py
+Each fixture = one synthetic pre-parsed picture (tools/synth.cpp, fixed seed) + its reference pictures + the planes the
+reference's DecCu / InterPrediction / IntraPrediction / LoopFilter / SampleAdaptiveOffset / AdaptiveLoopFilter produced
+after each stage (scalar code paths; the SIMD paths are checked to give the same bytes before anything is written)."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import numpy as np
+import refdrv
+import golden_io
+from vvdec_amd import abi, synth, stream
+
+ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST
+
+# name, W, H, log2_ctu, picture index in a GOP-4 stream with an I picture at POC 0, seed, tools, generator overrides
+CASES = [
+    ("i_256x128_ctu128", 256, 128, 7, 0, 11, ALL, {}),
+    ("i_200x136_ctu64", 200, 136, 6, 0, 12, ALL, {}),
+    ("i_128x64_ctu32_nodq", 128, 64, 5, 0, 13, ALL & ~abi.TOOL_DEP_QUANT, {}),
+    ("b_256x128_ctu128", 256, 128, 7, 2, 14, ALL, dict(p_intra=0.2)),
+    ("b_200x136_ctu64_inter", 200, 136, 6, 3, 15, ALL, dict(p_intra=0.0)),
+    ("b_256x192_ctu128_key", 256, 192, 7, 1, 16, ALL, dict(p_intra=0.3)),
+    ("b_128x128_ctu32_nofilters", 128, 128, 5, 4, 17, abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST, dict(p_intra=0.15)),
+]
+
+
+def main():
+    assert refdrv.available(), "oracle/_ref is not built (make -C oracle harness needs /root/reference)"
+    for (name, W, H, l2, idx, seed, tools, kw) in CASES:
+        plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+        pl = plans[idx]
+        d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
+        refs = {}
+        for lst in pl.ref_slots:
+            for (slot, poc) in lst:
+                refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc))
+        outs = {}
+        for st, fl in (("reco", refdrv.STOP_AFTER_RECO), ("dbk", refdrv.STOP_AFTER_DBK), ("sao", refdrv.STOP_AFTER_SAO), ("final", 0)):
+            scalar = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+            simd = refdrv.reconstruct(d, refs, flags=fl | refdrv.SIMD)["planes"]
+            assert all(np.array_equal(a, b) for a, b in zip(scalar, simd)), "%s/%s: the reference's scalar and SIMD paths disagree" % (name, st)
+            outs[st] = scalar
+        path = os.path.join(HERE, name + ".npz")
+        golden_io.save(path, d, refs, outs)
+        print("%-32s %6d CUs %6d TUs  %7.1f KiB" % (name, len(d.cu), len(d.tu), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

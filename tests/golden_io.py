@@ -1,0 +1,71 @@
+"""Serialisation of one pre-parsed picture + the reference decoder's outputs for it (tests/golden/*.npz).
+
+TEST INFRASTRUCTURE.  A fixture holds the complete input of DecLibRecon::decompressPicture as the C ABI sees it (header
+bytes, CU/TU records, packed levels, motion field, edge parameters, SAO/ALF controls), the reference pictures it predicts
+from and the planes the REAL reference classes (oracle/_ref, built from /root/reference by oracle/Makefile) produced after
+each stage.  tests/golden/make_golden.py writes them; /root/reference is not needed to read them."""
+import ctypes as C
+import numpy as np
+from vvdec_amd import abi
+from vvdec_amd.desc import PictureDesc, CU_DT, TU_DT, MOTION_DT, LFP_DT, SAO_DT, ALF_DT
+
+STAGES = ("reco", "dbk", "sao", "final")
+
+
+def _bytes_of(struct):
+    return np.frombuffer(bytes(struct), dtype=np.uint8).copy()
+
+
+def save(path, desc, refs, outputs):
+    """refs: {slot: [Y, Cb, Cr]}; outputs: {stage: [Y, Cb, Cr]} from the reference."""
+    d = dict(hdr=_bytes_of(desc.hdr), cu=desc.cu.view(np.uint8), tu=desc.tu.view(np.uint8), ctu_first_cu=desc.ctu_first_cu,
+             coef=np.asarray(desc.coef, np.int16), lfp0=desc.lfp[0].view(np.uint8), lfp1=desc.lfp[1].view(np.uint8))
+    if desc.motion is not None:
+        d["motion"] = desc.motion.view(np.uint8)
+    if desc.sao is not None:
+        d["sao"] = desc.sao.view(np.uint8)
+    if desc.alf is not None:
+        d["alf"] = desc.alf.view(np.uint8)
+    if desc.alf_params is not None:
+        d["alf_params"] = _bytes_of(desc.alf_params)
+    if desc.lmcs is not None:
+        d["lmcs"] = _bytes_of(desc.lmcs)
+    for slot, planes in refs.items():
+        for c, p in enumerate(planes):
+            d["ref_%d_%d" % (slot, c)] = np.asarray(p, np.uint16)
+    for st, planes in outputs.items():
+        for c, p in enumerate(planes):
+            d["out_%s_%d" % (st, c)] = np.asarray(p, np.uint16)
+    np.savez_compressed(path, **d)
+
+
+def load(path):
+    """-> (PictureDesc, refs {slot: planes}, outputs {stage: planes})"""
+    z = np.load(path)
+    hdr = abi.PicHeader.from_buffer_copy(z["hdr"].tobytes())
+    d = PictureDesc(hdr.width, hdr.height, hdr.bit_depth, hdr.log2_ctu, hdr.chroma_format)
+    d.hdr = hdr
+    d.cu = z["cu"].view(CU_DT).copy()
+    d.tu = z["tu"].view(TU_DT).copy()
+    d.ctu_first_cu = z["ctu_first_cu"].astype(np.uint32)
+    d.coef = z["coef"].astype(np.int16)
+    d.lfp = [z["lfp0"].view(LFP_DT).copy(), z["lfp1"].view(LFP_DT).copy()]
+    if "motion" in z:
+        d.motion = z["motion"].view(MOTION_DT).copy()
+    if "sao" in z:
+        d.sao = z["sao"].view(SAO_DT).copy()
+    if "alf" in z:
+        d.alf = z["alf"].view(ALF_DT).copy()
+    if "alf_params" in z:
+        d.alf_params = abi.AlfParams.from_buffer_copy(z["alf_params"].tobytes())
+    if "lmcs" in z:
+        d.lmcs = abi.LmcsParams.from_buffer_copy(z["lmcs"].tobytes())
+    refs, outs = {}, {}
+    for k in z.files:
+        if k.startswith("ref_"):
+            _, slot, c = k.split("_")
+            refs.setdefault(int(slot), [None, None, None])[int(c)] = z[k]
+        elif k.startswith("out_"):
+            _, st, c = k.split("_")
+            outs.setdefault(st, [None, None, None])[int(c)] = z[k]
+    return d, refs, outs

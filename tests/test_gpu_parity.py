@@ -120,3 +120,31 @@ def test_unsupported_tools_fail_loudly(built):
     with pytest.raises(vvdec_amd.VvrError):
         rec.decompress_picture(d)
     rec.close()
+
+
+def _golden_files():
+    import glob, os
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_fixtures_reference_outputs(built, path, monkeypatch):
+    """HIP path against what the REAL reference classes produced (tests/golden, written by make_golden.py), every stage."""
+    import vvdec_amd
+    import golden_io
+    d, refs, outs = golden_io.load(path)
+    h = d.hdr
+    nslots = max([h.out_slot] + list(refs.keys())) + 1
+    for st, env in (("final", None), ("reco", "reco"), ("dbk", "dbk"), ("sao", "sao")):
+        if env:
+            monkeypatch.setenv("VVR_STOP_AFTER", env)
+        else:
+            monkeypatch.delenv("VVR_STOP_AFTER", raising=False)
+        rec = vvdec_amd.Reconstructor(h.width, h.height, bit_depth=h.bit_depth, log2_ctu=h.log2_ctu, num_slots=nslots, num_streams=1)
+        for slot, planes in refs.items():
+            rec.write_picture(slot, planes)
+        rec.wait(rec.decompress_picture(d))
+        got = rec.read_picture(h.out_slot)
+        rec.close()
+        for c in range(3):
+            assert np.array_equal(got[c], outs[st][c]), "%s comp %d: %d samples differ from the reference decoder" % (st, c, int((got[c] != outs[st][c]).sum()))

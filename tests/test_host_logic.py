@@ -1,0 +1,87 @@
+"""CPU: host-side logic — decode-order/DPB plan of the synthetic stream, generator invariants, segment sharding."""
+import numpy as np
+import pytest
+
+from vvdec_amd import abi, synth, stream, parallel
+
+
+@pytest.mark.parametrize("gop,frames", [(4, 5), (8, 17), (16, 33), (32, 65)])
+def test_ra_plan_is_decodable(gop, frames):
+    for ext in (True, False):
+        plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=ext)
+        assert sorted(p.poc for p in plans) == list(range(1 if ext else 0, frames))
+        live = {0: 0} if ext else {}                 # slot -> poc currently stored there
+        for p in plans:
+            for lst, pocs in zip(p.ref_slots, (p.l0, p.l1)):
+                assert [poc for (_, poc) in lst] == pocs
+                for (slot, poc) in lst:
+                    assert live.get(slot) == poc, "POC %d reads POC %d from slot %d which holds %r" % (p.poc, poc, slot, live.get(slot))
+                    assert slot != p.slot, "a picture must not be written over one of its own references"
+            assert 0 <= p.slot < nslots
+            live[p.slot] = p.poc
+        assert nslots <= 8                           # hierarchical-B needs log2(gop) + a few pictures, never the whole GOP
+        assert plans[0].slice_type == (abi.SLICE_B if ext else abi.SLICE_I)
+
+
+def test_ra_plan_layers():
+    plans, _ = stream.ra_plan(17, gop=16)
+    by_layer = {}
+    for p in plans:
+        by_layer.setdefault(p.layer, []).append(p.poc)
+    assert [len(by_layer[l]) for l in sorted(by_layer)] == [1, 1, 2, 4, 8]
+    assert all(not p.is_ref for p in plans if p.layer == 4) and all(p.is_ref for p in plans if p.layer < 4)
+
+
+@pytest.mark.parametrize("W,H,l2", [(256, 128, 7), (200, 136, 6), (136, 72, 5)])
+def test_generator_invariants(built, W, H, l2):
+    tools = abi.TOOL_SAO_LUMA | abi.TOOL_ALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    for pl in plans[:3]:
+        d = synth.picture_for_plan(pl, W, H, seed=77, tool_flags=tools, log2_ctu=l2, p_intra=0.3)
+        d2 = synth.picture_for_plan(pl, W, H, seed=77, tool_flags=tools, log2_ctu=l2, p_intra=0.3)
+        same = lambda a, b: len(a) == len(b) and all(np.array_equal(a[n], b[n]) for n in a.dtype.names)      # field-wise: struct padding is not data
+        assert same(d.cu, d2.cu) and same(d.tu, d2.tu) and np.array_equal(d.coef, d2.coef) and same(d.motion, d2.motion), "generator must be deterministic"
+        # CUs tile the picture exactly once
+        cover = np.zeros((H, W), np.int32)
+        for cu in d.cu:
+            cover[cu["y"]:cu["y"] + cu["h"], cu["x"]:cu["x"] + cu["w"]] += 1
+        assert (cover == 1).all()
+        # CTU raster order, ctu_first_cu consistent
+        ctu = 1 << l2
+        ids = [(int(cu["y"]) // ctu) * d.ctus_x + int(cu["x"]) // ctu for cu in d.cu]
+        assert ids == sorted(ids)
+        assert d.ctu_first_cu[0] == 0 and d.ctu_first_cu[-1] == len(d.cu)
+        # TUs belong to their CU, level offsets stay inside the packed stream
+        for i, cu in enumerate(d.cu):
+            for t in range(cu["first_tu"], cu["first_tu"] + cu["num_tu"]):
+                tu = d.tu[t]
+                assert tu["cu"] == i
+                assert cu["x"] <= tu["x"] and tu["x"] + tu["w"] <= cu["x"] + cu["w"]
+                for c in range(3):
+                    if (tu["cbf"] >> c) & 1:
+                        n = (int(tu["max_scan_x"][c]) + 1) * (int(tu["max_scan_y"][c]) + 1)
+                        assert int(tu["coef_off"][c]) + n <= len(d.coef)
+            if pl.slice_type == abi.SLICE_I:
+                assert cu["pred_mode"] == abi.PRED_INTRA
+        # levels are conformant-stream-like: no int16 overflow after dequantisation is provoked
+        assert np.abs(d.coef.astype(np.int32)).max() < 32768
+
+
+def test_segment_sharding_partitions_the_stream():
+    for world in (1, 2, 3, 4, 8):
+        for nseg in (1, 2, 7, 8, 64):
+            seen = []
+            for r in range(world):
+                mine = parallel.segments_for_rank(nseg, r, world)
+                assert len(mine) in (nseg // world, nseg // world + 1)
+                seen += mine
+            assert sorted(seen) == list(range(nseg))
+    assert parallel.segment_seed(1234, 0) == 1234 and parallel.segment_seed(1234, 3) != parallel.segment_seed(1234, 2)
+
+
+def test_picture_md5_layout():
+    y = np.arange(8, dtype=np.uint16).reshape(2, 4)
+    cb = np.array([[1]], np.uint16)
+    cr = np.array([[2]], np.uint16)
+    import hashlib
+    assert parallel.picture_md5([y, cb, cr]) == hashlib.md5(y.tobytes() + cb.tobytes() + cr.tobytes()).hexdigest()

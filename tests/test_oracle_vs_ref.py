@@ -1,0 +1,55 @@
+"""CPU: the plain-C oracle against the real reference classes (oracle/_ref) on fresh seeds.  Skipped where oracle/_ref is
+not built (it needs /root/reference at build time); the committed golden fixtures cover that case."""
+import numpy as np
+import pytest
+
+import refdrv
+from vvdec_amd import abi, synth, stream
+
+pytestmark = pytest.mark.skipif(not refdrv.available(), reason="oracle/_ref not built")
+ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST
+STAGES = [refdrv.STOP_AFTER_RECO, refdrv.STOP_AFTER_DBK, refdrv.STOP_AFTER_SAO, 0]
+
+
+def _case(W, H, l2, idx, seed, **kw):
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=ALL, log2_ctu=l2, **kw)
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc))
+    return d, refs
+
+
+@pytest.mark.parametrize("W,H,l2,idx,seed,kw", [
+    (256, 128, 7, 0, 101, {}),
+    (384, 256, 7, 2, 102, dict(p_intra=0.25)),
+    (200, 136, 6, 3, 103, dict(p_intra=0.1)),
+    (320, 192, 5, 1, 104, dict(p_intra=0.0)),
+    (264, 200, 7, 4, 105, dict(p_intra=0.5)),
+])
+def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
+    d, refs = _case(W, H, l2, idx, seed, **kw)
+    for fl in STAGES:
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+
+
+def test_reference_simd_equals_scalar(built):
+    """the reference's own differential check (its unit test compares scalar vs SIMD kernels): same bytes at frame level"""
+    d, refs = _case(256, 192, 7, 2, 106, p_intra=0.2)
+    a = refdrv.reconstruct(d, refs, flags=0)["planes"]
+    b = refdrv.reconstruct(d, refs, flags=refdrv.SIMD)["planes"]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_edge_parameters_match_reference_derivation(built):
+    """deblocking with the edge parameters the reference derives itself (LoopFilter::calcFilterStrengthsCTU) == with the
+    job's table (the host glue's restatement of that derivation)"""
+    d, refs = _case(256, 128, 7, 2, 107, p_intra=0.2)
+    a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
+    b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))

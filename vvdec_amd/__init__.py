@@ -46,6 +46,7 @@ def lib():
         L.vvr_last_error.restype = C.c_char_p
         L.vvr_last_error.argtypes = [C.c_void_p]
         L.vvr_slot_bytes.restype = C.c_size_t
+        L.vvr_abi_sizeof.restype = C.c_size_t
         L.vvr_plane_ptr.restype = C.c_void_p
         L.vvr_plane_ptr.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.vvr_job_stream.restype = C.c_void_p
@@ -71,7 +72,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
                     "vvr_plane_ptr", "vvr_read_plane", "vvr_write_plane", "vvr_read_dmvr", "vvr_prepare", "vvr_submit_prepared",
-                    "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type"]
+                    "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof"]
 
 
 class Reconstructor:

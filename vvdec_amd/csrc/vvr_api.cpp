@@ -104,6 +104,13 @@ extern "C" {
 
 VVR_API const char* vvr_version( void ) { return "vvdec_amd 0.1 (gfx950, ABI 1)"; }
 
+VVR_API size_t vvr_abi_sizeof( int which )
+{
+  static const size_t sz[] = { sizeof( vvr_pic_header ), sizeof( vvr_cu ), sizeof( vvr_tu ), sizeof( vvr_motion ), sizeof( vvr_lfp ), sizeof( vvr_sao_ctu ),
+                               sizeof( vvr_alf_ctu ), sizeof( vvr_alf_params ), sizeof( vvr_lmcs_params ), sizeof( vvr_picture ), sizeof( vvr_config ), sizeof( vvr_kernel_stat ) };
+  return which >= 0 && which < (int) ( sizeof( sz ) / sizeof( sz[0] ) ) ? sz[which] : 0;
+}
+
 VVR_API size_t vvr_slot_bytes( const vvr_config* cfg )
 {
   int st[3]; size_t b[3], t; planeGeometry( cfg, st, b, &t ); return t;
