@@ -105,7 +105,8 @@ def main():
     K, Wm = a.steps, a.warmup
     nframes = ((max(K, Wm) - 1 + a.gop - 1) // a.gop) * a.gop + 1
     plans, nslots = stream.ra_plan(nframes, gop=a.gop, seed_poc0_is_external=False)   # POC 0 is an I picture
-    seed = 1234 + 100000 * rank                       # every rank reconstructs its own closed-GOP segment
+    from vvdec_amd import parallel
+    seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank)
     descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools) for pl in plans[:max(K, Wm)]]
     prepared = [rec.prepare(d) for d in descs]        # everything resident in HBM from here on
