@@ -281,7 +281,9 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
   std::vector<int32_t> order;
   std::vector<uint8_t> intraAt;          // per 4x4 luma unit: covered by an intra CU
-  std::vector<uint8_t> depMaskV( 3 * (size_t) numCtu, 0 );   // per (component, CTU): bit k set = must wait for neighbour k (L, AL, A, AR)
+  std::vector<uint8_t> depMaskV( 3 * (size_t) numCtu, 0 );
+  struct BBox { int y0 = 255, y1 = 0, c0 = 255, c1 = 0; };   // rows relative to (CTU top - 3), 8-sample chunks relative to (CTU left - 8), chunk index + 1
+  std::vector<BBox> bboxV( 3 * (size_t) numCtu );   // per (component, CTU): bit k set = must wait for neighbour k (L, AL, A, AR)
   bool anyIntra = false;
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA;
   if( anyIntra )
@@ -335,7 +337,12 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           const int totalAbove = ( 2 * w + unit - 1 ) / unit, totalLeft = ( 2 * hh + unit - 1 ) / unit;
           IntraItem it; memset( &it, 0, sizeof( it ) );
           it.tu = t; it.comp = (uint8_t) comp;
-          it.hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
+          it.x = (uint16_t) x0; it.y = (uint16_t) y0;
+          { int l = 0; while( ( 1 << l ) < w ) l++; it.lw = (uint8_t) l; l = 0; while( ( 1 << l ) < hh ) l++; it.lh = (uint8_t) l; }
+          it.mode = cu.intra_dir[chn];
+          const bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
+          const int bdp = cu.bdpcm[chn];
+          it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp ? 0 : cu.multi_ref_idx ) << 4 ) );
           it.nTL = (uint8_t) unitAvail( chn, x0 - 1, y0 - 1, (int32_t) t );
           if( unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
           if( unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }
@@ -353,11 +360,21 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
               uint8_t& m = depMaskV[(size_t) comp * numCtu + ctuOfCu];
               if( dx == -1 && dy == 0 ) m |= 1; else if( dx == -1 && dy == -1 ) m |= 2; else if( dx == 0 && dy == -1 ) m |= 4; else if( dx == 1 && dy == -1 ) m |= 8;
             };
+            {
+              // bounding box of everything the kernel's reference fill may read for this block (whole top / left lines incl. padding sources)
+              const int S = ( 1 << h.log2_ctu ) >> cs, ox = ctuX * S, oy = ctuY * S;
+              BBox& bb = bboxV[(size_t) comp * numCtu + ctuOfCu];
+              const int rx0 = x0 - 1 - mrl, rx1 = x0 + std::max( 2 * w, 1 ) + 1, ry0 = y0 - 1 - mrl, ry1 = y0 + 2 * hh + 1;
+              bb.y0 = std::min( bb.y0, std::max( 0, ry0 - ( oy - 3 ) ) );
+              bb.y1 = std::max( bb.y1, std::min( S + 3, ry1 - ( oy - 3 ) ) );
+              bb.c0 = std::min( bb.c0, std::max( 0, ( rx0 - ( ox - 8 ) ) >> 3 ) );
+              bb.c1 = std::max( bb.c1, std::min( ( 8 + S + 64 + 7 ) >> 3, ( rx1 - ( ox - 8 ) + 7 ) >> 3 ) );
+            }
             if( it.nTL ) touch( x0 - 1 - mrl, y0 - 1 - mrl );
             for( int k = 0; k < it.nA * unit; k += unit ) touch( x0 + k, y0 - 1 - mrl );
             for( int k = 0; k < it.nL * unit; k += unit ) touch( x0 - 1 - mrl, y0 + k );
           }
-          bytes[K_INTRA] += (double) w * hh * ( it.hasResi ? 4 : 2 ) + sizeof( IntraItem );
+          bytes[K_INTRA] += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
         }
       }
     }
@@ -412,8 +429,24 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   for( int a = 0; a < numCtu; a++ ) for( int k = 0; k < 3; k++ )
     if( ctuStartV[(size_t) k * ( numCtu + 1 ) + a + 1] > ctuStartV[(size_t) k * ( numCtu + 1 ) + a] ) activeV.push_back( ( (uint32_t) k << 24 ) | (uint32_t) a );
   {
+    // per active (component, CTU): dependency mask; bit 31 of the entry = every sample of the CTU is intra, so the kernel only
+    // stages the reference border (single tree: the same CUs cover all three components)
     const size_t na = activeV.size();
-    for( size_t t = 0; t < na; t++ ) activeV.push_back( depMaskV[(size_t) ( activeV[t] >> 24 ) * numCtu + ( activeV[t] & 0xffffff )] );
+    const int ctu4 = 1 << ( h.log2_ctu - 2 );
+    for( size_t t = 0; t < na; t++ )
+    {
+      const uint32_t k = activeV[t] >> 24, a = activeV[t] & 0xffffff;
+      const int ux = (int) ( a % ctusX ) * ctu4, uy = (int) ( a / ctusX ) * ctu4;
+      bool all = true;
+      for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( !intraAt[(size_t) y * w4 + x] ) { all = false; break; }
+      if( all ) activeV[t] |= 0x80000000u;
+      activeV.push_back( depMaskV[(size_t) k * numCtu + a] );
+    }
+    for( size_t t = 0; t < na; t++ )
+    {
+      const BBox& bb = bboxV[(size_t) ( ( activeV[t] >> 24 ) & 3 ) * numCtu + ( activeV[t] & 0xffffff )];
+      activeV.push_back( (uint32_t) bb.y0 | ( (uint32_t) bb.y1 << 8 ) | ( (uint32_t) bb.c0 << 16 ) | ( (uint32_t) bb.c1 << 24 ) );
+    }
   }
   const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
   bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
@@ -465,7 +498,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   for( int k = 0; k < 3; k++ ) { q->tbStore[k] = (TbItem*) ( base + parts[iTbS[k]].off ); q->numTbStore[k] = (int) tbS[k].size(); }
   q->intraItems = (IntraItem*) ( base + parts[iIntra].off ); q->numIntra = (int) intraAll.size();
   q->ctuStart = (uint32_t*) ( base + parts[iCtuStart].off );
-  q->active = (uint32_t*) ( base + parts[iActive].off ); q->numActive = (int) activeV.size() / 2;
+  q->active = (uint32_t*) ( base + parts[iActive].off ); q->numActive = (int) activeV.size() / 3;
   memcpy( q->bytes, bytes, sizeof( bytes ) );
   *out = q;
   return VVR_OK;

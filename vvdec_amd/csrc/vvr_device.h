@@ -39,12 +39,17 @@ enum { TB_ADD = 0, TB_STORE = 1 };
 // One intra-predicted transform block (decode order inside its CTU).  The reference-sample availability counts are the
 // m_neighborSize[] values IntraPrediction::xFillReferenceSamples derives by walking the CU/TU tree (IntraPrediction.cpp:1104-1139);
 // that walk is host glue here (vvr_prepare), the kernel only consumes the counts.
-struct IntraItem {
-  uint32_t tu;
-  uint8_t  comp;
+#define IT_F_RESI     1
+#define IT_F_BDPCM_H  2
+#define IT_F_BDPCM_V  4      /* bits 4..5: multi-reference-line index */
+struct IntraItem {        // 16 bytes, self-contained: the kernel never touches the CU/TU records on its serial path
+  uint16_t x, y;          // block position in the component plane
+  uint8_t  lw, lh;        // log2 size
+  uint8_t  mode;          // 0 planar, 1 DC, 2..66 angular (before the wide-angle remap)
+  uint8_t  flags;         // IT_F_*
   uint8_t  nTL, nA, nL;   // available units (4 luma samples): top-left (0/1), above incl. above-right, left incl. below-left
-  uint8_t  hasResi;
-  uint8_t  pad[3];
+  uint8_t  comp;
+  uint32_t tu;
 };
 
 struct PicDev {         // everything a kernel needs about one picture (passed by value)

@@ -1035,12 +1035,17 @@ void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst )
 #define IT_TS   ( IT_PADX + 128 + IT_RIGHT + 8 )     // LDS row stride in samples (16-byte multiple)
 #define IT_MAXREF ( 2 * 64 + 8 )
 
+#define IT_BATCH 64         // IntraItems staged in LDS at a time (64 x 16 B: one dword per thread)
+
 struct IntraShared {
   pel_t tile[( 128 + IT_PAD ) * IT_TS];
   pel_t top[IT_MAXREF + 8], left[IT_MAXREF + 8], ftop[IT_MAXREF + 8], fleft[IT_MAXREF + 8];
-  pel_t refA[2 * 64 + 3 + 99 + 64], refL[2 * 64 + 3 + 99 + 64];
+  IntraItem items[IT_BATCH];
+  int16_t resi[2][64 * 64];                            // residual of the current / next block (prefetched one block ahead)
+  int16_t angTab[32], invAngTab[32], cfilt[32][4];     // the small ROM tables the serial per-block path indexes: LDS latency instead of a memory round trip each
+  uint8_t filtThr[8];
   int   ticket;
-  int   dcSum;
+  int   dcSum[2];
 };
 
 __constant__ uint8_t c_intraFilterThr[8] = { 24, 24, 24, 14, 2, 0, 0, 0 };
@@ -1049,42 +1054,99 @@ __constant__ int16_t c_invAngTable[32] = { 0, 16384, 8192, 5461, 4096, 2731, 204
 
 __device__ __forceinline__ int intra_wide_angle( int w, int h, int mode )   // IntraPrediction::getWideAngle (:443)
 {
-  const int modeShift[6] = { 0, 6, 10, 12, 14, 15 };
   if( mode > 1 && mode <= 66 )
   {
     const int d = iabs( ilog2( w ) - ilog2( h ) );
-    if( w > h && mode < 2 + modeShift[d] ) mode += 65;
-    else if( h > w && mode > 66 - modeShift[d] ) mode -= 65;
+    const int modeShift = (int) ( ( 0x0F0E0C0A0600ull >> ( 8 * d ) ) & 0xff );      // { 0, 6, 10, 12, 14, 15 }
+    if( w > h && mode < 2 + modeShift ) mode += 65;
+    else if( h > w && mode > 66 - modeShift ) mode -= 65;
   }
   return mode;
 }
 
+#define IT_MAXR 16          // residual samples a lane holds for one block (64x64 / 256 threads)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding vector-memory operation
+// (vmcnt(0)), which would put an HBM/L2 round trip on the serial block-to-block path of k_intra; the samples the next block
+// reads come from the LDS tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile( "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory" ); }
+
+// Residual of one block: global -> registers (issued one block ahead of its use) -> LDS.  The loads are unconditional
+// (index clamped) and the count is a template parameter, so no load sits behind a divergent branch and the only thing in
+// flight on the vector-memory counter during the serial block loop is this prefetch (stores are deferred to the end of the CTU).
+template<int NL> __device__ __forceinline__ void intra_fetch_n( const IntraItem& it, const pel_t* __restrict__ rs, int rstride, int tid, int ( &r )[IT_MAXR] )
+{
+  const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
+#pragma unroll
+  for( int n = 0; n < NL; n++ )
+  {
+    const int i = min( tid + n * 256, wh - 1 );
+    r[n] = rs[(size_t) ( it.y + ( i >> lw ) ) * rstride + it.x + ( i & ( ( 1 << lw ) - 1 ) )];
+  }
+}
+template<int NL> __device__ __forceinline__ void intra_stash_n( const IntraItem& it, int16_t* __restrict__ dst, int tid, const int ( &r )[IT_MAXR] )
+{
+  const int wh = 1 << ( it.lw + it.lh );
+#pragma unroll
+  for( int n = 0; n < NL; n++ ) { const int i = tid + n * 256; if( i < wh ) dst[i] = (int16_t) r[n]; }
+}
+__device__ __forceinline__ void intra_fetch_resi( const IntraItem& it, const pel_t* __restrict__ rs, int rstride, int tid, int ( &r )[IT_MAXR] )
+{
+  if( !( it.flags & IT_F_RESI ) ) return;
+  switch( ( it.lw + it.lh ) > 8 ? it.lw + it.lh - 8 : 0 )
+  {
+    case 0:  intra_fetch_n<1>( it, rs, rstride, tid, r ); break;
+    case 1:  intra_fetch_n<2>( it, rs, rstride, tid, r ); break;
+    case 2:  intra_fetch_n<4>( it, rs, rstride, tid, r ); break;
+    case 3:  intra_fetch_n<8>( it, rs, rstride, tid, r ); break;
+    default: intra_fetch_n<16>( it, rs, rstride, tid, r ); break;
+  }
+}
+__device__ __forceinline__ void intra_stash_resi( const IntraItem& it, int16_t* __restrict__ dst, int tid, const int ( &r )[IT_MAXR] )
+{
+  if( !( it.flags & IT_F_RESI ) ) return;
+  switch( ( it.lw + it.lh ) > 8 ? it.lw + it.lh - 8 : 0 )
+  {
+    case 0:  intra_stash_n<1>( it, dst, tid, r ); break;
+    case 1:  intra_stash_n<2>( it, dst, tid, r ); break;
+    case 2:  intra_stash_n<4>( it, dst, tid, r ); break;
+    case 3:  intra_stash_n<8>( it, dst, tid, r ); break;
+    default: intra_stash_n<16>( it, dst, tid, r ); break;
+  }
+}
+
 __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, DevPlanes resi, const IntraItem* __restrict__ items,
                                                   const uint32_t* __restrict__ ctuStart /* [3][numCtu+1] */, const uint32_t* __restrict__ active /* [numActive] entries, then [numActive] dependency masks */, int numActive,
-                                                  int* __restrict__ sync /* [0]: ticket, [1 + comp*numCtu + ctu]: done flags */ )
+                                                  int* __restrict__ sync /* [0]: ticket, [1 + comp*numCtu + ctu]: done flags */, int dbg )
 {
   __shared__ IntraShared sh;
   const int tid = threadIdx.x;
   const int numCtu = pic.ctus_x * pic.ctus_y;
-  if( tid == 0 ) sh.ticket = atomicAdd( &sync[0], 1 );
+  if( tid == 0 ) { sh.ticket = atomicAdd( &sync[0], 1 ); sh.dcSum[0] = sh.dcSum[1] = 0; }
+  if( tid < 32 ) { sh.angTab[tid] = c_angTable[tid]; sh.invAngTab[tid] = c_invAngTable[tid]; }
+  if( tid < 8 ) sh.filtThr[tid] = c_intraFilterThr[tid];
+  if( tid < 128 ) sh.cfilt[tid >> 2][tid & 3] = d_chroma_filter[tid >> 2][tid & 3];
   __syncthreads();
   const int ticket = sh.ticket;
   if( ticket >= numActive ) return;
   const uint32_t ent = active[ticket];
-  const int comp = ent >> 24, ctu = ent & 0xffffff;
+  const int comp = ( ent >> 24 ) & 3, ctu = ent & 0xffffff;
+  const bool borderOnly = ( ent >> 31 ) != 0;          // every sample of the CTU is intra: the interior is produced here, never read first
   const int cxI = ctu % pic.ctus_x, cyI = ctu / pic.ctus_x;
-  const int cs = comp ? 1 : 0, ch = comp ? 1 : 0;
+  const int cs = comp ? 1 : 0;
   const int S = ( 1 << pic.hdr.log2_ctu ) >> cs;
   const int ox = cxI * S, oy = cyI * S;
   const int bd = pic.hdr.bit_depth;
   const int PW = reco.w[comp], PH = reco.h[comp], pstride = reco.stride[comp];
   pel_t* __restrict__ plane = reco.p[comp];
+  const pel_t* __restrict__ rs = resi.p[comp];
+  const int rstride = resi.stride[comp];
+  const uint32_t i0 = ctuStart[comp * ( numCtu + 1 ) + ctu], i1 = ctuStart[comp * ( numCtu + 1 ) + ctu + 1];
 #define TILE( x, y ) sh.tile[( ( y ) - oy + IT_PAD ) * IT_TS + ( ( x ) - ox + IT_PADX )]
-  // ---- wait for the CTUs this one reads from: left, above-left, above, above-right (only those that have intra blocks of this component)
+  // ---- wait for the CTUs this one reads INTRA samples from (the host glue marks which of L, AL, A, AR those are)
   if( tid == 0 )
   {
-    // the host glue marks which of the four neighbours actually contain intra samples this CTU's blocks read
-    const uint32_t depMask = active[numActive + ticket];
+    const uint32_t depMask = ( dbg & 1 ) ? 0 : active[numActive + ticket];
     const int nb[4][2] = { { -1, 0 }, { -1, -1 }, { 0, -1 }, { 1, -1 } };
     for( int k = 0; k < 4; k++ )
     {
@@ -1092,243 +1154,299 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int nx = cxI + nb[k][0], ny = cyI + nb[k][1];
       const int n = ny * pic.ctus_x + nx;
       int* flag = &sync[1 + comp * numCtu + n];
-      while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 2 );
+      while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 30 );
     }
     __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );
   }
   __syncthreads();
-  // ---- stage the CTU and its reference border in LDS
+  // ---- stage the needed part of the CTU and its reference border in LDS
   {
     // 16-byte chunks (8 samples); plane rows are 128-byte aligned and padded to a multiple of 64 samples, so a chunk that
-    // straddles the picture's right edge stays inside the row allocation (those samples are never used)
+    // straddles the picture's right edge stays inside the row allocation (those samples are never used).
+    // bbox (host glue): rows / chunks that hold reference samples of this CTU's blocks, relative to (oy - IT_PAD, ox - IT_PADX)
+    const uint32_t bb = active[2 * numActive + ticket];
     const int y0 = max( 0, oy - IT_PAD ), y1 = min( PH, oy + S );
     const int c0 = ox >= IT_PADX ? -1 : 0;                                  // first chunk relative to ox / 8
     const int c1 = ( min( PW, ox + S + IT_RIGHT ) - ox + 7 ) >> 3;           // one past the last chunk
-    const int nch = c1 - c0;
-    for( int i = tid; i < nch * ( y1 - y0 ); i += 256 )
+    const int by0 = max( y0, oy - IT_PAD + (int) ( bb & 0xff ) ), by1 = min( y1, oy - IT_PAD + (int) ( ( bb >> 8 ) & 0xff ) );
+    const int bc0 = max( c0, (int) ( ( bb >> 16 ) & 0xff ) - 1 ), bc1 = min( c1, (int) ( bb >> 24 ) - 1 );
+    const int nch = bc1 - bc0;
+    const int nTop = nch * max( 0, min( by1, oy ) - by0 );                   // chunks in the rows above the CTU
+    const int rowsIn = max( 0, by1 - max( by0, oy ) );
+    const int total = ( dbg & 2 ) ? 0 : borderOnly ? nTop + ( bc0 < 0 ? rowsIn : 0 ) : nch * ( by1 - by0 );
+    for( int base = 0; base < total; base += 256 * 4 )
     {
-      const int r = i / nch, cidx = c0 + ( i - r * nch );
-      const int y = y0 + r, x = ox + cidx * 8;
-      const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
-      *reinterpret_cast<uint4*>( &TILE( x, y ) ) = v;
+      // four 16-byte loads in flight per lane; the tail repeats the last chunk (same data to the same place) instead of branching
+      uint4 v0, v1, v2, v3; int o0, o1, o2, o3;
+#define IT_LD( V, O, U ) { const int i = min( base + U * 256 + tid, total - 1 ); int r, cidx; \
+        if( !borderOnly || i < nTop ) { r = i / nch; cidx = bc0 + ( i - r * nch ); } else { r = ( max( by0, oy ) - by0 ) + ( i - nTop ); cidx = -1; } \
+        const int y = by0 + r, x = ox + cidx * 8; V = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] ); O = ( y - oy + IT_PAD ) * IT_TS + ( x - ox + IT_PADX ); }
+      IT_LD( v0, o0, 0 ) IT_LD( v1, o1, 1 ) IT_LD( v2, o2, 2 ) IT_LD( v3, o3, 3 )
+#undef IT_LD
+      *reinterpret_cast<uint4*>( &sh.tile[o0] ) = v0; *reinterpret_cast<uint4*>( &sh.tile[o1] ) = v1;
+      *reinterpret_cast<uint4*>( &sh.tile[o2] ) = v2; *reinterpret_cast<uint4*>( &sh.tile[o3] ) = v3;
     }
   }
-  __syncthreads();
-  const uint32_t i0 = ctuStart[comp * ( numCtu + 1 ) + ctu], i1 = ctuStart[comp * ( numCtu + 1 ) + ctu + 1];
-  for( uint32_t ii = i0; ii < i1; ii++ )
+  int rnext[IT_MAXR];
+  lds_barrier();
+  for( uint32_t b0 = i0; b0 < ( ( dbg & 4 ) ? i0 : i1 ); b0 += IT_BATCH )
   {
-    const IntraItem it = items[ii];
-    const vvr_tu& tu = pic.tu[it.tu];
-    const vvr_cu& cu = pic.cu[tu.cu];
-    const int x0 = tu.x >> cs, y0 = tu.y >> cs, w = tu.w >> cs, h = tu.h >> cs;
-    const int mrl = comp ? 0 : cu.multi_ref_idx;
-    const int bdpcm = comp ? cu.bdpcm[1] : cu.bdpcm[0];
-    const int dirMode = cu.intra_dir[ch];
-    const int topLen = 2 * w, leftLen = 2 * h;
-    const int unit = 4 >> cs;
-    const int totalAbove = ( topLen + unit - 1 ) / unit, totalLeft = ( leftLen + unit - 1 ) / unit;
-    const int nTL = it.nTL, nA = it.nA, nL = it.nL;
-    const int nAll = nTL + nA + nL, total = totalAbove + totalLeft + 1;
-    // ---- xFillReferenceSamples: one lane per reference position
+    const int nb = (int) min( (uint32_t) IT_BATCH, i1 - b0 );
+    lds_barrier();                                  // previous batch fully consumed (and, first time, the tile is staged)
+    if( tid < nb * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = reinterpret_cast<const uint32_t*>( items + b0 )[tid];
+    lds_barrier();
+    intra_fetch_resi( sh.items[0], rs, rstride, tid, rnext );
+    intra_stash_resi( sh.items[0], sh.resi[0], tid, rnext );
+    for( int k = 0; k < nb; k++ )
     {
-      const int dcv = 1 << ( bd - 1 );
-      const int n = max( topLen, leftLen ) + mrl + 1;
-      for( int j = tid; j < n; j += 256 )
+      const IntraItem it = sh.items[k];
+      const int16_t* __restrict__ rcur = sh.resi[k & 1];
+      if( k + 1 < nb ) intra_fetch_resi( sh.items[k + 1], rs, rstride, tid, rnext );     // in flight while this block is predicted
+      const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
+      const int mrl = it.flags >> 4;
+      const int bdpcm = ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
+      const int dirMode = it.mode;
+      const bool hasResi = ( it.flags & IT_F_RESI ) != 0;
+      const int topLen = 2 * w, leftLen = 2 * h;
+      const int unit = 4 >> cs;
+      const int totalAbove = ( topLen + unit - 1 ) / unit, totalLeft = ( leftLen + unit - 1 ) / unit;
+      const int nTL = it.nTL, nA = it.nA, nL = it.nL;
+      const int nAll = nTL + nA + nL, total = totalAbove + totalLeft + 1;
+      const bool isDc = !bdpcm && dirMode == 1;
+      int* dcAcc = &sh.dcSum[k & 1];
+      // ---- xFillReferenceSamples: one lane per reference position (+ the DC sum while the values are in registers)
       {
-        int tv = dcv, lv = dcv;
-        if( nAll == 0 ) {}
-        else if( nAll == total )
+        const int dcv = 1 << ( bd - 1 );
+        const int n = max( topLen, leftLen ) + mrl + 1;
+        if( tid < ( ( n + 63 ) & ~63 ) )
         {
-          if( j <= topLen + mrl ) tv = TILE( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) );
-          if( j <= leftLen + mrl ) lv = j == 0 ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) ) : TILE( x0 - ( 1 + mrl ), y0 - mrl + ( j - 1 ) );
-        }
-        else if( nL > 0 )
-        {
-          const int szL = min( nL * unit, leftLen ), szA = min( nA * unit, topLen );
-          const int tpad = TILE( x0 - ( 1 + mrl ), y0 );
-          // left line
-          if( j == 0 ) lv = nTL ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) ) : tpad;
-          else if( j <= mrl ) lv = nTL ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) + j ) : tpad;
-          else if( j <= leftLen + mrl ) { const int i = j - 1 - mrl; lv = TILE( x0 - ( 1 + mrl ), y0 + min( i, szL - 1 ) ); }
-          // top line
-          if( j <= mrl ) tv = nTL ? TILE( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) ) : tpad;
-          else if( j <= topLen + mrl )
+          const int j = tid;
+          int tv = dcv, lv = dcv;
+          if( j < n )
           {
-            const int i = j - 1 - mrl;
-            if( nA ) tv = TILE( x0 + min( i, szA - 1 ), y0 - ( 1 + mrl ) );
-            else     tv = nTL ? TILE( x0 - 1, y0 - ( 1 + mrl ) ) : tpad;      // = top[mrl]
-          }
-        }
-        else
-        {
-          const int szA = min( nA * unit, topLen );
-          const int t = TILE( x0, y0 - ( 1 + mrl ) );
-          lv = t;
-          if( j <= mrl ) tv = t;
-          else if( j <= topLen + mrl ) tv = TILE( x0 + min( j - 1 - mrl, szA - 1 ), y0 - ( 1 + mrl ) );
-        }
-        if( j <= topLen + mrl ) sh.top[j] = (pel_t) tv;
-        if( j <= leftLen + mrl ) sh.left[j] = (pel_t) lv;
-      }
-    }
-    __syncthreads();
-    // ---- reference smoothing
-    bool useFilt = false;
-    if( !comp && !mrl && !cu.bdpcm[0] && dirMode != 1 )
-    {
-      if( dirMode == 0 ) useFilt = w * h > 32;
-      else
-      {
-        const int pm = intra_wide_angle( w, h, dirMode );
-        const int diff = min( iabs( pm - 18 ), iabs( pm - 50 ) );
-        const int l2 = ( ilog2( w ) + ilog2( h ) ) >> 1;
-        const int am = pm >= 34 ? pm - 50 : -( pm - 18 );
-        useFilt = diff > c_intraFilterThr[l2] && ( ( c_angTable[iabs( am )] & 0x1F ) == 0 );
-      }
-    }
-    if( useFilt )
-    {
-      for( int j = tid; j <= max( topLen, leftLen ); j += 256 )
-      {
-        if( j == 0 ) { const int v = ( sh.left[1] + 2 * sh.top[0] + sh.top[1] + 2 ) >> 2; sh.ftop[0] = sh.fleft[0] = (pel_t) v; }
-        else
-        {
-          if( j < topLen ) sh.ftop[j] = (pel_t) ( ( sh.top[j + 1] + 2 * sh.top[j] + sh.top[j - 1] + 2 ) >> 2 ); else if( j == topLen ) sh.ftop[j] = sh.top[j];
-          if( j < leftLen ) sh.fleft[j] = (pel_t) ( ( sh.left[j + 1] + 2 * sh.left[j] + sh.left[j - 1] + 2 ) >> 2 ); else if( j == leftLen ) sh.fleft[j] = sh.left[j];
-        }
-      }
-      __syncthreads();
-    }
-    const pel_t* T = useFilt ? sh.ftop : sh.top;
-    const pel_t* L = useFilt ? sh.fleft : sh.left;
-    const bool pdpcOK = ( w >= 4 && h >= 4 ) && mrl == 0;
-    const pel_t* __restrict__ rs = resi.p[comp];
-    const int rstride = resi.stride[comp];
-    const int lw = ilog2( w ), lh = ilog2( h );
-    // ---- mode-specific set-up
-    int predMode = 0, angle = 0, invAngle = 0, absAng = 0; bool isVer = true;
-    pel_t* refMain = nullptr; pel_t* refSide = nullptr;
-    int dcVal = 0;
-    const bool angular = !bdpcm && dirMode > 1;
-    if( !bdpcm && dirMode == 1 )
-    {
-      if( tid == 0 ) sh.dcSum = 0;
-      __syncthreads();
-      int part = 0;
-      if( w >= h ) for( int i = tid; i < w; i += 256 ) part += T[mrl + 1 + i];
-      if( w <= h ) for( int i = tid; i < h; i += 256 ) part += L[mrl + 1 + i];
-      if( part ) atomicAdd( &sh.dcSum, part );
-      __syncthreads();
-      const int denom = w == h ? w << 1 : max( w, h );
-      dcVal = ( sh.dcSum + ( denom >> 1 ) ) >> ilog2( denom );
-    }
-    else if( angular )
-    {
-      predMode = intra_wide_angle( w, h, dirMode );
-      isVer = predMode >= 34;
-      const int am = isVer ? predMode - 50 : -( predMode - 18 );
-      invAngle = c_invAngTable[iabs( am )]; absAng = c_angTable[iabs( am )]; angle = am < 0 ? -absAng : absAng;
-      if( angle < 0 )
-      {
-        pel_t* ra = sh.refA + 64; pel_t* rl = sh.refL + 64;       // room for the projected samples at negative indices
-        for( int j = tid; j <= max( w, h ) + 1 + mrl; j += 256 ) { if( j <= w + 1 + mrl ) ra[j] = T[j]; if( j <= h + 1 + mrl ) rl[j] = L[j]; }
-        __syncthreads();
-        refMain = isVer ? ra : rl; refSide = isVer ? rl : ra;
-        const int sizeSide = isVer ? h : w;
-        for( int k = tid + 1; k <= sizeSide; k += 256 ) refMain[-k] = refSide[min( ( k * invAngle + 256 ) >> 9, sizeSide )];
-      }
-      else
-      {
-        const int l2r = lw - lh;
-        const int s = max( 0, isVer ? l2r : -l2r );
-        const int maxIndex = ( mrl << s ) + 2;
-        const int refLength = isVer ? topLen : leftLen;
-        for( int j = tid; j <= max( topLen, leftLen ) + mrl; j += 256 ) { if( j <= topLen + mrl ) sh.refA[j] = T[j]; if( j <= leftLen + mrl ) sh.refL[j] = L[j]; }
-        __syncthreads();
-        refMain = isVer ? sh.refA : sh.refL; refSide = isVer ? sh.refL : sh.refA;
-        if( tid < maxIndex ) refMain[refLength + mrl + 1 + tid] = ( isVer ? T : L )[refLength + mrl];
-      }
-      __syncthreads();
-      refMain += mrl; refSide += mrl;
-    }
-    // ---- prediction + reconstruction, one sample per lane-iteration
-    const int bw = isVer ? w : h, bh = isVer ? h : w;       // angular modes predict in the transposed domain for horizontal modes
-    bool cubic = false, doAngPdpc = false; int angScale = 0;
-    if( angular )
-    {
-      if( !comp )
-      {
-        const int diff = min( iabs( predMode - 18 ), iabs( predMode - 50 ) );
-        const int l2 = ( ilog2( bw ) + ilog2( bh ) ) >> 1;
-        cubic = !( diff > c_intraFilterThr[l2] ) || mrl > 0;
-      }
-      if( angle > 0 )
-      {
-        const int sideSize = predMode >= 34 ? h : w;
-        angScale = min( 2, ilog2( sideSize ) - ( ilog2( 3 * invAngle - 2 ) - 8 ) );
-        doAngPdpc = pdpcOK && angScale >= 0;
-      }
-    }
-    const int pscale = ( lw - 2 + lh - 2 + 2 ) >> 2;
-    for( int i = tid; i < w * h; i += 256 )
-    {
-      const int x = i & ( w - 1 ), y = i >> lw;
-      int v;
-      if( bdpcm ) v = bdpcm == 1 ? L[y + 1] : T[x + 1];
-      else if( dirMode == 0 )
-      {
-        const int hor = ( L[y + 1] << lw ) + ( x + 1 ) * ( T[w + 1] - L[y + 1] );
-        const int ver = ( T[x + 1] << lh ) + ( y + 1 ) * ( L[h + 1] - T[x + 1] );
-        v = (int16_t) ( ( ( hor << lh ) + ( ver << lw ) + ( 1 << ( lw + lh ) ) ) >> ( 1 + lw + lh ) );
-      }
-      else if( dirMode == 1 ) v = dcVal;
-      else
-      {
-        const int xx = isVer ? x : y, yy = isVer ? y : x;      // position in the (possibly transposed) prediction block
-        if( angle == 0 )
-        {
-          if( pdpcOK )
-          {
-            const int lev = min( pscale == 0 ? 3 : pscale == 1 ? 6 : pscale == 2 ? 12 : 24, bw );
-            if( xx < lev ) { const int wL = 32 >> min( 31, ( xx << 1 ) >> pscale ); v = clip_pel( ( wL * ( refSide[yy + 1] - T[0] ) + ( refMain[xx + 1] << 6 ) + 32 ) >> 6, bd ); }
-            else v = refMain[xx + 1];
-          }
-          else v = refMain[xx + 1];
-        }
-        else
-        {
-          const int deltaPos = angle * ( 1 + mrl ) + yy * angle;
-          const int di = deltaPos >> 5, df = deltaPos & 31;
-          if( absAng & 0x1F )
-          {
-            if( !comp )
+            if( nAll == 0 ) {}
+            else if( nAll == total )
             {
-              const int k = di + 1 + xx;
-              if( cubic ) { const int16_t* f = d_chroma_filter[df]; v = (int16_t) ( ( f[0] * refMain[k - 1] + f[1] * refMain[k] + f[2] * refMain[k + 1] + f[3] * refMain[k + 2] + 32 ) >> 6 ); v = clip_pel( v, bd ); }
-              else { const int g0 = 16 - ( df >> 1 ), g1 = 32 - ( df >> 1 ), g2 = 16 + ( df >> 1 ), g3 = df >> 1;     // g_intraGaussFilter (:96)
-                     v = (int16_t) ( ( g0 * refMain[k - 1] + g1 * refMain[k] + g2 * refMain[k + 1] + g3 * refMain[k + 2] + 32 ) >> 6 ); }
+              if( j <= topLen + mrl ) tv = TILE( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) );
+              if( j <= leftLen + mrl ) lv = j == 0 ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) ) : TILE( x0 - ( 1 + mrl ), y0 - mrl + ( j - 1 ) );
             }
-            else v = (int16_t) ( ( ( 32 - df ) * refMain[xx + di + 1] + df * refMain[xx + di + 2] + 16 ) >> 5 );
+            else if( nL > 0 )
+            {
+              const int szL = min( nL * unit, leftLen ), szA = min( nA * unit, topLen );
+              const int tpad = TILE( x0 - ( 1 + mrl ), y0 );
+              // left line
+              if( j == 0 ) lv = nTL ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) ) : tpad;
+              else if( j <= mrl ) lv = nTL ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) + j ) : tpad;
+              else if( j <= leftLen + mrl ) { const int i = j - 1 - mrl; lv = TILE( x0 - ( 1 + mrl ), y0 + min( i, szL - 1 ) ); }
+              // top line
+              if( j <= mrl ) tv = nTL ? TILE( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) ) : tpad;
+              else if( j <= topLen + mrl )
+              {
+                const int i = j - 1 - mrl;
+                if( nA ) tv = TILE( x0 + min( i, szA - 1 ), y0 - ( 1 + mrl ) );
+                else     tv = nTL ? TILE( x0 - 1, y0 - ( 1 + mrl ) ) : tpad;      // = top[mrl]
+              }
+            }
+            else
+            {
+              const int szA = min( nA * unit, topLen );
+              const int t = TILE( x0, y0 - ( 1 + mrl ) );
+              lv = t;
+              if( j <= mrl ) tv = t;
+              else if( j <= topLen + mrl ) tv = TILE( x0 + min( j - 1 - mrl, szA - 1 ), y0 - ( 1 + mrl ) );
+            }
+            if( j <= topLen + mrl ) sh.top[j] = (pel_t) tv;
+            if( j <= leftLen + mrl ) sh.left[j] = (pel_t) lv;
           }
-          else v = refMain[di + 1 + xx];
-          if( doAngPdpc && xx < min( 3 << angScale, bw ) )
+          if( isDc )
           {
-            const int invAngleSum = 256 + ( xx + 1 ) * invAngle;
-            const int wL = 32 >> ( 2 * xx >> angScale );
-            v = (int16_t) ( v + ( ( wL * ( refSide[yy + ( invAngleSum >> 9 ) + 1] - v ) + 32 ) >> 6 ) );
+            int part = 0;
+            if( j < n && j > mrl )
+            {
+              if( w >= h && j <= mrl + w ) part += tv;
+              if( w <= h && j <= mrl + h ) part += lv;
+            }
+            for( int o = 32; o; o >>= 1 ) part += __shfl_down( part, o );
+            if( ( tid & 63 ) == 0 && part ) atomicAdd( dcAcc, part );
           }
         }
+        if( tid == 255 ) sh.dcSum[( k + 1 ) & 1] = 0;
       }
-      if( !bdpcm && pdpcOK && dirMode <= 1 )
+      lds_barrier();
+      // ---- reference smoothing
+      bool useFilt = false;
+      if( !comp && !mrl && !bdpcm && dirMode != 1 )
       {
-        const int wT = 32 >> min( 31, ( y << 1 ) >> pscale ), wL = 32 >> min( 31, ( x << 1 ) >> pscale );
-        v = (int16_t) ( v + ( ( wL * ( L[y + 1] - v ) + wT * ( T[x + 1] - v ) + 32 ) >> 6 ) );
+        if( dirMode == 0 ) useFilt = w * h > 32;
+        else
+        {
+          const int pm = intra_wide_angle( w, h, dirMode );
+          const int diff = min( iabs( pm - 18 ), iabs( pm - 50 ) );
+          const int l2 = ( lw + lh ) >> 1;
+          const int am = pm >= 34 ? pm - 50 : -( pm - 18 );
+          useFilt = diff > sh.filtThr[l2] && ( ( sh.angTab[iabs( am )] & 0x1F ) == 0 );
+        }
       }
-      if( it.hasResi ) v = clip_pel( v + rs[(size_t) ( y0 + y ) * rstride + x0 + x], bd );
-      TILE( x0 + x, y0 + y ) = (pel_t) v;
-      plane[(size_t) ( y0 + y ) * pstride + x0 + x] = (pel_t) v;
+      if( useFilt )
+      {
+        const int j = tid;
+        if( j <= max( topLen, leftLen ) )
+        {
+          if( j == 0 ) { const int v = ( sh.left[1] + 2 * sh.top[0] + sh.top[1] + 2 ) >> 2; sh.ftop[0] = sh.fleft[0] = (pel_t) v; }
+          else
+          {
+            if( j < topLen ) sh.ftop[j] = (pel_t) ( ( sh.top[j + 1] + 2 * sh.top[j] + sh.top[j - 1] + 2 ) >> 2 ); else if( j == topLen ) sh.ftop[j] = sh.top[j];
+            if( j < leftLen ) sh.fleft[j] = (pel_t) ( ( sh.left[j + 1] + 2 * sh.left[j] + sh.left[j - 1] + 2 ) >> 2 ); else if( j == leftLen ) sh.fleft[j] = sh.left[j];
+          }
+        }
+        lds_barrier();
+      }
+      const pel_t* T = useFilt ? sh.ftop : sh.top;
+      const pel_t* L = useFilt ? sh.fleft : sh.left;
+      const bool pdpcOK = ( w >= 4 && h >= 4 ) && mrl == 0;
+      // ---- mode-specific set-up (uniform scalar work)
+      int predMode = 0, angle = 0, invAngle = 0, absAng = 0; bool isVer = true;
+      int dcVal = 0;
+      const bool angular = !bdpcm && dirMode > 1;
+      if( isDc )
+      {
+        const int denom = w == h ? w << 1 : max( w, h );
+        dcVal = ( *dcAcc + ( denom >> 1 ) ) >> ilog2( denom );
+      }
+      else if( angular )
+      {
+        predMode = intra_wide_angle( w, h, dirMode );
+        isVer = predMode >= 34;
+        const int am = isVer ? predMode - 50 : -( predMode - 18 );
+        invAngle = sh.invAngTab[iabs( am )]; absAng = sh.angTab[iabs( am )]; angle = am < 0 ? -absAng : absAng;
+      }
+      // the main / side reference of xPredIntraAng (:640-690) without staging a copy: index j is relative to the block
+      // (after the multi-reference-line offset); negative indices are the side reference projected with invAngle,
+      // indices beyond the end replicate the last sample
+      const pel_t* Mn = isVer ? T : L;
+      const pel_t* Sd = isVer ? L : T;
+      const int sizeSide = isVer ? h : w;
+      const int refEnd = ( isVer ? topLen : leftLen ) + mrl;
+      auto MAIN = [&]( int j ) -> int
+      {
+        const int jj = j + mrl;
+        if( angle < 0 ) { if( jj >= 0 ) return Mn[jj]; return Sd[min( ( -jj * invAngle + 256 ) >> 9, sizeSide )]; }
+        return Mn[min( jj, refEnd )];
+      };
+      const int bw = isVer ? w : h, bh = isVer ? h : w;       // angular modes predict in the transposed domain for horizontal modes
+      bool cubic = false, doAngPdpc = false; int angScale = 0;
+      if( angular )
+      {
+        if( !comp )
+        {
+          const int diff = min( iabs( predMode - 18 ), iabs( predMode - 50 ) );
+          const int l2 = ( ilog2( bw ) + ilog2( bh ) ) >> 1;
+          cubic = !( diff > sh.filtThr[l2] ) || mrl > 0;
+        }
+        if( angle > 0 )
+        {
+          const int sideSize = predMode >= 34 ? h : w;
+          angScale = min( 2, ilog2( sideSize ) - ( ilog2( 3 * invAngle - 2 ) - 8 ) );
+          doAngPdpc = pdpcOK && angScale >= 0;
+        }
+      }
+      const int pscale = ( lw - 2 + lh - 2 + 2 ) >> 2;
+      const int wh = w * h;
+      // ---- prediction + reconstruction, one sample per lane-iteration
+#pragma unroll 1
+      for( int i = tid; i < ( ( dbg & 8 ) ? 0 : wh ); i += 256 )
+      {
+        const int x = i & ( w - 1 ), y = i >> lw;
+        int v;
+        if( bdpcm ) v = bdpcm == 1 ? L[y + 1] : T[x + 1];
+        else if( dirMode == 0 )
+        {
+          const int hor = ( L[y + 1] << lw ) + ( x + 1 ) * ( T[w + 1] - L[y + 1] );
+          const int ver = ( T[x + 1] << lh ) + ( y + 1 ) * ( L[h + 1] - T[x + 1] );
+          v = (int16_t) ( ( ( hor << lh ) + ( ver << lw ) + ( 1 << ( lw + lh ) ) ) >> ( 1 + lw + lh ) );
+        }
+        else if( dirMode == 1 ) v = dcVal;
+        else
+        {
+          const int xx = isVer ? x : y, yy = isVer ? y : x;      // position in the (possibly transposed) prediction block
+          if( angle == 0 )
+          {
+            v = Mn[xx + 1 + mrl];
+            if( pdpcOK )
+            {
+              const int lev = min( pscale == 0 ? 3 : pscale == 1 ? 6 : pscale == 2 ? 12 : 24, bw );
+              if( xx < lev ) { const int wL = 32 >> min( 31, ( xx << 1 ) >> pscale ); v = clip_pel( ( wL * ( Sd[yy + 1] - T[0] ) + ( v << 6 ) + 32 ) >> 6, bd ); }
+            }
+          }
+          else
+          {
+            const int deltaPos = angle * ( 1 + mrl ) + yy * angle;
+            const int di = deltaPos >> 5, df = deltaPos & 31;
+            if( absAng & 0x1F )
+            {
+              if( !comp )
+              {
+                const int k2 = di + 1 + xx;
+                const int p0 = MAIN( k2 - 1 ), p1 = MAIN( k2 ), p2 = MAIN( k2 + 1 ), p3 = MAIN( k2 + 2 );
+                if( cubic ) { const int16_t* f = sh.cfilt[df]; v = (int16_t) ( ( f[0] * p0 + f[1] * p1 + f[2] * p2 + f[3] * p3 + 32 ) >> 6 ); v = clip_pel( v, bd ); }
+                else { const int g0 = 16 - ( df >> 1 ), g1 = 32 - ( df >> 1 ), g2 = 16 + ( df >> 1 ), g3 = df >> 1;     // g_intraGaussFilter (:96)
+                       v = (int16_t) ( ( g0 * p0 + g1 * p1 + g2 * p2 + g3 * p3 + 32 ) >> 6 ); }
+              }
+              else v = (int16_t) ( ( ( 32 - df ) * MAIN( xx + di + 1 ) + df * MAIN( xx + di + 2 ) + 16 ) >> 5 );
+            }
+            else v = MAIN( di + 1 + xx );
+            if( doAngPdpc && xx < min( 3 << angScale, bw ) )
+            {
+              const int invAngleSum = 256 + ( xx + 1 ) * invAngle;
+              const int wL = 32 >> ( 2 * xx >> angScale );
+              v = (int16_t) ( v + ( ( wL * ( Sd[yy + ( invAngleSum >> 9 ) + 1] - v ) + 32 ) >> 6 ) );
+            }
+          }
+        }
+        if( !bdpcm && pdpcOK && dirMode <= 1 )
+        {
+          const int wT = 32 >> min( 31, ( y << 1 ) >> pscale ), wL = 32 >> min( 31, ( x << 1 ) >> pscale );
+          v = (int16_t) ( v + ( ( wL * ( L[y + 1] - v ) + wT * ( T[x + 1] - v ) + 32 ) >> 6 ) );
+        }
+        if( hasResi ) v = clip_pel( v + rcur[i], bd );
+        TILE( x0 + x, y0 + y ) = (pel_t) v;
+      }
+      if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
+      lds_barrier();
     }
-    __syncthreads();
+  }
+  // ---- write the reconstructed intra samples back to HBM (deferred so that the block loop never waits for a store)
+  if( borderOnly )
+  {
+    const int rows = min( PH, oy + S ) - oy, nch = ( min( PW, ox + S ) - ox + 7 ) >> 3;     // a chunk past the picture edge lands in the row padding
+    for( int i = tid; i < rows * nch; i += 256 )
+    {
+      const int r = i / nch, c = i - r * nch;
+      *reinterpret_cast<uint4*>( &plane[(size_t) ( oy + r ) * pstride + ox + c * 8] ) = *reinterpret_cast<const uint4*>( &TILE( ox + c * 8, oy + r ) );
+    }
+  }
+  else
+  {
+    for( uint32_t b0 = i0; b0 < ( ( dbg & 4 ) ? i0 : i1 ); b0 += IT_BATCH )
+    {
+      const int nb = (int) min( (uint32_t) IT_BATCH, i1 - b0 );
+      if( i1 - i0 > IT_BATCH )       // otherwise the only batch is still in LDS
+      {
+        lds_barrier();
+        if( tid < nb * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = reinterpret_cast<const uint32_t*>( items + b0 )[tid];
+        lds_barrier();
+      }
+      for( int k = 0; k < nb; k++ )
+      {
+        const IntraItem it = sh.items[k];
+        const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
+        for( int i = tid; i < wh; i += 256 )
+        {
+          const int x = it.x + ( i & ( ( 1 << lw ) - 1 ) ), y = it.y + ( i >> lw );
+          plane[(size_t) y * pstride + x] = TILE( x, y );
+        }
+      }
+    }
   }
 #undef TILE
   // ---- publish: all stores of the workgroup drained, one agent-scope release, then the flag
@@ -1347,5 +1465,6 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   if( !numActive ) return;
   const int numCtu = pic.ctus_x * pic.ctus_y;
   hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + 3 * (size_t) numCtu ), s );
-  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, ctuStart, active, numActive, sync );
+  static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
+  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, ctuStart, active, numActive, sync, dbg );
 }
