@@ -85,12 +85,113 @@ static void clip_mv( int mv[2], int x, int y, int W, int H, int ctu )   /* clipM
   mv[1] = vvo_min( verMax, vvo_max( verMin, mv[1] ) );
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * BDOF on one <= 16x16 luma sub-block: InterPrediction::xSubPuBio (InterPrediction.cpp:551) -> xPredInterUni( bi, bioApplied )
+ * -> xPredInterBlk border fill (:863-890, PaddBIOCore :269) -> xWeightedAverage( bioApplied ) (:1349) -> applyBiOptFlow (:1290):
+ * gradFilterCore<true> (:213), BiOptFlowCore (:162), calcBIOSums (:134), rightShiftMSB (:92), addBIOAvg4 (:108).
+ * src[l]: 14-bit predictions of both lists in a (w+8)-stride buffer, block at (row 2, col 1), one-sample border from the
+ * nearest integer reference samples around it. */
+#define BIO_STRIDE_MAX ( 16 + 8 )
+static int bdof_right_shift_msb( int numer, int denom )
+{
+  int msb = 0;
+  for( msb = 0; msb < 32; msb++ ) if( denom < ( 1 << msb ) ) break;
+  return numer >> ( msb - 1 );
+}
+
+static void bdof_border( const vvo_planes* ref, int bx, int by, int w, int h, int mvx, int mvy, int bd, pel* blk /* row 0 of the (w+8)-stride buffer */ )
+{
+  const int S = w + 8;
+  const int shift = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2;
+  const int x0 = bx + ( mvx >> 4 ), y0 = by + ( mvy >> 4 );
+  const int xOff = ( mvx & 15 ) < 8 ? 1 : 0, yOff = ( mvy & 15 ) < 8 ? 1 : 0;
+  for( int r = 0; r < h; r++ )
+  {
+    pel* d = blk + ( 2 + r ) * S;
+    d[0]     = (pel) ( vvo_ref_at( ref, 0, x0 - xOff,         y0 + 1 - yOff + r ) * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
+    d[w + 1] = (pel) ( vvo_ref_at( ref, 0, x0 - xOff + w + 1, y0 + 1 - yOff + r ) * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
+  }
+  for( int i = 0; i < w + 2; i++ )
+  {
+    blk[1 * S + i]         = (pel) ( vvo_ref_at( ref, 0, x0 - xOff + i, y0 - yOff )         * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
+    blk[( h + 2 ) * S + i] = (pel) ( vvo_ref_at( ref, 0, x0 - xOff + i, y0 + h + 1 - yOff ) * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
+  }
+}
+
+static void bdof_apply( pel* blk0, pel* blk1, int w, int h, int bd, pel* dst, int dstStride )
+{
+  const int S = w + 8;                                     /* stridePredMC = widthG = width + BIO_ALIGN_SIZE */
+  pel gx[2][( 16 + 2 ) * BIO_STRIDE_MAX], gy[2][( 16 + 2 ) * BIO_STRIDE_MAX];
+  pel* P[2] = { blk0 + S, blk1 + S };                      /* padded (w+2) x (h+2) region, origin = top border row */
+  for( int l = 0; l < 2; l++ )
+  {
+    pel* s = P[l];
+    for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+    {
+      gy[l][( 1 + y ) * S + 1 + x] = (pel) ( ( s[( 2 + y ) * S + 1 + x] >> 6 ) - ( s[y * S + 1 + x] >> 6 ) );
+      gx[l][( 1 + y ) * S + 1 + x] = (pel) ( ( s[( 1 + y ) * S + 2 + x] >> 6 ) - ( s[( 1 + y ) * S + x] >> 6 ) );
+    }
+    /* padding: gradients AND the prediction border are replaced by replicas of the interior (:236-264) */
+    for( int y = 1; y <= h; y++ )
+    {
+      gx[l][y * S] = gx[l][y * S + 1]; gx[l][y * S + w + 1] = gx[l][y * S + w];
+      gy[l][y * S] = gy[l][y * S + 1]; gy[l][y * S + w + 1] = gy[l][y * S + w];
+      s[y * S] = s[y * S + 1];         s[y * S + w + 1] = s[y * S + w];
+    }
+    memcpy( &gx[l][0], &gx[l][S], sizeof( pel ) * ( w + 2 ) ); memcpy( &gx[l][( h + 1 ) * S], &gx[l][h * S], sizeof( pel ) * ( w + 2 ) );
+    memcpy( &gy[l][0], &gy[l][S], sizeof( pel ) * ( w + 2 ) ); memcpy( &gy[l][( h + 1 ) * S], &gy[l][h * S], sizeof( pel ) * ( w + 2 ) );
+    memcpy( &s[0], &s[S], sizeof( pel ) * ( w + 2 ) );         memcpy( &s[( h + 1 ) * S], &s[h * S], sizeof( pel ) * ( w + 2 ) );
+  }
+  const int shiftNum = IF_INTERNAL_PREC + 1 - bd, offset = ( 1 << ( shiftNum - 1 ) ) + 2 * IF_INTERNAL_OFFS, limit = 15;
+  for( int yu = 0; yu < h >> 2; yu++ ) for( int xu = 0; xu < w >> 2; xu++ )
+  {
+    int sumAbsGX = 0, sumAbsGY = 0, sumDIX = 0, sumDIY = 0, sumSignGY_GX = 0;
+    for( int y = 0; y < 6; y++ ) for( int x = 0; x < 6; x++ )
+    {
+      const int o = ( ( yu << 2 ) + y ) * S + ( xu << 2 ) + x;
+      const int tGX = ( gx[0][o] + gx[1][o] ) >> 1, tGY = ( gy[0][o] + gy[1][o] ) >> 1;
+      const int tDI = ( P[1][o] >> 4 ) - ( P[0][o] >> 4 );
+      sumAbsGX += vvo_abs( tGX ); sumAbsGY += vvo_abs( tGY );
+      sumDIX += tGX < 0 ? -tDI : tGX == 0 ? 0 : tDI;
+      sumDIY += tGY < 0 ? -tDI : tGY == 0 ? 0 : tDI;
+      sumSignGY_GX += tGY < 0 ? -tGX : tGY == 0 ? 0 : tGX;
+    }
+    int tmpx = sumAbsGX == 0 ? 0 : bdof_right_shift_msb( sumDIX * 4, sumAbsGX );
+    tmpx = vvo_clip3( -limit, limit, tmpx );
+    const int mains = sumSignGY_GX >> 12, secs = sumSignGY_GX & ( ( 1 << 12 ) - 1 );
+    int tmpData = tmpx * mains;
+    tmpData = ( ( tmpData * ( 1 << 12 ) ) + tmpx * secs ) >> 1;
+    int tmpy = sumAbsGY == 0 ? 0 : bdof_right_shift_msb( ( sumDIY * 4 ) - tmpData, sumAbsGY );
+    tmpy = vvo_clip3( -limit, limit, tmpy );
+    for( int y = 0; y < 4; y++ ) for( int x = 0; x < 4; x++ )
+    {
+      const int o = ( 1 + ( yu << 2 ) + y ) * S + 1 + ( xu << 2 ) + x;
+      const int b = tmpx * ( gx[0][o] - gx[1][o] ) + tmpy * ( gy[0][o] - gy[1][o] );
+      dst[( ( yu << 2 ) + y ) * dstStride + ( xu << 2 ) + x] = (pel) vvo_clip_pel( (int16_t) ( ( P[0][o] + P[1][o] + b + offset ) >> shiftNum ), bd );
+    }
+  }
+}
+
+/* luma of one bi-predicted sub-block with BDOF; mv[l] already clipped against the CU (xPredInterUni :655-658) */
+static void bdof_luma_subblock( const vvo_planes* ref0, const vvo_planes* ref1, int bx, int by, int w, int h, const int mv0[2], const int mv1[2],
+                                int altHpel, int bd, pel* dst, int dstStride )
+{
+  pel blk[2][( 16 + 4 ) * BIO_STRIDE_MAX];
+  const int S = w + 8;
+  memset( blk, 0, sizeof( blk ) );
+  pred_block( ref0, 0, bx, by, w, h, mv0[0], mv0[1], 1, altHpel, bd, blk[0] + 2 * S + 1, S );
+  pred_block( ref1, 0, bx, by, w, h, mv1[0], mv1[1], 1, altHpel, bd, blk[1] + 2 * S + 1, S );
+  bdof_border( ref0, bx, by, w, h, mv0[0], mv0[1], bd, blk[0] );
+  bdof_border( ref1, bx, by, w, h, mv1[0], mv1[1], bd, blk[1] );
+  bdof_apply( blk[0], blk[1], w, h, bd, dst, dstStride );
+}
+
 int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* refs, int num_slots, vvo_planes* reco )
 {
   const vvr_pic_header* H = &pic->hdr;
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu;
   const int ncomp = H->chroma_format ? 3 : 1;
-  if( cu->mc_mode != VVR_MC_UNI && cu->mc_mode != VVR_MC_BI ) { vvo_set_error( "inter mode not restated yet" ); return -1; }
+  if( cu->mc_mode != VVR_MC_UNI && cu->mc_mode != VVR_MC_BI && cu->mc_mode != VVR_MC_BDOF ) { vvo_set_error( "inter mode not restated yet" ); return -1; }
   const int altHpel = cu->imv == 3;
   const int biPred = cu->ref_idx[0] >= 0 && cu->ref_idx[1] >= 0;
   for( int c = 0; c < ncomp; c++ )
@@ -119,7 +220,16 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
         if( slot < 0 || slot >= num_slots || !refs[slot].p[0] ) { free( t0 ); vvo_set_error( "missing reference slot" ); return -1; }
         pred_block( &refs[slot], c, bx, by, w, h, mv[0], mv[1], 1, altHpel, bd, l ? t1 : t0, w );
       }
-      if( cu->bcw_idx != 2 )
+      if( c == 0 && cu->mc_mode == VVR_MC_BDOF )
+      {   /* xSubPuBio (:551): sub-blocks of at most 16x16 (MAX_BDOF_APPLICATION_REGION), each with its own border fetch */
+        int mv0[2] = { cu->mv[0][0][0], cu->mv[0][0][1] }, mv1[2] = { cu->mv[1][0][0], cu->mv[1][0][1] };
+        clip_mv( mv0, cu->x, cu->y, H->width, H->height, ctu ); clip_mv( mv1, cu->x, cu->y, H->width, H->height, ctu );
+        const int sw = vvo_min( 16, w ), shh = vvo_min( 16, h );
+        for( int y = 0; y < h; y += shh ) for( int x = 0; x < w; x += sw )
+          bdof_luma_subblock( &refs[H->ref_slot[0][cu->ref_idx[0]]], &refs[H->ref_slot[1][cu->ref_idx[1]]], bx + x, by + y, sw, shh, mv0, mv1, altHpel, bd,
+                              dst + (size_t) y * reco->stride[c] + x, reco->stride[c] );
+      }
+      else if( cu->bcw_idx != 2 )
       {   /* addWeightedAvg (Buffer.cpp:372): BCW */
         const int w1 = vvc_bcw_weights[cu->bcw_idx], w0 = 8 - w1;
         const int shift = ( IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2 ) + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );

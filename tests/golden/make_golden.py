@@ -28,12 +28,17 @@ CASES = [
     ("b_200x136_ctu64_inter", 200, 136, 6, 3, 15, ALL, dict(p_intra=0.0)),
     ("b_256x192_ctu128_key", 256, 192, 7, 1, 16, ALL, dict(p_intra=0.3)),
     ("b_128x128_ctu32_nofilters", 128, 128, 5, 4, 17, abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST, dict(p_intra=0.15)),
+    ("b_256x128_ctu128_bdof", 256, 128, 7, 2, 18, ALL | abi.TOOL_BDOF, dict(p_intra=0.1, p_bi=0.9)),
+    ("b_200x136_ctu64_bdof", 200, 136, 6, 3, 19, ALL | abi.TOOL_BDOF, dict(p_intra=0.0, p_bi=0.8, mv_sigma=2.0)),
 ]
 
 
 def main():
     assert refdrv.available(), "oracle/_ref is not built (make -C oracle harness needs /root/reference)"
+    only = sys.argv[1:]
     for (name, W, H, l2, idx, seed, tools, kw) in CASES:
+        if only and name not in only:
+            continue
         plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
         pl = plans[idx]
         d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)

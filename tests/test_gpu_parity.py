@@ -92,6 +92,7 @@ def test_4k_determinism_and_oracle(built):
 
 
 TOOLS_I = TOOLS | abi.TOOL_LFNST
+TOOLS_B = TOOLS_I | abi.TOOL_BDOF
 
 
 @pytest.mark.parametrize("seed", [51, 52])
@@ -109,6 +110,17 @@ def test_intra_heavy(built):
 
 def test_1080p_intra_stream(built):
     _run_stream(1920, 1080, 3, 2, 71, TOOLS_I, intra=True, streams=3)
+
+
+@pytest.mark.parametrize("seed", [81, 82])
+def test_bdof_stream(built, seed):
+    """bi-predicted CUs with equal POC distance in opposite directions take the BDOF path (InterPrediction.cpp:1407-1427)"""
+    _run_stream(256, 128, 9, 8, seed, TOOLS_B, intra=True)
+    _run_stream(416, 240, 5, 4, seed + 10, TOOLS_B, intra=True, p_bi=0.9, p_intra=0.05, mv_sigma=3.0)
+
+
+def test_bdof_1080p(built):
+    _run_stream(1920, 1080, 3, 2, 91, TOOLS_B, intra=True, streams=3)
 
 
 def test_unsupported_tools_fail_loudly(built):

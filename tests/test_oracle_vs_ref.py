@@ -7,7 +7,7 @@ import refdrv
 from vvdec_amd import abi, synth, stream
 
 pytestmark = pytest.mark.skipif(not refdrv.available(), reason="oracle/_ref not built")
-ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST
+ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST | abi.TOOL_BDOF
 STAGES = [refdrv.STOP_AFTER_RECO, refdrv.STOP_AFTER_DBK, refdrv.STOP_AFTER_SAO, 0]
 
 

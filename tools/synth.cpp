@@ -206,10 +206,16 @@ struct Gen {
       }
       if( cu.imv == 3 ) for( int l = 0; l < 2; l++ ) { cu.mv[l][0][0] &= ~7; cu.mv[l][0][1] &= ~7; }
       cu.flags |= rng.p( 0.5 ) ? VVR_CU_MERGE : 0;
-      // branch taken by InterPrediction::motionCompensation (InterPrediction.cpp:1372): BDOF/DMVR are off in this generator version
+      // branch taken by InterPrediction::motionCompensation (InterPrediction.cpp:1372-1459)
       bool identical = false;
       if( bi && P.ref_poc[0][cu.ref_idx[0]] == P.ref_poc[1][cu.ref_idx[1]] && cu.mv[0][0][0] == cu.mv[1][0][0] && cu.mv[0][0][1] == cu.mv[1][0][1] ) identical = true;
-      cu.mc_mode = ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
+      // PU::isBiPredFromDifferentDirEqDistPoc (UnitTools.cpp:3094): one reference before, one after, same POC distance
+      bool eqDist = false;
+      if( bi ) { const int d0 = P.poc - P.ref_poc[0][cu.ref_idx[0]], d1 = P.poc - P.ref_poc[1][cu.ref_idx[1]]; eqDist = d0 * d1 < 0 && d0 == -d1; }
+      const bool sizeOk = w >= 8 && h >= 8 && w * h >= 128;
+      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2;      // (:1407-1427), no affine/CIIP/SMVD/WP here
+      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2;   // PU::checkDMVRCondition (UnitTools.cpp:1277)
+      cu.mc_mode = dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
     }
     // transform units: split at 64 (max TB size), cbf per block
     cu.first_tu = B.num_tu;

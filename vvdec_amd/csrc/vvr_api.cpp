@@ -232,7 +232,9 @@ static int validate( vvr_context* c, const vvr_picture* p )
     if( cu.x + cu.w > h.width || cu.y + cu.h > h.height || cu.first_tu + cu.num_tu > p->num_tu ) { c->setError( "CU outside the picture / bad TU range" ); return VVR_ERR_PARAMETER; }
     if( cu.pred_mode == VVR_PRED_INTER )
     {
-      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI ) { c->setError( "inter mode (BDOF/DMVR/affine/GPM/SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF ) { c->setError( "inter mode (DMVR/affine/GPM/SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
+      { c->setError( "mc_mode BDOF on a CU that cannot use BDOF (InterPrediction.cpp:1407-1427)" ); return VVR_ERR_PARAMETER; }
       if( cu.flags & ( VVR_CU_AFFINE | VVR_CU_CIIP | VVR_CU_GEO | VVR_CU_SBTMVP ) ) { c->setError( "affine / CIIP / GPM / SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) { c->setError( "ref_idx out of range" ); return VVR_ERR_PARAMETER; }
       if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
@@ -380,7 +382,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     }
     if( cu.pred_mode == VVR_PRED_INTER )
     {
-      const int nl = cu.mc_mode == VVR_MC_BI ? 2 : 1;
+      const int nl = cu.mc_mode == VVR_MC_UNI ? 1 : 2;
       for( int y = 0; y < cu.h; y += 16 ) for( int x = 0; x < cu.w; x += 16 )
       {
         McItem it; it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( 16, cu.w - x ); it.h = (uint8_t) std::min( 16, cu.h - y ); it.pad = 0; it.cu = i;

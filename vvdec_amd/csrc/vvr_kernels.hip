@@ -57,6 +57,7 @@ int vvr_upload_tables()
 // horizontal pass writes its 16-bit intermediates to LDS, the vertical pass reads them back column-wise.
 // =====================================================================================================================
 #define IF_INTERNAL_OFFS 8192
+#define BDOF_S 20           // row stride of the padded 18x18 BDOF prediction block
 
 // One (list, component) prediction segment of a tile.
 struct McSeg {
@@ -64,7 +65,7 @@ struct McSeg {
   int ww, wh;            // window size
   int xFrac, yFrac;
   int w, h;              // block size
-  int winOff, tmpOff;    // offsets (in samples) into the LDS arrays
+  int ox, oy;            // position of the block's integer-sample origin inside the window
 };
 
 #define MC_WIN_L   ( 23 * 24 )
@@ -76,12 +77,12 @@ struct McSeg {
 __device__ __forceinline__ int mc_final( const pel_t* win, int wstride, const pel_t* tmp, int tstride, const McSeg& g, const int16_t* ch, const int16_t* cv,
                                          int comp, bool bi, int bd, int px, int py )
 {
-  const int ntaps = comp ? 4 : 8;
+  const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
   if( !doH && !doV )
   {
-    const int s = win[py * wstride + px];
+    const int s = win[( py + g.oy ) * wstride + px + g.ox];
     return bi ? (int16_t) ( (int16_t) ( s << headroom ) - (int16_t) IF_INTERNAL_OFFS ) : s;
   }
   if( doH != doV )
@@ -89,15 +90,15 @@ __device__ __forceinline__ int mc_final( const pel_t* win, int wstride, const pe
     int shift, offset;
     if( !bi ) { shift = 6; offset = 32; } else { shift = 6 - headroom; offset = -IF_INTERNAL_OFFS * ( 1 << shift ); }
     int sum = 0;
-    if( doH ) { for( int t = 0; t < ntaps; t++ ) sum += win[py * wstride + px + t] * ch[t]; }
-    else      { for( int t = 0; t < ntaps; t++ ) sum += win[( py + t ) * wstride + px] * cv[t]; }
+    if( doH ) { for( int t = 0; t < ntaps; t++ ) sum += win[( py + g.oy ) * wstride + px + g.ox - half + t] * ch[t]; }
+    else      { for( int t = 0; t < ntaps; t++ ) sum += win[( py + g.oy - half + t ) * wstride + px + g.ox] * cv[t]; }
     int val = (int16_t) ( ( sum + offset ) >> shift );
     return bi ? val : clip_pel( val, bd );
   }
   int shift2, offset2;
   if( !bi ) { shift2 = 6 + headroom; offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 ); } else { shift2 = 6; offset2 = 0; }
   int sum = 0;
-  for( int t = 0; t < ntaps; t++ ) sum += tmp[( py + t ) * tstride + px] * cv[t];
+  for( int t = 0; t < ntaps; t++ ) sum += tmp[( py + g.oy - half + t ) * tstride + px] * cv[t];
   int val = (int16_t) ( ( sum + offset2 ) >> shift2 );
   return bi ? val : clip_pel( val, bd );
 }
@@ -114,6 +115,8 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   __shared__ McSeg seg[2][3];
   __shared__ const pel_t* refp[2][3];
   __shared__ int16_t coefH[2][3][8], coefV[2][3][8];
+  __shared__ pel_t bdBlk[2][( 16 + 2 ) * BDOF_S];          // BDOF: 14-bit luma predictions with a one-sample border, stride BDOF_S
+  __shared__ pel_t bdGx[2][16 * 16], bdGy[2][16 * 16];     // BDOF: gradients of the interior
   // XCD-aware mapping (cdna_hip_programming.md T1): consecutive workgroups are dealt round-robin to the 8 XCDs; give each XCD
   // a contiguous run of tiles so that the halo rows shared by neighbouring tiles hit the same L2.
   int item;
@@ -128,6 +131,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   const int tid = threadIdx.x;
   const bool biPred = cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0;
   const bool uni = cu.mc_mode == VVR_MC_UNI;
+  const bool bdof = cu.mc_mode == VVR_MC_BDOF;          // xSubPuBio (InterPrediction.cpp:551): the tile IS the <= 16x16 BDOF sub-block
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
   const int l0 = uni ? ( ( biPred || cu.ref_idx[0] >= 0 ) ? 0 : 1 ) : 0;
   const int nl = uni ? 1 : 2;
@@ -147,10 +151,11 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       g.w = it.w >> cs; g.h = it.h >> cs;
       g.xFrac = mvx & ( ( 1 << shf ) - 1 ); g.yFrac = mvy & ( ( 1 << shf ) - 1 );
       const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
-      g.ww = g.w + ( doH ? ntaps - 1 : 0 ); g.wh = g.h + ( doV ? ntaps - 1 : 0 );
-      g.x0 = ( it.x >> cs ) + ( mvx >> shf ) - ( doH ? half : 0 );
-      g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - ( doV ? half : 0 );
-      g.winOff = 0; g.tmpOff = 0;
+      const bool full = bdof && c == 0;                 // BDOF also reads the integer samples around the block (border fill, :863-890)
+      g.ox = ( doH || full ) ? half : 0; g.oy = ( doV || full ) ? half : 0;
+      g.ww = g.w + ( ( doH || full ) ? ntaps - 1 : 0 ); g.wh = g.h + ( ( doV || full ) ? ntaps - 1 : 0 );
+      g.x0 = ( it.x >> cs ) + ( mvx >> shf ) - g.ox;
+      g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - g.oy;
       seg[k][c] = g;
       refp[k][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
       // InterpolationFilter.cpp:1078-1085 / 669-676 (luma 4x4 blocks use the 6-tap table), :105 (alternative half-pel filter)
@@ -206,7 +211,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
         for( int yy = row0; yy < g.wh; yy += NT / 16 )
         {
           int sum = 0;
-          for( int t = 0; t < ntaps; t++ ) sum += win[yy * wst + col + t] * cf[t];
+          for( int t = 0; t < ntaps; t++ ) sum += win[yy * wst + col + t] * cf[t];          // 2-D segments always have ox = ntaps/2 - 1
           tmp[yy * tst + col] = (int16_t) ( ( sum + offset1 ) >> shift1 );
         }
       }
@@ -215,7 +220,94 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   __syncthreads();
   // ---- phase C: final samples
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  for( int c = 0; c < ncomp; c++ )
+  if( bdof )
+  {
+    // ---- BDOF luma (applyBiOptFlow :1290, gradFilterCore :213, BiOptFlowCore :162, calcBIOSums :134, addBIOAvg4 :108)
+    const int w = it.w, h = it.h, lw = w == 16 ? 4 : 3;
+    // (1) 14-bit predictions of both lists + the border of nearest integer samples
+    for( int i = tid; i < w * h; i += NT )
+    {
+      const int px = i & ( w - 1 ), py = i >> lw;
+      bdBlk[0][( 1 + py ) * BDOF_S + 1 + px] = (pel_t) mc_final( winL[0], 24, tmpL[0], 16, seg[0][0], coefH[0][0], coefV[0][0], 0, true, bd, px, py );
+      bdBlk[1][( 1 + py ) * BDOF_S + 1 + px] = (pel_t) mc_final( winL[1], 24, tmpL[1], 16, seg[1][0], coefH[1][0], coefV[1][0], 0, true, bd, px, py );
+    }
+    {
+      const int ring = 2 * ( w + 2 ) + 2 * h;
+      for( int i = tid; i < 2 * ring; i += NT )
+      {
+        const int l = i >= ring, r = i - l * ring;
+        int bi_, bj;                                       // padded coordinates: (0,0) = corner above-left of the block
+        if( r < w + 2 ) { bi_ = r; bj = 0; } else if( r < 2 * ( w + 2 ) ) { bi_ = r - ( w + 2 ); bj = h + 1; }
+        else { const int q = r - 2 * ( w + 2 ); bi_ = ( q & 1 ) ? w + 1 : 0; bj = 1 + ( q >> 1 ); }
+        const McSeg& g = seg[l][0];
+        const int xOff = g.xFrac < 8 ? 1 : 0, yOff = g.yFrac < 8 ? 1 : 0;
+        const int sref = winL[l][( g.oy - yOff + bj ) * 24 + g.ox - xOff + bi_];
+        bdBlk[l][bj * BDOF_S + bi_] = (pel_t) ( (int16_t) ( sref << headroom ) - (int16_t) IF_INTERNAL_OFFS );
+      }
+    }
+    __syncthreads();
+    // (2) gradients of the interior; everything outside is a replica of the nearest interior value (the padding of :236-264),
+    //     which is what the clamped indices below read
+    for( int i = tid; i < w * h; i += NT )
+    {
+      const int px = i & ( w - 1 ), py = i >> lw;
+      for( int l = 0; l < 2; l++ )
+      {
+        const pel_t* P = bdBlk[l];
+        bdGy[l][py * 16 + px] = (pel_t) ( ( P[( 2 + py ) * BDOF_S + 1 + px] >> 6 ) - ( P[py * BDOF_S + 1 + px] >> 6 ) );
+        bdGx[l][py * 16 + px] = (pel_t) ( ( P[( 1 + py ) * BDOF_S + 2 + px] >> 6 ) - ( P[( 1 + py ) * BDOF_S + px] >> 6 ) );
+      }
+    }
+    __syncthreads();
+    // (3) per 4x4 unit: 6x6 window sums by four lanes, motion refinement, output
+    const int shiftNum = 15 - bd, offset = ( 1 << ( shiftNum - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+    const int unitsX = w >> 2, units = unitsX * ( h >> 2 );
+    for( int u0 = 0; u0 < units; u0 += NT / 4 )
+    {
+      const int u = u0 + ( tid >> 2 ), q = tid & 3;
+      const bool act = u < units;
+      const int xu = act ? u % unitsX : 0, yu = act ? u / unitsX : 0;
+      int sAGX = 0, sAGY = 0, sDIX = 0, sDIY = 0, sSG = 0;
+      if( act )
+      {
+        for( int p = q; p < 36; p += 4 )
+        {
+          const int wy = p / 6, wx = p - wy * 6;
+          const int ix = min( w - 1, max( 0, ( xu << 2 ) + wx - 1 ) ), iy = min( h - 1, max( 0, ( yu << 2 ) + wy - 1 ) );    // interior coordinates, clamped
+          const int o = iy * 16 + ix, ob = ( 1 + iy ) * BDOF_S + 1 + ix;
+          const int tGX = ( bdGx[0][o] + bdGx[1][o] ) >> 1, tGY = ( bdGy[0][o] + bdGy[1][o] ) >> 1;
+          const int tDI = ( bdBlk[1][ob] >> 4 ) - ( bdBlk[0][ob] >> 4 );
+          sAGX += iabs( tGX ); sAGY += iabs( tGY );
+          sDIX += tGX < 0 ? -tDI : tGX == 0 ? 0 : tDI;
+          sDIY += tGY < 0 ? -tDI : tGY == 0 ? 0 : tDI;
+          sSG  += tGY < 0 ? -tGX : tGY == 0 ? 0 : tGX;
+        }
+      }
+      for( int o = 1; o < 4; o <<= 1 )
+      {
+        sAGX += __shfl_xor( sAGX, o ); sAGY += __shfl_xor( sAGY, o ); sDIX += __shfl_xor( sDIX, o ); sDIY += __shfl_xor( sDIY, o ); sSG += __shfl_xor( sSG, o );
+      }
+      if( act )
+      {
+        int tmpx = sAGX == 0 ? 0 : ( ( sDIX * 4 ) >> ( 31 - __clz( sAGX ) ) );        // rightShiftMSB (:92): shift by floor(log2(denominator))
+        tmpx = clip3( -15, 15, tmpx );
+        const int mains = sSG >> 12, secs = sSG & 4095;
+        int tmpData = tmpx * mains;
+        tmpData = ( ( tmpData * ( 1 << 12 ) ) + tmpx * secs ) >> 1;
+        int tmpy = sAGY == 0 ? 0 : ( ( ( sDIY * 4 ) - tmpData ) >> ( 31 - __clz( sAGY ) ) );
+        tmpy = clip3( -15, 15, tmpy );
+        const int py = ( yu << 2 ) + q;
+        for( int x = 0; x < 4; x++ )
+        {
+          const int px = ( xu << 2 ) + x, o = py * 16 + px, ob = ( 1 + py ) * BDOF_S + 1 + px;
+          const int b = tmpx * ( bdGx[0][o] - bdGx[1][o] ) + tmpy * ( bdGy[0][o] - bdGy[1][o] );
+          const int v = clip_pel( (int16_t) ( ( bdBlk[0][ob] + bdBlk[1][ob] + b + offset ) >> shiftNum ), bd );
+          reco.p[0][(size_t) ( it.y + py ) * reco.stride[0] + it.x + px] = (pel_t) v;
+        }
+      }
+    }
+  }
+  for( int c = bdof ? 1 : 0; c < ncomp; c++ )
   {
     const int cs = c ? 1 : 0;
     const int w = it.w >> cs, h = it.h >> cs;
