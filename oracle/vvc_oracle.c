@@ -67,6 +67,7 @@ static int tu_residuals( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu*
 
 int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, uint16_t* const* out_planes, int flags )
 {
+  vvo_dmvr_reset();
   const vvr_pic_header* H = &pic->hdr;
   const int W = H->width, Hh = H->height, ncomp = H->chroma_format ? 3 : 1;
   int rc = -1;

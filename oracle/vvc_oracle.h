@@ -25,6 +25,10 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
 /* one transform block: levels -> residual (row-major bw x bh) */
 int vvo_residual( const vvr_pic_header* hdr, const vvr_cu* cu, const vvr_tu* tu, int comp, const int16_t* coef, int16_t* resi );
 
+/* DMVR delta MVs (hor, ver in 1/16 sample) of the last vvo_reconstruct call, indexed like vvr_read_dmvr (cu.dmvr_off + sub-block);
+ * returns the number of entries produced */
+uint32_t vvo_get_dmvr( int32_t* dst, uint32_t max_entries );
+
 const char* vvo_last_error( void );
 
 #ifdef __cplusplus

@@ -37,6 +37,7 @@ void vvo_planes_free( vvo_planes* pl );
 int  vvo_residual_block( const vvr_pic_header* hdr, const vvr_cu* cu, const vvr_tu* tu, int comp, const int16_t* coef, int16_t* resi, int rstride );
 /* vvc_oracle_inter.c */
 int  vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* refs /* [slot] */, int num_slots, vvo_planes* reco );
+void vvo_dmvr_reset( void );
 /* vvc_oracle_intra.c */
 int  vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, vvo_planes* reco,
                    const int32_t* tu_order_map /* per 4x4 luma units, per channel type */, const int16_t* resi, int has_resi );

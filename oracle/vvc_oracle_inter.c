@@ -13,7 +13,25 @@
 
 /* one component of one uni-directional prediction block: xPredInterBlk (InterPrediction.cpp:751).
  * bi = 1: output stays at the 14-bit intermediate precision; bi = 0: rounded and clipped samples. */
+/* sample source of a prediction block: the (border-extended) reference picture, or DMVR's padded local copy of it */
+typedef struct {
+  const vvo_planes* ref; int comp;
+  const pel* pad; int padStride, padW, padH, padX0, padY0;   /* pad != NULL: pad[(y - padY0) * padStride + (x - padX0)], x/y in block-relative coordinates */
+} vvo_src;
+static inline int src_at( const vvo_src* s, int x, int y )
+{
+  if( s->pad ) return s->pad[( y - s->padY0 ) * s->padStride + ( x - s->padX0 )];
+  return vvo_ref_at( s->ref, s->comp, x, y );
+}
+static void pred_block_src( const vvo_src* src, int comp, int bx, int by, int w, int h, int mvx, int mvy, int bi, int altHpel, int bd, pel* dst, int dstStride );
 static void pred_block( const vvo_planes* ref, int comp, int bx, int by, int w, int h, int mvx, int mvy, int bi, int altHpel, int bd, pel* dst, int dstStride )
+{
+  vvo_src s; memset( &s, 0, sizeof( s ) ); s.ref = ref; s.comp = comp;
+  pred_block_src( &s, comp, bx, by, w, h, mvx, mvy, bi, altHpel, bd, dst, dstStride );
+}
+/* with a pad source (altSrc, InterPrediction.cpp:789-797) x0/y0 below are relative to the pad's own origin: the caller passes bx = by = 0
+ * and an mv whose integer part is zero */
+static void pred_block_src( const vvo_src* ref, int comp, int bx, int by, int w, int h, int mvx, int mvy, int bi, int altHpel, int bd, pel* dst, int dstStride )
 {
   const int sh = 4 + ( comp ? 1 : 0 );
   const int xFrac = mvx & ( ( 1 << sh ) - 1 ), yFrac = mvy & ( ( 1 << sh ) - 1 );
@@ -32,7 +50,7 @@ static void pred_block( const vvo_planes* ref, int comp, int bx, int by, int w, 
   {
     for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
     {
-      const int s = vvo_ref_at( ref, comp, x0 + x, y0 + y );
+      const int s = src_at( ref, x0 + x, y0 + y );
       dst[y * dstStride + x] = bi ? (pel) ( (pel) ( s * ( 1 << headroom ) ) - (pel) IF_INTERNAL_OFFS ) : (pel) s;
     }
     return;
@@ -47,7 +65,7 @@ static void pred_block( const vvo_planes* ref, int comp, int bx, int by, int w, 
     for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
     {
       int sum = 0;
-      for( int t = 0; t < ntaps; t++ ) sum += vvo_ref_at( ref, comp, x0 + x + ( t - half ) * dx, y0 + y + ( t - half ) * dy ) * c[t];
+      for( int t = 0; t < ntaps; t++ ) sum += src_at( ref, x0 + x + ( t - half ) * dx, y0 + y + ( t - half ) * dy ) * c[t];
       pel val = (pel) ( ( sum + offset ) >> shift );
       dst[y * dstStride + x] = bi ? val : (pel) vvo_clip_pel( val, bd );
     }
@@ -60,7 +78,7 @@ static void pred_block( const vvo_planes* ref, int comp, int bx, int by, int w, 
     for( int y = 0; y < th; y++ ) for( int x = 0; x < w; x++ )
     {
       int sum = 0;
-      for( int t = 0; t < ntaps; t++ ) sum += vvo_ref_at( ref, comp, x0 + x + t - half, y0 + y - half ) * ch[t];
+      for( int t = 0; t < ntaps; t++ ) sum += src_at( ref, x0 + x + t - half, y0 + y - half ) * ch[t];
       tmp[y * w + x] = (pel) ( ( sum + offset1 ) >> shift1 );
     }
     int shift2, offset2;
@@ -99,7 +117,13 @@ static int bdof_right_shift_msb( int numer, int denom )
   return numer >> ( msb - 1 );
 }
 
+static void bdof_border_src( const vvo_src* ref, int bx, int by, int w, int h, int mvx, int mvy, int bd, pel* blk );
 static void bdof_border( const vvo_planes* ref, int bx, int by, int w, int h, int mvx, int mvy, int bd, pel* blk /* row 0 of the (w+8)-stride buffer */ )
+{
+  vvo_src s; memset( &s, 0, sizeof( s ) ); s.ref = ref; s.comp = 0;
+  bdof_border_src( &s, bx, by, w, h, mvx, mvy, bd, blk );
+}
+static void bdof_border_src( const vvo_src* ref, int bx, int by, int w, int h, int mvx, int mvy, int bd, pel* blk )
 {
   const int S = w + 8;
   const int shift = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2;
@@ -108,13 +132,13 @@ static void bdof_border( const vvo_planes* ref, int bx, int by, int w, int h, in
   for( int r = 0; r < h; r++ )
   {
     pel* d = blk + ( 2 + r ) * S;
-    d[0]     = (pel) ( vvo_ref_at( ref, 0, x0 - xOff,         y0 + 1 - yOff + r ) * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
-    d[w + 1] = (pel) ( vvo_ref_at( ref, 0, x0 - xOff + w + 1, y0 + 1 - yOff + r ) * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
+    d[0]     = (pel) ( src_at( ref, x0 - xOff,         y0 + 1 - yOff + r ) * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
+    d[w + 1] = (pel) ( src_at( ref, x0 - xOff + w + 1, y0 + 1 - yOff + r ) * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
   }
   for( int i = 0; i < w + 2; i++ )
   {
-    blk[1 * S + i]         = (pel) ( vvo_ref_at( ref, 0, x0 - xOff + i, y0 - yOff )         * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
-    blk[( h + 2 ) * S + i] = (pel) ( vvo_ref_at( ref, 0, x0 - xOff + i, y0 + h + 1 - yOff ) * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
+    blk[1 * S + i]         = (pel) ( src_at( ref, x0 - xOff + i, y0 - yOff )         * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
+    blk[( h + 2 ) * S + i] = (pel) ( src_at( ref, x0 - xOff + i, y0 + h + 1 - yOff ) * ( 1 << shift ) - (pel) IF_INTERNAL_OFFS );
   }
 }
 
@@ -186,11 +210,204 @@ static void bdof_luma_subblock( const vvo_planes* ref0, const vvo_planes* ref1, 
   bdof_apply( blk[0], blk[1], w, h, bd, dst, dstStride );
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * DMVR: InterPrediction::xProcessDMVR (InterPrediction.cpp:1847), xinitMC (:1804), xBIPMVRefine (:1702),
+ * xDMVRSubPixelErrorSurface (:1785), xSubPelErrorSrfc (:1647), div_for_maxq7 (:1612), xPrefetchPad (:1525),
+ * prefetchPadCore / paddingCore (:283-315), xFinalPaddedMCForDMVR (:1731); SADs: RdCost::xGetSAD8/16 and X5 (RdCost.cpp:107-220);
+ * bilinear filter: InterpolationFilter::filter<2> (InterpolationFilter.cpp:589-600), filterCopy biMCForDMVR (:445-477). */
+static int32_t g_dmvr_out[2 * 65536]; static uint32_t g_dmvr_count;
+
+/* bilinear prediction at IF_INTERNAL_PREC_BILINEAR = 10 bit of a w x h block at integer position (x0, y0) + frac */
+static void bilinear_block( const vvo_planes* ref, int x0, int y0, int xFrac, int yFrac, int w, int h, int bd, pel* dst, int dstStride )
+{
+  const int shiftF = 4 - ( 10 - bd ), offF = shiftF > 0 ? 1 << ( shiftF - 1 ) : 0;
+  if( !xFrac && !yFrac ) { for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) dst[y * dstStride + x] = (pel) ( vvo_ref_at( ref, 0, x0 + x, y0 + y ) * ( 1 << ( 10 - bd ) ) ); return; }
+  if( !yFrac || !xFrac )
+  {
+    const int f = yFrac ? yFrac : xFrac, dx = yFrac ? 0 : 1, dy = yFrac ? 1 : 0;
+    for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+      dst[y * dstStride + x] = (pel) ( ( vvo_ref_at( ref, 0, x0 + x, y0 + y ) * ( 16 - f ) + vvo_ref_at( ref, 0, x0 + x + dx, y0 + y + dy ) * f + offF ) >> shiftF );
+    return;
+  }
+  pel tmp[( 128 + 4 + 1 ) * ( 128 + 4 )];
+  for( int y = 0; y < h + 1; y++ ) for( int x = 0; x < w; x++ )
+    tmp[y * w + x] = (pel) ( ( vvo_ref_at( ref, 0, x0 + x, y0 + y ) * ( 16 - xFrac ) + vvo_ref_at( ref, 0, x0 + x + 1, y0 + y ) * xFrac + offF ) >> shiftF );
+  for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+    dst[y * dstStride + x] = (pel) ( ( tmp[y * w + x] * ( 16 - yFrac ) + tmp[( y + 1 ) * w + x] * yFrac + 8 ) >> 4 );
+}
+
+static uint64_t dmvr_sad( const pel* a, const pel* b, int stride, int w, int h )     /* subShift = 1: even rows, << 1 */
+{
+  uint64_t s = 0;
+  for( int y = 0; y < h; y += 2 ) for( int x = 0; x < w; x++ ) s += (uint64_t) vvo_abs( a[y * stride + x] - b[y * stride + x] );
+  return s << 1;
+}
+
+static int32_t div_for_maxq7( int64_t N, int64_t D )
+{
+  int32_t sign = 0, q = 0;
+  if( N < 0 ) { sign = 1; N = -N; }
+  D = D << 3;
+  if( N >= D ) { N -= D; q++; }
+  q = q << 1;
+  D = D >> 1;
+  if( N >= D ) { N -= D; q++; }
+  q = q << 1;
+  if( N >= ( D >> 1 ) ) q++;
+  return sign ? -q : q;
+}
+
+static void dmvr_subpel( const uint64_t sad[5], int32_t delta[2] )
+{
+  int64_t num, den;
+  num = (int64_t) ( sad[1] - sad[3] ) * ( (int64_t) 1 << 4 );
+  den = (int64_t) ( sad[1] + sad[3] - ( sad[0] << 1 ) );
+  if( den != 0 )
+  {
+    if( sad[1] != sad[0] && sad[3] != sad[0] ) delta[0] = div_for_maxq7( num, den );
+    else delta[0] = sad[1] == sad[0] ? -8 : 8;
+  }
+  num = (int64_t) ( ( sad[2] - sad[4] ) << 4 );
+  den = (int64_t) ( sad[2] + sad[4] - ( sad[0] << 1 ) );
+  if( den != 0 )
+  {
+    if( sad[2] != sad[0] && sad[4] != sad[0] ) delta[1] = div_for_maxq7( num, den );
+    else delta[1] = sad[2] == sad[0] ? -8 : 8;
+  }
+}
+
+/* xPrefetchPad + prefetchPadCore: copy of the (w + ntaps - 1)^2 window at the (clipped) start MV, replicated `pad` samples outwards.
+ * The copy is addressed in coordinates relative to the sub-block origin displaced by the integer start MV. */
+static void dmvr_prefetch( const vvo_planes* ref, int comp, int sx, int sy /* luma pos of the sub-block */, int w, int h /* component size */,
+                           const int mergeMv[2], int W, int H, int ctu, pel* pad, int* padStride, int* originX, int* originY )
+{
+  const int cs = comp ? 1 : 0, sh = 4 + cs, ntaps = comp ? 4 : 8, half = ntaps / 2 - 1, padSize = comp ? 1 : 2;
+  int mv[2] = { mergeMv[0] - ( half << sh ), mergeMv[1] - ( half << sh ) };
+  clip_mv( mv, sx, sy, W, H, ctu );
+  const int px = ( sx >> cs ) + ( mv[0] >> sh ), py = ( sy >> cs ) + ( mv[1] >> sh );      /* top-left of the copied window in the reference */
+  const int cw = w + ntaps - 1, chh = h + ntaps - 1;
+  const int stride = w + 4 + ntaps;                                                        /* width + 2 * DMVR_NUM_ITERATION + filtersize */
+  for( int y = -padSize; y < chh + padSize; y++ ) for( int x = -padSize; x < cw + padSize; x++ )
+    pad[( y + 2 ) * stride + ( x + 2 )] = (pel) vvo_ref_at( ref, comp, px + vvo_clip3( 0, cw - 1, x ), py + vvo_clip3( 0, chh - 1, y ) );
+  *padStride = stride; *originX = 2 + half; *originY = 2 + half;    /* pad coordinates of the block's integer-sample origin for a zero integer delta */
+}
+
+static int dmvr_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* refs, vvo_planes* reco, int bio )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int bd = H->bit_depth, ctu = 1 << H->log2_ctu, W = H->width, Hh = H->height;
+  const int ncomp = H->chroma_format ? 3 : 1;
+  const int altHpel = cu->imv == 3;
+  const vvo_planes* ref[2] = { &refs[H->ref_slot[0][cu->ref_idx[0]]], &refs[H->ref_slot[1][cu->ref_idx[1]]] };
+  const int mergeMv[2][2] = { { cu->mv[0][0][0], cu->mv[0][0][1] }, { cu->mv[1][0][0], cu->mv[1][0][1] } };
+  /* xinitMC: bilinear prediction of the whole CU extended by 2 samples, start MVs clipped against the CU */
+  const int ew = cu->w + 4, eh = cu->h + 4;
+  pel* bil[2]; bil[0] = (pel*) malloc( sizeof( pel ) * (size_t) ew * eh * 2 ); bil[1] = bil[0] + (size_t) ew * eh;
+  for( int l = 0; l < 2; l++ )
+  {
+    int mv[2] = { mergeMv[l][0], mergeMv[l][1] };
+    clip_mv( mv, cu->x, cu->y, W, Hh, ctu );
+    mv[0] -= 2 << 4; mv[1] -= 2 << 4;
+    bilinear_block( ref[l], cu->x + ( mv[0] >> 4 ), cu->y + ( mv[1] >> 4 ), mv[0] & 15, mv[1] & 15, ew, eh, bd, bil[l], ew );
+  }
+  const int dx = vvo_min( cu->w, 16 ), dy = vvo_min( cu->h, 16 );
+  int num = 0;
+  for( int ys = 0; ys < cu->h; ys += dy ) for( int xs = 0; xs < cu->w; xs += dx, num++ )
+  {
+    const int sx = cu->x + xs, sy = cu->y + ys;
+    const pel* c0 = bil[0] + ( 2 + ys ) * ew + 2 + xs; const pel* c1 = bil[1] + ( 2 + ys ) * ew + 2 + xs;
+    uint64_t minCost = dmvr_sad( c0, c1, ew, dx, dy );
+    minCost >>= 1; minCost -= minCost >> 2;
+    int mv[2][2] = { { mergeMv[0][0], mergeMv[0][1] }, { mergeMv[1][0], mergeMv[1][1] } };
+    int16_t total[2] = { 0, 0 };
+    int refined = 0;
+    if( !( minCost < (uint64_t) ( dx * dy ) ) )
+    {
+      uint64_t sads[25]; int16_t d[2] = { 0, 0 };
+      sads[12] = minCost;
+      for( int ver = -2; ver <= 2; ver++ ) for( int hor = -2; hor <= 2; hor++ )
+      {
+        if( !( ver == 0 && hor == 0 ) ) sads[( ver + 2 ) * 5 + hor + 2] = dmvr_sad( c0 + ver * ew + hor, c1 - ver * ew - hor, ew, dx, dy ) >> 1;
+        const uint64_t cost = sads[( ver + 2 ) * 5 + hor + 2];
+        if( cost < minCost ) { minCost = cost; d[0] = (int16_t) hor; d[1] = (int16_t) ver; }
+      }
+      total[0] = (int16_t) ( d[0] * 16 ); total[1] = (int16_t) ( d[1] * 16 );
+      if( vvo_abs( total[0] ) != 32 && vvo_abs( total[1] ) != 32 )
+      {
+        const int ci = ( d[1] + 2 ) * 5 + d[0] + 2;
+        const uint64_t sb[5] = { sads[ci], sads[ci - 1], sads[ci - 5], sads[ci + 1], sads[ci + 5] };
+        int32_t t[2] = { 0, 0 };
+        dmvr_subpel( sb, t );
+        total[0] = (int16_t) ( total[0] + t[0] ); total[1] = (int16_t) ( total[1] + t[1] );
+      }
+      for( int k = 0; k < 2; k++ )
+      {
+        mv[0][k] = vvo_clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mergeMv[0][k] + total[k] );
+        mv[1][k] = vvo_clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mergeMv[1][k] - total[k] );
+      }
+      refined = 1;
+    }
+    if( g_dmvr_count <= cu->dmvr_off + num ) g_dmvr_count = cu->dmvr_off + num + 1;
+    if( cu->dmvr_off + num < 65536 ) { g_dmvr_out[2 * ( cu->dmvr_off + num )] = total[0]; g_dmvr_out[2 * ( cu->dmvr_off + num ) + 1] = total[1]; }
+    const int bioSub = minCost < (uint64_t) ( 2 * dx * dy ) ? 0 : bio;
+    /* xFinalPaddedMCForDMVR + xWeightedAverage on the sub-block */
+    pel blk[2][( 16 + 4 ) * BIO_STRIDE_MAX];
+    pel pr[2][3][16 * 16];
+    memset( blk, 0, sizeof( blk ) );
+    for( int l = 0; l < 2; l++ )
+    {
+      int cmv[2] = { mv[l][0], mv[l][1] };
+      clip_mv( cmv, sx, sy, W, Hh, ctu );                                      /* clipped against the SUB-block (:1752) */
+      for( int c = 0; c < ncomp; c++ )
+      {
+        const int cs = c ? 1 : 0, sh = 4 + cs, w = dx >> cs, h = dy >> cs;
+        const int dIntX = ( mv[l][0] >> sh ) - ( mergeMv[l][0] >> sh ), dIntY = ( mv[l][1] >> sh ) - ( mergeMv[l][1] >> sh );
+        pel* dst = ( c == 0 && bioSub ) ? blk[l] + 2 * ( dx + 8 ) + 1 : pr[l][c];
+        const int dstStride = ( c == 0 && bioSub ) ? dx + 8 : w;
+        if( refined && ( dIntX || dIntY ) )
+        {
+          pel pad[( 16 + 4 + 8 ) * ( 16 + 4 + 8 )]; int pst, ox, oy;
+          dmvr_prefetch( ref[l], c, sx, sy, w, h, mergeMv[l], W, Hh, ctu, pad, &pst, &ox, &oy );
+          vvo_src s; memset( &s, 0, sizeof( s ) ); s.pad = pad; s.padStride = pst; s.padX0 = -( ox + dIntX ); s.padY0 = -( oy + dIntY );
+          const int fmx = cmv[0] & ( ( 1 << sh ) - 1 ), fmy = cmv[1] & ( ( 1 << sh ) - 1 );
+          pred_block_src( &s, c, 0, 0, w, h, fmx, fmy, 1, altHpel, bd, dst, dstStride );
+          if( c == 0 && bioSub ) bdof_border_src( &s, 0, 0, w, h, fmx, fmy, bd, blk[l] );
+        }
+        else
+        {
+          pred_block( ref[l], c, sx >> cs, sy >> cs, w, h, cmv[0], cmv[1], 1, altHpel, bd, dst, dstStride );
+          if( c == 0 && bioSub ) bdof_border( ref[l], sx, sy, w, h, cmv[0], cmv[1], bd, blk[l] );
+        }
+      }
+    }
+    for( int c = 0; c < ncomp; c++ )
+    {
+      const int cs = c ? 1 : 0, w = dx >> cs, h = dy >> cs;
+      pel* dst = reco->p[c] + (size_t) ( sy >> cs ) * reco->stride[c] + ( sx >> cs );
+      if( c == 0 && bioSub ) { bdof_apply( blk[0], blk[1], w, h, bd, dst, reco->stride[c] ); continue; }
+      const int shift = ( IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2 ) + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+      for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+        dst[y * reco->stride[c] + x] = (pel) vvo_clip_pel( ( pr[0][c][y * w + x] + pr[1][c][y * w + x] + offset ) >> shift, bd );
+    }
+  }
+  free( bil[0] );
+  return 0;
+}
+
+void vvo_dmvr_reset( void ) { g_dmvr_count = 0; memset( g_dmvr_out, 0, sizeof( g_dmvr_out ) ); }
+uint32_t vvo_get_dmvr( int32_t* dst, uint32_t max_entries )
+{
+  const uint32_t n = g_dmvr_count < max_entries ? g_dmvr_count : max_entries;
+  if( dst ) memcpy( dst, g_dmvr_out, sizeof( int32_t ) * 2 * n );
+  return g_dmvr_count;
+}
+
 int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* refs, int num_slots, vvo_planes* reco )
 {
   const vvr_pic_header* H = &pic->hdr;
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu;
   const int ncomp = H->chroma_format ? 3 : 1;
+  if( cu->mc_mode == VVR_MC_DMVR || cu->mc_mode == VVR_MC_DMVR_BDOF ) return dmvr_cu( pic, cu, refs, reco, cu->mc_mode == VVR_MC_DMVR_BDOF );
   if( cu->mc_mode != VVR_MC_UNI && cu->mc_mode != VVR_MC_BI && cu->mc_mode != VVR_MC_BDOF ) { vvo_set_error( "inter mode not restated yet" ); return -1; }
   const int altHpel = cu->imv == 3;
   const int biPred = cu->ref_idx[0] >= 0 && cu->ref_idx[1] >= 0;

@@ -30,6 +30,8 @@ CASES = [
     ("b_128x128_ctu32_nofilters", 128, 128, 5, 4, 17, abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST, dict(p_intra=0.15)),
     ("b_256x128_ctu128_bdof", 256, 128, 7, 2, 18, ALL | abi.TOOL_BDOF, dict(p_intra=0.1, p_bi=0.9)),
     ("b_200x136_ctu64_bdof", 200, 136, 6, 3, 19, ALL | abi.TOOL_BDOF, dict(p_intra=0.0, p_bi=0.8, mv_sigma=2.0)),
+    ("b_256x128_ctu128_dmvr_bdof", 256, 128, 7, 2, 20, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR, dict(p_intra=0.1, p_bi=0.9)),
+    ("b_200x136_ctu64_dmvr", 200, 136, 6, 3, 21, ALL | abi.TOOL_DMVR, dict(p_intra=0.0, p_bi=0.8, mv_sigma=2.0)),
 ]
 
 

@@ -96,3 +96,12 @@ def oracle_reconstruct(desc, refs=None, flags=0):
     if rc != 0:
         raise RuntimeError("vvo_reconstruct failed: " + L.vvo_last_error().decode())
     return outs
+
+
+def oracle_dmvr(n):
+    """delta MVs (n x 2, 1/16 sample) of the last oracle_reconstruct call"""
+    L = oracle_lib()
+    L.vvo_get_dmvr.restype = C.c_uint32
+    a = np.zeros((max(1, n), 2), np.int32)
+    L.vvo_get_dmvr(a.ctypes.data_as(C.POINTER(C.c_int32)), n)
+    return a[:n]

@@ -36,7 +36,8 @@ def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=Tru
     if not intra:
         rec2.write_picture(0, seed_pic)
     for pl, d in zip(plans, descs):
-        rec2.wait(rec2.decompress_picture(d))
+        job = rec2.decompress_picture(d)
+        rec2.wait(job)
         got = rec2.read_picture(pl.slot)
         hashes.append(hashlib.md5(b"".join(p.tobytes() for p in got)).hexdigest())
         if check:
@@ -44,6 +45,9 @@ def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=Tru
             for c in range(3):
                 assert np.array_equal(got[c], want[c]), "POC %d comp %d: %d samples differ" % (pl.poc, c, int((got[c] != want[c]).sum()))
             cpu[pl.slot] = want
+            nd = getattr(d, "num_dmvr", 0)
+            if nd:      # refined MVs handed back to the host (DecCu::TaskFinishMotionInfo)
+                assert np.array_equal(rec2.read_dmvr(job, nd), refdrv.oracle_dmvr(nd)), "POC %d: DMVR delta MVs differ" % pl.poc
     # the pipelined run must have produced the same final pictures in the slots that were not overwritten
     last = {}
     for pl in plans:
@@ -93,6 +97,8 @@ def test_4k_determinism_and_oracle(built):
 
 TOOLS_I = TOOLS | abi.TOOL_LFNST
 TOOLS_B = TOOLS_I | abi.TOOL_BDOF
+TOOLS_D = TOOLS_I | abi.TOOL_DMVR
+TOOLS_DB = TOOLS_I | abi.TOOL_DMVR | abi.TOOL_BDOF
 
 
 @pytest.mark.parametrize("seed", [51, 52])
@@ -121,6 +127,17 @@ def test_bdof_stream(built, seed):
 
 def test_bdof_1080p(built):
     _run_stream(1920, 1080, 3, 2, 91, TOOLS_B, intra=True, streams=3)
+
+
+@pytest.mark.parametrize("tools,seed", [(TOOLS_D, 101), (TOOLS_DB, 102)])
+def test_dmvr_stream(built, tools, seed):
+    """merge-mode bi-predicted CUs with mirrored references run DMVR (+BDOF per sub-block); delta MVs are read back"""
+    _run_stream(256, 128, 9, 8, seed, tools, intra=True)
+    _run_stream(416, 240, 5, 4, seed + 10, tools, intra=True, p_bi=0.9, p_intra=0.05, mv_sigma=2.0)
+
+
+def test_dmvr_bdof_1080p(built):
+    _run_stream(1920, 1080, 3, 2, 111, TOOLS_DB, intra=True, streams=3)
 
 
 def test_unsupported_tools_fail_loudly(built):

@@ -7,7 +7,7 @@ import refdrv
 from vvdec_amd import abi, synth, stream
 
 pytestmark = pytest.mark.skipif(not refdrv.available(), reason="oracle/_ref not built")
-ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST | abi.TOOL_BDOF
+ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST | abi.TOOL_BDOF | abi.TOOL_DMVR
 STAGES = [refdrv.STOP_AFTER_RECO, refdrv.STOP_AFTER_DBK, refdrv.STOP_AFTER_SAO, 0]
 
 
@@ -31,11 +31,15 @@ def _case(W, H, l2, idx, seed, **kw):
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)
+    nd = getattr(d, "num_dmvr", 0)
     for fl in STAGES:
-        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        r = refdrv.reconstruct(d, refs, flags=fl, want_dmvr=nd)
+        want = r["planes"]
         got = refdrv.oracle_reconstruct(d, refs, flags=fl)
         for c in range(3):
             assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+        if nd:
+            assert np.array_equal(refdrv.oracle_dmvr(nd), r["dmvr"][:nd]), "DMVR delta MVs differ"
 
 
 def test_reference_simd_equals_scalar(built):

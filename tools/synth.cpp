@@ -216,6 +216,7 @@ struct Gen {
       const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2;      // (:1407-1427), no affine/CIIP/SMVD/WP here
       const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2;   // PU::checkDMVRCondition (UnitTools.cpp:1277)
       cu.mc_mode = dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
+      if( dmvr ) { cu.dmvr_off = B.num_dmvr; B.num_dmvr += ( ( w + 15 ) / 16 ) * ( ( h + 15 ) / 16 ); }     // one delta MV per 16x16 sub-block (m_dmvrMvCache)
     }
     // transform units: split at 64 (max TB size), cbf per block
     cu.first_tu = B.num_tu;

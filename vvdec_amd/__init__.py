@@ -63,6 +63,8 @@ def lib():
         L.vvr_free_prepared.argtypes = [C.c_void_p, C.c_void_p]
         L.vvr_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.vvr_write_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.vvr_read_dmvr.restype = C.c_int
+        L.vvr_read_dmvr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.vvr_enable_stats.argtypes = [C.c_void_p, C.c_int]
         L.vvr_get_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.vvr_plane_layout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -123,6 +125,12 @@ class Reconstructor:
     def sync(self):
         self._check(self.L.vvr_sync(self.ctx))
         self._keep.clear()
+
+    def read_dmvr(self, job, n):
+        """delta MVs (n x 2 int32, 1/16 sample) DMVR produced for job's picture, indexed cu.dmvr_off + sub-block"""
+        a = np.zeros((max(1, n), 2), np.int32)
+        self._check(self.L.vvr_read_dmvr(self.ctx, job, a.ctypes.data, n))
+        return a[:n]
 
     # -- resident pictures (pre-parsed stream already in HBM)
     def prepare(self, d: PictureDesc):

@@ -25,8 +25,8 @@ struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 
 struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
 
-enum { K_MC, K_ITRANS, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_NUM };
-const char* const kKernelNames[K_NUM] = { "k_mc", "k_itrans", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy" };
+enum { K_MC, K_MC_DMVR, K_ITRANS, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_NUM };
+const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_itrans", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy" };
 
 struct DevBuf {
   void* p = nullptr; size_t n = 0;
@@ -39,6 +39,8 @@ struct vvr_prepared {        // a picture description resident in HBM together w
   PicDev   pic;
   DevBuf   blob;             // one allocation holding every array
   McItem*  mcItems = nullptr; int numMc = 0;
+  McItem*  dmvrItems = nullptr; int numDmvrItems = 0;      // sub-blocks that run decoder-side MV refinement
+  int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64 (TB_ADD: after MC)
   TbItem*  tbStore[3] = { nullptr, nullptr, nullptr }; int numTbStore[3] = { 0, 0, 0 };   // residuals of intra blocks (TB_STORE)
   IntraItem* intraItems = nullptr; uint32_t* ctuStart = nullptr; uint32_t* active = nullptr; int numActive = 0, numIntra = 0;
@@ -60,7 +62,8 @@ struct vvr_context {
   size_t     planeBytes[3] = { 0, 0, 0 }, slotBytes = 0;
   int        stride[3] = { 0, 0, 0 };
   // jobs
-  struct Job { int id; int stream; hipEvent_t done; bool waited; vvr_prepared* autoFree; std::vector<PendingTiming> timings; };
+  struct Job { int id; int stream; hipEvent_t done; bool waited; vvr_prepared* autoFree; std::vector<PendingTiming> timings;
+               vvr_prepared* prepared = nullptr; std::vector<int32_t> dmvr; };     // dmvr: delta MVs copied to the host when the job is waited for
   std::vector<Job> jobs;
   int        nextJob = 0, nextStream = 0;
   std::vector<std::vector<int>> slotUsers;   // job ids that touched a slot since it was last written
@@ -232,7 +235,10 @@ static int validate( vvr_context* c, const vvr_picture* p )
     if( cu.x + cu.w > h.width || cu.y + cu.h > h.height || cu.first_tu + cu.num_tu > p->num_tu ) { c->setError( "CU outside the picture / bad TU range" ); return VVR_ERR_PARAMETER; }
     if( cu.pred_mode == VVR_PRED_INTER )
     {
-      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF ) { c->setError( "inter mode (DMVR/affine/GPM/SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      const bool isDmvr = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
+      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF && !isDmvr ) { c->setError( "inter mode (affine/GPM/SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( isDmvr && ( !( h.tool_flags & VVR_TOOL_DMVR ) || ( cu.mc_mode == VVR_MC_DMVR_BDOF && !( h.tool_flags & VVR_TOOL_BDOF ) ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
+      { c->setError( "mc_mode DMVR on a CU that cannot use DMVR (UnitTools.cpp:1277)" ); return VVR_ERR_PARAMETER; }
       if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
       { c->setError( "mc_mode BDOF on a CU that cannot use BDOF (InterPrediction.cpp:1407-1427)" ); return VVR_ERR_PARAMETER; }
       if( cu.flags & ( VVR_CU_AFFINE | VVR_CU_CIIP | VVR_CU_GEO | VVR_CU_SBTMVP ) ) { c->setError( "affine / CIIP / GPM / SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
@@ -273,7 +279,8 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   const int ctusX = ( h.width + ctu - 1 ) / ctu, ctusY = ( h.height + ctu - 1 ) / ctu, numCtu = ctusX * ctusY;
 
   // ---- host glue: work lists (what DecCu::TaskTrafoCtu / TaskInterCtu iterate over, DecCu.cpp:106-134)
-  std::vector<McItem> mc;
+  std::vector<McItem> mc, mcDmvr;
+  uint32_t numDmvr = 0;
   std::vector<TbItem> tb[3], tbS[3];
   std::vector<IntraItem> intra[3];
   std::vector<uint32_t> ctuStartV( 3 * (size_t) ( numCtu + 1 ), 0 );
@@ -386,10 +393,12 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       for( int y = 0; y < cu.h; y += 16 ) for( int x = 0; x < cu.w; x += 16 )
       {
         McItem it; it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( 16, cu.w - x ); it.h = (uint8_t) std::min( 16, cu.h - y ); it.pad = 0; it.cu = i;
-        mc.push_back( it );
+        const bool dm = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
+        ( dm ? mcDmvr : mc ).push_back( it );
         const double smp = (double) it.w * it.h * ( ncomp == 3 ? 1.5 : 1.0 );
-        bytes[K_MC] += smp * 2 * nl + smp * 2 + sizeof( McItem );
+        bytes[dm ? K_MC_DMVR : K_MC] += smp * 2 * nl + smp * 2 + sizeof( McItem ) + ( dm ? 8 : 0 );
       }
+      if( cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF ) numDmvr = std::max<uint32_t>( numDmvr, cu.dmvr_off + ( ( cu.w + 15 ) / 16 ) * ( ( cu.h + 15 ) / 16 ) );
       bytes[K_MC] += sizeof( vvr_cu );
     }
     if( !( cu.flags & VVR_CU_ROOT_CBF ) ) continue;
@@ -469,6 +478,8 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   const int iAlf = p->alf ? add( p->alf, sizeof( vvr_alf_ctu ) * numCtu ) : -1;
   const int iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
   const int iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
+  const int iMcD = add( mcDmvr.data(), sizeof( McItem ) * mcDmvr.size() );
+  const int iDmvrOut = add( nullptr, sizeof( int32_t ) * 2 * (size_t) numDmvr );
   int iTb[3]; for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
   int iTbS[3]; for( int k = 0; k < 3; k++ ) iTbS[k] = add( tbS[k].data(), sizeof( TbItem ) * tbS[k].size() );
   const int iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
@@ -482,7 +493,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   // stage through one pinned buffer -> a single H2D copy
   char* staging = nullptr;
   if( hipHostMalloc( (void**) &staging, total, hipHostMallocDefault ) != hipSuccess ) { hipFree( q->blob.p ); delete q; c->setError( "hipHostMalloc failed" ); return VVR_ERR_DEVICE; }
-  for( auto& pt : parts ) if( pt.n ) memcpy( staging + pt.off, pt.src, pt.n );
+  for( auto& pt : parts ) if( pt.n ) { if( pt.src ) memcpy( staging + pt.off, pt.src, pt.n ); else memset( staging + pt.off, 0, pt.n ); }
   hipError_t e = hipMemcpy( q->blob.p, staging, total, hipMemcpyHostToDevice );
   hipHostFree( staging );
   if( e != hipSuccess ) { hipFree( q->blob.p ); delete q; c->setError( "H2D copy failed" ); return VVR_ERR_DEVICE; }
@@ -496,6 +507,8 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   d.alf = iAlf >= 0 ? (const vvr_alf_ctu*) ( base + parts[iAlf].off ) : nullptr;
   d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
   q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();
+  q->dmvrItems = (McItem*) ( base + parts[iMcD].off ); q->numDmvrItems = (int) mcDmvr.size();
+  q->dmvrOut = (int32_t*) ( base + parts[iDmvrOut].off ); q->numDmvr = numDmvr;
   for( int k = 0; k < 3; k++ ) { q->tbItems[k] = (TbItem*) ( base + parts[iTb[k]].off ); q->numTb[k] = (int) tb[k].size(); }
   for( int k = 0; k < 3; k++ ) { q->tbStore[k] = (TbItem*) ( base + parts[iTbS[k]].off ); q->numTbStore[k] = (int) tbS[k].size(); }
   q->intraItems = (IntraItem*) ( base + parts[iIntra].off ); q->numIntra = (int) intraAll.size();
@@ -522,6 +535,13 @@ static int finishJob( vvr_context* c, vvr_context::Job& j )
     hipEventDestroy( t.a ); hipEventDestroy( t.b );
   }
   j.timings.clear();
+  if( j.prepared && j.prepared->numDmvr )
+  {
+    // refined MVs feed the temporal MV prediction of later pictures on the host (DecCu::TaskFinishMotionInfo, DecCu.cpp:161)
+    j.dmvr.resize( 2 * (size_t) j.prepared->numDmvr );
+    HIPCHK( c, hipMemcpy( j.dmvr.data(), j.prepared->dmvrOut, sizeof( int32_t ) * j.dmvr.size(), hipMemcpyDeviceToHost ) );
+  }
+  j.prepared = nullptr;
   if( j.autoFree ) { vvr_free_prepared( c, j.autoFree ); j.autoFree = nullptr; }
   j.waited = true;
   return VVR_OK;
@@ -558,6 +578,8 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
   };
   // INTER stage: prediction of every inter CU, then residual add (DecLibRecon.cpp:831-874)
   if( q->numMc ) timed( K_MC, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc ); } );
+  if( q->numDmvrItems ) timed( K_MC_DMVR, [&]{ launch_mc_dmvr( s, q->pic, refs, A, q->dmvrItems, q->numDmvrItems, q->dmvrOut ); } );
+  job.prepared = q;
   if( q->numTb[0] + q->numTb[1] + q->numTb[2] + q->numTbStore[0] + q->numTbStore[1] + q->numTbStore[2] )
     timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) { launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); launch_itrans( s, q->pic, A, R, q->tbStore[k], q->numTbStore[k], 16 << k ); } } );
   // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)
@@ -623,7 +645,18 @@ VVR_API int vvr_sync( vvr_context* c )
 
 VVR_API void* vvr_job_stream( vvr_context* c, int job ) { vvr_context::Job* j = c ? findJob( c, job ) : nullptr; return j ? (void*) c->streams[j->stream] : nullptr; }
 
-VVR_API int vvr_read_dmvr( vvr_context*, int, int32_t*, size_t ) { return VVR_ERR_UNSUPPORTED; }
+VVR_API int vvr_read_dmvr( vvr_context* c, int job, int32_t* dst, size_t numEntries )
+{
+  if( !c || ( !dst && numEntries ) ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  vvr_context::Job* j = findJob( c, job );
+  if( !j ) { c->setError( "vvr_read_dmvr: job already retired" ); return VVR_ERR_PARAMETER; }
+  const int rc = finishJob( c, *j );
+  if( rc != VVR_OK ) return rc;
+  const size_t n = std::min( numEntries, j->dmvr.size() / 2 );
+  if( n ) memcpy( dst, j->dmvr.data(), sizeof( int32_t ) * 2 * n );
+  return (int) ( j->dmvr.size() / 2 );
+}
 
 VVR_API int vvr_enable_stats( vvr_context* c, int on ) { if( !c ) return VVR_ERR_PARAMETER; vvr_sync( c ); c->statsOn = on != 0; for( auto& s : c->stats ) s = Stat(); return VVR_OK; }
 

@@ -61,17 +61,82 @@ int vvr_upload_tables()
 
 // One (list, component) prediction segment of a tile.
 struct McSeg {
-  int x0, y0;            // top-left of the window in the reference plane (may be outside: reads are clamped)
-  int ww, wh;            // window size
+  int x0, y0;            // reference-plane position of the window's first COPIED sample (may be outside: reads are clamped)
+  int ww, wh;            // size of the window held in LDS
   int xFrac, yFrac;
   int w, h;              // block size
   int ox, oy;            // position of the block's integer-sample origin inside the window
+  int padOff, cw, chh;   // DMVR padded copy (xPrefetchPad): window sample (u,v) = copied sample (clamp(u - padOff, 0, cw - 1), clamp(v - padOff, 0, chh - 1))
 };
 
 #define MC_WIN_L   ( 23 * 24 )
 #define MC_WIN_C   ( 11 * 12 )
 #define MC_TMP_L   ( 23 * 16 )
 #define MC_TMP_C   ( 11 * 8 )
+
+// XCD-aware mapping (cdna_hip_programming.md T1): consecutive workgroups are dealt round-robin to the 8 XCDs; give each XCD
+// a contiguous run of tiles so that the halo rows shared by neighbouring tiles hit the same L2.
+__device__ __forceinline__ int mc_item_index()
+{
+  const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + ( bid >> 3 );
+}
+
+// clipMvInPic (Mv.cpp:64) against the block at luma position (x, y)
+__device__ __forceinline__ void mc_clip_mv( const PicDev& pic, int x, int y, int& mvx, int& mvy )
+{
+  const int ctu = 1 << pic.hdr.log2_ctu;
+  const int horMax = ( pic.hdr.width + 8 - x - 1 ) * 16, horMin = ( -ctu - 8 - x + 1 ) * 16;
+  const int verMax = ( pic.hdr.height + 8 - y - 1 ) * 16, verMin = ( -ctu - 8 - y + 1 ) * 16;
+  mvx = min( horMax, max( horMin, mvx ) ); mvy = min( verMax, max( verMin, mvy ) );
+}
+
+// filter taps of one segment (InterpolationFilter.cpp:1078-1085 / 669-676: luma 4x4 blocks use the 6-tap table; :105 alternative half-pel filter)
+__device__ __forceinline__ void mc_taps( const McSeg& g, int c, bool altHpel, int16_t* coefH, int16_t* coefV )
+{
+  const int ntaps = c ? 4 : 8;
+  const bool f4 = g.w == 4 && g.h == 4;
+  const int16_t* ch = c ? d_chroma_filter[g.xFrac] : ( g.xFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[g.xFrac] : d_luma_filter[g.xFrac];
+  const int16_t* cv = c ? d_chroma_filter[g.yFrac] : ( g.yFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[g.yFrac] : d_luma_filter[g.yFrac];
+  for( int t = 0; t < ntaps; t++ ) { coefH[t] = ch[t]; coefV[t] = cv[t]; }
+}
+
+// window of one segment into LDS: clamped coordinates = border-extended reference (Picture::extendPicBorder)
+// lanes map to (row, column) with 32 columns per row group: no integer division, rows are contiguous 2-byte runs
+template<int NT>
+__device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg& g, const pel_t* __restrict__ ref, int stride, int pw, int ph, int tid )
+{
+  const int col = tid & 31, row0 = tid >> 5;
+  if( col < g.ww )
+  {
+    const int sx = clip3( 0, pw - 1, g.x0 + clip3( 0, g.cw - 1, col - g.padOff ) );
+    for( int yy = row0; yy < g.wh; yy += NT / 32 )
+    {
+      const int sy = clip3( 0, ph - 1, g.y0 + clip3( 0, g.chh - 1, yy - g.padOff ) );
+      win[yy * wst + col] = ref[(size_t) sy * stride + sx];
+    }
+  }
+}
+
+// horizontal pass of a 2-D segment (16-bit intermediates, InterpolationFilter.cpp:902-915): tmp row r = window row (oy - half + r)
+template<int NT>
+__device__ __forceinline__ void mc_hpass( const pel_t* win, int wst, pel_t* tmp, int tst, const McSeg& g, const int16_t* coefH, int c, int bd, int tid )
+{
+  const int col = tid & 15, row0 = tid >> 4;
+  if( !( g.xFrac && g.yFrac ) || col >= g.w ) return;
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+  const int ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
+  int cf[8];
+  for( int t = 0; t < 8; t++ ) cf[t] = coefH[t];
+  const pel_t* w0 = win + ( g.oy - half ) * wst + g.ox - half + col;
+  for( int r = row0; r < g.h + ntaps - 1; r += NT / 16 )
+  {
+    int sum = 0;
+    for( int t = 0; t < ntaps; t++ ) sum += w0[r * wst + t] * cf[t];
+    tmp[r * tst + col] = (int16_t) ( ( sum + offset1 ) >> shift1 );
+  }
+}
 
 // final sample of one segment at block position (px,py): all four (xFrac, yFrac) cases of xPredInterBlk
 __device__ __forceinline__ int mc_final( const pel_t* win, int wstride, const pel_t* tmp, int tstride, const McSeg& g, const int16_t* ch, const int16_t* cv,
@@ -98,9 +163,139 @@ __device__ __forceinline__ int mc_final( const pel_t* win, int wstride, const pe
   int shift2, offset2;
   if( !bi ) { shift2 = 6 + headroom; offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 ); } else { shift2 = 6; offset2 = 0; }
   int sum = 0;
-  for( int t = 0; t < ntaps; t++ ) sum += tmp[( py + g.oy - half + t ) * tstride + px] * cv[t];
+  for( int t = 0; t < ntaps; t++ ) sum += tmp[( py + t ) * tstride + px] * cv[t];
   int val = (int16_t) ( ( sum + offset2 ) >> shift2 );
   return bi ? val : clip_pel( val, bd );
+}
+
+// bi-predictive average / BCW of one component of a tile (AreaBuf::addAvg / addWeightedAvg, Buffer.cpp:441,372) or the uni-directional result
+template<int NT>
+__device__ __forceinline__ void mc_output( const pel_t* win0, const pel_t* tmp0, const pel_t* win1, const pel_t* tmp1, int wst, int tst, const McSeg* seg0, const McSeg* seg1,
+                                           const int16_t* cH0, const int16_t* cV0, const int16_t* cH1, const int16_t* cV1, int c, bool uni, int bcwIdx, int bd,
+                                           const DevPlanes& reco, int x0c, int y0c, int w, int h, int tid )
+{
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const int lw = w == 16 ? 4 : w == 8 ? 3 : w == 4 ? 2 : 1;       // log2 of the tile width
+  for( int i = tid; i < w * h; i += NT )
+  {
+    const int px = i & ( w - 1 ), py = i >> lw;
+    int out;
+    if( uni ) out = mc_final( win0, wst, tmp0, tst, *seg0, cH0, cV0, c, false, bd, px, py );
+    else
+    {
+      const int p0 = mc_final( win0, wst, tmp0, tst, *seg0, cH0, cV0, c, true, bd, px, py );
+      const int p1 = mc_final( win1, wst, tmp1, tst, *seg1, cH1, cV1, c, true, bd, px, py );
+      if( bcwIdx != 2 )
+      {
+        const int w1 = d_bcw_weights[bcwIdx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+        out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
+      }
+      else
+      {
+        const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+        out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
+      }
+    }
+    reco.p[c][(size_t) ( y0c + py ) * reco.stride[c] + x0c + px] = (pel_t) out;
+  }
+}
+
+// BDOF of one <= 16x16 luma tile (applyBiOptFlow :1290, gradFilterCore :213, BiOptFlowCore :162, calcBIOSums :134, addBIOAvg4 :108);
+// the windows must hold the integer samples around the block (ox, oy >= 1 beyond the filter support)
+struct BdofShared {
+  pel_t blk[2][( 16 + 2 ) * BDOF_S];       // 14-bit luma predictions with a one-sample border, stride BDOF_S
+  pel_t gx[2][16 * 16], gy[2][16 * 16];    // gradients of the interior
+};
+template<int NT>
+__device__ __forceinline__ void mc_bdof_luma( BdofShared& bs, const pel_t* win0, const pel_t* tmp0, const pel_t* win1, const pel_t* tmp1, int wst, int tst,
+                                              const McSeg* seg /* [2] for luma */, int segStride, const int16_t* cH0, const int16_t* cV0, const int16_t* cH1, const int16_t* cV1,
+                                              int bd, const DevPlanes& reco, int x0, int y0, int w, int h, int tid )
+{
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const int lw = w == 16 ? 4 : 3;
+  const McSeg& g0 = seg[0]; const McSeg& g1 = seg[segStride];
+  // (1) 14-bit predictions of both lists + the border of nearest integer samples (xPredInterBlk :863-890)
+  for( int i = tid; i < w * h; i += NT )
+  {
+    const int px = i & ( w - 1 ), py = i >> lw;
+    bs.blk[0][( 1 + py ) * BDOF_S + 1 + px] = (pel_t) mc_final( win0, wst, tmp0, tst, g0, cH0, cV0, 0, true, bd, px, py );
+    bs.blk[1][( 1 + py ) * BDOF_S + 1 + px] = (pel_t) mc_final( win1, wst, tmp1, tst, g1, cH1, cV1, 0, true, bd, px, py );
+  }
+  {
+    const int ring = 2 * ( w + 2 ) + 2 * h;
+    for( int i = tid; i < 2 * ring; i += NT )
+    {
+      const int l = i >= ring, r = i - l * ring;
+      int bi_, bj;                                       // padded coordinates: (0,0) = corner above-left of the block
+      if( r < w + 2 ) { bi_ = r; bj = 0; } else if( r < 2 * ( w + 2 ) ) { bi_ = r - ( w + 2 ); bj = h + 1; }
+      else { const int q = r - 2 * ( w + 2 ); bi_ = ( q & 1 ) ? w + 1 : 0; bj = 1 + ( q >> 1 ); }
+      const McSeg& g = l ? g1 : g0;
+      const int xOff = g.xFrac < 8 ? 1 : 0, yOff = g.yFrac < 8 ? 1 : 0;
+      const int sref = ( l ? win1 : win0 )[( g.oy - yOff + bj ) * wst + g.ox - xOff + bi_];
+      bs.blk[l][bj * BDOF_S + bi_] = (pel_t) ( (int16_t) ( sref << headroom ) - (int16_t) IF_INTERNAL_OFFS );
+    }
+  }
+  __syncthreads();
+  // (2) gradients of the interior; everything outside is a replica of the nearest interior value (the padding of :236-264),
+  //     which is what the clamped indices below read
+  for( int i = tid; i < w * h; i += NT )
+  {
+    const int px = i & ( w - 1 ), py = i >> lw;
+    for( int l = 0; l < 2; l++ )
+    {
+      const pel_t* P = bs.blk[l];
+      bs.gy[l][py * 16 + px] = (pel_t) ( ( P[( 2 + py ) * BDOF_S + 1 + px] >> 6 ) - ( P[py * BDOF_S + 1 + px] >> 6 ) );
+      bs.gx[l][py * 16 + px] = (pel_t) ( ( P[( 1 + py ) * BDOF_S + 2 + px] >> 6 ) - ( P[( 1 + py ) * BDOF_S + px] >> 6 ) );
+    }
+  }
+  __syncthreads();
+  // (3) per 4x4 unit: 6x6 window sums by four lanes, motion refinement, output
+  const int shiftNum = 15 - bd, offset = ( 1 << ( shiftNum - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+  const int unitsX = w >> 2, units = unitsX * ( h >> 2 );
+  for( int u0 = 0; u0 < units; u0 += NT / 4 )
+  {
+    const int u = u0 + ( tid >> 2 ), q = tid & 3;
+    const bool act = u < units;
+    const int xu = act ? u % unitsX : 0, yu = act ? u / unitsX : 0;
+    int sAGX = 0, sAGY = 0, sDIX = 0, sDIY = 0, sSG = 0;
+    if( act )
+    {
+      for( int p = q; p < 36; p += 4 )
+      {
+        const int wy = p / 6, wx = p - wy * 6;
+        const int ix = min( w - 1, max( 0, ( xu << 2 ) + wx - 1 ) ), iy = min( h - 1, max( 0, ( yu << 2 ) + wy - 1 ) );    // interior coordinates, clamped
+        const int o = iy * 16 + ix, ob = ( 1 + iy ) * BDOF_S + 1 + ix;
+        const int tGX = ( bs.gx[0][o] + bs.gx[1][o] ) >> 1, tGY = ( bs.gy[0][o] + bs.gy[1][o] ) >> 1;
+        const int tDI = ( bs.blk[1][ob] >> 4 ) - ( bs.blk[0][ob] >> 4 );
+        sAGX += iabs( tGX ); sAGY += iabs( tGY );
+        sDIX += tGX < 0 ? -tDI : tGX == 0 ? 0 : tDI;
+        sDIY += tGY < 0 ? -tDI : tGY == 0 ? 0 : tDI;
+        sSG  += tGY < 0 ? -tGX : tGY == 0 ? 0 : tGX;
+      }
+    }
+    for( int o = 1; o < 4; o <<= 1 )
+    {
+      sAGX += __shfl_xor( sAGX, o ); sAGY += __shfl_xor( sAGY, o ); sDIX += __shfl_xor( sDIX, o ); sDIY += __shfl_xor( sDIY, o ); sSG += __shfl_xor( sSG, o );
+    }
+    if( act )
+    {
+      int tmpx = sAGX == 0 ? 0 : ( ( sDIX * 4 ) >> ( 31 - __clz( sAGX ) ) );        // rightShiftMSB (:92): shift by floor(log2(denominator))
+      tmpx = clip3( -15, 15, tmpx );
+      const int mains = sSG >> 12, secs = sSG & 4095;
+      int tmpData = tmpx * mains;
+      tmpData = ( ( tmpData * ( 1 << 12 ) ) + tmpx * secs ) >> 1;
+      int tmpy = sAGY == 0 ? 0 : ( ( ( sDIY * 4 ) - tmpData ) >> ( 31 - __clz( sAGY ) ) );
+      tmpy = clip3( -15, 15, tmpy );
+      const int py = ( yu << 2 ) + q;
+      for( int x = 0; x < 4; x++ )
+      {
+        const int px = ( xu << 2 ) + x, o = py * 16 + px, ob = ( 1 + py ) * BDOF_S + 1 + px;
+        const int b = tmpx * ( bs.gx[0][o] - bs.gx[1][o] ) + tmpy * ( bs.gy[0][o] - bs.gy[1][o] );
+        const int v = clip_pel( (int16_t) ( ( bs.blk[0][ob] + bs.blk[1][ob] + b + offset ) >> shiftNum ), bd );
+        reco.p[0][(size_t) ( y0 + py ) * reco.stride[0] + x0 + px] = (pel_t) v;
+      }
+    }
+  }
 }
 
 // NT threads per tile.  With NT = 64 a tile is one wavefront: 32 tiles resident per CU, barriers are free, and the
@@ -115,19 +310,12 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   __shared__ McSeg seg[2][3];
   __shared__ const pel_t* refp[2][3];
   __shared__ int16_t coefH[2][3][8], coefV[2][3][8];
-  __shared__ pel_t bdBlk[2][( 16 + 2 ) * BDOF_S];          // BDOF: 14-bit luma predictions with a one-sample border, stride BDOF_S
-  __shared__ pel_t bdGx[2][16 * 16], bdGy[2][16 * 16];     // BDOF: gradients of the interior
-  // XCD-aware mapping (cdna_hip_programming.md T1): consecutive workgroups are dealt round-robin to the 8 XCDs; give each XCD
-  // a contiguous run of tiles so that the halo rows shared by neighbouring tiles hit the same L2.
-  int item;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    item = ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + ( bid >> 3 );
-  }
+  __shared__ BdofShared bs;
+  const int item = mc_item_index();
   if( item >= numItems ) return;
   const McItem it = items[item];
   const vvr_cu& cu = pic.cu[it.cu];
-  const int bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu;
+  const int bd = pic.hdr.bit_depth;
   const int tid = threadIdx.x;
   const bool biPred = cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0;
   const bool uni = cu.mc_mode == VVR_MC_UNI;
@@ -142,10 +330,8 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
     if( k < nl && c < ncomp )
     {
       const int l = uni ? l0 : k;
-      // clipMvInPic with the CU position (Mv.cpp:64; InterPrediction.cpp:657 uses m_currCuArea)
-      const int horMax = ( pic.hdr.width + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - cu.x + 1 ) * 16;
-      const int verMax = ( pic.hdr.height + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - cu.y + 1 ) * 16;
-      const int mvx = min( horMax, max( horMin, cu.mv[l][0][0] ) ), mvy = min( verMax, max( verMin, cu.mv[l][0][1] ) );
+      int mvx = cu.mv[l][0][0], mvy = cu.mv[l][0][1];
+      mc_clip_mv( pic, cu.x, cu.y, mvx, mvy );           // clipped with the CU position (InterPrediction.cpp:657 uses m_currCuArea)
       McSeg g;
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
       g.w = it.w >> cs; g.h = it.h >> cs;
@@ -156,187 +342,235 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       g.ww = g.w + ( ( doH || full ) ? ntaps - 1 : 0 ); g.wh = g.h + ( ( doV || full ) ? ntaps - 1 : 0 );
       g.x0 = ( it.x >> cs ) + ( mvx >> shf ) - g.ox;
       g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - g.oy;
+      g.padOff = 0; g.cw = g.ww; g.chh = g.wh;
       seg[k][c] = g;
       refp[k][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
-      // InterpolationFilter.cpp:1078-1085 / 669-676 (luma 4x4 blocks use the 6-tap table), :105 (alternative half-pel filter)
-      const bool altHpel = cu.imv == 3, f4 = g.w == 4 && g.h == 4;
-      const int16_t* ch = c ? d_chroma_filter[g.xFrac] : ( g.xFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[g.xFrac] : d_luma_filter[g.xFrac];
-      const int16_t* cv = c ? d_chroma_filter[g.yFrac] : ( g.yFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[g.yFrac] : d_luma_filter[g.yFrac];
-      for( int t = 0; t < ntaps; t++ ) { coefH[k][c][t] = ch[t]; coefV[k][c][t] = cv[t]; }
+      mc_taps( g, c, cu.imv == 3, coefH[k][c], coefV[k][c] );
     }
   }
   __syncthreads();
-  // ---- phase A: all reference windows of the tile into LDS, one exposure to HBM/L2 latency.
-  // lanes map to (row, column) with 32 columns per row group: no integer division, rows are contiguous 2-byte runs
-  {
-    const int col = tid & 31, row0 = tid >> 5;
-    for( int k = 0; k < nl; k++ )
-    {
-      for( int c = 0; c < ncomp; c++ )
-      {
-        const McSeg g = seg[k][c];
-        pel_t* win = c ? winC[k][c - 1] : winL[k];
-        const int wst = c ? 12 : 24;
-        const pel_t* __restrict__ ref = refp[k][c];
-        const int stride = reco.stride[c], pw = reco.w[c], ph = reco.h[c];
-        if( col < g.ww )
-        {
-          const int sx = clip3( 0, pw - 1, g.x0 + col );
-          for( int yy = row0; yy < g.wh; yy += NT / 32 )
-          {
-            const int sy = clip3( 0, ph - 1, g.y0 + yy );
-            win[yy * wst + col] = ref[(size_t) sy * stride + sx];
-          }
-        }
-      }
-    }
-  }
+  // ---- phase A: all reference windows of the tile into LDS, one exposure to HBM/L2 latency
+  for( int k = 0; k < nl; k++ ) for( int c = 0; c < ncomp; c++ )
+    mc_load_window<NT>( c ? winC[k][c - 1] : winL[k], c ? 12 : 24, seg[k][c], refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
   __syncthreads();
-  // ---- phase B: horizontal pass of the 2-D segments (16-bit intermediates, InterpolationFilter.cpp:902-915)
-  {
-    const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-    const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
-    const int col = tid & 15, row0 = tid >> 4;
-    for( int k = 0; k < nl; k++ )
-    {
-      for( int c = 0; c < ncomp; c++ )
-      {
-        const McSeg g = seg[k][c];
-        if( !( g.xFrac && g.yFrac ) || col >= g.w ) continue;
-        const pel_t* win = c ? winC[k][c - 1] : winL[k];
-        pel_t* tmp = c ? tmpC[k][c - 1] : tmpL[k];
-        const int wst = c ? 12 : 24, tst = c ? 8 : 16, ntaps = c ? 4 : 8;
-        int cf[8];
-        for( int t = 0; t < 8; t++ ) cf[t] = coefH[k][c][t];
-        for( int yy = row0; yy < g.wh; yy += NT / 16 )
-        {
-          int sum = 0;
-          for( int t = 0; t < ntaps; t++ ) sum += win[yy * wst + col + t] * cf[t];          // 2-D segments always have ox = ntaps/2 - 1
-          tmp[yy * tst + col] = (int16_t) ( ( sum + offset1 ) >> shift1 );
-        }
-      }
-    }
-  }
+  // ---- phase B: horizontal pass of the 2-D segments
+  for( int k = 0; k < nl; k++ ) for( int c = 0; c < ncomp; c++ )
+    mc_hpass<NT>( c ? winC[k][c - 1] : winL[k], c ? 12 : 24, c ? tmpC[k][c - 1] : tmpL[k], c ? 8 : 16, seg[k][c], coefH[k][c], c, bd, tid );
   __syncthreads();
   // ---- phase C: final samples
-  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  if( bdof )
-  {
-    // ---- BDOF luma (applyBiOptFlow :1290, gradFilterCore :213, BiOptFlowCore :162, calcBIOSums :134, addBIOAvg4 :108)
-    const int w = it.w, h = it.h, lw = w == 16 ? 4 : 3;
-    // (1) 14-bit predictions of both lists + the border of nearest integer samples
-    for( int i = tid; i < w * h; i += NT )
-    {
-      const int px = i & ( w - 1 ), py = i >> lw;
-      bdBlk[0][( 1 + py ) * BDOF_S + 1 + px] = (pel_t) mc_final( winL[0], 24, tmpL[0], 16, seg[0][0], coefH[0][0], coefV[0][0], 0, true, bd, px, py );
-      bdBlk[1][( 1 + py ) * BDOF_S + 1 + px] = (pel_t) mc_final( winL[1], 24, tmpL[1], 16, seg[1][0], coefH[1][0], coefV[1][0], 0, true, bd, px, py );
-    }
-    {
-      const int ring = 2 * ( w + 2 ) + 2 * h;
-      for( int i = tid; i < 2 * ring; i += NT )
-      {
-        const int l = i >= ring, r = i - l * ring;
-        int bi_, bj;                                       // padded coordinates: (0,0) = corner above-left of the block
-        if( r < w + 2 ) { bi_ = r; bj = 0; } else if( r < 2 * ( w + 2 ) ) { bi_ = r - ( w + 2 ); bj = h + 1; }
-        else { const int q = r - 2 * ( w + 2 ); bi_ = ( q & 1 ) ? w + 1 : 0; bj = 1 + ( q >> 1 ); }
-        const McSeg& g = seg[l][0];
-        const int xOff = g.xFrac < 8 ? 1 : 0, yOff = g.yFrac < 8 ? 1 : 0;
-        const int sref = winL[l][( g.oy - yOff + bj ) * 24 + g.ox - xOff + bi_];
-        bdBlk[l][bj * BDOF_S + bi_] = (pel_t) ( (int16_t) ( sref << headroom ) - (int16_t) IF_INTERNAL_OFFS );
-      }
-    }
-    __syncthreads();
-    // (2) gradients of the interior; everything outside is a replica of the nearest interior value (the padding of :236-264),
-    //     which is what the clamped indices below read
-    for( int i = tid; i < w * h; i += NT )
-    {
-      const int px = i & ( w - 1 ), py = i >> lw;
-      for( int l = 0; l < 2; l++ )
-      {
-        const pel_t* P = bdBlk[l];
-        bdGy[l][py * 16 + px] = (pel_t) ( ( P[( 2 + py ) * BDOF_S + 1 + px] >> 6 ) - ( P[py * BDOF_S + 1 + px] >> 6 ) );
-        bdGx[l][py * 16 + px] = (pel_t) ( ( P[( 1 + py ) * BDOF_S + 2 + px] >> 6 ) - ( P[( 1 + py ) * BDOF_S + px] >> 6 ) );
-      }
-    }
-    __syncthreads();
-    // (3) per 4x4 unit: 6x6 window sums by four lanes, motion refinement, output
-    const int shiftNum = 15 - bd, offset = ( 1 << ( shiftNum - 1 ) ) + 2 * IF_INTERNAL_OFFS;
-    const int unitsX = w >> 2, units = unitsX * ( h >> 2 );
-    for( int u0 = 0; u0 < units; u0 += NT / 4 )
-    {
-      const int u = u0 + ( tid >> 2 ), q = tid & 3;
-      const bool act = u < units;
-      const int xu = act ? u % unitsX : 0, yu = act ? u / unitsX : 0;
-      int sAGX = 0, sAGY = 0, sDIX = 0, sDIY = 0, sSG = 0;
-      if( act )
-      {
-        for( int p = q; p < 36; p += 4 )
-        {
-          const int wy = p / 6, wx = p - wy * 6;
-          const int ix = min( w - 1, max( 0, ( xu << 2 ) + wx - 1 ) ), iy = min( h - 1, max( 0, ( yu << 2 ) + wy - 1 ) );    // interior coordinates, clamped
-          const int o = iy * 16 + ix, ob = ( 1 + iy ) * BDOF_S + 1 + ix;
-          const int tGX = ( bdGx[0][o] + bdGx[1][o] ) >> 1, tGY = ( bdGy[0][o] + bdGy[1][o] ) >> 1;
-          const int tDI = ( bdBlk[1][ob] >> 4 ) - ( bdBlk[0][ob] >> 4 );
-          sAGX += iabs( tGX ); sAGY += iabs( tGY );
-          sDIX += tGX < 0 ? -tDI : tGX == 0 ? 0 : tDI;
-          sDIY += tGY < 0 ? -tDI : tGY == 0 ? 0 : tDI;
-          sSG  += tGY < 0 ? -tGX : tGY == 0 ? 0 : tGX;
-        }
-      }
-      for( int o = 1; o < 4; o <<= 1 )
-      {
-        sAGX += __shfl_xor( sAGX, o ); sAGY += __shfl_xor( sAGY, o ); sDIX += __shfl_xor( sDIX, o ); sDIY += __shfl_xor( sDIY, o ); sSG += __shfl_xor( sSG, o );
-      }
-      if( act )
-      {
-        int tmpx = sAGX == 0 ? 0 : ( ( sDIX * 4 ) >> ( 31 - __clz( sAGX ) ) );        // rightShiftMSB (:92): shift by floor(log2(denominator))
-        tmpx = clip3( -15, 15, tmpx );
-        const int mains = sSG >> 12, secs = sSG & 4095;
-        int tmpData = tmpx * mains;
-        tmpData = ( ( tmpData * ( 1 << 12 ) ) + tmpx * secs ) >> 1;
-        int tmpy = sAGY == 0 ? 0 : ( ( ( sDIY * 4 ) - tmpData ) >> ( 31 - __clz( sAGY ) ) );
-        tmpy = clip3( -15, 15, tmpy );
-        const int py = ( yu << 2 ) + q;
-        for( int x = 0; x < 4; x++ )
-        {
-          const int px = ( xu << 2 ) + x, o = py * 16 + px, ob = ( 1 + py ) * BDOF_S + 1 + px;
-          const int b = tmpx * ( bdGx[0][o] - bdGx[1][o] ) + tmpy * ( bdGy[0][o] - bdGy[1][o] );
-          const int v = clip_pel( (int16_t) ( ( bdBlk[0][ob] + bdBlk[1][ob] + b + offset ) >> shiftNum ), bd );
-          reco.p[0][(size_t) ( it.y + py ) * reco.stride[0] + it.x + px] = (pel_t) v;
-        }
-      }
-    }
-  }
+  if( bdof ) mc_bdof_luma<NT>( bs, winL[0], tmpL[0], winL[1], tmpL[1], 24, 16, &seg[0][0], 3, coefH[0][0], coefV[0][0], coefH[1][0], coefV[1][0], bd, reco, it.x, it.y, it.w, it.h, tid );
   for( int c = bdof ? 1 : 0; c < ncomp; c++ )
   {
     const int cs = c ? 1 : 0;
-    const int w = it.w >> cs, h = it.h >> cs;
-    const pel_t* win0 = c ? winC[0][c - 1] : winL[0]; const pel_t* tmp0 = c ? tmpC[0][c - 1] : tmpL[0];
-    const pel_t* win1 = c ? winC[1][c - 1] : winL[1]; const pel_t* tmp1 = c ? tmpC[1][c - 1] : tmpL[1];
-    const int wst = c ? 12 : 24, tst = c ? 8 : 16;
-    const int lw = w == 16 ? 4 : w == 8 ? 3 : w == 4 ? 2 : 1;       // log2 of the tile width
-    for( int i = tid; i < w * h; i += NT )
+    mc_output<NT>( c ? winC[0][c - 1] : winL[0], c ? tmpC[0][c - 1] : tmpL[0], c ? winC[1][c - 1] : winL[1], c ? tmpC[1][c - 1] : tmpL[1], c ? 12 : 24, c ? 8 : 16,
+                   &seg[0][c], &seg[1][c], coefH[0][c], coefV[0][c], coefH[1][c], coefV[1][c], c, uni, cu.bcw_idx, bd, reco, it.x >> cs, it.y >> cs, it.w >> cs, it.h >> cs, tid );
+  }
+}
+
+// =====================================================================================================================
+// k_mc_dmvr — decoder-side motion vector refinement + final prediction of one <= 16x16 sub-block (one wavefront).
+//   InterPrediction::xProcessDMVR (InterPrediction.cpp:1847): xinitMC (:1804) bilinear prediction at 10 bit, SAD at the centre
+//   (RdCost::xGetSAD8/16, every second row), early out, 25-point mirrored integer search (xBIPMVRefine :1702), parametric
+//   sub-sample refinement (xDMVRSubPixelErrorSurface :1785, xSubPelErrorSrfc :1647, div_for_maxq7 :1612), then the final 8/4-tap
+//   prediction from the padded local copy when the integer MV moved (xPrefetchPad :1525, xFinalPaddedMCForDMVR :1731) and
+//   the average or BDOF (bioAppliedSubblk :1984).  The delta MV goes to dmvrOut[cu.dmvr_off + sub-block] for the host
+//   (DecCu::TaskFinishMotionInfo, DecCu.cpp:161).
+// =====================================================================================================================
+#define DM_WST_L 28
+#define DM_WST_C 16
+struct DmvrShared {
+  pel_t winL[2][27 * DM_WST_L];
+  pel_t winC[2][2][15 * DM_WST_C];
+  pel_t tmpL[2][MC_TMP_L];
+  pel_t tmpC[2][2][MC_TMP_C];
+  pel_t bil[2][20 * 20];
+  McSeg seg[2][3];
+  const pel_t* refp[2][3];
+  int16_t coefH[2][3][8], coefV[2][3][8];
+  unsigned sad[25];
+  int dmv[2], bioSub, minCost;
+  BdofShared bs;
+};
+
+__device__ __forceinline__ int dmvr_div_for_maxq7( long long N, long long D )
+{
+  int sign = 0, q = 0;
+  if( N < 0 ) { sign = 1; N = -N; }
+  D = D << 3;
+  if( N >= D ) { N -= D; q++; }
+  q = q << 1;
+  D = D >> 1;
+  if( N >= D ) { N -= D; q++; }
+  q = q << 1;
+  if( N >= ( D >> 1 ) ) q++;
+  return sign ? -q : q;
+}
+
+template<int NT>
+__global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems, int32_t* __restrict__ dmvrOut )
+{
+  __shared__ DmvrShared sh;
+  const int item = mc_item_index();
+  if( item >= numItems ) return;
+  const McItem it = items[item];
+  const vvr_cu& cu = pic.cu[it.cu];
+  const int bd = pic.hdr.bit_depth;
+  const int tid = threadIdx.x;
+  const int ncomp = pic.hdr.chroma_format ? 3 : 1;
+  const int w = it.w, h = it.h;
+  const bool bio = cu.mc_mode == VVR_MC_DMVR_BDOF;
+  // ---- stage 1: bilinear predictions of the sub-block extended by 2 samples (start MVs clipped against the CU, then moved by -2)
+  if( tid < 2 )
+  {
+    const int l = tid;
+    int mvx = cu.mv[l][0][0], mvy = cu.mv[l][0][1];
+    mc_clip_mv( pic, cu.x, cu.y, mvx, mvy );
+    mvx -= 32; mvy -= 32;
+    McSeg g;
+    g.w = w + 4; g.h = h + 4; g.xFrac = mvx & 15; g.yFrac = mvy & 15;
+    g.x0 = it.x + ( mvx >> 4 ); g.y0 = it.y + ( mvy >> 4 ); g.ww = g.w + 1; g.wh = g.h + 1; g.ox = g.oy = 0; g.padOff = 0; g.cw = g.ww; g.chh = g.wh;
+    sh.seg[l][0] = g;
+    sh.refp[l][0] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][0];
+  }
+  __syncthreads();
+  for( int l = 0; l < 2; l++ ) mc_load_window<NT>( sh.winL[l], DM_WST_L, sh.seg[l][0], sh.refp[l][0], reco.stride[0], reco.w[0], reco.h[0], tid );
+  __syncthreads();
+  {
+    // InterpolationFilter::filter<2> (:589-600) / filterCopy biMCForDMVR (:445-477) at IF_INTERNAL_PREC_BILINEAR = 10
+    const int shiftF = 4 - ( 10 - bd ), offF = shiftF > 0 ? 1 << ( shiftF - 1 ) : 0;
+    const int ew = w + 4, eh = h + 4;
+    for( int i = tid; i < 2 * ew * eh; i += NT )
     {
-      const int px = i & ( w - 1 ), py = i >> lw;
-      int out;
-      if( uni ) out = mc_final( win0, wst, tmp0, tst, seg[0][c], coefH[0][c], coefV[0][c], c, false, bd, px, py );
+      const int l = i >= ew * eh, r = i - l * ew * eh, y = r / ew, x = r - y * ew;
+      const McSeg& g = sh.seg[l][0];
+      const pel_t* p = &sh.winL[l][y * DM_WST_L + x];
+      int v;
+      if( !g.xFrac && !g.yFrac ) v = p[0] * ( 1 << ( 10 - bd ) );
+      else if( !g.yFrac ) v = ( p[0] * ( 16 - g.xFrac ) + p[1] * g.xFrac + offF ) >> shiftF;
+      else if( !g.xFrac ) v = ( p[0] * ( 16 - g.yFrac ) + p[DM_WST_L] * g.yFrac + offF ) >> shiftF;
       else
       {
-        const int p0 = mc_final( win0, wst, tmp0, tst, seg[0][c], coefH[0][c], coefV[0][c], c, true, bd, px, py );
-        const int p1 = mc_final( win1, wst, tmp1, tst, seg[1][c], coefH[1][c], coefV[1][c], c, true, bd, px, py );
-        if( cu.bcw_idx != 2 )
-        {
-          const int w1 = d_bcw_weights[cu.bcw_idx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
-          out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
-        }
-        else
-        {
-          const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
-          out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
-        }
+        const int t0 = (int16_t) ( ( p[0] * ( 16 - g.xFrac ) + p[1] * g.xFrac + offF ) >> shiftF );
+        const int t1 = (int16_t) ( ( p[DM_WST_L] * ( 16 - g.xFrac ) + p[DM_WST_L + 1] * g.xFrac + offF ) >> shiftF );
+        v = ( t0 * ( 16 - g.yFrac ) + t1 * g.yFrac + 8 ) >> 4;
       }
-      reco.p[c][(size_t) ( ( it.y >> cs ) + py ) * reco.stride[c] + ( it.x >> cs ) + px] = (pel_t) out;
+      sh.bil[l][y * 20 + x] = (pel_t) v;
     }
+  }
+  __syncthreads();
+  // ---- stage 2: SAD at the centre on every second row, early termination, 25-point search with mirrored offsets
+  {
+    int part = 0;
+    const int lw = w == 16 ? 4 : 3;
+    for( int i = tid; i < w * ( h >> 1 ); i += NT )
+    {
+      const int x = i & ( w - 1 ), y = ( i >> lw ) << 1;
+      part += iabs( sh.bil[0][( 2 + y ) * 20 + 2 + x] - sh.bil[1][( 2 + y ) * 20 + 2 + x] );
+    }
+    for( int o = 32; o; o >>= 1 ) part += __shfl_xor( part, o );       // NT == 64: one wavefront
+    unsigned minCost = (unsigned) part << 1;                               // xGetSAD: uiSum <<= subShift
+    minCost >>= 1; minCost -= minCost >> 2;
+    const bool search = !( minCost < (unsigned) ( w * h ) );
+    if( search )
+    {
+      // two lanes per candidate: rows 0,4,8,.. and 2,6,10,..
+      const int cand = tid >> 1, half = tid & 1;
+      unsigned sad = 0;
+      if( cand < 25 && cand != 12 )
+      {
+        const int ver = cand / 5 - 2, hor = cand - ( cand / 5 ) * 5 - 2;
+        const pel_t* a = &sh.bil[0][( 2 + ver ) * 20 + 2 + hor];
+        const pel_t* b = &sh.bil[1][( 2 - ver ) * 20 + 2 - hor];
+        for( int y = half * 2; y < h; y += 4 ) for( int x = 0; x < w; x++ ) sad += (unsigned) iabs( a[y * 20 + x] - b[y * 20 + x] );
+      }
+      sad += __shfl_xor( sad, 1 );
+      if( cand < 25 && !half ) sh.sad[cand] = cand == 12 ? minCost : ( ( sad << 1 ) >> 1 );      // X5: ( SAD << subShift ) >> 1
+    }
+    __syncthreads();
+    if( tid == 0 )
+    {
+      int total0 = 0, total1 = 0;
+      if( search )
+      {
+        int d0 = 0, d1 = 0;
+        for( int ver = -2; ver <= 2; ver++ ) for( int hor = -2; hor <= 2; hor++ )
+        {
+          const unsigned cost = sh.sad[( ver + 2 ) * 5 + hor + 2];
+          if( cost < minCost ) { minCost = cost; d0 = hor; d1 = ver; }
+        }
+        total0 = d0 * 16; total1 = d1 * 16;
+        if( iabs( total0 ) != 32 && iabs( total1 ) != 32 )
+        {
+          const int ci = ( d1 + 2 ) * 5 + d0 + 2;
+          const long long s0 = sh.sad[ci], s1 = sh.sad[ci - 1], s2 = sh.sad[ci - 5], s3 = sh.sad[ci + 1], s4 = sh.sad[ci + 5];
+          long long num = ( s1 - s3 ) * 16, den = s1 + s3 - 2 * s0;
+          if( den != 0 ) total0 += ( s1 != s0 && s3 != s0 ) ? dmvr_div_for_maxq7( num, den ) : ( s1 == s0 ? -8 : 8 );
+          num = ( s2 - s4 ) * 16; den = s2 + s4 - 2 * s0;
+          if( den != 0 ) total1 += ( s2 != s0 && s4 != s0 ) ? dmvr_div_for_maxq7( num, den ) : ( s2 == s0 ? -8 : 8 );
+        }
+        total0 = (int16_t) total0; total1 = (int16_t) total1;
+      }
+      sh.dmv[0] = total0; sh.dmv[1] = total1;
+      sh.bioSub = ( minCost < (unsigned) ( 2 * w * h ) ) ? 0 : ( bio ? 1 : 0 );
+      const int sub = ( ( it.y - cu.y ) / min( 16, (int) cu.h ) ) * ( ( cu.w + 15 ) >> 4 ) + ( ( it.x - cu.x ) >> 4 );
+      dmvrOut[2 * ( cu.dmvr_off + sub )] = total0; dmvrOut[2 * ( cu.dmvr_off + sub ) + 1] = total1;
+    }
+    __syncthreads();
+  }
+  const bool bioSub = sh.bioSub != 0;
+  // ---- stage 3: final prediction with the refined MVs (clipped against the SUB-block, :1752)
+  if( tid < 6 )
+  {
+    const int l = tid / 3, c = tid - 3 * l;
+    if( c < ncomp )
+    {
+      const int sgn = l ? -1 : 1;
+      const int mgx = cu.mv[l][0][0], mgy = cu.mv[l][0][1];
+      const int rmx = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mgx + sgn * sh.dmv[0] ), rmy = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mgy + sgn * sh.dmv[1] );
+      int cmx = rmx, cmy = rmy;
+      mc_clip_mv( pic, it.x, it.y, cmx, cmy );
+      const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
+      const int dIntX = ( rmx >> shf ) - ( mgx >> shf ), dIntY = ( rmy >> shf ) - ( mgy >> shf );
+      McSeg g;
+      g.w = w >> cs; g.h = h >> cs;
+      g.xFrac = cmx & ( ( 1 << shf ) - 1 ); g.yFrac = cmy & ( ( 1 << shf ) - 1 );
+      if( dIntX || dIntY )
+      {
+        // padded local copy: the (w + ntaps - 1)^2 window at the start MV, replicated outwards (xPrefetchPad + paddingCore)
+        int pmx = mgx - ( half << shf ), pmy = mgy - ( half << shf );
+        mc_clip_mv( pic, it.x, it.y, pmx, pmy );
+        g.x0 = ( it.x >> cs ) + ( pmx >> shf ); g.y0 = ( it.y >> cs ) + ( pmy >> shf );
+        g.cw = g.w + ntaps - 1; g.chh = g.h + ntaps - 1; g.padOff = 2;
+        g.ww = g.cw + 4; g.wh = g.chh + 4;
+        g.ox = 2 + half + dIntX; g.oy = 2 + half + dIntY;
+      }
+      else
+      {
+        const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
+        const bool full = bioSub && c == 0;
+        g.ox = ( doH || full ) ? half : 0; g.oy = ( doV || full ) ? half : 0;
+        g.ww = g.w + ( ( doH || full ) ? ntaps - 1 : 0 ); g.wh = g.h + ( ( doV || full ) ? ntaps - 1 : 0 );
+        g.x0 = ( it.x >> cs ) + ( cmx >> shf ) - g.ox; g.y0 = ( it.y >> cs ) + ( cmy >> shf ) - g.oy;
+        g.padOff = 0; g.cw = g.ww; g.chh = g.wh;
+      }
+      sh.seg[l][c] = g;
+      sh.refp[l][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
+      mc_taps( g, c, cu.imv == 3, sh.coefH[l][c], sh.coefV[l][c] );
+    }
+  }
+  __syncthreads();
+  for( int k = 0; k < 2; k++ ) for( int c = 0; c < ncomp; c++ )
+    mc_load_window<NT>( c ? sh.winC[k][c - 1] : sh.winL[k], c ? DM_WST_C : DM_WST_L, sh.seg[k][c], sh.refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
+  __syncthreads();
+  for( int k = 0; k < 2; k++ ) for( int c = 0; c < ncomp; c++ )
+    mc_hpass<NT>( c ? sh.winC[k][c - 1] : sh.winL[k], c ? DM_WST_C : DM_WST_L, c ? sh.tmpC[k][c - 1] : sh.tmpL[k], c ? 8 : 16, sh.seg[k][c], sh.coefH[k][c], c, bd, tid );
+  __syncthreads();
+  if( bioSub ) mc_bdof_luma<NT>( sh.bs, sh.winL[0], sh.tmpL[0], sh.winL[1], sh.tmpL[1], DM_WST_L, 16, &sh.seg[0][0], 3, sh.coefH[0][0], sh.coefV[0][0], sh.coefH[1][0], sh.coefV[1][0], bd, reco, it.x, it.y, w, h, tid );
+  for( int c = bioSub ? 1 : 0; c < ncomp; c++ )
+  {
+    const int cs = c ? 1 : 0;
+    mc_output<NT>( c ? sh.winC[0][c - 1] : sh.winL[0], c ? sh.tmpC[0][c - 1] : sh.tmpL[0], c ? sh.winC[1][c - 1] : sh.winL[1], c ? sh.tmpC[1][c - 1] : sh.tmpL[1], c ? DM_WST_C : DM_WST_L, c ? 8 : 16,
+                   &sh.seg[0][c], &sh.seg[1][c], sh.coefH[0][c], sh.coefV[0][c], sh.coefH[1][c], sh.coefV[1][c], c, false, 2, bd, reco, it.x >> cs, it.y >> cs, w >> cs, h >> cs, tid );
   }
 }
 
@@ -348,6 +582,12 @@ void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes 
   if( g_mcThreads == 256 )      hipLaunchKernelGGL( k_mc<256>, dim3( numItems ), dim3( 256 ), 0, s, pic, refs, reco, items, numItems );
   else if( g_mcThreads == 128 ) hipLaunchKernelGGL( k_mc<128>, dim3( numItems ), dim3( 128 ), 0, s, pic, refs, reco, items, numItems );
   else                          hipLaunchKernelGGL( k_mc<64>,  dim3( numItems ), dim3( 64 ),  0, s, pic, refs, reco, items, numItems );
+}
+
+void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut )
+{
+  if( !numItems ) return;
+  hipLaunchKernelGGL( k_mc_dmvr<64>, dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems, dmvrOut );
 }
 
 // =====================================================================================================================
