@@ -394,6 +394,165 @@ static int dmvr_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* 
   return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Affine motion compensation + PROF: InterPrediction::xPredAffineBlk (InterPrediction.cpp:934-1288),
+ * isSubblockVectorSpreadOverLimit (:892), applyPROFCore (:61), gradFilterCore<false> (:213), roundAffineMv (Mv.cpp:57).
+ * Sub-block MVs are read from the motion field (the parser side stores them, PU::setAllAffineMv UnitTools.cpp:2689). */
+static void round_affine_mv( int* mx, int* my, int sh ) { const int o = 1 << ( sh - 1 ); *mx = ( *mx + o - ( *mx >= 0 ) ) >> sh; *my = ( *my + o - ( *my >= 0 ) ) >> sh; }
+
+static int affine_spread_over_limit( int a, int b, int c, int d, int predType )
+{
+  const int s4 = 4 << 11, filterTap = 6;
+  if( predType == 3 )
+  {
+    int rw = vvo_max( vvo_max( 0, 4 * a + s4 ), vvo_max( 4 * c, 4 * a + 4 * c + s4 ) ) - vvo_min( vvo_min( 0, 4 * a + s4 ), vvo_min( 4 * c, 4 * a + 4 * c + s4 ) );
+    int rh = vvo_max( vvo_max( 0, 4 * b ), vvo_max( 4 * d + s4, 4 * b + 4 * d + s4 ) ) - vvo_min( vvo_min( 0, 4 * b ), vvo_min( 4 * d + s4, 4 * b + 4 * d + s4 ) );
+    rw = ( rw >> 11 ) + filterTap + 3; rh = ( rh >> 11 ) + filterTap + 3;
+    return rw * rh > ( filterTap + 9 ) * ( filterTap + 9 );
+  }
+  int rw = vvo_max( 0, 4 * a + s4 ) - vvo_min( 0, 4 * a + s4 ), rh = vvo_max( 0, 4 * b ) - vvo_min( 0, 4 * b );
+  rw = ( rw >> 11 ) + filterTap + 3; rh = ( rh >> 11 ) + filterTap + 3;
+  if( rw * rh > ( filterTap + 9 ) * ( filterTap + 5 ) ) return 1;
+  rw = vvo_max( 0, 4 * c ) - vvo_min( 0, 4 * c ); rh = vvo_max( 0, 4 * d + s4 ) - vvo_min( 0, 4 * d + s4 );
+  rw = ( rw >> 11 ) + filterTap + 3; rh = ( rh >> 11 ) + filterTap + 3;
+  return rw * rh > ( filterTap + 5 ) * ( filterTap + 9 );
+}
+
+/* one list of an affine CU into dst[c] (component-sized buffers, stride = component width); bi = 1 keeps 14-bit samples */
+static void affine_list( const vvr_picture* pic, const vvr_cu* cu, int l, const vvo_planes* ref, int bi, pel* const dst[3] )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int bd = H->bit_depth, ctu = 1 << H->log2_ctu, w4 = ( H->width + 3 ) >> 2;
+  const int ncomp = H->chroma_format ? 3 : 1;
+  const int shift = 7;                                               /* MAX_CU_DEPTH */
+  const int lw = vvo_log2( cu->w ), lh = vvo_log2( cu->h );
+  const int dHX = ( cu->mv[l][1][0] - cu->mv[l][0][0] ) * ( 1 << ( shift - lw ) ), dHY = ( cu->mv[l][1][1] - cu->mv[l][0][1] ) * ( 1 << ( shift - lw ) );
+  int dVX, dVY;
+  if( cu->flags & VVR_CU_AFFINE_6P ) { dVX = ( cu->mv[l][2][0] - cu->mv[l][0][0] ) * ( 1 << ( shift - lh ) ); dVY = ( cu->mv[l][2][1] - cu->mv[l][0][1] ) * ( 1 << ( shift - lh ) ); }
+  else { dVX = -dHY; dVY = dHX; }
+  const int over = affine_spread_over_limit( dHX, dHY, dVX, dVY, cu->inter_dir );
+  const int sixP = ( cu->flags & VVR_CU_AFFINE_6P ) != 0;
+  const int eqRT = cu->mv[l][0][0] == cu->mv[l][1][0] && cu->mv[l][0][1] == cu->mv[l][1][1];
+  const int eqLB = cu->mv[l][0][0] == cu->mv[l][2][0] && cu->mv[l][0][1] == cu->mv[l][2][1];
+  int prof = ( H->tool_flags & VVR_TOOL_PROF ) != 0;
+  prof &= !( ( sixP && eqRT && eqLB ) || ( !sixP && eqRT ) );
+  prof &= !over;
+  int dMvH[16], dMvV[16];
+  if( prof )
+  {
+    const int qHX = dHX * 4, qHY = dHY * 4, qVX = dVX * 4, qVY = dVY * 4;
+    dMvH[0] = ( ( dHX + dVX ) * 2 ) - ( ( qHX + qVX ) * 2 );
+    dMvV[0] = ( ( dHY + dVY ) * 2 ) - ( ( qHY + qVY ) * 2 );
+    for( int x = 1; x < 4; x++ ) { dMvH[x] = dMvH[x - 1] + qHX; dMvV[x] = dMvV[x - 1] + qHY; }
+    for( int y = 1; y < 4; y++ ) for( int x = 0; x < 4; x++ ) { dMvH[y * 4 + x] = dMvH[( y - 1 ) * 4 + x] + qVX; dMvV[y * 4 + x] = dMvV[( y - 1 ) * 4 + x] + qVY; }
+    for( int i = 0; i < 16; i++ ) { round_affine_mv( &dMvH[i], &dMvV[i], 8 ); dMvH[i] = vvo_clip3( -31, 31, dMvH[i] ); dMvV[i] = vvo_clip3( -31, 31, dMvV[i] ); }
+  }
+  const int horMax = ( H->width + 8 - cu->x - 1 ) * 16, horMin = ( -ctu - 8 - cu->x + 1 ) * 16;
+  const int verMax = ( H->height + 8 - cu->y - 1 ) * 16, verMin = ( -ctu - 8 - cu->y + 1 ) * 16;
+  const int headroom = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2;
+  for( int c = 0; c < ncomp; c++ )
+  {
+    const int cs = c ? 1 : 0, sh = 4 + cs;
+    const int cw = cu->w >> cs, chh = cu->h >> cs;
+    for( int y = 0; y < chh; y += 4 ) for( int x = 0; x < cw; x += 4 )
+    {
+      int mx, my;
+      if( c == 0 )
+      {
+        const vvr_motion* m = &pic->motion[(size_t) ( ( cu->y + y ) >> 2 ) * w4 + ( ( cu->x + x ) >> 2 )];
+        mx = m->mv[l][0]; my = m->mv[l][1];
+      }
+      else
+      {   /* 4:2:0: sum of the luma sub-block MVs at (0,0) and (1,1) of the 2x2 group, halved with rounding (:1156-1176) */
+        const int lx = cu->x + 2 * x, ly = cu->y + 2 * y;
+        const vvr_motion* m0 = &pic->motion[(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )];
+        const vvr_motion* m1 = &pic->motion[(size_t) ( ( ly >> 2 ) + 1 ) * w4 + ( lx >> 2 ) + 1];
+        mx = m0->mv[l][0] + m1->mv[l][0]; my = m0->mv[l][1] + m1->mv[l][1];
+        round_affine_mv( &mx, &my, 1 );
+      }
+      mx = vvo_min( horMax, vvo_max( horMin, mx ) ); my = vvo_min( verMax, vvo_max( verMin, my ) );
+      const int bx = ( cu->x >> cs ) + x, by = ( cu->y >> cs ) + y;
+      pel* d = dst[c] + y * cw + x;
+      if( c == 0 && prof )
+      {
+        pel ext[6 * 6], gX[16], gY[16];
+        pred_block( ref, 0, bx, by, 4, 4, mx, my, 1, 0, bd, ext + 6 + 1, 6 );
+        const int xFrac = mx & 15, yFrac = my & 15, xOff = xFrac >> 3, yOff = yFrac >> 3;
+        const int x0 = bx + ( mx >> 4 ), y0 = by + ( my >> 4 );
+        for( int j = 0; j < 6; j++ ) for( int i = 0; i < 6; i++ )
+        {
+          if( i >= 1 && i <= 4 && j >= 1 && j <= 4 ) continue;
+          if( ( i == 0 || i == 5 ) && ( j == 0 || j == 5 ) && 0 ) continue;
+          ext[j * 6 + i] = (pel) ( vvo_ref_at( ref, 0, x0 + i - 1 + xOff, y0 + j - 1 + yOff ) * ( 1 << headroom ) - (pel) IF_INTERNAL_OFFS );
+        }
+        for( int yy = 0; yy < 4; yy++ ) for( int xx = 0; xx < 4; xx++ )
+        {
+          const pel* sp = ext + ( 1 + yy ) * 6 + 1 + xx;
+          gY[yy * 4 + xx] = (pel) ( ( sp[6] >> 6 ) - ( sp[-6] >> 6 ) );
+          gX[yy * 4 + xx] = (pel) ( ( sp[1] >> 6 ) - ( sp[-1] >> 6 ) );
+        }
+        const int dILimit = 1 << vvo_max( bd + 1, 13 );
+        const int offset = ( 1 << ( headroom - 1 ) ) + IF_INTERNAL_OFFS;
+        for( int yy = 0; yy < 4; yy++ ) for( int xx = 0; xx < 4; xx++ )
+        {
+          int dI = dMvH[yy * 4 + xx] * gX[yy * 4 + xx] + dMvV[yy * 4 + xx] * gY[yy * 4 + xx];
+          dI = vvo_clip3( -dILimit, dILimit - 1, dI );
+          pel v = (pel) ( ext[( 1 + yy ) * 6 + 1 + xx] + dI );
+          if( !bi ) { v = (pel) ( ( v + offset ) >> headroom ); v = (pel) vvo_clip_pel( v, bd ); }
+          d[yy * cw + xx] = v;
+        }
+      }
+      else pred_block( ref, c, bx, by, 4, 4, mx, my, bi, 0, bd, d, cw );
+    }
+  }
+}
+
+static int affine_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* refs, vvo_planes* reco )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int bd = H->bit_depth, ncomp = H->chroma_format ? 3 : 1;
+  const int biPred = cu->ref_idx[0] >= 0 && cu->ref_idx[1] >= 0;
+  const size_t n = (size_t) cu->w * cu->h;
+  pel* buf = (pel*) malloc( sizeof( pel ) * n * 3 );
+  pel* p0[3] = { buf, buf + n, buf + n + n / 4 };
+  pel* p1[3] = { buf + n + n / 2, buf + 2 * n + n / 2, buf + 2 * n + n / 2 + n / 4 };
+  if( !pic->motion ) { free( buf ); vvo_set_error( "affine CU without a motion field" ); return -1; }
+  if( biPred )
+  {
+    affine_list( pic, cu, 0, &refs[H->ref_slot[0][cu->ref_idx[0]]], 1, p0 );
+    affine_list( pic, cu, 1, &refs[H->ref_slot[1][cu->ref_idx[1]]], 1, p1 );
+  }
+  else
+  {
+    const int l = cu->ref_idx[0] >= 0 ? 0 : 1;
+    affine_list( pic, cu, l, &refs[H->ref_slot[l][cu->ref_idx[l]]], 0, p0 );
+  }
+  for( int c = 0; c < ncomp; c++ )
+  {
+    const int cs = c ? 1 : 0, w = cu->w >> cs, h = cu->h >> cs;
+    pel* dst = reco->p[c] + (size_t) ( cu->y >> cs ) * reco->stride[c] + ( cu->x >> cs );
+    for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+    {
+      int v;
+      if( !biPred ) v = p0[c][y * w + x];
+      else if( cu->bcw_idx != 2 )
+      {
+        const int w1 = vvc_bcw_weights[cu->bcw_idx], w0 = 8 - w1;
+        const int shift = ( IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2 ) + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+        v = vvo_clip_pel( ( p0[c][y * w + x] * w0 + p1[c][y * w + x] * w1 + offset ) >> shift, bd );
+      }
+      else
+      {
+        const int shift = ( IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2 ) + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+        v = vvo_clip_pel( ( p0[c][y * w + x] + p1[c][y * w + x] + offset ) >> shift, bd );
+      }
+      dst[y * reco->stride[c] + x] = (pel) v;
+    }
+  }
+  free( buf );
+  return 0;
+}
+
 void vvo_dmvr_reset( void ) { g_dmvr_count = 0; memset( g_dmvr_out, 0, sizeof( g_dmvr_out ) ); }
 uint32_t vvo_get_dmvr( int32_t* dst, uint32_t max_entries )
 {
@@ -407,6 +566,7 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
   const vvr_pic_header* H = &pic->hdr;
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu;
   const int ncomp = H->chroma_format ? 3 : 1;
+  if( cu->mc_mode == VVR_MC_AFFINE ) return affine_cu( pic, cu, refs, reco );
   if( cu->mc_mode == VVR_MC_DMVR || cu->mc_mode == VVR_MC_DMVR_BDOF ) return dmvr_cu( pic, cu, refs, reco, cu->mc_mode == VVR_MC_DMVR_BDOF );
   if( cu->mc_mode != VVR_MC_UNI && cu->mc_mode != VVR_MC_BI && cu->mc_mode != VVR_MC_BDOF ) { vvo_set_error( "inter mode not restated yet" ); return -1; }
   const int altHpel = cu->imv == 3;

@@ -32,6 +32,8 @@ CASES = [
     ("b_200x136_ctu64_bdof", 200, 136, 6, 3, 19, ALL | abi.TOOL_BDOF, dict(p_intra=0.0, p_bi=0.8, mv_sigma=2.0)),
     ("b_256x128_ctu128_dmvr_bdof", 256, 128, 7, 2, 20, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR, dict(p_intra=0.1, p_bi=0.9)),
     ("b_200x136_ctu64_dmvr", 200, 136, 6, 3, 21, ALL | abi.TOOL_DMVR, dict(p_intra=0.0, p_bi=0.8, mv_sigma=2.0)),
+    ("b_256x128_ctu128_affine_prof", 256, 128, 7, 2, 22, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.1, p_affine=0.5)),
+    ("b_200x136_ctu64_affine", 200, 136, 6, 1, 23, ALL, dict(p_intra=0.0, p_affine=0.5, mv_sigma=3.0)),
 ]
 
 

@@ -99,6 +99,7 @@ TOOLS_I = TOOLS | abi.TOOL_LFNST
 TOOLS_B = TOOLS_I | abi.TOOL_BDOF
 TOOLS_D = TOOLS_I | abi.TOOL_DMVR
 TOOLS_DB = TOOLS_I | abi.TOOL_DMVR | abi.TOOL_BDOF
+TOOLS_A = TOOLS_DB | abi.TOOL_PROF
 
 
 @pytest.mark.parametrize("seed", [51, 52])
@@ -138,6 +139,17 @@ def test_dmvr_stream(built, tools, seed):
 
 def test_dmvr_bdof_1080p(built):
     _run_stream(1920, 1080, 3, 2, 111, TOOLS_DB, intra=True, streams=3)
+
+
+@pytest.mark.parametrize("tools,seed", [(TOOLS_DB, 121), (TOOLS_A, 122)])
+def test_affine_stream(built, tools, seed):
+    """4- and 6-parameter affine CUs (sub-block MVs from the motion field), with and without PROF, uni and bi"""
+    _run_stream(256, 128, 9, 8, seed, tools, intra=True, p_affine=0.4)
+    _run_stream(416, 240, 5, 4, seed + 10, tools, intra=True, p_bi=0.7, p_intra=0.05, mv_sigma=2.0, p_affine=0.6)
+
+
+def test_affine_prof_1080p(built):
+    _run_stream(1920, 1080, 3, 2, 131, TOOLS_A, intra=True, streams=3, p_affine=0.3)
 
 
 def test_unsupported_tools_fail_loudly(built):

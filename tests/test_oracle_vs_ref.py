@@ -7,7 +7,7 @@ import refdrv
 from vvdec_amd import abi, synth, stream
 
 pytestmark = pytest.mark.skipif(not refdrv.available(), reason="oracle/_ref not built")
-ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST | abi.TOOL_BDOF | abi.TOOL_DMVR
+ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF
 STAGES = [refdrv.STOP_AFTER_RECO, refdrv.STOP_AFTER_DBK, refdrv.STOP_AFTER_SAO, 0]
 
 
@@ -28,6 +28,8 @@ def _case(W, H, l2, idx, seed, **kw):
     (200, 136, 6, 3, 103, dict(p_intra=0.1)),
     (320, 192, 5, 1, 104, dict(p_intra=0.0)),
     (264, 200, 7, 4, 105, dict(p_intra=0.5)),
+    (384, 256, 7, 2, 106, dict(p_intra=0.1, p_affine=0.5)),
+    (200, 136, 6, 1, 107, dict(p_intra=0.0, p_affine=0.4, mv_sigma=2.0)),
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)
@@ -53,7 +55,7 @@ def test_reference_simd_equals_scalar(built):
 def test_edge_parameters_match_reference_derivation(built):
     """deblocking with the edge parameters the reference derives itself (LoopFilter::calcFilterStrengthsCTU) == with the
     job's table (the host glue's restatement of that derivation)"""
-    d, refs = _case(256, 128, 7, 2, 107, p_intra=0.2)
+    d, refs = _case(256, 128, 7, 2, 107, p_intra=0.2)       # no affine CUs: the generator's derivation has no sub-block edges
     a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
     b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))

@@ -59,6 +59,7 @@ typedef struct vvs_params {
   float    p_imv_hpel;
   float    p_jccr;
   float    p_mrl, p_bdpcm;
+  float    p_affine;            // of inter CUs >= 8x8 (half of them 6-parameter)
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -93,6 +94,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
+  P->p_affine = 0.0f;
 }
 
 namespace {
@@ -206,6 +208,19 @@ struct Gen {
       }
       if( cu.imv == 3 ) for( int l = 0; l < 2; l++ ) { cu.mv[l][0][0] &= ~7; cu.mv[l][0][1] &= ~7; }
       cu.flags |= rng.p( 0.5 ) ? VVR_CU_MERGE : 0;
+      // affine: control-point MVs = the translational MV plus small corner deltas (affine never uses the half-pel AMVR filter)
+      if( w >= 8 && h >= 8 && rng.p( P.p_affine ) )
+      {
+        cu.flags |= VVR_CU_AFFINE | ( rng.p( 0.5 ) ? VVR_CU_AFFINE_6P : 0 );
+        cu.imv = 0;
+        const int spread = rng.p( 0.1 ) ? 200 : 24;           // a few with a large spread: the fallback to one MV (isSubblockVectorSpreadOverLimit)
+        for( int l = 0; l < 2; l++ )
+        {
+          if( cu.ref_idx[l] < 0 ) continue;
+          for( int k = 1; k < 3; k++ ) { cu.mv[l][k][0] = cu.mv[l][0][0] + rng.laplace( spread ); cu.mv[l][k][1] = cu.mv[l][0][1] + rng.laplace( spread ); }
+          if( rng.p( 0.05 ) ) for( int k = 1; k < 3; k++ ) { cu.mv[l][k][0] = cu.mv[l][0][0]; cu.mv[l][k][1] = cu.mv[l][0][1]; }    // all equal: PROF off
+        }
+      }
       // branch taken by InterPrediction::motionCompensation (InterPrediction.cpp:1372-1459)
       bool identical = false;
       if( bi && P.ref_poc[0][cu.ref_idx[0]] == P.ref_poc[1][cu.ref_idx[1]] && cu.mv[0][0][0] == cu.mv[1][0][0] && cu.mv[0][0][1] == cu.mv[1][0][1] ) identical = true;
@@ -213,9 +228,11 @@ struct Gen {
       bool eqDist = false;
       if( bi ) { const int d0 = P.poc - P.ref_poc[0][cu.ref_idx[0]], d1 = P.poc - P.ref_poc[1][cu.ref_idx[1]]; eqDist = d0 * d1 < 0 && d0 == -d1; }
       const bool sizeOk = w >= 8 && h >= 8 && w * h >= 128;
-      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2;      // (:1407-1427), no affine/CIIP/SMVD/WP here
-      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2;   // PU::checkDMVRCondition (UnitTools.cpp:1277)
-      cu.mc_mode = dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
+      const bool aff = ( cu.flags & VVR_CU_AFFINE ) != 0;
+      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff;      // (:1407-1427), no CIIP/SMVD/WP here
+      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff;   // PU::checkDMVRCondition (UnitTools.cpp:1277)
+      // xCheckIdenticalMotion (:404) is false for affine CUs: they go through xPredInterBi -> xPredAffineBlk per list
+      cu.mc_mode = aff ? VVR_MC_AFFINE : dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
       if( dmvr ) { cu.dmvr_off = B.num_dmvr; B.num_dmvr += ( ( w + 15 ) / 16 ) * ( ( h + 15 ) / 16 ); }     // one delta MV per 16x16 sub-block (m_dmvrMvCache)
     }
     // transform units: split at 64 (max TB size), cbf per block
@@ -263,6 +280,53 @@ struct Gen {
       vvr_motion& m = B.motion[i4];
       m.ref_idx[0] = cu.ref_idx[0]; m.ref_idx[1] = cu.ref_idx[1];
       for( int l = 0; l < 2; l++ ) { m.mv[l][0] = cu.ref_idx[l] >= 0 ? cu.mv[l][0][0] : 0; m.mv[l][1] = cu.ref_idx[l] >= 0 ? cu.mv[l][0][1] : 0; }
+    }
+    if( cu.flags & VVR_CU_AFFINE ) for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= 0 ) setAllAffineMv( cu, l );
+  }
+
+  // PU::setAllAffineMv (UnitTools.cpp:2689): per-4x4 sub-block MVs from the control points, or one fallback MV when the
+  // sub-block vectors spread too far (InterPrediction::isSubblockVectorSpreadOverLimit, InterPrediction.cpp:892)
+  static bool spreadOverLimit( int a, int b, int c, int d, int predType )
+  {
+    const int s4 = 4 << 11, filterTap = 6;
+    if( predType == 3 )
+    {
+      int rw = std::max( std::max( 0, 4 * a + s4 ), std::max( 4 * c, 4 * a + 4 * c + s4 ) ) - std::min( std::min( 0, 4 * a + s4 ), std::min( 4 * c, 4 * a + 4 * c + s4 ) );
+      int rh = std::max( std::max( 0, 4 * b ), std::max( 4 * d + s4, 4 * b + 4 * d + s4 ) ) - std::min( std::min( 0, 4 * b ), std::min( 4 * d + s4, 4 * b + 4 * d + s4 ) );
+      rw = ( rw >> 11 ) + filterTap + 3; rh = ( rh >> 11 ) + filterTap + 3;
+      return rw * rh > ( filterTap + 9 ) * ( filterTap + 9 );
+    }
+    int rw = std::max( 0, 4 * a + s4 ) - std::min( 0, 4 * a + s4 ), rh = std::max( 0, 4 * b ) - std::min( 0, 4 * b );
+    rw = ( rw >> 11 ) + filterTap + 3; rh = ( rh >> 11 ) + filterTap + 3;
+    if( rw * rh > ( filterTap + 9 ) * ( filterTap + 5 ) ) return true;
+    rw = std::max( 0, 4 * c ) - std::min( 0, 4 * c ); rh = std::max( 0, 4 * d + s4 ) - std::min( 0, 4 * d + s4 );
+    rw = ( rw >> 11 ) + filterTap + 3; rh = ( rh >> 11 ) + filterTap + 3;
+    return rw * rh > ( filterTap + 5 ) * ( filterTap + 9 );
+  }
+  static void roundAffineMv( int& mx, int& my, int sh ) { const int o = 1 << ( sh - 1 ); mx = ( mx + o - ( mx >= 0 ) ) >> sh; my = ( my + o - ( my >= 0 ) ) >> sh; }
+  static int ilog2( int v ) { int l = 0; while( ( 1 << l ) < v ) l++; return l; }
+  void setAllAffineMv( const vvr_cu& cu, int l )
+  {
+    const int shift = 7;
+    const int dHX = ( cu.mv[l][1][0] - cu.mv[l][0][0] ) * ( 1 << ( shift - ilog2( cu.w ) ) ), dHY = ( cu.mv[l][1][1] - cu.mv[l][0][1] ) * ( 1 << ( shift - ilog2( cu.w ) ) );
+    int dVX, dVY;
+    if( cu.flags & VVR_CU_AFFINE_6P ) { dVX = ( cu.mv[l][2][0] - cu.mv[l][0][0] ) * ( 1 << ( shift - ilog2( cu.h ) ) ); dVY = ( cu.mv[l][2][1] - cu.mv[l][0][1] ) * ( 1 << ( shift - ilog2( cu.h ) ) ); }
+    else { dVX = -dHY; dVY = dHX; }
+    const int baseX = cu.mv[l][0][0] * ( 1 << shift ), baseY = cu.mv[l][0][1] * ( 1 << shift );
+    const bool over = spreadOverLimit( dHX, dHY, dVX, dVY, cu.inter_dir );
+    int fx = 0, fy = 0;
+    if( over ) { fx = baseX + dHX * ( cu.w >> 1 ) + dVX * ( cu.h >> 1 ); fy = baseY + dHY * ( cu.w >> 1 ) + dVY * ( cu.h >> 1 ); roundAffineMv( fx, fy, shift ); fx = std::min( ( 1 << 17 ) - 1, std::max( -( 1 << 17 ), fx ) ); fy = std::min( ( 1 << 17 ) - 1, std::max( -( 1 << 17 ), fy ) ); }
+    for( int hy = 0; hy < cu.h / 4; hy++ ) for( int wx = 0; wx < cu.w / 4; wx++ )
+    {
+      int mx = fx, my = fy;
+      if( !over )
+      {
+        mx = baseX + dHX * ( 2 + 4 * wx ) + dVX * ( 2 + 4 * hy ); my = baseY + dHY * ( 2 + 4 * wx ) + dVY * ( 2 + 4 * hy );
+        roundAffineMv( mx, my, shift );
+        mx = std::min( ( 1 << 17 ) - 1, std::max( -( 1 << 17 ), mx ) ); my = std::min( ( 1 << 17 ) - 1, std::max( -( 1 << 17 ), my ) );
+      }
+      vvr_motion& m = B.motion[(size_t) ( cu.y / 4 + hy ) * w4 + cu.x / 4 + wx];
+      m.mv[l][0] = mx; m.mv[l][1] = my;
     }
   }
 

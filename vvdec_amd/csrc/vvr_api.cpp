@@ -25,8 +25,8 @@ struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 
 struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
 
-enum { K_MC, K_MC_DMVR, K_ITRANS, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_NUM };
-const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_itrans", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy" };
+enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_ITRANS, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_NUM };
+const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_itrans", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy" };
 
 struct DevBuf {
   void* p = nullptr; size_t n = 0;
@@ -40,6 +40,7 @@ struct vvr_prepared {        // a picture description resident in HBM together w
   DevBuf   blob;             // one allocation holding every array
   McItem*  mcItems = nullptr; int numMc = 0;
   McItem*  dmvrItems = nullptr; int numDmvrItems = 0;      // sub-blocks that run decoder-side MV refinement
+  McItem*  affItems = nullptr; int numAffItems = 0;        // tiles of affine CUs
   int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64 (TB_ADD: after MC)
   TbItem*  tbStore[3] = { nullptr, nullptr, nullptr }; int numTbStore[3] = { 0, 0, 0 };   // residuals of intra blocks (TB_STORE)
@@ -236,12 +237,14 @@ static int validate( vvr_context* c, const vvr_picture* p )
     if( cu.pred_mode == VVR_PRED_INTER )
     {
       const bool isDmvr = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
-      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF && !isDmvr ) { c->setError( "inter mode (affine/GPM/SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      const bool isAff = cu.mc_mode == VVR_MC_AFFINE;
+      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF && !isDmvr && !isAff ) { c->setError( "inter mode (GPM/SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( isAff != ( ( cu.flags & VVR_CU_AFFINE ) != 0 ) || ( isAff && ( !p->motion || cu.w < 8 || cu.h < 8 ) ) ) { c->setError( "affine CU: mc_mode / flag mismatch, missing motion field or CU smaller than 8x8" ); return VVR_ERR_PARAMETER; }
       if( isDmvr && ( !( h.tool_flags & VVR_TOOL_DMVR ) || ( cu.mc_mode == VVR_MC_DMVR_BDOF && !( h.tool_flags & VVR_TOOL_BDOF ) ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
       { c->setError( "mc_mode DMVR on a CU that cannot use DMVR (UnitTools.cpp:1277)" ); return VVR_ERR_PARAMETER; }
       if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
       { c->setError( "mc_mode BDOF on a CU that cannot use BDOF (InterPrediction.cpp:1407-1427)" ); return VVR_ERR_PARAMETER; }
-      if( cu.flags & ( VVR_CU_AFFINE | VVR_CU_CIIP | VVR_CU_GEO | VVR_CU_SBTMVP ) ) { c->setError( "affine / CIIP / GPM / SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.flags & ( VVR_CU_CIIP | VVR_CU_GEO | VVR_CU_SBTMVP ) ) { c->setError( "CIIP / GPM / SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) { c->setError( "ref_idx out of range" ); return VVR_ERR_PARAMETER; }
       if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
       if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) { c->setError( "inter CU must be single tree" ); return VVR_ERR_PARAMETER; }
@@ -279,7 +282,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   const int ctusX = ( h.width + ctu - 1 ) / ctu, ctusY = ( h.height + ctu - 1 ) / ctu, numCtu = ctusX * ctusY;
 
   // ---- host glue: work lists (what DecCu::TaskTrafoCtu / TaskInterCtu iterate over, DecCu.cpp:106-134)
-  std::vector<McItem> mc, mcDmvr;
+  std::vector<McItem> mc, mcDmvr, mcAff;
   uint32_t numDmvr = 0;
   std::vector<TbItem> tb[3], tbS[3];
   std::vector<IntraItem> intra[3];
@@ -394,9 +397,11 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       {
         McItem it; it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( 16, cu.w - x ); it.h = (uint8_t) std::min( 16, cu.h - y ); it.pad = 0; it.cu = i;
         const bool dm = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
-        ( dm ? mcDmvr : mc ).push_back( it );
+        const bool af = cu.mc_mode == VVR_MC_AFFINE;
+        ( dm ? mcDmvr : af ? mcAff : mc ).push_back( it );
         const double smp = (double) it.w * it.h * ( ncomp == 3 ? 1.5 : 1.0 );
-        bytes[dm ? K_MC_DMVR : K_MC] += smp * 2 * nl + smp * 2 + sizeof( McItem ) + ( dm ? 8 : 0 );
+        const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
+        bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += smp * 2 * nla + smp * 2 + sizeof( McItem ) + ( dm ? 8 : 0 ) + ( af ? it.w * it.h / 16.0 * sizeof( vvr_motion ) : 0 );
       }
       if( cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF ) numDmvr = std::max<uint32_t>( numDmvr, cu.dmvr_off + ( ( cu.w + 15 ) / 16 ) * ( ( cu.h + 15 ) / 16 ) );
       bytes[K_MC] += sizeof( vvr_cu );
@@ -479,6 +484,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   const int iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
   const int iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
   const int iMcD = add( mcDmvr.data(), sizeof( McItem ) * mcDmvr.size() );
+  const int iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
   const int iDmvrOut = add( nullptr, sizeof( int32_t ) * 2 * (size_t) numDmvr );
   int iTb[3]; for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
   int iTbS[3]; for( int k = 0; k < 3; k++ ) iTbS[k] = add( tbS[k].data(), sizeof( TbItem ) * tbS[k].size() );
@@ -508,6 +514,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
   q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();
   q->dmvrItems = (McItem*) ( base + parts[iMcD].off ); q->numDmvrItems = (int) mcDmvr.size();
+  q->affItems = (McItem*) ( base + parts[iMcA].off ); q->numAffItems = (int) mcAff.size();
   q->dmvrOut = (int32_t*) ( base + parts[iDmvrOut].off ); q->numDmvr = numDmvr;
   for( int k = 0; k < 3; k++ ) { q->tbItems[k] = (TbItem*) ( base + parts[iTb[k]].off ); q->numTb[k] = (int) tb[k].size(); }
   for( int k = 0; k < 3; k++ ) { q->tbStore[k] = (TbItem*) ( base + parts[iTbS[k]].off ); q->numTbStore[k] = (int) tbS[k].size(); }
@@ -579,6 +586,7 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
   // INTER stage: prediction of every inter CU, then residual add (DecLibRecon.cpp:831-874)
   if( q->numMc ) timed( K_MC, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc ); } );
   if( q->numDmvrItems ) timed( K_MC_DMVR, [&]{ launch_mc_dmvr( s, q->pic, refs, A, q->dmvrItems, q->numDmvrItems, q->dmvrOut ); } );
+  if( q->numAffItems ) timed( K_MC_AFFINE, [&]{ launch_mc_affine( s, q->pic, refs, A, q->affItems, q->numAffItems ); } );
   job.prepared = q;
   if( q->numTb[0] + q->numTb[1] + q->numTb[2] + q->numTbStore[0] + q->numTbStore[1] + q->numTbStore[2] )
     timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) { launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); launch_itrans( s, q->pic, A, R, q->tbStore[k], q->numTbStore[k], 16 << k ); } } );

@@ -74,5 +74,6 @@ void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )
 void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 void launch_alf    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst );
+void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );
 void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const uint32_t* ctuStart, const uint32_t* active, int numActive, int* sync );

@@ -574,6 +574,277 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
   }
 }
 
+// =====================================================================================================================
+// k_mc_affine — affine motion compensation (+ PROF) of one <= 16x16 tile: 4x4 luma sub-blocks with their own MVs from the
+// motion field, 4x4 chroma sub-blocks with the rounded mean of two luma sub-block MVs.
+//   InterPrediction::xPredAffineBlk (InterPrediction.cpp:934-1288), applyPROFCore (:61), gradFilterCore<false> (:213),
+//   roundAffineMv (Mv.cpp:57), isSubblockVectorSpreadOverLimit (:892); luma 4x4 blocks use the 6-tap table
+//   (InterpolationFilter.cpp:1078-1085, 669-676).
+// =====================================================================================================================
+#define AF_WL 12            // row stride of a luma sub-block window (11 x 11)
+#define AF_WC 8             // row stride of a chroma sub-block window (7 x 7)
+struct AffSeg { int x0, y0, xFrac, yFrac; };     // window origin (block origin - 3 / - 1) in the reference plane, fractional MV
+struct AffShared {
+  pel_t  winL[2][16][11 * AF_WL];
+  pel_t  winC[2][2][4][7 * AF_WC];
+  pel_t  tmpL[2][16][11 * 4];
+  pel_t  tmpC[2][2][4][7 * 4];
+  pel_t  ext[2][16][36];          // PROF: 6x6 block of 14-bit luma samples (interior = prediction, ring = integer reference samples)
+  pel_t  predL[2][16 * 16];       // per list: final (uni) or 14-bit (bi) luma after PROF
+  AffSeg segL[2][16], segC[2][4];
+  int    dMvH[2][16], dMvV[2][16], prof[2];
+  const pel_t* refp[2][3];
+};
+
+__device__ __forceinline__ void aff_round_mv( int& mx, int& my, int sh ) { const int o = 1 << ( sh - 1 ); mx = ( mx + o - ( mx >= 0 ) ) >> sh; my = ( my + o - ( my >= 0 ) ) >> sh; }
+
+__device__ __forceinline__ bool aff_spread_over_limit( int a, int b, int c, int d, int predType )
+{
+  const int s4 = 4 << 11, ft = 6;
+  if( predType == 3 )
+  {
+    int rw = max( max( 0, 4 * a + s4 ), max( 4 * c, 4 * a + 4 * c + s4 ) ) - min( min( 0, 4 * a + s4 ), min( 4 * c, 4 * a + 4 * c + s4 ) );
+    int rh = max( max( 0, 4 * b ), max( 4 * d + s4, 4 * b + 4 * d + s4 ) ) - min( min( 0, 4 * b ), min( 4 * d + s4, 4 * b + 4 * d + s4 ) );
+    rw = ( rw >> 11 ) + ft + 3; rh = ( rh >> 11 ) + ft + 3;
+    return rw * rh > ( ft + 9 ) * ( ft + 9 );
+  }
+  int rw = max( 0, 4 * a + s4 ) - min( 0, 4 * a + s4 ), rh = max( 0, 4 * b ) - min( 0, 4 * b );
+  rw = ( rw >> 11 ) + ft + 3; rh = ( rh >> 11 ) + ft + 3;
+  if( rw * rh > ( ft + 9 ) * ( ft + 5 ) ) return true;
+  rw = max( 0, 4 * c ) - min( 0, 4 * c ); rh = max( 0, 4 * d + s4 ) - min( 0, 4 * d + s4 );
+  rw = ( rw >> 11 ) + ft + 3; rh = ( rh >> 11 ) + ft + 3;
+  return rw * rh > ( ft + 5 ) * ( ft + 9 );
+}
+
+// one 4x4 sub-block sample: the four (xFrac, yFrac) cases of xPredAffineBlk (:1224-1236) = xPredInterBlk's arithmetic
+__device__ __forceinline__ int aff_sample( const pel_t* win, int wst, const pel_t* tmp, const AffSeg& g, int comp, bool bi, int bd, int px, int py )
+{
+  const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const int16_t* ch = comp ? d_chroma_filter[g.xFrac] : d_luma_filter_4x4[g.xFrac];
+  const int16_t* cv = comp ? d_chroma_filter[g.yFrac] : d_luma_filter_4x4[g.yFrac];
+  const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
+  if( !doH && !doV )
+  {
+    const int s = win[( py + half ) * wst + px + half];
+    return bi ? (int16_t) ( (int16_t) ( s << headroom ) - (int16_t) IF_INTERNAL_OFFS ) : s;
+  }
+  if( doH != doV )
+  {
+    int shift, offset;
+    if( !bi ) { shift = 6; offset = 32; } else { shift = 6 - headroom; offset = -IF_INTERNAL_OFFS * ( 1 << shift ); }
+    int sum = 0;
+    if( doH ) { for( int t = 0; t < ntaps; t++ ) sum += win[( py + half ) * wst + px + t] * ch[t]; }
+    else      { for( int t = 0; t < ntaps; t++ ) sum += win[( py + t ) * wst + px + half] * cv[t]; }
+    const int val = (int16_t) ( ( sum + offset ) >> shift );
+    return bi ? val : clip_pel( val, bd );
+  }
+  int shift2, offset2;
+  if( !bi ) { shift2 = 6 + headroom; offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 ); } else { shift2 = 6; offset2 = 0; }
+  int sum = 0;
+  for( int t = 0; t < ntaps; t++ ) sum += tmp[( py + t ) * 4 + px] * cv[t];
+  const int val = (int16_t) ( ( sum + offset2 ) >> shift2 );
+  return bi ? val : clip_pel( val, bd );
+}
+
+template<int NT>
+__global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
+{
+  __shared__ AffShared sh;
+  const int item = mc_item_index();
+  if( item >= numItems ) return;
+  const McItem it = items[item];
+  const vvr_cu& cu = pic.cu[it.cu];
+  const int bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu;
+  const int tid = threadIdx.x;
+  const int ncomp = pic.hdr.chroma_format ? 3 : 1;
+  const int w = it.w, h = it.h;
+  const int sbx = w >> 2, nsb = sbx * ( h >> 2 );            // luma sub-blocks in the tile
+  const int cbx = w >> 3, ncb = cbx * ( h >> 3 );            // chroma sub-blocks (4x4 chroma samples = 8x8 luma)
+  const bool biPred = cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0;
+  const int l0 = cu.ref_idx[0] >= 0 ? 0 : 1, nl = biPred ? 2 : 1;
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  // ---- sub-block geometry
+  {
+    const int horMax = ( pic.hdr.width + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - cu.x + 1 ) * 16;
+    const int verMax = ( pic.hdr.height + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - cu.y + 1 ) * 16;
+    for( int i = tid; i < nl * ( nsb + ncb ); i += NT )
+    {
+      const int k = i / ( nsb + ncb ), r = i - k * ( nsb + ncb ), l = biPred ? k : l0;
+      AffSeg g;
+      if( r < nsb )
+      {
+        const int sx = r % sbx, sy = r / sbx;
+        const vvr_motion& m = pic.motion[(size_t) ( ( it.y >> 2 ) + sy ) * pic.w4 + ( it.x >> 2 ) + sx];
+        const int mx = min( horMax, max( horMin, m.mv[l][0] ) ), my = min( verMax, max( verMin, m.mv[l][1] ) );
+        g.xFrac = mx & 15; g.yFrac = my & 15;
+        g.x0 = it.x + 4 * sx + ( mx >> 4 ) - 3; g.y0 = it.y + 4 * sy + ( my >> 4 ) - 3;
+        sh.segL[k][r] = g;
+      }
+      else
+      {
+        const int q = r - nsb, sx = q % cbx, sy = q / cbx;
+        const vvr_motion& m0 = pic.motion[(size_t) ( ( it.y >> 2 ) + 2 * sy ) * pic.w4 + ( it.x >> 2 ) + 2 * sx];
+        const vvr_motion& m1 = pic.motion[(size_t) ( ( it.y >> 2 ) + 2 * sy + 1 ) * pic.w4 + ( it.x >> 2 ) + 2 * sx + 1];
+        int mx = m0.mv[l][0] + m1.mv[l][0], my = m0.mv[l][1] + m1.mv[l][1];
+        aff_round_mv( mx, my, 1 );
+        mx = min( horMax, max( horMin, mx ) ); my = min( verMax, max( verMin, my ) );
+        g.xFrac = mx & 31; g.yFrac = my & 31;
+        g.x0 = ( it.x >> 1 ) + 4 * sx + ( mx >> 5 ) - 1; g.y0 = ( it.y >> 1 ) + 4 * sy + ( my >> 5 ) - 1;
+        sh.segC[k][q] = g;
+      }
+    }
+    if( tid < nl )
+    {
+      const int k = tid, l = biPred ? k : l0;
+      for( int c = 0; c < ncomp; c++ ) sh.refp[k][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
+      // PROF switch and the per-position MV offsets of a 4x4 sub-block (:1015-1090)
+      const int lw = ilog2( cu.w ), lh = ilog2( cu.h );
+      const int dHX = ( cu.mv[l][1][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lw ) ), dHY = ( cu.mv[l][1][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lw ) );
+      int dVX, dVY;
+      const bool sixP = ( cu.flags & VVR_CU_AFFINE_6P ) != 0;
+      if( sixP ) { dVX = ( cu.mv[l][2][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lh ) ); dVY = ( cu.mv[l][2][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lh ) ); }
+      else { dVX = -dHY; dVY = dHX; }
+      const bool eqRT = cu.mv[l][0][0] == cu.mv[l][1][0] && cu.mv[l][0][1] == cu.mv[l][1][1];
+      const bool eqLB = cu.mv[l][0][0] == cu.mv[l][2][0] && cu.mv[l][0][1] == cu.mv[l][2][1];
+      bool prof = ( pic.hdr.tool_flags & VVR_TOOL_PROF ) != 0;
+      prof = prof && !( ( sixP && eqRT && eqLB ) || ( !sixP && eqRT ) ) && !aff_spread_over_limit( dHX, dHY, dVX, dVY, cu.inter_dir );
+      sh.prof[k] = prof;
+      if( prof )
+      {
+        const int qHX = dHX * 4, qHY = dHY * 4, qVX = dVX * 4, qVY = dVY * 4;
+        const int h0 = ( ( dHX + dVX ) * 2 ) - ( ( qHX + qVX ) * 2 ), v0 = ( ( dHY + dVY ) * 2 ) - ( ( qHY + qVY ) * 2 );
+        for( int y = 0; y < 4; y++ ) for( int x = 0; x < 4; x++ )
+        {
+          int a = h0 + x * qHX + y * qVX, b = v0 + x * qHY + y * qVY;
+          aff_round_mv( a, b, 8 );
+          sh.dMvH[k][y * 4 + x] = clip3( -31, 31, a ); sh.dMvV[k][y * 4 + x] = clip3( -31, 31, b );
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- windows: 11x11 per luma sub-block, 7x7 per chroma sub-block, clamped coordinates
+  {
+    const int nL = nl * nsb * 11 * AF_WL;
+    for( int i = tid; i < nL; i += NT )
+    {
+      const int blk = i / ( 11 * AF_WL ), r = i - blk * ( 11 * AF_WL ), yy = r / AF_WL, xx = r - yy * AF_WL;
+      if( xx >= 11 ) continue;
+      const int k = blk / nsb, sb = blk - k * nsb;
+      const AffSeg g = sh.segL[k][sb];
+      const int sx = clip3( 0, reco.w[0] - 1, g.x0 + xx ), sy = clip3( 0, reco.h[0] - 1, g.y0 + yy );
+      sh.winL[k][sb][r] = sh.refp[k][0][(size_t) sy * reco.stride[0] + sx];
+    }
+    if( ncomp == 3 )
+    {
+      const int nC = nl * 2 * ncb * 7 * AF_WC;
+      for( int i = tid; i < nC; i += NT )
+      {
+        const int blk = i / ( 7 * AF_WC ), r = i - blk * ( 7 * AF_WC ), yy = r / AF_WC, xx = r - yy * AF_WC;
+        if( xx >= 7 ) continue;
+        const int k = blk / ( 2 * ncb ), q = blk - k * 2 * ncb, c = q / ncb, sb = q - c * ncb;
+        const AffSeg g = sh.segC[k][sb];
+        const int sx = clip3( 0, reco.w[1] - 1, g.x0 + xx ), sy = clip3( 0, reco.h[1] - 1, g.y0 + yy );
+        sh.winC[k][c][sb][r] = sh.refp[k][1 + c][(size_t) sy * reco.stride[1] + sx];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- horizontal pass of the sub-blocks with a 2-D fractional MV
+  {
+    const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+    for( int i = tid; i < nl * nsb * 44; i += NT )
+    {
+      const int blk = i / 44, r = i - blk * 44, yy = r >> 2, xx = r & 3, k = blk / nsb, sb = blk - k * nsb;
+      const AffSeg g = sh.segL[k][sb];
+      if( !( g.xFrac && g.yFrac ) ) continue;
+      const int16_t* cf = d_luma_filter_4x4[g.xFrac];
+      int sum = 0;
+      for( int t = 0; t < 8; t++ ) sum += sh.winL[k][sb][yy * AF_WL + xx + t] * cf[t];
+      sh.tmpL[k][sb][r] = (int16_t) ( ( sum + offset1 ) >> shift1 );
+    }
+    if( ncomp == 3 )
+      for( int i = tid; i < nl * 2 * ncb * 28; i += NT )
+      {
+        const int blk = i / 28, r = i - blk * 28, yy = r >> 2, xx = r & 3, k = blk / ( 2 * ncb ), q = blk - k * 2 * ncb, c = q / ncb, sb = q - c * ncb;
+        const AffSeg g = sh.segC[k][sb];
+        if( !( g.xFrac && g.yFrac ) ) continue;
+        const int16_t* cf = d_chroma_filter[g.xFrac];
+        int sum = 0;
+        for( int t = 0; t < 4; t++ ) sum += sh.winC[k][c][sb][yy * AF_WC + xx + t] * cf[t];
+        sh.tmpC[k][c][sb][r] = (int16_t) ( ( sum + offset1 ) >> shift1 );
+      }
+  }
+  __syncthreads();
+  // ---- luma: prediction (14-bit when bi-predicted or refined by PROF), PROF border from the integer reference samples
+  for( int i = tid; i < nl * w * h; i += NT )
+  {
+    const int k = i / ( w * h ), r = i - k * w * h, sb = r >> 4, px = r & 3, py = ( r >> 2 ) & 3;
+    const bool prof = sh.prof[k] != 0;
+    const int v = aff_sample( sh.winL[k][sb], AF_WL, sh.tmpL[k][sb], sh.segL[k][sb], 0, biPred || prof, bd, px, py );
+    if( prof ) sh.ext[k][sb][( 1 + py ) * 6 + 1 + px] = (pel_t) v;
+    else sh.predL[k][sb * 16 + py * 4 + px] = (pel_t) v;
+  }
+  for( int i = tid; i < nl * nsb * 20; i += NT )
+  {
+    const int blk = i / 20, r = i - blk * 20, k = blk / nsb, sb = blk - k * nsb;
+    if( !sh.prof[k] ) continue;
+    int ei, ej;                                  // ring of the 6x6 block
+    if( r < 6 ) { ei = r; ej = 0; } else if( r < 12 ) { ei = r - 6; ej = 5; } else { ei = ( r & 1 ) ? 5 : 0; ej = 1 + ( ( r - 12 ) >> 1 ); }
+    const AffSeg g = sh.segL[k][sb];
+    const int sref = sh.winL[k][sb][( 3 + ej - 1 + ( g.yFrac >> 3 ) ) * AF_WL + 3 + ei - 1 + ( g.xFrac >> 3 )];
+    sh.ext[k][sb][ej * 6 + ei] = (pel_t) ( (int16_t) ( sref << headroom ) - (int16_t) IF_INTERNAL_OFFS );
+  }
+  __syncthreads();
+  for( int i = tid; i < nl * w * h; i += NT )
+  {
+    const int k = i / ( w * h ), r = i - k * w * h, sb = r >> 4, px = r & 3, py = ( r >> 2 ) & 3;
+    if( !sh.prof[k] ) continue;
+    const pel_t* sp = &sh.ext[k][sb][( 1 + py ) * 6 + 1 + px];
+    const int gY = (int16_t) ( ( sp[6] >> 6 ) - ( sp[-6] >> 6 ) ), gX = (int16_t) ( ( sp[1] >> 6 ) - ( sp[-1] >> 6 ) );
+    const int dILimit = 1 << max( bd + 1, 13 );
+    int dI = sh.dMvH[k][py * 4 + px] * gX + sh.dMvV[k][py * 4 + px] * gY;
+    dI = clip3( -dILimit, dILimit - 1, dI );
+    int v = (int16_t) ( sp[0] + dI );
+    if( !biPred ) { v = (int16_t) ( ( v + ( 1 << ( headroom - 1 ) ) + IF_INTERNAL_OFFS ) >> headroom ); v = clip_pel( v, bd ); }
+    sh.predL[k][sb * 16 + py * 4 + px] = (pel_t) v;
+  }
+  __syncthreads();
+  // ---- output: uni-directional result, bi-predictive average or BCW (xWeightedAverage :1349; no BDOF with affine)
+  for( int c = 0; c < ncomp; c++ )
+  {
+    const int cs = c ? 1 : 0, cw = w >> cs, chh = h >> cs, sbw = cw >> 2;
+    for( int i = tid; i < cw * chh; i += NT )
+    {
+      const int sb = i >> 4, px = i & 3, py = ( i >> 2 ) & 3;
+      int p0, p1 = 0;
+      if( c == 0 ) { p0 = sh.predL[0][sb * 16 + py * 4 + px]; if( biPred ) p1 = sh.predL[1][sb * 16 + py * 4 + px]; }
+      else
+      {
+        p0 = aff_sample( sh.winC[0][c - 1][sb], AF_WC, sh.tmpC[0][c - 1][sb], sh.segC[0][sb], c, biPred, bd, px, py );
+        if( biPred ) p1 = aff_sample( sh.winC[1][c - 1][sb], AF_WC, sh.tmpC[1][c - 1][sb], sh.segC[1][sb], c, true, bd, px, py );
+      }
+      int out = p0;
+      if( biPred )
+      {
+        if( cu.bcw_idx != 2 )
+        {
+          const int w1 = d_bcw_weights[cu.bcw_idx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+          out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
+        }
+        else
+        {
+          const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+          out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
+        }
+      }
+      const int x = ( it.x >> cs ) + 4 * ( sb % sbw ) + px, y = ( it.y >> cs ) + 4 * ( sb / sbw ) + py;
+      reco.p[c][(size_t) y * reco.stride[c] + x] = (pel_t) out;
+    }
+  }
+}
+
 static int g_mcThreads = 0;
 void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
 {
@@ -582,6 +853,12 @@ void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes 
   if( g_mcThreads == 256 )      hipLaunchKernelGGL( k_mc<256>, dim3( numItems ), dim3( 256 ), 0, s, pic, refs, reco, items, numItems );
   else if( g_mcThreads == 128 ) hipLaunchKernelGGL( k_mc<128>, dim3( numItems ), dim3( 128 ), 0, s, pic, refs, reco, items, numItems );
   else                          hipLaunchKernelGGL( k_mc<64>,  dim3( numItems ), dim3( 64 ),  0, s, pic, refs, reco, items, numItems );
+}
+
+void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
+{
+  if( !numItems ) return;
+  hipLaunchKernelGGL( k_mc_affine<64>, dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems );
 }
 
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut )

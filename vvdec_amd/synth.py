@@ -31,7 +31,8 @@ class Params(C.Structure):
                 ("p_small_corner", C.c_float), ("p_mts", C.c_float), ("p_ts", C.c_float), ("p_lfnst", C.c_float),
                 ("p_split_scale", C.c_float), ("mv_sigma", C.c_float),
                 ("p_sao", C.c_float), ("p_alf_luma", C.c_float), ("p_alf_chroma", C.c_float), ("p_ccalf", C.c_float),
-                ("p_imv_hpel", C.c_float), ("p_jccr", C.c_float), ("p_mrl", C.c_float), ("p_bdpcm", C.c_float)]
+                ("p_imv_hpel", C.c_float), ("p_jccr", C.c_float), ("p_mrl", C.c_float), ("p_bdpcm", C.c_float),
+                ("p_affine", C.c_float)]
 
 
 class Buffers(C.Structure):
