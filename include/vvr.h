@@ -177,7 +177,7 @@ typedef struct vvr_cu {
   uint8_t  bcw_idx;              /* 0..4, BCW_DEFAULT = 2                                                    */
   uint8_t  imv;                  /* 3 = IMV_HPEL selects the alternative half-pel filter                     */
   uint8_t  geo_split_dir;
-  uint8_t  geo_dir_ref[2];       /* interDirrefIdxGeo0/1 packing is resolved: [i] = (list << 4) | refIdx     */
+  uint8_t  geo_dir_ref[2];       /* interDirrefIdxGeo0/1: [i] = (interDir << 4) | refIdx, interDir 1 = L0, 2 = L1 */
   uint8_t  ciip_neigh_intra;     /* bit0: above neighbour intra, bit1: left neighbour intra (IntraPrediction.cpp:917-927) */
   uint8_t  lfnst_intra_mode;     /* intra mode used for LFNST set selection before wide-angle remap (TrQuant.cpp:213-221) */
   uint8_t  pad0[2];

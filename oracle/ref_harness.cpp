@@ -443,6 +443,8 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       cu.geoSplitDir = c.geo_split_dir;
       cu.setInterDirrefIdxGeo0( c.geo_dir_ref[0] ); cu.setInterDirrefIdxGeo1( c.geo_dir_ref[1] );
       for( int l = 0; l < 2; l++ ) for( int k = 0; k < 3; k++ ) cu.mv[l][k] = Mv( c.mv[l][k][0], c.mv[l][k][1] );
+      // GPM keeps its two uni-prediction MVs in mv[0][1] / mv[1][1] (InterPrediction::motionCompensationGeo, InterPrediction.cpp:1478,1489)
+      if( c.flags & VVR_CU_GEO ) { cu.mv[0][1] = Mv( c.geo_mv[0][0], c.geo_mv[0][1] ); cu.mv[1][1] = Mv( c.geo_mv[1][0], c.geo_mv[1][1] ); }
       cu.setPlaneCbf( 0, false ); cu.setPlaneCbf( 1, false ); cu.setPlaneCbf( 2, false );
 
       for( uint32_t t = c.first_tu; t < c.first_tu + c.num_tu; t++ )

@@ -553,6 +553,53 @@ static int affine_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes
   return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Geometric partitioning: InterPrediction::motionCompensationGeo (InterPrediction.cpp:1461) = two uni-directional predictions
+ * kept at 14 bit (xPredInterBi :711 with cu.geoFlag()), blended by InterpolationFilter::xWeightedGeoBlk
+ * (InterpolationFilter.cpp:1217) with the weight masks g_globalGeoWeights (Rom.cpp:519-586). */
+static int geo_weight( const vvr_cu* cu, int cs, int x, int y )      /* weight of partition 0 at component sample (x, y) of the CU */
+{
+  const int MS = 112;                                                 /* GEO_WEIGHT_MASK_SIZE */
+  const int angle = vvc_geo_params[cu->geo_split_dir][0];
+  const int wIdx = vvo_log2( cu->w ) - 3, hIdx = vvo_log2( cu->h ) - 3;
+  const int ox = vvc_geo_weight_offset[cu->geo_split_dir][hIdx][wIdx][0], oy = vvc_geo_weight_offset[cu->geo_split_dir][hIdx][wIdx][1];
+  const int8_t* W = vvc_geo_weights[vvc_geo_angle2mask[angle]];
+  const int lx = x << cs, ly = y << cs;
+  if( vvc_geo_angle2mirror[angle] == 2 ) return W[( MS - 1 - oy - ly ) * MS + ox + lx];
+  if( vvc_geo_angle2mirror[angle] == 1 ) return W[( oy + ly ) * MS + ( MS - 1 - ox ) - lx];
+  return W[( oy + ly ) * MS + ox + lx];
+}
+
+static int geo_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* refs, int num_slots, vvo_planes* reco )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int bd = H->bit_depth, ctu = 1 << H->log2_ctu, ncomp = H->chroma_format ? 3 : 1;
+  const size_t n = (size_t) cu->w * cu->h;
+  pel* buf = (pel*) malloc( sizeof( pel ) * n * 2 );
+  for( int c = 0; c < ncomp; c++ )
+  {
+    const int cs = c ? 1 : 0, w = cu->w >> cs, h = cu->h >> cs;
+    for( int k = 0; k < 2; k++ )
+    {
+      const int l = ( cu->geo_dir_ref[k] >> 4 ) - 1, ri = cu->geo_dir_ref[k] & 15;
+      const int slot = H->ref_slot[l][ri];
+      if( l < 0 || l > 1 || slot < 0 || slot >= num_slots || !refs[slot].p[0] ) { free( buf ); vvo_set_error( "GPM: bad reference" ); return -1; }
+      int mv[2] = { cu->geo_mv[k][0], cu->geo_mv[k][1] };
+      clip_mv( mv, cu->x, cu->y, H->width, H->height, ctu );
+      pred_block( &refs[slot], c, cu->x >> cs, cu->y >> cs, w, h, mv[0], mv[1], 1, 0, bd, buf + k * n, w );
+    }
+    const int shift = ( IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2 ) + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+    pel* dst = reco->p[c] + (size_t) ( cu->y >> cs ) * reco->stride[c] + ( cu->x >> cs );
+    for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+    {
+      const int wt = geo_weight( cu, cs, x, y );
+      dst[y * reco->stride[c] + x] = (pel) vvo_clip_pel( ( wt * buf[y * w + x] + ( 8 - wt ) * buf[n + y * w + x] + offset ) >> shift, bd );
+    }
+  }
+  free( buf );
+  return 0;
+}
+
 void vvo_dmvr_reset( void ) { g_dmvr_count = 0; memset( g_dmvr_out, 0, sizeof( g_dmvr_out ) ); }
 uint32_t vvo_get_dmvr( int32_t* dst, uint32_t max_entries )
 {
@@ -567,6 +614,7 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu;
   const int ncomp = H->chroma_format ? 3 : 1;
   if( cu->mc_mode == VVR_MC_AFFINE ) return affine_cu( pic, cu, refs, reco );
+  if( cu->mc_mode == VVR_MC_GEO ) return geo_cu( pic, cu, refs, num_slots, reco );
   if( cu->mc_mode == VVR_MC_DMVR || cu->mc_mode == VVR_MC_DMVR_BDOF ) return dmvr_cu( pic, cu, refs, reco, cu->mc_mode == VVR_MC_DMVR_BDOF );
   if( cu->mc_mode != VVR_MC_UNI && cu->mc_mode != VVR_MC_BI && cu->mc_mode != VVR_MC_BDOF ) { vvo_set_error( "inter mode not restated yet" ); return -1; }
   const int altHpel = cu->imv == 3;

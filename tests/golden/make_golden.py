@@ -34,6 +34,7 @@ CASES = [
     ("b_200x136_ctu64_dmvr", 200, 136, 6, 3, 21, ALL | abi.TOOL_DMVR, dict(p_intra=0.0, p_bi=0.8, mv_sigma=2.0)),
     ("b_256x128_ctu128_affine_prof", 256, 128, 7, 2, 22, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.1, p_affine=0.5)),
     ("b_200x136_ctu64_affine", 200, 136, 6, 1, 23, ALL, dict(p_intra=0.0, p_affine=0.5, mv_sigma=3.0)),
+    ("b_256x128_ctu128_gpm", 256, 128, 7, 2, 24, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.1, p_geo=0.5, p_affine=0.1)),
 ]
 
 

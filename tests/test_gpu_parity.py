@@ -152,6 +152,13 @@ def test_affine_prof_1080p(built):
     _run_stream(1920, 1080, 3, 2, 131, TOOLS_A, intra=True, streams=3, p_affine=0.3)
 
 
+def test_gpm_stream(built):
+    """geometric partitioning: two uni-predictions blended with the angle/offset dependent weight masks"""
+    _run_stream(256, 128, 9, 8, 141, TOOLS_A, intra=True, p_geo=0.4, p_affine=0.1)
+    _run_stream(416, 240, 5, 4, 142, TOOLS_A, intra=True, p_bi=0.7, p_intra=0.05, mv_sigma=2.0, p_geo=0.6)
+    _run_stream(1920, 1080, 3, 2, 143, TOOLS_A, intra=True, streams=3, p_geo=0.3)
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

@@ -60,6 +60,7 @@ typedef struct vvs_params {
   float    p_jccr;
   float    p_mrl, p_bdpcm;
   float    p_affine;            // of inter CUs >= 8x8 (half of them 6-parameter)
+  float    p_geo;               // of inter CUs that can use the geometric partitioning mode
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -94,7 +95,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f;
 }
 
 namespace {
@@ -228,11 +229,34 @@ struct Gen {
       bool eqDist = false;
       if( bi ) { const int d0 = P.poc - P.ref_poc[0][cu.ref_idx[0]], d1 = P.poc - P.ref_poc[1][cu.ref_idx[1]]; eqDist = d0 * d1 < 0 && d0 == -d1; }
       const bool sizeOk = w >= 8 && h >= 8 && w * h >= 128;
+      // geometric partitioning (merge mode of B slices, 8..64, aspect ratio < 8): two uni-predictions blended along a line
+      if( !( cu.flags & VVR_CU_AFFINE ) && P.slice_type == 0 && P.num_ref[1] > 0 && w >= 8 && h >= 8 && w <= 64 && h <= 64 && w < 8 * h && h < 8 * w && rng.p( P.p_geo ) )
+      {
+        cu.flags |= VVR_CU_GEO | VVR_CU_MERGE;
+        cu.imv = 0; cu.bcw_idx = 2;
+        cu.geo_split_dir = (uint8_t) rng.u( 64 );
+        for( int k = 0; k < 2; k++ )
+        {
+          const int l = rng.u( 2 ), r = rng.u( P.num_ref[l] );
+          cu.geo_dir_ref[k] = (uint8_t) ( ( ( l + 1 ) << 4 ) | r );
+          int32_t mv[2] = { rng.laplace( P.mv_sigma * 16 / 1.414 ), rng.laplace( P.mv_sigma * 16 / 1.414 ) };
+          if( rng.p( 0.2 ) ) { mv[0] &= ~15; mv[1] &= ~15; }
+          clipMv( mv, x, y );
+          cu.geo_mv[k][0] = mv[0]; cu.geo_mv[k][1] = mv[1];
+        }
+        // what the parser leaves in the CU / motion field for later stages: the stored motion is per 4x4 (GPM motion storage); for
+        // this generator the field simply carries partition 0 (uni) -- it only feeds the edge-parameter derivation, which is an input
+        const int l0g = ( cu.geo_dir_ref[0] >> 4 ) - 1;
+        cu.inter_dir = (uint8_t) ( l0g + 1 );
+        cu.ref_idx[0] = cu.ref_idx[1] = -1; cu.ref_idx[l0g] = (int8_t) ( cu.geo_dir_ref[0] & 15 );
+        memset( cu.mv, 0, sizeof( cu.mv ) );
+        cu.mv[l0g][0][0] = cu.geo_mv[0][0]; cu.mv[l0g][0][1] = cu.geo_mv[0][1];
+      }
       const bool aff = ( cu.flags & VVR_CU_AFFINE ) != 0;
       const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff;      // (:1407-1427), no CIIP/SMVD/WP here
       const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff;   // PU::checkDMVRCondition (UnitTools.cpp:1277)
       // xCheckIdenticalMotion (:404) is false for affine CUs: they go through xPredInterBi -> xPredAffineBlk per list
-      cu.mc_mode = aff ? VVR_MC_AFFINE : dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
+      cu.mc_mode = ( cu.flags & VVR_CU_GEO ) ? VVR_MC_GEO : aff ? VVR_MC_AFFINE : dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
       if( dmvr ) { cu.dmvr_off = B.num_dmvr; B.num_dmvr += ( ( w + 15 ) / 16 ) * ( ( h + 15 ) / 16 ); }     // one delta MV per 16x16 sub-block (m_dmvrMvCache)
     }
     // transform units: split at 64 (max TB size), cbf per block

@@ -238,15 +238,26 @@ static int validate( vvr_context* c, const vvr_picture* p )
     {
       const bool isDmvr = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
       const bool isAff = cu.mc_mode == VVR_MC_AFFINE;
-      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF && !isDmvr && !isAff ) { c->setError( "inter mode (GPM/SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      const bool isGeo = cu.mc_mode == VVR_MC_GEO;
+      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF && !isDmvr && !isAff && !isGeo ) { c->setError( "inter mode (SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( isGeo != ( ( cu.flags & VVR_CU_GEO ) != 0 ) ) { c->setError( "GPM CU: mc_mode / flag mismatch" ); return VVR_ERR_PARAMETER; }
+      if( isGeo )
+      {
+        if( cu.w < 8 || cu.h < 8 || cu.w > 64 || cu.h > 64 || cu.w >= 8 * cu.h || cu.h >= 8 * cu.w || cu.geo_split_dir >= 64 ) { c->setError( "GPM CU: size / split direction out of range" ); return VVR_ERR_PARAMETER; }
+        for( int k = 0; k < 2; k++ )
+        {
+          const int l = ( cu.geo_dir_ref[k] >> 4 ) - 1, ri = cu.geo_dir_ref[k] & 15;
+          if( l < 0 || l > 1 || ri >= h.num_ref[l] ) { c->setError( "GPM CU: bad reference" ); return VVR_ERR_PARAMETER; }
+        }
+      }
       if( isAff != ( ( cu.flags & VVR_CU_AFFINE ) != 0 ) || ( isAff && ( !p->motion || cu.w < 8 || cu.h < 8 ) ) ) { c->setError( "affine CU: mc_mode / flag mismatch, missing motion field or CU smaller than 8x8" ); return VVR_ERR_PARAMETER; }
       if( isDmvr && ( !( h.tool_flags & VVR_TOOL_DMVR ) || ( cu.mc_mode == VVR_MC_DMVR_BDOF && !( h.tool_flags & VVR_TOOL_BDOF ) ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
       { c->setError( "mc_mode DMVR on a CU that cannot use DMVR (UnitTools.cpp:1277)" ); return VVR_ERR_PARAMETER; }
       if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
       { c->setError( "mc_mode BDOF on a CU that cannot use BDOF (InterPrediction.cpp:1407-1427)" ); return VVR_ERR_PARAMETER; }
-      if( cu.flags & ( VVR_CU_CIIP | VVR_CU_GEO | VVR_CU_SBTMVP ) ) { c->setError( "CIIP / GPM / SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) ) { c->setError( "CIIP / SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) { c->setError( "ref_idx out of range" ); return VVR_ERR_PARAMETER; }
-      if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
+      if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
       if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) { c->setError( "inter CU must be single tree" ); return VVR_ERR_PARAMETER; }
     }
     else if( cu.pred_mode == VVR_PRED_INTRA )

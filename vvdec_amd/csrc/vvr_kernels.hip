@@ -30,6 +30,8 @@ __device__ int16_t d_dst7_4[16], d_dst7_8[64], d_dst7_16[256], d_dst7_32[1024];
 __device__ int8_t  d_lfnst8x8[4][2][48][16], d_lfnst4x4[4][2][16][16];
 __device__ uint8_t d_lfnst_lut[97], d_lfnst_scan8x8_xy[16][2], d_lfnst_scan4x4_xy[16][2];
 __device__ int32_t d_inv_quant_scales[2][6];
+__device__ int16_t d_geo_params[64][2], d_geo_weight_offset[64][4][4][2];
+__device__ int8_t  d_geo_weights[6][112 * 112], d_geo_angle2mask[32], d_geo_angle2mirror[32];
 __device__ int16_t d_luma_filter[16][8], d_luma_filter_4x4[16][8], d_luma_alt_hpel[8], d_chroma_filter[32][4];
 __device__ int8_t  d_bcw_weights[5];
 __device__ uint16_t d_db_tc_table[66];
@@ -46,6 +48,7 @@ int vvr_upload_tables()
   UPLOAD( lfnst8x8 ); UPLOAD( lfnst4x4 ); UPLOAD( lfnst_lut ); UPLOAD( lfnst_scan8x8_xy ); UPLOAD( lfnst_scan4x4_xy );
   UPLOAD( inv_quant_scales ); UPLOAD( luma_filter ); UPLOAD( luma_filter_4x4 ); UPLOAD( luma_alt_hpel ); UPLOAD( chroma_filter );
   UPLOAD( bcw_weights ); UPLOAD( db_tc_table ); UPLOAD( db_beta_table ); UPLOAD( alf_fixed_coeff ); UPLOAD( alf_class_to_filter );
+  UPLOAD( geo_params ); UPLOAD( geo_weight_offset ); UPLOAD( geo_weights ); UPLOAD( geo_angle2mask ); UPLOAD( geo_angle2mirror );
   return 0;
 }
 
@@ -172,8 +175,24 @@ __device__ __forceinline__ int mc_final( const pel_t* win, int wstride, const pe
 template<int NT>
 __device__ __forceinline__ void mc_output( const pel_t* win0, const pel_t* tmp0, const pel_t* win1, const pel_t* tmp1, int wst, int tst, const McSeg* seg0, const McSeg* seg1,
                                            const int16_t* cH0, const int16_t* cV0, const int16_t* cH1, const int16_t* cV1, int c, bool uni, int bcwIdx, int bd,
-                                           const DevPlanes& reco, int x0c, int y0c, int w, int h, int tid )
+                                           const DevPlanes& reco, int x0c, int y0c, int w, int h, int tid, const vvr_cu* geoCu = nullptr )
 {
+  // GPM (InterpolationFilter::xWeightedGeoBlk, InterpolationFilter.cpp:1217): weight of partition 0 from the mask tables, addressed
+  // in luma units relative to the CU with the mirroring of the split angle
+  const int8_t* gW = nullptr; int gBase = 0, gSX = 0, gSY = 0;
+  if( geoCu )
+  {
+    const int MS = 112, cs = c ? 1 : 0;
+    const int angle = d_geo_params[geoCu->geo_split_dir][0];
+    const int wIdx = ilog2( geoCu->w ) - 3, hIdx = ilog2( geoCu->h ) - 3;
+    const int ox = d_geo_weight_offset[geoCu->geo_split_dir][hIdx][wIdx][0], oy = d_geo_weight_offset[geoCu->geo_split_dir][hIdx][wIdx][1];
+    gW = d_geo_weights[d_geo_angle2mask[angle]];
+    const int mir = d_geo_angle2mirror[angle];
+    const int lx0 = ( x0c << cs ) - geoCu->x, ly0 = ( y0c << cs ) - geoCu->y;        // tile offset inside the CU, luma units
+    if( mir == 2 )      { gBase = ( MS - 1 - oy - ly0 ) * MS + ox + lx0; gSX = 1 << cs; gSY = -( MS << cs ); }
+    else if( mir == 1 ) { gBase = ( oy + ly0 ) * MS + ( MS - 1 - ox ) - lx0; gSX = -( 1 << cs ); gSY = MS << cs; }
+    else                { gBase = ( oy + ly0 ) * MS + ox + lx0; gSX = 1 << cs; gSY = MS << cs; }
+  }
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   const int lw = w == 16 ? 4 : w == 8 ? 3 : w == 4 ? 2 : 1;       // log2 of the tile width
   for( int i = tid; i < w * h; i += NT )
@@ -185,7 +204,12 @@ __device__ __forceinline__ void mc_output( const pel_t* win0, const pel_t* tmp0,
     {
       const int p0 = mc_final( win0, wst, tmp0, tst, *seg0, cH0, cV0, c, true, bd, px, py );
       const int p1 = mc_final( win1, wst, tmp1, tst, *seg1, cH1, cV1, c, true, bd, px, py );
-      if( bcwIdx != 2 )
+      if( gW )
+      {
+        const int wt = gW[gBase + py * gSY + px * gSX], shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+        out = clip_pel( ( wt * p0 + ( 8 - wt ) * p1 + offset ) >> shift, bd );
+      }
+      else if( bcwIdx != 2 )
       {
         const int w1 = d_bcw_weights[bcwIdx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
         out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
@@ -320,6 +344,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   const bool biPred = cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0;
   const bool uni = cu.mc_mode == VVR_MC_UNI;
   const bool bdof = cu.mc_mode == VVR_MC_BDOF;          // xSubPuBio (InterPrediction.cpp:551): the tile IS the <= 16x16 BDOF sub-block
+  const bool geo = cu.mc_mode == VVR_MC_GEO;            // motionCompensationGeo (:1461): two uni-predictions kept at 14 bit, blended with the GPM masks
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
   const int l0 = uni ? ( ( biPred || cu.ref_idx[0] >= 0 ) ? 0 : 1 ) : 0;
   const int nl = uni ? 1 : 2;
@@ -329,8 +354,9 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
     const int k = tid / 3, c = tid - 3 * k;
     if( k < nl && c < ncomp )
     {
-      const int l = uni ? l0 : k;
-      int mvx = cu.mv[l][0][0], mvy = cu.mv[l][0][1];
+      const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
+      const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : cu.ref_idx[l];
+      int mvx = geo ? cu.geo_mv[k][0] : cu.mv[l][0][0], mvy = geo ? cu.geo_mv[k][1] : cu.mv[l][0][1];
       mc_clip_mv( pic, cu.x, cu.y, mvx, mvy );           // clipped with the CU position (InterPrediction.cpp:657 uses m_currCuArea)
       McSeg g;
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
@@ -344,7 +370,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - g.oy;
       g.padOff = 0; g.cw = g.ww; g.chh = g.wh;
       seg[k][c] = g;
-      refp[k][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
+      refp[k][c] = refs.p[l * VVR_MAX_REFS + refIdx][c];
       mc_taps( g, c, cu.imv == 3, coefH[k][c], coefV[k][c] );
     }
   }
@@ -363,7 +389,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   {
     const int cs = c ? 1 : 0;
     mc_output<NT>( c ? winC[0][c - 1] : winL[0], c ? tmpC[0][c - 1] : tmpL[0], c ? winC[1][c - 1] : winL[1], c ? tmpC[1][c - 1] : tmpL[1], c ? 12 : 24, c ? 8 : 16,
-                   &seg[0][c], &seg[1][c], coefH[0][c], coefV[0][c], coefH[1][c], coefV[1][c], c, uni, cu.bcw_idx, bd, reco, it.x >> cs, it.y >> cs, it.w >> cs, it.h >> cs, tid );
+                   &seg[0][c], &seg[1][c], coefH[0][c], coefV[0][c], coefH[1][c], coefV[1][c], c, uni, cu.bcw_idx, bd, reco, it.x >> cs, it.y >> cs, it.w >> cs, it.h >> cs, tid, geo ? &cu : nullptr );
   }
 }
 
