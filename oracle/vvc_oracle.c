@@ -124,7 +124,23 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
     if( cu->pred_mode == VVR_PRED_INTER )
     {
       if( vvo_inter_cu( pic, cu, refs, numSlots, &reco ) ) goto done;
-      if( cu->flags & VVR_CU_ROOT_CBF )
+      if( cu->flags & VVR_CU_CIIP )
+      {
+        /* DecCu::predAndReco( cu, doCiipIntra ) (DecCu.cpp:453-470): planar intra prediction of the whole CU from the reconstructed
+         * neighbours, blended into the inter prediction, then the residual.  The reference runs this in its intra stage; a single
+         * pass in decoding order sees the same neighbours. */
+        vvr_cu icu = *cu;
+        icu.intra_dir[0] = icu.intra_dir[1] = 0; icu.multi_ref_idx = 0; icu.bdpcm[0] = icu.bdpcm[1] = 0; icu.isp_mode = 0; icu.flags &= (uint16_t) ~VVR_CU_MIP;
+        const int wIntra = 1 + ( cu->ciip_neigh_intra & 1 ) + ( ( cu->ciip_neigh_intra >> 1 ) & 1 );
+        if( cu->num_tu != 1 || cu->w < 8 ) { vvo_set_error( "CIIP: CU with several TUs / 4-wide CU not restated" ); goto done; }
+        const vvr_tu* tu = &pic->tu[cu->first_tu];
+        int bw[3], bh[3];
+        const int mask = ( cu->flags & VVR_CU_ROOT_CBF ) ? tu_residuals( pic, cu, tu, resi, bw, bh ) : 0;
+        if( mask < 0 ) goto done;
+        for( int c = 0; c < ncomp; c++ )
+          if( vvo_intra_tu( pic, &icu, tu, cu->first_tu, c, &reco, order, resi[c], ( mask >> c ) & 1, wIntra ) ) goto done;
+      }
+      else if( cu->flags & VVR_CU_ROOT_CBF )
         for( uint32_t t = cu->first_tu; t < cu->first_tu + cu->num_tu; t++ )
         {
           const vvr_tu* tu = &pic->tu[t];
@@ -155,7 +171,7 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
         for( int c = 0; c < ncomp; c++ )
         {
           if( !( tu->comp_mask & ( 1 << c ) ) ) continue;
-          if( vvo_intra_tu( pic, cu, tu, t, c, &reco, order, resi[c], ( mask >> c ) & 1 ) ) goto done;
+          if( vvo_intra_tu( pic, cu, tu, t, c, &reco, order, resi[c], ( mask >> c ) & 1, 0 ) ) goto done;
         }
       }
     }

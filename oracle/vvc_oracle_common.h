@@ -40,7 +40,7 @@ int  vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* r
 void vvo_dmvr_reset( void );
 /* vvc_oracle_intra.c */
 int  vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, vvo_planes* reco,
-                   const int32_t* tu_order_map /* per 4x4 luma units, per channel type */, const int16_t* resi, int has_resi );
+                   const int32_t* tu_order_map /* per 4x4 luma units, per channel type */, const int16_t* resi, int has_resi, int ciip_w_intra );
 /* vvc_oracle_loopfilter.c */
 void vvo_deblock( const vvr_picture* pic, vvo_planes* reco, int dir );
 void vvo_sao( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst );

@@ -45,8 +45,10 @@ static int unit_avail( const vvr_pic_header* H, const int32_t* order, int ch, in
   return order[(size_t) ch * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
 }
 
+/* ciip_w_intra != 0: the block already holds the inter prediction; the intra prediction is blended into it with weight
+ * ciip_w_intra / 4 before the residual is added (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:887-946) */
 int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, vvo_planes* reco,
-                  const int32_t* order, const int16_t* resi, int has_resi )
+                  const int32_t* order, const int16_t* resi, int has_resi, int ciip_w_intra )
 {
   const vvr_pic_header* H = &pic->hdr;
   const int bd = H->bit_depth, cs = comp ? 1 : 0, ch = comp ? 1 : 0;
@@ -322,7 +324,9 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
   /* ---- reconstruction (DecCu.cpp:396-403) */
   for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
   {
-    const int v = has_resi ? vvo_clip_pel( pred[y * w + x] + resi[y * w + x], bd ) : pred[y * w + x];
+    int pv = pred[y * w + x];
+    if( ciip_w_intra ) pv = ( ( 4 - ciip_w_intra ) * plane[(size_t) ( y0 + y ) * stride + x0 + x] + ciip_w_intra * pv + 2 ) >> 2;
+    const int v = has_resi ? vvo_clip_pel( pv + resi[y * w + x], bd ) : pv;
     plane[(size_t) ( y0 + y ) * stride + x0 + x] = (pel) v;
   }
   return 0;

@@ -159,6 +159,13 @@ def test_gpm_stream(built):
     _run_stream(1920, 1080, 3, 2, 143, TOOLS_A, intra=True, streams=3, p_geo=0.3)
 
 
+def test_ciip_stream(built):
+    """combined inter/intra prediction: inter prediction from k_mc, planar intra + blend + residual in the intra wavefront"""
+    _run_stream(256, 128, 9, 8, 151, TOOLS_A, intra=True, p_ciip=0.4, p_intra=0.2)
+    _run_stream(416, 240, 5, 4, 152, TOOLS_A, intra=True, p_bi=0.7, p_intra=0.3, mv_sigma=2.0, p_ciip=0.6, p_coded=0.7)
+    _run_stream(1920, 1080, 3, 2, 153, TOOLS_A, intra=True, streams=3, p_ciip=0.3, p_geo=0.1, p_affine=0.1)
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

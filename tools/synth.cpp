@@ -61,6 +61,7 @@ typedef struct vvs_params {
   float    p_mrl, p_bdpcm;
   float    p_affine;            // of inter CUs >= 8x8 (half of them 6-parameter)
   float    p_geo;               // of inter CUs that can use the geometric partitioning mode
+  float    p_ciip;              // of inter CUs that can combine inter and intra prediction
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -95,7 +96,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f; P->p_geo = 0.0f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f;
 }
 
 namespace {
@@ -252,9 +253,19 @@ struct Gen {
         memset( cu.mv, 0, sizeof( cu.mv ) );
         cu.mv[l0g][0][0] = cu.geo_mv[0][0]; cu.mv[l0g][0][1] = cu.geo_mv[0][1];
       }
+      // CIIP: regular merge CU (no affine/GPM/MMVD), 64 <= area, sides < 128 (8..64 here); the intra part is planar
+      if( !( cu.flags & ( VVR_CU_AFFINE | VVR_CU_GEO ) ) && w >= 8 && h >= 8 && w <= 64 && h <= 64 && rng.p( P.p_ciip ) )
+      {
+        cu.flags |= VVR_CU_CIIP | VVR_CU_MERGE;
+        cu.imv = 0; cu.bcw_idx = 2;
+        cu.intra_dir[0] = cu.intra_dir[1] = 0;
+        // neighbours the blend weights look at: the CU left of the bottom-left sample and the CU above the top-right sample
+        auto isIntraAt = [&]( int px, int py ) { if( px < 0 || py < 0 ) return false; const int32_t k = cuOf4[( py >> 2 ) * w4 + ( px >> 2 )]; return k >= 0 && B.cu[k].pred_mode == VVR_PRED_INTRA; };
+        cu.ciip_neigh_intra = (uint8_t) ( ( isIntraAt( x - 1, y + h - 1 ) ? 1 : 0 ) | ( isIntraAt( x + w - 1, y - 1 ) ? 2 : 0 ) );
+      }
       const bool aff = ( cu.flags & VVR_CU_AFFINE ) != 0;
-      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff;      // (:1407-1427), no CIIP/SMVD/WP here
-      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff;   // PU::checkDMVRCondition (UnitTools.cpp:1277)
+      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & VVR_CU_CIIP );      // (:1407-1427), no SMVD/WP here
+      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & VVR_CU_CIIP );   // PU::checkDMVRCondition (UnitTools.cpp:1277)
       // xCheckIdenticalMotion (:404) is false for affine CUs: they go through xPredInterBi -> xPredAffineBlk per list
       cu.mc_mode = ( cu.flags & VVR_CU_GEO ) ? VVR_MC_GEO : aff ? VVR_MC_AFFINE : dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
       if( dmvr ) { cu.dmvr_off = B.num_dmvr; B.num_dmvr += ( ( w + 15 ) / 16 ) * ( ( h + 15 ) / 16 ); }     // one delta MV per 16x16 sub-block (m_dmvrMvCache)
@@ -423,7 +434,7 @@ struct Gen {
         }
         // boundary strength (LoopFilter.cpp:1094-1360)
         int bsY = 0, bsCb = 0, bsCr = 0;
-        const bool intra = CQ.pred_mode == VVR_PRED_INTRA || CP.pred_mode == VVR_PRED_INTRA;
+        const bool intra = CQ.pred_mode == VVR_PRED_INTRA || CP.pred_mode == VVR_PRED_INTRA || ( ( CQ.flags | CP.flags ) & VVR_CU_CIIP );   // CIIP counts as intra for the BS
         if( intra ) { bsY = 2; bsCb = bsCr = chromaEdge ? 2 : 0; }
         else
         {

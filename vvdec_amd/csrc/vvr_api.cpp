@@ -255,7 +255,9 @@ static int validate( vvr_context* c, const vvr_picture* p )
       { c->setError( "mc_mode DMVR on a CU that cannot use DMVR (UnitTools.cpp:1277)" ); return VVR_ERR_PARAMETER; }
       if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
       { c->setError( "mc_mode BDOF on a CU that cannot use BDOF (InterPrediction.cpp:1407-1427)" ); return VVR_ERR_PARAMETER; }
-      if( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) ) { c->setError( "CIIP / SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.flags & VVR_CU_SBTMVP ) { c->setError( "SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( ( cu.flags & VVR_CU_CIIP ) && ( ( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI ) || cu.w < 8 || cu.h < 8 || cu.w > 64 || cu.h > 64 || cu.num_tu != 1 ) )
+      { c->setError( "CIIP CU: needs plain uni/bi prediction and a CU of 8..64 with one TU (4-wide CIIP CUs are not implemented)" ); return VVR_ERR_UNSUPPORTED; }
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) { c->setError( "ref_idx out of range" ); return VVR_ERR_PARAMETER; }
       if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
       if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) { c->setError( "inter CU must be single tree" ); return VVR_ERR_PARAMETER; }
@@ -308,7 +310,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   struct BBox { int y0 = 255, y1 = 0, c0 = 255, c1 = 0; };   // rows relative to (CTU top - 3), 8-sample chunks relative to (CTU left - 8), chunk index + 1
   std::vector<BBox> bboxV( 3 * (size_t) numCtu );   // per (component, CTU): bit k set = must wait for neighbour k (L, AL, A, AR)
   bool anyIntra = false;
-  for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA;
+  for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || ( p->cu[i].flags & VVR_CU_CIIP );
   if( anyIntra )
   {
     order.assign( (size_t) w4 * h4 * 2, 0x7fffffff );
@@ -316,8 +318,10 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     for( uint32_t i = 0; i < p->num_cu; i++ )
     {
       const vvr_cu& cu = p->cu[i];
-      if( cu.pred_mode == VVR_PRED_INTRA )
-        for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) intraAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = 1;
+      // 1: intra CU, 2: CIIP CU (inter prediction blended with planar intra in the intra stage, DecCu.cpp:137-140,453-456)
+      const bool ciip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
+      if( cu.pred_mode == VVR_PRED_INTRA || ciip )
+        for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) intraAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = ciip ? 2 : 1;
       for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
       {
         const vvr_tu& tu = p->tu[t];
@@ -347,7 +351,8 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       if( ctuOfCu < curCtu ) { c->setError( "CUs are not in CTU raster order" ); return VVR_ERR_PARAMETER; }
       while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
     }
-    if( cu.pred_mode == VVR_PRED_INTRA )
+    const bool isCiip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
+    if( cu.pred_mode == VVR_PRED_INTRA || isCiip )
     {
       for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
       {
@@ -362,10 +367,12 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           it.tu = t; it.comp = (uint8_t) comp;
           it.x = (uint16_t) x0; it.y = (uint16_t) y0;
           { int l = 0; while( ( 1 << l ) < w ) l++; it.lw = (uint8_t) l; l = 0; while( ( 1 << l ) < hh ) l++; it.lh = (uint8_t) l; }
-          it.mode = cu.intra_dir[chn];
+          it.mode = isCiip ? 0 : cu.intra_dir[chn];       // CIIP: planar
           const bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
-          const int bdp = cu.bdpcm[chn];
-          it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp ? 0 : cu.multi_ref_idx ) << 4 ) );
+          const int bdp = isCiip ? 0 : cu.bdpcm[chn];
+          // CIIP blend weight of the intra part (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:925-929): 1 + intra neighbours
+          const int wIntra = isCiip ? 1 + ( cu.ciip_neigh_intra & 1 ) + ( ( cu.ciip_neigh_intra >> 1 ) & 1 ) : 0;
+          it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
           it.nTL = (uint8_t) unitAvail( chn, x0 - 1, y0 - 1, (int32_t) t );
           if( unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
           if( unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }
@@ -424,7 +431,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       for( int comp = 0; comp < ncomp; comp++ )
       {
         if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
-        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.mode = cu.pred_mode == VVR_PRED_INTER ? TB_ADD : TB_STORE; it.ict = 0; it.pad = 0;
+        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.mode = ( cu.pred_mode == VVR_PRED_INTER && !( cu.flags & VVR_CU_CIIP ) ) ? TB_ADD : TB_STORE; it.ict = 0; it.pad = 0;
         if( comp && tu.joint_cbcr )
         {
           if( comp != 1 ) continue;
@@ -465,7 +472,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       const uint32_t k = activeV[t] >> 24, a = activeV[t] & 0xffffff;
       const int ux = (int) ( a % ctusX ) * ctu4, uy = (int) ( a / ctusX ) * ctu4;
       bool all = true;
-      for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( !intraAt[(size_t) y * w4 + x] ) { all = false; break; }
+      for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
       if( all ) activeV[t] |= 0x80000000u;
       activeV.push_back( depMaskV[(size_t) k * numCtu + a] );
     }

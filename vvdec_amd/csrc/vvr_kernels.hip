@@ -1838,7 +1838,8 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int16_t* __restrict__ rcur = sh.resi[k & 1];
       if( k + 1 < nb ) intra_fetch_resi( sh.items[k + 1], rs, rstride, tid, rnext );     // in flight while this block is predicted
       const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
-      const int mrl = it.flags >> 4;
+      const int mrl = ( it.flags >> 4 ) & 3;
+      const int wIntra = it.flags >> 6;               // CIIP: weight of the planar intra part, 0 = ordinary intra block
       const int bdpcm = ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
       const int dirMode = it.mode;
       const bool hasResi = ( it.flags & IT_F_RESI ) != 0;
@@ -2043,6 +2044,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           const int wT = 32 >> min( 31, ( y << 1 ) >> pscale ), wL = 32 >> min( 31, ( x << 1 ) >> pscale );
           v = (int16_t) ( v + ( ( wL * ( L[y + 1] - v ) + wT * ( T[x + 1] - v ) + 32 ) >> 6 ) );
         }
+        if( wIntra ) v = ( ( 4 - wIntra ) * TILE( x0 + x, y0 + y ) + wIntra * v + 2 ) >> 2;     // predBlendIntraCiip (:935-944): the tile holds the inter prediction
         if( hasResi ) v = clip_pel( v + rcur[i], bd );
         TILE( x0 + x, y0 + y ) = (pel_t) v;
       }
