@@ -511,7 +511,11 @@ static int affine_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes
 {
   const vvr_pic_header* H = &pic->hdr;
   const int bd = H->bit_depth, ncomp = H->chroma_format ? 3 : 1;
-  const int biPred = cu->ref_idx[0] >= 0 && cu->ref_idx[1] >= 0;
+  int biPred = cu->ref_idx[0] >= 0 && cu->ref_idx[1] >= 0;
+  /* xCheckIdenticalMotion (InterPrediction.cpp:404-436): same reference picture and same control-point MVs -> list 0 only */
+  if( biPred && H->ref_poc[0][cu->ref_idx[0]] == H->ref_poc[1][cu->ref_idx[1]]
+      && cu->mv[0][0][0] == cu->mv[1][0][0] && cu->mv[0][0][1] == cu->mv[1][0][1] && cu->mv[0][1][0] == cu->mv[1][1][0] && cu->mv[0][1][1] == cu->mv[1][1][1]
+      && ( !( cu->flags & VVR_CU_AFFINE_6P ) || ( cu->mv[0][2][0] == cu->mv[1][2][0] && cu->mv[0][2][1] == cu->mv[1][2][1] ) ) ) biPred = 0;
   const size_t n = (size_t) cu->w * cu->h;
   pel* buf = (pel*) malloc( sizeof( pel ) * n * 3 );
   pel* p0[3] = { buf, buf + n, buf + n + n / 4 };
@@ -600,6 +604,62 @@ static int geo_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* r
   return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Sub-block temporal MV prediction: InterPrediction::xSubPuMC (InterPrediction.cpp:438-549): 8x8 sub-blocks, each with the motion
+ * stored in the motion field, predicted by the regular uni/bi path (no BDOF, no DMVR: m_subPuMC).  The reference joins sub-blocks
+ * with equal motion before predicting; that changes nothing in the samples (the MV clip only acts outside the padded picture). */
+static void plain_block( const vvr_picture* pic, const vvo_planes* refs, int x, int y, int w, int h, const int mv[2][2], const int ref_idx[2], int bcw_idx, int altHpel, vvo_planes* reco )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int bd = H->bit_depth, ctu = 1 << H->log2_ctu, ncomp = H->chroma_format ? 3 : 1;
+  int bi = ref_idx[0] >= 0 && ref_idx[1] >= 0;
+  if( bi && H->ref_poc[0][ref_idx[0]] == H->ref_poc[1][ref_idx[1]] && mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1] ) bi = 0;     /* xCheckIdenticalMotion */
+  for( int c = 0; c < ncomp; c++ )
+  {
+    const int cs = c ? 1 : 0, bx = x >> cs, by = y >> cs, bw = w >> cs, bh = h >> cs;
+    pel* dst = reco->p[c] + (size_t) by * reco->stride[c] + bx;
+    if( !bi )
+    {
+      const int l = ref_idx[0] >= 0 ? 0 : 1;
+      int m[2] = { mv[l][0], mv[l][1] };
+      clip_mv( m, x, y, H->width, H->height, ctu );
+      pred_block( &refs[H->ref_slot[l][ref_idx[l]]], c, bx, by, bw, bh, m[0], m[1], 0, altHpel, bd, dst, reco->stride[c] );
+      continue;
+    }
+    pel t[2][16 * 16];
+    for( int l = 0; l < 2; l++ )
+    {
+      int m[2] = { mv[l][0], mv[l][1] };
+      clip_mv( m, x, y, H->width, H->height, ctu );
+      pred_block( &refs[H->ref_slot[l][ref_idx[l]]], c, bx, by, bw, bh, m[0], m[1], 1, altHpel, bd, t[l], bw );
+    }
+    const int hr = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2;
+    for( int yy = 0; yy < bh; yy++ ) for( int xx = 0; xx < bw; xx++ )
+    {
+      int v;
+      if( bcw_idx != 2 ) { const int w1 = vvc_bcw_weights[bcw_idx], w0 = 8 - w1; v = ( t[0][yy * bw + xx] * w0 + t[1][yy * bw + xx] * w1 + ( 1 << ( hr + 2 ) ) + ( IF_INTERNAL_OFFS << 3 ) ) >> ( hr + 3 ); }
+      else v = ( t[0][yy * bw + xx] + t[1][yy * bw + xx] + ( 1 << hr ) + 2 * IF_INTERNAL_OFFS ) >> ( hr + 1 );
+      dst[yy * reco->stride[c] + xx] = (pel) vvo_clip_pel( v, bd );
+    }
+  }
+}
+
+static int sbtmvp_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* refs, vvo_planes* reco )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int w4 = ( H->width + 3 ) >> 2;
+  if( !pic->motion ) { vvo_set_error( "SbTMVP CU without a motion field" ); return -1; }
+  for( int y = 0; y < cu->h; y += 8 ) for( int x = 0; x < cu->w; x += 8 )
+  {
+    const vvr_motion* m = &pic->motion[(size_t) ( ( cu->y + y ) >> 2 ) * w4 + ( ( cu->x + x ) >> 2 )];
+    const int mv[2][2] = { { m->mv[0][0], m->mv[0][1] }, { m->mv[1][0], m->mv[1][1] } };
+    const int ri[2] = { m->ref_idx[0], m->ref_idx[1] };
+    if( ( ri[0] < 0 && ri[1] < 0 ) || ri[0] >= H->num_ref[0] || ri[1] >= H->num_ref[1] ) { vvo_set_error( "SbTMVP: bad sub-block motion" ); return -1; }
+    plain_block( pic, refs, cu->x + x, cu->y + y, 8, 8, mv, ri, cu->bcw_idx, cu->imv == 3, reco );
+  }
+  return 0;
+}
+
 void vvo_dmvr_reset( void ) { g_dmvr_count = 0; memset( g_dmvr_out, 0, sizeof( g_dmvr_out ) ); }
 uint32_t vvo_get_dmvr( int32_t* dst, uint32_t max_entries )
 {
@@ -614,6 +674,7 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu;
   const int ncomp = H->chroma_format ? 3 : 1;
   if( cu->mc_mode == VVR_MC_AFFINE ) return affine_cu( pic, cu, refs, reco );
+  if( cu->mc_mode == VVR_MC_SBTMVP ) return sbtmvp_cu( pic, cu, refs, reco );
   if( cu->mc_mode == VVR_MC_GEO ) return geo_cu( pic, cu, refs, num_slots, reco );
   if( cu->mc_mode == VVR_MC_DMVR || cu->mc_mode == VVR_MC_DMVR_BDOF ) return dmvr_cu( pic, cu, refs, reco, cu->mc_mode == VVR_MC_DMVR_BDOF );
   if( cu->mc_mode != VVR_MC_UNI && cu->mc_mode != VVR_MC_BI && cu->mc_mode != VVR_MC_BDOF ) { vvo_set_error( "inter mode not restated yet" ); return -1; }

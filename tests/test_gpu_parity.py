@@ -166,6 +166,13 @@ def test_ciip_stream(built):
     _run_stream(1920, 1080, 3, 2, 153, TOOLS_A, intra=True, streams=3, p_ciip=0.3, p_geo=0.1, p_affine=0.1)
 
 
+def test_sbtmvp_and_all_inter_tools(built):
+    """SbTMVP (per-8x8 motion, uni/bi/identical) and a mix of every inter tool in one stream"""
+    _run_stream(256, 128, 9, 8, 161, TOOLS_A, intra=True, p_sbtmvp=0.4, p_intra=0.1)
+    _run_stream(416, 240, 5, 4, 162, TOOLS_A, intra=True, p_bi=0.7, p_intra=0.15, p_affine=0.2, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.15)
+    _run_stream(1920, 1080, 3, 2, 163, TOOLS_A, intra=True, streams=3, p_affine=0.15, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.15)
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

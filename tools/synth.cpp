@@ -62,6 +62,7 @@ typedef struct vvs_params {
   float    p_affine;            // of inter CUs >= 8x8 (half of them 6-parameter)
   float    p_geo;               // of inter CUs that can use the geometric partitioning mode
   float    p_ciip;              // of inter CUs that can combine inter and intra prediction
+  float    p_sbtmvp;            // of inter CUs >= 8x8: sub-block temporal merge (per-8x8 motion)
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -96,7 +97,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f;
 }
 
 namespace {
@@ -253,8 +254,10 @@ struct Gen {
         memset( cu.mv, 0, sizeof( cu.mv ) );
         cu.mv[l0g][0][0] = cu.geo_mv[0][0]; cu.mv[l0g][0][1] = cu.geo_mv[0][1];
       }
+      // SbTMVP: merge CU whose 8x8 sub-blocks carry their own motion (filled into the motion field below)
+      if( !( cu.flags & ( VVR_CU_AFFINE | VVR_CU_GEO ) ) && w >= 8 && h >= 8 && rng.p( P.p_sbtmvp ) ) { cu.flags |= VVR_CU_SBTMVP | VVR_CU_MERGE; cu.imv = 0; cu.bcw_idx = 2; }
       // CIIP: regular merge CU (no affine/GPM/MMVD), 64 <= area, sides < 128 (8..64 here); the intra part is planar
-      if( !( cu.flags & ( VVR_CU_AFFINE | VVR_CU_GEO ) ) && w >= 8 && h >= 8 && w <= 64 && h <= 64 && rng.p( P.p_ciip ) )
+      if( !( cu.flags & ( VVR_CU_AFFINE | VVR_CU_GEO | VVR_CU_SBTMVP ) ) && w >= 8 && h >= 8 && w <= 64 && h <= 64 && rng.p( P.p_ciip ) )
       {
         cu.flags |= VVR_CU_CIIP | VVR_CU_MERGE;
         cu.imv = 0; cu.bcw_idx = 2;
@@ -264,10 +267,12 @@ struct Gen {
         cu.ciip_neigh_intra = (uint8_t) ( ( isIntraAt( x - 1, y + h - 1 ) ? 1 : 0 ) | ( isIntraAt( x + w - 1, y - 1 ) ? 2 : 0 ) );
       }
       const bool aff = ( cu.flags & VVR_CU_AFFINE ) != 0;
-      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & VVR_CU_CIIP );      // (:1407-1427), no SMVD/WP here
-      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & VVR_CU_CIIP );   // PU::checkDMVRCondition (UnitTools.cpp:1277)
+      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );      // (:1407-1427), no SMVD/WP here
+      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );   // PU::checkDMVRCondition (UnitTools.cpp:1277)
       // xCheckIdenticalMotion (:404) is false for affine CUs: they go through xPredInterBi -> xPredAffineBlk per list
-      cu.mc_mode = ( cu.flags & VVR_CU_GEO ) ? VVR_MC_GEO : aff ? VVR_MC_AFFINE : dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
+      // affine CUs with the same reference picture and the same control points in both lists take the uni-directional path (:424-429)
+      if( aff && bi && P.ref_poc[0][cu.ref_idx[0]] == P.ref_poc[1][cu.ref_idx[1]] && rng.p( 0.3 ) ) memcpy( cu.mv[1], cu.mv[0], sizeof( cu.mv[0] ) );
+      cu.mc_mode = ( cu.flags & VVR_CU_SBTMVP ) ? VVR_MC_SBTMVP : ( cu.flags & VVR_CU_GEO ) ? VVR_MC_GEO : aff ? VVR_MC_AFFINE : dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
       if( dmvr ) { cu.dmvr_off = B.num_dmvr; B.num_dmvr += ( ( w + 15 ) / 16 ) * ( ( h + 15 ) / 16 ); }     // one delta MV per 16x16 sub-block (m_dmvrMvCache)
     }
     // transform units: split at 64 (max TB size), cbf per block
@@ -317,6 +322,31 @@ struct Gen {
       for( int l = 0; l < 2; l++ ) { m.mv[l][0] = cu.ref_idx[l] >= 0 ? cu.mv[l][0][0] : 0; m.mv[l][1] = cu.ref_idx[l] >= 0 ? cu.mv[l][0][1] : 0; }
     }
     if( cu.flags & VVR_CU_AFFINE ) for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= 0 ) setAllAffineMv( cu, l );
+    if( cu.flags & VVR_CU_SBTMVP )
+    {
+      // per 8x8: uni or bi, own reference indices and MVs; neighbours often share their motion (the reference joins those)
+      vvr_motion prev; memset( &prev, 0, sizeof( prev ) ); bool havePrev = false;
+      for( int yy = 0; yy < h; yy += 8 ) for( int xx = 0; xx < w; xx += 8 )
+      {
+        vvr_motion m; memset( &m, 0, sizeof( m ) ); m.ref_idx[0] = m.ref_idx[1] = -1;
+        if( havePrev && rng.p( 0.35 ) ) m = prev;
+        else
+        {
+          const int dir = ( P.slice_type == 0 && P.num_ref[1] > 0 ) ? 1 + rng.u( 3 ) : 1;
+          for( int l = 0; l < 2; l++ )
+          {
+            if( !( dir & ( 1 << l ) ) ) continue;
+            m.ref_idx[l] = (int8_t) rng.u( P.num_ref[l] );
+            int32_t mv[2] = { cu.mv[cu.ref_idx[0] >= 0 ? 0 : 1][0][0] + rng.laplace( 24 ), cu.mv[cu.ref_idx[0] >= 0 ? 0 : 1][0][1] + rng.laplace( 24 ) };
+            clipMv( mv, x + xx, y + yy );
+            m.mv[l][0] = mv[0]; m.mv[l][1] = mv[1];
+          }
+          if( dir == 3 && P.ref_poc[0][m.ref_idx[0]] == P.ref_poc[1][m.ref_idx[1]] && rng.p( 0.3 ) ) { m.mv[1][0] = m.mv[0][0]; m.mv[1][1] = m.mv[0][1]; }   // identical motion
+        }
+        prev = m; havePrev = true;
+        for( int sy = 0; sy < 8; sy += 4 ) for( int sx = 0; sx < 8; sx += 4 ) B.motion[(size_t) ( ( y + yy + sy ) >> 2 ) * w4 + ( ( x + xx + sx ) >> 2 )] = m;
+      }
+    }
   }
 
   // PU::setAllAffineMv (UnitTools.cpp:2689): per-4x4 sub-block MVs from the control points, or one fallback MV when the

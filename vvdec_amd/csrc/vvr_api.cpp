@@ -239,7 +239,15 @@ static int validate( vvr_context* c, const vvr_picture* p )
       const bool isDmvr = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
       const bool isAff = cu.mc_mode == VVR_MC_AFFINE;
       const bool isGeo = cu.mc_mode == VVR_MC_GEO;
-      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF && !isDmvr && !isAff && !isGeo ) { c->setError( "inter mode (SbTMVP) not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      const bool isSbt = cu.mc_mode == VVR_MC_SBTMVP;
+      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF && !isDmvr && !isAff && !isGeo && !isSbt ) { c->setError( "unknown mc_mode" ); return VVR_ERR_PARAMETER; }
+      if( isSbt != ( ( cu.flags & VVR_CU_SBTMVP ) != 0 ) || ( isSbt && ( !p->motion || cu.w < 8 || cu.h < 8 ) ) ) { c->setError( "SbTMVP CU: mc_mode / flag mismatch, missing motion field or CU smaller than 8x8" ); return VVR_ERR_PARAMETER; }
+      if( isSbt )
+        for( int y = 0; y < cu.h; y += 8 ) for( int x = 0; x < cu.w; x += 8 )
+        {
+          const vvr_motion& m = p->motion[(size_t) ( ( cu.y + y ) >> 2 ) * ( ( h.width + 3 ) >> 2 ) + ( ( cu.x + x ) >> 2 )];
+          if( ( m.ref_idx[0] < 0 && m.ref_idx[1] < 0 ) || m.ref_idx[0] >= h.num_ref[0] || m.ref_idx[1] >= h.num_ref[1] ) { c->setError( "SbTMVP CU: bad sub-block motion" ); return VVR_ERR_PARAMETER; }
+        }
       if( isGeo != ( ( cu.flags & VVR_CU_GEO ) != 0 ) ) { c->setError( "GPM CU: mc_mode / flag mismatch" ); return VVR_ERR_PARAMETER; }
       if( isGeo )
       {
@@ -255,11 +263,10 @@ static int validate( vvr_context* c, const vvr_picture* p )
       { c->setError( "mc_mode DMVR on a CU that cannot use DMVR (UnitTools.cpp:1277)" ); return VVR_ERR_PARAMETER; }
       if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
       { c->setError( "mc_mode BDOF on a CU that cannot use BDOF (InterPrediction.cpp:1407-1427)" ); return VVR_ERR_PARAMETER; }
-      if( cu.flags & VVR_CU_SBTMVP ) { c->setError( "SbTMVP not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
       if( ( cu.flags & VVR_CU_CIIP ) && ( ( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI ) || cu.w < 8 || cu.h < 8 || cu.w > 64 || cu.h > 64 || cu.num_tu != 1 ) )
       { c->setError( "CIIP CU: needs plain uni/bi prediction and a CU of 8..64 with one TU (4-wide CIIP CUs are not implemented)" ); return VVR_ERR_UNSUPPORTED; }
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) { c->setError( "ref_idx out of range" ); return VVR_ERR_PARAMETER; }
-      if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
+      if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo && !isSbt ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
       if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) { c->setError( "inter CU must be single tree" ); return VVR_ERR_PARAMETER; }
     }
     else if( cu.pred_mode == VVR_PRED_INTRA )
@@ -410,10 +417,12 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     }
     if( cu.pred_mode == VVR_PRED_INTER )
     {
-      const int nl = cu.mc_mode == VVR_MC_UNI ? 1 : 2;
-      for( int y = 0; y < cu.h; y += 16 ) for( int x = 0; x < cu.w; x += 16 )
+      const int nl = cu.mc_mode == VVR_MC_UNI ? 1 : 2;     // (SbTMVP: upper bound, sub-blocks may be uni-directional)
+      const bool sbt = cu.mc_mode == VVR_MC_SBTMVP;
+      const int ts = sbt ? 8 : 16;                       // SbTMVP: one item per 8x8 sub-block (ATMVP_SUB_BLOCK_SIZE)
+      for( int y = 0; y < cu.h; y += ts ) for( int x = 0; x < cu.w; x += ts )
       {
-        McItem it; it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( 16, cu.w - x ); it.h = (uint8_t) std::min( 16, cu.h - y ); it.pad = 0; it.cu = i;
+        McItem it; it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y ); it.flags = sbt ? MC_ITEM_SUBBLOCK : 0; it.cu = i;
         const bool dm = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
         const bool af = cu.mc_mode == VVR_MC_AFFINE;
         ( dm ? mcDmvr : af ? mcAff : mc ).push_back( it );

@@ -19,10 +19,11 @@ struct DevPlanes {
 
 // One motion-compensation tile: at most 16x16 luma samples (+ the co-located 8x8 chroma samples) of one inter CU.
 // 16x16 is the unit VVC itself uses for DMVR/BDOF processing (DMVR_SUBCU 16x16, MAX_BDOF_APPLICATION_REGION 16).
+#define MC_ITEM_SUBBLOCK 1     /* SbTMVP: the tile is one 8x8 sub-block, motion from the motion field */
 struct McItem {
   uint16_t x, y;       // luma position
   uint8_t  w, h;       // luma size: 4, 8 or 16
-  uint16_t pad;
+  uint16_t flags;      // MC_ITEM_*
   uint32_t cu;         // index into the CU array
 };
 

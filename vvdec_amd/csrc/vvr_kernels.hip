@@ -341,12 +341,24 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   const vvr_cu& cu = pic.cu[it.cu];
   const int bd = pic.hdr.bit_depth;
   const int tid = threadIdx.x;
-  const bool biPred = cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0;
-  const bool uni = cu.mc_mode == VVR_MC_UNI;
+  // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the tile is one 8x8 sub-block whose motion comes from the motion field; it goes
+  // through the plain uni / bi path with the identical-motion shortcut (xCheckIdenticalMotion :404), clipped at its own position
+  const bool sub = ( it.flags & MC_ITEM_SUBBLOCK ) != 0;
+  int mRef[2] = { cu.ref_idx[0], cu.ref_idx[1] }, mMv[2][2] = { { cu.mv[0][0][0], cu.mv[0][0][1] }, { cu.mv[1][0][0], cu.mv[1][0][1] } };
+  bool uni = cu.mc_mode == VVR_MC_UNI;
+  if( sub )
+  {
+    const vvr_motion& m = pic.motion[(size_t) ( it.y >> 2 ) * pic.w4 + ( it.x >> 2 )];
+    for( int l = 0; l < 2; l++ ) { mRef[l] = m.ref_idx[l]; mMv[l][0] = m.mv[l][0]; mMv[l][1] = m.mv[l][1]; }
+    const bool two = mRef[0] >= 0 && mRef[1] >= 0;
+    uni = !two || ( pic.hdr.ref_poc[0][mRef[0]] == pic.hdr.ref_poc[1][mRef[1]] && mMv[0][0] == mMv[1][0] && mMv[0][1] == mMv[1][1] );
+  }
+  const int clipX = sub ? it.x : cu.x, clipY = sub ? it.y : cu.y;
+  const bool biPred = mRef[0] >= 0 && mRef[1] >= 0;
   const bool bdof = cu.mc_mode == VVR_MC_BDOF;          // xSubPuBio (InterPrediction.cpp:551): the tile IS the <= 16x16 BDOF sub-block
   const bool geo = cu.mc_mode == VVR_MC_GEO;            // motionCompensationGeo (:1461): two uni-predictions kept at 14 bit, blended with the GPM masks
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
-  const int l0 = uni ? ( ( biPred || cu.ref_idx[0] >= 0 ) ? 0 : 1 ) : 0;
+  const int l0 = uni ? ( ( biPred || mRef[0] >= 0 ) ? 0 : 1 ) : 0;
   const int nl = uni ? 1 : 2;
   // ---- segment geometry + filter taps: computed once by six lanes, shared through LDS
   if( tid < 6 )
@@ -355,9 +367,9 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
     if( k < nl && c < ncomp )
     {
       const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
-      const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : cu.ref_idx[l];
-      int mvx = geo ? cu.geo_mv[k][0] : cu.mv[l][0][0], mvy = geo ? cu.geo_mv[k][1] : cu.mv[l][0][1];
-      mc_clip_mv( pic, cu.x, cu.y, mvx, mvy );           // clipped with the CU position (InterPrediction.cpp:657 uses m_currCuArea)
+      const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : mRef[l];
+      int mvx = geo ? cu.geo_mv[k][0] : mMv[l][0], mvy = geo ? cu.geo_mv[k][1] : mMv[l][1];
+      mc_clip_mv( pic, clipX, clipY, mvx, mvy );         // clipped with the CU position (InterPrediction.cpp:657 uses m_currCuArea)
       McSeg g;
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
       g.w = it.w >> cs; g.h = it.h >> cs;
@@ -687,7 +699,11 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   const int w = it.w, h = it.h;
   const int sbx = w >> 2, nsb = sbx * ( h >> 2 );            // luma sub-blocks in the tile
   const int cbx = w >> 3, ncb = cbx * ( h >> 3 );            // chroma sub-blocks (4x4 chroma samples = 8x8 luma)
-  const bool biPred = cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0;
+  bool biPred = cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0;
+  // xCheckIdenticalMotion (:404-436): same reference picture and same control-point MVs in both lists -> list 0 only
+  if( biPred && pic.hdr.ref_poc[0][cu.ref_idx[0]] == pic.hdr.ref_poc[1][cu.ref_idx[1]]
+      && cu.mv[0][0][0] == cu.mv[1][0][0] && cu.mv[0][0][1] == cu.mv[1][0][1] && cu.mv[0][1][0] == cu.mv[1][1][0] && cu.mv[0][1][1] == cu.mv[1][1][1]
+      && ( !( cu.flags & VVR_CU_AFFINE_6P ) || ( cu.mv[0][2][0] == cu.mv[1][2][0] && cu.mv[0][2][1] == cu.mv[1][2][1] ) ) ) biPred = false;
   const int l0 = cu.ref_idx[0] >= 0 ? 0 : 1, nl = biPred ? 2 : 1;
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   // ---- sub-block geometry
