@@ -34,6 +34,9 @@ static int tu_residuals( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu*
   {
     bw[c] = ( c && cu->isp_mode ) ? cu->w >> 1 : tu->w >> ( c ? 1 : 0 );
     bh[c] = ( c && cu->isp_mode ) ? cu->h >> 1 : tu->h >> ( c ? 1 : 0 );
+  }
+  for( int c = 0; c < ncomp; c++ )
+  {
     if( !( tu->comp_mask & ( 1 << c ) ) ) continue;
     if( c && tu->joint_cbcr )
     {

@@ -173,6 +173,12 @@ def test_sbtmvp_and_all_inter_tools(built):
     _run_stream(1920, 1080, 3, 2, 163, TOOLS_A, intra=True, streams=3, p_affine=0.15, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.15)
 
 
+def test_joint_cbcr(built):
+    """tu_joint_cbcr_residual: one coded chroma block, the other derived (all three modes, both signs)"""
+    _run_stream(256, 128, 5, 4, 171, TOOLS_A, intra=True, p_jccr=0.7, p_coded_chroma=0.7, p_intra=0.3)
+    _run_stream(416, 240, 5, 4, 172, TOOLS_A | abi.TOOL_JCCR_SIGN, intra=True, p_jccr=0.7, p_coded_chroma=0.7, p_intra=0.3)
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

@@ -33,6 +33,8 @@ def _case(W, H, l2, idx, seed, **kw):
     (384, 256, 7, 3, 108, dict(p_intra=0.1, p_geo=0.5)),
     (384, 256, 7, 2, 109, dict(p_intra=0.25, p_ciip=0.5, p_coded=0.6)),
     (384, 256, 7, 3, 110, dict(p_intra=0.1, p_affine=0.3, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.3)),
+    (256, 128, 6, 2, 111, dict(p_intra=0.3, p_jccr=0.7, p_coded_chroma=0.7)),
+    (256, 128, 6, 0, 112, dict(p_jccr=0.7, p_coded_chroma=0.7)),
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)

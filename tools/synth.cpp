@@ -63,6 +63,7 @@ typedef struct vvs_params {
   float    p_geo;               // of inter CUs that can use the geometric partitioning mode
   float    p_ciip;              // of inter CUs that can combine inter and intra prediction
   float    p_sbtmvp;            // of inter CUs >= 8x8: sub-block temporal merge (per-8x8 motion)
+  float    p_bcw;               // of bi-predicted CUs with at least 256 samples: unequal CU-level weights
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -97,7 +98,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f;
 }
 
 namespace {
@@ -211,6 +212,8 @@ struct Gen {
       }
       if( cu.imv == 3 ) for( int l = 0; l < 2; l++ ) { cu.mv[l][0][0] &= ~7; cu.mv[l][0][1] &= ~7; }
       cu.flags |= rng.p( 0.5 ) ? VVR_CU_MERGE : 0;
+      // BCW: bi-prediction with CU-level weights {-2,3,5,10}/8 instead of 4/8 (index into g_BcwWeights, 2 = equal weights)
+      if( bi && w * h >= 256 && rng.p( P.p_bcw ) ) { static const uint8_t idx[4] = { 0, 1, 3, 4 }; cu.bcw_idx = idx[rng.u( 4 )]; }
       // affine: control-point MVs = the translational MV plus small corner deltas (affine never uses the half-pel AMVR filter)
       if( w >= 8 && h >= 8 && rng.p( P.p_affine ) )
       {
@@ -288,12 +291,25 @@ struct Gen {
       const int qpBd = 6 * ( bd - 8 );
       tu.qp[0] = (int8_t) ( cu.qp + qpBd );
       tu.qp[1] = tu.qp[2] = (int8_t) ( std::min( 63, std::max( -qpBd, (int) cu.qp ) ) + qpBd );   // identity chroma QP mapping, zero offsets
+      // joint coding of the chroma residuals (tu_joint_cbcr_residual_flag): one coded block, mode = ( cbfCb << 1 ) | cbfCr,
+      // levels in Cb for modes 2 / 3 and in Cr for mode 1 (TrQuant::invTransformICT, TrQuant.cpp:320)
+      int jccr = 0;
+      if( P.chroma_format && P.p_jccr > 0 && rng.p( P.p_coded_chroma ) && rng.p( P.p_jccr ) ) jccr = 1 + rng.u( 3 );
+      tu.joint_cbcr = (uint8_t) jccr;
       for( int c = 0; c < ( P.chroma_format ? 3 : 1 ); c++ )
       {
         const int bw = c ? tw >> 1 : tw, bh = c ? th >> 1 : th;
         const bool force = c == 0 && intra && ( cu.bdpcm[0] || cu.lfnst_idx );     // these modes are only signalled with a coded luma block
-        if( !force && !rng.p( c ? P.p_coded_chroma : P.p_coded ) ) continue;
-        tu.cbf |= 1 << c;
+        if( c && jccr )
+        {
+          if( ( jccr >> ( 2 - c ) ) & 1 ) tu.cbf |= 1 << c;
+          if( c != ( ( jccr >> 1 ) ? 1 : 2 ) ) continue;                              // only the coded component carries levels
+        }
+        else
+        {
+          if( !force && !rng.p( c ? P.p_coded_chroma : P.p_coded ) ) continue;
+          tu.cbf |= 1 << c;
+        }
         bool ts = bw <= 32 && bh <= 32 && rng.p( P.p_ts );
         if( c == 0 && intra && cu.bdpcm[0] ) ts = true;
         if( c == 0 && intra && cu.lfnst_idx ) ts = false;
@@ -469,7 +485,8 @@ struct Gen {
         else
         {
           if( ( TQ.cbf & 1 ) || ( TP.cbf & 1 ) ) bsY = 1;
-          if( chromaEdge ) { if( ( TQ.cbf & 2 ) || ( TP.cbf & 2 ) ) bsCb = 1; if( ( TQ.cbf & 4 ) || ( TP.cbf & 4 ) ) bsCr = 1; }
+          const bool jointChr = TQ.joint_cbcr || TP.joint_cbcr;     // (LoopFilter.cpp:1180-1184)
+          if( chromaEdge ) { if( ( TQ.cbf & 2 ) || ( TP.cbf & 2 ) || jointChr ) bsCb = 1; if( ( TQ.cbf & 4 ) || ( TP.cbf & 4 ) || jointChr ) bsCr = 1; }
           if( !bsY && &CQ != &CP )
           {
             // motion-based rule
