@@ -29,13 +29,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
+# SURVEY.md §8(d) config 2 tool mix (fractions of inter CUs; BDOF / DMVR follow from the reference's own conditions:
+# bi-predicted, mirrored POC distances, >= 8x8 and >= 128 samples, merge mode for DMVR)
+MIX = dict(p_intra=0.15, p_bi=0.6, p_affine=0.06, p_geo=0.03, p_ciip=0.03, p_sbtmvp=0.03, p_bcw=0.05, p_jccr=0.1)
+
+
 def _cpu_worker(args):
     kind, W, H, seed, tools, gop, idx = args
     import refdrv
     from vvdec_amd import synth, stream
     plans, _ = stream.ra_plan(gop + 1, gop=gop, seed_poc0_is_external=False)
     pl = plans[idx % len(plans)]
-    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools)
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **MIX)
     refs = {}
     for lst in pl.ref_slots:
         for (slot, poc) in lst:
@@ -101,14 +106,15 @@ def main():
     from vvdec_amd import abi, synth, stream
     vvdec_amd.lib()
     W, H = a.width, a.height
-    tools = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST
+    tools = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST |
+             abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF)
     K, Wm = a.steps, a.warmup
     nframes = ((max(K, Wm) - 1 + a.gop - 1) // a.gop) * a.gop + 1
     plans, nslots = stream.ra_plan(nframes, gop=a.gop, seed_poc0_is_external=False)   # POC 0 is an I picture
     from vvdec_amd import parallel
     seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank)
-    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools) for pl in plans[:max(K, Wm)]]
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **MIX) for pl in plans[:max(K, Wm)]]
     prepared = [rec.prepare(d) for d in descs]        # everything resident in HBM from here on
 
     def one_pass(n):
@@ -169,8 +175,9 @@ def main():
                "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int16", "data": "synthetic",
                "config": {"workload": "%dx%d 10-bit 4:2:0 random-access QP32 (hierarchical-B GOP %d), CTU 128, pre-parsed records resident in HBM" % (W, H, a.gop),
-                          "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel), dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, deblocking, SAO, ALF + CC-ALF",
-                          "not_yet": "CCLM/MIP/ISP, BDOF/DMVR/affine/GPM/CIIP, LMCS (rejected with VVR_ERR_UNSUPPORTED)",
+                          "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
+                          "mix": MIX,
+                          "not_yet": "CCLM/MIP/ISP, LMCS, IBC, explicit weighted prediction (rejected with VVR_ERR_UNSUPPORTED)",
                           "pictures_in_flight": a.streams, "sharding": "closed-GOP segment per GPU, no data-path collective",
                           "verified_pictures_vs_oracle": verified},
                "roofline": roof}
