@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--gop", type=int, default=16)
     ap.add_argument("--streams", type=int, default=8, help="pictures in flight per GPU")
+    ap.add_argument("--slots", type=int, default=24, help="DPB slots used round-robin (0: smallest DPB, slots reused at once)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=2, help="number of pictures re-checked against the CPU oracle after the run")
     a = ap.parse_args()
@@ -110,7 +111,8 @@ def main():
              abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF)
     K, Wm = a.steps, a.warmup
     nframes = ((max(K, Wm) - 1 + a.gop - 1) // a.gop) * a.gop + 1
-    plans, nslots = stream.ra_plan(nframes, gop=a.gop, seed_poc0_is_external=False)   # POC 0 is an I picture
+    plans, nslots = stream.ra_plan(nframes, gop=a.gop, seed_poc0_is_external=False, pool=a.slots)   # POC 0 is an I picture
+    nslots = max(nslots, a.slots)
     from vvdec_amd import parallel
     seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank)

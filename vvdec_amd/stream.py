@@ -31,12 +31,16 @@ def _hier(lo, hi, layer, out):
     _hier(mid, hi, layer + 1, out)
 
 
-def ra_plan(num_frames, gop=16, seed_poc0_is_external=True):
+def ra_plan(num_frames, gop=16, seed_poc0_is_external=True, pool=0):
     """Decode-order list of PicPlan for POC 0..num_frames-1 (num_frames - 1 must be a multiple of gop).
 
     POC 0 is the IRAP picture; with seed_poc0_is_external it is not part of the plan (the caller uploads it into slot 0).
     Key pictures (multiples of gop) reference the two previous key pictures; B pictures reference the nearest decoded
     picture on each side (L0 = [past, future], L1 = [future, past]), which is the usual RA configuration.
+
+    pool = 0: a freed slot is reused at once (smallest DPB, what a memory-constrained host decoder does).  pool = N > 0: slots are
+    taken round-robin from N slots, so that independent pictures of one temporal layer do not serialise on a write-after-read /
+    write-after-write hazard of a shared slot when several pictures are in flight (HBM is not the scarce resource here).
     """
     assert (num_frames - 1) % gop == 0
     plans = []
@@ -62,14 +66,21 @@ def ra_plan(num_frames, gop=16, seed_poc0_is_external=True):
     free_at = {0: last_use.get(0, -1)} if seed_poc0_is_external else {}
     used = set(slot_of.values())
     max_slots = len(used)
+    nxt = len(used) % pool if pool else 0
     for i, p in enumerate(plans):
         for s, until in list(free_at.items()):
             if until < i:
                 used.discard(s)
                 del free_at[s]
-        s = 0
-        while s in used:
-            s += 1
+        if pool:
+            s = nxt
+            while s in used:
+                s = (s + 1) % pool
+            nxt = (s + 1) % pool
+        else:
+            s = 0
+            while s in used:
+                s += 1
         used.add(s)
         p.slot = s
         slot_of[p.poc] = s
