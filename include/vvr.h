@@ -79,7 +79,8 @@ enum {
   VVR_TOOL_JCCR_SIGN    = 1u << 11,  /* ph_joint_cbcr_sign_flag                                    */
   VVR_TOOL_STILL_REF    = 1u << 12,  /* picture is still referenced: DMVR refined MVs are returned */
   VVR_TOOL_LFNST        = 1u << 13,  /* sps LFNST on (TrQuant.cpp:301)                              */
-  VVR_TOOL_MTS          = 1u << 14,  /* sps MTS on (explicit+implicit selection resolved per TU)    */
+  VVR_TOOL_MTS          = 1u << 14,
+  VVR_TOOL_CCLM_COLLOC  = 1u << 15,  /* sps_chroma_vertical_collocated_flag: CCLM down-samples luma with the 5-tap cross filter */  /* sps MTS on (explicit+implicit selection resolved per TU)    */
 };
 
 typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::reconstructCoeff (AdaptiveLoopFilter.cpp:888) stays on the host */

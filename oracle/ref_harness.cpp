@@ -138,6 +138,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     sps.setUseISP( true );
     sps.setUseMIP( true );
     sps.setUseLMChroma( true );
+    sps.setVerCollocatedChromaFlag( !!( H.tool_flags & VVR_TOOL_CCLM_COLLOC ) );
     sps.setUseMRL( true );
     sps.setBDPCMEnabledFlag( true );
     sps.setTransformSkipEnabledFlag( true );

@@ -45,6 +45,148 @@ static int unit_avail( const vvr_pic_header* H, const int32_t* order, int ch, in
   return order[(size_t) ch * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Cross-component linear model (CCLM / MDLM_L / MDLM_T), 4:2:0, sps_cclm_collocated_chroma_flag = 0:
+ * IntraPrediction::xGetLumaRecPixels (IntraPrediction.cpp:1403-1690), xGetLMParameters (:1694-1905), predIntraChromaLM (:519),
+ * AreaBuf::linearTransform (Buffer.cpp:516).  top / left = the chroma block's unfiltered reference lines (xFillReferenceSamples).
+ * Only the template positions that xGetLMParameters selects are down-sampled (the reference down-samples whole lines, the
+ * unselected values never reach the output). */
+#define LM_CHROMA_IDX 67
+#define MDLM_L_IDX    68
+#define MDLM_T_IDX    69
+static void cclm_predict( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, const vvo_planes* reco, const int32_t* order,
+                          const pel* top, const pel* left, pel* pred )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int bd = H->bit_depth, ctu = 1 << H->log2_ctu;
+  const int cw = tu->w >> 1, chh = tu->h >> 1, x0 = tu->x >> 1, y0 = tu->y >> 1;
+  const int lx0 = tu->x, ly0 = tu->y;
+  const pel* Y = reco->p[0]; const int ys = reco->stride[0];
+#define LU( xx, yy ) ( (int) Y[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
+  const int mode = cu->intra_dir[1];
+  const int aboveCu = cu->y > 0 || tu->y > cu->y, leftCu = cu->x > 0 || tu->x > cu->x;      /* cu.above / cu.left: single slice, single tile */
+  const int unit = 2;                                                                       /* 4 luma samples in chroma units */
+  const int tuWU = cw / unit, tuHU = chh / unit;
+  /* ---- xGetLumaRecPixels: which borders take part in the edge handling of the down-sampling filters */
+  const int totalAboveUnits = mode == MDLM_T_IDX ? ( 2 * cw + unit - 1 ) / unit : tuWU;
+  const int totalLeftUnits  = mode == MDLM_L_IDX ? ( 2 * chh + unit - 1 ) / unit : tuHU;
+  const int bLeft  = ( leftCu ? totalLeftUnits : 0 ) >= tuHU;
+  const int bAbove = ( aboveCu ? totalAboveUnits : 0 ) >= tuWU;
+  const int firstRowOfCtu = ( ly0 & ( ctu - 1 ) ) == 0;
+  /* ---- xGetLMParameters: template sizes */
+  int aboveAvailable = 0, leftAvailable = 0, actualTop = 0, actualLeft = 0;
+  {
+    const int totA = ( 2 * cw + unit - 1 ) / unit, totL = ( 2 * chh + unit - 1 ) / unit;
+    int aboveRightUnits = totA - tuWU, leftBelowUnits = totL - tuHU;
+    if( mode == MDLM_T_IDX )
+    {
+      int avai = 0;
+      if( aboveCu )
+      {
+        avai = tuWU;
+        aboveRightUnits = aboveRightUnits > ( chh / unit ) ? chh / unit : aboveRightUnits;
+        int n = 0;
+        for( int k = 0; k < aboveRightUnits; k++ ) { if( !unit_avail( H, order, 1, x0 + cw + k * unit, y0 - 1, (int32_t) tu_idx ) ) break; n++; }
+        avai += n;
+      }
+      aboveAvailable = avai >= tuWU; actualTop = unit * avai;
+    }
+    else if( mode == MDLM_L_IDX )
+    {
+      int avai = 0;
+      if( leftCu )
+      {
+        avai = tuHU;
+        leftBelowUnits = leftBelowUnits > ( cw / unit ) ? cw / unit : leftBelowUnits;
+        int n = 0;
+        for( int k = 0; k < leftBelowUnits; k++ ) { if( !unit_avail( H, order, 1, x0 - 1, y0 + chh + k * unit, (int32_t) tu_idx ) ) break; n++; }
+        avai += n;
+      }
+      leftAvailable = avai >= tuHU; actualLeft = unit * avai;
+    }
+    else { aboveAvailable = aboveCu; leftAvailable = leftCu; actualTop = cw; actualLeft = chh; }
+  }
+  const int aboveIs4 = leftAvailable ? 0 : 1, leftIs4 = aboveAvailable ? 0 : 1;
+  const int startPos[2] = { actualTop >> ( 2 + aboveIs4 ), actualLeft >> ( 2 + leftIs4 ) };
+  const int pickStep[2] = { vvo_max( 1, actualTop >> ( 1 + aboveIs4 ) ), vvo_max( 1, actualLeft >> ( 1 + leftIs4 ) ) };
+  int selL[4] = { 0, 0, 0, 0 }, selC[4] = { 0, 0, 0, 0 };
+  int cntT = 0, cntL = 0;
+  if( aboveAvailable )
+  {
+    cntT = vvo_min( actualTop, ( 1 + aboveIs4 ) << 1 );
+    for( int k = 0, pos = startPos[0]; k < cntT; pos += pickStep[0], k++ )
+    {
+      const int i = pos; int v;
+      if( firstRowOfCtu )
+      {   /* one luma line above: [1 2 1] */
+        const int l = ( i == 0 && !bLeft ) ? LU( 2 * i, -1 ) : LU( 2 * i - 1, -1 );
+        v = ( LU( 2 * i, -1 ) * 2 + l + LU( 2 * i + 1, -1 ) + 2 ) >> 2;
+      }
+      else
+      {   /* two luma lines above: 6-tap */
+        const int xl = ( i == 0 && !bLeft ) ? 2 * i : 2 * i - 1;
+        v = ( LU( 2 * i, -2 ) * 2 + LU( xl, -2 ) + LU( 2 * i + 1, -2 ) + LU( 2 * i, -1 ) * 2 + LU( xl, -1 ) + LU( 2 * i + 1, -1 ) + 4 ) >> 3;
+      }
+      selL[k] = (pel) v; selC[k] = top[1 + pos];
+    }
+  }
+  if( leftAvailable )
+  {
+    cntL = vvo_min( actualLeft, ( 1 + leftIs4 ) << 1 );
+    for( int k = 0, pos = startPos[1]; k < cntL; pos += pickStep[1], k++ )
+    {
+      const int j = pos;
+      const int v = ( LU( -2, 2 * j ) * 2 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) * 2 + LU( -3, 2 * j + 1 ) + LU( -1, 2 * j + 1 ) + 4 ) >> 3;
+      selL[k + cntT] = (pel) v; selC[k + cntT] = left[1 + pos];
+    }
+  }
+  const int cnt = cntL + cntT;
+  if( cnt == 2 )
+  {
+    selL[3] = selL[0]; selC[3] = selC[0]; selL[2] = selL[1]; selC[2] = selC[1];
+    selL[0] = selL[1]; selC[0] = selC[1]; selL[1] = selL[3]; selC[1] = selC[3];
+  }
+  int minGrp[2] = { 0, 2 }, maxGrp[2] = { 1, 3 };
+  int *tmin = minGrp, *tmax = maxGrp;
+  if( selL[tmin[0]] > selL[tmin[1]] ) { const int t = tmin[0]; tmin[0] = tmin[1]; tmin[1] = t; }
+  if( selL[tmax[0]] > selL[tmax[1]] ) { const int t = tmax[0]; tmax[0] = tmax[1]; tmax[1] = t; }
+  if( selL[tmin[0]] > selL[tmax[1]] ) { int* t = tmin; tmin = tmax; tmax = t; }
+  if( selL[tmin[1]] > selL[tmax[0]] ) { const int t = tmin[1]; tmin[1] = tmax[0]; tmax[0] = t; }
+  const int minL = ( selL[tmin[0]] + selL[tmin[1]] + 1 ) >> 1, minC = ( selC[tmin[0]] + selC[tmin[1]] + 1 ) >> 1;
+  const int maxL = ( selL[tmax[0]] + selL[tmax[1]] + 1 ) >> 1, maxC = ( selC[tmax[0]] + selC[tmax[1]] + 1 ) >> 1;
+  int a, b, shift;
+  if( leftAvailable || aboveAvailable )
+  {
+    const int diff = maxL - minL;
+    if( diff > 0 )
+    {
+      static const uint8_t DivSigTable[16] = { 0, 7, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 1, 1, 0 };
+      const int diffC = maxC - minC;
+      int x = vvo_floor_log2( diff );
+      const int normDiff = ( diff << 4 >> x ) & 15;
+      const int v = DivSigTable[normDiff] | 8;
+      x += normDiff != 0;
+      const int y = diffC == 0 ? 0 : vvo_floor_log2( vvo_abs( diffC ) ) + 1;
+      const int add = 1 << y >> 1;
+      a = ( diffC * v + add ) >> y;
+      shift = 3 + x - y;
+      if( shift < 1 ) { shift = 1; a = a == 0 ? 0 : a < 0 ? -15 : 15; }
+      b = minC - ( ( a * minL ) >> shift );
+    }
+    else { a = 0; b = minC; shift = 0; }
+  }
+  else { a = 0; b = 1 << ( bd - 1 ); shift = 0; }
+  /* ---- down-sampled luma of the block + linear model */
+  for( int y = 0; y < chh; y++ ) for( int x = 0; x < cw; x++ )
+  {
+    const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
+    const int t = (pel) ( ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
+    pred[y * cw + x] = (pel) vvo_clip_pel( ( ( a * t ) >> shift ) + b, bd );
+  }
+  (void) bAbove; (void) comp;
+#undef LU
+}
+
 /* ciip_w_intra != 0: the block already holds the inter prediction; the intra prediction is blended into it with weight
  * ciip_w_intra / 4 before the residual is added (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:887-946) */
 int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, vvo_planes* reco,
@@ -54,7 +196,8 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
   const int bd = H->bit_depth, cs = comp ? 1 : 0, ch = comp ? 1 : 0;
   const int x0 = tu->x >> cs, y0 = tu->y >> cs, w = tu->w >> cs, h = tu->h >> cs;
   pel* plane = reco->p[comp]; const int stride = reco->stride[comp];
-  if( cu->isp_mode || ( ( cu->flags & VVR_CU_MIP ) && !comp ) || ( comp && cu->intra_dir[1] >= 67 ) ) { vvo_set_error( "ISP / MIP / CCLM are not restated" ); return -1; }
+  if( cu->isp_mode || ( ( cu->flags & VVR_CU_MIP ) && !comp ) ) { vvo_set_error( "ISP / MIP are not restated" ); return -1; }
+  if( comp && cu->intra_dir[1] > MDLM_T_IDX ) { vvo_set_error( "bad chroma intra mode" ); return -1; }
   if( w < 4 || h < 4 ) { vvo_set_error( "intra blocks narrower than 4 are not restated" ); return -1; }
   const int mrl = comp ? 0 : cu->multi_ref_idx;
   const int bdpcm = comp ? cu->bdpcm[1] : cu->bdpcm[0];
@@ -163,7 +306,12 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
   /* ---- prediction (predIntraAng :474) */
   pel pred[64 * 64];
   int doPDPC = ( w >= 4 && h >= 4 ) && mrl == 0;
-  if( bdpcm )
+  if( comp && dirMode >= LM_CHROMA_IDX )
+  {
+    cclm_predict( pic, cu, tu, tu_idx, comp, reco, order, top, left, pred );
+    doPDPC = 0;
+  }
+  else if( bdpcm )
   {   /* xPredIntraBDPCM (:850) */
     for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) pred[y * w + x] = bdpcm == 1 ? L[y + 1] : T[x + 1];
   }

@@ -179,6 +179,14 @@ def test_joint_cbcr(built):
     _run_stream(416, 240, 5, 4, 172, TOOLS_A | abi.TOOL_JCCR_SIGN, intra=True, p_jccr=0.7, p_coded_chroma=0.7, p_intra=0.3)
 
 
+def test_cclm(built):
+    """chroma predicted from reconstructed luma: CCLM, MDLM_L, MDLM_T; the chroma CTU waits for the luma CTUs it reads"""
+    _run_stream(256, 128, 5, 4, 181, TOOLS_A, intra=True, p_cclm=0.5, p_intra=0.3)
+    _run_stream(416, 240, 5, 4, 182, TOOLS_A, intra=True, p_cclm=0.6, p_intra=0.5, log2_ctu=6, p_coded=0.6, p_coded_chroma=0.5)
+    _run_stream(200, 136, 3, 2, 183, TOOLS_A, intra=True, p_cclm=0.7, p_intra=0.6, log2_ctu=5)
+    _run_stream(1920, 1080, 3, 2, 184, TOOLS_A, intra=True, streams=3, p_cclm=0.4)
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

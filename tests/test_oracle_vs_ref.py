@@ -35,6 +35,8 @@ def _case(W, H, l2, idx, seed, **kw):
     (384, 256, 7, 3, 110, dict(p_intra=0.1, p_affine=0.3, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.3)),
     (256, 128, 6, 2, 111, dict(p_intra=0.3, p_jccr=0.7, p_coded_chroma=0.7)),
     (256, 128, 6, 0, 112, dict(p_jccr=0.7, p_coded_chroma=0.7)),
+    (256, 128, 7, 0, 113, dict(p_cclm=0.5)),
+    (200, 136, 5, 2, 114, dict(p_cclm=0.6, p_intra=0.5)),
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)

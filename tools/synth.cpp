@@ -64,6 +64,7 @@ typedef struct vvs_params {
   float    p_ciip;              // of inter CUs that can combine inter and intra prediction
   float    p_sbtmvp;            // of inter CUs >= 8x8: sub-block temporal merge (per-8x8 motion)
   float    p_bcw;               // of bi-predicted CUs with at least 256 samples: unequal CU-level weights
+  float    p_cclm;              // of intra CUs: chroma predicted from the reconstructed luma (CCLM, MDLM_L, MDLM_T)
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -98,7 +99,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f;
 }
 
 namespace {
@@ -183,6 +184,7 @@ struct Gen {
       cu.intra_dir[0] = r < 20 ? 0 : r < 35 ? 1 : 2 + rng.u( 65 );
       const int rc = rng.u( 100 );
       cu.intra_dir[1] = rc < 40 ? cu.intra_dir[0] : rc < 55 ? 0 : rc < 65 ? 1 : rc < 75 ? 18 : rc < 85 ? 50 : 2 + rng.u( 65 );   // DM / planar / DC / hor / ver / any (CCLM: not generated yet)
+      if( P.chroma_format && rng.p( P.p_cclm ) ) cu.intra_dir[1] = (uint8_t) ( 67 + rng.u( 3 ) );     // LM_CHROMA_IDX, MDLM_L_IDX, MDLM_T_IDX
       cu.lfnst_intra_mode = cu.intra_dir[0];
       // multiple reference lines: luma only, never on the first row of a CTU, not with planar (intra_luma_ref_idx semantics)
       if( ( y & ( ctu - 1 ) ) != 0 && cu.intra_dir[0] != 0 && rng.p( P.p_mrl ) ) cu.multi_ref_idx = (uint8_t) ( 1 + rng.u( 2 ) );

@@ -271,7 +271,9 @@ static int validate( vvr_context* c, const vvr_picture* p )
     }
     else if( cu.pred_mode == VVR_PRED_INTRA )
     {
-      if( cu.isp_mode || ( cu.flags & VVR_CU_MIP ) || ( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] >= 67 ) ) { c->setError( "ISP / MIP / CCLM are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.isp_mode || ( cu.flags & VVR_CU_MIP ) ) { c->setError( "ISP / MIP are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] >= 67 && ( cu.intra_dir[1] > 69 || ( h.tool_flags & VVR_TOOL_CCLM_COLLOC ) ) )
+      { c->setError( "chroma mode out of range, or CCLM with sps_chroma_vertical_collocated_flag (not implemented in this build)" ); return VVR_ERR_UNSUPPORTED; }
       if( cu.w > 64 || cu.h > 64 || cu.w < 8 || cu.h < 8 ) { c->setError( "intra CU size outside 8..64 is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
       if( cu.tree != VVR_TREE_JOINT ) { c->setError( "dual-tree intra is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
       if( cu.intra_dir[0] > 66 || cu.multi_ref_idx > 2 || cu.bdpcm[1] ) { c->setError( "bad intra mode / chroma BDPCM not implemented" ); return VVR_ERR_UNSUPPORTED; }
@@ -314,6 +316,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   std::vector<int32_t> order;
   std::vector<uint8_t> intraAt;          // per 4x4 luma unit: covered by an intra CU
   std::vector<uint8_t> depMaskV( 3 * (size_t) numCtu, 0 );
+  std::vector<uint8_t> lumaReqV( 3 * (size_t) numCtu, 0 );   // CCLM: luma CTUs (L, AL, A, AR, SELF) whose reconstruction a chroma CTU reads
   struct BBox { int y0 = 255, y1 = 0, c0 = 255, c1 = 0; };   // rows relative to (CTU top - 3), 8-sample chunks relative to (CTU left - 8), chunk index + 1
   std::vector<BBox> bboxV( 3 * (size_t) numCtu );   // per (component, CTU): bit k set = must wait for neighbour k (L, AL, A, AR)
   bool anyIntra = false;
@@ -383,6 +386,41 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           it.nTL = (uint8_t) unitAvail( chn, x0 - 1, y0 - 1, (int32_t) t );
           if( unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
           if( unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }
+          if( comp && !isCiip && cu.intra_dir[1] >= 67 )
+          {
+            // CCLM / MDLM: template sizes and flags of IntraPrediction::xGetLMParameters (:1694-1800) and the border handling of
+            // xGetLumaRecPixels (:1403-1470); they ride in the item's `tu` word
+            const int mode = cu.intra_dir[1];
+            const bool aboveCu = cu.y > 0 || tu.y > cu.y, leftCu = cu.x > 0 || tu.x > cu.x;          // cu.above / cu.left (one slice, one tile)
+            const int tuWU = w / unit, tuHU = hh / unit;
+            const int totA = ( 2 * w + unit - 1 ) / unit, totL = ( 2 * hh + unit - 1 ) / unit;
+            int aboveAvail = 0, leftAvail = 0, actualTop = 0, actualLeft = 0;
+            if( mode == 69 )
+            {
+              int avai = 0;
+              if( aboveCu ) { avai = tuWU; const int lim = std::min( totA - tuWU, hh / unit ); for( int k = 0; k < lim; k++ ) { if( !unitAvail( 1, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; avai++; } }
+              aboveAvail = avai >= tuWU; actualTop = unit * avai;
+            }
+            else if( mode == 68 )
+            {
+              int avai = 0;
+              if( leftCu ) { avai = tuHU; const int lim = std::min( totL - tuHU, w / unit ); for( int k = 0; k < lim; k++ ) { if( !unitAvail( 1, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; avai++; } }
+              leftAvail = avai >= tuHU; actualLeft = unit * avai;
+            }
+            else { aboveAvail = aboveCu; leftAvail = leftCu; actualTop = w; actualLeft = hh; }
+            const int bLeft = leftCu ? 1 : 0;                                                          // availlableLeftUnit >= iTUHeightInUnits
+            const int firstRow = ( tu.y & ( ( 1 << h.log2_ctu ) - 1 ) ) == 0;
+            it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 );
+            // luma the prediction reads: the co-located block (this CTU) and the template rows / columns around it
+            const int S = ( 1 << h.log2_ctu ) >> 1, ox = ( cu.x >> h.log2_ctu ) * S, oy = ( cu.y >> h.log2_ctu ) * S;
+            uint8_t& rq = lumaReqV[(size_t) comp * numCtu + ctuOfCu];
+            rq |= 16;
+            const bool atL = x0 == ox, atT = y0 == oy;
+            if( atL && ( leftAvail || bLeft ) ) rq |= 1;
+            if( atT && aboveAvail ) rq |= 4;
+            if( atL && atT && aboveAvail && bLeft ) rq |= 2;
+            if( atT && aboveAvail && x0 + actualTop > ox + S ) rq |= 8;
+          }
           intra[comp].push_back( it );
           {
             // which neighbouring CTUs hold INTRA samples this block reads (inter samples are final before the intra stage starts)
@@ -483,7 +521,20 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       bool all = true;
       for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
       if( all ) activeV[t] |= 0x80000000u;
-      activeV.push_back( depMaskV[(size_t) k * numCtu + a] );
+      // bits 0..3: neighbours of the same component; bits 4..8: LUMA of the left / above-left / above / above-right / same CTU (CCLM),
+      // only where that luma CTU takes part in the intra stage at all (otherwise its samples are final already)
+      uint32_t dm = depMaskV[(size_t) k * numCtu + a];
+      const uint8_t rq = lumaReqV[(size_t) k * numCtu + a];
+      const int nbx[5] = { -1, -1, 0, 1, 0 }, nby[5] = { 0, -1, -1, -1, 0 };
+      for( int b = 0; b < 5; b++ )
+      {
+        if( !( rq & ( 1 << b ) ) ) continue;
+        const int nx = (int) ( a % ctusX ) + nbx[b], ny = (int) ( a / ctusX ) + nby[b];
+        if( nx < 0 || ny < 0 || nx >= ctusX ) continue;
+        const size_t n = (size_t) ny * ctusX + nx;
+        if( ctuStartV[n + 1] > ctuStartV[n] ) dm |= 16u << b;
+      }
+      activeV.push_back( dm );
     }
     for( size_t t = 0; t < na; t++ )
     {

@@ -1695,6 +1695,7 @@ struct IntraShared {
   int16_t resi[2][64 * 64];                            // residual of the current / next block (prefetched one block ahead)
   int16_t angTab[32], invAngTab[32], cfilt[32][4];     // the small ROM tables the serial per-block path indexes: LDS latency instead of a memory round trip each
   uint8_t filtThr[8];
+  int   lmSel[8];                                       // CCLM: the (luma, chroma) pairs of the selected template positions
   int   ticket;
   int   dcSum[2];
 };
@@ -1805,6 +1806,15 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int nx = cxI + nb[k][0], ny = cyI + nb[k][1];
       const int n = ny * pic.ctus_x + nx;
       int* flag = &sync[1 + comp * numCtu + n];
+      while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 30 );
+    }
+    // CCLM: the luma of this CTU and of the neighbours its templates reach (bits 4..8: L, AL, A, AR, SELF)
+    const int nbl[5][2] = { { -1, 0 }, { -1, -1 }, { 0, -1 }, { 1, -1 }, { 0, 0 } };
+    for( int k = 0; k < 5; k++ )
+    {
+      if( !( depMask & ( 16u << k ) ) ) continue;
+      const int n = ( cyI + nbl[k][1] ) * pic.ctus_x + cxI + nbl[k][0];
+      int* flag = &sync[1 + n];
       while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 30 );
     }
     __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );
@@ -1925,6 +1935,88 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         if( tid == 255 ) sh.dcSum[( k + 1 ) & 1] = 0;
       }
       lds_barrier();
+      // ---- CCLM / MDLM (xGetLumaRecPixels :1403, xGetLMParameters :1694, predIntraChromaLM :519; 4:2:0, non-collocated luma filter)
+      if( comp && dirMode >= 67 )
+      {
+        const pel_t* __restrict__ Yp = reco.p[0]; const int ys = reco.stride[0];
+        const int lx0 = x0 << 1, ly0 = y0 << 1;
+#define LU( xx, yy ) ( (int) Yp[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
+        const uint32_t lm = it.tu;
+        const int actualTop = lm & 0xff, actualLeft = ( lm >> 8 ) & 0xff;
+        const bool aboveAvail = ( lm >> 16 ) & 1, leftAvail = ( lm >> 17 ) & 1, bLeft = ( lm >> 18 ) & 1, firstRow = ( lm >> 19 ) & 1;
+        const int aboveIs4 = leftAvail ? 0 : 1, leftIs4 = aboveAvail ? 0 : 1;
+        const int cntT = aboveAvail ? min( actualTop, ( 1 + aboveIs4 ) << 1 ) : 0, cntL = leftAvail ? min( actualLeft, ( 1 + leftIs4 ) << 1 ) : 0;
+        if( tid < cntT + cntL )
+        {
+          int lv, cv;
+          if( tid < cntT )
+          {
+            const int i = ( actualTop >> ( 2 + aboveIs4 ) ) + tid * max( 1, actualTop >> ( 1 + aboveIs4 ) );
+            const int xl = ( i == 0 && !bLeft ) ? 2 * i : 2 * i - 1;
+            if( firstRow ) lv = ( LU( 2 * i, -1 ) * 2 + LU( xl, -1 ) + LU( 2 * i + 1, -1 ) + 2 ) >> 2;
+            else           lv = ( LU( 2 * i, -2 ) * 2 + LU( xl, -2 ) + LU( 2 * i + 1, -2 ) + LU( 2 * i, -1 ) * 2 + LU( xl, -1 ) + LU( 2 * i + 1, -1 ) + 4 ) >> 3;
+            cv = sh.top[1 + i];
+          }
+          else
+          {
+            const int j = ( actualLeft >> ( 2 + leftIs4 ) ) + ( tid - cntT ) * max( 1, actualLeft >> ( 1 + leftIs4 ) );
+            lv = ( LU( -2, 2 * j ) * 2 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) * 2 + LU( -3, 2 * j + 1 ) + LU( -1, 2 * j + 1 ) + 4 ) >> 3;
+            cv = sh.left[1 + j];
+          }
+          sh.lmSel[tid] = (int16_t) lv; sh.lmSel[4 + tid] = cv;
+        }
+        lds_barrier();
+        int selL[4] = { 0, 0, 0, 0 }, selC[4] = { 0, 0, 0, 0 };
+        const int cnt = cntT + cntL;
+        for( int q = 0; q < 4; q++ ) if( q < cnt ) { selL[q] = sh.lmSel[q]; selC[q] = sh.lmSel[4 + q]; }
+        if( cnt == 2 )
+        {
+          selL[3] = selL[0]; selC[3] = selC[0]; selL[2] = selL[1]; selC[2] = selC[1];
+          selL[0] = selL[1]; selC[0] = selC[1]; selL[1] = selL[3]; selC[1] = selC[3];
+        }
+        int mn0 = 0, mn1 = 2, mx0 = 1, mx1 = 3;
+        if( selL[mn0] > selL[mn1] ) { const int t = mn0; mn0 = mn1; mn1 = t; }
+        if( selL[mx0] > selL[mx1] ) { const int t = mx0; mx0 = mx1; mx1 = t; }
+        if( selL[mn0] > selL[mx1] ) { int t = mn0; mn0 = mx0; mx0 = t; t = mn1; mn1 = mx1; mx1 = t; }
+        if( selL[mn1] > selL[mx0] ) { const int t = mn1; mn1 = mx0; mx0 = t; }
+        const int minL = ( selL[mn0] + selL[mn1] + 1 ) >> 1, minC = ( selC[mn0] + selC[mn1] + 1 ) >> 1;
+        const int maxL = ( selL[mx0] + selL[mx1] + 1 ) >> 1, maxC = ( selC[mx0] + selC[mx1] + 1 ) >> 1;
+        int a = 0, b = 1 << ( bd - 1 ), shift = 0;
+        if( leftAvail || aboveAvail )
+        {
+          const int diff = maxL - minL;
+          b = minC;
+          if( diff > 0 )
+          {
+            const int diffC = maxC - minC;
+            int x = 31 - __clz( diff );
+            const int normDiff = ( diff << 4 >> x ) & 15;
+            const int v = (int) ( ( 0x0111122334455670ull >> ( 4 * normDiff ) ) & 15 ) | 8;      // DivSigTable { 0,7,6,5,5,4,4,3,3,2,2,1,1,1,1,0 }
+            x += normDiff != 0;
+            const int y = diffC == 0 ? 0 : 32 - __clz( iabs( diffC ) );
+            const int add = 1 << y >> 1;
+            a = ( diffC * v + add ) >> y;
+            shift = 3 + x - y;
+            if( shift < 1 ) { shift = 1; a = a == 0 ? 0 : a < 0 ? -15 : 15; }
+            b = minC - ( ( a * minL ) >> shift );
+          }
+        }
+        const int wh2 = w * h;
+#pragma unroll 1
+        for( int i = tid; i < wh2; i += 256 )
+        {
+          const int x = i & ( w - 1 ), y = i >> lw;
+          const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
+          const int t = (int16_t) ( ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
+          int v = clip_pel( ( ( a * t ) >> shift ) + b, bd );
+          if( hasResi ) v = clip_pel( v + rcur[i], bd );
+          TILE( x0 + x, y0 + y ) = (pel_t) v;
+        }
+#undef LU
+        if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
+        lds_barrier();
+        continue;
+      }
       // ---- reference smoothing
       bool useFilt = false;
       if( !comp && !mrl && !bdpcm && dirMode != 1 )
