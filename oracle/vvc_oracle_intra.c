@@ -187,6 +187,86 @@ static void cclm_predict( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu
 #undef LU
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Matrix-based intra prediction (luma): IntraPrediction::initIntraMip / predIntraMip (IntraPrediction.cpp:1906,1919),
+ * PredictorMIP::deriveBoundaryData (MatrixIntraPrediction.cpp:68), boundaryDownsampling1D (:170), computeReducedPred (:279),
+ * predictionUpsampling / predictionUpsampling1D (:196-262), matrices MipData.h:55,347,495. */
+static void mip_upsample_1d( pel* dst, const pel* src, const pel* bndry, int srcSizeUpsmpDim, int srcSizeOrthDim, int srcStep, int srcStride,
+                             int dstStep, int dstStride, int bndryStep, int upsmpFactor )
+{
+  const int l2 = vvo_log2( upsmpFactor ), rnd = 1 << ( l2 - 1 );
+  const pel* srcLine = src; pel* dstLine = dst; const pel* bndryLine = bndry + bndryStep - 1;
+  for( int k = 0; k < srcSizeOrthDim; k++ )
+  {
+    const pel* before = bndryLine; const pel* behind = srcLine; pel* cur = dstLine;
+    for( int j = 0; j < srcSizeUpsmpDim; j++ )
+    {
+      const pel vBehind = *behind, vBefore = *before, diff = (pel) ( vBehind - vBefore );
+      pel scaled = (pel) ( vBefore * ( 1 << l2 ) + rnd );
+      for( int i = 0; i < upsmpFactor; i++ ) { scaled = (pel) ( scaled + diff ); *cur = (pel) ( scaled >> l2 ); cur += dstStep; }
+      before = behind; behind += srcStep;
+    }
+    srcLine += srcStride; dstLine += dstStride; bndryLine += bndryStep;
+  }
+}
+
+static void mip_predict( int w, int h, int modeIdx, int transpose, int bd, const pel* top /* [0] = corner */, const pel* left, pel* pred /* w x h, stride w */ )
+{
+  const int sizeId = ( w == 4 && h == 4 ) ? 0 : ( w == 4 || h == 4 || ( w == 8 && h == 8 ) ) ? 1 : 2;
+  const int bdry = sizeId == 0 ? 2 : 4, red = sizeId < 2 ? 4 : 8;
+  const int upH = w / red, upV = h / red;
+  pel refT[64], refL[64], rb[8], rbT[8];
+  for( int x = 0; x < w; x++ ) refT[x] = top[1 + x];
+  for( int y = 0; y < h; y++ ) refL[y] = left[1 + y];
+  /* Haar down-sampling of the boundaries */
+  for( int side = 0; side < 2; side++ )
+  {
+    const pel* src = side ? refL : refT; const int len = side ? h : w; pel* dst = rb + side * bdry;
+    if( bdry < len )
+    {
+      const int f = len / bdry, l2 = vvo_log2( f ), rnd = 1 << ( l2 - 1 );
+      for( int i = 0, si = 0; i < bdry; i++ ) { int sum = 0; for( int k = 0; k < f; k++ ) sum += src[si++]; dst[i] = (pel) ( ( sum + rnd ) >> l2 ); }
+    }
+    else memcpy( dst, src, sizeof( pel ) * bdry );
+  }
+  for( int i = 0; i < bdry; i++ ) { rbT[bdry + i] = rb[i]; rbT[i] = rb[bdry + i]; }
+  const int inSize = 2 * bdry;
+  const int inOff = rb[0], inOffT = rbT[0];
+  const int hasFirstCol = sizeId < 2;
+  rb[0]  = (pel) ( hasFirstCol ? ( ( 1 << ( bd - 1 ) ) - inOff  ) : 0 );
+  rbT[0] = (pel) ( hasFirstCol ? ( ( 1 << ( bd - 1 ) ) - inOffT ) : 0 );
+  for( int i = 1; i < inSize; i++ ) { rb[i] = (pel) ( rb[i] - inOff ); rbT[i] = (pel) ( rbT[i] - inOffT ); }
+  /* matrix-vector product on the reduced boundary */
+  const uint8_t* matrix = sizeId == 0 ? &vvc_mip_matrix_4x4[modeIdx][0][0] : sizeId == 1 ? &vvc_mip_matrix_8x8[modeIdx][0][0] : &vvc_mip_matrix_16x16[modeIdx][0][0];
+  const pel* in = transpose ? rbT : rb;
+  const int inputOffset = transpose ? inOffT : inOff;
+  int sum = 0;
+  for( int i = 0; i < inSize; i++ ) sum += in[i];
+  const int offset = ( 1 << 5 ) - 32 * sum;                 /* MIP_SHIFT_MATRIX 6, MIP_OFFSET_MATRIX 32 */
+  const int redSize = sizeId == 2;
+  pel redPred[64], tmpT[64];
+  pel* res = transpose ? tmpT : redPred;
+  const uint8_t* wt = matrix;
+  for( int p = 0; p < red * red; p++ )
+  {
+    int acc = redSize ? 0 : in[0] * wt[0];
+    for( int i = 1; i < inSize; i++ ) acc += in[i] * wt[i - redSize];
+    res[p] = (pel) vvo_clip_pel( ( ( acc + offset ) >> 6 ) + inputOffset, bd );
+    wt += inSize - redSize;
+  }
+  if( transpose ) for( int y = 0; y < red; y++ ) for( int x = 0; x < red; x++ ) redPred[y * red + x] = tmpT[x * red + y];
+  /* up-sampling: horizontally into every upV-th row, then vertically */
+  if( upH == 1 && upV == 1 ) { memcpy( pred, redPred, sizeof( pel ) * w * h ); return; }
+  const pel* verSrc = redPred; int verSrcStep = w;
+  if( upH > 1 )
+  {
+    pel* horDst = pred + ( upV - 1 ) * w;
+    verSrc = horDst; verSrcStep *= upV;
+    mip_upsample_1d( horDst, redPred, refL, red, red, 1, red, 1, verSrcStep, upV, upH );
+  }
+  if( upV > 1 ) mip_upsample_1d( pred, verSrc, refT, red, w, verSrcStep, 1, w, 1, 1, upV );
+}
+
 /* ciip_w_intra != 0: the block already holds the inter prediction; the intra prediction is blended into it with weight
  * ciip_w_intra / 4 before the residual is added (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:887-946) */
 int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, vvo_planes* reco,
@@ -196,7 +276,7 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
   const int bd = H->bit_depth, cs = comp ? 1 : 0, ch = comp ? 1 : 0;
   const int x0 = tu->x >> cs, y0 = tu->y >> cs, w = tu->w >> cs, h = tu->h >> cs;
   pel* plane = reco->p[comp]; const int stride = reco->stride[comp];
-  if( cu->isp_mode || ( ( cu->flags & VVR_CU_MIP ) && !comp ) ) { vvo_set_error( "ISP / MIP are not restated" ); return -1; }
+  if( cu->isp_mode ) { vvo_set_error( "ISP is not restated" ); return -1; }
   if( comp && cu->intra_dir[1] > MDLM_T_IDX ) { vvo_set_error( "bad chroma intra mode" ); return -1; }
   if( w < 4 || h < 4 ) { vvo_set_error( "intra blocks narrower than 4 are not restated" ); return -1; }
   const int mrl = comp ? 0 : cu->multi_ref_idx;
@@ -280,7 +360,7 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
 
   /* ---- reference smoothing decision (DecCu.cpp:337 + useFilteredIntraRefSamples :1301) */
   int useFilt = 0;
-  if( !comp && !mrl && !bdpcm && dirMode != 1 )
+  if( !comp && !mrl && !bdpcm && dirMode != 1 && !( cu->flags & VVR_CU_MIP ) )
   {
     if( dirMode == 0 ) useFilt = w * h > 32;
     else
@@ -306,7 +386,12 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
   /* ---- prediction (predIntraAng :474) */
   pel pred[64 * 64];
   int doPDPC = ( w >= 4 && h >= 4 ) && mrl == 0;
-  if( comp && dirMode >= LM_CHROMA_IDX )
+  if( !comp && ( cu->flags & VVR_CU_MIP ) )
+  {
+    mip_predict( w, h, dirMode, ( cu->flags & VVR_CU_MIP_TRANSP ) != 0, bd, top, left, pred );
+    doPDPC = 0;
+  }
+  else if( comp && dirMode >= LM_CHROMA_IDX )
   {
     cclm_predict( pic, cu, tu, tu_idx, comp, reco, order, top, left, pred );
     doPDPC = 0;

@@ -187,6 +187,14 @@ def test_cclm(built):
     _run_stream(1920, 1080, 3, 2, 184, TOOLS_A, intra=True, streams=3, p_cclm=0.4)
 
 
+def test_mip(built):
+    """matrix-based intra prediction: all three size classes, transposition, up-sampling in one or both directions, LFNST on top"""
+    _run_stream(256, 128, 5, 4, 191, TOOLS_A, intra=True, p_mip=0.5, p_intra=0.3, p_cclm=0.2)
+    _run_stream(416, 240, 5, 4, 192, TOOLS_A, intra=True, p_mip=0.6, p_intra=0.5, log2_ctu=6, p_coded=0.6, p_lfnst=0.5)
+    _run_stream(200, 136, 3, 2, 193, TOOLS_A, intra=True, p_mip=0.7, p_intra=0.6, log2_ctu=5, p_split_scale=1.5)
+    _run_stream(1920, 1080, 3, 2, 194, TOOLS_A, intra=True, streams=3, p_mip=0.4, p_cclm=0.2)
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

@@ -37,6 +37,8 @@ def _case(W, H, l2, idx, seed, **kw):
     (256, 128, 6, 0, 112, dict(p_jccr=0.7, p_coded_chroma=0.7)),
     (256, 128, 7, 0, 113, dict(p_cclm=0.5)),
     (200, 136, 5, 2, 114, dict(p_cclm=0.6, p_intra=0.5)),
+    (256, 128, 7, 0, 115, dict(p_mip=0.5, p_cclm=0.2, p_lfnst=0.4)),
+    (200, 136, 6, 2, 116, dict(p_mip=0.6, p_intra=0.5, p_split_scale=1.5)),
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)

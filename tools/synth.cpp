@@ -65,6 +65,7 @@ typedef struct vvs_params {
   float    p_sbtmvp;            // of inter CUs >= 8x8: sub-block temporal merge (per-8x8 motion)
   float    p_bcw;               // of bi-predicted CUs with at least 256 samples: unequal CU-level weights
   float    p_cclm;              // of intra CUs: chroma predicted from the reconstructed luma (CCLM, MDLM_L, MDLM_T)
+  float    p_mip;               // of intra CUs: matrix-based luma prediction
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -99,7 +100,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f; P->p_mip = 0.0f;
 }
 
 namespace {
@@ -190,8 +191,18 @@ struct Gen {
       if( ( y & ( ctu - 1 ) ) != 0 && cu.intra_dir[0] != 0 && rng.p( P.p_mrl ) ) cu.multi_ref_idx = (uint8_t) ( 1 + rng.u( 2 ) );
       // BDPCM (implies transform skip of the luma block)
       if( w <= 32 && h <= 32 && !cu.multi_ref_idx && rng.p( P.p_bdpcm ) ) { cu.bdpcm[0] = (uint8_t) ( 1 + rng.u( 2 ) ); cu.intra_dir[0] = cu.bdpcm[0] == 1 ? 18 : 50; cu.lfnst_intra_mode = cu.intra_dir[0]; }
+      // MIP: luma mode index into the matrix set of the block size class (16 / 8 / 6 modes), optional transposition; the chroma
+      // derived mode of a MIP CU is planar; no MRL / BDPCM; LFNST only for blocks of at least 16x16 (allowLfnstWithMip)
+      if( !cu.bdpcm[0] && !cu.multi_ref_idx && w <= 64 && h <= 64 && rng.p( P.p_mip ) )
+      {
+        const int sizeId = ( w == 4 && h == 4 ) ? 0 : ( w == 4 || h == 4 || ( w == 8 && h == 8 ) ) ? 1 : 2;
+        cu.flags |= VVR_CU_MIP | ( rng.p( 0.5 ) ? VVR_CU_MIP_TRANSP : 0 );
+        cu.intra_dir[0] = (uint8_t) rng.u( sizeId == 0 ? 16 : sizeId == 1 ? 8 : 6 );
+        if( cu.intra_dir[1] < 67 ) cu.intra_dir[1] = 0;
+        cu.lfnst_intra_mode = 0;
+      }
       // LFNST index (luma of single-tree CUs): needs DCT2 and a residual confined to the first 8/16 scan positions, see genLevels
-      if( ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
+      if( ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && ( !( cu.flags & VVR_CU_MIP ) || ( w >= 16 && h >= 16 ) ) && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
     }
     else
     {

@@ -271,7 +271,12 @@ static int validate( vvr_context* c, const vvr_picture* p )
     }
     else if( cu.pred_mode == VVR_PRED_INTRA )
     {
-      if( cu.isp_mode || ( cu.flags & VVR_CU_MIP ) ) { c->setError( "ISP / MIP are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.isp_mode ) { c->setError( "ISP is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.flags & VVR_CU_MIP )
+      {
+        const int sizeId = ( cu.w == 4 && cu.h == 4 ) ? 0 : ( cu.w == 4 || cu.h == 4 || ( cu.w == 8 && cu.h == 8 ) ) ? 1 : 2;
+        if( cu.intra_dir[0] >= ( sizeId == 0 ? 16 : sizeId == 1 ? 8 : 6 ) || cu.multi_ref_idx || cu.bdpcm[0] ) { c->setError( "MIP CU: mode index out of range for the block size, or combined with MRL / BDPCM" ); return VVR_ERR_PARAMETER; }
+      }
       if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] >= 67 && ( cu.intra_dir[1] > 69 || ( h.tool_flags & VVR_TOOL_CCLM_COLLOC ) ) )
       { c->setError( "chroma mode out of range, or CCLM with sps_chroma_vertical_collocated_flag (not implemented in this build)" ); return VVR_ERR_UNSUPPORTED; }
       if( cu.w > 64 || cu.h > 64 || cu.w < 8 || cu.h < 8 ) { c->setError( "intra CU size outside 8..64 is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
@@ -383,6 +388,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           // CIIP blend weight of the intra part (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:925-929): 1 + intra neighbours
           const int wIntra = isCiip ? 1 + ( cu.ciip_neigh_intra & 1 ) + ( ( cu.ciip_neigh_intra >> 1 ) & 1 ) : 0;
           it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
+          if( !comp && !isCiip && ( cu.flags & VVR_CU_MIP ) ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_MIP | ( ( cu.flags & VVR_CU_MIP_TRANSP ) ? 0x10 : 0 ) );
           it.nTL = (uint8_t) unitAvail( chn, x0 - 1, y0 - 1, (int32_t) t );
           if( unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
           if( unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }

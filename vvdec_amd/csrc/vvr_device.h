@@ -42,6 +42,7 @@ enum { TB_ADD = 0, TB_STORE = 1 };
 // that walk is host glue here (vvr_prepare), the kernel only consumes the counts.
 #define IT_F_RESI     1
 #define IT_F_BDPCM_H  2
+#define IT_F_MIP      8      /* matrix-based intra prediction: mode = matrix index, bit 4 = transposed */
 #define IT_F_BDPCM_V  4      /* bits 4..5: multi-reference-line index; bits 6..7: CIIP intra weight (0 = ordinary intra block) */
 struct IntraItem {        // 16 bytes, self-contained: the kernel never touches the CU/TU records on its serial path
   uint16_t x, y;          // block position in the component plane

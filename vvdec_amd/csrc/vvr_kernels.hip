@@ -30,6 +30,7 @@ __device__ int16_t d_dst7_4[16], d_dst7_8[64], d_dst7_16[256], d_dst7_32[1024];
 __device__ int8_t  d_lfnst8x8[4][2][48][16], d_lfnst4x4[4][2][16][16];
 __device__ uint8_t d_lfnst_lut[97], d_lfnst_scan8x8_xy[16][2], d_lfnst_scan4x4_xy[16][2];
 __device__ int32_t d_inv_quant_scales[2][6];
+__device__ uint8_t d_mip_matrix_4x4[16][16][4], d_mip_matrix_8x8[8][16][8], d_mip_matrix_16x16[6][64][7];
 __device__ int16_t d_geo_params[64][2], d_geo_weight_offset[64][4][4][2];
 __device__ int8_t  d_geo_weights[6][112 * 112], d_geo_angle2mask[32], d_geo_angle2mirror[32];
 __device__ int16_t d_luma_filter[16][8], d_luma_filter_4x4[16][8], d_luma_alt_hpel[8], d_chroma_filter[32][4];
@@ -48,6 +49,7 @@ int vvr_upload_tables()
   UPLOAD( lfnst8x8 ); UPLOAD( lfnst4x4 ); UPLOAD( lfnst_lut ); UPLOAD( lfnst_scan8x8_xy ); UPLOAD( lfnst_scan4x4_xy );
   UPLOAD( inv_quant_scales ); UPLOAD( luma_filter ); UPLOAD( luma_filter_4x4 ); UPLOAD( luma_alt_hpel ); UPLOAD( chroma_filter );
   UPLOAD( bcw_weights ); UPLOAD( db_tc_table ); UPLOAD( db_beta_table ); UPLOAD( alf_fixed_coeff ); UPLOAD( alf_class_to_filter );
+  UPLOAD( mip_matrix_4x4 ); UPLOAD( mip_matrix_8x8 ); UPLOAD( mip_matrix_16x16 );
   UPLOAD( geo_params ); UPLOAD( geo_weight_offset ); UPLOAD( geo_weights ); UPLOAD( geo_angle2mask ); UPLOAD( geo_angle2mirror );
   return 0;
 }
@@ -1864,7 +1866,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int16_t* __restrict__ rcur = sh.resi[k & 1];
       if( k + 1 < nb ) intra_fetch_resi( sh.items[k + 1], rs, rstride, tid, rnext );     // in flight while this block is predicted
       const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
-      const int mrl = ( it.flags >> 4 ) & 3;
+      const int mrl = ( it.flags & IT_F_MIP ) ? 0 : ( it.flags >> 4 ) & 3;
       const int wIntra = it.flags >> 6;               // CIIP: weight of the planar intra part, 0 = ordinary intra block
       const int bdpcm = ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
       const int dirMode = it.mode;
@@ -1935,6 +1937,86 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         if( tid == 255 ) sh.dcSum[( k + 1 ) & 1] = 0;
       }
       lds_barrier();
+      // ---- MIP (PredictorMIP, MatrixIntraPrediction.cpp:68-330): boundary down-sampling, matrix-vector product, up-sampling
+      if( !comp && ( it.flags & IT_F_MIP ) )
+      {
+        const bool transp = ( it.flags & 0x10 ) != 0;
+        const int sizeId = ( w == 4 && h == 4 ) ? 0 : ( w == 4 || h == 4 || ( w == 8 && h == 8 ) ) ? 1 : 2;
+        const int bdry = sizeId == 0 ? 2 : 4, red = sizeId < 2 ? 4 : 8, l2red = sizeId < 2 ? 2 : 3;
+        const int upH = w / red, upV = h / red, l2H = ilog2( upH ), l2V = ilog2( upV );
+        if( tid < 2 * bdry )
+        {
+          const bool isL = tid >= bdry; const int q = isL ? tid - bdry : tid;
+          const pel_t* src = isL ? sh.left : sh.top; const int len = isL ? h : w;
+          const int f = len / bdry;
+          int sum = 0;
+          for( int t2 = 0; t2 < f; t2++ ) sum += src[1 + q * f + t2];
+          sh.lmSel[tid] = f > 1 ? ( sum + ( f >> 1 ) ) >> ilog2( f ) : sum;
+        }
+        lds_barrier();
+        {
+          const int inSize = 2 * bdry;
+          int in[8];
+          for( int q = 0; q < 8; q++ ) in[q] = q < inSize ? ( transp ? ( q < bdry ? sh.lmSel[bdry + q] : sh.lmSel[q - bdry] ) : sh.lmSel[q] ) : 0;
+          const int inOff = in[0];
+          in[0] = sizeId < 2 ? ( 1 << ( bd - 1 ) ) - inOff : 0;
+          int sum = in[0];
+          for( int q = 1; q < 8; q++ ) if( q < inSize ) { in[q] = (int16_t) ( in[q] - inOff ); sum += in[q]; }
+          const int offset = 32 - 32 * sum;
+          const int redSize = sizeId == 2;
+          if( tid < red * red )
+          {
+            const uint8_t* wt = ( sizeId == 0 ? &d_mip_matrix_4x4[dirMode][0][0] : sizeId == 1 ? &d_mip_matrix_8x8[dirMode][0][0] : &d_mip_matrix_16x16[dirMode][0][0] ) + tid * ( inSize - redSize );
+            int acc = redSize ? 0 : in[0] * wt[0];
+            for( int q = 1; q < 8; q++ ) if( q < inSize ) acc += in[q] * wt[q - redSize];
+            const int v = clip_pel( ( ( acc + offset ) >> 6 ) + inOff, bd );
+            const int py = tid >> l2red, px = tid & ( red - 1 );
+            sh.ftop[transp ? px * red + py : tid] = (pel_t) v;
+          }
+        }
+        lds_barrier();
+        // horizontal up-sampling into every upV-th row of the block (predictionUpsampling1D :196)
+        for( int i = tid; i < red * w; i += 256 )
+        {
+          const int kk = i / w, x = i - kk * w, row = ( upV - 1 ) + kk * upV;
+          int v;
+          if( upH == 1 ) v = sh.ftop[kk * red + x];
+          else
+          {
+            const int j = x >> l2H, ii = ( x & ( upH - 1 ) ) + 1;
+            const int before = j == 0 ? sh.left[1 + row] : sh.ftop[kk * red + j - 1], behind = sh.ftop[kk * red + j];
+            v = (int16_t) ( before * upH + ( upH >> 1 ) + ii * (int16_t) ( behind - before ) ) >> l2H;
+          }
+          TILE( x0 + x, y0 + row ) = (pel_t) v;
+        }
+        lds_barrier();
+        if( upV > 1 )
+        {
+          int vals[IT_MAXR];
+#pragma unroll 1
+          for( int n = 0, i = tid; i < w * h; i += 256, n++ )
+          {
+            const int x = i & ( w - 1 ), y = i >> lw;
+            const int j = y >> l2V, ii = ( y & ( upV - 1 ) ) + 1;
+            const int before = j == 0 ? sh.top[1 + x] : TILE( x0 + x, y0 + ( upV - 1 ) + ( j - 1 ) * upV ), behind = TILE( x0 + x, y0 + ( upV - 1 ) + j * upV );
+            const int v = (int16_t) ( before * upV + ( upV >> 1 ) + ii * (int16_t) ( behind - before ) ) >> l2V;
+            // the rows that hold the horizontally up-sampled lines keep their values (ii == upV gives `behind` again), so writing in place is safe
+            TILE( x0 + x, y0 + y ) = (pel_t) v;
+          }
+          (void) vals;
+          lds_barrier();
+        }
+        if( hasResi )
+#pragma unroll 1
+          for( int i = tid; i < w * h; i += 256 )
+          {
+            const int x = i & ( w - 1 ), y = i >> lw;
+            TILE( x0 + x, y0 + y ) = (pel_t) clip_pel( TILE( x0 + x, y0 + y ) + rcur[i], bd );
+          }
+        if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
+        lds_barrier();
+        continue;
+      }
       // ---- CCLM / MDLM (xGetLumaRecPixels :1403, xGetLMParameters :1694, predIntraChromaLM :519; 4:2:0, non-collocated luma filter)
       if( comp && dirMode >= 67 )
       {
