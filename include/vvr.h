@@ -94,11 +94,16 @@ typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::recons
 } vvr_alf_params;
 
 typedef struct vvr_lmcs_params {    /* Reshape::constructReshaper (Reshape.cpp:318) stays on the host */
-  int16_t fwd_lut[1024 * 4];        /* forward map, 1 << bit_depth entries used  */
-  int16_t inv_lut[1024 * 4];        /* inverse map                               */
-  int16_t chroma_scale[16];         /* m_chromaAdjHelpLUT                         */
-  int16_t pivot[17];                /* m_reshapePivot (input pivots of inverse)   */
-  int16_t pad[7];
+  int16_t fwd_lut[1024 * 4];        /* forward map of every sample value (rspFwdCore, Buffer.cpp:321), 1 << bit_depth entries used */
+  int16_t inv_lut[1024 * 4];        /* inverse map (m_invLUT)                                                                      */
+  int16_t chroma_scale[16];         /* m_chromaAdjHelpLUT                                                                          */
+  int16_t pivot[17];                /* m_reshapePivot                                                                              */
+  int16_t min_bin, max_bin;         /* lmcs_min_bin_idx, LmcsMaxBinIdx (Reshape::getPWLIdxInv, :280)                               */
+  /* the syntax-level model the tables were built from (lmcs_data()): the back-end does not read it; it lets a checker that
+   * drives the reference decoder's own Reshape class rebuild the same tables */
+  int16_t model_delta_cw[16];       /* lmcsDeltaCW[i] (signed)  */
+  int16_t model_delta_crs;          /* lmcsDeltaCrs             */
+  int16_t pad[4];
 } vvr_lmcs_params;
 
 typedef struct vvr_pic_header {

@@ -195,6 +195,20 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     ph->setJointCbCrSignFlag( !!( H.tool_flags & VVR_TOOL_JCCR_SIGN ) );
     ph->setLmcsEnabledFlag( !!( H.tool_flags & VVR_TOOL_LMCS ) );
     ph->setLmcsChromaResidualScaleFlag( !!( H.tool_flags & VVR_TOOL_LMCS_CSCALE ) );
+    std::shared_ptr<APS> lmcsAps;
+    if( ( H.tool_flags & VVR_TOOL_LMCS ) && vp->lmcs )
+    {
+      // LMCS APS with the syntax-level model (HLSyntaxReader.cpp:1030-1056); Reshape::initSlice builds its tables from it
+      lmcsAps = std::make_shared<APS>();
+      lmcsAps->setAPSId( 0 ); lmcsAps->setAPSType( LMCS_APS );
+      SliceReshapeInfo& ri = lmcsAps->getReshaperAPSInfo();
+      ri.sliceReshaperEnableFlag = true; ri.sliceReshaperModelPresentFlag = true;
+      ri.enableChromaAdj = !!( H.tool_flags & VVR_TOOL_LMCS_CSCALE );
+      ri.reshaperModelMinBinIdx = vp->lmcs->min_bin; ri.reshaperModelMaxBinIdx = vp->lmcs->max_bin;
+      for( int i = 0; i < 16; i++ ) ri.reshaperModelBinCWDelta[i] = vp->lmcs->model_delta_cw[i];
+      ri.chrResScalingOffset = vp->lmcs->model_delta_crs;
+      ph->setLmcsAPS( lmcsAps );
+    }
     ph->setVirtualBoundariesPresentFlag( false );
 
     TR("ps done\n");
@@ -282,7 +296,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
         alfApss[a] = aps.get();
       }
     }
-    pic.finalInit( &cuCache, &tuCache, &sps, &pps, ph, useAlf ? alfApss : nullAps, nullptr, nullptr );
+    pic.finalInit( &cuCache, &tuCache, &sps, &pps, ph, useAlf ? alfApss : nullAps, lmcsAps.get(), nullptr );
     CodingStructure& cs = *pic.cs;
     TR("finalInit done\n");
 
@@ -511,6 +525,14 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     intraPred->init( cf, bd );
     interPred->init( &rdCost, cf, ctuSize, enableOpt );
     trQuant->init( &pic );
+    if( sps.getUseReshaper() )
+    {
+      TR("reshaper create\n");
+      reshaper->createDec( sps.getBitDepth() );
+      TR("reshaper initSlice aps=%p lmcsflag=%d vp->lmcs=%p\n", (const void*) ph->getLmcsAPS().get(), (int) ph->getLmcsEnabledFlag(), (const void*) vp->lmcs);
+      reshaper->initSlice( 0, *ph, nullptr );          // DecLibRecon.cpp:449-453
+      TR("reshaper done\n");
+    }
     decCu.init( intraPred.get(), interPred.get(), reshaper.get(), trQuant.get() );
 
     PelStorage fltBuf;
@@ -554,6 +576,9 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       if( !cs.getCtuData( a ).firstCU ) continue;
       decCu.TaskCriticalIntraKernel( cs, a, getCtuArea( cs, col, line, true ) );
     }
+    if( sps.getUseReshaper() )                                           // RSP: inverse luma mapping of every CTU (DecLibRecon.cpp:935)
+      for( int line = 0; line < (int) pcv.heightInCtus; line++ ) for( int col = 0; col < (int) pcv.widthInCtus; col++ )
+        if( cs.getCtuData( col, line ).firstCU ) reshaper->rspCtuBcw( cs, col, line );
     auto tC = now(); st[1] = ms( tB, tC );
     TR("intra done\n");
 

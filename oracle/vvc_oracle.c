@@ -127,6 +127,14 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
     if( cu->pred_mode == VVR_PRED_INTER )
     {
       if( vvo_inter_cu( pic, cu, refs, numSlots, &reco ) ) goto done;
+      if( ( H->tool_flags & VVR_TOOL_LMCS ) && pic->lmcs )
+      {   /* forward luma mapping of the inter prediction (DecCu.cpp:458-476, Reshape::rspBufFwd :413, rspFwdCore Buffer.cpp:321) */
+        for( int y = 0; y < cu->h; y++ ) for( int x = 0; x < cu->w; x++ )
+        {
+          pel* d = &reco.p[0][(size_t) ( cu->y + y ) * reco.stride[0] + cu->x + x];
+          *d = pic->lmcs->fwd_lut[*d];
+        }
+      }
       if( cu->flags & VVR_CU_CIIP )
       {
         /* DecCu::predAndReco( cu, doCiipIntra ) (DecCu.cpp:453-470): planar intra prediction of the whole CU from the reconstructed
@@ -181,6 +189,11 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
     else { vvo_set_error( "IBC is not restated" ); goto done; }
   }
 
+  if( ( H->tool_flags & VVR_TOOL_LMCS ) && pic->lmcs )
+  {   /* inverse luma mapping of the whole picture (Reshape::rspCtuBcw :376, applyLutCore Buffer.cpp:200) */
+    if( H->tool_flags & VVR_TOOL_LMCS_CSCALE ) { vvo_set_error( "LMCS chroma residual scaling is not restated" ); goto done; }
+    for( size_t k = 0; k < (size_t) reco.stride[0] * reco.h[0]; k++ ) reco.p[0][k] = pic->lmcs->inv_lut[reco.p[0][k] & 4095];
+  }
   if( !( flags & VVO_STOP_AFTER_RECO ) )
   {
     vvo_deblock( pic, &reco, 0 );

@@ -11,10 +11,10 @@ ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | 
 STAGES = [refdrv.STOP_AFTER_RECO, refdrv.STOP_AFTER_DBK, refdrv.STOP_AFTER_SAO, 0]
 
 
-def _case(W, H, l2, idx, seed, **kw):
+def _case(W, H, l2, idx, seed, tools=ALL, **kw):
     plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
     pl = plans[idx]
-    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=ALL, log2_ctu=l2, **kw)
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
     refs = {}
     for lst in pl.ref_slots:
         for (slot, poc) in lst:
@@ -51,6 +51,16 @@ def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
             assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
         if nd:
             assert np.array_equal(refdrv.oracle_dmvr(nd), r["dmvr"][:nd]), "DMVR delta MVs differ"
+
+
+@pytest.mark.parametrize("idx,seed", [(0, 201), (2, 202), (3, 203)])
+def test_oracle_equals_reference_lmcs(built, idx, seed):
+    d, refs = _case(256, 192, 7, idx, seed, tools=ALL | abi.TOOL_LMCS, p_intra=0.3, p_cclm=0.2, p_mip=0.2, p_ciip=0.1, p_affine=0.1, p_geo=0.1)
+    for fl in STAGES:
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
 
 
 def test_reference_simd_equals_scalar(built):

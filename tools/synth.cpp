@@ -78,6 +78,7 @@ typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
   vvr_sao_ctu* sao;
   vvr_alf_ctu* alf;
   vvr_alf_params* alf_params;
+  vvr_lmcs_params* lmcs;          // filled when VVR_TOOL_LMCS is in tool_flags
   // outputs
   uint32_t     num_cu, num_tu; uint64_t num_coef; uint32_t num_dmvr;
   vvr_pic_header hdr;
@@ -312,7 +313,7 @@ struct Gen {
       for( int c = 0; c < ( P.chroma_format ? 3 : 1 ); c++ )
       {
         const int bw = c ? tw >> 1 : tw, bh = c ? th >> 1 : th;
-        const bool force = c == 0 && intra && ( cu.bdpcm[0] || cu.lfnst_idx );     // these modes are only signalled with a coded luma block
+        const bool force = c == 0 && ( ( intra && ( cu.bdpcm[0] || cu.lfnst_idx ) ) || ( cu.flags & VVR_CU_CIIP ) );     // these modes are only signalled with a coded luma block (CIIP: merge, never skip => cu_coded_flag = 1)
         if( c && jccr )
         {
           if( ( jccr >> ( 2 - c ) ) & 1 ) tu.cbf |= 1 << c;
@@ -564,6 +565,38 @@ struct Gen {
     }
   }
 
+  // LMCS model (lmcs_data()) + the tables Reshape::constructReshaper (Reshape.cpp:318-374) derives from it: this is host glue
+  // (the parser side owns it), the back-end consumes the two LUTs
+  void genLmcs()
+  {
+    vvr_lmcs_params& L = *B.lmcs; memset( &L, 0, sizeof( L ) );
+    const int lutSize = 1 << bd, orgCW = lutSize / 16, l2cw = ilog2( orgCW );
+    L.min_bin = (int16_t) rng.u( 2 ); L.max_bin = (int16_t) ( 14 + rng.u( 2 ) );
+    int binCW[16] = { 0 };
+    for( int i = L.min_bin; i <= L.max_bin; i++ ) binCW[i] = orgCW + (int) rng.u( 2 * ( orgCW / 3 ) + 1 ) - orgCW / 3;     // well inside [OrgCW >> 3, OrgCW << 3) and >= 1 << (bd - 5)
+    for( ;; ) { int sum = 0; for( int i = 0; i < 16; i++ ) sum += binCW[i]; if( sum <= lutSize - 1 ) break; binCW[L.min_bin + rng.u( L.max_bin - L.min_bin + 1 )] -= 1; }
+    for( int i = 0; i < 16; i++ ) L.model_delta_cw[i] = (int16_t) ( ( i >= L.min_bin && i <= L.max_bin ) ? binCW[i] - orgCW : 0 );
+    L.model_delta_crs = (int16_t) ( (int) rng.u( 5 ) - 2 );
+    int pivot[17] = { 0 }, inPivot[17] = { 0 }, fwdCoef[16], invCoef[16];
+    for( int i = 0; i < 16; i++ )
+    {
+      pivot[i + 1] = pivot[i] + binCW[i]; inPivot[i + 1] = inPivot[i] + orgCW;
+      fwdCoef[i] = ( binCW[i] * ( 1 << 11 ) + ( 1 << ( l2cw - 1 ) ) ) >> l2cw;
+      if( binCW[i] == 0 ) { invCoef[i] = 0; L.chroma_scale[i] = 1 << 11; }
+      else { invCoef[i] = orgCW * ( 1 << 11 ) / binCW[i]; L.chroma_scale[i] = (int16_t) ( orgCW * ( 1 << 11 ) / ( binCW[i] + L.model_delta_crs ) ); }
+    }
+    for( int i = 0; i < 17; i++ ) L.pivot[i] = (int16_t) pivot[i];
+    auto idxInv = [&]( int v ) { int k = L.min_bin; for( ; k <= L.max_bin; k++ ) if( v < pivot[k + 1] ) break; return std::min( k, 15 ); };   // getPWLIdxInv (:280)
+    for( int v = 0; v < lutSize; v++ )
+    {
+      const int ii = idxInv( v );
+      const int inv = inPivot[ii] + ( ( invCoef[ii] * ( v - pivot[ii] ) + ( 1 << 10 ) ) >> 11 );
+      L.inv_lut[v] = (int16_t) std::min( lutSize - 1, std::max( 0, (int) (int16_t) inv ) );
+      const int fi = v >> l2cw;                                                                        // rspFwdCore (Buffer.cpp:321)
+      L.fwd_lut[v] = (int16_t) std::min( lutSize - 1, std::max( 0, pivot[fi] + ( ( (int16_t) fwdCoef[fi] * ( v - inPivot[fi] ) + ( 1 << 10 ) ) >> 11 ) ) );
+    }
+  }
+
   void genAlfParams()
   {
     vvr_alf_params& A = *B.alf_params; memset( &A, 0, sizeof( A ) );
@@ -602,6 +635,7 @@ struct Gen {
     for( int y = 0; y < H; y += ctu ) for( int x = 0; x < W; x += ctu, a++ ) { B.ctu_first_cu[a] = B.num_cu; split( x, y, ctu, ctu ); }
     B.ctu_first_cu[a] = B.num_cu;
     deriveLfp();
+    if( ( P.tool_flags & VVR_TOOL_LMCS ) && B.lmcs ) genLmcs();
     genAlfParams();
     genLoopFilterParams();
     return 0;

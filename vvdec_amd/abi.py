@@ -43,7 +43,8 @@ class AlfParams(C.Structure):
 
 
 class LmcsParams(C.Structure):
-    _fields_ = [("fwd_lut", i16 * 4096), ("inv_lut", i16 * 4096), ("chroma_scale", i16 * 16), ("pivot", i16 * 17), ("pad", i16 * 7)]
+    _fields_ = [("fwd_lut", i16 * 4096), ("inv_lut", i16 * 4096), ("chroma_scale", i16 * 16), ("pivot", i16 * 17), ("min_bin", i16), ("max_bin", i16),
+                ("model_delta_cw", i16 * 16), ("model_delta_crs", i16), ("pad", i16 * 4)]
 
 
 class PicHeader(C.Structure):

@@ -25,8 +25,8 @@ struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 
 struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
 
-enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_ITRANS, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_NUM };
-const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_itrans", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy" };
+enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_NUM };
+const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy" };
 
 struct DevBuf {
   void* p = nullptr; size_t n = 0;
@@ -223,7 +223,8 @@ static int validate( vvr_context* c, const vvr_picture* p )
   { c->setError( "picture geometry differs from the context configuration" ); return VVR_ERR_PARAMETER; }
   if( ( h.width & 7 ) || ( h.height & 7 ) ) { c->setError( "picture size must be a multiple of 8 (minimum CU size)" ); return VVR_ERR_PARAMETER; }
   if( h.out_slot < 0 || h.out_slot >= c->cfg.num_slots ) { c->setError( "out_slot out of range" ); return VVR_ERR_PARAMETER; }
-  if( h.tool_flags & ( VVR_TOOL_LMCS | VVR_TOOL_LMCS_CSCALE ) ) { c->setError( "LMCS is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+  if( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) { c->setError( "LMCS chroma residual scaling is not implemented in this build (luma mapping is)" ); return VVR_ERR_UNSUPPORTED; }
+  if( ( h.tool_flags & VVR_TOOL_LMCS ) && !p->lmcs ) { c->setError( "LMCS enabled without tables" ); return VVR_ERR_PARAMETER; }
   if( !p->cu || !p->tu || !p->coef || !p->lfp[0] || !p->lfp[1] ) { c->setError( "missing arrays" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & VVR_TOOL_ALF ) && ( !p->alf || !p->alf_params ) ) { c->setError( "ALF enabled without parameters" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) && !p->sao ) { c->setError( "SAO enabled without parameters" ); return VVR_ERR_PARAMETER; }
@@ -566,6 +567,21 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   const int iSao = p->sao ? add( p->sao, sizeof( vvr_sao_ctu ) * numCtu ) : -1;
   const int iAlf = p->alf ? add( p->alf, sizeof( vvr_alf_ctu ) * numCtu ) : -1;
   const int iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
+  const bool lmcs = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
+  std::vector<uint8_t> interAtV;
+  if( lmcs )
+  {
+    interAtV.assign( (size_t) w4 * h4 + 8, 0 );
+    for( uint32_t i = 0; i < p->num_cu; i++ )
+    {
+      const vvr_cu& cu = p->cu[i];
+      if( cu.pred_mode != VVR_PRED_INTER ) continue;
+      for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) interAtV[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = 1;
+    }
+  }
+  const int iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
+  const int iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
+  if( lmcs ) { bytes[K_LMCS] = ( samples / ( ncomp == 3 ? 1.5 : 1.0 ) ) * 4 * 2; }     // forward pass over the inter luma (upper bound) + inverse pass over all luma
   const int iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
   const int iMcD = add( mcDmvr.data(), sizeof( McItem ) * mcDmvr.size() );
   const int iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
@@ -596,6 +612,8 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   d.sao = iSao >= 0 ? (const vvr_sao_ctu*) ( base + parts[iSao].off ) : nullptr;
   d.alf = iAlf >= 0 ? (const vvr_alf_ctu*) ( base + parts[iAlf].off ) : nullptr;
   d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
+  d.lmcs = iLmcs >= 0 ? (const vvr_lmcs_params*) ( base + parts[iLmcs].off ) : nullptr;
+  d.interAt = iInterAt >= 0 ? (const uint8_t*) ( base + parts[iInterAt].off ) : nullptr;
   q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();
   q->dmvrItems = (McItem*) ( base + parts[iMcD].off ); q->numDmvrItems = (int) mcDmvr.size();
   q->affItems = (McItem*) ( base + parts[iMcA].off ); q->numAffItems = (int) mcAff.size();
@@ -671,11 +689,16 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
   if( q->numMc ) timed( K_MC, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc ); } );
   if( q->numDmvrItems ) timed( K_MC_DMVR, [&]{ launch_mc_dmvr( s, q->pic, refs, A, q->dmvrItems, q->numDmvrItems, q->dmvrOut ); } );
   if( q->numAffItems ) timed( K_MC_AFFINE, [&]{ launch_mc_affine( s, q->pic, refs, A, q->affItems, q->numAffItems ); } );
+  const bool lmcsOn = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
+  // LMCS: the inter prediction is forward-mapped before any residual is added (DecCu.cpp:458-476); I pictures have no inter prediction
+  if( lmcsOn && h.slice_type != 2 && ( q->numMc + q->numDmvrItems + q->numAffItems ) ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 0 ); } );
   job.prepared = q;
   if( q->numTb[0] + q->numTb[1] + q->numTb[2] + q->numTbStore[0] + q->numTbStore[1] + q->numTbStore[2] )
     timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) { launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); launch_itrans( s, q->pic, A, R, q->tbStore[k], q->numTbStore[k], 16 << k ); } } );
   // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)
   if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->ctuStart, q->active, q->numActive, c->syncBuf[lane] ); } );
+  // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
+  if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
   // debugging aid (like the reference's per-stage CRC traces, LoopFilter.cpp:399-406): VVR_STOP_AFTER=reco|dbk|sao
   const char* stopEnv = getenv( "VVR_STOP_AFTER" );

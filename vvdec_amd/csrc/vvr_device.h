@@ -64,6 +64,8 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
   const vvr_sao_ctu* sao;
   const vvr_alf_ctu* alf;
   const vvr_alf_params* alf_params;
+  const vvr_lmcs_params* lmcs;       // LMCS tables (NULL when off)
+  const uint8_t*     interAt;        // per 4x4 luma unit: 1 = covered by an inter CU (LMCS forward mapping of the prediction)
   int                w4, h4, ctus_x, ctus_y;
 };
 
@@ -75,6 +77,7 @@ void launch_itrans ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir );
 void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 void launch_alf    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
+void launch_lmcs   ( hipStream_t s, const PicDev& pic, DevPlanes reco, int inverse );
 void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst );
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );

@@ -1657,6 +1657,45 @@ void launch_alf( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst 
 }
 
 // plain plane copy (used when a stage is disabled for a picture)
+// =====================================================================================================================
+// k_lmcs — luma mapping with chroma scaling, the luma part: forward mapping of the inter prediction (Reshape::rspBufFwd,
+// Reshape.cpp:413, rspFwdCore Buffer.cpp:321; DecCu.cpp:458-476) before the residual is added, and the inverse mapping of the
+// whole reconstructed picture before the in-loop filters (Reshape::rspCtuBcw :376, applyLutCore Buffer.cpp:200).  The piecewise
+// linear maps arrive as look-up tables (vvr_lmcs_params); one workgroup handles 2048 samples of a row, the table sits in LDS.
+// =====================================================================================================================
+__global__ __launch_bounds__( 256 ) void k_lmcs( PicDev pic, DevPlanes reco, int inverse )
+{
+  __shared__ int16_t lut[4096];
+  const int n = 1 << pic.hdr.bit_depth;
+  const int16_t* __restrict__ src = inverse ? pic.lmcs->inv_lut : pic.lmcs->fwd_lut;
+  for( int i = threadIdx.x; i < n; i += 256 ) lut[i] = src[i];
+  __syncthreads();
+  const int y = blockIdx.y, x = ( blockIdx.x * 256 + threadIdx.x ) * 8;
+  if( x >= reco.w[0] ) return;
+  pel_t* __restrict__ row = reco.p[0] + (size_t) y * reco.stride[0];
+  bool lo = true, hi = true;
+  if( !inverse )
+  {
+    const uint8_t* m = pic.interAt + (size_t) ( y >> 2 ) * pic.w4 + ( x >> 2 );
+    lo = m[0] != 0; hi = ( x + 4 < reco.w[0] ) && m[1] != 0;
+    if( !lo && !hi ) return;
+  }
+  uint4 v = *reinterpret_cast<const uint4*>( row + x );       // rows are padded to a multiple of 64 samples
+  uint32_t* w = reinterpret_cast<uint32_t*>( &v );
+  for( int k = 0; k < 4; k++ )
+  {
+    if( !( k < 2 ? lo : hi ) ) continue;
+    const uint32_t a = (uint16_t) lut[( w[k] & 0xffff ) & ( n - 1 )], b = (uint16_t) lut[( w[k] >> 16 ) & ( n - 1 )];
+    w[k] = a | ( b << 16 );
+  }
+  *reinterpret_cast<uint4*>( row + x ) = v;
+}
+
+void launch_lmcs( hipStream_t s, const PicDev& pic, DevPlanes reco, int inverse )
+{
+  hipLaunchKernelGGL( k_lmcs, dim3( ( reco.w[0] + 2047 ) / 2048, reco.h[0] ), dim3( 256 ), 0, s, pic, reco, inverse );
+}
+
 __global__ void k_copy( DevPlanes src, DevPlanes dst )
 {
   const int c = blockIdx.z, x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;

@@ -38,7 +38,7 @@ class Params(C.Structure):
 class Buffers(C.Structure):
     _fields_ = [("cu", C.c_void_p), ("max_cu", C.c_uint32), ("tu", C.c_void_p), ("max_tu", C.c_uint32),
                 ("coef", C.c_void_p), ("max_coef", C.c_uint64), ("ctu_first_cu", C.c_void_p),
-                ("motion", C.c_void_p), ("lfp", C.c_void_p * 2), ("sao", C.c_void_p), ("alf", C.c_void_p), ("alf_params", C.c_void_p),
+                ("motion", C.c_void_p), ("lfp", C.c_void_p * 2), ("sao", C.c_void_p), ("alf", C.c_void_p), ("alf_params", C.c_void_p), ("lmcs", C.c_void_p),
                 ("num_cu", C.c_uint32), ("num_tu", C.c_uint32), ("num_coef", C.c_uint64), ("num_dmvr", C.c_uint32),
                 ("hdr", abi.PicHeader)]
 
@@ -91,6 +91,9 @@ def generate(p):
     b.lfp[0], b.lfp[1] = d.lfp[0].ctypes.data, d.lfp[1].ctypes.data
     b.sao, b.alf = d.sao.ctypes.data, d.alf.ctypes.data
     b.alf_params = C.addressof(d.alf_params)
+    if p.tool_flags & abi.TOOL_LMCS:
+        d.lmcs = abi.LmcsParams()
+        b.lmcs = C.addressof(d.lmcs)
     rc = L.vvs_generate(C.byref(p), C.byref(b))
     if rc != 0:
         raise RuntimeError("vvs_generate failed (%d)" % rc)
