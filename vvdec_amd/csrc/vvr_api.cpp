@@ -39,6 +39,7 @@ struct vvr_prepared {        // a picture description resident in HBM together w
   PicDev   pic;
   DevBuf   blob;             // one allocation holding every array
   McItem*  mcItems = nullptr; int numMc = 0;
+  McItem*  bdofItems = nullptr; int numBdofItems = 0;      // tiles of CUs in BDOF mode (their own launch: larger LDS footprint)
   McItem*  dmvrItems = nullptr; int numDmvrItems = 0;      // sub-blocks that run decoder-side MV refinement
   McItem*  affItems = nullptr; int numAffItems = 0;        // tiles of affine CUs
   int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
@@ -310,7 +311,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   const int ctusX = ( h.width + ctu - 1 ) / ctu, ctusY = ( h.height + ctu - 1 ) / ctu, numCtu = ctusX * ctusY;
 
   // ---- host glue: work lists (what DecCu::TaskTrafoCtu / TaskInterCtu iterate over, DecCu.cpp:106-134)
-  std::vector<McItem> mc, mcDmvr, mcAff;
+  std::vector<McItem> mc, mcBdof, mcDmvr, mcAff;
   uint32_t numDmvr = 0;
   std::vector<TbItem> tb[3], tbS[3];
   std::vector<IntraItem> intra[3];
@@ -470,7 +471,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         McItem it; it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y ); it.flags = sbt ? MC_ITEM_SUBBLOCK : 0; it.cu = i;
         const bool dm = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
         const bool af = cu.mc_mode == VVR_MC_AFFINE;
-        ( dm ? mcDmvr : af ? mcAff : mc ).push_back( it );
+        ( dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc ).push_back( it );
         const double smp = (double) it.w * it.h * ( ncomp == 3 ? 1.5 : 1.0 );
         const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
         bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += smp * 2 * nla + smp * 2 + sizeof( McItem ) + ( dm ? 8 : 0 ) + ( af ? it.w * it.h / 16.0 * sizeof( vvr_motion ) : 0 );
@@ -583,6 +584,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   const int iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
   if( lmcs ) { bytes[K_LMCS] = ( samples / ( ncomp == 3 ? 1.5 : 1.0 ) ) * 4 * 2; }     // forward pass over the inter luma (upper bound) + inverse pass over all luma
   const int iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
+  const int iMcB = add( mcBdof.data(), sizeof( McItem ) * mcBdof.size() );
   const int iMcD = add( mcDmvr.data(), sizeof( McItem ) * mcDmvr.size() );
   const int iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
   const int iDmvrOut = add( nullptr, sizeof( int32_t ) * 2 * (size_t) numDmvr );
@@ -615,6 +617,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   d.lmcs = iLmcs >= 0 ? (const vvr_lmcs_params*) ( base + parts[iLmcs].off ) : nullptr;
   d.interAt = iInterAt >= 0 ? (const uint8_t*) ( base + parts[iInterAt].off ) : nullptr;
   q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();
+  q->bdofItems = (McItem*) ( base + parts[iMcB].off ); q->numBdofItems = (int) mcBdof.size();
   q->dmvrItems = (McItem*) ( base + parts[iMcD].off ); q->numDmvrItems = (int) mcDmvr.size();
   q->affItems = (McItem*) ( base + parts[iMcA].off ); q->numAffItems = (int) mcAff.size();
   q->dmvrOut = (int32_t*) ( base + parts[iDmvrOut].off ); q->numDmvr = numDmvr;
@@ -686,12 +689,12 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
     else fn();
   };
   // INTER stage: prediction of every inter CU, then residual add (DecLibRecon.cpp:831-874)
-  if( q->numMc ) timed( K_MC, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc ); } );
+  if( q->numMc + q->numBdofItems ) timed( K_MC, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc, 0 ); launch_mc( s, q->pic, refs, A, q->bdofItems, q->numBdofItems, 1 ); } );
   if( q->numDmvrItems ) timed( K_MC_DMVR, [&]{ launch_mc_dmvr( s, q->pic, refs, A, q->dmvrItems, q->numDmvrItems, q->dmvrOut ); } );
   if( q->numAffItems ) timed( K_MC_AFFINE, [&]{ launch_mc_affine( s, q->pic, refs, A, q->affItems, q->numAffItems ); } );
   const bool lmcsOn = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
   // LMCS: the inter prediction is forward-mapped before any residual is added (DecCu.cpp:458-476); I pictures have no inter prediction
-  if( lmcsOn && h.slice_type != 2 && ( q->numMc + q->numDmvrItems + q->numAffItems ) ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 0 ); } );
+  if( lmcsOn && h.slice_type != 2 && ( q->numMc + q->numBdofItems + q->numDmvrItems + q->numAffItems ) ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 0 ); } );
   job.prepared = q;
   if( q->numTb[0] + q->numTb[1] + q->numTb[2] + q->numTbStore[0] + q->numTbStore[1] + q->numTbStore[2] )
     timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) { launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); launch_itrans( s, q->pic, A, R, q->tbStore[k], q->numTbStore[k], 16 << k ); } } );

@@ -72,7 +72,7 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
 struct RefSet { const pel_t* p[2 * VVR_MAX_REFS][3]; };   // reference planes indexed [list * 16 + refIdx][comp]; geometry = the current picture's
 
 // kernel launchers (vvr_kernels.hip) ----------------------------------------------------------------------------------
-void launch_mc     ( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
+void launch_mc     ( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int bdof );
 void launch_itrans ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const TbItem* items, int numItems, int sizeClass );
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir );
 void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );

@@ -7,6 +7,7 @@
 //
 // Each kernel cites the reference function whose arithmetic it reproduces (paths relative to source/Lib of VVdeC);
 // bit-exactness is checked against the CPU restatement in oracle/ and the reference-driven golden fixtures.
+#include <type_traits>
 #include "vvr_device.h"
 
 namespace tbl {
@@ -115,10 +116,21 @@ __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg
   if( col < g.ww )
   {
     const int sx = clip3( 0, pw - 1, g.x0 + clip3( 0, g.cw - 1, col - g.padOff ) );
-    for( int yy = row0; yy < g.wh; yy += NT / 32 )
+    const pel_t* __restrict__ rc = ref + sx;
+    // four rows per step, all four loads issued before the first LDS store: one memory round trip per four rows instead of one per
+    // row (the tail repeats the last row: same value to the same place)
+    for( int yb = row0; yb < g.wh; yb += 4 * ( NT / 32 ) )
     {
-      const int sy = clip3( 0, ph - 1, g.y0 + clip3( 0, g.chh - 1, yy - g.padOff ) );
-      win[yy * wst + col] = ref[(size_t) sy * stride + sx];
+      int yy[4]; pel_t v[4];
+#pragma unroll
+      for( int u = 0; u < 4; u++ )
+      {
+        yy[u] = min( yb + u * ( NT / 32 ), g.wh - 1 - ( ( g.wh - 1 - row0 ) % ( NT / 32 ) ) );      // last row of this lane's parity
+        const int sy = clip3( 0, ph - 1, g.y0 + clip3( 0, g.chh - 1, yy[u] - g.padOff ) );
+        v[u] = rc[(size_t) sy * stride];
+      }
+#pragma unroll
+      for( int u = 0; u < 4; u++ ) win[yy[u] * wst + col] = v[u];
     }
   }
 }
@@ -235,13 +247,13 @@ struct BdofShared {
 template<int NT>
 __device__ __forceinline__ void mc_bdof_luma( BdofShared& bs, const pel_t* win0, const pel_t* tmp0, const pel_t* win1, const pel_t* tmp1, int wst, int tst,
                                               const McSeg* seg /* [2] for luma */, int segStride, const int16_t* cH0, const int16_t* cV0, const int16_t* cH1, const int16_t* cV1,
-                                              int bd, const DevPlanes& reco, int x0, int y0, int w, int h, int tid )
+                                              int bd, const DevPlanes& reco, int x0, int y0, int w, int h, int tid, bool interiorDone = false )
 {
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   const int lw = w == 16 ? 4 : 3;
   const McSeg& g0 = seg[0]; const McSeg& g1 = seg[segStride];
-  // (1) 14-bit predictions of both lists + the border of nearest integer samples (xPredInterBlk :863-890)
-  for( int i = tid; i < w * h; i += NT )
+  // (1) 14-bit predictions of both lists (unless the caller has put them into bs.blk already) + the border of nearest integer samples (xPredInterBlk :863-890)
+  if( !interiorDone ) for( int i = tid; i < w * h; i += NT )
   {
     const int px = i & ( w - 1 ), py = i >> lw;
     bs.blk[0][( 1 + py ) * BDOF_S + 1 + px] = (pel_t) mc_final( win0, wst, tmp0, tst, g0, cH0, cV0, 0, true, bd, px, py );
@@ -326,17 +338,57 @@ __device__ __forceinline__ void mc_bdof_luma( BdofShared& bs, const pel_t* win0,
 
 // NT threads per tile.  With NT = 64 a tile is one wavefront: 32 tiles resident per CU, barriers are free, and the
 // single exposure to global-memory latency (phase A) is hidden by the other resident tiles.
-template<int NT>
+// ---------------------------------------------------------------------------------------------------------------------
+// Register-blocked separable interpolation used by k_mc.  Every segment goes through the same two stages — horizontal filter to
+// 14-bit intermediates, vertical filter to the result — with the identity filter (64 at the centre tap) where the MV has no
+// fractional part in that direction.  That is bit-exact with the reference's four code paths (copy / horizontal only /
+// vertical only / separable, InterpolationFilter.cpp:556-651): the intermediate rounding of a pass with the identity filter
+// is exact (64 * s = s << 6), see DESIGN.md §5.
+// One work item = 8 neighbouring outputs of one row (stage 1) or one column (stage 2): 16 input samples are read with two
+// 16-byte LDS loads and each output costs four v_dot2_i32_i16 (two for the 4-tap chroma filter).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mc_dot2( uint32_t a, uint32_t b, int c )
+{
+  typedef short s2v __attribute__( ( ext_vector_type( 2 ) ) );
+  return __builtin_amdgcn_sdot2( __builtin_bit_cast( s2v, a ), __builtin_bit_cast( s2v, b ), c, false );
+}
+
+// 8 outputs out[j] = sum_t s[j + t] * c[t], s = the 16 samples in D (two per dword), NTAPS = 8 or 4
+template<int NTAPS>
+__device__ __forceinline__ void mc_fir8( const uint4 lo, const uint4 hi, const uint32_t* __restrict__ C /* NTAPS / 2 packed pairs */, int ( &out )[8] )
+{
+  const uint32_t D[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+  uint32_t S[7];
+#pragma unroll
+  for( int i = 0; i < 7; i++ ) S[i] = __builtin_amdgcn_alignbit( D[i + 1], D[i], 16 );
+#pragma unroll
+  for( int m = 0; m < 4; m++ )
+  {
+    int e = 0, o = 0;
+#pragma unroll
+    for( int t = 0; t < NTAPS / 2; t++ ) { e = mc_dot2( D[m + t], C[t], e ); o = mc_dot2( S[m + t], C[t], o ); }
+    out[2 * m] = e; out[2 * m + 1] = o;
+  }
+}
+
+#define MC2_WST_L 24        // luma window: 23 x 23 samples, row stride 24 (48 bytes: every row and every 8-sample group is 16-byte aligned)
+#define MC2_WST_C 16        // chroma window: 11 x 11 samples, row stride 16
+#define MC2_TST_L 24        // transposed intermediates: per column 23 values (+1 pad)
+#define MC2_TST_C 16
+
+// BDOF = true: the launch holds only tiles of CUs in BDOF mode (they need 3.5 KB more LDS for the gradient buffers; keeping them out
+// of the plain launch raises the number of resident tiles per CU there).
+template<int NT, bool BDOF>
 __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
 {
-  __shared__ pel_t winL[2][MC_WIN_L];
-  __shared__ pel_t winC[2][2][MC_WIN_C];
-  __shared__ pel_t tmpL[2][MC_TMP_L];
-  __shared__ pel_t tmpC[2][2][MC_TMP_C];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) pel_t winL[2][23 * MC2_WST_L];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) pel_t winC[2][2][11 * MC2_WST_C];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) pel_t tmpL[2][16 * MC2_TST_L];       // [column][row]
+  __shared__ __attribute__( ( aligned( 16 ) ) ) pel_t tmpC[2][2][8 * MC2_TST_C];
   __shared__ McSeg seg[2][3];
   __shared__ const pel_t* refp[2][3];
-  __shared__ int16_t coefH[2][3][8], coefV[2][3][8];
-  __shared__ BdofShared bs;
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t coefH[2][3][8], coefV[2][3][8];
+  __shared__ typename std::conditional<BDOF, BdofShared, int>::type bs;
   const int item = mc_item_index();
   if( item >= numItems ) return;
   const McItem it = items[item];
@@ -357,12 +409,13 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   }
   const int clipX = sub ? it.x : cu.x, clipY = sub ? it.y : cu.y;
   const bool biPred = mRef[0] >= 0 && mRef[1] >= 0;
-  const bool bdof = cu.mc_mode == VVR_MC_BDOF;          // xSubPuBio (InterPrediction.cpp:551): the tile IS the <= 16x16 BDOF sub-block
   const bool geo = cu.mc_mode == VVR_MC_GEO;            // motionCompensationGeo (:1461): two uni-predictions kept at 14 bit, blended with the GPM masks
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
   const int l0 = uni ? ( ( biPred || mRef[0] >= 0 ) ? 0 : 1 ) : 0;
   const int nl = uni ? 1 : 2;
-  // ---- segment geometry + filter taps: computed once by six lanes, shared through LDS
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  // ---- segment geometry + filter taps: computed once by six lanes, shared through LDS.  The window always spans the full filter
+  // support (the block's integer origin sits at (half, half)), whatever the fractional part of the MV
   if( tid < 6 )
   {
     const int k = tid / 3, c = tid - 3 * k;
@@ -376,34 +429,129 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
       g.w = it.w >> cs; g.h = it.h >> cs;
       g.xFrac = mvx & ( ( 1 << shf ) - 1 ); g.yFrac = mvy & ( ( 1 << shf ) - 1 );
-      const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
-      const bool full = bdof && c == 0;                 // BDOF also reads the integer samples around the block (border fill, :863-890)
-      g.ox = ( doH || full ) ? half : 0; g.oy = ( doV || full ) ? half : 0;
-      g.ww = g.w + ( ( doH || full ) ? ntaps - 1 : 0 ); g.wh = g.h + ( ( doV || full ) ? ntaps - 1 : 0 );
-      g.x0 = ( it.x >> cs ) + ( mvx >> shf ) - g.ox;
-      g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - g.oy;
+      g.ox = half; g.oy = half;
+      g.ww = g.w + ntaps - 1; g.wh = g.h + ntaps - 1;
+      g.x0 = ( it.x >> cs ) + ( mvx >> shf ) - half;
+      g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - half;
       g.padOff = 0; g.cw = g.ww; g.chh = g.wh;
       seg[k][c] = g;
       refp[k][c] = refs.p[l * VVR_MAX_REFS + refIdx][c];
-      mc_taps( g, c, cu.imv == 3, coefH[k][c], coefV[k][c] );
+      mc_taps( g, c, cu.imv == 3, coefH[k][c], coefV[k][c] );      // frac 0 selects the identity filter { .., 64, .. }
+      if( !c ) { for( int t = 0; t < 0; t++ ) {} } else { for( int t = 4; t < 8; t++ ) { coefH[k][c][t] = 0; coefV[k][c][t] = 0; } }
     }
   }
   __syncthreads();
   // ---- phase A: all reference windows of the tile into LDS, one exposure to HBM/L2 latency
   for( int k = 0; k < nl; k++ ) for( int c = 0; c < ncomp; c++ )
-    mc_load_window<NT>( c ? winC[k][c - 1] : winL[k], c ? 12 : 24, seg[k][c], refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
+    mc_load_window<NT>( c ? winC[k][c - 1] : winL[k], c ? MC2_WST_C : MC2_WST_L, seg[k][c], refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
   __syncthreads();
-  // ---- phase B: horizontal pass of the 2-D segments
-  for( int k = 0; k < nl; k++ ) for( int c = 0; c < ncomp; c++ )
-    mc_hpass<NT>( c ? winC[k][c - 1] : winL[k], c ? 12 : 24, c ? tmpC[k][c - 1] : tmpL[k], c ? 8 : 16, seg[k][c], coefH[k][c], c, bd, tid );
-  __syncthreads();
-  // ---- phase C: final samples
-  if( bdof ) mc_bdof_luma<NT>( bs, winL[0], tmpL[0], winL[1], tmpL[1], 24, 16, &seg[0][0], 3, coefH[0][0], coefV[0][0], coefH[1][0], coefV[1][0], bd, reco, it.x, it.y, it.w, it.h, tid );
-  for( int c = bdof ? 1 : 0; c < ncomp; c++ )
+  // ---- stage 1: horizontal filter of every window row, 8 outputs per work item, written transposed ([column][row])
   {
-    const int cs = c ? 1 : 0;
-    mc_output<NT>( c ? winC[0][c - 1] : winL[0], c ? tmpC[0][c - 1] : tmpL[0], c ? winC[1][c - 1] : winL[1], c ? tmpC[1][c - 1] : tmpL[1], c ? 12 : 24, c ? 8 : 16,
-                   &seg[0][c], &seg[1][c], coefH[0][c], coefV[0][c], coefH[1][c], coefV[1][c], c, uni, cu.bcw_idx, bd, reco, it.x >> cs, it.y >> cs, it.w >> cs, it.h >> cs, tid, geo ? &cu : nullptr );
+    const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+    const int wL = it.w, hL = it.h, wC = it.w >> 1, hC = it.h >> 1;
+    const int rowsL = hL + 7, grpL = ( wL + 7 ) >> 3, rowsC = hC + 3;
+    const int perList = rowsL * grpL + ( ncomp == 3 ? 2 * rowsC : 0 );
+    for( int idx = tid; idx < nl * perList; idx += NT )
+    {
+      const int k = idx >= perList, r0 = idx - k * perList;
+      int out[8];
+      if( r0 < rowsL * grpL )
+      {
+        const int r = r0 / grpL, g8 = r0 - r * grpL;
+        const pel_t* src = &winL[k][r * MC2_WST_L + 8 * g8];
+        mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), reinterpret_cast<const uint32_t*>( coefH[k][0] ), out );
+        pel_t* dst = &tmpL[k][( 8 * g8 ) * MC2_TST_L + r];
+#pragma unroll
+        for( int j = 0; j < 8; j++ ) if( 8 * g8 + j < wL ) dst[j * MC2_TST_L] = (pel_t) ( ( out[j] + offset1 ) >> shift1 );
+      }
+      else
+      {
+        const int q = r0 - rowsL * grpL, cc = q >= rowsC, r = q - cc * rowsC;
+        const pel_t* src = &winC[k][cc][r * MC2_WST_C];
+        mc_fir8<4>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), reinterpret_cast<const uint32_t*>( coefH[k][1 + cc] ), out );
+        pel_t* dst = &tmpC[k][cc][r];
+#pragma unroll
+        for( int j = 0; j < 8; j++ ) if( j < wC ) dst[j * MC2_TST_C] = (pel_t) ( ( out[j] + offset1 ) >> shift1 );
+      }
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: vertical filter, 8 rows of one column per work item, both lists in the same lane, then the combination
+  //      (AreaBuf::addAvg / addWeightedAvg, Buffer.cpp:441,372; GPM weights, InterpolationFilter.cpp:1217) or the BDOF input
+  {
+    const int wL = it.w, hL = it.h, wC = it.w >> 1, hC = it.h >> 1;
+    const int grpL = ( hL + 7 ) >> 3;
+    const int itemsL = wL * grpL, itemsC = ncomp == 3 ? 2 * wC : 0;            // chroma: at most 8 rows = one group
+    for( int idx = tid; idx < itemsL + itemsC; idx += NT )
+    {
+      int c, x, g8;
+      if( idx < itemsL ) { c = 0; g8 = idx / wL; x = idx - g8 * wL; } else { const int q = idx - itemsL; c = 1 + ( q >= wC ); x = q - ( c - 1 ) * wC; g8 = 0; }
+      const int cs = c ? 1 : 0, hh = c ? hC : hL;
+      int p[2][8];
+      for( int k = 0; k < nl; k++ )
+      {
+        const pel_t* src = c ? &tmpC[k][c - 1][x * MC2_TST_C] : &tmpL[k][x * MC2_TST_L + 8 * g8];
+        const uint4 lo = *reinterpret_cast<const uint4*>( src ), hi = *reinterpret_cast<const uint4*>( src + 8 );
+        if( c ) mc_fir8<4>( lo, hi, reinterpret_cast<const uint32_t*>( coefV[k][c] ), p[k] );
+        else    mc_fir8<8>( lo, hi, reinterpret_cast<const uint32_t*>( coefV[k][0] ), p[k] );
+      }
+      // GPM: weight of partition 0 from the mask tables, addressed in luma units relative to the CU with the mirroring of the split angle
+      const int8_t* gW = nullptr; int gBase = 0, gSY = 0;
+      if( geo )
+      {
+        const int MS = 112;
+        const int angle = d_geo_params[cu.geo_split_dir][0];
+        const int wIdx = ilog2( cu.w ) - 3, hIdx = ilog2( cu.h ) - 3;
+        const int ox = d_geo_weight_offset[cu.geo_split_dir][hIdx][wIdx][0], oy = d_geo_weight_offset[cu.geo_split_dir][hIdx][wIdx][1];
+        gW = d_geo_weights[d_geo_angle2mask[angle]];
+        const int mir = d_geo_angle2mirror[angle];
+        const int lx = ( ( ( it.x >> cs ) + x ) << cs ) - cu.x, ly0 = ( ( ( it.y >> cs ) + 8 * g8 ) << cs ) - cu.y;
+        if( mir == 2 )      { gBase = ( MS - 1 - oy - ly0 ) * MS + ox + lx; gSY = -( MS << cs ); }
+        else if( mir == 1 ) { gBase = ( oy + ly0 ) * MS + ( MS - 1 - ox ) - lx; gSY = MS << cs; }
+        else                { gBase = ( oy + ly0 ) * MS + ox + lx; gSY = MS << cs; }
+      }
+      pel_t* dstp = reco.p[c] + (size_t) ( ( it.y >> cs ) + 8 * g8 ) * reco.stride[c] + ( it.x >> cs ) + x;
+#pragma unroll
+      for( int i = 0; i < 8; i++ )
+      {
+        if( 8 * g8 + i >= hh ) break;
+        int out;
+        if( uni )
+        {
+          const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
+          out = clip_pel( (int16_t) ( ( p[0][i] + offset2 ) >> shift2 ), bd );
+        }
+        else
+        {
+          const int p0 = (int16_t) ( p[0][i] >> 6 ), p1 = (int16_t) ( p[1][i] >> 6 );
+          if constexpr( BDOF )
+          {
+            if( c == 0 ) { bs.blk[0][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) p0; bs.blk[1][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) p1; continue; }
+          }
+          if( gW )
+          {
+            const int wt = gW[gBase + i * gSY], shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+            out = clip_pel( ( wt * p0 + ( 8 - wt ) * p1 + offset ) >> shift, bd );
+          }
+          else if( cu.bcw_idx != 2 )
+          {
+            const int w1 = d_bcw_weights[cu.bcw_idx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+            out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
+          }
+          else
+          {
+            const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+            out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
+          }
+        }
+        dstp[(size_t) i * reco.stride[c]] = (pel_t) out;
+      }
+    }
+  }
+  if constexpr( BDOF )
+  {
+    __syncthreads();
+    mc_bdof_luma<NT>( bs, winL[0], nullptr, winL[1], nullptr, MC2_WST_L, 0, &seg[0][0], 3, nullptr, nullptr, nullptr, nullptr, bd, reco, it.x, it.y, it.w, it.h, tid, true );
   }
 }
 
@@ -889,14 +1037,11 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   }
 }
 
-static int g_mcThreads = 0;
-void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
+void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int bdof )
 {
   if( !numItems ) return;
-  if( !g_mcThreads ) { const char* e = getenv( "VVR_MC_THREADS" ); g_mcThreads = e ? atoi( e ) : 64; }
-  if( g_mcThreads == 256 )      hipLaunchKernelGGL( k_mc<256>, dim3( numItems ), dim3( 256 ), 0, s, pic, refs, reco, items, numItems );
-  else if( g_mcThreads == 128 ) hipLaunchKernelGGL( k_mc<128>, dim3( numItems ), dim3( 128 ), 0, s, pic, refs, reco, items, numItems );
-  else                          hipLaunchKernelGGL( k_mc<64>,  dim3( numItems ), dim3( 64 ),  0, s, pic, refs, reco, items, numItems );
+  if( bdof ) hipLaunchKernelGGL( ( k_mc<64, true> ),  dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems );
+  else       hipLaunchKernelGGL( ( k_mc<64, false> ), dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems );
 }
 
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
@@ -1901,7 +2046,14 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     intra_stash_resi( sh.items[0], sh.resi[0], tid, rnext );
     for( int k = 0; k < nb; k++ )
     {
-      const IntraItem it = sh.items[k];
+      // the item is the same for every lane: move it to scalar registers so that all the mode / size dependent set-up below runs on
+      // the scalar unit and every branch on it is a scalar branch
+      IntraItem it;
+      {
+        const uint32_t* ip = reinterpret_cast<const uint32_t*>( &sh.items[k] );
+        uint32_t* op = reinterpret_cast<uint32_t*>( &it );
+        for( int q = 0; q < 4; q++ ) op[q] = __builtin_amdgcn_readfirstlane( ip[q] );
+      }
       const int16_t* __restrict__ rcur = sh.resi[k & 1];
       if( k + 1 < nb ) intra_fetch_resi( sh.items[k + 1], rs, rstride, tid, rnext );     // in flight while this block is predicted
       const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
