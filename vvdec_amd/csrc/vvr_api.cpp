@@ -498,7 +498,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         const int bw = tu.w >> ( it.comp ? 1 : 0 ), bh = tu.h >> ( it.comp ? 1 : 0 );
         if( bw < 2 || bh < 2 ) { c->setError( "1-D transform blocks are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
         const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
-        ( it.mode == TB_ADD ? tb[cls] : tbS[cls] ).push_back( it );
+        tb[cls].push_back( it );        // ADD (inter: onto the prediction) and STORE (intra / CIIP: into the residual planes) items share a launch
         const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];
         const double ncoef = bdp ? (double) bw * bh : (double) ( tu.max_scan_x[it.comp] + 1 ) * ( tu.max_scan_y[it.comp] + 1 );
         bytes[K_ITRANS] += ncoef * 2 + (double) bw * bh * 4 * ( it.ict ? 2 : 1 ) + sizeof( TbItem ) + sizeof( vvr_tu ) / 3.0;

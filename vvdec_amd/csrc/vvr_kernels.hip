@@ -72,13 +72,10 @@ struct McSeg {
   int xFrac, yFrac;
   int w, h;              // block size
   int ox, oy;            // position of the block's integer-sample origin inside the window
-  int padOff, cw, chh;   // DMVR padded copy (xPrefetchPad): window sample (u,v) = copied sample (clamp(u - padOff, 0, cw - 1), clamp(v - padOff, 0, chh - 1))
+  int padOff, cw, chh;   // DMVR padded copy (xPrefetchPad): window sample (u,v) = copied sample (clamp(u + shX - padOff, 0, cw - 1), clamp(v + shY - padOff, 0, chh - 1))
+  int shX, shY;          // displacement of the window inside the padded copy (the integer part of the DMVR refinement)
 };
 
-#define MC_WIN_L   ( 23 * 24 )
-#define MC_WIN_C   ( 11 * 12 )
-#define MC_TMP_L   ( 23 * 16 )
-#define MC_TMP_C   ( 11 * 8 )
 
 // XCD-aware mapping (cdna_hip_programming.md T1): consecutive workgroups are dealt round-robin to the 8 XCDs; give each XCD
 // a contiguous run of tiles so that the halo rows shared by neighbouring tiles hit the same L2.
@@ -115,7 +112,7 @@ __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg
   const int col = tid & 31, row0 = tid >> 5;
   if( col < g.ww )
   {
-    const int sx = clip3( 0, pw - 1, g.x0 + clip3( 0, g.cw - 1, col - g.padOff ) );
+    const int sx = clip3( 0, pw - 1, g.x0 + clip3( 0, g.cw - 1, col + g.shX - g.padOff ) );
     const pel_t* __restrict__ rc = ref + sx;
     // four rows per step, all four loads issued before the first LDS store: one memory round trip per four rows instead of one per
     // row (the tail repeats the last row: same value to the same place)
@@ -126,115 +123,12 @@ __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg
       for( int u = 0; u < 4; u++ )
       {
         yy[u] = min( yb + u * ( NT / 32 ), g.wh - 1 - ( ( g.wh - 1 - row0 ) % ( NT / 32 ) ) );      // last row of this lane's parity
-        const int sy = clip3( 0, ph - 1, g.y0 + clip3( 0, g.chh - 1, yy[u] - g.padOff ) );
+        const int sy = clip3( 0, ph - 1, g.y0 + clip3( 0, g.chh - 1, yy[u] + g.shY - g.padOff ) );
         v[u] = rc[(size_t) sy * stride];
       }
 #pragma unroll
       for( int u = 0; u < 4; u++ ) win[yy[u] * wst + col] = v[u];
     }
-  }
-}
-
-// horizontal pass of a 2-D segment (16-bit intermediates, InterpolationFilter.cpp:902-915): tmp row r = window row (oy - half + r)
-template<int NT>
-__device__ __forceinline__ void mc_hpass( const pel_t* win, int wst, pel_t* tmp, int tst, const McSeg& g, const int16_t* coefH, int c, int bd, int tid )
-{
-  const int col = tid & 15, row0 = tid >> 4;
-  if( !( g.xFrac && g.yFrac ) || col >= g.w ) return;
-  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
-  const int ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
-  int cf[8];
-  for( int t = 0; t < 8; t++ ) cf[t] = coefH[t];
-  const pel_t* w0 = win + ( g.oy - half ) * wst + g.ox - half + col;
-  for( int r = row0; r < g.h + ntaps - 1; r += NT / 16 )
-  {
-    int sum = 0;
-    for( int t = 0; t < ntaps; t++ ) sum += w0[r * wst + t] * cf[t];
-    tmp[r * tst + col] = (int16_t) ( ( sum + offset1 ) >> shift1 );
-  }
-}
-
-// final sample of one segment at block position (px,py): all four (xFrac, yFrac) cases of xPredInterBlk
-__device__ __forceinline__ int mc_final( const pel_t* win, int wstride, const pel_t* tmp, int tstride, const McSeg& g, const int16_t* ch, const int16_t* cv,
-                                         int comp, bool bi, int bd, int px, int py )
-{
-  const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
-  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
-  if( !doH && !doV )
-  {
-    const int s = win[( py + g.oy ) * wstride + px + g.ox];
-    return bi ? (int16_t) ( (int16_t) ( s << headroom ) - (int16_t) IF_INTERNAL_OFFS ) : s;
-  }
-  if( doH != doV )
-  {
-    int shift, offset;
-    if( !bi ) { shift = 6; offset = 32; } else { shift = 6 - headroom; offset = -IF_INTERNAL_OFFS * ( 1 << shift ); }
-    int sum = 0;
-    if( doH ) { for( int t = 0; t < ntaps; t++ ) sum += win[( py + g.oy ) * wstride + px + g.ox - half + t] * ch[t]; }
-    else      { for( int t = 0; t < ntaps; t++ ) sum += win[( py + g.oy - half + t ) * wstride + px + g.ox] * cv[t]; }
-    int val = (int16_t) ( ( sum + offset ) >> shift );
-    return bi ? val : clip_pel( val, bd );
-  }
-  int shift2, offset2;
-  if( !bi ) { shift2 = 6 + headroom; offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 ); } else { shift2 = 6; offset2 = 0; }
-  int sum = 0;
-  for( int t = 0; t < ntaps; t++ ) sum += tmp[( py + t ) * tstride + px] * cv[t];
-  int val = (int16_t) ( ( sum + offset2 ) >> shift2 );
-  return bi ? val : clip_pel( val, bd );
-}
-
-// bi-predictive average / BCW of one component of a tile (AreaBuf::addAvg / addWeightedAvg, Buffer.cpp:441,372) or the uni-directional result
-template<int NT>
-__device__ __forceinline__ void mc_output( const pel_t* win0, const pel_t* tmp0, const pel_t* win1, const pel_t* tmp1, int wst, int tst, const McSeg* seg0, const McSeg* seg1,
-                                           const int16_t* cH0, const int16_t* cV0, const int16_t* cH1, const int16_t* cV1, int c, bool uni, int bcwIdx, int bd,
-                                           const DevPlanes& reco, int x0c, int y0c, int w, int h, int tid, const vvr_cu* geoCu = nullptr )
-{
-  // GPM (InterpolationFilter::xWeightedGeoBlk, InterpolationFilter.cpp:1217): weight of partition 0 from the mask tables, addressed
-  // in luma units relative to the CU with the mirroring of the split angle
-  const int8_t* gW = nullptr; int gBase = 0, gSX = 0, gSY = 0;
-  if( geoCu )
-  {
-    const int MS = 112, cs = c ? 1 : 0;
-    const int angle = d_geo_params[geoCu->geo_split_dir][0];
-    const int wIdx = ilog2( geoCu->w ) - 3, hIdx = ilog2( geoCu->h ) - 3;
-    const int ox = d_geo_weight_offset[geoCu->geo_split_dir][hIdx][wIdx][0], oy = d_geo_weight_offset[geoCu->geo_split_dir][hIdx][wIdx][1];
-    gW = d_geo_weights[d_geo_angle2mask[angle]];
-    const int mir = d_geo_angle2mirror[angle];
-    const int lx0 = ( x0c << cs ) - geoCu->x, ly0 = ( y0c << cs ) - geoCu->y;        // tile offset inside the CU, luma units
-    if( mir == 2 )      { gBase = ( MS - 1 - oy - ly0 ) * MS + ox + lx0; gSX = 1 << cs; gSY = -( MS << cs ); }
-    else if( mir == 1 ) { gBase = ( oy + ly0 ) * MS + ( MS - 1 - ox ) - lx0; gSX = -( 1 << cs ); gSY = MS << cs; }
-    else                { gBase = ( oy + ly0 ) * MS + ox + lx0; gSX = 1 << cs; gSY = MS << cs; }
-  }
-  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  const int lw = w == 16 ? 4 : w == 8 ? 3 : w == 4 ? 2 : 1;       // log2 of the tile width
-  for( int i = tid; i < w * h; i += NT )
-  {
-    const int px = i & ( w - 1 ), py = i >> lw;
-    int out;
-    if( uni ) out = mc_final( win0, wst, tmp0, tst, *seg0, cH0, cV0, c, false, bd, px, py );
-    else
-    {
-      const int p0 = mc_final( win0, wst, tmp0, tst, *seg0, cH0, cV0, c, true, bd, px, py );
-      const int p1 = mc_final( win1, wst, tmp1, tst, *seg1, cH1, cV1, c, true, bd, px, py );
-      if( gW )
-      {
-        const int wt = gW[gBase + py * gSY + px * gSX], shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
-        out = clip_pel( ( wt * p0 + ( 8 - wt ) * p1 + offset ) >> shift, bd );
-      }
-      else if( bcwIdx != 2 )
-      {
-        const int w1 = d_bcw_weights[bcwIdx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
-        out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
-      }
-      else
-      {
-        const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
-        out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
-      }
-    }
-    reco.p[c][(size_t) ( y0c + py ) * reco.stride[c] + x0c + px] = (pel_t) out;
   }
 }
 
@@ -245,20 +139,14 @@ struct BdofShared {
   pel_t gx[2][16 * 16], gy[2][16 * 16];    // gradients of the interior
 };
 template<int NT>
-__device__ __forceinline__ void mc_bdof_luma( BdofShared& bs, const pel_t* win0, const pel_t* tmp0, const pel_t* win1, const pel_t* tmp1, int wst, int tst,
-                                              const McSeg* seg /* [2] for luma */, int segStride, const int16_t* cH0, const int16_t* cV0, const int16_t* cH1, const int16_t* cV1,
-                                              int bd, const DevPlanes& reco, int x0, int y0, int w, int h, int tid, bool interiorDone = false )
+__device__ __forceinline__ void mc_bdof_luma( BdofShared& bs, const pel_t* win0, const pel_t* win1, int wst, const McSeg* seg /* luma segment of list 0 */, int segStride,
+                                              int bd, const DevPlanes& reco, int x0, int y0, int w, int h, int tid )
 {
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   const int lw = w == 16 ? 4 : 3;
   const McSeg& g0 = seg[0]; const McSeg& g1 = seg[segStride];
-  // (1) 14-bit predictions of both lists (unless the caller has put them into bs.blk already) + the border of nearest integer samples (xPredInterBlk :863-890)
-  if( !interiorDone ) for( int i = tid; i < w * h; i += NT )
-  {
-    const int px = i & ( w - 1 ), py = i >> lw;
-    bs.blk[0][( 1 + py ) * BDOF_S + 1 + px] = (pel_t) mc_final( win0, wst, tmp0, tst, g0, cH0, cV0, 0, true, bd, px, py );
-    bs.blk[1][( 1 + py ) * BDOF_S + 1 + px] = (pel_t) mc_final( win1, wst, tmp1, tst, g1, cH1, cV1, 0, true, bd, px, py );
-  }
+  // (1) bs.blk holds the 14-bit predictions of both lists (written by the vertical filter stage); add the border of nearest
+  //     integer samples around them (xPredInterBlk :863-890)
   {
     const int ring = 2 * ( w + 2 ) + 2 * h;
     for( int i = tid; i < 2 * ring; i += NT )
@@ -376,76 +264,23 @@ __device__ __forceinline__ void mc_fir8( const uint4 lo, const uint4 hi, const u
 #define MC2_TST_L 24        // transposed intermediates: per column 23 values (+1 pad)
 #define MC2_TST_C 16
 
-// BDOF = true: the launch holds only tiles of CUs in BDOF mode (they need 3.5 KB more LDS for the gradient buffers; keeping them out
-// of the plain launch raises the number of resident tiles per CU there).
-template<int NT, bool BDOF>
-__global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
+// LDS working set of the two filter stages (one tile = one wavefront)
+struct Mc2Shared {
+  __attribute__( ( aligned( 16 ) ) ) pel_t winL[2][23 * MC2_WST_L];
+  __attribute__( ( aligned( 16 ) ) ) pel_t winC[2][2][11 * MC2_WST_C];
+  __attribute__( ( aligned( 16 ) ) ) pel_t tmpL[2][16 * MC2_TST_L];       // [column][row]
+  __attribute__( ( aligned( 16 ) ) ) pel_t tmpC[2][2][8 * MC2_TST_C];
+  __attribute__( ( aligned( 16 ) ) ) int16_t coefH[2][3][8], coefV[2][3][8];
+  McSeg seg[2][3];
+  const pel_t* refp[2][3];
+};
+
+template<int NT>
+__device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int tw, int th, int headroom, int tid )
 {
-  __shared__ __attribute__( ( aligned( 16 ) ) ) pel_t winL[2][23 * MC2_WST_L];
-  __shared__ __attribute__( ( aligned( 16 ) ) ) pel_t winC[2][2][11 * MC2_WST_C];
-  __shared__ __attribute__( ( aligned( 16 ) ) ) pel_t tmpL[2][16 * MC2_TST_L];       // [column][row]
-  __shared__ __attribute__( ( aligned( 16 ) ) ) pel_t tmpC[2][2][8 * MC2_TST_C];
-  __shared__ McSeg seg[2][3];
-  __shared__ const pel_t* refp[2][3];
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t coefH[2][3][8], coefV[2][3][8];
-  __shared__ typename std::conditional<BDOF, BdofShared, int>::type bs;
-  const int item = mc_item_index();
-  if( item >= numItems ) return;
-  const McItem it = items[item];
-  const vvr_cu& cu = pic.cu[it.cu];
-  const int bd = pic.hdr.bit_depth;
-  const int tid = threadIdx.x;
-  // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the tile is one 8x8 sub-block whose motion comes from the motion field; it goes
-  // through the plain uni / bi path with the identical-motion shortcut (xCheckIdenticalMotion :404), clipped at its own position
-  const bool sub = ( it.flags & MC_ITEM_SUBBLOCK ) != 0;
-  int mRef[2] = { cu.ref_idx[0], cu.ref_idx[1] }, mMv[2][2] = { { cu.mv[0][0][0], cu.mv[0][0][1] }, { cu.mv[1][0][0], cu.mv[1][0][1] } };
-  bool uni = cu.mc_mode == VVR_MC_UNI;
-  if( sub )
-  {
-    const vvr_motion& m = pic.motion[(size_t) ( it.y >> 2 ) * pic.w4 + ( it.x >> 2 )];
-    for( int l = 0; l < 2; l++ ) { mRef[l] = m.ref_idx[l]; mMv[l][0] = m.mv[l][0]; mMv[l][1] = m.mv[l][1]; }
-    const bool two = mRef[0] >= 0 && mRef[1] >= 0;
-    uni = !two || ( pic.hdr.ref_poc[0][mRef[0]] == pic.hdr.ref_poc[1][mRef[1]] && mMv[0][0] == mMv[1][0] && mMv[0][1] == mMv[1][1] );
-  }
-  const int clipX = sub ? it.x : cu.x, clipY = sub ? it.y : cu.y;
-  const bool biPred = mRef[0] >= 0 && mRef[1] >= 0;
-  const bool geo = cu.mc_mode == VVR_MC_GEO;            // motionCompensationGeo (:1461): two uni-predictions kept at 14 bit, blended with the GPM masks
-  const int ncomp = pic.hdr.chroma_format ? 3 : 1;
-  const int l0 = uni ? ( ( biPred || mRef[0] >= 0 ) ? 0 : 1 ) : 0;
-  const int nl = uni ? 1 : 2;
-  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  // ---- segment geometry + filter taps: computed once by six lanes, shared through LDS.  The window always spans the full filter
-  // support (the block's integer origin sits at (half, half)), whatever the fractional part of the MV
-  if( tid < 6 )
-  {
-    const int k = tid / 3, c = tid - 3 * k;
-    if( k < nl && c < ncomp )
-    {
-      const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
-      const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : mRef[l];
-      int mvx = geo ? cu.geo_mv[k][0] : mMv[l][0], mvy = geo ? cu.geo_mv[k][1] : mMv[l][1];
-      mc_clip_mv( pic, clipX, clipY, mvx, mvy );         // clipped with the CU position (InterPrediction.cpp:657 uses m_currCuArea)
-      McSeg g;
-      const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
-      g.w = it.w >> cs; g.h = it.h >> cs;
-      g.xFrac = mvx & ( ( 1 << shf ) - 1 ); g.yFrac = mvy & ( ( 1 << shf ) - 1 );
-      g.ox = half; g.oy = half;
-      g.ww = g.w + ntaps - 1; g.wh = g.h + ntaps - 1;
-      g.x0 = ( it.x >> cs ) + ( mvx >> shf ) - half;
-      g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - half;
-      g.padOff = 0; g.cw = g.ww; g.chh = g.wh;
-      seg[k][c] = g;
-      refp[k][c] = refs.p[l * VVR_MAX_REFS + refIdx][c];
-      mc_taps( g, c, cu.imv == 3, coefH[k][c], coefV[k][c] );      // frac 0 selects the identity filter { .., 64, .. }
-      if( !c ) { for( int t = 0; t < 0; t++ ) {} } else { for( int t = 4; t < 8; t++ ) { coefH[k][c][t] = 0; coefV[k][c][t] = 0; } }
-    }
-  }
-  __syncthreads();
-  // ---- phase A: all reference windows of the tile into LDS, one exposure to HBM/L2 latency
-  for( int k = 0; k < nl; k++ ) for( int c = 0; c < ncomp; c++ )
-    mc_load_window<NT>( c ? winC[k][c - 1] : winL[k], c ? MC2_WST_C : MC2_WST_L, seg[k][c], refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
-  __syncthreads();
-  // ---- stage 1: horizontal filter of every window row, 8 outputs per work item, written transposed ([column][row])
+  struct { int w, h; } it = { tw, th };
+  auto& winL = m.winL; auto& winC = m.winC; auto& tmpL = m.tmpL; auto& tmpC = m.tmpC; auto& coefH = m.coefH;
+  // stage 1: horizontal filter of every window row, 8 outputs per work item, written transposed ([column][row])
   {
     const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
     const int wL = it.w, hL = it.h, wC = it.w >> 1, hC = it.h >> 1;
@@ -476,7 +311,16 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
     }
   }
   __syncthreads();
-  // ---- stage 2: vertical filter, 8 rows of one column per work item, both lists in the same lane, then the combination
+}
+
+// bs: BDOF buffers (the 14-bit luma predictions go there instead of being averaged) or nullptr
+template<int NT>
+__device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int nl, int ncomp, bool uni, const vvr_cu& cu, bool geo, int bcwIdx, int bd, int headroom,
+                                            const DevPlanes& reco, int tx, int ty, int tw, int th, int tid )
+{
+  struct { int x, y, w, h; } it = { tx, ty, tw, th };
+  auto& tmpL = m.tmpL; auto& tmpC = m.tmpC; auto& coefV = m.coefV;
+  // stage 2: vertical filter, 8 rows of one column per work item, both lists in the same lane, then the combination
   //      (AreaBuf::addAvg / addWeightedAvg, Buffer.cpp:441,372; GPM weights, InterpolationFilter.cpp:1217) or the BDOF input
   {
     const int wL = it.w, hL = it.h, wC = it.w >> 1, hC = it.h >> 1;
@@ -524,18 +368,15 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
         else
         {
           const int p0 = (int16_t) ( p[0][i] >> 6 ), p1 = (int16_t) ( p[1][i] >> 6 );
-          if constexpr( BDOF )
-          {
-            if( c == 0 ) { bs.blk[0][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) p0; bs.blk[1][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) p1; continue; }
-          }
+          if( bsp && c == 0 ) { bsp->blk[0][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) p0; bsp->blk[1][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) p1; continue; }
           if( gW )
           {
             const int wt = gW[gBase + i * gSY], shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
             out = clip_pel( ( wt * p0 + ( 8 - wt ) * p1 + offset ) >> shift, bd );
           }
-          else if( cu.bcw_idx != 2 )
+          else if( bcwIdx != 2 )
           {
-            const int w1 = d_bcw_weights[cu.bcw_idx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+            const int w1 = d_bcw_weights[bcwIdx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
             out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
           }
           else
@@ -548,10 +389,77 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       }
     }
   }
+}
+
+// BDOF = true: the launch holds only tiles of CUs in BDOF mode (they need 3.5 KB more LDS for the gradient buffers; keeping them out
+// of the plain launch raises the number of resident tiles per CU there).
+template<int NT, bool BDOF>
+__global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
+{
+  __shared__ Mc2Shared m;
+  __shared__ typename std::conditional<BDOF, BdofShared, int>::type bs;
+  const int item = mc_item_index();
+  if( item >= numItems ) return;
+  const McItem it = items[item];
+  const vvr_cu& cu = pic.cu[it.cu];
+  const int bd = pic.hdr.bit_depth;
+  const int tid = threadIdx.x;
+  // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the tile is one 8x8 sub-block whose motion comes from the motion field; it goes
+  // through the plain uni / bi path with the identical-motion shortcut (xCheckIdenticalMotion :404), clipped at its own position
+  const bool sub = ( it.flags & MC_ITEM_SUBBLOCK ) != 0;
+  int mRef[2] = { cu.ref_idx[0], cu.ref_idx[1] }, mMv[2][2] = { { cu.mv[0][0][0], cu.mv[0][0][1] }, { cu.mv[1][0][0], cu.mv[1][0][1] } };
+  bool uni = cu.mc_mode == VVR_MC_UNI;
+  if( sub )
+  {
+    const vvr_motion& m = pic.motion[(size_t) ( it.y >> 2 ) * pic.w4 + ( it.x >> 2 )];
+    for( int l = 0; l < 2; l++ ) { mRef[l] = m.ref_idx[l]; mMv[l][0] = m.mv[l][0]; mMv[l][1] = m.mv[l][1]; }
+    const bool two = mRef[0] >= 0 && mRef[1] >= 0;
+    uni = !two || ( pic.hdr.ref_poc[0][mRef[0]] == pic.hdr.ref_poc[1][mRef[1]] && mMv[0][0] == mMv[1][0] && mMv[0][1] == mMv[1][1] );
+  }
+  const int clipX = sub ? it.x : cu.x, clipY = sub ? it.y : cu.y;
+  const bool biPred = mRef[0] >= 0 && mRef[1] >= 0;
+  const bool geo = cu.mc_mode == VVR_MC_GEO;            // motionCompensationGeo (:1461): two uni-predictions kept at 14 bit, blended with the GPM masks
+  const int ncomp = pic.hdr.chroma_format ? 3 : 1;
+  const int l0 = uni ? ( ( biPred || mRef[0] >= 0 ) ? 0 : 1 ) : 0;
+  const int nl = uni ? 1 : 2;
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  // ---- segment geometry + filter taps: computed once by six lanes, shared through LDS.  The window always spans the full filter
+  // support (the block's integer origin sits at (half, half)), whatever the fractional part of the MV
+  if( tid < 6 )
+  {
+    const int k = tid / 3, c = tid - 3 * k;
+    if( k < nl && c < ncomp )
+    {
+      const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
+      const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : mRef[l];
+      int mvx = geo ? cu.geo_mv[k][0] : mMv[l][0], mvy = geo ? cu.geo_mv[k][1] : mMv[l][1];
+      mc_clip_mv( pic, clipX, clipY, mvx, mvy );         // clipped with the CU position (InterPrediction.cpp:657 uses m_currCuArea)
+      McSeg g;
+      const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
+      g.w = it.w >> cs; g.h = it.h >> cs;
+      g.xFrac = mvx & ( ( 1 << shf ) - 1 ); g.yFrac = mvy & ( ( 1 << shf ) - 1 );
+      g.ox = half; g.oy = half;
+      g.ww = g.w + ntaps - 1; g.wh = g.h + ntaps - 1;
+      g.x0 = ( it.x >> cs ) + ( mvx >> shf ) - half;
+      g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - half;
+      g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
+      m.seg[k][c] = g;
+      m.refp[k][c] = refs.p[l * VVR_MAX_REFS + refIdx][c];
+      mc_taps( g, c, cu.imv == 3, m.coefH[k][c], m.coefV[k][c] );      // frac 0 selects the identity filter { .., 64, .. }
+    }
+  }
+  __syncthreads();
+  // ---- phase A: all reference windows of the tile into LDS, one exposure to HBM/L2 latency
+  for( int k = 0; k < nl; k++ ) for( int c = 0; c < ncomp; c++ )
+    mc_load_window<NT>( c ? m.winC[k][c - 1] : m.winL[k], c ? MC2_WST_C : MC2_WST_L, m.seg[k][c], m.refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
+  __syncthreads();
+  mc2_stage1<NT>( m, nl, ncomp, it.w, it.h, headroom, tid );
+  __syncthreads();
+  mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, uni, cu, geo, cu.bcw_idx, bd, headroom, reco, it.x, it.y, it.w, it.h, tid );
   if constexpr( BDOF )
   {
     __syncthreads();
-    mc_bdof_luma<NT>( bs, winL[0], nullptr, winL[1], nullptr, MC2_WST_L, 0, &seg[0][0], 3, nullptr, nullptr, nullptr, nullptr, bd, reco, it.x, it.y, it.w, it.h, tid, true );
+    mc_bdof_luma<NT>( bs, m.winL[0], m.winL[1], MC2_WST_L, &m.seg[0][0], 3, bd, reco, it.x, it.y, it.w, it.h, tid );
   }
 }
 
@@ -564,17 +472,10 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
 //   the average or BDOF (bioAppliedSubblk :1984).  The delta MV goes to dmvrOut[cu.dmvr_off + sub-block] for the host
 //   (DecCu::TaskFinishMotionInfo, DecCu.cpp:161).
 // =====================================================================================================================
-#define DM_WST_L 28
-#define DM_WST_C 16
+#define DM_WST_L MC2_WST_L
 struct DmvrShared {
-  pel_t winL[2][27 * DM_WST_L];
-  pel_t winC[2][2][15 * DM_WST_C];
-  pel_t tmpL[2][MC_TMP_L];
-  pel_t tmpC[2][2][MC_TMP_C];
+  Mc2Shared m;                   // windows / intermediates / taps of the final prediction (stage 1 reuses winL for the bilinear windows)
   pel_t bil[2][20 * 20];
-  McSeg seg[2][3];
-  const pel_t* refp[2][3];
-  int16_t coefH[2][3][8], coefV[2][3][8];
   unsigned sad[25];
   int dmv[2], bioSub, minCost;
   BdofShared bs;
@@ -616,12 +517,12 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
     mvx -= 32; mvy -= 32;
     McSeg g;
     g.w = w + 4; g.h = h + 4; g.xFrac = mvx & 15; g.yFrac = mvy & 15;
-    g.x0 = it.x + ( mvx >> 4 ); g.y0 = it.y + ( mvy >> 4 ); g.ww = g.w + 1; g.wh = g.h + 1; g.ox = g.oy = 0; g.padOff = 0; g.cw = g.ww; g.chh = g.wh;
-    sh.seg[l][0] = g;
-    sh.refp[l][0] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][0];
+    g.x0 = it.x + ( mvx >> 4 ); g.y0 = it.y + ( mvy >> 4 ); g.ww = g.w + 1; g.wh = g.h + 1; g.ox = g.oy = 0; g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
+    sh.m.seg[l][0] = g;
+    sh.m.refp[l][0] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][0];
   }
   __syncthreads();
-  for( int l = 0; l < 2; l++ ) mc_load_window<NT>( sh.winL[l], DM_WST_L, sh.seg[l][0], sh.refp[l][0], reco.stride[0], reco.w[0], reco.h[0], tid );
+  for( int l = 0; l < 2; l++ ) mc_load_window<NT>( sh.m.winL[l], DM_WST_L, sh.m.seg[l][0], sh.m.refp[l][0], reco.stride[0], reco.w[0], reco.h[0], tid );
   __syncthreads();
   {
     // InterpolationFilter::filter<2> (:589-600) / filterCopy biMCForDMVR (:445-477) at IF_INTERNAL_PREC_BILINEAR = 10
@@ -630,8 +531,8 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
     for( int i = tid; i < 2 * ew * eh; i += NT )
     {
       const int l = i >= ew * eh, r = i - l * ew * eh, y = r / ew, x = r - y * ew;
-      const McSeg& g = sh.seg[l][0];
-      const pel_t* p = &sh.winL[l][y * DM_WST_L + x];
+      const McSeg& g = sh.m.seg[l][0];
+      const pel_t* p = &sh.m.winL[l][y * DM_WST_L + x];
       int v;
       if( !g.xFrac && !g.yFrac ) v = p[0] * ( 1 << ( 10 - bd ) );
       else if( !g.yFrac ) v = ( p[0] * ( 16 - g.xFrac ) + p[1] * g.xFrac + offF ) >> shiftF;
@@ -706,7 +607,8 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
     __syncthreads();
   }
   const bool bioSub = sh.bioSub != 0;
-  // ---- stage 3: final prediction with the refined MVs (clipped against the SUB-block, :1752)
+  // ---- stage 3: final prediction with the refined MVs (clipped against the SUB-block, :1752), same two filter stages as k_mc
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   if( tid < 6 )
   {
     const int l = tid / 3, c = tid - 3 * l;
@@ -722,43 +624,37 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
       McSeg g;
       g.w = w >> cs; g.h = h >> cs;
       g.xFrac = cmx & ( ( 1 << shf ) - 1 ); g.yFrac = cmy & ( ( 1 << shf ) - 1 );
+      g.ox = half; g.oy = half; g.ww = g.w + ntaps - 1; g.wh = g.h + ntaps - 1;
       if( dIntX || dIntY )
       {
-        // padded local copy: the (w + ntaps - 1)^2 window at the start MV, replicated outwards (xPrefetchPad + paddingCore)
+        // padded local copy: the (w + ntaps - 1)^2 window at the start MV, replicated outwards (xPrefetchPad + paddingCore); the
+        // window held in LDS is that copy displaced by the integer part of the refinement
         int pmx = mgx - ( half << shf ), pmy = mgy - ( half << shf );
         mc_clip_mv( pic, it.x, it.y, pmx, pmy );
         g.x0 = ( it.x >> cs ) + ( pmx >> shf ); g.y0 = ( it.y >> cs ) + ( pmy >> shf );
-        g.cw = g.w + ntaps - 1; g.chh = g.h + ntaps - 1; g.padOff = 2;
-        g.ww = g.cw + 4; g.wh = g.chh + 4;
-        g.ox = 2 + half + dIntX; g.oy = 2 + half + dIntY;
+        g.cw = g.ww; g.chh = g.wh; g.padOff = 2; g.shX = 2 + dIntX; g.shY = 2 + dIntY;
       }
       else
       {
-        const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
-        const bool full = bioSub && c == 0;
-        g.ox = ( doH || full ) ? half : 0; g.oy = ( doV || full ) ? half : 0;
-        g.ww = g.w + ( ( doH || full ) ? ntaps - 1 : 0 ); g.wh = g.h + ( ( doV || full ) ? ntaps - 1 : 0 );
-        g.x0 = ( it.x >> cs ) + ( cmx >> shf ) - g.ox; g.y0 = ( it.y >> cs ) + ( cmy >> shf ) - g.oy;
-        g.padOff = 0; g.cw = g.ww; g.chh = g.wh;
+        g.x0 = ( it.x >> cs ) + ( cmx >> shf ) - half; g.y0 = ( it.y >> cs ) + ( cmy >> shf ) - half;
+        g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
       }
-      sh.seg[l][c] = g;
-      sh.refp[l][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
-      mc_taps( g, c, cu.imv == 3, sh.coefH[l][c], sh.coefV[l][c] );
+      sh.m.seg[l][c] = g;
+      sh.m.refp[l][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
+      mc_taps( g, c, cu.imv == 3, sh.m.coefH[l][c], sh.m.coefV[l][c] );
     }
   }
   __syncthreads();
   for( int k = 0; k < 2; k++ ) for( int c = 0; c < ncomp; c++ )
-    mc_load_window<NT>( c ? sh.winC[k][c - 1] : sh.winL[k], c ? DM_WST_C : DM_WST_L, sh.seg[k][c], sh.refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
+    mc_load_window<NT>( c ? sh.m.winC[k][c - 1] : sh.m.winL[k], c ? MC2_WST_C : MC2_WST_L, sh.m.seg[k][c], sh.m.refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
   __syncthreads();
-  for( int k = 0; k < 2; k++ ) for( int c = 0; c < ncomp; c++ )
-    mc_hpass<NT>( c ? sh.winC[k][c - 1] : sh.winL[k], c ? DM_WST_C : DM_WST_L, c ? sh.tmpC[k][c - 1] : sh.tmpL[k], c ? 8 : 16, sh.seg[k][c], sh.coefH[k][c], c, bd, tid );
+  mc2_stage1<NT>( sh.m, 2, ncomp, w, h, headroom, tid );
   __syncthreads();
-  if( bioSub ) mc_bdof_luma<NT>( sh.bs, sh.winL[0], sh.tmpL[0], sh.winL[1], sh.tmpL[1], DM_WST_L, 16, &sh.seg[0][0], 3, sh.coefH[0][0], sh.coefV[0][0], sh.coefH[1][0], sh.coefV[1][0], bd, reco, it.x, it.y, w, h, tid );
-  for( int c = bioSub ? 1 : 0; c < ncomp; c++ )
+  mc2_stage2<NT>( sh.m, bioSub ? &sh.bs : nullptr, 2, ncomp, false, cu, false, 2, bd, headroom, reco, it.x, it.y, w, h, tid );
+  if( bioSub )
   {
-    const int cs = c ? 1 : 0;
-    mc_output<NT>( c ? sh.winC[0][c - 1] : sh.winL[0], c ? sh.tmpC[0][c - 1] : sh.tmpL[0], c ? sh.winC[1][c - 1] : sh.winL[1], c ? sh.tmpC[1][c - 1] : sh.tmpL[1], c ? DM_WST_C : DM_WST_L, c ? 8 : 16,
-                   &sh.seg[0][c], &sh.seg[1][c], sh.coefH[0][c], sh.coefV[0][c], sh.coefH[1][c], sh.coefV[1][c], c, false, 2, bd, reco, it.x >> cs, it.y >> cs, w >> cs, h >> cs, tid );
+    __syncthreads();
+    mc_bdof_luma<NT>( sh.bs, sh.m.winL[0], sh.m.winL[1], MC2_WST_L, &sh.m.seg[0][0], 3, bd, reco, it.x, it.y, w, h, tid );
   }
 }
 
@@ -1080,8 +976,10 @@ __device__ __forceinline__ int wide_angle_mode( int w, int h, int mode )   // PU
   return mode;
 }
 
-template<int MAXN>
-__global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, DevPlanes resi, const TbItem* __restrict__ items, int numItems )
+// NT threads per transform block: 64 for the <= 16x16 class (one wavefront per block: four times as many blocks resident, no
+// cross-wave barrier), 256 for the larger classes
+template<int MAXN, int NT>
+__global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, DevPlanes resi, const TbItem* __restrict__ items, int numItems )
 {
   __shared__ int32_t dq[MAXN * MAXN];
   __shared__ int32_t tmp[MAXN * MAXN];
@@ -1103,7 +1001,7 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
   const int16_t* __restrict__ lev = pic.coef + tu.coef_off[comp];
 
   const int n = bw * bh;
-  for( int i = tid; i < n; i += 256 ) dq[i] = 0;
+  for( int i = tid; i < n; i += NT ) dq[i] = 0;
   __syncthreads();
   // ---- dequantisation
   {
@@ -1122,7 +1020,7 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
     {
       // invResDPCM (Quant.cpp:239): running sums along rows (mode 1) / columns (mode 2); one thread per line
       const int lines = bdpcm == 1 ? bh : bw, len = bdpcm == 1 ? bw : bh;
-      for( int l = tid; l < lines; l += 256 )
+      for( int l = tid; l < lines; l += NT )
       {
         int acc = 0;
         for( int k = 0; k < len; k++ )
@@ -1135,7 +1033,7 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
       }
       __syncthreads();
       maxX = bw - 1; maxY = bh - 1;
-      for( int i = tid; i < n; i += 256 )
+      for( int i = tid; i < n; i += NT )
       {
         const int level = dq[i];
         if( level )
@@ -1149,7 +1047,7 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
     else
     {
       const int cw = maxX + 1, cn = cw * ( maxY + 1 );
-      for( int i = tid; i < cn; i += 256 )
+      for( int i = tid; i < cn; i += NT )
       {
         const int y = i / cw, x = i - y * cw;
         const int level = lev[i];
@@ -1225,11 +1123,11 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
     // the basis rows both passes touch, staged in LDS (the tables themselves stay L2-resident)
     const int16_t* __restrict__ Mv = tr_matrix( trVer, bh );
     const int16_t* __restrict__ Mh = tr_matrix( trHor, bw );
-    for( int i = tid; i < cutH * bh; i += 256 ) mvS[i] = Mv[i];
-    for( int i = tid; i < redW * bw; i += 256 ) mhS[i] = Mh[i];
+    for( int i = tid; i < cutH * bh; i += NT ) mvS[i] = Mv[i];
+    for( int i = tid; i < redW * bw; i += NT ) mhS[i] = Mh[i];
     __syncthreads();
     // pass 1 (vertical): tmp[x*bh + y] = clip16( ( sum_k dq[k*bw + x] * Mv[k*bh + y] + 64 ) >> 7 ), x < redW
-    for( int i = tid; i < redW * bh; i += 256 )
+    for( int i = tid; i < redW * bh; i += NT )
     {
       const int x = i / bh, y = i - x * bh;
       int sum = 0;
@@ -1240,7 +1138,7 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
   }
   // ---- pass 2 (horizontal) + output
   const int ict = it.ict ? (int) it.ict - 4 : 0;
-  for( int i = tid; i < n; i += 256 )
+  for( int i = tid; i < n; i += NT )
   {
     const int y = i / bw, x = i - y * bw;
     int r;
@@ -1283,9 +1181,9 @@ __global__ __launch_bounds__( 256 ) void k_itrans( PicDev pic, DevPlanes reco, D
 void launch_itrans( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const TbItem* items, int numItems, int sizeClass )
 {
   if( !numItems ) return;
-  if( sizeClass <= 16 )      hipLaunchKernelGGL( k_itrans<16>, dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
-  else if( sizeClass <= 32 ) hipLaunchKernelGGL( k_itrans<32>, dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
-  else                       hipLaunchKernelGGL( k_itrans<64>, dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
+  if( sizeClass <= 16 )      hipLaunchKernelGGL( ( k_itrans<16, 64> ),  dim3( numItems ), dim3( 64 ),  0, s, pic, reco, resi, items, numItems );
+  else if( sizeClass <= 32 ) hipLaunchKernelGGL( ( k_itrans<32, 256> ), dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
+  else                       hipLaunchKernelGGL( ( k_itrans<64, 256> ), dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
 }
 
 // =====================================================================================================================
