@@ -544,6 +544,24 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       }
       activeV.push_back( dm );
     }
+    // bit 30 of an entry: some other (component, CTU) waits for this one, so it has to publish its flag (agent-scope release);
+    // CTUs nobody depends on skip the fence
+    {
+      std::vector<uint8_t> waited( 3 * (size_t) numCtu, 0 );
+      const int nbx[5] = { -1, -1, 0, 1, 0 }, nby[5] = { 0, -1, -1, -1, 0 };
+      for( size_t t = 0; t < na; t++ )
+      {
+        const uint32_t k = ( activeV[t] >> 24 ) & 3, a = activeV[t] & 0xffffff, dm = activeV[na + t];
+        for( int b = 0; b < 9; b++ )
+        {
+          if( !( dm & ( 1u << b ) ) ) continue;
+          const int q = b < 4 ? b : b - 4, kk = b < 4 ? (int) k : 0;
+          const int nx = (int) ( a % ctusX ) + nbx[q], ny = (int) ( a / ctusX ) + nby[q];
+          if( nx >= 0 && ny >= 0 && nx < ctusX ) waited[(size_t) kk * numCtu + (size_t) ny * ctusX + nx] = 1;
+        }
+      }
+      for( size_t t = 0; t < na; t++ ) if( waited[(size_t) ( ( activeV[t] >> 24 ) & 3 ) * numCtu + ( activeV[t] & 0xffffff )] ) activeV[t] |= 0x40000000u;
+    }
     for( size_t t = 0; t < na; t++ )
     {
       const BBox& bb = bboxV[(size_t) ( ( activeV[t] >> 24 ) & 3 ) * numCtu + ( activeV[t] & 0xffffff )];

@@ -1868,6 +1868,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   const uint32_t ent = active[ticket];
   const int comp = ( ent >> 24 ) & 3, ctu = ent & 0xffffff;
   const bool borderOnly = ( ent >> 31 ) != 0;          // every sample of the CTU is intra: the interior is produced here, never read first
+  const bool publish = ( ( ent >> 30 ) & 1 ) != 0;     // another CTU waits for this one
   const int cxI = ctu % pic.ctus_x, cyI = ctu / pic.ctus_x;
   const int cs = comp ? 1 : 0;
   const int S = ( 1 << pic.hdr.log2_ctu ) >> cs;
@@ -1901,7 +1902,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       int* flag = &sync[1 + n];
       while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 30 );
     }
-    __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );
+    if( depMask ) __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );      // nothing produced by another workgroup is read otherwise
   }
   __syncthreads();
   // ---- stage the needed part of the CTU and its reference border in LDS
@@ -2366,6 +2367,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   }
 #undef TILE
   // ---- publish: all stores of the workgroup drained, one agent-scope release, then the flag
+  if( !publish ) return;
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
   __syncthreads();
   if( tid == 0 )
