@@ -567,6 +567,17 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       const BBox& bb = bboxV[(size_t) ( ( activeV[t] >> 24 ) & 3 ) * numCtu + ( activeV[t] & 0xffffff )];
       activeV.push_back( (uint32_t) bb.y0 | ( (uint32_t) bb.y1 << 8 ) | ( (uint32_t) bb.c0 << 16 ) | ( (uint32_t) bb.c1 << 24 ) );
     }
+    // ticket order: CTUs that wait for nothing first (they can never block a resident workgroup slot), then the others in raster
+    // order.  Every CTU a workgroup may wait for still holds a lower ticket: it is either independent (first group) or an earlier
+    // CTU of the second group.
+    {
+      std::vector<uint32_t> perm; perm.reserve( na );
+      for( size_t t = 0; t < na; t++ ) if( activeV[na + t] == 0 ) perm.push_back( (uint32_t) t );
+      for( size_t t = 0; t < na; t++ ) if( activeV[na + t] != 0 ) perm.push_back( (uint32_t) t );
+      std::vector<uint32_t> re( 3 * na );
+      for( size_t t = 0; t < na; t++ ) for( int part = 0; part < 3; part++ ) re[part * na + t] = activeV[part * na + perm[t]];
+      activeV.swap( re );
+    }
   }
   const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
   bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
