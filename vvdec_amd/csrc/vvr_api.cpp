@@ -45,7 +45,7 @@ struct vvr_prepared {        // a picture description resident in HBM together w
   int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64 (TB_ADD: after MC)
   TbItem*  tbStore[3] = { nullptr, nullptr, nullptr }; int numTbStore[3] = { 0, 0, 0 };   // residuals of intra blocks (TB_STORE)
-  IntraItem* intraItems = nullptr; uint32_t* ctuStart = nullptr; uint32_t* active = nullptr; int numActive = 0, numIntra = 0;
+  IntraItem* intraItems = nullptr; uint32_t* ctuStart = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
   double   bytes[K_NUM] = { 0 };
   bool     owned = false;
 };
@@ -152,7 +152,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   {
     const int ctu = 1 << cfg->log2_ctu;
     const size_t numCtu = (size_t) ( ( cfg->max_width + ctu - 1 ) / ctu ) * ( ( cfg->max_height + ctu - 1 ) / ctu );
-    for( int s = 0; s < ns; s++ ) { int* p = nullptr; if( hipMalloc( (void**) &p, sizeof( int ) * ( 1 + 3 * numCtu ) ) != hipSuccess ) { delete c; return VVR_ERR_DEVICE; } c->syncBuf.push_back( p ); }
+    for( int s = 0; s < ns; s++ ) { int* p = nullptr; if( hipMalloc( (void**) &p, sizeof( int ) * ( 1 + 24 * numCtu ) ) != hipSuccess ) { delete c; return VVR_ERR_DEVICE; } c->syncBuf.push_back( p ); }
   }
   c->slotUsers.resize( cfg->num_slots );
   *out = c;
@@ -322,16 +322,21 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
   std::vector<int32_t> order;
   std::vector<uint8_t> intraAt;          // per 4x4 luma unit: covered by an intra CU
-  std::vector<uint8_t> depMaskV( 3 * (size_t) numCtu, 0 );
-  std::vector<uint8_t> lumaReqV( 3 * (size_t) numCtu, 0 );   // CCLM: luma CTUs (L, AL, A, AR, SELF) whose reconstruction a chroma CTU reads
+  // Intra-stage work units: a unit is a run of consecutive blocks of one (component, CTU) that lie in the same quadrant of the CTU;
+  // one workgroup processes one unit.  Units depend on exactly those earlier units that produced a reference sample they read
+  // (inter samples are final before the stage starts), which the loop below finds through unitAt[].
   struct BBox { int y0 = 255, y1 = 0, c0 = 255, c1 = 0; };   // rows relative to (CTU top - 3), 8-sample chunks relative to (CTU left - 8), chunk index + 1
-  std::vector<BBox> bboxV( 3 * (size_t) numCtu );   // per (component, CTU): bit k set = must wait for neighbour k (L, AL, A, AR)
+  struct UnitH { uint32_t comp, ctu, i0, i1; int quad; BBox bb; std::vector<uint32_t> deps; bool waited = false; };
+  std::vector<UnitH> units;
+  int32_t curUnit[3] = { -1, -1, -1 }; int unitsInCtu[3] = { 0, 0, 0 };
+  std::vector<int32_t> unitAt[3];        // per component and 4x4 luma cell: the unit that reconstructs it in the intra stage (-1: none)
   bool anyIntra = false;
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || ( p->cu[i].flags & VVR_CU_CIIP );
   if( anyIntra )
   {
     order.assign( (size_t) w4 * h4 * 2, 0x7fffffff );
     intraAt.assign( (size_t) w4 * h4, 0 );
+    for( int k = 0; k < ncomp; k++ ) unitAt[k].assign( (size_t) w4 * h4, -1 );
     for( uint32_t i = 0; i < p->num_cu; i++ )
     {
       const vvr_cu& cu = p->cu[i];
@@ -366,7 +371,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     const uint32_t ctuOfCu = (uint32_t) ( ( cu.y >> h.log2_ctu ) * ctusX + ( cu.x >> h.log2_ctu ) );
     {
       if( ctuOfCu < curCtu ) { c->setError( "CUs are not in CTU raster order" ); return VVR_ERR_PARAMETER; }
-      while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
+      while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) { ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); curUnit[k] = -1; unitsInCtu[k] = 0; } }
     }
     const bool isCiip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
     if( cu.pred_mode == VVR_PRED_INTRA || isCiip )
@@ -394,6 +399,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           it.nTL = (uint8_t) unitAvail( chn, x0 - 1, y0 - 1, (int32_t) t );
           if( unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
           if( unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }
+          int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0; bool isCclm = false;
           if( comp && !isCiip && cu.intra_dir[1] >= 67 )
           {
             // CCLM / MDLM: template sizes and flags of IntraPrediction::xGetLMParameters (:1694-1800) and the border handling of
@@ -419,43 +425,58 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
             const int bLeft = leftCu ? 1 : 0;                                                          // availlableLeftUnit >= iTUHeightInUnits
             const int firstRow = ( tu.y & ( ( 1 << h.log2_ctu ) - 1 ) ) == 0;
             it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 );
-            // luma the prediction reads: the co-located block (this CTU) and the template rows / columns around it
-            const int S = ( 1 << h.log2_ctu ) >> 1, ox = ( cu.x >> h.log2_ctu ) * S, oy = ( cu.y >> h.log2_ctu ) * S;
-            uint8_t& rq = lumaReqV[(size_t) comp * numCtu + ctuOfCu];
-            rq |= 16;
-            const bool atL = x0 == ox, atT = y0 == oy;
-            if( atL && ( leftAvail || bLeft ) ) rq |= 1;
-            if( atT && aboveAvail ) rq |= 4;
-            if( atL && atT && aboveAvail && bLeft ) rq |= 2;
-            if( atT && aboveAvail && x0 + actualTop > ox + S ) rq |= 8;
+            cclmTop = aboveAvail ? actualTop : 0; cclmLeft = leftAvail ? actualLeft : 0; cclmBLeft = bLeft; isCclm = true;
           }
-          intra[comp].push_back( it );
+          // ---- unit of this block
           {
-            // which neighbouring CTUs hold INTRA samples this block reads (inter samples are final before the intra stage starts)
+            const int qsh = h.log2_ctu - 1 - cs;                                              // quadrant size in component samples
+            const int quad = ( ( ( y0 >> qsh ) & 1 ) << 1 ) | ( ( x0 >> qsh ) & 1 );
+            static const int maxUnitsPerCtu = getenv( "VVR_INTRA_UNITS_PER_CTU" ) ? atoi( getenv( "VVR_INTRA_UNITS_PER_CTU" ) ) : 1;
+            if( curUnit[comp] < 0 || ( units[curUnit[comp]].quad != quad && unitsInCtu[comp] < maxUnitsPerCtu ) )
+            {
+              UnitH u; u.comp = (uint32_t) comp; u.ctu = ctuOfCu; u.i0 = u.i1 = (uint32_t) intra[comp].size(); u.quad = quad;
+              units.push_back( u ); curUnit[comp] = (int32_t) units.size() - 1; unitsInCtu[comp]++;
+            }
+          }
+          UnitH& U = units[curUnit[comp]];
+          const uint32_t uId = (uint32_t) curUnit[comp];
+          intra[comp].push_back( it );
+          U.i1 = (uint32_t) intra[comp].size();
+          {
             const int ctuX = cu.x >> h.log2_ctu, ctuY = cu.y >> h.log2_ctu;
             const int mrl = comp ? 0 : cu.multi_ref_idx;
-            auto touch = [&]( int xc, int yc )   // component coordinates of a reference sample
+            auto addDep = [&]( int32_t d ) { if( d >= 0 && (uint32_t) d != uId && std::find( U.deps.begin(), U.deps.end(), (uint32_t) d ) == U.deps.end() ) U.deps.push_back( (uint32_t) d ); };
+            auto touch = [&]( int k, int xc, int yc )   // component k, component coordinates of a sample that is read
             {
-              const int lx = xc << cs, ly = yc << cs;
+              const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
               if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
-              if( !intraAt[(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )] ) return;
-              const int dx = ( lx >> h.log2_ctu ) - ctuX, dy = ( ly >> h.log2_ctu ) - ctuY;
-              uint8_t& m = depMaskV[(size_t) comp * numCtu + ctuOfCu];
-              if( dx == -1 && dy == 0 ) m |= 1; else if( dx == -1 && dy == -1 ) m |= 2; else if( dx == 0 && dy == -1 ) m |= 4; else if( dx == 1 && dy == -1 ) m |= 8;
+              addDep( unitAt[k][(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )] );
             };
             {
               // bounding box of everything the kernel's reference fill may read for this block (whole top / left lines incl. padding sources)
               const int S = ( 1 << h.log2_ctu ) >> cs, ox = ctuX * S, oy = ctuY * S;
-              BBox& bb = bboxV[(size_t) comp * numCtu + ctuOfCu];
+              BBox& bb = U.bb;
               const int rx0 = x0 - 1 - mrl, rx1 = x0 + std::max( 2 * w, 1 ) + 1, ry0 = y0 - 1 - mrl, ry1 = y0 + 2 * hh + 1;
               bb.y0 = std::min( bb.y0, std::max( 0, ry0 - ( oy - 3 ) ) );
               bb.y1 = std::max( bb.y1, std::min( S + 3, ry1 - ( oy - 3 ) ) );
               bb.c0 = std::min( bb.c0, std::max( 0, ( rx0 - ( ox - 8 ) ) >> 3 ) );
               bb.c1 = std::max( bb.c1, std::min( ( 8 + S + 64 + 7 ) >> 3, ( rx1 - ( ox - 8 ) + 7 ) >> 3 ) );
             }
-            if( it.nTL ) touch( x0 - 1 - mrl, y0 - 1 - mrl );
-            for( int k = 0; k < it.nA * unit; k += unit ) touch( x0 + k, y0 - 1 - mrl );
-            for( int k = 0; k < it.nL * unit; k += unit ) touch( x0 - 1 - mrl, y0 + k );
+            if( it.nTL ) touch( comp, x0 - 1 - mrl, y0 - 1 - mrl );
+            for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, x0 + k, y0 - 1 - mrl );
+            for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, x0 - 1 - mrl, y0 + k );
+            if( isCiip ) for( int yy = 0; yy < hh; yy += unit ) for( int xx = 0; xx < w; xx += unit ) touch( comp, x0 + xx, y0 + yy );   // (never produced by the intra stage: no-op, kept for symmetry)
+            if( isCclm )
+            {
+              // luma the prediction reads: the co-located block and the template rows / columns around it (luma coordinates)
+              const int lx0 = x0 << 1, ly0 = y0 << 1;
+              for( int yy = 0; yy < 2 * hh; yy += 4 ) for( int xx = ( cclmBLeft ? -4 : 0 ); xx < 2 * w; xx += 4 ) touch( 0, lx0 + xx, ly0 + yy );
+              for( int xx = ( cclmBLeft ? -4 : 0 ); xx < 2 * cclmTop + 4; xx += 4 ) touch( 0, lx0 + xx, ly0 - 1 );
+              for( int yy = 0; yy < 2 * cclmLeft + 4; yy += 4 ) touch( 0, lx0 - 1, ly0 + yy );
+            }
+            // the cells this block reconstructs
+            for( int yy = 0; yy < ( hh << cs ); yy += 4 ) for( int xx = 0; xx < ( w << cs ); xx += 4 )
+              if( ( x0 << cs ) + xx < h.width && ( y0 << cs ) + yy < h.height ) unitAt[comp][(size_t) ( ( ( y0 << cs ) + yy ) >> 2 ) * w4 + ( ( ( x0 << cs ) + xx ) >> 2 )] = (int32_t) uId;
           }
           bytes[K_INTRA] += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
         }
@@ -508,75 +529,51 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   while( curCtu < (uint32_t) numCtu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
   // one item array for the three components; ctuStart holds offsets into it; active (component, CTU) pairs in raster order
   std::vector<IntraItem> intraAll;
-  std::vector<uint32_t> activeV;
   for( int k = 0; k < 3; k++ )
   {
     const uint32_t base = (uint32_t) intraAll.size();
     intraAll.insert( intraAll.end(), intra[k].begin(), intra[k].end() );
     for( int a = 0; a <= numCtu; a++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + a] += base;
   }
-  for( int a = 0; a < numCtu; a++ ) for( int k = 0; k < 3; k++ )
-    if( ctuStartV[(size_t) k * ( numCtu + 1 ) + a + 1] > ctuStartV[(size_t) k * ( numCtu + 1 ) + a] ) activeV.push_back( ( (uint32_t) k << 24 ) | (uint32_t) a );
+  // device unit table: units that wait for nothing first (they can never block a resident workgroup slot), then the others in
+  // coding order; a unit only ever waits for units created before it, so every dependency holds a lower ticket
+  std::vector<IntraUnit> unitsDev;
   {
-    // per active (component, CTU): dependency mask; bit 31 of the entry = every sample of the CTU is intra, so the kernel only
-    // stages the reference border (single tree: the same CUs cover all three components)
-    const size_t na = activeV.size();
-    const int ctu4 = 1 << ( h.log2_ctu - 2 );
-    for( size_t t = 0; t < na; t++ )
+    const uint32_t itemBase[3] = { ctuStartV[0], ctuStartV[(size_t) 1 * ( numCtu + 1 )], ctuStartV[(size_t) 2 * ( numCtu + 1 )] };
+    std::vector<uint32_t> perm, inv( units.size() );
+    for( size_t t = 0; t < units.size(); t++ ) if( units[t].deps.empty() ) perm.push_back( (uint32_t) t );
     {
-      const uint32_t k = activeV[t] >> 24, a = activeV[t] & 0xffffff;
-      const int ux = (int) ( a % ctusX ) * ctu4, uy = (int) ( a / ctusX ) * ctu4;
-      bool all = true;
-      for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
-      if( all ) activeV[t] |= 0x80000000u;
-      // bits 0..3: neighbours of the same component; bits 4..8: LUMA of the left / above-left / above / above-right / same CTU (CCLM),
-      // only where that luma CTU takes part in the intra stage at all (otherwise its samples are final already)
-      uint32_t dm = depMaskV[(size_t) k * numCtu + a];
-      const uint8_t rq = lumaReqV[(size_t) k * numCtu + a];
-      const int nbx[5] = { -1, -1, 0, 1, 0 }, nby[5] = { 0, -1, -1, -1, 0 };
-      for( int b = 0; b < 5; b++ )
+      // dependent units in WAVEFRONT order (key = ctuX + 2 * ctuY, ties in coding order): every dependency (left, above-left, above,
+      // above-right CTU, or an earlier unit of the same CTU) has a smaller key or comes earlier at the same key, so it holds a lower
+      // ticket, and the workgroups that are resident at any time are the ones on or near the current wavefront
+      std::vector<uint32_t> dep;
+      for( size_t t = 0; t < units.size(); t++ ) if( !units[t].deps.empty() ) dep.push_back( (uint32_t) t );
+      std::stable_sort( dep.begin(), dep.end(), [&]( uint32_t a, uint32_t b )
+      { return (int) ( units[a].ctu % ctusX ) + 2 * (int) ( units[a].ctu / ctusX ) < (int) ( units[b].ctu % ctusX ) + 2 * (int) ( units[b].ctu / ctusX ); } );
+      perm.insert( perm.end(), dep.begin(), dep.end() );
+    }
+    for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
+    for( auto& u : units ) for( uint32_t d : u.deps ) units[d].waited = true;
+    std::vector<uint8_t> unitCount( 3 * (size_t) numCtu, 0 );
+    for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
+    unitsDev.resize( units.size() );
+    for( size_t t = 0; t < perm.size(); t++ )
+    {
+      const UnitH& u = units[perm[t]];
+      IntraUnit& d = unitsDev[t]; memset( &d, 0, sizeof( d ) );
+      // bit 31: the unit is the whole (component, CTU) and every sample of the CTU is intra, so the kernel only stages the reference
+      // border and writes the CTU back with 16-byte stores
+      bool all = unitCount[(size_t) u.comp * numCtu + u.ctu] == 1;
       {
-        if( !( rq & ( 1 << b ) ) ) continue;
-        const int nx = (int) ( a % ctusX ) + nbx[b], ny = (int) ( a / ctusX ) + nby[b];
-        if( nx < 0 || ny < 0 || nx >= ctusX ) continue;
-        const size_t n = (size_t) ny * ctusX + nx;
-        if( ctuStartV[n + 1] > ctuStartV[n] ) dm |= 16u << b;
+        const int ctu4 = 1 << ( h.log2_ctu - 2 ), ux = (int) ( u.ctu % ctusX ) * ctu4, uy = (int) ( u.ctu / ctusX ) * ctu4;
+        for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
       }
-      activeV.push_back( dm );
-    }
-    // bit 30 of an entry: some other (component, CTU) waits for this one, so it has to publish its flag (agent-scope release);
-    // CTUs nobody depends on skip the fence
-    {
-      std::vector<uint8_t> waited( 3 * (size_t) numCtu, 0 );
-      const int nbx[5] = { -1, -1, 0, 1, 0 }, nby[5] = { 0, -1, -1, -1, 0 };
-      for( size_t t = 0; t < na; t++ )
-      {
-        const uint32_t k = ( activeV[t] >> 24 ) & 3, a = activeV[t] & 0xffffff, dm = activeV[na + t];
-        for( int b = 0; b < 9; b++ )
-        {
-          if( !( dm & ( 1u << b ) ) ) continue;
-          const int q = b < 4 ? b : b - 4, kk = b < 4 ? (int) k : 0;
-          const int nx = (int) ( a % ctusX ) + nbx[q], ny = (int) ( a / ctusX ) + nby[q];
-          if( nx >= 0 && ny >= 0 && nx < ctusX ) waited[(size_t) kk * numCtu + (size_t) ny * ctusX + nx] = 1;
-        }
-      }
-      for( size_t t = 0; t < na; t++ ) if( waited[(size_t) ( ( activeV[t] >> 24 ) & 3 ) * numCtu + ( activeV[t] & 0xffffff )] ) activeV[t] |= 0x40000000u;
-    }
-    for( size_t t = 0; t < na; t++ )
-    {
-      const BBox& bb = bboxV[(size_t) ( ( activeV[t] >> 24 ) & 3 ) * numCtu + ( activeV[t] & 0xffffff )];
-      activeV.push_back( (uint32_t) bb.y0 | ( (uint32_t) bb.y1 << 8 ) | ( (uint32_t) bb.c0 << 16 ) | ( (uint32_t) bb.c1 << 24 ) );
-    }
-    // ticket order: CTUs that wait for nothing first (they can never block a resident workgroup slot), then the others in raster
-    // order.  Every CTU a workgroup may wait for still holds a lower ticket: it is either independent (first group) or an earlier
-    // CTU of the second group.
-    {
-      std::vector<uint32_t> perm; perm.reserve( na );
-      for( size_t t = 0; t < na; t++ ) if( activeV[na + t] == 0 ) perm.push_back( (uint32_t) t );
-      for( size_t t = 0; t < na; t++ ) if( activeV[na + t] != 0 ) perm.push_back( (uint32_t) t );
-      std::vector<uint32_t> re( 3 * na );
-      for( size_t t = 0; t < na; t++ ) for( int part = 0; part < 3; part++ ) re[part * na + t] = activeV[part * na + perm[t]];
-      activeV.swap( re );
+      d.ent = ( u.comp << 24 ) | u.ctu | ( u.waited ? 0x40000000u : 0 ) | ( all ? 0x80000000u : 0 );
+      d.i0 = itemBase[u.comp] + u.i0; d.i1 = itemBase[u.comp] + u.i1;
+      d.bbox = (uint32_t) u.bb.y0 | ( (uint32_t) u.bb.y1 << 8 ) | ( (uint32_t) u.bb.c0 << 16 ) | ( (uint32_t) u.bb.c1 << 24 );
+      d.ndeps = (uint32_t) std::min<size_t>( u.deps.size(), VVR_INTRA_MAX_DEPS );
+      if( u.deps.size() > VVR_INTRA_MAX_DEPS ) { c->setError( "internal: intra unit with too many dependencies" ); return VVR_ERR_UNSPECIFIED; }
+      for( uint32_t k = 0; k < d.ndeps; k++ ) d.deps[k] = inv[u.deps[k]];
     }
   }
   const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
@@ -621,7 +618,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   int iTbS[3]; for( int k = 0; k < 3; k++ ) iTbS[k] = add( tbS[k].data(), sizeof( TbItem ) * tbS[k].size() );
   const int iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
   const int iCtuStart = add( ctuStartV.data(), sizeof( uint32_t ) * ctuStartV.size() );
-  const int iActive = add( activeV.data(), sizeof( uint32_t ) * activeV.size() );
+  const int iActive = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
 
   vvr_prepared* q = new vvr_prepared();
   q->hdr = h;
@@ -654,7 +651,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   for( int k = 0; k < 3; k++ ) { q->tbStore[k] = (TbItem*) ( base + parts[iTbS[k]].off ); q->numTbStore[k] = (int) tbS[k].size(); }
   q->intraItems = (IntraItem*) ( base + parts[iIntra].off ); q->numIntra = (int) intraAll.size();
   q->ctuStart = (uint32_t*) ( base + parts[iCtuStart].off );
-  q->active = (uint32_t*) ( base + parts[iActive].off ); q->numActive = (int) activeV.size() / 3;
+  q->units = (IntraUnit*) ( base + parts[iActive].off ); q->numActive = (int) unitsDev.size();
   memcpy( q->bytes, bytes, sizeof( bytes ) );
   *out = q;
   return VVR_OK;
@@ -728,7 +725,7 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
   if( q->numTb[0] + q->numTb[1] + q->numTb[2] + q->numTbStore[0] + q->numTbStore[1] + q->numTbStore[2] )
     timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) { launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); launch_itrans( s, q->pic, A, R, q->tbStore[k], q->numTbStore[k], 16 << k ); } } );
   // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)
-  if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->ctuStart, q->active, q->numActive, c->syncBuf[lane] ); } );
+  if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->units, q->numActive, c->syncBuf[lane] ); } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
   if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)

@@ -54,6 +54,17 @@ struct IntraItem {        // 16 bytes, self-contained: the kernel never touches 
   uint32_t tu;
 };
 
+// One unit of the intra stage (a run of blocks of one component inside one CTU quadrant), processed by one workgroup.
+#define VVR_INTRA_MAX_DEPS 26
+struct IntraUnit {
+  uint32_t ent;           // (component << 24) | CTU address; bit 30: another unit waits for this one (it must publish its flag)
+  uint32_t i0, i1;        // item range
+  uint32_t bbox;          // part of the CTU tile the unit's blocks read: y0 | y1 << 8 | c0 << 16 | c1 << 24 (rows from CTU top - 3, 16-byte chunks from CTU left - 8, chunk + 1)
+  uint32_t ndeps;
+  uint32_t deps[VVR_INTRA_MAX_DEPS];   // tickets (= indices into the unit table) this unit waits for
+  uint32_t pad;                        // 32 dwords
+};
+
 struct PicDev {         // everything a kernel needs about one picture (passed by value)
   vvr_pic_header     hdr;
   const vvr_cu*      cu;
@@ -81,4 +92,4 @@ void launch_lmcs   ( hipStream_t s, const PicDev& pic, DevPlanes reco, int inver
 void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst );
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );
-void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const uint32_t* ctuStart, const uint32_t* active, int numActive, int* sync );
+void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numUnits, int* sync );

@@ -1852,8 +1852,8 @@ __device__ __forceinline__ void intra_stash_resi( const IntraItem& it, int16_t* 
 }
 
 __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, DevPlanes resi, const IntraItem* __restrict__ items,
-                                                  const uint32_t* __restrict__ ctuStart /* [3][numCtu+1] */, const uint32_t* __restrict__ active /* [numActive] entries, then [numActive] dependency masks */, int numActive,
-                                                  int* __restrict__ sync /* [0]: ticket, [1 + comp*numCtu + ctu]: done flags */, int dbg )
+                                                  const IntraUnit* __restrict__ units, int numActive,
+                                                  int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */, int dbg )
 {
   __shared__ IntraShared sh;
   const int tid = threadIdx.x;
@@ -1865,10 +1865,11 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   __syncthreads();
   const int ticket = sh.ticket;
   if( ticket >= numActive ) return;
-  const uint32_t ent = active[ticket];
+  const IntraUnit* __restrict__ un = &units[ticket];
+  const uint32_t ent = un->ent;
   const int comp = ( ent >> 24 ) & 3, ctu = ent & 0xffffff;
-  const bool borderOnly = ( ent >> 31 ) != 0;          // every sample of the CTU is intra: the interior is produced here, never read first
-  const bool publish = ( ( ent >> 30 ) & 1 ) != 0;     // another CTU waits for this one
+  const bool borderOnly = ( ent >> 31 ) != 0;          // whole CTU, every sample intra: the interior is produced here, never read first
+  const bool publish = ( ( ent >> 30 ) & 1 ) != 0;     // another unit waits for this one
   const int cxI = ctu % pic.ctus_x, cyI = ctu / pic.ctus_x;
   const int cs = comp ? 1 : 0;
   const int S = ( 1 << pic.hdr.log2_ctu ) >> cs;
@@ -1878,31 +1879,18 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   pel_t* __restrict__ plane = reco.p[comp];
   const pel_t* __restrict__ rs = resi.p[comp];
   const int rstride = resi.stride[comp];
-  const uint32_t i0 = ctuStart[comp * ( numCtu + 1 ) + ctu], i1 = ctuStart[comp * ( numCtu + 1 ) + ctu + 1];
+  const uint32_t i0 = un->i0, i1 = un->i1;
 #define TILE( x, y ) sh.tile[( ( y ) - oy + IT_PAD ) * IT_TS + ( ( x ) - ox + IT_PADX )]
-  // ---- wait for the CTUs this one reads INTRA samples from (the host glue marks which of L, AL, A, AR those are)
+  // ---- wait for the units that produce intra samples this one reads (same component: reference lines; luma: CCLM)
   if( tid == 0 )
   {
-    const uint32_t depMask = ( dbg & 1 ) ? 0 : active[numActive + ticket];
-    const int nb[4][2] = { { -1, 0 }, { -1, -1 }, { 0, -1 }, { 1, -1 } };
-    for( int k = 0; k < 4; k++ )
+    const uint32_t nd = ( dbg & 1 ) ? 0 : un->ndeps;
+    for( uint32_t k = 0; k < nd; k++ )
     {
-      if( !( depMask & ( 1u << k ) ) ) continue;
-      const int nx = cxI + nb[k][0], ny = cyI + nb[k][1];
-      const int n = ny * pic.ctus_x + nx;
-      int* flag = &sync[1 + comp * numCtu + n];
-      while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 30 );
+      int* flag = &sync[1 + un->deps[k]];
+      while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 8 );
     }
-    // CCLM: the luma of this CTU and of the neighbours its templates reach (bits 4..8: L, AL, A, AR, SELF)
-    const int nbl[5][2] = { { -1, 0 }, { -1, -1 }, { 0, -1 }, { 1, -1 }, { 0, 0 } };
-    for( int k = 0; k < 5; k++ )
-    {
-      if( !( depMask & ( 16u << k ) ) ) continue;
-      const int n = ( cyI + nbl[k][1] ) * pic.ctus_x + cxI + nbl[k][0];
-      int* flag = &sync[1 + n];
-      while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 30 );
-    }
-    if( depMask ) __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );      // nothing produced by another workgroup is read otherwise
+    if( nd ) __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );      // nothing produced by another workgroup is read otherwise
   }
   __syncthreads();
   // ---- stage the needed part of the CTU and its reference border in LDS
@@ -1910,7 +1898,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     // 16-byte chunks (8 samples); plane rows are 128-byte aligned and padded to a multiple of 64 samples, so a chunk that
     // straddles the picture's right edge stays inside the row allocation (those samples are never used).
     // bbox (host glue): rows / chunks that hold reference samples of this CTU's blocks, relative to (oy - IT_PAD, ox - IT_PADX)
-    const uint32_t bb = active[2 * numActive + ticket];
+    const uint32_t bb = un->bbox;
     const int y0 = max( 0, oy - IT_PAD ), y1 = min( PH, oy + S );
     const int c0 = ox >= IT_PADX ? -1 : 0;                                  // first chunk relative to ox / 8
     const int c1 = ( min( PW, ox + S + IT_RIGHT ) - ox + 7 ) >> 3;           // one past the last chunk
@@ -2374,15 +2362,14 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   {
     __builtin_amdgcn_fence( __ATOMIC_RELEASE, "agent" );
     asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-    __hip_atomic_store( &sync[1 + comp * numCtu + ctu], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    __hip_atomic_store( &sync[1 + ticket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
   }
 }
 
-void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const uint32_t* ctuStart, const uint32_t* active, int numActive, int* sync )
+void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numActive, int* sync )
 {
   if( !numActive ) return;
-  const int numCtu = pic.ctus_x * pic.ctus_y;
-  hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + 3 * (size_t) numCtu ), s );
+  hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + (size_t) numActive ), s );
   static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
-  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, ctuStart, active, numActive, sync, dbg );
+  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync, dbg );
 }
