@@ -68,6 +68,51 @@ static int tu_residuals( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu*
   return mask;
 }
 
+/* LMCS chroma residual scaling factor of the VPDU that contains luma position (x, y):
+ * Reshape::calculateChromaAdjVpduNei (Reshape.cpp:192-274), getPWLIdxInv (:280), calculateChromaAdj (:182).
+ * cuAt: index of the CU covering each 4x4 luma cell.  The neighbouring luma samples are reconstructed (mapped domain) samples of
+ * CUs that precede the VPDU in decoding order. */
+static int lmcs_chroma_scale( const vvr_picture* pic, const vvo_planes* reco, const int32_t* cuAt, int x, int y )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int ctu = 1 << H->log2_ctu, w4 = ( H->width + 3 ) >> 2;
+  const int n = ctu < 64 ? ctu : 64, nLog = vvo_log2( n );
+  int xPos = x & ~( n - 1 ), yPos = y & ~( n - 1 );
+  const int32_t tlIdx = cuAt[(size_t) ( yPos >> 2 ) * w4 + ( xPos >> 2 )];
+  const vvr_cu* tl = &pic->cu[tlIdx];
+  xPos = tl->x; yPos = tl->y;
+  /* CodingStructure::getCURestricted (CodingStructure.cpp:464-499), one slice, one tile: a neighbour inside the same CTU only counts
+   * if it precedes the CU at the VPDU origin in decoding order */
+  int hasLeft = xPos > 0, hasAbove = yPos > 0;
+  if( hasLeft && ( ( xPos - 1 ) >> H->log2_ctu ) == ( xPos >> H->log2_ctu ) && cuAt[(size_t) ( yPos >> 2 ) * w4 + ( ( xPos - 1 ) >> 2 )] > tlIdx ) hasLeft = 0;
+  if( hasAbove && ( ( yPos - 1 ) >> H->log2_ctu ) == ( yPos >> H->log2_ctu ) && cuAt[(size_t) ( ( yPos - 1 ) >> 2 ) * w4 + ( xPos >> 2 )] > tlIdx ) hasAbove = 0;
+  const pel* Y = reco->p[0]; const int st = reco->stride[0];
+  int recLuma = 0, pelnum = 0;
+  if( hasLeft )  for( int i = 0; i < n; i++ ) { const int k = ( yPos + i ) >= H->height ? H->height - yPos - 1 : i; recLuma += Y[(size_t) ( yPos + k ) * st + xPos - 1]; pelnum++; }
+  if( hasAbove ) for( int i = 0; i < n; i++ ) { const int k = ( xPos + i ) >= H->width  ? H->width  - xPos - 1 : i; recLuma += Y[(size_t) ( yPos - 1 ) * st + xPos + k]; pelnum++; }
+  int lumaValue;
+  if( pelnum == n ) lumaValue = ( recLuma + ( 1 << ( nLog - 1 ) ) ) >> nLog;
+  else if( pelnum == 2 * n ) lumaValue = ( recLuma + ( 1 << nLog ) ) >> ( nLog + 1 );
+  else lumaValue = 1 << ( H->bit_depth - 1 );
+  int idx = pic->lmcs->min_bin;
+  for( ; idx <= pic->lmcs->max_bin; idx++ ) if( lumaValue < pic->lmcs->pivot[idx + 1] ) break;
+  if( idx > 15 ) idx = 15;
+  return pic->lmcs->chroma_scale[idx];
+}
+
+/* AreaBuf::scaleSignal (Buffer.cpp:412) */
+static void lmcs_scale_residual( int16_t* r, int n, int scale, int bd )
+{
+  const int maxAbs = ( 1 << bd ) - 1;
+  for( int i = 0; i < n; i++ )
+  {
+    int v = vvo_clip3( -maxAbs - 1, maxAbs, r[i] );
+    const int sign = v >= 0 ? 1 : -1, a = sign * v;
+    v = sign * ( ( a * scale + ( 1 << 10 ) ) >> 11 );
+    r[i] = (int16_t) vvo_clip3( -32768, 32767, v );
+  }
+}
+
 int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, uint16_t* const* out_planes, int flags )
 {
   vvo_dmvr_reset();
@@ -83,6 +128,7 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
   memset( &reco, 0, sizeof( reco ) ); memset( &flt, 0, sizeof( flt ) );
   int16_t* resi[3] = { 0, 0, 0 };
   int32_t* order = 0;
+  int32_t* cuAt = 0;
   if( H->slice_type != 2 )
     for( int l = 0; l < 2; l++ ) for( int i = 0; i < H->num_ref[l]; i++ )
     {
@@ -120,6 +166,21 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
     }
   }
 
+  /* CU covering every 4x4 luma cell (LMCS chroma scaling looks up the CU at the VPDU origin) */
+  cuAt = (int32_t*) malloc( sizeof( int32_t ) * (size_t) w4 * h4 );
+  for( uint32_t i = 0; i < pic->num_cu; i++ )
+  {
+    const vvr_cu* cu = &pic->cu[i];
+    for( int y = cu->y; y < cu->y + cu->h && y < Hh; y += 4 ) for( int x = cu->x; x < cu->x + cu->w && x < W; x += 4 ) cuAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) i;
+  }
+  const int cscale = ( H->tool_flags & VVR_TOOL_LMCS ) && ( H->tool_flags & VVR_TOOL_LMCS_CSCALE ) && pic->lmcs && ncomp == 3;
+#define CSCALE_TU( tu_, mask_ ) \
+  if( cscale && ( ( mask_ ) & 6 ) && ( tu_->w >> 1 ) * ( tu_->h >> 1 ) > 4 ) \
+  { \
+    const int sc = lmcs_chroma_scale( pic, &reco, cuAt, tu_->x, tu_->y ); \
+    for( int c = 1; c < 3; c++ ) if( ( mask_ ) & ( 1 << c ) ) lmcs_scale_residual( resi[c], bw[c] * bh[c], sc, H->bit_depth ); \
+  }
+
   /* ---- INTER + INTRA stages */
   for( uint32_t i = 0; i < pic->num_cu; i++ )
   {
@@ -149,7 +210,10 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
         const int mask = ( cu->flags & VVR_CU_ROOT_CBF ) ? tu_residuals( pic, cu, tu, resi, bw, bh ) : 0;
         if( mask < 0 ) goto done;
         for( int c = 0; c < ncomp; c++ )
+        {
+          if( c == 1 ) { CSCALE_TU( tu, mask ) }            /* after the luma of this TU (finishLMCSAndReco order, DecCu.cpp:498-512) */
           if( vvo_intra_tu( pic, &icu, tu, cu->first_tu, c, &reco, order, resi[c], ( mask >> c ) & 1, wIntra ) ) goto done;
+        }
       }
       else if( cu->flags & VVR_CU_ROOT_CBF )
         for( uint32_t t = cu->first_tu; t < cu->first_tu + cu->num_tu; t++ )
@@ -160,6 +224,7 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
           if( mask < 0 ) goto done;
           for( int c = 0; c < ncomp; c++ )
           {
+            if( c == 1 ) { CSCALE_TU( tu, mask ) }
             if( !( mask & ( 1 << c ) ) ) continue;
             /* AreaBuf::reconstruct (Buffer.cpp:482): reco = clip( pred + resi ) */
             const int bx = tu->x >> ( c ? 1 : 0 ), by = tu->y >> ( c ? 1 : 0 );
@@ -181,6 +246,7 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
         if( mask < 0 ) goto done;
         for( int c = 0; c < ncomp; c++ )
         {
+          if( c == 1 ) { CSCALE_TU( tu, mask ) }
           if( !( tu->comp_mask & ( 1 << c ) ) ) continue;
           if( vvo_intra_tu( pic, cu, tu, t, c, &reco, order, resi[c], ( mask >> c ) & 1, 0 ) ) goto done;
         }
@@ -191,7 +257,6 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
 
   if( ( H->tool_flags & VVR_TOOL_LMCS ) && pic->lmcs )
   {   /* inverse luma mapping of the whole picture (Reshape::rspCtuBcw :376, applyLutCore Buffer.cpp:200) */
-    if( H->tool_flags & VVR_TOOL_LMCS_CSCALE ) { vvo_set_error( "LMCS chroma residual scaling is not restated" ); goto done; }
     for( size_t k = 0; k < (size_t) reco.stride[0] * reco.h[0]; k++ ) reco.p[0][k] = pic->lmcs->inv_lut[reco.p[0][k] & 4095];
   }
   if( !( flags & VVO_STOP_AFTER_RECO ) )
@@ -211,6 +276,6 @@ done:
   for( int s = 0; s < numSlots; s++ ) vvo_planes_free( &refs[s] );
   free( refs ); vvo_planes_free( &reco ); vvo_planes_free( &flt );
   for( int c = 0; c < 3; c++ ) free( resi[c] );
-  free( order );
+  free( order ); free( cuAt );
   return rc;
 }

@@ -195,9 +195,11 @@ def test_mip(built):
     _run_stream(1920, 1080, 3, 2, 194, TOOLS_A, intra=True, streams=3, p_mip=0.4, p_cclm=0.2)
 
 
-def test_lmcs_luma_mapping(built):
-    """LMCS luma mapping: inter prediction forward-mapped, intra in the mapped domain, inverse mapping before the loop filters"""
-    T = TOOLS_A | abi.TOOL_LMCS
+@pytest.mark.parametrize("cscale", [0, 1])
+def test_lmcs(built, cscale):
+    """LMCS: inter prediction forward-mapped, intra in the mapped domain, inverse mapping before the loop filters; with cscale
+    the chroma residuals are scaled by a factor looked up from the reconstructed luma around the 64x64 VPDU"""
+    T = TOOLS_A | abi.TOOL_LMCS | (abi.TOOL_LMCS_CSCALE if cscale else 0)
     _run_stream(256, 128, 5, 4, 201, T, intra=True, p_intra=0.3, p_cclm=0.2, p_mip=0.2, p_ciip=0.1)
     _run_stream(416, 240, 5, 4, 202, T, intra=True, p_intra=0.2, log2_ctu=6, p_affine=0.1, p_geo=0.1, p_sbtmvp=0.1, p_ciip=0.1)
     _run_stream(1920, 1080, 3, 2, 203, T, intra=True, streams=3)
@@ -206,8 +208,7 @@ def test_lmcs_luma_mapping(built):
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)
-    p = synth.default_params(width=128, height=64, seed=1, tool_flags=abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, slice_type=abi.SLICE_B)
-    synth.set_refs(p, [(1, -1)], [(1, -1)])
+    p = synth.default_params(width=128, height=64, seed=1, tool_flags=abi.TOOL_CCLM_COLLOC, slice_type=abi.SLICE_I, p_cclm=1.0)
     d = synth.generate(p)
     with pytest.raises(vvdec_amd.VvrError):
         rec.decompress_picture(d)

@@ -53,9 +53,9 @@ def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
             assert np.array_equal(refdrv.oracle_dmvr(nd), r["dmvr"][:nd]), "DMVR delta MVs differ"
 
 
-@pytest.mark.parametrize("idx,seed", [(0, 201), (2, 202), (3, 203)])
-def test_oracle_equals_reference_lmcs(built, idx, seed):
-    d, refs = _case(256, 192, 7, idx, seed, tools=ALL | abi.TOOL_LMCS, p_intra=0.3, p_cclm=0.2, p_mip=0.2, p_ciip=0.1, p_affine=0.1, p_geo=0.1)
+@pytest.mark.parametrize("idx,seed,cs", [(0, 201, 0), (2, 202, 0), (3, 203, 1), (0, 204, 1), (2, 205, 1)])
+def test_oracle_equals_reference_lmcs(built, idx, seed, cs):
+    d, refs = _case(256, 192, 7, idx, seed, tools=ALL | abi.TOOL_LMCS | (abi.TOOL_LMCS_CSCALE if cs else 0), p_intra=0.3, p_cclm=0.2, p_mip=0.2, p_ciip=0.1, p_affine=0.1, p_geo=0.1, p_coded_chroma=0.5)
     for fl in STAGES:
         want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
         got = refdrv.oracle_reconstruct(d, refs, flags=fl)

@@ -434,6 +434,8 @@ struct Gen {
     {
       // implicit boundary split: quad when possible, else binary in the crossing direction
       if( w > minS && h > minS && ( ( crossX && crossY ) || w == h ) ) { const int hw = w >> 1, hh = h >> 1; split( x, y, hw, hh ); split( x + hw, y, hw, hh ); split( x, y + hh, hw, hh ); split( x + hw, y + hh, hw, hh ); }
+      else if( w <= 64 && h > 64 ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); }                 // (VPDU rule first)
+      else if( w > 64 && h <= 64 ) { split( x, y, w >> 1, h ); split( x + ( w >> 1 ), y, w >> 1, h ); }
       else if( crossX && w > minS ) { split( x, y, w >> 1, h ); split( x + ( w >> 1 ), y, w >> 1, h ); }
       else if( crossY && h > minS ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); }
       return;
@@ -446,14 +448,19 @@ struct Gen {
     if( rng.p( ps ) )
     {
       const int r = rng.u( 100 );
-      const bool canQ = w == h && w > minS, canH = h > minS, canV = w > minS;
-      const bool canTH = h >= 4 * minS && h <= 64, canTV = w >= 4 * minS && w <= 64;
+      // VPDU rules of the standard (every 64x64 region is decoded completely before the next one, or a CU covers whole regions):
+      // no vertical binary split of a block that is at most 64 wide but taller than 64, no horizontal one of a block wider than 64 but
+      // at most 64 tall, ternary splits only inside 64x64
+      const bool canQ = w == h && w > minS, canH = h > minS && !( w > 64 && h <= 64 ), canV = w > minS && !( w <= 64 && h > 64 );
+      const bool canTH = h >= 4 * minS && h <= 64 && w <= 64, canTV = w >= 4 * minS && w <= 64 && h <= 64;
       if( canQ && r < 50 ) { const int hw = w >> 1; split( x, y, hw, hw ); split( x + hw, y, hw, hw ); split( x, y + hw, hw, hw ); split( x + hw, y + hw, hw, hw ); return; }
       if( canV && ( r < 68 || !canH ) ) { split( x, y, w >> 1, h ); split( x + ( w >> 1 ), y, w >> 1, h ); return; }
       if( canH && r < 86 ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); return; }
       if( canTV && r < 93 ) { split( x, y, w >> 2, h ); split( x + ( w >> 2 ), y, w >> 1, h ); split( x + 3 * ( w >> 2 ), y, w >> 2, h ); return; }
       if( canTH ) { split( x, y, w, h >> 2 ); split( x, y + ( h >> 2 ), w, h >> 1 ); split( x, y + 3 * ( h >> 2 ), w, h >> 2 ); return; }
       if( canH ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); return; }
+      if( canV ) { split( x, y, w >> 1, h ); split( x + ( w >> 1 ), y, w >> 1, h ); return; }
+      if( canQ ) { const int hw = w >> 1; split( x, y, hw, hw ); split( x + hw, y, hw, hw ); split( x, y + hw, hw, hw ); split( x + hw, y + hw, hw, hw ); return; }
     }
     addCu( x, y, w, h );
   }

@@ -44,7 +44,7 @@ struct vvr_prepared {        // a picture description resident in HBM together w
   McItem*  affItems = nullptr; int numAffItems = 0;        // tiles of affine CUs
   int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64 (TB_ADD: after MC)
-  TbItem*  tbStore[3] = { nullptr, nullptr, nullptr }; int numTbStore[3] = { 0, 0, 0 };   // residuals of intra blocks (TB_STORE)
+  TbItem*  tbStore[3] = { nullptr, nullptr, nullptr }; int numTbStore[3] = { 0, 0, 0 };   // LATE list: inter chroma blocks with LMCS chroma residual scaling (after the intra stage: the factor reads reconstructed luma)
   IntraItem* intraItems = nullptr; uint32_t* ctuStart = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
   double   bytes[K_NUM] = { 0 };
   bool     owned = false;
@@ -224,7 +224,7 @@ static int validate( vvr_context* c, const vvr_picture* p )
   { c->setError( "picture geometry differs from the context configuration" ); return VVR_ERR_PARAMETER; }
   if( ( h.width & 7 ) || ( h.height & 7 ) ) { c->setError( "picture size must be a multiple of 8 (minimum CU size)" ); return VVR_ERR_PARAMETER; }
   if( h.out_slot < 0 || h.out_slot >= c->cfg.num_slots ) { c->setError( "out_slot out of range" ); return VVR_ERR_PARAMETER; }
-  if( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) { c->setError( "LMCS chroma residual scaling is not implemented in this build (luma mapping is)" ); return VVR_ERR_UNSUPPORTED; }
+  if( ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && !( h.tool_flags & VVR_TOOL_LMCS ) ) { c->setError( "LMCS chroma residual scaling without LMCS" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & VVR_TOOL_LMCS ) && !p->lmcs ) { c->setError( "LMCS enabled without tables" ); return VVR_ERR_PARAMETER; }
   if( !p->cu || !p->tu || !p->coef || !p->lfp[0] || !p->lfp[1] ) { c->setError( "missing arrays" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & VVR_TOOL_ALF ) && ( !p->alf || !p->alf_params ) ) { c->setError( "ALF enabled without parameters" ); return VVR_ERR_PARAMETER; }
@@ -330,7 +330,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   std::vector<UnitH> units;
   int32_t curUnit[3] = { -1, -1, -1 }; int unitsInCtu[3] = { 0, 0, 0 };
   std::vector<int32_t> unitAt[3];        // per component and 4x4 luma cell: the unit that reconstructs it in the intra stage (-1: none)
-  bool anyIntra = false;
+  bool anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || ( p->cu[i].flags & VVR_CU_CIIP );
   if( anyIntra )
   {
@@ -363,6 +363,30 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     if( x < 0 || y < 0 || lx >= h.width || ly >= h.height ) return 0;
     return order[(size_t) chn * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
   };
+  // LMCS chroma residual scaling: per VPDU the luma neighbourhood its factor is averaged over (Reshape::calculateChromaAdjVpduNei,
+  // Reshape.cpp:192-274): left column / above row of the CU at the VPDU origin, where that neighbour precedes it in decoding order
+  const bool cscale = ( h.tool_flags & VVR_TOOL_LMCS ) && ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && ncomp == 3;
+  const int vpduLog2 = std::min<int>( 6, h.log2_ctu ), vpdusX = ( h.width + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2, vpdusY = ( h.height + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2;
+  std::vector<uint32_t> csVpduV;
+  if( cscale )
+  {
+    std::vector<int32_t> cuAt( (size_t) w4 * h4, -1 );
+    for( uint32_t i = 0; i < p->num_cu; i++ )
+    {
+      const vvr_cu& cu = p->cu[i];
+      for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) cuAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) i;
+    }
+    csVpduV.resize( (size_t) vpdusX * vpdusY );
+    for( int vy = 0; vy < vpdusY; vy++ ) for( int vx = 0; vx < vpdusX; vx++ )
+    {
+      const int32_t tl = cuAt[(size_t) ( ( vy << vpduLog2 ) >> 2 ) * w4 + ( ( vx << vpduLog2 ) >> 2 )];
+      const int xPos = p->cu[tl].x, yPos = p->cu[tl].y;
+      bool hasLeft = xPos > 0, hasAbove = yPos > 0;
+      if( hasLeft && ( ( xPos - 1 ) >> h.log2_ctu ) == ( xPos >> h.log2_ctu ) && cuAt[(size_t) ( yPos >> 2 ) * w4 + ( ( xPos - 1 ) >> 2 )] > tl ) hasLeft = false;
+      if( hasAbove && ( ( yPos - 1 ) >> h.log2_ctu ) == ( yPos >> h.log2_ctu ) && cuAt[(size_t) ( ( yPos - 1 ) >> 2 ) * w4 + ( xPos >> 2 )] > tl ) hasAbove = false;
+      csVpduV[(size_t) vy * vpdusX + vx] = (uint32_t) xPos | ( (uint32_t) yPos << 13 ) | ( hasLeft ? 1u << 26 : 0 ) | ( hasAbove ? 1u << 27 : 0 );
+    }
+  }
   uint32_t curCtu = 0;
   for( uint32_t i = 0; i < p->num_cu; i++ )
   {
@@ -374,7 +398,11 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) { ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); curUnit[k] = -1; unitsInCtu[k] = 0; } }
     }
     const bool isCiip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
-    if( cu.pred_mode == VVR_PRED_INTRA || isCiip )
+    // LMCS chroma residual scaling of an inter block: its factor reads reconstructed luma that the intra stage may still have to
+    // produce, and intra blocks next to it read its reconstructed chroma, so the residual add of such a block is an item of the
+    // intra stage too (IT_MODE_RESI_ADD: no prediction, scaled residual onto the inter prediction; finishLMCSAndReco, DecCu.cpp:483)
+    const bool isCsInter = cscale && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
+    if( cu.pred_mode == VVR_PRED_INTRA || isCiip || isCsInter )
     {
       for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
       {
@@ -382,6 +410,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         for( int comp = 0; comp < ncomp; comp++ )
         {
           if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
+          if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
           const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
           const int x0 = tu.x >> cs, y0 = tu.y >> cs, w = tu.w >> cs, hh = tu.h >> cs;
           const int totalAbove = ( 2 * w + unit - 1 ) / unit, totalLeft = ( 2 * hh + unit - 1 ) / unit;
@@ -389,18 +418,20 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           it.tu = t; it.comp = (uint8_t) comp;
           it.x = (uint16_t) x0; it.y = (uint16_t) y0;
           { int l = 0; while( ( 1 << l ) < w ) l++; it.lw = (uint8_t) l; l = 0; while( ( 1 << l ) < hh ) l++; it.lh = (uint8_t) l; }
-          it.mode = isCiip ? 0 : cu.intra_dir[chn];       // CIIP: planar
+          it.mode = isCsInter ? IT_MODE_RESI_ADD : isCiip ? 0 : cu.intra_dir[chn];       // CIIP: planar
           const bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
-          const int bdp = isCiip ? 0 : cu.bdpcm[chn];
+          const int bdp = ( isCiip || isCsInter ) ? 0 : cu.bdpcm[chn];
           // CIIP blend weight of the intra part (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:925-929): 1 + intra neighbours
           const int wIntra = isCiip ? 1 + ( cu.ciip_neigh_intra & 1 ) + ( ( cu.ciip_neigh_intra >> 1 ) & 1 ) : 0;
-          it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
+          it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip || isCsInter ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
           if( !comp && !isCiip && ( cu.flags & VVR_CU_MIP ) ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_MIP | ( ( cu.flags & VVR_CU_MIP_TRANSP ) ? 0x10 : 0 ) );
-          it.nTL = (uint8_t) unitAvail( chn, x0 - 1, y0 - 1, (int32_t) t );
-          if( unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
-          if( unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }
+          if( !isCsInter ) it.nTL = (uint8_t) unitAvail( chn, x0 - 1, y0 - 1, (int32_t) t );
+          if( !isCsInter && unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
+          if( !isCsInter && unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }
           int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0; bool isCclm = false;
-          if( comp && !isCiip && cu.intra_dir[1] >= 67 )
+          const bool csItem = cscale && comp && hasResi && w * hh > 4;             // DecCu.cpp:383-388 / :500-505
+          if( csItem ) it.flags |= IT_F_CSCALE;
+          if( comp && !isCiip && !isCsInter && cu.intra_dir[1] >= 67 )
           {
             // CCLM / MDLM: template sizes and flags of IntraPrediction::xGetLMParameters (:1694-1800) and the border handling of
             // xGetLumaRecPixels (:1403-1470); they ride in the item's `tu` word
@@ -466,6 +497,14 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
             for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, x0 + k, y0 - 1 - mrl );
             for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, x0 - 1 - mrl, y0 + k );
             if( isCiip ) for( int yy = 0; yy < hh; yy += unit ) for( int xx = 0; xx < w; xx += unit ) touch( comp, x0 + xx, y0 + yy );   // (never produced by the intra stage: no-op, kept for symmetry)
+            if( csItem )
+            {
+              // luma the chroma scaling factor is averaged over (the unit must wait for the luma units that reconstruct it)
+              const uint32_t d = csVpduV[(size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 )];
+              const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff, n = 1 << vpduLog2;
+              if( ( d >> 26 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, xPos - 1, std::min( yPos + k, (int) h.height - 1 ) );
+              if( ( d >> 27 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, std::min( xPos + k, (int) h.width - 1 ), yPos - 1 );
+            }
             if( isCclm )
             {
               // luma the prediction reads: the co-located block and the template rows / columns around it (luma coordinates)
@@ -507,7 +546,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       for( int comp = 0; comp < ncomp; comp++ )
       {
         if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
-        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.mode = ( cu.pred_mode == VVR_PRED_INTER && !( cu.flags & VVR_CU_CIIP ) ) ? TB_ADD : TB_STORE; it.ict = 0; it.pad = 0;
+        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.mode = ( cu.pred_mode == VVR_PRED_INTER && !( cu.flags & VVR_CU_CIIP ) ) ? TB_ADD : TB_STORE; it.ict = 0; it.cscale = 0;
         if( comp && tu.joint_cbcr )
         {
           if( comp != 1 ) continue;
@@ -519,6 +558,9 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         const int bw = tu.w >> ( it.comp ? 1 : 0 ), bh = tu.h >> ( it.comp ? 1 : 0 );
         if( bw < 2 || bh < 2 ) { c->setError( "1-D transform blocks are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
         const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
+        // LMCS chroma residual scaling of an inter block: the factor needs the reconstructed luma around the VPDU, which the intra stage
+        // may still have to produce -> late list.  (STORE items are scaled by k_intra when it reads the residual.)
+        if( cscale && it.comp && it.mode == TB_ADD && bw * bh > 4 ) it.mode = TB_STORE;      // added (scaled) by the intra stage, see isCsInter above
         tb[cls].push_back( it );        // ADD (inter: onto the prediction) and STORE (intra / CIIP: into the residual planes) items share a launch
         const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];
         const double ncoef = bdp ? (double) bw * bh : (double) ( tu.max_scan_x[it.comp] + 1 ) * ( tu.max_scan_y[it.comp] + 1 );
@@ -608,6 +650,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   }
   const int iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
   const int iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
+  const int iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
   if( lmcs ) { bytes[K_LMCS] = ( samples / ( ncomp == 3 ? 1.5 : 1.0 ) ) * 4 * 2; }     // forward pass over the inter luma (upper bound) + inverse pass over all luma
   const int iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
   const int iMcB = add( mcBdof.data(), sizeof( McItem ) * mcBdof.size() );
@@ -642,6 +685,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
   d.lmcs = iLmcs >= 0 ? (const vvr_lmcs_params*) ( base + parts[iLmcs].off ) : nullptr;
   d.interAt = iInterAt >= 0 ? (const uint8_t*) ( base + parts[iInterAt].off ) : nullptr;
+  d.csVpdu = iCsVpdu >= 0 ? (const uint32_t*) ( base + parts[iCsVpdu].off ) : nullptr; d.vpdusX = vpdusX; d.vpduLog2 = vpduLog2;
   q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();
   q->bdofItems = (McItem*) ( base + parts[iMcB].off ); q->numBdofItems = (int) mcBdof.size();
   q->dmvrItems = (McItem*) ( base + parts[iMcD].off ); q->numDmvrItems = (int) mcDmvr.size();
@@ -722,8 +766,8 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
   // LMCS: the inter prediction is forward-mapped before any residual is added (DecCu.cpp:458-476); I pictures have no inter prediction
   if( lmcsOn && h.slice_type != 2 && ( q->numMc + q->numBdofItems + q->numDmvrItems + q->numAffItems ) ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 0 ); } );
   job.prepared = q;
-  if( q->numTb[0] + q->numTb[1] + q->numTb[2] + q->numTbStore[0] + q->numTbStore[1] + q->numTbStore[2] )
-    timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) { launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); launch_itrans( s, q->pic, A, R, q->tbStore[k], q->numTbStore[k], 16 << k ); } } );
+  if( q->numTb[0] + q->numTb[1] + q->numTb[2] )
+    timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); } );
   // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)
   if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->units, q->numActive, c->syncBuf[lane] ); } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)

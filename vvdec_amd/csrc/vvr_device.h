@@ -33,7 +33,7 @@ struct TbItem {
   uint8_t  comp;       // component the coded levels belong to
   uint8_t  mode;       // TB_ADD: reco += residual (inter CU, prediction already in the picture); TB_STORE: write residual plane
   uint8_t  ict;        // 0, or 4 + ICT mode (-3..3 -> 1..7): joint Cb-Cr, the item writes both chroma blocks
-  uint8_t  pad;
+  uint8_t  cscale;     // 1: LMCS chroma residual scaling applies to this (chroma, inter) block
 };
 enum { TB_ADD = 0, TB_STORE = 1 };
 
@@ -42,7 +42,9 @@ enum { TB_ADD = 0, TB_STORE = 1 };
 // that walk is host glue here (vvr_prepare), the kernel only consumes the counts.
 #define IT_F_RESI     1
 #define IT_F_BDPCM_H  2
-#define IT_F_MIP      8      /* matrix-based intra prediction: mode = matrix index, bit 4 = transposed */
+#define IT_F_MIP      8      /* luma: matrix-based intra prediction: mode = matrix index, bit 4 = transposed */
+#define IT_MODE_RESI_ADD 255 /* mode value: no prediction, the (LMCS-scaled) residual is added to the inter prediction already in the picture */
+#define IT_F_CSCALE   8      /* chroma: LMCS chroma residual scaling applies to the residual */
 #define IT_F_BDPCM_V  4      /* bits 4..5: multi-reference-line index; bits 6..7: CIIP intra weight (0 = ordinary intra block) */
 struct IntraItem {        // 16 bytes, self-contained: the kernel never touches the CU/TU records on its serial path
   uint16_t x, y;          // block position in the component plane
@@ -77,6 +79,8 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
   const vvr_alf_params* alf_params;
   const vvr_lmcs_params* lmcs;       // LMCS tables (NULL when off)
   const uint8_t*     interAt;        // per 4x4 luma unit: 1 = covered by an inter CU (LMCS forward mapping of the prediction)
+  const uint32_t*    csVpdu;         // LMCS chroma residual scaling, per VPDU: x | y << 13 | hasLeft << 26 | hasAbove << 27 of the luma neighbourhood the factor is averaged over
+  int                vpdusX, vpduLog2;
   int                w4, h4, ctus_x, ctus_y;
 };
 

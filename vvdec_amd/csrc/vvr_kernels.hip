@@ -976,6 +976,48 @@ __device__ __forceinline__ int wide_angle_mode( int w, int h, int mode )   // PU
   return mode;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LMCS chroma residual scaling: Reshape::calculateChromaAdjVpduNei (Reshape.cpp:192-274) — the factor of a VPDU is looked up from
+// the mean of the reconstructed (mapped-domain) luma samples left of and above the CU at the VPDU origin; AreaBuf::scaleSignal
+// (Buffer.cpp:412) applies it.  The neighbourhood descriptor comes from the host glue (pic.csVpdu); `acc` is an LDS word.
+// Must be called by all threads of the workgroup.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lmcs_cscale_factor( const PicDev& pic, const DevPlanes& reco, int lumaX, int lumaY, int tid, int nthreads, int* acc )
+{
+  const uint32_t d = pic.csVpdu[( lumaY >> pic.vpduLog2 ) * pic.vpdusX + ( lumaX >> pic.vpduLog2 )];
+  const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff;
+  const bool hasLeft = ( d >> 26 ) & 1, hasAbove = ( d >> 27 ) & 1;
+  const int n = 1 << pic.vpduLog2, nLog = pic.vpduLog2;
+  if( tid == 0 ) *acc = 0;
+  __syncthreads();
+  const pel_t* __restrict__ Y = reco.p[0]; const int st = reco.stride[0];
+  int part = 0;
+  for( int t = tid; t < 2 * n; t += nthreads )
+  {
+    const int side = t >= n, i = t - side * n;
+    if( !side && hasLeft )  part += Y[(size_t) ( yPos + min( i, (int) pic.hdr.height - yPos - 1 ) ) * st + xPos - 1];
+    if( side && hasAbove )  part += Y[(size_t) ( yPos - 1 ) * st + xPos + min( i, (int) pic.hdr.width - xPos - 1 )];
+  }
+  if( part ) atomicAdd( acc, part );
+  __syncthreads();
+  const int recLuma = *acc;
+  int lumaValue;
+  if( hasLeft && hasAbove ) lumaValue = ( recLuma + ( 1 << nLog ) ) >> ( nLog + 1 );
+  else if( hasLeft || hasAbove ) lumaValue = ( recLuma + ( 1 << ( nLog - 1 ) ) ) >> nLog;
+  else lumaValue = 1 << ( pic.hdr.bit_depth - 1 );
+  int idx = pic.lmcs->min_bin;
+  for( ; idx <= pic.lmcs->max_bin; idx++ ) if( lumaValue < pic.lmcs->pivot[idx + 1] ) break;
+  return pic.lmcs->chroma_scale[min( idx, 15 )];
+}
+__device__ __forceinline__ int lmcs_scale_resi( int r, int scale, int bd )
+{
+  const int maxAbs = ( 1 << bd ) - 1;
+  int v = clip3( -maxAbs - 1, maxAbs, r );
+  const int sign = v >= 0 ? 1 : -1, a = sign * v;
+  v = sign * ( ( a * scale + ( 1 << 10 ) ) >> 11 );
+  return clip3( -32768, 32767, v );
+}
+
 // NT threads per transform block: 64 for the <= 16x16 class (one wavefront per block: four times as many blocks resident, no
 // cross-wave barrier), 256 for the larger classes
 template<int MAXN, int NT>
@@ -1137,6 +1179,8 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
     __syncthreads();
   }
   // ---- pass 2 (horizontal) + output
+  __shared__ int csAcc;
+  const int csScale = it.cscale ? lmcs_cscale_factor( pic, reco, tu.x, tu.y, tid, NT, &csAcc ) : 0;
   const int ict = it.ict ? (int) it.ict - 4 : 0;
   for( int i = tid; i < n; i += NT )
   {
@@ -1164,6 +1208,7 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
       else                 { rOther = -r >> 1; cOther = 1; }
       rOther = (int16_t) rOther;
     }
+    if( it.cscale ) { r = lmcs_scale_resi( r, csScale, bd ); if( ict ) rOther = lmcs_scale_resi( rOther, csScale, bd ); }
     if( it.mode == TB_ADD )
     {
       pel_t* d = &reco.p[cSelf][(size_t) ( by + y ) * reco.stride[cSelf] + bx + x];
@@ -1949,6 +1994,24 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int bdpcm = ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
       const int dirMode = it.mode;
       const bool hasResi = ( it.flags & IT_F_RESI ) != 0;
+      // LMCS chroma residual scaling factor of the block's VPDU (the unit has waited for the luma it is averaged over)
+      int csScale = 0;
+      const bool csOn = comp && ( it.flags & IT_F_CSCALE );
+      if( csOn ) csScale = lmcs_cscale_factor( pic, reco, x0 << 1, y0 << 1, tid, 256, &sh.lmSel[7] );
+      if( dirMode == IT_MODE_RESI_ADD )
+      {
+        // inter block: (scaled) chroma residual onto the prediction that k_mc left in the picture
+#pragma unroll 1
+        for( int i = tid; i < w * h; i += 256 )
+        {
+          const int x = i & ( w - 1 ), y = i >> lw;
+          TILE( x0 + x, y0 + y ) = (pel_t) clip_pel( TILE( x0 + x, y0 + y ) + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
+        }
+        if( tid == 255 ) sh.dcSum[( k + 1 ) & 1] = 0;
+        if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
+        lds_barrier();
+        continue;
+      }
       const int topLen = 2 * w, leftLen = 2 * h;
       const int unit = 4 >> cs;
       const int totalAbove = ( topLen + unit - 1 ) / unit, totalLeft = ( leftLen + unit - 1 ) / unit;
@@ -2169,7 +2232,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
           const int t = (int16_t) ( ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
           int v = clip_pel( ( ( a * t ) >> shift ) + b, bd );
-          if( hasResi ) v = clip_pel( v + rcur[i], bd );
+          if( hasResi ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
           TILE( x0 + x, y0 + y ) = (pel_t) v;
         }
 #undef LU
@@ -2313,7 +2376,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           v = (int16_t) ( v + ( ( wL * ( L[y + 1] - v ) + wT * ( T[x + 1] - v ) + 32 ) >> 6 ) );
         }
         if( wIntra ) v = ( ( 4 - wIntra ) * TILE( x0 + x, y0 + y ) + wIntra * v + 2 ) >> 2;     // predBlendIntraCiip (:935-944): the tile holds the inter prediction
-        if( hasResi ) v = clip_pel( v + rcur[i], bd );
+        if( hasResi ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
         TILE( x0 + x, y0 + y ) = (pel_t) v;
       }
       if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
