@@ -108,7 +108,7 @@ def main():
     vvdec_amd.lib()
     W, H = a.width, a.height
     tools = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST |
-             abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS)
+             abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE)
     K, Wm = a.steps, a.warmup
     nframes = ((max(K, Wm) - 1 + a.gop - 1) // a.gop) * a.gop + 1
     plans, nslots = stream.ra_plan(nframes, gop=a.gop, seed_poc0_is_external=False, pool=a.slots)   # POC 0 is an I picture
@@ -177,9 +177,9 @@ def main():
                "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int16", "data": "synthetic",
                "config": {"workload": "%dx%d 10-bit 4:2:0 random-access QP32 (hierarchical-B GOP %d), CTU 128, pre-parsed records resident in HBM" % (W, H, a.gop),
-                          "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
+                          "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
                           "mix": MIX,
-                          "not_yet": "ISP, LMCS chroma residual scaling, IBC, explicit weighted prediction, scaling lists (rejected with VVR_ERR_UNSUPPORTED)",
+                          "not_yet": "ISP, IBC, explicit weighted prediction, scaling lists (rejected with VVR_ERR_UNSUPPORTED)",
                           "pictures_in_flight": a.streams, "sharding": "closed-GOP segment per GPU, no data-path collective",
                           "verified_pictures_vs_oracle": verified},
                "roofline": roof}

@@ -200,7 +200,7 @@ def test_lmcs(built, cscale):
     """LMCS: inter prediction forward-mapped, intra in the mapped domain, inverse mapping before the loop filters; with cscale
     the chroma residuals are scaled by a factor looked up from the reconstructed luma around the 64x64 VPDU"""
     T = TOOLS_A | abi.TOOL_LMCS | (abi.TOOL_LMCS_CSCALE if cscale else 0)
-    _run_stream(256, 128, 5, 4, 201, T, intra=True, p_intra=0.3, p_cclm=0.2, p_mip=0.2, p_ciip=0.1)
+    _run_stream(256, 128, 5, 4, 201, T, intra=True, p_intra=0.3, p_cclm=0.2, p_mip=0.2, p_ciip=0.1, p_jccr=0.3)
     _run_stream(416, 240, 5, 4, 202, T, intra=True, p_intra=0.2, log2_ctu=6, p_affine=0.1, p_geo=0.1, p_sbtmvp=0.1, p_ciip=0.1)
     _run_stream(1920, 1080, 3, 2, 203, T, intra=True, streams=3)
 

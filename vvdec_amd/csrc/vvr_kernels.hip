@@ -1967,6 +1967,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     }
   }
   int rnext[IT_MAXR];
+  int csVpduCur = -1, csVpduVal = 0;
   lds_barrier();
   for( uint32_t b0 = i0; b0 < ( ( dbg & 4 ) ? i0 : i1 ); b0 += IT_BATCH )
   {
@@ -1997,7 +1998,13 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       // LMCS chroma residual scaling factor of the block's VPDU (the unit has waited for the luma it is averaged over)
       int csScale = 0;
       const bool csOn = comp && ( it.flags & IT_F_CSCALE );
-      if( csOn ) csScale = lmcs_cscale_factor( pic, reco, x0 << 1, y0 << 1, tid, 256, &sh.lmSel[7] );
+      if( csOn )
+      {
+        // one factor per VPDU; blocks arrive VPDU by VPDU, so it is computed once per VPDU and unit
+        const int vp = ( ( y0 << 1 ) >> pic.vpduLog2 ) * pic.vpdusX + ( ( x0 << 1 ) >> pic.vpduLog2 );
+        if( vp != csVpduCur ) { csVpduVal = lmcs_cscale_factor( pic, reco, x0 << 1, y0 << 1, tid, 256, &sh.lmSel[7] ); csVpduCur = vp; }
+        csScale = csVpduVal;
+      }
       if( dirMode == IT_MODE_RESI_ADD )
       {
         // inter block: (scaled) chroma residual onto the prediction that k_mc left in the picture
