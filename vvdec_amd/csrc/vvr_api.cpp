@@ -44,7 +44,6 @@ struct vvr_prepared {        // a picture description resident in HBM together w
   McItem*  affItems = nullptr; int numAffItems = 0;        // tiles of affine CUs
   int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64 (TB_ADD: after MC)
-  TbItem*  tbStore[3] = { nullptr, nullptr, nullptr }; int numTbStore[3] = { 0, 0, 0 };   // LATE list: inter chroma blocks with LMCS chroma residual scaling (after the intra stage: the factor reads reconstructed luma)
   IntraItem* intraItems = nullptr; uint32_t* ctuStart = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
   double   bytes[K_NUM] = { 0 };
   bool     owned = false;
@@ -313,7 +312,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   // ---- host glue: work lists (what DecCu::TaskTrafoCtu / TaskInterCtu iterate over, DecCu.cpp:106-134)
   std::vector<McItem> mc, mcBdof, mcDmvr, mcAff;
   uint32_t numDmvr = 0;
-  std::vector<TbItem> tb[3], tbS[3];
+  std::vector<TbItem> tb[3];
   std::vector<IntraItem> intra[3];
   std::vector<uint32_t> ctuStartV( 3 * (size_t) ( numCtu + 1 ), 0 );
   double bytes[K_NUM] = { 0 };
@@ -326,7 +325,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   // one workgroup processes one unit.  Units depend on exactly those earlier units that produced a reference sample they read
   // (inter samples are final before the stage starts), which the loop below finds through unitAt[].
   struct BBox { int y0 = 255, y1 = 0, c0 = 255, c1 = 0; };   // rows relative to (CTU top - 3), 8-sample chunks relative to (CTU left - 8), chunk index + 1
-  struct UnitH { uint32_t comp, ctu, i0, i1; int quad; BBox bb; std::vector<uint32_t> deps; bool waited = false; };
+  struct UnitH { uint32_t comp, ctu, i0, i1, iA = 0; bool hasCs = false; int quad; BBox bb; std::vector<uint32_t> deps; bool waited = false; };
   std::vector<UnitH> units;
   int32_t curUnit[3] = { -1, -1, -1 }; int unitsInCtu[3] = { 0, 0, 0 };
   std::vector<int32_t> unitAt[3];        // per component and 4x4 luma cell: the unit that reconstructs it in the intra stage (-1: none)
@@ -546,7 +545,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       for( int comp = 0; comp < ncomp; comp++ )
       {
         if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
-        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.mode = ( cu.pred_mode == VVR_PRED_INTER && !( cu.flags & VVR_CU_CIIP ) ) ? TB_ADD : TB_STORE; it.ict = 0; it.cscale = 0;
+        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.mode = ( cu.pred_mode == VVR_PRED_INTER && !( cu.flags & VVR_CU_CIIP ) ) ? TB_ADD : TB_STORE; it.ict = 0; it.pad = 0;
         if( comp && tu.joint_cbcr )
         {
           if( comp != 1 ) continue;
@@ -567,6 +566,13 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         bytes[K_ITRANS] += ncoef * 2 + (double) bw * bh * 4 * ( it.ict ? 2 : 1 ) + sizeof( TbItem ) + sizeof( vvr_tu ) / 3.0;
       }
     }
+  }
+  // residual-add items of inter blocks (LMCS chroma scaling) to the front of their unit: the kernel does them first, in parallel
+  for( auto& u : units )
+  {
+    auto b = intra[u.comp].begin() + u.i0, e = intra[u.comp].begin() + u.i1;
+    u.iA = u.i0 + (uint32_t) ( std::stable_partition( b, e, []( const IntraItem& it ) { return it.mode == IT_MODE_RESI_ADD; } ) - b );
+    u.hasCs = u.comp && std::any_of( b, e, []( const IntraItem& it ) { return ( it.flags & IT_F_CSCALE ) != 0; } );
   }
   while( curCtu < (uint32_t) numCtu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
   // one item array for the three components; ctuStart holds offsets into it; active (component, CTU) pairs in raster order
@@ -610,8 +616,8 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         const int ctu4 = 1 << ( h.log2_ctu - 2 ), ux = (int) ( u.ctu % ctusX ) * ctu4, uy = (int) ( u.ctu / ctusX ) * ctu4;
         for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
       }
-      d.ent = ( u.comp << 24 ) | u.ctu | ( u.waited ? 0x40000000u : 0 ) | ( all ? 0x80000000u : 0 );
-      d.i0 = itemBase[u.comp] + u.i0; d.i1 = itemBase[u.comp] + u.i1;
+      d.ent = ( u.comp << 24 ) | u.ctu | ( u.hasCs ? 0x20000000u : 0 ) | ( u.waited ? 0x40000000u : 0 ) | ( all ? 0x80000000u : 0 );
+      d.i0 = itemBase[u.comp] + u.i0; d.i1 = itemBase[u.comp] + u.i1; d.iA = itemBase[u.comp] + u.iA;
       d.bbox = (uint32_t) u.bb.y0 | ( (uint32_t) u.bb.y1 << 8 ) | ( (uint32_t) u.bb.c0 << 16 ) | ( (uint32_t) u.bb.c1 << 24 );
       d.ndeps = (uint32_t) std::min<size_t>( u.deps.size(), VVR_INTRA_MAX_DEPS );
       if( u.deps.size() > VVR_INTRA_MAX_DEPS ) { c->setError( "internal: intra unit with too many dependencies" ); return VVR_ERR_UNSPECIFIED; }
@@ -658,7 +664,6 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   const int iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
   const int iDmvrOut = add( nullptr, sizeof( int32_t ) * 2 * (size_t) numDmvr );
   int iTb[3]; for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
-  int iTbS[3]; for( int k = 0; k < 3; k++ ) iTbS[k] = add( tbS[k].data(), sizeof( TbItem ) * tbS[k].size() );
   const int iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
   const int iCtuStart = add( ctuStartV.data(), sizeof( uint32_t ) * ctuStartV.size() );
   const int iActive = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
@@ -692,7 +697,6 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   q->affItems = (McItem*) ( base + parts[iMcA].off ); q->numAffItems = (int) mcAff.size();
   q->dmvrOut = (int32_t*) ( base + parts[iDmvrOut].off ); q->numDmvr = numDmvr;
   for( int k = 0; k < 3; k++ ) { q->tbItems[k] = (TbItem*) ( base + parts[iTb[k]].off ); q->numTb[k] = (int) tb[k].size(); }
-  for( int k = 0; k < 3; k++ ) { q->tbStore[k] = (TbItem*) ( base + parts[iTbS[k]].off ); q->numTbStore[k] = (int) tbS[k].size(); }
   q->intraItems = (IntraItem*) ( base + parts[iIntra].off ); q->numIntra = (int) intraAll.size();
   q->ctuStart = (uint32_t*) ( base + parts[iCtuStart].off );
   q->units = (IntraUnit*) ( base + parts[iActive].off ); q->numActive = (int) unitsDev.size();

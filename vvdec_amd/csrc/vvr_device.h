@@ -33,7 +33,7 @@ struct TbItem {
   uint8_t  comp;       // component the coded levels belong to
   uint8_t  mode;       // TB_ADD: reco += residual (inter CU, prediction already in the picture); TB_STORE: write residual plane
   uint8_t  ict;        // 0, or 4 + ICT mode (-3..3 -> 1..7): joint Cb-Cr, the item writes both chroma blocks
-  uint8_t  cscale;     // 1: LMCS chroma residual scaling applies to this (chroma, inter) block
+  uint8_t  pad;
 };
 enum { TB_ADD = 0, TB_STORE = 1 };
 
@@ -59,12 +59,12 @@ struct IntraItem {        // 16 bytes, self-contained: the kernel never touches 
 // One unit of the intra stage (a run of blocks of one component inside one CTU quadrant), processed by one workgroup.
 #define VVR_INTRA_MAX_DEPS 26
 struct IntraUnit {
-  uint32_t ent;           // (component << 24) | CTU address; bit 30: another unit waits for this one (it must publish its flag)
+  uint32_t ent;           // (component << 24) | CTU address; bit 29: has blocks with LMCS chroma residual scaling; bit 30: another unit waits for this one (it must publish its flag)
   uint32_t i0, i1;        // item range
   uint32_t bbox;          // part of the CTU tile the unit's blocks read: y0 | y1 << 8 | c0 << 16 | c1 << 24 (rows from CTU top - 3, 16-byte chunks from CTU left - 8, chunk + 1)
   uint32_t ndeps;
   uint32_t deps[VVR_INTRA_MAX_DEPS];   // tickets (= indices into the unit table) this unit waits for
-  uint32_t pad;                        // 32 dwords
+  uint32_t iA;                         // [i0, iA): IT_MODE_RESI_ADD items (no mutual dependencies, done first and in parallel); 32 dwords
 };
 
 struct PicDev {         // everything a kernel needs about one picture (passed by value)

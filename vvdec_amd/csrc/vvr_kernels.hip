@@ -982,25 +982,24 @@ __device__ __forceinline__ int wide_angle_mode( int w, int h, int mode )   // PU
 // (Buffer.cpp:412) applies it.  The neighbourhood descriptor comes from the host glue (pic.csVpdu); `acc` is an LDS word.
 // Must be called by all threads of the workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lmcs_cscale_factor( const PicDev& pic, const DevPlanes& reco, int lumaX, int lumaY, int tid, int nthreads, int* acc )
+__device__ __forceinline__ int lmcs_cscale_factor_wave( const PicDev& pic, const DevPlanes& reco, int lumaX, int lumaY, int lane )
 {
+  // called by one whole wavefront; every lane returns the factor
   const uint32_t d = pic.csVpdu[( lumaY >> pic.vpduLog2 ) * pic.vpdusX + ( lumaX >> pic.vpduLog2 )];
   const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff;
   const bool hasLeft = ( d >> 26 ) & 1, hasAbove = ( d >> 27 ) & 1;
   const int n = 1 << pic.vpduLog2, nLog = pic.vpduLog2;
-  if( tid == 0 ) *acc = 0;
-  __syncthreads();
   const pel_t* __restrict__ Y = reco.p[0]; const int st = reco.stride[0];
   int part = 0;
-  for( int t = tid; t < 2 * n; t += nthreads )
+  for( int t = lane; t < 2 * n; t += 64 )
   {
     const int side = t >= n, i = t - side * n;
     if( !side && hasLeft )  part += Y[(size_t) ( yPos + min( i, (int) pic.hdr.height - yPos - 1 ) ) * st + xPos - 1];
     if( side && hasAbove )  part += Y[(size_t) ( yPos - 1 ) * st + xPos + min( i, (int) pic.hdr.width - xPos - 1 )];
   }
-  if( part ) atomicAdd( acc, part );
-  __syncthreads();
-  const int recLuma = *acc;
+#pragma unroll
+  for( int off = 32; off >= 1; off >>= 1 ) part += __shfl_xor( part, off, 64 );
+  const int recLuma = part;
   int lumaValue;
   if( hasLeft && hasAbove ) lumaValue = ( recLuma + ( 1 << nLog ) ) >> ( nLog + 1 );
   else if( hasLeft || hasAbove ) lumaValue = ( recLuma + ( 1 << ( nLog - 1 ) ) ) >> nLog;
@@ -1179,8 +1178,6 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
     __syncthreads();
   }
   // ---- pass 2 (horizontal) + output
-  __shared__ int csAcc;
-  const int csScale = it.cscale ? lmcs_cscale_factor( pic, reco, tu.x, tu.y, tid, NT, &csAcc ) : 0;
   const int ict = it.ict ? (int) it.ict - 4 : 0;
   for( int i = tid; i < n; i += NT )
   {
@@ -1208,7 +1205,6 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
       else                 { rOther = -r >> 1; cOther = 1; }
       rOther = (int16_t) rOther;
     }
-    if( it.cscale ) { r = lmcs_scale_resi( r, csScale, bd ); if( ict ) rOther = lmcs_scale_resi( rOther, csScale, bd ); }
     if( it.mode == TB_ADD )
     {
       pel_t* d = &reco.p[cSelf][(size_t) ( by + y ) * reco.stride[cSelf] + bx + x];
@@ -1827,6 +1823,7 @@ struct IntraShared {
   int   lmSel[8];                                       // CCLM: the (luma, chroma) pairs of the selected template positions
   int   ticket;
   int   dcSum[2];
+  int   csFac[4];                                       // LMCS chroma residual scaling factor of the CTU's VPDUs
 };
 
 __constant__ uint8_t c_intraFilterThr[8] = { 24, 24, 24, 14, 2, 0, 0, 0 };
@@ -1967,9 +1964,44 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     }
   }
   int rnext[IT_MAXR];
-  int csVpduCur = -1, csVpduVal = 0;
+  // ---- LMCS chroma residual scaling (DecCu.cpp:383-388,500-505): one factor per VPDU of the CTU, one wavefront each (the unit
+  // has waited for the luma units that reconstruct the samples the factors are averaged over)
+  const int csNv1 = pic.hdr.log2_ctu > pic.vpduLog2 ? 1 : 0;        // VPDUs per CTU side - 1
+  if( ( ent >> 29 ) & 1 )
+  {
+    const int wv = tid >> 6;
+    const int lx = ( cxI << pic.hdr.log2_ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.hdr.log2_ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
+    if( lx < (int) pic.hdr.width && ly < (int) pic.hdr.height && ( wv == 0 || csNv1 ) )
+    {
+      const int f = lmcs_cscale_factor_wave( pic, reco, lx, ly, tid & 63 );
+      if( ( tid & 63 ) == 0 ) sh.csFac[wv] = f;
+    }
+  }
   lds_barrier();
-  for( uint32_t b0 = i0; b0 < ( ( dbg & 4 ) ? i0 : i1 ); b0 += IT_BATCH )
+  // ---- inter blocks of the CTU whose chroma residual is scaled: they read nothing but their own prediction (already in the tile)
+  // and the factor, so they come first and in parallel, one block per wavefront
+  {
+    const uint32_t iA = un->iA;
+    for( uint32_t q = i0 + ( tid >> 6 ); q < iA; q += 4 )
+    {
+      IntraItem it;
+      {
+        const uint32_t* ip = reinterpret_cast<const uint32_t*>( &items[q] );
+        uint32_t* op = reinterpret_cast<uint32_t*>( &it );
+        for( int e = 0; e < 4; e++ ) op[e] = __builtin_amdgcn_readfirstlane( ip[e] );
+      }
+      const int x0 = it.x, y0 = it.y, lw = it.lw, wh = 1 << ( it.lw + it.lh );
+      const int f = ( it.flags & IT_F_CSCALE ) ? sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )] : 0;
+      for( int i = ( tid & 63 ); i < wh; i += 64 )
+      {
+        const int x = x0 + ( i & ( ( 1 << lw ) - 1 ) ), y = y0 + ( i >> lw );
+        const int r = (int16_t) rs[(size_t) y * rstride + x];
+        TILE( x, y ) = (pel_t) clip_pel( TILE( x, y ) + ( ( it.flags & IT_F_CSCALE ) ? lmcs_scale_resi( r, f, bd ) : r ), bd );
+      }
+    }
+  }
+  lds_barrier();
+  for( uint32_t b0 = un->iA; b0 < ( ( dbg & 4 ) ? i0 : i1 ); b0 += IT_BATCH )
   {
     const int nb = (int) min( (uint32_t) IT_BATCH, i1 - b0 );
     lds_barrier();                                  // previous batch fully consumed (and, first time, the tile is staged)
@@ -1998,27 +2030,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       // LMCS chroma residual scaling factor of the block's VPDU (the unit has waited for the luma it is averaged over)
       int csScale = 0;
       const bool csOn = comp && ( it.flags & IT_F_CSCALE );
-      if( csOn )
-      {
-        // one factor per VPDU; blocks arrive VPDU by VPDU, so it is computed once per VPDU and unit
-        const int vp = ( ( y0 << 1 ) >> pic.vpduLog2 ) * pic.vpdusX + ( ( x0 << 1 ) >> pic.vpduLog2 );
-        if( vp != csVpduCur ) { csVpduVal = lmcs_cscale_factor( pic, reco, x0 << 1, y0 << 1, tid, 256, &sh.lmSel[7] ); csVpduCur = vp; }
-        csScale = csVpduVal;
-      }
-      if( dirMode == IT_MODE_RESI_ADD )
-      {
-        // inter block: (scaled) chroma residual onto the prediction that k_mc left in the picture
-#pragma unroll 1
-        for( int i = tid; i < w * h; i += 256 )
-        {
-          const int x = i & ( w - 1 ), y = i >> lw;
-          TILE( x0 + x, y0 + y ) = (pel_t) clip_pel( TILE( x0 + x, y0 + y ) + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
-        }
-        if( tid == 255 ) sh.dcSum[( k + 1 ) & 1] = 0;
-        if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
-        lds_barrier();
-        continue;
-      }
+      if( csOn ) csScale = sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )];
       const int topLen = 2 * w, leftLen = 2 * h;
       const int unit = 4 >> cs;
       const int totalAbove = ( topLen + unit - 1 ) / unit, totalLeft = ( leftLen + unit - 1 ) / unit;
@@ -2405,7 +2417,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     for( uint32_t b0 = i0; b0 < ( ( dbg & 4 ) ? i0 : i1 ); b0 += IT_BATCH )
     {
       const int nb = (int) min( (uint32_t) IT_BATCH, i1 - b0 );
-      if( i1 - i0 > IT_BATCH )       // otherwise the only batch is still in LDS
+      if( i1 - i0 > IT_BATCH || un->iA != i0 )       // otherwise the only batch is still in LDS
       {
         lds_barrier();
         if( tid < nb * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = reinterpret_cast<const uint32_t*>( items + b0 )[tid];
