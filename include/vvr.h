@@ -79,8 +79,12 @@ enum {
   VVR_TOOL_JCCR_SIGN    = 1u << 11,  /* ph_joint_cbcr_sign_flag                                    */
   VVR_TOOL_STILL_REF    = 1u << 12,  /* picture is still referenced: DMVR refined MVs are returned */
   VVR_TOOL_LFNST        = 1u << 13,  /* sps LFNST on (TrQuant.cpp:301)                              */
-  VVR_TOOL_MTS          = 1u << 14,
-  VVR_TOOL_CCLM_COLLOC  = 1u << 15,  /* sps_chroma_vertical_collocated_flag: CCLM down-samples luma with the 5-tap cross filter */  /* sps MTS on (explicit+implicit selection resolved per TU)    */
+  VVR_TOOL_MTS          = 1u << 14,  /* sps MTS on (explicit+implicit selection resolved per TU)    */
+  VVR_TOOL_CCLM_COLLOC  = 1u << 15,  /* sps_chroma_vertical_collocated_flag: CCLM down-samples luma with the 5-tap cross filter */
+  VVR_TOOL_WP           = 1u << 16,  /* explicit weighted prediction applies to this picture: P slice with pps_weighted_pred_flag or
+                                        B slice with pps_weighted_bipred_flag (InterPrediction.cpp:707,735-742); vvr_picture.wp set */
+  VVR_TOOL_SCALING_LIST = 1u << 17,  /* explicit scaling list in use for the slice (Quant.cpp:330-336); vvr_picture.scaling set */
+  VVR_TOOL_SCALING_LIST_NO_LFNST = 1u << 18,  /* sps_scaling_matrix_for_lfnst_disabled_flag */
 };
 
 typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::reconstructCoeff (AdaptiveLoopFilter.cpp:888) stays on the host */
@@ -105,6 +109,25 @@ typedef struct vvr_lmcs_params {    /* Reshape::constructReshaper (Reshape.cpp:3
   int16_t model_delta_crs;          /* lmcsDeltaCrs             */
   int16_t pad[4];
 } vvr_lmcs_params;
+
+typedef struct vvr_wp_entry {        /* WPScalingParam (Slice.h:2215) of one reference picture and component, as parsed */
+  int16_t weight;                    /* iWeight ( 1 << log2_denom when the flag is off )                       */
+  int16_t offset;                    /* iOffset, in 8-bit units (scaled by 1 << (bit_depth - 8) when applied)  */
+  uint8_t present;                   /* bPresentFlag (luma_weight_lX_flag / chroma_weight_lX_flag)             */
+  uint8_t pad[3];
+} vvr_wp_entry;
+
+typedef struct vvr_wp_params {       /* pred_weight_table(): Slice::m_weightPredTable (Slice.h:2560) */
+  uint8_t      log2_denom[2];        /* uiLog2WeightDenom of luma / chroma                           */
+  uint8_t      pad[6];
+  vvr_wp_entry e[2][VVR_MAX_REFS][3];/* [list][refIdx][Y, Cb, Cr]                                    */
+} vvr_wp_params;
+
+typedef struct vvr_scaling_list {    /* ScalingList after scaling_list_data() decoding (prediction / DPCM resolved) */
+  uint8_t coef[28][64];              /* m_scalingListCoef[id]: ids 0-1 are 2x2 (4 entries), 2-7 4x4 (16), 8-27 8x8 (64), raster order */
+  uint8_t dc[28];                    /* m_scalingListDC[id] (ids >= 14: the DC of the up-sampled 16x16 .. 64x64 matrices) */
+  uint8_t pad[4];
+} vvr_scaling_list;
 
 typedef struct vvr_pic_header {
   uint32_t abi_version;             /* VVR_ABI_VERSION                                                  */
@@ -271,6 +294,8 @@ typedef struct vvr_picture {
   const vvr_alf_ctu*    alf;           /* [num_ctu] or NULL                                                      */
   const vvr_alf_params* alf_params;    /* NULL when ALF is off                                                   */
   const vvr_lmcs_params* lmcs;         /* NULL when LMCS is off                                                  */
+  const vvr_wp_params*  wp;            /* NULL unless VVR_TOOL_WP                                                */
+  const vvr_scaling_list* scaling;     /* NULL unless VVR_TOOL_SCALING_LIST                                      */
   int                   resident;      /* 0: all array pointers are host memory (copied H2D by vvr_submit);      */
                                        /* 1: all array pointers are DEVICE memory already resident in HBM        */
 } vvr_picture;

@@ -183,6 +183,8 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     pps.setLoopFilterAcrossTilesEnabledFlag( true );
     pps.setLoopFilterAcrossSlicesEnabledFlag( true );
     pps.setNumSubPics( 1 );
+    pps.setUseWP( ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 1 );        // pps_weighted_pred_flag (P slices)
+    pps.setWPBiPred( ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 0 );     // pps_weighted_bipred_flag (B slices)
     pps.pcv = std::make_unique<PreCalcValues>( sps, pps );
 
     auto ph = std::make_shared<PicHeader>();
@@ -330,6 +332,20 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
         slice->m_apcRefPicList[l][i]     = rp;
         slice->m_aiRefPOCList[l][i]      = H.ref_poc[l][i];
         slice->m_bIsUsedAsLongTerm[l][i] = false;
+      }
+    }
+    slice->resetWpScaling();
+    if( ( H.tool_flags & VVR_TOOL_WP ) && vp->wp && H.slice_type != 2 )
+    {   // pred_weight_table() as the parser leaves it (Slice::m_weightPredTable)
+      for( int l = 0; l < 2; l++ ) for( int i = 0; i < H.num_ref[l]; i++ )
+      {
+        WPScalingParam* wp = nullptr;
+        slice->getWpScaling( RefPicList( l ), i, wp );
+        for( int c = 0; c < 3; c++ )
+        {
+          const vvr_wp_entry& e = vp->wp->e[l][i][c];
+          wp[c].bPresentFlag = e.present != 0; wp[c].uiLog2WeightDenom = vp->wp->log2_denom[c ? 1 : 0]; wp[c].iWeight = e.weight; wp[c].iOffset = e.offset;
+        }
       }
     }
     pic.stillReferenced = !!( H.tool_flags & VVR_TOOL_STILL_REF );

@@ -95,6 +95,31 @@ static void pred_block_src( const vvo_src* ref, int comp, int bx, int by, int w,
   }
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Explicit weighted prediction: WeightPrediction::getWpScaling (WeightPrediction.cpp:66-157), addWeightUni (:238-338) and
+ * addWeightBi (:164-236).  It replaces the final rounding / averaging of plain, affine, SbTMVP and CIIP inter predictions of a
+ * picture with VVR_TOOL_WP (InterPrediction::xPredInterBi, InterPrediction.cpp:707,735-742) unless the CU uses BCW weights or GPM;
+ * the inputs are the 14-bit intermediate predictions.
+ * ------------------------------------------------------------------------------------------------------------------- */
+static int wp_on( const vvr_picture* pic, int bcw_idx ) { return ( pic->hdr.tool_flags & VVR_TOOL_WP ) && pic->wp && bcw_idx == 2; }
+static int wp_uni( const vvr_picture* pic, int l, int ri, int c, int p )
+{
+  const vvr_wp_entry* e = &pic->wp->e[l][ri][c];
+  const int bd = pic->hdr.bit_depth, den = pic->wp->log2_denom[c ? 1 : 0];
+  const int shiftNum = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2, shift = den + shiftNum;
+  const int offset = e->offset * ( 1 << ( bd - 8 ) );
+  if( e->weight != ( 1 << den ) ) return vvo_clip_pel( ( ( e->weight * ( p + IF_INTERNAL_OFFS ) + ( 1 << ( shift - 1 ) ) ) >> shift ) + offset, bd );
+  return vvo_clip_pel( ( ( p + IF_INTERNAL_OFFS + ( 1 << ( shiftNum - 1 ) ) ) >> shiftNum ) + offset, bd );
+}
+static int wp_bi( const vvr_picture* pic, int r0, int r1, int c, int p0, int p1 )
+{
+  const vvr_wp_entry* e0 = &pic->wp->e[0][r0][c]; const vvr_wp_entry* e1 = &pic->wp->e[1][r1][c];
+  const int bd = pic->hdr.bit_depth, den = pic->wp->log2_denom[c ? 1 : 0];
+  const int shiftNum = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2, shift = den + 1 + shiftNum;
+  const int offset = ( e0->offset + e1->offset ) * ( 1 << ( bd - 8 ) );
+  return vvo_clip_pel( ( e0->weight * ( p0 + IF_INTERNAL_OFFS ) + e1->weight * ( p1 + IF_INTERNAL_OFFS ) + ( ( 1 << shift ) >> 1 ) + offset * ( 1 << ( shift - 1 ) ) ) >> shift, bd );
+}
+
 static void clip_mv( int mv[2], int x, int y, int W, int H, int ctu )   /* clipMvInPic (Mv.cpp:64) */
 {
   const int horMax = ( W + 8 - x - 1 ) * 16, horMin = ( -ctu - 8 - x + 1 ) * 16;
@@ -515,7 +540,9 @@ static int affine_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes
   /* xCheckIdenticalMotion (InterPrediction.cpp:404-436): same reference picture and same control-point MVs -> list 0 only */
   if( biPred && H->ref_poc[0][cu->ref_idx[0]] == H->ref_poc[1][cu->ref_idx[1]]
       && cu->mv[0][0][0] == cu->mv[1][0][0] && cu->mv[0][0][1] == cu->mv[1][0][1] && cu->mv[0][1][0] == cu->mv[1][1][0] && cu->mv[0][1][1] == cu->mv[1][1][1]
-      && ( !( cu->flags & VVR_CU_AFFINE_6P ) || ( cu->mv[0][2][0] == cu->mv[1][2][0] && cu->mv[0][2][1] == cu->mv[1][2][1] ) ) ) biPred = 0;
+      && ( !( cu->flags & VVR_CU_AFFINE_6P ) || ( cu->mv[0][2][0] == cu->mv[1][2][0] && cu->mv[0][2][1] == cu->mv[1][2][1] ) )
+      && !( H->tool_flags & VVR_TOOL_WP ) /* :408 */ ) biPred = 0;
+  const int wp = wp_on( pic, cu->bcw_idx );
   const size_t n = (size_t) cu->w * cu->h;
   pel* buf = (pel*) malloc( sizeof( pel ) * n * 3 );
   pel* p0[3] = { buf, buf + n, buf + n + n / 4 };
@@ -529,7 +556,7 @@ static int affine_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes
   else
   {
     const int l = cu->ref_idx[0] >= 0 ? 0 : 1;
-    affine_list( pic, cu, l, &refs[H->ref_slot[l][cu->ref_idx[l]]], 0, p0 );
+    affine_list( pic, cu, l, &refs[H->ref_slot[l][cu->ref_idx[l]]], wp, p0 );
   }
   for( int c = 0; c < ncomp; c++ )
   {
@@ -538,7 +565,8 @@ static int affine_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes
     for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
     {
       int v;
-      if( !biPred ) v = p0[c][y * w + x];
+      if( wp ) { const int l = cu->ref_idx[0] >= 0 ? 0 : 1; v = biPred ? wp_bi( pic, cu->ref_idx[0], cu->ref_idx[1], c, p0[c][y * w + x], p1[c][y * w + x] ) : wp_uni( pic, l, cu->ref_idx[l], c, p0[c][y * w + x] ); }
+      else if( !biPred ) v = p0[c][y * w + x];
       else if( cu->bcw_idx != 2 )
       {
         const int w1 = vvc_bcw_weights[cu->bcw_idx], w0 = 8 - w1;
@@ -613,7 +641,8 @@ static void plain_block( const vvr_picture* pic, const vvo_planes* refs, int x, 
   const vvr_pic_header* H = &pic->hdr;
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu, ncomp = H->chroma_format ? 3 : 1;
   int bi = ref_idx[0] >= 0 && ref_idx[1] >= 0;
-  if( bi && H->ref_poc[0][ref_idx[0]] == H->ref_poc[1][ref_idx[1]] && mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1] ) bi = 0;     /* xCheckIdenticalMotion */
+  if( bi && H->ref_poc[0][ref_idx[0]] == H->ref_poc[1][ref_idx[1]] && mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1] && !( H->tool_flags & VVR_TOOL_WP ) ) bi = 0;     /* xCheckIdenticalMotion */
+  const int wp = wp_on( pic, bcw_idx );
   for( int c = 0; c < ncomp; c++ )
   {
     const int cs = c ? 1 : 0, bx = x >> cs, by = y >> cs, bw = w >> cs, bh = h >> cs;
@@ -623,7 +652,13 @@ static void plain_block( const vvr_picture* pic, const vvo_planes* refs, int x, 
       const int l = ref_idx[0] >= 0 ? 0 : 1;
       int m[2] = { mv[l][0], mv[l][1] };
       clip_mv( m, x, y, H->width, H->height, ctu );
-      pred_block( &refs[H->ref_slot[l][ref_idx[l]]], c, bx, by, bw, bh, m[0], m[1], 0, altHpel, bd, dst, reco->stride[c] );
+      if( wp )
+      {
+        pel t[16 * 16];
+        pred_block( &refs[H->ref_slot[l][ref_idx[l]]], c, bx, by, bw, bh, m[0], m[1], 1, altHpel, bd, t, bw );
+        for( int yy = 0; yy < bh; yy++ ) for( int xx = 0; xx < bw; xx++ ) dst[yy * reco->stride[c] + xx] = (pel) wp_uni( pic, l, ref_idx[l], c, t[yy * bw + xx] );
+      }
+      else pred_block( &refs[H->ref_slot[l][ref_idx[l]]], c, bx, by, bw, bh, m[0], m[1], 0, altHpel, bd, dst, reco->stride[c] );
       continue;
     }
     pel t[2][16 * 16];
@@ -637,6 +672,7 @@ static void plain_block( const vvr_picture* pic, const vvo_planes* refs, int x, 
     for( int yy = 0; yy < bh; yy++ ) for( int xx = 0; xx < bw; xx++ )
     {
       int v;
+      if( wp ) { dst[yy * reco->stride[c] + xx] = (pel) wp_bi( pic, ref_idx[0], ref_idx[1], c, t[0][yy * bw + xx], t[1][yy * bw + xx] ); continue; }
       if( bcw_idx != 2 ) { const int w1 = vvc_bcw_weights[bcw_idx], w0 = 8 - w1; v = ( t[0][yy * bw + xx] * w0 + t[1][yy * bw + xx] * w1 + ( 1 << ( hr + 2 ) ) + ( IF_INTERNAL_OFFS << 3 ) ) >> ( hr + 3 ); }
       else v = ( t[0][yy * bw + xx] + t[1][yy * bw + xx] + ( 1 << hr ) + 2 * IF_INTERNAL_OFFS ) >> ( hr + 1 );
       dst[yy * reco->stride[c] + xx] = (pel) vvo_clip_pel( v, bd );
@@ -693,7 +729,14 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
       clip_mv( mv, cu->x, cu->y, H->width, H->height, ctu );
       const int slot = H->ref_slot[l][cu->ref_idx[l]];
       if( slot < 0 || slot >= num_slots || !refs[slot].p[0] ) { vvo_set_error( "missing reference slot" ); return -1; }
-      pred_block( &refs[slot], c, bx, by, w, h, mv[0], mv[1], 0, altHpel, bd, dst, reco->stride[c] );
+      if( wp_on( pic, cu->bcw_idx ) )
+      {   /* xPredInterUni at 14 bit, then addWeightUni */
+        pel* t = (pel*) malloc( sizeof( pel ) * (size_t) w * h );
+        pred_block( &refs[slot], c, bx, by, w, h, mv[0], mv[1], 1, altHpel, bd, t, w );
+        for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) dst[y * reco->stride[c] + x] = (pel) wp_uni( pic, l, cu->ref_idx[l], c, t[y * w + x] );
+        free( t );
+      }
+      else pred_block( &refs[slot], c, bx, by, w, h, mv[0], mv[1], 0, altHpel, bd, dst, reco->stride[c] );
     }
     else
     {
@@ -714,6 +757,11 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
         for( int y = 0; y < h; y += shh ) for( int x = 0; x < w; x += sw )
           bdof_luma_subblock( &refs[H->ref_slot[0][cu->ref_idx[0]]], &refs[H->ref_slot[1][cu->ref_idx[1]]], bx + x, by + y, sw, shh, mv0, mv1, altHpel, bd,
                               dst + (size_t) y * reco->stride[c] + x, reco->stride[c] );
+      }
+      else if( wp_on( pic, cu->bcw_idx ) )
+      {
+        for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+          dst[y * reco->stride[c] + x] = (pel) wp_bi( pic, cu->ref_idx[0], cu->ref_idx[1], c, t0[y * w + x], t1[y * w + x] );
       }
       else if( cu->bcw_idx != 2 )
       {   /* addWeightedAvg (Buffer.cpp:372): BCW */

@@ -30,6 +30,10 @@ def save(path, desc, refs, outputs):
         d["alf_params"] = _bytes_of(desc.alf_params)
     if desc.lmcs is not None:
         d["lmcs"] = _bytes_of(desc.lmcs)
+    if desc.wp is not None:
+        d["wp"] = _bytes_of(desc.wp)
+    if desc.scaling is not None:
+        d["scaling"] = _bytes_of(desc.scaling)
     for slot, planes in refs.items():
         for c, p in enumerate(planes):
             d["ref_%d_%d" % (slot, c)] = np.asarray(p, np.uint16)
@@ -60,6 +64,10 @@ def load(path):
         d.alf_params = abi.AlfParams.from_buffer_copy(z["alf_params"].tobytes())
     if "lmcs" in z:
         d.lmcs = abi.LmcsParams.from_buffer_copy(z["lmcs"].tobytes())
+    if "wp" in z:
+        d.wp = abi.WpParams.from_buffer_copy(z["wp"].tobytes())
+    if "scaling" in z:
+        d.scaling = abi.ScalingList.from_buffer_copy(z["scaling"].tobytes())
     refs, outs = {}, {}
     for k in z.files:
         if k.startswith("ref_"):

@@ -173,6 +173,38 @@ def test_sbtmvp_and_all_inter_tools(built):
     _run_stream(1920, 1080, 3, 2, 163, TOOLS_A, intra=True, streams=3, p_affine=0.15, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.15)
 
 
+def test_sub_block_transform(built):
+    """cu_sbt_flag: residual in one half / quarter of an inter CU (DST-7 / DCT-8 pairs by position, 2-wide chroma blocks), with and
+    without LMCS chroma residual scaling"""
+    _run_stream(256, 128, 5, 4, 171, TOOLS_A, intra=True, p_sbt=0.6, p_intra=0.1, p_coded_chroma=0.5, p_jccr=0.2)
+    T = TOOLS_A | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE
+    _run_stream(416, 240, 5, 4, 172, T, intra=True, log2_ctu=6, p_sbt=0.5, p_intra=0.15, p_affine=0.2, p_geo=0.1, p_coded_chroma=0.5)
+    _run_stream(1920, 1080, 3, 2, 173, T, intra=True, streams=3, p_sbt=0.3)
+
+
+def test_weighted_prediction(built):
+    """explicit weighted prediction: B pictures of a stream and one P picture (weights / offsets per reference and component)"""
+    import vvdec_amd
+    T = TOOLS_A | abi.TOOL_WP
+    _run_stream(256, 128, 5, 4, 181, T, intra=True, p_intra=0.1, p_affine=0.2, p_sbtmvp=0.15, p_ciip=0.1, p_geo=0.1, p_bcw=0.2)
+    _run_stream(1920, 1080, 3, 2, 182, T | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, intra=True, streams=3, p_affine=0.1, p_ciip=0.05)
+    W, H = 416, 240
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=3, num_streams=1)
+    refs = {1: synth.natural_picture(W, H, 183), 2: synth.natural_picture(W, H, 184)}
+    for slot, pic in refs.items():
+        rec.write_picture(slot, pic)
+    p = synth.default_params(width=W, height=H, seed=185, tool_flags=T, slice_type=abi.SLICE_P, p_affine=0.2, p_sbtmvp=0.15, p_ciip=0.1, p_intra=0.1)
+    p.poc, p.out_slot = 4, 0
+    synth.set_refs(p, [(1, 0), (2, 8)], [])
+    d = synth.generate(p)
+    rec.wait(rec.decompress_picture(d))
+    got = rec.read_picture(0)
+    want = refdrv.oracle_reconstruct(d, refs)
+    for c in range(3):
+        assert np.array_equal(got[c], want[c]), "P picture comp %d: %d samples differ" % (c, int((got[c] != want[c]).sum()))
+    rec.close()
+
+
 def test_joint_cbcr(built):
     """tu_joint_cbcr_residual: one coded chroma block, the other derived (all three modes, both signs)"""
     _run_stream(256, 128, 5, 4, 171, TOOLS_A, intra=True, p_jccr=0.7, p_coded_chroma=0.7, p_intra=0.3)

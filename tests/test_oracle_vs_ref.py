@@ -39,6 +39,8 @@ def _case(W, H, l2, idx, seed, tools=ALL, **kw):
     (200, 136, 5, 2, 114, dict(p_cclm=0.6, p_intra=0.5)),
     (256, 128, 7, 0, 115, dict(p_mip=0.5, p_cclm=0.2, p_lfnst=0.4)),
     (200, 136, 6, 2, 116, dict(p_mip=0.6, p_intra=0.5, p_split_scale=1.5)),
+    (256, 128, 7, 2, 117, dict(p_sbt=0.5, p_coded_chroma=0.5, p_jccr=0.2)),
+    (200, 136, 5, 3, 118, dict(p_sbt=0.7, p_intra=0.1, p_affine=0.2, p_geo=0.1)),
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)
@@ -63,6 +65,25 @@ def test_oracle_equals_reference_lmcs(built, idx, seed, cs):
             assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
 
 
+@pytest.mark.parametrize("slice_type,seed", [(0, 211), (1, 212), (0, 213)])
+def test_oracle_equals_reference_weighted_prediction(built, slice_type, seed):
+    """explicit weighted prediction of B (pps_weighted_bipred_flag) and P (pps_weighted_pred_flag) pictures: plain, affine,
+    SbTMVP and CIIP predictions weighted, BCW / GPM CUs untouched, BDOF / DMVR only between references with default weights"""
+    W, H = 256, 128
+    p = synth.default_params(width=W, height=H, seed=seed, tool_flags=ALL | abi.TOOL_WP, slice_type=slice_type, log2_ctu=6,
+                             p_affine=0.2, p_sbtmvp=0.15, p_ciip=0.1, p_geo=0.1, p_bcw=0.2, p_intra=0.1)
+    p.poc, p.out_slot = 4, 0
+    synth.set_refs(p, [(1, 0), (2, 8)], [] if slice_type == 1 else [(2, 8), (1, 0)])
+    d = synth.generate(p)
+    refs = {1: synth.natural_picture(W, H, seed + 1), 2: synth.natural_picture(W, H, seed + 2)}
+    for fl in (refdrv.STOP_AFTER_RECO, 0):
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+    assert d.wp is not None and any(d.wp.e[0][i][0].present for i in range(2))
+
+
 def test_reference_simd_equals_scalar(built):
     """the reference's own differential check (its unit test compares scalar vs SIMD kernels): same bytes at frame level"""
     d, refs = _case(256, 192, 7, 2, 106, p_intra=0.2)
@@ -75,6 +96,10 @@ def test_edge_parameters_match_reference_derivation(built):
     """deblocking with the edge parameters the reference derives itself (LoopFilter::calcFilterStrengthsCTU) == with the
     job's table (the host glue's restatement of that derivation)"""
     d, refs = _case(256, 128, 7, 2, 107, p_intra=0.2)       # no affine CUs: the generator's derivation has no sub-block edges
+    a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
+    b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    d, refs = _case(256, 128, 6, 3, 119, p_intra=0.1, p_sbt=0.6, p_coded_chroma=0.4)     # sub-block transform: TU edges inside inter CUs
     a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
     b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))

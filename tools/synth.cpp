@@ -66,6 +66,7 @@ typedef struct vvs_params {
   float    p_bcw;               // of bi-predicted CUs with at least 256 samples: unequal CU-level weights
   float    p_cclm;              // of intra CUs: chroma predicted from the reconstructed luma (CCLM, MDLM_L, MDLM_T)
   float    p_mip;               // of intra CUs: matrix-based luma prediction
+  float    p_sbt;               // of inter CUs (not CIIP, at most 64x64): sub-block transform (residual in one half / quarter of the CU)
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -79,6 +80,8 @@ typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
   vvr_alf_ctu* alf;
   vvr_alf_params* alf_params;
   vvr_lmcs_params* lmcs;          // filled when VVR_TOOL_LMCS is in tool_flags
+  vvr_wp_params*   wp;            // filled when VVR_TOOL_WP is in tool_flags (P / B pictures)
+  vvr_scaling_list* scaling;      // filled when VVR_TOOL_SCALING_LIST is in tool_flags
   // outputs
   uint32_t     num_cu, num_tu; uint64_t num_coef; uint32_t num_dmvr;
   vvr_pic_header hdr;
@@ -101,7 +104,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f; P->p_mip = 0.0f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f; P->p_mip = 0.0f; P->p_sbt = 0.0f;
 }
 
 namespace {
@@ -112,6 +115,32 @@ struct Gen {
   std::vector<int32_t> cuOf4;      // per 4x4: CU index
   std::vector<int32_t> tuOf4;      // per 4x4: TU index
   Gen( const vvs_params& p, vvs_buffers& b ) : P( p ), B( b ), rng( p.seed ) {}
+
+  bool wpOn = false;
+  bool wpPresent( int l, int r ) const { return wpOn && r >= 0 && ( B.wp->e[l][r][0].present || B.wp->e[l][r][1].present || B.wp->e[l][r][2].present ); }
+  // pred_weight_table(): denominators 0..7, weights 1 << denom + delta (delta in -128..127), offsets in -128..127 (8-bit units);
+  // one flag for luma and one for both chroma components per reference picture; own random stream
+  void genWp()
+  {
+    Rng r( P.seed * 0x9E3779B97F4A7C15ull + 77 );
+    vvr_wp_params& w = *B.wp; memset( &w, 0, sizeof( w ) );
+    w.log2_denom[0] = (uint8_t) r.u( 8 );
+    w.log2_denom[1] = (uint8_t) std::min( 7, std::max( 0, (int) w.log2_denom[0] + (int) r.u( 5 ) - 2 ) );
+    for( int l = 0; l < 2; l++ ) for( int i = 0; i < VVR_MAX_REFS; i++ )
+    {
+      const bool fl = i < P.num_ref[l] && r.p( 0.6 ), fc = i < P.num_ref[l] && P.chroma_format && r.p( 0.5 );
+      for( int c = 0; c < 3; c++ )
+      {
+        vvr_wp_entry& e = w.e[l][i][c];
+        const int den = w.log2_denom[c ? 1 : 0];
+        e.weight = (int16_t) ( 1 << den ); e.offset = 0; e.present = (uint8_t) ( c ? fc : fl );
+        if( !e.present ) continue;
+        const int span = std::max( 2, ( 1 << den ) / 2 );
+        e.weight = (int16_t) ( ( 1 << den ) + std::min( 127, std::max( -128, r.laplace( span / 3.0 ) ) ) );
+        e.offset = (int16_t) ( r.p( 0.1 ) ? ( r.p( 0.5 ) ? 127 : -128 ) : std::min( 127, std::max( -128, r.laplace( 6.0 ) ) ) );
+      }
+    }
+  }
 
   void clipMv( int32_t mv[2], int x, int y ) const   // clipMvInPic, Mv.cpp:64
   {
@@ -244,6 +273,7 @@ struct Gen {
       // branch taken by InterPrediction::motionCompensation (InterPrediction.cpp:1372-1459)
       bool identical = false;
       if( bi && P.ref_poc[0][cu.ref_idx[0]] == P.ref_poc[1][cu.ref_idx[1]] && cu.mv[0][0][0] == cu.mv[1][0][0] && cu.mv[0][0][1] == cu.mv[1][0][1] ) identical = true;
+      if( wpOn ) identical = false;                       // xCheckIdenticalMotion (:408): never with weighted bi-prediction
       // PU::isBiPredFromDifferentDirEqDistPoc (UnitTools.cpp:3094): one reference before, one after, same POC distance
       bool eqDist = false;
       if( bi ) { const int d0 = P.poc - P.ref_poc[0][cu.ref_idx[0]], d1 = P.poc - P.ref_poc[1][cu.ref_idx[1]]; eqDist = d0 * d1 < 0 && d0 == -d1; }
@@ -284,20 +314,44 @@ struct Gen {
         cu.ciip_neigh_intra = (uint8_t) ( ( isIntraAt( x - 1, y + h - 1 ) ? 1 : 0 ) | ( isIntraAt( x + w - 1, y - 1 ) ? 2 : 0 ) );
       }
       const bool aff = ( cu.flags & VVR_CU_AFFINE ) != 0;
-      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );      // (:1407-1427), no SMVD/WP here
-      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );   // PU::checkDMVRCondition (UnitTools.cpp:1277)
+      const bool wpAny = bi && ( wpPresent( 0, cu.ref_idx[0] ) || wpPresent( 1, cu.ref_idx[1] ) );       // BDOF / DMVR only with default weights (:1420, UnitTools.cpp:1297-1302)
+      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && !wpAny && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );      // (:1407-1427), no SMVD/WP here
+      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && !wpAny && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );   // PU::checkDMVRCondition (UnitTools.cpp:1277)
       // xCheckIdenticalMotion (:404) is false for affine CUs: they go through xPredInterBi -> xPredAffineBlk per list
       // affine CUs with the same reference picture and the same control points in both lists take the uni-directional path (:424-429)
       if( aff && bi && P.ref_poc[0][cu.ref_idx[0]] == P.ref_poc[1][cu.ref_idx[1]] && rng.p( 0.3 ) ) memcpy( cu.mv[1], cu.mv[0], sizeof( cu.mv[0] ) );
       cu.mc_mode = ( cu.flags & VVR_CU_SBTMVP ) ? VVR_MC_SBTMVP : ( cu.flags & VVR_CU_GEO ) ? VVR_MC_GEO : aff ? VVR_MC_AFFINE : dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
       if( dmvr ) { cu.dmvr_off = B.num_dmvr; B.num_dmvr += ( ( w + 15 ) / 16 ) * ( ( h + 15 ) / 16 ); }     // one delta MV per 16x16 sub-block (m_dmvrMvCache)
     }
+    // sub-block transform (cu_sbt_flag): the CU is split in two TUs, half/half or quarter/three quarters, and only one carries a residual
+    int sbtIdx = 0, sbtPos = 0;
+    if( !intra && P.p_sbt > 0 && !( cu.flags & VVR_CU_CIIP ) && w <= 64 && h <= 64 && rng.p( P.p_sbt ) )
+    {
+      int cand[4], n = 0;
+      if( w >= 8 ) cand[n++] = 1;      // SBT_VER_HALF
+      if( h >= 8 ) cand[n++] = 2;      // SBT_HOR_HALF
+      if( w >= 16 ) cand[n++] = 3;     // SBT_VER_QUAD
+      if( h >= 16 ) cand[n++] = 4;     // SBT_HOR_QUAD
+      sbtIdx = cand[rng.u( n )]; sbtPos = rng.u( 2 );
+      cu.sbt_info = (uint8_t) ( sbtIdx | ( sbtPos << 4 ) );
+    }
     // transform units: split at 64 (max TB size), cbf per block
     cu.first_tu = B.num_tu;
     bool rootCbf = false;
     const int tw = std::min( w, 64 ), th = std::min( h, 64 );
-    for( int ty = 0; ty < h; ty += th ) for( int tx = 0; tx < w; tx += tw )
+    struct Tb { int x, y, w, h; bool resi; } tbs[4]; int ntb = 0;
+    if( sbtIdx )
     {
+      const bool ver = sbtIdx == 1 || sbtIdx == 3, quad = sbtIdx >= 3;
+      const int full = ver ? w : h, a = quad ? ( sbtPos == 0 ? full / 4 : 3 * full / 4 ) : full / 2;
+      tbs[0] = ver ? Tb{ 0, 0, a, h, sbtPos == 0 } : Tb{ 0, 0, w, a, sbtPos == 0 };
+      tbs[1] = ver ? Tb{ a, 0, w - a, h, sbtPos == 1 } : Tb{ 0, a, w, h - a, sbtPos == 1 };
+      ntb = 2;
+    }
+    else for( int ty = 0; ty < h; ty += th ) for( int tx = 0; tx < w; tx += tw ) tbs[ntb++] = Tb{ tx, ty, tw, th, true };
+    for( int ti = 0; ti < ntb; ti++ )
+    {
+      const int tx = tbs[ti].x, ty = tbs[ti].y, tw = tbs[ti].w, th = tbs[ti].h;
       vvr_tu& tu = B.tu[B.num_tu]; memset( &tu, 0, sizeof( tu ) );
       const uint32_t tuIdx = B.num_tu++;
       tu.x = x + tx; tu.y = y + ty; tu.w = tw; tu.h = th; tu.cu = cuIdx;
@@ -308,12 +362,13 @@ struct Gen {
       // joint coding of the chroma residuals (tu_joint_cbcr_residual_flag): one coded block, mode = ( cbfCb << 1 ) | cbfCr,
       // levels in Cb for modes 2 / 3 and in Cr for mode 1 (TrQuant::invTransformICT, TrQuant.cpp:320)
       int jccr = 0;
+      if( sbtIdx && !tbs[ti].resi ) goto tu_done;       // the other part of an SBT CU: no residual at all
       if( P.chroma_format && P.p_jccr > 0 && rng.p( P.p_coded_chroma ) && rng.p( P.p_jccr ) ) jccr = 1 + rng.u( 3 );
       tu.joint_cbcr = (uint8_t) jccr;
       for( int c = 0; c < ( P.chroma_format ? 3 : 1 ); c++ )
       {
         const int bw = c ? tw >> 1 : tw, bh = c ? th >> 1 : th;
-        const bool force = c == 0 && ( ( intra && ( cu.bdpcm[0] || cu.lfnst_idx ) ) || ( cu.flags & VVR_CU_CIIP ) );     // these modes are only signalled with a coded luma block (CIIP: merge, never skip => cu_coded_flag = 1)
+        const bool force = c == 0 && ( ( intra && ( cu.bdpcm[0] || cu.lfnst_idx ) ) || ( cu.flags & VVR_CU_CIIP ) || sbtIdx );     // these modes are only signalled with a coded luma block (CIIP: merge, never skip => cu_coded_flag = 1)
         if( c && jccr )
         {
           if( ( jccr >> ( 2 - c ) ) & 1 ) tu.cbf |= 1 << c;
@@ -324,18 +379,24 @@ struct Gen {
           if( !force && !rng.p( c ? P.p_coded_chroma : P.p_coded ) ) continue;
           tu.cbf |= 1 << c;
         }
-        bool ts = bw <= 32 && bh <= 32 && rng.p( P.p_ts );
+        bool ts = bw <= 32 && bh <= 32 && !sbtIdx && rng.p( P.p_ts );
         if( c == 0 && intra && cu.bdpcm[0] ) ts = true;
         if( c == 0 && intra && cu.lfnst_idx ) ts = false;
         tu.mts_idx[c] = ts ? VVR_MTS_SKIP : VVR_MTS_DCT2;
-        if( !ts && c == 0 && bw <= 32 && bh <= 32 && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
+        if( !ts && c == 0 && bw <= 32 && bh <= 32 && !sbtIdx && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
         // getTrTypes (TrQuant.cpp:330): explicit MTS -> hor = (idx-2)&1 ? DCT8 : DST7 ; ver = (idx-2)>>1 ? DCT8 : DST7
         int hor = 0, ver = 0;
         if( tu.mts_idx[c] > 1 ) { hor = ( ( tu.mts_idx[c] - 2 ) & 1 ) ? 1 : 2; ver = ( ( tu.mts_idx[c] - 2 ) >> 1 ) ? 1 : 2; }
+        if( sbtIdx && c == 0 )
+        {   // the transform pair follows from the position of the residual part (getTrTypes, TrQuant.cpp:366-398); 1 = DCT8, 2 = DST7
+          if( sbtIdx == 1 || sbtIdx == 3 ) { if( bh > 32 ) hor = ver = 0; else { hor = sbtPos == 0 ? 1 : 2; ver = 2; } }
+          else                             { if( bw > 32 ) hor = ver = 0; else { hor = 2; ver = sbtPos == 0 ? 1 : 2; } }
+        }
         tu.tr_type[c] = (uint8_t) ( ( ver << 2 ) | hor );
         genLevels( tu, c, bw, bh, ts, c == 0 && intra && cu.bdpcm[0], c == 0 && intra && cu.lfnst_idx );
         rootCbf = true;
       }
+      tu_done:
       for( int yy = 0; yy < th; yy += 4 ) for( int xx = 0; xx < tw; xx += 4 )
         if( tu.x + xx < W && tu.y + yy < H ) tuOf4[( ( tu.y + yy ) >> 2 ) * w4 + ( ( tu.x + xx ) >> 2 )] = (int32_t) tuIdx;
     }
@@ -638,6 +699,9 @@ struct Gen {
     h.log2_ctu = P.log2_ctu; h.slice_type = P.slice_type; h.poc = P.poc; h.out_slot = P.out_slot; h.min_qp_ts = 4;
     for( int l = 0; l < 2; l++ ) { h.num_ref[l] = P.slice_type == 2 ? 0 : P.num_ref[l]; for( int i = 0; i < VVR_MAX_REFS; i++ ) { h.ref_slot[l][i] = P.ref_slot[l][i]; h.ref_poc[l][i] = P.ref_poc[l][i]; } }
     for( int c = 0; c < 3; c++ ) { h.deblock_beta_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); h.deblock_tc_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); }
+    if( P.slice_type == 2 ) h.tool_flags &= ~(uint32_t) VVR_TOOL_WP;
+    wpOn = ( h.tool_flags & VVR_TOOL_WP ) && B.wp;
+    if( wpOn ) genWp();
     int a = 0;
     for( int y = 0; y < H; y += ctu ) for( int x = 0; x < W; x += ctu, a++ ) { B.ctu_first_cu[a] = B.num_cu; split( x, y, ctu, ctu ); }
     B.ctu_first_cu[a] = B.num_cu;

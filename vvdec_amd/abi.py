@@ -20,7 +20,8 @@ VVR_OK, VVR_ERR_UNSPECIFIED, VVR_ERR_PARAMETER, VVR_ERR_UNSUPPORTED, VVR_ERR_DEV
 
 # tool flags
 TOOL_SAO_LUMA, TOOL_SAO_CHROMA, TOOL_ALF, TOOL_CCALF, TOOL_LMCS, TOOL_LMCS_CSCALE, TOOL_DEBLOCK_OFF, TOOL_DEP_QUANT, \
-    TOOL_BDOF, TOOL_DMVR, TOOL_PROF, TOOL_JCCR_SIGN, TOOL_STILL_REF, TOOL_LFNST, TOOL_MTS, TOOL_CCLM_COLLOC = [1 << i for i in range(16)]
+    TOOL_BDOF, TOOL_DMVR, TOOL_PROF, TOOL_JCCR_SIGN, TOOL_STILL_REF, TOOL_LFNST, TOOL_MTS, TOOL_CCLM_COLLOC, \
+    TOOL_WP, TOOL_SCALING_LIST, TOOL_SCALING_LIST_NO_LFNST = [1 << i for i in range(19)]
 
 PRED_INTER, PRED_INTRA, PRED_IBC = 0, 1, 2
 TREE_JOINT, TREE_LUMA, TREE_CHROMA = 0, 1, 2
@@ -88,13 +89,26 @@ class AlfCtu(C.Structure):
     _fields_ = [("cc_idc", u8 * 2), ("enable", u8 * 3), ("alt", u8 * 2), ("pad", u8), ("luma_filter_idx", i16), ("pad2", u8 * 2)]
 
 
+class WpEntry(C.Structure):
+    _fields_ = [("weight", i16), ("offset", i16), ("present", u8), ("pad", u8 * 3)]
+
+
+class WpParams(C.Structure):
+    _fields_ = [("log2_denom", u8 * 2), ("pad", u8 * 6), ("e", WpEntry * 3 * VVR_MAX_REFS * 2)]
+
+
+class ScalingList(C.Structure):
+    _fields_ = [("coef", u8 * 64 * 28), ("dc", u8 * 28), ("pad", u8 * 4)]
+
+
 class Picture(C.Structure):
     _fields_ = [("hdr", PicHeader), ("num_cu", u32), ("num_tu", u32),
                 ("cu", C.POINTER(Cu)), ("tu", C.POINTER(Tu)), ("ctu_first_cu", C.POINTER(u32)),
                 ("coef", C.POINTER(i16)), ("num_coef", u64),
                 ("motion", C.POINTER(Motion)), ("lfp", C.POINTER(Lfp) * 2),
                 ("sao", C.POINTER(SaoCtu)), ("alf", C.POINTER(AlfCtu)),
-                ("alf_params", C.POINTER(AlfParams)), ("lmcs", C.POINTER(LmcsParams)), ("resident", C.c_int)]
+                ("alf_params", C.POINTER(AlfParams)), ("lmcs", C.POINTER(LmcsParams)),
+                ("wp", C.POINTER(WpParams)), ("scaling", C.POINTER(ScalingList)), ("resident", C.c_int)]
 
 
 class Config(C.Structure):

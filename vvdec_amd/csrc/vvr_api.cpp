@@ -111,7 +111,8 @@ VVR_API const char* vvr_version( void ) { return "vvdec_amd 0.1 (gfx950, ABI 1)"
 VVR_API size_t vvr_abi_sizeof( int which )
 {
   static const size_t sz[] = { sizeof( vvr_pic_header ), sizeof( vvr_cu ), sizeof( vvr_tu ), sizeof( vvr_motion ), sizeof( vvr_lfp ), sizeof( vvr_sao_ctu ),
-                               sizeof( vvr_alf_ctu ), sizeof( vvr_alf_params ), sizeof( vvr_lmcs_params ), sizeof( vvr_picture ), sizeof( vvr_config ), sizeof( vvr_kernel_stat ) };
+                               sizeof( vvr_alf_ctu ), sizeof( vvr_alf_params ), sizeof( vvr_lmcs_params ), sizeof( vvr_picture ), sizeof( vvr_config ), sizeof( vvr_kernel_stat ),
+                               sizeof( vvr_wp_params ), sizeof( vvr_scaling_list ) };
   return which >= 0 && which < (int) ( sizeof( sz ) / sizeof( sz[0] ) ) ? sz[which] : 0;
 }
 
@@ -225,6 +226,10 @@ static int validate( vvr_context* c, const vvr_picture* p )
   if( h.out_slot < 0 || h.out_slot >= c->cfg.num_slots ) { c->setError( "out_slot out of range" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && !( h.tool_flags & VVR_TOOL_LMCS ) ) { c->setError( "LMCS chroma residual scaling without LMCS" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & VVR_TOOL_LMCS ) && !p->lmcs ) { c->setError( "LMCS enabled without tables" ); return VVR_ERR_PARAMETER; }
+  const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
+  if( wpOn && !p->wp ) { c->setError( "weighted prediction enabled without the weight table" ); return VVR_ERR_PARAMETER; }
+  if( wpOn && ( p->wp->log2_denom[0] > 7 || p->wp->log2_denom[1] > 7 ) ) { c->setError( "weighted prediction: log2 denominator out of range" ); return VVR_ERR_PARAMETER; }
+  if( h.tool_flags & VVR_TOOL_SCALING_LIST ) { c->setError( "explicit scaling lists are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
   if( !p->cu || !p->tu || !p->coef || !p->lfp[0] || !p->lfp[1] ) { c->setError( "missing arrays" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & VVR_TOOL_ALF ) && ( !p->alf || !p->alf_params ) ) { c->setError( "ALF enabled without parameters" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) && !p->sao ) { c->setError( "SAO enabled without parameters" ); return VVR_ERR_PARAMETER; }
@@ -268,6 +273,15 @@ static int validate( vvr_context* c, const vvr_picture* p )
       { c->setError( "CIIP CU: needs plain uni/bi prediction and a CU of 8..64 with one TU (4-wide CIIP CUs are not implemented)" ); return VVR_ERR_UNSUPPORTED; }
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) { c->setError( "ref_idx out of range" ); return VVR_ERR_PARAMETER; }
       if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo && !isSbt ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
+      if( wpOn && cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 )
+      {
+        // weighted prediction: BDOF / DMVR only between references with default weights (InterPrediction.cpp:1420, UnitTools.cpp:1297-1302);
+        // no identical-motion shortcut (:408)
+        bool present = false;
+        for( int l = 0; l < 2; l++ ) for( int k = 0; k < 3; k++ ) present |= p->wp->e[l][cu.ref_idx[l]][k].present != 0;
+        if( present && ( isDmvr || cu.mc_mode == VVR_MC_BDOF ) ) { c->setError( "mc_mode BDOF / DMVR between references with explicit prediction weights" ); return VVR_ERR_PARAMETER; }
+        if( cu.mc_mode == VVR_MC_UNI ) { c->setError( "mc_mode UNI on a bi-predicted CU of a picture with weighted prediction" ); return VVR_ERR_PARAMETER; }
+      }
       if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) { c->setError( "inter CU must be single tree" ); return VVR_ERR_PARAMETER; }
     }
     else if( cu.pred_mode == VVR_PRED_INTRA )
@@ -655,6 +669,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     }
   }
   const int iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
+  const int iWp = ( ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2 ) ? add( p->wp, sizeof( vvr_wp_params ) ) : -1;
   const int iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
   const int iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
   if( lmcs ) { bytes[K_LMCS] = ( samples / ( ncomp == 3 ? 1.5 : 1.0 ) ) * 4 * 2; }     // forward pass over the inter luma (upper bound) + inverse pass over all luma
@@ -689,6 +704,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   d.alf = iAlf >= 0 ? (const vvr_alf_ctu*) ( base + parts[iAlf].off ) : nullptr;
   d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
   d.lmcs = iLmcs >= 0 ? (const vvr_lmcs_params*) ( base + parts[iLmcs].off ) : nullptr;
+  d.wp = iWp >= 0 ? (const vvr_wp_params*) ( base + parts[iWp].off ) : nullptr;
   d.interAt = iInterAt >= 0 ? (const uint8_t*) ( base + parts[iInterAt].off ) : nullptr;
   d.csVpdu = iCsVpdu >= 0 ? (const uint32_t*) ( base + parts[iCsVpdu].off ) : nullptr; d.vpdusX = vpdusX; d.vpduLog2 = vpduLog2;
   q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();

@@ -265,6 +265,23 @@ __device__ __forceinline__ void mc_fir8( const uint4 lo, const uint4 hi, const u
 #define MC2_TST_C 16
 
 // LDS working set of the two filter stages (one tile = one wavefront)
+// Explicit weighted prediction (WeightPrediction::getWpScaling / addWeightUni / addWeightBi, WeightPrediction.cpp:66-157,238-338,164-236):
+// final stage of plain, SbTMVP, CIIP and affine predictions of a picture with VVR_TOOL_WP (unless BCW weights or GPM are in use);
+// p, p0, p1 are the 14-bit intermediate predictions, headroom = max( 2, 14 - bitDepth )
+__device__ __forceinline__ int wp_uni( const vvr_wp_params* __restrict__ wp, int l, int ri, int c, int p, int bd, int headroom )
+{
+  const vvr_wp_entry e = wp->e[l][ri][c];
+  const int den = wp->log2_denom[c ? 1 : 0], shift = den + headroom, offset = e.offset * ( 1 << ( bd - 8 ) );
+  if( e.weight != ( 1 << den ) ) return clip_pel( ( ( e.weight * ( p + IF_INTERNAL_OFFS ) + ( 1 << ( shift - 1 ) ) ) >> shift ) + offset, bd );
+  return clip_pel( ( ( p + IF_INTERNAL_OFFS + ( 1 << ( headroom - 1 ) ) ) >> headroom ) + offset, bd );
+}
+__device__ __forceinline__ int wp_bi( const vvr_wp_params* __restrict__ wp, int r0, int r1, int c, int p0, int p1, int bd, int headroom )
+{
+  const vvr_wp_entry e0 = wp->e[0][r0][c], e1 = wp->e[1][r1][c];
+  const int den = wp->log2_denom[c ? 1 : 0], shift = den + 1 + headroom, offset = ( e0.offset + e1.offset ) * ( 1 << ( bd - 8 ) );
+  return clip_pel( ( e0.weight * ( p0 + IF_INTERNAL_OFFS ) + e1.weight * ( p1 + IF_INTERNAL_OFFS ) + ( ( 1 << shift ) >> 1 ) + offset * ( 1 << ( shift - 1 ) ) ) >> shift, bd );
+}
+
 struct Mc2Shared {
   __attribute__( ( aligned( 16 ) ) ) pel_t winL[2][23 * MC2_WST_L];
   __attribute__( ( aligned( 16 ) ) ) pel_t winC[2][2][11 * MC2_WST_C];
@@ -316,7 +333,8 @@ __device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int
 // bs: BDOF buffers (the 14-bit luma predictions go there instead of being averaged) or nullptr
 template<int NT>
 __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int nl, int ncomp, bool uni, const vvr_cu& cu, bool geo, int bcwIdx, int bd, int headroom,
-                                            const DevPlanes& reco, int tx, int ty, int tw, int th, int tid )
+                                            const DevPlanes& reco, int tx, int ty, int tw, int th, int tid,
+                                            const vvr_wp_params* __restrict__ wp = nullptr /* non-null: explicit weighted prediction */, int wpL = 0, int wpR0 = 0, int wpR1 = 0 )
 {
   struct { int x, y, w, h; } it = { tx, ty, tw, th };
   auto& tmpL = m.tmpL; auto& tmpC = m.tmpC; auto& coefV = m.coefV;
@@ -360,7 +378,12 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
       {
         if( 8 * g8 + i >= hh ) break;
         int out;
-        if( uni )
+        if( wp )
+        {
+          if( uni ) out = wp_uni( wp, wpL, wpL ? wpR1 : wpR0, c, (int16_t) ( p[0][i] >> 6 ), bd, headroom );
+          else      out = wp_bi( wp, wpR0, wpR1, c, (int16_t) ( p[0][i] >> 6 ), (int16_t) ( p[1][i] >> 6 ), bd, headroom );
+        }
+        else if( uni )
         {
           const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
           out = clip_pel( (int16_t) ( ( p[0][i] + offset2 ) >> shift2 ), bd );
@@ -414,7 +437,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
     const vvr_motion& m = pic.motion[(size_t) ( it.y >> 2 ) * pic.w4 + ( it.x >> 2 )];
     for( int l = 0; l < 2; l++ ) { mRef[l] = m.ref_idx[l]; mMv[l][0] = m.mv[l][0]; mMv[l][1] = m.mv[l][1]; }
     const bool two = mRef[0] >= 0 && mRef[1] >= 0;
-    uni = !two || ( pic.hdr.ref_poc[0][mRef[0]] == pic.hdr.ref_poc[1][mRef[1]] && mMv[0][0] == mMv[1][0] && mMv[0][1] == mMv[1][1] );
+    uni = !two || ( pic.hdr.ref_poc[0][mRef[0]] == pic.hdr.ref_poc[1][mRef[1]] && mMv[0][0] == mMv[1][0] && mMv[0][1] == mMv[1][1] && !pic.wp /* :408 */ );
   }
   const int clipX = sub ? it.x : cu.x, clipY = sub ? it.y : cu.y;
   const bool biPred = mRef[0] >= 0 && mRef[1] >= 0;
@@ -455,7 +478,9 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   __syncthreads();
   mc2_stage1<NT>( m, nl, ncomp, it.w, it.h, headroom, tid );
   __syncthreads();
-  mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, uni, cu, geo, cu.bcw_idx, bd, headroom, reco, it.x, it.y, it.w, it.h, tid );
+  const bool wpOn = !BDOF && pic.wp && !geo && cu.bcw_idx == 2;          // xPredInterBi (:707,735-742)
+  mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, uni, cu, geo, cu.bcw_idx, bd, headroom, reco, it.x, it.y, it.w, it.h, tid,
+                  wpOn ? pic.wp : nullptr, l0, mRef[0], mRef[1] );
   if constexpr( BDOF )
   {
     __syncthreads();
@@ -749,8 +774,10 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   // xCheckIdenticalMotion (:404-436): same reference picture and same control-point MVs in both lists -> list 0 only
   if( biPred && pic.hdr.ref_poc[0][cu.ref_idx[0]] == pic.hdr.ref_poc[1][cu.ref_idx[1]]
       && cu.mv[0][0][0] == cu.mv[1][0][0] && cu.mv[0][0][1] == cu.mv[1][0][1] && cu.mv[0][1][0] == cu.mv[1][1][0] && cu.mv[0][1][1] == cu.mv[1][1][1]
-      && ( !( cu.flags & VVR_CU_AFFINE_6P ) || ( cu.mv[0][2][0] == cu.mv[1][2][0] && cu.mv[0][2][1] == cu.mv[1][2][1] ) ) ) biPred = false;
+      && ( !( cu.flags & VVR_CU_AFFINE_6P ) || ( cu.mv[0][2][0] == cu.mv[1][2][0] && cu.mv[0][2][1] == cu.mv[1][2][1] ) ) && !pic.wp /* :408 */ ) biPred = false;
   const int l0 = cu.ref_idx[0] >= 0 ? 0 : 1, nl = biPred ? 2 : 1;
+  const bool wpOn = pic.wp && cu.bcw_idx == 2;       // explicit weighted prediction: also a single list stays at 14 bit until the final stage
+  const bool hi = biPred || wpOn;
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   // ---- sub-block geometry
   {
@@ -870,7 +897,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   {
     const int k = i / ( w * h ), r = i - k * w * h, sb = r >> 4, px = r & 3, py = ( r >> 2 ) & 3;
     const bool prof = sh.prof[k] != 0;
-    const int v = aff_sample( sh.winL[k][sb], AF_WL, sh.tmpL[k][sb], sh.segL[k][sb], 0, biPred || prof, bd, px, py );
+    const int v = aff_sample( sh.winL[k][sb], AF_WL, sh.tmpL[k][sb], sh.segL[k][sb], 0, hi || prof, bd, px, py );
     if( prof ) sh.ext[k][sb][( 1 + py ) * 6 + 1 + px] = (pel_t) v;
     else sh.predL[k][sb * 16 + py * 4 + px] = (pel_t) v;
   }
@@ -895,7 +922,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
     int dI = sh.dMvH[k][py * 4 + px] * gX + sh.dMvV[k][py * 4 + px] * gY;
     dI = clip3( -dILimit, dILimit - 1, dI );
     int v = (int16_t) ( sp[0] + dI );
-    if( !biPred ) { v = (int16_t) ( ( v + ( 1 << ( headroom - 1 ) ) + IF_INTERNAL_OFFS ) >> headroom ); v = clip_pel( v, bd ); }
+    if( !hi ) { v = (int16_t) ( ( v + ( 1 << ( headroom - 1 ) ) + IF_INTERNAL_OFFS ) >> headroom ); v = clip_pel( v, bd ); }
     sh.predL[k][sb * 16 + py * 4 + px] = (pel_t) v;
   }
   __syncthreads();
@@ -910,11 +937,12 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       if( c == 0 ) { p0 = sh.predL[0][sb * 16 + py * 4 + px]; if( biPred ) p1 = sh.predL[1][sb * 16 + py * 4 + px]; }
       else
       {
-        p0 = aff_sample( sh.winC[0][c - 1][sb], AF_WC, sh.tmpC[0][c - 1][sb], sh.segC[0][sb], c, biPred, bd, px, py );
+        p0 = aff_sample( sh.winC[0][c - 1][sb], AF_WC, sh.tmpC[0][c - 1][sb], sh.segC[0][sb], c, hi, bd, px, py );
         if( biPred ) p1 = aff_sample( sh.winC[1][c - 1][sb], AF_WC, sh.tmpC[1][c - 1][sb], sh.segC[1][sb], c, true, bd, px, py );
       }
       int out = p0;
-      if( biPred )
+      if( wpOn ) out = biPred ? wp_bi( pic.wp, cu.ref_idx[0], cu.ref_idx[1], c, p0, p1, bd, headroom ) : wp_uni( pic.wp, l0, cu.ref_idx[l0], c, p0, bd, headroom );
+      else if( biPred )
       {
         if( cu.bcw_idx != 2 )
         {

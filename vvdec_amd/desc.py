@@ -39,6 +39,8 @@ class PictureDesc:
         self.alf = None
         self.alf_params = None
         self.lmcs = None
+        self.wp = None
+        self.scaling = None
 
     def set_refs(self, l0, l1=()):
         """l0/l1: lists of (slot, poc)."""
@@ -74,6 +76,10 @@ class PictureDesc:
             p.alf_params = C.pointer(self.alf_params)
         if self.lmcs is not None:
             p.lmcs = C.pointer(self.lmcs)
+        if self.wp is not None:
+            p.wp = C.pointer(self.wp)
+        if self.scaling is not None:
+            p.scaling = C.pointer(self.scaling)
         p.resident = 0
         self._keep = p
         return p

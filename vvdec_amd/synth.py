@@ -32,13 +32,13 @@ class Params(C.Structure):
                 ("p_split_scale", C.c_float), ("mv_sigma", C.c_float),
                 ("p_sao", C.c_float), ("p_alf_luma", C.c_float), ("p_alf_chroma", C.c_float), ("p_ccalf", C.c_float),
                 ("p_imv_hpel", C.c_float), ("p_jccr", C.c_float), ("p_mrl", C.c_float), ("p_bdpcm", C.c_float),
-                ("p_affine", C.c_float), ("p_geo", C.c_float), ("p_ciip", C.c_float), ("p_sbtmvp", C.c_float), ("p_bcw", C.c_float), ("p_cclm", C.c_float), ("p_mip", C.c_float)]
+                ("p_affine", C.c_float), ("p_geo", C.c_float), ("p_ciip", C.c_float), ("p_sbtmvp", C.c_float), ("p_bcw", C.c_float), ("p_cclm", C.c_float), ("p_mip", C.c_float), ("p_sbt", C.c_float)]
 
 
 class Buffers(C.Structure):
     _fields_ = [("cu", C.c_void_p), ("max_cu", C.c_uint32), ("tu", C.c_void_p), ("max_tu", C.c_uint32),
                 ("coef", C.c_void_p), ("max_coef", C.c_uint64), ("ctu_first_cu", C.c_void_p),
-                ("motion", C.c_void_p), ("lfp", C.c_void_p * 2), ("sao", C.c_void_p), ("alf", C.c_void_p), ("alf_params", C.c_void_p), ("lmcs", C.c_void_p),
+                ("motion", C.c_void_p), ("lfp", C.c_void_p * 2), ("sao", C.c_void_p), ("alf", C.c_void_p), ("alf_params", C.c_void_p), ("lmcs", C.c_void_p), ("wp", C.c_void_p), ("scaling", C.c_void_p),
                 ("num_cu", C.c_uint32), ("num_tu", C.c_uint32), ("num_coef", C.c_uint64), ("num_dmvr", C.c_uint32),
                 ("hdr", abi.PicHeader)]
 
@@ -94,6 +94,12 @@ def generate(p):
     if p.tool_flags & abi.TOOL_LMCS:
         d.lmcs = abi.LmcsParams()
         b.lmcs = C.addressof(d.lmcs)
+    if (p.tool_flags & abi.TOOL_WP) and p.slice_type != abi.SLICE_I:
+        d.wp = abi.WpParams()
+        b.wp = C.addressof(d.wp)
+    if p.tool_flags & abi.TOOL_SCALING_LIST:
+        d.scaling = abi.ScalingList()
+        b.scaling = C.addressof(d.scaling)
     rc = L.vvs_generate(C.byref(p), C.byref(b))
     if rc != 0:
         raise RuntimeError("vvs_generate failed (%d)" % rc)
