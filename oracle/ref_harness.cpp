@@ -156,6 +156,8 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     sps.setUseSMVD( true );
     sps.setAMVREnabledFlag( true );
     sps.setSBTMVPEnabledFlag( true );
+    sps.setScalingListFlag( !!( H.tool_flags & VVR_TOOL_SCALING_LIST ) );
+    sps.setDisableScalingMatrixForLfnstBlks( !!( H.tool_flags & VVR_TOOL_SCALING_LIST_NO_LFNST ) );
     sps.setDepQuantEnabledFlag( !!( H.tool_flags & VVR_TOOL_DEP_QUANT ) );
     sps.setMaxTLayers( 1 );
     {
@@ -197,6 +199,22 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     ph->setJointCbCrSignFlag( !!( H.tool_flags & VVR_TOOL_JCCR_SIGN ) );
     ph->setLmcsEnabledFlag( !!( H.tool_flags & VVR_TOOL_LMCS ) );
     ph->setLmcsChromaResidualScaleFlag( !!( H.tool_flags & VVR_TOOL_LMCS_CSCALE ) );
+    std::shared_ptr<APS> slAps;
+    if( ( H.tool_flags & VVR_TOOL_SCALING_LIST ) && vp->scaling )
+    {   // scaling list APS as the parser leaves it (APS::m_scalingListApsInfo); Quant::init (Quant.cpp:622) expands it
+      slAps = std::make_shared<APS>();
+      slAps->setAPSId( 0 ); slAps->setAPSType( SCALING_LIST_APS );
+      ScalingList& sl = slAps->getScalingList();
+      for( int id = 0; id < 28; id++ )
+      {
+        const int n = ScalingList::matrixSize( id );
+        int* dst = sl.getScalingListAddress( id );
+        for( int k = 0; k < n * n; k++ ) dst[k] = vp->scaling->coef[id][k];
+        sl.setScalingListDC( id, vp->scaling->dc[id] );
+      }
+      ph->setExplicitScalingListEnabledFlag( true );
+      ph->setScalingListAPS( slAps );
+    }
     std::shared_ptr<APS> lmcsAps;
     if( ( H.tool_flags & VVR_TOOL_LMCS ) && vp->lmcs )
     {
@@ -298,7 +316,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
         alfApss[a] = aps.get();
       }
     }
-    pic.finalInit( &cuCache, &tuCache, &sps, &pps, ph, useAlf ? alfApss : nullAps, lmcsAps.get(), nullptr );
+    pic.finalInit( &cuCache, &tuCache, &sps, &pps, ph, useAlf ? alfApss : nullAps, lmcsAps.get(), slAps.get() );
     CodingStructure& cs = *pic.cs;
     TR("finalInit done\n");
 
@@ -319,7 +337,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     slice->setSaoEnabledFlag( CHANNEL_TYPE_LUMA, !!( H.tool_flags & VVR_TOOL_SAO_LUMA ) );
     slice->setSaoEnabledFlag( CHANNEL_TYPE_CHROMA, !!( H.tool_flags & VVR_TOOL_SAO_CHROMA ) );
     slice->setLmcsEnabledFlag( !!( H.tool_flags & VVR_TOOL_LMCS ) );
-    slice->setExplicitScalingListUsed( false );
+    slice->setExplicitScalingListUsed( ( H.tool_flags & VVR_TOOL_SCALING_LIST ) && vp->scaling );
     slice->setIndependentSliceIdx( 0 );
     slice->resetSliceMap();
     slice->addCtusToSlice( 0, pps.pcv->widthInCtus, 0, pps.pcv->heightInCtus, pps.pcv->widthInCtus );

@@ -116,6 +116,7 @@ static void lmcs_scale_residual( int16_t* r, int n, int scale, int bd )
 int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, uint16_t* const* out_planes, int flags )
 {
   vvo_dmvr_reset();
+  vvo_set_scaling_list( ( pic->hdr.tool_flags & VVR_TOOL_SCALING_LIST ) ? pic->scaling : 0 );
   const vvr_pic_header* H = &pic->hdr;
   const int W = H->width, Hh = H->height, ncomp = H->chroma_format ? 3 : 1;
   int rc = -1;

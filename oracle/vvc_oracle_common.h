@@ -34,6 +34,7 @@ int  vvo_planes_alloc( vvo_planes* pl, int width, int height, int chroma_format 
 void vvo_planes_free( vvo_planes* pl );
 
 /* vvc_oracle_trafo.c */
+void vvo_set_scaling_list( const vvr_scaling_list* sl );     /* the picture's explicit scaling lists (NULL: flat) */
 int  vvo_residual_block( const vvr_pic_header* hdr, const vvr_cu* cu, const vvr_tu* tu, int comp, const int16_t* coef, int16_t* resi, int rstride );
 /* vvc_oracle_inter.c */
 int  vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* refs /* [slot] */, int num_slots, vvo_planes* reco );

@@ -15,6 +15,29 @@ static const int16_t* tr_matrix( int type, int n )   /* type: 0 DCT2, 1 DCT8, 2 
   return 0;
 }
 
+/* Explicit scaling lists: the matrix entry the reference's expanded tables hold at (x, y) of a (1 << lw) x (1 << lh) block
+ * (Quant::setScalingListDec / xSetScalingListDec / xSetRecScalingListDec / processScalingListDec, Quant.cpp:386-570; list ids
+ * g_scalingListId, Rom.cpp:504; list type = ( intra ? 0 : 3 ) + component, Quant.h getScalingListType). */
+static const vvr_scaling_list* g_scaling = 0;
+void vvo_set_scaling_list( const vvr_scaling_list* sl ) { g_scaling = sl; }
+static int scaling_entry( const vvr_scaling_list* sl, int listType, int lw, int lh, int x, int y )
+{
+  static const uint8_t ids[7][6] = { { 0, 0, 0, 0, 0, 0 }, { 0, 0, 0, 0, 0, 1 }, { 2, 3, 4, 5, 6, 7 }, { 8, 9, 10, 11, 12, 13 }, { 14, 15, 16, 17, 18, 19 },
+                                     { 20, 21, 22, 23, 24, 25 }, { 26, 21, 22, 27, 24, 25 } };
+  const int large = lw > lh ? lw : lh, id = ids[large][listType];
+  if( x >= 32 || y >= 32 ) return 0;                                  /* zero-out region: never written */
+  if( lw == lh )
+  {
+    const int sl2 = lw < 3 ? lw : 3, rl2 = lw - sl2;
+    if( rl2 > 0 && x == 0 && y == 0 ) return sl->dc[id];
+    return sl->coef[id][( ( y >> rl2 ) << sl2 ) + ( x >> rl2 )];
+  }
+  const int sl2 = large >= 3 ? 3 : 2;
+  if( large > 3 && x == 0 && y == 0 ) return sl->dc[id];
+  if( lh > lw ) { const int rWH = lh - lw, rH = lh - sl2; return sl->coef[id][( ( y >> rH ) << sl2 ) + ( ( x << rWH ) >> rH )]; }
+  { const int rWH = lw - lh, rW = lw - sl2; return sl->coef[id][( ( ( y << rWH ) >> rW ) << sl2 ) + ( x >> rW )]; }
+}
+
 /* one 1-D inverse pass: TrQuant_EMT.cpp:103-123 + fastInvCore_ :389-404.
  * dst[i*N + j] = sum_{k < N - skipRows} src[k*lines + i] * M[k*N + j]   for i < lines - skipLines, 0 elsewhere;
  * with clip: dst = clip16( (dst + rnd) >> shift ) on the computed lines. */
@@ -83,8 +106,12 @@ int vvo_residual_block( const vvr_pic_header* hdr, const vvr_cu* cu, const vvr_t
     const int rem = depQuant ? ( qp + 1 - 6 * per ) : qp - 6 * per;
     const int needSqrt = !isTS && ( ( lw + lh ) & 1 );                  /* TU::needsSqrt2Scale (UnitTools.cpp:3620) */
     const int trShift  = 15 - bd - ( ( lw + lh ) >> 1 ) - ( needSqrt ? 1 : 0 );
-    const int rightShift = 6 + ( depQuant ? 1 : 0 ) - ( ( isTS ? 0 : trShift ) + per );
-    const int scale = vvc_inv_quant_scales[needSqrt ? 1 : 0][rem];
+    /* getUseScalingList (Quant.h:103): not for transform skip, optionally not for LFNST blocks */
+    const int lfnstApplied = cu->lfnst_idx > 0 && ( cu->tree != VVR_TREE_JOINT || comp == 0 );
+    const int useSL = ( hdr->tool_flags & VVR_TOOL_SCALING_LIST ) && g_scaling && !isTS && !( lfnstApplied && ( hdr->tool_flags & VVR_TOOL_SCALING_LIST_NO_LFNST ) );
+    const int listType = ( cu->pred_mode == VVR_PRED_INTRA ? 0 : 3 ) + comp;
+    const int rightShift = 6 + ( depQuant ? 1 : 0 ) - ( ( isTS ? 0 : trShift ) + per ) + ( useSL ? 4 : 0 );
+    const int scaleQP = vvc_inv_quant_scales[needSqrt ? 1 : 0][rem];
     int targetBits = 32 + rightShift - 7; if( targetBits > 16 ) targetBits = 16;
     const int inMax = ( 1 << ( targetBits - 1 ) ) - 1, inMin = -inMax - 1;
     for( int y = 0; y <= maxY; y++ ) for( int x = 0; x <= maxX; x++ )
@@ -92,6 +119,7 @@ int vvo_residual_block( const vvr_pic_header* hdr, const vvr_cu* cu, const vvr_t
       const int level = bdpcm ? dq[y * bw + x] : lev[y * levStride + x];
       if( !level ) { if( bdpcm ) dq[y * bw + x] = 0; continue; }
       const int64_t c = vvo_clip3( inMin, inMax, level );
+      const int scale = useSL ? scaling_entry( g_scaling, listType, lw, lh, x, y ) * scaleQP : scaleQP;
       int64_t v;
       if( rightShift > 0 ) v = ( c * scale + ( (int64_t) 1 << ( rightShift - 1 ) ) ) >> rightShift;
       else                 v = ( c * scale ) * ( (int64_t) 1 << -rightShift );

@@ -205,6 +205,16 @@ def test_weighted_prediction(built):
     rec.close()
 
 
+@pytest.mark.parametrize("no_lfnst", [0, 1])
+def test_scaling_lists(built, no_lfnst):
+    """explicit scaling lists in the dequantisation (all matrix sizes, rectangular blocks, DC entries; flat for transform skip and,
+    with sps_scaling_matrix_for_lfnst_disabled_flag, for LFNST blocks)"""
+    T = TOOLS_A | abi.TOOL_SCALING_LIST | (abi.TOOL_SCALING_LIST_NO_LFNST if no_lfnst else 0)
+    _run_stream(256, 128, 5, 4, 191, T, intra=True, p_intra=0.3, p_coded=0.8, p_coded_chroma=0.6, p_lfnst=0.5, p_sbt=0.2, p_jccr=0.2)
+    _run_stream(416, 240, 3, 2, 192, T, intra=True, log2_ctu=5, p_coded=0.9, p_mts=0.5, p_ts=0.2, p_small_corner=0.2)
+    _run_stream(1920, 1080, 3, 2, 193, T | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, intra=True, streams=3, p_coded=0.6)
+
+
 def test_joint_cbcr(built):
     """tu_joint_cbcr_residual: one coded chroma block, the other derived (all three modes, both signs)"""
     _run_stream(256, 128, 5, 4, 171, TOOLS_A, intra=True, p_jccr=0.7, p_coded_chroma=0.7, p_intra=0.3)

@@ -84,6 +84,25 @@ def test_oracle_equals_reference_weighted_prediction(built, slice_type, seed):
     assert d.wp is not None and any(d.wp.e[0][i][0].present for i in range(2))
 
 
+@pytest.mark.parametrize("l2,idx,seed,extra,kw", [
+    (7, 0, 221, 0, dict(p_coded=0.8, p_coded_chroma=0.6)),
+    (7, 2, 222, abi.TOOL_SCALING_LIST_NO_LFNST, dict(p_intra=0.3, p_coded=0.8, p_coded_chroma=0.6, p_lfnst=0.5, p_sbt=0.3)),
+    (6, 3, 223, 0, dict(p_intra=0.2, p_coded=0.8, p_coded_chroma=0.6, p_jccr=0.3, p_small_corner=0.2, p_split_scale=0.5)),
+    (5, 1, 224, 0, dict(p_intra=0.1, p_coded=0.9, p_mts=0.5, p_ts=0.2, p_lfnst=0.5)),
+])
+def test_oracle_equals_reference_scaling_lists(built, l2, idx, seed, extra, kw):
+    """explicit scaling lists: 2x2 .. 64x64 matrices incl. rectangular blocks, DC entries, transform-skip and (optionally) LFNST
+    blocks left flat"""
+    d, refs = _case(256, 192, l2, idx, seed, tools=ALL | abi.TOOL_SCALING_LIST | extra, **kw)
+    want = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_RECO)["planes"]
+    got = refdrv.oracle_reconstruct(d, refs, flags=refdrv.STOP_AFTER_RECO)
+    for c in range(3):
+        assert np.array_equal(got[c], want[c]), "comp %d: %d differ" % (c, int((got[c] != want[c]).sum()))
+    d.hdr.tool_flags &= ~abi.TOOL_SCALING_LIST
+    flat = refdrv.oracle_reconstruct(d, refs, flags=refdrv.STOP_AFTER_RECO)
+    assert any(not np.array_equal(flat[c], got[c]) for c in range(3)), "the lists changed nothing"
+
+
 def test_reference_simd_equals_scalar(built):
     """the reference's own differential check (its unit test compares scalar vs SIMD kernels): same bytes at frame level"""
     d, refs = _case(256, 192, 7, 2, 106, p_intra=0.2)

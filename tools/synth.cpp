@@ -142,6 +142,23 @@ struct Gen {
     }
   }
 
+  // scaling_list_data(): 28 matrices (2 of 2x2, 6 of 4x4, 20 of 8x8) with entries 1..255 around the neutral 16, smoothly growing
+  // with the frequency like real quantisation matrices, plus the DC entries of the up-sampled ones; own random stream
+  void genScalingList()
+  {
+    Rng r( P.seed * 0xD1B54A32D192ED03ull + 99 );
+    vvr_scaling_list& L = *B.scaling; memset( &L, 0, sizeof( L ) );
+    for( int id = 0; id < 28; id++ )
+    {
+      const int n = id < 2 ? 2 : id < 8 ? 4 : 8;
+      const int base = 8 + (int) r.u( 17 ), slope = (int) r.u( 4 * 8 / n + 1 );
+      for( int y = 0; y < n; y++ ) for( int x = 0; x < n; x++ )
+        L.coef[id][y * n + x] = (uint8_t) std::min( 255, std::max( 1, base + slope * ( x + y ) + r.laplace( 2.0 ) ) );
+      if( r.p( 0.1 ) ) L.coef[id][r.u( n * n )] = (uint8_t) ( r.p( 0.5 ) ? 255 : 1 );
+      L.dc[id] = (uint8_t) ( id >= 14 ? std::min( 255, std::max( 1, base + r.laplace( 2.0 ) ) ) : 16 );
+    }
+  }
+
   void clipMv( int32_t mv[2], int x, int y ) const   // clipMvInPic, Mv.cpp:64
   {
     const int off = 8;
@@ -702,6 +719,7 @@ struct Gen {
     if( P.slice_type == 2 ) h.tool_flags &= ~(uint32_t) VVR_TOOL_WP;
     wpOn = ( h.tool_flags & VVR_TOOL_WP ) && B.wp;
     if( wpOn ) genWp();
+    if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && B.scaling ) genScalingList();
     int a = 0;
     for( int y = 0; y < H; y += ctu ) for( int x = 0; x < W; x += ctu, a++ ) { B.ctu_first_cu[a] = B.num_cu; split( x, y, ctu, ctu ); }
     B.ctu_first_cu[a] = B.num_cu;

@@ -229,7 +229,9 @@ static int validate( vvr_context* c, const vvr_picture* p )
   const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
   if( wpOn && !p->wp ) { c->setError( "weighted prediction enabled without the weight table" ); return VVR_ERR_PARAMETER; }
   if( wpOn && ( p->wp->log2_denom[0] > 7 || p->wp->log2_denom[1] > 7 ) ) { c->setError( "weighted prediction: log2 denominator out of range" ); return VVR_ERR_PARAMETER; }
-  if( h.tool_flags & VVR_TOOL_SCALING_LIST ) { c->setError( "explicit scaling lists are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+  if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && !p->scaling ) { c->setError( "explicit scaling lists enabled without the lists" ); return VVR_ERR_PARAMETER; }
+  if( h.tool_flags & VVR_TOOL_SCALING_LIST )
+    for( int id = 0; id < 28; id++ ) for( int k = 0; k < ( id < 2 ? 4 : id < 8 ? 16 : 64 ); k++ ) if( !p->scaling->coef[id][k] ) { c->setError( "scaling list entry 0" ); return VVR_ERR_PARAMETER; }
   if( !p->cu || !p->tu || !p->coef || !p->lfp[0] || !p->lfp[1] ) { c->setError( "missing arrays" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & VVR_TOOL_ALF ) && ( !p->alf || !p->alf_params ) ) { c->setError( "ALF enabled without parameters" ); return VVR_ERR_PARAMETER; }
   if( ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) && !p->sao ) { c->setError( "SAO enabled without parameters" ); return VVR_ERR_PARAMETER; }
@@ -669,6 +671,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     }
   }
   const int iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
+  const int iSl = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? add( p->scaling, sizeof( vvr_scaling_list ) ) : -1;
   const int iWp = ( ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2 ) ? add( p->wp, sizeof( vvr_wp_params ) ) : -1;
   const int iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
   const int iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
@@ -704,6 +707,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   d.alf = iAlf >= 0 ? (const vvr_alf_ctu*) ( base + parts[iAlf].off ) : nullptr;
   d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
   d.lmcs = iLmcs >= 0 ? (const vvr_lmcs_params*) ( base + parts[iLmcs].off ) : nullptr;
+  d.scaling = iSl >= 0 ? (const vvr_scaling_list*) ( base + parts[iSl].off ) : nullptr;
   d.wp = iWp >= 0 ? (const vvr_wp_params*) ( base + parts[iWp].off ) : nullptr;
   d.interAt = iInterAt >= 0 ? (const uint8_t*) ( base + parts[iInterAt].off ) : nullptr;
   d.csVpdu = iCsVpdu >= 0 ? (const uint32_t*) ( base + parts[iCsVpdu].off ) : nullptr; d.vpdusX = vpdusX; d.vpduLog2 = vpduLog2;

@@ -1045,6 +1045,29 @@ __device__ __forceinline__ int lmcs_scale_resi( int r, int scale, int bd )
   return clip3( -32768, 32767, v );
 }
 
+// Explicit scaling lists: the matrix entry at (x, y) of a (1 << lw) x (1 << lh) block, i.e. what the reference's expanded tables hold
+// (Quant::setScalingListDec / processScalingListDec, Quant.cpp:386-570; list ids g_scalingListId, Rom.cpp:504)
+__device__ __forceinline__ int scaling_entry( const vvr_scaling_list* __restrict__ sl, int listType, int lw, int lh, int x, int y )
+{
+  const int large = max( lw, lh );
+  // g_scalingListId[large][listType]
+  int id;
+  if( large == 1 ) id = listType == 5 ? 1 : 0;
+  else if( large < 6 ) id = 2 + 6 * ( large - 2 ) + listType;
+  else id = listType == 0 ? 26 : listType == 3 ? 27 : 20 + listType;
+  if( lw == lh )
+  {
+    const int sl2 = min( lw, 3 ), rl2 = lw - sl2;
+    if( rl2 > 0 && x == 0 && y == 0 ) return sl->dc[id];
+    return sl->coef[id][( ( y >> rl2 ) << sl2 ) + ( x >> rl2 )];
+  }
+  const int sl2 = large >= 3 ? 3 : 2;
+  if( large > 3 && x == 0 && y == 0 ) return sl->dc[id];
+  if( lh > lw ) { const int rWH = lh - lw, rH = lh - sl2; return sl->coef[id][( ( y >> rH ) << sl2 ) + ( ( x << rWH ) >> rH )]; }
+  const int rWH = lw - lh, rW = lw - sl2;
+  return sl->coef[id][( ( ( y << rWH ) >> rW ) << sl2 ) + ( x >> rW )];
+}
+
 // NT threads per transform block: 64 for the <= 16x16 class (one wavefront per block: four times as many blocks resident, no
 // cross-wave barrier), 256 for the larger classes
 template<int MAXN, int NT>
@@ -1081,8 +1104,13 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
     const int rem = depQuant ? ( qp + 1 - 6 * per ) : qp - 6 * per;
     const bool needSqrt = !isTS && ( ( lw + lh ) & 1 );
     const int trShift = 15 - bd - ( ( lw + lh ) >> 1 ) - ( needSqrt ? 1 : 0 );
-    const int rightShift = 6 + ( depQuant ? 1 : 0 ) - ( ( isTS ? 0 : trShift ) + per );
-    const int scale = d_inv_quant_scales[needSqrt ? 1 : 0][rem];
+    // explicit scaling list (getUseScalingList, Quant.h:103): not for transform skip, optionally not for LFNST blocks
+    const bool lfnstApplied = cu.lfnst_idx > 0 && ( cu.tree != VVR_TREE_JOINT || comp == 0 );
+    const bool useSL = pic.scaling && !isTS && !( lfnstApplied && ( pic.hdr.tool_flags & VVR_TOOL_SCALING_LIST_NO_LFNST ) );
+    const int listType = ( cu.pred_mode == VVR_PRED_INTRA ? 0 : 3 ) + comp;
+    const int rightShift = 6 + ( depQuant ? 1 : 0 ) - ( ( isTS ? 0 : trShift ) + per ) + ( useSL ? 4 : 0 );
+    const int scaleQP = d_inv_quant_scales[needSqrt ? 1 : 0][rem];
+    const int scale = scaleQP;
     int targetBits = 32 + rightShift - 7; if( targetBits > 16 ) targetBits = 16;
     const int inMax = ( 1 << ( targetBits - 1 ) ) - 1, inMin = -inMax - 1;
     if( bdpcm )
@@ -1123,6 +1151,7 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
         if( level )
         {
           const long long c = clip3( inMin, inMax, level );
+          const int scale = useSL ? scaling_entry( pic.scaling, listType, lw, lh, x, y ) * scaleQP : scaleQP;
           const long long v = rightShift > 0 ? ( c * scale + ( 1ll << ( rightShift - 1 ) ) ) >> rightShift : ( c * scale ) * ( 1ll << -rightShift );
           dq[y * bw + x] = clip3( -32768, 32767, (int) v );
         }
