@@ -176,7 +176,7 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
   }
   const int cscale = ( H->tool_flags & VVR_TOOL_LMCS ) && ( H->tool_flags & VVR_TOOL_LMCS_CSCALE ) && pic->lmcs && ncomp == 3;
 #define CSCALE_TU( tu_, mask_ ) \
-  if( cscale && ( ( mask_ ) & 6 ) && ( tu_->w >> 1 ) * ( tu_->h >> 1 ) > 4 ) \
+  if( cscale && ( ( mask_ ) & 6 ) && bw[1] * bh[1] > 4 ) \
   { \
     const int sc = lmcs_chroma_scale( pic, &reco, cuAt, tu_->x, tu_->y ); \
     for( int c = 1; c < 3; c++ ) if( ( mask_ ) & ( 1 << c ) ) lmcs_scale_residual( resi[c], bw[c] * bh[c], sc, H->bit_depth ); \

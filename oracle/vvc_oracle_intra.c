@@ -59,12 +59,13 @@ static void cclm_predict( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu
 {
   const vvr_pic_header* H = &pic->hdr;
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu;
-  const int cw = tu->w >> 1, chh = tu->h >> 1, x0 = tu->x >> 1, y0 = tu->y >> 1;
-  const int lx0 = tu->x, ly0 = tu->y;
+  /* ISP: the chroma block of the whole CU sits in the last TU */
+  const int lx0 = cu->isp_mode ? cu->x : tu->x, ly0 = cu->isp_mode ? cu->y : tu->y;
+  const int cw = ( cu->isp_mode ? cu->w : tu->w ) >> 1, chh = ( cu->isp_mode ? cu->h : tu->h ) >> 1, x0 = lx0 >> 1, y0 = ly0 >> 1;
   const pel* Y = reco->p[0]; const int ys = reco->stride[0];
 #define LU( xx, yy ) ( (int) Y[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
   const int mode = cu->intra_dir[1];
-  const int aboveCu = cu->y > 0 || tu->y > cu->y, leftCu = cu->x > 0 || tu->x > cu->x;      /* cu.above / cu.left: single slice, single tile */
+  const int aboveCu = cu->y > 0 || ly0 > cu->y, leftCu = cu->x > 0 || lx0 > cu->x;      /* cu.above / cu.left: single slice, single tile */
   const int unit = 2;                                                                       /* 4 luma samples in chroma units */
   const int tuWU = cw / unit, tuHU = chh / unit;
   /* ---- xGetLumaRecPixels: which borders take part in the edge handling of the down-sampling filters */
@@ -269,27 +270,15 @@ static void mip_predict( int w, int h, int modeIdx, int transpose, int bd, const
 
 /* ciip_w_intra != 0: the block already holds the inter prediction; the intra prediction is blended into it with weight
  * ciip_w_intra / 4 before the residual is added (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:887-946) */
-int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, vvo_planes* reco,
-                  const int32_t* order, const int16_t* resi, int has_resi, int ciip_w_intra )
+/* IntraPrediction::xFillReferenceSamples (:1072): reference line of a w x h block at (x0, y0) of channel ch; top[0] = left[0] = corner.
+ * Returns ( left available ) | ( above available ) << 1. */
+static int fill_reference( const vvr_pic_header* H, const int32_t* order, const pel* plane, int stride, int ch, int x0, int y0, int w, int h,
+                           int topLen, int leftLen, int mrl, int32_t cur, pel* top, pel* left )
 {
-  const vvr_pic_header* H = &pic->hdr;
-  const int bd = H->bit_depth, cs = comp ? 1 : 0, ch = comp ? 1 : 0;
-  const int x0 = tu->x >> cs, y0 = tu->y >> cs, w = tu->w >> cs, h = tu->h >> cs;
-  pel* plane = reco->p[comp]; const int stride = reco->stride[comp];
-  if( cu->isp_mode ) { vvo_set_error( "ISP is not restated" ); return -1; }
-  if( comp && cu->intra_dir[1] > MDLM_T_IDX ) { vvo_set_error( "bad chroma intra mode" ); return -1; }
-  if( w < 4 || h < 4 ) { vvo_set_error( "intra blocks narrower than 4 are not restated" ); return -1; }
-  const int mrl = comp ? 0 : cu->multi_ref_idx;
-  const int bdpcm = comp ? cu->bdpcm[1] : cu->bdpcm[0];
-  const int dirMode = cu->intra_dir[ch];
-  const int topLen = 2 * w, leftLen = 2 * h;                 /* setReferenceArrayLengths (:460) */
-  pel top[MAXREF + 8], left[MAXREF + 8], ftop[MAXREF + 8], fleft[MAXREF + 8];
-
-  /* ---- xFillReferenceSamples (:1072): availability in units of 4 luma samples */
+  const int bd = H->bit_depth, cs = ch;
   const int unit = 4 >> cs;
   const int totalAbove = ( topLen + unit - 1 ) / unit, totalLeft = ( leftLen + unit - 1 ) / unit;
   const int numAbove = w / unit, numLeft = h / unit;
-  const int32_t cur = (int32_t) tu_idx;
   int nTL = unit_avail( H, order, ch, x0 - 1, y0 - 1, cur );
   int nA = 0, nL = 0;
   if( unit_avail( H, order, ch, x0, y0 - 1, cur ) )
@@ -357,10 +346,76 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
     for( int i = 0; i < leftLen; i++ ) left[1 + mrl + i] = t;
   }
 #undef R
+  return ( nL > 0 ) | ( ( nA > 0 ) << 1 );
+}
+
+int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, uint32_t tu_idx, int comp, vvo_planes* reco,
+                  const int32_t* order, const int16_t* resi, int has_resi, int ciip_w_intra )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int bd = H->bit_depth, cs = comp ? 1 : 0, ch = comp ? 1 : 0;
+  const int x0 = ( comp && cu->isp_mode ) ? cu->x >> 1 : tu->x >> cs, y0 = ( comp && cu->isp_mode ) ? cu->y >> 1 : tu->y >> cs;
+  const int tbw = ( comp && cu->isp_mode ) ? cu->w >> 1 : tu->w >> cs;      /* ISP: the chroma block of the CU sits in the last TU */
+  int w = tbw, h = ( comp && cu->isp_mode ) ? cu->h >> 1 : tu->h >> cs;
+  pel* plane = reco->p[comp]; const int stride = reco->stride[comp];
+  /* intra sub-partitions (luma): 1 = horizontal split, 2 = vertical split (HOR/VER_INTRA_SUBPARTITIONS) */
+  const int isp = !comp && cu->isp_mode, ispVer = cu->isp_mode == 2;
+  if( isp && ( cu->multi_ref_idx || cu->bdpcm[0] || ( cu->flags & VVR_CU_MIP ) ) ) { vvo_set_error( "ISP combined with MRL / BDPCM / MIP" ); return -1; }
+  if( isp && ispVer && w < 4 )
+  {
+    /* sub-partitions narrower than 4 are predicted in groups of width 4 (CU::isPredRegDiffFromTB / isFirstTBInPredReg / adjustPredArea,
+     * DecCu.cpp:333-371): the first block of a group predicts the group, the others only add their residual */
+    if( ( x0 - cu->x ) & 3 )
+    {
+      if( has_resi ) for( int y = 0; y < h; y++ ) for( int x = 0; x < tbw; x++ )
+        plane[(size_t) ( y0 + y ) * stride + x0 + x] = (pel) vvo_clip_pel( plane[(size_t) ( y0 + y ) * stride + x0 + x] + resi[y * tbw + x], bd );
+      return 0;
+    }
+    w = 4;
+  }
+  if( comp && cu->intra_dir[1] > MDLM_T_IDX ) { vvo_set_error( "bad chroma intra mode" ); return -1; }
+  if( !isp && ( w < 4 || h < 4 ) ) { vvo_set_error( "intra blocks narrower than 4 are not restated" ); return -1; }
+  const int mrl = comp ? 0 : cu->multi_ref_idx;
+  const int bdpcm = comp ? cu->bdpcm[1] : cu->bdpcm[0];
+  const int dirMode = cu->intra_dir[ch];
+  /* setReferenceArrayLengths (:460); ISP: CU size + sub-partition size along the split, twice the CU size across (:1000-1001) */
+  const int topLen = isp ? ( ispVer ? cu->w + w : 2 * cu->w ) : 2 * w, leftLen = isp ? ( ispVer ? 2 * cu->h : cu->h + h ) : 2 * h;
+  const int waW = isp ? cu->w : w, waH = isp ? cu->h : h;      /* the wide-angle mapping of ISP blocks uses the CU size (:502,604) */
+  pel top[MAXREF + 8], left[MAXREF + 8], ftop[MAXREF + 8], fleft[MAXREF + 8];
+
+  /* ---- reference samples */
+  if( !isp ) fill_reference( H, order, plane, stride, ch, x0, y0, w, h, topLen, leftLen, mrl, (int32_t) tu_idx, top, left );
+  else
+  {
+    /* initIntraPatternChTypeISP (:966): the whole CU's reference line is fetched once (first sub-partition); later sub-partitions take
+     * the row above / column left of them from the reconstruction of the previous one and the other line from the CU's line */
+    pel ctop[MAXREF + 8], cleft[MAXREF + 8];
+    const int avail = fill_reference( H, order, plane, stride, 0, cu->x, cu->y, cu->w, cu->h, 2 * cu->w, 2 * cu->h, 0, (int32_t) cu->first_tu, ctop, cleft );
+    const int dx = x0 - cu->x, dy = y0 - cu->y;
+#define R( xx, yy ) plane[(size_t) ( yy ) * stride + ( xx )]
+    if( !dx && !dy ) { for( int j = 0; j <= topLen; j++ ) top[j] = ctop[j]; for( int i = 0; i <= leftLen; i++ ) left[i] = cleft[i]; }
+    else if( !ispVer )
+    {
+      for( int j = 0; j < w; j++ ) top[1 + j] = R( x0 + j, y0 - 1 );
+      for( int j = w; j < topLen; j++ ) top[1 + j] = R( x0 + w - 1, y0 - 1 );
+      for( int i = 0; i <= leftLen; i++ ) left[i] = cleft[dy + i];
+      if( !( avail & 1 ) ) for( int i = 0; i <= leftLen; i++ ) left[i] = R( x0, y0 - 1 );
+      top[0] = left[0];
+    }
+    else
+    {
+      for( int i = 0; i < h; i++ ) left[1 + i] = R( x0 - 1, y0 + i );
+      for( int i = h; i < leftLen; i++ ) left[1 + i] = R( x0 - 1, y0 + h - 1 );
+      for( int j = 0; j <= topLen; j++ ) top[j] = ctop[dx + j];
+      if( !( avail & 2 ) ) for( int j = 0; j <= topLen; j++ ) top[j] = R( x0 - 1, y0 );
+      left[0] = top[0];
+    }
+#undef R
+  }
 
   /* ---- reference smoothing decision (DecCu.cpp:337 + useFilteredIntraRefSamples :1301) */
   int useFilt = 0;
-  if( !comp && !mrl && !bdpcm && dirMode != 1 && !( cu->flags & VVR_CU_MIP ) )
+  if( !comp && !mrl && !bdpcm && dirMode != 1 && !( cu->flags & VVR_CU_MIP ) && !isp )
   {
     if( dirMode == 0 ) useFilt = w * h > 32;
     else
@@ -422,7 +477,7 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
   }
   else
   {   /* xPredIntraAng (:592) */
-    const int predMode = wide_angle( w, h, dirMode );
+    const int predMode = wide_angle( waW, waH, dirMode );
     const int isVer = predMode >= 34;
     const int am = isVer ? predMode - 50 : -( predMode - 18 );
     const int absAm = vvo_abs( am ), sign = am < 0 ? -1 : 1;
@@ -482,7 +537,7 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
           const int diff = vvo_min( vvo_abs( predMode - 18 ), vvo_abs( predMode - 50 ) );
           const int l2 = ( vvo_log2( bw ) + vvo_log2( bh ) ) >> 1;
           const int filterFlag = diff > intraFilterThr[0][l2];
-          const int useCubic = !filterFlag || mrl > 0;
+          const int useCubic = isp ? 1 : ( !filterFlag || mrl > 0 );
           int deltaPos = angle * ( 1 + mrl );
           for( int y = 0; y < bh; y++, deltaPos += angle )
           {
@@ -559,7 +614,7 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
   {
     int pv = pred[y * w + x];
     if( ciip_w_intra ) pv = ( ( 4 - ciip_w_intra ) * plane[(size_t) ( y0 + y ) * stride + x0 + x] + ciip_w_intra * pv + 2 ) >> 2;
-    const int v = has_resi ? vvo_clip_pel( pv + resi[y * w + x], bd ) : pv;
+    const int v = ( has_resi && x < tbw ) ? vvo_clip_pel( pv + resi[y * tbw + x], bd ) : pv;
     plane[(size_t) ( y0 + y ) * stride + x0 + x] = (pel) v;
   }
   return 0;

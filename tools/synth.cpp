@@ -67,6 +67,7 @@ typedef struct vvs_params {
   float    p_cclm;              // of intra CUs: chroma predicted from the reconstructed luma (CCLM, MDLM_L, MDLM_T)
   float    p_mip;               // of intra CUs: matrix-based luma prediction
   float    p_sbt;               // of inter CUs (not CIIP, at most 64x64): sub-block transform (residual in one half / quarter of the CU)
+  float    p_isp;               // of intra CUs (no MRL / BDPCM / MIP): intra sub-partitions, four luma partitions predicted one after the other
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -104,7 +105,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f; P->p_mip = 0.0f; P->p_sbt = 0.0f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f; P->p_mip = 0.0f; P->p_sbt = 0.0f; P->p_isp = 0.0f;
 }
 
 namespace {
@@ -248,8 +249,12 @@ struct Gen {
         if( cu.intra_dir[1] < 67 ) cu.intra_dir[1] = 0;
         cu.lfnst_intra_mode = 0;
       }
+      // intra sub-partitions: horizontal (1) or vertical (2) split of the luma block in four (CU::canUseISP: more than 16 samples,
+      // at most the maximum transform size); LFNST only while the partitions are at least 4x4 (CU::canUseLfnstWithISP)
+      if( P.p_isp > 0 && !cu.bdpcm[0] && !cu.multi_ref_idx && !( cu.flags & VVR_CU_MIP ) && w <= 64 && h <= 64 && rng.p( P.p_isp ) ) cu.isp_mode = (uint8_t) ( 1 + rng.u( 2 ) );
+      const bool ispNoLfnst = cu.isp_mode && ( cu.isp_mode == 1 ? h / 4 < 4 : w / 4 < 4 );
       // LFNST index (luma of single-tree CUs): needs DCT2 and a residual confined to the first 8/16 scan positions, see genLevels
-      if( ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && ( !( cu.flags & VVR_CU_MIP ) || ( w >= 16 && h >= 16 ) ) && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
+      if( ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && ( !( cu.flags & VVR_CU_MIP ) || ( w >= 16 && h >= 16 ) ) && !ispNoLfnst && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
     }
     else
     {
@@ -365,7 +370,12 @@ struct Gen {
       tbs[1] = ver ? Tb{ a, 0, w - a, h, sbtPos == 1 } : Tb{ 0, a, w, h - a, sbtPos == 1 };
       ntb = 2;
     }
+    else if( cu.isp_mode )
+    {
+      for( int k = 0; k < 4; k++ ) tbs[ntb++] = cu.isp_mode == 1 ? Tb{ 0, k * ( h / 4 ), w, h / 4, true } : Tb{ k * ( w / 4 ), 0, w / 4, h, true };
+    }
     else for( int ty = 0; ty < h; ty += th ) for( int tx = 0; tx < w; tx += tw ) tbs[ntb++] = Tb{ tx, ty, tw, th, true };
+    bool ispAnyLuma = false;
     for( int ti = 0; ti < ntb; ti++ )
     {
       const int tx = tbs[ti].x, ty = tbs[ti].y, tw = tbs[ti].w, th = tbs[ti].h;
@@ -373,6 +383,7 @@ struct Gen {
       const uint32_t tuIdx = B.num_tu++;
       tu.x = x + tx; tu.y = y + ty; tu.w = tw; tu.h = th; tu.cu = cuIdx;
       tu.comp_mask = P.chroma_format ? 7 : 1;
+      if( cu.isp_mode && ti != ntb - 1 ) tu.comp_mask = 1;          // the (unsplit) chroma blocks of an ISP CU belong to the last TU
       const int qpBd = 6 * ( bd - 8 );
       tu.qp[0] = (int8_t) ( cu.qp + qpBd );
       tu.qp[1] = tu.qp[2] = (int8_t) ( std::min( 63, std::max( -qpBd, (int) cu.qp ) ) + qpBd );   // identity chroma QP mapping, zero offsets
@@ -384,8 +395,10 @@ struct Gen {
       tu.joint_cbcr = (uint8_t) jccr;
       for( int c = 0; c < ( P.chroma_format ? 3 : 1 ); c++ )
       {
-        const int bw = c ? tw >> 1 : tw, bh = c ? th >> 1 : th;
-        const bool force = c == 0 && ( ( intra && ( cu.bdpcm[0] || cu.lfnst_idx ) ) || ( cu.flags & VVR_CU_CIIP ) || sbtIdx );     // these modes are only signalled with a coded luma block (CIIP: merge, never skip => cu_coded_flag = 1)
+        if( !( tu.comp_mask & ( 1 << c ) ) ) continue;
+        const int bw = c ? ( cu.isp_mode ? w >> 1 : tw >> 1 ) : tw, bh = c ? ( cu.isp_mode ? h >> 1 : th >> 1 ) : th;
+        const bool ispLast = c == 0 && cu.isp_mode && ti == ntb - 1 && !ispAnyLuma;      // at least one partition is coded (the last cbf is inferred)
+        const bool force = ispLast || ( c == 0 && ( ( intra && ( cu.bdpcm[0] || cu.lfnst_idx ) ) || ( cu.flags & VVR_CU_CIIP ) || sbtIdx ) );     // these modes are only signalled with a coded luma block (CIIP: merge, never skip => cu_coded_flag = 1)
         if( c && jccr )
         {
           if( ( jccr >> ( 2 - c ) ) & 1 ) tu.cbf |= 1 << c;
@@ -396,14 +409,19 @@ struct Gen {
           if( !force && !rng.p( c ? P.p_coded_chroma : P.p_coded ) ) continue;
           tu.cbf |= 1 << c;
         }
-        bool ts = bw <= 32 && bh <= 32 && !sbtIdx && rng.p( P.p_ts );
+        if( c == 0 && cu.isp_mode ) ispAnyLuma = true;
+        bool ts = bw <= 32 && bh <= 32 && !sbtIdx && !( c == 0 && cu.isp_mode ) && rng.p( P.p_ts );
         if( c == 0 && intra && cu.bdpcm[0] ) ts = true;
         if( c == 0 && intra && cu.lfnst_idx ) ts = false;
         tu.mts_idx[c] = ts ? VVR_MTS_SKIP : VVR_MTS_DCT2;
-        if( !ts && c == 0 && bw <= 32 && bh <= 32 && !sbtIdx && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
+        if( !ts && c == 0 && bw <= 32 && bh <= 32 && !sbtIdx && !cu.isp_mode && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
         // getTrTypes (TrQuant.cpp:330): explicit MTS -> hor = (idx-2)&1 ? DCT8 : DST7 ; ver = (idx-2)>>1 ? DCT8 : DST7
         int hor = 0, ver = 0;
         if( tu.mts_idx[c] > 1 ) { hor = ( ( tu.mts_idx[c] - 2 ) & 1 ) ? 1 : 2; ver = ( ( tu.mts_idx[c] - 2 ) >> 1 ) ? 1 : 2; }
+        if( cu.isp_mode && c == 0 && !cu.lfnst_idx )
+        {   // ISP: DST-7 along every dimension of 4..16 samples, DCT-2 otherwise (getTrTypes, TrQuant.cpp:349-360)
+          hor = ( bw >= 4 && bw <= 16 ) ? 2 : 0; ver = ( bh >= 4 && bh <= 16 ) ? 2 : 0;
+        }
         if( sbtIdx && c == 0 )
         {   // the transform pair follows from the position of the residual part (getTrTypes, TrQuant.cpp:366-398); 1 = DCT8, 2 = DST7
           if( sbtIdx == 1 || sbtIdx == 3 ) { if( bh > 32 ) hor = ver = 0; else { hor = sbtPos == 0 ? 1 : 2; ver = 2; } }
@@ -572,10 +590,12 @@ struct Gen {
         L.flags = 1;                                           // filterEdge luma
         // chroma edges live on the 8x8 chroma-sample grid = 16 luma samples
         const int posAlong = d == 0 ? ( x4 << 2 ) : ( y4 << 2 );
-        const bool chromaEdge = P.chroma_format && ( posAlong % 16 == 0 );
+        const bool chromaEdge = P.chroma_format && ( posAlong % 16 == 0 ) && !( &CQ == &CP && CQ.isp_mode );     // the chroma block of an ISP CU is not split
         if( chromaEdge )
         {
-          if( ( sizeP >> 1 ) >= 8 && ( sizeQ >> 1 ) >= 8 ) L.flags |= 0x20;   // both sides >= 8 chroma samples: long chroma filter allowed
+          // (the chroma block of an ISP CU is not split: its size is the CU's)
+          const int sizeQc = ( CQ.isp_mode ? ( d == 0 ? CQ.w : CQ.h ) : sizeQ ) >> 1, sizePc = ( CP.isp_mode ? ( d == 0 ? CP.w : CP.h ) : sizeP ) >> 1;
+          if( sizePc >= 8 && sizeQc >= 8 ) L.flags |= 0x20;   // both sides >= 8 chroma samples: long chroma filter allowed
         }
         // boundary strength (LoopFilter.cpp:1094-1360)
         int bsY = 0, bsCb = 0, bsCr = 0;
