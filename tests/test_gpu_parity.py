@@ -215,6 +215,15 @@ def test_scaling_lists(built, no_lfnst):
     _run_stream(1920, 1080, 3, 2, 193, T | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, intra=True, streams=3, p_coded=0.6)
 
 
+def test_intra_sub_partitions(built):
+    """ISP: four luma partitions predicted one after the other from the CU's reference line (2-wide partitions in pairs), implicit
+    DST-7, LFNST, unsplit chroma incl. CCLM and LMCS chroma scaling"""
+    _run_stream(256, 128, 5, 4, 211, TOOLS_A, intra=True, p_isp=0.6, p_intra=0.4, p_lfnst=0.4, p_coded=0.7)
+    _run_stream(416, 240, 3, 2, 212, TOOLS_A | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, intra=True, log2_ctu=5, p_isp=0.5, p_intra=0.4, p_cclm=0.3, p_jccr=0.3, p_coded_chroma=0.6)
+    _run_stream(1920, 1080, 3, 2, 213, TOOLS_A, intra=True, streams=3, p_isp=0.3, p_cclm=0.2, p_mip=0.1)
+    _run_stream(256, 192, 3, 2, 214, TOOLS_A, intra=True, log2_ctu=6, p_isp=0.8, p_split_scale=1.6)
+
+
 def test_joint_cbcr(built):
     """tu_joint_cbcr_residual: one coded chroma block, the other derived (all three modes, both signs)"""
     _run_stream(256, 128, 5, 4, 171, TOOLS_A, intra=True, p_jccr=0.7, p_coded_chroma=0.7, p_intra=0.3)

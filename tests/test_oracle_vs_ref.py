@@ -41,6 +41,9 @@ def _case(W, H, l2, idx, seed, tools=ALL, **kw):
     (200, 136, 6, 2, 116, dict(p_mip=0.6, p_intra=0.5, p_split_scale=1.5)),
     (256, 128, 7, 2, 117, dict(p_sbt=0.5, p_coded_chroma=0.5, p_jccr=0.2)),
     (200, 136, 5, 3, 118, dict(p_sbt=0.7, p_intra=0.1, p_affine=0.2, p_geo=0.1)),
+    (256, 128, 7, 0, 119, dict(p_isp=0.6, p_lfnst=0.4, p_coded=0.7)),
+    (200, 136, 5, 2, 120, dict(p_isp=0.7, p_intra=0.5, p_cclm=0.3)),
+    (384, 256, 6, 0, 121, dict(p_isp=0.5, p_split_scale=0.5, p_cclm=0.3, p_lfnst=0.4, p_jccr=0.3)),
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)
@@ -118,6 +121,11 @@ def test_edge_parameters_match_reference_derivation(built):
     a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
     b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    for args, kw in (((256, 128, 7, 0, 122), dict(p_isp=0.7, p_split_scale=1.6)), ((384, 256, 6, 2, 123), dict(p_isp=0.5, p_intra=0.4, p_cclm=0.3))):
+        d, refs = _case(*args, **kw)                                                       # ISP: partition edges, unsplit chroma
+        a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
+        b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
     d, refs = _case(256, 128, 6, 3, 119, p_intra=0.1, p_sbt=0.6, p_coded_chroma=0.4)     # sub-block transform: TU edges inside inter CUs
     a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
     b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]

@@ -20,6 +20,7 @@ int vvr_upload_tables();
 #define HIPCHK( ctx, call ) do { hipError_t e_ = ( call ); if( e_ != hipSuccess ) { ( ctx )->setError( std::string( #call ) + ": " + hipGetErrorString( e_ ) ); return VVR_ERR_DEVICE; } } while( 0 )
 
 namespace {
+static inline int ilog2i( int v ) { int l = 0; while( ( 1 << l ) < v ) l++; return l; }
 
 struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 
@@ -288,7 +289,17 @@ static int validate( vvr_context* c, const vvr_picture* p )
     }
     else if( cu.pred_mode == VVR_PRED_INTRA )
     {
-      if( cu.isp_mode ) { c->setError( "ISP is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.isp_mode )
+      {
+        // intra sub-partitions (CU::canUseISP, UnitTools.cpp): luma split in four, chroma unsplit in the last TU
+        if( cu.isp_mode > 2 || cu.multi_ref_idx || cu.bdpcm[0] || ( cu.flags & VVR_CU_MIP ) || cu.num_tu != 4 ) { c->setError( "ISP CU: bad split mode, combined with MRL / BDPCM / MIP, or not four TUs" ); return VVR_ERR_PARAMETER; }
+        for( uint32_t k = 0; k < 4; k++ )
+        {
+          const vvr_tu& t4 = p->tu[cu.first_tu + k];
+          const bool ok = cu.isp_mode == 1 ? ( t4.x == cu.x && t4.w == cu.w && t4.h * 4 == cu.h && t4.y == cu.y + (int) k * t4.h ) : ( t4.y == cu.y && t4.h == cu.h && t4.w * 4 == cu.w && t4.x == cu.x + (int) k * t4.w );
+          if( !ok || ( t4.comp_mask & 6 ) != ( k == 3 && h.chroma_format ? 6 : 0 ) || t4.mts_idx[0] == VVR_MTS_SKIP ) { c->setError( "ISP CU: TU layout" ); return VVR_ERR_PARAMETER; }
+        }
+      }
       if( cu.flags & VVR_CU_MIP )
       {
         const int sizeId = ( cu.w == 4 && cu.h == 4 ) ? 0 : ( cu.w == 4 || cu.h == 4 || ( cu.w == 8 && cu.h == 8 ) ) ? 1 : 2;
@@ -366,7 +377,9 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         {
           if( chn == 0 && !( tu.comp_mask & 1 ) ) continue;
           if( chn == 1 && !( tu.comp_mask & 6 ) ) continue;
-          for( int y = tu.y; y < tu.y + tu.h && y < h.height; y += 4 ) for( int x = tu.x; x < tu.x + tu.w && x < h.width; x += 4 )
+          int ax = tu.x, ay = tu.y, aw = tu.w, ah = tu.h;
+          if( chn == 1 && cu.isp_mode ) { ax = cu.x; ay = cu.y; aw = cu.w; ah = cu.h; }      // ISP: the unsplit chroma blocks sit in the last TU
+          for( int y = ay; y < ay + ah && y < h.height; y += 4 ) for( int x = ax; x < ax + aw && x < h.width; x += 4 )
             order[(size_t) chn * w4 * h4 + ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) t;
         }
       }
@@ -427,22 +440,40 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
           if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
           const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
-          const int x0 = tu.x >> cs, y0 = tu.y >> cs, w = tu.w >> cs, hh = tu.h >> cs;
-          const int totalAbove = ( 2 * w + unit - 1 ) / unit, totalLeft = ( 2 * hh + unit - 1 ) / unit;
+          // intra sub-partitions: luma partitions are blocks of their own that share the reference line of the whole CU
+          // (initIntraPatternChTypeISP, IntraPrediction.cpp:966); partitions narrower than 4 are predicted in pairs (DecCu.cpp:333-371):
+          // one item of width 4 carries both; the unsplit chroma blocks come with the last TU
+          const bool ispL = cu.isp_mode && !comp, ispC = cu.isp_mode && comp;
+          const bool ispPair = ispL && cu.isp_mode == 2 && tu.w < 4;
+          if( ispPair && ( ( tu.x - cu.x ) & 3 ) ) continue;                                      // second of a pair: part of the previous item
+          const int x0 = ( ispC ? cu.x : tu.x ) >> cs, y0 = ( ispC ? cu.y : tu.y ) >> cs, w = ispPair ? 4 : ( ispC ? cu.w : tu.w ) >> cs, hh = ( ispC ? cu.h : tu.h ) >> cs;
+          // block whose neighbourhood decides the availability of the reference samples
+          const int rx0 = ispL ? cu.x : x0, ry0 = ispL ? cu.y : y0, rw = ispL ? cu.w : w, rh = ispL ? cu.h : hh;
+          const int32_t rcur = ispL ? (int32_t) cu.first_tu : (int32_t) t;
+          const int totalAbove = ( 2 * rw + unit - 1 ) / unit, totalLeft = ( 2 * rh + unit - 1 ) / unit;
           IntraItem it; memset( &it, 0, sizeof( it ) );
           it.tu = t; it.comp = (uint8_t) comp;
           it.x = (uint16_t) x0; it.y = (uint16_t) y0;
           { int l = 0; while( ( 1 << l ) < w ) l++; it.lw = (uint8_t) l; l = 0; while( ( 1 << l ) < hh ) l++; it.lh = (uint8_t) l; }
           it.mode = isCsInter ? IT_MODE_RESI_ADD : isCiip ? 0 : cu.intra_dir[chn];       // CIIP: planar
-          const bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
+          bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
+          if( ispL )
+          {
+            const int second = ispPair && t + 1 < cu.first_tu + cu.num_tu ? ( p->tu[t + 1].cbf & 1 ) : 0;
+            // geometry of the partition inside its CU, residual flags of the two halves of a pair
+            it.tu = (uint32_t) ( tu.x - cu.x ) | ( (uint32_t) ( tu.y - cu.y ) << 6 ) | ( (uint32_t) ilog2i( cu.w ) << 12 ) | ( (uint32_t) ilog2i( cu.h ) << 15 )
+                  | ( (uint32_t) ( cu.isp_mode == 2 ) << 18 ) | ( (uint32_t) ( ( tu.cbf & 1 ) | ( second << 1 ) ) << 19 ) | ( (uint32_t) ispPair << 21 );
+            hasResi = hasResi || second;
+          }
           const int bdp = ( isCiip || isCsInter ) ? 0 : cu.bdpcm[chn];
           // CIIP blend weight of the intra part (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:925-929): 1 + intra neighbours
           const int wIntra = isCiip ? 1 + ( cu.ciip_neigh_intra & 1 ) + ( ( cu.ciip_neigh_intra >> 1 ) & 1 ) : 0;
           it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip || isCsInter ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
           if( !comp && !isCiip && ( cu.flags & VVR_CU_MIP ) ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_MIP | ( ( cu.flags & VVR_CU_MIP_TRANSP ) ? 0x10 : 0 ) );
-          if( !isCsInter ) it.nTL = (uint8_t) unitAvail( chn, x0 - 1, y0 - 1, (int32_t) t );
-          if( !isCsInter && unitAvail( chn, x0, y0 - 1, (int32_t) t ) ) { int n = w / unit; for( int k = 0; k < totalAbove - w / unit; k++ ) { if( !unitAvail( chn, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; n++; } it.nA = (uint8_t) n; }
-          if( !isCsInter && unitAvail( chn, x0 - 1, y0, (int32_t) t ) ) { int n = hh / unit; for( int k = 0; k < totalLeft - hh / unit; k++ ) { if( !unitAvail( chn, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; n++; } it.nL = (uint8_t) n; }
+          if( ispL ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_ISP );
+          if( !isCsInter ) it.nTL = (uint8_t) unitAvail( chn, rx0 - 1, ry0 - 1, rcur );
+          if( !isCsInter && unitAvail( chn, rx0, ry0 - 1, rcur ) ) { int n = rw / unit; for( int k = 0; k < totalAbove - rw / unit; k++ ) { if( !unitAvail( chn, rx0 + rw + k * unit, ry0 - 1, rcur ) ) break; n++; } it.nA = (uint8_t) n; }
+          if( !isCsInter && unitAvail( chn, rx0 - 1, ry0, rcur ) ) { int n = rh / unit; for( int k = 0; k < totalLeft - rh / unit; k++ ) { if( !unitAvail( chn, rx0 - 1, ry0 + rh + k * unit, rcur ) ) break; n++; } it.nL = (uint8_t) n; }
           int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0; bool isCclm = false;
           const bool csItem = cscale && comp && hasResi && w * hh > 4;             // DecCu.cpp:383-388 / :500-505
           if( csItem ) it.flags |= IT_F_CSCALE;
@@ -451,7 +482,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
             // CCLM / MDLM: template sizes and flags of IntraPrediction::xGetLMParameters (:1694-1800) and the border handling of
             // xGetLumaRecPixels (:1403-1470); they ride in the item's `tu` word
             const int mode = cu.intra_dir[1];
-            const bool aboveCu = cu.y > 0 || tu.y > cu.y, leftCu = cu.x > 0 || tu.x > cu.x;          // cu.above / cu.left (one slice, one tile)
+            const bool aboveCu = cu.y > 0 || ( y0 << 1 ) > cu.y, leftCu = cu.x > 0 || ( x0 << 1 ) > cu.x;          // cu.above / cu.left (one slice, one tile)
             const int tuWU = w / unit, tuHU = hh / unit;
             const int totA = ( 2 * w + unit - 1 ) / unit, totL = ( 2 * hh + unit - 1 ) / unit;
             int aboveAvail = 0, leftAvail = 0, actualTop = 0, actualLeft = 0;
@@ -469,7 +500,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
             }
             else { aboveAvail = aboveCu; leftAvail = leftCu; actualTop = w; actualLeft = hh; }
             const int bLeft = leftCu ? 1 : 0;                                                          // availlableLeftUnit >= iTUHeightInUnits
-            const int firstRow = ( tu.y & ( ( 1 << h.log2_ctu ) - 1 ) ) == 0;
+            const int firstRow = ( ( y0 << 1 ) & ( ( 1 << h.log2_ctu ) - 1 ) ) == 0;
             it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 );
             cclmTop = aboveAvail ? actualTop : 0; cclmLeft = leftAvail ? actualLeft : 0; cclmBLeft = bLeft; isCclm = true;
           }
@@ -502,15 +533,15 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
               // bounding box of everything the kernel's reference fill may read for this block (whole top / left lines incl. padding sources)
               const int S = ( 1 << h.log2_ctu ) >> cs, ox = ctuX * S, oy = ctuY * S;
               BBox& bb = U.bb;
-              const int rx0 = x0 - 1 - mrl, rx1 = x0 + std::max( 2 * w, 1 ) + 1, ry0 = y0 - 1 - mrl, ry1 = y0 + 2 * hh + 1;
-              bb.y0 = std::min( bb.y0, std::max( 0, ry0 - ( oy - 3 ) ) );
-              bb.y1 = std::max( bb.y1, std::min( S + 3, ry1 - ( oy - 3 ) ) );
-              bb.c0 = std::min( bb.c0, std::max( 0, ( rx0 - ( ox - 8 ) ) >> 3 ) );
-              bb.c1 = std::max( bb.c1, std::min( ( 8 + S + 64 + 7 ) >> 3, ( rx1 - ( ox - 8 ) + 7 ) >> 3 ) );
+              const int bx0 = rx0 - 1 - mrl, bx1 = rx0 + std::max( 2 * rw, 1 ) + 1, by0 = ry0 - 1 - mrl, by1 = ry0 + 2 * rh + 1;
+              bb.y0 = std::min( bb.y0, std::max( 0, by0 - ( oy - 3 ) ) );
+              bb.y1 = std::max( bb.y1, std::min( S + 3, by1 - ( oy - 3 ) ) );
+              bb.c0 = std::min( bb.c0, std::max( 0, ( bx0 - ( ox - 8 ) ) >> 3 ) );
+              bb.c1 = std::max( bb.c1, std::min( ( 8 + S + 64 + 7 ) >> 3, ( bx1 - ( ox - 8 ) + 7 ) >> 3 ) );
             }
-            if( it.nTL ) touch( comp, x0 - 1 - mrl, y0 - 1 - mrl );
-            for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, x0 + k, y0 - 1 - mrl );
-            for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, x0 - 1 - mrl, y0 + k );
+            if( it.nTL ) touch( comp, rx0 - 1 - mrl, ry0 - 1 - mrl );
+            for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, rx0 + k, ry0 - 1 - mrl );
+            for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, rx0 - 1 - mrl, ry0 + k );
             if( isCiip ) for( int yy = 0; yy < hh; yy += unit ) for( int xx = 0; xx < w; xx += unit ) touch( comp, x0 + xx, y0 + yy );   // (never produced by the intra stage: no-op, kept for symmetry)
             if( csItem )
             {
@@ -570,7 +601,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           it.ict = (uint8_t) ( 4 + ict[( h.tool_flags & VVR_TOOL_JCCR_SIGN ) ? 1 : 0][tu.joint_cbcr] );
         }
         else if( !( tu.cbf & ( 1 << comp ) ) ) continue;
-        const int bw = tu.w >> ( it.comp ? 1 : 0 ), bh = tu.h >> ( it.comp ? 1 : 0 );
+        const int bw = ( ( it.comp && cu.isp_mode ) ? cu.w : tu.w ) >> ( it.comp ? 1 : 0 ), bh = ( ( it.comp && cu.isp_mode ) ? cu.h : tu.h ) >> ( it.comp ? 1 : 0 );
         if( bw < 2 || bh < 2 ) { c->setError( "1-D transform blocks are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
         const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
         // LMCS chroma residual scaling of an inter block: the factor needs the reconstructed luma around the VPDU, which the intra stage

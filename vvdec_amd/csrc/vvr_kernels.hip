@@ -2081,16 +2081,25 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
       const int mrl = ( it.flags & IT_F_MIP ) ? 0 : ( it.flags >> 4 ) & 3;
       const int wIntra = it.flags >> 6;               // CIIP: weight of the planar intra part, 0 = ordinary intra block
-      const int bdpcm = ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
+      // intra sub-partition (luma): the reference line is cut out of the line of the whole CU, see below
+      const bool isp = !comp && ( it.flags & IT_F_ISP ) == IT_F_ISP;
+      const uint32_t ispw = isp ? it.tu : 0;
+      const int ispDx = ispw & 63, ispDy = ( ispw >> 6 ) & 63, cuW = 1 << ( ( ispw >> 12 ) & 7 ), cuH = 1 << ( ( ispw >> 15 ) & 7 );
+      const bool ispVer = ( ispw >> 18 ) & 1, ispPair = ( ispw >> 21 ) & 1;
+      const int ispResi = ( ispw >> 19 ) & 3;
+      const int bdpcm = isp ? 0 : ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
       const int dirMode = it.mode;
       const bool hasResi = ( it.flags & IT_F_RESI ) != 0;
       // LMCS chroma residual scaling factor of the block's VPDU (the unit has waited for the luma it is averaged over)
       int csScale = 0;
       const bool csOn = comp && ( it.flags & IT_F_CSCALE );
       if( csOn ) csScale = sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )];
-      const int topLen = 2 * w, leftLen = 2 * h;
+      // reference line lengths; ISP: CU size + partition size along the split, twice the CU size across (IntraPrediction.cpp:1000-1001).
+      // f*: the block whose line is fetched from the picture (ISP: the whole CU, initIntraPatternChTypeISP :966-999)
+      const int topLen = isp ? ( ispVer ? cuW + w : 2 * cuW ) : 2 * w, leftLen = isp ? ( ispVer ? 2 * cuH : cuH + h ) : 2 * h;
+      const int fx0 = x0 - ispDx, fy0 = y0 - ispDy, fTopLen = isp ? 2 * cuW : topLen, fLeftLen = isp ? 2 * cuH : leftLen;
       const int unit = 4 >> cs;
-      const int totalAbove = ( topLen + unit - 1 ) / unit, totalLeft = ( leftLen + unit - 1 ) / unit;
+      const int totalAbove = ( fTopLen + unit - 1 ) / unit, totalLeft = ( fLeftLen + unit - 1 ) / unit;
       const int nTL = it.nTL, nA = it.nA, nL = it.nL;
       const int nAll = nTL + nA + nL, total = totalAbove + totalLeft + 1;
       const bool isDc = !bdpcm && dirMode == 1;
@@ -2098,44 +2107,78 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       // ---- xFillReferenceSamples: one lane per reference position (+ the DC sum while the values are in registers)
       {
         const int dcv = 1 << ( bd - 1 );
-        const int n = max( topLen, leftLen ) + mrl + 1;
+        const int n = max( max( topLen, leftLen ), max( fTopLen, fLeftLen ) ) + mrl + 1;
+        int tv = dcv, lv = dcv;
         if( tid < ( ( n + 63 ) & ~63 ) )
         {
           const int j = tid;
-          int tv = dcv, lv = dcv;
           if( j < n )
           {
             if( nAll == 0 ) {}
             else if( nAll == total )
             {
-              if( j <= topLen + mrl ) tv = TILE( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) );
-              if( j <= leftLen + mrl ) lv = j == 0 ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) ) : TILE( x0 - ( 1 + mrl ), y0 - mrl + ( j - 1 ) );
+              if( j <= fTopLen + mrl ) tv = TILE( fx0 - ( 1 + mrl ) + j, fy0 - ( 1 + mrl ) );
+              if( j <= fLeftLen + mrl ) lv = j == 0 ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) ) : TILE( fx0 - ( 1 + mrl ), fy0 - mrl + ( j - 1 ) );
             }
             else if( nL > 0 )
             {
-              const int szL = min( nL * unit, leftLen ), szA = min( nA * unit, topLen );
-              const int tpad = TILE( x0 - ( 1 + mrl ), y0 );
+              const int szL = min( nL * unit, fLeftLen ), szA = min( nA * unit, fTopLen );
+              const int tpad = TILE( fx0 - ( 1 + mrl ), fy0 );
               // left line
-              if( j == 0 ) lv = nTL ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) ) : tpad;
-              else if( j <= mrl ) lv = nTL ? TILE( x0 - ( 1 + mrl ), y0 - ( 1 + mrl ) + j ) : tpad;
-              else if( j <= leftLen + mrl ) { const int i = j - 1 - mrl; lv = TILE( x0 - ( 1 + mrl ), y0 + min( i, szL - 1 ) ); }
+              if( j == 0 ) lv = nTL ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) ) : tpad;
+              else if( j <= mrl ) lv = nTL ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) + j ) : tpad;
+              else if( j <= fLeftLen + mrl ) { const int i = j - 1 - mrl; lv = TILE( fx0 - ( 1 + mrl ), fy0 + min( i, szL - 1 ) ); }
               // top line
-              if( j <= mrl ) tv = nTL ? TILE( x0 - ( 1 + mrl ) + j, y0 - ( 1 + mrl ) ) : tpad;
-              else if( j <= topLen + mrl )
+              if( j <= mrl ) tv = nTL ? TILE( fx0 - ( 1 + mrl ) + j, fy0 - ( 1 + mrl ) ) : tpad;
+              else if( j <= fTopLen + mrl )
               {
                 const int i = j - 1 - mrl;
-                if( nA ) tv = TILE( x0 + min( i, szA - 1 ), y0 - ( 1 + mrl ) );
-                else     tv = nTL ? TILE( x0 - 1, y0 - ( 1 + mrl ) ) : tpad;      // = top[mrl]
+                if( nA ) tv = TILE( fx0 + min( i, szA - 1 ), fy0 - ( 1 + mrl ) );
+                else     tv = nTL ? TILE( fx0 - 1, fy0 - ( 1 + mrl ) ) : tpad;      // = top[mrl]
               }
             }
             else
             {
-              const int szA = min( nA * unit, topLen );
-              const int t = TILE( x0, y0 - ( 1 + mrl ) );
+              const int szA = min( nA * unit, fTopLen );
+              const int t = TILE( fx0, fy0 - ( 1 + mrl ) );
               lv = t;
               if( j <= mrl ) tv = t;
-              else if( j <= topLen + mrl ) tv = TILE( x0 + min( j - 1 - mrl, szA - 1 ), y0 - ( 1 + mrl ) );
+              else if( j <= fTopLen + mrl ) tv = TILE( fx0 + min( j - 1 - mrl, szA - 1 ), fy0 - ( 1 + mrl ) );
             }
+            if( isp )
+            {
+              // the CU's line, kept aside; the partition's own line is cut out of it after the barrier
+              if( j <= fTopLen ) sh.ftop[j] = (pel_t) tv;
+              if( j <= fLeftLen ) sh.fleft[j] = (pel_t) lv;
+            }
+          }
+        }
+        if( isp )
+        {
+          lds_barrier();
+          if( tid < ( ( n + 63 ) & ~63 ) && tid < n )
+          {
+            const int j = tid;
+            // later partitions: the row above / column left comes from the reconstruction of the previous partition (padded with its
+            // last sample), the other line continues the CU's line (:1003-1069)
+            if( !ispDx && !ispDy ) { tv = sh.ftop[min( j, fTopLen )]; lv = sh.fleft[min( j, fLeftLen )]; }
+            else if( !ispVer )
+            {
+              lv = nL ? sh.fleft[min( ispDy + j, fLeftLen )] : TILE( x0, y0 - 1 );
+              tv = j == 0 ? lv : TILE( x0 + min( j - 1, w - 1 ), y0 - 1 );
+            }
+            else
+            {
+              tv = nA ? sh.ftop[min( ispDx + j, fTopLen )] : TILE( x0 - 1, y0 );
+              lv = j == 0 ? tv : TILE( x0 - 1, y0 + min( j - 1, h - 1 ) );
+            }
+          }
+        }
+        if( tid < ( ( n + 63 ) & ~63 ) )
+        {
+          const int j = tid;
+          if( j < n )
+          {
             if( j <= topLen + mrl ) sh.top[j] = (pel_t) tv;
             if( j <= leftLen + mrl ) sh.left[j] = (pel_t) lv;
           }
@@ -2318,7 +2361,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       }
       // ---- reference smoothing
       bool useFilt = false;
-      if( !comp && !mrl && !bdpcm && dirMode != 1 )
+      if( !comp && !mrl && !bdpcm && dirMode != 1 && !isp )
       {
         if( dirMode == 0 ) useFilt = w * h > 32;
         else
@@ -2358,7 +2401,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       }
       else if( angular )
       {
-        predMode = intra_wide_angle( w, h, dirMode );
+        predMode = isp ? intra_wide_angle( cuW, cuH, dirMode ) : intra_wide_angle( w, h, dirMode );     // ISP: the CU's shape (:502,604)
         isVer = predMode >= 34;
         const int am = isVer ? predMode - 50 : -( predMode - 18 );
         invAngle = sh.invAngTab[iabs( am )]; absAng = sh.angTab[iabs( am )]; angle = am < 0 ? -absAng : absAng;
@@ -2384,7 +2427,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         {
           const int diff = min( iabs( predMode - 18 ), iabs( predMode - 50 ) );
           const int l2 = ( ilog2( bw ) + ilog2( bh ) ) >> 1;
-          cubic = !( diff > sh.filtThr[l2] ) || mrl > 0;
+          cubic = isp || !( diff > sh.filtThr[l2] ) || mrl > 0;
         }
         if( angle > 0 )
         {
@@ -2452,7 +2495,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           v = (int16_t) ( v + ( ( wL * ( L[y + 1] - v ) + wT * ( T[x + 1] - v ) + 32 ) >> 6 ) );
         }
         if( wIntra ) v = ( ( 4 - wIntra ) * TILE( x0 + x, y0 + y ) + wIntra * v + 2 ) >> 2;     // predBlendIntraCiip (:935-944): the tile holds the inter prediction
-        if( hasResi ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
+        if( hasResi && ( !ispPair || ( ( ispResi >> ( x >> 1 ) ) & 1 ) ) ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
         TILE( x0 + x, y0 + y ) = (pel_t) v;
       }
       if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
