@@ -31,7 +31,7 @@ import numpy as np
 
 # SURVEY.md §8(d) config 2 tool mix (fractions of inter CUs; BDOF / DMVR follow from the reference's own conditions:
 # bi-predicted, mirrored POC distances, >= 8x8 and >= 128 samples, merge mode for DMVR)
-MIX = dict(p_intra=0.15, p_bi=0.6, p_affine=0.06, p_geo=0.03, p_ciip=0.03, p_sbtmvp=0.03, p_bcw=0.05, p_jccr=0.1, p_cclm=0.10, p_mip=0.05)
+MIX = dict(p_intra=0.15, p_bi=0.6, p_affine=0.06, p_geo=0.03, p_ciip=0.03, p_sbtmvp=0.03, p_bcw=0.05, p_jccr=0.1, p_cclm=0.10, p_mip=0.05, p_isp=0.05)
 
 
 def _cpu_worker(args):
@@ -177,9 +177,9 @@ def main():
                "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int16", "data": "synthetic",
                "config": {"workload": "%dx%d 10-bit 4:2:0 random-access QP32 (hierarchical-B GOP %d), CTU 128, pre-parsed records resident in HBM" % (W, H, a.gop),
-                          "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
+                          "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM + ISP, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
                           "mix": MIX,
-                          "not_yet": "ISP, IBC, explicit weighted prediction, scaling lists (rejected with VVR_ERR_UNSUPPORTED)",
+                          "not_in_mix": "SBT, explicit weighted prediction, scaling lists (implemented and tested, not part of the configuration of SURVEY.md 8(d)); IBC, dual tree and 4xN intra CUs are rejected with VVR_ERR_UNSUPPORTED",
                           "pictures_in_flight": a.streams, "sharding": "closed-GOP segment per GPU, no data-path collective",
                           "verified_pictures_vs_oracle": verified},
                "roofline": roof}

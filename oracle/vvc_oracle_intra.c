@@ -74,6 +74,7 @@ static void cclm_predict( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu
   const int bLeft  = ( leftCu ? totalLeftUnits : 0 ) >= tuHU;
   const int bAbove = ( aboveCu ? totalAboveUnits : 0 ) >= tuWU;
   const int firstRowOfCtu = ( ly0 & ( ctu - 1 ) ) == 0;
+  const int colloc = ( H->tool_flags & VVR_TOOL_CCLM_COLLOC ) != 0;
   /* ---- xGetLMParameters: template sizes */
   int aboveAvailable = 0, leftAvailable = 0, actualTop = 0, actualLeft = 0;
   {
@@ -123,6 +124,11 @@ static void cclm_predict( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu
         const int l = ( i == 0 && !bLeft ) ? LU( 2 * i, -1 ) : LU( 2 * i - 1, -1 );
         v = ( LU( 2 * i, -1 ) * 2 + l + LU( 2 * i + 1, -1 ) + 2 ) >> 2;
       }
+      else if( colloc )
+      {   /* sps_chroma_vertical_collocated_flag: 5-tap cross centred on the luma sample that sits at the chroma position (:1516-1534) */
+        const int xl = ( i == 0 && !bLeft ) ? 2 * i : 2 * i - 1;
+        v = ( LU( 2 * i, -3 ) + LU( 2 * i, -2 ) * 4 + LU( xl, -2 ) + LU( 2 * i + 1, -2 ) + LU( 2 * i, -1 ) + 4 ) >> 3;
+      }
       else
       {   /* two luma lines above: 6-tap */
         const int xl = ( i == 0 && !bLeft ) ? 2 * i : 2 * i - 1;
@@ -137,7 +143,9 @@ static void cclm_predict( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu
     for( int k = 0, pos = startPos[1]; k < cntL; pos += pickStep[1], k++ )
     {
       const int j = pos;
-      const int v = ( LU( -2, 2 * j ) * 2 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) * 2 + LU( -3, 2 * j + 1 ) + LU( -1, 2 * j + 1 ) + 4 ) >> 3;
+      int v;
+      if( colloc ) { const int yu = ( j == 0 && !bAbove ) ? 2 * j : 2 * j - 1; v = ( LU( -2, yu ) + LU( -2, 2 * j ) * 4 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) + 4 ) >> 3; }     /* (:1556-1571) */
+      else v = ( LU( -2, 2 * j ) * 2 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) * 2 + LU( -3, 2 * j + 1 ) + LU( -1, 2 * j + 1 ) + 4 ) >> 3;
       selL[k + cntT] = (pel) v; selC[k + cntT] = left[1 + pos];
     }
   }
@@ -181,10 +189,12 @@ static void cclm_predict( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu
   for( int y = 0; y < chh; y++ ) for( int x = 0; x < cw; x++ )
   {
     const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
-    const int t = (pel) ( ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
+    const int yu = ( y == 0 && !bAbove ) ? 0 : 2 * y - 1;
+    const int t = colloc ? (pel) ( ( LU( 2 * x, yu ) + LU( 2 * x, 2 * y ) * 4 + LU( xl, 2 * y ) + LU( 2 * x + 1, 2 * y ) + LU( 2 * x, 2 * y + 1 ) + 4 ) >> 3 )       /* (:1588-1625) */
+                       : (pel) ( ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
     pred[y * cw + x] = (pel) vvo_clip_pel( ( ( a * t ) >> shift ) + b, bd );
   }
-  (void) bAbove; (void) comp;
+  (void) comp;
 #undef LU
 }
 

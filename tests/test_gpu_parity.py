@@ -224,6 +224,34 @@ def test_intra_sub_partitions(built):
     _run_stream(256, 192, 3, 2, 214, TOOLS_A, intra=True, log2_ctu=6, p_isp=0.8, p_split_scale=1.6)
 
 
+def test_cclm_collocated_chroma(built):
+    """CCLM / MDLM with sps_chroma_vertical_collocated_flag = 1: the 5-tap cross down-sampling of the luma"""
+    T = TOOLS_A | abi.TOOL_CCLM_COLLOC
+    _run_stream(256, 128, 5, 4, 221, T, intra=True, p_cclm=0.6, p_intra=0.4)
+    _run_stream(416, 240, 3, 2, 222, T | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, intra=True, log2_ctu=5, p_cclm=0.5, p_intra=0.4, p_isp=0.3)
+    _run_stream(1920, 1080, 2, 1, 223, T, intra=True, p_cclm=0.4)
+
+
+def test_config3_8k_and_config5_all_intra(built):
+    """BASELINE configs 3 and 5 as parity cases: one 8K I + B pair, and 4K all-intra pictures with the intra / LFNST heavy mix
+    (dual-tree chroma of config 5 is not covered: single-tree pictures)"""
+    _run_stream(7680, 4320, 2, 1, 231, TOOLS_A | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, intra=True, streams=2, p_coded=0.5, p_affine=0.06, p_geo=0.03, p_ciip=0.03, p_cclm=0.1, p_mip=0.05, p_isp=0.05)
+    import vvdec_amd
+    W, H = 3840, 2160
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=2, num_streams=2)
+    for k in range(2):
+        p = synth.default_params(width=W, height=H, seed=240 + k, tool_flags=TOOLS_A, slice_type=abi.SLICE_I, base_qp=22, p_coded=0.7, p_small_corner=0.5,
+                                 p_lfnst=0.4, p_isp=0.1, p_mip=0.1, p_cclm=0.15)
+        p.poc, p.out_slot = k, k
+        d = synth.generate(p)
+        rec.wait(rec.decompress_picture(d))
+        got = rec.read_picture(k)
+        want = refdrv.oracle_reconstruct(d, {})
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "all-intra picture %d comp %d: %d samples differ" % (k, c, int((got[c] != want[c]).sum()))
+    rec.close()
+
+
 def test_joint_cbcr(built):
     """tu_joint_cbcr_residual: one coded chroma block, the other derived (all three modes, both signs)"""
     _run_stream(256, 128, 5, 4, 171, TOOLS_A, intra=True, p_jccr=0.7, p_coded_chroma=0.7, p_intra=0.3)
@@ -259,8 +287,13 @@ def test_lmcs(built, cscale):
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)
-    p = synth.default_params(width=128, height=64, seed=1, tool_flags=abi.TOOL_CCLM_COLLOC, slice_type=abi.SLICE_I, p_cclm=1.0)
+    p = synth.default_params(width=128, height=64, seed=1, tool_flags=0, slice_type=abi.SLICE_I)
     d = synth.generate(p)
+    d.cu["pred_mode"][0] = abi.PRED_IBC                    # intra block copy: not reconstructed by this build
+    with pytest.raises(vvdec_amd.VvrError):
+        rec.decompress_picture(d)
+    d = synth.generate(p)
+    d.cu["tree"][0] = abi.TREE_LUMA                        # dual tree: not reconstructed by this build
     with pytest.raises(vvdec_amd.VvrError):
         rec.decompress_picture(d)
     rec.close()

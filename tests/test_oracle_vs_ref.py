@@ -106,6 +106,16 @@ def test_oracle_equals_reference_scaling_lists(built, l2, idx, seed, extra, kw):
     assert any(not np.array_equal(flat[c], got[c]) for c in range(3)), "the lists changed nothing"
 
 
+@pytest.mark.parametrize("l2,idx,seed", [(7, 0, 231), (6, 2, 232), (5, 0, 233)])
+def test_oracle_equals_reference_cclm_collocated(built, l2, idx, seed):
+    """CCLM with sps_chroma_vertical_collocated_flag = 1 (5-tap cross down-sampling)"""
+    d, refs = _case(256, 192, l2, idx, seed, tools=ALL | abi.TOOL_CCLM_COLLOC, p_cclm=0.6, p_intra=0.5, p_isp=0.2)
+    want = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_RECO)["planes"]
+    got = refdrv.oracle_reconstruct(d, refs, flags=refdrv.STOP_AFTER_RECO)
+    for c in range(3):
+        assert np.array_equal(got[c], want[c]), "comp %d: %d differ" % (c, int((got[c] != want[c]).sum()))
+
+
 def test_reference_simd_equals_scalar(built):
     """the reference's own differential check (its unit test compares scalar vs SIMD kernels): same bytes at frame level"""
     d, refs = _case(256, 192, 7, 2, 106, p_intra=0.2)

@@ -305,8 +305,7 @@ static int validate( vvr_context* c, const vvr_picture* p )
         const int sizeId = ( cu.w == 4 && cu.h == 4 ) ? 0 : ( cu.w == 4 || cu.h == 4 || ( cu.w == 8 && cu.h == 8 ) ) ? 1 : 2;
         if( cu.intra_dir[0] >= ( sizeId == 0 ? 16 : sizeId == 1 ? 8 : 6 ) || cu.multi_ref_idx || cu.bdpcm[0] ) { c->setError( "MIP CU: mode index out of range for the block size, or combined with MRL / BDPCM" ); return VVR_ERR_PARAMETER; }
       }
-      if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] >= 67 && ( cu.intra_dir[1] > 69 || ( h.tool_flags & VVR_TOOL_CCLM_COLLOC ) ) )
-      { c->setError( "chroma mode out of range, or CCLM with sps_chroma_vertical_collocated_flag (not implemented in this build)" ); return VVR_ERR_UNSUPPORTED; }
+      if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] > 69 ) { c->setError( "chroma intra mode out of range" ); return VVR_ERR_PARAMETER; }
       if( cu.w > 64 || cu.h > 64 || cu.w < 8 || cu.h < 8 ) { c->setError( "intra CU size outside 8..64 is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
       if( cu.tree != VVR_TREE_JOINT ) { c->setError( "dual-tree intra is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
       if( cu.intra_dir[0] > 66 || cu.multi_ref_idx > 2 || cu.bdpcm[1] ) { c->setError( "bad intra mode / chroma BDPCM not implemented" ); return VVR_ERR_UNSUPPORTED; }
@@ -501,7 +500,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
             else { aboveAvail = aboveCu; leftAvail = leftCu; actualTop = w; actualLeft = hh; }
             const int bLeft = leftCu ? 1 : 0;                                                          // availlableLeftUnit >= iTUHeightInUnits
             const int firstRow = ( ( y0 << 1 ) & ( ( 1 << h.log2_ctu ) - 1 ) ) == 0;
-            it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 );
+            it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 ) | ( (uint32_t) ( aboveCu ? 1 : 0 ) << 20 );
             cclmTop = aboveAvail ? actualTop : 0; cclmLeft = leftAvail ? actualLeft : 0; cclmBLeft = bLeft; isCclm = true;
           }
           // ---- unit of this block

@@ -2285,7 +2285,8 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
 #define LU( xx, yy ) ( (int) Yp[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
         const uint32_t lm = it.tu;
         const int actualTop = lm & 0xff, actualLeft = ( lm >> 8 ) & 0xff;
-        const bool aboveAvail = ( lm >> 16 ) & 1, leftAvail = ( lm >> 17 ) & 1, bLeft = ( lm >> 18 ) & 1, firstRow = ( lm >> 19 ) & 1;
+        const bool aboveAvail = ( lm >> 16 ) & 1, leftAvail = ( lm >> 17 ) & 1, bLeft = ( lm >> 18 ) & 1, firstRow = ( lm >> 19 ) & 1, bAbove = ( lm >> 20 ) & 1;
+        const bool colloc = ( pic.hdr.tool_flags & VVR_TOOL_CCLM_COLLOC ) != 0;      // sps_chroma_vertical_collocated_flag: 5-tap cross instead of the 6-tap filter
         const int aboveIs4 = leftAvail ? 0 : 1, leftIs4 = aboveAvail ? 0 : 1;
         const int cntT = aboveAvail ? min( actualTop, ( 1 + aboveIs4 ) << 1 ) : 0, cntL = leftAvail ? min( actualLeft, ( 1 + leftIs4 ) << 1 ) : 0;
         if( tid < cntT + cntL )
@@ -2296,13 +2297,15 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
             const int i = ( actualTop >> ( 2 + aboveIs4 ) ) + tid * max( 1, actualTop >> ( 1 + aboveIs4 ) );
             const int xl = ( i == 0 && !bLeft ) ? 2 * i : 2 * i - 1;
             if( firstRow ) lv = ( LU( 2 * i, -1 ) * 2 + LU( xl, -1 ) + LU( 2 * i + 1, -1 ) + 2 ) >> 2;
+            else if( colloc ) lv = ( LU( 2 * i, -3 ) + LU( 2 * i, -2 ) * 4 + LU( xl, -2 ) + LU( 2 * i + 1, -2 ) + LU( 2 * i, -1 ) + 4 ) >> 3;
             else           lv = ( LU( 2 * i, -2 ) * 2 + LU( xl, -2 ) + LU( 2 * i + 1, -2 ) + LU( 2 * i, -1 ) * 2 + LU( xl, -1 ) + LU( 2 * i + 1, -1 ) + 4 ) >> 3;
             cv = sh.top[1 + i];
           }
           else
           {
             const int j = ( actualLeft >> ( 2 + leftIs4 ) ) + ( tid - cntT ) * max( 1, actualLeft >> ( 1 + leftIs4 ) );
-            lv = ( LU( -2, 2 * j ) * 2 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) * 2 + LU( -3, 2 * j + 1 ) + LU( -1, 2 * j + 1 ) + 4 ) >> 3;
+            if( colloc ) { const int yu = ( j == 0 && !bAbove ) ? 2 * j : 2 * j - 1; lv = ( LU( -2, yu ) + LU( -2, 2 * j ) * 4 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) + 4 ) >> 3; }
+            else lv = ( LU( -2, 2 * j ) * 2 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) * 2 + LU( -3, 2 * j + 1 ) + LU( -1, 2 * j + 1 ) + 4 ) >> 3;
             cv = sh.left[1 + j];
           }
           sh.lmSel[tid] = (int16_t) lv; sh.lmSel[4 + tid] = cv;
@@ -2349,7 +2352,9 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         {
           const int x = i & ( w - 1 ), y = i >> lw;
           const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
-          const int t = (int16_t) ( ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
+          const int yu = ( y == 0 && !bAbove ) ? 0 : 2 * y - 1;
+          const int t = colloc ? (int16_t) ( ( LU( 2 * x, yu ) + LU( 2 * x, 2 * y ) * 4 + LU( xl, 2 * y ) + LU( 2 * x + 1, 2 * y ) + LU( 2 * x, 2 * y + 1 ) + 4 ) >> 3 )
+                               : (int16_t) ( ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
           int v = clip_pel( ( ( a * t ) >> shift ) + b, bd );
           if( hasResi ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
           TILE( x0 + x, y0 + y ) = (pel_t) v;
