@@ -172,6 +172,7 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
   for( uint32_t i = 0; i < pic->num_cu; i++ )
   {
     const vvr_cu* cu = &pic->cu[i];
+    if( cu->tree == VVR_TREE_CHROMA ) continue;                      /* dual tree: the luma CUs */
     for( int y = cu->y; y < cu->y + cu->h && y < Hh; y += 4 ) for( int x = cu->x; x < cu->x + cu->w && x < W; x += 4 ) cuAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) i;
   }
   const int cscale = ( H->tool_flags & VVR_TOOL_LMCS ) && ( H->tool_flags & VVR_TOOL_LMCS_CSCALE ) && pic->lmcs && ncomp == 3;

@@ -234,14 +234,14 @@ def test_cclm_collocated_chroma(built):
 
 def test_config3_8k_and_config5_all_intra(built):
     """BASELINE configs 3 and 5 as parity cases: one 8K I + B pair, and 4K all-intra pictures with the intra / LFNST heavy mix
-    (dual-tree chroma of config 5 is not covered: single-tree pictures)"""
+    and dual-tree chroma"""
     _run_stream(7680, 4320, 2, 1, 231, TOOLS_A | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, intra=True, streams=2, p_coded=0.5, p_affine=0.06, p_geo=0.03, p_ciip=0.03, p_cclm=0.1, p_mip=0.05, p_isp=0.05)
     import vvdec_amd
     W, H = 3840, 2160
     rec = vvdec_amd.Reconstructor(W, H, num_slots=2, num_streams=2)
     for k in range(2):
         p = synth.default_params(width=W, height=H, seed=240 + k, tool_flags=TOOLS_A, slice_type=abi.SLICE_I, base_qp=22, p_coded=0.7, p_small_corner=0.5,
-                                 p_lfnst=0.4, p_isp=0.1, p_mip=0.1, p_cclm=0.15)
+                                 p_lfnst=0.4, p_isp=0.1, p_mip=0.1, p_cclm=0.15, dual_tree=1.0)
         p.poc, p.out_slot = k, k
         d = synth.generate(p)
         rec.wait(rec.decompress_picture(d))
@@ -250,6 +250,14 @@ def test_config3_8k_and_config5_all_intra(built):
         for c in range(3):
             assert np.array_equal(got[c], want[c]), "all-intra picture %d comp %d: %d samples differ" % (k, c, int((got[c] != want[c]).sum()))
     rec.close()
+
+
+def test_dual_tree_intra_pictures(built):
+    """I pictures with separate luma and chroma coding trees (qtbtt_dual_tree_intra_flag): chroma CUs with derived / CCLM modes and
+    their own LFNST, chroma edges of the deblocking from the chroma tree; the B pictures that follow are single tree"""
+    _run_stream(256, 128, 5, 4, 241, TOOLS_A, intra=True, dual_tree=1.0, p_cclm=0.4, p_lfnst=0.5, p_isp=0.3, p_mip=0.2, p_coded_chroma=0.6)
+    _run_stream(416, 240, 3, 2, 242, TOOLS_A | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, intra=True, log2_ctu=5, dual_tree=1.0, p_cclm=0.4, p_jccr=0.3, p_coded_chroma=0.6)
+    _run_stream(1920, 1080, 3, 2, 243, TOOLS_A, intra=True, streams=3, log2_ctu=6, dual_tree=1.0, p_cclm=0.2, p_isp=0.1)
 
 
 def test_joint_cbcr(built):
@@ -292,8 +300,11 @@ def test_unsupported_tools_fail_loudly(built):
     d.cu["pred_mode"][0] = abi.PRED_IBC                    # intra block copy: not reconstructed by this build
     with pytest.raises(vvdec_amd.VvrError):
         rec.decompress_picture(d)
+    p.slice_type = abi.SLICE_B
+    synth.set_refs(p, [(1, 0)], [(1, 0)])
+    p.poc = 1
     d = synth.generate(p)
-    d.cu["tree"][0] = abi.TREE_LUMA                        # dual tree: not reconstructed by this build
+    d.cu["tree"][0] = abi.TREE_LUMA                        # separate trees outside intra pictures (local dual tree): not in this build
     with pytest.raises(vvdec_amd.VvrError):
         rec.decompress_picture(d)
     rec.close()

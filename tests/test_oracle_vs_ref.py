@@ -44,6 +44,9 @@ def _case(W, H, l2, idx, seed, tools=ALL, **kw):
     (256, 128, 7, 0, 119, dict(p_isp=0.6, p_lfnst=0.4, p_coded=0.7)),
     (200, 136, 5, 2, 120, dict(p_isp=0.7, p_intra=0.5, p_cclm=0.3)),
     (384, 256, 6, 0, 121, dict(p_isp=0.5, p_split_scale=0.5, p_cclm=0.3, p_lfnst=0.4, p_jccr=0.3)),
+    (256, 128, 7, 0, 124, dict(dual_tree=1.0, p_cclm=0.4, p_lfnst=0.5, p_isp=0.3, p_mip=0.2, p_coded_chroma=0.6)),
+    (200, 136, 5, 0, 125, dict(dual_tree=1.0, p_cclm=0.4, p_jccr=0.3, p_coded_chroma=0.6)),
+    (384, 256, 6, 0, 126, dict(dual_tree=1.0, p_split_scale=0.6, p_lfnst=0.4, p_bdpcm=0.2)),
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)
@@ -131,7 +134,8 @@ def test_edge_parameters_match_reference_derivation(built):
     a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
     b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
-    for args, kw in (((256, 128, 7, 0, 122), dict(p_isp=0.7, p_split_scale=1.6)), ((384, 256, 6, 2, 123), dict(p_isp=0.5, p_intra=0.4, p_cclm=0.3))):
+    for args, kw in (((256, 128, 7, 0, 122), dict(p_isp=0.7, p_split_scale=1.6)), ((384, 256, 6, 2, 123), dict(p_isp=0.5, p_intra=0.4, p_cclm=0.3)),
+                     ((384, 256, 7, 0, 127), dict(dual_tree=1.0, p_isp=0.2, p_bdpcm=0.3, p_coded_chroma=0.6)), ((256, 128, 6, 2, 128), dict(p_bdpcm=0.5, p_intra=0.6))):
         d, refs = _case(*args, **kw)                                                       # ISP: partition edges, unsplit chroma
         a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
         b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]

@@ -68,6 +68,7 @@ typedef struct vvs_params {
   float    p_mip;               // of intra CUs: matrix-based luma prediction
   float    p_sbt;               // of inter CUs (not CIIP, at most 64x64): sub-block transform (residual in one half / quarter of the CU)
   float    p_isp;               // of intra CUs (no MRL / BDPCM / MIP): intra sub-partitions, four luma partitions predicted one after the other
+  float    dual_tree;           // > 0: I pictures use separate luma and chroma coding trees below 64x64 (qtbtt_dual_tree_intra_flag)
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -93,7 +94,8 @@ void vvs_bounds( const vvs_params* P, uint32_t* max_cu, uint32_t* max_tu, uint64
 {
   const uint32_t m = 1u << P->min_cu_log2;
   const uint32_t n = ( ( P->width + m - 1 ) / m ) * ( ( P->height + m - 1 ) / m );
-  *max_cu = n; *max_tu = n + n / 4 + 16;
+  const uint32_t trees = P->dual_tree > 0 ? 2 : 1;                 // dual tree: luma and chroma CUs
+  *max_cu = n * trees; *max_tu = ( P->p_isp > 0 ? 4 * n : n + n / 4 ) * trees + 16;      // ISP: four TUs per CU
   *max_coef = (uint64_t) P->width * P->height * 3 / 2 + 4096;
 }
 
@@ -105,7 +107,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f; P->p_mip = 0.0f; P->p_sbt = 0.0f; P->p_isp = 0.0f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f; P->p_mip = 0.0f; P->p_sbt = 0.0f; P->p_isp = 0.0f; P->dual_tree = 0.0f;
 }
 
 namespace {
@@ -115,6 +117,9 @@ struct Gen {
   int W, H, w4, h4, ctu, bd;
   std::vector<int32_t> cuOf4;      // per 4x4: CU index
   std::vector<int32_t> tuOf4;      // per 4x4: TU index
+  std::vector<int32_t> cuOf4C, tuOf4C;   // dual tree: the same maps of the chroma tree
+  int curTree = VVR_TREE_JOINT;    // tree the CUs being added belong to
+  bool cclmOk = true;              // CCLM allowed for the chroma CUs being added (CU::checkCCLMAllowed, UnitTools.cpp:3439)
   Gen( const vvs_params& p, vvs_buffers& b ) : P( p ), B( b ), rng( p.seed ) {}
 
   bool wpOn = false;
@@ -221,7 +226,8 @@ struct Gen {
   {
     vvr_cu& cu = B.cu[B.num_cu]; memset( &cu, 0, sizeof( cu ) );
     const uint32_t cuIdx = B.num_cu++;
-    cu.x = x; cu.y = y; cu.w = w; cu.h = h; cu.tree = VVR_TREE_JOINT;
+    cu.x = x; cu.y = y; cu.w = w; cu.h = h; cu.tree = (uint8_t) curTree;
+    const bool treeL = curTree == VVR_TREE_LUMA, treeC = curTree == VVR_TREE_CHROMA;
     cu.qp = (int8_t) std::min( 63, std::max( 0, P.base_qp + (int) rng.u( 7 ) - 3 ) );
     cu.bcw_idx = 2; cu.ref_idx[0] = cu.ref_idx[1] = -1;
     const bool isI = P.slice_type == 2;
@@ -233,15 +239,26 @@ struct Gen {
       cu.intra_dir[0] = r < 20 ? 0 : r < 35 ? 1 : 2 + rng.u( 65 );
       const int rc = rng.u( 100 );
       cu.intra_dir[1] = rc < 40 ? cu.intra_dir[0] : rc < 55 ? 0 : rc < 65 ? 1 : rc < 75 ? 18 : rc < 85 ? 50 : 2 + rng.u( 65 );   // DM / planar / DC / hor / ver / any (CCLM: not generated yet)
-      if( P.chroma_format && rng.p( P.p_cclm ) ) cu.intra_dir[1] = (uint8_t) ( 67 + rng.u( 3 ) );     // LM_CHROMA_IDX, MDLM_L_IDX, MDLM_T_IDX
+      if( P.chroma_format && !treeL && cclmOk && rng.p( P.p_cclm ) ) cu.intra_dir[1] = (uint8_t) ( 67 + rng.u( 3 ) );     // LM_CHROMA_IDX, MDLM_L_IDX, MDLM_T_IDX
       cu.lfnst_intra_mode = cu.intra_dir[0];
+      if( treeC )
+      {
+        // chroma CU of a dual tree: the derived mode is the luma mode at the centre of the co-located luma area
+        // (PU::getCoLocatedIntraLumaMode: MIP -> planar); it also selects the LFNST set of CCLM blocks
+        const vvr_cu& lc = B.cu[cuOf4[( ( y + h / 2 ) >> 2 ) * w4 + ( ( x + w / 2 ) >> 2 )]];
+        const uint8_t colMode = ( lc.flags & VVR_CU_MIP ) ? 0 : lc.intra_dir[0];
+        if( rc < 40 ) cu.intra_dir[1] = colMode;
+        cu.intra_dir[0] = colMode; cu.lfnst_intra_mode = colMode;
+        // LFNST of a chroma tree CU applies to both chroma blocks (at least 4x4 each)
+        if( ( P.tool_flags & VVR_TOOL_LFNST ) && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
+      }
       // multiple reference lines: luma only, never on the first row of a CTU, not with planar (intra_luma_ref_idx semantics)
-      if( ( y & ( ctu - 1 ) ) != 0 && cu.intra_dir[0] != 0 && rng.p( P.p_mrl ) ) cu.multi_ref_idx = (uint8_t) ( 1 + rng.u( 2 ) );
+      if( !treeC && ( y & ( ctu - 1 ) ) != 0 && cu.intra_dir[0] != 0 && rng.p( P.p_mrl ) ) cu.multi_ref_idx = (uint8_t) ( 1 + rng.u( 2 ) );
       // BDPCM (implies transform skip of the luma block)
-      if( w <= 32 && h <= 32 && !cu.multi_ref_idx && rng.p( P.p_bdpcm ) ) { cu.bdpcm[0] = (uint8_t) ( 1 + rng.u( 2 ) ); cu.intra_dir[0] = cu.bdpcm[0] == 1 ? 18 : 50; cu.lfnst_intra_mode = cu.intra_dir[0]; }
+      if( !treeC && w <= 32 && h <= 32 && !cu.multi_ref_idx && rng.p( P.p_bdpcm ) ) { cu.bdpcm[0] = (uint8_t) ( 1 + rng.u( 2 ) ); cu.intra_dir[0] = cu.bdpcm[0] == 1 ? 18 : 50; cu.lfnst_intra_mode = cu.intra_dir[0]; }
       // MIP: luma mode index into the matrix set of the block size class (16 / 8 / 6 modes), optional transposition; the chroma
       // derived mode of a MIP CU is planar; no MRL / BDPCM; LFNST only for blocks of at least 16x16 (allowLfnstWithMip)
-      if( !cu.bdpcm[0] && !cu.multi_ref_idx && w <= 64 && h <= 64 && rng.p( P.p_mip ) )
+      if( !treeC && !cu.bdpcm[0] && !cu.multi_ref_idx && w <= 64 && h <= 64 && rng.p( P.p_mip ) )
       {
         const int sizeId = ( w == 4 && h == 4 ) ? 0 : ( w == 4 || h == 4 || ( w == 8 && h == 8 ) ) ? 1 : 2;
         cu.flags |= VVR_CU_MIP | ( rng.p( 0.5 ) ? VVR_CU_MIP_TRANSP : 0 );
@@ -251,10 +268,10 @@ struct Gen {
       }
       // intra sub-partitions: horizontal (1) or vertical (2) split of the luma block in four (CU::canUseISP: more than 16 samples,
       // at most the maximum transform size); LFNST only while the partitions are at least 4x4 (CU::canUseLfnstWithISP)
-      if( P.p_isp > 0 && !cu.bdpcm[0] && !cu.multi_ref_idx && !( cu.flags & VVR_CU_MIP ) && w <= 64 && h <= 64 && rng.p( P.p_isp ) ) cu.isp_mode = (uint8_t) ( 1 + rng.u( 2 ) );
+      if( P.p_isp > 0 && !treeC && !( treeL && w == 64 && h == 64 ) && !cu.bdpcm[0] && !cu.multi_ref_idx && !( cu.flags & VVR_CU_MIP ) && w <= 64 && h <= 64 && rng.p( P.p_isp ) ) cu.isp_mode = (uint8_t) ( 1 + rng.u( 2 ) );
       const bool ispNoLfnst = cu.isp_mode && ( cu.isp_mode == 1 ? h / 4 < 4 : w / 4 < 4 );
       // LFNST index (luma of single-tree CUs): needs DCT2 and a residual confined to the first 8/16 scan positions, see genLevels
-      if( ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && ( !( cu.flags & VVR_CU_MIP ) || ( w >= 16 && h >= 16 ) ) && !ispNoLfnst && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
+      if( !treeC && ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && ( !( cu.flags & VVR_CU_MIP ) || ( w >= 16 && h >= 16 ) ) && !ispNoLfnst && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
     }
     else
     {
@@ -382,7 +399,7 @@ struct Gen {
       vvr_tu& tu = B.tu[B.num_tu]; memset( &tu, 0, sizeof( tu ) );
       const uint32_t tuIdx = B.num_tu++;
       tu.x = x + tx; tu.y = y + ty; tu.w = tw; tu.h = th; tu.cu = cuIdx;
-      tu.comp_mask = P.chroma_format ? 7 : 1;
+      tu.comp_mask = treeL ? 1 : treeC ? 6 : P.chroma_format ? 7 : 1;
       if( cu.isp_mode && ti != ntb - 1 ) tu.comp_mask = 1;          // the (unsplit) chroma blocks of an ISP CU belong to the last TU
       const int qpBd = 6 * ( bd - 8 );
       tu.qp[0] = (int8_t) ( cu.qp + qpBd );
@@ -412,7 +429,7 @@ struct Gen {
         if( c == 0 && cu.isp_mode ) ispAnyLuma = true;
         bool ts = bw <= 32 && bh <= 32 && !sbtIdx && !( c == 0 && cu.isp_mode ) && rng.p( P.p_ts );
         if( c == 0 && intra && cu.bdpcm[0] ) ts = true;
-        if( c == 0 && intra && cu.lfnst_idx ) ts = false;
+        if( ( c == 0 || treeC ) && intra && cu.lfnst_idx ) ts = false;
         tu.mts_idx[c] = ts ? VVR_MTS_SKIP : VVR_MTS_DCT2;
         if( !ts && c == 0 && bw <= 32 && bh <= 32 && !sbtIdx && !cu.isp_mode && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
         // getTrTypes (TrQuant.cpp:330): explicit MTS -> hor = (idx-2)&1 ? DCT8 : DST7 ; ver = (idx-2)>>1 ? DCT8 : DST7
@@ -428,12 +445,12 @@ struct Gen {
           else                             { if( bw > 32 ) hor = ver = 0; else { hor = 2; ver = sbtPos == 0 ? 1 : 2; } }
         }
         tu.tr_type[c] = (uint8_t) ( ( ver << 2 ) | hor );
-        genLevels( tu, c, bw, bh, ts, c == 0 && intra && cu.bdpcm[0], c == 0 && intra && cu.lfnst_idx );
+        genLevels( tu, c, bw, bh, ts, c == 0 && intra && cu.bdpcm[0], ( c == 0 || treeC ) && intra && cu.lfnst_idx );
         rootCbf = true;
       }
       tu_done:
       for( int yy = 0; yy < th; yy += 4 ) for( int xx = 0; xx < tw; xx += 4 )
-        if( tu.x + xx < W && tu.y + yy < H ) tuOf4[( ( tu.y + yy ) >> 2 ) * w4 + ( ( tu.x + xx ) >> 2 )] = (int32_t) tuIdx;
+        if( tu.x + xx < W && tu.y + yy < H ) ( treeC ? tuOf4C : tuOf4 )[( ( tu.y + yy ) >> 2 ) * w4 + ( ( tu.x + xx ) >> 2 )] = (int32_t) tuIdx;
     }
     cu.num_tu = B.num_tu - cu.first_tu;
     if( rootCbf ) cu.flags |= VVR_CU_ROOT_CBF;
@@ -442,6 +459,7 @@ struct Gen {
     for( int yy = 0; yy < h; yy += 4 ) for( int xx = 0; xx < w; xx += 4 )
     {
       const int i4 = ( ( y + yy ) >> 2 ) * w4 + ( ( x + xx ) >> 2 );
+      if( treeC ) { cuOf4C[i4] = (int32_t) cuIdx; continue; }
       cuOf4[i4] = (int32_t) cuIdx;
       vvr_motion& m = B.motion[i4];
       m.ref_idx[0] = cu.ref_idx[0]; m.ref_idx[1] = cu.ref_idx[1];
@@ -565,6 +583,46 @@ struct Gen {
   // deblocking edge parameters: the table LoopFilter::calcFilterStrengthsCTU (LoopFilter.cpp:495-1360) fills.
   // This generator version has no sub-block (affine/SbTMVP) edges, no ISP/SBT, single tree.
   // ---------------------------------------------------------------------------------------------------------------
+  // dual tree (intra pictures): luma edges from the luma tree, chroma edges (8x8 chroma-sample grid) from the chroma tree; every
+  // edge separates intra blocks (boundary strength 2)
+  void deriveLfpDual()
+  {
+    const int qpBd = 6 * ( bd - 8 );
+    for( int d = 0; d < 2; d++ )
+    {
+      memset( B.lfp[d], 0, sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+      for( int y4 = 0; y4 < h4; y4++ ) for( int x4 = 0; x4 < w4; x4++ )
+      {
+        const int px4 = d == 0 ? x4 - 1 : x4, py4 = d == 0 ? y4 : y4 - 1;
+        if( px4 < 0 || py4 < 0 ) continue;
+        const int iq = y4 * w4 + x4, ip = py4 * w4 + px4;
+        vvr_lfp& L = B.lfp[d][iq];
+        int bsY = 0, bsC = 0;
+        if( tuOf4[iq] != tuOf4[ip] )
+        {
+          const vvr_tu& TQ = B.tu[tuOf4[iq]]; const vvr_tu& TP = B.tu[tuOf4[ip]];
+          const int sizeQ = d == 0 ? TQ.w : TQ.h, sizeP = d == 0 ? TP.w : TP.h;
+          int lenP, lenQ;
+          if( sizeP <= 4 || sizeQ <= 4 ) lenP = lenQ = 1;
+          else { lenP = sizeP >= 32 ? 7 : 3; lenQ = sizeQ >= 32 ? 7 : 3; }
+          L.side_max_filt_length = (uint8_t) ( 0x80 | ( lenP << 4 ) | lenQ );
+          L.flags |= 1; bsY = ( B.cu[TQ.cu].bdpcm[0] && B.cu[TP.cu].bdpcm[0] ) ? 0 : 2;      // no filtering between two BDPCM blocks (LoopFilter.cpp:1146)
+          L.qp[0] = (int8_t) ( ( B.cu[TQ.cu].qp + B.cu[TP.cu].qp + 1 ) >> 1 );
+        }
+        const int posAlong = d == 0 ? ( x4 << 2 ) : ( y4 << 2 );
+        if( posAlong % 16 == 0 && tuOf4C[iq] != tuOf4C[ip] )
+        {
+          const vvr_tu& TQ = B.tu[tuOf4C[iq]]; const vvr_tu& TP = B.tu[tuOf4C[ip]];
+          const int sizeQ = ( d == 0 ? TQ.w : TQ.h ) >> 1, sizeP = ( d == 0 ? TP.w : TP.h ) >> 1;
+          L.flags |= 2 | ( ( sizeP >= 8 && sizeQ >= 8 ) ? 0x20 : 0 ); bsC = 2;
+          L.qp[1] = (int8_t) ( ( TQ.qp[1] + TP.qp[1] - 2 * qpBd + 1 ) >> 1 );
+          L.qp[2] = (int8_t) ( ( TQ.qp[2] + TP.qp[2] - 2 * qpBd + 1 ) >> 1 );
+        }
+        L.bs = (uint8_t) ( bsY | ( bsC << 2 ) | ( bsC << 4 ) );
+      }
+    }
+  }
+
   void deriveLfp()
   {
     const int qpBd = 6 * ( bd - 8 );
@@ -600,7 +658,7 @@ struct Gen {
         // boundary strength (LoopFilter.cpp:1094-1360)
         int bsY = 0, bsCb = 0, bsCr = 0;
         const bool intra = CQ.pred_mode == VVR_PRED_INTRA || CP.pred_mode == VVR_PRED_INTRA || ( ( CQ.flags | CP.flags ) & VVR_CU_CIIP );   // CIIP counts as intra for the BS
-        if( intra ) { bsY = 2; bsCb = bsCr = chromaEdge ? 2 : 0; }
+        if( intra ) { bsY = ( CQ.bdpcm[0] && CP.bdpcm[0] ) ? 0 : 2; bsCb = bsCr = chromaEdge ? 2 : 0; }     // no luma filtering between two BDPCM blocks (LoopFilter.cpp:1146)
         else
         {
           if( ( TQ.cbf & 1 ) || ( TP.cbf & 1 ) ) bsY = 1;
@@ -741,9 +799,31 @@ struct Gen {
     if( wpOn ) genWp();
     if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && B.scaling ) genScalingList();
     int a = 0;
-    for( int y = 0; y < H; y += ctu ) for( int x = 0; x < W; x += ctu, a++ ) { B.ctu_first_cu[a] = B.num_cu; split( x, y, ctu, ctu ); }
+    const bool dual = P.slice_type == 2 && P.dual_tree > 0 && P.chroma_format;
+    if( dual ) { cuOf4C.assign( (size_t) w4 * h4, -1 ); tuOf4C.assign( (size_t) w4 * h4, -1 ); }
+    for( int y = 0; y < H; y += ctu ) for( int x = 0; x < W; x += ctu, a++ )
+    {
+      B.ctu_first_cu[a] = B.num_cu;
+      if( !dual ) { split( x, y, ctu, ctu ); continue; }
+      // dual tree: the CTU is split down to 64x64 implicitly; every such node carries its luma tree, then its chroma tree.
+      // Inside the picture the node is either not split or quad-split in both trees, which keeps CCLM legal (checkCCLMAllowed)
+      const int R = std::min( ctu, 64 );
+      for( int ry = y; ry < y + ctu && ry < H; ry += R ) for( int rx = x; rx < x + ctu && rx < W; rx += R )
+      {
+        const bool inside = rx + R <= W && ry + R <= H;
+        const bool nodeQT = R == 64 && inside && rng.p( 0.85 ), nodeNS = R == 64 && inside && !nodeQT;
+        for( int tree = VVR_TREE_LUMA; tree <= VVR_TREE_CHROMA; tree++ )
+        {
+          curTree = tree; cclmOk = R < 64 || inside;
+          if( nodeNS ) addCu( rx, ry, R, R );
+          else if( nodeQT ) { const int hs = R >> 1; split( rx, ry, hs, hs ); split( rx + hs, ry, hs, hs ); split( rx, ry + hs, hs, hs ); split( rx + hs, ry + hs, hs, hs ); }
+          else split( rx, ry, R, R );
+        }
+      }
+      curTree = VVR_TREE_JOINT; cclmOk = true;
+    }
     B.ctu_first_cu[a] = B.num_cu;
-    deriveLfp();
+    if( dual ) deriveLfpDual(); else deriveLfp();
     if( ( P.tool_flags & VVR_TOOL_LMCS ) && B.lmcs ) genLmcs();
     genAlfParams();
     genLoopFilterParams();

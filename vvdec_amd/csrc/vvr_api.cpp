@@ -297,7 +297,7 @@ static int validate( vvr_context* c, const vvr_picture* p )
         {
           const vvr_tu& t4 = p->tu[cu.first_tu + k];
           const bool ok = cu.isp_mode == 1 ? ( t4.x == cu.x && t4.w == cu.w && t4.h * 4 == cu.h && t4.y == cu.y + (int) k * t4.h ) : ( t4.y == cu.y && t4.h == cu.h && t4.w * 4 == cu.w && t4.x == cu.x + (int) k * t4.w );
-          if( !ok || ( t4.comp_mask & 6 ) != ( k == 3 && h.chroma_format ? 6 : 0 ) || t4.mts_idx[0] == VVR_MTS_SKIP ) { c->setError( "ISP CU: TU layout" ); return VVR_ERR_PARAMETER; }
+          if( !ok || ( t4.comp_mask & 6 ) != ( k == 3 && h.chroma_format && cu.tree == VVR_TREE_JOINT ? 6 : 0 ) || t4.mts_idx[0] == VVR_MTS_SKIP ) { c->setError( "ISP CU: TU layout" ); return VVR_ERR_PARAMETER; }
         }
       }
       if( cu.flags & VVR_CU_MIP )
@@ -307,7 +307,14 @@ static int validate( vvr_context* c, const vvr_picture* p )
       }
       if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] > 69 ) { c->setError( "chroma intra mode out of range" ); return VVR_ERR_PARAMETER; }
       if( cu.w > 64 || cu.h > 64 || cu.w < 8 || cu.h < 8 ) { c->setError( "intra CU size outside 8..64 is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
-      if( cu.tree != VVR_TREE_JOINT ) { c->setError( "dual-tree intra is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      if( cu.tree != VVR_TREE_JOINT )
+      {
+        // dual tree (I slices, qtbtt_dual_tree_intra_flag): luma CUs carry luma blocks only, chroma CUs chroma blocks only
+        if( cu.tree > VVR_TREE_CHROMA || h.slice_type != 2 || !h.chroma_format ) { c->setError( "separate-tree CU outside an intra picture (local dual tree is not implemented in this build)" ); return VVR_ERR_UNSUPPORTED; }
+        const int want = cu.tree == VVR_TREE_LUMA ? 1 : 6;
+        for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ ) if( p->tu[t].comp_mask != want ) { c->setError( "separate-tree CU: TU component mask" ); return VVR_ERR_PARAMETER; }
+        if( cu.tree == VVR_TREE_CHROMA && ( cu.isp_mode || cu.multi_ref_idx || cu.bdpcm[0] || ( cu.flags & VVR_CU_MIP ) ) ) { c->setError( "chroma-tree CU with luma tools" ); return VVR_ERR_PARAMETER; }
+      }
       if( cu.intra_dir[0] > 66 || cu.multi_ref_idx > 2 || cu.bdpcm[1] ) { c->setError( "bad intra mode / chroma BDPCM not implemented" ); return VVR_ERR_UNSUPPORTED; }
     }
     else { c->setError( "IBC CUs are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
@@ -401,6 +408,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     for( uint32_t i = 0; i < p->num_cu; i++ )
     {
       const vvr_cu& cu = p->cu[i];
+      if( cu.tree == VVR_TREE_CHROMA ) continue;                     // dual tree: the luma CUs
       for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) cuAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) i;
     }
     csVpduV.resize( (size_t) vpdusX * vpdusY );
