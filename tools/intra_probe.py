@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
-"""developer helper (GPU box): k_intra time of one 4K I picture and one 4K B picture, alone on the device"""
+"""developer helper (GPU box): per-kernel time of one 4K I picture and of B pictures of the benchmark stream, alone on the device"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vvdec_amd
 from vvdec_amd import abi, synth, stream
+import bench
 W, H = 3840, 2160
-tools = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST
+tools = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST |
+         abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE)
+if os.environ.get("PROBE_NO_CS"):
+    tools &= ~abi.TOOL_LMCS_CSCALE
 plans, nslots = stream.ra_plan(17, gop=16, seed_poc0_is_external=False)
 rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1)
-out = []
-for pl in plans[:2]:
-    d = synth.picture_for_plan(pl, W, H, seed=1234, tool_flags=tools)
+for pl in plans[:4]:
+    d = synth.picture_for_plan(pl, W, H, seed=1234, tool_flags=tools, **bench.MIX)
     h = rec.prepare(d)
     for i in range(3):
         rec.submit_prepared(h)
@@ -21,5 +24,4 @@ for pl in plans[:2]:
     rec.sync()
     st = {s["name"]: 1e3 * s["total_ms"] / max(1, s["launches"]) for s in rec.stats()}
     rec.enable_stats(False)
-    out.append("POC %d k_intra %.1f us" % (pl.poc, st.get("k_intra", 0)))
-print(os.environ.get("VVR_INTRA_DBG", "0"), " | ".join(out))
+    print("POC %2d  " % pl.poc + "  ".join("%s %.0f" % (k[2:], v) for k, v in st.items() if v > 0), " sum %.0f" % sum(st.values()), flush=True)

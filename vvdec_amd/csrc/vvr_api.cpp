@@ -354,21 +354,24 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
   std::vector<int32_t> order;
   std::vector<uint8_t> intraAt;          // per 4x4 luma unit: covered by an intra CU
-  // Intra-stage work units: a unit is a run of consecutive blocks of one (component, CTU) that lie in the same quadrant of the CTU;
-  // one workgroup processes one unit.  Units depend on exactly those earlier units that produced a reference sample they read
-  // (inter samples are final before the stage starts), which the loop below finds through unitAt[].
+  // Intra-stage work units: a unit is a set of blocks of one (component, CTU) that are connected through the reference samples they
+  // read from each other (a whole CTU in an intra picture, a few blocks around an isolated intra CU in a B picture); one workgroup
+  // processes one unit, its blocks in coding order.  Units depend on exactly those other units that produced a sample they read
+  // (inter samples are final before the stage starts).  The loop below records per block which blocks it reads from (itemAt[]);
+  // the units are formed afterwards.
   struct BBox { int y0 = 255, y1 = 0, c0 = 255, c1 = 0; };   // rows relative to (CTU top - 3), 8-sample chunks relative to (CTU left - 8), chunk index + 1
-  struct UnitH { uint32_t comp, ctu, i0, i1, iA = 0; bool hasCs = false; int quad; BBox bb; std::vector<uint32_t> deps; bool waited = false; };
+  struct UnitH { uint32_t comp, ctu, i0, i1, iA = 0; bool hasCs = false; BBox bb; std::vector<uint32_t> deps; bool waited = false; int rank = 0; };
+  struct ItemH { uint32_t ctu; BBox bb; std::vector<uint32_t> prod; };      // prod: ( component << 28 ) | item index of the blocks it reads from
   std::vector<UnitH> units;
-  int32_t curUnit[3] = { -1, -1, -1 }; int unitsInCtu[3] = { 0, 0, 0 };
-  std::vector<int32_t> unitAt[3];        // per component and 4x4 luma cell: the unit that reconstructs it in the intra stage (-1: none)
+  std::vector<ItemH> itemH[3];
+  std::vector<int32_t> itemAt[3];        // per component and 4x4 luma cell: the block that reconstructs it in the intra stage (-1: none)
   bool anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || ( p->cu[i].flags & VVR_CU_CIIP );
   if( anyIntra )
   {
     order.assign( (size_t) w4 * h4 * 2, 0x7fffffff );
     intraAt.assign( (size_t) w4 * h4, 0 );
-    for( int k = 0; k < ncomp; k++ ) unitAt[k].assign( (size_t) w4 * h4, -1 );
+    for( int k = 0; k < ncomp; k++ ) itemAt[k].assign( (size_t) w4 * h4, -1 );
     for( uint32_t i = 0; i < p->num_cu; i++ )
     {
       const vvr_cu& cu = p->cu[i];
@@ -430,7 +433,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     const uint32_t ctuOfCu = (uint32_t) ( ( cu.y >> h.log2_ctu ) * ctusX + ( cu.x >> h.log2_ctu ) );
     {
       if( ctuOfCu < curCtu ) { c->setError( "CUs are not in CTU raster order" ); return VVR_ERR_PARAMETER; }
-      while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) { ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); curUnit[k] = -1; unitsInCtu[k] = 0; } }
+      while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
     }
     const bool isCiip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
     // LMCS chroma residual scaling of an inter block: its factor reads reconstructed luma that the intra stage may still have to
@@ -511,35 +514,28 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
             it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 ) | ( (uint32_t) ( aboveCu ? 1 : 0 ) << 20 );
             cclmTop = aboveAvail ? actualTop : 0; cclmLeft = leftAvail ? actualLeft : 0; cclmBLeft = bLeft; isCclm = true;
           }
-          // ---- unit of this block
-          {
-            const int qsh = h.log2_ctu - 1 - cs;                                              // quadrant size in component samples
-            const int quad = ( ( ( y0 >> qsh ) & 1 ) << 1 ) | ( ( x0 >> qsh ) & 1 );
-            static const int maxUnitsPerCtu = getenv( "VVR_INTRA_UNITS_PER_CTU" ) ? atoi( getenv( "VVR_INTRA_UNITS_PER_CTU" ) ) : 1;
-            if( curUnit[comp] < 0 || ( units[curUnit[comp]].quad != quad && unitsInCtu[comp] < maxUnitsPerCtu ) )
-            {
-              UnitH u; u.comp = (uint32_t) comp; u.ctu = ctuOfCu; u.i0 = u.i1 = (uint32_t) intra[comp].size(); u.quad = quad;
-              units.push_back( u ); curUnit[comp] = (int32_t) units.size() - 1; unitsInCtu[comp]++;
-            }
-          }
-          UnitH& U = units[curUnit[comp]];
-          const uint32_t uId = (uint32_t) curUnit[comp];
+          // ---- the blocks this one reads from, its part of the CTU tile
+          const uint32_t myId = (uint32_t) intra[comp].size();
           intra[comp].push_back( it );
-          U.i1 = (uint32_t) intra[comp].size();
+          itemH[comp].emplace_back();
+          ItemH& IH = itemH[comp].back();
+          IH.ctu = ctuOfCu;
           {
             const int ctuX = cu.x >> h.log2_ctu, ctuY = cu.y >> h.log2_ctu;
             const int mrl = comp ? 0 : cu.multi_ref_idx;
-            auto addDep = [&]( int32_t d ) { if( d >= 0 && (uint32_t) d != uId && std::find( U.deps.begin(), U.deps.end(), (uint32_t) d ) == U.deps.end() ) U.deps.push_back( (uint32_t) d ); };
             auto touch = [&]( int k, int xc, int yc )   // component k, component coordinates of a sample that is read
             {
               const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
               if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
-              addDep( unitAt[k][(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )] );
+              const int32_t d = itemAt[k][(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )];
+              if( d < 0 ) return;
+              const uint32_t key = ( (uint32_t) k << 28 ) | (uint32_t) d;
+              if( ( k != comp || (uint32_t) d != myId ) && std::find( IH.prod.begin(), IH.prod.end(), key ) == IH.prod.end() ) IH.prod.push_back( key );
             };
             {
               // bounding box of everything the kernel's reference fill may read for this block (whole top / left lines incl. padding sources)
               const int S = ( 1 << h.log2_ctu ) >> cs, ox = ctuX * S, oy = ctuY * S;
-              BBox& bb = U.bb;
+              BBox& bb = IH.bb;
               const int bx0 = rx0 - 1 - mrl, bx1 = rx0 + std::max( 2 * rw, 1 ) + 1, by0 = ry0 - 1 - mrl, by1 = ry0 + 2 * rh + 1;
               bb.y0 = std::min( bb.y0, std::max( 0, by0 - ( oy - 3 ) ) );
               bb.y1 = std::max( bb.y1, std::min( S + 3, by1 - ( oy - 3 ) ) );
@@ -549,7 +545,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
             if( it.nTL ) touch( comp, rx0 - 1 - mrl, ry0 - 1 - mrl );
             for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, rx0 + k, ry0 - 1 - mrl );
             for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, rx0 - 1 - mrl, ry0 + k );
-            if( isCiip ) for( int yy = 0; yy < hh; yy += unit ) for( int xx = 0; xx < w; xx += unit ) touch( comp, x0 + xx, y0 + yy );   // (never produced by the intra stage: no-op, kept for symmetry)
+            if( ispL && ( x0 != rx0 || y0 != ry0 ) ) touch( 0, cu.isp_mode == 2 ? x0 - 1 : x0, cu.isp_mode == 2 ? y0 : y0 - 1 );   // ISP: the previous partition
             if( csItem )
             {
               // luma the chroma scaling factor is averaged over (the unit must wait for the luma units that reconstruct it)
@@ -568,7 +564,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
             }
             // the cells this block reconstructs
             for( int yy = 0; yy < ( hh << cs ); yy += 4 ) for( int xx = 0; xx < ( w << cs ); xx += 4 )
-              if( ( x0 << cs ) + xx < h.width && ( y0 << cs ) + yy < h.height ) unitAt[comp][(size_t) ( ( ( y0 << cs ) + yy ) >> 2 ) * w4 + ( ( ( x0 << cs ) + xx ) >> 2 )] = (int32_t) uId;
+              if( ( x0 << cs ) + xx < h.width && ( y0 << cs ) + yy < h.height ) itemAt[comp][(size_t) ( ( ( y0 << cs ) + yy ) >> 2 ) * w4 + ( ( ( x0 << cs ) + xx ) >> 2 )] = (int32_t) myId;
           }
           bytes[K_INTRA] += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
         }
@@ -621,14 +617,102 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       }
     }
   }
-  // residual-add items of inter blocks (LMCS chroma scaling) to the front of their unit: the kernel does them first, in parallel
-  for( auto& u : units )
+  // ---- form the units: blocks of one (component, CTU) that read from each other belong together (union-find); the residual-add items of
+  // inter blocks (LMCS chroma scaling) of a (component, CTU) form a unit of their own that the kernel processes in parallel
+  for( int k = 0; k < ncomp; k++ )
   {
-    auto b = intra[u.comp].begin() + u.i0, e = intra[u.comp].begin() + u.i1;
-    u.iA = u.i0 + (uint32_t) ( std::stable_partition( b, e, []( const IntraItem& it ) { return it.mode == IT_MODE_RESI_ADD; } ) - b );
-    u.hasCs = u.comp && std::any_of( b, e, []( const IntraItem& it ) { return ( it.flags & IT_F_CSCALE ) != 0; } );
+    const size_t n = intra[k].size();
+    if( !n ) continue;
+    std::vector<uint32_t> parent( n );
+    for( size_t i = 0; i < n; i++ ) parent[i] = (uint32_t) i;
+    auto find = [&]( uint32_t a ) { while( parent[a] != a ) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+    auto unite = [&]( uint32_t a, uint32_t b ) { a = find( a ); b = find( b ); if( a != b ) parent[std::max( a, b )] = std::min( a, b ); };     // root = first block
+    int64_t bulk = -1; uint32_t bulkCtu = 0;
+    for( size_t i = 0; i < n; i++ )
+    {
+      const bool ra = intra[k][i].mode == IT_MODE_RESI_ADD && k;
+      if( ra ) { if( bulk >= 0 && bulkCtu == itemH[k][i].ctu ) unite( (uint32_t) bulk, (uint32_t) i ); else { bulk = (int64_t) i; bulkCtu = itemH[k][i].ctu; } continue; }
+      for( uint32_t key : itemH[k][i].prod )
+      {
+        const uint32_t pk = key >> 28, pi = key & 0x0fffffff;
+        if( (int) pk == k && itemH[k][pi].ctu == itemH[k][i].ctu && !( intra[k][pi].mode == IT_MODE_RESI_ADD && k ) ) unite( (uint32_t) i, pi );
+      }
+    }
+    // units in the order of their first block; blocks of a unit contiguous and in coding order
+    std::vector<int32_t> unitOfRoot( n, -1 );
+    std::vector<std::vector<uint32_t>> members;
+    std::vector<uint32_t> firstUnit( 1, (uint32_t) units.size() );
+    for( size_t i = 0; i < n; i++ )
+    {
+      const uint32_t r = find( (uint32_t) i );
+      if( unitOfRoot[r] < 0 ) { unitOfRoot[r] = (int32_t) members.size(); members.emplace_back(); }
+      members[unitOfRoot[r]].push_back( (uint32_t) i );
+    }
+    std::vector<IntraItem> sorted; sorted.reserve( n );
+    std::vector<ItemH> sortedH; sortedH.reserve( n );
+    std::vector<uint32_t> newIdx( n );
+    for( auto& m : members )
+    {
+      UnitH u; u.comp = (uint32_t) k; u.ctu = itemH[k][m[0]].ctu; u.i0 = (uint32_t) sorted.size();
+      for( uint32_t i : m )
+      {
+        newIdx[i] = (uint32_t) sorted.size();
+        sorted.push_back( intra[k][i] ); sortedH.push_back( std::move( itemH[k][i] ) );
+        const BBox& b = sortedH.back().bb;
+        u.bb.y0 = std::min( u.bb.y0, b.y0 ); u.bb.y1 = std::max( u.bb.y1, b.y1 ); u.bb.c0 = std::min( u.bb.c0, b.c0 ); u.bb.c1 = std::max( u.bb.c1, b.c1 );
+        if( k && ( intra[k][i].flags & IT_F_CSCALE ) ) u.hasCs = true;
+      }
+      u.i1 = (uint32_t) sorted.size();
+      u.iA = ( k && sorted[u.i0].mode == IT_MODE_RESI_ADD ) ? u.i1 : u.i0;
+      units.push_back( u );
+    }
+    intra[k].swap( sorted ); itemH[k].swap( sortedH );
+    // item index -> unit, kept for the dependency pass (old index space -> new)
+    for( auto& ih : itemH[k] ) for( uint32_t& key : ih.prod ) if( (int) ( key >> 28 ) == k ) key = ( (uint32_t) k << 28 ) | newIdx[key & 0x0fffffff];
+    for( int k2 = k + 1; k2 < ncomp; k2++ ) for( auto& ih : itemH[k2] ) for( uint32_t& key : ih.prod ) if( (int) ( key >> 28 ) == k ) key = ( (uint32_t) k << 28 ) | newIdx[key & 0x0fffffff];
+    // (chroma never is a producer for luma, and components are processed in ascending order, so every reference to component k is fixed here)
+    // the per-CTU offsets follow the new order (units, hence blocks, stay grouped by CTU)
+    {
+      std::vector<uint32_t> cnt( (size_t) numCtu + 1, 0 );
+      for( auto& ih : itemH[k] ) cnt[ih.ctu + 1]++;
+      for( int a = 0; a < numCtu; a++ ) cnt[a + 1] += cnt[a];
+      for( int a = 0; a <= numCtu; a++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + a] = cnt[a];
+    }
   }
-  while( curCtu < (uint32_t) numCtu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
+  // dependencies between units
+  {
+    std::vector<uint32_t> unitOfItem[3];
+    for( int k = 0; k < ncomp; k++ ) unitOfItem[k].assign( intra[k].size(), 0 );
+    for( size_t u = 0; u < units.size(); u++ ) for( uint32_t i = units[u].i0; i < units[u].i1; i++ ) unitOfItem[units[u].comp][i] = (uint32_t) u;
+    for( size_t u = 0; u < units.size(); u++ )
+    {
+      UnitH& U = units[u];
+      for( uint32_t i = U.i0; i < U.i1; i++ ) for( uint32_t key : itemH[U.comp][i].prod )
+      {
+        const uint32_t d = unitOfItem[key >> 28][key & 0x0fffffff];
+        if( d != u && std::find( U.deps.begin(), U.deps.end(), d ) == U.deps.end() ) U.deps.push_back( d );
+      }
+    }
+    // a unit lists at most VVR_INTRA_MAX_DEPS producers: longer lists are folded through empty join units
+    for( size_t u = 0; u < units.size(); u++ )
+      while( units[u].deps.size() > VVR_INTRA_MAX_DEPS )
+      {
+        UnitH j; j.comp = units[u].comp; j.ctu = units[u].ctu; j.i0 = j.i1 = j.iA = units[u].i0; j.bb.y0 = j.bb.y1 = 0; j.bb.c0 = j.bb.c1 = 1;
+        j.deps.assign( units[u].deps.end() - VVR_INTRA_MAX_DEPS, units[u].deps.end() );
+        units[u].deps.resize( units[u].deps.size() - VVR_INTRA_MAX_DEPS );
+        units[u].deps.push_back( (uint32_t) units.size() );
+        units.push_back( j );
+      }
+    // rank = length of the longest dependency chain below a unit (the unit graph is acyclic: luma never reads chroma, residual-add
+    // units only read luma, other CTUs' units only earlier CTUs'); computed by relaxation in creation order until stable
+    bool changed = true;
+    for( int pass = 0; changed && pass < 64; pass++ )
+    {
+      changed = false;
+      for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
+    }
+  }
+
   // one item array for the three components; ctuStart holds offsets into it; active (component, CTU) pairs in raster order
   std::vector<IntraItem> intraAll;
   for( int k = 0; k < 3; k++ )
@@ -651,7 +735,10 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       std::vector<uint32_t> dep;
       for( size_t t = 0; t < units.size(); t++ ) if( !units[t].deps.empty() ) dep.push_back( (uint32_t) t );
       std::stable_sort( dep.begin(), dep.end(), [&]( uint32_t a, uint32_t b )
-      { return (int) ( units[a].ctu % ctusX ) + 2 * (int) ( units[a].ctu / ctusX ) < (int) ( units[b].ctu % ctusX ) + 2 * (int) ( units[b].ctu / ctusX ); } );
+      {
+        const int ka = (int) ( units[a].ctu % ctusX ) + 2 * (int) ( units[a].ctu / ctusX ), kb = (int) ( units[b].ctu % ctusX ) + 2 * (int) ( units[b].ctu / ctusX );
+        return ka != kb ? ka < kb : units[a].rank < units[b].rank;
+      } );
       perm.insert( perm.end(), dep.begin(), dep.end() );
     }
     for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
