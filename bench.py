@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--gop", type=int, default=16)
     ap.add_argument("--streams", type=int, default=8, help="pictures in flight per GPU")
     ap.add_argument("--slots", type=int, default=24, help="DPB slots used round-robin (0: smallest DPB, slots reused at once)")
+    ap.add_argument("--intra-period", type=int, default=64, help="an IRAP picture every N pictures (multiple of --gop; 0: only POC 0)")
+    ap.add_argument("--irap-lookahead", type=int, default=8, help="IRAP pictures are submitted N pictures ahead of their decoding-order position (they depend on nothing)")
+    ap.add_argument("--cold", action="store_true", help="time the first K pictures of the stream (from the IRAP at POC 0, nothing to overlap it with) instead of K pictures of the running stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=2, help="number of pictures re-checked against the CPU oracle after the run")
     a = ap.parse_args()
@@ -110,23 +113,28 @@ def main():
     tools = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST |
              abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE)
     K, Wm = a.steps, a.warmup
-    nframes = ((max(K, Wm) - 1 + a.gop - 1) // a.gop) * a.gop + 1
-    plans, nslots = stream.ra_plan(nframes, gop=a.gop, seed_poc0_is_external=False, pool=a.slots)   # POC 0 is an I picture
+    # the stream: W warm-up pictures, then the K timed ones; --cold: the K timed pictures are the first K again (start of a stream)
+    total = max(K, Wm) if a.cold else Wm + K
+    nframes = ((total - 1 + a.gop - 1) // a.gop) * a.gop + 1
+    plans, nslots = stream.ra_plan(nframes, gop=a.gop, seed_poc0_is_external=False, pool=a.slots, intra_period=a.intra_period,
+                                   irap_lookahead=0 if a.cold else a.irap_lookahead)   # POC 0 is an I picture
     nslots = max(nslots, a.slots)
     from vvdec_amd import parallel
     seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank)
-    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **MIX) for pl in plans[:max(K, Wm)]]
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **MIX) for pl in plans[:total]]
     prepared = [rec.prepare(d) for d in descs]        # everything resident in HBM from here on
+    first = 0 if a.cold else Wm                       # first timed picture (submission order)
+    n_irap = sum(1 for pl in plans[first:first + K] if pl.slice_type == abi.SLICE_I)
 
-    def one_pass(n):
+    def one_pass(i0, n):
         rec.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(n):
+        for i in range(i0, i0 + n):
             rec.submit_prepared(prepared[i])
         rec.sync()
         torch.cuda.synchronize()
@@ -135,8 +143,8 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    one_pass(Wm)                                       # warm-up (untimed)
-    dt = one_pass(K)                                   # timed: exactly K steps
+    one_pass(0, Wm)                                    # warm-up (untimed): the first W pictures of the stream
+    dt = one_pass(first, K)                            # timed: exactly K steps
     if world > 1:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -150,17 +158,25 @@ def main():
             import refdrv
             cpu = {}
             rec2 = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, device=local_rank)
-            for pl, d in list(zip(plans, descs))[:a.verify]:
+            tail = {pl.slot: pl for pl in plans[first + K - 8:first + K]}           # the last timed pictures still sit in their slots
+            timed_out = {slot: rec.read_picture(slot) for slot in tail}
+            for i, (pl, d) in enumerate(zip(plans[:first + K], descs)):
                 rec2.wait(rec2.decompress_picture(d))
-                got = rec2.read_picture(pl.slot)
-                want = refdrv.oracle_reconstruct(d, cpu)
-                assert all(np.array_equal(g, w) for g, w in zip(got, want)), "bench: POC %d differs from the oracle" % pl.poc
-                cpu[pl.slot] = want
-                verified += 1
+                if i < a.verify:                                                    # against the CPU oracle
+                    got = rec2.read_picture(pl.slot)
+                    want = refdrv.oracle_reconstruct(d, cpu)
+                    assert all(np.array_equal(g, w) for g, w in zip(got, want)), "bench: POC %d differs from the oracle" % pl.poc
+                    cpu[pl.slot] = want
+                    verified += 1
+            for slot, pl in tail.items():                                           # pipelined timed run == one picture at a time
+                got = rec2.read_picture(slot)
+                assert all(np.array_equal(g, w) for g, w in zip(got, timed_out[slot])), "bench: POC %d differs between the timed run and a serial run" % pl.poc
             rec2.close()
         # ---- roofline of the dominant kernel: second identical pass with HIP-event timing on the launch streams
         rec.enable_stats(True)
-        one_pass(K)
+        if not a.cold:
+            one_pass(0, Wm)
+        one_pass(first, K)
         st = rec.stats()
         rec.enable_stats(False)
         st.sort(key=lambda s: -s["total_ms"])
@@ -176,12 +192,14 @@ def main():
                "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
                "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int16", "data": "synthetic",
-               "config": {"workload": "%dx%d 10-bit 4:2:0 random-access QP32 (hierarchical-B GOP %d), CTU 128, pre-parsed records resident in HBM" % (W, H, a.gop),
+               "config": {"workload": "%dx%d 10-bit 4:2:0 random-access QP32 (hierarchical-B GOP %d, IRAP every %d pictures), CTU 128, pre-parsed records resident in HBM; %s"
+                                      % (W, H, a.gop, a.intra_period, "the first K pictures of the stream (cold start at the IRAP)" if a.cold else
+                                         "K pictures of the running stream after W warm-up pictures (%d IRAP in the timed pictures, submitted %d pictures ahead of its decoding-order position)" % (n_irap, a.irap_lookahead)),
                           "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM + ISP, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
                           "mix": MIX,
                           "not_in_mix": "SBT, explicit weighted prediction, scaling lists (implemented and tested, not part of the configuration of SURVEY.md 8(d)); IBC, dual tree and 4xN intra CUs are rejected with VVR_ERR_UNSUPPORTED",
                           "pictures_in_flight": a.streams, "sharding": "closed-GOP segment per GPU, no data-path collective",
-                          "verified_pictures_vs_oracle": verified},
+                          "verified_pictures_vs_oracle": verified, "timed_run_equals_serial_run": bool(a.verify)},
                "roofline": roof}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, seed, tools, a.gop)

@@ -765,6 +765,13 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       for( uint32_t k = 0; k < d.ndeps; k++ ) d.deps[k] = inv[u.deps[k]];
     }
   }
+  if( getenv( "VVR_INTRA_STATS" ) )
+  {
+    size_t nIndep = 0, nBulk = 0, nItems = 0, nResiAdd = 0; int maxRank = 0; size_t perComp[3] = { 0, 0, 0 }, big = 0;
+    for( auto& u : units ) { nIndep += u.deps.empty(); nBulk += u.iA == u.i1 && u.i1 > u.i0; maxRank = std::max( maxRank, u.rank ); perComp[u.comp]++; nItems += u.i1 - u.i0; if( u.iA == u.i1 ) nResiAdd += u.i1 - u.i0; big += ( u.i1 - u.i0 ) > 8; }
+    fprintf( stderr, "[vvr] POC %d: %zu intra units (Y %zu Cb %zu Cr %zu), %zu independent, %zu residual-add units, %zu blocks (%zu residual-add), %zu units > 8 blocks, longest chain %d\n",
+             h.poc, units.size(), perComp[0], perComp[1], perComp[2], nIndep, nBulk, nItems, nResiAdd, big, maxRank );
+  }
   const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
   bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
   bytes[K_SAO] = samples * 4; bytes[K_ALF] = samples * 4; bytes[K_COPY] = samples * 4;

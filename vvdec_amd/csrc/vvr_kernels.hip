@@ -1992,6 +1992,68 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     if( nd ) __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );      // nothing produced by another workgroup is read otherwise
   }
   __syncthreads();
+  // ---- a unit of residual-add blocks only (inter blocks with LMCS chroma scaling): no neighbourhood is read, so the blocks go
+  // straight from HBM to HBM, one block per wavefront, without staging the CTU
+  if( un->iA == i1 && i1 > i0 )
+  {
+    const int csNv1 = pic.hdr.log2_ctu > pic.vpduLog2 ? 1 : 0;
+    if( ( ent >> 29 ) & 1 )
+    {
+      const int wv = tid >> 6;
+      const int lx = ( cxI << pic.hdr.log2_ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.hdr.log2_ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
+      if( lx < (int) pic.hdr.width && ly < (int) pic.hdr.height && ( wv == 0 || csNv1 ) )
+      {
+        const int f = lmcs_cscale_factor_wave( pic, reco, lx, ly, tid & 63 );
+        if( ( tid & 63 ) == 0 ) sh.csFac[wv] = f;
+      }
+    }
+    __syncthreads();
+    for( uint32_t q = i0 + ( tid >> 6 ); q < i1; q += 4 )
+    {
+      IntraItem it;
+      {
+        const uint32_t* ip = reinterpret_cast<const uint32_t*>( &items[q] );
+        uint32_t* op = reinterpret_cast<uint32_t*>( &it );
+        for( int e = 0; e < 4; e++ ) op[e] = __builtin_amdgcn_readfirstlane( ip[e] );
+      }
+      const int x0 = it.x, y0 = it.y, lw = it.lw, wh = 1 << ( it.lw + it.lh );
+      const bool cs = ( it.flags & IT_F_CSCALE ) != 0;
+      const int f = cs ? sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )] : 0;
+      if( lw >= 2 )
+      {
+        // four samples of a row per lane (8-byte accesses; x0 and the row strides are multiples of 4 samples)
+        for( int i = ( tid & 63 ); i < ( wh >> 2 ); i += 64 )
+        {
+          const int x = x0 + ( ( i << 2 ) & ( ( 1 << lw ) - 1 ) ), y = y0 + ( ( i << 2 ) >> lw );
+          const uint2 rv = *reinterpret_cast<const uint2*>( &rs[(size_t) y * rstride + x] );
+          uint2* pp = reinterpret_cast<uint2*>( &plane[(size_t) y * pstride + x] );
+          const uint2 pv = *pp;
+          int r[4] = { (int16_t) ( rv.x & 0xffff ), (int16_t) ( rv.x >> 16 ), (int16_t) ( rv.y & 0xffff ), (int16_t) ( rv.y >> 16 ) };
+          const int pr[4] = { (int) ( pv.x & 0xffff ), (int) ( pv.x >> 16 ), (int) ( pv.y & 0xffff ), (int) ( pv.y >> 16 ) };
+          int o[4];
+          for( int e = 0; e < 4; e++ ) o[e] = clip_pel( pr[e] + ( cs ? lmcs_scale_resi( r[e], f, bd ) : r[e] ), bd );
+          *pp = make_uint2( (uint32_t) o[0] | ( (uint32_t) o[1] << 16 ), (uint32_t) o[2] | ( (uint32_t) o[3] << 16 ) );
+        }
+      }
+      else
+        for( int i = ( tid & 63 ); i < wh; i += 64 )
+        {
+          const int x = x0 + ( i & ( ( 1 << lw ) - 1 ) ), y = y0 + ( i >> lw );
+          const int r = (int16_t) rs[(size_t) y * rstride + x];
+          plane[(size_t) y * pstride + x] = (pel_t) clip_pel( plane[(size_t) y * pstride + x] + ( cs ? lmcs_scale_resi( r, f, bd ) : r ), bd );
+        }
+    }
+    if( !publish ) return;
+    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+    __syncthreads();
+    if( tid == 0 )
+    {
+      __builtin_amdgcn_fence( __ATOMIC_RELEASE, "agent" );
+      asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+      __hip_atomic_store( &sync[1 + ticket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    }
+    return;
+  }
   // ---- stage the needed part of the CTU and its reference border in LDS
   {
     // 16-byte chunks (8 samples); plane rows are 128-byte aligned and padded to a multiple of 64 samples, so a chunk that
@@ -2077,7 +2139,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         for( int q = 0; q < 4; q++ ) op[q] = __builtin_amdgcn_readfirstlane( ip[q] );
       }
       const int16_t* __restrict__ rcur = sh.resi[k & 1];
-      if( k + 1 < nb ) intra_fetch_resi( sh.items[k + 1], rs, rstride, tid, rnext );     // in flight while this block is predicted
+      if( k + 1 < nb && !( dbg & 16 ) ) intra_fetch_resi( sh.items[k + 1], rs, rstride, tid, rnext );     // in flight while this block is predicted
       const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
       const int mrl = ( it.flags & IT_F_MIP ) ? 0 : ( it.flags >> 4 ) & 3;
       const int wIntra = it.flags >> 6;               // CIIP: weight of the planar intra part, 0 = ordinary intra block

@@ -31,7 +31,7 @@ def _hier(lo, hi, layer, out):
     _hier(mid, hi, layer + 1, out)
 
 
-def ra_plan(num_frames, gop=16, seed_poc0_is_external=True, pool=0):
+def ra_plan(num_frames, gop=16, seed_poc0_is_external=True, pool=0, intra_period=0, irap_lookahead=0):
     """Decode-order list of PicPlan for POC 0..num_frames-1 (num_frames - 1 must be a multiple of gop).
 
     POC 0 is the IRAP picture; with seed_poc0_is_external it is not part of the plan (the caller uploads it into slot 0).
@@ -41,18 +41,35 @@ def ra_plan(num_frames, gop=16, seed_poc0_is_external=True, pool=0):
     pool = 0: a freed slot is reused at once (smallest DPB, what a memory-constrained host decoder does).  pool = N > 0: slots are
     taken round-robin from N slots, so that independent pictures of one temporal layer do not serialise on a write-after-read /
     write-after-write hazard of a shared slot when several pictures are in flight (HBM is not the scarce resource here).
+
+    intra_period > 0: every key picture whose POC is a multiple of it is an IRAP picture (I slice, no references).
+    irap_lookahead = N: IRAP pictures other than the first are placed N positions earlier in the SUBMISSION order (see below).
     """
     assert (num_frames - 1) % gop == 0
+    assert intra_period % gop == 0
     plans = []
     if not seed_poc0_is_external:
         plans.append(PicPlan(0, 0, 2))
+    last_irap = 0
     for k in range(gop, num_frames, gop):
-        prev_keys = [k - gop] + ([k - 2 * gop] if k - 2 * gop >= 0 else [])
-        plans.append(PicPlan(k, 0, 0, l0=list(prev_keys), l1=list(prev_keys)))
+        if intra_period and k % intra_period == 0:
+            # IRAP (CRA-like: the B pictures before it in output order still reference the previous key picture)
+            plans.append(PicPlan(k, 0, 2))
+            last_irap = k
+        else:
+            prev_keys = [k - gop] + ([k - 2 * gop] if k - 2 * gop >= last_irap else [])
+            plans.append(PicPlan(k, 0, 0, l0=list(prev_keys), l1=list(prev_keys)))
         inner = []
         _hier(k - gop, k, 1, inner)
         for (poc, layer, lo, hi) in inner:
             plans.append(PicPlan(poc, layer, 0, l0=[lo, hi], l1=[hi, lo]))
+    if irap_lookahead:
+        # an IRAP picture has no dependencies: a host that parses ahead hands it to the back-end before the pictures that precede
+        # it in decoding order, so that its long intra wavefront overlaps with them instead of stalling everything that follows
+        for i in range(1, len(plans)):
+            if plans[i].slice_type == 2:
+                j = max(1, i - irap_lookahead)
+                plans.insert(j, plans.pop(i))
     # a picture is a reference if any later picture lists it
     last_use = {}
     for i, p in enumerate(plans):
