@@ -712,6 +712,79 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
     }
   }
+  // ---- group the clusters of one (component, CTU) that sit at the same depth of the dependency graph into one unit: they cannot depend
+  // on each other, a workgroup start costs more than a few small blocks, and waiting for the union of their producers delays nothing
+  // that matters (all of them are less deep).  Residual-add units keep their own (HBM to HBM) workgroup.
+  if( !getenv( "VVR_INTRA_NO_GROUPING" ) && !units.empty() )
+  {
+    std::vector<int32_t> target( units.size(), -1 );            // original unit -> group
+    std::vector<std::vector<uint32_t>> parts;                    // groups: original units in creation order
+    {
+      std::vector<std::pair<uint64_t, uint32_t>> keyed;
+      for( size_t u = 0; u < units.size(); u++ )
+      {
+        const bool own = units[u].iA == units[u].i1;             // residual-add unit (or empty): not grouped
+        keyed.emplace_back( own ? ( ( (uint64_t) 1 << 63 ) | u ) : ( ( (uint64_t) units[u].comp << 56 ) | ( (uint64_t) units[u].ctu << 24 ) | (uint64_t) std::min( units[u].rank, 0xffffff ) ), (uint32_t) u );
+      }
+      std::stable_sort( keyed.begin(), keyed.end(), []( const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y ) { return x.first < y.first; } );
+      for( size_t i = 0; i < keyed.size(); )
+      {
+        size_t j = i; parts.emplace_back();
+        while( j < keyed.size() && keyed[j].first == keyed[i].first ) { parts.back().push_back( keyed[j].second ); target[keyed[j].second] = (int32_t) parts.size() - 1; j++; }
+        i = j;
+      }
+    }
+    // groups in the order of their first original unit (keeps the blocks grouped by CTU)
+    std::vector<uint32_t> orderM( parts.size() );
+    for( size_t m = 0; m < parts.size(); m++ ) orderM[m] = (uint32_t) m;
+    std::stable_sort( orderM.begin(), orderM.end(), [&]( uint32_t x, uint32_t y ) { return parts[x][0] < parts[y][0]; } );
+    std::vector<IntraItem> newItems[3];
+    std::vector<UnitH> merged;
+    std::vector<uint32_t> newIndexOfGroup( parts.size(), 0 );
+    for( uint32_t m : orderM )
+    {
+      const UnitH& f = units[parts[m][0]];
+      UnitH U; U.comp = f.comp; U.ctu = f.ctu; U.i0 = (uint32_t) newItems[f.comp].size();
+      for( uint32_t u : parts[m] )
+      {
+        const UnitH& o = units[u];
+        newItems[o.comp].insert( newItems[o.comp].end(), intra[o.comp].begin() + o.i0, intra[o.comp].begin() + o.i1 );
+        U.bb.y0 = std::min( U.bb.y0, o.bb.y0 ); U.bb.y1 = std::max( U.bb.y1, o.bb.y1 ); U.bb.c0 = std::min( U.bb.c0, o.bb.c0 ); U.bb.c1 = std::max( U.bb.c1, o.bb.c1 );
+        U.hasCs = U.hasCs || o.hasCs;
+      }
+      U.i1 = (uint32_t) newItems[f.comp].size();
+      U.iA = f.iA == f.i1 ? U.i1 : U.i0;
+      newIndexOfGroup[m] = (uint32_t) merged.size();
+      merged.push_back( U );
+    }
+    for( size_t m = 0; m < parts.size(); m++ )
+    {
+      UnitH& U = merged[newIndexOfGroup[m]];
+      for( uint32_t u : parts[m] ) for( uint32_t d : units[u].deps )
+      {
+        const uint32_t nd = newIndexOfGroup[target[d]];
+        if( nd != newIndexOfGroup[m] && std::find( U.deps.begin(), U.deps.end(), nd ) == U.deps.end() ) U.deps.push_back( nd );
+      }
+    }
+    for( int k = 0; k < ncomp; k++ ) intra[k].swap( newItems[k] );
+    units.swap( merged );
+    for( size_t u = 0; u < units.size(); u++ )
+      while( units[u].deps.size() > VVR_INTRA_MAX_DEPS )
+      {
+        UnitH j; j.comp = units[u].comp; j.ctu = units[u].ctu; j.i0 = j.i1 = j.iA = units[u].i0; j.bb.y0 = j.bb.y1 = 0; j.bb.c0 = j.bb.c1 = 1;
+        j.deps.assign( units[u].deps.end() - VVR_INTRA_MAX_DEPS, units[u].deps.end() );
+        units[u].deps.resize( units[u].deps.size() - VVR_INTRA_MAX_DEPS );
+        units[u].deps.push_back( (uint32_t) units.size() );
+        units.push_back( j );
+      }
+    for( auto& U : units ) U.rank = 0;
+    bool changed = true;
+    for( int pass = 0; changed && pass < 256; pass++ )
+    {
+      changed = false;
+      for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
+    }
+  }
 
   // one item array for the three components; ctuStart holds offsets into it; active (component, CTU) pairs in raster order
   std::vector<IntraItem> intraAll;

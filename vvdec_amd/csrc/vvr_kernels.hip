@@ -1981,15 +1981,19 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   const uint32_t i0 = un->i0, i1 = un->i1;
 #define TILE( x, y ) sh.tile[( ( y ) - oy + IT_PAD ) * IT_TS + ( ( x ) - ox + IT_PADX )]
   // ---- wait for the units that produce intra samples this one reads (same component: reference lines; luma: CCLM)
-  if( tid == 0 )
   {
+    // one lane per producer (at most VVR_INTRA_MAX_DEPS of them): the polls overlap instead of queueing behind each other
     const uint32_t nd = ( dbg & 1 ) ? 0 : un->ndeps;
-    for( uint32_t k = 0; k < nd; k++ )
+    if( (uint32_t) tid < nd )
     {
-      int* flag = &sync[1 + un->deps[k]];
+      int* flag = &sync[1 + un->deps[tid]];
       while( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == 0 ) __builtin_amdgcn_s_sleep( 8 );
     }
-    if( nd ) __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );      // nothing produced by another workgroup is read otherwise
+    if( nd )
+    {
+      __syncthreads();
+      __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );      // nothing produced by another workgroup is read otherwise
+    }
   }
   __syncthreads();
   // ---- a unit of residual-add blocks only (inter blocks with LMCS chroma scaling): no neighbourhood is read, so the blocks go
