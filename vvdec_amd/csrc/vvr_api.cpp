@@ -727,10 +727,18 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         keyed.emplace_back( own ? ( ( (uint64_t) 1 << 63 ) | u ) : ( ( (uint64_t) units[u].comp << 56 ) | ( (uint64_t) units[u].ctu << 24 ) | (uint64_t) std::min( units[u].rank, 0xffffff ) ), (uint32_t) u );
       }
       std::stable_sort( keyed.begin(), keyed.end(), []( const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y ) { return x.first < y.first; } );
+      static const uint32_t groupMax = getenv( "VVR_INTRA_GROUP_MAX" ) ? (uint32_t) atoi( getenv( "VVR_INTRA_GROUP_MAX" ) ) : 12;    // blocks per grouped unit
       for( size_t i = 0; i < keyed.size(); )
       {
         size_t j = i; parts.emplace_back();
-        while( j < keyed.size() && keyed[j].first == keyed[i].first ) { parts.back().push_back( keyed[j].second ); target[keyed[j].second] = (int32_t) parts.size() - 1; j++; }
+        uint32_t blocks = 0;
+        while( j < keyed.size() && keyed[j].first == keyed[i].first )
+        {
+          const uint32_t nb = units[keyed[j].second].i1 - units[keyed[j].second].i0;
+          if( blocks && blocks + nb > groupMax ) break;                   // a serial workgroup should stay short: start another one
+          blocks += nb;
+          parts.back().push_back( keyed[j].second ); target[keyed[j].second] = (int32_t) parts.size() - 1; j++;
+        }
         i = j;
       }
     }
@@ -840,7 +848,9 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   }
   if( getenv( "VVR_INTRA_STATS" ) )
   {
-    size_t nIndep = 0, nBulk = 0, nItems = 0, nResiAdd = 0; int maxRank = 0; size_t perComp[3] = { 0, 0, 0 }, big = 0;
+    size_t nIndep = 0, nBulk = 0, nItems = 0, nResiAdd = 0; int maxRank = 0; size_t perComp[3] = { 0, 0, 0 }, big = 0, maxBlocks = 0;
+    for( auto& u : units ) if( u.iA != u.i1 ) maxBlocks = std::max<size_t>( maxBlocks, u.i1 - u.i0 );
+    fprintf( stderr, "[vvr] largest serial unit: %zu blocks\n", maxBlocks );
     for( auto& u : units ) { nIndep += u.deps.empty(); nBulk += u.iA == u.i1 && u.i1 > u.i0; maxRank = std::max( maxRank, u.rank ); perComp[u.comp]++; nItems += u.i1 - u.i0; if( u.iA == u.i1 ) nResiAdd += u.i1 - u.i0; big += ( u.i1 - u.i0 ) > 8; }
     fprintf( stderr, "[vvr] POC %d: %zu intra units (Y %zu Cb %zu Cr %zu), %zu independent, %zu residual-add units, %zu blocks (%zu residual-add), %zu units > 8 blocks, longest chain %d\n",
              h.poc, units.size(), perComp[0], perComp[1], perComp[2], nIndep, nBulk, nItems, nResiAdd, big, maxRank );

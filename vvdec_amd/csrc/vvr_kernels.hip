@@ -1012,8 +1012,12 @@ __device__ __forceinline__ int wide_angle_mode( int w, int h, int mode )   // PU
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lmcs_cscale_factor_wave( const PicDev& pic, const DevPlanes& reco, int lumaX, int lumaY, int lane )
 {
-  // called by one whole wavefront; every lane returns the factor
+  // called by one whole wavefront; every lane returns the factor.  All table reads are issued up front, one entry per lane, so the
+  // function costs two memory round trips (VPDU record, then luma samples + tables) instead of one per pivot of the search
   const uint32_t d = pic.csVpdu[( lumaY >> pic.vpduLog2 ) * pic.vpdusX + ( lumaX >> pic.vpduLog2 )];
+  const int pivotL = pic.lmcs->pivot[min( lane + 1, 16 )];                 // pivot[idx + 1] for idx = lane
+  const int scaleL = pic.lmcs->chroma_scale[min( lane, 15 )];
+  const int minBin = pic.lmcs->min_bin, maxBin = pic.lmcs->max_bin;
   const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff;
   const bool hasLeft = ( d >> 26 ) & 1, hasAbove = ( d >> 27 ) & 1;
   const int n = 1 << pic.vpduLog2, nLog = pic.vpduLog2;
@@ -1032,9 +1036,10 @@ __device__ __forceinline__ int lmcs_cscale_factor_wave( const PicDev& pic, const
   if( hasLeft && hasAbove ) lumaValue = ( recLuma + ( 1 << nLog ) ) >> ( nLog + 1 );
   else if( hasLeft || hasAbove ) lumaValue = ( recLuma + ( 1 << ( nLog - 1 ) ) ) >> nLog;
   else lumaValue = 1 << ( pic.hdr.bit_depth - 1 );
-  int idx = pic.lmcs->min_bin;
-  for( ; idx <= pic.lmcs->max_bin; idx++ ) if( lumaValue < pic.lmcs->pivot[idx + 1] ) break;
-  return pic.lmcs->chroma_scale[min( idx, 15 )];
+  // first idx in [minBin, maxBin] with lumaValue < pivot[idx + 1], else maxBin + 1 (Reshape::getPWLIdxInv, :280); table entry min( idx, 15 )
+  const unsigned long long hit = __ballot( lane >= minBin && lane <= maxBin && lumaValue < pivotL );
+  const int idx = hit ? __builtin_ctzll( hit ) : maxBin + 1;
+  return __shfl( scaleL, min( idx, 15 ), 64 );
 }
 __device__ __forceinline__ int lmcs_scale_resi( int r, int scale, int bd )
 {
@@ -1950,11 +1955,34 @@ __device__ __forceinline__ void intra_stash_resi( const IntraItem& it, int16_t* 
   }
 }
 
+// Residual prefetch of the block loop, version without control flow around the load: ONE sample per lane (blocks of at most 256
+// samples, the common case), index clamped, issued whether or not the block has a residual.  (A switch over load counts makes the
+// compiler merge the destination registers of the variants right behind the loads, which needs s_waitcnt vmcnt(0) there and turns
+// the prefetch into a synchronous load: ~1 us per block, measured with the in-kernel timeline.)  Larger blocks are read when they
+// are stashed.
+__device__ __forceinline__ int intra_prefetch_resi( const IntraItem& it, const pel_t* __restrict__ rs, int rstride, int tid )
+{
+  const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
+  const int i = min( tid, wh - 1 );
+  return (int16_t) rs[(size_t) ( it.y + ( i >> lw ) ) * rstride + it.x + ( i & ( ( 1 << lw ) - 1 ) )];
+}
+__device__ __forceinline__ void intra_stash_resi1( const IntraItem& it, int16_t* __restrict__ dst, int tid, int pre, const pel_t* __restrict__ rs, int rstride )
+{
+  if( !( it.flags & IT_F_RESI ) ) return;
+  const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
+  if( wh <= 256 ) { if( tid < wh ) dst[tid] = (int16_t) pre; return; }
+#pragma unroll 4
+  for( int i = tid; i < wh; i += 256 ) dst[i] = (int16_t) rs[(size_t) ( it.y + ( i >> lw ) ) * rstride + it.x + ( i & ( ( 1 << lw ) - 1 ) )];
+}
+
 __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, DevPlanes resi, const IntraItem* __restrict__ items,
                                                   const IntraUnit* __restrict__ units, int numActive,
-                                                  int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */, int dbg )
+                                                  int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */, int dbg,
+                                                  unsigned long long* __restrict__ trace /* developer timeline (VVR_INTRA_TRACE) or nullptr */ )
 {
   __shared__ IntraShared sh;
+#define IT_TRACE( K ) if( trace && threadIdx.x == 0 ) trace[(size_t) 8 * tr_ticket + ( K )] = wall_clock64()
+  int tr_ticket = 0;
   const int tid = threadIdx.x;
   const int numCtu = pic.ctus_x * pic.ctus_y;
   if( tid == 0 ) { sh.ticket = atomicAdd( &sync[0], 1 ); sh.dcSum[0] = sh.dcSum[1] = 0; }
@@ -1964,6 +1992,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   __syncthreads();
   const int ticket = sh.ticket;
   if( ticket >= numActive ) return;
+  tr_ticket = ticket; IT_TRACE( 0 );
   const IntraUnit* __restrict__ un = &units[ticket];
   const uint32_t ent = un->ent;
   const int comp = ( ent >> 24 ) & 3, ctu = ent & 0xffffff;
@@ -1996,6 +2025,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     }
   }
   __syncthreads();
+  IT_TRACE( 1 );
   // ---- a unit of residual-add blocks only (inter blocks with LMCS chroma scaling): no neighbourhood is read, so the blocks go
   // straight from HBM to HBM, one block per wavefront, without staging the CTU
   if( un->iA == i1 && i1 > i0 )
@@ -2047,6 +2077,8 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           plane[(size_t) y * pstride + x] = (pel_t) clip_pel( plane[(size_t) y * pstride + x] + ( cs ? lmcs_scale_resi( r, f, bd ) : r ), bd );
         }
     }
+    IT_TRACE( 4 );
+    if( trace && threadIdx.x == 0 ) { trace[(size_t) 8 * tr_ticket + 6] = ( (unsigned long long) ( i1 - i0 ) << 32 ) | ent; trace[(size_t) 8 * tr_ticket + 7] = un->ndeps | 0x100; }
     if( !publish ) return;
     asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
     __syncthreads();
@@ -2056,6 +2088,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
       __hip_atomic_store( &sync[1 + ticket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     }
+    IT_TRACE( 5 );
     return;
   }
   // ---- stage the needed part of the CTU and its reference border in LDS
@@ -2072,7 +2105,46 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     const int nch = bc1 - bc0;
     const int nTop = nch * max( 0, min( by1, oy ) - by0 );                   // chunks in the rows above the CTU
     const int rowsIn = max( 0, by1 - max( by0, oy ) );
-    const int total = ( dbg & 2 ) ? 0 : borderOnly ? nTop + ( bc0 < 0 ? rowsIn : 0 ) : nch * ( by1 - by0 );
+    const bool perBlock = !borderOnly && !( dbg & 32 );
+    const int total = ( ( dbg & 2 ) || perBlock ) ? 0 : borderOnly ? nTop + ( bc0 < 0 ? rowsIn : 0 ) : nch * ( by1 - by0 );
+    if( perBlock && !( dbg & 2 ) )
+    {
+      // a unit that is not a whole intra CTU: only the reference lines its blocks read (one row above, one column left of every
+      // block, as far as they are available) instead of the bounding box; one block per wavefront, 16-byte chunks
+      for( uint32_t q = i0 + ( tid >> 6 ); q < i1; q += 4 )
+      {
+        IntraItem it;
+        {
+          const uint32_t* ip = reinterpret_cast<const uint32_t*>( &items[q] );
+          uint32_t* op = reinterpret_cast<uint32_t*>( &it );
+          for( int e = 0; e < 4; e++ ) op[e] = __builtin_amdgcn_readfirstlane( ip[e] );
+        }
+        const bool isp = !comp && ( it.flags & IT_F_ISP ) == IT_F_ISP;
+        if( isp && ( it.tu & 0xfff ) ) continue;                               // later ISP partitions: the CU's line was fetched with the first one
+        const int bw = isp ? 1 << ( ( it.tu >> 12 ) & 7 ) : 1 << it.lw, bh = isp ? 1 << ( ( it.tu >> 15 ) & 7 ) : 1 << it.lh;
+        const int mrl = ( isp || comp || ( it.flags & IT_F_MIP ) ) ? 0 : ( it.flags >> 4 ) & 3;
+        const int unit = 4 >> cs;
+        const int lx = (int) it.x - 1 - mrl, ty = (int) it.y - 1 - mrl;
+        // row above: from the corner column to the last available sample above / above-right
+        const int tx0 = max( 0, lx ) & ~7, tx1 = (int) it.x + max( (int) it.nA * unit, 1 );
+        const int nT = ty >= 0 ? ( tx1 - tx0 + 7 ) >> 3 : 0;
+        // column left: from the corner row to the last available sample left / below-left
+        const int ly0 = max( 0, ty ), ly1 = (int) it.y + (int) it.nL * unit;
+        const int nL = lx >= 0 ? max( 0, ly1 - ly0 ) : 0;
+        // CIIP: the inter prediction of the block itself
+        const int wIntra = isp ? 0 : it.flags >> 6;                             // (the two bits are zero for every other kind of block)
+        const int cch = ( ( (int) it.x & 7 ) + bw + 7 ) >> 3, nC = wIntra ? cch * bh : 0;
+        for( int i = ( tid & 63 ); i < nT + nL + nC; i += 64 )
+        {
+          int x, y;
+          if( i < nT ) { x = tx0 + 8 * i; y = ty; }
+          else if( i < nT + nL ) { x = lx & ~7; y = ly0 + ( i - nT ); }
+          else { const int j = i - nT - nL; y = (int) it.y + j / cch; x = ( (int) it.x & ~7 ) + 8 * ( j % cch ); }
+          const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
+          *reinterpret_cast<uint4*>( &sh.tile[( y - oy + IT_PAD ) * IT_TS + ( x - ox + IT_PADX )] ) = v;
+        }
+      }
+    }
     for( int base = 0; base < total; base += 256 * 4 )
     {
       // four 16-byte loads in flight per lane; the tail repeats the last chunk (same data to the same place) instead of branching
@@ -2086,7 +2158,9 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       *reinterpret_cast<uint4*>( &sh.tile[o2] ) = v2; *reinterpret_cast<uint4*>( &sh.tile[o3] ) = v3;
     }
   }
-  int rnext[IT_MAXR];
+  IT_TRACE( 2 );
+  unsigned long long trA = 0, trB = 0, trC = 0, trD = 0, trT = 0;      // developer timeline: time per phase of the block loop
+#define IT_PH( ACC ) if( trace ) { const unsigned long long now_ = wall_clock64(); ACC += now_ - trT; trT = now_; }
   // ---- LMCS chroma residual scaling (DecCu.cpp:383-388,500-505): one factor per VPDU of the CTU, one wavefront each (the unit
   // has waited for the luma units that reconstruct the samples the factors are averaged over)
   const int csNv1 = pic.hdr.log2_ctu > pic.vpduLog2 ? 1 : 0;        // VPDUs per CTU side - 1
@@ -2130,8 +2204,8 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     lds_barrier();                                  // previous batch fully consumed (and, first time, the tile is staged)
     if( tid < nb * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = reinterpret_cast<const uint32_t*>( items + b0 )[tid];
     lds_barrier();
-    intra_fetch_resi( sh.items[0], rs, rstride, tid, rnext );
-    intra_stash_resi( sh.items[0], sh.resi[0], tid, rnext );
+    int rpre = intra_prefetch_resi( sh.items[0], rs, rstride, tid );
+    intra_stash_resi1( sh.items[0], sh.resi[0], tid, rpre, rs, rstride );
     for( int k = 0; k < nb; k++ )
     {
       // the item is the same for every lane: move it to scalar registers so that all the mode / size dependent set-up below runs on
@@ -2142,8 +2216,9 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         uint32_t* op = reinterpret_cast<uint32_t*>( &it );
         for( int q = 0; q < 4; q++ ) op[q] = __builtin_amdgcn_readfirstlane( ip[q] );
       }
+      if( trace ) trT = wall_clock64();
       const int16_t* __restrict__ rcur = sh.resi[k & 1];
-      if( k + 1 < nb && !( dbg & 16 ) ) intra_fetch_resi( sh.items[k + 1], rs, rstride, tid, rnext );     // in flight while this block is predicted
+      if( !( dbg & 16 ) ) rpre = intra_prefetch_resi( sh.items[min( k + 1, nb - 1 )], rs, rstride, tid );     // in flight while this block is predicted
       const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
       const int mrl = ( it.flags & IT_F_MIP ) ? 0 : ( it.flags >> 4 ) & 3;
       const int wIntra = it.flags >> 6;               // CIIP: weight of the planar intra part, 0 = ordinary intra block
@@ -2263,6 +2338,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         if( tid == 255 ) sh.dcSum[( k + 1 ) & 1] = 0;
       }
       lds_barrier();
+      IT_PH( trA )
       // ---- MIP (PredictorMIP, MatrixIntraPrediction.cpp:68-330): boundary down-sampling, matrix-vector product, up-sampling
       if( !comp && ( it.flags & IT_F_MIP ) )
       {
@@ -2339,7 +2415,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
             const int x = i & ( w - 1 ), y = i >> lw;
             TILE( x0 + x, y0 + y ) = (pel_t) clip_pel( TILE( x0 + x, y0 + y ) + rcur[i], bd );
           }
-        if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
+        if( k + 1 < nb ) intra_stash_resi1( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rpre, rs, rstride );
         lds_barrier();
         continue;
       }
@@ -2426,7 +2502,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           TILE( x0 + x, y0 + y ) = (pel_t) v;
         }
 #undef LU
-        if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
+        if( k + 1 < nb ) intra_stash_resi1( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rpre, rs, rstride );
         lds_barrier();
         continue;
       }
@@ -2509,6 +2585,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       }
       const int pscale = ( lw - 2 + lh - 2 + 2 ) >> 2;
       const int wh = w * h;
+      IT_PH( trB )
       // ---- prediction + reconstruction, one sample per lane-iteration
 #pragma unroll 1
       for( int i = tid; i < ( ( dbg & 8 ) ? 0 : wh ); i += 256 )
@@ -2569,10 +2646,14 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         if( hasResi && ( !ispPair || ( ( ispResi >> ( x >> 1 ) ) & 1 ) ) ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
         TILE( x0 + x, y0 + y ) = (pel_t) v;
       }
-      if( k + 1 < nb ) intra_stash_resi( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rnext );
+      IT_PH( trC )
+      if( k + 1 < nb ) intra_stash_resi1( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rpre, rs, rstride );
       lds_barrier();
+      IT_PH( trD )
     }
   }
+  if( trace && threadIdx.x == 0 ) { trace[(size_t) 8 * tr_ticket + 5] = trA | ( trB << 32 ); trace[(size_t) 8 * tr_ticket + 7] |= ( trC << 16 ) | ( trD << 40 ); }
+  IT_TRACE( 3 );
   // ---- write the reconstructed intra samples back to HBM (deferred so that the block loop never waits for a store)
   if( borderOnly )
   {
@@ -2598,16 +2679,28 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       {
         const IntraItem it = sh.items[k];
         const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
-        for( int i = tid; i < wh; i += 256 )
+        if( lw >= 2 )
         {
-          const int x = it.x + ( i & ( ( 1 << lw ) - 1 ) ), y = it.y + ( i >> lw );
-          plane[(size_t) y * pstride + x] = TILE( x, y );
+          // four samples (8 bytes) per lane: block positions and widths are multiples of 4 samples
+          for( int i = tid; i < ( wh >> 2 ); i += 256 )
+          {
+            const int x = it.x + ( ( i << 2 ) & ( ( 1 << lw ) - 1 ) ), y = it.y + ( ( i << 2 ) >> lw );
+            *reinterpret_cast<uint2*>( &plane[(size_t) y * pstride + x] ) = *reinterpret_cast<const uint2*>( &TILE( x, y ) );
+          }
         }
+        else
+          for( int i = tid; i < wh; i += 256 )
+          {
+            const int x = it.x + ( i & ( ( 1 << lw ) - 1 ) ), y = it.y + ( i >> lw );
+            plane[(size_t) y * pstride + x] = TILE( x, y );
+          }
       }
     }
   }
 #undef TILE
   // ---- publish: all stores of the workgroup drained, one agent-scope release, then the flag
+  IT_TRACE( 4 );
+  if( trace && threadIdx.x == 0 ) { trace[(size_t) 8 * tr_ticket + 6] = ( (unsigned long long) ( i1 - i0 ) << 32 ) | ent; trace[(size_t) 8 * tr_ticket + 7] |= un->ndeps; }
   if( !publish ) return;
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
   __syncthreads();
@@ -2617,6 +2710,8 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
     __hip_atomic_store( &sync[1 + ticket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
   }
+#undef IT_TRACE
+#undef IT_PH
 }
 
 void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numActive, int* sync )
@@ -2624,5 +2719,18 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   if( !numActive ) return;
   hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + (size_t) numActive ), s );
   static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
-  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync, dbg );
+  static const bool tr = getenv( "VVR_INTRA_TRACE" ) != nullptr;
+  unsigned long long* trace = nullptr;
+  if( tr ) { hipMalloc( (void**) &trace, sizeof( unsigned long long ) * 8 * (size_t) numActive ); hipMemsetAsync( trace, 0, sizeof( unsigned long long ) * 8 * (size_t) numActive, s ); }
+  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync, dbg, trace );
+  if( tr )
+  {
+    // developer timeline: ticket, phase time stamps (100 MHz), block count / unit word, number of producers
+    std::vector<unsigned long long> h( 8 * (size_t) numActive );
+    hipStreamSynchronize( s );
+    hipMemcpy( h.data(), trace, h.size() * sizeof( unsigned long long ), hipMemcpyDeviceToHost );
+    hipFree( trace );
+    char name[128]; snprintf( name, sizeof( name ), "gpurun_out/intra_trace_poc%d.bin", pic.hdr.poc );
+    if( FILE* f = fopen( name, "wb" ) ) { fwrite( h.data(), sizeof( unsigned long long ), h.size(), f ); fclose( f ); }
+  }
 }
