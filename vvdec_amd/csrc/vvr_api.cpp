@@ -46,6 +46,7 @@ struct vvr_prepared {        // a picture description resident in HBM together w
   int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64 (TB_ADD: after MC)
   IntraItem* intraItems = nullptr; uint32_t* ctuStart = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
+  std::vector<std::pair<int, int>> intraLevels;     // non-empty: the intra stage runs as one launch per dependency level (first unit, count)
   double   bytes[K_NUM] = { 0 };
   bool     owned = false;
 };
@@ -805,9 +806,34 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   // device unit table: units that wait for nothing first (they can never block a resident workgroup slot), then the others in
   // coding order; a unit only ever waits for units created before it, so every dependency holds a lower ticket
   std::vector<IntraUnit> unitsDev;
+  std::vector<std::pair<int, int>> intraLevelsV;
   {
     const uint32_t itemBase[3] = { ctuStartV[0], ctuStartV[(size_t) 1 * ( numCtu + 1 )], ctuStartV[(size_t) 2 * ( numCtu + 1 )] };
     std::vector<uint32_t> perm, inv( units.size() );
+    // Long dependency chains (an intra picture: one CTU wavefront, ~60 levels): units that spin on their producers would hold most
+    // workgroup slots (and their LDS) of the device for milliseconds while other pictures are in flight.  Such a picture runs its
+    // intra stage as one launch per dependency level instead - units of one level never depend on each other, the launch boundary is
+    // the synchronisation, nothing waits inside a kernel.  Short chains (isolated intra blocks of B pictures) keep the single
+    // launch with flags, where a level barrier would cost more than the few waits.
+    int maxRank = 0;
+    for( auto& u : units ) maxRank = std::max( maxRank, u.rank );
+    static const int levelThr = getenv( "VVR_INTRA_LEVEL_THR" ) ? atoi( getenv( "VVR_INTRA_LEVEL_THR" ) ) : 1 << 30;     // measured: slower (9.2 vs 8.0 ms for a 4K I picture, 1457 vs 1508 frames/s), off by default
+    const bool byLevel = maxRank > levelThr;
+    std::vector<std::pair<int, int>> levels;
+    if( byLevel )
+    {
+      for( size_t t = 0; t < units.size(); t++ ) perm.push_back( (uint32_t) t );
+      std::stable_sort( perm.begin(), perm.end(), [&]( uint32_t a, uint32_t b ) { return units[a].rank < units[b].rank; } );
+      for( size_t t = 0; t < perm.size(); )
+      {
+        size_t e = t; while( e < perm.size() && units[perm[e]].rank == units[perm[t]].rank ) e++;
+        levels.emplace_back( (int) t, (int) ( e - t ) );
+        t = e;
+      }
+      for( auto& u : units ) u.deps.clear();                  // ordered by the launches
+    }
+    else
+    {
     for( size_t t = 0; t < units.size(); t++ ) if( units[t].deps.empty() ) perm.push_back( (uint32_t) t );
     {
       // dependent units in WAVEFRONT order (key = ctuX + 2 * ctuY, ties in coding order): every dependency (left, above-left, above,
@@ -822,6 +848,8 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       } );
       perm.insert( perm.end(), dep.begin(), dep.end() );
     }
+    }
+    intraLevelsV = levels;
     for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
     for( auto& u : units ) for( uint32_t d : u.deps ) units[d].waited = true;
     std::vector<uint8_t> unitCount( 3 * (size_t) numCtu, 0 );
@@ -935,6 +963,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   q->intraItems = (IntraItem*) ( base + parts[iIntra].off ); q->numIntra = (int) intraAll.size();
   q->ctuStart = (uint32_t*) ( base + parts[iCtuStart].off );
   q->units = (IntraUnit*) ( base + parts[iActive].off ); q->numActive = (int) unitsDev.size();
+  q->intraLevels = intraLevelsV;
   memcpy( q->bytes, bytes, sizeof( bytes ) );
   *out = q;
   return VVR_OK;
@@ -1008,7 +1037,11 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
   if( q->numTb[0] + q->numTb[1] + q->numTb[2] )
     timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); } );
   // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)
-  if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->units, q->numActive, c->syncBuf[lane] ); } );
+  if( q->numActive ) timed( K_INTRA, [&]
+  {
+    if( q->intraLevels.empty() ) launch_intra( s, q->pic, A, R, q->intraItems, q->units, q->numActive, c->syncBuf[lane] );
+    else launch_intra_levels( s, q->pic, A, R, q->intraItems, q->units, q->intraLevels.data(), (int) q->intraLevels.size(), c->syncBuf[lane] );
+  } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
   if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "../../include/vvr.h"
 
 typedef int16_t pel_t;
@@ -101,3 +102,5 @@ void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst );
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );
 void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numUnits, int* sync );
+void launch_intra_levels( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units,
+                          const std::pair<int, int>* levels, int numLevels, int* sync );      // one launch per dependency level (first unit, count)

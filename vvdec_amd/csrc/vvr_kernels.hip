@@ -1526,49 +1526,75 @@ void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )
 // =====================================================================================================================
 __global__ __launch_bounds__( 256 ) void k_sao( PicDev pic, DevPlanes src, DevPlanes dst )
 {
+  // eight consecutive samples of a row per thread (one 16-byte load / store; they share a CTU, hence the SAO parameters); a wavefront
+  // covers 512 samples of a row, a workgroup four rows
   const int c = blockIdx.z;
   const int cs = c ? 1 : 0;
   const int cw = src.w[c], chh = src.h[c];
-  const int x = blockIdx.x * 64 + ( threadIdx.x & 63 );    // one sample per thread, a wavefront covers 64 consecutive samples of a row
+  const int x0 = ( blockIdx.x * 64 + ( threadIdx.x & 63 ) ) * 8;
   const int y = blockIdx.y * 4 + ( threadIdx.x >> 6 );
-  if( x >= cw || y >= chh ) return;
+  if( x0 >= cw || y >= chh ) return;
   const int bd = pic.hdr.bit_depth, ctuC = ( 1 << pic.hdr.log2_ctu ) >> cs;
   const pel_t* __restrict__ S = src.p[c];
   const int st = src.stride[c];
-  const int v = S[(size_t) y * st + x];
-  int out = v;
+  const uint4 cv = *reinterpret_cast<const uint4*>( &S[(size_t) y * st + x0] );
+  int v[8] = { (int) ( cv.x & 0xffff ), (int) ( cv.x >> 16 ), (int) ( cv.y & 0xffff ), (int) ( cv.y >> 16 ), (int) ( cv.z & 0xffff ), (int) ( cv.z >> 16 ), (int) ( cv.w & 0xffff ), (int) ( cv.w >> 16 ) };
+  int out[8];
+#pragma unroll
+  for( int i = 0; i < 8; i++ ) out[i] = v[i];
   const bool enabled = pic.sao && ( pic.hdr.tool_flags & ( c ? VVR_TOOL_SAO_CHROMA : VVR_TOOL_SAO_LUMA ) );
   if( enabled )
   {
-    const vvr_sao_ctu& s = pic.sao[( y / ctuC ) * pic.ctus_x + ( x / ctuC )];
+    const vvr_sao_ctu& s = pic.sao[( y / ctuC ) * pic.ctus_x + ( x0 / ctuC )];
     if( s.mode[c] )
     {
       const int type = s.type[c];
       if( type == 4 )
       {
-        const int k = ( ( v >> ( bd - 5 ) ) - s.band_pos[c] ) & 31;
-        if( k < 4 ) out = clip_pel( v + s.offset[c][k], bd );
+        // band offset (SampleAdaptiveOffset.cpp offsetBlock_core, SAO_TYPE_BO)
+#pragma unroll
+        for( int i = 0; i < 8; i++ ) { const int k = ( ( v[i] >> ( bd - 5 ) ) - s.band_pos[c] ) & 31; if( k < 4 ) out[i] = clip_pel( v[i] + s.offset[c][k], bd ); }
       }
       else
       {
+        // edge offset: neighbours a = ( x - dx, y - dy ), b = ( x + dx, y + dy ); nothing across the picture boundary
         const int dx = type == 1 ? 0 : ( type == 3 ? -1 : 1 ), dy = type == 0 ? 0 : 1;
-        const int ax = x - dx, ay = y - dy, bx = x + dx, by = y + dy;
-        if( ax >= 0 && ax < cw && ay >= 0 && ay < chh && bx >= 0 && bx < cw && by >= 0 && by < chh )
+        const int ya = y - dy, yb = y + dy;
+        if( ya >= 0 && yb < chh )
         {
-          const int a = S[(size_t) ay * st + ax], b = S[(size_t) by * st + bx];
-          const int e = sgn( v - a ) + sgn( v - b );
-          if( e ) out = clip_pel( v + s.offset[c][e < 0 ? e + 2 : e + 1], bd );
+          // windows [x0 - 1, x0 + 8] of the two neighbour rows (the row itself for the horizontal class)
+          int wa[10], wb[10];
+          {
+            const pel_t* ra = &S[(size_t) ya * st + x0]; const pel_t* rb = &S[(size_t) yb * st + x0];
+            const uint4 av = dy ? *reinterpret_cast<const uint4*>( ra ) : cv, bv = dy ? *reinterpret_cast<const uint4*>( rb ) : cv;
+            wa[1] = av.x & 0xffff; wa[2] = av.x >> 16; wa[3] = av.y & 0xffff; wa[4] = av.y >> 16; wa[5] = av.z & 0xffff; wa[6] = av.z >> 16; wa[7] = av.w & 0xffff; wa[8] = av.w >> 16;
+            wb[1] = bv.x & 0xffff; wb[2] = bv.x >> 16; wb[3] = bv.y & 0xffff; wb[4] = bv.y >> 16; wb[5] = bv.z & 0xffff; wb[6] = bv.z >> 16; wb[7] = bv.w & 0xffff; wb[8] = bv.w >> 16;
+            wa[0] = wb[0] = wa[9] = wb[9] = 0;
+            if( dx )
+            {
+              if( x0 > 0 ) { wa[0] = ra[-1]; wb[0] = rb[-1]; }
+              if( x0 + 8 < cw ) { wa[9] = ra[8]; wb[9] = rb[8]; }
+            }
+          }
+#pragma unroll
+          for( int i = 0; i < 8; i++ )
+          {
+            const int x = x0 + i;
+            if( x - dx < 0 || x - dx >= cw || x + dx < 0 || x + dx >= cw ) continue;
+            const int e = sgn( v[i] - wa[1 + i - dx] ) + sgn( v[i] - wb[1 + i + dx] );
+            if( e ) out[i] = clip_pel( v[i] + s.offset[c][e < 0 ? e + 2 : e + 1], bd );
+          }
         }
       }
     }
   }
-  dst.p[c][(size_t) y * dst.stride[c] + x] = (pel_t) out;
+  *reinterpret_cast<uint4*>( &dst.p[c][(size_t) y * dst.stride[c] + x0] ) =
+      make_uint4( (uint32_t) out[0] | ( (uint32_t) out[1] << 16 ), (uint32_t) out[2] | ( (uint32_t) out[3] << 16 ), (uint32_t) out[4] | ( (uint32_t) out[5] << 16 ), (uint32_t) out[6] | ( (uint32_t) out[7] << 16 ) );
 }
-
 void launch_sao( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst )
 {
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
-  hipLaunchKernelGGL( k_sao, dim3( ( src.w[0] + 63 ) / 64, ( src.h[0] + 3 ) / 4, ncomp ), dim3( 256 ), 0, s, pic, src, dst );
+  hipLaunchKernelGGL( k_sao, dim3( ( src.w[0] + 511 ) / 512, ( src.h[0] + 3 ) / 4, ncomp ), dim3( 256 ), 0, s, pic, src, dst );
 }
 
 // =====================================================================================================================
@@ -1904,56 +1930,12 @@ __device__ __forceinline__ int intra_wide_angle( int w, int h, int mode )   // I
   return mode;
 }
 
-#define IT_MAXR 16          // residual samples a lane holds for one block (64x64 / 256 threads)
+#define IT_MAXR 16          // samples a lane holds for one block (64x64 / 256 threads)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding vector-memory operation
 // (vmcnt(0)), which would put an HBM/L2 round trip on the serial block-to-block path of k_intra; the samples the next block
 // reads come from the LDS tile.
 __device__ __forceinline__ void lds_barrier() { asm volatile( "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory" ); }
-
-// Residual of one block: global -> registers (issued one block ahead of its use) -> LDS.  The loads are unconditional
-// (index clamped) and the count is a template parameter, so no load sits behind a divergent branch and the only thing in
-// flight on the vector-memory counter during the serial block loop is this prefetch (stores are deferred to the end of the CTU).
-template<int NL> __device__ __forceinline__ void intra_fetch_n( const IntraItem& it, const pel_t* __restrict__ rs, int rstride, int tid, int ( &r )[IT_MAXR] )
-{
-  const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
-#pragma unroll
-  for( int n = 0; n < NL; n++ )
-  {
-    const int i = min( tid + n * 256, wh - 1 );
-    r[n] = rs[(size_t) ( it.y + ( i >> lw ) ) * rstride + it.x + ( i & ( ( 1 << lw ) - 1 ) )];
-  }
-}
-template<int NL> __device__ __forceinline__ void intra_stash_n( const IntraItem& it, int16_t* __restrict__ dst, int tid, const int ( &r )[IT_MAXR] )
-{
-  const int wh = 1 << ( it.lw + it.lh );
-#pragma unroll
-  for( int n = 0; n < NL; n++ ) { const int i = tid + n * 256; if( i < wh ) dst[i] = (int16_t) r[n]; }
-}
-__device__ __forceinline__ void intra_fetch_resi( const IntraItem& it, const pel_t* __restrict__ rs, int rstride, int tid, int ( &r )[IT_MAXR] )
-{
-  if( !( it.flags & IT_F_RESI ) ) return;
-  switch( ( it.lw + it.lh ) > 8 ? it.lw + it.lh - 8 : 0 )
-  {
-    case 0:  intra_fetch_n<1>( it, rs, rstride, tid, r ); break;
-    case 1:  intra_fetch_n<2>( it, rs, rstride, tid, r ); break;
-    case 2:  intra_fetch_n<4>( it, rs, rstride, tid, r ); break;
-    case 3:  intra_fetch_n<8>( it, rs, rstride, tid, r ); break;
-    default: intra_fetch_n<16>( it, rs, rstride, tid, r ); break;
-  }
-}
-__device__ __forceinline__ void intra_stash_resi( const IntraItem& it, int16_t* __restrict__ dst, int tid, const int ( &r )[IT_MAXR] )
-{
-  if( !( it.flags & IT_F_RESI ) ) return;
-  switch( ( it.lw + it.lh ) > 8 ? it.lw + it.lh - 8 : 0 )
-  {
-    case 0:  intra_stash_n<1>( it, dst, tid, r ); break;
-    case 1:  intra_stash_n<2>( it, dst, tid, r ); break;
-    case 2:  intra_stash_n<4>( it, dst, tid, r ); break;
-    case 3:  intra_stash_n<8>( it, dst, tid, r ); break;
-    default: intra_stash_n<16>( it, dst, tid, r ); break;
-  }
-}
 
 // Residual prefetch of the block loop, version without control flow around the load: ONE sample per lane (blocks of at most 256
 // samples, the common case), index clamped, issued whether or not the block has a residual.  (A switch over load counts makes the
@@ -1997,7 +1979,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   const uint32_t ent = un->ent;
   const int comp = ( ent >> 24 ) & 3, ctu = ent & 0xffffff;
   const bool borderOnly = ( ent >> 31 ) != 0;          // whole CTU, every sample intra: the interior is produced here, never read first
-  const bool publish = ( ( ent >> 30 ) & 1 ) != 0;     // another unit waits for this one
+  const bool publish = ( ( ent >> 30 ) & 1 ) != 0 && !( dbg & 0x100 );     // another unit waits for this one (level launches: nobody does)
   const int cxI = ctu % pic.ctus_x, cyI = ctu / pic.ctus_x;
   const int cs = comp ? 1 : 0;
   const int S = ( 1 << pic.hdr.log2_ctu ) >> cs;
@@ -2172,29 +2154,6 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     {
       const int f = lmcs_cscale_factor_wave( pic, reco, lx, ly, tid & 63 );
       if( ( tid & 63 ) == 0 ) sh.csFac[wv] = f;
-    }
-  }
-  lds_barrier();
-  // ---- inter blocks of the CTU whose chroma residual is scaled: they read nothing but their own prediction (already in the tile)
-  // and the factor, so they come first and in parallel, one block per wavefront
-  {
-    const uint32_t iA = un->iA;
-    for( uint32_t q = i0 + ( tid >> 6 ); q < iA; q += 4 )
-    {
-      IntraItem it;
-      {
-        const uint32_t* ip = reinterpret_cast<const uint32_t*>( &items[q] );
-        uint32_t* op = reinterpret_cast<uint32_t*>( &it );
-        for( int e = 0; e < 4; e++ ) op[e] = __builtin_amdgcn_readfirstlane( ip[e] );
-      }
-      const int x0 = it.x, y0 = it.y, lw = it.lw, wh = 1 << ( it.lw + it.lh );
-      const int f = ( it.flags & IT_F_CSCALE ) ? sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )] : 0;
-      for( int i = ( tid & 63 ); i < wh; i += 64 )
-      {
-        const int x = x0 + ( i & ( ( 1 << lw ) - 1 ) ), y = y0 + ( i >> lw );
-        const int r = (int16_t) rs[(size_t) y * rstride + x];
-        TILE( x, y ) = (pel_t) clip_pel( TILE( x, y ) + ( ( it.flags & IT_F_CSCALE ) ? lmcs_scale_resi( r, f, bd ) : r ), bd );
-      }
     }
   }
   lds_barrier();
@@ -2712,6 +2671,16 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   }
 #undef IT_TRACE
 #undef IT_PH
+}
+
+void launch_intra_levels( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units,
+                          const std::pair<int, int>* levels, int numLevels, int* sync )
+{
+  // every level has its own ticket counter (sync[l]); no flags are used: the units of a level only read what earlier launches wrote
+  static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;
+  hipMemsetAsync( sync, 0, sizeof( int ) * (size_t) numLevels, s );
+  for( int l = 0; l < numLevels; l++ )
+    hipLaunchKernelGGL( k_intra, dim3( levels[l].second ), dim3( 256 ), 0, s, pic, reco, resi, items, units + levels[l].first, levels[l].second, sync + l, dbg | 0x100, nullptr );
 }
 
 void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numActive, int* sync )
