@@ -85,6 +85,8 @@ enum {
                                         B slice with pps_weighted_bipred_flag (InterPrediction.cpp:707,735-742); vvr_picture.wp set */
   VVR_TOOL_SCALING_LIST = 1u << 17,  /* explicit scaling list in use for the slice (Quant.cpp:330-336); vvr_picture.scaling set */
   VVR_TOOL_SCALING_LIST_NO_LFNST = 1u << 18,  /* sps_scaling_matrix_for_lfnst_disabled_flag */
+  VVR_TOOL_IMPLICIT_MTS = 1u << 19,  /* MTS on without sps_explicit_mts_intra_enabled_flag: intra luma blocks use the implicit DST-7 rule.
+                                        Informative (vvr_tu.tr_type is already resolved); a checker that drives the reference decoder needs it */
 };
 
 typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::reconstructCoeff (AdaptiveLoopFilter.cpp:888) stays on the host */

@@ -132,7 +132,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     sps.setUseReshaper( !!( H.tool_flags & VVR_TOOL_LMCS ) );
     sps.setUseLFNST( !!( H.tool_flags & VVR_TOOL_LFNST ) );
     sps.setUseMTS( true );            // the per-TU transform types are forced below through mtsIdx/implicit rules, see tu setup
-    sps.setUseIntraMTS( true );
+    sps.setUseIntraMTS( !( H.tool_flags & VVR_TOOL_IMPLICIT_MTS ) );       // off: implicit MTS for intra luma blocks (SPS::getUseImplicitMTS)
     sps.setUseInterMTS( true );
     sps.setUseSBT( true );
     sps.setUseISP( true );

@@ -258,6 +258,9 @@ def test_dual_tree_intra_pictures(built):
     _run_stream(256, 128, 5, 4, 241, TOOLS_A, intra=True, dual_tree=1.0, p_cclm=0.4, p_lfnst=0.5, p_isp=0.3, p_mip=0.2, p_coded_chroma=0.6)
     _run_stream(416, 240, 3, 2, 242, TOOLS_A | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, intra=True, log2_ctu=5, dual_tree=1.0, p_cclm=0.4, p_jccr=0.3, p_coded_chroma=0.6)
     _run_stream(1920, 1080, 3, 2, 243, TOOLS_A, intra=True, streams=3, log2_ctu=6, dual_tree=1.0, p_cclm=0.2, p_isp=0.1)
+    # luma CUs down to 4x4 (4x4 MIP / LFNST / BDPCM blocks), implicit MTS
+    _run_stream(256, 128, 3, 2, 244, TOOLS_A | abi.TOOL_IMPLICIT_MTS, intra=True, dual_tree=2.0, p_cclm=0.3, p_lfnst=0.4, p_isp=0.2, p_mip=0.3, p_coded=0.7, p_split_scale=1.5)
+    _run_stream(1920, 1080, 2, 1, 245, TOOLS_A | abi.TOOL_IMPLICIT_MTS, intra=True, dual_tree=2.0, p_mip=0.1, p_isp=0.1, p_split_scale=1.3)
 
 
 def test_joint_cbcr(built):

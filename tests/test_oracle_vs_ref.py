@@ -47,6 +47,7 @@ def _case(W, H, l2, idx, seed, tools=ALL, **kw):
     (256, 128, 7, 0, 124, dict(dual_tree=1.0, p_cclm=0.4, p_lfnst=0.5, p_isp=0.3, p_mip=0.2, p_coded_chroma=0.6)),
     (200, 136, 5, 0, 125, dict(dual_tree=1.0, p_cclm=0.4, p_jccr=0.3, p_coded_chroma=0.6)),
     (384, 256, 6, 0, 126, dict(dual_tree=1.0, p_split_scale=0.6, p_lfnst=0.4, p_bdpcm=0.2)),
+    (256, 128, 6, 0, 129, dict(dual_tree=2.0, p_cclm=0.4, p_lfnst=0.5, p_isp=0.3, p_mip=0.3, p_coded_chroma=0.6, p_split_scale=1.5)),
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)
@@ -119,6 +120,16 @@ def test_oracle_equals_reference_cclm_collocated(built, l2, idx, seed):
         assert np.array_equal(got[c], want[c]), "comp %d: %d differ" % (c, int((got[c] != want[c]).sum()))
 
 
+@pytest.mark.parametrize("l2,idx,seed,kw", [(5, 0, 241, dict(dual_tree=2.0)), (6, 2, 242, dict(p_intra=0.5)), (7, 0, 243, dict())])
+def test_oracle_equals_reference_implicit_mts(built, l2, idx, seed, kw):
+    """MTS without explicit intra MTS: intra luma blocks take DST-7 along every dimension of 4..16 samples (host-resolved tr_type)"""
+    d, refs = _case(256, 128, l2, idx, seed, tools=ALL | abi.TOOL_IMPLICIT_MTS, p_mip=0.2, p_lfnst=0.3, p_isp=0.2, p_coded=0.8, **kw)
+    want = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_RECO)["planes"]
+    got = refdrv.oracle_reconstruct(d, refs, flags=refdrv.STOP_AFTER_RECO)
+    for c in range(3):
+        assert np.array_equal(got[c], want[c]), "comp %d: %d differ" % (c, int((got[c] != want[c]).sum()))
+
+
 def test_reference_simd_equals_scalar(built):
     """the reference's own differential check (its unit test compares scalar vs SIMD kernels): same bytes at frame level"""
     d, refs = _case(256, 192, 7, 2, 106, p_intra=0.2)
@@ -135,7 +146,8 @@ def test_edge_parameters_match_reference_derivation(built):
     b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     for args, kw in (((256, 128, 7, 0, 122), dict(p_isp=0.7, p_split_scale=1.6)), ((384, 256, 6, 2, 123), dict(p_isp=0.5, p_intra=0.4, p_cclm=0.3)),
-                     ((384, 256, 7, 0, 127), dict(dual_tree=1.0, p_isp=0.2, p_bdpcm=0.3, p_coded_chroma=0.6)), ((256, 128, 6, 2, 128), dict(p_bdpcm=0.5, p_intra=0.6))):
+                     ((384, 256, 7, 0, 127), dict(dual_tree=1.0, p_isp=0.2, p_bdpcm=0.3, p_coded_chroma=0.6)),
+                     ((256, 128, 6, 0, 130), dict(dual_tree=2.0, p_split_scale=1.5, p_isp=0.2)), ((256, 128, 6, 2, 128), dict(p_bdpcm=0.5, p_intra=0.6))):
         d, refs = _case(*args, **kw)                                                       # ISP: partition edges, unsplit chroma
         a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
         b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]

@@ -68,7 +68,7 @@ typedef struct vvs_params {
   float    p_mip;               // of intra CUs: matrix-based luma prediction
   float    p_sbt;               // of inter CUs (not CIIP, at most 64x64): sub-block transform (residual in one half / quarter of the CU)
   float    p_isp;               // of intra CUs (no MRL / BDPCM / MIP): intra sub-partitions, four luma partitions predicted one after the other
-  float    dual_tree;           // > 0: I pictures use separate luma and chroma coding trees below 64x64 (qtbtt_dual_tree_intra_flag)
+  float    dual_tree;           // > 0: I pictures use separate luma and chroma coding trees below 64x64 (qtbtt_dual_tree_intra_flag); 2: luma CUs down to 4x4
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -94,7 +94,7 @@ void vvs_bounds( const vvs_params* P, uint32_t* max_cu, uint32_t* max_tu, uint64
 {
   const uint32_t m = 1u << P->min_cu_log2;
   const uint32_t n = ( ( P->width + m - 1 ) / m ) * ( ( P->height + m - 1 ) / m );
-  const uint32_t trees = P->dual_tree > 0 ? 2 : 1;                 // dual tree: luma and chroma CUs
+  const uint32_t trees = P->dual_tree >= 2.0f ? 5 : P->dual_tree > 0 ? 2 : 1;                 // dual tree: luma and chroma CUs (luma down to 4x4: four times as many)
   *max_cu = n * trees; *max_tu = ( P->p_isp > 0 ? 4 * n : n + n / 4 ) * trees + 16;      // ISP: four TUs per CU
   *max_coef = (uint64_t) P->width * P->height * 3 / 2 + 4096;
 }
@@ -268,7 +268,7 @@ struct Gen {
       }
       // intra sub-partitions: horizontal (1) or vertical (2) split of the luma block in four (CU::canUseISP: more than 16 samples,
       // at most the maximum transform size); LFNST only while the partitions are at least 4x4 (CU::canUseLfnstWithISP)
-      if( P.p_isp > 0 && !treeC && !( treeL && w == 64 && h == 64 ) && !cu.bdpcm[0] && !cu.multi_ref_idx && !( cu.flags & VVR_CU_MIP ) && w <= 64 && h <= 64 && rng.p( P.p_isp ) ) cu.isp_mode = (uint8_t) ( 1 + rng.u( 2 ) );
+      if( P.p_isp > 0 && !treeC && w >= 8 && h >= 8 && !( treeL && w == 64 && h == 64 ) && !cu.bdpcm[0] && !cu.multi_ref_idx && !( cu.flags & VVR_CU_MIP ) && w <= 64 && h <= 64 && rng.p( P.p_isp ) ) cu.isp_mode = (uint8_t) ( 1 + rng.u( 2 ) );
       const bool ispNoLfnst = cu.isp_mode && ( cu.isp_mode == 1 ? h / 4 < 4 : w / 4 < 4 );
       // LFNST index (luma of single-tree CUs): needs DCT2 and a residual confined to the first 8/16 scan positions, see genLevels
       if( !treeC && ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && ( !( cu.flags & VVR_CU_MIP ) || ( w >= 16 && h >= 16 ) ) && !ispNoLfnst && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
@@ -431,10 +431,15 @@ struct Gen {
         if( c == 0 && intra && cu.bdpcm[0] ) ts = true;
         if( ( c == 0 || treeC ) && intra && cu.lfnst_idx ) ts = false;
         tu.mts_idx[c] = ts ? VVR_MTS_SKIP : VVR_MTS_DCT2;
-        if( !ts && c == 0 && bw <= 32 && bh <= 32 && !sbtIdx && !cu.isp_mode && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
+        const bool implicitMts = intra && ( P.tool_flags & VVR_TOOL_IMPLICIT_MTS );
+        if( !ts && c == 0 && bw <= 32 && bh <= 32 && !sbtIdx && !cu.isp_mode && !implicitMts && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
         // getTrTypes (TrQuant.cpp:330): explicit MTS -> hor = (idx-2)&1 ? DCT8 : DST7 ; ver = (idx-2)>>1 ? DCT8 : DST7
         int hor = 0, ver = 0;
         if( tu.mts_idx[c] > 1 ) { hor = ( ( tu.mts_idx[c] - 2 ) & 1 ) ? 1 : 2; ver = ( ( tu.mts_idx[c] - 2 ) >> 1 ) ? 1 : 2; }
+        if( implicitMts && c == 0 && !ts && !cu.isp_mode && !cu.lfnst_idx && !( cu.flags & VVR_CU_MIP ) )
+        {   // implicit MTS (getTrTypes, TrQuant.cpp:336,349-360): DST-7 along every dimension of 4..16 samples
+          hor = ( bw >= 4 && bw <= 16 ) ? 2 : 0; ver = ( bh >= 4 && bh <= 16 ) ? 2 : 0;
+        }
         if( cu.isp_mode && c == 0 && !cu.lfnst_idx )
         {   // ISP: DST-7 along every dimension of 4..16 samples, DCT-2 otherwise (getTrTypes, TrQuant.cpp:349-360)
           hor = ( bw >= 4 && bw <= 16 ) ? 2 : 0; ver = ( bh >= 4 && bh <= 16 ) ? 2 : 0;
@@ -542,7 +547,7 @@ struct Gen {
   void split( int x, int y, int w, int h )
   {
     if( x >= W || y >= H ) return;
-    const int minS = 1 << P.min_cu_log2;
+    const int minS = ( curTree == VVR_TREE_LUMA && P.dual_tree >= 2.0f ) ? 4 : 1 << P.min_cu_log2;      // dual_tree = 2: luma CUs down to 4x4
     const bool crossX = x + w > W, crossY = y + h > H;
     if( crossX || crossY )
     {

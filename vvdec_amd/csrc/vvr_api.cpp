@@ -307,7 +307,12 @@ static int validate( vvr_context* c, const vvr_picture* p )
         if( cu.intra_dir[0] >= ( sizeId == 0 ? 16 : sizeId == 1 ? 8 : 6 ) || cu.multi_ref_idx || cu.bdpcm[0] ) { c->setError( "MIP CU: mode index out of range for the block size, or combined with MRL / BDPCM" ); return VVR_ERR_PARAMETER; }
       }
       if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] > 69 ) { c->setError( "chroma intra mode out of range" ); return VVR_ERR_PARAMETER; }
-      if( cu.w > 64 || cu.h > 64 || cu.w < 8 || cu.h < 8 ) { c->setError( "intra CU size outside 8..64 is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      {
+        // luma-tree CUs of dual-tree pictures go down to 4x4; a 4-wide CU with chroma (2xN chroma blocks / local dual tree) and ISP of
+        // 4xN CUs (1xN partitions) are not in this build
+        const int minSize = cu.tree == VVR_TREE_LUMA && !cu.isp_mode ? 4 : 8;
+        if( cu.w > 64 || cu.h > 64 || cu.w < minSize || cu.h < minSize ) { c->setError( "intra CU size outside 8..64 (4..64 for luma-tree CUs without ISP) is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+      }
       if( cu.tree != VVR_TREE_JOINT )
       {
         // dual tree (I slices, qtbtt_dual_tree_intra_flag): luma CUs carry luma blocks only, chroma CUs chroma blocks only
