@@ -127,10 +127,11 @@ def main():
     first = 0 if a.cold else Wm                       # first timed picture (submission order)
     n_irap = sum(1 for pl in plans[first:first + K] if pl.slice_type == abi.SLICE_I)
 
-    def one_pass(i0, n):
+    def one_pass(i0, n, all_ranks=True):
+        # all_ranks=False: a pass that only rank 0 runs (statistics): no collective inside
         rec.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 and all_ranks:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -138,7 +139,7 @@ def main():
             rec.submit_prepared(prepared[i])
         rec.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 and all_ranks:
             dist.barrier()
         torch.cuda.synchronize()
         return time.perf_counter() - t0
@@ -175,8 +176,8 @@ def main():
         # ---- roofline of the dominant kernel: second identical pass with HIP-event timing on the launch streams
         rec.enable_stats(True)
         if not a.cold:
-            one_pass(0, Wm)
-        one_pass(first, K)
+            one_pass(0, Wm, all_ranks=False)
+        one_pass(first, K, all_ranks=False)
         st = rec.stats()
         rec.enable_stats(False)
         st.sort(key=lambda s: -s["total_ms"])
