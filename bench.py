@@ -102,9 +102,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    backend = os.environ.get("VVR_BENCH_BACKEND", "nccl")     # "gloo": control-flow test of the multi-rank path on a box with fewer GPUs than ranks
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import vvdec_amd
     from vvdec_amd import abi, synth, stream
@@ -147,7 +153,7 @@ def main():
     one_pass(0, Wm)                                    # warm-up (untimed): the first W pictures of the stream
     dt = one_pass(first, K)                            # timed: exactly K steps
     if world > 1:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
