@@ -194,6 +194,16 @@ def main():
                 "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                 "all_kernels": {s["name"]: {"avg_us": round(1e3 * s["total_ms"] / s["launches"], 2), "launches": s["launches"],
                                             "algo_GBps": round(s["algo_bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1)} for s in st}}
+        # HBM-side traffic of that kernel from the separate PMC passes (profiles/round1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+        # --pmc WRITE_SIZE, gfx950 correction applied); counters cannot be collected inside this run
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")))["kernels"]
+            ent = next(v for k, v in pmc.items() if k.split("<")[0] == dom["name"])
+            roof["traffic"] = ent["hbm_side_bytes_per_launch_corrected"]
+            roof["traffic_source"] = "profiles/round1_pmc_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)"
+            roof["algorithmic_bytes_per_launch"] = int(dom["algo_bytes"] / dom["launches"])
+        except Exception:
+            pass
         fps = world * K / dt
         out = {"metric": "decoded frames/sec (4K 10-bit RA) on MI355X, synthetic pre-parsed stream, bit-exact vs ref",
                "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,

@@ -79,6 +79,14 @@ struct McSeg {
 
 // XCD-aware mapping (cdna_hip_programming.md T1): consecutive workgroups are dealt round-robin to the 8 XCDs; give each XCD
 // a contiguous run of tiles so that the halo rows shared by neighbouring tiles hit the same L2.
+// XCD-aware work assignment: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Remapping the linear id
+// so that every XCD owns one contiguous range of work items keeps neighbours (which share cache lines: halos, 128-byte lines cut by
+// tile edges) in the same L2.  (PMC: k_alf_luma fetched 3.5x its input through the fabric before.)
+__device__ __forceinline__ int xcd_contiguous( int lin, int nwg )
+{
+  const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
+  return ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + ( lin >> 3 );
+}
 __device__ __forceinline__ int mc_item_index()
 {
   const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -1531,8 +1539,9 @@ __global__ __launch_bounds__( 256 ) void k_sao( PicDev pic, DevPlanes src, DevPl
   const int c = blockIdx.z;
   const int cs = c ? 1 : 0;
   const int cw = src.w[c], chh = src.h[c];
-  const int x0 = ( blockIdx.x * 64 + ( threadIdx.x & 63 ) ) * 8;
-  const int y = blockIdx.y * 4 + ( threadIdx.x >> 6 );
+  const int blkLin = xcd_contiguous( blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y );
+  const int x0 = ( ( blkLin % gridDim.x ) * 64 + ( threadIdx.x & 63 ) ) * 8;
+  const int y = ( blkLin / gridDim.x ) * 4 + ( threadIdx.x >> 6 );
   if( x0 >= cw || y >= chh ) return;
   const int bd = pic.hdr.bit_depth, ctuC = ( 1 << pic.hdr.log2_ctu ) >> cs;
   const pel_t* __restrict__ S = src.p[c];
@@ -1621,7 +1630,8 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
   __shared__ pel_t tile[( ALF_T + 2 * ALF_HALO ) * ALF_LW];
   __shared__ int16_t fCoef[25 * 12], fClip[25 * 12];      // the CTU's filter set: per class, un-transposed
   __shared__ uint8_t cls[64], trp[64];
-  const int tx0 = blockIdx.x * ALF_T, ty0 = blockIdx.y * ALF_T;
+  const int tileLin = xcd_contiguous( blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y );
+  const int tx0 = ( tileLin % gridDim.x ) * ALF_T, ty0 = ( tileLin / gridDim.x ) * ALF_T;
   const int W = src.w[0], H = src.h[0], st = src.stride[0];
   const int tid = threadIdx.x, bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu;
   const pel_t* __restrict__ S = src.p[0];
@@ -1755,7 +1765,8 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
 __global__ __launch_bounds__( 256 ) void k_alf_chroma( PicDev pic, DevPlanes src, DevPlanes dst )
 {
   const int c = 1 + blockIdx.z;
-  const int x = blockIdx.x * 64 + ( threadIdx.x & 63 ), y = blockIdx.y * 4 + ( threadIdx.x >> 6 );
+  const int blkLin = xcd_contiguous( blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y );
+  const int x = ( blkLin % gridDim.x ) * 64 + ( threadIdx.x & 63 ), y = ( blkLin / gridDim.x ) * 4 + ( threadIdx.x >> 6 );
   const int W = src.w[c], H = src.h[c];
   if( x >= W || y >= H ) return;
   const int bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu, ctuC = ctu >> 1;
