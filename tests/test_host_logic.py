@@ -23,6 +23,31 @@ def test_ra_plan_is_decodable(gop, frames):
         assert plans[0].slice_type == (abi.SLICE_B if ext else abi.SLICE_I)
 
 
+@pytest.mark.parametrize("pool,lookahead", [(0, 0), (24, 0), (24, 8), (0, 5)])
+def test_ra_plan_with_periodic_irap(pool, lookahead):
+    """IRAP every 64 pictures, optionally submitted ahead of its decoding-order position: every reference precedes its user in the
+    submission order, key pictures do not reference across the IRAP, no slot is overwritten while a later picture still reads it"""
+    plans, nslots = stream.ra_plan(161, gop=16, seed_poc0_is_external=False, pool=pool, intra_period=64, irap_lookahead=lookahead)
+    assert sorted(p.poc for p in plans) == list(range(161))
+    iraps = [p.poc for p in plans if p.slice_type == 2]
+    assert iraps == [0, 64, 128]
+    pos = {p.poc: i for i, p in enumerate(plans)}
+    content = {}
+    for i, p in enumerate(plans):
+        for lst in p.ref_slots:
+            for slot, poc in lst:
+                assert pos[poc] < i and content.get(slot) == poc, "POC %d reads POC %d from slot %d" % (p.poc, poc, slot)
+        if p.slice_type != 2 and p.layer == 0:
+            irap = max(q for q in iraps if q <= p.poc)
+            assert all(r >= irap for r in p.l0 + p.l1)
+        content[p.slot] = p.poc
+        assert p.slot < nslots
+    if lookahead:
+        base, _ = stream.ra_plan(161, gop=16, seed_poc0_is_external=False, pool=pool, intra_period=64)
+        bpos = {p.poc: i for i, p in enumerate(base)}
+        assert all(pos[q] == max(1, bpos[q] - lookahead) for q in iraps[1:])
+
+
 def test_ra_plan_layers():
     plans, _ = stream.ra_plan(17, gop=16)
     by_layer = {}
