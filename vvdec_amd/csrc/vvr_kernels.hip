@@ -1907,16 +1907,23 @@ void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst )
 #define IT_PAD    3      // reference lines above the CTU (multiRefIdx <= 2)
 #define IT_PADX   8      // columns left of the CTU kept in LDS: 8 samples = 16 bytes, so that every tile row starts 16-byte aligned in HBM
 #define IT_RIGHT 64
-#define IT_TS   ( IT_PADX + 128 + IT_RIGHT + 8 )     // LDS row stride in samples (16-byte multiple)
+#define IT_TS   ( IT_PADX + 128 + IT_RIGHT + 8 )     // LDS row stride of the rows ABOVE the CTU (they reach 64 samples into the above-right CTU)
+#define IT_TSB  ( IT_PADX + 128 + 8 )                // row stride of the rows inside the CTU (nothing right of the CTU is ever available there)
+// index of sample (ox + dx, oy + dy) in the tile: IT_PAD long rows, then the CTU rows
+__device__ __forceinline__ int tile_idx( int dx, int dy )
+{
+  return dy < 0 ? ( dy + IT_PAD ) * IT_TS + dx + IT_PADX : IT_PAD * IT_TS + dy * IT_TSB + dx + IT_PADX;
+}
 #define IT_MAXREF ( 2 * 64 + 8 )
 
 #define IT_BATCH 64         // IntraItems staged in LDS at a time (64 x 16 B: one dword per thread)
 
 struct IntraShared {
-  pel_t tile[( 128 + IT_PAD ) * IT_TS];
+  pel_t tile[IT_PAD * IT_TS + 128 * IT_TSB];
   pel_t top[IT_MAXREF + 8], left[IT_MAXREF + 8], ftop[IT_MAXREF + 8], fleft[IT_MAXREF + 8];
   IntraItem items[IT_BATCH];
-  int16_t resi[2][64 * 64];                            // residual of the current / next block (prefetched one block ahead)
+  int16_t resiS[2][256];                               // residual of the current / next block of at most 256 samples (prefetched one block ahead)
+  int16_t resiB[64 * 64];                              // residual of a larger block (read when the block before it is done)
   int16_t angTab[32], invAngTab[32], cfilt[32][4];     // the small ROM tables the serial per-block path indexes: LDS latency instead of a memory round trip each
   uint8_t filtThr[8];
   int   lmSel[8];                                       // CCLM: the (luma, chroma) pairs of the selected template positions
@@ -2001,7 +2008,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   const pel_t* __restrict__ rs = resi.p[comp];
   const int rstride = resi.stride[comp];
   const uint32_t i0 = un->i0, i1 = un->i1;
-#define TILE( x, y ) sh.tile[( ( y ) - oy + IT_PAD ) * IT_TS + ( ( x ) - ox + IT_PADX )]
+#define TILE( x, y ) sh.tile[tile_idx( ( x ) - ox, ( y ) - oy )]
   // ---- wait for the units that produce intra samples this one reads (same component: reference lines; luma: CCLM)
   {
     // one lane per producer (at most VVR_INTRA_MAX_DEPS of them): the polls overlap instead of queueing behind each other
@@ -2098,7 +2105,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     const int nch = bc1 - bc0;
     const int nTop = nch * max( 0, min( by1, oy ) - by0 );                   // chunks in the rows above the CTU
     const int rowsIn = max( 0, by1 - max( by0, oy ) );
-    const bool perBlock = !borderOnly && !( dbg & 32 );
+    const bool perBlock = !borderOnly;
     const int total = ( ( dbg & 2 ) || perBlock ) ? 0 : borderOnly ? nTop + ( bc0 < 0 ? rowsIn : 0 ) : nch * ( by1 - by0 );
     if( perBlock && !( dbg & 2 ) )
     {
@@ -2134,7 +2141,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           else if( i < nT + nL ) { x = lx & ~7; y = ly0 + ( i - nT ); }
           else { const int j = i - nT - nL; y = (int) it.y + j / cch; x = ( (int) it.x & ~7 ) + 8 * ( j % cch ); }
           const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
-          *reinterpret_cast<uint4*>( &sh.tile[( y - oy + IT_PAD ) * IT_TS + ( x - ox + IT_PADX )] ) = v;
+          *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
         }
       }
     }
@@ -2144,7 +2151,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       uint4 v0, v1, v2, v3; int o0, o1, o2, o3;
 #define IT_LD( V, O, U ) { const int i = min( base + U * 256 + tid, total - 1 ); int r, cidx; \
         if( !borderOnly || i < nTop ) { r = i / nch; cidx = bc0 + ( i - r * nch ); } else { r = ( max( by0, oy ) - by0 ) + ( i - nTop ); cidx = -1; } \
-        const int y = by0 + r, x = ox + cidx * 8; V = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] ); O = ( y - oy + IT_PAD ) * IT_TS + ( x - ox + IT_PADX ); }
+        const int y = by0 + r, x = ox + cidx * 8; V = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] ); O = tile_idx( x - ox, y - oy ); }
       IT_LD( v0, o0, 0 ) IT_LD( v1, o1, 1 ) IT_LD( v2, o2, 2 ) IT_LD( v3, o3, 3 )
 #undef IT_LD
       *reinterpret_cast<uint4*>( &sh.tile[o0] ) = v0; *reinterpret_cast<uint4*>( &sh.tile[o1] ) = v1;
@@ -2175,7 +2182,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     if( tid < nb * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = reinterpret_cast<const uint32_t*>( items + b0 )[tid];
     lds_barrier();
     int rpre = intra_prefetch_resi( sh.items[0], rs, rstride, tid );
-    intra_stash_resi1( sh.items[0], sh.resi[0], tid, rpre, rs, rstride );
+    intra_stash_resi1( sh.items[0], ( sh.items[0].lw + sh.items[0].lh ) > 8 ? sh.resiB : sh.resiS[0], tid, rpre, rs, rstride );
     for( int k = 0; k < nb; k++ )
     {
       // the item is the same for every lane: move it to scalar registers so that all the mode / size dependent set-up below runs on
@@ -2187,7 +2194,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         for( int q = 0; q < 4; q++ ) op[q] = __builtin_amdgcn_readfirstlane( ip[q] );
       }
       if( trace ) trT = wall_clock64();
-      const int16_t* __restrict__ rcur = sh.resi[k & 1];
+      const int16_t* __restrict__ rcur = ( sh.items[k].lw + sh.items[k].lh ) > 8 ? sh.resiB : sh.resiS[k & 1];
       if( !( dbg & 16 ) ) rpre = intra_prefetch_resi( sh.items[min( k + 1, nb - 1 )], rs, rstride, tid );     // in flight while this block is predicted
       const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
       const int mrl = ( it.flags & IT_F_MIP ) ? 0 : ( it.flags >> 4 ) & 3;
@@ -2385,7 +2392,12 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
             const int x = i & ( w - 1 ), y = i >> lw;
             TILE( x0 + x, y0 + y ) = (pel_t) clip_pel( TILE( x0 + x, y0 + y ) + rcur[i], bd );
           }
-        if( k + 1 < nb ) intra_stash_resi1( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rpre, rs, rstride );
+        if( k + 1 < nb )
+      {
+        const bool big = ( sh.items[k + 1].lw + sh.items[k + 1].lh ) > 8;
+        if( big ) lds_barrier();                                 // the single large buffer may still be read by slower wavefronts of this block
+        intra_stash_resi1( sh.items[k + 1], big ? sh.resiB : sh.resiS[( k + 1 ) & 1], tid, rpre, rs, rstride );
+      }
         lds_barrier();
         continue;
       }
@@ -2472,7 +2484,12 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           TILE( x0 + x, y0 + y ) = (pel_t) v;
         }
 #undef LU
-        if( k + 1 < nb ) intra_stash_resi1( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rpre, rs, rstride );
+        if( k + 1 < nb )
+      {
+        const bool big = ( sh.items[k + 1].lw + sh.items[k + 1].lh ) > 8;
+        if( big ) lds_barrier();                                 // the single large buffer may still be read by slower wavefronts of this block
+        intra_stash_resi1( sh.items[k + 1], big ? sh.resiB : sh.resiS[( k + 1 ) & 1], tid, rpre, rs, rstride );
+      }
         lds_barrier();
         continue;
       }
@@ -2617,7 +2634,12 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         TILE( x0 + x, y0 + y ) = (pel_t) v;
       }
       IT_PH( trC )
-      if( k + 1 < nb ) intra_stash_resi1( sh.items[k + 1], sh.resi[( k + 1 ) & 1], tid, rpre, rs, rstride );
+      if( k + 1 < nb )
+      {
+        const bool big = ( sh.items[k + 1].lw + sh.items[k + 1].lh ) > 8;
+        if( big ) lds_barrier();                                 // the single large buffer may still be read by slower wavefronts of this block
+        intra_stash_resi1( sh.items[k + 1], big ? sh.resiB : sh.resiS[( k + 1 ) & 1], tid, rpre, rs, rstride );
+      }
       lds_barrier();
       IT_PH( trD )
     }
