@@ -121,3 +121,31 @@ def test_tr_type_helper(built):
     # explicit MTS, mts_idx = MTS_DCT8_DST7 -> horizontal DCT8 (1), vertical DST7 (2)
     tu.mts_idx[0] = abi.MTS_DCT8_DST7
     assert L.vvr_resolve_tr_type(C.byref(h), C.byref(cu), C.byref(tu), 0, 0, 1, 0) == ((2 << 2) | 1)
+
+
+@pytest.mark.parametrize("implicit", [0, 1])
+def test_resolver_matches_reference_checked_streams(built, implicit):
+    """vvr_resolve_tr_type (the host helper an integrator calls per TU) against the transform types of generated pictures whose
+    reconstruction is checked against the reference decoder (explicit MTS, SBT by position, ISP / implicit DST-7, LFNST and MIP exemptions)"""
+    import vvdec_amd
+    from vvdec_amd import abi, synth, stream
+    L = vvdec_amd.lib()
+    L.vvr_resolve_tr_type.restype = C.c_uint8
+    tools = abi.TOOL_MTS | abi.TOOL_LFNST | abi.TOOL_DEP_QUANT | (abi.TOOL_IMPLICIT_MTS if implicit else 0)
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    checked = 0
+    for idx, kw in ((0, dict(p_isp=0.4, p_mip=0.2, p_lfnst=0.3, p_mts=0.4, p_coded=0.8)), (2, dict(p_intra=0.3, p_sbt=0.4, p_isp=0.3, p_mts=0.4, p_coded=0.8))):
+        d = synth.picture_for_plan(plans[idx], 256, 128, seed=900 + idx, tool_flags=tools, log2_ctu=6, **kw)
+        hdr = d.hdr
+        cus = (abi.Cu * len(d.cu)).from_buffer_copy(d.cu.tobytes())
+        tus = (abi.Tu * len(d.tu)).from_buffer_copy(d.tu.tobytes())
+        for t in tus:
+            cu = cus[t.cu]
+            for comp in range(3):
+                coded = (t.cbf >> comp) & 1
+                if not coded or t.mts_idx[comp] == abi.MTS_SKIP:
+                    continue
+                got = L.vvr_resolve_tr_type(C.byref(hdr), C.byref(cu), C.byref(t), comp, implicit, 0 if implicit else 1, 1)
+                assert got == t.tr_type[comp], "CU %dx%d pred %d isp %d sbt %d lfnst %d comp %d: %d != %d" % (cu.w, cu.h, cu.pred_mode, cu.isp_mode, cu.sbt_info, cu.lfnst_idx, comp, got, t.tr_type[comp])
+                checked += 1
+    assert checked > 100
