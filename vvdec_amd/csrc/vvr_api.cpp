@@ -345,6 +345,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   hipSetDevice( c->device );
   const vvr_pic_header& h = p->hdr;
   const int ncomp = h.chroma_format ? 3 : 1;
+  const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
   const int w4 = ( h.width + 3 ) >> 2, h4 = ( h.height + 3 ) >> 2, ctu = 1 << h.log2_ctu;
   const int ctusX = ( h.width + ctu - 1 ) / ctu, ctusY = ( h.height + ctu - 1 ) / ctu, numCtu = ctusX * ctusY;
 
@@ -583,9 +584,30 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       const int ts = sbt ? 8 : 16;                       // SbTMVP: one item per 8x8 sub-block (ATMVP_SUB_BLOCK_SIZE)
       for( int y = 0; y < cu.h; y += ts ) for( int x = 0; x < cu.w; x += ts )
       {
-        McItem it; it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y ); it.flags = sbt ? MC_ITEM_SUBBLOCK : 0; it.cu = i;
+        McItem it; memset( &it, 0, sizeof( it ) );
+        it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y ); it.flags = sbt ? MC_ITEM_SUBBLOCK : 0; it.cu = i;
         const bool dm = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
         const bool af = cu.mc_mode == VVR_MC_AFFINE;
+        if( !dm && !af )
+        {
+          // everything k_mc needs about the motion of the tile
+          bool uni = cu.mc_mode == VVR_MC_UNI;
+          it.ref[0] = cu.ref_idx[0]; it.ref[1] = cu.ref_idx[1];
+          for( int l = 0; l < 2; l++ ) { it.mv[l][0] = cu.mv[l][0][0]; it.mv[l][1] = cu.mv[l][0][1]; }
+          it.clipX = cu.x; it.clipY = cu.y;
+          if( sbt )
+          {
+            // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the motion of the 8x8 sub-block from the motion field, the identical-motion
+            // shortcut (xCheckIdenticalMotion :404, not with weighted bi-prediction :408) decided per sub-block, clipped at its own position
+            const vvr_motion& m = p->motion[(size_t) ( it.y >> 2 ) * w4 + ( it.x >> 2 )];
+            for( int l = 0; l < 2; l++ ) { it.ref[l] = m.ref_idx[l]; it.mv[l][0] = m.mv[l][0]; it.mv[l][1] = m.mv[l][1]; }
+            const bool two = it.ref[0] >= 0 && it.ref[1] >= 0;
+            uni = !two || ( h.ref_poc[0][it.ref[0]] == h.ref_poc[1][it.ref[1]] && it.mv[0][0] == it.mv[1][0] && it.mv[0][1] == it.mv[1][1] && !wpOn );
+            it.clipX = it.x; it.clipY = it.y;
+          }
+          it.bcw = cu.bcw_idx;
+          it.flags |= ( uni ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 );
+        }
         ( dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc ).push_back( it );
         const double smp = (double) it.w * it.h * ( ncomp == 3 ? 1.5 : 1.0 );
         const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;

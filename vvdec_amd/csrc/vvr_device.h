@@ -26,7 +26,17 @@ struct McItem {
   uint8_t  w, h;       // luma size: 4, 8 or 16
   uint16_t flags;      // MC_ITEM_*
   uint32_t cu;         // index into the CU array
+  // plain (k_mc) tiles are self-contained: the kernel starts its reference fetch after ONE dependent load (this record) instead of
+  // item -> CU -> motion field; GPM tiles still read their CU
+  int32_t  mv[2][2];   // motion vectors of the two lists (1/16 sample), unclipped
+  int8_t   ref[2];     // reference indices (-1: list not used)
+  uint8_t  bcw;        // BCW weight index (2 = equal weights)
+  uint8_t  pad;
+  uint16_t clipX, clipY;   // position the MV clipping refers to (the CU, or the sub-block itself for SbTMVP)
 };
+#define MC_ITEM_UNI   2    /* one prediction only: a single list, or identical motion in both (xCheckIdenticalMotion) */
+#define MC_ITEM_HPEL  4    /* half-sample AMVR: alternative luma half-sample filter */
+#define MC_ITEM_GEO   8
 
 // One transform block that carries a residual.
 struct TbItem {

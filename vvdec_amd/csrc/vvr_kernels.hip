@@ -432,24 +432,16 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   const int item = mc_item_index();
   if( item >= numItems ) return;
   const McItem it = items[item];
-  const vvr_cu& cu = pic.cu[it.cu];
   const int bd = pic.hdr.bit_depth;
   const int tid = threadIdx.x;
-  // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the tile is one 8x8 sub-block whose motion comes from the motion field; it goes
-  // through the plain uni / bi path with the identical-motion shortcut (xCheckIdenticalMotion :404), clipped at its own position
-  const bool sub = ( it.flags & MC_ITEM_SUBBLOCK ) != 0;
-  int mRef[2] = { cu.ref_idx[0], cu.ref_idx[1] }, mMv[2][2] = { { cu.mv[0][0][0], cu.mv[0][0][1] }, { cu.mv[1][0][0], cu.mv[1][0][1] } };
-  bool uni = cu.mc_mode == VVR_MC_UNI;
-  if( sub )
-  {
-    const vvr_motion& m = pic.motion[(size_t) ( it.y >> 2 ) * pic.w4 + ( it.x >> 2 )];
-    for( int l = 0; l < 2; l++ ) { mRef[l] = m.ref_idx[l]; mMv[l][0] = m.mv[l][0]; mMv[l][1] = m.mv[l][1]; }
-    const bool two = mRef[0] >= 0 && mRef[1] >= 0;
-    uni = !two || ( pic.hdr.ref_poc[0][mRef[0]] == pic.hdr.ref_poc[1][mRef[1]] && mMv[0][0] == mMv[1][0] && mMv[0][1] == mMv[1][1] && !pic.wp /* :408 */ );
-  }
-  const int clipX = sub ? it.x : cu.x, clipY = sub ? it.y : cu.y;
+  // the tile record is self-contained (motion of the CU, or of the 8x8 sub-block for SbTMVP, with the identical-motion shortcut already
+  // decided, xCheckIdenticalMotion :404); only GPM tiles read their CU (split direction, the two uni-directional motions)
+  const bool geo = ( it.flags & MC_ITEM_GEO ) != 0;       // motionCompensationGeo (:1461): two uni-predictions kept at 14 bit, blended with the GPM masks
+  const vvr_cu& cu = pic.cu[it.cu];                      // (dereferenced for GPM tiles only)
+  const int mRef[2] = { it.ref[0], it.ref[1] };
+  const bool uni = ( it.flags & MC_ITEM_UNI ) != 0;
+  const int clipX = it.clipX, clipY = it.clipY;
   const bool biPred = mRef[0] >= 0 && mRef[1] >= 0;
-  const bool geo = cu.mc_mode == VVR_MC_GEO;            // motionCompensationGeo (:1461): two uni-predictions kept at 14 bit, blended with the GPM masks
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
   const int l0 = uni ? ( ( biPred || mRef[0] >= 0 ) ? 0 : 1 ) : 0;
   const int nl = uni ? 1 : 2;
@@ -462,8 +454,8 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
     if( k < nl && c < ncomp )
     {
       const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
-      const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : mRef[l];
-      int mvx = geo ? cu.geo_mv[k][0] : mMv[l][0], mvy = geo ? cu.geo_mv[k][1] : mMv[l][1];
+      const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : ( l ? mRef[1] : mRef[0] );
+      int mvx = geo ? cu.geo_mv[k][0] : ( l ? it.mv[1][0] : it.mv[0][0] ), mvy = geo ? cu.geo_mv[k][1] : ( l ? it.mv[1][1] : it.mv[0][1] );
       mc_clip_mv( pic, clipX, clipY, mvx, mvy );         // clipped with the CU position (InterPrediction.cpp:657 uses m_currCuArea)
       McSeg g;
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
@@ -476,7 +468,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
       m.seg[k][c] = g;
       m.refp[k][c] = refs.p[l * VVR_MAX_REFS + refIdx][c];
-      mc_taps( g, c, cu.imv == 3, m.coefH[k][c], m.coefV[k][c] );      // frac 0 selects the identity filter { .., 64, .. }
+      mc_taps( g, c, ( it.flags & MC_ITEM_HPEL ) != 0, m.coefH[k][c], m.coefV[k][c] );      // frac 0 selects the identity filter { .., 64, .. }
     }
   }
   __syncthreads();
@@ -486,8 +478,8 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   __syncthreads();
   mc2_stage1<NT>( m, nl, ncomp, it.w, it.h, headroom, tid );
   __syncthreads();
-  const bool wpOn = !BDOF && pic.wp && !geo && cu.bcw_idx == 2;          // xPredInterBi (:707,735-742)
-  mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, uni, cu, geo, cu.bcw_idx, bd, headroom, reco, it.x, it.y, it.w, it.h, tid,
+  const bool wpOn = !BDOF && pic.wp && !geo && it.bcw == 2;          // xPredInterBi (:707,735-742)
+  mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, uni, cu, geo, it.bcw, bd, headroom, reco, it.x, it.y, it.w, it.h, tid,
                   wpOn ? pic.wp : nullptr, l0, mRef[0], mRef[1] );
   if constexpr( BDOF )
   {
