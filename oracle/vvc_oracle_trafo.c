@@ -197,7 +197,14 @@ int vvo_residual_block( const vvr_pic_header* hdr, const vvr_cu* cu, const vvr_t
       const int rnd = 1 << ( shift2 - 1 );
       for( int y = 0; y < bh; y++ ) for( int x = 0; x < bw; x++ ) resi[y * rstride + x] = (int16_t) vvo_clip3( -32768, 32767, ( blk[y * bw + x] + rnd ) >> shift2 );
     }
-    else { free( dq ); free( tmp ); free( blk ); vvo_set_error( "1-D transform blocks are not restated" ); return -1; }
+    else
+    {   /* 1-D blocks (ISP partitions of 4xN / Nx4 CUs): one pass, no intermediate clipping, shift_2nd + 1 (TrQuant.cpp:466-482) */
+      const int n = bw == 1 ? bh : bw, tr = bw == 1 ? trVer : trHor, maxPos = bw == 1 ? maxY : maxX;
+      const int skip = vvo_max( ( tr != 0 && n == 32 ) ? 16 : n > 32 ? n - 32 : 0, n - maxPos - 1 );
+      const int sh = shift2 + 1, rnd = 1 << ( sh - 1 );
+      inv_pass( dq, blk, tr_matrix( tr, n ), n, 1, 0, skip, 0, sh );
+      for( int y = 0; y < bh; y++ ) for( int x = 0; x < bw; x++ ) resi[y * rstride + x] = (int16_t) vvo_clip3( -32768, 32767, ( blk[y * bw + x] + rnd ) >> sh );
+    }
   }
   free( dq ); free( tmp ); free( blk );
   return 0;

@@ -52,6 +52,7 @@ CASES = [
     ("i_256x192_ctu128_dual_tree", 256, 192, 7, 0, 40, ALL | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(dual_tree=1.0, p_cclm=0.3, p_lfnst=0.4, p_isp=0.2, p_mip=0.2, p_coded_chroma=0.6, p_jccr=0.2)),
     ("i_200x136_ctu32_dual_tree", 200, 136, 5, 0, 41, ALL, dict(dual_tree=1.0, p_cclm=0.4, p_coded_chroma=0.6)),
     ("i_256x128_ctu64_dual_tree_4xn_implicit_mts", 256, 128, 6, 0, 42, ALL | abi.TOOL_IMPLICIT_MTS, dict(dual_tree=2.0, p_cclm=0.3, p_lfnst=0.4, p_isp=0.2, p_mip=0.3, p_coded=0.7, p_coded_chroma=0.5, p_split_scale=1.5)),
+    ("i_256x128_ctu64_isp_4xn", 256, 128, 6, 0, 43, ALL | abi.TOOL_IMPLICIT_MTS, dict(dual_tree=3.0, p_isp=0.7, p_lfnst=0.3, p_coded=0.8, p_split_scale=1.8)),
     ("b_256x192_ctu128_all_inter", 256, 192, 7, 2, 26, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.1, p_affine=0.2, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.2)),
 ]
 

@@ -261,6 +261,9 @@ def test_dual_tree_intra_pictures(built):
     # luma CUs down to 4x4 (4x4 MIP / LFNST / BDPCM blocks), implicit MTS
     _run_stream(256, 128, 3, 2, 244, TOOLS_A | abi.TOOL_IMPLICIT_MTS, intra=True, dual_tree=2.0, p_cclm=0.3, p_lfnst=0.4, p_isp=0.2, p_mip=0.3, p_coded=0.7, p_split_scale=1.5)
     _run_stream(1920, 1080, 2, 1, 245, TOOLS_A | abi.TOOL_IMPLICIT_MTS, intra=True, dual_tree=2.0, p_mip=0.1, p_isp=0.1, p_split_scale=1.3)
+    # ISP on 4xN / Nx4 CUs: 1xN, Nx1 (1-D transforms), 2xN, Nx2 partitions, groups of four 1-wide partitions predicted together
+    _run_stream(256, 128, 3, 2, 246, TOOLS_A | abi.TOOL_IMPLICIT_MTS, intra=True, dual_tree=3.0, p_isp=0.7, p_lfnst=0.3, p_coded=0.8, p_split_scale=1.8)
+    _run_stream(416, 240, 2, 1, 247, TOOLS_A, intra=True, log2_ctu=5, dual_tree=3.0, p_isp=0.6, p_coded=0.8, p_split_scale=2.0)
 
 
 def test_joint_cbcr(built):

@@ -48,6 +48,8 @@ def _case(W, H, l2, idx, seed, tools=ALL, **kw):
     (200, 136, 5, 0, 125, dict(dual_tree=1.0, p_cclm=0.4, p_jccr=0.3, p_coded_chroma=0.6)),
     (384, 256, 6, 0, 126, dict(dual_tree=1.0, p_split_scale=0.6, p_lfnst=0.4, p_bdpcm=0.2)),
     (256, 128, 6, 0, 129, dict(dual_tree=2.0, p_cclm=0.4, p_lfnst=0.5, p_isp=0.3, p_mip=0.3, p_coded_chroma=0.6, p_split_scale=1.5)),
+    (256, 128, 6, 0, 131, dict(dual_tree=3.0, p_isp=0.7, p_split_scale=1.8, p_coded=0.8, p_lfnst=0.3)),
+    (200, 136, 5, 0, 132, dict(dual_tree=3.0, p_isp=0.6, p_split_scale=2.0, p_coded=0.8)),
 ])
 def test_oracle_equals_reference_every_stage(built, W, H, l2, idx, seed, kw):
     d, refs = _case(W, H, l2, idx, seed, **kw)
@@ -147,7 +149,7 @@ def test_edge_parameters_match_reference_derivation(built):
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     for args, kw in (((256, 128, 7, 0, 122), dict(p_isp=0.7, p_split_scale=1.6)), ((384, 256, 6, 2, 123), dict(p_isp=0.5, p_intra=0.4, p_cclm=0.3)),
                      ((384, 256, 7, 0, 127), dict(dual_tree=1.0, p_isp=0.2, p_bdpcm=0.3, p_coded_chroma=0.6)),
-                     ((256, 128, 6, 0, 130), dict(dual_tree=2.0, p_split_scale=1.5, p_isp=0.2)), ((256, 128, 6, 2, 128), dict(p_bdpcm=0.5, p_intra=0.6))):
+                     ((256, 128, 6, 0, 130), dict(dual_tree=2.0, p_split_scale=1.5, p_isp=0.2)), ((256, 128, 6, 0, 133), dict(dual_tree=3.0, p_split_scale=1.8, p_isp=0.7)), ((256, 128, 6, 2, 128), dict(p_bdpcm=0.5, p_intra=0.6))):
         d, refs = _case(*args, **kw)                                                       # ISP: partition edges, unsplit chroma
         a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
         b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]

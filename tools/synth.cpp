@@ -68,7 +68,7 @@ typedef struct vvs_params {
   float    p_mip;               // of intra CUs: matrix-based luma prediction
   float    p_sbt;               // of inter CUs (not CIIP, at most 64x64): sub-block transform (residual in one half / quarter of the CU)
   float    p_isp;               // of intra CUs (no MRL / BDPCM / MIP): intra sub-partitions, four luma partitions predicted one after the other
-  float    dual_tree;           // > 0: I pictures use separate luma and chroma coding trees below 64x64 (qtbtt_dual_tree_intra_flag); 2: luma CUs down to 4x4
+  float    dual_tree;           // > 0: I pictures use separate luma and chroma coding trees below 64x64 (qtbtt_dual_tree_intra_flag); 2: luma CUs down to 4x4; 3: and ISP on 4xN / Nx4 CUs (1xN, Nx1, 2xN, Nx2 partitions)
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -268,8 +268,9 @@ struct Gen {
       }
       // intra sub-partitions: horizontal (1) or vertical (2) split of the luma block in four (CU::canUseISP: more than 16 samples,
       // at most the maximum transform size); LFNST only while the partitions are at least 4x4 (CU::canUseLfnstWithISP)
-      if( P.p_isp > 0 && !treeC && w >= 8 && h >= 8 && !( treeL && w == 64 && h == 64 ) && !cu.bdpcm[0] && !cu.multi_ref_idx && !( cu.flags & VVR_CU_MIP ) && w <= 64 && h <= 64 && rng.p( P.p_isp ) ) cu.isp_mode = (uint8_t) ( 1 + rng.u( 2 ) );
-      const bool ispNoLfnst = cu.isp_mode && ( cu.isp_mode == 1 ? h / 4 < 4 : w / 4 < 4 );
+      if( P.p_isp > 0 && !treeC && w * h > 16 && ( ( w >= 8 && h >= 8 ) || P.dual_tree >= 3.0f ) && !( treeL && w == 64 && h == 64 ) && !cu.bdpcm[0] && !cu.multi_ref_idx && !( cu.flags & VVR_CU_MIP ) && w <= 64 && h <= 64 && rng.p( P.p_isp ) ) cu.isp_mode = (uint8_t) ( 1 + rng.u( 2 ) );
+      const int ispParts = ( ( w == 4 && h == 8 ) || ( w == 8 && h == 4 ) ) ? 2 : 4;      // 4x8 / 8x4 CUs are split in two
+      const bool ispNoLfnst = cu.isp_mode && ( cu.isp_mode == 1 ? h / ispParts < 4 : w / ispParts < 4 );
       // LFNST index (luma of single-tree CUs): needs DCT2 and a residual confined to the first 8/16 scan positions, see genLevels
       if( !treeC && ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && ( !( cu.flags & VVR_CU_MIP ) || ( w >= 16 && h >= 16 ) ) && !ispNoLfnst && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
     }
@@ -389,7 +390,8 @@ struct Gen {
     }
     else if( cu.isp_mode )
     {
-      for( int k = 0; k < 4; k++ ) tbs[ntb++] = cu.isp_mode == 1 ? Tb{ 0, k * ( h / 4 ), w, h / 4, true } : Tb{ k * ( w / 4 ), 0, w / 4, h, true };
+      const int np = ( ( w == 4 && h == 8 ) || ( w == 8 && h == 4 ) ) ? 2 : 4;
+      for( int k = 0; k < np; k++ ) tbs[ntb++] = cu.isp_mode == 1 ? Tb{ 0, k * ( h / np ), w, h / np, true } : Tb{ k * ( w / np ), 0, w / np, h, true };
     }
     else for( int ty = 0; ty < h; ty += th ) for( int tx = 0; tx < w; tx += tw ) tbs[ntb++] = Tb{ tx, ty, tw, th, true };
     bool ispAnyLuma = false;

@@ -293,12 +293,13 @@ static int validate( vvr_context* c, const vvr_picture* p )
       if( cu.isp_mode )
       {
         // intra sub-partitions (CU::canUseISP, UnitTools.cpp): luma split in four, chroma unsplit in the last TU
-        if( cu.isp_mode > 2 || cu.multi_ref_idx || cu.bdpcm[0] || ( cu.flags & VVR_CU_MIP ) || cu.num_tu != 4 ) { c->setError( "ISP CU: bad split mode, combined with MRL / BDPCM / MIP, or not four TUs" ); return VVR_ERR_PARAMETER; }
-        for( uint32_t k = 0; k < 4; k++ )
+        const uint32_t np = ( ( cu.w == 4 && cu.h == 8 ) || ( cu.w == 8 && cu.h == 4 ) ) ? 2 : 4;      // 4x8 / 8x4: two partitions
+        if( cu.isp_mode > 2 || cu.multi_ref_idx || cu.bdpcm[0] || ( cu.flags & VVR_CU_MIP ) || cu.num_tu != np || cu.w * cu.h <= 16 ) { c->setError( "ISP CU: bad split mode, combined with MRL / BDPCM / MIP, or wrong number of TUs" ); return VVR_ERR_PARAMETER; }
+        for( uint32_t k = 0; k < np; k++ )
         {
           const vvr_tu& t4 = p->tu[cu.first_tu + k];
-          const bool ok = cu.isp_mode == 1 ? ( t4.x == cu.x && t4.w == cu.w && t4.h * 4 == cu.h && t4.y == cu.y + (int) k * t4.h ) : ( t4.y == cu.y && t4.h == cu.h && t4.w * 4 == cu.w && t4.x == cu.x + (int) k * t4.w );
-          if( !ok || ( t4.comp_mask & 6 ) != ( k == 3 && h.chroma_format && cu.tree == VVR_TREE_JOINT ? 6 : 0 ) || t4.mts_idx[0] == VVR_MTS_SKIP ) { c->setError( "ISP CU: TU layout" ); return VVR_ERR_PARAMETER; }
+          const bool ok = cu.isp_mode == 1 ? ( t4.x == cu.x && t4.w == cu.w && t4.h * (int) np == cu.h && t4.y == cu.y + (int) k * t4.h ) : ( t4.y == cu.y && t4.h == cu.h && t4.w * (int) np == cu.w && t4.x == cu.x + (int) k * t4.w );
+          if( !ok || ( t4.comp_mask & 6 ) != ( k == np - 1 && h.chroma_format && cu.tree == VVR_TREE_JOINT ? 6 : 0 ) || t4.mts_idx[0] == VVR_MTS_SKIP ) { c->setError( "ISP CU: TU layout" ); return VVR_ERR_PARAMETER; }
         }
       }
       if( cu.flags & VVR_CU_MIP )
@@ -308,10 +309,9 @@ static int validate( vvr_context* c, const vvr_picture* p )
       }
       if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] > 69 ) { c->setError( "chroma intra mode out of range" ); return VVR_ERR_PARAMETER; }
       {
-        // luma-tree CUs of dual-tree pictures go down to 4x4; a 4-wide CU with chroma (2xN chroma blocks / local dual tree) and ISP of
-        // 4xN CUs (1xN partitions) are not in this build
-        const int minSize = cu.tree == VVR_TREE_LUMA && !cu.isp_mode ? 4 : 8;
-        if( cu.w > 64 || cu.h > 64 || cu.w < minSize || cu.h < minSize ) { c->setError( "intra CU size outside 8..64 (4..64 for luma-tree CUs without ISP) is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+        // luma-tree CUs of dual-tree pictures go down to 4x4; a 4-wide CU with chroma (2xN chroma blocks / local dual tree) is not in this build
+        const int minSize = cu.tree == VVR_TREE_LUMA ? 4 : 8;
+        if( cu.w > 64 || cu.h > 64 || cu.w < minSize || cu.h < minSize ) { c->setError( "intra CU size outside 8..64 (4..64 for luma-tree CUs) is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
       }
       if( cu.tree != VVR_TREE_JOINT )
       {
@@ -461,8 +461,8 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           // (initIntraPatternChTypeISP, IntraPrediction.cpp:966); partitions narrower than 4 are predicted in pairs (DecCu.cpp:333-371):
           // one item of width 4 carries both; the unsplit chroma blocks come with the last TU
           const bool ispL = cu.isp_mode && !comp, ispC = cu.isp_mode && comp;
-          const bool ispPair = ispL && cu.isp_mode == 2 && tu.w < 4;
-          if( ispPair && ( ( tu.x - cu.x ) & 3 ) ) continue;                                      // second of a pair: part of the previous item
+          const bool ispPair = ispL && cu.isp_mode == 2 && tu.w < 4;                              // group of 4 / tu.w partitions
+          if( ispPair && ( ( tu.x - cu.x ) & 3 ) ) continue;                                      // not the first of its group: part of the group's item
           const int x0 = ( ispC ? cu.x : tu.x ) >> cs, y0 = ( ispC ? cu.y : tu.y ) >> cs, w = ispPair ? 4 : ( ispC ? cu.w : tu.w ) >> cs, hh = ( ispC ? cu.h : tu.h ) >> cs;
           // block whose neighbourhood decides the availability of the reference samples
           const int rx0 = ispL ? cu.x : x0, ry0 = ispL ? cu.y : y0, rw = ispL ? cu.w : w, rh = ispL ? cu.h : hh;
@@ -476,11 +476,16 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
           if( ispL )
           {
-            const int second = ispPair && t + 1 < cu.first_tu + cu.num_tu ? ( p->tu[t + 1].cbf & 1 ) : 0;
-            // geometry of the partition inside its CU, residual flags of the two halves of a pair
+            // residual flags of the partitions of a group (2 of width 2, or 4 of width 1), geometry of the partition inside its CU
+            uint32_t mask = tu.cbf & 1, grp = 0;
+            if( ispPair )
+            {
+              grp = tu.w == 2 ? 1 : 2;
+              for( uint32_t k = 1; k < 4u / tu.w && t + k < cu.first_tu + cu.num_tu; k++ ) mask |= (uint32_t) ( p->tu[t + k].cbf & 1 ) << k;
+            }
             it.tu = (uint32_t) ( tu.x - cu.x ) | ( (uint32_t) ( tu.y - cu.y ) << 6 ) | ( (uint32_t) ilog2i( cu.w ) << 12 ) | ( (uint32_t) ilog2i( cu.h ) << 15 )
-                  | ( (uint32_t) ( cu.isp_mode == 2 ) << 18 ) | ( (uint32_t) ( ( tu.cbf & 1 ) | ( second << 1 ) ) << 19 ) | ( (uint32_t) ispPair << 21 );
-            hasResi = hasResi || second;
+                  | ( (uint32_t) ( cu.isp_mode == 2 ) << 18 ) | ( mask << 19 ) | ( grp << 23 );
+            hasResi = mask != 0;
           }
           const int bdp = ( isCiip || isCsInter ) ? 0 : cu.bdpcm[chn];
           // CIIP blend weight of the intra part (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:925-929): 1 + intra neighbours
@@ -633,7 +638,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         }
         else if( !( tu.cbf & ( 1 << comp ) ) ) continue;
         const int bw = ( ( it.comp && cu.isp_mode ) ? cu.w : tu.w ) >> ( it.comp ? 1 : 0 ), bh = ( ( it.comp && cu.isp_mode ) ? cu.h : tu.h ) >> ( it.comp ? 1 : 0 );
-        if( bw < 2 || bh < 2 ) { c->setError( "1-D transform blocks are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+        if( ( bw < 2 || bh < 2 ) && !( cu.isp_mode && !it.comp && bw * bh >= 16 ) ) { c->setError( "1-D transform block outside an ISP CU" ); return VVR_ERR_PARAMETER; }
         const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
         // LMCS chroma residual scaling of an inter block: the factor needs the reconstructed luma around the VPDU, which the intra stage
         // may still have to produce -> late list.  (STORE items are scaled by k_intra when it reads the residual.)

@@ -55,7 +55,7 @@ enum { TB_ADD = 0, TB_STORE = 1 };
 #define IT_F_BDPCM_H  2
 #define IT_F_MIP      8      /* luma: matrix-based intra prediction: mode = matrix index, bit 4 = transposed */
 #define IT_F_ISP      6   /* both BDPCM bits (never together otherwise): luma intra sub-partition; IntraItem::tu then holds x - cuX | ( y - cuY ) << 6
-                             | log2 cuW << 12 | log2 cuH << 15 | vertical split << 18 | residual flags of the two halves of a pair << 19 | pair << 21 */
+                             | log2 cuW << 12 | log2 cuH << 15 | vertical split << 18 | residual flags of the partitions of a group << 19 (4 bits) | group << 23 (1: two 2-wide, 2: four 1-wide partitions) */
 #define IT_MODE_RESI_ADD 255 /* mode value: no prediction, the (LMCS-scaled) residual is added to the inter prediction already in the picture */
 #define IT_F_CSCALE   8      /* chroma: LMCS chroma residual scaling applies to the residual */
 #define IT_F_BDPCM_V  4      /* bits 4..5: multi-reference-line index; bits 6..7: CIIP intra weight (0 = ordinary intra block) */

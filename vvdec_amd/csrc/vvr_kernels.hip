@@ -1210,12 +1210,26 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
   const int trHor = tu.tr_type[comp] & 3, trVer = tu.tr_type[comp] >> 2;
   const int shift1 = 7, shift2 = 20 - bd;
   const bool dcOnly = !isTS && maxX == 0 && maxY == 0 && trHor == 0 && trVer == 0;
+  const bool oneD = !isTS && ( bw == 1 || bh == 1 );        // ISP partitions of 4xN / Nx4 CUs: one pass, shift_2nd + 1 (TrQuant.cpp:466-482)
   int redW = 0;
   int dcVal = 0;
   if( dcOnly )
   {
-    dcVal = ( dq[0] * 64 + ( 1 << ( shift1 - 1 ) ) ) >> shift1;
-    dcVal = (int16_t) ( ( dcVal * 64 + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
+    if( oneD ) dcVal = (int16_t) ( ( dq[0] * 64 + ( 1 << shift2 ) ) >> ( shift2 + 1 ) );
+    else
+    {
+      dcVal = ( dq[0] * 64 + ( 1 << ( shift1 - 1 ) ) ) >> shift1;
+      dcVal = (int16_t) ( ( dcVal * 64 + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
+    }
+  }
+  else if( oneD )
+  {
+    const int n1 = bw == 1 ? bh : bw, tr = bw == 1 ? trVer : trHor, maxPos = bw == 1 ? maxY : maxX;
+    const int skip = max( ( tr != 0 && n1 == 32 ) ? 16 : n1 > 32 ? n1 - 32 : 0, n1 - maxPos - 1 );
+    redW = n1 - skip;                                        // rows of the basis that take part
+    const int16_t* __restrict__ M1 = tr_matrix( tr, n1 );
+    for( int i = tid; i < redW * n1; i += NT ) mhS[i] = M1[i];
+    __syncthreads();
   }
   else if( !isTS )
   {
@@ -1247,6 +1261,13 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
     int r;
     if( isTS ) r = (int16_t) dq[i];
     else if( dcOnly ) r = dcVal;
+    else if( oneD )
+    {
+      const int n1 = bw == 1 ? bh : bw;
+      int sum = 0;
+      for( int k = 0; k < redW; k++ ) sum += dq[k] * mhS[k * n1 + i];        // (i runs along the only dimension)
+      r = clip3( -32768, 32767, ( sum + ( 1 << shift2 ) ) >> ( shift2 + 1 ) );
+    }
     else
     {
       // out[y*bw + x] = clip16( ( sum_{k<redW} tmp[k*bh + y] * Mh[k*bw + x] + rnd ) >> shift2 )
@@ -2195,8 +2216,9 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const bool isp = !comp && ( it.flags & IT_F_ISP ) == IT_F_ISP;
       const uint32_t ispw = isp ? it.tu : 0;
       const int ispDx = ispw & 63, ispDy = ( ispw >> 6 ) & 63, cuW = 1 << ( ( ispw >> 12 ) & 7 ), cuH = 1 << ( ( ispw >> 15 ) & 7 );
-      const bool ispVer = ( ispw >> 18 ) & 1, ispPair = ( ispw >> 21 ) & 1;
-      const int ispResi = ( ispw >> 19 ) & 3;
+      const bool ispVer = ( ispw >> 18 ) & 1;
+      const int ispGrp = ( ispw >> 23 ) & 3;          // partitions narrower than 4 are predicted in groups of width 4: 1 = two 2-wide, 2 = four 1-wide
+      const int ispResi = ( ispw >> 19 ) & 15;
       const int bdpcm = isp ? 0 : ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
       const int dirMode = it.mode;
       const bool hasResi = ( it.flags & IT_F_RESI ) != 0;
@@ -2622,7 +2644,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           v = (int16_t) ( v + ( ( wL * ( L[y + 1] - v ) + wT * ( T[x + 1] - v ) + 32 ) >> 6 ) );
         }
         if( wIntra ) v = ( ( 4 - wIntra ) * TILE( x0 + x, y0 + y ) + wIntra * v + 2 ) >> 2;     // predBlendIntraCiip (:935-944): the tile holds the inter prediction
-        if( hasResi && ( !ispPair || ( ( ispResi >> ( x >> 1 ) ) & 1 ) ) ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
+        if( hasResi && ( !ispGrp || ( ( ispResi >> ( x >> ( 2 - ispGrp ) ) ) & 1 ) ) ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
         TILE( x0 + x, y0 + y ) = (pel_t) v;
       }
       IT_PH( trC )
