@@ -384,7 +384,7 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
     w = 4;
   }
   if( comp && cu->intra_dir[1] > MDLM_T_IDX ) { vvo_set_error( "bad chroma intra mode" ); return -1; }
-  if( !isp && ( w < 4 || h < 4 ) ) { vvo_set_error( "intra blocks narrower than 4 are not restated" ); return -1; }
+  if( !isp && ( w < 4 || h < ( comp ? 2 : 4 ) ) ) { vvo_set_error( "intra blocks narrower than 4 are not restated" ); return -1; }     /* (chroma Nx2 blocks of Nx4 luma CUs exist; 2xN ones do not) */
   const int mrl = comp ? 0 : cu->multi_ref_idx;
   const int bdpcm = comp ? cu->bdpcm[1] : cu->bdpcm[0];
   const int dirMode = cu->intra_dir[ch];

@@ -266,6 +266,15 @@ def test_dual_tree_intra_pictures(built):
     _run_stream(416, 240, 2, 1, 247, TOOLS_A, intra=True, log2_ctu=5, dual_tree=3.0, p_isp=0.6, p_coded=0.8, p_split_scale=2.0)
 
 
+def test_small_cus_and_local_dual_tree(built):
+    """minimum CU size 4 in single-tree pictures: 4xN inter CUs with 2xN chroma blocks, Nx4 intra CUs with Nx2 chroma blocks, intra-only
+    sub-trees with a local dual tree (luma-tree CUs down to 4x4, one chroma-tree CU per node), in I and B pictures"""
+    T = TOOLS_A | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE
+    _run_stream(256, 128, 5, 4, 251, TOOLS_A, intra=True, min_cu_log2=2, p_intra=0.3, p_split_scale=1.8, p_cclm=0.3, p_isp=0.2, p_mip=0.2)
+    _run_stream(416, 240, 3, 2, 252, T, intra=True, log2_ctu=5, min_cu_log2=2, p_intra=0.25, p_split_scale=2.0, p_sbt=0.2, p_cclm=0.3, p_jccr=0.2, p_coded_chroma=0.5)
+    _run_stream(1920, 1080, 3, 2, 253, T, intra=True, streams=3, min_cu_log2=2, p_split_scale=1.5, p_affine=0.1, p_ciip=0.05)
+
+
 def test_joint_cbcr(built):
     """tu_joint_cbcr_residual: one coded chroma block, the other derived (all three modes, both signs)"""
     _run_stream(256, 128, 5, 4, 171, TOOLS_A, intra=True, p_jccr=0.7, p_coded_chroma=0.7, p_intra=0.3)
@@ -306,11 +315,8 @@ def test_unsupported_tools_fail_loudly(built):
     d.cu["pred_mode"][0] = abi.PRED_IBC                    # intra block copy: not reconstructed by this build
     with pytest.raises(vvdec_amd.VvrError):
         rec.decompress_picture(d)
-    p.slice_type = abi.SLICE_B
-    synth.set_refs(p, [(1, 0)], [(1, 0)])
-    p.poc = 1
     d = synth.generate(p)
-    d.cu["tree"][0] = abi.TREE_LUMA                        # separate trees outside intra pictures (local dual tree): not in this build
+    d.cu["tree"][0] = abi.TREE_LUMA                        # a luma-tree CU whose TUs still carry chroma: inconsistent description
     with pytest.raises(vvdec_amd.VvrError):
         rec.decompress_picture(d)
     rec.close()

@@ -132,6 +132,24 @@ def test_oracle_equals_reference_implicit_mts(built, l2, idx, seed, kw):
         assert np.array_equal(got[c], want[c]), "comp %d: %d differ" % (c, int((got[c] != want[c]).sum()))
 
 
+@pytest.mark.parametrize("W,H,l2,idx,seed,tools,kw", [
+    (256, 128, 6, 2, 251, ALL, dict(p_intra=0.3, p_split_scale=1.8)),
+    (256, 128, 7, 0, 252, ALL, dict(p_split_scale=1.8, p_cclm=0.3, p_isp=0.3, p_mip=0.2, p_lfnst=0.3)),
+    (200, 136, 5, 3, 253, ALL | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.25, p_split_scale=2.0, p_sbt=0.2, p_cclm=0.3, p_jccr=0.2, p_coded_chroma=0.5)),
+    (384, 256, 6, 1, 254, ALL | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP, dict(p_intra=0.2, p_split_scale=1.7, p_isp=0.2, p_coded_chroma=0.5)),
+])
+def test_oracle_equals_reference_small_cus(built, W, H, l2, idx, seed, tools, kw):
+    """minimum CU size 4: 4xN inter CUs (2xN chroma blocks), Nx4 intra CUs (Nx2 chroma blocks), and the local dual tree of intra-only
+    sub-trees (luma-tree CUs down to 4x4 + one chroma-tree CU per node) in I and B pictures; edge parameters included"""
+    d, refs = _case(W, H, l2, idx, seed, tools=tools, min_cu_log2=2, **kw)
+    assert int((d.cu["tree"] == abi.TREE_CHROMA).sum()) > 0 and int(((d.cu["w"] == 4) | (d.cu["h"] == 4)).sum()) > 0
+    for fl in (refdrv.STOP_AFTER_RECO, 0, refdrv.DERIVE_LFP):
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl & ~refdrv.DERIVE_LFP)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+
+
 def test_reference_simd_equals_scalar(built):
     """the reference's own differential check (its unit test compares scalar vs SIMD kernels): same bytes at frame level"""
     d, refs = _case(256, 192, 7, 2, 106, p_intra=0.2)

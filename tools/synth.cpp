@@ -94,7 +94,7 @@ void vvs_bounds( const vvs_params* P, uint32_t* max_cu, uint32_t* max_tu, uint64
 {
   const uint32_t m = 1u << P->min_cu_log2;
   const uint32_t n = ( ( P->width + m - 1 ) / m ) * ( ( P->height + m - 1 ) / m );
-  const uint32_t trees = P->dual_tree >= 2.0f ? 5 : P->dual_tree > 0 ? 2 : 1;                 // dual tree: luma and chroma CUs (luma down to 4x4: four times as many)
+  const uint32_t trees = P->dual_tree >= 2.0f ? 5 : ( P->dual_tree > 0 || P->min_cu_log2 == 2 ) ? 2 : 1;                 // dual tree: luma and chroma CUs (luma down to 4x4: four times as many)
   *max_cu = n * trees; *max_tu = ( P->p_isp > 0 ? 4 * n : n + n / 4 ) * trees + 16;      // ISP: four TUs per CU
   *max_coef = (uint64_t) P->width * P->height * 3 / 2 + 4096;
 }
@@ -119,6 +119,7 @@ struct Gen {
   std::vector<int32_t> tuOf4;      // per 4x4: TU index
   std::vector<int32_t> cuOf4C, tuOf4C;   // dual tree: the same maps of the chroma tree
   int curTree = VVR_TREE_JOINT;    // tree the CUs being added belong to
+  int modeType = 0;                // mode constraint of the current sub-tree (SCIPU): 0 all, 1 inter only, 2 intra only (local dual tree)
   bool cclmOk = true;              // CCLM allowed for the chroma CUs being added (CU::checkCCLMAllowed, UnitTools.cpp:3439)
   Gen( const vvs_params& p, vvs_buffers& b ) : P( p ), B( b ), rng( p.seed ) {}
 
@@ -231,7 +232,7 @@ struct Gen {
     cu.qp = (int8_t) std::min( 63, std::max( 0, P.base_qp + (int) rng.u( 7 ) - 3 ) );
     cu.bcw_idx = 2; cu.ref_idx[0] = cu.ref_idx[1] = -1;
     const bool isI = P.slice_type == 2;
-    const bool intra = isI || ( std::max( w, h ) <= 64 && rng.p( P.p_intra ) );
+    const bool intra = isI || modeType == 2 || ( modeType != 1 && std::max( w, h ) <= 64 && rng.p( P.p_intra ) );
     cu.pred_mode = intra ? VVR_PRED_INTRA : VVR_PRED_INTER;
     if( intra )
     {
@@ -250,7 +251,7 @@ struct Gen {
         if( rc < 40 ) cu.intra_dir[1] = colMode;
         cu.intra_dir[0] = colMode; cu.lfnst_intra_mode = colMode;
         // LFNST of a chroma tree CU applies to both chroma blocks (at least 4x4 each)
-        if( ( P.tool_flags & VVR_TOOL_LFNST ) && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
+        if( ( P.tool_flags & VVR_TOOL_LFNST ) && w >= 8 && h >= 8 && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );      // (lfnst_idx needs min( width, height ) >= 4 of the chroma blocks)
       }
       // multiple reference lines: luma only, never on the first row of a CTU, not with planar (intra_luma_ref_idx semantics)
       if( !treeC && ( y & ( ctu - 1 ) ) != 0 && cu.intra_dir[0] != 0 && rng.p( P.p_mrl ) ) cu.multi_ref_idx = (uint8_t) ( 1 + rng.u( 2 ) );
@@ -268,7 +269,7 @@ struct Gen {
       }
       // intra sub-partitions: horizontal (1) or vertical (2) split of the luma block in four (CU::canUseISP: more than 16 samples,
       // at most the maximum transform size); LFNST only while the partitions are at least 4x4 (CU::canUseLfnstWithISP)
-      if( P.p_isp > 0 && !treeC && w * h > 16 && ( ( w >= 8 && h >= 8 ) || P.dual_tree >= 3.0f ) && !( treeL && w == 64 && h == 64 ) && !cu.bdpcm[0] && !cu.multi_ref_idx && !( cu.flags & VVR_CU_MIP ) && w <= 64 && h <= 64 && rng.p( P.p_isp ) ) cu.isp_mode = (uint8_t) ( 1 + rng.u( 2 ) );
+      if( P.p_isp > 0 && !treeC && w * h > 16 && ( ( w >= 8 && h >= 8 ) || P.dual_tree >= 3.0f || P.min_cu_log2 == 2 ) && !( treeL && w == 64 && h == 64 ) && !cu.bdpcm[0] && !cu.multi_ref_idx && !( cu.flags & VVR_CU_MIP ) && w <= 64 && h <= 64 && rng.p( P.p_isp ) ) cu.isp_mode = (uint8_t) ( 1 + rng.u( 2 ) );
       const int ispParts = ( ( w == 4 && h == 8 ) || ( w == 8 && h == 4 ) ) ? 2 : 4;      // 4x8 / 8x4 CUs are split in two
       const bool ispNoLfnst = cu.isp_mode && ( cu.isp_mode == 1 ? h / ispParts < 4 : w / ispParts < 4 );
       // LFNST index (luma of single-tree CUs): needs DCT2 and a residual confined to the first 8/16 scan positions, see genLevels
@@ -549,10 +550,13 @@ struct Gen {
   void split( int x, int y, int w, int h )
   {
     if( x >= W || y >= H ) return;
-    const int minS = ( curTree == VVR_TREE_LUMA && P.dual_tree >= 2.0f ) ? 4 : 1 << P.min_cu_log2;      // dual_tree = 2: luma CUs down to 4x4
+    // smallest CU side: 4 in the luma tree of dual-tree pictures (dual_tree >= 2) and, with min_cu_log2 = 2, everywhere a 4-wide CU is
+    // legal (luma-tree CUs of a local dual tree, inter-only sub-trees); chroma-tree nodes stay at 8 luma samples (4 chroma)
+    const int minS = curTree == VVR_TREE_CHROMA ? 8 : ( curTree == VVR_TREE_LUMA && P.dual_tree >= 2.0f ) ? 4 : 1 << P.min_cu_log2;
     const bool crossX = x + w > W, crossY = y + h > H;
     if( crossX || crossY )
     {
+      const int minS = std::max( 8, 1 << P.min_cu_log2 );       // (implicit splits at the picture boundary stop at 8x8: picture sizes are multiples of 8)
       // implicit boundary split: quad when possible, else binary in the crossing direction
       if( w > minS && h > minS && ( ( crossX && crossY ) || w == h ) ) { const int hw = w >> 1, hh = h >> 1; split( x, y, hw, hh ); split( x + hw, y, hw, hh ); split( x, y + hh, hw, hh ); split( x + hw, y + hh, hw, hh ); }
       else if( w <= 64 && h > 64 ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); }                 // (VPDU rule first)
@@ -562,28 +566,57 @@ struct Gen {
       return;
     }
     const int s = std::max( w, h );
-    double ps = s >= 128 ? 0.92 : s >= 64 ? 0.70 : s >= 32 ? 0.45 : s >= 16 ? 0.25 : 0.0;
+    double ps = s >= 128 ? 0.92 : s >= 64 ? 0.70 : s >= 32 ? 0.45 : s >= 16 ? 0.25 : s >= 8 && minS < 8 ? 0.2 : 0.0;
     ps = std::min( 0.98, ps * P.p_split_scale );
     if( w != h && std::min( w, h ) <= minS ) ps *= 0.5;
     if( P.slice_type == 2 && s > 64 ) ps = 1.0;   // intra pictures: CUs <= 64
+    enum { S_NONE, S_QT, S_BV, S_BH, S_TV, S_TH };
+    int type = S_NONE;
     if( rng.p( ps ) )
     {
       const int r = rng.u( 100 );
       // VPDU rules of the standard (every 64x64 region is decoded completely before the next one, or a CU covers whole regions):
       // no vertical binary split of a block that is at most 64 wide but taller than 64, no horizontal one of a block wider than 64 but
-      // at most 64 tall, ternary splits only inside 64x64
-      const bool canQ = w == h && w > minS, canH = h > minS && !( w > 64 && h <= 64 ), canV = w > minS && !( w <= 64 && h > 64 );
-      const bool canTH = h >= 4 * minS && h <= 64 && w <= 64, canTV = w >= 4 * minS && w <= 64 && h <= 64;
-      if( canQ && r < 50 ) { const int hw = w >> 1; split( x, y, hw, hw ); split( x + hw, y, hw, hw ); split( x, y + hw, hw, hw ); split( x + hw, y + hw, hw, hw ); return; }
-      if( canV && ( r < 68 || !canH ) ) { split( x, y, w >> 1, h ); split( x + ( w >> 1 ), y, w >> 1, h ); return; }
-      if( canH && r < 86 ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); return; }
-      if( canTV && r < 93 ) { split( x, y, w >> 2, h ); split( x + ( w >> 2 ), y, w >> 1, h ); split( x + 3 * ( w >> 2 ), y, w >> 2, h ); return; }
-      if( canTH ) { split( x, y, w, h >> 2 ); split( x, y + ( h >> 2 ), w, h >> 1 ); split( x, y + 3 * ( h >> 2 ), w, h >> 2 ); return; }
-      if( canH ) { split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); return; }
-      if( canV ) { split( x, y, w >> 1, h ); split( x + ( w >> 1 ), y, w >> 1, h ); return; }
-      if( canQ ) { const int hw = w >> 1; split( x, y, hw, hw ); split( x + hw, y, hw, hw ); split( x, y + hw, hw, hw ); split( x + hw, y + hw, hw, hw ); return; }
+      // at most 64 tall, ternary splits only inside 64x64.  Inter-only sub-trees (SCIPU) keep at least 32 luma samples per CU.
+      const bool interOnly = modeType == 1;
+      const bool canQ = w == h && w > minS && !( interOnly && w * h <= 64 ), canH = h > minS && !( w > 64 && h <= 64 ) && !( interOnly && w * h <= 32 ), canV = w > minS && !( w <= 64 && h > 64 ) && !( interOnly && w * h <= 32 );
+      const bool canTH = h >= 4 * minS && h <= 64 && w <= 64 && !( interOnly && w * h <= 64 ), canTV = w >= 4 * minS && w <= 64 && h <= 64 && !( interOnly && w * h <= 64 );
+      if( canQ && r < 50 ) type = S_QT;
+      else if( canV && ( r < 68 || !canH ) ) type = S_BV;
+      else if( canH && r < 86 ) type = S_BH;
+      else if( canTV && r < 93 ) type = S_TV;
+      else if( canTH ) type = S_TH;
+      else if( canH ) type = S_BH;
+      else if( canV ) type = S_BV;
+      else if( canQ ) type = S_QT;
     }
-    addCu( x, y, w, h );
+    if( type == S_NONE ) { addCu( x, y, w, h ); return; }
+    // smallest chroma intra prediction unit (mode_constraint, modeTypeCondition of the coding_tree semantics): a split of a single-tree
+    // node that would create chroma blocks of fewer than 16 samples or 2-wide intra chroma blocks makes the sub-tree either inter-only
+    // (chroma follows the split) or intra-only with a LOCAL DUAL TREE: the luma children are luma-tree CUs, then one chroma-tree CU
+    // covers the node
+    int cond = 0;
+    if( curTree == VVR_TREE_JOINT && modeType == 0 && P.chroma_format )
+    {
+      const int area = w * h; const bool bt = type == S_BV || type == S_BH, tt = type == S_TV || type == S_TH;
+      if( ( area == 64 && ( type == S_QT || tt ) ) || ( area == 32 && bt ) ) cond = 1;
+      else if( ( area == 64 && bt ) || ( area == 128 && tt ) || ( w == 8 && type == S_BV ) || ( w == 16 && type == S_TV ) ) cond = 1 + ( P.slice_type != 2 ? 1 : 0 );
+    }
+    const int oldMode = modeType, oldTree = curTree;
+    bool localDual = false;
+    if( cond == 1 ) { modeType = 2; localDual = true; }
+    else if( cond == 2 ) { if( rng.p( 0.5 ) ) { modeType = 2; localDual = true; } else modeType = 1; }
+    if( localDual ) curTree = VVR_TREE_LUMA;
+    switch( type )
+    {
+      case S_QT: { const int hw = w >> 1, hh = h >> 1; split( x, y, hw, hh ); split( x + hw, y, hw, hh ); split( x, y + hh, hw, hh ); split( x + hw, y + hh, hw, hh ); break; }
+      case S_BV: split( x, y, w >> 1, h ); split( x + ( w >> 1 ), y, w >> 1, h ); break;
+      case S_BH: split( x, y, w, h >> 1 ); split( x, y + ( h >> 1 ), w, h >> 1 ); break;
+      case S_TV: split( x, y, w >> 2, h ); split( x + ( w >> 2 ), y, w >> 1, h ); split( x + 3 * ( w >> 2 ), y, w >> 2, h ); break;
+      default:   split( x, y, w, h >> 2 ); split( x, y + ( h >> 2 ), w, h >> 1 ); split( x, y + 3 * ( h >> 2 ), w, h >> 2 ); break;
+    }
+    if( localDual ) { curTree = VVR_TREE_CHROMA; addCu( x, y, w, h ); }
+    modeType = oldMode; curTree = oldTree;
   }
 
   // ---------------------------------------------------------------------------------------------------------------
@@ -645,6 +678,11 @@ struct Gen {
         if( tq == tp ) continue;                               // not a transform (or CU) edge
         const vvr_tu& TQ = B.tu[tq]; const vvr_tu& TP = B.tu[tp];
         const vvr_cu& CQ = B.cu[TQ.cu]; const vvr_cu& CP = B.cu[TP.cu];
+        // the blocks that own the chroma on either side: the chroma-tree CU of a local dual tree where there is one, else the same block
+        const bool haveC = !tuOf4C.empty();
+        const int tqc = haveC && tuOf4C[iq] >= 0 ? tuOf4C[iq] : tq, tpc = haveC && tuOf4C[ip] >= 0 ? tuOf4C[ip] : tp;
+        const vvr_tu& TQc = B.tu[tqc]; const vvr_tu& TPc = B.tu[tpc];
+        const vvr_cu& CQc = B.cu[TQc.cu]; const vvr_cu& CPc = B.cu[TPc.cu];
         vvr_lfp& L = B.lfp[d][iq];
         // maximum filter lengths from the transform sizes orthogonal to the edge (LoopFilter.cpp:910-922)
         const int sizeQ = d == 0 ? TQ.w : TQ.h, sizeP = d == 0 ? TP.w : TP.h;
@@ -655,11 +693,11 @@ struct Gen {
         L.flags = 1;                                           // filterEdge luma
         // chroma edges live on the 8x8 chroma-sample grid = 16 luma samples
         const int posAlong = d == 0 ? ( x4 << 2 ) : ( y4 << 2 );
-        const bool chromaEdge = P.chroma_format && ( posAlong % 16 == 0 ) && !( &CQ == &CP && CQ.isp_mode );     // the chroma block of an ISP CU is not split
+        const bool chromaEdge = P.chroma_format && ( posAlong % 16 == 0 ) && tqc != tpc && !( &CQc == &CPc && CQc.isp_mode );     // the chroma block of an ISP CU is not split
         if( chromaEdge )
         {
           // (the chroma block of an ISP CU is not split: its size is the CU's)
-          const int sizeQc = ( CQ.isp_mode ? ( d == 0 ? CQ.w : CQ.h ) : sizeQ ) >> 1, sizePc = ( CP.isp_mode ? ( d == 0 ? CP.w : CP.h ) : sizeP ) >> 1;
+          const int sizeQc = ( CQc.isp_mode ? ( d == 0 ? CQc.w : CQc.h ) : ( d == 0 ? TQc.w : TQc.h ) ) >> 1, sizePc = ( CPc.isp_mode ? ( d == 0 ? CPc.w : CPc.h ) : ( d == 0 ? TPc.w : TPc.h ) ) >> 1;
           if( sizePc >= 8 && sizeQc >= 8 ) L.flags |= 0x20;   // both sides >= 8 chroma samples: long chroma filter allowed
         }
         // boundary strength (LoopFilter.cpp:1094-1360)
@@ -669,8 +707,8 @@ struct Gen {
         else
         {
           if( ( TQ.cbf & 1 ) || ( TP.cbf & 1 ) ) bsY = 1;
-          const bool jointChr = TQ.joint_cbcr || TP.joint_cbcr;     // (LoopFilter.cpp:1180-1184)
-          if( chromaEdge ) { if( ( TQ.cbf & 2 ) || ( TP.cbf & 2 ) || jointChr ) bsCb = 1; if( ( TQ.cbf & 4 ) || ( TP.cbf & 4 ) || jointChr ) bsCr = 1; }
+          const bool jointChr = TQc.joint_cbcr || TPc.joint_cbcr;     // (LoopFilter.cpp:1180-1184)
+          if( chromaEdge ) { if( ( TQc.cbf & 2 ) || ( TPc.cbf & 2 ) || jointChr ) bsCb = 1; if( ( TQc.cbf & 4 ) || ( TPc.cbf & 4 ) || jointChr ) bsCr = 1; }
           if( !bsY && &CQ != &CP )
           {
             // motion-based rule
@@ -700,8 +738,8 @@ struct Gen {
         }
         L.bs = (uint8_t) ( bsY | ( bsCb << 2 ) | ( bsCr << 4 ) );
         L.qp[0] = (int8_t) ( ( CQ.qp + CP.qp + 1 ) >> 1 );
-        L.qp[1] = (int8_t) ( ( TQ.qp[1] + TP.qp[1] - 2 * qpBd + 1 ) >> 1 );
-        L.qp[2] = (int8_t) ( ( TQ.qp[2] + TP.qp[2] - 2 * qpBd + 1 ) >> 1 );
+        L.qp[1] = (int8_t) ( ( TQc.qp[1] + TPc.qp[1] - 2 * qpBd + 1 ) >> 1 );
+        L.qp[2] = (int8_t) ( ( TQc.qp[2] + TPc.qp[2] - 2 * qpBd + 1 ) >> 1 );
         if( !L.bs ) { /* edge without any filtering keeps its length info, like the reference table */ }
       }
     }
@@ -807,7 +845,7 @@ struct Gen {
     if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && B.scaling ) genScalingList();
     int a = 0;
     const bool dual = P.slice_type == 2 && P.dual_tree > 0 && P.chroma_format;
-    if( dual ) { cuOf4C.assign( (size_t) w4 * h4, -1 ); tuOf4C.assign( (size_t) w4 * h4, -1 ); }
+    if( dual || P.min_cu_log2 == 2 ) { cuOf4C.assign( (size_t) w4 * h4, -1 ); tuOf4C.assign( (size_t) w4 * h4, -1 ); }
     for( int y = 0; y < H; y += ctu ) for( int x = 0; x < W; x += ctu, a++ )
     {
       B.ctu_first_cu[a] = B.num_cu;
@@ -830,7 +868,7 @@ struct Gen {
       curTree = VVR_TREE_JOINT; cclmOk = true;
     }
     B.ctu_first_cu[a] = B.num_cu;
-    if( dual ) deriveLfpDual(); else deriveLfp();
+    if( dual ) deriveLfpDual(); else deriveLfp();       // (deriveLfp handles the chroma-tree CUs of local dual trees through the chroma owner maps)
     if( ( P.tool_flags & VVR_TOOL_LMCS ) && B.lmcs ) genLmcs();
     genAlfParams();
     genLoopFilterParams();
@@ -843,7 +881,7 @@ struct Gen {
 __attribute__((visibility("default")))
 int vvs_generate( const vvs_params* P, vvs_buffers* B )
 {
-  if( P->min_cu_log2 < 3 || P->chroma_format > 1 || P->bit_depth < 8 || P->bit_depth > 10 ) return -1;
+  if( P->min_cu_log2 < 2 || P->chroma_format > 1 || P->bit_depth < 8 || P->bit_depth > 10 ) return -1;
   Gen g( *P, *B );
   return g.run();
 }

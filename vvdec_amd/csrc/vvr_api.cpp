@@ -310,13 +310,15 @@ static int validate( vvr_context* c, const vvr_picture* p )
       if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] > 69 ) { c->setError( "chroma intra mode out of range" ); return VVR_ERR_PARAMETER; }
       {
         // luma-tree CUs of dual-tree pictures go down to 4x4; a 4-wide CU with chroma (2xN chroma blocks / local dual tree) is not in this build
-        const int minSize = cu.tree == VVR_TREE_LUMA ? 4 : 8;
-        if( cu.w > 64 || cu.h > 64 || cu.w < minSize || cu.h < minSize ) { c->setError( "intra CU size outside 8..64 (4..64 for luma-tree CUs) is not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+        // luma-tree CUs go down to 4x4; CUs with chroma need 8 luma samples of width (no 2-wide intra chroma blocks) and 4 of height
+        const int minW = cu.tree == VVR_TREE_LUMA ? 4 : 8;
+        if( cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( cu.tree != VVR_TREE_LUMA && cu.w * cu.h < 64 ) ) { c->setError( "intra CU size out of range (luma tree 4..64, with chroma at least 8 wide and 16 chroma samples)" ); return VVR_ERR_PARAMETER; }
       }
       if( cu.tree != VVR_TREE_JOINT )
       {
-        // dual tree (I slices, qtbtt_dual_tree_intra_flag): luma CUs carry luma blocks only, chroma CUs chroma blocks only
-        if( cu.tree > VVR_TREE_CHROMA || h.slice_type != 2 || !h.chroma_format ) { c->setError( "separate-tree CU outside an intra picture (local dual tree is not implemented in this build)" ); return VVR_ERR_UNSUPPORTED; }
+        // dual tree (I slices, qtbtt_dual_tree_intra_flag) and local dual tree (intra-only sub-trees of small blocks in any slice):
+        // luma CUs carry luma blocks only, chroma CUs chroma blocks only
+        if( cu.tree > VVR_TREE_CHROMA || !h.chroma_format ) { c->setError( "bad tree type" ); return VVR_ERR_PARAMETER; }
         const int want = cu.tree == VVR_TREE_LUMA ? 1 : 6;
         for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ ) if( p->tu[t].comp_mask != want ) { c->setError( "separate-tree CU: TU component mask" ); return VVR_ERR_PARAMETER; }
         if( cu.tree == VVR_TREE_CHROMA && ( cu.isp_mode || cu.multi_ref_idx || cu.bdpcm[0] || ( cu.flags & VVR_CU_MIP ) ) ) { c->setError( "chroma-tree CU with luma tools" ); return VVR_ERR_PARAMETER; }

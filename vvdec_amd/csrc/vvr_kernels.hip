@@ -2066,9 +2066,10 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int x0 = it.x, y0 = it.y, lw = it.lw, wh = 1 << ( it.lw + it.lh );
       const bool cs = ( it.flags & IT_F_CSCALE ) != 0;
       const int f = cs ? sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )] : 0;
-      if( lw >= 2 )
+      if( lw >= 2 && !( x0 & 3 ) )
       {
-        // four samples of a row per lane (8-byte accesses; x0 and the row strides are multiples of 4 samples)
+        // four samples of a row per lane (8-byte accesses; x0 and the row strides are multiples of 4 samples - not so for the chroma of
+        // an 8-wide inter CU that is the middle part of a ternary split of 16)
         for( int i = ( tid & 63 ); i < ( wh >> 2 ); i += 64 )
         {
           const int x = x0 + ( ( i << 2 ) & ( ( 1 << lw ) - 1 ) ), y = y0 + ( ( i << 2 ) >> lw );
@@ -2685,7 +2686,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       {
         const IntraItem it = sh.items[k];
         const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
-        if( lw >= 2 )
+        if( lw >= 2 && !( it.x & 3 ) )
         {
           // four samples (8 bytes) per lane: block positions and widths are multiples of 4 samples
           for( int i = tid; i < ( wh >> 2 ); i += 256 )
