@@ -206,7 +206,7 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
         vvr_cu icu = *cu;
         icu.intra_dir[0] = icu.intra_dir[1] = 0; icu.multi_ref_idx = 0; icu.bdpcm[0] = icu.bdpcm[1] = 0; icu.isp_mode = 0; icu.flags &= (uint16_t) ~VVR_CU_MIP;
         const int wIntra = 1 + ( cu->ciip_neigh_intra & 1 ) + ( ( cu->ciip_neigh_intra >> 1 ) & 1 );
-        if( cu->num_tu != 1 || cu->w < 8 ) { vvo_set_error( "CIIP: CU with several TUs / 4-wide CU not restated" ); goto done; }
+        if( cu->num_tu != 1 ) { vvo_set_error( "CIIP: CU with several TUs not restated" ); goto done; }
         const vvr_tu* tu = &pic->tu[cu->first_tu];
         int bw[3], bh[3];
         const int mask = ( cu->flags & VVR_CU_ROOT_CBF ) ? tu_residuals( pic, cu, tu, resi, bw, bh ) : 0;
@@ -214,6 +214,16 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
         for( int c = 0; c < ncomp; c++ )
         {
           if( c == 1 ) { CSCALE_TU( tu, mask ) }            /* after the luma of this TU (finishLMCSAndReco order, DecCu.cpp:498-512) */
+          if( c && cu->w == 4 )
+          {   /* 2-wide chroma blocks are not blended (predBlendIntraCiip, IntraPrediction.cpp:891): inter prediction + residual */
+            if( mask & ( 1 << c ) )
+              for( int y = 0; y < bh[c]; y++ ) for( int x = 0; x < bw[c]; x++ )
+              {
+                pel* d = &reco.p[c][(size_t) ( ( tu->y >> 1 ) + y ) * reco.stride[c] + ( tu->x >> 1 ) + x];
+                *d = (pel) vvo_clip_pel( *d + resi[c][y * bw[c] + x], H->bit_depth );
+              }
+            continue;
+          }
           if( vvo_intra_tu( pic, &icu, tu, cu->first_tu, c, &reco, order, resi[c], ( mask >> c ) & 1, wIntra ) ) goto done;
         }
       }

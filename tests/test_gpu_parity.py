@@ -273,6 +273,8 @@ def test_small_cus_and_local_dual_tree(built):
     _run_stream(256, 128, 5, 4, 251, TOOLS_A, intra=True, min_cu_log2=2, p_intra=0.3, p_split_scale=1.8, p_cclm=0.3, p_isp=0.2, p_mip=0.2)
     _run_stream(416, 240, 3, 2, 252, T, intra=True, log2_ctu=5, min_cu_log2=2, p_intra=0.25, p_split_scale=2.0, p_sbt=0.2, p_cclm=0.3, p_jccr=0.2, p_coded_chroma=0.5)
     _run_stream(1920, 1080, 3, 2, 253, T, intra=True, streams=3, min_cu_log2=2, p_split_scale=1.5, p_affine=0.1, p_ciip=0.05)
+    # 4xN / Nx4 CIIP CUs: the 2-wide chroma blocks stay pure inter, the Nx2 ones are blended
+    _run_stream(256, 128, 5, 4, 254, T, intra=True, min_cu_log2=2, p_intra=0.2, p_split_scale=1.8, p_ciip=0.6, p_coded=0.6, p_coded_chroma=0.5)
 
 
 def test_joint_cbcr(built):

@@ -137,6 +137,7 @@ def test_oracle_equals_reference_implicit_mts(built, l2, idx, seed, kw):
     (256, 128, 7, 0, 252, ALL, dict(p_split_scale=1.8, p_cclm=0.3, p_isp=0.3, p_mip=0.2, p_lfnst=0.3)),
     (200, 136, 5, 3, 253, ALL | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.25, p_split_scale=2.0, p_sbt=0.2, p_cclm=0.3, p_jccr=0.2, p_coded_chroma=0.5)),
     (384, 256, 6, 1, 254, ALL | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP, dict(p_intra=0.2, p_split_scale=1.7, p_isp=0.2, p_coded_chroma=0.5)),
+    (200, 136, 5, 3, 255, ALL | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.2, p_split_scale=2.0, p_ciip=0.6, p_coded=0.6, p_coded_chroma=0.5)),     # 4xN / Nx4 CIIP
 ])
 def test_oracle_equals_reference_small_cus(built, W, H, l2, idx, seed, tools, kw):
     """minimum CU size 4: 4xN inter CUs (2xN chroma blocks), Nx4 intra CUs (Nx2 chroma blocks), and the local dual tree of intra-only

@@ -345,7 +345,7 @@ struct Gen {
       // SbTMVP: merge CU whose 8x8 sub-blocks carry their own motion (filled into the motion field below)
       if( !( cu.flags & ( VVR_CU_AFFINE | VVR_CU_GEO ) ) && w >= 8 && h >= 8 && rng.p( P.p_sbtmvp ) ) { cu.flags |= VVR_CU_SBTMVP | VVR_CU_MERGE; cu.imv = 0; cu.bcw_idx = 2; }
       // CIIP: regular merge CU (no affine/GPM/MMVD), 64 <= area, sides < 128 (8..64 here); the intra part is planar
-      if( !( cu.flags & ( VVR_CU_AFFINE | VVR_CU_GEO | VVR_CU_SBTMVP ) ) && w >= 8 && h >= 8 && w <= 64 && h <= 64 && rng.p( P.p_ciip ) )
+      if( !( cu.flags & ( VVR_CU_AFFINE | VVR_CU_GEO | VVR_CU_SBTMVP ) ) && w * h >= 64 && w <= 64 && h <= 64 && rng.p( P.p_ciip ) )
       {
         cu.flags |= VVR_CU_CIIP | VVR_CU_MERGE;
         cu.imv = 0; cu.bcw_idx = 2;

@@ -273,8 +273,8 @@ static int validate( vvr_context* c, const vvr_picture* p )
       { c->setError( "mc_mode DMVR on a CU that cannot use DMVR (UnitTools.cpp:1277)" ); return VVR_ERR_PARAMETER; }
       if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
       { c->setError( "mc_mode BDOF on a CU that cannot use BDOF (InterPrediction.cpp:1407-1427)" ); return VVR_ERR_PARAMETER; }
-      if( ( cu.flags & VVR_CU_CIIP ) && ( ( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI ) || cu.w < 8 || cu.h < 8 || cu.w > 64 || cu.h > 64 || cu.num_tu != 1 ) )
-      { c->setError( "CIIP CU: needs plain uni/bi prediction and a CU of 8..64 with one TU (4-wide CIIP CUs are not implemented)" ); return VVR_ERR_UNSUPPORTED; }
+      if( ( cu.flags & VVR_CU_CIIP ) && ( ( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI ) || cu.w * cu.h < 64 || cu.w > 64 || cu.h > 64 || cu.num_tu != 1 ) )
+      { c->setError( "CIIP CU: needs plain uni/bi prediction, at least 64 luma samples, sides of at most 64 and one TU" ); return VVR_ERR_PARAMETER; }
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) { c->setError( "ref_idx out of range" ); return VVR_ERR_PARAMETER; }
       if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo && !isSbt ) { c->setError( "inter CU without reference" ); return VVR_ERR_PARAMETER; }
       if( wpOn && cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 )
@@ -444,12 +444,12 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       if( ctuOfCu < curCtu ) { c->setError( "CUs are not in CTU raster order" ); return VVR_ERR_PARAMETER; }
       while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
     }
-    const bool isCiip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
+    const bool isCiipCu = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
     // LMCS chroma residual scaling of an inter block: its factor reads reconstructed luma that the intra stage may still have to
     // produce, and intra blocks next to it read its reconstructed chroma, so the residual add of such a block is an item of the
     // intra stage too (IT_MODE_RESI_ADD: no prediction, scaled residual onto the inter prediction; finishLMCSAndReco, DecCu.cpp:483)
-    const bool isCsInter = cscale && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
-    if( cu.pred_mode == VVR_PRED_INTRA || isCiip || isCsInter )
+    const bool isCsInterCu = cscale && cu.pred_mode == VVR_PRED_INTER && ( !isCiipCu || cu.w == 4 ) && ( cu.flags & VVR_CU_ROOT_CBF );
+    if( cu.pred_mode == VVR_PRED_INTRA || isCiipCu || isCsInterCu )
     {
       for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
       {
@@ -457,6 +457,10 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         for( int comp = 0; comp < ncomp; comp++ )
         {
           if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
+          // the 2-wide chroma blocks of a 4-wide CIIP CU are not blended (predBlendIntraCiip, IntraPrediction.cpp:891): plain inter blocks
+          const bool isCiip = isCiipCu && !( comp && cu.w == 4 );
+          const bool isCsInter = cscale && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
+          if( cu.pred_mode != VVR_PRED_INTRA && !isCiip && !isCsInter ) continue;
           if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
           const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
           // intra sub-partitions: luma partitions are blocks of their own that share the reference line of the whole CU
@@ -630,7 +634,8 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       for( int comp = 0; comp < ncomp; comp++ )
       {
         if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
-        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.mode = ( cu.pred_mode == VVR_PRED_INTER && !( cu.flags & VVR_CU_CIIP ) ) ? TB_ADD : TB_STORE; it.ict = 0; it.pad = 0;
+        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.ict = 0; it.pad = 0;
+        it.mode = ( cu.pred_mode == VVR_PRED_INTER && ( !( cu.flags & VVR_CU_CIIP ) || ( comp && cu.w == 4 ) ) ) ? TB_ADD : TB_STORE;      // (2-wide chroma of a 4-wide CIIP CU: plain inter)
         if( comp && tu.joint_cbcr )
         {
           if( comp != 1 ) continue;
