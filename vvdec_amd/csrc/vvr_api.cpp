@@ -648,7 +648,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
         if( ( bw < 2 || bh < 2 ) && !( cu.isp_mode && !it.comp && bw * bh >= 16 ) ) { c->setError( "1-D transform block outside an ISP CU" ); return VVR_ERR_PARAMETER; }
         const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
         // LMCS chroma residual scaling of an inter block: the factor needs the reconstructed luma around the VPDU, which the intra stage
-        // may still have to produce -> late list.  (STORE items are scaled by k_intra when it reads the residual.)
+        // may still have to produce, so the block's residual is stored and added (scaled) by a residual-add item of the intra stage
         if( cscale && it.comp && it.mode == TB_ADD && bw * bh > 4 ) it.mode = TB_STORE;      // added (scaled) by the intra stage, see isCsInter above
         tb[cls].push_back( it );        // ADD (inter: onto the prediction) and STORE (intra / CIIP: into the residual planes) items share a launch
         const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];

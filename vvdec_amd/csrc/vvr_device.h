@@ -69,12 +69,13 @@ struct IntraItem {        // 16 bytes, self-contained: the kernel never touches 
   uint32_t tu;
 };
 
-// One unit of the intra stage (a run of blocks of one component inside one CTU quadrant), processed by one workgroup.
+// One unit of the intra stage (blocks of one component inside one CTU that read reference samples from each other, or a group of such
+// clusters at the same dependency depth), processed by one workgroup.
 #define VVR_INTRA_MAX_DEPS 26
 struct IntraUnit {
   uint32_t ent;           // (component << 24) | CTU address; bit 29: has blocks with LMCS chroma residual scaling; bit 30: another unit waits for this one (it must publish its flag)
   uint32_t i0, i1;        // item range
-  uint32_t bbox;          // part of the CTU tile the unit's blocks read: y0 | y1 << 8 | c0 << 16 | c1 << 24 (rows from CTU top - 3, 16-byte chunks from CTU left - 8, chunk + 1)
+  uint32_t bbox;          // (whole-CTU units only) part of the CTU tile the unit's blocks read: y0 | y1 << 8 | c0 << 16 | c1 << 24 (rows from CTU top - 3, 16-byte chunks from CTU left - 8, chunk + 1)
   uint32_t ndeps;
   uint32_t deps[VVR_INTRA_MAX_DEPS];   // tickets (= indices into the unit table) this unit waits for
   uint32_t iA;                         // [i0, iA): IT_MODE_RESI_ADD items (no mutual dependencies, done first and in parallel); 32 dwords
