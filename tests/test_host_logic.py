@@ -110,3 +110,43 @@ def test_picture_md5_layout():
     cr = np.array([[2]], np.uint16)
     import hashlib
     assert parallel.picture_md5([y, cb, cr]) == hashlib.md5(y.tobytes() + cb.tobytes() + cr.tobytes()).hexdigest()
+
+
+def _edge_reach(l, dr, pos, ctu):
+    """(written P, written Q, read P, read Q) sample counts of one luma edge segment; mirrors xEdgeFilterLuma (LoopFilter.cpp:1464)."""
+    if not (int(l["bs"]) & 3):
+        return None
+    v = int(l["side_max_filt_length"])
+    lp, lq = (v >> 4) & 7, v & 7
+    pl, ql = lp > 3, lq > 3
+    if dr == 1 and pos % ctu == 0:
+        pl = False
+    w = 3 if (lp > 2 and lq > 2) else 2 if (lp > 1 and lq > 1) else 1
+    r = 4 if (lp > 2 and lq > 2) else 3
+    wp, wq, rp, rq = w, w, r, r
+    if pl or ql:
+        wp, wq = max(wp, lp if pl else 3), max(wq, lq if ql else 3)
+        rp, rq = max(rp, lp + 1 if pl else 4), max(rq, lq + 1 if ql else 4)
+    return wp, wq, rp, rq
+
+
+def test_luma_edges_of_one_direction_are_independent(built):
+    """k_deblock filters all edges of one direction in one launch.  That needs the sample sets of neighbouring edges to be disjoint,
+    except for the one pair the kernel orders itself: a 7-sample P side right after a coding-sub-block edge (SbTMVP CU on the
+    P side, LoopFilter.cpp:920).  Checked on generated edge tables with affine / SbTMVP / SBT / small-CU content."""
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    tools = abi.TOOL_SAO_LUMA | abi.TOOL_ALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS
+    ordered = 0
+    for pl in plans:
+        d = synth.picture_for_plan(pl, 416, 240, seed=162, tool_flags=tools, log2_ctu=7, p_intra=0.15, p_affine=0.2, p_sbtmvp=0.3, p_sbt=0.2, p_geo=0.1, p_ciip=0.1)
+        ctu = 1 << d.hdr.log2_ctu
+        for dr in range(2):
+            lf = d.lfp[dr].reshape(d.h4, d.w4)
+            lines = lf if dr == 0 else lf.T
+            for line in lines:
+                edges = [(b * 4, _edge_reach(l, dr, b * 4, ctu), l) for b, l in enumerate(line) if int(l["bs"]) & 3]
+                for (e0, r0, l0), (e1, r1, l1) in zip(edges, edges[1:]):
+                    if e0 + r0[1] - 1 >= e1 - r1[2] or e1 - r1[0] <= e0 + r0[3] - 1:
+                        assert e1 - e0 == 8 and (int(l1["side_max_filt_length"]) >> 4) & 7 == 7, (pl.poc, dr, e0, e1)
+                        ordered += 1
+    assert ordered > 0          # the stream does contain the ordered pair

@@ -162,12 +162,14 @@ def test_reference_simd_equals_scalar(built):
 def test_edge_parameters_match_reference_derivation(built):
     """deblocking with the edge parameters the reference derives itself (LoopFilter::calcFilterStrengthsCTU) == with the
     job's table (the host glue's restatement of that derivation)"""
-    d, refs = _case(256, 128, 7, 2, 107, p_intra=0.2)       # no affine CUs: the generator's derivation has no sub-block edges
+    d, refs = _case(256, 128, 7, 2, 107, p_intra=0.2)
     a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
     b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     for args, kw in (((256, 128, 7, 0, 122), dict(p_isp=0.7, p_split_scale=1.6)), ((384, 256, 6, 2, 123), dict(p_isp=0.5, p_intra=0.4, p_cclm=0.3)),
                      ((384, 256, 7, 0, 127), dict(dual_tree=1.0, p_isp=0.2, p_bdpcm=0.3, p_coded_chroma=0.6)),
+                     ((384, 256, 7, 1, 134), dict(p_intra=0.0, p_affine=0.5, p_sbtmvp=0.2, p_split_scale=0.5)),      # sub-block edges of affine / SbTMVP CUs, also across TU edges of 128x128 CUs
+                     ((200, 136, 6, 3, 135), dict(p_intra=0.1, p_affine=0.3, p_sbtmvp=0.4, mv_sigma=3.0, p_geo=0.1, p_ciip=0.1)),
                      ((256, 128, 6, 0, 130), dict(dual_tree=2.0, p_split_scale=1.5, p_isp=0.2)), ((256, 128, 6, 0, 133), dict(dual_tree=3.0, p_split_scale=1.8, p_isp=0.7)), ((256, 128, 6, 2, 128), dict(p_bdpcm=0.5, p_intra=0.6))):
         d, refs = _case(*args, **kw)                                                       # ISP: partition edges, unsplit chroma
         a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]

@@ -621,7 +621,6 @@ struct Gen {
 
   // ---------------------------------------------------------------------------------------------------------------
   // deblocking edge parameters: the table LoopFilter::calcFilterStrengthsCTU (LoopFilter.cpp:495-1360) fills.
-  // This generator version has no sub-block (affine/SbTMVP) edges, no ISP/SBT, single tree.
   // ---------------------------------------------------------------------------------------------------------------
   // dual tree (intra pictures): luma edges from the luma tree, chroma edges (8x8 chroma-sample grid) from the chroma tree; every
   // edge separates intra blocks (boundary strength 2)
@@ -666,6 +665,28 @@ struct Gen {
   void deriveLfp()
   {
     const int qpBd = 6 * ( bd - 8 );
+    // boundary strength from the motion of the two 4x4 units next to the edge (LoopFilter.cpp:1222-1360)
+    auto motionBs = [&]( int iq, int ip ) -> int
+    {
+      const vvr_motion& mq = B.motion[iq]; const vvr_motion& mp = B.motion[ip];
+      auto refPoc = [&]( const vvr_motion& m, int l ) { return m.ref_idx[l] >= 0 ? P.ref_poc[l][m.ref_idx[l]] : INT32_MIN; };
+      const int nq = ( mq.ref_idx[0] >= 0 ) + ( mq.ref_idx[1] >= 0 ), np = ( mp.ref_idx[0] >= 0 ) + ( mp.ref_idx[1] >= 0 );
+      auto far = [&]( const int32_t a[2], const int32_t b[2] ) { return std::abs( a[0] - b[0] ) >= 8 || std::abs( a[1] - b[1] ) >= 8; };
+      if( nq != np ) return 1;
+      if( nq == 1 )
+      {
+        const int lq = mq.ref_idx[0] >= 0 ? 0 : 1, lp = mp.ref_idx[0] >= 0 ? 0 : 1;
+        return ( refPoc( mq, lq ) != refPoc( mp, lp ) || far( mq.mv[lq], mp.mv[lp] ) ) ? 1 : 0;
+      }
+      const int q0 = refPoc( mq, 0 ), q1 = refPoc( mq, 1 ), p0 = refPoc( mp, 0 ), p1 = refPoc( mp, 1 );
+      if( !( ( q0 == p0 && q1 == p1 ) || ( q0 == p1 && q1 == p0 ) ) ) return 1;
+      if( p0 != p1 )
+      {
+        if( q0 == p0 ) return ( far( mq.mv[0], mp.mv[0] ) || far( mq.mv[1], mp.mv[1] ) ) ? 1 : 0;
+        return ( far( mq.mv[0], mp.mv[1] ) || far( mq.mv[1], mp.mv[0] ) ) ? 1 : 0;
+      }
+      return ( ( far( mq.mv[0], mp.mv[0] ) || far( mq.mv[1], mp.mv[1] ) ) && ( far( mq.mv[0], mp.mv[1] ) || far( mq.mv[1], mp.mv[0] ) ) ) ? 1 : 0;
+    };
     for( int d = 0; d < 2; d++ )
     {
       memset( B.lfp[d], 0, sizeof( vvr_lfp ) * (size_t) w4 * h4 );
@@ -688,7 +709,7 @@ struct Gen {
         const int sizeQ = d == 0 ? TQ.w : TQ.h, sizeP = d == 0 ? TP.w : TP.h;
         int lenP, lenQ;
         if( sizeP <= 4 || sizeQ <= 4 ) lenP = lenQ = 1;
-        else { lenP = sizeP >= 32 ? 7 : 3; lenQ = sizeQ >= 32 ? 7 : 3; }
+        else { lenP = sizeP >= 32 ? ( ( CP.flags & VVR_CU_AFFINE ) ? 5 : 7 ) : 3; lenQ = sizeQ >= 32 ? 7 : 3; }      // (:911 cuP->affineFlag())
         L.side_max_filt_length = (uint8_t) ( 0x80 | ( lenP << 4 ) | lenQ );
         L.flags = 1;                                           // filterEdge luma
         // chroma edges live on the 8x8 chroma-sample grid = 16 luma samples
@@ -709,38 +730,52 @@ struct Gen {
           if( ( TQ.cbf & 1 ) || ( TP.cbf & 1 ) ) bsY = 1;
           const bool jointChr = TQc.joint_cbcr || TPc.joint_cbcr;     // (LoopFilter.cpp:1180-1184)
           if( chromaEdge ) { if( ( TQc.cbf & 2 ) || ( TPc.cbf & 2 ) || jointChr ) bsCb = 1; if( ( TQc.cbf & 4 ) || ( TPc.cbf & 4 ) || jointChr ) bsCr = 1; }
-          if( !bsY && &CQ != &CP )
-          {
-            // motion-based rule
-            const vvr_motion& mq = B.motion[iq]; const vvr_motion& mp = B.motion[ip];
-            auto refPoc = [&]( const vvr_motion& m, int l ) { return m.ref_idx[l] >= 0 ? P.ref_poc[l][m.ref_idx[l]] : INT32_MIN; };
-            const int nq = ( mq.ref_idx[0] >= 0 ) + ( mq.ref_idx[1] >= 0 ), np = ( mp.ref_idx[0] >= 0 ) + ( mp.ref_idx[1] >= 0 );
-            auto far = [&]( const int32_t a[2], const int32_t b[2] ) { return std::abs( a[0] - b[0] ) >= 8 || std::abs( a[1] - b[1] ) >= 8; };
-            if( nq != np ) bsY = 1;
-            else if( nq == 1 )
-            {
-              const int lq = mq.ref_idx[0] >= 0 ? 0 : 1, lp = mp.ref_idx[0] >= 0 ? 0 : 1;
-              bsY = ( refPoc( mq, lq ) != refPoc( mp, lp ) || far( mq.mv[lq], mp.mv[lp] ) ) ? 1 : 0;
-            }
-            else
-            {
-              const int q0 = refPoc( mq, 0 ), q1 = refPoc( mq, 1 ), p0 = refPoc( mp, 0 ), p1 = refPoc( mp, 1 );
-              if( !( ( q0 == p0 && q1 == p1 ) || ( q0 == p1 && q1 == p0 ) ) ) bsY = 1;
-              else if( p0 != p1 )
-              {
-                if( q0 == p0 ) bsY = ( far( mq.mv[0], mp.mv[0] ) || far( mq.mv[1], mp.mv[1] ) ) ? 1 : 0;
-                else           bsY = ( far( mq.mv[0], mp.mv[1] ) || far( mq.mv[1], mp.mv[0] ) ) ? 1 : 0;
-              }
-              else
-                bsY = ( ( far( mq.mv[0], mp.mv[0] ) || far( mq.mv[1], mp.mv[1] ) ) && ( far( mq.mv[0], mp.mv[1] ) || far( mq.mv[1], mp.mv[0] ) ) ) ? 1 : 0;
-            }
-          }
+          if( !bsY && &CQ != &CP ) bsY = motionBs( iq, ip );
         }
         L.bs = (uint8_t) ( bsY | ( bsCb << 2 ) | ( bsCr << 4 ) );
         L.qp[0] = (int8_t) ( ( CQ.qp + CP.qp + 1 ) >> 1 );
         L.qp[1] = (int8_t) ( ( TQc.qp[1] + TPc.qp[1] - 2 * qpBd + 1 ) >> 1 );
         L.qp[2] = (int8_t) ( ( TQc.qp[2] + TPc.qp[2] - 2 * qpBd + 1 ) >> 1 );
         if( !L.bs ) { /* edge without any filtering keeps its length info, like the reference table */ }
+      }
+      // sub-block edges of affine and SbTMVP CUs (8x8 grid; xSetEdgeFilterInsidePu :1032, xSetMaxFilterLengthPQForCodingSubBlocks :707):
+      // luma only, strength from the motion of the sub-blocks, filter lengths limited by the distance to the next transform edge
+      for( uint32_t ci = 0; ci < B.num_cu; ci++ )
+      {
+        const vvr_cu& cu = B.cu[ci];
+        if( cu.pred_mode != VVR_PRED_INTER || !( cu.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP ) ) || cu.tree == VVR_TREE_CHROMA ) continue;
+        const int perp = d == 0 ? cu.w : cu.h, parl = d == 0 ? cu.h : cu.w;
+        auto cell = [&]( int pp, int pl ) { const int x = d == 0 ? cu.x + pp : cu.x + pl, y = d == 0 ? cu.y + pl : cu.y + pp; return ( y >> 2 ) * w4 + ( x >> 2 ); };
+        auto isTe = [&]( int pp, int pl ) { return pp >= 0 && pp < perp && ( B.lfp[d][cell( pp, pl )].side_max_filt_length & 0x80 ) != 0; };
+        for( int pl = 0; pl < parl; pl += 4 ) for( int pp = 0; pp < perp; pp += 8 )
+        {
+          if( ( d == 0 ? cu.x : cu.y ) + pp == 0 ) continue;                       // picture boundary
+          vvr_lfp& L = B.lfp[d][cell( pp, pl )];
+          int lenP, lenQ, te = 0;
+          if( L.side_max_filt_length & 0x80 )
+          {
+            te = 0x80; lenQ = std::min( L.side_max_filt_length & 7, 5 ); lenP = ( L.side_max_filt_length >> 4 ) & 7;
+            if( pp > 0 )
+            {
+              lenP = std::min( lenP, 5 );
+              // a transform edge inside the CU that is also a sub-block edge: without a coded block on either side the motion decides
+              // (xSetEdgeFilterInsidePu :1046 turns the edge marker into 3, so xGetBoundaryStrengthSingle goes on to the motion test)
+              if( !( L.bs & 3 ) ) L.bs = (uint8_t) ( L.bs | ( ( cu.flags & VVR_CU_CIIP ) ? 1 : motionBs( cell( pp, pl ), cell( pp - 4, pl ) ) ) );
+            }
+          }
+          else
+          {
+            if( isTe( pp - 4, pl ) || pp + 4 >= perp || isTe( pp + 4, pl ) ) lenP = lenQ = 1;
+            else if( pp == 8 || isTe( pp - 8, pl ) || pp + 8 >= perp || isTe( pp + 8, pl ) ) lenP = lenQ = 2;
+            else lenP = lenQ = 3;
+            // a pure sub-block edge: filtered where the motion of the two sub-blocks differs
+            const int iq = cell( pp, pl ), ip = cell( pp - 4, pl );
+            L.flags |= 1;
+            L.bs = (uint8_t) ( ( cu.flags & VVR_CU_CIIP ) ? 1 : motionBs( iq, ip ) );
+            L.qp[0] = cu.qp;
+          }
+          L.side_max_filt_length = (uint8_t) ( te | ( lenP << 4 ) | lenQ );
+        }
       }
     }
   }

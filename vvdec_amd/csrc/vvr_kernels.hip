@@ -1450,61 +1450,78 @@ __device__ __forceinline__ void filter_chroma_pel( pel_t* s, int o, int tc, bool
 
 __device__ __forceinline__ int tc_value( int idx, int bd ) { const int t = d_db_tc_table[idx]; return bd < 10 ? ( t + ( 1 << ( 9 - bd ) ) ) >> ( 10 - bd ) : t << ( bd - 10 ); }
 
+// luma filtering of the 4-sample edge segment at 4x4 unit (x4, y4)
+__device__ void deblock_luma_segment( const PicDev& pic, const DevPlanes& r, int dir, int x4, int y4, const vvr_lfp& l )
+{
+  const vvr_pic_header& H = pic.hdr;
+  const int bd = H.bit_depth;
+  const int bsY = BS_GET( l.bs, 0 );
+  const int stride = r.stride[0], x = x4 * 4, y = y4 * 4;
+  pel_t* src = r.p[0] + (size_t) y * stride + x;
+  const int o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
+  const int qp = l.qp[0];
+  const int lenP = ( l.side_max_filt_length >> 4 ) & 7, lenQ = l.side_max_filt_length & 7;
+  bool pLarge = lenP > 3, qLarge = lenQ > 3;
+  if( dir == 1 && ( y & ( ( 1 << H.log2_ctu ) - 1 ) ) == 0 ) pLarge = false;
+  const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * H.deblock_tc_offset_div2[0] );
+  const int idxB  = clip3( 0, 63, qp + 2 * H.deblock_beta_offset_div2[0] );
+  const int tc = tc_value( idxTC, bd ), beta = d_db_beta_table[idxB] << ( bd - 8 );
+  const int sideThr = ( beta + ( beta >> 1 ) ) >> 3, thrCut = tc * 10;
+  const pel_t* s0 = src; const pel_t* s3 = src + 3 * step;
+  const int dp0 = calc_dp( s0, o ), dq0 = calc_dq( s0, o ), dp3 = calc_dp( s3, o ), dq3 = calc_dq( s3, o );
+  const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+  if( pLarge || qLarge )
+  {
+    const int o3 = 3 * o;
+    const int dp0L = pLarge ? ( dp0 + calc_dp( s0 - o3, o ) + 1 ) >> 1 : dp0;
+    const int dq0L = qLarge ? ( dq0 + calc_dq( s0 + o3, o ) + 1 ) >> 1 : dq0;
+    const int dp3L = pLarge ? ( dp3 + calc_dp( s3 - o3, o ) + 1 ) >> 1 : dp3;
+    const int dq3L = qLarge ? ( dq3 + calc_dq( s3 + o3, o ) + 1 ) >> 1 : dq3;
+    const int d0L = dp0L + dq0L, d3L = dp3L + dq3L, dL = d0L + d3L;
+    if( dL < beta )
+    {
+      const bool swL = use_strong( s0, o, 2 * d0L, beta, tc, pLarge, qLarge, lenP, lenQ, false ) && use_strong( s3, o, 2 * d3L, beta, tc, pLarge, qLarge, lenP, lenQ, false );
+      if( swL ) { filter_long( src, step, o, pLarge ? lenP : 3, qLarge ? lenQ : 3, tc ); return; }
+    }
+  }
+  const int dp = dp0 + dp3, dq = dq0 + dq3, d = d0 + d3;
+  if( d < beta )
+  {
+    bool fP = false, fQ = false, sw = false;
+    if( lenP > 1 && lenQ > 1 ) { fP = dp < sideThr; fQ = dq < sideThr; }
+    if( lenP > 2 && lenQ > 2 ) sw = use_strong( s0, o, 2 * d0, beta, tc, false, false, 7, 7, false ) && use_strong( s3, o, 2 * d3, beta, tc, false, false, 7, 7, false );
+    for( int i = 0; i < 4; i++ ) filter_luma_pel( src + step * i, o, tc, sw, thrCut, fP, fQ, bd );
+  }
+}
+
+// An edge whose P side may be filtered over 7 samples reaches the samples of a coding-sub-block edge 8 samples before it
+// (SbTMVP CU on the P side: the reference keeps 7 there, LoopFilter.cpp:920, and filters the edges of a CTU in raster
+// order, :447-462, so the sub-block edge comes first).  Such a pair is handled by ONE thread, in that order; every other
+// pair of edges of one direction touches disjoint samples.
+__device__ __forceinline__ bool db_luma_p7( const vvr_lfp& l ) { return BS_GET( l.bs, 0 ) && ( ( l.side_max_filt_length >> 4 ) & 7 ) == 7; }
+
 __global__ __launch_bounds__( 256 ) void k_deblock( PicDev pic, DevPlanes r, int dir )
 {
   // thread -> 4x4 unit; along the edge direction neighbouring threads handle neighbouring segments of the same edge line
   const int x4 = blockIdx.x * 16 + ( dir == 0 ? threadIdx.x / 16 : threadIdx.x % 16 );
   const int y4 = blockIdx.y * 16 + ( dir == 0 ? threadIdx.x % 16 : threadIdx.x / 16 );
   if( x4 >= pic.w4 || y4 >= pic.h4 ) return;
-  const vvr_lfp l = pic.lfp[dir][(size_t) y4 * pic.w4 + x4];
+  const vvr_lfp* lp = pic.lfp[dir] + (size_t) y4 * pic.w4 + x4;
+  const vvr_lfp l = *lp;
+  const int nStep = dir == 0 ? 2 : 2 * pic.w4;                      // table distance of the unit 8 samples across the edge
+  const bool hasNext = dir == 0 ? x4 + 2 < pic.w4 : y4 + 2 < pic.h4, hasPrev = dir == 0 ? x4 >= 2 : y4 >= 2;
+  if( BS_GET( l.bs, 0 ) && !( hasNext && db_luma_p7( lp[nStep] ) ) )
+  {
+    if( db_luma_p7( l ) && hasPrev )
+    {
+      const vvr_lfp lPrev = lp[-nStep];
+      if( BS_GET( lPrev.bs, 0 ) ) deblock_luma_segment( pic, r, dir, dir == 0 ? x4 - 2 : x4, dir == 0 ? y4 : y4 - 2, lPrev );
+    }
+    deblock_luma_segment( pic, r, dir, x4, y4, l );
+  }
   if( !l.bs ) return;
   const vvr_pic_header& H = pic.hdr;
   const int bd = H.bit_depth;
-  // ---- luma
-  const int bsY = BS_GET( l.bs, 0 );
-  if( bsY )
-  {
-    const int stride = r.stride[0], x = x4 * 4, y = y4 * 4;
-    pel_t* src = r.p[0] + (size_t) y * stride + x;
-    const int o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
-    const int qp = l.qp[0];
-    const int lenP = ( l.side_max_filt_length >> 4 ) & 7, lenQ = l.side_max_filt_length & 7;
-    bool pLarge = lenP > 3, qLarge = lenQ > 3;
-    if( dir == 1 && ( y & ( ( 1 << H.log2_ctu ) - 1 ) ) == 0 ) pLarge = false;
-    const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * H.deblock_tc_offset_div2[0] );
-    const int idxB  = clip3( 0, 63, qp + 2 * H.deblock_beta_offset_div2[0] );
-    const int tc = tc_value( idxTC, bd ), beta = d_db_beta_table[idxB] << ( bd - 8 );
-    const int sideThr = ( beta + ( beta >> 1 ) ) >> 3, thrCut = tc * 10;
-    const pel_t* s0 = src; const pel_t* s3 = src + 3 * step;
-    const int dp0 = calc_dp( s0, o ), dq0 = calc_dq( s0, o ), dp3 = calc_dp( s3, o ), dq3 = calc_dq( s3, o );
-    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
-    bool done = false;
-    if( pLarge || qLarge )
-    {
-      const int o3 = 3 * o;
-      const int dp0L = pLarge ? ( dp0 + calc_dp( s0 - o3, o ) + 1 ) >> 1 : dp0;
-      const int dq0L = qLarge ? ( dq0 + calc_dq( s0 + o3, o ) + 1 ) >> 1 : dq0;
-      const int dp3L = pLarge ? ( dp3 + calc_dp( s3 - o3, o ) + 1 ) >> 1 : dp3;
-      const int dq3L = qLarge ? ( dq3 + calc_dq( s3 + o3, o ) + 1 ) >> 1 : dq3;
-      const int d0L = dp0L + dq0L, d3L = dp3L + dq3L, dL = d0L + d3L;
-      if( dL < beta )
-      {
-        const bool swL = use_strong( s0, o, 2 * d0L, beta, tc, pLarge, qLarge, lenP, lenQ, false ) && use_strong( s3, o, 2 * d3L, beta, tc, pLarge, qLarge, lenP, lenQ, false );
-        if( swL ) { filter_long( src, step, o, pLarge ? lenP : 3, qLarge ? lenQ : 3, tc ); done = true; }
-      }
-    }
-    if( !done )
-    {
-      const int dp = dp0 + dp3, dq = dq0 + dq3, d = d0 + d3;
-      if( d < beta )
-      {
-        bool fP = false, fQ = false, sw = false;
-        if( lenP > 1 && lenQ > 1 ) { fP = dp < sideThr; fQ = dq < sideThr; }
-        if( lenP > 2 && lenQ > 2 ) sw = use_strong( s0, o, 2 * d0, beta, tc, false, false, 7, 7, false ) && use_strong( s3, o, 2 * d3, beta, tc, false, false, 7, 7, false );
-        for( int i = 0; i < 4; i++ ) filter_luma_pel( src + step * i, o, tc, sw, thrCut, fP, fQ, bd );
-      }
-    }
-  }
   // ---- chroma (4:2:0): edges on the 8-chroma-sample grid, two chroma lines per 4x4 luma unit
   if( !H.chroma_format ) return;
   if( dir == 0 ? ( x4 & 3 ) : ( y4 & 3 ) ) return;
