@@ -87,6 +87,10 @@ enum {
   VVR_TOOL_SCALING_LIST_NO_LFNST = 1u << 18,  /* sps_scaling_matrix_for_lfnst_disabled_flag */
   VVR_TOOL_IMPLICIT_MTS = 1u << 19,  /* MTS on without sps_explicit_mts_intra_enabled_flag: intra luma blocks use the implicit DST-7 rule.
                                         Informative (vvr_tu.tr_type is already resolved); a checker that drives the reference decoder needs it */
+  VVR_TOOL_IBC          = 1u << 20,  /* sps_ibc_enabled_flag: the picture may hold VVR_PRED_IBC CUs (InterPrediction::xIntraBlockCopy,
+                                        InterPrediction.cpp:1995).  Block vector in vvr_cu.mv[0][0] (1/16 units, integer sample
+                                        positions); it must point at samples of the same CTU row that precede the CU in decoding order
+                                        and still sit in the IBC virtual buffer (CodingStructure::fillIBCbuffer, CodingStructure.cpp:550) */
 };
 
 typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::reconstructCoeff (AdaptiveLoopFilter.cpp:888) stays on the host */
@@ -247,7 +251,7 @@ typedef struct vvr_tu {
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct vvr_motion {      /* MotionInfo, MotionInfo.h:122 */
   int32_t mv[2][2];              /* [list][hor,ver]                                                            */
-  int8_t  ref_idx[2];            /* -1 unused (MI_NOT_VALID for intra)                                         */
+  int8_t  ref_idx[2];            /* -1 unused (MI_NOT_VALID for intra; IBC: both -1, mv[0] = block vector, UnitTools.cpp:3018) */
   uint8_t pad[2];
 } vvr_motion;
 

@@ -159,6 +159,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     sps.setScalingListFlag( !!( H.tool_flags & VVR_TOOL_SCALING_LIST ) );
     sps.setDisableScalingMatrixForLfnstBlks( !!( H.tool_flags & VVR_TOOL_SCALING_LIST_NO_LFNST ) );
     sps.setDepQuantEnabledFlag( !!( H.tool_flags & VVR_TOOL_DEP_QUANT ) );
+    sps.setIBCFlag( !!( H.tool_flags & VVR_TOOL_IBC ) );              // Picture::finalInit creates the IBC virtual buffers (Picture.cpp:294)
     sps.setMaxTLayers( 1 );
     {
       ChromaQpMappingTable& t = sps.m_chromaQpMappingTable;
@@ -487,6 +488,11 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       cu.setSbtInfo( c.sbt_info );
       cu.setInterDir( c.inter_dir );
       cu.refIdx[0] = c.ref_idx[0]; cu.refIdx[1] = c.ref_idx[1];
+      if( c.pred_mode == VVR_PRED_IBC )
+      {   // what the parser leaves for an IBC CU (CABACReader.cpp:930-968, DecCu.cpp:850-870): list 0, no reference index, the CTU row marked
+        cu.setInterDir( 1 ); cu.refIdx[0] = MAX_NUM_REF; cu.refIdx[1] = -1;
+        cs.hasIbcBlock[c.y >> H.log2_ctu] = 1;
+      }
       cu.setBcwIdx( c.pred_mode == VVR_PRED_INTER ? g_BcwInternFwd[c.bcw_idx] : BCW_DEFAULT );   // description uses the weight-table index (2 = default), the reference its "internal domain"
       cu.setImv( c.imv );
       cu.geoSplitDir = c.geo_split_dir;

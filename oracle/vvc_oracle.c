@@ -264,7 +264,49 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
         }
       }
     }
-    else { vvo_set_error( "IBC is not restated" ); goto done; }
+    else if( cu->pred_mode == VVR_PRED_IBC )
+    {
+      /* intra block copy (InterPrediction::xIntraBlockCopy, InterPrediction.cpp:1995; DecCu::predAndReco, DecCu.cpp:442-470): the
+       * prediction is a copy of reconstructed, not yet loop-filtered samples of the current picture at the block vector; chroma uses
+       * the halved vector.  The reference reads them from the IBC virtual buffer of the CTU row (CodingStructure::fillIBCbuffer,
+       * CodingStructure.cpp:550), which holds exactly these picture samples for a valid vector.  No forward luma mapping (the copied
+       * samples are in the mapped domain already, DecCu.cpp:460,472); the residual is added as for an inter CU (finishLMCSAndReco). */
+      if( !( H->tool_flags & VVR_TOOL_IBC ) ) { vvo_set_error( "IBC CU in a picture without VVR_TOOL_IBC" ); goto done; }
+      if( cu->tree == VVR_TREE_CHROMA || cu->w > 64 || cu->h > 64 || ( ( cu->mv[0][0][0] | cu->mv[0][0][1] ) & 15 ) ) { vvo_set_error( "IBC CU: chroma tree, larger than 64, or fractional block vector" ); goto done; }
+      const int bvx = cu->mv[0][0][0] >> 4, bvy = cu->mv[0][0][1] >> 4;
+      const int nc = ( cu->tree == VVR_TREE_JOINT ) ? ncomp : 1;
+      const int ctuMask = ( 1 << H->log2_ctu ) - 1;
+      for( int c = 0; c < nc; c++ )
+      {
+        const int sh = c ? 1 : 0;
+        const int bx = cu->x >> sh, by = cu->y >> sh, bw_ = cu->w >> sh, bh_ = cu->h >> sh;
+        const int rx = bx + ( c ? bvx >> 1 : bvx ), ry = by + ( c ? bvy >> 1 : bvy );
+        const int rowTop = ( cu->y & ~ctuMask ) >> sh, rowEnd = ( ( cu->y & ~ctuMask ) + ctuMask + 1 ) >> sh;
+        if( rx < 0 || ry < rowTop || rx + bw_ > reco.w[c] || ry + bh_ > rowEnd || ry + bh_ > reco.h[c] ) { vvo_set_error( "IBC CU: reference block outside the picture or the CTU row" ); goto done; }
+        for( int y = 0; y < bh_; y++ )
+          memmove( &reco.p[c][(size_t) ( by + y ) * reco.stride[c] + bx], &reco.p[c][(size_t) ( ry + y ) * reco.stride[c] + rx], sizeof( pel ) * (size_t) bw_ );
+      }
+      if( cu->flags & VVR_CU_ROOT_CBF )
+        for( uint32_t t = cu->first_tu; t < cu->first_tu + cu->num_tu; t++ )
+        {
+          const vvr_tu* tu = &pic->tu[t];
+          int bw[3], bh[3];
+          const int mask = tu_residuals( pic, cu, tu, resi, bw, bh );
+          if( mask < 0 ) goto done;
+          for( int c = 0; c < ncomp; c++ )
+          {
+            if( c == 1 ) { CSCALE_TU( tu, mask ) }
+            if( !( mask & ( 1 << c ) ) ) continue;
+            const int bx = tu->x >> ( c ? 1 : 0 ), by = tu->y >> ( c ? 1 : 0 );
+            for( int y = 0; y < bh[c]; y++ ) for( int x = 0; x < bw[c]; x++ )
+            {
+              pel* d = &reco.p[c][(size_t) ( by + y ) * reco.stride[c] + bx + x];
+              *d = (pel) vvo_clip_pel( *d + resi[c][y * bw[c] + x], H->bit_depth );
+            }
+          }
+        }
+    }
+    else { vvo_set_error( "unknown prediction mode" ); goto done; }
   }
 
   if( ( H->tool_flags & VVR_TOOL_LMCS ) && pic->lmcs )

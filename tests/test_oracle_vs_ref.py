@@ -151,6 +151,28 @@ def test_oracle_equals_reference_small_cus(built, W, H, l2, idx, seed, tools, kw
             assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
 
 
+@pytest.mark.parametrize("W,H,l2,idx,seed,lmcs,kw", [
+    (256, 128, 7, 0, 301, 0, dict(p_ibc=0.4, p_coded=0.5)),
+    (384, 256, 6, 0, 302, 1, dict(p_ibc=0.5, p_split_scale=1.4, p_cclm=0.3, p_jccr=0.3, p_coded_chroma=0.5)),
+    (200, 136, 5, 0, 303, 0, dict(p_ibc=0.7, p_coded=0.3)),
+    (384, 256, 7, 2, 304, 1, dict(p_ibc=0.6, p_intra=0.5, p_ciip=0.1, p_affine=0.1)),
+    (256, 128, 6, 0, 305, 1, dict(p_ibc=0.5, dual_tree=2.0, p_split_scale=1.5, p_cclm=0.3)),
+    (264, 200, 7, 3, 306, 0, dict(p_ibc=0.6, p_intra=0.4, min_cu_log2=2, p_split_scale=1.6)),
+])
+def test_oracle_equals_reference_intra_block_copy(built, W, H, l2, idx, seed, lmcs, kw):
+    """IBC CUs (InterPrediction::xIntraBlockCopy): block vectors into the current and the left CTUs of the row, luma + chroma at the
+    halved vector, luma-only CUs of dual / local dual trees, with and without LMCS chroma residual scaling; every stage, and the
+    generator's edge parameters against the reference's own derivation (IBC boundary-strength rules)"""
+    tools = ALL | abi.TOOL_IBC | ((abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE) if lmcs else 0)
+    d, refs = _case(W, H, l2, idx, seed, tools=tools, **kw)
+    assert int((d.cu["pred_mode"] == abi.PRED_IBC).sum()) > 10
+    for fl in STAGES + [refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP]:
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl & ~refdrv.DERIVE_LFP)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+
+
 def test_reference_simd_equals_scalar(built):
     """the reference's own differential check (its unit test compares scalar vs SIMD kernels): same bytes at frame level"""
     d, refs = _case(256, 192, 7, 2, 106, p_intra=0.2)

@@ -69,6 +69,8 @@ typedef struct vvs_params {
   float    p_sbt;               // of inter CUs (not CIIP, at most 64x64): sub-block transform (residual in one half / quarter of the CU)
   float    p_isp;               // of intra CUs (no MRL / BDPCM / MIP): intra sub-partitions, four luma partitions predicted one after the other
   float    dual_tree;           // > 0: I pictures use separate luma and chroma coding trees below 64x64 (qtbtt_dual_tree_intra_flag); 2: luma CUs down to 4x4; 3: and ISP on 4xN / Nx4 CUs (1xN, Nx1, 2xN, Nx2 partitions)
+  float    p_ibc;               // with VVR_TOOL_IBC: of the CUs that would be intra (luma at most 64x64, not in a chroma tree): intra block copy,
+                                // where a block vector into the valid part of the IBC virtual buffer is found
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -107,7 +109,7 @@ void vvs_default_params( vvs_params* P )
   P->base_qp = 32; P->min_cu_log2 = 3;
   P->p_intra = 0.15f; P->p_bi = 0.6f; P->p_coded = 0.35f; P->p_coded_chroma = 0.2f; P->p_small_corner = 0.8f; P->p_mts = 0.15f; P->p_ts = 0.03f; P->p_lfnst = 0.2f;
   P->p_split_scale = 1.0f; P->mv_sigma = 8.0f; P->p_sao = 0.4f; P->p_alf_luma = 0.8f; P->p_alf_chroma = 0.5f; P->p_ccalf = 0.3f; P->p_imv_hpel = 0.1f; P->p_jccr = 0.1f; P->p_mrl = 0.15f; P->p_bdpcm = 0.03f;
-  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f; P->p_mip = 0.0f; P->p_sbt = 0.0f; P->p_isp = 0.0f; P->dual_tree = 0.0f;
+  P->p_affine = 0.0f; P->p_geo = 0.0f; P->p_ciip = 0.0f; P->p_sbtmvp = 0.0f; P->p_bcw = 0.05f; P->p_cclm = 0.0f; P->p_mip = 0.0f; P->p_sbt = 0.0f; P->p_isp = 0.0f; P->dual_tree = 0.0f; P->p_ibc = 0.0f;
 }
 
 namespace {
@@ -122,6 +124,62 @@ struct Gen {
   int modeType = 0;                // mode constraint of the current sub-tree (SCIPU): 0 all, 1 inter only, 2 intra only (local dual tree)
   bool cclmOk = true;              // CCLM allowed for the chroma CUs being added (CU::checkCCLMAllowed, UnitTools.cpp:3439)
   Gen( const vvs_params& p, vvs_buffers& b ) : P( p ), B( b ), rng( p.seed ) {}
+
+  // intra block copy: what the IBC virtual buffer of every CTU row holds (CodingStructure::fillIBCbuffer, CodingStructure.cpp:550): per
+  // 4x4 cell of the buffer the picture column (in 4-sample units) of the samples stored there, -1 = nothing valid; luma and chroma
+  // are filled by different CUs in separate trees.  The buffer is 256 * 128 / CtbSize luma samples wide and wraps.
+  bool ibcOn = false;
+  int ibcW4 = 0;
+  std::vector<int32_t> vbL, vbC;
+  bool ibcCellsValid( const std::vector<int32_t>& vb, int rx, int ry, int w, int h, int ctuY0 ) const
+  {
+    if( rx < 0 || ry < ctuY0 || rx + w > W || ry + h > std::min( H, ctuY0 + ctu ) ) return false;
+    for( int cy = ry >> 2; cy <= ( ry + h - 1 ) >> 2; cy++ ) for( int cx = rx >> 2; cx <= ( rx + w - 1 ) >> 2; cx++ )
+      if( vb[(size_t) cy * ibcW4 + ( cx % ibcW4 )] != cx ) return false;
+    return true;
+  }
+  // a block vector whose reference block is completely valid in the virtual buffer (luma, and chroma at the halved vector for CUs
+  // that carry chroma); tries a few candidates left of / above the CU inside the CTU row
+  bool findBv( int x, int y, int w, int h, bool withChroma, int& bvx, int& bvy )
+  {
+    const int ctuY0 = y & ~( ctu - 1 );
+    for( int t = 0; t < 24; t++ )
+    {
+      int rx, ry;
+      const int kind = rng.u( 3 );
+      if( kind == 0 ) { rx = x - w - (int) rng.u( 48 ); ry = y + (int) rng.u( 17 ) - 8; }                  // left of the CU
+      else if( kind == 1 ) { rx = x + (int) rng.u( 17 ) - 8; ry = y - h - (int) rng.u( 32 ); }             // above it
+      else { rx = x - (int) rng.u( std::min( x, 4 * ibcW4 - ctu ) + 1 ); ry = ctuY0 + (int) rng.u( ctu - h + 1 ); }   // anywhere in the buffer
+      if( rng.p( 0.3 ) ) { rx &= ~3; ry &= ~3; }
+      const int vx = rx - x, vy = ry - y;
+      if( !ibcCellsValid( vbL, rx, ry, w, h, ctuY0 ) ) continue;
+      if( withChroma && !ibcCellsValid( vbC, x + 2 * ( vx >> 1 ), y + 2 * ( vy >> 1 ), w, h, ctuY0 ) ) continue;
+      bvx = vx; bvy = vy;
+      return true;
+    }
+    return false;
+  }
+  void ibcTrack( const vvr_cu& cu )
+  {
+    const int vS = std::min( ctu, 64 );
+    if( cu.tree != VVR_TREE_CHROMA && ( cu.x % vS ) == 0 && ( cu.y % vS ) == 0 )
+    {
+      // start of a VPDU: the area half a buffer away is given up (DecCu.cpp:84-91, the virtual buffer reset of the decoding process)
+      const int rw = std::max<int>( vS, cu.w ), rh = std::max<int>( vS, cu.h );
+      for( int yy = 0; yy < rh && cu.y + yy < H; yy += 4 ) for( int xx = 0; xx < rw; xx += 4 )
+      {
+        const size_t k = (size_t) ( ( cu.y + yy ) >> 2 ) * ibcW4 + ( ( ( cu.x + xx ) >> 2 ) + ibcW4 / 2 ) % ibcW4;
+        vbL[k] = -1; vbC[k] = -1;
+      }
+    }
+    for( int yy = 0; yy < cu.h; yy += 4 ) for( int xx = 0; xx < cu.w; xx += 4 )
+    {
+      const int cx = ( cu.x + xx ) >> 2;
+      const size_t k = (size_t) ( ( cu.y + yy ) >> 2 ) * ibcW4 + cx % ibcW4;
+      if( cu.tree != VVR_TREE_CHROMA ) vbL[k] = cx;
+      if( cu.tree != VVR_TREE_LUMA ) vbC[k] = cx;
+    }
+  }
 
   bool wpOn = false;
   bool wpPresent( int l, int r ) const { return wpOn && r >= 0 && ( B.wp->e[l][r][0].present || B.wp->e[l][r][1].present || B.wp->e[l][r][2].present ); }
@@ -232,9 +290,19 @@ struct Gen {
     cu.qp = (int8_t) std::min( 63, std::max( 0, P.base_qp + (int) rng.u( 7 ) - 3 ) );
     cu.bcw_idx = 2; cu.ref_idx[0] = cu.ref_idx[1] = -1;
     const bool isI = P.slice_type == 2;
-    const bool intra = isI || modeType == 2 || ( modeType != 1 && std::max( w, h ) <= 64 && rng.p( P.p_intra ) );
-    cu.pred_mode = intra ? VVR_PRED_INTRA : VVR_PRED_INTER;
-    if( intra )
+    const bool intraCand = isI || modeType == 2 || ( modeType != 1 && std::max( w, h ) <= 64 && rng.p( P.p_intra ) );
+    // intra block copy instead of intra prediction (IBC CUs take the place of intra CUs in the coding tree: same size limits)
+    bool ibc = false;
+    if( intraCand && ibcOn && P.p_ibc > 0 && !treeC && w <= 64 && h <= 64 && rng.p( P.p_ibc ) )
+    {
+      int bvx = 0, bvy = 0;
+      ibc = findBv( x, y, w, h, !treeL && P.chroma_format, bvx, bvy );
+      if( ibc ) { cu.mv[0][0][0] = bvx * 16; cu.mv[0][0][1] = bvy * 16; cu.inter_dir = 1; cu.intra_dir[0] = 1; /* DC: what a co-located chroma CU derives */ }
+    }
+    const bool intra = intraCand && !ibc;
+    cu.pred_mode = ibc ? VVR_PRED_IBC : intra ? VVR_PRED_INTRA : VVR_PRED_INTER;
+    if( ibc ) {}
+    else if( intra )
     {
       const int r = rng.u( 100 );
       cu.intra_dir[0] = r < 20 ? 0 : r < 35 ? 1 : 2 + rng.u( 65 );
@@ -366,7 +434,7 @@ struct Gen {
     }
     // sub-block transform (cu_sbt_flag): the CU is split in two TUs, half/half or quarter/three quarters, and only one carries a residual
     int sbtIdx = 0, sbtPos = 0;
-    if( !intra && P.p_sbt > 0 && !( cu.flags & VVR_CU_CIIP ) && w <= 64 && h <= 64 && rng.p( P.p_sbt ) )
+    if( !intra && !ibc && P.p_sbt > 0 && !( cu.flags & VVR_CU_CIIP ) && w <= 64 && h <= 64 && rng.p( P.p_sbt ) )
     {
       int cand[4], n = 0;
       if( w >= 8 ) cand[n++] = 1;      // SBT_VER_HALF
@@ -435,7 +503,7 @@ struct Gen {
         if( ( c == 0 || treeC ) && intra && cu.lfnst_idx ) ts = false;
         tu.mts_idx[c] = ts ? VVR_MTS_SKIP : VVR_MTS_DCT2;
         const bool implicitMts = intra && ( P.tool_flags & VVR_TOOL_IMPLICIT_MTS );
-        if( !ts && c == 0 && bw <= 32 && bh <= 32 && !sbtIdx && !cu.isp_mode && !implicitMts && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
+        if( !ts && c == 0 && bw <= 32 && bh <= 32 && !sbtIdx && !cu.isp_mode && !implicitMts && !ibc && !( intra && cu.lfnst_idx ) && rng.p( P.p_mts ) ) tu.mts_idx[c] = (uint8_t) ( 2 + rng.u( 4 ) );
         // getTrTypes (TrQuant.cpp:330): explicit MTS -> hor = (idx-2)&1 ? DCT8 : DST7 ; ver = (idx-2)>>1 ? DCT8 : DST7
         int hor = 0, ver = 0;
         if( tu.mts_idx[c] > 1 ) { hor = ( ( tu.mts_idx[c] - 2 ) & 1 ) ? 1 : 2; ver = ( ( tu.mts_idx[c] - 2 ) >> 1 ) ? 1 : 2; }
@@ -472,7 +540,9 @@ struct Gen {
       vvr_motion& m = B.motion[i4];
       m.ref_idx[0] = cu.ref_idx[0]; m.ref_idx[1] = cu.ref_idx[1];
       for( int l = 0; l < 2; l++ ) { m.mv[l][0] = cu.ref_idx[l] >= 0 ? cu.mv[l][0][0] : 0; m.mv[l][1] = cu.ref_idx[l] >= 0 ? cu.mv[l][0][1] : 0; }
+      if( ibc ) { m.mv[0][0] = cu.mv[0][0][0]; m.mv[0][1] = cu.mv[0][0][1]; }      // block vector, no reference index (PU::spanMotionInfo, UnitTools.cpp:3018)
     }
+    if( ibcOn ) ibcTrack( cu );
     if( cu.flags & VVR_CU_AFFINE ) for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= 0 ) setAllAffineMv( cu, l );
     if( cu.flags & VVR_CU_SBTMVP )
     {
@@ -646,6 +716,11 @@ struct Gen {
           else { lenP = sizeP >= 32 ? 7 : 3; lenQ = sizeQ >= 32 ? 7 : 3; }
           L.side_max_filt_length = (uint8_t) ( 0x80 | ( lenP << 4 ) | lenQ );
           L.flags |= 1; bsY = ( B.cu[TQ.cu].bdpcm[0] && B.cu[TP.cu].bdpcm[0] ) ? 0 : 2;      // no filtering between two BDPCM blocks (LoopFilter.cpp:1146)
+          if( B.cu[TQ.cu].pred_mode == VVR_PRED_IBC && B.cu[TP.cu].pred_mode == VVR_PRED_IBC )
+          {   // two IBC blocks: coded residual, else the block vectors (the current picture is the reference of both, LoopFilter.cpp:1346-1360)
+            const vvr_motion& mq = B.motion[iq]; const vvr_motion& mp = B.motion[ip];
+            bsY = ( ( TQ.cbf & 1 ) || ( TP.cbf & 1 ) ) ? 1 : ( TQ.cu != TP.cu && ( std::abs( mq.mv[0][0] - mp.mv[0][0] ) >= 8 || std::abs( mq.mv[0][1] - mp.mv[0][1] ) >= 8 ) ) ? 1 : 0;
+          }
           L.qp[0] = (int8_t) ( ( B.cu[TQ.cu].qp + B.cu[TP.cu].qp + 1 ) >> 1 );
         }
         const int posAlong = d == 0 ? ( x4 << 2 ) : ( y4 << 2 );
@@ -724,13 +799,26 @@ struct Gen {
         // boundary strength (LoopFilter.cpp:1094-1360)
         int bsY = 0, bsCb = 0, bsCr = 0;
         const bool intra = CQ.pred_mode == VVR_PRED_INTRA || CP.pred_mode == VVR_PRED_INTRA || ( ( CQ.flags | CP.flags ) & VVR_CU_CIIP );   // CIIP counts as intra for the BS
-        if( intra ) { bsY = ( CQ.bdpcm[0] && CP.bdpcm[0] ) ? 0 : 2; bsCb = bsCr = chromaEdge ? 2 : 0; }     // no luma filtering between two BDPCM blocks (LoopFilter.cpp:1146)
+        // (the chroma of a local dual tree is always intra, also next to IBC luma CUs)
+        const bool intraC = CQc.pred_mode == VVR_PRED_INTRA || CPc.pred_mode == VVR_PRED_INTRA || ( ( CQc.flags | CPc.flags ) & VVR_CU_CIIP );
+        if( chromaEdge )
+        {
+          const bool jointChr = TQc.joint_cbcr || TPc.joint_cbcr;     // (LoopFilter.cpp:1180-1184)
+          if( intraC ) bsCb = bsCr = 2;
+          else { if( ( TQc.cbf & 2 ) || ( TPc.cbf & 2 ) || jointChr ) bsCb = 1; if( ( TQc.cbf & 4 ) || ( TPc.cbf & 4 ) || jointChr ) bsCr = 1; }
+        }
+        if( intra ) bsY = ( CQ.bdpcm[0] && CP.bdpcm[0] ) ? 0 : 2;      // no luma filtering between two BDPCM blocks (LoopFilter.cpp:1146)
         else
         {
           if( ( TQ.cbf & 1 ) || ( TP.cbf & 1 ) ) bsY = 1;
-          const bool jointChr = TQc.joint_cbcr || TPc.joint_cbcr;     // (LoopFilter.cpp:1180-1184)
-          if( chromaEdge ) { if( ( TQc.cbf & 2 ) || ( TPc.cbf & 2 ) || jointChr ) bsCb = 1; if( ( TQc.cbf & 4 ) || ( TPc.cbf & 4 ) || jointChr ) bsCr = 1; }
-          if( !bsY && &CQ != &CP ) bsY = motionBs( iq, ip );
+          if( !bsY && &CQ != &CP )
+          {
+            // IBC: a different prediction mode on the other side always filters (:1218); two IBC blocks compare their block vectors,
+            // the current picture being the reference of both (:1237-1240,1346-1360)
+            if( CQ.pred_mode != CP.pred_mode ) bsY = 1;
+            else if( CQ.pred_mode == VVR_PRED_IBC ) bsY = ( std::abs( B.motion[iq].mv[0][0] - B.motion[ip].mv[0][0] ) >= 8 || std::abs( B.motion[iq].mv[0][1] - B.motion[ip].mv[0][1] ) >= 8 ) ? 1 : 0;
+            else bsY = motionBs( iq, ip );
+          }
         }
         L.bs = (uint8_t) ( bsY | ( bsCb << 2 ) | ( bsCr << 4 ) );
         L.qp[0] = (int8_t) ( ( CQ.qp + CP.qp + 1 ) >> 1 );
@@ -878,6 +966,8 @@ struct Gen {
     wpOn = ( h.tool_flags & VVR_TOOL_WP ) && B.wp;
     if( wpOn ) genWp();
     if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && B.scaling ) genScalingList();
+    ibcOn = ( h.tool_flags & VVR_TOOL_IBC ) != 0;
+    if( ibcOn ) { ibcW4 = ( 256 * 128 / ctu ) >> 2; vbL.assign( (size_t) h4 * ibcW4, -1 ); vbC.assign( (size_t) h4 * ibcW4, -1 ); }
     int a = 0;
     const bool dual = P.slice_type == 2 && P.dual_tree > 0 && P.chroma_format;
     if( dual || P.min_cu_log2 == 2 ) { cuOf4C.assign( (size_t) w4 * h4, -1 ); tuOf4C.assign( (size_t) w4 * h4, -1 ); }
