@@ -214,7 +214,7 @@ def main():
                                          "K pictures of the running stream after W warm-up pictures (%d IRAP in the timed pictures, submitted %d pictures ahead of its decoding-order position)" % (n_irap, a.irap_lookahead)),
                           "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM + ISP, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
                           "mix": MIX,
-                          "not_in_mix": "SBT, explicit weighted prediction, scaling lists (implemented and tested, not part of the configuration of SURVEY.md 8(d)); dual-tree I pictures, CUs down to 4x4 and local dual trees are implemented and tested too; IBC is rejected with VVR_ERR_UNSUPPORTED",
+                          "not_in_mix": "SBT, explicit weighted prediction, scaling lists (implemented and tested, not part of the configuration of SURVEY.md 8(d)); dual-tree I pictures, CUs down to 4x4, local dual trees and IBC are implemented and tested too",
                           "pictures_in_flight": a.streams, "sharding": "closed-GOP segment per GPU, no data-path collective",
                           "verified_pictures_vs_oracle": verified, "timed_run_equals_serial_run": bool(a.verify)},
                "roofline": roof}

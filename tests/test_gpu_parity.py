@@ -277,6 +277,24 @@ def test_small_cus_and_local_dual_tree(built):
     _run_stream(256, 128, 5, 4, 254, T, intra=True, min_cu_log2=2, p_intra=0.2, p_split_scale=1.8, p_ciip=0.6, p_coded=0.6, p_coded_chroma=0.5)
 
 
+_IBC = abi.TOOL_IBC
+_IBC_L = abi.TOOL_IBC | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE
+
+
+@pytest.mark.parametrize("W,H,frames,gop,seed,extra,kw", [
+    (256, 128, 5, 4, 261, _IBC, dict(p_ibc=0.5, p_intra=0.4, p_coded=0.5)),
+    (416, 240, 3, 2, 262, _IBC_L, dict(log2_ctu=6, p_ibc=0.5, p_intra=0.3, p_split_scale=1.4, p_cclm=0.3, p_jccr=0.3, p_coded_chroma=0.5, p_ciip=0.1)),
+    (256, 192, 3, 2, 263, _IBC_L, dict(log2_ctu=5, p_ibc=0.6, p_intra=0.5, p_isp=0.2, p_mip=0.2)),
+    (256, 128, 3, 2, 264, _IBC_L, dict(dual_tree=2.0, p_ibc=0.5, p_split_scale=1.5, p_cclm=0.3)),
+    (416, 240, 3, 2, 265, _IBC, dict(min_cu_log2=2, p_ibc=0.6, p_intra=0.4, p_split_scale=1.6)),
+    (1920, 1080, 3, 2, 266, _IBC_L, dict(streams=3, p_ibc=0.3, p_affine=0.1, p_ciip=0.05)),
+], ids=["ctu128", "ctu64_lmcs", "ctu32_lmcs", "dual_tree", "small_cus", "1080p"])
+def test_intra_block_copy(built, W, H, frames, gop, seed, extra, kw):
+    """IBC CUs: copies of reconstructed samples of the current picture (block vectors into the CTU itself and into the CTUs left of it),
+    chroma at the halved vector, luma-only CUs of dual / local dual trees, LMCS chroma residual scaling, I and B pictures"""
+    _run_stream(W, H, frames, gop, seed, TOOLS_A | extra, intra=True, **kw)
+
+
 def test_joint_cbcr(built):
     """tu_joint_cbcr_residual: one coded chroma block, the other derived (all three modes, both signs)"""
     _run_stream(256, 128, 5, 4, 171, TOOLS_A, intra=True, p_jccr=0.7, p_coded_chroma=0.7, p_intra=0.3)

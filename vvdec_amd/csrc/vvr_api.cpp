@@ -325,7 +325,31 @@ static int validate( vvr_context* c, const vvr_picture* p )
       }
       if( cu.intra_dir[0] > 66 || cu.multi_ref_idx > 2 || cu.bdpcm[1] ) { c->setError( "bad intra mode / chroma BDPCM not implemented" ); return VVR_ERR_UNSUPPORTED; }
     }
-    else { c->setError( "IBC CUs are not implemented in this build" ); return VVR_ERR_UNSUPPORTED; }
+    else if( cu.pred_mode == VVR_PRED_IBC )
+    {
+      // intra block copy (InterPrediction::xIntraBlockCopy, InterPrediction.cpp:1995): integer block vector in mv[0][0], luma at most 64x64
+      // (IBC_MAX_CU_SIZE), one TU, no intra / inter tools; sizes as for intra CUs.  That the reference block precedes the CU in decoding order
+      // is checked where the work lists are built.
+      if( !( h.tool_flags & VVR_TOOL_IBC ) ) { c->setError( "IBC CU in a picture without VVR_TOOL_IBC" ); return VVR_ERR_PARAMETER; }
+      const int minW = cu.tree == VVR_TREE_LUMA ? 4 : 8;
+      if( cu.tree == VVR_TREE_CHROMA || cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( cu.tree != VVR_TREE_LUMA && cu.w * cu.h < 64 ) || cu.num_tu != 1 )
+      { c->setError( "IBC CU: chroma tree, size out of range or more than one TU" ); return VVR_ERR_PARAMETER; }
+      if( ( cu.mv[0][0][0] | cu.mv[0][0][1] ) & 15 ) { c->setError( "IBC CU: fractional block vector" ); return VVR_ERR_PARAMETER; }
+      if( cu.isp_mode || cu.bdpcm[0] || cu.bdpcm[1] || cu.lfnst_idx || cu.sbt_info || ( cu.flags & ( VVR_CU_MIP | VVR_CU_CIIP | VVR_CU_AFFINE | VVR_CU_GEO | VVR_CU_SBTMVP ) ) )
+      { c->setError( "IBC CU combined with an intra / inter tool" ); return VVR_ERR_PARAMETER; }
+      if( cu.tree == VVR_TREE_LUMA && h.chroma_format && p->tu[cu.first_tu].comp_mask != 1 ) { c->setError( "separate-tree CU: TU component mask" ); return VVR_ERR_PARAMETER; }
+      const int bvx = cu.mv[0][0][0] >> 4, bvy = cu.mv[0][0][1] >> 4, ctuS = 1 << h.log2_ctu, rowTop = cu.y & ~( ctuS - 1 );
+      const int bufW = 256 * 128 / ctuS;                              // width of the IBC virtual buffer (Rom.h:210, CodingStructure.cpp:543)
+      bool ok = cu.x + bvx >= 0 && cu.x + bvx + cu.w <= h.width && cu.y + bvy >= rowTop && cu.y + bvy + cu.h <= std::min<int>( h.height, rowTop + ctuS )
+             && cu.x + bvx + cu.w <= ( ( cu.x >> h.log2_ctu ) + 1 ) * ctuS && cu.x + bvx >= ( cu.x & ~( ctuS - 1 ) ) - ( bufW - ctuS );
+      if( ok && cu.tree == VVR_TREE_JOINT && h.chroma_format )
+      {
+        const int cxr = ( cu.x >> 1 ) + ( bvx >> 1 ), cyr = ( cu.y >> 1 ) + ( bvy >> 1 );
+        ok = cxr >= 0 && cxr + ( cu.w >> 1 ) <= ( h.width >> 1 ) && cyr >= ( rowTop >> 1 ) && cyr + ( cu.h >> 1 ) <= std::min<int>( h.height, rowTop + ctuS ) >> 1 && 2 * cxr >= ( cu.x & ~( ctuS - 1 ) ) - ( bufW - ctuS );
+      }
+      if( !ok ) { c->setError( "IBC CU: reference block outside the picture, the CTU row or the reach of the IBC buffer" ); return VVR_ERR_PARAMETER; }
+    }
+    else { c->setError( "unknown prediction mode" ); return VVR_ERR_PARAMETER; }
   }
   return VVR_OK;
 }
@@ -375,7 +399,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   std::vector<ItemH> itemH[3];
   std::vector<int32_t> itemAt[3];        // per component and 4x4 luma cell: the block that reconstructs it in the intra stage (-1: none)
   bool anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
-  for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || ( p->cu[i].flags & VVR_CU_CIIP );
+  for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
   if( anyIntra )
   {
     order.assign( (size_t) w4 * h4 * 2, 0x7fffffff );
@@ -449,7 +473,10 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     // produce, and intra blocks next to it read its reconstructed chroma, so the residual add of such a block is an item of the
     // intra stage too (IT_MODE_RESI_ADD: no prediction, scaled residual onto the inter prediction; finishLMCSAndReco, DecCu.cpp:483)
     const bool isCsInterCu = cscale && cu.pred_mode == VVR_PRED_INTER && ( !isCiipCu || cu.w == 4 ) && ( cu.flags & VVR_CU_ROOT_CBF );
-    if( cu.pred_mode == VVR_PRED_INTRA || isCiipCu || isCsInterCu )
+    // intra block copy: the block is a copy of reconstructed samples of this picture that the intra stage may still have to produce, so it
+    // is an item of the intra stage as well (IT_MODE_IBC; the reference does it in its intra task too, DecCu.cpp:145)
+    const bool isIbcCu = cu.pred_mode == VVR_PRED_IBC;
+    if( cu.pred_mode == VVR_PRED_INTRA || isCiipCu || isCsInterCu || isIbcCu )
     {
       for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
       {
@@ -460,7 +487,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           // the 2-wide chroma blocks of a 4-wide CIIP CU are not blended (predBlendIntraCiip, IntraPrediction.cpp:891): plain inter blocks
           const bool isCiip = isCiipCu && !( comp && cu.w == 4 );
           const bool isCsInter = cscale && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
-          if( cu.pred_mode != VVR_PRED_INTRA && !isCiip && !isCsInter ) continue;
+          if( cu.pred_mode != VVR_PRED_INTRA && !isCiip && !isCsInter && !isIbcCu ) continue;
           if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
           const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
           // intra sub-partitions: luma partitions are blocks of their own that share the reference line of the whole CU
@@ -478,7 +505,10 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           it.tu = t; it.comp = (uint8_t) comp;
           it.x = (uint16_t) x0; it.y = (uint16_t) y0;
           { int l = 0; while( ( 1 << l ) < w ) l++; it.lw = (uint8_t) l; l = 0; while( ( 1 << l ) < hh ) l++; it.lh = (uint8_t) l; }
-          it.mode = isCsInter ? IT_MODE_RESI_ADD : isCiip ? 0 : cu.intra_dir[chn];       // CIIP: planar
+          it.mode = isIbcCu ? IT_MODE_IBC : isCsInter ? IT_MODE_RESI_ADD : isCiip ? 0 : cu.intra_dir[chn];       // CIIP: planar
+          // IBC: the block vector in samples of the component (chroma: halved, InterPrediction.cpp:2010-2011)
+          const int ibcDx = isIbcCu ? ( cu.mv[0][0][0] >> 4 ) >> cs : 0, ibcDy = isIbcCu ? ( cu.mv[0][0][1] >> 4 ) >> cs : 0;
+          if( isIbcCu ) it.tu = ( (uint32_t) ibcDx & 0xffff ) | ( (uint32_t) ibcDy << 16 );
           bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
           if( ispL )
           {
@@ -493,19 +523,20 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
                   | ( (uint32_t) ( cu.isp_mode == 2 ) << 18 ) | ( mask << 19 ) | ( grp << 23 );
             hasResi = mask != 0;
           }
-          const int bdp = ( isCiip || isCsInter ) ? 0 : cu.bdpcm[chn];
+          const int bdp = ( isCiip || isCsInter || isIbcCu ) ? 0 : cu.bdpcm[chn];
           // CIIP blend weight of the intra part (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:925-929): 1 + intra neighbours
           const int wIntra = isCiip ? 1 + ( cu.ciip_neigh_intra & 1 ) + ( ( cu.ciip_neigh_intra >> 1 ) & 1 ) : 0;
-          it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip || isCsInter ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
+          it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip || isCsInter || isIbcCu ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
           if( !comp && !isCiip && ( cu.flags & VVR_CU_MIP ) ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_MIP | ( ( cu.flags & VVR_CU_MIP_TRANSP ) ? 0x10 : 0 ) );
           if( ispL ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_ISP );
-          if( !isCsInter ) it.nTL = (uint8_t) unitAvail( chn, rx0 - 1, ry0 - 1, rcur );
-          if( !isCsInter && unitAvail( chn, rx0, ry0 - 1, rcur ) ) { int n = rw / unit; for( int k = 0; k < totalAbove - rw / unit; k++ ) { if( !unitAvail( chn, rx0 + rw + k * unit, ry0 - 1, rcur ) ) break; n++; } it.nA = (uint8_t) n; }
-          if( !isCsInter && unitAvail( chn, rx0 - 1, ry0, rcur ) ) { int n = rh / unit; for( int k = 0; k < totalLeft - rh / unit; k++ ) { if( !unitAvail( chn, rx0 - 1, ry0 + rh + k * unit, rcur ) ) break; n++; } it.nL = (uint8_t) n; }
+          const bool noRef = isCsInter || isIbcCu;                                  // no intra reference lines
+          if( !noRef ) it.nTL = (uint8_t) unitAvail( chn, rx0 - 1, ry0 - 1, rcur );
+          if( !noRef && unitAvail( chn, rx0, ry0 - 1, rcur ) ) { int n = rw / unit; for( int k = 0; k < totalAbove - rw / unit; k++ ) { if( !unitAvail( chn, rx0 + rw + k * unit, ry0 - 1, rcur ) ) break; n++; } it.nA = (uint8_t) n; }
+          if( !noRef && unitAvail( chn, rx0 - 1, ry0, rcur ) ) { int n = rh / unit; for( int k = 0; k < totalLeft - rh / unit; k++ ) { if( !unitAvail( chn, rx0 - 1, ry0 + rh + k * unit, rcur ) ) break; n++; } it.nL = (uint8_t) n; }
           int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0; bool isCclm = false;
           const bool csItem = cscale && comp && hasResi && w * hh > 4;             // DecCu.cpp:383-388 / :500-505
           if( csItem ) it.flags |= IT_F_CSCALE;
-          if( comp && !isCiip && !isCsInter && cu.intra_dir[1] >= 67 )
+          if( comp && !isCiip && !isCsInter && !isIbcCu && cu.intra_dir[1] >= 67 )
           {
             // CCLM / MDLM: template sizes and flags of IntraPrediction::xGetLMParameters (:1694-1800) and the border handling of
             // xGetLumaRecPixels (:1403-1470); they ride in the item's `tu` word
@@ -540,7 +571,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
           IH.ctu = ctuOfCu;
           {
             const int ctuX = cu.x >> h.log2_ctu, ctuY = cu.y >> h.log2_ctu;
-            const int mrl = comp ? 0 : cu.multi_ref_idx;
+            const int mrl = ( comp || isIbcCu ) ? 0 : cu.multi_ref_idx;
             auto touch = [&]( int k, int xc, int yc )   // component k, component coordinates of a sample that is read
             {
               const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
@@ -564,6 +595,17 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
             for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, rx0 + k, ry0 - 1 - mrl );
             for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, rx0 - 1 - mrl, ry0 + k );
             if( ispL && ( x0 != rx0 || y0 != ry0 ) ) touch( 0, cu.isp_mode == 2 ? x0 - 1 : x0, cu.isp_mode == 2 ? y0 : y0 - 1 );   // ISP: the previous partition
+            if( isIbcCu )
+            {
+              // the reference block: every cell must precede this block in decoding order; the intra-stage blocks that produce it are producers
+              const int qx = x0 + ibcDx, qy = y0 + ibcDy;
+              for( int yy = 0; yy < hh + unit - 1; yy += unit ) for( int xx = 0; xx < w + unit - 1; xx += unit )
+              {
+                const int sx = qx + std::min( xx, w - 1 ), sy = qy + std::min( yy, hh - 1 );
+                if( !unitAvail( chn, sx, sy, (int32_t) t ) ) { c->setError( "IBC CU: the reference block is not reconstructed before the CU" ); return VVR_ERR_PARAMETER; }
+                touch( comp, sx, sy );
+              }
+            }
             if( csItem )
             {
               // luma the chroma scaling factor is averaged over (the unit must wait for the luma units that reconstruct it)

@@ -57,6 +57,7 @@ enum { TB_ADD = 0, TB_STORE = 1 };
 #define IT_F_ISP      6   /* both BDPCM bits (never together otherwise): luma intra sub-partition; IntraItem::tu then holds x - cuX | ( y - cuY ) << 6
                              | log2 cuW << 12 | log2 cuH << 15 | vertical split << 18 | residual flags of the partitions of a group << 19 (4 bits) | group << 23 (1: two 2-wide, 2: four 1-wide partitions) */
 #define IT_MODE_RESI_ADD 255 /* mode value: no prediction, the (LMCS-scaled) residual is added to the inter prediction already in the picture */
+#define IT_MODE_IBC      254 /* mode value: intra block copy, the prediction is a copy of reconstructed samples of this picture; IntraItem::tu = dx & 0xffff | dy << 16 (component samples) */
 #define IT_F_CSCALE   8      /* chroma: LMCS chroma residual scaling applies to the residual */
 #define IT_F_BDPCM_V  4      /* bits 4..5: multi-reference-line index; bits 6..7: CIIP intra weight (0 = ordinary intra block) */
 struct IntraItem {        // 16 bytes, self-contained: the kernel never touches the CU/TU records on its serial path

@@ -2150,6 +2150,21 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           uint32_t* op = reinterpret_cast<uint32_t*>( &it );
           for( int e = 0; e < 4; e++ ) op[e] = __builtin_amdgcn_readfirstlane( ip[e] );
         }
+        if( it.mode == IT_MODE_IBC )
+        {
+          // intra block copy: the part of the reference block that lies in this CTU is read from the tile (blocks of this unit write
+          // their samples there first), so it is staged like a reference line; the part in a CTU further left is read from HBM
+          const int bw = 1 << it.lw, bh = 1 << it.lh;
+          const int rx = (int) it.x + (int16_t) ( it.tu & 0xffff ), ry = (int) it.y + (int16_t) ( it.tu >> 16 );
+          const int cx0 = max( rx, ox ) & ~7, cch = max( 0, ( rx + bw - cx0 + 7 ) >> 3 );
+          for( int i = ( tid & 63 ); i < cch * bh; i += 64 )
+          {
+            const int y = ry + i / cch, x = cx0 + 8 * ( i % cch );
+            const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
+            *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
+          }
+          continue;
+        }
         const bool isp = !comp && ( it.flags & IT_F_ISP ) == IT_F_ISP;
         if( isp && ( it.tu & 0xfff ) ) continue;                               // later ISP partitions: the CU's line was fetched with the first one
         const int bw = isp ? 1 << ( ( it.tu >> 12 ) & 7 ) : 1 << it.lw, bh = isp ? 1 << ( ( it.tu >> 15 ) & 7 ) : 1 << it.lh;
@@ -2244,6 +2259,31 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       int csScale = 0;
       const bool csOn = comp && ( it.flags & IT_F_CSCALE );
       if( csOn ) csScale = sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )];
+      // ---- intra block copy (InterPrediction::xIntraBlockCopy :1995, DecCu.cpp:442-470): copy of reconstructed samples of this picture
+      // at the block vector (+ residual).  Samples of this CTU come from the tile, where the blocks of this unit have put theirs and
+      // the others were staged after the wait for their producers; samples of a CTU further left come from HBM.
+      if( dirMode == IT_MODE_IBC )
+      {
+        const int qx = x0 + (int16_t) ( it.tu & 0xffff ), qy = y0 + (int16_t) ( it.tu >> 16 );
+        if( tid == 255 ) sh.dcSum[( k + 1 ) & 1] = 0;
+#pragma unroll 1
+        for( int i = tid; i < w * h; i += 256 )
+        {
+          const int x = i & ( w - 1 ), y = i >> lw;
+          const int sx = qx + x, sy = qy + y;
+          int v = sx >= ox ? (int) TILE( sx, sy ) : (int) plane[(size_t) sy * pstride + sx];
+          if( hasResi ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
+          TILE( x0 + x, y0 + y ) = (pel_t) v;
+        }
+        if( k + 1 < nb )
+        {
+          const bool big = ( sh.items[k + 1].lw + sh.items[k + 1].lh ) > 8;
+          if( big ) lds_barrier();                                 // the single large buffer may still be read by slower wavefronts of this block
+          intra_stash_resi1( sh.items[k + 1], big ? sh.resiB : sh.resiS[( k + 1 ) & 1], tid, rpre, rs, rstride );
+        }
+        lds_barrier();
+        continue;
+      }
       // reference line lengths; ISP: CU size + partition size along the split, twice the CU size across (IntraPrediction.cpp:1000-1001).
       // f*: the block whose line is fetched from the picture (ISP: the whole CU, initIntraPatternChTypeISP :966-999)
       const int topLen = isp ? ( ispVer ? cuW + w : 2 * cuW ) : 2 * w, leftLen = isp ? ( ispVer ? 2 * cuH : cuH + h ) : 2 * h;
