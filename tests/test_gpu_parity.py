@@ -14,25 +14,27 @@ pytestmark = pytest.mark.gpu
 TOOLS = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS
 
 
-def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=True, intra=False, **kw):
+def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=True, intra=False, bit_depth=10, chroma_format=1, **kw):
     """intra=False: POC 0 is an uploaded picture and all CUs are inter; intra=True: POC 0 is an I picture reconstructed by the
     back-end and the B pictures contain intra CUs (p_intra)."""
     import vvdec_amd
     plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=not intra)
-    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=streams, log2_ctu=log2_ctu)
-    seed_pic = synth.natural_picture(W, H, seed)
+    ncomp = 3 if chroma_format else 1
+    geo = dict(log2_ctu=log2_ctu, bit_depth=bit_depth, chroma_format=chroma_format)
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=streams, **geo)
+    seed_pic = synth.natural_picture(W, H, seed, bit_depth=bit_depth)[:ncomp]
     cpu = {}
     if not intra:
         rec.write_picture(0, seed_pic)
         cpu = {0: seed_pic}
         kw.setdefault("p_intra", 0.0)
     hashes = []
-    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=log2_ctu, **kw) for pl in plans]
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **geo, **kw) for pl in plans]
     jobs = [rec.decompress_picture(d) for d in descs]          # everything in flight: the back-end orders the dependencies
     rec.sync()
     # verify in decode order; the CPU oracle consumes its own previous outputs as references.  A slot is overwritten
     # later in the stream, so pictures are read back in a second, serial pass.
-    rec2 = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, log2_ctu=log2_ctu)
+    rec2 = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, **geo)
     if not intra:
         rec2.write_picture(0, seed_pic)
     for pl, d in zip(plans, descs):
@@ -42,7 +44,7 @@ def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=Tru
         hashes.append(hashlib.md5(b"".join(p.tobytes() for p in got)).hexdigest())
         if check:
             want = refdrv.oracle_reconstruct(d, cpu)
-            for c in range(3):
+            for c in range(ncomp):
                 assert np.array_equal(got[c], want[c]), "POC %d comp %d: %d samples differ" % (pl.poc, c, int((got[c] != want[c]).sum()))
             cpu[pl.slot] = want
             nd = getattr(d, "num_dmvr", 0)
@@ -55,7 +57,7 @@ def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=Tru
     for slot, pl in last.items():
         a = rec.read_picture(slot)
         b = rec2.read_picture(slot)
-        for c in range(3):
+        for c in range(ncomp):
             assert np.array_equal(a[c], b[c]), "pipelined vs serial differ in slot %d" % slot
     rec.close()
     rec2.close()
@@ -275,6 +277,18 @@ def test_small_cus_and_local_dual_tree(built):
     _run_stream(1920, 1080, 3, 2, 253, T, intra=True, streams=3, min_cu_log2=2, p_split_scale=1.5, p_affine=0.1, p_ciip=0.05)
     # 4xN / Nx4 CIIP CUs: the 2-wide chroma blocks stay pure inter, the Nx2 ones are blended
     _run_stream(256, 128, 5, 4, 254, T, intra=True, min_cu_log2=2, p_intra=0.2, p_split_scale=1.8, p_ciip=0.6, p_coded=0.6, p_coded_chroma=0.5)
+
+
+@pytest.mark.parametrize("bit_depth,chroma_format", [(8, 1), (10, 0), (8, 0)], ids=["8bit_420", "10bit_400", "8bit_400"])
+def test_bit_depth_8_and_monochrome(built, bit_depth, chroma_format):
+    """the other sample formats of the Main 10 profile: 8-bit samples (interpolation head-room, deblocking tc, SAO / ALF / LMCS scales
+    change with the bit depth) and 4:0:0 pictures (luma only), every tool on, I and B pictures"""
+    T = TOOLS_A | abi.TOOL_LMCS | (abi.TOOL_LMCS_CSCALE if chroma_format else 0)
+    mix = dict(p_intra=0.25, p_affine=0.15, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.1, p_mip=0.2, p_isp=0.2, p_sbt=0.15, p_bcw=0.2)
+    if chroma_format:
+        mix.update(p_cclm=0.3, p_jccr=0.2, p_coded_chroma=0.5)
+    _run_stream(256, 128, 5, 4, 271, T, intra=True, bit_depth=bit_depth, chroma_format=chroma_format, **mix)
+    _run_stream(416, 240, 3, 2, 272, TOOLS_A | abi.TOOL_WP, intra=True, log2_ctu=6, bit_depth=bit_depth, chroma_format=chroma_format, **mix)
 
 
 _IBC = abi.TOOL_IBC

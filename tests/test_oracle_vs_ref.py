@@ -173,6 +173,26 @@ def test_oracle_equals_reference_intra_block_copy(built, W, H, l2, idx, seed, lm
             assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
 
 
+@pytest.mark.parametrize("bit_depth,chroma_format", [(8, 1), (10, 0), (8, 0)], ids=["8bit_420", "10bit_400", "8bit_400"])
+def test_oracle_equals_reference_other_sample_formats(built, bit_depth, chroma_format):
+    """8-bit samples and 4:0:0 pictures (the other formats of the Main 10 profile), intra and inter tools, with and without LMCS"""
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    for (W, H, l2, idx, seed, kw) in ((256, 128, 7, 0, 401, dict(p_cclm=0.3, p_mip=0.2, p_isp=0.2)),
+                                      (384, 256, 6, 2, 402, dict(p_intra=0.25, p_affine=0.2, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.1, p_sbt=0.1, p_bcw=0.2))):
+        for lm in (0, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE):
+            pl = plans[idx]
+            d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=ALL | lm, log2_ctu=l2, bit_depth=bit_depth, chroma_format=chroma_format, **kw)
+            refs = {}
+            for lst in pl.ref_slots:
+                for (slot, poc) in lst:
+                    refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc, bit_depth=bit_depth))
+            for fl in STAGES:
+                want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+                got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+                for c in range(3 if chroma_format else 1):
+                    assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+
+
 def test_reference_simd_equals_scalar(built):
     """the reference's own differential check (its unit test compares scalar vs SIMD kernels): same bytes at frame level"""
     d, refs = _case(256, 192, 7, 2, 106, p_intra=0.2)
