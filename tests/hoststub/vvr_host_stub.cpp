@@ -1,0 +1,62 @@
+// TEST INFRASTRUCTURE (tests/ only): the product's host glue (vvdec_amd/csrc/vvr_api.cpp: validation, work lists, intra-stage units and
+// their dependency graph, job bookkeeping) compiled for the CPU against a stand-in HIP runtime, so that the part of the scheduler that
+// lives on the host can be checked without a GPU.  "Device" memory is host memory, streams and events are inert, kernel launches do
+// nothing: no sample is ever computed here.  The product library never contains any of this.
+#include <hip/hip_runtime_api.h>
+#include <cstdlib>
+#include <cstring>
+
+extern "C" {
+hipError_t hipGetDeviceCount( int* n ) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice( int ) { return hipSuccess; }
+hipError_t hipGetDeviceProperties( hipDeviceProp_t* p, int ) { memset( p, 0, sizeof( *p ) ); strcpy( p->gcnArchName, "gfx950:host-stub" ); p->multiProcessorCount = 256; return hipSuccess; }
+hipError_t hipMalloc( void** p, size_t n ) { *p = calloc( 1, n ? n : 1 ); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree( void* p ) { free( p ); return hipSuccess; }
+hipError_t hipHostMalloc( void** p, size_t n, unsigned int ) { *p = calloc( 1, n ? n : 1 ); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree( void* p ) { free( p ); return hipSuccess; }
+hipError_t hipMemcpy( void* d, const void* s, size_t n, hipMemcpyKind ) { memcpy( d, s, n ); return hipSuccess; }
+hipError_t hipMemcpy2D( void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind ) { for( size_t y = 0; y < h; y++ ) memcpy( (char*) d + y * dp, (const char*) s + y * sp, w ); return hipSuccess; }
+hipError_t hipMemset( void* d, int v, size_t n ) { memset( d, v, n ); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags( hipStream_t* s, unsigned int ) { *s = (hipStream_t) calloc( 1, 8 ); return hipSuccess; }
+hipError_t hipStreamDestroy( hipStream_t s ) { free( s ); return hipSuccess; }
+hipError_t hipStreamSynchronize( hipStream_t ) { return hipSuccess; }
+hipError_t hipStreamWaitEvent( hipStream_t, hipEvent_t, unsigned int ) { return hipSuccess; }
+hipError_t hipEventCreate( hipEvent_t* e ) { *e = (hipEvent_t) calloc( 1, 8 ); return hipSuccess; }
+hipError_t hipEventCreateWithFlags( hipEvent_t* e, unsigned ) { *e = (hipEvent_t) calloc( 1, 8 ); return hipSuccess; }
+hipError_t hipEventDestroy( hipEvent_t e ) { free( e ); return hipSuccess; }
+hipError_t hipEventRecord( hipEvent_t, hipStream_t ) { return hipSuccess; }
+hipError_t hipEventSynchronize( hipEvent_t ) { return hipSuccess; }
+hipError_t hipEventElapsedTime( float* ms, hipEvent_t, hipEvent_t ) { *ms = 0.f; return hipSuccess; }
+hipError_t hipGetLastError( void ) { return hipSuccess; }
+const char* hipGetErrorString( hipError_t ) { return "host stub"; }
+}
+
+#include "../../vvdec_amd/csrc/vvr_api.cpp"
+
+// kernel launches: nothing to run on the host; the launch of the intra stage records what it was handed
+static int g_lastIntraUnits = -1; static const int* g_lastSync = nullptr;
+int  vvr_upload_tables() { return 0; }
+void launch_mc( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int ) {}
+void launch_itrans( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const TbItem*, int, int ) {}
+void launch_deblock( hipStream_t, const PicDev&, DevPlanes, int ) {}
+void launch_sao( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) {}
+void launch_alf( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) {}
+void launch_lmcs( hipStream_t, const PicDev&, DevPlanes, int ) {}
+void launch_copy_planes( hipStream_t, DevPlanes, DevPlanes ) {}
+void launch_mc_affine( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int ) {}
+void launch_mc_dmvr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int32_t* ) {}
+void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, int numUnits, int* sync ) { g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
+void launch_intra_levels( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, const std::pair<int, int>*, int numLevels, int* sync ) { g_lastIntraUnits = -numLevels; g_lastSync = sync; }
+
+extern "C" {
+// the intra-stage tables of a prepared picture (host memory in this build): units in ticket order, items, counts
+__attribute__(( visibility( "default" ) )) int vvt_intra_tables( const vvr_prepared* q, const IntraUnit** units, int* numUnits, const IntraItem** items, int* numItems )
+{
+  if( !q ) return -1;
+  *units = q->units; *numUnits = q->numActive; *items = q->intraItems; *numItems = q->numIntra;
+  return 0;
+}
+__attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
+__attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }
+__attribute__(( visibility( "default" ) )) size_t vvt_sync_capacity( const vvr_context* c, int lane ) { return c && lane < (int) c->syncCap.size() ? c->syncCap[lane] : 0; }
+}

@@ -1,0 +1,267 @@
+"""CPU: the host half of the intra-stage scheduler (vvdec_amd/csrc/vvr_api.cpp: work lists, units, dependency graph, ticket order),
+compiled against a stand-in HIP runtime (tests/hoststub) so that it runs without a GPU.  Nothing is reconstructed here: the
+tests check the tables the kernel would be handed.
+
+Properties checked on generated pictures (I / B, every tool, IBC, dual tree, 4xN CUs, LMCS chroma scaling):
+  * forward progress: a unit only waits for units with a lower ticket (workgroups take tickets in order, so a waiting workgroup's
+    producers have always started), at most VVR_INTRA_MAX_DEPS of them;
+  * the units partition the block list; blocks sit in their unit's (component, CTU);
+  * soundness: wherever a block reads samples another intra-stage block produces (the row above / column left of it, the
+    co-located luma of a CCLM block, the reference block of an IBC block), the producer is either an earlier block of the same
+    unit or belongs to a unit the consumer's unit (transitively) waits for;
+  * coverage: every cell of an intra / IBC / CIIP CU is produced by exactly the blocks of the list.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+
+from vvdec_amd import abi, synth, stream
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hoststub", "vvr_host_stub.cpp")
+LIB = os.path.join(HERE, "hoststub", "libvvr_hoststub.so")
+API = os.path.join(os.path.dirname(HERE), "vvdec_amd", "csrc", "vvr_api.cpp")
+HIP_INC = "/opt/rocm/include"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(HIP_INC, "hip", "hip_runtime_api.h")), reason="HIP headers not installed")
+
+UNIT_DT = np.dtype([("ent", "<u4"), ("i0", "<u4"), ("i1", "<u4"), ("bbox", "<u4"), ("ndeps", "<u4"), ("deps", "<u4", (26,)), ("iA", "<u4")])
+ITEM_DT = np.dtype([("x", "<u2"), ("y", "<u2"), ("lw", "u1"), ("lh", "u1"), ("mode", "u1"), ("flags", "u1"), ("nTL", "u1"), ("nA", "u1"), ("nL", "u1"), ("comp", "u1"), ("tu", "<u4")])
+MODE_RESI_ADD, MODE_IBC = 255, 254
+TOOLS = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST |
+         abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF)
+
+
+@pytest.fixture(scope="module")
+def stub():
+    deps = [SRC, API, os.path.join(os.path.dirname(API), "vvr_device.h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-I" + HIP_INC, "-D__HIP_PLATFORM_AMD__", "-w", SRC, "-o", LIB])
+    L = C.CDLL(LIB)
+    L.vvr_last_error.restype = C.c_char_p
+    L.vvr_last_error.argtypes = [C.c_void_p]
+    L.vvt_sizeof.restype = C.c_size_t
+    L.vvt_sync_capacity.restype = C.c_size_t
+    L.vvt_sync_capacity.argtypes = [C.c_void_p, C.c_int]
+    L.vvr_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vvr_submit_prepared.argtypes = [C.c_void_p, C.c_void_p]
+    L.vvr_free_prepared.argtypes = [C.c_void_p, C.c_void_p]
+    L.vvr_destroy.argtypes = [C.c_void_p]
+    L.vvr_sync.argtypes = [C.c_void_p]
+    L.vvt_intra_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    assert L.vvt_sizeof(0) == UNIT_DT.itemsize and L.vvt_sizeof(1) == ITEM_DT.itemsize
+    return L
+
+
+class Ctx:
+    def __init__(self, L, W, H, nslots, log2_ctu=7, bit_depth=10, chroma_format=1, streams=1):
+        self.L = L
+        cfg = abi.Config()
+        cfg.abi_version = abi.VVR_ABI_VERSION
+        cfg.device, cfg.max_width, cfg.max_height = 0, W, H
+        cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = chroma_format, bit_depth, log2_ctu
+        cfg.num_slots, cfg.num_streams = nslots, streams
+        self.ctx = C.c_void_p()
+        assert L.vvr_create(C.byref(cfg), C.byref(self.ctx)) == abi.VVR_OK
+
+    def prepare(self, d):
+        p = d.c()
+        h = C.c_void_p()
+        rc = self.L.vvr_prepare(self.ctx, C.byref(p), C.byref(h))
+        assert rc == abi.VVR_OK, self.L.vvr_last_error(self.ctx).decode()
+        return h
+
+    def tables(self, h):
+        up, ip, nu, ni = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+        assert self.L.vvt_intra_tables(h, C.byref(up), C.byref(nu), C.byref(ip), C.byref(ni)) == 0
+        units = np.frombuffer((C.c_char * (UNIT_DT.itemsize * nu.value)).from_address(up.value), UNIT_DT).copy() if nu.value else np.zeros(0, UNIT_DT)
+        items = np.frombuffer((C.c_char * (ITEM_DT.itemsize * ni.value)).from_address(ip.value), ITEM_DT).copy() if ni.value else np.zeros(0, ITEM_DT)
+        return units, items
+
+    def close(self):
+        self.L.vvr_destroy(self.ctx)
+
+
+def _check_tables(d, units, items):
+    h = d.hdr
+    W, H, l2 = h.width, h.height, h.log2_ctu
+    w4, h4 = (W + 3) >> 2, (H + 3) >> 2
+    ctusX = (W + (1 << l2) - 1) >> l2
+    ncomp = 3 if h.chroma_format else 1
+    nU, nI = len(units), len(items)
+    # ---- forward progress
+    for t in range(nU):
+        nd = int(units["ndeps"][t])
+        assert nd <= 26
+        assert all(int(x) < t for x in units["deps"][t][:nd]), "unit %d waits for a unit with a higher ticket" % t
+    # ---- the units partition the block list; blocks sit in their unit's (component, CTU)
+    unit_of = np.full(nI, -1, np.int64)
+    for t in range(nU):
+        i0, i1, iA = int(units["i0"][t]), int(units["i1"][t]), int(units["iA"][t])
+        assert i0 <= i1 <= nI and iA in (i0, i1)
+        assert (unit_of[i0:i1] == -1).all(), "blocks in two units"
+        unit_of[i0:i1] = t
+        comp, ctu = (int(units["ent"][t]) >> 24) & 3, int(units["ent"][t]) & 0xffffff
+        S = (1 << l2) >> (1 if comp else 0)
+        ox, oy = (ctu % ctusX) * S, (ctu // ctusX) * S
+        it = items[i0:i1]
+        assert (it["comp"] == comp).all()
+        assert ((it["x"] >= ox) & (it["x"] < ox + S) & (it["y"] >= oy) & (it["y"] < oy + S)).all(), "block outside its unit's CTU"
+        if i1 > i0:
+            assert ((it["mode"] == MODE_RESI_ADD).all() and comp > 0) if iA == i1 else not (it["mode"] == MODE_RESI_ADD).any()
+    assert (unit_of >= 0).all(), "block without a unit"
+    # ---- transitive producers of every unit (bit sets)
+    anc = [0] * nU
+    for t in range(nU):
+        a = 0
+        for x in units["deps"][t][:int(units["ndeps"][t])]:
+            a |= anc[int(x)] | (1 << int(x))
+        anc[t] = a
+    # ---- who produces which cell, decode order of the cells
+    order = np.full((2, h4, w4), 1 << 30, np.int64)
+    for cu in d.cu:
+        for t in range(int(cu["first_tu"]), int(cu["first_tu"]) + int(cu["num_tu"])):
+            tu = d.tu[t]
+            for chn, m in ((0, 1), (1, 6)):
+                if not (int(tu["comp_mask"]) & m):
+                    continue
+                x0, y0, ww, hh = (int(cu[k]) for k in "xywh") if (chn == 1 and cu["isp_mode"]) else (int(tu[k]) for k in "xywh")
+                order[chn, y0 >> 2:(y0 + hh + 3) >> 2, x0 >> 2:(x0 + ww + 3) >> 2] = t
+    prod = np.full((ncomp, h4, w4), -1, np.int64)
+    for i in range(nI):
+        it = items[i]
+        cs = 1 if it["comp"] else 0
+        x0, y0, ww, hh = int(it["x"]) << cs, int(it["y"]) << cs, (1 << int(it["lw"])) << cs, (1 << int(it["lh"])) << cs
+        sub = prod[int(it["comp"]), y0 >> 2:(y0 + hh + 3) >> 2, x0 >> 2:(x0 + ww + 3) >> 2]
+        isp_narrow = (int(it["flags"]) & 6) == 6 and not it["comp"] and min(ww, hh) < 4
+        assert isp_narrow or (sub == -1).all(), "two blocks produce one cell"
+        sub[...] = i
+
+    def ordered_before(j, i):
+        if j == i or j < 0:
+            return True
+        uj, ui = int(unit_of[j]), int(unit_of[i])
+        return (j < i) if uj == ui else bool((anc[ui] >> uj) & 1)
+
+    def cell(comp, xc, yc):            # component sample -> cell of the 4x4 luma grid
+        cs = 1 if comp else 0
+        return (yc << cs) >> 2, (xc << cs) >> 2
+
+    nchk = 0
+    for i in range(nI):
+        it = items[i]
+        comp, mode = int(it["comp"]), int(it["mode"])
+        if mode == MODE_RESI_ADD:
+            continue
+        cs, chn = (1 if comp else 0), (1 if comp else 0)
+        unit = 4 >> cs
+        x0, y0, ww, hh = int(it["x"]), int(it["y"]), 1 << int(it["lw"]), 1 << int(it["lh"])
+        myo = order[(chn,) + cell(comp, x0, y0)]
+        reads = []
+        if mode == MODE_IBC:
+            dx, dy = ((int(it["tu"]) & 0xffff) ^ 0x8000) - 0x8000, ((int(it["tu"]) >> 16) ^ 0x8000) - 0x8000
+            for yy in list(range(0, hh, unit)) + [hh - 1]:
+                for xx in list(range(0, ww, unit)) + [ww - 1]:
+                    reads.append((comp, x0 + dx + xx, y0 + dy + yy, True))
+        elif (int(it["flags"]) & 6) == 6 and not comp:
+            pass                        # ISP partitions: their CU's reference line and the partition chain (inside one unit by construction)
+        else:
+            for k in range(0, ww, unit):
+                reads.append((comp, x0 + k, y0 - 1, False))
+            for k in range(0, hh, unit):
+                reads.append((comp, x0 - 1, y0 + k, False))
+            reads.append((comp, x0 - 1, y0 - 1, False))
+            if comp and 67 <= mode <= 69:
+                for yy in range(0, 2 * hh, 4):
+                    for xx in range(0, 2 * ww, 4):
+                        reads.append((0, 2 * x0 + xx, 2 * y0 + yy, True))
+        for (k, xc, yc, must) in reads:
+            sh = 1 if k else 0
+            if xc < 0 or yc < 0 or (xc << sh) >= W or (yc << sh) >= H:
+                assert not must
+                continue
+            cy, cx = cell(k, xc, yc)
+            if not must and order[1 if k else 0, cy, cx] >= myo:
+                continue                # not reconstructed before the block: not available, not read
+            if must and k == comp:
+                assert order[1 if k else 0, cy, cx] < myo, "IBC reference block is not reconstructed before the block"
+            j = int(prod[k, cy, cx])
+            assert ordered_before(j, i), "block %d (unit %d) reads block %d (unit %d) without waiting for it" % (i, unit_of[i], j, unit_of[j])
+            nchk += j >= 0 and j != i
+    # ---- coverage: the cells of intra / IBC / CIIP CUs are produced by blocks of the list
+    for cu in d.cu:
+        intra_stage = cu["pred_mode"] in (abi.PRED_INTRA, abi.PRED_IBC) or (int(cu["flags"]) & abi.CU_CIIP)
+        if not intra_stage:
+            continue
+        x0, y0, ww, hh = (int(cu[k]) for k in "xywh")
+        comps = [0] if cu["tree"] == abi.TREE_LUMA else [1, 2] if cu["tree"] == abi.TREE_CHROMA else list(range(ncomp))
+        for k in comps:
+            if k and (int(cu["flags"]) & abi.CU_CIIP) and ww == 4:
+                continue                # 2-wide chroma of a 4-wide CIIP CU stays pure inter
+            assert (prod[k, y0 >> 2:(y0 + hh) >> 2, x0 >> 2:(x0 + ww) >> 2] >= 0).all(), "CU cells without a block"
+    return nchk
+
+
+STREAMS = [
+    ("i_b_all_tools", 416, 240, 5, 4, 501, TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.3, p_affine=0.1, p_geo=0.1, p_ciip=0.15, p_sbtmvp=0.1, p_cclm=0.3, p_mip=0.2, p_isp=0.2, p_sbt=0.1, p_jccr=0.2, p_coded_chroma=0.5)),
+    ("ibc_lmcs_ctu64", 416, 240, 3, 2, 502, TOOLS | abi.TOOL_IBC | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(log2_ctu=6, p_ibc=0.5, p_intra=0.4, p_cclm=0.3, p_ciip=0.1, p_coded_chroma=0.5)),
+    ("ibc_ctu32", 256, 192, 3, 2, 503, TOOLS | abi.TOOL_IBC, dict(log2_ctu=5, p_ibc=0.6, p_intra=0.5)),
+    ("dual_tree_ibc", 256, 128, 3, 2, 504, TOOLS | abi.TOOL_IBC | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(dual_tree=2.0, p_ibc=0.4, p_split_scale=1.5, p_cclm=0.3, p_isp=0.2)),
+    ("small_cus", 416, 240, 3, 2, 505, TOOLS | abi.TOOL_IBC | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(min_cu_log2=2, p_ibc=0.3, p_intra=0.4, p_split_scale=1.8, p_cclm=0.3, p_ciip=0.3)),
+    ("1080p", 1920, 1080, 3, 2, 506, TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.15, p_cclm=0.1, p_ciip=0.03, p_isp=0.05, p_mip=0.05)),
+]
+
+
+@pytest.mark.parametrize("name,W,H,frames,gop,seed,tools,kw", STREAMS, ids=[s[0] for s in STREAMS])
+def test_intra_stage_tables(stub, name, W, H, frames, gop, seed, tools, kw):
+    kw = dict(kw)
+    l2 = kw.pop("log2_ctu", 7)
+    plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=False)
+    ctx = Ctx(stub, W, H, nslots, log2_ctu=l2)
+    checked = 0
+    for pl in plans:
+        d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
+        hnd = ctx.prepare(d)
+        units, items = ctx.tables(hnd)
+        checked += _check_tables(d, units, items)
+        stub.vvr_free_prepared(ctx.ctx, hnd)
+    ctx.close()
+    assert checked > 0
+
+
+def test_sync_buffer_grows_with_the_number_of_units(stub, monkeypatch):
+    """the per-lane ticket / flag buffer is sized for ordinary pictures and grows when a picture has more units"""
+    monkeypatch.setenv("VVR_SYNC_UNITS_PER_CTU", "1")
+    W, H = 416, 240
+    plans, nslots = stream.ra_plan(3, gop=2, seed_poc0_is_external=False)
+    ctx = Ctx(stub, W, H, nslots)
+    cap0 = stub.vvt_sync_capacity(ctx.ctx, 0)
+    d = synth.picture_for_plan(plans[1], W, H, seed=507, tool_flags=TOOLS, p_intra=0.4, p_split_scale=1.6)
+    hnd = ctx.prepare(d)
+    units, _ = ctx.tables(hnd)
+    assert len(units) + 1 > cap0          # the case the test is about
+    assert stub.vvr_submit_prepared(ctx.ctx, hnd) >= 0
+    assert stub.vvt_last_intra_launch() == len(units)
+    assert stub.vvt_sync_capacity(ctx.ctx, 0) >= len(units) + 1
+    stub.vvr_sync(ctx.ctx)
+    stub.vvr_free_prepared(ctx.ctx, hnd)
+    ctx.close()
+
+
+def test_checker_detects_a_missing_dependency(stub):
+    """the soundness check is not vacuous: removing the producers of the units of a picture is noticed"""
+    W, H = 416, 240
+    plans, nslots = stream.ra_plan(3, gop=2, seed_poc0_is_external=False)
+    ctx = Ctx(stub, W, H, nslots)
+    d = synth.picture_for_plan(plans[1], W, H, seed=508, tool_flags=TOOLS | abi.TOOL_IBC, p_intra=0.4, p_ibc=0.4, p_cclm=0.3)
+    hnd = ctx.prepare(d)
+    units, items = ctx.tables(hnd)
+    assert _check_tables(d, units, items) > 0
+    broken = units.copy()
+    broken["ndeps"][:] = 0
+    with pytest.raises(AssertionError, match="without waiting"):
+        _check_tables(d, broken, items)
+    stub.vvr_free_prepared(ctx.ctx, hnd)
+    ctx.close()

@@ -61,7 +61,8 @@ struct vvr_context {
   std::vector<DevPlanes>   scratchR;    // per stream: residual planes (intra)
   void*      planeMem = nullptr; bool planeMemOwned = false;
   void*      scratchMem = nullptr;
-  std::vector<int*> syncBuf;            // per stream: ticket + per-(component, CTU) flags of the intra wavefront
+  std::vector<int*> syncBuf;            // per stream: ticket + one flag per unit of the intra stage
+  std::vector<size_t> syncCap;          // ints allocated in syncBuf[lane]; grown when a picture has more units (ensureSync)
   size_t     planeBytes[3] = { 0, 0, 0 }, slotBytes = 0;
   int        stride[3] = { 0, 0, 0 };
   // jobs
@@ -154,7 +155,10 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   {
     const int ctu = 1 << cfg->log2_ctu;
     const size_t numCtu = (size_t) ( ( cfg->max_width + ctu - 1 ) / ctu ) * ( ( cfg->max_height + ctu - 1 ) / ctu );
-    for( int s = 0; s < ns; s++ ) { int* p = nullptr; if( hipMalloc( (void**) &p, sizeof( int ) * ( 1 + 24 * numCtu ) ) != hipSuccess ) { delete c; return VVR_ERR_DEVICE; } c->syncBuf.push_back( p ); }
+    // sized for the usual pictures (a 4K B picture of the benchmark has about 6 units per CTU, an intra picture 3); pictures with more
+    // units than that (many isolated small intra CUs) make the lane's buffer grow when they are submitted
+    const size_t perCtu = getenv( "VVR_SYNC_UNITS_PER_CTU" ) ? (size_t) std::max( 1, atoi( getenv( "VVR_SYNC_UNITS_PER_CTU" ) ) ) : 24;
+    for( int s = 0; s < ns; s++ ) { int* p = nullptr; const size_t cap = 1 + perCtu * numCtu; if( hipMalloc( (void**) &p, sizeof( int ) * cap ) != hipSuccess ) { delete c; return VVR_ERR_DEVICE; } c->syncBuf.push_back( p ); c->syncCap.push_back( cap ); }
   }
   c->slotUsers.resize( cfg->num_slots );
   *out = c;
@@ -788,7 +792,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     // rank = length of the longest dependency chain below a unit (the unit graph is acyclic: luma never reads chroma, residual-add
     // units only read luma, other CTUs' units only earlier CTUs'); computed by relaxation in creation order until stable
     bool changed = true;
-    for( int pass = 0; changed && pass < 64; pass++ )
+    for( size_t pass = 0; changed && pass <= units.size(); pass++ )      // (acyclic: stable after at most one pass per level; creation order makes it 2-3)
     {
       changed = false;
       for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
@@ -869,7 +873,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
       }
     for( auto& U : units ) U.rank = 0;
     bool changed = true;
-    for( int pass = 0; changed && pass < 256; pass++ )
+    for( size_t pass = 0; changed && pass <= units.size(); pass++ )
     {
       changed = false;
       for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
@@ -1122,6 +1126,19 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
   if( q->numTb[0] + q->numTb[1] + q->numTb[2] )
     timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); } );
   // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)
+  {
+    // ticket + one flag per unit (or one counter per level): a picture with more units than the lane's buffer holds gets a larger one;
+    // work queued on the lane may still use the old buffer, so the lane is drained first (rare: see vvr_create)
+    const size_t need = 1 + std::max<size_t>( (size_t) q->numActive, q->intraLevels.size() );
+    if( need > c->syncCap[lane] )
+    {
+      HIPCHK( c, hipStreamSynchronize( s ) );
+      int* p = nullptr;
+      HIPCHK( c, hipMalloc( (void**) &p, sizeof( int ) * need * 2 ) );
+      hipFree( c->syncBuf[lane] );
+      c->syncBuf[lane] = p; c->syncCap[lane] = need * 2;
+    }
+  }
   if( q->numActive ) timed( K_INTRA, [&]
   {
     if( q->intraLevels.empty() ) launch_intra( s, q->pic, A, R, q->intraItems, q->units, q->numActive, c->syncBuf[lane] );
