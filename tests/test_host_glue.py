@@ -265,3 +265,52 @@ def test_checker_detects_a_missing_dependency(stub):
         _check_tables(d, broken, items)
     stub.vvr_free_prepared(ctx.ctx, hnd)
     ctx.close()
+
+
+def _expect_error(ctx, d, code, text):
+    p = d.c()
+    h = C.c_void_p()
+    rc = ctx.L.vvr_prepare(ctx.ctx, C.byref(p), C.byref(h))
+    assert rc == code, "expected %d, got %d (%s)" % (code, rc, ctx.L.vvr_last_error(ctx.ctx).decode())
+    assert text in ctx.L.vvr_last_error(ctx.ctx).decode()
+
+
+def test_malformed_descriptions_are_rejected(stub):
+    """validate() / the work-list builder refuse descriptions the kernels could not run safely (error code + message, nothing queued)"""
+    W, H = 256, 128
+    plans, nslots = stream.ra_plan(3, gop=2, seed_poc0_is_external=False)
+    ctx = Ctx(stub, W, H, nslots)
+    mk = lambda pl, tools=TOOLS, **kw: synth.picture_for_plan(pl, W, H, seed=509, tool_flags=tools, **kw)
+    # geometry / header
+    d = mk(plans[0]); d.hdr.abi_version += 1
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "abi_version")
+    d = mk(plans[0]); d.hdr.out_slot = nslots
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "out_slot")
+    d = mk(plans[1]); d.hdr.ref_slot[0][0] = d.hdr.out_slot
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "reference slot")
+    d = mk(plans[0], tools=TOOLS | abi.TOOL_LMCS_CSCALE)
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "LMCS")
+    # coding units
+    d = mk(plans[0]); d.cu["x"][0] = W - 4
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "CU outside")
+    d = mk(plans[1], p_intra=0.0); d.cu["ref_idx"][0] = (5, 5)
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "ref_idx")
+    d = mk(plans[1], p_intra=0.0); d.cu["mc_mode"][0] = 77
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "mc_mode")
+    d = mk(plans[0]); d.cu["intra_dir"][0] = (90, 0)
+    _expect_error(ctx, d, abi.VVR_ERR_UNSUPPORTED, "intra mode")
+    # intra block copy
+    d = mk(plans[0], tools=TOOLS | abi.TOOL_IBC, p_ibc=0.6)
+    k = int(np.nonzero(d.cu["pred_mode"] == abi.PRED_IBC)[0][0])
+    d.hdr.tool_flags &= ~abi.TOOL_IBC
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "VVR_TOOL_IBC")
+    d = mk(plans[0], tools=TOOLS | abi.TOOL_IBC, p_ibc=0.6); d.cu["mv"][k][0][0][0] += 3
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "fractional block vector")
+    d = mk(plans[0], tools=TOOLS | abi.TOOL_IBC, p_ibc=0.6); d.cu["mv"][k][0][0] = (-16 * 4096, 0)
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "reference block outside")
+    d = mk(plans[0], tools=TOOLS | abi.TOOL_IBC, p_ibc=0.6); d.cu["mv"][k][0][0] = (0, 0)       # "copies" itself: not reconstructed yet
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "not reconstructed before")
+    # a well-formed description still goes through afterwards
+    hnd = ctx.prepare(mk(plans[0], tools=TOOLS | abi.TOOL_IBC, p_ibc=0.6))
+    stub.vvr_free_prepared(ctx.ctx, hnd)
+    ctx.close()
