@@ -140,7 +140,7 @@ typedef struct vvr_pic_header {
   uint32_t tool_flags;              /* VVR_TOOL_*                                                       */
   uint16_t width, height;           /* luma samples                                                     */
   uint8_t  chroma_format;           /* 0 = 4:0:0, 1 = 4:2:0                                             */
-  uint8_t  bit_depth;               /* 8..12                                                            */
+  uint8_t  bit_depth;               /* 8..10 (Main 10)                                                  */
   uint8_t  log2_ctu;                /* 5..7                                                             */
   uint8_t  slice_type;              /* 0 B, 1 P, 2 I  (SliceType, CommonDef.h)                          */
   int32_t  poc;

@@ -314,3 +314,24 @@ def test_malformed_descriptions_are_rejected(stub):
     hnd = ctx.prepare(mk(plans[0], tools=TOOLS | abi.TOOL_IBC, p_ibc=0.6))
     stub.vvr_free_prepared(ctx.ctx, hnd)
     ctx.close()
+
+
+def test_context_configuration_limits(stub):
+    """vvr_create: Main 10 sample formats and CTU sizes only, ABI version checked"""
+    def create(**kw):
+        cfg = abi.Config()
+        cfg.abi_version = abi.VVR_ABI_VERSION
+        cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu, cfg.num_slots, cfg.num_streams = 0, 256, 128, 1, 10, 7, 4, 1
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        ctx = C.c_void_p()
+        rc = stub.vvr_create(C.byref(cfg), C.byref(ctx))
+        if rc == abi.VVR_OK:
+            stub.vvr_destroy(ctx)
+        return rc
+    assert create() == abi.VVR_OK
+    assert create(bit_depth=8) == abi.VVR_OK and create(chroma_format=0) == abi.VVR_OK and create(log2_ctu=5) == abi.VVR_OK
+    assert create(bit_depth=12) == abi.VVR_ERR_UNSUPPORTED and create(bit_depth=7) == abi.VVR_ERR_UNSUPPORTED
+    assert create(chroma_format=2) == abi.VVR_ERR_UNSUPPORTED and create(log2_ctu=4) == abi.VVR_ERR_UNSUPPORTED
+    assert create(abi_version=abi.VVR_ABI_VERSION + 1) == abi.VVR_ERR_PARAMETER
+    assert create(device=3) == abi.VVR_ERR_NO_DEVICE          # the stand-in runtime reports one device

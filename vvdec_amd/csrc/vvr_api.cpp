@@ -127,7 +127,8 @@ VVR_API size_t vvr_slot_bytes( const vvr_config* cfg )
 VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
 {
   if( !cfg || !out || cfg->abi_version != VVR_ABI_VERSION ) return VVR_ERR_PARAMETER;
-  if( cfg->chroma_format > 1 || cfg->bit_depth < 8 || cfg->bit_depth > 12 || cfg->log2_ctu < 5 || cfg->log2_ctu > 7 || !cfg->num_slots ) return VVR_ERR_UNSUPPORTED;
+  // Main 10: 4:0:0 / 4:2:0, 8..10-bit samples (the formats the parity tests cover); CTU 32..128
+  if( cfg->chroma_format > 1 || cfg->bit_depth < 8 || cfg->bit_depth > 10 || cfg->log2_ctu < 5 || cfg->log2_ctu > 7 || !cfg->num_slots ) return VVR_ERR_UNSUPPORTED;
   int ndev = 0;
   if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0 || cfg->device >= ndev ) return VVR_ERR_NO_DEVICE;
   vvr_context* c = new vvr_context();
