@@ -5,6 +5,13 @@
 #include <hip/hip_runtime_api.h>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
+
+// trace of the stream / event operations the host glue issues: { op (0 wait, 1 record), stream number, event number }, numbers in creation order
+static std::vector<int> g_trace;
+struct StubStream { int id; };
+struct StubEvent { int id; };
+static int g_numStreams = 0, g_numEvents = 0;
 
 extern "C" {
 hipError_t hipGetDeviceCount( int* n ) { *n = 1; return hipSuccess; }
@@ -17,14 +24,14 @@ hipError_t hipHostFree( void* p ) { free( p ); return hipSuccess; }
 hipError_t hipMemcpy( void* d, const void* s, size_t n, hipMemcpyKind ) { memcpy( d, s, n ); return hipSuccess; }
 hipError_t hipMemcpy2D( void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind ) { for( size_t y = 0; y < h; y++ ) memcpy( (char*) d + y * dp, (const char*) s + y * sp, w ); return hipSuccess; }
 hipError_t hipMemset( void* d, int v, size_t n ) { memset( d, v, n ); return hipSuccess; }
-hipError_t hipStreamCreateWithFlags( hipStream_t* s, unsigned int ) { *s = (hipStream_t) calloc( 1, 8 ); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags( hipStream_t* s, unsigned int ) { StubStream* p = (StubStream*) calloc( 1, sizeof( StubStream ) ); p->id = g_numStreams++; *s = (hipStream_t) p; return hipSuccess; }
 hipError_t hipStreamDestroy( hipStream_t s ) { free( s ); return hipSuccess; }
 hipError_t hipStreamSynchronize( hipStream_t ) { return hipSuccess; }
-hipError_t hipStreamWaitEvent( hipStream_t, hipEvent_t, unsigned int ) { return hipSuccess; }
-hipError_t hipEventCreate( hipEvent_t* e ) { *e = (hipEvent_t) calloc( 1, 8 ); return hipSuccess; }
-hipError_t hipEventCreateWithFlags( hipEvent_t* e, unsigned ) { *e = (hipEvent_t) calloc( 1, 8 ); return hipSuccess; }
+hipError_t hipStreamWaitEvent( hipStream_t s, hipEvent_t e, unsigned int ) { g_trace.push_back( 0 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( ( (StubEvent*) e )->id ); return hipSuccess; }
+hipError_t hipEventCreate( hipEvent_t* e ) { StubEvent* p = (StubEvent*) calloc( 1, sizeof( StubEvent ) ); p->id = g_numEvents++; *e = (hipEvent_t) p; return hipSuccess; }
+hipError_t hipEventCreateWithFlags( hipEvent_t* e, unsigned ) { return hipEventCreate( e ); }
 hipError_t hipEventDestroy( hipEvent_t e ) { free( e ); return hipSuccess; }
-hipError_t hipEventRecord( hipEvent_t, hipStream_t ) { return hipSuccess; }
+hipError_t hipEventRecord( hipEvent_t e, hipStream_t s ) { g_trace.push_back( 1 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( ( (StubEvent*) e )->id ); return hipSuccess; }
 hipError_t hipEventSynchronize( hipEvent_t ) { return hipSuccess; }
 hipError_t hipEventElapsedTime( float* ms, hipEvent_t, hipEvent_t ) { *ms = 0.f; return hipSuccess; }
 hipError_t hipGetLastError( void ) { return hipSuccess; }
@@ -55,6 +62,14 @@ __attribute__(( visibility( "default" ) )) int vvt_intra_tables( const vvr_prepa
   if( !q ) return -1;
   *units = q->units; *numUnits = q->numActive; *items = q->intraItems; *numItems = q->numIntra;
   return 0;
+}
+// the recorded stream / event operations (triples), cleared by the call
+__attribute__(( visibility( "default" ) )) int vvt_take_trace( int* dst, int maxInts )
+{
+  const int n = (int) g_trace.size() < maxInts ? (int) g_trace.size() : maxInts;
+  for( int i = 0; i < n; i++ ) dst[i] = g_trace[i];
+  g_trace.clear();
+  return n;
 }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }

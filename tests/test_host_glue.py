@@ -335,3 +335,58 @@ def test_context_configuration_limits(stub):
     assert create(chroma_format=2) == abi.VVR_ERR_UNSUPPORTED and create(log2_ctu=4) == abi.VVR_ERR_UNSUPPORTED
     assert create(abi_version=abi.VVR_ABI_VERSION + 1) == abi.VVR_ERR_PARAMETER
     assert create(device=3) == abi.VVR_ERR_NO_DEVICE          # the stand-in runtime reports one device
+
+
+@pytest.mark.parametrize("lanes,frames,gop,pool", [(3, 17, 8, 0), (4, 33, 16, 12), (2, 9, 4, 0)])
+def test_pictures_in_flight_are_ordered_by_their_slots(stub, lanes, frames, gop, pool):
+    """several pictures in flight on different streams: a picture must be ordered (stream order or event waits, transitively) after the
+    writer of every reference slot it reads and after every earlier user of the slot it writes (DPB slots are reused)"""
+    W, H = 64, 64
+    plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=False, pool=pool)
+    ctx = Ctx(stub, W, H, nslots, log2_ctu=5, streams=lanes)
+    buf = (C.c_int * 30000)()
+    stub.vvt_take_trace(buf, len(buf))
+    jobs = []                                   # per picture: (lane, set of event numbers waited for, event number of the picture)
+    for pl in plans:
+        d = synth.picture_for_plan(pl, W, H, seed=510, tool_flags=TOOLS, log2_ctu=5, p_intra=0.1)
+        hnd = ctx.prepare(d)
+        assert stub.vvr_submit_prepared(ctx.ctx, hnd) >= 0
+        n = stub.vvt_take_trace(buf, len(buf))
+        ops = [tuple(buf[i:i + 3]) for i in range(0, n, 3)]
+        rec = [o for o in ops if o[0] == 1]
+        assert len(rec) == 1                    # the picture's completion event, recorded on its lane
+        jobs.append((rec[0][1], {o[2] for o in ops if o[0] == 0}, rec[0][2], hnd))
+        assert all(o[1] == rec[0][1] for o in ops)
+    assert len({j[0] for j in jobs}) == lanes   # all lanes are used
+    ev_to_job = {j[2]: k for k, j in enumerate(jobs)}
+
+    def violations(use_waits):
+        before, last_on_lane, users, bad = [], {}, {}, []
+        for k, (lane, waits, _, _) in enumerate(jobs):
+            hb = set()
+            if lane in last_on_lane:
+                hb |= before[last_on_lane[lane]] | {last_on_lane[lane]}
+            for e in (waits if use_waits else ()):
+                hb |= before[ev_to_job[e]] | {ev_to_job[e]}
+            before.append(hb)
+            last_on_lane[lane] = k
+        for k, pl in enumerate(plans):           # users[slot] = [writer, readers...] since the last write
+            reads = [slot for lst in pl.ref_slots for (slot, poc) in lst]
+            for slot in reads:
+                assert slot in users, "reference slot never written"
+                if users[slot][0] not in before[k]:
+                    bad.append("picture %d reads slot %d without being ordered after its writer" % (k, slot))
+            for u in users.get(pl.slot, []):
+                if u not in before[k]:
+                    bad.append("picture %d overwrites slot %d while picture %d may still use it" % (k, pl.slot, u))
+            for slot in reads:
+                users[slot].append(k)
+            users[pl.slot] = [k]
+        return bad
+
+    assert violations(True) == []
+    assert violations(False) != []              # (the check is not vacuous: stream order alone does not cover the hazards)
+    stub.vvr_sync(ctx.ctx)
+    for j in jobs:
+        stub.vvr_free_prepared(ctx.ctx, j[3])
+    ctx.close()

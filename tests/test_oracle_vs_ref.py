@@ -173,7 +173,7 @@ def test_oracle_equals_reference_intra_block_copy(built, W, H, l2, idx, seed, lm
             assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
 
 
-@pytest.mark.parametrize("bit_depth,chroma_format", [(8, 1), (10, 0), (8, 0)], ids=["8bit_420", "10bit_400", "8bit_400"])
+@pytest.mark.parametrize("bit_depth,chroma_format", [(8, 1), (10, 0), (8, 0), (9, 1)], ids=["8bit_420", "10bit_400", "8bit_400", "9bit_420"])
 def test_oracle_equals_reference_other_sample_formats(built, bit_depth, chroma_format):
     """8-bit samples and 4:0:0 pictures (the other formats of the Main 10 profile), intra and inter tools, with and without LMCS"""
     plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
