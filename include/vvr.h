@@ -178,7 +178,7 @@ enum {
 };
 
 /* cu.mc_mode: the branch InterPrediction::motionCompensation (InterPrediction.cpp:1372-1459) takes for this CU.
- * Resolving it needs POCs/flags only and is done once per CU by the host glue (vvr_resolve_mc_mode below). */
+ * Resolving it needs POCs/flags only and is done once per CU by the host glue (integration/vvr_extract.h::resolveMcMode). */
 enum {
   VVR_MC_NONE = 0,
   VVR_MC_UNI,          /* one list, or identical-motion shortcut (xCheckIdenticalMotion, :404)          */

@@ -1,0 +1,357 @@
+// integration/vvr_extract.h — reference-side glue: walks a picture of the reference decoder after
+// parsing, motion derivation (MIDER) and edge-parameter derivation (LF_INIT) and writes the flat description of include/vvr.h that
+// vvr_submit() consumes.  It is what a maintainer compiles INTO the reference (next to DecLibRecon): it includes the reference's own
+// headers and uses its own helpers for everything that is "derived state" (final intra modes, transform types, the branch
+// InterPrediction::motionCompensation takes, CIIP neighbour flags, LMCS tables, final ALF filters, resolved SAO merges).
+//
+// It is not part of the product library (that one never sees reference types).  In this repository it is compiled only by the test
+// harness (oracle/ref_harness.cpp, which needs /root/reference), where a round trip  description -> reference objects -> extractor ->
+// description  is checked field by field (tests/test_extractor_roundtrip.py).  Members that are not public in the reference
+// (Reshape tables, TrQuant::getTrTypes) are reached the way a member function of those classes would reach them.
+#pragma once
+#include <vector>
+#include <functional>
+#include <cstring>
+#include <algorithm>
+
+namespace vvr_glue
+{
+using namespace vvdec;
+
+struct Extracted
+{
+  vvr_picture               pic;          // pointers into the members below
+  std::vector<vvr_cu>       cu;
+  std::vector<vvr_tu>       tu;
+  std::vector<int16_t>      coef;
+  std::vector<uint32_t>     ctuFirstCu;
+  std::vector<vvr_motion>   motion;
+  std::vector<vvr_lfp>      lfp[2];
+  std::vector<vvr_sao_ctu>  sao;
+  std::vector<vvr_alf_ctu>  alf;
+  vvr_alf_params            alfParams;
+  vvr_lmcs_params           lmcs;
+  vvr_wp_params             wp;
+  vvr_scaling_list          scaling;
+  uint32_t                  numDmvr = 0;
+};
+
+// branch of InterPrediction::motionCompensation (InterPrediction.cpp:1372-1459) for one CU
+static inline uint8_t resolveMcMode( const CodingUnit& cu )
+{
+  if( cu.geoFlag() ) return VVR_MC_GEO;
+  if( cu.affineFlag() ) return VVR_MC_AFFINE;
+  const Slice& slice = *cu.slice;
+  const bool subPu = cu.mergeFlag() && cu.mergeType() == MRG_TYPE_SUBPU_ATMVP;
+  bool bio = false;
+  if( cu.sps->getUseBIO() && !cu.cs->picHeader->getDisBdofFlag() && !cu.ciipFlag() && !cu.smvdMode() && !( cu.sps->getUseBcw() && cu.BcwIdx() != BCW_DEFAULT ) )
+  {
+    const WPScalingParam *wp0 = nullptr, *wp1 = nullptr;
+    slice.getWpScaling( REF_PIC_LIST_0, cu.refIdx[0], wp0 );
+    slice.getWpScaling( REF_PIC_LIST_1, cu.refIdx[1], wp1 );
+    const bool anyWp = wp0[0].bPresentFlag || wp0[1].bPresentFlag || wp0[2].bPresentFlag || wp1[0].bPresentFlag || wp1[1].bPresentFlag || wp1[2].bPresentFlag;
+    const bool chk0 = !( anyWp && slice.getSliceType() == B_SLICE ), chk1 = !( cu.pps->getUseWP() && slice.getSliceType() == P_SLICE );
+    bio = chk0 && chk1 && PU::isBiPredFromDifferentDirEqDistPoc( cu ) && cu.Y().height >= 8 && cu.Y().width >= 8 && cu.Y().area() >= 128;
+  }
+  const bool dmvr = !subPu && PU::checkDMVRCondition( cu );
+  if( !subPu && bio && !dmvr ) return VVR_MC_BDOF;
+  if( dmvr ) return bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR;
+  if( subPu ) return VVR_MC_SBTMVP;
+  if( cu.refIdx[0] < 0 || cu.refIdx[1] < 0 ) return VVR_MC_UNI;
+  // xCheckIdenticalMotion (:404): same reference picture and motion in both lists, not with weighted bi-prediction
+  if( slice.isInterB() && !cu.pps->getWPBiPred() && slice.getRefPOC( REF_PIC_LIST_0, cu.refIdx[0] ) == slice.getRefPOC( REF_PIC_LIST_1, cu.refIdx[1] ) && cu.mv[0][0] == cu.mv[1][0] ) return VVR_MC_UNI;
+  return VVR_MC_BI;
+}
+
+static inline uint32_t toolFlags( const CodingStructure& cs, const Slice& slice, const Picture& pic )
+{
+  const SPS& sps = *cs.sps; const PPS& pps = *cs.pps; const PicHeader& ph = *cs.picHeader;
+  uint32_t f = 0;
+  if( slice.getSaoEnabledFlag( CHANNEL_TYPE_LUMA ) )   f |= VVR_TOOL_SAO_LUMA;
+  if( slice.getSaoEnabledFlag( CHANNEL_TYPE_CHROMA ) ) f |= VVR_TOOL_SAO_CHROMA;
+  if( sps.getUseALF() && ( slice.getAlfEnabledFlag( COMPONENT_Y ) || slice.getAlfEnabledFlag( COMPONENT_Cb ) || slice.getAlfEnabledFlag( COMPONENT_Cr ) ) ) f |= VVR_TOOL_ALF;
+  if( sps.getUseCCALF() && ( slice.getCcAlfCbEnabledFlag() || slice.getCcAlfCrEnabledFlag() ) ) f |= VVR_TOOL_CCALF;
+  if( slice.getLmcsEnabledFlag() ) f |= VVR_TOOL_LMCS;
+  if( ph.getLmcsChromaResidualScaleFlag() ) f |= VVR_TOOL_LMCS_CSCALE;
+  if( slice.getDeblockingFilterDisable() ) f |= VVR_TOOL_DEBLOCK_OFF;
+  if( slice.getDepQuantEnabledFlag() ) f |= VVR_TOOL_DEP_QUANT;
+  if( sps.getUseBIO() && !ph.getDisBdofFlag() ) f |= VVR_TOOL_BDOF;
+  if( sps.getUseDMVR() && !ph.getDisDmvrFlag() ) f |= VVR_TOOL_DMVR;
+  if( sps.getUsePROF() && !ph.getDisProfFlag() ) f |= VVR_TOOL_PROF;
+  if( ph.getJointCbCrSignFlag() ) f |= VVR_TOOL_JCCR_SIGN;
+  if( pic.stillReferenced ) f |= VVR_TOOL_STILL_REF;
+  if( sps.getUseLFNST() ) f |= VVR_TOOL_LFNST;
+  if( sps.getUseMTS() ) f |= VVR_TOOL_MTS;
+  if( sps.getVerCollocatedChromaFlag() ) f |= VVR_TOOL_CCLM_COLLOC;
+  if( ( pps.getUseWP() && slice.getSliceType() == P_SLICE ) || ( pps.getWPBiPred() && slice.getSliceType() == B_SLICE ) ) f |= VVR_TOOL_WP;
+  if( slice.getExplicitScalingListUsed() ) f |= VVR_TOOL_SCALING_LIST;
+  if( sps.getDisableScalingMatrixForLfnstBlks() ) f |= VVR_TOOL_SCALING_LIST_NO_LFNST;
+  if( sps.getUseImplicitMTS() ) f |= VVR_TOOL_IMPLICIT_MTS;
+  if( sps.getIBCFlag() ) f |= VVR_TOOL_IBC;
+  return f;
+}
+
+// slotOf: DPB slot of a reference picture (the caller owns the mapping picture <-> slot); outSlot: slot of the picture itself
+static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& pic, Reshape* reshaper, TrQuant& trQuant,
+                                   const std::function<int( const Picture* )>& slotOf, int outSlot, Extracted& E )
+{
+  const SPS& sps = *cs.sps; const PPS& pps = *cs.pps; const PreCalcValues& pcv = *cs.pcv;
+  const int W = pps.getPicWidthInLumaSamples(), H = pps.getPicHeightInLumaSamples();
+  const int w4 = ( W + 3 ) >> 2, h4 = ( H + 3 ) >> 2, ctu4 = pcv.maxCUWidth >> 2, numCtu = pcv.sizeInCtus;
+  const bool chroma = pcv.chrFormat != CHROMA_400;
+  const int nComp = chroma ? 3 : 1;
+  const int bd = sps.getBitDepth(), qpBd = sps.getQpBDOffset();
+
+  // ---- header
+  vvr_pic_header& h = E.pic.hdr; memset( &E.pic, 0, sizeof( E.pic ) );
+  h.abi_version = VVR_ABI_VERSION;
+  h.tool_flags = toolFlags( cs, slice, pic );
+  h.width = (uint16_t) W; h.height = (uint16_t) H; h.chroma_format = chroma ? 1 : 0; h.bit_depth = (uint8_t) bd;
+  h.log2_ctu = (uint8_t) getLog2( pcv.maxCUWidth ); h.slice_type = (uint8_t) slice.getSliceType(); h.poc = slice.getPOC(); h.out_slot = (int16_t) outSlot;
+  for( int l = 0; l < 2; l++ )
+  {
+    h.num_ref[l] = slice.isIntra() ? 0 : (int8_t) slice.getNumRefIdx( RefPicList( l ) );
+    for( int i = 0; i < h.num_ref[l]; i++ ) { h.ref_poc[l][i] = slice.getRefPOC( RefPicList( l ), i ); h.ref_slot[l][i] = (int16_t) slotOf( slice.getRefPic( RefPicList( l ), i ) ); }
+  }
+  h.deblock_beta_offset_div2[0] = (int8_t) slice.getDeblockingFilterBetaOffsetDiv2();   h.deblock_tc_offset_div2[0] = (int8_t) slice.getDeblockingFilterTcOffsetDiv2();
+  h.deblock_beta_offset_div2[1] = (int8_t) slice.getDeblockingFilterCbBetaOffsetDiv2(); h.deblock_tc_offset_div2[1] = (int8_t) slice.getDeblockingFilterCbTcOffsetDiv2();
+  h.deblock_beta_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrBetaOffsetDiv2(); h.deblock_tc_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrTcOffsetDiv2();
+  h.log2_sao_offset_scale[0] = h.log2_sao_offset_scale[1] = (uint8_t) std::max( 0, bd - MAX_SAO_TRUNCATED_BITDEPTH );
+  h.min_qp_ts = (int8_t) ( 4 + 6 * sps.getInternalMinusInputBitDepth() );
+
+  // ---- coding units, transform units, levels
+  E.cu.clear(); E.tu.clear(); E.coef.clear(); E.ctuFirstCu.assign( numCtu + 1, 0 ); E.numDmvr = 0;
+  PelUnitBuf reco = cs.getRecoBuf();
+  auto isIntraAt = [&]( const CodingUnit& cur, const Position& p ) { const CodingUnit* n = cs.getCURestricted( p, cur, CHANNEL_TYPE_LUMA ); return n && CU::isIntra( *n ); };
+  for( int a = 0; a < numCtu; a++ )
+  {
+    E.ctuFirstCu[a] = (uint32_t) E.cu.size();
+    if( !cs.getCtuData( a ).firstCU ) continue;
+    for( auto& cu : cs.traverseCUs( a ) )
+    {
+      vvr_cu c; memset( &c, 0, sizeof( c ) );
+      const ChannelType cht = cu.chType();
+      const bool treeL = CU::isSepTree( cu ) && isLuma( cht ) && chroma, treeC = CU::isSepTree( cu ) && isChroma( cht );
+      const Area la = treeC ? Area( cu.Cb().x << 1, cu.Cb().y << 1, cu.Cb().width << 1, cu.Cb().height << 1 ) : Area( cu.Y() );
+      c.x = (uint16_t) la.x; c.y = (uint16_t) la.y; c.w = (uint8_t) la.width; c.h = (uint8_t) la.height;
+      c.tree = treeL ? VVR_TREE_LUMA : treeC ? VVR_TREE_CHROMA : VVR_TREE_JOINT;
+      c.pred_mode = CU::isIntra( cu ) ? VVR_PRED_INTRA : CU::isIBC( cu ) ? VVR_PRED_IBC : VVR_PRED_INTER;
+      c.flags = (uint16_t) ( ( cu.rootCbf() ? VVR_CU_ROOT_CBF : 0 ) | ( cu.skip() ? VVR_CU_SKIP : 0 ) | ( cu.mergeFlag() ? VVR_CU_MERGE : 0 ) | ( cu.affineFlag() ? VVR_CU_AFFINE : 0 )
+                           | ( cu.affineFlag() && cu.affineType() == AFFINEMODEL_6PARAM ? VVR_CU_AFFINE_6P : 0 ) | ( cu.ciipFlag() ? VVR_CU_CIIP : 0 ) | ( cu.geoFlag() ? VVR_CU_GEO : 0 )
+                           | ( cu.mergeFlag() && cu.mergeType() == MRG_TYPE_SUBPU_ATMVP ? VVR_CU_SBTMVP : 0 ) | ( cu.mipFlag() ? VVR_CU_MIP : 0 ) | ( cu.mipTransposedFlag() ? VVR_CU_MIP_TRANSP : 0 )
+                           | ( cu.smvdMode() ? VVR_CU_SMVD : 0 ) | ( cu.mmvdFlag() ? VVR_CU_MMVD : 0 ) );
+      c.qp = (int8_t) cu.qp;
+      c.bcw_idx = 2; c.ref_idx[0] = c.ref_idx[1] = -1;
+      if( c.pred_mode == VVR_PRED_INTRA )
+      {
+        // final modes (PU::getFinalIntraMode, UnitTools.cpp:587); MIP keeps its matrix index; the mode LFNST derives its set from for LM chroma
+        c.intra_dir[0] = treeC ? (uint8_t) PU::getCoLocatedIntraLumaMode( cu ) : (uint8_t) cu.intraDir[0];
+        c.intra_dir[1] = chroma && !treeL ? (uint8_t) PU::getFinalIntraMode( cu, CHANNEL_TYPE_CHROMA ) : (uint8_t) cu.intraDir[1];
+        c.lfnst_intra_mode = (uint8_t) ( treeC || !cu.mipFlag() ? PU::getCoLocatedIntraLumaMode( cu ) : PLANAR_IDX );
+        if( !treeC && cu.mipFlag() ) c.lfnst_intra_mode = PLANAR_IDX;
+        c.multi_ref_idx = (uint8_t) cu.multiRefIdx(); c.isp_mode = (uint8_t) cu.ispMode();
+        c.bdpcm[0] = (uint8_t) cu.bdpcmMode(); c.bdpcm[1] = (uint8_t) cu.bdpcmModeChroma();
+        c.lfnst_idx = (uint8_t) cu.lfnstIdx();
+      }
+      else if( c.pred_mode == VVR_PRED_IBC )
+      {
+        c.intra_dir[0] = (uint8_t) cu.intraDir[0];
+        c.inter_dir = 1;
+        c.mv[0][0][0] = cu.mv[0][0].getHor(); c.mv[0][0][1] = cu.mv[0][0].getVer();
+      }
+      else
+      {
+        c.inter_dir = (uint8_t) cu.interDir(); c.ref_idx[0] = (int8_t) cu.refIdx[0]; c.ref_idx[1] = (int8_t) cu.refIdx[1];
+        for( int k = 0; k < 5; k++ ) if( g_BcwInternFwd[k] == cu.BcwIdx() ) c.bcw_idx = (uint8_t) k;      // description: index into the weight table
+        c.imv = (uint8_t) cu.imv(); c.sbt_info = (uint8_t) cu.sbtInfo(); c.lfnst_idx = 0;
+        // control-point MVs only for affine CUs (a GPM CU keeps its two MVs in mv[0][1] / mv[1][1], InterPrediction.cpp:1478,1489: they go to geo_mv)
+        for( int l = 0; l < 2; l++ ) for( int k = 0; k < ( cu.affineFlag() ? 3 : 1 ); k++ ) { c.mv[l][k][0] = cu.mv[l][k].getHor(); c.mv[l][k][1] = cu.mv[l][k].getVer(); }
+        if( cu.geoFlag() )
+        {
+          c.geo_split_dir = cu.geoSplitDir; c.geo_dir_ref[0] = cu.interDirrefIdxGeo0(); c.geo_dir_ref[1] = cu.interDirrefIdxGeo1();
+          c.geo_mv[0][0] = cu.mv[0][1].getHor(); c.geo_mv[0][1] = cu.mv[0][1].getVer(); c.geo_mv[1][0] = cu.mv[1][1].getHor(); c.geo_mv[1][1] = cu.mv[1][1].getVer();
+        }
+        if( cu.ciipFlag() )
+        {
+          // IntraPrediction::predBlendIntraCiip (IntraPrediction.cpp:917-927): the CU left of the bottom-left sample and the CU above the top-right sample
+          const Position posBL = cu.Y().bottomLeft(), posTR = cu.Y().topRight();
+          c.ciip_neigh_intra = (uint8_t) ( ( isIntraAt( cu, posBL.offset( -1, 0 ) ) ? 1 : 0 ) | ( isIntraAt( cu, posTR.offset( 0, -1 ) ) ? 2 : 0 ) );
+        }
+        c.mc_mode = resolveMcMode( cu );
+        if( c.mc_mode == VVR_MC_DMVR || c.mc_mode == VVR_MC_DMVR_BDOF ) { c.dmvr_off = E.numDmvr; E.numDmvr += ( ( la.width + 15 ) / 16 ) * ( ( la.height + 15 ) / 16 ); }
+      }
+      c.first_tu = (uint32_t) E.tu.size();
+      const uint32_t cuIdx = (uint32_t) E.cu.size();
+      for( auto& tu : TUTraverser( &cu.firstTU, cu.lastTU->next ) )
+      {
+        vvr_tu t; memset( &t, 0, sizeof( t ) );
+        const bool hasL = tu.blocks[0].valid(), hasC = chroma && tu.blocks.size() > 1 && tu.blocks[1].valid();
+        const Area ta = hasL ? Area( tu.blocks[0] ) : Area( tu.blocks[1].x << 1, tu.blocks[1].y << 1, tu.blocks[1].width << 1, tu.blocks[1].height << 1 );
+        t.x = (uint16_t) ta.x; t.y = (uint16_t) ta.y; t.w = (uint8_t) ta.width; t.h = (uint8_t) ta.height;
+        t.comp_mask = (uint8_t) ( ( hasL ? 1 : 0 ) | ( hasC ? 6 : 0 ) );
+        t.cbf = tu.cbf; t.joint_cbcr = tu.jointCbCr; t.cu = cuIdx;
+        t.qp[0] = (int8_t) ( cu.qp + qpBd ); t.qp[1] = (int8_t) tu.chromaQp[0]; t.qp[2] = (int8_t) tu.chromaQp[1];
+        for( int k = 0; k < nComp; k++ )
+        {
+          t.mts_idx[k] = (uint8_t) tu.mtsIdx( ComponentID( k ) ); t.max_scan_x[k] = (uint8_t) tu.maxScanPosX[k]; t.max_scan_y[k] = (uint8_t) tu.maxScanPosY[k];
+          if( !( t.comp_mask & ( 1 << k ) ) ) continue;
+          // joint Cb-Cr: one coded block carries the levels of both components (Cb for modes 2 / 3, Cr for mode 1, TrQuant.cpp:320)
+          const bool coded = ( ( tu.cbf >> k ) & 1 ) && !( k && tu.jointCbCr && k != ( ( tu.jointCbCr >> 1 ) ? 1 : 2 ) );
+          if( coded && t.mts_idx[k] != VVR_MTS_SKIP )
+          {
+            int trHor = 0, trVer = 0;
+            trQuant.getTrTypes( tu, ComponentID( k ), trHor, trVer );          // (TrQuant.cpp:330-407) DCT2 0, DCT8 1, DST7 2
+            t.tr_type[k] = (uint8_t) ( ( trVer << 2 ) | trHor );
+          }
+          if( !coded ) continue;
+          // levels: the parser leaves them in the reconstruction buffer at the block position (CABACReader.cpp:2457-2478); only the
+          // corner up to the last significant position is meaningful (the whole block for BDPCM)
+          const CompArea& blk = tu.blocks[k];
+          const bool full = ( k == 0 ? cu.bdpcmMode() : cu.bdpcmModeChroma() ) != 0;
+          const int cw = full ? (int) blk.width : t.max_scan_x[k] + 1, ch = full ? (int) blk.height : t.max_scan_y[k] + 1;
+          t.coef_off[k] = (uint32_t) E.coef.size();
+          const PelBuf src = reco.bufs[k].subBuf( blk.pos(), blk.size() );
+          for( int y = 0; y < ch; y++ ) for( int x = 0; x < cw; x++ ) E.coef.push_back( (int16_t) src.at( x, y ) );
+        }
+        E.tu.push_back( t );
+      }
+      c.num_tu = (uint32_t) E.tu.size() - c.first_tu;
+      E.cu.push_back( c );
+    }
+  }
+  E.ctuFirstCu[numCtu] = (uint32_t) E.cu.size();
+
+  // ---- per-4x4 tables: motion (after MIDER), edge parameters (after LF_INIT)
+  E.motion.assign( (size_t) w4 * h4, vvr_motion() ); E.lfp[0].assign( (size_t) w4 * h4, vvr_lfp() ); E.lfp[1].assign( (size_t) w4 * h4, vvr_lfp() );
+  for( int y = 0; y < h4; y++ ) for( int x = 0; x < w4; x++ )
+  {
+    const int a = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 ), in = ( y % ctu4 ) * ctu4 + ( x % ctu4 );
+    const CtuData& cd = cs.getCtuData( a );
+    vvr_motion& m = E.motion[(size_t) y * w4 + x]; memset( &m, 0, sizeof( m ) );
+    const MotionInfo& mi = cd.motion[in];
+    for( int l = 0; l < 2; l++ )
+    {
+      m.ref_idx[l] = isMotionValid( mi.miRefIdx[l], MI_NOT_VALID ) ? (int8_t) mi.miRefIdx[l] : -1;
+      m.mv[l][0] = mi.mv[l].getHor(); m.mv[l][1] = mi.mv[l].getVer();
+    }
+    for( int d = 0; d < 2; d++ )
+    {
+      const LoopFilterParam& s = cd.lfParam[d][in];
+      vvr_lfp& o = E.lfp[d][(size_t) y * w4 + x]; memset( &o, 0, sizeof( o ) );
+      o.qp[0] = s.qp[0]; o.qp[1] = s.qp[1]; o.qp[2] = s.qp[2]; o.bs = s.bs; o.side_max_filt_length = s.sideMaxFiltLength; o.flags = s.flags;
+    }
+  }
+
+  // ---- per-CTU loop filter controls: SAO with merges resolved and offsets scaled (SampleAdaptiveOffset::reconstructBlkSAOParam), ALF
+  E.sao.assign( numCtu, vvr_sao_ctu() ); E.alf.assign( numCtu, vvr_alf_ctu() );
+  for( int a = 0; a < numCtu; a++ )
+  {
+    vvr_sao_ctu& s = E.sao[a]; memset( &s, 0, sizeof( s ) );
+    for( int k = 0; k < nComp; k++ )
+    {
+      int src = a;
+      const SAOOffset* o = &cs.getCtuData( src ).saoParam[k];
+      while( o->modeIdc == SAO_MODE_MERGE ) { src = o->typeIdc == SAO_MERGE_LEFT ? src - 1 : src - (int) pcv.widthInCtus; o = &cs.getCtuData( src ).saoParam[k]; }
+      if( o->modeIdc == SAO_MODE_OFF ) continue;
+      const int sc = h.log2_sao_offset_scale[k ? 1 : 0];
+      s.mode[k] = 1; s.type[k] = (uint8_t) o->typeIdc;
+      if( o->typeIdc == SAO_TYPE_BO ) { s.band_pos[k] = (uint8_t) o->typeAuxInfo; for( int i = 0; i < 4; i++ ) s.offset[k][i] = (int8_t) ( o->offset[( o->typeAuxInfo + i ) % NUM_SAO_BO_CLASSES] << sc ); }
+      else
+      {
+        s.offset[k][0] = (int8_t) ( o->offset[SAO_CLASS_EO_FULL_VALLEY] << sc ); s.offset[k][1] = (int8_t) ( o->offset[SAO_CLASS_EO_HALF_VALLEY] << sc );
+        s.offset[k][2] = (int8_t) ( o->offset[SAO_CLASS_EO_HALF_PEAK] << sc );   s.offset[k][3] = (int8_t) ( o->offset[SAO_CLASS_EO_FULL_PEAK] << sc );
+      }
+    }
+    vvr_alf_ctu& f = E.alf[a]; memset( &f, 0, sizeof( f ) );
+    const CtuAlfData& ad = cs.getCtuData( a ).alfParam;
+    for( int k = 0; k < 3; k++ ) f.enable[k] = ad.alfCtuEnableFlag[k];
+    for( int k = 0; k < 2; k++ ) { f.alt[k] = ad.alfCtuAlternative[k]; f.cc_idc[k] = ad.ccAlfFilterControl[k]; }
+    f.luma_filter_idx = ad.alfCtbFilterIndex;
+  }
+
+  // ---- final ALF filters of the APSs the slice refers to (after AdaptiveLoopFilter::reconstructCoeffAPSs)
+  memset( &E.alfParams, 0, sizeof( E.alfParams ) );
+  if( h.tool_flags & VVR_TOOL_ALF )
+  {
+    const APS* const* apss = slice.getAlfAPSs();
+    E.alfParams.num_luma_aps = (uint8_t) slice.getNumAlfAps();
+    for( int i = 0; i < slice.getNumAlfAps() && i < VVR_MAX_ALF_APS; i++ )
+    {
+      const AlfSliceParam& p = apss[slice.getAlfApsIdsLuma()[i]]->getAlfAPSParam();
+      for( int cl = 0; cl < VVR_ALF_CLASSES; cl++ ) for( int k = 0; k < MAX_NUM_ALF_LUMA_COEFF - 1; k++ )      // (the centre tap is implied)
+      { E.alfParams.luma_coeff[i][cl][k] = p.lumaCoeffFinal[cl * MAX_NUM_ALF_LUMA_COEFF + k]; E.alfParams.luma_clip[i][cl][k] = p.lumaClippFinal[cl * MAX_NUM_ALF_LUMA_COEFF + k]; }
+    }
+    if( chroma && apss[slice.getAlfApsIdChroma()] )
+    {
+      const AlfSliceParam& p = apss[slice.getAlfApsIdChroma()]->getAlfAPSParam();
+      for( int alt = 0; alt < VVR_ALF_MAX_CHR_ALT && alt < p.numAlternativesChroma; alt++ ) for( int k = 0; k < MAX_NUM_ALF_CHROMA_COEFF - 1; k++ )
+      { E.alfParams.chroma_coeff[alt][k] = p.chromaCoeff[alt * MAX_NUM_ALF_CHROMA_COEFF + k]; E.alfParams.chroma_clip[alt][k] = p.chrmClippFinal[alt * MAX_NUM_ALF_CHROMA_COEFF + k]; }
+    }
+    if( chroma && ( h.tool_flags & VVR_TOOL_CCALF ) )
+      for( int k = 0; k < 2; k++ )
+      {
+        const APS* aps = apss[k == 0 ? slice.getCcAlfCbApsId() : slice.getCcAlfCrApsId()];
+        if( !aps ) continue;
+        const CcAlfFilterParam& cc = aps->getCcAlfAPSParam();
+        for( int fI = 0; fI < VVR_CCALF_FILTERS; fI++ ) for( int j = 0; j < VVR_CCALF_TAPS + 1 && j < MAX_NUM_CC_ALF_CHROMA_COEFF; j++ ) E.alfParams.ccalf_coeff[k][fI][j] = cc.ccAlfCoeff[k][fI][j];
+      }
+  }
+
+  // ---- LMCS: the tables Reshape::constructReshaper built (Reshape.cpp:318-374); the forward map is tabulated with rspFwdCore's formula
+  memset( &E.lmcs, 0, sizeof( E.lmcs ) );
+  if( ( h.tool_flags & VVR_TOOL_LMCS ) && reshaper )
+  {
+    const int lutSize = 1 << bd, orgCW = lutSize / PIC_CODE_CW_BINS, l2cw = getLog2( orgCW );
+    const SliceReshapeInfo& ri = reshaper->getSliceReshaperInfo();
+    for( int v = 0; v < lutSize; v++ )
+    {
+      E.lmcs.inv_lut[v] = reshaper->m_invLUT[v];
+      const int i = v >> l2cw;
+      E.lmcs.fwd_lut[v] = (int16_t) Clip3( 0, lutSize - 1, (int) reshaper->m_reshapePivot[i] + ( ( (int) reshaper->m_fwdScaleCoef[i] * ( v - (int) reshaper->m_inputPivot[i] ) + ( 1 << ( FP_PREC - 1 ) ) ) >> FP_PREC ) );
+    }
+    for( int i = 0; i < 16; i++ ) { E.lmcs.chroma_scale[i] = (int16_t) reshaper->m_chromaAdjHelpLUT[i]; E.lmcs.model_delta_cw[i] = (int16_t) ri.reshaperModelBinCWDelta[i]; }
+    for( int i = 0; i < 17; i++ ) E.lmcs.pivot[i] = reshaper->m_reshapePivot[i];
+    E.lmcs.min_bin = (int16_t) ri.reshaperModelMinBinIdx; E.lmcs.max_bin = (int16_t) ri.reshaperModelMaxBinIdx; E.lmcs.model_delta_crs = (int16_t) ri.chrResScalingOffset;
+  }
+
+  // ---- explicit weighted prediction, scaling lists
+  memset( &E.wp, 0, sizeof( E.wp ) );
+  if( h.tool_flags & VVR_TOOL_WP )
+    for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
+    {
+      const WPScalingParam* wp = nullptr;
+      slice.getWpScaling( RefPicList( l ), i, wp );
+      for( int k = 0; k < 3; k++ )
+      {
+        E.wp.log2_denom[k ? 1 : 0] = (uint8_t) wp[k].uiLog2WeightDenom;
+        vvr_wp_entry& e = E.wp.e[l][i][k]; e.present = wp[k].bPresentFlag; e.weight = (int16_t) wp[k].iWeight; e.offset = (int16_t) wp[k].iOffset;
+      }
+    }
+  memset( &E.scaling, 0, sizeof( E.scaling ) );
+  if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && cs.picHeader->getScalingListAPS() )
+  {
+    const ScalingList& sl = cs.picHeader->getScalingListAPS()->getScalingList();
+    for( int id = 0; id < 28; id++ )
+    {
+      const int n = ScalingList::matrixSize( id );
+      const int* src = sl.getScalingListAddress( id );
+      for( int k = 0; k < n * n; k++ ) E.scaling.coef[id][k] = (uint8_t) src[k];
+      E.scaling.dc[id] = (uint8_t) sl.getScalingListDC( id );
+    }
+  }
+
+  // ---- the picture
+  E.pic.num_cu = (uint32_t) E.cu.size(); E.pic.num_tu = (uint32_t) E.tu.size();
+  if( E.coef.empty() ) E.coef.push_back( 0 );
+  E.pic.cu = E.cu.data(); E.pic.tu = E.tu.data(); E.pic.ctu_first_cu = E.ctuFirstCu.data(); E.pic.coef = E.coef.data(); E.pic.num_coef = E.coef.size();
+  E.pic.motion = E.motion.data(); E.pic.lfp[0] = E.lfp[0].data(); E.pic.lfp[1] = E.lfp[1].data();
+  E.pic.sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) ? E.sao.data() : nullptr;
+  E.pic.alf = ( h.tool_flags & VVR_TOOL_ALF ) ? E.alf.data() : nullptr;
+  E.pic.alf_params = ( h.tool_flags & VVR_TOOL_ALF ) ? &E.alfParams : nullptr;
+  E.pic.lmcs = ( h.tool_flags & VVR_TOOL_LMCS ) ? &E.lmcs : nullptr;
+  E.pic.wp = ( h.tool_flags & VVR_TOOL_WP ) ? &E.wp : nullptr;
+  E.pic.scaling = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? &E.scaling : nullptr;
+  E.pic.resident = 0;
+}
+
+}   // namespace vvr_glue

@@ -61,6 +61,7 @@
 #undef protected
 
 #include "../include/vvr.h"
+#include "../integration/vvr_extract.h"      // the reference-side glue under test (round trip, see vvref_extract below)
 
 using namespace vvdec;
 
@@ -76,6 +77,9 @@ enum {
 };
 
 static std::string g_err;
+// round trip of the reference-side glue: when set, vvref_reconstruct stops after it has built the reference's objects from the
+// description and lets integration/vvr_extract.h turn them back into a description
+static vvr_glue::Extracted* g_extractTo = nullptr;
 static bool g_trace = getenv("VVREF_TRACE") != nullptr;
 #define TR(...) do { if( g_trace ) { fprintf( stderr, __VA_ARGS__ ); fflush( stderr ); } } while(0)
 __attribute__((visibility("default"))) const char* vvref_last_error() { return g_err.c_str(); }
@@ -574,6 +578,13 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       TR("reshaper done\n");
     }
     decCu.init( intraPred.get(), interPred.get(), reshaper.get(), trQuant.get() );
+    if( g_extractTo )
+    {
+      auto slotOf = [&]( const Picture* p ) { for( auto& kv : refPics ) if( kv.second.get() == p ) return kv.first; return -1; };
+      vvr_glue::extractPicture( cs, *slice, pic, sps.getUseReshaper() ? reshaper.get() : nullptr, *trQuant, slotOf, H.out_slot, *g_extractTo );
+      for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
+      return 0;
+    }
 
     PelStorage fltBuf;
     fltBuf.create( cf, Size( W, Hh ), ctuSize, margin, MEMORY_ALIGN_DEF_SIZE, true, nullptr );
@@ -703,6 +714,20 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     g_err = e.what();
     return -1;
   }
+}
+
+// description -> the reference's objects -> description (integration/vvr_extract.h).  The result stays valid until the next call.
+__attribute__((visibility("default")))
+const vvr_picture* vvref_extract( const vvr_picture* vp, const uint16_t* const* ref_planes, uint32_t* num_dmvr )
+{
+  static vvr_glue::Extracted E;
+  g_extractTo = &E;
+  uint16_t* none[3] = { nullptr, nullptr, nullptr };
+  const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, 0, nullptr );
+  g_extractTo = nullptr;
+  if( rc != 0 ) return nullptr;
+  if( num_dmvr ) *num_dmvr = E.numDmvr;
+  return &E.pic;
 }
 
 } // extern "C"

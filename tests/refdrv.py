@@ -57,6 +57,44 @@ def reconstruct(desc, refs=None, flags=0, want_lfp=False, want_dmvr=0):
     return dict(planes=outs, ms=list(ms), lfp=lfps, dmvr=dmvr)
 
 
+def extract(desc, refs=None):
+    """description -> the reference decoder's own objects -> description, through the reference-side glue integration/vvr_extract.h.
+    Returns a dict of numpy copies of every array of the extracted vvr_picture (and its header)."""
+    L = lib()
+    L.vvref_extract.restype = C.POINTER(abi.Picture)
+    p = desc.c()
+    nslots = (max(refs.keys()) + 1) if refs else 0
+    ref_ptrs = (C.POINTER(C.c_uint16) * max(1, nslots * 3))()
+    keep = []
+    for slot, planes in (refs or {}).items():
+        for c, pl in enumerate(planes):
+            a = np.ascontiguousarray(pl, dtype=np.uint16)
+            keep.append(a)
+            ref_ptrs[slot * 3 + c] = a.ctypes.data_as(C.POINTER(C.c_uint16))
+    nd = C.c_uint32()
+    r = L.vvref_extract(C.byref(p), ref_ptrs, C.byref(nd))
+    if not r:
+        raise RuntimeError("vvref_extract failed: " + L.vvref_last_error().decode())
+    q = r.contents
+    h = abi.PicHeader.from_buffer_copy(q.hdr)
+    n4 = ((h.width + 3) >> 2) * ((h.height + 3) >> 2)
+    ctu = 1 << h.log2_ctu
+    nctu = ((h.width + ctu - 1) // ctu) * ((h.height + ctu - 1) // ctu)
+
+    def arr(ptr, n, ctype):
+        if not ptr or not n:
+            return None
+        return np.frombuffer((C.c_char * (C.sizeof(ctype) * n)).from_address(C.addressof(ptr.contents)), np.dtype(ctype)).copy()
+
+    def one(ptr, ctype):
+        return ctype.from_buffer_copy(ptr.contents) if ptr else None
+
+    return dict(hdr=h, num_dmvr=nd.value, cu=arr(q.cu, q.num_cu, abi.Cu), tu=arr(q.tu, q.num_tu, abi.Tu), coef=arr(q.coef, q.num_coef, abi.i16),
+                ctu_first_cu=arr(q.ctu_first_cu, nctu + 1, abi.u32), motion=arr(q.motion, n4, abi.Motion),
+                lfp=[arr(q.lfp[0], n4, abi.Lfp), arr(q.lfp[1], n4, abi.Lfp)], sao=arr(q.sao, nctu, abi.SaoCtu), alf=arr(q.alf, nctu, abi.AlfCtu),
+                alf_params=one(q.alf_params, abi.AlfParams), lmcs=one(q.lmcs, abi.LmcsParams), wp=one(q.wp, abi.WpParams), scaling=one(q.scaling, abi.ScalingList))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the plain-C restatement (oracle/libvvoracle.so) through the same calling convention
 # ---------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,147 @@
+"""CPU: round trip of the reference-side glue (integration/vvr_extract.h).
+
+A generated description is turned into the reference decoder's own objects by the test harness (oracle/ref_harness.cpp: SPS / PPS /
+picture header / slice / APSs / CodingStructure with CUs, TUs, motion, edge parameters, SAO / ALF CTU data, levels in the
+reconstruction buffer -- the state the reference is in after parsing, MIDER and LF_INIT).  The extractor walks those objects with the
+reference's own helpers and writes a description again; every field must come back: the "derived" ones (final intra modes, transform
+types from TrQuant::getTrTypes, the motion-compensation branch, CIIP neighbour flags, DMVR offsets, LMCS tables rebuilt by the
+reference's Reshape class, final ALF filters after reconstructCoeffAPSs, SAO offsets) are recomputed on the way, not copied.
+
+Needs oracle/_ref (built where /root/reference exists); skipped elsewhere."""
+import numpy as np
+import pytest
+
+import refdrv
+from vvdec_amd import abi, synth, stream
+
+pytestmark = pytest.mark.skipif(not refdrv.available(), reason="oracle/_ref not built")
+ALL = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST | abi.TOOL_BDOF |
+       abi.TOOL_DMVR | abi.TOOL_PROF)
+LM = abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE
+
+
+def _fields_differ(a, b, what):
+    out = []
+    assert len(a) == len(b), "%s: %d vs %d entries" % (what, len(a), len(b))
+    for name in a.dtype.names:
+        if name.startswith("pad"):
+            continue
+        if not np.array_equal(a[name], b[name]):
+            idx = np.nonzero((a[name] != b[name]).reshape(len(a), -1).any(axis=1))[0]
+            out.append("%s.%s differs in %d entries, first #%d: %s vs %s" % (what, name, len(idx), idx[0], a[name][idx[0]], b[name][idx[0]]))
+    return out
+
+
+def _struct_differ(a, b, what, skip=()):
+    out = []
+    for (name, _) in a._fields_:
+        if name.startswith("pad") or name in skip:
+            continue
+        v0, v1 = getattr(a, name), getattr(b, name)
+        if hasattr(v0, "__len__"):
+            v0, v1 = np.ctypeslib.as_array(v0), np.ctypeslib.as_array(v1)
+            if not np.array_equal(v0, v1):
+                out.append("%s.%s differs" % (what, name))
+        elif v0 != v1:
+            out.append("%s.%s: %s vs %s" % (what, name, v0, v1))
+    return out
+
+
+def _compare(d, e):
+    bad = []
+    h0, h1 = d.hdr, e["hdr"]
+    # (the harness always switches the SPS MTS flag on and resolves the transform types per TU, so that bit is not a property of the stream)
+    f0, f1 = h0.tool_flags | abi.TOOL_MTS, h1.tool_flags | abi.TOOL_MTS
+    if f0 != f1:
+        bad.append("hdr.tool_flags %x vs %x" % (f0, f1))
+    bad += _struct_differ(h0, h1, "hdr", skip=("tool_flags",))
+    bad += _fields_differ(d.cu, e["cu"], "cu")
+    bad += _fields_differ(d.tu, e["tu"], "tu")
+    if not np.array_equal(d.ctu_first_cu, e["ctu_first_cu"]):
+        bad.append("ctu_first_cu differs")
+    n = max(len(d.coef), len(e["coef"]))
+    c0, c1 = np.zeros(n, np.int16), np.zeros(n, np.int16)
+    c0[:len(d.coef)], c1[:len(e["coef"])] = d.coef, e["coef"]
+    if not np.array_equal(c0, c1):
+        bad.append("coef differs")
+    bad += _fields_differ(d.motion, e["motion"], "motion")
+    for k in range(2):
+        bad += _fields_differ(d.lfp[k], e["lfp"][k], "lfp%d" % k)
+    if h0.tool_flags & (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA):
+        bad += _fields_differ(d.sao, e["sao"], "sao")
+    if h0.tool_flags & abi.TOOL_ALF:
+        bad += _fields_differ(d.alf, e["alf"], "alf")
+        a0, a1 = d.alf_params, e["alf_params"]
+        na = a0.num_luma_aps
+        if a1.num_luma_aps != na:
+            bad.append("alf_params.num_luma_aps")
+        for name in ("luma_coeff", "luma_clip"):
+            if not np.array_equal(np.ctypeslib.as_array(getattr(a0, name))[:na], np.ctypeslib.as_array(getattr(a1, name))[:na]):
+                bad.append("alf_params.%s differs" % name)
+        if h0.chroma_format:
+            names = ("chroma_coeff", "chroma_clip") + (("ccalf_coeff",) if h0.tool_flags & abi.TOOL_CCALF else ())
+            for name in names:
+                if not np.array_equal(np.ctypeslib.as_array(getattr(a0, name)), np.ctypeslib.as_array(getattr(a1, name))):
+                    bad.append("alf_params.%s differs" % name)
+    if h0.tool_flags & abi.TOOL_LMCS:
+        l0, l1 = d.lmcs, e["lmcs"]
+        nv = 1 << h0.bit_depth
+        for name in ("fwd_lut", "inv_lut"):
+            if not np.array_equal(np.ctypeslib.as_array(getattr(l0, name))[:nv], np.ctypeslib.as_array(getattr(l1, name))[:nv]):
+                bad.append("lmcs.%s differs" % name)
+        bad += _struct_differ(l0, l1, "lmcs", skip=("fwd_lut", "inv_lut"))
+    if (h0.tool_flags & abi.TOOL_WP) and h0.slice_type != abi.SLICE_I:
+        w0, w1 = d.wp, e["wp"]
+        if list(w0.log2_denom) != list(w1.log2_denom):
+            bad.append("wp.log2_denom")
+        for l in range(2):
+            for i in range(h0.num_ref[l]):
+                for c in range(3):
+                    a, b = w0.e[l][i][c], w1.e[l][i][c]
+                    if (a.weight, a.offset, a.present) != (b.weight, b.offset, b.present):
+                        bad.append("wp.e[%d][%d][%d]" % (l, i, c))
+    if h0.tool_flags & abi.TOOL_SCALING_LIST:
+        bad += _struct_differ(d.scaling, e["scaling"], "scaling")
+    return bad
+
+
+CASES = [
+    ("intra_tools", 256, 128, 7, 0, 601, ALL, dict(p_cclm=0.3, p_mip=0.2, p_isp=0.2, p_lfnst=0.3, p_bdpcm=0.1)),
+    ("inter_tools_lmcs", 384, 256, 6, 2, 602, ALL | LM, dict(p_intra=0.25, p_affine=0.2, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.1, p_sbt=0.1, p_bcw=0.2, p_jccr=0.3, p_coded_chroma=0.5)),
+    ("key_picture", 256, 192, 7, 1, 603, ALL | LM | abi.TOOL_JCCR_SIGN | abi.TOOL_STILL_REF, dict(p_intra=0.2, p_affine=0.1, p_jccr=0.4, p_coded_chroma=0.6)),
+    ("weighted_prediction", 256, 128, 6, 3, 604, ALL | abi.TOOL_WP, dict(p_intra=0.1, p_affine=0.2, p_sbtmvp=0.15, p_ciip=0.1)),
+    ("scaling_lists", 256, 128, 7, 2, 605, ALL | abi.TOOL_SCALING_LIST | abi.TOOL_SCALING_LIST_NO_LFNST, dict(p_intra=0.3, p_coded=0.8, p_coded_chroma=0.6, p_lfnst=0.5, p_sbt=0.3)),
+    ("dual_tree_implicit_mts", 256, 128, 6, 0, 606, ALL | LM | abi.TOOL_IMPLICIT_MTS, dict(dual_tree=2.0, p_cclm=0.3, p_lfnst=0.4, p_isp=0.3, p_mip=0.3, p_coded=0.7, p_coded_chroma=0.5, p_split_scale=1.5)),
+    ("small_cus_local_dual_tree", 264, 200, 7, 3, 607, ALL | LM, dict(min_cu_log2=2, p_intra=0.3, p_split_scale=1.8, p_cclm=0.3, p_isp=0.2, p_sbt=0.2, p_ciip=0.3, p_coded_chroma=0.5)),
+    ("intra_block_copy", 384, 256, 6, 0, 608, ALL | LM | abi.TOOL_IBC | abi.TOOL_CCLM_COLLOC, dict(p_ibc=0.5, p_split_scale=1.4, p_cclm=0.3, p_jccr=0.3, p_coded_chroma=0.5)),
+    ("ibc_b_picture", 264, 200, 7, 2, 609, ALL | abi.TOOL_IBC, dict(p_ibc=0.6, p_intra=0.4, min_cu_log2=2, p_split_scale=1.6)),
+    ("8bit", 256, 128, 6, 2, 610, ALL | LM, dict(bit_depth=8, p_intra=0.25, p_affine=0.15, p_geo=0.1, p_ciip=0.1, p_mip=0.2, p_isp=0.2, p_cclm=0.3)),
+    ("monochrome", 256, 128, 7, 3, 611, ALL | abi.TOOL_LMCS, dict(chroma_format=0, p_intra=0.3, p_affine=0.2, p_mip=0.2, p_isp=0.2)),
+    ("no_filters", 200, 136, 5, 2, 612, abi.TOOL_DEP_QUANT | abi.TOOL_DEBLOCK_OFF, dict(p_intra=0.2)),
+]
+
+
+@pytest.mark.parametrize("name,W,H,l2,idx,seed,tools,kw", CASES, ids=[c[0] for c in CASES])
+def test_description_survives_the_reference_objects(built, name, W, H, l2, idx, seed, tools, kw):
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc, bit_depth=kw.get("bit_depth", 10)))
+    e = refdrv.extract(d, refs)
+    bad = _compare(d, e)
+    assert not bad, "\n".join(bad)
+    assert e["num_dmvr"] == d.num_dmvr
+
+
+def test_p_slice(built):
+    W, H = 256, 128
+    p = synth.default_params(width=W, height=H, seed=613, tool_flags=ALL | abi.TOOL_WP, slice_type=abi.SLICE_P, p_affine=0.2, p_sbtmvp=0.15, p_ciip=0.1, p_intra=0.1)
+    p.poc, p.out_slot = 4, 0
+    synth.set_refs(p, [(1, 0), (2, 8)])
+    d = synth.generate(p)
+    refs = {1: synth.natural_picture(W, H, 614), 2: synth.natural_picture(W, H, 615)}
+    bad = _compare(d, refdrv.extract(d, refs))
+    assert not bad, "\n".join(bad)

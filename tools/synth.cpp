@@ -430,7 +430,7 @@ struct Gen {
       // affine CUs with the same reference picture and the same control points in both lists take the uni-directional path (:424-429)
       if( aff && bi && P.ref_poc[0][cu.ref_idx[0]] == P.ref_poc[1][cu.ref_idx[1]] && rng.p( 0.3 ) ) memcpy( cu.mv[1], cu.mv[0], sizeof( cu.mv[0] ) );
       cu.mc_mode = ( cu.flags & VVR_CU_SBTMVP ) ? VVR_MC_SBTMVP : ( cu.flags & VVR_CU_GEO ) ? VVR_MC_GEO : aff ? VVR_MC_AFFINE : dmvr ? ( bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR ) : bio ? VVR_MC_BDOF : ( !bi || identical ) ? VVR_MC_UNI : VVR_MC_BI;
-      if( dmvr ) { cu.dmvr_off = B.num_dmvr; B.num_dmvr += ( ( w + 15 ) / 16 ) * ( ( h + 15 ) / 16 ); }     // one delta MV per 16x16 sub-block (m_dmvrMvCache)
+      if( cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF ) { cu.dmvr_off = B.num_dmvr; B.num_dmvr += ( ( w + 15 ) / 16 ) * ( ( h + 15 ) / 16 ); }     // one delta MV per 16x16 sub-block (m_dmvrMvCache)
     }
     // sub-block transform (cu_sbt_flag): the CU is split in two TUs, half/half or quarter/three quarters, and only one carries a residual
     int sbtIdx = 0, sbtPos = 0;
