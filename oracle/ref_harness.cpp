@@ -581,6 +581,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     if( g_extractTo )
     {
       auto slotOf = [&]( const Picture* p ) { for( auto& kv : refPics ) if( kv.second.get() == p ) return kv.first; return -1; };
+      if( flags & VVREF_DERIVE_LFP ) for( int a = 0; a < numCtu; a++ ) lf.calcFilterStrengthsCTU( cs, a );      // LF_INIT by the reference itself
       vvr_glue::extractPicture( cs, *slice, pic, sps.getUseReshaper() ? reshaper.get() : nullptr, *trQuant, slotOf, H.out_slot, *g_extractTo );
       for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
       return 0;
@@ -718,12 +719,12 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
 
 // description -> the reference's objects -> description (integration/vvr_extract.h).  The result stays valid until the next call.
 __attribute__((visibility("default")))
-const vvr_picture* vvref_extract( const vvr_picture* vp, const uint16_t* const* ref_planes, uint32_t* num_dmvr )
+const vvr_picture* vvref_extract( const vvr_picture* vp, const uint16_t* const* ref_planes, uint32_t* num_dmvr, int flags )
 {
   static vvr_glue::Extracted E;
   g_extractTo = &E;
   uint16_t* none[3] = { nullptr, nullptr, nullptr };
-  const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, 0, nullptr );
+  const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, flags & VVREF_DERIVE_LFP, nullptr );
   g_extractTo = nullptr;
   if( rc != 0 ) return nullptr;
   if( num_dmvr ) *num_dmvr = E.numDmvr;

@@ -57,7 +57,7 @@ def reconstruct(desc, refs=None, flags=0, want_lfp=False, want_dmvr=0):
     return dict(planes=outs, ms=list(ms), lfp=lfps, dmvr=dmvr)
 
 
-def extract(desc, refs=None):
+def extract(desc, refs=None, flags=0):
     """description -> the reference decoder's own objects -> description, through the reference-side glue integration/vvr_extract.h.
     Returns a dict of numpy copies of every array of the extracted vvr_picture (and its header)."""
     L = lib()
@@ -72,7 +72,7 @@ def extract(desc, refs=None):
             keep.append(a)
             ref_ptrs[slot * 3 + c] = a.ctypes.data_as(C.POINTER(C.c_uint16))
     nd = C.c_uint32()
-    r = L.vvref_extract(C.byref(p), ref_ptrs, C.byref(nd))
+    r = L.vvref_extract(C.byref(p), ref_ptrs, C.byref(nd), flags)      # flags: DERIVE_LFP = the reference derives the edge parameters itself
     if not r:
         raise RuntimeError("vvref_extract failed: " + L.vvref_last_error().decode())
     q = r.contents

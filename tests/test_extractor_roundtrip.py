@@ -145,3 +145,23 @@ def test_p_slice(built):
     refs = {1: synth.natural_picture(W, H, 614), 2: synth.natural_picture(W, H, 615)}
     bad = _compare(d, refdrv.extract(d, refs))
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name,W,H,l2,idx,seed,tools,kw", CASES, ids=[c[0] for c in CASES])
+def test_edge_tables_of_the_reference_drive_the_oracle(built, name, W, H, l2, idx, seed, tools, kw):
+    """the way a real integration runs: the reference derives the edge parameters itself (LF_INIT, calcFilterStrengthsCTU), the extractor
+    copies its raw tables (including bits the filters never look at), and the back-end's arithmetic (here: the oracle restatement) must
+    reproduce the reference's output from them"""
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc, bit_depth=kw.get("bit_depth", 10)))
+    e = refdrv.extract(d, refs, flags=refdrv.DERIVE_LFP)
+    want = refdrv.reconstruct(d, refs, flags=refdrv.DERIVE_LFP)["planes"]
+    d.lfp = [e["lfp"][0], e["lfp"][1]]
+    got = refdrv.oracle_reconstruct(d, refs)
+    for c in range(len(got)):
+        assert np.array_equal(got[c], want[c]), "comp %d: %d differ" % (c, int((got[c] != want[c]).sum()))
