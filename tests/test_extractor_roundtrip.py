@@ -165,3 +165,31 @@ def test_edge_tables_of_the_reference_drive_the_oracle(built, name, W, H, l2, id
     got = refdrv.oracle_reconstruct(d, refs)
     for c in range(len(got)):
         assert np.array_equal(got[c], want[c]), "comp %d: %d differ" % (c, int((got[c] != want[c]).sum()))
+
+
+def test_reference_edge_tables_are_safe_for_one_launch_per_direction(built):
+    """k_deblock filters all edges of a direction in one launch: on the tables the reference derives itself, neighbouring luma edges touch
+    disjoint samples, except the pair the kernel orders itself (7-sample P side 8 samples after a coding-sub-block edge)"""
+    from test_host_logic import _edge_reach
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    ordered = 0
+    for (name, W, H, l2, idx, seed, tools, kw) in CASES + [("sbtmvp", 384, 256, 7, 1, 620, ALL, dict(p_intra=0.05, p_affine=0.3, p_sbtmvp=0.4, p_split_scale=0.5))]:
+        if tools & abi.TOOL_DEBLOCK_OFF:
+            continue
+        pl = plans[idx]
+        d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
+        refs = {}
+        for lst in pl.ref_slots:
+            for (slot, poc) in lst:
+                refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc, bit_depth=kw.get("bit_depth", 10)))
+        e = refdrv.extract(d, refs, flags=refdrv.DERIVE_LFP)
+        ctu = 1 << l2
+        for dr in range(2):
+            lf = e["lfp"][dr].reshape(d.h4, d.w4)
+            for line in (lf if dr == 0 else lf.T):
+                edges = [(b * 4, _edge_reach(l, dr, b * 4, ctu), l) for b, l in enumerate(line) if int(l["bs"]) & 3]
+                for (e0, r0, l0), (e1, r1, l1) in zip(edges, edges[1:]):
+                    if e0 + r0[1] - 1 >= e1 - r1[2] or e1 - r1[0] <= e0 + r0[3] - 1:
+                        assert e1 - e0 == 8 and (int(l1["side_max_filt_length"]) >> 4) & 7 == 7, (name, dr, e0, e1)
+                        ordered += 1
+    assert ordered > 0
