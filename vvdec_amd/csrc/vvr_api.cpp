@@ -942,7 +942,7 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
     intraLevelsV = levels;
     for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
     for( auto& u : units ) for( uint32_t d : u.deps ) units[d].waited = true;
-    std::vector<uint8_t> unitCount( 3 * (size_t) numCtu, 0 );
+    std::vector<uint32_t> unitCount( 3 * (size_t) numCtu, 0 );
     for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
     unitsDev.resize( units.size() );
     for( size_t t = 0; t < perm.size(); t++ )
