@@ -71,6 +71,8 @@ __attribute__(( visibility( "default" ) )) int vvt_take_trace( int* dst, int max
   g_trace.clear();
   return n;
 }
+// everything vvr_prepare uploaded for one picture (work lists, tables, the description's arrays): one allocation
+__attribute__(( visibility( "default" ) )) int vvt_blob( const vvr_prepared* q, const void** p, size_t* n ) { if( !q ) return -1; *p = q->blob.p; *n = q->blob.n; return 0; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sync_capacity( const vvr_context* c, int lane ) { return c && lane < (int) c->syncCap.size() ? c->syncCap[lane] : 0; }

@@ -367,25 +367,19 @@ VVR_API void vvr_free_prepared( vvr_context* c, vvr_prepared* q )
   delete q;
 }
 
-VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** out )
+namespace {
+// vvr_prepare in stages: everything a picture's device work lists are built from lives in one object; the stages run in the order of
+// the member functions below (each keeps the reference citations of the code it holds)
+struct PicturePreparer
 {
-  if( !c || !p || !out ) return VVR_ERR_PARAMETER;
-  if( p->resident ) { c->setError( "vvr_prepare needs host arrays" ); return VVR_ERR_PARAMETER; }
-  int rc = validate( c, p );
-  if( rc != VVR_OK ) return rc;
-  hipSetDevice( c->device );
-  const vvr_pic_header& h = p->hdr;
-  const int ncomp = h.chroma_format ? 3 : 1;
-  const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
-  const int w4 = ( h.width + 3 ) >> 2, h4 = ( h.height + 3 ) >> 2, ctu = 1 << h.log2_ctu;
-  const int ctusX = ( h.width + ctu - 1 ) / ctu, ctusY = ( h.height + ctu - 1 ) / ctu, numCtu = ctusX * ctusY;
-
+  vvr_context* const c; const vvr_picture* const p; const vvr_pic_header& h;
+  const int ncomp; const bool wpOn; const int w4, h4, ctu, ctusX, ctusY, numCtu;
   // ---- host glue: work lists (what DecCu::TaskTrafoCtu / TaskInterCtu iterate over, DecCu.cpp:106-134)
   std::vector<McItem> mc, mcBdof, mcDmvr, mcAff;
   uint32_t numDmvr = 0;
   std::vector<TbItem> tb[3];
   std::vector<IntraItem> intra[3];
-  std::vector<uint32_t> ctuStartV( 3 * (size_t) ( numCtu + 1 ), 0 );
+  std::vector<uint32_t> ctuStartV;
   double bytes[K_NUM] = { 0 };
   // decode-order index of the transform block covering every 4x4 luma unit (both channel types): reference availability
   // = "inside the picture and reconstructed before me" (CodingStructure::getCURestricted, CodingStructure.cpp:464, and the
@@ -403,660 +397,713 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   std::vector<UnitH> units;
   std::vector<ItemH> itemH[3];
   std::vector<int32_t> itemAt[3];        // per component and 4x4 luma cell: the block that reconstructs it in the intra stage (-1: none)
-  bool anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
-  for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
-  if( anyIntra )
-  {
-    order.assign( (size_t) w4 * h4 * 2, 0x7fffffff );
-    intraAt.assign( (size_t) w4 * h4, 0 );
-    for( int k = 0; k < ncomp; k++ ) itemAt[k].assign( (size_t) w4 * h4, -1 );
-    for( uint32_t i = 0; i < p->num_cu; i++ )
-    {
-      const vvr_cu& cu = p->cu[i];
-      // 1: intra CU, 2: CIIP CU (inter prediction blended with planar intra in the intra stage, DecCu.cpp:137-140,453-456)
-      const bool ciip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
-      if( cu.pred_mode == VVR_PRED_INTRA || ciip )
-        for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) intraAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = ciip ? 2 : 1;
-      for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
-      {
-        const vvr_tu& tu = p->tu[t];
-        for( int chn = 0; chn < 2; chn++ )
-        {
-          if( chn == 0 && !( tu.comp_mask & 1 ) ) continue;
-          if( chn == 1 && !( tu.comp_mask & 6 ) ) continue;
-          int ax = tu.x, ay = tu.y, aw = tu.w, ah = tu.h;
-          if( chn == 1 && cu.isp_mode ) { ax = cu.x; ay = cu.y; aw = cu.w; ah = cu.h; }      // ISP: the unsplit chroma blocks sit in the last TU
-          for( int y = ay; y < ay + ah && y < h.height; y += 4 ) for( int x = ax; x < ax + aw && x < h.width; x += 4 )
-            order[(size_t) chn * w4 * h4 + ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) t;
-        }
-      }
-    }
-  }
-  auto unitAvail = [&]( int chn, int x, int y, int32_t cur ) -> int
+  // LMCS chroma residual scaling: per VPDU the luma neighbourhood its factor is averaged over (Reshape::calculateChromaAdjVpduNei,
+  // Reshape.cpp:192-274): left column / above row of the CU at the VPDU origin, where that neighbour precedes it in decoding order
+  const bool cscale;
+  const int vpduLog2, vpdusX, vpdusY;
+  std::vector<uint32_t> csVpduV;
+  std::vector<IntraItem> intraAll;
+  std::vector<IntraUnit> unitsDev;
+  std::vector<std::pair<int, int>> intraLevelsV;
+
+  PicturePreparer( vvr_context* c_, const vvr_picture* p_ )
+    : c( c_ ), p( p_ ), h( p_->hdr ), ncomp( h.chroma_format ? 3 : 1 ), wpOn( ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2 ),
+      w4( ( h.width + 3 ) >> 2 ), h4( ( h.height + 3 ) >> 2 ), ctu( 1 << h.log2_ctu ), ctusX( ( h.width + ctu - 1 ) / ctu ), ctusY( ( h.height + ctu - 1 ) / ctu ), numCtu( ctusX * ctusY ),
+      ctuStartV( 3 * (size_t) ( numCtu + 1 ), 0 ),
+      cscale( ( h.tool_flags & VVR_TOOL_LMCS ) && ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && ncomp == 3 ),
+      vpduLog2( std::min<int>( 6, h.log2_ctu ) ), vpdusX( ( h.width + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2 ), vpdusY( ( h.height + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2 ) {}
+
+  int unitAvail( int chn, int x, int y, int32_t cur ) const
   {
     const int cs = chn ? 1 : 0, lx = x << cs, ly = y << cs;
     if( x < 0 || y < 0 || lx >= h.width || ly >= h.height ) return 0;
     return order[(size_t) chn * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
-  };
-  // LMCS chroma residual scaling: per VPDU the luma neighbourhood its factor is averaged over (Reshape::calculateChromaAdjVpduNei,
-  // Reshape.cpp:192-274): left column / above row of the CU at the VPDU origin, where that neighbour precedes it in decoding order
-  const bool cscale = ( h.tool_flags & VVR_TOOL_LMCS ) && ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && ncomp == 3;
-  const int vpduLog2 = std::min<int>( 6, h.log2_ctu ), vpdusX = ( h.width + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2, vpdusY = ( h.height + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2;
-  std::vector<uint32_t> csVpduV;
-  if( cscale )
+  }
+
+  // decoding order of the transform blocks, cells covered by intra CUs, the luma neighbourhood of every VPDU's chroma scaling factor
+  int mapDecodingOrder()
   {
-    std::vector<int32_t> cuAt( (size_t) w4 * h4, -1 );
+    bool anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
+    for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
+    if( anyIntra )
+    {
+      order.assign( (size_t) w4 * h4 * 2, 0x7fffffff );
+      intraAt.assign( (size_t) w4 * h4, 0 );
+      for( int k = 0; k < ncomp; k++ ) itemAt[k].assign( (size_t) w4 * h4, -1 );
+      for( uint32_t i = 0; i < p->num_cu; i++ )
+      {
+        const vvr_cu& cu = p->cu[i];
+        // 1: intra CU, 2: CIIP CU (inter prediction blended with planar intra in the intra stage, DecCu.cpp:137-140,453-456)
+        const bool ciip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
+        if( cu.pred_mode == VVR_PRED_INTRA || ciip )
+          for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) intraAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = ciip ? 2 : 1;
+        for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+        {
+          const vvr_tu& tu = p->tu[t];
+          for( int chn = 0; chn < 2; chn++ )
+          {
+            if( chn == 0 && !( tu.comp_mask & 1 ) ) continue;
+            if( chn == 1 && !( tu.comp_mask & 6 ) ) continue;
+            int ax = tu.x, ay = tu.y, aw = tu.w, ah = tu.h;
+            if( chn == 1 && cu.isp_mode ) { ax = cu.x; ay = cu.y; aw = cu.w; ah = cu.h; }      // ISP: the unsplit chroma blocks sit in the last TU
+            for( int y = ay; y < ay + ah && y < h.height; y += 4 ) for( int x = ax; x < ax + aw && x < h.width; x += 4 )
+              order[(size_t) chn * w4 * h4 + ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) t;
+          }
+        }
+      }
+    }
+    if( cscale )
+    {
+      std::vector<int32_t> cuAt( (size_t) w4 * h4, -1 );
+      for( uint32_t i = 0; i < p->num_cu; i++ )
+      {
+        const vvr_cu& cu = p->cu[i];
+        if( cu.tree == VVR_TREE_CHROMA ) continue;                     // dual tree: the luma CUs
+        for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) cuAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) i;
+      }
+      csVpduV.resize( (size_t) vpdusX * vpdusY );
+      for( int vy = 0; vy < vpdusY; vy++ ) for( int vx = 0; vx < vpdusX; vx++ )
+      {
+        const int32_t tl = cuAt[(size_t) ( ( vy << vpduLog2 ) >> 2 ) * w4 + ( ( vx << vpduLog2 ) >> 2 )];
+        const int xPos = p->cu[tl].x, yPos = p->cu[tl].y;
+        bool hasLeft = xPos > 0, hasAbove = yPos > 0;
+        if( hasLeft && ( ( xPos - 1 ) >> h.log2_ctu ) == ( xPos >> h.log2_ctu ) && cuAt[(size_t) ( yPos >> 2 ) * w4 + ( ( xPos - 1 ) >> 2 )] > tl ) hasLeft = false;
+        if( hasAbove && ( ( yPos - 1 ) >> h.log2_ctu ) == ( yPos >> h.log2_ctu ) && cuAt[(size_t) ( ( yPos - 1 ) >> 2 ) * w4 + ( xPos >> 2 )] > tl ) hasAbove = false;
+        csVpduV[(size_t) vy * vpdusX + vx] = (uint32_t) xPos | ( (uint32_t) yPos << 13 ) | ( hasLeft ? 1u << 26 : 0 ) | ( hasAbove ? 1u << 27 : 0 );
+      }
+    }
+    return VVR_OK;
+  }
+
+  // the work lists: intra-stage blocks with the blocks they read from, motion-compensation tiles, transform blocks
+  int buildWorkLists()
+  {
+    uint32_t curCtu = 0;
     for( uint32_t i = 0; i < p->num_cu; i++ )
     {
       const vvr_cu& cu = p->cu[i];
-      if( cu.tree == VVR_TREE_CHROMA ) continue;                     // dual tree: the luma CUs
-      for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) cuAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) i;
-    }
-    csVpduV.resize( (size_t) vpdusX * vpdusY );
-    for( int vy = 0; vy < vpdusY; vy++ ) for( int vx = 0; vx < vpdusX; vx++ )
-    {
-      const int32_t tl = cuAt[(size_t) ( ( vy << vpduLog2 ) >> 2 ) * w4 + ( ( vx << vpduLog2 ) >> 2 )];
-      const int xPos = p->cu[tl].x, yPos = p->cu[tl].y;
-      bool hasLeft = xPos > 0, hasAbove = yPos > 0;
-      if( hasLeft && ( ( xPos - 1 ) >> h.log2_ctu ) == ( xPos >> h.log2_ctu ) && cuAt[(size_t) ( yPos >> 2 ) * w4 + ( ( xPos - 1 ) >> 2 )] > tl ) hasLeft = false;
-      if( hasAbove && ( ( yPos - 1 ) >> h.log2_ctu ) == ( yPos >> h.log2_ctu ) && cuAt[(size_t) ( ( yPos - 1 ) >> 2 ) * w4 + ( xPos >> 2 )] > tl ) hasAbove = false;
-      csVpduV[(size_t) vy * vpdusX + vx] = (uint32_t) xPos | ( (uint32_t) yPos << 13 ) | ( hasLeft ? 1u << 26 : 0 ) | ( hasAbove ? 1u << 27 : 0 );
-    }
-  }
-  uint32_t curCtu = 0;
-  for( uint32_t i = 0; i < p->num_cu; i++ )
-  {
-    const vvr_cu& cu = p->cu[i];
-    // CTU bookkeeping for the per-CTU intra lists (CUs arrive in CTU raster order)
-    const uint32_t ctuOfCu = (uint32_t) ( ( cu.y >> h.log2_ctu ) * ctusX + ( cu.x >> h.log2_ctu ) );
-    {
-      if( ctuOfCu < curCtu ) { c->setError( "CUs are not in CTU raster order" ); return VVR_ERR_PARAMETER; }
-      while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
-    }
-    const bool isCiipCu = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
-    // LMCS chroma residual scaling of an inter block: its factor reads reconstructed luma that the intra stage may still have to
-    // produce, and intra blocks next to it read its reconstructed chroma, so the residual add of such a block is an item of the
-    // intra stage too (IT_MODE_RESI_ADD: no prediction, scaled residual onto the inter prediction; finishLMCSAndReco, DecCu.cpp:483)
-    const bool isCsInterCu = cscale && cu.pred_mode == VVR_PRED_INTER && ( !isCiipCu || cu.w == 4 ) && ( cu.flags & VVR_CU_ROOT_CBF );
-    // intra block copy: the block is a copy of reconstructed samples of this picture that the intra stage may still have to produce, so it
-    // is an item of the intra stage as well (IT_MODE_IBC; the reference does it in its intra task too, DecCu.cpp:145)
-    const bool isIbcCu = cu.pred_mode == VVR_PRED_IBC;
-    if( cu.pred_mode == VVR_PRED_INTRA || isCiipCu || isCsInterCu || isIbcCu )
-    {
+      // CTU bookkeeping for the per-CTU intra lists (CUs arrive in CTU raster order)
+      const uint32_t ctuOfCu = (uint32_t) ( ( cu.y >> h.log2_ctu ) * ctusX + ( cu.x >> h.log2_ctu ) );
+      {
+        if( ctuOfCu < curCtu ) { c->setError( "CUs are not in CTU raster order" ); return VVR_ERR_PARAMETER; }
+        while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
+      }
+      const bool isCiipCu = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
+      // LMCS chroma residual scaling of an inter block: its factor reads reconstructed luma that the intra stage may still have to
+      // produce, and intra blocks next to it read its reconstructed chroma, so the residual add of such a block is an item of the
+      // intra stage too (IT_MODE_RESI_ADD: no prediction, scaled residual onto the inter prediction; finishLMCSAndReco, DecCu.cpp:483)
+      const bool isCsInterCu = cscale && cu.pred_mode == VVR_PRED_INTER && ( !isCiipCu || cu.w == 4 ) && ( cu.flags & VVR_CU_ROOT_CBF );
+      // intra block copy: the block is a copy of reconstructed samples of this picture that the intra stage may still have to produce, so it
+      // is an item of the intra stage as well (IT_MODE_IBC; the reference does it in its intra task too, DecCu.cpp:145)
+      const bool isIbcCu = cu.pred_mode == VVR_PRED_IBC;
+      if( cu.pred_mode == VVR_PRED_INTRA || isCiipCu || isCsInterCu || isIbcCu )
+      {
+        for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+        {
+          const vvr_tu& tu = p->tu[t];
+          for( int comp = 0; comp < ncomp; comp++ )
+          {
+            if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
+            // the 2-wide chroma blocks of a 4-wide CIIP CU are not blended (predBlendIntraCiip, IntraPrediction.cpp:891): plain inter blocks
+            const bool isCiip = isCiipCu && !( comp && cu.w == 4 );
+            const bool isCsInter = cscale && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
+            if( cu.pred_mode != VVR_PRED_INTRA && !isCiip && !isCsInter && !isIbcCu ) continue;
+            if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
+            const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
+            // intra sub-partitions: luma partitions are blocks of their own that share the reference line of the whole CU
+            // (initIntraPatternChTypeISP, IntraPrediction.cpp:966); partitions narrower than 4 are predicted in pairs (DecCu.cpp:333-371):
+            // one item of width 4 carries both; the unsplit chroma blocks come with the last TU
+            const bool ispL = cu.isp_mode && !comp, ispC = cu.isp_mode && comp;
+            const bool ispPair = ispL && cu.isp_mode == 2 && tu.w < 4;                              // group of 4 / tu.w partitions
+            if( ispPair && ( ( tu.x - cu.x ) & 3 ) ) continue;                                      // not the first of its group: part of the group's item
+            const int x0 = ( ispC ? cu.x : tu.x ) >> cs, y0 = ( ispC ? cu.y : tu.y ) >> cs, w = ispPair ? 4 : ( ispC ? cu.w : tu.w ) >> cs, hh = ( ispC ? cu.h : tu.h ) >> cs;
+            // block whose neighbourhood decides the availability of the reference samples
+            const int rx0 = ispL ? cu.x : x0, ry0 = ispL ? cu.y : y0, rw = ispL ? cu.w : w, rh = ispL ? cu.h : hh;
+            const int32_t rcur = ispL ? (int32_t) cu.first_tu : (int32_t) t;
+            const int totalAbove = ( 2 * rw + unit - 1 ) / unit, totalLeft = ( 2 * rh + unit - 1 ) / unit;
+            IntraItem it; memset( &it, 0, sizeof( it ) );
+            it.tu = t; it.comp = (uint8_t) comp;
+            it.x = (uint16_t) x0; it.y = (uint16_t) y0;
+            { int l = 0; while( ( 1 << l ) < w ) l++; it.lw = (uint8_t) l; l = 0; while( ( 1 << l ) < hh ) l++; it.lh = (uint8_t) l; }
+            it.mode = isIbcCu ? IT_MODE_IBC : isCsInter ? IT_MODE_RESI_ADD : isCiip ? 0 : cu.intra_dir[chn];       // CIIP: planar
+            // IBC: the block vector in samples of the component (chroma: halved, InterPrediction.cpp:2010-2011)
+            const int ibcDx = isIbcCu ? ( cu.mv[0][0][0] >> 4 ) >> cs : 0, ibcDy = isIbcCu ? ( cu.mv[0][0][1] >> 4 ) >> cs : 0;
+            if( isIbcCu ) it.tu = ( (uint32_t) ibcDx & 0xffff ) | ( (uint32_t) ibcDy << 16 );
+            bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
+            if( ispL )
+            {
+              // residual flags of the partitions of a group (2 of width 2, or 4 of width 1), geometry of the partition inside its CU
+              uint32_t mask = tu.cbf & 1, grp = 0;
+              if( ispPair )
+              {
+                grp = tu.w == 2 ? 1 : 2;
+                for( uint32_t k = 1; k < 4u / tu.w && t + k < cu.first_tu + cu.num_tu; k++ ) mask |= (uint32_t) ( p->tu[t + k].cbf & 1 ) << k;
+              }
+              it.tu = (uint32_t) ( tu.x - cu.x ) | ( (uint32_t) ( tu.y - cu.y ) << 6 ) | ( (uint32_t) ilog2i( cu.w ) << 12 ) | ( (uint32_t) ilog2i( cu.h ) << 15 )
+                    | ( (uint32_t) ( cu.isp_mode == 2 ) << 18 ) | ( mask << 19 ) | ( grp << 23 );
+              hasResi = mask != 0;
+            }
+            const int bdp = ( isCiip || isCsInter || isIbcCu ) ? 0 : cu.bdpcm[chn];
+            // CIIP blend weight of the intra part (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:925-929): 1 + intra neighbours
+            const int wIntra = isCiip ? 1 + ( cu.ciip_neigh_intra & 1 ) + ( ( cu.ciip_neigh_intra >> 1 ) & 1 ) : 0;
+            it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip || isCsInter || isIbcCu ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
+            if( !comp && !isCiip && ( cu.flags & VVR_CU_MIP ) ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_MIP | ( ( cu.flags & VVR_CU_MIP_TRANSP ) ? 0x10 : 0 ) );
+            if( ispL ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_ISP );
+            const bool noRef = isCsInter || isIbcCu;                                  // no intra reference lines
+            if( !noRef ) it.nTL = (uint8_t) unitAvail( chn, rx0 - 1, ry0 - 1, rcur );
+            if( !noRef && unitAvail( chn, rx0, ry0 - 1, rcur ) ) { int n = rw / unit; for( int k = 0; k < totalAbove - rw / unit; k++ ) { if( !unitAvail( chn, rx0 + rw + k * unit, ry0 - 1, rcur ) ) break; n++; } it.nA = (uint8_t) n; }
+            if( !noRef && unitAvail( chn, rx0 - 1, ry0, rcur ) ) { int n = rh / unit; for( int k = 0; k < totalLeft - rh / unit; k++ ) { if( !unitAvail( chn, rx0 - 1, ry0 + rh + k * unit, rcur ) ) break; n++; } it.nL = (uint8_t) n; }
+            int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0; bool isCclm = false;
+            const bool csItem = cscale && comp && hasResi && w * hh > 4;             // DecCu.cpp:383-388 / :500-505
+            if( csItem ) it.flags |= IT_F_CSCALE;
+            if( comp && !isCiip && !isCsInter && !isIbcCu && cu.intra_dir[1] >= 67 )
+            {
+              // CCLM / MDLM: template sizes and flags of IntraPrediction::xGetLMParameters (:1694-1800) and the border handling of
+              // xGetLumaRecPixels (:1403-1470); they ride in the item's `tu` word
+              const int mode = cu.intra_dir[1];
+              const bool aboveCu = cu.y > 0 || ( y0 << 1 ) > cu.y, leftCu = cu.x > 0 || ( x0 << 1 ) > cu.x;          // cu.above / cu.left (one slice, one tile)
+              const int tuWU = w / unit, tuHU = hh / unit;
+              const int totA = ( 2 * w + unit - 1 ) / unit, totL = ( 2 * hh + unit - 1 ) / unit;
+              int aboveAvail = 0, leftAvail = 0, actualTop = 0, actualLeft = 0;
+              if( mode == 69 )
+              {
+                int avai = 0;
+                if( aboveCu ) { avai = tuWU; const int lim = std::min( totA - tuWU, hh / unit ); for( int k = 0; k < lim; k++ ) { if( !unitAvail( 1, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; avai++; } }
+                aboveAvail = avai >= tuWU; actualTop = unit * avai;
+              }
+              else if( mode == 68 )
+              {
+                int avai = 0;
+                if( leftCu ) { avai = tuHU; const int lim = std::min( totL - tuHU, w / unit ); for( int k = 0; k < lim; k++ ) { if( !unitAvail( 1, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; avai++; } }
+                leftAvail = avai >= tuHU; actualLeft = unit * avai;
+              }
+              else { aboveAvail = aboveCu; leftAvail = leftCu; actualTop = w; actualLeft = hh; }
+              const int bLeft = leftCu ? 1 : 0;                                                          // availlableLeftUnit >= iTUHeightInUnits
+              const int firstRow = ( ( y0 << 1 ) & ( ( 1 << h.log2_ctu ) - 1 ) ) == 0;
+              it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 ) | ( (uint32_t) ( aboveCu ? 1 : 0 ) << 20 );
+              cclmTop = aboveAvail ? actualTop : 0; cclmLeft = leftAvail ? actualLeft : 0; cclmBLeft = bLeft; isCclm = true;
+            }
+            // ---- the blocks this one reads from, its part of the CTU tile
+            const uint32_t myId = (uint32_t) intra[comp].size();
+            intra[comp].push_back( it );
+            itemH[comp].emplace_back();
+            ItemH& IH = itemH[comp].back();
+            IH.ctu = ctuOfCu;
+            {
+              const int ctuX = cu.x >> h.log2_ctu, ctuY = cu.y >> h.log2_ctu;
+              const int mrl = ( comp || isIbcCu ) ? 0 : cu.multi_ref_idx;
+              auto touch = [&]( int k, int xc, int yc )   // component k, component coordinates of a sample that is read
+              {
+                const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
+                if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
+                const int32_t d = itemAt[k][(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )];
+                if( d < 0 ) return;
+                const uint32_t key = ( (uint32_t) k << 28 ) | (uint32_t) d;
+                if( ( k != comp || (uint32_t) d != myId ) && std::find( IH.prod.begin(), IH.prod.end(), key ) == IH.prod.end() ) IH.prod.push_back( key );
+              };
+              {
+                // bounding box of everything the kernel's reference fill may read for this block (whole top / left lines incl. padding sources)
+                const int S = ( 1 << h.log2_ctu ) >> cs, ox = ctuX * S, oy = ctuY * S;
+                BBox& bb = IH.bb;
+                const int bx0 = rx0 - 1 - mrl, bx1 = rx0 + std::max( 2 * rw, 1 ) + 1, by0 = ry0 - 1 - mrl, by1 = ry0 + 2 * rh + 1;
+                bb.y0 = std::min( bb.y0, std::max( 0, by0 - ( oy - 3 ) ) );
+                bb.y1 = std::max( bb.y1, std::min( S + 3, by1 - ( oy - 3 ) ) );
+                bb.c0 = std::min( bb.c0, std::max( 0, ( bx0 - ( ox - 8 ) ) >> 3 ) );
+                bb.c1 = std::max( bb.c1, std::min( ( 8 + S + 64 + 7 ) >> 3, ( bx1 - ( ox - 8 ) + 7 ) >> 3 ) );
+              }
+              if( it.nTL ) touch( comp, rx0 - 1 - mrl, ry0 - 1 - mrl );
+              for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, rx0 + k, ry0 - 1 - mrl );
+              for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, rx0 - 1 - mrl, ry0 + k );
+              if( ispL && ( x0 != rx0 || y0 != ry0 ) ) touch( 0, cu.isp_mode == 2 ? x0 - 1 : x0, cu.isp_mode == 2 ? y0 : y0 - 1 );   // ISP: the previous partition
+              if( isIbcCu )
+              {
+                // the reference block: every cell must precede this block in decoding order; the intra-stage blocks that produce it are producers
+                const int qx = x0 + ibcDx, qy = y0 + ibcDy;
+                for( int yy = 0; yy < hh + unit - 1; yy += unit ) for( int xx = 0; xx < w + unit - 1; xx += unit )
+                {
+                  const int sx = qx + std::min( xx, w - 1 ), sy = qy + std::min( yy, hh - 1 );
+                  if( !unitAvail( chn, sx, sy, (int32_t) t ) ) { c->setError( "IBC CU: the reference block is not reconstructed before the CU" ); return VVR_ERR_PARAMETER; }
+                  touch( comp, sx, sy );
+                }
+              }
+              if( csItem )
+              {
+                // luma the chroma scaling factor is averaged over (the unit must wait for the luma units that reconstruct it)
+                const uint32_t d = csVpduV[(size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 )];
+                const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff, n = 1 << vpduLog2;
+                if( ( d >> 26 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, xPos - 1, std::min( yPos + k, (int) h.height - 1 ) );
+                if( ( d >> 27 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, std::min( xPos + k, (int) h.width - 1 ), yPos - 1 );
+              }
+              if( isCclm )
+              {
+                // luma the prediction reads: the co-located block and the template rows / columns around it (luma coordinates)
+                const int lx0 = x0 << 1, ly0 = y0 << 1;
+                for( int yy = 0; yy < 2 * hh; yy += 4 ) for( int xx = ( cclmBLeft ? -4 : 0 ); xx < 2 * w; xx += 4 ) touch( 0, lx0 + xx, ly0 + yy );
+                for( int xx = ( cclmBLeft ? -4 : 0 ); xx < 2 * cclmTop + 4; xx += 4 ) touch( 0, lx0 + xx, ly0 - 1 );
+                for( int yy = 0; yy < 2 * cclmLeft + 4; yy += 4 ) touch( 0, lx0 - 1, ly0 + yy );
+              }
+              // the cells this block reconstructs
+              for( int yy = 0; yy < ( hh << cs ); yy += 4 ) for( int xx = 0; xx < ( w << cs ); xx += 4 )
+                if( ( x0 << cs ) + xx < h.width && ( y0 << cs ) + yy < h.height ) itemAt[comp][(size_t) ( ( ( y0 << cs ) + yy ) >> 2 ) * w4 + ( ( ( x0 << cs ) + xx ) >> 2 )] = (int32_t) myId;
+            }
+            bytes[K_INTRA] += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
+          }
+        }
+      }
+      if( cu.pred_mode == VVR_PRED_INTER )
+      {
+        const int nl = cu.mc_mode == VVR_MC_UNI ? 1 : 2;     // (SbTMVP: upper bound, sub-blocks may be uni-directional)
+        const bool sbt = cu.mc_mode == VVR_MC_SBTMVP;
+        const int ts = sbt ? 8 : 16;                       // SbTMVP: one item per 8x8 sub-block (ATMVP_SUB_BLOCK_SIZE)
+        for( int y = 0; y < cu.h; y += ts ) for( int x = 0; x < cu.w; x += ts )
+        {
+          McItem it; memset( &it, 0, sizeof( it ) );
+          it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y ); it.flags = sbt ? MC_ITEM_SUBBLOCK : 0; it.cu = i;
+          const bool dm = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
+          const bool af = cu.mc_mode == VVR_MC_AFFINE;
+          if( !dm && !af )
+          {
+            // everything k_mc needs about the motion of the tile
+            bool uni = cu.mc_mode == VVR_MC_UNI;
+            it.ref[0] = cu.ref_idx[0]; it.ref[1] = cu.ref_idx[1];
+            for( int l = 0; l < 2; l++ ) { it.mv[l][0] = cu.mv[l][0][0]; it.mv[l][1] = cu.mv[l][0][1]; }
+            it.clipX = cu.x; it.clipY = cu.y;
+            if( sbt )
+            {
+              // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the motion of the 8x8 sub-block from the motion field, the identical-motion
+              // shortcut (xCheckIdenticalMotion :404, not with weighted bi-prediction :408) decided per sub-block, clipped at its own position
+              const vvr_motion& m = p->motion[(size_t) ( it.y >> 2 ) * w4 + ( it.x >> 2 )];
+              for( int l = 0; l < 2; l++ ) { it.ref[l] = m.ref_idx[l]; it.mv[l][0] = m.mv[l][0]; it.mv[l][1] = m.mv[l][1]; }
+              const bool two = it.ref[0] >= 0 && it.ref[1] >= 0;
+              uni = !two || ( h.ref_poc[0][it.ref[0]] == h.ref_poc[1][it.ref[1]] && it.mv[0][0] == it.mv[1][0] && it.mv[0][1] == it.mv[1][1] && !wpOn );
+              it.clipX = it.x; it.clipY = it.y;
+            }
+            it.bcw = cu.bcw_idx;
+            it.flags |= ( uni ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 );
+          }
+          ( dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc ).push_back( it );
+          const double smp = (double) it.w * it.h * ( ncomp == 3 ? 1.5 : 1.0 );
+          const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
+          bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += smp * 2 * nla + smp * 2 + sizeof( McItem ) + ( dm ? 8 : 0 ) + ( af ? it.w * it.h / 16.0 * sizeof( vvr_motion ) : 0 );
+        }
+        if( cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF ) numDmvr = std::max<uint32_t>( numDmvr, cu.dmvr_off + ( ( cu.w + 15 ) / 16 ) * ( ( cu.h + 15 ) / 16 ) );
+        bytes[K_MC] += sizeof( vvr_cu );
+      }
+      if( !( cu.flags & VVR_CU_ROOT_CBF ) ) continue;
       for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
       {
         const vvr_tu& tu = p->tu[t];
         for( int comp = 0; comp < ncomp; comp++ )
         {
           if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
-          // the 2-wide chroma blocks of a 4-wide CIIP CU are not blended (predBlendIntraCiip, IntraPrediction.cpp:891): plain inter blocks
-          const bool isCiip = isCiipCu && !( comp && cu.w == 4 );
-          const bool isCsInter = cscale && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
-          if( cu.pred_mode != VVR_PRED_INTRA && !isCiip && !isCsInter && !isIbcCu ) continue;
-          if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
-          const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
-          // intra sub-partitions: luma partitions are blocks of their own that share the reference line of the whole CU
-          // (initIntraPatternChTypeISP, IntraPrediction.cpp:966); partitions narrower than 4 are predicted in pairs (DecCu.cpp:333-371):
-          // one item of width 4 carries both; the unsplit chroma blocks come with the last TU
-          const bool ispL = cu.isp_mode && !comp, ispC = cu.isp_mode && comp;
-          const bool ispPair = ispL && cu.isp_mode == 2 && tu.w < 4;                              // group of 4 / tu.w partitions
-          if( ispPair && ( ( tu.x - cu.x ) & 3 ) ) continue;                                      // not the first of its group: part of the group's item
-          const int x0 = ( ispC ? cu.x : tu.x ) >> cs, y0 = ( ispC ? cu.y : tu.y ) >> cs, w = ispPair ? 4 : ( ispC ? cu.w : tu.w ) >> cs, hh = ( ispC ? cu.h : tu.h ) >> cs;
-          // block whose neighbourhood decides the availability of the reference samples
-          const int rx0 = ispL ? cu.x : x0, ry0 = ispL ? cu.y : y0, rw = ispL ? cu.w : w, rh = ispL ? cu.h : hh;
-          const int32_t rcur = ispL ? (int32_t) cu.first_tu : (int32_t) t;
-          const int totalAbove = ( 2 * rw + unit - 1 ) / unit, totalLeft = ( 2 * rh + unit - 1 ) / unit;
-          IntraItem it; memset( &it, 0, sizeof( it ) );
-          it.tu = t; it.comp = (uint8_t) comp;
-          it.x = (uint16_t) x0; it.y = (uint16_t) y0;
-          { int l = 0; while( ( 1 << l ) < w ) l++; it.lw = (uint8_t) l; l = 0; while( ( 1 << l ) < hh ) l++; it.lh = (uint8_t) l; }
-          it.mode = isIbcCu ? IT_MODE_IBC : isCsInter ? IT_MODE_RESI_ADD : isCiip ? 0 : cu.intra_dir[chn];       // CIIP: planar
-          // IBC: the block vector in samples of the component (chroma: halved, InterPrediction.cpp:2010-2011)
-          const int ibcDx = isIbcCu ? ( cu.mv[0][0][0] >> 4 ) >> cs : 0, ibcDy = isIbcCu ? ( cu.mv[0][0][1] >> 4 ) >> cs : 0;
-          if( isIbcCu ) it.tu = ( (uint32_t) ibcDx & 0xffff ) | ( (uint32_t) ibcDy << 16 );
-          bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
-          if( ispL )
+          TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.ict = 0; it.pad = 0;
+          it.mode = ( cu.pred_mode == VVR_PRED_INTER && ( !( cu.flags & VVR_CU_CIIP ) || ( comp && cu.w == 4 ) ) ) ? TB_ADD : TB_STORE;      // (2-wide chroma of a 4-wide CIIP CU: plain inter)
+          if( comp && tu.joint_cbcr )
           {
-            // residual flags of the partitions of a group (2 of width 2, or 4 of width 1), geometry of the partition inside its CU
-            uint32_t mask = tu.cbf & 1, grp = 0;
-            if( ispPair )
-            {
-              grp = tu.w == 2 ? 1 : 2;
-              for( uint32_t k = 1; k < 4u / tu.w && t + k < cu.first_tu + cu.num_tu; k++ ) mask |= (uint32_t) ( p->tu[t + k].cbf & 1 ) << k;
-            }
-            it.tu = (uint32_t) ( tu.x - cu.x ) | ( (uint32_t) ( tu.y - cu.y ) << 6 ) | ( (uint32_t) ilog2i( cu.w ) << 12 ) | ( (uint32_t) ilog2i( cu.h ) << 15 )
-                  | ( (uint32_t) ( cu.isp_mode == 2 ) << 18 ) | ( mask << 19 ) | ( grp << 23 );
-            hasResi = mask != 0;
+            if( comp != 1 ) continue;
+            static const int ict[2][4] = { { 0, 3, 1, 2 }, { 0, -3, -1, -2 } };           // g_ictModes (Rom.cpp:409)
+            it.comp = (uint8_t) ( ( tu.joint_cbcr >> 1 ) ? 1 : 2 );
+            it.ict = (uint8_t) ( 4 + ict[( h.tool_flags & VVR_TOOL_JCCR_SIGN ) ? 1 : 0][tu.joint_cbcr] );
           }
-          const int bdp = ( isCiip || isCsInter || isIbcCu ) ? 0 : cu.bdpcm[chn];
-          // CIIP blend weight of the intra part (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:925-929): 1 + intra neighbours
-          const int wIntra = isCiip ? 1 + ( cu.ciip_neigh_intra & 1 ) + ( ( cu.ciip_neigh_intra >> 1 ) & 1 ) : 0;
-          it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip || isCsInter || isIbcCu ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
-          if( !comp && !isCiip && ( cu.flags & VVR_CU_MIP ) ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_MIP | ( ( cu.flags & VVR_CU_MIP_TRANSP ) ? 0x10 : 0 ) );
-          if( ispL ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_ISP );
-          const bool noRef = isCsInter || isIbcCu;                                  // no intra reference lines
-          if( !noRef ) it.nTL = (uint8_t) unitAvail( chn, rx0 - 1, ry0 - 1, rcur );
-          if( !noRef && unitAvail( chn, rx0, ry0 - 1, rcur ) ) { int n = rw / unit; for( int k = 0; k < totalAbove - rw / unit; k++ ) { if( !unitAvail( chn, rx0 + rw + k * unit, ry0 - 1, rcur ) ) break; n++; } it.nA = (uint8_t) n; }
-          if( !noRef && unitAvail( chn, rx0 - 1, ry0, rcur ) ) { int n = rh / unit; for( int k = 0; k < totalLeft - rh / unit; k++ ) { if( !unitAvail( chn, rx0 - 1, ry0 + rh + k * unit, rcur ) ) break; n++; } it.nL = (uint8_t) n; }
-          int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0; bool isCclm = false;
-          const bool csItem = cscale && comp && hasResi && w * hh > 4;             // DecCu.cpp:383-388 / :500-505
-          if( csItem ) it.flags |= IT_F_CSCALE;
-          if( comp && !isCiip && !isCsInter && !isIbcCu && cu.intra_dir[1] >= 67 )
-          {
-            // CCLM / MDLM: template sizes and flags of IntraPrediction::xGetLMParameters (:1694-1800) and the border handling of
-            // xGetLumaRecPixels (:1403-1470); they ride in the item's `tu` word
-            const int mode = cu.intra_dir[1];
-            const bool aboveCu = cu.y > 0 || ( y0 << 1 ) > cu.y, leftCu = cu.x > 0 || ( x0 << 1 ) > cu.x;          // cu.above / cu.left (one slice, one tile)
-            const int tuWU = w / unit, tuHU = hh / unit;
-            const int totA = ( 2 * w + unit - 1 ) / unit, totL = ( 2 * hh + unit - 1 ) / unit;
-            int aboveAvail = 0, leftAvail = 0, actualTop = 0, actualLeft = 0;
-            if( mode == 69 )
-            {
-              int avai = 0;
-              if( aboveCu ) { avai = tuWU; const int lim = std::min( totA - tuWU, hh / unit ); for( int k = 0; k < lim; k++ ) { if( !unitAvail( 1, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; avai++; } }
-              aboveAvail = avai >= tuWU; actualTop = unit * avai;
-            }
-            else if( mode == 68 )
-            {
-              int avai = 0;
-              if( leftCu ) { avai = tuHU; const int lim = std::min( totL - tuHU, w / unit ); for( int k = 0; k < lim; k++ ) { if( !unitAvail( 1, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; avai++; } }
-              leftAvail = avai >= tuHU; actualLeft = unit * avai;
-            }
-            else { aboveAvail = aboveCu; leftAvail = leftCu; actualTop = w; actualLeft = hh; }
-            const int bLeft = leftCu ? 1 : 0;                                                          // availlableLeftUnit >= iTUHeightInUnits
-            const int firstRow = ( ( y0 << 1 ) & ( ( 1 << h.log2_ctu ) - 1 ) ) == 0;
-            it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 ) | ( (uint32_t) ( aboveCu ? 1 : 0 ) << 20 );
-            cclmTop = aboveAvail ? actualTop : 0; cclmLeft = leftAvail ? actualLeft : 0; cclmBLeft = bLeft; isCclm = true;
-          }
-          // ---- the blocks this one reads from, its part of the CTU tile
-          const uint32_t myId = (uint32_t) intra[comp].size();
-          intra[comp].push_back( it );
-          itemH[comp].emplace_back();
-          ItemH& IH = itemH[comp].back();
-          IH.ctu = ctuOfCu;
-          {
-            const int ctuX = cu.x >> h.log2_ctu, ctuY = cu.y >> h.log2_ctu;
-            const int mrl = ( comp || isIbcCu ) ? 0 : cu.multi_ref_idx;
-            auto touch = [&]( int k, int xc, int yc )   // component k, component coordinates of a sample that is read
-            {
-              const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
-              if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
-              const int32_t d = itemAt[k][(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )];
-              if( d < 0 ) return;
-              const uint32_t key = ( (uint32_t) k << 28 ) | (uint32_t) d;
-              if( ( k != comp || (uint32_t) d != myId ) && std::find( IH.prod.begin(), IH.prod.end(), key ) == IH.prod.end() ) IH.prod.push_back( key );
-            };
-            {
-              // bounding box of everything the kernel's reference fill may read for this block (whole top / left lines incl. padding sources)
-              const int S = ( 1 << h.log2_ctu ) >> cs, ox = ctuX * S, oy = ctuY * S;
-              BBox& bb = IH.bb;
-              const int bx0 = rx0 - 1 - mrl, bx1 = rx0 + std::max( 2 * rw, 1 ) + 1, by0 = ry0 - 1 - mrl, by1 = ry0 + 2 * rh + 1;
-              bb.y0 = std::min( bb.y0, std::max( 0, by0 - ( oy - 3 ) ) );
-              bb.y1 = std::max( bb.y1, std::min( S + 3, by1 - ( oy - 3 ) ) );
-              bb.c0 = std::min( bb.c0, std::max( 0, ( bx0 - ( ox - 8 ) ) >> 3 ) );
-              bb.c1 = std::max( bb.c1, std::min( ( 8 + S + 64 + 7 ) >> 3, ( bx1 - ( ox - 8 ) + 7 ) >> 3 ) );
-            }
-            if( it.nTL ) touch( comp, rx0 - 1 - mrl, ry0 - 1 - mrl );
-            for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, rx0 + k, ry0 - 1 - mrl );
-            for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, rx0 - 1 - mrl, ry0 + k );
-            if( ispL && ( x0 != rx0 || y0 != ry0 ) ) touch( 0, cu.isp_mode == 2 ? x0 - 1 : x0, cu.isp_mode == 2 ? y0 : y0 - 1 );   // ISP: the previous partition
-            if( isIbcCu )
-            {
-              // the reference block: every cell must precede this block in decoding order; the intra-stage blocks that produce it are producers
-              const int qx = x0 + ibcDx, qy = y0 + ibcDy;
-              for( int yy = 0; yy < hh + unit - 1; yy += unit ) for( int xx = 0; xx < w + unit - 1; xx += unit )
-              {
-                const int sx = qx + std::min( xx, w - 1 ), sy = qy + std::min( yy, hh - 1 );
-                if( !unitAvail( chn, sx, sy, (int32_t) t ) ) { c->setError( "IBC CU: the reference block is not reconstructed before the CU" ); return VVR_ERR_PARAMETER; }
-                touch( comp, sx, sy );
-              }
-            }
-            if( csItem )
-            {
-              // luma the chroma scaling factor is averaged over (the unit must wait for the luma units that reconstruct it)
-              const uint32_t d = csVpduV[(size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 )];
-              const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff, n = 1 << vpduLog2;
-              if( ( d >> 26 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, xPos - 1, std::min( yPos + k, (int) h.height - 1 ) );
-              if( ( d >> 27 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, std::min( xPos + k, (int) h.width - 1 ), yPos - 1 );
-            }
-            if( isCclm )
-            {
-              // luma the prediction reads: the co-located block and the template rows / columns around it (luma coordinates)
-              const int lx0 = x0 << 1, ly0 = y0 << 1;
-              for( int yy = 0; yy < 2 * hh; yy += 4 ) for( int xx = ( cclmBLeft ? -4 : 0 ); xx < 2 * w; xx += 4 ) touch( 0, lx0 + xx, ly0 + yy );
-              for( int xx = ( cclmBLeft ? -4 : 0 ); xx < 2 * cclmTop + 4; xx += 4 ) touch( 0, lx0 + xx, ly0 - 1 );
-              for( int yy = 0; yy < 2 * cclmLeft + 4; yy += 4 ) touch( 0, lx0 - 1, ly0 + yy );
-            }
-            // the cells this block reconstructs
-            for( int yy = 0; yy < ( hh << cs ); yy += 4 ) for( int xx = 0; xx < ( w << cs ); xx += 4 )
-              if( ( x0 << cs ) + xx < h.width && ( y0 << cs ) + yy < h.height ) itemAt[comp][(size_t) ( ( ( y0 << cs ) + yy ) >> 2 ) * w4 + ( ( ( x0 << cs ) + xx ) >> 2 )] = (int32_t) myId;
-          }
-          bytes[K_INTRA] += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
+          else if( !( tu.cbf & ( 1 << comp ) ) ) continue;
+          const int bw = ( ( it.comp && cu.isp_mode ) ? cu.w : tu.w ) >> ( it.comp ? 1 : 0 ), bh = ( ( it.comp && cu.isp_mode ) ? cu.h : tu.h ) >> ( it.comp ? 1 : 0 );
+          if( ( bw < 2 || bh < 2 ) && !( cu.isp_mode && !it.comp && bw * bh >= 16 ) ) { c->setError( "1-D transform block outside an ISP CU" ); return VVR_ERR_PARAMETER; }
+          const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
+          // LMCS chroma residual scaling of an inter block: the factor needs the reconstructed luma around the VPDU, which the intra stage
+          // may still have to produce, so the block's residual is stored and added (scaled) by a residual-add item of the intra stage
+          if( cscale && it.comp && it.mode == TB_ADD && bw * bh > 4 ) it.mode = TB_STORE;      // added (scaled) by the intra stage, see isCsInter above
+          tb[cls].push_back( it );        // ADD (inter: onto the prediction) and STORE (intra / CIIP: into the residual planes) items share a launch
+          const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];
+          const double ncoef = bdp ? (double) bw * bh : (double) ( tu.max_scan_x[it.comp] + 1 ) * ( tu.max_scan_y[it.comp] + 1 );
+          bytes[K_ITRANS] += ncoef * 2 + (double) bw * bh * 4 * ( it.ict ? 2 : 1 ) + sizeof( TbItem ) + sizeof( vvr_tu ) / 3.0;
         }
       }
     }
-    if( cu.pred_mode == VVR_PRED_INTER )
+    return VVR_OK;
+  }
+
+  int formUnits()
+  {
+    // ---- form the units: blocks of one (component, CTU) that read from each other belong together (union-find); the residual-add items of
+    // inter blocks (LMCS chroma scaling) of a (component, CTU) form a unit of their own that the kernel processes in parallel
+    for( int k = 0; k < ncomp; k++ )
     {
-      const int nl = cu.mc_mode == VVR_MC_UNI ? 1 : 2;     // (SbTMVP: upper bound, sub-blocks may be uni-directional)
-      const bool sbt = cu.mc_mode == VVR_MC_SBTMVP;
-      const int ts = sbt ? 8 : 16;                       // SbTMVP: one item per 8x8 sub-block (ATMVP_SUB_BLOCK_SIZE)
-      for( int y = 0; y < cu.h; y += ts ) for( int x = 0; x < cu.w; x += ts )
+      const size_t n = intra[k].size();
+      if( !n ) continue;
+      std::vector<uint32_t> parent( n );
+      for( size_t i = 0; i < n; i++ ) parent[i] = (uint32_t) i;
+      auto find = [&]( uint32_t a ) { while( parent[a] != a ) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+      auto unite = [&]( uint32_t a, uint32_t b ) { a = find( a ); b = find( b ); if( a != b ) parent[std::max( a, b )] = std::min( a, b ); };     // root = first block
+      int64_t bulk = -1; uint32_t bulkCtu = 0;
+      for( size_t i = 0; i < n; i++ )
       {
-        McItem it; memset( &it, 0, sizeof( it ) );
-        it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y ); it.flags = sbt ? MC_ITEM_SUBBLOCK : 0; it.cu = i;
-        const bool dm = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
-        const bool af = cu.mc_mode == VVR_MC_AFFINE;
-        if( !dm && !af )
+        const bool ra = intra[k][i].mode == IT_MODE_RESI_ADD && k;
+        if( ra ) { if( bulk >= 0 && bulkCtu == itemH[k][i].ctu ) unite( (uint32_t) bulk, (uint32_t) i ); else { bulk = (int64_t) i; bulkCtu = itemH[k][i].ctu; } continue; }
+        for( uint32_t key : itemH[k][i].prod )
         {
-          // everything k_mc needs about the motion of the tile
-          bool uni = cu.mc_mode == VVR_MC_UNI;
-          it.ref[0] = cu.ref_idx[0]; it.ref[1] = cu.ref_idx[1];
-          for( int l = 0; l < 2; l++ ) { it.mv[l][0] = cu.mv[l][0][0]; it.mv[l][1] = cu.mv[l][0][1]; }
-          it.clipX = cu.x; it.clipY = cu.y;
-          if( sbt )
-          {
-            // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the motion of the 8x8 sub-block from the motion field, the identical-motion
-            // shortcut (xCheckIdenticalMotion :404, not with weighted bi-prediction :408) decided per sub-block, clipped at its own position
-            const vvr_motion& m = p->motion[(size_t) ( it.y >> 2 ) * w4 + ( it.x >> 2 )];
-            for( int l = 0; l < 2; l++ ) { it.ref[l] = m.ref_idx[l]; it.mv[l][0] = m.mv[l][0]; it.mv[l][1] = m.mv[l][1]; }
-            const bool two = it.ref[0] >= 0 && it.ref[1] >= 0;
-            uni = !two || ( h.ref_poc[0][it.ref[0]] == h.ref_poc[1][it.ref[1]] && it.mv[0][0] == it.mv[1][0] && it.mv[0][1] == it.mv[1][1] && !wpOn );
-            it.clipX = it.x; it.clipY = it.y;
-          }
-          it.bcw = cu.bcw_idx;
-          it.flags |= ( uni ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 );
+          const uint32_t pk = key >> 28, pi = key & 0x0fffffff;
+          if( (int) pk == k && itemH[k][pi].ctu == itemH[k][i].ctu && !( intra[k][pi].mode == IT_MODE_RESI_ADD && k ) ) unite( (uint32_t) i, pi );
         }
-        ( dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc ).push_back( it );
-        const double smp = (double) it.w * it.h * ( ncomp == 3 ? 1.5 : 1.0 );
-        const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
-        bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += smp * 2 * nla + smp * 2 + sizeof( McItem ) + ( dm ? 8 : 0 ) + ( af ? it.w * it.h / 16.0 * sizeof( vvr_motion ) : 0 );
       }
-      if( cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF ) numDmvr = std::max<uint32_t>( numDmvr, cu.dmvr_off + ( ( cu.w + 15 ) / 16 ) * ( ( cu.h + 15 ) / 16 ) );
-      bytes[K_MC] += sizeof( vvr_cu );
-    }
-    if( !( cu.flags & VVR_CU_ROOT_CBF ) ) continue;
-    for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
-    {
-      const vvr_tu& tu = p->tu[t];
-      for( int comp = 0; comp < ncomp; comp++ )
+      // units in the order of their first block; blocks of a unit contiguous and in coding order
+      std::vector<int32_t> unitOfRoot( n, -1 );
+      std::vector<std::vector<uint32_t>> members;
+      std::vector<uint32_t> firstUnit( 1, (uint32_t) units.size() );
+      for( size_t i = 0; i < n; i++ )
       {
-        if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
-        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.ict = 0; it.pad = 0;
-        it.mode = ( cu.pred_mode == VVR_PRED_INTER && ( !( cu.flags & VVR_CU_CIIP ) || ( comp && cu.w == 4 ) ) ) ? TB_ADD : TB_STORE;      // (2-wide chroma of a 4-wide CIIP CU: plain inter)
-        if( comp && tu.joint_cbcr )
+        const uint32_t r = find( (uint32_t) i );
+        if( unitOfRoot[r] < 0 ) { unitOfRoot[r] = (int32_t) members.size(); members.emplace_back(); }
+        members[unitOfRoot[r]].push_back( (uint32_t) i );
+      }
+      std::vector<IntraItem> sorted; sorted.reserve( n );
+      std::vector<ItemH> sortedH; sortedH.reserve( n );
+      std::vector<uint32_t> newIdx( n );
+      for( auto& m : members )
+      {
+        UnitH u; u.comp = (uint32_t) k; u.ctu = itemH[k][m[0]].ctu; u.i0 = (uint32_t) sorted.size();
+        for( uint32_t i : m )
         {
-          if( comp != 1 ) continue;
-          static const int ict[2][4] = { { 0, 3, 1, 2 }, { 0, -3, -1, -2 } };           // g_ictModes (Rom.cpp:409)
-          it.comp = (uint8_t) ( ( tu.joint_cbcr >> 1 ) ? 1 : 2 );
-          it.ict = (uint8_t) ( 4 + ict[( h.tool_flags & VVR_TOOL_JCCR_SIGN ) ? 1 : 0][tu.joint_cbcr] );
+          newIdx[i] = (uint32_t) sorted.size();
+          sorted.push_back( intra[k][i] ); sortedH.push_back( std::move( itemH[k][i] ) );
+          const BBox& b = sortedH.back().bb;
+          u.bb.y0 = std::min( u.bb.y0, b.y0 ); u.bb.y1 = std::max( u.bb.y1, b.y1 ); u.bb.c0 = std::min( u.bb.c0, b.c0 ); u.bb.c1 = std::max( u.bb.c1, b.c1 );
+          if( k && ( intra[k][i].flags & IT_F_CSCALE ) ) u.hasCs = true;
         }
-        else if( !( tu.cbf & ( 1 << comp ) ) ) continue;
-        const int bw = ( ( it.comp && cu.isp_mode ) ? cu.w : tu.w ) >> ( it.comp ? 1 : 0 ), bh = ( ( it.comp && cu.isp_mode ) ? cu.h : tu.h ) >> ( it.comp ? 1 : 0 );
-        if( ( bw < 2 || bh < 2 ) && !( cu.isp_mode && !it.comp && bw * bh >= 16 ) ) { c->setError( "1-D transform block outside an ISP CU" ); return VVR_ERR_PARAMETER; }
-        const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
-        // LMCS chroma residual scaling of an inter block: the factor needs the reconstructed luma around the VPDU, which the intra stage
-        // may still have to produce, so the block's residual is stored and added (scaled) by a residual-add item of the intra stage
-        if( cscale && it.comp && it.mode == TB_ADD && bw * bh > 4 ) it.mode = TB_STORE;      // added (scaled) by the intra stage, see isCsInter above
-        tb[cls].push_back( it );        // ADD (inter: onto the prediction) and STORE (intra / CIIP: into the residual planes) items share a launch
-        const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];
-        const double ncoef = bdp ? (double) bw * bh : (double) ( tu.max_scan_x[it.comp] + 1 ) * ( tu.max_scan_y[it.comp] + 1 );
-        bytes[K_ITRANS] += ncoef * 2 + (double) bw * bh * 4 * ( it.ict ? 2 : 1 ) + sizeof( TbItem ) + sizeof( vvr_tu ) / 3.0;
+        u.i1 = (uint32_t) sorted.size();
+        u.iA = ( k && sorted[u.i0].mode == IT_MODE_RESI_ADD ) ? u.i1 : u.i0;
+        units.push_back( u );
       }
-    }
-  }
-  // ---- form the units: blocks of one (component, CTU) that read from each other belong together (union-find); the residual-add items of
-  // inter blocks (LMCS chroma scaling) of a (component, CTU) form a unit of their own that the kernel processes in parallel
-  for( int k = 0; k < ncomp; k++ )
-  {
-    const size_t n = intra[k].size();
-    if( !n ) continue;
-    std::vector<uint32_t> parent( n );
-    for( size_t i = 0; i < n; i++ ) parent[i] = (uint32_t) i;
-    auto find = [&]( uint32_t a ) { while( parent[a] != a ) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
-    auto unite = [&]( uint32_t a, uint32_t b ) { a = find( a ); b = find( b ); if( a != b ) parent[std::max( a, b )] = std::min( a, b ); };     // root = first block
-    int64_t bulk = -1; uint32_t bulkCtu = 0;
-    for( size_t i = 0; i < n; i++ )
-    {
-      const bool ra = intra[k][i].mode == IT_MODE_RESI_ADD && k;
-      if( ra ) { if( bulk >= 0 && bulkCtu == itemH[k][i].ctu ) unite( (uint32_t) bulk, (uint32_t) i ); else { bulk = (int64_t) i; bulkCtu = itemH[k][i].ctu; } continue; }
-      for( uint32_t key : itemH[k][i].prod )
+      intra[k].swap( sorted ); itemH[k].swap( sortedH );
+      // item index -> unit, kept for the dependency pass (old index space -> new)
+      for( auto& ih : itemH[k] ) for( uint32_t& key : ih.prod ) if( (int) ( key >> 28 ) == k ) key = ( (uint32_t) k << 28 ) | newIdx[key & 0x0fffffff];
+      for( int k2 = k + 1; k2 < ncomp; k2++ ) for( auto& ih : itemH[k2] ) for( uint32_t& key : ih.prod ) if( (int) ( key >> 28 ) == k ) key = ( (uint32_t) k << 28 ) | newIdx[key & 0x0fffffff];
+      // (chroma never is a producer for luma, and components are processed in ascending order, so every reference to component k is fixed here)
+      // the per-CTU offsets follow the new order (units, hence blocks, stay grouped by CTU)
       {
-        const uint32_t pk = key >> 28, pi = key & 0x0fffffff;
-        if( (int) pk == k && itemH[k][pi].ctu == itemH[k][i].ctu && !( intra[k][pi].mode == IT_MODE_RESI_ADD && k ) ) unite( (uint32_t) i, pi );
+        std::vector<uint32_t> cnt( (size_t) numCtu + 1, 0 );
+        for( auto& ih : itemH[k] ) cnt[ih.ctu + 1]++;
+        for( int a = 0; a < numCtu; a++ ) cnt[a + 1] += cnt[a];
+        for( int a = 0; a <= numCtu; a++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + a] = cnt[a];
       }
     }
-    // units in the order of their first block; blocks of a unit contiguous and in coding order
-    std::vector<int32_t> unitOfRoot( n, -1 );
-    std::vector<std::vector<uint32_t>> members;
-    std::vector<uint32_t> firstUnit( 1, (uint32_t) units.size() );
-    for( size_t i = 0; i < n; i++ )
+    // dependencies between units
     {
-      const uint32_t r = find( (uint32_t) i );
-      if( unitOfRoot[r] < 0 ) { unitOfRoot[r] = (int32_t) members.size(); members.emplace_back(); }
-      members[unitOfRoot[r]].push_back( (uint32_t) i );
-    }
-    std::vector<IntraItem> sorted; sorted.reserve( n );
-    std::vector<ItemH> sortedH; sortedH.reserve( n );
-    std::vector<uint32_t> newIdx( n );
-    for( auto& m : members )
-    {
-      UnitH u; u.comp = (uint32_t) k; u.ctu = itemH[k][m[0]].ctu; u.i0 = (uint32_t) sorted.size();
-      for( uint32_t i : m )
-      {
-        newIdx[i] = (uint32_t) sorted.size();
-        sorted.push_back( intra[k][i] ); sortedH.push_back( std::move( itemH[k][i] ) );
-        const BBox& b = sortedH.back().bb;
-        u.bb.y0 = std::min( u.bb.y0, b.y0 ); u.bb.y1 = std::max( u.bb.y1, b.y1 ); u.bb.c0 = std::min( u.bb.c0, b.c0 ); u.bb.c1 = std::max( u.bb.c1, b.c1 );
-        if( k && ( intra[k][i].flags & IT_F_CSCALE ) ) u.hasCs = true;
-      }
-      u.i1 = (uint32_t) sorted.size();
-      u.iA = ( k && sorted[u.i0].mode == IT_MODE_RESI_ADD ) ? u.i1 : u.i0;
-      units.push_back( u );
-    }
-    intra[k].swap( sorted ); itemH[k].swap( sortedH );
-    // item index -> unit, kept for the dependency pass (old index space -> new)
-    for( auto& ih : itemH[k] ) for( uint32_t& key : ih.prod ) if( (int) ( key >> 28 ) == k ) key = ( (uint32_t) k << 28 ) | newIdx[key & 0x0fffffff];
-    for( int k2 = k + 1; k2 < ncomp; k2++ ) for( auto& ih : itemH[k2] ) for( uint32_t& key : ih.prod ) if( (int) ( key >> 28 ) == k ) key = ( (uint32_t) k << 28 ) | newIdx[key & 0x0fffffff];
-    // (chroma never is a producer for luma, and components are processed in ascending order, so every reference to component k is fixed here)
-    // the per-CTU offsets follow the new order (units, hence blocks, stay grouped by CTU)
-    {
-      std::vector<uint32_t> cnt( (size_t) numCtu + 1, 0 );
-      for( auto& ih : itemH[k] ) cnt[ih.ctu + 1]++;
-      for( int a = 0; a < numCtu; a++ ) cnt[a + 1] += cnt[a];
-      for( int a = 0; a <= numCtu; a++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + a] = cnt[a];
-    }
-  }
-  // dependencies between units
-  {
-    std::vector<uint32_t> unitOfItem[3];
-    for( int k = 0; k < ncomp; k++ ) unitOfItem[k].assign( intra[k].size(), 0 );
-    for( size_t u = 0; u < units.size(); u++ ) for( uint32_t i = units[u].i0; i < units[u].i1; i++ ) unitOfItem[units[u].comp][i] = (uint32_t) u;
-    for( size_t u = 0; u < units.size(); u++ )
-    {
-      UnitH& U = units[u];
-      for( uint32_t i = U.i0; i < U.i1; i++ ) for( uint32_t key : itemH[U.comp][i].prod )
-      {
-        const uint32_t d = unitOfItem[key >> 28][key & 0x0fffffff];
-        if( d != u && std::find( U.deps.begin(), U.deps.end(), d ) == U.deps.end() ) U.deps.push_back( d );
-      }
-    }
-    // a unit lists at most VVR_INTRA_MAX_DEPS producers: longer lists are folded through empty join units
-    for( size_t u = 0; u < units.size(); u++ )
-      while( units[u].deps.size() > VVR_INTRA_MAX_DEPS )
-      {
-        UnitH j; j.comp = units[u].comp; j.ctu = units[u].ctu; j.i0 = j.i1 = j.iA = units[u].i0; j.bb.y0 = j.bb.y1 = 0; j.bb.c0 = j.bb.c1 = 1;
-        j.deps.assign( units[u].deps.end() - VVR_INTRA_MAX_DEPS, units[u].deps.end() );
-        units[u].deps.resize( units[u].deps.size() - VVR_INTRA_MAX_DEPS );
-        units[u].deps.push_back( (uint32_t) units.size() );
-        units.push_back( j );
-      }
-    // rank = length of the longest dependency chain below a unit (the unit graph is acyclic: luma never reads chroma, residual-add
-    // units only read luma, other CTUs' units only earlier CTUs'); computed by relaxation in creation order until stable
-    bool changed = true;
-    for( size_t pass = 0; changed && pass <= units.size(); pass++ )      // (acyclic: stable after at most one pass per level; creation order makes it 2-3)
-    {
-      changed = false;
-      for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
-    }
-  }
-  // ---- group the clusters of one (component, CTU) that sit at the same depth of the dependency graph into one unit: they cannot depend
-  // on each other, a workgroup start costs more than a few small blocks, and waiting for the union of their producers delays nothing
-  // that matters (all of them are less deep).  Residual-add units keep their own (HBM to HBM) workgroup.
-  if( !getenv( "VVR_INTRA_NO_GROUPING" ) && !units.empty() )
-  {
-    std::vector<int32_t> target( units.size(), -1 );            // original unit -> group
-    std::vector<std::vector<uint32_t>> parts;                    // groups: original units in creation order
-    {
-      std::vector<std::pair<uint64_t, uint32_t>> keyed;
+      std::vector<uint32_t> unitOfItem[3];
+      for( int k = 0; k < ncomp; k++ ) unitOfItem[k].assign( intra[k].size(), 0 );
+      for( size_t u = 0; u < units.size(); u++ ) for( uint32_t i = units[u].i0; i < units[u].i1; i++ ) unitOfItem[units[u].comp][i] = (uint32_t) u;
       for( size_t u = 0; u < units.size(); u++ )
       {
-        const bool own = units[u].iA == units[u].i1;             // residual-add unit (or empty): not grouped
-        keyed.emplace_back( own ? ( ( (uint64_t) 1 << 63 ) | u ) : ( ( (uint64_t) units[u].comp << 56 ) | ( (uint64_t) units[u].ctu << 24 ) | (uint64_t) std::min( units[u].rank, 0xffffff ) ), (uint32_t) u );
-      }
-      std::stable_sort( keyed.begin(), keyed.end(), []( const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y ) { return x.first < y.first; } );
-      static const uint32_t groupMax = getenv( "VVR_INTRA_GROUP_MAX" ) ? (uint32_t) atoi( getenv( "VVR_INTRA_GROUP_MAX" ) ) : 12;    // blocks per grouped unit
-      for( size_t i = 0; i < keyed.size(); )
-      {
-        size_t j = i; parts.emplace_back();
-        uint32_t blocks = 0;
-        while( j < keyed.size() && keyed[j].first == keyed[i].first )
+        UnitH& U = units[u];
+        for( uint32_t i = U.i0; i < U.i1; i++ ) for( uint32_t key : itemH[U.comp][i].prod )
         {
-          const uint32_t nb = units[keyed[j].second].i1 - units[keyed[j].second].i0;
-          if( blocks && blocks + nb > groupMax ) break;                   // a serial workgroup should stay short: start another one
-          blocks += nb;
-          parts.back().push_back( keyed[j].second ); target[keyed[j].second] = (int32_t) parts.size() - 1; j++;
+          const uint32_t d = unitOfItem[key >> 28][key & 0x0fffffff];
+          if( d != u && std::find( U.deps.begin(), U.deps.end(), d ) == U.deps.end() ) U.deps.push_back( d );
         }
-        i = j;
       }
-    }
-    // groups in the order of their first original unit (keeps the blocks grouped by CTU)
-    std::vector<uint32_t> orderM( parts.size() );
-    for( size_t m = 0; m < parts.size(); m++ ) orderM[m] = (uint32_t) m;
-    std::stable_sort( orderM.begin(), orderM.end(), [&]( uint32_t x, uint32_t y ) { return parts[x][0] < parts[y][0]; } );
-    std::vector<IntraItem> newItems[3];
-    std::vector<UnitH> merged;
-    std::vector<uint32_t> newIndexOfGroup( parts.size(), 0 );
-    for( uint32_t m : orderM )
-    {
-      const UnitH& f = units[parts[m][0]];
-      UnitH U; U.comp = f.comp; U.ctu = f.ctu; U.i0 = (uint32_t) newItems[f.comp].size();
-      for( uint32_t u : parts[m] )
+      // a unit lists at most VVR_INTRA_MAX_DEPS producers: longer lists are folded through empty join units
+      for( size_t u = 0; u < units.size(); u++ )
+        while( units[u].deps.size() > VVR_INTRA_MAX_DEPS )
+        {
+          UnitH j; j.comp = units[u].comp; j.ctu = units[u].ctu; j.i0 = j.i1 = j.iA = units[u].i0; j.bb.y0 = j.bb.y1 = 0; j.bb.c0 = j.bb.c1 = 1;
+          j.deps.assign( units[u].deps.end() - VVR_INTRA_MAX_DEPS, units[u].deps.end() );
+          units[u].deps.resize( units[u].deps.size() - VVR_INTRA_MAX_DEPS );
+          units[u].deps.push_back( (uint32_t) units.size() );
+          units.push_back( j );
+        }
+      // rank = length of the longest dependency chain below a unit (the unit graph is acyclic: luma never reads chroma, residual-add
+      // units only read luma, other CTUs' units only earlier CTUs'); computed by relaxation in creation order until stable
+      bool changed = true;
+      for( size_t pass = 0; changed && pass <= units.size(); pass++ )      // (acyclic: stable after at most one pass per level; creation order makes it 2-3)
       {
-        const UnitH& o = units[u];
-        newItems[o.comp].insert( newItems[o.comp].end(), intra[o.comp].begin() + o.i0, intra[o.comp].begin() + o.i1 );
-        U.bb.y0 = std::min( U.bb.y0, o.bb.y0 ); U.bb.y1 = std::max( U.bb.y1, o.bb.y1 ); U.bb.c0 = std::min( U.bb.c0, o.bb.c0 ); U.bb.c1 = std::max( U.bb.c1, o.bb.c1 );
-        U.hasCs = U.hasCs || o.hasCs;
-      }
-      U.i1 = (uint32_t) newItems[f.comp].size();
-      U.iA = f.iA == f.i1 ? U.i1 : U.i0;
-      newIndexOfGroup[m] = (uint32_t) merged.size();
-      merged.push_back( U );
-    }
-    for( size_t m = 0; m < parts.size(); m++ )
-    {
-      UnitH& U = merged[newIndexOfGroup[m]];
-      for( uint32_t u : parts[m] ) for( uint32_t d : units[u].deps )
-      {
-        const uint32_t nd = newIndexOfGroup[target[d]];
-        if( nd != newIndexOfGroup[m] && std::find( U.deps.begin(), U.deps.end(), nd ) == U.deps.end() ) U.deps.push_back( nd );
+        changed = false;
+        for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
       }
     }
-    for( int k = 0; k < ncomp; k++ ) intra[k].swap( newItems[k] );
-    units.swap( merged );
-    for( size_t u = 0; u < units.size(); u++ )
-      while( units[u].deps.size() > VVR_INTRA_MAX_DEPS )
-      {
-        UnitH j; j.comp = units[u].comp; j.ctu = units[u].ctu; j.i0 = j.i1 = j.iA = units[u].i0; j.bb.y0 = j.bb.y1 = 0; j.bb.c0 = j.bb.c1 = 1;
-        j.deps.assign( units[u].deps.end() - VVR_INTRA_MAX_DEPS, units[u].deps.end() );
-        units[u].deps.resize( units[u].deps.size() - VVR_INTRA_MAX_DEPS );
-        units[u].deps.push_back( (uint32_t) units.size() );
-        units.push_back( j );
-      }
-    for( auto& U : units ) U.rank = 0;
-    bool changed = true;
-    for( size_t pass = 0; changed && pass <= units.size(); pass++ )
-    {
-      changed = false;
-      for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
-    }
+    return VVR_OK;
   }
 
-  // one item array for the three components; ctuStart holds offsets into it; active (component, CTU) pairs in raster order
-  std::vector<IntraItem> intraAll;
-  for( int k = 0; k < 3; k++ )
+  int groupUnits()
   {
-    const uint32_t base = (uint32_t) intraAll.size();
-    intraAll.insert( intraAll.end(), intra[k].begin(), intra[k].end() );
-    for( int a = 0; a <= numCtu; a++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + a] += base;
-  }
-  // device unit table: units that wait for nothing first (they can never block a resident workgroup slot), then the others in
-  // coding order; a unit only ever waits for units created before it, so every dependency holds a lower ticket
-  std::vector<IntraUnit> unitsDev;
-  std::vector<std::pair<int, int>> intraLevelsV;
-  {
-    const uint32_t itemBase[3] = { ctuStartV[0], ctuStartV[(size_t) 1 * ( numCtu + 1 )], ctuStartV[(size_t) 2 * ( numCtu + 1 )] };
-    std::vector<uint32_t> perm, inv( units.size() );
-    // Long dependency chains (an intra picture: one CTU wavefront, ~60 levels): units that spin on their producers would hold most
-    // workgroup slots (and their LDS) of the device for milliseconds while other pictures are in flight.  Such a picture runs its
-    // intra stage as one launch per dependency level instead - units of one level never depend on each other, the launch boundary is
-    // the synchronisation, nothing waits inside a kernel.  Short chains (isolated intra blocks of B pictures) keep the single
-    // launch with flags, where a level barrier would cost more than the few waits.
-    int maxRank = 0;
-    for( auto& u : units ) maxRank = std::max( maxRank, u.rank );
-    static const int levelThr = getenv( "VVR_INTRA_LEVEL_THR" ) ? atoi( getenv( "VVR_INTRA_LEVEL_THR" ) ) : 1 << 30;     // measured: slower (9.2 vs 8.0 ms for a 4K I picture, 1457 vs 1508 frames/s), off by default
-    const bool byLevel = maxRank > levelThr;
-    std::vector<std::pair<int, int>> levels;
-    if( byLevel )
+    // ---- group the clusters of one (component, CTU) that sit at the same depth of the dependency graph into one unit: they cannot depend
+    // on each other, a workgroup start costs more than a few small blocks, and waiting for the union of their producers delays nothing
+    // that matters (all of them are less deep).  Residual-add units keep their own (HBM to HBM) workgroup.
+    if( !getenv( "VVR_INTRA_NO_GROUPING" ) && !units.empty() )
     {
-      for( size_t t = 0; t < units.size(); t++ ) perm.push_back( (uint32_t) t );
-      std::stable_sort( perm.begin(), perm.end(), [&]( uint32_t a, uint32_t b ) { return units[a].rank < units[b].rank; } );
-      for( size_t t = 0; t < perm.size(); )
+      std::vector<int32_t> target( units.size(), -1 );            // original unit -> group
+      std::vector<std::vector<uint32_t>> parts;                    // groups: original units in creation order
       {
-        size_t e = t; while( e < perm.size() && units[perm[e]].rank == units[perm[t]].rank ) e++;
-        levels.emplace_back( (int) t, (int) ( e - t ) );
-        t = e;
+        std::vector<std::pair<uint64_t, uint32_t>> keyed;
+        for( size_t u = 0; u < units.size(); u++ )
+        {
+          const bool own = units[u].iA == units[u].i1;             // residual-add unit (or empty): not grouped
+          keyed.emplace_back( own ? ( ( (uint64_t) 1 << 63 ) | u ) : ( ( (uint64_t) units[u].comp << 56 ) | ( (uint64_t) units[u].ctu << 24 ) | (uint64_t) std::min( units[u].rank, 0xffffff ) ), (uint32_t) u );
+        }
+        std::stable_sort( keyed.begin(), keyed.end(), []( const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y ) { return x.first < y.first; } );
+        static const uint32_t groupMax = getenv( "VVR_INTRA_GROUP_MAX" ) ? (uint32_t) atoi( getenv( "VVR_INTRA_GROUP_MAX" ) ) : 12;    // blocks per grouped unit
+        for( size_t i = 0; i < keyed.size(); )
+        {
+          size_t j = i; parts.emplace_back();
+          uint32_t blocks = 0;
+          while( j < keyed.size() && keyed[j].first == keyed[i].first )
+          {
+            const uint32_t nb = units[keyed[j].second].i1 - units[keyed[j].second].i0;
+            if( blocks && blocks + nb > groupMax ) break;                   // a serial workgroup should stay short: start another one
+            blocks += nb;
+            parts.back().push_back( keyed[j].second ); target[keyed[j].second] = (int32_t) parts.size() - 1; j++;
+          }
+          i = j;
+        }
       }
-      for( auto& u : units ) u.deps.clear();                  // ordered by the launches
-    }
-    else
-    {
-    for( size_t t = 0; t < units.size(); t++ ) if( units[t].deps.empty() ) perm.push_back( (uint32_t) t );
-    {
-      // dependent units by depth of the dependency graph, then in WAVEFRONT order (key = ctuX + 2 * ctuY): every producer holds a
-      // lower ticket, and the workgroups that are resident at any time are the ones on or near the current front
-      std::vector<uint32_t> dep;
-      for( size_t t = 0; t < units.size(); t++ ) if( !units[t].deps.empty() ) dep.push_back( (uint32_t) t );
-      std::stable_sort( dep.begin(), dep.end(), [&]( uint32_t a, uint32_t b )
+      // groups in the order of their first original unit (keeps the blocks grouped by CTU)
+      std::vector<uint32_t> orderM( parts.size() );
+      for( size_t m = 0; m < parts.size(); m++ ) orderM[m] = (uint32_t) m;
+      std::stable_sort( orderM.begin(), orderM.end(), [&]( uint32_t x, uint32_t y ) { return parts[x][0] < parts[y][0]; } );
+      std::vector<IntraItem> newItems[3];
+      std::vector<UnitH> merged;
+      std::vector<uint32_t> newIndexOfGroup( parts.size(), 0 );
+      for( uint32_t m : orderM )
       {
-        const int ka = (int) ( units[a].ctu % ctusX ) + 2 * (int) ( units[a].ctu / ctusX ), kb = (int) ( units[b].ctu % ctusX ) + 2 * (int) ( units[b].ctu / ctusX );
-        // by depth first (every producer is less deep, hence holds a lower ticket; units of one depth start together, so few of
-        // them find a producer that has not even started), then along the CTU wavefront.  Measured 7 % faster on B pictures than
-        // wavefront-major order (VVR_INTRA_KEY_MAJOR), the same on intra pictures where depth and wavefront coincide.
-        static const bool keyMajor = getenv( "VVR_INTRA_KEY_MAJOR" ) != nullptr;
-        if( !keyMajor ) return units[a].rank != units[b].rank ? units[a].rank < units[b].rank : ka < kb;
-        return ka != kb ? ka < kb : units[a].rank < units[b].rank;
-      } );
-      perm.insert( perm.end(), dep.begin(), dep.end() );
-    }
-    }
-    intraLevelsV = levels;
-    for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
-    for( auto& u : units ) for( uint32_t d : u.deps ) units[d].waited = true;
-    std::vector<uint32_t> unitCount( 3 * (size_t) numCtu, 0 );
-    for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
-    unitsDev.resize( units.size() );
-    for( size_t t = 0; t < perm.size(); t++ )
-    {
-      const UnitH& u = units[perm[t]];
-      IntraUnit& d = unitsDev[t]; memset( &d, 0, sizeof( d ) );
-      // bit 31: the unit is the whole (component, CTU) and every sample of the CTU is intra, so the kernel only stages the reference
-      // border and writes the CTU back with 16-byte stores
-      bool all = unitCount[(size_t) u.comp * numCtu + u.ctu] == 1;
-      {
-        const int ctu4 = 1 << ( h.log2_ctu - 2 ), ux = (int) ( u.ctu % ctusX ) * ctu4, uy = (int) ( u.ctu / ctusX ) * ctu4;
-        for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
+        const UnitH& f = units[parts[m][0]];
+        UnitH U; U.comp = f.comp; U.ctu = f.ctu; U.i0 = (uint32_t) newItems[f.comp].size();
+        for( uint32_t u : parts[m] )
+        {
+          const UnitH& o = units[u];
+          newItems[o.comp].insert( newItems[o.comp].end(), intra[o.comp].begin() + o.i0, intra[o.comp].begin() + o.i1 );
+          U.bb.y0 = std::min( U.bb.y0, o.bb.y0 ); U.bb.y1 = std::max( U.bb.y1, o.bb.y1 ); U.bb.c0 = std::min( U.bb.c0, o.bb.c0 ); U.bb.c1 = std::max( U.bb.c1, o.bb.c1 );
+          U.hasCs = U.hasCs || o.hasCs;
+        }
+        U.i1 = (uint32_t) newItems[f.comp].size();
+        U.iA = f.iA == f.i1 ? U.i1 : U.i0;
+        newIndexOfGroup[m] = (uint32_t) merged.size();
+        merged.push_back( U );
       }
-      d.ent = ( u.comp << 24 ) | u.ctu | ( u.hasCs ? 0x20000000u : 0 ) | ( u.waited ? 0x40000000u : 0 ) | ( all ? 0x80000000u : 0 );
-      d.i0 = itemBase[u.comp] + u.i0; d.i1 = itemBase[u.comp] + u.i1; d.iA = itemBase[u.comp] + u.iA;
-      d.bbox = (uint32_t) u.bb.y0 | ( (uint32_t) u.bb.y1 << 8 ) | ( (uint32_t) u.bb.c0 << 16 ) | ( (uint32_t) u.bb.c1 << 24 );
-      d.ndeps = (uint32_t) std::min<size_t>( u.deps.size(), VVR_INTRA_MAX_DEPS );
-      if( u.deps.size() > VVR_INTRA_MAX_DEPS ) { c->setError( "internal: intra unit with too many dependencies" ); return VVR_ERR_UNSPECIFIED; }
-      for( uint32_t k = 0; k < d.ndeps; k++ ) d.deps[k] = inv[u.deps[k]];
+      for( size_t m = 0; m < parts.size(); m++ )
+      {
+        UnitH& U = merged[newIndexOfGroup[m]];
+        for( uint32_t u : parts[m] ) for( uint32_t d : units[u].deps )
+        {
+          const uint32_t nd = newIndexOfGroup[target[d]];
+          if( nd != newIndexOfGroup[m] && std::find( U.deps.begin(), U.deps.end(), nd ) == U.deps.end() ) U.deps.push_back( nd );
+        }
+      }
+      for( int k = 0; k < ncomp; k++ ) intra[k].swap( newItems[k] );
+      units.swap( merged );
+      for( size_t u = 0; u < units.size(); u++ )
+        while( units[u].deps.size() > VVR_INTRA_MAX_DEPS )
+        {
+          UnitH j; j.comp = units[u].comp; j.ctu = units[u].ctu; j.i0 = j.i1 = j.iA = units[u].i0; j.bb.y0 = j.bb.y1 = 0; j.bb.c0 = j.bb.c1 = 1;
+          j.deps.assign( units[u].deps.end() - VVR_INTRA_MAX_DEPS, units[u].deps.end() );
+          units[u].deps.resize( units[u].deps.size() - VVR_INTRA_MAX_DEPS );
+          units[u].deps.push_back( (uint32_t) units.size() );
+          units.push_back( j );
+        }
+      for( auto& U : units ) U.rank = 0;
+      bool changed = true;
+      for( size_t pass = 0; changed && pass <= units.size(); pass++ )
+      {
+        changed = false;
+        for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
+      }
     }
-  }
-  if( getenv( "VVR_INTRA_STATS" ) )
-  {
-    size_t nIndep = 0, nBulk = 0, nItems = 0, nResiAdd = 0; int maxRank = 0; size_t perComp[3] = { 0, 0, 0 }, big = 0, maxBlocks = 0;
-    for( auto& u : units ) if( u.iA != u.i1 ) maxBlocks = std::max<size_t>( maxBlocks, u.i1 - u.i0 );
-    fprintf( stderr, "[vvr] largest serial unit: %zu blocks\n", maxBlocks );
-    for( auto& u : units ) { nIndep += u.deps.empty(); nBulk += u.iA == u.i1 && u.i1 > u.i0; maxRank = std::max( maxRank, u.rank ); perComp[u.comp]++; nItems += u.i1 - u.i0; if( u.iA == u.i1 ) nResiAdd += u.i1 - u.i0; big += ( u.i1 - u.i0 ) > 8; }
-    fprintf( stderr, "[vvr] POC %d: %zu intra units (Y %zu Cb %zu Cr %zu), %zu independent, %zu residual-add units, %zu blocks (%zu residual-add), %zu units > 8 blocks, longest chain %d\n",
-             h.poc, units.size(), perComp[0], perComp[1], perComp[2], nIndep, nBulk, nItems, nResiAdd, big, maxRank );
-  }
-  const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
-  bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
-  bytes[K_SAO] = samples * 4; bytes[K_ALF] = samples * 4; bytes[K_COPY] = samples * 4;
 
-  // ---- one device allocation for everything
-  struct Part { const void* src; size_t n; size_t off; };
-  std::vector<Part> parts;
-  size_t total = 0;
-  auto add = [&]( const void* src, size_t n ) { Part q{ src, n, total }; parts.push_back( q ); total += alignUp( std::max<size_t>( n, 16 ), 256 ); return (int) parts.size() - 1; };
-  const int iCu = add( p->cu, sizeof( vvr_cu ) * p->num_cu );
-  const int iTu = add( p->tu, sizeof( vvr_tu ) * p->num_tu );
-  const int iCoef = add( p->coef, sizeof( int16_t ) * (size_t) p->num_coef );
-  const int iMot = p->motion ? add( p->motion, sizeof( vvr_motion ) * (size_t) w4 * h4 ) : -1;
-  const int iL0 = add( p->lfp[0], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
-  const int iL1 = add( p->lfp[1], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
-  const int iSao = p->sao ? add( p->sao, sizeof( vvr_sao_ctu ) * numCtu ) : -1;
-  const int iAlf = p->alf ? add( p->alf, sizeof( vvr_alf_ctu ) * numCtu ) : -1;
-  const int iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
-  const bool lmcs = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
-  std::vector<uint8_t> interAtV;
-  if( lmcs )
+    return VVR_OK;
+  }
+
+  int emitUnitTable()
   {
-    interAtV.assign( (size_t) w4 * h4 + 8, 0 );
-    for( uint32_t i = 0; i < p->num_cu; i++ )
+    // one item array for the three components; ctuStart holds offsets into it; active (component, CTU) pairs in raster order
+    for( int k = 0; k < 3; k++ )
     {
-      const vvr_cu& cu = p->cu[i];
-      if( cu.pred_mode != VVR_PRED_INTER ) continue;
-      for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) interAtV[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = 1;
+      const uint32_t base = (uint32_t) intraAll.size();
+      intraAll.insert( intraAll.end(), intra[k].begin(), intra[k].end() );
+      for( int a = 0; a <= numCtu; a++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + a] += base;
     }
+    // device unit table: units that wait for nothing first (they can never block a resident workgroup slot), then the others in
+    // coding order; a unit only ever waits for units created before it, so every dependency holds a lower ticket
+    {
+      const uint32_t itemBase[3] = { ctuStartV[0], ctuStartV[(size_t) 1 * ( numCtu + 1 )], ctuStartV[(size_t) 2 * ( numCtu + 1 )] };
+      std::vector<uint32_t> perm, inv( units.size() );
+      // Long dependency chains (an intra picture: one CTU wavefront, ~60 levels): units that spin on their producers would hold most
+      // workgroup slots (and their LDS) of the device for milliseconds while other pictures are in flight.  Such a picture runs its
+      // intra stage as one launch per dependency level instead - units of one level never depend on each other, the launch boundary is
+      // the synchronisation, nothing waits inside a kernel.  Short chains (isolated intra blocks of B pictures) keep the single
+      // launch with flags, where a level barrier would cost more than the few waits.
+      int maxRank = 0;
+      for( auto& u : units ) maxRank = std::max( maxRank, u.rank );
+      static const int levelThr = getenv( "VVR_INTRA_LEVEL_THR" ) ? atoi( getenv( "VVR_INTRA_LEVEL_THR" ) ) : 1 << 30;     // measured: slower (9.2 vs 8.0 ms for a 4K I picture, 1457 vs 1508 frames/s), off by default
+      const bool byLevel = maxRank > levelThr;
+      std::vector<std::pair<int, int>> levels;
+      if( byLevel )
+      {
+        for( size_t t = 0; t < units.size(); t++ ) perm.push_back( (uint32_t) t );
+        std::stable_sort( perm.begin(), perm.end(), [&]( uint32_t a, uint32_t b ) { return units[a].rank < units[b].rank; } );
+        for( size_t t = 0; t < perm.size(); )
+        {
+          size_t e = t; while( e < perm.size() && units[perm[e]].rank == units[perm[t]].rank ) e++;
+          levels.emplace_back( (int) t, (int) ( e - t ) );
+          t = e;
+        }
+        for( auto& u : units ) u.deps.clear();                  // ordered by the launches
+      }
+      else
+      {
+      for( size_t t = 0; t < units.size(); t++ ) if( units[t].deps.empty() ) perm.push_back( (uint32_t) t );
+      {
+        // dependent units by depth of the dependency graph, then in WAVEFRONT order (key = ctuX + 2 * ctuY): every producer holds a
+        // lower ticket, and the workgroups that are resident at any time are the ones on or near the current front
+        std::vector<uint32_t> dep;
+        for( size_t t = 0; t < units.size(); t++ ) if( !units[t].deps.empty() ) dep.push_back( (uint32_t) t );
+        std::stable_sort( dep.begin(), dep.end(), [&]( uint32_t a, uint32_t b )
+        {
+          const int ka = (int) ( units[a].ctu % ctusX ) + 2 * (int) ( units[a].ctu / ctusX ), kb = (int) ( units[b].ctu % ctusX ) + 2 * (int) ( units[b].ctu / ctusX );
+          // by depth first (every producer is less deep, hence holds a lower ticket; units of one depth start together, so few of
+          // them find a producer that has not even started), then along the CTU wavefront.  Measured 7 % faster on B pictures than
+          // wavefront-major order (VVR_INTRA_KEY_MAJOR), the same on intra pictures where depth and wavefront coincide.
+          static const bool keyMajor = getenv( "VVR_INTRA_KEY_MAJOR" ) != nullptr;
+          if( !keyMajor ) return units[a].rank != units[b].rank ? units[a].rank < units[b].rank : ka < kb;
+          return ka != kb ? ka < kb : units[a].rank < units[b].rank;
+        } );
+        perm.insert( perm.end(), dep.begin(), dep.end() );
+      }
+      }
+      intraLevelsV = levels;
+      for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
+      for( auto& u : units ) for( uint32_t d : u.deps ) units[d].waited = true;
+      std::vector<uint32_t> unitCount( 3 * (size_t) numCtu, 0 );
+      for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
+      unitsDev.resize( units.size() );
+      for( size_t t = 0; t < perm.size(); t++ )
+      {
+        const UnitH& u = units[perm[t]];
+        IntraUnit& d = unitsDev[t]; memset( &d, 0, sizeof( d ) );
+        // bit 31: the unit is the whole (component, CTU) and every sample of the CTU is intra, so the kernel only stages the reference
+        // border and writes the CTU back with 16-byte stores
+        bool all = unitCount[(size_t) u.comp * numCtu + u.ctu] == 1;
+        {
+          const int ctu4 = 1 << ( h.log2_ctu - 2 ), ux = (int) ( u.ctu % ctusX ) * ctu4, uy = (int) ( u.ctu / ctusX ) * ctu4;
+          for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
+        }
+        d.ent = ( u.comp << 24 ) | u.ctu | ( u.hasCs ? 0x20000000u : 0 ) | ( u.waited ? 0x40000000u : 0 ) | ( all ? 0x80000000u : 0 );
+        d.i0 = itemBase[u.comp] + u.i0; d.i1 = itemBase[u.comp] + u.i1; d.iA = itemBase[u.comp] + u.iA;
+        d.bbox = (uint32_t) u.bb.y0 | ( (uint32_t) u.bb.y1 << 8 ) | ( (uint32_t) u.bb.c0 << 16 ) | ( (uint32_t) u.bb.c1 << 24 );
+        d.ndeps = (uint32_t) std::min<size_t>( u.deps.size(), VVR_INTRA_MAX_DEPS );
+        if( u.deps.size() > VVR_INTRA_MAX_DEPS ) { c->setError( "internal: intra unit with too many dependencies" ); return VVR_ERR_UNSPECIFIED; }
+        for( uint32_t k = 0; k < d.ndeps; k++ ) d.deps[k] = inv[u.deps[k]];
+      }
+    }
+    if( getenv( "VVR_INTRA_STATS" ) )
+    {
+      size_t nIndep = 0, nBulk = 0, nItems = 0, nResiAdd = 0; int maxRank = 0; size_t perComp[3] = { 0, 0, 0 }, big = 0, maxBlocks = 0;
+      for( auto& u : units ) if( u.iA != u.i1 ) maxBlocks = std::max<size_t>( maxBlocks, u.i1 - u.i0 );
+      fprintf( stderr, "[vvr] largest serial unit: %zu blocks\n", maxBlocks );
+      for( auto& u : units ) { nIndep += u.deps.empty(); nBulk += u.iA == u.i1 && u.i1 > u.i0; maxRank = std::max( maxRank, u.rank ); perComp[u.comp]++; nItems += u.i1 - u.i0; if( u.iA == u.i1 ) nResiAdd += u.i1 - u.i0; big += ( u.i1 - u.i0 ) > 8; }
+      fprintf( stderr, "[vvr] POC %d: %zu intra units (Y %zu Cb %zu Cr %zu), %zu independent, %zu residual-add units, %zu blocks (%zu residual-add), %zu units > 8 blocks, longest chain %d\n",
+               h.poc, units.size(), perComp[0], perComp[1], perComp[2], nIndep, nBulk, nItems, nResiAdd, big, maxRank );
+    }
+    return VVR_OK;
   }
-  const int iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
-  const int iSl = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? add( p->scaling, sizeof( vvr_scaling_list ) ) : -1;
-  const int iWp = ( ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2 ) ? add( p->wp, sizeof( vvr_wp_params ) ) : -1;
-  const int iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
-  const int iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
-  if( lmcs ) { bytes[K_LMCS] = ( samples / ( ncomp == 3 ? 1.5 : 1.0 ) ) * 4 * 2; }     // forward pass over the inter luma (upper bound) + inverse pass over all luma
-  const int iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
-  const int iMcB = add( mcBdof.data(), sizeof( McItem ) * mcBdof.size() );
-  const int iMcD = add( mcDmvr.data(), sizeof( McItem ) * mcDmvr.size() );
-  const int iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
-  const int iDmvrOut = add( nullptr, sizeof( int32_t ) * 2 * (size_t) numDmvr );
-  int iTb[3]; for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
-  const int iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
-  const int iCtuStart = add( ctuStartV.data(), sizeof( uint32_t ) * ctuStartV.size() );
-  const int iActive = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
 
-  vvr_prepared* q = new vvr_prepared();
-  q->hdr = h;
-  if( hipMalloc( &q->blob.p, total ) != hipSuccess ) { delete q; c->setError( "hipMalloc failed" ); return VVR_ERR_DEVICE; }
-  q->blob.n = total;
-  // stage through one pinned buffer -> a single H2D copy
-  char* staging = nullptr;
-  if( hipHostMalloc( (void**) &staging, total, hipHostMallocDefault ) != hipSuccess ) { hipFree( q->blob.p ); delete q; c->setError( "hipHostMalloc failed" ); return VVR_ERR_DEVICE; }
-  for( auto& pt : parts ) if( pt.n ) { if( pt.src ) memcpy( staging + pt.off, pt.src, pt.n ); else memset( staging + pt.off, 0, pt.n ); }
-  hipError_t e = hipMemcpy( q->blob.p, staging, total, hipMemcpyHostToDevice );
-  hipHostFree( staging );
-  if( e != hipSuccess ) { hipFree( q->blob.p ); delete q; c->setError( "H2D copy failed" ); return VVR_ERR_DEVICE; }
-  char* base = (char*) q->blob.p;
-  PicDev& d = q->pic; memset( &d, 0, sizeof( d ) );
-  d.hdr = h; d.w4 = w4; d.h4 = h4; d.ctus_x = ctusX; d.ctus_y = ctusY;
-  d.cu = (const vvr_cu*) ( base + parts[iCu].off ); d.tu = (const vvr_tu*) ( base + parts[iTu].off ); d.coef = (const int16_t*) ( base + parts[iCoef].off );
-  d.motion = iMot >= 0 ? (const vvr_motion*) ( base + parts[iMot].off ) : nullptr;
-  d.lfp[0] = (const vvr_lfp*) ( base + parts[iL0].off ); d.lfp[1] = (const vvr_lfp*) ( base + parts[iL1].off );
-  d.sao = iSao >= 0 ? (const vvr_sao_ctu*) ( base + parts[iSao].off ) : nullptr;
-  d.alf = iAlf >= 0 ? (const vvr_alf_ctu*) ( base + parts[iAlf].off ) : nullptr;
-  d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
-  d.lmcs = iLmcs >= 0 ? (const vvr_lmcs_params*) ( base + parts[iLmcs].off ) : nullptr;
-  d.scaling = iSl >= 0 ? (const vvr_scaling_list*) ( base + parts[iSl].off ) : nullptr;
-  d.wp = iWp >= 0 ? (const vvr_wp_params*) ( base + parts[iWp].off ) : nullptr;
-  d.interAt = iInterAt >= 0 ? (const uint8_t*) ( base + parts[iInterAt].off ) : nullptr;
-  d.csVpdu = iCsVpdu >= 0 ? (const uint32_t*) ( base + parts[iCsVpdu].off ) : nullptr; d.vpdusX = vpdusX; d.vpduLog2 = vpduLog2;
-  q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();
-  q->bdofItems = (McItem*) ( base + parts[iMcB].off ); q->numBdofItems = (int) mcBdof.size();
-  q->dmvrItems = (McItem*) ( base + parts[iMcD].off ); q->numDmvrItems = (int) mcDmvr.size();
-  q->affItems = (McItem*) ( base + parts[iMcA].off ); q->numAffItems = (int) mcAff.size();
-  q->dmvrOut = (int32_t*) ( base + parts[iDmvrOut].off ); q->numDmvr = numDmvr;
-  for( int k = 0; k < 3; k++ ) { q->tbItems[k] = (TbItem*) ( base + parts[iTb[k]].off ); q->numTb[k] = (int) tb[k].size(); }
-  q->intraItems = (IntraItem*) ( base + parts[iIntra].off ); q->numIntra = (int) intraAll.size();
-  q->ctuStart = (uint32_t*) ( base + parts[iCtuStart].off );
-  q->units = (IntraUnit*) ( base + parts[iActive].off ); q->numActive = (int) unitsDev.size();
-  q->intraLevels = intraLevelsV;
-  memcpy( q->bytes, bytes, sizeof( bytes ) );
-  *out = q;
-  return VVR_OK;
+  int upload( vvr_prepared** out )
+  {
+    const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
+    bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
+    bytes[K_SAO] = samples * 4; bytes[K_ALF] = samples * 4; bytes[K_COPY] = samples * 4;
+
+    // ---- one device allocation for everything
+    struct Part { const void* src; size_t n; size_t off; };
+    std::vector<Part> parts;
+    size_t total = 0;
+    auto add = [&]( const void* src, size_t n ) { Part q{ src, n, total }; parts.push_back( q ); total += alignUp( std::max<size_t>( n, 16 ), 256 ); return (int) parts.size() - 1; };
+    const int iCu = add( p->cu, sizeof( vvr_cu ) * p->num_cu );
+    const int iTu = add( p->tu, sizeof( vvr_tu ) * p->num_tu );
+    const int iCoef = add( p->coef, sizeof( int16_t ) * (size_t) p->num_coef );
+    const int iMot = p->motion ? add( p->motion, sizeof( vvr_motion ) * (size_t) w4 * h4 ) : -1;
+    const int iL0 = add( p->lfp[0], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+    const int iL1 = add( p->lfp[1], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+    const int iSao = p->sao ? add( p->sao, sizeof( vvr_sao_ctu ) * numCtu ) : -1;
+    const int iAlf = p->alf ? add( p->alf, sizeof( vvr_alf_ctu ) * numCtu ) : -1;
+    const int iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
+    const bool lmcs = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
+    std::vector<uint8_t> interAtV;
+    if( lmcs )
+    {
+      interAtV.assign( (size_t) w4 * h4 + 8, 0 );
+      for( uint32_t i = 0; i < p->num_cu; i++ )
+      {
+        const vvr_cu& cu = p->cu[i];
+        if( cu.pred_mode != VVR_PRED_INTER ) continue;
+        for( int y = cu.y; y < cu.y + cu.h; y += 4 ) for( int x = cu.x; x < cu.x + cu.w; x += 4 ) interAtV[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = 1;
+      }
+    }
+    const int iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
+    const int iSl = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? add( p->scaling, sizeof( vvr_scaling_list ) ) : -1;
+    const int iWp = ( ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2 ) ? add( p->wp, sizeof( vvr_wp_params ) ) : -1;
+    const int iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
+    const int iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
+    if( lmcs ) { bytes[K_LMCS] = ( samples / ( ncomp == 3 ? 1.5 : 1.0 ) ) * 4 * 2; }     // forward pass over the inter luma (upper bound) + inverse pass over all luma
+    const int iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
+    const int iMcB = add( mcBdof.data(), sizeof( McItem ) * mcBdof.size() );
+    const int iMcD = add( mcDmvr.data(), sizeof( McItem ) * mcDmvr.size() );
+    const int iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
+    const int iDmvrOut = add( nullptr, sizeof( int32_t ) * 2 * (size_t) numDmvr );
+    int iTb[3]; for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
+    const int iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
+    const int iCtuStart = add( ctuStartV.data(), sizeof( uint32_t ) * ctuStartV.size() );
+    const int iActive = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
+
+    vvr_prepared* q = new vvr_prepared();
+    q->hdr = h;
+    if( hipMalloc( &q->blob.p, total ) != hipSuccess ) { delete q; c->setError( "hipMalloc failed" ); return VVR_ERR_DEVICE; }
+    q->blob.n = total;
+    // stage through one pinned buffer -> a single H2D copy
+    char* staging = nullptr;
+    if( hipHostMalloc( (void**) &staging, total, hipHostMallocDefault ) != hipSuccess ) { hipFree( q->blob.p ); delete q; c->setError( "hipHostMalloc failed" ); return VVR_ERR_DEVICE; }
+    for( auto& pt : parts ) if( pt.n ) { if( pt.src ) memcpy( staging + pt.off, pt.src, pt.n ); else memset( staging + pt.off, 0, pt.n ); }
+    hipError_t e = hipMemcpy( q->blob.p, staging, total, hipMemcpyHostToDevice );
+    hipHostFree( staging );
+    if( e != hipSuccess ) { hipFree( q->blob.p ); delete q; c->setError( "H2D copy failed" ); return VVR_ERR_DEVICE; }
+    char* base = (char*) q->blob.p;
+    PicDev& d = q->pic; memset( &d, 0, sizeof( d ) );
+    d.hdr = h; d.w4 = w4; d.h4 = h4; d.ctus_x = ctusX; d.ctus_y = ctusY;
+    d.cu = (const vvr_cu*) ( base + parts[iCu].off ); d.tu = (const vvr_tu*) ( base + parts[iTu].off ); d.coef = (const int16_t*) ( base + parts[iCoef].off );
+    d.motion = iMot >= 0 ? (const vvr_motion*) ( base + parts[iMot].off ) : nullptr;
+    d.lfp[0] = (const vvr_lfp*) ( base + parts[iL0].off ); d.lfp[1] = (const vvr_lfp*) ( base + parts[iL1].off );
+    d.sao = iSao >= 0 ? (const vvr_sao_ctu*) ( base + parts[iSao].off ) : nullptr;
+    d.alf = iAlf >= 0 ? (const vvr_alf_ctu*) ( base + parts[iAlf].off ) : nullptr;
+    d.alf_params = iAlfP >= 0 ? (const vvr_alf_params*) ( base + parts[iAlfP].off ) : nullptr;
+    d.lmcs = iLmcs >= 0 ? (const vvr_lmcs_params*) ( base + parts[iLmcs].off ) : nullptr;
+    d.scaling = iSl >= 0 ? (const vvr_scaling_list*) ( base + parts[iSl].off ) : nullptr;
+    d.wp = iWp >= 0 ? (const vvr_wp_params*) ( base + parts[iWp].off ) : nullptr;
+    d.interAt = iInterAt >= 0 ? (const uint8_t*) ( base + parts[iInterAt].off ) : nullptr;
+    d.csVpdu = iCsVpdu >= 0 ? (const uint32_t*) ( base + parts[iCsVpdu].off ) : nullptr; d.vpdusX = vpdusX; d.vpduLog2 = vpduLog2;
+    q->mcItems = (McItem*) ( base + parts[iMc].off ); q->numMc = (int) mc.size();
+    q->bdofItems = (McItem*) ( base + parts[iMcB].off ); q->numBdofItems = (int) mcBdof.size();
+    q->dmvrItems = (McItem*) ( base + parts[iMcD].off ); q->numDmvrItems = (int) mcDmvr.size();
+    q->affItems = (McItem*) ( base + parts[iMcA].off ); q->numAffItems = (int) mcAff.size();
+    q->dmvrOut = (int32_t*) ( base + parts[iDmvrOut].off ); q->numDmvr = numDmvr;
+    for( int k = 0; k < 3; k++ ) { q->tbItems[k] = (TbItem*) ( base + parts[iTb[k]].off ); q->numTb[k] = (int) tb[k].size(); }
+    q->intraItems = (IntraItem*) ( base + parts[iIntra].off ); q->numIntra = (int) intraAll.size();
+    q->ctuStart = (uint32_t*) ( base + parts[iCtuStart].off );
+    q->units = (IntraUnit*) ( base + parts[iActive].off ); q->numActive = (int) unitsDev.size();
+    q->intraLevels = intraLevelsV;
+    memcpy( q->bytes, bytes, sizeof( bytes ) );
+    *out = q;
+    return VVR_OK;
+  }
+};
+}   // namespace
+
+VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** out )
+{
+  if( !c || !p || !out ) return VVR_ERR_PARAMETER;
+  if( p->resident ) { c->setError( "vvr_prepare needs host arrays" ); return VVR_ERR_PARAMETER; }
+  int rc = validate( c, p );
+  if( rc != VVR_OK ) return rc;
+  hipSetDevice( c->device );
+  PicturePreparer P( c, p );
+  if( ( rc = P.mapDecodingOrder() ) != VVR_OK || ( rc = P.buildWorkLists() ) != VVR_OK || ( rc = P.formUnits() ) != VVR_OK || ( rc = P.groupUnits() ) != VVR_OK
+   || ( rc = P.emitUnitTable() ) != VVR_OK ) return rc;
+  return P.upload( out );
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -70,6 +70,14 @@ def set_refs(p, l0, l1=()):
             p.ref_poc[l][i] = poc
 
 
+def _compact(a, n):
+    """the first n records as an array of their own, copied byte by byte (a field-wise copy would leave the padding bytes of the
+    records uninitialised, and descriptions should be reproducible down to the byte)"""
+    out = np.zeros(n, a.dtype)
+    out.view(np.uint8)[:] = a[:n].view(np.uint8)
+    return out
+
+
 def generate(p):
     """Run the generator; returns a desc.PictureDesc owning compact copies of all arrays."""
     L = lib()
@@ -104,8 +112,8 @@ def generate(p):
     if rc != 0:
         raise RuntimeError("vvs_generate failed (%d)" % rc)
     d.hdr = abi.PicHeader.from_buffer_copy(b.hdr)
-    d.cu = cu[:b.num_cu].copy()
-    d.tu = tu[:b.num_tu].copy()
+    d.cu = _compact(cu, b.num_cu)
+    d.tu = _compact(tu, b.num_tu)
     d.coef = coef[:max(1, b.num_coef)].copy()
     d.num_dmvr = b.num_dmvr
     return d
