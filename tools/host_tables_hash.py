@@ -1,3 +1,6 @@
+"""developer helper: md5 of everything vvr_prepare uploads (work lists, unit tables, description arrays) for a corpus of generated
+pictures, through the stand-in HIP runtime of tests/hoststub.  Usage: tools/host_tables_hash.py out.json -- run before and after a
+host-side restructuring and compare the two files."""
 import sys, hashlib, ctypes as C, json
 sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
 import numpy as np
