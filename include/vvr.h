@@ -340,6 +340,11 @@ VVR_API int          vvr_plane_layout(const vvr_context* ctx, int comp, size_t* 
 VVR_API void*        vvr_plane_ptr(vvr_context* ctx, int slot, int comp);
 /* vvdecFrame-style export (vvdecimpl.cpp:957 xAddPicture): copies plane `comp` of `slot` into a host buffer of 16-bit samples */
 VVR_API int          vvr_read_plane(vvr_context* ctx, int slot, int comp, uint16_t* dst, size_t dst_stride_samples);
+/* output of one plane the way the reference hands frames to the application (VVDecImpl::copyComp, vvdecimpl.cpp:818-880, called with the
+ * conformance window applied): the window (x, y, w, h in samples of the component) is copied to dst with dst_stride_bytes between rows;
+ * bytes_per_sample 2 = 16-bit samples, 1 = the low byte of every sample (8-bit streams; "only narrowing conversions", :853).  Waits for
+ * all work on the slot. */
+VVR_API int          vvr_read_output(vvr_context* ctx, int slot, int comp, int x, int y, int w, int h, int bytes_per_sample, void* dst, size_t dst_stride_bytes);
 /* upload a reference picture produced elsewhere (another GPU / a test) into a slot */
 VVR_API int          vvr_write_plane(vvr_context* ctx, int slot, int comp, const uint16_t* src, size_t src_stride_samples);
 /* DMVR refined delta MVs of job (TaskFinishMotionInfo, DecCu.cpp:161): copies num_entries * 2 int32 */

@@ -390,3 +390,30 @@ def test_pictures_in_flight_are_ordered_by_their_slots(stub, lanes, frames, gop,
     for j in jobs:
         stub.vvr_free_prepared(ctx.ctx, j[3])
     ctx.close()
+
+
+def test_output_window_and_8bit_frames(stub):
+    """vvr_read_output: conformance-window crop and the narrowing to 8-bit frames (VVDecImpl::copyComp), on planes written through the ABI"""
+    W, H = 64, 48
+    stub.vvr_read_output.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_size_t]
+    stub.vvr_write_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(3)
+    for bd in (8, 10):
+        ctx = Ctx(stub, W, H, 2, log2_ctu=5, bit_depth=bd)
+        planes = [rng.integers(0, 1 << bd, (H >> s, W >> s)).astype(np.uint16) for s in (0, 1, 1)]
+        for c, pl in enumerate(planes):
+            assert stub.vvr_write_plane(ctx.ctx, 1, c, pl.ctypes.data, pl.shape[1]) == abi.VVR_OK
+        x, y, w, h = 8, 4, 40, 36
+        for c, pl in enumerate(planes):
+            s = 1 if c else 0
+            out = np.zeros((h >> s, (w >> s) + 5), np.uint16)                       # row pitch larger than the window
+            assert stub.vvr_read_output(ctx.ctx, 1, c, x >> s, y >> s, w >> s, h >> s, 2, out.ctypes.data, out.strides[0]) == abi.VVR_OK
+            assert np.array_equal(out[:, :w >> s], pl[y >> s:(y + h) >> s, x >> s:(x + w) >> s]) and not out[:, w >> s:].any()
+            out8 = np.zeros((h >> s, w >> s), np.uint8)
+            rc = stub.vvr_read_output(ctx.ctx, 1, c, x >> s, y >> s, w >> s, h >> s, 1, out8.ctypes.data, out8.strides[0])
+            if bd == 8:
+                assert rc == abi.VVR_OK and np.array_equal(out8, pl[y >> s:(y + h) >> s, x >> s:(x + w) >> s].astype(np.uint8))
+            else:
+                assert rc == abi.VVR_ERR_PARAMETER                                   # only 8-bit content is narrowed
+        assert stub.vvr_read_output(ctx.ctx, 1, 0, 32, 0, 40, 8, 2, out.ctypes.data, 256) == abi.VVR_ERR_PARAMETER      # window leaves the plane
+        ctx.close()

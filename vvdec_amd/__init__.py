@@ -63,6 +63,8 @@ def lib():
         L.vvr_free_prepared.argtypes = [C.c_void_p, C.c_void_p]
         L.vvr_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.vvr_write_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.vvr_read_output.restype = C.c_int
+        L.vvr_read_output.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_size_t]
         L.vvr_read_dmvr.restype = C.c_int
         L.vvr_read_dmvr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.vvr_enable_stats.argtypes = [C.c_void_p, C.c_int]
@@ -73,7 +75,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
-                    "vvr_plane_ptr", "vvr_read_plane", "vvr_write_plane", "vvr_read_dmvr", "vvr_prepare", "vvr_submit_prepared",
+                    "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_write_plane", "vvr_read_dmvr", "vvr_prepare", "vvr_submit_prepared",
                     "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof"]
 
 
@@ -154,6 +156,17 @@ class Reconstructor:
         for c in range(3 if self.chroma_format else 1):
             a = np.zeros(self.plane_shape(c), np.uint16)
             self._check(self.L.vvr_read_plane(self.ctx, slot, c, a.ctypes.data, a.shape[1]))
+            out.append(a)
+        return out
+
+    def read_output(self, slot, window=None, bytes_per_sample=2):
+        """the picture as the application gets it: conformance window (x, y, w, h in luma samples, even) applied, 8- or 16-bit samples"""
+        x, y, w, h = window or (0, 0, self.width, self.height)
+        out = []
+        for c in range(3 if self.chroma_format else 1):
+            s = 1 if c else 0
+            a = np.zeros((h >> s, w >> s), np.uint8 if bytes_per_sample == 1 else np.uint16)
+            self._check(self.L.vvr_read_output(self.ctx, slot, c, x >> s, y >> s, w >> s, h >> s, bytes_per_sample, a.ctypes.data, a.strides[0]))
             out.append(a)
         return out
 

@@ -210,6 +210,28 @@ VVR_API int vvr_read_plane( vvr_context* c, int slot, int comp, uint16_t* dst, s
   return VVR_OK;
 }
 
+VVR_API int vvr_read_output( vvr_context* c, int slot, int comp, int x, int y, int w, int h, int bytesPerSample, void* dst, size_t dstStrideBytes )
+{
+  if( !c || slot < 0 || slot >= (int) c->slots.size() || comp < 0 || comp > 2 || !c->slots[slot].p[comp] || !dst ) return VVR_ERR_PARAMETER;
+  const DevPlanes& d = c->slots[slot];
+  if( x < 0 || y < 0 || w <= 0 || h <= 0 || x + w > d.w[comp] || y + h > d.h[comp] || ( bytesPerSample != 1 && bytesPerSample != 2 ) || dstStrideBytes < (size_t) w * bytesPerSample )
+  { c->setError( "vvr_read_output: window outside the plane, bad sample size or stride" ); return VVR_ERR_PARAMETER; }
+  if( bytesPerSample == 1 && c->cfg.bit_depth > 8 ) { c->setError( "vvr_read_output: 8-bit output of a stream with more than 8 bits per sample (only narrowing of 8-bit content, vvdecimpl.cpp:853)" ); return VVR_ERR_PARAMETER; }
+  hipSetDevice( c->device );
+  vvr_sync( c );
+  const pel_t* src = d.p[comp] + (size_t) y * d.stride[comp] + x;
+  if( bytesPerSample == 2 )
+  {
+    HIPCHK( c, hipMemcpy2D( dst, dstStrideBytes, src, (size_t) d.stride[comp] * 2, (size_t) w * 2, h, hipMemcpyDeviceToHost ) );
+    return VVR_OK;
+  }
+  // 8-bit frames: the window comes over as 16-bit samples, the low bytes are packed on the host (what copyComp does with its SSE loop)
+  std::vector<uint16_t> tmp( (size_t) w * h );
+  HIPCHK( c, hipMemcpy2D( tmp.data(), (size_t) w * 2, src, (size_t) d.stride[comp] * 2, (size_t) w * 2, h, hipMemcpyDeviceToHost ) );
+  for( int r = 0; r < h; r++ ) { uint8_t* o = (uint8_t*) dst + (size_t) r * dstStrideBytes; const uint16_t* in = tmp.data() + (size_t) r * w; for( int k = 0; k < w; k++ ) o[k] = (uint8_t) in[k]; }
+  return VVR_OK;
+}
+
 VVR_API int vvr_write_plane( vvr_context* c, int slot, int comp, const uint16_t* src, size_t srcStride )
 {
   if( !c || slot < 0 || slot >= (int) c->slots.size() || comp < 0 || comp > 2 || !c->slots[slot].p[comp] ) return VVR_ERR_PARAMETER;
