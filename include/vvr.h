@@ -345,6 +345,12 @@ VVR_API int          vvr_read_plane(vvr_context* ctx, int slot, int comp, uint16
  * bytes_per_sample 2 = 16-bit samples, 1 = the low byte of every sample (8-bit streams; "only narrowing conversions", :853).  Waits for
  * all work on the slot. */
 VVR_API int          vvr_read_output(vvr_context* ctx, int slot, int comp, int x, int y, int w, int h, int bytes_per_sample, void* dst, size_t dst_stride_bytes);
+/* decoded picture hash of a slot, as the decoded-picture-hash SEI defines it and the reference checks it (calcMD5 / calcCRC / calcChecksum,
+ * PicYuvMD5.cpp:99-221): one digest per component over the whole plane in raster order, samples as 1 byte (bit depth 8) or 2 bytes little
+ * endian.  digest receives num_components x digest_len bytes (MD5 16, CRC 2, checksum 4), *digest_len the length of one.  The planes are
+ * copied to the host and hashed there, like the reference does (MD5 is a serial chain over the plane). */
+enum { VVR_HASH_MD5 = 0, VVR_HASH_CRC = 1, VVR_HASH_CHECKSUM = 2 };
+VVR_API int          vvr_picture_hash(vvr_context* ctx, int slot, int method, uint8_t* digest, int* digest_len);
 /* upload a reference picture produced elsewhere (another GPU / a test) into a slot */
 VVR_API int          vvr_write_plane(vvr_context* ctx, int slot, int comp, const uint16_t* src, size_t src_stride_samples);
 /* DMVR refined delta MVs of job (TaskFinishMotionInfo, DecCu.cpp:161): copies num_entries * 2 int32 */

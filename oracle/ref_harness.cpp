@@ -60,6 +60,13 @@
 #undef private
 #undef protected
 
+#include "CommonLib/SEI_internal.h"
+namespace vvdec   // (defined in CommonLib/PicYuvMD5.cpp, declared in no header)
+{
+uint32_t calcMD5( const CPelUnitBuf& pic, PictureHash& digest, const BitDepths& bitDepths );
+uint32_t calcCRC( const CPelUnitBuf& pic, PictureHash& digest, const BitDepths& bitDepths );
+uint32_t calcChecksum( const CPelUnitBuf& pic, PictureHash& digest, const BitDepths& bitDepths );
+}
 #include "../include/vvr.h"
 #include "../integration/vvr_extract.h"      // the reference-side glue under test (round trip, see vvref_extract below)
 
@@ -715,6 +722,26 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     g_err = e.what();
     return -1;
   }
+}
+
+// decoded picture hash by the reference's own functions (PicYuvMD5.cpp): planes tightly packed, digest = per-component digests back to back
+__attribute__((visibility("default")))
+int vvref_picture_hash( const uint16_t* const* planes, int W, int Hh, int chroma_format, int bit_depth, int method, uint8_t* digest )
+{
+  try
+  {
+    const ChromaFormat cf = chroma_format == 0 ? CHROMA_400 : CHROMA_420;
+    PelStorage st; st.create( cf, Area( 0, 0, W, Hh ) );
+    const int nc = cf == CHROMA_400 ? 1 : 3;
+    for( int c = 0; c < nc; c++ ) fillPlane( st.bufs[c], planes[c], c ? W >> 1 : W, c ? Hh >> 1 : Hh );
+    BitDepths bds; bds.recon = bit_depth;
+    PictureHash h;
+    const CPelUnitBuf buf = st;
+    const uint32_t len = method == 0 ? calcMD5( buf, h, bds ) : method == 1 ? calcCRC( buf, h, bds ) : calcChecksum( buf, h, bds );
+    for( size_t i = 0; i < h.hash.size(); i++ ) digest[i] = h.hash[i];
+    return (int) len;
+  }
+  catch( std::exception& e ) { g_err = e.what(); return -1; }
 }
 
 // description -> the reference's objects -> description (integration/vvr_extract.h).  The result stays valid until the next call.

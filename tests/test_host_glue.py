@@ -417,3 +417,36 @@ def test_output_window_and_8bit_frames(stub):
                 assert rc == abi.VVR_ERR_PARAMETER                                   # only 8-bit content is narrowed
         assert stub.vvr_read_output(ctx.ctx, 1, 0, 32, 0, 40, 8, 2, out.ctypes.data, 256) == abi.VVR_ERR_PARAMETER      # window leaves the plane
         ctx.close()
+
+
+@pytest.mark.parametrize("bd,cf", [(10, 1), (8, 1), (10, 0)])
+def test_decoded_picture_hash(stub, bd, cf):
+    """vvr_picture_hash (MD5 / CRC / checksum of the decoded-picture-hash SEI) against the reference's own functions (PicYuvMD5.cpp) and,
+    for MD5, Python's hashlib, on planes written through the ABI"""
+    import hashlib
+    import refdrv
+    W, H = 136, 72                                          # not a multiple of the 32-sample blocks the reference feeds MD5 with
+    stub.vvr_write_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    stub.vvr_picture_hash.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(bd * 10 + cf)
+    ctx = Ctx(stub, W, H, 2, log2_ctu=5, bit_depth=bd, chroma_format=cf)
+    planes = [rng.integers(0, 1 << bd, (H >> s, W >> s)).astype(np.uint16) for s in ((0, 1, 1) if cf else (0,))]
+    for c, pl in enumerate(planes):
+        assert stub.vvr_write_plane(ctx.ctx, 1, c, pl.ctypes.data, pl.shape[1]) == abi.VVR_OK
+    for method, length in ((0, 16), (1, 2), (2, 4)):
+        buf = (C.c_uint8 * 48)()
+        n = C.c_int()
+        assert stub.vvr_picture_hash(ctx.ctx, 1, method, buf, C.byref(n)) == abi.VVR_OK and n.value == length
+        got = bytes(buf[:length * len(planes)])
+        if method == 0:
+            want = b"".join(hashlib.md5(pl.astype(np.uint8 if bd == 8 else "<u2").tobytes()).digest() for pl in planes)
+            assert got == want
+        if refdrv.available():
+            L = refdrv.lib()
+            ptrs = (C.POINTER(C.c_uint16) * 3)()
+            for c, pl in enumerate(planes):
+                ptrs[c] = pl.ctypes.data_as(C.POINTER(C.c_uint16))
+            ref = (C.c_uint8 * 48)()
+            assert L.vvref_picture_hash(ptrs, W, H, cf, bd, method, ref) == length
+            assert got == bytes(ref[:length * len(planes)]), "method %d differs from the reference" % method
+    ctx.close()

@@ -63,6 +63,8 @@ def lib():
         L.vvr_free_prepared.argtypes = [C.c_void_p, C.c_void_p]
         L.vvr_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.vvr_write_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.vvr_picture_hash.restype = C.c_int
+        L.vvr_picture_hash.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.vvr_read_output.restype = C.c_int
         L.vvr_read_output.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_size_t]
         L.vvr_read_dmvr.restype = C.c_int
@@ -75,7 +77,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
-                    "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_write_plane", "vvr_read_dmvr", "vvr_prepare", "vvr_submit_prepared",
+                    "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_picture_hash", "vvr_write_plane", "vvr_read_dmvr", "vvr_prepare", "vvr_submit_prepared",
                     "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof"]
 
 
@@ -158,6 +160,13 @@ class Reconstructor:
             self._check(self.L.vvr_read_plane(self.ctx, slot, c, a.ctypes.data, a.shape[1]))
             out.append(a)
         return out
+
+    def picture_hash(self, slot, method=0):
+        """decoded picture hash (0 MD5, 1 CRC, 2 checksum): list of per-component digests (bytes)"""
+        buf = (C.c_uint8 * 48)()
+        n = C.c_int()
+        self._check(self.L.vvr_picture_hash(self.ctx, slot, method, buf, C.byref(n)))
+        return [bytes(buf[k * n.value:(k + 1) * n.value]) for k in range(3 if self.chroma_format else 1)]
 
     def read_output(self, slot, window=None, bytes_per_sample=2):
         """the picture as the application gets it: conformance window (x, y, w, h in luma samples, even) applied, 8- or 16-bit samples"""

@@ -232,6 +232,99 @@ VVR_API int vvr_read_output( vvr_context* c, int slot, int comp, int x, int y, i
   return VVR_OK;
 }
 
+// ---- decoded picture hash (SEI decoded_picture_hash; reference: PicYuvMD5.cpp).  MD5 after RFC 1321.
+namespace {
+struct Md5
+{
+  uint32_t a = 0x67452301u, b = 0xefcdab89u, c = 0x98badcfeu, d = 0x10325476u; uint64_t len = 0; uint8_t buf[64]; size_t fill = 0;
+  static uint32_t rol( uint32_t v, int s ) { return ( v << s ) | ( v >> ( 32 - s ) ); }
+  void block( const uint8_t* p )
+  {
+    static const uint32_t K[64] = {
+      0xd76aa478,0xe8c7b756,0x242070db,0xc1bdceee,0xf57c0faf,0x4787c62a,0xa8304613,0xfd469501,0x698098d8,0x8b44f7af,0xffff5bb1,0x895cd7be,0x6b901122,0xfd987193,0xa679438e,0x49b40821,
+      0xf61e2562,0xc040b340,0x265e5a51,0xe9b6c7aa,0xd62f105d,0x02441453,0xd8a1e681,0xe7d3fbc8,0x21e1cde6,0xc33707d6,0xf4d50d87,0x455a14ed,0xa9e3e905,0xfcefa3f8,0x676f02d9,0x8d2a4c8a,
+      0xfffa3942,0x8771f681,0x6d9d6122,0xfde5380c,0xa4beea44,0x4bdecfa9,0xf6bb4b60,0xbebfbc70,0x289b7ec6,0xeaa127fa,0xd4ef3085,0x04881d05,0xd9d4d039,0xe6db99e5,0x1fa27cf8,0xc4ac5665,
+      0xf4292244,0x432aff97,0xab9423a7,0xfc93a039,0x655b59c3,0x8f0ccc92,0xffeff47d,0x85845dd1,0x6fa87e4f,0xfe2ce6e0,0xa3014314,0x4e0811a1,0xf7537e82,0xbd3af235,0x2ad7d2bb,0xeb86d391 };
+    static const int S[64] = { 7,12,17,22,7,12,17,22,7,12,17,22,7,12,17,22, 5,9,14,20,5,9,14,20,5,9,14,20,5,9,14,20, 4,11,16,23,4,11,16,23,4,11,16,23,4,11,16,23, 6,10,15,21,6,10,15,21,6,10,15,21,6,10,15,21 };
+    uint32_t m[16]; for( int i = 0; i < 16; i++ ) m[i] = (uint32_t) p[4 * i] | ( (uint32_t) p[4 * i + 1] << 8 ) | ( (uint32_t) p[4 * i + 2] << 16 ) | ( (uint32_t) p[4 * i + 3] << 24 );
+    uint32_t A = a, B = b, C = c, D = d;
+    for( int i = 0; i < 64; i++ )
+    {
+      uint32_t f; int g;
+      if( i < 16 ) { f = ( B & C ) | ( ~B & D ); g = i; } else if( i < 32 ) { f = ( D & B ) | ( ~D & C ); g = ( 5 * i + 1 ) & 15; }
+      else if( i < 48 ) { f = B ^ C ^ D; g = ( 3 * i + 5 ) & 15; } else { f = C ^ ( B | ~D ); g = ( 7 * i ) & 15; }
+      const uint32_t t = D; D = C; C = B; B = B + rol( A + f + K[i] + m[g], S[i] ); A = t;
+    }
+    a += A; b += B; c += C; d += D;
+  }
+  void update( const uint8_t* p, size_t n )
+  {
+    len += n;
+    while( n ) { const size_t k = std::min( n, 64 - fill ); memcpy( buf + fill, p, k ); fill += k; p += k; n -= k; if( fill == 64 ) { block( buf ); fill = 0; } }
+  }
+  void finish( uint8_t out[16] )
+  {
+    const uint64_t bits = len * 8; const uint8_t one = 0x80, zero = 0;
+    update( &one, 1 ); while( fill != 56 ) update( &zero, 1 );
+    uint8_t l[8]; for( int i = 0; i < 8; i++ ) l[i] = (uint8_t) ( bits >> ( 8 * i ) );
+    update( l, 8 );
+    const uint32_t v[4] = { a, b, c, d }; for( int i = 0; i < 16; i++ ) out[i] = (uint8_t) ( v[i >> 2] >> ( 8 * ( i & 3 ) ) );
+  }
+};
+}
+
+VVR_API int vvr_picture_hash( vvr_context* c, int slot, int method, uint8_t* digest, int* digestLen )
+{
+  if( !c || slot < 0 || slot >= (int) c->slots.size() || !digest || method < VVR_HASH_MD5 || method > VVR_HASH_CHECKSUM ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  vvr_sync( c );
+  const DevPlanes& d = c->slots[slot];
+  const int nc = c->cfg.chroma_format ? 3 : 1, len = method == VVR_HASH_MD5 ? 16 : method == VVR_HASH_CRC ? 2 : 4;
+  const bool two = c->cfg.bit_depth > 8;
+  std::vector<uint16_t> pl;
+  for( int k = 0; k < nc; k++ )
+  {
+    const int w = d.w[k], h = d.h[k];
+    pl.resize( (size_t) w * h );
+    HIPCHK( c, hipMemcpy2D( pl.data(), (size_t) w * 2, d.p[k], (size_t) d.stride[k] * 2, (size_t) w * 2, h, hipMemcpyDeviceToHost ) );
+    uint8_t* out = digest + (size_t) k * len;
+    if( method == VVR_HASH_MD5 )
+    {
+      Md5 m; std::vector<uint8_t> row( (size_t) w * 2 );
+      for( int y = 0; y < h; y++ )
+      {
+        const uint16_t* s = pl.data() + (size_t) y * w; size_t n = 0;
+        for( int x = 0; x < w; x++ ) { row[n++] = (uint8_t) s[x]; if( two ) row[n++] = (uint8_t) ( s[x] >> 8 ); }
+        m.update( row.data(), n );
+      }
+      m.finish( out );
+    }
+    else if( method == VVR_HASH_CRC )
+    {
+      // CRC-16 with polynomial 0x1021 over the bytes of every sample (low byte first), most significant bit first, 16 zero bits appended (:99-137)
+      uint32_t crc = 0xffff;
+      auto feed = [&]( uint32_t byte ) { for( int bit = 7; bit >= 0; bit-- ) { const uint32_t msb = ( crc >> 15 ) & 1; crc = ( ( ( crc << 1 ) + ( ( byte >> bit ) & 1 ) ) & 0xffff ) ^ ( msb * 0x1021 ); } };
+      for( size_t i = 0; i < pl.size(); i++ ) { feed( pl[i] & 0xff ); if( two ) feed( pl[i] >> 8 ); }
+      for( int bit = 0; bit < 16; bit++ ) { const uint32_t msb = ( crc >> 15 ) & 1; crc = ( ( crc << 1 ) & 0xffff ) ^ ( msb * 0x1021 ); }
+      out[0] = (uint8_t) ( crc >> 8 ); out[1] = (uint8_t) crc;
+    }
+    else
+    {
+      // 32-bit sum of the sample bytes, each xor-ed with a mask of its position (:152-181)
+      uint32_t sum = 0;
+      for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+      {
+        const uint32_t mask = ( x & 0xff ) ^ ( y & 0xff ) ^ ( x >> 8 ) ^ ( y >> 8 ), v = pl[(size_t) y * w + x];
+        sum += ( ( v & 0xff ) ^ mask ) & 0xff;
+        if( two ) sum += ( ( v >> 8 ) ^ mask ) & 0xffffffffu;
+      }
+      out[0] = (uint8_t) ( sum >> 24 ); out[1] = (uint8_t) ( sum >> 16 ); out[2] = (uint8_t) ( sum >> 8 ); out[3] = (uint8_t) sum;
+    }
+  }
+  if( digestLen ) *digestLen = len;
+  return VVR_OK;
+}
+
 VVR_API int vvr_write_plane( vvr_context* c, int slot, int comp, const uint16_t* src, size_t srcStride )
 {
   if( !c || slot < 0 || slot >= (int) c->slots.size() || comp < 0 || comp > 2 || !c->slots[slot].p[comp] ) return VVR_ERR_PARAMETER;
