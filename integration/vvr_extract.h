@@ -34,6 +34,7 @@ struct Extracted
   vvr_wp_params             wp;
   vvr_scaling_list          scaling;
   uint32_t                  numDmvr = 0;
+  std::vector<std::pair<CodingUnit*, uint32_t>> dmvrCus;   // CUs that run DMVR with their offset into the delta-MV output (vvr_read_dmvr)
 };
 
 // branch of InterPrediction::motionCompensation (InterPrediction.cpp:1372-1459) for one CU
@@ -120,7 +121,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   h.min_qp_ts = (int8_t) ( 4 + 6 * sps.getInternalMinusInputBitDepth() );
 
   // ---- coding units, transform units, levels
-  E.cu.clear(); E.tu.clear(); E.coef.clear(); E.ctuFirstCu.assign( numCtu + 1, 0 ); E.numDmvr = 0;
+  E.cu.clear(); E.tu.clear(); E.coef.clear(); E.ctuFirstCu.assign( numCtu + 1, 0 ); E.numDmvr = 0; E.dmvrCus.clear();
   PelUnitBuf reco = cs.getRecoBuf();
   auto isIntraAt = [&]( const CodingUnit& cur, const Position& p ) { const CodingUnit* n = cs.getCURestricted( p, cur, CHANNEL_TYPE_LUMA ); return n && CU::isIntra( *n ); };
   for( int a = 0; a < numCtu; a++ )
@@ -178,7 +179,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
           c.ciip_neigh_intra = (uint8_t) ( ( isIntraAt( cu, posBL.offset( -1, 0 ) ) ? 1 : 0 ) | ( isIntraAt( cu, posTR.offset( 0, -1 ) ) ? 2 : 0 ) );
         }
         c.mc_mode = resolveMcMode( cu );
-        if( c.mc_mode == VVR_MC_DMVR || c.mc_mode == VVR_MC_DMVR_BDOF ) { c.dmvr_off = E.numDmvr; E.numDmvr += ( ( la.width + 15 ) / 16 ) * ( ( la.height + 15 ) / 16 ); }
+        if( c.mc_mode == VVR_MC_DMVR || c.mc_mode == VVR_MC_DMVR_BDOF ) { c.dmvr_off = E.numDmvr; E.dmvrCus.emplace_back( &cu, E.numDmvr ); E.numDmvr += ( ( la.width + 15 ) / 16 ) * ( ( la.height + 15 ) / 16 ); }
       }
       c.first_tu = (uint32_t) E.tu.size();
       const uint32_t cuIdx = (uint32_t) E.cu.size();

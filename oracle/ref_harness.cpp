@@ -69,6 +69,7 @@ uint32_t calcChecksum( const CPelUnitBuf& pic, PictureHash& digest, const BitDep
 }
 #include "../include/vvr.h"
 #include "../integration/vvr_extract.h"      // the reference-side glue under test (round trip, see vvref_extract below)
+#include "../integration/DecLibReconAmd.h"   // compiled only: keeps the binding of INTEGRATION.md in step with both sides
 
 using namespace vvdec;
 
@@ -723,6 +724,9 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     return -1;
   }
 }
+
+// (forces the compiler to check the member functions of the binding; never called)
+__attribute__((unused)) static void vvref_compile_check_binding( vvr_glue::DecLibReconAmd* b, Picture* pic ) { b->decompressPicture( pic ); b->waitForPrevDecompressedPic(); }
 
 // decoded picture hash by the reference's own functions (PicYuvMD5.cpp): planes tightly packed, digest = per-component digests back to back
 __attribute__((visibility("default")))
