@@ -221,3 +221,13 @@ def test_edge_parameters_match_reference_derivation(built):
     a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
     b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_oracle_equals_reference_random_sweep(built):
+    """a fixed-seed slice of tools/fuzz_oracle_vs_ref.py: random tool combinations, sizes, CTU sizes, sample formats and stages"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_oracle_vs_ref", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_oracle_vs_ref.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    n, bad = fz.sweep(2026, cases=250)
+    assert n == 250 and bad == 0

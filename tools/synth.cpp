@@ -290,7 +290,8 @@ struct Gen {
     cu.qp = (int8_t) std::min( 63, std::max( 0, P.base_qp + (int) rng.u( 7 ) - 3 ) );
     cu.bcw_idx = 2; cu.ref_idx[0] = cu.ref_idx[1] = -1;
     const bool isI = P.slice_type == 2;
-    const bool intraCand = isI || modeType == 2 || ( modeType != 1 && std::max( w, h ) <= 64 && rng.p( P.p_intra ) );
+    // (a 4x4 CU is never inter predicted: pred_mode is inferred; it only gets here in 4:0:0 pictures, where no chroma constraint forces a mode)
+    const bool intraCand = isI || modeType == 2 || ( w == 4 && h == 4 ) || ( modeType != 1 && std::max( w, h ) <= 64 && rng.p( P.p_intra ) );
     // intra block copy instead of intra prediction (IBC CUs take the place of intra CUs in the coding tree: same size limits)
     bool ibc = false;
     if( intraCand && ibcOn && P.p_ibc > 0 && !treeC && w <= 64 && h <= 64 && rng.p( P.p_ibc ) )
