@@ -297,6 +297,8 @@ def test_malformed_descriptions_are_rejected(stub):
     _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "ref_idx")
     d = mk(plans[1], p_intra=0.0); d.cu["mc_mode"][0] = 77
     _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "mc_mode")
+    d = mk(plans[1], p_intra=0.0); d.cu["w"][0] = 4; d.cu["h"][0] = 4
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "4x4 inter CU")
     d = mk(plans[0]); d.cu["intra_dir"][0] = (90, 0)
     _expect_error(ctx, d, abi.VVR_ERR_UNSUPPORTED, "intra mode")
     # intra block copy

@@ -407,6 +407,7 @@ static int validate( vvr_context* c, const vvr_picture* p )
         if( cu.mc_mode == VVR_MC_UNI ) { c->setError( "mc_mode UNI on a bi-predicted CU of a picture with weighted prediction" ); return VVR_ERR_PARAMETER; }
       }
       if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) { c->setError( "inter CU must be single tree" ); return VVR_ERR_PARAMETER; }
+      if( cu.w == 4 && cu.h == 4 ) { c->setError( "4x4 inter CU (never inter predicted, InterPrediction.cpp:634)" ); return VVR_ERR_PARAMETER; }
     }
     else if( cu.pred_mode == VVR_PRED_INTRA )
     {
