@@ -356,6 +356,28 @@ def test_unsupported_tools_fail_loudly(built):
     rec.close()
 
 
+def test_output_window_and_picture_hash(built):
+    """the output side of the boundary on reconstructed pictures: conformance-window crop (vvr_read_output) and the decoded-picture-hash
+    digests (vvr_picture_hash) agree with the full planes read back through vvr_read_plane"""
+    import vvdec_amd
+    W, H = 256, 128
+    plans, nslots = stream.ra_plan(3, gop=2, seed_poc0_is_external=False)
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=2)
+    for pl in plans:
+        rec.decompress_picture(synth.picture_for_plan(pl, W, H, seed=281, tool_flags=TOOLS_A, p_intra=0.2))
+    rec.sync()
+    for pl in plans:
+        full = rec.read_picture(pl.slot)
+        win = rec.read_output(pl.slot, window=(16, 8, 200, 96))
+        for c in range(3):
+            s = 1 if c else 0
+            assert np.array_equal(win[c], full[c][8 >> s:(8 + 96) >> s, 16 >> s:(16 + 200) >> s])
+        md5 = rec.picture_hash(pl.slot, 0)
+        assert md5 == [hashlib.md5(p.astype("<u2").tobytes()).digest() for p in full]
+        assert [len(x) for x in rec.picture_hash(pl.slot, 1)] == [2, 2, 2] and [len(x) for x in rec.picture_hash(pl.slot, 2)] == [4, 4, 4]
+    rec.close()
+
+
 def _golden_files():
     import glob, os
     return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
