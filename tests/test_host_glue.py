@@ -470,3 +470,25 @@ def test_golden_fixtures_pass_the_host_glue(stub):
         ctx.close()
         n += 1
     assert n >= 39
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_control_flow(stub, ranks):
+    """bench.py against the stand-in runtime, one process and two ranks over gloo (the N > 1 launch of the driver): every rank gets through
+    the barriers, rank 0 prints exactly one JSON line with the contract's keys"""
+    import json
+    import sys
+    tool = os.path.join(os.path.dirname(HERE), "tools", "bench_host_side.py")
+    env = dict(os.environ, VVR_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, tool] if ranks == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                                                    "--master-addr", "127.0.0.1", "--master-port", "29533", tool]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out
+    assert out["n_gpus"] == ranks and out["steps"] == 6 and out["warmup"] == 4 and out["scaling"] == "weak" and "workload" in out["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in out["roofline"]
