@@ -316,7 +316,11 @@ typedef struct vvr_config {
   uint8_t  chroma_format, bit_depth, log2_ctu;
   uint8_t  num_slots;            /* DPB slots (pictures resident in HBM)                                        */
   uint8_t  num_streams;          /* pictures reconstructing concurrently (reference: 2, DecLib.h:70)            */
-  uint8_t  pad[3];
+  uint8_t  host_threads;         /* worker threads that build the device work lists of submitted pictures (the reference spreads the set-up of
+                                    decompressPicture over its thread pool, DecLibRecon.cpp:429-682).  0: the submitting thread does it inside
+                                    vvr_submit; N > 0: vvr_submit only queues the picture, N pictures are prepared concurrently and enqueued
+                                    on the device in submission order                                                                        */
+  uint8_t  pad[2];
   void*    ext_planes;           /* optional: caller-owned device memory for the DPB, num_slots * vvr_slot_bytes */
                                  /* (mirrors vvdec_decoder_open_with_allocator, vvdec.h.in:576)                 */
 } vvr_config;
@@ -327,9 +331,15 @@ typedef struct vvr_context vvr_context;
 VVR_API int          vvr_create(const vvr_config* cfg, vvr_context** out);
 /* DecLibRecon::destroy */
 VVR_API void         vvr_destroy(vvr_context* ctx);
-/* DecLibRecon::decompressPicture (DecLibRecon.cpp:429): asynchronous; returns a job id >= 0 or an error code. */
+/* DecLibRecon::decompressPicture (DecLibRecon.cpp:429): asynchronous; returns a job id >= 0 or an error code.  Called from ONE submitting
+ * thread.  The description is validated before the call returns; the arrays it points to must stay valid and unchanged until
+ * vvr_inputs_done(job) or vvr_wait(job) has returned (with host_threads == 0 they are consumed before vvr_submit returns).  Errors that
+ * only show later (work lists, device) are parked on the job, the way the reference parks exceptions on reconDone, and come back from
+ * vvr_wait.  Pictures are enqueued on the device in submission order; every job should eventually be waited for (vvr_wait / vvr_sync). */
 VVR_API int          vvr_submit(vvr_context* ctx, const vvr_picture* pic);
-/* DecLibRecon::waitForPrevDecompressedPic (DecLibRecon.cpp:684): blocks until job `job` is reconstructed. */
+/* blocks until the host arrays of job `job` are no longer needed (its device work lists are built and staged in pinned memory) */
+VVR_API int          vvr_inputs_done(vvr_context* ctx, int job);
+/* DecLibRecon::waitForPrevDecompressedPic (DecLibRecon.cpp:684): blocks until job `job` is reconstructed; returns its status. */
 VVR_API int          vvr_wait(vvr_context* ctx, int job);
 /* wait for everything in flight */
 VVR_API int          vvr_sync(vvr_context* ctx);
@@ -342,13 +352,14 @@ VVR_API void*        vvr_plane_ptr(vvr_context* ctx, int slot, int comp);
 VVR_API int          vvr_read_plane(vvr_context* ctx, int slot, int comp, uint16_t* dst, size_t dst_stride_samples);
 /* output of one plane the way the reference hands frames to the application (VVDecImpl::copyComp, vvdecimpl.cpp:818-880, called with the
  * conformance window applied): the window (x, y, w, h in samples of the component) is copied to dst with dst_stride_bytes between rows;
- * bytes_per_sample 2 = 16-bit samples, 1 = the low byte of every sample (8-bit streams; "only narrowing conversions", :853).  Waits for
- * all work on the slot. */
+ * bytes_per_sample 2 = 16-bit samples, 1 = the low byte of every sample (8-bit streams; "only narrowing conversions", :853).  Crop and
+ * narrowing run on the device: exactly w * h * bytes_per_sample bytes cross PCIe.  Waits for all work on the slot. */
 VVR_API int          vvr_read_output(vvr_context* ctx, int slot, int comp, int x, int y, int w, int h, int bytes_per_sample, void* dst, size_t dst_stride_bytes);
 /* decoded picture hash of a slot, as the decoded-picture-hash SEI defines it and the reference checks it (calcMD5 / calcCRC / calcChecksum,
  * PicYuvMD5.cpp:99-221): one digest per component over the whole plane in raster order, samples as 1 byte (bit depth 8) or 2 bytes little
- * endian.  digest receives num_components x digest_len bytes (MD5 16, CRC 2, checksum 4), *digest_len the length of one.  The planes are
- * copied to the host and hashed there, like the reference does (MD5 is a serial chain over the plane). */
+ * endian.  digest receives num_components x digest_len bytes (MD5 16, CRC 2, checksum 4), *digest_len the length of one.  CRC and checksum
+ * are computed on the device (only per-row partial results cross PCIe); for MD5, a serial chain over the bytes of a plane, the device packs
+ * the plane to exactly those bytes and the host hashes them. */
 enum { VVR_HASH_MD5 = 0, VVR_HASH_CRC = 1, VVR_HASH_CHECKSUM = 2 };
 VVR_API int          vvr_picture_hash(vvr_context* ctx, int slot, int method, uint8_t* digest, int* digest_len);
 /* upload a reference picture produced elsewhere (another GPU / a test) into a slot */
@@ -381,6 +392,9 @@ typedef struct vvr_kernel_stat {
 } vvr_kernel_stat;
 VVR_API int          vvr_enable_stats(vvr_context* ctx, int on);
 VVR_API int          vvr_get_stats(vvr_context* ctx, vvr_kernel_stat* out, int max_entries);
+/* practical HBM ceiling of this device: bytes per second (read + written) of the library's device copy kernel over one DPB
+ * slot, HIP-event timed, averaged over `iters` launches; slot 0 is read, nothing of any slot is modified */
+VVR_API double       vvr_measure_copy_bandwidth(vvr_context* ctx, int iters);
 
 /* Host glue helpers (pure functions, no device): what the reference computes per CU/TU on the CPU before the
  * arithmetic starts.  They are part of the ABI so that the parser-side integration and the tests use one definition. */

@@ -36,8 +36,11 @@ hipError_t hipEventSynchronize( hipEvent_t ) { return hipSuccess; }
 hipError_t hipEventElapsedTime( float* ms, hipEvent_t, hipEvent_t ) { *ms = 0.f; return hipSuccess; }
 hipError_t hipGetLastError( void ) { return hipSuccess; }
 const char* hipGetErrorString( hipError_t ) { return "host stub"; }
+hipError_t hipMemcpyAsync( void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t ) { memcpy( d, s, n ); return hipSuccess; }
+hipError_t hipMemsetAsync( void* d, int v, size_t n, hipStream_t ) { memset( d, v, n ); return hipSuccess; }
 }
 
+#include "../../vvdec_amd/csrc/vvr_prepare.cpp"
 #include "../../vvdec_amd/csrc/vvr_api.cpp"
 
 // kernel launches: nothing to run on the host; the launch of the intra stage records what it was handed
@@ -53,7 +56,35 @@ void launch_copy_planes( hipStream_t, DevPlanes, DevPlanes ) {}
 void launch_mc_affine( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int ) {}
 void launch_mc_dmvr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int32_t* ) {}
 void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, int numUnits, int* sync ) { g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
-void launch_intra_levels( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, const std::pair<int, int>*, int numLevels, int* sync ) { g_lastIntraUnits = -numLevels; g_lastSync = sync; }
+// the two output-stage kernels have functional stand-ins (a few plain loops with the kernels' contract: packed window; per row the checksum
+// share or the CRC register reached from 0), so that the host half of vvr_read_output / vvr_picture_hash - window geometry, chaining the rows'
+// CRC pieces - is checked against the reference's own functions without a GPU
+void launch_output_window( hipStream_t, const pel_t* src, int stride, int w, int h, int bps, void* dst )
+{
+  for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+  {
+    const uint16_t v = (uint16_t) src[(size_t) y * stride + x];
+    if( bps == 2 ) ( (uint16_t*) dst )[(size_t) y * w + x] = v; else ( (uint8_t*) dst )[(size_t) y * w + x] = (uint8_t) v;
+  }
+}
+void launch_plane_hash_rows( hipStream_t, const pel_t* plane, int stride, int w, int h, int two, int crcMode, uint32_t* out )
+{
+  for( int y = 0; y < h; y++ )
+  {
+    uint32_t acc = 0;
+    for( int x = 0; x < w; x++ )
+    {
+      const uint32_t v = (uint16_t) plane[(size_t) y * stride + x];
+      if( !crcMode ) { const uint32_t mask = ( ( x & 0xff ) ^ ( y & 0xff ) ^ ( x >> 8 ) ^ ( y >> 8 ) ) & 0xff; acc += ( v & 0xff ) ^ mask; if( two ) acc += ( v >> 8 ) ^ mask; }
+      else for( int b = 0; b < ( two ? 2 : 1 ); b++ ) for( int bit = 7; bit >= 0; bit-- )
+      {
+        const uint32_t byte = b ? v >> 8 : v & 0xff, msb = ( acc >> 15 ) & 1;
+        acc = ( ( ( acc << 1 ) + ( ( byte >> bit ) & 1 ) ) & 0xffff ) ^ ( msb * 0x1021 );
+      }
+    }
+    out[y] = acc;
+  }
+}
 
 extern "C" {
 // the intra-stage tables of a prepared picture (host memory in this build): units in ticket order, items, counts
@@ -72,8 +103,28 @@ __attribute__(( visibility( "default" ) )) int vvt_take_trace( int* dst, int max
   return n;
 }
 // everything vvr_prepare uploaded for one picture (work lists, tables, the description's arrays): one allocation
-__attribute__(( visibility( "default" ) )) int vvt_blob( const vvr_prepared* q, const void** p, size_t* n ) { if( !q ) return -1; *p = q->blob.p; *n = q->blob.n; return 0; }
+__attribute__(( visibility( "default" ) )) int vvt_blob( const vvr_prepared* q, const void** p, size_t* n ) { if( !q ) return -1; *p = q->blob; *n = q->blobBytes; return 0; }
+// one logical table of a prepared picture (developer regression check of the host glue, tools/host_tables_hash.py): 0..3 MC tile lists (plain, BDOF,
+// DMVR, affine), 4..6 transform block lists by size class, 7 intra-stage blocks, 8 intra-stage units
+__attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q, int which, const void** p, size_t* n )
+{
+  if( !q ) return -1;
+  switch( which )
+  {
+  case 0: *p = q->mcItems;   *n = sizeof( McItem ) * q->numMc; break;
+  case 1: *p = q->bdofItems; *n = sizeof( McItem ) * q->numBdofItems; break;
+  case 2: *p = q->dmvrItems; *n = sizeof( McItem ) * q->numDmvrItems; break;
+  case 3: *p = q->affItems;  *n = sizeof( McItem ) * q->numAffItems; break;
+  case 4: case 5: case 6: *p = q->tbItems[which - 4]; *n = sizeof( TbItem ) * q->numTb[which - 4]; break;
+  case 7: *p = q->intraItems; *n = sizeof( IntraItem ) * q->numIntra; break;
+  case 8: *p = q->units; *n = sizeof( IntraUnit ) * q->numActive; break;
+  default: return -1;
+  }
+  return 0;
+}
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }
+// pretend the lane's flag buffer is small (the product sizes it for ordinary pictures; the growth path needs a picture with more units than that)
+__attribute__(( visibility( "default" ) )) void vvt_shrink_sync( vvr_context* c, int lane, size_t cap ) { if( c && lane < (int) c->syncCap.size() && cap < c->syncCap[lane] ) c->syncCap[lane] = cap; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sync_capacity( const vvr_context* c, int lane ) { return c && lane < (int) c->syncCap.size() ? c->syncCap[lane] : 0; }
 }

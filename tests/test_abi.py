@@ -112,7 +112,16 @@ def test_tr_type_helper(built):
     h = abi.PicHeader(); cu = abi.Cu(); tu = abi.Tu()
     cu.pred_mode = abi.PRED_INTRA; cu.w = cu.h = 16
     tu.w, tu.h = 16, 16
-    # no MTS at all -> DCT2/DCT2
+    # sps_mts_enabled_flag off -> DCT2/DCT2, also for ISP and SBT blocks and whatever the other switches say (TrQuant.cpp:346)
+    assert L.vvr_resolve_tr_type(C.byref(h), C.byref(cu), C.byref(tu), 0, 1, 1, 1) == 0
+    cu.isp_mode = 1
+    assert L.vvr_resolve_tr_type(C.byref(h), C.byref(cu), C.byref(tu), 0, 0, 0, 0) == 0
+    cu.isp_mode = 0
+    inter = abi.Cu(); inter.pred_mode = abi.PRED_INTER; inter.w = inter.h = 16; inter.sbt_info = 1 | (1 << 4)
+    assert L.vvr_resolve_tr_type(C.byref(h), C.byref(inter), C.byref(tu), 0, 0, 0, 1) == 0
+    h.tool_flags = abi.TOOL_MTS
+    assert L.vvr_resolve_tr_type(C.byref(h), C.byref(inter), C.byref(tu), 0, 0, 0, 1) != 0
+    # MTS on, but neither implicit nor explicit selection -> DCT2/DCT2
     assert L.vvr_resolve_tr_type(C.byref(h), C.byref(cu), C.byref(tu), 0, 0, 0, 0) == 0
     # implicit MTS on an intra luma block 4..16 -> DST7 both ways ((ver<<2)|hor with DST7 = 2)
     assert L.vvr_resolve_tr_type(C.byref(h), C.byref(cu), C.byref(tu), 0, 1, 0, 0) == ((2 << 2) | 2)

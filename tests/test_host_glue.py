@@ -36,9 +36,9 @@ TOOLS = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF
 
 @pytest.fixture(scope="module")
 def stub():
-    deps = [SRC, API, os.path.join(os.path.dirname(API), "vvr_device.h")]
+    deps = [SRC, API] + [os.path.join(os.path.dirname(API), f) for f in ("vvr_device.h", "vvr_host.h", "vvr_prepare.cpp", "vvr_output.inc")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-I" + HIP_INC, "-D__HIP_PLATFORM_AMD__", "-w", SRC, "-o", LIB])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I" + HIP_INC, "-D__HIP_PLATFORM_AMD__", "-w", SRC, "-o", LIB])
     L = C.CDLL(LIB)
     L.vvr_last_error.restype = C.c_char_p
     L.vvr_last_error.argtypes = [C.c_void_p]
@@ -231,12 +231,13 @@ def test_intra_stage_tables(stub, name, W, H, frames, gop, seed, tools, kw):
     assert checked > 0
 
 
-def test_sync_buffer_grows_with_the_number_of_units(stub, monkeypatch):
+def test_sync_buffer_grows_with_the_number_of_units(stub):
     """the per-lane ticket / flag buffer is sized for ordinary pictures and grows when a picture has more units"""
-    monkeypatch.setenv("VVR_SYNC_UNITS_PER_CTU", "1")
     W, H = 416, 240
     plans, nslots = stream.ra_plan(3, gop=2, seed_poc0_is_external=False)
     ctx = Ctx(stub, W, H, nslots)
+    stub.vvt_shrink_sync.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    stub.vvt_shrink_sync(ctx.ctx, 0, 9)            # as if the context had been sized for one unit per CTU
     cap0 = stub.vvt_sync_capacity(ctx.ctx, 0)
     d = synth.picture_for_plan(plans[1], W, H, seed=507, tool_flags=TOOLS, p_intra=0.4, p_split_scale=1.6)
     hnd = ctx.prepare(d)
@@ -298,7 +299,22 @@ def test_malformed_descriptions_are_rejected(stub):
     d = mk(plans[1], p_intra=0.0); d.cu["mc_mode"][0] = 77
     _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "mc_mode")
     d = mk(plans[1], p_intra=0.0); d.cu["w"][0] = 4; d.cu["h"][0] = 4
+    t0 = int(d.cu["first_tu"][0]); d.tu["w"][t0:t0 + int(d.cu["num_tu"][0])] = 4; d.tu["h"][t0:t0 + int(d.cu["num_tu"][0])] = 4
     _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "4x4 inter CU")
+    d = mk(plans[1], p_intra=0.0); d.cu["w"][0] //= 2             # a hole in the picture (and a TU that sticks out of its CU)
+    t0 = int(d.cu["first_tu"][0]); d.tu["w"][t0:t0 + int(d.cu["num_tu"][0])] //= 2
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "do not cover the picture")
+    # transform units: owned by their CU, inside it, coded corner inside the block and the level stream
+    d = mk(plans[0]); d.tu["cu"][0] = 1
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "does not name its CU")
+    d = mk(plans[0]); d.tu["x"][0] += 4
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "TU outside its CU")
+    d = mk(plans[0], p_coded=1.0, p_ts=0.0, p_bdpcm=0.0)
+    k = int(np.nonzero((d.tu["cbf"] & 1) != 0)[0][0])
+    d.tu["max_scan_x"][k][0] = 200
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "last significant position")
+    d = mk(plans[0], p_coded=1.0, p_ts=0.0, p_bdpcm=0.0); d.tu["coef_off"][k][0] = len(d.coef)
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "outside the level stream")
     d = mk(plans[0]); d.cu["intra_dir"][0] = (90, 0)
     _expect_error(ctx, d, abi.VVR_ERR_UNSUPPORTED, "intra mode")
     # intra block copy

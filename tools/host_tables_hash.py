@@ -7,11 +7,11 @@ import numpy as np
 from vvdec_amd import abi, synth, stream
 import test_host_glue as T
 import subprocess, os
-subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-I" + T.HIP_INC, "-D__HIP_PLATFORM_AMD__", "-w", T.SRC, "-o", T.LIB])
+subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I" + T.HIP_INC, "-D__HIP_PLATFORM_AMD__", "-w", T.SRC, "-o", T.LIB])
 L = C.CDLL(T.LIB)
 L.vvr_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; L.vvr_free_prepared.argtypes = [C.c_void_p, C.c_void_p]; L.vvr_destroy.argtypes = [C.c_void_p]
 L.vvr_last_error.restype = C.c_char_p; L.vvr_last_error.argtypes = [C.c_void_p]
-L.vvt_blob.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+L.vvt_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
 out = {}
 extra = [("wp_sl", 256, 128, 5, 4, 520, T.TOOLS | abi.TOOL_WP | abi.TOOL_SCALING_LIST, dict(p_intra=0.2, p_affine=0.2, p_sbtmvp=0.2, p_geo=0.1, p_sbt=0.2)),
          ("mono8", 256, 128, 3, 2, 521, T.TOOLS | abi.TOOL_LMCS, dict(bit_depth=8, chroma_format=0, p_intra=0.3, p_mip=0.2))]
@@ -25,8 +25,11 @@ for (name, W, H, frames, gop, seed, tools, kw) in T.STREAMS + extra:
         d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
         h = ctx.prepare(d)
         p, n = C.c_void_p(), C.c_size_t()
-        assert L.vvt_blob(h, C.byref(p), C.byref(n)) == 0
-        hs.append(hashlib.md5(C.string_at(p.value, n.value)).hexdigest() + ":%d" % n.value)
+        parts = []
+        for which in range(9):                     # logical tables (independent of how the upload is laid out)
+            assert L.vvt_table(h, which, C.byref(p), C.byref(n)) == 0
+            parts.append(hashlib.md5(C.string_at(p.value, n.value) if n.value else b"").hexdigest()[:12] + ":%d" % n.value)
+        hs.append(" ".join(parts))
         L.vvr_free_prepared(ctx.ctx, h)
     ctx.close()
     out[name] = hs

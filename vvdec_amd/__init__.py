@@ -72,23 +72,28 @@ def lib():
         L.vvr_enable_stats.argtypes = [C.c_void_p, C.c_int]
         L.vvr_get_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.vvr_plane_layout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vvr_inputs_done.restype = C.c_int
+        L.vvr_inputs_done.argtypes = [C.c_void_p, C.c_int]
+        L.vvr_measure_copy_bandwidth.restype = C.c_double
+        L.vvr_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
 
 EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
                     "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_picture_hash", "vvr_write_plane", "vvr_read_dmvr", "vvr_prepare", "vvr_submit_prepared",
-                    "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof"]
+                    "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof",
+                    "vvr_inputs_done", "vvr_measure_copy_bandwidth"]
 
 
 class Reconstructor:
-    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, num_slots=8, num_streams=2, device=0, ext_planes=None):
+    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, num_slots=8, num_streams=2, device=0, ext_planes=None, host_threads=0):
         self.L = lib()
         cfg = abi.Config()
         cfg.abi_version = abi.VVR_ABI_VERSION
         cfg.device, cfg.max_width, cfg.max_height = device, width, height
         cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = chroma_format, bit_depth, log2_ctu
-        cfg.num_slots, cfg.num_streams = num_slots, num_streams
+        cfg.num_slots, cfg.num_streams, cfg.host_threads = num_slots, num_streams, host_threads
         cfg.ext_planes = ext_planes
         self.cfg = cfg
         self.ctx = C.c_void_p()
@@ -122,9 +127,22 @@ class Reconstructor:
         self._keep[job] = (d, p)
         return job
 
+    def submit_c(self, p):
+        """vvr_submit of a ctypes abi.Picture built beforehand (`desc.c()`); the caller keeps the description alive until wait()"""
+        return self._check(self.L.vvr_submit(self.ctx, C.byref(p)))
+
     def wait(self, job):
-        self._check(self.L.vvr_wait(self.ctx, job))
-        self._keep.pop(job, None)
+        try:
+            self._check(self.L.vvr_wait(self.ctx, job))
+        finally:
+            self._keep.pop(job, None)
+
+    def inputs_done(self, job):
+        self._check(self.L.vvr_inputs_done(self.ctx, job))
+
+    def copy_bandwidth(self, iters=20):
+        """practical HBM ceiling: bytes/s (read + written) of the library's copy kernel over one DPB slot"""
+        return self.L.vvr_measure_copy_bandwidth(self.ctx, iters)
 
     def sync(self):
         self._check(self.L.vvr_sync(self.ctx))

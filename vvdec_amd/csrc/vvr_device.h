@@ -87,7 +87,7 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
   const vvr_cu*      cu;
   const vvr_tu*      tu;
   const int16_t*     coef;
-  const vvr_motion*  motion;
+  const vvr_motion*  affMotion;      // motion of the 4x4 sub-blocks of the affine tiles: 16 entries (4 x 4) per tile, first entry = McItem::mv[0][0]
   const vvr_lfp*     lfp[2];
   const vvr_sao_ctu* sao;
   const vvr_alf_ctu* alf;
@@ -111,8 +111,9 @@ void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes 
 void launch_alf    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 void launch_lmcs   ( hipStream_t s, const PicDev& pic, DevPlanes reco, int inverse );
 void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst );
+void launch_output_window( hipStream_t s, const pel_t* src, int stride, int w, int h, int bytesPerSample, void* dst );      // window rows packed back to back, 1 or 2 bytes per sample
+void launch_plane_hash_rows( hipStream_t s, const pel_t* plane, int stride, int w, int h, int two, int crcMode, uint32_t* out );   // per row: checksum share / CRC piece
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );
 void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numUnits, int* sync );
-void launch_intra_levels( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units,
-                          const std::pair<int, int>* levels, int numLevels, int* sync );      // one launch per dependency level (first unit, count)
+

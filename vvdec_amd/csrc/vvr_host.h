@@ -1,0 +1,44 @@
+// vvdec_amd/csrc/vvr_host.h — host-side internals shared by vvr_api.cpp (context, job pipeline, launches) and vvr_prepare.cpp (validation and
+// the work lists a picture's kernels iterate over).  Nothing here is part of the ABI (include/vvr.h).
+#pragma once
+#include "vvr_device.h"
+#include <string>
+#include <vector>
+
+static inline size_t alignUp( size_t v, size_t a ) { return ( v + a - 1 ) / a * a; }
+
+enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_OUTPUT, K_NUM };
+
+// A picture description resident in HBM together with its device work lists: every pointer is a device address inside one blob.
+// Streaming submissions (vvr_submit) use the blob of a ring entry owned by the context; vvr_prepare gives the handle a blob of its own.
+struct vvr_prepared {
+  vvr_pic_header hdr;
+  PicDev   pic;
+  McItem*  mcItems = nullptr; int numMc = 0;
+  McItem*  bdofItems = nullptr; int numBdofItems = 0;      // tiles of CUs in BDOF mode (their own launch: larger LDS footprint)
+  McItem*  dmvrItems = nullptr; int numDmvrItems = 0;      // sub-blocks that run decoder-side MV refinement
+  McItem*  affItems = nullptr; int numAffItems = 0;        // tiles of affine CUs
+  int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
+  TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64
+  IntraItem* intraItems = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
+  double   bytes[K_NUM] = { 0 };                           // algorithmic bytes per kernel
+  // ownership (vvr_prepare handles only)
+  void*    blob = nullptr; size_t blobBytes = 0;
+  int32_t* dmvrHost = nullptr;                             // pinned, 2 * numDmvr ints: the delta MVs land here behind the DMVR kernel
+  struct vvr_context* owner = nullptr;
+};
+
+// Reusable scratch of one preparing thread: the lists are built here (no allocation in the steady state), then packed into pinned memory.
+struct PrepScratch;
+PrepScratch* vvr_scratch_create();
+void         vvr_scratch_destroy( PrepScratch* );
+
+// validation of a picture description against the context configuration (no device access)
+int    vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string& err );
+// host glue: the work lists of one picture (what DecCu::TaskTrafoCtu / TaskInterCtu / the intra task iterate over, DecCu.cpp:106-160); returns the
+// number of bytes the picture needs in HBM
+int    vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err );
+// the H2D image: every part at its offset (256-byte aligned) into `host` (pinned memory of at least totalBytes)
+void   vvr_host_pack( const PrepScratch& S, char* host );
+// device pointers of a prepared picture whose image sits at devBase
+void   vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* devBase );

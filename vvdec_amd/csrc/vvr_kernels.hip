@@ -790,7 +790,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       if( r < nsb )
       {
         const int sx = r % sbx, sy = r / sbx;
-        const vvr_motion& m = pic.motion[(size_t) ( ( it.y >> 2 ) + sy ) * pic.w4 + ( it.x >> 2 ) + sx];
+        const vvr_motion& m = pic.affMotion[it.mv[0][0] + 4 * sy + sx];
         const int mx = min( horMax, max( horMin, m.mv[l][0] ) ), my = min( verMax, max( verMin, m.mv[l][1] ) );
         g.xFrac = mx & 15; g.yFrac = my & 15;
         g.x0 = it.x + 4 * sx + ( mx >> 4 ) - 3; g.y0 = it.y + 4 * sy + ( my >> 4 ) - 3;
@@ -799,8 +799,8 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       else
       {
         const int q = r - nsb, sx = q % cbx, sy = q / cbx;
-        const vvr_motion& m0 = pic.motion[(size_t) ( ( it.y >> 2 ) + 2 * sy ) * pic.w4 + ( it.x >> 2 ) + 2 * sx];
-        const vvr_motion& m1 = pic.motion[(size_t) ( ( it.y >> 2 ) + 2 * sy + 1 ) * pic.w4 + ( it.x >> 2 ) + 2 * sx + 1];
+        const vvr_motion& m0 = pic.affMotion[it.mv[0][0] + 4 * ( 2 * sy ) + 2 * sx];
+        const vvr_motion& m1 = pic.affMotion[it.mv[0][0] + 4 * ( 2 * sy + 1 ) + 2 * sx + 1];
         int mx = m0.mv[l][0] + m1.mv[l][0], my = m0.mv[l][1] + m1.mv[l][1];
         aff_round_mv( mx, my, 1 );
         mx = min( horMax, max( horMin, mx ) ); my = min( verMax, max( verMin, my ) );
@@ -1909,15 +1909,88 @@ void launch_lmcs( hipStream_t s, const PicDev& pic, DevPlanes reco, int inverse 
   hipLaunchKernelGGL( k_lmcs, dim3( ( reco.w[0] + 2047 ) / 2048, reco.h[0] ), dim3( 256 ), 0, s, pic, reco, inverse );
 }
 
-__global__ void k_copy( DevPlanes src, DevPlanes dst )
+// k_copy — copy of one picture (all planes, rows with their padding: both pictures share one geometry), 16 bytes per lane and access.  Also
+// the copy kernel the practical HBM ceiling is measured with (vvr_measure_copy_bandwidth).
+__global__ __launch_bounds__( 256 ) void k_copy( const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16 )
 {
-  const int c = blockIdx.z, x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if( x < src.w[c] && y < src.h[c] ) dst.p[c][(size_t) y * dst.stride[c] + x] = src.p[c][(size_t) y * src.stride[c] + x];
+  const size_t step = (size_t) gridDim.x * 256;
+  for( size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += step ) dst[i] = src[i];
 }
 void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst )
 {
   const int ncomp = src.p[1] ? 3 : 1;
-  hipLaunchKernelGGL( k_copy, dim3( ( src.w[0] + 255 ) / 256, src.h[0], ncomp ), dim3( 256 ), 0, s, src, dst );
+  for( int c = 0; c < ncomp; c++ )
+  {
+    const size_t n16 = (size_t) src.stride[c] * src.h[c] * sizeof( pel_t ) / 16;
+    hipLaunchKernelGGL( k_copy, dim3( (unsigned) std::min<size_t>( ( n16 + 255 ) / 256, 256 * 16 ) ), dim3( 256 ), 0, s, (const uint4*) src.p[c], (uint4*) dst.p[c], n16 );
+  }
+}
+
+// =====================================================================================================================
+// output stage: window of a plane packed to the bytes the application / the MD5 wants; per-row CRC and checksum pieces
+//   VVDecImpl::copyComp (vvdecimpl.cpp:818-880), compCRC / compChecksum (PicYuvMD5.cpp:99-176)
+// =====================================================================================================================
+__global__ __launch_bounds__( 256 ) void k_output_window( const pel_t* __restrict__ src, int stride, int w, int h, int bytesPerSample, uint8_t* __restrict__ dst )
+{
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if( x >= w ) return;
+  const uint16_t v = (uint16_t) src[(size_t) y * stride + x];
+  if( bytesPerSample == 2 ) ( (uint16_t*) dst )[(size_t) y * w + x] = v;
+  else dst[(size_t) y * w + x] = (uint8_t) v;          // "only narrowing conversions" of 8-bit content (vvdecimpl.cpp:853)
+}
+void launch_output_window( hipStream_t s, const pel_t* src, int stride, int w, int h, int bytesPerSample, void* dst )
+{
+  hipLaunchKernelGGL( k_output_window, dim3( ( w + 255 ) / 256, h ), dim3( 256 ), 0, s, src, stride, w, h, bytesPerSample, (uint8_t*) dst );
+}
+
+// multiplication in GF(2)[x] / (x^16 + x^12 + x^5 + 1), the ring the CRC of the decoded picture hash lives in
+__device__ __forceinline__ uint32_t crc_mul( uint32_t a, uint32_t b )
+{
+  uint32_t r = 0;
+#pragma unroll
+  for( int bit = 15; bit >= 0; bit-- ) { r <<= 1; r ^= ( ( r >> 16 ) & 1 ) * 0x11021u; r ^= ( ( b >> bit ) & 1 ) * a; }
+  return r;
+}
+__device__ __forceinline__ uint32_t crc_xpow( uint32_t n ) { uint32_t r = 1, base = 2; while( n ) { if( n & 1 ) r = crc_mul( r, base ); base = crc_mul( base, base ); n >>= 1; } return r; }
+
+// One wavefront per row.  Checksum: the row's share of the 32-bit sum.  CRC: the row's bytes as a polynomial reduced mod P (register value
+// from 0); lane l folds samples l, l + 64, ... by Horner's rule ( acc = acc * x^(64 * bits) + sample ), shifts its share to the end of the
+// row and the shares are XOR-ed together - the CRC is linear.  The host chains the rows (vvr_picture_hash).
+__global__ __launch_bounds__( 64 ) void k_plane_hash_rows( const pel_t* __restrict__ plane, int stride, int w, int two, int crcMode, uint32_t* __restrict__ out )
+{
+  const int y = blockIdx.x, lane = threadIdx.x;
+  const pel_t* __restrict__ row = plane + (size_t) y * stride;
+  uint32_t acc = 0;
+  if( !crcMode )
+  {
+    for( int x = lane; x < w; x += 64 )
+    {
+      const uint32_t v = (uint16_t) row[x], mask = ( ( x & 0xff ) ^ ( y & 0xff ) ^ ( x >> 8 ) ^ ( y >> 8 ) ) & 0xff;
+      acc += ( v & 0xff ) ^ mask;
+      if( two ) acc += ( v >> 8 ) ^ mask;
+    }
+    for( int o = 32; o; o >>= 1 ) acc += __shfl_down( acc, o, 64 );
+  }
+  else
+  {
+    const int bits = two ? 16 : 8;
+    const uint32_t X = crc_xpow( 64 * bits );
+    int last = -1;
+    for( int x = lane; x < w; x += 64 )
+    {
+      const uint32_t v = (uint16_t) row[x];
+      const uint32_t smp = two ? ( ( v & 0xff ) << 8 ) | ( v >> 8 ) : ( v & 0xff );      // low byte first, most significant bit first
+      acc = crc_mul( acc, X ) ^ smp;
+      last = x;
+    }
+    if( last >= 0 ) acc = crc_mul( acc, crc_xpow( (uint32_t) ( w - 1 - last ) * bits ) );
+    for( int o = 32; o; o >>= 1 ) acc ^= __shfl_down( acc, o, 64 );
+  }
+  if( lane == 0 ) out[y] = acc;
+}
+void launch_plane_hash_rows( hipStream_t s, const pel_t* plane, int stride, int w, int h, int two, int crcMode, uint32_t* out )
+{
+  hipLaunchKernelGGL( k_plane_hash_rows, dim3( h ), dim3( 64 ), 0, s, plane, stride, w, two, crcMode, out );
 }
 
 // =====================================================================================================================
@@ -2007,9 +2080,15 @@ __device__ __forceinline__ void intra_stash_resi1( const IntraItem& it, int16_t*
 
 __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, DevPlanes resi, const IntraItem* __restrict__ items,
                                                   const IntraUnit* __restrict__ units, int numActive,
-                                                  int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */, int dbg,
-                                                  unsigned long long* __restrict__ trace /* developer timeline (VVR_INTRA_TRACE) or nullptr */ )
+                                                  int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */
+#ifdef VVR_INTRA_DEV
+                                                  , int dbg, unsigned long long* __restrict__ trace /* developer timeline (VVR_INTRA_TRACE) or nullptr */
+#endif
+                                                  )
 {
+#ifndef VVR_INTRA_DEV
+  constexpr int dbg = 0; constexpr unsigned long long* trace = nullptr;      // (the timing experiments and the in-kernel timeline are developer builds only)
+#endif
   __shared__ IntraShared sh;
 #define IT_TRACE( K ) if( trace && threadIdx.x == 0 ) trace[(size_t) 8 * tr_ticket + ( K )] = wall_clock64()
   int tr_ticket = 0;
@@ -2778,20 +2857,13 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
 #undef IT_PH
 }
 
-void launch_intra_levels( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units,
-                          const std::pair<int, int>* levels, int numLevels, int* sync )
-{
-  // every level has its own ticket counter (sync[l]); no flags are used: the units of a level only read what earlier launches wrote
-  static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;
-  hipMemsetAsync( sync, 0, sizeof( int ) * (size_t) numLevels, s );
-  for( int l = 0; l < numLevels; l++ )
-    hipLaunchKernelGGL( k_intra, dim3( levels[l].second ), dim3( 256 ), 0, s, pic, reco, resi, items, units + levels[l].first, levels[l].second, sync + l, dbg | 0x100, nullptr );
-}
-
 void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numActive, int* sync )
 {
   if( !numActive ) return;
   hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + (size_t) numActive ), s );
+#ifndef VVR_INTRA_DEV
+  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync );
+#else
   static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
   static const bool tr = getenv( "VVR_INTRA_TRACE" ) != nullptr;
   unsigned long long* trace = nullptr;
@@ -2807,4 +2879,5 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
     char name[128]; snprintf( name, sizeof( name ), "gpurun_out/intra_trace_poc%d.bin", pic.hdr.poc );
     if( FILE* f = fopen( name, "wb" ) ) { fwrite( h.data(), sizeof( unsigned long long ), h.size(), f ); fclose( f ); }
   }
+#endif
 }

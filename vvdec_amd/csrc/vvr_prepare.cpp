@@ -1,0 +1,939 @@
+// vvdec_amd/csrc/vvr_prepare.cpp — host glue of the reconstruction back-end: validation of a picture description and the device work lists
+// built from it (what DecCu::TaskTrafoCtu / TaskInterCtu / TaskCriticalIntraKernel iterate over in the reference, DecCu.cpp:106-160).
+//
+// This stage runs once per picture on a host thread (several pictures are prepared concurrently by the context's worker threads,
+// vvr_api.cpp), so it is written for throughput: all containers live in a per-thread PrepScratch that is reused from picture to picture
+// (no allocation in the steady state), per-block producer lists sit in one flat pool, and the result is packed straight into the pinned
+// staging memory of the upload ring.  No device call happens here.
+#include "vvr_host.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+static inline int ilog2i( int v ) { int l = 0; while( ( 1 << l ) < v ) l++; return l; }
+
+struct BBox { int y0 = 255, y1 = 0, c0 = 255, c1 = 0; };   // rows relative to (CTU top - 3), 8-sample chunks relative to (CTU left - 8), chunk index + 1
+// a block of the intra stage on the host: its CTU, the part of the CTU tile it may read, the blocks it reads from (range of the flat pool;
+// entries are ( component << 28 ) | block index)
+struct ItemH { uint32_t ctu; BBox bb; uint32_t p0, pn; };
+// Intra-stage work units: a unit is a set of blocks of one (component, CTU) that are connected through the reference samples they read from
+// each other (a whole CTU in an intra picture, a few blocks around an isolated intra CU in a B picture); one workgroup processes one unit,
+// its blocks in coding order.  Units depend on exactly those other units that produced a sample they read (inter samples are final before
+// the stage starts).
+struct UnitH { uint32_t comp, ctu, i0, i1, iA = 0; bool hasCs = false; BBox bb; std::vector<uint32_t> deps; bool waited = false; int rank = 0; };
+
+struct Part { const void* src; size_t n, off; };
+
+struct PrepScratch
+{
+  // ---- the picture being prepared
+  const vvr_picture* p = nullptr;
+  vvr_pic_header h;
+  int ncomp = 0, w4 = 0, h4 = 0, ctu = 0, ctusX = 0, ctusY = 0, numCtu = 0, vpduLog2 = 0, vpdusX = 0, vpdusY = 0;
+  bool wpOn = false, cscale = false, lmcs = false;
+  // ---- work lists
+  std::vector<McItem> mc, mcBdof, mcDmvr, mcAff;
+  std::vector<vvr_motion> affMv;           // motion of the 4x4 sub-blocks of the affine tiles, 16 entries per tile (the only part of the motion field a kernel reads)
+  uint32_t numDmvr = 0;
+  std::vector<TbItem> tb[3];
+  std::vector<IntraItem> intra[3], intraTmp[3], intraAll;
+  std::vector<ItemH> itemH[3], itemHTmp;
+  std::vector<uint32_t> prodPool[3];
+  std::vector<uint32_t> ctuStartV;
+  double bytes[K_NUM] = { 0 };
+  // decode-order index of the transform block covering every 4x4 luma unit (both channel types): reference availability
+  // = "inside the picture and reconstructed before me" (CodingStructure::getCURestricted, CodingStructure.cpp:464, and the
+  // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
+  std::vector<int32_t> order;
+  std::vector<uint8_t> intraAt;            // per 4x4 luma unit: covered by an intra CU (1) / a CIIP CU (2)
+  std::vector<int32_t> itemAt[3];          // per component and 4x4 luma cell: the block that reconstructs it in the intra stage (-1: none)
+  std::vector<int32_t> cuAt;
+  std::vector<uint8_t> interAtV;
+  std::vector<UnitH> units, unitsTmp;
+  // LMCS chroma residual scaling: per VPDU the luma neighbourhood its factor is averaged over (Reshape::calculateChromaAdjVpduNei,
+  // Reshape.cpp:192-274): left column / above row of the CU at the VPDU origin, where that neighbour precedes it in decoding order
+  std::vector<uint32_t> csVpduV;
+  std::vector<IntraUnit> unitsDev;
+  // union-find / grouping scratch
+  std::vector<uint32_t> parent, newIdx, firstOf, perm, inv, unitCount, unitOfItem[3];
+  std::vector<int32_t> unitOfRoot, target;
+  std::vector<std::vector<uint32_t>> members, groups;
+  // ---- layout of the H2D image
+  std::vector<Part> parts;
+  size_t total = 0;
+  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iLmcs, iSl, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iDmvrOut, iTb[3], iIntra, iUnits;
+
+  void begin( const vvr_picture* pic )
+  {
+    p = pic; h = pic->hdr;
+    ncomp = h.chroma_format ? 3 : 1;
+    wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
+    w4 = ( h.width + 3 ) >> 2; h4 = ( h.height + 3 ) >> 2; ctu = 1 << h.log2_ctu;
+    ctusX = ( h.width + ctu - 1 ) / ctu; ctusY = ( h.height + ctu - 1 ) / ctu; numCtu = ctusX * ctusY;
+    lmcs = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
+    cscale = lmcs && ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && ncomp == 3;
+    vpduLog2 = std::min<int>( 6, h.log2_ctu ); vpdusX = ( h.width + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2; vpdusY = ( h.height + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2;
+    mc.clear(); mcBdof.clear(); mcDmvr.clear(); mcAff.clear(); affMv.clear(); numDmvr = 0;
+    for( int k = 0; k < 3; k++ ) { tb[k].clear(); intra[k].clear(); itemH[k].clear(); prodPool[k].clear(); }
+    intraAll.clear(); units.clear(); unitsDev.clear(); csVpduV.clear(); interAtV.clear();
+    ctuStartV.assign( 3 * (size_t) ( numCtu + 1 ), 0 );
+    for( double& b : bytes ) b = 0;
+  }
+
+  int unitAvail( int chn, int x, int y, int32_t cur ) const
+  {
+    const int cs = chn ? 1 : 0, lx = x << cs, ly = y << cs;
+    if( x < 0 || y < 0 || lx >= h.width || ly >= h.height ) return 0;
+    return order[(size_t) chn * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
+  }
+
+  int mapDecodingOrder( std::string& err );
+  int buildWorkLists( std::string& err );
+  int formUnits();
+  int groupUnits();
+  int emitUnitTable( std::string& err );
+  void layout();
+  void foldLongDepLists();
+  void rankUnits();
+};
+
+PrepScratch* vvr_scratch_create() { return new PrepScratch(); }
+void vvr_scratch_destroy( PrepScratch* s ) { delete s; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// validation
+// ---------------------------------------------------------------------------------------------------------------------
+#define FAIL( code, msg ) do { err = ( msg ); return ( code ); } while( 0 )
+
+int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string& err )
+{
+  const vvr_pic_header& h = p->hdr;
+  if( h.abi_version != VVR_ABI_VERSION ) FAIL( VVR_ERR_PARAMETER, "abi_version mismatch" );
+  if( h.width != cfg.max_width || h.height != cfg.max_height || h.chroma_format != cfg.chroma_format || h.bit_depth != cfg.bit_depth || h.log2_ctu != cfg.log2_ctu )
+    FAIL( VVR_ERR_PARAMETER, "picture geometry differs from the context configuration" );
+  if( ( h.width & 7 ) || ( h.height & 7 ) ) FAIL( VVR_ERR_PARAMETER, "picture size must be a multiple of 8 (minimum CU size)" );
+  if( h.out_slot < 0 || h.out_slot >= cfg.num_slots ) FAIL( VVR_ERR_PARAMETER, "out_slot out of range" );
+  if( h.slice_type > 2 ) FAIL( VVR_ERR_PARAMETER, "unknown slice type" );
+  if( ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && !( h.tool_flags & VVR_TOOL_LMCS ) ) FAIL( VVR_ERR_PARAMETER, "LMCS chroma residual scaling without LMCS" );
+  if( ( h.tool_flags & VVR_TOOL_LMCS ) && !p->lmcs ) FAIL( VVR_ERR_PARAMETER, "LMCS enabled without tables" );
+  const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
+  if( wpOn && !p->wp ) FAIL( VVR_ERR_PARAMETER, "weighted prediction enabled without the weight table" );
+  if( wpOn && ( p->wp->log2_denom[0] > 7 || p->wp->log2_denom[1] > 7 ) ) FAIL( VVR_ERR_PARAMETER, "weighted prediction: log2 denominator out of range" );
+  if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && !p->scaling ) FAIL( VVR_ERR_PARAMETER, "explicit scaling lists enabled without the lists" );
+  if( h.tool_flags & VVR_TOOL_SCALING_LIST )
+    for( int id = 0; id < 28; id++ ) for( int k = 0; k < ( id < 2 ? 4 : id < 8 ? 16 : 64 ); k++ ) if( !p->scaling->coef[id][k] ) FAIL( VVR_ERR_PARAMETER, "scaling list entry 0" );
+  if( !p->cu || !p->tu || !p->coef || !p->lfp[0] || !p->lfp[1] ) FAIL( VVR_ERR_PARAMETER, "missing arrays" );
+  if( ( h.tool_flags & VVR_TOOL_ALF ) && ( !p->alf || !p->alf_params ) ) FAIL( VVR_ERR_PARAMETER, "ALF enabled without parameters" );
+  if( ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) && !p->sao ) FAIL( VVR_ERR_PARAMETER, "SAO enabled without parameters" );
+  if( h.slice_type != 2 )
+    for( int l = 0; l < 2; l++ )
+    {
+      if( h.num_ref[l] < 0 || h.num_ref[l] > VVR_MAX_REFS ) FAIL( VVR_ERR_PARAMETER, "bad number of reference pictures" );
+      for( int i = 0; i < h.num_ref[l]; i++ )
+        if( h.ref_slot[l][i] < 0 || h.ref_slot[l][i] >= cfg.num_slots || h.ref_slot[l][i] == h.out_slot ) FAIL( VVR_ERR_PARAMETER, "bad reference slot" );
+    }
+  const int ncomp = h.chroma_format ? 3 : 1;
+  uint64_t areaLuma = 0, areaChroma = 0;
+  for( uint32_t i = 0; i < p->num_cu; i++ )
+  {
+    const vvr_cu& cu = p->cu[i];
+    if( !cu.w || !cu.h || cu.x + cu.w > h.width || cu.y + cu.h > h.height || cu.first_tu + cu.num_tu > p->num_tu ) FAIL( VVR_ERR_PARAMETER, "CU outside the picture / bad TU range" );
+    if( cu.tree != VVR_TREE_CHROMA ) areaLuma += (uint64_t) cu.w * cu.h;
+    if( cu.tree != VVR_TREE_LUMA ) areaChroma += (uint64_t) cu.w * cu.h;
+    // ---- the CU's transform units: inside the CU, owned by it, coded corners inside the level stream
+    for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+    {
+      const vvr_tu& tu = p->tu[t];
+      if( tu.cu != i ) FAIL( VVR_ERR_PARAMETER, "TU does not name its CU" );
+      if( !tu.w || !tu.h || tu.x < cu.x || tu.y < cu.y || tu.x + tu.w > cu.x + cu.w || tu.y + tu.h > cu.y + cu.h ) FAIL( VVR_ERR_PARAMETER, "TU outside its CU" );
+      if( tu.w > 64 || tu.h > 64 || ( tu.comp_mask & ~( ncomp == 3 ? 7 : 1 ) ) ) FAIL( VVR_ERR_PARAMETER, "TU larger than 64 samples or with components the format does not have" );
+      if( tu.joint_cbcr > 3 ) FAIL( VVR_ERR_PARAMETER, "TU: joint Cb-Cr mode out of range" );
+      for( int c = 0; c < ncomp; c++ )
+      {
+        if( !( tu.comp_mask & ( 1 << c ) ) ) continue;
+        // (joint Cb-Cr: the levels belong to Cb for modes 2 / 3, to Cr for mode 1)
+        const bool coded = ( c && tu.joint_cbcr ) ? c == ( ( tu.joint_cbcr >> 1 ) ? 1 : 2 ) : ( ( tu.cbf >> c ) & 1 ) != 0;
+        if( !coded || !( cu.flags & VVR_CU_ROOT_CBF ) ) continue;
+        const int bw = ( ( c && cu.isp_mode ) ? cu.w : tu.w ) >> ( c ? 1 : 0 ), bh = ( ( c && cu.isp_mode ) ? cu.h : tu.h ) >> ( c ? 1 : 0 );
+        if( tu.mts_idx[c] > VVR_MTS_DCT8_DCT8 || ( tu.tr_type[c] & 3 ) > 2 || ( tu.tr_type[c] >> 2 ) > 2 ) FAIL( VVR_ERR_PARAMETER, "TU: transform type out of range" );
+        const int bdp = c ? cu.bdpcm[1] : cu.bdpcm[0];
+        if( !bdp && ( tu.max_scan_x[c] >= bw || tu.max_scan_y[c] >= bh ) ) FAIL( VVR_ERR_PARAMETER, "TU: last significant position outside the block" );
+        const uint64_t n = bdp ? (uint64_t) bw * bh : (uint64_t) ( tu.max_scan_x[c] + 1 ) * ( tu.max_scan_y[c] + 1 );
+        if( (uint64_t) tu.coef_off[c] + n > p->num_coef ) FAIL( VVR_ERR_PARAMETER, "TU: coded corner outside the level stream" );
+      }
+    }
+    if( cu.pred_mode == VVR_PRED_INTER )
+    {
+      const bool isDmvr = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
+      const bool isAff = cu.mc_mode == VVR_MC_AFFINE;
+      const bool isGeo = cu.mc_mode == VVR_MC_GEO;
+      const bool isSbt = cu.mc_mode == VVR_MC_SBTMVP;
+      if( h.slice_type == 2 ) FAIL( VVR_ERR_PARAMETER, "inter CU in an I picture" );
+      if( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI && cu.mc_mode != VVR_MC_BDOF && !isDmvr && !isAff && !isGeo && !isSbt ) FAIL( VVR_ERR_PARAMETER, "unknown mc_mode" );
+      if( isSbt != ( ( cu.flags & VVR_CU_SBTMVP ) != 0 ) || ( isSbt && ( !p->motion || cu.w < 8 || cu.h < 8 ) ) ) FAIL( VVR_ERR_PARAMETER, "SbTMVP CU: mc_mode / flag mismatch, missing motion field or CU smaller than 8x8" );
+      if( isSbt )
+        for( int y = 0; y < cu.h; y += 8 ) for( int x = 0; x < cu.w; x += 8 )
+        {
+          const vvr_motion& m = p->motion[(size_t) ( ( cu.y + y ) >> 2 ) * ( ( h.width + 3 ) >> 2 ) + ( ( cu.x + x ) >> 2 )];
+          if( ( m.ref_idx[0] < 0 && m.ref_idx[1] < 0 ) || m.ref_idx[0] >= h.num_ref[0] || m.ref_idx[1] >= h.num_ref[1] ) FAIL( VVR_ERR_PARAMETER, "SbTMVP CU: bad sub-block motion" );
+        }
+      if( isGeo != ( ( cu.flags & VVR_CU_GEO ) != 0 ) ) FAIL( VVR_ERR_PARAMETER, "GPM CU: mc_mode / flag mismatch" );
+      if( isGeo )
+      {
+        if( cu.w < 8 || cu.h < 8 || cu.w > 64 || cu.h > 64 || cu.w >= 8 * cu.h || cu.h >= 8 * cu.w || cu.geo_split_dir >= 64 ) FAIL( VVR_ERR_PARAMETER, "GPM CU: size / split direction out of range" );
+        for( int k = 0; k < 2; k++ )
+        {
+          const int l = ( cu.geo_dir_ref[k] >> 4 ) - 1, ri = cu.geo_dir_ref[k] & 15;
+          if( l < 0 || l > 1 || ri >= h.num_ref[l] ) FAIL( VVR_ERR_PARAMETER, "GPM CU: bad reference" );
+        }
+      }
+      if( isAff != ( ( cu.flags & VVR_CU_AFFINE ) != 0 ) || ( isAff && ( !p->motion || cu.w < 8 || cu.h < 8 ) ) ) FAIL( VVR_ERR_PARAMETER, "affine CU: mc_mode / flag mismatch, missing motion field or CU smaller than 8x8" );
+      if( isDmvr && ( !( h.tool_flags & VVR_TOOL_DMVR ) || ( cu.mc_mode == VVR_MC_DMVR_BDOF && !( h.tool_flags & VVR_TOOL_BDOF ) ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
+        FAIL( VVR_ERR_PARAMETER, "mc_mode DMVR on a CU that cannot use DMVR (UnitTools.cpp:1277)" );
+      if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
+        FAIL( VVR_ERR_PARAMETER, "mc_mode BDOF on a CU that cannot use BDOF (InterPrediction.cpp:1407-1427)" );
+      if( ( cu.flags & VVR_CU_CIIP ) && ( ( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI ) || cu.w * cu.h < 64 || cu.w > 64 || cu.h > 64 || cu.num_tu != 1 ) )
+        FAIL( VVR_ERR_PARAMETER, "CIIP CU: needs plain uni/bi prediction, at least 64 luma samples, sides of at most 64 and one TU" );
+      if( cu.bcw_idx > 4 ) FAIL( VVR_ERR_PARAMETER, "BCW index out of range" );
+      for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) FAIL( VVR_ERR_PARAMETER, "ref_idx out of range" );
+      if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo && !isSbt ) FAIL( VVR_ERR_PARAMETER, "inter CU without reference" );
+      if( wpOn && cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 )
+      {
+        // weighted prediction: BDOF / DMVR only between references with default weights (InterPrediction.cpp:1420, UnitTools.cpp:1297-1302);
+        // no identical-motion shortcut (:408)
+        bool present = false;
+        for( int l = 0; l < 2; l++ ) for( int k = 0; k < 3; k++ ) present |= p->wp->e[l][cu.ref_idx[l]][k].present != 0;
+        if( present && ( isDmvr || cu.mc_mode == VVR_MC_BDOF ) ) FAIL( VVR_ERR_PARAMETER, "mc_mode BDOF / DMVR between references with explicit prediction weights" );
+        if( cu.mc_mode == VVR_MC_UNI ) FAIL( VVR_ERR_PARAMETER, "mc_mode UNI on a bi-predicted CU of a picture with weighted prediction" );
+      }
+      if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) FAIL( VVR_ERR_PARAMETER, "inter CU must be single tree" );
+      if( cu.w == 4 && cu.h == 4 ) FAIL( VVR_ERR_PARAMETER, "4x4 inter CU (never inter predicted, InterPrediction.cpp:634)" );
+    }
+    else if( cu.pred_mode == VVR_PRED_INTRA )
+    {
+      if( cu.isp_mode )
+      {
+        // intra sub-partitions (CU::canUseISP, UnitTools.cpp): luma split in four, chroma unsplit in the last TU
+        const uint32_t np = ( ( cu.w == 4 && cu.h == 8 ) || ( cu.w == 8 && cu.h == 4 ) ) ? 2 : 4;      // 4x8 / 8x4: two partitions
+        if( cu.isp_mode > 2 || cu.multi_ref_idx || cu.bdpcm[0] || ( cu.flags & VVR_CU_MIP ) || cu.num_tu != np || cu.w * cu.h <= 16 ) FAIL( VVR_ERR_PARAMETER, "ISP CU: bad split mode, combined with MRL / BDPCM / MIP, or wrong number of TUs" );
+        for( uint32_t k = 0; k < np; k++ )
+        {
+          const vvr_tu& t4 = p->tu[cu.first_tu + k];
+          const bool ok = cu.isp_mode == 1 ? ( t4.x == cu.x && t4.w == cu.w && t4.h * (int) np == cu.h && t4.y == cu.y + (int) k * t4.h ) : ( t4.y == cu.y && t4.h == cu.h && t4.w * (int) np == cu.w && t4.x == cu.x + (int) k * t4.w );
+          if( !ok || ( t4.comp_mask & 6 ) != ( k == np - 1 && h.chroma_format && cu.tree == VVR_TREE_JOINT ? 6 : 0 ) || t4.mts_idx[0] == VVR_MTS_SKIP ) FAIL( VVR_ERR_PARAMETER, "ISP CU: TU layout" );
+        }
+      }
+      if( cu.flags & VVR_CU_MIP )
+      {
+        const int sizeId = ( cu.w == 4 && cu.h == 4 ) ? 0 : ( cu.w == 4 || cu.h == 4 || ( cu.w == 8 && cu.h == 8 ) ) ? 1 : 2;
+        if( cu.intra_dir[0] >= ( sizeId == 0 ? 16 : sizeId == 1 ? 8 : 6 ) || cu.multi_ref_idx || cu.bdpcm[0] ) FAIL( VVR_ERR_PARAMETER, "MIP CU: mode index out of range for the block size, or combined with MRL / BDPCM" );
+      }
+      if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] > 69 ) FAIL( VVR_ERR_PARAMETER, "chroma intra mode out of range" );
+      {
+        // luma-tree CUs go down to 4x4; CUs with chroma need 8 luma samples of width (no 2-wide intra chroma blocks) and 4 of height
+        const int minW = cu.tree == VVR_TREE_LUMA ? 4 : 8;
+        if( cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( cu.tree != VVR_TREE_LUMA && cu.w * cu.h < 64 ) ) FAIL( VVR_ERR_PARAMETER, "intra CU size out of range (luma tree 4..64, with chroma at least 8 wide and 16 chroma samples)" );
+      }
+      if( cu.tree != VVR_TREE_JOINT )
+      {
+        // dual tree (I slices, qtbtt_dual_tree_intra_flag) and local dual tree (intra-only sub-trees of small blocks in any slice):
+        // luma CUs carry luma blocks only, chroma CUs chroma blocks only
+        if( cu.tree > VVR_TREE_CHROMA || !h.chroma_format ) FAIL( VVR_ERR_PARAMETER, "bad tree type" );
+        const int want = cu.tree == VVR_TREE_LUMA ? 1 : 6;
+        for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ ) if( p->tu[t].comp_mask != want ) FAIL( VVR_ERR_PARAMETER, "separate-tree CU: TU component mask" );
+        if( cu.tree == VVR_TREE_CHROMA && ( cu.isp_mode || cu.multi_ref_idx || cu.bdpcm[0] || ( cu.flags & VVR_CU_MIP ) ) ) FAIL( VVR_ERR_PARAMETER, "chroma-tree CU with luma tools" );
+      }
+      if( cu.intra_dir[0] > 66 || cu.multi_ref_idx > 2 || cu.bdpcm[1] ) FAIL( VVR_ERR_UNSUPPORTED, "bad intra mode / chroma BDPCM not implemented" );
+    }
+    else if( cu.pred_mode == VVR_PRED_IBC )
+    {
+      // intra block copy (InterPrediction::xIntraBlockCopy, InterPrediction.cpp:1995): integer block vector in mv[0][0], luma at most 64x64
+      // (IBC_MAX_CU_SIZE), one TU, no intra / inter tools; sizes as for intra CUs.  That the reference block precedes the CU in decoding order
+      // is checked where the work lists are built.
+      if( !( h.tool_flags & VVR_TOOL_IBC ) ) FAIL( VVR_ERR_PARAMETER, "IBC CU in a picture without VVR_TOOL_IBC" );
+      const int minW = cu.tree == VVR_TREE_LUMA ? 4 : 8;
+      if( cu.tree == VVR_TREE_CHROMA || cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( cu.tree != VVR_TREE_LUMA && cu.w * cu.h < 64 ) || cu.num_tu != 1 )
+        FAIL( VVR_ERR_PARAMETER, "IBC CU: chroma tree, size out of range or more than one TU" );
+      if( ( cu.mv[0][0][0] | cu.mv[0][0][1] ) & 15 ) FAIL( VVR_ERR_PARAMETER, "IBC CU: fractional block vector" );
+      if( cu.isp_mode || cu.bdpcm[0] || cu.bdpcm[1] || cu.lfnst_idx || cu.sbt_info || ( cu.flags & ( VVR_CU_MIP | VVR_CU_CIIP | VVR_CU_AFFINE | VVR_CU_GEO | VVR_CU_SBTMVP ) ) )
+        FAIL( VVR_ERR_PARAMETER, "IBC CU combined with an intra / inter tool" );
+      if( cu.tree == VVR_TREE_LUMA && h.chroma_format && p->tu[cu.first_tu].comp_mask != 1 ) FAIL( VVR_ERR_PARAMETER, "separate-tree CU: TU component mask" );
+      const int bvx = cu.mv[0][0][0] >> 4, bvy = cu.mv[0][0][1] >> 4, ctuS = 1 << h.log2_ctu, rowTop = cu.y & ~( ctuS - 1 );
+      const int bufW = 256 * 128 / ctuS;                              // width of the IBC virtual buffer (Rom.h:210, CodingStructure.cpp:543)
+      bool ok = cu.x + bvx >= 0 && cu.x + bvx + cu.w <= h.width && cu.y + bvy >= rowTop && cu.y + bvy + cu.h <= std::min<int>( h.height, rowTop + ctuS )
+             && cu.x + bvx + cu.w <= ( ( cu.x >> h.log2_ctu ) + 1 ) * ctuS && cu.x + bvx >= ( cu.x & ~( ctuS - 1 ) ) - ( bufW - ctuS );
+      if( ok && cu.tree == VVR_TREE_JOINT && h.chroma_format )
+      {
+        const int cxr = ( cu.x >> 1 ) + ( bvx >> 1 ), cyr = ( cu.y >> 1 ) + ( bvy >> 1 );
+        ok = cxr >= 0 && cxr + ( cu.w >> 1 ) <= ( h.width >> 1 ) && cyr >= ( rowTop >> 1 ) && cyr + ( cu.h >> 1 ) <= std::min<int>( h.height, rowTop + ctuS ) >> 1 && 2 * cxr >= ( cu.x & ~( ctuS - 1 ) ) - ( bufW - ctuS );
+      }
+      if( !ok ) FAIL( VVR_ERR_PARAMETER, "IBC CU: reference block outside the picture, the CTU row or the reach of the IBC buffer" );
+    }
+    else FAIL( VVR_ERR_PARAMETER, "unknown prediction mode" );
+  }
+  // the CUs tile the picture: with every CU inside the picture, equal areas leave no cell uncovered unless two CUs overlap (which the device
+  // tolerates: it only ever addresses samples inside the CUs it was given)
+  if( areaLuma != (uint64_t) h.width * h.height || ( h.chroma_format && areaChroma != (uint64_t) h.width * h.height ) ) FAIL( VVR_ERR_PARAMETER, "the CUs do not cover the picture" );
+  return VVR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// work lists
+// ---------------------------------------------------------------------------------------------------------------------
+// decoding order of the transform blocks, cells covered by intra CUs, the luma neighbourhood of every VPDU's chroma scaling factor
+int PrepScratch::mapDecodingOrder( std::string& err )
+{
+  bool anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
+  for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
+  order.clear(); intraAt.clear();
+  if( anyIntra )
+  {
+    const size_t cells = (size_t) w4 * h4;
+    order.assign( cells * 2, 0x7fffffff );
+    intraAt.assign( cells, 0 );
+    for( int k = 0; k < ncomp; k++ ) itemAt[k].assign( cells, -1 );
+    for( uint32_t i = 0; i < p->num_cu; i++ )
+    {
+      const vvr_cu& cu = p->cu[i];
+      // 1: intra CU, 2: CIIP CU (inter prediction blended with planar intra in the intra stage, DecCu.cpp:137-140,453-456)
+      const bool ciip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
+      if( cu.pred_mode == VVR_PRED_INTRA || ciip )
+      {
+        const int cw = ( cu.w + 3 ) >> 2;
+        for( int y = cu.y >> 2; y < ( cu.y + cu.h + 3 ) >> 2; y++ ) memset( &intraAt[(size_t) y * w4 + ( cu.x >> 2 )], ciip ? 2 : 1, cw );
+      }
+      for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+      {
+        const vvr_tu& tu = p->tu[t];
+        for( int chn = 0; chn < 2; chn++ )
+        {
+          if( chn == 0 && !( tu.comp_mask & 1 ) ) continue;
+          if( chn == 1 && !( tu.comp_mask & 6 ) ) continue;
+          int ax = tu.x, ay = tu.y, aw = tu.w, ah = tu.h;
+          if( chn == 1 && cu.isp_mode ) { ax = cu.x; ay = cu.y; aw = cu.w; ah = cu.h; }      // ISP: the unsplit chroma blocks sit in the last TU
+          const int x0 = ax >> 2, x1 = std::min( ( ax + aw + 3 ) >> 2, w4 ), y1 = std::min( ( ay + ah + 3 ) >> 2, h4 );
+          int32_t* base = &order[(size_t) chn * cells];
+          for( int y = ay >> 2; y < y1; y++ ) std::fill( base + (size_t) y * w4 + x0, base + (size_t) y * w4 + x1, (int32_t) t );
+        }
+      }
+    }
+  }
+  if( cscale )
+  {
+    cuAt.assign( (size_t) w4 * h4, -1 );
+    for( uint32_t i = 0; i < p->num_cu; i++ )
+    {
+      const vvr_cu& cu = p->cu[i];
+      if( cu.tree == VVR_TREE_CHROMA ) continue;                     // dual tree: the luma CUs
+      const int x0 = cu.x >> 2, x1 = ( cu.x + cu.w + 3 ) >> 2;
+      for( int y = cu.y >> 2; y < ( cu.y + cu.h + 3 ) >> 2; y++ ) std::fill( &cuAt[(size_t) y * w4 + x0], &cuAt[(size_t) y * w4 + x1], (int32_t) i );
+    }
+    csVpduV.resize( (size_t) vpdusX * vpdusY );
+    for( int vy = 0; vy < vpdusY; vy++ ) for( int vx = 0; vx < vpdusX; vx++ )
+    {
+      const int32_t tl = cuAt[(size_t) ( ( vy << vpduLog2 ) >> 2 ) * w4 + ( ( vx << vpduLog2 ) >> 2 )];
+      if( tl < 0 ) FAIL( VVR_ERR_PARAMETER, "no luma CU at the origin of a VPDU" );
+      const int xPos = p->cu[tl].x, yPos = p->cu[tl].y;
+      bool hasLeft = xPos > 0, hasAbove = yPos > 0;
+      if( hasLeft && ( ( xPos - 1 ) >> h.log2_ctu ) == ( xPos >> h.log2_ctu ) && cuAt[(size_t) ( yPos >> 2 ) * w4 + ( ( xPos - 1 ) >> 2 )] > tl ) hasLeft = false;
+      if( hasAbove && ( ( yPos - 1 ) >> h.log2_ctu ) == ( yPos >> h.log2_ctu ) && cuAt[(size_t) ( ( yPos - 1 ) >> 2 ) * w4 + ( xPos >> 2 )] > tl ) hasAbove = false;
+      csVpduV[(size_t) vy * vpdusX + vx] = (uint32_t) xPos | ( (uint32_t) yPos << 13 ) | ( hasLeft ? 1u << 26 : 0 ) | ( hasAbove ? 1u << 27 : 0 );
+    }
+  }
+  return VVR_OK;
+}
+
+// the work lists: intra-stage blocks with the blocks they read from, motion-compensation tiles, transform blocks
+int PrepScratch::buildWorkLists( std::string& err )
+{
+  uint32_t curCtu = 0;
+  for( uint32_t i = 0; i < p->num_cu; i++ )
+  {
+    const vvr_cu& cu = p->cu[i];
+    // CTU bookkeeping for the per-CTU intra lists (CUs arrive in CTU raster order)
+    const uint32_t ctuOfCu = (uint32_t) ( ( cu.y >> h.log2_ctu ) * ctusX + ( cu.x >> h.log2_ctu ) );
+    {
+      if( ctuOfCu < curCtu ) FAIL( VVR_ERR_PARAMETER, "CUs are not in CTU raster order" );
+      while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
+    }
+    const bool isCiipCu = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
+    // LMCS chroma residual scaling of an inter block: its factor reads reconstructed luma that the intra stage may still have to
+    // produce, and intra blocks next to it read its reconstructed chroma, so the residual add of such a block is an item of the
+    // intra stage too (IT_MODE_RESI_ADD: no prediction, scaled residual onto the inter prediction; finishLMCSAndReco, DecCu.cpp:483)
+    const bool isCsInterCu = cscale && cu.pred_mode == VVR_PRED_INTER && ( !isCiipCu || cu.w == 4 ) && ( cu.flags & VVR_CU_ROOT_CBF );
+    // intra block copy: the block is a copy of reconstructed samples of this picture that the intra stage may still have to produce, so it
+    // is an item of the intra stage as well (IT_MODE_IBC; the reference does it in its intra task too, DecCu.cpp:145)
+    const bool isIbcCu = cu.pred_mode == VVR_PRED_IBC;
+    if( cu.pred_mode == VVR_PRED_INTRA || isCiipCu || isCsInterCu || isIbcCu )
+    {
+      for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+      {
+        const vvr_tu& tu = p->tu[t];
+        for( int comp = 0; comp < ncomp; comp++ )
+        {
+          if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
+          // the 2-wide chroma blocks of a 4-wide CIIP CU are not blended (predBlendIntraCiip, IntraPrediction.cpp:891): plain inter blocks
+          const bool isCiip = isCiipCu && !( comp && cu.w == 4 );
+          const bool isCsInter = cscale && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
+          if( cu.pred_mode != VVR_PRED_INTRA && !isCiip && !isCsInter && !isIbcCu ) continue;
+          if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
+          const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
+          // intra sub-partitions: luma partitions are blocks of their own that share the reference line of the whole CU
+          // (initIntraPatternChTypeISP, IntraPrediction.cpp:966); partitions narrower than 4 are predicted in pairs (DecCu.cpp:333-371):
+          // one item of width 4 carries both; the unsplit chroma blocks come with the last TU
+          const bool ispL = cu.isp_mode && !comp, ispC = cu.isp_mode && comp;
+          const bool ispPair = ispL && cu.isp_mode == 2 && tu.w < 4;                              // group of 4 / tu.w partitions
+          if( ispPair && ( ( tu.x - cu.x ) & 3 ) ) continue;                                      // not the first of its group: part of the group's item
+          const int x0 = ( ispC ? cu.x : tu.x ) >> cs, y0 = ( ispC ? cu.y : tu.y ) >> cs, w = ispPair ? 4 : ( ispC ? cu.w : tu.w ) >> cs, hh = ( ispC ? cu.h : tu.h ) >> cs;
+          // block whose neighbourhood decides the availability of the reference samples
+          const int rx0 = ispL ? cu.x : x0, ry0 = ispL ? cu.y : y0, rw = ispL ? cu.w : w, rh = ispL ? cu.h : hh;
+          const int32_t rcur = ispL ? (int32_t) cu.first_tu : (int32_t) t;
+          const int totalAbove = ( 2 * rw + unit - 1 ) / unit, totalLeft = ( 2 * rh + unit - 1 ) / unit;
+          IntraItem it; memset( &it, 0, sizeof( it ) );
+          it.tu = t; it.comp = (uint8_t) comp;
+          it.x = (uint16_t) x0; it.y = (uint16_t) y0;
+          it.lw = (uint8_t) ilog2i( w ); it.lh = (uint8_t) ilog2i( hh );
+          it.mode = isIbcCu ? IT_MODE_IBC : isCsInter ? IT_MODE_RESI_ADD : isCiip ? 0 : cu.intra_dir[chn];       // CIIP: planar
+          // IBC: the block vector in samples of the component (chroma: halved, InterPrediction.cpp:2010-2011)
+          const int ibcDx = isIbcCu ? ( cu.mv[0][0][0] >> 4 ) >> cs : 0, ibcDy = isIbcCu ? ( cu.mv[0][0][1] >> 4 ) >> cs : 0;
+          if( isIbcCu ) it.tu = ( (uint32_t) ibcDx & 0xffff ) | ( (uint32_t) ibcDy << 16 );
+          bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
+          if( ispL )
+          {
+            // residual flags of the partitions of a group (2 of width 2, or 4 of width 1), geometry of the partition inside its CU
+            uint32_t mask = tu.cbf & 1, grp = 0;
+            if( ispPair )
+            {
+              grp = tu.w == 2 ? 1 : 2;
+              for( uint32_t k = 1; k < 4u / tu.w && t + k < cu.first_tu + cu.num_tu; k++ ) mask |= (uint32_t) ( p->tu[t + k].cbf & 1 ) << k;
+            }
+            it.tu = (uint32_t) ( tu.x - cu.x ) | ( (uint32_t) ( tu.y - cu.y ) << 6 ) | ( (uint32_t) ilog2i( cu.w ) << 12 ) | ( (uint32_t) ilog2i( cu.h ) << 15 )
+                  | ( (uint32_t) ( cu.isp_mode == 2 ) << 18 ) | ( mask << 19 ) | ( grp << 23 );
+            hasResi = mask != 0;
+          }
+          const int bdp = ( isCiip || isCsInter || isIbcCu ) ? 0 : cu.bdpcm[chn];
+          // CIIP blend weight of the intra part (IntraPrediction::predBlendIntraCiip, IntraPrediction.cpp:925-929): 1 + intra neighbours
+          const int wIntra = isCiip ? 1 + ( cu.ciip_neigh_intra & 1 ) + ( ( cu.ciip_neigh_intra >> 1 ) & 1 ) : 0;
+          it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | ( bdp == 1 ? IT_F_BDPCM_H : bdp == 2 ? IT_F_BDPCM_V : 0 ) | ( ( comp || isCiip || isCsInter || isIbcCu ? 0 : cu.multi_ref_idx ) << 4 ) | ( wIntra << 6 ) );
+          if( !comp && !isCiip && ( cu.flags & VVR_CU_MIP ) ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_MIP | ( ( cu.flags & VVR_CU_MIP_TRANSP ) ? 0x10 : 0 ) );
+          if( ispL ) it.flags = (uint8_t) ( ( hasResi ? IT_F_RESI : 0 ) | IT_F_ISP );
+          const bool noRef = isCsInter || isIbcCu;                                  // no intra reference lines
+          if( !noRef ) it.nTL = (uint8_t) unitAvail( chn, rx0 - 1, ry0 - 1, rcur );
+          if( !noRef && unitAvail( chn, rx0, ry0 - 1, rcur ) ) { int n = rw / unit; for( int k = 0; k < totalAbove - rw / unit; k++ ) { if( !unitAvail( chn, rx0 + rw + k * unit, ry0 - 1, rcur ) ) break; n++; } it.nA = (uint8_t) n; }
+          if( !noRef && unitAvail( chn, rx0 - 1, ry0, rcur ) ) { int n = rh / unit; for( int k = 0; k < totalLeft - rh / unit; k++ ) { if( !unitAvail( chn, rx0 - 1, ry0 + rh + k * unit, rcur ) ) break; n++; } it.nL = (uint8_t) n; }
+          int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0; bool isCclm = false;
+          const bool csItem = cscale && comp && hasResi && w * hh > 4;             // DecCu.cpp:383-388 / :500-505
+          if( csItem ) it.flags |= IT_F_CSCALE;
+          if( comp && !isCiip && !isCsInter && !isIbcCu && cu.intra_dir[1] >= 67 )
+          {
+            // CCLM / MDLM: template sizes and flags of IntraPrediction::xGetLMParameters (:1694-1800) and the border handling of
+            // xGetLumaRecPixels (:1403-1470); they ride in the item's `tu` word
+            const int mode = cu.intra_dir[1];
+            const bool aboveCu = cu.y > 0 || ( y0 << 1 ) > cu.y, leftCu = cu.x > 0 || ( x0 << 1 ) > cu.x;          // cu.above / cu.left (one slice, one tile)
+            const int tuWU = w / unit, tuHU = hh / unit;
+            const int totA = ( 2 * w + unit - 1 ) / unit, totL = ( 2 * hh + unit - 1 ) / unit;
+            int aboveAvail = 0, leftAvail = 0, actualTop = 0, actualLeft = 0;
+            if( mode == 69 )
+            {
+              int avai = 0;
+              if( aboveCu ) { avai = tuWU; const int lim = std::min( totA - tuWU, hh / unit ); for( int k = 0; k < lim; k++ ) { if( !unitAvail( 1, x0 + w + k * unit, y0 - 1, (int32_t) t ) ) break; avai++; } }
+              aboveAvail = avai >= tuWU; actualTop = unit * avai;
+            }
+            else if( mode == 68 )
+            {
+              int avai = 0;
+              if( leftCu ) { avai = tuHU; const int lim = std::min( totL - tuHU, w / unit ); for( int k = 0; k < lim; k++ ) { if( !unitAvail( 1, x0 - 1, y0 + hh + k * unit, (int32_t) t ) ) break; avai++; } }
+              leftAvail = avai >= tuHU; actualLeft = unit * avai;
+            }
+            else { aboveAvail = aboveCu; leftAvail = leftCu; actualTop = w; actualLeft = hh; }
+            const int bLeft = leftCu ? 1 : 0;                                                          // availlableLeftUnit >= iTUHeightInUnits
+            const int firstRow = ( ( y0 << 1 ) & ( ( 1 << h.log2_ctu ) - 1 ) ) == 0;
+            it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 ) | ( (uint32_t) ( aboveCu ? 1 : 0 ) << 20 );
+            cclmTop = aboveAvail ? actualTop : 0; cclmLeft = leftAvail ? actualLeft : 0; cclmBLeft = bLeft; isCclm = true;
+          }
+          // ---- the blocks this one reads from, its part of the CTU tile
+          const uint32_t myId = (uint32_t) intra[comp].size();
+          intra[comp].push_back( it );
+          std::vector<uint32_t>& pool = prodPool[comp];
+          ItemH IH; IH.ctu = ctuOfCu; IH.p0 = (uint32_t) pool.size(); IH.pn = 0;
+          {
+            const int ctuX = cu.x >> h.log2_ctu, ctuY = cu.y >> h.log2_ctu;
+            const int mrl = ( comp || isIbcCu ) ? 0 : cu.multi_ref_idx;
+            uint32_t lastKey = 0xffffffffu;
+            auto touch = [&]( int k, int xc, int yc )   // component k, component coordinates of a sample that is read
+            {
+              const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
+              if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
+              const int32_t d = itemAt[k][(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )];
+              if( d < 0 ) return;
+              const uint32_t key = ( (uint32_t) k << 28 ) | (uint32_t) d;
+              if( key == lastKey || ( k == comp && (uint32_t) d == myId ) ) return;      // (neighbouring cells mostly belong to the same block)
+              lastKey = key;
+              if( std::find( pool.begin() + IH.p0, pool.end(), key ) == pool.end() ) pool.push_back( key );
+            };
+            {
+              // bounding box of everything the kernel's reference fill may read for this block (whole top / left lines incl. padding sources)
+              const int S = ( 1 << h.log2_ctu ) >> cs, ox = ctuX * S, oy = ctuY * S;
+              BBox& bb = IH.bb;
+              const int bx0 = rx0 - 1 - mrl, bx1 = rx0 + std::max( 2 * rw, 1 ) + 1, by0 = ry0 - 1 - mrl, by1 = ry0 + 2 * rh + 1;
+              bb.y0 = std::min( bb.y0, std::max( 0, by0 - ( oy - 3 ) ) );
+              bb.y1 = std::max( bb.y1, std::min( S + 3, by1 - ( oy - 3 ) ) );
+              bb.c0 = std::min( bb.c0, std::max( 0, ( bx0 - ( ox - 8 ) ) >> 3 ) );
+              bb.c1 = std::max( bb.c1, std::min( ( 8 + S + 64 + 7 ) >> 3, ( bx1 - ( ox - 8 ) + 7 ) >> 3 ) );
+            }
+            if( it.nTL ) touch( comp, rx0 - 1 - mrl, ry0 - 1 - mrl );
+            for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, rx0 + k, ry0 - 1 - mrl );
+            for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, rx0 - 1 - mrl, ry0 + k );
+            if( ispL && ( x0 != rx0 || y0 != ry0 ) ) touch( 0, cu.isp_mode == 2 ? x0 - 1 : x0, cu.isp_mode == 2 ? y0 : y0 - 1 );   // ISP: the previous partition
+            if( isIbcCu )
+            {
+              // the reference block: every cell must precede this block in decoding order; the intra-stage blocks that produce it are producers
+              const int qx = x0 + ibcDx, qy = y0 + ibcDy;
+              for( int yy = 0; yy < hh + unit - 1; yy += unit ) for( int xx = 0; xx < w + unit - 1; xx += unit )
+              {
+                const int sx = qx + std::min( xx, w - 1 ), sy = qy + std::min( yy, hh - 1 );
+                if( !unitAvail( chn, sx, sy, (int32_t) t ) ) FAIL( VVR_ERR_PARAMETER, "IBC CU: the reference block is not reconstructed before the CU" );
+                touch( comp, sx, sy );
+              }
+            }
+            if( csItem )
+            {
+              // luma the chroma scaling factor is averaged over (the unit must wait for the luma units that reconstruct it)
+              const uint32_t d = csVpduV[(size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 )];
+              const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff, n = 1 << vpduLog2;
+              if( ( d >> 26 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, xPos - 1, std::min( yPos + k, (int) h.height - 1 ) );
+              if( ( d >> 27 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, std::min( xPos + k, (int) h.width - 1 ), yPos - 1 );
+            }
+            if( isCclm )
+            {
+              // luma the prediction reads: the co-located block and the template rows / columns around it (luma coordinates)
+              const int lx0 = x0 << 1, ly0 = y0 << 1;
+              for( int yy = 0; yy < 2 * hh; yy += 4 ) for( int xx = ( cclmBLeft ? -4 : 0 ); xx < 2 * w; xx += 4 ) touch( 0, lx0 + xx, ly0 + yy );
+              for( int xx = ( cclmBLeft ? -4 : 0 ); xx < 2 * cclmTop + 4; xx += 4 ) touch( 0, lx0 + xx, ly0 - 1 );
+              for( int yy = 0; yy < 2 * cclmLeft + 4; yy += 4 ) touch( 0, lx0 - 1, ly0 + yy );
+            }
+            // the cells this block reconstructs
+            {
+              const int cx0 = ( x0 << cs ) >> 2, cx1 = std::min( ( ( ( x0 + w ) << cs ) + 3 ) >> 2, w4 ), cy1 = std::min( ( ( ( y0 + hh ) << cs ) + 3 ) >> 2, h4 );
+              for( int cy = ( y0 << cs ) >> 2; cy < cy1; cy++ ) std::fill( &itemAt[comp][(size_t) cy * w4 + cx0], &itemAt[comp][(size_t) cy * w4 + std::max( cx0, cx1 )], (int32_t) myId );
+            }
+          }
+          IH.pn = (uint32_t) pool.size() - IH.p0;
+          itemH[comp].push_back( IH );
+          bytes[K_INTRA] += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
+        }
+      }
+    }
+    if( cu.pred_mode == VVR_PRED_INTER )
+    {
+      const int nl = cu.mc_mode == VVR_MC_UNI ? 1 : 2;     // (SbTMVP: upper bound, sub-blocks may be uni-directional)
+      const bool sbt = cu.mc_mode == VVR_MC_SBTMVP;
+      const int ts = sbt ? 8 : 16;                       // SbTMVP: one item per 8x8 sub-block (ATMVP_SUB_BLOCK_SIZE)
+      const bool dm = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
+      const bool af = cu.mc_mode == VVR_MC_AFFINE;
+      std::vector<McItem>& list = dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc;
+      const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
+      for( int y = 0; y < cu.h; y += ts ) for( int x = 0; x < cu.w; x += ts )
+      {
+        McItem it; memset( &it, 0, sizeof( it ) );
+        it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y ); it.flags = sbt ? MC_ITEM_SUBBLOCK : 0; it.cu = i;
+        if( af )
+        {
+          // the motion of the tile's 4x4 sub-blocks (MotionInfo of the affine CU, filled by PU::setAllAffineMv, UnitTools.cpp:3005): the kernel reads
+          // them from a compact array, 4 x 4 entries per tile, so the motion field itself never crosses PCIe
+          it.mv[0][0] = (int32_t) affMv.size();
+          const size_t base = affMv.size();
+          affMv.resize( base + 16 );
+          for( int sy = 0; sy < it.h >> 2; sy++ ) memcpy( &affMv[base + 4 * sy], &p->motion[(size_t) ( ( it.y >> 2 ) + sy ) * w4 + ( it.x >> 2 )], sizeof( vvr_motion ) * ( it.w >> 2 ) );
+        }
+        else if( !dm )
+        {
+          // everything k_mc needs about the motion of the tile
+          bool uni = cu.mc_mode == VVR_MC_UNI;
+          it.ref[0] = cu.ref_idx[0]; it.ref[1] = cu.ref_idx[1];
+          for( int l = 0; l < 2; l++ ) { it.mv[l][0] = cu.mv[l][0][0]; it.mv[l][1] = cu.mv[l][0][1]; }
+          it.clipX = cu.x; it.clipY = cu.y;
+          if( sbt )
+          {
+            // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the motion of the 8x8 sub-block from the motion field, the identical-motion
+            // shortcut (xCheckIdenticalMotion :404, not with weighted bi-prediction :408) decided per sub-block, clipped at its own position
+            const vvr_motion& m = p->motion[(size_t) ( it.y >> 2 ) * w4 + ( it.x >> 2 )];
+            for( int l = 0; l < 2; l++ ) { it.ref[l] = m.ref_idx[l]; it.mv[l][0] = m.mv[l][0]; it.mv[l][1] = m.mv[l][1]; }
+            const bool two = it.ref[0] >= 0 && it.ref[1] >= 0;
+            uni = !two || ( h.ref_poc[0][it.ref[0]] == h.ref_poc[1][it.ref[1]] && it.mv[0][0] == it.mv[1][0] && it.mv[0][1] == it.mv[1][1] && !wpOn );
+            it.clipX = it.x; it.clipY = it.y;
+          }
+          it.bcw = cu.bcw_idx;
+          it.flags |= ( uni ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 );
+        }
+        list.push_back( it );
+        const double smp = (double) it.w * it.h * ( ncomp == 3 ? 1.5 : 1.0 );
+        bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += smp * 2 * nla + smp * 2 + sizeof( McItem ) + ( dm ? 8 : 0 ) + ( af ? it.w * it.h / 16.0 * sizeof( vvr_motion ) : 0 );
+      }
+      if( dm ) numDmvr = std::max<uint32_t>( numDmvr, cu.dmvr_off + ( ( cu.w + 15 ) / 16 ) * ( ( cu.h + 15 ) / 16 ) );
+      bytes[K_MC] += sizeof( vvr_cu );
+    }
+    if( !( cu.flags & VVR_CU_ROOT_CBF ) ) continue;
+    for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+    {
+      const vvr_tu& tu = p->tu[t];
+      for( int comp = 0; comp < ncomp; comp++ )
+      {
+        if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
+        TbItem it; it.tu = t; it.comp = (uint8_t) comp; it.ict = 0; it.pad = 0;
+        it.mode = ( cu.pred_mode == VVR_PRED_INTER && ( !( cu.flags & VVR_CU_CIIP ) || ( comp && cu.w == 4 ) ) ) ? TB_ADD : TB_STORE;      // (2-wide chroma of a 4-wide CIIP CU: plain inter)
+        if( comp && tu.joint_cbcr )
+        {
+          if( comp != 1 ) continue;
+          static const int ict[2][4] = { { 0, 3, 1, 2 }, { 0, -3, -1, -2 } };           // g_ictModes (Rom.cpp:409)
+          it.comp = (uint8_t) ( ( tu.joint_cbcr >> 1 ) ? 1 : 2 );
+          it.ict = (uint8_t) ( 4 + ict[( h.tool_flags & VVR_TOOL_JCCR_SIGN ) ? 1 : 0][tu.joint_cbcr] );
+        }
+        else if( !( tu.cbf & ( 1 << comp ) ) ) continue;
+        const int bw = ( ( it.comp && cu.isp_mode ) ? cu.w : tu.w ) >> ( it.comp ? 1 : 0 ), bh = ( ( it.comp && cu.isp_mode ) ? cu.h : tu.h ) >> ( it.comp ? 1 : 0 );
+        if( ( bw < 2 || bh < 2 ) && !( cu.isp_mode && !it.comp && bw * bh >= 16 ) ) FAIL( VVR_ERR_PARAMETER, "1-D transform block outside an ISP CU" );
+        const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
+        // LMCS chroma residual scaling of an inter block: the factor needs the reconstructed luma around the VPDU, which the intra stage
+        // may still have to produce, so the block's residual is stored and added (scaled) by a residual-add item of the intra stage
+        if( cscale && it.comp && it.mode == TB_ADD && bw * bh > 4 ) it.mode = TB_STORE;      // added (scaled) by the intra stage, see isCsInter above
+        tb[cls].push_back( it );        // ADD (inter: onto the prediction) and STORE (intra / CIIP: into the residual planes) items share a launch
+        const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];
+        const double ncoef = bdp ? (double) bw * bh : (double) ( tu.max_scan_x[it.comp] + 1 ) * ( tu.max_scan_y[it.comp] + 1 );
+        bytes[K_ITRANS] += ncoef * 2 + (double) bw * bh * 4 * ( it.ict ? 2 : 1 ) + sizeof( TbItem ) + sizeof( vvr_tu ) / 3.0;
+      }
+    }
+  }
+  return VVR_OK;
+}
+
+// a unit lists at most VVR_INTRA_MAX_DEPS producers: longer lists are folded through empty join units
+void PrepScratch::foldLongDepLists()
+{
+  for( size_t u = 0; u < units.size(); u++ )
+    while( units[u].deps.size() > VVR_INTRA_MAX_DEPS )
+    {
+      UnitH j; j.comp = units[u].comp; j.ctu = units[u].ctu; j.i0 = j.i1 = j.iA = units[u].i0; j.bb.y0 = j.bb.y1 = 0; j.bb.c0 = j.bb.c1 = 1;
+      j.deps.assign( units[u].deps.end() - VVR_INTRA_MAX_DEPS, units[u].deps.end() );
+      units[u].deps.resize( units[u].deps.size() - VVR_INTRA_MAX_DEPS );
+      units[u].deps.push_back( (uint32_t) units.size() );
+      units.push_back( j );
+    }
+}
+
+// rank = length of the longest dependency chain below a unit (the unit graph is acyclic: luma never reads chroma, residual-add units only
+// read luma, other CTUs' units only earlier CTUs'); computed by relaxation in creation order until stable
+void PrepScratch::rankUnits()
+{
+  for( auto& U : units ) U.rank = 0;
+  bool changed = true;
+  for( size_t pass = 0; changed && pass <= units.size(); pass++ )      // (acyclic: stable after at most one pass per level; creation order makes it 2-3)
+  {
+    changed = false;
+    for( auto& U : units ) for( uint32_t d : U.deps ) if( units[d].rank + 1 > U.rank ) { U.rank = units[d].rank + 1; changed = true; }
+  }
+}
+
+int PrepScratch::formUnits()
+{
+  // ---- form the units: blocks of one (component, CTU) that read from each other belong together (union-find); the residual-add items of
+  // inter blocks (LMCS chroma scaling) of a (component, CTU) form a unit of their own that the kernel processes in parallel
+  for( int k = 0; k < ncomp; k++ )
+  {
+    const size_t n = intra[k].size();
+    if( !n ) continue;
+    const std::vector<uint32_t>& pool = prodPool[k];
+    parent.resize( n );
+    for( size_t i = 0; i < n; i++ ) parent[i] = (uint32_t) i;
+    auto find = [&]( uint32_t a ) { while( parent[a] != a ) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+    auto unite = [&]( uint32_t a, uint32_t b ) { a = find( a ); b = find( b ); if( a != b ) parent[std::max( a, b )] = std::min( a, b ); };     // root = first block
+    int64_t bulk = -1; uint32_t bulkCtu = 0;
+    for( size_t i = 0; i < n; i++ )
+    {
+      const bool ra = intra[k][i].mode == IT_MODE_RESI_ADD && k;
+      if( ra ) { if( bulk >= 0 && bulkCtu == itemH[k][i].ctu ) unite( (uint32_t) bulk, (uint32_t) i ); else { bulk = (int64_t) i; bulkCtu = itemH[k][i].ctu; } continue; }
+      const ItemH& ih = itemH[k][i];
+      for( uint32_t q = ih.p0; q < ih.p0 + ih.pn; q++ )
+      {
+        const uint32_t key = pool[q], pk = key >> 28, pi = key & 0x0fffffff;
+        if( (int) pk == k && itemH[k][pi].ctu == ih.ctu && !( intra[k][pi].mode == IT_MODE_RESI_ADD && k ) ) unite( (uint32_t) i, pi );
+      }
+    }
+    // units in the order of their first block; blocks of a unit contiguous and in coding order
+    unitOfRoot.assign( n, -1 );
+    size_t numMembers = 0;
+    for( size_t i = 0; i < n; i++ )
+    {
+      const uint32_t r = find( (uint32_t) i );
+      if( unitOfRoot[r] < 0 ) { unitOfRoot[r] = (int32_t) numMembers; if( members.size() <= numMembers ) members.emplace_back(); members[numMembers].clear(); numMembers++; }
+      members[unitOfRoot[r]].push_back( (uint32_t) i );
+    }
+    std::vector<IntraItem>& sorted = intraTmp[k]; sorted.clear(); sorted.reserve( n );
+    std::vector<ItemH>& sortedH = itemHTmp; sortedH.clear(); sortedH.reserve( n );
+    newIdx.resize( n );
+    for( size_t mi = 0; mi < numMembers; mi++ )
+    {
+      const std::vector<uint32_t>& m = members[mi];
+      UnitH u; u.comp = (uint32_t) k; u.ctu = itemH[k][m[0]].ctu; u.i0 = (uint32_t) sorted.size();
+      for( uint32_t i : m )
+      {
+        newIdx[i] = (uint32_t) sorted.size();
+        sorted.push_back( intra[k][i] ); sortedH.push_back( itemH[k][i] );
+        const BBox& b = sortedH.back().bb;
+        u.bb.y0 = std::min( u.bb.y0, b.y0 ); u.bb.y1 = std::max( u.bb.y1, b.y1 ); u.bb.c0 = std::min( u.bb.c0, b.c0 ); u.bb.c1 = std::max( u.bb.c1, b.c1 );
+        if( k && ( intra[k][i].flags & IT_F_CSCALE ) ) u.hasCs = true;
+      }
+      u.i1 = (uint32_t) sorted.size();
+      u.iA = ( k && sorted[u.i0].mode == IT_MODE_RESI_ADD ) ? u.i1 : u.i0;
+      units.push_back( std::move( u ) );
+    }
+    intra[k].swap( sorted ); itemH[k].swap( sortedH );
+    // block index -> its new place, in every producer list that names a block of component k (chroma never is a producer for luma, and
+    // components are processed in ascending order, so every reference to component k is fixed here)
+    for( int k2 = k; k2 < ncomp; k2++ ) for( uint32_t& key : prodPool[k2] ) if( (int) ( key >> 28 ) == k ) key = ( (uint32_t) k << 28 ) | newIdx[key & 0x0fffffff];
+    // the per-CTU offsets follow the new order (units, hence blocks, stay grouped by CTU)
+    {
+      uint32_t* cnt = &ctuStartV[(size_t) k * ( numCtu + 1 )];
+      std::fill( cnt, cnt + numCtu + 1, 0u );
+      for( auto& ih : itemH[k] ) cnt[ih.ctu + 1]++;
+      for( int a = 0; a < numCtu; a++ ) cnt[a + 1] += cnt[a];
+    }
+  }
+  // dependencies between units
+  {
+    for( int k = 0; k < ncomp; k++ ) unitOfItem[k].assign( intra[k].size(), 0 );
+    for( size_t u = 0; u < units.size(); u++ ) for( uint32_t i = units[u].i0; i < units[u].i1; i++ ) unitOfItem[units[u].comp][i] = (uint32_t) u;
+    for( size_t u = 0; u < units.size(); u++ )
+    {
+      UnitH& U = units[u];
+      const std::vector<uint32_t>& pool = prodPool[U.comp];
+      uint32_t last = 0xffffffffu;
+      for( uint32_t i = U.i0; i < U.i1; i++ )
+      {
+        const ItemH& ih = itemH[U.comp][i];
+        for( uint32_t q = ih.p0; q < ih.p0 + ih.pn; q++ )
+        {
+          const uint32_t d = unitOfItem[pool[q] >> 28][pool[q] & 0x0fffffff];
+          if( d == u || d == last ) continue;
+          last = d;
+          if( std::find( U.deps.begin(), U.deps.end(), d ) == U.deps.end() ) U.deps.push_back( d );
+        }
+      }
+    }
+    foldLongDepLists();
+    rankUnits();
+  }
+  return VVR_OK;
+}
+
+int PrepScratch::groupUnits()
+{
+  // ---- group the clusters of one (component, CTU) that sit at the same depth of the dependency graph into one unit: they cannot depend
+  // on each other, a workgroup start costs more than a few small blocks, and waiting for the union of their producers delays nothing
+  // that matters (all of them are less deep).  Residual-add units keep their own (HBM to HBM) workgroup.
+  if( units.empty() ) return VVR_OK;
+  target.assign( units.size(), -1 );            // original unit -> group
+  size_t numGroups = 0;                         // groups: original units in creation order
+  auto newGroup = [&]() { if( groups.size() <= numGroups ) groups.emplace_back(); groups[numGroups].clear(); return numGroups++; };
+  {
+    std::vector<std::pair<uint64_t, uint32_t>> keyed; keyed.reserve( units.size() );
+    for( size_t u = 0; u < units.size(); u++ )
+    {
+      const bool own = units[u].iA == units[u].i1;             // residual-add unit (or empty): not grouped
+      keyed.emplace_back( own ? ( ( (uint64_t) 1 << 63 ) | u ) : ( ( (uint64_t) units[u].comp << 56 ) | ( (uint64_t) units[u].ctu << 24 ) | (uint64_t) std::min( units[u].rank, 0xffffff ) ), (uint32_t) u );
+    }
+    std::stable_sort( keyed.begin(), keyed.end(), []( const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y ) { return x.first < y.first; } );
+    const uint32_t groupMax = 12;               // blocks per grouped unit: a serial workgroup should stay short
+    for( size_t i = 0; i < keyed.size(); )
+    {
+      size_t j = i; const size_t g = newGroup();
+      uint32_t blocks = 0;
+      while( j < keyed.size() && keyed[j].first == keyed[i].first )
+      {
+        const uint32_t nb = units[keyed[j].second].i1 - units[keyed[j].second].i0;
+        if( blocks && blocks + nb > groupMax ) break;                   // start another one
+        blocks += nb;
+        groups[g].push_back( keyed[j].second ); target[keyed[j].second] = (int32_t) g; j++;
+      }
+      i = j;
+    }
+  }
+  // groups in the order of their first original unit (keeps the blocks grouped by CTU)
+  std::vector<uint32_t> orderM( numGroups );
+  for( size_t m = 0; m < numGroups; m++ ) orderM[m] = (uint32_t) m;
+  std::stable_sort( orderM.begin(), orderM.end(), [&]( uint32_t x, uint32_t y ) { return groups[x][0] < groups[y][0]; } );
+  for( int k = 0; k < 3; k++ ) intraTmp[k].clear();
+  std::vector<UnitH>& merged = unitsTmp; merged.clear();
+  std::vector<uint32_t>& newIndexOfGroup = newIdx; newIndexOfGroup.assign( numGroups, 0 );
+  for( uint32_t m : orderM )
+  {
+    const UnitH& f = units[groups[m][0]];
+    UnitH U; U.comp = f.comp; U.ctu = f.ctu; U.i0 = (uint32_t) intraTmp[f.comp].size();
+    for( uint32_t u : groups[m] )
+    {
+      const UnitH& o = units[u];
+      intraTmp[o.comp].insert( intraTmp[o.comp].end(), intra[o.comp].begin() + o.i0, intra[o.comp].begin() + o.i1 );
+      U.bb.y0 = std::min( U.bb.y0, o.bb.y0 ); U.bb.y1 = std::max( U.bb.y1, o.bb.y1 ); U.bb.c0 = std::min( U.bb.c0, o.bb.c0 ); U.bb.c1 = std::max( U.bb.c1, o.bb.c1 );
+      U.hasCs = U.hasCs || o.hasCs;
+    }
+    U.i1 = (uint32_t) intraTmp[f.comp].size();
+    U.iA = f.iA == f.i1 ? U.i1 : U.i0;
+    newIndexOfGroup[m] = (uint32_t) merged.size();
+    merged.push_back( std::move( U ) );
+  }
+  for( size_t m = 0; m < numGroups; m++ )
+  {
+    UnitH& U = merged[newIndexOfGroup[m]];
+    for( uint32_t u : groups[m] ) for( uint32_t d : units[u].deps )
+    {
+      const uint32_t nd = newIndexOfGroup[target[d]];
+      if( nd != newIndexOfGroup[m] && std::find( U.deps.begin(), U.deps.end(), nd ) == U.deps.end() ) U.deps.push_back( nd );
+    }
+  }
+  for( int k = 0; k < ncomp; k++ ) intra[k].swap( intraTmp[k] );
+  units.swap( merged );
+  foldLongDepLists();
+  rankUnits();
+  return VVR_OK;
+}
+
+int PrepScratch::emitUnitTable( std::string& err )
+{
+  // one item array for the three components; active (component, CTU) pairs in raster order
+  uint32_t itemBase[3] = { 0, 0, 0 };
+  for( int k = 0; k < 3; k++ )
+  {
+    itemBase[k] = (uint32_t) intraAll.size();
+    intraAll.insert( intraAll.end(), intra[k].begin(), intra[k].end() );
+  }
+  // device unit table: units that wait for nothing first (they can never block a resident workgroup slot), then the others by depth of the
+  // dependency graph and along the CTU wavefront; a unit only ever waits for units that hold a lower ticket
+  {
+    perm.clear(); inv.assign( units.size(), 0 );
+    for( size_t t = 0; t < units.size(); t++ ) if( units[t].deps.empty() ) perm.push_back( (uint32_t) t );
+    {
+      // dependent units by depth first (every producer is less deep, hence holds a lower ticket; units of one depth start together, so few of
+      // them find a producer that has not even started), then in WAVEFRONT order (key = ctuX + 2 * ctuY): the workgroups that are resident at
+      // any time are the ones on or near the current front.  Measured 7 % faster on B pictures than wavefront-major order, the same on intra
+      // pictures where depth and wavefront coincide.
+      const size_t first = perm.size();
+      for( size_t t = 0; t < units.size(); t++ ) if( !units[t].deps.empty() ) perm.push_back( (uint32_t) t );
+      std::stable_sort( perm.begin() + first, perm.end(), [&]( uint32_t a, uint32_t b )
+      {
+        const int ka = (int) ( units[a].ctu % ctusX ) + 2 * (int) ( units[a].ctu / ctusX ), kb = (int) ( units[b].ctu % ctusX ) + 2 * (int) ( units[b].ctu / ctusX );
+        return units[a].rank != units[b].rank ? units[a].rank < units[b].rank : ka < kb;
+      } );
+    }
+    for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
+    for( auto& u : units ) for( uint32_t d : u.deps ) units[d].waited = true;
+    unitCount.assign( 3 * (size_t) numCtu, 0 );
+    for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
+    unitsDev.resize( units.size() );
+    for( size_t t = 0; t < perm.size(); t++ )
+    {
+      const UnitH& u = units[perm[t]];
+      IntraUnit& d = unitsDev[t]; memset( &d, 0, sizeof( d ) );
+      // bit 31: the unit is the whole (component, CTU) and every sample of the CTU is intra, so the kernel only stages the reference
+      // border and writes the CTU back with 16-byte stores
+      bool all = unitCount[(size_t) u.comp * numCtu + u.ctu] == 1;
+      {
+        const int ctu4 = 1 << ( h.log2_ctu - 2 ), ux = (int) ( u.ctu % ctusX ) * ctu4, uy = (int) ( u.ctu / ctusX ) * ctu4;
+        for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
+      }
+      d.ent = ( u.comp << 24 ) | u.ctu | ( u.hasCs ? 0x20000000u : 0 ) | ( u.waited ? 0x40000000u : 0 ) | ( all ? 0x80000000u : 0 );
+      d.i0 = itemBase[u.comp] + u.i0; d.i1 = itemBase[u.comp] + u.i1; d.iA = itemBase[u.comp] + u.iA;
+      d.bbox = (uint32_t) u.bb.y0 | ( (uint32_t) u.bb.y1 << 8 ) | ( (uint32_t) u.bb.c0 << 16 ) | ( (uint32_t) u.bb.c1 << 24 );
+      d.ndeps = (uint32_t) std::min<size_t>( u.deps.size(), VVR_INTRA_MAX_DEPS );
+      if( u.deps.size() > VVR_INTRA_MAX_DEPS ) FAIL( VVR_ERR_UNSPECIFIED, "internal: intra unit with too many dependencies" );
+      for( uint32_t k = 0; k < d.ndeps; k++ ) d.deps[k] = inv[u.deps[k]];
+    }
+  }
+  return VVR_OK;
+}
+
+void PrepScratch::layout()
+{
+  const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
+  bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
+  bytes[K_SAO] = samples * 4; bytes[K_ALF] = samples * 4; bytes[K_COPY] = samples * 4;
+  // LMCS, per launch: the inverse pass reads and writes every luma sample; the forward pass those of the inter CUs (upper bound: all)
+  if( lmcs ) bytes[K_LMCS] = (double) h.width * h.height * 4;
+  parts.clear(); total = 0;
+  auto add = [&]( const void* src, size_t n ) { Part q{ src, n, total }; parts.push_back( q ); total += alignUp( std::max<size_t>( n, 16 ), 256 ); return (int) parts.size() - 1; };
+  iCu = add( p->cu, sizeof( vvr_cu ) * p->num_cu );
+  iTu = add( p->tu, sizeof( vvr_tu ) * p->num_tu );
+  iCoef = add( p->coef, sizeof( int16_t ) * (size_t) p->num_coef );
+  iAffMv = add( affMv.data(), sizeof( vvr_motion ) * affMv.size() );
+  iL0 = add( p->lfp[0], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+  iL1 = add( p->lfp[1], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+  iSao = p->sao ? add( p->sao, sizeof( vvr_sao_ctu ) * numCtu ) : -1;
+  iAlf = p->alf ? add( p->alf, sizeof( vvr_alf_ctu ) * numCtu ) : -1;
+  iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
+  if( lmcs )
+  {
+    interAtV.assign( (size_t) w4 * h4 + 8, 0 );
+    for( uint32_t i = 0; i < p->num_cu; i++ )
+    {
+      const vvr_cu& cu = p->cu[i];
+      if( cu.pred_mode != VVR_PRED_INTER ) continue;
+      for( int y = cu.y >> 2; y < ( cu.y + cu.h + 3 ) >> 2; y++ ) memset( &interAtV[(size_t) y * w4 + ( cu.x >> 2 )], 1, ( cu.w + 3 ) >> 2 );
+    }
+  }
+  iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
+  iSl = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? add( p->scaling, sizeof( vvr_scaling_list ) ) : -1;
+  iWp = wpOn ? add( p->wp, sizeof( vvr_wp_params ) ) : -1;
+  iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
+  iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
+  iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
+  iMcB = add( mcBdof.data(), sizeof( McItem ) * mcBdof.size() );
+  iMcD = add( mcDmvr.data(), sizeof( McItem ) * mcDmvr.size() );
+  iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
+  for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
+  iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
+  iUnits = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
+  iDmvrOut = add( nullptr, sizeof( int32_t ) * 2 * (size_t) numDmvr );       // last: written by the device, not part of the upload
+}
+
+int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err )
+{
+  S.begin( p );
+  int rc;
+  if( ( rc = S.mapDecodingOrder( err ) ) != VVR_OK || ( rc = S.buildWorkLists( err ) ) != VVR_OK || ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK
+   || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
+  S.layout();
+  *totalBytes = S.total;
+  return VVR_OK;
+}
+
+void vvr_host_pack( const PrepScratch& S, char* host )
+{
+  for( size_t i = 0; i + 1 < S.parts.size(); i++ ) { const Part& pt = S.parts[i]; if( pt.n && pt.src ) memcpy( host + pt.off, pt.src, pt.n ); }
+}
+
+// bytes of the image that have to cross PCIe (everything but the trailing DMVR output area)
+size_t vvr_host_upload_bytes( const PrepScratch& S ) { return S.parts.back().off; }
+
+void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
+{
+  const vvr_picture* p = S.p;
+  auto at = [&]( int i ) -> char* { return i >= 0 ? base + S.parts[i].off : nullptr; };
+  q.hdr = S.h;
+  PicDev& d = q.pic; memset( &d, 0, sizeof( d ) );
+  d.hdr = S.h; d.w4 = S.w4; d.h4 = S.h4; d.ctus_x = S.ctusX; d.ctus_y = S.ctusY;
+  d.cu = (const vvr_cu*) at( S.iCu ); d.tu = (const vvr_tu*) at( S.iTu ); d.coef = (const int16_t*) at( S.iCoef );
+  d.affMotion = (const vvr_motion*) at( S.iAffMv );
+  d.lfp[0] = (const vvr_lfp*) at( S.iL0 ); d.lfp[1] = (const vvr_lfp*) at( S.iL1 );
+  d.sao = (const vvr_sao_ctu*) at( S.iSao ); d.alf = (const vvr_alf_ctu*) at( S.iAlf ); d.alf_params = (const vvr_alf_params*) at( S.iAlfP );
+  d.lmcs = (const vvr_lmcs_params*) at( S.iLmcs ); d.scaling = (const vvr_scaling_list*) at( S.iSl ); d.wp = (const vvr_wp_params*) at( S.iWp );
+  d.interAt = (const uint8_t*) at( S.iInterAt );
+  d.csVpdu = (const uint32_t*) at( S.iCsVpdu ); d.vpdusX = S.vpdusX; d.vpduLog2 = S.vpduLog2;
+  (void) p;
+  q.mcItems = (McItem*) at( S.iMc ); q.numMc = (int) S.mc.size();
+  q.bdofItems = (McItem*) at( S.iMcB ); q.numBdofItems = (int) S.mcBdof.size();
+  q.dmvrItems = (McItem*) at( S.iMcD ); q.numDmvrItems = (int) S.mcDmvr.size();
+  q.affItems = (McItem*) at( S.iMcA ); q.numAffItems = (int) S.mcAff.size();
+  q.dmvrOut = (int32_t*) at( S.iDmvrOut ); q.numDmvr = S.numDmvr;
+  for( int k = 0; k < 3; k++ ) { q.tbItems[k] = (TbItem*) at( S.iTb[k] ); q.numTb[k] = (int) S.tb[k].size(); }
+  q.intraItems = (IntraItem*) at( S.iIntra ); q.numIntra = (int) S.intraAll.size();
+  q.units = (IntraUnit*) at( S.iUnits ); q.numActive = (int) S.unitsDev.size();
+  memcpy( q.bytes, S.bytes, sizeof( q.bytes ) );
+}
