@@ -2,21 +2,35 @@
 """bench.py — decoded frames/s of the MI355X-native VVC reconstruction back-end on a synthetic PRE-PARSED stream.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: launched through torch.distributed.run)
-  * a "step" is one pass of the hot path over one picture of the stream (all kernels: MC, residual, deblock, SAO, ALF);
-  * workload at N = 1: BASELINE.json configs[1], "3840x2160 10-bit random-access QP32, single MI355X" — a hierarchical-B
-    GOP-16 stream of synthetic pre-parsed pictures (SURVEY.md §8(d) config 2, tool subset listed in config.tools);
-  * inputs (CU/TU records, packed levels, motion field, edge parameters, filter controls) are resident in HBM before the
-    timed region starts (vvr_prepare); the timed region is K x vvr_submit_prepared + one sync, bracketed by a barrier and
-    torch.cuda.synchronize() on both sides; value = pictures of all ranks / max-over-ranks time;
+  * a "step" is one pass of the hot path over one picture of the stream (all kernels: MC, residual, intra, deblock, SAO, ALF);
+  * workload at N = 1 (--config 4k, the default): BASELINE.json configs[1], "3840x2160 10-bit random-access QP32, single MI355X" — a
+    hierarchical-B GOP-16 stream of synthetic pre-parsed pictures with an IRAP every 64 pictures (SURVEY.md §8(d) config 2);
+    --config 8k = configs[2] (7680x4320 RA QP27), --config allintra = configs[4] (4K all-intra QP22, dual tree);
+  * WHAT IS TIMED (`value`): the C-ABI path a decoder uses.  The timed region is K x vvr_submit(host records) + one vvr_sync,
+    bracketed by a barrier and torch.cuda.synchronize() on both sides: validation, the host glue that turns the records into
+    device work lists (--host-threads worker threads inside the library, default 8), the H2D copy of every picture (pinned ring,
+    async) and all kernels.  The records sit in host memory when the region starts — what a CABAC parser leaves behind.
+    `config.device_only_fps` is a second timed pass over the same K pictures with the records and work lists already resident in
+    HBM (vvr_prepare / vvr_submit_prepared): the number the device pipeline alone sustains.
+  * the stream runs P pre-roll pictures (untimed: they only build the DPB the window's pictures reference), W warm-up pictures,
+    then the K timed ones; P is chosen so that the timed window holds IRAP pictures in (at least) stream proportion,
+    max(1, round(K / intra period)) of them, whatever K is; an IRAP is handed to the back-end --irap-lookahead pictures ahead of its
+    decoding-order position (it depends on nothing; a host that parses ahead does the same);
   * N > 1: the stream shards by closed-GOP segment (each rank reconstructs its own independently decodable segment with its
-    own DPB): no data-path collective, "scaling": "weak".
-  * roofline: per-kernel durations come from HIP events recorded on the launch streams in a second, identical pass
-    (vvr_enable_stats); achieved = algorithmic bytes (DESIGN.md table) / duration for the kernel with the largest total time;
+    own DPB): no data-path collective, "scaling": "weak"; value = pictures of all ranks / max-over-ranks time;
+  * verification (rank 0, after the timed passes): the timed run's last pictures == a one-picture-at-a-time run, and --verify of those
+    timed pictures == the CPU oracle fed with the same reference pictures (checker only, never timed or shipped);
+  * roofline: per-kernel durations from HIP events recorded on the launch streams in a further pass over the K timed pictures only
+    (vvr_enable_stats; resident records so that launches are back to back); achieved = algorithmic bytes / duration
+    for the kernel with the largest total time; `peak_measured` = the library's copy kernel over one DPB slot in the same run;
   * cpu_baseline: the reference decoder's own reconstruction classes (oracle/_ref, SIMD enabled) when that build is present,
-    else the plain-C restatement (oracle/), timed on a bounded sample of the same pictures, one picture per process on all
-    host cores (frame-parallel, the same sharding the GPU path uses).
+    else the plain-C restatement (oracle/), on a bounded sample of the same pictures, one picture per process on all host cores
+    (frame-parallel, the sharding the GPU path uses; fewer processes only if host memory would not hold them - both numbers are
+    stated); value = pictures / (summed reconstruction-stage time / processes), i.e. the stage throughput of that many busy cores
+    (picture generation and building the reference's object graph are not reconstruction work); the sample's wall clock is stated.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -29,18 +43,57 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
-# SURVEY.md §8(d) config 2 tool mix (fractions of inter CUs; BDOF / DMVR follow from the reference's own conditions:
+# SURVEY.md §8(d) tool mixes (fractions of inter CUs; BDOF / DMVR follow from the reference's own conditions:
 # bi-predicted, mirrored POC distances, >= 8x8 and >= 128 samples, merge mode for DMVR)
 MIX = dict(p_intra=0.15, p_bi=0.6, p_affine=0.06, p_geo=0.03, p_ciip=0.03, p_sbtmvp=0.03, p_bcw=0.05, p_jccr=0.1, p_cclm=0.10, p_mip=0.05, p_isp=0.05)
+CONFIGS = {
+    # name: (width, height, generator parameters, intra period, description)
+    "4k": (3840, 2160, dict(MIX, base_qp=32), 64, "BASELINE configs[1]: 3840x2160 10-bit 4:2:0 random-access QP32"),
+    "8k": (7680, 4320, dict(MIX, base_qp=27, p_coded=0.5), 64, "BASELINE configs[2]: 7680x4320 10-bit 4:2:0 random-access QP27"),
+    "allintra": (3840, 2160, dict(p_intra=1.0, base_qp=22, p_coded=0.7, p_coded_chroma=0.5, p_small_corner=0.5, p_lfnst=0.4, p_isp=0.10, p_mip=0.10, p_cclm=0.10, p_jccr=0.1, dual_tree=1.0), 1,
+                 "BASELINE configs[4]: 3840x2160 10-bit 4:2:0 all-intra QP22 (every picture an I picture, dual tree)"),
+}
+
+
+def _tools(abi):
+    return (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST |
+            abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE)
+
+
+def stream_plan(cfg_name, gop, intra_period, irap_lookahead, slots, K, Wm):
+    """-> (plans in submission order, number of DPB slots, index of the first timed picture)"""
+    from vvdec_amd import abi, stream
+    if cfg_name == "allintra":
+        pool = max(slots, 2)
+        plans = [stream.PicPlan(poc=i, layer=0, slice_type=abi.SLICE_I, slot=i % pool, ref_slots=([], [])) for i in range(Wm + K)]
+        return plans, pool, Wm
+    n_irap = max(1, int(round(K / float(intra_period))))
+    # enough stream for: a first intra period (pre-roll), the window, the look-ahead
+    nframes = intra_period * (n_irap + 2) + K + Wm + gop
+    nframes = ((nframes - 1 + gop - 1) // gop) * gop + 1
+    plans, nslots = stream.ra_plan(nframes, gop=gop, seed_poc0_is_external=False, pool=slots, intra_period=intra_period, irap_lookahead=irap_lookahead)
+    iraps = [i for i, pl in enumerate(plans) if pl.slice_type == abi.SLICE_I and i > Wm]
+    # the window [first, first + K) holds iraps[0 .. n_irap): centre it on them
+    lo, hi = iraps[0], iraps[n_irap - 1]
+    first = max(Wm, min(lo - 1, (lo + hi) // 2 - K // 2))
+    first = max(first, hi - K + 1)
+    got = sum(1 for i in iraps if first <= i < first + K)
+    assert got >= n_irap and first + K <= len(plans), (first, K, iraps[:4], len(plans))
+    return plans[:first + K], max(nslots, slots), first
 
 
 def _cpu_worker(args):
-    kind, W, H, seed, tools, gop, idx = args
+    kind, cfg_name, seed, gop, idx = args
     import refdrv
-    from vvdec_amd import synth, stream
-    plans, _ = stream.ra_plan(gop + 1, gop=gop, seed_poc0_is_external=False)
-    pl = plans[idx % len(plans)]
-    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **MIX)
+    from vvdec_amd import abi, synth, stream
+    W, H, mix, _, _ = CONFIGS[cfg_name]
+    tools = _tools(abi)
+    if cfg_name == "allintra":
+        pl = stream.PicPlan(poc=idx, layer=0, slice_type=abi.SLICE_I, slot=0, ref_slots=([], []))
+    else:
+        plans, _ = stream.ra_plan(gop + 1, gop=gop, seed_poc0_is_external=False)
+        pl = plans[1 + idx % (len(plans) - 1)]                     # the B pictures of one GOP (the IRAP share of the stream is 1 / 64)
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **mix)
     refs = {}
     for lst in pl.ref_slots:
         for (slot, poc) in lst:
@@ -49,32 +102,39 @@ def _cpu_worker(args):
     t0 = time.perf_counter()
     if kind == "reference":
         r = refdrv.reconstruct(d, refs, flags=refdrv.SIMD)
-        dt = r["ms"][7] / 1e3          # stage time only (excludes building the reference's object graph)
+        dt = r["ms"][7] / 1e3          # stage time only (excludes building the reference's object graph from the records)
     else:
         refdrv.oracle_reconstruct(d, refs)
         dt = time.perf_counter() - t0
     return dt
 
 
-def cpu_baseline(W, H, seed, tools, gop, budget_s=20.0):
+def cpu_baseline(cfg_name, seed, gop, budget_s=20.0):
     import refdrv
+    import multiprocessing
     from concurrent.futures import ProcessPoolExecutor
     kind = "reference" if refdrv.available() else "port"
-    # bounded sample: at most 32 worker processes (more only adds memory-bandwidth contention on the GPU box's host and
-    # burns wall-clock), a few pictures each, sized to ~budget_s of wall time after a one-picture calibration
-    cores = min(os.cpu_count() or 1, 32)
-    t1 = _cpu_worker((kind, W, H, seed, tools, gop, 0))
-    per_core = max(1, min(4, int(budget_s / max(4 * t1, 1e-3))))
+    W, H = CONFIGS[cfg_name][:2]
+    cores = os.cpu_count() or 1
+    try:
+        import psutil                                             # one process holds a picture description, its planes and the reference's object graph
+        cores = max(1, min(cores, int(psutil.virtual_memory().available / (3.0e9 * (4 if W > 4000 else 1)))))
+    except Exception:
+        pass
+    t1 = _cpu_worker((kind, cfg_name, seed, gop, 0))             # calibration: one picture on one core
+    per_core = max(1, min(4, int(budget_s / max(3 * t1, 1e-3))))
     n = cores * per_core
-    t0 = time.perf_counter()
-    import multiprocessing
     with ProcessPoolExecutor(max_workers=cores, mp_context=multiprocessing.get_context("spawn")) as ex:
-        times = list(ex.map(_cpu_worker, [(kind, W, H, seed, tools, gop, i) for i in range(n)]))
-    wall = time.perf_counter() - t0
-    # throughput of the reconstruction stage itself: pictures / (sum of stage times / cores)
+        list(ex.map(_cpu_worker, [(kind, cfg_name, seed, gop, i) for i in range(cores)]))       # start the workers (imports, library loads)
+        t0 = time.perf_counter()
+        times = list(ex.map(_cpu_worker, [(kind, cfg_name, seed, gop, i) for i in range(n)]))
+        wall = time.perf_counter() - t0
+    # the workers also generate their picture and (reference) build the reference's object graph, which is not reconstruction work:
+    # value = pictures / (summed reconstruction-stage time / cores), the stage throughput of `cores` busy cores; the wall clock is stated
     fps = n / (sum(times) / cores)
     return {"value": round(fps, 2), "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": "%d pictures of the same %dx%d stream, one picture per process on %d cores (stage time %.0f ms/picture/core, wall %.1f s)%s" %
+            "host_cores": os.cpu_count(),
+            "sample": "%d pictures of the same %dx%d stream, one picture per process on %d cores (reconstruction stage %.0f ms/picture/core; wall clock of the sample incl. picture generation %.1f s)%s" %
                       (n, W, H, cores, 1e3 * sum(times) / n, wall, ", reference classes with SIMD" if kind == "reference" else ", plain-C restatement")}
 
 
@@ -83,16 +143,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="4k")
+    ap.add_argument("--width", type=int, default=0, help="override the configuration's picture size (tests)")
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--gop", type=int, default=16)
     ap.add_argument("--streams", type=int, default=8, help="pictures in flight per GPU")
-    ap.add_argument("--slots", type=int, default=24, help="DPB slots used round-robin (0: smallest DPB, slots reused at once)")
-    ap.add_argument("--intra-period", type=int, default=64, help="an IRAP picture every N pictures (multiple of --gop; 0: only POC 0)")
+    ap.add_argument("--host-threads", type=int, default=8, help="worker threads inside the library that prepare submitted pictures")
+    ap.add_argument("--slots", type=int, default=24, help="DPB slots used round-robin")
+    ap.add_argument("--intra-period", type=int, default=-1, help="an IRAP picture every N pictures (multiple of --gop); default: the configuration's")
     ap.add_argument("--irap-lookahead", type=int, default=8, help="IRAP pictures are submitted N pictures ahead of their decoding-order position (they depend on nothing)")
-    ap.add_argument("--cold", action="store_true", help="time the first K pictures of the stream (from the IRAP at POC 0, nothing to overlap it with) instead of K pictures of the running stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", type=int, default=2, help="number of pictures re-checked against the CPU oracle after the run")
+    ap.add_argument("--verify", type=int, default=8, help="number of timed pictures re-checked against the CPU oracle after the run")
     a = ap.parse_args()
 
     import torch
@@ -113,116 +174,150 @@ def main():
             dist.init_process_group(backend=backend)
 
     import vvdec_amd
-    from vvdec_amd import abi, synth, stream
+    from vvdec_amd import abi, synth, parallel
     vvdec_amd.lib()
-    W, H = a.width, a.height
-    tools = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST |
-             abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE)
+    W, H, mix, ip_default, cfg_text = CONFIGS[a.config]
+    if a.width:
+        W, H = a.width, a.height
+    tools = _tools(abi)
     K, Wm = a.steps, a.warmup
-    # the stream: W warm-up pictures, then the K timed ones; --cold: the K timed pictures are the first K again (start of a stream)
-    total = max(K, Wm) if a.cold else Wm + K
-    nframes = ((total - 1 + a.gop - 1) // a.gop) * a.gop + 1
-    plans, nslots = stream.ra_plan(nframes, gop=a.gop, seed_poc0_is_external=False, pool=a.slots, intra_period=a.intra_period,
-                                   irap_lookahead=0 if a.cold else a.irap_lookahead)   # POC 0 is an I picture
-    nslots = max(nslots, a.slots)
-    from vvdec_amd import parallel
-    seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
-    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank)
-    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **MIX) for pl in plans[:total]]
-    prepared = [rec.prepare(d) for d in descs]        # everything resident in HBM from here on
-    first = 0 if a.cold else Wm                       # first timed picture (submission order)
+    intra_period = ip_default if a.intra_period < 0 else a.intra_period
+    plans, nslots, first = stream_plan(a.config, a.gop, intra_period, a.irap_lookahead, a.slots, K, Wm)
     n_irap = sum(1 for pl in plans[first:first + K] if pl.slice_type == abi.SLICE_I)
+    seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads)
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **mix) for pl in plans]
+    cpics = [d.c() for d in descs]                     # the host records as the C ABI sees them (plain structs pointing at the arrays)
+    upload_mb = sum(d.cu.nbytes + d.tu.nbytes + d.coef.nbytes + d.lfp[0].nbytes + d.lfp[1].nbytes for d in descs[first:first + K]) / K / 1e6
 
-    def one_pass(i0, n, all_ranks=True):
-        # all_ranks=False: a pass that only rank 0 runs (statistics): no collective inside
+    def barrier(all_ranks):
         rec.sync()
         torch.cuda.synchronize()
         if world > 1 and all_ranks:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def host_pass(i0, n, all_ranks=True):
+        # the C-ABI path: host records in, reconstructed pictures in the DPB
+        barrier(all_ranks)
         t0 = time.perf_counter()
         for i in range(i0, i0 + n):
-            rec.submit_prepared(prepared[i])
-        rec.sync()
-        torch.cuda.synchronize()
-        if world > 1 and all_ranks:
-            dist.barrier()
-        torch.cuda.synchronize()
+            rec.submit_c(cpics[i])
+        barrier(all_ranks)
         return time.perf_counter() - t0
 
-    one_pass(0, Wm)                                    # warm-up (untimed): the first W pictures of the stream
-    dt = one_pass(first, K)                            # timed: exactly K steps
+    # ---- the timed run: pre-roll and warm-up untimed, then exactly K steps through vvr_submit
+    host_pass(0, first - Wm)
+    host_pass(first - Wm, Wm)
+    dt = host_pass(first, K)
     if world > 1:
         t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    tail_n = min(8, K)
+    tail = list(range(first + K - tail_n, first + K))                       # the last timed pictures still sit in their slots
+    timed_out = {i: rec.read_picture(plans[i].slot) for i in tail if all(plans[j].slot != plans[i].slot for j in range(i + 1, first + K))}
+
+    # ---- the same K pictures with records and work lists resident in HBM (the device pipeline alone)
+    prepared = {}
+
+    def resident_pass(i0, n, all_ranks=True):
+        for i in range(i0, i0 + n):
+            if i not in prepared:
+                prepared[i] = rec.prepare(descs[i])
+        barrier(all_ranks)
+        t0 = time.perf_counter()
+        for i in range(i0, i0 + n):
+            rec.submit_prepared(prepared[i])
+        barrier(all_ranks)
+        return time.perf_counter() - t0
+
+    resident_pass(first - Wm, Wm)
+    dt_dev = resident_pass(first, K)
+    if world > 1:
+        t = torch.tensor([dt_dev], device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_dev = float(t.item())
 
     out = None
     if rank == 0:
-        # ---- correctness of what was just timed: re-check pictures against the CPU oracle (checker only)
-        verified = 0
-        if a.verify:
-            import refdrv
-            cpu = {}
-            rec2 = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, device=local_rank)
-            tail = {pl.slot: pl for pl in plans[first + K - 8:first + K]}           # the last timed pictures still sit in their slots
-            timed_out = {slot: rec.read_picture(slot) for slot in tail}
-            for i, (pl, d) in enumerate(zip(plans[:first + K], descs)):
-                rec2.wait(rec2.decompress_picture(d))
-                if i < a.verify:                                                    # against the CPU oracle
-                    got = rec2.read_picture(pl.slot)
-                    want = refdrv.oracle_reconstruct(d, cpu)
-                    assert all(np.array_equal(g, w) for g, w in zip(got, want)), "bench: POC %d differs from the oracle" % pl.poc
-                    cpu[pl.slot] = want
-                    verified += 1
-            for slot, pl in tail.items():                                           # pipelined timed run == one picture at a time
-                got = rec2.read_picture(slot)
-                assert all(np.array_equal(g, w) for g, w in zip(got, timed_out[slot])), "bench: POC %d differs between the timed run and a serial run" % pl.poc
-            rec2.close()
-        # ---- roofline of the dominant kernel: second identical pass with HIP-event timing on the launch streams
+        # ---- roofline of the dominant kernel: a further pass over the K timed pictures only, HIP-event timing on the launch streams
+        resident_pass(first - Wm, Wm, all_ranks=False)
         rec.enable_stats(True)
-        if not a.cold:
-            one_pass(0, Wm, all_ranks=False)
-        one_pass(first, K, all_ranks=False)
+        resident_pass(first, K, all_ranks=False)
         st = rec.stats()
         rec.enable_stats(False)
-        st.sort(key=lambda s: -s["total_ms"])
-        dom = st[0]
+        copy_bps = rec.copy_bandwidth(20)
         for x in st:
             x["total_ms"] = max(x["total_ms"], 1e-6)          # (a kernel that never ran has no time)
+        st.sort(key=lambda s: -s["total_ms"])
+        dom = st[0]
         achieved = dom["algo_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "peak_measured": round(copy_bps / 1e9, 1), "peak_measured_how": "k_copy over one DPB slot (read + write), HIP events, 20 launches, same run",
+                "frac_of_measured": round(achieved / max(copy_bps / 1e9, 1e-9), 4),
                 "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
+                "algorithmic_bytes_per_launch": int(dom["algo_bytes"] / dom["launches"]),
+                "frame_level": {"algorithmic_MB_per_picture": round(sum(s["algo_bytes"] for s in st) / K / 1e6, 1),
+                                "achieved_GBps_at_value": None},
                 "all_kernels": {s["name"]: {"avg_us": round(1e3 * s["total_ms"] / s["launches"], 2), "launches": s["launches"],
                                             "algo_GBps": round(s["algo_bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1)} for s in st}}
-        # HBM-side traffic of that kernel from the separate PMC passes (profiles/round1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
-        # --pmc WRITE_SIZE, gfx950 correction applied); counters cannot be collected inside this run
-        try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")))["kernels"]
-            ent = next(v for k, v in pmc.items() if k.split("<")[0] == dom["name"])
-            roof["traffic"] = ent["hbm_side_bytes_per_launch_corrected"]
-            roof["traffic_source"] = "profiles/round1_pmc_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)"
-            roof["algorithmic_bytes_per_launch"] = int(dom["algo_bytes"] / dom["launches"])
-        except Exception:
-            pass
+        # HBM-side traffic of that kernel from the separate PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over this command,
+        # gfx950 correction applied, profiles/*_pmc_traffic.json); counters cannot be collected inside this run
+        for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+                ent = next(v for k, v in pmc.items() if k.split("<")[0] == dom["name"])
+                roof["traffic"] = ent["hbm_side_bytes_per_launch_corrected"]
+                roof["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes, bytes per launch)" % name
+                break
+            except Exception:
+                pass
+        # ---- correctness of what was timed
+        verified = 0
+        serial_equal = False
+        if a.verify:
+            import refdrv
+            rec2 = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, device=local_rank)
+            check = set(tail[-min(a.verify, len(tail)):])
+            for i, (pl, d) in enumerate(zip(plans, descs)):
+                refs = None
+                if i in check:
+                    refs = {slot: rec2.read_picture(slot) for lst in pl.ref_slots for (slot, _) in lst}
+                rec2.wait(rec2.decompress_picture(d))
+                if i in timed_out:
+                    got = rec2.read_picture(pl.slot)
+                    assert all(np.array_equal(g, w) for g, w in zip(got, timed_out[i])), "bench: POC %d differs between the timed run and a one-picture-at-a-time run" % pl.poc
+                    serial_equal = True
+                    if i in check:                                                  # the timed picture against the CPU oracle, same reference pictures
+                        want = refdrv.oracle_reconstruct(d, refs)
+                        assert all(np.array_equal(g, w) for g, w in zip(got, want)), "bench: POC %d differs from the oracle" % pl.poc
+                        verified += 1
+            rec2.close()
         fps = world * K / dt
-        out = {"metric": "decoded frames/sec (4K 10-bit RA) on MI355X, synthetic pre-parsed stream, bit-exact vs ref",
-               "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        roof["frame_level"]["achieved_GBps_at_value"] = round(roof["frame_level"]["algorithmic_MB_per_picture"] * 1e6 * fps / world / 1e9, 1)
+        metric = {"4k": "decoded frames/sec (4K 10-bit RA) on MI355X, synthetic pre-parsed stream, bit-exact vs ref",
+                  "8k": "decoded frames/sec (8K 10-bit RA) on MI355X, synthetic pre-parsed stream, bit-exact vs ref",
+                  "allintra": "decoded frames/sec (4K 10-bit all-intra) on MI355X, synthetic pre-parsed stream, bit-exact vs ref"}[a.config]
+        out = {"metric": metric, "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
                "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int16", "data": "synthetic",
-               "config": {"workload": "%dx%d 10-bit 4:2:0 random-access QP32 (hierarchical-B GOP %d, IRAP every %d pictures), CTU 128, pre-parsed records resident in HBM; %s"
-                                      % (W, H, a.gop, a.intra_period, "the first K pictures of the stream (cold start at the IRAP)" if a.cold else
-                                         "K pictures of the running stream after W warm-up pictures (%d IRAP in the timed pictures, submitted %d pictures ahead of its decoding-order position)" % (n_irap, a.irap_lookahead)),
-                          "tools": "I picture + hierarchical-B pictures with 15 % intra CUs: intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM + ISP, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
-                          "mix": MIX,
-                          "not_in_mix": "SBT, explicit weighted prediction, scaling lists (implemented and tested, not part of the configuration of SURVEY.md 8(d)); dual-tree I pictures, CUs down to 4x4, local dual trees and IBC are implemented and tested too",
+               "config": {"workload": "%s, %dx%d, CTU 128%s; timed: K pictures through vvr_submit from host records (validation, work lists on %d library threads, H2D of %.1f MB per picture, all kernels); %d pre-roll + W warm-up pictures untimed; %d IRAP picture(s) in the timed window"
+                                      % (cfg_text, W, H, "" if a.config == "allintra" else ", hierarchical-B GOP %d, IRAP every %d pictures, submitted %d pictures ahead of its decoding-order position" % (a.gop, intra_period, a.irap_lookahead),
+                                         a.host_threads, upload_mb, first - Wm, n_irap),
+                          "timed_path": "vvr_submit(host records)", "host_threads": a.host_threads, "host_cores": os.cpu_count(),
+                          "device_only_fps": round(world * K / dt_dev, 2), "device_only_ms_per_step": round(1e3 * dt_dev / K, 4),
+                          "device_only_what": "same K pictures, records and work lists resident in HBM (vvr_prepare + vvr_submit_prepared)",
+                          "irap_in_window": n_irap, "irap_share_of_stream": "1/%d" % intra_period if a.config != "allintra" else "1/1",
+                          "tools": "intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM + ISP, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
+                          "mix": mix,
                           "pictures_in_flight": a.streams, "sharding": "closed-GOP segment per GPU, no data-path collective",
-                          "verified_pictures_vs_oracle": verified, "timed_run_equals_serial_run": bool(a.verify)},
+                          "verified_timed_pictures_vs_oracle": verified, "timed_run_equals_serial_run": serial_equal},
                "roofline": roof}
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, seed, tools, a.gop)
-    for h in prepared:
+            out["cpu_baseline"] = cpu_baseline(a.config, seed, a.gop)
+    for h in prepared.values():
         rec.free_prepared(h)
     rec.close()
     if world > 1:

@@ -21,7 +21,7 @@ def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=Tru
     plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=not intra)
     ncomp = 3 if chroma_format else 1
     geo = dict(log2_ctu=log2_ctu, bit_depth=bit_depth, chroma_format=chroma_format)
-    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=streams, **geo)
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=streams, host_threads=3, **geo)     # pictures prepared by worker threads
     seed_pic = synth.natural_picture(W, H, seed, bit_depth=bit_depth)[:ncomp]
     cpu = {}
     if not intra:
@@ -404,3 +404,16 @@ def test_golden_fixtures_reference_outputs(built, path, monkeypatch):
         rec.close()
         for c in range(3):
             assert np.array_equal(got[c], outs[st][c]), "%s comp %d: %d samples differ from the reference decoder" % (st, c, int((got[c] != outs[st][c]).sum()))
+
+
+def test_copy_kernel_bandwidth(built):
+    """the measured HBM ceiling bench.py reports next to the nominal 8 TB/s: the library's copy kernel over one DPB slot"""
+    import vvdec_amd
+    rec = vvdec_amd.Reconstructor(3840, 2160, num_slots=2, num_streams=1)
+    pic = synth.natural_picture(3840, 2160, 5)
+    rec.write_picture(0, pic)
+    bps = rec.copy_bandwidth(10)
+    assert 0.2e12 < bps < 8.0e12, bps
+    got = rec.read_picture(0)
+    assert all(np.array_equal(g, w) for g, w in zip(got, pic))          # slot 0 is only read
+    rec.close()

@@ -508,3 +508,71 @@ def test_bench_control_flow(stub, ranks):
     assert out["n_gpus"] == ranks and out["steps"] == 6 and out["warmup"] == 4 and out["scaling"] == "weak" and "workload" in out["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in out["roofline"]
+
+
+def _submit_stream(stub, threads, W=416, H=240, frames=17, gop=8, lanes=3):
+    """a whole stream through vvr_submit on a context with `threads` worker threads -> the (op, stream) sequence of the stream / event operations"""
+    plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=False, pool=12)
+    cfg = abi.Config()
+    cfg.abi_version = abi.VVR_ABI_VERSION
+    cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, 5
+    cfg.num_slots, cfg.num_streams, cfg.host_threads = max(nslots, 12), lanes, threads
+    ctx = C.c_void_p()
+    assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    stub.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+    buf = (C.c_int * 60000)()
+    stub.vvt_take_trace(buf, len(buf))
+    descs = [synth.picture_for_plan(pl, W, H, seed=511, tool_flags=TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, log2_ctu=5, p_intra=0.15, p_affine=0.1) for pl in plans]
+    pics = [d.c() for d in descs]
+    jobs = [stub.vvr_submit(ctx, C.byref(p)) for p in pics]
+    assert all(j >= 0 for j in jobs) and jobs == sorted(jobs)
+    for j in jobs:
+        assert stub.vvr_wait(ctx, j) == abi.VVR_OK
+    n = stub.vvt_take_trace(buf, len(buf))
+    ops = [(buf[i], buf[i + 1]) for i in range(0, n, 3)]
+    base = min(o[1] for o in ops)                       # (the stand-in runtime numbers streams across contexts)
+    stub.vvr_destroy(ctx)
+    # the event records: per picture one on the copy stream (its upload) and one on its lane (its completion).  Which waits are issued also
+    # depends on which earlier pictures the host already knows to be finished (their events are not waited for again), i.e. on the ring size
+    return [(op, st - base) for op, st in ops if op == 1]
+
+
+def test_worker_threads_commit_in_submission_order(stub):
+    """pictures prepared concurrently by worker threads are enqueued on the device exactly like pictures prepared by the submitting thread:
+    same lanes, same copies, uploads and completions in the same order"""
+    inline = _submit_stream(stub, 0)
+    assert len(inline) == 17 * 2
+    for threads in (1, 3):
+        assert _submit_stream(stub, threads) == inline
+
+
+def test_errors_of_queued_pictures_come_back_from_wait(stub):
+    """with worker threads, what only shows while the work lists are built is parked on the job (the reference parks exceptions on reconDone):
+    vvr_submit has returned a job id, vvr_wait returns the error, later pictures are not held up"""
+    W, H = 256, 128
+    plans, nslots = stream.ra_plan(3, gop=2, seed_poc0_is_external=False)
+    cfg = abi.Config()
+    cfg.abi_version = abi.VVR_ABI_VERSION
+    cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, 7
+    cfg.num_slots, cfg.num_streams, cfg.host_threads = nslots, 2, 2
+    ctx = C.c_void_p()
+    assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    stub.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+    mk = lambda pl: synth.picture_for_plan(pl, W, H, seed=509, tool_flags=TOOLS | abi.TOOL_IBC, p_ibc=0.6)
+    bad = mk(plans[0])
+    k = int(np.nonzero(bad.cu["pred_mode"] == abi.PRED_IBC)[0][0])
+    bad.cu["mv"][k][0][0] = (0, 0)                       # "copies" itself: only the work-list builder sees that
+    good = [mk(plans[0]), mk(plans[1])]
+    pb, pg = bad.c(), [g.c() for g in good]
+    jb = stub.vvr_submit(ctx, C.byref(pb))
+    jg = [stub.vvr_submit(ctx, C.byref(p)) for p in pg]
+    assert jb >= 0 and all(j >= 0 for j in jg)
+    assert stub.vvr_wait(ctx, jg[1]) == abi.VVR_OK and stub.vvr_wait(ctx, jg[0]) == abi.VVR_OK
+    assert stub.vvr_wait(ctx, jb) == abi.VVR_ERR_PARAMETER
+    assert "not reconstructed before" in stub.vvr_last_error(ctx).decode()
+    # what is wrong with the description itself is still refused by vvr_submit at once
+    bad2 = mk(plans[0]); bad2.hdr.out_slot = nslots
+    assert stub.vvr_submit(ctx, C.byref(bad2.c())) == abi.VVR_ERR_PARAMETER
+    stub.vvr_destroy(ctx)
