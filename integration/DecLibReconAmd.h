@@ -49,6 +49,7 @@ public:
     Slice& slice = *pic->slices[0];
     const int numCtu = cs.pcv->sizeInCtus;
     pic->parseDone.wait();                                                             // simplest correct integration
+    { std::string why; if( checkExpressible( cs, *pic, why ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << why ); }    // never flattened into something it is not
     for( int a = 0; a < numCtu; a++ ) m_loopFilter.calcFilterStrengthsCTU( cs, a );     // LF_INIT (DecLibRecon.cpp:912-941)
     Reshape* rsp = nullptr;
     if( cs.sps->getUseReshaper() && slice.getLmcsEnabledFlag() )

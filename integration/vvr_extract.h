@@ -92,6 +92,36 @@ static inline uint32_t toolFlags( const CodingStructure& cs, const Slice& slice,
   return f;
 }
 
+// What a vvr_picture of this ABI version cannot express: such a picture must not be flattened (it would be reconstructed silently wrong).
+// Returns VVR_OK, or VVR_ERR_UNSUPPORTED with the reason; the binding (DecLibReconAmd) turns that into the reference's own
+// "not supported" error path.  One header per picture means: one slice, one tile, one sub-picture - the reference restricts intra
+// availability, motion candidates and the in-loop filters at every slice / tile / sub-picture edge (CodingStructure::getCURestricted,
+// SampleAdaptiveOffset.cpp:741-830, AdaptiveLoopFilter.cpp:118-200, LoopFilter.cpp:780-800) and switches reference lists, filter
+// parameters and weights per slice.
+static inline int checkExpressible( const CodingStructure& cs, const Picture& pic, std::string& why )
+{
+  const SPS& sps = *cs.sps; const PPS& pps = *cs.pps; const PicHeader& ph = *cs.picHeader;
+  if( sps.getChromaFormatIdc() != CHROMA_400 && sps.getChromaFormatIdc() != CHROMA_420 ) { why = "chroma format other than 4:0:0 / 4:2:0"; return VVR_ERR_UNSUPPORTED; }
+  if( sps.getBitDepth() > 10 || sps.getBitDepth() < 8 ) { why = "bit depth outside 8..10"; return VVR_ERR_UNSUPPORTED; }
+  if( sps.getLadfEnabled() ) { why = "luma-adaptive deblocking (LADF, LoopFilter.cpp:1363)"; return VVR_ERR_UNSUPPORTED; }
+  if( sps.getUseWrapAround() || pps.getUseWrapAround() ) { why = "horizontal wrap-around motion compensation (Picture.cpp:404-518)"; return VVR_ERR_UNSUPPORTED; }
+  if( sps.getVirtualBoundariesPresentFlag() || ph.getVirtualBoundariesPresentFlag() ) { why = "virtual boundaries of the in-loop filters"; return VVR_ERR_UNSUPPORTED; }
+  if( sps.getUseColorTrans() ) { why = "adaptive colour transform"; return VVR_ERR_UNSUPPORTED; }
+  if( pic.slices.size() != 1 ) { why = "picture with more than one slice"; return VVR_ERR_UNSUPPORTED; }
+  if( pps.getNumTiles() > 1 ) { why = "picture with more than one tile"; return VVR_ERR_UNSUPPORTED; }
+  if( pps.getNumSubPics() > 1 ) { why = "picture with sub-pictures"; return VVR_ERR_UNSUPPORTED; }
+  const Slice& slice = *pic.slices[0];
+  if( !slice.isIntra() )
+    for( int l = 0; l < 2; l++ ) for( int i = 0; i < slice.getNumRefIdx( RefPicList( l ) ); i++ )
+    {
+      const Picture* ref = slice.getRefPic( RefPicList( l ), i );
+      if( !ref ) { why = "missing reference picture"; return VVR_ERR_UNSUPPORTED; }
+      if( ref->isRefScaled( &pps ) ) { why = "reference picture of another size (reference picture resampling, InterPrediction.cpp:631-675)"; return VVR_ERR_UNSUPPORTED; }
+      if( i >= VVR_MAX_REFS ) { why = "more reference pictures than VVR_MAX_REFS"; return VVR_ERR_UNSUPPORTED; }
+    }
+  return VVR_OK;
+}
+
 // slotOf: DPB slot of a reference picture (the caller owns the mapping picture <-> slot); outSlot: slot of the picture itself
 static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& pic, Reshape* reshaper, TrQuant& trQuant,
                                    const std::function<int( const Picture* )>& slotOf, int outSlot, Extracted& E )

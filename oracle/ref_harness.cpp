@@ -88,6 +88,9 @@ static std::string g_err;
 // round trip of the reference-side glue: when set, vvref_reconstruct stops after it has built the reference's objects from the
 // description and lets integration/vvr_extract.h turn them back into a description
 static vvr_glue::Extracted* g_extractTo = nullptr;
+// test hook of the extractor's refusals (vvref_check_expressible): a feature the flat description cannot express is switched on in the
+// reference's objects before they are handed to the glue; g_expressible receives what the glue says
+static int g_feature = 0, g_expressible = 0; static std::string g_why;
 static bool g_trace = getenv("VVREF_TRACE") != nullptr;
 #define TR(...) do { if( g_trace ) { fprintf( stderr, __VA_ARGS__ ); fflush( stderr ); } } while(0)
 __attribute__((visibility("default"))) const char* vvref_last_error() { return g_err.c_str(); }
@@ -586,8 +589,30 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       TR("reshaper done\n");
     }
     decCu.init( intraPred.get(), interPred.get(), reshaper.get(), trQuant.get() );
+    if( g_feature )
+    {
+      switch( g_feature )
+      {
+      case 1: sps.setLadfEnabled( true ); break;
+      case 2: sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); break;
+      case 3: ph->setVirtualBoundariesPresentFlag( true ); break;
+      case 4: { Slice* s2 = pic.allocateNewSlice(); s2->setPicHeader( ph.get() ); s2->setSliceType( SliceType( H.slice_type ) ); s2->setPOC( H.poc ); } break;
+      case 5: pps.setNumSubPics( 2 ); break;
+      case 6: sps.setUseColorTrans( true ); break;
+      case 7: sps.setBitDepth( 12 ); break;
+      case 8: pps.setNumTileColumns( 2 ); break;                                                           // (a second tile column)
+      case 9: pps.setPicWidthInLumaSamples( W / 2 ); break;                                              // (the references keep their size: Picture::isRefScaled)
+      default: break;
+      }
+      g_expressible = vvr_glue::checkExpressible( cs, pic, g_why );
+      if( g_feature == 9 ) pps.setPicWidthInLumaSamples( W );
+      if( g_feature == 8 ) pps.setNumTileColumns( 1 );
+      for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
+      return 0;
+    }
     if( g_extractTo )
     {
+      { std::string why; CHECK( vvr_glue::checkExpressible( cs, pic, why ) != VVR_OK, why ); }
       auto slotOf = [&]( const Picture* p ) { for( auto& kv : refPics ) if( kv.second.get() == p ) return kv.first; return -1; };
       if( flags & VVREF_DERIVE_LFP ) for( int a = 0; a < numCtu; a++ ) lf.calcFilterStrengthsCTU( cs, a );      // LF_INIT by the reference itself
       vvr_glue::extractPicture( cs, *slice, pic, sps.getUseReshaper() ? reshaper.get() : nullptr, *trQuant, slotOf, H.out_slot, *g_extractTo );
@@ -760,6 +785,21 @@ const vvr_picture* vvref_extract( const vvr_picture* vp, const uint16_t* const* 
   if( rc != 0 ) return nullptr;
   if( num_dmvr ) *num_dmvr = E.numDmvr;
   return &E.pic;
+}
+
+// the extractor's refusals: the description is turned into reference objects, `feature` switches on something a flat description cannot express
+// (0 nothing, 1 LADF, 2 wrap-around, 3 virtual boundaries, 4 a second slice, 5 sub-pictures, 6 ACT, 7 12-bit samples, 8 a second tile column,
+// 9 a reference picture of another size); returns what vvr_glue::checkExpressible says (VVR_OK / VVR_ERR_UNSUPPORTED), the reason in `why`
+__attribute__((visibility("default")))
+int vvref_check_expressible( const vvr_picture* vp, const uint16_t* const* ref_planes, int feature, char* why, int whyLen )
+{
+  g_feature = feature ? feature : 100; g_expressible = -1; g_why.clear();
+  uint16_t* none[3] = { nullptr, nullptr, nullptr };
+  const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, 0, nullptr );
+  g_feature = 0;
+  if( rc != 0 ) { snprintf( why, whyLen, "harness: %s", g_err.c_str() ); return -100; }
+  snprintf( why, whyLen, "%s", g_why.c_str() );
+  return g_expressible;
 }
 
 } // extern "C"

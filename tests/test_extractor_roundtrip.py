@@ -8,6 +8,7 @@ types from TrQuant::getTrTypes, the motion-compensation branch, CIIP neighbour f
 reference's Reshape class, final ALF filters after reconstructCoeffAPSs, SAO offsets) are recomputed on the way, not copied.
 
 Needs oracle/_ref (built where /root/reference exists); skipped elsewhere."""
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -193,3 +194,29 @@ def test_reference_edge_tables_are_safe_for_one_launch_per_direction(built):
                         assert e1 - e0 == 8 and (int(l1["side_max_filt_length"]) >> 4) & 7 == 7, (name, dr, e0, e1)
                         ordered += 1
     assert ordered > 0
+
+
+@pytest.mark.parametrize("feature,text", [(1, "LADF"), (2, "wrap-around"), (3, "virtual boundaries"), (4, "more than one slice"), (5, "sub-pictures"),
+                                          (6, "colour transform"), (7, "bit depth"), (8, "more than one tile"), (9, "another size")])
+def test_extractor_refuses_what_the_description_cannot_express(built, feature, text):
+    """the reference-side glue never flattens a picture into something it is not: LADF, wrap-around, virtual boundaries, several slices / tiles /
+    sub-pictures, ACT, more than 10 bits, scaled references are refused with VVR_ERR_UNSUPPORTED (the binding raises the reference's own
+    'not supported' error); the same picture without the feature is accepted"""
+    L = refdrv.lib()
+    W, H = 256, 128
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[1]
+    d = synth.picture_for_plan(pl, W, H, seed=631, tool_flags=ALL, p_intra=0.2)
+    refs = {slot: synth.natural_picture(W, H, 632 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
+    p = d.c()
+    nslots = max(refs) + 1
+    ref_ptrs = (C.POINTER(C.c_uint16) * (nslots * 3))()
+    keep = []
+    for slot, planes in refs.items():
+        for c, plane in enumerate(planes):
+            a = np.ascontiguousarray(plane, dtype=np.uint16); keep.append(a)
+            ref_ptrs[slot * 3 + c] = a.ctypes.data_as(C.POINTER(C.c_uint16))
+    why = C.create_string_buffer(256)
+    assert L.vvref_check_expressible(C.byref(p), ref_ptrs, 0, why, 256) == abi.VVR_OK, why.value
+    rc = L.vvref_check_expressible(C.byref(p), ref_ptrs, feature, why, 256)
+    assert rc == abi.VVR_ERR_UNSUPPORTED and text in why.value.decode(), (rc, why.value)

@@ -53,6 +53,8 @@ struct PrepScratch
   // LMCS chroma residual scaling: per VPDU the luma neighbourhood its factor is averaged over (Reshape::calculateChromaAdjVpduNei,
   // Reshape.cpp:192-274): left column / above row of the CU at the VPDU origin, where that neighbour precedes it in decoding order
   std::vector<uint32_t> csVpduV;
+  std::vector<std::pair<uint32_t, uint32_t>> csProdRange;   // per VPDU: the luma blocks that produce that neighbourhood (range of csProdPool), looked up on first use
+  std::vector<uint32_t> csProdPool;
   std::vector<IntraUnit> unitsDev;
   // union-find / grouping scratch
   std::vector<uint32_t> parent, newIdx, firstOf, perm, inv, unitCount, unitOfItem[3];
@@ -329,6 +331,7 @@ int PrepScratch::mapDecodingOrder( std::string& err )
       for( int y = cu.y >> 2; y < ( cu.y + cu.h + 3 ) >> 2; y++ ) std::fill( &cuAt[(size_t) y * w4 + x0], &cuAt[(size_t) y * w4 + x1], (int32_t) i );
     }
     csVpduV.resize( (size_t) vpdusX * vpdusY );
+    csProdRange.assign( (size_t) vpdusX * vpdusY, std::make_pair( 0xffffffffu, 0u ) ); csProdPool.clear();
     for( int vy = 0; vy < vpdusY; vy++ ) for( int vx = 0; vx < vpdusX; vx++ )
     {
       const int32_t tl = cuAt[(size_t) ( ( vy << vpduLog2 ) >> 2 ) * w4 + ( ( vx << vpduLog2 ) >> 2 )];
@@ -498,11 +501,30 @@ int PrepScratch::buildWorkLists( std::string& err )
             }
             if( csItem )
             {
-              // luma the chroma scaling factor is averaged over (the unit must wait for the luma units that reconstruct it)
-              const uint32_t d = csVpduV[(size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 )];
-              const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff, n = 1 << vpduLog2;
-              if( ( d >> 26 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, xPos - 1, std::min( yPos + k, (int) h.height - 1 ) );
-              if( ( d >> 27 ) & 1 ) for( int k = 0; k < n; k += 4 ) touch( 0, std::min( xPos + k, (int) h.width - 1 ), yPos - 1 );
+              // luma the chroma scaling factor is averaged over (the unit must wait for the luma units that reconstruct it).  The luma blocks
+              // that produce it are the same for every chroma block of the VPDU and all precede the VPDU's first CU in decoding order, so
+              // they are looked up once per VPDU
+              const size_t vp = (size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 );
+              if( csProdRange[vp].first == 0xffffffffu )
+              {
+                const uint32_t d = csVpduV[vp];
+                const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff, n = 1 << vpduLog2;
+                const uint32_t start = (uint32_t) csProdPool.size();
+                auto look = [&]( int lx, int ly )
+                {
+                  const int32_t id = itemAt[0][(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )];
+                  if( id >= 0 && std::find( csProdPool.begin() + start, csProdPool.end(), (uint32_t) id ) == csProdPool.end() ) csProdPool.push_back( (uint32_t) id );
+                };
+                if( ( d >> 26 ) & 1 ) for( int k = 0; k < n; k += 4 ) look( xPos - 1, std::min( yPos + k, (int) h.height - 1 ) );
+                if( ( d >> 27 ) & 1 ) for( int k = 0; k < n; k += 4 ) look( std::min( xPos + k, (int) h.width - 1 ), yPos - 1 );
+                csProdRange[vp] = std::make_pair( start, (uint32_t) csProdPool.size() - start );
+              }
+              for( uint32_t q = csProdRange[vp].first; q < csProdRange[vp].first + csProdRange[vp].second; q++ )
+              {
+                const uint32_t key = csProdPool[q];          // (component 0)
+                if( std::find( pool.begin() + IH.p0, pool.end(), key ) == pool.end() ) pool.push_back( key );
+              }
+              lastKey = 0xffffffffu;
             }
             if( isCclm )
             {
