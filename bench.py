@@ -115,14 +115,16 @@ def cpu_baseline(cfg_name, seed, gop, budget_s=20.0):
     from concurrent.futures import ProcessPoolExecutor
     kind = "reference" if refdrv.available() else "port"
     W, H = CONFIGS[cfg_name][:2]
-    cores = os.cpu_count() or 1
+    # one process per picture.  Not more than 64 of them: with one per hardware thread of a 256-thread host the processes fight for memory
+    # bandwidth (measured on the MI355X box: 256 processes 70 frames/s at 3.6 s per picture, 32 processes 158 frames/s at 0.2 s)
+    cores = min(os.cpu_count() or 1, 64)
     try:
         import psutil                                             # one process holds a picture description, its planes and the reference's object graph
         cores = max(1, min(cores, int(psutil.virtual_memory().available / (3.0e9 * (4 if W > 4000 else 1)))))
     except Exception:
         pass
     t1 = _cpu_worker((kind, cfg_name, seed, gop, 0))             # calibration: one picture on one core
-    per_core = max(1, min(4, int(budget_s / max(3 * t1, 1e-3))))
+    per_core = max(1, min(3, int(budget_s / max(6 * t1, 1e-3))))
     n = cores * per_core
     with ProcessPoolExecutor(max_workers=cores, mp_context=multiprocessing.get_context("spawn")) as ex:
         list(ex.map(_cpu_worker, [(kind, cfg_name, seed, gop, i) for i in range(cores)]))       # start the workers (imports, library loads)
@@ -152,6 +154,7 @@ def main():
     ap.add_argument("--slots", type=int, default=24, help="DPB slots used round-robin")
     ap.add_argument("--intra-period", type=int, default=-1, help="an IRAP picture every N pictures (multiple of --gop); default: the configuration's")
     ap.add_argument("--irap-lookahead", type=int, default=8, help="IRAP pictures are submitted N pictures ahead of their decoding-order position (they depend on nothing)")
+    ap.add_argument("--pageable-records", action="store_true", help="keep the host records in ordinary (pageable) memory: the library stages them through its pinned ring")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=8, help="number of timed pictures re-checked against the CPU oracle after the run")
     a = ap.parse_args()
@@ -186,7 +189,8 @@ def main():
     n_irap = sum(1 for pl in plans[first:first + K] if pl.slice_type == abi.SLICE_I)
     seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads)
-    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **mix) for pl in plans]
+    # the records are written where a parser integrated with the back-end would write them: host memory the device reads directly (vvr_host_alloc)
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, alloc=None if a.pageable_records else rec.host_array, **mix) for pl in plans]
     cpics = [d.c() for d in descs]                     # the host records as the C ABI sees them (plain structs pointing at the arrays)
     upload_mb = sum(d.cu.nbytes + d.tu.nbytes + d.coef.nbytes + d.lfp[0].nbytes + d.lfp[1].nbytes for d in descs[first:first + K]) / K / 1e6
 
@@ -255,7 +259,7 @@ def main():
         achieved = dom["algo_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": None,
-                "peak_measured": round(copy_bps / 1e9, 1), "peak_measured_how": "k_copy over one DPB slot (read + write), HIP events, 20 launches, same run",
+                "peak_measured": round(copy_bps / 1e9, 1), "peak_measured_how": "the library's copy kernel over the DPB (%d MB read + %d MB written per launch), HIP events, 20 launches, same run" % ((min(nslots, 2 * a.streams) * rec.slot_bytes()) >> 20, (min(nslots, 2 * a.streams) * rec.slot_bytes()) >> 20),
                 "frac_of_measured": round(achieved / max(copy_bps / 1e9, 1e-9), 4),
                 "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                 "algorithmic_bytes_per_launch": int(dom["algo_bytes"] / dom["launches"]),
@@ -306,7 +310,7 @@ def main():
                "config": {"workload": "%s, %dx%d, CTU 128%s; timed: K pictures through vvr_submit from host records (validation, work lists on %d library threads, H2D of %.1f MB per picture, all kernels); %d pre-roll + W warm-up pictures untimed; %d IRAP picture(s) in the timed window"
                                       % (cfg_text, W, H, "" if a.config == "allintra" else ", hierarchical-B GOP %d, IRAP every %d pictures, submitted %d pictures ahead of its decoding-order position" % (a.gop, intra_period, a.irap_lookahead),
                                          a.host_threads, upload_mb, first - Wm, n_irap),
-                          "timed_path": "vvr_submit(host records)", "host_threads": a.host_threads, "host_cores": os.cpu_count(),
+                          "timed_path": "vvr_submit(host records)", "host_records_in": "pageable memory (staged by the library)" if a.pageable_records else "pinned host memory of the context (vvr_host_alloc): cu / tu / coef / lfp arrays are copied to HBM from where the generator wrote them", "host_threads": a.host_threads, "host_cores": os.cpu_count(),
                           "device_only_fps": round(world * K / dt_dev, 2), "device_only_ms_per_step": round(1e3 * dt_dev / K, 4),
                           "device_only_what": "same K pictures, records and work lists resident in HBM (vvr_prepare + vvr_submit_prepared)",
                           "irap_in_window": n_irap, "irap_share_of_stream": "1/%d" % intra_period if a.config != "allintra" else "1/1",

@@ -309,6 +309,8 @@ typedef struct vvr_picture {
 /* ------------------------------------------------------------------------------------------------------------------
  * context  (replaces DecLibRecon instances + the DPB picture buffers they write)
  * ---------------------------------------------------------------------------------------------------------------- */
+enum { VVR_STOP_NONE = 0, VVR_STOP_RECO = 1, VVR_STOP_DEBLOCK = 2, VVR_STOP_SAO = 3 };
+
 typedef struct vvr_config {
   uint32_t abi_version;
   int32_t  device;               /* HIP device ordinal                                                          */
@@ -320,7 +322,10 @@ typedef struct vvr_config {
                                     decompressPicture over its thread pool, DecLibRecon.cpp:429-682).  0: the submitting thread does it inside
                                     vvr_submit; N > 0: vvr_submit only queues the picture, N pictures are prepared concurrently and enqueued
                                     on the device in submission order                                                                        */
-  uint8_t  pad[2];
+  uint8_t  stop_after;           /* conformance aid (the reference has per-stage CRC traces for the same purpose, LoopFilter.cpp:399-406): 0 =
+                                    full reconstruction; VVR_STOP_RECO / _DEBLOCK / _SAO: the pictures of this context stop after that stage, so
+                                    that they can be compared with the reference's picture at the same point                                  */
+  uint8_t  pad;
   void*    ext_planes;           /* optional: caller-owned device memory for the DPB, num_slots * vvr_slot_bytes */
                                  /* (mirrors vvdec_decoder_open_with_allocator, vvdec.h.in:576)                 */
 } vvr_config;
@@ -339,6 +344,12 @@ VVR_API void         vvr_destroy(vvr_context* ctx);
 VVR_API int          vvr_submit(vvr_context* ctx, const vvr_picture* pic);
 /* blocks until the host arrays of job `job` are no longer needed (its device work lists are built and staged in pinned memory) */
 VVR_API int          vvr_inputs_done(vvr_context* ctx, int job);
+/* Host memory the device reads directly (pinned), owned by the context (freed with it at the latest).  A parser that writes its records into
+ * such memory (the way vvdec_decoder_open_with_allocator, vvdec.h.in:576, lets the application own the picture buffers) saves the back-end the
+ * staging copy: the cu / tu / coef / lfp arrays of a submitted picture that lie in it are copied to HBM from where they are, and must then stay
+ * unchanged until vvr_inputs_done(job) (which waits for that copy) or vvr_wait(job). */
+VVR_API void*        vvr_host_alloc(vvr_context* ctx, size_t bytes);
+VVR_API void         vvr_host_free(vvr_context* ctx, void* p);
 /* DecLibRecon::waitForPrevDecompressedPic (DecLibRecon.cpp:684): blocks until job `job` is reconstructed; returns its status. */
 VVR_API int          vvr_wait(vvr_context* ctx, int job);
 /* wait for everything in flight */

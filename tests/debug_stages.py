@@ -12,10 +12,8 @@ plans, nslots = stream.ra_plan(5, gop=4)
 seed_pic = synth.natural_picture(W, H, seed)
 pl = plans[0]
 d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, p_intra=0.0, **kw)
-for name, flag in (("reco", 4), ("dbk", 8), ("sao", 16), ("", 0)):
-    if name: os.environ["VVR_STOP_AFTER"] = name
-    else: os.environ.pop("VVR_STOP_AFTER", None)
-    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, log2_ctu=d.hdr.log2_ctu)
+for name, flag, stop in (("reco", 4, abi.STOP_RECO), ("dbk", 8, abi.STOP_DEBLOCK), ("sao", 16, abi.STOP_SAO), ("", 0, abi.STOP_NONE)):
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, log2_ctu=d.hdr.log2_ctu, stop_after=stop)
     rec.write_picture(0, seed_pic)
     rec.wait(rec.decompress_picture(d))
     got = rec.read_picture(pl.slot)

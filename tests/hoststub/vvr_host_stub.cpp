@@ -36,7 +36,8 @@ hipError_t hipEventSynchronize( hipEvent_t ) { return hipSuccess; }
 hipError_t hipEventElapsedTime( float* ms, hipEvent_t, hipEvent_t ) { *ms = 0.f; return hipSuccess; }
 hipError_t hipGetLastError( void ) { return hipSuccess; }
 const char* hipGetErrorString( hipError_t ) { return "host stub"; }
-hipError_t hipMemcpyAsync( void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t ) { memcpy( d, s, n ); return hipSuccess; }
+static size_t g_h2dCopies = 0, g_h2dBytes = 0;
+hipError_t hipMemcpyAsync( void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t ) { memcpy( d, s, n ); if( k == hipMemcpyHostToDevice ) { g_h2dCopies++; g_h2dBytes += n; } return hipSuccess; }
 hipError_t hipMemsetAsync( void* d, int v, size_t n, hipStream_t ) { memset( d, v, n ); return hipSuccess; }
 }
 
@@ -53,6 +54,7 @@ void launch_sao( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) {}
 void launch_alf( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) {}
 void launch_lmcs( hipStream_t, const PicDev&, DevPlanes, int ) {}
 void launch_copy_planes( hipStream_t, DevPlanes, DevPlanes ) {}
+void launch_copy_bytes( hipStream_t, const void*, void*, size_t ) {}
 void launch_mc_affine( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int ) {}
 void launch_mc_dmvr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int32_t* ) {}
 void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, int numUnits, int* sync ) { g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
@@ -122,6 +124,8 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
   }
   return 0;
 }
+// asynchronous host-to-device copies issued so far: count and bytes (cleared by the call)
+__attribute__(( visibility( "default" ) )) void vvt_take_h2d( size_t* copies, size_t* bytes ) { *copies = g_h2dCopies; *bytes = g_h2dBytes; g_h2dCopies = g_h2dBytes = 0; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }
 // pretend the lane's flag buffer is small (the product sizes it for ordinary pictures; the growth path needs a picture with more units than that)

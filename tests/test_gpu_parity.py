@@ -29,7 +29,7 @@ def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=Tru
         cpu = {0: seed_pic}
         kw.setdefault("p_intra", 0.0)
     hashes = []
-    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **geo, **kw) for pl in plans]
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, alloc=rec.host_array, **geo, **kw) for pl in plans]     # records in pinned memory of `rec`
     jobs = [rec.decompress_picture(d) for d in descs]          # everything in flight: the back-end orders the dependencies
     rec.sync()
     # verify in decode order; the CPU oracle consumes its own previous outputs as references.  A slot is overwritten
@@ -384,19 +384,15 @@ def _golden_files():
 
 
 @pytest.mark.parametrize("path", _golden_files(), ids=lambda p: p.split("/")[-1][:-4])
-def test_golden_fixtures_reference_outputs(built, path, monkeypatch):
+def test_golden_fixtures_reference_outputs(built, path):
     """HIP path against what the REAL reference classes produced (tests/golden, written by make_golden.py), every stage."""
     import vvdec_amd
     import golden_io
     d, refs, outs = golden_io.load(path)
     h = d.hdr
     nslots = max([h.out_slot] + list(refs.keys())) + 1
-    for st, env in (("final", None), ("reco", "reco"), ("dbk", "dbk"), ("sao", "sao")):
-        if env:
-            monkeypatch.setenv("VVR_STOP_AFTER", env)
-        else:
-            monkeypatch.delenv("VVR_STOP_AFTER", raising=False)
-        rec = vvdec_amd.Reconstructor(h.width, h.height, bit_depth=h.bit_depth, log2_ctu=h.log2_ctu, num_slots=nslots, num_streams=1)
+    for st, stop in (("final", abi.STOP_NONE), ("reco", abi.STOP_RECO), ("dbk", abi.STOP_DEBLOCK), ("sao", abi.STOP_SAO)):
+        rec = vvdec_amd.Reconstructor(h.width, h.height, bit_depth=h.bit_depth, log2_ctu=h.log2_ctu, num_slots=nslots, num_streams=1, stop_after=stop)
         for slot, planes in refs.items():
             rec.write_picture(slot, planes)
         rec.wait(rec.decompress_picture(d))
@@ -407,13 +403,14 @@ def test_golden_fixtures_reference_outputs(built, path, monkeypatch):
 
 
 def test_copy_kernel_bandwidth(built):
-    """the measured HBM ceiling bench.py reports next to the nominal 8 TB/s: the library's copy kernel over one DPB slot"""
+    """the measured HBM ceiling bench.py reports next to the nominal 8 TB/s: the library's copy kernel over the DPB (16 slots -> 8 lanes of scratch
+    planes: 400 MB each way, beyond the caches)"""
     import vvdec_amd
-    rec = vvdec_amd.Reconstructor(3840, 2160, num_slots=2, num_streams=1)
+    rec = vvdec_amd.Reconstructor(3840, 2160, num_slots=16, num_streams=8)
     pic = synth.natural_picture(3840, 2160, 5)
     rec.write_picture(0, pic)
     bps = rec.copy_bandwidth(10)
-    assert 0.2e12 < bps < 8.0e12, bps
+    assert 1.0e12 < bps < 8.0e12, bps
     got = rec.read_picture(0)
     assert all(np.array_equal(g, w) for g, w in zip(got, pic))          # slot 0 is only read
     rec.close()

@@ -576,3 +576,50 @@ def test_errors_of_queued_pictures_come_back_from_wait(stub):
     bad2 = mk(plans[0]); bad2.hdr.out_slot = nslots
     assert stub.vvr_submit(ctx, C.byref(bad2.c())) == abi.VVR_ERR_PARAMETER
     stub.vvr_destroy(ctx)
+
+
+def test_records_in_pinned_memory_are_not_staged(stub):
+    """arrays of a description that lie in memory of vvr_host_alloc go to the device from where they are: per picture one copy of the staged
+    rest plus one per pinned array, the same bytes in total (up to alignment padding)"""
+    W, H = 832, 480
+    plans, nslots = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    cfg = abi.Config()
+    cfg.abi_version = abi.VVR_ABI_VERSION
+    cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, 6
+    cfg.num_slots, cfg.num_streams, cfg.host_threads = nslots, 2, 2
+    ctx = C.c_void_p()
+    assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    stub.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+    stub.vvr_inputs_done.argtypes = [C.c_void_p, C.c_int]
+    stub.vvr_host_alloc.restype = C.c_void_p
+    stub.vvr_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    stub.vvt_take_h2d.argtypes = [C.c_void_p, C.c_void_p]
+
+    def pinned(n, dt):
+        dt = np.dtype(dt)
+        nb = max(1, n) * dt.itemsize
+        return np.frombuffer((C.c_char * nb).from_address(stub.vvr_host_alloc(ctx, nb)), dt, count=max(1, n))[:n]
+
+    def run(alloc):
+        cnt, nbytes = C.c_size_t(), C.c_size_t()
+        stub.vvt_take_h2d(C.byref(cnt), C.byref(nbytes))
+        out = []
+        for pl in plans:
+            d = synth.picture_for_plan(pl, W, H, seed=512, tool_flags=TOOLS, log2_ctu=6, p_intra=0.2, p_split_scale=1.5, p_coded=0.9, p_small_corner=0.1, alloc=alloc)
+            p = d.c()
+            j = stub.vvr_submit(ctx, C.byref(p))
+            assert j >= 0 and stub.vvr_inputs_done(ctx, j) == abi.VVR_OK and stub.vvr_wait(ctx, j) == abi.VVR_OK
+            stub.vvt_take_h2d(C.byref(cnt), C.byref(nbytes))
+            out.append((cnt.value, nbytes.value, [a.nbytes >= 65536 for a in (d.lfp[0], d.lfp[1], d.cu, d.coef, d.tu)]))
+        return out
+
+    staged, direct = run(None), run(pinned)
+    for (c0, b0, _), (c1, b1, big) in zip(staged, direct):
+        ndirect = 0
+        for flag in big:                       # (only a leading run of large arrays is copied directly)
+            if not flag:
+                break
+            ndirect += 1
+        assert c0 == 1 and c1 == 1 + ndirect and ndirect >= 2 and 0 <= b0 - b1 < 256 * ndirect      # (the staged image pads every array to 256 bytes)
+    stub.vvr_destroy(ctx)

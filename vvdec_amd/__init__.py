@@ -74,6 +74,9 @@ def lib():
         L.vvr_plane_layout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vvr_inputs_done.restype = C.c_int
         L.vvr_inputs_done.argtypes = [C.c_void_p, C.c_int]
+        L.vvr_host_alloc.restype = C.c_void_p
+        L.vvr_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        L.vvr_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.vvr_measure_copy_bandwidth.restype = C.c_double
         L.vvr_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int]
         _lib = L
@@ -83,17 +86,17 @@ def lib():
 EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
                     "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_picture_hash", "vvr_write_plane", "vvr_read_dmvr", "vvr_prepare", "vvr_submit_prepared",
                     "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof",
-                    "vvr_inputs_done", "vvr_measure_copy_bandwidth"]
+                    "vvr_inputs_done", "vvr_measure_copy_bandwidth", "vvr_host_alloc", "vvr_host_free"]
 
 
 class Reconstructor:
-    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, num_slots=8, num_streams=2, device=0, ext_planes=None, host_threads=0):
+    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, num_slots=8, num_streams=2, device=0, ext_planes=None, host_threads=0, stop_after=0):
         self.L = lib()
         cfg = abi.Config()
         cfg.abi_version = abi.VVR_ABI_VERSION
         cfg.device, cfg.max_width, cfg.max_height = device, width, height
         cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = chroma_format, bit_depth, log2_ctu
-        cfg.num_slots, cfg.num_streams, cfg.host_threads = num_slots, num_streams, host_threads
+        cfg.num_slots, cfg.num_streams, cfg.host_threads, cfg.stop_after = num_slots, num_streams, host_threads, stop_after
         cfg.ext_planes = ext_planes
         self.cfg = cfg
         self.ctx = C.c_void_p()
@@ -139,6 +142,16 @@ class Reconstructor:
 
     def inputs_done(self, job):
         self._check(self.L.vvr_inputs_done(self.ctx, job))
+
+    def host_array(self, n, dtype):
+        """numpy array of n records in host memory the device reads directly (vvr_host_alloc): descriptions built in such arrays are
+        uploaded without a staging copy.  The memory belongs to the context (freed by close())."""
+        dt = np.dtype(dtype)
+        nbytes = max(1, int(n)) * dt.itemsize
+        ptr = self.L.vvr_host_alloc(self.ctx, nbytes)
+        if not ptr:
+            raise VvrError("vvr_host_alloc(%d) failed" % nbytes)
+        return np.frombuffer((C.c_char * nbytes).from_address(ptr), dt, count=max(1, int(n)))[:int(n)]
 
     def copy_bandwidth(self, iters=20):
         """practical HBM ceiling: bytes/s (read + written) of the library's copy kernel over one DPB slot"""

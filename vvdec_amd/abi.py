@@ -30,6 +30,7 @@ MC_NONE, MC_UNI, MC_BI, MC_BDOF, MC_DMVR, MC_DMVR_BDOF, MC_AFFINE, MC_SBTMVP, MC
 MTS_DCT2, MTS_SKIP, MTS_DST7_DST7, MTS_DCT8_DST7, MTS_DST7_DCT8, MTS_DCT8_DCT8 = range(6)
 TR_DCT2, TR_DCT8, TR_DST7 = 0, 1, 2
 SLICE_B, SLICE_P, SLICE_I = 0, 1, 2
+STOP_NONE, STOP_RECO, STOP_DEBLOCK, STOP_SAO = 0, 1, 2, 3
 
 u8, i8, u16, i16, u32, i32, u64 = C.c_uint8, C.c_int8, C.c_uint16, C.c_int16, C.c_uint32, C.c_int32, C.c_uint64
 
@@ -113,7 +114,7 @@ class Picture(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("abi_version", u32), ("device", i32), ("max_width", u16), ("max_height", u16),
-                ("chroma_format", u8), ("bit_depth", u8), ("log2_ctu", u8), ("num_slots", u8), ("num_streams", u8), ("host_threads", u8), ("pad", u8 * 2),
+                ("chroma_format", u8), ("bit_depth", u8), ("log2_ctu", u8), ("num_slots", u8), ("num_streams", u8), ("host_threads", u8), ("stop_after", u8), ("pad", u8),
                 ("ext_planes", C.c_void_p)]
 
 

@@ -26,7 +26,6 @@
 #include <thread>
 
 int vvr_upload_tables();
-size_t vvr_host_upload_bytes( const PrepScratch& S );
 
 #define HIPCHK( ctx, call ) do { hipError_t e_ = ( call ); if( e_ != hipSuccess ) { ( ctx )->setError( std::string( #call ) + ": " + hipGetErrorString( e_ ) ); return VVR_ERR_DEVICE; } } while( 0 )
 
@@ -42,7 +41,8 @@ struct RingEntry {
   int32_t* dmvrHost = nullptr; size_t dmvrCap = 0;      // ints
   hipEvent_t copied = nullptr;
   vvr_prepared q;
-  size_t uploadBytes = 0;
+  size_t stagedBegin = 0, stagedEnd = 0;                // the part of the image that goes through `host`
+  std::vector<DirectCopy> direct;                       // arrays copied straight from the caller's pinned memory
   struct Job* owner = nullptr;                          // the job whose picture sits in the entry (nullptr: free)
 };
 
@@ -94,6 +94,7 @@ struct vvr_context {
   std::vector<std::thread> workers;
   bool       stop = false;
   PrepScratch* inlineScratch = nullptr; // host_threads == 0, and vvr_prepare
+  PinnedRanges pinned;                  // vvr_host_alloc
   bool       statsOn = false;
   Stat       stats[K_NUM];
   void setError( const std::string& e ) { err = e; }
@@ -174,7 +175,8 @@ static int commitLocked( vvr_context* c, Job& job )
   if( job.ring )
   {
     RingEntry& e = *job.ring;
-    HIPCHK( c, hipMemcpyAsync( e.dev, e.host, e.uploadBytes, hipMemcpyHostToDevice, c->copyStream ) );
+    HIPCHK( c, hipMemcpyAsync( e.dev + e.stagedBegin, e.host + e.stagedBegin, e.stagedEnd - e.stagedBegin, hipMemcpyHostToDevice, c->copyStream ) );
+    for( auto& d : e.direct ) HIPCHK( c, hipMemcpyAsync( e.dev + d.off, d.src, d.n, hipMemcpyHostToDevice, c->copyStream ) );
     HIPCHK( c, hipEventRecord( e.copied, c->copyStream ) );
     HIPCHK( c, hipStreamWaitEvent( s, e.copied, 0 ) );
   }
@@ -232,11 +234,7 @@ static int commitLocked( vvr_context* c, Job& job )
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
   if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
-  int stopAfter = 0;
-#ifdef VVR_DEBUG_STAGES
-  // debugging aid (like the reference's per-stage CRC traces, LoopFilter.cpp:399-406): VVR_STOP_AFTER=reco|dbk|sao
-  { const char* e = getenv( "VVR_STOP_AFTER" ); stopAfter = !e ? 0 : !strcmp( e, "reco" ) ? 1 : !strcmp( e, "dbk" ) ? 2 : !strcmp( e, "sao" ) ? 3 : 0; }
-#endif
+  const int stopAfter = c->cfg.stop_after;       // conformance aid: vvr_config.stop_after
   if( !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF ) && stopAfter != 1 )
   {
     timed( K_DEBLOCK_V, [&]{ launch_deblock( s, q->pic, A, 0 ); } );
@@ -296,7 +294,7 @@ static void commitReadyLocked( vvr_context* c )
 static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
 {
   size_t total = 0; std::string err;
-  int rc = vvr_host_build( &job.pic, S, &total, err );
+  int rc = vvr_host_build( &job.pic, S, &total, err, &c->pinned );
   RingEntry& e = c->ring[job.seq % c->ring.size()];
   if( rc == VVR_OK )
   {
@@ -337,7 +335,7 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
   {
     vvr_host_pack( S, e.host );
     vvr_host_bind( S, e.q, e.dev );
-    e.uploadBytes = vvr_host_upload_bytes( S );
+    vvr_host_upload_plan( S, e.direct, &e.stagedBegin, &e.stagedEnd );
     const size_t nInts = 2 * (size_t) e.q.numDmvr;
     if( nInts > e.dmvrCap )
     {
@@ -437,7 +435,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
 {
   if( !cfg || !out || cfg->abi_version != VVR_ABI_VERSION ) return VVR_ERR_PARAMETER;
   // Main 10: 4:0:0 / 4:2:0, 8..10-bit samples (the formats the parity tests cover); CTU 32..128
-  if( cfg->chroma_format > 1 || cfg->bit_depth < 8 || cfg->bit_depth > 10 || cfg->log2_ctu < 5 || cfg->log2_ctu > 7 || !cfg->num_slots || cfg->host_threads > 64 ) return VVR_ERR_UNSUPPORTED;
+  if( cfg->chroma_format > 1 || cfg->bit_depth < 8 || cfg->bit_depth > 10 || cfg->log2_ctu < 5 || cfg->log2_ctu > 7 || !cfg->num_slots || cfg->host_threads > 64 || cfg->stop_after > VVR_STOP_SAO ) return VVR_ERR_UNSUPPORTED;
   int ndev = 0;
   if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0 || cfg->device >= ndev ) return VVR_ERR_NO_DEVICE;
   if( hipSetDevice( cfg->device ) != hipSuccess ) return VVR_ERR_NO_DEVICE;
@@ -509,6 +507,7 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( c->outHost ) hipHostFree( c->outHost );
   for( auto p : c->syncBuf ) hipFree( p );
   if( c->inlineScratch ) vvr_scratch_destroy( c->inlineScratch );
+  for( auto& e : c->pinned.r ) hipHostFree( (void*) e.first );
   delete c;
 }
 
@@ -591,7 +590,38 @@ VVR_API int vvr_inputs_done( vvr_context* c, int id )
   if( it == c->jobs.end() ) return VVR_OK;
   Job& j = *it->second;
   c->cv.wait( lk, [&]{ return j.state >= J_READY; } );
+  if( j.ring && !j.ring->direct.empty() && j.ring->owner == &j )
+  {
+    // arrays in pinned memory are read by the copy engine: wait for the picture's upload
+    c->cv.wait( lk, [&]{ return j.state == J_COMMITTED || j.completed; } );
+    if( !j.completed )
+    {
+      hipEvent_t ev = j.ring->copied;
+      lk.unlock();
+      hipSetDevice( c->device );
+      hipEventSynchronize( ev );
+    }
+  }
   return VVR_OK;
+}
+
+VVR_API void* vvr_host_alloc( vvr_context* c, size_t bytes )
+{
+  if( !c || !bytes ) return nullptr;
+  hipSetDevice( c->device );
+  void* p = nullptr;
+  if( hipHostMalloc( &p, bytes, hipHostMallocDefault ) != hipSuccess ) return nullptr;
+  std::lock_guard<std::mutex> lk( c->pinned.mu );
+  c->pinned.r.emplace_back( (const char*) p, bytes );
+  return p;
+}
+
+VVR_API void vvr_host_free( vvr_context* c, void* p )
+{
+  if( !c || !p ) return;
+  { std::lock_guard<std::mutex> lk( c->pinned.mu ); for( auto it = c->pinned.r.begin(); it != c->pinned.r.end(); ++it ) if( it->first == (const char*) p ) { c->pinned.r.erase( it ); break; } }
+  hipSetDevice( c->device );
+  hipHostFree( p );
 }
 
 VVR_API void vvr_free_prepared( vvr_context* c, vvr_prepared* q )
@@ -630,7 +660,9 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   q->blobBytes = total;
   vvr_host_pack( S, staging );
   vvr_host_bind( S, *q, (char*) q->blob );
-  const hipError_t e = hipMemcpy( q->blob, staging, vvr_host_upload_bytes( S ), hipMemcpyHostToDevice );
+  std::vector<DirectCopy> none; size_t b0 = 0, b1 = 0;
+  vvr_host_upload_plan( S, none, &b0, &b1 );
+  const hipError_t e = hipMemcpy( q->blob, staging, b1, hipMemcpyHostToDevice );
   hipHostFree( staging );
   if( e == hipSuccess && q->numDmvr && hipHostMalloc( (void**) &q->dmvrHost, sizeof( int32_t ) * 2 * (size_t) q->numDmvr, hipHostMallocDefault ) != hipSuccess )
   { vvr_free_prepared( c, q ); c->setError( "vvr_prepare: out of pinned memory" ); return VVR_ERR_DEVICE; }
@@ -719,8 +751,9 @@ VVR_API int vvr_get_stats( vvr_context* c, vvr_kernel_stat* out, int maxEntries 
   return n;
 }
 
-// practical HBM ceiling: a device copy of one DPB slot into a lane's scratch slot, timed with HIP events ("measure the practical
-// ceiling with a device copy kernel"); returns bytes moved per second (read + write), averaged over `iters` launches
+// practical HBM ceiling ("measure the practical ceiling with a device copy kernel"): the library's copy kernel over as much of
+// the DPB as the scratch planes hold (hundreds of MB for a 4K context: well beyond L2 and the Infinity Cache), HIP-event timed; returns bytes
+// moved per second (read + written), averaged over `iters` launches.  The DPB is only read; the scratch planes hold nothing between pictures.
 VVR_API double vvr_measure_copy_bandwidth( vvr_context* c, int iters )
 {
   if( !c || iters <= 0 ) return 0.0;
@@ -729,16 +762,15 @@ VVR_API double vvr_measure_copy_bandwidth( vvr_context* c, int iters )
   hipEvent_t a, b;
   if( hipEventCreate( &a ) != hipSuccess || hipEventCreate( &b ) != hipSuccess ) return 0.0;
   hipStream_t s = c->streams[0];
-  launch_copy_planes( s, c->slots[0], c->scratchB[0] );       // warm-up
+  const size_t bytes = std::min( c->slotBytes * c->cfg.num_slots, c->slotBytes * 2 * c->streams.size() ) & ~(size_t) 4095;
+  launch_copy_bytes( s, c->planeMem, c->scratchMem, bytes );       // warm-up
   hipEventRecord( a, s );
-  for( int i = 0; i < iters; i++ ) launch_copy_planes( s, c->slots[0], c->scratchB[0] );
+  for( int i = 0; i < iters; i++ ) launch_copy_bytes( s, c->planeMem, c->scratchMem, bytes );
   hipEventRecord( b, s );
   hipEventSynchronize( b );
   float ms = 0; hipEventElapsedTime( &ms, a, b );
   hipEventDestroy( a ); hipEventDestroy( b );
-  double bytes = 0;
-  for( int k = 0; k < 3; k++ ) bytes += 2.0 * sizeof( pel_t ) * (double) c->slots[0].w[k] * c->slots[0].h[k];
-  return ms > 0 ? bytes * iters / ( ms * 1e-3 ) : 0.0;
+  return ms > 0 ? 2.0 * (double) bytes * iters / ( ms * 1e-3 ) : 0.0;
 }
 
 VVR_API uint8_t vvr_resolve_tr_type( const vvr_pic_header* hdr, const vvr_cu* cu, const vvr_tu* tu, int comp, int implicit_mts, int explicit_intra, int explicit_inter )

@@ -111,6 +111,7 @@ void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes 
 void launch_alf    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 void launch_lmcs   ( hipStream_t s, const PicDev& pic, DevPlanes reco, int inverse );
 void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst );
+void launch_copy_bytes( hipStream_t s, const void* src, void* dst, size_t bytes );
 void launch_output_window( hipStream_t s, const pel_t* src, int stride, int w, int h, int bytesPerSample, void* dst );      // window rows packed back to back, 1 or 2 bytes per sample
 void launch_plane_hash_rows( hipStream_t s, const pel_t* plane, int stride, int w, int h, int two, int crcMode, uint32_t* out );   // per row: checksum share / CRC piece
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );

@@ -2,6 +2,7 @@
 // the work lists a picture's kernels iterate over).  Nothing here is part of the ABI (include/vvr.h).
 #pragma once
 #include "vvr_device.h"
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,20 @@ struct vvr_prepared {
   struct vvr_context* owner = nullptr;
 };
 
+// Host memory the device can read directly (vvr_host_alloc): arrays of a submitted picture that lie in it are not staged, they are copied to HBM
+// from where they are.
+struct PinnedRanges {
+  std::mutex mu;
+  std::vector<std::pair<const char*, size_t>> r;
+  bool contains( const void* p, size_t n )
+  {
+    std::lock_guard<std::mutex> lk( mu );
+    for( auto& e : r ) if( (const char*) p >= e.first && (const char*) p + n <= e.first + e.second ) return true;
+    return false;
+  }
+};
+struct DirectCopy { const void* src; size_t n, off; };
+
 // Reusable scratch of one preparing thread: the lists are built here (no allocation in the steady state), then packed into pinned memory.
 struct PrepScratch;
 PrepScratch* vvr_scratch_create();
@@ -37,8 +52,10 @@ void         vvr_scratch_destroy( PrepScratch* );
 int    vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string& err );
 // host glue: the work lists of one picture (what DecCu::TaskTrafoCtu / TaskInterCtu / the intra task iterate over, DecCu.cpp:106-160); returns the
 // number of bytes the picture needs in HBM
-int    vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err );
-// the H2D image: every part at its offset (256-byte aligned) into `host` (pinned memory of at least totalBytes)
+int    vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err, PinnedRanges* pinned = nullptr );
+// the H2D image: every staged part at its offset (256-byte aligned) into `host` (pinned memory of at least totalBytes); the parts that are
+// copied straight from the caller's pinned arrays, and the byte range [begin, end) of the image that is staged
 void   vvr_host_pack( const PrepScratch& S, char* host );
+void   vvr_host_upload_plan( const PrepScratch& S, std::vector<DirectCopy>& direct, size_t* stagedBegin, size_t* stagedEnd );
 // device pointers of a prepared picture whose image sits at devBase
 void   vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* devBase );

@@ -1926,6 +1926,12 @@ void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst )
   }
 }
 
+void launch_copy_bytes( hipStream_t s, const void* src, void* dst, size_t bytes )
+{
+  const size_t n16 = bytes / 16;
+  hipLaunchKernelGGL( k_copy, dim3( (unsigned) std::min<size_t>( ( n16 + 255 ) / 256, 256 * 32 ) ), dim3( 256 ), 0, s, (const uint4*) src, (uint4*) dst, n16 );
+}
+
 // =====================================================================================================================
 // output stage: window of a plane packed to the bytes the application / the MD5 wants; per-row CRC and checksum pieces
 //   VVDecImpl::copyComp (vvdecimpl.cpp:818-880), compCRC / compChecksum (PicYuvMD5.cpp:99-176)

@@ -22,7 +22,7 @@ struct ItemH { uint32_t ctu; BBox bb; uint32_t p0, pn; };
 // the stage starts).
 struct UnitH { uint32_t comp, ctu, i0, i1, iA = 0; bool hasCs = false; BBox bb; std::vector<uint32_t> deps; bool waited = false; int rank = 0; };
 
-struct Part { const void* src; size_t n, off; };
+struct Part { const void* src; size_t n, off; bool direct; };
 
 struct PrepScratch
 {
@@ -46,8 +46,11 @@ struct PrepScratch
   // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
   std::vector<int32_t> order;
   std::vector<uint8_t> intraAt;            // per 4x4 luma unit: covered by an intra CU (1) / a CIIP CU (2)
-  std::vector<int32_t> itemAt[3];          // per component and 4x4 luma cell: the block that reconstructs it in the intra stage (-1: none)
-  std::vector<int32_t> cuAt;
+  // per component and 4x4 luma cell: the block that reconstructs it in the intra stage, stamped with the number of the picture it was written for
+  // ( epoch << 22 | block ): the maps are never cleared, an entry of another picture reads as "none"
+  std::vector<uint32_t> itemAtE[3];
+  uint32_t epoch = 0;
+  int32_t itemAtGet( int k, size_t cell ) const { const uint32_t v = itemAtE[k][cell]; return ( v >> 22 ) == epoch ? (int32_t) ( v & 0x3fffffu ) : -1; }
   std::vector<uint8_t> interAtV;
   std::vector<UnitH> units, unitsTmp;
   // LMCS chroma residual scaling: per VPDU the luma neighbourhood its factor is averaged over (Reshape::calculateChromaAdjVpduNei,
@@ -62,7 +65,7 @@ struct PrepScratch
   std::vector<std::vector<uint32_t>> members, groups;
   // ---- layout of the H2D image
   std::vector<Part> parts;
-  size_t total = 0;
+  size_t total = 0, numDirect = 0;          // parts [0, numDirect) are copied from the caller's pinned arrays
   int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iLmcs, iSl, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iDmvrOut, iTb[3], iIntra, iUnits;
 
   void begin( const vvr_picture* pic )
@@ -94,7 +97,7 @@ struct PrepScratch
   int formUnits();
   int groupUnits();
   int emitUnitTable( std::string& err );
-  void layout();
+  void layout( PinnedRanges* pinned );
   void foldLongDepLists();
   void rankUnits();
 };
@@ -142,10 +145,13 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
     if( !cu.w || !cu.h || cu.x + cu.w > h.width || cu.y + cu.h > h.height || cu.first_tu + cu.num_tu > p->num_tu ) FAIL( VVR_ERR_PARAMETER, "CU outside the picture / bad TU range" );
     if( cu.tree != VVR_TREE_CHROMA ) areaLuma += (uint64_t) cu.w * cu.h;
     if( cu.tree != VVR_TREE_LUMA ) areaChroma += (uint64_t) cu.w * cu.h;
-    // ---- the CU's transform units: inside the CU, owned by it, coded corners inside the level stream
+    // ---- the CU's transform units: inside the CU, owned by it, tiling it, coded corners inside the level stream
+    uint32_t tuAreaL = 0, tuAreaC = 0;
     for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
     {
       const vvr_tu& tu = p->tu[t];
+      if( tu.comp_mask & 1 ) tuAreaL += (uint32_t) tu.w * tu.h;
+      if( tu.comp_mask & 6 ) tuAreaC += cu.isp_mode ? (uint32_t) cu.w * cu.h : (uint32_t) tu.w * tu.h;      // ISP: the unsplit chroma blocks sit in the last TU
       if( tu.cu != i ) FAIL( VVR_ERR_PARAMETER, "TU does not name its CU" );
       if( !tu.w || !tu.h || tu.x < cu.x || tu.y < cu.y || tu.x + tu.w > cu.x + cu.w || tu.y + tu.h > cu.y + cu.h ) FAIL( VVR_ERR_PARAMETER, "TU outside its CU" );
       if( tu.w > 64 || tu.h > 64 || ( tu.comp_mask & ~( ncomp == 3 ? 7 : 1 ) ) ) FAIL( VVR_ERR_PARAMETER, "TU larger than 64 samples or with components the format does not have" );
@@ -164,6 +170,8 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
         if( (uint64_t) tu.coef_off[c] + n > p->num_coef ) FAIL( VVR_ERR_PARAMETER, "TU: coded corner outside the level stream" );
       }
     }
+    if( ( cu.tree != VVR_TREE_CHROMA && tuAreaL != (uint32_t) cu.w * cu.h ) || ( ncomp == 3 && cu.tree != VVR_TREE_LUMA && tuAreaC != (uint32_t) cu.w * cu.h ) )
+      FAIL( VVR_ERR_PARAMETER, "the TUs of a CU do not cover it" );
     if( cu.pred_mode == VVR_PRED_INTER )
     {
       const bool isDmvr = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
@@ -291,9 +299,12 @@ int PrepScratch::mapDecodingOrder( std::string& err )
   if( anyIntra )
   {
     const size_t cells = (size_t) w4 * h4;
-    order.assign( cells * 2, 0x7fffffff );
+    // every cell of `order` is written below (validation: the CUs tile the picture, the TUs tile their CUs), so it is not cleared either
+    if( order.size() != cells * 2 ) order.assign( cells * 2, 0x7fffffff );
     intraAt.assign( cells, 0 );
-    for( int k = 0; k < ncomp; k++ ) itemAt[k].assign( cells, -1 );
+    epoch = ( epoch + 1 ) & 0x3ff;
+    for( int k = 0; k < ncomp; k++ ) if( itemAtE[k].size() != cells || epoch == 0 ) itemAtE[k].assign( cells, 0xffffffffu );
+    if( epoch == 0 ) epoch = 1;
     for( uint32_t i = 0; i < p->num_cu; i++ )
     {
       const vvr_cu& cu = p->cu[i];
@@ -322,24 +333,19 @@ int PrepScratch::mapDecodingOrder( std::string& err )
   }
   if( cscale )
   {
-    cuAt.assign( (size_t) w4 * h4, -1 );
-    for( uint32_t i = 0; i < p->num_cu; i++ )
-    {
-      const vvr_cu& cu = p->cu[i];
-      if( cu.tree == VVR_TREE_CHROMA ) continue;                     // dual tree: the luma CUs
-      const int x0 = cu.x >> 2, x1 = ( cu.x + cu.w + 3 ) >> 2;
-      for( int y = cu.y >> 2; y < ( cu.y + cu.h + 3 ) >> 2; y++ ) std::fill( &cuAt[(size_t) y * w4 + x0], &cuAt[(size_t) y * w4 + x1], (int32_t) i );
-    }
+    // the luma CU that covers a cell: owner of the transform block recorded there
+    const int32_t* ord0 = order.data();
+    auto cuAt = [&]( int x, int y ) -> int32_t { const int32_t t = ord0[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )]; return t == 0x7fffffff ? -1 : (int32_t) p->tu[t].cu; };
     csVpduV.resize( (size_t) vpdusX * vpdusY );
     csProdRange.assign( (size_t) vpdusX * vpdusY, std::make_pair( 0xffffffffu, 0u ) ); csProdPool.clear();
     for( int vy = 0; vy < vpdusY; vy++ ) for( int vx = 0; vx < vpdusX; vx++ )
     {
-      const int32_t tl = cuAt[(size_t) ( ( vy << vpduLog2 ) >> 2 ) * w4 + ( ( vx << vpduLog2 ) >> 2 )];
+      const int32_t tl = cuAt( vx << vpduLog2, vy << vpduLog2 );
       if( tl < 0 ) FAIL( VVR_ERR_PARAMETER, "no luma CU at the origin of a VPDU" );
       const int xPos = p->cu[tl].x, yPos = p->cu[tl].y;
       bool hasLeft = xPos > 0, hasAbove = yPos > 0;
-      if( hasLeft && ( ( xPos - 1 ) >> h.log2_ctu ) == ( xPos >> h.log2_ctu ) && cuAt[(size_t) ( yPos >> 2 ) * w4 + ( ( xPos - 1 ) >> 2 )] > tl ) hasLeft = false;
-      if( hasAbove && ( ( yPos - 1 ) >> h.log2_ctu ) == ( yPos >> h.log2_ctu ) && cuAt[(size_t) ( ( yPos - 1 ) >> 2 ) * w4 + ( xPos >> 2 )] > tl ) hasAbove = false;
+      if( hasLeft && ( ( xPos - 1 ) >> h.log2_ctu ) == ( xPos >> h.log2_ctu ) && cuAt( xPos - 1, yPos ) > tl ) hasLeft = false;
+      if( hasAbove && ( ( yPos - 1 ) >> h.log2_ctu ) == ( yPos >> h.log2_ctu ) && cuAt( xPos, yPos - 1 ) > tl ) hasAbove = false;
       csVpduV[(size_t) vy * vpdusX + vx] = (uint32_t) xPos | ( (uint32_t) yPos << 13 ) | ( hasLeft ? 1u << 26 : 0 ) | ( hasAbove ? 1u << 27 : 0 );
     }
   }
@@ -456,6 +462,7 @@ int PrepScratch::buildWorkLists( std::string& err )
           }
           // ---- the blocks this one reads from, its part of the CTU tile
           const uint32_t myId = (uint32_t) intra[comp].size();
+          if( myId >= 0x3fffffu ) FAIL( VVR_ERR_UNSUPPORTED, "too many intra-stage blocks" );
           intra[comp].push_back( it );
           std::vector<uint32_t>& pool = prodPool[comp];
           ItemH IH; IH.ctu = ctuOfCu; IH.p0 = (uint32_t) pool.size(); IH.pn = 0;
@@ -467,7 +474,7 @@ int PrepScratch::buildWorkLists( std::string& err )
             {
               const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
               if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
-              const int32_t d = itemAt[k][(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )];
+              const int32_t d = itemAtGet( k, (size_t) ( ly >> 2 ) * w4 + ( lx >> 2 ) );
               if( d < 0 ) return;
               const uint32_t key = ( (uint32_t) k << 28 ) | (uint32_t) d;
               if( key == lastKey || ( k == comp && (uint32_t) d == myId ) ) return;      // (neighbouring cells mostly belong to the same block)
@@ -512,7 +519,7 @@ int PrepScratch::buildWorkLists( std::string& err )
                 const uint32_t start = (uint32_t) csProdPool.size();
                 auto look = [&]( int lx, int ly )
                 {
-                  const int32_t id = itemAt[0][(size_t) ( ly >> 2 ) * w4 + ( lx >> 2 )];
+                  const int32_t id = itemAtGet( 0, (size_t) ( ly >> 2 ) * w4 + ( lx >> 2 ) );
                   if( id >= 0 && std::find( csProdPool.begin() + start, csProdPool.end(), (uint32_t) id ) == csProdPool.end() ) csProdPool.push_back( (uint32_t) id );
                 };
                 if( ( d >> 26 ) & 1 ) for( int k = 0; k < n; k += 4 ) look( xPos - 1, std::min( yPos + k, (int) h.height - 1 ) );
@@ -537,7 +544,7 @@ int PrepScratch::buildWorkLists( std::string& err )
             // the cells this block reconstructs
             {
               const int cx0 = ( x0 << cs ) >> 2, cx1 = std::min( ( ( ( x0 + w ) << cs ) + 3 ) >> 2, w4 ), cy1 = std::min( ( ( ( y0 + hh ) << cs ) + 3 ) >> 2, h4 );
-              for( int cy = ( y0 << cs ) >> 2; cy < cy1; cy++ ) std::fill( &itemAt[comp][(size_t) cy * w4 + cx0], &itemAt[comp][(size_t) cy * w4 + std::max( cx0, cx1 )], (int32_t) myId );
+              for( int cy = ( y0 << cs ) >> 2; cy < cy1; cy++ ) std::fill( &itemAtE[comp][(size_t) cy * w4 + cx0], &itemAtE[comp][(size_t) cy * w4 + std::max( cx0, cx1 )], ( epoch << 22 ) | myId );
             }
           }
           IH.pn = (uint32_t) pool.size() - IH.p0;
@@ -872,7 +879,7 @@ int PrepScratch::emitUnitTable( std::string& err )
   return VVR_OK;
 }
 
-void PrepScratch::layout()
+void PrepScratch::layout( PinnedRanges* pinned )
 {
   const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
   bytes[K_DEBLOCK_V] = bytes[K_DEBLOCK_H] = samples * 4 + (double) w4 * h4 * sizeof( vvr_lfp );
@@ -880,13 +887,17 @@ void PrepScratch::layout()
   // LMCS, per launch: the inverse pass reads and writes every luma sample; the forward pass those of the inter CUs (upper bound: all)
   if( lmcs ) bytes[K_LMCS] = (double) h.width * h.height * 4;
   parts.clear(); total = 0;
-  auto add = [&]( const void* src, size_t n ) { Part q{ src, n, total }; parts.push_back( q ); total += alignUp( std::max<size_t>( n, 16 ), 256 ); return (int) parts.size() - 1; };
-  iCu = add( p->cu, sizeof( vvr_cu ) * p->num_cu );
-  iTu = add( p->tu, sizeof( vvr_tu ) * p->num_tu );
-  iCoef = add( p->coef, sizeof( int16_t ) * (size_t) p->num_coef );
+  auto add = [&]( const void* src, size_t n ) { Part q{ src, n, total, false }; parts.push_back( q ); total += alignUp( std::max<size_t>( n, 16 ), 256 ); return (int) parts.size() - 1; };
+  // the large arrays of the description come first: those that lie in pinned memory of the context (vvr_host_alloc) are copied to HBM from
+  // where they are, everything behind them is staged (one contiguous range of the image)
+  auto addCaller = [&]( const void* src, size_t n ) { const int i = add( src, n ); parts[i].direct = pinned && n >= 65536 && (size_t) i == numDirect && pinned->contains( src, n ); if( parts[i].direct ) numDirect++; return i; };
+  numDirect = 0;
+  iL0 = addCaller( p->lfp[0], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+  iL1 = addCaller( p->lfp[1], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+  iCu = addCaller( p->cu, sizeof( vvr_cu ) * p->num_cu );
+  iCoef = addCaller( p->coef, sizeof( int16_t ) * (size_t) p->num_coef );
+  iTu = addCaller( p->tu, sizeof( vvr_tu ) * p->num_tu );
   iAffMv = add( affMv.data(), sizeof( vvr_motion ) * affMv.size() );
-  iL0 = add( p->lfp[0], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
-  iL1 = add( p->lfp[1], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
   iSao = p->sao ? add( p->sao, sizeof( vvr_sao_ctu ) * numCtu ) : -1;
   iAlf = p->alf ? add( p->alf, sizeof( vvr_alf_ctu ) * numCtu ) : -1;
   iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
@@ -915,24 +926,30 @@ void PrepScratch::layout()
   iDmvrOut = add( nullptr, sizeof( int32_t ) * 2 * (size_t) numDmvr );       // last: written by the device, not part of the upload
 }
 
-int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err )
+int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err, PinnedRanges* pinned )
 {
   S.begin( p );
   int rc;
   if( ( rc = S.mapDecodingOrder( err ) ) != VVR_OK || ( rc = S.buildWorkLists( err ) ) != VVR_OK || ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK
    || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
-  S.layout();
+  S.layout( pinned );
   *totalBytes = S.total;
   return VVR_OK;
 }
 
 void vvr_host_pack( const PrepScratch& S, char* host )
 {
-  for( size_t i = 0; i + 1 < S.parts.size(); i++ ) { const Part& pt = S.parts[i]; if( pt.n && pt.src ) memcpy( host + pt.off, pt.src, pt.n ); }
+  for( size_t i = S.numDirect; i + 1 < S.parts.size(); i++ ) { const Part& pt = S.parts[i]; if( pt.n && pt.src ) memcpy( host + pt.off, pt.src, pt.n ); }
 }
 
-// bytes of the image that have to cross PCIe (everything but the trailing DMVR output area)
-size_t vvr_host_upload_bytes( const PrepScratch& S ) { return S.parts.back().off; }
+void vvr_host_upload_plan( const PrepScratch& S, std::vector<DirectCopy>& direct, size_t* stagedBegin, size_t* stagedEnd )
+{
+  direct.clear();
+  for( size_t i = 0; i < S.numDirect; i++ ) direct.push_back( DirectCopy{ S.parts[i].src, S.parts[i].n, S.parts[i].off } );
+  *stagedBegin = S.parts[S.numDirect].off;
+  *stagedEnd = S.parts.back().off;         // (the trailing DMVR output area is written by the device)
+}
+
 
 void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
 {

@@ -18,7 +18,7 @@ ALF_DT = np.dtype(abi.AlfCtu)
 class PictureDesc:
     """Owns the arrays of one picture description; `.c()` returns a ctypes Picture that points into them."""
 
-    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, slice_type=abi.SLICE_I, poc=0, out_slot=0, tool_flags=0):
+    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, slice_type=abi.SLICE_I, poc=0, out_slot=0, tool_flags=0, alloc=None):
         h = abi.PicHeader()
         h.abi_version = abi.VVR_ABI_VERSION
         h.width, h.height, h.bit_depth, h.log2_ctu, h.chroma_format = width, height, bit_depth, log2_ctu, chroma_format
@@ -34,7 +34,11 @@ class PictureDesc:
         self.ctu_first_cu = np.zeros(self.num_ctu + 1, np.uint32)
         self.coef = np.zeros(0, np.int16)
         self.motion = None
-        self.lfp = [np.zeros(self.w4 * self.h4, LFP_DT), np.zeros(self.w4 * self.h4, LFP_DT)]
+        # alloc(n, dtype): where the large arrays live (default: ordinary numpy memory; Reconstructor.host_array: memory the device reads directly)
+        self.alloc = alloc or (lambda n, dt: np.zeros(n, dt))
+        self.lfp = [self.alloc(self.w4 * self.h4, LFP_DT), self.alloc(self.w4 * self.h4, LFP_DT)]
+        for a in self.lfp:
+            a.view(np.uint8)[:] = 0
         self.sao = None
         self.alf = None
         self.alf_params = None

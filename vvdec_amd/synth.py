@@ -70,20 +70,20 @@ def set_refs(p, l0, l1=()):
             p.ref_poc[l][i] = poc
 
 
-def _compact(a, n):
+def _compact(a, n, alloc=None):
     """the first n records as an array of their own, copied byte by byte (a field-wise copy would leave the padding bytes of the
     records uninitialised, and descriptions should be reproducible down to the byte)"""
-    out = np.zeros(n, a.dtype)
+    out = alloc(n, a.dtype) if alloc else np.zeros(n, a.dtype)
     out.view(np.uint8)[:] = a[:n].view(np.uint8)
     return out
 
 
-def generate(p):
-    """Run the generator; returns a desc.PictureDesc owning compact copies of all arrays."""
+def generate(p, alloc=None):
+    """Run the generator; returns a desc.PictureDesc owning compact copies of all arrays (alloc: see desc.PictureDesc)."""
     L = lib()
     mcu, mtu, mcoef = C.c_uint32(), C.c_uint32(), C.c_uint64()
     L.vvs_bounds(C.byref(p), C.byref(mcu), C.byref(mtu), C.byref(mcoef))
-    d = desc.PictureDesc(p.width, p.height, p.bit_depth, p.log2_ctu, p.chroma_format, p.slice_type, p.poc, p.out_slot, p.tool_flags)
+    d = desc.PictureDesc(p.width, p.height, p.bit_depth, p.log2_ctu, p.chroma_format, p.slice_type, p.poc, p.out_slot, p.tool_flags, alloc=alloc)
     cu = np.zeros(mcu.value, desc.CU_DT)
     tu = np.zeros(mtu.value, desc.TU_DT)
     coef = np.zeros(mcoef.value, np.int16)
@@ -112,21 +112,21 @@ def generate(p):
     if rc != 0:
         raise RuntimeError("vvs_generate failed (%d)" % rc)
     d.hdr = abi.PicHeader.from_buffer_copy(b.hdr)
-    d.cu = _compact(cu, b.num_cu)
-    d.tu = _compact(tu, b.num_tu)
-    d.coef = coef[:max(1, b.num_coef)].copy()
+    d.cu = _compact(cu, b.num_cu, alloc)
+    d.tu = _compact(tu, b.num_tu, alloc)
+    d.coef = _compact(coef, max(1, b.num_coef), alloc)
     d.num_dmvr = b.num_dmvr
     return d
 
 
-def picture_for_plan(plan, width, height, seed=1234, tool_flags=0, **kw):
+def picture_for_plan(plan, width, height, seed=1234, tool_flags=0, alloc=None, **kw):
     """PictureDesc of one stream.PicPlan (generator seed = base seed + POC)."""
     p = default_params(width=width, height=height, seed=seed + plan.poc, tool_flags=tool_flags, slice_type=plan.slice_type, **kw)
     p.poc = plan.poc
     p.out_slot = plan.slot
     if plan.slice_type != abi.SLICE_I:
         set_refs(p, plan.ref_slots[0], plan.ref_slots[1])
-    return generate(p)
+    return generate(p, alloc)
 
 
 def natural_picture(width, height, seed, bit_depth=10):
