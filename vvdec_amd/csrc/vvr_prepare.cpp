@@ -89,10 +89,15 @@ struct PrepScratch
   {
     const int cs = chn ? 1 : 0, lx = x << cs, ly = y << cs;
     if( x < 0 || y < 0 || lx >= h.width || ly >= h.height ) return 0;
+    // CTUs are decoded in raster order: everything in an earlier CTU is there, nothing in a later one (whose cells are not even mapped yet)
+    const uint32_t c = (uint32_t) ( ( ly >> h.log2_ctu ) * ctusX + ( lx >> h.log2_ctu ) );
+    if( c != curCtuIdx ) return c < curCtuIdx;
     return order[(size_t) chn * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
   }
 
-  int mapDecodingOrder( std::string& err );
+  int beginMaps();
+  int mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string& err );
+  bool anyIntra = false; uint32_t curCtuIdx = 0;
   int buildWorkLists( std::string& err );
   int formUnits();
   int groupUnits();
@@ -290,63 +295,81 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
 // ---------------------------------------------------------------------------------------------------------------------
 // work lists
 // ---------------------------------------------------------------------------------------------------------------------
-// decoding order of the transform blocks, cells covered by intra CUs, the luma neighbourhood of every VPDU's chroma scaling factor
-int PrepScratch::mapDecodingOrder( std::string& err )
+// The per-cell maps the intra-stage analysis looks things up in are filled CTU by CTU, right before the CTU's blocks are analysed: everything a
+// block looks at lies in its own CTU, the CTU to the left or the CTU row above, so the lines it touches are still in the cache (a whole-picture
+// pass in front would have been evicted again: the lookups are what this stage spends its time on).  Nothing is cleared per picture: cells of
+// later CTUs are known to be "not decoded yet" from their position, the block map carries the picture's epoch.
+int PrepScratch::beginMaps()
 {
-  bool anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
+  anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
-  order.clear(); intraAt.clear();
+  intraAt.clear();
   if( anyIntra )
   {
     const size_t cells = (size_t) w4 * h4;
-    // every cell of `order` is written below (validation: the CUs tile the picture, the TUs tile their CUs), so it is not cleared either
     if( order.size() != cells * 2 ) order.assign( cells * 2, 0x7fffffff );
     intraAt.assign( cells, 0 );
     epoch = ( epoch + 1 ) & 0x3ff;
     for( int k = 0; k < ncomp; k++ ) if( itemAtE[k].size() != cells || epoch == 0 ) itemAtE[k].assign( cells, 0xffffffffu );
     if( epoch == 0 ) epoch = 1;
-    for( uint32_t i = 0; i < p->num_cu; i++ )
+  }
+  if( cscale )
+  {
+    csVpduV.assign( (size_t) vpdusX * vpdusY, 0 );
+    csProdRange.assign( (size_t) vpdusX * vpdusY, std::make_pair( 0xffffffffu, 0u ) ); csProdPool.clear();
+  }
+  return VVR_OK;
+}
+
+// decoding order of the transform blocks of CTU `ctuIdx` (CUs [i0, i1)), its cells covered by intra CUs, the luma neighbourhood of the chroma
+// scaling factor of its VPDUs
+int PrepScratch::mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string& err )
+{
+  curCtuIdx = ctuIdx;
+  if( !anyIntra ) return VVR_OK;
+  const size_t cells = (size_t) w4 * h4;
+  for( uint32_t i = i0; i < i1; i++ )
+  {
+    const vvr_cu& cu = p->cu[i];
+    // 1: intra CU, 2: CIIP CU (inter prediction blended with planar intra in the intra stage, DecCu.cpp:137-140,453-456)
+    const bool ciip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
+    if( cu.pred_mode == VVR_PRED_INTRA || ciip )
     {
-      const vvr_cu& cu = p->cu[i];
-      // 1: intra CU, 2: CIIP CU (inter prediction blended with planar intra in the intra stage, DecCu.cpp:137-140,453-456)
-      const bool ciip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
-      if( cu.pred_mode == VVR_PRED_INTRA || ciip )
+      const int cw = ( cu.w + 3 ) >> 2;
+      for( int y = cu.y >> 2; y < ( cu.y + cu.h + 3 ) >> 2; y++ ) memset( &intraAt[(size_t) y * w4 + ( cu.x >> 2 )], ciip ? 2 : 1, cw );
+    }
+    for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+    {
+      const vvr_tu& tu = p->tu[t];
+      for( int chn = 0; chn < 2; chn++ )
       {
-        const int cw = ( cu.w + 3 ) >> 2;
-        for( int y = cu.y >> 2; y < ( cu.y + cu.h + 3 ) >> 2; y++ ) memset( &intraAt[(size_t) y * w4 + ( cu.x >> 2 )], ciip ? 2 : 1, cw );
-      }
-      for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
-      {
-        const vvr_tu& tu = p->tu[t];
-        for( int chn = 0; chn < 2; chn++ )
-        {
-          if( chn == 0 && !( tu.comp_mask & 1 ) ) continue;
-          if( chn == 1 && !( tu.comp_mask & 6 ) ) continue;
-          int ax = tu.x, ay = tu.y, aw = tu.w, ah = tu.h;
-          if( chn == 1 && cu.isp_mode ) { ax = cu.x; ay = cu.y; aw = cu.w; ah = cu.h; }      // ISP: the unsplit chroma blocks sit in the last TU
-          const int x0 = ax >> 2, x1 = std::min( ( ax + aw + 3 ) >> 2, w4 ), y1 = std::min( ( ay + ah + 3 ) >> 2, h4 );
-          int32_t* base = &order[(size_t) chn * cells];
-          for( int y = ay >> 2; y < y1; y++ ) std::fill( base + (size_t) y * w4 + x0, base + (size_t) y * w4 + x1, (int32_t) t );
-        }
+        if( chn == 0 && !( tu.comp_mask & 1 ) ) continue;
+        if( chn == 1 && !( tu.comp_mask & 6 ) ) continue;
+        int ax = tu.x, ay = tu.y, aw = tu.w, ah = tu.h;
+        if( chn == 1 && cu.isp_mode ) { ax = cu.x; ay = cu.y; aw = cu.w; ah = cu.h; }      // ISP: the unsplit chroma blocks sit in the last TU
+        const int x0 = ax >> 2, x1 = std::min( ( ax + aw + 3 ) >> 2, w4 ), y1 = std::min( ( ay + ah + 3 ) >> 2, h4 );
+        int32_t* base = &order[(size_t) chn * cells];
+        for( int y = ay >> 2; y < y1; y++ ) std::fill( base + (size_t) y * w4 + x0, base + (size_t) y * w4 + x1, (int32_t) t );
       }
     }
   }
   if( cscale )
   {
-    // the luma CU that covers a cell: owner of the transform block recorded there
+    // the luma CU that covers a cell of this CTU: owner of the transform block recorded there
     const int32_t* ord0 = order.data();
-    auto cuAt = [&]( int x, int y ) -> int32_t { const int32_t t = ord0[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )]; return t == 0x7fffffff ? -1 : (int32_t) p->tu[t].cu; };
-    csVpduV.resize( (size_t) vpdusX * vpdusY );
-    csProdRange.assign( (size_t) vpdusX * vpdusY, std::make_pair( 0xffffffffu, 0u ) ); csProdPool.clear();
-    for( int vy = 0; vy < vpdusY; vy++ ) for( int vx = 0; vx < vpdusX; vx++ )
+    auto cuAt = [&]( int x, int y ) -> int32_t { const int32_t t = ord0[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )]; return ( t < 0 || (uint32_t) t >= p->num_tu ) ? -1 : (int32_t) p->tu[t].cu; };
+    const int cx = (int) ( ctuIdx % ctusX ) << h.log2_ctu, cy = (int) ( ctuIdx / ctusX ) << h.log2_ctu, nv = 1 << ( h.log2_ctu - vpduLog2 );
+    for( int jy = 0; jy < nv; jy++ ) for( int jx = 0; jx < nv; jx++ )
     {
-      const int32_t tl = cuAt( vx << vpduLog2, vy << vpduLog2 );
-      if( tl < 0 ) FAIL( VVR_ERR_PARAMETER, "no luma CU at the origin of a VPDU" );
+      const int vxp = cx + ( jx << vpduLog2 ), vyp = cy + ( jy << vpduLog2 );
+      if( vxp >= h.width || vyp >= h.height ) continue;
+      const int32_t tl = cuAt( vxp, vyp );
+      if( tl < (int32_t) i0 || tl >= (int32_t) i1 ) FAIL( VVR_ERR_PARAMETER, "no luma CU at the origin of a VPDU" );
       const int xPos = p->cu[tl].x, yPos = p->cu[tl].y;
       bool hasLeft = xPos > 0, hasAbove = yPos > 0;
       if( hasLeft && ( ( xPos - 1 ) >> h.log2_ctu ) == ( xPos >> h.log2_ctu ) && cuAt( xPos - 1, yPos ) > tl ) hasLeft = false;
       if( hasAbove && ( ( yPos - 1 ) >> h.log2_ctu ) == ( yPos >> h.log2_ctu ) && cuAt( xPos, yPos - 1 ) > tl ) hasAbove = false;
-      csVpduV[(size_t) vy * vpdusX + vx] = (uint32_t) xPos | ( (uint32_t) yPos << 13 ) | ( hasLeft ? 1u << 26 : 0 ) | ( hasAbove ? 1u << 27 : 0 );
+      csVpduV[(size_t) ( vyp >> vpduLog2 ) * vpdusX + ( vxp >> vpduLog2 )] = (uint32_t) xPos | ( (uint32_t) yPos << 13 ) | ( hasLeft ? 1u << 26 : 0 ) | ( hasAbove ? 1u << 27 : 0 );
     }
   }
   return VVR_OK;
@@ -355,7 +378,7 @@ int PrepScratch::mapDecodingOrder( std::string& err )
 // the work lists: intra-stage blocks with the blocks they read from, motion-compensation tiles, transform blocks
 int PrepScratch::buildWorkLists( std::string& err )
 {
-  uint32_t curCtu = 0;
+  uint32_t curCtu = 0, mappedEnd = 0;
   for( uint32_t i = 0; i < p->num_cu; i++ )
   {
     const vvr_cu& cu = p->cu[i];
@@ -364,6 +387,15 @@ int PrepScratch::buildWorkLists( std::string& err )
     {
       if( ctuOfCu < curCtu ) FAIL( VVR_ERR_PARAMETER, "CUs are not in CTU raster order" );
       while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
+    }
+    if( i == mappedEnd )
+    {
+      // first CU of a CTU: map the CTU's cells before its blocks are analysed
+      uint32_t j = i + 1;
+      while( j < p->num_cu && (uint32_t) ( ( p->cu[j].y >> h.log2_ctu ) * ctusX + ( p->cu[j].x >> h.log2_ctu ) ) == ctuOfCu ) j++;
+      const int rc = mapCtu( i, j, ctuOfCu, err );
+      if( rc != VVR_OK ) return rc;
+      mappedEnd = j;
     }
     const bool isCiipCu = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
     // LMCS chroma residual scaling of an inter block: its factor reads reconstructed luma that the intra stage may still have to
@@ -930,7 +962,7 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
 {
   S.begin( p );
   int rc;
-  if( ( rc = S.mapDecodingOrder( err ) ) != VVR_OK || ( rc = S.buildWorkLists( err ) ) != VVR_OK || ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK
+  if( ( rc = S.beginMaps() ) != VVR_OK || ( rc = S.buildWorkLists( err ) ) != VVR_OK || ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK
    || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
   S.layout( pinned );
   *totalBytes = S.total;
