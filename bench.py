@@ -194,6 +194,8 @@ def main():
     cpics = [d.c() for d in descs]                     # the host records as the C ABI sees them (plain structs pointing at the arrays)
     upload_mb = sum(d.cu.nbytes + d.tu.nbytes + d.coef.nbytes + d.lfp[0].nbytes + d.lfp[1].nbytes for d in descs[first:first + K]) / K / 1e6
 
+    enq = {}
+
     def barrier(all_ranks):
         rec.sync()
         torch.cuda.synchronize()
@@ -207,6 +209,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(i0, i0 + n):
             rec.submit_c(cpics[i])
+        enq["host"] = time.perf_counter() - t0              # the submitting thread is done here; the rest is the wait for the pictures
         barrier(all_ranks)
         return time.perf_counter() - t0
 
@@ -214,6 +217,7 @@ def main():
     host_pass(0, first - Wm)
     host_pass(first - Wm, Wm)
     dt = host_pass(first, K)
+    enq_host = enq["host"]
     if world > 1:
         t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,11 +237,13 @@ def main():
         t0 = time.perf_counter()
         for i in range(i0, i0 + n):
             rec.submit_prepared(prepared[i])
+        enq["device"] = time.perf_counter() - t0
         barrier(all_ranks)
         return time.perf_counter() - t0
 
     resident_pass(first - Wm, Wm)
     dt_dev = resident_pass(first, K)
+    enq_dev = enq["device"]
     if world > 1:
         t = torch.tensor([dt_dev], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -312,6 +318,7 @@ def main():
                                          a.host_threads, upload_mb, first - Wm, n_irap),
                           "timed_path": "vvr_submit(host records)", "host_records_in": "pageable memory (staged by the library)" if a.pageable_records else "pinned host memory of the context (vvr_host_alloc): cu / tu / coef / lfp arrays are copied to HBM from where the generator wrote them", "host_threads": a.host_threads, "host_cores": os.cpu_count(),
                           "device_only_fps": round(world * K / dt_dev, 2), "device_only_ms_per_step": round(1e3 * dt_dev / K, 4),
+                          "submit_loop_ms": {"vvr_submit": round(1e3 * enq_host, 2), "vvr_submit_prepared": round(1e3 * enq_dev, 2), "what": "time the submitting thread spends in the K calls (of the timed K-picture passes: %.2f / %.2f ms)" % (1e3 * dt, 1e3 * dt_dev)},
                           "device_only_what": "same K pictures, records and work lists resident in HBM (vvr_prepare + vvr_submit_prepared)",
                           "irap_in_window": n_irap, "irap_share_of_stream": "1/%d" % intra_period if a.config != "allintra" else "1/1",
                           "tools": "intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM + ISP, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",

@@ -49,7 +49,27 @@ static int g_lastIntraUnits = -1; static const int* g_lastSync = nullptr;
 int  vvr_upload_tables() { return 0; }
 void launch_mc( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int ) {}
 void launch_itrans( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const TbItem*, int, int ) {}
-void launch_deblock( hipStream_t, const PicDev&, DevPlanes, int ) {}
+// The one launch that leaves a trace in the "picture": the vertical deblocking pass stamps the first four luma samples of the output slot with
+// a hash of the picture's POC and of the stamps found in its reference slots at that moment.  Launches run at submission time here, so
+// the stamp of a picture is right exactly if every reference slot held the right picture when it was submitted - which is what the tests
+// of the multi-rank scheduler (broadcast of reference pictures between ranks, tests/test_multi_gpu_gloo.py) need to see.
+void launch_deblock( hipStream_t, const PicDev& pic, DevPlanes reco, int dir )
+{
+  if( dir != 0 ) return;
+  const vvr_pic_header& h = pic.hdr;
+  size_t slotBytes = 0;
+  for( int c = 0; c < 3; c++ ) if( reco.p[c] ) slotBytes += ( (size_t) reco.stride[c] * reco.h[c] * sizeof( pel_t ) + 255 ) / 256 * 256;
+  uint64_t x = 1469598103934665603ull ^ (uint64_t) (uint32_t) h.poc;
+  auto mix = [&]( uint64_t v ) { x = ( x ^ v ) * 1099511628211ull; };
+  mix( 0x9e37 );
+  if( h.slice_type != 2 )
+    for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
+    {
+      const pel_t* r = (const pel_t*) ( (const char*) reco.p[0] + ( (ptrdiff_t) h.ref_slot[l][i] - h.out_slot ) * (ptrdiff_t) slotBytes );
+      uint64_t v; memcpy( &v, r, 8 ); mix( v ); mix( (uint64_t) h.ref_poc[l][i] );
+    }
+  for( int k = 0; k < 4; k++ ) reco.p[0][k] = (pel_t) ( ( x >> ( 16 * k ) ) & 0x3ff );
+}
 void launch_sao( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) {}
 void launch_alf( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) {}
 void launch_lmcs( hipStream_t, const PicDev&, DevPlanes, int ) {}
@@ -57,7 +77,7 @@ void launch_copy_planes( hipStream_t, DevPlanes, DevPlanes ) {}
 void launch_copy_bytes( hipStream_t, const void*, void*, size_t ) {}
 void launch_mc_affine( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int ) {}
 void launch_mc_dmvr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int32_t* ) {}
-void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, int numUnits, int* sync ) { g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
+void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, int numUnits, int, int* sync ) { g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
 // the two output-stage kernels have functional stand-ins (a few plain loops with the kernels' contract: packed window; per row the checksum
 // share or the CRC register reached from 0), so that the host half of vvr_read_output / vvr_picture_hash - window geometry, chaining the rows'
 // CRC pieces - is checked against the reference's own functions without a GPU

@@ -86,3 +86,94 @@ def test_two_ranks_equal_one_rank(built, tmp_path):
     # different segments are different content (different seeds), same POC structure
     md5s = {(s, poc): m for (s, poc, m) in one["res"]}
     assert md5s[(0, 0)] != md5s[(1, 0)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# picture-level sharding of one stream (vvdec_amd.parallel.PictureParallel): reference pictures broadcast between ranks
+# ---------------------------------------------------------------------------------------------------------------------
+PIC_WORKER = r'''
+import ctypes as C, json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch
+import vvdec_amd
+import test_host_glue as T
+from vvdec_amd import abi, synth, stream, parallel
+
+# the product's host code against the stand-in HIP runtime (tests/hoststub): "device" memory is host memory, so the DPB tensor is a CPU tensor
+# and gloo carries the broadcasts.  No sample is computed; the stand-in stamps every picture with a hash of its POC and of what it found in its
+# reference slots when it was submitted (see launch_deblock in the stub).
+vvdec_amd._LIBPATH = T.LIB
+W, H, GOP, FRAMES = 128, 64, 8, 17
+TOOLS = abi.TOOL_SAO_LUMA | abi.TOOL_ALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS
+replicate = {replicate}
+rank, world, _ = parallel.init(backend="gloo")
+plans, nslots = stream.ra_plan(FRAMES, gop=GOP, seed_poc0_is_external=False, pool=10)
+nslots = max(nslots, 10)
+dpb = vvdec_amd.Reconstructor.new_dpb_tensor(W, H, nslots, device="cpu")
+rec = vvdec_amd.Reconstructor(W, H, log2_ctu=6, num_slots=nslots, num_streams=3, host_threads=2, ext_planes=dpb.data_ptr())
+pp = parallel.PictureParallel(rec, dpb, plans, rank, world, replicate=replicate)
+descs = [synth.picture_for_plan(pl, W, H, seed=77, tool_flags=TOOLS, log2_ctu=6, p_intra=0.1) if pp.owners[i] == rank else None for i, pl in enumerate(plans)]
+# the stamp of a picture has to be read before its slot is reused: run the plan in pieces that end where a slot is about to be overwritten
+stamps = {{}}
+jobs = pp.run(descs)
+last_in_slot = {{}}
+for i, pl in enumerate(plans):
+    last_in_slot[pl.slot] = i
+for slot, i in last_in_slot.items():
+    if pp.owners[i] == rank:
+        y = rec.read_picture(slot)[0]
+        stamps[plans[i].poc] = [int(v) for v in y[0, :4]]
+res = parallel.gather_results(sorted(stamps.items()))
+print("RESULT " + json.dumps(dict(rank=rank, world=world, owners=pp.owners, need=pp.need, trace=pp.trace, n_bcast=pp.n_bcast, stamps=sorted(res))))
+rec.close()
+import torch.distributed as dist
+if dist.is_initialized():
+    dist.destroy_process_group()
+'''
+
+
+def _run_pic(world, tmp_path, replicate=True):
+    script = tmp_path / ("pic_worker_%d_%d.py" % (world, int(replicate)))
+    script.write_text(PIC_WORKER.format(root=ROOT, replicate=replicate))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]))
+    return outs
+
+
+def test_picture_parallel_two_ranks(built, tmp_path):
+    """one stream over two ranks, pictures round-robin within their temporal layer, reference pictures broadcast slot to slot (gloo): the product's
+    host code runs on both ranks against the stand-in runtime, whose picture stamps depend on the content of the reference slots at submission
+    time - they must equal the stamps of a one-rank run, and they must not when the broadcasts are left out"""
+    import test_host_glue as T
+    if not os.path.exists(T.LIB):
+        pytest.skip("stand-in runtime not built")
+    one = _run_pic(1, tmp_path)[0]
+    two = _run_pic(2, tmp_path)
+    assert one["n_bcast"] == 0 and len(one["stamps"]) >= 8
+    for r in two:
+        assert r["stamps"] == one["stamps"], "pictures reconstructed from other reference content than in the one-rank run"
+        assert r["n_bcast"] == sum(r["need"]) > 0 and set(r["owners"]) == {0, 1}
+    # both ranks took part in the same broadcasts, in the same order; the owner sends after it has waited for the picture
+    b0 = [i for (op, i) in two[0]["trace"] if op.startswith("bcast")]
+    b1 = [i for (op, i) in two[1]["trace"] if op.startswith("bcast")]
+    assert b0 == b1
+    for r in two:
+        tr = [tuple(t) for t in r["trace"]]
+        for k, (op, i) in enumerate(tr):
+            if op == "bcast_send":
+                assert tr[k - 1] == ("wait", i) and ("submit", i) in tr[:k]
+            if op == "bcast_recv":
+                assert r["owners"][i] != r["rank"]
+    # top-layer pictures are not referenced: never broadcast
+    assert not any(two[0]["need"][i] for i in range(len(two[0]["need"])) if i not in b0)
+    broken = _run_pic(2, tmp_path, replicate=False)
+    assert broken[0]["stamps"] != one["stamps"]

@@ -216,6 +216,17 @@ class Reconstructor:
             assert a.shape == self.plane_shape(c)
             self._check(self.L.vvr_write_plane(self.ctx, slot, c, a.ctypes.data, a.shape[1]))
 
+    @staticmethod
+    def new_dpb_tensor(width, height, num_slots, chroma_format=1, device="cuda"):
+        """uint8 torch tensor that can hold the DPB of a context (pass its data_ptr() as ext_planes): slot s is the byte range
+        [s * slot_bytes, (s + 1) * slot_bytes), which is what vvdec_amd.parallel.PictureParallel broadcasts between ranks"""
+        import torch
+        cfg = abi.Config()
+        cfg.abi_version = abi.VVR_ABI_VERSION
+        cfg.max_width, cfg.max_height, cfg.chroma_format = width, height, chroma_format
+        nbytes = lib().vvr_slot_bytes(C.byref(cfg)) * num_slots
+        return torch.zeros(nbytes, dtype=torch.uint8, device=device)
+
     def plane_ptr(self, slot, comp):
         return self.L.vvr_plane_ptr(self.ctx, slot, comp)
 

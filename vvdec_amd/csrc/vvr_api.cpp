@@ -90,6 +90,8 @@ struct vvr_context {
   std::map<uint64_t, Job*> bySeq;       // jobs that have not been committed yet
   std::vector<std::vector<int>> slotUsers;   // job ids that touched a slot since it was last written (first entry: the writer)
   std::vector<RingEntry> ring;
+  size_t     ringLargest = 0;           // bytes of the largest picture image seen (+ 25 %): what a ring entry grows to
+  std::vector<char*> retiredHost, retiredDev;   // outgrown ring buffers, freed with the context
   std::vector<hipEvent_t> eventPool;
   std::vector<std::thread> workers;
   bool       stop = false;
@@ -230,7 +232,7 @@ static int commitLocked( vvr_context* c, Job& job )
       c->syncBuf[lane] = p; c->syncCap[lane] = need * 2;
     }
   }
-  if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->units, q->numActive, c->syncBuf[lane] ); } );
+  if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->units, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
   if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
@@ -315,20 +317,22 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
   }
   if( rc == VVR_OK )
   {
-    const size_t need = alignUp( total, 1 << 16 );
-    if( need > e.hostCap )
+    // Buffers only ever grow, and an entry that has to grow takes the size of the largest picture seen so far (an intra picture needs several
+    // times the bytes of a B picture: after the first one has come by, no entry is reallocated when the next one lands on it).  The old
+    // buffers are kept until the context goes: hipFree would wait for the device, i.e. for every picture in flight.
+    size_t want;
+    { std::lock_guard<std::mutex> lk( c->mu ); c->ringLargest = std::max( c->ringLargest, alignUp( total + total / 4, 1 << 16 ) ); want = c->ringLargest; }
+    if( total > e.hostCap )
     {
-      if( e.host ) hipHostFree( e.host );
+      if( e.host ) { std::lock_guard<std::mutex> lk( c->mu ); c->retiredHost.push_back( e.host ); }
       e.host = nullptr; e.hostCap = 0;
-      const size_t cap = need + need / 4;
-      if( hipHostMalloc( (void**) &e.host, cap, hipHostMallocDefault ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipHostMalloc failed"; } else e.hostCap = cap;
+      if( hipHostMalloc( (void**) &e.host, want, hipHostMallocDefault ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipHostMalloc failed"; } else e.hostCap = want;
     }
-    if( rc == VVR_OK && need > e.devCap )
+    if( rc == VVR_OK && total > e.devCap )
     {
-      if( e.dev ) hipFree( e.dev );
+      if( e.dev ) { std::lock_guard<std::mutex> lk( c->mu ); c->retiredDev.push_back( e.dev ); }
       e.dev = nullptr; e.devCap = 0;
-      const size_t cap = need + need / 4;
-      if( hipMalloc( (void**) &e.dev, cap ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipMalloc failed"; } else e.devCap = cap;
+      if( hipMalloc( (void**) &e.dev, want ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipMalloc failed"; } else e.devCap = want;
     }
   }
   if( rc == VVR_OK )
@@ -339,9 +343,10 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
     const size_t nInts = 2 * (size_t) e.q.numDmvr;
     if( nInts > e.dmvrCap )
     {
-      if( e.dmvrHost ) hipHostFree( e.dmvrHost );
+      if( e.dmvrHost ) { std::lock_guard<std::mutex> lk( c->mu ); c->retiredHost.push_back( (char*) e.dmvrHost ); }
       e.dmvrHost = nullptr; e.dmvrCap = 0;
-      if( hipHostMalloc( (void**) &e.dmvrHost, sizeof( int32_t ) * nInts * 2, hipHostMallocDefault ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipHostMalloc failed"; } else e.dmvrCap = nInts * 2;
+      const size_t cap = std::max( nInts, 2 * ( (size_t) c->cfg.max_width * c->cfg.max_height / 128 + 1 ) );      // (no picture of this size has more DMVR sub-blocks)
+      if( hipHostMalloc( (void**) &e.dmvrHost, sizeof( int32_t ) * cap, hipHostMallocDefault ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipHostMalloc failed"; } else e.dmvrCap = cap;
     }
   }
   std::lock_guard<std::mutex> lk( c->mu );
@@ -499,6 +504,8 @@ VVR_API void vvr_destroy( vvr_context* c )
   for( auto& kv : c->jobs ) { Job& j = *kv.second; for( auto& t : j.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); } if( j.done ) hipEventDestroy( j.done ); }
   for( auto e : c->eventPool ) hipEventDestroy( e );
   for( auto& e : c->ring ) { if( e.host ) hipHostFree( e.host ); if( e.dev ) hipFree( e.dev ); if( e.dmvrHost ) hipHostFree( e.dmvrHost ); if( e.copied ) hipEventDestroy( e.copied ); }
+  for( auto p : c->retiredHost ) hipHostFree( p );
+  for( auto p : c->retiredDev ) hipFree( p );
   for( auto s : c->streams ) if( s ) hipStreamDestroy( s );
   if( c->copyStream ) hipStreamDestroy( c->copyStream );
   if( c->planeMemOwned && c->planeMem ) hipFree( c->planeMem );

@@ -22,6 +22,7 @@ struct vvr_prepared {
   int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64
   IntraItem* intraItems = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
+  int      intraWorkgroups = 0;                            // workgroups the intra stage is launched with (the dependency front they can keep busy)
   double   bytes[K_NUM] = { 0 };                           // algorithmic bytes per kernel
   // ownership (vvr_prepare handles only)
   void*    blob = nullptr; size_t blobBytes = 0;

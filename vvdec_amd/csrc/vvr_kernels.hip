@@ -2100,10 +2100,18 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   int tr_ticket = 0;
   const int tid = threadIdx.x;
   const int numCtu = pic.ctus_x * pic.ctus_y;
-  if( tid == 0 ) { sh.ticket = atomicAdd( &sync[0], 1 ); sh.dcSum[0] = sh.dcSum[1] = 0; }
   if( tid < 32 ) { sh.angTab[tid] = c_angTable[tid]; sh.invAngTab[tid] = c_invAngTable[tid]; }
   if( tid < 8 ) sh.filtThr[tid] = c_intraFilterThr[tid];
   if( tid < 128 ) sh.cfilt[tid >> 2][tid & 3] = d_chroma_filter[tid >> 2][tid & 3];
+  // Persistent workgroups: the launch holds at most as many workgroups as the picture's dependency front can keep busy (launch_intra), and
+  // every workgroup takes tickets until none is left.  A picture with a long dependency chain (an intra picture: one CTU wavefront) would
+  // otherwise park a workgroup per unit on the device, nearly all of them spinning on their producers while holding 50 KB of LDS each - which
+  // starves the kernels of every other picture in flight.  Forward progress is as before: every producer holds a lower ticket than its
+  // consumers and tickets are taken in order, so whoever waits, waits for a unit that a running workgroup already holds.
+  for( ;; )
+  {
+  __syncthreads();                    // the previous unit of this workgroup is done with the LDS
+  if( tid == 0 ) { sh.ticket = atomicAdd( &sync[0], 1 ); sh.dcSum[0] = sh.dcSum[1] = 0; }
   __syncthreads();
   const int ticket = sh.ticket;
   if( ticket >= numActive ) return;
@@ -2195,7 +2203,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     }
     IT_TRACE( 4 );
     if( trace && threadIdx.x == 0 ) { trace[(size_t) 8 * tr_ticket + 6] = ( (unsigned long long) ( i1 - i0 ) << 32 ) | ent; trace[(size_t) 8 * tr_ticket + 7] = un->ndeps | 0x100; }
-    if( !publish ) return;
+    if( !publish ) continue;
     asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
     __syncthreads();
     if( tid == 0 )
@@ -2205,7 +2213,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       __hip_atomic_store( &sync[1 + ticket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     }
     IT_TRACE( 5 );
-    return;
+    continue;
   }
   // ---- stage the needed part of the CTU and its reference border in LDS
   {
@@ -2850,7 +2858,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   // ---- publish: all stores of the workgroup drained, one agent-scope release, then the flag
   IT_TRACE( 4 );
   if( trace && threadIdx.x == 0 ) { trace[(size_t) 8 * tr_ticket + 6] = ( (unsigned long long) ( i1 - i0 ) << 32 ) | ent; trace[(size_t) 8 * tr_ticket + 7] |= un->ndeps; }
-  if( !publish ) return;
+  if( !publish ) continue;
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
   __syncthreads();
   if( tid == 0 )
@@ -2859,22 +2867,24 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
     __hip_atomic_store( &sync[1 + ticket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
   }
+  }     // next ticket
 #undef IT_TRACE
 #undef IT_PH
 }
 
-void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numActive, int* sync )
+void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numActive, int numWorkgroups, int* sync )
 {
   if( !numActive ) return;
+  numWorkgroups = std::max( 1, std::min( numWorkgroups, numActive ) );
   hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + (size_t) numActive ), s );
 #ifndef VVR_INTRA_DEV
-  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync );
+  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync );
 #else
   static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
   static const bool tr = getenv( "VVR_INTRA_TRACE" ) != nullptr;
   unsigned long long* trace = nullptr;
   if( tr ) { hipMalloc( (void**) &trace, sizeof( unsigned long long ) * 8 * (size_t) numActive ); hipMemsetAsync( trace, 0, sizeof( unsigned long long ) * 8 * (size_t) numActive, s ); }
-  hipLaunchKernelGGL( k_intra, dim3( numActive ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync, dbg, trace );
+  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync, dbg, trace );
   if( tr )
   {
     // developer timeline: ticket, phase time stamps (100 MHz), block count / unit word, number of producers

@@ -59,6 +59,7 @@ struct PrepScratch
   std::vector<std::pair<uint32_t, uint32_t>> csProdRange;   // per VPDU: the luma blocks that produce that neighbourhood (range of csProdPool), looked up on first use
   std::vector<uint32_t> csProdPool;
   std::vector<IntraUnit> unitsDev;
+  int intraWorkgroups = 0;
   // union-find / grouping scratch
   std::vector<uint32_t> parent, newIdx, firstOf, perm, inv, unitCount, unitOfItem[3];
   std::vector<int32_t> unitOfRoot, target;
@@ -886,6 +887,16 @@ int PrepScratch::emitUnitTable( std::string& err )
     }
     for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
     for( auto& u : units ) for( uint32_t d : u.deps ) units[d].waited = true;
+    {
+      // workgroups the stage is launched with: twice the widest dependency front (a unit of the next depth can start as soon as ITS producers
+      // are done, not only when the whole front is), at least 64
+      std::vector<uint32_t>& width = unitCount;           // (reused below)
+      int maxRank = 0; for( auto& u : units ) maxRank = std::max( maxRank, u.rank );
+      width.assign( (size_t) maxRank + 1, 0 );
+      uint32_t widest = 0;
+      for( auto& u : units ) widest = std::max( widest, ++width[u.rank] );
+      intraWorkgroups = (int) std::min<size_t>( units.size(), std::max<uint32_t>( 64, 2 * widest ) );
+    }
     unitCount.assign( 3 * (size_t) numCtu, 0 );
     for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
     unitsDev.resize( units.size() );
@@ -1005,6 +1016,6 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   q.dmvrOut = (int32_t*) at( S.iDmvrOut ); q.numDmvr = S.numDmvr;
   for( int k = 0; k < 3; k++ ) { q.tbItems[k] = (TbItem*) at( S.iTb[k] ); q.numTb[k] = (int) S.tb[k].size(); }
   q.intraItems = (IntraItem*) at( S.iIntra ); q.numIntra = (int) S.intraAll.size();
-  q.units = (IntraUnit*) at( S.iUnits ); q.numActive = (int) S.unitsDev.size();
+  q.units = (IntraUnit*) at( S.iUnits ); q.numActive = (int) S.unitsDev.size(); q.intraWorkgroups = S.intraWorkgroups;
   memcpy( q.bytes, S.bytes, sizeof( q.bytes ) );
 }
