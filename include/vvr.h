@@ -36,7 +36,7 @@ extern "C" {
 #define VVR_API
 #endif
 
-#define VVR_ABI_VERSION 1
+#define VVR_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------------------------------------------------
  * status codes (negative = error; mirrors the style of vvdecErrorCodes, include/vvdec/vvdec.h.in:91-105)
@@ -91,6 +91,11 @@ enum {
                                         InterPrediction.cpp:1995).  Block vector in vvr_cu.mv[0][0] (1/16 units, integer sample
                                         positions); it must point at samples of the same CTU row that precede the CU in decoding order
                                         and still sit in the IBC virtual buffer (CodingStructure::fillIBCbuffer, CodingStructure.cpp:550) */
+  VVR_TOOL_LADF         = 1u << 21,  /* sps_ladf_enabled_flag: luma-adaptive deblocking, parameters in vvr_pic_header.ladf_* (LoopFilter.cpp:1363,1519).
+                                        Informative like VVR_TOOL_IMPLICIT_MTS: the back-end looks at ladf_num_intervals                       */
+  VVR_TOOL_NO_LF_ACROSS_SLICES = 1u << 22,  /* !pps_loop_filter_across_slices_enabled_flag: SAO and ALF do not look across slice boundaries (the deblocking
+                                        edges there are already switched off in the edge-parameter table the host derives)                     */
+  VVR_TOOL_NO_LF_ACROSS_TILES  = 1u << 23,  /* !pps_loop_filter_across_tiles_enabled_flag, likewise for tile boundaries                              */
 };
 
 typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::reconstructCoeff (AdaptiveLoopFilter.cpp:888) stays on the host */
@@ -152,7 +157,11 @@ typedef struct vvr_pic_header {
   int8_t   deblock_tc_offset_div2[3];
   uint8_t  log2_sao_offset_scale[2];      /* luma, chroma                                               */
   int8_t   min_qp_ts;               /* 4 + 6*internalMinusInputBitDepth (Quant.cpp:104)                  */
-  uint8_t  pad[7];
+  uint8_t  ladf_num_intervals;      /* 0: LADF off; else sps_num_ladf_intervals_minus2 + 2 (2..5), LoopFilter::deriveLADFShift (LoopFilter.cpp:1363) */
+  int8_t   ladf_qp_offset[5];       /* SPS::getLadfQpOffset(k): [0] = sps_ladf_lowest_interval_qp_offset   */
+  uint8_t  pad;
+  int16_t  ladf_lower_bound[5];     /* SPS::getLadfIntervalLowerBound(k), luma level; [0] unused           */
+  uint8_t  pad2[6];
 } vvr_pic_header;
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -302,6 +311,14 @@ typedef struct vvr_picture {
   const vvr_lmcs_params* lmcs;         /* NULL when LMCS is off                                                  */
   const vvr_wp_params*  wp;            /* NULL unless VVR_TOOL_WP                                                */
   const vvr_scaling_list* scaling;     /* NULL unless VVR_TOOL_SCALING_LIST                                      */
+  /* Slices and tiles.  The CTUs of the description are listed in picture raster order whatever order the bit stream coded them in.  Across a
+   * slice or tile boundary nothing is available to intra prediction, CCLM or the LMCS chroma-scaling neighbourhood (CodingStructure::
+   * getCURestricted, CodingStructure.cpp:464), and SAO / ALF stop there when the VVR_TOOL_NO_LF_ACROSS_* flag of the kind of boundary is set
+   * (SampleAdaptiveOffset.cpp:741-830, AdaptiveLoopFilter.cpp:118-200).  All slices of the picture share the header above: a picture whose
+   * slices differ in slice type, reference lists, deblocking / SAO / ALF / LMCS / scaling-list switches or weights is not expressible (the
+   * reference-side glue refuses it). */
+  const uint16_t*       ctu_slice;     /* [num_ctu] slice index of every CTU, NULL = one slice                   */
+  const uint16_t*       ctu_tile;      /* [num_ctu] tile index of every CTU, NULL = one tile                     */
   int                   resident;      /* 0: all array pointers are host memory (copied H2D by vvr_submit);      */
                                        /* 1: all array pointers are DEVICE memory already resident in HBM        */
 } vvr_picture;

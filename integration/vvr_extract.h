@@ -89,6 +89,9 @@ static inline uint32_t toolFlags( const CodingStructure& cs, const Slice& slice,
   if( sps.getDisableScalingMatrixForLfnstBlks() ) f |= VVR_TOOL_SCALING_LIST_NO_LFNST;
   if( sps.getUseImplicitMTS() ) f |= VVR_TOOL_IMPLICIT_MTS;
   if( sps.getIBCFlag() ) f |= VVR_TOOL_IBC;
+  if( sps.getLadfEnabled() ) f |= VVR_TOOL_LADF;
+  if( !pps.getLoopFilterAcrossSlicesEnabledFlag() ) f |= VVR_TOOL_NO_LF_ACROSS_SLICES;
+  if( !pps.getLoopFilterAcrossTilesEnabledFlag() ) f |= VVR_TOOL_NO_LF_ACROSS_TILES;
   return f;
 }
 
@@ -103,7 +106,7 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
   const SPS& sps = *cs.sps; const PPS& pps = *cs.pps; const PicHeader& ph = *cs.picHeader;
   if( sps.getChromaFormatIdc() != CHROMA_400 && sps.getChromaFormatIdc() != CHROMA_420 ) { why = "chroma format other than 4:0:0 / 4:2:0"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getBitDepth() > 10 || sps.getBitDepth() < 8 ) { why = "bit depth outside 8..10"; return VVR_ERR_UNSUPPORTED; }
-  if( sps.getLadfEnabled() ) { why = "luma-adaptive deblocking (LADF, LoopFilter.cpp:1363)"; return VVR_ERR_UNSUPPORTED; }
+  if( sps.getLadfEnabled() && sps.getLadfNumIntervals() > 5 ) { why = "LADF with more than 5 intervals"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getUseWrapAround() || pps.getUseWrapAround() ) { why = "horizontal wrap-around motion compensation (Picture.cpp:404-518)"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getVirtualBoundariesPresentFlag() || ph.getVirtualBoundariesPresentFlag() ) { why = "virtual boundaries of the in-loop filters"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getUseColorTrans() ) { why = "adaptive colour transform"; return VVR_ERR_UNSUPPORTED; }
@@ -149,6 +152,11 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   h.deblock_beta_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrBetaOffsetDiv2(); h.deblock_tc_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrTcOffsetDiv2();
   h.log2_sao_offset_scale[0] = h.log2_sao_offset_scale[1] = (uint8_t) std::max( 0, bd - MAX_SAO_TRUNCATED_BITDEPTH );
   h.min_qp_ts = (int8_t) ( 4 + 6 * sps.getInternalMinusInputBitDepth() );
+  if( sps.getLadfEnabled() )
+  {
+    h.ladf_num_intervals = (uint8_t) sps.getLadfNumIntervals();
+    for( int k = 0; k < sps.getLadfNumIntervals(); k++ ) { h.ladf_qp_offset[k] = (int8_t) sps.getLadfQpOffset( k ); h.ladf_lower_bound[k] = (int16_t) sps.getLadfIntervalLowerBound( k ); }
+  }
 
   // ---- coding units, transform units, levels
   E.cu.clear(); E.tu.clear(); E.coef.clear(); E.ctuFirstCu.assign( numCtu + 1, 0 ); E.numDmvr = 0; E.dmvrCus.clear();

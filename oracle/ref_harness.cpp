@@ -176,6 +176,11 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     sps.setDepQuantEnabledFlag( !!( H.tool_flags & VVR_TOOL_DEP_QUANT ) );
     sps.setIBCFlag( !!( H.tool_flags & VVR_TOOL_IBC ) );              // Picture::finalInit creates the IBC virtual buffers (Picture.cpp:294)
     sps.setMaxTLayers( 1 );
+    if( H.ladf_num_intervals )
+    {
+      sps.setLadfEnabled( true ); sps.setLadfNumIntervals( H.ladf_num_intervals );
+      for( int k = 0; k < H.ladf_num_intervals; k++ ) { sps.setLadfQpOffset( H.ladf_qp_offset[k], k ); sps.setLadfIntervalLowerBound( H.ladf_lower_bound[k], k ); }
+    }
     {
       ChromaQpMappingTable& t = sps.m_chromaQpMappingTable;
       t.m_qpBdOffset = sps.getQpBDOffset();
@@ -593,7 +598,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     {
       switch( g_feature )
       {
-      case 1: sps.setLadfEnabled( true ); break;
+      case 1: sps.setLadfEnabled( true ); sps.setLadfNumIntervals( 6 ); break;                             // (more LADF intervals than the header holds)
       case 2: sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); break;
       case 3: ph->setVirtualBoundariesPresentFlag( true ); break;
       case 4: { Slice* s2 = pic.allocateNewSlice(); s2->setPicHeader( ph.get() ); s2->setSliceType( SliceType( H.slice_type ) ); s2->setPOC( H.poc ); } break;

@@ -145,7 +145,15 @@ static void edge_luma( const vvr_pic_header* H, vvo_planes* r, int x, int y, con
   const ptrdiff_t o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
   const int bs = BS_GET( lfp->bs, 0 );
   if( !bs ) return;
-  const int qp = lfp->qp[0];
+  int qp = lfp->qp[0];
+  if( H->ladf_num_intervals )
+  {
+    /* deriveLADFShift (LoopFilter.cpp:1363-1386): EDGE_VER (src[0] + src[3*stride] + src[-1] + src[3*stride - 1]) >> 2, EDGE_HOR likewise with the roles swapped */
+    const int level = ( src[0] + src[3 * step] + src[-o] + src[3 * step - o] ) >> 2;
+    int shift = H->ladf_qp_offset[0];
+    for( int k = 1; k < H->ladf_num_intervals; k++ ) { if( level > H->ladf_lower_bound[k] ) shift = H->ladf_qp_offset[k]; else break; }
+    qp += shift;
+  }
   const int lenP = ( lfp->side_max_filt_length >> 4 ) & 7, lenQ = lfp->side_max_filt_length & 7;
   int pLarge = lenP > 3, qLarge = lenQ > 3;
   if( dir == 1 && ( y & ( ( 1 << H->log2_ctu ) - 1 ) ) == 0 ) pLarge = 0;

@@ -341,6 +341,14 @@ def test_lmcs(built, cscale):
     _run_stream(1920, 1080, 3, 2, 203, T, intra=True, streams=3)
 
 
+def test_luma_adaptive_deblocking(built):
+    """LADF: QP offset of every luma edge segment from the local luma level (LoopFilter::deriveLADFShift)"""
+    T = TOOLS_A | abi.TOOL_LADF | abi.TOOL_LMCS
+    _run_stream(256, 128, 5, 4, 211, T, intra=True, p_intra=0.3)
+    _run_stream(416, 240, 5, 4, 212, T, intra=True, p_intra=0.15, log2_ctu=6, p_affine=0.2, p_sbtmvp=0.1)
+    _run_stream(1920, 1080, 3, 2, 213, TOOLS_A | abi.TOOL_LADF, intra=True, streams=3)
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

@@ -231,3 +231,26 @@ def test_oracle_equals_reference_random_sweep(built):
     spec.loader.exec_module(fz)
     n, bad = fz.sweep(2026, cases=250)
     assert n == 250 and bad == 0
+
+
+@pytest.mark.parametrize("W,H,l2,idx,seed,bd,kw", [(256, 128, 7, 0, 251, 10, {}), (384, 256, 6, 2, 252, 10, dict(p_intra=0.25, p_affine=0.2)), (200, 136, 5, 3, 253, 8, dict(p_intra=0.1))])
+def test_oracle_equals_reference_ladf(built, W, H, l2, idx, seed, bd, kw):
+    """luma-adaptive deblocking (sps_ladf_enabled_flag): the QP of a luma edge segment is shifted by an offset chosen from the local luma level
+    (LoopFilter::deriveLADFShift, LoopFilter.cpp:1363)"""
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=ALL | abi.TOOL_LADF, log2_ctu=l2, bit_depth=bd, **kw)
+    assert 2 <= d.hdr.ladf_num_intervals <= 5
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc, bit_depth=bd))
+    for fl in (refdrv.STOP_AFTER_DBK, 0):
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+    # the offsets matter: without them the deblocked picture is another one
+    final = want
+    d.hdr.ladf_num_intervals = 0
+    assert not np.array_equal(refdrv.oracle_reconstruct(d, refs, flags=0)[0], final[0])

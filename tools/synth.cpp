@@ -963,6 +963,17 @@ struct Gen {
     h.log2_ctu = P.log2_ctu; h.slice_type = P.slice_type; h.poc = P.poc; h.out_slot = P.out_slot; h.min_qp_ts = 4;
     for( int l = 0; l < 2; l++ ) { h.num_ref[l] = P.slice_type == 2 ? 0 : P.num_ref[l]; for( int i = 0; i < VVR_MAX_REFS; i++ ) { h.ref_slot[l][i] = P.ref_slot[l][i]; h.ref_poc[l][i] = P.ref_poc[l][i]; } }
     for( int c = 0; c < 3; c++ ) { h.deblock_beta_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); h.deblock_tc_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); }
+    if( h.tool_flags & VVR_TOOL_LADF )
+    {
+      // sps_ladf_*: 2..5 intervals with rising lower bounds (luma levels) and QP offsets in the syntax range (-63..63, kept small)
+      h.ladf_num_intervals = (uint8_t) ( 2 + rng.u( 4 ) );
+      int lb = 0;
+      for( int k = 0; k < h.ladf_num_intervals; k++ )
+      {
+        h.ladf_qp_offset[k] = (int8_t) ( (int) rng.u( 13 ) - 6 );
+        if( k ) { lb += 1 + (int) rng.u( ( 1u << bd ) / h.ladf_num_intervals ); h.ladf_lower_bound[k] = (int16_t) std::min( lb, ( 1 << bd ) - 2 ); }
+      }
+    }
     if( P.slice_type == 2 ) h.tool_flags &= ~(uint32_t) VVR_TOOL_WP;
     wpOn = ( h.tool_flags & VVR_TOOL_WP ) && B.wp;
     if( wpOn ) genWp();

@@ -5,7 +5,7 @@ compiled library so the two cannot drift apart silently.
 """
 import ctypes as C
 
-VVR_ABI_VERSION = 1
+VVR_ABI_VERSION = 2
 VVR_MAX_REFS = 16
 VVR_MAX_ALF_APS = 8
 VVR_ALF_CLASSES = 25
@@ -21,7 +21,7 @@ VVR_OK, VVR_ERR_UNSPECIFIED, VVR_ERR_PARAMETER, VVR_ERR_UNSUPPORTED, VVR_ERR_DEV
 # tool flags
 TOOL_SAO_LUMA, TOOL_SAO_CHROMA, TOOL_ALF, TOOL_CCALF, TOOL_LMCS, TOOL_LMCS_CSCALE, TOOL_DEBLOCK_OFF, TOOL_DEP_QUANT, \
     TOOL_BDOF, TOOL_DMVR, TOOL_PROF, TOOL_JCCR_SIGN, TOOL_STILL_REF, TOOL_LFNST, TOOL_MTS, TOOL_CCLM_COLLOC, \
-    TOOL_WP, TOOL_SCALING_LIST, TOOL_SCALING_LIST_NO_LFNST, TOOL_IMPLICIT_MTS, TOOL_IBC = [1 << i for i in range(21)]
+    TOOL_WP, TOOL_SCALING_LIST, TOOL_SCALING_LIST_NO_LFNST, TOOL_IMPLICIT_MTS, TOOL_IBC, TOOL_LADF, TOOL_NO_LF_ACROSS_SLICES, TOOL_NO_LF_ACROSS_TILES = [1 << i for i in range(24)]
 
 PRED_INTER, PRED_INTRA, PRED_IBC = 0, 1, 2
 TREE_JOINT, TREE_LUMA, TREE_CHROMA = 0, 1, 2
@@ -55,7 +55,8 @@ class PicHeader(C.Structure):
                 ("poc", i32), ("out_slot", i16), ("num_ref", i8 * 2),
                 ("ref_slot", i16 * VVR_MAX_REFS * 2), ("ref_poc", i32 * VVR_MAX_REFS * 2),
                 ("deblock_beta_offset_div2", i8 * 3), ("deblock_tc_offset_div2", i8 * 3),
-                ("log2_sao_offset_scale", u8 * 2), ("min_qp_ts", i8), ("pad", u8 * 7)]
+                ("log2_sao_offset_scale", u8 * 2), ("min_qp_ts", i8),
+                ("ladf_num_intervals", u8), ("ladf_qp_offset", i8 * 5), ("pad", u8), ("ladf_lower_bound", i16 * 5), ("pad2", u8 * 6)]
 
 
 class Cu(C.Structure):
@@ -109,7 +110,8 @@ class Picture(C.Structure):
                 ("motion", C.POINTER(Motion)), ("lfp", C.POINTER(Lfp) * 2),
                 ("sao", C.POINTER(SaoCtu)), ("alf", C.POINTER(AlfCtu)),
                 ("alf_params", C.POINTER(AlfParams)), ("lmcs", C.POINTER(LmcsParams)),
-                ("wp", C.POINTER(WpParams)), ("scaling", C.POINTER(ScalingList)), ("resident", C.c_int)]
+                ("wp", C.POINTER(WpParams)), ("scaling", C.POINTER(ScalingList)),
+                ("ctu_slice", C.POINTER(u16)), ("ctu_tile", C.POINTER(u16)), ("resident", C.c_int)]
 
 
 class Config(C.Structure):

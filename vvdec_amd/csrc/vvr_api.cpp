@@ -81,7 +81,7 @@ struct vvr_context {
   void*      outDev = nullptr; size_t outDevCap = 0;
   void*      outHost = nullptr; size_t outHostCap = 0;
   // ---- job pipeline (everything below is guarded by mu)
-  std::mutex mu;
+  std::mutex mu, commitMu;              // commitMu: one committing thread at a time (it takes mu only around its bookkeeping)
   std::condition_variable cv;
   std::map<int, std::unique_ptr<Job>> jobs;
   std::deque<Job*> queue;               // submitted, not yet taken by a worker
@@ -94,6 +94,7 @@ struct vvr_context {
   std::vector<char*> retiredHost, retiredDev;   // outgrown ring buffers, freed with the context
   std::vector<hipEvent_t> eventPool;
   std::vector<std::thread> workers;
+  std::thread launcher;                 // commits prepared pictures in submission order (contexts with worker threads)
   bool       stop = false;
   PrepScratch* inlineScratch = nullptr; // host_threads == 0, and vvr_prepare
   PinnedRanges pinned;                  // vvr_host_alloc
@@ -166,14 +167,43 @@ static void completeLocked( vvr_context* c, Job& j )
   c->cv.notify_all();
 }
 
-// enqueue one prepared picture: H2D copy of its ring entry, dependencies, kernels.  mu held; called in submission order.
-static int commitLocked( vvr_context* c, Job& job )
+// What the committer decides about a picture while it holds mu: its lane, the events of the pictures it has to be ordered behind, its
+// reference planes.  The HIP calls themselves (enqueuePicture) run WITHOUT mu: a launch blocks when the device's queues are full, and the
+// worker threads must be able to go on preparing pictures meanwhile.
+struct CommitPlan { int lane; std::vector<hipEvent_t> waits; RefSet refs; };
+
+static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
 {
+  const vvr_pic_header& h = job.q->hdr;
+  const int lane = c->nextStream; c->nextStream = ( c->nextStream + 1 ) % (int) c->streams.size();
+  plan.lane = lane; plan.waits.clear();
+  job.lane = lane;
+  // a lane's scratch planes are reused: the previous job of this lane is ordered before us by the stream itself
+  // ---- dependencies: every job that read or wrote one of our slots
+  auto waitFor = [&]( int id ) { auto it = c->jobs.find( id ); if( it != c->jobs.end() ) { Job& j = *it->second; if( !j.completed && j.state == J_COMMITTED && j.lane != lane ) plan.waits.push_back( j.done ); } };
+  for( int id : c->slotUsers[h.out_slot] ) waitFor( id );
+  memset( &plan.refs, 0, sizeof( plan.refs ) );
+  if( h.slice_type != 2 )
+    for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
+    {
+      const int slot = h.ref_slot[l][i];
+      // wait for the writer of the reference (it is the first entry since the slot was last written)
+      if( !c->slotUsers[slot].empty() ) waitFor( c->slotUsers[slot][0] );
+      for( int k = 0; k < 3; k++ ) plan.refs.p[l * VVR_MAX_REFS + i][k] = c->slots[slot].p[k];
+    }
+  job.done = takeEvent( c );
+}
+
+// enqueue one prepared picture: H2D copy of its ring entry, dependencies, kernels.  Called by the one committing thread, without mu.
+static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std::string& err )
+{
+#undef HIPCHK
+#define HIPCHK( ctx, call ) do { hipError_t e_ = ( call ); if( e_ != hipSuccess ) { err = std::string( #call ) + ": " + hipGetErrorString( e_ ); return VVR_ERR_DEVICE; } } while( 0 )
   vvr_prepared* q = job.q;
   const vvr_pic_header& h = q->hdr;
-  const int lane = c->nextStream; c->nextStream = ( c->nextStream + 1 ) % (int) c->streams.size();
+  const int lane = plan.lane;
   hipStream_t s = c->streams[lane];
-  job.lane = lane;
+  if( !job.done ) { err = "hipEventCreate failed"; return VVR_ERR_DEVICE; }
   if( job.ring )
   {
     RingEntry& e = *job.ring;
@@ -182,22 +212,8 @@ static int commitLocked( vvr_context* c, Job& job )
     HIPCHK( c, hipEventRecord( e.copied, c->copyStream ) );
     HIPCHK( c, hipStreamWaitEvent( s, e.copied, 0 ) );
   }
-  // a lane's scratch planes are reused: the previous job of this lane is ordered before us by the stream itself
-  // ---- dependencies: every job that read or wrote one of our slots
-  auto waitFor = [&]( int id ) { auto it = c->jobs.find( id ); if( it != c->jobs.end() ) { Job& j = *it->second; if( !j.completed && j.state == J_COMMITTED && j.lane != lane ) hipStreamWaitEvent( s, j.done, 0 ); } };
-  for( int id : c->slotUsers[h.out_slot] ) waitFor( id );
-  RefSet refs; memset( &refs, 0, sizeof( refs ) );
-  if( h.slice_type != 2 )
-    for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
-    {
-      const int slot = h.ref_slot[l][i];
-      // wait for the writer of the reference (it is the first entry since the slot was last written)
-      if( !c->slotUsers[slot].empty() ) waitFor( c->slotUsers[slot][0] );
-      for( int k = 0; k < 3; k++ ) refs.p[l * VVR_MAX_REFS + i][k] = c->slots[slot].p[k];
-    }
-  job.done = takeEvent( c );
-  if( !job.done ) { c->setError( "hipEventCreate failed" ); return VVR_ERR_DEVICE; }
-
+  for( hipEvent_t ev : plan.waits ) hipStreamWaitEvent( s, ev, 0 );
+  const RefSet& refs = plan.refs;
   DevPlanes A = c->slots[h.out_slot], B = c->scratchB[lane], R = c->scratchR[lane];
   auto timed = [&]( int k, auto&& fn )
   {
@@ -251,45 +267,80 @@ static int commitLocked( vvr_context* c, Job& job )
   if( le == hipSuccess ) le = hipEventRecord( job.done, s );
   if( le != hipSuccess )
   {
-    // nothing may keep running behind a failed submission: drain the lane, give the events back
+    // nothing may keep running behind a failed submission: drain the lane
     hipStreamSynchronize( s );
-    for( auto& t : job.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); }
-    job.timings.clear();
-    c->eventPool.push_back( job.done ); job.done = nullptr;
-    c->setError( std::string( "kernel launch: " ) + hipGetErrorString( le ) );
+    err = std::string( "kernel launch: " ) + hipGetErrorString( le );
     return VVR_ERR_DEVICE;
   }
-  // bookkeeping
-  c->slotUsers[h.out_slot].clear(); c->slotUsers[h.out_slot].push_back( job.id );
-  if( h.slice_type != 2 ) for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ ) c->slotUsers[h.ref_slot[l][i]].push_back( job.id );
   return VVR_OK;
+#undef HIPCHK
+#define HIPCHK( ctx, call ) do { hipError_t e_ = ( call ); if( e_ != hipSuccess ) { ( ctx )->setError( std::string( #call ) + ": " + hipGetErrorString( e_ ) ); return VVR_ERR_DEVICE; } } while( 0 )
 }
 
-// commit every job that is next in submission order and ready.  mu held.
-static void commitReadyLocked( vvr_context* c )
+// commit every job that is next in submission order and ready.  One thread at a time (commitMu): the launcher thread of a context with worker
+// threads, else the thread inside vvr_submit / vvr_submit_prepared.  mu is only held around the bookkeeping, never across a HIP call.
+static void commitReady( vvr_context* c )
 {
+  std::lock_guard<std::mutex> cm( c->commitMu );
+  CommitPlan plan;
   for( ;; )
   {
-    auto it = c->bySeq.find( c->nextCommit );
-    if( it == c->bySeq.end() ) break;
-    Job& j = *it->second;
-    if( j.state != J_READY && j.state != J_FAILED ) break;
-    if( j.state == J_READY )
+    Job* j = nullptr;
     {
-      const int rc = commitLocked( c, j );
-      if( rc == VVR_OK ) j.state = J_COMMITTED;
-      else { j.state = J_FAILED; j.rc = rc; j.err = c->err; }
+      std::lock_guard<std::mutex> lk( c->mu );
+      auto it = c->bySeq.find( c->nextCommit );
+      if( it == c->bySeq.end() ) break;
+      j = it->second;
+      if( j->state != J_READY && j->state != J_FAILED ) break;
+      if( j->state == J_READY ) planCommitLocked( c, *j, plan );
     }
-    if( j.state == J_FAILED )
+    int rc = VVR_OK; std::string err;
+    if( j->state == J_READY ) rc = enqueuePicture( c, *j, plan, err );
     {
-      // a failed picture holds nothing: its ring entry is free again, waiting for it returns the error
-      if( j.ring && j.ring->owner == &j ) j.ring->owner = nullptr;
-      j.q = nullptr; j.completed = true;
+      std::lock_guard<std::mutex> lk( c->mu );
+      if( j->state == J_READY )
+      {
+        if( rc == VVR_OK )
+        {
+          const vvr_pic_header& h = j->q->hdr;
+          c->slotUsers[h.out_slot].clear(); c->slotUsers[h.out_slot].push_back( j->id );
+          if( h.slice_type != 2 ) for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ ) c->slotUsers[h.ref_slot[l][i]].push_back( j->id );
+          j->state = J_COMMITTED;
+        }
+        else
+        {
+          for( auto& t : j->timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); }
+          j->timings.clear();
+          if( j->done ) { c->eventPool.push_back( j->done ); j->done = nullptr; }
+          j->state = J_FAILED; j->rc = rc; j->err = err; c->setError( err );
+        }
+      }
+      if( j->state == J_FAILED )
+      {
+        // a failed picture holds nothing: its ring entry is free again, waiting for it returns the error
+        if( j->ring && j->ring->owner == j ) j->ring->owner = nullptr;
+        j->q = nullptr; j->completed = true;
+      }
+      c->bySeq.erase( c->nextCommit );
+      c->nextCommit++;
+      c->cv.notify_all();
     }
-    c->bySeq.erase( it );
-    c->nextCommit++;
   }
-  c->cv.notify_all();
+}
+
+// the committing thread of a context with worker threads
+static void launcherMain( vvr_context* c )
+{
+  hipSetDevice( c->device );
+  for( ;; )
+  {
+    {
+      std::unique_lock<std::mutex> lk( c->mu );
+      c->cv.wait( lk, [&]{ if( c->stop ) return true; auto it = c->bySeq.find( c->nextCommit ); return it != c->bySeq.end() && ( it->second->state == J_READY || it->second->state == J_FAILED ); } );
+      if( c->stop ) break;
+    }
+    commitReady( c );
+  }
 }
 
 // stage 1 of a streaming job: work lists into scratch, then packed into the job's ring entry.  Called without mu.
@@ -349,10 +400,13 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
       if( hipHostMalloc( (void**) &e.dmvrHost, sizeof( int32_t ) * cap, hipHostMallocDefault ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipHostMalloc failed"; } else e.dmvrCap = cap;
     }
   }
-  std::lock_guard<std::mutex> lk( c->mu );
-  if( rc == VVR_OK ) { job.q = &e.q; job.ring = &e; job.state = J_READY; }
-  else { job.rc = rc; job.err = err; job.state = J_FAILED; if( e.owner == &job ) { job.ring = &e; } }
-  commitReadyLocked( c );
+  {
+    std::lock_guard<std::mutex> lk( c->mu );
+    if( rc == VVR_OK ) { job.q = &e.q; job.ring = &e; job.state = J_READY; }
+    else { job.rc = rc; job.err = err; job.state = J_FAILED; if( e.owner == &job ) { job.ring = &e; } }
+    c->cv.notify_all();                                 // (the launcher, if there is one)
+  }
+  if( c->workers.empty() ) commitReady( c );            // no worker threads: the submitting thread commits
 }
 
 static void workerMain( vvr_context* c )
@@ -488,6 +542,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   c->slotUsers.resize( cfg->num_slots );
   c->inlineScratch = vvr_scratch_create();
   for( int t = 0; t < cfg->host_threads; t++ ) c->workers.emplace_back( workerMain, c );
+  if( cfg->host_threads ) c->launcher = std::thread( launcherMain, c );
   *out = c;
   return VVR_OK;
 }
@@ -501,6 +556,7 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( !c->streams.empty() && c->inlineScratch ) vvr_sync( c );
   { std::lock_guard<std::mutex> lk( c->mu ); c->stop = true; c->cv.notify_all(); }
   for( auto& t : c->workers ) t.join();
+  if( c->launcher.joinable() ) c->launcher.join();
   for( auto& kv : c->jobs ) { Job& j = *kv.second; for( auto& t : j.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); } if( j.done ) hipEventDestroy( j.done ); }
   for( auto e : c->eventPool ) hipEventDestroy( e );
   for( auto& e : c->ring ) { if( e.host ) hipHostFree( e.host ); if( e.dev ) hipFree( e.dev ); if( e.dmvrHost ) hipHostFree( e.dmvrHost ); if( e.copied ) hipEventDestroy( e.copied ); }
@@ -682,13 +738,17 @@ VVR_API int vvr_submit_prepared( vvr_context* c, vvr_prepared* q )
 {
   if( !c || !q ) return VVR_ERR_PARAMETER;
   hipSetDevice( c->device );
+  Job* job;
+  {
+    std::lock_guard<std::mutex> lk( c->mu );
+    retireLocked( c );
+    job = newJobLocked( c );
+    job->q = q; job->state = J_READY;
+  }
+  commitReady( c );                   // (commits nothing yet if pictures queued by vvr_submit are still ahead of it; the launcher gets to it then)
   std::lock_guard<std::mutex> lk( c->mu );
-  retireLocked( c );
-  Job* job = newJobLocked( c );
-  job->q = q; job->state = J_READY;
-  const bool inOrder = c->nextCommit == job->seq;
-  commitReadyLocked( c );
-  if( inOrder && job->state == J_FAILED ) { const int rc = job->rc; c->setError( job->err ); job->waited = true; return rc; }
+  c->cv.notify_all();
+  if( job->state == J_FAILED ) { const int rc = job->rc; c->setError( job->err ); job->waited = true; return rc; }
   return job->id;
 }
 

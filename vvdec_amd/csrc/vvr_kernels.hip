@@ -1459,7 +1459,15 @@ __device__ void deblock_luma_segment( const PicDev& pic, const DevPlanes& r, int
   const int stride = r.stride[0], x = x4 * 4, y = y4 * 4;
   pel_t* src = r.p[0] + (size_t) y * stride + x;
   const int o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
-  const int qp = l.qp[0];
+  int qp = l.qp[0];
+  if( H.ladf_num_intervals )
+  {
+    // luma-adaptive deblocking: QP offset chosen by the mean of four samples at the corners of the segment (deriveLADFShift, LoopFilter.cpp:1363-1386)
+    const int level = ( src[0] + src[3 * step] + src[-o] + src[3 * step - o] ) >> 2;
+    int shift = H.ladf_qp_offset[0];
+    for( int k = 1; k < H.ladf_num_intervals; k++ ) { if( level > H.ladf_lower_bound[k] ) shift = H.ladf_qp_offset[k]; else break; }
+    qp += shift;
+  }
   const int lenP = ( l.side_max_filt_length >> 4 ) & 7, lenQ = l.side_max_filt_length & 7;
   bool pLarge = lenP > 3, qLarge = lenQ > 3;
   if( dir == 1 && ( y & ( ( 1 << H.log2_ctu ) - 1 ) ) == 0 ) pLarge = false;

@@ -125,6 +125,7 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
   if( ( h.width & 7 ) || ( h.height & 7 ) ) FAIL( VVR_ERR_PARAMETER, "picture size must be a multiple of 8 (minimum CU size)" );
   if( h.out_slot < 0 || h.out_slot >= cfg.num_slots ) FAIL( VVR_ERR_PARAMETER, "out_slot out of range" );
   if( h.slice_type > 2 ) FAIL( VVR_ERR_PARAMETER, "unknown slice type" );
+  if( h.ladf_num_intervals == 1 || h.ladf_num_intervals > 5 ) FAIL( VVR_ERR_PARAMETER, "LADF: 2..5 intervals" );
   if( ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && !( h.tool_flags & VVR_TOOL_LMCS ) ) FAIL( VVR_ERR_PARAMETER, "LMCS chroma residual scaling without LMCS" );
   if( ( h.tool_flags & VVR_TOOL_LMCS ) && !p->lmcs ) FAIL( VVR_ERR_PARAMETER, "LMCS enabled without tables" );
   const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;

@@ -45,6 +45,8 @@ class PictureDesc:
         self.lmcs = None
         self.wp = None
         self.scaling = None
+        self.ctu_slice = None          # uint16 [num_ctu] or None (one slice)
+        self.ctu_tile = None           # uint16 [num_ctu] or None (one tile)
 
     def set_refs(self, l0, l1=()):
         """l0/l1: lists of (slot, poc)."""
@@ -84,6 +86,12 @@ class PictureDesc:
             p.wp = C.pointer(self.wp)
         if self.scaling is not None:
             p.scaling = C.pointer(self.scaling)
+        if self.ctu_slice is not None:
+            self.ctu_slice = np.ascontiguousarray(self.ctu_slice, dtype=np.uint16)
+            p.ctu_slice = self.ctu_slice.ctypes.data_as(C.POINTER(abi.u16))
+        if self.ctu_tile is not None:
+            self.ctu_tile = np.ascontiguousarray(self.ctu_tile, dtype=np.uint16)
+            p.ctu_tile = self.ctu_tile.ctypes.data_as(C.POINTER(abi.u16))
         p.resident = 0
         self._keep = p
         return p
