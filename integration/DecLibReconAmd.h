@@ -1,10 +1,14 @@
 // integration/DecLibReconAmd.h — the class of INTEGRATION.md §2 as code: same public interface as the reference's DecLibRecon
 // (DecoderLib/DecLibRecon.h:185-192), reconstruction done by libvvdec_amd.so.  Like vvr_extract.h it belongs INTO the reference tree; here
-// it is only compiled (by the test harness, against the reference's headers and include/vvr.h) so that it cannot rot: nothing in this
-// repository instantiates it, because running it needs the reference's parser and a bitstream.
+// it is compiled by the test harness against the reference's headers and include/vvr.h AND executed by it (oracle/ref_harness.cpp,
+// vvref_run_binding): reference-built objects of a picture go through decompressPicture / waitForPrevDecompressedPic, on the stand-in runtime
+// in the CPU tests and on the GPU in tests/test_gpu_parity.py, where planes and motion field are compared with the reference's own DecLibRecon
+// stages.  What it has not seen is a picture parsed from a bitstream (none are available offline).
 #pragma once
 #include <unordered_map>
 #include <memory>
+#include <thread>
+#include <exception>
 #include "vvr_extract.h"
 
 namespace vvr_glue
@@ -42,6 +46,17 @@ public:
   void destroy() { m_ctx = nullptr; }
   Picture* getCurrPic() const { return m_currDecompPic; }
 
+  // LF_INIT: the CTUs are independent (the reference runs one task per CTU on its thread pool); here a few threads take every n-th CTU
+  void deriveEdgeParameters( CodingStructure& cs, int numCtu )
+  {
+    const int nt = std::max( 1, std::min<int>( 8, std::min<int>( (int) std::thread::hardware_concurrency(), numCtu / 16 ) ) );
+    if( nt == 1 ) { for( int a = 0; a < numCtu; a++ ) m_loopFilter.calcFilterStrengthsCTU( cs, a ); return; }
+    std::vector<std::thread> th; std::vector<std::exception_ptr> err( nt );
+    for( int t = 0; t < nt; t++ ) th.emplace_back( [&, t]{ try { for( int a = t; a < numCtu; a += nt ) m_loopFilter.calcFilterStrengthsCTU( cs, a ); } catch( ... ) { err[t] = std::current_exception(); } } );
+    for( auto& x : th ) x.join();
+    for( auto& e : err ) if( e ) std::rethrow_exception( e );
+  }
+
   // DecLibRecon::decompressPicture (DecLibRecon.cpp:429): host-only stages, flatten, submit
   void decompressPicture( Picture* pic )
   {
@@ -50,12 +65,12 @@ public:
     const int numCtu = cs.pcv->sizeInCtus;
     pic->parseDone.wait();                                                             // simplest correct integration
     { std::string why; if( checkExpressible( cs, *pic, why ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << why ); }    // never flattened into something it is not
-    for( int a = 0; a < numCtu; a++ ) m_loopFilter.calcFilterStrengthsCTU( cs, a );     // LF_INIT (DecLibRecon.cpp:912-941)
+    deriveEdgeParameters( cs, numCtu );                                                // LF_INIT (DecLibRecon.cpp:912-941)
     Reshape* rsp = nullptr;
     if( cs.sps->getUseReshaper() && slice.getLmcsEnabledFlag() )
     {
       m_reshaper.createDec( cs.sps->getBitDepth() );
-      m_reshaper.initSlice( slice.getNalUnitLayerId(), *slice.getPicHeader(), slice.getVPS() );   // DecLibRecon.cpp:449-453
+      m_reshaper.initSlice( slice.getNalUnitLayerId(), *slice.getPicHeader(), slice.getVPS_nothrow() );   // DecLibRecon.cpp:449-453
       rsp = &m_reshaper;
     }
     if( cs.sps->getUseALF() ) AdaptiveLoopFilter::reconstructCoeffAPSs( slice );

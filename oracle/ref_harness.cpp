@@ -91,6 +91,23 @@ static vvr_glue::Extracted* g_extractTo = nullptr;
 // test hook of the extractor's refusals (vvref_check_expressible): a feature the flat description cannot express is switched on in the
 // reference's objects before they are handed to the glue; g_expressible receives what the glue says
 static int g_feature = 0, g_expressible = 0; static std::string g_why;
+// motion field of the picture after DecCu::TaskFinishMotionInfo (DMVR-refined MVs written back), picture raster 4x4 grid: set by
+// vvref_reconstruct_with_motion (the reference's own stages) and by vvref_run_binding (the DecLibRecon replacement on the GPU back-end)
+static vvr_motion* g_motionOut = nullptr;
+#ifdef VVREF_WITH_BINDING
+struct BindingRun { uint16_t* const* out_planes; int numSlots; };
+static BindingRun* g_binding = nullptr;
+#endif
+static void dumpMotion( CodingStructure& cs, int W, int Hh, vvr_motion* out )
+{
+  const int w4 = ( W + 3 ) >> 2, h4 = ( Hh + 3 ) >> 2;
+  for( int y = 0; y < h4; y++ ) for( int x = 0; x < w4; x++ )
+  {
+    const MotionInfo& mi = cs.getMotionInfo( Position( x << 2, y << 2 ) );
+    vvr_motion& o = out[(size_t) y * w4 + x]; memset( &o, 0, sizeof( o ) );
+    for( int l = 0; l < 2; l++ ) { o.mv[l][0] = mi.mv[l].hor; o.mv[l][1] = mi.mv[l].ver; o.ref_idx[l] = (int8_t) mi.miRefIdx[l]; }
+  }
+}
 static bool g_trace = getenv("VVREF_TRACE") != nullptr;
 #define TR(...) do { if( g_trace ) { fprintf( stderr, __VA_ARGS__ ); fflush( stderr ); } } while(0)
 __attribute__((visibility("default"))) const char* vvref_last_error() { return g_err.c_str(); }
@@ -615,6 +632,44 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
       return 0;
     }
+#ifdef VVREF_WITH_BINDING
+    if( g_binding )
+    {
+      // The DecLibRecon replacement of integration/DecLibReconAmd.h, executed: the reference's objects of this picture go through the extractor
+      // into vvr_submit of whichever back-end library the process has loaded, vvr_wait, the DMVR delta MVs come back into the reference's motion
+      // field (DecCu::TaskFinishMotionInfo).  The reference pictures are uploaded into the DPB slots the binding's SlotPool assigns to them.
+      vvr_config cfg; memset( &cfg, 0, sizeof( cfg ) );
+      cfg.abi_version = VVR_ABI_VERSION; cfg.device = 0; cfg.max_width = (uint16_t) W; cfg.max_height = (uint16_t) Hh;
+      cfg.chroma_format = H.chroma_format; cfg.bit_depth = H.bit_depth; cfg.log2_ctu = H.log2_ctu; cfg.num_slots = (uint8_t) g_binding->numSlots; cfg.num_streams = 2;
+      vvr_context* ctx = nullptr;
+      const int crc = vvr_create( &cfg, &ctx );
+      CHECK( crc != VVR_OK, "vvr_create failed with " << crc );
+      try
+      {
+        vvr_glue::SlotPool pool( cfg.num_slots );
+        const int nc = cf == CHROMA_400 ? 1 : 3;
+        std::vector<uint16_t> tmp;
+        for( auto& kv : refPics )
+        {
+          const int s = pool.acquire( kv.second.get() );
+          for( int c = 0; c < nc; c++ ) CHECK( vvr_write_plane( ctx, s, c, ref_planes[kv.first * 3 + c], (size_t) ( c ? W >> 1 : W ) ) != VVR_OK, vvr_last_error( ctx ) );
+        }
+        pic.parseDone.unlock();
+        vvr_glue::DecLibReconAmd binding;
+        binding.create( ctx, &pool );
+        binding.decompressPicture( &pic );
+        Picture* done = binding.waitForPrevDecompressedPic();
+        CHECK( done != &pic || binding.getCurrPic() != nullptr, "the binding did not hand the picture back" );
+        for( int c = 0; c < nc; c++ ) CHECK( vvr_read_plane( ctx, pool.slotOf( &pic ), c, g_binding->out_planes[c], (size_t) ( c ? W >> 1 : W ) ) != VVR_OK, vvr_last_error( ctx ) );
+        if( g_motionOut ) dumpMotion( cs, W, Hh, g_motionOut );
+        binding.destroy();
+      }
+      catch( ... ) { vvr_destroy( ctx ); for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; } throw; }
+      vvr_destroy( ctx );
+      for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
+      return 0;
+    }
+#endif
     if( g_extractTo )
     {
       { std::string why; CHECK( vvr_glue::checkExpressible( cs, pic, why ) != VVR_OK, why ); }
@@ -743,6 +798,13 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
         }
       }
     }
+    if( g_motionOut )
+    {
+      // what DecLibRecon does for a picture that is still referenced (MIDER_cont / TaskFinishMotionInfo, DecLibRecon.cpp:1080-1100): the
+      // DMVR-refined MVs go into the motion field
+      if( pic.stillReferenced ) for( int a = 0; a < numCtu; a++ ) if( cs.getCtuData( a ).firstCU ) decCu.TaskFinishMotionInfo( cs, a, a % pcv.widthInCtus, a / pcv.widthInCtus );
+      dumpMotion( cs, W, Hh, g_motionOut );
+    }
     cs.m_predBuf = nullptr; cs.m_dmvrMvCache = nullptr;
     for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
     fltBuf.destroy();
@@ -791,6 +853,31 @@ const vvr_picture* vvref_extract( const vvr_picture* vp, const uint16_t* const* 
   if( num_dmvr ) *num_dmvr = E.numDmvr;
   return &E.pic;
 }
+
+// the reference's own stages, plus the motion field after DecCu::TaskFinishMotionInfo (w4 * h4 entries)
+__attribute__((visibility("default")))
+int vvref_reconstruct_with_motion( const vvr_picture* vp, const uint16_t* const* ref_planes, uint16_t* const* out_planes, vvr_motion* motion_out, int flags )
+{
+  g_motionOut = motion_out;
+  const int rc = vvref_reconstruct( vp, ref_planes, out_planes, nullptr, nullptr, flags, nullptr );
+  g_motionOut = nullptr;
+  return rc;
+}
+
+#ifdef VVREF_WITH_BINDING
+// f1 executed: the picture through integration/DecLibReconAmd.h (extractor -> vvr_submit -> vvr_wait -> TaskFinishMotionInfo) on the back-end
+// library loaded in this process (libvvdec_amd.so on a GPU box; the stand-in build in the CPU tests).  out_planes / motion_out as above.
+__attribute__((visibility("default")))
+int vvref_run_binding( const vvr_picture* vp, const uint16_t* const* ref_planes, uint16_t* const* out_planes, vvr_motion* motion_out, int num_slots )
+{
+  BindingRun run{ out_planes, num_slots };
+  g_binding = &run; g_motionOut = motion_out;
+  uint16_t* none[3] = { nullptr, nullptr, nullptr };
+  const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, VVREF_DERIVE_LFP, nullptr );
+  g_binding = nullptr; g_motionOut = nullptr;
+  return rc;
+}
+#endif
 
 // the extractor's refusals: the description is turned into reference objects, `feature` switches on something a flat description cannot express
 // (0 nothing, 1 LADF, 2 wrap-around, 3 virtual boundaries, 4 a second slice, 5 sub-pictures, 6 ACT, 7 12-bit samples, 8 a second tile column,

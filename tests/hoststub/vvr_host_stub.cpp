@@ -77,7 +77,8 @@ void launch_copy_planes( hipStream_t, DevPlanes, DevPlanes ) {}
 void launch_copy_bytes( hipStream_t, const void*, void*, size_t ) {}
 void launch_mc_affine( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int ) {}
 void launch_mc_dmvr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int32_t* ) {}
-void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, int numUnits, int, int* sync ) { g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
+static int g_lastIntraWg = 0;
+void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, int numUnits, int numWg, int* sync ) { g_lastIntraWg = numWg; g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
 // the two output-stage kernels have functional stand-ins (a few plain loops with the kernels' contract: packed window; per row the checksum
 // share or the CRC register reached from 0), so that the host half of vvr_read_output / vvr_picture_hash - window geometry, chaining the rows'
 // CRC pieces - is checked against the reference's own functions without a GPU
@@ -148,6 +149,7 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
 __attribute__(( visibility( "default" ) )) void vvt_take_h2d( size_t* copies, size_t* bytes ) { *copies = g_h2dCopies; *bytes = g_h2dBytes; g_h2dCopies = g_h2dBytes = 0; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }
+__attribute__(( visibility( "default" ) )) int vvt_last_intra_wg( void ) { return g_lastIntraWg; }
 // pretend the lane's flag buffer is small (the product sizes it for ordinary pictures; the growth path needs a picture with more units than that)
 __attribute__(( visibility( "default" ) )) void vvt_shrink_sync( vvr_context* c, int lane, size_t cap ) { if( c && lane < (int) c->syncCap.size() && cap < c->syncCap[lane] ) c->syncCap[lane] = cap; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sync_capacity( const vvr_context* c, int lane ) { return c && lane < (int) c->syncCap.size() ? c->syncCap[lane] : 0; }

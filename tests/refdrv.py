@@ -57,6 +57,67 @@ def reconstruct(desc, refs=None, flags=0, want_lfp=False, want_dmvr=0):
     return dict(planes=outs, ms=list(ms), lfp=lfps, dmvr=dmvr)
 
 
+def _ref_ptrs(refs):
+    nslots = (max(refs.keys()) + 1) if refs else 0
+    ref_ptrs = (C.POINTER(C.c_uint16) * max(1, nslots * 3))()
+    keep = []
+    for slot, planes in (refs or {}).items():
+        for c, pl in enumerate(planes):
+            a = np.ascontiguousarray(pl, dtype=np.uint16)
+            keep.append(a)
+            ref_ptrs[slot * 3 + c] = a.ctypes.data_as(C.POINTER(C.c_uint16))
+    return ref_ptrs, keep, nslots
+
+
+def reconstruct_with_motion(desc, refs=None, flags=0):
+    """the reference's own stages -> (planes, motion field after DecCu::TaskFinishMotionInfo as an array of abi.Motion, picture raster 4x4 grid)"""
+    L = lib()
+    p = desc.c()
+    ref_ptrs, keep, _ = _ref_ptrs(refs)
+    ncomp = 3 if desc.hdr.chroma_format else 1
+    outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
+    out_ptrs = (C.POINTER(C.c_uint16) * 3)()
+    for c in range(ncomp):
+        out_ptrs[c] = outs[c].ctypes.data_as(C.POINTER(C.c_uint16))
+    motion = np.zeros(desc.w4 * desc.h4, np.dtype(abi.Motion))
+    L.vvref_reconstruct_with_motion.restype = C.c_int
+    rc = L.vvref_reconstruct_with_motion(C.byref(p), ref_ptrs, out_ptrs, motion.ctypes.data_as(C.c_void_p), flags)
+    if rc != 0:
+        raise RuntimeError("vvref_reconstruct_with_motion failed: " + L.vvref_last_error().decode())
+    return outs, motion
+
+
+_BIND = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libvvrefbind.so")
+_bind = None
+
+
+def binding_available():
+    return os.path.exists(_BIND)
+
+
+def run_binding(desc, refs, backend_path, num_slots=8):
+    """the picture through integration/DecLibReconAmd.h (the DecLibRecon replacement: extractor -> vvr_submit -> vvr_wait -> TaskFinishMotionInfo),
+    executed on the back-end library `backend_path` (libvvdec_amd.so, or the stand-in build of the CPU tests).  -> (planes, motion field)"""
+    global _bind
+    if _bind is None:
+        C.CDLL(backend_path, mode=C.RTLD_GLOBAL)        # the harness's vvr_* calls bind to this library
+        _bind = C.CDLL(_BIND)
+        _bind.vvref_run_binding.restype = C.c_int
+        _bind.vvref_last_error.restype = C.c_char_p
+    p = desc.c()
+    ref_ptrs, keep, nslots = _ref_ptrs(refs)
+    ncomp = 3 if desc.hdr.chroma_format else 1
+    outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
+    out_ptrs = (C.POINTER(C.c_uint16) * 3)()
+    for c in range(ncomp):
+        out_ptrs[c] = outs[c].ctypes.data_as(C.POINTER(C.c_uint16))
+    motion = np.zeros(desc.w4 * desc.h4, np.dtype(abi.Motion))
+    rc = _bind.vvref_run_binding(C.byref(p), ref_ptrs, out_ptrs, motion.ctypes.data_as(C.c_void_p), max(num_slots, nslots + 2))
+    if rc != 0:
+        raise RuntimeError("vvref_run_binding failed: " + _bind.vvref_last_error().decode())
+    return outs, motion
+
+
 def extract(desc, refs=None, flags=0):
     """description -> the reference decoder's own objects -> description, through the reference-side glue integration/vvr_extract.h.
     Returns a dict of numpy copies of every array of the extracted vvr_picture (and its header)."""

@@ -9,6 +9,7 @@ reference's Reshape class, final ALF filters after reconstructCoeffAPSs, SAO off
 
 Needs oracle/_ref (built where /root/reference exists); skipped elsewhere."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 
@@ -220,3 +221,29 @@ def test_extractor_refuses_what_the_description_cannot_express(built, feature, t
     assert L.vvref_check_expressible(C.byref(p), ref_ptrs, 0, why, 256) == abi.VVR_OK, why.value
     rc = L.vvref_check_expressible(C.byref(p), ref_ptrs, feature, why, 256)
     assert rc == abi.VVR_ERR_UNSUPPORTED and text in why.value.decode(), (rc, why.value)
+
+
+def test_binding_executes_on_the_stand_in_runtime(built):
+    """integration/DecLibReconAmd.h instantiated and run: reference-built objects of a picture -> LF_INIT by the reference ->
+    extractor -> vvr_submit -> vvr_wait -> DMVR delta MVs back through DecCu::TaskFinishMotionInfo.  Here the back-end is the product's host code
+    on the stand-in runtime (no sample is computed, delta MVs are zero): the description the extractor writes from the reference's own state
+    passes the product's validation and the work-list builder, and the motion field that comes back is the one the reference derives when no
+    refinement moves anything.  The same test with samples runs on the GPU (tests/test_gpu_parity.py)."""
+    import test_host_glue as T
+    if not refdrv.binding_available() or not os.path.exists(T.LIB):
+        pytest.skip("binding harness or stand-in runtime not built")
+    W, H = 256, 128
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    for idx, tools, kw in ((0, ALL, dict(p_cclm=0.3, p_mip=0.2)), (2, ALL | abi.TOOL_STILL_REF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.2, p_affine=0.2, p_sbtmvp=0.1, p_ciip=0.1))):
+        pl = plans[idx]
+        d = synth.picture_for_plan(pl, W, H, seed=641 + idx, tool_flags=tools, **kw)
+        refs = {slot: synth.natural_picture(W, H, 650 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
+        planes, motion = refdrv.run_binding(d, refs, T.LIB)
+        assert [p.shape for p in planes] == [d.plane_shape(c) for c in range(3)]
+        if pl.slice_type != abi.SLICE_I:
+            inter = d.motion["ref_idx"].max(axis=1) >= 0
+            assert inter.any()
+            # no refinement on the stand-in: DMVR CUs keep their MVs, everything else is the field the description was built from
+            assert np.array_equal(motion["ref_idx"][inter], d.motion["ref_idx"][inter])
+            l0 = inter & (d.motion["ref_idx"][:, 0] >= 0)
+            assert np.array_equal(motion["mv"][l0][:, 0], d.motion["mv"][l0][:, 0])

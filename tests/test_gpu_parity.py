@@ -422,3 +422,33 @@ def test_copy_kernel_bandwidth(built):
     got = rec.read_picture(0)
     assert all(np.array_equal(g, w) for g, w in zip(got, pic))          # slot 0 is only read
     rec.close()
+
+
+@pytest.mark.parametrize("idx,seed,tools_extra,kw", [
+    (0, 701, abi.TOOL_LMCS, dict(p_cclm=0.3, p_mip=0.2, p_isp=0.2)),
+    (2, 702, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_STILL_REF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.2, p_bi=0.9, p_affine=0.15, p_sbtmvp=0.1, p_ciip=0.1, p_geo=0.1)),
+    (3, 703, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_STILL_REF, dict(p_intra=0.05, p_bi=0.95, mv_sigma=2.0)),
+])
+def test_declibrecon_replacement_executed(built, idx, seed, tools_extra, kw):
+    """SURVEY 8(f)-1 executed: reference-built objects of a picture through integration/DecLibReconAmd.h (LF_INIT by the reference's own
+    calcFilterStrengthsCTU, extractor, vvr_submit, vvr_wait, DMVR delta MVs from the GPU back through DecCu::TaskFinishMotionInfo) - planes and
+    motion field equal what the reference's own DecLibRecon stages produce for the same objects"""
+    import os
+    import vvdec_amd
+    if not (refdrv.available() and refdrv.binding_available()):
+        pytest.skip("the reference build (oracle/_ref) is not present")
+    W, H = 384, 256
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=TOOLS | abi.TOOL_LFNST | tools_extra, **kw)
+    refs = {slot: synth.natural_picture(W, H, seed + 100 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
+    want_planes, want_motion = refdrv.reconstruct_with_motion(d, refs, flags=refdrv.DERIVE_LFP)
+    got_planes, got_motion = refdrv.run_binding(d, refs, vvdec_amd._LIBPATH)
+    for c in range(3):
+        assert np.array_equal(got_planes[c], want_planes[c]), "comp %d: %d samples differ from the reference's DecLibRecon" % (c, int((got_planes[c] != want_planes[c]).sum()))
+    valid = want_motion["ref_idx"] >= 0
+    assert np.array_equal(got_motion["ref_idx"], want_motion["ref_idx"])
+    assert np.array_equal(got_motion["mv"][valid], want_motion["mv"][valid]), "motion field after TaskFinishMotionInfo differs"
+    if idx == 3:
+        both = valid & (d.motion["ref_idx"] >= 0)
+        assert getattr(d, "num_dmvr", 0) > 0 and not np.array_equal(want_motion["mv"][both], d.motion["mv"][both]), "no DMVR refinement in this picture: the test would be vacuous"

@@ -889,14 +889,23 @@ int PrepScratch::emitUnitTable( std::string& err )
     for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
     for( auto& u : units ) for( uint32_t d : u.deps ) units[d].waited = true;
     {
-      // workgroups the stage is launched with: twice the widest dependency front (a unit of the next depth can start as soon as ITS producers
-      // are done, not only when the whole front is), at least 64
-      std::vector<uint32_t>& width = unitCount;           // (reused below)
-      int maxRank = 0; for( auto& u : units ) maxRank = std::max( maxRank, u.rank );
-      width.assign( (size_t) maxRank + 1, 0 );
-      uint32_t widest = 0;
-      for( auto& u : units ) widest = std::max( widest, ++width[u.rank] );
-      intraWorkgroups = (int) std::min<size_t>( units.size(), std::max<uint32_t>( 64, 2 * widest ) );
+      // Workgroups the stage is launched with: about twice the AVERAGE parallelism of the dependency graph = total work / critical path, work
+      // counted in blocks.  More would only add workgroups that spin on their producers while holding 50 KB of LDS each (an intra picture: 1530
+      // units, a 62-CTU-deep wavefront, about 15 of them busy at any time), and those are taken away from the other pictures in flight; a
+      // picture of isolated intra blocks (B picture: chains a few units deep) gets hundreds.
+      std::vector<uint32_t>& path = unitCount;            // (reused below) longest chain ending in the unit, in blocks; tickets are a topological order
+      path.assign( units.size(), 0 );
+      uint64_t work = 0; uint32_t critical = 1;
+      for( size_t t = 0; t < perm.size(); t++ )
+      {
+        const UnitH& u = units[perm[t]];
+        const uint32_t cost = 1 + ( u.i1 - u.i0 );
+        uint32_t before = 0;
+        for( uint32_t d : u.deps ) before = std::max( before, path[inv[d]] );
+        path[t] = before + cost;
+        work += cost; critical = std::max( critical, path[t] );
+      }
+      intraWorkgroups = (int) std::min<uint64_t>( units.size(), std::max<uint64_t>( 32, 2 * ( ( work + critical - 1 ) / critical ) ) );
     }
     unitCount.assign( 3 * (size_t) numCtu, 0 );
     for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
