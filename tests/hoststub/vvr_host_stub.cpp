@@ -3,6 +3,7 @@
 // lives on the host can be checked without a GPU.  "Device" memory is host memory, streams and events are inert, kernel launches do
 // nothing: no sample is ever computed here.  The product library never contains any of this.
 #include <hip/hip_runtime_api.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -32,7 +33,8 @@ hipError_t hipEventCreate( hipEvent_t* e ) { StubEvent* p = (StubEvent*) calloc(
 hipError_t hipEventCreateWithFlags( hipEvent_t* e, unsigned ) { return hipEventCreate( e ); }
 hipError_t hipEventDestroy( hipEvent_t e ) { free( e ); return hipSuccess; }
 hipError_t hipEventRecord( hipEvent_t e, hipStream_t s ) { g_trace.push_back( 1 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( ( (StubEvent*) e )->id ); return hipSuccess; }
-hipError_t hipEventSynchronize( hipEvent_t ) { return hipSuccess; }
+static int g_delayUs = 0;      // vvt_set_delay: calls that block on a real device take this long here (stress tests of the host pipeline)
+hipError_t hipEventSynchronize( hipEvent_t ) { if( g_delayUs ) usleep( g_delayUs ); return hipSuccess; }
 hipError_t hipEventElapsedTime( float* ms, hipEvent_t, hipEvent_t ) { *ms = 0.f; return hipSuccess; }
 hipError_t hipGetLastError( void ) { return hipSuccess; }
 const char* hipGetErrorString( hipError_t ) { return "host stub"; }
@@ -47,7 +49,7 @@ hipError_t hipMemsetAsync( void* d, int v, size_t n, hipStream_t ) { memset( d, 
 // kernel launches: nothing to run on the host; the launch of the intra stage records what it was handed
 static int g_lastIntraUnits = -1; static const int* g_lastSync = nullptr;
 int  vvr_upload_tables() { return 0; }
-void launch_mc( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int ) {}
+void launch_mc( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int ) { if( g_delayUs ) usleep( g_delayUs ); }
 void launch_itrans( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const TbItem*, int, int ) {}
 // The one launch that leaves a trace in the "picture": the vertical deblocking pass stamps the first four luma samples of the output slot with
 // a hash of the picture's POC and of the stamps found in its reference slots at that moment.  Launches run at submission time here, so
@@ -70,7 +72,7 @@ void launch_deblock( hipStream_t, const PicDev& pic, DevPlanes reco, int dir )
     }
   for( int k = 0; k < 4; k++ ) reco.p[0][k] = (pel_t) ( ( x >> ( 16 * k ) ) & 0x3ff );
 }
-void launch_sao( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) {}
+void launch_sao( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) { if( g_delayUs ) usleep( 2 * g_delayUs ); }
 void launch_alf( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) {}
 void launch_lmcs( hipStream_t, const PicDev&, DevPlanes, int ) {}
 void launch_copy_planes( hipStream_t, DevPlanes, DevPlanes ) {}
@@ -147,6 +149,7 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
 }
 // asynchronous host-to-device copies issued so far: count and bytes (cleared by the call)
 __attribute__(( visibility( "default" ) )) void vvt_take_h2d( size_t* copies, size_t* bytes ) { *copies = g_h2dCopies; *bytes = g_h2dBytes; g_h2dCopies = g_h2dBytes = 0; }
+__attribute__(( visibility( "default" ) )) void vvt_set_delay( int us ) { g_delayUs = us; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_wg( void ) { return g_lastIntraWg; }

@@ -623,3 +623,39 @@ def test_records_in_pinned_memory_are_not_staged(stub):
             ndirect += 1
         assert c0 == 1 and c1 == 1 + ndirect and ndirect >= 2 and 0 <= b0 - b1 < 256 * ndirect      # (the staged image pads every array to 256 bytes)
     stub.vvr_destroy(ctx)
+
+
+@pytest.mark.timeout(240)
+def test_pipeline_under_load_does_not_stall(stub):
+    """many pictures through 8 worker threads, the launcher and the upload ring, with device calls that take time (the stand-in sleeps where a real
+    device would block): every picture completes.  (Found by a hang on the GPU: a job further back took the ring entry of the job whose turn it
+    was, which then waited for an entry that could only be freed behind its own commit - entries are taken strictly by turn now.)"""
+    W, H = 416, 240
+    plans, nslots = stream.ra_plan(65, gop=16, seed_poc0_is_external=False, pool=24, intra_period=32, irap_lookahead=8)
+    cfg = abi.Config()
+    cfg.abi_version = abi.VVR_ABI_VERSION
+    cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, 6
+    cfg.num_slots, cfg.num_streams, cfg.host_threads = max(nslots, 24), 8, 8
+    ctx = C.c_void_p()
+    assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    stub.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+    descs = [synth.picture_for_plan(pl, W, H, seed=513, tool_flags=TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, log2_ctu=6, p_intra=0.15) for pl in plans]
+    pics = [d.c() for d in descs]
+    stub.vvt_set_delay(150)
+    try:
+        for rep in range(4):
+            jobs = [stub.vvr_submit(ctx, C.byref(p)) for p in pics]
+            assert all(j >= 0 for j in jobs)
+            hs = []
+            for p in pics[:20]:                                   # resident pictures queue up behind the streaming ones
+                h = C.c_void_p()
+                assert stub.vvr_prepare(ctx, C.byref(p), C.byref(h)) == abi.VVR_OK
+                assert stub.vvr_submit_prepared(ctx, h) >= 0
+                hs.append(h)
+            assert stub.vvr_sync(ctx) == abi.VVR_OK
+            for h in hs:
+                stub.vvr_free_prepared(ctx, h)
+    finally:
+        stub.vvt_set_delay(0)
+    stub.vvr_destroy(ctx)

@@ -4,20 +4,20 @@
 out=gpurun_out/${1:-run}; mkdir -p $out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-echo "== pytest" ; timeout 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
-echo "== bench driver args"; timeout 600 python bench.py --steps 20 --warmup 5 > $out/bench_20_5.json 2> $out/bench_20_5.err; tail -c 400 $out/bench_20_5.json
-echo "== bench default"; timeout 600 python bench.py --no-cpu-baseline > $out/bench_64_16.json 2> $out/bench_64_16.err; tail -c 200 $out/bench_64_16.json
+echo "== pytest" ; timeout 420 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+echo "== bench driver args"; timeout 300 python bench.py --steps 20 --warmup 5 > $out/bench_20_5.json 2> $out/bench_20_5.err; tail -c 400 $out/bench_20_5.json
+echo "== bench default"; timeout 300 python bench.py --no-cpu-baseline > $out/bench_64_16.json 2> $out/bench_64_16.err; tail -c 200 $out/bench_64_16.json
 if [ "$2" == "mid" ]; then
-echo "== allintra"; timeout 600 python bench.py --config allintra --steps 32 --warmup 8 --no-cpu-baseline --verify 2 > $out/bench_allintra.json 2> $out/bench_allintra.err
-echo "== allintra 24 streams"; timeout 600 python bench.py --config allintra --steps 48 --warmup 24 --streams 24 --slots 48 --no-cpu-baseline --verify 0 > $out/bench_allintra_s24.json 2> $out/bench_allintra_s24.err
+echo "== allintra"; timeout 300 python bench.py --config allintra --steps 32 --warmup 8 --no-cpu-baseline --verify 2 > $out/bench_allintra.json 2> $out/bench_allintra.err
+echo "== allintra 24 streams"; timeout 300 python bench.py --config allintra --steps 48 --warmup 24 --streams 24 --slots 48 --no-cpu-baseline --verify 0 > $out/bench_allintra_s24.json 2> $out/bench_allintra_s24.err
 fi
 if [ "$2" == "full" ]; then
-echo "== bench 16 host threads"; timeout 600 python bench.py --no-cpu-baseline --verify 0 --host-threads 16 > $out/bench_64_16_ht16.json 2> $out/bench_64_16_ht16.err
-echo "== bench pageable records"; timeout 600 python bench.py --no-cpu-baseline --verify 0 --pageable-records > $out/bench_64_16_pageable.json 2> $out/bench_64_16_pageable.err
+echo "== bench 16 host threads"; timeout 300 python bench.py --no-cpu-baseline --verify 0 --host-threads 16 > $out/bench_64_16_ht16.json 2> $out/bench_64_16_ht16.err
+echo "== bench pageable records"; timeout 300 python bench.py --no-cpu-baseline --verify 0 --pageable-records > $out/bench_64_16_pageable.json 2> $out/bench_64_16_pageable.err
 echo "== rocprof stats"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -o bench -- python $R/bench.py --no-cpu-baseline --verify 0 > $R/$out/bench_rocprof.json 2> $R/$out/rocprof.err); ls $out/prof | head
-echo "== allintra"; timeout 600 python bench.py --config allintra --steps 16 --warmup 4 --no-cpu-baseline --verify 2 > $out/bench_allintra.json 2> $out/bench_allintra.err
-echo "== allintra 24 streams"; timeout 600 python bench.py --config allintra --steps 48 --warmup 24 --streams 24 --slots 48 --no-cpu-baseline --verify 0 > $out/bench_allintra_s24.json 2> $out/bench_allintra_s24.err
-echo "== 8k"; timeout 900 python bench.py --config 8k --steps 16 --warmup 4 --no-cpu-baseline --verify 1 > $out/bench_8k.json 2> $out/bench_8k.err
+echo "== allintra"; timeout 300 python bench.py --config allintra --steps 16 --warmup 4 --no-cpu-baseline --verify 2 > $out/bench_allintra.json 2> $out/bench_allintra.err
+echo "== allintra 24 streams"; timeout 300 python bench.py --config allintra --steps 48 --warmup 24 --streams 24 --slots 48 --no-cpu-baseline --verify 0 > $out/bench_allintra_s24.json 2> $out/bench_allintra_s24.err
+echo "== 8k"; timeout 420 python bench.py --config 8k --steps 16 --warmup 4 --no-cpu-baseline --verify 1 > $out/bench_8k.json 2> $out/bench_8k.err
 fi
 for f in $out/bench_*.json; do python - "$f" <<'PY'
 import json,sys

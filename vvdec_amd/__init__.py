@@ -18,7 +18,7 @@ from . import abi
 from .desc import PictureDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libvvdec_amd.so")
+_LIBPATH = os.environ.get("VVDEC_AMD_LIB") or os.path.join(_HERE, "libvvdec_amd.so")      # (VVDEC_AMD_LIB: developer builds of the same library, e.g. `make watchdog`)
 _lib = None
 
 

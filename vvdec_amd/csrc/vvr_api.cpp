@@ -29,6 +29,15 @@ int vvr_upload_tables();
 
 #define HIPCHK( ctx, call ) do { hipError_t e_ = ( call ); if( e_ != hipSuccess ) { ( ctx )->setError( std::string( #call ) + ": " + hipGetErrorString( e_ ) ); return VVR_ERR_DEVICE; } } while( 0 )
 
+#ifdef VVR_WATCHDOG
+#include <atomic>
+#include <chrono>
+static std::atomic<uint64_t> g_wdProgress{ 0 };
+#define WD_PROGRESS() g_wdProgress.fetch_add( 1 )
+#else
+#define WD_PROGRESS() do {} while( 0 )
+#endif
+
 struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
 const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy", "k_output" };
@@ -44,12 +53,14 @@ struct RingEntry {
   size_t stagedBegin = 0, stagedEnd = 0;                // the part of the image that goes through `host`
   std::vector<DirectCopy> direct;                       // arrays copied straight from the caller's pinned memory
   struct Job* owner = nullptr;                          // the job whose picture sits in the entry (nullptr: free)
+  uint64_t turn = 0;                                    // ring number (Job::ringSeq) of the streaming job the entry serves next: entry i serves i, i + R, i + 2R, ...
 };
 
 enum { J_QUEUED, J_PREPARING, J_READY, J_FAILED, J_COMMITTED };
 
 struct Job {
   int id = 0; uint64_t seq = 0;
+  uint64_t ringSeq = 0;             // streaming jobs: position in the sequence of ring users (entry = ringSeq % ring size)
   int state = J_QUEUED;
   int rc = VVR_OK; std::string err;
   vvr_picture pic;                  // shallow copy: the arrays stay the caller's until the job is prepared
@@ -86,7 +97,7 @@ struct vvr_context {
   std::map<int, std::unique_ptr<Job>> jobs;
   std::deque<Job*> queue;               // submitted, not yet taken by a worker
   int        nextJob = 0, nextStream = 0;
-  uint64_t   nextSeq = 0, nextCommit = 0;
+  uint64_t   nextSeq = 0, nextCommit = 0, nextRingSeq = 0;
   std::map<uint64_t, Job*> bySeq;       // jobs that have not been committed yet
   std::vector<std::vector<int>> slotUsers;   // job ids that touched a slot since it was last written (first entry: the writer)
   std::vector<RingEntry> ring;
@@ -95,6 +106,9 @@ struct vvr_context {
   std::vector<hipEvent_t> eventPool;
   std::vector<std::thread> workers;
   std::thread launcher;                 // commits prepared pictures in submission order (contexts with worker threads)
+#ifdef VVR_WATCHDOG
+  std::thread watchdog;
+#endif
   bool       stop = false;
   PrepScratch* inlineScratch = nullptr; // host_threads == 0, and vvr_prepare
   PinnedRanges pinned;                  // vvr_host_alloc
@@ -160,10 +174,11 @@ static void completeLocked( vvr_context* c, Job& j )
     const int32_t* src = j.ring ? j.ring->dmvrHost : j.q->dmvrHost;
     j.dmvr.assign( src, src + 2 * (size_t) j.q->numDmvr );
   }
-  if( j.ring && j.ring->owner == &j ) j.ring->owner = nullptr;
+  if( j.ring && j.ring->owner == &j ) { j.ring->owner = nullptr; j.ring->turn += c->ring.size(); }
   if( j.done ) { c->eventPool.push_back( j.done ); j.done = nullptr; }
   j.q = nullptr;
   j.completed = true;
+  WD_PROGRESS();
   c->cv.notify_all();
 }
 
@@ -318,7 +333,7 @@ static void commitReady( vvr_context* c )
       if( j->state == J_FAILED )
       {
         // a failed picture holds nothing: its ring entry is free again, waiting for it returns the error
-        if( j->ring && j->ring->owner == j ) j->ring->owner = nullptr;
+        if( j->ring && j->ring->owner == j ) { j->ring->owner = nullptr; j->ring->turn += c->ring.size(); }
         j->q = nullptr; j->completed = true;
       }
       c->bySeq.erase( c->nextCommit );
@@ -348,23 +363,31 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
 {
   size_t total = 0; std::string err;
   int rc = vvr_host_build( &job.pic, S, &total, err, &c->pinned );
-  RingEntry& e = c->ring[job.seq % c->ring.size()];
-  if( rc == VVR_OK )
+  RingEntry& e = c->ring[job.ringSeq % c->ring.size()];
   {
-    // the ring entry is ours once the picture that used it last (ring.size() submissions ago, hence committed before us) is reconstructed
+    // The ring entry is ours when it is this job's turn: the streaming job ring.size() places ahead of us has used it and its picture is
+    // reconstructed (that job is committed before us and never waits for us).  Strictly by turn - a later job that finds the entry free
+    // must not take it, or the job whose turn it is could wait for it forever while everything behind waits for that job's commit.  A job
+    // whose work lists could not be built takes its turn all the same (and gives the entry back when its place in the commit order comes).
     std::unique_lock<std::mutex> lk( c->mu );
-    while( e.owner )
+    for( ;; )
     {
-      Job* prev = e.owner;
-      c->cv.wait( lk, [&]{ return e.owner != prev || prev->state == J_COMMITTED || prev->completed; } );
-      if( e.owner != prev || prev->completed ) continue;
-      hipEvent_t ev = prev->done;
-      lk.unlock();
-      hipEventSynchronize( ev );
-      lk.lock();
-      if( e.owner == prev ) completeLocked( c, *prev );
+      if( e.owner )
+      {
+        Job* prev = e.owner;
+        c->cv.wait( lk, [&]{ return e.owner != prev || prev->state == J_COMMITTED || prev->completed; } );
+        if( e.owner != prev || prev->completed ) continue;
+        hipEvent_t ev = prev->done;
+        lk.unlock();
+        hipEventSynchronize( ev );
+        lk.lock();
+        if( e.owner == prev ) completeLocked( c, *prev );
+        continue;
+      }
+      if( e.turn == job.ringSeq ) break;
+      c->cv.wait( lk, [&]{ return e.owner != nullptr || e.turn == job.ringSeq; } );
     }
-    e.owner = &job;
+    e.owner = &job; job.ring = &e;
   }
   if( rc == VVR_OK )
   {
@@ -403,11 +426,36 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
   {
     std::lock_guard<std::mutex> lk( c->mu );
     if( rc == VVR_OK ) { job.q = &e.q; job.ring = &e; job.state = J_READY; }
-    else { job.rc = rc; job.err = err; job.state = J_FAILED; if( e.owner == &job ) { job.ring = &e; } }
+    else { job.rc = rc; job.err = err; job.state = J_FAILED; }
     c->cv.notify_all();                                 // (the launcher, if there is one)
   }
   if( c->workers.empty() ) commitReady( c );            // no worker threads: the submitting thread commits
 }
+
+#ifdef VVR_WATCHDOG
+// developer build (make watchdog): when nothing completes for 15 s, the state of the pipeline goes to stderr and the process aborts
+static void watchdogMain( vvr_context* c )
+{
+  uint64_t last = g_wdProgress.load(); int idle = 0;
+  while( !c->stop )
+  {
+    std::this_thread::sleep_for( std::chrono::seconds( 1 ) );
+    const uint64_t now = g_wdProgress.load();
+    bool pending = false;
+    if( c->mu.try_lock() ) { for( auto& kv : c->jobs ) if( !kv.second->completed ) pending = true; c->mu.unlock(); } else pending = true;
+    if( now != last || !pending ) { last = now; idle = 0; continue; }
+    if( ++idle < 15 ) continue;
+    fprintf( stderr, "[vvr watchdog] no progress for 15 s; mu %s, commitMu %s\n", c->mu.try_lock() ? ( c->mu.unlock(), "free" ) : "HELD", c->commitMu.try_lock() ? ( c->commitMu.unlock(), "free" ) : "HELD" );
+    fprintf( stderr, "  nextSeq %llu nextCommit %llu queue %zu workers %zu\n", (unsigned long long) c->nextSeq, (unsigned long long) c->nextCommit, c->queue.size(), c->workers.size() );
+    for( auto& kv : c->jobs ) { Job& j = *kv.second; if( j.completed && j.waited ) continue; fprintf( stderr, "  job %d seq %llu state %d completed %d waited %d lane %d ring %d done %p\n", j.id, (unsigned long long) j.seq, j.state, (int) j.completed, (int) j.waited, j.lane, j.ring ? (int) ( j.ring - c->ring.data() ) : -1, (void*) j.done ); }
+    for( size_t i = 0; i < c->ring.size(); i++ ) fprintf( stderr, "  ring %zu owner %d\n", i, c->ring[i].owner ? c->ring[i].owner->id : -1 );
+    for( size_t i = 0; i < c->streams.size(); i++ ) fprintf( stderr, "  stream %zu query %d\n", i, (int) hipStreamQuery( c->streams[i] ) );
+    fprintf( stderr, "  copyStream query %d\n", (int) hipStreamQuery( c->copyStream ) );
+    fflush( stderr );
+    abort();
+  }
+}
+#endif
 
 static void workerMain( vvr_context* c )
 {
@@ -536,13 +584,16 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   {
     // upload ring: one entry per picture that can be between "being prepared" and "reconstructed"
     c->ring.resize( (size_t) ns + cfg->host_threads + 2 );
-    for( auto& e : c->ring ) ok = ok && hipEventCreateWithFlags( &e.copied, hipEventDisableTiming ) == hipSuccess;
+    for( size_t i = 0; i < c->ring.size(); i++ ) { c->ring[i].turn = i; ok = ok && hipEventCreateWithFlags( &c->ring[i].copied, hipEventDisableTiming ) == hipSuccess; }
   }
   if( !ok ) { vvr_destroy( c ); return VVR_ERR_DEVICE; }
   c->slotUsers.resize( cfg->num_slots );
   c->inlineScratch = vvr_scratch_create();
   for( int t = 0; t < cfg->host_threads; t++ ) c->workers.emplace_back( workerMain, c );
   if( cfg->host_threads ) c->launcher = std::thread( launcherMain, c );
+#ifdef VVR_WATCHDOG
+  c->watchdog = std::thread( watchdogMain, c );
+#endif
   *out = c;
   return VVR_OK;
 }
@@ -557,6 +608,9 @@ VVR_API void vvr_destroy( vvr_context* c )
   { std::lock_guard<std::mutex> lk( c->mu ); c->stop = true; c->cv.notify_all(); }
   for( auto& t : c->workers ) t.join();
   if( c->launcher.joinable() ) c->launcher.join();
+#ifdef VVR_WATCHDOG
+  if( c->watchdog.joinable() ) c->watchdog.join();
+#endif
   for( auto& kv : c->jobs ) { Job& j = *kv.second; for( auto& t : j.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); } if( j.done ) hipEventDestroy( j.done ); }
   for( auto e : c->eventPool ) hipEventDestroy( e );
   for( auto& e : c->ring ) { if( e.host ) hipHostFree( e.host ); if( e.dev ) hipFree( e.dev ); if( e.dmvrHost ) hipHostFree( e.dmvrHost ); if( e.copied ) hipEventDestroy( e.copied ); }
@@ -634,7 +688,7 @@ VVR_API int vvr_submit( vvr_context* c, const vvr_picture* p )
     retireLocked( c );
     if( !c->workers.empty() ) c->cv.wait( lk, [&]{ return c->queue.size() < 2 * c->workers.size(); } );       // back-pressure
     job = newJobLocked( c );
-    job->pic = *p;
+    job->pic = *p; job->ringSeq = c->nextRingSeq++;
     if( !c->workers.empty() ) { c->queue.push_back( job ); c->cv.notify_all(); return job->id; }
     job->state = J_PREPARING;
   }
