@@ -42,6 +42,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 
+# Pictures in flight run on HIP streams of their own; the ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4),
+# and kernels of streams that share a queue do not overlap.  One queue per lane (the variable is read when HIP initialises: before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 
 # SURVEY.md §8(d) tool mixes (fractions of inter CUs; BDOF / DMVR follow from the reference's own conditions:
 # bi-predicted, mirrored POC distances, >= 8x8 and >= 128 samples, merge mode for DMVR)
@@ -323,7 +327,7 @@ def main():
                           "irap_in_window": n_irap, "irap_share_of_stream": "1/%d" % intra_period if a.config != "allintra" else "1/1",
                           "tools": "intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM + ISP, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
                           "mix": mix,
-                          "pictures_in_flight": a.streams, "sharding": "closed-GOP segment per GPU, no data-path collective",
+                          "pictures_in_flight": a.streams, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "sharding": "closed-GOP segment per GPU, no data-path collective",
                           "verified_timed_pictures_vs_oracle": verified, "timed_run_equals_serial_run": serial_equal},
                "roofline": roof}
         if not a.no_cpu_baseline:

@@ -81,9 +81,10 @@ static int lmcs_chroma_scale( const vvr_picture* pic, const vvo_planes* reco, co
   const int32_t tlIdx = cuAt[(size_t) ( yPos >> 2 ) * w4 + ( xPos >> 2 )];
   const vvr_cu* tl = &pic->cu[tlIdx];
   xPos = tl->x; yPos = tl->y;
-  /* CodingStructure::getCURestricted (CodingStructure.cpp:464-499), one slice, one tile: a neighbour inside the same CTU only counts
+  /* CodingStructure::getCURestricted (CodingStructure.cpp:464-499), a neighbour in another slice or tile does not count, one inside the same CTU only
    * if it precedes the CU at the VPDU origin in decoding order */
-  int hasLeft = xPos > 0, hasAbove = yPos > 0;
+  const int curCtu = vvo_ctu_of( H, xPos, yPos );
+  int hasLeft = xPos > 0 && vvo_same_slice_tile( pic, vvo_ctu_of( H, xPos - 1, yPos ), curCtu ), hasAbove = yPos > 0 && vvo_same_slice_tile( pic, vvo_ctu_of( H, xPos, yPos - 1 ), curCtu );
   if( hasLeft && ( ( xPos - 1 ) >> H->log2_ctu ) == ( xPos >> H->log2_ctu ) && cuAt[(size_t) ( yPos >> 2 ) * w4 + ( ( xPos - 1 ) >> 2 )] > tlIdx ) hasLeft = 0;
   if( hasAbove && ( ( yPos - 1 ) >> H->log2_ctu ) == ( yPos >> H->log2_ctu ) && cuAt[(size_t) ( ( yPos - 1 ) >> 2 ) * w4 + ( xPos >> 2 )] > tlIdx ) hasAbove = 0;
   const pel* Y = reco->p[0]; const int st = reco->stride[0];

@@ -30,6 +30,22 @@ static inline int vvo_ref_at( const vvo_planes* r, int c, int x, int y )
   return r->p[c][(size_t) y * r->stride[c] + x];
 }
 
+/* slices and tiles (vvr_picture.ctu_slice / ctu_tile): luma position -> CTU; nothing is available to intra prediction, CCLM or the LMCS chroma
+ * scaling neighbourhood across a slice or tile boundary (CodingStructure::getCURestricted, CodingStructure.cpp:464) */
+static inline int vvo_ctu_of( const vvr_pic_header* H, int lx, int ly ) { const int ctu = 1 << H->log2_ctu; return ( ly >> H->log2_ctu ) * ( ( H->width + ctu - 1 ) >> H->log2_ctu ) + ( lx >> H->log2_ctu ); }
+static inline int vvo_same_slice_tile( const vvr_picture* pic, int ctuA, int ctuB )
+{
+  return ( !pic->ctu_slice || pic->ctu_slice[ctuA] == pic->ctu_slice[ctuB] ) && ( !pic->ctu_tile || pic->ctu_tile[ctuA] == pic->ctu_tile[ctuB] );
+}
+/* may SAO / ALF of CTU a read samples of CTU b (pps_loop_filter_across_slices / tiles_enabled_flag) */
+static inline int vvo_lf_may_cross( const vvr_picture* pic, int a, int b )
+{
+  if( a == b ) return 1;
+  if( ( pic->hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && pic->ctu_slice && pic->ctu_slice[a] != pic->ctu_slice[b] ) return 0;
+  if( ( pic->hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) && pic->ctu_tile && pic->ctu_tile[a] != pic->ctu_tile[b] ) return 0;
+  return 1;
+}
+
 int  vvo_planes_alloc( vvo_planes* pl, int width, int height, int chroma_format );
 void vvo_planes_free( vvo_planes* pl );
 

@@ -36,12 +36,15 @@ static int wide_angle( int w, int h, int mode )   /* IntraPrediction::getWideAng
 
 /* reference availability of the 4x4 luma-grid unit that contains channel position (x,y): the unit must lie inside the picture and
  * its transform block must precede the current one in decoding order (getCURestricted + the TU index test of is*Available). */
+static const vvr_picture* g_pic;      /* the picture being reconstructed (slice / tile maps) */
+static int g_curCtu;                  /* CTU of the block whose neighbourhood is looked at */
 static int unit_avail( const vvr_pic_header* H, const int32_t* order, int ch, int x, int y, int32_t cur )
 {
   const int cs = ch ? 1 : 0;
   const int lx = x << cs, ly = y << cs;
   if( x < 0 || y < 0 || lx >= H->width || ly >= H->height ) return 0;
   const int w4 = ( H->width + 3 ) >> 2, h4 = ( H->height + 3 ) >> 2;
+  if( g_pic && !vvo_same_slice_tile( g_pic, vvo_ctu_of( H, lx, ly ), g_curCtu ) ) return 0;      /* getCURestricted: same slice, same tile */
   return order[(size_t) ch * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
 }
 
@@ -65,7 +68,10 @@ static void cclm_predict( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu
   const pel* Y = reco->p[0]; const int ys = reco->stride[0];
 #define LU( xx, yy ) ( (int) Y[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
   const int mode = cu->intra_dir[1];
-  const int aboveCu = cu->y > 0 || ly0 > cu->y, leftCu = cu->x > 0 || lx0 > cu->x;      /* cu.above / cu.left: single slice, single tile */
+  /* cu.above / cu.left: the neighbouring CU exists in this slice and tile (a block inside its CU has the CU itself above / left) */
+  const int curCtu = vvo_ctu_of( H, cu->x, cu->y );
+  const int aboveCu = ly0 > cu->y || ( cu->y > 0 && vvo_same_slice_tile( pic, vvo_ctu_of( H, cu->x, cu->y - 1 ), curCtu ) );
+  const int leftCu = lx0 > cu->x || ( cu->x > 0 && vvo_same_slice_tile( pic, vvo_ctu_of( H, cu->x - 1, cu->y ), curCtu ) );
   const int unit = 2;                                                                       /* 4 luma samples in chroma units */
   const int tuWU = cw / unit, tuHU = chh / unit;
   /* ---- xGetLumaRecPixels: which borders take part in the edge handling of the down-sampling filters */
@@ -363,6 +369,7 @@ int vvo_intra_tu( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, ui
                   const int32_t* order, const int16_t* resi, int has_resi, int ciip_w_intra )
 {
   const vvr_pic_header* H = &pic->hdr;
+  g_pic = pic; g_curCtu = vvo_ctu_of( H, cu->x, cu->y );
   const int bd = H->bit_depth, cs = comp ? 1 : 0, ch = comp ? 1 : 0;
   const int x0 = ( comp && cu->isp_mode ) ? cu->x >> 1 : tu->x >> cs, y0 = ( comp && cu->isp_mode ) ? cu->y >> 1 : tu->y >> cs;
   const int tbw = ( comp && cu->isp_mode ) ? cu->w >> 1 : tu->w >> cs;      /* ISP: the chroma block of the CU sits in the last TU */

@@ -273,7 +273,10 @@ void vvo_sao( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )
         {
           const int dx = dxy[s->type[c]][0], dy = dxy[s->type[c]][1];
           const int ax = x - dx, ay = y - dy, bx = x + dx, by = y + dy;
-          if( ax >= 0 && ax < cw && ay >= 0 && ay < chh && bx >= 0 && bx < cw && by >= 0 && by < chh )
+          /* neighbours outside the picture, or in a CTU of another slice / tile the loop filters may not cross, are not available
+             (deriveLoopFilterBoundaryAvailibility, SampleAdaptiveOffset.cpp:741-805): the sample is left alone */
+          if( ax >= 0 && ax < cw && ay >= 0 && ay < chh && bx >= 0 && bx < cw && by >= 0 && by < chh
+              && vvo_lf_may_cross( pic, ( y / cctu ) * ctusX + x / cctu, ( ay / cctu ) * ctusX + ax / cctu ) && vvo_lf_may_cross( pic, ( y / cctu ) * ctusX + x / cctu, ( by / cctu ) * ctusX + bx / cctu ) )
           {
             const int a = src->p[c][(size_t) ay * src->stride[c] + ax], b = src->p[c][(size_t) by * src->stride[c] + bx];
             const int e = vvo_sgn( v - a ) + vvo_sgn( v - b );      /* -2 valley .. +2 peak */
@@ -290,8 +293,40 @@ void vvo_sao( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )
 /* ================================================================================================================= */
 /* ALF                                                                                                               */
 /* ================================================================================================================= */
-static inline int alf_at( const vvo_planes* s, int c, int x, int y )   /* prepareCTU (:453): picture borders replicated */
+/* What the ALF of the current CTU may read.  Picture borders are replicated (prepareCTU :453); at a CTU edge behind which lies a slice or tile the
+ * filter must not look into, the reference filters a padded copy of the CTU instead (isClipOrCrossedByVirtualBoundaries :118-291, filterCTU
+ * :764-840: copy + extendBorderPel), which is the same as clamping the coordinates to the CTU on the clipped sides.  rasterSliceAlfPad: the CTU
+ * diagonally above-left (below-right) belongs to another slice while the ones above and left (below and right) do not - that corner is filled
+ * from the first (last) column of the CTU, row by row (AreaBuf::padBorderPel, Buffer.h:608). */
+static struct { int on; int x0[2], y0[2], x1[2], y1[2]; int l, r, t, b, tl, br; } g_alf;     /* [0] luma, [1] chroma coordinates of the CTU */
+static void alf_set_ctu( const vvr_picture* pic, int ctuX, int ctuY )
 {
+  const vvr_pic_header* H = &pic->hdr;
+  const int ctu = 1 << H->log2_ctu, ctusX = ( H->width + ctu - 1 ) / ctu, ctusY = ( H->height + ctu - 1 ) / ctu, a = ctuY * ctusX + ctuX;
+  memset( &g_alf, 0, sizeof( g_alf ) );
+  for( int k = 0; k < 2; k++ ) { const int S = ctu >> k; g_alf.x0[k] = ctuX * S; g_alf.y0[k] = ctuY * S; g_alf.x1[k] = g_alf.x0[k] + S - 1; g_alf.y1[k] = g_alf.y0[k] + S - 1; }
+  const int hasL = ctuX > 0, hasR = ctuX + 1 < ctusX, hasT = ctuY > 0, hasB = ctuY + 1 < ctusY;
+  g_alf.l = hasL && !vvo_lf_may_cross( pic, a, a - 1 );     g_alf.r = hasR && !vvo_lf_may_cross( pic, a, a + 1 );
+  g_alf.t = hasT && !vvo_lf_may_cross( pic, a, a - ctusX ); g_alf.b = hasB && !vvo_lf_may_cross( pic, a, a + ctusX );
+  if( ( H->tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && pic->ctu_slice )
+  {
+    g_alf.tl = !g_alf.t && !g_alf.l && hasL && hasT && pic->ctu_slice[a - ctusX - 1] != pic->ctu_slice[a];
+    g_alf.br = !g_alf.b && !g_alf.r && hasR && hasB && pic->ctu_slice[a + ctusX + 1] != pic->ctu_slice[a];
+  }
+  g_alf.on = g_alf.l | g_alf.r | g_alf.t | g_alf.b | g_alf.tl | g_alf.br;
+}
+static inline int alf_at( const vvo_planes* s, int c, int x, int y )
+{
+  if( g_alf.on )
+  {
+    const int k = c ? 1 : 0;
+    if( g_alf.l && x < g_alf.x0[k] ) x = g_alf.x0[k];
+    if( g_alf.r && x > g_alf.x1[k] ) x = g_alf.x1[k];
+    if( g_alf.t && y < g_alf.y0[k] ) y = g_alf.y0[k];
+    if( g_alf.b && y > g_alf.y1[k] ) y = g_alf.y1[k];
+    if( g_alf.tl && x < g_alf.x0[k] && y < g_alf.y0[k] ) x = g_alf.x0[k];
+    if( g_alf.br && x > g_alf.x1[k] && y > g_alf.y1[k] ) x = g_alf.x1[k];
+  }
   x = vvo_clip3( 0, s->w[c] - 1, x ); y = vvo_clip3( 0, s->h[c] - 1, y );
   return s->p[c][(size_t) y * s->stride[c] + x];
 }
@@ -418,7 +453,7 @@ static int ccalf_sample( const vvo_planes* s, int cx, int cy, const int16_t* cf,
   return vvo_clip_pel( sum + off, bd ) - off;
 }
 
-void vvo_alf( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )   /* filterCTU (:664), no virtual-boundary / slice / tile clipping */
+void vvo_alf( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )   /* filterCTU (:664); slice / tile clipping through alf_at; no picture-header virtual boundaries */
 {
   const vvr_pic_header* H = &pic->hdr;
   const int ctu = 1 << H->log2_ctu, ctusX = ( H->width + ctu - 1 ) / ctu, bd = H->bit_depth;
@@ -430,6 +465,7 @@ void vvo_alf( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )  
     for( int y = 0; y < src->h[c]; y += 4 ) for( int x = 0; x < src->w[c]; x += 4 )
     {
       const vvr_alf_ctu* f = &pic->alf[( y / cctu ) * ctusX + ( x / cctu )];
+      alf_set_ctu( pic, x / cctu, y / cctu );
       int16_t cf[13], cl[13];
       int on = f->enable[c];
       if( on && c == 0 )

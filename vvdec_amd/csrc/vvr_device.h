@@ -95,6 +95,8 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
   const vvr_lmcs_params* lmcs;       // LMCS tables (NULL when off)
   const vvr_scaling_list* scaling;   // explicit scaling lists (NULL unless VVR_TOOL_SCALING_LIST)
   const vvr_wp_params*   wp;         // explicit weighted prediction table (NULL unless VVR_TOOL_WP on a P / B picture)
+  const uint16_t*    ctuSlice;       // slice / tile index of every CTU (NULL: one slice / one tile): where SAO and ALF stop when the picture says so
+  const uint16_t*    ctuTile;
   const uint8_t*     interAt;        // per 4x4 luma unit: 1 = covered by an inter CU (LMCS forward mapping of the prediction)
   const uint32_t*    csVpdu;         // LMCS chroma residual scaling, per VPDU: x | y << 13 | hasLeft << 26 | hasAbove << 27 of the luma neighbourhood the factor is averaged over
   int                vpdusX, vpduLog2;

@@ -1567,6 +1567,58 @@ void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )
 }
 
 // =====================================================================================================================
+// slice / tile boundaries in the in-loop filters.  SAO and ALF of a CTU may not look at samples of a neighbouring CTU in another slice
+// (tile) when pps_loop_filter_across_slices (tiles)_enabled_flag is off: SAO leaves the samples whose neighbour would lie there alone
+// (deriveLoopFilterBoundaryAvailibility, SampleAdaptiveOffset.cpp:741-805), ALF reads a replicated border instead
+// (isClipOrCrossedByVirtualBoundaries + the padded copy of filterCTU, AdaptiveLoopFilter.cpp:118-291,764-840).
+// =====================================================================================================================
+__device__ __forceinline__ bool lf_restricted( const PicDev& pic )
+{
+  return ( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && pic.ctuSlice ) || ( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) && pic.ctuTile );
+}
+// may a filter working on CTU a read samples of CTU b?
+__device__ __forceinline__ bool lf_may_cross( const PicDev& pic, int a, int b )
+{
+  if( a == b ) return true;
+  if( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && pic.ctuSlice && pic.ctuSlice[a] != pic.ctuSlice[b] ) return false;
+  if( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) && pic.ctuTile && pic.ctuTile[a] != pic.ctuTile[b] ) return false;
+  return true;
+}
+// ALF: the part of the plane a CTU may read, as a clamp of the coordinates.  Bits of f: 1 left, 2 right, 4 top, 8 bottom edge of the CTU clipped;
+// 16 / 32: the CTU diagonally above-left / below-right lies in another slice while the CTUs above and left (below and right) do not (raster-
+// scan slices): the corner beyond is read from the CTU's first (last) column of the same row (AreaBuf::padBorderPel, Buffer.h:608).
+struct AlfClip { int x0, y0, x1, y1; uint32_t f; };
+__device__ __forceinline__ AlfClip alf_clip_of_ctu( const PicDev& pic, int ctuX, int ctuY, int cs )
+{
+  AlfClip k; k.f = 0;
+  const int S = ( 1 << pic.hdr.log2_ctu ) >> cs;
+  k.x0 = ctuX * S; k.y0 = ctuY * S; k.x1 = k.x0 + S - 1; k.y1 = k.y0 + S - 1;
+  if( !lf_restricted( pic ) ) return k;
+  const int a = ctuY * pic.ctus_x + ctuX;
+  const bool hasL = ctuX > 0, hasR = ctuX + 1 < pic.ctus_x, hasT = ctuY > 0, hasB = ctuY + 1 < pic.ctus_y;
+  if( hasL && !lf_may_cross( pic, a, a - 1 ) ) k.f |= 1;
+  if( hasR && !lf_may_cross( pic, a, a + 1 ) ) k.f |= 2;
+  if( hasT && !lf_may_cross( pic, a, a - pic.ctus_x ) ) k.f |= 4;
+  if( hasB && !lf_may_cross( pic, a, a + pic.ctus_x ) ) k.f |= 8;
+  if( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && pic.ctuSlice )
+  {
+    if( !( k.f & 5 ) && hasL && hasT && pic.ctuSlice[a - pic.ctus_x - 1] != pic.ctuSlice[a] ) k.f |= 16;
+    if( !( k.f & 10 ) && hasR && hasB && pic.ctuSlice[a + pic.ctus_x + 1] != pic.ctuSlice[a] ) k.f |= 32;
+  }
+  return k;
+}
+__device__ __forceinline__ void alf_clip_coord( const AlfClip& k, int& x, int& y )
+{
+  if( !k.f ) return;
+  if( ( k.f & 1 ) && x < k.x0 ) x = k.x0;
+  if( ( k.f & 2 ) && x > k.x1 ) x = k.x1;
+  if( ( k.f & 4 ) && y < k.y0 ) y = k.y0;
+  if( ( k.f & 8 ) && y > k.y1 ) y = k.y1;
+  if( ( k.f & 16 ) && x < k.x0 && y < k.y0 ) x = k.x0;
+  if( ( k.f & 32 ) && x > k.x1 && y > k.y1 ) x = k.x1;
+}
+
+// =====================================================================================================================
 // k_sao — SampleAdaptiveOffset::offsetBlock_core (SampleAdaptiveOffset.cpp:64) per sample; reads the deblocked picture,
 // writes a second picture, so neighbour reads always see pre-SAO samples (the reference needs a line copy for that, :400).
 // =====================================================================================================================
@@ -1623,11 +1675,15 @@ __global__ __launch_bounds__( 256 ) void k_sao( PicDev pic, DevPlanes src, DevPl
               if( x0 + 8 < cw ) { wa[9] = ra[8]; wb[9] = rb[8]; }
             }
           }
+          const bool restricted = lf_restricted( pic );
+          const int curCtu = ( y / ctuC ) * pic.ctus_x + ( x0 / ctuC );
 #pragma unroll
           for( int i = 0; i < 8; i++ )
           {
             const int x = x0 + i;
             if( x - dx < 0 || x - dx >= cw || x + dx < 0 || x + dx >= cw ) continue;
+            // nothing across a slice / tile boundary the loop filters must not cross
+            if( restricted && ( !lf_may_cross( pic, curCtu, ( ya / ctuC ) * pic.ctus_x + ( x - dx ) / ctuC ) || !lf_may_cross( pic, curCtu, ( yb / ctuC ) * pic.ctus_x + ( x + dx ) / ctuC ) ) ) continue;
             const int e = sgn( v[i] - wa[1 + i - dx] ) + sgn( v[i] - wb[1 + i + dx] );
             if( e ) out[i] = clip_pel( v[i] + s.offset[c][e < 0 ? e + 2 : e + 1], bd );
           }
@@ -1685,10 +1741,13 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
     return;
   }
   const int TW = ALF_T + 2 * ALF_HALO;
+  const AlfClip kclip = alf_clip_of_ctu( pic, tx0 >> pic.hdr.log2_ctu, ty0 >> pic.hdr.log2_ctu, 0 );
   for( int i = tid; i < TW * TW; i += 256 )
   {
     const int yy = i / TW, xx = i - yy * TW;
-    const int sx = clip3( 0, W - 1, tx0 - ALF_HALO + xx ), sy = clip3( 0, H - 1, ty0 - ALF_HALO + yy );
+    int sx = tx0 - ALF_HALO + xx, sy = ty0 - ALF_HALO + yy;
+    alf_clip_coord( kclip, sx, sy );                              // slice / tile boundaries the filter must not cross
+    sx = clip3( 0, W - 1, sx ); sy = clip3( 0, H - 1, sy );
     tile[yy * ALF_LW + xx] = S[(size_t) sy * st + sx];
   }
   {
@@ -1811,7 +1870,13 @@ __global__ __launch_bounds__( 256 ) void k_alf_chroma( PicDev pic, DevPlanes src
   const vvr_alf_ctu& f = pic.alf[( y / ctuC ) * pic.ctus_x + ( x / ctuC )];
   const pel_t* __restrict__ S = src.p[c];
   const int st = src.stride[c];
-#define C( xx, yy ) S[(size_t) clip3( 0, H - 1, ( yy ) ) * st + clip3( 0, W - 1, ( xx ) )]
+  const AlfClip kc = alf_clip_of_ctu( pic, x / ctuC, y / ctuC, 1 ), kl = alf_clip_of_ctu( pic, x / ctuC, y / ctuC, 0 );
+  auto fetch = [&]( const pel_t* __restrict__ P, int pst, int PW, int PH, const AlfClip& k, int xx, int yy ) -> int
+  {
+    alf_clip_coord( k, xx, yy );
+    return P[(size_t) clip3( 0, PH - 1, yy ) * pst + clip3( 0, PW - 1, xx )];
+  };
+#define C( xx, yy ) fetch( S, st, W, H, kc, ( xx ), ( yy ) )
   const int cur = S[(size_t) y * st + x];
   int v = cur;
   const vvr_alf_params* __restrict__ A = pic.alf_params;
@@ -1847,7 +1912,7 @@ __global__ __launch_bounds__( 256 ) void k_alf_chroma( PicDev pic, DevPlanes src
     const int16_t* cf = A->ccalf_coeff[c - 1][f.cc_idc[c - 1] - 1];
     const pel_t* __restrict__ L = src.p[0];
     const int ls = src.stride[0], LW = src.w[0], LH = src.h[0];
-#define Y( xx, yy ) L[(size_t) clip3( 0, LH - 1, ( yy ) ) * ls + clip3( 0, LW - 1, ( xx ) )]
+#define Y( xx, yy ) fetch( L, ls, LW, LH, kl, ( xx ), ( yy ) )
     const int vbPos = ctu - 4, lx = x << 1, ly = y << 1, pos = ly & ( ctu - 1 );
     int o1 = 1, o2 = -1, o3 = 2;
     if( pos == vbPos - 2 || pos == vbPos + 1 ) o3 = o1;

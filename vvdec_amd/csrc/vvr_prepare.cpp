@@ -67,7 +67,7 @@ struct PrepScratch
   // ---- layout of the H2D image
   std::vector<Part> parts;
   size_t total = 0, numDirect = 0;          // parts [0, numDirect) are copied from the caller's pinned arrays
-  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iLmcs, iSl, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iDmvrOut, iTb[3], iIntra, iUnits;
+  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iLmcs, iSl, iCtuSlice, iCtuTile, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iDmvrOut, iTb[3], iIntra, iUnits;
 
   void begin( const vvr_picture* pic )
   {
@@ -90,12 +90,16 @@ struct PrepScratch
   {
     const int cs = chn ? 1 : 0, lx = x << cs, ly = y << cs;
     if( x < 0 || y < 0 || lx >= h.width || ly >= h.height ) return 0;
-    // CTUs are decoded in raster order: everything in an earlier CTU is there, nothing in a later one (whose cells are not even mapped yet)
+    // CTUs are decoded in raster order (inside a tile; CTUs of another tile are never available): everything in an earlier CTU is there, nothing
+    // in a later one (whose cells are not even mapped yet).  Nothing is available across a slice or tile boundary (CodingStructure::
+    // getCURestricted, CodingStructure.cpp:464).
     const uint32_t c = (uint32_t) ( ( ly >> h.log2_ctu ) * ctusX + ( lx >> h.log2_ctu ) );
-    if( c != curCtuIdx ) return c < curCtuIdx;
+    if( c != curCtuIdx ) return c < curCtuIdx && sameSliceAndTile( c, curCtuIdx );
     return order[(size_t) chn * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
   }
 
+  bool sameSliceAndTile( uint32_t a, uint32_t b ) const { return ( !p->ctu_slice || p->ctu_slice[a] == p->ctu_slice[b] ) && ( !p->ctu_tile || p->ctu_tile[a] == p->ctu_tile[b] ); }
+  uint32_t ctuAt( int lx, int ly ) const { return (uint32_t) ( ( ly >> h.log2_ctu ) * ctusX + ( lx >> h.log2_ctu ) ); }
   int beginMaps();
   int mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string& err );
   bool anyIntra = false; uint32_t curCtuIdx = 0;
@@ -368,7 +372,8 @@ int PrepScratch::mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string&
       const int32_t tl = cuAt( vxp, vyp );
       if( tl < (int32_t) i0 || tl >= (int32_t) i1 ) FAIL( VVR_ERR_PARAMETER, "no luma CU at the origin of a VPDU" );
       const int xPos = p->cu[tl].x, yPos = p->cu[tl].y;
-      bool hasLeft = xPos > 0, hasAbove = yPos > 0;
+      // the neighbouring CU has to be available: decoded before, same slice, same tile (getCURestricted in calculateChromaAdjVpduNei)
+      bool hasLeft = xPos > 0 && sameSliceAndTile( ctuAt( xPos - 1, yPos ), ctuIdx ), hasAbove = yPos > 0 && sameSliceAndTile( ctuAt( xPos, yPos - 1 ), ctuIdx );
       if( hasLeft && ( ( xPos - 1 ) >> h.log2_ctu ) == ( xPos >> h.log2_ctu ) && cuAt( xPos - 1, yPos ) > tl ) hasLeft = false;
       if( hasAbove && ( ( yPos - 1 ) >> h.log2_ctu ) == ( yPos >> h.log2_ctu ) && cuAt( xPos, yPos - 1 ) > tl ) hasAbove = false;
       csVpduV[(size_t) ( vyp >> vpduLog2 ) * vpdusX + ( vxp >> vpduLog2 )] = (uint32_t) xPos | ( (uint32_t) yPos << 13 ) | ( hasLeft ? 1u << 26 : 0 ) | ( hasAbove ? 1u << 27 : 0 );
@@ -472,7 +477,9 @@ int PrepScratch::buildWorkLists( std::string& err )
             // CCLM / MDLM: template sizes and flags of IntraPrediction::xGetLMParameters (:1694-1800) and the border handling of
             // xGetLumaRecPixels (:1403-1470); they ride in the item's `tu` word
             const int mode = cu.intra_dir[1];
-            const bool aboveCu = cu.y > 0 || ( y0 << 1 ) > cu.y, leftCu = cu.x > 0 || ( x0 << 1 ) > cu.x;          // cu.above / cu.left (one slice, one tile)
+            // cu.above / cu.left: the neighbouring CU exists in this slice and tile (for a block inside its CU: the CU itself lies above / left)
+            const bool aboveCu = ( y0 << 1 ) > cu.y || ( cu.y > 0 && sameSliceAndTile( ctuAt( cu.x, cu.y - 1 ), ctuOfCu ) );
+            const bool leftCu = ( x0 << 1 ) > cu.x || ( cu.x > 0 && sameSliceAndTile( ctuAt( cu.x - 1, cu.y ), ctuOfCu ) );
             const int tuWU = w / unit, tuHU = hh / unit;
             const int totA = ( 2 * w + unit - 1 ) / unit, totL = ( 2 * hh + unit - 1 ) / unit;
             int aboveAvail = 0, leftAvail = 0, actualTop = 0, actualLeft = 0;
@@ -966,6 +973,8 @@ void PrepScratch::layout( PinnedRanges* pinned )
   }
   iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
   iSl = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? add( p->scaling, sizeof( vvr_scaling_list ) ) : -1;
+  iCtuSlice = p->ctu_slice ? add( p->ctu_slice, sizeof( uint16_t ) * numCtu ) : -1;
+  iCtuTile = p->ctu_tile ? add( p->ctu_tile, sizeof( uint16_t ) * numCtu ) : -1;
   iWp = wpOn ? add( p->wp, sizeof( vvr_wp_params ) ) : -1;
   iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
   iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
@@ -1016,6 +1025,7 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   d.lfp[0] = (const vvr_lfp*) at( S.iL0 ); d.lfp[1] = (const vvr_lfp*) at( S.iL1 );
   d.sao = (const vvr_sao_ctu*) at( S.iSao ); d.alf = (const vvr_alf_ctu*) at( S.iAlf ); d.alf_params = (const vvr_alf_params*) at( S.iAlfP );
   d.lmcs = (const vvr_lmcs_params*) at( S.iLmcs ); d.scaling = (const vvr_scaling_list*) at( S.iSl ); d.wp = (const vvr_wp_params*) at( S.iWp );
+  d.ctuSlice = (const uint16_t*) at( S.iCtuSlice ); d.ctuTile = (const uint16_t*) at( S.iCtuTile );
   d.interAt = (const uint8_t*) at( S.iInterAt );
   d.csVpdu = (const uint32_t*) at( S.iCsVpdu ); d.vpdusX = S.vpdusX; d.vpduLog2 = S.vpduLog2;
   (void) p;
