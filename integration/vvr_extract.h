@@ -33,6 +33,7 @@ struct Extracted
   vvr_lmcs_params           lmcs;
   vvr_wp_params             wp;
   vvr_scaling_list          scaling;
+  std::vector<uint16_t>     ctuSlice, ctuTile;    // filled (and pointed to) when the picture has more than one slice / tile
   uint32_t                  numDmvr = 0;
   std::vector<std::pair<CodingUnit*, uint32_t>> dmvrCus;   // CUs that run DMVR with their offset into the delta-MV output (vvr_read_dmvr)
 };
@@ -95,12 +96,44 @@ static inline uint32_t toolFlags( const CodingStructure& cs, const Slice& slice,
   return f;
 }
 
+// do two slices of a picture agree in everything the one header of a vvr_picture carries?
+static inline bool sameSliceHeader( const Slice& a, const Slice& b )
+{
+  if( a.getSliceType() != b.getSliceType() || a.getDepQuantEnabledFlag() != b.getDepQuantEnabledFlag() || a.getLmcsEnabledFlag() != b.getLmcsEnabledFlag()
+      || a.getExplicitScalingListUsed() != b.getExplicitScalingListUsed() || a.getDeblockingFilterDisable() != b.getDeblockingFilterDisable()
+      || a.getDeblockingFilterBetaOffsetDiv2() != b.getDeblockingFilterBetaOffsetDiv2() || a.getDeblockingFilterTcOffsetDiv2() != b.getDeblockingFilterTcOffsetDiv2()
+      || a.getDeblockingFilterCbBetaOffsetDiv2() != b.getDeblockingFilterCbBetaOffsetDiv2() || a.getDeblockingFilterCbTcOffsetDiv2() != b.getDeblockingFilterCbTcOffsetDiv2()
+      || a.getDeblockingFilterCrBetaOffsetDiv2() != b.getDeblockingFilterCrBetaOffsetDiv2() || a.getDeblockingFilterCrTcOffsetDiv2() != b.getDeblockingFilterCrTcOffsetDiv2()
+      || a.getSaoEnabledFlag( CHANNEL_TYPE_LUMA ) != b.getSaoEnabledFlag( CHANNEL_TYPE_LUMA ) || a.getSaoEnabledFlag( CHANNEL_TYPE_CHROMA ) != b.getSaoEnabledFlag( CHANNEL_TYPE_CHROMA ) ) return false;
+  for( int c = 0; c < 3; c++ ) if( a.getAlfEnabledFlag( ComponentID( c ) ) != b.getAlfEnabledFlag( ComponentID( c ) ) ) return false;
+  if( a.getAlfEnabledFlag( COMPONENT_Y ) )
+  {
+    if( a.getNumAlfAps() != b.getNumAlfAps() ) return false;
+    for( int k = 0; k < a.getNumAlfAps(); k++ ) if( a.getAlfApsIdsLuma()[k] != b.getAlfApsIdsLuma()[k] ) return false;
+  }
+  if( ( a.getAlfEnabledFlag( COMPONENT_Cb ) || a.getAlfEnabledFlag( COMPONENT_Cr ) ) && a.getAlfApsIdChroma() != b.getAlfApsIdChroma() ) return false;
+  if( a.getCcAlfCbEnabledFlag() != b.getCcAlfCbEnabledFlag() || a.getCcAlfCrEnabledFlag() != b.getCcAlfCrEnabledFlag()
+      || ( a.getCcAlfCbEnabledFlag() && a.getCcAlfCbApsId() != b.getCcAlfCbApsId() ) || ( a.getCcAlfCrEnabledFlag() && a.getCcAlfCrApsId() != b.getCcAlfCrApsId() ) ) return false;
+  if( !a.isIntra() )
+    for( int l = 0; l < 2; l++ )
+    {
+      if( a.getNumRefIdx( RefPicList( l ) ) != b.getNumRefIdx( RefPicList( l ) ) ) return false;
+      for( int i = 0; i < a.getNumRefIdx( RefPicList( l ) ); i++ )
+      {
+        if( a.getRefPic( RefPicList( l ), i ) != b.getRefPic( RefPicList( l ), i ) ) return false;
+        const WPScalingParam *wa = nullptr, *wb = nullptr;
+        a.getWpScaling( RefPicList( l ), i, wa ); b.getWpScaling( RefPicList( l ), i, wb );
+        for( int c = 0; c < 3; c++ ) if( wa[c].bPresentFlag != wb[c].bPresentFlag || ( wa[c].bPresentFlag && ( wa[c].iWeight != wb[c].iWeight || wa[c].iOffset != wb[c].iOffset || wa[c].uiLog2WeightDenom != wb[c].uiLog2WeightDenom ) ) ) return false;
+      }
+    }
+  return true;
+}
+
 // What a vvr_picture of this ABI version cannot express: such a picture must not be flattened (it would be reconstructed silently wrong).
 // Returns VVR_OK, or VVR_ERR_UNSUPPORTED with the reason; the binding (DecLibReconAmd) turns that into the reference's own
-// "not supported" error path.  One header per picture means: one slice, one tile, one sub-picture - the reference restricts intra
-// availability, motion candidates and the in-loop filters at every slice / tile / sub-picture edge (CodingStructure::getCURestricted,
-// SampleAdaptiveOffset.cpp:741-830, AdaptiveLoopFilter.cpp:118-200, LoopFilter.cpp:780-800) and switches reference lists, filter
-// parameters and weights per slice.
+// "not supported" error path.  Slices and tiles are carried as per-CTU indices (the reference restricts intra availability and the in-loop
+// filters at their edges: CodingStructure::getCURestricted, SampleAdaptiveOffset.cpp:741-830, AdaptiveLoopFilter.cpp:118-291,
+// LoopFilter.cpp:1078-1088), but there is ONE header per picture: slices that differ in what it carries are refused, and so are sub-pictures.
 static inline int checkExpressible( const CodingStructure& cs, const Picture& pic, std::string& why )
 {
   const SPS& sps = *cs.sps; const PPS& pps = *cs.pps; const PicHeader& ph = *cs.picHeader;
@@ -110,9 +143,11 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
   if( sps.getUseWrapAround() || pps.getUseWrapAround() ) { why = "horizontal wrap-around motion compensation (Picture.cpp:404-518)"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getVirtualBoundariesPresentFlag() || ph.getVirtualBoundariesPresentFlag() ) { why = "virtual boundaries of the in-loop filters"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getUseColorTrans() ) { why = "adaptive colour transform"; return VVR_ERR_UNSUPPORTED; }
-  if( pic.slices.size() != 1 ) { why = "picture with more than one slice"; return VVR_ERR_UNSUPPORTED; }
-  if( pps.getNumTiles() > 1 ) { why = "picture with more than one tile"; return VVR_ERR_UNSUPPORTED; }
+  if( pic.slices.empty() ) { why = "picture without a slice"; return VVR_ERR_UNSUPPORTED; }
   if( pps.getNumSubPics() > 1 ) { why = "picture with sub-pictures"; return VVR_ERR_UNSUPPORTED; }
+  // several slices and tiles are expressible (vvr_picture.ctu_slice / ctu_tile) as long as the slices share their header
+  for( size_t k = 1; k < pic.slices.size(); k++ ) if( !sameSliceHeader( *pic.slices[0], *pic.slices[k] ) ) { why = "slices with different headers (slice type, reference lists, weights, filter or quantisation switches)"; return VVR_ERR_UNSUPPORTED; }
+  if( pic.slices.size() > 65535 || pps.getNumTiles() > 65535 ) { why = "more slices or tiles than a 16-bit index holds"; return VVR_ERR_UNSUPPORTED; }
   const Slice& slice = *pic.slices[0];
   if( !slice.isIntra() )
     for( int l = 0; l < 2; l++ ) for( int i = 0; i < slice.getNumRefIdx( RefPicList( l ) ); i++ )
@@ -390,6 +425,20 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   E.pic.lmcs = ( h.tool_flags & VVR_TOOL_LMCS ) ? &E.lmcs : nullptr;
   E.pic.wp = ( h.tool_flags & VVR_TOOL_WP ) ? &E.wp : nullptr;
   E.pic.scaling = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? &E.scaling : nullptr;
+  // ---- slices and tiles: index of every CTU (picture raster order)
+  E.ctuSlice.clear(); E.ctuTile.clear();
+  if( pic.slices.size() > 1 || pps.getNumTiles() > 1 )
+  {
+    E.ctuSlice.resize( numCtu ); E.ctuTile.resize( numCtu );
+    for( int a = 0; a < numCtu; a++ )
+    {
+      const CodingUnit* first = cs.getCtuData( a ).cuPtr[0][0];
+      E.ctuSlice[a] = first ? (uint16_t) first->slice->getIndependentSliceIdx() : 0;
+      E.ctuTile[a] = first ? (uint16_t) first->tileIdx : 0;
+    }
+    if( pic.slices.size() > 1 ) E.pic.ctu_slice = E.ctuSlice.data();
+    if( pps.getNumTiles() > 1 ) E.pic.ctu_tile = E.ctuTile.data();
+  }
   E.pic.resident = 0;
 }
 

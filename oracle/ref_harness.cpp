@@ -215,13 +215,24 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     pps.setPicWidthInLumaSamples( W );
     pps.setPicHeightInLumaSamples( Hh );
     pps.setLog2CtuSize( H.log2_ctu );
-    pps.setNumExpTileColumns( 1 );
-    pps.setNumExpTileRows( 1 );
-    pps.addTileColumnWidth( ( W + ctuSize - 1 ) / ctuSize );
-    pps.addTileRowHeight( ( Hh + ctuSize - 1 ) / ctuSize );
-    pps.initTiles();
-    pps.setLoopFilterAcrossTilesEnabledFlag( true );
-    pps.setLoopFilterAcrossSlicesEnabledFlag( true );
+    {
+      // tile grid as the description's CTU -> tile map says (uniform grids only differ in where the columns / rows are cut)
+      const int cX = ( W + ctuSize - 1 ) / ctuSize, cY = ( Hh + ctuSize - 1 ) / ctuSize;
+      std::vector<int> colW, rowH;
+      if( vp->ctu_tile )
+      {
+        int run = 1; for( int x = 1; x <= cX; x++ ) { if( x == cX || vp->ctu_tile[x] != vp->ctu_tile[x - 1] ) { colW.push_back( run ); run = 1; } else run++; }
+        run = 1; for( int y = 1; y <= cY; y++ ) { if( y == cY || vp->ctu_tile[(size_t) y * cX] != vp->ctu_tile[(size_t) ( y - 1 ) * cX] ) { rowH.push_back( run ); run = 1; } else run++; }
+      }
+      else { colW.push_back( cX ); rowH.push_back( cY ); }
+      pps.setNumExpTileColumns( (uint32_t) colW.size() );
+      pps.setNumExpTileRows( (uint32_t) rowH.size() );
+      for( int w : colW ) pps.addTileColumnWidth( w );
+      for( int h : rowH ) pps.addTileRowHeight( h );
+      pps.initTiles();
+    }
+    pps.setLoopFilterAcrossTilesEnabledFlag( !( H.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) );
+    pps.setLoopFilterAcrossSlicesEnabledFlag( !( H.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) );
     pps.setNumSubPics( 1 );
     pps.setUseWP( ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 1 );        // pps_weighted_pred_flag (P slices)
     pps.setWPBiPred( ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 0 );     // pps_weighted_bipred_flag (B slices)
@@ -358,7 +369,15 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     CodingStructure& cs = *pic.cs;
     TR("finalInit done\n");
 
+    // one Slice object per slice of the description, all with the same header (that is what a vvr_picture can express); `slice` is the first
+    int numSlices = 1;
+    const int numCtuAll = ( ( W + ctuSize - 1 ) / ctuSize ) * ( ( Hh + ctuSize - 1 ) / ctuSize );
+    if( vp->ctu_slice ) for( int a = 0; a < numCtuAll; a++ ) numSlices = std::max( numSlices, vp->ctu_slice[a] + 1 );
+    std::vector<Slice*> slices;
+    for( int si = 0; si < numSlices; si++ )
+    {
     Slice* slice = pic.allocateNewSlice();
+    slices.push_back( slice );
     slice->setPicHeader( ph.get() );
     slice->setSliceType( SliceType( H.slice_type ) );
     slice->setPOC( H.poc );
@@ -376,9 +395,10 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     slice->setSaoEnabledFlag( CHANNEL_TYPE_CHROMA, !!( H.tool_flags & VVR_TOOL_SAO_CHROMA ) );
     slice->setLmcsEnabledFlag( !!( H.tool_flags & VVR_TOOL_LMCS ) );
     slice->setExplicitScalingListUsed( ( H.tool_flags & VVR_TOOL_SCALING_LIST ) && vp->scaling );
-    slice->setIndependentSliceIdx( 0 );
+    slice->setIndependentSliceIdx( si );
     slice->resetSliceMap();
-    slice->addCtusToSlice( 0, pps.pcv->widthInCtus, 0, pps.pcv->heightInCtus, pps.pcv->widthInCtus );
+    if( !vp->ctu_slice ) slice->addCtusToSlice( 0, pps.pcv->widthInCtus, 0, pps.pcv->heightInCtus, pps.pcv->widthInCtus );
+    else for( int a = 0; a < numCtuAll; a++ ) if( vp->ctu_slice[a] == si ) { const int cx = a % (int) pps.pcv->widthInCtus, cy = a / (int) pps.pcv->widthInCtus; slice->addCtusToSlice( cx, cx + 1, cy, cy + 1, pps.pcv->widthInCtus ); }
     for( int l = 0; l < 2; l++ )
     {
       slice->setNumRefIdx( RefPicList( l ), H.slice_type == 2 ? 0 : H.num_ref[l] );
@@ -416,6 +436,10 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       slice->setCcAlfCbEnabledFlag( cc ); slice->setCcAlfCrEnabledFlag( cc ); slice->setCcAlfCbApsId( 0 ); slice->setCcAlfCrApsId( 0 );
       AdaptiveLoopFilter::reconstructCoeffAPSs( *slice );
     }
+    }   // slices
+    Slice* slice = slices[0];
+    auto sliceOfCtu = [&]( int a ) { return vp->ctu_slice ? slices[vp->ctu_slice[a]] : slices[0]; };
+    auto tileOfCtu  = [&]( int a ) { return vp->ctu_tile ? (int) vp->ctu_tile[a] : 0; };
 
     TR("slice done\n");
     // ------------------------------------------------------------------ CTU data, CUs, TUs
@@ -431,7 +455,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     for( int a = 0; a < numCtu; a++ )
     {
       CtuData& cd = cs.getCtuData( a );
-      cd.slice = slice; cd.pps = &pps; cd.sps = &sps; cd.ph = ph.get();
+      cd.slice = sliceOfCtu( a ); cd.pps = &pps; cd.sps = &sps; cd.ph = ph.get();
       cd.motion     = &miStore[(size_t) pcv.num4x4CtuBlks * a];
       cd.lfParam[0] = &lfpStore[(size_t) pcv.num4x4CtuBlks * ( 2 * a + 0 )];
       cd.lfParam[1] = &lfpStore[(size_t) pcv.num4x4CtuBlks * ( 2 * a + 1 )];
@@ -498,11 +522,13 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       if( c.tree == VVR_TREE_CHROMA ) { ua.blocks[0] = CompArea(); tt = TREE_C; chType = CHANNEL_TYPE_CHROMA; }
       if( cf == CHROMA_400 ) ua.blocks.resize( 1 );
       const Position p0 = ua.blocks[chType].pos();
-      const CodingUnit* cuL = cs.getCURestricted( p0.offset( -1, 0 ), p0, 0, 0, chType );
-      const CodingUnit* cuA = cs.getCURestricted( p0.offset( 0, -1 ), p0, 0, 0, chType );
+      const int ctuOfCu = ( c.y >> H.log2_ctu ) * (int) pcv.widthInCtus + ( c.x >> H.log2_ctu );
+      Slice* cuSlice = sliceOfCtu( ctuOfCu );
+      const CodingUnit* cuL = cs.getCURestricted( p0.offset( -1, 0 ), p0, cuSlice->getIndependentSliceIdx(), tileOfCtu( ctuOfCu ), chType );
+      const CodingUnit* cuA = cs.getCURestricted( p0.offset( 0, -1 ), p0, cuSlice->getIndependentSliceIdx(), tileOfCtu( ctuOfCu ), chType );
       CodingUnit& cu = cs.addCU( ua, chType, tt, MODE_TYPE_ALL, cuL, cuA );
       cuPtrs[i] = &cu;
-      cu.slice = slice; cu.pps = &pps; cu.sps = &sps; cu.tileIdx = 0;
+      cu.slice = cuSlice; cu.pps = &pps; cu.sps = &sps; cu.tileIdx = tileOfCtu( ctuOfCu );
       cu.qp = c.qp; cu.chromaQpAdj = 0;
       cu.setPredMode( c.pred_mode == VVR_PRED_INTRA ? MODE_INTRA : c.pred_mode == VVR_PRED_IBC ? MODE_IBC : MODE_INTER );
       cu.setRootCbf( !!( c.flags & VVR_CU_ROOT_CBF ) );
@@ -618,11 +644,11 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       case 1: sps.setLadfEnabled( true ); sps.setLadfNumIntervals( 6 ); break;                             // (more LADF intervals than the header holds)
       case 2: sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); break;
       case 3: ph->setVirtualBoundariesPresentFlag( true ); break;
-      case 4: { Slice* s2 = pic.allocateNewSlice(); s2->setPicHeader( ph.get() ); s2->setSliceType( SliceType( H.slice_type ) ); s2->setPOC( H.poc ); } break;
+      case 4: { Slice* s2 = pic.allocateNewSlice(); s2->setPicHeader( ph.get() ); s2->setSliceType( SliceType( H.slice_type ) ); s2->setPOC( H.poc ); s2->setDepQuantEnabledFlag( !slice->getDepQuantEnabledFlag() ); } break;     // (a second slice with another header)
       case 5: pps.setNumSubPics( 2 ); break;
       case 6: sps.setUseColorTrans( true ); break;
       case 7: sps.setBitDepth( 12 ); break;
-      case 8: pps.setNumTileColumns( 2 ); break;                                                           // (a second tile column)
+      case 8: pps.setNumTileColumns( 70000 ); break;                                                       // (more tiles than an index holds)
       case 9: pps.setPicWidthInLumaSamples( W / 2 ); break;                                              // (the references keep their size: Picture::isRefScaled)
       default: break;
       }

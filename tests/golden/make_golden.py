@@ -59,6 +59,9 @@ CASES = [
     ("i_256x128_ctu64_ibc_lmcs", 256, 128, 6, 0, 47, ALL | abi.TOOL_IBC | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_ibc=0.5, p_split_scale=1.4, p_cclm=0.3, p_jccr=0.3, p_coded_chroma=0.5)),
     ("b_264x200_ctu128_ibc_small_cus", 264, 200, 7, 3, 48, ALL | abi.TOOL_IBC | abi.TOOL_BDOF | abi.TOOL_DMVR, dict(p_ibc=0.6, p_intra=0.4, min_cu_log2=2, p_split_scale=1.6, p_ciip=0.1)),
     ("b_256x128_ctu64_8bit", 256, 128, 6, 2, 49, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(bit_depth=8, p_intra=0.25, p_affine=0.15, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.1, p_mip=0.2, p_isp=0.2, p_cclm=0.3, p_jccr=0.2, p_coded_chroma=0.5)),
+    ("i_384x256_ctu64_slices", 384, 256, 6, 0, 51, ALL | abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=3, p_cclm=0.3, p_mip=0.2)),
+    ("b_384x256_ctu64_tiles_slices", 384, 256, 6, 2, 52, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES,
+     dict(num_slices=3, tile_cols=2, tile_rows=2, p_intra=0.3, p_cclm=0.3, p_ciip=0.1, p_affine=0.1, p_coded_chroma=0.5)),
     ("b_256x128_ctu64_ladf", 256, 128, 6, 2, 50, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LADF, dict(p_intra=0.3, p_affine=0.1, p_coded=0.5)),
     ("b_256x192_ctu128_all_inter", 256, 192, 7, 2, 26, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.1, p_affine=0.2, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.2)),
 ]

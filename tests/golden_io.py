@@ -34,6 +34,10 @@ def save(path, desc, refs, outputs):
         d["wp"] = _bytes_of(desc.wp)
     if desc.scaling is not None:
         d["scaling"] = _bytes_of(desc.scaling)
+    if desc.ctu_slice is not None:
+        d["ctu_slice"] = np.asarray(desc.ctu_slice, np.uint16)
+    if desc.ctu_tile is not None:
+        d["ctu_tile"] = np.asarray(desc.ctu_tile, np.uint16)
     for slot, planes in refs.items():
         for c, p in enumerate(planes):
             d["ref_%d_%d" % (slot, c)] = np.asarray(p, np.uint16)
@@ -72,6 +76,10 @@ def load(path):
         d.wp = abi.WpParams.from_buffer_copy(z["wp"].tobytes())
     if "scaling" in z:
         d.scaling = abi.ScalingList.from_buffer_copy(z["scaling"].tobytes())
+    if "ctu_slice" in z:
+        d.ctu_slice = z["ctu_slice"].astype(np.uint16)
+    if "ctu_tile" in z:
+        d.ctu_tile = z["ctu_tile"].astype(np.uint16)
     refs, outs = {}, {}
     for k in z.files:
         if k.startswith("ref_"):

@@ -349,6 +349,21 @@ def test_luma_adaptive_deblocking(built):
     _run_stream(1920, 1080, 3, 2, 213, TOOLS_A | abi.TOOL_LADF, intra=True, streams=3)
 
 
+@pytest.mark.parametrize("extra,kw", [
+    (abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=3)),
+    (0, dict(num_slices=3, tile_cols=2, tile_rows=2)),
+    (abi.TOOL_NO_LF_ACROSS_TILES, dict(tile_cols=3, tile_rows=2)),
+    (abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=3, tile_cols=2, tile_rows=2)),
+])
+def test_slices_and_tiles(built, extra, kw):
+    """several slices / tiles per picture: availability of intra references, CCLM templates and the chroma-scaling neighbourhood ends at their
+    boundaries (host glue), SAO and ALF stop there when the loop filters may not cross them (k_sao, k_alf_*)"""
+    T = TOOLS_A | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | extra
+    _run_stream(512, 384, 5, 4, 221, T, intra=True, log2_ctu=6, p_intra=0.3, p_cclm=0.3, p_ciip=0.1, p_coded_chroma=0.5, **kw)
+    _run_stream(640, 256, 3, 2, 222, T, intra=True, log2_ctu=5, p_intra=0.2, p_affine=0.2, **kw)
+    _run_stream(1920, 1080, 3, 2, 223, TOOLS_A | extra, intra=True, streams=3, **kw)
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

@@ -254,3 +254,42 @@ def test_oracle_equals_reference_ladf(built, W, H, l2, idx, seed, bd, kw):
     final = want
     d.hdr.ladf_num_intervals = 0
     assert not np.array_equal(refdrv.oracle_reconstruct(d, refs, flags=0)[0], final[0])
+
+
+SLICE_TILE_CASES = [
+    # W, H, l2, idx, seed, extra tool flags, generator parameters
+    (512, 384, 6, 0, 261, abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=3, p_cclm=0.3, p_mip=0.2)),
+    (512, 384, 6, 0, 262, 0, dict(num_slices=3, p_cclm=0.3)),                                                    # slices, loop filters cross them
+    (512, 384, 6, 2, 263, abi.TOOL_NO_LF_ACROSS_TILES, dict(tile_cols=2, tile_rows=2, p_intra=0.3, p_ciip=0.2, p_cclm=0.3)),
+    (512, 384, 6, 2, 264, abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=3, tile_cols=2, tile_rows=2, p_intra=0.3, p_affine=0.2)),
+    (512, 384, 6, 3, 265, abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=3, tile_cols=2, tile_rows=2, p_intra=0.2)),   # raster slices over tiles: the ALF corner padding
+    (640, 256, 5, 0, 266, abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(num_slices=4, tile_cols=3, tile_rows=2, p_cclm=0.4, p_coded_chroma=0.6)),
+    (384, 256, 7, 2, 267, abi.TOOL_NO_LF_ACROSS_TILES | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(tile_cols=3, tile_rows=1, p_intra=0.3, p_coded_chroma=0.6, p_cclm=0.3)),
+    (512, 384, 6, 0, 268, abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=2, tile_cols=2, tile_rows=2, dual_tree=1.0, p_cclm=0.4)),
+]
+
+
+@pytest.mark.parametrize("W,H,l2,idx,seed,extra,kw", SLICE_TILE_CASES)
+def test_oracle_equals_reference_slices_and_tiles(built, W, H, l2, idx, seed, extra, kw):
+    """pictures of several slices and tiles: no intra / CCLM / chroma-scaling neighbourhood across their boundaries (getCURestricted); SAO and ALF stop
+    there when the loop filters may not cross (SAO availability flags, ALF border padding incl. the raster-slice corners); deblocking edges switched
+    off by the host-derived table.  The reference runs with real Slice objects and a real tile grid (oracle/ref_harness.cpp)."""
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=ALL | extra, log2_ctu=l2, **kw)
+    assert (d.ctu_slice is not None) == (kw.get("num_slices", 1) > 1) and (d.ctu_tile is not None) == (kw.get("tile_cols", 1) * kw.get("tile_rows", 1) > 1)
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc))
+    for fl in STAGES:
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+    # the boundaries matter: the same records without the maps give another picture
+    final = want
+    d.ctu_slice = d.ctu_tile = None
+    d.hdr.tool_flags &= ~(abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES)
+    other = refdrv.oracle_reconstruct(d, refs, flags=0)
+    assert any(not np.array_equal(a, b) for a, b in zip(other, final))

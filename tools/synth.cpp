@@ -71,6 +71,9 @@ typedef struct vvs_params {
   float    dual_tree;           // > 0: I pictures use separate luma and chroma coding trees below 64x64 (qtbtt_dual_tree_intra_flag); 2: luma CUs down to 4x4; 3: and ISP on 4xN / Nx4 CUs (1xN, Nx1, 2xN, Nx2 partitions)
   float    p_ibc;               // with VVR_TOOL_IBC: of the CUs that would be intra (luma at most 64x64, not in a chroma tree): intra block copy,
                                 // where a block vector into the valid part of the IBC virtual buffer is found
+  uint8_t  num_slices;          // > 1: the picture is cut into that many slices (one tile: bands of CTU rows; several tiles: runs of tiles in raster order)
+  uint8_t  tile_cols, tile_rows;// > 1: uniform tile grid.  Whether the loop filters cross these boundaries is in tool_flags (VVR_TOOL_NO_LF_ACROSS_*)
+  uint8_t  pad_st;
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -86,6 +89,8 @@ typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
   vvr_lmcs_params* lmcs;          // filled when VVR_TOOL_LMCS is in tool_flags
   vvr_wp_params*   wp;            // filled when VVR_TOOL_WP is in tool_flags (P / B pictures)
   vvr_scaling_list* scaling;      // filled when VVR_TOOL_SCALING_LIST is in tool_flags
+  uint16_t*    ctu_slice;         // [num_ctu], filled when the parameters ask for more than one slice (else left alone)
+  uint16_t*    ctu_tile;          // [num_ctu], likewise for tiles
   // outputs
   uint32_t     num_cu, num_tu; uint64_t num_coef; uint32_t num_dmvr;
   vvr_pic_header hdr;
@@ -124,6 +129,45 @@ struct Gen {
   int modeType = 0;                // mode constraint of the current sub-tree (SCIPU): 0 all, 1 inter only, 2 intra only (local dual tree)
   bool cclmOk = true;              // CCLM allowed for the chroma CUs being added (CU::checkCCLMAllowed, UnitTools.cpp:3439)
   Gen( const vvs_params& p, vvs_buffers& b ) : P( p ), B( b ), rng( p.seed ) {}
+
+  // slices and tiles: index of every CTU; two positions see each other (intra availability, CIIP neighbours: CodingStructure::getCURestricted)
+  // only inside one slice and one tile; the loop filters additionally obey the pps_loop_filter_across_* flags
+  std::vector<uint16_t> sliceOfCtu, tileOfCtu;
+  int ctusX = 0, ctusY = 0;
+  int ctuOfPos( int x, int y ) const { return ( y >> P.log2_ctu ) * ctusX + ( x >> P.log2_ctu ); }
+  bool sameSliceTile( int a, int b ) const { return sliceOfCtu[a] == sliceOfCtu[b] && tileOfCtu[a] == tileOfCtu[b]; }
+  bool lfMayCross( int a, int b ) const
+  {
+    if( ( P.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && sliceOfCtu[a] != sliceOfCtu[b] ) return false;
+    if( ( P.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) && tileOfCtu[a] != tileOfCtu[b] ) return false;
+    return true;
+  }
+  void layoutSlicesAndTiles()
+  {
+    ctusX = ( W + ctu - 1 ) / ctu; ctusY = ( H + ctu - 1 ) / ctu;
+    const int n = ctusX * ctusY;
+    sliceOfCtu.assign( n, 0 ); tileOfCtu.assign( n, 0 );
+    const int tc = std::max<int>( 1, std::min<int>( P.tile_cols, ctusX ) ), tr = std::max<int>( 1, std::min<int>( P.tile_rows, ctusY ) );
+    for( int cy = 0; cy < ctusY; cy++ ) for( int cx = 0; cx < ctusX; cx++ ) tileOfCtu[cy * ctusX + cx] = (uint16_t) ( ( cy * tr / ctusY ) * tc + cx * tc / ctusX );
+    const int numTiles = tc * tr, ns = std::max<int>( 1, P.num_slices );
+    if( ns > 1 )
+    {
+      if( numTiles > 1 )
+      {
+        // raster-scan slices: runs of complete tiles
+        const int k = std::min( ns, numTiles );
+        for( int a = 0; a < n; a++ ) sliceOfCtu[a] = (uint16_t) ( tileOfCtu[a] * k / numTiles );
+      }
+      else
+      {
+        // one tile, rectangular slices: bands of complete CTU rows
+        const int k = std::min( ns, ctusY );
+        for( int a = 0; a < n; a++ ) sliceOfCtu[a] = (uint16_t) ( ( a / ctusX ) * k / ctusY );
+      }
+    }
+    if( B.ctu_slice && ns > 1 ) memcpy( B.ctu_slice, sliceOfCtu.data(), sizeof( uint16_t ) * n );
+    if( B.ctu_tile && numTiles > 1 ) memcpy( B.ctu_tile, tileOfCtu.data(), sizeof( uint16_t ) * n );
+  }
 
   // intra block copy: what the IBC virtual buffer of every CTU row holds (CodingStructure::fillIBCbuffer, CodingStructure.cpp:550): per
   // 4x4 cell of the buffer the picture column (in 4-sample units) of the samples stored there, -1 = nothing valid; luma and chroma
@@ -420,7 +464,7 @@ struct Gen {
         cu.imv = 0; cu.bcw_idx = 2;
         cu.intra_dir[0] = cu.intra_dir[1] = 0;
         // neighbours the blend weights look at: the CU left of the bottom-left sample and the CU above the top-right sample
-        auto isIntraAt = [&]( int px, int py ) { if( px < 0 || py < 0 ) return false; const int32_t k = cuOf4[( py >> 2 ) * w4 + ( px >> 2 )]; return k >= 0 && B.cu[k].pred_mode == VVR_PRED_INTRA; };
+        auto isIntraAt = [&]( int px, int py ) { if( px < 0 || py < 0 || !sameSliceTile( ctuOfPos( px, py ), ctuOfPos( x, y ) ) ) return false; const int32_t k = cuOf4[( py >> 2 ) * w4 + ( px >> 2 )]; return k >= 0 && B.cu[k].pred_mode == VVR_PRED_INTRA; };
         cu.ciip_neigh_intra = (uint8_t) ( ( isIntraAt( x - 1, y + h - 1 ) ? 1 : 0 ) | ( isIntraAt( x + w - 1, y - 1 ) ? 2 : 0 ) );
       }
       const bool aff = ( cu.flags & VVR_CU_AFFINE ) != 0;
@@ -734,6 +778,7 @@ struct Gen {
           L.qp[2] = (int8_t) ( ( TQ.qp[2] + TP.qp[2] - 2 * qpBd + 1 ) >> 1 );
         }
         L.bs = (uint8_t) ( bsY | ( bsC << 2 ) | ( bsC << 4 ) );
+        if( !lfMayCross( ctuOfPos( x4 << 2, y4 << 2 ), ctuOfPos( px4 << 2, py4 << 2 ) ) ) { L.bs = 0; L.flags &= (uint8_t) ~3; }
       }
     }
   }
@@ -822,6 +867,8 @@ struct Gen {
           }
         }
         L.bs = (uint8_t) ( bsY | ( bsCb << 2 ) | ( bsCr << 4 ) );
+        // an edge on a slice / tile boundary the loop filters must not cross is not filtered (m_stLFCUParam.leftEdge / topEdge, LoopFilter.cpp:1078,1088)
+        if( !lfMayCross( ctuOfPos( x4 << 2, y4 << 2 ), ctuOfPos( px4 << 2, py4 << 2 ) ) ) { L.bs = 0; L.flags &= (uint8_t) ~3; }
         L.qp[0] = (int8_t) ( ( CQ.qp + CP.qp + 1 ) >> 1 );
         L.qp[1] = (int8_t) ( ( TQc.qp[1] + TPc.qp[1] - 2 * qpBd + 1 ) >> 1 );
         L.qp[2] = (int8_t) ( ( TQc.qp[2] + TPc.qp[2] - 2 * qpBd + 1 ) >> 1 );
@@ -955,6 +1002,7 @@ struct Gen {
   int run()
   {
     W = P.width; H = P.height; w4 = ( W + 3 ) >> 2; h4 = ( H + 3 ) >> 2; ctu = 1 << P.log2_ctu; bd = P.bit_depth;
+    layoutSlicesAndTiles();
     cuOf4.assign( (size_t) w4 * h4, -1 ); tuOf4.assign( (size_t) w4 * h4, -1 );
     B.num_cu = B.num_tu = 0; B.num_coef = 0; B.num_dmvr = 0;
     for( size_t i = 0; i < (size_t) w4 * h4; i++ ) { memset( &B.motion[i], 0, sizeof( vvr_motion ) ); B.motion[i].ref_idx[0] = B.motion[i].ref_idx[1] = -1; }

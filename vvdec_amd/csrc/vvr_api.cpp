@@ -33,6 +33,7 @@ int vvr_upload_tables();
 #include <atomic>
 #include <chrono>
 static std::atomic<uint64_t> g_wdProgress{ 0 };
+static double g_wdEnqMs = 0, g_wdEnqMax = 0; static uint64_t g_wdEnqN = 0;      // time the committing thread spends enqueuing pictures
 #define WD_PROGRESS() g_wdProgress.fetch_add( 1 )
 #else
 #define WD_PROGRESS() do {} while( 0 )
@@ -310,7 +311,13 @@ static void commitReady( vvr_context* c )
       if( j->state == J_READY ) planCommitLocked( c, *j, plan );
     }
     int rc = VVR_OK; std::string err;
+#ifdef VVR_WATCHDOG
+    const auto wdT0 = std::chrono::steady_clock::now();
+#endif
     if( j->state == J_READY ) rc = enqueuePicture( c, *j, plan, err );
+#ifdef VVR_WATCHDOG
+    { const double ms = std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - wdT0 ).count(); g_wdEnqMs = g_wdEnqMs + ms; g_wdEnqMax = std::max( g_wdEnqMax, ms ); g_wdEnqN++; }
+#endif
     {
       std::lock_guard<std::mutex> lk( c->mu );
       if( j->state == J_READY )
@@ -610,6 +617,7 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( c->launcher.joinable() ) c->launcher.join();
 #ifdef VVR_WATCHDOG
   if( c->watchdog.joinable() ) c->watchdog.join();
+  if( g_wdEnqN ) fprintf( stderr, "[vvr] enqueue: %llu pictures, %.3f ms each on average, %.3f ms at most\n", (unsigned long long) g_wdEnqN, g_wdEnqMs / g_wdEnqN, g_wdEnqMax );
 #endif
   for( auto& kv : c->jobs ) { Job& j = *kv.second; for( auto& t : j.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); } if( j.done ) hipEventDestroy( j.done ); }
   for( auto e : c->eventPool ) hipEventDestroy( e );
