@@ -145,6 +145,12 @@ def _check_tables(d, units, items):
         uj, ui = int(unit_of[j]), int(unit_of[i])
         return (j < i) if uj == ui else bool((anc[ui] >> uj) & 1)
 
+    ctu4 = 1 << (l2 - 2)
+
+    def same_slice_tile(cy, cx, by, bx):
+        a, b = (cy // ctu4) * ctusX + cx // ctu4, (by // ctu4) * ctusX + bx // ctu4
+        return (d.ctu_slice is None or d.ctu_slice[a] == d.ctu_slice[b]) and (d.ctu_tile is None or d.ctu_tile[a] == d.ctu_tile[b])
+
     def cell(comp, xc, yc):            # component sample -> cell of the 4x4 luma grid
         cs = 1 if comp else 0
         return (yc << cs) >> 2, (xc << cs) >> 2
@@ -185,6 +191,8 @@ def _check_tables(d, units, items):
             cy, cx = cell(k, xc, yc)
             if not must and order[1 if k else 0, cy, cx] >= myo:
                 continue                # not reconstructed before the block: not available, not read
+            if not must and not same_slice_tile(cy, cx, *cell(comp, x0, y0)):
+                continue                # in another slice or tile: not available, not read
             if must and k == comp:
                 assert order[1 if k else 0, cy, cx] < myo, "IBC reference block is not reconstructed before the block"
             j = int(prod[k, cy, cx])

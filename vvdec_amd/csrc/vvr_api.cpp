@@ -590,7 +590,10 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   if( ok )
   {
     // upload ring: one entry per picture that can be between "being prepared" and "reconstructed"
-    c->ring.resize( (size_t) ns + cfg->host_threads + 2 );
+    // (a picture holds its entry from the moment a worker starts packing it until the device has finished it: the pictures in the workers' hands,
+    // those waiting for their turn to be committed, and those in flight on the device - the lanes and what is queued behind them.  An entry too few
+    // makes a worker wait for the device instead of preparing ahead.)
+    c->ring.resize( 2 * (size_t) ns + 2 * (size_t) cfg->host_threads + 4 );
     for( size_t i = 0; i < c->ring.size(); i++ ) { c->ring[i].turn = i; ok = ok && hipEventCreateWithFlags( &c->ring[i].copied, hipEventDisableTiming ) == hipSuccess; }
   }
   if( !ok ) { vvr_destroy( c ); return VVR_ERR_DEVICE; }
