@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--gop", type=int, default=16)
     ap.add_argument("--streams", type=int, default=8, help="pictures in flight per GPU")
     ap.add_argument("--host-threads", type=int, default=8, help="worker threads inside the library that prepare submitted pictures")
+    ap.add_argument("--ring", type=int, default=0, help="entries of the library's upload ring (0: its default)")
     ap.add_argument("--slots", type=int, default=24, help="DPB slots used round-robin")
     ap.add_argument("--intra-period", type=int, default=-1, help="an IRAP picture every N pictures (multiple of --gop); default: the configuration's")
     ap.add_argument("--irap-lookahead", type=int, default=8, help="IRAP pictures are submitted N pictures ahead of their decoding-order position (they depend on nothing)")
@@ -192,7 +193,7 @@ def main():
     plans, nslots, first = stream_plan(a.config, a.gop, intra_period, a.irap_lookahead, a.slots, K, Wm)
     n_irap = sum(1 for pl in plans[first:first + K] if pl.slice_type == abi.SLICE_I)
     seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
-    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads)
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads, ring_entries=a.ring)
     # the records are written where a parser integrated with the back-end would write them: host memory the device reads directly (vvr_host_alloc)
     descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, alloc=None if a.pageable_records else rec.host_array, **mix) for pl in plans]
     cpics = [d.c() for d in descs]                     # the host records as the C ABI sees them (plain structs pointing at the arrays)

@@ -342,7 +342,8 @@ typedef struct vvr_config {
   uint8_t  stop_after;           /* conformance aid (the reference has per-stage CRC traces for the same purpose, LoopFilter.cpp:399-406): 0 =
                                     full reconstruction; VVR_STOP_RECO / _DEBLOCK / _SAO: the pictures of this context stop after that stage, so
                                     that they can be compared with the reference's picture at the same point                                  */
-  uint8_t  pad;
+  uint8_t  ring_entries;         /* entries of the upload ring (pinned staging + HBM image of one picture each); 0: 2 * num_streams +
+                                    2 * host_threads + 4, enough for the pictures in the workers' hands plus those in flight on the device   */
   void*    ext_planes;           /* optional: caller-owned device memory for the DPB, num_slots * vvr_slot_bytes */
                                  /* (mirrors vvdec_decoder_open_with_allocator, vvdec.h.in:576)                 */
 } vvr_config;

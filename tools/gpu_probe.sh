@@ -1,9 +1,6 @@
 #!/bin/bash
-# developer helper: experiments of one gpurun call
 out=gpurun_out/${1:-probe}; mkdir -p $out
 export TMPDIR=/tmp
-echo "== pytest (new tests)"; timeout 400 python -m pytest tests -m gpu -q -k "slices or golden or ladf or luma_adaptive or declibrecon" > $out/pytest_new.log 2>&1; tail -4 $out/pytest_new.log
-echo "== H2D"; timeout 100 python tools/h2d_probe.py 2>&1 | tee $out/h2d.txt
 run() { name=$1; shift; timeout 240 "$@" > $out/$name.json 2> $out/$name.err; grep "vvr\]" $out/$name.err; python - $out/$name.json <<'PY'
 import json,sys
 try:
@@ -11,7 +8,7 @@ try:
 except Exception as e: print(sys.argv[1],'ERR',e)
 PY
 }
-VVDEC_AMD_LIB=$GRAFT_REPO_ROOT/vvdec_amd/libvvdec_amd_wd.so run ra_wd python bench.py --no-cpu-baseline --verify 0
-VVDEC_AMD_LIB=$GRAFT_REPO_ROOT/vvdec_amd/libvvdec_amd_wd.so run ra_wd_pageable python bench.py --no-cpu-baseline --verify 0 --pageable-records
-run ra_ht12 python bench.py --no-cpu-baseline --verify 0 --host-threads 12
-run ra_s6 python bench.py --no-cpu-baseline --verify 0 --streams 6
+for r in 12 18 24 36 64; do run ra_ring$r python bench.py --no-cpu-baseline --verify 0 --ring $r; done
+run ra_ring36_ht12 python bench.py --no-cpu-baseline --verify 0 --ring 36 --host-threads 12
+run ra_ring24_ht4 python bench.py --no-cpu-baseline --verify 0 --ring 24 --host-threads 4
+timeout 300 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log

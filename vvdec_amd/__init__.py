@@ -90,13 +90,13 @@ EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "v
 
 
 class Reconstructor:
-    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, num_slots=8, num_streams=2, device=0, ext_planes=None, host_threads=0, stop_after=0):
+    def __init__(self, width, height, bit_depth=10, log2_ctu=7, chroma_format=1, num_slots=8, num_streams=2, device=0, ext_planes=None, host_threads=0, stop_after=0, ring_entries=0):
         self.L = lib()
         cfg = abi.Config()
         cfg.abi_version = abi.VVR_ABI_VERSION
         cfg.device, cfg.max_width, cfg.max_height = device, width, height
         cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = chroma_format, bit_depth, log2_ctu
-        cfg.num_slots, cfg.num_streams, cfg.host_threads, cfg.stop_after = num_slots, num_streams, host_threads, stop_after
+        cfg.num_slots, cfg.num_streams, cfg.host_threads, cfg.stop_after, cfg.ring_entries = num_slots, num_streams, host_threads, stop_after, ring_entries
         cfg.ext_planes = ext_planes
         self.cfg = cfg
         self.ctx = C.c_void_p()

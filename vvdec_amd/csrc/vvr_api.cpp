@@ -35,8 +35,12 @@ int vvr_upload_tables();
 static std::atomic<uint64_t> g_wdProgress{ 0 };
 static double g_wdEnqMs = 0, g_wdEnqMax = 0; static uint64_t g_wdEnqN = 0;      // time the committing thread spends enqueuing pictures
 #define WD_PROGRESS() g_wdProgress.fetch_add( 1 )
+static double wdNow() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
+#define WD_STAMP( job, field ) ( job ).field = wdNow()
+static double g_wdSum[6]; static uint64_t g_wdJobs;
 #else
 #define WD_PROGRESS() do {} while( 0 )
+#define WD_STAMP( job, field ) do {} while( 0 )
 #endif
 
 struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
@@ -72,6 +76,9 @@ struct Job {
   bool completed = false, waited = false;
   std::vector<PendingTiming> timings;
   std::vector<int32_t> dmvr;        // delta MVs, copied out of pinned memory when the job completes
+#ifdef VVR_WATCHDOG
+  double tSubmit = 0, tPrep = 0, tBuilt = 0, tRing = 0, tReady = 0, tCommit0 = 0, tCommit1 = 0;      // developer build: where a picture spends its time on the host
+#endif
 };
 
 struct vvr_context {
@@ -313,10 +320,12 @@ static void commitReady( vvr_context* c )
     int rc = VVR_OK; std::string err;
 #ifdef VVR_WATCHDOG
     const auto wdT0 = std::chrono::steady_clock::now();
+    WD_STAMP( *j, tCommit0 );
 #endif
     if( j->state == J_READY ) rc = enqueuePicture( c, *j, plan, err );
 #ifdef VVR_WATCHDOG
-    { const double ms = std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - wdT0 ).count(); g_wdEnqMs = g_wdEnqMs + ms; g_wdEnqMax = std::max( g_wdEnqMax, ms ); g_wdEnqN++; }
+    { const double ms = std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - wdT0 ).count(); g_wdEnqMs = g_wdEnqMs + ms; g_wdEnqMax = std::max( g_wdEnqMax, ms ); g_wdEnqN++; WD_STAMP( *j, tCommit1 );
+      if( j->ring ) { g_wdSum[0] += j->tPrep - j->tSubmit; g_wdSum[1] += j->tBuilt - j->tPrep; g_wdSum[2] += j->tRing - j->tBuilt; g_wdSum[3] += j->tReady - j->tRing; g_wdSum[4] += j->tCommit0 - j->tReady; g_wdSum[5] += j->tCommit1 - j->tCommit0; g_wdJobs++; } }
 #endif
     {
       std::lock_guard<std::mutex> lk( c->mu );
@@ -369,7 +378,9 @@ static void launcherMain( vvr_context* c )
 static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
 {
   size_t total = 0; std::string err;
+  WD_STAMP( job, tPrep );
   int rc = vvr_host_build( &job.pic, S, &total, err, &c->pinned );
+  WD_STAMP( job, tBuilt );
   RingEntry& e = c->ring[job.ringSeq % c->ring.size()];
   {
     // The ring entry is ours when it is this job's turn: the streaming job ring.size() places ahead of us has used it and its picture is
@@ -396,6 +407,7 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
     }
     e.owner = &job; job.ring = &e;
   }
+  WD_STAMP( job, tRing );
   if( rc == VVR_OK )
   {
     // Buffers only ever grow, and an entry that has to grow takes the size of the largest picture seen so far (an intra picture needs several
@@ -432,6 +444,7 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
   }
   {
     std::lock_guard<std::mutex> lk( c->mu );
+    WD_STAMP( job, tReady );
     if( rc == VVR_OK ) { job.q = &e.q; job.ring = &e; job.state = J_READY; }
     else { job.rc = rc; job.err = err; job.state = J_FAILED; }
     c->cv.notify_all();                                 // (the launcher, if there is one)
@@ -593,8 +606,23 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
     // (a picture holds its entry from the moment a worker starts packing it until the device has finished it: the pictures in the workers' hands,
     // those waiting for their turn to be committed, and those in flight on the device - the lanes and what is queued behind them.  An entry too few
     // makes a worker wait for the device instead of preparing ahead.)
-    c->ring.resize( 2 * (size_t) ns + 2 * (size_t) cfg->host_threads + 4 );
-    for( size_t i = 0; i < c->ring.size(); i++ ) { c->ring[i].turn = i; ok = ok && hipEventCreateWithFlags( &c->ring[i].copied, hipEventDisableTiming ) == hipSuccess; }
+    c->ring.resize( cfg->ring_entries ? std::max<size_t>( cfg->ring_entries, 2 ) : 2 * (size_t) ns + 2 * (size_t) cfg->host_threads + 4 );
+    // Every entry starts with room for an ordinary picture of this size (the two edge-parameter tables, CU / TU records and levels of a
+    // moderately split picture, the work lists): allocating pinned and device memory takes milliseconds and must not happen while a stream runs.
+    // Larger pictures (an intra picture with small CUs) make the entries grow, see prepareJob.
+    const size_t w4 = ( cfg->max_width + 3 ) >> 2, h4 = ( cfg->max_height + 3 ) >> 2;
+    const size_t estimate = alignUp( w4 * h4 * ( 2 * sizeof( vvr_lfp ) + 14 ) + ( 1u << 20 ), 1 << 16 );
+    const size_t dmvrInts = 2 * ( (size_t) cfg->max_width * cfg->max_height / 128 + 1 );
+    c->ringLargest = estimate;
+    for( size_t i = 0; i < c->ring.size() && ok; i++ )
+    {
+      RingEntry& e = c->ring[i];
+      e.turn = i;
+      ok = hipEventCreateWithFlags( &e.copied, hipEventDisableTiming ) == hipSuccess
+        && hipHostMalloc( (void**) &e.host, estimate, hipHostMallocDefault ) == hipSuccess && hipMalloc( (void**) &e.dev, estimate ) == hipSuccess
+        && hipHostMalloc( (void**) &e.dmvrHost, sizeof( int32_t ) * dmvrInts, hipHostMallocDefault ) == hipSuccess;
+      if( ok ) { e.hostCap = e.devCap = estimate; e.dmvrCap = dmvrInts; }
+    }
   }
   if( !ok ) { vvr_destroy( c ); return VVR_ERR_DEVICE; }
   c->slotUsers.resize( cfg->num_slots );
@@ -620,6 +648,8 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( c->launcher.joinable() ) c->launcher.join();
 #ifdef VVR_WATCHDOG
   if( c->watchdog.joinable() ) c->watchdog.join();
+  if( g_wdJobs ) fprintf( stderr, "[vvr] per streamed picture (ms): queued %.2f, work lists %.2f, wait for ring entry %.2f, pack %.2f, wait for commit %.2f, enqueue %.2f (%llu pictures)\n",
+                          g_wdSum[0] / g_wdJobs, g_wdSum[1] / g_wdJobs, g_wdSum[2] / g_wdJobs, g_wdSum[3] / g_wdJobs, g_wdSum[4] / g_wdJobs, g_wdSum[5] / g_wdJobs, (unsigned long long) g_wdJobs );
   if( g_wdEnqN ) fprintf( stderr, "[vvr] enqueue: %llu pictures, %.3f ms each on average, %.3f ms at most\n", (unsigned long long) g_wdEnqN, g_wdEnqMs / g_wdEnqN, g_wdEnqMax );
 #endif
   for( auto& kv : c->jobs ) { Job& j = *kv.second; for( auto& t : j.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); } if( j.done ) hipEventDestroy( j.done ); }
@@ -700,6 +730,7 @@ VVR_API int vvr_submit( vvr_context* c, const vvr_picture* p )
     if( !c->workers.empty() ) c->cv.wait( lk, [&]{ return c->queue.size() < 2 * c->workers.size(); } );       // back-pressure
     job = newJobLocked( c );
     job->pic = *p; job->ringSeq = c->nextRingSeq++;
+    WD_STAMP( *job, tSubmit );
     if( !c->workers.empty() ) { c->queue.push_back( job ); c->cv.notify_all(); return job->id; }
     job->state = J_PREPARING;
   }

@@ -506,18 +506,19 @@ struct DmvrShared {
   BdofShared bs;
 };
 
+// quotient of the parametric error-surface minimum, in 1/16 sample: N / ( 2 * D ) truncated to three bits, sign restored (the result lies in
+// -7 .. 7; xSubPelErrorSrfc, InterPrediction.cpp:1647-1700): three steps of a restoring division against 8 D, 4 D, 2 D
 __device__ __forceinline__ int dmvr_div_for_maxq7( long long N, long long D )
 {
-  int sign = 0, q = 0;
-  if( N < 0 ) { sign = 1; N = -N; }
-  D = D << 3;
-  if( N >= D ) { N -= D; q++; }
-  q = q << 1;
-  D = D >> 1;
-  if( N >= D ) { N -= D; q++; }
-  q = q << 1;
-  if( N >= ( D >> 1 ) ) q++;
-  return sign ? -q : q;
+  const bool neg = N < 0;
+  if( neg ) N = -N;
+  int q = 0;
+  for( int b = 3; b >= 1; b-- )
+  {
+    q <<= 1;
+    if( N >= ( D << b ) ) { N -= D << b; q |= 1; }
+  }
+  return neg ? -q : q;
 }
 
 template<int NT>
@@ -1350,40 +1351,33 @@ __device__ bool use_strong( const pel_t* s, int o, int d, int beta, int tc, bool
   return d_strong < ( beta >> 3 );
 }
 
+// Long luma filter (VVC 8.8.3.6.7, the reference's xFilteringPandQCore, LoopFilter.cpp:129-196), table-driven: the filtered samples are a linear
+// interpolation between a "middle" value at the edge and a reference value at the far end of each side, limited to +-( tc * tcFactor ) / 2.
+//   middle  = weighted mean (weights sum to 16) of the samples next to the edge; the weights of a side depend on its own length and the other's
+//   coefficient of sample k of a side of n samples = round-down( ( 64 * ( 2 * ( n - k ) - 1 ) + n ) / ( 2 * n ) ): 59 50 41 32 23 14 5 / 58 45 32 19 6 / 53 32 11
+__constant__ uint8_t c_dbLongMidW[3][3][7] = {       // [own length 3 / 5 / 7][other side's length][sample]
+  { { 0, 0, 0, 0, 0, 0, 0 }, { 2, 2, 2, 2, 0, 0, 0 }, { 3, 3, 2, 0, 0, 0, 0 } },
+  { { 2, 2, 2, 2, 0, 0, 0 }, { 2, 2, 2, 1, 1, 0, 0 }, { 2, 2, 1, 1, 1, 1, 0 } },
+  { { 2, 1, 1, 1, 1, 1, 1 }, { 2, 2, 1, 1, 1, 1, 0 }, { 2, 1, 1, 1, 1, 1, 1 } } };
+__constant__ uint8_t c_dbLongTc[2][7] = { { 6, 4, 2, 0, 0, 0, 0 }, { 6, 5, 4, 3, 2, 1, 1 } };      // tc factor per sample: sides of 3, sides of 5 or 7
 __device__ void filter_long( pel_t* src, int step, int o, int nP, int nQ, int tc )
 {
-  const int c7[7] = { 59, 50, 41, 32, 23, 14, 5 }, c5[5] = { 58, 45, 32, 19, 6 }, c3[3] = { 53, 32, 11 };
-  const int tc7[7] = { 6, 5, 4, 3, 2, 1, 1 }, tc3[3] = { 6, 4, 2 };
-  for( int i = 0; i < 4; i++ )
+  const int iP = ( nP - 3 ) >> 1, iQ = ( nQ - 3 ) >> 1;
+  for( int line = 0; line < 4; line++ )
   {
-    pel_t* sP = src + step * i - o; pel_t* sQ = src + step * i;
-    const int refP = ( sP[-( nP - 1 ) * o] + sP[-nP * o] + 1 ) >> 1;
-    const int refQ = ( sQ[( nQ - 1 ) * o] + sQ[nQ * o] + 1 ) >> 1;
-    int refM;
-    if( nP == nQ )
+    pel_t* q0 = src + step * line; pel_t* p0 = q0 - o;       // sample k of the P side: p0[-k * o], of the Q side: q0[k * o]
+    int mid = 8;
+    for( int k = 0; k < 7; k++ ) mid += c_dbLongMidW[iP][iQ][k] * p0[-k * o] + c_dbLongMidW[iQ][iP][k] * q0[k * o];
+    mid >>= 4;
+    const int farP = ( p0[-( nP - 1 ) * o] + p0[-nP * o] + 1 ) >> 1, farQ = ( q0[( nQ - 1 ) * o] + q0[nQ * o] + 1 ) >> 1;
+    for( int side = 0; side < 2; side++ )
     {
-      if( nP == 5 ) refM = ( 2 * ( sP[0] + sQ[0] + sP[-o] + sQ[o] + sP[-2 * o] + sQ[2 * o] ) + sP[-3 * o] + sQ[3 * o] + sP[-4 * o] + sQ[4 * o] + 8 ) >> 4;
-      else          refM = ( 2 * ( sP[0] + sQ[0] ) + sP[-o] + sQ[o] + sP[-2 * o] + sQ[2 * o] + sP[-3 * o] + sQ[3 * o] + sP[-4 * o] + sQ[4 * o] + sP[-5 * o] + sQ[5 * o] + sP[-6 * o] + sQ[6 * o] + 8 ) >> 4;
-    }
-    else
-    {
-      pel_t *pt = sP, *qt = sQ; int oP = -o, oQ = o; int nnP = nP, nnQ = nQ;
-      if( nQ > nP ) { pel_t* t = pt; pt = qt; qt = t; oP = o; oQ = -o; nnQ = nP; nnP = nQ; }
-      if( nnP == 7 && nnQ == 5 ) refM = ( 2 * ( sP[0] + sQ[0] + sP[-o] + sQ[o] ) + sP[-2 * o] + sQ[2 * o] + sP[-3 * o] + sQ[3 * o] + sP[-4 * o] + sQ[4 * o] + sP[-5 * o] + sQ[5 * o] + 8 ) >> 4;
-      else if( nnP == 7 && nnQ == 3 ) refM = ( 2 * ( pt[0] + qt[0] ) + qt[0] + 2 * ( qt[oQ] + qt[2 * oQ] ) + pt[oP] + qt[oQ] + pt[2 * oP] + pt[3 * oP] + pt[4 * oP] + pt[5 * oP] + pt[6 * oP] + 8 ) >> 4;
-      else refM = ( sP[0] + sQ[0] + sP[-o] + sQ[o] + sP[-2 * o] + sQ[2 * o] + sP[-3 * o] + sQ[3 * o] + 4 ) >> 3;
-    }
-    for( int p = 0; p < nP; p++ )
-    {
-      const int cf = nP == 7 ? c7[p] : nP == 5 ? c5[p] : c3[p], tcf = nP == 3 ? tc3[p] : tc7[p];
-      const int v = sP[-o * p], cv = ( tc * tcf ) >> 1;
-      sP[-o * p] = (pel_t) clip3( v - cv, v + cv, ( refM * cf + refP * ( 64 - cf ) + 32 ) >> 6 );
-    }
-    for( int p = 0; p < nQ; p++ )
-    {
-      const int cf = nQ == 7 ? c7[p] : nQ == 5 ? c5[p] : c3[p], tcf = nQ == 3 ? tc3[p] : tc7[p];
-      const int v = sQ[o * p], cv = ( tc * tcf ) >> 1;
-      sQ[o * p] = (pel_t) clip3( v - cv, v + cv, ( refM * cf + refQ * ( 64 - cf ) + 32 ) >> 6 );
+      pel_t* s = side ? q0 : p0; const int d = side ? o : -o, n = side ? nQ : nP, far = side ? farQ : farP;
+      for( int k = 0; k < n; k++ )
+      {
+        const int cf = ( 64 * ( 2 * ( n - k ) - 1 ) + n ) / ( 2 * n ), lim = ( tc * c_dbLongTc[n > 3][k] ) >> 1, v = s[d * k];
+        s[d * k] = (pel_t) clip3( v - lim, v + lim, ( mid * cf + far * ( 64 - cf ) + 32 ) >> 6 );
+      }
     }
   }
 }
