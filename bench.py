@@ -144,6 +144,33 @@ def cpu_baseline(cfg_name, seed, gop, budget_s=20.0):
                       (n, W, H, cores, 1e3 * sum(times) / n, wall, ", reference classes with SIMD" if kind == "reference" else ", plain-C restatement")}
 
 
+def picture_sharding_pass(a, W, H, mix, tools, plans, nslots, first, K, Wm, rank, world, local_rank, backend):
+    """ONE stream over all ranks, a picture per rank at a time (vvdec_amd.parallel.PictureParallel); timed like the main pass: the K pictures of the
+    window between barriers, max over ranks.  Strong scaling: the work is the same whatever N is."""
+    import torch
+    import torch.distributed as dist
+    import vvdec_amd
+    from vvdec_amd import synth, parallel
+    dev = "cuda" if backend == "nccl" else "cpu"
+    dpb = vvdec_amd.Reconstructor.new_dpb_tensor(W, H, nslots, device=dev)
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads, ext_planes=dpb.data_ptr())
+    pp = parallel.PictureParallel(rec, dpb, plans, rank, world)
+    descs = [synth.picture_for_plan(pl, W, H, seed=1234, tool_flags=tools, alloc=rec.host_array, **mix) if pp.owners[i] == rank else None for i, pl in enumerate(plans)]
+    pp.run(descs, 0, first)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pp.run(descs, first, first + K)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    nb = sum(1 for i in range(first, first + K) if pp.need[i])
+    rec.close()
+    return {"fps": round(K / float(t.item()), 2), "scaling": "strong", "pictures": K, "broadcasts_in_window": nb,
+            "slot_MB": round(rec.slot_bytes() / 1e6, 1) if False else round(dpb.numel() / nslots / 1e6, 1),
+            "what": "one stream, pictures round-robin within their temporal layer, reference slots broadcast from their owner (RCCL); K pictures / max-over-ranks time"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +187,7 @@ def main():
     ap.add_argument("--intra-period", type=int, default=-1, help="an IRAP picture every N pictures (multiple of --gop); default: the configuration's")
     ap.add_argument("--irap-lookahead", type=int, default=8, help="IRAP pictures are submitted N pictures ahead of their decoding-order position (they depend on nothing)")
     ap.add_argument("--pageable-records", action="store_true", help="keep the host records in ordinary (pageable) memory: the library stages them through its pinned ring")
+    ap.add_argument("--no-picture-sharding", action="store_true", help="N > 1: skip the additional pass that shards ONE stream by picture over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=8, help="number of timed pictures re-checked against the CPU oracle after the run")
     a = ap.parse_args()
@@ -254,6 +282,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_dev = float(t.item())
 
+    # ---- N > 1: the same stream sharded by PICTURE over the ranks (BASELINE north_star / SURVEY 8(e): pictures round-robin within their temporal
+    # layer, reference pictures broadcast slot to slot over RCCL), next to the segment mode above.  Reported under config.picture_sharding; a
+    # failure there does not take the line away.
+    pic_mode = None
+    if world > 1 and a.config != "allintra" and not a.no_picture_sharding:
+        try:
+            pic_mode = picture_sharding_pass(a, W, H, mix, tools, plans, nslots, first, K, Wm, rank, world, local_rank, backend)
+        except Exception as e:            # noqa: BLE001 - the segment-mode line must survive
+            pic_mode = {"error": repr(e)[:300]}
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel: a further pass over the K timed pictures only, HIP-event timing on the launch streams
@@ -328,7 +366,7 @@ def main():
                           "irap_in_window": n_irap, "irap_share_of_stream": "1/%d" % intra_period if a.config != "allintra" else "1/1",
                           "tools": "intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM + ISP, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
                           "mix": mix,
-                          "pictures_in_flight": a.streams, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "sharding": "closed-GOP segment per GPU, no data-path collective",
+                          "picture_sharding": pic_mode, "pictures_in_flight": a.streams, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "sharding": "closed-GOP segment per GPU, no data-path collective",
                           "verified_timed_pictures_vs_oracle": verified, "timed_run_equals_serial_run": serial_equal},
                "roofline": roof}
         if not a.no_cpu_baseline:

@@ -8,7 +8,7 @@ try:
 except Exception as e: print(sys.argv[1],'ERR',e)
 PY
 }
-for r in 12 18 24 36 64; do run ra_ring$r python bench.py --no-cpu-baseline --verify 0 --ring $r; done
-run ra_ring36_ht12 python bench.py --no-cpu-baseline --verify 0 --ring 36 --host-threads 12
-run ra_ring24_ht4 python bench.py --no-cpu-baseline --verify 0 --ring 24 --host-threads 4
-timeout 300 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+export VVDEC_AMD_LIB=$GRAFT_REPO_ROOT/vvdec_amd/libvvdec_amd_wd.so
+run ra_wd python bench.py --no-cpu-baseline --verify 0
+
+

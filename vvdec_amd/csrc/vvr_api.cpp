@@ -37,7 +37,7 @@ static double g_wdEnqMs = 0, g_wdEnqMax = 0; static uint64_t g_wdEnqN = 0;      
 #define WD_PROGRESS() g_wdProgress.fetch_add( 1 )
 static double wdNow() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
 #define WD_STAMP( job, field ) ( job ).field = wdNow()
-static double g_wdSum[6]; static uint64_t g_wdJobs;
+static double g_wdSum[6]; static uint64_t g_wdJobs; static double g_wdPart[4], g_wdPartMax[4]; static uint64_t g_wdPartN; static double g_wdCall[K_NUM][3];
 #else
 #define WD_PROGRESS() do {} while( 0 )
 #define WD_STAMP( job, field ) do {} while( 0 )
@@ -227,6 +227,9 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   const int lane = plan.lane;
   hipStream_t s = c->streams[lane];
   if( !job.done ) { err = "hipEventCreate failed"; return VVR_ERR_DEVICE; }
+#ifdef VVR_WATCHDOG
+  const double wdA = wdNow();
+#endif
   if( job.ring )
   {
     RingEntry& e = *job.ring;
@@ -235,21 +238,35 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
     HIPCHK( c, hipEventRecord( e.copied, c->copyStream ) );
     HIPCHK( c, hipStreamWaitEvent( s, e.copied, 0 ) );
   }
+#ifdef VVR_WATCHDOG
+  const double wdB = wdNow(); g_wdPart[0] += wdB - wdA; g_wdPartMax[0] = std::max( g_wdPartMax[0], wdB - wdA );
+#endif
   for( hipEvent_t ev : plan.waits ) hipStreamWaitEvent( s, ev, 0 );
+#ifdef VVR_WATCHDOG
+  const double wdC = wdNow(); g_wdPart[1] += wdC - wdB; g_wdPartMax[1] = std::max( g_wdPartMax[1], wdC - wdB );
+#endif
   const RefSet& refs = plan.refs;
   DevPlanes A = c->slots[h.out_slot], B = c->scratchB[lane], R = c->scratchR[lane];
   auto timed = [&]( int k, auto&& fn )
   {
+#ifdef VVR_WATCHDOG
+    const double w0 = wdNow();
+#endif
     if( c->statsOn ) { PendingTiming t; hipEventCreate( &t.a ); hipEventCreate( &t.b ); t.kernel = k; t.bytes = q->bytes[k]; hipEventRecord( t.a, s ); fn(); hipEventRecord( t.b, s ); job.timings.push_back( t ); }
     else fn();
+#ifdef VVR_WATCHDOG
+    const double w = wdNow() - w0; g_wdCall[k][0] += w; g_wdCall[k][1] = std::max( g_wdCall[k][1], w ); g_wdCall[k][2] += 1;
+#endif
   };
   // INTER stage: prediction of every inter CU, then residual add (DecLibRecon.cpp:831-874)
   if( q->numMc + q->numBdofItems ) timed( K_MC, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc, 0 ); launch_mc( s, q->pic, refs, A, q->bdofItems, q->numBdofItems, 1 ); } );
   if( q->numDmvrItems )
   {
-    hipMemsetAsync( q->dmvrOut, 0, sizeof( int32_t ) * 2 * (size_t) q->numDmvr, s );
-    timed( K_MC_DMVR, [&]{ launch_mc_dmvr( s, q->pic, refs, A, q->dmvrItems, q->numDmvrItems, q->dmvrOut ); } );
-    hipMemcpyAsync( job.ring ? job.ring->dmvrHost : q->dmvrHost, q->dmvrOut, sizeof( int32_t ) * 2 * (size_t) q->numDmvr, hipMemcpyDeviceToHost, s );
+    // the delta MVs go straight into pinned host memory (device-mapped): a few bytes per 16x16 sub-block, and no copy call on the
+    // launcher's path - hipMemcpyAsync device-to-host was found to block the calling thread until the stream had drained
+    int32_t* out = job.ring ? job.ring->dmvrHost : q->dmvrHost;
+    memset( out, 0, sizeof( int32_t ) * 2 * (size_t) q->numDmvr );        // (offsets no CU owns stay zero)
+    timed( K_MC_DMVR, [&]{ launch_mc_dmvr( s, q->pic, refs, A, q->dmvrItems, q->numDmvrItems, out ); } );
   }
   if( q->numAffItems ) timed( K_MC_AFFINE, [&]{ launch_mc_affine( s, q->pic, refs, A, q->affItems, q->numAffItems ); } );
   const bool lmcsOn = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
@@ -286,8 +303,14 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   if( sao && alf ) { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
   else if( sao )   { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_COPY, [&]{ launch_copy_planes( s, B, A ); } ); }
   else if( alf )   { timed( K_COPY, [&]{ launch_copy_planes( s, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
+#ifdef VVR_WATCHDOG
+  const double wdD = wdNow(); g_wdPart[2] += wdD - wdC; g_wdPartMax[2] = std::max( g_wdPartMax[2], wdD - wdC );
+#endif
   hipError_t le = hipGetLastError();
   if( le == hipSuccess ) le = hipEventRecord( job.done, s );
+#ifdef VVR_WATCHDOG
+  g_wdPart[3] += wdNow() - wdD; if( job.ring ) g_wdPartN++;
+#endif
   if( le != hipSuccess )
   {
     // nothing may keep running behind a failed submission: drain the lane
@@ -650,6 +673,9 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( c->watchdog.joinable() ) c->watchdog.join();
   if( g_wdJobs ) fprintf( stderr, "[vvr] per streamed picture (ms): queued %.2f, work lists %.2f, wait for ring entry %.2f, pack %.2f, wait for commit %.2f, enqueue %.2f (%llu pictures)\n",
                           g_wdSum[0] / g_wdJobs, g_wdSum[1] / g_wdJobs, g_wdSum[2] / g_wdJobs, g_wdSum[3] / g_wdJobs, g_wdSum[4] / g_wdJobs, g_wdSum[5] / g_wdJobs, (unsigned long long) g_wdJobs );
+  for( int k = 0; k < K_NUM; k++ ) if( g_wdCall[k][2] ) fprintf( stderr, "[vvr] host time of %-12s: %5.0f calls, %.1f us on average, %.0f us at most\n", kKernelNames[k], g_wdCall[k][2], 1e3 * g_wdCall[k][0] / g_wdCall[k][2], 1e3 * g_wdCall[k][1] );
+  if( g_wdEnqN ) fprintf( stderr, "[vvr] enqueue parts, ms per picture over ALL %llu pictures: upload calls %.3f, event waits %.3f, kernel launches %.3f, record %.3f\n", (unsigned long long) g_wdEnqN, g_wdPart[0] / g_wdEnqN, g_wdPart[1] / g_wdEnqN, g_wdPart[2] / g_wdEnqN, g_wdPart[3] / g_wdEnqN );
+  if( g_wdEnqN ) fprintf( stderr, "[vvr] enqueue parts at most (ms): upload calls %.3f, event waits %.3f, kernel launches %.3f\n", g_wdPartMax[0], g_wdPartMax[1], g_wdPartMax[2] );
   if( g_wdEnqN ) fprintf( stderr, "[vvr] enqueue: %llu pictures, %.3f ms each on average, %.3f ms at most\n", (unsigned long long) g_wdEnqN, g_wdEnqMs / g_wdEnqN, g_wdEnqMax );
 #endif
   for( auto& kv : c->jobs ) { Job& j = *kv.second; for( auto& t : j.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); } if( j.done ) hipEventDestroy( j.done ); }

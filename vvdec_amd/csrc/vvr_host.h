@@ -19,14 +19,14 @@ struct vvr_prepared {
   McItem*  bdofItems = nullptr; int numBdofItems = 0;      // tiles of CUs in BDOF mode (their own launch: larger LDS footprint)
   McItem*  dmvrItems = nullptr; int numDmvrItems = 0;      // sub-blocks that run decoder-side MV refinement
   McItem*  affItems = nullptr; int numAffItems = 0;        // tiles of affine CUs
-  int32_t* dmvrOut = nullptr; uint32_t numDmvr = 0;        // delta MVs, device (inside the blob)
+  uint32_t numDmvr = 0;                                    // delta-MV entries the DMVR kernel writes (pairs of ints)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64
   IntraItem* intraItems = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
   int      intraWorkgroups = 0;                            // workgroups the intra stage is launched with (the dependency front they can keep busy)
   double   bytes[K_NUM] = { 0 };                           // algorithmic bytes per kernel
   // ownership (vvr_prepare handles only)
   void*    blob = nullptr; size_t blobBytes = 0;
-  int32_t* dmvrHost = nullptr;                             // pinned, 2 * numDmvr ints: the delta MVs land here behind the DMVR kernel
+  int32_t* dmvrHost = nullptr;                             // pinned + device-mapped, 2 * numDmvr ints: the DMVR kernel writes the delta MVs here
   struct vvr_context* owner = nullptr;
 };
 

@@ -67,7 +67,7 @@ struct PrepScratch
   // ---- layout of the H2D image
   std::vector<Part> parts;
   size_t total = 0, numDirect = 0;          // parts [0, numDirect) are copied from the caller's pinned arrays
-  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iLmcs, iSl, iCtuSlice, iCtuTile, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iDmvrOut, iTb[3], iIntra, iUnits;
+  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iLmcs, iSl, iCtuSlice, iCtuTile, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iUnits;
 
   void begin( const vvr_picture* pic )
   {
@@ -985,7 +985,6 @@ void PrepScratch::layout( PinnedRanges* pinned )
   for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
   iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
   iUnits = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
-  iDmvrOut = add( nullptr, sizeof( int32_t ) * 2 * (size_t) numDmvr );       // last: written by the device, not part of the upload
 }
 
 int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err, PinnedRanges* pinned )
@@ -1001,7 +1000,7 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
 
 void vvr_host_pack( const PrepScratch& S, char* host )
 {
-  for( size_t i = S.numDirect; i + 1 < S.parts.size(); i++ ) { const Part& pt = S.parts[i]; if( pt.n && pt.src ) memcpy( host + pt.off, pt.src, pt.n ); }
+  for( size_t i = S.numDirect; i < S.parts.size(); i++ ) { const Part& pt = S.parts[i]; if( pt.n && pt.src ) memcpy( host + pt.off, pt.src, pt.n ); }
 }
 
 void vvr_host_upload_plan( const PrepScratch& S, std::vector<DirectCopy>& direct, size_t* stagedBegin, size_t* stagedEnd )
@@ -1009,7 +1008,7 @@ void vvr_host_upload_plan( const PrepScratch& S, std::vector<DirectCopy>& direct
   direct.clear();
   for( size_t i = 0; i < S.numDirect; i++ ) direct.push_back( DirectCopy{ S.parts[i].src, S.parts[i].n, S.parts[i].off } );
   *stagedBegin = S.parts[S.numDirect].off;
-  *stagedEnd = S.parts.back().off;         // (the trailing DMVR output area is written by the device)
+  *stagedEnd = S.total;
 }
 
 
@@ -1033,7 +1032,7 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   q.bdofItems = (McItem*) at( S.iMcB ); q.numBdofItems = (int) S.mcBdof.size();
   q.dmvrItems = (McItem*) at( S.iMcD ); q.numDmvrItems = (int) S.mcDmvr.size();
   q.affItems = (McItem*) at( S.iMcA ); q.numAffItems = (int) S.mcAff.size();
-  q.dmvrOut = (int32_t*) at( S.iDmvrOut ); q.numDmvr = S.numDmvr;
+  q.numDmvr = S.numDmvr;
   for( int k = 0; k < 3; k++ ) { q.tbItems[k] = (TbItem*) at( S.iTb[k] ); q.numTb[k] = (int) S.tb[k].size(); }
   q.intraItems = (IntraItem*) at( S.iIntra ); q.numIntra = (int) S.intraAll.size();
   q.units = (IntraUnit*) at( S.iUnits ); q.numActive = (int) S.unitsDev.size(); q.intraWorkgroups = S.intraWorkgroups;

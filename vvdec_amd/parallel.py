@@ -162,12 +162,14 @@ class PictureParallel:
         for job in self.users.pop(slot, []):
             self.rec.wait(job)
 
-    def run(self, descs):
-        """descs[i]: description of plans[i] for the pictures this rank owns (None elsewhere is fine).  Returns {picture index: job}
-        of the pictures reconstructed here; everything is complete on return."""
+    def run(self, descs, i0=0, i1=None):
+        """pictures [i0, i1) of the plan (default: all).  descs[i]: description of plans[i] for the pictures this rank owns (None elsewhere is
+        fine).  Returns {picture index: job} of the pictures reconstructed here; everything of the range is complete on return, the DPB state
+        carries over to the next call."""
         import torch.distributed as dist
         jobs = {}
-        for i, pl in enumerate(self.plans):
+        for i in range(i0, len(self.plans) if i1 is None else i1):
+            pl = self.plans[i]
             mine = self.owners[i] == self.rank
             ref_slots = [slot for lst in (pl.ref_slots or ([], [])) for (slot, _) in lst]
             if mine:
