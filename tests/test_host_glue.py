@@ -380,7 +380,7 @@ def test_pictures_in_flight_are_ordered_by_their_slots(stub, lanes, frames, gop,
         n = stub.vvt_take_trace(buf, len(buf))
         ops = [tuple(buf[i:i + 3]) for i in range(0, n, 3)]
         rec = [o for o in ops if o[0] == 1]
-        assert len(rec) == 1                    # the picture's completion event, recorded on its lane
+        assert len(rec) == 2                    # the picture's completion events (one for later pictures' streams, one for host threads), on its lane
         jobs.append((rec[0][1], {o[2] for o in ops if o[0] == 0}, rec[0][2], hnd))
         assert all(o[1] == rec[0][1] for o in ops)
     assert len({j[0] for j in jobs}) == lanes   # all lanes are used
@@ -541,7 +541,7 @@ def _submit_stream(stub, threads, W=416, H=240, frames=17, gop=8, lanes=3):
     ops = [(buf[i], buf[i + 1]) for i in range(0, n, 3)]
     base = min(o[1] for o in ops)                       # (the stand-in runtime numbers streams across contexts)
     stub.vvr_destroy(ctx)
-    # the event records: per picture one on the copy stream (its upload) and one on its lane (its completion).  Which waits are issued also
+    # the event records: per picture one on the copy stream (its upload) and two on its lane (its completion: for streams, for host threads).  Which waits are issued also
     # depends on which earlier pictures the host already knows to be finished (their events are not waited for again), i.e. on the ring size
     return [(op, st - base) for op, st in ops if op == 1]
 
@@ -550,7 +550,7 @@ def test_worker_threads_commit_in_submission_order(stub):
     """pictures prepared concurrently by worker threads are enqueued on the device exactly like pictures prepared by the submitting thread:
     same lanes, same copies, uploads and completions in the same order"""
     inline = _submit_stream(stub, 0)
-    assert len(inline) == 17 * 2
+    assert len(inline) == 17 * 3
     for threads in (1, 3):
         assert _submit_stream(stub, threads) == inline
 

@@ -72,7 +72,9 @@ struct Job {
   vvr_prepared* q = nullptr;        // what the kernels read (ring entry or resident handle)
   RingEntry* ring = nullptr;
   int lane = -1;
-  hipEvent_t done = nullptr;
+  hipEvent_t done = nullptr;          // what later pictures' streams wait for
+  hipEvent_t doneHost = nullptr;      // what host threads wait for: hipEventSynchronize holds the event's lock for as long as it waits, and a
+                                      // hipStreamWaitEvent on the same event (the launcher ordering a later picture) would block behind it
   bool completed = false, waited = false;
   std::vector<PendingTiming> timings;
   std::vector<int32_t> dmvr;        // delta MVs, copied out of pinned memory when the job completes
@@ -184,6 +186,7 @@ static void completeLocked( vvr_context* c, Job& j )
   }
   if( j.ring && j.ring->owner == &j ) { j.ring->owner = nullptr; j.ring->turn += c->ring.size(); }
   if( j.done ) { c->eventPool.push_back( j.done ); j.done = nullptr; }
+  if( j.doneHost ) { c->eventPool.push_back( j.doneHost ); j.doneHost = nullptr; }
   j.q = nullptr;
   j.completed = true;
   WD_PROGRESS();
@@ -193,17 +196,17 @@ static void completeLocked( vvr_context* c, Job& j )
 // What the committer decides about a picture while it holds mu: its lane, the events of the pictures it has to be ordered behind, its
 // reference planes.  The HIP calls themselves (enqueuePicture) run WITHOUT mu: a launch blocks when the device's queues are full, and the
 // worker threads must be able to go on preparing pictures meanwhile.
-struct CommitPlan { int lane; std::vector<hipEvent_t> waits; RefSet refs; };
+struct CommitPlan { int lane; std::vector<hipEvent_t> waits; RefSet refs; std::vector<int> waitInfo; };
 
 static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
 {
   const vvr_pic_header& h = job.q->hdr;
   const int lane = c->nextStream; c->nextStream = ( c->nextStream + 1 ) % (int) c->streams.size();
-  plan.lane = lane; plan.waits.clear();
+  plan.lane = lane; plan.waits.clear(); plan.waitInfo.clear();
   job.lane = lane;
   // a lane's scratch planes are reused: the previous job of this lane is ordered before us by the stream itself
   // ---- dependencies: every job that read or wrote one of our slots
-  auto waitFor = [&]( int id ) { auto it = c->jobs.find( id ); if( it != c->jobs.end() ) { Job& j = *it->second; if( !j.completed && j.state == J_COMMITTED && j.lane != lane ) plan.waits.push_back( j.done ); } };
+  auto waitFor = [&]( int id ) { auto it = c->jobs.find( id ); if( it != c->jobs.end() ) { Job& j = *it->second; if( !j.completed && j.state == J_COMMITTED && j.lane != lane ) { plan.waits.push_back( j.done ); plan.waitInfo.push_back( j.q ? ( j.id * 16 + j.q->hdr.slice_type * 4 ) : -1 ); plan.waitInfo.push_back( j.lane ); } } };
   for( int id : c->slotUsers[h.out_slot] ) waitFor( id );
   memset( &plan.refs, 0, sizeof( plan.refs ) );
   if( h.slice_type != 2 )
@@ -214,7 +217,7 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
       if( !c->slotUsers[slot].empty() ) waitFor( c->slotUsers[slot][0] );
       for( int k = 0; k < 3; k++ ) plan.refs.p[l * VVR_MAX_REFS + i][k] = c->slots[slot].p[k];
     }
-  job.done = takeEvent( c );
+  job.done = takeEvent( c ); job.doneHost = takeEvent( c );
 }
 
 // enqueue one prepared picture: H2D copy of its ring entry, dependencies, kernels.  Called by the one committing thread, without mu.
@@ -226,7 +229,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   const vvr_pic_header& h = q->hdr;
   const int lane = plan.lane;
   hipStream_t s = c->streams[lane];
-  if( !job.done ) { err = "hipEventCreate failed"; return VVR_ERR_DEVICE; }
+  if( !job.done || !job.doneHost ) { err = "hipEventCreate failed"; return VVR_ERR_DEVICE; }
 #ifdef VVR_WATCHDOG
   const double wdA = wdNow();
 #endif
@@ -241,7 +244,15 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
 #ifdef VVR_WATCHDOG
   const double wdB = wdNow(); g_wdPart[0] += wdB - wdA; g_wdPartMax[0] = std::max( g_wdPartMax[0], wdB - wdA );
 #endif
+#ifdef VVR_WATCHDOG
+  for( size_t wi = 0; wi < plan.waits.size(); wi++ )
+  {
+    const double w0 = wdNow(); hipStreamWaitEvent( s, plan.waits[wi], 0 ); const double w = wdNow() - w0;
+    if( w > 0.5 ) fprintf( stderr, "[vvr] slow wait: picture %d (type %d, lane %d) wait %zu of %zu on job %d (type %d, lane %d): %.2f ms\n", job.id, (int) h.slice_type, lane, wi, plan.waits.size(), plan.waitInfo[2 * wi] >> 4, ( plan.waitInfo[2 * wi] >> 2 ) & 3, plan.waitInfo[2 * wi + 1], w );
+  }
+#else
   for( hipEvent_t ev : plan.waits ) hipStreamWaitEvent( s, ev, 0 );
+#endif
 #ifdef VVR_WATCHDOG
   const double wdC = wdNow(); g_wdPart[1] += wdC - wdB; g_wdPartMax[1] = std::max( g_wdPartMax[1], wdC - wdB );
 #endif
@@ -308,6 +319,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
 #endif
   hipError_t le = hipGetLastError();
   if( le == hipSuccess ) le = hipEventRecord( job.done, s );
+  if( le == hipSuccess ) le = hipEventRecord( job.doneHost, s );
 #ifdef VVR_WATCHDOG
   g_wdPart[3] += wdNow() - wdD; if( job.ring ) g_wdPartN++;
 #endif
@@ -366,6 +378,7 @@ static void commitReady( vvr_context* c )
           for( auto& t : j->timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); }
           j->timings.clear();
           if( j->done ) { c->eventPool.push_back( j->done ); j->done = nullptr; }
+          if( j->doneHost ) { c->eventPool.push_back( j->doneHost ); j->doneHost = nullptr; }
           j->state = J_FAILED; j->rc = rc; j->err = err; c->setError( err );
         }
       }
@@ -418,7 +431,7 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
         Job* prev = e.owner;
         c->cv.wait( lk, [&]{ return e.owner != prev || prev->state == J_COMMITTED || prev->completed; } );
         if( e.owner != prev || prev->completed ) continue;
-        hipEvent_t ev = prev->done;
+        hipEvent_t ev = prev->doneHost;
         lk.unlock();
         hipEventSynchronize( ev );
         lk.lock();
@@ -530,7 +543,7 @@ static int finishJob( vvr_context* c, int id )
   c->cv.wait( lk, [&]{ return j.state == J_COMMITTED || j.completed; } );
   if( !j.completed )
   {
-    hipEvent_t ev = j.done;
+    hipEvent_t ev = j.doneHost;
     lk.unlock();
     const hipError_t e = hipEventSynchronize( ev );
     lk.lock();
@@ -678,7 +691,7 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( g_wdEnqN ) fprintf( stderr, "[vvr] enqueue parts at most (ms): upload calls %.3f, event waits %.3f, kernel launches %.3f\n", g_wdPartMax[0], g_wdPartMax[1], g_wdPartMax[2] );
   if( g_wdEnqN ) fprintf( stderr, "[vvr] enqueue: %llu pictures, %.3f ms each on average, %.3f ms at most\n", (unsigned long long) g_wdEnqN, g_wdEnqMs / g_wdEnqN, g_wdEnqMax );
 #endif
-  for( auto& kv : c->jobs ) { Job& j = *kv.second; for( auto& t : j.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); } if( j.done ) hipEventDestroy( j.done ); }
+  for( auto& kv : c->jobs ) { Job& j = *kv.second; for( auto& t : j.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); } if( j.done ) hipEventDestroy( j.done ); if( j.doneHost ) hipEventDestroy( j.doneHost ); }
   for( auto e : c->eventPool ) hipEventDestroy( e );
   for( auto& e : c->ring ) { if( e.host ) hipHostFree( e.host ); if( e.dev ) hipFree( e.dev ); if( e.dmvrHost ) hipHostFree( e.dmvrHost ); if( e.copied ) hipEventDestroy( e.copied ); }
   for( auto p : c->retiredHost ) hipHostFree( p );
