@@ -60,6 +60,7 @@ struct PrepScratch
   std::vector<uint32_t> csProdPool;
   std::vector<IntraUnit> unitsDev;
   int intraWorkgroups = 0;
+  size_t intraChunk = 24;                    // blocks per unit of a long intra cluster (formUnits)
   // union-find / grouping scratch
   std::vector<uint32_t> parent, newIdx, firstOf, perm, inv, unitCount, unitOfItem[3];
   std::vector<int32_t> unitOfRoot, target;
@@ -72,6 +73,9 @@ struct PrepScratch
   void begin( const vvr_picture* pic )
   {
     p = pic; h = pic->hdr;
+#ifdef VVR_WATCHDOG
+    if( const char* e = getenv( "VVR_INTRA_CHUNK" ) ) intraChunk = (size_t) atoi( e );      // developer build: sweep of the piece length
+#endif
     ncomp = h.chroma_format ? 3 : 1;
     wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
     w4 = ( h.width + 3 ) >> 2; h4 = ( h.height + 3 ) >> 2; ctu = 1 << h.log2_ctu;
@@ -742,10 +746,25 @@ int PrepScratch::formUnits()
     newIdx.resize( n );
     for( size_t mi = 0; mi < numMembers; mi++ )
     {
-      const std::vector<uint32_t>& m = members[mi];
-      UnitH u; u.comp = (uint32_t) k; u.ctu = itemH[k][m[0]].ctu; u.i0 = (uint32_t) sorted.size();
-      for( uint32_t i : m )
+      const std::vector<uint32_t>& all = members[mi];
+      // A long cluster (an intra CTU: every block reads from the one before it) is cut into pieces of at most intraChunk blocks in coding order.
+      // The blocks stay serial, but the pieces are units of their own: the CTU to the right starts when the piece that holds its left
+      // neighbours is done, not when the whole CTU is - the wavefront of an intra picture advances in pieces instead of CTUs.
+      const bool cut = all.size() > intraChunk && !( k && intra[k][all[0]].mode == IT_MODE_RESI_ADD );
+      for( size_t a = 0; a < all.size(); )
       {
+      size_t b = all.size();
+      if( cut )
+      {
+        b = std::min( all.size(), a + intraChunk );
+        if( all.size() - b < intraChunk / 2 ) b = all.size();                   // (no tiny last piece)
+        // the partitions of an ISP coding unit share the reference line fetched with the first one: they stay together
+        while( b < all.size() && !k && ( intra[k][all[b]].flags & IT_F_ISP ) == IT_F_ISP && !( intra[k][all[b]].flags & IT_F_MIP ) && ( intra[k][all[b]].tu & 0xfff ) ) b++;
+      }
+      UnitH u; u.comp = (uint32_t) k; u.ctu = itemH[k][all[a]].ctu; u.i0 = (uint32_t) sorted.size();
+      for( ; a < b; a++ )
+      {
+        const uint32_t i = all[a];
         newIdx[i] = (uint32_t) sorted.size();
         sorted.push_back( intra[k][i] ); sortedH.push_back( itemH[k][i] );
         const BBox& b = sortedH.back().bb;
@@ -755,6 +774,7 @@ int PrepScratch::formUnits()
       u.i1 = (uint32_t) sorted.size();
       u.iA = ( k && sorted[u.i0].mode == IT_MODE_RESI_ADD ) ? u.i1 : u.i0;
       units.push_back( std::move( u ) );
+      }
     }
     intra[k].swap( sorted ); itemH[k].swap( sortedH );
     // block index -> its new place, in every producer list that names a block of component k (chroma never is a producer for luma, and
