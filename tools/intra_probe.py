@@ -12,8 +12,11 @@ if os.environ.get("PROBE_NO_CS"):
     tools &= ~abi.TOOL_LMCS_CSCALE
 plans, nslots = stream.ra_plan(17, gop=16, seed_poc0_is_external=False)
 rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1)
-for pl in plans[:4]:
-    d = synth.picture_for_plan(pl, W, H, seed=1234, tool_flags=tools, **bench.MIX)
+for pl in plans[:int(os.environ.get("PROBE_PICTURES", "4"))]:
+    mix = dict(bench.MIX)
+    if os.environ.get("PROBE_SPLIT"):
+        mix["p_split_scale"] = float(os.environ["PROBE_SPLIT"])
+    d = synth.picture_for_plan(pl, W, H, seed=1234, tool_flags=tools, **mix)
     h = rec.prepare(d)
     for i in range(3):
         rec.submit_prepared(h)

@@ -60,7 +60,7 @@ struct PrepScratch
   std::vector<uint32_t> csProdPool;
   std::vector<IntraUnit> unitsDev;
   int intraWorkgroups = 0;
-  size_t intraChunk = 24;                    // blocks per unit of a long intra cluster (formUnits)
+  size_t intraChunk = (size_t) 1 << 30;      // blocks per unit of a long intra cluster (formUnits); off: measured, no gain
   // union-find / grouping scratch
   std::vector<uint32_t> parent, newIdx, firstOf, perm, inv, unitCount, unitOfItem[3];
   std::vector<int32_t> unitOfRoot, target;
@@ -73,7 +73,7 @@ struct PrepScratch
   void begin( const vvr_picture* pic )
   {
     p = pic; h = pic->hdr;
-#ifdef VVR_WATCHDOG
+#if defined( VVR_WATCHDOG ) || defined( VVR_DEV_ENV )
     if( const char* e = getenv( "VVR_INTRA_CHUNK" ) ) intraChunk = (size_t) atoi( e );      // developer build: sweep of the piece length
 #endif
     ncomp = h.chroma_format ? 3 : 1;
@@ -747,9 +747,10 @@ int PrepScratch::formUnits()
     for( size_t mi = 0; mi < numMembers; mi++ )
     {
       const std::vector<uint32_t>& all = members[mi];
-      // A long cluster (an intra CTU: every block reads from the one before it) is cut into pieces of at most intraChunk blocks in coding order.
-      // The blocks stay serial, but the pieces are units of their own: the CTU to the right starts when the piece that holds its left
-      // neighbours is done, not when the whole CTU is - the wavefront of an intra picture advances in pieces instead of CTUs.
+      // Developer option (VVR_INTRA_CHUNK in developer builds): a long cluster (an intra CTU: every block reads from the one before it) cut into
+      // pieces of at most intraChunk blocks in coding order, each a unit of its own, so that the CTU to the right could start when the piece that
+      // holds its left neighbours is done.  Measured on 4K intra pictures with mean CU sizes 32 / 20 / 16: 0 .. -9 % at best, the below-left
+      // reference samples of the first blocks of a CTU reach far down the left CTU's last column.
       const bool cut = all.size() > intraChunk && !( k && intra[k][all[0]].mode == IT_MODE_RESI_ADD );
       for( size_t a = 0; a < all.size(); )
       {
