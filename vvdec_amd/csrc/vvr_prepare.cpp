@@ -7,6 +7,7 @@
 // staging memory of the upload ring.  No device call happens here.
 #include "vvr_host.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -1012,6 +1013,24 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
 {
   S.begin( p );
   int rc;
+#ifdef VVR_DEV_ENV
+  if( getenv( "VVR_PHASES" ) )
+  {
+    // developer build: time per phase of the work-list builder
+    auto now = []{ return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); };
+    double t[7]; t[0] = now();
+    rc = S.beginMaps(); t[1] = now();
+    if( rc == VVR_OK ) rc = S.buildWorkLists( err ); t[2] = now();
+    if( rc == VVR_OK ) rc = S.formUnits(); t[3] = now();
+    if( rc == VVR_OK ) rc = S.groupUnits(); t[4] = now();
+    if( rc == VVR_OK ) rc = S.emitUnitTable( err ); t[5] = now();
+    if( rc != VVR_OK ) return rc;
+    S.layout( pinned ); t[6] = now();
+    fprintf( stderr, "[vvr] phases (ms): maps %.2f, work lists %.2f, units %.2f, groups %.2f, unit table %.2f, layout %.2f\n", t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5] );
+    *totalBytes = S.total;
+    return VVR_OK;
+  }
+#endif
   if( ( rc = S.beginMaps() ) != VVR_OK || ( rc = S.buildWorkLists( err ) ) != VVR_OK || ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK
    || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
   S.layout( pinned );
