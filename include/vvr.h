@@ -36,7 +36,7 @@ extern "C" {
 #define VVR_API
 #endif
 
-#define VVR_ABI_VERSION 2
+#define VVR_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------------------------------------------------
  * status codes (negative = error; mirrors the style of vvdecErrorCodes, include/vvdec/vvdec.h.in:91-105)
@@ -161,7 +161,15 @@ typedef struct vvr_pic_header {
   int8_t   ladf_qp_offset[5];       /* SPS::getLadfQpOffset(k): [0] = sps_ladf_lowest_interval_qp_offset   */
   uint8_t  pad;
   int16_t  ladf_lower_bound[5];     /* SPS::getLadfIntervalLowerBound(k), luma level; [0] unused           */
-  uint8_t  pad2[6];
+  /* virtual boundaries of the picture header (ph_virtual_boundaries_present_flag; PicHeader::getVirtualBoundariesPosX / PosY, Slice.h): luma
+   * positions, multiples of 8, inside the picture, ascending.  The in-loop filters do not work across them: edges on a boundary are not
+   * deblocked (that is part of the edge tables the host supplies, LoopFilter.cpp:669-690), SAO leaves the two sample columns / rows at a
+   * boundary alone for the edge classes that look across it (SampleAdaptiveOffset.cpp:823), ALF filters every part of a CTU the boundaries cut
+   * out with its own replicated border (AdaptiveLoopFilter.cpp:142-175,764-850).                                                              */
+  uint8_t  num_ver_vb, num_hor_vb;  /* 0..3 each                                                          */
+  uint8_t  pad2[4];
+  uint16_t vb_pos_x[3], vb_pos_y[3];
+  uint8_t  pad3[4];
 } vvr_pic_header;
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -141,7 +141,13 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
   if( sps.getBitDepth() > 10 || sps.getBitDepth() < 8 ) { why = "bit depth outside 8..10"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getLadfEnabled() && sps.getLadfNumIntervals() > 5 ) { why = "LADF with more than 5 intervals"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getUseWrapAround() || pps.getUseWrapAround() ) { why = "horizontal wrap-around motion compensation (Picture.cpp:404-518)"; return VVR_ERR_UNSUPPORTED; }
-  if( sps.getVirtualBoundariesPresentFlag() || ph.getVirtualBoundariesPresentFlag() ) { why = "virtual boundaries of the in-loop filters"; return VVR_ERR_UNSUPPORTED; }
+  // virtual boundaries: the picture header holds the effective ones (its own or the SPS's, HLSyntaxReader.cpp:2924-2970), at most three per direction
+  if( ph.getVirtualBoundariesPresentFlag() )
+  {
+    if( ph.getNumVerVirtualBoundaries() > 3 || ph.getNumHorVirtualBoundaries() > 3 ) { why = "more than three virtual boundaries per direction"; return VVR_ERR_UNSUPPORTED; }
+    for( unsigned i = 0; i < ph.getNumVerVirtualBoundaries(); i++ ) if( ph.getVirtualBoundariesPosX( i ) & 7 ) { why = "virtual boundary off the 8-sample grid"; return VVR_ERR_UNSUPPORTED; }
+    for( unsigned i = 0; i < ph.getNumHorVirtualBoundaries(); i++ ) if( ph.getVirtualBoundariesPosY( i ) & 7 ) { why = "virtual boundary off the 8-sample grid"; return VVR_ERR_UNSUPPORTED; }
+  }
   if( sps.getUseColorTrans() ) { why = "adaptive colour transform"; return VVR_ERR_UNSUPPORTED; }
   if( pic.slices.empty() ) { why = "picture without a slice"; return VVR_ERR_UNSUPPORTED; }
   if( pps.getNumSubPics() > 1 ) { why = "picture with sub-pictures"; return VVR_ERR_UNSUPPORTED; }
@@ -187,6 +193,13 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   h.deblock_beta_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrBetaOffsetDiv2(); h.deblock_tc_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrTcOffsetDiv2();
   h.log2_sao_offset_scale[0] = h.log2_sao_offset_scale[1] = (uint8_t) std::max( 0, bd - MAX_SAO_TRUNCATED_BITDEPTH );
   h.min_qp_ts = (int8_t) ( 4 + 6 * sps.getInternalMinusInputBitDepth() );
+  if( cs.picHeader->getVirtualBoundariesPresentFlag() )
+  {
+    const PicHeader& ph = *cs.picHeader;
+    h.num_ver_vb = (uint8_t) ph.getNumVerVirtualBoundaries(); h.num_hor_vb = (uint8_t) ph.getNumHorVirtualBoundaries();
+    for( int i = 0; i < h.num_ver_vb; i++ ) h.vb_pos_x[i] = (uint16_t) ph.getVirtualBoundariesPosX( i );
+    for( int i = 0; i < h.num_hor_vb; i++ ) h.vb_pos_y[i] = (uint16_t) ph.getVirtualBoundariesPosY( i );
+  }
   if( sps.getLadfEnabled() )
   {
     h.ladf_num_intervals = (uint8_t) sps.getLadfNumIntervals();

@@ -278,7 +278,11 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       ri.chrResScalingOffset = vp->lmcs->model_delta_crs;
       ph->setLmcsAPS( lmcsAps );
     }
-    ph->setVirtualBoundariesPresentFlag( false );
+    // virtual boundaries of the in-loop filters (ph_virtual_boundaries_present_flag, or the SPS's copied into the picture header, HLSyntaxReader.cpp:2924-2970)
+    ph->setVirtualBoundariesPresentFlag( ( H.num_ver_vb | H.num_hor_vb ) != 0 );
+    ph->setNumVerVirtualBoundaries( H.num_ver_vb ); ph->setNumHorVirtualBoundaries( H.num_hor_vb );
+    for( int i = 0; i < H.num_ver_vb; i++ ) ph->setVirtualBoundariesPosX( H.vb_pos_x[i], i );
+    for( int i = 0; i < H.num_hor_vb; i++ ) ph->setVirtualBoundariesPosY( H.vb_pos_y[i], i );
 
     TR("ps done\n");
     // ------------------------------------------------------------------ pictures
@@ -643,7 +647,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       {
       case 1: sps.setLadfEnabled( true ); sps.setLadfNumIntervals( 6 ); break;                             // (more LADF intervals than the header holds)
       case 2: sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); break;
-      case 3: ph->setVirtualBoundariesPresentFlag( true ); break;
+      case 3: ph->setVirtualBoundariesPresentFlag( true ); ph->setNumVerVirtualBoundaries( 1 ); ph->setVirtualBoundariesPosX( 12, 0 ); break;     // (not on the 8-sample grid: no conforming stream has it)
       case 4: { Slice* s2 = pic.allocateNewSlice(); s2->setPicHeader( ph.get() ); s2->setSliceType( SliceType( H.slice_type ) ); s2->setPOC( H.poc ); s2->setDepQuantEnabledFlag( !slice->getDepQuantEnabledFlag() ); } break;     // (a second slice with another header)
       case 5: pps.setNumSubPics( 2 ); break;
       case 6: sps.setUseColorTrans( true ); break;

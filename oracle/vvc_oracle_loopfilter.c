@@ -275,7 +275,12 @@ void vvo_sao( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )
           const int ax = x - dx, ay = y - dy, bx = x + dx, by = y + dy;
           /* neighbours outside the picture, or in a CTU of another slice / tile the loop filters may not cross, are not available
              (deriveLoopFilterBoundaryAvailibility, SampleAdaptiveOffset.cpp:741-805): the sample is left alone */
-          if( ax >= 0 && ax < cw && ay >= 0 && ay < chh && bx >= 0 && bx < cw && by >= 0 && by < chh
+          /* picture-header virtual boundaries: the sample column (row) on either side of a boundary is skipped by the classes that look across
+             it (isProcessDisabled :823; EO_0 only tests vertical boundaries :112, EO_90 only horizontal ones :156) */
+          int atVb = 0;
+          if( dx ) for( int i = 0; i < H->num_ver_vb; i++ ) { const int vb = H->vb_pos_x[i] >> cs; if( x == vb || x == vb - 1 ) atVb = 1; }
+          if( dy ) for( int i = 0; i < H->num_hor_vb; i++ ) { const int vb = H->vb_pos_y[i] >> cs; if( y == vb || y == vb - 1 ) atVb = 1; }
+          if( !atVb && ax >= 0 && ax < cw && ay >= 0 && ay < chh && bx >= 0 && bx < cw && by >= 0 && by < chh
               && vvo_lf_may_cross( pic, ( y / cctu ) * ctusX + x / cctu, ( ay / cctu ) * ctusX + ax / cctu ) && vvo_lf_may_cross( pic, ( y / cctu ) * ctusX + x / cctu, ( by / cctu ) * ctusX + bx / cctu ) )
           {
             const int a = src->p[c][(size_t) ay * src->stride[c] + ax], b = src->p[c][(size_t) by * src->stride[c] + bx];
@@ -312,6 +317,29 @@ static void alf_set_ctu( const vvr_picture* pic, int ctuX, int ctuY )
   {
     g_alf.tl = !g_alf.t && !g_alf.l && hasL && hasT && pic->ctu_slice[a - ctusX - 1] != pic->ctu_slice[a];
     g_alf.br = !g_alf.b && !g_alf.r && hasR && hasB && pic->ctu_slice[a + ctusX + 1] != pic->ctu_slice[a];
+  }
+  g_alf.on = g_alf.l | g_alf.r | g_alf.t | g_alf.b | g_alf.tl | g_alf.br;
+}
+/* picture-header virtual boundaries: those that touch or cross the CTU cut it into parts, each filtered with a replicated border of its own (a
+ * boundary on the CTU's edge is a clipped edge, :146-172; interior ones: the loops of filterCTU :764-850).  Narrows the CTU's clip to the part
+ * that holds the luma position (lx, ly); the corner padding of raster-scan slices only belongs to the part at the CTU's origin / end (:792,798). */
+static void alf_set_part( const vvr_picture* pic, int lx, int ly )
+{
+  const vvr_pic_header* H = &pic->hdr;
+  const int S = 1 << H->log2_ctu, cx0 = lx & ~( S - 1 ), cy0 = ly & ~( S - 1 );
+  for( int i = 0; i < H->num_ver_vb; i++ )
+  {
+    const int v = H->vb_pos_x[i];
+    if( v < cx0 || v > cx0 + S ) continue;
+    if( v <= lx ) { g_alf.l = 1; g_alf.tl = 0; for( int k = 0; k < 2; k++ ) g_alf.x0[k] = vvo_max( g_alf.x0[k], v >> k ); }
+    else          { g_alf.r = 1; g_alf.br = 0; for( int k = 0; k < 2; k++ ) g_alf.x1[k] = vvo_min( g_alf.x1[k], ( v >> k ) - 1 ); }
+  }
+  for( int i = 0; i < H->num_hor_vb; i++ )
+  {
+    const int v = H->vb_pos_y[i];
+    if( v < cy0 || v > cy0 + S ) continue;
+    if( v <= ly ) { g_alf.t = 1; g_alf.tl = 0; for( int k = 0; k < 2; k++ ) g_alf.y0[k] = vvo_max( g_alf.y0[k], v >> k ); }
+    else          { g_alf.b = 1; g_alf.br = 0; for( int k = 0; k < 2; k++ ) g_alf.y1[k] = vvo_min( g_alf.y1[k], ( v >> k ) - 1 ); }
   }
   g_alf.on = g_alf.l | g_alf.r | g_alf.t | g_alf.b | g_alf.tl | g_alf.br;
 }
@@ -453,7 +481,7 @@ static int ccalf_sample( const vvo_planes* s, int cx, int cy, const int16_t* cf,
   return vvo_clip_pel( sum + off, bd ) - off;
 }
 
-void vvo_alf( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )   /* filterCTU (:664); slice / tile clipping through alf_at; no picture-header virtual boundaries */
+void vvo_alf( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )   /* filterCTU (:664); slice / tile clipping and picture-header virtual boundaries through alf_at */
 {
   const vvr_pic_header* H = &pic->hdr;
   const int ctu = 1 << H->log2_ctu, ctusX = ( H->width + ctu - 1 ) / ctu, bd = H->bit_depth;
@@ -466,6 +494,7 @@ void vvo_alf( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )  
     {
       const vvr_alf_ctu* f = &pic->alf[( y / cctu ) * ctusX + ( x / cctu )];
       alf_set_ctu( pic, x / cctu, y / cctu );
+      if( H->num_ver_vb | H->num_hor_vb ) alf_set_part( pic, x << cs, y << cs );
       int16_t cf[13], cl[13];
       int on = f->enable[c];
       if( on && c == 0 )

@@ -197,7 +197,7 @@ def test_reference_edge_tables_are_safe_for_one_launch_per_direction(built):
     assert ordered > 0
 
 
-@pytest.mark.parametrize("feature,text", [(1, "LADF with more than 5"), (2, "wrap-around"), (3, "virtual boundaries"), (4, "slices with different headers"), (5, "sub-pictures"),
+@pytest.mark.parametrize("feature,text", [(1, "LADF with more than 5"), (2, "wrap-around"), (3, "virtual boundary off the 8-sample grid"), (4, "slices with different headers"), (5, "sub-pictures"),
                                           (6, "colour transform"), (7, "bit depth"), (8, "more slices or tiles"), (9, "another size")])
 def test_extractor_refuses_what_the_description_cannot_express(built, feature, text):
     """the reference-side glue never flattens a picture into something it is not: LADF, wrap-around, virtual boundaries, several slices / tiles /
@@ -230,8 +230,9 @@ def test_binding_executes_on_the_stand_in_runtime(built):
     passes the product's validation and the work-list builder, and the motion field that comes back is the one the reference derives when no
     refinement moves anything.  The same test with samples runs on the GPU (tests/test_gpu_parity.py)."""
     import test_host_glue as T
-    if not refdrv.binding_available() or not os.path.exists(T.LIB):
-        pytest.skip("binding harness or stand-in runtime not built")
+    if not refdrv.binding_available() or not os.path.exists(os.path.join(T.HIP_INC, "hip", "hip_runtime_api.h")):
+        pytest.skip("binding harness not built or HIP headers not installed")
+    T.build_stub()
     W, H = 256, 128
     plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
     for idx, tools, kw in ((0, ALL, dict(p_cclm=0.3, p_mip=0.2)), (2, ALL | abi.TOOL_STILL_REF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.2, p_affine=0.2, p_sbtmvp=0.1, p_ciip=0.1))):

@@ -364,6 +364,21 @@ def test_slices_and_tiles(built, extra, kw):
     _run_stream(1920, 1080, 3, 2, 223, TOOLS_A | extra, intra=True, streams=3, **kw)
 
 
+@pytest.mark.parametrize("vb,extra,kw", [
+    (1 | (1 << 2), 0, dict()),
+    (3 | (3 << 2), 0, dict(p_affine=0.3, p_sbtmvp=0.2)),
+    (2 | (2 << 2) | 16, 0, dict()),
+    (3 | (2 << 2) | 16, abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=3, tile_cols=2, tile_rows=2)),
+])
+def test_virtual_boundaries(built, vb, extra, kw):
+    """virtual boundaries of the picture header: SAO leaves the columns / rows next to them alone (k_sao), ALF filters the parts of a CTU they cut out
+    with a border of their own (k_alf_luma: one pass per part of a tile; k_alf_chroma and CC-ALF: per-sample clip); deblocking follows the host table"""
+    T = TOOLS_A | abi.TOOL_LMCS | extra
+    _run_stream(512, 384, 5, 4, 231, T, intra=True, log2_ctu=6, p_intra=0.3, p_cclm=0.3, virtual_boundaries=vb, **kw)
+    _run_stream(640, 256, 3, 2, 232, T, intra=True, log2_ctu=5, p_intra=0.2, virtual_boundaries=vb, **kw)
+    _run_stream(1920, 1080, 3, 2, 233, TOOLS_A | extra, intra=True, streams=3, virtual_boundaries=vb, **kw)
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

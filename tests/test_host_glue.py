@@ -34,12 +34,17 @@ TOOLS = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF
          abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF)
 
 
-@pytest.fixture(scope="module")
-def stub():
-    deps = [SRC, API] + [os.path.join(os.path.dirname(API), f) for f in ("vvr_device.h", "vvr_host.h", "vvr_prepare.cpp", "vvr_output.inc")]
+def build_stub():
+    """(re)build the product's host code against the stand-in runtime when a source is newer -> path of the library"""
+    deps = [SRC, API] + [os.path.join(os.path.dirname(API), f) for f in ("vvr_device.h", "vvr_host.h", "vvr_prepare.cpp", "vvr_output.inc")] + [os.path.join(os.path.dirname(HERE), "include", "vvr.h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I" + HIP_INC, "-D__HIP_PLATFORM_AMD__", "-w", SRC, "-o", LIB])
-    L = C.CDLL(LIB)
+    return LIB
+
+
+@pytest.fixture(scope="module")
+def stub():
+    L = C.CDLL(build_stub())
     L.vvr_last_error.restype = C.c_char_p
     L.vvr_last_error.argtypes = [C.c_void_p]
     L.vvt_sizeof.restype = C.c_size_t

@@ -293,3 +293,42 @@ def test_oracle_equals_reference_slices_and_tiles(built, W, H, l2, idx, seed, ex
     d.hdr.tool_flags &= ~(abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES)
     other = refdrv.oracle_reconstruct(d, refs, flags=0)
     assert any(not np.array_equal(a, b) for a, b in zip(other, final))
+
+
+VB_CASES = [
+    # W, H, l2, idx, seed, virtual_boundaries (bits 0-1 vertical, 2-3 horizontal, 16: first on a CTU boundary), extra tool flags, generator parameters
+    (512, 384, 6, 0, 271, 1 | (1 << 2), 0, dict(p_cclm=0.2)),
+    (512, 384, 6, 2, 272, 3 | (3 << 2), 0, dict(p_intra=0.2, p_affine=0.3, p_sbtmvp=0.2)),                        # three each; sub-block edges on a boundary
+    (512, 384, 7, 3, 273, 2 | (2 << 2) | 16, 0, dict(p_intra=0.2)),                                               # one of each on a CTU boundary
+    (384, 256, 5, 0, 274, 3 | (2 << 2) | 16, abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=3, dual_tree=1.0)),    # together with slices the filters do not cross
+    (640, 256, 6, 2, 275, 2 | (1 << 2), abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(num_slices=3, tile_cols=2, tile_rows=2, p_intra=0.3)),
+]
+
+
+@pytest.mark.parametrize("W,H,l2,idx,seed,vb,extra,kw", VB_CASES)
+def test_oracle_equals_reference_virtual_boundaries(built, W, H, l2, idx, seed, vb, extra, kw):
+    """virtual boundaries of the picture header: edges on them are not deblocked (host table; the reference derives the same from its own objects), SAO
+    skips the sample columns / rows next to them for the classes that look across (isProcessDisabled), ALF filters every part of a CTU they cut out
+    with a border of its own (filterCTU)"""
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=ALL | extra, log2_ctu=l2, virtual_boundaries=vb, **kw)
+    assert d.hdr.num_ver_vb == (vb & 3) and d.hdr.num_hor_vb == ((vb >> 2) & 3)
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc))
+    for fl in STAGES:
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+    # the job's edge table == what the reference derives from its own objects with the boundaries in its picture header
+    a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
+    b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # the boundaries matter
+    final = want
+    d.hdr.num_ver_vb = d.hdr.num_hor_vb = 0
+    other = refdrv.oracle_reconstruct(d, refs, flags=0)
+    assert any(not np.array_equal(x, y) for x, y in zip(other, final))

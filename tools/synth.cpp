@@ -73,7 +73,8 @@ typedef struct vvs_params {
                                 // where a block vector into the valid part of the IBC virtual buffer is found
   uint8_t  num_slices;          // > 1: the picture is cut into that many slices (one tile: bands of CTU rows; several tiles: runs of tiles in raster order)
   uint8_t  tile_cols, tile_rows;// > 1: uniform tile grid.  Whether the loop filters cross these boundaries is in tool_flags (VVR_TOOL_NO_LF_ACROSS_*)
-  uint8_t  pad_st;
+  uint8_t  virtual_boundaries;  // bits 0-1: number of vertical, bits 2-3: of horizontal virtual boundaries of the in-loop filters (picture header); bit 4: the first
+                                // of each direction lies on a CTU boundary
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -136,6 +137,14 @@ struct Gen {
   int ctusX = 0, ctusY = 0;
   int ctuOfPos( int x, int y ) const { return ( y >> P.log2_ctu ) * ctusX + ( x >> P.log2_ctu ); }
   bool sameSliceTile( int a, int b ) const { return sliceOfCtu[a] == sliceOfCtu[b] && tileOfCtu[a] == tileOfCtu[b]; }
+  // is the edge left of / above the 4x4 unit (x4, y4) on a virtual boundary of the picture header?  (LoopFilter::xDeriveEdgefilterParam, LoopFilter.cpp:669)
+  bool onVirtualBoundary( int d, int x4, int y4 ) const
+  {
+    const vvr_pic_header& h = B.hdr;
+    if( d == 0 ) { for( int i = 0; i < h.num_ver_vb; i++ ) if( h.vb_pos_x[i] == ( x4 << 2 ) ) return true; }
+    else         { for( int i = 0; i < h.num_hor_vb; i++ ) if( h.vb_pos_y[i] == ( y4 << 2 ) ) return true; }
+    return false;
+  }
   bool lfMayCross( int a, int b ) const
   {
     if( ( P.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && sliceOfCtu[a] != sliceOfCtu[b] ) return false;
@@ -778,7 +787,7 @@ struct Gen {
           L.qp[2] = (int8_t) ( ( TQ.qp[2] + TP.qp[2] - 2 * qpBd + 1 ) >> 1 );
         }
         L.bs = (uint8_t) ( bsY | ( bsC << 2 ) | ( bsC << 4 ) );
-        if( !lfMayCross( ctuOfPos( x4 << 2, y4 << 2 ), ctuOfPos( px4 << 2, py4 << 2 ) ) ) { L.bs = 0; L.flags &= (uint8_t) ~3; }
+        if( !lfMayCross( ctuOfPos( x4 << 2, y4 << 2 ), ctuOfPos( px4 << 2, py4 << 2 ) ) || onVirtualBoundary( d, x4, y4 ) ) { L.bs = 0; L.flags &= (uint8_t) ~3; }
       }
     }
   }
@@ -868,7 +877,7 @@ struct Gen {
         }
         L.bs = (uint8_t) ( bsY | ( bsCb << 2 ) | ( bsCr << 4 ) );
         // an edge on a slice / tile boundary the loop filters must not cross is not filtered (m_stLFCUParam.leftEdge / topEdge, LoopFilter.cpp:1078,1088)
-        if( !lfMayCross( ctuOfPos( x4 << 2, y4 << 2 ), ctuOfPos( px4 << 2, py4 << 2 ) ) ) { L.bs = 0; L.flags &= (uint8_t) ~3; }
+        if( !lfMayCross( ctuOfPos( x4 << 2, y4 << 2 ), ctuOfPos( px4 << 2, py4 << 2 ) ) || onVirtualBoundary( d, x4, y4 ) ) { L.bs = 0; L.flags &= (uint8_t) ~3; }
         L.qp[0] = (int8_t) ( ( CQ.qp + CP.qp + 1 ) >> 1 );
         L.qp[1] = (int8_t) ( ( TQc.qp[1] + TPc.qp[1] - 2 * qpBd + 1 ) >> 1 );
         L.qp[2] = (int8_t) ( ( TQc.qp[2] + TPc.qp[2] - 2 * qpBd + 1 ) >> 1 );
@@ -887,6 +896,7 @@ struct Gen {
         {
           if( ( d == 0 ? cu.x : cu.y ) + pp == 0 ) continue;                       // picture boundary
           vvr_lfp& L = B.lfp[d][cell( pp, pl )];
+          const bool onVb = onVirtualBoundary( d, ( d == 0 ? cu.x + pp : cu.x + pl ) >> 2, ( d == 0 ? cu.y + pl : cu.y + pp ) >> 2 );      // an edge on a virtual boundary is not filtered (:575-600)
           int lenP, lenQ, te = 0;
           if( L.side_max_filt_length & 0x80 )
           {
@@ -896,7 +906,8 @@ struct Gen {
               lenP = std::min( lenP, 5 );
               // a transform edge inside the CU that is also a sub-block edge: without a coded block on either side the motion decides
               // (xSetEdgeFilterInsidePu :1046 turns the edge marker into 3, so xGetBoundaryStrengthSingle goes on to the motion test)
-              if( !( L.bs & 3 ) ) L.bs = (uint8_t) ( L.bs | ( ( cu.flags & VVR_CU_CIIP ) ? 1 : motionBs( cell( pp, pl ), cell( pp - 4, pl ) ) ) );
+              if( onVb ) { L.flags &= (uint8_t) ~1; }       // (xSetEdgeFilterInsidePu with bValue = false, :1053)
+              else if( !( L.bs & 3 ) ) L.bs = (uint8_t) ( L.bs | ( ( cu.flags & VVR_CU_CIIP ) ? 1 : motionBs( cell( pp, pl ), cell( pp - 4, pl ) ) ) );
             }
           }
           else
@@ -906,9 +917,12 @@ struct Gen {
             else lenP = lenQ = 3;
             // a pure sub-block edge: filtered where the motion of the two sub-blocks differs
             const int iq = cell( pp, pl ), ip = cell( pp - 4, pl );
-            L.flags |= 1;
-            L.bs = (uint8_t) ( ( cu.flags & VVR_CU_CIIP ) ? 1 : motionBs( iq, ip ) );
-            L.qp[0] = cu.qp;
+            if( !onVb )
+            {
+              L.flags |= 1;
+              L.bs = (uint8_t) ( ( cu.flags & VVR_CU_CIIP ) ? 1 : motionBs( iq, ip ) );
+              L.qp[0] = cu.qp;
+            }
           }
           L.side_max_filt_length = (uint8_t) ( te | ( lenP << 4 ) | lenQ );
         }
@@ -1011,6 +1025,23 @@ struct Gen {
     h.log2_ctu = P.log2_ctu; h.slice_type = P.slice_type; h.poc = P.poc; h.out_slot = P.out_slot; h.min_qp_ts = 4;
     for( int l = 0; l < 2; l++ ) { h.num_ref[l] = P.slice_type == 2 ? 0 : P.num_ref[l]; for( int i = 0; i < VVR_MAX_REFS; i++ ) { h.ref_slot[l][i] = P.ref_slot[l][i]; h.ref_poc[l][i] = P.ref_poc[l][i]; } }
     for( int c = 0; c < 3; c++ ) { h.deblock_beta_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); h.deblock_tc_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); }
+    for( int d = 0; d < 2; d++ )
+    {
+      // virtual boundaries: distinct multiples of 8 inside the picture, ascending (ph_virtual_boundary_pos_x/y_minus1)
+      const int n = ( P.virtual_boundaries >> ( 2 * d ) ) & 3, lim = d ? H : W;
+      uint16_t* pos = d ? h.vb_pos_y : h.vb_pos_x;
+      int got = 0;
+      for( int tries = 0; got < n && tries < 64; tries++ )
+      {
+        int v = 8 * ( 1 + (int) rng.u( (uint32_t) std::max( 1, lim / 8 - 1 ) ) );
+        if( got == 0 && ( P.virtual_boundaries & 16 ) && lim > ctu ) v = ctu * ( 1 + (int) rng.u( (uint32_t) ( ( lim - 1 ) / ctu ) ) );
+        if( v <= 0 || v >= lim ) continue;
+        bool dup = false; for( int i = 0; i < got; i++ ) dup |= pos[i] == v;
+        if( !dup ) pos[got++] = (uint16_t) v;
+      }
+      std::sort( pos, pos + got );
+      if( d ) h.num_hor_vb = (uint8_t) got; else h.num_ver_vb = (uint8_t) got;
+    }
     if( h.tool_flags & VVR_TOOL_LADF )
     {
       // sps_ladf_*: 2..5 intervals with rising lower bounds (luma levels) and QP offsets in the syntax range (-63..63, kept small)

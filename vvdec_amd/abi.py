@@ -5,7 +5,7 @@ compiled library so the two cannot drift apart silently.
 """
 import ctypes as C
 
-VVR_ABI_VERSION = 2
+VVR_ABI_VERSION = 3
 VVR_MAX_REFS = 16
 VVR_MAX_ALF_APS = 8
 VVR_ALF_CLASSES = 25
@@ -56,7 +56,8 @@ class PicHeader(C.Structure):
                 ("ref_slot", i16 * VVR_MAX_REFS * 2), ("ref_poc", i32 * VVR_MAX_REFS * 2),
                 ("deblock_beta_offset_div2", i8 * 3), ("deblock_tc_offset_div2", i8 * 3),
                 ("log2_sao_offset_scale", u8 * 2), ("min_qp_ts", i8),
-                ("ladf_num_intervals", u8), ("ladf_qp_offset", i8 * 5), ("pad", u8), ("ladf_lower_bound", i16 * 5), ("pad2", u8 * 6)]
+                ("ladf_num_intervals", u8), ("ladf_qp_offset", i8 * 5), ("pad", u8), ("ladf_lower_bound", i16 * 5),
+                ("num_ver_vb", u8), ("num_hor_vb", u8), ("pad2", u8 * 4), ("vb_pos_x", u16 * 3), ("vb_pos_y", u16 * 3), ("pad3", u8 * 4)]
 
 
 class Cu(C.Structure):

@@ -1611,6 +1611,39 @@ __device__ __forceinline__ void alf_clip_coord( const AlfClip& k, int& x, int& y
   if( ( k.f & 16 ) && x < k.x0 && y < k.y0 ) x = k.x0;
   if( ( k.f & 32 ) && x > k.x1 && y > k.y1 ) x = k.x1;
 }
+// Virtual boundaries of the picture header.  ALF: the boundaries that touch or cross the CTU cut it into parts, each filtered with a replicated
+// border of its own (filterCTU, AdaptiveLoopFilter.cpp:764-850; a boundary on the CTU's edge is a clipped edge, :146-172).  For the part that holds
+// the luma position (lx, ly): the CTU's clip `k` (component cs) narrowed to that part.  The corner padding of raster-scan slices belongs to the
+// part at the CTU's origin / end only, which is what remains of it when the clipped sides are applied first (alf_clip_coord).
+__device__ __forceinline__ bool vb_present( const PicDev& pic ) { return ( pic.hdr.num_ver_vb | pic.hdr.num_hor_vb ) != 0; }
+__device__ __forceinline__ AlfClip alf_clip_vb( const PicDev& pic, AlfClip k, int lx, int ly, int cs )
+{
+  const int S = 1 << pic.hdr.log2_ctu, cx0 = lx & ~( S - 1 ), cy0 = ly & ~( S - 1 );
+  for( int i = 0; i < pic.hdr.num_ver_vb; i++ )
+  {
+    const int v = pic.hdr.vb_pos_x[i];
+    if( v < cx0 || v > cx0 + S ) continue;
+    if( v <= lx ) { k.f = ( k.f | 1 ) & ~16u; k.x0 = max( k.x0, v >> cs ); }
+    else          { k.f = ( k.f | 2 ) & ~32u; k.x1 = min( k.x1, ( v >> cs ) - 1 ); }
+  }
+  for( int i = 0; i < pic.hdr.num_hor_vb; i++ )
+  {
+    const int v = pic.hdr.vb_pos_y[i];
+    if( v < cy0 || v > cy0 + S ) continue;
+    if( v <= ly ) { k.f = ( k.f | 4 ) & ~16u; k.y0 = max( k.y0, v >> cs ); }
+    else          { k.f = ( k.f | 8 ) & ~32u; k.y1 = min( k.y1, ( v >> cs ) - 1 ); }
+  }
+  return k;
+}
+// SAO: a sample in the column (row) on either side of a virtual boundary is left alone by the edge classes that look across it
+// (SampleAdaptiveOffset::isProcessDisabled, SampleAdaptiveOffset.cpp:823; the horizontal class only knows vertical boundaries, the vertical class only
+// horizontal ones, :112,156).  x, y in component samples.
+__device__ __forceinline__ bool sao_at_vb( const PicDev& pic, int x, int y, int cs, bool ver, bool hor )
+{
+  if( ver ) for( int i = 0; i < pic.hdr.num_ver_vb; i++ ) { const int v = pic.hdr.vb_pos_x[i] >> cs; if( x == v || x == v - 1 ) return true; }
+  if( hor ) for( int i = 0; i < pic.hdr.num_hor_vb; i++ ) { const int v = pic.hdr.vb_pos_y[i] >> cs; if( y == v || y == v - 1 ) return true; }
+  return false;
+}
 
 // =====================================================================================================================
 // k_sao — SampleAdaptiveOffset::offsetBlock_core (SampleAdaptiveOffset.cpp:64) per sample; reads the deblocked picture,
@@ -1669,7 +1702,7 @@ __global__ __launch_bounds__( 256 ) void k_sao( PicDev pic, DevPlanes src, DevPl
               if( x0 + 8 < cw ) { wa[9] = ra[8]; wb[9] = rb[8]; }
             }
           }
-          const bool restricted = lf_restricted( pic );
+          const bool restricted = lf_restricted( pic ), vbOn = vb_present( pic );
           const int curCtu = ( y / ctuC ) * pic.ctus_x + ( x0 / ctuC );
 #pragma unroll
           for( int i = 0; i < 8; i++ )
@@ -1678,6 +1711,7 @@ __global__ __launch_bounds__( 256 ) void k_sao( PicDev pic, DevPlanes src, DevPl
             if( x - dx < 0 || x - dx >= cw || x + dx < 0 || x + dx >= cw ) continue;
             // nothing across a slice / tile boundary the loop filters must not cross
             if( restricted && ( !lf_may_cross( pic, curCtu, ( ya / ctuC ) * pic.ctus_x + ( x - dx ) / ctuC ) || !lf_may_cross( pic, curCtu, ( yb / ctuC ) * pic.ctus_x + ( x + dx ) / ctuC ) ) ) continue;
+            if( vbOn && sao_at_vb( pic, x, y, cs, dx != 0, dy != 0 ) ) continue;
             const int e = sgn( v[i] - wa[1 + i - dx] ) + sgn( v[i] - wb[1 + i + dx] );
             if( e ) out[i] = clip_pel( v[i] + s.offset[c][e < 0 ? e + 2 : e + 1], bd );
           }
@@ -1735,7 +1769,19 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
     return;
   }
   const int TW = ALF_T + 2 * ALF_HALO;
-  const AlfClip kclip = alf_clip_of_ctu( pic, tx0 >> pic.hdr.log2_ctu, ty0 >> pic.hdr.log2_ctu, 0 );
+  const AlfClip kctu = alf_clip_of_ctu( pic, tx0 >> pic.hdr.log2_ctu, ty0 >> pic.hdr.log2_ctu, 0 );
+  // virtual boundaries (picture header) that run through the tile cut it into parts with a border of their own: one pass per part (usually: one)
+  int px[5], py[5], npx = 1, npy = 1;
+  px[0] = tx0; py[0] = ty0;
+  for( int i = 0; i < pic.hdr.num_ver_vb; i++ ) { const int v = pic.hdr.vb_pos_x[i]; if( v > tx0 && v < tx0 + ALF_T ) px[npx++] = v; }
+  for( int i = 0; i < pic.hdr.num_hor_vb; i++ ) { const int v = pic.hdr.vb_pos_y[i]; if( v > ty0 && v < ty0 + ALF_T ) py[npy++] = v; }
+  px[npx] = tx0 + ALF_T; py[npy] = ty0 + ALF_T;
+  const bool vbOn = vb_present( pic );
+  for( int part = 0; part < npx * npy; part++ )
+  {
+  const int ax0 = px[part % npx], ax1 = px[part % npx + 1], ay0 = py[part / npx], ay1 = py[part / npx + 1];      // the part, luma samples
+  const AlfClip kclip = vbOn ? alf_clip_vb( pic, kctu, ax0, ay0, 0 ) : kctu;
+  if( part ) __syncthreads();                                     // the previous part is done with the tile and the classes
   for( int i = tid; i < TW * TW; i += 256 )
   {
     const int yy = i / TW, xx = i - yy * TW;
@@ -1744,6 +1790,7 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
     sx = clip3( 0, W - 1, sx ); sy = clip3( 0, H - 1, sy );
     tile[yy * ALF_LW + xx] = S[(size_t) sy * st + sx];
   }
+  if( part == 0 )
   {
     const vvr_alf_params* __restrict__ A = pic.alf_params;
     const int clipDef = 1 << bd;      // m_alfClippVls[bd-8][0] = 256 << (bd - 8)
@@ -1763,7 +1810,8 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
     const int bx = ( blk & 7 ) * 4, by = ( blk >> 3 ) * 4;
     const int yInCtu = ( ty0 + by ) & ( ctu - 1 );
     int sumV = 0, sumH = 0, sumD0 = 0, sumD1 = 0;
-    if( !( ( yInCtu == vbPos - 4 && i == 6 ) || ( yInCtu == vbPos && i == 0 ) ) )
+    const bool inPart = tx0 + bx >= ax0 && tx0 + bx < ax1 && ty0 + by >= ay0 && ty0 + by < ay1;      // (4x4 blocks never straddle a boundary: multiples of 8)
+    if( inPart && !( ( yInCtu == vbPos - 4 && i == 6 ) || ( yInCtu == vbPos && i == 0 ) ) )
     {
       const int r = by - 2 + i, rel = yInCtu - 2 + i;
       int rm1 = r - 1, rp2 = r + 2;
@@ -1783,7 +1831,7 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
     sumH  += __shfl_xor( sumH, 1 );  sumH  += __shfl_xor( sumH, 2 );
     sumD0 += __shfl_xor( sumD0, 1 ); sumD0 += __shfl_xor( sumD0, 2 );
     sumD1 += __shfl_xor( sumD1, 1 ); sumD1 += __shfl_xor( sumD1, 2 );
-    if( ( tid & 3 ) == 0 )
+    if( ( tid & 3 ) == 0 && inPart )
     {
       const int th[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
       const int act = clip3( 0, 15, ( ( sumV + sumH ) * ( ( yInCtu == vbPos - 4 || yInCtu == vbPos ) ? 96 : 64 ) ) >> ( bd + 4 ) );
@@ -1806,7 +1854,7 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
   {
     const int y = tid >> 3, x4 = ( tid & 7 ) * 4;
     const int gy = ty0 + y;
-    if( gy < H && tx0 + x4 < W )
+    if( gy < H && tx0 + x4 < W && tx0 + x4 >= ax0 && tx0 + x4 < ax1 && gy >= ay0 && gy < ay1 )
     {
       const int b = ( y >> 2 ) * 8 + ( x4 >> 2 );
       const int cl = cls[b], tr = trp[b];
@@ -1849,6 +1897,7 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
       }
     }
   }
+  }     // parts
 #undef T
 }
 
@@ -1864,7 +1913,8 @@ __global__ __launch_bounds__( 256 ) void k_alf_chroma( PicDev pic, DevPlanes src
   const vvr_alf_ctu& f = pic.alf[( y / ctuC ) * pic.ctus_x + ( x / ctuC )];
   const pel_t* __restrict__ S = src.p[c];
   const int st = src.stride[c];
-  const AlfClip kc = alf_clip_of_ctu( pic, x / ctuC, y / ctuC, 1 ), kl = alf_clip_of_ctu( pic, x / ctuC, y / ctuC, 0 );
+  AlfClip kc = alf_clip_of_ctu( pic, x / ctuC, y / ctuC, 1 ), kl = alf_clip_of_ctu( pic, x / ctuC, y / ctuC, 0 );
+  if( vb_present( pic ) ) { kc = alf_clip_vb( pic, kc, x << 1, y << 1, 1 ); kl = alf_clip_vb( pic, kl, x << 1, y << 1, 0 ); }
   auto fetch = [&]( const pel_t* __restrict__ P, int pst, int PW, int PH, const AlfClip& k, int xx, int yy ) -> int
   {
     alf_clip_coord( k, xx, yy );

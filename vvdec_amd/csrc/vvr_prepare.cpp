@@ -135,6 +135,13 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
   if( h.out_slot < 0 || h.out_slot >= cfg.num_slots ) FAIL( VVR_ERR_PARAMETER, "out_slot out of range" );
   if( h.slice_type > 2 ) FAIL( VVR_ERR_PARAMETER, "unknown slice type" );
   if( h.ladf_num_intervals == 1 || h.ladf_num_intervals > 5 ) FAIL( VVR_ERR_PARAMETER, "LADF: 2..5 intervals" );
+  if( h.num_ver_vb > 3 || h.num_hor_vb > 3 ) FAIL( VVR_ERR_PARAMETER, "at most three virtual boundaries per direction" );
+  for( int d = 0; d < 2; d++ )
+  {
+    const uint16_t* pos = d ? h.vb_pos_y : h.vb_pos_x; const int n = d ? h.num_hor_vb : h.num_ver_vb, lim = d ? h.height : h.width;
+    for( int i = 0; i < n; i++ )
+      if( ( pos[i] & 7 ) || pos[i] == 0 || pos[i] >= lim || ( i && pos[i] <= pos[i - 1] ) ) FAIL( VVR_ERR_PARAMETER, "virtual boundary positions: multiples of 8 inside the picture, ascending" );
+  }
   if( ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && !( h.tool_flags & VVR_TOOL_LMCS ) ) FAIL( VVR_ERR_PARAMETER, "LMCS chroma residual scaling without LMCS" );
   if( ( h.tool_flags & VVR_TOOL_LMCS ) && !p->lmcs ) FAIL( VVR_ERR_PARAMETER, "LMCS enabled without tables" );
   const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
