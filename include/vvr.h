@@ -96,6 +96,8 @@ enum {
   VVR_TOOL_NO_LF_ACROSS_SLICES = 1u << 22,  /* !pps_loop_filter_across_slices_enabled_flag: SAO and ALF do not look across slice boundaries (the deblocking
                                         edges there are already switched off in the edge-parameter table the host derives)                     */
   VVR_TOOL_NO_LF_ACROSS_TILES  = 1u << 23,  /* !pps_loop_filter_across_tiles_enabled_flag, likewise for tile boundaries                              */
+  VVR_TOOL_AFFINE_MV_ON_DEVICE = 1u << 24,  /* the sub-block MVs of affine CUs are spanned by the back-end from the CU's control-point MVs (cu.mv[list][0..2];
+                                               PU::setAllAffineMv, UnitTools.cpp:2689): vvr_picture.motion is not read for affine CUs and need not hold them   */
 };
 
 typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::reconstructCoeff (AdaptiveLoopFilter.cpp:888) stays on the host */

@@ -82,6 +82,7 @@ enum {
   VVREF_STOP_AFTER_RECO = 4,   // output after INTRA stage (no in-loop filters)
   VVREF_STOP_AFTER_DBK  = 8,
   VVREF_STOP_AFTER_SAO  = 16,
+  VVREF_SPAN_AFFINE     = 32,  // the motion of affine CUs is not taken from the description: PU::setAllAffineMv spans it from the control-point MVs
 };
 
 static std::string g_err;
@@ -567,6 +568,12 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       for( int l = 0; l < 2; l++ ) for( int k = 0; k < 3; k++ ) cu.mv[l][k] = Mv( c.mv[l][k][0], c.mv[l][k][1] );
       // GPM keeps its two uni-prediction MVs in mv[0][1] / mv[1][1] (InterPrediction::motionCompensationGeo, InterPrediction.cpp:1478,1489)
       if( c.flags & VVR_CU_GEO ) { cu.mv[0][1] = Mv( c.geo_mv[0][0], c.geo_mv[0][1] ); cu.mv[1][1] = Mv( c.geo_mv[1][0], c.geo_mv[1][1] ); }
+      if( ( flags & VVREF_SPAN_AFFINE ) && ( c.flags & VVR_CU_AFFINE ) )
+      {
+        MotionBuf mb = cu.getMotionBuf();
+        for( unsigned yy = 0; yy < mb.height; yy++ ) for( unsigned xx = 0; xx < mb.width; xx++ ) { mb.at( xx, yy ).mv[0] = Mv(); mb.at( xx, yy ).mv[1] = Mv(); }
+        for( int l = 0; l < 2; l++ ) if( c.ref_idx[l] >= 0 ) PU::setAllAffineMv( cu, cu.mv[l][0], cu.mv[l][1], cu.mv[l][2], RefPicList( l ), false );
+      }
       cu.setPlaneCbf( 0, false ); cu.setPlaneCbf( 1, false ); cu.setPlaneCbf( 2, false );
 
       for( uint32_t t = c.first_tu; t < c.first_tu + c.num_tu; t++ )

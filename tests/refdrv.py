@@ -8,7 +8,7 @@ import numpy as np
 from vvdec_amd import abi
 
 _LIB = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libvvref.so")
-SIMD, DERIVE_LFP, STOP_AFTER_RECO, STOP_AFTER_DBK, STOP_AFTER_SAO = 1, 2, 4, 8, 16
+SIMD, DERIVE_LFP, STOP_AFTER_RECO, STOP_AFTER_DBK, STOP_AFTER_SAO, SPAN_AFFINE = 1, 2, 4, 8, 16, 32
 _lib = None
 
 

@@ -379,6 +379,35 @@ def test_virtual_boundaries(built, vb, extra, kw):
     _run_stream(1920, 1080, 3, 2, 233, TOOLS_A | extra, intra=True, streams=3, virtual_boundaries=vb, **kw)
 
 
+def test_affine_motion_spanned_on_the_device(built):
+    """VVR_TOOL_AFFINE_MV_ON_DEVICE (SURVEY 8(f)-4): the back-end spans the sub-block MVs of affine CUs from the control-point MVs (PU::setAllAffineMv)
+    instead of reading them from the motion field - with the motion of the affine CUs wiped from the description the pictures are the ones the oracle
+    reconstructs from the complete description (4- and 6-parameter models, PROF, the single fallback vector of widely spread models)"""
+    import vvdec_amd
+    for W, H, seed, kw in ((416, 240, 291, dict(p_affine=0.6, p_intra=0.05)), (512, 384, 292, dict(p_affine=0.5, mv_sigma=40.0, log2_ctu=6)), (1920, 1080, 293, dict(p_affine=0.3))):
+        plans, nslots = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+        rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=2, log2_ctu=kw.get("log2_ctu", 7))
+        dpb = {}
+        n_aff = 0
+        for pl in plans:
+            d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=TOOLS_A, **kw)
+            refs = {slot: dpb[slot] for lst in pl.ref_slots for (slot, _) in lst}
+            want = refdrv.oracle_reconstruct(d, refs)
+            # wipe the motion of the affine CUs and let the device span it
+            for cu in d.cu[(d.cu["flags"] & abi.CU_AFFINE) != 0]:
+                x4, y4, w4, h4 = int(cu["x"]) >> 2, int(cu["y"]) >> 2, int(cu["w"]) >> 2, int(cu["h"]) >> 2
+                d.motion.reshape(d.h4, d.w4)["mv"][y4:y4 + h4, x4:x4 + w4] = 0
+                n_aff += 1
+            d.hdr.tool_flags |= abi.TOOL_AFFINE_MV_ON_DEVICE
+            rec.wait(rec.decompress_picture(d))
+            got = rec.read_picture(pl.slot)
+            for c in range(3):
+                assert np.array_equal(got[c], want[c]), "POC %d comp %d: %d samples differ" % (pl.poc, c, int((got[c] != want[c]).sum()))
+            dpb[pl.slot] = want
+        rec.close()
+        assert n_aff > 10
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

@@ -332,3 +332,24 @@ def test_oracle_equals_reference_virtual_boundaries(built, W, H, l2, idx, seed, 
     d.hdr.num_ver_vb = d.hdr.num_hor_vb = 0
     other = refdrv.oracle_reconstruct(d, refs, flags=0)
     assert any(not np.array_equal(x, y) for x, y in zip(other, final))
+
+
+@pytest.mark.parametrize("W,H,l2,idx,seed,kw", [(384, 256, 7, 2, 281, dict(p_affine=0.6, p_intra=0.05)), (416, 240, 6, 1, 282, dict(p_affine=0.5, mv_sigma=30.0, p_intra=0.1)),
+                                                  (256, 128, 5, 3, 283, dict(p_affine=0.7, p_intra=0.0, mv_sigma=60.0))])
+def test_affine_motion_spanned_by_the_reference(built, W, H, l2, idx, seed, kw):
+    """the sub-block MVs the descriptions carry for affine CUs are what the reference's own PU::setAllAffineMv spans from the control-point MVs (incl.
+    the single fallback vector when the sub-block vectors spread too far): the reference fills the motion of the affine CUs itself and ends with the
+    same motion field and the same picture.  Pins the restatement the device-side spanning (VVR_TOOL_AFFINE_MV_ON_DEVICE) is tested against."""
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=ALL | abi.TOOL_PROF, log2_ctu=l2, **kw)
+    aff = (d.cu["flags"] & abi.CU_AFFINE) != 0
+    assert aff.sum() >= 3
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc))
+    a, ma = refdrv.reconstruct_with_motion(d, refs, flags=0)
+    b, mb = refdrv.reconstruct_with_motion(d, refs, flags=refdrv.SPAN_AFFINE)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert ma.tobytes() == mb.tobytes()

@@ -726,6 +726,24 @@ __device__ __forceinline__ bool aff_spread_over_limit( int a, int b, int c, int 
   return rw * rh > ( ft + 5 ) * ( ft + 9 );
 }
 
+// MV of the 4x4 luma sub-block (wx, wy) of an affine CU for list l, spanned from the CU's control points the way the motion field is filled on the
+// host (PU::setAllAffineMv, UnitTools.cpp:2689-2810): the affine model evaluated at the sub-block's centre in 1/16 sample with 7 fractional bits
+// more, rounded away from zero at .5, clipped to the 18-bit MV storage range; ONE vector for the whole CU (the model at the CU's centre) when the
+// sub-block vectors would spread too far (isSubblockVectorSpreadOverLimit, InterPrediction.cpp:892).  VVR_TOOL_AFFINE_MV_ON_DEVICE.
+__device__ __forceinline__ void aff_span_mv( const vvr_cu& cu, int l, int wx, int wy, int& mx, int& my )
+{
+  const int lw = ilog2( cu.w ), lh = ilog2( cu.h );
+  const int dHX = ( cu.mv[l][1][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lw ) ), dHY = ( cu.mv[l][1][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lw ) );
+  int dVX, dVY;
+  if( cu.flags & VVR_CU_AFFINE_6P ) { dVX = ( cu.mv[l][2][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lh ) ); dVY = ( cu.mv[l][2][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lh ) ); }
+  else { dVX = -dHY; dVY = dHX; }
+  const bool over = aff_spread_over_limit( dHX, dHY, dVX, dVY, cu.inter_dir );
+  const int px = over ? cu.w >> 1 : 2 + 4 * wx, py = over ? cu.h >> 1 : 2 + 4 * wy;
+  mx = cu.mv[l][0][0] * 128 + dHX * px + dVX * py; my = cu.mv[l][0][1] * 128 + dHY * px + dVY * py;
+  aff_round_mv( mx, my, 7 );
+  mx = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mx ); my = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, my );
+}
+
 // one 4x4 sub-block sample: the four (xFrac, yFrac) cases of xPredAffineBlk (:1224-1236) = xPredInterBlk's arithmetic
 __device__ __forceinline__ int aff_sample( const pel_t* win, int wst, const pel_t* tmp, const AffSeg& g, int comp, bool bi, int bd, int px, int py )
 {
@@ -784,6 +802,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   {
     const int horMax = ( pic.hdr.width + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - cu.x + 1 ) * 16;
     const int verMax = ( pic.hdr.height + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - cu.y + 1 ) * 16;
+    const bool onDev = ( pic.hdr.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) != 0;
     for( int i = tid; i < nl * ( nsb + ncb ); i += NT )
     {
       const int k = i / ( nsb + ncb ), r = i - k * ( nsb + ncb ), l = biPred ? k : l0;
@@ -791,8 +810,10 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       if( r < nsb )
       {
         const int sx = r % sbx, sy = r / sbx;
-        const vvr_motion& m = pic.affMotion[it.mv[0][0] + 4 * sy + sx];
-        const int mx = min( horMax, max( horMin, m.mv[l][0] ) ), my = min( verMax, max( verMin, m.mv[l][1] ) );
+        int smx, smy;
+        if( onDev ) aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + sx, ( ( it.y - cu.y ) >> 2 ) + sy, smx, smy );
+        else { const vvr_motion& m = pic.affMotion[it.mv[0][0] + 4 * sy + sx]; smx = m.mv[l][0]; smy = m.mv[l][1]; }
+        const int mx = min( horMax, max( horMin, smx ) ), my = min( verMax, max( verMin, smy ) );
         g.xFrac = mx & 15; g.yFrac = my & 15;
         g.x0 = it.x + 4 * sx + ( mx >> 4 ) - 3; g.y0 = it.y + 4 * sy + ( my >> 4 ) - 3;
         sh.segL[k][r] = g;
@@ -800,9 +821,20 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       else
       {
         const int q = r - nsb, sx = q % cbx, sy = q / cbx;
-        const vvr_motion& m0 = pic.affMotion[it.mv[0][0] + 4 * ( 2 * sy ) + 2 * sx];
-        const vvr_motion& m1 = pic.affMotion[it.mv[0][0] + 4 * ( 2 * sy + 1 ) + 2 * sx + 1];
-        int mx = m0.mv[l][0] + m1.mv[l][0], my = m0.mv[l][1] + m1.mv[l][1];
+        int mx, my;
+        if( onDev )
+        {
+          int ax, ay, bx, by;
+          aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + 2 * sx, ( ( it.y - cu.y ) >> 2 ) + 2 * sy, ax, ay );
+          aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + 2 * sx + 1, ( ( it.y - cu.y ) >> 2 ) + 2 * sy + 1, bx, by );
+          mx = ax + bx; my = ay + by;
+        }
+        else
+        {
+          const vvr_motion& m0 = pic.affMotion[it.mv[0][0] + 4 * ( 2 * sy ) + 2 * sx];
+          const vvr_motion& m1 = pic.affMotion[it.mv[0][0] + 4 * ( 2 * sy + 1 ) + 2 * sx + 1];
+          mx = m0.mv[l][0] + m1.mv[l][0]; my = m0.mv[l][1] + m1.mv[l][1];
+        }
         aff_round_mv( mx, my, 1 );
         mx = min( horMax, max( horMin, mx ) ); my = min( verMax, max( verMin, my ) );
         g.xFrac = mx & 31; g.yFrac = my & 31;

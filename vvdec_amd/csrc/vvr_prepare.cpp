@@ -220,7 +220,7 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
           if( l < 0 || l > 1 || ri >= h.num_ref[l] ) FAIL( VVR_ERR_PARAMETER, "GPM CU: bad reference" );
         }
       }
-      if( isAff != ( ( cu.flags & VVR_CU_AFFINE ) != 0 ) || ( isAff && ( !p->motion || cu.w < 8 || cu.h < 8 ) ) ) FAIL( VVR_ERR_PARAMETER, "affine CU: mc_mode / flag mismatch, missing motion field or CU smaller than 8x8" );
+      if( isAff != ( ( cu.flags & VVR_CU_AFFINE ) != 0 ) || ( isAff && ( ( !p->motion && !( h.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) ) || cu.w < 8 || cu.h < 8 ) ) ) FAIL( VVR_ERR_PARAMETER, "affine CU: mc_mode / flag mismatch, missing motion field or CU smaller than 8x8" );
       if( isDmvr && ( !( h.tool_flags & VVR_TOOL_DMVR ) || ( cu.mc_mode == VVR_MC_DMVR_BDOF && !( h.tool_flags & VVR_TOOL_BDOF ) ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
         FAIL( VVR_ERR_PARAMETER, "mc_mode DMVR on a CU that cannot use DMVR (UnitTools.cpp:1277)" );
       if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
@@ -619,7 +619,8 @@ int PrepScratch::buildWorkLists( std::string& err )
       {
         McItem it; memset( &it, 0, sizeof( it ) );
         it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y ); it.flags = sbt ? MC_ITEM_SUBBLOCK : 0; it.cu = i;
-        if( af )
+        if( af && ( h.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) ) it.mv[0][0] = -1;      // the kernel spans the sub-block MVs from the control points itself
+        else if( af )
         {
           // the motion of the tile's 4x4 sub-blocks (MotionInfo of the affine CU, filled by PU::setAllAffineMv, UnitTools.cpp:3005): the kernel reads
           // them from a compact array, 4 x 4 entries per tile, so the motion field itself never crosses PCIe
