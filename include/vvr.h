@@ -98,6 +98,10 @@ enum {
   VVR_TOOL_NO_LF_ACROSS_TILES  = 1u << 23,  /* !pps_loop_filter_across_tiles_enabled_flag, likewise for tile boundaries                              */
   VVR_TOOL_AFFINE_MV_ON_DEVICE = 1u << 24,  /* the sub-block MVs of affine CUs are spanned by the back-end from the CU's control-point MVs (cu.mv[list][0..2];
                                                PU::setAllAffineMv, UnitTools.cpp:2689): vvr_picture.motion is not read for affine CUs and need not hold them   */
+  VVR_TOOL_COL_MOTION   = 1u << 25,  /* the back-end keeps the picture's collocated motion (the TMVP storage of later pictures): vvr_picture.motion at every
+                                        second 4x4 unit in both directions, with the MVs of DMVR CUs replaced by the refined ones as soon as the DMVR
+                                        kernel has them (DecCu::TaskFinishMotionInfo, DecCu.cpp:161-253).  vvr_read_col_motion() hands it out; the host
+                                        neither reads the delta MVs nor patches / subsamples its motion field                                      */
 };
 
 typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::reconstructCoeff (AdaptiveLoopFilter.cpp:888) stays on the host */
@@ -405,6 +409,10 @@ VVR_API int          vvr_picture_hash(vvr_context* ctx, int slot, int method, ui
 VVR_API int          vvr_write_plane(vvr_context* ctx, int slot, int comp, const uint16_t* src, size_t src_stride_samples);
 /* DMVR refined delta MVs of job (TaskFinishMotionInfo, DecCu.cpp:161): copies num_entries * 2 int32 */
 VVR_API int          vvr_read_dmvr(vvr_context* ctx, int job, int32_t* dst, size_t num_entries);
+/* Collocated motion of a picture submitted with VVR_TOOL_COL_MOTION (blocks until the job is done): ceil(w4 / 2) * ceil(h4 / 2) records in raster order,
+ * record (x, y) = the final motion of the 4x4 unit (2x, 2y) - the layout of ColocatedMotionInfo = MotionInfo (MotionInfo.h:157), what
+ * DecCu::TaskFinishMotionInfo leaves in CtuData::colMotion.  Returns the number of records of the picture (copies at most num_entries), < 0 on error. */
+VVR_API int          vvr_read_col_motion(vvr_context* ctx, int job, vvr_motion* dst, size_t num_entries);
 /* Two-step submission for pipelined hosts and for the synthetic pre-parsed stream benchmark:
  * vvr_prepare validates the description, runs the host glue (builds the device work lists the reference iterates over
  * in DecCu::TaskTrafoCtu / TaskInterCtu, DecCu.cpp:106-134) and makes everything resident in HBM;

@@ -408,6 +408,43 @@ def test_affine_motion_spanned_on_the_device(built):
         assert n_aff > 10
 
 
+def test_collocated_motion_on_the_device(built):
+    """VVR_TOOL_COL_MOTION: the collocated motion the back-end hands out - the motion field at every second 4x4 unit with the
+    DMVR-refined MVs written by the DMVR kernel - is what the reference's DecCu::TaskFinishMotionInfo leaves for the same picture (its final motion
+    field, sub-sampled), through vvr_submit with worker threads and through vvr_prepare / vvr_submit_prepared"""
+    import vvdec_amd
+    if not refdrv.available():
+        pytest.skip("reference build not present")
+    T = TOOLS_A | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_STILL_REF       # (still referenced: the reference finishes the motion of such pictures only, DecLibRecon.cpp:1080-1100)
+    for W, H, seed, kw in ((416, 240, 301, dict(p_bi=0.9, p_intra=0.05, mv_sigma=2.0)), (512, 384, 302, dict(p_bi=0.8, p_affine=0.2, log2_ctu=6, mv_sigma=3.0))):
+        plans, nslots = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+        rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=2, log2_ctu=kw.get("log2_ctu", 7), host_threads=2)
+        dpb = {}
+        refined = 0
+        for k, pl in enumerate(plans):
+            d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=T, **kw)
+            refs = {slot: dpb[slot] for lst in pl.ref_slots for (slot, _) in lst}
+            planes, motion = refdrv.reconstruct_with_motion(d, refs, flags=0)
+            want = motion.reshape(d.h4, d.w4)[::2, ::2].reshape(-1)
+            d.hdr.tool_flags |= abi.TOOL_COL_MOTION
+            if k & 1:
+                hnd = rec.prepare(d)
+                job = rec.submit_prepared(hnd)
+            else:
+                job = rec.decompress_picture(d)
+            got = rec.read_col_motion(job)
+            if k & 1:
+                rec.free_prepared(hnd)
+            assert len(got) == len(want)
+            assert np.array_equal(got["mv"], want["mv"]) and np.array_equal(got["ref_idx"], want["ref_idx"]), "POC %d: %d records differ" % (pl.poc, int((got["mv"] != want["mv"]).any(axis=(1, 2)).sum()))
+            refined += int((want["mv"] != d.motion.reshape(d.h4, d.w4)[::2, ::2].reshape(-1)["mv"]).any(axis=(1, 2)).sum())
+            got_planes = rec.read_picture(pl.slot)
+            assert all(np.array_equal(g, w) for g, w in zip(got_planes, planes))
+            dpb[pl.slot] = planes
+        rec.close()
+        assert refined > 0          # DMVR moved something: the test is about the refined vectors
+
+
 def test_unsupported_tools_fail_loudly(built):
     import vvdec_amd
     rec = vvdec_amd.Reconstructor(128, 64, num_slots=2)

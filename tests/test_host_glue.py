@@ -672,3 +672,43 @@ def test_pipeline_under_load_does_not_stall(stub):
     finally:
         stub.vvt_set_delay(0)
     stub.vvr_destroy(ctx)
+
+
+def test_collocated_motion_host_stage(stub):
+    """VVR_TOOL_COL_MOTION against the stand-in runtime (no DMVR kernel runs): what vvr_read_col_motion returns is the motion field at every second
+    4x4 unit in both directions, for odd numbers of 4x4 columns / rows too, with worker threads and through prepared handles; asking without a
+    motion field is refused"""
+    stub.vvr_read_col_motion.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    stub.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+    for (W, H, threads) in ((200, 136, 0), (416, 240, 2)):
+        plans, nslots = stream.ra_plan(3, gop=2, seed_poc0_is_external=False)
+        cfg = abi.Config()
+        cfg.abi_version = abi.VVR_ABI_VERSION
+        cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, 7
+        cfg.num_slots, cfg.num_streams, cfg.host_threads = nslots, 2, threads
+        ctx = C.c_void_p()
+        assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+        for k, pl in enumerate(plans):
+            d = synth.picture_for_plan(pl, W, H, seed=521, tool_flags=TOOLS | abi.TOOL_COL_MOTION, p_intra=0.1, p_bi=0.8)
+            p = d.c()
+            if k == 1:
+                h = C.c_void_p()
+                assert stub.vvr_prepare(ctx, C.byref(p), C.byref(h)) == abi.VVR_OK
+                job = stub.vvr_submit_prepared(ctx, h)
+            else:
+                job = stub.vvr_submit(ctx, C.byref(p))
+            assert job >= 0
+            n = stub.vvr_read_col_motion(ctx, job, None, 0)
+            assert n == ((d.w4 + 1) // 2) * ((d.h4 + 1) // 2)
+            got = np.zeros(n, np.dtype(abi.Motion))
+            assert stub.vvr_read_col_motion(ctx, job, got.ctypes.data_as(C.c_void_p), n) == n
+            want = d.motion.reshape(d.h4, d.w4)[::2, ::2].reshape(-1)
+            assert got.tobytes() == want.tobytes()
+            if k == 1:
+                stub.vvr_free_prepared(ctx, h)
+        d.motion = None
+        p = d.c()
+        job = stub.vvr_submit(ctx, C.byref(p))
+        assert job == abi.VVR_ERR_PARAMETER or stub.vvr_wait(ctx, job) == abi.VVR_ERR_PARAMETER
+        stub.vvr_destroy(ctx)

@@ -69,6 +69,8 @@ def lib():
         L.vvr_read_output.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_size_t]
         L.vvr_read_dmvr.restype = C.c_int
         L.vvr_read_dmvr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.vvr_read_col_motion.restype = C.c_int
+        L.vvr_read_col_motion.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.vvr_enable_stats.argtypes = [C.c_void_p, C.c_int]
         L.vvr_get_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.vvr_plane_layout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -84,7 +86,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
-                    "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_picture_hash", "vvr_write_plane", "vvr_read_dmvr", "vvr_prepare", "vvr_submit_prepared",
+                    "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_picture_hash", "vvr_write_plane", "vvr_read_dmvr", "vvr_read_col_motion", "vvr_prepare", "vvr_submit_prepared",
                     "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof",
                     "vvr_inputs_done", "vvr_measure_copy_bandwidth", "vvr_host_alloc", "vvr_host_free"]
 
@@ -166,6 +168,14 @@ class Reconstructor:
         a = np.zeros((max(1, n), 2), np.int32)
         self._check(self.L.vvr_read_dmvr(self.ctx, job, a.ctypes.data, n))
         return a[:n]
+
+    def read_col_motion(self, job):
+        """collocated motion of a picture submitted with TOOL_COL_MOTION: abi.Motion records, ((h4 + 1) // 2) * ((w4 + 1) // 2) of them in raster order"""
+        n = self._check(self.L.vvr_read_col_motion(self.ctx, job, None, 0))
+        a = np.zeros(n, np.dtype(abi.Motion))
+        if n:
+            self._check(self.L.vvr_read_col_motion(self.ctx, job, a.ctypes.data, n))
+        return a
 
     # -- resident pictures (pre-parsed stream already in HBM)
     def prepare(self, d: PictureDesc):

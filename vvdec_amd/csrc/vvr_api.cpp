@@ -53,6 +53,7 @@ struct RingEntry {
   char* host = nullptr; size_t hostCap = 0;
   char* dev = nullptr;  size_t devCap = 0;
   int32_t* dmvrHost = nullptr; size_t dmvrCap = 0;      // ints
+  vvr_motion* colHost = nullptr; size_t colCap = 0;     // records: collocated motion of the picture (VVR_TOOL_COL_MOTION), pinned + device-mapped
   hipEvent_t copied = nullptr;
   vvr_prepared q;
   size_t stagedBegin = 0, stagedEnd = 0;                // the part of the image that goes through `host`
@@ -78,6 +79,7 @@ struct Job {
   bool completed = false, waited = false;
   std::vector<PendingTiming> timings;
   std::vector<int32_t> dmvr;        // delta MVs, copied out of pinned memory when the job completes
+  std::vector<vvr_motion> col;      // collocated motion (VVR_TOOL_COL_MOTION), likewise
 #ifdef VVR_WATCHDOG
   double tSubmit = 0, tPrep = 0, tBuilt = 0, tRing = 0, tReady = 0, tCommit0 = 0, tCommit1 = 0;      // developer build: where a picture spends its time on the host
 #endif
@@ -184,6 +186,7 @@ static void completeLocked( vvr_context* c, Job& j )
     const int32_t* src = j.ring ? j.ring->dmvrHost : j.q->dmvrHost;
     j.dmvr.assign( src, src + 2 * (size_t) j.q->numDmvr );
   }
+  if( j.q && j.q->colHost && j.state == J_COMMITTED ) j.col.assign( j.q->colHost, j.q->colHost + j.q->numCol );
   if( j.ring && j.ring->owner == &j ) { j.ring->owner = nullptr; j.ring->turn += c->ring.size(); }
   if( j.done ) { c->eventPool.push_back( j.done ); j.done = nullptr; }
   if( j.doneHost ) { c->eventPool.push_back( j.doneHost ); j.doneHost = nullptr; }
@@ -469,8 +472,26 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
     vvr_host_pack( S, e.host );
     vvr_host_bind( S, e.q, e.dev );
     vvr_host_upload_plan( S, e.direct, &e.stagedBegin, &e.stagedEnd );
+    e.q.colHost = nullptr; e.q.numCol = 0; e.q.pic.colMotion = nullptr; e.q.pic.colStride = 0;
+    if( job.pic.hdr.tool_flags & VVR_TOOL_COL_MOTION )
+    {
+      // collocated motion: the unrefined subsample is written here by this thread, the DMVR kernel replaces the MVs it refines
+      const size_t n = vvr_host_num_col( &job.pic );
+      if( n > e.colCap )
+      {
+        if( e.colHost ) { std::lock_guard<std::mutex> lk( c->mu ); c->retiredHost.push_back( (char*) e.colHost ); }
+        e.colHost = nullptr; e.colCap = 0;
+        const size_t cap = std::max( n, ( ( (size_t) c->cfg.max_width + 7 ) >> 3 ) * ( ( (size_t) c->cfg.max_height + 7 ) >> 3 ) );
+        if( hipHostMalloc( (void**) &e.colHost, sizeof( vvr_motion ) * cap, hipHostMallocDefault ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipHostMalloc failed"; } else e.colCap = cap;
+      }
+      if( rc == VVR_OK )
+      {
+        vvr_host_gather_col( &job.pic, e.colHost );
+        e.q.colHost = e.colHost; e.q.numCol = n; e.q.pic.colMotion = e.colHost; e.q.pic.colStride = (int) ( ( ( ( job.pic.hdr.width + 3 ) >> 2 ) + 1 ) >> 1 );
+      }
+    }
     const size_t nInts = 2 * (size_t) e.q.numDmvr;
-    if( nInts > e.dmvrCap )
+    if( rc == VVR_OK && nInts > e.dmvrCap )
     {
       if( e.dmvrHost ) { std::lock_guard<std::mutex> lk( c->mu ); c->retiredHost.push_back( (char*) e.dmvrHost ); }
       e.dmvrHost = nullptr; e.dmvrCap = 0;
@@ -693,7 +714,7 @@ VVR_API void vvr_destroy( vvr_context* c )
 #endif
   for( auto& kv : c->jobs ) { Job& j = *kv.second; for( auto& t : j.timings ) { hipEventDestroy( t.a ); hipEventDestroy( t.b ); } if( j.done ) hipEventDestroy( j.done ); if( j.doneHost ) hipEventDestroy( j.doneHost ); }
   for( auto e : c->eventPool ) hipEventDestroy( e );
-  for( auto& e : c->ring ) { if( e.host ) hipHostFree( e.host ); if( e.dev ) hipFree( e.dev ); if( e.dmvrHost ) hipHostFree( e.dmvrHost ); if( e.copied ) hipEventDestroy( e.copied ); }
+  for( auto& e : c->ring ) { if( e.host ) hipHostFree( e.host ); if( e.dev ) hipFree( e.dev ); if( e.dmvrHost ) hipHostFree( e.dmvrHost ); if( e.colHost ) hipHostFree( e.colHost ); if( e.copied ) hipEventDestroy( e.copied ); }
   for( auto p : c->retiredHost ) hipHostFree( p );
   for( auto p : c->retiredDev ) hipFree( p );
   for( auto s : c->streams ) if( s ) hipStreamDestroy( s );
@@ -836,6 +857,7 @@ VVR_API void vvr_free_prepared( vvr_context* c, vvr_prepared* q )
   }
   if( q->blob ) hipFree( q->blob );
   if( q->dmvrHost ) hipHostFree( q->dmvrHost );
+  if( q->colHost ) hipHostFree( q->colHost );
   delete q;
 }
 
@@ -862,6 +884,13 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   vvr_host_upload_plan( S, none, &b0, &b1 );
   const hipError_t e = hipMemcpy( q->blob, staging, b1, hipMemcpyHostToDevice );
   hipHostFree( staging );
+  if( e == hipSuccess && ( p->hdr.tool_flags & VVR_TOOL_COL_MOTION ) )
+  {
+    q->numCol = vvr_host_num_col( p );
+    if( hipHostMalloc( (void**) &q->colHost, sizeof( vvr_motion ) * q->numCol, hipHostMallocDefault ) != hipSuccess ) { vvr_free_prepared( c, q ); c->setError( "vvr_prepare: out of pinned memory" ); return VVR_ERR_DEVICE; }
+    vvr_host_gather_col( p, q->colHost );          // (a handle submitted again starts from the motion its last run left: refinement is a function of the picture alone)
+    q->pic.colMotion = q->colHost; q->pic.colStride = (int) ( ( ( ( p->hdr.width + 3 ) >> 2 ) + 1 ) >> 1 );
+  }
   if( e == hipSuccess && q->numDmvr && hipHostMalloc( (void**) &q->dmvrHost, sizeof( int32_t ) * 2 * (size_t) q->numDmvr, hipHostMallocDefault ) != hipSuccess )
   { vvr_free_prepared( c, q ); c->setError( "vvr_prepare: out of pinned memory" ); return VVR_ERR_DEVICE; }
   if( e != hipSuccess ) { vvr_free_prepared( c, q ); c->setError( "H2D copy failed" ); return VVR_ERR_DEVICE; }
@@ -932,6 +961,22 @@ VVR_API int vvr_read_dmvr( vvr_context* c, int job, int32_t* dst, size_t numEntr
   const size_t n = std::min( numEntries, j.dmvr.size() / 2 );
   if( n ) memcpy( dst, j.dmvr.data(), sizeof( int32_t ) * 2 * n );
   return (int) ( j.dmvr.size() / 2 );
+}
+
+VVR_API int vvr_read_col_motion( vvr_context* c, int job, vvr_motion* dst, size_t numEntries )
+{
+  if( !c || ( !dst && numEntries ) ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  { std::lock_guard<std::mutex> lk( c->mu ); if( c->jobs.find( job ) == c->jobs.end() ) { c->setError( "vvr_read_col_motion: job already retired" ); return VVR_ERR_PARAMETER; } }
+  const int rc = finishJob( c, job );
+  if( rc != VVR_OK ) return rc;
+  std::lock_guard<std::mutex> lk( c->mu );
+  auto it = c->jobs.find( job );
+  if( it == c->jobs.end() ) { c->setError( "vvr_read_col_motion: job already retired" ); return VVR_ERR_PARAMETER; }
+  Job& j = *it->second;
+  const size_t n = std::min( numEntries, j.col.size() );
+  if( n ) memcpy( dst, j.col.data(), sizeof( vvr_motion ) * n );
+  return (int) j.col.size();
 }
 
 VVR_API int vvr_enable_stats( vvr_context* c, int on ) { if( !c ) return VVR_ERR_PARAMETER; vvr_sync( c ); std::lock_guard<std::mutex> lk( c->mu ); c->statsOn = on != 0; for( auto& s : c->stats ) s = Stat(); return VVR_OK; }

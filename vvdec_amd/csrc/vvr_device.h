@@ -99,6 +99,8 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
   const uint16_t*    ctuTile;
   const uint8_t*     interAt;        // per 4x4 luma unit: 1 = covered by an inter CU (LMCS forward mapping of the prediction)
   const uint32_t*    csVpdu;         // LMCS chroma residual scaling, per VPDU: x | y << 13 | hasLeft << 26 | hasAbove << 27 of the luma neighbourhood the factor is averaged over
+  vvr_motion*        colMotion;      // collocated motion of the picture (pinned host memory, device-mapped; NULL unless VVR_TOOL_COL_MOTION): the DMVR kernel patches it
+  int                colStride;      // records per row = ( w4 + 1 ) / 2
   int                vpdusX, vpduLog2;
   int                w4, h4, ctus_x, ctus_y;
 };

@@ -27,6 +27,7 @@ struct vvr_prepared {
   // ownership (vvr_prepare handles only)
   void*    blob = nullptr; size_t blobBytes = 0;
   int32_t* dmvrHost = nullptr;                             // pinned + device-mapped, 2 * numDmvr ints: the DMVR kernel writes the delta MVs here
+  vvr_motion* colHost = nullptr; size_t numCol = 0;        // pinned + device-mapped: collocated motion (VVR_TOOL_COL_MOTION), filled by the host stage, patched by the DMVR kernel
   struct vvr_context* owner = nullptr;
 };
 
@@ -57,6 +58,9 @@ int    vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes,
 // the H2D image: every staged part at its offset (256-byte aligned) into `host` (pinned memory of at least totalBytes); the parts that are
 // copied straight from the caller's pinned arrays, and the byte range [begin, end) of the image that is staged
 void   vvr_host_pack( const PrepScratch& S, char* host );
+// collocated motion before refinement: every second 4x4 unit of the picture's motion field in both directions (DecCu.cpp:232-253); dst holds vvr_host_num_col() records
+size_t vvr_host_num_col( const vvr_picture* p );
+void   vvr_host_gather_col( const vvr_picture* p, vvr_motion* dst );
 void   vvr_host_upload_plan( const PrepScratch& S, std::vector<DirectCopy>& direct, size_t* stagedBegin, size_t* stagedEnd );
 // device pointers of a prepared picture whose image sits at devBase
 void   vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* devBase );

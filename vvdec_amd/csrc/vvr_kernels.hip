@@ -629,6 +629,17 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
       sh.bioSub = ( minCost < (unsigned) ( 2 * w * h ) ) ? 0 : ( bio ? 1 : 0 );
       const int sub = ( ( it.y - cu.y ) / min( 16, (int) cu.h ) ) * ( ( cu.w + 15 ) >> 4 ) + ( ( it.x - cu.x ) >> 4 );
       dmvrOut[2 * ( cu.dmvr_off + sub )] = total0; dmvrOut[2 * ( cu.dmvr_off + sub ) + 1] = total1;
+      if( pic.colMotion )
+      {
+        // collocated motion (VVR_TOOL_COL_MOTION): the 4x4 units at multiples of 8 luma samples inside the sub-block get the refined MVs, list 0 plus,
+        // list 1 minus the delta (DecCu::TaskFinishMotionInfo, DecCu.cpp:186-213)
+        for( int y2 = ( it.y + 7 ) & ~7; y2 < it.y + h; y2 += 8 ) for( int x2 = ( it.x + 7 ) & ~7; x2 < it.x + w; x2 += 8 )
+        {
+          vvr_motion& m = pic.colMotion[( y2 >> 3 ) * pic.colStride + ( x2 >> 3 )];
+          m.mv[0][0] = cu.mv[0][0][0] + total0; m.mv[0][1] = cu.mv[0][0][1] + total1;
+          m.mv[1][0] = cu.mv[1][0][0] - total0; m.mv[1][1] = cu.mv[1][0][1] - total1;
+        }
+      }
     }
     __syncthreads();
   }

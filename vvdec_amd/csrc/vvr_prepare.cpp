@@ -135,6 +135,7 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
   if( h.out_slot < 0 || h.out_slot >= cfg.num_slots ) FAIL( VVR_ERR_PARAMETER, "out_slot out of range" );
   if( h.slice_type > 2 ) FAIL( VVR_ERR_PARAMETER, "unknown slice type" );
   if( h.ladf_num_intervals == 1 || h.ladf_num_intervals > 5 ) FAIL( VVR_ERR_PARAMETER, "LADF: 2..5 intervals" );
+  if( ( h.tool_flags & VVR_TOOL_COL_MOTION ) && !p->motion ) FAIL( VVR_ERR_PARAMETER, "collocated motion requested without a motion field" );
   if( h.num_ver_vb > 3 || h.num_hor_vb > 3 ) FAIL( VVR_ERR_PARAMETER, "at most three virtual boundaries per direction" );
   for( int d = 0; d < 2; d++ )
   {
@@ -1044,6 +1045,23 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
   S.layout( pinned );
   *totalBytes = S.total;
   return VVR_OK;
+}
+
+size_t vvr_host_num_col( const vvr_picture* p )
+{
+  const size_t w4 = ( p->hdr.width + 3 ) >> 2, h4 = ( p->hdr.height + 3 ) >> 2;
+  return ( ( w4 + 1 ) >> 1 ) * ( ( h4 + 1 ) >> 1 );
+}
+
+void vvr_host_gather_col( const vvr_picture* p, vvr_motion* dst )
+{
+  const size_t w4 = ( p->hdr.width + 3 ) >> 2, h4 = ( p->hdr.height + 3 ) >> 2, w8 = ( w4 + 1 ) >> 1;
+  for( size_t y = 0; y < h4; y += 2 )
+  {
+    const vvr_motion* src = p->motion + y * w4;
+    vvr_motion* d = dst + ( y >> 1 ) * w8;
+    for( size_t x = 0; x < w4; x += 2 ) d[x >> 1] = src[x];
+  }
 }
 
 void vvr_host_pack( const PrepScratch& S, char* host )
