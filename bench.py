@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--pageable-records", action="store_true", help="keep the host records in ordinary (pageable) memory: the library stages them through its pinned ring")
     ap.add_argument("--no-picture-sharding", action="store_true", help="N > 1: skip the additional pass that shards ONE stream by picture over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stop-after", type=int, default=0, help="developer: end the kernel chain after the reconstruction (1), deblocking (2) or SAO (3) stage, to see what a stage costs; needs --verify 0")
     ap.add_argument("--verify", type=int, default=8, help="number of timed pictures re-checked against the CPU oracle after the run")
     a = ap.parse_args()
 
@@ -221,7 +222,7 @@ def main():
     plans, nslots, first = stream_plan(a.config, a.gop, intra_period, a.irap_lookahead, a.slots, K, Wm)
     n_irap = sum(1 for pl in plans[first:first + K] if pl.slice_type == abi.SLICE_I)
     seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
-    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads, ring_entries=a.ring)
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads, ring_entries=a.ring, stop_after=a.stop_after)
     # the records are written where a parser integrated with the back-end would write them: host memory the device reads directly (vvr_host_alloc)
     descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, alloc=None if a.pageable_records else rec.host_array, **mix) for pl in plans]
     cpics = [d.c() for d in descs]                     # the host records as the C ABI sees them (plain structs pointing at the arrays)

@@ -598,7 +598,9 @@ static Job* newJobLocked( vvr_context* c )
 
 extern "C" {
 
-VVR_API const char* vvr_version( void ) { return "vvdec_amd 0.2 (gfx950, ABI 1)"; }
+#define VVR_STR2( x ) #x
+#define VVR_STR( x ) VVR_STR2( x )
+VVR_API const char* vvr_version( void ) { return "vvdec_amd 0.3 (gfx950, ABI " VVR_STR( VVR_ABI_VERSION ) ")"; }
 
 VVR_API size_t vvr_abi_sizeof( int which )
 {

@@ -1659,23 +1659,15 @@ __device__ __forceinline__ void alf_clip_coord( const AlfClip& k, int& x, int& y
 // the luma position (lx, ly): the CTU's clip `k` (component cs) narrowed to that part.  The corner padding of raster-scan slices belongs to the
 // part at the CTU's origin / end only, which is what remains of it when the clipped sides are applied first (alf_clip_coord).
 __device__ __forceinline__ bool vb_present( const PicDev& pic ) { return ( pic.hdr.num_ver_vb | pic.hdr.num_hor_vb ) != 0; }
+// (the boundary positions are read with constant indices: a run-time index into the by-value kernel argument would make the compiler keep an addressable
+// copy of it per thread, in LDS)
+#define VB_EACH_X( BODY ) { if( pic.hdr.num_ver_vb > 0 ) { const int v = pic.hdr.vb_pos_x[0]; BODY } if( pic.hdr.num_ver_vb > 1 ) { const int v = pic.hdr.vb_pos_x[1]; BODY } if( pic.hdr.num_ver_vb > 2 ) { const int v = pic.hdr.vb_pos_x[2]; BODY } }
+#define VB_EACH_Y( BODY ) { if( pic.hdr.num_hor_vb > 0 ) { const int v = pic.hdr.vb_pos_y[0]; BODY } if( pic.hdr.num_hor_vb > 1 ) { const int v = pic.hdr.vb_pos_y[1]; BODY } if( pic.hdr.num_hor_vb > 2 ) { const int v = pic.hdr.vb_pos_y[2]; BODY } }
 __device__ __forceinline__ AlfClip alf_clip_vb( const PicDev& pic, AlfClip k, int lx, int ly, int cs )
 {
   const int S = 1 << pic.hdr.log2_ctu, cx0 = lx & ~( S - 1 ), cy0 = ly & ~( S - 1 );
-  for( int i = 0; i < pic.hdr.num_ver_vb; i++ )
-  {
-    const int v = pic.hdr.vb_pos_x[i];
-    if( v < cx0 || v > cx0 + S ) continue;
-    if( v <= lx ) { k.f = ( k.f | 1 ) & ~16u; k.x0 = max( k.x0, v >> cs ); }
-    else          { k.f = ( k.f | 2 ) & ~32u; k.x1 = min( k.x1, ( v >> cs ) - 1 ); }
-  }
-  for( int i = 0; i < pic.hdr.num_hor_vb; i++ )
-  {
-    const int v = pic.hdr.vb_pos_y[i];
-    if( v < cy0 || v > cy0 + S ) continue;
-    if( v <= ly ) { k.f = ( k.f | 4 ) & ~16u; k.y0 = max( k.y0, v >> cs ); }
-    else          { k.f = ( k.f | 8 ) & ~32u; k.y1 = min( k.y1, ( v >> cs ) - 1 ); }
-  }
+  VB_EACH_X( if( v >= cx0 && v <= cx0 + S ) { if( v <= lx ) { k.f = ( k.f | 1 ) & ~16u; k.x0 = max( k.x0, v >> cs ); } else { k.f = ( k.f | 2 ) & ~32u; k.x1 = min( k.x1, ( v >> cs ) - 1 ); } } )
+  VB_EACH_Y( if( v >= cy0 && v <= cy0 + S ) { if( v <= ly ) { k.f = ( k.f | 4 ) & ~16u; k.y0 = max( k.y0, v >> cs ); } else { k.f = ( k.f | 8 ) & ~32u; k.y1 = min( k.y1, ( v >> cs ) - 1 ); } } )
   return k;
 }
 // SAO: a sample in the column (row) on either side of a virtual boundary is left alone by the edge classes that look across it
@@ -1683,9 +1675,10 @@ __device__ __forceinline__ AlfClip alf_clip_vb( const PicDev& pic, AlfClip k, in
 // horizontal ones, :112,156).  x, y in component samples.
 __device__ __forceinline__ bool sao_at_vb( const PicDev& pic, int x, int y, int cs, bool ver, bool hor )
 {
-  if( ver ) for( int i = 0; i < pic.hdr.num_ver_vb; i++ ) { const int v = pic.hdr.vb_pos_x[i] >> cs; if( x == v || x == v - 1 ) return true; }
-  if( hor ) for( int i = 0; i < pic.hdr.num_hor_vb; i++ ) { const int v = pic.hdr.vb_pos_y[i] >> cs; if( y == v || y == v - 1 ) return true; }
-  return false;
+  bool at = false;
+  if( ver ) VB_EACH_X( { const int p = v >> cs; at = at || x == p || x == p - 1; } )
+  if( hor ) VB_EACH_Y( { const int p = v >> cs; at = at || y == p || y == p - 1; } )
+  return at;
 }
 
 // =====================================================================================================================
@@ -1695,74 +1688,93 @@ __device__ __forceinline__ bool sao_at_vb( const PicDev& pic, int x, int y, int 
 __global__ __launch_bounds__( 256 ) void k_sao( PicDev pic, DevPlanes src, DevPlanes dst )
 {
   // eight consecutive samples of a row per thread (one 16-byte load / store; they share a CTU, hence the SAO parameters); a wavefront
-  // covers 512 samples of a row, a workgroup four rows
+  // covers 512 samples of a row, a workgroup four rows.  Everything a thread may need is loaded before anything is looked at - its own
+  // eight samples, the eight above and below, the CTU's parameters - so that the kernel pays ONE memory round trip (it used to pay three:
+  // parameters, then the rows the class asks for, then their outer samples); the samples left and right of the three runs come from the
+  // neighbouring lanes, only the first and the last lane of a wavefront load them.
   const int c = blockIdx.z;
   const int cs = c ? 1 : 0;
-  const int cw = src.w[c], chh = src.h[c];
-  const int blkLin = xcd_contiguous( blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y );
-  const int x0 = ( ( blkLin % gridDim.x ) * 64 + ( threadIdx.x & 63 ) ) * 8;
-  const int y = ( blkLin / gridDim.x ) * 4 + ( threadIdx.x >> 6 );
-  if( x0 >= cw || y >= chh ) return;
+  // (selects instead of src.p[c]: a run-time index into the by-value argument makes the compiler keep a per-thread copy of the array in LDS)
+  const int cw = c ? src.w[1] : src.w[0], chh = c ? src.h[1] : src.h[0];
+  const int nbx = ( cw + 511 ) >> 9, nby = ( chh + 3 ) >> 2;                 // workgroups this plane needs (the grid is sized for luma)
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  if( blk >= nbx * nby ) return;
+  const int blkLin = xcd_contiguous( blk, nbx * nby );
+  const int lane = threadIdx.x & 63;
+  const int x0 = ( ( blkLin % nbx ) * 64 + lane ) * 8;
+  const int y = ( blkLin / nbx ) * 4 + ( threadIdx.x >> 6 );
+  if( y >= chh ) return;                                                    // (whole wavefronts leave: a wavefront is one row)
+  const bool inside = x0 < cw;
+  const int xl = inside ? x0 : 0;                                           // lanes right of the plane take part in the shuffles with harmless data
   const int bd = pic.hdr.bit_depth, ctuC = ( 1 << pic.hdr.log2_ctu ) >> cs;
-  const pel_t* __restrict__ S = src.p[c];
-  const int st = src.stride[c];
-  const uint4 cv = *reinterpret_cast<const uint4*>( &S[(size_t) y * st + x0] );
+  const pel_t* __restrict__ S = c == 0 ? src.p[0] : c == 1 ? src.p[1] : src.p[2];
+  const int st = c ? src.stride[1] : src.stride[0];
+  const int ya = max( y - 1, 0 ), yb = min( y + 1, chh - 1 );
+  const uint4 cv = *reinterpret_cast<const uint4*>( &S[(size_t) y * st + xl] );
+  const uint4 av = *reinterpret_cast<const uint4*>( &S[(size_t) ya * st + xl] );
+  const uint4 bv = *reinterpret_cast<const uint4*>( &S[(size_t) yb * st + xl] );
+  const bool enabled = pic.sao && ( pic.hdr.tool_flags & ( c ? VVR_TOOL_SAO_CHROMA : VVR_TOOL_SAO_LUMA ) );
+  const int curCtu = ( y / ctuC ) * pic.ctus_x + ( xl / ctuC );
+  int mode = 0, type = 0, bandPos = 0; int off[4] = { 0, 0, 0, 0 };
+  if( enabled )
+  {
+    const vvr_sao_ctu s = pic.sao[curCtu];
+    mode = c == 0 ? s.mode[0] : c == 1 ? s.mode[1] : s.mode[2]; type = c == 0 ? s.type[0] : c == 1 ? s.type[1] : s.type[2]; bandPos = c == 0 ? s.band_pos[0] : c == 1 ? s.band_pos[1] : s.band_pos[2];
+#pragma unroll
+    for( int k = 0; k < 4; k++ ) off[k] = c == 0 ? s.offset[0][k] : c == 1 ? s.offset[1][k] : s.offset[2][k];
+  }
+  // outer samples of the three runs: lane - 1's last and lane + 1's first sample; the wavefront's first / last lane load them
+  int cl = __shfl_up( (int) ( cv.w >> 16 ), 1 ), al = __shfl_up( (int) ( av.w >> 16 ), 1 ), bl = __shfl_up( (int) ( bv.w >> 16 ), 1 );
+  int cr = __shfl_down( (int) ( cv.x & 0xffff ), 1 ), ar = __shfl_down( (int) ( av.x & 0xffff ), 1 ), br = __shfl_down( (int) ( bv.x & 0xffff ), 1 );
+  if( lane == 0 && x0 > 0 ) { cl = S[(size_t) y * st + x0 - 1]; al = S[(size_t) ya * st + x0 - 1]; bl = S[(size_t) yb * st + x0 - 1]; }
+  if( lane == 63 && x0 + 8 < cw ) { cr = S[(size_t) y * st + x0 + 8]; ar = S[(size_t) ya * st + x0 + 8]; br = S[(size_t) yb * st + x0 + 8]; }
+  if( !inside ) return;
   int v[8] = { (int) ( cv.x & 0xffff ), (int) ( cv.x >> 16 ), (int) ( cv.y & 0xffff ), (int) ( cv.y >> 16 ), (int) ( cv.z & 0xffff ), (int) ( cv.z >> 16 ), (int) ( cv.w & 0xffff ), (int) ( cv.w >> 16 ) };
   int out[8];
 #pragma unroll
   for( int i = 0; i < 8; i++ ) out[i] = v[i];
-  const bool enabled = pic.sao && ( pic.hdr.tool_flags & ( c ? VVR_TOOL_SAO_CHROMA : VVR_TOOL_SAO_LUMA ) );
-  if( enabled )
+  if( mode )
   {
-    const vvr_sao_ctu& s = pic.sao[( y / ctuC ) * pic.ctus_x + ( x0 / ctuC )];
-    if( s.mode[c] )
+    if( type == 4 )
     {
-      const int type = s.type[c];
-      if( type == 4 )
-      {
-        // band offset (SampleAdaptiveOffset.cpp offsetBlock_core, SAO_TYPE_BO)
+      // band offset (SampleAdaptiveOffset.cpp offsetBlock_core, SAO_TYPE_BO)
 #pragma unroll
-        for( int i = 0; i < 8; i++ ) { const int k = ( ( v[i] >> ( bd - 5 ) ) - s.band_pos[c] ) & 31; if( k < 4 ) out[i] = clip_pel( v[i] + s.offset[c][k], bd ); }
-      }
-      else
+      for( int i = 0; i < 8; i++ ) { const int k = ( ( v[i] >> ( bd - 5 ) ) - bandPos ) & 31; if( k < 4 ) out[i] = clip_pel( v[i] + ( k == 0 ? off[0] : k == 1 ? off[1] : k == 2 ? off[2] : off[3] ), bd ); }
+    }
+    else
+    {
+      // edge offset: neighbours a = ( x - dx, y - dy ), b = ( x + dx, y + dy ); nothing across the picture boundary
+      const int dx = type == 1 ? 0 : ( type == 3 ? -1 : 1 ), dy = type == 0 ? 0 : 1;
+      if( y - dy >= 0 && y + dy < chh )
       {
-        // edge offset: neighbours a = ( x - dx, y - dy ), b = ( x + dx, y + dy ); nothing across the picture boundary
-        const int dx = type == 1 ? 0 : ( type == 3 ? -1 : 1 ), dy = type == 0 ? 0 : 1;
-        const int ya = y - dy, yb = y + dy;
-        if( ya >= 0 && yb < chh )
+        // windows [x0 - 1, x0 + 8] of the two neighbour rows (the row itself for the horizontal class)
+        int wa[10], wb[10];
         {
-          // windows [x0 - 1, x0 + 8] of the two neighbour rows (the row itself for the horizontal class)
-          int wa[10], wb[10];
-          {
-            const pel_t* ra = &S[(size_t) ya * st + x0]; const pel_t* rb = &S[(size_t) yb * st + x0];
-            const uint4 av = dy ? *reinterpret_cast<const uint4*>( ra ) : cv, bv = dy ? *reinterpret_cast<const uint4*>( rb ) : cv;
-            wa[1] = av.x & 0xffff; wa[2] = av.x >> 16; wa[3] = av.y & 0xffff; wa[4] = av.y >> 16; wa[5] = av.z & 0xffff; wa[6] = av.z >> 16; wa[7] = av.w & 0xffff; wa[8] = av.w >> 16;
-            wb[1] = bv.x & 0xffff; wb[2] = bv.x >> 16; wb[3] = bv.y & 0xffff; wb[4] = bv.y >> 16; wb[5] = bv.z & 0xffff; wb[6] = bv.z >> 16; wb[7] = bv.w & 0xffff; wb[8] = bv.w >> 16;
-            wa[0] = wb[0] = wa[9] = wb[9] = 0;
-            if( dx )
-            {
-              if( x0 > 0 ) { wa[0] = ra[-1]; wb[0] = rb[-1]; }
-              if( x0 + 8 < cw ) { wa[9] = ra[8]; wb[9] = rb[8]; }
-            }
-          }
-          const bool restricted = lf_restricted( pic ), vbOn = vb_present( pic );
-          const int curCtu = ( y / ctuC ) * pic.ctus_x + ( x0 / ctuC );
+          const uint4 ua = dy ? av : cv, ub = dy ? bv : cv;
+          wa[1] = ua.x & 0xffff; wa[2] = ua.x >> 16; wa[3] = ua.y & 0xffff; wa[4] = ua.y >> 16; wa[5] = ua.z & 0xffff; wa[6] = ua.z >> 16; wa[7] = ua.w & 0xffff; wa[8] = ua.w >> 16;
+          wb[1] = ub.x & 0xffff; wb[2] = ub.x >> 16; wb[3] = ub.y & 0xffff; wb[4] = ub.y >> 16; wb[5] = ub.z & 0xffff; wb[6] = ub.z >> 16; wb[7] = ub.w & 0xffff; wb[8] = ub.w >> 16;
+          wa[0] = dy ? al : cl; wb[0] = dy ? bl : cl; wa[9] = dy ? ar : cr; wb[9] = dy ? br : cr;
+        }
+        const bool restricted = lf_restricted( pic ), vbOn = vb_present( pic );
+        const int yA = y - dy, yB = y + dy;
 #pragma unroll
-          for( int i = 0; i < 8; i++ )
-          {
-            const int x = x0 + i;
-            if( x - dx < 0 || x - dx >= cw || x + dx < 0 || x + dx >= cw ) continue;
-            // nothing across a slice / tile boundary the loop filters must not cross
-            if( restricted && ( !lf_may_cross( pic, curCtu, ( ya / ctuC ) * pic.ctus_x + ( x - dx ) / ctuC ) || !lf_may_cross( pic, curCtu, ( yb / ctuC ) * pic.ctus_x + ( x + dx ) / ctuC ) ) ) continue;
-            if( vbOn && sao_at_vb( pic, x, y, cs, dx != 0, dy != 0 ) ) continue;
-            const int e = sgn( v[i] - wa[1 + i - dx] ) + sgn( v[i] - wb[1 + i + dx] );
-            if( e ) out[i] = clip_pel( v[i] + s.offset[c][e < 0 ? e + 2 : e + 1], bd );
-          }
+        for( int i = 0; i < 8; i++ )
+        {
+          const int x = x0 + i;
+          if( x - dx < 0 || x - dx >= cw || x + dx < 0 || x + dx >= cw ) continue;
+          // nothing across a slice / tile boundary the loop filters must not cross
+          if( restricted && ( !lf_may_cross( pic, curCtu, ( yA / ctuC ) * pic.ctus_x + ( x - dx ) / ctuC ) || !lf_may_cross( pic, curCtu, ( yB / ctuC ) * pic.ctus_x + ( x + dx ) / ctuC ) ) ) continue;
+          if( vbOn && sao_at_vb( pic, x, y, cs, dx != 0, dy != 0 ) ) continue;
+          // (static indices + selects: run-time indices would put the windows into LDS)
+          const int na = dx == 0 ? wa[1 + i] : dx == 1 ? wa[i] : wa[2 + i], nb = dx == 0 ? wb[1 + i] : dx == 1 ? wb[2 + i] : wb[i];
+          const int e = sgn( v[i] - na ) + sgn( v[i] - nb );
+          if( e ) out[i] = clip_pel( v[i] + ( e == -2 ? off[0] : e == -1 ? off[1] : e == 1 ? off[2] : off[3] ), bd );      // (selects: an indexed private array would be put into LDS)
         }
       }
     }
   }
-  *reinterpret_cast<uint4*>( &dst.p[c][(size_t) y * dst.stride[c] + x0] ) =
+  pel_t* __restrict__ D = c == 0 ? dst.p[0] : c == 1 ? dst.p[1] : dst.p[2];
+  *reinterpret_cast<uint4*>( &D[(size_t) y * ( c ? dst.stride[1] : dst.stride[0] ) + x0] ) =
       make_uint4( (uint32_t) out[0] | ( (uint32_t) out[1] << 16 ), (uint32_t) out[2] | ( (uint32_t) out[3] << 16 ), (uint32_t) out[4] | ( (uint32_t) out[5] << 16 ), (uint32_t) out[6] | ( (uint32_t) out[7] << 16 ) );
 }
 void launch_sao( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst )
@@ -1790,6 +1802,7 @@ __constant__ int8_t c_alf_perm[4][12] = {
   { 0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11 },
   { 9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6 } };
 
+template<bool VB /* virtual boundaries of the picture header present */>
 __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, DevPlanes dst )
 {
   __shared__ pel_t tile[( ALF_T + 2 * ALF_HALO ) * ALF_LW];
@@ -1813,18 +1826,24 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
   }
   const int TW = ALF_T + 2 * ALF_HALO;
   const AlfClip kctu = alf_clip_of_ctu( pic, tx0 >> pic.hdr.log2_ctu, ty0 >> pic.hdr.log2_ctu, 0 );
-  // virtual boundaries (picture header) that run through the tile cut it into parts with a border of their own: one pass per part (usually: one)
-  int px[5], py[5], npx = 1, npy = 1;
-  px[0] = tx0; py[0] = ty0;
-  for( int i = 0; i < pic.hdr.num_ver_vb; i++ ) { const int v = pic.hdr.vb_pos_x[i]; if( v > tx0 && v < tx0 + ALF_T ) px[npx++] = v; }
-  for( int i = 0; i < pic.hdr.num_hor_vb; i++ ) { const int v = pic.hdr.vb_pos_y[i]; if( v > ty0 && v < ty0 + ALF_T ) py[npy++] = v; }
-  px[npx] = tx0 + ALF_T; py[npy] = ty0 + ALF_T;
-  const bool vbOn = vb_present( pic );
-  for( int part = 0; part < npx * npy; part++ )
+  // virtual boundaries (picture header) that run through the tile cut it into parts with a border of their own: one pass per part (usually: one).
+  // The parts are walked by their start: the next boundary inside the tile ends a part (no local arrays: they would live in scratch memory).
+  // (two instantiations: without virtual boundaries the loops below disappear and the kernel is the single-pass one, 61 VGPRs instead of 102)
+  constexpr bool vbOn = VB;
+  bool firstPart = true;
+  for( int ay0 = ty0; ay0 < ty0 + ALF_T; )
   {
-  const int ax0 = px[part % npx], ax1 = px[part % npx + 1], ay0 = py[part / npx], ay1 = py[part / npx + 1];      // the part, luma samples
-  const AlfClip kclip = vbOn ? alf_clip_vb( pic, kctu, ax0, ay0, 0 ) : kctu;
+  int ay1 = ty0 + ALF_T;
+  if constexpr( VB ) VB_EACH_Y( if( v > ay0 && v < ay1 ) ay1 = v; )
+  for( int ax0 = tx0; ax0 < tx0 + ALF_T; )
+  {
+  int ax1 = tx0 + ALF_T;
+  if constexpr( VB ) VB_EACH_X( if( v > ax0 && v < ax1 ) ax1 = v; )
+  AlfClip kclip = kctu;
+  if constexpr( VB ) kclip = alf_clip_vb( pic, kctu, ax0, ay0, 0 );
+  const int part = firstPart ? 0 : 1;
   if( part ) __syncthreads();                                     // the previous part is done with the tile and the classes
+  firstPart = false;
   for( int i = tid; i < TW * TW; i += 256 )
   {
     const int yy = i / TW, xx = i - yy * TW;
@@ -1940,7 +1959,10 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
       }
     }
   }
-  }     // parts
+  ax0 = ax1;
+  }     // parts of a row of parts
+  ay0 = ay1;
+  }     // rows of parts
 #undef T
 }
 
@@ -2024,7 +2046,9 @@ __global__ __launch_bounds__( 256 ) void k_alf_chroma( PicDev pic, DevPlanes src
 
 void launch_alf( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst )
 {
-  hipLaunchKernelGGL( k_alf_luma, dim3( ( src.w[0] + ALF_T - 1 ) / ALF_T, ( src.h[0] + ALF_T - 1 ) / ALF_T ), dim3( 256 ), 0, s, pic, src, dst );
+  const dim3 grid( ( src.w[0] + ALF_T - 1 ) / ALF_T, ( src.h[0] + ALF_T - 1 ) / ALF_T );
+  if( pic.hdr.num_ver_vb | pic.hdr.num_hor_vb ) hipLaunchKernelGGL( k_alf_luma<true>, grid, dim3( 256 ), 0, s, pic, src, dst );
+  else hipLaunchKernelGGL( k_alf_luma<false>, grid, dim3( 256 ), 0, s, pic, src, dst );
   if( pic.hdr.chroma_format )
     hipLaunchKernelGGL( k_alf_chroma, dim3( ( src.w[1] + 63 ) / 64, ( src.h[1] + 3 ) / 4, 2 ), dim3( 256 ), 0, s, pic, src, dst );
 }
