@@ -173,7 +173,10 @@ typedef struct vvr_pic_header {
    * boundary alone for the edge classes that look across it (SampleAdaptiveOffset.cpp:823), ALF filters every part of a CTU the boundaries cut
    * out with its own replicated border (AdaptiveLoopFilter.cpp:142-175,764-850).                                                              */
   uint8_t  num_ver_vb, num_hor_vb;  /* 0..3 each                                                          */
-  uint8_t  pad2[4];
+  uint16_t wrap_offset;             /* 0: off; else pps_ref_wraparound_enabled_flag with PPS::getWrapAroundOffset() luma samples: motion compensation reads
+                                       a reference picture as if it wrapped around horizontally at that period (360-degree video; wrapClipMv, Mv.cpp:112,
+                                       Picture::extendPicBorderWrap, Picture.cpp:410).  Multiple of 8, CTU size + 16 .. picture width                        */
+  uint8_t  pad2[2];
   uint16_t vb_pos_x[3], vb_pos_y[3];
   uint8_t  pad3[4];
 } vvr_pic_header;

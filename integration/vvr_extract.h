@@ -140,7 +140,7 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
   if( sps.getChromaFormatIdc() != CHROMA_400 && sps.getChromaFormatIdc() != CHROMA_420 ) { why = "chroma format other than 4:0:0 / 4:2:0"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getBitDepth() > 10 || sps.getBitDepth() < 8 ) { why = "bit depth outside 8..10"; return VVR_ERR_UNSUPPORTED; }
   if( sps.getLadfEnabled() && sps.getLadfNumIntervals() > 5 ) { why = "LADF with more than 5 intervals"; return VVR_ERR_UNSUPPORTED; }
-  if( sps.getUseWrapAround() || pps.getUseWrapAround() ) { why = "horizontal wrap-around motion compensation (Picture.cpp:404-518)"; return VVR_ERR_UNSUPPORTED; }
+  if( pps.getUseWrapAround() && ( pps.getWrapAroundOffset() == 0 || pps.getWrapAroundOffset() > 65535 || ( pps.getWrapAroundOffset() & 7 ) ) ) { why = "horizontal wrap-around motion compensation with a period off the 8-sample grid"; return VVR_ERR_UNSUPPORTED; }
   // virtual boundaries: the picture header holds the effective ones (its own or the SPS's, HLSyntaxReader.cpp:2924-2970), at most three per direction
   if( ph.getVirtualBoundariesPresentFlag() )
   {
@@ -193,6 +193,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   h.deblock_beta_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrBetaOffsetDiv2(); h.deblock_tc_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrTcOffsetDiv2();
   h.log2_sao_offset_scale[0] = h.log2_sao_offset_scale[1] = (uint8_t) std::max( 0, bd - MAX_SAO_TRUNCATED_BITDEPTH );
   h.min_qp_ts = (int8_t) ( 4 + 6 * sps.getInternalMinusInputBitDepth() );
+  if( pps.getUseWrapAround() ) h.wrap_offset = (uint16_t) pps.getWrapAroundOffset();       // (Picture::isWrapAroundEnabled: references of another size are refused above)
   if( cs.picHeader->getVirtualBoundariesPresentFlag() )
   {
     const PicHeader& ph = *cs.picHeader;

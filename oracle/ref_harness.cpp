@@ -232,6 +232,8 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       for( int h : rowH ) pps.addTileRowHeight( h );
       pps.initTiles();
     }
+    // horizontal reference wrap-around (sps_ref_wraparound_enabled_flag / pps_ref_wraparound_enabled_flag + offset)
+    sps.setUseWrapAround( H.wrap_offset != 0 ); pps.setUseWrapAround( H.wrap_offset != 0 ); pps.setWrapAroundOffset( H.wrap_offset );
     pps.setLoopFilterAcrossTilesEnabledFlag( !( H.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) );
     pps.setLoopFilterAcrossSlicesEnabledFlag( !( H.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) );
     pps.setNumSubPics( 1 );
@@ -310,6 +312,11 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
         p->finalInit( &cuCache, &tuCache, &sps, &pps, ph, noAps, nullptr, nullptr, false );   // gives the picture a CodingStructure (pps/sps/pcv) like a decoded one has
       }
       { Slice* rs = p->allocateNewSlice(); rs->setPOC( poc ); rs->setPicHeader( ph.get() ); rs->setSliceType( I_SLICE ); }
+      if( H.wrap_offset )
+      {   // the wrap-around copy of a reference picture (DecLibRecon::borderExtPic, DecLibRecon.cpp:262-283; its margins are filled by extendPicBorder below)
+        p->createWrapAroundBuf( true, ctuSize );
+        p->getRecoBuf( true ).copyFrom( p->getRecoBuf() );
+      }
       p->extendPicBorder( true, true, true, true );   // DecLibRecon::borderExtPic (DecLibRecon.cpp:236) does the same through 6 tasks
       p->borderExtStarted = true;
       p->progress = Picture::reconstructed;
@@ -653,7 +660,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       switch( g_feature )
       {
       case 1: sps.setLadfEnabled( true ); sps.setLadfNumIntervals( 6 ); break;                             // (more LADF intervals than the header holds)
-      case 2: sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); break;
+      case 2: sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); pps.setWrapAroundOffset( 0 ); break;            // (a period of zero: no conforming stream has it)
       case 3: ph->setVirtualBoundariesPresentFlag( true ); ph->setNumVerVirtualBoundaries( 1 ); ph->setVirtualBoundariesPosX( 12, 0 ); break;     // (not on the 8-sample grid: no conforming stream has it)
       case 4: { Slice* s2 = pic.allocateNewSlice(); s2->setPicHeader( ph.get() ); s2->setSliceType( SliceType( H.slice_type ) ); s2->setPOC( H.poc ); s2->setDepQuantEnabledFlag( !slice->getDepQuantEnabledFlag() ); } break;     // (a second slice with another header)
       case 5: pps.setNumSubPics( 2 ); break;

@@ -18,10 +18,25 @@ typedef struct {
   const vvo_planes* ref; int comp;
   const pel* pad; int padStride, padW, padH, padX0, padY0;   /* pad != NULL: pad[(y - padY0) * padStride + (x - padX0)], x/y in block-relative coordinates */
 } vvo_src;
+/* Reference wrap-around (pps_ref_wraparound_enabled_flag, vvr_pic_header.wrap_offset): the reference keeps a second copy of every reference picture
+ * whose left / right margins continue the picture one period further on (Picture::extendPicBorderWrap, Picture.cpp:410-518: margin sample -k-1 =
+ * sample offset-k-1 as long as k < offset, else the edge sample), and every prediction reads either that copy or the ordinary, edge-replicated one:
+ * g_wrapFetch says which, set by the callers from what wrapClipMv (Mv.cpp:112) returned for the block. */
+static int g_wrapOff = 0, g_wrapFetch = 0;
+static inline int ref_at( const vvo_planes* r, int c, int x, int y )
+{
+  if( g_wrapFetch )
+  {
+    const int w = r->w[c], off = g_wrapOff >> ( c ? 1 : 0 );
+    if( x < 0 ) x = -x <= off ? x + off : 0;
+    else if( x >= w ) x = x - w < off ? x - off : w - 1;
+  }
+  return vvo_ref_at( r, c, x, y );
+}
 static inline int src_at( const vvo_src* s, int x, int y )
 {
   if( s->pad ) return s->pad[( y - s->padY0 ) * s->padStride + ( x - s->padX0 )];
-  return vvo_ref_at( s->ref, s->comp, x, y );
+  return ref_at( s->ref, s->comp, x, y );
 }
 static void pred_block_src( const vvo_src* src, int comp, int bx, int by, int w, int h, int mvx, int mvy, int bi, int altHpel, int bd, pel* dst, int dstStride );
 static void pred_block( const vvo_planes* ref, int comp, int bx, int by, int w, int h, int mvx, int mvy, int bi, int altHpel, int bd, pel* dst, int dstStride )
@@ -120,8 +135,25 @@ static int wp_bi( const vvr_picture* pic, int r0, int r1, int c, int p0, int p1 
   return vvo_clip_pel( ( e0->weight * ( p0 + IF_INTERNAL_OFFS ) + e1->weight * ( p1 + IF_INTERNAL_OFFS ) + ( ( 1 << shift ) >> 1 ) + offset * ( 1 << ( shift - 1 ) ) ) >> shift, bd );
 }
 
-static void clip_mv( int mv[2], int x, int y, int W, int H, int ctu )   /* clipMvInPic (Mv.cpp:64) */
+/* wrapClipMv (Mv.cpp:112): an MV that points further out than the wrap copy's margins is moved by one period and clamped; returns whether the wrap
+ * copy is the one to read (it is not after a move).  bw: width of the block the MV belongs to. */
+static int wrap_clip_mv( int mv[2], int x, int y, int bw, int W, int H, int ctu )
 {
+  int wrapRef = 1;
+  const int horMax = ( W + ctu - bw + 8 - x - 1 ) * 16, horMin = ( -ctu - 8 - x + 1 ) * 16;
+  const int verMax = ( H + 8 - y - 1 ) * 16, verMin = ( -ctu - 8 - y + 1 ) * 16;
+  int mx = mv[0];
+  if( mx > horMax ) { mx -= g_wrapOff * 16; mx = vvo_min( horMax, vvo_max( horMin, mx ) ); wrapRef = 0; }
+  if( mx < horMin ) { mx += g_wrapOff * 16; mx = vvo_min( horMax, vvo_max( horMin, mx ) ); wrapRef = 0; }
+  mv[0] = mx; mv[1] = vvo_min( verMax, vvo_max( verMin, mv[1] ) );
+  return wrapRef;
+}
+/* clipMvInPic (Mv.cpp:64) for the block at luma (x, y), bw wide; with wrap-around it is wrapClipMv (:66-70).  Sets g_wrapFetch for the prediction that
+ * follows: the regular paths call wrapClipMv a second time on the result (InterPrediction.cpp:656,1752,1814), which then lies inside the range, so they
+ * always read the wrap copy. */
+static void clip_mv_w( int mv[2], int x, int y, int bw, int W, int H, int ctu )
+{
+  if( g_wrapOff ) { wrap_clip_mv( mv, x, y, bw, W, H, ctu ); g_wrapFetch = 1; return; }
   const int horMax = ( W + 8 - x - 1 ) * 16, horMin = ( -ctu - 8 - x + 1 ) * 16;
   const int verMax = ( H + 8 - y - 1 ) * 16, verMin = ( -ctu - 8 - y + 1 ) * 16;
   mv[0] = vvo_min( horMax, vvo_max( horMin, mv[0] ) );
@@ -246,17 +278,17 @@ static int32_t g_dmvr_out[2 * 65536]; static uint32_t g_dmvr_count;
 static void bilinear_block( const vvo_planes* ref, int x0, int y0, int xFrac, int yFrac, int w, int h, int bd, pel* dst, int dstStride )
 {
   const int shiftF = 4 - ( 10 - bd ), offF = shiftF > 0 ? 1 << ( shiftF - 1 ) : 0;
-  if( !xFrac && !yFrac ) { for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) dst[y * dstStride + x] = (pel) ( vvo_ref_at( ref, 0, x0 + x, y0 + y ) * ( 1 << ( 10 - bd ) ) ); return; }
+  if( !xFrac && !yFrac ) { for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) dst[y * dstStride + x] = (pel) ( ref_at( ref, 0, x0 + x, y0 + y ) * ( 1 << ( 10 - bd ) ) ); return; }
   if( !yFrac || !xFrac )
   {
     const int f = yFrac ? yFrac : xFrac, dx = yFrac ? 0 : 1, dy = yFrac ? 1 : 0;
     for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
-      dst[y * dstStride + x] = (pel) ( ( vvo_ref_at( ref, 0, x0 + x, y0 + y ) * ( 16 - f ) + vvo_ref_at( ref, 0, x0 + x + dx, y0 + y + dy ) * f + offF ) >> shiftF );
+      dst[y * dstStride + x] = (pel) ( ( ref_at( ref, 0, x0 + x, y0 + y ) * ( 16 - f ) + ref_at( ref, 0, x0 + x + dx, y0 + y + dy ) * f + offF ) >> shiftF );
     return;
   }
   pel tmp[( 128 + 4 + 1 ) * ( 128 + 4 )];
   for( int y = 0; y < h + 1; y++ ) for( int x = 0; x < w; x++ )
-    tmp[y * w + x] = (pel) ( ( vvo_ref_at( ref, 0, x0 + x, y0 + y ) * ( 16 - xFrac ) + vvo_ref_at( ref, 0, x0 + x + 1, y0 + y ) * xFrac + offF ) >> shiftF );
+    tmp[y * w + x] = (pel) ( ( ref_at( ref, 0, x0 + x, y0 + y ) * ( 16 - xFrac ) + ref_at( ref, 0, x0 + x + 1, y0 + y ) * xFrac + offF ) >> shiftF );
   for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
     dst[y * dstStride + x] = (pel) ( ( tmp[y * w + x] * ( 16 - yFrac ) + tmp[( y + 1 ) * w + x] * yFrac + 8 ) >> 4 );
 }
@@ -308,12 +340,13 @@ static void dmvr_prefetch( const vvo_planes* ref, int comp, int sx, int sy /* lu
 {
   const int cs = comp ? 1 : 0, sh = 4 + cs, ntaps = comp ? 4 : 8, half = ntaps / 2 - 1, padSize = comp ? 1 : 2;
   int mv[2] = { mergeMv[0] - ( half << sh ), mergeMv[1] - ( half << sh ) };
-  clip_mv( mv, sx, sy, W, H, ctu );
+  if( g_wrapOff ) g_wrapFetch = wrap_clip_mv( mv, sx, sy, w << cs, W, H, ctu );      /* one call here (:1551): the ordinary copy after a move by one period */
+  else clip_mv_w( mv, sx, sy, w << cs, W, H, ctu );
   const int px = ( sx >> cs ) + ( mv[0] >> sh ), py = ( sy >> cs ) + ( mv[1] >> sh );      /* top-left of the copied window in the reference */
   const int cw = w + ntaps - 1, chh = h + ntaps - 1;
   const int stride = w + 4 + ntaps;                                                        /* width + 2 * DMVR_NUM_ITERATION + filtersize */
   for( int y = -padSize; y < chh + padSize; y++ ) for( int x = -padSize; x < cw + padSize; x++ )
-    pad[( y + 2 ) * stride + ( x + 2 )] = (pel) vvo_ref_at( ref, comp, px + vvo_clip3( 0, cw - 1, x ), py + vvo_clip3( 0, chh - 1, y ) );
+    pad[( y + 2 ) * stride + ( x + 2 )] = (pel) ref_at( ref, comp, px + vvo_clip3( 0, cw - 1, x ), py + vvo_clip3( 0, chh - 1, y ) );
   *padStride = stride; *originX = 2 + half; *originY = 2 + half;    /* pad coordinates of the block's integer-sample origin for a zero integer delta */
 }
 
@@ -331,7 +364,7 @@ static int dmvr_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* 
   for( int l = 0; l < 2; l++ )
   {
     int mv[2] = { mergeMv[l][0], mergeMv[l][1] };
-    clip_mv( mv, cu->x, cu->y, W, Hh, ctu );
+    clip_mv_w( mv, cu->x, cu->y, cu->w, W, Hh, ctu );     /* (with wrap-around the start MVs are clipped per sub-block, below: the period shift depends on the block) */
     mv[0] -= 2 << 4; mv[1] -= 2 << 4;
     bilinear_block( ref[l], cu->x + ( mv[0] >> 4 ), cu->y + ( mv[1] >> 4 ), mv[0] & 15, mv[1] & 15, ew, eh, bd, bil[l], ew );
   }
@@ -341,7 +374,20 @@ static int dmvr_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* 
   {
     const int sx = cu->x + xs, sy = cu->y + ys;
     const pel* c0 = bil[0] + ( 2 + ys ) * ew + 2 + xs; const pel* c1 = bil[1] + ( 2 + ys ) * ew + 2 + xs;
-    uint64_t minCost = dmvr_sad( c0, c1, ew, dx, dy );
+    int bst = ew;
+    pel lbil[2][20 * 20];
+    if( g_wrapOff )
+    {   /* xinitMC runs per sub-CU (:1804-1845): start MVs clipped against the sub-block, bilinear prediction of the sub-block extended by 2 samples */
+      for( int l = 0; l < 2; l++ )
+      {
+        int smv[2] = { mergeMv[l][0], mergeMv[l][1] };
+        clip_mv_w( smv, sx, sy, dx, W, Hh, ctu );
+        smv[0] -= 2 << 4; smv[1] -= 2 << 4;
+        bilinear_block( ref[l], sx + ( smv[0] >> 4 ), sy + ( smv[1] >> 4 ), smv[0] & 15, smv[1] & 15, dx + 4, dy + 4, bd, lbil[l], dx + 4 );
+      }
+      bst = dx + 4; c0 = lbil[0] + 2 * bst + 2; c1 = lbil[1] + 2 * bst + 2;
+    }
+    uint64_t minCost = dmvr_sad( c0, c1, bst, dx, dy );
     minCost >>= 1; minCost -= minCost >> 2;
     int mv[2][2] = { { mergeMv[0][0], mergeMv[0][1] }, { mergeMv[1][0], mergeMv[1][1] } };
     int16_t total[2] = { 0, 0 };
@@ -352,7 +398,7 @@ static int dmvr_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* 
       sads[12] = minCost;
       for( int ver = -2; ver <= 2; ver++ ) for( int hor = -2; hor <= 2; hor++ )
       {
-        if( !( ver == 0 && hor == 0 ) ) sads[( ver + 2 ) * 5 + hor + 2] = dmvr_sad( c0 + ver * ew + hor, c1 - ver * ew - hor, ew, dx, dy ) >> 1;
+        if( !( ver == 0 && hor == 0 ) ) sads[( ver + 2 ) * 5 + hor + 2] = dmvr_sad( c0 + ver * bst + hor, c1 - ver * bst - hor, bst, dx, dy ) >> 1;
         const uint64_t cost = sads[( ver + 2 ) * 5 + hor + 2];
         if( cost < minCost ) { minCost = cost; d[0] = (int16_t) hor; d[1] = (int16_t) ver; }
       }
@@ -382,7 +428,7 @@ static int dmvr_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* 
     for( int l = 0; l < 2; l++ )
     {
       int cmv[2] = { mv[l][0], mv[l][1] };
-      clip_mv( cmv, sx, sy, W, Hh, ctu );                                      /* clipped against the SUB-block (:1752) */
+      clip_mv_w( cmv, sx, sy, dx, W, Hh, ctu );                                 /* clipped against the SUB-block (:1752) */
       for( int c = 0; c < ncomp; c++ )
       {
         const int cs = c ? 1 : 0, sh = 4 + cs, w = dx >> cs, h = dy >> cs;
@@ -400,6 +446,7 @@ static int dmvr_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* 
         }
         else
         {
+          if( g_wrapOff ) g_wrapFetch = 1;                                        /* (the prefetch of another component may have chosen the ordinary copy) */
           pred_block( ref[l], c, sx >> cs, sy >> cs, w, h, cmv[0], cmv[1], 1, altHpel, bd, dst, dstStride );
           if( c == 0 && bioSub ) bdof_border( ref[l], sx, sy, w, h, cmv[0], cmv[1], bd, blk[l] );
         }
@@ -495,7 +542,13 @@ static void affine_list( const vvr_picture* pic, const vvr_cu* cu, int l, const 
         mx = m0->mv[l][0] + m1->mv[l][0]; my = m0->mv[l][1] + m1->mv[l][1];
         round_affine_mv( &mx, &my, 1 );
       }
-      mx = vvo_min( horMax, vvo_max( horMin, mx ) ); my = vvo_min( verMax, vvo_max( verMin, my ) );
+      if( g_wrapOff )
+      {   /* one wrapClipMv per sub-block, against the sub-block (luma position, luma size; :1177-1186) */
+        int t[2] = { mx, my };
+        g_wrapFetch = wrap_clip_mv( t, cu->x + ( x << cs ), cu->y + ( y << cs ), 4 << cs, H->width, H->height, ctu );
+        mx = t[0]; my = t[1];
+      }
+      else { mx = vvo_min( horMax, vvo_max( horMin, mx ) ); my = vvo_min( verMax, vvo_max( verMin, my ) ); }
       const int bx = ( cu->x >> cs ) + x, by = ( cu->y >> cs ) + y;
       pel* d = dst[c] + y * cw + x;
       if( c == 0 && prof )
@@ -508,7 +561,7 @@ static void affine_list( const vvr_picture* pic, const vvr_cu* cu, int l, const 
         {
           if( i >= 1 && i <= 4 && j >= 1 && j <= 4 ) continue;
           if( ( i == 0 || i == 5 ) && ( j == 0 || j == 5 ) && 0 ) continue;
-          ext[j * 6 + i] = (pel) ( vvo_ref_at( ref, 0, x0 + i - 1 + xOff, y0 + j - 1 + yOff ) * ( 1 << headroom ) - (pel) IF_INTERNAL_OFFS );
+          ext[j * 6 + i] = (pel) ( ref_at( ref, 0, x0 + i - 1 + xOff, y0 + j - 1 + yOff ) * ( 1 << headroom ) - (pel) IF_INTERNAL_OFFS );
         }
         for( int yy = 0; yy < 4; yy++ ) for( int xx = 0; xx < 4; xx++ )
         {
@@ -617,7 +670,7 @@ static int geo_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* r
       const int slot = H->ref_slot[l][ri];
       if( l < 0 || l > 1 || slot < 0 || slot >= num_slots || !refs[slot].p[0] ) { free( buf ); vvo_set_error( "GPM: bad reference" ); return -1; }
       int mv[2] = { cu->geo_mv[k][0], cu->geo_mv[k][1] };
-      clip_mv( mv, cu->x, cu->y, H->width, H->height, ctu );
+      clip_mv_w( mv, cu->x, cu->y, cu->w, H->width, H->height, ctu );
       pred_block( &refs[slot], c, cu->x >> cs, cu->y >> cs, w, h, mv[0], mv[1], 1, 0, bd, buf + k * n, w );
     }
     const int shift = ( IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2 ) + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
@@ -636,7 +689,7 @@ static int geo_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* r
  * Sub-block temporal MV prediction: InterPrediction::xSubPuMC (InterPrediction.cpp:438-549): 8x8 sub-blocks, each with the motion
  * stored in the motion field, predicted by the regular uni/bi path (no BDOF, no DMVR: m_subPuMC).  The reference joins sub-blocks
  * with equal motion before predicting; that changes nothing in the samples (the MV clip only acts outside the padded picture). */
-static void plain_block( const vvr_picture* pic, const vvo_planes* refs, int x, int y, int w, int h, const int mv[2][2], const int ref_idx[2], int bcw_idx, int altHpel, vvo_planes* reco )
+static void plain_block( const vvr_picture* pic, const vvo_planes* refs, const vvr_cu* cu /* m_currCuArea: what the MVs are clipped against */, int x, int y, int w, int h, const int mv[2][2], const int ref_idx[2], int bcw_idx, int altHpel, vvo_planes* reco )
 {
   const vvr_pic_header* H = &pic->hdr;
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu, ncomp = H->chroma_format ? 3 : 1;
@@ -651,7 +704,7 @@ static void plain_block( const vvr_picture* pic, const vvo_planes* refs, int x, 
     {
       const int l = ref_idx[0] >= 0 ? 0 : 1;
       int m[2] = { mv[l][0], mv[l][1] };
-      clip_mv( m, x, y, H->width, H->height, ctu );
+      if( g_wrapOff ) clip_mv_w( m, cu->x, cu->y, cu->w, H->width, H->height, ctu ); else clip_mv_w( m, x, y, w, H->width, H->height, ctu );
       if( wp )
       {
         pel t[16 * 16];
@@ -665,7 +718,7 @@ static void plain_block( const vvr_picture* pic, const vvo_planes* refs, int x, 
     for( int l = 0; l < 2; l++ )
     {
       int m[2] = { mv[l][0], mv[l][1] };
-      clip_mv( m, x, y, H->width, H->height, ctu );
+      if( g_wrapOff ) clip_mv_w( m, cu->x, cu->y, cu->w, H->width, H->height, ctu ); else clip_mv_w( m, x, y, w, H->width, H->height, ctu );
       pred_block( &refs[H->ref_slot[l][ref_idx[l]]], c, bx, by, bw, bh, m[0], m[1], 1, altHpel, bd, t[l], bw );
     }
     const int hr = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2;
@@ -691,7 +744,7 @@ static int sbtmvp_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes
     const int mv[2][2] = { { m->mv[0][0], m->mv[0][1] }, { m->mv[1][0], m->mv[1][1] } };
     const int ri[2] = { m->ref_idx[0], m->ref_idx[1] };
     if( ( ri[0] < 0 && ri[1] < 0 ) || ri[0] >= H->num_ref[0] || ri[1] >= H->num_ref[1] ) { vvo_set_error( "SbTMVP: bad sub-block motion" ); return -1; }
-    plain_block( pic, refs, cu->x + x, cu->y + y, 8, 8, mv, ri, cu->bcw_idx, cu->imv == 3, reco );
+    plain_block( pic, refs, cu, cu->x + x, cu->y + y, 8, 8, mv, ri, cu->bcw_idx, cu->imv == 3, reco );
   }
   return 0;
 }
@@ -709,6 +762,7 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
   const vvr_pic_header* H = &pic->hdr;
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu;
   const int ncomp = H->chroma_format ? 3 : 1;
+  g_wrapOff = H->wrap_offset; g_wrapFetch = 0;
   if( cu->mc_mode == VVR_MC_AFFINE ) return affine_cu( pic, cu, refs, reco );
   if( cu->mc_mode == VVR_MC_SBTMVP ) return sbtmvp_cu( pic, cu, refs, reco );
   if( cu->mc_mode == VVR_MC_GEO ) return geo_cu( pic, cu, refs, num_slots, reco );
@@ -726,7 +780,7 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
       /* one list, or bi with identical motion: xPredInterUni( cu, L0, predBuf, bi=false ) (InterPrediction.cpp:1451-1454) */
       const int l = ( biPred || cu->ref_idx[0] >= 0 ) ? 0 : 1;
       int mv[2] = { cu->mv[l][0][0], cu->mv[l][0][1] };
-      clip_mv( mv, cu->x, cu->y, H->width, H->height, ctu );
+      clip_mv_w( mv, cu->x, cu->y, cu->w, H->width, H->height, ctu );
       const int slot = H->ref_slot[l][cu->ref_idx[l]];
       if( slot < 0 || slot >= num_slots || !refs[slot].p[0] ) { vvo_set_error( "missing reference slot" ); return -1; }
       if( wp_on( pic, cu->bcw_idx ) )
@@ -744,7 +798,7 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
       for( int l = 0; l < 2; l++ )
       {
         int mv[2] = { cu->mv[l][0][0], cu->mv[l][0][1] };
-        clip_mv( mv, cu->x, cu->y, H->width, H->height, ctu );
+        clip_mv_w( mv, cu->x, cu->y, cu->w, H->width, H->height, ctu );
         const int slot = H->ref_slot[l][cu->ref_idx[l]];
         if( slot < 0 || slot >= num_slots || !refs[slot].p[0] ) { free( t0 ); vvo_set_error( "missing reference slot" ); return -1; }
         pred_block( &refs[slot], c, bx, by, w, h, mv[0], mv[1], 1, altHpel, bd, l ? t1 : t0, w );
@@ -752,7 +806,7 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
       if( c == 0 && cu->mc_mode == VVR_MC_BDOF )
       {   /* xSubPuBio (:551): sub-blocks of at most 16x16 (MAX_BDOF_APPLICATION_REGION), each with its own border fetch */
         int mv0[2] = { cu->mv[0][0][0], cu->mv[0][0][1] }, mv1[2] = { cu->mv[1][0][0], cu->mv[1][0][1] };
-        clip_mv( mv0, cu->x, cu->y, H->width, H->height, ctu ); clip_mv( mv1, cu->x, cu->y, H->width, H->height, ctu );
+        clip_mv_w( mv0, cu->x, cu->y, cu->w, H->width, H->height, ctu ); clip_mv_w( mv1, cu->x, cu->y, cu->w, H->width, H->height, ctu );
         const int sw = vvo_min( 16, w ), shh = vvo_min( 16, h );
         for( int y = 0; y < h; y += shh ) for( int x = 0; x < w; x += sw )
           bdof_luma_subblock( &refs[H->ref_slot[0][cu->ref_idx[0]]], &refs[H->ref_slot[1][cu->ref_idx[1]]], bx + x, by + y, sw, shh, mv0, mv1, altHpel, bd,

@@ -197,7 +197,7 @@ def test_reference_edge_tables_are_safe_for_one_launch_per_direction(built):
     assert ordered > 0
 
 
-@pytest.mark.parametrize("feature,text", [(1, "LADF with more than 5"), (2, "wrap-around"), (3, "virtual boundary off the 8-sample grid"), (4, "slices with different headers"), (5, "sub-pictures"),
+@pytest.mark.parametrize("feature,text", [(1, "LADF with more than 5"), (2, "wrap-around motion compensation with a period off"), (3, "virtual boundary off the 8-sample grid"), (4, "slices with different headers"), (5, "sub-pictures"),
                                           (6, "colour transform"), (7, "bit depth"), (8, "more slices or tiles"), (9, "another size")])
 def test_extractor_refuses_what_the_description_cannot_express(built, feature, text):
     """the reference-side glue never flattens a picture into something it is not: LADF, wrap-around, virtual boundaries, several slices / tiles /

@@ -379,6 +379,20 @@ def test_virtual_boundaries(built, vb, extra, kw):
     _run_stream(1920, 1080, 3, 2, 233, TOOLS_A | extra, intra=True, streams=3, virtual_boundaries=vb, **kw)
 
 
+@pytest.mark.parametrize("W,H,off,kw", [
+    (512, 256, 512, dict(log2_ctu=6, mv_sigma=12.0)),
+    (512, 256, 480, dict(log2_ctu=6, p_bi=0.9, mv_sigma=4.0)),
+    (640, 256, 640, dict(p_affine=0.4, p_sbtmvp=0.2, p_geo=0.2, p_ciip=0.1)),
+    (384, 256, 320, dict(log2_ctu=5, p_affine=0.3, p_bi=0.8, mv_sigma=20.0)),
+    (1920, 1080, 1920, dict(p_affine=0.1, p_geo=0.05, p_sbtmvp=0.05)),
+])
+def test_reference_wrap_around(built, W, H, off, kw):
+    """horizontal reference wrap-around (360-degree video): every MC kernel reads the reference with the period of the picture header where the
+    reference decoder reads its wrap copy, and with the ordinary clamp after an MV was moved by one period (k_mc, k_mc_dmvr incl. its padded local
+    copy, k_mc_affine per sub-block)"""
+    _run_stream(W, H, 5, 4, 311, TOOLS_A | abi.TOOL_LMCS, intra=True, p_intra=0.1, wrap_offset=off, **kw)
+
+
 def test_affine_motion_spanned_on_the_device(built):
     """VVR_TOOL_AFFINE_MV_ON_DEVICE (SURVEY 8(f)-4): the back-end spans the sub-block MVs of affine CUs from the control-point MVs (PU::setAllAffineMv)
     instead of reading them from the motion field - with the motion of the affine CUs wiped from the description the pictures are the ones the oracle

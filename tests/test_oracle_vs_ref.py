@@ -353,3 +353,41 @@ def test_affine_motion_spanned_by_the_reference(built, W, H, l2, idx, seed, kw):
     b, mb = refdrv.reconstruct_with_motion(d, refs, flags=refdrv.SPAN_AFFINE)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert ma.tobytes() == mb.tobytes()
+
+
+WRAP_CASES = [
+    # W, H, l2, idx, seed, wrap offset, extra tools, generator parameters
+    (512, 256, 6, 2, 291, 512, 0, dict(p_intra=0.05, mv_sigma=12.0)),                                                       # the period is the picture width (360-degree video)
+    (512, 256, 6, 1, 292, 480, abi.TOOL_BDOF | abi.TOOL_DMVR, dict(p_intra=0.05, p_bi=0.9, mv_sigma=4.0)),                   # BDOF / DMVR sub-blocks
+    (640, 256, 7, 3, 293, 640, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.1, p_affine=0.4, p_sbtmvp=0.2, p_geo=0.2, p_ciip=0.1)),
+    (384, 256, 5, 2, 294, 320, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS, dict(p_intra=0.1, p_affine=0.3, p_bi=0.8, mv_sigma=20.0)),
+    (416, 240, 6, 3, 295, 416, abi.TOOL_WP, dict(p_intra=0.1, p_bi=0.7)),
+]
+
+
+@pytest.mark.parametrize("W,H,l2,idx,seed,off,extra,kw", WRAP_CASES)
+def test_oracle_equals_reference_wrap_around(built, W, H, l2, idx, seed, off, extra, kw):
+    """horizontal reference wrap-around (pps_ref_wraparound_enabled_flag): every MC path reads the wrap copy of the reference pictures or, after an MV
+    was moved by one period, the ordinary one (wrapClipMv; regular, BDOF, DMVR prefetch / start / final, affine per sub-block, GPM, SbTMVP, CIIP)"""
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=ALL | extra, log2_ctu=l2, wrap_offset=off, **kw)
+    assert d.hdr.wrap_offset == off
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc))
+    nd = d.num_dmvr
+    r = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_RECO, want_dmvr=nd)
+    got = refdrv.oracle_reconstruct(d, refs, flags=refdrv.STOP_AFTER_RECO)
+    for c in range(3):
+        assert np.array_equal(got[c], r["planes"][c]), "comp %d: %d differ" % (c, int((got[c] != r["planes"][c]).sum()))
+    if nd:
+        assert np.array_equal(refdrv.oracle_dmvr(nd), r["dmvr"][:nd])
+    want = refdrv.reconstruct(d, refs, flags=0)["planes"]
+    got = refdrv.oracle_reconstruct(d, refs, flags=0)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    # the wrap-around matters: the same records without it give another picture
+    d.hdr.wrap_offset = 0
+    other = refdrv.oracle_reconstruct(d, refs, flags=0)
+    assert any(not np.array_equal(a, b) for a, b in zip(other, want))

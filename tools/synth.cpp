@@ -73,6 +73,8 @@ typedef struct vvs_params {
                                 // where a block vector into the valid part of the IBC virtual buffer is found
   uint8_t  num_slices;          // > 1: the picture is cut into that many slices (one tile: bands of CTU rows; several tiles: runs of tiles in raster order)
   uint8_t  tile_cols, tile_rows;// > 1: uniform tile grid.  Whether the loop filters cross these boundaries is in tool_flags (VVR_TOOL_NO_LF_ACROSS_*)
+  uint16_t wrap_offset;         // > 0: horizontal reference wrap-around with this period (luma samples; header field of the same name), and inter CUs close
+                                // to the left / right picture edge point across it more often
   uint8_t  virtual_boundaries;  // bits 0-1: number of vertical, bits 2-3: of horizontal virtual boundaries of the in-loop filters (picture header); bit 4: the first
                                 // of each direction lies on a CTU boundary
 } vvs_params;
@@ -277,10 +279,18 @@ struct Gen {
     }
   }
 
-  void clipMv( int32_t mv[2], int x, int y ) const   // clipMvInPic, Mv.cpp:64
+  // reference wrap-around: inter CUs near the left / right picture edge point across it often, some of them further than the wrap copy's margin
+  void wrapBias( int32_t mv[2], int x, int w )
+  {
+    if( !P.wrap_offset || !rng.p( 0.4 ) ) return;
+    const int reach = ( ctu + 96 ) * 16;
+    if( x < 2 * ctu ) mv[0] -= (int32_t) rng.u( (uint32_t) reach );
+    else if( x + w > W - 2 * ctu ) mv[0] += (int32_t) rng.u( (uint32_t) reach );
+  }
+  void clipMv( int32_t mv[2], int x, int y ) const   // clipMvInPic, Mv.cpp:64 (with wrap-around the stream may carry MVs beyond it: kept inside a wider window)
   {
     const int off = 8;
-    const int horMax = ( W + off - x - 1 ) * 16, horMin = ( -ctu - off - x + 1 ) * 16;
+    const int horMax = ( W + off - x - 1 + ( P.wrap_offset ? 2 * ctu + 64 : 0 ) ) * 16, horMin = ( -ctu - off - x + 1 - ( P.wrap_offset ? 2 * ctu + 64 : 0 ) ) * 16;
     const int verMax = ( H + off - y - 1 ) * 16, verMin = ( -ctu - off - y + 1 ) * 16;
     mv[0] = std::min( horMax, std::max( horMin, mv[0] ) );
     mv[1] = std::min( verMax, std::max( verMin, mv[1] ) );
@@ -413,6 +423,7 @@ struct Gen {
         else if( r < 25 ) mv[0] &= ~15;
         else if( r < 35 ) mv[1] &= ~15;
         if( rng.p( P.p_imv_hpel ) ) { cu.imv = 3; mv[0] &= ~7; mv[1] &= ~7; }
+        wrapBias( mv, x, w );
         clipMv( mv, x, y );
         cu.mv[l][0][0] = mv[0]; cu.mv[l][0][1] = mv[1];
       }
@@ -453,6 +464,7 @@ struct Gen {
           cu.geo_dir_ref[k] = (uint8_t) ( ( ( l + 1 ) << 4 ) | r );
           int32_t mv[2] = { rng.laplace( P.mv_sigma * 16 / 1.414 ), rng.laplace( P.mv_sigma * 16 / 1.414 ) };
           if( rng.p( 0.2 ) ) { mv[0] &= ~15; mv[1] &= ~15; }
+          wrapBias( mv, x, w );
           clipMv( mv, x, y );
           cu.geo_mv[k][0] = mv[0]; cu.geo_mv[k][1] = mv[1];
         }
@@ -1025,6 +1037,7 @@ struct Gen {
     h.log2_ctu = P.log2_ctu; h.slice_type = P.slice_type; h.poc = P.poc; h.out_slot = P.out_slot; h.min_qp_ts = 4;
     for( int l = 0; l < 2; l++ ) { h.num_ref[l] = P.slice_type == 2 ? 0 : P.num_ref[l]; for( int i = 0; i < VVR_MAX_REFS; i++ ) { h.ref_slot[l][i] = P.ref_slot[l][i]; h.ref_poc[l][i] = P.ref_poc[l][i]; } }
     for( int c = 0; c < 3; c++ ) { h.deblock_beta_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); h.deblock_tc_offset_div2[c] = (int8_t) ( (int) rng.u( 5 ) - 2 ); }
+    h.wrap_offset = P.wrap_offset;
     for( int d = 0; d < 2; d++ )
     {
       // virtual boundaries: distinct multiples of 8 inside the picture, ascending (ph_virtual_boundary_pos_x/y_minus1)

@@ -57,7 +57,7 @@ class PicHeader(C.Structure):
                 ("deblock_beta_offset_div2", i8 * 3), ("deblock_tc_offset_div2", i8 * 3),
                 ("log2_sao_offset_scale", u8 * 2), ("min_qp_ts", i8),
                 ("ladf_num_intervals", u8), ("ladf_qp_offset", i8 * 5), ("pad", u8), ("ladf_lower_bound", i16 * 5),
-                ("num_ver_vb", u8), ("num_hor_vb", u8), ("pad2", u8 * 4), ("vb_pos_x", u16 * 3), ("vb_pos_y", u16 * 3), ("pad3", u8 * 4)]
+                ("num_ver_vb", u8), ("num_hor_vb", u8), ("wrap_offset", u16), ("pad2", u8 * 2), ("vb_pos_x", u16 * 3), ("vb_pos_y", u16 * 3), ("pad3", u8 * 4)]
 
 
 class Cu(C.Structure):

@@ -74,6 +74,7 @@ struct McSeg {
   int ox, oy;            // position of the block's integer-sample origin inside the window
   int padOff, cw, chh;   // DMVR padded copy (xPrefetchPad): window sample (u,v) = copied sample (clamp(u + shX - padOff, 0, cw - 1), clamp(v + shY - padOff, 0, chh - 1))
   int shX, shY;          // displacement of the window inside the padded copy (the integer part of the DMVR refinement)
+  int wrapOff;           // > 0: the reference is read as if it wrapped around horizontally at this period (component samples): the reference's wrap copy
 };
 
 
@@ -102,6 +103,36 @@ __device__ __forceinline__ void mc_clip_mv( const PicDev& pic, int x, int y, int
   mvx = min( horMax, max( horMin, mvx ) ); mvy = min( verMax, max( verMin, mvy ) );
 }
 
+// Reference wrap-around (vvr_pic_header.wrap_offset; pps_ref_wraparound_enabled_flag).  wrapClipMv (Mv.cpp:112) for the block at luma (x, y), bw wide:
+// an MV that points further out than the margins of the reference's wrap copy is moved by one period and clamped; returns whether the wrap copy is
+// the one to read (it is not after a move).
+__device__ __forceinline__ bool mc_wrap_clip_mv( const PicDev& pic, int x, int y, int bw, int& mvx, int& mvy )
+{
+  const int ctu = 1 << pic.hdr.log2_ctu;
+  const int horMax = ( pic.hdr.width + ctu - bw + 8 - x - 1 ) * 16, horMin = ( -ctu - 8 - x + 1 ) * 16;
+  const int verMax = ( pic.hdr.height + 8 - y - 1 ) * 16, verMin = ( -ctu - 8 - y + 1 ) * 16;
+  bool wrapRef = true;
+  if( mvx > horMax ) { mvx -= pic.hdr.wrap_offset * 16; mvx = min( horMax, max( horMin, mvx ) ); wrapRef = false; }
+  if( mvx < horMin ) { mvx += pic.hdr.wrap_offset * 16; mvx = min( horMax, max( horMin, mvx ) ); wrapRef = false; }
+  mvy = min( verMax, max( verMin, mvy ) );
+  return wrapRef;
+}
+// The MV clip of the regular prediction paths (clipMv = clipMvInPic, then wrapClipMv once more on the result: InterPrediction.cpp:651-656, 1751-1752,
+// 1810-1815): without wrap-around the clamp of mc_clip_mv; with it the MV after wrapClipMv, and the second call - which finds the MV inside its range -
+// always selects the wrap copy.  Returns the period to read the reference with (luma samples), 0 = ordinary clamped reads.
+__device__ __forceinline__ int mc_clip_mv_w( const PicDev& pic, int x, int y, int bw, int& mvx, int& mvy )
+{
+  if( !pic.hdr.wrap_offset ) { mc_clip_mv( pic, x, y, mvx, mvy ); return 0; }
+  mc_wrap_clip_mv( pic, x, y, bw, mvx, mvy );
+  return pic.hdr.wrap_offset;
+}
+// column of the reference's wrap copy (Picture::extendPicBorderWrap, Picture.cpp:410-518): margin sample -k-1 = sample off-k-1 while k < off, else the edge
+__device__ __forceinline__ int mc_ref_col( int x, int pw, int off )
+{
+  if( off ) { if( x < 0 ) return -x <= off ? x + off : 0; if( x >= pw ) return x - pw < off ? x - off : pw - 1; return x; }
+  return clip3( 0, pw - 1, x );
+}
+
 // filter taps of one segment (InterpolationFilter.cpp:1078-1085 / 669-676: luma 4x4 blocks use the 6-tap table; :105 alternative half-pel filter)
 __device__ __forceinline__ void mc_taps( const McSeg& g, int c, bool altHpel, int16_t* coefH, int16_t* coefV )
 {
@@ -120,7 +151,7 @@ __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg
   const int col = tid & 31, row0 = tid >> 5;
   if( col < g.ww )
   {
-    const int sx = clip3( 0, pw - 1, g.x0 + clip3( 0, g.cw - 1, col + g.shX - g.padOff ) );
+    const int sx = mc_ref_col( g.x0 + clip3( 0, g.cw - 1, col + g.shX - g.padOff ), pw, g.wrapOff );
     const pel_t* __restrict__ rc = ref + sx;
     // four rows per step, all four loads issued before the first LDS store: one memory round trip per four rows instead of one per
     // row (the tail repeats the last row: same value to the same place)
@@ -456,9 +487,10 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
       const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : ( l ? mRef[1] : mRef[0] );
       int mvx = geo ? cu.geo_mv[k][0] : ( l ? it.mv[1][0] : it.mv[0][0] ), mvy = geo ? cu.geo_mv[k][1] : ( l ? it.mv[1][1] : it.mv[0][1] );
-      mc_clip_mv( pic, clipX, clipY, mvx, mvy );         // clipped with the CU position (InterPrediction.cpp:657 uses m_currCuArea)
+      const int wrapOff = mc_clip_mv_w( pic, clipX, clipY, pic.hdr.wrap_offset ? (int) cu.w : 0, mvx, mvy );         // clipped with the CU position and size (InterPrediction.cpp:651-656 uses m_currCuArea)
       McSeg g;
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
+      g.wrapOff = wrapOff >> cs;
       g.w = it.w >> cs; g.h = it.h >> cs;
       g.xFrac = mvx & ( ( 1 << shf ) - 1 ); g.yFrac = mvy & ( ( 1 << shf ) - 1 );
       g.ox = half; g.oy = half;
@@ -539,9 +571,11 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
   {
     const int l = tid;
     int mvx = cu.mv[l][0][0], mvy = cu.mv[l][0][1];
-    mc_clip_mv( pic, cu.x, cu.y, mvx, mvy );
+    // (xinitMC runs per sub-CU, :1804-1815: with wrap-around the period shift depends on the sub-block's position and width; without it the clamp against
+    // the CU gives the same samples)
+    const int wrapOff = pic.hdr.wrap_offset ? mc_clip_mv_w( pic, it.x, it.y, w, mvx, mvy ) : mc_clip_mv_w( pic, cu.x, cu.y, 0, mvx, mvy );
     mvx -= 32; mvy -= 32;
-    McSeg g;
+    McSeg g; g.wrapOff = wrapOff;
     g.w = w + 4; g.h = h + 4; g.xFrac = mvx & 15; g.yFrac = mvy & 15;
     g.x0 = it.x + ( mvx >> 4 ); g.y0 = it.y + ( mvy >> 4 ); g.ww = g.w + 1; g.wh = g.h + 1; g.ox = g.oy = 0; g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
     sh.m.seg[l][0] = g;
@@ -655,7 +689,7 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
       const int mgx = cu.mv[l][0][0], mgy = cu.mv[l][0][1];
       const int rmx = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mgx + sgn * sh.dmv[0] ), rmy = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mgy + sgn * sh.dmv[1] );
       int cmx = rmx, cmy = rmy;
-      mc_clip_mv( pic, it.x, it.y, cmx, cmy );
+      const int wrapOffF = mc_clip_mv_w( pic, it.x, it.y, w, cmx, cmy );
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
       const int dIntX = ( rmx >> shf ) - ( mgx >> shf ), dIntY = ( rmy >> shf ) - ( mgy >> shf );
       McSeg g;
@@ -667,14 +701,16 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
         // padded local copy: the (w + ntaps - 1)^2 window at the start MV, replicated outwards (xPrefetchPad + paddingCore); the
         // window held in LDS is that copy displaced by the integer part of the refinement
         int pmx = mgx - ( half << shf ), pmy = mgy - ( half << shf );
-        mc_clip_mv( pic, it.x, it.y, pmx, pmy );
+        // xPrefetchPad (:1545-1556): ONE wrapClipMv, so the ordinary copy is read after a move by one period
+        if( pic.hdr.wrap_offset ) g.wrapOff = mc_wrap_clip_mv( pic, it.x, it.y, w, pmx, pmy ) ? pic.hdr.wrap_offset >> cs : 0;
+        else { mc_clip_mv( pic, it.x, it.y, pmx, pmy ); g.wrapOff = 0; }
         g.x0 = ( it.x >> cs ) + ( pmx >> shf ); g.y0 = ( it.y >> cs ) + ( pmy >> shf );
         g.cw = g.ww; g.chh = g.wh; g.padOff = 2; g.shX = 2 + dIntX; g.shY = 2 + dIntY;
       }
       else
       {
         g.x0 = ( it.x >> cs ) + ( cmx >> shf ) - half; g.y0 = ( it.y >> cs ) + ( cmy >> shf ) - half;
-        g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
+        g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0; g.wrapOff = wrapOffF >> cs;
       }
       sh.m.seg[l][c] = g;
       sh.m.refp[l][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
@@ -704,7 +740,7 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
 // =====================================================================================================================
 #define AF_WL 12            // row stride of a luma sub-block window (11 x 11)
 #define AF_WC 8             // row stride of a chroma sub-block window (7 x 7)
-struct AffSeg { int x0, y0, xFrac, yFrac; };     // window origin (block origin - 3 / - 1) in the reference plane, fractional MV
+struct AffSeg { int x0, y0, xFrac, yFrac, wrapOff; };     // window origin (block origin - 3 / - 1) in the reference plane, fractional MV, wrap-around period (0: clamped reads)
 struct AffShared {
   pel_t  winL[2][16][11 * AF_WL];
   pel_t  winC[2][2][4][7 * AF_WC];
@@ -824,7 +860,10 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
         int smx, smy;
         if( onDev ) aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + sx, ( ( it.y - cu.y ) >> 2 ) + sy, smx, smy );
         else { const vvr_motion& m = pic.affMotion[it.mv[0][0] + 4 * sy + sx]; smx = m.mv[l][0]; smy = m.mv[l][1]; }
-        const int mx = min( horMax, max( horMin, smx ) ), my = min( verMax, max( verMin, smy ) );
+        int mx = smx, my = smy;
+        // wrap-around: ONE wrapClipMv per sub-block, against the sub-block (:1177-1186)
+        if( pic.hdr.wrap_offset ) g.wrapOff = mc_wrap_clip_mv( pic, it.x + 4 * sx, it.y + 4 * sy, 4, mx, my ) ? pic.hdr.wrap_offset : 0;
+        else { mx = min( horMax, max( horMin, smx ) ); my = min( verMax, max( verMin, smy ) ); g.wrapOff = 0; }
         g.xFrac = mx & 15; g.yFrac = my & 15;
         g.x0 = it.x + 4 * sx + ( mx >> 4 ) - 3; g.y0 = it.y + 4 * sy + ( my >> 4 ) - 3;
         sh.segL[k][r] = g;
@@ -847,7 +886,8 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
           mx = m0.mv[l][0] + m1.mv[l][0]; my = m0.mv[l][1] + m1.mv[l][1];
         }
         aff_round_mv( mx, my, 1 );
-        mx = min( horMax, max( horMin, mx ) ); my = min( verMax, max( verMin, my ) );
+        if( pic.hdr.wrap_offset ) g.wrapOff = mc_wrap_clip_mv( pic, it.x + 8 * sx, it.y + 8 * sy, 8, mx, my ) ? pic.hdr.wrap_offset >> 1 : 0;
+        else { mx = min( horMax, max( horMin, mx ) ); my = min( verMax, max( verMin, my ) ); g.wrapOff = 0; }
         g.xFrac = mx & 31; g.yFrac = my & 31;
         g.x0 = ( it.x >> 1 ) + 4 * sx + ( mx >> 5 ) - 1; g.y0 = ( it.y >> 1 ) + 4 * sy + ( my >> 5 ) - 1;
         sh.segC[k][q] = g;
@@ -892,7 +932,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       if( xx >= 11 ) continue;
       const int k = blk / nsb, sb = blk - k * nsb;
       const AffSeg g = sh.segL[k][sb];
-      const int sx = clip3( 0, reco.w[0] - 1, g.x0 + xx ), sy = clip3( 0, reco.h[0] - 1, g.y0 + yy );
+      const int sx = mc_ref_col( g.x0 + xx, reco.w[0], g.wrapOff ), sy = clip3( 0, reco.h[0] - 1, g.y0 + yy );
       sh.winL[k][sb][r] = sh.refp[k][0][(size_t) sy * reco.stride[0] + sx];
     }
     if( ncomp == 3 )
@@ -904,7 +944,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
         if( xx >= 7 ) continue;
         const int k = blk / ( 2 * ncb ), q = blk - k * 2 * ncb, c = q / ncb, sb = q - c * ncb;
         const AffSeg g = sh.segC[k][sb];
-        const int sx = clip3( 0, reco.w[1] - 1, g.x0 + xx ), sy = clip3( 0, reco.h[1] - 1, g.y0 + yy );
+        const int sx = mc_ref_col( g.x0 + xx, reco.w[1], g.wrapOff ), sy = clip3( 0, reco.h[1] - 1, g.y0 + yy );
         sh.winC[k][c][sb][r] = sh.refp[k][1 + c][(size_t) sy * reco.stride[1] + sx];
       }
     }

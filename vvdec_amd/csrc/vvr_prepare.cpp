@@ -136,6 +136,7 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
   if( h.slice_type > 2 ) FAIL( VVR_ERR_PARAMETER, "unknown slice type" );
   if( h.ladf_num_intervals == 1 || h.ladf_num_intervals > 5 ) FAIL( VVR_ERR_PARAMETER, "LADF: 2..5 intervals" );
   if( ( h.tool_flags & VVR_TOOL_COL_MOTION ) && !p->motion ) FAIL( VVR_ERR_PARAMETER, "collocated motion requested without a motion field" );
+  if( h.wrap_offset && ( ( h.wrap_offset & 7 ) || h.wrap_offset < ( 1 << h.log2_ctu ) + 16 || h.wrap_offset > h.width ) ) FAIL( VVR_ERR_PARAMETER, "reference wrap-around offset: a multiple of 8 between CTU size + 16 and the picture width" );
   if( h.num_ver_vb > 3 || h.num_hor_vb > 3 ) FAIL( VVR_ERR_PARAMETER, "at most three virtual boundaries per direction" );
   for( int d = 0; d < 2; d++ )
   {
