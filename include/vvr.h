@@ -309,6 +309,14 @@ typedef struct vvr_alf_ctu {     /* CtuAlfData, CodingStructure.h:75 */
   uint8_t pad2[2];
 } vvr_alf_ctu;
 
+typedef struct vvr_subpic {      /* SubPic (Slice.h:820): one sub-picture of the layout the SPS signals (sps_subpic_info_present_flag)        */
+  uint16_t x0, y0, x1, y1;       /* luma samples, inclusive: getSubPicLeft / Top / Right / Bottom; x0, y0 on the CTU grid                      */
+  uint8_t  treated_as_pic;       /* sps_subpic_treated_as_pic_flag: motion compensation of its CUs reads nothing outside the sub-picture       */
+                                 /* (clipMvInSubpic, Mv.cpp:84; Picture::getSubPicBuf + DecLibRecon::createSubPicRefBufs, DecLibRecon.cpp:388)   */
+  uint8_t  lf_across;            /* sps_loop_filter_across_subpic_enabled_flag: 0 = SAO and ALF of its CTUs do not look into other sub-pictures */
+  uint8_t  pad[2];
+} vvr_subpic;
+
 /* ------------------------------------------------------------------------------------------------------------------
  * one picture to reconstruct
  * ---------------------------------------------------------------------------------------------------------------- */
@@ -336,6 +344,10 @@ typedef struct vvr_picture {
    * reference-side glue refuses it). */
   const uint16_t*       ctu_slice;     /* [num_ctu] slice index of every CTU, NULL = one slice                   */
   const uint16_t*       ctu_tile;      /* [num_ctu] tile index of every CTU, NULL = one tile                     */
+  /* Sub-pictures: rectangles of whole CTUs that tile the picture (NULL / 0 or 1: the picture is its only sub-picture).  Not combined with
+   * reference wrap-around (the reference does not support the pair either, Picture.h:114).                                                   */
+  const vvr_subpic*     subpics;
+  uint32_t              num_subpics;
   int                   resident;      /* 0: all array pointers are host memory (copied H2D by vvr_submit);      */
                                        /* 1: all array pointers are DEVICE memory already resident in HBM        */
 } vvr_picture;

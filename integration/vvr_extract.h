@@ -34,6 +34,7 @@ struct Extracted
   vvr_wp_params             wp;
   vvr_scaling_list          scaling;
   std::vector<uint16_t>     ctuSlice, ctuTile;    // filled (and pointed to) when the picture has more than one slice / tile
+  std::vector<vvr_subpic>   subpics;              // filled (and pointed to) when the picture has more than one sub-picture
   uint32_t                  numDmvr = 0;
   std::vector<std::pair<CodingUnit*, uint32_t>> dmvrCus;   // CUs that run DMVR with their offset into the delta-MV output (vvr_read_dmvr)
 };
@@ -150,7 +151,8 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
   }
   if( sps.getUseColorTrans() ) { why = "adaptive colour transform"; return VVR_ERR_UNSUPPORTED; }
   if( pic.slices.empty() ) { why = "picture without a slice"; return VVR_ERR_UNSUPPORTED; }
-  if( pps.getNumSubPics() > 1 ) { why = "picture with sub-pictures"; return VVR_ERR_UNSUPPORTED; }
+  if( pps.getNumSubPics() > 1 && pps.getUseWrapAround() ) { why = "sub-pictures together with reference wrap-around"; return VVR_ERR_UNSUPPORTED; }
+  if( pps.getNumSubPics() > 255 ) { why = "more than 255 sub-pictures"; return VVR_ERR_UNSUPPORTED; }
   // several slices and tiles are expressible (vvr_picture.ctu_slice / ctu_tile) as long as the slices share their header
   for( size_t k = 1; k < pic.slices.size(); k++ ) if( !sameSliceHeader( *pic.slices[0], *pic.slices[k] ) ) { why = "slices with different headers (slice type, reference lists, weights, filter or quantisation switches)"; return VVR_ERR_UNSUPPORTED; }
   if( pic.slices.size() > 65535 || pps.getNumTiles() > 65535 ) { why = "more slices or tiles than a 16-bit index holds"; return VVR_ERR_UNSUPPORTED; }
@@ -452,6 +454,20 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
     }
     if( pic.slices.size() > 1 ) E.pic.ctu_slice = E.ctuSlice.data();
     if( pps.getNumTiles() > 1 ) E.pic.ctu_tile = E.ctuTile.data();
+  }
+  // ---- sub-pictures (PPS::initSubPic has the rectangles; the flags come from the SPS)
+  E.subpics.clear(); E.pic.subpics = nullptr; E.pic.num_subpics = 0;
+  if( pps.getNumSubPics() > 1 )
+  {
+    for( int k = 0; k < pps.getNumSubPics(); k++ )
+    {
+      const SubPic& sp = pps.getSubPic( k );
+      vvr_subpic o; memset( &o, 0, sizeof( o ) );
+      o.x0 = (uint16_t) sp.getSubPicLeft(); o.y0 = (uint16_t) sp.getSubPicTop(); o.x1 = (uint16_t) sp.getSubPicRight(); o.y1 = (uint16_t) sp.getSubPicBottom();
+      o.treated_as_pic = sp.getTreatedAsPicFlag(); o.lf_across = sp.getloopFilterAcrossSubPicEnabledFlag();
+      E.subpics.push_back( o );
+    }
+    E.pic.subpics = E.subpics.data(); E.pic.num_subpics = (uint32_t) E.subpics.size();
   }
   E.pic.resident = 0;
 }

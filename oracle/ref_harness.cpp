@@ -237,6 +237,23 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     pps.setLoopFilterAcrossTilesEnabledFlag( !( H.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) );
     pps.setLoopFilterAcrossSlicesEnabledFlag( !( H.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) );
     pps.setNumSubPics( 1 );
+    if( vp->subpics && vp->num_subpics > 1 )
+    {
+      // sub-picture layout as the SPS signals it (sps_subpic_info_present_flag), one rectangular slice per sub-picture
+      // (pps_single_slice_per_subpic_flag): PPS::initRectSliceMap builds the slice map from it and PPS::initSubPic the SubPic objects
+      sps.setSubPicInfoPresentFlag( true ); sps.setNumSubPics( (uint8_t) vp->num_subpics );
+      for( uint32_t k = 0; k < vp->num_subpics; k++ )
+      {
+        const vvr_subpic& sp = vp->subpics[k];
+        sps.setSubPicCtuTopLeftX( k, sp.x0 >> H.log2_ctu ); sps.setSubPicCtuTopLeftY( k, sp.y0 >> H.log2_ctu );
+        sps.setSubPicWidth( k, ( sp.x1 >> H.log2_ctu ) - ( sp.x0 >> H.log2_ctu ) + 1 ); sps.setSubPicHeight( k, ( sp.y1 >> H.log2_ctu ) - ( sp.y0 >> H.log2_ctu ) + 1 );
+        sps.setSubPicTreatedAsPicFlag( k, sp.treated_as_pic != 0 ); sps.setLoopFilterAcrossSubpicEnabledFlag( k, sp.lf_across != 0 );
+      }
+      pps.setRectSliceFlag( true ); pps.setSingleSlicePerSubPicFlag( true );
+      pps.setNumSubPics( (uint8_t) vp->num_subpics );
+      pps.initRectSliceMap( &sps );
+      pps.initSubPic( sps );
+    }
     pps.setUseWP( ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 1 );        // pps_weighted_pred_flag (P slices)
     pps.setWPBiPred( ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 0 );     // pps_weighted_bipred_flag (B slices)
     pps.pcv = std::make_unique<PreCalcValues>( sps, pps );
@@ -316,6 +333,22 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       {   // the wrap-around copy of a reference picture (DecLibRecon::borderExtPic, DecLibRecon.cpp:262-283; its margins are filled by extendPicBorder below)
         p->createWrapAroundBuf( true, ctuSize );
         p->getRecoBuf( true ).copyFrom( p->getRecoBuf() );
+      }
+      if( vp->subpics && vp->num_subpics > 1 )
+      {   // what the parser and DecLibRecon::createSubPicRefBufs (DecLibRecon.cpp:388-421) do for a reference picture with sub-pictures: the layout, and a
+          // copy of every sub-picture with its own replicated border
+        p->subPictures.clear();
+        for( uint32_t k = 0; k < vp->num_subpics; k++ ) p->subPictures.push_back( pps.getSubPic( k ) );
+        p->m_subPicRefBufs.resize( vp->num_subpics );
+        for( uint32_t k = 0; k < vp->num_subpics; k++ )
+        {
+          const SubPic& sp = pps.getSubPic( k );
+          const Area area( sp.getSubPicLeft(), sp.getSubPicTop(), sp.getSubPicWidthInLumaSample(), sp.getSubPicHeightInLumaSample() );
+          p->m_subPicRefBufs[k].create( p->chromaFormat, Size( area ), ctuSize, p->margin, MEMORY_ALIGN_DEF_SIZE );
+          p->m_subPicRefBufs[k].copyFrom( p->getRecoBuf().subBuf( area ) );
+          p->extendPicBorderBuf( p->m_subPicRefBufs[k] );
+        }
+        p->subPicExtStarted = true;
       }
       p->extendPicBorder( true, true, true, true );   // DecLibRecon::borderExtPic (DecLibRecon.cpp:236) does the same through 6 tasks
       p->borderExtStarted = true;
@@ -663,7 +696,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       case 2: sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); pps.setWrapAroundOffset( 0 ); break;            // (a period of zero: no conforming stream has it)
       case 3: ph->setVirtualBoundariesPresentFlag( true ); ph->setNumVerVirtualBoundaries( 1 ); ph->setVirtualBoundariesPosX( 12, 0 ); break;     // (not on the 8-sample grid: no conforming stream has it)
       case 4: { Slice* s2 = pic.allocateNewSlice(); s2->setPicHeader( ph.get() ); s2->setSliceType( SliceType( H.slice_type ) ); s2->setPOC( H.poc ); s2->setDepQuantEnabledFlag( !slice->getDepQuantEnabledFlag() ); } break;     // (a second slice with another header)
-      case 5: pps.setNumSubPics( 2 ); break;
+      case 5: pps.setNumSubPics( 2 ); sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); pps.setWrapAroundOffset( W ); break;      // (sub-pictures together with wrap-around)
       case 6: sps.setUseColorTrans( true ); break;
       case 7: sps.setBitDepth( 12 ); break;
       case 8: pps.setNumTileColumns( 70000 ); break;                                                       // (more tiles than an index holds)

@@ -43,6 +43,20 @@ static inline int vvo_lf_may_cross( const vvr_picture* pic, int a, int b )
   if( a == b ) return 1;
   if( ( pic->hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && pic->ctu_slice && pic->ctu_slice[a] != pic->ctu_slice[b] ) return 0;
   if( ( pic->hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) && pic->ctu_tile && pic->ctu_tile[a] != pic->ctu_tile[b] ) return 0;
+  if( pic->subpics && pic->num_subpics > 1 )
+  {
+    /* sub-pictures: the flag of the sub-picture the filtered CTU lies in decides (SampleAdaptiveOffset.cpp:806-818, AdaptiveLoopFilter.cpp:183-186) */
+    const int ctu = 1 << pic->hdr.log2_ctu, ctusX = ( pic->hdr.width + ctu - 1 ) / ctu;
+    int sa = -1, sb = -1;
+    for( uint32_t k = 0; k < pic->num_subpics; k++ )
+    {
+      const vvr_subpic* sp = &pic->subpics[k];
+      const int ax = ( a % ctusX ) * ctu, ay = ( a / ctusX ) * ctu, bx = ( b % ctusX ) * ctu, by = ( b / ctusX ) * ctu;
+      if( ax >= sp->x0 && ax <= sp->x1 && ay >= sp->y0 && ay <= sp->y1 ) sa = (int) k;
+      if( bx >= sp->x0 && bx <= sp->x1 && by >= sp->y0 && by <= sp->y1 ) sb = (int) k;
+    }
+    if( sa != sb && sa >= 0 && !pic->subpics[sa].lf_across ) return 0;
+  }
   return 1;
 }
 

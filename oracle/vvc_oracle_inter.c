@@ -23,8 +23,17 @@ typedef struct {
  * sample offset-k-1 as long as k < offset, else the edge sample), and every prediction reads either that copy or the ordinary, edge-replicated one:
  * g_wrapFetch says which, set by the callers from what wrapClipMv (Mv.cpp:112) returned for the block. */
 static int g_wrapOff = 0, g_wrapFetch = 0;
+/* Sub-pictures: a CU in a sub-picture that is treated as a picture (sps_subpic_treated_as_pic_flag) is predicted from a copy of that sub-picture of
+ * the reference picture with its own replicated border (Picture::getSubPicBuf, DecLibRecon::createSubPicRefBufs, DecLibRecon.cpp:388-421) = reads
+ * clamped to the rectangle, and its MVs are clipped against the rectangle (clipMvInSubpic, Mv.cpp:84).  g_mcRect: luma rectangle of the current CU. */
+static int g_mcRect[4] = { 0, 0, 0, 0 }, g_mcRectOn = 0;
 static inline int ref_at( const vvo_planes* r, int c, int x, int y )
 {
+  if( g_mcRectOn )
+  {
+    const int cs = c ? 1 : 0;
+    x = vvo_clip3( g_mcRect[0] >> cs, g_mcRect[2] >> cs, x ); y = vvo_clip3( g_mcRect[1] >> cs, g_mcRect[3] >> cs, y );
+  }
   if( g_wrapFetch )
   {
     const int w = r->w[c], off = g_wrapOff >> ( c ? 1 : 0 );
@@ -154,8 +163,13 @@ static int wrap_clip_mv( int mv[2], int x, int y, int bw, int W, int H, int ctu 
 static void clip_mv_w( int mv[2], int x, int y, int bw, int W, int H, int ctu )
 {
   if( g_wrapOff ) { wrap_clip_mv( mv, x, y, bw, W, H, ctu ); g_wrapFetch = 1; return; }
-  const int horMax = ( W + 8 - x - 1 ) * 16, horMin = ( -ctu - 8 - x + 1 ) * 16;
-  const int verMax = ( H + 8 - y - 1 ) * 16, verMin = ( -ctu - 8 - y + 1 ) * 16;
+  int horMax = ( W + 8 - x - 1 ) * 16, horMin = ( -ctu - 8 - x + 1 ) * 16;
+  int verMax = ( H + 8 - y - 1 ) * 16, verMin = ( -ctu - 8 - y + 1 ) * 16;
+  if( g_mcRectOn )
+  {   /* clipMvInSubpic (Mv.cpp:84-107) */
+    horMax = ( g_mcRect[2] + 1 + 8 - x - 1 ) * 16; horMin = ( -ctu - 8 - ( x - g_mcRect[0] ) + 1 ) * 16;
+    verMax = ( g_mcRect[3] + 1 + 8 - y - 1 ) * 16; verMin = ( -ctu - 8 - ( y - g_mcRect[1] ) + 1 ) * 16;
+  }
   mv[0] = vvo_min( horMax, vvo_max( horMin, mv[0] ) );
   mv[1] = vvo_min( verMax, vvo_max( verMin, mv[1] ) );
 }
@@ -519,8 +533,13 @@ static void affine_list( const vvr_picture* pic, const vvr_cu* cu, int l, const 
     for( int y = 1; y < 4; y++ ) for( int x = 0; x < 4; x++ ) { dMvH[y * 4 + x] = dMvH[( y - 1 ) * 4 + x] + qVX; dMvV[y * 4 + x] = dMvV[( y - 1 ) * 4 + x] + qVY; }
     for( int i = 0; i < 16; i++ ) { round_affine_mv( &dMvH[i], &dMvV[i], 8 ); dMvH[i] = vvo_clip3( -31, 31, dMvH[i] ); dMvV[i] = vvo_clip3( -31, 31, dMvV[i] ); }
   }
-  const int horMax = ( H->width + 8 - cu->x - 1 ) * 16, horMin = ( -ctu - 8 - cu->x + 1 ) * 16;
-  const int verMax = ( H->height + 8 - cu->y - 1 ) * 16, verMin = ( -ctu - 8 - cu->y + 1 ) * 16;
+  int horMax = ( H->width + 8 - cu->x - 1 ) * 16, horMin = ( -ctu - 8 - cu->x + 1 ) * 16;
+  int verMax = ( H->height + 8 - cu->y - 1 ) * 16, verMin = ( -ctu - 8 - cu->y + 1 ) * 16;
+  if( g_mcRectOn )
+  {   /* clipSubPic: clipMvInSubpic against the CU (:1188-1193) */
+    horMax = ( g_mcRect[2] + 1 + 8 - cu->x - 1 ) * 16; horMin = ( -ctu - 8 - ( cu->x - g_mcRect[0] ) + 1 ) * 16;
+    verMax = ( g_mcRect[3] + 1 + 8 - cu->y - 1 ) * 16; verMin = ( -ctu - 8 - ( cu->y - g_mcRect[1] ) + 1 ) * 16;
+  }
   const int headroom = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2;
   for( int c = 0; c < ncomp; c++ )
   {
@@ -763,6 +782,13 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
   const int bd = H->bit_depth, ctu = 1 << H->log2_ctu;
   const int ncomp = H->chroma_format ? 3 : 1;
   g_wrapOff = H->wrap_offset; g_wrapFetch = 0;
+  g_mcRectOn = 0;
+  if( pic->subpics && pic->num_subpics > 1 )
+    for( uint32_t k = 0; k < pic->num_subpics; k++ )
+    {
+      const vvr_subpic* sp = &pic->subpics[k];
+      if( cu->x >= sp->x0 && cu->x <= sp->x1 && cu->y >= sp->y0 && cu->y <= sp->y1 && sp->treated_as_pic ) { g_mcRect[0] = sp->x0; g_mcRect[1] = sp->y0; g_mcRect[2] = sp->x1; g_mcRect[3] = sp->y1; g_mcRectOn = 1; }
+    }
   if( cu->mc_mode == VVR_MC_AFFINE ) return affine_cu( pic, cu, refs, reco );
   if( cu->mc_mode == VVR_MC_SBTMVP ) return sbtmvp_cu( pic, cu, refs, reco );
   if( cu->mc_mode == VVR_MC_GEO ) return geo_cu( pic, cu, refs, num_slots, reco );

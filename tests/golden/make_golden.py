@@ -62,6 +62,7 @@ CASES = [
     ("i_384x256_ctu64_slices", 384, 256, 6, 0, 51, ALL | abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=3, p_cclm=0.3, p_mip=0.2)),
     ("b_384x256_ctu64_tiles_slices", 384, 256, 6, 2, 52, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES,
      dict(num_slices=3, tile_cols=2, tile_rows=2, p_intra=0.3, p_cclm=0.3, p_ciip=0.1, p_affine=0.1, p_coded_chroma=0.5)),
+    ("b_384x256_ctu64_subpictures", 384, 256, 6, 2, 55, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS, dict(subpics=1 | (2 << 1) | (2 << 3), tile_cols=2, tile_rows=2, p_intra=0.15, p_affine=0.2, p_bi=0.8, mv_sigma=24.0)),
     ("b_384x256_ctu64_wrap_around", 384, 256, 6, 3, 54, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(wrap_offset=384, p_intra=0.1, p_affine=0.3, p_bi=0.8, p_geo=0.1, mv_sigma=10.0)),
     ("b_384x256_ctu64_virtual_boundaries", 384, 256, 6, 2, 53, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LMCS, dict(virtual_boundaries=2 | (2 << 2) | 16, p_intra=0.3, p_cclm=0.3, p_affine=0.2, p_coded_chroma=0.5)),
     ("b_256x128_ctu64_ladf", 256, 128, 6, 2, 50, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LADF, dict(p_intra=0.3, p_affine=0.1, p_coded=0.5)),

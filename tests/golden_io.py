@@ -38,6 +38,8 @@ def save(path, desc, refs, outputs):
         d["ctu_slice"] = np.asarray(desc.ctu_slice, np.uint16)
     if desc.ctu_tile is not None:
         d["ctu_tile"] = np.asarray(desc.ctu_tile, np.uint16)
+    if desc.subpics is not None and len(desc.subpics):
+        d["subpics"] = np.frombuffer(np.ascontiguousarray(desc.subpics).tobytes(), np.uint8)
     for slot, planes in refs.items():
         for c, p in enumerate(planes):
             d["ref_%d_%d" % (slot, c)] = np.asarray(p, np.uint16)
@@ -80,6 +82,8 @@ def load(path):
         d.ctu_slice = z["ctu_slice"].astype(np.uint16)
     if "ctu_tile" in z:
         d.ctu_tile = z["ctu_tile"].astype(np.uint16)
+    if "subpics" in z:
+        d.subpics = np.frombuffer(z["subpics"].tobytes(), np.dtype(abi.Subpic)).copy()
     refs, outs = {}, {}
     for k in z.files:
         if k.startswith("ref_"):

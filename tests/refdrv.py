@@ -153,7 +153,9 @@ def extract(desc, refs=None, flags=0):
     return dict(hdr=h, num_dmvr=nd.value, cu=arr(q.cu, q.num_cu, abi.Cu), tu=arr(q.tu, q.num_tu, abi.Tu), coef=arr(q.coef, q.num_coef, abi.i16),
                 ctu_first_cu=arr(q.ctu_first_cu, nctu + 1, abi.u32), motion=arr(q.motion, n4, abi.Motion),
                 lfp=[arr(q.lfp[0], n4, abi.Lfp), arr(q.lfp[1], n4, abi.Lfp)], sao=arr(q.sao, nctu, abi.SaoCtu), alf=arr(q.alf, nctu, abi.AlfCtu),
-                alf_params=one(q.alf_params, abi.AlfParams), lmcs=one(q.lmcs, abi.LmcsParams), wp=one(q.wp, abi.WpParams), scaling=one(q.scaling, abi.ScalingList))
+                alf_params=one(q.alf_params, abi.AlfParams), lmcs=one(q.lmcs, abi.LmcsParams), wp=one(q.wp, abi.WpParams), scaling=one(q.scaling, abi.ScalingList),
+                ctu_slice=arr(q.ctu_slice, nctu, abi.u16), ctu_tile=arr(q.ctu_tile, nctu, abi.u16),
+                subpics=(np.frombuffer((C.c_char * (C.sizeof(abi.Subpic) * q.num_subpics)).from_address(q.subpics), np.dtype(abi.Subpic)).copy() if q.subpics and q.num_subpics else None))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -104,6 +104,17 @@ def _compare(d, e):
                         bad.append("wp.e[%d][%d][%d]" % (l, i, c))
     if h0.tool_flags & abi.TOOL_SCALING_LIST:
         bad += _struct_differ(d.scaling, e["scaling"], "scaling")
+    # slices, tiles (the index of a slice / tile is what the reference numbers them with: compared as partitions), sub-pictures
+    for name in ("ctu_slice", "ctu_tile"):
+        a, b = getattr(d, name), e[name]
+        if (a is None) != (b is None):
+            bad.append("%s present %s vs %s" % (name, a is not None, b is not None))
+        elif a is not None and not np.array_equal(a[:, None] == a[None, :], b[:, None] == b[None, :]):
+            bad.append("%s: another partition" % name)
+    if (d.subpics is None) != (e["subpics"] is None):
+        bad.append("subpics present %s vs %s" % (d.subpics is not None, e["subpics"] is not None))
+    elif d.subpics is not None:
+        bad += _fields_differ(np.ascontiguousarray(d.subpics), e["subpics"], "subpics")
     return bad
 
 
@@ -120,6 +131,9 @@ CASES = [
     ("8bit", 256, 128, 6, 2, 610, ALL | LM, dict(bit_depth=8, p_intra=0.25, p_affine=0.15, p_geo=0.1, p_ciip=0.1, p_mip=0.2, p_isp=0.2, p_cclm=0.3)),
     ("monochrome", 256, 128, 7, 3, 611, ALL | abi.TOOL_LMCS, dict(chroma_format=0, p_intra=0.3, p_affine=0.2, p_mip=0.2, p_isp=0.2)),
     ("no_filters", 200, 136, 5, 2, 612, abi.TOOL_DEP_QUANT | abi.TOOL_DEBLOCK_OFF, dict(p_intra=0.2)),
+    ("ladf_virtual_boundaries_wrap_around", 384, 256, 6, 2, 613, ALL | abi.TOOL_LADF, dict(p_intra=0.2, p_affine=0.2, virtual_boundaries=2 | (2 << 2) | 16, wrap_offset=384)),
+    ("slices_tiles_subpictures", 512, 384, 6, 3, 614, ALL | abi.TOOL_NO_LF_ACROSS_SLICES, dict(p_intra=0.2, tile_cols=2, tile_rows=2, subpics=1 | (2 << 1) | (2 << 3))),
+    ("raster_slices_over_tiles", 512, 384, 6, 1, 615, ALL | abi.TOOL_NO_LF_ACROSS_TILES, dict(p_intra=0.2, num_slices=3, tile_cols=2, tile_rows=2)),
 ]
 
 
@@ -197,7 +211,7 @@ def test_reference_edge_tables_are_safe_for_one_launch_per_direction(built):
     assert ordered > 0
 
 
-@pytest.mark.parametrize("feature,text", [(1, "LADF with more than 5"), (2, "wrap-around motion compensation with a period off"), (3, "virtual boundary off the 8-sample grid"), (4, "slices with different headers"), (5, "sub-pictures"),
+@pytest.mark.parametrize("feature,text", [(1, "LADF with more than 5"), (2, "wrap-around motion compensation with a period off"), (3, "virtual boundary off the 8-sample grid"), (4, "slices with different headers"), (5, "sub-pictures together with reference wrap-around"),
                                           (6, "colour transform"), (7, "bit depth"), (8, "more slices or tiles"), (9, "another size")])
 def test_extractor_refuses_what_the_description_cannot_express(built, feature, text):
     """the reference-side glue never flattens a picture into something it is not: LADF, wrap-around, virtual boundaries, several slices / tiles /

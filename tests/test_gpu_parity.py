@@ -393,6 +393,21 @@ def test_reference_wrap_around(built, W, H, off, kw):
     _run_stream(W, H, 5, 4, 311, TOOLS_A | abi.TOOL_LMCS, intra=True, p_intra=0.1, wrap_offset=off, **kw)
 
 
+@pytest.mark.parametrize("sp,extra,kw", [
+    (1 | (1 << 1) | (1 << 3), 0, dict(tile_cols=2, tile_rows=2, mv_sigma=24.0)),
+    (1 | (2 << 1) | (2 << 3), 0, dict(tile_cols=2, tile_rows=2, p_bi=0.9, mv_sigma=16.0)),
+    (1 | (1 << 1) | (0 << 3), 0, dict(tile_cols=3, tile_rows=2, p_affine=0.4, p_sbtmvp=0.2, p_geo=0.2, p_ciip=0.1, mv_sigma=30.0)),
+    (1 | (2 << 1) | (1 << 3), abi.TOOL_NO_LF_ACROSS_SLICES, dict(tile_cols=3, tile_rows=1, p_cclm=0.3, mv_sigma=40.0)),
+])
+def test_subpictures(built, sp, extra, kw):
+    """sub-pictures: motion compensation of a CU in a sub-picture that is treated as a picture reads the reference pictures inside that sub-picture only (MV
+    clip and clamp rectangle in k_mc, k_mc_dmvr, k_mc_affine), SAO / ALF of a sub-picture whose flag says so stop at its boundary"""
+    T = TOOLS_A | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | extra
+    _run_stream(512, 384, 5, 4, 321, T, intra=True, log2_ctu=6, p_intra=0.15, subpics=sp, **kw)
+    _run_stream(640, 256, 3, 2, 322, T, intra=True, log2_ctu=5, p_intra=0.1, subpics=sp, **kw)
+    _run_stream(1920, 1080, 3, 2, 323, TOOLS_A | extra, intra=True, streams=3, subpics=sp, **kw)
+
+
 def test_affine_motion_spanned_on_the_device(built):
     """VVR_TOOL_AFFINE_MV_ON_DEVICE (SURVEY 8(f)-4): the back-end spans the sub-block MVs of affine CUs from the control-point MVs (PU::setAllAffineMv)
     instead of reading them from the motion field - with the motion of the affine CUs wiped from the description the pictures are the ones the oracle

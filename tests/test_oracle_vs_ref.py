@@ -391,3 +391,41 @@ def test_oracle_equals_reference_wrap_around(built, W, H, l2, idx, seed, off, ex
     d.hdr.wrap_offset = 0
     other = refdrv.oracle_reconstruct(d, refs, flags=0)
     assert any(not np.array_equal(a, b) for a, b in zip(other, want))
+
+
+SUBPIC_CASES = [
+    # W, H, l2, idx, seed, subpics (bit 0 on; bits 1-2 treated as a picture: 0 none 1 all 2 some; bits 3-4 loop filters across: 0 all 1 none 2 some), extra tools, generator parameters
+    (512, 384, 6, 2, 301, 1 | (1 << 1) | (1 << 3), 0, dict(tile_cols=2, tile_rows=2, p_intra=0.1, mv_sigma=24.0)),
+    (512, 384, 6, 1, 302, 1 | (2 << 1) | (2 << 3), abi.TOOL_BDOF | abi.TOOL_DMVR, dict(tile_cols=2, tile_rows=2, p_intra=0.1, p_bi=0.9, mv_sigma=16.0)),
+    (640, 256, 5, 3, 303, 1 | (1 << 1) | (0 << 3), abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(tile_cols=3, tile_rows=2, p_intra=0.1, p_affine=0.4, p_sbtmvp=0.2, p_geo=0.2, p_ciip=0.1, mv_sigma=30.0)),
+    (384, 256, 7, 2, 304, 1 | (2 << 1) | (1 << 3), abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_NO_LF_ACROSS_SLICES, dict(tile_cols=3, tile_rows=1, p_intra=0.3, p_cclm=0.3, mv_sigma=40.0)),
+    (512, 384, 6, 0, 305, 1 | (1 << 1) | (1 << 3), 0, dict(tile_cols=2, tile_rows=3, dual_tree=1.0)),                    # I picture: only the loop filters know about sub-pictures
+]
+
+
+@pytest.mark.parametrize("W,H,l2,idx,seed,sp,extra,kw", SUBPIC_CASES)
+def test_oracle_equals_reference_subpictures(built, W, H, l2, idx, seed, sp, extra, kw):
+    """sub-pictures (one per tile, one slice each): CUs of a sub-picture that is treated as a picture are predicted from that sub-picture of the reference
+    pictures only (clipMvInSubpic + the sub-picture copies with their own border), SAO and ALF of a sub-picture whose flag says so do not look into other
+    sub-pictures, deblocking across a boundary needs the flag of both sides (host table, checked against the reference's derivation)"""
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=ALL | extra, log2_ctu=l2, subpics=sp, **kw)
+    assert d.subpics is not None and len(d.subpics) == kw["tile_cols"] * kw["tile_rows"]
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc))
+    for fl in STAGES:
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+    a = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK)["planes"]
+    b = refdrv.reconstruct(d, refs, flags=refdrv.STOP_AFTER_DBK | refdrv.DERIVE_LFP)["planes"]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # the sub-pictures matter
+    final = want
+    d.subpics = None
+    other = refdrv.oracle_reconstruct(d, refs, flags=0)
+    assert any(not np.array_equal(x, y) for x, y in zip(other, final))

@@ -75,6 +75,8 @@ typedef struct vvs_params {
   uint8_t  tile_cols, tile_rows;// > 1: uniform tile grid.  Whether the loop filters cross these boundaries is in tool_flags (VVR_TOOL_NO_LF_ACROSS_*)
   uint16_t wrap_offset;         // > 0: horizontal reference wrap-around with this period (luma samples; header field of the same name), and inter CUs close
                                 // to the left / right picture edge point across it more often
+  uint8_t  subpics;             // bit 0: one sub-picture per tile (needs a tile grid; slices are then one per tile as well); bits 1-2: treated as a picture:
+                                // 0 none, 1 all, 2 some; bits 3-4: loop filters across sub-picture boundaries: 0 everywhere, 1 nowhere, 2 for some
   uint8_t  virtual_boundaries;  // bits 0-1: number of vertical, bits 2-3: of horizontal virtual boundaries of the in-loop filters (picture header); bit 4: the first
                                 // of each direction lies on a CTU boundary
 } vvs_params;
@@ -94,8 +96,9 @@ typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
   vvr_scaling_list* scaling;      // filled when VVR_TOOL_SCALING_LIST is in tool_flags
   uint16_t*    ctu_slice;         // [num_ctu], filled when the parameters ask for more than one slice (else left alone)
   uint16_t*    ctu_tile;          // [num_ctu], likewise for tiles
+  vvr_subpic*  subpics;           // [up to 255], filled when the parameters ask for sub-pictures
   // outputs
-  uint32_t     num_cu, num_tu; uint64_t num_coef; uint32_t num_dmvr;
+  uint32_t     num_cu, num_tu; uint64_t num_coef; uint32_t num_dmvr; uint32_t num_subpics;
   vvr_pic_header hdr;
 } vvs_buffers;
 
@@ -147,10 +150,13 @@ struct Gen {
     else         { for( int i = 0; i < h.num_hor_vb; i++ ) if( h.vb_pos_y[i] == ( y4 << 2 ) ) return true; }
     return false;
   }
+  std::vector<uint16_t> subpicOfCtu; std::vector<vvr_subpic> subpicV;
   bool lfMayCross( int a, int b ) const
   {
     if( ( P.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && sliceOfCtu[a] != sliceOfCtu[b] ) return false;
     if( ( P.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) && tileOfCtu[a] != tileOfCtu[b] ) return false;
+    // deblocking between two sub-pictures needs the flag of both (LoopFilter.cpp:1074-1088)
+    if( !subpicV.empty() && subpicOfCtu[a] != subpicOfCtu[b] && !( subpicV[subpicOfCtu[a]].lf_across && subpicV[subpicOfCtu[b]].lf_across ) ) return false;
     return true;
   }
   void layoutSlicesAndTiles()
@@ -176,7 +182,29 @@ struct Gen {
         for( int a = 0; a < n; a++ ) sliceOfCtu[a] = (uint16_t) ( ( a / ctusX ) * k / ctusY );
       }
     }
-    if( B.ctu_slice && ns > 1 ) memcpy( B.ctu_slice, sliceOfCtu.data(), sizeof( uint16_t ) * n );
+    subpicV.clear(); B.num_subpics = 0;
+    if( ( P.subpics & 1 ) && numTiles > 1 && B.subpics )
+    {
+      // one sub-picture per tile, one (rectangular) slice per sub-picture (pps_single_slice_per_subpic_flag)
+      subpicOfCtu = tileOfCtu; sliceOfCtu = tileOfCtu;
+      subpicV.resize( numTiles );
+      for( int k = 0; k < numTiles; k++ ) { vvr_subpic& sp = subpicV[k]; memset( &sp, 0, sizeof( sp ) ); sp.x0 = sp.y0 = 0xffff; }
+      for( int a = 0; a < n; a++ )
+      {
+        vvr_subpic& sp = subpicV[tileOfCtu[a]];
+        const int x0 = ( a % ctusX ) * ctu, y0 = ( a / ctusX ) * ctu, x1 = std::min( W, x0 + ctu ) - 1, y1 = std::min( H, y0 + ctu ) - 1;
+        sp.x0 = (uint16_t) std::min<int>( sp.x0, x0 ); sp.y0 = (uint16_t) std::min<int>( sp.y0, y0 ); sp.x1 = (uint16_t) std::max<int>( sp.x1, x1 ); sp.y1 = (uint16_t) std::max<int>( sp.y1, y1 );
+      }
+      const int tm = ( P.subpics >> 1 ) & 3, lm = ( P.subpics >> 3 ) & 3;
+      for( int k = 0; k < numTiles; k++ )
+      {
+        subpicV[k].treated_as_pic = (uint8_t) ( tm == 1 || ( tm == 2 && rng.p( 0.6 ) ) );
+        subpicV[k].lf_across = (uint8_t) ( lm == 0 || ( lm == 2 && rng.p( 0.5 ) ) );
+      }
+      memcpy( B.subpics, subpicV.data(), sizeof( vvr_subpic ) * numTiles ); B.num_subpics = (uint32_t) numTiles;
+      if( B.ctu_slice ) memcpy( B.ctu_slice, sliceOfCtu.data(), sizeof( uint16_t ) * n );
+    }
+    if( B.ctu_slice && ns > 1 && subpicV.empty() ) memcpy( B.ctu_slice, sliceOfCtu.data(), sizeof( uint16_t ) * n );
     if( B.ctu_tile && numTiles > 1 ) memcpy( B.ctu_tile, tileOfCtu.data(), sizeof( uint16_t ) * n );
   }
 

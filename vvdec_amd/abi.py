@@ -104,6 +104,10 @@ class ScalingList(C.Structure):
     _fields_ = [("coef", u8 * 64 * 28), ("dc", u8 * 28), ("pad", u8 * 4)]
 
 
+class Subpic(C.Structure):
+    _fields_ = [("x0", u16), ("y0", u16), ("x1", u16), ("y1", u16), ("treated_as_pic", u8), ("lf_across", u8), ("pad", u8 * 2)]
+
+
 class Picture(C.Structure):
     _fields_ = [("hdr", PicHeader), ("num_cu", u32), ("num_tu", u32),
                 ("cu", C.POINTER(Cu)), ("tu", C.POINTER(Tu)), ("ctu_first_cu", C.POINTER(u32)),
@@ -112,7 +116,7 @@ class Picture(C.Structure):
                 ("sao", C.POINTER(SaoCtu)), ("alf", C.POINTER(AlfCtu)),
                 ("alf_params", C.POINTER(AlfParams)), ("lmcs", C.POINTER(LmcsParams)),
                 ("wp", C.POINTER(WpParams)), ("scaling", C.POINTER(ScalingList)),
-                ("ctu_slice", C.POINTER(u16)), ("ctu_tile", C.POINTER(u16)), ("resident", C.c_int)]
+                ("ctu_slice", C.POINTER(u16)), ("ctu_tile", C.POINTER(u16)), ("subpics", C.c_void_p), ("num_subpics", u32), ("resident", C.c_int)]
 
 
 class Config(C.Structure):

@@ -97,6 +97,8 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
   const vvr_wp_params*   wp;         // explicit weighted prediction table (NULL unless VVR_TOOL_WP on a P / B picture)
   const uint16_t*    ctuSlice;       // slice / tile index of every CTU (NULL: one slice / one tile): where SAO and ALF stop when the picture says so
   const uint16_t*    ctuTile;
+  const vvr_subpic*  subpics;        // sub-pictures (NULL: the picture is its only sub-picture) and the sub-picture of every CTU: MC of a CU in a sub-picture
+  const uint16_t*    ctuSubpic;      // treated as a picture stays inside it; SAO / ALF of a CTU whose sub-picture says so do not look into other sub-pictures
   const uint8_t*     interAt;        // per 4x4 luma unit: 1 = covered by an inter CU (LMCS forward mapping of the prediction)
   const uint32_t*    csVpdu;         // LMCS chroma residual scaling, per VPDU: x | y << 13 | hasLeft << 26 | hasAbove << 27 of the luma neighbourhood the factor is averaged over
   vvr_motion*        colMotion;      // collocated motion of the picture (pinned host memory, device-mapped; NULL unless VVR_TOOL_COL_MOTION): the DMVR kernel patches it

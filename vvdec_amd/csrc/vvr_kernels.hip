@@ -74,6 +74,7 @@ struct McSeg {
   int ox, oy;            // position of the block's integer-sample origin inside the window
   int padOff, cw, chh;   // DMVR padded copy (xPrefetchPad): window sample (u,v) = copied sample (clamp(u + shX - padOff, 0, cw - 1), clamp(v + shY - padOff, 0, chh - 1))
   int shX, shY;          // displacement of the window inside the padded copy (the integer part of the DMVR refinement)
+  int bx0, by0, bx1, by1;// what may be read of the reference plane (component samples, inclusive): the plane, or the CU's sub-picture (mc_bounds)
   int wrapOff;           // > 0: the reference is read as if it wrapped around horizontally at this period (component samples): the reference's wrap copy
 };
 
@@ -94,12 +95,26 @@ __device__ __forceinline__ int mc_item_index()
   return ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + ( bid >> 3 );
 }
 
-// clipMvInPic (Mv.cpp:64) against the block at luma position (x, y)
-__device__ __forceinline__ void mc_clip_mv( const PicDev& pic, int x, int y, int& mvx, int& mvy )
+// What motion compensation of a CU may read of a reference picture (luma samples, inclusive): the picture - or, for a CU in a sub-picture that is
+// treated as a picture, that sub-picture: the reference predicts such CUs from a copy of the sub-picture with its own replicated border
+// (Picture::getSubPicBuf, DecLibRecon::createSubPicRefBufs, DecLibRecon.cpp:388-421), which is the clamp to its rectangle here.
+struct McBounds { int x0, y0, x1, y1; };
+__device__ __forceinline__ McBounds mc_bounds( const PicDev& pic, int cuX, int cuY )
+{
+  McBounds b = { 0, 0, (int) pic.hdr.width - 1, (int) pic.hdr.height - 1 };
+  if( pic.subpics )
+  {
+    const vvr_subpic sp = pic.subpics[pic.ctuSubpic[( cuY >> pic.hdr.log2_ctu ) * pic.ctus_x + ( cuX >> pic.hdr.log2_ctu )]];
+    if( sp.treated_as_pic ) { b.x0 = sp.x0; b.y0 = sp.y0; b.x1 = sp.x1; b.y1 = sp.y1; }
+  }
+  return b;
+}
+// clipMvInPic / clipMvInSubpic (Mv.cpp:64,84) against the block at luma position (x, y)
+__device__ __forceinline__ void mc_clip_mv( const PicDev& pic, const McBounds& b, int x, int y, int& mvx, int& mvy )
 {
   const int ctu = 1 << pic.hdr.log2_ctu;
-  const int horMax = ( pic.hdr.width + 8 - x - 1 ) * 16, horMin = ( -ctu - 8 - x + 1 ) * 16;
-  const int verMax = ( pic.hdr.height + 8 - y - 1 ) * 16, verMin = ( -ctu - 8 - y + 1 ) * 16;
+  const int horMax = ( b.x1 + 1 + 8 - x - 1 ) * 16, horMin = ( -ctu - 8 - ( x - b.x0 ) + 1 ) * 16;
+  const int verMax = ( b.y1 + 1 + 8 - y - 1 ) * 16, verMin = ( -ctu - 8 - ( y - b.y0 ) + 1 ) * 16;
   mvx = min( horMax, max( horMin, mvx ) ); mvy = min( verMax, max( verMin, mvy ) );
 }
 
@@ -120,17 +135,17 @@ __device__ __forceinline__ bool mc_wrap_clip_mv( const PicDev& pic, int x, int y
 // The MV clip of the regular prediction paths (clipMv = clipMvInPic, then wrapClipMv once more on the result: InterPrediction.cpp:651-656, 1751-1752,
 // 1810-1815): without wrap-around the clamp of mc_clip_mv; with it the MV after wrapClipMv, and the second call - which finds the MV inside its range -
 // always selects the wrap copy.  Returns the period to read the reference with (luma samples), 0 = ordinary clamped reads.
-__device__ __forceinline__ int mc_clip_mv_w( const PicDev& pic, int x, int y, int bw, int& mvx, int& mvy )
+__device__ __forceinline__ int mc_clip_mv_w( const PicDev& pic, const McBounds& b, int x, int y, int bw, int& mvx, int& mvy )
 {
-  if( !pic.hdr.wrap_offset ) { mc_clip_mv( pic, x, y, mvx, mvy ); return 0; }
+  if( !pic.hdr.wrap_offset ) { mc_clip_mv( pic, b, x, y, mvx, mvy ); return 0; }
   mc_wrap_clip_mv( pic, x, y, bw, mvx, mvy );
   return pic.hdr.wrap_offset;
 }
 // column of the reference's wrap copy (Picture::extendPicBorderWrap, Picture.cpp:410-518): margin sample -k-1 = sample off-k-1 while k < off, else the edge
-__device__ __forceinline__ int mc_ref_col( int x, int pw, int off )
+__device__ __forceinline__ int mc_ref_col( int x, int lo, int hi, int pw, int off )
 {
   if( off ) { if( x < 0 ) return -x <= off ? x + off : 0; if( x >= pw ) return x - pw < off ? x - off : pw - 1; return x; }
-  return clip3( 0, pw - 1, x );
+  return clip3( lo, hi, x );
 }
 
 // filter taps of one segment (InterpolationFilter.cpp:1078-1085 / 669-676: luma 4x4 blocks use the 6-tap table; :105 alternative half-pel filter)
@@ -151,7 +166,7 @@ __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg
   const int col = tid & 31, row0 = tid >> 5;
   if( col < g.ww )
   {
-    const int sx = mc_ref_col( g.x0 + clip3( 0, g.cw - 1, col + g.shX - g.padOff ), pw, g.wrapOff );
+    const int sx = mc_ref_col( g.x0 + clip3( 0, g.cw - 1, col + g.shX - g.padOff ), g.bx0, g.bx1, pw, g.wrapOff );
     const pel_t* __restrict__ rc = ref + sx;
     // four rows per step, all four loads issued before the first LDS store: one memory round trip per four rows instead of one per
     // row (the tail repeats the last row: same value to the same place)
@@ -162,7 +177,7 @@ __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg
       for( int u = 0; u < 4; u++ )
       {
         yy[u] = min( yb + u * ( NT / 32 ), g.wh - 1 - ( ( g.wh - 1 - row0 ) % ( NT / 32 ) ) );      // last row of this lane's parity
-        const int sy = clip3( 0, ph - 1, g.y0 + clip3( 0, g.chh - 1, yy[u] + g.shY - g.padOff ) );
+        const int sy = clip3( g.by0, g.by1, g.y0 + clip3( 0, g.chh - 1, yy[u] + g.shY - g.padOff ) );
         v[u] = rc[(size_t) sy * stride];
       }
 #pragma unroll
@@ -487,10 +502,11 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
       const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : ( l ? mRef[1] : mRef[0] );
       int mvx = geo ? cu.geo_mv[k][0] : ( l ? it.mv[1][0] : it.mv[0][0] ), mvy = geo ? cu.geo_mv[k][1] : ( l ? it.mv[1][1] : it.mv[0][1] );
-      const int wrapOff = mc_clip_mv_w( pic, clipX, clipY, pic.hdr.wrap_offset ? (int) cu.w : 0, mvx, mvy );         // clipped with the CU position and size (InterPrediction.cpp:651-656 uses m_currCuArea)
+      const McBounds B = mc_bounds( pic, clipX, clipY );
+      const int wrapOff = mc_clip_mv_w( pic, B, clipX, clipY, pic.hdr.wrap_offset ? (int) cu.w : 0, mvx, mvy );         // clipped with the CU position and size (InterPrediction.cpp:651-656 uses m_currCuArea)
       McSeg g;
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
-      g.wrapOff = wrapOff >> cs;
+      g.wrapOff = wrapOff >> cs; g.bx0 = B.x0 >> cs; g.by0 = B.y0 >> cs; g.bx1 = B.x1 >> cs; g.by1 = B.y1 >> cs;
       g.w = it.w >> cs; g.h = it.h >> cs;
       g.xFrac = mvx & ( ( 1 << shf ) - 1 ); g.yFrac = mvy & ( ( 1 << shf ) - 1 );
       g.ox = half; g.oy = half;
@@ -573,9 +589,10 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
     int mvx = cu.mv[l][0][0], mvy = cu.mv[l][0][1];
     // (xinitMC runs per sub-CU, :1804-1815: with wrap-around the period shift depends on the sub-block's position and width; without it the clamp against
     // the CU gives the same samples)
-    const int wrapOff = pic.hdr.wrap_offset ? mc_clip_mv_w( pic, it.x, it.y, w, mvx, mvy ) : mc_clip_mv_w( pic, cu.x, cu.y, 0, mvx, mvy );
+    const McBounds B = mc_bounds( pic, cu.x, cu.y );
+    const int wrapOff = pic.hdr.wrap_offset ? mc_clip_mv_w( pic, B, it.x, it.y, w, mvx, mvy ) : mc_clip_mv_w( pic, B, cu.x, cu.y, 0, mvx, mvy );
     mvx -= 32; mvy -= 32;
-    McSeg g; g.wrapOff = wrapOff;
+    McSeg g; g.wrapOff = wrapOff; g.bx0 = B.x0; g.by0 = B.y0; g.bx1 = B.x1; g.by1 = B.y1;
     g.w = w + 4; g.h = h + 4; g.xFrac = mvx & 15; g.yFrac = mvy & 15;
     g.x0 = it.x + ( mvx >> 4 ); g.y0 = it.y + ( mvy >> 4 ); g.ww = g.w + 1; g.wh = g.h + 1; g.ox = g.oy = 0; g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
     sh.m.seg[l][0] = g;
@@ -689,10 +706,11 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
       const int mgx = cu.mv[l][0][0], mgy = cu.mv[l][0][1];
       const int rmx = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mgx + sgn * sh.dmv[0] ), rmy = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mgy + sgn * sh.dmv[1] );
       int cmx = rmx, cmy = rmy;
-      const int wrapOffF = mc_clip_mv_w( pic, it.x, it.y, w, cmx, cmy );
+      const McBounds B = mc_bounds( pic, cu.x, cu.y );
+      const int wrapOffF = mc_clip_mv_w( pic, B, it.x, it.y, w, cmx, cmy );
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
       const int dIntX = ( rmx >> shf ) - ( mgx >> shf ), dIntY = ( rmy >> shf ) - ( mgy >> shf );
-      McSeg g;
+      McSeg g; g.bx0 = B.x0 >> cs; g.by0 = B.y0 >> cs; g.bx1 = B.x1 >> cs; g.by1 = B.y1 >> cs;
       g.w = w >> cs; g.h = h >> cs;
       g.xFrac = cmx & ( ( 1 << shf ) - 1 ); g.yFrac = cmy & ( ( 1 << shf ) - 1 );
       g.ox = half; g.oy = half; g.ww = g.w + ntaps - 1; g.wh = g.h + ntaps - 1;
@@ -703,7 +721,7 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
         int pmx = mgx - ( half << shf ), pmy = mgy - ( half << shf );
         // xPrefetchPad (:1545-1556): ONE wrapClipMv, so the ordinary copy is read after a move by one period
         if( pic.hdr.wrap_offset ) g.wrapOff = mc_wrap_clip_mv( pic, it.x, it.y, w, pmx, pmy ) ? pic.hdr.wrap_offset >> cs : 0;
-        else { mc_clip_mv( pic, it.x, it.y, pmx, pmy ); g.wrapOff = 0; }
+        else { mc_clip_mv( pic, B, it.x, it.y, pmx, pmy ); g.wrapOff = 0; }
         g.x0 = ( it.x >> cs ) + ( pmx >> shf ); g.y0 = ( it.y >> cs ) + ( pmy >> shf );
         g.cw = g.ww; g.chh = g.wh; g.padOff = 2; g.shX = 2 + dIntX; g.shY = 2 + dIntY;
       }
@@ -845,10 +863,12 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   const bool wpOn = pic.wp && cu.bcw_idx == 2;       // explicit weighted prediction: also a single list stays at 14 bit until the final stage
   const bool hi = biPred || wpOn;
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const McBounds AB = mc_bounds( pic, cu.x, cu.y );
   // ---- sub-block geometry
   {
-    const int horMax = ( pic.hdr.width + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - cu.x + 1 ) * 16;
-    const int verMax = ( pic.hdr.height + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - cu.y + 1 ) * 16;
+    // (picture bounds, or the CU's sub-picture when that is treated as a picture: clipMvInSubpic against the CU, :1188-1193)
+    const int horMax = ( AB.x1 + 1 + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - ( cu.x - AB.x0 ) + 1 ) * 16;
+    const int verMax = ( AB.y1 + 1 + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - ( cu.y - AB.y0 ) + 1 ) * 16;
     const bool onDev = ( pic.hdr.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) != 0;
     for( int i = tid; i < nl * ( nsb + ncb ); i += NT )
     {
@@ -932,7 +952,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       if( xx >= 11 ) continue;
       const int k = blk / nsb, sb = blk - k * nsb;
       const AffSeg g = sh.segL[k][sb];
-      const int sx = mc_ref_col( g.x0 + xx, reco.w[0], g.wrapOff ), sy = clip3( 0, reco.h[0] - 1, g.y0 + yy );
+      const int sx = mc_ref_col( g.x0 + xx, AB.x0, AB.x1, reco.w[0], g.wrapOff ), sy = clip3( AB.y0, AB.y1, g.y0 + yy );
       sh.winL[k][sb][r] = sh.refp[k][0][(size_t) sy * reco.stride[0] + sx];
     }
     if( ncomp == 3 )
@@ -944,7 +964,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
         if( xx >= 7 ) continue;
         const int k = blk / ( 2 * ncb ), q = blk - k * 2 * ncb, c = q / ncb, sb = q - c * ncb;
         const AffSeg g = sh.segC[k][sb];
-        const int sx = mc_ref_col( g.x0 + xx, reco.w[1], g.wrapOff ), sy = clip3( 0, reco.h[1] - 1, g.y0 + yy );
+        const int sx = mc_ref_col( g.x0 + xx, AB.x0 >> 1, AB.x1 >> 1, reco.w[1], g.wrapOff ), sy = clip3( AB.y0 >> 1, AB.y1 >> 1, g.y0 + yy );
         sh.winC[k][c][sb][r] = sh.refp[k][1 + c][(size_t) sy * reco.stride[1] + sx];
       }
     }
@@ -1651,7 +1671,7 @@ void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )
 // =====================================================================================================================
 __device__ __forceinline__ bool lf_restricted( const PicDev& pic )
 {
-  return ( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && pic.ctuSlice ) || ( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) && pic.ctuTile );
+  return ( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && pic.ctuSlice ) || ( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) && pic.ctuTile ) || pic.ctuSubpic;
 }
 // may a filter working on CTU a read samples of CTU b?
 __device__ __forceinline__ bool lf_may_cross( const PicDev& pic, int a, int b )
@@ -1659,6 +1679,8 @@ __device__ __forceinline__ bool lf_may_cross( const PicDev& pic, int a, int b )
   if( a == b ) return true;
   if( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_SLICES ) && pic.ctuSlice && pic.ctuSlice[a] != pic.ctuSlice[b] ) return false;
   if( ( pic.hdr.tool_flags & VVR_TOOL_NO_LF_ACROSS_TILES ) && pic.ctuTile && pic.ctuTile[a] != pic.ctuTile[b] ) return false;
+  // sub-pictures: the flag of the sub-picture the filtered CTU lies in decides (SampleAdaptiveOffset.cpp:806-818, AdaptiveLoopFilter.cpp:183-186)
+  if( pic.ctuSubpic && pic.ctuSubpic[a] != pic.ctuSubpic[b] && !pic.subpics[pic.ctuSubpic[a]].lf_across ) return false;
   return true;
 }
 // ALF: the part of the plane a CTU may read, as a clamp of the coordinates.  Bits of f: 1 left, 2 right, 4 top, 8 bottom edge of the CTU clipped;

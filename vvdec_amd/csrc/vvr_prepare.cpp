@@ -34,6 +34,7 @@ struct PrepScratch
   bool wpOn = false, cscale = false, lmcs = false;
   // ---- work lists
   std::vector<McItem> mc, mcBdof, mcDmvr, mcAff;
+  std::vector<uint16_t> ctuSubpicV;        // sub-picture of every CTU, built from the rectangles (layout)
   std::vector<vvr_motion> affMv;           // motion of the 4x4 sub-blocks of the affine tiles, 16 entries per tile (the only part of the motion field a kernel reads)
   uint32_t numDmvr = 0;
   std::vector<TbItem> tb[3];
@@ -69,7 +70,7 @@ struct PrepScratch
   // ---- layout of the H2D image
   std::vector<Part> parts;
   size_t total = 0, numDirect = 0;          // parts [0, numDirect) are copied from the caller's pinned arrays
-  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iLmcs, iSl, iCtuSlice, iCtuTile, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iUnits;
+  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iUnits;
 
   void begin( const vvr_picture* pic )
   {
@@ -137,6 +138,23 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
   if( h.ladf_num_intervals == 1 || h.ladf_num_intervals > 5 ) FAIL( VVR_ERR_PARAMETER, "LADF: 2..5 intervals" );
   if( ( h.tool_flags & VVR_TOOL_COL_MOTION ) && !p->motion ) FAIL( VVR_ERR_PARAMETER, "collocated motion requested without a motion field" );
   if( h.wrap_offset && ( ( h.wrap_offset & 7 ) || h.wrap_offset < ( 1 << h.log2_ctu ) + 16 || h.wrap_offset > h.width ) ) FAIL( VVR_ERR_PARAMETER, "reference wrap-around offset: a multiple of 8 between CTU size + 16 and the picture width" );
+  if( p->num_subpics > 1 )
+  {
+    // sub-pictures: rectangles of whole CTUs that tile the picture
+    if( !p->subpics || p->num_subpics > 255 ) FAIL( VVR_ERR_PARAMETER, "sub-pictures: at most 255, with their table" );
+    if( h.wrap_offset ) FAIL( VVR_ERR_UNSUPPORTED, "sub-pictures together with reference wrap-around (the reference decoder does not support the pair either)" );
+    const int ctuM = ( 1 << h.log2_ctu ) - 1;
+    uint64_t area = 0;
+    for( uint32_t k = 0; k < p->num_subpics; k++ )
+    {
+      const vvr_subpic& sp = p->subpics[k];
+      if( ( sp.x0 & ctuM ) || ( sp.y0 & ctuM ) || sp.x1 < sp.x0 || sp.y1 < sp.y0 || sp.x1 >= h.width || sp.y1 >= h.height
+       || ( sp.x1 != h.width - 1 && ( ( sp.x1 + 1 ) & ctuM ) ) || ( sp.y1 != h.height - 1 && ( ( sp.y1 + 1 ) & ctuM ) ) ) FAIL( VVR_ERR_PARAMETER, "sub-picture rectangle off the CTU grid or outside the picture" );
+      for( uint32_t j = 0; j < k; j++ ) { const vvr_subpic& o = p->subpics[j]; if( sp.x0 <= o.x1 && o.x0 <= sp.x1 && sp.y0 <= o.y1 && o.y0 <= sp.y1 ) FAIL( VVR_ERR_PARAMETER, "sub-pictures overlap" ); }
+      area += (uint64_t) ( sp.x1 - sp.x0 + 1 ) * ( sp.y1 - sp.y0 + 1 );
+    }
+    if( area != (uint64_t) h.width * h.height ) FAIL( VVR_ERR_PARAMETER, "sub-pictures do not cover the picture" );
+  }
   if( h.num_ver_vb > 3 || h.num_hor_vb > 3 ) FAIL( VVR_ERR_PARAMETER, "at most three virtual boundaries per direction" );
   for( int d = 0; d < 2; d++ )
   {
@@ -1006,6 +1024,18 @@ void PrepScratch::layout( PinnedRanges* pinned )
   iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
   iSl = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? add( p->scaling, sizeof( vvr_scaling_list ) ) : -1;
   iCtuSlice = p->ctu_slice ? add( p->ctu_slice, sizeof( uint16_t ) * numCtu ) : -1;
+  iSubpics = iCtuSubpic = -1;
+  if( p->subpics && p->num_subpics > 1 )
+  {
+    ctuSubpicV.assign( (size_t) numCtu, 0 );
+    for( uint32_t k = 0; k < p->num_subpics; k++ )
+    {
+      const vvr_subpic& sp = p->subpics[k];
+      for( int y = sp.y0 >> h.log2_ctu; y <= sp.y1 >> h.log2_ctu; y++ ) for( int x = sp.x0 >> h.log2_ctu; x <= sp.x1 >> h.log2_ctu; x++ ) ctuSubpicV[(size_t) y * ctusX + x] = (uint16_t) k;
+    }
+    iSubpics = add( p->subpics, sizeof( vvr_subpic ) * p->num_subpics );
+    iCtuSubpic = add( ctuSubpicV.data(), sizeof( uint16_t ) * ctuSubpicV.size() );
+  }
   iCtuTile = p->ctu_tile ? add( p->ctu_tile, sizeof( uint16_t ) * numCtu ) : -1;
   iWp = wpOn ? add( p->wp, sizeof( vvr_wp_params ) ) : -1;
   iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
@@ -1092,6 +1122,7 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   d.sao = (const vvr_sao_ctu*) at( S.iSao ); d.alf = (const vvr_alf_ctu*) at( S.iAlf ); d.alf_params = (const vvr_alf_params*) at( S.iAlfP );
   d.lmcs = (const vvr_lmcs_params*) at( S.iLmcs ); d.scaling = (const vvr_scaling_list*) at( S.iSl ); d.wp = (const vvr_wp_params*) at( S.iWp );
   d.ctuSlice = (const uint16_t*) at( S.iCtuSlice ); d.ctuTile = (const uint16_t*) at( S.iCtuTile );
+  d.subpics = (const vvr_subpic*) at( S.iSubpics ); d.ctuSubpic = (const uint16_t*) at( S.iCtuSubpic );
   d.interAt = (const uint8_t*) at( S.iInterAt );
   d.csVpdu = (const uint32_t*) at( S.iCsVpdu ); d.vpdusX = S.vpdusX; d.vpduLog2 = S.vpduLog2;
   (void) p;

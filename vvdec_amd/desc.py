@@ -47,6 +47,7 @@ class PictureDesc:
         self.scaling = None
         self.ctu_slice = None          # uint16 [num_ctu] or None (one slice)
         self.ctu_tile = None           # uint16 [num_ctu] or None (one tile)
+        self.subpics = None            # array of abi.Subpic records or None (the picture is its only sub-picture)
 
     def set_refs(self, l0, l1=()):
         """l0/l1: lists of (slot, poc)."""
@@ -92,6 +93,10 @@ class PictureDesc:
         if self.ctu_tile is not None:
             self.ctu_tile = np.ascontiguousarray(self.ctu_tile, dtype=np.uint16)
             p.ctu_tile = self.ctu_tile.ctypes.data_as(C.POINTER(abi.u16))
+        if self.subpics is not None and len(self.subpics):
+            self.subpics = np.ascontiguousarray(self.subpics, dtype=np.dtype(abi.Subpic))
+            p.subpics = self.subpics.ctypes.data
+            p.num_subpics = len(self.subpics)
         p.resident = 0
         self._keep = p
         return p

@@ -33,14 +33,14 @@ class Params(C.Structure):
                 ("p_sao", C.c_float), ("p_alf_luma", C.c_float), ("p_alf_chroma", C.c_float), ("p_ccalf", C.c_float),
                 ("p_imv_hpel", C.c_float), ("p_jccr", C.c_float), ("p_mrl", C.c_float), ("p_bdpcm", C.c_float),
                 ("p_affine", C.c_float), ("p_geo", C.c_float), ("p_ciip", C.c_float), ("p_sbtmvp", C.c_float), ("p_bcw", C.c_float), ("p_cclm", C.c_float), ("p_mip", C.c_float), ("p_sbt", C.c_float), ("p_isp", C.c_float), ("dual_tree", C.c_float), ("p_ibc", C.c_float),
-                ("num_slices", C.c_uint8), ("tile_cols", C.c_uint8), ("tile_rows", C.c_uint8), ("wrap_offset", C.c_uint16), ("virtual_boundaries", C.c_uint8)]
+                ("num_slices", C.c_uint8), ("tile_cols", C.c_uint8), ("tile_rows", C.c_uint8), ("wrap_offset", C.c_uint16), ("subpics", C.c_uint8), ("virtual_boundaries", C.c_uint8)]
 
 
 class Buffers(C.Structure):
     _fields_ = [("cu", C.c_void_p), ("max_cu", C.c_uint32), ("tu", C.c_void_p), ("max_tu", C.c_uint32),
                 ("coef", C.c_void_p), ("max_coef", C.c_uint64), ("ctu_first_cu", C.c_void_p),
-                ("motion", C.c_void_p), ("lfp", C.c_void_p * 2), ("sao", C.c_void_p), ("alf", C.c_void_p), ("alf_params", C.c_void_p), ("lmcs", C.c_void_p), ("wp", C.c_void_p), ("scaling", C.c_void_p), ("ctu_slice", C.c_void_p), ("ctu_tile", C.c_void_p),
-                ("num_cu", C.c_uint32), ("num_tu", C.c_uint32), ("num_coef", C.c_uint64), ("num_dmvr", C.c_uint32),
+                ("motion", C.c_void_p), ("lfp", C.c_void_p * 2), ("sao", C.c_void_p), ("alf", C.c_void_p), ("alf_params", C.c_void_p), ("lmcs", C.c_void_p), ("wp", C.c_void_p), ("scaling", C.c_void_p), ("ctu_slice", C.c_void_p), ("ctu_tile", C.c_void_p), ("subpics", C.c_void_p),
+                ("num_cu", C.c_uint32), ("num_tu", C.c_uint32), ("num_coef", C.c_uint64), ("num_dmvr", C.c_uint32), ("num_subpics", C.c_uint32),
                 ("hdr", abi.PicHeader)]
 
 
@@ -115,6 +115,13 @@ def generate(p, alloc=None):
     if p.tile_cols > 1 or p.tile_rows > 1:
         d.ctu_tile = np.zeros(d.num_ctu, np.uint16)
         b.ctu_tile = d.ctu_tile.ctypes.data
+    subpics = None
+    if p.subpics & 1:
+        subpics = np.zeros(255, np.dtype(abi.Subpic))
+        b.subpics = subpics.ctypes.data
+        if d.ctu_slice is None:                      # one slice per sub-picture
+            d.ctu_slice = np.zeros(d.num_ctu, np.uint16)
+            b.ctu_slice = d.ctu_slice.ctypes.data
     rc = L.vvs_generate(C.byref(p), C.byref(b))
     if rc != 0:
         raise RuntimeError("vvs_generate failed (%d)" % rc)
@@ -123,6 +130,8 @@ def generate(p, alloc=None):
     d.tu = _compact(tu, b.num_tu, alloc)
     d.coef = _compact(coef, max(1, b.num_coef), alloc)
     d.num_dmvr = b.num_dmvr
+    if subpics is not None and b.num_subpics:
+        d.subpics = subpics[:b.num_subpics].copy()
     return d
 
 
