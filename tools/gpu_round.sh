@@ -12,15 +12,15 @@ echo "== allintra"; timeout 300 python bench.py --config allintra --steps 32 --w
 echo "== allintra 24 streams"; timeout 300 python bench.py --config allintra --steps 48 --warmup 24 --streams 24 --slots 48 --no-cpu-baseline --verify 0 > $out/bench_allintra_s24.json 2> $out/bench_allintra_s24.err
 fi
 if [ "$2" == "full" ]; then
-echo "== bench 16 host threads"; timeout 300 python bench.py --no-cpu-baseline --verify 0 --host-threads 16 > $out/bench_64_16_ht16.json 2> $out/bench_64_16_ht16.err
+echo "== bench 8 host threads"; timeout 300 python bench.py --no-cpu-baseline --verify 0 --host-threads 8 > $out/bench_64_16_ht8.json 2> $out/bench_64_16_ht8.err; echo "== driver args 8 threads"; timeout 300 python bench.py --no-cpu-baseline --verify 0 --steps 20 --warmup 5 --host-threads 8 > $out/bench_20_5_ht8.json 2> $out/bench_20_5_ht8.err
 echo "== bench pageable records"; timeout 300 python bench.py --no-cpu-baseline --verify 0 --pageable-records > $out/bench_64_16_pageable.json 2> $out/bench_64_16_pageable.err
 echo "== rocprof stats"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -o bench -- python $R/bench.py --no-cpu-baseline --verify 0 > $R/$out/bench_rocprof.json 2> $R/$out/rocprof.err); ls $out/prof | head
 for ctr in FETCH_SIZE WRITE_SIZE; do
 echo "== pmc $ctr"; (cd /tmp && timeout 500 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $R/$out/pmc_$ctr -o pmc -- python $R/bench.py --steps 8 --warmup 4 --verify 0 --no-cpu-baseline --streams 1 --host-threads 0 > $R/$out/bench_pmc_$ctr.json 2> $R/$out/pmc_$ctr.err); find $out/pmc_$ctr -name "*counter_collection.csv" | head -2
 done
-echo "== allintra"; timeout 300 python bench.py --config allintra --steps 16 --warmup 4 --no-cpu-baseline --verify 2 > $out/bench_allintra.json 2> $out/bench_allintra.err
+echo "== allintra"; timeout 300 python bench.py --config allintra --no-cpu-baseline --verify 2 > $out/bench_allintra.json 2> $out/bench_allintra.err
 echo "== allintra 24 streams"; timeout 300 python bench.py --config allintra --steps 48 --warmup 24 --streams 24 --slots 48 --no-cpu-baseline --verify 0 > $out/bench_allintra_s24.json 2> $out/bench_allintra_s24.err
-echo "== 8k"; timeout 420 python bench.py --config 8k --steps 16 --warmup 4 --no-cpu-baseline --verify 1 > $out/bench_8k.json 2> $out/bench_8k.err
+echo "== 8k"; timeout 420 python bench.py --config 8k --steps 32 --warmup 8 --no-cpu-baseline --verify 1 > $out/bench_8k.json 2> $out/bench_8k.err
 fi
 for f in $out/bench_*.json; do python - "$f" <<'PY'
 import json,sys
