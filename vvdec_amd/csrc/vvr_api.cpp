@@ -8,11 +8,14 @@
 //   1. prepare (host, vvr_prepare.cpp): validation, then the device work lists, built by one of `host_threads` worker threads (or by the
 //      submitting thread when host_threads is 0) and packed into the pinned half of a ring entry — the reference does the same set-up inline
 //      in decompressPicture (:429-682) and spreads it over its thread pool;
-//   2. commit (in submission order, by whichever thread finishes the next picture in line): one asynchronous H2D copy of the ring entry on the
-//      copy stream, then the kernels of the picture on one of `num_streams` HIP streams, ordered against other pictures by whole-picture HIP
-//      events (reference pictures: the "refPicExtDepBarriers" of :544-581; slot reuse: write-after-read);
-//   3. completion: the `done` event of the picture; DMVR delta MVs land in pinned memory behind the DMVR kernel.
-// Nothing is allocated, freed or synchronised device-wide on this path once the ring has warmed up.
+//   2. commit (in submission order, by the launcher thread - by the submitting thread when host_threads is 0): asynchronous H2D copies on the copy
+//      stream (the ring entry; record arrays in pinned caller memory straight from where they are), then the kernels of the picture on one of
+//      `num_streams` HIP streams, ordered against other pictures by whole-picture HIP events (reference pictures: the "refPicExtDepBarriers" of
+//      :544-581; slot reuse: write-after-read);
+//   3. completion: two events per picture, one later pictures' streams wait for and one host threads wait for (hipEventSynchronize holds the event's
+//      lock while it waits: a hipStreamWaitEvent on the same event would stall the launcher behind it); DMVR delta MVs and the collocated motion
+//      are written by the DMVR kernel straight into device-mapped pinned memory (no device-to-host copy call: it blocked the calling thread).
+// Nothing is allocated, freed or synchronised device-wide on this path: the ring is allocated when the context is created.
 // There is NO CPU fallback: without a gfx950 device every entry point fails with VVR_ERR_NO_DEVICE.
 #include "vvr_host.h"
 #include <algorithm>
