@@ -2106,13 +2106,139 @@ __global__ __launch_bounds__( 256 ) void k_alf_chroma( PicDev pic, DevPlanes src
   dst.p[c][(size_t) y * dst.stride[c] + x] = (pel_t) v;
 }
 
+// The same for the common case (no picture-header virtual boundaries, CTU of at least 64): one workgroup filters a 32x32 tile of BOTH chroma planes -
+// the tile lies in one chroma CTU, so one clip rectangle serves it.  Tile + 2-sample halo of each plane and, when the CTU uses CC-ALF, the co-located
+// 66x66 luma window sit in LDS (16-byte / coalesced loads instead of 21 two-byte loads per sample: the per-sample kernel is bound by its load
+// instructions).  Arithmetic, row re-mapping at the CTU-row boundary and clipping are those of k_alf_chroma.
+#define ALFC_T   32
+#define ALFC_LW  40                    // LDS row stride of a chroma tile (36 used)
+#define ALFC_LL  72                    // LDS row stride of the luma window (66 used)
+__global__ __launch_bounds__( 256 ) void k_alf_chroma_tile( PicDev pic, DevPlanes src, DevPlanes dst )
+{
+  __shared__ pel_t tc[2][( ALFC_T + 4 ) * ALFC_LW];
+  __shared__ pel_t tl[( 2 * ALFC_T + 2 ) * ALFC_LL];
+  const int tileLin = xcd_contiguous( blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y );
+  const int tx0 = ( tileLin % gridDim.x ) * ALFC_T, ty0 = ( tileLin / gridDim.x ) * ALFC_T;
+  const int W = src.w[1], H = src.h[1], st = src.stride[1];
+  const int tid = threadIdx.x, bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu, ctuC = ctu >> 1;
+  const vvr_alf_ctu f = pic.alf[( ty0 / ctuC ) * pic.ctus_x + ( tx0 / ctuC )];
+  const bool ccOn = ( pic.hdr.tool_flags & VVR_TOOL_CCALF ) != 0;
+  const bool cc[2] = { ccOn && f.cc_idc[0], ccOn && f.cc_idc[1] };
+  const AlfClip kc = alf_clip_of_ctu( pic, tx0 / ctuC, ty0 / ctuC, 1 ), kl = alf_clip_of_ctu( pic, tx0 / ctuC, ty0 / ctuC, 0 );
+  // ---- stage the tiles (clipped coordinates = what the filter of this CTU may read)
+  for( int i = tid; i < 2 * ( ALFC_T + 4 ) * ( ALFC_T + 4 ); i += 256 )
+  {
+    const int k = i / ( ( ALFC_T + 4 ) * ( ALFC_T + 4 ) ), r = i - k * ( ALFC_T + 4 ) * ( ALFC_T + 4 ), yy = r / ( ALFC_T + 4 ), xx = r - yy * ( ALFC_T + 4 );
+    if( !f.enable[1 + k] && !cc[k] ) continue;
+    int sx = tx0 - 2 + xx, sy = ty0 - 2 + yy;
+    alf_clip_coord( kc, sx, sy );
+    tc[k][yy * ALFC_LW + xx] = ( k ? src.p[2] : src.p[1] )[(size_t) clip3( 0, H - 1, sy ) * st + clip3( 0, W - 1, sx )];
+  }
+  if( cc[0] || cc[1] )
+  {
+    const pel_t* __restrict__ L = src.p[0];
+    const int ls = src.stride[0], LW = src.w[0], LH = src.h[0];
+    for( int i = tid; i < ( 2 * ALFC_T + 2 ) * ( 2 * ALFC_T + 2 ); i += 256 )
+    {
+      const int yy = i / ( 2 * ALFC_T + 2 ), xx = i - yy * ( 2 * ALFC_T + 2 );
+      int sx = 2 * tx0 - 1 + xx, sy = 2 * ty0 - 1 + yy;
+      alf_clip_coord( kl, sx, sy );
+      tl[yy * ALFC_LL + xx] = L[(size_t) clip3( 0, LH - 1, sy ) * ls + clip3( 0, LW - 1, sx )];
+    }
+  }
+  __syncthreads();
+  // ---- thread -> (row, 4 consecutive columns) of the tile, both planes
+  const int ly = tid >> 3, lx4 = ( tid & 7 ) * 4;
+  const int y = ty0 + ly;
+  if( y >= H || tx0 + lx4 >= W ) return;
+  const vvr_alf_params* __restrict__ A = pic.alf_params;
+  // rows of the 5x5 diamond at the ALF line-buffer boundary of the CTU row (chroma: 2 rows above the CTU's last 2)
+  const int vbPos = ctuC - 2, yVb = y & ( ctuC - 1 );
+  int r1 = ly + 1, r2 = ly - 1, r3 = ly + 2, r4 = ly - 2;
+  if( yVb < vbPos && yVb >= vbPos - 2 )
+  {
+    r1 = ( yVb == vbPos - 1 ) ? ly : r1;  r3 = ( yVb >= vbPos - 2 ) ? r1 : r3;
+    r2 = ( yVb == vbPos - 1 ) ? ly : r2;  r4 = ( yVb >= vbPos - 2 ) ? r2 : r4;
+  }
+  else if( yVb >= vbPos && yVb <= vbPos + 1 )
+  {
+    r2 = ( yVb == vbPos ) ? ly : r2;  r4 = ( yVb <= vbPos + 1 ) ? r2 : r4;
+    r1 = ( yVb == vbPos ) ? ly : r1;  r3 = ( yVb <= vbPos + 1 ) ? r1 : r3;
+  }
+  const bool nearVb = ( yVb == vbPos - 1 ) || ( yVb == vbPos );
+  // luma rows of the CC-ALF cross (filterBlkCcAlf :1348)
+  const int vbL = ctu - 4, posL = ( y << 1 ) & ( ctu - 1 );
+  int o1 = 1, o2 = -1, o3 = 2;
+  if( posL == vbL - 2 || posL == vbL + 1 ) o3 = o1;
+  else if( posL == vbL - 1 || posL == vbL ) { o1 = 0; o2 = 0; o3 = 0; }
+#pragma unroll
+  for( int k = 0; k < 2; k++ )
+  {
+    pel_t* __restrict__ D = k ? dst.p[2] : dst.p[1];
+    const pel_t* __restrict__ S = k ? src.p[2] : src.p[1];
+    const bool en = f.enable[1 + k] != 0;
+    if( !en && !cc[k] )
+    {
+      for( int xx = lx4; xx < lx4 + 4 && tx0 + xx < W; xx++ ) D[(size_t) y * dst.stride[1] + tx0 + xx] = S[(size_t) y * st + tx0 + xx];
+      continue;
+    }
+#define C( xx, rr ) ( (int) tc[k][( ( rr ) + 2 ) * ALFC_LW + ( xx ) + 2] )
+#define Y( xx, yy ) ( (int) tl[( ( yy ) + 1 ) * ALFC_LL + ( xx ) + 1] )
+    const int16_t* cf = A->chroma_coeff[k ? f.alt[1] : f.alt[0]]; const int16_t* cp = A->chroma_clip[k ? f.alt[1] : f.alt[0]];
+    const int16_t* ccf = cc[k] ? A->ccalf_coeff[k][( k ? f.cc_idc[1] : f.cc_idc[0] ) - 1] : nullptr;
+    for( int xx = lx4; xx < lx4 + 4; xx++ )
+    {
+      if( tx0 + xx >= W ) break;
+      const int cur = C( xx, ly );
+      int v = cur;
+      if( en )
+      {
+        int sum = 0;
+        sum += cf[0] * clip_alf( cp[0], cur, C( xx, r3 ),     C( xx, r4 ) );
+        sum += cf[1] * clip_alf( cp[1], cur, C( xx + 1, r1 ), C( xx - 1, r2 ) );
+        sum += cf[2] * clip_alf( cp[2], cur, C( xx, r1 ),     C( xx, r2 ) );
+        sum += cf[3] * clip_alf( cp[3], cur, C( xx - 1, r1 ), C( xx + 1, r2 ) );
+        sum += cf[4] * clip_alf( cp[4], cur, C( xx + 2, ly ), C( xx - 2, ly ) );
+        sum += cf[5] * clip_alf( cp[5], cur, C( xx + 1, ly ), C( xx - 1, ly ) );
+        sum = nearVb ? ( sum + 512 ) >> 10 : ( sum + 64 ) >> 7;
+        v = clip_pel( sum + cur, bd );
+      }
+      if( ccf )
+      {
+        const int qx = 2 * xx, qy = 2 * ly;
+        const int cl = Y( qx, qy );
+        int sum = 0;
+        sum += ccf[0] * ( Y( qx,     qy + o2 ) - cl );
+        sum += ccf[1] * ( Y( qx - 1, qy      ) - cl );
+        sum += ccf[2] * ( Y( qx + 1, qy      ) - cl );
+        sum += ccf[3] * ( Y( qx - 1, qy + o1 ) - cl );
+        sum += ccf[4] * ( Y( qx,     qy + o1 ) - cl );
+        sum += ccf[5] * ( Y( qx + 1, qy + o1 ) - cl );
+        sum += ccf[6] * ( Y( qx,     qy + o3 ) - cl );
+        sum = ( sum + 64 ) >> 7;
+        const int off = 1 << bd >> 1;
+        sum = clip_pel( sum + off, bd ) - off;
+        v = clip_pel( v + sum, bd );
+      }
+      D[(size_t) y * dst.stride[1] + tx0 + xx] = (pel_t) v;
+    }
+#undef C
+#undef Y
+  }
+}
+
 void launch_alf( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst )
 {
   const dim3 grid( ( src.w[0] + ALF_T - 1 ) / ALF_T, ( src.h[0] + ALF_T - 1 ) / ALF_T );
   if( pic.hdr.num_ver_vb | pic.hdr.num_hor_vb ) hipLaunchKernelGGL( k_alf_luma<true>, grid, dim3( 256 ), 0, s, pic, src, dst );
   else hipLaunchKernelGGL( k_alf_luma<false>, grid, dim3( 256 ), 0, s, pic, src, dst );
   if( pic.hdr.chroma_format )
-    hipLaunchKernelGGL( k_alf_chroma, dim3( ( src.w[1] + 63 ) / 64, ( src.h[1] + 3 ) / 4, 2 ), dim3( 256 ), 0, s, pic, src, dst );
+  {
+    if( !( pic.hdr.num_ver_vb | pic.hdr.num_hor_vb ) && pic.hdr.log2_ctu >= 6 )
+      hipLaunchKernelGGL( k_alf_chroma_tile, dim3( ( src.w[1] + ALFC_T - 1 ) / ALFC_T, ( src.h[1] + ALFC_T - 1 ) / ALFC_T ), dim3( 256 ), 0, s, pic, src, dst );
+    else
+      hipLaunchKernelGGL( k_alf_chroma, dim3( ( src.w[1] + 63 ) / 64, ( src.h[1] + 3 ) / 4, 2 ), dim3( 256 ), 0, s, pic, src, dst );
+  }
 }
 
 // plain plane copy (used when a stage is disabled for a picture)
