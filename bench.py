@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--irap-lookahead", type=int, default=8, help="IRAP pictures are submitted N pictures ahead of their decoding-order position (they depend on nothing)")
     ap.add_argument("--pageable-records", action="store_true", help="keep the host records in ordinary (pageable) memory: the library stages them through its pinned ring")
     ap.add_argument("--no-picture-sharding", action="store_true", help="N > 1: skip the additional pass that shards ONE stream by picture over the ranks")
+    ap.add_argument("--picture-sharding-timeout", type=int, default=150, help="N > 1: seconds after which the picture-sharding pass is given up and the line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stop-after", type=int, default=0, help="developer: end the kernel chain after the reconstruction (1), deblocking (2) or SAO (3) stage, to see what a stage costs; needs --verify 0")
     ap.add_argument("--verify", type=int, default=8, help="number of timed pictures re-checked against the CPU oracle after the run")
@@ -283,16 +284,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_dev = float(t.item())
 
-    # ---- N > 1: the same stream sharded by PICTURE over the ranks (BASELINE north_star / SURVEY 8(e): pictures round-robin within their temporal
-    # layer, reference pictures broadcast slot to slot over RCCL), next to the segment mode above.  Reported under config.picture_sharding; a
-    # failure there does not take the line away.
-    pic_mode = None
-    if world > 1 and a.config != "allintra" and not a.no_picture_sharding:
-        try:
-            pic_mode = picture_sharding_pass(a, W, H, mix, tools, plans, nslots, first, K, Wm, rank, world, local_rank, backend)
-        except Exception as e:            # noqa: BLE001 - the segment-mode line must survive
-            pic_mode = {"error": repr(e)[:300]}
-
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel: a further pass over the K timed pictures only, HIP-event timing on the launch streams
@@ -367,7 +358,7 @@ def main():
                           "irap_in_window": n_irap, "irap_share_of_stream": "1/%d" % intra_period if a.config != "allintra" else "1/1",
                           "tools": "intra planar/DC/angular/wide-angle + PDPC + MRL + reference smoothing + BDPCM + ISP, LFNST, inter uni/bi MC (8/4-tap DCTIF, alt half-pel, BCW), BDOF, DMVR, affine 4/6-parameter + PROF, GPM, CIIP, SbTMVP, CCLM/MDLM, MIP, LMCS luma mapping + chroma residual scaling, dequant + dep-quant, DCT2/DST7/DCT8 + transform skip, joint Cb-Cr, deblocking, SAO, ALF + CC-ALF",
                           "mix": mix,
-                          "picture_sharding": pic_mode, "pictures_in_flight": a.streams, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "sharding": "closed-GOP segment per GPU, no data-path collective",
+                          "picture_sharding": None, "pictures_in_flight": a.streams, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "sharding": "closed-GOP segment per GPU, no data-path collective",
                           "verified_timed_pictures_vs_oracle": verified, "timed_run_equals_serial_run": serial_equal},
                "roofline": roof}
         if not a.no_cpu_baseline:
@@ -375,6 +366,30 @@ def main():
     for h in prepared.values():
         rec.free_prepared(h)
     rec.close()
+    # ---- N > 1: the same stream sharded by PICTURE over the ranks (BASELINE north_star / SURVEY 8(e): pictures round-robin within their temporal layer,
+    # reference pictures broadcast slot to slot over RCCL), next to the segment mode above.  Reported under config.picture_sharding.  It runs last and
+    # under a watchdog: whatever happens to it (an exception, a collective that never completes), the line with the segment-mode result is printed.
+    if world > 1 and a.config != "allintra" and not a.no_picture_sharding:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["config"]["picture_sharding"] = {"error": "no result within %d s" % a.picture_sharding_timeout}
+                print(json.dumps(out), flush=True)
+            else:
+                time.sleep(3)
+            os._exit(0)
+
+        timer = threading.Timer(a.picture_sharding_timeout, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            pic_mode = picture_sharding_pass(a, W, H, mix, tools, plans, nslots, first, K, Wm, rank, world, local_rank, backend)
+        except Exception as e:            # noqa: BLE001 - the segment-mode line must survive
+            pic_mode = {"error": repr(e)[:300]}
+        timer.cancel()
+        if rank == 0:
+            out["config"]["picture_sharding"] = pic_mode
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -521,6 +521,25 @@ def test_bench_control_flow(stub, ranks):
     assert out["n_gpus"] == ranks and out["steps"] == 6 and out["warmup"] == 4 and out["scaling"] == "weak" and "workload" in out["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in out["roofline"]
+    if ranks > 1:
+        ps = out["config"]["picture_sharding"]           # the second mode: ONE stream, pictures sharded over the ranks, reference slots broadcast
+        assert "error" not in ps and ps["fps"] > 0 and ps["scaling"] == "strong" and ps["broadcasts_in_window"] > 0, ps
+
+
+def test_bench_line_survives_the_picture_sharding_pass(stub):
+    """the picture-sharding pass of bench.py runs last and under a watchdog: if it does not come back (here: a deadline of zero seconds), rank 0 still
+    prints the line with the segment-mode result, and every rank exits"""
+    import json
+    import sys
+    tool = os.path.join(os.path.dirname(HERE), "tools", "bench_host_side.py")
+    env = dict(os.environ, VVR_BENCH_BACKEND="gloo", VVR_BENCH_EXTRA="--picture-sharding-timeout 0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29535", tool]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.returncode, r.stderr[-1500:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "error" in out["config"]["picture_sharding"] or "fps" in out["config"]["picture_sharding"]      # (it may have finished before the deadline fired)
 
 
 def _submit_stream(stub, threads, W=416, H=240, frames=17, gop=8, lanes=3):

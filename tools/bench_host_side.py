@@ -18,5 +18,5 @@ import test_host_glue as T
 vvdec_amd._LIBPATH = T.LIB
 import bench
 sys.argv = ["bench.py", "--width", "256", "--height", "128", "--steps", "6", "--warmup", "4", "--gop", "4", "--intra-period", "8", "--irap-lookahead", "2",
-            "--streams", "3", "--slots", "10", "--no-cpu-baseline", "--verify", "0"]
+            "--streams", "3", "--slots", "10", "--no-cpu-baseline", "--verify", "0"] + os.environ.get("VVR_BENCH_EXTRA", "").split()
 bench.main()
