@@ -43,6 +43,8 @@ hipError_t hipMemcpyAsync( void* d, const void* s, size_t n, hipMemcpyKind k, hi
 hipError_t hipMemsetAsync( void* d, int v, size_t n, hipStream_t ) { memset( d, v, n ); return hipSuccess; }
 }
 
+#define VVT_SLOW_I_PICTURES
+#include <chrono>
 #include "../../vvdec_amd/csrc/vvr_prepare.cpp"
 #include "../../vvdec_amd/csrc/vvr_api.cpp"
 
@@ -150,6 +152,8 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
 // asynchronous host-to-device copies issued so far: count and bytes (cleared by the call)
 __attribute__(( visibility( "default" ) )) void vvt_take_h2d( size_t* copies, size_t* bytes ) { *copies = g_h2dCopies; *bytes = g_h2dBytes; g_h2dCopies = g_h2dBytes = 0; }
 __attribute__(( visibility( "default" ) )) void vvt_set_delay( int us ) { g_delayUs = us; }
+__attribute__(( visibility( "default" ) )) void vvt_slow_i_pictures( int us ) { g_vvtSlowIUs = us; }
+__attribute__(( visibility( "default" ) )) unsigned long long vvt_overtakes( vvr_context* c ) { return c->overtakes; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_wg( void ) { return g_lastIntraWg; }

@@ -731,3 +731,50 @@ def test_collocated_motion_host_stage(stub):
         job = stub.vvr_submit(ctx, C.byref(p))
         assert job == abi.VVR_ERR_PARAMETER or stub.vvr_wait(ctx, job) == abi.VVR_ERR_PARAMETER
         stub.vvr_destroy(ctx)
+
+
+def test_pictures_pass_i_pictures_that_are_still_being_prepared(stub):
+    """commit order: a picture may be enqueued ahead of an I picture that was submitted before it and whose host stage is still running, if it has nothing
+    to do with that picture (no slot in common, transitively) - and only then.  A stream with IRAPs handed over early (as a parsing-ahead host does):
+    with worker threads the pictures behind an IRAP in submission order overtake it, every picture still finds in its reference slots exactly what it
+    finds when everything is prepared and enqueued inline in submission order (the stand-in stamps a picture with a hash of its reference slots'
+    stamps), and the I picture is not held up"""
+    W, H = 416, 240
+    plans, nslots = stream.ra_plan(33, gop=8, seed_poc0_is_external=False, pool=40, intra_period=16, irap_lookahead=6)
+    assert nslots >= len(plans)                         # no slot is reused: every stamp can be read at the end
+    descs = [synth.picture_for_plan(pl, W, H, seed=531, tool_flags=TOOLS, p_intra=0.1) for pl in plans]
+    pics = [d.c() for d in descs]
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    stub.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+    stub.vvr_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    buf = (C.c_int * 60000)()
+    results = {}
+    for threads in (0, 4):
+        cfg = abi.Config()
+        cfg.abi_version = abi.VVR_ABI_VERSION
+        cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, 7
+        cfg.num_slots, cfg.num_streams, cfg.host_threads = nslots, 3, threads
+        ctx = C.c_void_p()
+        assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+        stub.vvt_take_trace(buf, len(buf))
+        stub.vvt_slow_i_pictures(20000)                 # the host stage of the IRAPs after the first takes 20 ms longer here: the pictures behind them are ready first
+        jobs = [stub.vvr_submit(ctx, C.byref(p)) for p in pics]
+        assert all(j >= 0 for j in jobs)
+        for j in jobs:
+            assert stub.vvr_wait(ctx, j) == abi.VVR_OK
+        stub.vvt_slow_i_pictures(0)
+        stub.vvt_overtakes.restype = C.c_ulonglong
+        stub.vvt_overtakes.argtypes = [C.c_void_p]
+        overtakes = stub.vvt_overtakes(ctx)
+        assert (overtakes > 0) == (threads > 0), overtakes          # pictures did pass the I pictures - and never without worker threads
+        n = stub.vvt_take_trace(buf, len(buf))
+        ops = [tuple(buf[i:i + 3]) for i in range(0, n, 3)]
+        stamps = []
+        row = np.zeros(W * H, np.uint16)
+        for pl in plans:
+            assert stub.vvr_read_plane(ctx, pl.slot, 0, row.ctypes.data_as(C.c_void_p), W) == abi.VVR_OK
+            stamps.append(tuple(int(v) for v in row[:4]))
+        results[threads] = (stamps, ops)
+        stub.vvr_destroy(ctx)
+    assert results[0][0] == results[4][0], "a picture was enqueued before a picture it depends on"
+    assert len(set(results[0][0])) == len(plans)          # (the stamps tell the pictures apart)
