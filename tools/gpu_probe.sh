@@ -11,5 +11,6 @@ PY
 }
 run k20_t8 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --host-threads 8
 run k20_t16 python bench.py --no-cpu-baseline --steps 20 --warmup 5
-run k64_t8 python bench.py --no-cpu-baseline --host-threads 8
 run k64_t16 python bench.py --no-cpu-baseline
+run ai python bench.py --no-cpu-baseline --config allintra --verify 2
+PROBE_PICTURES=2 timeout 120 python tools/intra_probe.py 2>&1 | grep -v "vvr\]" | head -3

@@ -48,6 +48,8 @@ struct PrepScratch
   // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
   std::vector<int32_t> order;
   std::vector<uint8_t> intraAt;            // per 4x4 luma unit: covered by an intra CU (1) / a CIIP CU (2)
+  std::vector<uint8_t> fastCtu;            // per CTU: every CU is an intra CU.  Its blocks form one unit per component whatever they read from each other, and that unit reads
+                                           // from the CTUs left, above-left, above and above-right only: no per-block producer analysis (formUnits)
   // per component and 4x4 luma cell: the block that reconstructs it in the intra stage, stamped with the number of the picture it was written for
   // ( epoch << 22 | block ): the maps are never cleared, an entry of another picture reads as "none"
   std::vector<uint32_t> itemAtE[3];
@@ -342,6 +344,7 @@ int PrepScratch::beginMaps()
   anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
   intraAt.clear();
+  fastCtu.assign( (size_t) numCtu, 0 );
   if( anyIntra )
   {
     const size_t cells = (size_t) w4 * h4;
@@ -365,6 +368,11 @@ int PrepScratch::mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string&
 {
   curCtuIdx = ctuIdx;
   if( !anyIntra ) return VVR_OK;
+  {
+    bool fast = true;
+    for( uint32_t i = i0; i < i1 && fast; i++ ) fast = p->cu[i].pred_mode == VVR_PRED_INTRA;
+    fastCtu[ctuIdx] = fast;
+  }
   const size_t cells = (size_t) w4 * h4;
   for( uint32_t i = i0; i < i1; i++ )
   {
@@ -564,6 +572,8 @@ int PrepScratch::buildWorkLists( std::string& err )
               bb.c0 = std::min( bb.c0, std::max( 0, ( bx0 - ( ox - 8 ) ) >> 3 ) );
               bb.c1 = std::max( bb.c1, std::min( ( 8 + S + 64 + 7 ) >> 3, ( bx1 - ( ox - 8 ) + 7 ) >> 3 ) );
             }
+            if( !fastCtu[ctuOfCu] )
+            {
             if( it.nTL ) touch( comp, rx0 - 1 - mrl, ry0 - 1 - mrl );
             for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, rx0 + k, ry0 - 1 - mrl );
             for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, rx0 - 1 - mrl, ry0 + k );
@@ -614,6 +624,7 @@ int PrepScratch::buildWorkLists( std::string& err )
               for( int xx = ( cclmBLeft ? -4 : 0 ); xx < 2 * cclmTop + 4; xx += 4 ) touch( 0, lx0 + xx, ly0 - 1 );
               for( int yy = 0; yy < 2 * cclmLeft + 4; yy += 4 ) touch( 0, lx0 - 1, ly0 + yy );
             }
+            }     // (not an all-intra CTU)
             // the cells this block reconstructs
             {
               const int cx0 = ( x0 << cs ) >> 2, cx1 = std::min( ( ( ( x0 + w ) << cs ) + 3 ) >> 2, w4 ), cy1 = std::min( ( ( ( y0 + hh ) << cs ) + 3 ) >> 2, h4 );
@@ -755,6 +766,8 @@ int PrepScratch::formUnits()
       const bool ra = intra[k][i].mode == IT_MODE_RESI_ADD && k;
       if( ra ) { if( bulk >= 0 && bulkCtu == itemH[k][i].ctu ) unite( (uint32_t) bulk, (uint32_t) i ); else { bulk = (int64_t) i; bulkCtu = itemH[k][i].ctu; } continue; }
       const ItemH& ih = itemH[k][i];
+      // an all-intra CTU: one unit per component (every block but the first reads from a block of its CTU that precedes it)
+      if( fastCtu[ih.ctu] ) { if( i > 0 && itemH[k][i - 1].ctu == ih.ctu ) unite( (uint32_t) i, (uint32_t) i - 1 ); continue; }
       for( uint32_t q = ih.p0; q < ih.p0 + ih.pn; q++ )
       {
         const uint32_t key = pool[q], pk = key >> 28, pi = key & 0x0fffffff;
@@ -836,6 +849,39 @@ int PrepScratch::formUnits()
           if( d == u || d == last ) continue;
           last = d;
           if( std::find( U.deps.begin(), U.deps.end(), d ) == U.deps.end() ) U.deps.push_back( d );
+        }
+      }
+    }
+    // units of all-intra CTUs (no per-block producers were collected): everything such a unit can read outside itself lies in the CTUs left,
+    // above-left, above and above-right of its own - reference lines incl. the above-right extension, multi-reference lines, the top-left sample -
+    // as far as they belong to its slice and tile; a chroma unit also reads luma there and in its own CTU (CCLM templates, the neighbourhood of
+    // the chroma-scaling factor).  It waits for every unit of these (component, CTU) pairs: a superset of what its blocks read, of CTUs that
+    // precede it in the wavefront anyway.
+    {
+      std::vector<uint32_t>& uFirst = unitCount;                       // (reused scratch) first unit / number of units per (component, CTU); units of a pair are contiguous
+      uFirst.assign( 2 * 3 * (size_t) numCtu, 0 );
+      uint32_t* uNum = uFirst.data() + 3 * (size_t) numCtu;
+      for( size_t u = units.size(); u-- > 0; ) { const size_t key = (size_t) units[u].comp * numCtu + units[u].ctu; uFirst[key] = (uint32_t) u; uNum[key]++; }
+      for( size_t u = 0; u < units.size(); u++ )
+      {
+        UnitH& U = units[u];
+        if( !fastCtu[U.ctu] ) continue;
+        const int cx = (int) ( U.ctu % ctusX ), cy = (int) ( U.ctu / ctusX );
+        auto addAll = [&]( uint32_t comp, uint32_t ctuIdx )
+        {
+          const size_t key = (size_t) comp * numCtu + ctuIdx;
+          for( uint32_t q = uFirst[key]; q < uFirst[key] + uNum[key]; q++ ) if( q != u && std::find( U.deps.begin(), U.deps.end(), q ) == U.deps.end() ) U.deps.push_back( q );
+        };
+        if( U.comp ) addAll( 0, U.ctu );
+        const int nb[4][2] = { { -1, 0 }, { -1, -1 }, { 0, -1 }, { 1, -1 } };
+        for( int n = 0; n < 4; n++ )
+        {
+          const int nx = cx + nb[n][0], ny = cy + nb[n][1];
+          if( nx < 0 || ny < 0 || nx >= ctusX ) continue;
+          const uint32_t nc = (uint32_t) ( ny * ctusX + nx );
+          if( !sameSliceAndTile( nc, U.ctu ) ) continue;
+          addAll( U.comp, nc );
+          if( U.comp ) addAll( 0, nc );
         }
       }
     }
