@@ -300,7 +300,7 @@ def main():
         achieved = dom["algo_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": None,
-                "peak_measured": round(copy_bps / 1e9, 1), "peak_measured_how": "the library's copy kernel over the DPB (%d MB read + %d MB written per launch), HIP events, 20 launches, same run" % ((min(nslots, 2 * a.streams) * rec.slot_bytes()) >> 20, (min(nslots, 2 * a.streams) * rec.slot_bytes()) >> 20),
+                "peak_measured": round(copy_bps / 1e9, 1), "peak_measured_how": "the library's copy kernel over the DPB (%d MB read + %d MB written per launch), HIP events, 20 launches, same run" % ((min(nslots, 2 * (a.streams + (a.streams >= 2))) * rec.slot_bytes()) >> 20, (min(nslots, 2 * (a.streams + (a.streams >= 2))) * rec.slot_bytes()) >> 20),
                 "frac_of_measured": round(achieved / max(copy_bps / 1e9, 1e-9), 4),
                 "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                 "algorithmic_bytes_per_launch": int(dom["algo_bytes"] / dom["launches"]),

@@ -26,6 +26,9 @@ hipError_t hipMemcpy( void* d, const void* s, size_t n, hipMemcpyKind ) { memcpy
 hipError_t hipMemcpy2D( void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind ) { for( size_t y = 0; y < h; y++ ) memcpy( (char*) d + y * dp, (const char*) s + y * sp, w ); return hipSuccess; }
 hipError_t hipMemset( void* d, int v, size_t n ) { memset( d, v, n ); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags( hipStream_t* s, unsigned int ) { StubStream* p = (StubStream*) calloc( 1, sizeof( StubStream ) ); p->id = g_numStreams++; *s = (hipStream_t) p; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority( hipStream_t* s, unsigned int f, int ) { return hipStreamCreateWithFlags( s, f ); }
+hipError_t hipDeviceGetStreamPriorityRange( int* least, int* greatest ) { *least = 0; *greatest = -1; return hipSuccess; }
+hipError_t hipEventQuery( hipEvent_t ) { return hipSuccess; }       // (the stand-in device has finished everything it was given)
 hipError_t hipStreamDestroy( hipStream_t s ) { free( s ); return hipSuccess; }
 hipError_t hipStreamSynchronize( hipStream_t ) { return hipSuccess; }
 hipError_t hipStreamWaitEvent( hipStream_t s, hipEvent_t e, unsigned int ) { g_trace.push_back( 0 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( ( (StubEvent*) e )->id ); return hipSuccess; }
@@ -153,6 +156,7 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
 __attribute__(( visibility( "default" ) )) void vvt_take_h2d( size_t* copies, size_t* bytes ) { *copies = g_h2dCopies; *bytes = g_h2dBytes; g_h2dCopies = g_h2dBytes = 0; }
 __attribute__(( visibility( "default" ) )) void vvt_set_delay( int us ) { g_delayUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_slow_i_pictures( int us ) { g_vvtSlowIUs = us; }
+__attribute__(( visibility( "default" ) )) void vvt_slow_b_pictures( int us ) { g_vvtSlowBUs = us; }
 __attribute__(( visibility( "default" ) )) unsigned long long vvt_overtakes( vvr_context* c ) { return c->overtakes; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }

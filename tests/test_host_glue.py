@@ -388,7 +388,10 @@ def test_pictures_in_flight_are_ordered_by_their_slots(stub, lanes, frames, gop,
         assert len(rec) == 2                    # the picture's completion events (one for later pictures' streams, one for host threads), on its lane
         jobs.append((rec[0][1], {o[2] for o in ops if o[0] == 0}, rec[0][2], hnd))
         assert all(o[1] == rec[0][1] for o in ops)
-    assert len({j[0] for j in jobs}) == lanes   # all lanes are used
+    # all lanes are used; with more than one, the I picture at the head of the stream goes to the lane with the high-priority stream
+    assert len({j[0] for j in jobs}) == lanes + (1 if lanes >= 2 else 0)
+    if lanes >= 2:
+        assert all(jobs[0][0] != j[0] for j in jobs[1:])
     ev_to_job = {j[2]: k for k, j in enumerate(jobs)}
 
     def violations(use_waits):
@@ -604,9 +607,17 @@ def test_errors_of_queued_pictures_come_back_from_wait(stub):
     assert stub.vvr_wait(ctx, jg[1]) == abi.VVR_OK and stub.vvr_wait(ctx, jg[0]) == abi.VVR_OK
     assert stub.vvr_wait(ctx, jb) == abi.VVR_ERR_PARAMETER
     assert "not reconstructed before" in stub.vvr_last_error(ctx).decode()
-    # what is wrong with the description itself is still refused by vvr_submit at once
+    # what is wrong with the header is still refused by vvr_submit at once
     bad2 = mk(plans[0]); bad2.hdr.out_slot = nslots
     assert stub.vvr_submit(ctx, C.byref(bad2.c())) == abi.VVR_ERR_PARAMETER
+    # the records are checked by the picture's worker (the submitting thread does not spend 0.3 ms per 4K picture on them): the job fails
+    bad3 = mk(plans[0]); bad3.cu["w"][3] = 0
+    pb3 = bad3.c()
+    jb3 = stub.vvr_submit(ctx, C.byref(pb3))
+    assert jb3 >= 0 and stub.vvr_wait(ctx, jb3) == abi.VVR_ERR_PARAMETER
+    assert "CU outside the picture" in stub.vvr_last_error(ctx).decode()
+    jg = stub.vvr_submit(ctx, C.byref(pg[0]))
+    assert jg >= 0 and stub.vvr_wait(ctx, jg) == abi.VVR_OK
     stub.vvr_destroy(ctx)
 
 
@@ -733,12 +744,12 @@ def test_collocated_motion_host_stage(stub):
         stub.vvr_destroy(ctx)
 
 
-def test_pictures_pass_i_pictures_that_are_still_being_prepared(stub):
-    """commit order: a picture may be enqueued ahead of an I picture that was submitted before it and whose host stage is still running, if it has nothing
-    to do with that picture (no slot in common, transitively) - and only then.  A stream with IRAPs handed over early (as a parsing-ahead host does):
-    with worker threads the pictures behind an IRAP in submission order overtake it, every picture still finds in its reference slots exactly what it
-    finds when everything is prepared and enqueued inline in submission order (the stand-in stamps a picture with a hash of its reference slots'
-    stamps), and the I picture is not held up"""
+def test_pictures_pass_pictures_that_are_still_being_prepared(stub):
+    """commit order: a picture may be enqueued ahead of a picture that was submitted before it and whose host stage is still running, if it has nothing
+    to do with that picture (no slot in common, transitively) - and only then.  A stream with IRAPs handed over early (as a parsing-ahead host does);
+    with worker threads, (a) slow I pictures: the pictures behind an IRAP in submission order overtake it; (b) slow B pictures: an IRAP, which depends
+    on nothing, overtakes the B pictures submitted before it.  Either way every picture still finds in its reference slots exactly what it finds when
+    everything is prepared and enqueued inline in submission order (the stand-in stamps a picture with a hash of its reference slots' stamps)"""
     W, H = 416, 240
     plans, nslots = stream.ra_plan(33, gop=8, seed_poc0_is_external=False, pool=40, intra_period=16, irap_lookahead=6)
     assert nslots >= len(plans)                         # no slot is reused: every stamp can be read at the end
@@ -749,7 +760,9 @@ def test_pictures_pass_i_pictures_that_are_still_being_prepared(stub):
     stub.vvr_read_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     buf = (C.c_int * 60000)()
     results = {}
-    for threads in (0, 4):
+    stub.vvt_overtakes.restype = C.c_ulonglong
+    stub.vvt_overtakes.argtypes = [C.c_void_p]
+    for threads, slow in ((0, "I"), (4, "I"), (4, "B")):
         cfg = abi.Config()
         cfg.abi_version = abi.VVR_ABI_VERSION
         cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, 7
@@ -757,16 +770,18 @@ def test_pictures_pass_i_pictures_that_are_still_being_prepared(stub):
         ctx = C.c_void_p()
         assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
         stub.vvt_take_trace(buf, len(buf))
-        stub.vvt_slow_i_pictures(20000)                 # the host stage of the IRAPs after the first takes 20 ms longer here: the pictures behind them are ready first
+        if slow == "I":
+            stub.vvt_slow_i_pictures(20000)             # the host stage of the IRAPs after the first takes 20 ms longer here: the pictures behind them are ready first
+        else:
+            stub.vvt_slow_b_pictures(4000)              # ... of every B picture 4 ms longer: an IRAP is ready long before the B pictures in front of it
         jobs = [stub.vvr_submit(ctx, C.byref(p)) for p in pics]
         assert all(j >= 0 for j in jobs)
         for j in jobs:
             assert stub.vvr_wait(ctx, j) == abi.VVR_OK
         stub.vvt_slow_i_pictures(0)
-        stub.vvt_overtakes.restype = C.c_ulonglong
-        stub.vvt_overtakes.argtypes = [C.c_void_p]
+        stub.vvt_slow_b_pictures(0)
         overtakes = stub.vvt_overtakes(ctx)
-        assert (overtakes > 0) == (threads > 0), overtakes          # pictures did pass the I pictures - and never without worker threads
+        assert (overtakes > 0) == (threads > 0), overtakes          # pictures did pass others - and never without worker threads
         n = stub.vvt_take_trace(buf, len(buf))
         ops = [tuple(buf[i:i + 3]) for i in range(0, n, 3)]
         stamps = []
@@ -774,7 +789,7 @@ def test_pictures_pass_i_pictures_that_are_still_being_prepared(stub):
         for pl in plans:
             assert stub.vvr_read_plane(ctx, pl.slot, 0, row.ctypes.data_as(C.c_void_p), W) == abi.VVR_OK
             stamps.append(tuple(int(v) for v in row[:4]))
-        results[threads] = (stamps, ops)
+        results[(threads, slow)] = (stamps, ops)
         stub.vvr_destroy(ctx)
-    assert results[0][0] == results[4][0], "a picture was enqueued before a picture it depends on"
-    assert len(set(results[0][0])) == len(plans)          # (the stamps tell the pictures apart)
+    assert results[(0, "I")][0] == results[(4, "I")][0] == results[(4, "B")][0], "a picture was enqueued before a picture it depends on"
+    assert len(set(results[(0, "I")][0])) == len(plans)          # (the stamps tell the pictures apart)

@@ -1,16 +1,17 @@
 #!/bin/bash
-out=gpurun_out/${1:-probe}; mkdir -p $out
 export TMPDIR=/tmp
-timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-run() { name=$1; shift; timeout 300 "$@" > $out/$name.json 2> $out/$name.err; python - $out/$name.json <<'PY'
-import json,sys
-try:
-    d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1],'value',d['value'],'dev_only',d['config']['device_only_fps'],'threads',d['config']['host_threads'],'verified',d['config']['verified_timed_pictures_vs_oracle'])
-except Exception as e: print(sys.argv[1],'ERR',e)
-PY
-}
-run k20_t8 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --host-threads 8
-run k20_t16 python bench.py --no-cpu-baseline --steps 20 --warmup 5
-run k64_t16 python bench.py --no-cpu-baseline
-run ai python bench.py --no-cpu-baseline --config allintra --verify 2
-PROBE_PICTURES=2 timeout 120 python tools/intra_probe.py 2>&1 | grep -v "vvr\]" | head -3
+out=gpurun_out/tl5; mkdir -p $out
+timeout 600 python -m pytest tests -m gpu -x -q -k "stream or golden" 2>&1 | tail -2
+for rep in 1 2 3; do for t in 8 16; do
+VVDEC_AMD_LIB=$PWD/vvdec_amd/libvvdec_amd_wd.so VVR_TIMELINE=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --verify 0 --host-threads $t > $out/k20_t${t}_$rep.json 2> $out/k20_t${t}_$rep.err
+python -c "
+import json; d=json.load(open('$out/k20_t${t}_$rep.json')); print($t, 'K20', d['value'], d['config']['device_only_fps'])"
+done; done
+for t in 8 16; do
+timeout 300 python bench.py --no-cpu-baseline --verify 0 --host-threads $t > $out/k64_t$t.json 2> $out/k64_t$t.err
+python -c "
+import json; d=json.load(open('$out/k64_t$t.json')); print($t, 'K64', d['value'], d['config']['device_only_fps'])"
+done
+timeout 300 python bench.py --config allintra --no-cpu-baseline --verify 0 > $out/ai.json 2> $out/ai.err
+python -c "
+import json; d=json.load(open('$out/ai.json')); print('allintra', d['value'], d['config']['device_only_fps'])"

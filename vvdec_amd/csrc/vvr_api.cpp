@@ -113,8 +113,10 @@ struct vvr_context {
   std::map<int, std::unique_ptr<Job>> jobs;
   std::deque<Job*> queue;               // submitted, not yet taken by a worker
   int        nextJob = 0, nextStream = 0;
+  int        numLanesRR = 1;               // lanes the pictures go round: all but the priority lane
+  int        prioLane = -1, prioJob = -1;  // lane with a high-priority stream for I pictures (planCommitLocked), the last picture that took it
   uint64_t   nextSeq = 0, nextCommit = 0, nextRingSeq = 0;
-  uint64_t   overtakes = 0;                // pictures enqueued ahead of an I picture that was still being prepared (nextToCommitLocked)
+  uint64_t   overtakes = 0;                // pictures enqueued ahead of a picture submitted before them that was still being prepared (nextToCommitLocked)
   std::map<uint64_t, Job*> bySeq;       // jobs that have not been committed yet
   std::vector<std::vector<int>> slotUsers;   // job ids that touched a slot since it was last written (first entry: the writer)
   std::vector<RingEntry> ring;
@@ -209,7 +211,20 @@ struct CommitPlan { int lane; std::vector<hipEvent_t> waits; RefSet refs; std::v
 static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
 {
   const vvr_pic_header& h = job.q->hdr;
-  const int lane = c->nextStream; c->nextStream = ( c->nextStream + 1 ) % (int) c->streams.size();
+  // An I picture of a stream with inter pictures takes the priority lane when that is free: its intra stage is one 8 ms chain of dependent blocks
+  // (36 workgroups at 4K) that the whole next GOP waits for, while the kernels of the B pictures in flight are bulk work that fills whatever is
+  // left - queued behind them (20 4K pictures arriving at once: 15 of them enqueued before it) it was seen to finish 5 ms later in one run out of
+  // two.  The hardware queue of a high-priority stream is served first when workgroup slots free up; nothing that runs is pre-empted.  A stream of
+  // I pictures only (all-intra) finds the lane taken by the picture before and goes round the other lanes as ever.
+  int lane = -1;
+  if( c->prioLane >= 0 && h.slice_type == 2 )
+  {
+    auto it = c->jobs.find( c->prioJob );
+    bool idle = it == c->jobs.end() || it->second->completed;
+    if( !idle && it->second->state == J_COMMITTED && it->second->doneHost ) idle = hipEventQuery( it->second->doneHost ) == hipSuccess;
+    if( idle ) { lane = c->prioLane; c->prioJob = job.id; }
+  }
+  if( lane < 0 ) { lane = c->nextStream; c->nextStream = ( c->nextStream + 1 ) % c->numLanesRR; }
   plan.lane = lane; plan.waits.clear(); plan.waitInfo.clear();
   job.lane = lane;
   // a lane's scratch planes are reused: the previous job of this lane is ordered before us by the stream itself
@@ -348,11 +363,13 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
 
 // commit every job that is next in submission order and ready.  One thread at a time (commitMu): the launcher thread of a context with worker
 // threads, else the thread inside vvr_submit / vvr_submit_prepared.  mu is only held around the bookkeeping, never across a HIP call.
-// The next picture to enqueue on the device.  Pictures are committed in submission order - except that a picture may pass I pictures whose host stage is
-// still running (the longest of the stream: 12 ms at 4K against 5.6 ms, and an I picture depends on nothing, so a host that parses ahead hands it
-// over early): the pictures submitted behind it that have nothing to do with it need not wait for its work lists.  "Nothing to do with it" is decided
-// from the picture headers alone (slots known at submission): the later picture reads no slot an overtaken picture writes, writes no slot an
-// overtaken picture reads or writes - transitively, since a picture that may not pass joins the overtaken ones.  mu held.
+// The next picture to enqueue on the device.  Pictures are committed in submission order - except that a picture whose work lists are ready may pass
+// pictures whose host stage is still running if it has nothing to do with them.  Two cases matter: the pictures behind an I picture (the longest
+// host stage of the stream, and a host that parses ahead hands it over early) need not wait for its work lists; and an I picture, which depends on
+// nothing and whose 8 ms intra stage everything of the next GOP waits for, need not wait for the work lists of the B pictures submitted before it
+// (workers finish in any order; measured on 20 4K pictures arriving at once: the I picture was ready at 5.9 ms and enqueued at 9.3 ms).  "Nothing to
+// do with them" is decided from the picture headers alone (slots known at submission): the later picture reads no slot an overtaken picture writes,
+// writes no slot an overtaken picture reads or writes - transitively, since a picture that may not pass joins the overtaken ones.  mu held.
 static const vvr_pic_header& hdrOfJob( const Job& j ) { return j.q ? j.q->hdr : j.pic.hdr; }
 static bool slotConflict( const vvr_pic_header& later, const vvr_pic_header& earlier )
 {
@@ -377,7 +394,6 @@ static Job* nextToCommitLocked( vvr_context* c )
       for( int k = 0; k < n && free; k++ ) free = !slotConflict( hdrOfJob( *j ), hdrOfJob( *overtaken[k] ) );
       if( free ) return j;
     }
-    else if( hdrOfJob( *j ).slice_type != 2 ) break;      // only I pictures are passed while they are being prepared
     overtaken[n++] = j;
   }
   return nullptr;
@@ -405,7 +421,12 @@ static void commitReady( vvr_context* c )
     if( j->state == J_READY ) rc = enqueuePicture( c, *j, plan, err );
 #ifdef VVR_WATCHDOG
     { const double ms = std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - wdT0 ).count(); g_wdEnqMs = g_wdEnqMs + ms; g_wdEnqMax = std::max( g_wdEnqMax, ms ); g_wdEnqN++; WD_STAMP( *j, tCommit1 );
-      if( j->ring ) { g_wdSum[0] += j->tPrep - j->tSubmit; g_wdSum[1] += j->tBuilt - j->tPrep; g_wdSum[2] += j->tRing - j->tBuilt; g_wdSum[3] += j->tReady - j->tRing; g_wdSum[4] += j->tCommit0 - j->tReady; g_wdSum[5] += j->tCommit1 - j->tCommit0; g_wdJobs++; } }
+      if( j->ring ) { g_wdSum[0] += j->tPrep - j->tSubmit; g_wdSum[1] += j->tBuilt - j->tPrep; g_wdSum[2] += j->tRing - j->tBuilt; g_wdSum[3] += j->tReady - j->tRing; g_wdSum[4] += j->tCommit0 - j->tReady; g_wdSum[5] += j->tCommit1 - j->tCommit0; g_wdJobs++; }
+      // developer build: one line per picture with the times of its host stages (VVR_TIMELINE)
+      static const bool tl = getenv( "VVR_TIMELINE" ) != nullptr; static double tl0 = 0;
+      if( tl && j->ring ) { if( j->tSubmit - tl0 > 50 ) { tl0 = j->tSubmit; fprintf( stderr, "[vvr timeline] ---- (ms since the first submit of the burst)\n" ); }
+        fprintf( stderr, "[vvr timeline] seq %3llu poc %4d type %d: submit %6.2f prepare %6.2f built %6.2f ring %6.2f ready %6.2f commit %6.2f..%6.2f\n", (unsigned long long) j->seq, j->pic.hdr.poc, j->pic.hdr.slice_type,
+                 j->tSubmit - tl0, j->tPrep - tl0, j->tBuilt - tl0, j->tRing - tl0, j->tReady - tl0, j->tCommit0 - tl0, j->tCommit1 - tl0 ); } }
 #endif
     {
       std::lock_guard<std::mutex> lk( c->mu );
@@ -458,15 +479,18 @@ static void launcherMain( vvr_context* c )
 // stage 1 of a streaming job: work lists into scratch, then packed into the job's ring entry.  Called without mu.
 #ifdef VVT_SLOW_I_PICTURES
 static int g_vvtSlowIUs = 0;       // stand-in runtime (tests): extra time the host stage of an I picture other than the first of the stream takes
+static int g_vvtSlowBUs = 0;       // ... and of every picture that is not an I picture
 #endif
 static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
 {
 #ifdef VVT_SLOW_I_PICTURES
   if( g_vvtSlowIUs && job.pic.hdr.slice_type == 2 && job.pic.hdr.poc != 0 ) std::this_thread::sleep_for( std::chrono::microseconds( g_vvtSlowIUs ) );
+  if( g_vvtSlowBUs && job.pic.hdr.slice_type != 2 ) std::this_thread::sleep_for( std::chrono::microseconds( g_vvtSlowBUs ) );
 #endif
   size_t total = 0; std::string err;
   WD_STAMP( job, tPrep );
-  int rc = vvr_host_build( &job.pic, S, &total, err, &c->pinned );
+  int rc = c->workers.empty() ? VVR_OK : vvr_host_validate_records( c->cfg, &job.pic, err );        // (no workers: vvr_submit has checked them)
+  if( rc == VVR_OK ) rc = vvr_host_build( &job.pic, S, &total, err, &c->pinned );
   WD_STAMP( job, tBuilt );
   RingEntry& e = c->ring[job.ringSeq % c->ring.size()];
   {
@@ -586,6 +610,7 @@ static void workerMain( vvr_context* c )
 {
   hipSetDevice( c->device );
   PrepScratch* S = vvr_scratch_create();
+  vvr_scratch_warm( S, c->cfg );
   for( ;; )
   {
     Job* job = nullptr;
@@ -694,9 +719,18 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   vvr_context* c = new vvr_context();
   c->cfg = *cfg; c->device = cfg->device;
   const int ns = std::max<int>( 1, cfg->num_streams );
-  c->streams.resize( ns, nullptr );
+  // lanes: num_streams of them taken in turn, plus (streaming contexts) one with a high-priority stream for I pictures, see planCommitLocked
+  const int nl = ns + ( ns >= 2 ? 1 : 0 );
+  c->numLanesRR = ns; c->prioLane = nl > ns ? ns : -1;
+  c->streams.resize( nl, nullptr );
   bool ok = true;
   for( int i = 0; i < ns && ok; i++ ) ok = hipStreamCreateWithFlags( &c->streams[i], hipStreamNonBlocking ) == hipSuccess;
+  if( ok && c->prioLane >= 0 )
+  {
+    int least = 0, greatest = 0;
+    hipDeviceGetStreamPriorityRange( &least, &greatest );                    // (numerically lower = higher priority)
+    ok = hipStreamCreateWithPriority( &c->streams[c->prioLane], hipStreamNonBlocking, greatest ) == hipSuccess;
+  }
   ok = ok && hipStreamCreateWithFlags( &c->copyStream, hipStreamNonBlocking ) == hipSuccess;
   planeGeometry( cfg, c->stride, c->planeBytes, &c->slotBytes );
   if( ok )
@@ -704,11 +738,11 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
     if( cfg->ext_planes ) c->planeMem = cfg->ext_planes;
     else { ok = hipMalloc( &c->planeMem, c->slotBytes * cfg->num_slots ) == hipSuccess; if( ok ) { c->planeMemOwned = true; hipMemset( c->planeMem, 0, c->slotBytes * cfg->num_slots ); } }
   }
-  ok = ok && hipMalloc( &c->scratchMem, c->slotBytes * 2 * ns ) == hipSuccess;
+  ok = ok && hipMalloc( &c->scratchMem, c->slotBytes * 2 * nl ) == hipSuccess;
   if( ok )
   {
     for( int s = 0; s < cfg->num_slots; s++ ) c->slots.push_back( carve( (char*) c->planeMem + c->slotBytes * s, cfg, c->stride, c->planeBytes ) );
-    for( int s = 0; s < ns; s++ )
+    for( int s = 0; s < nl; s++ )
     {
       c->scratchB.push_back( carve( (char*) c->scratchMem + c->slotBytes * ( 2 * s ), cfg, c->stride, c->planeBytes ) );
       c->scratchR.push_back( carve( (char*) c->scratchMem + c->slotBytes * ( 2 * s + 1 ), cfg, c->stride, c->planeBytes ) );
@@ -717,7 +751,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
     const size_t numCtu = (size_t) ( ( cfg->max_width + ctu - 1 ) / ctu ) * ( ( cfg->max_height + ctu - 1 ) / ctu );
     // sized for the usual pictures (a 4K B picture of the benchmark has about 6 units per CTU, an intra picture 3); pictures with more
     // units than that (many isolated small intra CUs) make the lane's buffer grow when they are submitted
-    for( int s = 0; s < ns && ok; s++ ) { int* p = nullptr; const size_t cap = 1 + 24 * numCtu; ok = hipMalloc( (void**) &p, sizeof( int ) * cap ) == hipSuccess; if( ok ) { c->syncBuf.push_back( p ); c->syncCap.push_back( cap ); } }
+    for( int s = 0; s < nl && ok; s++ ) { int* p = nullptr; const size_t cap = 1 + 24 * numCtu; ok = hipMalloc( (void**) &p, sizeof( int ) * cap ) == hipSuccess; if( ok ) { c->syncBuf.push_back( p ); c->syncCap.push_back( cap ); } }
   }
   if( ok )
   {
@@ -746,6 +780,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   if( !ok ) { vvr_destroy( c ); return VVR_ERR_DEVICE; }
   c->slotUsers.resize( cfg->num_slots );
   c->inlineScratch = vvr_scratch_create();
+  if( cfg->host_threads <= 0 ) vvr_scratch_warm( c->inlineScratch, c->cfg );
   for( int t = 0; t < cfg->host_threads; t++ ) c->workers.emplace_back( workerMain, c );
   if( cfg->host_threads ) c->launcher = std::thread( launcherMain, c );
 #ifdef VVR_WATCHDOG
@@ -839,10 +874,13 @@ VVR_API int vvr_submit( vvr_context* c, const vvr_picture* p )
   if( p->resident ) { c->setError( "vvr_submit needs host arrays" ); return VVR_ERR_PARAMETER; }
   hipSetDevice( c->device );
   {
-    // what is wrong with the description itself is reported here; what only shows while the work lists are built (and device errors) is
-    // parked on the job like the reference parks exceptions on reconDone, and comes back from vvr_wait
+    // What is wrong with the header, the tables or the set of arrays is reported here.  The CU / TU records (0.3 ms for a 4K picture) are checked
+    // here as well when there are no worker threads; with worker threads that is the first thing the picture's worker does - the submitting
+    // thread is the decoder's parser, and a picture further down its queue should not wait behind the checks of the ones before it - and what it
+    // finds comes back from vvr_wait, like everything that only shows while the work lists are built and like device errors (the reference
+    // parks exceptions on reconDone in the same way).
     std::string err;
-    const int rc = vvr_host_validate( c->cfg, p, err );
+    const int rc = c->workers.empty() ? vvr_host_validate( c->cfg, p, err ) : vvr_host_validate_header( c->cfg, p, err );
     if( rc != VVR_OK ) { std::lock_guard<std::mutex> lk( c->mu ); c->setError( err ); return rc; }
   }
   Job* job;

@@ -49,9 +49,12 @@ struct DirectCopy { const void* src; size_t n, off; };
 struct PrepScratch;
 PrepScratch* vvr_scratch_create();
 void         vvr_scratch_destroy( PrepScratch* );
+void         vvr_scratch_warm( PrepScratch*, const vvr_config& cfg );      // allocate and touch room for an ordinary picture of this size (call from the thread that will use it)
 
 // validation of a picture description against the context configuration (no device access)
 int    vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string& err );
+int    vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::string& err );      // the O(1) part of it: header, tables, presence of the arrays
+int    vvr_host_validate_records( const vvr_config& cfg, const vvr_picture* p, std::string& err );     // the per-record part
 // host glue: the work lists of one picture (what DecCu::TaskTrafoCtu / TaskInterCtu / the intra task iterate over, DecCu.cpp:106-160); returns the
 // number of bytes the picture needs in HBM
 int    vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err, PinnedRanges* pinned = nullptr );

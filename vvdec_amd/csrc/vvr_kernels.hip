@@ -2468,6 +2468,8 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   constexpr int dbg = 0; constexpr unsigned long long* trace = nullptr;      // (the timing experiments and the in-kernel timeline are developer builds only)
 #endif
   __shared__ IntraShared sh;
+  // (Measured and left out: s_setprio 3 for this kernel, whose wavefronts share their SIMDs with the bulk kernels of the other pictures in flight -
+  // nothing alone on the device, 0 .. -15 % through vvr_submit with 16 pictures arriving at once.)
 #define IT_TRACE( K ) if( trace && threadIdx.x == 0 ) trace[(size_t) 8 * tr_ticket + ( K )] = wall_clock64()
   int tr_ticket = 0;
   const int tid = threadIdx.x;
