@@ -384,10 +384,12 @@ VVR_API int          vvr_create(const vvr_config* cfg, vvr_context** out);
 /* DecLibRecon::destroy */
 VVR_API void         vvr_destroy(vvr_context* ctx);
 /* DecLibRecon::decompressPicture (DecLibRecon.cpp:429): asynchronous; returns a job id >= 0 or an error code.  Called from ONE submitting
- * thread.  The description is validated before the call returns; the arrays it points to must stay valid and unchanged until
- * vvr_inputs_done(job) or vvr_wait(job) has returned (with host_threads == 0 they are consumed before vvr_submit returns).  Errors that
- * only show later (work lists, device) are parked on the job, the way the reference parks exceptions on reconDone, and come back from
- * vvr_wait.  Pictures are enqueued on the device in submission order; every job should eventually be waited for (vvr_wait / vvr_sync). */
+ * thread.  Header, tables and the set of arrays are validated before the call returns (with host_threads == 0 the CU / TU records as well);
+ * the arrays the description points to must stay valid and unchanged until vvr_inputs_done(job) or vvr_wait(job) has returned (with
+ * host_threads == 0 they are consumed before vvr_submit returns).  Errors that only show later (with worker threads: bad CU / TU records;
+ * work lists; device) are parked on the job, the way the reference parks exceptions on reconDone, and come back from vvr_wait.  Pictures
+ * take effect in submission order (one that shares no DPB slot with a picture still being prepared may be enqueued on the device ahead of
+ * it); every job should eventually be waited for (vvr_wait / vvr_sync). */
 VVR_API int          vvr_submit(vvr_context* ctx, const vvr_picture* pic);
 /* blocks until the host arrays of job `job` are no longer needed (its device work lists are built and staged in pinned memory) */
 VVR_API int          vvr_inputs_done(vvr_context* ctx, int job);
