@@ -1068,6 +1068,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
 void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int bdof )
 {
   if( !numItems ) return;
+  // (one wavefront per tile; two were measured: 123 instead of 106 us per 4K B picture - the stages of a 16x16 tile are 136 and 48 work items)
   if( bdof ) hipLaunchKernelGGL( ( k_mc<64, true> ),  dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems );
   else       hipLaunchKernelGGL( ( k_mc<64, false> ), dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems );
 }
@@ -1075,7 +1076,10 @@ void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes 
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
 {
   if( !numItems ) return;
-  hipLaunchKernelGGL( k_mc_affine<64>, dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems );
+  // four wavefronts per tile: every stage is a loop over independent elements (1056 window samples, 704 first-stage samples per list of a
+  // 16x16 tile), and the 18 KB of LDS per tile allow 8 tiles per CU whatever the workgroup size - with one wavefront per tile that is 2
+  // wavefronts per SIMD, each walking through 66 dependent rounds of scattered 2-byte loads
+  hipLaunchKernelGGL( k_mc_affine<256>, dim3( numItems ), dim3( 256 ), 0, s, pic, refs, reco, items, numItems );
 }
 
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut )
