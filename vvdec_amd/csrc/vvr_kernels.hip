@@ -2509,7 +2509,14 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   const pel_t* __restrict__ rs = resi.p[comp];
   const int rstride = resi.stride[comp];
   const uint32_t i0 = un->i0, i1 = un->i1;
+  // the unit's first IT_BATCH block records are on their way while the producers' flags are polled (one dword per lane; stored to LDS behind the
+  // wait): the reference staging below and the first batch of the block loop read them from LDS instead of each waiting for HBM / L2 again
+  const int nb0 = (int) min( (uint32_t) IT_BATCH, i1 - i0 );
+  const uint32_t itemPre = tid < nb0 * 4 ? reinterpret_cast<const uint32_t*>( items + i0 )[tid] : 0u;
 #define TILE( x, y ) sh.tile[tile_idx( ( x ) - ox, ( y ) - oy )]
+  // block record q of this unit into scalar registers (uniform per wavefront)
+#define IT_FETCH( IT, Q ) { const uint32_t* ip_ = ( Q ) - i0 < (uint32_t) IT_BATCH ? reinterpret_cast<const uint32_t*>( &sh.items[( Q ) - i0] ) : reinterpret_cast<const uint32_t*>( &items[Q] ); \
+                            uint32_t* op_ = reinterpret_cast<uint32_t*>( &IT ); for( int e_ = 0; e_ < 4; e_++ ) op_[e_] = __builtin_amdgcn_readfirstlane( ip_[e_] ); }
   // ---- wait for the units that produce intra samples this one reads (same component: reference lines; luma: CCLM)
   {
     // one lane per producer (at most VVR_INTRA_MAX_DEPS of them): the polls overlap instead of queueing behind each other
@@ -2525,6 +2532,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );      // nothing produced by another workgroup is read otherwise
     }
   }
+  if( tid < nb0 * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = itemPre;
   __syncthreads();
   IT_TRACE( 1 );
   // ---- a unit of residual-add blocks only (inter blocks with LMCS chroma scaling): no neighbourhood is read, so the blocks go
@@ -2546,11 +2554,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     for( uint32_t q = i0 + ( tid >> 6 ); q < i1; q += 4 )
     {
       IntraItem it;
-      {
-        const uint32_t* ip = reinterpret_cast<const uint32_t*>( &items[q] );
-        uint32_t* op = reinterpret_cast<uint32_t*>( &it );
-        for( int e = 0; e < 4; e++ ) op[e] = __builtin_amdgcn_readfirstlane( ip[e] );
-      }
+      IT_FETCH( it, q )
       const int x0 = it.x, y0 = it.y, lw = it.lw, wh = 1 << ( it.lw + it.lh );
       const bool cs = ( it.flags & IT_F_CSCALE ) != 0;
       const int f = cs ? sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )] : 0;
@@ -2616,11 +2620,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       for( uint32_t q = i0 + ( tid >> 6 ); q < i1; q += 4 )
       {
         IntraItem it;
-        {
-          const uint32_t* ip = reinterpret_cast<const uint32_t*>( &items[q] );
-          uint32_t* op = reinterpret_cast<uint32_t*>( &it );
-          for( int e = 0; e < 4; e++ ) op[e] = __builtin_amdgcn_readfirstlane( ip[e] );
-        }
+        IT_FETCH( it, q )
         if( it.mode == IT_MODE_IBC )
         {
           // intra block copy: the part of the reference block that lies in this CTU is read from the tile (blocks of this unit write
@@ -2695,9 +2695,12 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   for( uint32_t b0 = un->iA; b0 < ( ( dbg & 4 ) ? i0 : i1 ); b0 += IT_BATCH )
   {
     const int nb = (int) min( (uint32_t) IT_BATCH, i1 - b0 );
-    lds_barrier();                                  // previous batch fully consumed (and, first time, the tile is staged)
-    if( tid < nb * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = reinterpret_cast<const uint32_t*>( items + b0 )[tid];
-    lds_barrier();
+    if( b0 != i0 )                                  // (the first batch came with the unit, and the barrier above covers the staged tile)
+    {
+      lds_barrier();                                // previous batch fully consumed
+      if( tid < nb * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = reinterpret_cast<const uint32_t*>( items + b0 )[tid];
+      lds_barrier();
+    }
     int rpre = intra_prefetch_resi( sh.items[0], rs, rstride, tid );
     intra_stash_resi1( sh.items[0], ( sh.items[0].lw + sh.items[0].lh ) > 8 ? sh.resiB : sh.resiS[0], tid, rpre, rs, rstride );
     for( int k = 0; k < nb; k++ )
@@ -3233,6 +3236,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     }
   }
 #undef TILE
+#undef IT_FETCH
   // ---- publish: all stores of the workgroup drained, one agent-scope release, then the flag
   IT_TRACE( 4 );
   if( trace && threadIdx.x == 0 ) { trace[(size_t) 8 * tr_ticket + 6] = ( (unsigned long long) ( i1 - i0 ) << 32 ) | ent; trace[(size_t) 8 * tr_ticket + 7] |= un->ndeps; }

@@ -1050,7 +1050,11 @@ int PrepScratch::emitUnitTable( std::string& err )
         path[t] = before + cost;
         work += cost; critical = std::max( critical, path[t] );
       }
-      intraWorkgroups = (int) std::min<uint64_t>( units.size(), std::max<uint64_t>( 32, 2 * ( ( work + critical - 1 ) / critical ) ) );
+      uint64_t mult = 2;
+#if defined( VVR_WATCHDOG ) || defined( VVR_DEV_ENV )
+      if( const char* e = getenv( "VVR_INTRA_WG_MULT" ) ) mult = (uint64_t) atoi( e );      // developer build: sweep
+#endif
+      intraWorkgroups = (int) std::min<uint64_t>( units.size(), std::max<uint64_t>( 32, mult * ( ( work + critical - 1 ) / critical ) ) );
     }
     unitCount.assign( 3 * (size_t) numCtu, 0 );
     for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
