@@ -28,7 +28,8 @@ hipError_t hipMemset( void* d, int v, size_t n ) { memset( d, v, n ); return hip
 hipError_t hipStreamCreateWithFlags( hipStream_t* s, unsigned int ) { StubStream* p = (StubStream*) calloc( 1, sizeof( StubStream ) ); p->id = g_numStreams++; *s = (hipStream_t) p; return hipSuccess; }
 hipError_t hipStreamCreateWithPriority( hipStream_t* s, unsigned int f, int ) { return hipStreamCreateWithFlags( s, f ); }
 hipError_t hipDeviceGetStreamPriorityRange( int* least, int* greatest ) { *least = 0; *greatest = -1; return hipSuccess; }
-hipError_t hipEventQuery( hipEvent_t ) { return hipSuccess; }       // (the stand-in device has finished everything it was given)
+static int g_eventsPending = 0;                                      // tests: pretend nothing enqueued has finished yet
+hipError_t hipEventQuery( hipEvent_t ) { return g_eventsPending ? hipErrorNotReady : hipSuccess; }       // (by default the stand-in device has finished everything it was given)
 hipError_t hipStreamDestroy( hipStream_t s ) { free( s ); return hipSuccess; }
 hipError_t hipStreamSynchronize( hipStream_t ) { return hipSuccess; }
 hipError_t hipStreamWaitEvent( hipStream_t s, hipEvent_t e, unsigned int ) { g_trace.push_back( 0 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( ( (StubEvent*) e )->id ); return hipSuccess; }
@@ -157,6 +158,7 @@ __attribute__(( visibility( "default" ) )) void vvt_take_h2d( size_t* copies, si
 __attribute__(( visibility( "default" ) )) void vvt_set_delay( int us ) { g_delayUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_slow_i_pictures( int us ) { g_vvtSlowIUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_slow_b_pictures( int us ) { g_vvtSlowBUs = us; }
+__attribute__(( visibility( "default" ) )) void vvt_events_pending( int on ) { g_eventsPending = on; }
 __attribute__(( visibility( "default" ) )) unsigned long long vvt_overtakes( vvr_context* c ) { return c->overtakes; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }

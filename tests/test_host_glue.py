@@ -793,3 +793,33 @@ def test_pictures_pass_pictures_that_are_still_being_prepared(stub):
         stub.vvr_destroy(ctx)
     assert results[(0, "I")][0] == results[(4, "I")][0] == results[(4, "B")][0], "a picture was enqueued before a picture it depends on"
     assert len(set(results[(0, "I")][0])) == len(plans)          # (the stamps tell the pictures apart)
+
+
+def test_i_pictures_take_the_priority_lane_when_it_is_free(stub):
+    """lanes: an I picture goes to the lane with the high-priority stream - unless the I picture before it is still running there, in which case it
+    goes round the ordinary lanes like every other picture (a stream of I pictures only must not queue up on one lane).  Stream ids tell the lanes
+    apart in the stand-in's trace: the picture's completion events are recorded on its lane's stream."""
+    W, H = 64, 64
+    plans, nslots = stream.ra_plan(7, gop=1, seed_poc0_is_external=False, pool=8, intra_period=1)       # I pictures only
+    assert all(pl.slice_type == abi.SLICE_I for pl in plans)
+    buf = (C.c_int * 30000)()
+    lanes_used = {}
+    for pending in (0, 1):
+        ctx = Ctx(stub, W, H, nslots, log2_ctu=5, streams=3)
+        stub.vvt_take_trace(buf, len(buf))
+        stub.vvt_events_pending(pending)
+        lanes = []
+        for pl in plans:
+            d = synth.picture_for_plan(pl, W, H, seed=540, tool_flags=TOOLS, log2_ctu=5)
+            hnd = ctx.prepare(d)
+            assert stub.vvr_submit_prepared(ctx.ctx, hnd) >= 0
+            n = stub.vvt_take_trace(buf, len(buf))
+            ops = [tuple(buf[i:i + 3]) for i in range(0, n, 3)]
+            lanes.append([o for o in ops if o[0] == 1][0][1])
+        stub.vvt_events_pending(0)
+        stub.vvr_sync(ctx.ctx)
+        lanes_used[pending] = lanes
+    free, busy = lanes_used[0], lanes_used[1]
+    assert len(set(free)) == 1                              # the device keeps up: every I picture finds the priority lane free
+    assert busy[0] == min(busy[1:]) + 3                     # nothing finishes: only the first one gets it (the stream created after the three ordinary ones) ...
+    assert len(set(busy[1:])) == 3                          # ... the others go round the three ordinary lanes
