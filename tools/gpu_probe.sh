@@ -1,5 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/driver_line.json 2> gpurun_out/driver_line.err; tail -c 300 gpurun_out/driver_line.json; python -c "
-import json; d=json.load(open('gpurun_out/driver_line.json')); print(); print('value', d['value'], d['ms_per_step'], d['cpu_baseline']['value'], d['roofline']['frac'])"
+PROBE_PICTURES=2 timeout 120 python tools/intra_probe.py 2>&1 | grep "^POC" | head -3
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+timeout 300 python bench.py --no-cpu-baseline --verify 0 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('K64', d['value'], d['config']['device_only_fps'])"
