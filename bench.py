@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8, help="pictures in flight per GPU")
     ap.add_argument("--host-threads", type=int, default=16, help="worker threads inside the library that prepare submitted pictures")
     ap.add_argument("--ring", type=int, default=0, help="entries of the library's upload ring (0: its default)")
-    ap.add_argument("--slots", type=int, default=24, help="DPB slots used round-robin")
+    ap.add_argument("--slots", type=int, default=48, help="DPB slots used round-robin (physical slots are cheap in 288 GB: 48 x 25 MB at 4K; fewer slots = more write-after-read waits between pictures in flight)")
     ap.add_argument("--intra-period", type=int, default=-1, help="an IRAP picture every N pictures (multiple of --gop); default: the configuration's")
     ap.add_argument("--irap-lookahead", type=int, default=8, help="IRAP pictures are submitted N pictures ahead of their decoding-order position (they depend on nothing)")
     ap.add_argument("--pageable-records", action="store_true", help="keep the host records in ordinary (pageable) memory: the library stages them through its pinned ring")
