@@ -1,8 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for sl in 24 32 48 32 24; do
-timeout 300 python bench.py --no-cpu-baseline --verify 0 --slots $sl 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('slots $sl K64', d['value'], d['config']['device_only_fps'])"
-done
-timeout 300 python bench.py --no-cpu-baseline --verify 0 --slots 32 --steps 20 --warmup 5 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('slots 32 K20', d['value'], d['config']['device_only_fps'])"
+mkdir -p gpurun_out/tl6
+VVDEC_AMD_LIB=$PWD/vvdec_amd/libvvdec_amd_wd.so VVR_TIMELINE=1 timeout 300 python bench.py --no-cpu-baseline --verify 0 > gpurun_out/tl6/k64.json 2> gpurun_out/tl6/k64.err
+python -c "
+import json; d=json.load(open('gpurun_out/tl6/k64.json')); print('K64', d['value'], d['config']['device_only_fps'], d['config']['submit_loop_ms'])"
