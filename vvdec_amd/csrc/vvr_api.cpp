@@ -221,7 +221,9 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
   {
     auto it = c->jobs.find( c->prioJob );
     bool idle = it == c->jobs.end() || it->second->completed;
-    if( !idle && it->second->state == J_COMMITTED && it->second->doneHost ) idle = hipEventQuery( it->second->doneHost ) == hipSuccess;
+    // (the event the streams wait on, not the one host threads wait on: hipEventSynchronize holds the event's lock while it waits - see the
+    // two completion events of a job - and this thread holds mu)
+    if( !idle && it->second->state == J_COMMITTED && it->second->done ) idle = hipEventQuery( it->second->done ) == hipSuccess;
     if( idle ) { lane = c->prioLane; c->prioJob = job.id; }
   }
   if( lane < 0 ) { lane = c->nextStream; c->nextStream = ( c->nextStream + 1 ) % c->numLanesRR; }
