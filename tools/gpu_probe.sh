@@ -1,6 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
-mkdir -p gpurun_out/tl6
-VVDEC_AMD_LIB=$PWD/vvdec_amd/libvvdec_amd_wd.so VVR_TIMELINE=1 timeout 300 python bench.py --no-cpu-baseline --verify 0 > gpurun_out/tl6/k64.json 2> gpurun_out/tl6/k64.err
-python -c "
-import json; d=json.load(open('gpurun_out/tl6/k64.json')); print('K64', d['value'], d['config']['device_only_fps'], d['config']['submit_loop_ms'])"
+timeout 600 python -m pytest tests -m gpu -x -q -k "stream or golden" 2>&1 | tail -2
+timeout 300 python bench.py --no-cpu-baseline --verify 2 --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('K20', d['value'], d['config']['device_only_fps'], d['config']['verified_timed_pictures_vs_oracle'])"
+timeout 300 python bench.py --no-cpu-baseline --verify 0 --config allintra 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('allintra', d['value'], d['config']['device_only_fps'])"

@@ -111,6 +111,7 @@ struct PrepScratch
   int beginMaps();
   int mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string& err );
   bool anyIntra = false; uint32_t curCtuIdx = 0;
+  bool allIntraCus = false;                // every CU of the picture is an intra CU: every CTU takes the fast path, nobody ever looks a producer up
   int buildWorkLists( std::string& err );
   int formUnits();
   int groupUnits();
@@ -385,6 +386,8 @@ int PrepScratch::beginMaps()
 {
   anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
+  allIntraCus = h.slice_type == 2;
+  for( uint32_t i = 0; i < p->num_cu && allIntraCus; i++ ) allIntraCus = p->cu[i].pred_mode == VVR_PRED_INTRA;
   intraAt.clear();
   fastCtu.assign( (size_t) numCtu, 0 );
   if( anyIntra )
@@ -667,7 +670,8 @@ int PrepScratch::buildWorkLists( std::string& err )
               for( int yy = 0; yy < 2 * cclmLeft + 4; yy += 4 ) touch( 0, lx0 - 1, ly0 + yy );
             }
             }     // (not an all-intra CTU)
-            // the cells this block reconstructs
+            // the cells this block reconstructs (the map is only ever read by the producer analysis of CTUs that are not all intra)
+            if( !allIntraCus )
             {
               const int cx0 = ( x0 << cs ) >> 2, cx1 = std::min( ( ( ( x0 + w ) << cs ) + 3 ) >> 2, w4 ), cy1 = std::min( ( ( ( y0 + hh ) << cs ) + 3 ) >> 2, h4 );
               for( int cy = ( y0 << cs ) >> 2; cy < cy1; cy++ ) std::fill( &itemAtE[comp][(size_t) cy * w4 + cx0], &itemAtE[comp][(size_t) cy * w4 + std::max( cx0, cx1 )], ( epoch << 22 ) | myId );
