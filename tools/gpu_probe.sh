@@ -1,4 +1,5 @@
 #!/bin/bash
+# developer scratch: the quick GPU check between changes (one gpurun call): parity subset, the driver's bench line, the all-intra line
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests -m gpu -x -q -k "stream or golden" 2>&1 | tail -2
 timeout 300 python bench.py --no-cpu-baseline --verify 2 --steps 20 --warmup 5 2>/dev/null | python -c "
