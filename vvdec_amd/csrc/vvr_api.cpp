@@ -8,9 +8,10 @@
 //   1. prepare (host, vvr_prepare.cpp): validation, then the device work lists, built by one of `host_threads` worker threads (or by the
 //      submitting thread when host_threads is 0) and packed into the pinned half of a ring entry — the reference does the same set-up inline
 //      in decompressPicture (:429-682) and spreads it over its thread pool;
-//   2. commit (in submission order, by the launcher thread - by the submitting thread when host_threads is 0): asynchronous H2D copies on the copy
+//   2. commit (by the launcher thread in submission order, except that a ready picture passes pictures still in stage 1 that it shares no DPB
+//      slot with, nextToCommitLocked - by the submitting thread when host_threads is 0): asynchronous H2D copies on the copy
 //      stream (the ring entry; record arrays in pinned caller memory straight from where they are), then the kernels of the picture on one of
-//      `num_streams` HIP streams, ordered against other pictures by whole-picture HIP events (reference pictures: the "refPicExtDepBarriers" of
+//      `num_streams` HIP streams (an I picture: on the high-priority stream when that is free), ordered against other pictures by whole-picture HIP events (reference pictures: the "refPicExtDepBarriers" of
 //      :544-581; slot reuse: write-after-read);
 //   3. completion: two events per picture, one later pictures' streams wait for and one host threads wait for (hipEventSynchronize holds the event's
 //      lock while it waits: a hipStreamWaitEvent on the same event would stall the launcher behind it); DMVR delta MVs and the collocated motion
@@ -124,7 +125,7 @@ struct vvr_context {
   std::vector<char*> retiredHost, retiredDev;   // outgrown ring buffers, freed with the context
   std::vector<hipEvent_t> eventPool;
   std::vector<std::thread> workers;
-  std::thread launcher;                 // commits prepared pictures in submission order (contexts with worker threads)
+  std::thread launcher;                 // commits prepared pictures (contexts with worker threads), see nextToCommitLocked for the order
 #ifdef VVR_WATCHDOG
   std::thread watchdog;
 #endif
@@ -620,9 +621,9 @@ static void workerMain( vvr_context* c )
       std::unique_lock<std::mutex> lk( c->mu );
       c->cv.wait( lk, [&]{ return c->stop || !c->queue.empty(); } );
       if( c->queue.empty() ) break;       // (stop, and nothing left to do)
-      // An I picture among the next few waiting pictures goes first: its host stage and its intra stage on the device are the longest of the stream
-      // (12 ms + 8 ms at 4K against 5.6 ms + 0.7 ms of a B picture) and it waits for nothing, so it should not queue behind pictures that take
-      // their turn on the device before it anyway (the commit order stays the submission order).  Only as far ahead as the upload ring reaches: the
+      // An I picture among the next few waiting pictures goes first: its intra stage is the longest thing the device does for the stream (8 ms at
+      // 4K against 0.7 ms for a whole B picture), everything of the next GOP waits for it, and it waits for nothing itself, so it should not queue
+      // behind the host stage of pictures that do not depend on it.  Only as far ahead as the upload ring reaches: the
       // ring entry of a picture that far down is free as soon as pictures already handed to workers are done, never one still in this queue.
       size_t pick = 0;
       for( size_t k = 1; k < c->queue.size() && k < 16; k++ )
