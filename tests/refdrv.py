@@ -206,3 +206,53 @@ def oracle_dmvr(n):
     a = np.zeros((max(1, n), 2), np.int32)
     L.vvo_get_dmvr(a.ctypes.data_as(C.POINTER(C.c_int32)), n)
     return a[:n]
+
+
+# ---- decoded picture hash, restated (test infrastructure; pinned against the reference's functions in tests/test_oracle_vs_ref.py) ---------------
+_CRC_T = None
+
+
+def hash_crc(plane, bit_depth):
+    """compCRC (CommonLib/PicYuvMD5.cpp:99-138): CRC-16 / 0x1021, start 0xffff, message bits shifted in at the bottom - low byte, then (bit depth
+    > 8) high byte of every sample in raster order - and 16 zero bits at the end; 2 digest bytes, high byte first"""
+    global _CRC_T
+    if _CRC_T is None:
+        _CRC_T = []
+        for t in range(256):
+            v = t << 8
+            for _ in range(8):
+                v = ((v << 1) & 0xffff) ^ (0x1021 if v & 0x8000 else 0)
+            _CRC_T.append(v)
+    a = np.ascontiguousarray(plane, dtype=np.uint16)
+    data = (a.astype("<u2").tobytes() if bit_depth > 8 else a.astype(np.uint8).tobytes()) + b"\0\0"
+    crc = 0xffff
+    for b in data:
+        crc = ((((crc << 8) & 0xffff) | b) ^ _CRC_T[crc >> 8])
+    return bytes([(crc >> 8) & 0xff, crc & 0xff])
+
+
+def hash_checksum(plane, bit_depth):
+    """compChecksum (CommonLib/PicYuvMD5.cpp:153-179): sum over the samples of (low byte ^ m) [+ (high byte ^ m) when the bit depth exceeds 8],
+    m = (x & 255) ^ (y & 255) ^ (x >> 8) ^ (y >> 8) as uint8, modulo 2^32; 4 digest bytes, most significant first"""
+    a = np.ascontiguousarray(plane, dtype=np.uint16).astype(np.uint64)
+    h, w = a.shape
+    y, x = np.mgrid[0:h, 0:w]
+    m = ((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)).astype(np.uint64) & 0xff
+    s = int(((a & 0xff) ^ m).sum())
+    if bit_depth > 8:
+        s += int(((a >> 8) ^ m).sum())
+    s &= 0xffffffff
+    return bytes([(s >> 24) & 0xff, (s >> 16) & 0xff, (s >> 8) & 0xff, s & 0xff])
+
+
+def hash_md5(plane, bit_depth):
+    """calcMD5 (CommonLib/PicYuvMD5.cpp:197-221): MD5 over the samples in raster order, one byte per sample up to 8 bits, else two (little endian)"""
+    import hashlib
+    a = np.ascontiguousarray(plane, dtype=np.uint16)
+    return hashlib.md5(a.astype(np.uint8).tobytes() if bit_depth <= 8 else a.astype("<u2").tobytes()).digest()
+
+
+def picture_hash(planes, bit_depth, method):
+    """per-component digests of a picture: method 0 MD5, 1 CRC, 2 checksum (the hash types of the decoded-picture-hash SEI)"""
+    f = (hash_md5, hash_crc, hash_checksum)[method]
+    return [f(p, bit_depth) for p in planes]

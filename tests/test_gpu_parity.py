@@ -491,7 +491,8 @@ def test_unsupported_tools_fail_loudly(built):
 
 def test_output_window_and_picture_hash(built):
     """the output side of the boundary on reconstructed pictures: conformance-window crop (vvr_read_output) and the decoded-picture-hash
-    digests (vvr_picture_hash) agree with the full planes read back through vvr_read_plane"""
+    digests (vvr_picture_hash: MD5, CRC, checksum - k_plane_hash_rows on the device) against the restatement of PicYuvMD5.cpp in
+    tests/refdrv.py (pinned against the reference's functions on the CPU) over the full planes read back through vvr_read_plane"""
     import vvdec_amd
     W, H = 256, 128
     plans, nslots = stream.ra_plan(3, gop=2, seed_poc0_is_external=False)
@@ -505,9 +506,43 @@ def test_output_window_and_picture_hash(built):
         for c in range(3):
             s = 1 if c else 0
             assert np.array_equal(win[c], full[c][8 >> s:(8 + 96) >> s, 16 >> s:(16 + 200) >> s])
-        md5 = rec.picture_hash(pl.slot, 0)
-        assert md5 == [hashlib.md5(p.astype("<u2").tobytes()).digest() for p in full]
-        assert [len(x) for x in rec.picture_hash(pl.slot, 1)] == [2, 2, 2] and [len(x) for x in rec.picture_hash(pl.slot, 2)] == [4, 4, 4]
+        for method in (0, 1, 2):
+            assert rec.picture_hash(pl.slot, method) == refdrv.picture_hash(full, 10, method), "hash method %d" % method
+    rec.close()
+
+
+@pytest.mark.parametrize("bd,cf,W,H", [(10, 1, 200, 136), (8, 1, 200, 136), (10, 0, 200, 136), (8, 0, 136, 72), (10, 1, 584, 328)])
+def test_output_stage_on_the_device(built, bd, cf, W, H):
+    """f3 on the device, values not lengths: MD5 / CRC / checksum of vvr_picture_hash (CommonLib/PicYuvMD5.cpp:99-221) and the 8-bit narrowing of
+    vvr_read_output (VVDecImpl::copyComp, vvdecimpl.cpp:818-880) for 8- and 10-bit samples, 4:2:0 and 4:0:0, picture sizes that are no multiple
+    of anything (and one beyond 256 in both directions: the checksum mask folds x >> 8 and y >> 8), on a reconstructed picture and on random planes"""
+    import vvdec_amd
+    ncomp = 3 if cf else 1
+    geo = dict(bit_depth=bd, chroma_format=cf, log2_ctu=6)
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=3, num_streams=1, **geo)
+    rng = np.random.default_rng(bd * 7 + cf + W)
+    rnd = [rng.integers(0, 1 << bd, rec.plane_shape(c)).astype(np.uint16) for c in range(ncomp)]
+    rec.write_picture(1, rnd)
+    plans, _ = stream.ra_plan(1, gop=1, seed_poc0_is_external=False)
+    d = synth.picture_for_plan(plans[0], W, H, seed=977, tool_flags=TOOLS_A, **geo)
+    rec.wait(rec.decompress_picture(d))
+    for slot, planes in ((1, rnd), (plans[0].slot, rec.read_picture(plans[0].slot)[:ncomp])):
+        for method in (0, 1, 2):
+            got = rec.picture_hash(slot, method)
+            assert got == refdrv.picture_hash(planes, bd, method), "slot %d hash method %d: %r" % (slot, method, got)
+        wx, wy, ww, wh = 8, 4, W - 24, H - 12
+        win16 = rec.read_output(slot, window=(wx, wy, ww, wh))
+        for c in range(ncomp):
+            s = 1 if c else 0
+            assert np.array_equal(win16[c], planes[c][wy >> s:(wy + wh) >> s, wx >> s:(wx + ww) >> s])
+        if bd == 8:
+            win8 = rec.read_output(slot, window=(wx, wy, ww, wh), bytes_per_sample=1)
+            for c in range(ncomp):
+                s = 1 if c else 0
+                assert win8[c].dtype == np.uint8 and np.array_equal(win8[c], planes[c][wy >> s:(wy + wh) >> s, wx >> s:(wx + ww) >> s].astype(np.uint8))
+        else:
+            with pytest.raises(vvdec_amd.VvrError):
+                rec.read_output(slot, window=(wx, wy, ww, wh), bytes_per_sample=1)        # only 8-bit content is narrowed
     rec.close()
 
 

@@ -112,7 +112,7 @@ def _check_tables(d, units, items):
         S = (1 << l2) >> (1 if comp else 0)
         ox, oy = (ctu % ctusX) * S, (ctu // ctusX) * S
         it = items[i0:i1]
-        assert (it["comp"] == comp).all()
+        assert ((it["comp"] & 3) == comp).all()
         assert ((it["x"] >= ox) & (it["x"] < ox + S) & (it["y"] >= oy) & (it["y"] < oy + S)).all(), "block outside its unit's CTU"
         if i1 > i0:
             assert ((it["mode"] == MODE_RESI_ADD).all() and comp > 0) if iA == i1 else not (it["mode"] == MODE_RESI_ADD).any()
@@ -137,10 +137,22 @@ def _check_tables(d, units, items):
     prod = np.full((ncomp, h4, w4), -1, np.int64)
     for i in range(nI):
         it = items[i]
-        cs = 1 if it["comp"] else 0
+        icomp = int(it["comp"]) & 3
+        cs = 1 if icomp else 0
         x0, y0, ww, hh = int(it["x"]) << cs, int(it["y"]) << cs, (1 << int(it["lw"])) << cs, (1 << int(it["lh"])) << cs
-        sub = prod[int(it["comp"]), y0 >> 2:(y0 + hh + 3) >> 2, x0 >> 2:(x0 + ww + 3) >> 2]
-        isp_narrow = (int(it["flags"]) & 6) == 6 and not it["comp"] and min(ww, hh) < 4
+        # a block of more than 1024 samples comes as 2 or 4 items, one band of rows each (one wavefront per band)
+        part, lparts = (int(it["nTL"]) >> 4) & 3, int(it["nTL"]) >> 6
+        assert part < (1 << lparts) and (lparts == 0 or (icomp == 0 and ((ww * hh) >> lparts) == 1024))
+        assert ((ww * hh) >> (2 * cs)) >> lparts <= 1024 or int(it["mode"]) >= 254 or (int(it["flags"]) & 8), "an ordinary block of more than 1024 samples in one item"
+        if lparts:
+            assert i - part >= 0 and all(int(items[i - part + e]["x"]) == int(it["x"]) and int(items[i - part + e]["y"]) == int(it["y"]) and ((int(items[i - part + e]["nTL"]) >> 4) & 3) == e for e in range(1 << lparts)), "the bands of a block are consecutive items"
+            assert unit_of[i - part] == unit_of[i - part + (1 << lparts) - 1]
+            # a band reads what the whole block reads and nothing of the bands before it
+            assert (int(it["comp"]) >> 2) == (int(items[i - part]["comp"]) >> 2) + part
+            y0 += part * (hh >> lparts)
+            hh >>= lparts
+        sub = prod[icomp, y0 >> 2:(y0 + hh + 3) >> 2, x0 >> 2:(x0 + ww + 3) >> 2]
+        isp_narrow = (int(it["flags"]) & 6) == 6 and not icomp and min(ww, hh) < 4
         assert isp_narrow or (sub == -1).all(), "two blocks produce one cell"
         sub[...] = i
 
@@ -148,7 +160,8 @@ def _check_tables(d, units, items):
         if j == i or j < 0:
             return True
         uj, ui = int(unit_of[j]), int(unit_of[i])
-        return (j < i) if uj == ui else bool((anc[ui] >> uj) & 1)
+        # inside a unit: block i starts when every block of the unit before i - indep is done (the kernel's progress counters)
+        return (j < i - (int(items[i]["comp"]) >> 2)) if uj == ui else bool((anc[ui] >> uj) & 1)
 
     ctu4 = 1 << (l2 - 2)
 
@@ -163,7 +176,7 @@ def _check_tables(d, units, items):
     nchk = 0
     for i in range(nI):
         it = items[i]
-        comp, mode = int(it["comp"]), int(it["mode"])
+        comp, mode = int(it["comp"]) & 3, int(it["mode"])
         if mode == MODE_RESI_ADD:
             continue
         cs, chn = (1 if comp else 0), (1 if comp else 0)

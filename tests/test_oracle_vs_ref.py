@@ -429,3 +429,20 @@ def test_oracle_equals_reference_subpictures(built, W, H, l2, idx, seed, sp, ext
     d.subpics = None
     other = refdrv.oracle_reconstruct(d, refs, flags=0)
     assert any(not np.array_equal(x, y) for x, y in zip(other, final))
+
+
+@pytest.mark.parametrize("bd,cf,W,H", [(10, 1, 136, 72), (8, 1, 136, 72), (10, 0, 136, 72), (10, 1, 520, 264)])
+def test_picture_hash_restatement_equals_reference(built, bd, cf, W, H):
+    """tests/refdrv.py's restatement of the decoded-picture-hash functions (the checker of the GPU output stage) against the reference's own
+    calcMD5 / calcCRC / calcChecksum (PicYuvMD5.cpp), incl. a picture wider and taller than 256 samples (the checksum's mask folds x >> 8, y >> 8)"""
+    import ctypes as C
+    rng = np.random.default_rng(bd * 100 + cf * 10 + W)
+    planes = [rng.integers(0, 1 << bd, (H >> s, W >> s)).astype(np.uint16) for s in ((0, 1, 1) if cf else (0,))]
+    L = refdrv.lib()
+    ptrs = (C.POINTER(C.c_uint16) * 3)()
+    for c, pl in enumerate(planes):
+        ptrs[c] = pl.ctypes.data_as(C.POINTER(C.c_uint16))
+    for method, length in ((0, 16), (1, 2), (2, 4)):
+        ref = (C.c_uint8 * 48)()
+        assert L.vvref_picture_hash(ptrs, W, H, cf, bd, method, ref) == length
+        assert b"".join(refdrv.picture_hash(planes, bd, method)) == bytes(ref[:length * len(planes)]), "method %d" % method

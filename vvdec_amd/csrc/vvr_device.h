@@ -65,10 +65,18 @@ struct IntraItem {        // 16 bytes, self-contained: the kernel never touches 
   uint8_t  lw, lh;        // log2 size
   uint8_t  mode;          // 0 planar, 1 DC, 2..66 angular (before the wide-angle remap)
   uint8_t  flags;         // IT_F_*
-  uint8_t  nTL, nA, nL;   // available units (4 luma samples): top-left (0/1), above incl. above-right, left incl. below-left
-  uint8_t  comp;
+  uint8_t  nTL;           // bit 0: top-left reference sample available; bits 4..5: row part of the block this item predicts, bits 6..7: log2( parts )
+                          // (a block of more than 1024 samples is predicted by 2 or 4 wavefronts, each a band of rows: one item per band)
+  uint8_t  nA, nL;        // available units (4 luma samples): above incl. above-right, left incl. below-left
+  uint8_t  comp;          // bits 0..1: component; bits 2..7: `indep` - the block reads nothing that the `indep` blocks before it in its unit produce
+                          // (it starts when every block of the unit up to index - indep - 1 is done)
   uint32_t tu;
 };
+#define IT_PART( it )    ( ( (it).nTL >> 4 ) & 3 )
+#define IT_LPARTS( it )  ( (it).nTL >> 6 )
+#define IT_COMP( it )    ( (it).comp & 3 )
+#define IT_INDEP( it )   ( (it).comp >> 2 )
+#define IT_PART_SAMPLES 1024   /* samples one wavefront predicts at most (blocks of 2048 / 4096 samples: 2 / 4 parts) */
 
 // One unit of the intra stage (blocks of one component inside one CTU that read reference samples from each other, or a group of such
 // clusters at the same dependency depth), processed by one workgroup.

@@ -2393,7 +2393,7 @@ void launch_plane_hash_rows( hipStream_t s, const pel_t* plane, int stride, int 
 #define IT_PADX   8      // columns left of the CTU kept in LDS: 8 samples = 16 bytes, so that every tile row starts 16-byte aligned in HBM
 #define IT_RIGHT 64
 #define IT_TS   ( IT_PADX + 128 + IT_RIGHT + 8 )     // LDS row stride of the rows ABOVE the CTU (they reach 64 samples into the above-right CTU)
-#define IT_TSB  ( IT_PADX + 128 + 8 )                // row stride of the rows inside the CTU (nothing right of the CTU is ever available there)
+#define IT_TSB  ( IT_PADX + 128 )                    // row stride of the rows inside the CTU (nothing right of the CTU is ever available there); 68 dwords: a column read spreads over 16 banks
 // index of sample (ox + dx, oy + dy) in the tile: IT_PAD long rows, then the CTU rows
 __device__ __forceinline__ int tile_idx( int dx, int dy )
 {
@@ -2402,19 +2402,26 @@ __device__ __forceinline__ int tile_idx( int dx, int dy )
 #define IT_MAXREF ( 2 * 64 + 8 )
 
 #define IT_BATCH 64         // IntraItems staged in LDS at a time (64 x 16 B: one dword per thread)
+#define IT_WAVES 4          // wavefronts of a workgroup: each predicts one block at a time
+
+// scratch of one wavefront (one block at a time)
+#define IT_NEG 72           // entries in front of a reference line: the side reference projected onto negative indices of the main reference
+struct IntraWave {
+  pel_t topB[IT_NEG + IT_MAXREF + 8], leftB[IT_NEG + IT_MAXREF + 8];     // reference lines of the block (index 0 = the corner sample), smoothed in place
+  pel_t auxT[IT_MAXREF + 8], auxL[IT_MAXREF + 8];    // ISP: the line of the whole CU; MIP: the reduced prediction
+  int16_t resi[IT_PART_SAMPLES];                      // residual of the block (fetched while the blocks before it are predicted)
+  int   lmSel[8];                                     // CCLM: the (luma, chroma) pairs of the selected template positions; MIP: the reduced boundary
+};
 
 struct IntraShared {
   pel_t tile[IT_PAD * IT_TS + 128 * IT_TSB];
-  pel_t top[IT_MAXREF + 8], left[IT_MAXREF + 8], ftop[IT_MAXREF + 8], fleft[IT_MAXREF + 8];
-  IntraItem items[IT_BATCH];
-  int16_t resiS[2][256];                               // residual of the current / next block of at most 256 samples (prefetched one block ahead)
-  int16_t resiB[64 * 64];                              // residual of a larger block (read when the block before it is done)
+  IntraWave wave[IT_WAVES];
+  IntraItem items[IT_BATCH];                           // the unit's first block records (reference staging, residual-add units, write-back)
   int16_t angTab[32], invAngTab[32], cfilt[32][4];     // the small ROM tables the serial per-block path indexes: LDS latency instead of a memory round trip each
   uint8_t filtThr[8];
-  int   lmSel[8];                                       // CCLM: the (luma, chroma) pairs of the selected template positions
   int   ticket;
-  int   dcSum[2];
   int   csFac[4];                                       // LMCS chroma residual scaling factor of the CTU's VPDUs
+  int   prog[IT_WAVES];                                 // blocks of the unit each wavefront has finished (wavefront w: blocks w, w + 4, ... in order)
 };
 
 __constant__ uint8_t c_intraFilterThr[8] = { 24, 24, 24, 14, 2, 0, 0, 0 };
@@ -2433,31 +2440,131 @@ __device__ __forceinline__ int intra_wide_angle( int w, int h, int mode )   // I
   return mode;
 }
 
-#define IT_MAXR 16          // samples a lane holds for one block (64x64 / 256 threads)
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding vector-memory operation
-// (vmcnt(0)), which would put an HBM/L2 round trip on the serial block-to-block path of k_intra; the samples the next block
-// reads come from the LDS tile.
+// (vmcnt(0)), which would put an HBM/L2 round trip on the serial path of k_intra.
 __device__ __forceinline__ void lds_barrier() { asm volatile( "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory" ); }
+// Ordering inside ONE wavefront: its LDS operations execute in issue order, so a value another lane of the same wavefront wrote is there
+// once the write has been issued; the wait keeps the compiler from moving accesses across and covers the write's completion.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" ); }
 
-// Residual prefetch of the block loop, version without control flow around the load: ONE sample per lane (blocks of at most 256
-// samples, the common case), index clamped, issued whether or not the block has a residual.  (A switch over load counts makes the
-// compiler merge the destination registers of the variants right behind the loads, which needs s_waitcnt vmcnt(0) there and turns
-// the prefetch into a synchronous load: ~1 us per block, measured with the in-kernel timeline.)  Larger blocks are read when they
-// are stashed.
-__device__ __forceinline__ int intra_prefetch_resi( const IntraItem& it, const pel_t* __restrict__ rs, int rstride, int tid )
+// sum over the 64 lanes (DPP row shifts inside the rows of 16, then the four row totals through scalar registers): no LDS round trips
+__device__ __forceinline__ int wave_sum( int v )
 {
-  const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
-  const int i = min( tid, wh - 1 );
-  return (int16_t) rs[(size_t) ( it.y + ( i >> lw ) ) * rstride + it.x + ( i & ( ( 1 << lw ) - 1 ) )];
+  v += __builtin_amdgcn_update_dpp( 0, v, 0x111, 0xf, 0xf, false );     // row_shr:1
+  v += __builtin_amdgcn_update_dpp( 0, v, 0x112, 0xf, 0xf, false );     // row_shr:2
+  v += __builtin_amdgcn_update_dpp( 0, v, 0x114, 0xf, 0xf, false );     // row_shr:4
+  v += __builtin_amdgcn_update_dpp( 0, v, 0x118, 0xf, 0xf, false );     // row_shr:8  -> lane 15 of every row holds the row's sum
+  return __builtin_amdgcn_readlane( v, 15 ) + __builtin_amdgcn_readlane( v, 31 ) + __builtin_amdgcn_readlane( v, 47 ) + __builtin_amdgcn_readlane( v, 63 );
 }
-__device__ __forceinline__ void intra_stash_resi1( const IntraItem& it, int16_t* __restrict__ dst, int tid, int pre, const pel_t* __restrict__ rs, int rstride )
+
+// the 16-byte record of block q, the same for every lane (one request); decoded into scalar registers by intra_item_of
+__device__ __forceinline__ uint4 intra_load_item( const IntraItem* __restrict__ items, uint32_t q ) { return *reinterpret_cast<const uint4*>( &items[q] ); }
+__device__ __forceinline__ IntraItem intra_item_of( const uint4 v )
+{
+  IntraItem it; uint32_t* op = reinterpret_cast<uint32_t*>( &it );
+  op[0] = __builtin_amdgcn_readfirstlane( v.x ); op[1] = __builtin_amdgcn_readfirstlane( v.y ); op[2] = __builtin_amdgcn_readfirstlane( v.z ); op[3] = __builtin_amdgcn_readfirstlane( v.w );
+  return it;
+}
+
+// Residual of a block (its row part) into registers: issued one block ahead of its use by the same wavefront, stored to the wavefront's LDS
+// scratch when the block's turn comes.  Four samples (8 bytes) per lane and load where positions allow it (luma always; chroma unless the
+// block sits at x = 2 mod 4: the 4-wide chroma of the middle part of a ternary split of 16), else one sample per load (blocks of <= 512 samples).
+struct IntraResiRegs { uint2 v[4]; };
+__device__ __forceinline__ bool intra_resi_vec4( const IntraItem& it ) { return it.lw >= 2 && !( it.x & 3 ); }
+__device__ __forceinline__ int intra_part_rows( const IntraItem& it ) { return ( 1 << it.lh ) >> IT_LPARTS( it ); }
+__device__ __forceinline__ void intra_load_resi( IntraResiRegs& R, const IntraItem& it, const pel_t* __restrict__ rs, int rstride, int lane )
 {
   if( !( it.flags & IT_F_RESI ) ) return;
-  const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
-  if( wh <= 256 ) { if( tid < wh ) dst[tid] = (int16_t) pre; return; }
-#pragma unroll 4
-  for( int i = tid; i < wh; i += 256 ) dst[i] = (int16_t) rs[(size_t) ( it.y + ( i >> lw ) ) * rstride + it.x + ( i & ( ( 1 << lw ) - 1 ) )];
+  const int lw = it.lw, rows = intra_part_rows( it ), wh = rows << lw, y0 = it.y + IT_PART( it ) * rows;
+  if( wh > IT_PART_SAMPLES ) return;                 // (a block that is not split: read where it is added)
+  if( intra_resi_vec4( it ) )
+  {
+#pragma unroll
+    for( int e = 0; e < 4; e++ )
+    {
+      const int i = ( e * 64 + lane ) << 2;
+      if( e * 256 < wh ) { const int ii = min( i, wh - 4 ); R.v[e] = *reinterpret_cast<const uint2*>( &rs[(size_t) ( y0 + ( ii >> lw ) ) * rstride + it.x + ( ii & ( ( 1 << lw ) - 1 ) )] ); }
+    }
+  }
+  else
+  {
+#pragma unroll
+    for( int e = 0; e < 8; e++ )
+    {
+      const int i = e * 64 + lane;
+      if( e * 64 < wh ) { const int ii = min( i, wh - 1 ); const uint32_t s = (uint16_t) rs[(size_t) ( y0 + ( ii >> lw ) ) * rstride + it.x + ( ii & ( ( 1 << lw ) - 1 ) )]; if( e & 1 ) R.v[e >> 1].y = s; else R.v[e >> 1].x = s; }
+    }
+  }
+}
+__device__ __forceinline__ void intra_stash_resi( const IntraResiRegs& R, const IntraItem& it, int16_t* __restrict__ dst, int lane )
+{
+  if( !( it.flags & IT_F_RESI ) ) return;
+  const int wh = intra_part_rows( it ) << it.lw;
+  if( wh > IT_PART_SAMPLES ) return;
+  if( intra_resi_vec4( it ) )
+  {
+#pragma unroll
+    for( int e = 0; e < 4; e++ ) { const int i = ( e * 64 + lane ) << 2; if( e * 256 < wh && i < wh ) *reinterpret_cast<uint2*>( &dst[i] ) = R.v[e]; }
+  }
+  else
+  {
+#pragma unroll
+    for( int e = 0; e < 8; e++ ) { const int i = e * 64 + lane; if( e * 64 < wh && i < wh ) dst[i] = (int16_t) ( ( e & 1 ) ? R.v[e >> 1].y : R.v[e >> 1].x ); }
+  }
+}
+
+// CCLM / MDLM: the down-sampled luma a chroma block is predicted from (xGetLumaRecPixels, IntraPrediction.cpp:1403-1470; 4:2:0, both luma
+// filters) - sample e * 64 + lane of the block, 16 bits each - and of this lane's template position (xGetLMParameters :1694-1800).  It only
+// depends on luma that is final before the chroma unit starts, so it is fetched one block ahead of its use, like the residual.
+struct IntraLumaRegs { uint32_t v[8]; int tpl; };
+__device__ __forceinline__ void intra_load_cclm_luma( IntraLumaRegs& R, const IntraItem& it, const PicDev& pic, const DevPlanes& reco, int lane )
+{
+  if( it.mode < 67 || it.mode > 69 ) return;
+  const pel_t* __restrict__ Yp = reco.p[0]; const int ys = reco.stride[0];
+  const int lw = it.lw, w = 1 << lw, wh = 1 << ( it.lw + it.lh );
+  const int lx0 = (int) it.x << 1, ly0 = (int) it.y << 1;
+#define LU( xx, yy ) ( (int) Yp[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
+  const uint32_t lm = it.tu;
+  const int actualTop = lm & 0xff, actualLeft = ( lm >> 8 ) & 0xff;
+  const bool aboveAvail = ( lm >> 16 ) & 1, leftAvail = ( lm >> 17 ) & 1, bLeft = ( lm >> 18 ) & 1, firstRow = ( lm >> 19 ) & 1, bAbove = ( lm >> 20 ) & 1;
+  const bool colloc = ( pic.hdr.tool_flags & VVR_TOOL_CCLM_COLLOC ) != 0;      // sps_chroma_vertical_collocated_flag: 5-tap cross instead of the 6-tap filter
+  const int aboveIs4 = leftAvail ? 0 : 1, leftIs4 = aboveAvail ? 0 : 1;
+  const int cntT = aboveAvail ? min( actualTop, ( 1 + aboveIs4 ) << 1 ) : 0, cntL = leftAvail ? min( actualLeft, ( 1 + leftIs4 ) << 1 ) : 0;
+  R.tpl = 0;
+  if( lane < cntT + cntL )
+  {
+    int lv;
+    if( lane < cntT )
+    {
+      const int i = ( actualTop >> ( 2 + aboveIs4 ) ) + lane * max( 1, actualTop >> ( 1 + aboveIs4 ) );
+      const int xl = ( i == 0 && !bLeft ) ? 2 * i : 2 * i - 1;
+      if( firstRow ) lv = ( LU( 2 * i, -1 ) * 2 + LU( xl, -1 ) + LU( 2 * i + 1, -1 ) + 2 ) >> 2;
+      else if( colloc ) lv = ( LU( 2 * i, -3 ) + LU( 2 * i, -2 ) * 4 + LU( xl, -2 ) + LU( 2 * i + 1, -2 ) + LU( 2 * i, -1 ) + 4 ) >> 3;
+      else           lv = ( LU( 2 * i, -2 ) * 2 + LU( xl, -2 ) + LU( 2 * i + 1, -2 ) + LU( 2 * i, -1 ) * 2 + LU( xl, -1 ) + LU( 2 * i + 1, -1 ) + 4 ) >> 3;
+    }
+    else
+    {
+      const int j = ( actualLeft >> ( 2 + leftIs4 ) ) + ( lane - cntT ) * max( 1, actualLeft >> ( 1 + leftIs4 ) );
+      if( colloc ) { const int yu = ( j == 0 && !bAbove ) ? 2 * j : 2 * j - 1; lv = ( LU( -2, yu ) + LU( -2, 2 * j ) * 4 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) + 4 ) >> 3; }
+      else lv = ( LU( -2, 2 * j ) * 2 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) * 2 + LU( -3, 2 * j + 1 ) + LU( -1, 2 * j + 1 ) + 4 ) >> 3;
+    }
+    R.tpl = lv;
+  }
+#pragma unroll
+  for( int e = 0; e < 16; e++ )
+  {
+    if( e * 64 < wh )
+    {
+      const int i = min( e * 64 + lane, wh - 1 );
+      const int x = i & ( w - 1 ), y = i >> lw;
+      const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
+      const int yu = ( y == 0 && !bAbove ) ? 0 : 2 * y - 1;
+      const uint32_t t = (uint16_t) ( colloc ? ( LU( 2 * x, yu ) + LU( 2 * x, 2 * y ) * 4 + LU( xl, 2 * y ) + LU( 2 * x + 1, 2 * y ) + LU( 2 * x, 2 * y + 1 ) + 4 ) >> 3
+                                            : ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
+      if( e & 1 ) R.v[e >> 1] = ( R.v[e >> 1] & 0xffffu ) | ( t << 16 ); else R.v[e >> 1] = t;
+    }
+  }
+#undef LU
 }
 
 __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, DevPlanes resi, const IntraItem* __restrict__ items,
@@ -2472,12 +2579,10 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   constexpr int dbg = 0; constexpr unsigned long long* trace = nullptr;      // (the timing experiments and the in-kernel timeline are developer builds only)
 #endif
   __shared__ IntraShared sh;
-  // (Measured and left out: s_setprio 3 for this kernel, whose wavefronts share their SIMDs with the bulk kernels of the other pictures in flight -
-  // nothing alone on the device, 0 .. -15 % through vvr_submit with 16 pictures arriving at once.)
 #define IT_TRACE( K ) if( trace && threadIdx.x == 0 ) trace[(size_t) 8 * tr_ticket + ( K )] = wall_clock64()
   int tr_ticket = 0;
   const int tid = threadIdx.x;
-  const int numCtu = pic.ctus_x * pic.ctus_y;
+  const int wv = tid >> 6, lane = tid & 63;
   if( tid < 32 ) { sh.angTab[tid] = c_angTable[tid]; sh.invAngTab[tid] = c_invAngTable[tid]; }
   if( tid < 8 ) sh.filtThr[tid] = c_intraFilterThr[tid];
   if( tid < 128 ) sh.cfilt[tid >> 2][tid & 3] = d_chroma_filter[tid >> 2][tid & 3];
@@ -2489,7 +2594,8 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   for( ;; )
   {
   __syncthreads();                    // the previous unit of this workgroup is done with the LDS
-  if( tid == 0 ) { sh.ticket = atomicAdd( &sync[0], 1 ); sh.dcSum[0] = sh.dcSum[1] = 0; }
+  if( tid == 0 ) sh.ticket = atomicAdd( &sync[0], 1 );
+  if( tid < IT_WAVES ) sh.prog[tid] = 0;
   __syncthreads();
   const int ticket = sh.ticket;
   if( ticket >= numActive ) return;
@@ -2498,7 +2604,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   const uint32_t ent = un->ent;
   const int comp = ( ent >> 24 ) & 3, ctu = ent & 0xffffff;
   const bool borderOnly = ( ent >> 31 ) != 0;          // whole CTU, every sample intra: the interior is produced here, never read first
-  const bool publish = ( ( ent >> 30 ) & 1 ) != 0 && !( dbg & 0x100 );     // another unit waits for this one (level launches: nobody does)
+  const bool publish = ( ( ent >> 30 ) & 1 ) != 0 && !( dbg & 0x100 );     // another unit waits for this one
   const int cxI = ctu % pic.ctus_x, cyI = ctu / pic.ctus_x;
   const int cs = comp ? 1 : 0;
   const int S = ( 1 << pic.hdr.log2_ctu ) >> cs;
@@ -2508,11 +2614,15 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   pel_t* __restrict__ plane = reco.p[comp];
   const pel_t* __restrict__ rs = resi.p[comp];
   const int rstride = resi.stride[comp];
-  const uint32_t i0 = un->i0, i1 = un->i1;
+  const uint32_t i0 = un->i0, i1 = un->i1, iA = un->iA;
   // the unit's first IT_BATCH block records are on their way while the producers' flags are polled (one dword per lane; stored to LDS behind the
-  // wait): the reference staging below and the first batch of the block loop read them from LDS instead of each waiting for HBM / L2 again
+  // wait): the reference staging below reads them from LDS instead of waiting for HBM / L2 again; so are the records of the first two blocks
+  // of every wavefront
   const int nb0 = (int) min( (uint32_t) IT_BATCH, i1 - i0 );
   const uint32_t itemPre = tid < nb0 * 4 ? reinterpret_cast<const uint32_t*>( items + i0 )[tid] : 0u;
+  uint4 recA = make_uint4( 0, 0, 0, 0 ), recB = make_uint4( 0, 0, 0, 0 );
+  if( iA + wv < i1 ) recA = intra_load_item( items, iA + wv );
+  if( iA + wv + IT_WAVES < i1 ) recB = intra_load_item( items, iA + wv + IT_WAVES );
 #define TILE( x, y ) sh.tile[tile_idx( ( x ) - ox, ( y ) - oy )]
   // block record q of this unit into scalar registers (uniform per wavefront)
 #define IT_FETCH( IT, Q ) { const uint32_t* ip_ = ( Q ) - i0 < (uint32_t) IT_BATCH ? reinterpret_cast<const uint32_t*>( &sh.items[( Q ) - i0] ) : reinterpret_cast<const uint32_t*>( &items[Q] ); \
@@ -2537,21 +2647,20 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   IT_TRACE( 1 );
   // ---- a unit of residual-add blocks only (inter blocks with LMCS chroma scaling): no neighbourhood is read, so the blocks go
   // straight from HBM to HBM, one block per wavefront, without staging the CTU
-  if( un->iA == i1 && i1 > i0 )
+  if( iA == i1 && i1 > i0 )
   {
     const int csNv1 = pic.hdr.log2_ctu > pic.vpduLog2 ? 1 : 0;
     if( ( ent >> 29 ) & 1 )
     {
-      const int wv = tid >> 6;
       const int lx = ( cxI << pic.hdr.log2_ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.hdr.log2_ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
       if( lx < (int) pic.hdr.width && ly < (int) pic.hdr.height && ( wv == 0 || csNv1 ) )
       {
-        const int f = lmcs_cscale_factor_wave( pic, reco, lx, ly, tid & 63 );
-        if( ( tid & 63 ) == 0 ) sh.csFac[wv] = f;
+        const int f = lmcs_cscale_factor_wave( pic, reco, lx, ly, lane );
+        if( lane == 0 ) sh.csFac[wv] = f;
       }
     }
     __syncthreads();
-    for( uint32_t q = i0 + ( tid >> 6 ); q < i1; q += 4 )
+    for( uint32_t q = i0 + wv; q < i1; q += IT_WAVES )
     {
       IntraItem it;
       IT_FETCH( it, q )
@@ -2562,7 +2671,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       {
         // four samples of a row per lane (8-byte accesses; x0 and the row strides are multiples of 4 samples - not so for the chroma of
         // an 8-wide inter CU that is the middle part of a ternary split of 16)
-        for( int i = ( tid & 63 ); i < ( wh >> 2 ); i += 64 )
+        for( int i = lane; i < ( wh >> 2 ); i += 64 )
         {
           const int x = x0 + ( ( i << 2 ) & ( ( 1 << lw ) - 1 ) ), y = y0 + ( ( i << 2 ) >> lw );
           const uint2 rv = *reinterpret_cast<const uint2*>( &rs[(size_t) y * rstride + x] );
@@ -2576,7 +2685,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         }
       }
       else
-        for( int i = ( tid & 63 ); i < wh; i += 64 )
+        for( int i = lane; i < wh; i += 64 )
         {
           const int x = x0 + ( i & ( ( 1 << lw ) - 1 ) ), y = y0 + ( i >> lw );
           const int r = (int16_t) rs[(size_t) y * rstride + x];
@@ -2612,15 +2721,16 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     const int nTop = nch * max( 0, min( by1, oy ) - by0 );                   // chunks in the rows above the CTU
     const int rowsIn = max( 0, by1 - max( by0, oy ) );
     const bool perBlock = !borderOnly;
-    const int total = ( ( dbg & 2 ) || perBlock ) ? 0 : borderOnly ? nTop + ( bc0 < 0 ? rowsIn : 0 ) : nch * ( by1 - by0 );
+    const int total = ( ( dbg & 2 ) || perBlock ) ? 0 : nTop + ( bc0 < 0 ? rowsIn : 0 );
     if( perBlock && !( dbg & 2 ) )
     {
       // a unit that is not a whole intra CTU: only the reference lines its blocks read (one row above, one column left of every
       // block, as far as they are available) instead of the bounding box; one block per wavefront, 16-byte chunks
-      for( uint32_t q = i0 + ( tid >> 6 ); q < i1; q += 4 )
+      for( uint32_t q = i0 + wv; q < i1; q += IT_WAVES )
       {
         IntraItem it;
         IT_FETCH( it, q )
+        if( IT_PART( it ) ) continue;                                            // (row parts of one block: fetched with the first)
         if( it.mode == IT_MODE_IBC )
         {
           // intra block copy: the part of the reference block that lies in this CTU is read from the tile (blocks of this unit write
@@ -2628,7 +2738,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           const int bw = 1 << it.lw, bh = 1 << it.lh;
           const int rx = (int) it.x + (int16_t) ( it.tu & 0xffff ), ry = (int) it.y + (int16_t) ( it.tu >> 16 );
           const int cx0 = max( rx, ox ) & ~7, cch = max( 0, ( rx + bw - cx0 + 7 ) >> 3 );
-          for( int i = ( tid & 63 ); i < cch * bh; i += 64 )
+          for( int i = lane; i < cch * bh; i += 64 )
           {
             const int y = ry + i / cch, x = cx0 + 8 * ( i % cch );
             const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
@@ -2651,7 +2761,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         // CIIP: the inter prediction of the block itself
         const int wIntra = isp ? 0 : it.flags >> 6;                             // (the two bits are zero for every other kind of block)
         const int cch = ( ( (int) it.x & 7 ) + bw + 7 ) >> 3, nC = wIntra ? cch * bh : 0;
-        for( int i = ( tid & 63 ); i < nT + nL + nC; i += 64 )
+        for( int i = lane; i < nT + nL + nC; i += 64 )
         {
           int x, y;
           if( i < nT ) { x = tx0 + 8 * i; y = ty; }
@@ -2667,7 +2777,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       // four 16-byte loads in flight per lane; the tail repeats the last chunk (same data to the same place) instead of branching
       uint4 v0, v1, v2, v3; int o0, o1, o2, o3;
 #define IT_LD( V, O, U ) { const int i = min( base + U * 256 + tid, total - 1 ); int r, cidx; \
-        if( !borderOnly || i < nTop ) { r = i / nch; cidx = bc0 + ( i - r * nch ); } else { r = ( max( by0, oy ) - by0 ) + ( i - nTop ); cidx = -1; } \
+        if( i < nTop ) { r = i / nch; cidx = bc0 + ( i - r * nch ); } else { r = ( max( by0, oy ) - by0 ) + ( i - nTop ); cidx = -1; } \
         const int y = by0 + r, x = ox + cidx * 8; V = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] ); O = tile_idx( x - ox, y - oy ); }
       IT_LD( v0, o0, 0 ) IT_LD( v1, o1, 1 ) IT_LD( v2, o2, 2 ) IT_LD( v3, o3, 3 )
 #undef IT_LD
@@ -2676,47 +2786,54 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     }
   }
   IT_TRACE( 2 );
-  unsigned long long trA = 0, trB = 0, trC = 0, trD = 0, trT = 0;      // developer timeline: time per phase of the block loop
-#define IT_PH( ACC ) if( trace ) { const unsigned long long now_ = wall_clock64(); ACC += now_ - trT; trT = now_; }
   // ---- LMCS chroma residual scaling (DecCu.cpp:383-388,500-505): one factor per VPDU of the CTU, one wavefront each (the unit
   // has waited for the luma units that reconstruct the samples the factors are averaged over)
   const int csNv1 = pic.hdr.log2_ctu > pic.vpduLog2 ? 1 : 0;        // VPDUs per CTU side - 1
   if( ( ent >> 29 ) & 1 )
   {
-    const int wv = tid >> 6;
     const int lx = ( cxI << pic.hdr.log2_ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.hdr.log2_ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
     if( lx < (int) pic.hdr.width && ly < (int) pic.hdr.height && ( wv == 0 || csNv1 ) )
     {
-      const int f = lmcs_cscale_factor_wave( pic, reco, lx, ly, tid & 63 );
-      if( ( tid & 63 ) == 0 ) sh.csFac[wv] = f;
+      const int f = lmcs_cscale_factor_wave( pic, reco, lx, ly, lane );
+      if( lane == 0 ) sh.csFac[wv] = f;
     }
   }
+  // the residual of the wavefront's first block is on its way while the staged tile settles
+  IntraResiRegs RR;
+  IntraLumaRegs LR;
+  for( int e = 0; e < 8; e++ ) LR.v[e] = 0;
+  LR.tpl = 0;
+  if( iA + wv < i1 ) { const IntraItem itF = intra_item_of( recA ); intra_load_resi( RR, itF, rs, rstride, lane ); if( comp ) intra_load_cclm_luma( LR, itF, pic, reco, lane ); }
   lds_barrier();
-  for( uint32_t b0 = un->iA; b0 < ( ( dbg & 4 ) ? i0 : i1 ); b0 += IT_BATCH )
+  // ---- block loop: ONE WAVEFRONT PER BLOCK.  Wavefront w takes the unit's blocks w, w + 4, ... in order.  Everything that does not depend on
+  // neighbouring samples - the block's record, its residual, the co-located luma of a CCLM block, the mode set-up - is done before the block's
+  // turn comes (records two blocks ahead, residual and luma one block ahead, all in registers); a block starts when the blocks before it (all
+  // but the `indep` directly before it, which it does not read) are finished: progress counters in LDS, one per wavefront.  No workgroup
+  // barrier on the block-to-block path: inside a wavefront LDS operations execute in order.  What is left on that path is kept short in
+  // round trips, not in instructions: all reference samples of a block are read from the tile at once, smoothing happens in place, the side
+  // reference of a negative prediction angle is projected onto negative indices of the main reference once per block, and a lane predicts
+  // four neighbouring samples of a row of the (possibly transposed) block from seven reference samples with one filter.
   {
-    const int nb = (int) min( (uint32_t) IT_BATCH, i1 - b0 );
-    if( b0 != i0 )                                  // (the first batch came with the unit, and the barrier above covers the staged tile)
+    IntraWave& W = sh.wave[wv];
+    pel_t* const T = W.topB + IT_NEG;
+    pel_t* const L = W.leftB + IT_NEG;
+    volatile int* prog = sh.prog;
+    int done = 0;                     // blocks this wavefront has finished
+    for( uint32_t q = iA + wv; q < ( ( dbg & 4 ) ? i0 : i1 ); q += IT_WAVES )
     {
-      lds_barrier();                                // previous batch fully consumed
-      if( tid < nb * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = reinterpret_cast<const uint32_t*>( items + b0 )[tid];
-      lds_barrier();
-    }
-    int rpre = intra_prefetch_resi( sh.items[0], rs, rstride, tid );
-    intra_stash_resi1( sh.items[0], ( sh.items[0].lw + sh.items[0].lh ) > 8 ? sh.resiB : sh.resiS[0], tid, rpre, rs, rstride );
-    for( int k = 0; k < nb; k++ )
-    {
-      // the item is the same for every lane: move it to scalar registers so that all the mode / size dependent set-up below runs on
-      // the scalar unit and every branch on it is a scalar branch
-      IntraItem it;
-      {
-        const uint32_t* ip = reinterpret_cast<const uint32_t*>( &sh.items[k] );
-        uint32_t* op = reinterpret_cast<uint32_t*>( &it );
-        for( int q = 0; q < 4; q++ ) op[q] = __builtin_amdgcn_readfirstlane( ip[q] );
-      }
-      if( trace ) trT = wall_clock64();
-      const int16_t* __restrict__ rcur = ( sh.items[k].lw + sh.items[k].lh ) > 8 ? sh.resiB : sh.resiS[k & 1];
-      if( !( dbg & 16 ) ) rpre = intra_prefetch_resi( sh.items[min( k + 1, nb - 1 )], rs, rstride, tid );     // in flight while this block is predicted
-      const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
+      const IntraItem it = intra_item_of( recA );
+      const int x0 = it.x, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
+      const int rows = h >> IT_LPARTS( it ), yb = IT_PART( it ) * rows;        // the band of rows this item predicts
+      const int y0 = it.y;
+      const int wh = rows << lw;                                               // samples of this item
+      const bool stashed = wh <= IT_PART_SAMPLES;
+      intra_stash_resi( RR, it, W.resi, lane );
+      const IntraLumaRegs LC = LR;                                             // (CCLM) co-located luma of this block, fetched while the block before was predicted
+      // the records move up, the residual (and the luma of a CCLM block) of the wavefront's next block starts
+      recA = recB;
+      if( q + 2 * IT_WAVES < i1 ) recB = intra_load_item( items, q + 2 * IT_WAVES );
+      if( q + IT_WAVES < i1 ) { const IntraItem itN = intra_item_of( recA ); intra_load_resi( RR, itN, rs, rstride, lane ); if( comp ) intra_load_cclm_luma( LR, itN, pic, reco, lane ); }
+      const bool mip = !comp && ( it.flags & IT_F_MIP );      // (chroma: the same bit says LMCS chroma residual scaling)
       const int mrl = ( it.flags & IT_F_MIP ) ? 0 : ( it.flags >> 4 ) & 3;
       const int wIntra = it.flags >> 6;               // CIIP: weight of the planar intra part, 0 = ordinary intra block
       // intra sub-partition (luma): the reference line is cut out of the line of the whole CU, see below
@@ -2729,261 +2846,323 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int bdpcm = isp ? 0 : ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
       const int dirMode = it.mode;
       const bool hasResi = ( it.flags & IT_F_RESI ) != 0;
+      // residual of sample i of the item (row-major inside its band): from the scratch, or from the residual plane for a block that is not split
+      auto RES = [&]( int i ) -> int { return stashed ? (int) W.resi[i] : (int) (int16_t) rs[(size_t) ( y0 + yb + ( i >> lw ) ) * rstride + x0 + ( i & ( w - 1 ) )]; };
       // LMCS chroma residual scaling factor of the block's VPDU (the unit has waited for the luma it is averaged over)
       int csScale = 0;
       const bool csOn = comp && ( it.flags & IT_F_CSCALE );
       if( csOn ) csScale = sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )];
-      // ---- intra block copy (InterPrediction::xIntraBlockCopy :1995, DecCu.cpp:442-470): copy of reconstructed samples of this picture
-      // at the block vector (+ residual).  Samples of this CTU come from the tile, where the blocks of this unit have put theirs and
-      // the others were staged after the wait for their producers; samples of a CTU further left come from HBM.
-      if( dirMode == IT_MODE_IBC )
-      {
-        const int qx = x0 + (int16_t) ( it.tu & 0xffff ), qy = y0 + (int16_t) ( it.tu >> 16 );
-        if( tid == 255 ) sh.dcSum[( k + 1 ) & 1] = 0;
-#pragma unroll 1
-        for( int i = tid; i < w * h; i += 256 )
-        {
-          const int x = i & ( w - 1 ), y = i >> lw;
-          const int sx = qx + x, sy = qy + y;
-          int v = sx >= ox ? (int) TILE( sx, sy ) : (int) plane[(size_t) sy * pstride + sx];
-          if( hasResi ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
-          TILE( x0 + x, y0 + y ) = (pel_t) v;
-        }
-        if( k + 1 < nb )
-        {
-          const bool big = ( sh.items[k + 1].lw + sh.items[k + 1].lh ) > 8;
-          if( big ) lds_barrier();                                 // the single large buffer may still be read by slower wavefronts of this block
-          intra_stash_resi1( sh.items[k + 1], big ? sh.resiB : sh.resiS[( k + 1 ) & 1], tid, rpre, rs, rstride );
-        }
-        lds_barrier();
-        continue;
-      }
       // reference line lengths; ISP: CU size + partition size along the split, twice the CU size across (IntraPrediction.cpp:1000-1001).
       // f*: the block whose line is fetched from the picture (ISP: the whole CU, initIntraPatternChTypeISP :966-999)
       const int topLen = isp ? ( ispVer ? cuW + w : 2 * cuW ) : 2 * w, leftLen = isp ? ( ispVer ? 2 * cuH : cuH + h ) : 2 * h;
       const int fx0 = x0 - ispDx, fy0 = y0 - ispDy, fTopLen = isp ? 2 * cuW : topLen, fLeftLen = isp ? 2 * cuH : leftLen;
       const int unit = 4 >> cs;
       const int totalAbove = ( fTopLen + unit - 1 ) / unit, totalLeft = ( fLeftLen + unit - 1 ) / unit;
-      const int nTL = it.nTL, nA = it.nA, nL = it.nL;
+      const int nTL = it.nTL & 1, nA = it.nA, nL = it.nL;
       const int nAll = nTL + nA + nL, total = totalAbove + totalLeft + 1;
       const bool isDc = !bdpcm && dirMode == 1;
-      int* dcAcc = &sh.dcSum[k & 1];
-      // ---- xFillReferenceSamples: one lane per reference position (+ the DC sum while the values are in registers)
+      // ---- reference smoothing decision, mode-specific set-up (uniform scalar work, none of it depends on a sample)
+      bool useFilt = false;
+      if( !comp && !mrl && !bdpcm && dirMode != 1 && !isp && dirMode <= 66 && !mip )
+      {
+        if( dirMode == 0 ) useFilt = w * h > 32;
+        else
+        {
+          const int pm = intra_wide_angle( w, h, dirMode );
+          const int diff = min( iabs( pm - 18 ), iabs( pm - 50 ) );
+          const int l2 = ( lw + lh ) >> 1;
+          const int am = pm >= 34 ? pm - 50 : -( pm - 18 );
+          useFilt = diff > sh.filtThr[l2] && ( ( sh.angTab[iabs( am )] & 0x1F ) == 0 );
+        }
+      }
+      const bool pdpcOK = ( w >= 4 && h >= 4 ) && mrl == 0;
+      int predMode = 0, angle = 0, invAngle = 0, absAng = 0; bool isVer = true;
+      const bool angular = !bdpcm && dirMode > 1 && dirMode <= 66 && !mip;
+      if( angular )
+      {
+        predMode = isp ? intra_wide_angle( cuW, cuH, dirMode ) : intra_wide_angle( w, h, dirMode );     // ISP: the CU's shape (:502,604)
+        isVer = predMode >= 34;
+        const int am = isVer ? predMode - 50 : -( predMode - 18 );
+        invAngle = sh.invAngTab[iabs( am )]; absAng = sh.angTab[iabs( am )]; angle = am < 0 ? -absAng : absAng;
+      }
+      const int bw = isVer ? w : h, bh = isVer ? h : w;       // angular modes predict in the transposed domain for horizontal modes
+      bool cubic = false, doAngPdpc = false; int angScale = 0;
+      if( angular )
+      {
+        if( !comp )
+        {
+          const int diff = min( iabs( predMode - 18 ), iabs( predMode - 50 ) );
+          const int l2 = ( ilog2( bw ) + ilog2( bh ) ) >> 1;
+          cubic = isp || !( diff > sh.filtThr[l2] ) || mrl > 0;
+        }
+        if( angle > 0 )
+        {
+          const int sideSize = predMode >= 34 ? h : w;
+          angScale = min( 2, ilog2( sideSize ) - ( ilog2( 3 * invAngle - 2 ) - 8 ) );
+          doAngPdpc = pdpcOK && angScale >= 0;
+        }
+      }
+      const int pscale = ( lw - 2 + lh - 2 + 2 ) >> 2;
+      // geometry of the group loop: a lane predicts g = min( 4, extent ) neighbouring samples of a row of the prediction block; (xx, yy) are the
+      // coordinates there: xx = x, yy = y, for horizontal angular modes transposed (xx = y, yy = x)
+      const bool tr = angular && !isVer;
+      const int nxl = tr ? ilog2( rows ) : lw;                                  // log2 extent of the item in xx
+      const int gl = min( 2, nxl ), g = 1 << gl, lgpr = nxl - gl;                // log2 / group size, log2 groups per row
+      const int ngroups = ( tr ? w : rows ) << lgpr;
+      const int xxb = tr ? yb : 0, yyb = tr ? 0 : yb;
+      const bool vec = !tr && g == 4 && !( x0 & 3 );                            // 8-byte LDS accesses to the tile row and the residual
+      const int tileBase = IT_PAD * IT_TS + ( y0 - oy ) * IT_TSB + ( x0 - ox ) + IT_PADX;       // block origin in the tile (rows inside the CTU)
+      // ---- the block's turn: every block of the unit it may read from is finished
+      {
+        const int m = (int) ( q - iA ) - IT_INDEP( it );         // blocks 0 .. m - 1 of the unit
+        if( m > 0 )
+        {
+          const int need = lane < IT_WAVES ? max( 0, ( m - lane + IT_WAVES - 1 ) / IT_WAVES ) : 0;
+          for( ;; )
+          {
+            const int p = lane < IT_WAVES ? prog[lane] : 0;
+            if( !__builtin_amdgcn_ballot_w64( p < need ) ) break;
+            __builtin_amdgcn_s_sleep( 1 );
+          }
+        }
+        asm volatile( "" ::: "memory" );
+      }
+#define IT_DONE() { wave_lds_sync(); done++; if( lane == 0 ) prog[wv] = done; }
+      // ---- intra block copy (InterPrediction::xIntraBlockCopy :1995, DecCu.cpp:442-470): copy of reconstructed samples of this picture
+      // at the block vector (+ residual).  Samples of this CTU come from the tile, where the blocks of this unit have put theirs and
+      // the others were staged after the wait for their producers; samples of a CTU further left come from HBM.
+      if( dirMode == IT_MODE_IBC )
+      {
+        const int qx = x0 + (int16_t) ( it.tu & 0xffff ), qy = y0 + (int16_t) ( it.tu >> 16 );
+#pragma unroll 2
+        for( int i = lane; i < wh; i += 64 )
+        {
+          const int x = i & ( w - 1 ), y = yb + ( i >> lw );
+          const int sx = qx + x, sy = qy + y;
+          int v = sx >= ox ? (int) TILE( sx, sy ) : (int) plane[(size_t) sy * pstride + sx];
+          if( hasResi ) { const int r = RES( i ); v = clip_pel( v + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); }
+          sh.tile[tileBase + y * IT_TSB + x] = (pel_t) v;
+        }
+        IT_DONE()
+        continue;
+      }
+      // ---- xFillReferenceSamples: one lane per reference position, all positions read at once (+ the DC sum while the values are in registers)
+      int dcPart = 0;
       {
         const int dcv = 1 << ( bd - 1 );
-        const int n = max( max( topLen, leftLen ), max( fTopLen, fLeftLen ) ) + mrl + 1;
-        int tv = dcv, lv = dcv;
-        if( tid < ( ( n + 63 ) & ~63 ) )
+        const int n = max( max( topLen, leftLen ), max( fTopLen, fLeftLen ) ) + mrl + 1;       // <= 131: three rounds of 64 lanes
+        pel_t* const dT = isp ? W.auxT : T;        // ISP: the CU's line, kept aside; the partition's own line is cut out of it below
+        pel_t* const dL = isp ? W.auxL : L;
+        const int wT = isp ? fTopLen : topLen + mrl, wL = isp ? fLeftLen : leftLen + mrl;
+        int tvv[3], lvv[3];
+        if( nAll == total )
         {
-          const int j = tid;
-          if( j < n )
+          const int cidx = tile_idx( fx0 - ( 1 + mrl ) - ox, fy0 - ( 1 + mrl ) - oy );       // the corner: row above (any kind of tile row), column left
+          const int lidx = tile_idx( fx0 - ( 1 + mrl ) - ox, fy0 - mrl - oy );                // first sample of the left column below the corner row
+          const int lstep = fy0 - mrl < oy ? 0 : IT_TSB;                                      // (rows above the CTU only occur with mrl = 0 or in the corner row)
+#pragma unroll
+          for( int u = 0; u < 3; u++ )
           {
-            if( nAll == 0 ) {}
-            else if( nAll == total )
+            const int j = lane + 64 * u;
+            tvv[u] = lvv[u] = dcv;
+            if( j < n )
             {
-              if( j <= fTopLen + mrl ) tv = TILE( fx0 - ( 1 + mrl ) + j, fy0 - ( 1 + mrl ) );
-              if( j <= fLeftLen + mrl ) lv = j == 0 ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) ) : TILE( fx0 - ( 1 + mrl ), fy0 - mrl + ( j - 1 ) );
+              if( j <= fTopLen + mrl ) tvv[u] = sh.tile[cidx + j];
+              if( j <= fLeftLen + mrl ) lvv[u] = j == 0 ? sh.tile[cidx] : ( lstep ? sh.tile[lidx + ( j - 1 ) * IT_TSB] : TILE( fx0 - ( 1 + mrl ), fy0 - mrl + ( j - 1 ) ) );
             }
-            else if( nL > 0 )
+          }
+        }
+        else
+        {
+#pragma unroll
+          for( int u = 0; u < 3; u++ )
+          {
+            const int j = lane + 64 * u;
+            int tv = dcv, lv = dcv;
+            if( j < n && nAll )
             {
-              const int szL = min( nL * unit, fLeftLen ), szA = min( nA * unit, fTopLen );
-              const int tpad = TILE( fx0 - ( 1 + mrl ), fy0 );
-              // left line
-              if( j == 0 ) lv = nTL ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) ) : tpad;
-              else if( j <= mrl ) lv = nTL ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) + j ) : tpad;
-              else if( j <= fLeftLen + mrl ) { const int i = j - 1 - mrl; lv = TILE( fx0 - ( 1 + mrl ), fy0 + min( i, szL - 1 ) ); }
-              // top line
-              if( j <= mrl ) tv = nTL ? TILE( fx0 - ( 1 + mrl ) + j, fy0 - ( 1 + mrl ) ) : tpad;
-              else if( j <= fTopLen + mrl )
+              if( nL > 0 )
               {
-                const int i = j - 1 - mrl;
-                if( nA ) tv = TILE( fx0 + min( i, szA - 1 ), fy0 - ( 1 + mrl ) );
-                else     tv = nTL ? TILE( fx0 - 1, fy0 - ( 1 + mrl ) ) : tpad;      // = top[mrl]
+                const int szL = min( nL * unit, fLeftLen ), szA = min( nA * unit, fTopLen );
+                const int tpad = TILE( fx0 - ( 1 + mrl ), fy0 );
+                // left line
+                if( j == 0 ) lv = nTL ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) ) : tpad;
+                else if( j <= mrl ) lv = nTL ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) + j ) : tpad;
+                else if( j <= fLeftLen + mrl ) { const int i = j - 1 - mrl; lv = TILE( fx0 - ( 1 + mrl ), fy0 + min( i, szL - 1 ) ); }
+                // top line
+                if( j <= mrl ) tv = nTL ? TILE( fx0 - ( 1 + mrl ) + j, fy0 - ( 1 + mrl ) ) : tpad;
+                else if( j <= fTopLen + mrl )
+                {
+                  const int i = j - 1 - mrl;
+                  if( nA ) tv = TILE( fx0 + min( i, szA - 1 ), fy0 - ( 1 + mrl ) );
+                  else     tv = nTL ? TILE( fx0 - 1, fy0 - ( 1 + mrl ) ) : tpad;      // = top[mrl]
+                }
+              }
+              else
+              {
+                const int szA = min( nA * unit, fTopLen );
+                const int t = TILE( fx0, fy0 - ( 1 + mrl ) );
+                lv = t;
+                if( j <= mrl ) tv = t;
+                else if( j <= fTopLen + mrl ) tv = TILE( fx0 + min( j - 1 - mrl, szA - 1 ), fy0 - ( 1 + mrl ) );
               }
             }
-            else
+            tvv[u] = tv; lvv[u] = lv;
+          }
+        }
+#pragma unroll
+        for( int u = 0; u < 3; u++ )
+        {
+          const int j = lane + 64 * u;
+          if( j < n )
+          {
+            if( j <= wT ) dT[j] = (pel_t) tvv[u];
+            if( j <= wL ) dL[j] = (pel_t) lvv[u];
+            if( isDc && !isp && j > mrl )
             {
-              const int szA = min( nA * unit, fTopLen );
-              const int t = TILE( fx0, fy0 - ( 1 + mrl ) );
-              lv = t;
-              if( j <= mrl ) tv = t;
-              else if( j <= fTopLen + mrl ) tv = TILE( fx0 + min( j - 1 - mrl, szA - 1 ), fy0 - ( 1 + mrl ) );
-            }
-            if( isp )
-            {
-              // the CU's line, kept aside; the partition's own line is cut out of it after the barrier
-              if( j <= fTopLen ) sh.ftop[j] = (pel_t) tv;
-              if( j <= fLeftLen ) sh.fleft[j] = (pel_t) lv;
+              if( w >= h && j <= mrl + w ) dcPart += tvv[u];
+              if( w <= h && j <= mrl + h ) dcPart += lvv[u];
             }
           }
         }
         if( isp )
         {
-          lds_barrier();
-          if( tid < ( ( n + 63 ) & ~63 ) && tid < n )
+          wave_lds_sync();
+#pragma unroll
+          for( int u = 0; u < 3; u++ )
           {
-            const int j = tid;
+            const int j = lane + 64 * u;
+            if( j >= n ) continue;
+            int tv, lv;
             // later partitions: the row above / column left comes from the reconstruction of the previous partition (padded with its
             // last sample), the other line continues the CU's line (:1003-1069)
-            if( !ispDx && !ispDy ) { tv = sh.ftop[min( j, fTopLen )]; lv = sh.fleft[min( j, fLeftLen )]; }
+            if( !ispDx && !ispDy ) { tv = W.auxT[min( j, fTopLen )]; lv = W.auxL[min( j, fLeftLen )]; }
             else if( !ispVer )
             {
-              lv = nL ? sh.fleft[min( ispDy + j, fLeftLen )] : TILE( x0, y0 - 1 );
+              lv = nL ? W.auxL[min( ispDy + j, fLeftLen )] : TILE( x0, y0 - 1 );
               tv = j == 0 ? lv : TILE( x0 + min( j - 1, w - 1 ), y0 - 1 );
             }
             else
             {
-              tv = nA ? sh.ftop[min( ispDx + j, fTopLen )] : TILE( x0 - 1, y0 );
+              tv = nA ? W.auxT[min( ispDx + j, fTopLen )] : TILE( x0 - 1, y0 );
               lv = j == 0 ? tv : TILE( x0 - 1, y0 + min( j - 1, h - 1 ) );
             }
-          }
-        }
-        if( tid < ( ( n + 63 ) & ~63 ) )
-        {
-          const int j = tid;
-          if( j < n )
-          {
-            if( j <= topLen + mrl ) sh.top[j] = (pel_t) tv;
-            if( j <= leftLen + mrl ) sh.left[j] = (pel_t) lv;
-          }
-          if( isDc )
-          {
-            int part = 0;
-            if( j < n && j > mrl )
+            if( j <= topLen + mrl ) T[j] = (pel_t) tv;
+            if( j <= leftLen + mrl ) L[j] = (pel_t) lv;
+            if( isDc && j > mrl )
             {
-              if( w >= h && j <= mrl + w ) part += tv;
-              if( w <= h && j <= mrl + h ) part += lv;
+              if( w >= h && j <= mrl + w ) dcPart += tv;
+              if( w <= h && j <= mrl + h ) dcPart += lv;
             }
-            for( int o = 32; o; o >>= 1 ) part += __shfl_down( part, o );
-            if( ( tid & 63 ) == 0 && part ) atomicAdd( dcAcc, part );
           }
         }
-        if( tid == 255 ) sh.dcSum[( k + 1 ) & 1] = 0;
       }
-      lds_barrier();
-      IT_PH( trA )
+      int dcVal = 0;
+      if( isDc )
+      {
+        const int denom = w == h ? w << 1 : max( w, h );
+        dcVal = ( wave_sum( dcPart ) + ( denom >> 1 ) ) >> ilog2( denom );
+      }
+      wave_lds_sync();
       // ---- MIP (PredictorMIP, MatrixIntraPrediction.cpp:68-330): boundary down-sampling, matrix-vector product, up-sampling
-      if( !comp && ( it.flags & IT_F_MIP ) )
+      if( mip )
       {
         const bool transp = ( it.flags & 0x10 ) != 0;
         const int sizeId = ( w == 4 && h == 4 ) ? 0 : ( w == 4 || h == 4 || ( w == 8 && h == 8 ) ) ? 1 : 2;
         const int bdry = sizeId == 0 ? 2 : 4, red = sizeId < 2 ? 4 : 8, l2red = sizeId < 2 ? 2 : 3;
         const int upH = w / red, upV = h / red, l2H = ilog2( upH ), l2V = ilog2( upV );
-        if( tid < 2 * bdry )
+        if( lane < 2 * bdry )
         {
-          const bool isL = tid >= bdry; const int q = isL ? tid - bdry : tid;
-          const pel_t* src = isL ? sh.left : sh.top; const int len = isL ? h : w;
+          const bool isL = lane >= bdry; const int qq = isL ? lane - bdry : lane;
+          const pel_t* src = isL ? L : T; const int len = isL ? h : w;
           const int f = len / bdry;
           int sum = 0;
-          for( int t2 = 0; t2 < f; t2++ ) sum += src[1 + q * f + t2];
-          sh.lmSel[tid] = f > 1 ? ( sum + ( f >> 1 ) ) >> ilog2( f ) : sum;
+          for( int t2 = 0; t2 < f; t2++ ) sum += src[1 + qq * f + t2];
+          W.lmSel[lane] = f > 1 ? ( sum + ( f >> 1 ) ) >> ilog2( f ) : sum;
         }
-        lds_barrier();
+        wave_lds_sync();
         {
           const int inSize = 2 * bdry;
           int in[8];
-          for( int q = 0; q < 8; q++ ) in[q] = q < inSize ? ( transp ? ( q < bdry ? sh.lmSel[bdry + q] : sh.lmSel[q - bdry] ) : sh.lmSel[q] ) : 0;
+          for( int qq = 0; qq < 8; qq++ ) in[qq] = qq < inSize ? ( transp ? ( qq < bdry ? W.lmSel[bdry + qq] : W.lmSel[qq - bdry] ) : W.lmSel[qq] ) : 0;
           const int inOff = in[0];
           in[0] = sizeId < 2 ? ( 1 << ( bd - 1 ) ) - inOff : 0;
           int sum = in[0];
-          for( int q = 1; q < 8; q++ ) if( q < inSize ) { in[q] = (int16_t) ( in[q] - inOff ); sum += in[q]; }
+          for( int qq = 1; qq < 8; qq++ ) if( qq < inSize ) { in[qq] = (int16_t) ( in[qq] - inOff ); sum += in[qq]; }
           const int offset = 32 - 32 * sum;
           const int redSize = sizeId == 2;
-          if( tid < red * red )
+          if( lane < red * red )
           {
-            const uint8_t* wt = ( sizeId == 0 ? &d_mip_matrix_4x4[dirMode][0][0] : sizeId == 1 ? &d_mip_matrix_8x8[dirMode][0][0] : &d_mip_matrix_16x16[dirMode][0][0] ) + tid * ( inSize - redSize );
+            const uint8_t* wt = ( sizeId == 0 ? &d_mip_matrix_4x4[dirMode][0][0] : sizeId == 1 ? &d_mip_matrix_8x8[dirMode][0][0] : &d_mip_matrix_16x16[dirMode][0][0] ) + lane * ( inSize - redSize );
             int acc = redSize ? 0 : in[0] * wt[0];
-            for( int q = 1; q < 8; q++ ) if( q < inSize ) acc += in[q] * wt[q - redSize];
+            for( int qq = 1; qq < 8; qq++ ) if( qq < inSize ) acc += in[qq] * wt[qq - redSize];
             const int v = clip_pel( ( ( acc + offset ) >> 6 ) + inOff, bd );
-            const int py = tid >> l2red, px = tid & ( red - 1 );
-            sh.ftop[transp ? px * red + py : tid] = (pel_t) v;
+            const int py = lane >> l2red, px = lane & ( red - 1 );
+            W.auxT[transp ? px * red + py : lane] = (pel_t) v;
           }
         }
-        lds_barrier();
+        wave_lds_sync();
         // horizontal up-sampling into every upV-th row of the block (predictionUpsampling1D :196)
-        for( int i = tid; i < red * w; i += 256 )
+#pragma unroll 2
+        for( int i = lane; i < red * w; i += 64 )
         {
-          const int kk = i / w, x = i - kk * w, row = ( upV - 1 ) + kk * upV;
+          const int kk = i >> lw, x = i & ( w - 1 ), row = ( upV - 1 ) + kk * upV;
           int v;
-          if( upH == 1 ) v = sh.ftop[kk * red + x];
+          if( upH == 1 ) v = W.auxT[kk * red + x];
           else
           {
             const int j = x >> l2H, ii = ( x & ( upH - 1 ) ) + 1;
-            const int before = j == 0 ? sh.left[1 + row] : sh.ftop[kk * red + j - 1], behind = sh.ftop[kk * red + j];
+            const int before = j == 0 ? L[1 + row] : W.auxT[kk * red + j - 1], behind = W.auxT[kk * red + j];
             v = (int16_t) ( before * upH + ( upH >> 1 ) + ii * (int16_t) ( behind - before ) ) >> l2H;
           }
-          TILE( x0 + x, y0 + row ) = (pel_t) v;
+          sh.tile[tileBase + row * IT_TSB + x] = (pel_t) v;
         }
-        lds_barrier();
+        wave_lds_sync();
         if( upV > 1 )
         {
-          int vals[IT_MAXR];
-#pragma unroll 1
-          for( int n = 0, i = tid; i < w * h; i += 256, n++ )
+          // the rows that hold the horizontally up-sampled lines keep their values; the others only read those rows, so writing in place is safe
+#pragma unroll 2
+          for( int i = lane; i < w * h; i += 64 )
           {
             const int x = i & ( w - 1 ), y = i >> lw;
             const int j = y >> l2V, ii = ( y & ( upV - 1 ) ) + 1;
-            const int before = j == 0 ? sh.top[1 + x] : TILE( x0 + x, y0 + ( upV - 1 ) + ( j - 1 ) * upV ), behind = TILE( x0 + x, y0 + ( upV - 1 ) + j * upV );
+            if( ii == upV ) continue;
+            const int before = j == 0 ? T[1 + x] : sh.tile[tileBase + ( ( upV - 1 ) + ( j - 1 ) * upV ) * IT_TSB + x], behind = sh.tile[tileBase + ( ( upV - 1 ) + j * upV ) * IT_TSB + x];
             const int v = (int16_t) ( before * upV + ( upV >> 1 ) + ii * (int16_t) ( behind - before ) ) >> l2V;
-            // the rows that hold the horizontally up-sampled lines keep their values (ii == upV gives `behind` again), so writing in place is safe
-            TILE( x0 + x, y0 + y ) = (pel_t) v;
+            sh.tile[tileBase + y * IT_TSB + x] = (pel_t) v;
           }
-          (void) vals;
-          lds_barrier();
+          wave_lds_sync();
         }
         if( hasResi )
-#pragma unroll 1
-          for( int i = tid; i < w * h; i += 256 )
+#pragma unroll 2
+          for( int i = lane; i < w * h; i += 64 )
           {
             const int x = i & ( w - 1 ), y = i >> lw;
-            TILE( x0 + x, y0 + y ) = (pel_t) clip_pel( TILE( x0 + x, y0 + y ) + rcur[i], bd );
+            sh.tile[tileBase + y * IT_TSB + x] = (pel_t) clip_pel( sh.tile[tileBase + y * IT_TSB + x] + RES( i ), bd );
           }
-        if( k + 1 < nb )
-      {
-        const bool big = ( sh.items[k + 1].lw + sh.items[k + 1].lh ) > 8;
-        if( big ) lds_barrier();                                 // the single large buffer may still be read by slower wavefronts of this block
-        intra_stash_resi1( sh.items[k + 1], big ? sh.resiB : sh.resiS[( k + 1 ) & 1], tid, rpre, rs, rstride );
-      }
-        lds_barrier();
+        IT_DONE()
         continue;
       }
-      // ---- CCLM / MDLM (xGetLumaRecPixels :1403, xGetLMParameters :1694, predIntraChromaLM :519; 4:2:0, non-collocated luma filter)
+      // ---- CCLM / MDLM (xGetLumaRecPixels :1403, xGetLMParameters :1694, predIntraChromaLM :519; 4:2:0): the down-sampled luma of the block
+      // and of the template positions is in registers already (intra_load_cclm_luma)
       if( comp && dirMode >= 67 )
       {
-        const pel_t* __restrict__ Yp = reco.p[0]; const int ys = reco.stride[0];
-        const int lx0 = x0 << 1, ly0 = y0 << 1;
-#define LU( xx, yy ) ( (int) Yp[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
         const uint32_t lm = it.tu;
         const int actualTop = lm & 0xff, actualLeft = ( lm >> 8 ) & 0xff;
-        const bool aboveAvail = ( lm >> 16 ) & 1, leftAvail = ( lm >> 17 ) & 1, bLeft = ( lm >> 18 ) & 1, firstRow = ( lm >> 19 ) & 1, bAbove = ( lm >> 20 ) & 1;
-        const bool colloc = ( pic.hdr.tool_flags & VVR_TOOL_CCLM_COLLOC ) != 0;      // sps_chroma_vertical_collocated_flag: 5-tap cross instead of the 6-tap filter
+        const bool aboveAvail = ( lm >> 16 ) & 1, leftAvail = ( lm >> 17 ) & 1;
         const int aboveIs4 = leftAvail ? 0 : 1, leftIs4 = aboveAvail ? 0 : 1;
         const int cntT = aboveAvail ? min( actualTop, ( 1 + aboveIs4 ) << 1 ) : 0, cntL = leftAvail ? min( actualLeft, ( 1 + leftIs4 ) << 1 ) : 0;
-        if( tid < cntT + cntL )
+        if( lane < cntT + cntL )
         {
-          int lv, cv;
-          if( tid < cntT )
-          {
-            const int i = ( actualTop >> ( 2 + aboveIs4 ) ) + tid * max( 1, actualTop >> ( 1 + aboveIs4 ) );
-            const int xl = ( i == 0 && !bLeft ) ? 2 * i : 2 * i - 1;
-            if( firstRow ) lv = ( LU( 2 * i, -1 ) * 2 + LU( xl, -1 ) + LU( 2 * i + 1, -1 ) + 2 ) >> 2;
-            else if( colloc ) lv = ( LU( 2 * i, -3 ) + LU( 2 * i, -2 ) * 4 + LU( xl, -2 ) + LU( 2 * i + 1, -2 ) + LU( 2 * i, -1 ) + 4 ) >> 3;
-            else           lv = ( LU( 2 * i, -2 ) * 2 + LU( xl, -2 ) + LU( 2 * i + 1, -2 ) + LU( 2 * i, -1 ) * 2 + LU( xl, -1 ) + LU( 2 * i + 1, -1 ) + 4 ) >> 3;
-            cv = sh.top[1 + i];
-          }
-          else
-          {
-            const int j = ( actualLeft >> ( 2 + leftIs4 ) ) + ( tid - cntT ) * max( 1, actualLeft >> ( 1 + leftIs4 ) );
-            if( colloc ) { const int yu = ( j == 0 && !bAbove ) ? 2 * j : 2 * j - 1; lv = ( LU( -2, yu ) + LU( -2, 2 * j ) * 4 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) + 4 ) >> 3; }
-            else lv = ( LU( -2, 2 * j ) * 2 + LU( -3, 2 * j ) + LU( -1, 2 * j ) + LU( -2, 2 * j + 1 ) * 2 + LU( -3, 2 * j + 1 ) + LU( -1, 2 * j + 1 ) + 4 ) >> 3;
-            cv = sh.left[1 + j];
-          }
-          sh.lmSel[tid] = (int16_t) lv; sh.lmSel[4 + tid] = cv;
+          int cv;
+          if( lane < cntT ) cv = T[1 + ( actualTop >> ( 2 + aboveIs4 ) ) + lane * max( 1, actualTop >> ( 1 + aboveIs4 ) )];
+          else              cv = L[1 + ( actualLeft >> ( 2 + leftIs4 ) ) + ( lane - cntT ) * max( 1, actualLeft >> ( 1 + leftIs4 ) )];
+          W.lmSel[lane] = (int16_t) LC.tpl; W.lmSel[4 + lane] = cv;
         }
-        lds_barrier();
+        wave_lds_sync();
         int selL[4] = { 0, 0, 0, 0 }, selC[4] = { 0, 0, 0, 0 };
         const int cnt = cntT + cntL;
-        for( int q = 0; q < 4; q++ ) if( q < cnt ) { selL[q] = sh.lmSel[q]; selC[q] = sh.lmSel[4 + q]; }
+        for( int qq = 0; qq < 4; qq++ ) if( qq < cnt ) { selL[qq] = W.lmSel[qq]; selC[qq] = W.lmSel[4 + qq]; }
         if( cnt == 2 )
         {
           selL[3] = selL[0]; selC[3] = selC[0]; selL[2] = selL[1]; selC[2] = selC[1];
@@ -3016,181 +3195,170 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
             b = minC - ( ( a * minL ) >> shift );
           }
         }
-        const int wh2 = w * h;
-#pragma unroll 1
-        for( int i = tid; i < wh2; i += 256 )
+#pragma unroll
+        for( int e = 0; e < 16; e++ )
         {
-          const int x = i & ( w - 1 ), y = i >> lw;
-          const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
-          const int yu = ( y == 0 && !bAbove ) ? 0 : 2 * y - 1;
-          const int t = colloc ? (int16_t) ( ( LU( 2 * x, yu ) + LU( 2 * x, 2 * y ) * 4 + LU( xl, 2 * y ) + LU( 2 * x + 1, 2 * y ) + LU( 2 * x, 2 * y + 1 ) + 4 ) >> 3 )
-                               : (int16_t) ( ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
-          int v = clip_pel( ( ( a * t ) >> shift ) + b, bd );
-          if( hasResi ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
-          TILE( x0 + x, y0 + y ) = (pel_t) v;
+          const int i = e * 64 + lane;
+          if( e * 64 < wh && i < wh )
+          {
+            const int x = i & ( w - 1 ), y = yb + ( i >> lw );
+            const int t = (int16_t) ( ( e & 1 ) ? LC.v[e >> 1] >> 16 : LC.v[e >> 1] & 0xffff );
+            int v = clip_pel( ( ( a * t ) >> shift ) + b, bd );
+            if( hasResi ) { const int r = W.resi[i]; v = clip_pel( v + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); }
+            sh.tile[tileBase + y * IT_TSB + x] = (pel_t) v;
+          }
         }
-#undef LU
-        if( k + 1 < nb )
-      {
-        const bool big = ( sh.items[k + 1].lw + sh.items[k + 1].lh ) > 8;
-        if( big ) lds_barrier();                                 // the single large buffer may still be read by slower wavefronts of this block
-        intra_stash_resi1( sh.items[k + 1], big ? sh.resiB : sh.resiS[( k + 1 ) & 1], tid, rpre, rs, rstride );
-      }
-        lds_barrier();
+        IT_DONE()
         continue;
       }
-      // ---- reference smoothing
-      bool useFilt = false;
-      if( !comp && !mrl && !bdpcm && dirMode != 1 && !isp )
-      {
-        if( dirMode == 0 ) useFilt = w * h > 32;
-        else
-        {
-          const int pm = intra_wide_angle( w, h, dirMode );
-          const int diff = min( iabs( pm - 18 ), iabs( pm - 50 ) );
-          const int l2 = ( lw + lh ) >> 1;
-          const int am = pm >= 34 ? pm - 50 : -( pm - 18 );
-          useFilt = diff > sh.filtThr[l2] && ( ( sh.angTab[iabs( am )] & 0x1F ) == 0 );
-        }
-      }
+      // ---- reference smoothing, in place: every lane reads its three neighbours of both lines before any lane writes
       if( useFilt )
       {
-        const int j = tid;
-        if( j <= max( topLen, leftLen ) )
+        int ft[3], fl[3];
+        const int mx = max( topLen, leftLen );
+#pragma unroll
+        for( int u = 0; u < 3; u++ )
         {
-          if( j == 0 ) { const int v = ( sh.left[1] + 2 * sh.top[0] + sh.top[1] + 2 ) >> 2; sh.ftop[0] = sh.fleft[0] = (pel_t) v; }
-          else
+          const int j = lane + 64 * u;
+          ft[u] = fl[u] = 0;
+          if( j == 0 ) ft[u] = fl[u] = ( L[1] + 2 * T[0] + T[1] + 2 ) >> 2;
+          else if( j <= mx )
           {
-            if( j < topLen ) sh.ftop[j] = (pel_t) ( ( sh.top[j + 1] + 2 * sh.top[j] + sh.top[j - 1] + 2 ) >> 2 ); else if( j == topLen ) sh.ftop[j] = sh.top[j];
-            if( j < leftLen ) sh.fleft[j] = (pel_t) ( ( sh.left[j + 1] + 2 * sh.left[j] + sh.left[j - 1] + 2 ) >> 2 ); else if( j == leftLen ) sh.fleft[j] = sh.left[j];
+            if( j < topLen ) ft[u] = ( T[j + 1] + 2 * T[j] + T[j - 1] + 2 ) >> 2;
+            if( j < leftLen ) fl[u] = ( L[j + 1] + 2 * L[j] + L[j - 1] + 2 ) >> 2;
           }
         }
-        lds_barrier();
+        wave_lds_sync();
+#pragma unroll
+        for( int u = 0; u < 3; u++ )
+        {
+          const int j = lane + 64 * u;
+          if( j < topLen ) T[j] = (pel_t) ft[u];          // (the last sample of a line stays as it is)
+          if( j < leftLen ) L[j] = (pel_t) fl[u];
+        }
+        wave_lds_sync();
       }
-      const pel_t* T = useFilt ? sh.ftop : sh.top;
-      const pel_t* L = useFilt ? sh.fleft : sh.left;
-      const bool pdpcOK = ( w >= 4 && h >= 4 ) && mrl == 0;
-      // ---- mode-specific set-up (uniform scalar work)
-      int predMode = 0, angle = 0, invAngle = 0, absAng = 0; bool isVer = true;
-      int dcVal = 0;
-      const bool angular = !bdpcm && dirMode > 1;
-      if( isDc )
-      {
-        const int denom = w == h ? w << 1 : max( w, h );
-        dcVal = ( *dcAcc + ( denom >> 1 ) ) >> ilog2( denom );
-      }
-      else if( angular )
-      {
-        predMode = isp ? intra_wide_angle( cuW, cuH, dirMode ) : intra_wide_angle( w, h, dirMode );     // ISP: the CU's shape (:502,604)
-        isVer = predMode >= 34;
-        const int am = isVer ? predMode - 50 : -( predMode - 18 );
-        invAngle = sh.invAngTab[iabs( am )]; absAng = sh.angTab[iabs( am )]; angle = am < 0 ? -absAng : absAng;
-      }
-      // the main / side reference of xPredIntraAng (:640-690) without staging a copy: index j is relative to the block
-      // (after the multi-reference-line offset); negative indices are the side reference projected with invAngle,
+      // the main / side reference of xPredIntraAng (:640-690): index j is relative to the block (after the multi-reference-line offset);
+      // negative indices are the side reference projected with invAngle - written in front of the main reference once per block -,
       // indices beyond the end replicate the last sample
-      const pel_t* Mn = isVer ? T : L;
-      const pel_t* Sd = isVer ? L : T;
-      const int sizeSide = isVer ? h : w;
+      pel_t* const Mn = isVer ? T : L;
+      const pel_t* const Sd = isVer ? L : T;
       const int refEnd = ( isVer ? topLen : leftLen ) + mrl;
-      auto MAIN = [&]( int j ) -> int
+      if( angle < 0 )
       {
-        const int jj = j + mrl;
-        if( angle < 0 ) { if( jj >= 0 ) return Mn[jj]; return Sd[min( ( -jj * invAngle + 256 ) >> 9, sizeSide )]; }
-        return Mn[min( jj, refEnd )];
-      };
-      const int bw = isVer ? w : h, bh = isVer ? h : w;       // angular modes predict in the transposed domain for horizontal modes
-      bool cubic = false, doAngPdpc = false; int angScale = 0;
-      if( angular )
-      {
-        if( !comp )
-        {
-          const int diff = min( iabs( predMode - 18 ), iabs( predMode - 50 ) );
-          const int l2 = ( ilog2( bw ) + ilog2( bh ) ) >> 1;
-          cubic = isp || !( diff > sh.filtThr[l2] ) || mrl > 0;
-        }
-        if( angle > 0 )
-        {
-          const int sideSize = predMode >= 34 ? h : w;
-          angScale = min( 2, ilog2( sideSize ) - ( ilog2( 3 * invAngle - 2 ) - 8 ) );
-          doAngPdpc = pdpcOK && angScale >= 0;
-        }
+        const int sizeSide = isVer ? h : w;
+        const int k = 1 + lane;                                 // (the lowest index read is ( angle * ( mrl + bh ) >> 5 ) + mrl >= -bh >= -64: one round)
+        int pv = 0;
+        if( k <= bh ) pv = Sd[min( ( k * invAngle + 256 ) >> 9, sizeSide )];
+        wave_lds_sync();
+        if( k <= bh ) Mn[-k] = (pel_t) pv;
+        wave_lds_sync();
       }
-      const int pscale = ( lw - 2 + lh - 2 + 2 ) >> 2;
-      const int wh = w * h;
-      IT_PH( trB )
-      // ---- prediction + reconstruction, one sample per lane-iteration
-#pragma unroll 1
-      for( int i = tid; i < ( ( dbg & 8 ) ? 0 : wh ); i += 256 )
+      // store of one group: CIIP blend, residual, clipping, the tile (8-byte accesses where the positions allow it)
+#define IT_STORE_GROUP() \
+      if( vec ) \
+      { \
+        const int to = tileBase + yy * IT_TSB + xx0, ri = ( ( yy - yb ) << lw ) + xx0; \
+        if( wIntra ) { const uint2 tv = *reinterpret_cast<const uint2*>( &sh.tile[to] ); const int ip[4] = { (int) ( tv.x & 0xffff ), (int) ( tv.x >> 16 ), (int) ( tv.y & 0xffff ), (int) ( tv.y >> 16 ) }; \
+                       for( int e = 0; e < 4; e++ ) v[e] = ( ( 4 - wIntra ) * ip[e] + wIntra * v[e] + 2 ) >> 2; }     /* predBlendIntraCiip (:935-944): the tile holds the inter prediction */ \
+        if( hasResi ) { const uint2 rv = *reinterpret_cast<const uint2*>( &W.resi[ri] ); const int r[4] = { (int16_t) ( rv.x & 0xffff ), (int16_t) ( rv.x >> 16 ), (int16_t) ( rv.y & 0xffff ), (int16_t) ( rv.y >> 16 ) }; \
+                        for( int e = 0; e < 4; e++ ) if( !ispGrp || ( ( ispResi >> ( ( xx0 + e ) >> ( 2 - ispGrp ) ) ) & 1 ) ) v[e] = clip_pel( v[e] + ( csOn ? lmcs_scale_resi( r[e], csScale, bd ) : r[e] ), bd ); } \
+        *reinterpret_cast<uint2*>( &sh.tile[to] ) = make_uint2( ( v[0] & 0xffff ) | ( (uint32_t) v[1] << 16 ), ( v[2] & 0xffff ) | ( (uint32_t) v[3] << 16 ) ); \
+      } \
+      else \
+      { \
+        for( int e = 0; e < 4; e++ ) if( e < g ) \
+        { \
+          const int x = tr ? yy : xx0 + e, y = tr ? xx0 + e : yy; \
+          const int to = tileBase + y * IT_TSB + x; \
+          int vv = v[e]; \
+          if( wIntra ) vv = ( ( 4 - wIntra ) * sh.tile[to] + wIntra * vv + 2 ) >> 2; \
+          if( hasResi && ( !ispGrp || ( ( ispResi >> ( x >> ( 2 - ispGrp ) ) ) & 1 ) ) ) { const int r = W.resi[( ( y - yb ) << lw ) + x]; vv = clip_pel( vv + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); } \
+          sh.tile[to] = (pel_t) vv; \
+        } \
+      }
+      if( !angular )
       {
-        const int x = i & ( w - 1 ), y = i >> lw;
-        int v;
-        if( bdpcm ) v = bdpcm == 1 ? L[y + 1] : T[x + 1];
-        else if( dirMode == 0 )
+        // ---- planar (:154), DC (:541), BDPCM (:850) and their position-dependent combination (IntraPredSampleFilterCore :212)
+        const int tR = T[w + 1], lB = L[h + 1];
+        const bool pdpc = !bdpcm && pdpcOK;
+#pragma unroll 2
+        for( int gi = lane; gi < ngroups; gi += 64 )
         {
-          const int hor = ( L[y + 1] << lw ) + ( x + 1 ) * ( T[w + 1] - L[y + 1] );
-          const int ver = ( T[x + 1] << lh ) + ( y + 1 ) * ( L[h + 1] - T[x + 1] );
-          v = (int16_t) ( ( ( hor << lh ) + ( ver << lw ) + ( 1 << ( lw + lh ) ) ) >> ( 1 + lw + lh ) );
-        }
-        else if( dirMode == 1 ) v = dcVal;
-        else
-        {
-          const int xx = isVer ? x : y, yy = isVer ? y : x;      // position in the (possibly transposed) prediction block
-          if( angle == 0 )
+          const int yy = yyb + ( gi >> lgpr ), xx0 = xxb + ( ( gi & ( ( 1 << lgpr ) - 1 ) ) << gl );
+          const int lft = L[yy + 1];
+          int tp[4], v[4];
+          for( int e = 0; e < 4; e++ ) tp[e] = e < g ? (int) T[xx0 + e + 1] : 0;
+          for( int e = 0; e < 4; e++ )
           {
-            v = Mn[xx + 1 + mrl];
-            if( pdpcOK )
+            const int x = xx0 + e;
+            if( bdpcm ) v[e] = bdpcm == 1 ? lft : tp[e];
+            else if( dirMode == 0 )
             {
-              const int lev = min( pscale == 0 ? 3 : pscale == 1 ? 6 : pscale == 2 ? 12 : 24, bw );
-              if( xx < lev ) { const int wL = 32 >> min( 31, ( xx << 1 ) >> pscale ); v = clip_pel( ( wL * ( Sd[yy + 1] - T[0] ) + ( v << 6 ) + 32 ) >> 6, bd ); }
+              const int hor = ( lft << lw ) + ( x + 1 ) * ( tR - lft );
+              const int ver = ( tp[e] << lh ) + ( yy + 1 ) * ( lB - tp[e] );
+              v[e] = (int16_t) ( ( ( hor << lh ) + ( ver << lw ) + ( 1 << ( lw + lh ) ) ) >> ( 1 + lw + lh ) );
+            }
+            else v[e] = dcVal;
+            if( pdpc )
+            {
+              const int wTp = 32 >> min( 31, ( yy << 1 ) >> pscale ), wLp = 32 >> min( 31, ( x << 1 ) >> pscale );
+              v[e] = (int16_t) ( v[e] + ( ( wLp * ( lft - v[e] ) + wTp * ( tp[e] - v[e] ) + 32 ) >> 6 ) );
             }
           }
-          else
+          IT_STORE_GROUP()
+        }
+      }
+      else
+      {
+        // ---- angular (xPredIntraAng :592): one 4-tap form for every kind - c = the cubic / Gauss filter of the row's fraction (luma), { 0, 64 - 2 f, 2 f, 0 }
+        // for the 2-tap chroma interpolation, { 0, 64, 0, 0 } for whole-sample angles - over 7 neighbouring reference samples
+        const bool frac = ( absAng & 0x1F ) != 0;
+        const int pdpcLev = angle == 0 ? ( pdpcOK ? min( pscale == 0 ? 3 : pscale == 1 ? 6 : pscale == 2 ? 12 : 24, bw ) : 0 ) : doAngPdpc ? min( 3 << angScale, bw ) : 0;
+        const int t0 = T[0];
+#pragma unroll 2
+        for( int gi = lane; gi < ngroups; gi += 64 )
+        {
+          const int yy = yyb + ( gi >> lgpr ), xx0 = xxb + ( ( gi & ( ( 1 << lgpr ) - 1 ) ) << gl );
+          const int deltaPos = angle * ( 1 + mrl + yy );
+          const int di = deltaPos >> 5, df = deltaPos & 31;
+          const int kb = di + xx0 + mrl;
+          int r[7];
+          for( int t = 0; t < 7; t++ ) r[t] = t < g + 3 ? (int) Mn[min( kb + t, refEnd )] : 0;
+          int c0 = 0, c1 = 64, c2 = 0, c3 = 0;
+          if( frac )
           {
-            const int deltaPos = angle * ( 1 + mrl ) + yy * angle;
-            const int di = deltaPos >> 5, df = deltaPos & 31;
-            if( absAng & 0x1F )
+            if( comp ) { c1 = 64 - 2 * df; c2 = 2 * df; }
+            else if( cubic ) { const uint2 cv = *reinterpret_cast<const uint2*>( sh.cfilt[df] ); c0 = (int16_t) ( cv.x & 0xffff ); c1 = (int16_t) ( cv.x >> 16 ); c2 = (int16_t) ( cv.y & 0xffff ); c3 = (int16_t) ( cv.y >> 16 ); }
+            else { c0 = 16 - ( df >> 1 ); c1 = 32 - ( df >> 1 ); c2 = 16 + ( df >> 1 ); c3 = df >> 1; }     // g_intraGaussFilter (:96)
+          }
+          int v[4];
+          for( int e = 0; e < 4; e++ ) v[e] = clip_pel( (int16_t) ( ( c0 * r[e] + c1 * r[e + 1] + c2 * r[e + 2] + c3 * r[e + 3] + 32 ) >> 6 ), bd );
+          if( xx0 < pdpcLev )
+          {
+            if( angle == 0 )
             {
-              if( !comp )
+              const int sd = Sd[yy + 1];
+              for( int e = 0; e < 4; e++ ) if( xx0 + e < pdpcLev ) { const int wLp = 32 >> min( 31, ( ( xx0 + e ) << 1 ) >> pscale ); v[e] = clip_pel( ( wLp * ( sd - t0 ) + ( v[e] << 6 ) + 32 ) >> 6, bd ); }
+            }
+            else
+              for( int e = 0; e < 4; e++ ) if( e < g && xx0 + e < pdpcLev )
               {
-                const int k2 = di + 1 + xx;
-                const int p0 = MAIN( k2 - 1 ), p1 = MAIN( k2 ), p2 = MAIN( k2 + 1 ), p3 = MAIN( k2 + 2 );
-                if( cubic ) { const int16_t* f = sh.cfilt[df]; v = (int16_t) ( ( f[0] * p0 + f[1] * p1 + f[2] * p2 + f[3] * p3 + 32 ) >> 6 ); v = clip_pel( v, bd ); }
-                else { const int g0 = 16 - ( df >> 1 ), g1 = 32 - ( df >> 1 ), g2 = 16 + ( df >> 1 ), g3 = df >> 1;     // g_intraGaussFilter (:96)
-                       v = (int16_t) ( ( g0 * p0 + g1 * p1 + g2 * p2 + g3 * p3 + 32 ) >> 6 ); }
+                const int xx = xx0 + e;
+                const int invAngleSum = 256 + ( xx + 1 ) * invAngle;
+                const int wLp = 32 >> ( 2 * xx >> angScale );
+                v[e] = (int16_t) ( v[e] + ( ( wLp * ( Sd[yy + ( invAngleSum >> 9 ) + 1] - v[e] ) + 32 ) >> 6 ) );
               }
-              else v = (int16_t) ( ( ( 32 - df ) * MAIN( xx + di + 1 ) + df * MAIN( xx + di + 2 ) + 16 ) >> 5 );
-            }
-            else v = MAIN( di + 1 + xx );
-            if( doAngPdpc && xx < min( 3 << angScale, bw ) )
-            {
-              const int invAngleSum = 256 + ( xx + 1 ) * invAngle;
-              const int wL = 32 >> ( 2 * xx >> angScale );
-              v = (int16_t) ( v + ( ( wL * ( Sd[yy + ( invAngleSum >> 9 ) + 1] - v ) + 32 ) >> 6 ) );
-            }
           }
+          IT_STORE_GROUP()
         }
-        if( !bdpcm && pdpcOK && dirMode <= 1 )
-        {
-          const int wT = 32 >> min( 31, ( y << 1 ) >> pscale ), wL = 32 >> min( 31, ( x << 1 ) >> pscale );
-          v = (int16_t) ( v + ( ( wL * ( L[y + 1] - v ) + wT * ( T[x + 1] - v ) + 32 ) >> 6 ) );
-        }
-        if( wIntra ) v = ( ( 4 - wIntra ) * TILE( x0 + x, y0 + y ) + wIntra * v + 2 ) >> 2;     // predBlendIntraCiip (:935-944): the tile holds the inter prediction
-        if( hasResi && ( !ispGrp || ( ( ispResi >> ( x >> ( 2 - ispGrp ) ) ) & 1 ) ) ) v = clip_pel( v + ( csOn ? lmcs_scale_resi( rcur[i], csScale, bd ) : (int) rcur[i] ), bd );
-        TILE( x0 + x, y0 + y ) = (pel_t) v;
       }
-      IT_PH( trC )
-      if( k + 1 < nb )
-      {
-        const bool big = ( sh.items[k + 1].lw + sh.items[k + 1].lh ) > 8;
-        if( big ) lds_barrier();                                 // the single large buffer may still be read by slower wavefronts of this block
-        intra_stash_resi1( sh.items[k + 1], big ? sh.resiB : sh.resiS[( k + 1 ) & 1], tid, rpre, rs, rstride );
-      }
-      lds_barrier();
-      IT_PH( trD )
+#undef IT_STORE_GROUP
+      IT_DONE()
     }
+#undef IT_DONE
   }
-  if( trace && threadIdx.x == 0 ) { trace[(size_t) 8 * tr_ticket + 5] = trA | ( trB << 32 ); trace[(size_t) 8 * tr_ticket + 7] |= ( trC << 16 ) | ( trD << 40 ); }
+  __syncthreads();                    // every block of the unit is in the tile
   IT_TRACE( 3 );
   // ---- write the reconstructed intra samples back to HBM (deferred so that the block loop never waits for a store)
   if( borderOnly )
@@ -3204,42 +3372,34 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   }
   else
   {
-    for( uint32_t b0 = i0; b0 < ( ( dbg & 4 ) ? i0 : i1 ); b0 += IT_BATCH )
+    // one block per wavefront
+    for( uint32_t q = i0 + wv; q < ( ( dbg & 4 ) ? i0 : i1 ); q += IT_WAVES )
     {
-      const int nb = (int) min( (uint32_t) IT_BATCH, i1 - b0 );
-      if( i1 - i0 > IT_BATCH || un->iA != i0 )       // otherwise the only batch is still in LDS
+      IntraItem it;
+      IT_FETCH( it, q )
+      const int lw = it.lw, rows = intra_part_rows( it ), wh = rows << lw, yb = IT_PART( it ) * rows;
+      if( lw >= 2 && !( it.x & 3 ) )
       {
-        lds_barrier();
-        if( tid < nb * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = reinterpret_cast<const uint32_t*>( items + b0 )[tid];
-        lds_barrier();
-      }
-      for( int k = 0; k < nb; k++ )
-      {
-        const IntraItem it = sh.items[k];
-        const int lw = it.lw, wh = 1 << ( it.lw + it.lh );
-        if( lw >= 2 && !( it.x & 3 ) )
+        // four samples (8 bytes) per lane: block positions and widths are multiples of 4 samples
+        for( int i = lane; i < ( wh >> 2 ); i += 64 )
         {
-          // four samples (8 bytes) per lane: block positions and widths are multiples of 4 samples
-          for( int i = tid; i < ( wh >> 2 ); i += 256 )
-          {
-            const int x = it.x + ( ( i << 2 ) & ( ( 1 << lw ) - 1 ) ), y = it.y + ( ( i << 2 ) >> lw );
-            *reinterpret_cast<uint2*>( &plane[(size_t) y * pstride + x] ) = *reinterpret_cast<const uint2*>( &TILE( x, y ) );
-          }
+          const int x = it.x + ( ( i << 2 ) & ( ( 1 << lw ) - 1 ) ), y = it.y + yb + ( ( i << 2 ) >> lw );
+          *reinterpret_cast<uint2*>( &plane[(size_t) y * pstride + x] ) = *reinterpret_cast<const uint2*>( &TILE( x, y ) );
         }
-        else
-          for( int i = tid; i < wh; i += 256 )
-          {
-            const int x = it.x + ( i & ( ( 1 << lw ) - 1 ) ), y = it.y + ( i >> lw );
-            plane[(size_t) y * pstride + x] = TILE( x, y );
-          }
       }
+      else
+        for( int i = lane; i < wh; i += 64 )
+        {
+          const int x = it.x + ( i & ( ( 1 << lw ) - 1 ) ), y = it.y + yb + ( i >> lw );
+          plane[(size_t) y * pstride + x] = TILE( x, y );
+        }
     }
   }
 #undef TILE
 #undef IT_FETCH
   // ---- publish: all stores of the workgroup drained, one agent-scope release, then the flag
   IT_TRACE( 4 );
-  if( trace && threadIdx.x == 0 ) { trace[(size_t) 8 * tr_ticket + 6] = ( (unsigned long long) ( i1 - i0 ) << 32 ) | ent; trace[(size_t) 8 * tr_ticket + 7] |= un->ndeps; }
+  if( trace && threadIdx.x == 0 ) { trace[(size_t) 8 * tr_ticket + 6] = ( (unsigned long long) ( i1 - i0 ) << 32 ) | ent; trace[(size_t) 8 * tr_ticket + 7] = un->ndeps; }
   if( !publish ) continue;
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
   __syncthreads();
@@ -3251,7 +3411,6 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   }
   }     // next ticket
 #undef IT_TRACE
-#undef IT_PH
 }
 
 void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numActive, int numWorkgroups, int* sync )

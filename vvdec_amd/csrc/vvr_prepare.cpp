@@ -39,6 +39,7 @@ struct PrepScratch
   uint32_t numDmvr = 0;
   std::vector<TbItem> tb[3];
   std::vector<IntraItem> intra[3], intraTmp[3], intraAll;
+  std::vector<uint32_t> itemMap[3];                       // block of a component -> its first item in intraAll (large blocks become several items)
   std::vector<ItemH> itemH[3], itemHTmp;
   std::vector<uint32_t> prodPool[3];
   std::vector<uint32_t> ctuStartV;
@@ -1010,12 +1011,29 @@ int PrepScratch::groupUnits()
 
 int PrepScratch::emitUnitTable( std::string& err )
 {
-  // one item array for the three components; active (component, CTU) pairs in raster order
-  uint32_t itemBase[3] = { 0, 0, 0 };
+  // one item array for the three components; active (component, CTU) pairs in raster order.  A block of more than IT_PART_SAMPLES samples
+  // (luma 64x64, 64x32, 32x64; ordinary prediction modes and CIIP) becomes 2 or 4 items, one band of rows each: the kernel predicts a block
+  // with one wavefront, the bands of a large block with several at once (they read the same reference samples and write disjoint rows, so
+  // band p is independent of the p items before it)
+  itemMap[0].clear(); itemMap[1].clear(); itemMap[2].clear();
   for( int k = 0; k < 3; k++ )
   {
-    itemBase[k] = (uint32_t) intraAll.size();
-    intraAll.insert( intraAll.end(), intra[k].begin(), intra[k].end() );
+    itemMap[k].reserve( intra[k].size() + 1 );
+    for( const IntraItem& src : intra[k] )
+    {
+      itemMap[k].push_back( (uint32_t) intraAll.size() );
+      const int samples = 1 << ( src.lw + src.lh );
+      const bool split = !k && samples > IT_PART_SAMPLES && src.mode <= 66 && !( src.flags & IT_F_MIP ) && ( src.flags & IT_F_ISP ) != IT_F_ISP;
+      const int lp = split ? ( samples > 2 * IT_PART_SAMPLES ? 2 : 1 ) : 0;
+      for( int part = 0; part < ( 1 << lp ); part++ )
+      {
+        IntraItem it = src;
+        it.nTL = (uint8_t) ( ( src.nTL & 1 ) | ( part << 4 ) | ( lp << 6 ) );
+        it.comp = (uint8_t) ( k | ( part << 2 ) );
+        intraAll.push_back( it );
+      }
+    }
+    itemMap[k].push_back( (uint32_t) intraAll.size() );
   }
   // device unit table: units that wait for nothing first (they can never block a resident workgroup slot), then the others by depth of the
   // dependency graph and along the CTU wavefront; a unit only ever waits for units that hold a lower ticket
@@ -1075,7 +1093,7 @@ int PrepScratch::emitUnitTable( std::string& err )
         for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
       }
       d.ent = ( u.comp << 24 ) | u.ctu | ( u.hasCs ? 0x20000000u : 0 ) | ( u.waited ? 0x40000000u : 0 ) | ( all ? 0x80000000u : 0 );
-      d.i0 = itemBase[u.comp] + u.i0; d.i1 = itemBase[u.comp] + u.i1; d.iA = itemBase[u.comp] + u.iA;
+      d.i0 = itemMap[u.comp][u.i0]; d.i1 = itemMap[u.comp][u.i1]; d.iA = itemMap[u.comp][u.iA];
       d.bbox = (uint32_t) u.bb.y0 | ( (uint32_t) u.bb.y1 << 8 ) | ( (uint32_t) u.bb.c0 << 16 ) | ( (uint32_t) u.bb.c1 << 24 );
       d.ndeps = (uint32_t) std::min<size_t>( u.deps.size(), VVR_INTRA_MAX_DEPS );
       if( u.deps.size() > VVR_INTRA_MAX_DEPS ) FAIL( VVR_ERR_UNSPECIFIED, "internal: intra unit with too many dependencies" );
