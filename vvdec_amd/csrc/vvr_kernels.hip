@@ -1118,7 +1118,17 @@ __device__ __forceinline__ int wide_angle_mode( int w, int h, int mode )   // PU
 // (Buffer.cpp:412) applies it.  The neighbourhood descriptor comes from the host glue (pic.csVpdu); `acc` is an LDS word.
 // Must be called by all threads of the workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lmcs_cscale_factor_wave( const PicDev& pic, const DevPlanes& reco, int lumaX, int lumaY, int lane )
+// what k_intra reads of a picture: a kernel that keeps a long list of uniform values per block cannot afford the whole PicDev in scalar
+// registers (it spilled them into vector lanes on its serial path)
+struct IntraPic {
+  pel_t*       plane[3];
+  const pel_t* resi[3];
+  int          stride[3], rstride[3], w[3], h[3];
+  const uint32_t* csVpdu;            // as PicDev
+  const vvr_lmcs_params* lmcs;
+  int vpdusX, vpduLog2, ctusX, log2Ctu, bitDepth, width, height, colloc;
+};
+__device__ __forceinline__ int lmcs_cscale_factor_wave( const IntraPic& pic, int lumaX, int lumaY, int lane )
 {
   // called by one whole wavefront; every lane returns the factor.  All table reads are issued up front, one entry per lane, so the
   // function costs two memory round trips (VPDU record, then luma samples + tables) instead of one per pivot of the search
@@ -1129,13 +1139,13 @@ __device__ __forceinline__ int lmcs_cscale_factor_wave( const PicDev& pic, const
   const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff;
   const bool hasLeft = ( d >> 26 ) & 1, hasAbove = ( d >> 27 ) & 1;
   const int n = 1 << pic.vpduLog2, nLog = pic.vpduLog2;
-  const pel_t* __restrict__ Y = reco.p[0]; const int st = reco.stride[0];
+  const pel_t* __restrict__ Y = pic.plane[0]; const int st = pic.stride[0];
   int part = 0;
   for( int t = lane; t < 2 * n; t += 64 )
   {
     const int side = t >= n, i = t - side * n;
-    if( !side && hasLeft )  part += Y[(size_t) ( yPos + min( i, (int) pic.hdr.height - yPos - 1 ) ) * st + xPos - 1];
-    if( side && hasAbove )  part += Y[(size_t) ( yPos - 1 ) * st + xPos + min( i, (int) pic.hdr.width - xPos - 1 )];
+    if( !side && hasLeft )  part += Y[(size_t) ( yPos + min( i, pic.height - yPos - 1 ) ) * st + xPos - 1];
+    if( side && hasAbove )  part += Y[(size_t) ( yPos - 1 ) * st + xPos + min( i, pic.width - xPos - 1 )];
   }
 #pragma unroll
   for( int off = 32; off >= 1; off >>= 1 ) part += __shfl_xor( part, off, 64 );
@@ -1143,7 +1153,7 @@ __device__ __forceinline__ int lmcs_cscale_factor_wave( const PicDev& pic, const
   int lumaValue;
   if( hasLeft && hasAbove ) lumaValue = ( recLuma + ( 1 << nLog ) ) >> ( nLog + 1 );
   else if( hasLeft || hasAbove ) lumaValue = ( recLuma + ( 1 << ( nLog - 1 ) ) ) >> nLog;
-  else lumaValue = 1 << ( pic.hdr.bit_depth - 1 );
+  else lumaValue = 1 << ( pic.bitDepth - 1 );
   // first idx in [minBin, maxBin] with lumaValue < pivot[idx + 1], else maxBin + 1 (Reshape::getPWLIdxInv, :280); table entry min( idx, 15 )
   const unsigned long long hit = __ballot( lane >= minBin && lane <= maxBin && lumaValue < pivotL );
   const int idx = hit ? __builtin_ctzll( hit ) : maxBin + 1;
@@ -2407,8 +2417,8 @@ __device__ __forceinline__ int tile_idx( int dx, int dy )
 // scratch of one wavefront (one block at a time)
 #define IT_NEG 72           // entries in front of a reference line: the side reference projected onto negative indices of the main reference
 struct IntraWave {
-  pel_t topB[IT_NEG + IT_MAXREF + 8], leftB[IT_NEG + IT_MAXREF + 8];     // reference lines of the block (index 0 = the corner sample), smoothed in place
-  pel_t auxT[IT_MAXREF + 8], auxL[IT_MAXREF + 8];    // ISP: the line of the whole CU; MIP: the reduced prediction
+  pel_t topB[IT_NEG + IT_MAXREF + 8], leftB[IT_NEG + IT_MAXREF + 8];     // reference lines of the block (index 0 = the corner sample; IT_NEG entries in front)
+  pel_t auxT[IT_NEG + IT_MAXREF + 8], auxL[IT_NEG + IT_MAXREF + 8];    // the smoothed lines (same layout); ISP: the line of the whole CU; MIP: the reduced prediction
   int16_t resi[IT_PART_SAMPLES];                      // residual of the block (fetched while the blocks before it are predicted)
   int   lmSel[8];                                     // CCLM: the (luma, chroma) pairs of the selected template positions; MIP: the reduced boundary
 };
@@ -2514,20 +2524,36 @@ __device__ __forceinline__ void intra_stash_resi( const IntraResiRegs& R, const 
 }
 
 // CCLM / MDLM: the down-sampled luma a chroma block is predicted from (xGetLumaRecPixels, IntraPrediction.cpp:1403-1470; 4:2:0, both luma
-// filters) - sample e * 64 + lane of the block, 16 bits each - and of this lane's template position (xGetLMParameters :1694-1800).  It only
-// depends on luma that is final before the chroma unit starts, so it is fetched one block ahead of its use, like the residual.
-struct IntraLumaRegs { uint32_t v[8]; int tpl; };
-__device__ __forceinline__ void intra_load_cclm_luma( IntraLumaRegs& R, const IntraItem& it, const PicDev& pic, const DevPlanes& reco, int lane )
+// filters) - sample e * 64 + lane of a block of up to IT_CCLM_REGS samples, 16 bits each - and of this lane's template position
+// (xGetLMParameters :1694-1800).  It only depends on luma that is final before the chroma unit starts, so it is fetched one block ahead of its
+// use, like the residual.
+#define IT_CCLM_REGS 256    /* samples of a CCLM block whose luma is fetched ahead (4 per lane); larger blocks fetch it when they are predicted */
+struct IntraLumaRegs { uint32_t v[IT_CCLM_REGS / 128]; int tpl; };
+// luma of chroma sample (x, y) of the block whose co-located luma block starts at (lx0, ly0); the pairs (2x, 2x + 1) are dword loads
+__device__ __forceinline__ int intra_cclm_luma_at( const pel_t* __restrict__ Yp, int ys, int lx0, int ly0, int x, int y, bool bLeft, bool bAbove, bool colloc )
+{
+  const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
+  const pel_t* r0 = Yp + (size_t) ( ly0 + 2 * y ) * ys + lx0;
+  const uint32_t m0 = *reinterpret_cast<const uint32_t*>( r0 + 2 * x ), m1 = *reinterpret_cast<const uint32_t*>( r0 + ys + 2 * x );
+  const int a0 = m0 & 0xffff, b0 = m0 >> 16, a1 = m1 & 0xffff, b1 = m1 >> 16;
+  if( colloc )
+  {
+    const int yu = ( y == 0 && !bAbove ) ? 0 : 2 * y - 1;
+    return ( (int) Yp[(size_t) ( ly0 + yu ) * ys + lx0 + 2 * x] + a0 * 4 + (int) r0[xl] + b0 + a1 + 4 ) >> 3;
+  }
+  return ( a0 * 2 + b0 + (int) r0[xl] + a1 * 2 + b1 + (int) r0[ys + xl] + 4 ) >> 3;
+}
+__device__ __forceinline__ void intra_load_cclm_luma( IntraLumaRegs& R, const IntraItem& it, const IntraPic& pic, int lane )
 {
   if( it.mode < 67 || it.mode > 69 ) return;
-  const pel_t* __restrict__ Yp = reco.p[0]; const int ys = reco.stride[0];
+  const pel_t* __restrict__ Yp = pic.plane[0]; const int ys = pic.stride[0];
   const int lw = it.lw, w = 1 << lw, wh = 1 << ( it.lw + it.lh );
   const int lx0 = (int) it.x << 1, ly0 = (int) it.y << 1;
 #define LU( xx, yy ) ( (int) Yp[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
   const uint32_t lm = it.tu;
   const int actualTop = lm & 0xff, actualLeft = ( lm >> 8 ) & 0xff;
   const bool aboveAvail = ( lm >> 16 ) & 1, leftAvail = ( lm >> 17 ) & 1, bLeft = ( lm >> 18 ) & 1, firstRow = ( lm >> 19 ) & 1, bAbove = ( lm >> 20 ) & 1;
-  const bool colloc = ( pic.hdr.tool_flags & VVR_TOOL_CCLM_COLLOC ) != 0;      // sps_chroma_vertical_collocated_flag: 5-tap cross instead of the 6-tap filter
+  const bool colloc = pic.colloc != 0;      // sps_chroma_vertical_collocated_flag: 5-tap cross instead of the 6-tap filter
   const int aboveIs4 = leftAvail ? 0 : 1, leftIs4 = aboveAvail ? 0 : 1;
   const int cntT = aboveAvail ? min( actualTop, ( 1 + aboveIs4 ) << 1 ) : 0, cntL = leftAvail ? min( actualLeft, ( 1 + leftIs4 ) << 1 ) : 0;
   R.tpl = 0;
@@ -2550,33 +2576,31 @@ __device__ __forceinline__ void intra_load_cclm_luma( IntraLumaRegs& R, const In
     }
     R.tpl = lv;
   }
+#undef LU
+  if( wh > IT_CCLM_REGS ) return;
 #pragma unroll
-  for( int e = 0; e < 16; e++ )
+  for( int e = 0; e < IT_CCLM_REGS / 64; e++ )
   {
     if( e * 64 < wh )
     {
       const int i = min( e * 64 + lane, wh - 1 );
-      const int x = i & ( w - 1 ), y = i >> lw;
-      const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
-      const int yu = ( y == 0 && !bAbove ) ? 0 : 2 * y - 1;
-      const uint32_t t = (uint16_t) ( colloc ? ( LU( 2 * x, yu ) + LU( 2 * x, 2 * y ) * 4 + LU( xl, 2 * y ) + LU( 2 * x + 1, 2 * y ) + LU( 2 * x, 2 * y + 1 ) + 4 ) >> 3
-                                            : ( LU( 2 * x, 2 * y ) * 2 + LU( 2 * x + 1, 2 * y ) + LU( xl, 2 * y ) + LU( 2 * x, 2 * y + 1 ) * 2 + LU( 2 * x + 1, 2 * y + 1 ) + LU( xl, 2 * y + 1 ) + 4 ) >> 3 );
+      const uint32_t t = (uint16_t) intra_cclm_luma_at( Yp, ys, lx0, ly0, i & ( w - 1 ), i >> lw, bLeft, bAbove, colloc );
       if( e & 1 ) R.v[e >> 1] = ( R.v[e >> 1] & 0xffffu ) | ( t << 16 ); else R.v[e >> 1] = t;
     }
   }
-#undef LU
 }
 
-__global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, DevPlanes resi, const IntraItem* __restrict__ items,
+__global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem* __restrict__ items,
                                                   const IntraUnit* __restrict__ units, int numActive,
                                                   int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */
 #ifdef VVR_INTRA_DEV
-                                                  , int dbg, unsigned long long* __restrict__ trace /* developer timeline (VVR_INTRA_TRACE) or nullptr */
+                                                  , int dbg, unsigned long long* __restrict__ trace /* developer timeline (VVR_INTRA_TRACE) or nullptr */,
+                                                  unsigned long long* __restrict__ btrace /* per block: ready / go / filled / done (shader clock) */
 #endif
                                                   )
 {
 #ifndef VVR_INTRA_DEV
-  constexpr int dbg = 0; constexpr unsigned long long* trace = nullptr;      // (the timing experiments and the in-kernel timeline are developer builds only)
+  constexpr int dbg = 0; constexpr unsigned long long* trace = nullptr, * btrace = nullptr;      // (the timing experiments and the in-kernel timeline are developer builds only)
 #endif
   __shared__ IntraShared sh;
 #define IT_TRACE( K ) if( trace && threadIdx.x == 0 ) trace[(size_t) 8 * tr_ticket + ( K )] = wall_clock64()
@@ -2605,24 +2629,24 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   const int comp = ( ent >> 24 ) & 3, ctu = ent & 0xffffff;
   const bool borderOnly = ( ent >> 31 ) != 0;          // whole CTU, every sample intra: the interior is produced here, never read first
   const bool publish = ( ( ent >> 30 ) & 1 ) != 0 && !( dbg & 0x100 );     // another unit waits for this one
-  const int cxI = ctu % pic.ctus_x, cyI = ctu / pic.ctus_x;
+  const int cxI = ctu % pic.ctusX, cyI = ctu / pic.ctusX;
   const int cs = comp ? 1 : 0;
-  const int S = ( 1 << pic.hdr.log2_ctu ) >> cs;
+  const int S = ( 1 << pic.log2Ctu ) >> cs;
   const int ox = cxI * S, oy = cyI * S;
-  const int bd = pic.hdr.bit_depth;
-  const int PW = reco.w[comp], PH = reco.h[comp], pstride = reco.stride[comp];
-  pel_t* __restrict__ plane = reco.p[comp];
-  const pel_t* __restrict__ rs = resi.p[comp];
-  const int rstride = resi.stride[comp];
+  const int bd = pic.bitDepth;
+  const int PW = pic.w[comp], PH = pic.h[comp], pstride = pic.stride[comp];
+  pel_t* __restrict__ plane = pic.plane[comp];
+  const pel_t* __restrict__ rs = pic.resi[comp];
+  const int rstride = pic.rstride[comp];
   const uint32_t i0 = un->i0, i1 = un->i1, iA = un->iA;
   // the unit's first IT_BATCH block records are on their way while the producers' flags are polled (one dword per lane; stored to LDS behind the
   // wait): the reference staging below reads them from LDS instead of waiting for HBM / L2 again; so are the records of the first two blocks
   // of every wavefront
   const int nb0 = (int) min( (uint32_t) IT_BATCH, i1 - i0 );
   const uint32_t itemPre = tid < nb0 * 4 ? reinterpret_cast<const uint32_t*>( items + i0 )[tid] : 0u;
-  uint4 recA = make_uint4( 0, 0, 0, 0 ), recB = make_uint4( 0, 0, 0, 0 );
-  if( iA + wv < i1 ) recA = intra_load_item( items, iA + wv );
-  if( iA + wv + IT_WAVES < i1 ) recB = intra_load_item( items, iA + wv + IT_WAVES );
+  uint4 recN = make_uint4( 0, 0, 0, 0 ), recNN = make_uint4( 0, 0, 0, 0 );
+  if( iA + wv < i1 ) recN = intra_load_item( items, iA + wv );
+  if( iA + wv + IT_WAVES < i1 ) recNN = intra_load_item( items, iA + wv + IT_WAVES );
 #define TILE( x, y ) sh.tile[tile_idx( ( x ) - ox, ( y ) - oy )]
   // block record q of this unit into scalar registers (uniform per wavefront)
 #define IT_FETCH( IT, Q ) { const uint32_t* ip_ = ( Q ) - i0 < (uint32_t) IT_BATCH ? reinterpret_cast<const uint32_t*>( &sh.items[( Q ) - i0] ) : reinterpret_cast<const uint32_t*>( &items[Q] ); \
@@ -2649,13 +2673,13 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
   // straight from HBM to HBM, one block per wavefront, without staging the CTU
   if( iA == i1 && i1 > i0 )
   {
-    const int csNv1 = pic.hdr.log2_ctu > pic.vpduLog2 ? 1 : 0;
+    const int csNv1 = pic.log2Ctu > pic.vpduLog2 ? 1 : 0;
     if( ( ent >> 29 ) & 1 )
     {
-      const int lx = ( cxI << pic.hdr.log2_ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.hdr.log2_ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
-      if( lx < (int) pic.hdr.width && ly < (int) pic.hdr.height && ( wv == 0 || csNv1 ) )
+      const int lx = ( cxI << pic.log2Ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.log2Ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
+      if( lx < pic.width && ly < pic.height && ( wv == 0 || csNv1 ) )
       {
-        const int f = lmcs_cscale_factor_wave( pic, reco, lx, ly, lane );
+        const int f = lmcs_cscale_factor_wave( pic, lx, ly, lane );
         if( lane == 0 ) sh.csFac[wv] = f;
       }
     }
@@ -2706,133 +2730,143 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
     IT_TRACE( 5 );
     continue;
   }
-  // ---- stage the needed part of the CTU and its reference border in LDS
-  {
-    // 16-byte chunks (8 samples); plane rows are 128-byte aligned and padded to a multiple of 64 samples, so a chunk that
-    // straddles the picture's right edge stays inside the row allocation (those samples are never used).
-    // bbox (host glue): rows / chunks that hold reference samples of this CTU's blocks, relative to (oy - IT_PAD, ox - IT_PADX)
-    const uint32_t bb = un->bbox;
-    const int y0 = max( 0, oy - IT_PAD ), y1 = min( PH, oy + S );
-    const int c0 = ox >= IT_PADX ? -1 : 0;                                  // first chunk relative to ox / 8
-    const int c1 = ( min( PW, ox + S + IT_RIGHT ) - ox + 7 ) >> 3;           // one past the last chunk
-    const int by0 = max( y0, oy - IT_PAD + (int) ( bb & 0xff ) ), by1 = min( y1, oy - IT_PAD + (int) ( ( bb >> 8 ) & 0xff ) );
-    const int bc0 = max( c0, (int) ( ( bb >> 16 ) & 0xff ) - 1 ), bc1 = min( c1, (int) ( bb >> 24 ) - 1 );
-    const int nch = bc1 - bc0;
-    const int nTop = nch * max( 0, min( by1, oy ) - by0 );                   // chunks in the rows above the CTU
-    const int rowsIn = max( 0, by1 - max( by0, oy ) );
-    const bool perBlock = !borderOnly;
-    const int total = ( ( dbg & 2 ) || perBlock ) ? 0 : nTop + ( bc0 < 0 ? rowsIn : 0 );
-    if( perBlock && !( dbg & 2 ) )
-    {
-      // a unit that is not a whole intra CTU: only the reference lines its blocks read (one row above, one column left of every
-      // block, as far as they are available) instead of the bounding box; one block per wavefront, 16-byte chunks
-      for( uint32_t q = i0 + wv; q < i1; q += IT_WAVES )
-      {
-        IntraItem it;
-        IT_FETCH( it, q )
-        if( IT_PART( it ) ) continue;                                            // (row parts of one block: fetched with the first)
-        if( it.mode == IT_MODE_IBC )
-        {
-          // intra block copy: the part of the reference block that lies in this CTU is read from the tile (blocks of this unit write
-          // their samples there first), so it is staged like a reference line; the part in a CTU further left is read from HBM
-          const int bw = 1 << it.lw, bh = 1 << it.lh;
-          const int rx = (int) it.x + (int16_t) ( it.tu & 0xffff ), ry = (int) it.y + (int16_t) ( it.tu >> 16 );
-          const int cx0 = max( rx, ox ) & ~7, cch = max( 0, ( rx + bw - cx0 + 7 ) >> 3 );
-          for( int i = lane; i < cch * bh; i += 64 )
-          {
-            const int y = ry + i / cch, x = cx0 + 8 * ( i % cch );
-            const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
-            *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
-          }
-          continue;
-        }
-        const bool isp = !comp && ( it.flags & IT_F_ISP ) == IT_F_ISP;
-        if( isp && ( it.tu & 0xfff ) ) continue;                               // later ISP partitions: the CU's line was fetched with the first one
-        const int bw = isp ? 1 << ( ( it.tu >> 12 ) & 7 ) : 1 << it.lw, bh = isp ? 1 << ( ( it.tu >> 15 ) & 7 ) : 1 << it.lh;
-        const int mrl = ( isp || comp || ( it.flags & IT_F_MIP ) ) ? 0 : ( it.flags >> 4 ) & 3;
-        const int unit = 4 >> cs;
-        const int lx = (int) it.x - 1 - mrl, ty = (int) it.y - 1 - mrl;
-        // row above: from the corner column to the last available sample above / above-right
-        const int tx0 = max( 0, lx ) & ~7, tx1 = (int) it.x + max( (int) it.nA * unit, 1 );
-        const int nT = ty >= 0 ? ( tx1 - tx0 + 7 ) >> 3 : 0;
-        // column left: from the corner row to the last available sample left / below-left
-        const int ly0 = max( 0, ty ), ly1 = (int) it.y + (int) it.nL * unit;
-        const int nL = lx >= 0 ? max( 0, ly1 - ly0 ) : 0;
-        // CIIP: the inter prediction of the block itself
-        const int wIntra = isp ? 0 : it.flags >> 6;                             // (the two bits are zero for every other kind of block)
-        const int cch = ( ( (int) it.x & 7 ) + bw + 7 ) >> 3, nC = wIntra ? cch * bh : 0;
-        for( int i = lane; i < nT + nL + nC; i += 64 )
-        {
-          int x, y;
-          if( i < nT ) { x = tx0 + 8 * i; y = ty; }
-          else if( i < nT + nL ) { x = lx & ~7; y = ly0 + ( i - nT ); }
-          else { const int j = i - nT - nL; y = (int) it.y + j / cch; x = ( (int) it.x & ~7 ) + 8 * ( j % cch ); }
-          const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
-          *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
-        }
-      }
-    }
-    for( int base = 0; base < total; base += 256 * 4 )
-    {
-      // four 16-byte loads in flight per lane; the tail repeats the last chunk (same data to the same place) instead of branching
-      uint4 v0, v1, v2, v3; int o0, o1, o2, o3;
-#define IT_LD( V, O, U ) { const int i = min( base + U * 256 + tid, total - 1 ); int r, cidx; \
-        if( i < nTop ) { r = i / nch; cidx = bc0 + ( i - r * nch ); } else { r = ( max( by0, oy ) - by0 ) + ( i - nTop ); cidx = -1; } \
-        const int y = by0 + r, x = ox + cidx * 8; V = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] ); O = tile_idx( x - ox, y - oy ); }
-      IT_LD( v0, o0, 0 ) IT_LD( v1, o1, 1 ) IT_LD( v2, o2, 2 ) IT_LD( v3, o3, 3 )
-#undef IT_LD
-      *reinterpret_cast<uint4*>( &sh.tile[o0] ) = v0; *reinterpret_cast<uint4*>( &sh.tile[o1] ) = v1;
-      *reinterpret_cast<uint4*>( &sh.tile[o2] ) = v2; *reinterpret_cast<uint4*>( &sh.tile[o3] ) = v3;
-    }
-  }
-  IT_TRACE( 2 );
-  // ---- LMCS chroma residual scaling (DecCu.cpp:383-388,500-505): one factor per VPDU of the CTU, one wavefront each (the unit
-  // has waited for the luma units that reconstruct the samples the factors are averaged over)
-  const int csNv1 = pic.hdr.log2_ctu > pic.vpduLog2 ? 1 : 0;        // VPDUs per CTU side - 1
-  if( ( ent >> 29 ) & 1 )
-  {
-    const int lx = ( cxI << pic.hdr.log2_ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.hdr.log2_ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
-    if( lx < (int) pic.hdr.width && ly < (int) pic.hdr.height && ( wv == 0 || csNv1 ) )
-    {
-      const int f = lmcs_cscale_factor_wave( pic, reco, lx, ly, lane );
-      if( lane == 0 ) sh.csFac[wv] = f;
-    }
-  }
-  // the residual of the wavefront's first block is on its way while the staged tile settles
-  IntraResiRegs RR;
-  IntraLumaRegs LR;
-  for( int e = 0; e < 8; e++ ) LR.v[e] = 0;
-  LR.tpl = 0;
-  if( iA + wv < i1 ) { const IntraItem itF = intra_item_of( recA ); intra_load_resi( RR, itF, rs, rstride, lane ); if( comp ) intra_load_cclm_luma( LR, itF, pic, reco, lane ); }
-  lds_barrier();
+  const int csNv1 = pic.log2Ctu > pic.vpduLog2 ? 1 : 0;        // VPDUs per CTU side - 1
   // ---- block loop: ONE WAVEFRONT PER BLOCK.  Wavefront w takes the unit's blocks w, w + 4, ... in order.  Everything that does not depend on
   // neighbouring samples - the block's record, its residual, the co-located luma of a CCLM block, the mode set-up - is done before the block's
   // turn comes (records two blocks ahead, residual and luma one block ahead, all in registers); a block starts when the blocks before it (all
   // but the `indep` directly before it, which it does not read) are finished: progress counters in LDS, one per wavefront.  No workgroup
-  // barrier on the block-to-block path: inside a wavefront LDS operations execute in order.  What is left on that path is kept short in
-  // round trips, not in instructions: all reference samples of a block are read from the tile at once, smoothing happens in place, the side
-  // reference of a negative prediction angle is projected onto negative indices of the main reference once per block, and a lane predicts
-  // four neighbouring samples of a row of the (possibly transposed) block from seven reference samples with one filter.
+  // barrier on the block-to-block path, and one wait for the LDS per block: inside a wavefront LDS operations execute in order.  What is
+  // left on that path is kept short: all reference samples of a block are read from the tile at once (one read per line and lane, the
+  // substitution of unavailable samples is index arithmetic), smoothing happens in place, the side reference of a negative prediction
+  // angle is projected onto negative indices of the main reference once per block, and a lane predicts four neighbouring samples of a row
+  // of the (possibly transposed) block from seven reference samples with one filter.
+  // The loop is software-pipelined without a copy of its loads in front of it: its first round has no block, it only starts the fetches of
+  // the wavefront's first block - and stages the unit's part of the tile behind them.
   {
     IntraWave& W = sh.wave[wv];
     pel_t* const T = W.topB + IT_NEG;
     pel_t* const L = W.leftB + IT_NEG;
     volatile int* prog = sh.prog;
     int done = 0;                     // blocks this wavefront has finished
-    for( uint32_t q = iA + wv; q < ( ( dbg & 4 ) ? i0 : i1 ); q += IT_WAVES )
+    IntraResiRegs RR;
+    IntraLumaRegs LR;
+    for( int e = 0; e < 4; e++ ) RR.v[e] = make_uint2( 0, 0 );
+    for( int e = 0; e < IT_CCLM_REGS / 128; e++ ) LR.v[e] = 0;
+    LR.tpl = 0;
+    const int q0 = (int) iA + wv, qEnd = ( dbg & 4 ) ? (int) i0 : (int) i1;
+    uint4 recC = make_uint4( 0, 0, 0, 0 );
+#define IT_CSYNC() asm volatile( "" ::: "memory" )      /* LDS accesses of one wavefront execute in order: only the compiler has to keep them in order */
+    for( int q = q0 - IT_WAVES; ; q += IT_WAVES )
     {
-      const IntraItem it = intra_item_of( recA );
-      const int x0 = it.x, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
+      const bool cur = q >= q0;
+      if( cur && q >= qEnd ) break;
+      const IntraItem it = intra_item_of( recC );
+      if( cur ) intra_stash_resi( RR, it, W.resi, lane );
+      const IntraLumaRegs LC = LR;                                             // (CCLM) co-located luma of this block, fetched while the block before was predicted
+      // the residual (and the luma of a CCLM block) of the wavefront's next block starts, the records move up
+      if( q + IT_WAVES < qEnd ) { const IntraItem itN = intra_item_of( recN ); intra_load_resi( RR, itN, rs, rstride, lane ); if( comp ) intra_load_cclm_luma( LR, itN, pic, lane ); }
+      recC = recN; recN = recNN;
+      if( q + 3 * IT_WAVES < qEnd ) recNN = intra_load_item( items, (uint32_t) ( q + 3 * IT_WAVES ) );
+      if( !cur )
+      {
+      // ---- stage the needed part of the CTU and its reference border in LDS
+      {
+        // 16-byte chunks (8 samples); plane rows are 128-byte aligned and padded to a multiple of 64 samples, so a chunk that
+        // straddles the picture's right edge stays inside the row allocation (those samples are never used).
+        // bbox (host glue): rows / chunks that hold reference samples of this CTU's blocks, relative to (oy - IT_PAD, ox - IT_PADX)
+        const uint32_t bb = un->bbox;
+        const int y0 = max( 0, oy - IT_PAD ), y1 = min( PH, oy + S );
+        const int c0 = ox >= IT_PADX ? -1 : 0;                                  // first chunk relative to ox / 8
+        const int c1 = ( min( PW, ox + S + IT_RIGHT ) - ox + 7 ) >> 3;           // one past the last chunk
+        const int by0 = max( y0, oy - IT_PAD + (int) ( bb & 0xff ) ), by1 = min( y1, oy - IT_PAD + (int) ( ( bb >> 8 ) & 0xff ) );
+        const int bc0 = max( c0, (int) ( ( bb >> 16 ) & 0xff ) - 1 ), bc1 = min( c1, (int) ( bb >> 24 ) - 1 );
+        const int nch = bc1 - bc0;
+        const int nTop = nch * max( 0, min( by1, oy ) - by0 );                   // chunks in the rows above the CTU
+        const int rowsIn = max( 0, by1 - max( by0, oy ) );
+        const bool perBlock = !borderOnly;
+        const int total = ( ( dbg & 2 ) || perBlock ) ? 0 : nTop + ( bc0 < 0 ? rowsIn : 0 );
+        if( perBlock && !( dbg & 2 ) )
+        {
+          // a unit that is not a whole intra CTU: only the reference lines its blocks read (one row above, one column left of every
+          // block, as far as they are available) instead of the bounding box; one block per wavefront, 16-byte chunks
+          for( uint32_t q = i0 + wv; q < i1; q += IT_WAVES )
+          {
+            IntraItem it;
+            IT_FETCH( it, q )
+            if( IT_PART( it ) ) continue;                                            // (row parts of one block: fetched with the first)
+            if( it.mode == IT_MODE_IBC )
+            {
+              // intra block copy: the part of the reference block that lies in this CTU is read from the tile (blocks of this unit write
+              // their samples there first), so it is staged like a reference line; the part in a CTU further left is read from HBM
+              const int bw = 1 << it.lw, bh = 1 << it.lh;
+              const int rx = (int) it.x + (int16_t) ( it.tu & 0xffff ), ry = (int) it.y + (int16_t) ( it.tu >> 16 );
+              const int cx0 = max( rx, ox ) & ~7, cch = max( 0, ( rx + bw - cx0 + 7 ) >> 3 );
+              for( int i = lane; i < cch * bh; i += 64 )
+              {
+                const int y = ry + i / cch, x = cx0 + 8 * ( i % cch );
+                const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
+                *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
+              }
+              continue;
+            }
+            const bool isp = !comp && ( it.flags & IT_F_ISP ) == IT_F_ISP;
+            if( isp && ( it.tu & 0xfff ) ) continue;                               // later ISP partitions: the CU's line was fetched with the first one
+            const int bw = isp ? 1 << ( ( it.tu >> 12 ) & 7 ) : 1 << it.lw, bh = isp ? 1 << ( ( it.tu >> 15 ) & 7 ) : 1 << it.lh;
+            const int mrl = ( isp || comp || ( it.flags & IT_F_MIP ) ) ? 0 : ( it.flags >> 4 ) & 3;
+            const int unit = 4 >> cs;
+            const int lx = (int) it.x - 1 - mrl, ty = (int) it.y - 1 - mrl;
+            // row above: from the corner column to the last available sample above / above-right
+            const int tx0 = max( 0, lx ) & ~7, tx1 = (int) it.x + max( (int) it.nA * unit, 1 );
+            const int nT = ty >= 0 ? ( tx1 - tx0 + 7 ) >> 3 : 0;
+            // column left: from the corner row to the last available sample left / below-left
+            const int ly0 = max( 0, ty ), ly1 = (int) it.y + (int) it.nL * unit;
+            const int nL = lx >= 0 ? max( 0, ly1 - ly0 ) : 0;
+            // CIIP: the inter prediction of the block itself
+            const int wIntra = isp ? 0 : it.flags >> 6;                             // (the two bits are zero for every other kind of block)
+            const int cch = ( ( (int) it.x & 7 ) + bw + 7 ) >> 3, nC = wIntra ? cch * bh : 0;
+            for( int i = lane; i < nT + nL + nC; i += 64 )
+            {
+              int x, y;
+              if( i < nT ) { x = tx0 + 8 * i; y = ty; }
+              else if( i < nT + nL ) { x = lx & ~7; y = ly0 + ( i - nT ); }
+              else { const int j = i - nT - nL; y = (int) it.y + j / cch; x = ( (int) it.x & ~7 ) + 8 * ( j % cch ); }
+              const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
+              *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
+            }
+          }
+        }
+        for( int base = 0; base < total; base += 256 * 4 )
+        {
+          // four 16-byte loads in flight per lane; the tail repeats the last chunk (same data to the same place) instead of branching
+          uint4 v0, v1, v2, v3; int o0, o1, o2, o3;
+#define IT_LD( V, O, U ) { const int i = min( base + U * 256 + tid, total - 1 ); int r, cidx; \
+            if( i < nTop ) { r = i / nch; cidx = bc0 + ( i - r * nch ); } else { r = ( max( by0, oy ) - by0 ) + ( i - nTop ); cidx = -1; } \
+            const int y = by0 + r, x = ox + cidx * 8; V = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] ); O = tile_idx( x - ox, y - oy ); }
+          IT_LD( v0, o0, 0 ) IT_LD( v1, o1, 1 ) IT_LD( v2, o2, 2 ) IT_LD( v3, o3, 3 )
+#undef IT_LD
+          *reinterpret_cast<uint4*>( &sh.tile[o0] ) = v0; *reinterpret_cast<uint4*>( &sh.tile[o1] ) = v1;
+          *reinterpret_cast<uint4*>( &sh.tile[o2] ) = v2; *reinterpret_cast<uint4*>( &sh.tile[o3] ) = v3;
+        }
+      }
+    IT_TRACE( 2 );
+    // ---- LMCS chroma residual scaling (DecCu.cpp:383-388,500-505): one factor per VPDU of the CTU, one wavefront each (the unit
+    // has waited for the luma units that reconstruct the samples the factors are averaged over)
+    if( ( ent >> 29 ) & 1 )
+    {
+      const int lx = ( cxI << pic.log2Ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.log2Ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
+      if( lx < pic.width && ly < pic.height && ( wv == 0 || csNv1 ) )
+      {
+        const int f = lmcs_cscale_factor_wave( pic, lx, ly, lane );
+        if( lane == 0 ) sh.csFac[wv] = f;
+      }
+    }
+    lds_barrier();
+        continue;
+      }
+      const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
       const int rows = h >> IT_LPARTS( it ), yb = IT_PART( it ) * rows;        // the band of rows this item predicts
-      const int y0 = it.y;
       const int wh = rows << lw;                                               // samples of this item
       const bool stashed = wh <= IT_PART_SAMPLES;
-      intra_stash_resi( RR, it, W.resi, lane );
-      const IntraLumaRegs LC = LR;                                             // (CCLM) co-located luma of this block, fetched while the block before was predicted
-      // the records move up, the residual (and the luma of a CCLM block) of the wavefront's next block starts
-      recA = recB;
-      if( q + 2 * IT_WAVES < i1 ) recB = intra_load_item( items, q + 2 * IT_WAVES );
-      if( q + IT_WAVES < i1 ) { const IntraItem itN = intra_item_of( recA ); intra_load_resi( RR, itN, rs, rstride, lane ); if( comp ) intra_load_cclm_luma( LR, itN, pic, reco, lane ); }
       const bool mip = !comp && ( it.flags & IT_F_MIP );      // (chroma: the same bit says LMCS chroma residual scaling)
       const int mrl = ( it.flags & IT_F_MIP ) ? 0 : ( it.flags >> 4 ) & 3;
       const int wIntra = it.flags >> 6;               // CIIP: weight of the planar intra part, 0 = ordinary intra block
@@ -2857,9 +2891,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int topLen = isp ? ( ispVer ? cuW + w : 2 * cuW ) : 2 * w, leftLen = isp ? ( ispVer ? 2 * cuH : cuH + h ) : 2 * h;
       const int fx0 = x0 - ispDx, fy0 = y0 - ispDy, fTopLen = isp ? 2 * cuW : topLen, fLeftLen = isp ? 2 * cuH : leftLen;
       const int unit = 4 >> cs;
-      const int totalAbove = ( fTopLen + unit - 1 ) / unit, totalLeft = ( fLeftLen + unit - 1 ) / unit;
       const int nTL = it.nTL & 1, nA = it.nA, nL = it.nL;
-      const int nAll = nTL + nA + nL, total = totalAbove + totalLeft + 1;
       const bool isDc = !bdpcm && dirMode == 1;
       // ---- reference smoothing decision, mode-specific set-up (uniform scalar work, none of it depends on a sample)
       bool useFilt = false;
@@ -2912,9 +2944,11 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
       const int xxb = tr ? yb : 0, yyb = tr ? 0 : yb;
       const bool vec = !tr && g == 4 && !( x0 & 3 );                            // 8-byte LDS accesses to the tile row and the residual
       const int tileBase = IT_PAD * IT_TS + ( y0 - oy ) * IT_TSB + ( x0 - ox ) + IT_PADX;       // block origin in the tile (rows inside the CTU)
+#define IT_BT( K ) if( btrace && lane == 0 ) btrace[(size_t) 4 * q + ( K )] = clock64()
+      IT_BT( 0 );
       // ---- the block's turn: every block of the unit it may read from is finished
       {
-        const int m = (int) ( q - iA ) - IT_INDEP( it );         // blocks 0 .. m - 1 of the unit
+        const int m = q - (int) iA - IT_INDEP( it );              // blocks 0 .. m - 1 of the unit
         if( m > 0 )
         {
           const int need = lane < IT_WAVES ? max( 0, ( m - lane + IT_WAVES - 1 ) / IT_WAVES ) : 0;
@@ -2925,16 +2959,18 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
             __builtin_amdgcn_s_sleep( 1 );
           }
         }
-        asm volatile( "" ::: "memory" );
+        IT_CSYNC();
       }
-#define IT_DONE() { wave_lds_sync(); done++; if( lane == 0 ) prog[wv] = done; }
+      IT_BT( 1 );
+      // (the wait makes the block's samples visible to the other wavefronts before the counter moves)
+#define IT_DONE() { wave_lds_sync(); done++; if( lane == 0 ) prog[wv] = done; IT_BT( 3 ); }
       // ---- intra block copy (InterPrediction::xIntraBlockCopy :1995, DecCu.cpp:442-470): copy of reconstructed samples of this picture
       // at the block vector (+ residual).  Samples of this CTU come from the tile, where the blocks of this unit have put theirs and
       // the others were staged after the wait for their producers; samples of a CTU further left come from HBM.
       if( dirMode == IT_MODE_IBC )
       {
         const int qx = x0 + (int16_t) ( it.tu & 0xffff ), qy = y0 + (int16_t) ( it.tu >> 16 );
-#pragma unroll 2
+#pragma unroll 1
         for( int i = lane; i < wh; i += 64 )
         {
           const int x = i & ( w - 1 ), y = yb + ( i >> lw );
@@ -2946,93 +2982,50 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         IT_DONE()
         continue;
       }
-      // ---- xFillReferenceSamples: one lane per reference position, all positions read at once (+ the DC sum while the values are in registers)
+      // ---- xFillReferenceSamples (:1072-1250): one lane per reference position, ONE read per line and lane - the substitution of samples that
+      // are not available (the nearest available one along the line, the first left sample for an unavailable corner, mid grey if nothing is)
+      // only moves the position that is read: index <= mrl (the corner and the extension of its row / column): base0 + step0 * index; beyond:
+      // base1 + min( index - 1 - mrl, limit1 ) [* row stride], all uniform.  Lines: index 0 = the corner, then the samples above (left of) the
+      // block.  ISP: the line of the whole CU first, the partition's own line is cut out of it below.
       int dcPart = 0;
       {
-        const int dcv = 1 << ( bd - 1 );
-        const int n = max( max( topLen, leftLen ), max( fTopLen, fLeftLen ) ) + mrl + 1;       // <= 131: three rounds of 64 lanes
-        pel_t* const dT = isp ? W.auxT : T;        // ISP: the CU's line, kept aside; the partition's own line is cut out of it below
+        const int n = max( max( topLen, leftLen ), max( fTopLen, fLeftLen ) ) + mrl + 1;       // <= 131
+        pel_t* const dT = isp ? W.auxT : T;
         pel_t* const dL = isp ? W.auxL : L;
-        const int wT = isp ? fTopLen : topLen + mrl, wL = isp ? fLeftLen : leftLen + mrl;
-        int tvv[3], lvv[3];
-        if( nAll == total )
+        const int cx = fx0 - ( 1 + mrl ), cy = fy0 - ( 1 + mrl );          // corner
+        const int iCorner = tile_idx( cx - ox, cy - oy ), iPad = tile_idx( cx - ox, fy0 - oy ), iAbove = tile_idx( fx0 - ox, cy - oy );
+        const int szL = min( nL * unit, fLeftLen ), szA = min( nA * unit, fTopLen );
+        // top: tb0 + ts0 * j | tb1 + min( i, tl1 );  left: lb0 + ls0 * j | lb1 + min( i, ll1 ) * IT_TSB   (rows cy .. cy + mrl lie inside the CTU when mrl > 0)
+        const int tb0 = nL ? ( nTL ? iCorner : iPad ) : iAbove, ts0 = ( nL && nTL ) ? 1 : 0;
+        const int tb1 = nA ? iAbove : nTL ? iAbove - 1 : iPad, tl1 = nA ? szA - 1 : 0;
+        const int lb0 = tb0, ls0 = ( nL && nTL ) ? IT_TSB : 0;
+        const int lb1 = nL ? iPad : iAbove, ll1 = nL ? szL - 1 : 0;
+        const int dcT = w >= h ? mrl + w : -1, dcL = w <= h ? mrl + h : -1;      // DC: the samples next to the longer side(s)
+        if( nTL | nA | nL )
         {
-          const int cidx = tile_idx( fx0 - ( 1 + mrl ) - ox, fy0 - ( 1 + mrl ) - oy );       // the corner: row above (any kind of tile row), column left
-          const int lidx = tile_idx( fx0 - ( 1 + mrl ) - ox, fy0 - mrl - oy );                // first sample of the left column below the corner row
-          const int lstep = fy0 - mrl < oy ? 0 : IT_TSB;                                      // (rows above the CTU only occur with mrl = 0 or in the corner row)
-#pragma unroll
-          for( int u = 0; u < 3; u++ )
+#pragma unroll 1
+          for( int j = lane; j < n; j += 64 )
           {
-            const int j = lane + 64 * u;
-            tvv[u] = lvv[u] = dcv;
-            if( j < n )
-            {
-              if( j <= fTopLen + mrl ) tvv[u] = sh.tile[cidx + j];
-              if( j <= fLeftLen + mrl ) lvv[u] = j == 0 ? sh.tile[cidx] : ( lstep ? sh.tile[lidx + ( j - 1 ) * IT_TSB] : TILE( fx0 - ( 1 + mrl ), fy0 - mrl + ( j - 1 ) ) );
-            }
+            const int i = j - 1 - mrl;
+            const bool c = j <= mrl;
+            const int tv = sh.tile[c ? tb0 + ts0 * j : tb1 + min( i, tl1 )];
+            const int lv = sh.tile[c ? lb0 + ls0 * j : lb1 + min( i, ll1 ) * IT_TSB];
+            dT[j] = (pel_t) tv; dL[j] = (pel_t) lv;          // (entries past a line's end are written but never used; n <= 131 fits both arrays)
+            if( isDc ) dcPart += ( ( j > mrl && j <= dcT ) ? tv : 0 ) + ( ( j > mrl && j <= dcL ) ? lv : 0 );
           }
         }
         else
         {
-#pragma unroll
-          for( int u = 0; u < 3; u++ )
-          {
-            const int j = lane + 64 * u;
-            int tv = dcv, lv = dcv;
-            if( j < n && nAll )
-            {
-              if( nL > 0 )
-              {
-                const int szL = min( nL * unit, fLeftLen ), szA = min( nA * unit, fTopLen );
-                const int tpad = TILE( fx0 - ( 1 + mrl ), fy0 );
-                // left line
-                if( j == 0 ) lv = nTL ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) ) : tpad;
-                else if( j <= mrl ) lv = nTL ? TILE( fx0 - ( 1 + mrl ), fy0 - ( 1 + mrl ) + j ) : tpad;
-                else if( j <= fLeftLen + mrl ) { const int i = j - 1 - mrl; lv = TILE( fx0 - ( 1 + mrl ), fy0 + min( i, szL - 1 ) ); }
-                // top line
-                if( j <= mrl ) tv = nTL ? TILE( fx0 - ( 1 + mrl ) + j, fy0 - ( 1 + mrl ) ) : tpad;
-                else if( j <= fTopLen + mrl )
-                {
-                  const int i = j - 1 - mrl;
-                  if( nA ) tv = TILE( fx0 + min( i, szA - 1 ), fy0 - ( 1 + mrl ) );
-                  else     tv = nTL ? TILE( fx0 - 1, fy0 - ( 1 + mrl ) ) : tpad;      // = top[mrl]
-                }
-              }
-              else
-              {
-                const int szA = min( nA * unit, fTopLen );
-                const int t = TILE( fx0, fy0 - ( 1 + mrl ) );
-                lv = t;
-                if( j <= mrl ) tv = t;
-                else if( j <= fTopLen + mrl ) tv = TILE( fx0 + min( j - 1 - mrl, szA - 1 ), fy0 - ( 1 + mrl ) );
-              }
-            }
-            tvv[u] = tv; lvv[u] = lv;
-          }
-        }
-#pragma unroll
-        for( int u = 0; u < 3; u++ )
-        {
-          const int j = lane + 64 * u;
-          if( j < n )
-          {
-            if( j <= wT ) dT[j] = (pel_t) tvv[u];
-            if( j <= wL ) dL[j] = (pel_t) lvv[u];
-            if( isDc && !isp && j > mrl )
-            {
-              if( w >= h && j <= mrl + w ) dcPart += tvv[u];
-              if( w <= h && j <= mrl + h ) dcPart += lvv[u];
-            }
-          }
+          const int dcv = 1 << ( bd - 1 );
+          for( int j = lane; j < n; j += 64 ) { dT[j] = (pel_t) dcv; dL[j] = (pel_t) dcv; if( isDc ) dcPart += ( ( j > mrl && j <= dcT ) ? dcv : 0 ) + ( ( j > mrl && j <= dcL ) ? dcv : 0 ); }
         }
         if( isp )
         {
-          wave_lds_sync();
-#pragma unroll
-          for( int u = 0; u < 3; u++ )
+          IT_CSYNC();
+          dcPart = 0;
+#pragma unroll 1
+          for( int j = lane; j < n; j += 64 )
           {
-            const int j = lane + 64 * u;
-            if( j >= n ) continue;
             int tv, lv;
             // later partitions: the row above / column left comes from the reconstruction of the previous partition (padded with its
             // last sample), the other line continues the CU's line (:1003-1069)
@@ -3049,11 +3042,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
             }
             if( j <= topLen + mrl ) T[j] = (pel_t) tv;
             if( j <= leftLen + mrl ) L[j] = (pel_t) lv;
-            if( isDc && j > mrl )
-            {
-              if( w >= h && j <= mrl + w ) dcPart += tv;
-              if( w <= h && j <= mrl + h ) dcPart += lv;
-            }
+            if( isDc ) dcPart += ( ( j > mrl && j <= dcT ) ? tv : 0 ) + ( ( j > mrl && j <= dcL ) ? lv : 0 );
           }
         }
       }
@@ -3063,7 +3052,8 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         const int denom = w == h ? w << 1 : max( w, h );
         dcVal = ( wave_sum( dcPart ) + ( denom >> 1 ) ) >> ilog2( denom );
       }
-      wave_lds_sync();
+      IT_CSYNC();
+      IT_BT( 2 );
       // ---- MIP (PredictorMIP, MatrixIntraPrediction.cpp:68-330): boundary down-sampling, matrix-vector product, up-sampling
       if( mip )
       {
@@ -3080,7 +3070,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           for( int t2 = 0; t2 < f; t2++ ) sum += src[1 + qq * f + t2];
           W.lmSel[lane] = f > 1 ? ( sum + ( f >> 1 ) ) >> ilog2( f ) : sum;
         }
-        wave_lds_sync();
+        IT_CSYNC();
         {
           const int inSize = 2 * bdry;
           int in[8];
@@ -3101,9 +3091,9 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
             W.auxT[transp ? px * red + py : lane] = (pel_t) v;
           }
         }
-        wave_lds_sync();
+        IT_CSYNC();
         // horizontal up-sampling into every upV-th row of the block (predictionUpsampling1D :196)
-#pragma unroll 2
+#pragma unroll 1
         for( int i = lane; i < red * w; i += 64 )
         {
           const int kk = i >> lw, x = i & ( w - 1 ), row = ( upV - 1 ) + kk * upV;
@@ -3117,34 +3107,40 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           }
           sh.tile[tileBase + row * IT_TSB + x] = (pel_t) v;
         }
-        wave_lds_sync();
-        if( upV > 1 )
+        IT_CSYNC();
+        // vertical up-sampling (the rows that hold the horizontally up-sampled lines keep their values; the others only read those rows, so
+        // writing in place is safe) and the residual
+#pragma unroll 1
+        for( int i = lane; i < w * h; i += 64 )
         {
-          // the rows that hold the horizontally up-sampled lines keep their values; the others only read those rows, so writing in place is safe
-#pragma unroll 2
-          for( int i = lane; i < w * h; i += 64 )
+          const int x = i & ( w - 1 ), y = i >> lw;
+          const int j = y >> l2V, ii = ( y & ( upV - 1 ) ) + 1;
+          const int behind = sh.tile[tileBase + ( ( upV - 1 ) + j * upV ) * IT_TSB + x];
+          int v = behind;
+          if( ii != upV )
           {
-            const int x = i & ( w - 1 ), y = i >> lw;
-            const int j = y >> l2V, ii = ( y & ( upV - 1 ) ) + 1;
-            if( ii == upV ) continue;
-            const int before = j == 0 ? T[1 + x] : sh.tile[tileBase + ( ( upV - 1 ) + ( j - 1 ) * upV ) * IT_TSB + x], behind = sh.tile[tileBase + ( ( upV - 1 ) + j * upV ) * IT_TSB + x];
-            const int v = (int16_t) ( before * upV + ( upV >> 1 ) + ii * (int16_t) ( behind - before ) ) >> l2V;
-            sh.tile[tileBase + y * IT_TSB + x] = (pel_t) v;
+            const int before = j == 0 ? T[1 + x] : sh.tile[tileBase + ( ( upV - 1 ) + ( j - 1 ) * upV ) * IT_TSB + x];
+            v = (int16_t) ( before * upV + ( upV >> 1 ) + ii * (int16_t) ( behind - before ) ) >> l2V;
           }
-          wave_lds_sync();
+          if( !hasResi ) { if( ii != upV ) sh.tile[tileBase + y * IT_TSB + x] = (pel_t) v; }
+          else if( ii != upV ) sh.tile[tileBase + y * IT_TSB + x] = (pel_t) clip_pel( v + RES( i ), bd );
         }
         if( hasResi )
-#pragma unroll 2
-          for( int i = lane; i < w * h; i += 64 )
+        {
+          // (the kept rows last: the rows between them were interpolated from their prediction values)
+          IT_CSYNC();
+#pragma unroll 1
+          for( int i = lane; i < red * w; i += 64 )
           {
-            const int x = i & ( w - 1 ), y = i >> lw;
-            sh.tile[tileBase + y * IT_TSB + x] = (pel_t) clip_pel( sh.tile[tileBase + y * IT_TSB + x] + RES( i ), bd );
+            const int kk = i >> lw, x = i & ( w - 1 ), y = ( upV - 1 ) + kk * upV;
+            sh.tile[tileBase + y * IT_TSB + x] = (pel_t) clip_pel( sh.tile[tileBase + y * IT_TSB + x] + RES( ( y << lw ) + x ), bd );
           }
+        }
         IT_DONE()
         continue;
       }
       // ---- CCLM / MDLM (xGetLumaRecPixels :1403, xGetLMParameters :1694, predIntraChromaLM :519; 4:2:0): the down-sampled luma of the block
-      // and of the template positions is in registers already (intra_load_cclm_luma)
+      // (up to 256 samples) and of the template positions is in registers already (intra_load_cclm_luma)
       if( comp && dirMode >= 67 )
       {
         const uint32_t lm = it.tu;
@@ -3159,7 +3155,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
           else              cv = L[1 + ( actualLeft >> ( 2 + leftIs4 ) ) + ( lane - cntT ) * max( 1, actualLeft >> ( 1 + leftIs4 ) )];
           W.lmSel[lane] = (int16_t) LC.tpl; W.lmSel[4 + lane] = cv;
         }
-        wave_lds_sync();
+        IT_CSYNC();
         int selL[4] = { 0, 0, 0, 0 }, selC[4] = { 0, 0, 0, 0 };
         const int cnt = cntT + cntL;
         for( int qq = 0; qq < 4; qq++ ) if( qq < cnt ) { selL[qq] = W.lmSel[qq]; selC[qq] = W.lmSel[4 + qq]; }
@@ -3195,14 +3191,30 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
             b = minC - ( ( a * minL ) >> shift );
           }
         }
-#pragma unroll
-        for( int e = 0; e < 16; e++ )
+        if( wh <= IT_CCLM_REGS )
         {
-          const int i = e * 64 + lane;
-          if( e * 64 < wh && i < wh )
+#pragma unroll
+          for( int e = 0; e < IT_CCLM_REGS / 64; e++ )
           {
-            const int x = i & ( w - 1 ), y = yb + ( i >> lw );
-            const int t = (int16_t) ( ( e & 1 ) ? LC.v[e >> 1] >> 16 : LC.v[e >> 1] & 0xffff );
+            const int i = e * 64 + lane;
+            if( e * 64 < wh && i < wh )
+            {
+              const int t = (int16_t) ( ( e & 1 ) ? LC.v[e >> 1] >> 16 : LC.v[e >> 1] & 0xffff );
+              int v = clip_pel( ( ( a * t ) >> shift ) + b, bd );
+              if( hasResi ) { const int r = W.resi[i]; v = clip_pel( v + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); }
+              sh.tile[tileBase + ( i >> lw ) * IT_TSB + ( i & ( w - 1 ) )] = (pel_t) v;
+            }
+          }
+        }
+        else
+        {
+          // a large block (512 / 1024 samples): the luma is fetched here
+          const bool bLeft = ( lm >> 18 ) & 1, bAbove = ( lm >> 20 ) & 1, colloc = pic.colloc != 0;
+#pragma unroll 2
+          for( int i = lane; i < wh; i += 64 )
+          {
+            const int x = i & ( w - 1 ), y = i >> lw;
+            const int t = (int16_t) intra_cclm_luma_at( pic.plane[0], pic.stride[0], x0 << 1, y0 << 1, x, y, bLeft, bAbove, colloc );
             int v = clip_pel( ( ( a * t ) >> shift ) + b, bd );
             if( hasResi ) { const int r = W.resi[i]; v = clip_pel( v + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); }
             sh.tile[tileBase + y * IT_TSB + x] = (pel_t) v;
@@ -3211,152 +3223,144 @@ __global__ __launch_bounds__( 256 ) void k_intra( PicDev pic, DevPlanes reco, De
         IT_DONE()
         continue;
       }
-      // ---- reference smoothing, in place: every lane reads its three neighbours of both lines before any lane writes
+      // ---- reference smoothing (xFilterReferenceSamples :1251): into the second pair of lines
+      pel_t* Tp = T; pel_t* Lp = L;
       if( useFilt )
       {
-        int ft[3], fl[3];
+        pel_t* const fT = W.auxT + IT_NEG; pel_t* const fL = W.auxL + IT_NEG;
         const int mx = max( topLen, leftLen );
-#pragma unroll
-        for( int u = 0; u < 3; u++ )
+#pragma unroll 1
+        for( int j = lane; j <= mx; j += 64 )
         {
-          const int j = lane + 64 * u;
-          ft[u] = fl[u] = 0;
-          if( j == 0 ) ft[u] = fl[u] = ( L[1] + 2 * T[0] + T[1] + 2 ) >> 2;
-          else if( j <= mx )
-          {
-            if( j < topLen ) ft[u] = ( T[j + 1] + 2 * T[j] + T[j - 1] + 2 ) >> 2;
-            if( j < leftLen ) fl[u] = ( L[j + 1] + 2 * L[j] + L[j - 1] + 2 ) >> 2;
-          }
+          const int jm = max( j - 1, 0 );
+          const int t1 = T[j + 1], t0_ = T[j], tm = j ? (int) T[jm] : (int) L[1];
+          const int l1 = L[j + 1], l0_ = L[j], lm_ = j ? (int) L[jm] : (int) T[1];
+          fT[j] = (pel_t) ( j < topLen ? ( t1 + 2 * t0_ + tm + 2 ) >> 2 : t0_ );          // (the last sample of a line stays as it is; index 0 is the same corner value in both)
+          fL[j] = (pel_t) ( j < leftLen ? ( l1 + 2 * l0_ + lm_ + 2 ) >> 2 : l0_ );
         }
-        wave_lds_sync();
-#pragma unroll
-        for( int u = 0; u < 3; u++ )
-        {
-          const int j = lane + 64 * u;
-          if( j < topLen ) T[j] = (pel_t) ft[u];          // (the last sample of a line stays as it is)
-          if( j < leftLen ) L[j] = (pel_t) fl[u];
-        }
-        wave_lds_sync();
+        Tp = fT; Lp = fL;
+        IT_CSYNC();
       }
       // the main / side reference of xPredIntraAng (:640-690): index j is relative to the block (after the multi-reference-line offset);
       // negative indices are the side reference projected with invAngle - written in front of the main reference once per block -,
       // indices beyond the end replicate the last sample
-      pel_t* const Mn = isVer ? T : L;
-      const pel_t* const Sd = isVer ? L : T;
+      pel_t* const Mn = isVer ? Tp : Lp;
+      const pel_t* const Sd = isVer ? Lp : Tp;
       const int refEnd = ( isVer ? topLen : leftLen ) + mrl;
       if( angle < 0 )
       {
-        const int sizeSide = isVer ? h : w;
         const int k = 1 + lane;                                 // (the lowest index read is ( angle * ( mrl + bh ) >> 5 ) + mrl >= -bh >= -64: one round)
-        int pv = 0;
-        if( k <= bh ) pv = Sd[min( ( k * invAngle + 256 ) >> 9, sizeSide )];
-        wave_lds_sync();
-        if( k <= bh ) Mn[-k] = (pel_t) pv;
-        wave_lds_sync();
+        if( k <= bh ) Mn[-k] = Sd[min( ( k * invAngle + 256 ) >> 9, bh )];
+        IT_CSYNC();
       }
-      // store of one group: CIIP blend, residual, clipping, the tile (8-byte accesses where the positions allow it)
-#define IT_STORE_GROUP() \
-      if( vec ) \
-      { \
-        const int to = tileBase + yy * IT_TSB + xx0, ri = ( ( yy - yb ) << lw ) + xx0; \
-        if( wIntra ) { const uint2 tv = *reinterpret_cast<const uint2*>( &sh.tile[to] ); const int ip[4] = { (int) ( tv.x & 0xffff ), (int) ( tv.x >> 16 ), (int) ( tv.y & 0xffff ), (int) ( tv.y >> 16 ) }; \
-                       for( int e = 0; e < 4; e++ ) v[e] = ( ( 4 - wIntra ) * ip[e] + wIntra * v[e] + 2 ) >> 2; }     /* predBlendIntraCiip (:935-944): the tile holds the inter prediction */ \
-        if( hasResi ) { const uint2 rv = *reinterpret_cast<const uint2*>( &W.resi[ri] ); const int r[4] = { (int16_t) ( rv.x & 0xffff ), (int16_t) ( rv.x >> 16 ), (int16_t) ( rv.y & 0xffff ), (int16_t) ( rv.y >> 16 ) }; \
-                        for( int e = 0; e < 4; e++ ) if( !ispGrp || ( ( ispResi >> ( ( xx0 + e ) >> ( 2 - ispGrp ) ) ) & 1 ) ) v[e] = clip_pel( v[e] + ( csOn ? lmcs_scale_resi( r[e], csScale, bd ) : r[e] ), bd ); } \
-        *reinterpret_cast<uint2*>( &sh.tile[to] ) = make_uint2( ( v[0] & 0xffff ) | ( (uint32_t) v[1] << 16 ), ( v[2] & 0xffff ) | ( (uint32_t) v[3] << 16 ) ); \
-      } \
-      else \
-      { \
-        for( int e = 0; e < 4; e++ ) if( e < g ) \
-        { \
-          const int x = tr ? yy : xx0 + e, y = tr ? xx0 + e : yy; \
-          const int to = tileBase + y * IT_TSB + x; \
-          int vv = v[e]; \
-          if( wIntra ) vv = ( ( 4 - wIntra ) * sh.tile[to] + wIntra * vv + 2 ) >> 2; \
-          if( hasResi && ( !ispGrp || ( ( ispResi >> ( x >> ( 2 - ispGrp ) ) ) & 1 ) ) ) { const int r = W.resi[( ( y - yb ) << lw ) + x]; vv = clip_pel( vv + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); } \
-          sh.tile[to] = (pel_t) vv; \
-        } \
-      }
-      if( !angular )
       {
-        // ---- planar (:154), DC (:541), BDPCM (:850) and their position-dependent combination (IntraPredSampleFilterCore :212)
-        const int tR = T[w + 1], lB = L[h + 1];
+        // ---- prediction, one group of samples per lane and round.  Planar (:154), DC (:541), BDPCM (:850) with their position-dependent
+        // combination (IntraPredSampleFilterCore :212); angular (xPredIntraAng :592) in one 4-tap form for every kind - c = the cubic / Gauss
+        // filter of the row's fraction (luma), { 0, 64 - 2 f, 2 f, 0 } for the 2-tap chroma interpolation, { 0, 64, 0, 0 } for whole-sample
+        // angles - over 7 neighbouring reference samples
+        const int tR = Tp[w + 1], lB = Lp[h + 1], t0 = Tp[0];
         const bool pdpc = !bdpcm && pdpcOK;
-#pragma unroll 2
-        for( int gi = lane; gi < ngroups; gi += 64 )
-        {
-          const int yy = yyb + ( gi >> lgpr ), xx0 = xxb + ( ( gi & ( ( 1 << lgpr ) - 1 ) ) << gl );
-          const int lft = L[yy + 1];
-          int tp[4], v[4];
-          for( int e = 0; e < 4; e++ ) tp[e] = e < g ? (int) T[xx0 + e + 1] : 0;
-          for( int e = 0; e < 4; e++ )
-          {
-            const int x = xx0 + e;
-            if( bdpcm ) v[e] = bdpcm == 1 ? lft : tp[e];
-            else if( dirMode == 0 )
-            {
-              const int hor = ( lft << lw ) + ( x + 1 ) * ( tR - lft );
-              const int ver = ( tp[e] << lh ) + ( yy + 1 ) * ( lB - tp[e] );
-              v[e] = (int16_t) ( ( ( hor << lh ) + ( ver << lw ) + ( 1 << ( lw + lh ) ) ) >> ( 1 + lw + lh ) );
-            }
-            else v[e] = dcVal;
-            if( pdpc )
-            {
-              const int wTp = 32 >> min( 31, ( yy << 1 ) >> pscale ), wLp = 32 >> min( 31, ( x << 1 ) >> pscale );
-              v[e] = (int16_t) ( v[e] + ( ( wLp * ( lft - v[e] ) + wTp * ( tp[e] - v[e] ) + 32 ) >> 6 ) );
-            }
-          }
-          IT_STORE_GROUP()
-        }
-      }
-      else
-      {
-        // ---- angular (xPredIntraAng :592): one 4-tap form for every kind - c = the cubic / Gauss filter of the row's fraction (luma), { 0, 64 - 2 f, 2 f, 0 }
-        // for the 2-tap chroma interpolation, { 0, 64, 0, 0 } for whole-sample angles - over 7 neighbouring reference samples
         const bool frac = ( absAng & 0x1F ) != 0;
-        const int pdpcLev = angle == 0 ? ( pdpcOK ? min( pscale == 0 ? 3 : pscale == 1 ? 6 : pscale == 2 ? 12 : 24, bw ) : 0 ) : doAngPdpc ? min( 3 << angScale, bw ) : 0;
-        const int t0 = T[0];
-#pragma unroll 2
+        const int pdpcLev = !angular ? 0 : angle == 0 ? ( pdpcOK ? min( pscale == 0 ? 3 : pscale == 1 ? 6 : pscale == 2 ? 12 : 24, bw ) : 0 ) : doAngPdpc ? min( 3 << angScale, bw ) : 0;
+        const int maxv = ( 1 << bd ) - 1;
+#pragma unroll 1
         for( int gi = lane; gi < ngroups; gi += 64 )
         {
           const int yy = yyb + ( gi >> lgpr ), xx0 = xxb + ( ( gi & ( ( 1 << lgpr ) - 1 ) ) << gl );
-          const int deltaPos = angle * ( 1 + mrl + yy );
-          const int di = deltaPos >> 5, df = deltaPos & 31;
-          const int kb = di + xx0 + mrl;
-          int r[7];
-          for( int t = 0; t < 7; t++ ) r[t] = t < g + 3 ? (int) Mn[min( kb + t, refEnd )] : 0;
-          int c0 = 0, c1 = 64, c2 = 0, c3 = 0;
-          if( frac )
-          {
-            if( comp ) { c1 = 64 - 2 * df; c2 = 2 * df; }
-            else if( cubic ) { const uint2 cv = *reinterpret_cast<const uint2*>( sh.cfilt[df] ); c0 = (int16_t) ( cv.x & 0xffff ); c1 = (int16_t) ( cv.x >> 16 ); c2 = (int16_t) ( cv.y & 0xffff ); c3 = (int16_t) ( cv.y >> 16 ); }
-            else { c0 = 16 - ( df >> 1 ); c1 = 32 - ( df >> 1 ); c2 = 16 + ( df >> 1 ); c3 = df >> 1; }     // g_intraGaussFilter (:96)
-          }
           int v[4];
-          for( int e = 0; e < 4; e++ ) v[e] = clip_pel( (int16_t) ( ( c0 * r[e] + c1 * r[e + 1] + c2 * r[e + 2] + c3 * r[e + 3] + 32 ) >> 6 ), bd );
-          if( xx0 < pdpcLev )
+          if( !angular )
           {
-            if( angle == 0 )
+            const int lft = Lp[yy + 1];
+            int tp[4];
+            for( int e = 0; e < 4; e++ ) tp[e] = Tp[xx0 + e + 1];
+            const int wTp = 32 >> min( 31, ( yy << 1 ) >> pscale );
+            for( int e = 0; e < 4; e++ )
             {
-              const int sd = Sd[yy + 1];
-              for( int e = 0; e < 4; e++ ) if( xx0 + e < pdpcLev ) { const int wLp = 32 >> min( 31, ( ( xx0 + e ) << 1 ) >> pscale ); v[e] = clip_pel( ( wLp * ( sd - t0 ) + ( v[e] << 6 ) + 32 ) >> 6, bd ); }
-            }
-            else
-              for( int e = 0; e < 4; e++ ) if( e < g && xx0 + e < pdpcLev )
+              const int x = xx0 + e;
+              if( bdpcm ) v[e] = bdpcm == 1 ? lft : tp[e];
+              else if( dirMode == 0 )
               {
-                const int xx = xx0 + e;
-                const int invAngleSum = 256 + ( xx + 1 ) * invAngle;
-                const int wLp = 32 >> ( 2 * xx >> angScale );
-                v[e] = (int16_t) ( v[e] + ( ( wLp * ( Sd[yy + ( invAngleSum >> 9 ) + 1] - v[e] ) + 32 ) >> 6 ) );
+                const int hor = ( lft << lw ) + __mul24( x + 1, tR - lft );
+                const int ver = ( tp[e] << lh ) + __mul24( yy + 1, lB - tp[e] );
+                v[e] = (int16_t) ( ( ( hor << lh ) + ( ver << lw ) + ( 1 << ( lw + lh ) ) ) >> ( 1 + lw + lh ) );
               }
+              else v[e] = dcVal;
+              if( pdpc )
+              {
+                const int wLp = 32 >> min( 31, ( x << 1 ) >> pscale );
+                v[e] = (int16_t) ( v[e] + ( ( __mul24( wLp, lft - v[e] ) + __mul24( wTp, tp[e] - v[e] ) + 32 ) >> 6 ) );
+              }
+            }
           }
-          IT_STORE_GROUP()
+          else
+          {
+            const int deltaPos = __mul24( angle, 1 + mrl + yy );
+            const int di = deltaPos >> 5, df = deltaPos & 31;
+            const int kb = di + xx0 + mrl;
+            int r[7];
+            for( int t = 0; t < 7; t++ ) r[t] = Mn[min( kb + t, refEnd )];
+            int c0 = 0, c1 = 64, c2 = 0, c3 = 0;
+            if( frac )
+            {
+              if( comp ) { c1 = 64 - 2 * df; c2 = 2 * df; }
+              else if( cubic ) { const uint2 cv = *reinterpret_cast<const uint2*>( sh.cfilt[df] ); c0 = (int16_t) ( cv.x & 0xffff ); c1 = (int16_t) ( cv.x >> 16 ); c2 = (int16_t) ( cv.y & 0xffff ); c3 = (int16_t) ( cv.y >> 16 ); }
+              else { c0 = 16 - ( df >> 1 ); c1 = 32 - ( df >> 1 ); c2 = 16 + ( df >> 1 ); c3 = df >> 1; }     // g_intraGaussFilter (:96)
+            }
+            for( int e = 0; e < 4; e++ ) v[e] = min( max( ( __mul24( c0, r[e] ) + __mul24( c1, r[e + 1] ) + __mul24( c2, r[e + 2] ) + __mul24( c3, r[e + 3] ) + 32 ) >> 6, 0 ), maxv );
+            if( xx0 < pdpcLev )
+            {
+              // (the weights of positions at and beyond the level are zero by themselves: 32 >> 6)
+              if( angle == 0 )
+              {
+                const int sd = Sd[yy + 1] - t0;
+                for( int e = 0; e < 4; e++ ) { const int wLp = 32 >> min( 31, ( ( xx0 + e ) << 1 ) >> pscale ); v[e] = min( max( ( __mul24( wLp, sd ) + ( v[e] << 6 ) + 32 ) >> 6, 0 ), maxv ); }
+              }
+              else
+                for( int e = 0; e < 4; e++ )
+                {
+                  const int xx = xx0 + e;
+                  const int wLp = 32 >> min( 31, 2 * xx >> angScale );
+                  const int sv = Sd[min( yy + ( ( 256 + ( xx + 1 ) * invAngle ) >> 9 ) + 1, IT_MAXREF )];
+                  v[e] = (int16_t) ( v[e] + ( ( __mul24( wLp, sv - v[e] ) + 32 ) >> 6 ) );
+                }
+            }
+          }
+          // store of the group: CIIP blend, residual, clipping, the tile (8-byte accesses where the positions allow it)
+          if( vec )
+          {
+            const int to = tileBase + yy * IT_TSB + xx0, ri = ( ( yy - yb ) << lw ) + xx0;
+            if( wIntra )
+            {
+              // predBlendIntraCiip (:935-944): the tile holds the inter prediction
+              const uint2 tv = *reinterpret_cast<const uint2*>( &sh.tile[to] ); const int ip[4] = { (int) ( tv.x & 0xffff ), (int) ( tv.x >> 16 ), (int) ( tv.y & 0xffff ), (int) ( tv.y >> 16 ) };
+              for( int e = 0; e < 4; e++ ) v[e] = ( ( 4 - wIntra ) * ip[e] + wIntra * v[e] + 2 ) >> 2;
+            }
+            if( hasResi )
+            {
+              const uint2 rv = *reinterpret_cast<const uint2*>( &W.resi[ri] ); const int r[4] = { (int16_t) ( rv.x & 0xffff ), (int16_t) ( rv.x >> 16 ), (int16_t) ( rv.y & 0xffff ), (int16_t) ( rv.y >> 16 ) };
+              for( int e = 0; e < 4; e++ ) if( !ispGrp || ( ( ispResi >> ( ( xx0 + e ) >> ( 2 - ispGrp ) ) ) & 1 ) ) v[e] = clip_pel( v[e] + ( csOn ? lmcs_scale_resi( r[e], csScale, bd ) : r[e] ), bd );
+            }
+            *reinterpret_cast<uint2*>( &sh.tile[to] ) = make_uint2( ( v[0] & 0xffff ) | ( (uint32_t) v[1] << 16 ), ( v[2] & 0xffff ) | ( (uint32_t) v[3] << 16 ) );
+          }
+          else
+          {
+            for( int e = 0; e < 4; e++ ) if( e < g )
+            {
+              const int x = tr ? yy : xx0 + e, y = tr ? xx0 + e : yy;
+              const int to = tileBase + y * IT_TSB + x;
+              int vv = v[e];
+              if( wIntra ) vv = ( ( 4 - wIntra ) * sh.tile[to] + wIntra * vv + 2 ) >> 2;
+              if( hasResi && ( !ispGrp || ( ( ispResi >> ( x >> ( 2 - ispGrp ) ) ) & 1 ) ) ) { const int r = W.resi[( ( y - yb ) << lw ) + x]; vv = clip_pel( vv + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); }
+              sh.tile[to] = (pel_t) vv;
+            }
+          }
         }
       }
-#undef IT_STORE_GROUP
       IT_DONE()
     }
 #undef IT_DONE
+#undef IT_BT
+#undef IT_CSYNC
   }
   __syncthreads();                    // every block of the unit is in the tile
   IT_TRACE( 3 );
@@ -3418,23 +3422,39 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   if( !numActive ) return;
   numWorkgroups = std::max( 1, std::min( numWorkgroups, numActive ) );
   hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + (size_t) numActive ), s );
+  IntraPic ip;
+  for( int c = 0; c < 3; c++ ) { ip.plane[c] = reco.p[c]; ip.resi[c] = resi.p[c]; ip.stride[c] = reco.stride[c]; ip.rstride[c] = resi.stride[c]; ip.w[c] = reco.w[c]; ip.h[c] = reco.h[c]; }
+  ip.csVpdu = pic.csVpdu; ip.lmcs = pic.lmcs; ip.vpdusX = pic.vpdusX; ip.vpduLog2 = pic.vpduLog2; ip.ctusX = pic.ctus_x; ip.log2Ctu = pic.hdr.log2_ctu;
+  ip.bitDepth = pic.hdr.bit_depth; ip.width = pic.hdr.width; ip.height = pic.hdr.height; ip.colloc = ( pic.hdr.tool_flags & VVR_TOOL_CCLM_COLLOC ) ? 1 : 0;
 #ifndef VVR_INTRA_DEV
-  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync );
+  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, units, numActive, sync );
 #else
   static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
   static const bool tr = getenv( "VVR_INTRA_TRACE" ) != nullptr;
-  unsigned long long* trace = nullptr;
-  if( tr ) { hipMalloc( (void**) &trace, sizeof( unsigned long long ) * 8 * (size_t) numActive ); hipMemsetAsync( trace, 0, sizeof( unsigned long long ) * 8 * (size_t) numActive, s ); }
-  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, pic, reco, resi, items, units, numActive, sync, dbg, trace );
+  unsigned long long* trace = nullptr, * btrace = nullptr;
+  const size_t nItems = 1 << 20;      // (block timeline: sized generously, indexed by item)
+  if( tr ) { hipMalloc( (void**) &trace, sizeof( unsigned long long ) * 8 * (size_t) numActive ); hipMemsetAsync( trace, 0, sizeof( unsigned long long ) * 8 * (size_t) numActive, s );
+             hipMalloc( (void**) &btrace, sizeof( unsigned long long ) * 4 * nItems ); hipMemsetAsync( btrace, 0, sizeof( unsigned long long ) * 4 * nItems, s ); }
+  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, units, numActive, sync, dbg, trace, btrace );
   if( tr )
   {
-    // developer timeline: ticket, phase time stamps (100 MHz), block count / unit word, number of producers
-    std::vector<unsigned long long> h( 8 * (size_t) numActive );
+    // developer timeline: ticket, phase time stamps (100 MHz), block count / unit word, number of producers; per block four shader-clock stamps
+    std::vector<unsigned long long> h( 8 * (size_t) numActive ), hb( 4 * nItems );
     hipStreamSynchronize( s );
     hipMemcpy( h.data(), trace, h.size() * sizeof( unsigned long long ), hipMemcpyDeviceToHost );
-    hipFree( trace );
+    hipMemcpy( hb.data(), btrace, hb.size() * sizeof( unsigned long long ), hipMemcpyDeviceToHost );
+    hipFree( trace ); hipFree( btrace );
+    std::vector<IntraUnit> hu( numActive ); hipMemcpy( hu.data(), units, sizeof( IntraUnit ) * (size_t) numActive, hipMemcpyDeviceToHost );
+    size_t maxItem = 0; for( auto& u : hu ) maxItem = std::max<size_t>( maxItem, u.i1 );
+    std::vector<IntraItem> hi( maxItem ); hipMemcpy( hi.data(), items, sizeof( IntraItem ) * maxItem, hipMemcpyDeviceToHost );
     char name[128]; snprintf( name, sizeof( name ), "gpurun_out/intra_trace_poc%d.bin", pic.hdr.poc );
     if( FILE* f = fopen( name, "wb" ) ) { fwrite( h.data(), sizeof( unsigned long long ), h.size(), f ); fclose( f ); }
+    snprintf( name, sizeof( name ), "gpurun_out/intra_btrace_poc%d.bin", pic.hdr.poc );
+    if( FILE* f = fopen( name, "wb" ) ) { fwrite( hb.data(), sizeof( unsigned long long ), 4 * maxItem, f ); fclose( f ); }
+    snprintf( name, sizeof( name ), "gpurun_out/intra_units_poc%d.bin", pic.hdr.poc );
+    if( FILE* f = fopen( name, "wb" ) ) { fwrite( hu.data(), sizeof( IntraUnit ), hu.size(), f ); fclose( f ); }
+    snprintf( name, sizeof( name ), "gpurun_out/intra_items_poc%d.bin", pic.hdr.poc );
+    if( FILE* f = fopen( name, "wb" ) ) { fwrite( hi.data(), sizeof( IntraItem ), hi.size(), f ); fclose( f ); }
   }
 #endif
 }
