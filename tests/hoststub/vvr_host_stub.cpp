@@ -86,7 +86,8 @@ void launch_copy_bytes( hipStream_t, const void*, void*, size_t ) {}
 void launch_mc_affine( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int ) {}
 void launch_mc_dmvr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int32_t* ) {}
 static int g_lastIntraWg = 0;
-void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, const IntraUnit*, int numUnits, int numWg, int* sync ) { g_lastIntraWg = numWg; g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
+size_t intra_sync_ints( int numUnits, int numItems ) { return ( ( (size_t) 1 + (size_t) numUnits + 63 ) & ~(size_t) 63 ) + (size_t) numItems * 64; }
+void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int, const IntraUnit*, int numUnits, int numWg, int* sync ) { g_lastIntraWg = numWg; g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
 // the two output-stage kernels have functional stand-ins (a few plain loops with the kernels' contract: packed window; per row the checksum
 // share or the CRC register reached from 0), so that the host half of vvr_read_output / vvr_picture_hash - window geometry, chaining the rows'
 // CRC pieces - is checked against the reference's own functions without a GPU

@@ -318,7 +318,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   {
     // ticket + one flag per unit: a picture with more units than the lane's buffer holds gets a larger one; work queued on the lane may
     // still use the old buffer, so the lane is drained first (rare: see vvr_create)
-    const size_t need = 1 + (size_t) q->numActive;
+    const size_t need = intra_sync_ints( q->numActive, q->numIntra );
     if( need > c->syncCap[lane] )
     {
       HIPCHK( c, hipStreamSynchronize( s ) );
@@ -328,7 +328,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
       c->syncBuf[lane] = p; c->syncCap[lane] = need * 2;
     }
   }
-  if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->units, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
+  if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
   if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
@@ -752,9 +752,10 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
     }
     const int ctu = 1 << cfg->log2_ctu;
     const size_t numCtu = (size_t) ( ( cfg->max_width + ctu - 1 ) / ctu ) * ( ( cfg->max_height + ctu - 1 ) / ctu );
-    // sized for the usual pictures (a 4K B picture of the benchmark has about 6 units per CTU, an intra picture 3); pictures with more
-    // units than that (many isolated small intra CUs) make the lane's buffer grow when they are submitted
-    for( int s = 0; s < nl && ok; s++ ) { int* p = nullptr; const size_t cap = 1 + 24 * numCtu; ok = hipMalloc( (void**) &p, sizeof( int ) * cap ) == hipSuccess; if( ok ) { c->syncBuf.push_back( p ); c->syncCap.push_back( cap ); } }
+    // sized for the usual pictures (a 4K B picture of the benchmark has about 6 units per CTU, an intra picture 3, and about 100 blocks per CTU
+    // with a 256-byte parameter record each: 13 MB per lane at 4K); pictures with more units or blocks than that (many isolated small intra
+    // CUs) make the lane's buffer grow when they are submitted
+    for( int s = 0; s < nl && ok; s++ ) { int* p = nullptr; const size_t cap = intra_sync_ints( (int) ( 24 * numCtu ), (int) ( 100 * numCtu ) ); ok = hipMalloc( (void**) &p, sizeof( int ) * cap ) == hipSuccess; if( ok ) { c->syncBuf.push_back( p ); c->syncCap.push_back( cap ); } }
   }
   if( ok )
   {

@@ -130,5 +130,6 @@ void launch_output_window( hipStream_t s, const pel_t* src, int stride, int w, i
 void launch_plane_hash_rows( hipStream_t s, const pel_t* plane, int stride, int w, int h, int two, int crcMode, uint32_t* out );   // per row: checksum share / CRC piece
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );
-void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numUnits, int numWorkgroups, int* sync );
+void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numUnits, int numWorkgroups, int* sync );
+size_t intra_sync_ints( int numUnits, int numItems );      // ints `sync` has to hold: ticket, unit flags, the blocks' parameter records
 

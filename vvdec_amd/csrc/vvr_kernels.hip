@@ -2590,7 +2590,174 @@ __device__ __forceinline__ void intra_load_cclm_luma( IntraLumaRegs& R, const In
   }
 }
 
-__global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem* __restrict__ items,
+// ---- per-block parameters, computed once per picture by a pass of its own (k_intra_setup: one thread per block) ---------------------------------
+// Everything about a block that does not depend on sample values - geometry, where in the tile its reference samples come from, the mode's
+// angle and filters, the loop bounds - is uniform scalar work, a few hundred instructions per block.  On a wavefront that predicts the block
+// by itself that work sat on the serial path (or kept ~100 scalar registers alive across it: the compiler spilled them into vector lanes).  The
+// pass below writes the values to a 64-dword record per block; k_intra loads the record with one instruction (lane k holds value k) and
+// takes a value out with v_readlane where it is used.
+enum {
+  C_FLAGS = 0, C_POS, C_GEO, C_TILEBASE, C_N, C_TB0, C_TS0, C_TB1, C_TL1, C_LB0, C_LS0, C_LB1, C_LL1, C_DCT, C_DCL, C_DCDEN,
+  C_TOPLEN, C_LEFTLEN, C_ANGLE, C_INVANGLE, C_REFEND, C_BH, C_PDPCLEV, C_ANGSCALE, C_PSCALE, C_NGROUPS, C_XXB, C_YYB, C_CSIDX, C_ORIGIN,
+  C_COUNT
+};
+#define IT_CTX 64          // dwords per record
+// C_FLAGS bits
+#define CF_RESI    ( 1u << 0 )
+#define CF_CSON    ( 1u << 1 )
+#define CF_DC      ( 1u << 2 )
+#define CF_FILT    ( 1u << 3 )
+#define CF_ANG     ( 1u << 4 )
+#define CF_TR      ( 1u << 5 )
+#define CF_FRAC    ( 1u << 6 )
+#define CF_CUBIC   ( 1u << 7 )
+#define CF_VEC     ( 1u << 8 )
+#define CF_ANY     ( 1u << 9 )
+#define CF_ISP     ( 1u << 10 )
+#define CF_MIP     ( 1u << 11 )
+#define CF_IBC     ( 1u << 12 )
+#define CF_CCLM    ( 1u << 13 )
+#define CF_PDPC    ( 1u << 14 )
+#define CF_STASHED ( 1u << 15 )
+#define CF_PLANAR  ( 1u << 16 )
+#define CF_NEG     ( 1u << 17 )
+#define CF_ANG0    ( 1u << 18 )
+// C_GEO: lw | lh << 4 | log2( rows of the band ) << 8 | first row of the band << 12 (7 bits) | mrl << 19 | wIntra << 21 | bdpcm << 23 | log2 group size << 25 | log2 groups per row << 27 | indep << 30 ... kept in C_WAIT instead
+#define CG_LW( g )     ( ( g ) & 15 )
+#define CG_LH( g )     ( ( ( g ) >> 4 ) & 15 )
+#define CG_LROWS( g )  ( ( ( g ) >> 8 ) & 15 )
+#define CG_YB( g )     ( ( ( g ) >> 12 ) & 127 )
+#define CG_MRL( g )    ( ( ( g ) >> 19 ) & 3 )
+#define CG_WINTRA( g ) ( ( ( g ) >> 21 ) & 3 )
+#define CG_BDPCM( g )  ( ( ( g ) >> 23 ) & 3 )
+#define CG_GL( g )     ( ( ( g ) >> 25 ) & 3 )
+#define CG_LGPR( g )   ( ( ( g ) >> 27 ) & 7 )
+
+__global__ __launch_bounds__( 256 ) void k_intra_setup( IntraPic pic, const IntraItem* __restrict__ items, int numItems, uint32_t* __restrict__ ctx )
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if( idx >= numItems ) return;
+  const IntraItem it = items[idx];
+  if( it.mode == IT_MODE_RESI_ADD ) return;                // (residual-add items never enter the block loop)
+  uint32_t* __restrict__ c = ctx + (size_t) idx * IT_CTX;
+  const int comp = IT_COMP( it ), cs = comp ? 1 : 0;
+  const int l2 = pic.log2Ctu - cs;
+  const int x0 = it.x, y0 = it.y, ox = ( x0 >> l2 ) << l2, oy = ( y0 >> l2 ) << l2;
+  const int lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
+  const int rows = h >> IT_LPARTS( it ), yb = IT_PART( it ) * rows, wh = rows << lw;
+  const bool mip = !comp && ( it.flags & IT_F_MIP );      // (chroma: the same bit says LMCS chroma residual scaling)
+  const int mrl = ( it.flags & IT_F_MIP ) ? 0 : ( it.flags >> 4 ) & 3;
+  const bool isp = !comp && ( it.flags & IT_F_ISP ) == IT_F_ISP;
+  const int wIntra = isp ? 0 : it.flags >> 6;              // CIIP: weight of the planar intra part, 0 = ordinary intra block
+  const uint32_t ispw = isp ? it.tu : 0;
+  const int ispDx = ispw & 63, ispDy = ( ispw >> 6 ) & 63, cuW = 1 << ( ( ispw >> 12 ) & 7 ), cuH = 1 << ( ( ispw >> 15 ) & 7 );
+  const bool ispVer = ( ispw >> 18 ) & 1;
+  const int bdpcm = isp ? 0 : ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
+  const int dirMode = it.mode;
+  const bool ibc = dirMode == IT_MODE_IBC, cclm = comp && dirMode >= 67 && dirMode <= 69;
+  // reference line lengths; ISP: CU size + partition size along the split, twice the CU size across (IntraPrediction.cpp:1000-1001).
+  // f*: the block whose line is fetched from the picture (ISP: the whole CU, initIntraPatternChTypeISP :966-999)
+  const int topLen = isp ? ( ispVer ? cuW + w : 2 * cuW ) : 2 * w, leftLen = isp ? ( ispVer ? 2 * cuH : cuH + h ) : 2 * h;
+  const int fx0 = x0 - ispDx, fy0 = y0 - ispDy, fTopLen = isp ? 2 * cuW : topLen, fLeftLen = isp ? 2 * cuH : leftLen;
+  const int unit = 4 >> cs;
+  const int nTL = it.nTL & 1, nA = it.nA, nL = it.nL;
+  const bool isDc = !bdpcm && dirMode == 1;
+  // reference smoothing (useFilteredIntraRefSamples :1301), mode-specific set-up (xPredIntraAng :592-615)
+  bool useFilt = false;
+  if( !comp && !mrl && !bdpcm && dirMode != 1 && !isp && dirMode <= 66 && !mip )
+  {
+    if( dirMode == 0 ) useFilt = w * h > 32;
+    else
+    {
+      const int pm = intra_wide_angle( w, h, dirMode );
+      const int diff = min( iabs( pm - 18 ), iabs( pm - 50 ) );
+      const int am = pm >= 34 ? pm - 50 : -( pm - 18 );
+      useFilt = diff > c_intraFilterThr[( lw + lh ) >> 1] && ( ( c_angTable[iabs( am )] & 0x1F ) == 0 );
+    }
+  }
+  const bool pdpcOK = ( w >= 4 && h >= 4 ) && mrl == 0;
+  int predMode = 0, angle = 0, invAngle = 0, absAng = 0; bool isVer = true;
+  const bool angular = !bdpcm && dirMode > 1 && dirMode <= 66 && !mip;
+  if( angular )
+  {
+    predMode = isp ? intra_wide_angle( cuW, cuH, dirMode ) : intra_wide_angle( w, h, dirMode );     // ISP: the CU's shape (:502,604)
+    isVer = predMode >= 34;
+    const int am = isVer ? predMode - 50 : -( predMode - 18 );
+    invAngle = c_invAngTable[iabs( am )]; absAng = c_angTable[iabs( am )]; angle = am < 0 ? -absAng : absAng;
+  }
+  const int bw = isVer ? w : h, bh = isVer ? h : w;       // angular modes predict in the transposed domain for horizontal modes
+  bool cubic = false, doAngPdpc = false; int angScale = 0;
+  if( angular )
+  {
+    if( !comp )
+    {
+      const int diff = min( iabs( predMode - 18 ), iabs( predMode - 50 ) );
+      cubic = isp || !( diff > c_intraFilterThr[( ilog2( bw ) + ilog2( bh ) ) >> 1] ) || mrl > 0;
+    }
+    if( angle > 0 )
+    {
+      const int sideSize = predMode >= 34 ? h : w;
+      angScale = min( 2, ilog2( sideSize ) - ( ilog2( 3 * invAngle - 2 ) - 8 ) );
+      doAngPdpc = pdpcOK && angScale >= 0;
+    }
+  }
+  const int pscale = ( lw - 2 + lh - 2 + 2 ) >> 2;
+  const int pdpcLev = !angular ? 0 : angle == 0 ? ( pdpcOK ? min( pscale == 0 ? 3 : pscale == 1 ? 6 : pscale == 2 ? 12 : 24, bw ) : 0 ) : doAngPdpc ? min( 3 << angScale, bw ) : 0;
+  // group loop: a lane predicts g = min( 4, extent ) neighbouring samples of a row of the prediction block; (xx, yy) are the coordinates
+  // there: xx = x, yy = y, for horizontal angular modes transposed (xx = y, yy = x)
+  const bool tr = angular && !isVer;
+  const int nxl = tr ? ilog2( rows ) : lw;                                  // log2 extent of the item in xx
+  const int gl = min( 2, nxl ), lgpr = nxl - gl;                             // log2 group size, log2 groups per row
+  const int ngroups = ( tr ? w : rows ) << lgpr;
+  const bool vec = !tr && gl == 2 && !( x0 & 3 );                           // 8-byte LDS accesses to the tile row and the residual
+  const int tileBase = IT_PAD * IT_TS + ( y0 - oy ) * IT_TSB + ( x0 - ox ) + IT_PADX;       // block origin in the tile (rows inside the CTU)
+  // reference fill (xFillReferenceSamples :1072-1250): index <= mrl: base0 + step0 * index; beyond: base1 + min( index - 1 - mrl, limit1 ) [* row stride]
+  const int cx = fx0 - ( 1 + mrl ), cy = fy0 - ( 1 + mrl );                  // corner
+  const int iCorner = tile_idx( cx - ox, cy - oy ), iPad = tile_idx( cx - ox, fy0 - oy ), iAbove = tile_idx( fx0 - ox, cy - oy );
+  const int szL = min( nL * unit, fLeftLen ), szA = min( nA * unit, fTopLen );
+  const int tb0 = nL ? ( nTL ? iCorner : iPad ) : iAbove, ts0 = ( nL && nTL ) ? 1 : 0;
+  const int tb1 = nA ? iAbove : nTL ? iAbove - 1 : iPad, tl1 = nA ? szA - 1 : 0;
+  const int lb0 = tb0, ls0 = ( nL && nTL ) ? IT_TSB : 0;        // (rows cy .. cy + mrl lie inside the CTU when mrl > 0)
+  const int lb1 = nL ? iPad : iAbove, ll1 = nL ? szL - 1 : 0;
+  const int denom = w == h ? w << 1 : max( w, h );
+  uint32_t F = 0;
+  if( it.flags & IT_F_RESI ) F |= CF_RESI;
+  if( comp && ( it.flags & IT_F_CSCALE ) ) F |= CF_CSON;
+  if( isDc ) F |= CF_DC;
+  if( useFilt ) F |= CF_FILT;
+  if( angular ) F |= CF_ANG;
+  if( tr ) F |= CF_TR;
+  if( absAng & 0x1F ) F |= CF_FRAC;
+  if( cubic ) F |= CF_CUBIC;
+  if( vec ) F |= CF_VEC;
+  if( nTL | nA | nL ) F |= CF_ANY;
+  if( isp ) F |= CF_ISP;
+  if( mip ) F |= CF_MIP;
+  if( ibc ) F |= CF_IBC;
+  if( cclm ) F |= CF_CCLM;
+  if( !bdpcm && pdpcOK ) F |= CF_PDPC;
+  if( wh <= IT_PART_SAMPLES ) F |= CF_STASHED;
+  if( dirMode == 0 ) F |= CF_PLANAR;
+  if( angle < 0 ) F |= CF_NEG;
+  if( angular && angle == 0 ) F |= CF_ANG0;
+  c[C_FLAGS] = F;
+  c[C_POS] = (uint32_t) x0 | ( (uint32_t) y0 << 16 );
+  c[C_GEO] = (uint32_t) lw | ( lh << 4 ) | ( ilog2( rows ) << 8 ) | ( yb << 12 ) | ( mrl << 19 ) | ( wIntra << 21 ) | ( bdpcm << 23 ) | ( gl << 25 ) | ( lgpr << 27 );
+  c[C_TILEBASE] = tileBase;
+  c[C_N] = max( max( topLen, leftLen ), max( fTopLen, fLeftLen ) ) + mrl + 1;       // <= 131
+  c[C_TB0] = tb0; c[C_TS0] = ts0; c[C_TB1] = tb1; c[C_TL1] = tl1; c[C_LB0] = lb0; c[C_LS0] = ls0; c[C_LB1] = lb1; c[C_LL1] = ll1;
+  c[C_DCT] = w >= h ? mrl + w : -1; c[C_DCL] = w <= h ? mrl + h : -1;              // DC: the samples next to the longer side(s)
+  c[C_DCDEN] = (uint32_t) ilog2( denom ) | ( ( denom >> 1 ) << 8 );
+  c[C_TOPLEN] = topLen; c[C_LEFTLEN] = leftLen;
+  c[C_ANGLE] = angle; c[C_INVANGLE] = invAngle; c[C_REFEND] = ( isVer ? topLen : leftLen ) + mrl; c[C_BH] = bh;
+  c[C_PDPCLEV] = pdpcLev; c[C_ANGSCALE] = angScale; c[C_PSCALE] = pscale;
+  c[C_NGROUPS] = ngroups; c[C_XXB] = tr ? yb : 0; c[C_YYB] = tr ? 0 : yb;
+  const int csNv1 = pic.log2Ctu > pic.vpduLog2 ? 1 : 0;
+  c[C_CSIDX] = ( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 );
+  c[C_ORIGIN] = (uint32_t) ox | ( (uint32_t) oy << 16 );
+}
+
+__global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem* __restrict__ items, const uint32_t* __restrict__ ctx /* k_intra_setup */,
                                                   const IntraUnit* __restrict__ units, int numActive,
                                                   int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */
 #ifdef VVR_INTRA_DEV
@@ -2647,6 +2814,8 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
   uint4 recN = make_uint4( 0, 0, 0, 0 ), recNN = make_uint4( 0, 0, 0, 0 );
   if( iA + wv < i1 ) recN = intra_load_item( items, iA + wv );
   if( iA + wv + IT_WAVES < i1 ) recNN = intra_load_item( items, iA + wv + IT_WAVES );
+  uint32_t ctxPre = 0;
+  if( iA + wv < i1 ) ctxPre = ctx[(size_t) ( iA + wv ) * IT_CTX + lane];
 #define TILE( x, y ) sh.tile[tile_idx( ( x ) - ox, ( y ) - oy )]
   // block record q of this unit into scalar registers (uniform per wavefront)
 #define IT_FETCH( IT, Q ) { const uint32_t* ip_ = ( Q ) - i0 < (uint32_t) IT_BATCH ? reinterpret_cast<const uint32_t*>( &sh.items[( Q ) - i0] ) : reinterpret_cast<const uint32_t*>( &items[Q] ); \
@@ -2755,6 +2924,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
     LR.tpl = 0;
     const int q0 = (int) iA + wv, qEnd = ( dbg & 4 ) ? (int) i0 : (int) i1;
     uint4 recC = make_uint4( 0, 0, 0, 0 );
+    uint32_t ctxCur = 0, ctxN = ctxPre;
 #define IT_CSYNC() asm volatile( "" ::: "memory" )      /* LDS accesses of one wavefront execute in order: only the compiler has to keep them in order */
     for( int q = q0 - IT_WAVES; ; q += IT_WAVES )
     {
@@ -2767,6 +2937,9 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
       if( q + IT_WAVES < qEnd ) { const IntraItem itN = intra_item_of( recN ); intra_load_resi( RR, itN, rs, rstride, lane ); if( comp ) intra_load_cclm_luma( LR, itN, pic, lane ); }
       recC = recN; recN = recNN;
       if( q + 3 * IT_WAVES < qEnd ) recNN = intra_load_item( items, (uint32_t) ( q + 3 * IT_WAVES ) );
+      const uint32_t ctxC = ctxCur;                                           // the block's parameter record (lane k: value k), fetched two blocks ahead
+      ctxCur = ctxN;
+      if( q + 2 * IT_WAVES < qEnd ) ctxN = ctx[(size_t) ( q + 2 * IT_WAVES ) * IT_CTX + lane];
       if( !cur )
       {
       // ---- stage the needed part of the CTU and its reference border in LDS
@@ -2863,87 +3036,18 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
     lds_barrier();
         continue;
       }
-      const int x0 = it.x, y0 = it.y, lw = it.lw, lh = it.lh, w = 1 << lw, h = 1 << lh;
-      const int rows = h >> IT_LPARTS( it ), yb = IT_PART( it ) * rows;        // the band of rows this item predicts
-      const int wh = rows << lw;                                               // samples of this item
-      const bool stashed = wh <= IT_PART_SAMPLES;
-      const bool mip = !comp && ( it.flags & IT_F_MIP );      // (chroma: the same bit says LMCS chroma residual scaling)
-      const int mrl = ( it.flags & IT_F_MIP ) ? 0 : ( it.flags >> 4 ) & 3;
-      const int wIntra = it.flags >> 6;               // CIIP: weight of the planar intra part, 0 = ordinary intra block
-      // intra sub-partition (luma): the reference line is cut out of the line of the whole CU, see below
-      const bool isp = !comp && ( it.flags & IT_F_ISP ) == IT_F_ISP;
-      const uint32_t ispw = isp ? it.tu : 0;
-      const int ispDx = ispw & 63, ispDy = ( ispw >> 6 ) & 63, cuW = 1 << ( ( ispw >> 12 ) & 7 ), cuH = 1 << ( ( ispw >> 15 ) & 7 );
-      const bool ispVer = ( ispw >> 18 ) & 1;
-      const int ispGrp = ( ispw >> 23 ) & 3;          // partitions narrower than 4 are predicted in groups of width 4: 1 = two 2-wide, 2 = four 1-wide
-      const int ispResi = ( ispw >> 19 ) & 15;
-      const int bdpcm = isp ? 0 : ( it.flags & IT_F_BDPCM_H ) ? 1 : ( it.flags & IT_F_BDPCM_V ) ? 2 : 0;
-      const int dirMode = it.mode;
-      const bool hasResi = ( it.flags & IT_F_RESI ) != 0;
-      // residual of sample i of the item (row-major inside its band): from the scratch, or from the residual plane for a block that is not split
-      auto RES = [&]( int i ) -> int { return stashed ? (int) W.resi[i] : (int) (int16_t) rs[(size_t) ( y0 + yb + ( i >> lw ) ) * rstride + x0 + ( i & ( w - 1 ) )]; };
+      // ---- the block's parameters come from its record (k_intra_setup), a value at a time where it is needed
+#define CP( K ) ( (int) __builtin_amdgcn_readlane( ctxC, K ) )
+      const uint32_t F = (uint32_t) CP( C_FLAGS ), G = (uint32_t) CP( C_GEO );
+      const int lw = CG_LW( G ), lh = CG_LH( G ), w = 1 << lw, h = 1 << lh;
+      const int yb = CG_YB( G );                                               // first row of the band of rows this item predicts
+      const int wh = 1 << ( lw + CG_LROWS( G ) );                              // samples of this item
+      const int mrl = CG_MRL( G );
+      const bool hasResi = ( F & CF_RESI ) != 0, csOn = ( F & CF_CSON ) != 0, stashed = ( F & CF_STASHED ) != 0;
+      const int tileBase = CP( C_TILEBASE );                                   // block origin in the tile (rows inside the CTU)
       // LMCS chroma residual scaling factor of the block's VPDU (the unit has waited for the luma it is averaged over)
       int csScale = 0;
-      const bool csOn = comp && ( it.flags & IT_F_CSCALE );
-      if( csOn ) csScale = sh.csFac[( ( ( y0 << 1 ) >> pic.vpduLog2 ) & csNv1 ) * 2 + ( ( ( x0 << 1 ) >> pic.vpduLog2 ) & csNv1 )];
-      // reference line lengths; ISP: CU size + partition size along the split, twice the CU size across (IntraPrediction.cpp:1000-1001).
-      // f*: the block whose line is fetched from the picture (ISP: the whole CU, initIntraPatternChTypeISP :966-999)
-      const int topLen = isp ? ( ispVer ? cuW + w : 2 * cuW ) : 2 * w, leftLen = isp ? ( ispVer ? 2 * cuH : cuH + h ) : 2 * h;
-      const int fx0 = x0 - ispDx, fy0 = y0 - ispDy, fTopLen = isp ? 2 * cuW : topLen, fLeftLen = isp ? 2 * cuH : leftLen;
-      const int unit = 4 >> cs;
-      const int nTL = it.nTL & 1, nA = it.nA, nL = it.nL;
-      const bool isDc = !bdpcm && dirMode == 1;
-      // ---- reference smoothing decision, mode-specific set-up (uniform scalar work, none of it depends on a sample)
-      bool useFilt = false;
-      if( !comp && !mrl && !bdpcm && dirMode != 1 && !isp && dirMode <= 66 && !mip )
-      {
-        if( dirMode == 0 ) useFilt = w * h > 32;
-        else
-        {
-          const int pm = intra_wide_angle( w, h, dirMode );
-          const int diff = min( iabs( pm - 18 ), iabs( pm - 50 ) );
-          const int l2 = ( lw + lh ) >> 1;
-          const int am = pm >= 34 ? pm - 50 : -( pm - 18 );
-          useFilt = diff > sh.filtThr[l2] && ( ( sh.angTab[iabs( am )] & 0x1F ) == 0 );
-        }
-      }
-      const bool pdpcOK = ( w >= 4 && h >= 4 ) && mrl == 0;
-      int predMode = 0, angle = 0, invAngle = 0, absAng = 0; bool isVer = true;
-      const bool angular = !bdpcm && dirMode > 1 && dirMode <= 66 && !mip;
-      if( angular )
-      {
-        predMode = isp ? intra_wide_angle( cuW, cuH, dirMode ) : intra_wide_angle( w, h, dirMode );     // ISP: the CU's shape (:502,604)
-        isVer = predMode >= 34;
-        const int am = isVer ? predMode - 50 : -( predMode - 18 );
-        invAngle = sh.invAngTab[iabs( am )]; absAng = sh.angTab[iabs( am )]; angle = am < 0 ? -absAng : absAng;
-      }
-      const int bw = isVer ? w : h, bh = isVer ? h : w;       // angular modes predict in the transposed domain for horizontal modes
-      bool cubic = false, doAngPdpc = false; int angScale = 0;
-      if( angular )
-      {
-        if( !comp )
-        {
-          const int diff = min( iabs( predMode - 18 ), iabs( predMode - 50 ) );
-          const int l2 = ( ilog2( bw ) + ilog2( bh ) ) >> 1;
-          cubic = isp || !( diff > sh.filtThr[l2] ) || mrl > 0;
-        }
-        if( angle > 0 )
-        {
-          const int sideSize = predMode >= 34 ? h : w;
-          angScale = min( 2, ilog2( sideSize ) - ( ilog2( 3 * invAngle - 2 ) - 8 ) );
-          doAngPdpc = pdpcOK && angScale >= 0;
-        }
-      }
-      const int pscale = ( lw - 2 + lh - 2 + 2 ) >> 2;
-      // geometry of the group loop: a lane predicts g = min( 4, extent ) neighbouring samples of a row of the prediction block; (xx, yy) are the
-      // coordinates there: xx = x, yy = y, for horizontal angular modes transposed (xx = y, yy = x)
-      const bool tr = angular && !isVer;
-      const int nxl = tr ? ilog2( rows ) : lw;                                  // log2 extent of the item in xx
-      const int gl = min( 2, nxl ), g = 1 << gl, lgpr = nxl - gl;                // log2 / group size, log2 groups per row
-      const int ngroups = ( tr ? w : rows ) << lgpr;
-      const int xxb = tr ? yb : 0, yyb = tr ? 0 : yb;
-      const bool vec = !tr && g == 4 && !( x0 & 3 );                            // 8-byte LDS accesses to the tile row and the residual
-      const int tileBase = IT_PAD * IT_TS + ( y0 - oy ) * IT_TSB + ( x0 - ox ) + IT_PADX;       // block origin in the tile (rows inside the CTU)
+      if( csOn ) csScale = sh.csFac[CP( C_CSIDX )];
 #define IT_BT( K ) if( btrace && lane == 0 ) btrace[(size_t) 4 * q + ( K )] = clock64()
       IT_BT( 0 );
       // ---- the block's turn: every block of the unit it may read from is finished
@@ -2964,11 +3068,14 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
       IT_BT( 1 );
       // (the wait makes the block's samples visible to the other wavefronts before the counter moves)
 #define IT_DONE() { wave_lds_sync(); done++; if( lane == 0 ) prog[wv] = done; IT_BT( 3 ); }
+      // residual of sample i of the item (row-major inside its band): from the scratch, or from the residual plane for a block that is not split
+      auto RES = [&]( int i ) -> int { const int pos = CP( C_POS ); return stashed ? (int) W.resi[i] : (int) (int16_t) rs[(size_t) ( ( pos >> 16 ) + yb + ( i >> lw ) ) * rstride + ( pos & 0xffff ) + ( i & ( w - 1 ) )]; };
       // ---- intra block copy (InterPrediction::xIntraBlockCopy :1995, DecCu.cpp:442-470): copy of reconstructed samples of this picture
       // at the block vector (+ residual).  Samples of this CTU come from the tile, where the blocks of this unit have put theirs and
       // the others were staged after the wait for their producers; samples of a CTU further left come from HBM.
-      if( dirMode == IT_MODE_IBC )
+      if( F & CF_IBC )
       {
+        const int x0 = it.x, y0 = it.y;
         const int qx = x0 + (int16_t) ( it.tu & 0xffff ), qy = y0 + (int16_t) ( it.tu >> 16 );
 #pragma unroll 1
         for( int i = lane; i < wh; i += 64 )
@@ -2985,24 +3092,18 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
       // ---- xFillReferenceSamples (:1072-1250): one lane per reference position, ONE read per line and lane - the substitution of samples that
       // are not available (the nearest available one along the line, the first left sample for an unavailable corner, mid grey if nothing is)
       // only moves the position that is read: index <= mrl (the corner and the extension of its row / column): base0 + step0 * index; beyond:
-      // base1 + min( index - 1 - mrl, limit1 ) [* row stride], all uniform.  Lines: index 0 = the corner, then the samples above (left of) the
-      // block.  ISP: the line of the whole CU first, the partition's own line is cut out of it below.
+      // base1 + min( index - 1 - mrl, limit1 ) [* row stride], all from the record.  Lines: index 0 = the corner, then the samples above (left
+      // of) the block.  ISP: the line of the whole CU first, the partition's own line is cut out of it below.
       int dcPart = 0;
       {
-        const int n = max( max( topLen, leftLen ), max( fTopLen, fLeftLen ) ) + mrl + 1;       // <= 131
+        const bool isp = ( F & CF_ISP ) != 0, isDc = ( F & CF_DC ) != 0;
+        const int n = CP( C_N );
         pel_t* const dT = isp ? W.auxT : T;
         pel_t* const dL = isp ? W.auxL : L;
-        const int cx = fx0 - ( 1 + mrl ), cy = fy0 - ( 1 + mrl );          // corner
-        const int iCorner = tile_idx( cx - ox, cy - oy ), iPad = tile_idx( cx - ox, fy0 - oy ), iAbove = tile_idx( fx0 - ox, cy - oy );
-        const int szL = min( nL * unit, fLeftLen ), szA = min( nA * unit, fTopLen );
-        // top: tb0 + ts0 * j | tb1 + min( i, tl1 );  left: lb0 + ls0 * j | lb1 + min( i, ll1 ) * IT_TSB   (rows cy .. cy + mrl lie inside the CTU when mrl > 0)
-        const int tb0 = nL ? ( nTL ? iCorner : iPad ) : iAbove, ts0 = ( nL && nTL ) ? 1 : 0;
-        const int tb1 = nA ? iAbove : nTL ? iAbove - 1 : iPad, tl1 = nA ? szA - 1 : 0;
-        const int lb0 = tb0, ls0 = ( nL && nTL ) ? IT_TSB : 0;
-        const int lb1 = nL ? iPad : iAbove, ll1 = nL ? szL - 1 : 0;
-        const int dcT = w >= h ? mrl + w : -1, dcL = w <= h ? mrl + h : -1;      // DC: the samples next to the longer side(s)
-        if( nTL | nA | nL )
+        const int dcT = CP( C_DCT ), dcL = CP( C_DCL );
+        if( F & CF_ANY )
         {
+          const int tb0 = CP( C_TB0 ), ts0 = CP( C_TS0 ), tb1 = CP( C_TB1 ), tl1 = CP( C_TL1 ), lb0 = CP( C_LB0 ), ls0 = CP( C_LS0 ), lb1 = CP( C_LB1 ), ll1 = CP( C_LL1 );
 #pragma unroll 1
           for( int j = lane; j < n; j += 64 )
           {
@@ -3021,6 +3122,13 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
         }
         if( isp )
         {
+          // intra sub-partition (luma): the partition's line is cut out of the line of the whole CU
+          const uint32_t ispw = it.tu;
+          const int x0 = it.x, y0 = it.y;
+          const int ispDx = ispw & 63, ispDy = ( ispw >> 6 ) & 63, cuW = 1 << ( ( ispw >> 12 ) & 7 ), cuH = 1 << ( ( ispw >> 15 ) & 7 );
+          const bool ispVer = ( ispw >> 18 ) & 1;
+          const int fTopLen = 2 * cuW, fLeftLen = 2 * cuH, topLen = CP( C_TOPLEN ), leftLen = CP( C_LEFTLEN );
+          const int nA = it.nA, nL = it.nL;
           IT_CSYNC();
           dcPart = 0;
 #pragma unroll 1
@@ -3047,16 +3155,13 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
         }
       }
       int dcVal = 0;
-      if( isDc )
-      {
-        const int denom = w == h ? w << 1 : max( w, h );
-        dcVal = ( wave_sum( dcPart ) + ( denom >> 1 ) ) >> ilog2( denom );
-      }
+      if( F & CF_DC ) { const int dd = CP( C_DCDEN ); dcVal = ( wave_sum( dcPart ) + ( dd >> 8 ) ) >> ( dd & 0xff ); }
       IT_CSYNC();
       IT_BT( 2 );
       // ---- MIP (PredictorMIP, MatrixIntraPrediction.cpp:68-330): boundary down-sampling, matrix-vector product, up-sampling
-      if( mip )
+      if( F & CF_MIP )
       {
+        const int dirMode = it.mode;
         const bool transp = ( it.flags & 0x10 ) != 0;
         const int sizeId = ( w == 4 && h == 4 ) ? 0 : ( w == 4 || h == 4 || ( w == 8 && h == 8 ) ) ? 1 : 2;
         const int bdry = sizeId == 0 ? 2 : 4, red = sizeId < 2 ? 4 : 8, l2red = sizeId < 2 ? 2 : 3;
@@ -3141,7 +3246,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
       }
       // ---- CCLM / MDLM (xGetLumaRecPixels :1403, xGetLMParameters :1694, predIntraChromaLM :519; 4:2:0): the down-sampled luma of the block
       // (up to 256 samples) and of the template positions is in registers already (intra_load_cclm_luma)
-      if( comp && dirMode >= 67 )
+      if( F & CF_CCLM )
       {
         const uint32_t lm = it.tu;
         const int actualTop = lm & 0xff, actualLeft = ( lm >> 8 ) & 0xff;
@@ -3210,6 +3315,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
         {
           // a large block (512 / 1024 samples): the luma is fetched here
           const bool bLeft = ( lm >> 18 ) & 1, bAbove = ( lm >> 20 ) & 1, colloc = pic.colloc != 0;
+          const int x0 = it.x, y0 = it.y;
 #pragma unroll 2
           for( int i = lane; i < wh; i += 64 )
           {
@@ -3225,9 +3331,10 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
       }
       // ---- reference smoothing (xFilterReferenceSamples :1251): into the second pair of lines
       pel_t* Tp = T; pel_t* Lp = L;
-      if( useFilt )
+      if( F & CF_FILT )
       {
         pel_t* const fT = W.auxT + IT_NEG; pel_t* const fL = W.auxL + IT_NEG;
+        const int topLen = CP( C_TOPLEN ), leftLen = CP( C_LEFTLEN );
         const int mx = max( topLen, leftLen );
 #pragma unroll 1
         for( int j = lane; j <= mx; j += 64 )
@@ -3244,12 +3351,12 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
       // the main / side reference of xPredIntraAng (:640-690): index j is relative to the block (after the multi-reference-line offset);
       // negative indices are the side reference projected with invAngle - written in front of the main reference once per block -,
       // indices beyond the end replicate the last sample
-      pel_t* const Mn = isVer ? Tp : Lp;
-      const pel_t* const Sd = isVer ? Lp : Tp;
-      const int refEnd = ( isVer ? topLen : leftLen ) + mrl;
-      if( angle < 0 )
+      const bool tr = ( F & CF_TR ) != 0;
+      pel_t* const Mn = tr ? Lp : Tp;
+      const pel_t* const Sd = tr ? Tp : Lp;
+      if( F & CF_NEG )
       {
-        const int k = 1 + lane;                                 // (the lowest index read is ( angle * ( mrl + bh ) >> 5 ) + mrl >= -bh >= -64: one round)
+        const int k = 1 + lane, bh = CP( C_BH ), invAngle = CP( C_INVANGLE );   // (the lowest index read is ( angle * ( mrl + bh ) >> 5 ) + mrl >= -bh >= -64: one round)
         if( k <= bh ) Mn[-k] = Sd[min( ( k * invAngle + 256 ) >> 9, bh )];
         IT_CSYNC();
       }
@@ -3258,11 +3365,17 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
         // combination (IntraPredSampleFilterCore :212); angular (xPredIntraAng :592) in one 4-tap form for every kind - c = the cubic / Gauss
         // filter of the row's fraction (luma), { 0, 64 - 2 f, 2 f, 0 } for the 2-tap chroma interpolation, { 0, 64, 0, 0 } for whole-sample
         // angles - over 7 neighbouring reference samples
-        const int tR = Tp[w + 1], lB = Lp[h + 1], t0 = Tp[0];
-        const bool pdpc = !bdpcm && pdpcOK;
-        const bool frac = ( absAng & 0x1F ) != 0;
-        const int pdpcLev = !angular ? 0 : angle == 0 ? ( pdpcOK ? min( pscale == 0 ? 3 : pscale == 1 ? 6 : pscale == 2 ? 12 : 24, bw ) : 0 ) : doAngPdpc ? min( 3 << angScale, bw ) : 0;
+        const bool angular = ( F & CF_ANG ) != 0, vec = ( F & CF_VEC ) != 0;
+        const int ngroups = CP( C_NGROUPS ), lgpr = CG_LGPR( G ), gl = CG_GL( G ), g = 1 << gl;
+        const int xxb = CP( C_XXB ), yyb = CP( C_YYB ), pscale = CP( C_PSCALE );
         const int maxv = ( 1 << bd ) - 1;
+        const int wIntra = CG_WINTRA( G );
+        // ISP: partitions narrower than 4 are predicted in groups of width 4 (1 = two 2-wide, 2 = four 1-wide); residual flags of the group's partitions
+        const int ispGrp = ( F & CF_ISP ) ? ( it.tu >> 23 ) & 3 : 0, ispResi = ( F & CF_ISP ) ? ( it.tu >> 19 ) & 15 : 0;
+        // (uniform values of the two kinds of prediction, fetched before the loop)
+        int tR = 0, lB = 0, t0 = 0, angle = 0, refEnd = 0, pdpcLev = 0, angScale = 0, invAngle = 0, bdpcm = 0;
+        if( angular ) { angle = CP( C_ANGLE ); refEnd = CP( C_REFEND ); pdpcLev = CP( C_PDPCLEV ); angScale = CP( C_ANGSCALE ); invAngle = CP( C_INVANGLE ); t0 = Tp[0]; }
+        else { tR = Tp[w + 1]; lB = Lp[h + 1]; bdpcm = CG_BDPCM( G ); }
 #pragma unroll 1
         for( int gi = lane; gi < ngroups; gi += 64 )
         {
@@ -3278,14 +3391,14 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
             {
               const int x = xx0 + e;
               if( bdpcm ) v[e] = bdpcm == 1 ? lft : tp[e];
-              else if( dirMode == 0 )
+              else if( F & CF_PLANAR )
               {
                 const int hor = ( lft << lw ) + __mul24( x + 1, tR - lft );
                 const int ver = ( tp[e] << lh ) + __mul24( yy + 1, lB - tp[e] );
                 v[e] = (int16_t) ( ( ( hor << lh ) + ( ver << lw ) + ( 1 << ( lw + lh ) ) ) >> ( 1 + lw + lh ) );
               }
               else v[e] = dcVal;
-              if( pdpc )
+              if( F & CF_PDPC )
               {
                 const int wLp = 32 >> min( 31, ( x << 1 ) >> pscale );
                 v[e] = (int16_t) ( v[e] + ( ( __mul24( wLp, lft - v[e] ) + __mul24( wTp, tp[e] - v[e] ) + 32 ) >> 6 ) );
@@ -3300,17 +3413,17 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
             int r[7];
             for( int t = 0; t < 7; t++ ) r[t] = Mn[min( kb + t, refEnd )];
             int c0 = 0, c1 = 64, c2 = 0, c3 = 0;
-            if( frac )
+            if( F & CF_FRAC )
             {
               if( comp ) { c1 = 64 - 2 * df; c2 = 2 * df; }
-              else if( cubic ) { const uint2 cv = *reinterpret_cast<const uint2*>( sh.cfilt[df] ); c0 = (int16_t) ( cv.x & 0xffff ); c1 = (int16_t) ( cv.x >> 16 ); c2 = (int16_t) ( cv.y & 0xffff ); c3 = (int16_t) ( cv.y >> 16 ); }
+              else if( F & CF_CUBIC ) { const uint2 cv = *reinterpret_cast<const uint2*>( sh.cfilt[df] ); c0 = (int16_t) ( cv.x & 0xffff ); c1 = (int16_t) ( cv.x >> 16 ); c2 = (int16_t) ( cv.y & 0xffff ); c3 = (int16_t) ( cv.y >> 16 ); }
               else { c0 = 16 - ( df >> 1 ); c1 = 32 - ( df >> 1 ); c2 = 16 + ( df >> 1 ); c3 = df >> 1; }     // g_intraGaussFilter (:96)
             }
             for( int e = 0; e < 4; e++ ) v[e] = min( max( ( __mul24( c0, r[e] ) + __mul24( c1, r[e + 1] ) + __mul24( c2, r[e + 2] ) + __mul24( c3, r[e + 3] ) + 32 ) >> 6, 0 ), maxv );
             if( xx0 < pdpcLev )
             {
               // (the weights of positions at and beyond the level are zero by themselves: 32 >> 6)
-              if( angle == 0 )
+              if( F & CF_ANG0 )
               {
                 const int sd = Sd[yy + 1] - t0;
                 for( int e = 0; e < 4; e++ ) { const int wLp = 32 >> min( 31, ( ( xx0 + e ) << 1 ) >> pscale ); v[e] = min( max( ( __mul24( wLp, sd ) + ( v[e] << 6 ) + 32 ) >> 6, 0 ), maxv ); }
@@ -3361,6 +3474,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
 #undef IT_DONE
 #undef IT_BT
 #undef IT_CSYNC
+#undef CP
   }
   __syncthreads();                    // every block of the unit is in the tile
   IT_TRACE( 3 );
@@ -3417,7 +3531,11 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
 #undef IT_TRACE
 }
 
-void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, const IntraUnit* units, int numActive, int numWorkgroups, int* sync )
+// ints of the per-lane buffer of the intra stage: ticket + one flag per unit, then (64-dword aligned) one parameter record per block
+size_t intra_ctx_offset( int numUnits ) { return ( (size_t) 1 + (size_t) numUnits + 63 ) & ~(size_t) 63; }
+size_t intra_sync_ints( int numUnits, int numItems ) { return intra_ctx_offset( numUnits ) + (size_t) numItems * IT_CTX; }
+
+void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numActive, int numWorkgroups, int* sync )
 {
   if( !numActive ) return;
   numWorkgroups = std::max( 1, std::min( numWorkgroups, numActive ) );
@@ -3426,8 +3544,11 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   for( int c = 0; c < 3; c++ ) { ip.plane[c] = reco.p[c]; ip.resi[c] = resi.p[c]; ip.stride[c] = reco.stride[c]; ip.rstride[c] = resi.stride[c]; ip.w[c] = reco.w[c]; ip.h[c] = reco.h[c]; }
   ip.csVpdu = pic.csVpdu; ip.lmcs = pic.lmcs; ip.vpdusX = pic.vpdusX; ip.vpduLog2 = pic.vpduLog2; ip.ctusX = pic.ctus_x; ip.log2Ctu = pic.hdr.log2_ctu;
   ip.bitDepth = pic.hdr.bit_depth; ip.width = pic.hdr.width; ip.height = pic.hdr.height; ip.colloc = ( pic.hdr.tool_flags & VVR_TOOL_CCLM_COLLOC ) ? 1 : 0;
+  // the blocks' parameter records live behind the flags (intra_sync_ints): one pass over all blocks writes them
+  uint32_t* ctx = reinterpret_cast<uint32_t*>( sync ) + intra_ctx_offset( numActive );
+  hipLaunchKernelGGL( k_intra_setup, dim3( ( numItems + 255 ) / 256 ), dim3( 256 ), 0, s, ip, items, numItems, ctx );
 #ifndef VVR_INTRA_DEV
-  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, units, numActive, sync );
+  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync );
 #else
   static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
   static const bool tr = getenv( "VVR_INTRA_TRACE" ) != nullptr;
@@ -3435,7 +3556,7 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   const size_t nItems = 1 << 20;      // (block timeline: sized generously, indexed by item)
   if( tr ) { hipMalloc( (void**) &trace, sizeof( unsigned long long ) * 8 * (size_t) numActive ); hipMemsetAsync( trace, 0, sizeof( unsigned long long ) * 8 * (size_t) numActive, s );
              hipMalloc( (void**) &btrace, sizeof( unsigned long long ) * 4 * nItems ); hipMemsetAsync( btrace, 0, sizeof( unsigned long long ) * 4 * nItems, s ); }
-  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, units, numActive, sync, dbg, trace, btrace );
+  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync, dbg, trace, btrace );
   if( tr )
   {
     // developer timeline: ticket, phase time stamps (100 MHz), block count / unit word, number of producers; per block four shader-clock stamps
