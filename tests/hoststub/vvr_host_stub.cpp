@@ -17,6 +17,7 @@ static int g_numStreams = 0, g_numEvents = 0;
 extern "C" {
 hipError_t hipGetDeviceCount( int* n ) { *n = 1; return hipSuccess; }
 hipError_t hipSetDevice( int ) { return hipSuccess; }
+hipError_t hipDeviceGetPCIBusId( char* b, int n, int ) { if( n > 0 ) b[0] = 0; return hipErrorInvalidDevice; }      // (no device: host threads are not pinned)
 hipError_t hipGetDeviceProperties( hipDeviceProp_t* p, int ) { memset( p, 0, sizeof( *p ) ); strcpy( p->gcnArchName, "gfx950:host-stub" ); p->multiProcessorCount = 256; return hipSuccess; }
 hipError_t hipMalloc( void** p, size_t n ) { *p = calloc( 1, n ? n : 1 ); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipFree( void* p ) { free( p ); return hipSuccess; }

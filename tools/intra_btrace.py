@@ -8,7 +8,7 @@ UNIT = np.dtype([("ent", "<u4"), ("i0", "<u4"), ("i1", "<u4"), ("bbox", "<u4"), 
 ITEM = np.dtype([("x", "<u2"), ("y", "<u2"), ("lw", "u1"), ("lh", "u1"), ("mode", "u1"), ("flags", "u1"), ("nTL", "u1"), ("nA", "u1"), ("nL", "u1"), ("comp", "u1"), ("tu", "<u4")])
 units = np.fromfile("%s/intra_units_poc%s.bin" % (d, poc), UNIT)
 items = np.fromfile("%s/intra_items_poc%s.bin" % (d, poc), ITEM)
-bt = np.fromfile("%s/intra_btrace_poc%s.bin" % (d, poc), "<u8").reshape(-1, 4).astype(np.int64)
+bt = np.fromfile("%s/intra_btrace_poc%s.bin" % (d, poc), "<u8").reshape(-1, 8).astype(np.int64)
 ut = np.fromfile("%s/intra_trace_poc%s.bin" % (d, poc), "<u8").reshape(-1, 8).astype(np.int64)
 print("units", len(units), "items", len(items))
 # shader clock per 100 MHz tick: block loop of the long units
@@ -32,9 +32,15 @@ for comp in (0, 1):
         u = units[t]
         for q in range(u["iA"], u["i1"]):
             prev = bt[q - 4, 3] if q - 4 >= u["iA"] else bt[q, 0]
-            rows.append((int(items[q]["lw"]) + int(items[q]["lh"]), us(bt[q, 0] - prev), us(bt[q, 1] - bt[q, 0]), us(bt[q, 2] - bt[q, 1]), us(bt[q, 3] - bt[q, 2]), int(items[q]["mode"]), int(items[q]["flags"])))
+            rows.append((int(items[q]["lw"]) + int(items[q]["lh"]), us(bt[q, 0] - prev), us(bt[q, 1] - bt[q, 0]), us(bt[q, 2] - bt[q, 1]), us(bt[q, 3] - bt[q, 2]), int(items[q]["mode"]), int(items[q]["flags"]),
+                         us(bt[q, 4] - bt[q, 2]) if bt[q, 4] else -1, us(bt[q, 5] - bt[q, 4]) if bt[q, 4] else -1, us(bt[q, 6] - bt[q, 5]) if bt[q, 4] else -1, us(bt[q, 3] - bt[q, 6]) if bt[q, 4] else -1))
     a = np.array(rows)
     print("   blocks %d: prologue %.2f  wait %.2f  fill %.2f  predict %.2f   (critical = fill + predict %.2f us)" % (len(a), a[:, 1].mean(), a[:, 2].mean(), a[:, 3].mean(), a[:, 4].mean(), (a[:, 3] + a[:, 4]).mean()))
+    m = a[:, 7] >= 0
+    if m.any():
+        print("   regular blocks %d: smoothing + projection %.2f  loop set-up %.2f  group loop %.2f  done %.2f" % (m.sum(), a[m, 7].mean(), a[m, 8].mean(), a[m, 9].mean(), a[m, 10].mean()))
+        sm = m & (a[:, 0] <= 8)
+        print("   regular blocks of <= 256 samples %d: smoothing + projection %.2f  loop set-up %.2f  group loop %.2f  done %.2f" % (sm.sum(), a[sm, 7].mean(), a[sm, 8].mean(), a[sm, 9].mean(), a[sm, 10].mean()))
     for l2 in sorted(set(a[:, 0])):
         s = a[a[:, 0] == l2]
         print("     log2 samples %2d: n %6d  prologue %.2f  wait %.2f  fill %.2f  predict %.2f" % (l2, len(s), s[:, 1].mean(), s[:, 2].mean(), s[:, 3].mean(), s[:, 4].mean()))

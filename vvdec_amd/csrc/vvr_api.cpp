@@ -28,8 +28,48 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <sched.h>
+#include <pthread.h>
 
 int vvr_upload_tables();
+
+// Host threads of a context stay on the NUMA node its GPU hangs off: the work lists are written into pinned memory the device reads, and a
+// worker that wanders to the other socket of a two-socket host takes 6-9 instead of 4.4 ms for a 4K picture (round 2: the spread of the
+// benchmark line).  The node comes from sysfs (PCI bus id of the HIP device -> numa_node -> cpulist); VVR_NO_PIN=1 leaves the threads alone.
+static std::vector<int> gpuNodeCpus( int device )
+{
+  std::vector<int> cpus;
+  if( const char* e = getenv( "VVR_NO_PIN" ) ) if( atoi( e ) ) return cpus;
+  char bus[64] = { 0 };
+  if( hipDeviceGetPCIBusId( bus, sizeof( bus ), device ) != hipSuccess ) return cpus;
+  for( char* q = bus; *q; q++ ) *q = (char) tolower( *q );
+  char path[256]; snprintf( path, sizeof( path ), "/sys/bus/pci/devices/%s/numa_node", bus );
+  int node = -1;
+  if( FILE* f = fopen( path, "r" ) ) { if( fscanf( f, "%d", &node ) != 1 ) node = -1; fclose( f ); }
+  if( node < 0 ) return cpus;
+  snprintf( path, sizeof( path ), "/sys/devices/system/node/node%d/cpulist", node );
+  if( FILE* f = fopen( path, "r" ) )
+  {
+    int a, b; char sep;
+    while( fscanf( f, "%d", &a ) == 1 )
+    {
+      b = a;
+      const int ch = fgetc( f );
+      if( ch == '-' ) { if( fscanf( f, "%d", &b ) != 1 ) b = a; sep = (char) fgetc( f ); (void) sep; }
+      for( int k = a; k <= b && k < CPU_SETSIZE; k++ ) cpus.push_back( k );
+      if( ch == EOF || ch == '\n' ) break;
+    }
+    fclose( f );
+  }
+  return cpus;
+}
+static void pinToCpus( const std::vector<int>& cpus )
+{
+  if( cpus.empty() ) return;
+  cpu_set_t set; CPU_ZERO( &set );
+  for( int k : cpus ) CPU_SET( k, &set );
+  pthread_setaffinity_np( pthread_self(), sizeof( set ), &set );      // (a failure leaves the thread where it was: nothing depends on it)
+}
 
 #define HIPCHK( ctx, call ) do { hipError_t e_ = ( call ); if( e_ != hipSuccess ) { ( ctx )->setError( std::string( #call ) + ": " + hipGetErrorString( e_ ) ); return VVR_ERR_DEVICE; } } while( 0 )
 
@@ -124,6 +164,7 @@ struct vvr_context {
   size_t     ringLargest = 0;           // bytes of the largest picture image seen (+ 25 %): what a ring entry grows to
   std::vector<char*> retiredHost, retiredDev;   // outgrown ring buffers, freed with the context
   std::vector<hipEvent_t> eventPool;
+  std::vector<int> nodeCpus;            // CPUs of the NUMA node the device is attached to (empty: unknown / pinning off)
   std::vector<std::thread> workers;
   std::thread launcher;                 // commits prepared pictures (contexts with worker threads), see nextToCommitLocked for the order
 #ifdef VVR_WATCHDOG
@@ -250,7 +291,10 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
 static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std::string& err )
 {
 #undef HIPCHK
-#define HIPCHK( ctx, call ) do { hipError_t e_ = ( call ); if( e_ != hipSuccess ) { err = std::string( #call ) + ": " + hipGetErrorString( e_ ); return VVR_ERR_DEVICE; } } while( 0 )
+  // a failure after the first copy / kernel of the picture has been enqueued leaves work in flight: the copy stream still reads the ring entry, the
+  // lane still writes the output slot.  Every failure exit therefore drains both before it returns - the caller marks the job failed, gives the
+  // ring entry to the next picture and does not record this one as a user of its slots, all of which is only safe once nothing of it runs.
+#define HIPCHK( ctx, call ) do { hipError_t e_ = ( call ); if( e_ != hipSuccess ) { err = std::string( #call ) + ": " + hipGetErrorString( e_ ); hipStreamSynchronize( ( ctx )->copyStream ); hipStreamSynchronize( ( ctx )->streams[plan.lane] ); return VVR_ERR_DEVICE; } } while( 0 )
   vvr_prepared* q = job.q;
   const vvr_pic_header& h = q->hdr;
   const int lane = plan.lane;
@@ -273,11 +317,11 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
 #ifdef VVR_WATCHDOG
   for( size_t wi = 0; wi < plan.waits.size(); wi++ )
   {
-    const double w0 = wdNow(); hipStreamWaitEvent( s, plan.waits[wi], 0 ); const double w = wdNow() - w0;
+    const double w0 = wdNow(); HIPCHK( c, hipStreamWaitEvent( s, plan.waits[wi], 0 ) ); const double w = wdNow() - w0;
     if( w > 0.5 ) fprintf( stderr, "[vvr] slow wait: picture %d (type %d, lane %d) wait %zu of %zu on job %d (type %d, lane %d): %.2f ms\n", job.id, (int) h.slice_type, lane, wi, plan.waits.size(), plan.waitInfo[2 * wi] >> 4, ( plan.waitInfo[2 * wi] >> 2 ) & 3, plan.waitInfo[2 * wi + 1], w );
   }
 #else
-  for( hipEvent_t ev : plan.waits ) hipStreamWaitEvent( s, ev, 0 );
+  for( hipEvent_t ev : plan.waits ) HIPCHK( c, hipStreamWaitEvent( s, ev, 0 ) );      // (a picture that cannot be ordered behind its references must not run)
 #endif
 #ifdef VVR_WATCHDOG
   const double wdC = wdNow(); g_wdPart[1] += wdC - wdB; g_wdPartMax[1] = std::max( g_wdPartMax[1], wdC - wdB );
@@ -468,6 +512,7 @@ static void commitReady( vvr_context* c )
 static void launcherMain( vvr_context* c )
 {
   hipSetDevice( c->device );
+  pinToCpus( c->nodeCpus );
   for( ;; )
   {
     {
@@ -612,6 +657,7 @@ static void watchdogMain( vvr_context* c )
 static void workerMain( vvr_context* c )
 {
   hipSetDevice( c->device );
+  pinToCpus( c->nodeCpus );
   PrepScratch* S = vvr_scratch_create();
   vvr_scratch_warm( S, c->cfg );
   for( ;; )
@@ -657,7 +703,14 @@ static int finishJob( vvr_context* c, int id )
     const hipError_t e = hipEventSynchronize( ev );
     lk.lock();
     if( e != hipSuccess ) { c->setError( std::string( "hipEventSynchronize: " ) + hipGetErrorString( e ) ); return VVR_ERR_DEVICE; }
-    completeLocked( c, j );
+    // mu was released: another thread may have finished, waited for and - through a later vvr_submit - retired the job meanwhile
+    it = c->jobs.find( id );
+    if( it == c->jobs.end() ) return VVR_OK;
+    Job& jj = *it->second;
+    if( !jj.completed ) completeLocked( c, jj );
+    jj.waited = true;
+    if( jj.state == J_FAILED ) { c->setError( jj.err ); return jj.rc; }
+    return VVR_OK;
   }
   j.waited = true;
   if( j.state == J_FAILED ) { c->setError( j.err ); return j.rc; }
@@ -785,6 +838,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   c->slotUsers.resize( cfg->num_slots );
   c->inlineScratch = vvr_scratch_create();
   if( cfg->host_threads <= 0 ) vvr_scratch_warm( c->inlineScratch, c->cfg );
+  if( cfg->host_threads ) c->nodeCpus = gpuNodeCpus( c->device );
   for( int t = 0; t < cfg->host_threads; t++ ) c->workers.emplace_back( workerMain, c );
   if( cfg->host_threads ) c->launcher = std::thread( launcherMain, c );
 #ifdef VVR_WATCHDOG

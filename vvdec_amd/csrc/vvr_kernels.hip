@@ -2915,7 +2915,6 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
     IntraWave& W = sh.wave[wv];
     pel_t* const T = W.topB + IT_NEG;
     pel_t* const L = W.leftB + IT_NEG;
-    volatile int* prog = sh.prog;
     int done = 0;                     // blocks this wavefront has finished
     IntraResiRegs RR;
     IntraLumaRegs LR;
@@ -2961,12 +2960,14 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
         if( perBlock && !( dbg & 2 ) )
         {
           // a unit that is not a whole intra CTU: only the reference lines its blocks read (one row above, one column left of every
-          // block, as far as they are available) instead of the bounding box; one block per wavefront, 16-byte chunks
-          for( uint32_t q = i0 + wv; q < i1; q += IT_WAVES )
+          // block, as far as they are available) instead of the bounding box; one block per wavefront, 16-byte chunks.  The fetches of up to
+          // four blocks of a wavefront are in flight together (a block's lines are 64 chunks at most, one per lane, in all but rare cases):
+          // one memory round trip per unit instead of one per block
+          auto stageItem = [&]( uint32_t q, uint4& sv, int& so )
           {
             IntraItem it;
             IT_FETCH( it, q )
-            if( IT_PART( it ) ) continue;                                            // (row parts of one block: fetched with the first)
+            if( IT_PART( it ) ) return;                                              // (row parts of one block: fetched with the first)
             if( it.mode == IT_MODE_IBC )
             {
               // intra block copy: the part of the reference block that lies in this CTU is read from the tile (blocks of this unit write
@@ -2980,10 +2981,10 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
                 const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
                 *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
               }
-              continue;
+              return;
             }
             const bool isp = !comp && ( it.flags & IT_F_ISP ) == IT_F_ISP;
-            if( isp && ( it.tu & 0xfff ) ) continue;                               // later ISP partitions: the CU's line was fetched with the first one
+            if( isp && ( it.tu & 0xfff ) ) return;                                 // later ISP partitions: the CU's line was fetched with the first one
             const int bw = isp ? 1 << ( ( it.tu >> 12 ) & 7 ) : 1 << it.lw, bh = isp ? 1 << ( ( it.tu >> 15 ) & 7 ) : 1 << it.lh;
             const int mrl = ( isp || comp || ( it.flags & IT_F_MIP ) ) ? 0 : ( it.flags >> 4 ) & 3;
             const int unit = 4 >> cs;
@@ -2997,15 +2998,32 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
             // CIIP: the inter prediction of the block itself
             const int wIntra = isp ? 0 : it.flags >> 6;                             // (the two bits are zero for every other kind of block)
             const int cch = ( ( (int) it.x & 7 ) + bw + 7 ) >> 3, nC = wIntra ? cch * bh : 0;
-            for( int i = lane; i < nT + nL + nC; i += 64 )
+            auto chunkAt = [&]( int i, int& x, int& y )
             {
-              int x, y;
               if( i < nT ) { x = tx0 + 8 * i; y = ty; }
               else if( i < nT + nL ) { x = lx & ~7; y = ly0 + ( i - nT ); }
               else { const int j = i - nT - nL; y = (int) it.y + j / cch; x = ( (int) it.x & ~7 ) + 8 * ( j % cch ); }
+            };
+            if( lane < nT + nL + nC )
+            {
+              int x, y; chunkAt( lane, x, y );
+              sv = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
+              so = tile_idx( x - ox, y - oy );
+            }
+            for( int i = lane + 64; i < nT + nL + nC; i += 64 )
+            {
+              int x, y; chunkAt( i, x, y );
               const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
               *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
             }
+          };
+          for( uint32_t qb = i0 + wv; qb < i1; qb += 4 * IT_WAVES )
+          {
+            uint4 sv[4]; int so[4];
+#pragma unroll
+            for( int r = 0; r < 4; r++ ) { so[r] = -1; sv[r] = make_uint4( 0, 0, 0, 0 ); const uint32_t q = qb + r * IT_WAVES; if( q < i1 ) stageItem( q, sv[r], so[r] ); }
+#pragma unroll
+            for( int r = 0; r < 4; r++ ) if( so[r] >= 0 ) *reinterpret_cast<uint4*>( &sh.tile[so[r]] ) = sv[r];
           }
         }
         for( int base = 0; base < total; base += 256 * 4 )
@@ -3048,17 +3066,17 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
       // LMCS chroma residual scaling factor of the block's VPDU (the unit has waited for the luma it is averaged over)
       int csScale = 0;
       if( csOn ) csScale = sh.csFac[CP( C_CSIDX )];
-#define IT_BT( K ) if( btrace && lane == 0 ) btrace[(size_t) 4 * q + ( K )] = clock64()
+#define IT_BT( K ) if( btrace && lane == 0 ) btrace[(size_t) 8 * q + ( K )] = clock64()
       IT_BT( 0 );
       // ---- the block's turn: every block of the unit it may read from is finished
       {
         const int m = q - (int) iA - IT_INDEP( it );              // blocks 0 .. m - 1 of the unit
         if( m > 0 )
         {
-          const int need = lane < IT_WAVES ? max( 0, ( m - lane + IT_WAVES - 1 ) / IT_WAVES ) : 0;
+          const int need = max( 0, ( m - ( lane & ( IT_WAVES - 1 ) ) + IT_WAVES - 1 ) / IT_WAVES );
           for( ;; )
           {
-            const int p = lane < IT_WAVES ? prog[lane] : 0;
+            const int p = __hip_atomic_load( &sh.prog[lane & ( IT_WAVES - 1 )], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );      // (LDS-typed: a generic pointer made this a flat load that waited for every outstanding fetch)
             if( !__builtin_amdgcn_ballot_w64( p < need ) ) break;
             __builtin_amdgcn_s_sleep( 1 );
           }
@@ -3067,7 +3085,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
       }
       IT_BT( 1 );
       // (the wait makes the block's samples visible to the other wavefronts before the counter moves)
-#define IT_DONE() { wave_lds_sync(); done++; if( lane == 0 ) prog[wv] = done; IT_BT( 3 ); }
+#define IT_DONE() { wave_lds_sync(); done++; if( lane == 0 ) __hip_atomic_store( &sh.prog[wv], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ); IT_BT( 3 ); }
       // residual of sample i of the item (row-major inside its band): from the scratch, or from the residual plane for a block that is not split
       auto RES = [&]( int i ) -> int { const int pos = CP( C_POS ); return stashed ? (int) W.resi[i] : (int) (int16_t) rs[(size_t) ( ( pos >> 16 ) + yb + ( i >> lw ) ) * rstride + ( pos & 0xffff ) + ( i & ( w - 1 ) )]; };
       // ---- intra block copy (InterPrediction::xIntraBlockCopy :1995, DecCu.cpp:442-470): copy of reconstructed samples of this picture
@@ -3365,6 +3383,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
         // combination (IntraPredSampleFilterCore :212); angular (xPredIntraAng :592) in one 4-tap form for every kind - c = the cubic / Gauss
         // filter of the row's fraction (luma), { 0, 64 - 2 f, 2 f, 0 } for the 2-tap chroma interpolation, { 0, 64, 0, 0 } for whole-sample
         // angles - over 7 neighbouring reference samples
+        IT_BT( 4 );
         const bool angular = ( F & CF_ANG ) != 0, vec = ( F & CF_VEC ) != 0;
         const int ngroups = CP( C_NGROUPS ), lgpr = CG_LGPR( G ), gl = CG_GL( G ), g = 1 << gl;
         const int xxb = CP( C_XXB ), yyb = CP( C_YYB ), pscale = CP( C_PSCALE );
@@ -3376,6 +3395,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
         int tR = 0, lB = 0, t0 = 0, angle = 0, refEnd = 0, pdpcLev = 0, angScale = 0, invAngle = 0, bdpcm = 0;
         if( angular ) { angle = CP( C_ANGLE ); refEnd = CP( C_REFEND ); pdpcLev = CP( C_PDPCLEV ); angScale = CP( C_ANGSCALE ); invAngle = CP( C_INVANGLE ); t0 = Tp[0]; }
         else { tR = Tp[w + 1]; lB = Lp[h + 1]; bdpcm = CG_BDPCM( G ); }
+        IT_BT( 5 );
 #pragma unroll 1
         for( int gi = lane; gi < ngroups; gi += 64 )
         {
@@ -3468,6 +3488,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
             }
           }
         }
+        IT_BT( 6 );
       }
       IT_DONE()
     }
@@ -3555,12 +3576,12 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   unsigned long long* trace = nullptr, * btrace = nullptr;
   const size_t nItems = 1 << 20;      // (block timeline: sized generously, indexed by item)
   if( tr ) { hipMalloc( (void**) &trace, sizeof( unsigned long long ) * 8 * (size_t) numActive ); hipMemsetAsync( trace, 0, sizeof( unsigned long long ) * 8 * (size_t) numActive, s );
-             hipMalloc( (void**) &btrace, sizeof( unsigned long long ) * 4 * nItems ); hipMemsetAsync( btrace, 0, sizeof( unsigned long long ) * 4 * nItems, s ); }
+             hipMalloc( (void**) &btrace, sizeof( unsigned long long ) * 8 * nItems ); hipMemsetAsync( btrace, 0, sizeof( unsigned long long ) * 8 * nItems, s ); }
   hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync, dbg, trace, btrace );
   if( tr )
   {
     // developer timeline: ticket, phase time stamps (100 MHz), block count / unit word, number of producers; per block four shader-clock stamps
-    std::vector<unsigned long long> h( 8 * (size_t) numActive ), hb( 4 * nItems );
+    std::vector<unsigned long long> h( 8 * (size_t) numActive ), hb( 8 * nItems );
     hipStreamSynchronize( s );
     hipMemcpy( h.data(), trace, h.size() * sizeof( unsigned long long ), hipMemcpyDeviceToHost );
     hipMemcpy( hb.data(), btrace, hb.size() * sizeof( unsigned long long ), hipMemcpyDeviceToHost );
@@ -3571,7 +3592,7 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
     char name[128]; snprintf( name, sizeof( name ), "gpurun_out/intra_trace_poc%d.bin", pic.hdr.poc );
     if( FILE* f = fopen( name, "wb" ) ) { fwrite( h.data(), sizeof( unsigned long long ), h.size(), f ); fclose( f ); }
     snprintf( name, sizeof( name ), "gpurun_out/intra_btrace_poc%d.bin", pic.hdr.poc );
-    if( FILE* f = fopen( name, "wb" ) ) { fwrite( hb.data(), sizeof( unsigned long long ), 4 * maxItem, f ); fclose( f ); }
+    if( FILE* f = fopen( name, "wb" ) ) { fwrite( hb.data(), sizeof( unsigned long long ), 8 * maxItem, f ); fclose( f ); }
     snprintf( name, sizeof( name ), "gpurun_out/intra_units_poc%d.bin", pic.hdr.poc );
     if( FILE* f = fopen( name, "wb" ) ) { fwrite( hu.data(), sizeof( IntraUnit ), hu.size(), f ); fclose( f ); }
     snprintf( name, sizeof( name ), "gpurun_out/intra_items_poc%d.bin", pic.hdr.poc );

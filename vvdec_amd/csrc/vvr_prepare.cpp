@@ -173,6 +173,9 @@ int vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::
   {
     // sub-pictures: rectangles of whole CTUs that tile the picture
     if( !p->subpics || p->num_subpics > 255 ) FAIL( VVR_ERR_PARAMETER, "sub-pictures: at most 255, with their table" );
+    // a sub-picture consists of whole slices (VVC 6.3.1), and the availability rule of the intra stage looks at slices and tiles only: without
+    // the slice map intra prediction would read across sub-picture boundaries
+    if( !p->ctu_slice ) FAIL( VVR_ERR_PARAMETER, "sub-pictures need the slice map (ctu_slice): a sub-picture consists of whole slices" );
     if( h.wrap_offset ) FAIL( VVR_ERR_UNSUPPORTED, "sub-pictures together with reference wrap-around (the reference decoder does not support the pair either)" );
     const int ctuM = ( 1 << h.log2_ctu ) - 1;
     uint64_t area = 0;
