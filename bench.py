@@ -4,7 +4,7 @@
 Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: launched through torch.distributed.run)
   * a "step" is one pass of the hot path over one picture of the stream (all kernels: MC, residual, intra, deblock, SAO, ALF);
   * workload at N = 1 (--config 4k, the default): BASELINE.json configs[1], "3840x2160 10-bit random-access QP32, single MI355X" — a
-    hierarchical-B GOP-16 stream of synthetic pre-parsed pictures with an IRAP every 64 pictures (SURVEY.md §8(d) config 2);
+    hierarchical-B GOP-32 stream (six temporal layers) of synthetic pre-parsed pictures with an IRAP every 64 pictures (SURVEY.md §8(d) config 2);
     --config 8k = configs[2] (7680x4320 RA QP27), --config allintra = configs[4] (4K all-intra QP22, dual tree);
   * WHAT IS TIMED (`value`): the C-ABI path a decoder uses.  The timed region is K x vvr_submit(host records) + one vvr_sync,
     bracketed by a barrier and torch.cuda.synchronize() on both sides: validation, the host glue that turns the records into
@@ -16,10 +16,13 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: l
     then the K timed ones; P is chosen so that the timed window holds IRAP pictures in (at least) stream proportion,
     max(1, round(K / intra period)) of them, whatever K is; an IRAP is handed to the back-end --irap-lookahead pictures ahead of its
     decoding-order position (it depends on nothing; a host that parses ahead does the same);
+  * a K-picture window is 10-20 ms of a pipeline with host threads in it, so the whole sequence - stream from its first picture, pre-roll,
+    warm-up, K timed pictures - is run --repeats times (default 5) and `value` is the MEDIAN of the K-picture times (all samples, minimum and
+    maximum are in `config`); `config.value_irap_lookahead_0` is the same stream submitted in plain decoding order (no look-ahead);
   * N > 1: the stream shards by closed-GOP segment (each rank reconstructs its own independently decodable segment with its
     own DPB): no data-path collective, "scaling": "weak"; value = pictures of all ranks / max-over-ranks time;
-  * verification (rank 0, after the timed passes): the timed run's last pictures == a one-picture-at-a-time run, and --verify of those
-    timed pictures == the CPU oracle fed with the same reference pictures (checker only, never timed or shipped);
+  * verification (rank 0, after the timed passes): the last timed run's last pictures and the IRAP of its window == a one-picture-at-a-time
+    run, and the IRAP + --verify of those last pictures == the CPU oracle fed with the same reference pictures (checker only, never timed or shipped);
   * roofline: per-kernel durations from HIP events recorded on the launch streams in a further pass over the K timed pictures only
     (vvr_enable_stats; resident records so that launches are back to back); achieved = algorithmic bytes / duration
     for the kernel with the largest total time; `peak_measured` = the library's copy kernel over one DPB slot in the same run;
@@ -64,26 +67,37 @@ def _tools(abi):
             abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE)
 
 
+def _window(plans, order, K, Wm, n_irap):
+    """index (into `order`) of the first timed picture: the window [first, first + K) holds n_irap IRAP pictures, centred on them"""
+    from vvdec_amd import abi
+    iraps = [k for k, i in enumerate(order) if plans[i].slice_type == abi.SLICE_I and k > Wm]
+    lo, hi = iraps[0], iraps[n_irap - 1]
+    first = max(Wm, min(lo - 1, (lo + hi) // 2 - K // 2))
+    first = max(first, hi - K + 1)
+    got = sum(1 for k in iraps if first <= k < first + K)
+    assert got >= n_irap and first + K <= len(order), (first, K, iraps[:4], len(order))
+    return first
+
+
 def stream_plan(cfg_name, gop, intra_period, irap_lookahead, slots, K, Wm):
-    """-> (plans in submission order, number of DPB slots, index of the first timed picture)"""
+    """-> (plans in DECODING order with their DPB slots, number of slots, {look-ahead: (submission order = indices into plans, index of the
+    first timed picture in that order)}).  The same picture descriptions serve every submission order (vvdec_amd.stream.submission_order)."""
     from vvdec_amd import abi, stream
     if cfg_name == "allintra":
         pool = max(slots, 2)
         plans = [stream.PicPlan(poc=i, layer=0, slice_type=abi.SLICE_I, slot=i % pool, ref_slots=([], [])) for i in range(Wm + K)]
-        return plans, pool, Wm
+        return plans, pool, {irap_lookahead: (list(range(Wm + K)), Wm), 0: (list(range(Wm + K)), Wm)}
     n_irap = max(1, int(round(K / float(intra_period))))
     # enough stream for: a first intra period (pre-roll), the window, the look-ahead
     nframes = intra_period * (n_irap + 2) + K + Wm + gop
     nframes = ((nframes - 1 + gop - 1) // gop) * gop + 1
-    plans, nslots = stream.ra_plan(nframes, gop=gop, seed_poc0_is_external=False, pool=slots, intra_period=intra_period, irap_lookahead=irap_lookahead)
-    iraps = [i for i, pl in enumerate(plans) if pl.slice_type == abi.SLICE_I and i > Wm]
-    # the window [first, first + K) holds iraps[0 .. n_irap): centre it on them
-    lo, hi = iraps[0], iraps[n_irap - 1]
-    first = max(Wm, min(lo - 1, (lo + hi) // 2 - K // 2))
-    first = max(first, hi - K + 1)
-    got = sum(1 for i in iraps if first <= i < first + K)
-    assert got >= n_irap and first + K <= len(plans), (first, K, iraps[:4], len(plans))
-    return plans[:first + K], max(nslots, slots), first
+    plans, nslots = stream.ra_plan(nframes, gop=gop, seed_poc0_is_external=False, pool=slots, intra_period=intra_period)
+    orders = {}
+    for la in sorted({irap_lookahead, 0}):
+        order = stream.submission_order(plans, la)
+        first = _window(plans, order, K, Wm, n_irap)
+        orders[la] = (order[:first + K], first)
+    return plans, max(nslots, slots), orders
 
 
 def _cpu_worker(args):
@@ -96,7 +110,8 @@ def _cpu_worker(args):
         pl = stream.PicPlan(poc=idx, layer=0, slice_type=abi.SLICE_I, slot=0, ref_slots=([], []))
     else:
         plans, _ = stream.ra_plan(gop + 1, gop=gop, seed_poc0_is_external=False)
-        pl = plans[1 + idx % (len(plans) - 1)]                     # the B pictures of one GOP (the IRAP share of the stream is 1 / 64)
+        # the pictures of the stream in its proportions: one IRAP (the I picture of the plan) per intra period, B pictures of one GOP otherwise
+        pl = plans[0] if idx % CONFIGS[cfg_name][3] == CONFIGS[cfg_name][3] - 1 else plans[1 + idx % (len(plans) - 1)]
     d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, **mix)
     refs = {}
     for lst in pl.ref_slots:
@@ -179,7 +194,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="4k")
     ap.add_argument("--width", type=int, default=0, help="override the configuration's picture size (tests)")
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--gop", type=int, default=16)
+    ap.add_argument("--gop", type=int, default=32, help="hierarchical-B GOP size (SURVEY 8(d) config 2: 32, six temporal layers)")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed K-picture window is run this many times, each from the first picture of the stream; value = the median")
     ap.add_argument("--streams", type=int, default=8, help="pictures in flight per GPU")
     ap.add_argument("--host-threads", type=int, default=16, help="worker threads inside the library that prepare submitted pictures")
     ap.add_argument("--ring", type=int, default=0, help="entries of the library's upload ring (0: its default)")
@@ -220,14 +236,16 @@ def main():
     tools = _tools(abi)
     K, Wm = a.steps, a.warmup
     intra_period = ip_default if a.intra_period < 0 else a.intra_period
-    plans, nslots, first = stream_plan(a.config, a.gop, intra_period, a.irap_lookahead, a.slots, K, Wm)
-    n_irap = sum(1 for pl in plans[first:first + K] if pl.slice_type == abi.SLICE_I)
+    plans, nslots, orders = stream_plan(a.config, a.gop, intra_period, a.irap_lookahead, a.slots, K, Wm)
+    order, first = orders[a.irap_lookahead]           # submission order of the headline figure (indices into plans) and its first timed picture
+    n_irap = sum(1 for i in order[first:first + K] if plans[i].slice_type == abi.SLICE_I)
     seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads, ring_entries=a.ring, stop_after=a.stop_after)
     # the records are written where a parser integrated with the back-end would write them: host memory the device reads directly (vvr_host_alloc)
-    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, alloc=None if a.pageable_records else rec.host_array, **mix) for pl in plans]
+    needed = max(max(o) for o, _ in orders.values()) + 1
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, alloc=None if a.pageable_records else rec.host_array, **mix) for pl in plans[:needed]]
     cpics = [d.c() for d in descs]                     # the host records as the C ABI sees them (plain structs pointing at the arrays)
-    upload_mb = sum(d.cu.nbytes + d.tu.nbytes + d.coef.nbytes + d.lfp[0].nbytes + d.lfp[1].nbytes for d in descs[first:first + K]) / K / 1e6
+    upload_mb = sum(descs[i].cu.nbytes + descs[i].tu.nbytes + descs[i].coef.nbytes + descs[i].lfp[0].nbytes + descs[i].lfp[1].nbytes for i in order[first:first + K]) / K / 1e6
 
     enq = {}
 
@@ -238,44 +256,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def host_pass(i0, n, all_ranks=True):
+    def host_pass(idx, all_ranks=True):
         # the C-ABI path: host records in, reconstructed pictures in the DPB
         barrier(all_ranks)
         t0 = time.perf_counter()
-        for i in range(i0, i0 + n):
+        for i in idx:
             rec.submit_c(cpics[i])
         enq["host"] = time.perf_counter() - t0              # the submitting thread is done here; the rest is the wait for the pictures
         barrier(all_ranks)
         return time.perf_counter() - t0
 
-    # ---- the timed run: pre-roll and warm-up untimed, then exactly K steps through vvr_submit
-    host_pass(0, first - Wm)
-    host_pass(first - Wm, Wm)
-    dt = host_pass(first, K)
+    def window(order_, first_):
+        """the stream from its first picture: pre-roll and warm-up untimed, then exactly K steps through vvr_submit, timed (max over ranks)"""
+        host_pass(order_[:first_ - Wm])
+        host_pass(order_[first_ - Wm:first_])
+        dt_ = host_pass(order_[first_:first_ + K])
+        if world > 1:
+            t = torch.tensor([dt_], device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_
+
+    # ---- the timed runs.  One K-picture window is 10-20 ms of a pipeline with 16 host threads in it: a noisy instrument.  The window is therefore
+    # run --repeats times, every time from the first picture of the stream (fresh pre-roll), and `value` is the MEDIAN; all samples are printed.
+    # The same stream in plain decoding order (no IRAP look-ahead: what a host without a reorder buffer submits) is timed next to it.
+    dts = [window(order, first) for _ in range(max(1, a.repeats))]
     enq_host = enq["host"]
-    if world > 1:
-        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     tail_n = min(8, K)
-    tail = list(range(first + K - tail_n, first + K))                       # the last timed pictures still sit in their slots
-    timed_out = {i: rec.read_picture(plans[i].slot) for i in tail if all(plans[j].slot != plans[i].slot for j in range(i + 1, first + K))}
+    keep = order[first + K - tail_n:first + K] + [i for i in order[first:first + K] if plans[i].slice_type == abi.SLICE_I]
+    later = {i: k for k, i in enumerate(order[:first + K])}
+    # (a timed picture can be checked if nothing submitted after it has overwritten its slot: the last pictures and, with a 48-slot DPB, the IRAP)
+    timed_out = {i: rec.read_picture(plans[i].slot) for i in dict.fromkeys(keep) if all(plans[j].slot != plans[i].slot for j in order[later[i] + 1:first + K])}
+    dts0 = []
+    if a.irap_lookahead and a.config != "allintra":
+        order0, first0 = orders[0]
+        dts0 = [window(order0, first0) for _ in range(max(1, min(3, a.repeats)))]
+    dt = float(np.median(dts))
 
     # ---- the same K pictures with records and work lists resident in HBM (the device pipeline alone)
     prepared = {}
 
-    def resident_pass(i0, n, all_ranks=True):
-        for i in range(i0, i0 + n):
+    def resident_pass(k0, n, all_ranks=True):
+        idx = order[k0:k0 + n]
+        for i in idx:
             if i not in prepared:
                 prepared[i] = rec.prepare(descs[i])
         barrier(all_ranks)
         t0 = time.perf_counter()
-        for i in range(i0, i0 + n):
+        for i in idx:
             rec.submit_prepared(prepared[i])
         enq["device"] = time.perf_counter() - t0
         barrier(all_ranks)
         return time.perf_counter() - t0
 
+    window(order, first)                               # (the DPB as the headline order leaves it)
     resident_pass(first - Wm, Wm)
     dt_dev = resident_pass(first, K)
     enq_dev = enq["device"]
@@ -310,12 +344,13 @@ def main():
                                             "algo_GBps": round(s["algo_bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1)} for s in st}}
         # HBM-side traffic of that kernel from the separate PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over this command,
         # gfx950 correction applied, profiles/*_pmc_traffic.json); counters cannot be collected inside this run
-        for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+        # (keyed by configuration AND kernel: the 8K and all-intra lines must not carry the 4K figure)
+        for name in ("round3_pmc_traffic.json",):
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["configs"][a.config]["kernels"]
                 ent = next(v for k, v in pmc.items() if k.split("<")[0] == dom["name"])
                 roof["traffic"] = ent["hbm_side_bytes_per_launch_corrected"]
-                roof["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes, bytes per launch)" % name
+                roof["traffic_source"] = "profiles/%s, configuration %s (separate rocprofv3 --pmc passes, bytes per launch)" % (name, a.config)
                 break
             except Exception:
                 pass
@@ -325,8 +360,10 @@ def main():
         if a.verify:
             import refdrv
             rec2 = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, device=local_rank)
-            check = set(tail[-min(a.verify, len(tail)):])
-            for i, (pl, d) in enumerate(zip(plans, descs)):
+            # the IRAP of the window (the picture that took the priority lane and overtook others) and the last timed pictures
+            check = set([i for i in timed_out if plans[i].slice_type == abi.SLICE_I] + [i for i in order[first + K - tail_n:first + K] if i in timed_out][-min(a.verify, tail_n):])
+            for i in order:
+                pl, d = plans[i], descs[i]
                 refs = None
                 if i in check:
                     refs = {slot: rec2.read_picture(slot) for lst in pl.ref_slots for (slot, _) in lst}
@@ -352,6 +389,11 @@ def main():
                                       % (cfg_text, W, H, "" if a.config == "allintra" else ", hierarchical-B GOP %d, IRAP every %d pictures, submitted %d pictures ahead of its decoding-order position" % (a.gop, intra_period, a.irap_lookahead),
                                          a.host_threads, upload_mb, first - Wm, n_irap),
                           "timed_path": "vvr_submit(host records)", "host_records_in": "pageable memory (staged by the library)" if a.pageable_records else "pinned host memory of the context (vvr_host_alloc): cu / tu / coef / lfp arrays are copied to HBM from where the generator wrote them", "host_threads": a.host_threads, "host_cores": os.cpu_count(),
+                          "value_is": "median of %d runs of the K-picture window, each from the first picture of the stream (pre-roll and warm-up untimed)" % len(dts),
+                          "value_samples_fps": [round(world * K / x, 1) for x in dts], "value_min_fps": round(world * K / max(dts), 2), "value_max_fps": round(world * K / min(dts), 2),
+                          "value_irap_lookahead_0": round(world * K / float(np.median(dts0)), 2) if dts0 else None,
+                          "value_irap_lookahead_0_samples_fps": [round(world * K / x, 1) for x in dts0],
+                          "value_irap_lookahead_0_what": "the same stream submitted in plain decoding order (a host without a reorder buffer): the IRAP arrives when its turn comes",
                           "device_only_fps": round(world * K / dt_dev, 2), "device_only_ms_per_step": round(1e3 * dt_dev / K, 4),
                           "submit_loop_ms": {"vvr_submit": round(1e3 * enq_host, 2), "vvr_submit_prepared": round(1e3 * enq_dev, 2), "what": "time the submitting thread spends in the K calls (of the timed K-picture passes: %.2f / %.2f ms)" % (1e3 * dt, 1e3 * dt_dev)},
                           "device_only_what": "same K pictures, records and work lists resident in HBM (vvr_prepare + vvr_submit_prepared)",
@@ -371,25 +413,40 @@ def main():
     # under a watchdog: whatever happens to it (an exception, a collective that never completes), the line with the segment-mode result is printed.
     if world > 1 and a.config != "allintra" and not a.no_picture_sharding:
         import threading
+        line_lock = threading.Lock()           # the line is printed once: by the watchdog or by the main path, whoever takes the lock first
+        state = {"printed": False}
 
         def give_up():
-            if rank == 0:
-                out["config"]["picture_sharding"] = {"error": "no result within %d s" % a.picture_sharding_timeout}
-                print(json.dumps(out), flush=True)
-            else:
+            with line_lock:
+                if state["printed"]:
+                    return
+                state["printed"] = True
+                if rank == 0:
+                    out["config"]["picture_sharding"] = {"error": "no result within %d s" % a.picture_sharding_timeout, "timeout": True}
+                    print(json.dumps(out), flush=True)
+            if rank != 0:
                 time.sleep(3)
-            os._exit(0)
+            os._exit(0)          # (ranks may hang in a collective: the process ends here; the line carries the timeout)
 
         timer = threading.Timer(a.picture_sharding_timeout, give_up)
         timer.daemon = True
         timer.start()
         try:
-            pic_mode = picture_sharding_pass(a, W, H, mix, tools, plans, nslots, first, K, Wm, rank, world, local_rank, backend)
+            pic_mode = picture_sharding_pass(a, W, H, mix, tools, [plans[i] for i in order], nslots, first, K, Wm, rank, world, local_rank, backend)
         except Exception as e:            # noqa: BLE001 - the segment-mode line must survive
             pic_mode = {"error": repr(e)[:300]}
-        timer.cancel()
-        if rank == 0:
-            out["config"]["picture_sharding"] = pic_mode
+        with line_lock:
+            timer.cancel()
+            if state["printed"]:
+                return
+            if rank == 0:
+                out["config"]["picture_sharding"] = pic_mode
+            state["printed"] = True
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

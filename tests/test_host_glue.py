@@ -192,11 +192,15 @@ def _check_tables(d, units, items):
         elif (int(it["flags"]) & 6) == 6 and not comp:
             pass                        # ISP partitions: their CU's reference line and the partition chain (inside one unit by construction)
         else:
-            for k in range(0, ww, unit):
-                reads.append((comp, x0 + k, y0 - 1, False))
-            for k in range(0, hh, unit):
-                reads.append((comp, x0 - 1, y0 + k, False))
-            reads.append((comp, x0 - 1, y0 - 1, False))
+            # what the kernel reads (k_intra's reference fill): the nA units above incl. above-right, the nL units left incl. below-left, the
+            # corner - one line (luma: possibly a line 1 or 2 further out, multi-reference-line prediction)
+            mrl = 0 if (comp or (int(it["flags"]) & 8)) else (int(it["flags"]) >> 4) & 3
+            for k in range(0, int(it["nA"]) * unit, unit):
+                reads.append((comp, x0 + k, y0 - 1 - mrl, True))
+            for k in range(0, int(it["nL"]) * unit, unit):
+                reads.append((comp, x0 - 1 - mrl, y0 + k, True))
+            if int(it["nTL"]) & 1:
+                reads.append((comp, x0 - 1 - mrl, y0 - 1 - mrl, True))
             if comp and 67 <= mode <= 69:
                 for yy in range(0, 2 * hh, 4):
                     for xx in range(0, 2 * ww, 4):
@@ -212,7 +216,7 @@ def _check_tables(d, units, items):
             if not must and not same_slice_tile(cy, cx, *cell(comp, x0, y0)):
                 continue                # in another slice or tile: not available, not read
             if must and k == comp:
-                assert order[1 if k else 0, cy, cx] < myo, "IBC reference block is not reconstructed before the block"
+                assert order[1 if k else 0, cy, cx] < myo, "a sample the block reads is not reconstructed before the block"
             j = int(prod[k, cy, cx])
             assert ordered_before(j, i), "block %d (unit %d) reads block %d (unit %d) without waiting for it" % (i, unit_of[i], j, unit_of[j])
             nchk += j >= 0 and j != i
@@ -290,6 +294,33 @@ def test_checker_detects_a_missing_dependency(stub):
     broken["ndeps"][:] = 0
     with pytest.raises(AssertionError, match="without waiting"):
         _check_tables(d, broken, items)
+    stub.vvr_free_prepared(ctx.ctx, hnd)
+    ctx.close()
+
+
+def test_blocks_of_a_unit_that_do_not_read_from_each_other(stub):
+    """the kernel predicts a unit's blocks with several wavefronts; a block starts when every block up to index - indep - 1 of its unit is done
+    (IntraItem::comp bits 2..7).  The host finds independent blocks (B pictures: the clusters that share a unit), and the checker notices when a
+    block claims more independence than it has"""
+    W, H = 416, 240
+    plans, nslots = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    ctx = Ctx(stub, W, H, nslots)
+    d = synth.picture_for_plan(plans[2], W, H, seed=509, tool_flags=TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, p_intra=0.3, p_cclm=0.3, p_ciip=0.15, p_isp=0.2)
+    hnd = ctx.prepare(d)
+    units, items = ctx.tables(hnd)
+    assert _check_tables(d, units, items) > 0
+    indep = items["comp"] >> 2
+    assert (indep > 0).sum() > 10, "no independent blocks found in a B picture with isolated intra CUs"
+    caught = 0
+    serial = [i for i in range(1, len(items)) if indep[i] == 0 and items["mode"][i] < 254]
+    for i in serial[:60]:
+        b = items.copy()
+        b["comp"][i] = (int(b["comp"][i]) & 3) | (1 << 2)
+        try:
+            _check_tables(d, units, b)
+        except AssertionError:
+            caught += 1
+    assert caught > 0
     stub.vvr_free_prepared(ctx.ctx, hnd)
     ctx.close()
 

@@ -39,6 +39,7 @@ struct PrepScratch
   uint32_t numDmvr = 0;
   std::vector<TbItem> tb[3];
   std::vector<IntraItem> intra[3], intraTmp[3], intraAll;
+  std::vector<uint32_t> posAfterGrouping[3]; uint32_t groupFill[3] = { 0, 0, 0 };      // (groupUnits) block -> its place in the regrouped list
   std::vector<uint32_t> itemMap[3];                       // block of a component -> its first item in intraAll (large blocks become several items)
   std::vector<ItemH> itemH[3], itemHTmp;
   std::vector<uint32_t> prodPool[3];
@@ -996,6 +997,46 @@ int PrepScratch::groupUnits()
     newIndexOfGroup[m] = (uint32_t) merged.size();
     merged.push_back( std::move( U ) );
   }
+  // ---- which of the blocks directly before it in its unit a block does NOT read from (IntraItem::comp bits 2..7, in blocks here; emitUnitTable
+  // turns it into items): the kernel predicts a unit's blocks with several wavefronts and starts a block when all blocks up to the last one
+  // it reads from are done.  The clusters that share a unit cannot depend on each other, and inside a cluster a block mostly reads from the
+  // one before it - but not always (the first block of the lower half of a split reads from the upper half's first blocks only).
+  // Blocks of all-intra CTUs (no producer lists were collected) stay serial.
+  {
+    for( int k = 0; k < ncomp; k++ ) posAfterGrouping[k].assign( intra[k].size(), 0xffffffffu );
+    for( int k = 0; k < 3; k++ ) groupFill[k] = 0;
+    for( uint32_t m : orderM ) for( uint32_t u : groups[m] )
+    {
+      const UnitH& o = units[u];
+      for( uint32_t i = o.i0; i < o.i1; i++ ) posAfterGrouping[o.comp][i] = groupFill[o.comp]++;
+    }
+    for( uint32_t m : orderM )
+    {
+      const UnitH& U = merged[newIndexOfGroup[m]];
+      if( U.iA == U.i1 || fastCtu[U.ctu] ) continue;
+      const uint32_t c = U.comp;
+      for( uint32_t u : groups[m] )
+      {
+        const UnitH& o = units[u];
+        for( uint32_t i = o.i0; i < o.i1; i++ )
+        {
+          const uint32_t local = posAfterGrouping[c][i] - U.i0;
+          int64_t last = -1;                       // the last block of the unit this one reads from
+          const ItemH& ih = itemH[c][i];
+          for( uint32_t q = ih.p0; q < ih.p0 + ih.pn; q++ )
+          {
+            const uint32_t key = prodPool[c][q], pk = key >> 28, pi = key & 0x0fffffffu;
+            if( pk != c || target[unitOfItem[pk][pi]] != (int32_t) m ) continue;
+            last = std::max<int64_t>( last, (int64_t) posAfterGrouping[c][pi] - (int64_t) U.i0 );
+          }
+          if( last >= (int64_t) local ) last = (int64_t) local - 1;      // (cannot happen: producers precede their readers in coding order)
+          const uint32_t indep = std::min<uint32_t>( 63, (uint32_t) ( (int64_t) local - 1 - last ) );
+          IntraItem& dst = intraTmp[c][posAfterGrouping[c][i]];
+          dst.comp = (uint8_t) ( ( dst.comp & 3 ) | ( indep << 2 ) );
+        }
+      }
+    }
+  }
   for( size_t m = 0; m < numGroups; m++ )
   {
     UnitH& U = merged[newIndexOfGroup[m]];
@@ -1022,9 +1063,13 @@ int PrepScratch::emitUnitTable( std::string& err )
   for( int k = 0; k < 3; k++ )
   {
     itemMap[k].reserve( intra[k].size() + 1 );
-    for( const IntraItem& src : intra[k] )
+    for( size_t bi = 0; bi < intra[k].size(); bi++ )
     {
+      const IntraItem& src = intra[k][bi];
       itemMap[k].push_back( (uint32_t) intraAll.size() );
+      // the blocks before this one that it does not read from (groupUnits), counted in items
+      const uint32_t indepBlocks = std::min<uint32_t>( src.comp >> 2, (uint32_t) bi );
+      const uint32_t indepItems = itemMap[k][bi] - itemMap[k][bi - indepBlocks];
       const int samples = 1 << ( src.lw + src.lh );
       const bool split = !k && samples > IT_PART_SAMPLES && src.mode <= 66 && !( src.flags & IT_F_MIP ) && ( src.flags & IT_F_ISP ) != IT_F_ISP;
       const int lp = split ? ( samples > 2 * IT_PART_SAMPLES ? 2 : 1 ) : 0;
@@ -1032,7 +1077,7 @@ int PrepScratch::emitUnitTable( std::string& err )
       {
         IntraItem it = src;
         it.nTL = (uint8_t) ( ( src.nTL & 1 ) | ( part << 4 ) | ( lp << 6 ) );
-        it.comp = (uint8_t) ( k | ( part << 2 ) );
+        it.comp = (uint8_t) ( k | ( std::min<uint32_t>( 63, indepItems + part ) << 2 ) );
         intraAll.push_back( it );
       }
     }

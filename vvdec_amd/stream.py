@@ -105,3 +105,25 @@ def ra_plan(num_frames, gop=16, seed_poc0_is_external=True, pool=0, intra_period
         free_at[s] = last_use.get(p.poc, i)
         p.ref_slots = ([(slot_of[r], r) for r in p.l0], [(slot_of[r], r) for r in p.l1])
     return plans, max_slots
+
+
+def submission_order(plans, irap_lookahead):
+    """Order in which a host that parses `irap_lookahead` pictures ahead hands the pictures of `plans` (decoding order, slots assigned, i.e. what
+    ra_plan(..., irap_lookahead=0) returns) to the back-end: an IRAP picture depends on nothing, so it is submitted that many positions before its
+    decoding-order position (its long intra wavefront then overlaps with the pictures it jumped).  -> list of indices into `plans`.
+
+    The slot plan is the decoding-order one, so the two orders of one stream use the same picture descriptions.  That is only sound if the slot
+    an IRAP writes is not read by a picture it jumps over (the back-end orders a writer behind the readers submitted BEFORE it): checked here."""
+    order = list(range(len(plans)))
+    if irap_lookahead <= 0:
+        return order
+    for i in range(1, len(plans)):
+        if plans[i].slice_type == 2:
+            pos = order.index(i)
+            j = max(1, pos - irap_lookahead)
+            jumped = order[j:pos]
+            for k in jumped:
+                slots = [s for lst in plans[k].ref_slots for (s, _) in lst] + [plans[k].slot]
+                assert plans[i].slot not in slots, "IRAP POC %d would overwrite slot %d before POC %d has used it: more DPB slots (pool) needed for this look-ahead" % (plans[i].poc, plans[i].slot, plans[k].poc)
+            order.insert(j, order.pop(pos))
+    return order
