@@ -8,7 +8,7 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: l
     --config 8k = configs[2] (7680x4320 RA QP27), --config allintra = configs[4] (4K all-intra QP22, dual tree);
   * WHAT IS TIMED (`value`): the C-ABI path a decoder uses.  The timed region is K x vvr_submit(host records) + one vvr_sync,
     bracketed by a barrier and torch.cuda.synchronize() on both sides: validation, the host glue that turns the records into
-    device work lists (--host-threads worker threads inside the library, default 16; the 8-thread figure is in DESIGN.md section 6), the H2D copy of every picture (pinned ring,
+    device work lists (--host-threads worker threads inside the library, default 8, pinned to the GPU's NUMA node), the H2D copy of every picture (pinned ring,
     async) and all kernels.  The records sit in host memory when the region starts — what a CABAC parser leaves behind.
     `config.device_only_fps` is a second timed pass over the same K pictures with the records and work lists already resident in
     HBM (vvr_prepare / vvr_submit_prepared): the number the device pipeline alone sustains.
@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--gop", type=int, default=32, help="hierarchical-B GOP size (SURVEY 8(d) config 2: 32, six temporal layers)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed K-picture window is run this many times, each from the first picture of the stream; value = the median")
     ap.add_argument("--streams", type=int, default=8, help="pictures in flight per GPU")
-    ap.add_argument("--host-threads", type=int, default=16, help="worker threads inside the library that prepare submitted pictures")
+    ap.add_argument("--host-threads", type=int, default=8, help="worker threads inside the library that prepare submitted pictures (round 3, driver arguments: 8 threads 1014..1063 frames/s over five windows, 16 threads 780..1048: sixteen pictures prepared at once contend for memory bandwidth)")
     ap.add_argument("--ring", type=int, default=0, help="entries of the library's upload ring (0: its default)")
     ap.add_argument("--slots", type=int, default=48, help="DPB slots used round-robin (physical slots are cheap in 288 GB: 48 x 25 MB at 4K; fewer slots = more write-after-read waits between pictures in flight)")
     ap.add_argument("--intra-period", type=int, default=-1, help="an IRAP picture every N pictures (multiple of --gop); default: the configuration's")
