@@ -354,8 +354,8 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   }
   if( q->numAffItems ) timed( K_MC_AFFINE, [&]{ launch_mc_affine( s, q->pic, refs, A, q->affItems, q->numAffItems ); } );
   const bool lmcsOn = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
-  // LMCS: the inter prediction is forward-mapped before any residual is added (DecCu.cpp:458-476); I pictures have no inter prediction
-  if( lmcsOn && h.slice_type != 2 && ( q->numMc + q->numBdofItems + q->numDmvrItems + q->numAffItems ) ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 0 ); } );
+  // LMCS: the inter prediction is forward-mapped before any residual is added (DecCu.cpp:458-476) - by the motion-compensation kernels themselves
+  // where they store their luma samples (lmcs_fwd_luma): no pass over the picture
   if( q->numTb[0] + q->numTb[1] + q->numTb[2] )
     timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); } );
   // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)

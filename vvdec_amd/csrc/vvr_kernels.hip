@@ -21,6 +21,9 @@ __device__ __forceinline__ int clip_pel( int v, int bd ) { return clip3( 0, ( 1 
 __device__ __forceinline__ int iabs( int v ) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int ilog2( int v ) { return 31 - __clz( v ); }
 __device__ __forceinline__ int sgn( int v ) { return ( v > 0 ) - ( v < 0 ); }
+// LMCS: the luma prediction of an inter CU is mapped forward before anything is added to it (DecCu.cpp:458-476, Reshape::rspFwdCore) - applied where
+// the motion-compensation kernels store their luma samples (the table is 2 KB and stays in the vector cache), not by a pass of its own
+__device__ __forceinline__ int lmcs_fwd_luma( const int16_t* __restrict__ fwdLut, int c, int v ) { return ( fwdLut && c == 0 ) ? (int) fwdLut[v] : v; }
 
 } // namespace
 
@@ -194,7 +197,7 @@ struct BdofShared {
 };
 template<int NT>
 __device__ __forceinline__ void mc_bdof_luma( BdofShared& bs, const pel_t* win0, const pel_t* win1, int wst, const McSeg* seg /* luma segment of list 0 */, int segStride,
-                                              int bd, const DevPlanes& reco, int x0, int y0, int w, int h, int tid )
+                                              int bd, const DevPlanes& reco, int x0, int y0, int w, int h, int tid, const int16_t* __restrict__ fwdLut /* LMCS forward map or nullptr */ )
 {
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   const int lw = w == 16 ? 4 : 3;
@@ -272,7 +275,7 @@ __device__ __forceinline__ void mc_bdof_luma( BdofShared& bs, const pel_t* win0,
         const int px = ( xu << 2 ) + x, o = py * 16 + px, ob = ( 1 + py ) * BDOF_S + 1 + px;
         const int b = tmpx * ( bs.gx[0][o] - bs.gx[1][o] ) + tmpy * ( bs.gy[0][o] - bs.gy[1][o] );
         const int v = clip_pel( (int16_t) ( ( bs.blk[0][ob] + bs.blk[1][ob] + b + offset ) >> shiftNum ), bd );
-        reco.p[0][(size_t) ( y0 + py ) * reco.stride[0] + x0 + px] = (pel_t) v;
+        reco.p[0][(size_t) ( y0 + py ) * reco.stride[0] + x0 + px] = (pel_t) lmcs_fwd_luma( fwdLut, 0, v );
       }
     }
   }
@@ -387,7 +390,7 @@ __device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int
 // bs: BDOF buffers (the 14-bit luma predictions go there instead of being averaged) or nullptr
 template<int NT>
 __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int nl, int ncomp, bool uni, const vvr_cu& cu, bool geo, int bcwIdx, int bd, int headroom,
-                                            const DevPlanes& reco, int tx, int ty, int tw, int th, int tid,
+                                            const DevPlanes& reco, int tx, int ty, int tw, int th, int tid, const int16_t* __restrict__ fwdLut /* LMCS forward map or nullptr */,
                                             const vvr_wp_params* __restrict__ wp = nullptr /* non-null: explicit weighted prediction */, int wpL = 0, int wpR0 = 0, int wpR1 = 0 )
 {
   struct { int x, y, w, h; } it = { tx, ty, tw, th };
@@ -462,7 +465,7 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
             out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
           }
         }
-        dstp[(size_t) i * reco.stride[c]] = (pel_t) out;
+        dstp[(size_t) i * reco.stride[c]] = (pel_t) lmcs_fwd_luma( fwdLut, c, out );
       }
     }
   }
@@ -475,6 +478,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
 {
   __shared__ Mc2Shared m;
   __shared__ typename std::conditional<BDOF, BdofShared, int>::type bs;
+  const int16_t* __restrict__ fwdLut = pic.lmcs ? pic.lmcs->fwd_lut : nullptr;      // LMCS: luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const int item = mc_item_index();
   if( item >= numItems ) return;
   const McItem it = items[item];
@@ -527,12 +531,12 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   mc2_stage1<NT>( m, nl, ncomp, it.w, it.h, headroom, tid );
   __syncthreads();
   const bool wpOn = !BDOF && pic.wp && !geo && it.bcw == 2;          // xPredInterBi (:707,735-742)
-  mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, uni, cu, geo, it.bcw, bd, headroom, reco, it.x, it.y, it.w, it.h, tid,
+  mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, uni, cu, geo, it.bcw, bd, headroom, reco, it.x, it.y, it.w, it.h, tid, fwdLut,
                   wpOn ? pic.wp : nullptr, l0, mRef[0], mRef[1] );
   if constexpr( BDOF )
   {
     __syncthreads();
-    mc_bdof_luma<NT>( bs, m.winL[0], m.winL[1], MC2_WST_L, &m.seg[0][0], 3, bd, reco, it.x, it.y, it.w, it.h, tid );
+    mc_bdof_luma<NT>( bs, m.winL[0], m.winL[1], MC2_WST_L, &m.seg[0][0], 3, bd, reco, it.x, it.y, it.w, it.h, tid, fwdLut );
   }
 }
 
@@ -573,6 +577,7 @@ template<int NT>
 __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems, int32_t* __restrict__ dmvrOut )
 {
   __shared__ DmvrShared sh;
+  const int16_t* __restrict__ fwdLut = pic.lmcs ? pic.lmcs->fwd_lut : nullptr;      // LMCS: luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const int item = mc_item_index();
   if( item >= numItems ) return;
   const McItem it = items[item];
@@ -741,11 +746,11 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
   __syncthreads();
   mc2_stage1<NT>( sh.m, 2, ncomp, w, h, headroom, tid );
   __syncthreads();
-  mc2_stage2<NT>( sh.m, bioSub ? &sh.bs : nullptr, 2, ncomp, false, cu, false, 2, bd, headroom, reco, it.x, it.y, w, h, tid );
+  mc2_stage2<NT>( sh.m, bioSub ? &sh.bs : nullptr, 2, ncomp, false, cu, false, 2, bd, headroom, reco, it.x, it.y, w, h, tid, fwdLut );
   if( bioSub )
   {
     __syncthreads();
-    mc_bdof_luma<NT>( sh.bs, sh.m.winL[0], sh.m.winL[1], MC2_WST_L, &sh.m.seg[0][0], 3, bd, reco, it.x, it.y, w, h, tid );
+    mc_bdof_luma<NT>( sh.bs, sh.m.winL[0], sh.m.winL[1], MC2_WST_L, &sh.m.seg[0][0], 3, bd, reco, it.x, it.y, w, h, tid, fwdLut );
   }
 }
 
@@ -844,6 +849,7 @@ template<int NT>
 __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
 {
   __shared__ AffShared sh;
+  const int16_t* __restrict__ fwdLut = pic.lmcs ? pic.lmcs->fwd_lut : nullptr;      // LMCS: luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const int item = mc_item_index();
   if( item >= numItems ) return;
   const McItem it = items[item];
@@ -1060,7 +1066,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
         }
       }
       const int x = ( it.x >> cs ) + 4 * ( sb % sbw ) + px, y = ( it.y >> cs ) + 4 * ( sb / sbw ) + py;
-      reco.p[c][(size_t) y * reco.stride[c] + x] = (pel_t) out;
+      reco.p[c][(size_t) y * reco.stride[c] + x] = (pel_t) lmcs_fwd_luma( fwdLut, c, out );
     }
   }
 }
@@ -1477,6 +1483,9 @@ __constant__ uint8_t c_dbLongMidW[3][3][7] = {       // [own length 3 / 5 / 7][o
   { { 2, 2, 2, 2, 0, 0, 0 }, { 2, 2, 2, 1, 1, 0, 0 }, { 2, 2, 1, 1, 1, 1, 0 } },
   { { 2, 1, 1, 1, 1, 1, 1 }, { 2, 2, 1, 1, 1, 1, 0 }, { 2, 1, 1, 1, 1, 1, 1 } } };
 __constant__ uint8_t c_dbLongTc[2][7] = { { 6, 4, 2, 0, 0, 0, 0 }, { 6, 5, 4, 3, 2, 1, 1 } };      // tc factor per sample: sides of 3, sides of 5 or 7
+// interpolation weights of the long filters, ( 64 * ( 2 * ( n - k ) - 1 ) + n ) / ( 2 * n ) for n = 3, 5, 7 (dbCoeffs3 / 5 / 7 of the standard): a table, not a
+// division per sample
+__constant__ uint8_t c_dbLongCf[3][8] = { { 53, 32, 11, 0, 0, 0, 0, 0 }, { 58, 45, 32, 19, 6, 0, 0, 0 }, { 59, 50, 41, 32, 23, 14, 5, 0 } };
 __device__ void filter_long( pel_t* src, int step, int o, int nP, int nQ, int tc )
 {
   const int iP = ( nP - 3 ) >> 1, iQ = ( nQ - 3 ) >> 1;
@@ -1492,7 +1501,7 @@ __device__ void filter_long( pel_t* src, int step, int o, int nP, int nQ, int tc
       pel_t* s = side ? q0 : p0; const int d = side ? o : -o, n = side ? nQ : nP, far = side ? farQ : farP;
       for( int k = 0; k < n; k++ )
       {
-        const int cf = ( 64 * ( 2 * ( n - k ) - 1 ) + n ) / ( 2 * n ), lim = ( tc * c_dbLongTc[n > 3][k] ) >> 1, v = s[d * k];
+        const int cf = c_dbLongCf[( n - 3 ) >> 1][k], lim = ( tc * c_dbLongTc[n > 3][k] ) >> 1, v = s[d * k];
         s[d * k] = (pel_t) clip3( v - lim, v + lim, ( mid * cf + far * ( 64 - cf ) + 32 ) >> 6 );
       }
     }
@@ -2272,13 +2281,7 @@ __global__ __launch_bounds__( 256 ) void k_lmcs( PicDev pic, DevPlanes reco, int
   const int y = blockIdx.y, x = ( blockIdx.x * 256 + threadIdx.x ) * 8;
   if( x >= reco.w[0] ) return;
   pel_t* __restrict__ row = reco.p[0] + (size_t) y * reco.stride[0];
-  bool lo = true, hi = true;
-  if( !inverse )
-  {
-    const uint8_t* m = pic.interAt + (size_t) ( y >> 2 ) * pic.w4 + ( x >> 2 );
-    lo = m[0] != 0; hi = ( x + 4 < reco.w[0] ) && m[1] != 0;
-    if( !lo && !hi ) return;
-  }
+  const bool lo = true, hi = true;                 // (round 3: only the inverse pass is left; the forward map is applied by the motion-compensation kernels)
   uint4 v = *reinterpret_cast<const uint4*>( row + x );       // rows are padded to a multiple of 64 samples
   uint32_t* w = reinterpret_cast<uint32_t*>( &v );
   for( int k = 0; k < 4; k++ )

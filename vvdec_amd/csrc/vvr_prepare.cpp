@@ -1173,16 +1173,7 @@ void PrepScratch::layout( PinnedRanges* pinned )
   iSao = p->sao ? add( p->sao, sizeof( vvr_sao_ctu ) * numCtu ) : -1;
   iAlf = p->alf ? add( p->alf, sizeof( vvr_alf_ctu ) * numCtu ) : -1;
   iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
-  if( lmcs )
-  {
-    interAtV.assign( (size_t) w4 * h4 + 8, 0 );
-    for( uint32_t i = 0; i < p->num_cu; i++ )
-    {
-      const vvr_cu& cu = p->cu[i];
-      if( cu.pred_mode != VVR_PRED_INTER ) continue;
-      for( int y = cu.y >> 2; y < ( cu.y + cu.h + 3 ) >> 2; y++ ) memset( &interAtV[(size_t) y * w4 + ( cu.x >> 2 )], 1, ( cu.w + 3 ) >> 2 );
-    }
-  }
+  // (LMCS: the forward mapping of inter predictions happens where the motion-compensation kernels store them: no per-cell map of inter CUs any more)
   iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
   iSl = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? add( p->scaling, sizeof( vvr_scaling_list ) ) : -1;
   iCtuSlice = p->ctu_slice ? add( p->ctu_slice, sizeof( uint16_t ) * numCtu ) : -1;
@@ -1200,7 +1191,7 @@ void PrepScratch::layout( PinnedRanges* pinned )
   }
   iCtuTile = p->ctu_tile ? add( p->ctu_tile, sizeof( uint16_t ) * numCtu ) : -1;
   iWp = wpOn ? add( p->wp, sizeof( vvr_wp_params ) ) : -1;
-  iInterAt = lmcs ? add( interAtV.data(), interAtV.size() ) : -1;
+  iInterAt = -1;
   iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
   iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
   iMcB = add( mcBdof.data(), sizeof( McItem ) * mcBdof.size() );
