@@ -13,10 +13,26 @@
 #include <functional>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+#include <exception>
 
 namespace vvr_glue
 {
 using namespace vvdec;
+
+// [0, n) over up to `threads` threads (contiguous chunks); the first exception is rethrown.  The per-picture host steps of an integration (LF_INIT,
+// the 4x4 tables of the flat description) are independent per CTU / row; a decoder that keeps its own pool busy with other pictures passes 1.
+template<class F> static inline void parallelFor( int n, int threads, F&& fn )
+{
+  threads = std::max( 1, std::min( threads, n ) );
+  if( threads == 1 ) { for( int i = 0; i < n; i++ ) fn( i ); return; }
+  std::vector<std::thread> th; std::vector<std::exception_ptr> err( threads );
+  for( int t = 0; t < threads; t++ ) th.emplace_back( [&, t]{ try { for( int i = (int) ( (int64_t) n * t / threads ); i < (int) ( (int64_t) n * ( t + 1 ) / threads ); i++ ) fn( i ); } catch( ... ) { err[t] = std::current_exception(); } } );
+  for( auto& x : th ) x.join();
+  for( auto& e : err ) if( e ) std::rethrow_exception( e );
+}
 
 struct Extracted
 {
@@ -170,7 +186,7 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
 
 // slotOf: DPB slot of a reference picture (the caller owns the mapping picture <-> slot); outSlot: slot of the picture itself
 static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& pic, Reshape* reshaper, TrQuant& trQuant,
-                                   const std::function<int( const Picture* )>& slotOf, int outSlot, Extracted& E )
+                                   const std::function<int( const Picture* )>& slotOf, int outSlot, Extracted& E, int threads = 1 )
 {
   const SPS& sps = *cs.sps; const PPS& pps = *cs.pps; const PreCalcValues& pcv = *cs.pcv;
   const int W = pps.getPicWidthInLumaSamples(), H = pps.getPicHeightInLumaSamples();
@@ -209,6 +225,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
     for( int k = 0; k < sps.getLadfNumIntervals(); k++ ) { h.ladf_qp_offset[k] = (int8_t) sps.getLadfQpOffset( k ); h.ladf_lower_bound[k] = (int16_t) sps.getLadfIntervalLowerBound( k ); }
   }
 
+  const auto tX0 = std::chrono::steady_clock::now();
   // ---- coding units, transform units, levels
   E.cu.clear(); E.tu.clear(); E.coef.clear(); E.ctuFirstCu.assign( numCtu + 1, 0 ); E.numDmvr = 0; E.dmvrCus.clear();
   PelUnitBuf reco = cs.getRecoBuf();
@@ -311,27 +328,33 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   }
   E.ctuFirstCu[numCtu] = (uint32_t) E.cu.size();
 
+  const auto tX1 = std::chrono::steady_clock::now();
   // ---- per-4x4 tables: motion (after MIDER), edge parameters (after LF_INIT)
-  E.motion.assign( (size_t) w4 * h4, vvr_motion() ); E.lfp[0].assign( (size_t) w4 * h4, vvr_lfp() ); E.lfp[1].assign( (size_t) w4 * h4, vvr_lfp() );
-  for( int y = 0; y < h4; y++ ) for( int x = 0; x < w4; x++ )
+  E.motion.resize( (size_t) w4 * h4 ); E.lfp[0].resize( (size_t) w4 * h4 ); E.lfp[1].resize( (size_t) w4 * h4 );
+  parallelFor( h4, threads, [&]( int y )
   {
-    const int a = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 ), in = ( y % ctu4 ) * ctu4 + ( x % ctu4 );
-    const CtuData& cd = cs.getCtuData( a );
-    vvr_motion& m = E.motion[(size_t) y * w4 + x]; memset( &m, 0, sizeof( m ) );
-    const MotionInfo& mi = cd.motion[in];
-    for( int l = 0; l < 2; l++ )
+    for( int x = 0; x < w4; x++ )
     {
-      m.ref_idx[l] = isMotionValid( mi.miRefIdx[l], MI_NOT_VALID ) ? (int8_t) mi.miRefIdx[l] : -1;
-      m.mv[l][0] = mi.mv[l].getHor(); m.mv[l][1] = mi.mv[l].getVer();
+      const int a = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 ), in = ( y % ctu4 ) * ctu4 + ( x % ctu4 );
+      const CtuData& cd = cs.getCtuData( a );
+      vvr_motion& m = E.motion[(size_t) y * w4 + x]; memset( &m, 0, sizeof( m ) );
+      const MotionInfo& mi = cd.motion[in];
+      for( int l = 0; l < 2; l++ )
+      {
+        m.ref_idx[l] = isMotionValid( mi.miRefIdx[l], MI_NOT_VALID ) ? (int8_t) mi.miRefIdx[l] : -1;
+        m.mv[l][0] = mi.mv[l].getHor(); m.mv[l][1] = mi.mv[l].getVer();
+      }
+      for( int d = 0; d < 2; d++ )
+      {
+        const LoopFilterParam& s = cd.lfParam[d][in];
+        vvr_lfp& o = E.lfp[d][(size_t) y * w4 + x]; memset( &o, 0, sizeof( o ) );
+        o.qp[0] = s.qp[0]; o.qp[1] = s.qp[1]; o.qp[2] = s.qp[2]; o.bs = s.bs; o.side_max_filt_length = s.sideMaxFiltLength; o.flags = s.flags;
+      }
     }
-    for( int d = 0; d < 2; d++ )
-    {
-      const LoopFilterParam& s = cd.lfParam[d][in];
-      vvr_lfp& o = E.lfp[d][(size_t) y * w4 + x]; memset( &o, 0, sizeof( o ) );
-      o.qp[0] = s.qp[0]; o.qp[1] = s.qp[1]; o.qp[2] = s.qp[2]; o.bs = s.bs; o.side_max_filt_length = s.sideMaxFiltLength; o.flags = s.flags;
-    }
-  }
+  } );
 
+  const auto tX2 = std::chrono::steady_clock::now();
+  if( getenv( "VVR_EXTRACT_TIMES" ) ) fprintf( stderr, "[extract] CU/TU/levels %.2f ms, 4x4 tables %.2f ms\n", std::chrono::duration<double, std::milli>( tX1 - tX0 ).count(), std::chrono::duration<double, std::milli>( tX2 - tX1 ).count() );
   // ---- per-CTU loop filter controls: SAO with merges resolved and offsets scaled (SampleAdaptiveOffset::reconstructBlkSAOParam), ALF
   E.sao.assign( numCtu, vvr_sao_ctu() ); E.alf.assign( numCtu, vvr_alf_ctu() );
   for( int a = 0; a < numCtu; a++ )

@@ -55,6 +55,9 @@
 #include "CommonLib/AdaptiveLoopFilter.h"
 #include "CommonLib/RdCost.h"
 #include "DecoderLib/DecCu.h"
+#ifdef VVREF_WITH_DROPIN
+#include "DecoderLib/DecLibRecon.h"
+#endif
 #include "CommonLib/TrQuant_EMT.h"
 #include "CommonLib/x86/CommonDefX86.h"
 #undef private
@@ -98,6 +101,10 @@ static vvr_motion* g_motionOut = nullptr;
 #ifdef VVREF_WITH_BINDING
 struct BindingRun { uint16_t* const* out_planes; int numSlots; };
 static BindingRun* g_binding = nullptr;
+#endif
+#ifdef VVREF_WITH_DROPIN
+struct DropInRun { uint16_t* const* out_planes; int threads; };
+static DropInRun* g_dropin = nullptr;
 #endif
 static void dumpMotion( CodingStructure& cs, int W, int Hh, vvr_motion* out )
 {
@@ -747,6 +754,42 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       return 0;
     }
 #endif
+#ifdef VVREF_WITH_DROPIN
+    if( g_dropin )
+    {
+      // The DROP-IN: the reference's own class vvdec::DecLibRecon, whose member functions this library takes from integration/DecLibReconDropIn.cpp
+      // instead of DecoderLib/DecLibRecon.cpp (oracle/Makefile, libvvrefdropin.so), driven the way DecLib::reconPicture drives it (DecLib.cpp:612-636):
+      // create( ThreadPool*, instance, upscale ) / decompressPicture / waitForPrevDecompressedPic / destroy, on a pool of g_dropin->threads threads
+      // (0: everything on the calling thread, like vvdec_params.threads = 0).  The result is read from the Picture's own buffers - where the rest of
+      // the decoder looks for it.
+      const int nc = cf == CHROMA_400 ? 1 : 3;
+      for( auto& kv : refPics ) { kv.second->reconDone.unlock(); }          // (reference pictures handed in from outside: finished)
+      pic.parseDone.unlock();
+      {
+        ThreadPool pool( g_dropin->threads, "dropin" );
+        std::list<DecLibRecon> recon( 2 );                                   // (two instances share one back-end, as in DecLib.h:70)
+        unsigned id = 0;
+        for( auto& r : recon ) r.create( &pool, id++, false );
+        DecLibRecon& rec = recon.front();
+        CHECK( rec.waitForPrevDecompressedPic() != nullptr, "an idle instance handed a picture back" );
+        rec.decompressPicture( &pic );
+        CHECK( rec.getCurrPic() != &pic, "getCurrPic() is not the picture in progress" );
+        Picture* done = rec.waitForPrevDecompressedPic();
+        CHECK( done != &pic || rec.getCurrPic() != nullptr, "the drop-in did not hand the picture back" );
+        if( pic.reconDone.hasException() ) std::rethrow_exception( pic.reconDone.getException() );
+        CHECK( pic.progress != Picture::reconstructed || pic.reconDone.isBlocked(), "picture not marked reconstructed" );
+        for( int c = 0; c < nc; c++ )
+        {
+          const CPelBuf b = const_cast<const Picture&>( pic ).getRecoBuf( ComponentID( c ) );
+          for( int y = 0; y < (int) b.height; y++ ) for( int x = 0; x < (int) b.width; x++ ) g_dropin->out_planes[c][(size_t) y * b.width + x] = (uint16_t) b.at( x, y );
+        }
+        if( g_motionOut ) dumpMotion( cs, W, Hh, g_motionOut );
+        for( auto& r : recon ) r.destroy();
+      }
+      for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
+      return 0;
+    }
+#endif
     if( g_extractTo )
     {
       { std::string why; CHECK( vvr_glue::checkExpressible( cs, pic, why ) != VVR_OK, why ); }
@@ -952,6 +995,20 @@ int vvref_run_binding( const vvr_picture* vp, const uint16_t* const* ref_planes,
   uint16_t* none[3] = { nullptr, nullptr, nullptr };
   const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, VVREF_DERIVE_LFP, nullptr );
   g_binding = nullptr; g_motionOut = nullptr;
+  return rc;
+}
+#endif
+
+#ifdef VVREF_WITH_DROPIN
+// one picture through the drop-in implementation of vvdec::DecLibRecon (see above); `threads` = threads of the decoder's pool
+__attribute__((visibility("default")))
+int vvref_run_dropin( const vvr_picture* vp, const uint16_t* const* ref_planes, uint16_t* const* out_planes, vvr_motion* motion_out, int threads )
+{
+  DropInRun run{ out_planes, threads };
+  g_dropin = &run; g_motionOut = motion_out;
+  uint16_t* none[3] = { nullptr, nullptr, nullptr };
+  const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, 0, nullptr );
+  g_dropin = nullptr; g_motionOut = nullptr;
   return rc;
 }
 #endif

@@ -118,6 +118,39 @@ def run_binding(desc, refs, backend_path, num_slots=8):
     return outs, motion
 
 
+_DROPIN_HARNESS = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libvvrefdropin.so")
+DROPIN_LIB = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libvvdec.so")
+_dropin = None
+
+
+def dropin_available():
+    return os.path.exists(_DROPIN_HARNESS) and os.path.exists(DROPIN_LIB)
+
+
+def run_dropin(desc, refs, backend_path, threads=2):
+    """the picture through the DROP-IN: the reference's class vvdec::DecLibRecon with the member functions of integration/DecLibReconDropIn.cpp
+    (create( ThreadPool*, id, upscale ) / decompressPicture / waitForPrevDecompressedPic / destroy on a thread pool of `threads` threads), on the
+    back-end library `backend_path`.  -> (planes as they sit in the Picture's own buffers, motion field)"""
+    global _dropin
+    if _dropin is None:
+        C.CDLL(backend_path, mode=C.RTLD_GLOBAL)        # the drop-in's vvr_* calls bind to this library
+        _dropin = C.CDLL(_DROPIN_HARNESS)
+        _dropin.vvref_run_dropin.restype = C.c_int
+        _dropin.vvref_last_error.restype = C.c_char_p
+    p = desc.c()
+    ref_ptrs, keep, nslots = _ref_ptrs(refs)
+    ncomp = 3 if desc.hdr.chroma_format else 1
+    outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
+    out_ptrs = (C.POINTER(C.c_uint16) * 3)()
+    for c in range(ncomp):
+        out_ptrs[c] = outs[c].ctypes.data_as(C.POINTER(C.c_uint16))
+    motion = np.zeros(desc.w4 * desc.h4, np.dtype(abi.Motion))
+    rc = _dropin.vvref_run_dropin(C.byref(p), ref_ptrs, out_ptrs, motion.ctypes.data_as(C.c_void_p), threads)
+    if rc != 0:
+        raise RuntimeError("vvref_run_dropin failed: " + _dropin.vvref_last_error().decode())
+    return outs, motion
+
+
 def extract(desc, refs=None, flags=0):
     """description -> the reference decoder's own objects -> description, through the reference-side glue integration/vvr_extract.h.
     Returns a dict of numpy copies of every array of the extracted vvr_picture (and its header)."""

