@@ -48,6 +48,7 @@ enum {
   VVR_ERR_UNSUPPORTED  = -3,   /* a coding tool / format this build does not reconstruct            */
   VVR_ERR_DEVICE       = -4,   /* HIP runtime error (message via vvr_last_error)                    */
   VVR_ERR_NO_DEVICE    = -5,   /* no usable gfx950 device: the back-end never falls back to the CPU */
+  VVR_NOT_READY        = 1,    /* (non-blocking queries) the pictures concerned have not been handed to the device yet: ask again */
   VVR_ERR_BUSY         = -6,   /* DPB slot still in use / too many pictures in flight               */
 };
 
@@ -440,6 +441,20 @@ VVR_API int          vvr_submit_prepared(vvr_context* ctx, vvr_prepared* prepare
 VVR_API void         vvr_free_prepared(vvr_context* ctx, vvr_prepared* prepared);
 /* the HIP stream (hipStream_t) job `job` runs on, and the per-kernel timing of the last waited job (bench/profiling) */
 VVR_API void*        vvr_job_stream(vvr_context* ctx, int job);
+/* External producers and consumers of DPB slots - the collective that replicates a reference picture to the GPUs whose pictures predict from it
+ *  - ordered on the DEVICE: the host never waits for a picture.
+ *   vvr_stream_wait_job   `stream` (hipStream_t of the caller) waits for picture `job`: what a sender does before the collective reads the slot;
+ *   vvr_stream_wait_slot  `stream` waits for every picture submitted so far that reads or writes `slot` (and for earlier external users): what a
+ *                         receiver does before the collective overwrites the slot;
+ *   vvr_slot_external_event  pictures submitted from now on that use `slot` wait for `event` (hipEvent_t, recorded by the caller behind its
+ *                         collective) first; writes != 0: the external work wrote the slot (earlier users were ordered before it by
+ *                         vvr_stream_wait_slot), 0: it only reads it (a sender: later pictures must not overwrite the slot under it).  The
+ *                         caller keeps the event alive until those pictures are done.
+ * A picture can only be waited for once it has been handed to the device (its work lists are built by worker threads): blocking = 0 returns
+ * VVR_NOT_READY instead of waiting for that on the host.                                                                                      */
+VVR_API int          vvr_stream_wait_job(vvr_context* ctx, int job, void* stream, int blocking);
+VVR_API int          vvr_stream_wait_slot(vvr_context* ctx, int slot, void* stream, int blocking);
+VVR_API int          vvr_slot_external_event(vvr_context* ctx, int slot, void* event, int writes);
 VVR_API const char*  vvr_last_error(const vvr_context* ctx);
 VVR_API const char*  vvr_version(void);
 /* sizeof() of ABI struct number `which` as this library was compiled (0 vvr_pic_header, 1 vvr_cu, 2 vvr_tu, 3 vvr_motion,

@@ -325,6 +325,59 @@ def test_blocks_of_a_unit_that_do_not_read_from_each_other(stub):
     ctx.close()
 
 
+def test_external_slot_users_are_ordered_on_the_device(stub):
+    """vvr_stream_wait_job / vvr_stream_wait_slot / vvr_slot_external_event (the collective that replicates reference pictures between GPUs): the
+    caller's stream waits for the picture's completion EVENT, a later picture that reads a slot an external producer wrote waits for the caller's
+    event on its lane - stream and event operations only, recorded by the stand-in runtime; the non-blocking forms say VVR_NOT_READY while a
+    picture is still with the worker threads"""
+    W, H = 256, 128
+    plans, nslots = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    cfg = abi.Config()
+    cfg.abi_version = abi.VVR_ABI_VERSION
+    cfg.device, cfg.max_width, cfg.max_height = 0, W, H
+    cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 1, 10, 7
+    cfg.num_slots, cfg.num_streams, cfg.host_threads = nslots, 3, 2
+    ctx = C.c_void_p()
+    assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+    stub.vvr_stream_wait_job.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    stub.vvr_stream_wait_slot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    stub.vvr_slot_external_event.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    ext = C.c_void_p()
+    stub.hipStreamCreateWithFlags(C.byref(ext), 0)
+    descs = [synth.picture_for_plan(pl, W, H, seed=611, tool_flags=TOOLS) for pl in plans[:3]]
+    pics = [d.c() for d in descs]
+    stub.vvt_set_delay(20000)                               # the workers take a while: the picture is not with the device yet
+    j0 = stub.vvr_submit(ctx, C.byref(pics[0]))
+    assert j0 >= 0
+    assert stub.vvr_stream_wait_job(ctx, j0, ext, 0) in (abi.VVR_NOT_READY, abi.VVR_OK)
+    stub.vvt_set_delay(0)
+    scratch = (C.c_int * 30000)()
+    stub.vvt_take_trace(scratch, len(scratch))              # (start the record of stream / event operations here)
+    assert stub.vvr_stream_wait_job(ctx, j0, ext, 1) == abi.VVR_OK       # waits (host) for the hand-over to the device only
+    # an external producer writes the slot of the next key picture (as a receive from another GPU would): nobody uses it yet
+    slot = plans[1].slot
+    assert stub.vvr_stream_wait_slot(ctx, slot, ext, 1) == abi.VVR_OK
+    ev = C.c_void_p()
+    stub.hipEventCreate(C.byref(ev))
+    stub.hipEventRecord(ev, ext)
+    assert stub.vvr_slot_external_event(ctx, slot, ev, 1) == abi.VVR_OK
+    # picture 2 predicts from that slot: its lane waits for the external event before anything of it runs
+    assert plans[2].ref_slots and slot in [s for lst in plans[2].ref_slots for (s, _) in lst]
+    j2 = stub.vvr_submit(ctx, C.byref(pics[2]))
+    assert j2 >= 0 and stub.vvr_sync(ctx) == abi.VVR_OK
+    n = stub.vvt_take_trace(scratch, len(scratch))
+    ops = [(scratch[3 * k], scratch[3 * k + 1], scratch[3 * k + 2]) for k in range(n // 3)]
+    waits = [(s, e) for (op, s, e) in ops if op == 0]
+    records = [(s, e) for (op, s, e) in ops if op == 1]
+    ext_stream = max([s for (s, _) in records] + [s for (s, _) in waits])   # (the stream created last: ours)
+    ext_events = [e for (s, e) in records if s == ext_stream]
+    assert ext_events, "the external event was not recorded on the external stream"
+    assert any(s == ext_stream for (s, e) in waits), "the external stream never waited for a picture's event"
+    assert any(e == ext_events[-1] and s != ext_stream for (s, e) in waits), "no lane waited for the external producer's event"
+    stub.vvr_destroy(ctx)
+
+
 def _expect_error(ctx, d, code, text):
     p = d.c()
     h = C.c_void_p()

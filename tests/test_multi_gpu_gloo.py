@@ -89,7 +89,7 @@ def test_two_ranks_equal_one_rank(built, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# picture-level sharding of one stream (vvdec_amd.parallel.PictureParallel): reference pictures broadcast between ranks
+# picture-level sharding of one stream (vvdec_amd.parallel.PictureParallel): reference pictures sent to the ranks that predict from them
 # ---------------------------------------------------------------------------------------------------------------------
 PIC_WORKER = r'''
 import ctypes as C, json, os, sys
@@ -112,7 +112,7 @@ plans, nslots = stream.ra_plan(FRAMES, gop=GOP, seed_poc0_is_external=False, poo
 nslots = max(nslots, 10)
 dpb = vvdec_amd.Reconstructor.new_dpb_tensor(W, H, nslots, device="cpu")
 rec = vvdec_amd.Reconstructor(W, H, log2_ctu=6, num_slots=nslots, num_streams=3, host_threads=2, ext_planes=dpb.data_ptr())
-pp = parallel.PictureParallel(rec, dpb, plans, rank, world, replicate=replicate)
+pp = parallel.PictureParallel(rec, dpb, plans, rank, world, replicate=replicate, runtime=parallel.HostStubRuntime(vvdec_amd.lib()))
 descs = [synth.picture_for_plan(pl, W, H, seed=77, tool_flags=TOOLS, log2_ctu=6, p_intra=0.1) if pp.owners[i] == rank else None for i, pl in enumerate(plans)]
 # the stamp of a picture has to be read before its slot is reused: run the plan in pieces that end where a slot is about to be overwritten
 stamps = {{}}
@@ -125,7 +125,7 @@ for slot, i in last_in_slot.items():
         y = rec.read_picture(slot)[0]
         stamps[plans[i].poc] = [int(v) for v in y[0, :4]]
 res = parallel.gather_results(sorted(stamps.items()))
-print("RESULT " + json.dumps(dict(rank=rank, world=world, owners=pp.owners, need=pp.need, trace=pp.trace, n_bcast=pp.n_bcast, stamps=sorted(res))))
+print("RESULT " + json.dumps(dict(rank=rank, world=world, owners=pp.owners, need=pp.need, deps=pp.deps, trace=pp.trace, n_bcast=pp.n_bcast, stamps=sorted(res))))
 rec.close()
 import torch.distributed as dist
 if dist.is_initialized():
@@ -163,18 +163,45 @@ def test_picture_parallel_two_ranks(built, tmp_path):
     for r in two:
         assert r["stamps"] == one["stamps"], "pictures reconstructed from other reference content than in the one-rank run"
         assert r["n_bcast"] == sum(r["need"]) > 0 and set(r["owners"]) == {0, 1}
-    # both ranks took part in the same broadcasts, in the same order; the owner sends after it has waited for the picture
-    b0 = [i for (op, i) in two[0]["trace"] if op.startswith("bcast")]
-    b1 = [i for (op, i) in two[1]["trace"] if op.startswith("bcast")]
-    assert b0 == b1
+    # what one rank sends the other receives, in the same order; a picture goes only to ranks that predict from it; the owner sends after it
+    # has SUBMITTED the picture and never waits for it on the host (the transfer is ordered behind the picture on the device)
+    s0 = [i for (op, i) in two[0]["trace"] if op == "send"]
+    r1 = [i for (op, i) in two[1]["trace"] if op == "recv"]
+    s1 = [i for (op, i) in two[1]["trace"] if op == "send"]
+    r0 = [i for (op, i) in two[0]["trace"] if op == "recv"]
+    assert s0 == r1 and s1 == r0 and s0 and s1
     for r in two:
         tr = [tuple(t) for t in r["trace"]]
+        assert not any(op == "wait" for (op, _) in tr)
         for k, (op, i) in enumerate(tr):
-            if op == "bcast_send":
-                assert tr[k - 1] == ("wait", i) and ("submit", i) in tr[:k]
-            if op == "bcast_recv":
-                assert r["owners"][i] != r["rank"]
-    # top-layer pictures are not referenced: never broadcast
-    assert not any(two[0]["need"][i] for i in range(len(two[0]["need"])) if i not in b0)
+            if op == "send":
+                assert ("submit", i) in tr[:k] and r["owners"][i] == r["rank"] and r["deps"][i] == [1 - r["rank"]]
+            if op == "recv":
+                assert r["owners"][i] != r["rank"] and r["rank"] in r["deps"][i]
+    # top-layer pictures are not referenced: never sent
+    assert not any(two[0]["need"][i] for i in range(len(two[0]["need"])) if i not in s0 + s1)
     broken = _run_pic(2, tmp_path, replicate=False)
     assert broken[0]["stamps"] != one["stamps"]
+
+
+def test_picture_parallel_three_ranks_send_only_to_dependants(built, tmp_path):
+    """three ranks: a reference picture goes from its owner to the ranks whose pictures predict from it and to nobody else (point-to-point, no
+    rank-wide collective); the pictures equal the one-rank run"""
+    import test_host_glue as T
+    if not os.path.exists(os.path.join(T.HIP_INC, "hip", "hip_runtime_api.h")):
+        pytest.skip("HIP headers not installed")
+    T.build_stub()
+    one = _run_pic(1, tmp_path)[0]
+    three = _run_pic(3, tmp_path)
+    sent = 0
+    for r in three:
+        assert r["stamps"] == one["stamps"]
+        tr = [tuple(t) for t in r["trace"]]
+        for (op, i) in tr:
+            if op == "recv":
+                assert r["rank"] in r["deps"][i] and r["owners"][i] != r["rank"]
+            if op == "send":
+                sent += len(r["deps"][i])
+    assert sent == sum(1 for r in three for (op, _) in r["trace"] if op == "recv")
+    # some picture has a single dependant: the third rank stayed out of that transfer
+    assert any(len(d) == 1 for d in three[0]["deps"])

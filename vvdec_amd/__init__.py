@@ -81,6 +81,9 @@ def lib():
         L.vvr_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.vvr_measure_copy_bandwidth.restype = C.c_double
         L.vvr_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int]
+        L.vvr_stream_wait_job.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.vvr_stream_wait_slot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.vvr_slot_external_event.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -88,7 +91,8 @@ def lib():
 EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
                     "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_picture_hash", "vvr_write_plane", "vvr_read_dmvr", "vvr_read_col_motion", "vvr_prepare", "vvr_submit_prepared",
                     "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof",
-                    "vvr_inputs_done", "vvr_measure_copy_bandwidth", "vvr_host_alloc", "vvr_host_free"]
+                    "vvr_inputs_done", "vvr_measure_copy_bandwidth", "vvr_host_alloc", "vvr_host_free",
+                    "vvr_stream_wait_job", "vvr_stream_wait_slot", "vvr_slot_external_event"]
 
 
 class Reconstructor:
@@ -141,6 +145,19 @@ class Reconstructor:
             self._check(self.L.vvr_wait(self.ctx, job))
         finally:
             self._keep.pop(job, None)
+
+    # -- external users of DPB slots, ordered on the device (the collective of vvdec_amd.parallel.PictureParallel)
+    def stream_wait_job(self, job, stream_ptr, blocking=True):
+        """the caller's stream waits for picture `job`; False: not handed to the device yet (blocking=False only)"""
+        return self._check(self.L.vvr_stream_wait_job(self.ctx, job, stream_ptr, 1 if blocking else 0)) == abi.VVR_OK
+
+    def stream_wait_slot(self, slot, stream_ptr, blocking=True):
+        """the caller's stream waits for every picture submitted so far that reads or writes `slot`; False: some of them are still being prepared"""
+        return self._check(self.L.vvr_stream_wait_slot(self.ctx, slot, stream_ptr, 1 if blocking else 0)) == abi.VVR_OK
+
+    def slot_external_event(self, slot, event_ptr, writes):
+        """pictures submitted from now on that use `slot` wait for the caller's event first"""
+        self._check(self.L.vvr_slot_external_event(self.ctx, slot, event_ptr, 1 if writes else 0))
 
     def inputs_done(self, job):
         self._check(self.L.vvr_inputs_done(self.ctx, job))

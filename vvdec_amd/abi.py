@@ -17,6 +17,7 @@ VVR_CCALF_TAPS = 7
 
 # status codes
 VVR_OK, VVR_ERR_UNSPECIFIED, VVR_ERR_PARAMETER, VVR_ERR_UNSUPPORTED, VVR_ERR_DEVICE, VVR_ERR_NO_DEVICE, VVR_ERR_BUSY = 0, -1, -2, -3, -4, -5, -6
+VVR_NOT_READY = 1          # non-blocking stream-order queries: ask again
 
 # tool flags
 TOOL_SAO_LUMA, TOOL_SAO_CHROMA, TOOL_ALF, TOOL_CCALF, TOOL_LMCS, TOOL_LMCS_CSCALE, TOOL_DEBLOCK_OFF, TOOL_DEP_QUANT, \

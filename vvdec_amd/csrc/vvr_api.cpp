@@ -160,6 +160,7 @@ struct vvr_context {
   uint64_t   overtakes = 0;                // pictures enqueued ahead of a picture submitted before them that was still being prepared (nextToCommitLocked)
   std::map<uint64_t, Job*> bySeq;       // jobs that have not been committed yet
   std::vector<std::vector<int>> slotUsers;   // job ids that touched a slot since it was last written (first entry: the writer)
+  std::vector<std::vector<hipEvent_t>> slotExt;   // events of external work on a slot (vvr_slot_external_event): pictures that use the slot wait for them
   std::vector<RingEntry> ring;
   size_t     ringLargest = 0;           // bytes of the largest picture image seen (+ 25 %): what a ring entry grows to
   std::vector<char*> retiredHost, retiredDev;   // outgrown ring buffers, freed with the context
@@ -275,6 +276,8 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
   // ---- dependencies: every job that read or wrote one of our slots
   auto waitFor = [&]( int id ) { auto it = c->jobs.find( id ); if( it != c->jobs.end() ) { Job& j = *it->second; if( !j.completed && j.state == J_COMMITTED && j.lane != lane ) { plan.waits.push_back( j.done ); plan.waitInfo.push_back( j.q ? ( j.id * 16 + j.q->hdr.slice_type * 4 ) : -1 ); plan.waitInfo.push_back( j.lane ); } } };
   for( int id : c->slotUsers[h.out_slot] ) waitFor( id );
+  // external work on our slots (a collective that wrote a reference slot, or still reads the slot we overwrite)
+  for( hipEvent_t ev : c->slotExt[h.out_slot] ) { plan.waits.push_back( ev ); plan.waitInfo.push_back( -2 ); plan.waitInfo.push_back( -1 ); }
   memset( &plan.refs, 0, sizeof( plan.refs ) );
   if( h.slice_type != 2 )
     for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
@@ -282,6 +285,7 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
       const int slot = h.ref_slot[l][i];
       // wait for the writer of the reference (it is the first entry since the slot was last written)
       if( !c->slotUsers[slot].empty() ) waitFor( c->slotUsers[slot][0] );
+      for( hipEvent_t ev : c->slotExt[slot] ) if( std::find( plan.waits.begin(), plan.waits.end(), ev ) == plan.waits.end() ) { plan.waits.push_back( ev ); plan.waitInfo.push_back( -2 ); plan.waitInfo.push_back( -1 ); }
       for( int k = 0; k < 3; k++ ) plan.refs.p[l * VVR_MAX_REFS + i][k] = c->slots[slot].p[k];
     }
   job.done = takeEvent( c ); job.doneHost = takeEvent( c );
@@ -483,6 +487,7 @@ static void commitReady( vvr_context* c )
         {
           const vvr_pic_header& h = j->q->hdr;
           c->slotUsers[h.out_slot].clear(); c->slotUsers[h.out_slot].push_back( j->id );
+          c->slotExt[h.out_slot].clear();          // (whatever happened to the slot outside is ordered before this writer now)
           if( h.slice_type != 2 ) for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ ) c->slotUsers[h.ref_slot[l][i]].push_back( j->id );
           j->state = J_COMMITTED;
         }
@@ -835,7 +840,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
     }
   }
   if( !ok ) { vvr_destroy( c ); return VVR_ERR_DEVICE; }
-  c->slotUsers.resize( cfg->num_slots );
+  c->slotUsers.resize( cfg->num_slots ); c->slotExt.resize( cfg->num_slots );
   c->inlineScratch = vvr_scratch_create();
   if( cfg->host_threads <= 0 ) vvr_scratch_warm( c->inlineScratch, c->cfg );
   if( cfg->host_threads ) c->nodeCpus = gpuNodeCpus( c->device );
@@ -1091,6 +1096,57 @@ VVR_API int vvr_sync( vvr_context* c )
   for( int id : ids ) { const int r = finishJob( c, id ); if( r != VVR_OK && rc == VVR_OK ) rc = r; }
   if( rc != VVR_OK ) return rc;
   for( auto s : c->streams ) HIPCHK( c, hipStreamSynchronize( s ) );
+  return VVR_OK;
+}
+
+VVR_API int vvr_stream_wait_job( vvr_context* c, int job, void* stream, int blocking )
+{
+  if( !c ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  std::unique_lock<std::mutex> lk( c->mu );
+  auto it = c->jobs.find( job );
+  if( it == c->jobs.end() ) return VVR_OK;          // retired: finished long ago
+  Job* j = it->second.get();
+  if( !( j->state == J_COMMITTED || j->completed ) )
+  {
+    if( !blocking ) return VVR_NOT_READY;
+    c->cv.wait( lk, [&]{ auto q = c->jobs.find( job ); return q == c->jobs.end() || q->second->state == J_COMMITTED || q->second->completed; } );
+    it = c->jobs.find( job );
+    if( it == c->jobs.end() ) return VVR_OK;
+    j = it->second.get();
+  }
+  if( j->state == J_FAILED ) { c->setError( j->err ); return j->rc; }
+  if( !j->completed && j->done ) HIPCHK( c, hipStreamWaitEvent( (hipStream_t) stream, j->done, 0 ) );
+  return VVR_OK;
+}
+
+VVR_API int vvr_stream_wait_slot( vvr_context* c, int slot, void* stream, int blocking )
+{
+  if( !c || slot < 0 || slot >= (int) c->slotUsers.size() ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  std::unique_lock<std::mutex> lk( c->mu );
+  if( !c->bySeq.empty() )                            // pictures still with the workers: who uses the slot is only known once they are committed
+  {
+    if( !blocking ) return VVR_NOT_READY;
+    c->cv.wait( lk, [&]{ return c->bySeq.empty(); } );
+  }
+  for( int id : c->slotUsers[slot] )
+  {
+    auto it = c->jobs.find( id );
+    if( it == c->jobs.end() ) continue;
+    Job& j = *it->second;
+    if( !j.completed && j.state == J_COMMITTED && j.done ) HIPCHK( c, hipStreamWaitEvent( (hipStream_t) stream, j.done, 0 ) );
+  }
+  for( hipEvent_t ev : c->slotExt[slot] ) HIPCHK( c, hipStreamWaitEvent( (hipStream_t) stream, ev, 0 ) );
+  return VVR_OK;
+}
+
+VVR_API int vvr_slot_external_event( vvr_context* c, int slot, void* event, int writes )
+{
+  if( !c || !event || slot < 0 || slot >= (int) c->slotUsers.size() ) return VVR_ERR_PARAMETER;
+  std::lock_guard<std::mutex> lk( c->mu );
+  if( writes ) { c->slotUsers[slot].clear(); c->slotExt[slot].clear(); }
+  c->slotExt[slot].push_back( (hipEvent_t) event );
   return VVR_OK;
 }
 

@@ -124,75 +124,175 @@ def broadcast_plan(plans, owners):
     return need
 
 
+def dependants(plans, owners):
+    """for every picture: the ranks (other than its owner) that reconstruct a picture predicting from it - the only ranks its slot is sent to"""
+    deps = [set() for _ in plans]
+    by_poc = {pl.poc: i for i, pl in enumerate(plans)}
+    for j, pl in enumerate(plans):
+        for poc in list(pl.l0) + list(pl.l1):
+            i = by_poc.get(poc)
+            if i is not None and owners[i] != owners[j]:
+                deps[i].add(owners[j])
+    return [sorted(d) for d in deps]
+
+
+class TorchDeviceRuntime:
+    """streams and events of the collective on a GPU: one torch stream the RCCL operations are ordered on"""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.stream = torch.cuda.Stream()
+        self.events = []
+
+    def stream_ptr(self):
+        return self.stream.cuda_stream
+
+    def transfer(self, ops):
+        """point-to-point operations (torch.distributed.P2POp) ordered behind everything on the collective's stream so far; the stream then
+        waits for them (NCCL: Work.wait() orders the stream, it does not block the host)"""
+        import torch.distributed as dist
+        with self.torch.cuda.stream(self.stream):
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def event_ptr(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.stream)
+        self.events.append(ev)          # kept alive until the run is over (the back-end's pictures wait for it)
+        return ev.cuda_event
+
+    def finish(self):
+        self.stream.synchronize()
+        self.events.clear()
+
+
+class HostStubRuntime:
+    """the same on the stand-in runtime of the CPU tests (tests/hoststub: streams and events are inert objects whose waits / records are traced);
+    the transfer itself is a blocking gloo operation"""
+
+    def __init__(self, stub):
+        import ctypes as C
+        self.C, self.L = C, stub
+        s = C.c_void_p()
+        stub.hipStreamCreateWithFlags(C.byref(s), 0)
+        self.s = s
+        self.events = []
+
+    def stream_ptr(self):
+        return self.s
+
+    def transfer(self, ops):
+        import torch.distributed as dist
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def event_ptr(self):
+        e = self.C.c_void_p()
+        self.L.hipEventCreate(self.C.byref(e))
+        self.L.hipEventRecord(e, self.s)
+        self.events.append(e)
+        return e
+
+    def finish(self):
+        pass
+
+
 class PictureParallel:
     """One stream over `world` ranks, one picture per rank at a time (DecLibRecon's whole-picture reference gating,
     DecLibRecon.cpp:460-489, across GPUs).
 
-    Every rank walks the same plan.  The owner of a picture submits it to its back-end; if a picture on another rank references it,
-    all ranks then take part in one broadcast of its DPB slot (three planes, one contiguous range of the DPB tensor) rooted at the
-    owner - RCCL over xGMI on GPUs, gloo in the CPU tests.  Ordering:
-      * the owner waits for the picture (vvr_wait) before the broadcast reads the slot;
-      * a receiver waits for its own pictures that still read the slot's previous content before the broadcast overwrites it;
-      * before a rank submits a picture, the broadcasts into its reference slots have completed.
-    `rec` is this rank's Reconstructor created with ext_planes = dpb.data_ptr(); `dpb` a uint8 tensor of num_slots * rec.slot_bytes()."""
+    Every rank walks the same plan.  The owner of a picture submits it to its back-end; if pictures on OTHER ranks predict from it, its DPB
+    slot (three planes, one contiguous range of the DPB tensor) goes from the owner to exactly those ranks - point-to-point sends over the
+    xGMI links of the pairs concerned (RCCL; gloo in the CPU tests), no rank that has no use for the picture takes part.  Everything is ordered
+    ON THE DEVICE; the host waits for no picture:
+      * sender: the collective's stream waits for the picture's completion event (vvr_stream_wait_job), the sends follow on that stream, an event
+        behind them keeps later pictures from overwriting the slot under the transfer (vvr_slot_external_event, reader);
+      * receiver: the collective's stream first waits for every local picture that still uses what the slot held before (vvr_stream_wait_slot),
+        then receives; pictures submitted afterwards that read the slot wait for the event behind the receive (vvr_slot_external_event, writer);
+      * the owner goes on submitting its next pictures while the transfer of the last one runs.
+    A picture can only be waited for once its work lists are built and it has been handed to the device (worker threads of the back-end); the
+    communication steps therefore sit in a first-in first-out queue per rank that is pumped without blocking before every submit - in plan
+    order, which keeps the sends and receives of every pair of ranks matched - and drained at the end of run().
+    `rec` is this rank's Reconstructor created with ext_planes = dpb.data_ptr(); `dpb` a uint8 tensor of num_slots * rec.slot_bytes();
+    `runtime`: TorchDeviceRuntime() on GPUs (default when dpb is a CUDA tensor), HostStubRuntime(stub library) in the CPU tests."""
 
-    def __init__(self, rec, dpb, plans, rank, world, replicate=True):
+    def __init__(self, rec, dpb, plans, rank, world, replicate=True, runtime=None):
         self.rec, self.dpb, self.plans, self.rank, self.world = rec, dpb, plans, rank, world
         self.owners = assign_owners(plans, world)
-        self.need = broadcast_plan(plans, self.owners) if replicate else [False] * len(plans)
+        self.deps = dependants(plans, self.owners) if replicate else [[] for _ in plans]
+        self.need = [bool(d) for d in self.deps]
         self.slot_bytes = rec.slot_bytes()
-        self.pending = {}           # slot -> broadcast still in flight into / out of it
-        self.users = {}             # slot -> local jobs that read or write it and have not been waited for
-        self.trace = []             # (op, picture index): "submit", "wait", "bcast_send", "bcast_recv" - what the tests look at
+        self.rt = runtime if runtime is not None else (TorchDeviceRuntime() if getattr(dpb, "is_cuda", False) else None)
+        self.fifo = []              # communication steps not issued yet: (picture index, job or None)
+        self.trace = []             # (op, picture index): "submit", "send", "recv", and "host_wait" whenever the host had to wait - what the tests look at
         self.n_bcast = 0
+        self.bytes_sent = 0
 
     def _slot_view(self, slot):
         return self.dpb[slot * self.slot_bytes:(slot + 1) * self.slot_bytes]
 
-    def _settle(self, slot):
-        """the broadcast touching `slot` is complete as far as this rank's device is concerned"""
-        import torch
-        w = self.pending.pop(slot, None)
-        if w is not None:
-            w.wait()
-            if self.dpb.is_cuda:
-                torch.cuda.current_stream().synchronize()      # (RCCL: wait() only orders the current torch stream; the back-end has streams of its own)
+    def _issue(self, i, job, blocking):
+        """the communication step of picture i; False if it cannot be ordered yet (blocking=False) - nothing was issued then"""
+        import torch.distributed as dist
+        pl, owner = self.plans[i], self.owners[i]
+        view = self._slot_view(pl.slot)
+        if owner == self.rank:
+            if not self.rec.stream_wait_job(job, self.rt.stream_ptr(), blocking):
+                return False
+            self.rt.transfer([dist.P2POp(dist.isend, view, r) for r in self.deps[i]])
+            self.rec.slot_external_event(pl.slot, self.rt.event_ptr(), writes=False)
+            self.trace.append(("send", i))
+            self.bytes_sent += self.slot_bytes * len(self.deps[i])
+        else:
+            if not self.rec.stream_wait_slot(pl.slot, self.rt.stream_ptr(), blocking):
+                return False
+            self.rt.transfer([dist.P2POp(dist.irecv, view, owner)])
+            self.rec.slot_external_event(pl.slot, self.rt.event_ptr(), writes=True)
+            self.trace.append(("recv", i))
+        self.n_bcast += 1
+        return True
 
-    def _drain_users(self, slot):
-        for job in self.users.pop(slot, []):
-            self.rec.wait(job)
+    def _pump(self, blocking=False):
+        while self.fifo:
+            i, job = self.fifo[0]
+            if not self._issue(i, job, blocking):
+                return
+            self.fifo.pop(0)
 
     def run(self, descs, i0=0, i1=None):
         """pictures [i0, i1) of the plan (default: all).  descs[i]: description of plans[i] for the pictures this rank owns (None elsewhere is
         fine).  Returns {picture index: job} of the pictures reconstructed here; everything of the range is complete on return, the DPB state
         carries over to the next call."""
-        import torch.distributed as dist
         jobs = {}
         for i in range(i0, len(self.plans) if i1 is None else i1):
             pl = self.plans[i]
             mine = self.owners[i] == self.rank
             ref_slots = [slot for lst in (pl.ref_slots or ([], [])) for (slot, _) in lst]
             if mine:
-                for slot in ref_slots + [pl.slot]:
-                    self._settle(slot)
+                # a reference slot (or the slot this picture overwrites) that a queued receive / send still has to touch: that step must be
+                # issued first - its event is what orders this picture behind it.  Only then does the host wait (for a picture to be handed
+                # to the device, never for the device)
+                touched = set(ref_slots + [pl.slot])
+                if any(self.plans[k].slot in touched for k, _ in self.fifo):
+                    before = len(self.fifo)
+                    self._pump(False)
+                    if any(self.plans[k].slot in touched for k, _ in self.fifo):
+                        self.trace.append(("host_wait", i))
+                        while any(self.plans[k].slot in touched for k, _ in self.fifo):
+                            k, job = self.fifo[0]
+                            self._issue(k, job, True)
+                            self.fifo.pop(0)
+                else:
+                    self._pump(False)
                 job = self.rec.decompress_picture(descs[i])
                 jobs[i] = job
                 self.trace.append(("submit", i))
-                for slot in ref_slots + [pl.slot]:
-                    self.users.setdefault(slot, []).append(job)
-            if self.need[i] and self.world > 1:
-                if mine:
-                    self.rec.wait(jobs[i])                              # the slot holds the picture
-                    self.trace.append(("wait", i))
-                    self.users[pl.slot] = [j for j in self.users.get(pl.slot, []) if j != jobs[i]]
-                else:
-                    self._settle(pl.slot)
-                    self._drain_users(pl.slot)                          # nobody here still reads what the slot held before
-                self.pending[pl.slot] = dist.broadcast(self._slot_view(pl.slot), src=self.owners[i], async_op=True)
-                self.trace.append(("bcast_send" if mine else "bcast_recv", i))
-                self.n_bcast += 1
-        for slot in list(self.pending):
-            self._settle(slot)
+            if self.need[i] and self.world > 1 and (mine or self.rank in self.deps[i]):
+                self.fifo.append((i, jobs.get(i)))
+                self._pump(False)
+        self._pump(True)
+        if self.rt is not None:
+            self.rt.finish()
         self.rec.sync()
-        self.users.clear()
         return jobs
