@@ -618,7 +618,12 @@ def test_bench_control_flow(stub, ranks):
     out = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out
-    assert out["n_gpus"] == ranks and out["steps"] == 6 and out["warmup"] == 4 and out["scaling"] == "weak" and "workload" in out["config"]
+    assert out["n_gpus"] == ranks and out["steps"] == 6 and out["warmup"] == 4 and "workload" in out["config"]
+    if ranks == 1:
+        assert out["scaling"] == "weak"
+    else:
+        # N > 1: the headline is ONE stream sharded by picture (strong scaling), the segment mode sits next to it
+        assert out["scaling"] == "strong" and out["config"]["picture_sharding"]["fps"] == out["value"] and out["config"]["segment_mode"]["scaling"] == "weak"
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in out["roofline"]
     if ranks > 1:
