@@ -628,7 +628,7 @@ def test_bench_control_flow(stub, ranks):
         assert k in out["roofline"]
     if ranks > 1:
         ps = out["config"]["picture_sharding"]           # the second mode: ONE stream, pictures sharded over the ranks, reference slots broadcast
-        assert "error" not in ps and ps["fps"] > 0 and ps["scaling"] == "strong" and ps["broadcasts_in_window"] > 0, ps
+        assert "error" not in ps and ps["fps"] > 0 and ps["scaling"] == "strong" and ps["point_to_point_sends_in_window"] > 0, ps
 
 
 def test_bench_line_survives_the_picture_sharding_pass(stub):
