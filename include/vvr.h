@@ -36,7 +36,7 @@ extern "C" {
 #define VVR_API
 #endif
 
-#define VVR_ABI_VERSION 3
+#define VVR_ABI_VERSION 4
 
 /* ------------------------------------------------------------------------------------------------------------------
  * status codes (negative = error; mirrors the style of vvdecErrorCodes, include/vvdec/vvdec.h.in:91-105)
@@ -321,6 +321,25 @@ typedef struct vvr_subpic {      /* SubPic (Slice.h:820): one sub-picture of the
 /* ------------------------------------------------------------------------------------------------------------------
  * one picture to reconstruct
  * ---------------------------------------------------------------------------------------------------------------- */
+/* What a slice header sets for its slice only (DecLibRecon switches on ctuData.slice per CTU, DecLibRecon.cpp:787-790,856-860; every stage reads
+ * cu.slice / the CTU's slice: Quant.cpp:306,336, DecCu.cpp:383,460,489, LoopFilter.cpp:423,1473,1637, Reshape.cpp:385, AdaptiveLoopFilter.cpp:515,558,603).
+ * NOT here, by construction of the description: the slice's reference picture lists - hdr.ref_slot / ref_poc hold the UNION of the slices' lists
+ * per list (at most VVR_MAX_REFS pictures) and every cu.ref_idx / vvr_motion.ref_idx indexes that union (whoever flattens the picture renumbers
+ * them; an I slice simply has no inter CUs) - and SAO / ALF on-off switches, which are resolved into the per-CTU records.                       */
+#define VVR_SLICE_TOOL_MASK ( VVR_TOOL_DEP_QUANT | VVR_TOOL_LMCS | VVR_TOOL_LMCS_CSCALE | VVR_TOOL_SCALING_LIST | VVR_TOOL_WP )
+typedef struct vvr_slice_header {
+  uint32_t tool_flags;               /* this slice's value of the switches a slice header carries: VVR_TOOL_DEP_QUANT (sh_dep_quant_used_flag), VVR_TOOL_LMCS
+                                        (sh_lmcs_used_flag), VVR_TOOL_LMCS_CSCALE (the picture's flag and sh_lmcs_used_flag), VVR_TOOL_SCALING_LIST
+                                        (sh_explicit_scaling_list_used_flag), VVR_TOOL_WP (a P / B slice with weights); all other bits are ignored: those
+                                        tools follow hdr.tool_flags                                                                                       */
+  int8_t   deblock_beta_offset_div2[3];   /* Y, Cb, Cr: of the slice the deblocked CTU belongs to (LoopFilter.cpp:421,1473,1637)                        */
+  int8_t   deblock_tc_offset_div2[3];
+  uint8_t  slice_type;               /* 0 B, 1 P, 2 I (informative: the CUs say how they are predicted)                                                */
+  uint8_t  alf_set;                  /* which of vvr_picture.alf_params[] holds the filters of the APSs this slice refers to (luma list, chroma, CC-ALF)   */
+  uint8_t  wp_set;                   /* which of vvr_picture.wp[] holds this slice's pred_weight_table()                                               */
+  uint8_t  pad[3];
+} vvr_slice_header;
+
 typedef struct vvr_picture {
   vvr_pic_header        hdr;
   uint32_t              num_cu, num_tu;
@@ -333,22 +352,26 @@ typedef struct vvr_picture {
   const vvr_lfp*        lfp[2];        /* [EDGE_VER, EDGE_HOR][h4][w4]                                           */
   const vvr_sao_ctu*    sao;           /* [num_ctu] or NULL                                                      */
   const vvr_alf_ctu*    alf;           /* [num_ctu] or NULL                                                      */
-  const vvr_alf_params* alf_params;    /* NULL when ALF is off                                                   */
+  const vvr_alf_params* alf_params;    /* NULL when ALF is off; [num_alf_sets] tables when slices refer to different APSs */
   const vvr_lmcs_params* lmcs;         /* NULL when LMCS is off                                                  */
-  const vvr_wp_params*  wp;            /* NULL unless VVR_TOOL_WP                                                */
+  const vvr_wp_params*  wp;            /* NULL unless VVR_TOOL_WP; [num_wp_sets] tables when slices carry different weights */
   const vvr_scaling_list* scaling;     /* NULL unless VVR_TOOL_SCALING_LIST                                      */
   /* Slices and tiles.  The CTUs of the description are listed in picture raster order whatever order the bit stream coded them in.  Across a
    * slice or tile boundary nothing is available to intra prediction, CCLM or the LMCS chroma-scaling neighbourhood (CodingStructure::
    * getCURestricted, CodingStructure.cpp:464), and SAO / ALF stop there when the VVR_TOOL_NO_LF_ACROSS_* flag of the kind of boundary is set
-   * (SampleAdaptiveOffset.cpp:741-830, AdaptiveLoopFilter.cpp:118-200).  All slices of the picture share the header above: a picture whose
-   * slices differ in slice type, reference lists, deblocking / SAO / ALF / LMCS / scaling-list switches or weights is not expressible (the
-   * reference-side glue refuses it). */
+   * (SampleAdaptiveOffset.cpp:741-830, AdaptiveLoopFilter.cpp:118-200).
+   * Slices with headers of their own (ABI 4): `slices[ctu_slice[ctu]]` carries what a slice header can set differently from its neighbours -
+   * see vvr_slice_header.  slices == NULL: every slice takes the values of `hdr` (and alf_params / wp are single tables). */
   const uint16_t*       ctu_slice;     /* [num_ctu] slice index of every CTU, NULL = one slice                   */
   const uint16_t*       ctu_tile;      /* [num_ctu] tile index of every CTU, NULL = one tile                     */
   /* Sub-pictures: rectangles of whole CTUs that tile the picture (NULL / 0 or 1: the picture is its only sub-picture).  Not combined with
    * reference wrap-around (the reference does not support the pair either, Picture.h:114).                                                   */
   const vvr_subpic*     subpics;
   uint32_t              num_subpics;
+  const vvr_slice_header* slices;      /* [num_slices] or NULL                                                   */
+  uint32_t              num_slices;    /* (ctu_slice values are < num_slices when slices != NULL)                */
+  uint32_t              num_alf_sets;  /* entries of alf_params[] (0 or 1: one table), selected by vvr_slice_header.alf_set */
+  uint32_t              num_wp_sets;   /* entries of wp[] (0 or 1: one table), selected by vvr_slice_header.wp_set          */
   int                   resident;      /* 0: all array pointers are host memory (copied H2D by vvr_submit);      */
                                        /* 1: all array pointers are DEVICE memory already resident in HBM        */
 } vvr_picture;
@@ -459,7 +482,7 @@ VVR_API const char*  vvr_last_error(const vvr_context* ctx);
 VVR_API const char*  vvr_version(void);
 /* sizeof() of ABI struct number `which` as this library was compiled (0 vvr_pic_header, 1 vvr_cu, 2 vvr_tu, 3 vvr_motion,
  * 4 vvr_lfp, 5 vvr_sao_ctu, 6 vvr_alf_ctu, 7 vvr_alf_params, 8 vvr_lmcs_params, 9 vvr_picture, 10 vvr_config,
- * 11 vvr_kernel_stat; anything else 0): lets a binding written in another language verify its struct mirror at load time */
+ * 11 vvr_kernel_stat, 12 vvr_wp_params, 13 vvr_scaling_list, 14 vvr_subpic, 15 vvr_slice_header; anything else 0): lets a binding written in another language verify its struct mirror at load time */
 VVR_API size_t       vvr_abi_sizeof(int which);
 
 /* kernel statistics accumulated with HIP events on the launch streams when enabled */

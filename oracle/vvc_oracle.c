@@ -27,7 +27,9 @@ void vvo_planes_free( vvo_planes* pl ) { for( int c = 0; c < 3; c++ ) { free( pl
 /* residuals of one TU into tight per-component buffers (DecCu::reconstructResi, DecCu.cpp:536); returns mask of components that carry a residual */
 static int tu_residuals( const vvr_picture* pic, const vvr_cu* cu, const vvr_tu* tu, int16_t* resi[3], int bw[3], int bh[3] )
 {
-  const vvr_pic_header* H = &pic->hdr;
+  /* the header as the block's slice sees it: dependent quantisation and the explicit scaling lists are switches of the slice (Quant.cpp:306,336) */
+  vvr_pic_header Hs = pic->hdr; Hs.tool_flags = vvo_flags_at( pic, cu->x, cu->y );
+  const vvr_pic_header* H = &Hs;
   const int ncomp = H->chroma_format ? 3 : 1;
   int mask = 0;
   for( int c = 0; c < ncomp; c++ )
@@ -117,7 +119,7 @@ static void lmcs_scale_residual( int16_t* r, int n, int scale, int bd )
 int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, uint16_t* const* out_planes, int flags )
 {
   vvo_dmvr_reset();
-  vvo_set_scaling_list( ( pic->hdr.tool_flags & VVR_TOOL_SCALING_LIST ) ? pic->scaling : 0 );
+  vvo_set_scaling_list( pic->scaling );      /* (whether a block uses it is the switch of its slice: vvo_flags_at) */
   const vvr_pic_header* H = &pic->hdr;
   const int W = H->width, Hh = H->height, ncomp = H->chroma_format ? 3 : 1;
   int rc = -1;
@@ -176,9 +178,10 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
     if( cu->tree == VVR_TREE_CHROMA ) continue;                      /* dual tree: the luma CUs */
     for( int y = cu->y; y < cu->y + cu->h && y < Hh; y += 4 ) for( int x = cu->x; x < cu->x + cu->w && x < W; x += 4 ) cuAt[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )] = (int32_t) i;
   }
-  const int cscale = ( H->tool_flags & VVR_TOOL_LMCS ) && ( H->tool_flags & VVR_TOOL_LMCS_CSCALE ) && pic->lmcs && ncomp == 3;
+  /* LMCS chroma residual scaling: the picture's flag and the slice's LMCS switch (DecCu.cpp:383,489,618) */
+#define CSCALE_AT( x_, y_ ) ( ( vvo_flags_at( pic, x_, y_ ) & VVR_TOOL_LMCS ) && ( vvo_flags_at( pic, x_, y_ ) & VVR_TOOL_LMCS_CSCALE ) && pic->lmcs && ncomp == 3 )
 #define CSCALE_TU( tu_, mask_ ) \
-  if( cscale && ( ( mask_ ) & 6 ) && bw[1] * bh[1] > 4 ) \
+  if( CSCALE_AT( tu_->x, tu_->y ) && ( ( mask_ ) & 6 ) && bw[1] * bh[1] > 4 ) \
   { \
     const int sc = lmcs_chroma_scale( pic, &reco, cuAt, tu_->x, tu_->y ); \
     for( int c = 1; c < 3; c++ ) if( ( mask_ ) & ( 1 << c ) ) lmcs_scale_residual( resi[c], bw[c] * bh[c], sc, H->bit_depth ); \
@@ -191,7 +194,7 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
     if( cu->pred_mode == VVR_PRED_INTER )
     {
       if( vvo_inter_cu( pic, cu, refs, numSlots, &reco ) ) goto done;
-      if( ( H->tool_flags & VVR_TOOL_LMCS ) && pic->lmcs )
+      if( ( vvo_flags_at( pic, cu->x, cu->y ) & VVR_TOOL_LMCS ) && pic->lmcs )
       {   /* forward luma mapping of the inter prediction (DecCu.cpp:458-476, Reshape::rspBufFwd :413, rspFwdCore Buffer.cpp:321) */
         for( int y = 0; y < cu->h; y++ ) for( int x = 0; x < cu->w; x++ )
         {
@@ -310,9 +313,10 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
     else { vvo_set_error( "unknown prediction mode" ); goto done; }
   }
 
-  if( ( H->tool_flags & VVR_TOOL_LMCS ) && pic->lmcs )
-  {   /* inverse luma mapping of the whole picture (Reshape::rspCtuBcw :376, applyLutCore Buffer.cpp:200) */
-    for( size_t k = 0; k < (size_t) reco.stride[0] * reco.h[0]; k++ ) reco.p[0][k] = pic->lmcs->inv_lut[reco.p[0][k] & 4095];
+  if( pic->lmcs )
+  {   /* inverse luma mapping, CTU by CTU: where the CTU's slice uses LMCS (Reshape::rspCtuBcw :376-392, applyLutCore Buffer.cpp:200) */
+    for( int y = 0; y < reco.h[0]; y++ ) for( int x = 0; x < reco.w[0]; x++ )
+      if( vvo_flags_at( pic, x, y ) & VVR_TOOL_LMCS ) { pel* d = &reco.p[0][(size_t) y * reco.stride[0] + x]; *d = pic->lmcs->inv_lut[*d & 4095]; }
   }
   if( !( flags & VVO_STOP_AFTER_RECO ) )
   {

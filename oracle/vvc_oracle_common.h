@@ -37,6 +37,28 @@ static inline int vvo_same_slice_tile( const vvr_picture* pic, int ctuA, int ctu
 {
   return ( !pic->ctu_slice || pic->ctu_slice[ctuA] == pic->ctu_slice[ctuB] ) && ( !pic->ctu_tile || pic->ctu_tile[ctuA] == pic->ctu_tile[ctuB] );
 }
+/* slices with headers of their own (vvr_picture.slices): the slice of a luma position, the tool switches that hold there (the slice's value for
+ * the switches a slice header carries, the picture's for the rest), the slice's ALF / weighted-prediction tables */
+static inline const vvr_slice_header* vvo_slice_at( const vvr_picture* pic, int lx, int ly )
+{
+  if( !pic->slices || !pic->ctu_slice ) return 0;
+  return &pic->slices[pic->ctu_slice[vvo_ctu_of( &pic->hdr, lx, ly )]];
+}
+static inline uint32_t vvo_flags_at( const vvr_picture* pic, int lx, int ly )
+{
+  const vvr_slice_header* s = vvo_slice_at( pic, lx, ly );
+  return s ? ( pic->hdr.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | ( s->tool_flags & VVR_SLICE_TOOL_MASK ) : pic->hdr.tool_flags;
+}
+static inline const vvr_alf_params* vvo_alf_set_at( const vvr_picture* pic, int lx, int ly )
+{
+  const vvr_slice_header* s = vvo_slice_at( pic, lx, ly );
+  return pic->alf_params ? &pic->alf_params[s && pic->num_alf_sets > 1 ? s->alf_set : 0] : 0;
+}
+static inline const vvr_wp_params* vvo_wp_set_at( const vvr_picture* pic, int lx, int ly )
+{
+  const vvr_slice_header* s = vvo_slice_at( pic, lx, ly );
+  return pic->wp ? &pic->wp[s && pic->num_wp_sets > 1 ? s->wp_set : 0] : 0;
+}
 /* may SAO / ALF of CTU a read samples of CTU b (pps_loop_filter_across_slices / tiles_enabled_flag) */
 static inline int vvo_lf_may_cross( const vvr_picture* pic, int a, int b )
 {

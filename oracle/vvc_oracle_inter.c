@@ -125,11 +125,14 @@ static void pred_block_src( const vvo_src* ref, int comp, int bx, int by, int w,
  * picture with VVR_TOOL_WP (InterPrediction::xPredInterBi, InterPrediction.cpp:707,735-742) unless the CU uses BCW weights or GPM;
  * the inputs are the 14-bit intermediate predictions.
  * ------------------------------------------------------------------------------------------------------------------- */
-static int wp_on( const vvr_picture* pic, int bcw_idx ) { return ( pic->hdr.tool_flags & VVR_TOOL_WP ) && pic->wp && bcw_idx == 2; }
+/* the table and the switch are the slice's (vvr_slice_header.wp_set, VVR_TOOL_WP among its flags): set per CU by vvo_inter_cu */
+static const vvr_wp_params* g_wp = 0;
+static int g_wpOn = 0;
+static int wp_on( const vvr_picture* pic, int bcw_idx ) { (void) pic; return g_wpOn && g_wp && bcw_idx == 2; }
 static int wp_uni( const vvr_picture* pic, int l, int ri, int c, int p )
 {
-  const vvr_wp_entry* e = &pic->wp->e[l][ri][c];
-  const int bd = pic->hdr.bit_depth, den = pic->wp->log2_denom[c ? 1 : 0];
+  const vvr_wp_entry* e = &g_wp->e[l][ri][c];
+  const int bd = pic->hdr.bit_depth, den = g_wp->log2_denom[c ? 1 : 0];
   const int shiftNum = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2, shift = den + shiftNum;
   const int offset = e->offset * ( 1 << ( bd - 8 ) );
   if( e->weight != ( 1 << den ) ) return vvo_clip_pel( ( ( e->weight * ( p + IF_INTERNAL_OFFS ) + ( 1 << ( shift - 1 ) ) ) >> shift ) + offset, bd );
@@ -137,8 +140,8 @@ static int wp_uni( const vvr_picture* pic, int l, int ri, int c, int p )
 }
 static int wp_bi( const vvr_picture* pic, int r0, int r1, int c, int p0, int p1 )
 {
-  const vvr_wp_entry* e0 = &pic->wp->e[0][r0][c]; const vvr_wp_entry* e1 = &pic->wp->e[1][r1][c];
-  const int bd = pic->hdr.bit_depth, den = pic->wp->log2_denom[c ? 1 : 0];
+  const vvr_wp_entry* e0 = &g_wp->e[0][r0][c]; const vvr_wp_entry* e1 = &g_wp->e[1][r1][c];
+  const int bd = pic->hdr.bit_depth, den = g_wp->log2_denom[c ? 1 : 0];
   const int shiftNum = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2, shift = den + 1 + shiftNum;
   const int offset = ( e0->offset + e1->offset ) * ( 1 << ( bd - 8 ) );
   return vvo_clip_pel( ( e0->weight * ( p0 + IF_INTERNAL_OFFS ) + e1->weight * ( p1 + IF_INTERNAL_OFFS ) + ( ( 1 << shift ) >> 1 ) + offset * ( 1 << ( shift - 1 ) ) ) >> shift, bd );
@@ -783,6 +786,7 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
   const int ncomp = H->chroma_format ? 3 : 1;
   g_wrapOff = H->wrap_offset; g_wrapFetch = 0;
   g_mcRectOn = 0;
+  g_wp = vvo_wp_set_at( pic, cu->x, cu->y ); g_wpOn = ( vvo_flags_at( pic, cu->x, cu->y ) & VVR_TOOL_WP ) != 0;
   if( pic->subpics && pic->num_subpics > 1 )
     for( uint32_t k = 0; k < pic->num_subpics; k++ )
     {

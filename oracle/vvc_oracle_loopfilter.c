@@ -224,6 +224,16 @@ static void edge_chroma( const vvr_pic_header* H, vvo_planes* r, int cx, int cy,
   }
 }
 
+/* the deblocking offsets are those of the slice the deblocked CTU belongs to - the CTU that holds the edge's position, i.e. its Q side
+ * (LoopFilter::xDeblockCtuArea :421-422 passes ctuData.slice down to xEdgeFilterLuma :1473 / xEdgeFilterChroma :1637) */
+static vvr_pic_header deblock_header_at( const vvr_picture* pic, int lx, int ly )
+{
+  vvr_pic_header h = pic->hdr;
+  const vvr_slice_header* s = vvo_slice_at( pic, lx, ly );
+  if( s ) for( int c = 0; c < 3; c++ ) { h.deblock_beta_offset_div2[c] = s->deblock_beta_offset_div2[c]; h.deblock_tc_offset_div2[c] = s->deblock_tc_offset_div2[c]; }
+  return h;
+}
+
 void vvo_deblock( const vvr_picture* pic, vvo_planes* r, int dir )   /* xDeblockCtuArea (:419) for every CTU; order inside a direction is immaterial for valid streams */
 {
   const vvr_pic_header* H = &pic->hdr;
@@ -233,7 +243,7 @@ void vvo_deblock( const vvr_picture* pic, vvo_planes* r, int dir )   /* xDeblock
   for( int y4 = 0; y4 < h4; y4++ ) for( int x4 = 0; x4 < w4; x4++ )
   {
     const vvr_lfp* l = &T[(size_t) y4 * w4 + x4];
-    if( BS_GET( l->bs, 0 ) ) edge_luma( H, r, x4 * 4, y4 * 4, l, dir );
+    if( BS_GET( l->bs, 0 ) ) { const vvr_pic_header Hs = deblock_header_at( pic, x4 * 4, y4 * 4 ); edge_luma( &Hs, r, x4 * 4, y4 * 4, l, dir ); }
   }
   if( !H->chroma_format ) return;
   /* chroma: edges on the 8-chroma-sample grid across, 2 chroma rows (one 4x4 luma unit) along (:457-489) */
@@ -241,7 +251,7 @@ void vvo_deblock( const vvr_picture* pic, vvo_planes* r, int dir )   /* xDeblock
   {
     if( dir == 0 ? ( x4 & 3 ) : ( y4 & 3 ) ) continue;
     const vvr_lfp* l = &T[(size_t) y4 * w4 + x4];
-    if( BS_GET( l->bs, 1 ) | BS_GET( l->bs, 2 ) ) edge_chroma( H, r, x4 * 2, y4 * 2, l, dir );
+    if( BS_GET( l->bs, 1 ) | BS_GET( l->bs, 2 ) ) { const vvr_pic_header Hs = deblock_header_at( pic, x4 * 4, y4 * 4 ); edge_chroma( &Hs, r, x4 * 2, y4 * 2, l, dir ); }
   }
 }
 
@@ -485,7 +495,6 @@ void vvo_alf( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )  
 {
   const vvr_pic_header* H = &pic->hdr;
   const int ctu = 1 << H->log2_ctu, ctusX = ( H->width + ctu - 1 ) / ctu, bd = H->bit_depth;
-  const vvr_alf_params* A = pic->alf_params;
   static const int clipDef[3] = { 256, 512, 1024 };
   for( int c = 0; c < src->ncomp; c++ )
   {
@@ -493,6 +502,7 @@ void vvo_alf( const vvr_picture* pic, const vvo_planes* src, vvo_planes* dst )  
     for( int y = 0; y < src->h[c]; y += 4 ) for( int x = 0; x < src->w[c]; x += 4 )
     {
       const vvr_alf_ctu* f = &pic->alf[( y / cctu ) * ctusX + ( x / cctu )];
+      const vvr_alf_params* A = vvo_alf_set_at( pic, x << cs, y << cs );      /* the filters of the APSs the CTU's slice refers to (AdaptiveLoopFilter.cpp:515,558,603) */
       alf_set_ctu( pic, x / cctu, y / cctu );
       if( H->num_ver_vb | H->num_hor_vb ) alf_set_part( pic, x << cs, y << cs );
       int16_t cf[13], cl[13];

@@ -5,7 +5,7 @@ compiled library so the two cannot drift apart silently.
 """
 import ctypes as C
 
-VVR_ABI_VERSION = 3
+VVR_ABI_VERSION = 4
 VVR_MAX_REFS = 16
 VVR_MAX_ALF_APS = 8
 VVR_ALF_CLASSES = 25
@@ -109,6 +109,10 @@ class Subpic(C.Structure):
     _fields_ = [("x0", u16), ("y0", u16), ("x1", u16), ("y1", u16), ("treated_as_pic", u8), ("lf_across", u8), ("pad", u8 * 2)]
 
 
+class SliceHeader(C.Structure):      # vvr_slice_header: what a slice header sets for its slice only
+    _fields_ = [("tool_flags", u32), ("deblock_beta_offset_div2", i8 * 3), ("deblock_tc_offset_div2", i8 * 3), ("slice_type", u8), ("alf_set", u8), ("wp_set", u8), ("pad", u8 * 3)]
+
+
 class Picture(C.Structure):
     _fields_ = [("hdr", PicHeader), ("num_cu", u32), ("num_tu", u32),
                 ("cu", C.POINTER(Cu)), ("tu", C.POINTER(Tu)), ("ctu_first_cu", C.POINTER(u32)),
@@ -117,7 +121,8 @@ class Picture(C.Structure):
                 ("sao", C.POINTER(SaoCtu)), ("alf", C.POINTER(AlfCtu)),
                 ("alf_params", C.POINTER(AlfParams)), ("lmcs", C.POINTER(LmcsParams)),
                 ("wp", C.POINTER(WpParams)), ("scaling", C.POINTER(ScalingList)),
-                ("ctu_slice", C.POINTER(u16)), ("ctu_tile", C.POINTER(u16)), ("subpics", C.c_void_p), ("num_subpics", u32), ("resident", C.c_int)]
+                ("ctu_slice", C.POINTER(u16)), ("ctu_tile", C.POINTER(u16)), ("subpics", C.c_void_p), ("num_subpics", u32),
+                ("slices", C.POINTER(SliceHeader)), ("num_slices", u32), ("num_alf_sets", u32), ("num_wp_sets", u32), ("resident", C.c_int)]
 
 
 class Config(C.Structure):

@@ -48,6 +48,9 @@ class PictureDesc:
         self.ctu_slice = None          # uint16 [num_ctu] or None (one slice)
         self.ctu_tile = None           # uint16 [num_ctu] or None (one tile)
         self.subpics = None            # array of abi.Subpic records or None (the picture is its only sub-picture)
+        self.slices = None             # array of abi.SliceHeader records (indexed by ctu_slice) or None: every slice takes the picture header's values
+        self.alf_sets = None           # list of abi.AlfParams selected by SliceHeader.alf_set (None: the single table alf_params)
+        self.wp_sets = None            # list of abi.WpParams selected by SliceHeader.wp_set (None: the single table wp)
 
     def set_refs(self, l0, l1=()):
         """l0/l1: lists of (slot, poc)."""
@@ -79,12 +82,22 @@ class PictureDesc:
             p.sao = self.sao.ctypes.data_as(C.POINTER(abi.SaoCtu))
         if self.alf is not None:
             p.alf = self.alf.ctypes.data_as(C.POINTER(abi.AlfCtu))
-        if self.alf_params is not None:
+        if self.alf_sets:
+            self._alf_arr = (abi.AlfParams * len(self.alf_sets))(*self.alf_sets)
+            p.alf_params = C.cast(self._alf_arr, C.POINTER(abi.AlfParams))
+            p.num_alf_sets = len(self.alf_sets)
+        elif self.alf_params is not None:
             p.alf_params = C.pointer(self.alf_params)
+            p.num_alf_sets = 1
         if self.lmcs is not None:
             p.lmcs = C.pointer(self.lmcs)
-        if self.wp is not None:
+        if self.wp_sets:
+            self._wp_arr = (abi.WpParams * len(self.wp_sets))(*self.wp_sets)
+            p.wp = C.cast(self._wp_arr, C.POINTER(abi.WpParams))
+            p.num_wp_sets = len(self.wp_sets)
+        elif self.wp is not None:
             p.wp = C.pointer(self.wp)
+            p.num_wp_sets = 1
         if self.scaling is not None:
             p.scaling = C.pointer(self.scaling)
         if self.ctu_slice is not None:
@@ -97,6 +110,10 @@ class PictureDesc:
             self.subpics = np.ascontiguousarray(self.subpics, dtype=np.dtype(abi.Subpic))
             p.subpics = self.subpics.ctypes.data
             p.num_subpics = len(self.subpics)
+        if self.slices is not None and len(self.slices):
+            self.slices = np.ascontiguousarray(self.slices, dtype=np.dtype(abi.SliceHeader))
+            p.slices = C.cast(self.slices.ctypes.data, C.POINTER(abi.SliceHeader))
+            p.num_slices = len(self.slices)
         p.resident = 0
         self._keep = p
         return p
