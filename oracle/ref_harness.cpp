@@ -142,7 +142,10 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     static bool romInit = false;
     if( !romInit ) { initROM(); romInit = true; }
 
-    const vvr_pic_header& H = vp->hdr;
+    // picture-level switches (SPS / PPS / PH) are on when any slice uses the tool; the slices then say which of them do (vvr_slice_header)
+    vvr_pic_header Hunion = vp->hdr;
+    if( vp->slices ) { uint32_t any = 0; for( uint32_t i = 0; i < vp->num_slices; i++ ) any |= vp->slices[i].tool_flags & VVR_SLICE_TOOL_MASK; Hunion.tool_flags = ( Hunion.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | any; }
+    const vvr_pic_header& H = Hunion;
     const bool enableOpt  = !!( flags & VVREF_SIMD );
     // same switch as vvdecParams::simd (vvdecimpl.cpp:92-100): SCALAR keeps every function pointer on its "Core" version
     read_x86_extension_flags( enableOpt ? x86_simd::UNDEFINED : x86_simd::SCALAR );
@@ -261,8 +264,16 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       pps.initRectSliceMap( &sps );
       pps.initSubPic( sps );
     }
-    pps.setUseWP( ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 1 );        // pps_weighted_pred_flag (P slices)
-    pps.setWPBiPred( ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 0 );     // pps_weighted_bipred_flag (B slices)
+    {
+      bool wpP = ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 1, wpB = ( H.tool_flags & VVR_TOOL_WP ) && H.slice_type == 0;
+      if( vp->slices )
+      {
+        wpP = wpB = false;
+        for( uint32_t i = 0; i < vp->num_slices; i++ ) if( vp->slices[i].tool_flags & VVR_TOOL_WP ) { wpP |= vp->slices[i].slice_type == 1; wpB |= vp->slices[i].slice_type == 0; }
+      }
+      pps.setUseWP( wpP );        // pps_weighted_pred_flag (P slices)
+      pps.setWPBiPred( wpB );     // pps_weighted_bipred_flag (B slices)
+    }
     pps.pcv = std::make_unique<PreCalcValues>( sps, pps );
 
     auto ph = std::make_shared<PicHeader>();
@@ -372,13 +383,17 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     pic.poc = H.poc;
     const APS* nullAps[ALF_CTB_MAX_NUM_APS] = { nullptr };
 
-    // ALF APSs
+    // ALF APSs: one array of APS objects per parameter set of the description (slices name their set, vvr_slice_header::alf_set;
+    // every Slice holds its own APS pointers, Slice.h:2570)
     std::vector<std::shared_ptr<APS>> alfApsStore;
-    const APS* alfApss[ALF_CTB_MAX_NUM_APS] = { nullptr };
+    const int numAlfSets = vp->slices && vp->num_alf_sets > 1 ? (int) vp->num_alf_sets : 1;
+    std::vector<std::array<const APS*, ALF_CTB_MAX_NUM_APS>> alfSetApss( numAlfSets );
+    for( auto& s : alfSetApss ) s.fill( nullptr );
+    const APS** alfApss = alfSetApss[0].data();
     const bool useAlf = !!( H.tool_flags & VVR_TOOL_ALF ) && vp->alf && vp->alf_params;
-    if( useAlf )
+    for( int set = 0; useAlf && set < numAlfSets; set++ )
     {
-      const vvr_alf_params& A = *vp->alf_params;
+      const vvr_alf_params& A = vp->alf_params[set];
       auto clipIdx = [&]( int v ) { for( int i = 0; i < 4; i++ ) if( AdaptiveLoopFilter::m_alfClippVls[bd - 8][i] == v ) return i; THROW_FATAL( "bad ALF clip value " << v ); return 0; };
       for( int a = 0; a < ALF_CTB_MAX_NUM_APS; a++ )
       {
@@ -414,47 +429,63 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
           for( int f = 0; f < MAX_NUM_CC_ALF_FILTERS; f++ ) { cc.ccAlfFilterIdxEnabled[c][f] = true; for( int k = 0; k < MAX_NUM_CC_ALF_CHROMA_COEFF; k++ ) cc.ccAlfCoeff[c][f][k] = A.ccalf_coeff[c][f][k]; }
         }
         alfApsStore.push_back( aps );
-        alfApss[a] = aps.get();
+        alfSetApss[set][a] = aps.get();
       }
     }
     pic.finalInit( &cuCache, &tuCache, &sps, &pps, ph, useAlf ? alfApss : nullAps, lmcsAps.get(), slAps.get() );
     CodingStructure& cs = *pic.cs;
     TR("finalInit done\n");
 
-    // one Slice object per slice of the description, all with the same header (that is what a vvr_picture can express); `slice` is the first
+    // one Slice object per slice of the description; with vvr_picture::slices every one carries its own header values, else all those of `hdr`
     int numSlices = 1;
     const int numCtuAll = ( ( W + ctuSize - 1 ) / ctuSize ) * ( ( Hh + ctuSize - 1 ) / ctuSize );
     if( vp->ctu_slice ) for( int a = 0; a < numCtuAll; a++ ) numSlices = std::max( numSlices, vp->ctu_slice[a] + 1 );
+    if( vp->slices && (int) vp->num_slices < numSlices ) THROW_FATAL( "ctu_slice names a slice without a header" );
     std::vector<Slice*> slices;
     for( int si = 0; si < numSlices; si++ )
     {
+    vvr_slice_header SH;
+    if( vp->slices ) SH = vp->slices[si];
+    else
+    {
+      memset( &SH, 0, sizeof( SH ) );
+      SH.tool_flags = H.tool_flags; SH.slice_type = H.slice_type;
+      for( int c = 0; c < 3; c++ ) { SH.deblock_beta_offset_div2[c] = H.deblock_beta_offset_div2[c]; SH.deblock_tc_offset_div2[c] = H.deblock_tc_offset_div2[c]; }
+    }
+    const bool sliceWp = ( SH.tool_flags & VVR_TOOL_WP ) && vp->wp && SH.slice_type != 2;
+    if( SH.slice_type != 2 && !sliceWp && ( ( SH.slice_type == 1 && pps.getUseWP() ) || ( SH.slice_type == 0 && pps.getWPBiPred() ) ) )
+      THROW_FATAL( "slices of the same type disagree about weighted prediction: the PPS flag holds for all of them" );
     Slice* slice = pic.allocateNewSlice();
     slices.push_back( slice );
     slice->setPicHeader( ph.get() );
-    slice->setSliceType( SliceType( H.slice_type ) );
+    slice->setSliceType( SliceType( SH.slice_type ) );
     slice->setPOC( H.poc );
     slice->setSliceQp( 32 );
     slice->setDefaultClpRng( sps );
-    slice->setDepQuantEnabledFlag( !!( H.tool_flags & VVR_TOOL_DEP_QUANT ) );
+    slice->setDepQuantEnabledFlag( !!( SH.tool_flags & VVR_TOOL_DEP_QUANT ) );
     slice->setDeblockingFilterDisable( !!( H.tool_flags & VVR_TOOL_DEBLOCK_OFF ) );
-    slice->setDeblockingFilterBetaOffsetDiv2( H.deblock_beta_offset_div2[0] );
-    slice->setDeblockingFilterTcOffsetDiv2( H.deblock_tc_offset_div2[0] );
-    slice->setDeblockingFilterCbBetaOffsetDiv2( H.deblock_beta_offset_div2[1] );
-    slice->setDeblockingFilterCbTcOffsetDiv2( H.deblock_tc_offset_div2[1] );
-    slice->setDeblockingFilterCrBetaOffsetDiv2( H.deblock_beta_offset_div2[2] );
-    slice->setDeblockingFilterCrTcOffsetDiv2( H.deblock_tc_offset_div2[2] );
+    slice->setDeblockingFilterBetaOffsetDiv2( SH.deblock_beta_offset_div2[0] );
+    slice->setDeblockingFilterTcOffsetDiv2( SH.deblock_tc_offset_div2[0] );
+    slice->setDeblockingFilterCbBetaOffsetDiv2( SH.deblock_beta_offset_div2[1] );
+    slice->setDeblockingFilterCbTcOffsetDiv2( SH.deblock_tc_offset_div2[1] );
+    slice->setDeblockingFilterCrBetaOffsetDiv2( SH.deblock_beta_offset_div2[2] );
+    slice->setDeblockingFilterCrTcOffsetDiv2( SH.deblock_tc_offset_div2[2] );
     slice->setSaoEnabledFlag( CHANNEL_TYPE_LUMA, !!( H.tool_flags & VVR_TOOL_SAO_LUMA ) );
     slice->setSaoEnabledFlag( CHANNEL_TYPE_CHROMA, !!( H.tool_flags & VVR_TOOL_SAO_CHROMA ) );
-    slice->setLmcsEnabledFlag( !!( H.tool_flags & VVR_TOOL_LMCS ) );
-    slice->setExplicitScalingListUsed( ( H.tool_flags & VVR_TOOL_SCALING_LIST ) && vp->scaling );
+    slice->setLmcsEnabledFlag( !!( SH.tool_flags & VVR_TOOL_LMCS ) );
+    if( vp->slices && ( SH.tool_flags & VVR_TOOL_LMCS ) && !!( SH.tool_flags & VVR_TOOL_LMCS_CSCALE ) != !!( vp->hdr.tool_flags & VVR_TOOL_LMCS_CSCALE ) )
+      THROW_FATAL( "chroma residual scaling is a picture header flag: a slice with LMCS has it when the picture does" );
+    slice->setExplicitScalingListUsed( ( SH.tool_flags & VVR_TOOL_SCALING_LIST ) && vp->scaling );
     slice->setIndependentSliceIdx( si );
     slice->resetSliceMap();
     if( !vp->ctu_slice ) slice->addCtusToSlice( 0, pps.pcv->widthInCtus, 0, pps.pcv->heightInCtus, pps.pcv->widthInCtus );
     else for( int a = 0; a < numCtuAll; a++ ) if( vp->ctu_slice[a] == si ) { const int cx = a % (int) pps.pcv->widthInCtus, cy = a / (int) pps.pcv->widthInCtus; slice->addCtusToSlice( cx, cx + 1, cy, cy + 1, pps.pcv->widthInCtus ); }
+    // reference picture lists: the description holds the union of the slices' lists and its CUs index that union, so every non-I slice is
+    // given the union (a decoder's slices hold their own lists; whoever flattens a picture renumbers the indices, integration/vvr_extract.h)
     for( int l = 0; l < 2; l++ )
     {
-      slice->setNumRefIdx( RefPicList( l ), H.slice_type == 2 ? 0 : H.num_ref[l] );
-      for( int i = 0; i < H.num_ref[l] && H.slice_type != 2; i++ )
+      slice->setNumRefIdx( RefPicList( l ), SH.slice_type == 2 ? 0 : H.num_ref[l] );
+      for( int i = 0; i < H.num_ref[l] && SH.slice_type != 2; i++ )
       {
         Picture* rp = getRefPic( H.ref_slot[l][i], H.ref_poc[l][i] );
         slice->m_apcRefPicList[l][i]     = rp;
@@ -463,25 +494,30 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       }
     }
     slice->resetWpScaling();
-    if( ( H.tool_flags & VVR_TOOL_WP ) && vp->wp && H.slice_type != 2 )
+    if( sliceWp )
     {   // pred_weight_table() as the parser leaves it (Slice::m_weightPredTable)
+      const vvr_wp_params& WP = vp->wp[vp->slices && vp->num_wp_sets > 1 ? SH.wp_set : 0];
       for( int l = 0; l < 2; l++ ) for( int i = 0; i < H.num_ref[l]; i++ )
       {
         WPScalingParam* wp = nullptr;
         slice->getWpScaling( RefPicList( l ), i, wp );
         for( int c = 0; c < 3; c++ )
         {
-          const vvr_wp_entry& e = vp->wp->e[l][i][c];
-          wp[c].bPresentFlag = e.present != 0; wp[c].uiLog2WeightDenom = vp->wp->log2_denom[c ? 1 : 0]; wp[c].iWeight = e.weight; wp[c].iOffset = e.offset;
+          const vvr_wp_entry& e = WP.e[l][i][c];
+          wp[c].bPresentFlag = e.present != 0; wp[c].uiLog2WeightDenom = WP.log2_denom[c ? 1 : 0]; wp[c].iWeight = e.weight; wp[c].iOffset = e.offset;
         }
       }
     }
     pic.stillReferenced = !!( H.tool_flags & VVR_TOOL_STILL_REF );
     if( useAlf )
     {
+      const int set = vp->slices && numAlfSets > 1 ? SH.alf_set : 0;
+      if( set >= numAlfSets ) THROW_FATAL( "slice names an ALF parameter set the picture does not have" );
+      const vvr_alf_params& A = vp->alf_params[set];
+      slice->setAlfApss( alfSetApss[set].data() );
       slice->setAlfEnabledFlag( COMPONENT_Y, true ); slice->setAlfEnabledFlag( COMPONENT_Cb, cf != CHROMA_400 ); slice->setAlfEnabledFlag( COMPONENT_Cr, cf != CHROMA_400 );
-      slice->setNumAlfAps( vp->alf_params->num_luma_aps );
-      AlfApsIdVec ids; for( int a = 0; a < vp->alf_params->num_luma_aps; a++ ) ids.push_back( a );
+      slice->setNumAlfAps( A.num_luma_aps );
+      AlfApsIdVec ids; for( int a = 0; a < A.num_luma_aps; a++ ) ids.push_back( a );
       slice->setAlfApsIdsLuma( ids );
       slice->setAlfApsIdChroma( 0 );
       const bool cc = !!( H.tool_flags & VVR_TOOL_CCALF );

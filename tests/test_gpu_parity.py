@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 TOOLS = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS
 
 
-def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=True, intra=False, bit_depth=10, chroma_format=1, **kw):
+def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=True, intra=False, bit_depth=10, chroma_format=1, post=None, **kw):
     """intra=False: POC 0 is an uploaded picture and all CUs are inter; intra=True: POC 0 is an I picture reconstructed by the
     back-end and the B pictures contain intra CUs (p_intra)."""
     import vvdec_amd
@@ -30,6 +30,9 @@ def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=Tru
         kw.setdefault("p_intra", 0.0)
     hashes = []
     descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, alloc=rec.host_array, **geo, **kw) for pl in plans]     # records in pinned memory of `rec`
+    if post:
+        for d in descs:
+            post(d)
     jobs = [rec.decompress_picture(d) for d in descs]          # everything in flight: the back-end orders the dependencies
     rec.sync()
     # verify in decode order; the CPU oracle consumes its own previous outputs as references.  A slot is overwritten
@@ -362,6 +365,26 @@ def test_slices_and_tiles(built, extra, kw):
     _run_stream(512, 384, 5, 4, 221, T, intra=True, log2_ctu=6, p_intra=0.3, p_cclm=0.3, p_ciip=0.1, p_coded_chroma=0.5, **kw)
     _run_stream(640, 256, 3, 2, 222, T, intra=True, log2_ctu=5, p_intra=0.2, p_affine=0.2, **kw)
     _run_stream(1920, 1080, 3, 2, 223, TOOLS_A | extra, intra=True, streams=3, **kw)
+
+
+@pytest.mark.parametrize("extra,kw", [
+    (abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST, dict(num_slices=3)),
+    (abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=4, p_ciip=0.2, p_affine=0.2, p_sbtmvp=0.1)),
+    (abi.TOOL_SCALING_LIST | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=4, tile_cols=3, tile_rows=2)),
+])
+def test_slice_headers(built, extra, kw):
+    """slices with headers of their own (vvr_picture::slices): dependent quantisation, LMCS, chroma residual scaling, scaling lists per slice
+    (k_itrans, k_intra, the MC kernels' forward mapping, k_lmcs), deblocking offsets (k_deblock), ALF tables (k_alf_*), prediction weights (MC)"""
+    T = TOOLS_A | extra
+    seen = []
+
+    def vary(d):
+        synth.vary_slices(d, 230 + d.hdr.poc)
+        seen.append(len(set(int(f) for f in d.slices["tool_flags"])))
+    _run_stream(512, 384, 5, 4, 231, T, intra=True, log2_ctu=6, p_intra=0.3, p_cclm=0.3, p_coded=0.8, p_coded_chroma=0.6, post=vary, **kw)
+    _run_stream(640, 256, 3, 2, 232, T, intra=True, log2_ctu=5, p_intra=0.2, p_coded=0.8, post=vary, **kw)
+    _run_stream(1920, 1080, 3, 2, 233, T, intra=True, streams=3, p_coded=0.7, post=vary, **kw)
+    assert max(seen) > 1
 
 
 @pytest.mark.parametrize("vb,extra,kw", [

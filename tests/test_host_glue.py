@@ -38,7 +38,10 @@ def build_stub():
     """(re)build the product's host code against the stand-in runtime when a source is newer -> path of the library"""
     deps = [SRC, API] + [os.path.join(os.path.dirname(API), f) for f in ("vvr_device.h", "vvr_host.h", "vvr_prepare.cpp", "vvr_output.inc")] + [os.path.join(os.path.dirname(HERE), "include", "vvr.h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I" + HIP_INC, "-D__HIP_PLATFORM_AMD__", "-w", SRC, "-o", LIB])
+        # (several test processes may get here at once - pytest -n: build under a private name, then rename into place)
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I" + HIP_INC, "-D__HIP_PLATFORM_AMD__", "-w", SRC, "-o", tmp])
+        os.replace(tmp, LIB)
     return LIB
 
 
@@ -441,6 +444,45 @@ def test_malformed_descriptions_are_rejected(stub):
     # a well-formed description still goes through afterwards
     hnd = ctx.prepare(mk(plans[0], tools=TOOLS | abi.TOOL_IBC, p_ibc=0.6))
     stub.vvr_free_prepared(ctx.ctx, hnd)
+    ctx.close()
+
+
+def test_slice_headers_in_the_host_glue(stub):
+    """slices with headers of their own: the chroma blocks' residual-scaling flag follows the slice of the CTU, the intra tables stay valid, and
+    headers that do not fit the picture are refused"""
+    W, H, l2 = 512, 384, 6
+    plans, nslots = stream.ra_plan(3, gop=2, seed_poc0_is_external=False)
+    ctx = Ctx(stub, W, H, nslots, log2_ctu=l2)
+    T = TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST | abi.TOOL_WP
+
+    def mk(pl):
+        d = synth.picture_for_plan(pl, W, H, seed=520, tool_flags=T, log2_ctu=l2, num_slices=3, p_intra=0.4, p_coded=0.9, p_coded_chroma=0.8, p_cclm=0.3)
+        return synth.vary_slices(d, 521 + pl.poc)
+    for pl in plans:
+        d = mk(pl)
+        hnd = ctx.prepare(d)
+        units, items = ctx.tables(hnd)
+        assert _check_tables(d, units, items) > 0
+        ch = items[((items["comp"] & 3) != 0) & (items["mode"] != 254)]                         # chroma blocks (not IBC): bit 8 = IT_F_CSCALE
+        ctus_x = (W + (1 << l2) - 1) >> l2
+        sl = d.ctu_slice[(ch["y"].astype(int) >> (l2 - 1)) * ctus_x + (ch["x"].astype(int) >> (l2 - 1))]
+        on = (d.slices["tool_flags"][sl] & abi.TOOL_LMCS_CSCALE) != 0
+        assert on.any() and (~on).any()
+        assert not (ch["flags"][~on] & 8).any(), "chroma residual scaling in a slice without it"
+        assert (ch["flags"][on] & 8).any()
+        stub.vvr_free_prepared(ctx.ctx, hnd)
+    d = mk(plans[0]); d.slices = d.slices[:2]
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "without a header")
+    d = mk(plans[0]); d.slices["alf_set"][1] = 2
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "table that is not there")
+    d = mk(plans[1]); d.slices["wp_set"][0] = 2
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "table that is not there")
+    d = mk(plans[0]); d.slices["tool_flags"][1] |= abi.TOOL_LMCS_CSCALE
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "LMCS chroma residual scaling without LMCS")
+    d = mk(plans[0]); d.ctu_slice = None
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "slice map")
+    d = mk(plans[0]); d.slices["slice_type"][0] = 3
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "slice type")
     ctx.close()
 
 

@@ -295,6 +295,47 @@ def test_oracle_equals_reference_slices_and_tiles(built, W, H, l2, idx, seed, ex
     assert any(not np.array_equal(a, b) for a, b in zip(other, final))
 
 
+SLICE_HEADER_CASES = [
+    # W, H, l2, idx, seed, extra tool flags, generator parameters
+    (512, 384, 6, 0, 281, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST, dict(num_slices=3, p_cclm=0.3, p_coded=0.8, p_coded_chroma=0.6)),
+    (512, 384, 6, 2, 282, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=4, p_intra=0.3, p_ciip=0.2, p_coded=0.8, p_coded_chroma=0.6, p_affine=0.2)),
+    (640, 256, 5, 3, 283, abi.TOOL_SCALING_LIST | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=4, tile_cols=3, tile_rows=2, p_intra=0.2, p_coded=0.8, p_sbtmvp=0.2)),
+    (512, 384, 6, 1, 284, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST, dict(num_slices=5, p_intra=0.2, p_coded=0.7, p_coded_chroma=0.6, p_geo=0.2)),
+]
+
+
+@pytest.mark.parametrize("W,H,l2,idx,seed,extra,kw", SLICE_HEADER_CASES)
+def test_oracle_equals_reference_slice_headers(built, W, H, l2, idx, seed, extra, kw):
+    """slices whose headers differ (vvr_slice_header): dependent quantisation, LMCS (+ chroma residual scaling), explicit scaling lists on or
+    off per slice, deblocking offsets, the APSs the ALF takes its filters from and the prediction weights - every stage takes the values of
+    the slice the CU / CTU lies in (ctuData.slice).  The reference runs with Slice objects that carry exactly these headers."""
+    d, refs = _case(W, H, l2, idx, seed, tools=ALL | extra, **kw)
+    synth.vary_slices(d, seed)
+    n = len(d.slices)
+    assert n == kw["num_slices"] and len(set(int(f) for f in d.slices["tool_flags"])) > 1
+    for fl in STAGES:
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+    # every field matters: the picture changes when the slices lose it
+    final = want
+
+    def changed(edit):
+        keep = d.slices.copy(), d.alf_sets, d.wp_sets
+        edit()
+        out = refdrv.oracle_reconstruct(d, refs, flags=0)
+        d.slices, d.alf_sets, d.wp_sets = keep
+        return any(not np.array_equal(a, b) for a, b in zip(out, final))
+
+    def all_like_first(name):
+        def f():
+            d.slices[name] = d.slices[name][0]
+        return f
+    for name in ("tool_flags", "deblock_beta_offset_div2", "deblock_tc_offset_div2", "alf_set") + (("wp_set",) if d.wp is not None else ()):
+        assert changed(all_like_first(name)), name
+
+
 VB_CASES = [
     # W, H, l2, idx, seed, virtual_boundaries (bits 0-1 vertical, 2-3 horizontal, 16: first on a CTU boundary), extra tool flags, generator parameters
     (512, 384, 6, 0, 271, 1 | (1 << 2), 0, dict(p_cclm=0.2)),

@@ -105,6 +105,8 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
   const vvr_wp_params*   wp;         // explicit weighted prediction table (NULL unless VVR_TOOL_WP on a P / B picture)
   const uint16_t*    ctuSlice;       // slice / tile index of every CTU (NULL: one slice / one tile): where SAO and ALF stop when the picture says so
   const uint16_t*    ctuTile;
+  const vvr_slice_header* slices;    // headers of the slices (indexed by ctuSlice), NULL: every slice takes hdr's values; alf_params / wp then are arrays
+  int                numAlfSets, numWpSets;
   const vvr_subpic*  subpics;        // sub-pictures (NULL: the picture is its only sub-picture) and the sub-picture of every CTU: MC of a CU in a sub-picture
   const uint16_t*    ctuSubpic;      // treated as a picture stays inside it; SAO / ALF of a CTU whose sub-picture says so do not look into other sub-pictures
   const uint8_t*     interAt;        // per 4x4 luma unit: 1 = covered by an inter CU (LMCS forward mapping of the prediction)

@@ -101,6 +101,37 @@ __device__ __forceinline__ int mc_item_index()
 // What motion compensation of a CU may read of a reference picture (luma samples, inclusive): the picture - or, for a CU in a sub-picture that is
 // treated as a picture, that sub-picture: the reference predicts such CUs from a copy of the sub-picture with its own replicated border
 // (Picture::getSubPicBuf, DecLibRecon::createSubPicRefBufs, DecLibRecon.cpp:388-421), which is the clamp to its rectangle here.
+// Slices with headers of their own (vvr_picture.slices, ABI 4): the header of the slice a luma position lies in; the tool switches that hold there
+// (the slice's value for the switches a slice header carries - VVR_SLICE_TOOL_MASK -, the picture's for the rest); the slice's ALF / weight tables.
+// Without slice headers everything is the picture's (one uniform branch).
+__device__ __forceinline__ const vvr_slice_header* slice_at( const PicDev& pic, int lx, int ly )
+{
+  if( !pic.slices ) return nullptr;
+  return &pic.slices[pic.ctuSlice[( ly >> pic.hdr.log2_ctu ) * pic.ctus_x + ( lx >> pic.hdr.log2_ctu )]];
+}
+__device__ __forceinline__ uint32_t flags_at( const PicDev& pic, int lx, int ly )
+{
+  const vvr_slice_header* s = slice_at( pic, lx, ly );
+  return s ? ( pic.hdr.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | ( s->tool_flags & VVR_SLICE_TOOL_MASK ) : pic.hdr.tool_flags;
+}
+__device__ __forceinline__ const vvr_wp_params* wp_at( const PicDev& pic, int lx, int ly )
+{
+  if( !pic.wp ) return nullptr;
+  const vvr_slice_header* s = slice_at( pic, lx, ly );
+  if( s && !( s->tool_flags & VVR_TOOL_WP ) ) return nullptr;
+  return &pic.wp[s && pic.numWpSets > 1 ? s->wp_set : 0];
+}
+__device__ __forceinline__ const vvr_alf_params* alf_set_at( const PicDev& pic, int lx, int ly )
+{
+  const vvr_slice_header* s = slice_at( pic, lx, ly );
+  return &pic.alf_params[s && pic.numAlfSets > 1 ? s->alf_set : 0];
+}
+// LMCS forward map of the slice a block lies in (nullptr: the slice does not use LMCS)
+__device__ __forceinline__ const int16_t* lmcs_fwd_at( const PicDev& pic, int lx, int ly )
+{
+  if( !pic.lmcs ) return nullptr;
+  return ( flags_at( pic, lx, ly ) & VVR_TOOL_LMCS ) ? pic.lmcs->fwd_lut : nullptr;
+}
 struct McBounds { int x0, y0, x1, y1; };
 __device__ __forceinline__ McBounds mc_bounds( const PicDev& pic, int cuX, int cuY )
 {
@@ -478,10 +509,10 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
 {
   __shared__ Mc2Shared m;
   __shared__ typename std::conditional<BDOF, BdofShared, int>::type bs;
-  const int16_t* __restrict__ fwdLut = pic.lmcs ? pic.lmcs->fwd_lut : nullptr;      // LMCS: luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const int item = mc_item_index();
   if( item >= numItems ) return;
   const McItem it = items[item];
+  const int16_t* __restrict__ fwdLut = lmcs_fwd_at( pic, it.x, it.y );      // LMCS (where the tile's slice uses it): luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const int bd = pic.hdr.bit_depth;
   const int tid = threadIdx.x;
   // the tile record is self-contained (motion of the CU, or of the 8x8 sub-block for SbTMVP, with the identical-motion shortcut already
@@ -530,9 +561,10 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   __syncthreads();
   mc2_stage1<NT>( m, nl, ncomp, it.w, it.h, headroom, tid );
   __syncthreads();
-  const bool wpOn = !BDOF && pic.wp && !geo && it.bcw == 2;          // xPredInterBi (:707,735-742)
+  const vvr_wp_params* __restrict__ wpT = wp_at( pic, it.x, it.y );      // the weight table of the tile's slice
+  const bool wpOn = !BDOF && wpT && !geo && it.bcw == 2;          // xPredInterBi (:707,735-742)
   mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, uni, cu, geo, it.bcw, bd, headroom, reco, it.x, it.y, it.w, it.h, tid, fwdLut,
-                  wpOn ? pic.wp : nullptr, l0, mRef[0], mRef[1] );
+                  wpOn ? wpT : nullptr, l0, mRef[0], mRef[1] );
   if constexpr( BDOF )
   {
     __syncthreads();
@@ -577,10 +609,10 @@ template<int NT>
 __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems, int32_t* __restrict__ dmvrOut )
 {
   __shared__ DmvrShared sh;
-  const int16_t* __restrict__ fwdLut = pic.lmcs ? pic.lmcs->fwd_lut : nullptr;      // LMCS: luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const int item = mc_item_index();
   if( item >= numItems ) return;
   const McItem it = items[item];
+  const int16_t* __restrict__ fwdLut = lmcs_fwd_at( pic, it.x, it.y );      // LMCS (where the tile's slice uses it): luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const vvr_cu& cu = pic.cu[it.cu];
   const int bd = pic.hdr.bit_depth;
   const int tid = threadIdx.x;
@@ -849,10 +881,10 @@ template<int NT>
 __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
 {
   __shared__ AffShared sh;
-  const int16_t* __restrict__ fwdLut = pic.lmcs ? pic.lmcs->fwd_lut : nullptr;      // LMCS: luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const int item = mc_item_index();
   if( item >= numItems ) return;
   const McItem it = items[item];
+  const int16_t* __restrict__ fwdLut = lmcs_fwd_at( pic, it.x, it.y );      // LMCS (where the tile's slice uses it): luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const vvr_cu& cu = pic.cu[it.cu];
   const int bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu;
   const int tid = threadIdx.x;
@@ -866,7 +898,8 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       && cu.mv[0][0][0] == cu.mv[1][0][0] && cu.mv[0][0][1] == cu.mv[1][0][1] && cu.mv[0][1][0] == cu.mv[1][1][0] && cu.mv[0][1][1] == cu.mv[1][1][1]
       && ( !( cu.flags & VVR_CU_AFFINE_6P ) || ( cu.mv[0][2][0] == cu.mv[1][2][0] && cu.mv[0][2][1] == cu.mv[1][2][1] ) ) && !pic.wp /* :408 */ ) biPred = false;
   const int l0 = cu.ref_idx[0] >= 0 ? 0 : 1, nl = biPred ? 2 : 1;
-  const bool wpOn = pic.wp && cu.bcw_idx == 2;       // explicit weighted prediction: also a single list stays at 14 bit until the final stage
+  const vvr_wp_params* __restrict__ wpT = wp_at( pic, cu.x, cu.y );
+  const bool wpOn = wpT && cu.bcw_idx == 2;       // explicit weighted prediction: also a single list stays at 14 bit until the final stage
   const bool hi = biPred || wpOn;
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   const McBounds AB = mc_bounds( pic, cu.x, cu.y );
@@ -1051,7 +1084,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
         if( biPred ) p1 = aff_sample( sh.winC[1][c - 1][sb], AF_WC, sh.tmpC[1][c - 1][sb], sh.segC[1][sb], c, true, bd, px, py );
       }
       int out = p0;
-      if( wpOn ) out = biPred ? wp_bi( pic.wp, cu.ref_idx[0], cu.ref_idx[1], c, p0, p1, bd, headroom ) : wp_uni( pic.wp, l0, cu.ref_idx[l0], c, p0, bd, headroom );
+      if( wpOn ) out = biPred ? wp_bi( wpT, cu.ref_idx[0], cu.ref_idx[1], c, p0, p1, bd, headroom ) : wp_uni( wpT, l0, cu.ref_idx[l0], c, p0, bd, headroom );
       else if( biPred )
       {
         if( cu.bcw_idx != 2 )
@@ -1226,7 +1259,8 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
   __syncthreads();
   // ---- dequantisation
   {
-    const bool depQuant = ( pic.hdr.tool_flags & VVR_TOOL_DEP_QUANT ) && !isTS;
+    const uint32_t sliceFlags = flags_at( pic, tu.x, tu.y );      // dependent quantisation and the scaling lists are switches of the block's slice (Quant.cpp:306,336)
+    const bool depQuant = ( sliceFlags & VVR_TOOL_DEP_QUANT ) && !isTS;
     int qp = tu.qp[comp];
     if( isTS ) qp = max( qp, (int) pic.hdr.min_qp_ts );
     const int per = depQuant ? ( qp + 1 ) / 6 : qp / 6;
@@ -1235,7 +1269,7 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
     const int trShift = 15 - bd - ( ( lw + lh ) >> 1 ) - ( needSqrt ? 1 : 0 );
     // explicit scaling list (getUseScalingList, Quant.h:103): not for transform skip, optionally not for LFNST blocks
     const bool lfnstApplied = cu.lfnst_idx > 0 && ( cu.tree != VVR_TREE_JOINT || comp == 0 );
-    const bool useSL = pic.scaling && !isTS && !( lfnstApplied && ( pic.hdr.tool_flags & VVR_TOOL_SCALING_LIST_NO_LFNST ) );
+    const bool useSL = pic.scaling && ( sliceFlags & VVR_TOOL_SCALING_LIST ) && !isTS && !( lfnstApplied && ( pic.hdr.tool_flags & VVR_TOOL_SCALING_LIST_NO_LFNST ) );
     const int listType = ( cu.pred_mode == VVR_PRED_INTRA ? 0 : 3 ) + comp;
     const int rightShift = 6 + ( depQuant ? 1 : 0 ) - ( ( isTS ? 0 : trShift ) + per ) + ( useSL ? 4 : 0 );
     const int scaleQP = d_inv_quant_scales[needSqrt ? 1 : 0][rem];
@@ -1591,8 +1625,10 @@ __device__ void deblock_luma_segment( const PicDev& pic, const DevPlanes& r, int
   const int lenP = ( l.side_max_filt_length >> 4 ) & 7, lenQ = l.side_max_filt_length & 7;
   bool pLarge = lenP > 3, qLarge = lenQ > 3;
   if( dir == 1 && ( y & ( ( 1 << H.log2_ctu ) - 1 ) ) == 0 ) pLarge = false;
-  const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * H.deblock_tc_offset_div2[0] );
-  const int idxB  = clip3( 0, 63, qp + 2 * H.deblock_beta_offset_div2[0] );
+  // the offsets of the slice the deblocked CTU belongs to - the CTU that holds the segment, its Q side (LoopFilter.cpp:421,1473)
+  const vvr_slice_header* sl = slice_at( pic, x, y );
+  const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * ( sl ? sl->deblock_tc_offset_div2[0] : H.deblock_tc_offset_div2[0] ) );
+  const int idxB  = clip3( 0, 63, qp + 2 * ( sl ? sl->deblock_beta_offset_div2[0] : H.deblock_beta_offset_div2[0] ) );
   const int tc = tc_value( idxTC, bd ), beta = d_db_beta_table[idxB] << ( bd - 8 );
   const int sideThr = ( beta + ( beta >> 1 ) ) >> 3, thrCut = tc * 10;
   const pel_t* s0 = src; const pel_t* s3 = src + 3 * step;
@@ -1659,17 +1695,18 @@ __global__ __launch_bounds__( 256 ) void k_deblock( PicDev pic, DevPlanes r, int
   const int o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
   const bool large = ( l.flags >> 5 ) & 1;
   const bool ctb = dir == 1 && ( cy & ( ( ( 1 << H.log2_ctu ) - 1 ) >> 1 ) ) == 0;
+  const vvr_slice_header* sl = slice_at( pic, x4 * 4, y4 * 4 );      // offsets of the deblocked CTU's slice (LoopFilter.cpp:1637-1638)
   for( int c = 0; c < 2; c++ )
   {
     if( !( bS[c] == 2 || ( large && bS[c] == 1 ) ) ) continue;
     pel_t* src = r.p[c + 1] + (size_t) cy * stride + cx;
     const int qp = l.qp[c + 1];
-    const int idxTC = clip3( 0, 65, qp + 2 * ( bS[c] - 1 ) + 2 * H.deblock_tc_offset_div2[c + 1] );
+    const int idxTC = clip3( 0, 65, qp + 2 * ( bS[c] - 1 ) + 2 * ( sl ? sl->deblock_tc_offset_div2[c + 1] : H.deblock_tc_offset_div2[c + 1] ) );
     const int tc = tc_value( idxTC, bd );
     bool sw = false;
     if( large )
     {
-      const int idxB = clip3( 0, 63, qp + 2 * H.deblock_beta_offset_div2[c + 1] );
+      const int idxB = clip3( 0, 63, qp + 2 * ( sl ? sl->deblock_beta_offset_div2[c + 1] : H.deblock_beta_offset_div2[c + 1] ) );
       const int beta = d_db_beta_table[idxB] * ( 1 << ( bd - 8 ) );
       const int dp0 = ctb ? calc_dp_ctb( src, o ) : calc_dp( src, o ), dq0 = calc_dq( src, o );
       const int dp3 = ctb ? calc_dp_ctb( src + step, o ) : calc_dp( src + step, o ), dq3 = calc_dq( src + step, o );
@@ -1939,7 +1976,7 @@ __global__ __launch_bounds__( 256 ) void k_alf_luma( PicDev pic, DevPlanes src, 
   }
   if( part == 0 )
   {
-    const vvr_alf_params* __restrict__ A = pic.alf_params;
+    const vvr_alf_params* __restrict__ A = alf_set_at( pic, tx0, ty0 );      // the filters of the APSs the CTU's slice refers to (AdaptiveLoopFilter.cpp:515)
     const int clipDef = 1 << bd;      // m_alfClippVls[bd-8][0] = 256 << (bd - 8)
     for( int i = tid; i < 25 * 12; i += 256 )
     {
@@ -2073,7 +2110,7 @@ __global__ __launch_bounds__( 256 ) void k_alf_chroma( PicDev pic, DevPlanes src
 #define C( xx, yy ) fetch( S, st, W, H, kc, ( xx ), ( yy ) )
   const int cur = S[(size_t) y * st + x];
   int v = cur;
-  const vvr_alf_params* __restrict__ A = pic.alf_params;
+  const vvr_alf_params* __restrict__ A = alf_set_at( pic, x << 1, y << 1 );
   if( f.enable[c] )
   {
     const int16_t* cf = A->chroma_coeff[f.alt[c - 1]]; const int16_t* cp = A->chroma_clip[f.alt[c - 1]];
@@ -2174,7 +2211,7 @@ __global__ __launch_bounds__( 256 ) void k_alf_chroma_tile( PicDev pic, DevPlane
   const int ly = tid >> 3, lx4 = ( tid & 7 ) * 4;
   const int y = ty0 + ly;
   if( y >= H || tx0 + lx4 >= W ) return;
-  const vvr_alf_params* __restrict__ A = pic.alf_params;
+  const vvr_alf_params* __restrict__ A = alf_set_at( pic, tx0 << 1, ty0 << 1 );      // (a tile lies inside one CTU)
   // rows of the 5x5 diamond at the ALF line-buffer boundary of the CTU row (chroma: 2 rows above the CTU's last 2)
   const int vbPos = ctuC - 2, yVb = y & ( ctuC - 1 );
   int r1 = ly + 1, r2 = ly - 1, r3 = ly + 2, r4 = ly - 2;
@@ -2280,6 +2317,7 @@ __global__ __launch_bounds__( 256 ) void k_lmcs( PicDev pic, DevPlanes reco, int
   __syncthreads();
   const int y = blockIdx.y, x = ( blockIdx.x * 256 + threadIdx.x ) * 8;
   if( x >= reco.w[0] ) return;
+  if( pic.slices && !( flags_at( pic, x, y ) & VVR_TOOL_LMCS ) ) return;       // (8 samples lie inside one CTU) the CTU's slice does not use LMCS (Reshape.cpp:385)
   pel_t* __restrict__ row = reco.p[0] + (size_t) y * reco.stride[0];
   const bool lo = true, hi = true;                 // (round 3: only the inverse pass is left; the forward map is applied by the motion-compensation kernels)
   uint4 v = *reinterpret_cast<const uint4*>( row + x );       // rows are padded to a multiple of 64 samples

@@ -74,7 +74,7 @@ struct PrepScratch
   // ---- layout of the H2D image
   std::vector<Part> parts;
   size_t total = 0, numDirect = 0;          // parts [0, numDirect) are copied from the caller's pinned arrays
-  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iUnits;
+  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iSlices, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iUnits;
 
   void begin( const vvr_picture* pic )
   {
@@ -83,6 +83,15 @@ struct PrepScratch
     if( const char* e = getenv( "VVR_INTRA_CHUNK" ) ) intraChunk = (size_t) atoi( e );      // developer build: sweep of the piece length
 #endif
     ncomp = h.chroma_format ? 3 : 1;
+    // slices with headers of their own: the switches a slice header carries hold per slice (vvr_slice_header.tool_flags); the working copy of the
+    // picture header gets their UNION - "does any slice use the tool" is what decides which tables travel and which passes run, the kernels and
+    // the per-block decisions below look the slice up
+    if( p->slices && p->num_slices )
+    {
+      uint32_t any = 0;
+      for( uint32_t i = 0; i < p->num_slices; i++ ) any |= p->slices[i].tool_flags & VVR_SLICE_TOOL_MASK;
+      h.tool_flags = ( h.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | any;
+    }
     wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
     w4 = ( h.width + 3 ) >> 2; h4 = ( h.height + 3 ) >> 2; ctu = 1 << h.log2_ctu;
     ctusX = ( h.width + ctu - 1 ) / ctu; ctusY = ( h.height + ctu - 1 ) / ctu; numCtu = ctusX * ctusY;
@@ -108,6 +117,9 @@ struct PrepScratch
     return order[(size_t) chn * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
   }
 
+  // the switches of the slice CTU `c` lies in
+  uint32_t flagsOfCtu( uint32_t c ) const { return ( p->slices && p->ctu_slice ) ? ( h.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | ( p->slices[p->ctu_slice[c]].tool_flags & VVR_SLICE_TOOL_MASK ) : h.tool_flags; }
+  bool cscaleCtu( uint32_t c ) const { const uint32_t f = flagsOfCtu( c ); return cscale && ( f & VVR_TOOL_LMCS ) && ( f & VVR_TOOL_LMCS_CSCALE ); }
   bool sameSliceAndTile( uint32_t a, uint32_t b ) const { return ( !p->ctu_slice || p->ctu_slice[a] == p->ctu_slice[b] ) && ( !p->ctu_tile || p->ctu_tile[a] == p->ctu_tile[b] ); }
   uint32_t ctuAt( int lx, int ly ) const { return (uint32_t) ( ( ly >> h.log2_ctu ) * ctusX + ( lx >> h.log2_ctu ) ); }
   int beginMaps();
@@ -158,9 +170,10 @@ void vvr_scratch_destroy( PrepScratch* s ) { delete s; }
 #define FAIL( code, msg ) do { err = ( msg ); return ( code ); } while( 0 )
 
 // the header, the tables and the presence of the arrays: a few hundred bytes, checked where the picture is submitted
+static bool wpOnAny( const vvr_pic_header& h ) { return ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2; }
 int vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::string& err )
 {
-  const vvr_pic_header& h = p->hdr;
+  vvr_pic_header h = p->hdr;           // (working copy: with slice headers the slice-level switches become their union)
   if( h.abi_version != VVR_ABI_VERSION ) FAIL( VVR_ERR_PARAMETER, "abi_version mismatch" );
   if( h.width != cfg.max_width || h.height != cfg.max_height || h.chroma_format != cfg.chroma_format || h.bit_depth != cfg.bit_depth || h.log2_ctu != cfg.log2_ctu )
     FAIL( VVR_ERR_PARAMETER, "picture geometry differs from the context configuration" );
@@ -197,11 +210,31 @@ int vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::
     for( int i = 0; i < n; i++ )
       if( ( pos[i] & 7 ) || pos[i] == 0 || pos[i] >= lim || ( i && pos[i] <= pos[i - 1] ) ) FAIL( VVR_ERR_PARAMETER, "virtual boundary positions: multiples of 8 inside the picture, ascending" );
   }
+  if( p->slices )
+  {
+    // slices with headers of their own (ABI 4)
+    const int numCtuV = ( ( h.width + ( 1 << h.log2_ctu ) - 1 ) >> h.log2_ctu ) * ( ( h.height + ( 1 << h.log2_ctu ) - 1 ) >> h.log2_ctu );
+    if( !p->ctu_slice || !p->num_slices || p->num_slices > 256 ) FAIL( VVR_ERR_PARAMETER, "slice headers: 1..256 of them, with the slice map (ctu_slice)" );
+    for( int a = 0; a < numCtuV; a++ ) if( p->ctu_slice[a] >= p->num_slices ) FAIL( VVR_ERR_PARAMETER, "ctu_slice names a slice without a header" );
+    if( p->num_alf_sets > 64 || p->num_wp_sets > 64 ) FAIL( VVR_ERR_PARAMETER, "at most 64 ALF / weighted-prediction tables" );
+    uint32_t any = 0;
+    for( uint32_t i = 0; i < p->num_slices; i++ )
+    {
+      const vvr_slice_header& sh = p->slices[i];
+      any |= sh.tool_flags & VVR_SLICE_TOOL_MASK;
+      if( sh.slice_type > 2 ) FAIL( VVR_ERR_PARAMETER, "unknown slice type" );
+      if( ( sh.tool_flags & VVR_TOOL_LMCS_CSCALE ) && !( sh.tool_flags & VVR_TOOL_LMCS ) ) FAIL( VVR_ERR_PARAMETER, "LMCS chroma residual scaling without LMCS" );
+      if( sh.alf_set >= std::max<uint32_t>( 1, p->num_alf_sets ) || sh.wp_set >= std::max<uint32_t>( 1, p->num_wp_sets ) ) FAIL( VVR_ERR_PARAMETER, "slice header names an ALF / weight table that is not there" );
+    }
+    h.tool_flags = ( h.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | any;       // (the checks below: is the table there when ANY slice uses the tool)
+  }
+  for( uint32_t k = 0; wpOnAny( h ) && p->wp && k < std::max<uint32_t>( 1, p->num_wp_sets ); k++ )
+    if( p->wp[k].log2_denom[0] > 7 || p->wp[k].log2_denom[1] > 7 ) FAIL( VVR_ERR_PARAMETER, "weighted prediction: log2 denominator out of range" );
   if( ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && !( h.tool_flags & VVR_TOOL_LMCS ) ) FAIL( VVR_ERR_PARAMETER, "LMCS chroma residual scaling without LMCS" );
   if( ( h.tool_flags & VVR_TOOL_LMCS ) && !p->lmcs ) FAIL( VVR_ERR_PARAMETER, "LMCS enabled without tables" );
   const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
   if( wpOn && !p->wp ) FAIL( VVR_ERR_PARAMETER, "weighted prediction enabled without the weight table" );
-  if( wpOn && ( p->wp->log2_denom[0] > 7 || p->wp->log2_denom[1] > 7 ) ) FAIL( VVR_ERR_PARAMETER, "weighted prediction: log2 denominator out of range" );
+
   if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && !p->scaling ) FAIL( VVR_ERR_PARAMETER, "explicit scaling lists enabled without the lists" );
   if( h.tool_flags & VVR_TOOL_SCALING_LIST )
     for( int id = 0; id < 28; id++ ) for( int k = 0; k < ( id < 2 ? 4 : id < 8 ? 16 : 64 ); k++ ) if( !p->scaling->coef[id][k] ) FAIL( VVR_ERR_PARAMETER, "scaling list entry 0" );
@@ -222,7 +255,8 @@ int vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::
 int vvr_host_validate_records( const vvr_config& cfg, const vvr_picture* p, std::string& err )
 {
   (void) cfg;
-  const vvr_pic_header& h = p->hdr;
+  vvr_pic_header h = p->hdr;
+  if( p->slices ) { uint32_t any = 0; for( uint32_t i = 0; i < p->num_slices; i++ ) any |= p->slices[i].tool_flags & VVR_SLICE_TOOL_MASK; h.tool_flags = ( h.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | any; }
   const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
   const int ncomp = h.chroma_format ? 3 : 1;
   uint64_t areaLuma = 0, areaChroma = 0;
@@ -294,12 +328,15 @@ int vvr_host_validate_records( const vvr_config& cfg, const vvr_picture* p, std:
       if( cu.bcw_idx > 4 ) FAIL( VVR_ERR_PARAMETER, "BCW index out of range" );
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) FAIL( VVR_ERR_PARAMETER, "ref_idx out of range" );
       if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo && !isSbt ) FAIL( VVR_ERR_PARAMETER, "inter CU without reference" );
-      if( wpOn && cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 )
+      // (the switch and the table are those of the CU's slice)
+      const vvr_slice_header* sh = p->slices ? &p->slices[p->ctu_slice[( cu.y >> h.log2_ctu ) * ( ( h.width + ( 1 << h.log2_ctu ) - 1 ) >> h.log2_ctu ) + ( cu.x >> h.log2_ctu )]] : nullptr;
+      if( ( sh ? ( sh->tool_flags & VVR_TOOL_WP ) != 0 : wpOn ) && cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 )
       {
         // weighted prediction: BDOF / DMVR only between references with default weights (InterPrediction.cpp:1420, UnitTools.cpp:1297-1302);
         // no identical-motion shortcut (:408)
+        const vvr_wp_params& wpT = p->wp[sh && p->num_wp_sets > 1 ? sh->wp_set : 0];
         bool present = false;
-        for( int l = 0; l < 2; l++ ) for( int k = 0; k < 3; k++ ) present |= p->wp->e[l][cu.ref_idx[l]][k].present != 0;
+        for( int l = 0; l < 2; l++ ) for( int k = 0; k < 3; k++ ) present |= wpT.e[l][cu.ref_idx[l]][k].present != 0;
         if( present && ( isDmvr || cu.mc_mode == VVR_MC_BDOF ) ) FAIL( VVR_ERR_PARAMETER, "mc_mode BDOF / DMVR between references with explicit prediction weights" );
         if( cu.mc_mode == VVR_MC_UNI ) FAIL( VVR_ERR_PARAMETER, "mc_mode UNI on a bi-predicted CU of a picture with weighted prediction" );
       }
@@ -498,7 +535,7 @@ int PrepScratch::buildWorkLists( std::string& err )
     // LMCS chroma residual scaling of an inter block: its factor reads reconstructed luma that the intra stage may still have to
     // produce, and intra blocks next to it read its reconstructed chroma, so the residual add of such a block is an item of the
     // intra stage too (IT_MODE_RESI_ADD: no prediction, scaled residual onto the inter prediction; finishLMCSAndReco, DecCu.cpp:483)
-    const bool isCsInterCu = cscale && cu.pred_mode == VVR_PRED_INTER && ( !isCiipCu || cu.w == 4 ) && ( cu.flags & VVR_CU_ROOT_CBF );
+    const bool isCsInterCu = cscaleCtu( ctuOfCu ) && cu.pred_mode == VVR_PRED_INTER && ( !isCiipCu || cu.w == 4 ) && ( cu.flags & VVR_CU_ROOT_CBF );
     // intra block copy: the block is a copy of reconstructed samples of this picture that the intra stage may still have to produce, so it
     // is an item of the intra stage as well (IT_MODE_IBC; the reference does it in its intra task too, DecCu.cpp:145)
     const bool isIbcCu = cu.pred_mode == VVR_PRED_IBC;
@@ -512,7 +549,7 @@ int PrepScratch::buildWorkLists( std::string& err )
           if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
           // the 2-wide chroma blocks of a 4-wide CIIP CU are not blended (predBlendIntraCiip, IntraPrediction.cpp:891): plain inter blocks
           const bool isCiip = isCiipCu && !( comp && cu.w == 4 );
-          const bool isCsInter = cscale && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
+          const bool isCsInter = cscaleCtu( ctuOfCu ) && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
           if( cu.pred_mode != VVR_PRED_INTRA && !isCiip && !isCsInter && !isIbcCu ) continue;
           if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
           const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
@@ -560,7 +597,7 @@ int PrepScratch::buildWorkLists( std::string& err )
           if( !noRef && unitAvail( chn, rx0, ry0 - 1, rcur ) ) { int n = rw / unit; for( int k = 0; k < totalAbove - rw / unit; k++ ) { if( !unitAvail( chn, rx0 + rw + k * unit, ry0 - 1, rcur ) ) break; n++; } it.nA = (uint8_t) n; }
           if( !noRef && unitAvail( chn, rx0 - 1, ry0, rcur ) ) { int n = rh / unit; for( int k = 0; k < totalLeft - rh / unit; k++ ) { if( !unitAvail( chn, rx0 - 1, ry0 + rh + k * unit, rcur ) ) break; n++; } it.nL = (uint8_t) n; }
           int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0; bool isCclm = false;
-          const bool csItem = cscale && comp && hasResi && w * hh > 4;             // DecCu.cpp:383-388 / :500-505
+          const bool csItem = cscaleCtu( ctuOfCu ) && comp && hasResi && w * hh > 4;             // DecCu.cpp:383-388 / :500-505
           if( csItem ) it.flags |= IT_F_CSCALE;
           if( comp && !isCiip && !isCsInter && !isIbcCu && cu.intra_dir[1] >= 67 )
           {
@@ -725,7 +762,7 @@ int PrepScratch::buildWorkLists( std::string& err )
             const vvr_motion& m = p->motion[(size_t) ( it.y >> 2 ) * w4 + ( it.x >> 2 )];
             for( int l = 0; l < 2; l++ ) { it.ref[l] = m.ref_idx[l]; it.mv[l][0] = m.mv[l][0]; it.mv[l][1] = m.mv[l][1]; }
             const bool two = it.ref[0] >= 0 && it.ref[1] >= 0;
-            uni = !two || ( h.ref_poc[0][it.ref[0]] == h.ref_poc[1][it.ref[1]] && it.mv[0][0] == it.mv[1][0] && it.mv[0][1] == it.mv[1][1] && !wpOn );
+            uni = !two || ( h.ref_poc[0][it.ref[0]] == h.ref_poc[1][it.ref[1]] && it.mv[0][0] == it.mv[1][0] && it.mv[0][1] == it.mv[1][1] && !( wpOn && ( flagsOfCtu( ctuAt( it.x, it.y ) ) & VVR_TOOL_WP ) ) );
             it.clipX = it.x; it.clipY = it.y;
           }
           it.bcw = cu.bcw_idx;
@@ -760,7 +797,7 @@ int PrepScratch::buildWorkLists( std::string& err )
         const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
         // LMCS chroma residual scaling of an inter block: the factor needs the reconstructed luma around the VPDU, which the intra stage
         // may still have to produce, so the block's residual is stored and added (scaled) by a residual-add item of the intra stage
-        if( cscale && it.comp && it.mode == TB_ADD && bw * bh > 4 ) it.mode = TB_STORE;      // added (scaled) by the intra stage, see isCsInter above
+        if( cscaleCtu( ctuOfCu ) && it.comp && it.mode == TB_ADD && bw * bh > 4 ) it.mode = TB_STORE;      // added (scaled) by the intra stage, see isCsInter above
         tb[cls].push_back( it );        // ADD (inter: onto the prediction) and STORE (intra / CIIP: into the residual planes) items share a launch
         const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];
         const double ncoef = bdp ? (double) bw * bh : (double) ( tu.max_scan_x[it.comp] + 1 ) * ( tu.max_scan_y[it.comp] + 1 );
@@ -1172,7 +1209,8 @@ void PrepScratch::layout( PinnedRanges* pinned )
   iAffMv = add( affMv.data(), sizeof( vvr_motion ) * affMv.size() );
   iSao = p->sao ? add( p->sao, sizeof( vvr_sao_ctu ) * numCtu ) : -1;
   iAlf = p->alf ? add( p->alf, sizeof( vvr_alf_ctu ) * numCtu ) : -1;
-  iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) ) : -1;
+  iAlfP = p->alf_params ? add( p->alf_params, sizeof( vvr_alf_params ) * std::max<uint32_t>( 1, p->num_alf_sets ) ) : -1;
+  iSlices = ( p->slices && p->num_slices ) ? add( p->slices, sizeof( vvr_slice_header ) * p->num_slices ) : -1;
   // (LMCS: the forward mapping of inter predictions happens where the motion-compensation kernels store them: no per-cell map of inter CUs any more)
   iLmcs = lmcs ? add( p->lmcs, sizeof( vvr_lmcs_params ) ) : -1;
   iSl = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? add( p->scaling, sizeof( vvr_scaling_list ) ) : -1;
@@ -1190,7 +1228,7 @@ void PrepScratch::layout( PinnedRanges* pinned )
     iCtuSubpic = add( ctuSubpicV.data(), sizeof( uint16_t ) * ctuSubpicV.size() );
   }
   iCtuTile = p->ctu_tile ? add( p->ctu_tile, sizeof( uint16_t ) * numCtu ) : -1;
-  iWp = wpOn ? add( p->wp, sizeof( vvr_wp_params ) ) : -1;
+  iWp = wpOn ? add( p->wp, sizeof( vvr_wp_params ) * std::max<uint32_t>( 1, p->num_wp_sets ) ) : -1;
   iInterAt = -1;
   iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
   iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
@@ -1275,10 +1313,10 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   d.sao = (const vvr_sao_ctu*) at( S.iSao ); d.alf = (const vvr_alf_ctu*) at( S.iAlf ); d.alf_params = (const vvr_alf_params*) at( S.iAlfP );
   d.lmcs = (const vvr_lmcs_params*) at( S.iLmcs ); d.scaling = (const vvr_scaling_list*) at( S.iSl ); d.wp = (const vvr_wp_params*) at( S.iWp );
   d.ctuSlice = (const uint16_t*) at( S.iCtuSlice ); d.ctuTile = (const uint16_t*) at( S.iCtuTile );
+  d.slices = (const vvr_slice_header*) at( S.iSlices ); d.numAlfSets = (int) std::max<uint32_t>( 1, p->num_alf_sets ); d.numWpSets = (int) std::max<uint32_t>( 1, p->num_wp_sets );
   d.subpics = (const vvr_subpic*) at( S.iSubpics ); d.ctuSubpic = (const uint16_t*) at( S.iCtuSubpic );
   d.interAt = (const uint8_t*) at( S.iInterAt );
   d.csVpdu = (const uint32_t*) at( S.iCsVpdu ); d.vpdusX = S.vpdusX; d.vpduLog2 = S.vpduLog2;
-  (void) p;
   q.mcItems = (McItem*) at( S.iMc ); q.numMc = (int) S.mc.size();
   q.bdofItems = (McItem*) at( S.iMcB ); q.numBdofItems = (int) S.mcBdof.size();
   q.dmvrItems = (McItem*) at( S.iMcD ); q.numDmvrItems = (int) S.mcDmvr.size();

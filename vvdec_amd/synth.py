@@ -16,7 +16,8 @@ _LIB = os.path.join(_ROOT, "tools", "libvvrsynth.so")
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "vvr.h")       # (the generator writes vvr.h records and the ABI version)
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(_SRC), os.path.getmtime(hdr)):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-Wall", _SRC, "-o", _LIB])
     return _LIB
 
@@ -132,6 +133,54 @@ def generate(p, alloc=None):
     d.num_dmvr = b.num_dmvr
     if subpics is not None and b.num_subpics:
         d.subpics = subpics[:b.num_subpics].copy()
+    return d
+
+
+def vary_slices(d, seed, alf_sets=2, wp_sets=2):
+    """Give the slices of a generated multi-slice description headers of their own (vvr_slice_header): each slice draws whether it uses dependent
+    quantisation, LMCS, the explicit scaling lists (of the tools the picture has), its deblocking offsets, and which ALF / weight tables it
+    refers to.  The extra tables are rearrangements of the generated one (classes, alternatives and filters rolled; weights of the entries that
+    are `present` changed) so every value stays in the range the syntax allows and the CUs' mc_mode stays valid."""
+    assert d.ctu_slice is not None, "a description with more than one slice"
+    rng = np.random.default_rng(seed)
+    n = int(d.ctu_slice.max()) + 1
+    f = int(d.hdr.tool_flags)
+    sl = np.zeros(n, np.dtype(abi.SliceHeader))
+    for i in range(n):
+        t = f & abi.SLICE_TOOL_MASK
+        for bit in (abi.TOOL_DEP_QUANT, abi.TOOL_LMCS, abi.TOOL_SCALING_LIST):
+            have = bool(f & bit) or bit == abi.TOOL_DEP_QUANT
+            on = have and (i == 0 or (i > 1 and rng.random() < 0.5))      # slice 0: everything the picture has, slice 1: nothing
+            t = (t | bit) if on else (t & ~bit)
+        if not (t & abi.TOOL_LMCS):
+            t &= ~abi.TOOL_LMCS_CSCALE
+        sl["tool_flags"][i] = t
+        sl["deblock_beta_offset_div2"][i] = rng.integers(-6, 7, 3)
+        sl["deblock_tc_offset_div2"][i] = rng.integers(-6, 7, 3)
+        sl["slice_type"][i] = d.hdr.slice_type
+        sl["alf_set"][i] = i % alf_sets if d.alf_params is not None else 0
+        sl["wp_set"][i] = i % wp_sets if d.wp is not None else 0
+    d.slices = sl
+    if d.alf_params is not None and alf_sets > 1:
+        d.alf_sets = [d.alf_params]
+        for k in range(1, alf_sets):
+            a = abi.AlfParams.from_buffer_copy(d.alf_params)
+            for name, axes in (("luma_coeff", (0, 1)), ("luma_clip", (0, 1)), ("chroma_coeff", (0,)), ("chroma_clip", (0,)), ("ccalf_coeff", (1,))):
+                v = np.ctypeslib.as_array(getattr(a, name))
+                v[...] = np.roll(v, k, axis=axes)
+            d.alf_sets.append(a)
+    if d.wp is not None and wp_sets > 1:
+        d.wp_sets = [d.wp]
+        for k in range(1, wp_sets):
+            w = abi.WpParams.from_buffer_copy(d.wp)
+            for l in range(2):
+                for i in range(abi.VVR_MAX_REFS):
+                    for c in range(3):
+                        e = w.e[l][i][c]
+                        if e.present:
+                            e.weight = int(np.clip(e.weight + (k if (i + c) & 1 else -k) * 3, (1 << w.log2_denom[1 if c else 0]) - 128, (1 << w.log2_denom[1 if c else 0]) + 127))
+                            e.offset = int(np.clip(-e.offset + k, -128, 127))
+            d.wp_sets.append(w)
     return d
 
 
