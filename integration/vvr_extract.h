@@ -10,6 +10,7 @@
 // (Reshape tables, TrQuant::getTrTypes) are reached the way a member function of those classes would reach them.
 #pragma once
 #include <vector>
+#include <array>
 #include <functional>
 #include <cstring>
 #include <algorithm>
@@ -45,9 +46,10 @@ struct Extracted
   std::vector<vvr_lfp>      lfp[2];
   std::vector<vvr_sao_ctu>  sao;
   std::vector<vvr_alf_ctu>  alf;
-  vvr_alf_params            alfParams;
+  std::vector<vvr_alf_params> alfSets;            // final filters of the APSs the slices refer to: one table per distinct choice (vvr_slice_header::alf_set)
   vvr_lmcs_params           lmcs;
-  vvr_wp_params             wp;
+  std::vector<vvr_wp_params> wpSets;              // pred_weight_table() of the slices over the union of their reference lists (vvr_slice_header::wp_set)
+  std::vector<vvr_slice_header> slices;           // filled (and pointed to) when the picture has more than one slice
   vvr_scaling_list          scaling;
   std::vector<uint16_t>     ctuSlice, ctuTile;    // filled (and pointed to) when the picture has more than one slice / tile
   std::vector<vvr_subpic>   subpics;              // filled (and pointed to) when the picture has more than one sub-picture
@@ -113,44 +115,60 @@ static inline uint32_t toolFlags( const CodingStructure& cs, const Slice& slice,
   return f;
 }
 
-// do two slices of a picture agree in everything the one header of a vvr_picture carries?
-static inline bool sameSliceHeader( const Slice& a, const Slice& b )
+// The slices of a picture as the description numbers them: one entry per independent slice, in the order they appear (dependent slices
+// continue the slice they depend on and share its header).
+struct SliceTable
 {
-  if( a.getSliceType() != b.getSliceType() || a.getDepQuantEnabledFlag() != b.getDepQuantEnabledFlag() || a.getLmcsEnabledFlag() != b.getLmcsEnabledFlag()
-      || a.getExplicitScalingListUsed() != b.getExplicitScalingListUsed() || a.getDeblockingFilterDisable() != b.getDeblockingFilterDisable()
-      || a.getDeblockingFilterBetaOffsetDiv2() != b.getDeblockingFilterBetaOffsetDiv2() || a.getDeblockingFilterTcOffsetDiv2() != b.getDeblockingFilterTcOffsetDiv2()
-      || a.getDeblockingFilterCbBetaOffsetDiv2() != b.getDeblockingFilterCbBetaOffsetDiv2() || a.getDeblockingFilterCbTcOffsetDiv2() != b.getDeblockingFilterCbTcOffsetDiv2()
-      || a.getDeblockingFilterCrBetaOffsetDiv2() != b.getDeblockingFilterCrBetaOffsetDiv2() || a.getDeblockingFilterCrTcOffsetDiv2() != b.getDeblockingFilterCrTcOffsetDiv2()
-      || a.getSaoEnabledFlag( CHANNEL_TYPE_LUMA ) != b.getSaoEnabledFlag( CHANNEL_TYPE_LUMA ) || a.getSaoEnabledFlag( CHANNEL_TYPE_CHROMA ) != b.getSaoEnabledFlag( CHANNEL_TYPE_CHROMA ) ) return false;
-  for( int c = 0; c < 3; c++ ) if( a.getAlfEnabledFlag( ComponentID( c ) ) != b.getAlfEnabledFlag( ComponentID( c ) ) ) return false;
-  if( a.getAlfEnabledFlag( COMPONENT_Y ) )
+  std::vector<const Slice*> first;      // header-carrying Slice object of every entry
+  std::vector<int>          ofIdx;      // getIndependentSliceIdx() -> entry
+  int entryOf( const Slice& s ) const { return ofIdx[s.getIndependentSliceIdx()]; }
+  explicit SliceTable( const Picture& pic )
   {
-    if( a.getNumAlfAps() != b.getNumAlfAps() ) return false;
-    for( int k = 0; k < a.getNumAlfAps(); k++ ) if( a.getAlfApsIdsLuma()[k] != b.getAlfApsIdsLuma()[k] ) return false;
-  }
-  if( ( a.getAlfEnabledFlag( COMPONENT_Cb ) || a.getAlfEnabledFlag( COMPONENT_Cr ) ) && a.getAlfApsIdChroma() != b.getAlfApsIdChroma() ) return false;
-  if( a.getCcAlfCbEnabledFlag() != b.getCcAlfCbEnabledFlag() || a.getCcAlfCrEnabledFlag() != b.getCcAlfCrEnabledFlag()
-      || ( a.getCcAlfCbEnabledFlag() && a.getCcAlfCbApsId() != b.getCcAlfCbApsId() ) || ( a.getCcAlfCrEnabledFlag() && a.getCcAlfCrApsId() != b.getCcAlfCrApsId() ) ) return false;
-  if( !a.isIntra() )
-    for( int l = 0; l < 2; l++ )
+    for( const Slice* s : pic.slices )
     {
-      if( a.getNumRefIdx( RefPicList( l ) ) != b.getNumRefIdx( RefPicList( l ) ) ) return false;
-      for( int i = 0; i < a.getNumRefIdx( RefPicList( l ) ); i++ )
+      const size_t k = s->getIndependentSliceIdx();
+      if( ofIdx.size() <= k ) ofIdx.resize( k + 1, -1 );
+      if( ofIdx[k] < 0 ) { ofIdx[k] = (int) first.size(); first.push_back( s ); }
+    }
+  }
+};
+
+// The reference picture lists of a description are the UNION of the slices' lists (vvr.h: vvr_slice_header): `uni[l]` collects the pictures,
+// `map[slice][l][i]` is where entry i of the slice's list l sits in the union.  A picture a slice lists twice (the way streams give one
+// picture two sets of prediction weights) takes two entries of the union, so the per-slice weight tables stay addressable by union index.
+struct RefUnion
+{
+  std::vector<const Picture*> uni[2];
+  std::vector<std::array<std::array<int8_t, MAX_NUM_REF>, 2>> map;
+  RefUnion( const SliceTable& st )
+  {
+    map.resize( st.first.size() );
+    for( size_t k = 0; k < st.first.size(); k++ )
+    {
+      const Slice& s = *st.first[k];
+      for( int l = 0; l < 2; l++ )
       {
-        if( a.getRefPic( RefPicList( l ), i ) != b.getRefPic( RefPicList( l ), i ) ) return false;
-        const WPScalingParam *wa = nullptr, *wb = nullptr;
-        a.getWpScaling( RefPicList( l ), i, wa ); b.getWpScaling( RefPicList( l ), i, wb );
-        for( int c = 0; c < 3; c++ ) if( wa[c].bPresentFlag != wb[c].bPresentFlag || ( wa[c].bPresentFlag && ( wa[c].iWeight != wb[c].iWeight || wa[c].iOffset != wb[c].iOffset || wa[c].uiLog2WeightDenom != wb[c].uiLog2WeightDenom ) ) ) return false;
+        map[k][l].fill( -1 );
+        if( s.isIntra() ) continue;
+        std::vector<char> used( uni[l].size(), 0 );
+        for( int i = 0; i < s.getNumRefIdx( RefPicList( l ) ) && i < MAX_NUM_REF; i++ )
+        {
+          const Picture* rp = s.getRefPic( RefPicList( l ), i );
+          size_t j = 0;
+          while( j < uni[l].size() && ( uni[l][j] != rp || used[j] ) ) j++;
+          if( j == uni[l].size() ) { uni[l].push_back( rp ); used.push_back( 0 ); }
+          used[j] = 1; map[k][l][i] = (int8_t) std::min<size_t>( j, 127 );
+        }
       }
     }
-  return true;
-}
+  }
+};
 
 // What a vvr_picture of this ABI version cannot express: such a picture must not be flattened (it would be reconstructed silently wrong).
 // Returns VVR_OK, or VVR_ERR_UNSUPPORTED with the reason; the binding (DecLibReconAmd) turns that into the reference's own
 // "not supported" error path.  Slices and tiles are carried as per-CTU indices (the reference restricts intra availability and the in-loop
 // filters at their edges: CodingStructure::getCURestricted, SampleAdaptiveOffset.cpp:741-830, AdaptiveLoopFilter.cpp:118-291,
-// LoopFilter.cpp:1078-1088), but there is ONE header per picture: slices that differ in what it carries are refused, and so are sub-pictures.
+// LoopFilter.cpp:1078-1088) and every slice brings its own header (vvr_picture.slices); the reference picture lists of the slices are merged.
 static inline int checkExpressible( const CodingStructure& cs, const Picture& pic, std::string& why )
 {
   const SPS& sps = *cs.sps; const PPS& pps = *cs.pps; const PicHeader& ph = *cs.picHeader;
@@ -169,18 +187,24 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
   if( pic.slices.empty() ) { why = "picture without a slice"; return VVR_ERR_UNSUPPORTED; }
   if( pps.getNumSubPics() > 1 && pps.getUseWrapAround() ) { why = "sub-pictures together with reference wrap-around"; return VVR_ERR_UNSUPPORTED; }
   if( pps.getNumSubPics() > 255 ) { why = "more than 255 sub-pictures"; return VVR_ERR_UNSUPPORTED; }
-  // several slices and tiles are expressible (vvr_picture.ctu_slice / ctu_tile) as long as the slices share their header
-  for( size_t k = 1; k < pic.slices.size(); k++ ) if( !sameSliceHeader( *pic.slices[0], *pic.slices[k] ) ) { why = "slices with different headers (slice type, reference lists, weights, filter or quantisation switches)"; return VVR_ERR_UNSUPPORTED; }
+  // several slices and tiles are expressible (vvr_picture.ctu_slice / ctu_tile, one vvr_slice_header per slice)
   if( pic.slices.size() > 65535 || pps.getNumTiles() > 65535 ) { why = "more slices or tiles than a 16-bit index holds"; return VVR_ERR_UNSUPPORTED; }
-  const Slice& slice = *pic.slices[0];
-  if( !slice.isIntra() )
-    for( int l = 0; l < 2; l++ ) for( int i = 0; i < slice.getNumRefIdx( RefPicList( l ) ); i++ )
-    {
-      const Picture* ref = slice.getRefPic( RefPicList( l ), i );
-      if( !ref ) { why = "missing reference picture"; return VVR_ERR_UNSUPPORTED; }
-      if( ref->isRefScaled( &pps ) ) { why = "reference picture of another size (reference picture resampling, InterPrediction.cpp:631-675)"; return VVR_ERR_UNSUPPORTED; }
-      if( i >= VVR_MAX_REFS ) { why = "more reference pictures than VVR_MAX_REFS"; return VVR_ERR_UNSUPPORTED; }
-    }
+  const SliceTable st( pic );
+  if( st.first.size() > 256 ) { why = "more than 256 slices with headers of their own"; return VVR_ERR_UNSUPPORTED; }
+  for( const Slice* sp : st.first )
+  {
+    const Slice& slice = *sp;
+    if( !slice.isIntra() )
+      for( int l = 0; l < 2; l++ ) for( int i = 0; i < slice.getNumRefIdx( RefPicList( l ) ); i++ )
+      {
+        const Picture* ref = slice.getRefPic( RefPicList( l ), i );
+        if( !ref ) { why = "missing reference picture"; return VVR_ERR_UNSUPPORTED; }
+        if( ref->isRefScaled( &pps ) ) { why = "reference picture of another size (reference picture resampling, InterPrediction.cpp:631-675)"; return VVR_ERR_UNSUPPORTED; }
+        if( i >= VVR_MAX_REFS ) { why = "more reference pictures than VVR_MAX_REFS"; return VVR_ERR_UNSUPPORTED; }
+      }
+  }
+  const RefUnion ru( st );
+  if( ru.uni[0].size() > VVR_MAX_REFS || ru.uni[1].size() > VVR_MAX_REFS ) { why = "the slices' reference picture lists together hold more pictures than VVR_MAX_REFS"; return VVR_ERR_UNSUPPORTED; }
   return VVR_OK;
 }
 
@@ -198,17 +222,41 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   // ---- header
   vvr_pic_header& h = E.pic.hdr; memset( &E.pic, 0, sizeof( E.pic ) );
   h.abi_version = VVR_ABI_VERSION;
+  // what a slice header can set differently goes into E.slices (one vvr_slice_header per slice, below); the picture's own header holds the
+  // first slice's values, with a tool on when any slice uses it, and the union of the slices' reference picture lists
+  const SliceTable st( pic );
+  const RefUnion   ru( st );
+  const bool multi = st.first.size() > 1;
   h.tool_flags = toolFlags( cs, slice, pic );
+  h.slice_type = (uint8_t) slice.getSliceType();
+  bool allDbkOff = slice.getDeblockingFilterDisable();
+  if( multi )
+  {
+    allDbkOff = true;
+    for( const Slice* s : st.first )
+    {
+      h.tool_flags |= toolFlags( cs, *s, pic ) & ( VVR_SLICE_TOOL_MASK | VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA | VVR_TOOL_ALF | VVR_TOOL_CCALF );
+      allDbkOff &= s->getDeblockingFilterDisable();
+      h.slice_type = std::min<uint8_t>( h.slice_type, (uint8_t) s->getSliceType() );          // B < P < I: the picture is of the most general kind
+    }
+    h.tool_flags = ( h.tool_flags & ~(uint32_t) VVR_TOOL_DEBLOCK_OFF ) | ( allDbkOff ? VVR_TOOL_DEBLOCK_OFF : 0 );
+  }
   h.width = (uint16_t) W; h.height = (uint16_t) H; h.chroma_format = chroma ? 1 : 0; h.bit_depth = (uint8_t) bd;
-  h.log2_ctu = (uint8_t) getLog2( pcv.maxCUWidth ); h.slice_type = (uint8_t) slice.getSliceType(); h.poc = slice.getPOC(); h.out_slot = (int16_t) outSlot;
+  h.log2_ctu = (uint8_t) getLog2( pcv.maxCUWidth ); h.poc = slice.getPOC(); h.out_slot = (int16_t) outSlot;
   for( int l = 0; l < 2; l++ )
   {
-    h.num_ref[l] = slice.isIntra() ? 0 : (int8_t) slice.getNumRefIdx( RefPicList( l ) );
-    for( int i = 0; i < h.num_ref[l]; i++ ) { h.ref_poc[l][i] = slice.getRefPOC( RefPicList( l ), i ); h.ref_slot[l][i] = (int16_t) slotOf( slice.getRefPic( RefPicList( l ), i ) ); }
+    h.num_ref[l] = (int8_t) ru.uni[l].size();
+    for( int i = 0; i < h.num_ref[l]; i++ ) { h.ref_poc[l][i] = ru.uni[l][i]->getPOC(); h.ref_slot[l][i] = (int16_t) slotOf( ru.uni[l][i] ); }
   }
-  h.deblock_beta_offset_div2[0] = (int8_t) slice.getDeblockingFilterBetaOffsetDiv2();   h.deblock_tc_offset_div2[0] = (int8_t) slice.getDeblockingFilterTcOffsetDiv2();
-  h.deblock_beta_offset_div2[1] = (int8_t) slice.getDeblockingFilterCbBetaOffsetDiv2(); h.deblock_tc_offset_div2[1] = (int8_t) slice.getDeblockingFilterCbTcOffsetDiv2();
-  h.deblock_beta_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrBetaOffsetDiv2(); h.deblock_tc_offset_div2[2] = (int8_t) slice.getDeblockingFilterCrTcOffsetDiv2();
+  auto sliceDbk = [&]( const Slice& s, int8_t beta[3], int8_t tc[3] )
+  {
+    beta[0] = (int8_t) s.getDeblockingFilterBetaOffsetDiv2();   tc[0] = (int8_t) s.getDeblockingFilterTcOffsetDiv2();
+    beta[1] = (int8_t) s.getDeblockingFilterCbBetaOffsetDiv2(); tc[1] = (int8_t) s.getDeblockingFilterCbTcOffsetDiv2();
+    beta[2] = (int8_t) s.getDeblockingFilterCrBetaOffsetDiv2(); tc[2] = (int8_t) s.getDeblockingFilterCrTcOffsetDiv2();
+  };
+  sliceDbk( slice, h.deblock_beta_offset_div2, h.deblock_tc_offset_div2 );
+  // index of a reference picture in the union, for a CU / a motion record of slice entry `se`
+  auto uniIdx = [&]( int se, int l, int refIdx ) -> int8_t { return refIdx < 0 || refIdx >= MAX_NUM_REF ? (int8_t) -1 : ru.map[se][l][refIdx]; };
   h.log2_sao_offset_scale[0] = h.log2_sao_offset_scale[1] = (uint8_t) std::max( 0, bd - MAX_SAO_TRUNCATED_BITDEPTH );
   h.min_qp_ts = (int8_t) ( 4 + 6 * sps.getInternalMinusInputBitDepth() );
   if( pps.getUseWrapAround() ) h.wrap_offset = (uint16_t) pps.getWrapAroundOffset();       // (Picture::isWrapAroundEnabled: references of another size are refused above)
@@ -268,14 +316,17 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
       }
       else
       {
-        c.inter_dir = (uint8_t) cu.interDir(); c.ref_idx[0] = (int8_t) cu.refIdx[0]; c.ref_idx[1] = (int8_t) cu.refIdx[1];
+        const int se = st.entryOf( *cu.slice );
+        c.inter_dir = (uint8_t) cu.interDir(); c.ref_idx[0] = uniIdx( se, 0, cu.refIdx[0] ); c.ref_idx[1] = uniIdx( se, 1, cu.refIdx[1] );
         for( int k = 0; k < 5; k++ ) if( g_BcwInternFwd[k] == cu.BcwIdx() ) c.bcw_idx = (uint8_t) k;      // description: index into the weight table
         c.imv = (uint8_t) cu.imv(); c.sbt_info = (uint8_t) cu.sbtInfo(); c.lfnst_idx = 0;
         // control-point MVs only for affine CUs (a GPM CU keeps its two MVs in mv[0][1] / mv[1][1], InterPrediction.cpp:1478,1489: they go to geo_mv)
         for( int l = 0; l < 2; l++ ) for( int k = 0; k < ( cu.affineFlag() ? 3 : 1 ); k++ ) { c.mv[l][k][0] = cu.mv[l][k].getHor(); c.mv[l][k][1] = cu.mv[l][k].getVer(); }
         if( cu.geoFlag() )
         {
-          c.geo_split_dir = cu.geoSplitDir; c.geo_dir_ref[0] = cu.interDirrefIdxGeo0(); c.geo_dir_ref[1] = cu.interDirrefIdxGeo1();
+          c.geo_split_dir = cu.geoSplitDir;
+          const uint8_t g[2] = { cu.interDirrefIdxGeo0(), cu.interDirrefIdxGeo1() };      // (interDir << 4) | refIdx of the partition's list
+          for( int k = 0; k < 2; k++ ) c.geo_dir_ref[k] = (uint8_t) ( ( g[k] & 0xf0 ) | ( uniIdx( se, ( g[k] >> 4 ) == 1 ? 0 : 1, g[k] & 15 ) & 15 ) );
           c.geo_mv[0][0] = cu.mv[0][1].getHor(); c.geo_mv[0][1] = cu.mv[0][1].getVer(); c.geo_mv[1][0] = cu.mv[1][1].getHor(); c.geo_mv[1][1] = cu.mv[1][1].getVer();
         }
         if( cu.ciipFlag() )
@@ -337,17 +388,21 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
     {
       const int a = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 ), in = ( y % ctu4 ) * ctu4 + ( x % ctu4 );
       const CtuData& cd = cs.getCtuData( a );
+      const int se = multi && cd.slice ? st.entryOf( *cd.slice ) : 0;
       vvr_motion& m = E.motion[(size_t) y * w4 + x]; memset( &m, 0, sizeof( m ) );
       const MotionInfo& mi = cd.motion[in];
       for( int l = 0; l < 2; l++ )
       {
-        m.ref_idx[l] = isMotionValid( mi.miRefIdx[l], MI_NOT_VALID ) ? (int8_t) mi.miRefIdx[l] : -1;
+        m.ref_idx[l] = isMotionValid( mi.miRefIdx[l], MI_NOT_VALID ) ? uniIdx( se, l, mi.miRefIdx[l] ) : (int8_t) -1;
         m.mv[l][0] = mi.mv[l].getHor(); m.mv[l][1] = mi.mv[l].getVer();
       }
       for( int d = 0; d < 2; d++ )
       {
         const LoopFilterParam& s = cd.lfParam[d][in];
         vvr_lfp& o = E.lfp[d][(size_t) y * w4 + x]; memset( &o, 0, sizeof( o ) );
+        // a slice with deblocking switched off in a picture that deblocks: LF_INIT leaves the edge parameters of its CTUs untouched and the
+        // filter skips them (LoopFilter.cpp:366,423) - here they carry no edge
+        if( !allDbkOff && cd.slice && cd.slice->getDeblockingFilterDisable() ) continue;
         o.qp[0] = s.qp[0]; o.qp[1] = s.qp[1]; o.qp[2] = s.qp[2]; o.bs = s.bs; o.side_max_filt_length = s.sideMaxFiltLength; o.flags = s.flags;
       }
     }
@@ -378,37 +433,55 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
     vvr_alf_ctu& f = E.alf[a]; memset( &f, 0, sizeof( f ) );
     const CtuAlfData& ad = cs.getCtuData( a ).alfParam;
     for( int k = 0; k < 3; k++ ) f.enable[k] = ad.alfCtuEnableFlag[k];
-    for( int k = 0; k < 2; k++ ) { f.alt[k] = ad.alfCtuAlternative[k]; f.cc_idc[k] = ad.ccAlfFilterControl[k]; }
+    const Slice* cs_ = cs.getCtuData( a ).slice;      // (the reference filters with the control value only where the CTU's slice has CC-ALF on, AdaptiveLoopFilter.cpp:623-625)
+    for( int k = 0; k < 2; k++ ) { f.alt[k] = ad.alfCtuAlternative[k]; f.cc_idc[k] = !cs_ || cs_->getCcAlfEnabledFlag( k + 1 ) ? ad.ccAlfFilterControl[k] : 0; }
     f.luma_filter_idx = ad.alfCtbFilterIndex;
   }
 
-  // ---- final ALF filters of the APSs the slice refers to (after AdaptiveLoopFilter::reconstructCoeffAPSs)
-  memset( &E.alfParams, 0, sizeof( E.alfParams ) );
-  if( h.tool_flags & VVR_TOOL_ALF )
+  // ---- final ALF filters of the APSs the slices refer to (after AdaptiveLoopFilter::reconstructCoeffAPSs): one table per distinct choice
+  E.slices.assign( st.first.size(), vvr_slice_header() ); memset( (void*) E.slices.data(), 0, E.slices.size() * sizeof( vvr_slice_header ) );
+  E.alfSets.clear();
+  auto alfOf = [&]( const Slice& sl, vvr_alf_params& A )
   {
-    const APS* const* apss = slice.getAlfAPSs();
-    E.alfParams.num_luma_aps = (uint8_t) slice.getNumAlfAps();
-    for( int i = 0; i < slice.getNumAlfAps() && i < VVR_MAX_ALF_APS; i++ )
+    memset( &A, 0, sizeof( A ) );
+    const APS* const* apss = sl.getAlfAPSs();
+    A.num_luma_aps = (uint8_t) sl.getNumAlfAps();
+    for( int i = 0; i < sl.getNumAlfAps() && i < VVR_MAX_ALF_APS; i++ )
     {
-      const AlfSliceParam& p = apss[slice.getAlfApsIdsLuma()[i]]->getAlfAPSParam();
+      const AlfSliceParam& p = apss[sl.getAlfApsIdsLuma()[i]]->getAlfAPSParam();
       for( int cl = 0; cl < VVR_ALF_CLASSES; cl++ ) for( int k = 0; k < MAX_NUM_ALF_LUMA_COEFF - 1; k++ )      // (the centre tap is implied)
-      { E.alfParams.luma_coeff[i][cl][k] = p.lumaCoeffFinal[cl * MAX_NUM_ALF_LUMA_COEFF + k]; E.alfParams.luma_clip[i][cl][k] = p.lumaClippFinal[cl * MAX_NUM_ALF_LUMA_COEFF + k]; }
+      { A.luma_coeff[i][cl][k] = p.lumaCoeffFinal[cl * MAX_NUM_ALF_LUMA_COEFF + k]; A.luma_clip[i][cl][k] = p.lumaClippFinal[cl * MAX_NUM_ALF_LUMA_COEFF + k]; }
     }
-    if( chroma && apss[slice.getAlfApsIdChroma()] )
+    if( chroma && ( sl.getAlfEnabledFlag( COMPONENT_Cb ) || sl.getAlfEnabledFlag( COMPONENT_Cr ) || !multi ) && apss[sl.getAlfApsIdChroma()] )
     {
-      const AlfSliceParam& p = apss[slice.getAlfApsIdChroma()]->getAlfAPSParam();
+      const AlfSliceParam& p = apss[sl.getAlfApsIdChroma()]->getAlfAPSParam();
       for( int alt = 0; alt < VVR_ALF_MAX_CHR_ALT && alt < p.numAlternativesChroma; alt++ ) for( int k = 0; k < MAX_NUM_ALF_CHROMA_COEFF - 1; k++ )
-      { E.alfParams.chroma_coeff[alt][k] = p.chromaCoeff[alt * MAX_NUM_ALF_CHROMA_COEFF + k]; E.alfParams.chroma_clip[alt][k] = p.chrmClippFinal[alt * MAX_NUM_ALF_CHROMA_COEFF + k]; }
+      { A.chroma_coeff[alt][k] = p.chromaCoeff[alt * MAX_NUM_ALF_CHROMA_COEFF + k]; A.chroma_clip[alt][k] = p.chrmClippFinal[alt * MAX_NUM_ALF_CHROMA_COEFF + k]; }
     }
     if( chroma && ( h.tool_flags & VVR_TOOL_CCALF ) )
       for( int k = 0; k < 2; k++ )
       {
-        const APS* aps = apss[k == 0 ? slice.getCcAlfCbApsId() : slice.getCcAlfCrApsId()];
+        if( multi && !sl.getCcAlfEnabledFlag( k + 1 ) ) continue;
+        const APS* aps = apss[k == 0 ? sl.getCcAlfCbApsId() : sl.getCcAlfCrApsId()];
         if( !aps ) continue;
         const CcAlfFilterParam& cc = aps->getCcAlfAPSParam();
-        for( int fI = 0; fI < VVR_CCALF_FILTERS; fI++ ) for( int j = 0; j < VVR_CCALF_TAPS + 1 && j < MAX_NUM_CC_ALF_CHROMA_COEFF; j++ ) E.alfParams.ccalf_coeff[k][fI][j] = cc.ccAlfCoeff[k][fI][j];
+        for( int fI = 0; fI < VVR_CCALF_FILTERS; fI++ ) for( int j = 0; j < VVR_CCALF_TAPS + 1 && j < MAX_NUM_CC_ALF_CHROMA_COEFF; j++ ) A.ccalf_coeff[k][fI][j] = cc.ccAlfCoeff[k][fI][j];
       }
-  }
+  };
+  auto setOf = [&]( auto& sets, const auto& t ) -> uint8_t
+  {
+    for( size_t k = 0; k < sets.size(); k++ ) if( !memcmp( &sets[k], &t, sizeof( t ) ) ) return (uint8_t) k;
+    sets.push_back( t ); return (uint8_t) ( sets.size() - 1 );
+  };
+  if( h.tool_flags & VVR_TOOL_ALF )
+    for( size_t k = 0; k < st.first.size(); k++ )
+    {
+      const Slice& sl = *st.first[k];
+      if( multi && !sl.getAlfEnabledFlag( COMPONENT_Y ) ) continue;        // (sh_alf_enabled_flag off: no APS ids, no CTU of the slice is filtered)
+      vvr_alf_params A; alfOf( sl, A );
+      E.slices[k].alf_set = setOf( E.alfSets, A );
+    }
+  if( E.alfSets.empty() ) { E.alfSets.emplace_back(); memset( &E.alfSets[0], 0, sizeof( vvr_alf_params ) ); }
 
   // ---- LMCS: the tables Reshape::constructReshaper built (Reshape.cpp:318-374); the forward map is tabulated with rspFwdCore's formula
   memset( &E.lmcs, 0, sizeof( E.lmcs ) );
@@ -427,19 +500,27 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
     E.lmcs.min_bin = (int16_t) ri.reshaperModelMinBinIdx; E.lmcs.max_bin = (int16_t) ri.reshaperModelMaxBinIdx; E.lmcs.model_delta_crs = (int16_t) ri.chrResScalingOffset;
   }
 
-  // ---- explicit weighted prediction, scaling lists
-  memset( &E.wp, 0, sizeof( E.wp ) );
+  // ---- explicit weighted prediction (the slices' tables re-indexed to the union of the reference lists), scaling lists
+  E.wpSets.clear();
   if( h.tool_flags & VVR_TOOL_WP )
-    for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
+    for( size_t k = 0; k < st.first.size(); k++ )
     {
-      const WPScalingParam* wp = nullptr;
-      slice.getWpScaling( RefPicList( l ), i, wp );
-      for( int k = 0; k < 3; k++ )
+      const Slice& sl = *st.first[k];
+      if( !( toolFlags( cs, sl, pic ) & VVR_TOOL_WP ) ) continue;
+      vvr_wp_params T; memset( &T, 0, sizeof( T ) );
+      for( int l = 0; l < 2; l++ ) for( int i = 0; i < sl.getNumRefIdx( RefPicList( l ) ) && i < MAX_NUM_REF; i++ )
       {
-        E.wp.log2_denom[k ? 1 : 0] = (uint8_t) wp[k].uiLog2WeightDenom;
-        vvr_wp_entry& e = E.wp.e[l][i][k]; e.present = wp[k].bPresentFlag; e.weight = (int16_t) wp[k].iWeight; e.offset = (int16_t) wp[k].iOffset;
+        const WPScalingParam* wp = nullptr;
+        sl.getWpScaling( RefPicList( l ), i, wp );
+        for( int c = 0; c < 3; c++ )
+        {
+          T.log2_denom[c ? 1 : 0] = (uint8_t) wp[c].uiLog2WeightDenom;
+          vvr_wp_entry& e = T.e[l][ru.map[k][l][i]][c]; e.present = wp[c].bPresentFlag; e.weight = (int16_t) wp[c].iWeight; e.offset = (int16_t) wp[c].iOffset;
+        }
       }
+      E.slices[k].wp_set = setOf( E.wpSets, T );
     }
+  if( E.wpSets.empty() ) { E.wpSets.emplace_back(); memset( &E.wpSets[0], 0, sizeof( vvr_wp_params ) ); }
   memset( &E.scaling, 0, sizeof( E.scaling ) );
   if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && cs.picHeader->getScalingListAPS() )
   {
@@ -460,23 +541,38 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   E.pic.motion = E.motion.data(); E.pic.lfp[0] = E.lfp[0].data(); E.pic.lfp[1] = E.lfp[1].data();
   E.pic.sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) ? E.sao.data() : nullptr;
   E.pic.alf = ( h.tool_flags & VVR_TOOL_ALF ) ? E.alf.data() : nullptr;
-  E.pic.alf_params = ( h.tool_flags & VVR_TOOL_ALF ) ? &E.alfParams : nullptr;
+  E.pic.alf_params = ( h.tool_flags & VVR_TOOL_ALF ) ? E.alfSets.data() : nullptr; E.pic.num_alf_sets = (uint32_t) E.alfSets.size();
   E.pic.lmcs = ( h.tool_flags & VVR_TOOL_LMCS ) ? &E.lmcs : nullptr;
-  E.pic.wp = ( h.tool_flags & VVR_TOOL_WP ) ? &E.wp : nullptr;
+  E.pic.wp = ( h.tool_flags & VVR_TOOL_WP ) ? E.wpSets.data() : nullptr; E.pic.num_wp_sets = (uint32_t) E.wpSets.size();
   E.pic.scaling = ( h.tool_flags & VVR_TOOL_SCALING_LIST ) ? &E.scaling : nullptr;
   // ---- slices and tiles: index of every CTU (picture raster order)
   E.ctuSlice.clear(); E.ctuTile.clear();
-  if( pic.slices.size() > 1 || pps.getNumTiles() > 1 )
+  if( multi || pps.getNumTiles() > 1 )
   {
     E.ctuSlice.resize( numCtu ); E.ctuTile.resize( numCtu );
     for( int a = 0; a < numCtu; a++ )
     {
       const CodingUnit* first = cs.getCtuData( a ).cuPtr[0][0];
-      E.ctuSlice[a] = first ? (uint16_t) first->slice->getIndependentSliceIdx() : 0;
+      E.ctuSlice[a] = first ? (uint16_t) st.entryOf( *first->slice ) : 0;
       E.ctuTile[a] = first ? (uint16_t) first->tileIdx : 0;
     }
-    if( pic.slices.size() > 1 ) E.pic.ctu_slice = E.ctuSlice.data();
+    if( multi ) E.pic.ctu_slice = E.ctuSlice.data();
     if( pps.getNumTiles() > 1 ) E.pic.ctu_tile = E.ctuTile.data();
+  }
+  // ---- slices with headers of their own
+  E.pic.slices = nullptr; E.pic.num_slices = 0;
+  if( multi )
+  {
+    for( size_t k = 0; k < st.first.size(); k++ )
+    {
+      const Slice& sl = *st.first[k];
+      vvr_slice_header& o = E.slices[k];
+      o.tool_flags = toolFlags( cs, sl, pic ) & VVR_SLICE_TOOL_MASK;
+      if( !( o.tool_flags & VVR_TOOL_LMCS ) ) o.tool_flags &= ~(uint32_t) VVR_TOOL_LMCS_CSCALE;       // (the picture's flag and sh_lmcs_used_flag)
+      sliceDbk( sl, o.deblock_beta_offset_div2, o.deblock_tc_offset_div2 );
+      o.slice_type = (uint8_t) sl.getSliceType();
+    }
+    E.pic.slices = E.slices.data(); E.pic.num_slices = (uint32_t) E.slices.size();
   }
   // ---- sub-pictures (PPS::initSubPic has the rectangles; the flags come from the SPS)
   E.subpics.clear(); E.pic.subpics = nullptr; E.pic.num_subpics = 0;

@@ -86,6 +86,8 @@ enum {
   VVREF_STOP_AFTER_DBK  = 8,
   VVREF_STOP_AFTER_SAO  = 16,
   VVREF_SPAN_AFFINE     = 32,  // the motion of affine CUs is not taken from the description: PU::setAllAffineMv spans it from the control-point MVs
+  VVREF_ROTATE_REF_LISTS = 64, // slices with headers of their own: slice k holds the description's (union) reference lists rotated by k entries, its CUs, motion
+                               // and weights renumbered to match - pictures as a decoder sees them, for the extractor to merge again
 };
 
 static std::string g_err;
@@ -106,6 +108,7 @@ static BindingRun* g_binding = nullptr;
 struct DropInRun { uint16_t* const* out_planes; int threads; };
 static DropInRun* g_dropin = nullptr;
 #endif
+static std::function<int( int, int, int, int )> g_unionIdx;      // ( x, y, list, index in the slice's list ) -> index in the description's lists (VVREF_ROTATE_REF_LISTS)
 static void dumpMotion( CodingStructure& cs, int W, int Hh, vvr_motion* out )
 {
   const int w4 = ( W + 3 ) >> 2, h4 = ( Hh + 3 ) >> 2;
@@ -113,7 +116,7 @@ static void dumpMotion( CodingStructure& cs, int W, int Hh, vvr_motion* out )
   {
     const MotionInfo& mi = cs.getMotionInfo( Position( x << 2, y << 2 ) );
     vvr_motion& o = out[(size_t) y * w4 + x]; memset( &o, 0, sizeof( o ) );
-    for( int l = 0; l < 2; l++ ) { o.mv[l][0] = mi.mv[l].hor; o.mv[l][1] = mi.mv[l].ver; o.ref_idx[l] = (int8_t) mi.miRefIdx[l]; }
+    for( int l = 0; l < 2; l++ ) { o.mv[l][0] = mi.mv[l].hor; o.mv[l][1] = mi.mv[l].ver; o.ref_idx[l] = (int8_t) ( g_unionIdx && mi.miRefIdx[l] >= 0 && mi.miRefIdx[l] < MAX_NUM_REF ? g_unionIdx( x << 2, y << 2, l, mi.miRefIdx[l] ) : mi.miRefIdx[l] ); }
   }
 }
 static bool g_trace = getenv("VVREF_TRACE") != nullptr;
@@ -134,9 +137,13 @@ static void fillPlane( PelBuf dst, const uint16_t* src, int w, int h )
 //   dmvr_out              : optional, receives m_dmvrMvCache entries (hor,ver) in CU order (cu.dmvr_off)
 //   stage_ms[8]           : optional wall time per stage {trafo+inter, intra, rsp, lf_v, lf_h, sao, alf, total}
 __attribute__((visibility("default")))
+static int g_extraFlags = 0;      // VVREF_* flags for the entry points that have no flags argument (vvref_run_binding / vvref_run_dropin)
+extern "C" __attribute__((visibility("default"))) void vvref_set_extra_flags( int f ) { g_extraFlags = f; }
+
 int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes, uint16_t* const* out_planes,
                        vvr_lfp* const* lfp_out, int32_t* dmvr_out, int flags, double* stage_ms )
 {
+  flags |= g_extraFlags;
   try
   {
     static bool romInit = false;
@@ -442,6 +449,15 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     if( vp->ctu_slice ) for( int a = 0; a < numCtuAll; a++ ) numSlices = std::max( numSlices, vp->ctu_slice[a] + 1 );
     if( vp->slices && (int) vp->num_slices < numSlices ) THROW_FATAL( "ctu_slice names a slice without a header" );
     std::vector<Slice*> slices;
+    // VVREF_ROTATE_REF_LISTS: entry i of slice si's list l is entry ( i + rot ) % n of the description's list
+    std::vector<std::array<int, 2>> rot( numSlices, std::array<int, 2>{ { 0, 0 } } );
+    if( ( flags & VVREF_ROTATE_REF_LISTS ) && vp->slices ) for( int si = 0; si < numSlices; si++ ) for( int l = 0; l < 2; l++ ) rot[si][l] = H.num_ref[l] > 1 ? si % H.num_ref[l] : 0;
+    const int ctusXAll = ( W + ctuSize - 1 ) / ctuSize;
+    auto sliceIdxAt = [&]( int x, int y ) { return vp->ctu_slice ? (int) vp->ctu_slice[( y / ctuSize ) * ctusXAll + x / ctuSize] : 0; };
+    auto toSlice = [&]( int si, int l, int u ) { const int n = H.num_ref[l]; return u < 0 || u >= n ? u : ( u - rot[si][l] + n ) % n; };
+    auto toUnion = [&]( int si, int l, int i ) { const int n = H.num_ref[l]; return i < 0 || i >= n ? i : ( i + rot[si][l] ) % n; };
+    g_unionIdx = nullptr;
+    if( flags & VVREF_ROTATE_REF_LISTS ) g_unionIdx = [=]( int x, int y, int l, int i ) { return toUnion( sliceIdxAt( x, y ), l, i ); };
     for( int si = 0; si < numSlices; si++ )
     {
     vvr_slice_header SH;
@@ -487,9 +503,10 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       slice->setNumRefIdx( RefPicList( l ), SH.slice_type == 2 ? 0 : H.num_ref[l] );
       for( int i = 0; i < H.num_ref[l] && SH.slice_type != 2; i++ )
       {
-        Picture* rp = getRefPic( H.ref_slot[l][i], H.ref_poc[l][i] );
+        const int u = toUnion( si, l, i );
+        Picture* rp = getRefPic( H.ref_slot[l][u], H.ref_poc[l][u] );
         slice->m_apcRefPicList[l][i]     = rp;
-        slice->m_aiRefPOCList[l][i]      = H.ref_poc[l][i];
+        slice->m_aiRefPOCList[l][i]      = H.ref_poc[l][u];
         slice->m_bIsUsedAsLongTerm[l][i] = false;
       }
     }
@@ -503,7 +520,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
         slice->getWpScaling( RefPicList( l ), i, wp );
         for( int c = 0; c < 3; c++ )
         {
-          const vvr_wp_entry& e = WP.e[l][i][c];
+          const vvr_wp_entry& e = WP.e[l][toUnion( si, l, i )][c];
           wp[c].bPresentFlag = e.present != 0; wp[c].uiLog2WeightDenom = WP.log2_denom[c ? 1 : 0]; wp[c].iWeight = e.weight; wp[c].iOffset = e.offset;
         }
       }
@@ -593,8 +610,9 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
         MotionInfo& mi = miStore[(size_t) pcv.num4x4CtuBlks * ctuA + ( y % ctu4 ) * ctu4 + ( x % ctu4 )];
         mi.mv[0] = Mv( m.mv[0][0], m.mv[0][1] );
         mi.mv[1] = Mv( m.mv[1][0], m.mv[1][1] );
-        mi.miRefIdx[0] = m.ref_idx[0] < 0 ? MI_NOT_VALID : m.ref_idx[0];
-        mi.miRefIdx[1] = m.ref_idx[1] < 0 ? MI_NOT_VALID : m.ref_idx[1];
+        const int si = sliceIdxAt( x << 2, y << 2 );
+        mi.miRefIdx[0] = m.ref_idx[0] < 0 ? MI_NOT_VALID : toSlice( si, 0, m.ref_idx[0] );
+        mi.miRefIdx[1] = m.ref_idx[1] < 0 ? MI_NOT_VALID : toSlice( si, 1, m.ref_idx[1] );
       }
     }
 
@@ -638,7 +656,8 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       cu.setLfnstIdx( c.lfnst_idx );
       cu.setSbtInfo( c.sbt_info );
       cu.setInterDir( c.inter_dir );
-      cu.refIdx[0] = c.ref_idx[0]; cu.refIdx[1] = c.ref_idx[1];
+      const int cuSl = sliceIdxAt( c.x, c.y );
+      cu.refIdx[0] = toSlice( cuSl, 0, c.ref_idx[0] ); cu.refIdx[1] = toSlice( cuSl, 1, c.ref_idx[1] );
       if( c.pred_mode == VVR_PRED_IBC )
       {   // what the parser leaves for an IBC CU (CABACReader.cpp:930-968, DecCu.cpp:850-870): list 0, no reference index, the CTU row marked
         cu.setInterDir( 1 ); cu.refIdx[0] = MAX_NUM_REF; cu.refIdx[1] = -1;
@@ -647,7 +666,11 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       cu.setBcwIdx( c.pred_mode == VVR_PRED_INTER ? g_BcwInternFwd[c.bcw_idx] : BCW_DEFAULT );   // description uses the weight-table index (2 = default), the reference its "internal domain"
       cu.setImv( c.imv );
       cu.geoSplitDir = c.geo_split_dir;
-      cu.setInterDirrefIdxGeo0( c.geo_dir_ref[0] ); cu.setInterDirrefIdxGeo1( c.geo_dir_ref[1] );
+      {
+        uint8_t g[2];
+        for( int k = 0; k < 2; k++ ) g[k] = (uint8_t) ( ( c.geo_dir_ref[k] & 0xf0 ) | ( ( c.flags & VVR_CU_GEO ) ? toSlice( cuSl, ( c.geo_dir_ref[k] >> 4 ) == 1 ? 0 : 1, c.geo_dir_ref[k] & 15 ) : ( c.geo_dir_ref[k] & 15 ) ) );
+        cu.setInterDirrefIdxGeo0( g[0] ); cu.setInterDirrefIdxGeo1( g[1] );
+      }
       for( int l = 0; l < 2; l++ ) for( int k = 0; k < 3; k++ ) cu.mv[l][k] = Mv( c.mv[l][k][0], c.mv[l][k][1] );
       // GPM keeps its two uni-prediction MVs in mv[0][1] / mv[1][1] (InterPrediction::motionCompensationGeo, InterPrediction.cpp:1478,1489)
       if( c.flags & VVR_CU_GEO ) { cu.mv[0][1] = Mv( c.geo_mv[0][0], c.geo_mv[0][1] ); cu.mv[1][1] = Mv( c.geo_mv[1][0], c.geo_mv[1][1] ); }
@@ -738,7 +761,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       case 1: sps.setLadfEnabled( true ); sps.setLadfNumIntervals( 6 ); break;                             // (more LADF intervals than the header holds)
       case 2: sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); pps.setWrapAroundOffset( 0 ); break;            // (a period of zero: no conforming stream has it)
       case 3: ph->setVirtualBoundariesPresentFlag( true ); ph->setNumVerVirtualBoundaries( 1 ); ph->setVirtualBoundariesPosX( 12, 0 ); break;     // (not on the 8-sample grid: no conforming stream has it)
-      case 4: { Slice* s2 = pic.allocateNewSlice(); s2->setPicHeader( ph.get() ); s2->setSliceType( SliceType( H.slice_type ) ); s2->setPOC( H.poc ); s2->setDepQuantEnabledFlag( !slice->getDepQuantEnabledFlag() ); } break;     // (a second slice with another header)
+      case 4: { Slice* s2 = pic.allocateNewSlice(); s2->setPicHeader( ph.get() ); s2->setSliceType( B_SLICE ); s2->setPOC( H.poc ); s2->setIndependentSliceIdx( numSlices ); s2->setNumRefIdx( REF_PIC_LIST_0, 1 ); s2->m_apcRefPicList[0][0] = nullptr; } break;     // (a further slice that refers to a picture the DPB does not hold)
       case 5: pps.setNumSubPics( 2 ); sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); pps.setWrapAroundOffset( W ); break;      // (sub-pictures together with wrap-around)
       case 6: sps.setUseColorTrans( true ); break;
       case 7: sps.setBitDepth( 12 ); break;

@@ -66,6 +66,8 @@ CASES = [
     ("b_384x256_ctu64_wrap_around", 384, 256, 6, 3, 54, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(wrap_offset=384, p_intra=0.1, p_affine=0.3, p_bi=0.8, p_geo=0.1, mv_sigma=10.0)),
     ("b_384x256_ctu64_virtual_boundaries", 384, 256, 6, 2, 53, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LMCS, dict(virtual_boundaries=2 | (2 << 2) | 16, p_intra=0.3, p_cclm=0.3, p_affine=0.2, p_coded_chroma=0.5)),
     ("b_256x128_ctu64_ladf", 256, 128, 6, 2, 50, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LADF, dict(p_intra=0.3, p_affine=0.1, p_coded=0.5)),
+    ("b_384x256_ctu64_slice_headers", 384, 256, 6, 2, 56, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_SLICES,
+     dict(num_slices=4, vary_slices=1, p_intra=0.3, p_cclm=0.3, p_ciip=0.1, p_affine=0.1, p_coded=0.8, p_coded_chroma=0.5)),
     ("b_256x192_ctu128_all_inter", 256, 192, 7, 2, 26, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.1, p_affine=0.2, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.2)),
 ]
 
@@ -78,7 +80,11 @@ def main():
             continue
         plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
         pl = plans[idx]
+        kw = dict(kw)
+        vary = kw.pop("vary_slices", 0)
         d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
+        if vary:
+            synth.vary_slices(d, seed)           # slices with headers of their own (vvr_slice_header)
         refs = {}
         for lst in pl.ref_slots:
             for (slot, poc) in lst:

@@ -40,6 +40,12 @@ def save(path, desc, refs, outputs):
         d["ctu_tile"] = np.asarray(desc.ctu_tile, np.uint16)
     if desc.subpics is not None and len(desc.subpics):
         d["subpics"] = np.frombuffer(np.ascontiguousarray(desc.subpics).tobytes(), np.uint8)
+    if desc.slices is not None and len(desc.slices):
+        d["slices"] = np.frombuffer(np.ascontiguousarray(desc.slices, dtype=np.dtype(abi.SliceHeader)).tobytes(), np.uint8)
+    if desc.alf_sets:
+        d["alf_sets"] = np.concatenate([_bytes_of(a) for a in desc.alf_sets])
+    if desc.wp_sets:
+        d["wp_sets"] = np.concatenate([_bytes_of(w) for w in desc.wp_sets])
     for slot, planes in refs.items():
         for c, p in enumerate(planes):
             d["ref_%d_%d" % (slot, c)] = np.asarray(p, np.uint16)
@@ -84,6 +90,12 @@ def load(path):
         d.ctu_tile = z["ctu_tile"].astype(np.uint16)
     if "subpics" in z:
         d.subpics = np.frombuffer(z["subpics"].tobytes(), np.dtype(abi.Subpic)).copy()
+    if "slices" in z:
+        d.slices = np.frombuffer(z["slices"].tobytes(), np.dtype(abi.SliceHeader)).copy()
+    for key, cls in (("alf_sets", abi.AlfParams), ("wp_sets", abi.WpParams)):
+        if key in z:
+            raw = z[key].tobytes()
+            setattr(d, key, [cls.from_buffer_copy(raw[o:o + C.sizeof(cls)]) for o in range(0, len(raw), C.sizeof(cls))])
     refs, outs = {}, {}
     for k in z.files:
         if k.startswith("ref_"):

@@ -9,6 +9,7 @@ from vvdec_amd import abi
 
 _LIB = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libvvref.so")
 SIMD, DERIVE_LFP, STOP_AFTER_RECO, STOP_AFTER_DBK, STOP_AFTER_SAO, SPAN_AFFINE = 1, 2, 4, 8, 16, 32
+ROTATE_REF_LISTS = 64      # VVREF_ROTATE_REF_LISTS: every slice holds the description's reference lists rotated by its index (the extractor merges them again)
 _lib = None
 
 
@@ -95,7 +96,7 @@ def binding_available():
     return os.path.exists(_BIND)
 
 
-def run_binding(desc, refs, backend_path, num_slots=8):
+def run_binding(desc, refs, backend_path, num_slots=8, flags=0):
     """the picture through integration/DecLibReconAmd.h (the DecLibRecon replacement: extractor -> vvr_submit -> vvr_wait -> TaskFinishMotionInfo),
     executed on the back-end library `backend_path` (libvvdec_amd.so, or the stand-in build of the CPU tests).  -> (planes, motion field)"""
     global _bind
@@ -112,7 +113,11 @@ def run_binding(desc, refs, backend_path, num_slots=8):
     for c in range(ncomp):
         out_ptrs[c] = outs[c].ctypes.data_as(C.POINTER(C.c_uint16))
     motion = np.zeros(desc.w4 * desc.h4, np.dtype(abi.Motion))
-    rc = _bind.vvref_run_binding(C.byref(p), ref_ptrs, out_ptrs, motion.ctypes.data_as(C.c_void_p), max(num_slots, nslots + 2))
+    _bind.vvref_set_extra_flags(flags)
+    try:
+        rc = _bind.vvref_run_binding(C.byref(p), ref_ptrs, out_ptrs, motion.ctypes.data_as(C.c_void_p), max(num_slots, nslots + 2))
+    finally:
+        _bind.vvref_set_extra_flags(0)
     if rc != 0:
         raise RuntimeError("vvref_run_binding failed: " + _bind.vvref_last_error().decode())
     return outs, motion
@@ -127,7 +132,7 @@ def dropin_available():
     return os.path.exists(_DROPIN_HARNESS) and os.path.exists(DROPIN_LIB)
 
 
-def run_dropin(desc, refs, backend_path, threads=2):
+def run_dropin(desc, refs, backend_path, threads=2, flags=0):
     """the picture through the DROP-IN: the reference's class vvdec::DecLibRecon with the member functions of integration/DecLibReconDropIn.cpp
     (create( ThreadPool*, id, upscale ) / decompressPicture / waitForPrevDecompressedPic / destroy on a thread pool of `threads` threads), on the
     back-end library `backend_path`.  -> (planes as they sit in the Picture's own buffers, motion field)"""
@@ -145,7 +150,11 @@ def run_dropin(desc, refs, backend_path, threads=2):
     for c in range(ncomp):
         out_ptrs[c] = outs[c].ctypes.data_as(C.POINTER(C.c_uint16))
     motion = np.zeros(desc.w4 * desc.h4, np.dtype(abi.Motion))
-    rc = _dropin.vvref_run_dropin(C.byref(p), ref_ptrs, out_ptrs, motion.ctypes.data_as(C.c_void_p), threads)
+    _dropin.vvref_set_extra_flags(flags)              # (e.g. ROTATE_REF_LISTS: what the harness builds, not what the drop-in does)
+    try:
+        rc = _dropin.vvref_run_dropin(C.byref(p), ref_ptrs, out_ptrs, motion.ctypes.data_as(C.c_void_p), threads)
+    finally:
+        _dropin.vvref_set_extra_flags(0)
     if rc != 0:
         raise RuntimeError("vvref_run_dropin failed: " + _dropin.vvref_last_error().decode())
     return outs, motion
@@ -183,7 +192,11 @@ def extract(desc, refs=None, flags=0):
     def one(ptr, ctype):
         return ctype.from_buffer_copy(ptr.contents) if ptr else None
 
-    return dict(hdr=h, num_dmvr=nd.value, cu=arr(q.cu, q.num_cu, abi.Cu), tu=arr(q.tu, q.num_tu, abi.Tu), coef=arr(q.coef, q.num_coef, abi.i16),
+    def many(ptr, n, ctype):
+        return [ctype.from_buffer_copy(ptr[k]) for k in range(n)] if ptr and n else None
+
+    return dict(slices=arr(q.slices, q.num_slices, abi.SliceHeader), alf_sets=many(q.alf_params, q.num_alf_sets, abi.AlfParams), wp_sets=many(q.wp, q.num_wp_sets, abi.WpParams),
+                hdr=h, num_dmvr=nd.value, cu=arr(q.cu, q.num_cu, abi.Cu), tu=arr(q.tu, q.num_tu, abi.Tu), coef=arr(q.coef, q.num_coef, abi.i16),
                 ctu_first_cu=arr(q.ctu_first_cu, nctu + 1, abi.u32), motion=arr(q.motion, n4, abi.Motion),
                 lfp=[arr(q.lfp[0], n4, abi.Lfp), arr(q.lfp[1], n4, abi.Lfp)], sao=arr(q.sao, nctu, abi.SaoCtu), alf=arr(q.alf, nctu, abi.AlfCtu),
                 alf_params=one(q.alf_params, abi.AlfParams), lmcs=one(q.lmcs, abi.LmcsParams), wp=one(q.wp, abi.WpParams), scaling=one(q.scaling, abi.ScalingList),

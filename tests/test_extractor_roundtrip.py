@@ -49,14 +49,44 @@ def _struct_differ(a, b, what, skip=()):
     return out
 
 
-def _compare(d, e):
+def _alf_differ(a0, a1, h0):
+    bad = []
+    na = a0.num_luma_aps
+    if a1.num_luma_aps != na:
+        bad.append("alf_params.num_luma_aps")
+    for name in ("luma_coeff", "luma_clip"):
+        if not np.array_equal(np.ctypeslib.as_array(getattr(a0, name))[:na], np.ctypeslib.as_array(getattr(a1, name))[:na]):
+            bad.append("alf_params.%s differs" % name)
+    if h0.chroma_format:
+        names = ("chroma_coeff", "chroma_clip") + (("ccalf_coeff",) if h0.tool_flags & abi.TOOL_CCALF else ())
+        for name in names:
+            if not np.array_equal(np.ctypeslib.as_array(getattr(a0, name)), np.ctypeslib.as_array(getattr(a1, name))):
+                bad.append("alf_params.%s differs" % name)
+    return bad
+
+
+def _wp_differ(w0, w1, h0):
+    bad = []
+    if list(w0.log2_denom) != list(w1.log2_denom):
+        bad.append("wp.log2_denom")
+    for l in range(2):
+        for i in range(h0.num_ref[l]):
+            for c in range(3):
+                a, b = w0.e[l][i][c], w1.e[l][i][c]
+                if (a.weight, a.offset, a.present) != (b.weight, b.offset, b.present):
+                    bad.append("wp.e[%d][%d][%d]" % (l, i, c))
+    return bad
+
+
+def _compare(d, e, sets=True):
     bad = []
     h0, h1 = d.hdr, e["hdr"]
     # (the harness always switches the SPS MTS flag on and resolves the transform types per TU, so that bit is not a property of the stream)
     f0, f1 = h0.tool_flags | abi.TOOL_MTS, h1.tool_flags | abi.TOOL_MTS
     if f0 != f1:
         bad.append("hdr.tool_flags %x vs %x" % (f0, f1))
-    bad += _struct_differ(h0, h1, "hdr", skip=("tool_flags",))
+    # (with slice headers the picture header's own deblocking offsets are not used: the extractor puts the first slice's there)
+    bad += _struct_differ(h0, h1, "hdr", skip=("tool_flags",) + (() if sets else ("deblock_beta_offset_div2", "deblock_tc_offset_div2")))
     bad += _fields_differ(d.cu, e["cu"], "cu")
     bad += _fields_differ(d.tu, e["tu"], "tu")
     if not np.array_equal(d.ctu_first_cu, e["ctu_first_cu"]):
@@ -73,18 +103,8 @@ def _compare(d, e):
         bad += _fields_differ(d.sao, e["sao"], "sao")
     if h0.tool_flags & abi.TOOL_ALF:
         bad += _fields_differ(d.alf, e["alf"], "alf")
-        a0, a1 = d.alf_params, e["alf_params"]
-        na = a0.num_luma_aps
-        if a1.num_luma_aps != na:
-            bad.append("alf_params.num_luma_aps")
-        for name in ("luma_coeff", "luma_clip"):
-            if not np.array_equal(np.ctypeslib.as_array(getattr(a0, name))[:na], np.ctypeslib.as_array(getattr(a1, name))[:na]):
-                bad.append("alf_params.%s differs" % name)
-        if h0.chroma_format:
-            names = ("chroma_coeff", "chroma_clip") + (("ccalf_coeff",) if h0.tool_flags & abi.TOOL_CCALF else ())
-            for name in names:
-                if not np.array_equal(np.ctypeslib.as_array(getattr(a0, name)), np.ctypeslib.as_array(getattr(a1, name))):
-                    bad.append("alf_params.%s differs" % name)
+        if sets:
+            bad += _alf_differ(d.alf_params, e["alf_params"], h0)
     if h0.tool_flags & abi.TOOL_LMCS:
         l0, l1 = d.lmcs, e["lmcs"]
         nv = 1 << h0.bit_depth
@@ -92,16 +112,8 @@ def _compare(d, e):
             if not np.array_equal(np.ctypeslib.as_array(getattr(l0, name))[:nv], np.ctypeslib.as_array(getattr(l1, name))[:nv]):
                 bad.append("lmcs.%s differs" % name)
         bad += _struct_differ(l0, l1, "lmcs", skip=("fwd_lut", "inv_lut"))
-    if (h0.tool_flags & abi.TOOL_WP) and h0.slice_type != abi.SLICE_I:
-        w0, w1 = d.wp, e["wp"]
-        if list(w0.log2_denom) != list(w1.log2_denom):
-            bad.append("wp.log2_denom")
-        for l in range(2):
-            for i in range(h0.num_ref[l]):
-                for c in range(3):
-                    a, b = w0.e[l][i][c], w1.e[l][i][c]
-                    if (a.weight, a.offset, a.present) != (b.weight, b.offset, b.present):
-                        bad.append("wp.e[%d][%d][%d]" % (l, i, c))
+    if sets and (h0.tool_flags & abi.TOOL_WP) and h0.slice_type != abi.SLICE_I:
+        bad += _wp_differ(d.wp, e["wp"], h0)
     if h0.tool_flags & abi.TOOL_SCALING_LIST:
         bad += _struct_differ(d.scaling, e["scaling"], "scaling")
     # slices, tiles (the index of a slice / tile is what the reference numbers them with: compared as partitions), sub-pictures
@@ -211,7 +223,55 @@ def test_reference_edge_tables_are_safe_for_one_launch_per_direction(built):
     assert ordered > 0
 
 
-@pytest.mark.parametrize("feature,text", [(1, "LADF with more than 5"), (2, "wrap-around motion compensation with a period off"), (3, "virtual boundary off the 8-sample grid"), (4, "slices with different headers"), (5, "sub-pictures together with reference wrap-around"),
+def _sets_differ(want, got, what, used, cmp):
+    """tables selected by the slices: compared through the slices' choice (the extractor numbers distinct tables in the order it meets them)"""
+    return ["%s of slice %d differs" % (what, k) for k, (a, b) in enumerate(used) if cmp(want[a], got[b])]
+
+
+@pytest.mark.parametrize("idx,seed,tools,kw,rotate", [
+    (0, 641, ALL | LM | abi.TOOL_SCALING_LIST, dict(num_slices=3, p_cclm=0.3, p_coded=0.8), False),
+    (2, 642, ALL | LM | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=4, p_intra=0.3, p_ciip=0.2, p_affine=0.2, p_geo=0.2, p_sbtmvp=0.1), False),
+    (2, 643, ALL | LM | abi.TOOL_WP, dict(num_slices=4, p_intra=0.2, p_affine=0.2, p_geo=0.2, p_sbtmvp=0.2, p_bcw=0.2), True),
+    (3, 644, ALL | abi.TOOL_SCALING_LIST | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=5, tile_cols=3, tile_rows=2, p_intra=0.2, p_geo=0.3), True),
+])
+def test_slices_with_headers_of_their_own_survive_the_reference_objects(built, idx, seed, tools, kw, rotate):
+    """every slice of the reference's picture carries its own header (quantisation / LMCS / scaling-list switches, deblocking offsets, APS ids,
+    weights) and - with `rotate` - its own reference picture lists (the description's lists rotated by the slice index, CUs / motion / GPM
+    partitions / weights numbered to match): the extractor fills vvr_picture::slices, merges the lists into their union and renumbers every
+    reference index, so the original description comes back"""
+    W, H, l2 = 512, 384, 6
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
+    synth.vary_slices(d, seed)
+    refs = {slot: synth.natural_picture(W, H, seed + 100 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
+    if rotate:
+        assert max(d.hdr.num_ref[0], d.hdr.num_ref[1]) > 1
+    e = refdrv.extract(d, refs, flags=refdrv.ROTATE_REF_LISTS if rotate else 0)
+    bad = _compare(d, e, sets=False)
+    # the slice headers (the slice numbering is the reference's: compared through the CTU map)
+    assert e["slices"] is not None and len(e["slices"]) == len(d.slices)
+    pairs = sorted(set(zip(d.ctu_slice.tolist(), e["ctu_slice"].tolist())))
+    assert len(pairs) == len(d.slices)
+    for a, b in pairs:
+        s0, s1 = d.slices[a], e["slices"][b]
+        for name in ("tool_flags", "deblock_beta_offset_div2", "deblock_tc_offset_div2", "slice_type"):
+            v0, v1 = s0[name], s1[name]
+            if name == "tool_flags":
+                if d.hdr.slice_type == abi.SLICE_I:
+                    v0, v1 = int(v0) & ~abi.TOOL_WP, int(v1) & ~abi.TOOL_WP
+            if not np.array_equal(v0, v1):
+                bad.append("slice %d: %s %s vs %s" % (a, name, v0, v1))
+    if d.hdr.tool_flags & abi.TOOL_ALF:
+        used = [(int(d.slices["alf_set"][a]), int(e["slices"]["alf_set"][b])) for a, b in pairs]
+        bad += _sets_differ(d.alf_sets, e["alf_sets"], "ALF table", used, lambda x, y: bool(_alf_differ(x, y, d.hdr)))
+    if (d.hdr.tool_flags & abi.TOOL_WP) and d.hdr.slice_type != abi.SLICE_I:
+        used = [(int(d.slices["wp_set"][a]), int(e["slices"]["wp_set"][b])) for a, b in pairs]
+        bad += _sets_differ(d.wp_sets, e["wp_sets"], "weight table", used, lambda x, y: bool(_wp_differ(x, y, d.hdr)))
+    assert not bad, "\n".join(bad[:20])
+
+
+@pytest.mark.parametrize("feature,text", [(1, "LADF with more than 5"), (2, "wrap-around motion compensation with a period off"), (3, "virtual boundary off the 8-sample grid"), (4, "missing reference picture"), (5, "sub-pictures together with reference wrap-around"),
                                           (6, "colour transform"), (7, "bit depth"), (8, "more slices or tiles"), (9, "another size")])
 def test_extractor_refuses_what_the_description_cannot_express(built, feature, text):
     """the reference-side glue never flattens a picture into something it is not: LADF, wrap-around, virtual boundaries, several slices / tiles /
@@ -249,11 +309,15 @@ def test_binding_executes_on_the_stand_in_runtime(built):
     T.build_stub()
     W, H = 256, 128
     plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
-    for idx, tools, kw in ((0, ALL, dict(p_cclm=0.3, p_mip=0.2)), (2, ALL | abi.TOOL_STILL_REF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.2, p_affine=0.2, p_sbtmvp=0.1, p_ciip=0.1))):
+    for idx, tools, kw, fl in ((0, ALL, dict(p_cclm=0.3, p_mip=0.2), 0), (2, ALL | abi.TOOL_STILL_REF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.2, p_affine=0.2, p_sbtmvp=0.1, p_ciip=0.1), 0),
+                               # slices with headers and reference picture lists of their own (the harness rotates the lists per slice, the extractor merges them)
+                               (2, ALL | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP | abi.TOOL_SCALING_LIST, dict(num_slices=3, log2_ctu=5, p_intra=0.2, p_affine=0.2, p_geo=0.2, p_sbtmvp=0.1), refdrv.ROTATE_REF_LISTS)):
         pl = plans[idx]
         d = synth.picture_for_plan(pl, W, H, seed=641 + idx, tool_flags=tools, **kw)
+        if fl:
+            synth.vary_slices(d, 660)
         refs = {slot: synth.natural_picture(W, H, 650 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
-        planes, motion = refdrv.run_binding(d, refs, T.LIB)
+        planes, motion = refdrv.run_binding(d, refs, T.LIB, flags=fl)
         assert [p.shape for p in planes] == [d.plane_shape(c) for c in range(3)]
         if pl.slice_type != abi.SLICE_I:
             inter = d.motion["ref_idx"].max(axis=1) >= 0

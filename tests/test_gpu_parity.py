@@ -663,3 +663,35 @@ def test_dropin_declibrecon(built, idx, seed, tools_extra, kw, threads):
     valid = want_motion["ref_idx"] >= 0
     assert np.array_equal(got_motion["ref_idx"], want_motion["ref_idx"])
     assert np.array_equal(got_motion["mv"][valid], want_motion["mv"][valid]), "motion field after TaskFinishMotionInfo differs"
+
+
+@pytest.mark.parametrize("idx,seed,tools_extra,kw,threads,rotate", [
+    (0, 721, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST, dict(num_slices=3, p_cclm=0.3, p_mip=0.2, p_coded=0.8), 2, False),
+    (2, 722, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP, dict(num_slices=4, p_intra=0.2, p_bi=0.9, p_affine=0.15, p_sbtmvp=0.1, p_ciip=0.1, p_geo=0.15), 3, True),
+    (3, 723, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_SCALING_LIST | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=4, tile_cols=2, tile_rows=2, p_intra=0.1, p_bi=0.9, p_geo=0.1, mv_sigma=2.0), 2, True),
+])
+def test_dropin_slices_with_headers_of_their_own(built, idx, seed, tools_extra, kw, threads, rotate):
+    """the drop-in on pictures whose slices differ in their headers and (rotate) in their reference picture lists: the reference's objects carry
+    per-slice lists / reference indices / weights, the extractor merges them (vvr_picture::slices, union of the lists), the GPU reconstructs,
+    and the Picture's buffers and motion field equal what the reference's own DecLibRecon stages give for the same objects"""
+    import vvdec_amd
+    if not (refdrv.available() and refdrv.dropin_available()):
+        pytest.skip("the reference build (oracle/_ref) is not present")
+    W, H = 512, 384
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=TOOLS | abi.TOOL_LFNST | tools_extra, log2_ctu=6, **kw)
+    synth.vary_slices(d, seed)
+    refs = {slot: synth.natural_picture(W, H, seed + 100 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
+    fl = refdrv.ROTATE_REF_LISTS if rotate else 0
+    want_planes, want_motion = refdrv.reconstruct_with_motion(d, refs, flags=refdrv.DERIVE_LFP | fl)
+    got_planes, got_motion = refdrv.run_dropin(d, refs, vvdec_amd._LIBPATH, threads=threads, flags=fl)
+    for c in range(3):
+        assert np.array_equal(got_planes[c], want_planes[c]), "comp %d: %d samples differ from the reference's DecLibRecon" % (c, int((got_planes[c] != want_planes[c]).sum()))
+    valid = want_motion["ref_idx"] >= 0
+    assert np.array_equal(got_motion["ref_idx"], want_motion["ref_idx"])
+    assert np.array_equal(got_motion["mv"][valid], want_motion["mv"][valid]), "motion field after TaskFinishMotionInfo differs"
+    # and the rotation is immaterial: the same picture as without it
+    if rotate:
+        plain, _ = refdrv.reconstruct_with_motion(d, refs, flags=refdrv.DERIVE_LFP)
+        assert all(np.array_equal(a, b) for a, b in zip(plain, want_planes))
