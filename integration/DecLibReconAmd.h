@@ -67,13 +67,15 @@ public:
     { std::string why; if( checkExpressible( cs, *pic, why ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << why ); }    // never flattened into something it is not
     deriveEdgeParameters( cs, numCtu );                                                // LF_INIT (DecLibRecon.cpp:912-941)
     Reshape* rsp = nullptr;
-    if( cs.sps->getUseReshaper() && slice.getLmcsEnabledFlag() )
+    bool lmcs = false;                                                                 // (LMCS is a switch of every slice header: the tables are the picture's)
+    for( const Slice* sl : pic->slices ) lmcs |= sl->getLmcsEnabledFlag();
+    if( cs.sps->getUseReshaper() && lmcs )
     {
       m_reshaper.createDec( cs.sps->getBitDepth() );
       m_reshaper.initSlice( slice.getNalUnitLayerId(), *slice.getPicHeader(), slice.getVPS_nothrow() );   // DecLibRecon.cpp:449-453
       rsp = &m_reshaper;
     }
-    if( cs.sps->getUseALF() ) AdaptiveLoopFilter::reconstructCoeffAPSs( slice );
+    if( cs.sps->getUseALF() ) for( Slice* sl : pic->slices ) AdaptiveLoopFilter::reconstructCoeffAPSs( *sl );      // (every slice names its own APSs)
     extractPicture( cs, slice, *pic, rsp, m_trQuant, [this]( const Picture* p ) { return m_slots->slotOf( p ); }, m_slots->acquire( pic ), m_desc );
     m_job = vvr_submit( m_ctx, &m_desc.pic );                                          // asynchronous: the arrays may be reused when it returns
     if( m_job < 0 ) THROW_RECOVERABLE( vvr_last_error( m_ctx ) );

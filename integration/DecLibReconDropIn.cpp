@@ -229,8 +229,10 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
     if( vvr_glue::checkExpressible( cs, *pic, why ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << why );      // never flattened into something it is not
     Slice& slice = *pic->slices[0];
     Reshape* rsp = nullptr;
-    if( cs.sps->getUseReshaper() && slice.getLmcsEnabledFlag() ) rsp = &R.m_cReshaper;      // (initSlice was called in decompressPicture)
-    if( cs.sps->getUseALF() ) AdaptiveLoopFilter::reconstructCoeffAPSs( slice );
+    bool lmcs = false;                                                                   // (LMCS is a switch of every slice header: the tables are the picture's)
+    for( const Slice* sl : pic->slices ) lmcs |= sl->getLmcsEnabledFlag();
+    if( cs.sps->getUseReshaper() && lmcs ) rsp = &R.m_cReshaper;                         // (initSlice was called in decompressPicture)
+    if( cs.sps->getUseALF() ) for( Slice* sl : pic->slices ) AdaptiveLoopFilter::reconstructCoeffAPSs( *sl );      // (every slice names its own APSs)
     std::lock_guard<std::mutex> lk( S.mu );                                              // (one submitting thread at a time: vvr.h)
     if( !S.ctx )
     {

@@ -891,7 +891,7 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       TR("trafo ctu %d\n", a);
       decCu.TaskTrafoCtu( cs, a, ctuArea );
       TR("inter ctu %d\n", a);
-      if( !slice->isIntra() ) decCu.TaskInterCtu( cs, a, ctuArea );
+      if( !sliceOfCtu( a )->isIntra() ) decCu.TaskInterCtu( cs, a, ctuArea );
     }
     auto tB = now(); st[0] = ms( tA, tB );
     for( int a = 0; a < numCtu; a++ )                                    // INTRA (raster order satisfies the wavefront dependencies)
@@ -1026,7 +1026,7 @@ const vvr_picture* vvref_extract( const vvr_picture* vp, const uint16_t* const* 
   static vvr_glue::Extracted E;
   g_extractTo = &E;
   uint16_t* none[3] = { nullptr, nullptr, nullptr };
-  const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, flags & VVREF_DERIVE_LFP, nullptr );
+  const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, flags & ( VVREF_DERIVE_LFP | VVREF_ROTATE_REF_LISTS ), nullptr );
   g_extractTo = nullptr;
   if( rc != 0 ) return nullptr;
   if( num_dmvr ) *num_dmvr = E.numDmvr;

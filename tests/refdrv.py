@@ -204,6 +204,22 @@ def extract(desc, refs=None, flags=0):
                 subpics=(np.frombuffer((C.c_char * (C.sizeof(abi.Subpic) * q.num_subpics)).from_address(q.subpics), np.dtype(abi.Subpic)).copy() if q.subpics and q.num_subpics else None))
 
 
+def desc_from_extract(e):
+    """the dict extract() returns as a PictureDesc again (to run the oracle or the back-end on what the extractor wrote)"""
+    from vvdec_amd import desc as _desc
+    h = e["hdr"]
+    x = _desc.PictureDesc(h.width, h.height, h.bit_depth, h.log2_ctu, h.chroma_format)
+    x.hdr = h
+    for k in ("coef", "ctu_first_cu", "sao", "alf", "ctu_slice", "ctu_tile", "slices", "alf_sets", "wp_sets", "lmcs", "scaling", "subpics", "alf_params", "wp"):
+        setattr(x, k, e[k])
+    x.cu, x.tu, x.motion = e["cu"].view(_desc.CU_DT), e["tu"].view(_desc.TU_DT), e["motion"].view(_desc.MOTION_DT)
+    x.lfp = [e["lfp"][0].view(_desc.LFP_DT), e["lfp"][1].view(_desc.LFP_DT)]
+    x.sao = None if e["sao"] is None else e["sao"].view(_desc.SAO_DT)
+    x.alf = None if e["alf"] is None else e["alf"].view(_desc.ALF_DT)
+    x.num_dmvr = e["num_dmvr"]
+    return x
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the plain-C restatement (oracle/libvvoracle.so) through the same calling convention
 # ---------------------------------------------------------------------------------------------------------------------

@@ -371,6 +371,7 @@ def test_slices_and_tiles(built, extra, kw):
     (abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST, dict(num_slices=3)),
     (abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=4, p_ciip=0.2, p_affine=0.2, p_sbtmvp=0.1)),
     (abi.TOOL_SCALING_LIST | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=4, tile_cols=3, tile_rows=2)),
+    (abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=4, intra_slices=0b0110)),      # I slices in B pictures
 ])
 def test_slice_headers(built, extra, kw):
     """slices with headers of their own (vvr_picture::slices): dependent quantisation, LMCS, chroma residual scaling, scaling lists per slice
@@ -379,7 +380,7 @@ def test_slice_headers(built, extra, kw):
     seen = []
 
     def vary(d):
-        synth.vary_slices(d, 230 + d.hdr.poc)
+        synth.vary_slices(d, 230 + d.hdr.poc, intra_slices=kw.get("intra_slices", 0))
         seen.append(len(set(int(f) for f in d.slices["tool_flags"])))
     _run_stream(512, 384, 5, 4, 231, T, intra=True, log2_ctu=6, p_intra=0.3, p_cclm=0.3, p_coded=0.8, p_coded_chroma=0.6, post=vary, **kw)
     _run_stream(640, 256, 3, 2, 232, T, intra=True, log2_ctu=5, p_intra=0.2, p_coded=0.8, post=vary, **kw)
@@ -669,6 +670,7 @@ def test_dropin_declibrecon(built, idx, seed, tools_extra, kw, threads):
     (0, 721, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST, dict(num_slices=3, p_cclm=0.3, p_mip=0.2, p_coded=0.8), 2, False),
     (2, 722, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP, dict(num_slices=4, p_intra=0.2, p_bi=0.9, p_affine=0.15, p_sbtmvp=0.1, p_ciip=0.1, p_geo=0.15), 3, True),
     (3, 723, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_SCALING_LIST | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=4, tile_cols=2, tile_rows=2, p_intra=0.1, p_bi=0.9, p_geo=0.1, mv_sigma=2.0), 2, True),
+    (2, 724, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP, dict(num_slices=4, intra_slices=0b0101, p_intra=0.2, p_bi=0.9, p_cclm=0.3), 2, True),      # I slices among B slices
 ])
 def test_dropin_slices_with_headers_of_their_own(built, idx, seed, tools_extra, kw, threads, rotate):
     """the drop-in on pictures whose slices differ in their headers and (rotate) in their reference picture lists: the reference's objects carry
@@ -681,7 +683,7 @@ def test_dropin_slices_with_headers_of_their_own(built, idx, seed, tools_extra, 
     plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
     pl = plans[idx]
     d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=TOOLS | abi.TOOL_LFNST | tools_extra, log2_ctu=6, **kw)
-    synth.vary_slices(d, seed)
+    synth.vary_slices(d, seed, intra_slices=kw.get("intra_slices", 0))
     refs = {slot: synth.natural_picture(W, H, seed + 100 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
     fl = refdrv.ROTATE_REF_LISTS if rotate else 0
     want_planes, want_motion = refdrv.reconstruct_with_motion(d, refs, flags=refdrv.DERIVE_LFP | fl)

@@ -301,6 +301,8 @@ SLICE_HEADER_CASES = [
     (512, 384, 6, 2, 282, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=4, p_intra=0.3, p_ciip=0.2, p_coded=0.8, p_coded_chroma=0.6, p_affine=0.2)),
     (640, 256, 5, 3, 283, abi.TOOL_SCALING_LIST | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_TILES, dict(num_slices=4, tile_cols=3, tile_rows=2, p_intra=0.2, p_coded=0.8, p_sbtmvp=0.2)),
     (512, 384, 6, 1, 284, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST, dict(num_slices=5, p_intra=0.2, p_coded=0.7, p_coded_chroma=0.6, p_geo=0.2)),
+    # I slices in a B picture (slices 1 and 2 hold intra CUs only and carry slice type I: no reference lists, no weights)
+    (512, 384, 6, 2, 285, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_SLICES, dict(num_slices=4, intra_slices=0b0110, p_intra=0.2, p_cclm=0.3, p_coded=0.8, p_coded_chroma=0.6)),
 ]
 
 
@@ -310,8 +312,13 @@ def test_oracle_equals_reference_slice_headers(built, W, H, l2, idx, seed, extra
     off per slice, deblocking offsets, the APSs the ALF takes its filters from and the prediction weights - every stage takes the values of
     the slice the CU / CTU lies in (ctuData.slice).  The reference runs with Slice objects that carry exactly these headers."""
     d, refs = _case(W, H, l2, idx, seed, tools=ALL | extra, **kw)
-    synth.vary_slices(d, seed)
+    synth.vary_slices(d, seed, intra_slices=kw.get("intra_slices", 0))
     n = len(d.slices)
+    if kw.get("intra_slices"):
+        ctus_x = (W + (1 << l2) - 1) >> l2
+        cu_slice = d.ctu_slice[(d.cu["y"].astype(int) >> l2) * ctus_x + (d.cu["x"].astype(int) >> l2)]
+        is_i = d.slices["slice_type"][cu_slice] == abi.SLICE_I
+        assert is_i.any() and (~is_i).any() and (d.cu["pred_mode"][is_i] != abi.PRED_INTER).all() and (d.cu["pred_mode"][~is_i] == abi.PRED_INTER).any()
     assert n == kw["num_slices"] and len(set(int(f) for f in d.slices["tool_flags"])) > 1
     for fl in STAGES:
         want = refdrv.reconstruct(d, refs, flags=fl)["planes"]

@@ -77,6 +77,7 @@ typedef struct vvs_params {
                                 // to the left / right picture edge point across it more often
   uint8_t  subpics;             // bit 0: one sub-picture per tile (needs a tile grid; slices are then one per tile as well); bits 1-2: treated as a picture:
                                 // 0 none, 1 all, 2 some; bits 3-4: loop filters across sub-picture boundaries: 0 everywhere, 1 nowhere, 2 for some
+  uint8_t  intra_slices;        // P / B pictures with several slices: bit ( k & 7 ) set = slice k holds intra (and IBC) CUs only - an I slice in a picture of another kind
   uint8_t  virtual_boundaries;  // bits 0-1: number of vertical, bits 2-3: of horizontal virtual boundaries of the in-loop filters (picture header); bit 4: the first
                                 // of each direction lies on a CTU boundary
 } vvs_params;
@@ -132,6 +133,7 @@ struct Gen {
   std::vector<int32_t> tuOf4;      // per 4x4: TU index
   std::vector<int32_t> cuOf4C, tuOf4C;   // dual tree: the same maps of the chroma tree
   int curTree = VVR_TREE_JOINT;    // tree the CUs being added belong to
+  bool curI = false;               // the CTU being generated lies in an I slice (or the picture is an I picture)
   int modeType = 0;                // mode constraint of the current sub-tree (SCIPU): 0 all, 1 inter only, 2 intra only (local dual tree)
   bool cclmOk = true;              // CCLM allowed for the chroma CUs being added (CU::checkCCLMAllowed, UnitTools.cpp:3439)
   Gen( const vvs_params& p, vvs_buffers& b ) : P( p ), B( b ), rng( p.seed ) {}
@@ -380,7 +382,7 @@ struct Gen {
     const bool treeL = curTree == VVR_TREE_LUMA, treeC = curTree == VVR_TREE_CHROMA;
     cu.qp = (int8_t) std::min( 63, std::max( 0, P.base_qp + (int) rng.u( 7 ) - 3 ) );
     cu.bcw_idx = 2; cu.ref_idx[0] = cu.ref_idx[1] = -1;
-    const bool isI = P.slice_type == 2;
+    const bool isI = curI;
     // (a 4x4 CU is never inter predicted: pred_mode is inferred; it only gets here in 4:0:0 pictures, where no chroma constraint forces a mode)
     const bool intraCand = isI || modeType == 2 || ( w == 4 && h == 4 ) || ( modeType != 1 && std::max( w, h ) <= 64 && rng.p( P.p_intra ) );
     // intra block copy instead of intra prediction (IBC CUs take the place of intra CUs in the coding tree: same size limits)
@@ -733,7 +735,7 @@ struct Gen {
     double ps = s >= 128 ? 0.92 : s >= 64 ? 0.70 : s >= 32 ? 0.45 : s >= 16 ? 0.25 : s >= 8 && minS < 8 ? 0.2 : 0.0;
     ps = std::min( 0.98, ps * P.p_split_scale );
     if( w != h && std::min( w, h ) <= minS ) ps *= 0.5;
-    if( P.slice_type == 2 && s > 64 ) ps = 1.0;   // intra pictures: CUs <= 64
+    if( curI && s > 64 ) ps = 1.0;   // intra pictures / slices: CUs <= 64
     enum { S_NONE, S_QT, S_BV, S_BH, S_TV, S_TH };
     int type = S_NONE;
     if( rng.p( ps ) )
@@ -764,7 +766,7 @@ struct Gen {
     {
       const int area = w * h; const bool bt = type == S_BV || type == S_BH, tt = type == S_TV || type == S_TH;
       if( ( area == 64 && ( type == S_QT || tt ) ) || ( area == 32 && bt ) ) cond = 1;
-      else if( ( area == 64 && bt ) || ( area == 128 && tt ) || ( w == 8 && type == S_BV ) || ( w == 16 && type == S_TV ) ) cond = 1 + ( P.slice_type != 2 ? 1 : 0 );
+      else if( ( area == 64 && bt ) || ( area == 128 && tt ) || ( w == 8 && type == S_BV ) || ( w == 16 && type == S_TV ) ) cond = 1 + ( !curI ? 1 : 0 );
     }
     const int oldMode = modeType, oldTree = curTree;
     bool localDual = false;
@@ -1106,6 +1108,7 @@ struct Gen {
     for( int y = 0; y < H; y += ctu ) for( int x = 0; x < W; x += ctu, a++ )
     {
       B.ctu_first_cu[a] = B.num_cu;
+      curI = P.slice_type == 2 || ( P.num_slices > 1 && ( ( P.intra_slices >> ( sliceOfCtu[a] & 7 ) ) & 1 ) );
       if( !dual ) { split( x, y, ctu, ctu ); continue; }
       // dual tree: the CTU is split down to 64x64 implicitly; every such node carries its luma tree, then its chroma tree.
       // Inside the picture the node is either not split or quad-split in both trees, which keeps CCLM legal (checkCCLMAllowed)

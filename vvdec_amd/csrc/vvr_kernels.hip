@@ -111,8 +111,18 @@ __device__ __forceinline__ const vvr_slice_header* slice_at( const PicDev& pic, 
 }
 __device__ __forceinline__ uint32_t flags_at( const PicDev& pic, int lx, int ly )
 {
-  const vvr_slice_header* s = slice_at( pic, lx, ly );
-  return s ? ( pic.hdr.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | ( s->tool_flags & VVR_SLICE_TOOL_MASK ) : pic.hdr.tool_flags;
+  // (values, never a choice between a pointer into the kernel arguments and one into global memory: that would push the arguments into scratch)
+  uint32_t f = pic.hdr.tool_flags;
+  if( pic.slices ) f = ( f & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | ( slice_at( pic, lx, ly )->tool_flags & VVR_SLICE_TOOL_MASK );
+  return f;
+}
+// deblocking offsets ( beta | tc << 8, both + 64 ) of component c for the slice a luma position lies in
+__device__ __forceinline__ int deblock_offsets_at( const PicDev& pic, int lx, int ly, int c )
+{
+  int beta = c == 0 ? pic.hdr.deblock_beta_offset_div2[0] : c == 1 ? pic.hdr.deblock_beta_offset_div2[1] : pic.hdr.deblock_beta_offset_div2[2];
+  int tc   = c == 0 ? pic.hdr.deblock_tc_offset_div2[0]   : c == 1 ? pic.hdr.deblock_tc_offset_div2[1]   : pic.hdr.deblock_tc_offset_div2[2];
+  if( pic.slices ) { const vvr_slice_header* s = slice_at( pic, lx, ly ); beta = s->deblock_beta_offset_div2[c]; tc = s->deblock_tc_offset_div2[c]; }
+  return ( beta + 64 ) | ( ( tc + 64 ) << 8 );
 }
 __device__ __forceinline__ const vvr_wp_params* wp_at( const PicDev& pic, int lx, int ly )
 {
@@ -1605,7 +1615,7 @@ __device__ __forceinline__ void filter_chroma_pel( pel_t* s, int o, int tc, bool
 __device__ __forceinline__ int tc_value( int idx, int bd ) { const int t = d_db_tc_table[idx]; return bd < 10 ? ( t + ( 1 << ( 9 - bd ) ) ) >> ( 10 - bd ) : t << ( bd - 10 ); }
 
 // luma filtering of the 4-sample edge segment at 4x4 unit (x4, y4)
-__device__ void deblock_luma_segment( const PicDev& pic, const DevPlanes& r, int dir, int x4, int y4, const vvr_lfp& l )
+__device__ __forceinline__ void deblock_luma_segment( const PicDev& pic, const DevPlanes& r, int dir, int x4, int y4, const vvr_lfp& l )
 {
   const vvr_pic_header& H = pic.hdr;
   const int bd = H.bit_depth;
@@ -1626,9 +1636,9 @@ __device__ void deblock_luma_segment( const PicDev& pic, const DevPlanes& r, int
   bool pLarge = lenP > 3, qLarge = lenQ > 3;
   if( dir == 1 && ( y & ( ( 1 << H.log2_ctu ) - 1 ) ) == 0 ) pLarge = false;
   // the offsets of the slice the deblocked CTU belongs to - the CTU that holds the segment, its Q side (LoopFilter.cpp:421,1473)
-  const vvr_slice_header* sl = slice_at( pic, x, y );
-  const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * ( sl ? sl->deblock_tc_offset_div2[0] : H.deblock_tc_offset_div2[0] ) );
-  const int idxB  = clip3( 0, 63, qp + 2 * ( sl ? sl->deblock_beta_offset_div2[0] : H.deblock_beta_offset_div2[0] ) );
+  const int offs = deblock_offsets_at( pic, x, y, 0 );
+  const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * ( ( offs >> 8 ) - 64 ) );
+  const int idxB  = clip3( 0, 63, qp + 2 * ( ( offs & 255 ) - 64 ) );
   const int tc = tc_value( idxTC, bd ), beta = d_db_beta_table[idxB] << ( bd - 8 );
   const int sideThr = ( beta + ( beta >> 1 ) ) >> 3, thrCut = tc * 10;
   const pel_t* s0 = src; const pel_t* s3 = src + 3 * step;
@@ -1695,18 +1705,19 @@ __global__ __launch_bounds__( 256 ) void k_deblock( PicDev pic, DevPlanes r, int
   const int o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
   const bool large = ( l.flags >> 5 ) & 1;
   const bool ctb = dir == 1 && ( cy & ( ( ( 1 << H.log2_ctu ) - 1 ) >> 1 ) ) == 0;
-  const vvr_slice_header* sl = slice_at( pic, x4 * 4, y4 * 4 );      // offsets of the deblocked CTU's slice (LoopFilter.cpp:1637-1638)
+  const int offsC[2] = { deblock_offsets_at( pic, x4 * 4, y4 * 4, 1 ), deblock_offsets_at( pic, x4 * 4, y4 * 4, 2 ) };      // offsets of the deblocked CTU's slice (LoopFilter.cpp:1637-1638)
   for( int c = 0; c < 2; c++ )
   {
     if( !( bS[c] == 2 || ( large && bS[c] == 1 ) ) ) continue;
     pel_t* src = r.p[c + 1] + (size_t) cy * stride + cx;
     const int qp = l.qp[c + 1];
-    const int idxTC = clip3( 0, 65, qp + 2 * ( bS[c] - 1 ) + 2 * ( sl ? sl->deblock_tc_offset_div2[c + 1] : H.deblock_tc_offset_div2[c + 1] ) );
+    const int offs = c ? offsC[1] : offsC[0];
+    const int idxTC = clip3( 0, 65, qp + 2 * ( bS[c] - 1 ) + 2 * ( ( offs >> 8 ) - 64 ) );
     const int tc = tc_value( idxTC, bd );
     bool sw = false;
     if( large )
     {
-      const int idxB = clip3( 0, 63, qp + 2 * ( sl ? sl->deblock_beta_offset_div2[c + 1] : H.deblock_beta_offset_div2[c + 1] ) );
+      const int idxB = clip3( 0, 63, qp + 2 * ( ( offs & 255 ) - 64 ) );
       const int beta = d_db_beta_table[idxB] * ( 1 << ( bd - 8 ) );
       const int dp0 = ctb ? calc_dp_ctb( src, o ) : calc_dp( src, o ), dq0 = calc_dq( src, o );
       const int dp3 = ctb ? calc_dp_ctb( src + step, o ) : calc_dp( src + step, o ), dq3 = calc_dq( src + step, o );

@@ -34,7 +34,7 @@ class Params(C.Structure):
                 ("p_sao", C.c_float), ("p_alf_luma", C.c_float), ("p_alf_chroma", C.c_float), ("p_ccalf", C.c_float),
                 ("p_imv_hpel", C.c_float), ("p_jccr", C.c_float), ("p_mrl", C.c_float), ("p_bdpcm", C.c_float),
                 ("p_affine", C.c_float), ("p_geo", C.c_float), ("p_ciip", C.c_float), ("p_sbtmvp", C.c_float), ("p_bcw", C.c_float), ("p_cclm", C.c_float), ("p_mip", C.c_float), ("p_sbt", C.c_float), ("p_isp", C.c_float), ("dual_tree", C.c_float), ("p_ibc", C.c_float),
-                ("num_slices", C.c_uint8), ("tile_cols", C.c_uint8), ("tile_rows", C.c_uint8), ("wrap_offset", C.c_uint16), ("subpics", C.c_uint8), ("virtual_boundaries", C.c_uint8)]
+                ("num_slices", C.c_uint8), ("tile_cols", C.c_uint8), ("tile_rows", C.c_uint8), ("wrap_offset", C.c_uint16), ("subpics", C.c_uint8), ("intra_slices", C.c_uint8), ("virtual_boundaries", C.c_uint8)]
 
 
 class Buffers(C.Structure):
@@ -136,11 +136,12 @@ def generate(p, alloc=None):
     return d
 
 
-def vary_slices(d, seed, alf_sets=2, wp_sets=2):
+def vary_slices(d, seed, alf_sets=2, wp_sets=2, intra_slices=0):
     """Give the slices of a generated multi-slice description headers of their own (vvr_slice_header): each slice draws whether it uses dependent
     quantisation, LMCS, the explicit scaling lists (of the tools the picture has), its deblocking offsets, and which ALF / weight tables it
     refers to.  The extra tables are rearrangements of the generated one (classes, alternatives and filters rolled; weights of the entries that
-    are `present` changed) so every value stays in the range the syntax allows and the CUs' mc_mode stays valid."""
+    are `present` changed) so every value stays in the range the syntax allows and the CUs' mc_mode stays valid.  intra_slices: the mask the
+    picture was generated with (Params.intra_slices) - those slices are I slices."""
     assert d.ctu_slice is not None, "a description with more than one slice"
     rng = np.random.default_rng(seed)
     n = int(d.ctu_slice.max()) + 1
@@ -157,7 +158,9 @@ def vary_slices(d, seed, alf_sets=2, wp_sets=2):
         sl["tool_flags"][i] = t
         sl["deblock_beta_offset_div2"][i] = rng.integers(-6, 7, 3)
         sl["deblock_tc_offset_div2"][i] = rng.integers(-6, 7, 3)
-        sl["slice_type"][i] = d.hdr.slice_type
+        sl["slice_type"][i] = abi.SLICE_I if (intra_slices >> (i & 7)) & 1 else d.hdr.slice_type
+        if sl["slice_type"][i] == abi.SLICE_I:
+            sl["tool_flags"][i] = int(sl["tool_flags"][i]) & ~abi.TOOL_WP
         sl["alf_set"][i] = i % alf_sets if d.alf_params is not None else 0
         sl["wp_set"][i] = i % wp_sets if d.wp is not None else 0
     d.slices = sl
