@@ -88,7 +88,8 @@ void launch_mc_affine( hipStream_t, const PicDev&, const RefSet&, DevPlanes, con
 void launch_mc_dmvr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int32_t* ) {}
 static int g_lastIntraWg = 0;
 size_t intra_sync_ints( int numUnits, int numItems ) { return ( ( (size_t) 1 + (size_t) numUnits + 63 ) & ~(size_t) 63 ) + (size_t) numItems * 64; }
-void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int, const IntraUnit*, int numUnits, int numWg, int* sync ) { g_lastIntraWg = numWg; g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the kernel's memset touches */ }
+void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int, const IntraUnit*, int numUnits, int ticket0, int ticket1, int numWg, int* sync ) { (void) ticket1; if( ticket0 ) return; g_lastIntraWg = numWg; g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the launcher's memset touches */ }
+void launch_resi_add( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int ) {}
 // the two output-stage kernels have functional stand-ins (a few plain loops with the kernels' contract: packed window; per row the checksum
 // share or the CRC register reached from 0), so that the host half of vvr_read_output / vvr_picture_hash - window geometry, chaining the rows'
 // CRC pieces - is checked against the reference's own functions without a GPU
@@ -138,7 +139,7 @@ __attribute__(( visibility( "default" ) )) int vvt_take_trace( int* dst, int max
 // everything vvr_prepare uploaded for one picture (work lists, tables, the description's arrays): one allocation
 __attribute__(( visibility( "default" ) )) int vvt_blob( const vvr_prepared* q, const void** p, size_t* n ) { if( !q ) return -1; *p = q->blob; *n = q->blobBytes; return 0; }
 // one logical table of a prepared picture (developer regression check of the host glue, tools/host_tables_hash.py): 0..3 MC tile lists (plain, BDOF,
-// DMVR, affine), 4..6 transform block lists by size class, 7 intra-stage blocks, 8 intra-stage units
+// DMVR, affine), 4..6 transform block lists by size class, 7 intra-stage blocks, 8 intra-stage units, 9 residual-add blocks
 __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q, int which, const void** p, size_t* n )
 {
   if( !q ) return -1;
@@ -151,6 +152,7 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
   case 4: case 5: case 6: *p = q->tbItems[which - 4]; *n = sizeof( TbItem ) * q->numTb[which - 4]; break;
   case 7: *p = q->intraItems; *n = sizeof( IntraItem ) * q->numIntra; break;
   case 8: *p = q->units; *n = sizeof( IntraUnit ) * q->numActive; break;
+  case 9: *p = q->resiItems; *n = sizeof( IntraItem ) * q->numResi; break;      // residual-add blocks (k_resi_add)
   default: return -1;
   }
   return 0;
@@ -163,6 +165,8 @@ __attribute__(( visibility( "default" ) )) void vvt_slow_b_pictures( int us ) { 
 __attribute__(( visibility( "default" ) )) void vvt_events_pending( int on ) { g_eventsPending = on; }
 __attribute__(( visibility( "default" ) )) unsigned long long vvt_overtakes( vvr_context* c ) { return c->overtakes; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
+// the stage's launches of a prepared picture: number of luma units that go first when the picture has residual-add blocks (else 0), workgroups of both launches
+__attribute__(( visibility( "default" ) )) void vvt_intra_launches( const vvr_prepared* q, int* numLumaUnits, int* wg0, int* wg1 ) { *numLumaUnits = q->numLumaUnits; *wg0 = q->intraWorkgroups; *wg1 = q->intraWorkgroupsChroma; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_wg( void ) { return g_lastIntraWg; }
 // pretend the lane's flag buffer is small (the product sizes it for ordinary pictures; the growth path needs a picture with more units than that)

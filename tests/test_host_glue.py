@@ -88,8 +88,53 @@ class Ctx:
         items = np.frombuffer((C.c_char * (ITEM_DT.itemsize * ni.value)).from_address(ip.value), ITEM_DT).copy() if ni.value else np.zeros(0, ITEM_DT)
         return units, items
 
+    def resi_tables(self, h):
+        """the residual-add blocks (k_resi_add) of a prepared picture and how the stage is launched: (blocks, luma units that take the first tickets)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        self.L.vvt_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        assert self.L.vvt_table(h, 9, C.byref(p), C.byref(n)) == 0
+        resi = np.frombuffer(C.string_at(p.value, n.value), ITEM_DT).copy() if n.value else np.zeros(0, ITEM_DT)
+        nl, w0, w1 = C.c_int(), C.c_int(), C.c_int()
+        self.L.vvt_intra_launches.argtypes = [C.c_void_p] + [C.c_void_p] * 3
+        self.L.vvt_intra_launches(h, C.byref(nl), C.byref(w0), C.byref(w1))
+        return resi, nl.value, w0.value, w1.value
+
     def close(self):
         self.L.vvr_destroy(self.ctx)
+
+
+def _check_resi_add(d, units, resi, num_luma, wg0, wg1):
+    """the scaled chroma residuals of inter blocks (LMCS chroma residual scaling) are not blocks of the stage's dependency graph: k_resi_add adds
+    them between the luma units and the chroma units - every such transform block is in its list exactly once, and with the list present the
+    luma units hold the first tickets"""
+    h = d.hdr
+    l2, ctusX = h.log2_ctu, (h.width + (1 << h.log2_ctu) - 1) >> h.log2_ctu
+    want = set()
+    if (h.tool_flags & abi.TOOL_LMCS) and (h.tool_flags & abi.TOOL_LMCS_CSCALE) and h.chroma_format:
+        for cu in d.cu:
+            if cu["pred_mode"] != abi.PRED_INTER or not (int(cu["flags"]) & abi.CU_ROOT_CBF):
+                continue
+            if d.slices is not None:
+                f = int(d.slices["tool_flags"][d.ctu_slice[(int(cu["y"]) >> l2) * ctusX + (int(cu["x"]) >> l2)]])
+                if not (f & abi.TOOL_LMCS) or not (f & abi.TOOL_LMCS_CSCALE):
+                    continue
+            if (int(cu["flags"]) & abi.CU_CIIP) and int(cu["w"]) != 4:
+                continue            # blended in the stage itself
+            for t in range(int(cu["first_tu"]), int(cu["first_tu"]) + int(cu["num_tu"])):
+                tu = d.tu[t]
+                for comp in (1, 2):
+                    if (int(tu["comp_mask"]) & (1 << comp)) and (((int(tu["cbf"]) >> comp) & 1) or int(tu["joint_cbcr"])) and (int(tu["w"]) >> 1) * (int(tu["h"]) >> 1) > 4:
+                        want.add((comp, int(tu["x"]) >> 1, int(tu["y"]) >> 1, int(tu["w"]) >> 1, int(tu["h"]) >> 1))
+    got = [(int(r["comp"]) & 3, int(r["x"]), int(r["y"]), 1 << int(r["lw"]), 1 << int(r["lh"])) for r in resi]
+    assert len(got) == len(set(got)) and set(got) == want, "residual-add blocks: %d listed, %d expected" % (len(got), len(want))
+    assert all(int(r["mode"]) == MODE_RESI_ADD and (int(r["flags"]) & 9) == 9 for r in resi)
+    comps = (units["ent"] >> 24) & 3
+    if len(resi):
+        assert (comps[:num_luma] == 0).all() and (comps[num_luma:] != 0).all(), "with residual-add blocks the luma units take the first tickets"
+        assert (num_luma == 0) == (wg0 == 0) and (num_luma == len(units)) == (wg1 == 0) and wg0 <= max(num_luma, 0) and wg1 <= len(units) - num_luma
+    else:
+        assert num_luma == 0 and wg1 == 0
+    return len(got)
 
 
 def _check_tables(d, units, items):
@@ -253,15 +298,16 @@ def test_intra_stage_tables(stub, name, W, H, frames, gop, seed, tools, kw):
     l2 = kw.pop("log2_ctu", 7)
     plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=False)
     ctx = Ctx(stub, W, H, nslots, log2_ctu=l2)
-    checked = 0
+    checked = resi_blocks = 0
     for pl in plans:
         d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
         hnd = ctx.prepare(d)
         units, items = ctx.tables(hnd)
         checked += _check_tables(d, units, items)
+        resi_blocks += _check_resi_add(d, units, *ctx.resi_tables(hnd))
         stub.vvr_free_prepared(ctx.ctx, hnd)
     ctx.close()
-    assert checked > 0
+    assert checked > 0 and (resi_blocks > 0) == bool((tools & abi.TOOL_LMCS_CSCALE) and frames > 1)
 
 
 def test_sync_buffer_grows_with_the_number_of_units(stub):
@@ -463,6 +509,7 @@ def test_slice_headers_in_the_host_glue(stub):
         hnd = ctx.prepare(d)
         units, items = ctx.tables(hnd)
         assert _check_tables(d, units, items) > 0
+        assert _check_resi_add(d, units, *ctx.resi_tables(hnd)) > 0 or pl.slice_type == abi.SLICE_I
         ch = items[((items["comp"] & 3) != 0) & (items["mode"] != 254)]                         # chroma blocks (not IBC): bit 8 = IT_F_CSCALE
         ctus_x = (W + (1 << l2) - 1) >> l2
         sl = d.ctu_slice[(ch["y"].astype(int) >> (l2 - 1)) * ctus_x + (ch["x"].astype(int) >> (l2 - 1))]

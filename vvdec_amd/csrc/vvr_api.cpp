@@ -89,7 +89,7 @@ static double g_wdSum[6]; static uint64_t g_wdJobs; static double g_wdPart[4], g
 
 struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
-const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy", "k_output" };
+const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_resi_add", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy", "k_output" };
 
 // One slot of the upload ring: pinned staging memory and its image in HBM (grown on demand, never freed while the context lives), the device
 // pointers of the picture that currently sits in it, and the pinned landing area of its DMVR delta MVs.
@@ -376,7 +376,14 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
       c->syncBuf[lane] = p; c->syncCap[lane] = need * 2;
     }
   }
-  if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
+  // INTRA stage.  A picture whose inter blocks carry scaled chroma residuals (LMCS): luma units, the residual-add blocks, chroma units
+  if( q->numResi )
+  {
+    if( q->numLumaUnits ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numLumaUnits, q->intraWorkgroups, c->syncBuf[lane] ); } );
+    timed( K_RESI_ADD, [&]{ launch_resi_add( s, q->pic, A, R, q->resiItems, q->numResi ); } );
+    if( q->numActive > q->numLumaUnits ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, q->numLumaUnits, q->numActive, q->intraWorkgroupsChroma, c->syncBuf[lane] ); } );
+  }
+  else if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
   if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)

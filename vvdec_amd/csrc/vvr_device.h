@@ -109,7 +109,6 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
   int                numAlfSets, numWpSets;
   const vvr_subpic*  subpics;        // sub-pictures (NULL: the picture is its only sub-picture) and the sub-picture of every CTU: MC of a CU in a sub-picture
   const uint16_t*    ctuSubpic;      // treated as a picture stays inside it; SAO / ALF of a CTU whose sub-picture says so do not look into other sub-pictures
-  const uint8_t*     interAt;        // per 4x4 luma unit: 1 = covered by an inter CU (LMCS forward mapping of the prediction)
   const uint32_t*    csVpdu;         // LMCS chroma residual scaling, per VPDU: x | y << 13 | hasLeft << 26 | hasAbove << 27 of the luma neighbourhood the factor is averaged over
   vvr_motion*        colMotion;      // collocated motion of the picture (pinned host memory, device-mapped; NULL unless VVR_TOOL_COL_MOTION): the DMVR kernel patches it
   int                colStride;      // records per row = ( w4 + 1 ) / 2
@@ -132,6 +131,7 @@ void launch_output_window( hipStream_t s, const pel_t* src, int stride, int w, i
 void launch_plane_hash_rows( hipStream_t s, const pel_t* plane, int stride, int w, int h, int two, int crcMode, uint32_t* out );   // per row: checksum share / CRC piece
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );
-void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numUnits, int numWorkgroups, int* sync );
+void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numUnits, int ticket0, int ticket1, int numWorkgroups, int* sync );      // the units [ticket0, ticket1)
+void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems );      // scaled chroma residuals of inter blocks (between the luma and the chroma units)
 size_t intra_sync_ints( int numUnits, int numItems );      // ints `sync` has to hold: ticket, unit flags, the blocks' parameter records
 

@@ -8,7 +8,7 @@
 
 static inline size_t alignUp( size_t v, size_t a ) { return ( v + a - 1 ) / a * a; }
 
-enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_OUTPUT, K_NUM };
+enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_RESI_ADD, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_OUTPUT, K_NUM };
 
 // A picture description resident in HBM together with its device work lists: every pointer is a device address inside one blob.
 // Streaming submissions (vvr_submit) use the blob of a ring entry owned by the context; vvr_prepare gives the handle a blob of its own.
@@ -23,6 +23,8 @@ struct vvr_prepared {
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64
   IntraItem* intraItems = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
   int      intraWorkgroups = 0;                            // workgroups the intra stage is launched with (the dependency front they can keep busy)
+  IntraItem* resiItems = nullptr; int numResi = 0;         // scaled chroma residuals of inter blocks (k_resi_add); with them the stage runs as luma units, k_resi_add, chroma units
+  int      numLumaUnits = 0, intraWorkgroupsChroma = 0;    // (the first numLumaUnits entries of `units` are the luma units then)
   double   bytes[K_NUM] = { 0 };                           // algorithmic bytes per kernel
   // ownership (vvr_prepare handles only)
   void*    blob = nullptr; size_t blobBytes = 0;

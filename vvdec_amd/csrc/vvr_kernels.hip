@@ -3608,18 +3608,87 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
 size_t intra_ctx_offset( int numUnits ) { return ( (size_t) 1 + (size_t) numUnits + 63 ) & ~(size_t) 63; }
 size_t intra_sync_ints( int numUnits, int numItems ) { return intra_ctx_offset( numUnits ) + (size_t) numItems * IT_CTX; }
 
-void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numActive, int numWorkgroups, int* sync )
+// =====================================================================================================================
+// k_resi_add — the residual of the inter-predicted chroma blocks of a picture with LMCS chroma residual scaling (DecCu::finishLMCSAndReco,
+// DecCu.cpp:483-520; Reshape::calculateChromaAdjVpduNei, Reshape.cpp:192-274): the factor of the block's VPDU from the reconstructed luma left
+// of and above the VPDU's first CU, the scaled residual (k_itrans stored it) onto the prediction (AreaBuf::scaleSignal, Buffer.cpp:412).
+// Runs between the luma units and the chroma units of the intra stage: every luma sample of the picture is final by then, and the chroma
+// blocks of the intra stage that read these blocks come afterwards - so the blocks need no place in the stage's dependency graph.
+// One wavefront per block.
+// =====================================================================================================================
+__global__ __launch_bounds__( 256 ) void k_resi_add( IntraPic pic, const IntraItem* __restrict__ items, int numItems )
 {
-  if( !numActive ) return;
-  numWorkgroups = std::max( 1, std::min( numWorkgroups, numActive ) );
-  hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + (size_t) numActive ), s );
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + ( threadIdx.x >> 6 );
+  if( q >= numItems ) return;
+  uint4 rec = reinterpret_cast<const uint4*>( items )[q];
+  IntraItem it;
+  { uint32_t* op = reinterpret_cast<uint32_t*>( &it ); op[0] = __builtin_amdgcn_readfirstlane( rec.x ); op[1] = __builtin_amdgcn_readfirstlane( rec.y ); op[2] = __builtin_amdgcn_readfirstlane( rec.z ); op[3] = __builtin_amdgcn_readfirstlane( rec.w ); }
+  const int comp = IT_COMP( it ), bd = pic.bitDepth;
+  const int x0 = it.x, y0 = it.y, lw = it.lw, wh = 1 << ( it.lw + it.lh );
+  pel_t* __restrict__ plane = pic.plane[comp];
+  const pel_t* __restrict__ rs = pic.resi[comp];
+  const int pstride = pic.stride[comp], rstride = pic.rstride[comp];
+  const bool cs = ( it.flags & IT_F_CSCALE ) != 0;
+  const int f = cs ? lmcs_cscale_factor_wave( pic, x0 << 1, y0 << 1, lane ) : 0;
+  if( lw >= 2 && !( x0 & 3 ) )
+  {
+    // four samples of a row per lane (8-byte accesses; x0 and the row strides are multiples of 4 samples - not so for the chroma of
+    // an 8-wide inter CU that is the middle part of a ternary split of 16)
+    for( int i = lane; i < ( wh >> 2 ); i += 64 )
+    {
+      const int x = x0 + ( ( i << 2 ) & ( ( 1 << lw ) - 1 ) ), y = y0 + ( ( i << 2 ) >> lw );
+      const uint2 rv = *reinterpret_cast<const uint2*>( &rs[(size_t) y * rstride + x] );
+      uint2* pp = reinterpret_cast<uint2*>( &plane[(size_t) y * pstride + x] );
+      const uint2 pv = *pp;
+      int r[4] = { (int16_t) ( rv.x & 0xffff ), (int16_t) ( rv.x >> 16 ), (int16_t) ( rv.y & 0xffff ), (int16_t) ( rv.y >> 16 ) };
+      const int pr[4] = { (int) ( pv.x & 0xffff ), (int) ( pv.x >> 16 ), (int) ( pv.y & 0xffff ), (int) ( pv.y >> 16 ) };
+      int o[4];
+      for( int e = 0; e < 4; e++ ) o[e] = clip_pel( pr[e] + ( cs ? lmcs_scale_resi( r[e], f, bd ) : r[e] ), bd );
+      *pp = make_uint2( (uint32_t) o[0] | ( (uint32_t) o[1] << 16 ), (uint32_t) o[2] | ( (uint32_t) o[3] << 16 ) );
+    }
+  }
+  else
+    for( int i = lane; i < wh; i += 64 )
+    {
+      const int x = x0 + ( i & ( ( 1 << lw ) - 1 ) ), y = y0 + ( i >> lw );
+      const int r = (int16_t) rs[(size_t) y * rstride + x];
+      plane[(size_t) y * pstride + x] = (pel_t) clip_pel( plane[(size_t) y * pstride + x] + ( cs ? lmcs_scale_resi( r, f, bd ) : r ), bd );
+    }
+}
+
+static IntraPic intra_pic( const PicDev& pic, const DevPlanes& reco, const DevPlanes& resi )
+{
   IntraPic ip;
   for( int c = 0; c < 3; c++ ) { ip.plane[c] = reco.p[c]; ip.resi[c] = resi.p[c]; ip.stride[c] = reco.stride[c]; ip.rstride[c] = resi.stride[c]; ip.w[c] = reco.w[c]; ip.h[c] = reco.h[c]; }
   ip.csVpdu = pic.csVpdu; ip.lmcs = pic.lmcs; ip.vpdusX = pic.vpdusX; ip.vpduLog2 = pic.vpduLog2; ip.ctusX = pic.ctus_x; ip.log2Ctu = pic.hdr.log2_ctu;
   ip.bitDepth = pic.hdr.bit_depth; ip.width = pic.hdr.width; ip.height = pic.hdr.height; ip.colloc = ( pic.hdr.tool_flags & VVR_TOOL_CCLM_COLLOC ) ? 1 : 0;
-  // the blocks' parameter records live behind the flags (intra_sync_ints): one pass over all blocks writes them
+  return ip;
+}
+
+void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems )
+{
+  if( !numItems ) return;
+  hipLaunchKernelGGL( k_resi_add, dim3( ( numItems + 3 ) / 4 ), dim3( 256 ), 0, s, intra_pic( pic, reco, resi ), items, numItems );
+}
+
+// The units [ticket0, ticket1) of the table.  A picture whose inter blocks carry scaled chroma residuals runs the stage in two launches - the luma
+// units, then (behind k_resi_add) the chroma units: the flags of the first launch stay set, so a chroma unit that names a luma producer finds it done.
+void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numActive, int ticket0, int ticket1,
+                   int numWorkgroups, int* sync )
+{
+  if( !numActive || ticket1 <= ticket0 ) return;
+  numWorkgroups = std::max( 1, std::min( numWorkgroups, ticket1 - ticket0 ) );
+  const IntraPic ip = intra_pic( pic, reco, resi );
   uint32_t* ctx = reinterpret_cast<uint32_t*>( sync ) + intra_ctx_offset( numActive );
-  hipLaunchKernelGGL( k_intra_setup, dim3( ( numItems + 255 ) / 256 ), dim3( 256 ), 0, s, ip, items, numItems, ctx );
+  if( ticket0 == 0 )
+  {
+    hipMemsetAsync( sync, 0, sizeof( int ) * ( 1 + (size_t) numActive ), s );
+    // the blocks' parameter records live behind the flags (intra_sync_ints): one pass over all blocks writes them
+    hipLaunchKernelGGL( k_intra_setup, dim3( ( numItems + 255 ) / 256 ), dim3( 256 ), 0, s, ip, items, numItems, ctx );
+  }
+  else hipMemsetD32Async( (hipDeviceptr_t) sync, ticket0, 1, s );      // the ticket counter of the second launch starts where the first ended
+  numActive = ticket1;
 #ifndef VVR_INTRA_DEV
   hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync );
 #else

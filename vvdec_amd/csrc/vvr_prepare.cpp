@@ -49,15 +49,15 @@ struct PrepScratch
   // = "inside the picture and reconstructed before me" (CodingStructure::getCURestricted, CodingStructure.cpp:464, and the
   // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
   std::vector<int32_t> order;
-  std::vector<uint8_t> intraAt;            // per 4x4 luma unit: covered by an intra CU (1) / a CIIP CU (2)
   std::vector<uint8_t> fastCtu;            // per CTU: every CU is an intra CU.  Its blocks form one unit per component whatever they read from each other, and that unit reads
                                            // from the CTUs left, above-left, above and above-right only: no per-block producer analysis (formUnits)
   // per component and 4x4 luma cell: the block that reconstructs it in the intra stage, stamped with the number of the picture it was written for
   // ( epoch << 22 | block ): the maps are never cleared, an entry of another picture reads as "none"
   std::vector<uint32_t> itemAtE[3];
   uint32_t epoch = 0;
+  // (cells of one CTU lie together: a block and what it reads stay within a few KB)
+  size_t cellIdx( int cx, int cy ) const { const int l = h.log2_ctu - 2, m = ( 1 << l ) - 1; return ( ( (size_t) ( cy >> l ) * ctusX + ( cx >> l ) ) << ( 2 * l ) ) | (size_t) ( ( cy & m ) << l ) | (size_t) ( cx & m ); }
   int32_t itemAtGet( int k, size_t cell ) const { const uint32_t v = itemAtE[k][cell]; return ( v >> 22 ) == epoch ? (int32_t) ( v & 0x3fffffu ) : -1; }
-  std::vector<uint8_t> interAtV;
   std::vector<UnitH> units, unitsTmp;
   // LMCS chroma residual scaling: per VPDU the luma neighbourhood its factor is averaged over (Reshape::calculateChromaAdjVpduNei,
   // Reshape.cpp:192-274): left column / above row of the CU at the VPDU origin, where that neighbour precedes it in decoding order
@@ -65,7 +65,8 @@ struct PrepScratch
   std::vector<std::pair<uint32_t, uint32_t>> csProdRange;   // per VPDU: the luma blocks that produce that neighbourhood (range of csProdPool), looked up on first use
   std::vector<uint32_t> csProdPool;
   std::vector<IntraUnit> unitsDev;
-  int intraWorkgroups = 0;
+  int intraWorkgroups = 0, intraWorkgroupsChroma = 0, numLumaUnits = 0;
+  std::vector<IntraItem> resiAdd;          // residual-add blocks (inter chroma blocks with LMCS chroma residual scaling): k_resi_add, outside the stage's dependency graph
   size_t intraChunk = (size_t) 1 << 30;      // blocks per unit of a long intra cluster (formUnits); off: measured, no gain
   // union-find / grouping scratch
   std::vector<uint32_t> parent, newIdx, firstOf, perm, inv, unitCount, unitOfItem[3];
@@ -74,7 +75,7 @@ struct PrepScratch
   // ---- layout of the H2D image
   std::vector<Part> parts;
   size_t total = 0, numDirect = 0;          // parts [0, numDirect) are copied from the caller's pinned arrays
-  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iSlices, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iInterAt, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iUnits;
+  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iSlices, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iResi, iUnits;
 
   void begin( const vvr_picture* pic )
   {
@@ -100,11 +101,13 @@ struct PrepScratch
     vpduLog2 = std::min<int>( 6, h.log2_ctu ); vpdusX = ( h.width + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2; vpdusY = ( h.height + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2;
     mc.clear(); mcBdof.clear(); mcDmvr.clear(); mcAff.clear(); affMv.clear(); numDmvr = 0;
     for( int k = 0; k < 3; k++ ) { tb[k].clear(); intra[k].clear(); itemH[k].clear(); prodPool[k].clear(); }
-    intraAll.clear(); units.clear(); unitsDev.clear(); csVpduV.clear(); interAtV.clear();
+    resiAdd.clear(); intraAll.clear(); units.clear(); unitsDev.clear(); csVpduV.clear();
     ctuStartV.assign( 3 * (size_t) ( numCtu + 1 ), 0 );
     for( double& b : bytes ) b = 0;
   }
 
+  // `order` holds the cells of ONE CTU (both channel types): it is only ever asked about the CTU being analysed
+  size_t orderIdx( int chn, int lx, int ly ) const { const int m = ( 1 << ( h.log2_ctu - 2 ) ) - 1; return ( ( (size_t) chn << ( h.log2_ctu - 2 ) | (size_t) ( ( ly >> 2 ) & m ) ) << ( h.log2_ctu - 2 ) ) | (size_t) ( ( lx >> 2 ) & m ); }
   int unitAvail( int chn, int x, int y, int32_t cur ) const
   {
     const int cs = chn ? 1 : 0, lx = x << cs, ly = y << cs;
@@ -114,9 +117,25 @@ struct PrepScratch
     // getCURestricted, CodingStructure.cpp:464).
     const uint32_t c = (uint32_t) ( ( ly >> h.log2_ctu ) * ctusX + ( lx >> h.log2_ctu ) );
     if( c != curCtuIdx ) return c < curCtuIdx && sameSliceAndTile( c, curCtuIdx );
-    return order[(size_t) chn * w4 * h4 + ( ly >> 2 ) * w4 + ( lx >> 2 )] < cur;
+    return order[orderIdx( chn, lx, ly )] < cur;
   }
 
+  // the luma blocks of the intra stage that produce what the chroma scaling factor of VPDU `vp` is averaged over (they all precede the VPDU's
+  // first CU in decoding order and are the same for every chroma block of the VPDU: looked up once)
+  void lookUpCsProducers( size_t vp )
+  {
+    const uint32_t d = csVpduV[vp];
+    const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff, n = 1 << vpduLog2;
+    const uint32_t start = (uint32_t) csProdPool.size();
+    auto look = [&]( int lx, int ly )
+    {
+      const int32_t id = itemAtGet( 0, cellIdx( lx >> 2, ly >> 2 ) );
+      if( id >= 0 && std::find( csProdPool.begin() + start, csProdPool.end(), (uint32_t) id ) == csProdPool.end() ) csProdPool.push_back( (uint32_t) id );
+    };
+    if( ( d >> 26 ) & 1 ) for( int k = 0; k < n; k += 4 ) look( xPos - 1, std::min( yPos + k, (int) h.height - 1 ) );
+    if( ( d >> 27 ) & 1 ) for( int k = 0; k < n; k += 4 ) look( std::min( xPos + k, (int) h.width - 1 ), yPos - 1 );
+    csProdRange[vp] = std::make_pair( start, (uint32_t) csProdPool.size() - start );
+  }
   // the switches of the slice CTU `c` lies in
   uint32_t flagsOfCtu( uint32_t c ) const { return ( p->slices && p->ctu_slice ) ? ( h.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | ( p->slices[p->ctu_slice[c]].tool_flags & VVR_SLICE_TOOL_MASK ) : h.tool_flags; }
   bool cscaleCtu( uint32_t c ) const { const uint32_t f = flagsOfCtu( c ); return cscale && ( f & VVR_TOOL_LMCS ) && ( f & VVR_TOOL_LMCS_CSCALE ); }
@@ -149,15 +168,17 @@ void vvr_scratch_warm( PrepScratch* S, const vvr_config& cfg )
   const size_t w4 = ( (size_t) cfg.max_width + 3 ) >> 2, h4 = ( (size_t) cfg.max_height + 3 ) >> 2, cells = w4 * h4;
   auto warm = [&]( auto& v, size_t n ) { if( v.capacity() < n ) { v.resize( n ); memset( (void*) v.data(), 0, n * sizeof( v[0] ) ); } v.clear(); };
   const size_t items = cells / 8 + 64;
+  const int l2 = cfg.log2_ctu ? cfg.log2_ctu : 7;
+  const size_t blocked = ( ( ( (size_t) cfg.max_width + ( 1u << l2 ) - 1 ) >> l2 ) * ( ( (size_t) cfg.max_height + ( 1u << l2 ) - 1 ) >> l2 ) ) << ( 2 * ( l2 - 2 ) );      // cells of whole CTUs (itemAtE)
   warm( S->mc, cells / 16 + 64 ); warm( S->mcBdof, cells / 32 + 64 ); warm( S->mcDmvr, cells / 32 + 64 ); warm( S->mcAff, cells / 32 + 64 );
   warm( S->affMv, cells / 4 + 64 );
   for( int k = 0; k < 3; k++ )
   {
     warm( S->tb[k], items ); warm( S->intra[k], items ); warm( S->intraTmp[k], items ); warm( S->itemH[k], items ); warm( S->prodPool[k], 2 * items );
-    warm( S->unitOfItem[k], items ); warm( S->itemAtE[k], cells );
+    warm( S->unitOfItem[k], items ); warm( S->itemAtE[k], blocked );
   }
   warm( S->itemHTmp, items ); warm( S->intraAll, 3 * items );
-  warm( S->order, 2 * cells ); warm( S->intraAt, cells ); warm( S->interAtV, cells + 8 );
+  warm( S->order, 2 * 32 * 32 );
   warm( S->parent, items ); warm( S->newIdx, items ); warm( S->perm, items ); warm( S->inv, items ); warm( S->unitCount, items );
   warm( S->unitOfRoot, items ); warm( S->target, items ); warm( S->csProdPool, items ); warm( S->unitsDev, items / 8 );
   S->units.reserve( items / 8 ); S->unitsTmp.reserve( items / 8 );
@@ -430,15 +451,14 @@ int PrepScratch::beginMaps()
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
   allIntraCus = h.slice_type == 2;
   for( uint32_t i = 0; i < p->num_cu && allIntraCus; i++ ) allIntraCus = p->cu[i].pred_mode == VVR_PRED_INTRA;
-  intraAt.clear();
   fastCtu.assign( (size_t) numCtu, 0 );
   if( anyIntra )
   {
     const size_t cells = (size_t) w4 * h4;
-    if( order.size() != cells * 2 ) order.assign( cells * 2, 0x7fffffff );
-    intraAt.assign( cells, 0 );
+    order.assign( (size_t) 2 << ( 2 * ( h.log2_ctu - 2 ) ), 0x7fffffff );
     epoch = ( epoch + 1 ) & 0x3ff;
-    for( int k = 0; k < ncomp; k++ ) if( itemAtE[k].size() != cells || epoch == 0 ) itemAtE[k].assign( cells, 0xffffffffu );
+    const size_t blocked = (size_t) numCtu << ( 2 * ( h.log2_ctu - 2 ) );
+    for( int k = 0; k < ncomp; k++ ) if( itemAtE[k].size() != blocked || epoch == 0 ) itemAtE[k].assign( blocked, 0xffffffffu );
     if( epoch == 0 ) epoch = 1;
   }
   if( cscale )
@@ -464,13 +484,6 @@ int PrepScratch::mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string&
   for( uint32_t i = i0; i < i1; i++ )
   {
     const vvr_cu& cu = p->cu[i];
-    // 1: intra CU, 2: CIIP CU (inter prediction blended with planar intra in the intra stage, DecCu.cpp:137-140,453-456)
-    const bool ciip = cu.pred_mode == VVR_PRED_INTER && ( cu.flags & VVR_CU_CIIP );
-    if( cu.pred_mode == VVR_PRED_INTRA || ciip )
-    {
-      const int cw = ( cu.w + 3 ) >> 2;
-      for( int y = cu.y >> 2; y < ( cu.y + cu.h + 3 ) >> 2; y++ ) memset( &intraAt[(size_t) y * w4 + ( cu.x >> 2 )], ciip ? 2 : 1, cw );
-    }
     for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
     {
       const vvr_tu& tu = p->tu[t];
@@ -481,16 +494,15 @@ int PrepScratch::mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string&
         int ax = tu.x, ay = tu.y, aw = tu.w, ah = tu.h;
         if( chn == 1 && cu.isp_mode ) { ax = cu.x; ay = cu.y; aw = cu.w; ah = cu.h; }      // ISP: the unsplit chroma blocks sit in the last TU
         const int x0 = ax >> 2, x1 = std::min( ( ax + aw + 3 ) >> 2, w4 ), y1 = std::min( ( ay + ah + 3 ) >> 2, h4 );
-        int32_t* base = &order[(size_t) chn * cells];
-        for( int y = ay >> 2; y < y1; y++ ) std::fill( base + (size_t) y * w4 + x0, base + (size_t) y * w4 + x1, (int32_t) t );
+        for( int y = ay >> 2; y < y1; y++ ) { int32_t* row = &order[orderIdx( chn, x0 << 2, y << 2 )]; std::fill( row, row + ( x1 - x0 ), (int32_t) t ); }
       }
     }
   }
   if( cscale )
   {
     // the luma CU that covers a cell of this CTU: owner of the transform block recorded there
-    const int32_t* ord0 = order.data();
-    auto cuAt = [&]( int x, int y ) -> int32_t { const int32_t t = ord0[(size_t) ( y >> 2 ) * w4 + ( x >> 2 )]; return ( t < 0 || (uint32_t) t >= p->num_tu ) ? -1 : (int32_t) p->tu[t].cu; };
+    // (asked about positions of this CTU only: the origin of a VPDU, and its left / above neighbour where that lies in the same CTU)
+    auto cuAt = [&]( int x, int y ) -> int32_t { const int32_t t = order[orderIdx( 0, x, y )]; return ( t < 0 || (uint32_t) t >= p->num_tu ) ? -1 : (int32_t) p->tu[t].cu; };
     const int cx = (int) ( ctuIdx % ctusX ) << h.log2_ctu, cy = (int) ( ctuIdx / ctusX ) << h.log2_ctu, nv = 1 << ( h.log2_ctu - vpduLog2 );
     for( int jy = 0; jy < nv; jy++ ) for( int jx = 0; jx < nv; jx++ )
     {
@@ -552,6 +564,18 @@ int PrepScratch::buildWorkLists( std::string& err )
           const bool isCsInter = cscaleCtu( ctuOfCu ) && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
           if( cu.pred_mode != VVR_PRED_INTRA && !isCiip && !isCsInter && !isIbcCu ) continue;
           if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
+          if( isCsInter )
+          {
+            // the scaled residual of an inter chroma block is added by k_resi_add between the luma and the chroma units of the stage: every luma
+            // sample its factor is averaged over is final by then, and the chroma blocks that read its samples come later - no place in the
+            // dependency graph, no producer analysis
+            IntraItem it; memset( &it, 0, sizeof( it ) );
+            it.tu = t; it.comp = (uint8_t) comp; it.x = (uint16_t) ( tu.x >> 1 ); it.y = (uint16_t) ( tu.y >> 1 ); it.lw = (uint8_t) ilog2i( tu.w >> 1 ); it.lh = (uint8_t) ilog2i( tu.h >> 1 );
+            it.mode = IT_MODE_RESI_ADD; it.flags = IT_F_RESI | IT_F_CSCALE;
+            resiAdd.push_back( it );
+            bytes[K_INTRA] += (double) ( tu.w >> 1 ) * ( tu.h >> 1 ) * 4 + sizeof( IntraItem );
+            continue;
+          }
           const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
           // intra sub-partitions: luma partitions are blocks of their own that share the reference line of the whole CU
           // (initIntraPatternChTypeISP, IntraPrediction.cpp:966); partitions narrower than 4 are predicted in pairs (DecCu.cpp:333-371):
@@ -642,7 +666,7 @@ int PrepScratch::buildWorkLists( std::string& err )
             {
               const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
               if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
-              const int32_t d = itemAtGet( k, (size_t) ( ly >> 2 ) * w4 + ( lx >> 2 ) );
+              const int32_t d = itemAtGet( k, cellIdx( lx >> 2, ly >> 2 ) );
               if( d < 0 ) return;
               const uint32_t key = ( (uint32_t) k << 28 ) | (uint32_t) d;
               if( key == lastKey || ( k == comp && (uint32_t) d == myId ) ) return;      // (neighbouring cells mostly belong to the same block)
@@ -682,20 +706,7 @@ int PrepScratch::buildWorkLists( std::string& err )
               // that produce it are the same for every chroma block of the VPDU and all precede the VPDU's first CU in decoding order, so
               // they are looked up once per VPDU
               const size_t vp = (size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 );
-              if( csProdRange[vp].first == 0xffffffffu )
-              {
-                const uint32_t d = csVpduV[vp];
-                const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff, n = 1 << vpduLog2;
-                const uint32_t start = (uint32_t) csProdPool.size();
-                auto look = [&]( int lx, int ly )
-                {
-                  const int32_t id = itemAtGet( 0, (size_t) ( ly >> 2 ) * w4 + ( lx >> 2 ) );
-                  if( id >= 0 && std::find( csProdPool.begin() + start, csProdPool.end(), (uint32_t) id ) == csProdPool.end() ) csProdPool.push_back( (uint32_t) id );
-                };
-                if( ( d >> 26 ) & 1 ) for( int k = 0; k < n; k += 4 ) look( xPos - 1, std::min( yPos + k, (int) h.height - 1 ) );
-                if( ( d >> 27 ) & 1 ) for( int k = 0; k < n; k += 4 ) look( std::min( xPos + k, (int) h.width - 1 ), yPos - 1 );
-                csProdRange[vp] = std::make_pair( start, (uint32_t) csProdPool.size() - start );
-              }
+              if( csProdRange[vp].first == 0xffffffffu ) lookUpCsProducers( vp );
               for( uint32_t q = csProdRange[vp].first; q < csProdRange[vp].first + csProdRange[vp].second; q++ )
               {
                 const uint32_t key = csProdPool[q];          // (component 0)
@@ -716,7 +727,7 @@ int PrepScratch::buildWorkLists( std::string& err )
             if( !allIntraCus )
             {
               const int cx0 = ( x0 << cs ) >> 2, cx1 = std::min( ( ( ( x0 + w ) << cs ) + 3 ) >> 2, w4 ), cy1 = std::min( ( ( ( y0 + hh ) << cs ) + 3 ) >> 2, h4 );
-              for( int cy = ( y0 << cs ) >> 2; cy < cy1; cy++ ) std::fill( &itemAtE[comp][(size_t) cy * w4 + cx0], &itemAtE[comp][(size_t) cy * w4 + std::max( cx0, cx1 )], ( epoch << 22 ) | myId );
+              for( int cy = ( y0 << cs ) >> 2; cy < cy1; cy++ ) { uint32_t* row = &itemAtE[comp][cellIdx( cx0, cy )]; std::fill( row, row + std::max( 0, cx1 - cx0 ), ( epoch << 22 ) | myId ); }
             }
           }
           IH.pn = (uint32_t) pool.size() - IH.p0;
@@ -734,12 +745,29 @@ int PrepScratch::buildWorkLists( std::string& err )
       const bool af = cu.mc_mode == VVR_MC_AFFINE;
       std::vector<McItem>& list = dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc;
       const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
+      // one record per tile: what the tiles of a CU share is filled once
+      McItem base; memset( &base, 0, sizeof( base ) );
+      base.flags = sbt ? MC_ITEM_SUBBLOCK : 0; base.cu = i;
+      const bool plain = !af && !dm;
+      if( af && ( h.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) ) base.mv[0][0] = -1;      // the kernel spans the sub-block MVs from the control points itself
+      if( plain )
+      {
+        // everything k_mc needs about the motion of the tile
+        base.ref[0] = cu.ref_idx[0]; base.ref[1] = cu.ref_idx[1];
+        for( int l = 0; l < 2; l++ ) { base.mv[l][0] = cu.mv[l][0][0]; base.mv[l][1] = cu.mv[l][0][1]; }
+        base.clipX = cu.x; base.clipY = cu.y;
+        base.bcw = cu.bcw_idx;
+        base.flags |= ( cu.mc_mode == VVR_MC_UNI ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 );
+      }
+      const size_t first = list.size();
+      list.resize( first + (size_t) ( ( cu.w + ts - 1 ) / ts ) * ( ( cu.h + ts - 1 ) / ts ) );
+      McItem* out = &list[first];
       for( int y = 0; y < cu.h; y += ts ) for( int x = 0; x < cu.w; x += ts )
       {
-        McItem it; memset( &it, 0, sizeof( it ) );
-        it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y ); it.flags = sbt ? MC_ITEM_SUBBLOCK : 0; it.cu = i;
-        if( af && ( h.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) ) it.mv[0][0] = -1;      // the kernel spans the sub-block MVs from the control points itself
-        else if( af )
+        McItem& it = *out++;
+        it = base;
+        it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) std::min( ts, cu.w - x ); it.h = (uint8_t) std::min( ts, cu.h - y );
+        if( af && !( h.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) )
         {
           // the motion of the tile's 4x4 sub-blocks (MotionInfo of the affine CU, filled by PU::setAllAffineMv, UnitTools.cpp:3005): the kernel reads
           // them from a compact array, 4 x 4 entries per tile, so the motion field itself never crosses PCIe
@@ -748,29 +776,21 @@ int PrepScratch::buildWorkLists( std::string& err )
           affMv.resize( base + 16 );
           for( int sy = 0; sy < it.h >> 2; sy++ ) memcpy( &affMv[base + 4 * sy], &p->motion[(size_t) ( ( it.y >> 2 ) + sy ) * w4 + ( it.x >> 2 )], sizeof( vvr_motion ) * ( it.w >> 2 ) );
         }
-        else if( !dm )
+        else if( sbt )
         {
-          // everything k_mc needs about the motion of the tile
-          bool uni = cu.mc_mode == VVR_MC_UNI;
-          it.ref[0] = cu.ref_idx[0]; it.ref[1] = cu.ref_idx[1];
-          for( int l = 0; l < 2; l++ ) { it.mv[l][0] = cu.mv[l][0][0]; it.mv[l][1] = cu.mv[l][0][1]; }
-          it.clipX = cu.x; it.clipY = cu.y;
-          if( sbt )
-          {
-            // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the motion of the 8x8 sub-block from the motion field, the identical-motion
-            // shortcut (xCheckIdenticalMotion :404, not with weighted bi-prediction :408) decided per sub-block, clipped at its own position
-            const vvr_motion& m = p->motion[(size_t) ( it.y >> 2 ) * w4 + ( it.x >> 2 )];
-            for( int l = 0; l < 2; l++ ) { it.ref[l] = m.ref_idx[l]; it.mv[l][0] = m.mv[l][0]; it.mv[l][1] = m.mv[l][1]; }
-            const bool two = it.ref[0] >= 0 && it.ref[1] >= 0;
-            uni = !two || ( h.ref_poc[0][it.ref[0]] == h.ref_poc[1][it.ref[1]] && it.mv[0][0] == it.mv[1][0] && it.mv[0][1] == it.mv[1][1] && !( wpOn && ( flagsOfCtu( ctuAt( it.x, it.y ) ) & VVR_TOOL_WP ) ) );
-            it.clipX = it.x; it.clipY = it.y;
-          }
-          it.bcw = cu.bcw_idx;
-          it.flags |= ( uni ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 );
+          // SbTMVP (xSubPuMC, InterPrediction.cpp:438): the motion of the 8x8 sub-block from the motion field, the identical-motion
+          // shortcut (xCheckIdenticalMotion :404, not with weighted bi-prediction :408) decided per sub-block, clipped at its own position
+          const vvr_motion& m = p->motion[(size_t) ( it.y >> 2 ) * w4 + ( it.x >> 2 )];
+          for( int l = 0; l < 2; l++ ) { it.ref[l] = m.ref_idx[l]; it.mv[l][0] = m.mv[l][0]; it.mv[l][1] = m.mv[l][1]; }
+          const bool two = it.ref[0] >= 0 && it.ref[1] >= 0;
+          const bool uni = !two || ( h.ref_poc[0][it.ref[0]] == h.ref_poc[1][it.ref[1]] && it.mv[0][0] == it.mv[1][0] && it.mv[0][1] == it.mv[1][1] && !( wpOn && ( flagsOfCtu( ctuAt( it.x, it.y ) ) & VVR_TOOL_WP ) ) );
+          it.clipX = it.x; it.clipY = it.y;
+          it.flags = (uint16_t) ( ( it.flags & ~MC_ITEM_UNI ) | ( uni ? MC_ITEM_UNI : 0 ) );
         }
-        list.push_back( it );
-        const double smp = (double) it.w * it.h * ( ncomp == 3 ? 1.5 : 1.0 );
-        bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += smp * 2 * nla + smp * 2 + sizeof( McItem ) + ( dm ? 8 : 0 ) + ( af ? it.w * it.h / 16.0 * sizeof( vvr_motion ) : 0 );
+      }
+      {
+        const double smp = (double) cu.w * cu.h * ( ncomp == 3 ? 1.5 : 1.0 ), nt = (double) ( list.size() - first );
+        bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += smp * 2 * nla + smp * 2 + nt * ( sizeof( McItem ) + ( dm ? 8 : 0 ) ) + ( af ? cu.w * cu.h / 16.0 * sizeof( vvr_motion ) : 0 );
       }
       if( dm ) numDmvr = std::max<uint32_t>( numDmvr, cu.dmvr_off + ( ( cu.w + 15 ) / 16 ) * ( ( cu.h + 15 ) / 16 ) );
       bytes[K_MC] += sizeof( vvr_cu );
@@ -1138,6 +1158,11 @@ int PrepScratch::emitUnitTable( std::string& err )
         return units[a].rank != units[b].rank ? units[a].rank < units[b].rank : ka < kb;
       } );
     }
+    // with residual-add blocks in the picture the stage runs in two launches, luma units then chroma units (k_resi_add between them): the luma
+    // units take the first tickets; the order inside both parts stays (luma units never wait for chroma units)
+    numLumaUnits = 0;
+    const bool twoLaunches = !resiAdd.empty();
+    if( twoLaunches ) numLumaUnits = (int) ( std::stable_partition( perm.begin(), perm.end(), [&]( uint32_t u ) { return units[u].comp == 0; } ) - perm.begin() );
     for( size_t t = 0; t < perm.size(); t++ ) inv[perm[t]] = (uint32_t) t;
     for( auto& u : units ) for( uint32_t d : u.deps ) units[d].waited = true;
     {
@@ -1147,21 +1172,28 @@ int PrepScratch::emitUnitTable( std::string& err )
       // picture of isolated intra blocks (B picture: chains a few units deep) gets hundreds.
       std::vector<uint32_t>& path = unitCount;            // (reused below) longest chain ending in the unit, in blocks; tickets are a topological order
       path.assign( units.size(), 0 );
-      uint64_t work = 0; uint32_t critical = 1;
-      for( size_t t = 0; t < perm.size(); t++ )
-      {
-        const UnitH& u = units[perm[t]];
-        const uint32_t cost = 1 + ( u.i1 - u.i0 );
-        uint32_t before = 0;
-        for( uint32_t d : u.deps ) before = std::max( before, path[inv[d]] );
-        path[t] = before + cost;
-        work += cost; critical = std::max( critical, path[t] );
-      }
       uint64_t mult = 2;
 #if defined( VVR_WATCHDOG ) || defined( VVR_DEV_ENV )
       if( const char* e = getenv( "VVR_INTRA_WG_MULT" ) ) mult = (uint64_t) atoi( e );      // developer build: sweep
 #endif
-      intraWorkgroups = (int) std::min<uint64_t>( units.size(), std::max<uint64_t>( 32, mult * ( ( work + critical - 1 ) / critical ) ) );
+      // (two launches: each part on its own - the luma units are finished when the chroma units start)
+      auto workgroupsOf = [&]( size_t t0, size_t t1 ) -> int
+      {
+        if( t1 <= t0 ) return 0;
+        uint64_t work = 0; uint32_t critical = 1;
+        for( size_t t = t0; t < t1; t++ )
+        {
+          const UnitH& u = units[perm[t]];
+          const uint32_t cost = 1 + ( u.i1 - u.i0 );
+          uint32_t before = 0;
+          for( uint32_t d : u.deps ) if( inv[d] >= t0 ) before = std::max( before, path[inv[d]] );
+          path[t] = before + cost;
+          work += cost; critical = std::max( critical, path[t] );
+        }
+        return (int) std::min<uint64_t>( t1 - t0, std::max<uint64_t>( 32, mult * ( ( work + critical - 1 ) / critical ) ) );
+      };
+      intraWorkgroups = workgroupsOf( 0, twoLaunches ? (size_t) numLumaUnits : perm.size() );
+      intraWorkgroupsChroma = twoLaunches ? workgroupsOf( (size_t) numLumaUnits, perm.size() ) : 0;
     }
     unitCount.assign( 3 * (size_t) numCtu, 0 );
     for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
@@ -1172,11 +1204,7 @@ int PrepScratch::emitUnitTable( std::string& err )
       IntraUnit& d = unitsDev[t]; memset( &d, 0, sizeof( d ) );
       // bit 31: the unit is the whole (component, CTU) and every sample of the CTU is intra, so the kernel only stages the reference
       // border and writes the CTU back with 16-byte stores
-      bool all = unitCount[(size_t) u.comp * numCtu + u.ctu] == 1;
-      {
-        const int ctu4 = 1 << ( h.log2_ctu - 2 ), ux = (int) ( u.ctu % ctusX ) * ctu4, uy = (int) ( u.ctu / ctusX ) * ctu4;
-        for( int y = uy; y < std::min( uy + ctu4, h4 ) && all; y++ ) for( int x = ux; x < std::min( ux + ctu4, w4 ); x++ ) if( intraAt[(size_t) y * w4 + x] != 1 ) { all = false; break; }
-      }
+      const bool all = unitCount[(size_t) u.comp * numCtu + u.ctu] == 1 && fastCtu[u.ctu];      // (fastCtu: every CU of the CTU is an intra CU)
       d.ent = ( u.comp << 24 ) | u.ctu | ( u.hasCs ? 0x20000000u : 0 ) | ( u.waited ? 0x40000000u : 0 ) | ( all ? 0x80000000u : 0 );
       d.i0 = itemMap[u.comp][u.i0]; d.i1 = itemMap[u.comp][u.i1]; d.iA = itemMap[u.comp][u.iA];
       d.bbox = (uint32_t) u.bb.y0 | ( (uint32_t) u.bb.y1 << 8 ) | ( (uint32_t) u.bb.c0 << 16 ) | ( (uint32_t) u.bb.c1 << 24 );
@@ -1229,7 +1257,6 @@ void PrepScratch::layout( PinnedRanges* pinned )
   }
   iCtuTile = p->ctu_tile ? add( p->ctu_tile, sizeof( uint16_t ) * numCtu ) : -1;
   iWp = wpOn ? add( p->wp, sizeof( vvr_wp_params ) * std::max<uint32_t>( 1, p->num_wp_sets ) ) : -1;
-  iInterAt = -1;
   iCsVpdu = cscale ? add( csVpduV.data(), sizeof( uint32_t ) * csVpduV.size() ) : -1;
   iMc = add( mc.data(), sizeof( McItem ) * mc.size() );
   iMcB = add( mcBdof.data(), sizeof( McItem ) * mcBdof.size() );
@@ -1237,6 +1264,7 @@ void PrepScratch::layout( PinnedRanges* pinned )
   iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
   for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
   iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
+  iResi = add( resiAdd.data(), sizeof( IntraItem ) * resiAdd.size() );
   iUnits = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
 }
 
@@ -1315,7 +1343,6 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   d.ctuSlice = (const uint16_t*) at( S.iCtuSlice ); d.ctuTile = (const uint16_t*) at( S.iCtuTile );
   d.slices = (const vvr_slice_header*) at( S.iSlices ); d.numAlfSets = (int) std::max<uint32_t>( 1, p->num_alf_sets ); d.numWpSets = (int) std::max<uint32_t>( 1, p->num_wp_sets );
   d.subpics = (const vvr_subpic*) at( S.iSubpics ); d.ctuSubpic = (const uint16_t*) at( S.iCtuSubpic );
-  d.interAt = (const uint8_t*) at( S.iInterAt );
   d.csVpdu = (const uint32_t*) at( S.iCsVpdu ); d.vpdusX = S.vpdusX; d.vpduLog2 = S.vpduLog2;
   q.mcItems = (McItem*) at( S.iMc ); q.numMc = (int) S.mc.size();
   q.bdofItems = (McItem*) at( S.iMcB ); q.numBdofItems = (int) S.mcBdof.size();
@@ -1325,5 +1352,6 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   for( int k = 0; k < 3; k++ ) { q.tbItems[k] = (TbItem*) at( S.iTb[k] ); q.numTb[k] = (int) S.tb[k].size(); }
   q.intraItems = (IntraItem*) at( S.iIntra ); q.numIntra = (int) S.intraAll.size();
   q.units = (IntraUnit*) at( S.iUnits ); q.numActive = (int) S.unitsDev.size(); q.intraWorkgroups = S.intraWorkgroups;
+  q.resiItems = (IntraItem*) at( S.iResi ); q.numResi = (int) S.resiAdd.size(); q.numLumaUnits = S.numLumaUnits; q.intraWorkgroupsChroma = S.intraWorkgroupsChroma;
   memcpy( q.bytes, S.bytes, sizeof( q.bytes ) );
 }
