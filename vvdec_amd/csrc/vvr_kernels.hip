@@ -208,6 +208,30 @@ template<int NT>
 __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg& g, const pel_t* __restrict__ ref, int stride, int pw, int ph, int tid )
 {
   const int col = tid & 31, row0 = tid >> 5;
+  // The window of nearly every tile lies inside the picture (the sub-picture): no coordinate is clamped, a lane walks down its column with one
+  // address increment per row.  (The segment record sits in LDS: what decides the branch is made uniform first.)
+  const int ux0 = __builtin_amdgcn_readfirstlane( g.x0 ), uy0 = __builtin_amdgcn_readfirstlane( g.y0 ), uww = __builtin_amdgcn_readfirstlane( g.ww ), uwh = __builtin_amdgcn_readfirstlane( g.wh );
+  const int plain = __builtin_amdgcn_readfirstlane( ( g.wrapOff | g.padOff | g.shX | g.shY ) == 0 && g.cw == g.ww && g.chh == g.wh
+                                                    && g.x0 >= g.bx0 && g.x0 + g.ww - 1 <= g.bx1 && g.y0 >= g.by0 && g.y0 + g.wh - 1 <= g.by1 );
+  if( plain )
+  {
+    if( col < uww )
+    {
+      constexpr int RS = NT / 32;            // rows one pass of the wavefront(s) covers
+      const pel_t* __restrict__ rp = ref + (size_t) uy0 * stride + ux0 + col;
+      pel_t* wp = win + col;
+      const int last = uwh - 1 - ( ( uwh - 1 - row0 ) % RS );      // last row of this lane's parity (the tail repeats it: same value to the same place)
+      for( int yb = row0; yb < uwh; yb += 4 * RS )
+      {
+        int yy[4]; pel_t v[4];
+#pragma unroll
+        for( int u = 0; u < 4; u++ ) { yy[u] = min( yb + u * RS, last ); v[u] = rp[yy[u] * stride]; }
+#pragma unroll
+        for( int u = 0; u < 4; u++ ) wp[yy[u] * wst] = v[u];
+      }
+    }
+    return;
+  }
   if( col < g.ww )
   {
     const int sx = mc_ref_col( g.x0 + clip3( 0, g.cw - 1, col + g.shX - g.padOff ), g.bx0, g.bx1, pw, g.wrapOff );
@@ -226,6 +250,40 @@ __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg
       }
 #pragma unroll
       for( int u = 0; u < 4; u++ ) win[yy[u] * wst + col] = v[u];
+    }
+  }
+}
+
+// the two chroma windows of a list (same geometry, at most 16 columns): Cb in the lower, Cr in the upper half of every 32 lanes when the window lies
+// inside the picture; else one after the other
+template<int NT>
+__device__ __forceinline__ void mc_load_window_c2( pel_t* winCb, pel_t* winCr, int wst, const McSeg& gCb, const McSeg& gCr, const pel_t* __restrict__ refCb, const pel_t* __restrict__ refCr,
+                                                   int stride, int pw, int ph, int tid )
+{
+  const McSeg& g = gCb;
+  const int ux0 = __builtin_amdgcn_readfirstlane( g.x0 ), uy0 = __builtin_amdgcn_readfirstlane( g.y0 ), uww = __builtin_amdgcn_readfirstlane( g.ww ), uwh = __builtin_amdgcn_readfirstlane( g.wh );
+  const int plain = __builtin_amdgcn_readfirstlane( uww <= 16 && ( g.wrapOff | g.padOff | g.shX | g.shY ) == 0 && g.cw == g.ww && g.chh == g.wh
+                                                    && g.x0 >= g.bx0 && g.x0 + g.ww - 1 <= g.bx1 && g.y0 >= g.by0 && g.y0 + g.wh - 1 <= g.by1 );
+  if( !plain )
+  {
+    mc_load_window<NT>( winCb, wst, gCb, refCb, stride, pw, ph, tid );
+    mc_load_window<NT>( winCr, wst, gCr, refCr, stride, pw, ph, tid );
+    return;
+  }
+  const int col = tid & 15, cr = ( tid >> 4 ) & 1, row0 = tid >> 5;
+  if( col < uww )
+  {
+    constexpr int RS = NT / 32;
+    const pel_t* __restrict__ rp = ( cr ? refCr : refCb ) + (size_t) uy0 * stride + ux0 + col;
+    pel_t* wp = ( cr ? winCr : winCb ) + col;
+    const int last = uwh - 1 - ( ( uwh - 1 - row0 ) % RS );
+    for( int yb = row0; yb < uwh; yb += 4 * RS )
+    {
+      int yy[4]; pel_t v[4];
+#pragma unroll
+      for( int u = 0; u < 4; u++ ) { yy[u] = min( yb + u * RS, last ); v[u] = rp[yy[u] * stride]; }
+#pragma unroll
+      for( int u = 0; u < 4; u++ ) wp[yy[u] * wst] = v[u];
     }
   }
 }
@@ -399,8 +457,10 @@ __device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int
   {
     const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
     const int wL = it.w, hL = it.h, wC = it.w >> 1, hC = it.h >> 1;
-    const int rowsL = hL + 7, grpL = ( wL + 7 ) >> 3, rowsC = hC + 3;
-    const int perList = rowsL * grpL + ( ncomp == 3 ? 2 * rowsC : 0 );
+    const int rowsL = hL + 7, grpL = ( wL + 7 ) >> 3, rowsC = hC + 3, pairsC = ( rowsC + 1 ) >> 1;
+    // (a chroma work item filters two rows - as many multiply-adds as the eight luma outputs of an item: the 136 items of a bi-predicted 16x16
+    // tile would need a third, nearly empty pass of the wavefront)
+    const int perList = rowsL * grpL + ( ncomp == 3 ? 2 * pairsC : 0 );
     for( int idx = tid; idx < nl * perList; idx += NT )
     {
       const int k = idx >= perList, r0 = idx - k * perList;
@@ -416,12 +476,18 @@ __device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int
       }
       else
       {
-        const int q = r0 - rowsL * grpL, cc = q >= rowsC, r = q - cc * rowsC;
-        const pel_t* src = &winC[k][cc][r * MC2_WST_C];
-        mc_fir8<4>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), reinterpret_cast<const uint32_t*>( coefH[k][1 + cc] ), out );
-        pel_t* dst = &tmpC[k][cc][r];
+        const int q = r0 - rowsL * grpL, cc = q >= pairsC, rp = q - cc * pairsC;
 #pragma unroll
-        for( int j = 0; j < 8; j++ ) if( j < wC ) dst[j * MC2_TST_C] = (pel_t) ( ( out[j] + offset1 ) >> shift1 );
+        for( int half = 0; half < 2; half++ )
+        {
+          const int r = rp + half * pairsC;
+          if( r >= rowsC ) break;
+          const pel_t* src = &winC[k][cc][r * MC2_WST_C];
+          mc_fir8<4>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), reinterpret_cast<const uint32_t*>( coefH[k][1 + cc] ), out );
+          pel_t* dst = &tmpC[k][cc][r];
+#pragma unroll
+          for( int j = 0; j < 8; j++ ) if( j < wC ) dst[j * MC2_TST_C] = (pel_t) ( ( out[j] + offset1 ) >> shift1 );
+        }
       }
     }
   }
@@ -566,8 +632,11 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   }
   __syncthreads();
   // ---- phase A: all reference windows of the tile into LDS, one exposure to HBM/L2 latency
-  for( int k = 0; k < nl; k++ ) for( int c = 0; c < ncomp; c++ )
-    mc_load_window<NT>( c ? m.winC[k][c - 1] : m.winL[k], c ? MC2_WST_C : MC2_WST_L, m.seg[k][c], m.refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
+  for( int k = 0; k < nl; k++ )
+  {
+    mc_load_window<NT>( m.winL[k], MC2_WST_L, m.seg[k][0], m.refp[k][0], reco.stride[0], reco.w[0], reco.h[0], tid );
+    if( ncomp == 3 ) mc_load_window_c2<NT>( m.winC[k][0], m.winC[k][1], MC2_WST_C, m.seg[k][1], m.seg[k][2], m.refp[k][1], m.refp[k][2], reco.stride[1], reco.w[1], reco.h[1], tid );
+  }
   __syncthreads();
   mc2_stage1<NT>( m, nl, ncomp, it.w, it.h, headroom, tid );
   __syncthreads();
