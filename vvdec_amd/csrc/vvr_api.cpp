@@ -332,7 +332,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
 #endif
   const RefSet& refs = plan.refs;
   DevPlanes A = c->slots[h.out_slot], B = c->scratchB[lane], R = c->scratchR[lane];
-  auto timed = [&]( int k, auto&& fn )
+  auto timedOn = [&]( int k, hipStream_t st, double algoBytes, auto&& fn )
   {
 #ifdef VVR_WATCHDOG
     // developer experiment: what a stage costs in throughput (VVR_SKIP_KERNELS = bit mask over the kernel ids; the pictures are wrong, of course)
@@ -340,14 +340,19 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
     if( skipMask & ( 1 << k ) ) return;
     const double w0 = wdNow();
 #endif
-    if( c->statsOn ) { PendingTiming t; hipEventCreate( &t.a ); hipEventCreate( &t.b ); t.kernel = k; t.bytes = q->bytes[k]; hipEventRecord( t.a, s ); fn(); hipEventRecord( t.b, s ); job.timings.push_back( t ); }
+    // (the events bracket the launch on the stream it is issued to)
+    if( c->statsOn ) { PendingTiming t; hipEventCreate( &t.a ); hipEventCreate( &t.b ); t.kernel = k; t.bytes = algoBytes; hipEventRecord( t.a, st ); fn(); hipEventRecord( t.b, st ); job.timings.push_back( t ); }
     else fn();
 #ifdef VVR_WATCHDOG
     const double w = wdNow() - w0; g_wdCall[k][0] += w; g_wdCall[k][1] = std::max( g_wdCall[k][1], w ); g_wdCall[k][2] += 1;
 #endif
   };
+  auto timed = [&]( int k, auto&& fn ) { timedOn( k, s, q->bytes[k], fn ); };
   // INTER stage: prediction of every inter CU, then residual add (DecLibRecon.cpp:831-874)
-  if( q->numMc + q->numBdofItems ) timed( K_MC, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc, 0 ); launch_mc( s, q->pic, refs, A, q->bdofItems, q->numBdofItems, 1 ); } );
+  // (the four launches write disjoint tiles.  Running them side by side on extra streams of the lane, forked and joined with events, was measured:
+  // device-only throughput fell from 1870 to 1240 pictures/s with 4 lanes, to 970 with 8 - the cross-stream waits cost more than the overlap gives)
+  if( q->numMc ) timedOn( K_MC, s, q->bytes[K_MC] - q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc, 0 ); } );
+  if( q->numBdofItems ) timedOn( K_MC, s, q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, A, q->bdofItems, q->numBdofItems, 1 ); } );
   if( q->numDmvrItems )
   {
     // the delta MVs go straight into pinned host memory (device-mapped): a few bytes per 16x16 sub-block, and no copy call on the
@@ -360,8 +365,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   const bool lmcsOn = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
   // LMCS: the inter prediction is forward-mapped before any residual is added (DecCu.cpp:458-476) - by the motion-compensation kernels themselves
   // where they store their luma samples (lmcs_fwd_luma): no pass over the picture
-  if( q->numTb[0] + q->numTb[1] + q->numTb[2] )
-    timed( K_ITRANS, [&]{ for( int k = 0; k < 3; k++ ) launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); } );
+  for( int k = 0; k < 3; k++ ) if( q->numTb[k] ) timedOn( K_ITRANS, s, q->bytesTb[k], [&]{ launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); } );
   // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)
   {
     // ticket + one flag per unit: a picture with more units than the lane's buffer holds gets a larger one; work queued on the lane may
@@ -376,12 +380,12 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
       c->syncBuf[lane] = p; c->syncCap[lane] = need * 2;
     }
   }
-  // INTRA stage.  A picture whose inter blocks carry scaled chroma residuals (LMCS): luma units, the residual-add blocks, chroma units
+  // A picture whose inter blocks carry scaled chroma residuals (LMCS): luma units, the residual-add blocks, chroma units
   if( q->numResi )
   {
-    if( q->numLumaUnits ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numLumaUnits, q->intraWorkgroups, c->syncBuf[lane] ); } );
+    if( q->numLumaUnits ) timedOn( K_INTRA, s, q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numLumaUnits, q->intraWorkgroups, c->syncBuf[lane] ); } );
     timed( K_RESI_ADD, [&]{ launch_resi_add( s, q->pic, A, R, q->resiItems, q->numResi ); } );
-    if( q->numActive > q->numLumaUnits ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, q->numLumaUnits, q->numActive, q->intraWorkgroupsChroma, c->syncBuf[lane] ); } );
+    if( q->numActive > q->numLumaUnits ) timedOn( K_INTRA, s, q->bytes[K_INTRA] - q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, q->numLumaUnits, q->numActive, q->intraWorkgroupsChroma, c->syncBuf[lane] ); } );
   }
   else if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)

@@ -26,6 +26,7 @@ struct vvr_prepared {
   IntraItem* resiItems = nullptr; int numResi = 0;         // scaled chroma residuals of inter blocks (k_resi_add); with them the stage runs as luma units, k_resi_add, chroma units
   int      numLumaUnits = 0, intraWorkgroupsChroma = 0;    // (the first numLumaUnits entries of `units` are the luma units then)
   double   bytes[K_NUM] = { 0 };                           // algorithmic bytes per kernel
+  double   bytesBdof = 0, bytesIntraLuma = 0, bytesTb[3] = { 0, 0, 0 };      // shares of bytes[K_MC] (the BDOF launch), bytes[K_INTRA] (the luma launch), bytes[K_ITRANS] (per size class)
   // ownership (vvr_prepare handles only)
   void*    blob = nullptr; size_t blobBytes = 0;
   int32_t* dmvrHost = nullptr;                             // pinned + device-mapped, 2 * numDmvr ints: the DMVR kernel writes the delta MVs here

@@ -45,6 +45,7 @@ struct PrepScratch
   std::vector<uint32_t> prodPool[3];
   std::vector<uint32_t> ctuStartV;
   double bytes[K_NUM] = { 0 };
+  double bytesBdof = 0, bytesIntraLuma = 0, bytesTb[3] = { 0, 0, 0 };
   // decode-order index of the transform block covering every 4x4 luma unit (both channel types): reference availability
   // = "inside the picture and reconstructed before me" (CodingStructure::getCURestricted, CodingStructure.cpp:464, and the
   // TU-index test of isAboveAvailable / isLeftAvailable, IntraPrediction.cpp:1343-1400)
@@ -104,6 +105,7 @@ struct PrepScratch
     resiAdd.clear(); intraAll.clear(); units.clear(); unitsDev.clear(); csVpduV.clear();
     ctuStartV.assign( 3 * (size_t) ( numCtu + 1 ), 0 );
     for( double& b : bytes ) b = 0;
+    bytesBdof = bytesIntraLuma = 0; bytesTb[0] = bytesTb[1] = bytesTb[2] = 0;
   }
 
   // `order` holds the cells of ONE CTU (both channel types): it is only ever asked about the CTU being analysed
@@ -573,7 +575,7 @@ int PrepScratch::buildWorkLists( std::string& err )
             it.tu = t; it.comp = (uint8_t) comp; it.x = (uint16_t) ( tu.x >> 1 ); it.y = (uint16_t) ( tu.y >> 1 ); it.lw = (uint8_t) ilog2i( tu.w >> 1 ); it.lh = (uint8_t) ilog2i( tu.h >> 1 );
             it.mode = IT_MODE_RESI_ADD; it.flags = IT_F_RESI | IT_F_CSCALE;
             resiAdd.push_back( it );
-            bytes[K_INTRA] += (double) ( tu.w >> 1 ) * ( tu.h >> 1 ) * 4 + sizeof( IntraItem );
+            bytes[K_RESI_ADD] += (double) ( tu.w >> 1 ) * ( tu.h >> 1 ) * 6 + sizeof( IntraItem );      // prediction read, residual read, sample written
             continue;
           }
           const int cs = comp ? 1 : 0, chn = comp ? 1 : 0, unit = 4 >> cs;
@@ -733,6 +735,7 @@ int PrepScratch::buildWorkLists( std::string& err )
           IH.pn = (uint32_t) pool.size() - IH.p0;
           itemH[comp].push_back( IH );
           bytes[K_INTRA] += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
+          if( !comp ) bytesIntraLuma += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
         }
       }
     }
@@ -790,7 +793,9 @@ int PrepScratch::buildWorkLists( std::string& err )
       }
       {
         const double smp = (double) cu.w * cu.h * ( ncomp == 3 ? 1.5 : 1.0 ), nt = (double) ( list.size() - first );
-        bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += smp * 2 * nla + smp * 2 + nt * ( sizeof( McItem ) + ( dm ? 8 : 0 ) ) + ( af ? cu.w * cu.h / 16.0 * sizeof( vvr_motion ) : 0 );
+        const double bts = smp * 2 * nla + smp * 2 + nt * ( sizeof( McItem ) + ( dm ? 8 : 0 ) ) + ( af ? cu.w * cu.h / 16.0 * sizeof( vvr_motion ) : 0 );
+        bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += bts;
+        if( &list == &mcBdof ) bytesBdof += bts;
       }
       if( dm ) numDmvr = std::max<uint32_t>( numDmvr, cu.dmvr_off + ( ( cu.w + 15 ) / 16 ) * ( ( cu.h + 15 ) / 16 ) );
       bytes[K_MC] += sizeof( vvr_cu );
@@ -821,7 +826,8 @@ int PrepScratch::buildWorkLists( std::string& err )
         tb[cls].push_back( it );        // ADD (inter: onto the prediction) and STORE (intra / CIIP: into the residual planes) items share a launch
         const int bdp = it.comp ? cu.bdpcm[1] : cu.bdpcm[0];
         const double ncoef = bdp ? (double) bw * bh : (double) ( tu.max_scan_x[it.comp] + 1 ) * ( tu.max_scan_y[it.comp] + 1 );
-        bytes[K_ITRANS] += ncoef * 2 + (double) bw * bh * 4 * ( it.ict ? 2 : 1 ) + sizeof( TbItem ) + sizeof( vvr_tu ) / 3.0;
+        const double bts = ncoef * 2 + (double) bw * bh * 4 * ( it.ict ? 2 : 1 ) + sizeof( TbItem ) + sizeof( vvr_tu ) / 3.0;
+        bytes[K_ITRANS] += bts; bytesTb[cls] += bts;
       }
     }
   }
@@ -1354,4 +1360,5 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   q.units = (IntraUnit*) at( S.iUnits ); q.numActive = (int) S.unitsDev.size(); q.intraWorkgroups = S.intraWorkgroups;
   q.resiItems = (IntraItem*) at( S.iResi ); q.numResi = (int) S.resiAdd.size(); q.numLumaUnits = S.numLumaUnits; q.intraWorkgroupsChroma = S.intraWorkgroupsChroma;
   memcpy( q.bytes, S.bytes, sizeof( q.bytes ) );
+  q.bytesBdof = S.bytesBdof; q.bytesIntraLuma = S.bytesIntraLuma; for( int k = 0; k < 3; k++ ) q.bytesTb[k] = S.bytesTb[k];
 }
