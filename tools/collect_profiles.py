@@ -1,0 +1,24 @@
+"""developer helper: copies what tools/gpu_round3.sh left in gpurun_out/<tag>/ into profiles/ under the names the documents cite
+   (kernel statistics of the driver's command, PMC traffic per configuration, counters of the streaming kernels, the bench lines).
+   usage: python tools/collect_profiles.py gpurun_out/r3ev2 round3"""
+import glob, json, os, shutil, sys
+src, rnd = sys.argv[1], sys.argv[2]
+P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+stats = glob.glob(os.path.join(src, "prof", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(P, rnd + "_kernel_stats.csv"))
+configs = {}
+for cfg in ("4k", "allintra", "8k"):
+    f = os.path.join(src, "pmc_traffic_%s.json" % cfg)
+    if os.path.exists(f):
+        configs[cfg] = json.load(open(f))
+if configs:
+    json.dump({"_note": "HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over bench.py (one picture in flight), "
+                        "gfx950 correction of the MI355X guide applied (tools/pmc_summary.py); keyed by bench configuration and kernel", "configs": configs},
+              open(os.path.join(P, rnd + "_pmc_traffic.json"), "w"), indent=1)
+for a, b in (("deblock_counters.json", "_deblock_counters.json"), ("host.txt", "_gpu_box_host.txt"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
+             ("bench_4k_steps20_warmup5.json", "_bench_steps20_warmup5.json"), ("bench_4k_steps64_warmup16.json", "_bench_steps64_warmup16.json"),
+             ("bench_allintra.json", "_bench_allintra.json"), ("bench_8k.json", "_bench_8k.json")):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(P, rnd + b))
+print(sorted(f for f in os.listdir(P) if f.startswith(rnd)))
