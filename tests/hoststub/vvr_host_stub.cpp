@@ -43,8 +43,8 @@ hipError_t hipEventSynchronize( hipEvent_t ) { if( g_delayUs ) usleep( g_delayUs
 hipError_t hipEventElapsedTime( float* ms, hipEvent_t, hipEvent_t ) { *ms = 0.f; return hipSuccess; }
 hipError_t hipGetLastError( void ) { return hipSuccess; }
 const char* hipGetErrorString( hipError_t ) { return "host stub"; }
-static size_t g_h2dCopies = 0, g_h2dBytes = 0;
-hipError_t hipMemcpyAsync( void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t ) { memcpy( d, s, n ); if( k == hipMemcpyHostToDevice ) { g_h2dCopies++; g_h2dBytes += n; } return hipSuccess; }
+static size_t g_h2dCopies = 0, g_h2dBytes = 0; static uint64_t g_h2dHash = 1469598103934665603ull;      // (FNV-1a over everything copied to the device, in copy order)
+hipError_t hipMemcpyAsync( void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t ) { memcpy( d, s, n ); if( k == hipMemcpyHostToDevice ) { g_h2dCopies++; g_h2dBytes += n; const uint64_t* w = (const uint64_t*) s; uint64_t hsh = g_h2dHash; for( size_t i = 0; i < n / 8; i++ ) hsh = ( hsh ^ w[i] ) * 1099511628211ull; g_h2dHash = hsh; } return hipSuccess; }
 hipError_t hipMemsetAsync( void* d, int v, size_t n, hipStream_t ) { memset( d, v, n ); return hipSuccess; }
 }
 
@@ -158,6 +158,7 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
   return 0;
 }
 // asynchronous host-to-device copies issued so far: count and bytes (cleared by the call)
+__attribute__(( visibility( "default" ) )) unsigned long long vvt_take_h2d_hash( void ) { const uint64_t v = g_h2dHash; g_h2dHash = 1469598103934665603ull; return v; }
 __attribute__(( visibility( "default" ) )) void vvt_take_h2d( size_t* copies, size_t* bytes ) { *copies = g_h2dCopies; *bytes = g_h2dBytes; g_h2dCopies = g_h2dBytes = 0; }
 __attribute__(( visibility( "default" ) )) void vvt_set_delay( int us ) { g_delayUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_slow_i_pictures( int us ) { g_vvtSlowIUs = us; }

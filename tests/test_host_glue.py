@@ -773,6 +773,54 @@ def test_worker_threads_commit_in_submission_order(stub):
         assert _submit_stream(stub, threads) == inline
 
 
+def test_i_pictures_are_prepared_by_the_workers_together(stub):
+    """the work lists of a picture whose CUs are all intra CUs are built in parts (bands of CTU rows) by the worker threads together and appended in band
+    order: everything that is uploaded for a stream - I pictures of several sizes among B pictures - is byte for byte what one thread uploads"""
+    stub.vvt_take_h2d_hash.restype = C.c_ulonglong
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    stub.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+
+    def run(threads, W, H, l2, frames, gop, intra_period, tools, **kw):
+        plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=False, pool=12, intra_period=intra_period)
+        cfg = abi.Config()
+        cfg.abi_version = abi.VVR_ABI_VERSION
+        cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, l2
+        cfg.num_slots, cfg.num_streams, cfg.host_threads = max(nslots, 12), 2, threads
+        ctx = C.c_void_p()
+        assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+        stub.vvt_take_h2d_hash()
+        descs = [synth.picture_for_plan(pl, W, H, seed=530, tool_flags=tools, log2_ctu=l2, **kw) for pl in plans]
+        assert sum(1 for pl in plans if pl.slice_type == abi.SLICE_I) >= 2
+        pics = [d.c() for d in descs]
+        hashes = []
+        for p in pics:                           # one picture at a time: the copies of a picture are issued in a fixed order
+            j = stub.vvr_submit(ctx, C.byref(p))
+            assert j >= 0 and stub.vvr_wait(ctx, j) == abi.VVR_OK, stub.vvr_last_error(ctx).decode()
+            hashes.append(stub.vvt_take_h2d_hash())
+        stub.vvr_destroy(ctx)
+        return hashes
+    T = TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE
+    for (W, H, l2, kw) in ((1920, 1080, 7, dict(p_cclm=0.3, p_isp=0.2, p_mip=0.2)), (832, 480, 6, dict(dual_tree=1.0, p_cclm=0.3)), (416, 240, 5, dict())):
+        one = run(0, W, H, l2, 9, 4, 4, T, **kw)
+        assert len(set(one)) == len(one)
+        for threads in (2, 3, 8):
+            assert run(threads, W, H, l2, 9, 4, 4, T, **kw) == one, (W, H, threads)
+    # records that are wrong in a part other than the first are reported like by one thread
+    plans, nslots = stream.ra_plan(1, gop=1, seed_poc0_is_external=False)
+    d = synth.picture_for_plan(plans[0], 1920, 1080, seed=531, tool_flags=TOOLS)
+    d.cu["w"][len(d.cu) - 3] = 0
+    cfg = abi.Config()
+    cfg.abi_version = abi.VVR_ABI_VERSION
+    cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, 1920, 1080, 1, 10, 7
+    cfg.num_slots, cfg.num_streams, cfg.host_threads = 4, 2, 4
+    ctx = C.c_void_p()
+    assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+    p = d.c()
+    j = stub.vvr_submit(ctx, C.byref(p))
+    assert j >= 0 and stub.vvr_wait(ctx, j) == abi.VVR_ERR_PARAMETER and "CU outside" in stub.vvr_last_error(ctx).decode()
+    stub.vvr_destroy(ctx)
+
+
 def test_errors_of_queued_pictures_come_back_from_wait(stub):
     """with worker threads, what only shows while the work lists are built is parked on the job (the reference parks exceptions on reconDone):
     vvr_submit has returned a job id, vvr_wait returns the error, later pictures are not held up"""

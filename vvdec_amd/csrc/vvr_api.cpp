@@ -141,6 +141,7 @@ struct vvr_context {
   std::vector<DevPlanes>   scratchR;    // per stream: residual planes (intra)
   void*      planeMem = nullptr; bool planeMemOwned = false;
   void*      scratchMem = nullptr;
+  std::deque<std::function<void( PrepScratch& )>> subtasks;      // parts of a picture's host stage that any worker may run (an I picture is prepared by all of them together); guarded by mu, served before `queue`
   std::vector<int*> syncBuf;            // per stream: ticket + one flag per unit of the intra stage
   std::vector<size_t> syncCap;          // ints allocated in syncBuf[lane]; grown when a picture has more units
   size_t     planeBytes[3] = { 0, 0, 0 }, slotBytes = 0;
@@ -545,7 +546,7 @@ static void launcherMain( vvr_context* c )
 static int g_vvtSlowIUs = 0;       // stand-in runtime (tests): extra time the host stage of an I picture other than the first of the stream takes
 static int g_vvtSlowBUs = 0;       // ... and of every picture that is not an I picture
 #endif
-static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
+static void prepareJob( vvr_context* c, Job& job, PrepScratch& S, HostHelpers* helpers = nullptr )
 {
 #ifdef VVT_SLOW_I_PICTURES
   if( g_vvtSlowIUs && job.pic.hdr.slice_type == 2 && job.pic.hdr.poc != 0 ) std::this_thread::sleep_for( std::chrono::microseconds( g_vvtSlowIUs ) );
@@ -553,8 +554,8 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S )
 #endif
   size_t total = 0; std::string err;
   WD_STAMP( job, tPrep );
-  int rc = c->workers.empty() ? VVR_OK : vvr_host_validate_records( c->cfg, &job.pic, err );        // (no workers: vvr_submit has checked them)
-  if( rc == VVR_OK ) rc = vvr_host_build( &job.pic, S, &total, err, &c->pinned );
+  // (the CU / TU records are checked here - on the way, by whoever builds the part - unless there are no workers: then vvr_submit has checked them)
+  int rc = vvr_host_build( &job.pic, S, &total, err, &c->pinned, helpers, !c->workers.empty() );
   WD_STAMP( job, tBuilt );
   RingEntry& e = c->ring[job.ringSeq % c->ring.size()];
   {
@@ -670,18 +671,60 @@ static void watchdogMain( vvr_context* c )
 }
 #endif
 
+// The workers as helpers of the one among them that prepares an I picture (HostHelpers): the parts go into `subtasks`, which every worker serves before it
+// takes another picture; the caller runs part 0, then whatever parts are still unclaimed (on a second scratch of its own: its first one holds part 0),
+// and returns when all parts are done.  A part may block until the parts before it are done (they are appended in order): parts are claimed in order, and
+// the caller claims too, so the earliest part not yet done is always running or about to.
+struct WorkerHelpers : HostHelpers
+{
+  vvr_context* c; PrepScratch*& spare;
+  WorkerHelpers( vvr_context* c_, PrepScratch*& spare_ ) : c( c_ ), spare( spare_ ) {}
+  int width() const override { return c->cfg.host_threads; }
+  void run( int n, PrepScratch& own, const std::function<void( int, PrepScratch& )>& fn ) override
+  {
+    struct State { std::mutex mu; std::condition_variable cv; int remaining; } st; st.remaining = n - 1;
+    {
+      std::lock_guard<std::mutex> lk( c->mu );
+      for( int part = 1; part < n; part++ )
+        c->subtasks.push_back( [&st, &fn, part]( PrepScratch& R ) { fn( part, R ); { std::lock_guard<std::mutex> l2( st.mu ); st.remaining--; } st.cv.notify_all(); } );
+      c->cv.notify_all();
+    }
+    fn( 0, own );
+    for( ;; )
+    {
+      std::function<void( PrepScratch& )> task;
+      { std::lock_guard<std::mutex> lk( c->mu ); if( !c->subtasks.empty() ) { task = std::move( c->subtasks.front() ); c->subtasks.pop_front(); } }
+      if( !task ) break;
+      if( !spare ) { spare = vvr_scratch_create(); vvr_scratch_warm( spare, c->cfg ); }
+      task( *spare );
+    }
+    std::unique_lock<std::mutex> lk( st.mu );
+    st.cv.wait( lk, [&]{ return st.remaining == 0; } );
+  }
+};
+
 static void workerMain( vvr_context* c )
 {
   hipSetDevice( c->device );
   pinToCpus( c->nodeCpus );
   PrepScratch* S = vvr_scratch_create();
   vvr_scratch_warm( S, c->cfg );
+  PrepScratch* spare = nullptr;
+  WorkerHelpers helpers( c, spare );
   for( ;; )
   {
     Job* job = nullptr;
     {
       std::unique_lock<std::mutex> lk( c->mu );
-      c->cv.wait( lk, [&]{ return c->stop || !c->queue.empty(); } );
+      c->cv.wait( lk, [&]{ return c->stop || !c->queue.empty() || !c->subtasks.empty(); } );
+      if( !c->subtasks.empty() )
+      {
+        // a part of a picture another worker is preparing: before anything else (that picture is an I picture: the next GOP waits for it)
+        std::function<void( PrepScratch& )> task = std::move( c->subtasks.front() ); c->subtasks.pop_front();
+        lk.unlock();
+        task( *S );
+        continue;
+      }
       if( c->queue.empty() ) break;       // (stop, and nothing left to do)
       // An I picture among the next few waiting pictures goes first: its intra stage is the longest thing the device does for the stream (8 ms at
       // 4K against 0.7 ms for a whole B picture), everything of the next GOP waits for it, and it waits for nothing itself, so it should not queue
@@ -699,9 +742,10 @@ static void workerMain( vvr_context* c )
       job->state = J_PREPARING;
       c->cv.notify_all();                 // (a submitter may be waiting for room in the queue)
     }
-    prepareJob( c, *job, *S );
+    prepareJob( c, *job, *S, c->cfg.host_threads > 1 ? &helpers : nullptr );
   }
   vvr_scratch_destroy( S );
+  if( spare ) vvr_scratch_destroy( spare );
 }
 
 // wait until the job's picture is reconstructed (or has failed); returns its status

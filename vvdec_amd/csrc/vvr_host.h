@@ -60,7 +60,19 @@ int    vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, st
 int    vvr_host_validate_records( const vvr_config& cfg, const vvr_picture* p, std::string& err );     // the per-record part
 // host glue: the work lists of one picture (what DecCu::TaskTrafoCtu / TaskInterCtu / the intra task iterate over, DecCu.cpp:106-160); returns the
 // number of bytes the picture needs in HBM
-int    vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err, PinnedRanges* pinned = nullptr );
+// Other threads that can lend a hand to the thread that prepares a picture (vvr_api.cpp: the library's worker threads).  run( n, fn ): fn( part,
+// scratch ) for part = 0 .. n - 1, part 0 by the caller on `own`, the others by whoever is free - each with a scratch of its own - or by the caller
+// itself; returns when all are done.
+#include <functional>
+struct HostHelpers
+{
+  virtual ~HostHelpers() {}
+  virtual int  width() const = 0;       // threads that may run parts at the same time (incl. the caller)
+  virtual void run( int n, PrepScratch& own, const std::function<void( int, PrepScratch& )>& fn ) = 0;
+};
+// validateRecords: the CU / TU records are checked on the way (vvr_host_validate_records has not been called); helpers: a picture whose work lists can be
+// built in independent parts (every CU an intra CU: no analysis across CTUs) is - an I picture is what everything of the next GOP waits for
+int    vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err, PinnedRanges* pinned = nullptr, HostHelpers* helpers = nullptr, bool validateRecords = false );
 // the H2D image: every staged part at its offset (256-byte aligned) into `host` (pinned memory of at least totalBytes); the parts that are
 // copied straight from the caller's pinned arrays, and the byte range [begin, end) of the image that is staged
 void   vvr_host_pack( const PrepScratch& S, char* host );

@@ -10,6 +10,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <condition_variable>
 
 static inline int ilog2i( int v ) { int l = 0; while( ( 1 << l ) < v ) l++; return l; }
 
@@ -55,6 +57,9 @@ struct PrepScratch
   // per component and 4x4 luma cell: the block that reconstructs it in the intra stage, stamped with the number of the picture it was written for
   // ( epoch << 22 | block ): the maps are never cleared, an entry of another picture reads as "none"
   std::vector<uint32_t> itemAtE[3];
+  // all-intra CTUs: which block of the CTU's (component) list reconstructs a cell of the CTU - 32 x 32 cells at most, rewritten per CTU: enough to tell
+  // which of the blocks before it a block reads from (IntraItem `indep`), without the picture-wide producer analysis
+  uint16_t fastCell[3][32 * 32]; uint32_t fastFirst[3] = { 0, 0, 0 };
   uint32_t epoch = 0;
   // (cells of one CTU lie together: a block and what it reads stay within a few KB)
   size_t cellIdx( int cx, int cy ) const { const int l = h.log2_ctu - 2, m = ( 1 << l ) - 1; return ( ( (size_t) ( cy >> l ) * ctusX + ( cx >> l ) ) << ( 2 * l ) ) | (size_t) ( ( cy & m ) << l ) | (size_t) ( cx & m ); }
@@ -143,11 +148,13 @@ struct PrepScratch
   bool cscaleCtu( uint32_t c ) const { const uint32_t f = flagsOfCtu( c ); return cscale && ( f & VVR_TOOL_LMCS ) && ( f & VVR_TOOL_LMCS_CSCALE ); }
   bool sameSliceAndTile( uint32_t a, uint32_t b ) const { return ( !p->ctu_slice || p->ctu_slice[a] == p->ctu_slice[b] ) && ( !p->ctu_tile || p->ctu_tile[a] == p->ctu_tile[b] ); }
   uint32_t ctuAt( int lx, int ly ) const { return (uint32_t) ( ( ly >> h.log2_ctu ) * ctusX + ( lx >> h.log2_ctu ) ); }
-  int beginMaps();
+  int beginMaps( const PrepScratch* like = nullptr );
   int mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string& err );
   bool anyIntra = false; uint32_t curCtuIdx = 0;
+  uint32_t partCtu0 = 0, partCtu1 = 0xffffffffu;      // (buildInParts) the CTUs the CUs of the range being built have to lie in
   bool allIntraCus = false;                // every CU of the picture is an intra CU: every CTU takes the fast path, nobody ever looks a producer up
-  int buildWorkLists( std::string& err );
+  int buildWorkLists( std::string& err, uint32_t cu0 = 0, uint32_t cu1 = 0xffffffffu );
+  int buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool validate, std::string& err );
   int formUnits();
   int groupUnits();
   int emitUnitTable( std::string& err );
@@ -275,15 +282,16 @@ int vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::
 }
 
 // the CU / TU records (0.3 ms for a 4K picture): by the thread that builds the picture's work lists
-int vvr_host_validate_records( const vvr_config& cfg, const vvr_picture* p, std::string& err )
+// the CU / TU records [cu0, cu1) (a picture's records are checked in one go, or in parts by the threads that build its work lists in parts);
+// area[0 / 1]: luma / chroma area the CUs of the range cover
+static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t cu1, uint64_t area[2], std::string& err )
 {
-  (void) cfg;
   vvr_pic_header h = p->hdr;
   if( p->slices ) { uint32_t any = 0; for( uint32_t i = 0; i < p->num_slices; i++ ) any |= p->slices[i].tool_flags & VVR_SLICE_TOOL_MASK; h.tool_flags = ( h.tool_flags & ~(uint32_t) VVR_SLICE_TOOL_MASK ) | any; }
   const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
   const int ncomp = h.chroma_format ? 3 : 1;
   uint64_t areaLuma = 0, areaChroma = 0;
-  for( uint32_t i = 0; i < p->num_cu; i++ )
+  for( uint32_t i = cu0; i < cu1; i++ )
   {
     const vvr_cu& cu = p->cu[i];
     if( !cu.w || !cu.h || cu.x + cu.w > h.width || cu.y + cu.h > h.height || cu.first_tu + cu.num_tu > p->num_tu ) FAIL( VVR_ERR_PARAMETER, "CU outside the picture / bad TU range" );
@@ -428,10 +436,23 @@ int vvr_host_validate_records( const vvr_config& cfg, const vvr_picture* p, std:
     }
     else FAIL( VVR_ERR_PARAMETER, "unknown prediction mode" );
   }
-  // the CUs tile the picture: with every CU inside the picture, equal areas leave no cell uncovered unless two CUs overlap (which the device
-  // tolerates: it only ever addresses samples inside the CUs it was given)
-  if( areaLuma != (uint64_t) h.width * h.height || ( h.chroma_format && areaChroma != (uint64_t) h.width * h.height ) ) FAIL( VVR_ERR_PARAMETER, "the CUs do not cover the picture" );
+  area[0] = areaLuma; area[1] = areaChroma;
   return VVR_OK;
+}
+// the CUs tile the picture: with every CU inside the picture, equal areas leave no cell uncovered unless two CUs overlap (which the device
+// tolerates: it only ever addresses samples inside the CUs it was given)
+static int validate_cover( const vvr_picture* p, const uint64_t area[2], std::string& err )
+{
+  const vvr_pic_header& h = p->hdr;
+  if( area[0] != (uint64_t) h.width * h.height || ( h.chroma_format && area[1] != (uint64_t) h.width * h.height ) ) FAIL( VVR_ERR_PARAMETER, "the CUs do not cover the picture" );
+  return VVR_OK;
+}
+int vvr_host_validate_records( const vvr_config& cfg, const vvr_picture* p, std::string& err )
+{
+  (void) cfg;
+  uint64_t area[2];
+  const int rc = validate_records_range( p, 0, p->num_cu, area, err );
+  return rc != VVR_OK ? rc : validate_cover( p, area, err );
 }
 
 int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string& err )
@@ -447,12 +468,16 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
 // block looks at lies in its own CTU, the CTU to the left or the CTU row above, so the lines it touches are still in the cache (a whole-picture
 // pass in front would have been evicted again: the lookups are what this stage spends its time on).  Nothing is cleared per picture: cells of
 // later CTUs are known to be "not decoded yet" from their position, the block map carries the picture's epoch.
-int PrepScratch::beginMaps()
+int PrepScratch::beginMaps( const PrepScratch* like /* the same picture in another thread's scratch: what it found out about the picture as a whole */ )
 {
+  if( like ) { anyIntra = like->anyIntra; allIntraCus = like->allIntraCus; }
+  else
+  {
   anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
   allIntraCus = h.slice_type == 2;
   for( uint32_t i = 0; i < p->num_cu && allIntraCus; i++ ) allIntraCus = p->cu[i].pred_mode == VVR_PRED_INTRA;
+  }
   fastCtu.assign( (size_t) numCtu, 0 );
   if( anyIntra )
   {
@@ -481,6 +506,7 @@ int PrepScratch::mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string&
     bool fast = true;
     for( uint32_t i = i0; i < i1 && fast; i++ ) fast = p->cu[i].pred_mode == VVR_PRED_INTRA;
     fastCtu[ctuIdx] = fast;
+    if( fast ) { memset( fastCell, 0xff, sizeof( fastCell ) ); for( int k = 0; k < 3; k++ ) fastFirst[k] = (uint32_t) intra[k].size(); }
   }
   const size_t cells = (size_t) w4 * h4;
   for( uint32_t i = i0; i < i1; i++ )
@@ -524,23 +550,24 @@ int PrepScratch::mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string&
 }
 
 // the work lists: intra-stage blocks with the blocks they read from, motion-compensation tiles, transform blocks
-int PrepScratch::buildWorkLists( std::string& err )
+int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
 {
-  uint32_t curCtu = 0, mappedEnd = 0;
-  for( uint32_t i = 0; i < p->num_cu; i++ )
+  cu1 = std::min( cu1, p->num_cu );
+  uint32_t curCtu = cu0 < cu1 ? (uint32_t) ( ( p->cu[cu0].y >> h.log2_ctu ) * ctusX + ( p->cu[cu0].x >> h.log2_ctu ) ) : 0, mappedEnd = cu0;
+  for( uint32_t i = cu0; i < cu1; i++ )
   {
     const vvr_cu& cu = p->cu[i];
     // CTU bookkeeping for the per-CTU intra lists (CUs arrive in CTU raster order)
     const uint32_t ctuOfCu = (uint32_t) ( ( cu.y >> h.log2_ctu ) * ctusX + ( cu.x >> h.log2_ctu ) );
     {
-      if( ctuOfCu < curCtu ) FAIL( VVR_ERR_PARAMETER, "CUs are not in CTU raster order" );
+      if( ctuOfCu < curCtu || ctuOfCu < partCtu0 || ctuOfCu >= partCtu1 ) FAIL( VVR_ERR_PARAMETER, "CUs are not in CTU raster order" );
       while( curCtu < ctuOfCu ) { curCtu++; for( int k = 0; k < 3; k++ ) ctuStartV[(size_t) k * ( numCtu + 1 ) + curCtu] = (uint32_t) intra[k].size(); }
     }
     if( i == mappedEnd )
     {
       // first CU of a CTU: map the CTU's cells before its blocks are analysed
       uint32_t j = i + 1;
-      while( j < p->num_cu && (uint32_t) ( ( p->cu[j].y >> h.log2_ctu ) * ctusX + ( p->cu[j].x >> h.log2_ctu ) ) == ctuOfCu ) j++;
+      while( j < cu1 && (uint32_t) ( ( p->cu[j].y >> h.log2_ctu ) * ctusX + ( p->cu[j].x >> h.log2_ctu ) ) == ctuOfCu ) j++;
       const int rc = mapCtu( i, j, ctuOfCu, err );
       if( rc != VVR_OK ) return rc;
       mappedEnd = j;
@@ -725,6 +752,32 @@ int PrepScratch::buildWorkLists( std::string& err )
               for( int yy = 0; yy < 2 * cclmLeft + 4; yy += 4 ) touch( 0, lx0 - 1, ly0 + yy );
             }
             }     // (not an all-intra CTU)
+            else
+            {
+              // all-intra CTU: the unit is the whole (component, CTU) in coding order; the last block of it this one reads a reference sample from
+              // (same lines the kernel fills: corner, above incl. above-right, left incl. below-left, the previous ISP partition)
+              const int l2 = h.log2_ctu, m4 = ( 1 << ( l2 - 2 ) ) - 1, ctuX0 = ( cu.x >> l2 ) << l2, ctuY0 = ( cu.y >> l2 ) << l2;
+              int last = -1;
+              auto look = [&]( int xc, int yc )
+              {
+                const int lx = xc << cs, ly = yc << cs;
+                if( lx < ctuX0 || ly < ctuY0 || lx >= ctuX0 + ( 1 << l2 ) || ly >= ctuY0 + ( 1 << l2 ) ) return;
+                const uint16_t j = fastCell[comp][( ( ( ly >> 2 ) & m4 ) << ( l2 - 2 ) ) | ( ( lx >> 2 ) & m4 )];
+                if( j != 0xffff ) last = std::max<int>( last, j );
+              };
+              if( it.nTL ) look( rx0 - 1 - mrl, ry0 - 1 - mrl );
+              for( int k = 0; k < it.nA * unit; k += unit ) look( rx0 + k, ry0 - 1 - mrl );
+              for( int k = 0; k < it.nL * unit; k += unit ) look( rx0 - 1 - mrl, ry0 + k );
+              if( ispL && ( x0 != rx0 || y0 != ry0 ) ) look( cu.isp_mode == 2 ? x0 - 1 : x0, cu.isp_mode == 2 ? y0 : y0 - 1 );
+              const int local = (int) ( myId - fastFirst[comp] );
+              const uint32_t indep = (uint32_t) std::min( 63, std::max( 0, local - 1 - last ) );
+              intra[comp].back().comp = (uint8_t) ( comp | ( indep << 2 ) );
+              if( local < 0xffff )
+              {
+                const int cx0 = ( x0 << cs ) >> 2, cx1 = std::min( ( ( ( x0 + w ) << cs ) + 3 ) >> 2, w4 ), cy1 = std::min( ( ( ( y0 + hh ) << cs ) + 3 ) >> 2, h4 );
+                for( int cy = ( y0 << cs ) >> 2; cy < cy1; cy++ ) for( int cx = cx0; cx < cx1; cx++ ) fastCell[comp][( ( cy & m4 ) << ( l2 - 2 ) ) | ( cx & m4 )] = (uint16_t) local;
+              }
+            }
             // the cells this block reconstructs (the map is only ever read by the producer analysis of CTUs that are not all intra)
             if( !allIntraCus )
             {
@@ -1064,7 +1117,7 @@ int PrepScratch::groupUnits()
   // turns it into items): the kernel predicts a unit's blocks with several wavefronts and starts a block when all blocks up to the last one
   // it reads from are done.  The clusters that share a unit cannot depend on each other, and inside a cluster a block mostly reads from the
   // one before it - but not always (the first block of the lower half of a split reads from the upper half's first blocks only).
-  // Blocks of all-intra CTUs (no producer lists were collected) stay serial.
+  // Blocks of all-intra CTUs carry theirs already (buildWorkLists: the CTU-local cell map; no producer lists were collected for them).
   {
     for( int k = 0; k < ncomp; k++ ) posAfterGrouping[k].assign( intra[k].size(), 0xffffffffu );
     for( int k = 0; k < 3; k++ ) groupFill[k] = 0;
@@ -1274,10 +1327,82 @@ void PrepScratch::layout( PinnedRanges* pinned )
   iUnits = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
 }
 
-int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err, PinnedRanges* pinned )
+// The work lists of a picture whose CUs are all intra CUs, built in parts (bands of CTU rows) by several threads: such CTUs are analysed without looking
+// at any other CTU (mapCtu, the fast path of buildWorkLists), so the parts are independent; every part is built in the scratch of the thread that
+// runs it and appended to this one's lists in band order.  The records of a part are checked by the thread that builds it.
+int PrepScratch::buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool validate, std::string& err )
+{
+  (void) cfg;
+  const int n = std::min( helpers.width(), ctusY );
+  struct Shared { std::mutex mu; std::condition_variable cv; int turn = 0; int rc = VVR_OK; std::string err; uint64_t area[2] = { 0, 0 }; } sh;
+  const vvr_picture* pic = p;
+  PrepScratch* owner = this;
+  helpers.run( n, *this, [&]( int part, PrepScratch& R )
+  {
+    const int row0 = (int) ( (int64_t) owner->ctusY * part / n ), row1 = (int) ( (int64_t) owner->ctusY * ( part + 1 ) / n );
+    const uint32_t cu0 = pic->ctu_first_cu[(size_t) row0 * owner->ctusX], cu1 = pic->ctu_first_cu[(size_t) row1 * owner->ctusX];
+    int rc = VVR_OK; std::string e; uint64_t area[2] = { 0, 0 };
+    if( cu0 > cu1 || cu1 > pic->num_cu ) { rc = VVR_ERR_PARAMETER; e = "ctu_first_cu is not ascending"; }
+    if( rc == VVR_OK && validate ) rc = validate_records_range( pic, cu0, cu1, area, e );
+    if( rc == VVR_OK )
+    {
+      if( &R != owner ) { R.begin( pic ); rc = R.beginMaps( owner ); }
+      R.partCtu0 = (uint32_t) row0 * owner->ctusX; R.partCtu1 = (uint32_t) row1 * owner->ctusX;
+      if( rc == VVR_OK ) rc = R.buildWorkLists( e, cu0, cu1 );
+      R.partCtu0 = 0; R.partCtu1 = 0xffffffffu;
+    }
+    // append in band order (the owner's own part is the first and already in place)
+    std::unique_lock<std::mutex> lk( sh.mu );
+    sh.cv.wait( lk, [&]{ return sh.turn == part; } );
+    if( rc != VVR_OK && sh.rc == VVR_OK ) { sh.rc = rc; sh.err = e; }
+    if( rc == VVR_OK && sh.rc == VVR_OK )
+    {
+      sh.area[0] += area[0]; sh.area[1] += area[1];
+      if( &R != owner )
+      {
+        for( int k = 0; k < owner->ncomp; k++ )
+        {
+          owner->intra[k].insert( owner->intra[k].end(), R.intra[k].begin(), R.intra[k].end() );
+          owner->itemH[k].insert( owner->itemH[k].end(), R.itemH[k].begin(), R.itemH[k].end() );        // (no producer lists in all-intra CTUs: p0 / pn stay 0)
+        }
+        for( int k = 0; k < 3; k++ ) owner->tb[k].insert( owner->tb[k].end(), R.tb[k].begin(), R.tb[k].end() );
+        for( int k = 0; k < K_NUM; k++ ) owner->bytes[k] += R.bytes[k];
+        owner->bytesIntraLuma += R.bytesIntraLuma; for( int k = 0; k < 3; k++ ) owner->bytesTb[k] += R.bytesTb[k];
+        for( uint32_t c = (uint32_t) row0 * owner->ctusX; c < (uint32_t) row1 * owner->ctusX; c++ ) owner->fastCtu[c] = R.fastCtu[c];
+        if( owner->cscale )
+        {
+          const int nv = 1 << ( owner->h.log2_ctu - owner->vpduLog2 );
+          const size_t v0 = (size_t) row0 * nv * owner->vpdusX, v1 = std::min( (size_t) row1 * nv, (size_t) owner->vpdusY ) * owner->vpdusX;
+          if( v1 > v0 ) memcpy( &owner->csVpduV[v0], &R.csVpduV[v0], sizeof( uint32_t ) * ( v1 - v0 ) );
+        }
+      }
+    }
+    sh.turn = part + 1;
+    sh.cv.notify_all();
+  } );
+  if( sh.rc != VVR_OK ) { err = sh.err; return sh.rc; }
+  if( validate ) return validate_cover( p, sh.area, err );
+  return VVR_OK;
+}
+
+int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, std::string& err, PinnedRanges* pinned, HostHelpers* helpers, bool validateRecords )
 {
   S.begin( p );
   int rc;
+  // an I picture without intra block copy whose CUs are all intra CUs (beginMaps looks): in parts, when there is somebody to share the work with
+  if( helpers && helpers->width() > 1 && p->hdr.slice_type == 2 && !( p->hdr.tool_flags & VVR_TOOL_IBC ) && p->ctu_first_cu && p->num_cu >= 512 && S.ctusY >= 2 )
+  {
+    if( ( rc = S.beginMaps() ) != VVR_OK ) return rc;
+    if( S.allIntraCus )
+    {
+      if( ( rc = S.buildInParts( vvr_config(), *helpers, validateRecords, err ) ) != VVR_OK || ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK
+       || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
+      S.layout( pinned );
+      *totalBytes = S.total;
+      return VVR_OK;
+    }
+  }
+  if( validateRecords && ( rc = vvr_host_validate_records( vvr_config(), p, err ) ) != VVR_OK ) return rc;
 #ifdef VVR_DEV_ENV
   if( getenv( "VVR_PHASES" ) )
   {
@@ -1322,7 +1447,14 @@ void vvr_host_gather_col( const vvr_picture* p, vvr_motion* dst )
 
 void vvr_host_pack( const PrepScratch& S, char* host )
 {
-  for( size_t i = S.numDirect; i < S.parts.size(); i++ ) { const Part& pt = S.parts[i]; if( pt.n && pt.src ) memcpy( host + pt.off, pt.src, pt.n ); }
+  // (the alignment gap behind a part is cleared: what goes to the device is a function of the picture alone, not of what the ring entry held before)
+  for( size_t i = S.numDirect; i < S.parts.size(); i++ )
+  {
+    const Part& pt = S.parts[i];
+    if( pt.n && pt.src ) memcpy( host + pt.off, pt.src, pt.n );
+    const size_t end = pt.off + ( pt.src ? pt.n : 0 ), next = i + 1 < S.parts.size() ? S.parts[i + 1].off : S.total;
+    if( next > end && next - end < 4096 ) memset( host + end, 0, next - end );
+  }
 }
 
 void vvr_host_upload_plan( const PrepScratch& S, std::vector<DirectCopy>& direct, size_t* stagedBegin, size_t* stagedEnd )
