@@ -709,7 +709,9 @@ static void workerMain( vvr_context* c )
   pinToCpus( c->nodeCpus );
   PrepScratch* S = vvr_scratch_create();
   vvr_scratch_warm( S, c->cfg );
+  // (a second scratch for the parts of its own I picture that nobody else takes, see WorkerHelpers::run: allocated and touched now, not inside a picture)
   PrepScratch* spare = nullptr;
+  if( c->cfg.host_threads > 1 ) { spare = vvr_scratch_create(); vvr_scratch_warm( spare, c->cfg ); }
   WorkerHelpers helpers( c, spare );
   for( ;; )
   {
