@@ -494,8 +494,9 @@ typedef struct vvr_kernel_stat {
 } vvr_kernel_stat;
 VVR_API int          vvr_enable_stats(vvr_context* ctx, int on);
 VVR_API int          vvr_get_stats(vvr_context* ctx, vvr_kernel_stat* out, int max_entries);
-/* practical HBM ceiling of this device: bytes per second (read + written) of the library's device copy kernel over one DPB
- * slot, HIP-event timed, averaged over `iters` launches; slot 0 is read, nothing of any slot is modified */
+/* practical HBM ceiling of this device: bytes per second (read + written) of the library's device copy kernel over as much of the DPB
+ * as the context's scratch planes hold (hundreds of MB for a 4K context: far beyond the caches), HIP-event timed, averaged over `iters` launches;
+ * the DPB is only read, the scratch planes hold nothing between pictures */
 VVR_API double       vvr_measure_copy_bandwidth(vvr_context* ctx, int iters);
 
 /* Host glue helpers (pure functions, no device): what the reference computes per CU/TU on the CPU before the

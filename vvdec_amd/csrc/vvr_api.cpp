@@ -837,7 +837,8 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   vvr_context* c = new vvr_context();
   c->cfg = *cfg; c->device = cfg->device;
   const int ns = std::max<int>( 1, cfg->num_streams );
-  // lanes: num_streams of them taken in turn, plus (streaming contexts) one with a high-priority stream for I pictures, see planCommitLocked
+  // lanes: num_streams of them taken in turn, plus - whenever there are at least two - one with a high-priority stream for I pictures, see planCommitLocked
+  // (also without worker threads: vvr_submit_prepared and inline submission order pictures the same way)
   const int nl = ns + ( ns >= 2 ? 1 : 0 );
   c->numLanesRR = ns; c->prioLane = nl > ns ? ns : -1;
   c->streams.resize( nl, nullptr );
