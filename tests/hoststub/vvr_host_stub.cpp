@@ -56,7 +56,8 @@ hipError_t hipMemsetAsync( void* d, int v, size_t n, hipStream_t ) { memset( d, 
 // kernel launches: nothing to run on the host; the launch of the intra stage records what it was handed
 static int g_lastIntraUnits = -1; static const int* g_lastSync = nullptr;
 int  vvr_upload_tables() { return 0; }
-void launch_mc( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int ) { if( g_delayUs ) usleep( g_delayUs ); }
+void launch_expand_mc( hipStream_t, const PicDev&, const McCuRef*, int, McItem*, McItem*, McItem* ) {}
+void launch_mc( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, const McItem*, int, int ) { if( g_delayUs ) usleep( g_delayUs ); }
 void launch_itrans( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const TbItem*, int, int ) {}
 // The one launch that leaves a trace in the "picture": the vertical deblocking pass stamps the first four luma samples of the output slot with
 // a hash of the picture's POC and of the stamps found in its reference slots at that moment.  Launches run at submission time here, so
@@ -146,12 +147,13 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
   switch( which )
   {
   case 0: *p = q->mcItems;   *n = sizeof( McItem ) * q->numMc; break;
-  case 1: *p = q->bdofItems; *n = sizeof( McItem ) * q->numBdofItems; break;
-  case 2: *p = q->dmvrItems; *n = sizeof( McItem ) * q->numDmvrItems; break;
+  case 1: *p = nullptr; *n = 0; break;        // (BDOF and DMVR tiles: written by the device, see 10)
+  case 2: *p = nullptr; *n = 0; break;
   case 3: *p = q->affItems;  *n = sizeof( McItem ) * q->numAffItems; break;
   case 4: case 5: case 6: *p = q->tbItems[which - 4]; *n = sizeof( TbItem ) * q->numTb[which - 4]; break;
   case 7: *p = q->intraItems; *n = sizeof( IntraItem ) * q->numIntra; break;
   case 8: *p = q->units; *n = sizeof( IntraUnit ) * q->numActive; break;
+  case 10: *p = q->mcCus; *n = sizeof( McCuRef ) * q->numMcCus; break;      // CUs whose MC tiles the device writes
   case 9: *p = q->resiItems; *n = sizeof( IntraItem ) * q->numResi; break;      // residual-add blocks (k_resi_add)
   default: return -1;
   }

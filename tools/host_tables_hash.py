@@ -26,7 +26,7 @@ for (name, W, H, frames, gop, seed, tools, kw) in T.STREAMS + extra:
         h = ctx.prepare(d)
         p, n = C.c_void_p(), C.c_size_t()
         parts = []
-        for which in range(10):                     # logical tables (independent of how the upload is laid out)
+        for which in range(11):                     # logical tables (independent of how the upload is laid out)
             assert L.vvt_table(h, which, C.byref(p), C.byref(n)) == 0
             parts.append(hashlib.md5(C.string_at(p.value, n.value) if n.value else b"").hexdigest()[:12] + ":%d" % n.value)
         hs.append(" ".join(parts))

@@ -352,8 +352,10 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   // INTER stage: prediction of every inter CU, then residual add (DecLibRecon.cpp:831-874)
   // (the four launches write disjoint tiles.  Running them side by side on extra streams of the lane, forked and joined with events, was measured:
   // device-only throughput fell from 1870 to 1240 pictures/s with 4 lanes, to 970 with 8 - the cross-stream waits cost more than the overlap gives)
-  if( q->numMc ) timedOn( K_MC, s, q->bytes[K_MC] - q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc, 0 ); } );
-  if( q->numBdofItems ) timedOn( K_MC, s, q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, A, q->bdofItems, q->numBdofItems, 1 ); } );
+  // (the tiles of plain, BDOF and DMVR CUs are written on the device from the CU records: the host only counted them)
+  if( q->numMcCus ) launch_expand_mc( s, q->pic, q->mcCus, q->numMcCus, q->mcDev, q->bdofItems, q->dmvrItems );
+  if( q->numMc + q->numMcDev ) timedOn( K_MC, s, q->bytes[K_MC] - q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc, q->mcDev, q->numMcDev, 0 ); } );
+  if( q->numBdofItems ) timedOn( K_MC, s, q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, A, nullptr, 0, q->bdofItems, q->numBdofItems, 1 ); } );
   if( q->numDmvrItems )
   {
     // the delta MVs go straight into pinned host memory (device-mapped): a few bytes per 16x16 sub-block, and no copy call on the

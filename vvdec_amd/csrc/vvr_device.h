@@ -34,6 +34,9 @@ struct McItem {
   uint8_t  pad;
   uint16_t clipX, clipY;   // position the MV clipping refers to (the CU, or the sub-block itself for SbTMVP)
 };
+// An inter CU whose tiles the DEVICE writes (k_expand_mc): the host only counts the tiles of such a CU - plain, BDOF and DMVR tiles are a function of
+// the CU record alone (SbTMVP and affine tiles carry motion of the motion field, which stays on the host: those the host writes itself)
+struct McCuRef { uint32_t cu; uint32_t first; };      // index into the CU array; bits 30..31: list (0 plain, 1 BDOF, 2 DMVR), bits 0..29: index of the CU's first tile in that list's device-written part
 #define MC_ITEM_UNI   2    /* one prediction only: a single list, or identical motion in both (xCheckIdenticalMotion) */
 #define MC_ITEM_HPEL  4    /* half-sample AMVR: alternative luma half-sample filter */
 #define MC_ITEM_GEO   8
@@ -119,7 +122,8 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
 struct RefSet { const pel_t* p[2 * VVR_MAX_REFS][3]; };   // reference planes indexed [list * 16 + refIdx][comp]; geometry = the current picture's
 
 // kernel launchers (vvr_kernels.hip) ----------------------------------------------------------------------------------
-void launch_mc     ( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int bdof );
+void launch_mc     ( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, const McItem* items2, int numItems2, int bdof );      // tiles of two arrays (host-written, device-written) in one launch
+void launch_expand_mc( hipStream_t s, const PicDev& pic, const McCuRef* cus, int numCus, McItem* plain, McItem* bdof, McItem* dmvr );
 void launch_itrans ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const TbItem* items, int numItems, int sizeClass );
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir );
 void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );

@@ -15,7 +15,9 @@ enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_RESI_ADD, K_DE
 struct vvr_prepared {
   vvr_pic_header hdr;
   PicDev   pic;
-  McItem*  mcItems = nullptr; int numMc = 0;
+  McItem*  mcItems = nullptr; int numMc = 0;               // plain tiles the host wrote (SbTMVP sub-blocks: their motion comes from the motion field)
+  McItem*  mcDev = nullptr; int numMcDev = 0;              // plain tiles k_expand_mc writes (room reserved behind the uploaded image); BDOF and DMVR tiles are all written there
+  McCuRef* mcCus = nullptr; int numMcCus = 0;              // the CUs k_expand_mc expands
   McItem*  bdofItems = nullptr; int numBdofItems = 0;      // tiles of CUs in BDOF mode (their own launch: larger LDS footprint)
   McItem*  dmvrItems = nullptr; int numDmvrItems = 0;      // sub-blocks that run decoder-side MV refinement
   McItem*  affItems = nullptr; int numAffItems = 0;        // tiles of affine CUs

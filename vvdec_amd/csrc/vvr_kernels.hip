@@ -581,13 +581,13 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
 // BDOF = true: the launch holds only tiles of CUs in BDOF mode (they need 3.5 KB more LDS for the gradient buffers; keeping them out
 // of the plain launch raises the number of resident tiles per CU there).
 template<int NT, bool BDOF>
-__global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
+__global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems, const McItem* __restrict__ items2, int numItems2 )
 {
   __shared__ Mc2Shared m;
   __shared__ typename std::conditional<BDOF, BdofShared, int>::type bs;
   const int item = mc_item_index();
-  if( item >= numItems ) return;
-  const McItem it = items[item];
+  if( item >= numItems + numItems2 ) return;
+  const McItem it = item < numItems ? items[item] : items2[item - numItems];       // (tiles the host wrote - SbTMVP -, then the tiles k_expand_mc wrote)
   const int16_t* __restrict__ fwdLut = lmcs_fwd_at( pic, it.x, it.y );      // LMCS (where the tile's slice uses it): luma predictions are stored forward-mapped (lmcs_fwd_luma)
   const int bd = pic.hdr.bit_depth;
   const int tid = threadIdx.x;
@@ -1183,12 +1183,50 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   }
 }
 
-void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int bdof )
+void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, const McItem* items2, int numItems2, int bdof )
 {
-  if( !numItems ) return;
+  if( !( numItems + numItems2 ) ) return;
   // (one wavefront per tile; two were measured: 123 instead of 106 us per 4K B picture - the stages of a 16x16 tile are 136 and 48 work items)
-  if( bdof ) hipLaunchKernelGGL( ( k_mc<64, true> ),  dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems );
-  else       hipLaunchKernelGGL( ( k_mc<64, false> ), dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems );
+  if( bdof ) hipLaunchKernelGGL( ( k_mc<64, true> ),  dim3( numItems + numItems2 ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems, items2, numItems2 );
+  else       hipLaunchKernelGGL( ( k_mc<64, false> ), dim3( numItems + numItems2 ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems, items2, numItems2 );
+}
+
+// =====================================================================================================================
+// k_expand_mc - the motion-compensation tiles of the CUs whose tiles are a function of the CU record alone (plain, BDOF, DMVR): one thread per
+// CU writes the records of its <= 16x16 tiles where the host reserved room for them (the host only counted them).  Same records as
+// PrepScratch::buildWorkLists writes for the tiles it still writes itself.
+// =====================================================================================================================
+__global__ __launch_bounds__( 64 ) void k_expand_mc( const vvr_cu* __restrict__ cus, const McCuRef* __restrict__ refs, int numRefs, McItem* __restrict__ plain, McItem* __restrict__ bdof, McItem* __restrict__ dmvr )
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if( i >= numRefs ) return;
+  const McCuRef r = refs[i];
+  const vvr_cu cu = cus[r.cu];
+  const int cls = (int) ( r.first >> 30 );
+  McItem* __restrict__ out = ( cls == 0 ? plain : cls == 1 ? bdof : dmvr ) + ( r.first & 0x3fffffffu );
+  McItem base;
+  base.x = 0; base.y = 0; base.w = 0; base.h = 0; base.flags = 0; base.cu = r.cu;
+  base.mv[0][0] = base.mv[0][1] = base.mv[1][0] = base.mv[1][1] = 0; base.ref[0] = base.ref[1] = 0; base.bcw = 0; base.pad = 0; base.clipX = base.clipY = 0;
+  if( cls != 2 )
+  {
+    // everything k_mc needs about the motion of the tile
+    base.ref[0] = cu.ref_idx[0]; base.ref[1] = cu.ref_idx[1];
+    base.mv[0][0] = cu.mv[0][0][0]; base.mv[0][1] = cu.mv[0][0][1]; base.mv[1][0] = cu.mv[1][0][0]; base.mv[1][1] = cu.mv[1][0][1];
+    base.clipX = cu.x; base.clipY = cu.y;
+    base.bcw = cu.bcw_idx;
+    base.flags = (uint16_t) ( ( cu.mc_mode == VVR_MC_UNI ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 ) );
+  }
+  for( int y = 0; y < cu.h; y += 16 ) for( int x = 0; x < cu.w; x += 16 )
+  {
+    McItem it = base;
+    it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) min( 16, cu.w - x ); it.h = (uint8_t) min( 16, cu.h - y );
+    *out++ = it;
+  }
+}
+void launch_expand_mc( hipStream_t s, const PicDev& pic, const McCuRef* cus, int numCus, McItem* plain, McItem* bdof, McItem* dmvr )
+{
+  if( !numCus ) return;
+  hipLaunchKernelGGL( k_expand_mc, dim3( ( numCus + 63 ) / 64 ), dim3( 64 ), 0, s, pic.cu, cus, numCus, plain, bdof, dmvr );
 }
 
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )

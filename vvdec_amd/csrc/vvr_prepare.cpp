@@ -35,7 +35,9 @@ struct PrepScratch
   int ncomp = 0, w4 = 0, h4 = 0, ctu = 0, ctusX = 0, ctusY = 0, numCtu = 0, vpduLog2 = 0, vpdusX = 0, vpdusY = 0;
   bool wpOn = false, cscale = false, lmcs = false;
   // ---- work lists
-  std::vector<McItem> mc, mcBdof, mcDmvr, mcAff;
+  std::vector<McItem> mc, mcBdof, mcDmvr, mcAff;      // tiles the host writes: SbTMVP sub-blocks (mc), affine tiles (mcAff); mcBdof / mcDmvr stay empty (k_expand_mc)
+  std::vector<McCuRef> mcCus;              // CUs whose tiles the device writes, with where (list, first tile)
+  uint32_t devTiles[3] = { 0, 0, 0 };      // tiles the device writes per list (plain, BDOF, DMVR)
   std::vector<uint16_t> ctuSubpicV;        // sub-picture of every CTU, built from the rectangles (layout)
   std::vector<vvr_motion> affMv;           // motion of the 4x4 sub-blocks of the affine tiles, 16 entries per tile (the only part of the motion field a kernel reads)
   uint32_t numDmvr = 0;
@@ -81,7 +83,8 @@ struct PrepScratch
   // ---- layout of the H2D image
   std::vector<Part> parts;
   size_t total = 0, numDirect = 0;          // parts [0, numDirect) are copied from the caller's pinned arrays
-  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iSlices, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iResi, iUnits;
+  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iSlices, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iResi, iUnits, iMcCus, iMcDev[3];
+  size_t stagedEndOff = 0;                  // end of the uploaded part of the image
 
   void begin( const vvr_picture* pic )
   {
@@ -106,6 +109,7 @@ struct PrepScratch
     cscale = lmcs && ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && ncomp == 3;
     vpduLog2 = std::min<int>( 6, h.log2_ctu ); vpdusX = ( h.width + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2; vpdusY = ( h.height + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2;
     mc.clear(); mcBdof.clear(); mcDmvr.clear(); mcAff.clear(); affMv.clear(); numDmvr = 0;
+    mcCus.clear(); devTiles[0] = devTiles[1] = devTiles[2] = 0;
     for( int k = 0; k < 3; k++ ) { tb[k].clear(); intra[k].clear(); itemH[k].clear(); prodPool[k].clear(); }
     resiAdd.clear(); intraAll.clear(); units.clear(); unitsDev.clear(); csVpduV.clear();
     ctuStartV.assign( 3 * (size_t) ( numCtu + 1 ), 0 );
@@ -801,6 +805,20 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
       const bool af = cu.mc_mode == VVR_MC_AFFINE;
       std::vector<McItem>& list = dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc;
       const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
+      if( !af && !sbt )
+      {
+        // plain, BDOF and DMVR tiles are a function of the CU record: counted here, written on the device (k_expand_mc)
+        const int cls = dm ? 2 : cu.mc_mode == VVR_MC_BDOF ? 1 : 0;
+        const uint32_t nt = (uint32_t) ( ( cu.w + 15 ) >> 4 ) * ( ( cu.h + 15 ) >> 4 );
+        mcCus.push_back( McCuRef{ i, ( (uint32_t) cls << 30 ) | devTiles[cls] } );
+        devTiles[cls] += nt;
+        const double smp = (double) cu.w * cu.h * ( ncomp == 3 ? 1.5 : 1.0 );
+        const double bts = smp * 2 * nla + smp * 2 + nt * ( sizeof( McItem ) + ( dm ? 8 : 0 ) );
+        bytes[dm ? K_MC_DMVR : K_MC] += bts;
+        if( cls == 1 ) bytesBdof += bts;
+      }
+      else
+      {
       // one record per tile: what the tiles of a CU share is filled once
       McItem base; memset( &base, 0, sizeof( base ) );
       base.flags = sbt ? MC_ITEM_SUBBLOCK : 0; base.cu = i;
@@ -850,6 +868,7 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
         bytes[dm ? K_MC_DMVR : af ? K_MC_AFFINE : K_MC] += bts;
         if( &list == &mcBdof ) bytesBdof += bts;
       }
+      }     // (tiles written by the host)
       if( dm ) numDmvr = std::max<uint32_t>( numDmvr, cu.dmvr_off + ( ( cu.w + 15 ) / 16 ) * ( ( cu.h + 15 ) / 16 ) );
       bytes[K_MC] += sizeof( vvr_cu );
     }
@@ -1322,9 +1341,13 @@ void PrepScratch::layout( PinnedRanges* pinned )
   iMcD = add( mcDmvr.data(), sizeof( McItem ) * mcDmvr.size() );
   iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
   for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
+  iMcCus = add( mcCus.data(), sizeof( McCuRef ) * mcCus.size() );
   iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
   iResi = add( resiAdd.data(), sizeof( IntraItem ) * resiAdd.size() );
   iUnits = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
+  // behind everything that is uploaded: room for what the device writes itself (k_expand_mc)
+  stagedEndOff = total;
+  for( int k = 0; k < 3; k++ ) iMcDev[k] = add( nullptr, sizeof( McItem ) * devTiles[k] );
 }
 
 // The work lists of a picture whose CUs are all intra CUs, built in parts (bands of CTU rows) by several threads: such CTUs are analysed without looking
@@ -1462,7 +1485,7 @@ void vvr_host_upload_plan( const PrepScratch& S, std::vector<DirectCopy>& direct
   direct.clear();
   for( size_t i = 0; i < S.numDirect; i++ ) direct.push_back( DirectCopy{ S.parts[i].src, S.parts[i].n, S.parts[i].off } );
   *stagedBegin = S.parts[S.numDirect].off;
-  *stagedEnd = S.total;
+  *stagedEnd = S.stagedEndOff;
 }
 
 
@@ -1483,8 +1506,10 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   d.subpics = (const vvr_subpic*) at( S.iSubpics ); d.ctuSubpic = (const uint16_t*) at( S.iCtuSubpic );
   d.csVpdu = (const uint32_t*) at( S.iCsVpdu ); d.vpdusX = S.vpdusX; d.vpduLog2 = S.vpduLog2;
   q.mcItems = (McItem*) at( S.iMc ); q.numMc = (int) S.mc.size();
-  q.bdofItems = (McItem*) at( S.iMcB ); q.numBdofItems = (int) S.mcBdof.size();
-  q.dmvrItems = (McItem*) at( S.iMcD ); q.numDmvrItems = (int) S.mcDmvr.size();
+  q.mcDev = (McItem*) at( S.iMcDev[0] ); q.numMcDev = (int) S.devTiles[0];
+  q.bdofItems = (McItem*) at( S.iMcDev[1] ); q.numBdofItems = (int) S.devTiles[1];
+  q.dmvrItems = (McItem*) at( S.iMcDev[2] ); q.numDmvrItems = (int) S.devTiles[2];
+  q.mcCus = (McCuRef*) at( S.iMcCus ); q.numMcCus = (int) S.mcCus.size();
   q.affItems = (McItem*) at( S.iMcA ); q.numAffItems = (int) S.mcAff.size();
   q.numDmvr = S.numDmvr;
   for( int k = 0; k < 3; k++ ) { q.tbItems[k] = (TbItem*) at( S.iTb[k] ); q.numTb[k] = (int) S.tb[k].size(); }
