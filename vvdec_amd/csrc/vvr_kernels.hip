@@ -1352,8 +1352,8 @@ __device__ __forceinline__ int scaling_entry( const vvr_scaling_list* __restrict
 template<int MAXN, int NT>
 __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, DevPlanes resi, const TbItem* __restrict__ items, int numItems )
 {
-  __shared__ int32_t dq[MAXN * MAXN];
-  __shared__ int32_t tmp[MAXN * MAXN];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t dq[MAXN * MAXN];      // (16-byte reads in the two passes)
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t tmp[MAXN * MAXN];
   __shared__ int16_t mvS[MAXN * MAXN], mhS[MAXN * MAXN];
   __shared__ int32_t lf_in[16], lf_out[48];
   const int item = blockIdx.x;
@@ -1519,6 +1519,27 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
     for( int i = tid; i < redW * bw; i += NT ) mhS[i] = Mh[i];
     __syncthreads();
     // pass 1 (vertical): tmp[x*bh + y] = clip16( ( sum_k dq[k*bw + x] * Mv[k*bh + y] + 64 ) >> 7 ), x < redW
+    // Four neighbouring columns per work item: one 16-byte read of dq and one basis value per step instead of a read of each per multiply-add
+    // (the kernel lives on the LDS pipe: 512 + 1024 scalar reads per thread for a 64x64 block with a 32x32 corner before this)
+    if( bw >= 4 )
+    {
+      const int grpX = ( redW + 3 ) >> 2;
+      for( int i = tid; i < grpX * bh; i += NT )
+      {
+        const int xg = i / bh, y = i - xg * bh, x0 = xg << 2;
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for( int k = 0; k < cutH; k++ )
+        {
+          const int m = mvS[k * bh + y];
+          const int4 d = *reinterpret_cast<const int4*>( &dq[k * bw + x0] );
+          s0 += d.x * m; s1 += d.y * m; s2 += d.z * m; s3 += d.w * m;
+        }
+        const int sv[4] = { s0, s1, s2, s3 };
+#pragma unroll
+        for( int r = 0; r < 4; r++ ) if( x0 + r < redW ) tmp[( x0 + r ) * bh + y] = clip3( -32768, 32767, ( sv[r] + ( 1 << ( shift1 - 1 ) ) ) >> shift1 );
+      }
+    }
+    else
     for( int i = tid; i < redW * bh; i += NT )
     {
       const int x = i / bh, y = i - x * bh;
@@ -1530,28 +1551,11 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
   }
   // ---- pass 2 (horizontal) + output
   const int ict = it.ict ? (int) it.ict - 4 : 0;
-  for( int i = tid; i < n; i += NT )
+  // the residual r of sample (x, y) goes where it belongs: onto the prediction (inter blocks) or into the residual plane; joint Cb-Cr derives the second one
+  auto emit = [&]( int x, int y, int r )
   {
-    const int y = i / bw, x = i - y * bw;
-    int r;
-    if( isTS ) r = (int16_t) dq[i];
-    else if( dcOnly ) r = dcVal;
-    else if( oneD )
-    {
-      const int n1 = bw == 1 ? bh : bw;
-      int sum = 0;
-      for( int k = 0; k < redW; k++ ) sum += dq[k] * mhS[k * n1 + i];        // (i runs along the only dimension)
-      r = clip3( -32768, 32767, ( sum + ( 1 << shift2 ) ) >> ( shift2 + 1 ) );
-    }
-    else
-    {
-      // out[y*bw + x] = clip16( ( sum_{k<redW} tmp[k*bh + y] * Mh[k*bw + x] + rnd ) >> shift2 )
-      int sum = 0;
-      for( int k = 0; k < redW; k++ ) sum += tmp[k * bh + y] * mhS[k * bw + x];
-      r = clip3( -32768, 32767, ( sum + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
-    }
     int rOther = 0, cOther = 0;
-    int cSelf = comp;
+    const int cSelf = comp;
     if( ict )
     {
       // invTransformCbCr<mode> (TrQuant.cpp:108): derive the second chroma residual
@@ -1574,6 +1578,49 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
       resi.p[cSelf][(size_t) ( by + y ) * resi.stride[cSelf] + bx + x] = (pel_t) r;
       if( ict ) resi.p[cOther][(size_t) ( by + y ) * resi.stride[cOther] + bx + x] = (pel_t) rOther;
     }
+  };
+  if( !isTS && !dcOnly && !oneD && bh >= 4 )
+  {
+    // out[y*bw + x] = clip16( ( sum_{k<redW} tmp[k*bh + y] * Mh[k*bw + x] + rnd ) >> shift2 ): four neighbouring rows per work item (one 16-byte read of
+    // tmp and one basis value per step); neighbouring lanes hold neighbouring columns, so the stores of a row stay contiguous
+    const int grpY = bh >> 2;
+    for( int i = tid; i < grpY * bw; i += NT )
+    {
+      const int yg = i / bw, x = i - yg * bw, y0 = yg << 2;
+      int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      for( int k = 0; k < redW; k++ )
+      {
+        const int m = mhS[k * bw + x];
+        const int4 t = *reinterpret_cast<const int4*>( &tmp[k * bh + y0] );
+        s0 += t.x * m; s1 += t.y * m; s2 += t.z * m; s3 += t.w * m;
+      }
+      const int sv[4] = { s0, s1, s2, s3 };
+#pragma unroll
+      for( int r = 0; r < 4; r++ ) emit( x, y0 + r, clip3( -32768, 32767, ( sv[r] + ( 1 << ( shift2 - 1 ) ) ) >> shift2 ) );
+    }
+    return;
+  }
+  for( int i = tid; i < n; i += NT )
+  {
+    const int y = i / bw, x = i - y * bw;
+    int r;
+    if( isTS ) r = (int16_t) dq[i];
+    else if( dcOnly ) r = dcVal;
+    else if( oneD )
+    {
+      const int n1 = bw == 1 ? bh : bw;
+      int sum = 0;
+      for( int k = 0; k < redW; k++ ) sum += dq[k] * mhS[k * n1 + i];        // (i runs along the only dimension)
+      r = clip3( -32768, 32767, ( sum + ( 1 << shift2 ) ) >> ( shift2 + 1 ) );
+    }
+    else
+    {
+      // out[y*bw + x] = clip16( ( sum_{k<redW} tmp[k*bh + y] * Mh[k*bw + x] + rnd ) >> shift2 )
+      int sum = 0;
+      for( int k = 0; k < redW; k++ ) sum += tmp[k * bh + y] * mhS[k * bw + x];
+      r = clip3( -32768, 32767, ( sum + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
+    }
+    emit( x, y, r );
   }
 }
 
