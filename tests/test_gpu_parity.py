@@ -697,3 +697,17 @@ def test_dropin_slices_with_headers_of_their_own(built, idx, seed, tools_extra, 
     if rotate:
         plain, _ = refdrv.reconstruct_with_motion(d, refs, flags=refdrv.DERIVE_LFP)
         assert all(np.array_equal(a, b) for a, b in zip(plain, want_planes))
+
+
+@pytest.mark.parametrize("threads", [0, 3])
+def test_reference_slots_replicated_between_two_back_ends_on_the_device(built, threads):
+    """the device-side ordering the picture-level multi-GPU split rests on (vvr_stream_wait_job / vvr_stream_wait_slot / vvr_slot_external_event with a
+    torch stream and torch events, vvdec_amd.parallel.TorchDeviceRuntime), on ONE device: tests/two_back_ends_on_one_device.py, in a process of its
+    own (torch brings its own HIP runtime, which has to be the first one the process initialises - the order bench.py uses)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "two_back_ends_on_one_device.py"), str(threads)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "both DPBs equal the single back-end" in r.stdout
