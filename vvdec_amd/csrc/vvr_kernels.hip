@@ -1192,41 +1192,40 @@ void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes 
 }
 
 // =====================================================================================================================
-// k_expand_mc - the motion-compensation tiles of the CUs whose tiles are a function of the CU record alone (plain, BDOF, DMVR): one thread per
-// CU writes the records of its <= 16x16 tiles where the host reserved room for them (the host only counted them).  Same records as
+// k_expand_mc - the motion-compensation tiles of the CUs whose tiles are a function of the CU record alone (plain, BDOF, DMVR): the records of a
+// CU's <= 16x16 tiles, written where the host reserved room for them (the host only counted them).  Same records as
 // PrepScratch::buildWorkLists writes for the tiles it still writes itself.
 // =====================================================================================================================
-__global__ __launch_bounds__( 64 ) void k_expand_mc( const vvr_cu* __restrict__ cus, const McCuRef* __restrict__ refs, int numRefs, McItem* __restrict__ plain, McItem* __restrict__ bdof, McItem* __restrict__ dmvr )
+__global__ __launch_bounds__( 256 ) void k_expand_mc( const vvr_cu* __restrict__ cus, const McCuRef* __restrict__ refs, int numRefs, McItem* __restrict__ plain, McItem* __restrict__ bdof, McItem* __restrict__ dmvr )
 {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+  // one wavefront per CU, one lane per tile (a 128x128 CU has 64 of them)
+  const int i = blockIdx.x * 4 + ( threadIdx.x >> 6 ), t = threadIdx.x & 63;
   if( i >= numRefs ) return;
   const McCuRef r = refs[i];
-  const vvr_cu cu = cus[r.cu];
+  const vvr_cu& cu = cus[r.cu];
+  const int cw = cu.w, ch = cu.h, tilesX = ( cw + 15 ) >> 4, nt = tilesX * ( ( ch + 15 ) >> 4 );
+  if( t >= nt ) return;
   const int cls = (int) ( r.first >> 30 );
-  McItem* __restrict__ out = ( cls == 0 ? plain : cls == 1 ? bdof : dmvr ) + ( r.first & 0x3fffffffu );
-  McItem base;
-  base.x = 0; base.y = 0; base.w = 0; base.h = 0; base.flags = 0; base.cu = r.cu;
-  base.mv[0][0] = base.mv[0][1] = base.mv[1][0] = base.mv[1][1] = 0; base.ref[0] = base.ref[1] = 0; base.bcw = 0; base.pad = 0; base.clipX = base.clipY = 0;
+  McItem it;
+  it.flags = 0; it.cu = r.cu;
+  it.mv[0][0] = it.mv[0][1] = it.mv[1][0] = it.mv[1][1] = 0; it.ref[0] = it.ref[1] = 0; it.bcw = 0; it.pad = 0; it.clipX = it.clipY = 0;
   if( cls != 2 )
   {
     // everything k_mc needs about the motion of the tile
-    base.ref[0] = cu.ref_idx[0]; base.ref[1] = cu.ref_idx[1];
-    base.mv[0][0] = cu.mv[0][0][0]; base.mv[0][1] = cu.mv[0][0][1]; base.mv[1][0] = cu.mv[1][0][0]; base.mv[1][1] = cu.mv[1][0][1];
-    base.clipX = cu.x; base.clipY = cu.y;
-    base.bcw = cu.bcw_idx;
-    base.flags = (uint16_t) ( ( cu.mc_mode == VVR_MC_UNI ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 ) );
+    it.ref[0] = cu.ref_idx[0]; it.ref[1] = cu.ref_idx[1];
+    it.mv[0][0] = cu.mv[0][0][0]; it.mv[0][1] = cu.mv[0][0][1]; it.mv[1][0] = cu.mv[1][0][0]; it.mv[1][1] = cu.mv[1][0][1];
+    it.clipX = cu.x; it.clipY = cu.y;
+    it.bcw = cu.bcw_idx;
+    it.flags = (uint16_t) ( ( cu.mc_mode == VVR_MC_UNI ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 ) );
   }
-  for( int y = 0; y < cu.h; y += 16 ) for( int x = 0; x < cu.w; x += 16 )
-  {
-    McItem it = base;
-    it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) min( 16, cu.w - x ); it.h = (uint8_t) min( 16, cu.h - y );
-    *out++ = it;
-  }
+  const int ty = t / tilesX, tx = t - ty * tilesX, x = tx << 4, y = ty << 4;          // (rows of tiles, as the host writes them)
+  it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) min( 16, cw - x ); it.h = (uint8_t) min( 16, ch - y );
+  ( cls == 0 ? plain : cls == 1 ? bdof : dmvr )[( r.first & 0x3fffffffu ) + t] = it;
 }
 void launch_expand_mc( hipStream_t s, const PicDev& pic, const McCuRef* cus, int numCus, McItem* plain, McItem* bdof, McItem* dmvr )
 {
   if( !numCus ) return;
-  hipLaunchKernelGGL( k_expand_mc, dim3( ( numCus + 63 ) / 64 ), dim3( 64 ), 0, s, pic.cu, cus, numCus, plain, bdof, dmvr );
+  hipLaunchKernelGGL( k_expand_mc, dim3( ( numCus + 3 ) / 4 ), dim3( 256 ), 0, s, pic.cu, cus, numCus, plain, bdof, dmvr );
 }
 
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
