@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--gop", type=int, default=32, help="hierarchical-B GOP size (SURVEY 8(d) config 2: 32, six temporal layers)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed K-picture window is run this many times, each from the first picture of the stream; value = the median")
-    ap.add_argument("--streams", type=int, default=-1, help="pictures in flight per GPU (lanes).  Default: 4 for the random-access configurations (3-4 lanes give the device-only rate of 8 and a better window rate), 8 for all-intra (I pictures are bound by their dependency chain: more of them side by side); profiles/round3_lanes_and_host_threads.txt")
+    ap.add_argument("--streams", type=int, default=-1, help="pictures in flight per GPU (lanes).  Default: 4 for the random-access configurations (3-4 lanes give the device-only rate of 8 and a better window rate), 12 for all-intra (I pictures are bound by their dependency chain: more of them side by side); profiles/round3_lanes_and_host_threads.txt")
     ap.add_argument("--host-threads", type=int, default=-1, help="worker threads inside the library that prepare submitted pictures (default: 8, 16 for --config 8k; round 3, driver arguments: 8 threads 1014..1063 frames/s over five windows, 16 threads 780..1048: sixteen pictures prepared at once contend for memory bandwidth)")
     ap.add_argument("--ring", type=int, default=0, help="entries of the library's upload ring (0: its default)")
     ap.add_argument("--slots", type=int, default=48, help="DPB slots used round-robin (physical slots are cheap in 288 GB: 48 x 25 MB at 4K; fewer slots = more write-after-read waits between pictures in flight)")
@@ -213,7 +213,7 @@ def main():
     ap.add_argument("--verify", type=int, default=8, help="number of timed pictures re-checked against the CPU oracle after the run")
     a = ap.parse_args()
     if a.streams < 0:
-        a.streams = 8 if a.config == "allintra" else 4
+        a.streams = 12 if a.config == "allintra" else 4       # (all-intra: 8 / 10 / 12 / 14 / 16 lanes: device only 900 / 1009 / 1199 / 1236 / 880, through vvr_submit 816 / 934 / 936 / 937 / 629)
     if a.host_threads < 0:
         a.host_threads = 16 if a.config == "8k" else 8       # (8K: four times the host work per picture - 8 threads 261, 16 threads 339 frames/s through vvr_submit)
 
