@@ -756,10 +756,11 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
               for( int yy = 0; yy < 2 * cclmLeft + 4; yy += 4 ) touch( 0, lx0 - 1, ly0 + yy );
             }
             }     // (not an all-intra CTU)
-            else
+            else if( !comp )
             {
               // all-intra CTU: the unit is the whole (component, CTU) in coding order; the last block of it this one reads a reference sample from
-              // (same lines the kernel fills: corner, above incl. above-right, left incl. below-left, the previous ISP partition)
+              // (same lines the kernel fills: corner, above incl. above-right, left incl. below-left, the previous ISP partition).  Luma only: the CTU
+              // wavefront of an I picture advances with the luma units (33 blocks per CTU against a dozen chroma blocks, which stay serial)
               const int l2 = h.log2_ctu, m4 = ( 1 << ( l2 - 2 ) ) - 1, ctuX0 = ( cu.x >> l2 ) << l2, ctuY0 = ( cu.y >> l2 ) << l2;
               int last = -1;
               auto look = [&]( int xc, int yc )
@@ -769,17 +770,24 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
                 const uint16_t j = fastCell[comp][( ( ( ly >> 2 ) & m4 ) << ( l2 - 2 ) ) | ( ( lx >> 2 ) & m4 )];
                 if( j != 0xffff ) last = std::max<int>( last, j );
               };
-              if( it.nTL ) look( rx0 - 1 - mrl, ry0 - 1 - mrl );
-              for( int k = 0; k < it.nA * unit; k += unit ) look( rx0 + k, ry0 - 1 - mrl );
-              for( int k = 0; k < it.nL * unit; k += unit ) look( rx0 - 1 - mrl, ry0 + k );
-              if( ispL && ( x0 != rx0 || y0 != ry0 ) ) look( cu.isp_mode == 2 ? x0 - 1 : x0, cu.isp_mode == 2 ? y0 : y0 - 1 );
+              // (nearly nine blocks in ten read the block directly before them - their left or above neighbour in z order: those places first, and no
+              // further look once that block is found)
               const int local = (int) ( myId - fastFirst[comp] );
+              if( ispL && ( x0 != rx0 || y0 != ry0 ) ) look( cu.isp_mode == 2 ? x0 - 1 : x0, cu.isp_mode == 2 ? y0 : y0 - 1 );
+              if( last < local - 1 && it.nL ) look( rx0 - 1 - mrl, ry0 );
+              if( last < local - 1 && it.nA ) look( rx0, ry0 - 1 - mrl );
+              for( int k = it.nA * unit - unit; k > 0 && last < local - 1; k -= unit ) look( rx0 + k, ry0 - 1 - mrl );       // (above-right first: the latest blocks)
+              for( int k = it.nL * unit - unit; k > 0 && last < local - 1; k -= unit ) look( rx0 - 1 - mrl, ry0 + k );
+              if( last < local - 1 && it.nTL ) look( rx0 - 1 - mrl, ry0 - 1 - mrl );
               const uint32_t indep = (uint32_t) std::min( 63, std::max( 0, local - 1 - last ) );
               intra[comp].back().comp = (uint8_t) ( comp | ( indep << 2 ) );
               if( local < 0xffff )
               {
                 const int cx0 = ( x0 << cs ) >> 2, cx1 = std::min( ( ( ( x0 + w ) << cs ) + 3 ) >> 2, w4 ), cy1 = std::min( ( ( ( y0 + hh ) << cs ) + 3 ) >> 2, h4 );
-                for( int cy = ( y0 << cs ) >> 2; cy < cy1; cy++ ) for( int cx = cx0; cx < cx1; cx++ ) fastCell[comp][( ( cy & m4 ) << ( l2 - 2 ) ) | ( cx & m4 )] = (uint16_t) local;
+                // (later blocks only ever look at the cells along a block's right and bottom edge: their reference lines run there)
+                const int cy0 = ( y0 << cs ) >> 2;
+                for( int cx = cx0; cx < cx1; cx++ ) fastCell[comp][( ( ( cy1 - 1 ) & m4 ) << ( l2 - 2 ) ) | ( cx & m4 )] = (uint16_t) local;
+                for( int cy = cy0; cy < cy1 - 1; cy++ ) fastCell[comp][( ( cy & m4 ) << ( l2 - 2 ) ) | ( ( cx1 - 1 ) & m4 )] = (uint16_t) local;
               }
             }
             // the cells this block reconstructs (the map is only ever read by the producer analysis of CTUs that are not all intra)
