@@ -35,6 +35,7 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: l
 import argparse
 import ctypes as C
 import json
+import re
 import os
 import sys
 import time
@@ -126,6 +127,38 @@ def _cpu_worker(args):
         refdrv.oracle_reconstruct(d, refs)
         dt = time.perf_counter() - t0
     return dt
+
+
+def dropin_host_cost(cfg_name, seed, gop, threads=8):
+    """what the reference-side half of the DROP-IN costs per picture (integration/DecLibReconDropIn.cpp: LF_INIT by the reference's own
+    LoopFilter::calcFilterStrengthsCTU over the decoder's thread pool, flattening the reference's objects into a vvr_picture, the planes back into
+    the Picture's buffers) - one B picture of the stream through vvdec::DecLibRecon with this library behind it, in a process of its own.  Part of
+    the cpu_baseline leg (it runs the reference's classes from oracle/_ref); None where that build is absent."""
+    import subprocess
+    code = (
+        "import os, sys, re\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "os.environ['VVDEC_AMD_TIMES'] = '1'\n"
+        "import torch, refdrv, vvdec_amd, bench\n"
+        "from vvdec_amd import abi, synth, stream\n"
+        "assert refdrv.available() and refdrv.dropin_available()\n"
+        "W, H, mix, _, _ = bench.CONFIGS[%r]\n"
+        "plans, _ = stream.ra_plan(%d + 1, gop=%d, seed_poc0_is_external=False)\n"
+        "pl = plans[2]\n"
+        "d = synth.picture_for_plan(pl, W, H, seed=%d, tool_flags=bench._tools(abi), **mix)\n"
+        "refs = {slot: synth.natural_picture(W, H, %d + 100 + poc) for lst in pl.ref_slots for (slot, poc) in lst}\n"
+        "refdrv.run_dropin(d, refs, vvdec_amd._LIBPATH, threads=%d)\n"
+    ) % (ROOT, ROOT, cfg_name, gop, gop, seed, seed, threads)
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        m = re.search(r"host ms per picture: MIDER ([0-9.]+), LF_INIT ([0-9.]+), flatten ([0-9.]+), submit\+device ([0-9.]+), planes back ([0-9.]+)", r.stderr)
+        if not m:
+            return None
+        return {"lf_init": float(m.group(2)), "flatten": float(m.group(3)), "planes_back": float(m.group(5)), "pool_threads": threads,
+                "what": "ms per picture (one B picture of this stream) the reference-side half of the drop-in spends on the host: the reference's own edge-parameter derivation over its thread pool, "
+                        "the walk over the reference's CU / TU lists into the records of include/vvr.h, the finished planes copied back into the Picture's buffers"}
+    except Exception:
+        return None
 
 
 def cpu_baseline(cfg_name, seed, gop, budget_s=20.0):
@@ -412,6 +445,10 @@ def main():
                "roofline": roof}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.config, seed, a.gop)
+            if a.config != "allintra":
+                cost = dropin_host_cost(a.config, seed, a.gop)
+                if cost:
+                    out["cpu_baseline"]["dropin_host_ms_per_picture"] = cost
     for h in prepared.values():
         rec.free_prepared(h)
     rec.close()
