@@ -19,6 +19,13 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def built():
     """Everything compiled: product library (hipcc), oracle restatement (gcc), synthetic generator (g++)."""
+    import fcntl
     import __graft_entry__ as g
-    g.build()
+    # (pytest-xdist: every worker process has a session of its own - one of them builds, the others wait and then find everything up to date)
+    with open(os.path.join(ROOT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            g.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return True

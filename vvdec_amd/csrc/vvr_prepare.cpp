@@ -949,6 +949,28 @@ int PrepScratch::formUnits()
   {
     const size_t n = intra[k].size();
     if( !n ) continue;
+    if( allIntraCus && intraChunk >= n )
+    {
+      // a picture whose CUs are all intra CUs: the blocks of a (component, CTU) are one unit and already lie together, in coding order - the units
+      // are the runs of equal CTU (what the general way below arrives at through union-find, member lists and a sorted copy of the blocks)
+      for( size_t i = 0; i < n; )
+      {
+        UnitH u; u.comp = (uint32_t) k; u.ctu = itemH[k][i].ctu; u.i0 = (uint32_t) i;
+        for( ; i < n && itemH[k][i].ctu == u.ctu; i++ )
+        {
+          const BBox& b = itemH[k][i].bb;
+          u.bb.y0 = std::min( u.bb.y0, b.y0 ); u.bb.y1 = std::max( u.bb.y1, b.y1 ); u.bb.c0 = std::min( u.bb.c0, b.c0 ); u.bb.c1 = std::max( u.bb.c1, b.c1 );
+          if( k && ( intra[k][i].flags & IT_F_CSCALE ) ) u.hasCs = true;
+        }
+        u.i1 = (uint32_t) i; u.iA = u.i0;
+        units.push_back( std::move( u ) );
+      }
+      uint32_t* cnt = &ctuStartV[(size_t) k * ( numCtu + 1 )];
+      std::fill( cnt, cnt + numCtu + 1, 0u );
+      for( auto& ih : itemH[k] ) cnt[ih.ctu + 1]++;
+      for( int a = 0; a < numCtu; a++ ) cnt[a + 1] += cnt[a];
+      continue;
+    }
     const std::vector<uint32_t>& pool = prodPool[k];
     parent.resize( n );
     for( size_t i = 0; i < n; i++ ) parent[i] = (uint32_t) i;
@@ -1091,6 +1113,9 @@ int PrepScratch::groupUnits()
   // on each other, a workgroup start costs more than a few small blocks, and waiting for the union of their producers delays nothing
   // that matters (all of them are less deep).  Residual-add units keep their own (HBM to HBM) workgroup.
   if( units.empty() ) return VVR_OK;
+  // a picture whose CUs are all intra CUs: one unit per (component, CTU) and the join units of long dependency lists - nothing shares a
+  // (component, CTU, depth), every group would be a unit by itself, in the order they are in
+  if( allIntraCus ) return VVR_OK;
   target.assign( units.size(), -1 );            // original unit -> group
   size_t numGroups = 0;                         // groups: original units in creation order
   auto newGroup = [&]() { if( groups.size() <= numGroups ) groups.emplace_back(); groups[numGroups].clear(); return numGroups++; };
