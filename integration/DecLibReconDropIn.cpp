@@ -212,7 +212,8 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
   // ---- LF_INIT (DecLibRecon.cpp:807-829): the edge parameters are an input of the back-end
   // (the CTUs are independent - the reference runs one task per CTU; here the picture's task fans out over a few threads of its own.  VVDEC_AMD_HOST_THREADS,
   // default 4: with several pictures in flight the decoder's pool is busy with their tasks)
-  const int hostThreads = getenv( "VVDEC_AMD_HOST_THREADS" ) ? atoi( getenv( "VVDEC_AMD_HOST_THREADS" ) ) : 4;
+  // threads of this picture's host work (LF_INIT, the flattening): as many as the decoder's pool has, at least 4 (VVDEC_AMD_HOST_THREADS overrides)
+  const int hostThreads = getenv( "VVDEC_AMD_HOST_THREADS" ) ? atoi( getenv( "VVDEC_AMD_HOST_THREADS" ) ) : std::min( 16, std::max( 4, d.m_decodeThreadPool ? d.m_decodeThreadPool->numThreads() : 0 ) );
   vvr_glue::parallelFor( numCtu, hostThreads, [&]( int a )
   {
     CtuData& cd = cs.getCtuData( a );
@@ -264,7 +265,7 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
           if( vvr_write_plane( S.ctx, rs, (int) c, reinterpret_cast<const uint16_t*>( rb.bufs[c].buf ), (size_t) rb.bufs[c].stride ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( S.ctx ) );
       }
     double t2b = nowMs();
-    vvr_glue::extractPicture( cs, slice, *pic, rsp, R.m_cTrQuant, [&S]( const Picture* p ) { auto q = S.slotOf.find( p ); return q == S.slotOf.end() ? -1 : q->second; }, slot, I.desc, hostThreads );
+    vvr_glue::extractPicture( cs, slice, *pic, rsp, R.m_cTrQuant, [&S]( const Picture* p ) { auto q = S.slotOf.find( p ); return q == S.slotOf.end() ? -1 : q->second; }, slot, I.desc, hostThreads, /* the motion field only where the back-end reads it */ true );
     double t3 = nowMs(); I.msFlatten += t3 - t2b; t2 = t3;
     job = vvr_submit( S.ctx, &I.desc.pic );
     if( job < 0 ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( S.ctx ) );

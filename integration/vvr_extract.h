@@ -10,6 +10,7 @@
 // (Reshape tables, TrQuant::getTrTypes) are reached the way a member function of those classes would reach them.
 #pragma once
 #include <vector>
+#include <memory>
 #include <array>
 #include <functional>
 #include <cstring>
@@ -43,6 +44,7 @@ struct Extracted
   std::vector<int16_t>      coef;
   std::vector<uint32_t>     ctuFirstCu;
   std::vector<vvr_motion>   motion;
+  std::unique_ptr<vvr_motion[]> motionSparse; size_t motionSparseCells = 0;      // (subBlockMotionOnly) the cells under affine / SbTMVP CUs only: never cleared, pages nobody writes are never touched
   std::vector<vvr_lfp>      lfp[2];
   std::vector<vvr_sao_ctu>  sao;
   std::vector<vvr_alf_ctu>  alf;
@@ -53,6 +55,9 @@ struct Extracted
   vvr_scaling_list          scaling;
   std::vector<uint16_t>     ctuSlice, ctuTile;    // filled (and pointed to) when the picture has more than one slice / tile
   std::vector<vvr_subpic>   subpics;              // filled (and pointed to) when the picture has more than one sub-picture
+  // the CU / TU walk in parts (bands of CTUs, one per thread), merged into cu / tu / coef afterwards
+  struct Walk { std::vector<vvr_cu> cu; std::vector<vvr_tu> tu; std::vector<int16_t> coef; std::vector<uint32_t> first; uint32_t numDmvr = 0; std::vector<std::pair<CodingUnit*, uint32_t>> dmvrCus; };
+  std::vector<Walk>         walk;
   uint32_t                  numDmvr = 0;
   std::vector<std::pair<CodingUnit*, uint32_t>> dmvrCus;   // CUs that run DMVR with their offset into the delta-MV output (vvr_read_dmvr)
 };
@@ -210,7 +215,7 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
 
 // slotOf: DPB slot of a reference picture (the caller owns the mapping picture <-> slot); outSlot: slot of the picture itself
 static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& pic, Reshape* reshaper, TrQuant& trQuant,
-                                   const std::function<int( const Picture* )>& slotOf, int outSlot, Extracted& E, int threads = 1 )
+                                   const std::function<int( const Picture* )>& slotOf, int outSlot, Extracted& E, int threads = 1, bool subBlockMotionOnly = false )
 {
   const SPS& sps = *cs.sps; const PPS& pps = *cs.pps; const PreCalcValues& pcv = *cs.pcv;
   const int W = pps.getPicWidthInLumaSamples(), H = pps.getPicHeightInLumaSamples();
@@ -278,9 +283,15 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   E.cu.clear(); E.tu.clear(); E.coef.clear(); E.ctuFirstCu.assign( numCtu + 1, 0 ); E.numDmvr = 0; E.dmvrCus.clear();
   PelUnitBuf reco = cs.getRecoBuf();
   auto isIntraAt = [&]( const CodingUnit& cur, const Position& p ) { const CodingUnit* n = cs.getCURestricted( p, cur, CHANNEL_TYPE_LUMA ); return n && CU::isIntra( *n ); };
-  for( int a = 0; a < numCtu; a++ )
+  // (the walk is split into bands of CTUs, one per thread: every band writes records with band-local indices, the merge below makes them global)
+  const int nParts = std::max( 1, std::min( threads, numCtu ) );
+  if( (int) E.walk.size() < nParts ) E.walk.resize( nParts );
+  auto walkCtus = [&]( int a0, int a1, Extracted::Walk& o )
   {
-    E.ctuFirstCu[a] = (uint32_t) E.cu.size();
+  o.cu.clear(); o.tu.clear(); o.coef.clear(); o.dmvrCus.clear(); o.numDmvr = 0; o.first.assign( a1 - a0, 0 );
+  for( int a = a0; a < a1; a++ )
+  {
+    o.first[a - a0] = (uint32_t) o.cu.size();
     if( !cs.getCtuData( a ).firstCU ) continue;
     for( auto& cu : cs.traverseCUs( a ) )
     {
@@ -336,10 +347,10 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
           c.ciip_neigh_intra = (uint8_t) ( ( isIntraAt( cu, posBL.offset( -1, 0 ) ) ? 1 : 0 ) | ( isIntraAt( cu, posTR.offset( 0, -1 ) ) ? 2 : 0 ) );
         }
         c.mc_mode = resolveMcMode( cu );
-        if( c.mc_mode == VVR_MC_DMVR || c.mc_mode == VVR_MC_DMVR_BDOF ) { c.dmvr_off = E.numDmvr; E.dmvrCus.emplace_back( &cu, E.numDmvr ); E.numDmvr += ( ( la.width + 15 ) / 16 ) * ( ( la.height + 15 ) / 16 ); }
+        if( c.mc_mode == VVR_MC_DMVR || c.mc_mode == VVR_MC_DMVR_BDOF ) { c.dmvr_off = o.numDmvr; o.dmvrCus.emplace_back( &cu, o.numDmvr ); o.numDmvr += ( ( la.width + 15 ) / 16 ) * ( ( la.height + 15 ) / 16 ); }
       }
-      c.first_tu = (uint32_t) E.tu.size();
-      const uint32_t cuIdx = (uint32_t) E.cu.size();
+      c.first_tu = (uint32_t) o.tu.size();
+      const uint32_t cuIdx = (uint32_t) o.cu.size();
       for( auto& tu : TUTraverser( &cu.firstTU, cu.lastTU->next ) )
       {
         vvr_tu t; memset( &t, 0, sizeof( t ) );
@@ -367,35 +378,85 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
           const CompArea& blk = tu.blocks[k];
           const bool full = ( k == 0 ? cu.bdpcmMode() : cu.bdpcmModeChroma() ) != 0;
           const int cw = full ? (int) blk.width : t.max_scan_x[k] + 1, ch = full ? (int) blk.height : t.max_scan_y[k] + 1;
-          t.coef_off[k] = (uint32_t) E.coef.size();
+          t.coef_off[k] = (uint32_t) o.coef.size();
           const PelBuf src = reco.bufs[k].subBuf( blk.pos(), blk.size() );
-          for( int y = 0; y < ch; y++ ) for( int x = 0; x < cw; x++ ) E.coef.push_back( (int16_t) src.at( x, y ) );
+          {
+            // (rows of the corner at once: Pel is a 16-bit sample)
+            static_assert( sizeof( Pel ) == sizeof( int16_t ), "levels are copied as 16-bit values" );
+            const size_t at = o.coef.size();
+            o.coef.resize( at + (size_t) cw * ch );
+            for( int y = 0; y < ch; y++ ) memcpy( &o.coef[at + (size_t) y * cw], &src.at( 0, y ), sizeof( int16_t ) * cw );
+          }
         }
-        E.tu.push_back( t );
+        o.tu.push_back( t );
       }
-      c.num_tu = (uint32_t) E.tu.size() - c.first_tu;
-      E.cu.push_back( c );
+      c.num_tu = (uint32_t) o.tu.size() - c.first_tu;
+      o.cu.push_back( c );
     }
+  }
+  };
+  parallelFor( nParts, nParts, [&]( int r ) { walkCtus( (int) ( (int64_t) numCtu * r / nParts ), (int) ( (int64_t) numCtu * ( r + 1 ) / nParts ), E.walk[r] ); } );
+  {
+    size_t nCu = 0, nTu = 0, nCoef = 0;
+    for( int r = 0; r < nParts; r++ ) { nCu += E.walk[r].cu.size(); nTu += E.walk[r].tu.size(); nCoef += E.walk[r].coef.size(); }
+    E.cu.resize( nCu ); E.tu.resize( nTu ); E.coef.resize( nCoef );
+    uint32_t cuBase = 0, tuBase = 0, coefBase = 0, dmvrBase = 0;
+    for( int r = 0; r < nParts; r++ )
+    {
+      Extracted::Walk& o = E.walk[r];
+      const int a0 = (int) ( (int64_t) numCtu * r / nParts );
+      for( size_t k = 0; k < o.first.size(); k++ ) E.ctuFirstCu[a0 + k] = o.first[k] + cuBase;
+      for( size_t k = 0; k < o.cu.size(); k++ )
+      {
+        vvr_cu c = o.cu[k];
+        c.first_tu += tuBase;
+        if( c.pred_mode == VVR_PRED_INTER && ( c.mc_mode == VVR_MC_DMVR || c.mc_mode == VVR_MC_DMVR_BDOF ) ) c.dmvr_off += dmvrBase;
+        E.cu[cuBase + k] = c;
+      }
+      for( size_t k = 0; k < o.tu.size(); k++ )
+      {
+        vvr_tu t = o.tu[k];
+        t.cu += cuBase;
+        // (only the components with coded levels carry an offset into the level stream: the condition of the walk above)
+        for( int q = 0; q < nComp; q++ ) if( ( t.comp_mask & ( 1 << q ) ) && ( ( t.cbf >> q ) & 1 ) && !( q && t.joint_cbcr && q != ( ( t.joint_cbcr >> 1 ) ? 1 : 2 ) ) ) t.coef_off[q] += coefBase;
+        E.tu[tuBase + k] = t;
+      }
+      if( !o.coef.empty() ) memcpy( &E.coef[coefBase], o.coef.data(), sizeof( int16_t ) * o.coef.size() );
+      for( auto& d : o.dmvrCus ) E.dmvrCus.emplace_back( d.first, d.second + dmvrBase );
+      cuBase += (uint32_t) o.cu.size(); tuBase += (uint32_t) o.tu.size(); coefBase += (uint32_t) o.coef.size(); dmvrBase += o.numDmvr;
+    }
+    E.numDmvr = dmvrBase;
   }
   E.ctuFirstCu[numCtu] = (uint32_t) E.cu.size();
 
   const auto tX1 = std::chrono::steady_clock::now();
   // ---- per-4x4 tables: motion (after MIDER), edge parameters (after LF_INIT)
-  E.motion.resize( (size_t) w4 * h4 ); E.lfp[0].resize( (size_t) w4 * h4 ); E.lfp[1].resize( (size_t) w4 * h4 );
+  E.lfp[0].resize( (size_t) w4 * h4 ); E.lfp[1].resize( (size_t) w4 * h4 );
+  if( !subBlockMotionOnly ) E.motion.resize( (size_t) w4 * h4 );
+  else if( E.motionSparseCells < (size_t) w4 * h4 ) { E.motionSparse.reset( new vvr_motion[(size_t) w4 * h4] ); E.motionSparseCells = (size_t) w4 * h4; }
+  vvr_motion* const motionOut = subBlockMotionOnly ? E.motionSparse.get() : E.motion.data();
+  // motion of one 4x4 cell.  The back-end reads the motion field only under affine and SbTMVP CUs (their sub-block MVs) - and everywhere when it keeps the
+  // collocated motion (VVR_TOOL_COL_MOTION); subBlockMotionOnly: only those cells are written (20 of the 36 bytes per cell the tables take otherwise)
+  auto motionCell = [&]( int x, int y )
+  {
+    const int a = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 ), in = ( y % ctu4 ) * ctu4 + ( x % ctu4 );
+    const CtuData& cd = cs.getCtuData( a );
+    const int se = multi && cd.slice ? st.entryOf( *cd.slice ) : 0;
+    vvr_motion& m = motionOut[(size_t) y * w4 + x]; memset( &m, 0, sizeof( m ) );
+    const MotionInfo& mi = cd.motion[in];
+    for( int l = 0; l < 2; l++ )
+    {
+      m.ref_idx[l] = isMotionValid( mi.miRefIdx[l], MI_NOT_VALID ) ? uniIdx( se, l, mi.miRefIdx[l] ) : (int8_t) -1;
+      m.mv[l][0] = mi.mv[l].getHor(); m.mv[l][1] = mi.mv[l].getVer();
+    }
+  };
   parallelFor( h4, threads, [&]( int y )
   {
     for( int x = 0; x < w4; x++ )
     {
       const int a = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 ), in = ( y % ctu4 ) * ctu4 + ( x % ctu4 );
       const CtuData& cd = cs.getCtuData( a );
-      const int se = multi && cd.slice ? st.entryOf( *cd.slice ) : 0;
-      vvr_motion& m = E.motion[(size_t) y * w4 + x]; memset( &m, 0, sizeof( m ) );
-      const MotionInfo& mi = cd.motion[in];
-      for( int l = 0; l < 2; l++ )
-      {
-        m.ref_idx[l] = isMotionValid( mi.miRefIdx[l], MI_NOT_VALID ) ? uniIdx( se, l, mi.miRefIdx[l] ) : (int8_t) -1;
-        m.mv[l][0] = mi.mv[l].getHor(); m.mv[l][1] = mi.mv[l].getVer();
-      }
+      if( !subBlockMotionOnly ) motionCell( x, y );
       for( int d = 0; d < 2; d++ )
       {
         const LoopFilterParam& s = cd.lfParam[d][in];
@@ -408,6 +469,10 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
     }
   } );
 
+  if( subBlockMotionOnly )
+    for( const vvr_cu& c : E.cu )
+      if( c.pred_mode == VVR_PRED_INTER && ( c.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP ) ) )
+        for( int y = c.y >> 2; y < ( c.y + c.h + 3 ) >> 2; y++ ) for( int x = c.x >> 2; x < ( c.x + c.w + 3 ) >> 2; x++ ) motionCell( x, y );
   const auto tX2 = std::chrono::steady_clock::now();
   if( getenv( "VVR_EXTRACT_TIMES" ) ) fprintf( stderr, "[extract] CU/TU/levels %.2f ms, 4x4 tables %.2f ms\n", std::chrono::duration<double, std::milli>( tX1 - tX0 ).count(), std::chrono::duration<double, std::milli>( tX2 - tX1 ).count() );
   // ---- per-CTU loop filter controls: SAO with merges resolved and offsets scaled (SampleAdaptiveOffset::reconstructBlkSAOParam), ALF
@@ -538,7 +603,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   E.pic.num_cu = (uint32_t) E.cu.size(); E.pic.num_tu = (uint32_t) E.tu.size();
   if( E.coef.empty() ) E.coef.push_back( 0 );
   E.pic.cu = E.cu.data(); E.pic.tu = E.tu.data(); E.pic.ctu_first_cu = E.ctuFirstCu.data(); E.pic.coef = E.coef.data(); E.pic.num_coef = E.coef.size();
-  E.pic.motion = E.motion.data(); E.pic.lfp[0] = E.lfp[0].data(); E.pic.lfp[1] = E.lfp[1].data();
+  E.pic.motion = subBlockMotionOnly ? E.motionSparse.get() : E.motion.data(); E.pic.lfp[0] = E.lfp[0].data(); E.pic.lfp[1] = E.lfp[1].data();
   E.pic.sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) ? E.sao.data() : nullptr;
   E.pic.alf = ( h.tool_flags & VVR_TOOL_ALF ) ? E.alf.data() : nullptr;
   E.pic.alf_params = ( h.tool_flags & VVR_TOOL_ALF ) ? E.alfSets.data() : nullptr; E.pic.num_alf_sets = (uint32_t) E.alfSets.size();
