@@ -36,7 +36,7 @@ extern "C" {
 #define VVR_API
 #endif
 
-#define VVR_ABI_VERSION 4
+#define VVR_ABI_VERSION 5
 
 /* ------------------------------------------------------------------------------------------------------------------
  * status codes (negative = error; mirrors the style of vvdecErrorCodes, include/vvdec/vvdec.h.in:91-105)
@@ -340,6 +340,29 @@ typedef struct vvr_slice_header {
   uint8_t  pad[3];
 } vvr_slice_header;
 
+/* Reference picture resampling (RPR; sps_ref_pic_resampling_enabled_flag, scaling windows of the PPSs): how the current picture sees each of its
+ * reference pictures.  A reference picture is "scaled" when its size or its scaling window differs from the current picture's (Picture::isRefScaled,
+ * Picture.h:265); a prediction from such a picture is interpolated at positions that advance by the scaling ratio per sample, with low-pass filter
+ * sets above ratios of 1.25 and 1.75 (InterPrediction::xPredInterBlkRPR, InterPrediction.cpp:2081-2217), its motion vectors are not clipped, and the
+ * CU takes no BDOF, DMVR or PROF (InterPrediction.cpp:1431-1435,1029).  Indexed like hdr.ref_slot (the union of the slices' lists).  The DPB slot of a
+ * scaled reference picture holds a picture of `width` x `height` luma samples in its top left corner (vvr_config.max_width / max_height bound every
+ * picture of a context; a picture is reconstructed at hdr.width x hdr.height).
+ * Not combined with reference wrap-around or with sub-pictures treated as pictures (the reference keeps no wrap copy of a scaled picture,
+ * Picture.h:278, and a coded video sequence with such sub-pictures does not change its picture size).                                            */
+typedef struct vvr_rpr_ref {
+  int32_t  ratio[2];               /* Slice::getScalingRatio (CU::getRprScaling, UnitTools.cpp:92): x, y; 1 << 14 = same scale; 1 << 11 .. 1 << 15        */
+  int32_t  win_left, win_top;      /* scaling window of the reference picture's PPS: left / top offset in luma samples (offset * SPS::getWinUnitX / Y)    */
+  uint16_t width, height;          /* luma size of the reference picture                                                                                  */
+  uint8_t  scaled;                 /* Picture::isRefScaled( current PPS )                                                                                 */
+  uint8_t  hor_collocated_chroma;  /* sps_chroma_horizontal_collocated_flag / ..vertical.. of the reference picture's SPS (InterPrediction.cpp:2126)      */
+  uint8_t  ver_collocated_chroma;
+  uint8_t  pad;
+} vvr_rpr_ref;
+typedef struct vvr_rpr_params {
+  int32_t     win_left, win_top;   /* scaling window of the current picture's PPS, luma samples                                                           */
+  vvr_rpr_ref ref[2][VVR_MAX_REFS];
+} vvr_rpr_params;
+
 typedef struct vvr_picture {
   vvr_pic_header        hdr;
   uint32_t              num_cu, num_tu;
@@ -369,6 +392,7 @@ typedef struct vvr_picture {
   const vvr_subpic*     subpics;
   uint32_t              num_subpics;
   const vvr_slice_header* slices;      /* [num_slices] or NULL                                                   */
+  const vvr_rpr_params* rpr;           /* NULL: no reference picture of this picture is scaled (ABI 5)           */
   uint32_t              num_slices;    /* (ctu_slice values are < num_slices when slices != NULL)                */
   uint32_t              num_alf_sets;  /* entries of alf_params[] (0 or 1: one table), selected by vvr_slice_header.alf_set */
   uint32_t              num_wp_sets;   /* entries of wp[] (0 or 1: one table), selected by vvr_slice_header.wp_set          */

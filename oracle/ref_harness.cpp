@@ -281,6 +281,16 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       pps.setUseWP( wpP );        // pps_weighted_pred_flag (P slices)
       pps.setWPBiPred( wpB );     // pps_weighted_bipred_flag (B slices)
     }
+    // reference picture resampling (vvr_picture.rpr): the scaling window of the current picture's PPS; the reference pictures get PPSs of their own below.
+    // The description carries what the prediction reads (ratios, left / top offsets, sizes); the ratios are given to the slices as they are (the parser
+    // derives them from the complete windows, Slice::scaleRefPicList / CU::getRprScaling - host glue outside this path)
+    const int winUnitX = SPS::getWinUnitX( cf ), winUnitY = SPS::getWinUnitY( cf );
+    if( vp->rpr )
+    {
+      CHECK( vp->rpr->win_left % winUnitX || vp->rpr->win_top % winUnitY, "scaling window offsets are multiples of the chroma sub-sampling" );
+      sps.setRprEnabledFlag( true );
+      pps.getScalingWindow().setWindow( vp->rpr->win_left / winUnitX, 0, vp->rpr->win_top / winUnitY, 0 );
+    }
     pps.pcv = std::make_unique<PreCalcValues>( sps, pps );
 
     auto ph = std::make_shared<PicHeader>();
@@ -335,23 +345,49 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     const unsigned margin = 16 + ctuSize;
 
     std::map<int, std::unique_ptr<Picture>> refPics;
-    auto getRefPic = [&]( int slot, int poc ) -> Picture*
+    std::vector<std::shared_ptr<PPS>> refPpsStore;
+    std::map<int, std::shared_ptr<SPS>> refSpsStore;
+    auto getRefPic = [&]( int slot, int poc, const vvr_rpr_ref* rr ) -> Picture*
     {
       auto it = refPics.find( slot );
       if( it != refPics.end() ) return it->second.get();
       std::unique_ptr<Picture> p( new Picture( enableOpt ) );
-      p->create( cf, Size( W, Hh ), ctuSize, margin, 0, nullptr );
+      const int rW = rr ? rr->width : W, rH = rr ? rr->height : Hh;
+      p->create( cf, Size( rW, rH ), ctuSize, margin, 0, nullptr );
       p->poc = poc;
       const int nc = cf == CHROMA_400 ? 1 : 3;
       for( int c = 0; c < nc; c++ )
       {
-        const int cw = c ? W >> 1 : W, chh = c ? Hh >> 1 : Hh;
+        const int cw = c ? rW >> 1 : rW, chh = c ? rH >> 1 : rH;
         CHECK( !ref_planes || !ref_planes[slot * 3 + c], "missing reference plane" );
         fillPlane( p->getRecoBuf( ComponentID( c ) ), ref_planes[slot * 3 + c], cw, chh );
       }
+      const PPS* refPps = &pps; const SPS* refSps = &sps;
+      if( rr )
+      {   // the PPS (size, scaling window) and the SPS (chroma sample location) this reference picture was coded with
+        auto rp = std::make_shared<PPS>();
+        rp->setPPSId( 1 + (int) refPpsStore.size() ); rp->setSPSId( 0 );
+        rp->setPicWidthInLumaSamples( rW ); rp->setPicHeightInLumaSamples( rH ); rp->setLog2CtuSize( H.log2_ctu );
+        CHECK( rr->win_left % winUnitX || rr->win_top % winUnitY, "scaling window offsets are multiples of the chroma sub-sampling" );
+        const bool sameGeometry = rW == W && rH == Hh && rr->win_left == vp->rpr->win_left && rr->win_top == vp->rpr->win_top;
+        CHECK( !rr->scaled && ( !sameGeometry || rr->ratio[0] != SCALE_1X.first || rr->ratio[1] != SCALE_1X.second ), "a reference picture of another size / window / ratio is a scaled one" );
+        // Picture::isRefScaled compares the complete windows: a scaled reference of the same size and left / top offsets differs in the right offset
+        rp->getScalingWindow().setWindow( rr->win_left / winUnitX, rr->scaled && sameGeometry ? 1 : 0, rr->win_top / winUnitY, 0 );
+        const int key = ( rr->hor_collocated_chroma ? 1 : 0 ) | ( rr->ver_collocated_chroma ? 2 : 0 );
+        if( !refSpsStore.count( key ) )
+        {
+          auto rs = std::make_shared<SPS>( sps );
+          rs->setHorCollocatedChromaFlag( !!rr->hor_collocated_chroma ); rs->setVerCollocatedChromaFlag( !!rr->ver_collocated_chroma );
+          refSpsStore[key] = rs;
+        }
+        refSps = refSpsStore[key].get();
+        rp->pcv = std::make_unique<PreCalcValues>( *refSps, *rp );
+        refPpsStore.push_back( rp );
+        refPps = rp.get();
+      }
       {
         const APS* noAps[ALF_CTB_MAX_NUM_APS] = { nullptr };
-        p->finalInit( &cuCache, &tuCache, &sps, &pps, ph, noAps, nullptr, nullptr, false );   // gives the picture a CodingStructure (pps/sps/pcv) like a decoded one has
+        p->finalInit( &cuCache, &tuCache, refSps, refPps, ph, noAps, nullptr, nullptr, false );   // gives the picture a CodingStructure (pps/sps/pcv) like a decoded one has
       }
       { Slice* rs = p->allocateNewSlice(); rs->setPOC( poc ); rs->setPicHeader( ph.get() ); rs->setSliceType( I_SLICE ); }
       if( H.wrap_offset )
@@ -504,8 +540,10 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       for( int i = 0; i < H.num_ref[l] && SH.slice_type != 2; i++ )
       {
         const int u = toUnion( si, l, i );
-        Picture* rp = getRefPic( H.ref_slot[l][u], H.ref_poc[l][u] );
+        Picture* rp = getRefPic( H.ref_slot[l][u], H.ref_poc[l][u], vp->rpr ? &vp->rpr->ref[l][u] : nullptr );
         slice->m_apcRefPicList[l][i]     = rp;
+        slice->m_scalingRatio[l][i]      = vp->rpr ? std::pair<int, int>( vp->rpr->ref[l][u].ratio[0], vp->rpr->ref[l][u].ratio[1] ) : SCALE_1X;
+        CHECK( vp->rpr && rp->isRefScaled( &pps ) != !!vp->rpr->ref[l][u].scaled, "reference picture: scaled or not, the description and Picture::isRefScaled disagree" );
         slice->m_aiRefPOCList[l][i]      = H.ref_poc[l][u];
         slice->m_bIsUsedAsLongTerm[l][i] = false;
       }

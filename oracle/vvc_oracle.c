@@ -138,7 +138,9 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
     {
       const int s = H->ref_slot[l][i];
       if( refs[s].p[0] ) continue;
-      if( vvo_planes_alloc( &refs[s], W, Hh, H->chroma_format ) ) goto done;
+      /* a scaled reference picture comes with its own size (vvr_rpr_ref): its planes are tight at that size */
+      const int rw = pic->rpr ? pic->rpr->ref[l][i].width : W, rh = pic->rpr ? pic->rpr->ref[l][i].height : Hh;
+      if( vvo_planes_alloc( &refs[s], rw, rh, H->chroma_format ) ) goto done;
       for( int c = 0; c < ncomp; c++ )
       {
         if( !ref_planes || !ref_planes[s * 3 + c] ) { vvo_set_error( "missing reference plane" ); goto done; }

@@ -3,7 +3,8 @@
  * Follows  CommonLib/InterPrediction.cpp:1372-1459 (motionCompensation dispatch), :623-684 (xPredInterUni),
  *          :686-749 (xPredInterBi), :751-890 (xPredInterBlk), :1349-1370 (xWeightedAverage),
  *          CommonLib/InterpolationFilter.cpp:424-553 (filterCopy), :556-651 (filter<N>), :1057-1215 (filterHor/filterVer),
- *          CommonLib/Buffer.cpp:441-480 (addAvg), CommonLib/Mv.cpp:64-82 (clipMvInPic). */
+ *          CommonLib/Buffer.cpp:441-480 (addAvg), CommonLib/Mv.cpp:64-82 (clipMvInPic),
+ *          CommonLib/InterPrediction.cpp:2081-2217 (xPredInterBlkRPR: predictions from scaled reference pictures). */
 #include "vvc_oracle_common.h"
 #include "../tables/vvc_tables.inc"
 
@@ -117,6 +118,83 @@ static void pred_block_src( const vvo_src* ref, int comp, int bx, int by, int w,
     }
     free( tmp );
   }
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Reference picture resampling: InterPrediction::xPredInterBlkRPR (InterPrediction.cpp:2081-2217).  The reference filters column by column into a
+ * buffer and then row by row out of it; every output sample is  sum_t fV[yFrac(row)][t] * tmp( yInt(row) - (N/2 - 1) + t, col )  with
+ * tmp( y, col ) = ( sum_s fH[xFrac(col)][s] * ref( xInt(col) - (N/2 - 1) + s, y ) + offset ) >> shift  (16-bit), and the rows / columns it reads
+ * outside the picture are the border extension (the rows below picture + margin are copies of the last filtered row, :2188-2196, which is a row of
+ * the margin itself) = clamped reads.  frac == 0 with the regular filters takes filterCopy in the reference (InterpolationFilter.cpp:1059-1065,
+ * 1147-1150); the filters' phase 0 is { 0, 0, 0, 64, 0 .. } and gives the same numbers, so one code path serves.
+ * filterIndex: 0 regular CU, 2 affine sub-block (6-tap filters and their own low-pass sets).  No 4x4 special case: the reference calls
+ * filterHor / filterVer with width 1 / height 1 here. */
+static const vvr_rpr_params* g_rpr = 0;
+static const vvr_rpr_ref* rpr_of( int l, int ri ) { return g_rpr && l >= 0 && ri >= 0 && g_rpr->ref[l][ri].scaled ? &g_rpr->ref[l][ri] : 0; }
+static void pred_block_rpr( const vvo_planes* ref, const vvr_rpr_ref* rr, int comp, int bx, int by, int w, int h, int mvx, int mvy, int bi, int altHpel, int filterIndex, int bd, pel* dst, int dstStride )
+{
+  const int cs = comp ? 1 : 0, shiftHor = 4 + cs, shiftVer = 4 + cs;
+  const int thr1 = ( 1 << 14 ) * 5 / 4, thr2 = ( 1 << 14 ) * 7 / 4;
+  const int rx = rr->ratio[0], ry = rr->ratio[1];
+  int xFilter = filterIndex, yFilter = filterIndex;
+  if( rx > thr2 ) xFilter = 4; else if( rx > thr1 ) xFilter = 3;
+  if( ry > thr2 ) yFilter = 4; else if( ry > thr1 ) yFilter = 3;
+  if( !comp && filterIndex == 2 ) { if( rx > thr1 ) xFilter += 2; if( ry > thr1 ) yFilter += 2; }
+  const int posShift = 14 - 4;
+  const int stepX = ( rx + 8 ) >> 4, stepY = ( ry + 8 ) >> 4;
+  const int offX = 1 << ( posShift - shiftHor - 1 ), offY = 1 << ( posShift - shiftVer - 1 );
+  const int64_t posX = ( ( bx << cs ) - g_rpr->win_left ) >> cs, posY = ( ( by << cs ) - g_rpr->win_top ) >> cs;
+  const int addX = comp ? ( 1 - rr->hor_collocated_chroma ) * 8 * ( rx - ( 1 << 14 ) ) : 0;
+  const int addY = comp ? ( 1 - rr->ver_collocated_chroma ) * 8 * ( ry - ( 1 << 14 ) ) : 0;
+  int64_t x0 = ( posX * ( 1 << ( 4 + cs ) ) + mvx ) * (int64_t) rx + addX;
+  x0 = ( x0 >= 0 ? 1 : -1 ) * ( ( ( x0 >= 0 ? x0 : -x0 ) + ( (int64_t) 1 << ( 7 + cs ) ) ) >> ( 8 + cs ) ) + ( (int64_t) rr->win_left * ( 1 << ( posShift - cs ) ) );
+  int64_t y0 = ( posY * ( 1 << ( 4 + cs ) ) + mvy ) * (int64_t) ry + addY;
+  y0 = ( y0 >= 0 ? 1 : -1 ) * ( ( ( y0 >= 0 ? y0 : -y0 ) + ( (int64_t) 1 << ( 7 + cs ) ) ) >> ( 8 + cs ) ) + ( (int64_t) rr->win_top * ( 1 << ( posShift - cs ) ) );
+  const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
+  const int rw = rr->width >> cs, rh = rr->height >> cs;
+  const int headroom = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2;
+  const int shift1 = IF_FILTER_PREC - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+  int shift2, offset2;
+  if( !bi ) { shift2 = IF_FILTER_PREC + headroom; offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << IF_FILTER_PREC ); }
+  else      { shift2 = IF_FILTER_PREC; offset2 = 0; }
+  for( int row = 0; row < h; row++ )
+  {
+    const int32_t py = (int32_t) y0 + row * stepY;
+    const int yInt = vvo_clip3( -4, rh + 4, ( py + offY ) >> posShift );
+    const int yFrac = ( ( py + offY ) >> ( posShift - shiftVer ) ) & ( ( 1 << shiftVer ) - 1 );
+    const int16_t* cv;
+    if( comp ) cv = yFilter == 3 ? vvc_chroma_filter_rpr1[yFrac] : yFilter == 4 ? vvc_chroma_filter_rpr2[yFrac] : vvc_chroma_filter[yFrac];
+    else if( yFilter == 0 ) cv = ( yFrac == 8 && altHpel && ry == ( 1 << 14 ) ) ? vvc_luma_alt_hpel : vvc_luma_filter[yFrac];
+    else cv = yFilter == 2 ? vvc_luma_filter_4x4[yFrac] : yFilter == 3 ? vvc_luma_filter_rpr1[yFrac] : yFilter == 4 ? vvc_luma_filter_rpr2[yFrac]
+            : yFilter == 5 ? vvc_affine_luma_filter_rpr1[yFrac] : vvc_affine_luma_filter_rpr2[yFrac];
+    for( int col = 0; col < w; col++ )
+    {
+      const int32_t px = (int32_t) x0 + col * stepX;
+      const int xInt = vvo_clip3( -4, rw + 4, ( px + offX ) >> posShift );
+      const int xFrac = ( ( px + offX ) >> ( posShift - shiftHor ) ) & ( ( 1 << shiftHor ) - 1 );
+      const int16_t* ch;
+      if( comp ) ch = xFilter == 3 ? vvc_chroma_filter_rpr1[xFrac] : xFilter == 4 ? vvc_chroma_filter_rpr2[xFrac] : vvc_chroma_filter[xFrac];
+      else if( xFilter == 0 ) ch = ( xFrac == 8 && altHpel && rx == ( 1 << 14 ) ) ? vvc_luma_alt_hpel : vvc_luma_filter[xFrac];
+      else ch = xFilter == 2 ? vvc_luma_filter_4x4[xFrac] : xFilter == 3 ? vvc_luma_filter_rpr1[xFrac] : xFilter == 4 ? vvc_luma_filter_rpr2[xFrac]
+              : xFilter == 5 ? vvc_affine_luma_filter_rpr1[xFrac] : vvc_affine_luma_filter_rpr2[xFrac];
+      int sum2 = 0;
+      for( int t = 0; t < ntaps; t++ )
+      {
+        int sum = 0;
+        for( int u = 0; u < ntaps; u++ ) sum += vvo_ref_at( ref, comp, xInt - half + u, yInt - half + t ) * ch[u];
+        sum2 += (pel) ( ( sum + offset1 ) >> shift1 ) * cv[t];
+      }
+      const pel val = (pel) ( ( sum2 + offset2 ) >> shift2 );
+      dst[row * dstStride + col] = bi ? val : (pel) vvo_clip_pel( val, bd );
+    }
+  }
+}
+
+/* a block of a regular (non-affine) CU from reference picture (l, ri): scaled -> the RPR path, MV as it is (xPredInterUni, InterPrediction.cpp:650,673) */
+static void pred_any( const vvo_planes* ref, const vvr_rpr_ref* rr, int comp, int bx, int by, int w, int h, int mvx, int mvy, int bi, int altHpel, int bd, pel* dst, int dstStride )
+{
+  if( rr ) pred_block_rpr( ref, rr, comp, bx, by, w, h, mvx, mvy, bi, altHpel, 0, bd, dst, dstStride );
+  else pred_block( ref, comp, bx, by, w, h, mvx, mvy, bi, altHpel, bd, dst, dstStride );
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------
@@ -526,6 +604,8 @@ static void affine_list( const vvr_picture* pic, const vvr_cu* cu, int l, const 
   int prof = ( H->tool_flags & VVR_TOOL_PROF ) != 0;
   prof &= !( ( sixP && eqRT && eqLB ) || ( !sixP && eqRT ) );
   prof &= !over;
+  const vvr_rpr_ref* rr = rpr_of( l, cu->ref_idx[l] );
+  prof &= !rr;                                                       /* enablePROF &= !refPicScaled (:1029) */
   int dMvH[16], dMvV[16];
   if( prof )
   {
@@ -602,6 +682,7 @@ static void affine_list( const vvr_picture* pic, const vvr_cu* cu, int l, const 
           d[yy * cw + xx] = v;
         }
       }
+      else if( rr ) pred_block_rpr( ref, rr, c, bx, by, 4, 4, mx, my, bi, 0, 2, bd, d, cw );      /* :1200-1204, filterIndex 2 */
       else pred_block( ref, c, bx, by, 4, 4, mx, my, bi, 0, bd, d, cw );
     }
   }
@@ -692,8 +773,9 @@ static int geo_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* r
       const int slot = H->ref_slot[l][ri];
       if( l < 0 || l > 1 || slot < 0 || slot >= num_slots || !refs[slot].p[0] ) { free( buf ); vvo_set_error( "GPM: bad reference" ); return -1; }
       int mv[2] = { cu->geo_mv[k][0], cu->geo_mv[k][1] };
-      clip_mv_w( mv, cu->x, cu->y, cu->w, H->width, H->height, ctu );
-      pred_block( &refs[slot], c, cu->x >> cs, cu->y >> cs, w, h, mv[0], mv[1], 1, 0, bd, buf + k * n, w );
+      const vvr_rpr_ref* rr = rpr_of( l, ri );
+      if( !rr ) clip_mv_w( mv, cu->x, cu->y, cu->w, H->width, H->height, ctu );
+      pred_any( &refs[slot], rr, c, cu->x >> cs, cu->y >> cs, w, h, mv[0], mv[1], 1, 0, bd, buf + k * n, w );
     }
     const int shift = ( IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2 ) + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
     pel* dst = reco->p[c] + (size_t) ( cu->y >> cs ) * reco->stride[c] + ( cu->x >> cs );
@@ -726,22 +808,26 @@ static void plain_block( const vvr_picture* pic, const vvo_planes* refs, const v
     {
       const int l = ref_idx[0] >= 0 ? 0 : 1;
       int m[2] = { mv[l][0], mv[l][1] };
+      const vvr_rpr_ref* rr = rpr_of( l, ref_idx[l] );
+      if( rr ) ; else
       if( g_wrapOff ) clip_mv_w( m, cu->x, cu->y, cu->w, H->width, H->height, ctu ); else clip_mv_w( m, x, y, w, H->width, H->height, ctu );
       if( wp )
       {
         pel t[16 * 16];
-        pred_block( &refs[H->ref_slot[l][ref_idx[l]]], c, bx, by, bw, bh, m[0], m[1], 1, altHpel, bd, t, bw );
+        pred_any( &refs[H->ref_slot[l][ref_idx[l]]], rr, c, bx, by, bw, bh, m[0], m[1], 1, altHpel, bd, t, bw );
         for( int yy = 0; yy < bh; yy++ ) for( int xx = 0; xx < bw; xx++ ) dst[yy * reco->stride[c] + xx] = (pel) wp_uni( pic, l, ref_idx[l], c, t[yy * bw + xx] );
       }
-      else pred_block( &refs[H->ref_slot[l][ref_idx[l]]], c, bx, by, bw, bh, m[0], m[1], 0, altHpel, bd, dst, reco->stride[c] );
+      else pred_any( &refs[H->ref_slot[l][ref_idx[l]]], rr, c, bx, by, bw, bh, m[0], m[1], 0, altHpel, bd, dst, reco->stride[c] );
       continue;
     }
     pel t[2][16 * 16];
     for( int l = 0; l < 2; l++ )
     {
       int m[2] = { mv[l][0], mv[l][1] };
+      const vvr_rpr_ref* rr = rpr_of( l, ref_idx[l] );
+      if( rr ) ; else
       if( g_wrapOff ) clip_mv_w( m, cu->x, cu->y, cu->w, H->width, H->height, ctu ); else clip_mv_w( m, x, y, w, H->width, H->height, ctu );
-      pred_block( &refs[H->ref_slot[l][ref_idx[l]]], c, bx, by, bw, bh, m[0], m[1], 1, altHpel, bd, t[l], bw );
+      pred_any( &refs[H->ref_slot[l][ref_idx[l]]], rr, c, bx, by, bw, bh, m[0], m[1], 1, altHpel, bd, t[l], bw );
     }
     const int hr = IF_INTERNAL_PREC - bd > 2 ? IF_INTERNAL_PREC - bd : 2;
     for( int yy = 0; yy < bh; yy++ ) for( int xx = 0; xx < bw; xx++ )
@@ -786,6 +872,7 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
   const int ncomp = H->chroma_format ? 3 : 1;
   g_wrapOff = H->wrap_offset; g_wrapFetch = 0;
   g_mcRectOn = 0;
+  g_rpr = pic->rpr;
   g_wp = vvo_wp_set_at( pic, cu->x, cu->y ); g_wpOn = ( vvo_flags_at( pic, cu->x, cu->y ) & VVR_TOOL_WP ) != 0;
   if( pic->subpics && pic->num_subpics > 1 )
     for( uint32_t k = 0; k < pic->num_subpics; k++ )
@@ -796,6 +883,9 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
   if( cu->mc_mode == VVR_MC_AFFINE ) return affine_cu( pic, cu, refs, reco );
   if( cu->mc_mode == VVR_MC_SBTMVP ) return sbtmvp_cu( pic, cu, refs, reco );
   if( cu->mc_mode == VVR_MC_GEO ) return geo_cu( pic, cu, refs, num_slots, reco );
+  if( ( cu->mc_mode == VVR_MC_DMVR || cu->mc_mode == VVR_MC_DMVR_BDOF || cu->mc_mode == VVR_MC_BDOF ) && ( rpr_of( 0, cu->ref_idx[0] ) || rpr_of( 1, cu->ref_idx[1] ) ) )
+  { vvo_set_error( "BDOF / DMVR CU with a scaled reference picture (InterPrediction.cpp:1431-1435)" ); return -1; }
+  if( g_rpr && ( g_wrapOff || g_mcRectOn ) ) { vvo_set_error( "scaled reference pictures with wrap-around / sub-pictures treated as pictures" ); return -1; }
   if( cu->mc_mode == VVR_MC_DMVR || cu->mc_mode == VVR_MC_DMVR_BDOF ) return dmvr_cu( pic, cu, refs, reco, cu->mc_mode == VVR_MC_DMVR_BDOF );
   if( cu->mc_mode != VVR_MC_UNI && cu->mc_mode != VVR_MC_BI && cu->mc_mode != VVR_MC_BDOF ) { vvo_set_error( "inter mode not restated yet" ); return -1; }
   const int altHpel = cu->imv == 3;
@@ -810,17 +900,18 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
       /* one list, or bi with identical motion: xPredInterUni( cu, L0, predBuf, bi=false ) (InterPrediction.cpp:1451-1454) */
       const int l = ( biPred || cu->ref_idx[0] >= 0 ) ? 0 : 1;
       int mv[2] = { cu->mv[l][0][0], cu->mv[l][0][1] };
-      clip_mv_w( mv, cu->x, cu->y, cu->w, H->width, H->height, ctu );
+      const vvr_rpr_ref* rr = rpr_of( l, cu->ref_idx[l] );
+      if( !rr ) clip_mv_w( mv, cu->x, cu->y, cu->w, H->width, H->height, ctu );
       const int slot = H->ref_slot[l][cu->ref_idx[l]];
       if( slot < 0 || slot >= num_slots || !refs[slot].p[0] ) { vvo_set_error( "missing reference slot" ); return -1; }
       if( wp_on( pic, cu->bcw_idx ) )
       {   /* xPredInterUni at 14 bit, then addWeightUni */
         pel* t = (pel*) malloc( sizeof( pel ) * (size_t) w * h );
-        pred_block( &refs[slot], c, bx, by, w, h, mv[0], mv[1], 1, altHpel, bd, t, w );
+        pred_any( &refs[slot], rr, c, bx, by, w, h, mv[0], mv[1], 1, altHpel, bd, t, w );
         for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) dst[y * reco->stride[c] + x] = (pel) wp_uni( pic, l, cu->ref_idx[l], c, t[y * w + x] );
         free( t );
       }
-      else pred_block( &refs[slot], c, bx, by, w, h, mv[0], mv[1], 0, altHpel, bd, dst, reco->stride[c] );
+      else pred_any( &refs[slot], rr, c, bx, by, w, h, mv[0], mv[1], 0, altHpel, bd, dst, reco->stride[c] );
     }
     else
     {
@@ -828,10 +919,11 @@ int vvo_inter_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* re
       for( int l = 0; l < 2; l++ )
       {
         int mv[2] = { cu->mv[l][0][0], cu->mv[l][0][1] };
-        clip_mv_w( mv, cu->x, cu->y, cu->w, H->width, H->height, ctu );
+        const vvr_rpr_ref* rr = rpr_of( l, cu->ref_idx[l] );
+        if( !rr ) clip_mv_w( mv, cu->x, cu->y, cu->w, H->width, H->height, ctu );
         const int slot = H->ref_slot[l][cu->ref_idx[l]];
         if( slot < 0 || slot >= num_slots || !refs[slot].p[0] ) { free( t0 ); vvo_set_error( "missing reference slot" ); return -1; }
-        pred_block( &refs[slot], c, bx, by, w, h, mv[0], mv[1], 1, altHpel, bd, l ? t1 : t0, w );
+        pred_any( &refs[slot], rr, c, bx, by, w, h, mv[0], mv[1], 1, altHpel, bd, l ? t1 : t0, w );
       }
       if( c == 0 && cu->mc_mode == VVR_MC_BDOF )
       {   /* xSubPuBio (:551): sub-blocks of at most 16x16 (MAX_BDOF_APPLICATION_REGION), each with its own border fetch */

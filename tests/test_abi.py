@@ -13,7 +13,8 @@ HDR = os.path.join(ROOT, "include", "vvr.h")
 STRUCTS = [("vvr_pic_header", "PicHeader"), ("vvr_cu", "Cu"), ("vvr_tu", "Tu"), ("vvr_motion", "Motion"), ("vvr_lfp", "Lfp"),
            ("vvr_sao_ctu", "SaoCtu"), ("vvr_alf_ctu", "AlfCtu"), ("vvr_alf_params", "AlfParams"), ("vvr_lmcs_params", "LmcsParams"),
            ("vvr_picture", "Picture"), ("vvr_config", "Config"), ("vvr_kernel_stat", "KernelStat"),
-           ("vvr_wp_params", "WpParams"), ("vvr_scaling_list", "ScalingList"), ("vvr_subpic", "Subpic"), ("vvr_slice_header", "SliceHeader")]
+           ("vvr_wp_params", "WpParams"), ("vvr_scaling_list", "ScalingList"), ("vvr_subpic", "Subpic"), ("vvr_slice_header", "SliceHeader"),
+           ("vvr_rpr_ref", "RprRef"), ("vvr_rpr_params", "RprParams")]
 
 
 def declared_symbols():

@@ -494,3 +494,73 @@ def test_picture_hash_restatement_equals_reference(built, bd, cf, W, H):
         ref = (C.c_uint8 * 48)()
         assert L.vvref_picture_hash(ptrs, W, H, cf, bd, method, ref) == length
         assert b"".join(refdrv.picture_hash(planes, bd, method)) == bytes(ref[:length * len(planes)]), "method %d" % method
+
+
+def rpr_case(W, H, l2, idx, seed, specs, win=(0, 0), colloc=(1, 1), tools=ALL, bit_depth=10, chroma_format=1, **kw):
+    """a picture of the plan whose k-th distinct reference picture (in list order) is the scaled picture specs[k] (None: an ordinary one):
+    description with its vvr_rpr_params, reference pictures of their own sizes"""
+    import ctypes as C
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    pl = plans[idx]
+    slots = []
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            if slot not in slots:
+                slots.append(slot)
+    by_slot = {s: (specs[k] if k < len(specs) else None) for k, s in enumerate(slots)}
+    masks, refs_spec = [0, 0], {}
+    for l, lst in enumerate(pl.ref_slots):
+        for i, (slot, poc) in enumerate(lst):
+            if by_slot[slot]:
+                masks[l] |= 1 << i
+                refs_spec[(l, i)] = by_slot[slot]
+    d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, bit_depth=bit_depth, chroma_format=chroma_format, scaled_refs=(C.c_uint16 * 2)(*masks), **kw)
+    synth.attach_rpr(d, refs_spec, win=win, colloc=colloc)
+    refs = {}
+    for lst in pl.ref_slots:
+        for (slot, poc) in lst:
+            sz = (by_slot[slot] or {}).get("size", (W, H))
+            refs.setdefault(slot, [p if chroma_format or c == 0 else None for c, p in enumerate(synth.natural_picture(sz[0], sz[1], seed + 100 + poc, bit_depth=bit_depth))][:3 if chroma_format else 1])
+    return d, refs
+
+
+R1 = 1 << 14
+RPR_CASES = [
+    # W, H, l2, idx, seed, scaled reference pictures, window of the current picture, collocated flags, generator parameters
+    # same size, another window: 1.5x (the first low-pass filter set), one reference picture of two
+    (384, 256, 7, 2, 301, [dict(ratio=(R1 * 3 // 2, R1 * 3 // 2))], (0, 0), (1, 1), dict(p_intra=0.1)),
+    # a reference picture of twice the size: 2x (the second low-pass set), both reference pictures scaled
+    (256, 128, 6, 2, 302, [dict(ratio=(2 * R1, 2 * R1), size=(512, 256)), dict(ratio=(2 * R1, 2 * R1), size=(512, 256))], (0, 0), (1, 1), dict(p_intra=0.1)),
+    # half the size: up-sampling with the regular filters; affine, GPM, CIIP, SbTMVP, BCW, half-sample AMVR among the CUs
+    (384, 256, 7, 3, 303, [dict(ratio=(R1 // 2, R1 // 2), size=(192, 128))], (0, 0), (1, 1), dict(p_intra=0.1, p_affine=0.3, p_geo=0.15, p_ciip=0.15, p_sbtmvp=0.2, p_bcw=0.5, p_imv_hpel=0.3)),
+    # ratios that differ by direction, windows with offsets, chroma samples not collocated, weighted prediction; the second picture at 1.3 x 1.8
+    (400, 208, 6, 2, 304, [dict(ratio=(int(R1 * 1.3), int(R1 * 0.8)), size=(520, 168), win=(16, 6)), dict(ratio=(int(R1 * 1.3), int(R1 * 1.8)), size=(512, 376), win=(-8, 2))], (8, 4), (0, 0),
+     dict(p_intra=0.15, p_affine=0.3, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.2, mv_sigma=6.0, tool_flags_extra=abi.TOOL_WP)),
+    # a P picture (key picture of the plan) from a larger picture, 8 bit
+    (320, 192, 5, 1, 305, [dict(ratio=(int(R1 * 1.6), int(R1 * 1.25)), size=(512, 240))], (0, 0), (1, 0), dict(p_intra=0.1, p_affine=0.3, bit_depth=8)),
+    # 4:0:0
+    (256, 128, 6, 2, 306, [dict(ratio=(R1 * 7 // 4 + 1, R1 * 5 // 4 + 1), size=(448, 160))], (4, 2), (1, 1), dict(p_intra=0.1, p_affine=0.3, p_geo=0.1, chroma_format=0)),
+]
+
+
+@pytest.mark.parametrize("W,H,l2,idx,seed,specs,win,colloc,kw", RPR_CASES)
+def test_oracle_equals_reference_scaled_reference_pictures(built, W, H, l2, idx, seed, specs, win, colloc, kw):
+    """Reference picture resampling (vvr_picture.rpr): predictions from reference pictures of another size / scaling window go through
+    InterPrediction::xPredInterBlkRPR in the reference - positions advancing by the scaling ratio, the three filter sets per component,
+    the affine variants, no MV clipping, no BDOF / DMVR / PROF for those CUs."""
+    kw = dict(kw)
+    tools = ALL | kw.pop("tool_flags_extra", 0)
+    d, refs = rpr_case(W, H, l2, idx, seed, specs, win=win, colloc=colloc, tools=tools, **kw)
+    inter = d.cu[d.cu["pred_mode"] == abi.PRED_INTER]
+    assert len(inter) > 10
+    for fl in (refdrv.STOP_AFTER_RECO, 0):
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs, flags=fl)
+        for c in range(len(want)):
+            assert np.array_equal(got[c], want[c]), "flags %d comp %d: %d differ" % (fl, c, int((got[c] != want[c]).sum()))
+    # the table matters: without it (every reference picture read as an ordinary one of its own size) the picture differs
+    if all("size" not in (s or {}) for s in specs):
+        keep, d.rpr = d.rpr, None
+        other = refdrv.oracle_reconstruct(d, refs, flags=0)
+        d.rpr = keep
+        assert any(not np.array_equal(a, b) for a, b in zip(other, want))

@@ -80,6 +80,8 @@ typedef struct vvs_params {
   uint8_t  intra_slices;        // P / B pictures with several slices: bit ( k & 7 ) set = slice k holds intra (and IBC) CUs only - an I slice in a picture of another kind
   uint8_t  virtual_boundaries;  // bits 0-1: number of vertical, bits 2-3: of horizontal virtual boundaries of the in-loop filters (picture header); bit 4: the first
                                 // of each direction lies on a CTU boundary
+  uint16_t scaled_refs[2];      // reference picture resampling: bit i of [l] = reference picture i of list l is a scaled one (vvr_rpr_ref.scaled; the caller attaches
+                                // the table): CUs predicting from it take no BDOF / DMVR (InterPrediction.cpp:1431-1435) and their MVs are left as drawn
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -520,8 +522,9 @@ struct Gen {
       }
       const bool aff = ( cu.flags & VVR_CU_AFFINE ) != 0;
       const bool wpAny = bi && ( wpPresent( 0, cu.ref_idx[0] ) || wpPresent( 1, cu.ref_idx[1] ) );       // BDOF / DMVR only with default weights (:1420, UnitTools.cpp:1297-1302)
-      const bool bio = ( P.tool_flags & VVR_TOOL_BDOF ) && !wpAny && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );      // (:1407-1427), no SMVD/WP here
-      const bool dmvr = ( P.tool_flags & VVR_TOOL_DMVR ) && !wpAny && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );   // PU::checkDMVRCondition (UnitTools.cpp:1277)
+      const bool anyScaled = ( cu.ref_idx[0] >= 0 && ( ( P.scaled_refs[0] >> cu.ref_idx[0] ) & 1 ) ) || ( cu.ref_idx[1] >= 0 && ( ( P.scaled_refs[1] >> cu.ref_idx[1] ) & 1 ) );
+      const bool bio = !anyScaled && ( P.tool_flags & VVR_TOOL_BDOF ) && !wpAny && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );      // (:1407-1427), no SMVD/WP here
+      const bool dmvr = !anyScaled && ( P.tool_flags & VVR_TOOL_DMVR ) && !wpAny && ( cu.flags & VVR_CU_MERGE ) && bi && eqDist && sizeOk && cu.bcw_idx == 2 && !aff && !( cu.flags & ( VVR_CU_CIIP | VVR_CU_SBTMVP ) );   // PU::checkDMVRCondition (UnitTools.cpp:1277)
       // xCheckIdenticalMotion (:404) is false for affine CUs: they go through xPredInterBi -> xPredAffineBlk per list
       // affine CUs with the same reference picture and the same control points in both lists take the uni-directional path (:424-429)
       if( aff && bi && P.ref_poc[0][cu.ref_idx[0]] == P.ref_poc[1][cu.ref_idx[1]] && rng.p( 0.3 ) ) memcpy( cu.mv[1], cu.mv[0], sizeof( cu.mv[0] ) );

@@ -5,7 +5,7 @@ compiled library so the two cannot drift apart silently.
 """
 import ctypes as C
 
-VVR_ABI_VERSION = 4
+VVR_ABI_VERSION = 5
 VVR_MAX_REFS = 16
 VVR_MAX_ALF_APS = 8
 VVR_ALF_CLASSES = 25
@@ -114,6 +114,14 @@ class SliceHeader(C.Structure):      # vvr_slice_header: what a slice header set
     _fields_ = [("tool_flags", u32), ("deblock_beta_offset_div2", i8 * 3), ("deblock_tc_offset_div2", i8 * 3), ("slice_type", u8), ("alf_set", u8), ("wp_set", u8), ("pad", u8 * 3)]
 
 
+class RprRef(C.Structure):           # vvr_rpr_ref: one reference picture as the current picture sees it (reference picture resampling)
+    _fields_ = [("ratio", i32 * 2), ("win_left", i32), ("win_top", i32), ("width", u16), ("height", u16), ("scaled", u8), ("hor_collocated_chroma", u8), ("ver_collocated_chroma", u8), ("pad", u8)]
+
+
+class RprParams(C.Structure):
+    _fields_ = [("win_left", i32), ("win_top", i32), ("ref", RprRef * VVR_MAX_REFS * 2)]
+
+
 class Picture(C.Structure):
     _fields_ = [("hdr", PicHeader), ("num_cu", u32), ("num_tu", u32),
                 ("cu", C.POINTER(Cu)), ("tu", C.POINTER(Tu)), ("ctu_first_cu", C.POINTER(u32)),
@@ -123,7 +131,7 @@ class Picture(C.Structure):
                 ("alf_params", C.POINTER(AlfParams)), ("lmcs", C.POINTER(LmcsParams)),
                 ("wp", C.POINTER(WpParams)), ("scaling", C.POINTER(ScalingList)),
                 ("ctu_slice", C.POINTER(u16)), ("ctu_tile", C.POINTER(u16)), ("subpics", C.c_void_p), ("num_subpics", u32),
-                ("slices", C.POINTER(SliceHeader)), ("num_slices", u32), ("num_alf_sets", u32), ("num_wp_sets", u32), ("resident", C.c_int)]
+                ("slices", C.POINTER(SliceHeader)), ("rpr", C.POINTER(RprParams)), ("num_slices", u32), ("num_alf_sets", u32), ("num_wp_sets", u32), ("resident", C.c_int)]
 
 
 class Config(C.Structure):

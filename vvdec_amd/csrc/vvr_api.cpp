@@ -811,7 +811,8 @@ VVR_API size_t vvr_abi_sizeof( int which )
 {
   static const size_t sz[] = { sizeof( vvr_pic_header ), sizeof( vvr_cu ), sizeof( vvr_tu ), sizeof( vvr_motion ), sizeof( vvr_lfp ), sizeof( vvr_sao_ctu ),
                                sizeof( vvr_alf_ctu ), sizeof( vvr_alf_params ), sizeof( vvr_lmcs_params ), sizeof( vvr_picture ), sizeof( vvr_config ), sizeof( vvr_kernel_stat ),
-                               sizeof( vvr_wp_params ), sizeof( vvr_scaling_list ), sizeof( vvr_subpic ), sizeof( vvr_slice_header ) };
+                               sizeof( vvr_wp_params ), sizeof( vvr_scaling_list ), sizeof( vvr_subpic ), sizeof( vvr_slice_header ),
+                               sizeof( vvr_rpr_ref ), sizeof( vvr_rpr_params ) };
   return which >= 0 && which < (int) ( sizeof( sz ) / sizeof( sz[0] ) ) ? sz[which] : 0;
 }
 

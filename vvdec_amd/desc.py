@@ -51,6 +51,7 @@ class PictureDesc:
         self.slices = None             # array of abi.SliceHeader records (indexed by ctu_slice) or None: every slice takes the picture header's values
         self.alf_sets = None           # list of abi.AlfParams selected by SliceHeader.alf_set (None: the single table alf_params)
         self.wp_sets = None            # list of abi.WpParams selected by SliceHeader.wp_set (None: the single table wp)
+        self.rpr = None                # abi.RprParams or None: no reference picture is scaled
 
     def set_refs(self, l0, l1=()):
         """l0/l1: lists of (slot, poc)."""
@@ -114,6 +115,8 @@ class PictureDesc:
             self.slices = np.ascontiguousarray(self.slices, dtype=np.dtype(abi.SliceHeader))
             p.slices = C.cast(self.slices.ctypes.data, C.POINTER(abi.SliceHeader))
             p.num_slices = len(self.slices)
+        if self.rpr is not None:
+            p.rpr = C.pointer(self.rpr)
         p.resident = 0
         self._keep = p
         return p

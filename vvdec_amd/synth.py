@@ -34,7 +34,7 @@ class Params(C.Structure):
                 ("p_sao", C.c_float), ("p_alf_luma", C.c_float), ("p_alf_chroma", C.c_float), ("p_ccalf", C.c_float),
                 ("p_imv_hpel", C.c_float), ("p_jccr", C.c_float), ("p_mrl", C.c_float), ("p_bdpcm", C.c_float),
                 ("p_affine", C.c_float), ("p_geo", C.c_float), ("p_ciip", C.c_float), ("p_sbtmvp", C.c_float), ("p_bcw", C.c_float), ("p_cclm", C.c_float), ("p_mip", C.c_float), ("p_sbt", C.c_float), ("p_isp", C.c_float), ("dual_tree", C.c_float), ("p_ibc", C.c_float),
-                ("num_slices", C.c_uint8), ("tile_cols", C.c_uint8), ("tile_rows", C.c_uint8), ("wrap_offset", C.c_uint16), ("subpics", C.c_uint8), ("intra_slices", C.c_uint8), ("virtual_boundaries", C.c_uint8)]
+                ("num_slices", C.c_uint8), ("tile_cols", C.c_uint8), ("tile_rows", C.c_uint8), ("wrap_offset", C.c_uint16), ("subpics", C.c_uint8), ("intra_slices", C.c_uint8), ("virtual_boundaries", C.c_uint8), ("scaled_refs", C.c_uint16 * 2)]
 
 
 class Buffers(C.Structure):
@@ -184,6 +184,26 @@ def vary_slices(d, seed, alf_sets=2, wp_sets=2, intra_slices=0):
                             e.weight = int(np.clip(e.weight + (k if (i + c) & 1 else -k) * 3, (1 << w.log2_denom[1 if c else 0]) - 128, (1 << w.log2_denom[1 if c else 0]) + 127))
                             e.offset = int(np.clip(-e.offset + k, -128, 127))
             d.wp_sets.append(w)
+    return d
+
+
+def attach_rpr(d, refs, win=(0, 0), colloc=(1, 1)):
+    """Reference picture resampling: give a generated description its vvr_rpr_params.  refs: {(list, idx): dict(ratio=(rx, ry), size=(w, h), win=(left, top))}
+    names the scaled reference pictures (the description must have been generated with Params.scaled_refs naming the same ones); every other reference
+    picture of the lists has the current picture's size and window.  win: the current picture's scaling window offsets (luma samples);
+    colloc: sps_chroma_horizontal / vertical_collocated_flag of the reference pictures' SPS."""
+    r = abi.RprParams()
+    r.win_left, r.win_top = win
+    for l in range(2):
+        for i in range(d.hdr.num_ref[l]):
+            e = r.ref[l][i]
+            spec = refs.get((l, i))
+            e.ratio[0], e.ratio[1] = spec["ratio"] if spec else (1 << 14, 1 << 14)
+            e.width, e.height = spec.get("size", (d.hdr.width, d.hdr.height)) if spec else (d.hdr.width, d.hdr.height)
+            e.win_left, e.win_top = spec.get("win", win) if spec else win
+            e.scaled = 1 if spec else 0
+            e.hor_collocated_chroma, e.ver_collocated_chroma = colloc
+    d.rpr = r
     return d
 
 
