@@ -86,6 +86,7 @@ void launch_lmcs( hipStream_t, const PicDev&, DevPlanes, int ) {}
 void launch_copy_planes( hipStream_t, DevPlanes, DevPlanes ) {}
 void launch_copy_bytes( hipStream_t, const void*, void*, size_t ) {}
 void launch_mc_affine( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int ) {}
+void launch_mc_rpr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int ) {}
 void launch_mc_dmvr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int32_t* ) {}
 static int g_lastIntraWg = 0;
 size_t intra_sync_ints( int numUnits, int numItems ) { return ( ( (size_t) 1 + (size_t) numUnits + 63 ) & ~(size_t) 63 ) + (size_t) numItems * 64; }
@@ -155,6 +156,7 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
   case 8: *p = q->units; *n = sizeof( IntraUnit ) * q->numActive; break;
   case 10: *p = q->mcCus; *n = sizeof( McCuRef ) * q->numMcCus; break;      // CUs whose MC tiles the device writes
   case 9: *p = q->resiItems; *n = sizeof( IntraItem ) * q->numResi; break;      // residual-add blocks (k_resi_add)
+  case 11: *p = q->rprItems; *n = sizeof( McItem ) * q->numRprItems; break;      // tiles of CUs with a scaled reference picture (k_mc_rpr)
   default: return -1;
   }
   return 0;

@@ -711,3 +711,97 @@ def test_reference_slots_replicated_between_two_back_ends_on_the_device(built, t
     r = subprocess.run([sys.executable, os.path.join(here, "two_back_ends_on_one_device.py"), str(threads)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "both DPBs equal the single back-end" in r.stdout
+
+
+def _rpr_ratio(ref, cur):
+    return ((ref << 14) + (cur >> 1)) // cur          # CU::getRprScaling (UnitTools.cpp:101)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,kw", [
+    # size of the picture with POC k: the stream changes its resolution at POC 4 and goes back at POC 1 / 3
+    ({0: (512, 384), 4: (384, 256), 2: (384, 256), 1: (512, 384), 3: (384, 256)}, dict(log2_ctu=6, p_intra=0.2)),
+    ({0: (320, 192), 4: (512, 384), 2: (384, 256), 1: (320, 192), 3: (512, 384)}, dict(log2_ctu=5, p_intra=0.15, p_affine=0.3, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.2, p_bcw=0.4, p_imv_hpel=0.3)),
+    ({0: (512, 384), 4: (256, 192), 2: (512, 384), 1: (256, 192), 3: (384, 288)}, dict(log2_ctu=7, p_intra=0.2, p_affine=0.3, p_sbtmvp=0.1, tool_flags_extra=abi.TOOL_WP | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE)),
+])
+def test_stream_that_changes_its_picture_size(built, sizes, kw):
+    """Reference picture resampling: pictures of several sizes in one context (each in the top left corner of its DPB slot, every stage at the
+    picture's own size), CUs predicting from reference pictures of another size through k_mc_rpr (all three filter sets, both directions of
+    scaling), from same-size pictures through the ordinary kernels; the decoded picture hash covers the picture, not the slot."""
+    import ctypes as C
+    import vvdec_amd
+    kw = dict(kw)
+    tools = TOOLS_A | kw.pop("tool_flags_extra", 0)
+    l2 = kw.pop("log2_ctu")
+    MW, MH = max(s[0] for s in sizes.values()), max(s[1] for s in sizes.values())
+    plans, nslots = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    rec = vvdec_amd.Reconstructor(MW, MH, num_slots=nslots, num_streams=2, host_threads=2, log2_ctu=l2)
+    size_of_slot, cpu, descs = {}, {}, []
+    for pl in plans:
+        W, H = sizes[pl.poc]
+        masks, spec = [0, 0], {}
+        for l, lst in enumerate(pl.ref_slots):
+            for i, (slot, poc) in enumerate(lst):
+                rw, rh = sizes[poc]
+                if (rw, rh) != (W, H):
+                    masks[l] |= 1 << i
+                    spec[(l, i)] = dict(ratio=(_rpr_ratio(rw, W), _rpr_ratio(rh, H)), size=(rw, rh))
+        d = synth.picture_for_plan(pl, W, H, seed=900 + len(sizes), tool_flags=tools, log2_ctu=l2, alloc=rec.host_array, scaled_refs=(C.c_uint16 * 2)(*masks), **kw)
+        if pl.slice_type != abi.SLICE_I and (spec or pl.poc == 3):          # (POC 3: a table that names no scaled picture)
+            synth.attach_rpr(d, spec)
+        descs.append(d)
+    assert any(d.rpr is not None and any(d.rpr.ref[l][i].ratio[0] > (1 << 14) * 5 // 4 for l in range(2) for i in range(d.hdr.num_ref[l])) for d in descs)
+    for pl, d in zip(plans, descs):
+        W, H = sizes[pl.poc]
+        job = rec.decompress_picture(d)
+        rec.wait(job)
+        got = [p[:H >> (1 if c else 0), :W >> (1 if c else 0)] for c, p in enumerate(rec.read_picture(pl.slot))]
+        want = refdrv.oracle_reconstruct(d, cpu)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "POC %d (%dx%d) comp %d: %d samples differ" % (pl.poc, W, H, c, int((got[c] != want[c]).sum()))
+        cpu[pl.slot] = want
+        for method in (1, 2):
+            assert rec.picture_hash(pl.slot, method) == refdrv.picture_hash(want, 10, method), "hash method %d of POC %d" % (method, pl.poc)
+    # all in flight at once
+    rec2 = vvdec_amd.Reconstructor(MW, MH, num_slots=nslots, num_streams=3, host_threads=3, log2_ctu=l2)
+    for d in descs:
+        rec2.decompress_picture(d)
+    rec2.sync()
+    last = {}
+    for pl in plans:
+        last[pl.slot] = pl
+    for slot in last:
+        for a, b in zip(rec.read_picture(slot), rec2.read_picture(slot)):
+            assert np.array_equal(a, b)
+    rec.close()
+    rec2.close()
+
+
+@pytest.mark.gpu
+def test_scaled_reference_pictures_through_the_back_end(built):
+    """the cases the oracle is pinned with against the reference's xPredInterBlkRPR (test_oracle_vs_ref.py: scaling windows with offsets, ratios that
+    differ by direction, chroma sample locations, 8 bit, 4:0:0): one picture each, the reference pictures uploaded at their own sizes"""
+    import vvdec_amd
+    from test_oracle_vs_ref import RPR_CASES, rpr_case, ALL
+    for (W, H, l2, idx, seed, specs, win, colloc, kw) in RPR_CASES:
+        kw = dict(kw)
+        tools = ALL | kw.pop("tool_flags_extra", 0)
+        d, refs = rpr_case(W, H, l2, idx, seed, specs, win=win, colloc=colloc, tools=tools, **kw)
+        bd, cf = d.hdr.bit_depth, d.hdr.chroma_format
+        MW = max([W] + [r[0].shape[1] for r in refs.values()])
+        MH = max([H] + [r[0].shape[0] for r in refs.values()])
+        rec = vvdec_amd.Reconstructor(MW, MH, num_slots=max(list(refs) + [d.hdr.out_slot]) + 1, num_streams=1, log2_ctu=l2, bit_depth=bd, chroma_format=cf)
+        for slot, planes in refs.items():
+            full = []
+            for c, p in enumerate(planes):
+                a = np.zeros(rec.plane_shape(c), np.uint16)
+                a[:p.shape[0], :p.shape[1]] = p
+                full.append(a)
+            rec.write_picture(slot, full)
+        rec.wait(rec.decompress_picture(d))
+        got = rec.read_picture(d.hdr.out_slot)
+        want = refdrv.oracle_reconstruct(d, refs)
+        for c in range(len(want)):
+            g = got[c][:want[c].shape[0], :want[c].shape[1]]
+            assert np.array_equal(g, want[c]), "seed %d comp %d: %d samples differ" % (seed, c, int((g != want[c]).sum()))
+        rec.close()

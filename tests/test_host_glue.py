@@ -1062,3 +1062,72 @@ def test_i_pictures_take_the_priority_lane_when_it_is_free(stub):
     assert len(set(free)) == 1                              # the device keeps up: every I picture finds the priority lane free
     assert busy[0] == min(busy[1:]) + 3                     # nothing finishes: only the first one gets it (the stream created after the three ordinary ones) ...
     assert len(set(busy[1:])) == 3                          # ... the others go round the three ordinary lanes
+
+
+MC_ITEM_DT = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("flags", "<u2"), ("cu", "<u4"), ("mv", "<i4", (2, 2)), ("ref", "i1", (2,)), ("bcw", "u1"), ("pad", "u1"), ("clipX", "<u2"), ("clipY", "<u2")])
+
+
+def _mc_table(ctx, h, which, dt=MC_ITEM_DT):
+    p, n = C.c_void_p(), C.c_size_t()
+    ctx.L.vvt_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    assert ctx.L.vvt_table(h, which, C.byref(p), C.byref(n)) == 0
+    return np.frombuffer(C.string_at(p.value, n.value), dt).copy() if n.value else np.zeros(0, dt)
+
+
+def test_scaled_reference_pictures_in_the_host_glue(stub):
+    """reference picture resampling: the tiles of every CU (SbTMVP: sub-block) that reads a scaled reference picture are on the list of k_mc_rpr and on
+    no other, they cover those CUs exactly; a picture smaller than the context's is accepted; inconsistent tables are refused"""
+    from test_oracle_vs_ref import RPR_CASES, rpr_case, ALL
+    assert MC_ITEM_DT.itemsize == 36
+    for (W, H, l2, idx, seed, specs, win, colloc, kw) in RPR_CASES:
+        kw = dict(kw)
+        tools = ALL | kw.pop("tool_flags_extra", 0)
+        d, refs = rpr_case(W, H, l2, idx, seed, specs, win=win, colloc=colloc, tools=tools, **kw)
+        MW = max([W] + [r[0].shape[1] for r in refs.values()]); MH = max([H] + [r[0].shape[0] for r in refs.values()])
+        ctx = Ctx(stub, MW, MH, 8, log2_ctu=l2, bit_depth=d.hdr.bit_depth, chroma_format=d.hdr.chroma_format)
+        hnd = ctx.prepare(d)
+        rpr = _mc_table(ctx, hnd, 11)
+        others = np.concatenate([_mc_table(ctx, hnd, 0), _mc_table(ctx, hnd, 3)])
+        dev_cus = _mc_table(ctx, hnd, 10, np.dtype([("cu", "<u4"), ("first", "<u4")]))       # CUs whose tiles the device writes
+        scaled = lambda l, i: i >= 0 and bool(d.rpr.ref[l][i].scaled)
+        area = 0
+        for k, cu in enumerate(d.cu):
+            if cu["pred_mode"] != abi.PRED_INTER:
+                continue
+            mine = rpr[rpr["cu"] == k]
+            if cu["mc_mode"] == abi.MC_SBTMVP:
+                for t in mine:
+                    assert scaled(0, t["ref"][0]) or scaled(1, t["ref"][1])
+                for t in others[others["cu"] == k]:
+                    assert not (scaled(0, t["ref"][0]) or scaled(1, t["ref"][1]))
+                assert int((mine["w"].astype(int) * mine["h"]).sum()) + int((others[others["cu"] == k]["w"].astype(int) * others[others["cu"] == k]["h"]).sum()) == int(cu["w"]) * int(cu["h"])
+            else:
+                if cu["mc_mode"] == abi.MC_GEO:
+                    s = any(scaled((int(g) >> 4) - 1, int(g) & 15) for g in cu["geo_dir_ref"])
+                else:
+                    s = scaled(0, cu["ref_idx"][0]) or scaled(1, cu["ref_idx"][1])
+                assert (len(mine) > 0) == s, "CU %d" % k
+                if s:
+                    assert int((mine["w"].astype(int) * mine["h"]).sum()) == int(cu["w"]) * int(cu["h"]) and k not in dev_cus["cu"] and not (others["cu"] == k).any()
+                    assert bool(mine["flags"][0] & 16) == (cu["mc_mode"] == abi.MC_AFFINE)
+            area += int((mine["w"].astype(int) * mine["h"]).sum())
+        assert area > 0
+        stub.vvr_free_prepared(ctx.ctx, hnd)
+        # refusals
+        keep = abi.RprParams.from_buffer_copy(d.rpr)
+        l, i = [(l, i) for l in range(2) for i in range(d.hdr.num_ref[l]) if d.rpr.ref[l][i].scaled][0]
+        d.rpr.ref[l][i].ratio[0] = (1 << 15) + 1
+        _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "scaling ratio")
+        d.rpr = abi.RprParams.from_buffer_copy(keep); d.rpr.ref[l][i].scaled = 0
+        _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "is a scaled one")
+        d.rpr = abi.RprParams.from_buffer_copy(keep); d.rpr.ref[l][i].width = MW + 8
+        _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "reference picture size")
+        d.rpr = abi.RprParams.from_buffer_copy(keep); d.hdr.wrap_offset = W
+        _expect_error(ctx, d, abi.VVR_ERR_UNSUPPORTED, "wrap-around")
+        d.hdr.wrap_offset = 0
+        bi = np.nonzero((d.cu["pred_mode"] == abi.PRED_INTER) & (d.cu["mc_mode"] == abi.MC_BI) & (d.cu["w"] >= 8) & (d.cu["h"] >= 8) & (d.cu["w"].astype(int) * d.cu["h"] >= 128) & (d.cu["bcw_idx"] == 2) & ((d.cu["flags"] & abi.CU_CIIP) == 0))[0]
+        bi = [k for k in bi if scaled(0, d.cu["ref_idx"][k][0]) or scaled(1, d.cu["ref_idx"][k][1])]
+        if bi and d.wp is None:
+            d.cu["mc_mode"][bi[0]] = abi.MC_BDOF
+            _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "scaled reference picture")
+        ctx.close()

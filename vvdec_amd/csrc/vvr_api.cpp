@@ -137,6 +137,7 @@ struct vvr_context {
   std::vector<hipStream_t> streams;
   hipStream_t copyStream = nullptr;
   std::vector<DevPlanes>   slots;       // DPB
+  std::vector<std::pair<uint16_t, uint16_t>> slotDim;      // luma size of the picture last submitted into each slot (the context's size before that): what vvr_picture_hash covers
   std::vector<DevPlanes>   scratchB;    // per stream: second picture (SAO output)
   std::vector<DevPlanes>   scratchR;    // per stream: residual planes (intra)
   void*      planeMem = nullptr; bool planeMemOwned = false;
@@ -333,6 +334,8 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
 #endif
   const RefSet& refs = plan.refs;
   DevPlanes A = c->slots[h.out_slot], B = c->scratchB[lane], R = c->scratchR[lane];
+  // the picture's own size (it may be smaller than the context's pictures: it lies in the top left corner of its slot and of the scratch planes)
+  for( int k = 0; k < 3; k++ ) { const int w = k ? h.width >> 1 : h.width, hh = k ? h.height >> 1 : h.height; A.w[k] = B.w[k] = R.w[k] = w; A.h[k] = B.h[k] = R.h[k] = hh; }
   auto timedOn = [&]( int k, hipStream_t st, double algoBytes, auto&& fn )
   {
 #ifdef VVR_WATCHDOG
@@ -365,6 +368,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
     timed( K_MC_DMVR, [&]{ launch_mc_dmvr( s, q->pic, refs, A, q->dmvrItems, q->numDmvrItems, out ); } );
   }
   if( q->numAffItems ) timed( K_MC_AFFINE, [&]{ launch_mc_affine( s, q->pic, refs, A, q->affItems, q->numAffItems ); } );
+  if( q->numRprItems ) launch_mc_rpr( s, q->pic, refs, A, q->rprItems, q->numRprItems );      // CUs that read a scaled reference picture
   const bool lmcsOn = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
   // LMCS: the inter prediction is forward-mapped before any residual is added (DecCu.cpp:458-476) - by the motion-compensation kernels themselves
   // where they store their luma samples (lmcs_fwd_luma): no pass over the picture
@@ -863,6 +867,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   ok = ok && hipMalloc( &c->scratchMem, c->slotBytes * 2 * nl ) == hipSuccess;
   if( ok )
   {
+    c->slotDim.assign( cfg->num_slots, std::make_pair( cfg->max_width, cfg->max_height ) );
     for( int s = 0; s < cfg->num_slots; s++ ) c->slots.push_back( carve( (char*) c->planeMem + c->slotBytes * s, cfg, c->stride, c->planeBytes ) );
     for( int s = 0; s < nl; s++ )
     {
@@ -1006,6 +1011,7 @@ VVR_API int vvr_submit( vvr_context* c, const vvr_picture* p )
     std::string err;
     const int rc = c->workers.empty() ? vvr_host_validate( c->cfg, p, err ) : vvr_host_validate_header( c->cfg, p, err );
     if( rc != VVR_OK ) { std::lock_guard<std::mutex> lk( c->mu ); c->setError( err ); return rc; }
+    c->slotDim[p->hdr.out_slot] = std::make_pair( p->hdr.width, p->hdr.height );
   }
   Job* job;
   {

@@ -40,6 +40,7 @@ struct McCuRef { uint32_t cu; uint32_t first; };      // index into the CU array
 #define MC_ITEM_UNI   2    /* one prediction only: a single list, or identical motion in both (xCheckIdenticalMotion) */
 #define MC_ITEM_HPEL  4    /* half-sample AMVR: alternative luma half-sample filter */
 #define MC_ITEM_GEO   8
+#define MC_ITEM_AFFINE 16  /* (tiles of k_mc_rpr only) affine CU: sub-block MVs like the tiles of k_mc_affine */
 
 // One transform block that carries a residual.
 struct TbItem {
@@ -110,6 +111,7 @@ struct PicDev {         // everything a kernel needs about one picture (passed b
   const uint16_t*    ctuTile;
   const vvr_slice_header* slices;    // headers of the slices (indexed by ctuSlice), NULL: every slice takes hdr's values; alf_params / wp then are arrays
   int                numAlfSets, numWpSets;
+  const vvr_rpr_params* rpr;         // reference picture resampling: how the picture sees its reference pictures (NULL: none is scaled)
   const vvr_subpic*  subpics;        // sub-pictures (NULL: the picture is its only sub-picture) and the sub-picture of every CTU: MC of a CU in a sub-picture
   const uint16_t*    ctuSubpic;      // treated as a picture stays inside it; SAO / ALF of a CTU whose sub-picture says so do not look into other sub-pictures
   const uint32_t*    csVpdu;         // LMCS chroma residual scaling, per VPDU: x | y << 13 | hasLeft << 26 | hasAbove << 27 of the luma neighbourhood the factor is averaged over
@@ -134,6 +136,7 @@ void launch_copy_bytes( hipStream_t s, const void* src, void* dst, size_t bytes 
 void launch_output_window( hipStream_t s, const pel_t* src, int stride, int w, int h, int bytesPerSample, void* dst );      // window rows packed back to back, 1 or 2 bytes per sample
 void launch_plane_hash_rows( hipStream_t s, const pel_t* plane, int stride, int w, int h, int two, int crcMode, uint32_t* out );   // per row: checksum share / CRC piece
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
+void launch_mc_rpr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );      // tiles of CUs with a scaled reference picture
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );
 void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numUnits, int ticket0, int ticket1, int numWorkgroups, int* sync );      // the units [ticket0, ticket1)
 void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems );      // scaled chroma residuals of inter blocks (between the luma and the chroma units)

@@ -21,6 +21,7 @@ struct vvr_prepared {
   McItem*  bdofItems = nullptr; int numBdofItems = 0;      // tiles of CUs in BDOF mode (their own launch: larger LDS footprint)
   McItem*  dmvrItems = nullptr; int numDmvrItems = 0;      // sub-blocks that run decoder-side MV refinement
   McItem*  affItems = nullptr; int numAffItems = 0;        // tiles of affine CUs
+  McItem*  rprItems = nullptr; int numRprItems = 0;        // tiles of CUs that predict from a scaled reference picture
   uint32_t numDmvr = 0;                                    // delta-MV entries the DMVR kernel writes (pairs of ints)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64
   IntraItem* intraItems = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;

@@ -38,6 +38,7 @@ __device__ uint8_t d_mip_matrix_4x4[16][16][4], d_mip_matrix_8x8[8][16][8], d_mi
 __device__ int16_t d_geo_params[64][2], d_geo_weight_offset[64][4][4][2];
 __device__ int8_t  d_geo_weights[6][112 * 112], d_geo_angle2mask[32], d_geo_angle2mirror[32];
 __device__ int16_t d_luma_filter[16][8], d_luma_filter_4x4[16][8], d_luma_alt_hpel[8], d_chroma_filter[32][4];
+__device__ int16_t d_luma_filter_rpr1[16][8], d_luma_filter_rpr2[16][8], d_affine_luma_filter_rpr1[16][8], d_affine_luma_filter_rpr2[16][8], d_chroma_filter_rpr1[32][4], d_chroma_filter_rpr2[32][4];
 __device__ int8_t  d_bcw_weights[5];
 __device__ uint16_t d_db_tc_table[66];
 __device__ uint8_t d_db_beta_table[64];
@@ -54,6 +55,7 @@ int vvr_upload_tables()
   UPLOAD( inv_quant_scales ); UPLOAD( luma_filter ); UPLOAD( luma_filter_4x4 ); UPLOAD( luma_alt_hpel ); UPLOAD( chroma_filter );
   UPLOAD( bcw_weights ); UPLOAD( db_tc_table ); UPLOAD( db_beta_table ); UPLOAD( alf_fixed_coeff ); UPLOAD( alf_class_to_filter );
   UPLOAD( mip_matrix_4x4 ); UPLOAD( mip_matrix_8x8 ); UPLOAD( mip_matrix_16x16 );
+  UPLOAD( luma_filter_rpr1 ); UPLOAD( luma_filter_rpr2 ); UPLOAD( affine_luma_filter_rpr1 ); UPLOAD( affine_luma_filter_rpr2 ); UPLOAD( chroma_filter_rpr1 ); UPLOAD( chroma_filter_rpr2 );
   UPLOAD( geo_params ); UPLOAD( geo_weight_offset ); UPLOAD( geo_weights ); UPLOAD( geo_angle2mask ); UPLOAD( geo_angle2mirror );
   return 0;
 }
@@ -1181,6 +1183,264 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       reco.p[c][(size_t) y * reco.stride[c] + x] = (pel_t) lmcs_fwd_luma( fwdLut, c, out );
     }
   }
+}
+
+// =====================================================================================================================
+// k_mc_rpr - the tiles of CUs that predict from a SCALED reference picture (reference picture resampling, vvr_picture.rpr).
+//   InterPrediction::xPredInterBlkRPR (InterPrediction.cpp:2081-2217): the position in the reference picture advances by the scaling ratio per sample
+//   (1/1024 sample steps from the block's origin), every column has its own integer position and horizontal phase, every row its own vertical ones;
+//   ratios above 1.25 / 1.75 select the low-pass filter sets (regular CUs: m_lumaFilterRPR1/2, m_chromaFilterRPR1/2; affine sub-blocks:
+//   m_affineLumaFilterRPR1/2), the MV is taken as it is (no clipMv, :650), and such a CU has no BDOF, DMVR (:1431-1435) or PROF (:1029).
+//   The reference filters column by column into a buffer and row by row out of it; a sample is
+//     sum_t fV[yFrac(row)][t] * (int16) ( ( sum_s fH[xFrac(col)][s] * ref( xInt(col) - (N/2-1) + s, yInt(row) - (N/2-1) + t ) + offset1 ) >> shift1 )
+//   with clamped reads (= its border-extended picture; the rows it replicates below the margin, :2188-2196, are rows of the margin).
+// This is a conformance path, not a fast one: one workgroup per <= 16x16 tile, one work item per sample, each evaluating its sample straight from
+// the reference plane.  The other list of such a CU may be an ordinary reference picture: its prediction is the regular arithmetic
+// (xPredInterBlk in the separable 2-D form, which the 1-D and copy cases equal number for number: phase 0 of the regular filters is { .., 64, .. }
+// and the roundings nest), with PROF where the reference applies it to that list of an affine CU.  Plain, SbTMVP, GPM, CIIP (inter part) and affine
+// tiles; the combination (rounding, average, BCW, explicit weights, GPM blend) is the one of k_mc / k_mc_affine.
+// =====================================================================================================================
+#define MC_RPR_ONE ( 1 << 14 )
+__device__ __forceinline__ const int16_t* rpr_taps( int comp, int filter, int frac, bool altHpel )
+{
+  if( comp ) return filter == 3 ? d_chroma_filter_rpr1[frac] : filter == 4 ? d_chroma_filter_rpr2[frac] : d_chroma_filter[frac];
+  if( filter == 0 ) return ( frac == 8 && altHpel ) ? d_luma_alt_hpel : d_luma_filter[frac];
+  return filter == 2 ? d_luma_filter_4x4[frac] : filter == 3 ? d_luma_filter_rpr1[frac] : filter == 4 ? d_luma_filter_rpr2[frac] : filter == 5 ? d_affine_luma_filter_rpr1[frac] : d_affine_luma_filter_rpr2[frac];
+}
+// sample (col, row) of the block with origin (bx, by) (component samples) predicted from the scaled picture `ref` (rw x rh component samples):
+// 14-bit intermediate (bi) or rounded and clipped.  filterIndex: 0 regular CU, 2 affine sub-block.
+__device__ int rpr_sample( const pel_t* __restrict__ ref, int stride, const vvr_rpr_ref& rr, int winL, int winT, int comp, int bx, int by, int col, int row,
+                           int mvx, int mvy, bool bi, bool altHpel, int filterIndex, int bd )
+{
+  const int cs = comp ? 1 : 0, shiftHor = 4 + cs;
+  const int thr1 = MC_RPR_ONE * 5 / 4, thr2 = MC_RPR_ONE * 7 / 4;
+  const int rx = rr.ratio[0], ry = rr.ratio[1];
+  int xFilter = filterIndex, yFilter = filterIndex;
+  if( rx > thr2 ) xFilter = 4; else if( rx > thr1 ) xFilter = 3;
+  if( ry > thr2 ) yFilter = 4; else if( ry > thr1 ) yFilter = 3;
+  if( !comp && filterIndex == 2 ) { if( rx > thr1 ) xFilter += 2; if( ry > thr1 ) yFilter += 2; }
+  const int posShift = 10;
+  const int stepX = ( rx + 8 ) >> 4, stepY = ( ry + 8 ) >> 4;
+  const int off = 1 << ( posShift - shiftHor - 1 );
+  const long long posX = ( ( bx << cs ) - winL ) >> cs, posY = ( ( by << cs ) - winT ) >> cs;
+  const int addX = comp ? ( 1 - rr.hor_collocated_chroma ) * 8 * ( rx - MC_RPR_ONE ) : 0;
+  const int addY = comp ? ( 1 - rr.ver_collocated_chroma ) * 8 * ( ry - MC_RPR_ONE ) : 0;
+  long long x0 = ( posX * ( 1 << ( 4 + cs ) ) + mvx ) * (long long) rx + addX;
+  x0 = ( x0 >= 0 ? 1 : -1 ) * ( ( ( x0 >= 0 ? x0 : -x0 ) + ( 1ll << ( 7 + cs ) ) ) >> ( 8 + cs ) ) + (long long) rr.win_left * ( 1 << ( posShift - cs ) );
+  long long y0 = ( posY * ( 1 << ( 4 + cs ) ) + mvy ) * (long long) ry + addY;
+  y0 = ( y0 >= 0 ? 1 : -1 ) * ( ( ( y0 >= 0 ? y0 : -y0 ) + ( 1ll << ( 7 + cs ) ) ) >> ( 8 + cs ) ) + (long long) rr.win_top * ( 1 << ( posShift - cs ) );
+  const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
+  const int rw = rr.width >> cs, rh = rr.height >> cs;
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+  const int py = (int) y0 + row * stepY, px = (int) x0 + col * stepX;
+  const int yInt = clip3( -4, rh + 4, ( py + off ) >> posShift ), yFrac = ( ( py + off ) >> ( posShift - shiftHor ) ) & ( ( 1 << shiftHor ) - 1 );
+  const int xInt = clip3( -4, rw + 4, ( px + off ) >> posShift ), xFrac = ( ( px + off ) >> ( posShift - shiftHor ) ) & ( ( 1 << shiftHor ) - 1 );
+  const int16_t* cv = rpr_taps( comp, yFilter, yFrac, altHpel && ry == MC_RPR_ONE );
+  const int16_t* ch = rpr_taps( comp, xFilter, xFrac, altHpel && rx == MC_RPR_ONE );
+  int sum2 = 0;
+  for( int t = 0; t < ntaps; t++ )
+  {
+    const pel_t* line = ref + (size_t) clip3( 0, rh - 1, yInt - half + t ) * stride;
+    int sum = 0;
+    for( int u = 0; u < ntaps; u++ ) sum += line[clip3( 0, rw - 1, xInt - half + u )] * ch[u];
+    sum2 += (int16_t) ( ( sum + offset1 ) >> shift1 ) * cv[t];
+  }
+  if( bi ) return (int16_t) ( sum2 >> 6 );
+  const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
+  return clip_pel( (int16_t) ( ( sum2 + offset2 ) >> shift2 ), bd );
+}
+// the sample at (px, py) of the component plane predicted with the (clipped) MV from an ordinary reference picture of the current picture's size
+__device__ int reg_sample( const pel_t* __restrict__ ref, int stride, int pw, int ph, int comp, int px, int py, int mvx, int mvy, bool bi, bool altHpel, bool sixTap, int bd )
+{
+  const int sh = 4 + ( comp ? 1 : 0 ), ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
+  const int xFrac = mvx & ( ( 1 << sh ) - 1 ), yFrac = mvy & ( ( 1 << sh ) - 1 ), x0 = px + ( mvx >> sh ), y0 = py + ( mvy >> sh );
+  const int16_t* ch = comp ? d_chroma_filter[xFrac] : ( xFrac == 8 && altHpel ) ? d_luma_alt_hpel : sixTap ? d_luma_filter_4x4[xFrac] : d_luma_filter[xFrac];
+  const int16_t* cv = comp ? d_chroma_filter[yFrac] : ( yFrac == 8 && altHpel ) ? d_luma_alt_hpel : sixTap ? d_luma_filter_4x4[yFrac] : d_luma_filter[yFrac];
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+  int sum2 = 0;
+  for( int t = 0; t < ntaps; t++ )
+  {
+    const pel_t* line = ref + (size_t) clip3( 0, ph - 1, y0 - half + t ) * stride;
+    int sum = 0;
+    for( int u = 0; u < ntaps; u++ ) sum += line[clip3( 0, pw - 1, x0 - half + u )] * ch[u];
+    sum2 += (int16_t) ( ( sum + offset1 ) >> shift1 ) * cv[t];
+  }
+  if( bi ) return (int16_t) ( sum2 >> 6 );
+  const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
+  return clip_pel( (int16_t) ( ( sum2 + offset2 ) >> shift2 ), bd );
+}
+// sample (px, py) of the 4x4 luma sub-block at (sbx, sby) of an affine CU refined by PROF (applyPROFCore, InterPrediction.cpp:61; the 6x6 block of
+// xPredAffineBlk :1224-1290: the prediction inside, integer reference samples around it), from an ordinary reference picture
+__device__ int aff_prof_sample( const pel_t* __restrict__ ref, int stride, int pw, int ph, int sbx, int sby, int px, int py, int mx, int my, int dMvH, int dMvV, bool bi, int bd )
+{
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  auto ext = [&]( int i, int j ) -> int
+  {
+    if( i >= 1 && i <= 4 && j >= 1 && j <= 4 ) return reg_sample( ref, stride, pw, ph, 0, sbx + i - 1, sby + j - 1, mx, my, true, false, true, bd );
+    const int x = clip3( 0, pw - 1, sbx + ( mx >> 4 ) + i - 1 + ( ( mx & 15 ) >> 3 ) ), y = clip3( 0, ph - 1, sby + ( my >> 4 ) + j - 1 + ( ( my & 15 ) >> 3 ) );
+    return (int16_t) ( (int16_t) ( ref[(size_t) y * stride + x] << headroom ) - (int16_t) IF_INTERNAL_OFFS );
+  };
+  const int gX = (int16_t) ( ( ext( 2 + px, 1 + py ) >> 6 ) - ( ext( px, 1 + py ) >> 6 ) ), gY = (int16_t) ( ( ext( 1 + px, 2 + py ) >> 6 ) - ( ext( 1 + px, py ) >> 6 ) );
+  const int dILimit = 1 << max( bd + 1, 13 );
+  const int dI = clip3( -dILimit, dILimit - 1, dMvH * gX + dMvV * gY );
+  int v = (int16_t) ( ext( 1 + px, 1 + py ) + dI );
+  if( !bi ) { v = (int16_t) ( ( v + ( 1 << ( headroom - 1 ) ) + IF_INTERNAL_OFFS ) >> headroom ); v = clip_pel( v, bd ); }
+  return v;
+}
+
+__global__ __launch_bounds__( 256 ) void k_mc_rpr( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
+{
+  const int item = blockIdx.x;
+  if( item >= numItems ) return;
+  const McItem it = items[item];
+  const vvr_cu& cu = pic.cu[it.cu];
+  const vvr_rpr_params& R = *pic.rpr;
+  const int16_t* __restrict__ fwdLut = lmcs_fwd_at( pic, it.x, it.y );
+  const int bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu;
+  const int ncomp = pic.hdr.chroma_format ? 3 : 1;
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const bool aff = ( it.flags & MC_ITEM_AFFINE ) != 0, geo = ( it.flags & MC_ITEM_GEO ) != 0;
+  const bool altHpel = ( it.flags & MC_ITEM_HPEL ) != 0;
+  const vvr_wp_params* __restrict__ wpT = wp_at( pic, it.x, it.y );
+  int mRef[2] = { aff ? cu.ref_idx[0] : it.ref[0], aff ? cu.ref_idx[1] : it.ref[1] };
+  bool uni;
+  if( aff )
+  {
+    bool biPred = mRef[0] >= 0 && mRef[1] >= 0;
+    // xCheckIdenticalMotion (:404-436)
+    if( biPred && pic.hdr.ref_poc[0][mRef[0]] == pic.hdr.ref_poc[1][mRef[1]]
+        && cu.mv[0][0][0] == cu.mv[1][0][0] && cu.mv[0][0][1] == cu.mv[1][0][1] && cu.mv[0][1][0] == cu.mv[1][1][0] && cu.mv[0][1][1] == cu.mv[1][1][1]
+        && ( !( cu.flags & VVR_CU_AFFINE_6P ) || ( cu.mv[0][2][0] == cu.mv[1][2][0] && cu.mv[0][2][1] == cu.mv[1][2][1] ) ) && !pic.wp ) biPred = false;
+    uni = !biPred;
+  }
+  else uni = ( it.flags & MC_ITEM_UNI ) != 0;
+  const int l0 = uni ? ( mRef[0] >= 0 ? 0 : 1 ) : 0, nl = uni ? 1 : 2;
+  const int bcw = aff ? cu.bcw_idx : it.bcw;
+  const bool wpOn = wpT && !geo && bcw == 2;
+  const bool hi = !uni || wpOn;
+  // affine: clip range of the sub-block MVs (:1194-1197), PROF per list (:1015-1029) with the MV offset of this work item's position in a sub-block
+  const int horMax = ( pic.hdr.width + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - cu.x + 1 ) * 16;
+  const int verMax = ( pic.hdr.height + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - cu.y + 1 ) * 16;
+  const int wL = it.w, hL = it.h, wC = wL >> 1, hC = hL >> 1;
+  const int total = wL * hL + ( ncomp == 3 ? 2 * wC * hC : 0 );
+  for( int sidx = threadIdx.x; sidx < total; sidx += 256 )
+  {
+    int c, x, y;
+    if( sidx < wL * hL ) { c = 0; y = sidx / wL; x = sidx - y * wL; }
+    else { const int q = sidx - wL * hL; c = 1 + ( q >= wC * hC ); const int r = q - ( c - 1 ) * wC * hC; y = r / wC; x = r - y * wC; }
+    const int cs = c ? 1 : 0;
+    const int ax = ( it.x >> cs ) + x, ay = ( it.y >> cs ) + y;       // position in the component plane
+    int p[2] = { 0, 0 };
+    for( int k = 0; k < nl; k++ )
+    {
+      const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
+      const int ri = geo ? ( cu.geo_dir_ref[k] & 15 ) : mRef[l];
+      const vvr_rpr_ref& rr = R.ref[l][ri];
+      const pel_t* __restrict__ plane = refs.p[l * VVR_MAX_REFS + ri][c];
+      const bool bi = hi || geo;
+      if( !aff )
+      {
+        int mvx = geo ? cu.geo_mv[k][0] : it.mv[l][0], mvy = geo ? cu.geo_mv[k][1] : it.mv[l][1];
+        if( rr.scaled ) p[k] = rpr_sample( plane, reco.stride[c], rr, R.win_left, R.win_top, c, it.clipX >> cs, it.clipY >> cs, ax - ( it.clipX >> cs ), ay - ( it.clipY >> cs ), mvx, mvy, bi, altHpel, 0, bd );
+        else
+        {
+          const McBounds B = { 0, 0, (int) pic.hdr.width - 1, (int) pic.hdr.height - 1 };
+          mc_clip_mv( pic, B, it.clipX, it.clipY, mvx, mvy );
+          p[k] = reg_sample( plane, reco.stride[c], reco.w[c], reco.h[c], c, ax, ay, mvx, mvy, bi, altHpel, false, bd );
+        }
+      }
+      else
+      {
+        // the MV of the 4x4 sub-block (luma), or of the 4x4 chroma block from the luma sub-blocks (0,0) and (1,1) of its 2x2 group (:1156-1176)
+        const int sx = x >> 2, sy = y >> 2;
+        const bool onDev = ( pic.hdr.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) != 0;
+        int mx, my;
+        if( c == 0 )
+        {
+          if( onDev ) aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + sx, ( ( it.y - cu.y ) >> 2 ) + sy, mx, my );
+          else { const vvr_motion& m = pic.affMotion[it.mv[0][0] + 4 * sy + sx]; mx = m.mv[l][0]; my = m.mv[l][1]; }
+        }
+        else
+        {
+          if( onDev )
+          {
+            int a0, a1, b0, b1;
+            aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + 2 * sx, ( ( it.y - cu.y ) >> 2 ) + 2 * sy, a0, a1 );
+            aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + 2 * sx + 1, ( ( it.y - cu.y ) >> 2 ) + 2 * sy + 1, b0, b1 );
+            mx = a0 + b0; my = a1 + b1;
+          }
+          else
+          {
+            const vvr_motion& m0 = pic.affMotion[it.mv[0][0] + 4 * ( 2 * sy ) + 2 * sx];
+            const vvr_motion& m1 = pic.affMotion[it.mv[0][0] + 4 * ( 2 * sy + 1 ) + 2 * sx + 1];
+            mx = m0.mv[l][0] + m1.mv[l][0]; my = m0.mv[l][1] + m1.mv[l][1];
+          }
+          aff_round_mv( mx, my, 1 );
+        }
+        mx = min( horMax, max( horMin, mx ) ); my = min( verMax, max( verMin, my ) );
+        const int bx = ( it.x >> cs ) + 4 * sx, by = ( it.y >> cs ) + 4 * sy;
+        if( rr.scaled ) p[k] = rpr_sample( plane, reco.stride[c], rr, R.win_left, R.win_top, c, bx, by, x & 3, y & 3, mx, my, bi, false, 2, bd );
+        else if( c ) p[k] = reg_sample( plane, reco.stride[c], reco.w[c], reco.h[c], c, ax, ay, mx, my, bi, false, false, bd );
+        else
+        {
+          const int lw = ilog2( cu.w ), lh = ilog2( cu.h );
+          const int dHX = ( cu.mv[l][1][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lw ) ), dHY = ( cu.mv[l][1][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lw ) );
+          int dVX, dVY;
+          const bool sixP = ( cu.flags & VVR_CU_AFFINE_6P ) != 0;
+          if( sixP ) { dVX = ( cu.mv[l][2][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lh ) ); dVY = ( cu.mv[l][2][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lh ) ); }
+          else { dVX = -dHY; dVY = dHX; }
+          const bool eqRT = cu.mv[l][0][0] == cu.mv[l][1][0] && cu.mv[l][0][1] == cu.mv[l][1][1];
+          const bool eqLB = cu.mv[l][0][0] == cu.mv[l][2][0] && cu.mv[l][0][1] == cu.mv[l][2][1];
+          const bool prof = ( pic.hdr.tool_flags & VVR_TOOL_PROF ) && !( ( sixP && eqRT && eqLB ) || ( !sixP && eqRT ) ) && !aff_spread_over_limit( dHX, dHY, dVX, dVY, cu.inter_dir );
+          if( prof )
+          {
+            const int qHX = dHX * 4, qHY = dHY * 4, qVX = dVX * 4, qVY = dVY * 4;
+            int a = ( ( dHX + dVX ) * 2 ) - ( ( qHX + qVX ) * 2 ) + ( x & 3 ) * qHX + ( y & 3 ) * qVX, b = ( ( dHY + dVY ) * 2 ) - ( ( qHY + qVY ) * 2 ) + ( x & 3 ) * qHY + ( y & 3 ) * qVY;
+            aff_round_mv( a, b, 8 );
+            p[k] = aff_prof_sample( plane, reco.stride[0], reco.w[0], reco.h[0], bx, by, x & 3, y & 3, mx, my, clip3( -31, 31, a ), clip3( -31, 31, b ), bi, bd );
+          }
+          else p[k] = reg_sample( plane, reco.stride[0], reco.w[0], reco.h[0], 0, ax, ay, mx, my, bi, false, true, bd );
+        }
+      }
+    }
+    int out = p[0];
+    if( geo )
+    {
+      const int MS = 112;
+      const int angle = d_geo_params[cu.geo_split_dir][0];
+      const int wIdx = ilog2( cu.w ) - 3, hIdx = ilog2( cu.h ) - 3;
+      const int ox = d_geo_weight_offset[cu.geo_split_dir][hIdx][wIdx][0], oy = d_geo_weight_offset[cu.geo_split_dir][hIdx][wIdx][1];
+      const int8_t* gW = d_geo_weights[d_geo_angle2mask[angle]];
+      const int mir = d_geo_angle2mirror[angle];
+      const int lx = ( ax << cs ) - cu.x, ly = ( ay << cs ) - cu.y;
+      const int wt = mir == 2 ? gW[( MS - 1 - oy - ly ) * MS + ox + lx] : mir == 1 ? gW[( oy + ly ) * MS + ( MS - 1 - ox ) - lx] : gW[( oy + ly ) * MS + ox + lx];
+      const int shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+      out = clip_pel( ( wt * p[0] + ( 8 - wt ) * p[1] + offset ) >> shift, bd );
+    }
+    else if( wpOn ) out = uni ? wp_uni( wpT, l0, mRef[l0], c, p[0], bd, headroom ) : wp_bi( wpT, mRef[0], mRef[1], c, p[0], p[1], bd, headroom );
+    else if( !uni )
+    {
+      if( bcw != 2 )
+      {
+        const int w1 = d_bcw_weights[bcw], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+        out = clip_pel( ( p[0] * w0 + p[1] * w1 + offset ) >> shift, bd );
+      }
+      else
+      {
+        const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+        out = clip_pel( ( p[0] + p[1] + offset ) >> shift, bd );
+      }
+    }
+    reco.p[c][(size_t) ay * reco.stride[c] + ax] = (pel_t) lmcs_fwd_luma( fwdLut, c, out );
+  }
+}
+
+void launch_mc_rpr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
+{
+  if( !numItems ) return;
+  hipLaunchKernelGGL( k_mc_rpr, dim3( numItems ), dim3( 256 ), 0, s, pic, refs, reco, items, numItems );
 }
 
 void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, const McItem* items2, int numItems2, int bdof )

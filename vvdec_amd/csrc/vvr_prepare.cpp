@@ -35,6 +35,7 @@ struct PrepScratch
   int ncomp = 0, w4 = 0, h4 = 0, ctu = 0, ctusX = 0, ctusY = 0, numCtu = 0, vpduLog2 = 0, vpdusX = 0, vpdusY = 0;
   bool wpOn = false, cscale = false, lmcs = false;
   // ---- work lists
+  std::vector<McItem> mcRpr;                // tiles of CUs that predict from a scaled reference picture (k_mc_rpr): plain, SbTMVP, GPM and affine ones
   std::vector<McItem> mc, mcBdof, mcDmvr, mcAff;      // tiles the host writes: SbTMVP sub-blocks (mc), affine tiles (mcAff); mcBdof / mcDmvr stay empty (k_expand_mc)
   std::vector<McCuRef> mcCus;              // CUs whose tiles the device writes, with where (list, first tile)
   uint32_t devTiles[3] = { 0, 0, 0 };      // tiles the device writes per list (plain, BDOF, DMVR)
@@ -83,7 +84,7 @@ struct PrepScratch
   // ---- layout of the H2D image
   std::vector<Part> parts;
   size_t total = 0, numDirect = 0;          // parts [0, numDirect) are copied from the caller's pinned arrays
-  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iSlices, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iResi, iUnits, iMcCus, iMcDev[3];
+  int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iSlices, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iResi, iUnits, iMcCus, iMcDev[3], iRpr, iMcR;
   size_t stagedEndOff = 0;                  // end of the uploaded part of the image
 
   void begin( const vvr_picture* pic )
@@ -108,7 +109,7 @@ struct PrepScratch
     lmcs = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
     cscale = lmcs && ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && ncomp == 3;
     vpduLog2 = std::min<int>( 6, h.log2_ctu ); vpdusX = ( h.width + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2; vpdusY = ( h.height + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2;
-    mc.clear(); mcBdof.clear(); mcDmvr.clear(); mcAff.clear(); affMv.clear(); numDmvr = 0;
+    mc.clear(); mcBdof.clear(); mcDmvr.clear(); mcAff.clear(); mcRpr.clear(); affMv.clear(); numDmvr = 0;
     mcCus.clear(); devTiles[0] = devTiles[1] = devTiles[2] = 0;
     for( int k = 0; k < 3; k++ ) { tb[k].clear(); intra[k].clear(); itemH[k].clear(); prodPool[k].clear(); }
     resiAdd.clear(); intraAll.clear(); units.clear(); unitsDev.clear(); csVpduV.clear();
@@ -209,7 +210,9 @@ int vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::
 {
   vvr_pic_header h = p->hdr;           // (working copy: with slice headers the slice-level switches become their union)
   if( h.abi_version != VVR_ABI_VERSION ) FAIL( VVR_ERR_PARAMETER, "abi_version mismatch" );
-  if( h.width != cfg.max_width || h.height != cfg.max_height || h.chroma_format != cfg.chroma_format || h.bit_depth != cfg.bit_depth || h.log2_ctu != cfg.log2_ctu )
+  // (a picture may be smaller than the context's pictures - a coded video sequence with reference picture resampling changes its picture size -:
+  // it occupies the top left corner of its DPB slot)
+  if( !h.width || !h.height || h.width > cfg.max_width || h.height > cfg.max_height || h.chroma_format != cfg.chroma_format || h.bit_depth != cfg.bit_depth || h.log2_ctu != cfg.log2_ctu )
     FAIL( VVR_ERR_PARAMETER, "picture geometry differs from the context configuration" );
   if( ( h.width & 7 ) || ( h.height & 7 ) ) FAIL( VVR_ERR_PARAMETER, "picture size must be a multiple of 8 (minimum CU size)" );
   if( h.out_slot < 0 || h.out_slot >= cfg.num_slots ) FAIL( VVR_ERR_PARAMETER, "out_slot out of range" );
@@ -282,6 +285,28 @@ int vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::
       for( int i = 0; i < h.num_ref[l]; i++ )
         if( h.ref_slot[l][i] < 0 || h.ref_slot[l][i] >= cfg.num_slots || h.ref_slot[l][i] == h.out_slot ) FAIL( VVR_ERR_PARAMETER, "bad reference slot" );
     }
+  if( p->rpr && h.slice_type != 2 )
+  {
+    // reference picture resampling: the table is consistent in itself, and the pair of tools the reference does not combine it with is refused
+    const vvr_rpr_params& R = *p->rpr;
+    const int unit = h.chroma_format ? 2 : 1;
+    if( h.wrap_offset ) FAIL( VVR_ERR_UNSUPPORTED, "scaled reference pictures together with reference wrap-around (the reference keeps no wrap copy of a scaled picture, Picture.h:278)" );
+    for( uint32_t k = 0; k < p->num_subpics && p->num_subpics > 1; k++ ) if( p->subpics[k].treated_as_pic ) FAIL( VVR_ERR_UNSUPPORTED, "scaled reference pictures together with sub-pictures treated as pictures" );
+    if( R.win_left % unit || R.win_top % unit ) FAIL( VVR_ERR_PARAMETER, "scaling window offsets are multiples of the chroma sub-sampling" );
+    for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
+    {
+      const vvr_rpr_ref& r = R.ref[l][i];
+      if( !r.width || !r.height || ( r.width & 7 ) || ( r.height & 7 ) || r.width > cfg.max_width || r.height > cfg.max_height ) FAIL( VVR_ERR_PARAMETER, "reference picture size: a multiple of 8 within the context's picture size" );
+      if( r.win_left % unit || r.win_top % unit ) FAIL( VVR_ERR_PARAMETER, "scaling window offsets are multiples of the chroma sub-sampling" );
+      // CU::getRprScaling (UnitTools.cpp:113-116): the reference picture is at most twice and at least an eighth as large as the current picture
+      if( r.ratio[0] < ( 1 << 11 ) || r.ratio[0] > ( 1 << 15 ) || r.ratio[1] < ( 1 << 11 ) || r.ratio[1] > ( 1 << 15 ) ) FAIL( VVR_ERR_PARAMETER, "scaling ratio outside 1/8 .. 2" );
+      if( r.scaled > 1 || r.hor_collocated_chroma > 1 || r.ver_collocated_chroma > 1 ) FAIL( VVR_ERR_PARAMETER, "reference picture resampling: flags are 0 or 1" );
+      if( !r.scaled && ( r.width != h.width || r.height != h.height || r.win_left != R.win_left || r.win_top != R.win_top || r.ratio[0] != ( 1 << 14 ) || r.ratio[1] != ( 1 << 14 ) ) )
+        FAIL( VVR_ERR_PARAMETER, "a reference picture of another size, scaling window or ratio is a scaled one (Picture::isRefScaled)" );
+      for( int l2 = 0; l2 < 2; l2++ ) for( int j = 0; j < h.num_ref[l2]; j++ )
+        if( h.ref_slot[l2][j] == h.ref_slot[l][i] && memcmp( &R.ref[l2][j], &r, sizeof( r ) ) ) FAIL( VVR_ERR_PARAMETER, "one reference picture described in two ways" );
+    }
+  }
   return VVR_OK;
 }
 
@@ -375,6 +400,8 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
         if( present && ( isDmvr || cu.mc_mode == VVR_MC_BDOF ) ) FAIL( VVR_ERR_PARAMETER, "mc_mode BDOF / DMVR between references with explicit prediction weights" );
         if( cu.mc_mode == VVR_MC_UNI ) FAIL( VVR_ERR_PARAMETER, "mc_mode UNI on a bi-predicted CU of a picture with weighted prediction" );
       }
+      if( p->rpr && ( isDmvr || cu.mc_mode == VVR_MC_BDOF ) && ( p->rpr->ref[0][cu.ref_idx[0]].scaled || p->rpr->ref[1][cu.ref_idx[1]].scaled ) )
+        FAIL( VVR_ERR_PARAMETER, "mc_mode BDOF / DMVR on a CU with a scaled reference picture (InterPrediction.cpp:1431-1435)" );
       if( cu.tree != VVR_TREE_JOINT && h.chroma_format ) FAIL( VVR_ERR_PARAMETER, "inter CU must be single tree" );
       if( cu.w == 4 && cu.h == 4 ) FAIL( VVR_ERR_PARAMETER, "4x4 inter CU (never inter predicted, InterPrediction.cpp:634)" );
     }
@@ -811,9 +838,17 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
       const int ts = sbt ? 8 : 16;                       // SbTMVP: one item per 8x8 sub-block (ATMVP_SUB_BLOCK_SIZE)
       const bool dm = cu.mc_mode == VVR_MC_DMVR || cu.mc_mode == VVR_MC_DMVR_BDOF;
       const bool af = cu.mc_mode == VVR_MC_AFFINE;
-      std::vector<McItem>& list = dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc;
+      // reference picture resampling: a CU that reads a scaled reference picture goes to k_mc_rpr as a whole (tiles written here); the sub-blocks of an
+      // SbTMVP CU are sorted tile by tile below
+      bool rprCu = false;
+      if( p->rpr && !sbt )
+      {
+        if( cu.mc_mode == VVR_MC_GEO ) for( int k = 0; k < 2; k++ ) rprCu |= p->rpr->ref[( cu.geo_dir_ref[k] >> 4 ) - 1][cu.geo_dir_ref[k] & 15].scaled != 0;
+        else for( int l = 0; l < 2; l++ ) rprCu |= cu.ref_idx[l] >= 0 && p->rpr->ref[l][cu.ref_idx[l]].scaled;
+      }
+      std::vector<McItem>& list = rprCu ? mcRpr : dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc;
       const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
-      if( !af && !sbt )
+      if( !af && !sbt && !rprCu )
       {
         // plain, BDOF and DMVR tiles are a function of the CU record: counted here, written on the device (k_expand_mc)
         const int cls = dm ? 2 : cu.mc_mode == VVR_MC_BDOF ? 1 : 0;
@@ -829,7 +864,7 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
       {
       // one record per tile: what the tiles of a CU share is filled once
       McItem base; memset( &base, 0, sizeof( base ) );
-      base.flags = sbt ? MC_ITEM_SUBBLOCK : 0; base.cu = i;
+      base.flags = ( sbt ? MC_ITEM_SUBBLOCK : 0 ) | ( af && rprCu ? MC_ITEM_AFFINE : 0 ); base.cu = i;
       const bool plain = !af && !dm;
       if( af && ( h.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) ) base.mv[0][0] = -1;      // the kernel spans the sub-block MVs from the control points itself
       if( plain )
@@ -869,6 +904,16 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
           it.clipX = it.x; it.clipY = it.y;
           it.flags = (uint16_t) ( ( it.flags & ~MC_ITEM_UNI ) | ( uni ? MC_ITEM_UNI : 0 ) );
         }
+      }
+      if( p->rpr && sbt )
+      {   // the sub-blocks that read a scaled picture: to k_mc_rpr
+        size_t keep = first;
+        for( size_t k = first; k < list.size(); k++ )
+        {
+          const McItem& t = list[k];
+          if( ( t.ref[0] >= 0 && p->rpr->ref[0][t.ref[0]].scaled ) || ( t.ref[1] >= 0 && p->rpr->ref[1][t.ref[1]].scaled ) ) mcRpr.push_back( t ); else list[keep++] = t;
+        }
+        list.resize( keep );
       }
       {
         const double smp = (double) cu.w * cu.h * ( ncomp == 3 ? 1.5 : 1.0 ), nt = (double) ( list.size() - first );
@@ -1373,6 +1418,8 @@ void PrepScratch::layout( PinnedRanges* pinned )
   iMcB = add( mcBdof.data(), sizeof( McItem ) * mcBdof.size() );
   iMcD = add( mcDmvr.data(), sizeof( McItem ) * mcDmvr.size() );
   iMcA = add( mcAff.data(), sizeof( McItem ) * mcAff.size() );
+  iMcR = add( mcRpr.data(), sizeof( McItem ) * mcRpr.size() );
+  iRpr = p->rpr && p->hdr.slice_type != 2 ? add( p->rpr, sizeof( vvr_rpr_params ) ) : -1;
   for( int k = 0; k < 3; k++ ) iTb[k] = add( tb[k].data(), sizeof( TbItem ) * tb[k].size() );
   iMcCus = add( mcCus.data(), sizeof( McCuRef ) * mcCus.size() );
   iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
@@ -1533,7 +1580,7 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   d.affMotion = (const vvr_motion*) at( S.iAffMv );
   d.lfp[0] = (const vvr_lfp*) at( S.iL0 ); d.lfp[1] = (const vvr_lfp*) at( S.iL1 );
   d.sao = (const vvr_sao_ctu*) at( S.iSao ); d.alf = (const vvr_alf_ctu*) at( S.iAlf ); d.alf_params = (const vvr_alf_params*) at( S.iAlfP );
-  d.lmcs = (const vvr_lmcs_params*) at( S.iLmcs ); d.scaling = (const vvr_scaling_list*) at( S.iSl ); d.wp = (const vvr_wp_params*) at( S.iWp );
+  d.lmcs = (const vvr_lmcs_params*) at( S.iLmcs ); d.scaling = (const vvr_scaling_list*) at( S.iSl ); d.wp = (const vvr_wp_params*) at( S.iWp ); d.rpr = (const vvr_rpr_params*) at( S.iRpr );
   d.ctuSlice = (const uint16_t*) at( S.iCtuSlice ); d.ctuTile = (const uint16_t*) at( S.iCtuTile );
   d.slices = (const vvr_slice_header*) at( S.iSlices ); d.numAlfSets = (int) std::max<uint32_t>( 1, p->num_alf_sets ); d.numWpSets = (int) std::max<uint32_t>( 1, p->num_wp_sets );
   d.subpics = (const vvr_subpic*) at( S.iSubpics ); d.ctuSubpic = (const uint16_t*) at( S.iCtuSubpic );
@@ -1544,6 +1591,7 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   q.dmvrItems = (McItem*) at( S.iMcDev[2] ); q.numDmvrItems = (int) S.devTiles[2];
   q.mcCus = (McCuRef*) at( S.iMcCus ); q.numMcCus = (int) S.mcCus.size();
   q.affItems = (McItem*) at( S.iMcA ); q.numAffItems = (int) S.mcAff.size();
+  q.rprItems = (McItem*) at( S.iMcR ); q.numRprItems = (int) S.mcRpr.size();
   q.numDmvr = S.numDmvr;
   for( int k = 0; k < 3; k++ ) { q.tbItems[k] = (TbItem*) at( S.iTb[k] ); q.numTb[k] = (int) S.tb[k].size(); }
   q.intraItems = (IntraItem*) at( S.iIntra ); q.numIntra = (int) S.intraAll.size();
