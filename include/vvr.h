@@ -472,6 +472,11 @@ enum { VVR_HASH_MD5 = 0, VVR_HASH_CRC = 1, VVR_HASH_CHECKSUM = 2 };
 VVR_API int          vvr_picture_hash(vvr_context* ctx, int slot, int method, uint8_t* digest, int* digest_len);
 /* upload a reference picture produced elsewhere (another GPU / a test) into a slot */
 VVR_API int          vvr_write_plane(vvr_context* ctx, int slot, int comp, const uint16_t* src, size_t src_stride_samples);
+/* size of the picture a slot holds (luma samples; a picture lies in the top left corner of its slot): vvr_submit sets it to the size of the picture
+ * it reconstructs into the slot, this call is for pictures that come from outside (vvr_write_plane) when they are smaller than the context's
+ * pictures - a coded video sequence with reference picture resampling.  vvr_read_plane, vvr_write_plane and vvr_picture_hash move / cover that
+ * many samples; a new context's slots have the context's size.                                                                              */
+VVR_API int          vvr_slot_picture_size(vvr_context* ctx, int slot, int width, int height);
 /* DMVR refined delta MVs of job (TaskFinishMotionInfo, DecCu.cpp:161): copies num_entries * 2 int32 */
 VVR_API int          vvr_read_dmvr(vvr_context* ctx, int job, int32_t* dst, size_t num_entries);
 /* Collocated motion of a picture submitted with VVR_TOOL_COL_MOTION (blocks until the job is done): ceil(w4 / 2) * ceil(h4 / 2) records in raster order,

@@ -260,6 +260,7 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
       if( S.slotOf.find( ref ) == S.slotOf.end() )
       {
         const int rs = slotFor( ref );
+        vvr_slot_picture_size( S.ctx, rs, (int) ref->lwidth(), (int) ref->lheight() );      // (a coded video sequence may change its picture size)
         CPelUnitBuf rb = const_cast<const Picture*>( ref )->getRecoBuf();
         for( size_t c = 0; c < rb.bufs.size(); c++ )
           if( vvr_write_plane( S.ctx, rs, (int) c, reinterpret_cast<const uint16_t*>( rb.bufs[c].buf ), (size_t) rb.bufs[c].stride ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( S.ctx ) );

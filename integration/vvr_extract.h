@@ -53,6 +53,7 @@ struct Extracted
   std::vector<vvr_wp_params> wpSets;              // pred_weight_table() of the slices over the union of their reference lists (vvr_slice_header::wp_set)
   std::vector<vvr_slice_header> slices;           // filled (and pointed to) when the picture has more than one slice
   vvr_scaling_list          scaling;
+  vvr_rpr_params            rpr;                  // filled (and pointed to) when a reference picture of the picture is a scaled one
   std::vector<uint16_t>     ctuSlice, ctuTile;    // filled (and pointed to) when the picture has more than one slice / tile
   std::vector<vvr_subpic>   subpics;              // filled (and pointed to) when the picture has more than one sub-picture
   // the CU / TU walk in parts (bands of CTUs, one per thread), merged into cu / tu / coef afterwards
@@ -79,7 +80,10 @@ static inline uint8_t resolveMcMode( const CodingUnit& cu )
     const bool chk0 = !( anyWp && slice.getSliceType() == B_SLICE ), chk1 = !( cu.pps->getUseWP() && slice.getSliceType() == P_SLICE );
     bio = chk0 && chk1 && PU::isBiPredFromDifferentDirEqDistPoc( cu ) && cu.Y().height >= 8 && cu.Y().width >= 8 && cu.Y().area() >= 128;
   }
-  const bool dmvr = !subPu && PU::checkDMVRCondition( cu );
+  bool dmvr = !subPu && PU::checkDMVRCondition( cu );
+  // neither with a scaled reference picture (InterPrediction.cpp:1431-1435)
+  const bool refIsScaled = ( cu.refIdx[0] >= 0 && slice.getRefPic( REF_PIC_LIST_0, cu.refIdx[0] )->isRefScaled( cu.pps ) ) || ( cu.refIdx[1] >= 0 && slice.getRefPic( REF_PIC_LIST_1, cu.refIdx[1] )->isRefScaled( cu.pps ) );
+  dmvr = dmvr && !refIsScaled; bio = bio && !refIsScaled;
   if( !subPu && bio && !dmvr ) return VVR_MC_BDOF;
   if( dmvr ) return bio ? VVR_MC_DMVR_BDOF : VVR_MC_DMVR;
   if( subPu ) return VVR_MC_SBTMVP;
@@ -204,7 +208,13 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
       {
         const Picture* ref = slice.getRefPic( RefPicList( l ), i );
         if( !ref ) { why = "missing reference picture"; return VVR_ERR_UNSUPPORTED; }
-        if( ref->isRefScaled( &pps ) ) { why = "reference picture of another size (reference picture resampling, InterPrediction.cpp:631-675)"; return VVR_ERR_UNSUPPORTED; }
+        if( ref->isRefScaled( &pps ) )
+        {
+          // reference picture resampling is expressible (vvr_picture.rpr), not together with what the reference itself does not combine it with
+          if( pps.getUseWrapAround() ) { why = "scaled reference picture together with reference wrap-around"; return VVR_ERR_UNSUPPORTED; }
+          for( int k = 0; k < (int) pps.getNumSubPics() && pps.getNumSubPics() > 1; k++ ) if( pps.getSubPic( k ).getTreatedAsPicFlag() ) { why = "scaled reference picture together with sub-pictures treated as pictures"; return VVR_ERR_UNSUPPORTED; }
+          if( ref->lwidth() > 65535 || ref->lheight() > 65535 ) { why = "reference picture larger than 65535 samples"; return VVR_ERR_UNSUPPORTED; }
+        }
         if( i >= VVR_MAX_REFS ) { why = "more reference pictures than VVR_MAX_REFS"; return VVR_ERR_UNSUPPORTED; }
       }
   }
@@ -252,6 +262,33 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   {
     h.num_ref[l] = (int8_t) ru.uni[l].size();
     for( int i = 0; i < h.num_ref[l]; i++ ) { h.ref_poc[l][i] = ru.uni[l][i]->getPOC(); h.ref_slot[l][i] = (int16_t) slotOf( ru.uni[l][i] ); }
+  }
+  // reference picture resampling: how the picture sees its reference pictures (Slice::scaleRefPicList has set the ratios, Slice.cpp:1819); the table
+  // is there when one of them is a scaled picture
+  {
+    bool any = false;
+    for( int l = 0; l < 2; l++ ) for( const Picture* rp : ru.uni[l] ) any |= rp->isRefScaled( &pps );
+    if( any )
+    {
+      const int ux = SPS::getWinUnitX( sps.getChromaFormatIdc() ), uy = SPS::getWinUnitY( sps.getChromaFormatIdc() );
+      memset( &E.rpr, 0, sizeof( E.rpr ) );
+      E.rpr.win_left = pps.getScalingWindow().getWindowLeftOffset() * ux; E.rpr.win_top = pps.getScalingWindow().getWindowTopOffset() * uy;
+      for( int l = 0; l < 2; l++ ) for( int j = 0; j < h.num_ref[l]; j++ )
+      {
+        const Picture* rp = ru.uni[l][j];
+        vvr_rpr_ref& r = E.rpr.ref[l][j];
+        // (the ratio of a reference picture is the same in every slice that lists it: it follows from the two PPSs)
+        for( size_t k = 0; k < st.first.size(); k++ ) for( int i = 0; i < MAX_NUM_REF; i++ )
+          if( ru.map[k][l][i] == j ) { const auto& sr = st.first[k]->getScalingRatio( RefPicList( l ), i ); r.ratio[0] = sr.first; r.ratio[1] = sr.second; }
+        const PPS* rpps = rp->slices[0]->getPPS();
+        r.win_left = rpps->getScalingWindow().getWindowLeftOffset() * ux; r.win_top = rpps->getScalingWindow().getWindowTopOffset() * uy;
+        r.width = (uint16_t) rp->lwidth(); r.height = (uint16_t) rp->lheight();
+        r.scaled = rp->isRefScaled( &pps ) ? 1 : 0;
+        r.hor_collocated_chroma = rp->cs->sps->getHorCollocatedChromaFlag() ? 1 : 0; r.ver_collocated_chroma = rp->cs->sps->getVerCollocatedChromaFlag() ? 1 : 0;
+        if( !r.scaled ) { r.ratio[0] = r.ratio[1] = 1 << SCALE_RATIO_BITS; r.win_left = E.rpr.win_left; r.win_top = E.rpr.win_top; }     // (same size and window: Picture::isRefScaled)
+      }
+      E.pic.rpr = &E.rpr;
+    }
   }
   auto sliceDbk = [&]( const Slice& s, int8_t beta[3], int8_t tc[3] )
   {

@@ -166,8 +166,12 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
     auto spsP = std::make_shared<SPS>(); SPS& sps = *spsP;   // BasePS: shared_from_this needs shared ownership
     sps.setSPSId( 0 );
     sps.setChromaFormatIdc( cf );
-    sps.setMaxPicWidthInLumaSamples( W );
-    sps.setMaxPicHeightInLumaSamples( Hh );
+    {   // (pic_width_max_in_luma_samples: a sequence with reference picture resampling holds pictures of several sizes)
+      int maxW = W, maxH = Hh;
+      for( int l = 0; l < 2 && vp->rpr; l++ ) for( int i = 0; i < H.num_ref[l]; i++ ) { maxW = std::max<int>( maxW, vp->rpr->ref[l][i].width ); maxH = std::max<int>( maxH, vp->rpr->ref[l][i].height ); }
+      sps.setMaxPicWidthInLumaSamples( maxW );
+      sps.setMaxPicHeightInLumaSamples( maxH );
+    }
     sps.setBitDepth( bd );
     sps.setQpBDOffset( 6 * ( bd - 8 ) );
     sps.setInternalMinusInputBitDepth( ( H.min_qp_ts - 4 ) / 6 );
@@ -804,11 +808,11 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       case 6: sps.setUseColorTrans( true ); break;
       case 7: sps.setBitDepth( 12 ); break;
       case 8: pps.setNumTileColumns( 70000 ); break;                                                       // (more tiles than an index holds)
-      case 9: pps.setPicWidthInLumaSamples( W / 2 ); break;                                              // (the references keep their size: Picture::isRefScaled)
+      case 9: pps.setPicWidthInLumaSamples( W / 2 ); sps.setUseWrapAround( true ); pps.setUseWrapAround( true ); pps.setWrapAroundOffset( 128 ); break;      // (the references keep their size - Picture::isRefScaled - and the picture uses wrap-around)
       default: break;
       }
       g_expressible = vvr_glue::checkExpressible( cs, pic, g_why );
-      if( g_feature == 9 ) pps.setPicWidthInLumaSamples( W );
+      if( g_feature == 9 ) { pps.setPicWidthInLumaSamples( W ); sps.setUseWrapAround( false ); pps.setUseWrapAround( false ); }
       if( g_feature == 8 ) pps.setNumTileColumns( 1 );
       for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
       return 0;

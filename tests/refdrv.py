@@ -195,7 +195,7 @@ def extract(desc, refs=None, flags=0):
     def many(ptr, n, ctype):
         return [ctype.from_buffer_copy(ptr[k]) for k in range(n)] if ptr and n else None
 
-    return dict(slices=arr(q.slices, q.num_slices, abi.SliceHeader), alf_sets=many(q.alf_params, q.num_alf_sets, abi.AlfParams), wp_sets=many(q.wp, q.num_wp_sets, abi.WpParams),
+    return dict(rpr=one(q.rpr, abi.RprParams), slices=arr(q.slices, q.num_slices, abi.SliceHeader), alf_sets=many(q.alf_params, q.num_alf_sets, abi.AlfParams), wp_sets=many(q.wp, q.num_wp_sets, abi.WpParams),
                 hdr=h, num_dmvr=nd.value, cu=arr(q.cu, q.num_cu, abi.Cu), tu=arr(q.tu, q.num_tu, abi.Tu), coef=arr(q.coef, q.num_coef, abi.i16),
                 ctu_first_cu=arr(q.ctu_first_cu, nctu + 1, abi.u32), motion=arr(q.motion, n4, abi.Motion),
                 lfp=[arr(q.lfp[0], n4, abi.Lfp), arr(q.lfp[1], n4, abi.Lfp)], sao=arr(q.sao, nctu, abi.SaoCtu), alf=arr(q.alf, nctu, abi.AlfCtu),
@@ -210,7 +210,7 @@ def desc_from_extract(e):
     h = e["hdr"]
     x = _desc.PictureDesc(h.width, h.height, h.bit_depth, h.log2_ctu, h.chroma_format)
     x.hdr = h
-    for k in ("coef", "ctu_first_cu", "sao", "alf", "ctu_slice", "ctu_tile", "slices", "alf_sets", "wp_sets", "lmcs", "scaling", "subpics", "alf_params", "wp"):
+    for k in ("coef", "ctu_first_cu", "sao", "alf", "ctu_slice", "ctu_tile", "slices", "alf_sets", "wp_sets", "lmcs", "scaling", "subpics", "alf_params", "wp", "rpr"):
         setattr(x, k, e[k])
     x.cu, x.tu, x.motion = e["cu"].view(_desc.CU_DT), e["tu"].view(_desc.TU_DT), e["motion"].view(_desc.MOTION_DT)
     x.lfp = [e["lfp"][0].view(_desc.LFP_DT), e["lfp"][1].view(_desc.LFP_DT)]

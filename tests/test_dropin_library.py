@@ -117,3 +117,20 @@ def test_decodes_conformance_bitstreams():
     if not streams:
         pytest.skip("no conformance bitstreams (ext/bitstreams/) in this environment")
     pytest.skip("bitstreams present: run tools/dropin_decode.py on a GPU box")
+
+
+def test_pictures_with_scaled_reference_pictures_through_the_dropin_class():
+    """the drop-in on pictures whose reference pictures have another size (reference picture resampling), on the stand-in runtime: the context is
+    sized by the SPS's maximum picture size, the reference pictures are uploaded at their own sizes (vvr_slot_picture_size), the extractor's
+    vvr_rpr_params passes the product's validation and work-list builder, the picture comes back at its own size"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_vs_ref import RPR_CASES, rpr_case, ALL
+    for (W, H, l2, idx, seed, specs, win, colloc, kw) in RPR_CASES:
+        kw = dict(kw)
+        tools = ALL | kw.pop("tool_flags_extra", 0)
+        d, refs = rpr_case(W, H, l2, idx, seed, specs, win=win, colloc=colloc, tools=tools, **kw)
+        planes, motion = refdrv.run_dropin(d, refs, _stub_path(), threads=2)
+        assert [p.shape for p in planes] == [d.plane_shape(c) for c in range(len(planes))]
+        inter = d.motion["ref_idx"].max(axis=1) >= 0
+        assert inter.any() and np.array_equal(motion["ref_idx"][inter], d.motion["ref_idx"][inter])

@@ -295,10 +295,10 @@ def test_slices_with_headers_of_their_own_survive_the_reference_objects(built, i
 
 
 @pytest.mark.parametrize("feature,text", [(1, "LADF with more than 5"), (2, "wrap-around motion compensation with a period off"), (3, "virtual boundary off the 8-sample grid"), (4, "missing reference picture"), (5, "sub-pictures together with reference wrap-around"),
-                                          (6, "colour transform"), (7, "bit depth"), (8, "more slices or tiles"), (9, "another size")])
+                                          (6, "colour transform"), (7, "bit depth"), (8, "more slices or tiles"), (9, "scaled reference picture together with reference wrap-around")])
 def test_extractor_refuses_what_the_description_cannot_express(built, feature, text):
     """the reference-side glue never flattens a picture into something it is not: LADF, wrap-around, virtual boundaries, several slices / tiles /
-    sub-pictures, ACT, more than 10 bits, scaled references are refused with VVR_ERR_UNSUPPORTED (the binding raises the reference's own
+    sub-pictures, ACT, more than 10 bits, scaled references in a picture with wrap-around are refused with VVR_ERR_UNSUPPORTED (the binding raises the reference's own
     'not supported' error); the same picture without the feature is accepted"""
     L = refdrv.lib()
     W, H = 256, 128
@@ -349,3 +349,34 @@ def test_binding_executes_on_the_stand_in_runtime(built):
             assert np.array_equal(motion["ref_idx"][inter], d.motion["ref_idx"][inter])
             l0 = inter & (d.motion["ref_idx"][:, 0] >= 0)
             assert np.array_equal(motion["mv"][l0][:, 0], d.motion["mv"][l0][:, 0])
+
+
+def _rpr_differ(a, b, h):
+    bad = []
+    if (a is None) != (b is None):
+        return ["rpr present %s vs %s" % (a is not None, b is not None)]
+    if a is None:
+        return bad
+    if (a.win_left, a.win_top) != (b.win_left, b.win_top):
+        bad.append("rpr window %s vs %s" % ((a.win_left, a.win_top), (b.win_left, b.win_top)))
+    for l in range(2):
+        for i in range(h.num_ref[l]):
+            bad += _struct_differ(a.ref[l][i], b.ref[l][i], "rpr.ref[%d][%d]" % (l, i))
+    return bad
+
+
+def test_scaled_reference_pictures_survive_the_reference_objects(built):
+    """reference picture resampling: the extractor writes the table (ratios of the slices, windows and sizes of the PPSs, chroma sample location of
+    the reference pictures' SPS) from the reference's objects, decides BDOF / DMVR like the reference does for CUs with a scaled reference
+    picture, and what it wrote reconstructs to the reference's picture"""
+    from test_oracle_vs_ref import RPR_CASES, rpr_case
+    for (W, H, l2, idx, seed, specs, win, colloc, kw) in RPR_CASES:
+        kw = dict(kw)
+        tools = ALL | kw.pop("tool_flags_extra", 0)
+        d, refs = rpr_case(W, H, l2, idx, seed, specs, win=win, colloc=colloc, tools=tools, **kw)
+        e = refdrv.extract(d, refs)
+        bad = _compare(d, e) + _rpr_differ(d.rpr, e["rpr"], d.hdr)
+        assert not bad, "seed %d\n" % seed + "\n".join(bad)
+        want = refdrv.reconstruct(d, refs)["planes"]
+        got = refdrv.oracle_reconstruct(refdrv.desc_from_extract(e), refs)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))

@@ -805,3 +805,25 @@ def test_scaled_reference_pictures_through_the_back_end(built):
             g = got[c][:want[c].shape[0], :want[c].shape[1]]
             assert np.array_equal(g, want[c]), "seed %d comp %d: %d samples differ" % (seed, c, int((g != want[c]).sum()))
         rec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 3])
+def test_dropin_with_scaled_reference_pictures(built, threads):
+    """the drop-in on pictures whose reference pictures have another size / scaling window: the reference's objects (PPSs with scaling windows,
+    Slice::m_scalingRatio, reference Pictures of their own size) are flattened by the extractor (vvr_picture.rpr), the reference pictures are
+    uploaded at their own size, the GPU reconstructs, and the Picture's buffers equal what the reference's own DecLibRecon stages give"""
+    import vvdec_amd
+    from test_oracle_vs_ref import RPR_CASES, rpr_case, ALL
+    if not (refdrv.available() and refdrv.dropin_available()):
+        pytest.skip("the reference build (oracle/_ref) is not present")
+    for (W, H, l2, idx, seed, specs, win, colloc, kw) in RPR_CASES:
+        kw = dict(kw)
+        tools = ALL | kw.pop("tool_flags_extra", 0)
+        d, refs = rpr_case(W, H, l2, idx, seed, specs, win=win, colloc=colloc, tools=tools, **kw)
+        want_planes, want_motion = refdrv.reconstruct_with_motion(d, refs, flags=refdrv.DERIVE_LFP)
+        got_planes, got_motion = refdrv.run_dropin(d, refs, vvdec_amd._LIBPATH, threads=threads)
+        for c in range(len(want_planes)):
+            assert np.array_equal(got_planes[c], want_planes[c]), "seed %d comp %d: %d samples differ from the reference's DecLibRecon" % (seed, c, int((got_planes[c] != want_planes[c]).sum()))
+        valid = want_motion["ref_idx"] >= 0
+        assert np.array_equal(got_motion["ref_idx"], want_motion["ref_idx"]) and np.array_equal(got_motion["mv"][valid], want_motion["mv"][valid])

@@ -92,7 +92,7 @@ EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "v
                     "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_picture_hash", "vvr_write_plane", "vvr_read_dmvr", "vvr_read_col_motion", "vvr_prepare", "vvr_submit_prepared",
                     "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof",
                     "vvr_inputs_done", "vvr_measure_copy_bandwidth", "vvr_host_alloc", "vvr_host_free",
-                    "vvr_stream_wait_job", "vvr_stream_wait_slot", "vvr_slot_external_event"]
+                    "vvr_stream_wait_job", "vvr_stream_wait_slot", "vvr_slot_external_event", "vvr_slot_picture_size"]
 
 
 class Reconstructor:

@@ -974,12 +974,26 @@ VVR_API void* vvr_plane_ptr( vvr_context* c, int slot, int comp )
   return c->slots[slot].p[comp];
 }
 
+VVR_API int vvr_slot_picture_size( vvr_context* c, int slot, int width, int height )
+{
+  if( !c || slot < 0 || slot >= (int) c->slots.size() || width <= 0 || height <= 0 || width > c->cfg.max_width || height > c->cfg.max_height || ( width & 7 ) || ( height & 7 ) ) return VVR_ERR_PARAMETER;
+  c->slotDim[slot] = std::make_pair( (uint16_t) width, (uint16_t) height );
+  return VVR_OK;
+}
+// the picture in a slot: its planes at its own size
+static DevPlanes pictureIn( const vvr_context* c, int slot )
+{
+  DevPlanes d = c->slots[slot];
+  for( int k = 0; k < 3; k++ ) { d.w[k] = k ? c->slotDim[slot].first >> 1 : c->slotDim[slot].first; d.h[k] = k ? c->slotDim[slot].second >> 1 : c->slotDim[slot].second; }
+  return d;
+}
+
 VVR_API int vvr_read_plane( vvr_context* c, int slot, int comp, uint16_t* dst, size_t dstStride )
 {
   if( !c || slot < 0 || slot >= (int) c->slots.size() || comp < 0 || comp > 2 || !c->slots[slot].p[comp] ) return VVR_ERR_PARAMETER;
   hipSetDevice( c->device );
   const int rc = vvr_sync( c ); if( rc != VVR_OK ) return rc;
-  const DevPlanes& d = c->slots[slot];
+  const DevPlanes d = pictureIn( c, slot );
   HIPCHK( c, hipMemcpy2D( dst, dstStride * 2, d.p[comp], (size_t) d.stride[comp] * 2, (size_t) d.w[comp] * 2, d.h[comp], hipMemcpyDeviceToHost ) );
   return VVR_OK;
 }
@@ -989,7 +1003,7 @@ VVR_API int vvr_write_plane( vvr_context* c, int slot, int comp, const uint16_t*
   if( !c || slot < 0 || slot >= (int) c->slots.size() || comp < 0 || comp > 2 || !c->slots[slot].p[comp] ) return VVR_ERR_PARAMETER;
   hipSetDevice( c->device );
   const int rc = vvr_sync( c ); if( rc != VVR_OK ) return rc;
-  const DevPlanes& d = c->slots[slot];
+  const DevPlanes d = pictureIn( c, slot );
   HIPCHK( c, hipMemcpy2D( d.p[comp], (size_t) d.stride[comp] * 2, src, srcStride * 2, (size_t) d.w[comp] * 2, d.h[comp], hipMemcpyHostToDevice ) );
   return VVR_OK;
 }
