@@ -347,6 +347,9 @@ typedef struct vvr_slice_header {
  * CU takes no BDOF, DMVR or PROF (InterPrediction.cpp:1431-1435,1029).  Indexed like hdr.ref_slot (the union of the slices' lists).  The DPB slot of a
  * scaled reference picture holds a picture of `width` x `height` luma samples in its top left corner (vvr_config.max_width / max_height bound every
  * picture of a context; a picture is reconstructed at hdr.width x hdr.height).
+ * SbTMVP: every 8x8 sub-block is predicted on its own from the sub-block's position.  (The reference joins sub-blocks of equal motion unless the
+ * slice's first reference pictures are scaled, InterPrediction.cpp:477; sub-block motion refers to the first reference picture of each list, so a
+ * sub-block that reads a scaled picture is never part of a joined block.)
  * Not combined with reference wrap-around or with sub-pictures treated as pictures (the reference keeps no wrap copy of a scaled picture,
  * Picture.h:278, and a coded video sequence with such sub-pictures does not change its picture size).                                            */
 typedef struct vvr_rpr_ref {

@@ -301,7 +301,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   auto uniIdx = [&]( int se, int l, int refIdx ) -> int8_t { return refIdx < 0 || refIdx >= MAX_NUM_REF ? (int8_t) -1 : ru.map[se][l][refIdx]; };
   h.log2_sao_offset_scale[0] = h.log2_sao_offset_scale[1] = (uint8_t) std::max( 0, bd - MAX_SAO_TRUNCATED_BITDEPTH );
   h.min_qp_ts = (int8_t) ( 4 + 6 * sps.getInternalMinusInputBitDepth() );
-  if( pps.getUseWrapAround() ) h.wrap_offset = (uint16_t) pps.getWrapAroundOffset();       // (Picture::isWrapAroundEnabled: references of another size are refused above)
+  if( pps.getUseWrapAround() ) h.wrap_offset = (uint16_t) pps.getWrapAroundOffset();       // (Picture::isWrapAroundEnabled: scaled reference pictures in a picture with wrap-around are refused above)
   if( cs.picHeader->getVirtualBoundariesPresentFlag() )
   {
     const PicHeader& ph = *cs.picHeader;

@@ -68,6 +68,11 @@ CASES = [
     ("b_256x128_ctu64_ladf", 256, 128, 6, 2, 50, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LADF, dict(p_intra=0.3, p_affine=0.1, p_coded=0.5)),
     ("b_384x256_ctu64_slice_headers", 384, 256, 6, 2, 56, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_SCALING_LIST | abi.TOOL_WP | abi.TOOL_NO_LF_ACROSS_SLICES,
      dict(num_slices=4, vary_slices=1, p_intra=0.3, p_cclm=0.3, p_ciip=0.1, p_affine=0.1, p_coded=0.8, p_coded_chroma=0.5)),
+    # reference picture resampling: two scaled reference pictures of their own sizes (1.3 x 0.8 and 1.3 x 1.8: regular and both low-pass filter sets), scaling
+    # windows with offsets, chroma samples not collocated, weighted prediction, affine / GPM / CIIP / SbTMVP CUs among the ones that read them
+    ("b_400x208_ctu64_scaled_references", 400, 208, 6, 2, 57, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_WP,
+     dict(rpr=dict(specs=[dict(ratio=(int(1.3 * 16384), int(0.8 * 16384)), size=(520, 168), win=(16, 6)), dict(ratio=(int(1.3 * 16384), int(1.8 * 16384)), size=(512, 376), win=(-8, 2))], win=(8, 4), colloc=(0, 0)),
+          p_intra=0.15, p_affine=0.3, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.2, mv_sigma=6.0)),
     ("b_256x192_ctu128_all_inter", 256, 192, 7, 2, 26, ALL | abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.1, p_affine=0.2, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.2)),
 ]
 
@@ -82,13 +87,18 @@ def main():
         pl = plans[idx]
         kw = dict(kw)
         vary = kw.pop("vary_slices", 0)
-        d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
-        if vary:
-            synth.vary_slices(d, seed)           # slices with headers of their own (vvr_slice_header)
-        refs = {}
-        for lst in pl.ref_slots:
-            for (slot, poc) in lst:
-                refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc, bit_depth=kw.get("bit_depth", 10)))
+        rpr = kw.pop("rpr", None)
+        if rpr:
+            from test_oracle_vs_ref import rpr_case      # (description with its vvr_rpr_params, reference pictures of their own sizes)
+            d, refs = rpr_case(W, H, l2, idx, seed, rpr["specs"], win=rpr["win"], colloc=rpr["colloc"], tools=tools, **kw)
+        else:
+            d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
+            if vary:
+                synth.vary_slices(d, seed)           # slices with headers of their own (vvr_slice_header)
+            refs = {}
+            for lst in pl.ref_slots:
+                for (slot, poc) in lst:
+                    refs.setdefault(slot, synth.natural_picture(W, H, seed + 100 + poc, bit_depth=kw.get("bit_depth", 10)))
         outs = {}
         for st, fl in (("reco", refdrv.STOP_AFTER_RECO), ("dbk", refdrv.STOP_AFTER_DBK), ("sao", refdrv.STOP_AFTER_SAO), ("final", 0)):
             scalar = refdrv.reconstruct(d, refs, flags=fl)["planes"]

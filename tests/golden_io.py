@@ -42,6 +42,8 @@ def save(path, desc, refs, outputs):
         d["subpics"] = np.frombuffer(np.ascontiguousarray(desc.subpics).tobytes(), np.uint8)
     if desc.slices is not None and len(desc.slices):
         d["slices"] = np.frombuffer(np.ascontiguousarray(desc.slices, dtype=np.dtype(abi.SliceHeader)).tobytes(), np.uint8)
+    if getattr(desc, "rpr", None) is not None:
+        d["rpr"] = _bytes_of(desc.rpr)
     if desc.alf_sets:
         d["alf_sets"] = np.concatenate([_bytes_of(a) for a in desc.alf_sets])
     if desc.wp_sets:
@@ -92,6 +94,8 @@ def load(path):
         d.subpics = np.frombuffer(z["subpics"].tobytes(), np.dtype(abi.Subpic)).copy()
     if "slices" in z:
         d.slices = np.frombuffer(z["slices"].tobytes(), np.dtype(abi.SliceHeader)).copy()
+    if "rpr" in z:
+        d.rpr = abi.RprParams.from_buffer_copy(z["rpr"].tobytes())
     for key, cls in (("alf_sets", abi.AlfParams), ("wp_sets", abi.WpParams)):
         if key in z:
             raw = z[key].tobytes()

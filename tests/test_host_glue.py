@@ -680,7 +680,8 @@ def test_golden_fixtures_pass_the_host_glue(stub):
     for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))):
         d, refs, _ = golden_io.load(path)
         h = d.hdr
-        ctx = Ctx(stub, h.width, h.height, max([h.out_slot] + list(refs.keys())) + 1, log2_ctu=h.log2_ctu, bit_depth=h.bit_depth, chroma_format=h.chroma_format)
+        MW = max([h.width] + [r[0].shape[1] for r in refs.values()]); MH = max([h.height] + [r[0].shape[0] for r in refs.values()])      # (scaled reference pictures have their own sizes)
+        ctx = Ctx(stub, MW, MH, max([h.out_slot] + list(refs.keys())) + 1, log2_ctu=h.log2_ctu, bit_depth=h.bit_depth, chroma_format=h.chroma_format)
         hnd = ctx.prepare(d)
         units, items = ctx.tables(hnd)
         _check_tables(d, units, items)
