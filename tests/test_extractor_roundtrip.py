@@ -380,3 +380,25 @@ def test_scaled_reference_pictures_survive_the_reference_objects(built):
         want = refdrv.reconstruct(d, refs)["planes"]
         got = refdrv.oracle_reconstruct(refdrv.desc_from_extract(e), refs)
         assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_scaled_reference_pictures_with_slices_that_list_them_differently(built):
+    """reference picture resampling together with slices whose headers and reference picture lists differ: the harness rotates the lists per slice
+    (a picture is entry 0 of one slice and entry 1 of the next), the extractor merges them into the union and writes the table over the union;
+    what it wrote reconstructs (oracle) to the picture the reference's own stages produce from those objects"""
+    from test_oracle_vs_ref import rpr_case
+    R1 = 1 << 14
+    specs = [dict(ratio=(int(R1 * 1.3), int(R1 * 0.8)), size=(520, 168), win=(16, 6)), None]
+    for seed, idx in ((671, 2),):
+        d, refs = rpr_case(400, 208, 6, idx, seed, specs, win=(8, 4), colloc=(0, 1), tools=ALL | abi.TOOL_WP | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE,
+                           num_slices=3, p_intra=0.15, p_affine=0.3, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.2)
+        synth.vary_slices(d, seed)
+        assert sum(d.rpr.ref[l][i].scaled for l in range(2) for i in range(d.hdr.num_ref[l])) in (1, 2, 3)
+        fl = refdrv.ROTATE_REF_LISTS
+        want = refdrv.reconstruct(d, refs, flags=fl)["planes"]
+        assert all(np.array_equal(a, b) for a, b in zip(refdrv.oracle_reconstruct(d, refs), want))      # (the rotation is immaterial to the picture)
+        e = refdrv.extract(d, refs, flags=fl)
+        x = refdrv.desc_from_extract(e)
+        assert x.rpr is not None
+        got = refdrv.oracle_reconstruct(x, refs)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
