@@ -424,6 +424,9 @@ typedef struct vvr_config {
                                     that they can be compared with the reference's picture at the same point                                  */
   uint8_t  ring_entries;         /* entries of the upload ring (pinned staging + HBM image of one picture each); 0: 2 * num_streams +
                                     2 * host_threads + 4, enough for the pictures in the workers' hands plus those in flight on the device   */
+  uint8_t  read_buffers;         /* pinned staging buffers of vvr_read_picture (one picture each) allocated with the context; 0: the first calls that
+                                    need one allocate it (pinning 30 MB takes milliseconds: a decoder that reads every picture back asks for them here) */
+  uint8_t  pad[7];
   void*    ext_planes;           /* optional: caller-owned device memory for the DPB, num_slots * vvr_slot_bytes */
                                  /* (mirrors vvdec_decoder_open_with_allocator, vvdec.h.in:576)                 */
 } vvr_config;
@@ -473,6 +476,12 @@ VVR_API int          vvr_read_output(vvr_context* ctx, int slot, int comp, int x
  * the plane to exactly those bytes and the host hashes them. */
 enum { VVR_HASH_MD5 = 0, VVR_HASH_CRC = 1, VVR_HASH_CHECKSUM = 2 };
 VVR_API int          vvr_picture_hash(vvr_context* ctx, int slot, int method, uint8_t* digest, int* digest_len);
+/* the finished picture in `slot` (every plane, at the picture's size) into the caller's buffers - what a decoder does with each picture it hands to
+ * the application (the planes of a vvdecFrame live in the Picture's own buffers, vvdecimpl.cpp:1058).  Waits for NOTHING: the caller has waited for
+ * the picture (vvr_wait); other pictures in flight are not held up (vvr_read_plane drains the context).  Each plane crosses PCIe in one transfer
+ * into pinned memory of the context, from where `threads` (1..16) threads lay the rows out at dst[c] with dst_stride_samples[c]: a copy straight
+ * into pageable memory runs at a fraction of the link's rate.  May be called by several threads at once (one staging buffer per call in flight). */
+VVR_API int          vvr_read_picture(vvr_context* ctx, int slot, uint16_t* const* dst, const size_t* dst_stride_samples, int threads);
 /* upload a reference picture produced elsewhere (another GPU / a test) into a slot */
 VVR_API int          vvr_write_plane(vvr_context* ctx, int slot, int comp, const uint16_t* src, size_t src_stride_samples);
 /* size of the picture a slot holds (luma samples; a picture lies in the top left corner of its slot): vvr_submit sets it to the size of the picture

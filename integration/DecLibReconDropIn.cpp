@@ -244,7 +244,7 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
       cfg.chroma_format = cs.sps->getChromaFormatIdc() == CHROMA_400 ? 0 : 1; cfg.bit_depth = (uint8_t) cs.sps->getBitDepth();
       cfg.log2_ctu = (uint8_t) getLog2( cs.sps->getMaxCUWidth() );
       S.numSlots = getenv( "VVDEC_AMD_SLOTS" ) ? atoi( getenv( "VVDEC_AMD_SLOTS" ) ) : 48;       // Picture objects the decoder allocates: DPB size + pictures in flight
-      cfg.num_slots = (uint8_t) S.numSlots; cfg.num_streams = 4; cfg.host_threads = 0;           // (this task IS the worker thread of its picture)
+      cfg.num_slots = (uint8_t) S.numSlots; cfg.num_streams = 4; cfg.host_threads = 0; cfg.read_buffers = 2;           // (this task IS the worker thread of its picture)
       if( vvr_create( &cfg, &S.ctx ) != VVR_OK ) { S.ctx = nullptr; THROW_RECOVERABLE( "vvdec_amd: no MI355X back-end (vvr_create failed)" ); }
     }
     auto slotFor = [&S]( const Picture* p ) -> int
@@ -276,8 +276,10 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
   // ---- the picture as the rest of the decoder expects it: planes in the Picture's own buffers (output, hash SEI, film grain)
   {
     PelUnitBuf reco = pic->getRecoBuf();
-    for( size_t c = 0; c < reco.bufs.size(); c++ )
-      if( vvr_read_plane( S.ctx, slot, (int) c, reinterpret_cast<uint16_t*>( reco.bufs[c].buf ), (size_t) reco.bufs[c].stride ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( S.ctx ) );
+    uint16_t* dst[3] = { nullptr, nullptr, nullptr }; size_t stride[3] = { 0, 0, 0 };
+    for( size_t c = 0; c < reco.bufs.size(); c++ ) { dst[c] = reinterpret_cast<uint16_t*>( reco.bufs[c].buf ); stride[c] = (size_t) reco.bufs[c].stride; }
+    // (this picture only - the others in flight are not waited for -, through pinned staging, rows laid out by the picture's host threads)
+    if( vvr_read_picture( S.ctx, slot, dst, stride, hostThreads ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( S.ctx ) );
   }
   double t5 = nowMs(); I.msReadBack += t5 - t4; I.pictures++;
   // ---- DMVR-refined MVs feed the temporal MV prediction of later pictures: through the reference's own finish step (DecCu.cpp:161)

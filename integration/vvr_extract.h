@@ -36,16 +36,28 @@ template<class F> static inline void parallelFor( int n, int threads, F&& fn )
   for( auto& e : err ) if( e ) std::rethrow_exception( e );
 }
 
+// storage of records that are all written by the flattening: grows, is never value-initialised (a std::vector would clear megabytes per picture on
+// one thread before the walk's threads write them) and does not keep its contents over a resize
+template<class T> struct RawArray
+{
+  std::unique_ptr<T[]> p; size_t n = 0, cap = 0;
+  void resize( size_t k ) { if( k > cap ) { p.reset( new T[k] ); cap = k; } n = k; }
+  T* data() { return p.get(); } const T* data() const { return p.get(); }
+  size_t size() const { return n; } bool empty() const { return n == 0; }
+  T& operator[]( size_t i ) { return p[i]; } const T& operator[]( size_t i ) const { return p[i]; }
+  T* begin() { return p.get(); } T* end() { return p.get() + n; } const T* begin() const { return p.get(); } const T* end() const { return p.get() + n; }
+};
+
 struct Extracted
 {
   vvr_picture               pic;          // pointers into the members below
-  std::vector<vvr_cu>       cu;
-  std::vector<vvr_tu>       tu;
-  std::vector<int16_t>      coef;
+  RawArray<vvr_cu>          cu;
+  RawArray<vvr_tu>          tu;
+  RawArray<int16_t>         coef;
   std::vector<uint32_t>     ctuFirstCu;
   std::vector<vvr_motion>   motion;
   std::unique_ptr<vvr_motion[]> motionSparse; size_t motionSparseCells = 0;      // (subBlockMotionOnly) the cells under affine / SbTMVP CUs only: never cleared, pages nobody writes are never touched
-  std::vector<vvr_lfp>      lfp[2];
+  RawArray<vvr_lfp>         lfp[2];
   std::vector<vvr_sao_ctu>  sao;
   std::vector<vvr_alf_ctu>  alf;
   std::vector<vvr_alf_params> alfSets;            // final filters of the APSs the slices refer to: one table per distinct choice (vvr_slice_header::alf_set)
@@ -317,7 +329,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
 
   const auto tX0 = std::chrono::steady_clock::now();
   // ---- coding units, transform units, levels
-  E.cu.clear(); E.tu.clear(); E.coef.clear(); E.ctuFirstCu.assign( numCtu + 1, 0 ); E.numDmvr = 0; E.dmvrCus.clear();
+  E.cu.resize( 0 ); E.tu.resize( 0 ); E.coef.resize( 0 ); E.ctuFirstCu.assign( numCtu + 1, 0 ); E.numDmvr = 0; E.dmvrCus.clear();
   PelUnitBuf reco = cs.getRecoBuf();
   auto isIntraAt = [&]( const CodingUnit& cur, const Position& p ) { const CodingUnit* n = cs.getCURestricted( p, cur, CHANNEL_TYPE_LUMA ); return n && CU::isIntra( *n ); };
   // (the walk is split into bands of CTUs, one per thread: every band writes records with band-local indices, the merge below makes them global)
@@ -436,11 +448,18 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   {
     size_t nCu = 0, nTu = 0, nCoef = 0;
     for( int r = 0; r < nParts; r++ ) { nCu += E.walk[r].cu.size(); nTu += E.walk[r].tu.size(); nCoef += E.walk[r].coef.size(); }
-    E.cu.resize( nCu ); E.tu.resize( nTu ); E.coef.resize( nCoef );
-    uint32_t cuBase = 0, tuBase = 0, coefBase = 0, dmvrBase = 0;
+    E.cu.resize( nCu ); E.tu.resize( nTu ); E.coef.resize( std::max<size_t>( 1, nCoef ) ); if( !nCoef ) E.coef[0] = 0;
+    // (where every band's records go follows from the bands' sizes; the bands are then copied side by side)
+    std::vector<uint32_t> cuB( nParts + 1, 0 ), tuB( nParts + 1, 0 ), coefB( nParts + 1, 0 ), dmvrB( nParts + 1, 0 );
     for( int r = 0; r < nParts; r++ )
     {
+      cuB[r + 1] = cuB[r] + (uint32_t) E.walk[r].cu.size(); tuB[r + 1] = tuB[r] + (uint32_t) E.walk[r].tu.size();
+      coefB[r + 1] = coefB[r] + (uint32_t) E.walk[r].coef.size(); dmvrB[r + 1] = dmvrB[r] + E.walk[r].numDmvr;
+    }
+    parallelFor( nParts, nParts, [&]( int r )
+    {
       Extracted::Walk& o = E.walk[r];
+      const uint32_t cuBase = cuB[r], tuBase = tuB[r], coefBase = coefB[r], dmvrBase = dmvrB[r];
       const int a0 = (int) ( (int64_t) numCtu * r / nParts );
       for( size_t k = 0; k < o.first.size(); k++ ) E.ctuFirstCu[a0 + k] = o.first[k] + cuBase;
       for( size_t k = 0; k < o.cu.size(); k++ )
@@ -459,9 +478,9 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
         E.tu[tuBase + k] = t;
       }
       if( !o.coef.empty() ) memcpy( &E.coef[coefBase], o.coef.data(), sizeof( int16_t ) * o.coef.size() );
-      for( auto& d : o.dmvrCus ) E.dmvrCus.emplace_back( d.first, d.second + dmvrBase );
-      cuBase += (uint32_t) o.cu.size(); tuBase += (uint32_t) o.tu.size(); coefBase += (uint32_t) o.coef.size(); dmvrBase += o.numDmvr;
-    }
+    } );
+    for( int r = 0; r < nParts; r++ ) for( auto& d : E.walk[r].dmvrCus ) E.dmvrCus.emplace_back( d.first, d.second + dmvrB[r] );
+    const uint32_t dmvrBase = dmvrB[nParts];
     E.numDmvr = dmvrBase;
   }
   E.ctuFirstCu[numCtu] = (uint32_t) E.cu.size();
@@ -487,29 +506,39 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
       m.mv[l][0] = mi.mv[l].getHor(); m.mv[l][1] = mi.mv[l].getVer();
     }
   };
+  // (row y of the picture = one run of cells per CTU it crosses: the CTU, its slice and the row inside the CTU's tables are looked up once per run)
   parallelFor( h4, threads, [&]( int y )
   {
-    for( int x = 0; x < w4; x++ )
+    const int cy = y / ctu4, iy = y % ctu4;
+    for( int cx = 0; cx < (int) pcv.widthInCtus; cx++ )
     {
-      const int a = ( y / ctu4 ) * pcv.widthInCtus + ( x / ctu4 ), in = ( y % ctu4 ) * ctu4 + ( x % ctu4 );
-      const CtuData& cd = cs.getCtuData( a );
-      if( !subBlockMotionOnly ) motionCell( x, y );
+      const CtuData& cd = cs.getCtuData( cy * pcv.widthInCtus + cx );
+      const int x0 = cx * ctu4, n = std::min( ctu4, w4 - x0 );
+      // a slice with deblocking switched off in a picture that deblocks: LF_INIT leaves the edge parameters of its CTUs untouched and the
+      // filter skips them (LoopFilter.cpp:366,423) - here they carry no edge
+      const bool noEdges = !allDbkOff && cd.slice && cd.slice->getDeblockingFilterDisable();
       for( int d = 0; d < 2; d++ )
       {
-        const LoopFilterParam& s = cd.lfParam[d][in];
-        vvr_lfp& o = E.lfp[d][(size_t) y * w4 + x]; memset( &o, 0, sizeof( o ) );
-        // a slice with deblocking switched off in a picture that deblocks: LF_INIT leaves the edge parameters of its CTUs untouched and the
-        // filter skips them (LoopFilter.cpp:366,423) - here they carry no edge
-        if( !allDbkOff && cd.slice && cd.slice->getDeblockingFilterDisable() ) continue;
-        o.qp[0] = s.qp[0]; o.qp[1] = s.qp[1]; o.qp[2] = s.qp[2]; o.bs = s.bs; o.side_max_filt_length = s.sideMaxFiltLength; o.flags = s.flags;
+        vvr_lfp* o = &E.lfp[d][(size_t) y * w4 + x0];
+        memset( o, 0, sizeof( vvr_lfp ) * n );
+        if( noEdges ) continue;
+        const LoopFilterParam* s = &cd.lfParam[d][iy * ctu4];
+        for( int k = 0; k < n; k++ ) { o[k].qp[0] = s[k].qp[0]; o[k].qp[1] = s[k].qp[1]; o[k].qp[2] = s[k].qp[2]; o[k].bs = s[k].bs; o[k].side_max_filt_length = s[k].sideMaxFiltLength; o[k].flags = s[k].flags; }
       }
+      if( !subBlockMotionOnly ) for( int k = 0; k < n; k++ ) motionCell( x0 + k, y );
     }
   } );
 
   if( subBlockMotionOnly )
-    for( const vvr_cu& c : E.cu )
-      if( c.pred_mode == VVR_PRED_INTER && ( c.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP ) ) )
-        for( int y = c.y >> 2; y < ( c.y + c.h + 3 ) >> 2; y++ ) for( int x = c.x >> 2; x < ( c.x + c.w + 3 ) >> 2; x++ ) motionCell( x, y );
+    parallelFor( threads, threads, [&]( int r )
+    {
+      for( size_t k = E.cu.size() * r / threads; k < E.cu.size() * ( r + 1 ) / threads; k++ )
+      {
+        const vvr_cu& c = E.cu[k];
+        if( c.pred_mode == VVR_PRED_INTER && ( c.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP ) ) )
+          for( int y = c.y >> 2; y < ( c.y + c.h + 3 ) >> 2; y++ ) for( int x = c.x >> 2; x < ( c.x + c.w + 3 ) >> 2; x++ ) motionCell( x, y );
+      }
+    } );
   const auto tX2 = std::chrono::steady_clock::now();
   if( getenv( "VVR_EXTRACT_TIMES" ) ) fprintf( stderr, "[extract] CU/TU/levels %.2f ms, 4x4 tables %.2f ms\n", std::chrono::duration<double, std::milli>( tX1 - tX0 ).count(), std::chrono::duration<double, std::milli>( tX2 - tX1 ).count() );
   // ---- per-CTU loop filter controls: SAO with merges resolved and offsets scaled (SampleAdaptiveOffset::reconstructBlkSAOParam), ALF
@@ -638,7 +667,6 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
 
   // ---- the picture
   E.pic.num_cu = (uint32_t) E.cu.size(); E.pic.num_tu = (uint32_t) E.tu.size();
-  if( E.coef.empty() ) E.coef.push_back( 0 );
   E.pic.cu = E.cu.data(); E.pic.tu = E.tu.data(); E.pic.ctu_first_cu = E.ctuFirstCu.data(); E.pic.coef = E.coef.data(); E.pic.num_coef = E.coef.size();
   E.pic.motion = subBlockMotionOnly ? E.motionSparse.get() : E.motion.data(); E.pic.lfp[0] = E.lfp[0].data(); E.pic.lfp[1] = E.lfp[1].data();
   E.pic.sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) ? E.sao.data() : nullptr;

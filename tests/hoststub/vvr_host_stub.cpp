@@ -24,6 +24,7 @@ hipError_t hipFree( void* p ) { free( p ); return hipSuccess; }
 hipError_t hipHostMalloc( void** p, size_t n, unsigned int ) { *p = calloc( 1, n ? n : 1 ); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree( void* p ) { free( p ); return hipSuccess; }
 hipError_t hipMemcpy( void* d, const void* s, size_t n, hipMemcpyKind ) { memcpy( d, s, n ); return hipSuccess; }
+hipError_t hipMemcpy2DAsync( void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t ) { for( size_t y = 0; y < h; y++ ) memcpy( (char*) d + y * dp, (const char*) s + y * sp, w ); return hipSuccess; }
 hipError_t hipMemcpy2D( void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind ) { for( size_t y = 0; y < h; y++ ) memcpy( (char*) d + y * dp, (const char*) s + y * sp, w ); return hipSuccess; }
 hipError_t hipMemset( void* d, int v, size_t n ) { memset( d, v, n ); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags( hipStream_t* s, unsigned int ) { StubStream* p = (StubStream*) calloc( 1, sizeof( StubStream ) ); p->id = g_numStreams++; *s = (hipStream_t) p; return hipSuccess; }

@@ -767,6 +767,9 @@ def test_stream_that_changes_its_picture_size(built, sizes, kw):
         cpu[pl.slot] = want
         for method in (1, 2):
             assert rec.picture_hash(pl.slot, method) == refdrv.picture_hash(want, 10, method), "hash method %d of POC %d" % (method, pl.poc)
+        # the picture back the way the drop-in takes it (vvr_read_picture: this picture only, pinned staging, rows at the caller's strides)
+        for a, b in zip(rec.read_picture_into(pl.slot, (W, H), pad=24, threads=3), want):
+            assert np.array_equal(a, b)
     # all in flight at once
     rec2 = vvdec_amd.Reconstructor(MW, MH, num_slots=nslots, num_streams=3, host_threads=3, log2_ctu=l2)
     for d in descs:

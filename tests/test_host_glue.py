@@ -1132,3 +1132,32 @@ def test_scaled_reference_pictures_in_the_host_glue(stub):
             d.cu["mc_mode"][bi[0]] = abi.MC_BDOF
             _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "scaled reference picture")
         ctx.close()
+
+
+@pytest.mark.parametrize("threads", [1, 5])
+def test_read_picture_lays_the_rows_out_at_the_callers_strides(stub, threads):
+    """vvr_read_picture: every plane of the picture in a slot at the picture's own size (vvr_slot_picture_size), rows at the caller's strides and
+    nothing written past them; staging buffers allocated with the context (vvr_config.read_buffers) or with the first call"""
+    W, H = 96, 64
+    stub.vvr_write_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    stub.vvr_read_picture.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(5)
+    for pre in (0, 2):
+        cfg = abi.Config()
+        cfg.abi_version, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu, cfg.num_slots, cfg.num_streams, cfg.read_buffers = abi.VVR_ABI_VERSION, W, H, 1, 10, 5, 2, 1, pre
+        ctx = C.c_void_p()
+        assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+        for (w, h) in ((W, H), (64, 40)):
+            assert stub.vvr_slot_picture_size(ctx, 1, w, h) == abi.VVR_OK
+            planes = [rng.integers(0, 1024, (h >> s, w >> s)).astype(np.uint16) for s in (0, 1, 1)]
+            for c, pl in enumerate(planes):
+                assert stub.vvr_write_plane(ctx, 1, c, pl.ctypes.data, pl.shape[1]) == abi.VVR_OK
+            outs = [np.full((h >> s, (w >> s) + 7), 0xffff, np.uint16) for s in (0, 1, 1)]
+            dst = (C.c_void_p * 3)(*[o.ctypes.data for o in outs]); strides = (C.c_size_t * 3)(*[o.shape[1] for o in outs])
+            assert stub.vvr_read_picture(ctx, 1, dst, strides, threads) == abi.VVR_OK
+            for o, pl in zip(outs, planes):
+                assert np.array_equal(o[:, :pl.shape[1]], pl) and (o[:, pl.shape[1]:] == 0xffff).all()
+        short = (C.c_size_t * 3)(8, 8, 8)
+        assert stub.vvr_read_picture(ctx, 1, dst, short, threads) == abi.VVR_ERR_PARAMETER
+        assert stub.vvr_slot_picture_size(ctx, 1, W + 8, H) == abi.VVR_ERR_PARAMETER
+        stub.vvr_destroy(ctx)

@@ -92,7 +92,7 @@ EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "v
                     "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_picture_hash", "vvr_write_plane", "vvr_read_dmvr", "vvr_read_col_motion", "vvr_prepare", "vvr_submit_prepared",
                     "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof",
                     "vvr_inputs_done", "vvr_measure_copy_bandwidth", "vvr_host_alloc", "vvr_host_free",
-                    "vvr_stream_wait_job", "vvr_stream_wait_slot", "vvr_slot_external_event", "vvr_slot_picture_size"]
+                    "vvr_stream_wait_job", "vvr_stream_wait_slot", "vvr_slot_external_event", "vvr_slot_picture_size", "vvr_read_picture"]
 
 
 class Reconstructor:
@@ -218,6 +218,19 @@ class Reconstructor:
             self._check(self.L.vvr_read_plane(self.ctx, slot, c, a.ctypes.data, a.shape[1]))
             out.append(a)
         return out
+
+    def read_picture_into(self, slot, size, pad=0, threads=4):
+        """vvr_read_picture: the finished picture in `slot` (luma size `size`) into arrays whose rows are `pad` samples longer than the picture's
+        (a decoder's own buffers have margins); the caller has waited for the picture.  -> list of planes (views without the padding)"""
+        ncomp = 3 if self.chroma_format else 1
+        arrs = [np.full((size[1] >> (1 if c else 0), (size[0] >> (1 if c else 0)) + pad), 0xffff, np.uint16) for c in range(ncomp)]
+        dst = (C.c_void_p * 3)(*[a.ctypes.data for a in arrs] + [None] * (3 - ncomp))
+        strides = (C.c_size_t * 3)(*[a.shape[1] for a in arrs] + [0] * (3 - ncomp))
+        self.L.vvr_read_picture.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        self._check(self.L.vvr_read_picture(self.ctx, slot, dst, strides, threads))
+        for c, a in enumerate(arrs):
+            assert pad == 0 or (a[:, a.shape[1] - pad:] == 0xffff).all(), "vvr_read_picture wrote outside the picture"
+        return [a[:, :a.shape[1] - pad] if pad else a for a in arrs]
 
     def picture_hash(self, slot, method=0):
         """decoded picture hash (0 MD5, 1 CRC, 2 checksum): list of per-component digests (bytes)"""

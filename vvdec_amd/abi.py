@@ -137,7 +137,7 @@ class Picture(C.Structure):
 class Config(C.Structure):
     _fields_ = [("abi_version", u32), ("device", i32), ("max_width", u16), ("max_height", u16),
                 ("chroma_format", u8), ("bit_depth", u8), ("log2_ctu", u8), ("num_slots", u8), ("num_streams", u8), ("host_threads", u8), ("stop_after", u8), ("ring_entries", u8),
-                ("ext_planes", C.c_void_p)]
+                ("read_buffers", u8), ("pad", u8 * 7), ("ext_planes", C.c_void_p)]
 
 
 class KernelStat(C.Structure):

@@ -150,6 +150,8 @@ struct vvr_context {
   // output stage scratch (device + pinned), grown on demand
   void*      outDev = nullptr; size_t outDevCap = 0;
   void*      outHost = nullptr; size_t outHostCap = 0;
+  hipStream_t outStream = nullptr;                 // device-to-host copies of vvr_read_picture
+  std::vector<void*> stagePool;                    // pinned staging buffers of vvr_read_picture (one picture each), handed out under `mu`
   // ---- job pipeline (everything below is guarded by mu)
   std::mutex mu, commitMu;              // commitMu: one committing thread at a time (it takes mu only around its bookkeeping)
   std::condition_variable cv;
@@ -868,6 +870,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   if( ok )
   {
     c->slotDim.assign( cfg->num_slots, std::make_pair( cfg->max_width, cfg->max_height ) );
+    for( int k = 0; k < std::min<int>( cfg->read_buffers, 8 ) && ok; k++ ) { void* p = nullptr; ok = hipHostMalloc( &p, c->slotBytes, hipHostMallocDefault ) == hipSuccess; if( ok ) c->stagePool.push_back( p ); }
     for( int s = 0; s < cfg->num_slots; s++ ) c->slots.push_back( carve( (char*) c->planeMem + c->slotBytes * s, cfg, c->stride, c->planeBytes ) );
     for( int s = 0; s < nl; s++ )
     {
@@ -949,6 +952,8 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( c->scratchMem ) hipFree( c->scratchMem );
   if( c->outDev ) hipFree( c->outDev );
   if( c->outHost ) hipHostFree( c->outHost );
+  for( void* p : c->stagePool ) hipHostFree( p );
+  if( c->outStream ) hipStreamDestroy( c->outStream );
   for( auto p : c->syncBuf ) hipFree( p );
   if( c->inlineScratch ) vvr_scratch_destroy( c->inlineScratch );
   for( auto& e : c->pinned.r ) hipHostFree( (void*) e.first );
