@@ -751,23 +751,32 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
       const int x = i & ( w - 1 ), y = ( i >> lw ) << 1;
       part += iabs( sh.bil[0][( 2 + y ) * 20 + 2 + x] - sh.bil[1][( 2 + y ) * 20 + 2 + x] );
     }
-    for( int o = 32; o; o >>= 1 ) part += __shfl_xor( part, o );       // NT == 64: one wavefront
+    for( int o = 32; o; o >>= 1 ) part += __shfl_xor( part, o );
+    if constexpr( NT > 64 )
+    {   // (several wavefronts: their sums meet in LDS)
+      if( tid == 0 ) sh.minCost = 0;
+      __syncthreads();
+      if( ( tid & 63 ) == 0 ) atomicAdd( &sh.minCost, part );
+      __syncthreads();
+      part = sh.minCost;
+    }
     unsigned minCost = (unsigned) part << 1;                               // xGetSAD: uiSum <<= subShift
     minCost >>= 1; minCost -= minCost >> 2;
     const bool search = !( minCost < (unsigned) ( w * h ) );
     if( search )
     {
-      // two lanes per candidate: rows 0,4,8,.. and 2,6,10,..
-      const int cand = tid >> 1, half = tid & 1;
+      // LPC lanes per candidate (2 with one wavefront, 8 with four): each takes every LPC-th of the even rows
+      constexpr int LPC = NT / 32;
+      const int cand = tid / LPC, half = tid % LPC;
       unsigned sad = 0;
       if( cand < 25 && cand != 12 )
       {
         const int ver = cand / 5 - 2, hor = cand - ( cand / 5 ) * 5 - 2;
         const pel_t* a = &sh.bil[0][( 2 + ver ) * 20 + 2 + hor];
         const pel_t* b = &sh.bil[1][( 2 - ver ) * 20 + 2 - hor];
-        for( int y = half * 2; y < h; y += 4 ) for( int x = 0; x < w; x++ ) sad += (unsigned) iabs( a[y * 20 + x] - b[y * 20 + x] );
+        for( int y = half * 2; y < h; y += 2 * LPC ) for( int x = 0; x < w; x++ ) sad += (unsigned) iabs( a[y * 20 + x] - b[y * 20 + x] );
       }
-      sad += __shfl_xor( sad, 1 );
+      for( int o = 1; o < LPC; o <<= 1 ) sad += __shfl_xor( sad, o );
       if( cand < 25 && !half ) sh.sad[cand] = cand == 12 ? minCost : ( ( sad << 1 ) >> 1 );      // X5: ( SAD << subShift ) >> 1
     }
     __syncthreads();
@@ -1500,7 +1509,9 @@ void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, Dev
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut )
 {
   if( !numItems ) return;
-  hipLaunchKernelGGL( k_mc_dmvr<64>, dim3( numItems ), dim3( 64 ), 0, s, pic, refs, reco, items, numItems, dmvrOut );
+  // two wavefronts per sub-block: 52.5 us per 4K B picture alone against 59.8 with one and 58.3 with four (the search's serial decisions and the
+  // barriers between the stages weigh more with four; profiles/round3_lanes_and_host_threads.txt)
+  hipLaunchKernelGGL( k_mc_dmvr<128>, dim3( numItems ), dim3( 128 ), 0, s, pic, refs, reco, items, numItems, dmvrOut );
 }
 
 // =====================================================================================================================
