@@ -23,7 +23,28 @@ struct ItemH { uint32_t ctu; BBox bb; uint32_t p0, pn; };
 // each other (a whole CTU in an intra picture, a few blocks around an isolated intra CU in a B picture); one workgroup processes one unit,
 // its blocks in coding order.  Units depend on exactly those other units that produced a sample they read (inter samples are final before
 // the stage starts).
-struct UnitH { uint32_t comp, ctu, i0, i1, iA = 0; bool hasCs = false; BBox bb; std::vector<uint32_t> deps; bool waited = false; int rank = 0; };
+// the units a unit waits for: a handful (the neighbouring CTUs' units, the luma unit of the CTU), kept in the record itself - a heap block per unit
+// and picture was 1500 allocations per picture; the rare longer list moves to the heap
+struct DepList
+{
+  enum { INLINE = 8 };
+  uint32_t n = 0, cap = INLINE; uint32_t in[INLINE]; uint32_t* heap = nullptr;
+  DepList() {}
+  DepList( const DepList& o ) { *this = o; }
+  DepList( DepList&& o ) noexcept { n = o.n; cap = o.cap; heap = o.heap; memcpy( in, o.in, sizeof( in ) ); o.heap = nullptr; o.n = 0; o.cap = INLINE; }
+  DepList& operator=( const DepList& o ) { if( this != &o ) { n = 0; for( uint32_t v : o ) push_back( v ); } return *this; }
+  DepList& operator=( DepList&& o ) noexcept { if( this != &o ) { delete[] heap; n = o.n; cap = o.cap; heap = o.heap; memcpy( in, o.in, sizeof( in ) ); o.heap = nullptr; o.n = 0; o.cap = INLINE; } return *this; }
+  ~DepList() { delete[] heap; }
+  uint32_t* data() { return heap ? heap : in; } const uint32_t* data() const { return heap ? heap : in; }
+  uint32_t* begin() { return data(); } uint32_t* end() { return data() + n; } const uint32_t* begin() const { return data(); } const uint32_t* end() const { return data() + n; }
+  size_t size() const { return n; } bool empty() const { return n == 0; }
+  uint32_t& operator[]( size_t i ) { return data()[i]; } const uint32_t& operator[]( size_t i ) const { return data()[i]; }
+  void push_back( uint32_t v ) { if( n == cap ) { uint32_t* h = new uint32_t[2 * cap]; memcpy( h, data(), sizeof( uint32_t ) * n ); delete[] heap; heap = h; cap *= 2; } data()[n++] = v; }
+  void resize( size_t k ) { n = (uint32_t) std::min<size_t>( k, n ); }                                   // (only ever shortened)
+  void assign( const uint32_t* a, const uint32_t* b ) { n = 0; for( ; a != b; a++ ) push_back( *a ); }
+  void clear() { n = 0; }
+};
+struct UnitH { uint32_t comp, ctu, i0, i1, iA = 0; bool hasCs = false; BBox bb; DepList deps; bool waited = false; int rank = 0; };
 
 struct Part { const void* src; size_t n, off; bool direct; };
 
