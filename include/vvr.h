@@ -497,8 +497,8 @@ VVR_API int          vvr_read_dmvr(vvr_context* ctx, int job, int32_t* dst, size
 VVR_API int          vvr_read_col_motion(vvr_context* ctx, int job, vvr_motion* dst, size_t num_entries);
 /* Two-step submission, for measurements of the device pipeline alone (bench.py's device_only_fps) and for pictures that are reconstructed more
  * than once: vvr_prepare validates the description, runs the host glue (builds the device work lists the reference iterates over in
- * DecCu::TaskTrafoCtu / TaskInterCtu, DecCu.cpp:106-134) and makes everything resident in HBM - it allocates device and pinned memory of the
- * picture's size and copies with a blocking call, i.e. it is a set-up call, not part of a pipeline; vvr_submit_prepared only enqueues kernels.
+ * DecCu::TaskTrafoCtu / TaskInterCtu, DecCu.cpp:106-134) and makes everything resident in HBM - it allocates device memory of the picture's
+ * size and copies through pinned staging of the context with a blocking call, i.e. it is a set-up call, not part of a pipeline; vvr_submit_prepared only enqueues kernels.
  * A host that streams pictures uses vvr_submit with vvr_config.host_threads > 0: the same steps on the library's worker threads and upload ring,
  * without an allocation per picture. */
 typedef struct vvr_prepared vvr_prepared;

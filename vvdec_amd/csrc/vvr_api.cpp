@@ -151,6 +151,7 @@ struct vvr_context {
   void*      outDev = nullptr; size_t outDevCap = 0;
   void*      outHost = nullptr; size_t outHostCap = 0;
   hipStream_t outStream = nullptr;                 // device-to-host copies of vvr_read_picture
+  char*      prepStage = nullptr; size_t prepStageCap = 0;      // pinned staging of vvr_prepare
   std::vector<void*> stagePool;                    // pinned staging buffers of vvr_read_picture (one picture each), handed out under `mu`
   // ---- job pipeline (everything below is guarded by mu)
   std::mutex mu, commitMu;              // commitMu: one committing thread at a time (it takes mu only around its bookkeeping)
@@ -953,6 +954,7 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( c->outDev ) hipFree( c->outDev );
   if( c->outHost ) hipHostFree( c->outHost );
   for( void* p : c->stagePool ) hipHostFree( p );
+  if( c->prepStage ) hipHostFree( c->prepStage );
   if( c->outStream ) hipStreamDestroy( c->outStream );
   for( auto p : c->syncBuf ) hipFree( p );
   if( c->inlineScratch ) vvr_scratch_destroy( c->inlineScratch );
@@ -1123,8 +1125,16 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   if( rc != VVR_OK ) { std::lock_guard<std::mutex> lk( c->mu ); c->setError( err ); return rc; }
   vvr_prepared* q = new vvr_prepared();
   q->owner = c;
-  char* staging = nullptr;
-  if( hipMalloc( &q->blob, total ) != hipSuccess || hipHostMalloc( (void**) &staging, total, hipHostMallocDefault ) != hipSuccess )
+  // (pinned staging of the context, grown when a picture needs more: vvr_prepare comes from the one submitting thread)
+  if( total > c->prepStageCap )
+  {
+    if( c->prepStage ) hipHostFree( c->prepStage );
+    c->prepStage = nullptr; c->prepStageCap = 0;
+    const size_t want = alignUp( total + total / 4, 1 << 16 );
+    if( hipHostMalloc( (void**) &c->prepStage, want, hipHostMallocDefault ) == hipSuccess ) c->prepStageCap = want;
+  }
+  char* staging = c->prepStage;
+  if( !staging || hipMalloc( &q->blob, total ) != hipSuccess )
   { vvr_free_prepared( c, q ); c->setError( "vvr_prepare: out of device or pinned memory" ); return VVR_ERR_DEVICE; }
   q->blobBytes = total;
   vvr_host_pack( S, staging );
@@ -1132,7 +1142,6 @@ VVR_API int vvr_prepare( vvr_context* c, const vvr_picture* p, vvr_prepared** ou
   std::vector<DirectCopy> none; size_t b0 = 0, b1 = 0;
   vvr_host_upload_plan( S, none, &b0, &b1 );
   const hipError_t e = hipMemcpy( q->blob, staging, b1, hipMemcpyHostToDevice );
-  hipHostFree( staging );
   if( e == hipSuccess && ( p->hdr.tool_flags & VVR_TOOL_COL_MOTION ) )
   {
     q->numCol = vvr_host_num_col( p );
