@@ -564,3 +564,18 @@ def test_oracle_equals_reference_scaled_reference_pictures(built, W, H, l2, idx,
         other = refdrv.oracle_reconstruct(d, refs, flags=0)
         d.rpr = keep
         assert any(not np.array_equal(a, b) for a, b in zip(other, want))
+
+
+def test_random_scaled_reference_pictures_fixed_seed_slice(built):
+    """a fixed-seed slice of tools/fuzz_rpr.py (random sizes, ratios from 1/8 to 2 incl. the filter-set thresholds, windows with negative offsets, sample
+    formats, large MVs): oracle == reference"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_rpr", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_rpr.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    n = 0
+    for it, (d, refs), l2 in fz.cases(3, 8):
+        want = refdrv.reconstruct(d, refs)["planes"]
+        got = refdrv.oracle_reconstruct(d, refs)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), "case %d" % it
+        n += 1
+    assert n >= 5
