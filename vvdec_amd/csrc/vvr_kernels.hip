@@ -1203,8 +1203,11 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
 //   The reference filters column by column into a buffer and row by row out of it; a sample is
 //     sum_t fV[yFrac(row)][t] * (int16) ( ( sum_s fH[xFrac(col)][s] * ref( xInt(col) - (N/2-1) + s, yInt(row) - (N/2-1) + t ) + offset1 ) >> shift1 )
 //   with clamped reads (= its border-extended picture; the rows it replicates below the margin, :2188-2196, are rows of the margin).
-// This is a conformance path, not a fast one: one workgroup per <= 16x16 tile, one work item per sample, each evaluating its sample straight from
-// the reference plane.  The other list of such a CU may be an ordinary reference picture: its prediction is the regular arithmetic
+// One workgroup of 256 per <= 16x16 tile.  Plain, SbTMVP and GPM tiles: the source window of the tile in the scaled picture (its extent follows from
+// the ratio: at most 39 x 39 luma samples at 2x) is staged in LDS with clamped coordinates, a horizontal pass leaves one 16-bit row of intermediates
+// per window row, the vertical pass picks its rows with every output row's own offset and phase (rpr_tile).  Affine tiles - a block of its own per
+// 4x4 sub-block - are evaluated sample by sample straight from the reference plane (rpr_sample): rare among the rare.
+// The other list of such a CU may be an ordinary reference picture: its prediction is the regular arithmetic
 // (xPredInterBlk in the separable 2-D form, which the 1-D and copy cases equal number for number: phase 0 of the regular filters is { .., 64, .. }
 // and the roundings nest), with PROF where the reference applies it to that list of an affine CU.  Plain, SbTMVP, GPM, CIIP (inter part) and affine
 // tiles; the combination (rounding, average, BCW, explicit weights, GPM blend) is the one of k_mc / k_mc_affine.
@@ -1216,21 +1219,20 @@ __device__ __forceinline__ const int16_t* rpr_taps( int comp, int filter, int fr
   if( filter == 0 ) return ( frac == 8 && altHpel ) ? d_luma_alt_hpel : d_luma_filter[frac];
   return filter == 2 ? d_luma_filter_4x4[frac] : filter == 3 ? d_luma_filter_rpr1[frac] : filter == 4 ? d_luma_filter_rpr2[frac] : filter == 5 ? d_affine_luma_filter_rpr1[frac] : d_affine_luma_filter_rpr2[frac];
 }
-// sample (col, row) of the block with origin (bx, by) (component samples) predicted from the scaled picture `ref` (rw x rh component samples):
-// 14-bit intermediate (bi) or rounded and clipped.  filterIndex: 0 regular CU, 2 affine sub-block.
-__device__ int rpr_sample( const pel_t* __restrict__ ref, int stride, const vvr_rpr_ref& rr, int winL, int winT, int comp, int bx, int by, int col, int row,
-                           int mvx, int mvy, bool bi, bool altHpel, int filterIndex, int bd )
+// what a block predicted from a scaled picture shares: filter sets, the position of its first sample in the reference picture (1/1024 sample), the steps
+struct RprGeo { int xFilter, yFilter, stepX, stepY, x0, y0, rw, rh; };
+__device__ __forceinline__ RprGeo rpr_geometry( const vvr_rpr_ref& rr, int winL, int winT, int comp, int bx, int by, int mvx, int mvy, int filterIndex )
 {
-  const int cs = comp ? 1 : 0, shiftHor = 4 + cs;
+  RprGeo g;
+  const int cs = comp ? 1 : 0;
   const int thr1 = MC_RPR_ONE * 5 / 4, thr2 = MC_RPR_ONE * 7 / 4;
   const int rx = rr.ratio[0], ry = rr.ratio[1];
-  int xFilter = filterIndex, yFilter = filterIndex;
-  if( rx > thr2 ) xFilter = 4; else if( rx > thr1 ) xFilter = 3;
-  if( ry > thr2 ) yFilter = 4; else if( ry > thr1 ) yFilter = 3;
-  if( !comp && filterIndex == 2 ) { if( rx > thr1 ) xFilter += 2; if( ry > thr1 ) yFilter += 2; }
+  g.xFilter = filterIndex; g.yFilter = filterIndex;
+  if( rx > thr2 ) g.xFilter = 4; else if( rx > thr1 ) g.xFilter = 3;
+  if( ry > thr2 ) g.yFilter = 4; else if( ry > thr1 ) g.yFilter = 3;
+  if( !comp && filterIndex == 2 ) { if( rx > thr1 ) g.xFilter += 2; if( ry > thr1 ) g.yFilter += 2; }
   const int posShift = 10;
-  const int stepX = ( rx + 8 ) >> 4, stepY = ( ry + 8 ) >> 4;
-  const int off = 1 << ( posShift - shiftHor - 1 );
+  g.stepX = ( rx + 8 ) >> 4; g.stepY = ( ry + 8 ) >> 4;
   const long long posX = ( ( bx << cs ) - winL ) >> cs, posY = ( ( by << cs ) - winT ) >> cs;
   const int addX = comp ? ( 1 - rr.hor_collocated_chroma ) * 8 * ( rx - MC_RPR_ONE ) : 0;
   const int addY = comp ? ( 1 - rr.ver_collocated_chroma ) * 8 * ( ry - MC_RPR_ONE ) : 0;
@@ -1238,26 +1240,103 @@ __device__ int rpr_sample( const pel_t* __restrict__ ref, int stride, const vvr_
   x0 = ( x0 >= 0 ? 1 : -1 ) * ( ( ( x0 >= 0 ? x0 : -x0 ) + ( 1ll << ( 7 + cs ) ) ) >> ( 8 + cs ) ) + (long long) rr.win_left * ( 1 << ( posShift - cs ) );
   long long y0 = ( posY * ( 1 << ( 4 + cs ) ) + mvy ) * (long long) ry + addY;
   y0 = ( y0 >= 0 ? 1 : -1 ) * ( ( ( y0 >= 0 ? y0 : -y0 ) + ( 1ll << ( 7 + cs ) ) ) >> ( 8 + cs ) ) + (long long) rr.win_top * ( 1 << ( posShift - cs ) );
+  g.x0 = (int) x0; g.y0 = (int) y0;
+  g.rw = rr.width >> cs; g.rh = rr.height >> cs;
+  return g;
+}
+// integer position and phase of column / row `i` of such a block (dir 0: columns)
+__device__ __forceinline__ void rpr_position( const RprGeo& g, int comp, int dir, int i, int& pInt, int& pFrac )
+{
+  const int posShift = 10, shiftHor = 4 + ( comp ? 1 : 0 ), off = 1 << ( posShift - shiftHor - 1 );
+  const int p = ( dir ? g.y0 + i * g.stepY : g.x0 + i * g.stepX ) + off;
+  pInt = clip3( -4, ( dir ? g.rh : g.rw ) + 4, p >> posShift );
+  pFrac = ( p >> ( posShift - shiftHor ) ) & ( ( 1 << shiftHor ) - 1 );
+}
+// sample (col, row) of the block with origin (bx, by) (component samples) predicted from the scaled picture `ref` (rw x rh component samples):
+// 14-bit intermediate (bi) or rounded and clipped.  filterIndex: 0 regular CU, 2 affine sub-block.
+__device__ int rpr_sample( const pel_t* __restrict__ ref, int stride, const vvr_rpr_ref& rr, int winL, int winT, int comp, int bx, int by, int col, int row,
+                           int mvx, int mvy, bool bi, bool altHpel, int filterIndex, int bd )
+{
+  const RprGeo g = rpr_geometry( rr, winL, winT, comp, bx, by, mvx, mvy, filterIndex );
   const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
-  const int rw = rr.width >> cs, rh = rr.height >> cs;
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
-  const int py = (int) y0 + row * stepY, px = (int) x0 + col * stepX;
-  const int yInt = clip3( -4, rh + 4, ( py + off ) >> posShift ), yFrac = ( ( py + off ) >> ( posShift - shiftHor ) ) & ( ( 1 << shiftHor ) - 1 );
-  const int xInt = clip3( -4, rw + 4, ( px + off ) >> posShift ), xFrac = ( ( px + off ) >> ( posShift - shiftHor ) ) & ( ( 1 << shiftHor ) - 1 );
-  const int16_t* cv = rpr_taps( comp, yFilter, yFrac, altHpel && ry == MC_RPR_ONE );
-  const int16_t* ch = rpr_taps( comp, xFilter, xFrac, altHpel && rx == MC_RPR_ONE );
+  int xInt, xFrac, yInt, yFrac;
+  rpr_position( g, comp, 0, col, xInt, xFrac ); rpr_position( g, comp, 1, row, yInt, yFrac );
+  const int16_t* cv = rpr_taps( comp, g.yFilter, yFrac, altHpel && rr.ratio[1] == MC_RPR_ONE );
+  const int16_t* ch = rpr_taps( comp, g.xFilter, xFrac, altHpel && rr.ratio[0] == MC_RPR_ONE );
   int sum2 = 0;
   for( int t = 0; t < ntaps; t++ )
   {
-    const pel_t* line = ref + (size_t) clip3( 0, rh - 1, yInt - half + t ) * stride;
+    const pel_t* line = ref + (size_t) clip3( 0, g.rh - 1, yInt - half + t ) * stride;
     int sum = 0;
-    for( int u = 0; u < ntaps; u++ ) sum += line[clip3( 0, rw - 1, xInt - half + u )] * ch[u];
+    for( int u = 0; u < ntaps; u++ ) sum += line[clip3( 0, g.rw - 1, xInt - half + u )] * ch[u];
     sum2 += (int16_t) ( ( sum + offset1 ) >> shift1 ) * cv[t];
   }
   if( bi ) return (int16_t) ( sum2 >> 6 );
   const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
   return clip_pel( (int16_t) ( ( sum2 + offset2 ) >> shift2 ), bd );
+}
+// The same for a whole w x h part (columns col0 .., rows row0 .. of the block) by the 256 work items of a workgroup, through LDS: the source window
+// of the part - its extent follows from the ratio, at most 39 x 39 samples for 16 x 16 at 2x - is staged once with clamped coordinates, the horizontal
+// pass writes one 16-bit row of intermediates per window row, the vertical pass reads them back with every row's own offset and phase.  out[row * w + col].
+#define RPR_WIN 40
+struct RprShared {
+  pel_t   win[RPR_WIN * RPR_WIN];
+  int16_t tmp[RPR_WIN * 16];
+  int16_t pi[2][16], pf[2][16];          // [columns, rows]: integer position, phase
+  int16_t out[2][3][16 * 16];            // [list][component]: 14-bit (or final) prediction of the tile
+};
+__device__ void rpr_tile( RprShared& sh, const pel_t* __restrict__ ref, int stride, const vvr_rpr_ref& rr, int winL, int winT, int comp, int bx, int by, int col0, int row0, int w, int h,
+                          int mvx, int mvy, bool bi, bool altHpel, int bd, int16_t* __restrict__ out )
+{
+  const int tid = threadIdx.x;
+  const RprGeo g = rpr_geometry( rr, winL, winT, comp, bx, by, mvx, mvy, 0 );
+  const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
+  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
+  const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+  if( tid < 32 )
+  {
+    const int dir = tid >> 4, i = tid & 15;
+    if( i < ( dir ? h : w ) ) { int pI, pF; rpr_position( g, comp, dir, ( dir ? row0 : col0 ) + i, pI, pF ); sh.pi[dir][i] = (int16_t) pI; sh.pf[dir][i] = (int16_t) pF; }
+  }
+  __syncthreads();
+  // (positions do not decrease with the column / row: the steps are positive and the clip is monotonous)
+  const int wx0 = sh.pi[0][0] - half, wy0 = sh.pi[1][0] - half, ww = sh.pi[0][w - 1] - sh.pi[0][0] + ntaps, wh = sh.pi[1][h - 1] - sh.pi[1][0] + ntaps;
+  if( ww > RPR_WIN || wh > RPR_WIN )
+  {   // (cannot happen with ratios of at most 2; kept for a table that says otherwise)
+    for( int i = tid; i < w * h; i += 256 ) out[i] = (int16_t) rpr_sample( ref, stride, rr, winL, winT, comp, bx, by, col0 + i % w, row0 + i / w, mvx, mvy, bi, altHpel, 0, bd );
+    __syncthreads();
+    return;
+  }
+  for( int i = tid; i < ww * wh; i += 256 )
+  {
+    const int y = i / ww, x = i - y * ww;
+    sh.win[y * RPR_WIN + x] = ref[(size_t) clip3( 0, g.rh - 1, wy0 + y ) * stride + clip3( 0, g.rw - 1, wx0 + x )];
+  }
+  __syncthreads();
+  const bool altX = altHpel && rr.ratio[0] == MC_RPR_ONE, altY = altHpel && rr.ratio[1] == MC_RPR_ONE;
+  for( int i = tid; i < wh * w; i += 256 )
+  {
+    const int y = i / w, col = i - y * w;
+    const int16_t* ch = rpr_taps( comp, g.xFilter, sh.pf[0][col], altX );
+    const pel_t* src = &sh.win[y * RPR_WIN + sh.pi[0][col] - sh.pi[0][0]];
+    int sum = 0;
+    for( int u = 0; u < ntaps; u++ ) sum += src[u] * ch[u];
+    sh.tmp[y * 16 + col] = (int16_t) ( ( sum + offset1 ) >> shift1 );
+  }
+  __syncthreads();
+  const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
+  for( int i = tid; i < w * h; i += 256 )
+  {
+    const int row = i / w, col = i - row * w;
+    const int16_t* cv = rpr_taps( comp, g.yFilter, sh.pf[1][row], altY );
+    const int16_t* src = &sh.tmp[( sh.pi[1][row] - sh.pi[1][0] ) * 16 + col];
+    int sum2 = 0;
+    for( int t = 0; t < ntaps; t++ ) sum2 += src[t * 16] * cv[t];
+    out[i] = bi ? (int16_t) ( sum2 >> 6 ) : (int16_t) clip_pel( (int16_t) ( ( sum2 + offset2 ) >> shift2 ), bd );
+  }
+  __syncthreads();
 }
 // the sample at (px, py) of the component plane predicted with the (clipped) MV from an ordinary reference picture of the current picture's size
 __device__ int reg_sample( const pel_t* __restrict__ ref, int stride, int pw, int ph, int comp, int px, int py, int mvx, int mvy, bool bi, bool altHpel, bool sixTap, int bd )
@@ -1301,6 +1380,7 @@ __device__ int aff_prof_sample( const pel_t* __restrict__ ref, int stride, int p
 
 __global__ __launch_bounds__( 256 ) void k_mc_rpr( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems )
 {
+  __shared__ RprShared sh;
   const int item = blockIdx.x;
   if( item >= numItems ) return;
   const McItem it = items[item];
@@ -1334,6 +1414,28 @@ __global__ __launch_bounds__( 256 ) void k_mc_rpr( PicDev pic, RefSet refs, DevP
   const int verMax = ( pic.hdr.height + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - cu.y + 1 ) * 16;
   const int wL = it.w, hL = it.h, wC = wL >> 1, hC = hL >> 1;
   const int total = wL * hL + ( ncomp == 3 ? 2 * wC * hC : 0 );
+  // plain, SbTMVP and GPM tiles: the prediction of every (list, component) first - from a scaled picture through LDS (rpr_tile), from an ordinary one
+  // sample by sample -, combined below; affine tiles (a block of their own per 4x4 sub-block) are evaluated sample by sample in the loop below
+  if( !aff )
+  {
+    for( int k = 0; k < nl; k++ )
+    {
+      const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
+      const int ri = geo ? ( cu.geo_dir_ref[k] & 15 ) : mRef[l];
+      const vvr_rpr_ref& rr = R.ref[l][ri];
+      const bool bi = hi || geo;
+      int mvx = geo ? cu.geo_mv[k][0] : it.mv[l][0], mvy = geo ? cu.geo_mv[k][1] : it.mv[l][1];
+      if( !rr.scaled ) { const McBounds B = { 0, 0, (int) pic.hdr.width - 1, (int) pic.hdr.height - 1 }; mc_clip_mv( pic, B, it.clipX, it.clipY, mvx, mvy ); }
+      for( int c = 0; c < ncomp; c++ )
+      {
+        const int cs = c ? 1 : 0, cw = wL >> cs, chh = hL >> cs;
+        const pel_t* __restrict__ plane = refs.p[l * VVR_MAX_REFS + ri][c];
+        if( rr.scaled ) rpr_tile( sh, plane, reco.stride[c], rr, R.win_left, R.win_top, c, it.clipX >> cs, it.clipY >> cs, ( it.x - it.clipX ) >> cs, ( it.y - it.clipY ) >> cs, cw, chh, mvx, mvy, bi, altHpel, bd, sh.out[k][c] );
+        else for( int i = threadIdx.x; i < cw * chh; i += 256 ) sh.out[k][c][i] = (int16_t) reg_sample( plane, reco.stride[c], reco.w[c], reco.h[c], c, ( it.x >> cs ) + i % cw, ( it.y >> cs ) + i / cw, mvx, mvy, bi, altHpel, false, bd );
+      }
+    }
+    __syncthreads();
+  }
   for( int sidx = threadIdx.x; sidx < total; sidx += 256 )
   {
     int c, x, y;
@@ -1349,17 +1451,7 @@ __global__ __launch_bounds__( 256 ) void k_mc_rpr( PicDev pic, RefSet refs, DevP
       const vvr_rpr_ref& rr = R.ref[l][ri];
       const pel_t* __restrict__ plane = refs.p[l * VVR_MAX_REFS + ri][c];
       const bool bi = hi || geo;
-      if( !aff )
-      {
-        int mvx = geo ? cu.geo_mv[k][0] : it.mv[l][0], mvy = geo ? cu.geo_mv[k][1] : it.mv[l][1];
-        if( rr.scaled ) p[k] = rpr_sample( plane, reco.stride[c], rr, R.win_left, R.win_top, c, it.clipX >> cs, it.clipY >> cs, ax - ( it.clipX >> cs ), ay - ( it.clipY >> cs ), mvx, mvy, bi, altHpel, 0, bd );
-        else
-        {
-          const McBounds B = { 0, 0, (int) pic.hdr.width - 1, (int) pic.hdr.height - 1 };
-          mc_clip_mv( pic, B, it.clipX, it.clipY, mvx, mvy );
-          p[k] = reg_sample( plane, reco.stride[c], reco.w[c], reco.h[c], c, ax, ay, mvx, mvy, bi, altHpel, false, bd );
-        }
-      }
+      if( !aff ) p[k] = sh.out[k][c][y * ( c ? wC : wL ) + x];
       else
       {
         // the MV of the 4x4 sub-block (luma), or of the 4x4 chroma block from the luma sub-blocks (0,0) and (1,1) of its 2x2 group (:1156-1176)
