@@ -142,7 +142,6 @@ struct vvr_context {
   std::vector<DevPlanes>   scratchR;    // per stream: residual planes (intra)
   void*      planeMem = nullptr; bool planeMemOwned = false;
   void*      scratchMem = nullptr;
-  std::vector<std::deque<int>> laneJobs;      // per round-robin lane: the pictures committed to it that may still be on the device (planCommitLocked)
   std::deque<std::function<void( PrepScratch& )>> subtasks;      // parts of a picture's host stage that any worker may run (an I picture is prepared by all of them together); guarded by mu, served before `queue`
   std::vector<int*> syncBuf;            // per stream: ticket + one flag per unit of the intra stage
   std::vector<size_t> syncCap;          // ints allocated in syncBuf[lane]; grown when a picture has more units
@@ -275,26 +274,7 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
     if( !idle && it->second->state == J_COMMITTED && it->second->done ) idle = hipEventQuery( it->second->done ) == hipSuccess;
     if( idle ) { lane = c->prioLane; c->prioJob = job.id; }
   }
-  if( lane < 0 )
-  {
-    // the lane with the fewest pictures still on the device, starting the count at the one whose turn it is (all equal: round robin).  Plain round robin
-    // puts a picture behind one that is still waiting for its reference pictures while another lane has run dry (device only, K = 20: 2080 -> 2150 frames/s).
-    int best = c->nextStream; size_t bestN = ~(size_t) 0;
-    for( int k = 0; k < c->numLanesRR; k++ )
-    {
-      const int L = ( c->nextStream + k ) % c->numLanesRR;
-      std::deque<int>& q = c->laneJobs[L];
-      while( !q.empty() )
-      {
-        auto it = c->jobs.find( q.front() );
-        if( it != c->jobs.end() && !it->second->completed && !( it->second->state == J_COMMITTED && it->second->done && hipEventQuery( it->second->done ) == hipSuccess ) && it->second->state != J_FAILED ) break;
-        q.pop_front();
-      }
-      if( q.size() < bestN ) { bestN = q.size(); best = L; }
-    }
-    lane = best; c->nextStream = ( lane + 1 ) % c->numLanesRR;
-    c->laneJobs[lane].push_back( job.id );
-  }
+  if( lane < 0 ) { lane = c->nextStream; c->nextStream = ( c->nextStream + 1 ) % c->numLanesRR; }
   plan.lane = lane; plan.waits.clear(); plan.waitInfo.clear();
   job.lane = lane;
   // a lane's scratch planes are reused: the previous job of this lane is ordered before us by the stream itself
@@ -870,7 +850,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   // lanes: num_streams of them taken in turn, plus - whenever there are at least two - one with a high-priority stream for I pictures, see planCommitLocked
   // (also without worker threads: vvr_submit_prepared and inline submission order pictures the same way)
   const int nl = ns + ( ns >= 2 ? 1 : 0 );
-  c->numLanesRR = ns; c->prioLane = nl > ns ? ns : -1; c->laneJobs.assign( ns, std::deque<int>() );
+  c->numLanesRR = ns; c->prioLane = nl > ns ? ns : -1;
   c->streams.resize( nl, nullptr );
   bool ok = true;
   for( int i = 0; i < ns && ok; i++ ) ok = hipStreamCreateWithFlags( &c->streams[i], hipStreamNonBlocking ) == hipSuccess;
