@@ -515,7 +515,9 @@ VVR_API void*        vvr_job_stream(vvr_context* ctx, int job);
  *   vvr_slot_external_event  pictures submitted from now on that use `slot` wait for `event` (hipEvent_t, recorded by the caller behind its
  *                         collective) first; writes != 0: the external work wrote the slot (earlier users were ordered before it by
  *                         vvr_stream_wait_slot), 0: it only reads it (a sender: later pictures must not overwrite the slot under it).  The
- *                         caller keeps the event alive until those pictures are done.
+ *                         back-end keeps the handle until the slot is next written or until it finds the event complete (it looks when a
+ *                         picture that uses the slot is handed to the device, in vvr_stream_wait_slot and in vvr_sync): the caller keeps the
+ *                         event alive until it is complete AND a vvr_sync has returned since (or the slot has been overwritten).
  * A picture can only be waited for once it has been handed to the device (its work lists are built by worker threads): blocking = 0 returns
  * VVR_NOT_READY instead of waiting for that on the host.                                                                                      */
 VVR_API int          vvr_stream_wait_job(vvr_context* ctx, int job, void* stream, int blocking);

@@ -11,7 +11,9 @@
 // trace of the stream / event operations the host glue issues: { op (0 wait, 1 record), stream number, event number }, numbers in creation order
 static std::vector<int> g_trace;
 struct StubStream { int id; };
-struct StubEvent { int id; };
+struct StubEvent { int id; int dead; };      // (events are never given back to the allocator: a use after hipEventDestroy is counted, not undefined)
+static int g_deadEventUses = 0;
+static StubEvent* live( hipEvent_t e ) { StubEvent* p = (StubEvent*) e; if( p->dead ) g_deadEventUses++; return p; }
 static int g_numStreams = 0, g_numEvents = 0;
 
 extern "C" {
@@ -31,16 +33,16 @@ hipError_t hipStreamCreateWithFlags( hipStream_t* s, unsigned int ) { StubStream
 hipError_t hipStreamCreateWithPriority( hipStream_t* s, unsigned int f, int ) { return hipStreamCreateWithFlags( s, f ); }
 hipError_t hipDeviceGetStreamPriorityRange( int* least, int* greatest ) { *least = 0; *greatest = -1; return hipSuccess; }
 static int g_eventsPending = 0;                                      // tests: pretend nothing enqueued has finished yet
-hipError_t hipEventQuery( hipEvent_t ) { return g_eventsPending ? hipErrorNotReady : hipSuccess; }       // (by default the stand-in device has finished everything it was given)
+hipError_t hipEventQuery( hipEvent_t e ) { live( e ); return g_eventsPending ? hipErrorNotReady : hipSuccess; }       // (by default the stand-in device has finished everything it was given)
 hipError_t hipStreamDestroy( hipStream_t s ) { free( s ); return hipSuccess; }
 hipError_t hipStreamSynchronize( hipStream_t ) { return hipSuccess; }
-hipError_t hipStreamWaitEvent( hipStream_t s, hipEvent_t e, unsigned int ) { g_trace.push_back( 0 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( ( (StubEvent*) e )->id ); return hipSuccess; }
+hipError_t hipStreamWaitEvent( hipStream_t s, hipEvent_t e, unsigned int ) { g_trace.push_back( 0 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( live( e )->id ); return hipSuccess; }
 hipError_t hipEventCreate( hipEvent_t* e ) { StubEvent* p = (StubEvent*) calloc( 1, sizeof( StubEvent ) ); p->id = g_numEvents++; *e = (hipEvent_t) p; return hipSuccess; }
 hipError_t hipEventCreateWithFlags( hipEvent_t* e, unsigned ) { return hipEventCreate( e ); }
-hipError_t hipEventDestroy( hipEvent_t e ) { free( e ); return hipSuccess; }
-hipError_t hipEventRecord( hipEvent_t e, hipStream_t s ) { g_trace.push_back( 1 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( ( (StubEvent*) e )->id ); return hipSuccess; }
+hipError_t hipEventDestroy( hipEvent_t e ) { live( e )->dead = 1; return hipSuccess; }
+hipError_t hipEventRecord( hipEvent_t e, hipStream_t s ) { g_trace.push_back( 1 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( live( e )->id ); return hipSuccess; }
 static int g_delayUs = 0;      // vvt_set_delay: calls that block on a real device take this long here (stress tests of the host pipeline)
-hipError_t hipEventSynchronize( hipEvent_t ) { if( g_delayUs ) usleep( g_delayUs ); return hipSuccess; }
+hipError_t hipEventSynchronize( hipEvent_t e ) { live( e ); if( g_delayUs ) usleep( g_delayUs ); return hipSuccess; }
 hipError_t hipEventElapsedTime( float* ms, hipEvent_t, hipEvent_t ) { *ms = 0.f; return hipSuccess; }
 hipError_t hipGetLastError( void ) { return hipSuccess; }
 const char* hipGetErrorString( hipError_t ) { return "host stub"; }
@@ -169,6 +171,7 @@ __attribute__(( visibility( "default" ) )) void vvt_set_delay( int us ) { g_dela
 __attribute__(( visibility( "default" ) )) void vvt_slow_i_pictures( int us ) { g_vvtSlowIUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_slow_b_pictures( int us ) { g_vvtSlowBUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_events_pending( int on ) { g_eventsPending = on; }
+__attribute__(( visibility( "default" ) )) int vvt_dead_event_uses( void ) { return g_deadEventUses; }      // uses of an event after hipEventDestroy since the library was loaded
 __attribute__(( visibility( "default" ) )) unsigned long long vvt_overtakes( vvr_context* c ) { return c->overtakes; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }
 // the stage's launches of a prepared picture: number of luma units that go first when the picture has residual-add blocks (else 0), workgroups of both launches

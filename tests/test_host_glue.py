@@ -188,15 +188,18 @@ def _check_tables(d, units, items):
         icomp = int(it["comp"]) & 3
         cs = 1 if icomp else 0
         x0, y0, ww, hh = int(it["x"]) << cs, int(it["y"]) << cs, (1 << int(it["lw"])) << cs, (1 << int(it["lh"])) << cs
-        # a block of more than 1024 samples comes as 2 or 4 items, one band of rows each (one wavefront per band)
-        part, lparts = (int(it["nTL"]) >> 4) & 3, int(it["nTL"]) >> 6
-        assert part < (1 << lparts) and (lparts == 0 or (icomp == 0 and ((ww * hh) >> lparts) == 1024))
-        assert ((ww * hh) >> (2 * cs)) >> lparts <= 1024 or int(it["mode"]) >= 254 or (int(it["flags"]) & 8), "an ordinary block of more than 1024 samples in one item"
+        # a block of more than 256 samples (ordinary prediction modes) comes as 2, 4 or 8 items, one band of rows each (one wavefront per band)
+        part, lparts = (int(it["nTL"]) >> 1) & 7, (int(it["nTL"]) >> 4) & 3
+        samples = (ww * hh) >> (2 * cs)
+        assert part < (1 << lparts) and (lparts == 0 or (samples >> lparts) == 256 or (lparts == 3 and (samples >> lparts) > 256))
+        ordinary = int(it["mode"]) <= 66 and (icomp or ((int(it["flags"]) & 8) == 0 and (int(it["flags"]) & 6) != 6))
+        assert (samples >> lparts) <= 512 or not ordinary, "an ordinary block of more than 512 samples in one item"
+        assert lparts or samples <= 256 or not ordinary, "an ordinary block of more than 256 samples that is not split"
         if lparts:
-            assert i - part >= 0 and all(int(items[i - part + e]["x"]) == int(it["x"]) and int(items[i - part + e]["y"]) == int(it["y"]) and ((int(items[i - part + e]["nTL"]) >> 4) & 3) == e for e in range(1 << lparts)), "the bands of a block are consecutive items"
+            assert i - part >= 0 and all(int(items[i - part + e]["x"]) == int(it["x"]) and int(items[i - part + e]["y"]) == int(it["y"]) and ((int(items[i - part + e]["nTL"]) >> 1) & 7) == e for e in range(1 << lparts)), "the bands of a block are consecutive items"
             assert unit_of[i - part] == unit_of[i - part + (1 << lparts) - 1]
             # a band reads what the whole block reads and nothing of the bands before it
-            assert (int(it["comp"]) >> 2) == (int(items[i - part]["comp"]) >> 2) + part
+            assert (int(it["comp"]) >> 2) == min(63, (int(items[i - part]["comp"]) >> 2) + part)
             y0 += part * (hh >> lparts)
             hh >>= lparts
         sub = prod[icomp, y0 >> 2:(y0 + hh + 3) >> 2, x0 >> 2:(x0 + ww + 3) >> 2]
@@ -410,11 +413,21 @@ def test_external_slot_users_are_ordered_on_the_device(stub):
     ev = C.c_void_p()
     stub.hipEventCreate(C.byref(ev))
     stub.hipEventRecord(ev, ext)
+    stub.vvt_events_pending(1)                              # (the receive is still running: an external event that is complete would be dropped instead of waited for)
     assert stub.vvr_slot_external_event(ctx, slot, ev, 1) == abi.VVR_OK
     # picture 2 predicts from that slot: its lane waits for the external event before anything of it runs
     assert plans[2].ref_slots and slot in [s for lst in plans[2].ref_slots for (s, _) in lst]
     j2 = stub.vvr_submit(ctx, C.byref(pics[2]))
-    assert j2 >= 0 and stub.vvr_sync(ctx) == abi.VVR_OK
+    assert j2 >= 0 and stub.vvr_stream_wait_job(ctx, j2, ext, 1) == abi.VVR_OK      # (handed to the device)
+    stub.vvt_events_pending(0)
+    assert stub.vvr_sync(ctx) == abi.VVR_OK
+    # the event is complete and the back-end has been through vvr_sync: it holds the handle no longer, the caller may destroy it
+    dead0 = stub.vvt_dead_event_uses()
+    stub.hipEventDestroy(ev)
+    j1 = stub.vvr_submit(ctx, C.byref(pics[1]))             # writes the slot, then a picture that reads it again
+    assert j1 >= 0 and stub.vvr_sync(ctx) == abi.VVR_OK
+    assert stub.vvr_stream_wait_slot(ctx, slot, ext, 1) == abi.VVR_OK
+    assert stub.vvt_dead_event_uses() == dead0, "the back-end used an external event after it was complete and vvr_sync had returned"
     n = stub.vvt_take_trace(scratch, len(scratch))
     ops = [(scratch[3 * k], scratch[3 * k + 1], scratch[3 * k + 2]) for k in range(n // 3)]
     waits = [(s, e) for (op, s, e) in ops if op == 0]

@@ -256,6 +256,14 @@ static void completeLocked( vvr_context* c, Job& j )
 // worker threads must be able to go on preparing pictures meanwhile.
 struct CommitPlan { int lane; std::vector<hipEvent_t> waits; RefSet refs; std::vector<int> waitInfo; };
 
+// External events of a slot (vvr_slot_external_event) that the device has passed are dropped: nothing has to wait for them any more, and the caller
+// may destroy an event once it is complete and the back-end has been through vvr_sync (vvr.h).  Called with mu held.
+static void pruneExternalEventsLocked( vvr_context* c, int slot )
+{
+  auto& v = c->slotExt[slot];
+  v.erase( std::remove_if( v.begin(), v.end(), []( hipEvent_t ev ) { return hipEventQuery( ev ) == hipSuccess; } ), v.end() );
+}
+
 static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
 {
   const vvr_pic_header& h = job.q->hdr;
@@ -281,6 +289,7 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
   // ---- dependencies: every job that read or wrote one of our slots
   auto waitFor = [&]( int id ) { auto it = c->jobs.find( id ); if( it != c->jobs.end() ) { Job& j = *it->second; if( !j.completed && j.state == J_COMMITTED && j.lane != lane ) { plan.waits.push_back( j.done ); plan.waitInfo.push_back( j.q ? ( j.id * 16 + j.q->hdr.slice_type * 4 ) : -1 ); plan.waitInfo.push_back( j.lane ); } } };
   for( int id : c->slotUsers[h.out_slot] ) waitFor( id );
+  pruneExternalEventsLocked( c, h.out_slot );
   // external work on our slots (a collective that wrote a reference slot, or still reads the slot we overwrite)
   for( hipEvent_t ev : c->slotExt[h.out_slot] ) { plan.waits.push_back( ev ); plan.waitInfo.push_back( -2 ); plan.waitInfo.push_back( -1 ); }
   memset( &plan.refs, 0, sizeof( plan.refs ) );
@@ -290,6 +299,7 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
       const int slot = h.ref_slot[l][i];
       // wait for the writer of the reference (it is the first entry since the slot was last written)
       if( !c->slotUsers[slot].empty() ) waitFor( c->slotUsers[slot][0] );
+      pruneExternalEventsLocked( c, slot );
       for( hipEvent_t ev : c->slotExt[slot] ) if( std::find( plan.waits.begin(), plan.waits.end(), ev ) == plan.waits.end() ) { plan.waits.push_back( ev ); plan.waitInfo.push_back( -2 ); plan.waitInfo.push_back( -1 ); }
       for( int k = 0; k < 3; k++ ) plan.refs.p[l * VVR_MAX_REFS + i][k] = c->slots[slot].p[k];
     }
@@ -695,7 +705,7 @@ struct WorkerHelpers : HostHelpers
     {
       std::lock_guard<std::mutex> lk( c->mu );
       for( int part = 1; part < n; part++ )
-        c->subtasks.push_back( [&st, &fn, part]( PrepScratch& R ) { fn( part, R ); { std::lock_guard<std::mutex> l2( st.mu ); st.remaining--; } st.cv.notify_all(); } );
+        c->subtasks.push_back( [&st, &fn, part]( PrepScratch& R ) { fn( part, R ); std::lock_guard<std::mutex> l2( st.mu ); st.remaining--; st.cv.notify_all(); } );      // (notified under the lock: `st` lives on the caller's stack and is gone once the caller has seen remaining == 0)
       c->cv.notify_all();
     }
     fn( 0, own );
@@ -1191,6 +1201,8 @@ VVR_API int vvr_sync( vvr_context* c )
   for( int id : ids ) { const int r = finishJob( c, id ); if( r != VVR_OK && rc == VVR_OK ) rc = r; }
   if( rc != VVR_OK ) return rc;
   for( auto s : c->streams ) HIPCHK( c, hipStreamSynchronize( s ) );
+  // external events that are complete are forgotten here (the caller may destroy them after this call, vvr.h)
+  { std::lock_guard<std::mutex> lk( c->mu ); for( int slot = 0; slot < (int) c->slotExt.size(); slot++ ) pruneExternalEventsLocked( c, slot ); }
   return VVR_OK;
 }
 
@@ -1232,6 +1244,7 @@ VVR_API int vvr_stream_wait_slot( vvr_context* c, int slot, void* stream, int bl
     Job& j = *it->second;
     if( !j.completed && j.state == J_COMMITTED && j.done ) HIPCHK( c, hipStreamWaitEvent( (hipStream_t) stream, j.done, 0 ) );
   }
+  pruneExternalEventsLocked( c, slot );
   for( hipEvent_t ev : c->slotExt[slot] ) HIPCHK( c, hipStreamWaitEvent( (hipStream_t) stream, ev, 0 ) );
   return VVR_OK;
 }

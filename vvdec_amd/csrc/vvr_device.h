@@ -69,18 +69,20 @@ struct IntraItem {        // 16 bytes, self-contained: the kernel never touches 
   uint8_t  lw, lh;        // log2 size
   uint8_t  mode;          // 0 planar, 1 DC, 2..66 angular (before the wide-angle remap)
   uint8_t  flags;         // IT_F_*
-  uint8_t  nTL;           // bit 0: top-left reference sample available; bits 4..5: row part of the block this item predicts, bits 6..7: log2( parts )
-                          // (a block of more than 1024 samples is predicted by 2 or 4 wavefronts, each a band of rows: one item per band)
+  uint8_t  nTL;           // bit 0: top-left reference sample available; bits 1..3: row part of the block this item predicts, bits 4..5: log2( parts )
+                          // (a block of more than IT_SPLIT_SAMPLES samples is predicted by 2, 4 or 8 wavefronts, each a band of rows: one item per band)
   uint8_t  nA, nL;        // available units (4 luma samples): above incl. above-right, left incl. below-left
   uint8_t  comp;          // bits 0..1: component; bits 2..7: `indep` - the block reads nothing that the `indep` blocks before it in its unit produce
                           // (it starts when every block of the unit up to index - indep - 1 is done)
   uint32_t tu;
 };
-#define IT_PART( it )    ( ( (it).nTL >> 4 ) & 3 )
-#define IT_LPARTS( it )  ( (it).nTL >> 6 )
+#define IT_PART( it )    ( ( (it).nTL >> 1 ) & 7 )
+#define IT_LPARTS( it )  ( ( (it).nTL >> 4 ) & 3 )
 #define IT_COMP( it )    ( (it).comp & 3 )
 #define IT_INDEP( it )   ( (it).comp >> 2 )
-#define IT_PART_SAMPLES 1024   /* samples one wavefront predicts at most (blocks of 2048 / 4096 samples: 2 / 4 parts) */
+#define IT_PART_SAMPLES 1024   /* samples of an item whose residual is kept in the wavefront's LDS scratch (larger items - MIP, CCLM, IBC blocks that are not split - read it from the residual plane) */
+#define IT_SPLIT_SAMPLES 256   /* ordinary prediction modes: a block of more samples becomes 2, 4 or 8 items (bands of rows), so that a wavefront predicts a band in one round of four samples per lane */
+#define IT_MAX_LPARTS 3
 
 // One unit of the intra stage (blocks of one component inside one CTU that read reference samples from each other, or a group of such
 // clusters at the same dependency depth), processed by one workgroup.

@@ -2979,8 +2979,9 @@ __device__ __forceinline__ int tile_idx( int dx, int dy )
 }
 #define IT_MAXREF ( 2 * 64 + 8 )
 
-#define IT_BATCH 64         // IntraItems staged in LDS at a time (64 x 16 B: one dword per thread)
-#define IT_WAVES 4          // wavefronts of a workgroup: each predicts one block at a time
+#define IT_BATCH 128        // IntraItems staged in LDS at a time (128 x 16 B: one dword per thread)
+#define IT_WAVES 8          // wavefronts of a workgroup: each predicts one item (a block of up to 256 samples, or a band of rows of a larger one) at a time
+#define IT_NT ( IT_WAVES * 64 )
 
 // scratch of one wavefront (one block at a time)
 #define IT_NEG 72           // entries in front of a reference line: the side reference projected onto negative indices of the main reference
@@ -3325,7 +3326,7 @@ __global__ __launch_bounds__( 256 ) void k_intra_setup( IntraPic pic, const Intr
   c[C_ORIGIN] = (uint32_t) ox | ( (uint32_t) oy << 16 );
 }
 
-__global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem* __restrict__ items, const uint32_t* __restrict__ ctx /* k_intra_setup */,
+__global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraItem* __restrict__ items, const uint32_t* __restrict__ ctx /* k_intra_setup */,
                                                   const IntraUnit* __restrict__ units, int numActive,
                                                   int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */
 #ifdef VVR_INTRA_DEV
@@ -3414,7 +3415,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
     if( ( ent >> 29 ) & 1 )
     {
       const int lx = ( cxI << pic.log2Ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.log2Ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
-      if( lx < pic.width && ly < pic.height && ( wv == 0 || csNv1 ) )
+      if( wv < 4 && lx < pic.width && ly < pic.height && ( wv == 0 || csNv1 ) )
       {
         const int f = lmcs_cscale_factor_wave( pic, lx, ly, lane );
         if( lane == 0 ) sh.csFac[wv] = f;
@@ -3594,11 +3595,11 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
             for( int r = 0; r < 4; r++ ) if( so[r] >= 0 ) *reinterpret_cast<uint4*>( &sh.tile[so[r]] ) = sv[r];
           }
         }
-        for( int base = 0; base < total; base += 256 * 4 )
+        for( int base = 0; base < total; base += IT_NT * 4 )
         {
           // four 16-byte loads in flight per lane; the tail repeats the last chunk (same data to the same place) instead of branching
           uint4 v0, v1, v2, v3; int o0, o1, o2, o3;
-#define IT_LD( V, O, U ) { const int i = min( base + U * 256 + tid, total - 1 ); int r, cidx; \
+#define IT_LD( V, O, U ) { const int i = min( base + U * IT_NT + tid, total - 1 ); int r, cidx; \
             if( i < nTop ) { r = i / nch; cidx = bc0 + ( i - r * nch ); } else { r = ( max( by0, oy ) - by0 ) + ( i - nTop ); cidx = -1; } \
             const int y = by0 + r, x = ox + cidx * 8; V = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] ); O = tile_idx( x - ox, y - oy ); }
           IT_LD( v0, o0, 0 ) IT_LD( v1, o1, 1 ) IT_LD( v2, o2, 2 ) IT_LD( v3, o3, 3 )
@@ -3613,7 +3614,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
     if( ( ent >> 29 ) & 1 )
     {
       const int lx = ( cxI << pic.log2Ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.log2Ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
-      if( lx < pic.width && ly < pic.height && ( wv == 0 || csNv1 ) )
+      if( wv < 4 && lx < pic.width && ly < pic.height && ( wv == 0 || csNv1 ) )
       {
         const int f = lmcs_cscale_factor_wave( pic, lx, ly, lane );
         if( lane == 0 ) sh.csFac[wv] = f;
@@ -4071,7 +4072,7 @@ __global__ __launch_bounds__( 256 ) void k_intra( IntraPic pic, const IntraItem*
   if( borderOnly )
   {
     const int rows = min( PH, oy + S ) - oy, nch = ( min( PW, ox + S ) - ox + 7 ) >> 3;     // a chunk past the picture edge lands in the row padding
-    for( int i = tid; i < rows * nch; i += 256 )
+    for( int i = tid; i < rows * nch; i += IT_NT )
     {
       const int r = i / nch, c = i - r * nch;
       *reinterpret_cast<uint4*>( &plane[(size_t) ( oy + r ) * pstride + ox + c * 8] ) = *reinterpret_cast<const uint4*>( &TILE( ox + c * 8, oy + r ) );
@@ -4206,7 +4207,7 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   else hipMemsetD32Async( (hipDeviceptr_t) sync, ticket0, 1, s );      // the ticket counter of the second launch starts where the first ended
   numActive = ticket1;
 #ifndef VVR_INTRA_DEV
-  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync );
+  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( IT_NT ), 0, s, ip, items, ctx, units, numActive, sync );
 #else
   static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
   static const bool tr = getenv( "VVR_INTRA_TRACE" ) != nullptr;
@@ -4214,7 +4215,7 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   const size_t nItems = 1 << 20;      // (block timeline: sized generously, indexed by item)
   if( tr ) { hipMalloc( (void**) &trace, sizeof( unsigned long long ) * 8 * (size_t) numActive ); hipMemsetAsync( trace, 0, sizeof( unsigned long long ) * 8 * (size_t) numActive, s );
              hipMalloc( (void**) &btrace, sizeof( unsigned long long ) * 8 * nItems ); hipMemsetAsync( btrace, 0, sizeof( unsigned long long ) * 8 * nItems, s ); }
-  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync, dbg, trace, btrace );
+  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( IT_NT ), 0, s, ip, items, ctx, units, numActive, sync, dbg, trace, btrace );
   if( tr )
   {
     // developer timeline: ticket, phase time stamps (100 MHz), block count / unit word, number of producers; per block four shader-clock stamps

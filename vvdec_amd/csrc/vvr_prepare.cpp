@@ -1289,10 +1289,10 @@ int PrepScratch::groupUnits()
 
 int PrepScratch::emitUnitTable( std::string& err )
 {
-  // one item array for the three components; active (component, CTU) pairs in raster order.  A block of more than IT_PART_SAMPLES samples
-  // (luma 64x64, 64x32, 32x64; ordinary prediction modes and CIIP) becomes 2 or 4 items, one band of rows each: the kernel predicts a block
-  // with one wavefront, the bands of a large block with several at once (they read the same reference samples and write disjoint rows, so
-  // band p is independent of the p items before it)
+  // one item array for the three components; active (component, CTU) pairs in raster order.  A block of more than IT_SPLIT_SAMPLES samples
+  // (ordinary prediction modes and CIIP, luma and chroma) becomes 2, 4 or 8 items, one band of rows each: the kernel predicts an item
+  // with one wavefront, the bands of a block with several at once (they read the same reference samples and write disjoint rows, so
+  // band p is independent of the p items before it) - a band of 256 samples is one round of four samples per lane
   itemMap[0].clear(); itemMap[1].clear(); itemMap[2].clear();
   for( int k = 0; k < 3; k++ )
   {
@@ -1305,12 +1305,13 @@ int PrepScratch::emitUnitTable( std::string& err )
       const uint32_t indepBlocks = std::min<uint32_t>( src.comp >> 2, (uint32_t) bi );
       const uint32_t indepItems = itemMap[k][bi] - itemMap[k][bi - indepBlocks];
       const int samples = 1 << ( src.lw + src.lh );
-      const bool split = !k && samples > IT_PART_SAMPLES && src.mode <= 66 && !( src.flags & IT_F_MIP ) && ( src.flags & IT_F_ISP ) != IT_F_ISP;
-      const int lp = split ? ( samples > 2 * IT_PART_SAMPLES ? 2 : 1 ) : 0;
+      const bool split = samples > IT_SPLIT_SAMPLES && src.mode <= 66 && ( k || ( !( src.flags & IT_F_MIP ) && ( src.flags & IT_F_ISP ) != IT_F_ISP ) );
+      int lp = 0;
+      if( split ) while( lp < IT_MAX_LPARTS && ( samples >> lp ) > IT_SPLIT_SAMPLES ) lp++;
       for( int part = 0; part < ( 1 << lp ); part++ )
       {
         IntraItem it = src;
-        it.nTL = (uint8_t) ( ( src.nTL & 1 ) | ( part << 4 ) | ( lp << 6 ) );
+        it.nTL = (uint8_t) ( ( src.nTL & 1 ) | ( part << 1 ) | ( lp << 4 ) );
         it.comp = (uint8_t) ( k | ( std::min<uint32_t>( 63, indepItems + part ) << 2 ) );
         intraAll.push_back( it );
       }

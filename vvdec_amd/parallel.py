@@ -163,7 +163,11 @@ class TorchDeviceRuntime:
         return ev.cuda_event
 
     def finish(self):
+        """the collective's stream has drained: every event handed to the back-end is complete"""
         self.stream.synchronize()
+
+    def release(self):
+        """after finish() AND the back-end's sync(): the back-end has dropped the (complete) events, they may go (vvr.h, vvr_slot_external_event)"""
         self.events.clear()
 
 
@@ -196,6 +200,11 @@ class HostStubRuntime:
 
     def finish(self):
         pass
+
+    def release(self):
+        for e in self.events:
+            self.L.hipEventDestroy(e)       # (the stand-in runtime counts any later use of a destroyed event: vvt_dead_event_uses)
+        self.events = []
 
 
 class PictureParallel:
@@ -292,7 +301,11 @@ class PictureParallel:
                 self.fifo.append((i, jobs.get(i)))
                 self._pump(False)
         self._pump(True)
+        # order matters: the collective's stream drains (its events complete), the back-end syncs (and forgets the complete external events),
+        # only then are the events destroyed - the slots of the last pictures still name them until the back-end has looked
         if self.rt is not None:
             self.rt.finish()
         self.rec.sync()
+        if self.rt is not None:
+            self.rt.release()
         return jobs
