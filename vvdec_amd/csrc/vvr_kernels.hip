@@ -2979,8 +2979,10 @@ __device__ __forceinline__ int tile_idx( int dx, int dy )
 }
 #define IT_MAXREF ( 2 * 64 + 8 )
 
-#define IT_BATCH 128        // IntraItems staged in LDS at a time (128 x 16 B: one dword per thread)
-#define IT_WAVES 8          // wavefronts of a workgroup: each predicts one item (a block of up to 256 samples, or a band of rows of a larger one) at a time
+#define IT_BATCH ( IT_WAVES * 16 )   // IntraItems staged in LDS at a time (16 B each: one dword per thread)
+// wavefronts of a workgroup (template parameter of k_intra): each predicts one item (a block of up to 256 samples, or a band of rows of a larger one) at a time.
+// 8 for pictures of intra CTUs (the bands of a large block on four wavefronts while the other four prepare the next block), 4 for the scattered intra
+// blocks of an inter picture (units of a few blocks: twice the workgroups per CU)
 #define IT_NT ( IT_WAVES * 64 )
 
 // scratch of one wavefront (one block at a time)
@@ -2992,6 +2994,7 @@ struct IntraWave {
   int   lmSel[8];                                     // CCLM: the (luma, chroma) pairs of the selected template positions; MIP: the reduced boundary
 };
 
+template<int IT_WAVES>
 struct IntraShared {
   pel_t tile[IT_PAD * IT_TS + 128 * IT_TSB];
   IntraWave wave[IT_WAVES];
@@ -3326,6 +3329,7 @@ __global__ __launch_bounds__( 256 ) void k_intra_setup( IntraPic pic, const Intr
   c[C_ORIGIN] = (uint32_t) ox | ( (uint32_t) oy << 16 );
 }
 
+template<int IT_WAVES>
 __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraItem* __restrict__ items, const uint32_t* __restrict__ ctx /* k_intra_setup */,
                                                   const IntraUnit* __restrict__ units, int numActive,
                                                   int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */
@@ -3338,7 +3342,7 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
 #ifndef VVR_INTRA_DEV
   constexpr int dbg = 0; constexpr unsigned long long* trace = nullptr, * btrace = nullptr;      // (the timing experiments and the in-kernel timeline are developer builds only)
 #endif
-  __shared__ IntraShared sh;
+  __shared__ IntraShared<IT_WAVES> sh;
 #define IT_TRACE( K ) if( trace && threadIdx.x == 0 ) trace[(size_t) 8 * tr_ticket + ( K )] = wall_clock64()
   int tr_ticket = 0;
   const int tid = threadIdx.x;
@@ -4206,16 +4210,21 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   }
   else hipMemsetD32Async( (hipDeviceptr_t) sync, ticket0, 1, s );      // the ticket counter of the second launch starts where the first ended
   numActive = ticket1;
+  // a picture of intra CTUs: workgroups of eight wavefronts; the scattered intra blocks of an inter picture: four
+  int waves = pic.hdr.slice_type == 2 ? 8 : 4;
 #ifndef VVR_INTRA_DEV
-  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( IT_NT ), 0, s, ip, items, ctx, units, numActive, sync );
+  if( waves == 8 ) hipLaunchKernelGGL( k_intra<8>, dim3( numWorkgroups ), dim3( 512 ), 0, s, ip, items, ctx, units, numActive, sync );
+  else             hipLaunchKernelGGL( k_intra<4>, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync );
 #else
+  if( const char* e = getenv( "VVR_INTRA_WAVES" ) ) waves = atoi( e ) == 8 ? 8 : 4;
   static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
   static const bool tr = getenv( "VVR_INTRA_TRACE" ) != nullptr;
   unsigned long long* trace = nullptr, * btrace = nullptr;
   const size_t nItems = 1 << 20;      // (block timeline: sized generously, indexed by item)
   if( tr ) { hipMalloc( (void**) &trace, sizeof( unsigned long long ) * 8 * (size_t) numActive ); hipMemsetAsync( trace, 0, sizeof( unsigned long long ) * 8 * (size_t) numActive, s );
              hipMalloc( (void**) &btrace, sizeof( unsigned long long ) * 8 * nItems ); hipMemsetAsync( btrace, 0, sizeof( unsigned long long ) * 8 * nItems, s ); }
-  hipLaunchKernelGGL( k_intra, dim3( numWorkgroups ), dim3( IT_NT ), 0, s, ip, items, ctx, units, numActive, sync, dbg, trace, btrace );
+  if( waves == 8 ) hipLaunchKernelGGL( k_intra<8>, dim3( numWorkgroups ), dim3( 512 ), 0, s, ip, items, ctx, units, numActive, sync, dbg, trace, btrace );
+  else             hipLaunchKernelGGL( k_intra<4>, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync, dbg, trace, btrace );
   if( tr )
   {
     // developer timeline: ticket, phase time stamps (100 MHz), block count / unit word, number of producers; per block four shader-clock stamps
