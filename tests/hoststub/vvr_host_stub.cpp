@@ -66,9 +66,8 @@ void launch_itrans( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const TbIt
 // a hash of the picture's POC and of the stamps found in its reference slots at that moment.  Launches run at submission time here, so
 // the stamp of a picture is right exactly if every reference slot held the right picture when it was submitted - which is what the tests
 // of the multi-rank scheduler (broadcast of reference pictures between ranks, tests/test_multi_gpu_gloo.py) need to see.
-void launch_deblock( hipStream_t, const PicDev& pic, DevPlanes reco, int dir )
+static void stamp_picture( const PicDev& pic, DevPlanes reco )
 {
-  if( dir != 0 ) return;
   const vvr_pic_header& h = pic.hdr;
   size_t slotBytes = 0;
   for( int c = 0; c < 3; c++ ) if( reco.p[c] ) slotBytes += ( (size_t) reco.stride[c] * reco.h[c] * sizeof( pel_t ) + 255 ) / 256 * 256;
@@ -83,6 +82,12 @@ void launch_deblock( hipStream_t, const PicDev& pic, DevPlanes reco, int dir )
     }
   for( int k = 0; k < 4; k++ ) reco.p[0][k] = (pel_t) ( ( x >> ( 16 * k ) ) & 0x3ff );
 }
+// (the stamp needs the DPB slot: a picture with SAO or ALF is reconstructed in the lane's scratch picture and reaches its slot with the fused
+// SAO + ALF pass, every other picture is deblocked in its slot)
+static bool reaches_slot_with_sao_alf( const PicDev& pic ) { return ( pic.hdr.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA | VVR_TOOL_ALF ) ) != 0; }
+void launch_deblock( hipStream_t, const PicDev& pic, DevPlanes reco, int dir ) { if( dir == 0 && !reaches_slot_with_sao_alf( pic ) ) stamp_picture( pic, reco ); }
+bool sao_alf_fused( const PicDev& ) { return true; }
+void launch_sao_alf( hipStream_t, const PicDev& pic, DevPlanes, DevPlanes dst, bool, bool ) { if( g_delayUs ) usleep( 2 * g_delayUs ); stamp_picture( pic, dst ); }
 void launch_sao( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) { if( g_delayUs ) usleep( 2 * g_delayUs ); }
 void launch_alf( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) {}
 void launch_lmcs( hipStream_t, const PicDev&, DevPlanes, int ) {}

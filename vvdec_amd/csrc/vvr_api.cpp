@@ -349,6 +349,13 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   DevPlanes A = c->slots[h.out_slot], B = c->scratchB[lane], R = c->scratchR[lane];
   // the picture's own size (it may be smaller than the context's pictures: it lies in the top left corner of its slot and of the scratch planes)
   for( int k = 0; k < 3; k++ ) { const int w = k ? h.width >> 1 : h.width, hh = k ? h.height >> 1 : h.height; A.w[k] = B.w[k] = R.w[k] = w; A.h[k] = B.h[k] = R.h[k] = hh; }
+  // SAO and ALF in one pass (k_sao_alf): the picture is reconstructed and deblocked in the lane's scratch picture, the pass writes the DPB slot; else
+  // everything up to SAO works in the slot, SAO writes the scratch picture and ALF the slot (the reference's m_fltBuf round trip)
+  const int stopAfter = c->cfg.stop_after;       // conformance aid: vvr_config.stop_after
+  const bool sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) != 0 && stopAfter != 1 && stopAfter != 2;
+  const bool alf = ( h.tool_flags & VVR_TOOL_ALF ) != 0 && stopAfter == 0;
+  const bool fused = ( sao || alf ) && sao_alf_fused( q->pic );
+  const DevPlanes P = fused ? B : A;
   auto timedOn = [&]( int k, hipStream_t st, double algoBytes, auto&& fn )
   {
 #ifdef VVR_WATCHDOG
@@ -370,22 +377,22 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   // device-only throughput fell from 1870 to 1240 pictures/s with 4 lanes, to 970 with 8 - the cross-stream waits cost more than the overlap gives)
   // (the tiles of plain, BDOF and DMVR CUs are written on the device from the CU records: the host only counted them)
   if( q->numMcCus ) launch_expand_mc( s, q->pic, q->mcCus, q->numMcCus, q->mcDev, q->bdofItems, q->dmvrItems );
-  if( q->numMc + q->numMcDev ) timedOn( K_MC, s, q->bytes[K_MC] - q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, A, q->mcItems, q->numMc, q->mcDev, q->numMcDev, 0 ); } );
-  if( q->numBdofItems ) timedOn( K_MC, s, q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, A, nullptr, 0, q->bdofItems, q->numBdofItems, 1 ); } );
+  if( q->numMc + q->numMcDev ) timedOn( K_MC, s, q->bytes[K_MC] - q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, P, q->mcItems, q->numMc, q->mcDev, q->numMcDev, 0 ); } );
+  if( q->numBdofItems ) timedOn( K_MC, s, q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, P, nullptr, 0, q->bdofItems, q->numBdofItems, 1 ); } );
   if( q->numDmvrItems )
   {
     // the delta MVs go straight into pinned host memory (device-mapped): a few bytes per 16x16 sub-block, and no copy call on the
     // launcher's path - hipMemcpyAsync device-to-host was found to block the calling thread until the stream had drained
     int32_t* out = job.ring ? job.ring->dmvrHost : q->dmvrHost;
     memset( out, 0, sizeof( int32_t ) * 2 * (size_t) q->numDmvr );        // (offsets no CU owns stay zero)
-    timed( K_MC_DMVR, [&]{ launch_mc_dmvr( s, q->pic, refs, A, q->dmvrItems, q->numDmvrItems, out ); } );
+    timed( K_MC_DMVR, [&]{ launch_mc_dmvr( s, q->pic, refs, P, q->dmvrItems, q->numDmvrItems, out ); } );
   }
-  if( q->numAffItems ) timed( K_MC_AFFINE, [&]{ launch_mc_affine( s, q->pic, refs, A, q->affItems, q->numAffItems ); } );
-  if( q->numRprItems ) launch_mc_rpr( s, q->pic, refs, A, q->rprItems, q->numRprItems );      // CUs that read a scaled reference picture
+  if( q->numAffItems ) timed( K_MC_AFFINE, [&]{ launch_mc_affine( s, q->pic, refs, P, q->affItems, q->numAffItems ); } );
+  if( q->numRprItems ) launch_mc_rpr( s, q->pic, refs, P, q->rprItems, q->numRprItems );      // CUs that read a scaled reference picture
   const bool lmcsOn = ( h.tool_flags & VVR_TOOL_LMCS ) != 0;
   // LMCS: the inter prediction is forward-mapped before any residual is added (DecCu.cpp:458-476) - by the motion-compensation kernels themselves
   // where they store their luma samples (lmcs_fwd_luma): no pass over the picture
-  for( int k = 0; k < 3; k++ ) if( q->numTb[k] ) timedOn( K_ITRANS, s, q->bytesTb[k], [&]{ launch_itrans( s, q->pic, A, R, q->tbItems[k], q->numTb[k], 16 << k ); } );
+  for( int k = 0; k < 3; k++ ) if( q->numTb[k] ) timedOn( K_ITRANS, s, q->bytesTb[k], [&]{ launch_itrans( s, q->pic, P, R, q->tbItems[k], q->numTb[k], 16 << k ); } );
   // INTRA stage: wavefront over the CTUs that contain intra blocks (DecLibRecon.cpp:876-911)
   {
     // ticket + one flag per unit: a picture with more units than the lane's buffer holds gets a larger one; work queued on the lane may
@@ -403,23 +410,21 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   // A picture whose inter blocks carry scaled chroma residuals (LMCS): luma units, the residual-add blocks, chroma units
   if( q->numResi )
   {
-    if( q->numLumaUnits ) timedOn( K_INTRA, s, q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numLumaUnits, q->intraWorkgroups, c->syncBuf[lane] ); } );
-    timed( K_RESI_ADD, [&]{ launch_resi_add( s, q->pic, A, R, q->resiItems, q->numResi ); } );
-    if( q->numActive > q->numLumaUnits ) timedOn( K_INTRA, s, q->bytes[K_INTRA] - q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, q->numLumaUnits, q->numActive, q->intraWorkgroupsChroma, c->syncBuf[lane] ); } );
+    if( q->numLumaUnits ) timedOn( K_INTRA, s, q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numLumaUnits, q->intraWorkgroups, c->syncBuf[lane] ); } );
+    timed( K_RESI_ADD, [&]{ launch_resi_add( s, q->pic, P, R, q->resiItems, q->numResi ); } );
+    if( q->numActive > q->numLumaUnits ) timedOn( K_INTRA, s, q->bytes[K_INTRA] - q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, q->numLumaUnits, q->numActive, q->intraWorkgroupsChroma, c->syncBuf[lane] ); } );
   }
-  else if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, A, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
+  else if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
-  if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, A, 1 ); } );
+  if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, P, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
-  const int stopAfter = c->cfg.stop_after;       // conformance aid: vvr_config.stop_after
   if( !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF ) && stopAfter != 1 )
   {
-    timed( K_DEBLOCK_V, [&]{ launch_deblock( s, q->pic, A, 0 ); } );
-    timed( K_DEBLOCK_H, [&]{ launch_deblock( s, q->pic, A, 1 ); } );
+    timed( K_DEBLOCK_V, [&]{ launch_deblock( s, q->pic, P, 0 ); } );
+    timed( K_DEBLOCK_H, [&]{ launch_deblock( s, q->pic, P, 1 ); } );
   }
-  const bool sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) != 0 && stopAfter != 1 && stopAfter != 2;
-  const bool alf = ( h.tool_flags & VVR_TOOL_ALF ) != 0 && stopAfter == 0;
-  if( sao && alf ) { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
+  if( fused ) timed( K_ALF, [&]{ launch_sao_alf( s, q->pic, B, A, sao, alf ); } );
+  else if( sao && alf ) { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
   else if( sao )   { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_COPY, [&]{ launch_copy_planes( s, B, A ); } ); }
   else if( alf )   { timed( K_COPY, [&]{ launch_copy_planes( s, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
 #ifdef VVR_WATCHDOG

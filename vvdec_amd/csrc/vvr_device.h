@@ -132,6 +132,8 @@ void launch_itrans ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir );
 void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 void launch_alf    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
+bool sao_alf_fused ( const PicDev& pic );      // SAO + ALF in one pass (launch_sao_alf) apply to this picture; else launch_sao, launch_alf
+void launch_sao_alf( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst, bool sao, bool alf );
 void launch_lmcs   ( hipStream_t s, const PicDev& pic, DevPlanes reco, int inverse );
 void launch_copy_planes( hipStream_t s, DevPlanes src, DevPlanes dst );
 void launch_copy_bytes( hipStream_t s, const void* src, void* dst, size_t bytes );

@@ -2828,6 +2828,367 @@ void launch_alf( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst 
   }
 }
 
+// =====================================================================================================================
+// k_sao_alf — SAO, ALF and CC-ALF of one 64x64 luma region (and its 32x32 chroma regions) in ONE pass over the deblocked picture:
+//   SampleAdaptiveOffset::offsetBlock_core (SampleAdaptiveOffset.cpp:64) + deriveLoopFilterBoundaryAvailibility (:741), AdaptiveLoopFilter::filterCTU
+//   (AdaptiveLoopFilter.cpp:664): deriveClassificationBlk (:969), filterBlk<ALF_FILTER_7 / 5> (:1176), filterBlkCcAlf (:1348).
+// The reference runs SAO over the picture into a second picture and ALF back (m_fltBuf); k_sao / k_alf_* did the same: 4 bytes per sample more
+// than needed.  Here the deblocked window of the region (+ 4 samples around it: 3 for the 7x7 diamond, 1 for the SAO edge classes) is staged in LDS
+// with 16-byte loads, SAO is applied where the window is copied into the ALF tile - with the coordinate clamp of the CTU's ALF (slice / tile /
+// picture boundaries: the ALF of a CTU reads replicated samples, each of them a SAO OUTPUT of the sample it replicates, which SAO computes from
+// that sample's own neighbours and its own CTU's parameters) -, classification, luma filter, chroma filters and the CC-ALF cross (from the same
+// SAO-filtered luma tile) follow from LDS.  The picture is reconstructed into the lane's scratch picture and this kernel writes the DPB slot.
+// For CTUs of at least 64 samples and pictures without picture-header virtual boundaries (else: k_sao + k_alf_*).
+// =====================================================================================================================
+#define SA_T    64
+#define SA_DLW  80      // luma window of deblocked samples: columns tx0 - 8 .. tx0 + 71 (16-byte chunks), rows ty0 - 4 .. ty0 + 67
+#define SA_DLH  72
+#define SA_ALW  72      // SAO-filtered luma tile: rows ty0 - 3 .. ty0 + 66, column index = x - ( tx0 - 4 )
+#define SA_ALH  70
+#define SA_DCW  40      // chroma windows: columns cx0 - 4 .. cx0 + 35 (8-byte chunks), rows cy0 - 3 .. cy0 + 34
+#define SA_DCH  38
+#define SA_ACW  40      // SAO-filtered chroma tiles: rows cy0 - 2 .. cy0 + 33, column index = x - ( cx0 - 4 )
+#define SA_ACH  36
+struct SaoAlfShared {
+  pel_t dl[SA_DLH * SA_DLW];
+  pel_t al[SA_ALH * SA_ALW];
+  pel_t dc[2][SA_DCH * SA_DCW];
+  pel_t ac[2][SA_ACH * SA_ACW];
+  int16_t fCoef[25 * 12], fClip[25 * 12];      // the CTU's luma filter set: per class, un-transposed
+  uint8_t cls[256], trp[256];
+  uint32_t sao[9][3][2];                       // SAO parameters of the 3 x 3 CTUs around the region's, per component: mode | type << 8 | band << 16; the four offsets
+};
+
+// SAO of sample (sx, sy) of component C (cs = 1 for chroma): win = the window of deblocked samples (row stride ws) whose entry (0, 0) is sample (wx0, wy0)
+template<bool ON>
+__device__ __forceinline__ int sao_at( const PicDev& pic, const SaoAlfShared& sh, const pel_t* win, int ws, int wx0, int wy0, int c, int cs, int sx, int sy, int PW, int PH,
+                                       int ctuX, int ctuY, bool restricted )
+{
+  const pel_t* p = win + ( sy - wy0 ) * ws + ( sx - wx0 );
+  const int v = p[0];
+  if( !ON ) return v;
+  const int l2 = pic.hdr.log2_ctu - cs, bd = pic.hdr.bit_depth;
+  const int qx = sx >> l2, qy = sy >> l2;
+  const uint32_t* P = sh.sao[( qy - ctuY + 1 ) * 3 + ( qx - ctuX + 1 )][c];
+  const uint32_t m = P[0], ov = P[1];
+  if( !( m & 0xff ) ) return v;
+  const int type = ( m >> 8 ) & 0xff;
+  int k;
+  if( type == 4 )
+  {
+    k = ( ( v >> ( bd - 5 ) ) - (int) ( m >> 16 ) ) & 31;                                      // band offset
+    if( k >= 4 ) return v;
+  }
+  else
+  {
+    // edge offset: neighbours a = ( x - dx, y - dy ), b = ( x + dx, y + dy ); nothing across the picture boundary, nor across a slice / tile boundary the filters must not cross
+    const int dx = type == 1 ? 0 : ( type == 3 ? -1 : 1 ), dy = type == 0 ? 0 : 1;
+    if( sy - dy < 0 || sy + dy >= PH || sx - dx < 0 || sx - dx >= PW || sx + dx < 0 || sx + dx >= PW ) return v;
+    if( restricted )
+    {
+      const int cur = qy * pic.ctus_x + qx;
+      if( !lf_may_cross( pic, cur, ( ( sy - dy ) >> l2 ) * pic.ctus_x + ( ( sx - dx ) >> l2 ) ) || !lf_may_cross( pic, cur, ( ( sy + dy ) >> l2 ) * pic.ctus_x + ( ( sx + dx ) >> l2 ) ) ) return v;
+    }
+    const int o = dy * ws + dx;
+    const int e = sgn( v - (int) p[-o] ) + sgn( v - (int) p[o] );
+    if( !e ) return v;
+    k = e == -2 ? 0 : e == -1 ? 1 : e == 1 ? 2 : 3;
+  }
+  const int off = (int8_t) ( ov >> ( 8 * k ) );
+  return clip_pel( v + off, bd );
+}
+
+template<bool SAO, bool ALF>
+__global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, DevPlanes dst )
+{
+  __shared__ SaoAlfShared sh;
+  const int tilesX = gridDim.x;
+  const int tileLin = xcd_contiguous( blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y );
+  const int tx0 = ( tileLin % tilesX ) * SA_T, ty0 = ( tileLin / tilesX ) * SA_T;
+  const int tid = threadIdx.x, bd = pic.hdr.bit_depth, l2 = pic.hdr.log2_ctu, ctu = 1 << l2, ctuC = ctu >> 1;
+  const int W = src.w[0], H = src.h[0], st = src.stride[0];
+  const bool chroma = pic.hdr.chroma_format != 0;
+  const int CW = src.w[1], CH = src.h[1], cst = src.stride[1];
+  const int cx0 = tx0 >> 1, cy0 = ty0 >> 1;
+  const int ctuX = tx0 >> l2, ctuY = ty0 >> l2;                // (the region lies in one CTU)
+  const bool saoL = SAO && pic.sao && ( pic.hdr.tool_flags & VVR_TOOL_SAO_LUMA ), saoC = SAO && pic.sao && ( pic.hdr.tool_flags & VVR_TOOL_SAO_CHROMA );
+  // ---- the windows of deblocked samples; coordinates outside the picture repeat its border (the ALF's clamp; SAO never uses such a neighbour)
+  {
+    const pel_t* __restrict__ S = src.p[0];
+    for( int i = tid; i < SA_DLH * ( SA_DLW / 8 ); i += 256 )
+    {
+      const int r = i / ( SA_DLW / 8 ), cch = i - r * ( SA_DLW / 8 );
+      const int y = clip3( 0, H - 1, ty0 - 4 + r ), x = tx0 - 8 + 8 * cch;
+      uint4 v;
+      if( x >= 0 && x < W ) v = *reinterpret_cast<const uint4*>( &S[(size_t) y * st + x] );      // (the picture width is a multiple of 8: a chunk lies inside or outside)
+      else { const uint32_t e = (uint16_t) S[(size_t) y * st + ( x < 0 ? 0 : W - 1 )]; v.x = v.y = v.z = v.w = e | ( e << 16 ); }
+      *reinterpret_cast<uint4*>( &sh.dl[r * SA_DLW + 8 * cch] ) = v;
+    }
+    if( chroma )
+      for( int i = tid; i < 2 * SA_DCH * ( SA_DCW / 4 ); i += 256 )
+      {
+        const int k = i / ( SA_DCH * ( SA_DCW / 4 ) ), j = i - k * ( SA_DCH * ( SA_DCW / 4 ) ), r = j / ( SA_DCW / 4 ), cch = j - r * ( SA_DCW / 4 );
+        const pel_t* __restrict__ C = k ? src.p[2] : src.p[1];
+        const int y = clip3( 0, CH - 1, cy0 - 3 + r ), x = cx0 - 4 + 4 * cch;
+        uint2 v;
+        if( x >= 0 && x < CW ) v = *reinterpret_cast<const uint2*>( &C[(size_t) y * cst + x] );   // (the chroma width is a multiple of 4)
+        else { const uint32_t e = (uint16_t) C[(size_t) y * cst + ( x < 0 ? 0 : CW - 1 )]; v.x = v.y = e | ( e << 16 ); }
+        *reinterpret_cast<uint2*>( &sh.dc[k][r * SA_DCW + 4 * cch] ) = v;
+      }
+    if( SAO && pic.sao && tid < 27 )
+    {
+      const int q = tid / 3, c = tid - q * 3;
+      const int nx = clip3( 0, pic.ctus_x - 1, ctuX + q % 3 - 1 ), ny = clip3( 0, pic.ctus_y - 1, ctuY + q / 3 - 1 );
+      const vvr_sao_ctu* __restrict__ sp = &pic.sao[ny * pic.ctus_x + nx];
+      const uint8_t* ob = reinterpret_cast<const uint8_t*>( sp->offset[c] );
+      sh.sao[q][c][0] = (uint32_t) sp->mode[c] | ( (uint32_t) sp->type[c] << 8 ) | ( (uint32_t) sp->band_pos[c] << 16 );
+      sh.sao[q][c][1] = (uint32_t) ob[0] | ( (uint32_t) ob[1] << 8 ) | ( (uint32_t) ob[2] << 16 ) | ( (uint32_t) ob[3] << 24 );
+    }
+  }
+  vvr_alf_ctu f; f.enable[0] = f.enable[1] = f.enable[2] = 0; f.cc_idc[0] = f.cc_idc[1] = 0; f.alt[0] = f.alt[1] = 0; f.luma_filter_idx = 0;
+  const vvr_alf_params* __restrict__ A = nullptr;
+  if( ALF )
+  {
+    f = pic.alf[ctuY * pic.ctus_x + ctuX];
+    A = alf_set_at( pic, tx0, ty0 );                     // the filters of the APSs the CTU's slice refers to (AdaptiveLoopFilter.cpp:515)
+    if( f.enable[0] )
+    {
+      const int clipDef = 1 << bd;                       // m_alfClippVls[bd-8][0] = 256 << (bd - 8)
+      for( int i = tid; i < 25 * 12; i += 256 )
+      {
+        const int cl = i / 12, k = i - cl * 12;
+        if( f.luma_filter_idx < 16 ) { sh.fCoef[i] = d_alf_fixed_coeff[d_alf_class_to_filter[f.luma_filter_idx][cl]][k]; sh.fClip[i] = (int16_t) clipDef; }
+        else { sh.fCoef[i] = A->luma_coeff[f.luma_filter_idx - 16][cl][k]; sh.fClip[i] = A->luma_clip[f.luma_filter_idx - 16][cl][k]; }
+      }
+    }
+  }
+  const bool ccOn = ALF && ( pic.hdr.tool_flags & VVR_TOOL_CCALF ) != 0;
+  const bool cc[2] = { ccOn && f.cc_idc[0], ccOn && f.cc_idc[1] };
+  const bool restricted = lf_restricted( pic );
+  const AlfClip kl = alf_clip_of_ctu( pic, ctuX, ctuY, 0 ), kc = alf_clip_of_ctu( pic, ctuX, ctuY, 1 );
+  __syncthreads();
+  // ---- SAO where the windows are copied into the tiles the ALF reads: entry (x, y) of a tile is the SAO output of the sample the CTU's ALF reads there
+  for( int i = tid; i < SA_ALH * 70; i += 256 )
+  {
+    const int ay = i / 70, ax = i - ay * 70;
+    int sx = tx0 - 3 + ax, sy = ty0 - 3 + ay;
+    alf_clip_coord( kl, sx, sy );
+    sx = clip3( 0, W - 1, sx ); sy = clip3( 0, H - 1, sy );
+    sh.al[ay * SA_ALW + ax + 1] = (pel_t) ( saoL ? sao_at<true>( pic, sh, sh.dl, SA_DLW, tx0 - 8, ty0 - 4, 0, 0, sx, sy, W, H, ctuX, ctuY, restricted )
+                                                 : sao_at<false>( pic, sh, sh.dl, SA_DLW, tx0 - 8, ty0 - 4, 0, 0, sx, sy, W, H, ctuX, ctuY, restricted ) );
+  }
+  if( chroma )
+    for( int i = tid; i < 2 * SA_ACH * 36; i += 256 )
+    {
+      const int k = i / ( SA_ACH * 36 ), j = i - k * ( SA_ACH * 36 ), ay = j / 36, ax = j - ay * 36;
+      int sx = cx0 - 2 + ax, sy = cy0 - 2 + ay;
+      alf_clip_coord( kc, sx, sy );
+      sx = clip3( 0, CW - 1, sx ); sy = clip3( 0, CH - 1, sy );
+      sh.ac[k][ay * SA_ACW + ax + 2] = (pel_t) ( saoC ? sao_at<true>( pic, sh, sh.dc[k], SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted )
+                                                      : sao_at<false>( pic, sh, sh.dc[k], SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted ) );
+    }
+  __syncthreads();
+#define T( x, y ) sh.al[( ( y ) + 3 ) * SA_ALW + ( x ) + 4]      // region-relative luma sample
+  const int vbPos = ctu - 4;
+  if( ALF && f.enable[0] )
+  {
+    // ---- classification: 4 lanes per 4x4 block, one Laplacian cell-row pair each, reduced with lane shuffles; 256 blocks in four rounds
+#pragma unroll 1
+    for( int q = 0; q < 4; q++ )
+    {
+      const int blk = q * 64 + ( tid >> 2 ), i = ( tid & 3 ) * 2;
+      const int bx = ( blk & 15 ) * 4, by = ( blk >> 4 ) * 4;
+      const int yInCtu = ( ty0 + by ) & ( ctu - 1 );
+      int sumV = 0, sumH = 0, sumD0 = 0, sumD1 = 0;
+      if( !( ( yInCtu == vbPos - 4 && i == 6 ) || ( yInCtu == vbPos && i == 0 ) ) )
+      {
+        const int r = by - 2 + i, rel = yInCtu - 2 + i;
+        int rm1 = r - 1, rp2 = r + 2;
+        if( rel > 0 && ( rel % ctu ) == vbPos - 2 ) rp2 = r + 1;
+        else if( rel > 0 && ( rel % ctu ) == vbPos ) rm1 = r;
+#pragma unroll
+        for( int j = 0; j < 8; j += 2 )
+        {
+          const int cX = bx - 2 + j;
+          const int y0 = T( cX, r ) << 1, yup1 = T( cX + 1, r + 1 ) << 1;
+          sumV  += iabs( y0 - T( cX, rm1 ) - T( cX, r + 1 ) )         + iabs( yup1 - T( cX + 1, r ) - T( cX + 1, rp2 ) );
+          sumH  += iabs( y0 - T( cX + 1, r ) - T( cX - 1, r ) )       + iabs( yup1 - T( cX + 2, r + 1 ) - T( cX, r + 1 ) );
+          sumD0 += iabs( y0 - T( cX - 1, rm1 ) - T( cX + 1, r + 1 ) ) + iabs( yup1 - T( cX, r ) - T( cX + 2, rp2 ) );
+          sumD1 += iabs( y0 - T( cX - 1, r + 1 ) - T( cX + 1, rm1 ) ) + iabs( yup1 - T( cX, rp2 ) - T( cX + 2, r ) );
+        }
+      }
+      sumV  += __shfl_xor( sumV, 1 );  sumV  += __shfl_xor( sumV, 2 );
+      sumH  += __shfl_xor( sumH, 1 );  sumH  += __shfl_xor( sumH, 2 );
+      sumD0 += __shfl_xor( sumD0, 1 ); sumD0 += __shfl_xor( sumD0, 2 );
+      sumD1 += __shfl_xor( sumD1, 1 ); sumD1 += __shfl_xor( sumD1, 2 );
+      if( ( tid & 3 ) == 0 )
+      {
+        const int act = clip3( 0, 15, ( ( sumV + sumH ) * ( ( yInCtu == vbPos - 4 || yInCtu == vbPos ) ? 96 : 64 ) ) >> ( bd + 4 ) );
+        int cl = (int) ( ( 0x4333333332222210ull >> ( 4 * act ) ) & 15 );          // { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 }
+        int hv1, hv0, d1, d0, dirHV, dirD, hvd1, hvd0, mainDir, secDir;
+        if( sumV > sumH ) { hv1 = sumV; hv0 = sumH; dirHV = 1; } else { hv1 = sumH; hv0 = sumV; dirHV = 3; }
+        if( sumD0 > sumD1 ) { d1 = sumD0; d0 = sumD1; dirD = 0; } else { d1 = sumD1; d0 = sumD0; dirD = 2; }
+        if( (uint32_t) d1 * (uint32_t) hv0 > (uint32_t) hv1 * (uint32_t) d0 ) { hvd1 = d1; hvd0 = d0; mainDir = dirD; secDir = dirHV; }
+        else { hvd1 = hv1; hvd0 = hv0; mainDir = dirHV; secDir = dirD; }
+        int strength = 0;
+        if( hvd1 > 2 * hvd0 ) strength = 1;
+        if( hvd1 * 2 > 9 * hvd0 ) strength = 2;
+        if( strength ) cl += ( ( ( mainDir & 1 ) << 1 ) + strength ) * 5;
+        sh.cls[blk] = (uint8_t) cl; sh.trp[blk] = (uint8_t) ( ( 0x31322010u >> ( 4 * ( mainDir * 2 + ( secDir >> 1 ) ) ) ) & 15 );      // { 0, 1, 0, 2, 2, 3, 1, 3 }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- luma: thread -> (row, 4 consecutive columns) = one row of one 4x4 block, four rounds
+  {
+    pel_t* __restrict__ D = dst.p[0];
+    const int dstride = dst.stride[0];
+#pragma unroll 1
+    for( int q = 0; q < 4; q++ )
+    {
+      const int task = q * 256 + tid, y = task >> 4, x4 = ( task & 15 ) * 4;
+      const int gy = ty0 + y;
+      if( gy >= H || tx0 + x4 >= W ) continue;
+      int o[4];
+      if( ALF && f.enable[0] )
+      {
+        const int b = ( y >> 2 ) * 16 + ( x4 >> 2 );
+        const int cl = sh.cls[b], tr = sh.trp[b];
+        int cf[12], cp[12];
+#pragma unroll
+        for( int k = 0; k < 12; k++ ) { const int sk = c_alf_perm[tr][k]; cf[k] = sh.fCoef[cl * 12 + sk]; cp[k] = sh.fClip[cl * 12 + sk]; }
+        const int yVb = gy & ( ctu - 1 );
+        int r1 = y + 1, r2 = y - 1, r3 = y + 2, r4 = y - 2, r5 = y + 3, r6 = y - 3;
+        if( yVb < vbPos && yVb >= vbPos - 4 )
+        {
+          r1 = ( yVb == vbPos - 1 ) ? y : r1;  r3 = ( yVb >= vbPos - 2 ) ? r1 : r3;  r5 = ( yVb >= vbPos - 3 ) ? r3 : r5;
+          r2 = ( yVb == vbPos - 1 ) ? y : r2;  r4 = ( yVb >= vbPos - 2 ) ? r2 : r4;  r6 = ( yVb >= vbPos - 3 ) ? r4 : r6;
+        }
+        else if( yVb >= vbPos && yVb <= vbPos + 3 )
+        {
+          r2 = ( yVb == vbPos ) ? y : r2;  r4 = ( yVb <= vbPos + 1 ) ? r2 : r4;  r6 = ( yVb <= vbPos + 2 ) ? r4 : r6;
+          r1 = ( yVb == vbPos ) ? y : r1;  r3 = ( yVb <= vbPos + 1 ) ? r1 : r3;  r5 = ( yVb <= vbPos + 2 ) ? r3 : r5;
+        }
+        const bool nearVb = ( yVb == vbPos - 1 ) || ( yVb == vbPos );
+#pragma unroll
+        for( int e = 0; e < 4; e++ )
+        {
+          const int xx = x4 + e;
+          const int cur = T( xx, y );
+          int sum = 0;
+          sum += cf[0]  * clip_alf( cp[0],  cur, T( xx, r5 ),     T( xx, r6 ) );
+          sum += cf[1]  * clip_alf( cp[1],  cur, T( xx + 1, r3 ), T( xx - 1, r4 ) );
+          sum += cf[2]  * clip_alf( cp[2],  cur, T( xx, r3 ),     T( xx, r4 ) );
+          sum += cf[3]  * clip_alf( cp[3],  cur, T( xx - 1, r3 ), T( xx + 1, r4 ) );
+          sum += cf[4]  * clip_alf( cp[4],  cur, T( xx + 2, r1 ), T( xx - 2, r2 ) );
+          sum += cf[5]  * clip_alf( cp[5],  cur, T( xx + 1, r1 ), T( xx - 1, r2 ) );
+          sum += cf[6]  * clip_alf( cp[6],  cur, T( xx, r1 ),     T( xx, r2 ) );
+          sum += cf[7]  * clip_alf( cp[7],  cur, T( xx - 1, r1 ), T( xx + 1, r2 ) );
+          sum += cf[8]  * clip_alf( cp[8],  cur, T( xx - 2, r1 ), T( xx + 2, r2 ) );
+          sum += cf[9]  * clip_alf( cp[9],  cur, T( xx + 3, y ),  T( xx - 3, y ) );
+          sum += cf[10] * clip_alf( cp[10], cur, T( xx + 2, y ),  T( xx - 2, y ) );
+          sum += cf[11] * clip_alf( cp[11], cur, T( xx + 1, y ),  T( xx - 1, y ) );
+          sum = nearVb ? ( sum + 512 ) >> 10 : ( sum + 64 ) >> 7;
+          o[e] = clip_pel( sum + cur, bd );
+        }
+      }
+      else
+      {
+#pragma unroll
+        for( int e = 0; e < 4; e++ ) o[e] = (uint16_t) T( x4 + e, y );
+      }
+      *reinterpret_cast<uint2*>( &D[(size_t) gy * dstride + tx0 + x4] ) = make_uint2( (uint32_t) o[0] | ( (uint32_t) o[1] << 16 ), (uint32_t) o[2] | ( (uint32_t) o[3] << 16 ) );
+    }
+  }
+  if( !chroma ) return;
+  // ---- chroma: thread -> (row, 4 consecutive columns) of the 32x32 region, both planes: 5x5 diamond + the CC-ALF cross over the luma tile
+  {
+    const int ly = tid >> 3, lx4 = ( tid & 7 ) * 4;
+    const int y = cy0 + ly;
+    if( y >= CH || cx0 + lx4 >= CW ) return;
+    // rows of the 5x5 diamond at the ALF line-buffer boundary of the CTU row (chroma: 2 rows above the CTU's last 2)
+    const int vbC = ctuC - 2, yVb = y & ( ctuC - 1 );
+    int r1 = ly + 1, r2 = ly - 1, r3 = ly + 2, r4 = ly - 2;
+    if( yVb < vbC && yVb >= vbC - 2 )
+    {
+      r1 = ( yVb == vbC - 1 ) ? ly : r1;  r3 = ( yVb >= vbC - 2 ) ? r1 : r3;
+      r2 = ( yVb == vbC - 1 ) ? ly : r2;  r4 = ( yVb >= vbC - 2 ) ? r2 : r4;
+    }
+    else if( yVb >= vbC && yVb <= vbC + 1 )
+    {
+      r2 = ( yVb == vbC ) ? ly : r2;  r4 = ( yVb <= vbC + 1 ) ? r2 : r4;
+      r1 = ( yVb == vbC ) ? ly : r1;  r3 = ( yVb <= vbC + 1 ) ? r1 : r3;
+    }
+    const bool nearVb = ( yVb == vbC - 1 ) || ( yVb == vbC );
+    // luma rows of the CC-ALF cross (filterBlkCcAlf :1348)
+    const int posL = ( y << 1 ) & ( ctu - 1 );
+    int o1 = 1, o2 = -1, o3 = 2;
+    if( posL == vbPos - 2 || posL == vbPos + 1 ) o3 = o1;
+    else if( posL == vbPos - 1 || posL == vbPos ) { o1 = 0; o2 = 0; o3 = 0; }
+#pragma unroll
+    for( int k = 0; k < 2; k++ )
+    {
+      pel_t* __restrict__ D = k ? dst.p[2] : dst.p[1];
+      const bool en = ALF && f.enable[1 + k] != 0;
+#define C( xx, rr ) ( (int) sh.ac[k][( ( rr ) + 2 ) * SA_ACW + ( xx ) + 4] )
+      const int16_t* cf = nullptr; const int16_t* cp = nullptr; const int16_t* ccf = nullptr;
+      if( en ) { cf = A->chroma_coeff[k ? f.alt[1] : f.alt[0]]; cp = A->chroma_clip[k ? f.alt[1] : f.alt[0]]; }
+      if( cc[k] ) ccf = A->ccalf_coeff[k][( k ? f.cc_idc[1] : f.cc_idc[0] ) - 1];
+      int o[4];
+#pragma unroll
+      for( int e = 0; e < 4; e++ )
+      {
+        const int xx = lx4 + e;
+        const int cur = C( xx, ly );
+        int v = cur;
+        if( en )
+        {
+          int sum = 0;
+          sum += cf[0] * clip_alf( cp[0], cur, C( xx, r3 ),     C( xx, r4 ) );
+          sum += cf[1] * clip_alf( cp[1], cur, C( xx + 1, r1 ), C( xx - 1, r2 ) );
+          sum += cf[2] * clip_alf( cp[2], cur, C( xx, r1 ),     C( xx, r2 ) );
+          sum += cf[3] * clip_alf( cp[3], cur, C( xx - 1, r1 ), C( xx + 1, r2 ) );
+          sum += cf[4] * clip_alf( cp[4], cur, C( xx + 2, ly ), C( xx - 2, ly ) );
+          sum += cf[5] * clip_alf( cp[5], cur, C( xx + 1, ly ), C( xx - 1, ly ) );
+          sum = nearVb ? ( sum + 512 ) >> 10 : ( sum + 64 ) >> 7;
+          v = clip_pel( sum + cur, bd );
+        }
+        if( ccf )
+        {
+          const int qx = 2 * xx, qy = 2 * ly;
+          const int cl = T( qx, qy );
+          int sum = 0;
+          sum += ccf[0] * ( T( qx,     qy + o2 ) - cl );
+          sum += ccf[1] * ( T( qx - 1, qy      ) - cl );
+          sum += ccf[2] * ( T( qx + 1, qy      ) - cl );
+          sum += ccf[3] * ( T( qx - 1, qy + o1 ) - cl );
+          sum += ccf[4] * ( T( qx,     qy + o1 ) - cl );
+          sum += ccf[5] * ( T( qx + 1, qy + o1 ) - cl );
+          sum += ccf[6] * ( T( qx,     qy + o3 ) - cl );
+          sum = ( sum + 64 ) >> 7;
+          const int off = 1 << bd >> 1;
+          sum = clip_pel( sum + off, bd ) - off;
+          v = clip_pel( v + sum, bd );
+        }
+        o[e] = v;
+      }
+#undef C
+      *reinterpret_cast<uint2*>( &D[(size_t) y * dst.stride[1] + cx0 + lx4] ) = make_uint2( (uint32_t) o[0] | ( (uint32_t) o[1] << 16 ), (uint32_t) o[2] | ( (uint32_t) o[3] << 16 ) );
+    }
+  }
+#undef T
+}
+
+// the fused pass applies to pictures without picture-header virtual boundaries whose CTUs hold whole 64x64 regions
+bool sao_alf_fused( const PicDev& pic ) { return !( pic.hdr.num_ver_vb | pic.hdr.num_hor_vb ) && pic.hdr.log2_ctu >= 6; }
+void launch_sao_alf( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst, bool sao, bool alf )
+{
+  const dim3 grid( ( src.w[0] + SA_T - 1 ) / SA_T, ( src.h[0] + SA_T - 1 ) / SA_T );
+  if( sao && alf ) hipLaunchKernelGGL( ( k_sao_alf<true, true> ), grid, dim3( 256 ), 0, s, pic, src, dst );
+  else if( sao )   hipLaunchKernelGGL( ( k_sao_alf<true, false> ), grid, dim3( 256 ), 0, s, pic, src, dst );
+  else             hipLaunchKernelGGL( ( k_sao_alf<false, true> ), grid, dim3( 256 ), 0, s, pic, src, dst );
+}
+
 // plain plane copy (used when a stage is disabled for a picture)
 // =====================================================================================================================
 // k_lmcs — luma mapping with chroma scaling, the luma part: forward mapping of the inter prediction (Reshape::rspBufFwd,
