@@ -2898,6 +2898,42 @@ __device__ __forceinline__ int sao_at( const PicDev& pic, const SaoAlfShared& sh
   return clip_pel( v + off, bd );
 }
 
+typedef short alf_s2 __attribute__( ( ext_vector_type( 2 ) ) );      // two neighbouring samples (or their differences) in one register
+
+// SAO of the two samples (x, y), (x + 1, y) (x even) of component c in the register *w of a window of deblocked samples (ws registers per row) that lies inside
+// the picture, for a CTU whose filters may read everything around it: no boundary case applies.  Edge classes with packed 16-bit arithmetic.
+__device__ __forceinline__ uint32_t sao_pair( const SaoAlfShared& sh, const uint32_t* w, int ws, int c, int l2, int bd, int x, int y, int ctuX, int ctuY )
+{
+  const uint32_t v = w[0];
+  const uint32_t* P = sh.sao[( ( y >> l2 ) - ctuY + 1 ) * 3 + ( ( x >> l2 ) - ctuX + 1 )][c];
+  const uint32_t m = P[0];
+  if( !( m & 0xff ) ) return v;
+  const uint32_t ov = P[1];
+  const int type = ( m >> 8 ) & 0xff;
+  const int v0 = v & 0xffff, v1 = v >> 16;
+  int k0, k1;                                            // class of the two samples; >= 4: none
+  if( type == 4 )
+  {
+    const int bp = (int) ( m >> 16 );
+    k0 = ( ( v0 >> ( bd - 5 ) ) - bp ) & 31; k1 = ( ( v1 >> ( bd - 5 ) ) - bp ) & 31;
+  }
+  else
+  {
+    uint32_t a, b;
+    if( type == 0 )      { a = __builtin_amdgcn_alignbit( v, w[-1], 16 );           b = __builtin_amdgcn_alignbit( w[1], v, 16 ); }
+    else if( type == 1 ) { a = w[-ws];                                              b = w[ws]; }
+    else if( type == 2 ) { a = __builtin_amdgcn_alignbit( w[-ws], w[-ws - 1], 16 ); b = __builtin_amdgcn_alignbit( w[ws + 1], w[ws], 16 ); }
+    else                 { a = __builtin_amdgcn_alignbit( w[-ws + 1], w[-ws], 16 ); b = __builtin_amdgcn_alignbit( w[ws], w[ws - 1], 16 ); }
+    const alf_s2 vs = __builtin_bit_cast( alf_s2, v ), one = alf_s2{ 1, 1 }, mone = alf_s2{ -1, -1 };
+    const alf_s2 e = __builtin_elementwise_min( __builtin_elementwise_max( vs - __builtin_bit_cast( alf_s2, a ), mone ), one )
+                   + __builtin_elementwise_min( __builtin_elementwise_max( vs - __builtin_bit_cast( alf_s2, b ), mone ), one );
+    const int e0 = e.x, e1 = e.y;
+    k0 = e0 == 0 ? 4 : e0 < 0 ? e0 + 2 : e0 + 1; k1 = e1 == 0 ? 4 : e1 < 0 ? e1 + 2 : e1 + 1;
+  }
+  const int o0 = k0 < 4 ? (int) (int8_t) ( ov >> ( 8 * k0 ) ) : 0, o1 = k1 < 4 ? (int) (int8_t) ( ov >> ( 8 * k1 ) ) : 0;
+  return (uint32_t) clip_pel( v0 + o0, bd ) | ( (uint32_t) clip_pel( v1 + o1, bd ) << 16 );
+}
+
 template<bool SAO, bool ALF>
 __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, DevPlanes dst )
 {
@@ -2911,7 +2947,10 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
   const int CW = src.w[1], CH = src.h[1], cst = src.stride[1];
   const int cx0 = tx0 >> 1, cy0 = ty0 >> 1;
   const int ctuX = tx0 >> l2, ctuY = ty0 >> l2;                // (the region lies in one CTU)
-  const bool saoL = SAO && pic.sao && ( pic.hdr.tool_flags & VVR_TOOL_SAO_LUMA ), saoC = SAO && pic.sao && ( pic.hdr.tool_flags & VVR_TOOL_SAO_CHROMA );
+#ifndef SA_SKIP
+#define SA_SKIP 0          /* developer builds: phases left out for timing (1 SAO, 2 classification, 4 luma filter, 8 chroma filters, 16 CC-ALF); results are wrong */
+#endif
+  const bool saoL = !( SA_SKIP & 1 ) && SAO && pic.sao && ( pic.hdr.tool_flags & VVR_TOOL_SAO_LUMA ), saoC = !( SA_SKIP & 1 ) && SAO && pic.sao && ( pic.hdr.tool_flags & VVR_TOOL_SAO_CHROMA );
   // ---- the windows of deblocked samples; coordinates outside the picture repeat its border (the ALF's clamp; SAO never uses such a neighbour)
   {
     const pel_t* __restrict__ S = src.p[0];
@@ -2968,29 +3007,53 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
   const AlfClip kl = alf_clip_of_ctu( pic, ctuX, ctuY, 0 ), kc = alf_clip_of_ctu( pic, ctuX, ctuY, 1 );
   __syncthreads();
   // ---- SAO where the windows are copied into the tiles the ALF reads: entry (x, y) of a tile is the SAO output of the sample the CTU's ALF reads there
-  for( int i = tid; i < SA_ALH * 70; i += 256 )
+  // A region whose windows lie inside the picture, in a CTU whose filters may read everything around it (nearly all): no clamp, no boundary case -
+  // two neighbouring samples per step; else sample by sample with every rule
+  const bool plain = !kl.f && !kc.f && !restricted && tx0 >= 8 && ty0 >= 8 && tx0 + SA_T + 4 <= W && ty0 + SA_T + 4 <= H;
+  if( plain )
   {
-    const int ay = i / 70, ax = i - ay * 70;
-    int sx = tx0 - 3 + ax, sy = ty0 - 3 + ay;
-    alf_clip_coord( kl, sx, sy );
-    sx = clip3( 0, W - 1, sx ); sy = clip3( 0, H - 1, sy );
-    sh.al[ay * SA_ALW + ax + 1] = (pel_t) ( saoL ? sao_at<true>( pic, sh, sh.dl, SA_DLW, tx0 - 8, ty0 - 4, 0, 0, sx, sy, W, H, ctuX, ctuY, restricted )
-                                                 : sao_at<false>( pic, sh, sh.dl, SA_DLW, tx0 - 8, ty0 - 4, 0, 0, sx, sy, W, H, ctuX, ctuY, restricted ) );
-  }
-  if( chroma )
-    for( int i = tid; i < 2 * SA_ACH * 36; i += 256 )
+    const uint32_t* dlw = reinterpret_cast<const uint32_t*>( sh.dl );
+    uint32_t* alw = reinterpret_cast<uint32_t*>( sh.al );
+    for( int i = tid; i < SA_ALH * ( SA_ALW / 2 ); i += 256 )
     {
-      const int k = i / ( SA_ACH * 36 ), j = i - k * ( SA_ACH * 36 ), ay = j / 36, ax = j - ay * 36;
-      int sx = cx0 - 2 + ax, sy = cy0 - 2 + ay;
-      alf_clip_coord( kc, sx, sy );
-      sx = clip3( 0, CW - 1, sx ); sy = clip3( 0, CH - 1, sy );
-      sh.ac[k][ay * SA_ACW + ax + 2] = (pel_t) ( saoC ? sao_at<true>( pic, sh, sh.dc[k], SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted )
-                                                      : sao_at<false>( pic, sh, sh.dc[k], SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted ) );
+      const int ay = i / ( SA_ALW / 2 ), j = i - ay * ( SA_ALW / 2 );
+      const uint32_t* wp = dlw + ( ay + 1 ) * ( SA_DLW / 2 ) + j + 2;
+      alw[ay * ( SA_ALW / 2 ) + j] = saoL ? sao_pair( sh, wp, SA_DLW / 2, 0, l2, bd, tx0 - 4 + 2 * j, ty0 - 3 + ay, ctuX, ctuY ) : wp[0];
     }
+    if( chroma )
+      for( int i = tid; i < 2 * SA_ACH * 18; i += 256 )
+      {
+        const int k = i / ( SA_ACH * 18 ), r = i - k * ( SA_ACH * 18 ), ay = r / 18, j = 1 + ( r - ay * 18 );
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>( sh.dc[k] ) + ( ay + 1 ) * ( SA_DCW / 2 ) + j;
+        reinterpret_cast<uint32_t*>( sh.ac[k] )[ay * ( SA_ACW / 2 ) + j] = saoC ? sao_pair( sh, wp, SA_DCW / 2, 1 + k, l2 - 1, bd, cx0 - 4 + 2 * j, cy0 - 2 + ay, ctuX, ctuY ) : wp[0];
+      }
+  }
+  else
+  {
+    for( int i = tid; i < SA_ALH * 70; i += 256 )
+    {
+      const int ay = i / 70, ax = i - ay * 70;
+      int sx = tx0 - 3 + ax, sy = ty0 - 3 + ay;
+      alf_clip_coord( kl, sx, sy );
+      sx = clip3( 0, W - 1, sx ); sy = clip3( 0, H - 1, sy );
+      sh.al[ay * SA_ALW + ax + 1] = (pel_t) ( saoL ? sao_at<true>( pic, sh, sh.dl, SA_DLW, tx0 - 8, ty0 - 4, 0, 0, sx, sy, W, H, ctuX, ctuY, restricted )
+                                                   : sao_at<false>( pic, sh, sh.dl, SA_DLW, tx0 - 8, ty0 - 4, 0, 0, sx, sy, W, H, ctuX, ctuY, restricted ) );
+    }
+    if( chroma )
+      for( int i = tid; i < 2 * SA_ACH * 36; i += 256 )
+      {
+        const int k = i / ( SA_ACH * 36 ), j = i - k * ( SA_ACH * 36 ), ay = j / 36, ax = j - ay * 36;
+        int sx = cx0 - 2 + ax, sy = cy0 - 2 + ay;
+        alf_clip_coord( kc, sx, sy );
+        sx = clip3( 0, CW - 1, sx ); sy = clip3( 0, CH - 1, sy );
+        sh.ac[k][ay * SA_ACW + ax + 2] = (pel_t) ( saoC ? sao_at<true>( pic, sh, sh.dc[k], SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted )
+                                                        : sao_at<false>( pic, sh, sh.dc[k], SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted ) );
+      }
+  }
   __syncthreads();
 #define T( x, y ) sh.al[( ( y ) + 3 ) * SA_ALW + ( x ) + 4]      // region-relative luma sample
   const int vbPos = ctu - 4;
-  if( ALF && f.enable[0] )
+  if( !( SA_SKIP & 2 ) && ALF && f.enable[0] )
   {
     // ---- classification: 4 lanes per 4x4 block, one Laplacian cell-row pair each, reduced with lane shuffles; 256 blocks in four rounds
 #pragma unroll 1
@@ -3006,16 +3069,37 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
         int rm1 = r - 1, rp2 = r + 2;
         if( rel > 0 && ( rel % ctu ) == vbPos - 2 ) rp2 = r + 1;
         else if( rel > 0 && ( rel % ctu ) == vbPos ) rm1 = r;
-#pragma unroll
-        for( int j = 0; j < 8; j += 2 )
+        // rows rm1, r, r + 1, rp2, columns bx - 4 .. bx + 7 (three 8-byte reads each).  The Laplacians of the two cells of a step - (cX, r) and
+        // (cX + 1, r + 1) - are computed together in the two halves of a register: | 2 A - B - C | with A = the cells, B / C = their two neighbours
+        uint32_t wr[4][6];
         {
-          const int cX = bx - 2 + j;
-          const int y0 = T( cX, r ) << 1, yup1 = T( cX + 1, r + 1 ) << 1;
-          sumV  += iabs( y0 - T( cX, rm1 ) - T( cX, r + 1 ) )         + iabs( yup1 - T( cX + 1, r ) - T( cX + 1, rp2 ) );
-          sumH  += iabs( y0 - T( cX + 1, r ) - T( cX - 1, r ) )       + iabs( yup1 - T( cX + 2, r + 1 ) - T( cX, r + 1 ) );
-          sumD0 += iabs( y0 - T( cX - 1, rm1 ) - T( cX + 1, r + 1 ) ) + iabs( yup1 - T( cX, r ) - T( cX + 2, rp2 ) );
-          sumD1 += iabs( y0 - T( cX - 1, r + 1 ) - T( cX + 1, rm1 ) ) + iabs( yup1 - T( cX, rp2 ) - T( cX + 2, r ) );
+          const int rr[4] = { rm1, r, r + 1, rp2 };
+#pragma unroll
+          for( int k = 0; k < 4; k++ )
+          {
+            const uint2* rp = reinterpret_cast<const uint2*>( &sh.al[( rr[k] + 3 ) * SA_ALW + bx] );
+            const uint2 u0 = rp[0], u1 = rp[1], u2 = rp[2];
+            wr[k][0] = u0.x; wr[k][1] = u0.y; wr[k][2] = u1.x; wr[k][3] = u1.y; wr[k][4] = u2.x; wr[k][5] = u2.y;
+          }
         }
+        alf_s2 aV = alf_s2{ 0, 0 }, aH = aV, aD0 = aV, aD1 = aV;
+        const alf_s2 zero = alf_s2{ 0, 0 };
+#define LOHI( L, Hh ) __builtin_bit_cast( alf_s2, ( ( L ) & 0xffffu ) | ( ( Hh ) & 0xffff0000u ) )
+#define ALN( Hh, L )  __builtin_bit_cast( alf_s2, __builtin_amdgcn_alignbit( Hh, L, 16 ) )
+#define LAPL( ACC, B, C ) { const alf_s2 t_ = a2 - ( B ) - ( C ); ACC += __builtin_elementwise_max( t_, zero - t_ ); }
+#pragma unroll
+        for( int d = 1; d <= 4; d++ )          // cX = bx - 2 + 2 ( d - 1 ): register d of a row holds columns ( cX, cX + 1 )
+        {
+          const alf_s2 a1 = LOHI( wr[1][d], wr[2][d] ), a2 = a1 + a1;
+          LAPL( aV,  LOHI( wr[0][d], wr[1][d] ),    LOHI( wr[2][d], wr[3][d] ) )
+          LAPL( aH,  ALN( wr[2][d + 1], wr[1][d] ), ALN( wr[2][d], wr[1][d - 1] ) )
+          LAPL( aD0, ALN( wr[1][d], wr[0][d - 1] ), ALN( wr[3][d + 1], wr[2][d] ) )
+          LAPL( aD1, ALN( wr[3][d], wr[2][d - 1] ), ALN( wr[1][d + 1], wr[0][d] ) )
+        }
+#undef LAPL
+#undef ALN
+#undef LOHI
+        sumV = (int) aV.x + (int) aV.y; sumH = (int) aH.x + (int) aH.y; sumD0 = (int) aD0.x + (int) aD0.y; sumD1 = (int) aD1.x + (int) aD1.y;
       }
       sumV  += __shfl_xor( sumV, 1 );  sumV  += __shfl_xor( sumV, 2 );
       sumH  += __shfl_xor( sumH, 1 );  sumH  += __shfl_xor( sumH, 2 );
@@ -3050,7 +3134,7 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
       const int gy = ty0 + y;
       if( gy >= H || tx0 + x4 >= W ) continue;
       int o[4];
-      if( ALF && f.enable[0] )
+      if( !( SA_SKIP & 4 ) && ALF && f.enable[0] )
       {
         const int b = ( y >> 2 ) * 16 + ( x4 >> 2 );
         const int cl = sh.cls[b], tr = sh.trp[b];
@@ -3070,27 +3154,52 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
           r1 = ( yVb == vbPos ) ? y : r1;  r3 = ( yVb <= vbPos + 1 ) ? r1 : r3;  r5 = ( yVb <= vbPos + 2 ) ? r3 : r5;
         }
         const bool nearVb = ( yVb == vbPos - 1 ) || ( yVb == vbPos );
-#pragma unroll
-        for( int e = 0; e < 4; e++ )
+        // the rows of the diamond, columns x4 - 4 .. x4 + 7 of each (three 8-byte LDS reads): everything below works on PAIRS of neighbouring samples
+        // in the two halves of a register (v_pk_sub / max / min / add_i16, v_dot2_i32_i16): a pair of outputs per pass, 12 taps of ( 2 clipped
+        // differences, their sum, two multiply-adds ) each
+        uint32_t wv[7][6];
         {
-          const int xx = x4 + e;
-          const int cur = T( xx, y );
-          int sum = 0;
-          sum += cf[0]  * clip_alf( cp[0],  cur, T( xx, r5 ),     T( xx, r6 ) );
-          sum += cf[1]  * clip_alf( cp[1],  cur, T( xx + 1, r3 ), T( xx - 1, r4 ) );
-          sum += cf[2]  * clip_alf( cp[2],  cur, T( xx, r3 ),     T( xx, r4 ) );
-          sum += cf[3]  * clip_alf( cp[3],  cur, T( xx - 1, r3 ), T( xx + 1, r4 ) );
-          sum += cf[4]  * clip_alf( cp[4],  cur, T( xx + 2, r1 ), T( xx - 2, r2 ) );
-          sum += cf[5]  * clip_alf( cp[5],  cur, T( xx + 1, r1 ), T( xx - 1, r2 ) );
-          sum += cf[6]  * clip_alf( cp[6],  cur, T( xx, r1 ),     T( xx, r2 ) );
-          sum += cf[7]  * clip_alf( cp[7],  cur, T( xx - 1, r1 ), T( xx + 1, r2 ) );
-          sum += cf[8]  * clip_alf( cp[8],  cur, T( xx - 2, r1 ), T( xx + 2, r2 ) );
-          sum += cf[9]  * clip_alf( cp[9],  cur, T( xx + 3, y ),  T( xx - 3, y ) );
-          sum += cf[10] * clip_alf( cp[10], cur, T( xx + 2, y ),  T( xx - 2, y ) );
-          sum += cf[11] * clip_alf( cp[11], cur, T( xx + 1, y ),  T( xx - 1, y ) );
-          sum = nearVb ? ( sum + 512 ) >> 10 : ( sum + 64 ) >> 7;
-          o[e] = clip_pel( sum + cur, bd );
+          const int rr[7] = { r6, r4, r2, y, r1, r3, r5 };
+#pragma unroll
+          for( int k = 0; k < 7; k++ )
+          {
+            const uint2* rp = reinterpret_cast<const uint2*>( &sh.al[( rr[k] + 3 ) * SA_ALW + x4] );
+            const uint2 u0 = rp[0], u1 = rp[1], u2 = rp[2];
+            wv[k][0] = u0.x; wv[k][1] = u0.y; wv[k][2] = u1.x; wv[k][3] = u1.y; wv[k][4] = u2.x; wv[k][5] = u2.y;
+          }
         }
+        // pair of samples at columns ( x4 - 4 + OFF, + 1 ) of row K
+#define AP( K, OFF ) ( ( ( OFF ) & 1 ) ? __builtin_amdgcn_alignbit( wv[K][( ( OFF ) + 1 ) >> 1], wv[K][( ( OFF ) - 1 ) >> 1], 16 ) : wv[K][( OFF ) >> 1] )
+        uint32_t ck[12]; alf_s2 cpP[12], cpN[12];
+#pragma unroll
+        for( int k = 0; k < 12; k++ ) { ck[k] = (uint16_t) cf[k]; const short c = (short) cp[k]; cpP[k] = alf_s2{ c, c }; cpN[k] = alf_s2{ (short) -c, (short) -c }; }
+#pragma unroll
+        for( int p = 0; p < 2; p++ )
+        {
+          const alf_s2 cur = __builtin_bit_cast( alf_s2, wv[3][2 + p] );
+          int s0 = 0, s1 = 0;
+          // rows: 0 = r6, 1 = r4, 2 = r2, 3 = y, 4 = r1, 5 = r3, 6 = r5; OFF = 2 p + dx + 4
+#define TAP( K, KA, DXA, KB, DXB ) { const alf_s2 a = __builtin_bit_cast( alf_s2, AP( KA, 2 * p + ( DXA ) + 4 ) ), b = __builtin_bit_cast( alf_s2, AP( KB, 2 * p + ( DXB ) + 4 ) ); \
+            const alf_s2 d = __builtin_elementwise_min( __builtin_elementwise_max( a - cur, cpN[K] ), cpP[K] ) + __builtin_elementwise_min( __builtin_elementwise_max( b - cur, cpN[K] ), cpP[K] ); \
+            s0 = __builtin_amdgcn_sdot2( d, __builtin_bit_cast( alf_s2, ck[K] ), s0, false ); s1 = __builtin_amdgcn_sdot2( d, __builtin_bit_cast( alf_s2, ck[K] << 16 ), s1, false ); }
+          TAP( 0, 6, 0, 0, 0 )
+          TAP( 1, 5, 1, 1, -1 )
+          TAP( 2, 5, 0, 1, 0 )
+          TAP( 3, 5, -1, 1, 1 )
+          TAP( 4, 4, 2, 2, -2 )
+          TAP( 5, 4, 1, 2, -1 )
+          TAP( 6, 4, 0, 2, 0 )
+          TAP( 7, 4, -1, 2, 1 )
+          TAP( 8, 4, -2, 2, 2 )
+          TAP( 9, 3, 3, 3, -3 )
+          TAP( 10, 3, 2, 3, -2 )
+          TAP( 11, 3, 1, 3, -1 )
+#undef TAP
+          s0 = nearVb ? ( s0 + 512 ) >> 10 : ( s0 + 64 ) >> 7;
+          s1 = nearVb ? ( s1 + 512 ) >> 10 : ( s1 + 64 ) >> 7;
+          o[2 * p] = clip_pel( s0 + (int) cur.x, bd ); o[2 * p + 1] = clip_pel( s1 + (int) cur.y, bd );
+        }
+#undef AP
       }
       else
       {
@@ -3129,50 +3238,91 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
     for( int k = 0; k < 2; k++ )
     {
       pel_t* __restrict__ D = k ? dst.p[2] : dst.p[1];
-      const bool en = ALF && f.enable[1 + k] != 0;
-#define C( xx, rr ) ( (int) sh.ac[k][( ( rr ) + 2 ) * SA_ACW + ( xx ) + 4] )
+      const bool en = !( SA_SKIP & 8 ) && ALF && f.enable[1 + k] != 0;
       const int16_t* cf = nullptr; const int16_t* cp = nullptr; const int16_t* ccf = nullptr;
       if( en ) { cf = A->chroma_coeff[k ? f.alt[1] : f.alt[0]]; cp = A->chroma_clip[k ? f.alt[1] : f.alt[0]]; }
-      if( cc[k] ) ccf = A->ccalf_coeff[k][( k ? f.cc_idc[1] : f.cc_idc[0] ) - 1];
+      if( !( SA_SKIP & 16 ) && cc[k] ) ccf = A->ccalf_coeff[k][( k ? f.cc_idc[1] : f.cc_idc[0] ) - 1];
       int o[4];
-#pragma unroll
-      for( int e = 0; e < 4; e++ )
+      // the rows of the 5x5 diamond, columns lx4 - 4 .. lx4 + 7 (pairs of neighbouring samples per register, as for luma)
+      uint32_t wv[5][6];
       {
-        const int xx = lx4 + e;
-        const int cur = C( xx, ly );
-        int v = cur;
-        if( en )
+        const int rr[5] = { r4, r2, ly, r1, r3 };
+#pragma unroll
+        for( int j = 0; j < 5; j++ )
         {
-          int sum = 0;
-          sum += cf[0] * clip_alf( cp[0], cur, C( xx, r3 ),     C( xx, r4 ) );
-          sum += cf[1] * clip_alf( cp[1], cur, C( xx + 1, r1 ), C( xx - 1, r2 ) );
-          sum += cf[2] * clip_alf( cp[2], cur, C( xx, r1 ),     C( xx, r2 ) );
-          sum += cf[3] * clip_alf( cp[3], cur, C( xx - 1, r1 ), C( xx + 1, r2 ) );
-          sum += cf[4] * clip_alf( cp[4], cur, C( xx + 2, ly ), C( xx - 2, ly ) );
-          sum += cf[5] * clip_alf( cp[5], cur, C( xx + 1, ly ), C( xx - 1, ly ) );
-          sum = nearVb ? ( sum + 512 ) >> 10 : ( sum + 64 ) >> 7;
-          v = clip_pel( sum + cur, bd );
+          const uint2* rp = reinterpret_cast<const uint2*>( &sh.ac[k][( rr[j] + 2 ) * SA_ACW + lx4] );
+          const uint2 u0 = rp[0], u1 = rp[1], u2 = rp[2];
+          wv[j][0] = u0.x; wv[j][1] = u0.y; wv[j][2] = u1.x; wv[j][3] = u1.y; wv[j][4] = u2.x; wv[j][5] = u2.y;
         }
-        if( ccf )
-        {
-          const int qx = 2 * xx, qy = 2 * ly;
-          const int cl = T( qx, qy );
-          int sum = 0;
-          sum += ccf[0] * ( T( qx,     qy + o2 ) - cl );
-          sum += ccf[1] * ( T( qx - 1, qy      ) - cl );
-          sum += ccf[2] * ( T( qx + 1, qy      ) - cl );
-          sum += ccf[3] * ( T( qx - 1, qy + o1 ) - cl );
-          sum += ccf[4] * ( T( qx,     qy + o1 ) - cl );
-          sum += ccf[5] * ( T( qx + 1, qy + o1 ) - cl );
-          sum += ccf[6] * ( T( qx,     qy + o3 ) - cl );
-          sum = ( sum + 64 ) >> 7;
-          const int off = 1 << bd >> 1;
-          sum = clip_pel( sum + off, bd ) - off;
-          v = clip_pel( v + sum, bd );
-        }
-        o[e] = v;
       }
-#undef C
+#pragma unroll
+      for( int e = 0; e < 4; e++ ) o[e] = (int) ( ( wv[2][2 + ( e >> 1 )] >> ( 16 * ( e & 1 ) ) ) & 0xffff );
+      if( en )
+      {
+#define AP( K, OFF ) ( ( ( OFF ) & 1 ) ? __builtin_amdgcn_alignbit( wv[K][( ( OFF ) + 1 ) >> 1], wv[K][( ( OFF ) - 1 ) >> 1], 16 ) : wv[K][( OFF ) >> 1] )
+        uint32_t ck[6]; alf_s2 cpP[6], cpN[6];
+#pragma unroll
+        for( int j = 0; j < 6; j++ ) { ck[j] = (uint16_t) cf[j]; const short c = (short) cp[j]; cpP[j] = alf_s2{ c, c }; cpN[j] = alf_s2{ (short) -c, (short) -c }; }
+#pragma unroll
+        for( int p = 0; p < 2; p++ )
+        {
+          const alf_s2 cur = __builtin_bit_cast( alf_s2, wv[2][2 + p] );
+          int s0 = 0, s1 = 0;
+          // rows: 0 = r4, 1 = r2, 2 = ly, 3 = r1, 4 = r3
+#define TAP( K, KA, DXA, KB, DXB ) { const alf_s2 a = __builtin_bit_cast( alf_s2, AP( KA, 2 * p + ( DXA ) + 4 ) ), b = __builtin_bit_cast( alf_s2, AP( KB, 2 * p + ( DXB ) + 4 ) ); \
+            const alf_s2 d = __builtin_elementwise_min( __builtin_elementwise_max( a - cur, cpN[K] ), cpP[K] ) + __builtin_elementwise_min( __builtin_elementwise_max( b - cur, cpN[K] ), cpP[K] ); \
+            s0 = __builtin_amdgcn_sdot2( d, __builtin_bit_cast( alf_s2, ck[K] ), s0, false ); s1 = __builtin_amdgcn_sdot2( d, __builtin_bit_cast( alf_s2, ck[K] << 16 ), s1, false ); }
+          TAP( 0, 4, 0, 0, 0 )
+          TAP( 1, 3, 1, 1, -1 )
+          TAP( 2, 3, 0, 1, 0 )
+          TAP( 3, 3, -1, 1, 1 )
+          TAP( 4, 2, 2, 2, -2 )
+          TAP( 5, 2, 1, 2, -1 )
+#undef TAP
+          s0 = nearVb ? ( s0 + 512 ) >> 10 : ( s0 + 64 ) >> 7;
+          s1 = nearVb ? ( s1 + 512 ) >> 10 : ( s1 + 64 ) >> 7;
+          o[2 * p] = clip_pel( s0 + (int) cur.x, bd ); o[2 * p + 1] = clip_pel( s1 + (int) cur.y, bd );
+        }
+#undef AP
+      }
+      if( ccf )
+      {
+        // the cross over the SAO-filtered luma tile: rows 2 ly + { o2, 0, o1, o3 }, columns 2 lx4 - 4 .. 2 lx4 + 7; the centre's weight is minus the sum of the others
+        // ( sum of c * ( Y - centre ) ), two samples of a row per multiply-add (v_dot2_i32_i16)
+        uint32_t lw[4][6];
+        {
+          const int rr[4] = { 2 * ly + o2, 2 * ly, 2 * ly + o1, 2 * ly + o3 };
+#pragma unroll
+          for( int j = 0; j < 4; j++ )
+          {
+            const uint2* rp = reinterpret_cast<const uint2*>( &sh.al[( rr[j] + 3 ) * SA_ALW + 2 * lx4] );
+            const uint2 u0 = rp[0], u1 = rp[1], u2 = rp[2];
+            lw[j][0] = u0.x; lw[j][1] = u0.y; lw[j][2] = u1.x; lw[j][3] = u1.y; lw[j][4] = u2.x; lw[j][5] = u2.y;
+          }
+        }
+        const int csum = ccf[0] + ccf[1] + ccf[2] + ccf[3] + ccf[4] + ccf[5] + ccf[6];
+#define PK( LO, HI ) __builtin_bit_cast( alf_s2, (uint32_t) (uint16_t) ( LO ) | ( (uint32_t) (uint16_t) ( HI ) << 16 ) )
+        const alf_s2 q1 = PK( 0, ccf[1] ), q2 = PK( -csum, ccf[2] ), q3 = PK( 0, ccf[3] ), q45 = PK( ccf[4], ccf[5] ), q0 = PK( ccf[0], 0 ), q6 = PK( ccf[6], 0 );
+#undef PK
+        const int off = 1 << bd >> 1;
+#pragma unroll
+        for( int e = 0; e < 4; e++ )
+        {
+          // pixel e: luma columns ( 2 ( lx4 + e ), + 1 ) = register 2 + e of a row, ( - 2, - 1 ) = register 1 + e
+          int sum = 0;
+#define LP( R, J ) __builtin_bit_cast( alf_s2, lw[R][J] )
+          sum = __builtin_amdgcn_sdot2( LP( 1, 1 + e ), q1, sum, false );
+          sum = __builtin_amdgcn_sdot2( LP( 1, 2 + e ), q2, sum, false );
+          sum = __builtin_amdgcn_sdot2( LP( 2, 1 + e ), q3, sum, false );
+          sum = __builtin_amdgcn_sdot2( LP( 2, 2 + e ), q45, sum, false );
+          sum = __builtin_amdgcn_sdot2( LP( 0, 2 + e ), q0, sum, false );
+          sum = __builtin_amdgcn_sdot2( LP( 3, 2 + e ), q6, sum, false );
+#undef LP
+          sum = ( sum + 64 ) >> 7;
+          sum = clip_pel( sum + off, bd ) - off;
+          o[e] = clip_pel( o[e] + sum, bd );
+        }
+      }
       *reinterpret_cast<uint2*>( &D[(size_t) y * dst.stride[1] + cx0 + lx4] ) = make_uint2( (uint32_t) o[0] | ( (uint32_t) o[1] << 16 ), (uint32_t) o[2] | ( (uint32_t) o[3] << 16 ) );
     }
   }
