@@ -455,6 +455,10 @@ VVR_API void*        vvr_host_alloc(vvr_context* ctx, size_t bytes);
 VVR_API void         vvr_host_free(vvr_context* ctx, void* p);
 /* DecLibRecon::waitForPrevDecompressedPic (DecLibRecon.cpp:684): blocks until job `job` is reconstructed; returns its status. */
 VVR_API int          vvr_wait(vvr_context* ctx, int job);
+/* the same question without waiting (the ready check of a completion task on the decoder's thread pool, ThreadPool.cpp addBarrierTask: no pool
+ * thread sleeps in vvr_wait): VVR_OK - job `job` is reconstructed (vvr_wait would return at once, with this status); VVR_NOT_READY - not yet;
+ * negative - it failed.  The job stays to be waited for. */
+VVR_API int          vvr_test(vvr_context* ctx, int job);
 /* wait for everything in flight */
 VVR_API int          vvr_sync(vvr_context* ctx);
 /* geometry of a DPB slot: byte size, and per-plane offset / stride (bytes) / rows */

@@ -55,20 +55,50 @@ namespace vvdec
 
 namespace
 {
-struct AmdShared                      // one per decoder instance
+// The back-end of one coded video sequence: context + which picture every DPB slot holds.  Shared (shared_ptr) by the decoder's DecLibRecon
+// instances and by every picture in flight on it: a sequence that activates an SPS the context cannot hold (larger pictures, another sample
+// format or CTU size) gets a new one, and the old one goes when its last picture is finished.
+struct AmdCtx
 {
   vvr_context* ctx = nullptr;
+  int numSlots = 0;
+  // a Picture object keeps its slot (PicListManager recycles the objects); what the slot holds is a LIFE of the object: the POC it carried when the
+  // back-end last wrote the slot, and whether the back-end reconstructed it itself or it was uploaded from the Picture's buffers
+  struct Slot { const Picture* pic = nullptr; int poc = 0; bool ours = false; uint64_t lastUse = 0; };
+  std::vector<Slot> slots;
   std::map<const Picture*, int> slotOf;
-  int nextSlot = 0, numSlots = 0, users = 0;
-  std::mutex mu;
-  ~AmdShared() { if( ctx ) vvr_destroy( ctx ); }
+  uint64_t useCounter = 0;
+  uint16_t maxW = 0, maxH = 0; uint8_t chroma = 0, bitDepth = 0, log2Ctu = 0;
+  ~AmdCtx() { if( ctx ) vvr_destroy( ctx ); }
+  bool holds( const SPS& sps ) const
+  {
+    return ctx && sps.getMaxPicWidthInLumaSamples() <= maxW && sps.getMaxPicHeightInLumaSamples() <= maxH && ( sps.getChromaFormatIdc() == CHROMA_400 ? 0 : 1 ) == chroma
+        && sps.getBitDepth() == bitDepth && getLog2( sps.getMaxCUWidth() ) == log2Ctu;
+  }
 };
+struct AmdShared                      // one per decoder instance (keyed by its thread pool)
+{
+  std::shared_ptr<AmdCtx> cur;
+  int users = 0;
+  std::mutex mu;                      // one submitting thread at a time (vvr.h), and the slot table
+};
+enum AmdTaskKind { AMD_ROW, AMD_SUBMIT, AMD_FINISH };
+struct AmdTask { int kind; DecLibRecon* d; Picture* pic; int row; };
 struct AmdInst                        // one per DecLibRecon instance: what the reference's class has no member for
 {
   std::shared_ptr<AmdShared> sh;
+  std::shared_ptr<AmdCtx> ctx;        // the context the picture in progress runs on
   vvr_glue::Extracted desc;
   std::vector<int32_t> dmvrOut;
-  double msMider = 0, msLfInit = 0, msFlatten = 0, msDevice = 0, msReadBack = 0; int pictures = 0;
+  // the picture in progress
+  std::vector<AmdTask> rowTasks; AmdTask submitTask, finishTask;
+  std::unique_ptr<std::atomic<int>[]> rowProgress; int numRows = 0;      // CTUs of every CTU row that have their motion and edge parameters
+  std::atomic<int> job{ -1 };         // -1: not submitted yet, -2: failed before it could be, else the back-end's job
+  std::exception_ptr error;
+  int slot = -1;
+  bool planesPending = false;         // the planes are still to be copied into the Picture's buffers (waitForPrevDecompressedPic)
+  std::atomic<int64_t> usMider{ 0 }, usLfInit{ 0 };      // (summed over the row tasks, which run on several threads)
+  double msMider = 0, msLfInit = 0, msFlatten = 0, msSubmit = 0, msDevice = 0, msReadBack = 0, tSubmitted = 0; int pictures = 0;
 };
 std::mutex g_mu;
 std::map<const ThreadPool*, std::weak_ptr<AmdShared>> g_shared;
@@ -76,6 +106,7 @@ std::map<const DecLibRecon*, std::unique_ptr<AmdInst>> g_inst;
 
 AmdInst& instOf( const DecLibRecon* d ) { std::lock_guard<std::mutex> lk( g_mu ); return *g_inst.at( d ); }
 double nowMs() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
+int envInt( const char* name, int def ) { const char* e = getenv( name ); return e ? atoi( e ) : def; }
 }   // namespace
 
 DecLibRecon::DecLibRecon()
@@ -125,15 +156,26 @@ void DecLibRecon::destroy()
     if( getenv( "VVDEC_AMD_TIMES" ) && it->second->pictures )
       fprintf( stderr, "[vvdec_amd] %d pictures, host ms per picture: MIDER %.2f, LF_INIT %.2f, flatten %.2f, submit+device %.2f, planes back %.2f\n", it->second->pictures,
                it->second->msMider / it->second->pictures, it->second->msLfInit / it->second->pictures, it->second->msFlatten / it->second->pictures,
-               it->second->msDevice / it->second->pictures, it->second->msReadBack / it->second->pictures );
+               ( it->second->msSubmit + it->second->msDevice ) / it->second->pictures, it->second->msReadBack / it->second->pictures );
     g_inst.erase( it );        // (the last instance of a decoder takes the context, hence the DPB in HBM, with it)
   }
 }
 
 void DecLibRecon::swapBufs( CodingStructure& ) {}      // (ALF writes the DPB slot itself on the device: nothing to swap)
 
-// the whole picture as ONE task of the reference's thread pool (or of the main thread when the pool has no threads).  The class declares a private
-// task function, ctuTask (DecLibRecon.h:196-197): its definition here is that task, so it may use the class's members like the reference's does.
+// A picture is a handful of tasks on the reference's own thread pool, all added here (the pool takes tasks from one thread only, ThreadPool.h:67), none of
+// which waits for the device:
+//   one task per CTU ROW   MIDER + LF_INIT of its CTUs, gated on the parser's progress in that row (ctuParsedBarrier, DecLibRecon.cpp:617-620) and on the
+//                          pictures it references; a CTU waits for its above-right neighbour's motion like the reference's MIDER state (:762-805) - a
+//                          row that cannot go on hands its thread back and is called again
+//   the SUBMIT task        behind all rows: the flat description (vvr_extract.h), vvr_submit - which returns at once, the back-end's own workers build
+//                          the device work lists
+//   the FINISH task        ready when vvr_test says the picture is reconstructed: DMVR-refined motion through DecCu::TaskFinishMotionInfo, reconDone
+// so the decoder's DecLibRecon instances (DecLib.h:70) keep as many pictures on the back-end as there are instances, parsing of a picture overlaps with
+// the motion derivation of its upper rows, and no pool thread sleeps.  The planes are copied into the Picture's buffers (output, hash SEI, film grain
+// read them there) by waitForPrevDecompressedPic, on the thread that asks for the picture.
+// The class declares one private task function, ctuTask<onlyCheckReadyState> (DecLibRecon.h:196-197): its definition here is all three tasks and their
+// ready checks, so they may use the class's members like the reference's does.
 void DecLibRecon::decompressPicture( Picture* pcPic )
 {
   m_currDecompPic = pcPic;
@@ -166,140 +208,225 @@ void DecLibRecon::decompressPicture( Picture* pcPic )
     m_motionInfo      = (MotionInfo*) malloc( sizeof( MotionInfo ) * m_num4x4Elements );
   }
   pcPic->startProcessingTimer();
-  // ordered behind: the parser (the whole picture: the simplest correct gate) and every picture it references - their samples live in the
-  // back-end's DPB, but their FINISHED MOTION (TaskFinishMotionInfo) is what MIDER of this picture reads
-  CBarrierVec barriers;
-  barriers.push_back( &pcPic->parseDone );
-  for( Picture* ref : pcPic->buildAllRefPicsVec() ) if( std::find( barriers.cbegin(), barriers.cend(), &ref->reconDone ) == barriers.cend() ) barriers.push_back( &ref->reconDone );
+  AmdInst& I = instOf( this );
+  const int widthInCtus = (int) pcv->widthInCtus, heightInCtus = (int) pcv->heightInCtus;
+  I.numRows = heightInCtus;
+  I.rowProgress.reset( new std::atomic<int>[heightInCtus] );
+  for( int r = 0; r < heightInCtus; r++ ) I.rowProgress[r].store( 0 );
+  I.job.store( -1 ); I.error = nullptr; I.slot = -1; I.planesPending = false;
+  // a caller that hands over pictures whose motion is already derived (the test harness builds its coding units with final motion vectors and binds
+  // the per-CTU motion buffers itself) skips MIDER
   commonTaskParam.cs = &cs;
-  commonTaskParam.perLineMiHist = std::vector<MotionHist>( pcv->heightInCtus );
+  commonTaskParam.perLineMiHist = std::vector<MotionHist>( heightInCtus );
+  // ordered behind every picture it references: their samples live in the back-end's DPB, but their FINISHED MOTION (TaskFinishMotionInfo) is what
+  // MIDER of this picture reads
+  CBarrierVec refBarriers;
+  for( Picture* ref : pcPic->buildAllRefPicsVec() ) if( std::find( refBarriers.cbegin(), refBarriers.cend(), &ref->reconDone ) == refBarriers.cend() ) refBarriers.push_back( &ref->reconDone );
   pcPic->reconDone.lock();
-  taskFinishPic = FinishPicTaskParam( this, pcPic );
-  m_decodeThreadPool->addBarrierTask( TP_TASK_NAME_ARG( "POC:" + std::to_string( pcPic->poc ) + " vvdec_amd picture" )
-                                      ctuTask<false>, &taskFinishPic, &pcPic->m_divTasksCounter, &pcPic->reconDone, std::move( barriers ) );
+  I.rowTasks.assign( heightInCtus, AmdTask{ AMD_ROW, this, pcPic, 0 } );
+  for( int r = 0; r < heightInCtus; r++ )
+  {
+    I.rowTasks[r].row = r;
+    CBarrierVec barriers = refBarriers;
+    if( pcPic->parseDone.isBlocked() )
+    {
+      // wait for the last CTU of the row to be parsed (DecLibRecon.cpp:617-620); a picture without per-CTU barriers: for the whole picture
+      if( (int) pcPic->ctuParsedBarrier.size() >= ( r + 1 ) * widthInCtus ) barriers.push_back( &pcPic->ctuParsedBarrier[( r + 1 ) * widthInCtus - 1] );
+      else barriers.push_back( &pcPic->parseDone );
+    }
+    m_decodeThreadPool->addBarrierTask( TP_TASK_NAME_ARG( "POC:" + std::to_string( pcPic->poc ) + " vvdec_amd row " + std::to_string( r ) )
+                                        ctuTask<false>, &I.rowTasks[r], &pcPic->m_ctuTaskCounter, nullptr, std::move( barriers ), ctuTask<true> );
+  }
+  I.submitTask = AmdTask{ AMD_SUBMIT, this, pcPic, 0 };
+  m_decodeThreadPool->addBarrierTask( TP_TASK_NAME_ARG( "POC:" + std::to_string( pcPic->poc ) + " vvdec_amd submit" )
+                                      ctuTask<false>, &I.submitTask, &pcPic->m_divTasksCounter, nullptr, { pcPic->m_ctuTaskCounter.donePtr(), &pcPic->parseDone } );
+  I.finishTask = AmdTask{ AMD_FINISH, this, pcPic, 0 };
+  m_decodeThreadPool->addBarrierTask( TP_TASK_NAME_ARG( "POC:" + std::to_string( pcPic->poc ) + " vvdec_amd finish" )
+                                      ctuTask<false>, &I.finishTask, &pcPic->m_divTasksCounter, &pcPic->reconDone, { pcPic->m_ctuTaskCounter.donePtr() }, ctuTask<true> );
 }
 
 template<bool onlyCheckReadyState>
 bool DecLibRecon::ctuTask( int tid, void* task_param )
 {
-  FinishPicTaskParam* param = static_cast<FinishPicTaskParam*>( task_param );
-  DecLibRecon&        d     = *param->decLib;
-  Picture*            pic   = param->pic;
+  AmdTask*            T     = static_cast<AmdTask*>( task_param );
+  DecLibRecon&        d     = *T->d;
+  Picture*            pic   = T->pic;
   CodingStructure&    cs    = *pic->cs;
   AmdInst&            I     = instOf( &d );
-  AmdShared&          S     = *I.sh;
   const PreCalcValues& pcv  = *cs.pcv;
   const int numCtu = (int) pcv.sizeInCtus, wCtus = (int) pcv.widthInCtus;
   PerThreadResource&  R     = *d.m_pcThreadResource[std::max( 0, std::min( tid, d.m_numDecThreads - 1 ) )];
-  double t0 = nowMs();
-  // ---- MIDER (DecLibRecon.cpp:763-805).  A caller that hands over pictures whose motion is already derived (the test harness builds its
-  // coding units with final motion vectors and binds the per-CTU motion buffers itself) skips it.
-  bool haveMotion = true;
-  for( int a = 0; a < numCtu && haveMotion; a++ ) haveMotion = cs.getCtuData( a ).motion != nullptr;
-  if( !haveMotion )
-    for( int a = 0; a < numCtu; a++ )
+
+  if( T->kind == AMD_ROW )
+  {
+    // ---- MIDER (DecLibRecon.cpp:763-805) and LF_INIT (:807-829) of one CTU row.  CTU c needs the motion of its left neighbour (this task) and of its
+    // above-right neighbour (the row above has got past c + 1); the edge parameters of a CTU read the motion of the CTUs left of and above it.
+    const int r = T->row;
+    std::atomic<int>& mine = I.rowProgress[r];
+    int c = mine.load( std::memory_order_relaxed );
+    auto aboveAllows = [&]( int col ) { return r == 0 || I.rowProgress[r - 1].load( std::memory_order_acquire ) >= std::min( col + 2, wCtus ); };
+    if( onlyCheckReadyState ) return c >= wCtus || aboveAllows( c );
+    for( ; c < wCtus; c++ )
     {
+      if( !aboveAllows( c ) ) return false;                          // (called again when the pool gets round to it)
+      const int a = r * wCtus + c;
       CtuData& cd = cs.getCtuData( a );
-      cd.motion = &d.m_motionInfo[pcv.num4x4CtuBlks * a];
-      if( !cd.slice->isIntra() || cs.sps->getIBCFlag() )
+      const double t0 = nowMs();
+      if( cd.motion == nullptr )
       {
-        const UnitArea ctuArea = getCtuArea( cs, a % wCtus, a / wCtus, true );
-        R.m_cCuDecoder.TaskDeriveCtuMotionInfo( cs, a, ctuArea, d.commonTaskParam.perLineMiHist[a / wCtus] );
+        cd.motion = &d.m_motionInfo[pcv.num4x4CtuBlks * a];
+        if( !cd.slice->isIntra() || cs.sps->getIBCFlag() )
+        {
+          const UnitArea ctuArea = getCtuArea( cs, c, r, true );
+          R.m_cCuDecoder.TaskDeriveCtuMotionInfo( cs, a, ctuArea, d.commonTaskParam.perLineMiHist[r] );
+        }
+        else memset( NO_WARNING_class_memaccess( cd.motion ), MI_NOT_VALID, sizeof( MotionInfo ) * pcv.num4x4CtuBlks );
       }
-      else memset( NO_WARNING_class_memaccess( cd.motion ), MI_NOT_VALID, sizeof( MotionInfo ) * pcv.num4x4CtuBlks );
+      const double t1 = nowMs();
+      cd.lfParam[0] = &d.m_loopFilterParam[pcv.num4x4CtuBlks * ( 2 * a + 0 )];
+      cd.lfParam[1] = &d.m_loopFilterParam[pcv.num4x4CtuBlks * ( 2 * a + 1 )];
+      memset( cd.lfParam[0], 0, sizeof( LoopFilterParam ) * 2 * pcv.num4x4CtuBlks );
+      d.m_cLoopFilter.calcFilterStrengthsCTU( cs, a );
+      const double t2 = nowMs();
+      I.usMider += (int64_t) ( 1e3 * ( t1 - t0 ) ); I.usLfInit += (int64_t) ( 1e3 * ( t2 - t1 ) );
+      mine.store( c + 1, std::memory_order_release );
     }
-  double t1 = nowMs(); I.msMider += t1 - t0;
-  // ---- LF_INIT (DecLibRecon.cpp:807-829): the edge parameters are an input of the back-end
-  // (the CTUs are independent - the reference runs one task per CTU; here the picture's task fans out over a few threads of its own.  VVDEC_AMD_HOST_THREADS,
-  // default 4: with several pictures in flight the decoder's pool is busy with their tasks)
-  // threads of this picture's host work (LF_INIT, the flattening): as many as the decoder's pool has, at least 4 (VVDEC_AMD_HOST_THREADS overrides)
-  const int hostThreads = getenv( "VVDEC_AMD_HOST_THREADS" ) ? atoi( getenv( "VVDEC_AMD_HOST_THREADS" ) ) : std::min( 16, std::max( 4, d.m_decodeThreadPool ? d.m_decodeThreadPool->numThreads() : 0 ) );
-  vvr_glue::parallelFor( numCtu, hostThreads, [&]( int a )
+    return true;
+  }
+
+  if( T->kind == AMD_SUBMIT )
   {
-    CtuData& cd = cs.getCtuData( a );
-    cd.lfParam[0] = &d.m_loopFilterParam[pcv.num4x4CtuBlks * ( 2 * a + 0 )];
-    cd.lfParam[1] = &d.m_loopFilterParam[pcv.num4x4CtuBlks * ( 2 * a + 1 )];
-    memset( cd.lfParam[0], 0, sizeof( LoopFilterParam ) * 2 * pcv.num4x4CtuBlks );
-    d.m_cLoopFilter.calcFilterStrengthsCTU( cs, a );
-  } );
-  double t2 = nowMs(); I.msLfInit += t2 - t1;
-  // ---- the back-end of this decoder: created with the first picture (its size, sample format and CTU size are the sequence's)
-  int slot = -1, job = -1;
-  {
-    std::string why;
-    if( vvr_glue::checkExpressible( cs, *pic, why ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << why );      // never flattened into something it is not
-    Slice& slice = *pic->slices[0];
-    Reshape* rsp = nullptr;
-    bool lmcs = false;                                                                   // (LMCS is a switch of every slice header: the tables are the picture's)
-    for( const Slice* sl : pic->slices ) lmcs |= sl->getLmcsEnabledFlag();
-    if( cs.sps->getUseReshaper() && lmcs ) rsp = &R.m_cReshaper;                         // (initSlice was called in decompressPicture)
-    if( cs.sps->getUseALF() ) for( Slice* sl : pic->slices ) AdaptiveLoopFilter::reconstructCoeffAPSs( *sl );      // (every slice names its own APSs)
-    std::lock_guard<std::mutex> lk( S.mu );                                              // (one submitting thread at a time: vvr.h)
-    if( !S.ctx )
+    if( onlyCheckReadyState ) return true;
+    // ---- the flat description and the hand-over to the back-end.  Whatever goes wrong is kept for the finish task (which carries reconDone): a task
+    // that throws here would leave the finish task waiting for a job that never comes.
+    try
     {
-      vvr_config cfg; memset( &cfg, 0, sizeof( cfg ) );
-      cfg.abi_version = VVR_ABI_VERSION;
-      cfg.device = getenv( "VVDEC_AMD_DEVICE" ) ? atoi( getenv( "VVDEC_AMD_DEVICE" ) ) : 0;
-      cfg.max_width = (uint16_t) cs.sps->getMaxPicWidthInLumaSamples(); cfg.max_height = (uint16_t) cs.sps->getMaxPicHeightInLumaSamples();
-      cfg.chroma_format = cs.sps->getChromaFormatIdc() == CHROMA_400 ? 0 : 1; cfg.bit_depth = (uint8_t) cs.sps->getBitDepth();
-      cfg.log2_ctu = (uint8_t) getLog2( cs.sps->getMaxCUWidth() );
-      S.numSlots = getenv( "VVDEC_AMD_SLOTS" ) ? atoi( getenv( "VVDEC_AMD_SLOTS" ) ) : 48;       // Picture objects the decoder allocates: DPB size + pictures in flight
-      cfg.num_slots = (uint8_t) S.numSlots; cfg.num_streams = 4; cfg.host_threads = 0; cfg.read_buffers = 2;           // (this task IS the worker thread of its picture)
-      if( vvr_create( &cfg, &S.ctx ) != VVR_OK ) { S.ctx = nullptr; THROW_RECOVERABLE( "vvdec_amd: no MI355X back-end (vvr_create failed)" ); }
-    }
-    auto slotFor = [&S]( const Picture* p ) -> int
-    {
-      auto it = S.slotOf.find( p );
-      if( it == S.slotOf.end() ) { CHECK( S.nextSlot >= S.numSlots, "vvdec_amd: more Picture objects than DPB slots (VVDEC_AMD_SLOTS)" ); it = S.slotOf.emplace( p, S.nextSlot++ ).first; }
-      return it->second;
-    };
-    slot = slotFor( pic );
-    // a reference picture this back-end has not reconstructed - the grey picture the decoder makes up for a missing reference
-    // (DecLibParser::prepareUnavailablePicture), a picture handed in from outside - is uploaded from the Picture's own buffers once
-    for( Picture* ref : pic->buildAllRefPicsVec() )
-      if( S.slotOf.find( ref ) == S.slotOf.end() )
+      AmdShared& S = *I.sh;
+      const double t2 = nowMs();
+      const int hostThreads = envInt( "VVDEC_AMD_HOST_THREADS", std::min( 16, std::max( 4, d.m_decodeThreadPool ? d.m_decodeThreadPool->numThreads() : 0 ) ) );      // threads of the flattening
+      std::string why;
+      if( vvr_glue::checkExpressible( cs, *pic, why ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << why );      // never flattened into something it is not
+      Slice& slice = *pic->slices[0];
+      Reshape* rsp = nullptr;
+      bool lmcs = false;                                                                   // (LMCS is a switch of every slice header: the tables are the picture's)
+      for( const Slice* sl : pic->slices ) lmcs |= sl->getLmcsEnabledFlag();
+      if( cs.sps->getUseReshaper() && lmcs ) rsp = &R.m_cReshaper;                         // (initSlice was called in decompressPicture)
+      if( cs.sps->getUseALF() ) for( Slice* sl : pic->slices ) AdaptiveLoopFilter::reconstructCoeffAPSs( *sl );      // (every slice names its own APSs)
+      std::lock_guard<std::mutex> lk( S.mu );                                              // (one submitting thread at a time: vvr.h)
+      if( !S.cur || !S.cur->holds( *cs.sps ) )
       {
-        const int rs = slotFor( ref );
-        vvr_slot_picture_size( S.ctx, rs, (int) ref->lwidth(), (int) ref->lheight() );      // (a coded video sequence may change its picture size)
+        // the back-end of this coded video sequence: created with its first picture (size, sample format and CTU size are the sequence's).  A
+        // sequence the current context cannot hold gets a new one; the pictures still in flight on the old one keep it alive until they are finished,
+        // pictures of the old sequence that are still referenced are uploaded from their Picture's buffers like any picture this context has not seen.
+        std::shared_ptr<AmdCtx> N = std::make_shared<AmdCtx>();
+        vvr_config cfg; memset( &cfg, 0, sizeof( cfg ) );
+        cfg.abi_version = VVR_ABI_VERSION;
+        cfg.device = envInt( "VVDEC_AMD_DEVICE", 0 );
+        cfg.max_width = N->maxW = (uint16_t) cs.sps->getMaxPicWidthInLumaSamples(); cfg.max_height = N->maxH = (uint16_t) cs.sps->getMaxPicHeightInLumaSamples();
+        cfg.chroma_format = N->chroma = cs.sps->getChromaFormatIdc() == CHROMA_400 ? 0 : 1; cfg.bit_depth = N->bitDepth = (uint8_t) cs.sps->getBitDepth();
+        cfg.log2_ctu = N->log2Ctu = (uint8_t) getLog2( cs.sps->getMaxCUWidth() );
+        N->numSlots = envInt( "VVDEC_AMD_SLOTS", 48 );                                     // Picture objects the decoder keeps: DPB size + pictures in flight (more: least recently used slot is given up)
+        cfg.num_slots = (uint8_t) N->numSlots; cfg.num_streams = 4; cfg.read_buffers = 2;
+        cfg.host_threads = (uint8_t) envInt( "VVDEC_AMD_BACKEND_THREADS", 2 );             // the back-end's own workers build the device work lists: vvr_submit returns at once
+        if( vvr_create( &cfg, &N->ctx ) != VVR_OK ) { N->ctx = nullptr; THROW_RECOVERABLE( "vvdec_amd: no MI355X back-end (vvr_create failed)" ); }
+        N->slots.resize( N->numSlots );
+        S.cur = N;
+      }
+      I.ctx = S.cur;
+      AmdCtx& X = *I.ctx;
+      // the slot of a Picture object; when every slot is taken, the least recently used one that this picture does not need is given up (whoever
+      // references its picture later finds it gone and uploads it from the Picture's buffers)
+      std::vector<const Picture*> needed; needed.push_back( pic );
+      for( Picture* ref : pic->buildAllRefPicsVec() ) needed.push_back( ref );
+      auto slotFor = [&]( const Picture* p, bool* isNew ) -> int
+      {
+        auto it = X.slotOf.find( p );
+        if( isNew ) *isNew = it == X.slotOf.end();
+        if( it == X.slotOf.end() )
+        {
+          int s = -1;
+          for( int k = 0; k < X.numSlots && s < 0; k++ ) if( !X.slots[k].pic ) s = k;
+          if( s < 0 )
+          {
+            for( int k = 0; k < X.numSlots; k++ )
+              if( std::find( needed.begin(), needed.end(), X.slots[k].pic ) == needed.end() && ( s < 0 || X.slots[k].lastUse < X.slots[s].lastUse ) ) s = k;
+            CHECK( s < 0, "vvdec_amd: a picture and its reference pictures need more DPB slots than the back-end has (VVDEC_AMD_SLOTS)" );
+            X.slotOf.erase( X.slots[s].pic );
+          }
+          X.slots[s] = AmdCtx::Slot(); X.slots[s].pic = p;
+          it = X.slotOf.emplace( p, s ).first;
+        }
+        X.slots[it->second].lastUse = ++X.useCounter;
+        return it->second;
+      };
+      I.slot = slotFor( pic, nullptr );
+      // a reference picture whose slot does not hold what the Picture object holds now - a picture this back-end has not reconstructed: the grey
+      // picture the decoder makes up for a missing reference (DecLibParser::prepareUnavailablePicture: a recycled Picture object, no picture header),
+      // a picture of an earlier context, a picture handed in from outside - is uploaded from the Picture's own buffers, once per life of the object
+      for( Picture* ref : pic->buildAllRefPicsVec() )
+      {
+        bool isNew = false;
+        const int rs = slotFor( ref, &isNew );
+        AmdCtx::Slot& sl = X.slots[rs];
+        const bool madeUp = ref->slices.empty() || ref->slices[0]->getPicHeader() == nullptr;
+        const bool current = !isNew && sl.poc == ref->poc && ( sl.ours ? !madeUp : true );
+        if( current ) continue;
+        vvr_slot_picture_size( X.ctx, rs, (int) ref->lwidth(), (int) ref->lheight() );      // (a coded video sequence may change its picture size)
         CPelUnitBuf rb = const_cast<const Picture*>( ref )->getRecoBuf();
         for( size_t c = 0; c < rb.bufs.size(); c++ )
-          if( vvr_write_plane( S.ctx, rs, (int) c, reinterpret_cast<const uint16_t*>( rb.bufs[c].buf ), (size_t) rb.bufs[c].stride ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( S.ctx ) );
+          if( vvr_write_plane( X.ctx, rs, (int) c, reinterpret_cast<const uint16_t*>( rb.bufs[c].buf ), (size_t) rb.bufs[c].stride ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( X.ctx ) );
+        sl.poc = ref->poc; sl.ours = false;
       }
-    double t2b = nowMs();
-    vvr_glue::extractPicture( cs, slice, *pic, rsp, R.m_cTrQuant, [&S]( const Picture* p ) { auto q = S.slotOf.find( p ); return q == S.slotOf.end() ? -1 : q->second; }, slot, I.desc, hostThreads, /* the motion field only where the back-end reads it */ true );
-    double t3 = nowMs(); I.msFlatten += t3 - t2b; t2 = t3;
-    job = vvr_submit( S.ctx, &I.desc.pic );
-    if( job < 0 ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( S.ctx ) );
-  }
-  if( vvr_wait( S.ctx, job ) < 0 ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( S.ctx ) );
-  double t4 = nowMs(); I.msDevice += t4 - t2;
-  // ---- the picture as the rest of the decoder expects it: planes in the Picture's own buffers (output, hash SEI, film grain)
-  {
-    PelUnitBuf reco = pic->getRecoBuf();
-    uint16_t* dst[3] = { nullptr, nullptr, nullptr }; size_t stride[3] = { 0, 0, 0 };
-    for( size_t c = 0; c < reco.bufs.size(); c++ ) { dst[c] = reinterpret_cast<uint16_t*>( reco.bufs[c].buf ); stride[c] = (size_t) reco.bufs[c].stride; }
-    // (this picture only - the others in flight are not waited for -, through pinned staging, rows laid out by the picture's host threads)
-    if( vvr_read_picture( S.ctx, slot, dst, stride, hostThreads ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( S.ctx ) );
-  }
-  double t5 = nowMs(); I.msReadBack += t5 - t4; I.pictures++;
-  // ---- DMVR-refined MVs feed the temporal MV prediction of later pictures: through the reference's own finish step (DecCu.cpp:161)
-  if( pic->stillReferenced && I.desc.numDmvr )
-  {
-    I.dmvrOut.resize( 2 * (size_t) I.desc.numDmvr );
-    vvr_read_dmvr( S.ctx, job, I.dmvrOut.data(), I.desc.numDmvr );
-    for( auto& e : I.desc.dmvrCus )
-    {
-      CodingUnit& cu = *e.first;
-      const int n = std::max( 1, (int) cu.lwidth() >> 4 ) * std::max( 1, (int) cu.lheight() >> 4 );
-      for( int k = 0; k < n; k++ ) cs.m_dmvrMvCache[cu.mvdL0SubPuOff + k] = Mv( I.dmvrOut[2 * ( e.second + k )], I.dmvrOut[2 * ( e.second + k ) + 1] );
-      cu.setDmvrCondition( true );
+      { AmdCtx::Slot& sl = X.slots[I.slot]; sl.poc = pic->poc; sl.ours = true; }
+      const double t2b = nowMs();
+      vvr_glue::extractPicture( cs, slice, *pic, rsp, R.m_cTrQuant, [&X]( const Picture* p ) { auto q = X.slotOf.find( p ); return q == X.slotOf.end() ? -1 : q->second; }, I.slot, I.desc, hostThreads, /* the motion field only where the back-end reads it */ true );
+      const double t3 = nowMs(); I.msFlatten += t3 - t2b;
+      const int job = vvr_submit( X.ctx, &I.desc.pic );
+      if( job < 0 ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( X.ctx ) );
+      I.tSubmitted = nowMs(); I.msSubmit += I.tSubmitted - t3 + ( t2b - t2 );
+      I.job.store( job, std::memory_order_release );
     }
+    catch( ... )
+    {
+      I.error = std::current_exception();
+      I.job.store( -2, std::memory_order_release );
+    }
+    return true;
   }
-  if( pic->stillReferenced ) for( int a = 0; a < numCtu; a++ ) R.m_cCuDecoder.TaskFinishMotionInfo( cs, a, a % wCtus, a / wCtus );
-  cs.deallocTempInternals();
-  pic->stopProcessingTimer();
-  pic->progress = Picture::reconstructed;
-  return true;                                                  // (the pool unlocks reconDone)
+
+  // ---- AMD_FINISH: ready when the back-end says the picture is reconstructed (nobody sleeps in vvr_wait)
+  {
+    const int job = I.job.load( std::memory_order_acquire );
+    if( onlyCheckReadyState )
+    {
+      if( job == -1 ) return false;
+      if( job == -2 ) return true;
+      return vvr_test( I.ctx->ctx, job ) != VVR_NOT_READY;
+    }
+    if( job == -1 ) return false;
+    if( job == -2 ) std::rethrow_exception( I.error );
+    if( vvr_wait( I.ctx->ctx, job ) < 0 ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( I.ctx->ctx ) );        // (returns at once: the status)
+    I.msDevice += nowMs() - I.tSubmitted;
+    I.msMider += 1e-3 * (double) I.usMider.exchange( 0 ); I.msLfInit += 1e-3 * (double) I.usLfInit.exchange( 0 );
+    I.planesPending = true; I.pictures++;
+    // the DMVR-refined MVs feed the temporal MV prediction of later pictures: through the reference's own finish step (DecCu.cpp:161)
+    if( pic->stillReferenced && I.desc.numDmvr )
+    {
+      I.dmvrOut.resize( 2 * (size_t) I.desc.numDmvr );
+      vvr_read_dmvr( I.ctx->ctx, job, I.dmvrOut.data(), I.desc.numDmvr );
+      for( auto& e : I.desc.dmvrCus )
+      {
+        CodingUnit& cu = *e.first;
+        const int n = std::max( 1, (int) cu.lwidth() >> 4 ) * std::max( 1, (int) cu.lheight() >> 4 );
+        for( int k = 0; k < n; k++ ) cs.m_dmvrMvCache[cu.mvdL0SubPuOff + k] = Mv( I.dmvrOut[2 * ( e.second + k )], I.dmvrOut[2 * ( e.second + k ) + 1] );
+        cu.setDmvrCondition( true );
+      }
+    }
+    if( pic->stillReferenced ) for( int a = 0; a < numCtu; a++ ) R.m_cCuDecoder.TaskFinishMotionInfo( cs, a, a % wCtus, a / wCtus );
+    pic->stopProcessingTimer();
+    pic->progress = Picture::reconstructed;
+    return true;                                                  // (the pool unlocks reconDone)
+  }
 }
 template bool DecLibRecon::ctuTask<false>( int, void* );
 template bool DecLibRecon::ctuTask<true>( int, void* );
@@ -307,14 +434,34 @@ template bool DecLibRecon::ctuTask<true>( int, void* );
 Picture* DecLibRecon::waitForPrevDecompressedPic()
 {
   if( !m_currDecompPic ) return nullptr;
+  AmdInst& I = instOf( this );
   try
   {
     if( m_decodeThreadPool->numThreads() == 0 )
     {
+      // everything on the calling thread: the rows and the hand-over, the one wait for the device there is, the finish task
+      m_decodeThreadPool->processTasksOnMainThread();
+      const int job = I.job.load();
+      if( job >= 0 ) vvr_wait( I.ctx->ctx, job );
       m_decodeThreadPool->processTasksOnMainThread();
       CHECK_FATAL( m_currDecompPic->reconDone.isBlocked(), "can't make progress. some dependecy has not been finished" );
     }
     m_currDecompPic->reconDone.wait();
+    // ---- the picture as the rest of the decoder expects it: planes in the Picture's own buffers (output, hash SEI, film grain) - this picture only, the
+    // others in flight are not waited for; through pinned staging, rows laid out by a few threads of this call.  VVDEC_AMD_NO_READBACK=1 (throughput
+    // experiments only: output and hash checks then see stale buffers) leaves it out.
+    if( I.planesPending && !getenv( "VVDEC_AMD_NO_READBACK" ) )
+    {
+      const double t4 = nowMs();
+      PelUnitBuf reco = m_currDecompPic->getRecoBuf();
+      uint16_t* dst[3] = { nullptr, nullptr, nullptr }; size_t stride[3] = { 0, 0, 0 };
+      for( size_t c = 0; c < reco.bufs.size(); c++ ) { dst[c] = reinterpret_cast<uint16_t*>( reco.bufs[c].buf ); stride[c] = (size_t) reco.bufs[c].stride; }
+      const int hostThreads = envInt( "VVDEC_AMD_HOST_THREADS", std::min( 16, std::max( 4, m_decodeThreadPool->numThreads() ) ) );
+      if( vvr_read_picture( I.ctx->ctx, I.slot, dst, stride, hostThreads ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( I.ctx->ctx ) );
+      I.msReadBack += nowMs() - t4;
+    }
+    I.planesPending = false;
+    m_currDecompPic->cs->deallocTempInternals();
   }
   catch( ... )
   {

@@ -9,6 +9,7 @@ import glob
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -29,7 +30,10 @@ def _stub_path():
 def test_exports_are_the_vvdec_api():
     out = subprocess.check_output(["nm", "-D", "--defined-only", refdrv.DROPIN_LIB]).decode()
     exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
-    assert all(n.startswith("vvdec_") for n in exported), [n for n in exported if not n.startswith("vvdec_")]
+    # besides the C API the reference's library exports one C++ function for its application (VVDEC_DECL vvdec::rescalePlane, vvdecimpl.h:289): so does the drop-in
+    cxx = [n for n in exported if not n.startswith("vvdec_")]
+    assert all("rescalePlane" in n for n in cxx) and len(cxx) == 1, cxx
+    exported = [n for n in exported if n.startswith("vvdec_")]
     if os.path.exists(API_H):
         declared = sorted(set(re.findall(r"VVDEC_DECL[^;(]*?\b(vvdec_\w+)\s*\(", open(API_H).read())))
         assert exported == declared, (set(exported) ^ set(declared))
@@ -110,13 +114,63 @@ def test_picture_through_the_dropin_class(threads):
             assert np.array_equal(motion["mv"][l0][:, 0], d.motion["mv"][l0][:, 0])
 
 
+def _conformance_streams():
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import dropin_decode
+    for d in (os.environ.get("VVDEC_BITSTREAMS"), os.path.join(HERE, "..", "ext", "bitstreams"), os.path.join(HERE, "bitstreams")):
+        if d and dropin_decode.find_streams(d):
+            return dropin_decode, d
+    return dropin_decode, None
+
+
+@pytest.mark.gpu
 def test_decodes_conformance_bitstreams():
-    """ext/bitstreams/<name>/<name>.bit + <name>.yuv.md5 (the layout of the reference's conformance download, CMakeLists.txt:536-571): decoded through
-    the drop-in library on the GPU back-end, MD5 of the output == the stored one.  No bitstream is available offline."""
-    streams = sorted(glob.glob(os.path.join(HERE, "..", "ext", "bitstreams", "*", "*.bit")))
-    if not streams:
-        pytest.skip("no conformance bitstreams (ext/bitstreams/) in this environment")
-    pytest.skip("bitstreams present: run tools/dropin_decode.py on a GPU box")
+    """<dir>/<name>/<name>.bit + <name>.yuv.md5 (the layout of the reference's conformance download, CMakeLists.txt:509-571; also tests/bitstreams, where
+    the streams written by tools/mini_vvenc.py live): decoded by the reference's own application on the drop-in library with the GPU back-end behind
+    DecLibRecon, the way the reference's ctest does it - MD5 over the output frames == the stored one, and every decoded picture hash SEI checks"""
+    dd, d = _conformance_streams()
+    if d is None:
+        pytest.skip("no bitstreams (ext/bitstreams/, tests/bitstreams/, $VVDEC_BITSTREAMS) in this environment")
+    if not os.path.exists(dd.APP_DROPIN):
+        pytest.skip("oracle/_ref/vvdecapp_dropin not built")
+    bad = []
+    for b in dd.find_streams(d):
+        r = dd.decode_stream(b, threads=4, with_reference=False)
+        if not r["ok"]:
+            bad.append((r["stream"], r["dropin"].get("tail") or r["dropin_dph"].get("tail")))
+    assert not bad, bad
+
+
+def test_conformance_harness_on_the_stand_in_runtime(tmp_path):
+    """tools/dropin_decode.py end to end without a GPU: the reference's application (oracle/_ref/vvdecapp_dropin) starts on the drop-in library with
+    the stand-in back-end bound the way the tool binds the real one, refuses a stream that is noise without crashing, and the tool reports the
+    stream as failed (an MD5 was expected)"""
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import dropin_decode as dd
+    if not os.path.exists(dd.APP_DROPIN):
+        pytest.skip("oracle/_ref/vvdecapp_dropin not built (needs /root/reference)")
+    d = tmp_path / "noise"
+    d.mkdir()
+    rng = np.random.default_rng(3)
+    (d / "noise.bit").write_bytes(bytes([0, 0, 0, 1]) + bytes(rng.integers(0, 256, 4000, dtype=np.uint8)))
+    (d / "noise.yuv.md5").write_text("0123456789abcdef0123456789abcdef  noise.yuv\n")
+    assert dd.find_streams(str(tmp_path)) == [str(d / "noise.bit")] and dd.expected_md5(str(d / "noise.bit")) == "0123456789abcdef0123456789abcdef"
+    dd.BACKEND = _stub_path()
+    r = dd.decode_stream(str(d / "noise.bit"), threads=2, with_reference=False)
+    assert r["dropin"]["rc"] not in (-11, 139, 134) and not r["ok"], r            # no crash; nothing decodable, so the stored MD5 cannot match
+    v, _ = dd.run_app(dd.APP_DROPIN, ["--version"], preload=_stub_path())
+    assert v.returncode == 0 and re.search(r"\d+\.\d+", v.stdout + v.stderr)
+
+
+def test_reference_unit_test_on_the_dropin_object_set():
+    """the reference's own unit test (tests/vvdec_unit_test/vvdec_unit_test.cpp: scalar-vs-SIMD differential tests of its kernels), linked with
+    the objects the drop-in library is made of - all of the reference's except DecoderLib/DecLibRecon.o, plus integration/DecLibReconDropIn.cpp
+    (`make -C oracle unit_test`): passes"""
+    exe = os.path.join(os.path.dirname(refdrv.DROPIN_LIB), "vvdec_unit_test_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/vvdec_unit_test_dropin not built (needs /root/reference)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "success: all tests passed!" in r.stdout, (r.stdout[-800:], r.stderr[-400:])
 
 
 def test_pictures_with_scaled_reference_pictures_through_the_dropin_class():

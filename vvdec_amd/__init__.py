@@ -56,6 +56,7 @@ def lib():
             getattr(L, f).restype = C.c_int
         L.vvr_destroy.argtypes = [C.c_void_p]
         L.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+        L.vvr_test.argtypes = [C.c_void_p, C.c_int]
         L.vvr_sync.argtypes = [C.c_void_p]
         L.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
         L.vvr_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -88,7 +89,7 @@ def lib():
     return _lib
 
 
-EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
+EXPORTED_SYMBOLS = ["vvr_version", "vvr_create", "vvr_destroy", "vvr_submit", "vvr_wait", "vvr_test", "vvr_sync", "vvr_slot_bytes", "vvr_plane_layout",
                     "vvr_plane_ptr", "vvr_read_plane", "vvr_read_output", "vvr_picture_hash", "vvr_write_plane", "vvr_read_dmvr", "vvr_read_col_motion", "vvr_prepare", "vvr_submit_prepared",
                     "vvr_free_prepared", "vvr_job_stream", "vvr_last_error", "vvr_enable_stats", "vvr_get_stats", "vvr_resolve_tr_type", "vvr_abi_sizeof",
                     "vvr_inputs_done", "vvr_measure_copy_bandwidth", "vvr_host_alloc", "vvr_host_free",
@@ -139,6 +140,14 @@ class Reconstructor:
     def submit_c(self, p):
         """vvr_submit of a ctypes abi.Picture built beforehand (`desc.c()`); the caller keeps the description alive until wait()"""
         return self._check(self.L.vvr_submit(self.ctx, C.byref(p)))
+
+    def test(self, job):
+        """vvr_test: True when `job` is reconstructed (wait() returns at once), False when it is not yet; raises if it failed"""
+        rc = self.L.vvr_test(self.ctx, job)
+        if rc == abi.VVR_NOT_READY:
+            return False
+        self._check(rc)
+        return True
 
     def wait(self, job):
         try:

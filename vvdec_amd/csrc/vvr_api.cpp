@@ -1196,6 +1196,24 @@ VVR_API int vvr_wait( vvr_context* c, int job )
   return finishJob( c, job );
 }
 
+VVR_API int vvr_test( vvr_context* c, int job )
+{
+  if( !c ) return VVR_ERR_PARAMETER;
+  hipSetDevice( c->device );
+  std::lock_guard<std::mutex> lk( c->mu );
+  auto it = c->jobs.find( job );
+  if( it == c->jobs.end() ) return VVR_OK;          // retired: finished long ago
+  Job& j = *it->second;
+  if( !j.completed )
+  {
+    if( j.state == J_FAILED ) { c->setError( j.err ); return j.rc; }
+    if( j.state != J_COMMITTED || !j.doneHost || hipEventQuery( j.doneHost ) != hipSuccess ) return VVR_NOT_READY;
+    completeLocked( c, j );
+  }
+  if( j.state == J_FAILED ) { c->setError( j.err ); return j.rc; }
+  return VVR_OK;
+}
+
 VVR_API int vvr_sync( vvr_context* c )
 {
   if( !c ) return VVR_ERR_PARAMETER;

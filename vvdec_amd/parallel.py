@@ -136,6 +136,21 @@ def dependants(plans, owners):
     return [sorted(d) for d in deps]
 
 
+def strong_scaling_ceiling(plans, cost):
+    """What sharding ONE stream by picture can reach at best, whatever the number of ranks: total work / critical path of the pictures'
+    dependency graph (a picture starts when its reference pictures are done - DecLibRecon's whole-picture gating, DecLibRecon.cpp:460-489).
+    cost(plan) = time of one picture alone on a device.  Returns (ceiling, total, critical)."""
+    done = {}
+    total = critical = 0.0
+    for pl in plans:
+        c = float(cost(pl))
+        start = max([done.get(poc, 0.0) for poc in list(pl.l0 or []) + list(pl.l1 or [])], default=0.0)
+        done[pl.poc] = start + c
+        total += c
+        critical = max(critical, done[pl.poc])
+    return (total / critical if critical else 1.0), total, critical
+
+
 class TorchDeviceRuntime:
     """streams and events of the collective on a GPU: one torch stream the RCCL operations are ordered on"""
 
