@@ -55,9 +55,7 @@
 #include "CommonLib/AdaptiveLoopFilter.h"
 #include "CommonLib/RdCost.h"
 #include "DecoderLib/DecCu.h"
-#ifdef VVREF_WITH_DROPIN
 #include "DecoderLib/DecLibRecon.h"
-#endif
 #include "CommonLib/TrQuant_EMT.h"
 #include "CommonLib/x86/CommonDefX86.h"
 #undef private
@@ -75,6 +73,98 @@ uint32_t calcChecksum( const CPelUnitBuf& pic, PictureHash& digest, const BitDep
 #include "../integration/DecLibReconAmd.h"   // compiled only: keeps the binding of INTEGRATION.md in step with both sides
 
 using namespace vvdec;
+
+
+#ifndef VVREF_WITH_DROPIN
+// The reference's own multithreaded reconstruction of one picture - the CPU path the GPU back-end is measured against (bench.py cpu_baseline).  What
+// DecLibRecon::decompressPicture (DecLibRecon.cpp:429-682) does, restated with ONE difference: the CTU tasks start in state LF_INIT instead of MIDER
+// (the harness builds coding units that carry their final motion - there is nothing for the motion derivation to derive from - and binds the per-CTU
+// motion buffers itself).  Everything else is the reference's: its per-thread tool sets, its SAO / ALF objects and filter buffer, its 15-state CTU
+// task DecLibRecon::ctuTask (:732-1110) with the wavefront dependencies between the states, scheduled in its zig-zag order on its ThreadPool
+// (Utilities/ThreadPool.cpp), its finish task (swapBufs, reconDone).  Reference pictures come with their borders extended (buildRefPic).
+static void decompressFromLfInit( DecLibRecon& r, Picture* pcPic )
+{
+  r.m_currDecompPic = pcPic;
+  CodingStructure& cs = *pcPic->cs;
+  pcPic->progress = Picture::reconstructing;
+  const SPS* sps = cs.sps.get();
+  const PPS* pps = cs.pps.get();
+  const PreCalcValues* pcv0 = cs.pcv;
+  for( int i = 0; i < r.m_numDecThreads; i++ )
+  {
+    auto& R = *r.m_pcThreadResource[i];
+    if( sps->getUseReshaper() )
+    {
+      R.m_cReshaper.createDec( sps->getBitDepth() );
+      R.m_cReshaper.initSlice( pcPic->slices[0]->getNalUnitLayerId(), *pcPic->slices[0]->getPicHeader(), pcPic->slices[0]->getVPS_nothrow() );
+    }
+    R.m_cIntraPred.init( sps->getChromaFormatIdc(), sps->getBitDepth() );
+    R.m_cInterPred.init( &r.m_cRdCost, sps->getChromaFormatIdc(), sps->getMaxCUHeight() );
+    R.m_cTrQuant.init( pcPic );
+    R.m_cCuDecoder.init( &R.m_cIntraPred, &R.m_cInterPred, &R.m_cReshaper, &R.m_cTrQuant );
+  }
+  // (getCompatibleBuffer, :207-234, for a fresh instance: the filter buffer has the picture's geometry)
+  if( r.m_fltBuf.bufs.empty() ) r.m_fltBuf.create( cs.picture->chromaFormat, cs.picture->lumaSize(), pcv0->maxCUWidth, cs.picture->margin, MEMORY_ALIGN_DEF_SIZE, true, pcPic->getUserAllocator() );
+  const PreCalcValues* pcv = cs.pcv;
+  r.m_cSAO.create( pps->getPicWidthInLumaSamples(), pps->getPicHeightInLumaSamples(), sps->getChromaFormatIdc(), sps->getMaxCUWidth(), sps->getMaxCUHeight(),
+                   getLog2( sps->getMaxCUWidth() ) - pcv->minCUWidthLog2, (uint32_t) std::max( 0, sps->getBitDepth() - MAX_SAO_TRUNCATED_BITDEPTH ), r.m_fltBuf );
+  if( sps->getUseALF() ) r.m_cALF.create( cs.picHeader.get(), sps, pps, r.m_numDecThreads, r.m_fltBuf );
+  const ptrdiff_t lumaCtu = (ptrdiff_t) pcv->maxCUHeight * pcv->maxCUWidth;
+  const size_t predSize = (size_t) ( lumaCtu + ( isChromaEnabled( pcv->chrFormat ) ? 2 * ( lumaCtu >> 2 ) : 0 ) ) * pcv->sizeInCtus;
+  if( predSize != r.m_predBufSize ) { r.m_predBuf.reset( (Pel*) xMalloc( Pel, predSize ) ); r.m_predBufSize = predSize; }
+  cs.m_predBuf = r.m_predBuf.get();
+  const size_t maxDmvr = (size_t) pcv->num8x8CtuBlks * pcv->sizeInCtus;
+  if( maxDmvr != r.m_dmvrMvCacheSize ) { if( r.m_dmvrMvCache ) free( r.m_dmvrMvCache ); r.m_dmvrMvCacheSize = maxDmvr; r.m_dmvrMvCache = (Mv*) malloc( sizeof( Mv ) * maxDmvr ); }
+  cs.m_dmvrMvCache = r.m_dmvrMvCache;
+  if( r.m_num4x4Elements != (ptrdiff_t) ( pcv->num4x4CtuBlks * pcv->sizeInCtus ) )
+  {
+    if( r.m_loopFilterParam ) free( r.m_loopFilterParam );
+    if( r.m_motionInfo ) free( r.m_motionInfo );
+    r.m_num4x4Elements  = pcv->num4x4CtuBlks * pcv->sizeInCtus;
+    r.m_loopFilterParam = (LoopFilterParam*) malloc( sizeof( LoopFilterParam ) * r.m_num4x4Elements * 2 );
+    r.m_motionInfo      = (MotionInfo*) malloc( sizeof( MotionInfo ) * r.m_num4x4Elements );
+  }
+  const int wCtus = (int) pcv->widthInCtus, hCtus = (int) pcv->heightInCtus;
+  pcPic->startProcessingTimer();
+  r.picBarriers.clear();
+  const bool allIntra = std::all_of( pcPic->slices.begin(), pcPic->slices.end(), []( const Slice* sl ) { return sl->isIntra(); } );
+  const int colsPerTask  = std::max( std::min( wCtus, ( wCtus / std::max( r.m_numDecThreads * ( allIntra ? 2 : 1 ), 1 ) ) + ( allIntra ? 0 : 1 ) ), 1 );      // (:588)
+  const int tasksPerLine = wCtus / colsPerTask + !!( wCtus % colsPerTask );
+  pcPic->refPicExtDepBarriers.clear();
+  const bool doALF = sps->getUseALF() && !AdaptiveLoopFilter::getAlfSkipPic( cs );
+  r.commonTaskParam.reset( cs, LF_INIT, tasksPerLine, doALF );                                   // <- MIDER in the reference
+  r.tasksFinishMotion = std::vector<LineTaskParam>( hCtus, LineTaskParam{ r.commonTaskParam, -1 } );
+  r.tasksCtu          = std::vector<CtuTaskParam >( (size_t) hCtus * tasksPerLine, CtuTaskParam{ r.commonTaskParam, -1, -1, {} } );
+  pcPic->reconDone.lock();
+  for( int diag = 0; diag < tasksPerLine + hCtus; ++diag )                                       // zig-zag order (:611-650)
+  {
+    int line = 0;
+    for( int col = diag; col >= 0; --col, ++line )
+    {
+      if( line >= hCtus || col >= tasksPerLine ) continue;
+      CtuTaskParam* param    = &r.tasksCtu[(size_t) line * tasksPerLine + col];
+      param->taskLine        = line;
+      param->taskCol         = col;
+      param->ctuStart        = col * colsPerTask;
+      param->ctuEnd          = std::min( param->ctuStart + colsPerTask, wCtus );
+      param->numColPerTask   = colsPerTask;
+      param->numTasksPerLine = tasksPerLine;
+      r.m_decodeThreadPool->addBarrierTask( TP_TASK_NAME_ARG( "ctuTask" ) DecLibRecon::ctuTask<false>, param, &pcPic->m_ctuTaskCounter, nullptr, CBarrierVec( r.picBarriers ), DecLibRecon::ctuTask<true> );
+    }
+  }
+  static auto finishTask = []( int, void* p )                                                    // (:653-676)
+  {
+    FinishPicTaskParam* param = static_cast<FinishPicTaskParam*>( p );
+    CodingStructure& pcs = *param->pic->cs;
+    if( pcs.sps->getUseALF() && !AdaptiveLoopFilter::getAlfSkipPic( pcs ) ) param->decLib->swapBufs( pcs );
+    param->pic->stopProcessingTimer();
+    param->pic->progress = Picture::reconstructed;
+    return true;
+  };
+  r.taskFinishPic = FinishPicTaskParam( &r, pcPic );
+  r.m_decodeThreadPool->addBarrierTask( TP_TASK_NAME_ARG( "finishPicTask" ) finishTask, &r.taskFinishPic, &pcPic->m_divTasksCounter, &pcPic->reconDone, { pcPic->m_ctuTaskCounter.donePtr() } );
+}
+#endif
 
 extern "C" {
 
@@ -137,6 +227,9 @@ static void fillPlane( PelBuf dst, const uint16_t* src, int w, int h )
 //   dmvr_out              : optional, receives m_dmvrMvCache entries (hor,ver) in CU order (cu.dmvr_off)
 //   stage_ms[8]           : optional wall time per stage {trafo+inter, intra, rsp, lf_v, lf_h, sao, alf, total}
 __attribute__((visibility("default")))
+// vvref_reconstruct_threaded: the picture through the reference's own scheduler (ThreadPool + DecLibRecon::ctuTask) on `threads` threads
+struct ThreadedRun { int threads; double ms; };
+static ThreadedRun* g_threaded = nullptr;
 static int g_extraFlags = 0;      // VVREF_* flags for the entry points that have no flags argument (vvref_run_binding / vvref_run_dropin)
 extern "C" __attribute__((visibility("default"))) void vvref_set_extra_flags( int f ) { g_extraFlags = f; }
 
@@ -891,6 +984,37 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       return 0;
     }
 #endif
+#ifndef VVREF_WITH_DROPIN
+    if( g_threaded )
+    {
+      // the reference's own scheduler on g_threaded->threads threads (0: everything on the calling thread); timed: set-up of the picture's tools,
+      // LF_INIT, all CTU tasks, the finish task - what DecLibRecon::decompressPicture + waitForPrevDecompressedPic take for a parsed picture
+      for( auto& kv : refPics ) kv.second->reconDone.unlock();
+      pic.parseDone.unlock();
+      const int nc = cf == CHROMA_400 ? 1 : 3;
+      {
+        ThreadPool pool( g_threaded->threads, "ref" );
+        DecLibRecon rec;
+        rec.create( &pool, 0, false );
+        const auto t0 = std::chrono::steady_clock::now();
+        decompressFromLfInit( rec, &pic );
+        Picture* done = rec.waitForPrevDecompressedPic();
+        g_threaded->ms = std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count();
+        CHECK( done != &pic, "the reference's scheduler did not hand the picture back" );
+        if( pic.reconDone.hasException() ) std::rethrow_exception( pic.reconDone.getException() );
+        for( int c = 0; c < nc; c++ )
+        {
+          if( !out_planes[c] ) continue;
+          const CPelBuf b = const_cast<const Picture&>( pic ).getRecoBuf( ComponentID( c ) );
+          for( int y = 0; y < (int) b.height; y++ ) for( int x = 0; x < (int) b.width; x++ ) out_planes[c][(size_t) y * b.width + x] = (uint16_t) b.at( x, y );
+        }
+        cs.m_predBuf = nullptr; cs.m_dmvrMvCache = nullptr;
+        for( int a = 0; a < numCtu; a++ ) { CtuData& cd = cs.getCtuData( a ); cd.motion = nullptr; cd.lfParam[0] = cd.lfParam[1] = nullptr; }
+        rec.destroy();
+      }
+      return 0;
+    }
+#endif
     if( g_extractTo )
     {
       { std::string why; CHECK( vvr_glue::checkExpressible( cs, pic, why ) != VVR_OK, why ); }
@@ -1110,6 +1234,20 @@ int vvref_run_dropin( const vvr_picture* vp, const uint16_t* const* ref_planes, 
   uint16_t* none[3] = { nullptr, nullptr, nullptr };
   const int rc = vvref_reconstruct( vp, ref_planes, none, nullptr, nullptr, 0, nullptr );
   g_dropin = nullptr; g_motionOut = nullptr;
+  return rc;
+}
+#endif
+
+#ifndef VVREF_WITH_DROPIN
+// one picture through the reference's own multithreaded reconstruction (decompressFromLfInit above) on `threads` pool threads; *ms = wall clock of it
+__attribute__((visibility("default")))
+int vvref_reconstruct_threaded( const vvr_picture* vp, const uint16_t* const* ref_planes, uint16_t* const* out_planes, int threads, double* ms )
+{
+  ThreadedRun run{ threads, 0.0 };
+  g_threaded = &run;
+  const int rc = vvref_reconstruct( vp, ref_planes, out_planes, nullptr, nullptr, 0, nullptr );
+  g_threaded = nullptr;
+  if( ms ) *ms = run.ms;
   return rc;
 }
 #endif

@@ -58,6 +58,26 @@ def reconstruct(desc, refs=None, flags=0, want_lfp=False, want_dmvr=0):
     return dict(planes=outs, ms=list(ms), lfp=lfps, dmvr=dmvr)
 
 
+def reconstruct_threaded(desc, refs=None, threads=4):
+    """the picture through the reference's OWN scheduler: DecLibRecon's per-picture set-up and its 15-state CTU task (DecLibRecon.cpp:429-1110) on its
+    ThreadPool with `threads` threads (0: the calling thread), the tasks starting at LF_INIT (the harness hands over final motion).
+    -> dict(planes, ms = wall clock of decompressPicture + waitForPrevDecompressedPic)"""
+    L = lib()
+    p = desc.c()
+    ref_ptrs, keep, _ = _ref_ptrs(refs or {})
+    ncomp = 3 if desc.hdr.chroma_format else 1
+    outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
+    out_ptrs = (C.POINTER(C.c_uint16) * 3)()
+    for c in range(ncomp):
+        out_ptrs[c] = outs[c].ctypes.data_as(C.POINTER(C.c_uint16))
+    ms = C.c_double()
+    L.vvref_reconstruct_threaded.restype = C.c_int
+    rc = L.vvref_reconstruct_threaded(C.byref(p), ref_ptrs, out_ptrs, int(threads), C.byref(ms))
+    if rc != 0:
+        raise RuntimeError("vvref_reconstruct_threaded failed: " + L.vvref_last_error().decode())
+    return dict(planes=outs, ms=ms.value)
+
+
 def _ref_ptrs(refs):
     nslots = (max(refs.keys()) + 1) if refs else 0
     ref_ptrs = (C.POINTER(C.c_uint16) * max(1, nslots * 3))()

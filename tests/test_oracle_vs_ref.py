@@ -579,3 +579,23 @@ def test_random_scaled_reference_pictures_fixed_seed_slice(built):
         assert all(np.array_equal(a, b) for a, b in zip(got, want)), "case %d" % it
         n += 1
     assert n >= 5
+
+
+@pytest.mark.parametrize("threads", [0, 3])
+def test_reference_scheduler_equals_the_serial_stages(threads):
+    """the CPU baseline of bench.py drives the reference's own scheduler - DecLibRecon's set-up and ctuTask state machine on its ThreadPool, started at
+    LF_INIT (oracle/ref_harness.cpp::decompressFromLfInit) -: its pictures equal what the harness gets by calling the stage functions one after the
+    other (which is what the oracle is pinned against), for an I picture and a B picture with every tool"""
+    W, H = 416, 240
+    plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    ALL = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST | abi.TOOL_BDOF | abi.TOOL_DMVR |
+           abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE)
+    for idx, kw in ((0, dict(p_cclm=0.3, p_mip=0.2, p_isp=0.1)), (2, dict(p_intra=0.2, p_affine=0.15, p_geo=0.1, p_ciip=0.1, p_sbtmvp=0.1, p_bcw=0.1, p_jccr=0.2))):
+        pl = plans[idx]
+        d = synth.picture_for_plan(pl, W, H, seed=905 + idx, tool_flags=ALL, log2_ctu=6, **kw)
+        refs = {slot: synth.natural_picture(W, H, 910 + poc) for lst in pl.ref_slots for (slot, poc) in lst}
+        serial = refdrv.reconstruct(d, refs, flags=refdrv.SIMD | refdrv.DERIVE_LFP)
+        threaded = refdrv.reconstruct_threaded(d, refs, threads=threads)
+        assert threaded["ms"] > 0
+        for c in range(3):
+            assert np.array_equal(serial["planes"][c], threaded["planes"][c]), "component %d of picture %d differs between the reference's scheduler and its stages called in turn" % (c, idx)
