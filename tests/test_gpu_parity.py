@@ -257,6 +257,46 @@ def test_config3_8k_and_config5_all_intra(built):
     rec.close()
 
 
+def _pictures_against_the_oracle(W, H, plans, nslots, mix, tools, seed, lanes, threads):
+    """the pictures of a plan through the asynchronous path (worker threads, several pictures in flight, records in pinned memory), every picture
+    kept in a slot of its own; then picture by picture against the CPU oracle, which consumes its own previous outputs as reference pictures"""
+    import vvdec_amd
+    rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=lanes, host_threads=threads)
+    assert len({pl.slot for pl in plans}) == len(plans), "every picture needs a slot of its own here"
+    descs = [synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, alloc=rec.host_array, **mix) for pl in plans]
+    jobs = [rec.decompress_picture(d) for d in descs]
+    rec.sync()
+    cpu = {}
+    for pl, d, job in zip(plans, descs, jobs):
+        got = rec.read_picture(pl.slot)
+        want = refdrv.oracle_reconstruct(d, cpu)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "%dx%d POC %d comp %d: %d samples differ" % (W, H, pl.poc, c, int((got[c] != want[c]).sum()))
+        cpu[pl.slot] = want
+        nd = getattr(d, "num_dmvr", 0)
+        if nd:
+            assert np.array_equal(rec.read_dmvr(job, nd), refdrv.oracle_dmvr(nd)), "POC %d: DMVR delta MVs differ" % pl.poc
+    rec.close()
+    return len(plans)
+
+
+def test_baseline_sizes_picture_by_picture(built):
+    """Parity at BASELINE.json's sizes, every picture against the oracle, on the benchmark's own streams (bench.CONFIGS / bench.MIX): one full GOP 32 of
+    config 2 (the IRAP + 32 B pictures of six temporal layers at 3840x2160), 8 pictures of config 5 (4K all-intra, dual tree), 4 pictures of config 3
+    (7680x4320)"""
+    import bench
+    tools = bench._tools(abi)
+    W, H, mix, _, _ = bench.CONFIGS["4k"]
+    plans, nslots = stream.ra_plan(33, gop=32, seed_poc0_is_external=False, pool=40)
+    assert _pictures_against_the_oracle(W, H, plans, max(nslots, 40), mix, tools, 1234, lanes=4, threads=8) == 33
+    W, H, mix, _, _ = bench.CONFIGS["allintra"]
+    plans = [stream.PicPlan(poc=i, layer=0, slice_type=abi.SLICE_I, slot=i, ref_slots=([], [])) for i in range(8)]
+    assert _pictures_against_the_oracle(W, H, plans, 8, mix, tools, 1234, lanes=4, threads=8) == 8
+    W, H, mix, _, _ = bench.CONFIGS["8k"]
+    plans, nslots = stream.ra_plan(5, gop=4, seed_poc0_is_external=False, pool=8)
+    assert _pictures_against_the_oracle(W, H, plans[:4], max(nslots, 8), mix, tools, 1234, lanes=2, threads=8) == 4
+
+
 def test_dual_tree_intra_pictures(built):
     """I pictures with separate luma and chroma coding trees (qtbtt_dual_tree_intra_flag): chroma CUs with derived / CCLM modes and
     their own LFNST, chroma edges of the deblocking from the chroma tree; the B pictures that follow are single tree"""
