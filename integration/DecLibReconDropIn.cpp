@@ -94,6 +94,7 @@ struct AmdInst                        // one per DecLibRecon instance: what the 
   std::vector<AmdTask> rowTasks; AmdTask submitTask, finishTask;
   std::unique_ptr<std::atomic<int>[]> rowProgress; int numRows = 0;      // CTUs of every CTU row that have their motion and edge parameters
   std::atomic<int> job{ -1 };         // -1: not submitted yet, -2: failed before it could be, else the back-end's job
+  std::mutex jobMu; std::condition_variable jobCv;      // the thread that asks for the picture waits here for the hand-over
   std::exception_ptr error;
   int slot = -1;
   bool planesPending = false;         // the planes are still to be copied into the Picture's buffers (waitForPrevDecompressedPic)
@@ -384,13 +385,14 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
       const int job = vvr_submit( X.ctx, &I.desc.pic );
       if( job < 0 ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( X.ctx ) );
       I.tSubmitted = nowMs(); I.msSubmit += I.tSubmitted - t3 + ( t2b - t2 );
-      I.job.store( job, std::memory_order_release );
+      { std::lock_guard<std::mutex> jl( I.jobMu ); I.job.store( job, std::memory_order_release ); }
     }
     catch( ... )
     {
       I.error = std::current_exception();
-      I.job.store( -2, std::memory_order_release );
+      { std::lock_guard<std::mutex> jl( I.jobMu ); I.job.store( -2, std::memory_order_release ); }
     }
+    I.jobCv.notify_all();
     return true;
   }
 
@@ -445,6 +447,20 @@ Picture* DecLibRecon::waitForPrevDecompressedPic()
       if( job >= 0 ) vvr_wait( I.ctx->ctx, job );
       m_decodeThreadPool->processTasksOnMainThread();
       CHECK_FATAL( m_currDecompPic->reconDone.isBlocked(), "can't make progress. some dependecy has not been finished" );
+    }
+    else if( m_currDecompPic->reconDone.isBlocked() )
+    {
+      // The finish task is polled by the pool's threads while they look for work (its ready check is vvr_test) - but a pool that has been idle for a few
+      // milliseconds goes to sleep until a task is added (ThreadPool.cpp:241-256), and nothing tells it that the device is done.  The thread that
+      // asks for the picture is the one that may wait: for the hand-over, then for the device (vvr_wait), then it wakes the pool with an empty task.
+      {
+        std::unique_lock<std::mutex> jl( I.jobMu );
+        I.jobCv.wait( jl, [&]{ return I.job.load( std::memory_order_acquire ) != -1 || !m_currDecompPic->reconDone.isBlocked(); } );
+      }
+      const int job = I.job.load( std::memory_order_acquire );
+      if( job >= 0 ) vvr_wait( I.ctx->ctx, job );
+      static auto wakeUp = []( int, void* ) { return true; };
+      m_decodeThreadPool->addBarrierTask( TP_TASK_NAME_ARG( "vvdec_amd wake-up" ) wakeUp, nullptr );
     }
     m_currDecompPic->reconDone.wait();
     // ---- the picture as the rest of the decoder expects it: planes in the Picture's own buffers (output, hash SEI, film grain) - this picture only, the

@@ -1,0 +1,629 @@
+#!/usr/bin/env python3
+"""mini_vvenc.py - a deliberately small VVC (H.266) bitstream WRITER: TEST INFRASTRUCTURE, not an encoder anyone would ship.
+
+Why it exists: no VVC bitstream is available offline and no encoder is installed, so until now no picture that the reference's own PARSER
+(DecLibParser / HLSyntaxReader / CABACReader) produced had ever gone through the drop-in reconstruction stage.  This tool writes conforming Annex-B
+streams with random content - it chooses SYNTAX ELEMENT VALUES at random (split flags, MPM flags and indices, chroma mode indices, coded block
+flags, coefficient levels) and entropy-codes them; it never derives a prediction mode or reconstructs a sample.  What the values mean is decided by
+the decoder: the reference's own decoder (oracle/_ref/vvdecapp_ref, built from /root/reference) decodes each stream here and its output MD5 becomes
+the stream's `.yuv.md5` - the ground truth the drop-in decoder on the GPU back-end is then held to (tools/dropin_decode.py,
+tests/test_dropin_library.py::test_decodes_conformance_bitstreams).
+
+Syntax written (everything else is switched off in the parameter sets):
+  * SPS / PPS (HLSyntaxReader::parseSPS / parsePPS), one IDR slice per picture with the picture header inside the slice header (parseSliceHeader /
+    parsePictureHeader), Main 10, 4:2:0, 8 or 10 bit, CTU 32 / 64 / 128, single tree, quad-tree splits only;
+  * per CTU (CABACReader::coding_tree_unit): split_cu_flag, intra_luma_mpm_flag / intra_luma_not_planar_flag / intra_luma_mpm_idx /
+    intra_luma_mpm_remainder, intra_chroma_pred_mode, tu_cb_coded_flag / tu_cr_coded_flag / tu_y_coded_flag, residual_coding restricted to the first
+    coefficient group with levels up to 3 (last_sig_coeff_{x,y}_prefix, sig_coeff_flag, abs_level_gtx_flag[0 / 1], par_level_flag, coeff_sign_flag),
+    the implicit transform split of CUs larger than the maximum transform size; deblocking stays on.
+  * CABAC: the arithmetic encoder of the standard (9.3.4) with the two-rate probability model of Contexts.h; initial values of the context sets are
+    read from the reference's table (CommonLib/Contexts.cpp) when this tool runs.
+
+  python tools/mini_vvenc.py --out tests/bitstreams [--seed N]     writes the fixture set (needs /root/reference for the context tables and
+                                                                    oracle/_ref/vvdecapp_ref for the MD5s)
+"""
+import argparse
+import hashlib
+import os
+import random
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("VVDEC_REFERENCE", "/root/reference")
+APP_REF = os.path.join(ROOT, "oracle", "_ref", "vvdecapp_ref")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bits
+# ---------------------------------------------------------------------------------------------------------------------
+class Bits:
+    def __init__(self):
+        self.b = []
+
+    def u(self, n, v):
+        assert 0 <= v < (1 << n), (n, v)
+        for i in range(n - 1, -1, -1):
+            self.b.append((v >> i) & 1)
+
+    def flag(self, v):
+        self.b.append(1 if v else 0)
+
+    def ue(self, v):
+        assert v >= 0
+        v += 1
+        n = v.bit_length()
+        self.u(n - 1, 0)
+        self.u(n, v)
+
+    def se(self, v):
+        self.ue(2 * v - 1 if v > 0 else -2 * v)
+
+    def aligned(self):
+        return len(self.b) % 8 == 0
+
+    def align_zero(self):
+        while not self.aligned():
+            self.b.append(0)
+
+    def trailing(self):              # rbsp_trailing_bits / byte_alignment(): a one, then zeros
+        self.b.append(1)
+        self.align_zero()
+
+    def bytes(self):
+        assert self.aligned()
+        return bytes(int("".join(map(str, self.b[i:i + 8])), 2) for i in range(0, len(self.b), 8))
+
+
+def nal(nal_type, payload, long_start=False, tid=0):
+    """NAL unit header (7.3.1.2) + payload with emulation prevention, behind an Annex-B start code"""
+    hdr = bytes([0, (nal_type << 3) | (tid + 1)])          # forbidden_zero_bit, nuh_reserved_zero_bit, nuh_layer_id = 0; type; temporal id + 1
+    out = bytearray()
+    zeros = 0
+    for byte in hdr + payload:
+        if zeros >= 2 and byte <= 3:
+            out.append(3)
+            zeros = 0
+        out.append(byte)
+        zeros = zeros + 1 if byte == 0 else 0
+    return (b"\x00\x00\x00\x01" if long_start else b"\x00\x00\x01") + bytes(out)
+
+
+NAL_IDR_N_LP, NAL_SPS, NAL_PPS = 8, 15, 16
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CABAC
+# ---------------------------------------------------------------------------------------------------------------------
+def load_context_tables():
+    """{set name: [rows B, P, I, rate]} and the renormalisation table, from the reference's CommonLib/Contexts.cpp"""
+    src = open(os.path.join(REF, "source", "Lib", "CommonLib", "Contexts.cpp")).read()
+    tables = {}
+    for m in re.finditer(r"ContextSetCfg::(\w+)(\[\])?\s*=\s*(\{)?\s*((?:ContextSetCfg::addCtxSet\s*\(\{.*?\}\)\s*,?\s*)+)\}?;", src, re.S):
+        name, sets = m.group(1), []
+        for s in re.finditer(r"addCtxSet\s*\(\{(.*?)\}\)", m.group(4), re.S):
+            rows = [[int(v) for v in re.findall(r"\d+", r)] for r in re.findall(r"\{([^{}]*)\}", s.group(1))]
+            sets.append(rows)
+        tables[name] = sets if m.group(2) else sets[0]
+    rn = re.search(r"m_RenormTable_32\s*\[\s*32\s*\]\s*=\s*\{(.*?)\}", src, re.S)
+    renorm = [int(v) for v in re.findall(r"\d+", rn.group(1))]
+    assert len(renorm) == 32 and "SplitFlag" in tables and len(tables["SplitFlag"][0]) == 9
+    return tables, renorm
+
+
+class Ctx:
+    """BinProbModel (Contexts.h:71-160): two estimates of different adaptation rates"""
+    MASK_0, MASK_1 = ((1 << 10) - 1) << 5, ((1 << 14) - 1) << 1
+
+    def __init__(self, init_id, rate, qp):
+        slope = (init_id >> 3) - 4
+        offset = ((init_id & 7) * 18) + 1
+        inistate = ((slope * (qp - 16)) >> 1) + offset
+        p1 = min(127, max(1, inistate)) << 8
+        self.s0, self.s1 = p1 & Ctx.MASK_0, p1 & Ctx.MASK_1
+        r0 = 2 + ((rate >> 2) & 3)
+        r1 = 3 + r0 + (rate & 3)
+        self.r0, self.r1 = r0 + 5, r1 + 1
+        self.d0 = [0xFFFF >> (16 - self.r0), 0xFFFF >> 1]
+        self.d1 = [0xFFFF >> (16 - self.r1), 0xFFFF >> 1]
+
+    def state(self):
+        return (self.s0 + self.s1) >> 8
+
+    def update(self, b):
+        self.s0 += ((self.d0[b] - self.s0) >> self.r0) << 5
+        self.s1 += ((self.d1[b] - self.s1) >> self.r1) << 1
+
+
+class Cabac:
+    """the arithmetic encoder (9.3.4.x as the usual encoder-side mirror: low / range / outstanding bytes)"""
+
+    def __init__(self, tables, renorm, slice_type, qp):
+        self.tables, self.renorm, self.st, self.qp = tables, renorm, slice_type, qp
+        self.ctx = {}
+        self.low, self.range, self.bits_left, self.buffered, self.num_buffered = 0, 510, 23, 0xFF, 0
+        self.out = bytearray()
+        self.nbins = 0
+
+    def model(self, name, idx, sub=None):
+        key = (name, sub, idx)
+        if key not in self.ctx:
+            t = self.tables[name] if sub is None else self.tables[name][sub]
+            self.ctx[key] = Ctx(t[self.st][idx], t[3][idx], self.qp)
+        return self.ctx[key]
+
+    def _write_out(self):
+        lead = self.low >> (24 - self.bits_left)
+        self.bits_left += 8
+        self.low &= 0xFFFFFFFF >> self.bits_left
+        if lead == 0xFF:
+            self.num_buffered += 1
+        elif self.num_buffered > 0:
+            carry = lead >> 8
+            self.out.append((self.buffered + carry) & 0xFF)
+            self.buffered = lead & 0xFF
+            fill = (0xFF + carry) & 0xFF
+            while self.num_buffered > 1:
+                self.out.append(fill)
+                self.num_buffered -= 1
+        else:
+            self.num_buffered = 1
+            self.buffered = lead
+
+    def _test(self):
+        if self.bits_left < 12:
+            self._write_out()
+
+    def bin(self, b, name, idx, sub=None):
+        m = self.model(name, idx, sub)
+        self.nbins += 1
+        q = m.state()
+        mps = q >> 7
+        if q & 0x80:
+            q ^= 0xFF
+        lps = (((q >> 2) * (self.range >> 5)) >> 1) + 4
+        self.range -= lps
+        if b != mps:
+            n = self.renorm[lps >> 3]
+            self.low = (self.low + self.range) << n
+            self.range = lps << n
+            self.bits_left -= n
+        elif self.range < 256:
+            self.low <<= 1
+            self.range <<= 1
+            self.bits_left -= 1
+        m.update(b)
+        self._test()
+
+    def ep(self, b):
+        self.low <<= 1
+        if b:
+            self.low += self.range
+        self.bits_left -= 1
+        self._test()
+
+    def eps(self, v, n):
+        for i in range(n - 1, -1, -1):
+            self.ep((v >> i) & 1)
+
+    def trm(self, b):
+        self.range -= 2
+        if b:
+            self.low += self.range
+            self.low <<= 7
+            self.range = 2 << 7
+            self.bits_left -= 7
+        elif self.range >= 256:
+            return
+        else:
+            self.low <<= 1
+            self.range <<= 1
+            self.bits_left -= 1
+        self._test()
+
+    def finish(self):
+        """end_of_slice_one_bit was coded with trm(1): flush; returns the bits of the slice data (the caller appends rbsp_trailing_bits)"""
+        if self.low >> (32 - self.bits_left):
+            self.out.append((self.buffered + 1) & 0xFF)
+            while self.num_buffered > 1:
+                self.out.append(0)
+                self.num_buffered -= 1
+            self.low -= 1 << (32 - self.bits_left)
+        else:
+            if self.num_buffered > 0:
+                self.out.append(self.buffered)
+            while self.num_buffered > 1:
+                self.out.append(0xFF)
+                self.num_buffered -= 1
+        bits = []
+        for byte in self.out:
+            bits += [(byte >> i) & 1 for i in range(7, -1, -1)]
+        n = 24 - self.bits_left
+        v = self.low >> 8
+        bits += [(v >> i) & 1 for i in range(n - 1, -1, -1)]
+        return bits
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# parameter sets and headers
+# ---------------------------------------------------------------------------------------------------------------------
+class Cfg:
+    def __init__(self, width, height, log2_ctu=6, log2_min_qt=3, bit_depth=10, qp=30, max_tb64=True, p_split=0.6, p_cbf=0.5, p_cbf_chroma=0.3, deblock=True):
+        assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
+        self.__dict__.update(locals())
+        self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
+        self.log2_max_tb = 6 if (max_tb64 and log2_ctu > 5) else 5
+
+
+def write_sps(c):
+    b = Bits()
+    b.u(4, 0)                                        # sps_seq_parameter_set_id
+    b.u(4, 0)                                        # sps_video_parameter_set_id
+    b.u(3, 0)                                        # sps_max_sublayers_minus1
+    b.u(2, 1)                                        # sps_chroma_format_idc: 4:2:0
+    b.u(2, c.log2_ctu - 5)                           # sps_log2_ctu_size_minus5
+    b.flag(1)                                        # sps_ptl_dpb_hrd_params_present_flag
+    # profile_tier_level( 1, 0 )
+    b.u(7, 1)                                        # general_profile_idc: Main 10
+    b.flag(0)                                        # general_tier_flag
+    b.u(8, 16 * 5 + 3 * 1)                           # general_level_idc: 5.1
+    b.flag(1)                                        # ptl_frame_only_constraint_flag
+    b.flag(0)                                        # ptl_multilayer_enabled_flag
+    b.flag(0)                                        # gci_present_flag
+    b.align_zero()                                   # gci_alignment_zero_bit
+    b.align_zero()                                   # ptl_reserved_zero_bit
+    b.u(8, 0)                                        # ptl_num_sub_profiles
+    b.flag(0)                                        # sps_gdr_enabled_flag
+    b.flag(0)                                        # sps_ref_pic_resampling_enabled_flag
+    b.ue(c.width)                                    # sps_pic_width_max_in_luma_samples
+    b.ue(c.height)
+    b.flag(0)                                        # sps_conformance_window_flag
+    b.flag(0)                                        # sps_subpic_info_present_flag
+    b.ue(c.bit_depth - 8)                            # sps_bitdepth_minus8
+    b.flag(0)                                        # sps_entropy_coding_sync_enabled_flag
+    b.flag(0)                                        # sps_entry_point_offsets_present_flag
+    b.u(4, 4)                                        # sps_log2_max_pic_order_cnt_lsb_minus4
+    b.flag(0)                                        # sps_poc_msb_cycle_flag
+    b.u(2, 0)                                        # sps_num_extra_ph_bytes
+    b.u(2, 0)                                        # sps_num_extra_sh_bytes
+    b.ue(1)                                          # dpb_max_dec_pic_buffering_minus1[0]
+    b.ue(0)                                          # dpb_max_num_reorder_pics[0]
+    b.ue(0)                                          # dpb_max_latency_increase_plus1[0]
+    b.ue(c.log2_min_cb - 2)                          # sps_log2_min_luma_coding_block_size_minus2
+    b.flag(0)                                        # sps_partition_constraints_override_enabled_flag
+    b.ue(c.log2_min_qt - c.log2_min_cb)              # sps_log2_diff_min_qt_min_cb_intra_slice_luma
+    b.ue(0)                                          # sps_max_mtt_hierarchy_depth_intra_slice_luma
+    b.flag(0)                                        # sps_qtbtt_dual_tree_intra_flag
+    b.ue(c.log2_min_qt - c.log2_min_cb)              # sps_log2_diff_min_qt_min_cb_inter_slice
+    b.ue(0)                                          # sps_max_mtt_hierarchy_depth_inter_slice
+    if c.log2_ctu > 5:
+        b.flag(c.log2_max_tb == 6)                   # sps_max_luma_transform_size_64_flag
+    b.flag(0)                                        # sps_transform_skip_enabled_flag
+    b.flag(0)                                        # sps_mts_enabled_flag
+    b.flag(0)                                        # sps_lfnst_enabled_flag
+    b.flag(0)                                        # sps_joint_cbcr_enabled_flag
+    b.flag(1)                                        # sps_same_qp_table_for_chroma_flag
+    b.se(0)                                          # sps_qp_table_start_minus26[0]
+    b.ue(0)                                          # sps_num_points_in_qp_table_minus1[0]
+    b.ue(0)                                          # sps_delta_qp_in_val_minus1[0][0]
+    b.ue(1)                                          # sps_delta_qp_diff_val[0][0]: the identity table
+    b.flag(0)                                        # sps_sao_enabled_flag
+    b.flag(0)                                        # sps_alf_enabled_flag
+    b.flag(0)                                        # sps_lmcs_enable_flag
+    b.flag(0)                                        # sps_weighted_pred_flag
+    b.flag(0)                                        # sps_weighted_bipred_flag
+    b.flag(0)                                        # sps_long_term_ref_pics_flag
+    b.flag(0)                                        # sps_idr_rpl_present_flag
+    b.flag(1)                                        # sps_rpl1_same_as_rpl0_flag
+    b.ue(0)                                          # sps_num_ref_pic_lists[0]
+    b.flag(0)                                        # sps_ref_wraparound_enabled_flag
+    b.flag(0)                                        # sps_temporal_mvp_enabled_flag
+    b.flag(0)                                        # sps_amvr_enabled_flag
+    b.flag(0)                                        # sps_bdof_enabled_flag
+    b.flag(0)                                        # sps_smvd_enabled_flag
+    b.flag(0)                                        # sps_dmvr_enabled_flag
+    b.flag(0)                                        # sps_mmvd_enabled_flag
+    b.ue(0)                                          # sps_six_minus_max_num_merge_cand
+    b.flag(0)                                        # sps_sbt_enabled_flag
+    b.flag(0)                                        # sps_affine_enabled_flag
+    b.flag(0)                                        # sps_bcw_enabled_flag
+    b.flag(0)                                        # sps_ciip_enabled_flag
+    b.flag(0)                                        # sps_gpm_enabled_flag (MaxNumMergeCand = 6)
+    b.ue(0)                                          # sps_log2_parallel_merge_level_minus2
+    b.flag(0)                                        # sps_isp_enabled_flag
+    b.flag(0)                                        # sps_mrl_enabled_flag
+    b.flag(0)                                        # sps_mip_enabled_flag
+    b.flag(0)                                        # sps_cclm_enabled_flag
+    b.flag(0)                                        # sps_chroma_horizontal_collocated_flag
+    b.flag(0)                                        # sps_chroma_vertical_collocated_flag
+    b.flag(0)                                        # sps_palette_enabled_flag
+    b.flag(0)                                        # sps_ibc_enabled_flag
+    b.flag(0)                                        # sps_ladf_enabled_flag
+    b.flag(0)                                        # sps_explicit_scaling_list_enabled_flag
+    b.flag(0)                                        # sps_dep_quant_enabled_flag
+    b.flag(0)                                        # sps_sign_data_hiding_enabled_flag
+    b.flag(0)                                        # sps_virtual_boundaries_enabled_flag
+    b.flag(0)                                        # sps_timing_hrd_params_present_flag
+    b.flag(0)                                        # sps_field_seq_flag
+    b.flag(0)                                        # sps_vui_parameters_present_flag
+    b.flag(0)                                        # sps_extension_present_flag
+    b.trailing()
+    return b.bytes()
+
+
+def write_pps(c):
+    b = Bits()
+    b.u(6, 0)                                        # pps_pic_parameter_set_id
+    b.u(4, 0)                                        # pps_seq_parameter_set_id
+    b.flag(0)                                        # pps_mixed_nalu_types_in_pic_flag
+    b.ue(c.width)
+    b.ue(c.height)
+    b.flag(0)                                        # pps_conformance_window_flag
+    b.flag(0)                                        # pps_scaling_window_explicit_signalling_flag
+    b.flag(0)                                        # pps_output_flag_present_flag
+    b.flag(1)                                        # pps_no_pic_partition_flag
+    b.flag(0)                                        # pps_subpic_id_mapping_present_flag
+    b.flag(0)                                        # pps_cabac_init_present_flag
+    b.ue(0)                                          # pps_num_ref_idx_default_active_minus1[0]
+    b.ue(0)                                          # pps_num_ref_idx_default_active_minus1[1]
+    b.flag(0)                                        # pps_rpl1_idx_present_flag
+    b.flag(0)                                        # pps_weighted_pred_flag
+    b.flag(0)                                        # pps_weighted_bipred_flag
+    b.flag(0)                                        # pps_ref_wraparound_enabled_flag
+    b.se(0)                                          # pps_init_qp_minus26
+    b.flag(0)                                        # pps_cu_qp_delta_enabled_flag
+    b.flag(0)                                        # pps_chroma_tool_offsets_present_flag
+    b.flag(1)                                        # pps_deblocking_filter_control_present_flag
+    b.flag(0)                                        # pps_deblocking_filter_override_enabled_flag
+    b.flag(0 if c.deblock else 1)                    # pps_deblocking_filter_disabled_flag
+    if c.deblock:
+        b.se(0)                                      # pps_luma_beta_offset_div2
+        b.se(0)                                      # pps_luma_tc_offset_div2
+    b.flag(0)                                        # pps_picture_header_extension_present_flag
+    b.flag(0)                                        # pps_slice_header_extension_present_flag
+    b.flag(0)                                        # pps_extension_flag
+    b.trailing()
+    return b.bytes()
+
+
+def write_slice_header(c, b, poc_lsb, first):
+    b.flag(1)                                        # sh_picture_header_in_slice_header_flag
+    # picture_header_structure()
+    b.flag(1)                                        # ph_gdr_or_irap_pic_flag
+    b.flag(0)                                        # ph_non_ref_pic_flag
+    b.flag(0)                                        # ph_gdr_pic_flag
+    b.flag(0)                                        # ph_inter_slice_allowed_flag
+    b.ue(0)                                          # ph_pic_parameter_set_id
+    b.u(8, poc_lsb)                                  # ph_pic_order_cnt_lsb
+    # (no ALF, LMCS, scaling lists, virtual boundaries, output flag, RPL in the PH, partition overrides, QP delta info, SAO, deblocking info in the PH)
+    # slice header proper: one slice per picture, I slices only
+    b.flag(0 if first else 0)                        # sh_no_output_of_prior_pics_flag (IDR)
+    b.se(c.qp - 26)                                  # sh_qp_delta
+    b.trailing()                                     # byte_alignment()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# slice data
+# ---------------------------------------------------------------------------------------------------------------------
+SCAN4 = [(0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0), (0, 3), (1, 2), (2, 1), (3, 0), (1, 3), (2, 2), (3, 1), (2, 3), (3, 2), (3, 3)]      # diagonal scan of a 4x4 coefficient group: scan position -> (x, y)
+PREFIX_CTX = [0, 0, 0, 3, 6, 10, 15, 21]
+
+
+class PictureWriter:
+    def __init__(self, c, cab, rng):
+        self.c, self.cab, self.rng = c, cab, rng
+        w4, h4 = c.width >> 2, c.height >> 2
+        self.cu_w = [[0] * w4 for _ in range(h4)]      # luma width / height of the CU that covers a 4x4 cell (0: not coded yet)
+        self.cu_h = [[0] * w4 for _ in range(h4)]
+        self.stats = dict(cus=0, split=0, cbf=0, coefs=0)
+
+    def picture(self):
+        S = 1 << self.c.log2_ctu
+        for y in range(0, self.c.height, S):
+            for x in range(0, self.c.width, S):
+                self.coding_tree(x, y, S)
+        self.cab.trm(1)                              # end_of_slice_one_bit
+
+    # -- coding_tree (quad-tree only): split_cu_flag where both choices exist (CABACReader::split_cu_mode)
+    def coding_tree(self, x, y, size):
+        can_split = size > (1 << self.c.log2_min_qt)
+        split = False
+        if can_split:
+            split = self.rng.random() < self.c.p_split
+            left = self.cu_h[y >> 2][(x >> 2) - 1] if x > 0 else 0
+            above = self.cu_w[(y >> 2) - 1][x >> 2] if y > 0 else 0
+            ctx = (1 if (left and left < size) else 0) + (1 if (above and above < size) else 0)      # (+ ctxOffset[numSplit = 2] = 0)
+            self.cab.bin(1 if split else 0, "SplitFlag", ctx)
+        if split:
+            self.stats["split"] += 1
+            h = size >> 1
+            for (dx, dy) in ((0, 0), (h, 0), (0, h), (h, h)):
+                self.coding_tree(x + dx, y + dy, h)
+            return
+        self.coding_unit(x, y, size)
+        for yy in range(y >> 2, (y + size) >> 2):
+            for xx in range(x >> 2, (x + size) >> 2):
+                self.cu_w[yy][xx] = size
+                self.cu_h[yy][xx] = size
+
+    # -- coding_unit of an I slice, single tree: intra luma mode, intra chroma mode, transform tree
+    def coding_unit(self, x, y, size):
+        cab, rng = self.cab, self.rng
+        self.stats["cus"] += 1
+        mpm = rng.random() < 0.6
+        cab.bin(1 if mpm else 0, "IPredMode", 0, sub=0)                       # intra_luma_mpm_flag
+        if mpm:
+            not_planar = rng.random() < 0.7
+            cab.bin(1 if not_planar else 0, "IntraLumaPlanarFlag", 1)          # intra_luma_not_planar_flag (ctx 1: no ISP)
+            if not_planar:
+                idx = rng.randrange(0, 5)                                      # intra_luma_mpm_idx: truncated unary, bypass, cMax 4
+                for k in range(idx):
+                    cab.ep(1)
+                if idx < 4:
+                    cab.ep(0)
+        else:
+            self.trunc_bin(rng.randrange(0, 61), 61)                           # intra_luma_mpm_remainder
+        if rng.random() < 0.5:
+            cab.bin(0, "IPredMode", 0, sub=1)                                  # intra_chroma_pred_mode: derived mode
+        else:
+            cab.bin(1, "IPredMode", 0, sub=1)
+            cab.eps(rng.randrange(0, 4), 2)
+        self.transform_tree(size)
+
+    def trunc_bin(self, v, n):                                                 # xReadTruncBinCode
+        thresh = n.bit_length() - 1
+        val = 1 << thresh
+        b = n - val
+        if v < val - b:
+            self.cab.eps(v, thresh)
+        else:
+            self.cab.eps(v + val - b, thresh + 1)
+
+    def transform_tree(self, size):
+        mx = 1 << self.c.log2_max_tb
+        if size > mx:
+            for _ in range(4):                                                 # TU_MAX_TR_SPLIT: four transform units in z order
+                self.transform_tree(size >> 1)
+            return
+        self.transform_unit(size)
+
+    def transform_unit(self, size):
+        cab, rng, c = self.cab, self.rng, self.c
+        cb = rng.random() < c.p_cbf_chroma
+        cr = rng.random() < c.p_cbf_chroma
+        yy = rng.random() < c.p_cbf
+        cab.bin(1 if cb else 0, "QtCbf", 0, sub=1)                             # tu_cb_coded_flag
+        cab.bin(1 if cr else 0, "QtCbf", 1 if cb else 0, sub=2)                # tu_cr_coded_flag
+        cab.bin(1 if yy else 0, "QtCbf", 0, sub=0)                             # tu_y_coded_flag
+        if yy:
+            self.residual(size, size, 0)
+        if cb:
+            self.residual(size >> 1, size >> 1, 1)
+        if cr:
+            self.residual(size >> 1, size >> 1, 1)
+
+    # -- residual_coding: coefficients of the first 4x4 coefficient group only, levels 1..3, at most three of them (well inside the budget of
+    # context-coded bins, CoeffCodingContext::m_regBinLimit)
+    def residual(self, w, h, ch):
+        cab, rng = self.cab, self.rng
+        self.stats["cbf"] += 1
+        last = rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 7, 9, 12, 15])
+        levels = {last: rng.choice([1, 1, 1, 2, 3])}
+        for p in rng.sample(range(last), min(last, rng.randrange(0, 3))):
+            levels[p] = rng.choice([1, 1, 2, 3])
+        self.stats["coefs"] += len(levels)
+        log2w, log2h = w.bit_length() - 1, h.bit_length() - 1
+        lx, ly = SCAN4[last]
+        # last_sig_coeff_x_prefix / y_prefix (positions 0..3: no suffix)
+        for (pos, log2s, size, name) in ((lx, log2w, w, "LastX"), (ly, log2h, h, "LastY")):
+            off = PREFIX_CTX[log2s] if ch == 0 else 0
+            shift = ((log2s + 1) >> 2) if ch == 0 else min(2, max(0, size >> 3))
+            group_idx_max = [0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9][min(32, size) - 1]
+            for k in range(pos):
+                cab.bin(1, name, off + (k >> shift), sub=ch)
+            if pos < group_idx_max:
+                cab.bin(0, name, off + (pos >> shift), sub=ch)
+        # levels, from the last position down to 0
+        tpl = {}                                                               # template sums per block position: (sum of first-pass levels, count)
+        absl = {}
+        first = True
+        tmpl_diag, tmpl_sum1 = -1, -1
+        signs = []
+        for sp in range(last, -1, -1):
+            x, y = SCAN4[sp]
+            lv = levels.get(sp, 0)
+            if not first:
+                s, n = tpl.get((x, y), (0, 0))
+                diag = x + y
+                ofs = min((s + 1) >> 1, 3) + (4 if diag < 2 else 0)
+                if ch == 0:
+                    ofs += 4 if diag < 5 else 0
+                tmpl_diag, tmpl_sum1 = diag, s - n
+                cab.bin(1 if lv else 0, "SigFlag", ofs, sub=ch)                # sig_coeff_flag (state 0: SigFlag[chType])
+            if lv:
+                off = 0
+                if tmpl_diag != -1:
+                    off = min(tmpl_sum1, 4) + 1
+                    off += (15 if ch == 0 else 5) if tmpl_diag == 0 else ((10 if tmpl_diag < 3 else 5 if tmpl_diag < 10 else 0) if ch == 0 else 0)
+                gt1 = lv >= 2
+                cab.bin(1 if gt1 else 0, "GtxFlag", off, sub=ch + 2)           # abs_level_gtx_flag[0]
+                if gt1:
+                    cab.bin((lv - 2) & 1, "ParFlag", off, sub=ch)              # par_level_flag
+                    cab.bin(0, "GtxFlag", off, sub=ch)                         # abs_level_gtx_flag[1]: levels up to 3
+                signs.append(rng.randrange(0, 2))
+                # absVal1stPass: the positions whose template holds this one
+                for (dx, dy) in ((0, 2), (1, 1), (0, 1), (2, 0), (1, 0)):
+                    px, py = x - dx, y - dy
+                    if px >= 0 and py >= 0:
+                        s, n = tpl.get((px, py), (0, 0))
+                        tpl[(px, py)] = (s + lv, n + 1)
+            first = False
+        for s in signs:
+            cab.ep(s)                                                          # coeff_sign_flag, in coding order
+
+
+def write_stream(c, num_pictures, seed, tables, renorm):
+    rng = random.Random(seed)
+    out = bytearray()
+    out += nal(NAL_SPS, write_sps(c), long_start=True)
+    out += nal(NAL_PPS, write_pps(c), long_start=True)
+    stats = []
+    for k in range(num_pictures):
+        b = Bits()
+        write_slice_header(c, b, 0, k == 0)
+        cab = Cabac(tables, renorm, 2, c.qp)
+        pw = PictureWriter(c, cab, rng)
+        pw.picture()
+        b.b += cab.finish()
+        b.trailing()
+        out += nal(NAL_IDR_N_LP, b.bytes(), long_start=True)
+        stats.append(pw.stats)
+    return bytes(out), stats
+
+
+def reference_md5(path, frames_expected=None):
+    """decode with the reference's own decoder and application -> MD5 over the output frames (16-bit little endian for more than 8 bits, planar)"""
+    yuv = path + ".ref.yuv"
+    r = subprocess.run([APP_REF, "-b", path, "-o", yuv, "-t", "2", "-v", "3"], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 or not os.path.exists(yuv):
+        raise RuntimeError("the reference decoder refused %s:\n%s" % (path, (r.stdout + r.stderr)[-2000:]))
+    data = open(yuv, "rb").read()
+    os.remove(yuv)
+    return hashlib.md5(data).hexdigest(), len(data), r.stdout + r.stderr
+
+
+FIXTURES = [
+    # name, config, pictures, seed
+    ("mini_ctu32_64x64", dict(width=64, height=64, log2_ctu=5, qp=30), 2, 1),
+    ("mini_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=32), 3, 2),
+    ("mini_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, qp=27, p_split=0.7), 2, 3),
+    ("mini_ctu64_tb32_192x128_8bit", dict(width=192, height=128, log2_ctu=6, qp=35, bit_depth=8, max_tb64=False, p_cbf=0.8, p_cbf_chroma=0.6), 2, 4),
+    ("mini_ctu128_nodeblock_384x256", dict(width=384, height=256, log2_ctu=7, qp=24, deblock=False, p_split=0.8), 2, 5),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "bitstreams"))
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    tables, renorm = load_context_tables()
+    for name, kw, n, seed in FIXTURES:
+        if a.only and a.only not in name:
+            continue
+        c = Cfg(**kw)
+        data, stats = write_stream(c, n, seed, tables, renorm)
+        d = os.path.join(a.out, name)
+        os.makedirs(d, exist_ok=True)
+        bit = os.path.join(d, name + ".bit")
+        open(bit, "wb").write(data)
+        md5, nbytes, log = reference_md5(bit)
+        frame_bytes = c.width * c.height * 3 // 2 * (2 if c.bit_depth > 8 else 1)
+        assert nbytes == n * frame_bytes, "the reference decoder put out %d bytes, %d pictures of %d expected\n%s" % (nbytes, n, frame_bytes, log[-1500:])
+        open(os.path.join(d, name + ".yuv.md5"), "w").write("%s  %s.yuv\n" % (md5, name))
+        print("%-40s %6d bytes, %d pictures, %s  CUs %s" % (name, len(data), n, md5, [s["cus"] for s in stats]))
+
+
+if __name__ == "__main__":
+    main()

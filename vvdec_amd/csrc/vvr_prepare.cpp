@@ -449,7 +449,11 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
       {
         // luma-tree CUs go down to 4x4; CUs with chroma need 8 luma samples of width (no 2-wide intra chroma blocks) and 4 of height
         const int minW = cu.tree == VVR_TREE_LUMA ? 4 : 8;
-        if( cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( cu.tree != VVR_TREE_LUMA && cu.w * cu.h < 64 ) ) FAIL( VVR_ERR_PARAMETER, "intra CU size out of range (luma tree 4..64, with chroma at least 8 wide and 16 chroma samples)" );
+        // (a 128-wide or -high CU of a single tree is four or two transform units of 64: prediction and reconstruction go transform unit by transform unit,
+        // DecCu::xIntraRecQT, so nothing here is larger than 64; found with the first parser-fed stream that left a CTU of 128 unsplit)
+        if( cu.w > 128 || cu.h > 128 || cu.w < minW || cu.h < 4 || ( cu.tree != VVR_TREE_LUMA && cu.w * cu.h < 64 ) ) FAIL( VVR_ERR_PARAMETER, "intra CU size out of range (4..128, with chroma at least 8 wide and 16 chroma samples)" );
+        if( cu.w > 64 || cu.h > 64 )
+          for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ ) if( p->tu[t].w > 64 || p->tu[t].h > 64 ) FAIL( VVR_ERR_PARAMETER, "intra CU of more than 64 samples: transform units of at most 64 expected" );
       }
       if( cu.tree != VVR_TREE_JOINT )
       {
