@@ -75,13 +75,20 @@ struct Extracted
   std::vector<std::pair<CodingUnit*, uint32_t>> dmvrCus;   // CUs that run DMVR with their offset into the delta-MV output (vvr_read_dmvr)
 };
 
+// an affine CU: not the SbTMVP CUs, which carry the affine flag of the sub-block merge syntax too (see resolveMcMode)
+static inline bool isAffine( const CodingUnit& cu ) { return cu.affineFlag() && !( cu.mergeFlag() && cu.mergeType() == MRG_TYPE_SUBPU_ATMVP ); }
+
 // branch of InterPrediction::motionCompensation (InterPrediction.cpp:1372-1459) for one CU
 static inline uint8_t resolveMcMode( const CodingUnit& cu )
 {
   if( cu.geoFlag() ) return VVR_MC_GEO;
+  // A CU that the parser read as a sub-block merge CU (merge_subblock_flag: CABACReader::subblock_merge_flag sets affineFlag) and whose candidate
+  // turned out to be the SbTMVP one (DecCu.cpp:761-767) KEEPS its affine flag; the reference tells it from an affine CU by its merge type only
+  // (InterPrediction.cpp:1414,1446: no BDOF, no DMVR, xSubPuMC).  Found with the first parser-fed stream that had such CUs.
+  const bool subPu = cu.mergeFlag() && cu.mergeType() == MRG_TYPE_SUBPU_ATMVP;
+  if( subPu ) return VVR_MC_SBTMVP;
   if( cu.affineFlag() ) return VVR_MC_AFFINE;
   const Slice& slice = *cu.slice;
-  const bool subPu = cu.mergeFlag() && cu.mergeType() == MRG_TYPE_SUBPU_ATMVP;
   bool bio = false;
   if( cu.sps->getUseBIO() && !cu.cs->picHeader->getDisBdofFlag() && !cu.ciipFlag() && !cu.smvdMode() && !( cu.sps->getUseBcw() && cu.BcwIdx() != BCW_DEFAULT ) )
   {
@@ -351,8 +358,8 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
       c.x = (uint16_t) la.x; c.y = (uint16_t) la.y; c.w = (uint8_t) la.width; c.h = (uint8_t) la.height;
       c.tree = treeL ? VVR_TREE_LUMA : treeC ? VVR_TREE_CHROMA : VVR_TREE_JOINT;
       c.pred_mode = CU::isIntra( cu ) ? VVR_PRED_INTRA : CU::isIBC( cu ) ? VVR_PRED_IBC : VVR_PRED_INTER;
-      c.flags = (uint16_t) ( ( cu.rootCbf() ? VVR_CU_ROOT_CBF : 0 ) | ( cu.skip() ? VVR_CU_SKIP : 0 ) | ( cu.mergeFlag() ? VVR_CU_MERGE : 0 ) | ( cu.affineFlag() ? VVR_CU_AFFINE : 0 )
-                           | ( cu.affineFlag() && cu.affineType() == AFFINEMODEL_6PARAM ? VVR_CU_AFFINE_6P : 0 ) | ( cu.ciipFlag() ? VVR_CU_CIIP : 0 ) | ( cu.geoFlag() ? VVR_CU_GEO : 0 )
+      c.flags = (uint16_t) ( ( cu.rootCbf() ? VVR_CU_ROOT_CBF : 0 ) | ( cu.skip() ? VVR_CU_SKIP : 0 ) | ( cu.mergeFlag() ? VVR_CU_MERGE : 0 ) | ( isAffine( cu ) ? VVR_CU_AFFINE : 0 )
+                           | ( isAffine( cu ) && cu.affineType() == AFFINEMODEL_6PARAM ? VVR_CU_AFFINE_6P : 0 ) | ( cu.ciipFlag() ? VVR_CU_CIIP : 0 ) | ( cu.geoFlag() ? VVR_CU_GEO : 0 )
                            | ( cu.mergeFlag() && cu.mergeType() == MRG_TYPE_SUBPU_ATMVP ? VVR_CU_SBTMVP : 0 ) | ( cu.mipFlag() ? VVR_CU_MIP : 0 ) | ( cu.mipTransposedFlag() ? VVR_CU_MIP_TRANSP : 0 )
                            | ( cu.smvdMode() ? VVR_CU_SMVD : 0 ) | ( cu.mmvdFlag() ? VVR_CU_MMVD : 0 ) );
       c.qp = (int8_t) cu.qp;
@@ -381,7 +388,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
         for( int k = 0; k < 5; k++ ) if( g_BcwInternFwd[k] == cu.BcwIdx() ) c.bcw_idx = (uint8_t) k;      // description: index into the weight table
         c.imv = (uint8_t) cu.imv(); c.sbt_info = (uint8_t) cu.sbtInfo(); c.lfnst_idx = 0;
         // control-point MVs only for affine CUs (a GPM CU keeps its two MVs in mv[0][1] / mv[1][1], InterPrediction.cpp:1478,1489: they go to geo_mv)
-        for( int l = 0; l < 2; l++ ) for( int k = 0; k < ( cu.affineFlag() ? 3 : 1 ); k++ ) { c.mv[l][k][0] = cu.mv[l][k].getHor(); c.mv[l][k][1] = cu.mv[l][k].getVer(); }
+        for( int l = 0; l < 2; l++ ) for( int k = 0; k < ( isAffine( cu ) ? 3 : 1 ); k++ ) { c.mv[l][k][0] = cu.mv[l][k].getHor(); c.mv[l][k][1] = cu.mv[l][k].getVer(); }
         if( cu.geoFlag() )
         {
           c.geo_split_dir = cu.geoSplitDir;

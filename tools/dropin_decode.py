@@ -52,7 +52,7 @@ def frames_and_fps(text):
 def decode_stream(bit, threads, with_reference):
     md5 = expected_md5(bit)
     res = {"stream": os.path.basename(bit), "expected_md5": md5}
-    common = ["-b", bit, "-t", str(threads), "-v", "2"]
+    common = ["-b", bit, "-t", str(threads), "-v", "3"]
     # 1. the ctest command of the reference: MD5 over the output frames against the stored one (exit status 0 = match)
     r, dt = run_app(APP_DROPIN, common + (["-md5", md5] if md5 else []), preload=BACKEND)
     out = r.stdout + r.stderr

@@ -249,11 +249,15 @@ class Cabac:
 # parameter sets and headers
 # ---------------------------------------------------------------------------------------------------------------------
 class Cfg:
-    def __init__(self, width, height, log2_ctu=6, log2_min_qt=3, bit_depth=10, qp=30, max_tb64=True, p_split=0.6, p_cbf=0.5, p_cbf_chroma=0.3, deblock=True):
+    def __init__(self, width, height, log2_ctu=6, log2_min_qt=3, bit_depth=10, qp=30, max_tb64=True, p_split=0.6, p_cbf=0.5, p_cbf_chroma=0.3, deblock=True,
+                 inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
         self.log2_max_tb = 6 if (max_tb64 and log2_ctu > 5) else 5
+        if not inter:
+            self.tmvp = self.sbtmvp = self.bdof = self.dmvr = self.mmvd = self.affine = self.ciip = self.gpm = False
+        self.max_aff_merge = 5 if self.affine else (1 if (self.sbtmvp and self.tmvp) else 0)
 
 
 def write_sps(c):
@@ -287,8 +291,8 @@ def write_sps(c):
     b.flag(0)                                        # sps_poc_msb_cycle_flag
     b.u(2, 0)                                        # sps_num_extra_ph_bytes
     b.u(2, 0)                                        # sps_num_extra_sh_bytes
-    b.ue(1)                                          # dpb_max_dec_pic_buffering_minus1[0]
-    b.ue(0)                                          # dpb_max_num_reorder_pics[0]
+    b.ue(5 if c.inter else 1)                        # dpb_max_dec_pic_buffering_minus1[0]
+    b.ue(3 if c.inter else 0)                        # dpb_max_num_reorder_pics[0]
     b.ue(0)                                          # dpb_max_latency_increase_plus1[0]
     b.ue(c.log2_min_cb - 2)                          # sps_log2_min_luma_coding_block_size_minus2
     b.flag(0)                                        # sps_partition_constraints_override_enabled_flag
@@ -318,18 +322,33 @@ def write_sps(c):
     b.flag(1)                                        # sps_rpl1_same_as_rpl0_flag
     b.ue(0)                                          # sps_num_ref_pic_lists[0]
     b.flag(0)                                        # sps_ref_wraparound_enabled_flag
-    b.flag(0)                                        # sps_temporal_mvp_enabled_flag
+    b.flag(c.tmvp)                                   # sps_temporal_mvp_enabled_flag
+    if c.tmvp:
+        b.flag(c.sbtmvp)                             # sps_sbtmvp_enabled_flag
     b.flag(0)                                        # sps_amvr_enabled_flag
-    b.flag(0)                                        # sps_bdof_enabled_flag
+    b.flag(c.bdof)                                   # sps_bdof_enabled_flag
+    if c.bdof:
+        b.flag(0)                                    # sps_bdof_control_present_in_ph_flag
     b.flag(0)                                        # sps_smvd_enabled_flag
-    b.flag(0)                                        # sps_dmvr_enabled_flag
-    b.flag(0)                                        # sps_mmvd_enabled_flag
-    b.ue(0)                                          # sps_six_minus_max_num_merge_cand
+    b.flag(c.dmvr)                                   # sps_dmvr_enabled_flag
+    if c.dmvr:
+        b.flag(0)                                    # sps_dmvr_control_present_in_ph_flag
+    b.flag(c.mmvd)                                   # sps_mmvd_enabled_flag
+    if c.mmvd:
+        b.flag(0)                                    # sps_mmvd_fullpel_only_flag
+    b.ue(0)                                          # sps_six_minus_max_num_merge_cand: MaxNumMergeCand = 6
     b.flag(0)                                        # sps_sbt_enabled_flag
-    b.flag(0)                                        # sps_affine_enabled_flag
+    b.flag(c.affine)                                 # sps_affine_enabled_flag
+    if c.affine:
+        b.ue(0)                                      # sps_five_minus_max_num_subblock_merge_cand
+        b.flag(1)                                    # sps_6param_affine_enabled_flag
+        b.flag(1)                                    # sps_affine_prof_enabled_flag
+        b.flag(0)                                    # sps_prof_control_present_in_ph_flag
     b.flag(0)                                        # sps_bcw_enabled_flag
-    b.flag(0)                                        # sps_ciip_enabled_flag
-    b.flag(0)                                        # sps_gpm_enabled_flag (MaxNumMergeCand = 6)
+    b.flag(c.ciip)                                   # sps_ciip_enabled_flag
+    b.flag(c.gpm)                                    # sps_gpm_enabled_flag (MaxNumMergeCand = 6)
+    if c.gpm:
+        b.ue(0)                                      # sps_max_num_merge_cand_minus_max_num_gpm_cand
     b.ue(0)                                          # sps_log2_parallel_merge_level_minus2
     b.flag(0)                                        # sps_isp_enabled_flag
     b.flag(0)                                        # sps_mrl_enabled_flag
@@ -387,18 +406,61 @@ def write_pps(c):
     return b.bytes()
 
 
-def write_slice_header(c, b, poc_lsb, first):
+def write_rpl(b, cur_poc, ref_pocs):
+    """ref_pic_list_struct (parseRefPicList): short-term entries only, deltas relative to the previous entry"""
+    b.ue(len(ref_pocs))                              # num_ref_entries
+    prev = 0
+    for r in ref_pocs:
+        d = (cur_poc - r) - prev
+        assert d != 0
+        b.ue(abs(d) - 1)                             # abs_delta_poc_st (no weighted prediction: + 1)
+        b.flag(d > 0)                                # strp_entry_sign_flag: 1 = a picture that precedes the current one in output order
+        prev = cur_poc - r
+
+
+def write_slice_header(c, b, pic):
+    """pic: dict(poc, type 'I' / 'P' / 'B', idr, l0, l1 (POCs))"""
+    idr, st = pic["idr"], pic["type"]
     b.flag(1)                                        # sh_picture_header_in_slice_header_flag
     # picture_header_structure()
-    b.flag(1)                                        # ph_gdr_or_irap_pic_flag
+    b.flag(1 if idr else 0)                          # ph_gdr_or_irap_pic_flag
     b.flag(0)                                        # ph_non_ref_pic_flag
-    b.flag(0)                                        # ph_gdr_pic_flag
-    b.flag(0)                                        # ph_inter_slice_allowed_flag
+    if idr:
+        b.flag(0)                                    # ph_gdr_pic_flag
+    inter_allowed = not idr
+    b.flag(inter_allowed)                            # ph_inter_slice_allowed_flag
+    if inter_allowed:
+        b.flag(1)                                    # ph_intra_slice_allowed_flag
     b.ue(0)                                          # ph_pic_parameter_set_id
-    b.u(8, poc_lsb)                                  # ph_pic_order_cnt_lsb
-    # (no ALF, LMCS, scaling lists, virtual boundaries, output flag, RPL in the PH, partition overrides, QP delta info, SAO, deblocking info in the PH)
-    # slice header proper: one slice per picture, I slices only
-    b.flag(0 if first else 0)                        # sh_no_output_of_prior_pics_flag (IDR)
+    b.u(8, pic["poc"] & 255)                         # ph_pic_order_cnt_lsb
+    # (no ALF, LMCS, scaling lists, virtual boundaries, output flag, RPL in the PH, partition overrides, delta QP / chroma QP offset subdivisions)
+    if inter_allowed:
+        if c.tmvp:
+            b.flag(1)                                # ph_temporal_mvp_enabled_flag
+        b.flag(0)                                    # ph_mvd_l1_zero_flag
+    # (no QP delta, joint Cb-Cr sign, SAO, deblocking info in the PH)
+    # slice header proper: one slice per picture
+    if inter_allowed:
+        b.ue({"B": 0, "P": 1, "I": 2}[st])           # sh_slice_type
+    if idr:
+        b.flag(0)                                    # sh_no_output_of_prior_pics_flag
+    else:
+        write_rpl(b, pic["poc"], pic["l0"])          # ref_pic_lists(): both lists, whatever the slice type
+        write_rpl(b, pic["poc"], pic["l1"])
+        n0, n1 = len(pic["l0"]), len(pic["l1"])
+        if (st != "I" and n0 > 1) or (st == "B" and n1 > 1):
+            b.flag(1)                                # sh_num_ref_idx_active_override_flag
+            if n0 > 1:
+                b.ue(n0 - 1)                         # sh_num_ref_idx_active_minus1[0]
+            if st == "B" and n1 > 1:
+                b.ue(n1 - 1)
+        if st != "I" and c.tmvp:
+            col_l0 = 1
+            if st == "B":
+                col_l0 = pic.get("col_l0", 1)
+                b.flag(col_l0)                       # sh_collocated_from_l0_flag
+            if (col_l0 and n0 > 1) or (not col_l0 and n1 > 1):
+                b.ue(0)                              # sh_collocated_ref_idx
     b.se(c.qp - 26)                                  # sh_qp_delta
     b.trailing()                                     # byte_alignment()
 
@@ -411,12 +473,15 @@ PREFIX_CTX = [0, 0, 0, 3, 6, 10, 15, 21]
 
 
 class PictureWriter:
-    def __init__(self, c, cab, rng):
+    def __init__(self, c, cab, rng, pic=None):
         self.c, self.cab, self.rng = c, cab, rng
+        self.pic = pic or dict(type="I", l0=[], l1=[])
+        self.st = self.pic["type"]
         w4, h4 = c.width >> 2, c.height >> 2
         self.cu_w = [[0] * w4 for _ in range(h4)]      # luma width / height of the CU that covers a 4x4 cell (0: not coded yet)
         self.cu_h = [[0] * w4 for _ in range(h4)]
-        self.stats = dict(cus=0, split=0, cbf=0, coefs=0)
+        self.cu_f = [[0] * w4 for _ in range(h4)]      # per cell: 1 skip, 2 intra, 4 affine (context of the flags of later CUs)
+        self.stats = dict(cus=0, split=0, cbf=0, coefs=0, skip=0, merge=0, amvp=0, intra=0)
 
     def picture(self):
         S = 1 << self.c.log2_ctu
@@ -441,16 +506,209 @@ class PictureWriter:
             for (dx, dy) in ((0, 0), (h, 0), (0, h), (h, h)):
                 self.coding_tree(x + dx, y + dy, h)
             return
-        self.coding_unit(x, y, size)
+        f = self.coding_unit(x, y, size)
         for yy in range(y >> 2, (y + size) >> 2):
             for xx in range(x >> 2, (x + size) >> 2):
                 self.cu_w[yy][xx] = size
                 self.cu_h[yy][xx] = size
+                self.cu_f[yy][xx] = f
 
     # -- coding_unit of an I slice, single tree: intra luma mode, intra chroma mode, transform tree
     def coding_unit(self, x, y, size):
         cab, rng = self.cab, self.rng
         self.stats["cus"] += 1
+        if self.st != "I":
+            return self.coding_unit_inter(x, y, size)
+        self.intra_modes()
+        self.transform_tree(size, intra=True, root=True)
+        return 2
+
+    def neigh(self, x, y):
+        left = self.cu_f[y >> 2][(x >> 2) - 1] if x > 0 else 0
+        above = self.cu_f[(y >> 2) - 1][x >> 2] if y > 0 else 0
+        return left, above
+
+    # -- coding_unit of a P / B slice (CABACReader::coding_unit, prediction_unit, merge_data)
+    def coding_unit_inter(self, x, y, size):
+        cab, rng, c = self.cab, self.rng, self.c
+        left, above = self.neigh(x, y)
+        skip = rng.random() < c.p_skip
+        cab.bin(1 if skip else 0, "SkipFlag", (left & 1) + (above & 1))        # cu_skip_flag
+        if skip:
+            self.stats["skip"] += 1
+            aff = self.merge_data(x, y, size, True, left, above)
+            return 1 | (4 if aff else 0)
+        intra = rng.random() < c.p_intra
+        cab.bin(1 if intra else 0, "PredMode", 1 if ((left & 2) or (above & 2)) else 0)      # pred_mode_flag
+        if intra:
+            self.stats["intra"] += 1
+            self.intra_modes()
+            self.transform_tree(size, intra=True, root=True)
+            return 2
+        merge = rng.random() < c.p_merge
+        cab.bin(1 if merge else 0, "MergeFlag", 0)                             # general_merge_flag
+        aff = False
+        if merge:
+            self.stats["merge"] += 1
+            aff = self.merge_data(x, y, size, False, left, above)
+            root = True                                                        # (a merge CU that is not skipped has a residual)
+        else:
+            self.stats["amvp"] += 1
+            aff = self.amvp(size, left, above)
+            root = rng.random() < 0.7
+            cab.bin(1 if root else 0, "QtRootCbf", 0)                          # cu_coded_flag
+        if root:
+            self.transform_tree(size, intra=False, root=True)
+        return 4 if aff else 0
+
+    def merge_idx(self, name, num_minus1):
+        idx = self.rng.randrange(0, num_minus1 + 1)
+        if num_minus1 > 0:
+            self.cab.bin(1 if idx else 0, name, 0)
+            if idx:
+                for k in range(1, idx):
+                    self.cab.ep(1)
+                if idx < num_minus1:
+                    self.cab.ep(0)
+
+    def unary_eq(self, v, mx):                                                 # unary_max_eqprob
+        for _ in range(v):
+            self.cab.ep(1)
+        if v < mx:
+            self.cab.ep(0)
+
+    def merge_data(self, x, y, size, skip, left, above):
+        cab, rng, c = self.cab, self.rng, self.c
+        if c.max_aff_merge > 0 and size >= 8:
+            aff = rng.random() < 0.25
+            cab.bin(1 if aff else 0, "SubblockMergeFlag", (1 if left & 4 else 0) + (1 if above & 4 else 0))      # merge_subblock_flag
+            if aff:
+                self.merge_idx("AffMergeIdx", c.max_aff_merge - 1)             # merge_subblock_idx
+                return True
+        ciip_av = c.ciip and not skip and size < 128 and size * size >= 64
+        geo_av = c.gpm and self.st == "B" and 8 <= size <= 64
+        regular = True
+        if geo_av or ciip_av:
+            regular = rng.random() < 0.6
+            cab.bin(1 if regular else 0, "RegularMergeFlag", 0 if skip else 1)      # regular_merge_flag
+        if regular:
+            mmvd = False
+            if c.mmvd:
+                mmvd = rng.random() < 0.3
+                cab.bin(1 if mmvd else 0, "MmvdFlag", 0)                       # mmvd_merge_flag
+            if mmvd:
+                cab.bin(rng.randrange(0, 2), "MmvdMergeIdx", 0)                # mmvd_cand_flag
+                step = rng.randrange(0, 8)
+                cab.bin(1 if step else 0, "MmvdStepMvpIdx", 0)                 # mmvd_distance_idx
+                if step:
+                    for k in range(1, step):
+                        cab.ep(1)
+                    if step < 7:
+                        cab.ep(0)
+                cab.eps(rng.randrange(0, 4), 2)                                # mmvd_direction_idx
+            else:
+                self.merge_idx("MergeIdx", 5)                                  # merge_idx (MaxNumMergeCand 6)
+            return False
+        ciip = False
+        if geo_av and ciip_av:
+            ciip = rng.random() < 0.5
+            cab.bin(1 if ciip else 0, "CiipFlag", 0)                           # ciip_flag
+        elif ciip_av:
+            ciip = True
+        if ciip:
+            self.merge_idx("MergeIdx", 5)
+            return False
+        # geometric partitioning: split direction, two different candidates out of MaxNumGpmMergeCand = 6
+        self.trunc_bin(rng.randrange(0, 64), 64)                               # merge_gpm_partition_idx
+        c0 = rng.randrange(0, 6)
+        cab.bin(1 if c0 else 0, "MergeIdx", 0)                                 # merge_gpm_idx0
+        if c0:
+            self.unary_eq(c0 - 1, 4)
+        c1 = rng.randrange(0, 5)
+        cab.bin(1 if c1 else 0, "MergeIdx", 0)                                 # merge_gpm_idx1
+        if c1:
+            self.unary_eq(c1 - 1, 3)
+        return False
+
+    def mvd(self):
+        cab, rng, m = self.cab, self.rng, self.c.max_mvd
+        h, v = rng.randrange(-m, m + 1), rng.randrange(-m, m + 1)
+        if rng.random() < 0.3:
+            h = 0
+        if rng.random() < 0.3:
+            v = 0
+        cab.bin(1 if h else 0, "Mvd", 0)                                       # abs_mvd_greater0_flag[0 / 1]
+        cab.bin(1 if v else 0, "Mvd", 0)
+        if h:
+            cab.bin(1 if abs(h) > 1 else 0, "Mvd", 1)                          # abs_mvd_greater1_flag
+        if v:
+            cab.bin(1 if abs(v) > 1 else 0, "Mvd", 1)
+        for a in (h, v):
+            if a:
+                if abs(a) > 1:
+                    self.rem_abs_ep(abs(a) - 2, 1, 0)                          # abs_mvd_minus2: EG1
+                cab.ep(1 if a < 0 else 0)                                      # mvd_sign_flag
+
+    def rem_abs_ep(self, v, rice, cutoff):
+        """inverse of BinDecoder::decodeRemAbsEP for values far below the escape length"""
+        p = 0
+        while True:
+            off = (p << rice) if p < cutoff else ((((1 << (p - cutoff)) + cutoff - 1)) << rice)
+            length = rice if p < cutoff else rice + (p - cutoff)
+            if v < off + (1 << length):
+                break
+            p += 1
+        assert p < 16
+        for _ in range(p):
+            self.cab.ep(1)
+        self.cab.ep(0)
+        self.cab.eps(v - off, length)
+
+    def ref_idx(self, n):
+        r = self.rng.randrange(0, n)
+        if n <= 1:
+            return
+        self.cab.bin(1 if r else 0, "RefPic", 0)
+        if not r:
+            return
+        if n > 2:
+            self.cab.bin(1 if r > 1 else 0, "RefPic", 1)
+            if r > 1:
+                for idx in range(3, n + 1):
+                    if idx == n:
+                        break
+                    b = 1 if r >= idx else 0
+                    self.cab.ep(b)
+                    if not b:
+                        break
+
+    def amvp(self, size, left, above):
+        cab, rng, c = self.cab, self.rng, self.c
+        n0, n1 = len(self.pic["l0"]), len(self.pic["l1"])
+        log2 = size.bit_length() - 1
+        dirn = 1
+        if self.st == "B":
+            dirn = rng.choice([1, 2, 3, 3])
+            cab.bin(1 if dirn == 3 else 0, "InterDir", 7 - ((2 * log2 + 1) >> 1))      # inter_pred_idc (no 4x8 / 8x4 blocks here)
+            if dirn != 3:
+                cab.bin(1 if dirn == 2 else 0, "InterDir", 5)
+        aff, six = False, False
+        if c.affine and size >= 16:
+            aff = rng.random() < 0.3
+            cab.bin(1 if aff else 0, "AffineFlag", (1 if left & 4 else 0) + (1 if above & 4 else 0))      # inter_affine_flag
+            if aff:
+                six = rng.random() < 0.5
+                cab.bin(1 if six else 0, "AffineType", 0)                      # cu_affine_type_flag
+        for lst, n in ((1, n0), (2, n1)):
+            if dirn & lst:
+                self.ref_idx(n)                                                # ref_idx_l0 / l1
+                for _ in range(1 + (aff and 1) + (six and 1)):
+                    self.mvd()
+                cab.bin(rng.randrange(0, 2), "MVPIdx", 0)                      # mvp_l0_flag / mvp_l1_flag
+        return aff
+
+    def intra_modes(self):
+        cab, rng = self.cab, self.rng
         mpm = rng.random() < 0.6
         cab.bin(1 if mpm else 0, "IPredMode", 0, sub=0)                       # intra_luma_mpm_flag
         if mpm:
@@ -469,7 +727,6 @@ class PictureWriter:
         else:
             cab.bin(1, "IPredMode", 0, sub=1)
             cab.eps(rng.randrange(0, 4), 2)
-        self.transform_tree(size)
 
     def trunc_bin(self, v, n):                                                 # xReadTruncBinCode
         thresh = n.bit_length() - 1
@@ -480,22 +737,25 @@ class PictureWriter:
         else:
             self.cab.eps(v + val - b, thresh + 1)
 
-    def transform_tree(self, size):
+    def transform_tree(self, size, intra, root):
         mx = 1 << self.c.log2_max_tb
         if size > mx:
             for _ in range(4):                                                 # TU_MAX_TR_SPLIT: four transform units in z order
-                self.transform_tree(size >> 1)
+                self.transform_tree(size >> 1, intra, False)
             return
-        self.transform_unit(size)
+        self.transform_unit(size, intra, root)
 
-    def transform_unit(self, size):
+    def transform_unit(self, size, intra, depth0):
         cab, rng, c = self.cab, self.rng, self.c
         cb = rng.random() < c.p_cbf_chroma
         cr = rng.random() < c.p_cbf_chroma
         yy = rng.random() < c.p_cbf
         cab.bin(1 if cb else 0, "QtCbf", 0, sub=1)                             # tu_cb_coded_flag
         cab.bin(1 if cr else 0, "QtCbf", 1 if cb else 0, sub=2)                # tu_cr_coded_flag
-        cab.bin(1 if yy else 0, "QtCbf", 0, sub=0)                             # tu_y_coded_flag
+        if not intra and depth0 and not (cb or cr):
+            yy = True                                                          # (inferred: the CU has a residual and chroma has none)
+        else:
+            cab.bin(1 if yy else 0, "QtCbf", 0, sub=0)                         # tu_y_coded_flag
         if yy:
             self.residual(size, size, 0)
         if cb:
@@ -563,21 +823,43 @@ class PictureWriter:
             cab.ep(s)                                                          # coeff_sign_flag, in coding order
 
 
+NAL_TRAIL = 0
+
+
+def gop_plan(num_pictures, inter):
+    """pictures in decoding order.  Intra streams: IDR pictures only.  Inter streams: an IDR picture, then groups of four - a key picture (P, or B with
+    both lists in the past), a B picture half way between two decoded pictures (reference pictures at equal distance on either side: what DMVR and
+    BDOF ask for), its two B neighbours"""
+    if not inter:
+        return [dict(poc=0, type="I", idr=True, l0=[], l1=[]) for _ in range(num_pictures)]
+    pics = [dict(poc=0, type="I", idr=True, l0=[], l1=[])]
+    base = 0
+    while len(pics) < num_pictures:
+        k = base + 4
+        prev = [base] + ([base - 4] if base >= 4 else [])
+        pics.append(dict(poc=k, type="P" if (k // 4) % 2 else "B", idr=False, l0=prev, l1=(prev if (k // 4) % 2 == 0 else [])))
+        pics.append(dict(poc=base + 2, type="B", idr=False, l0=[base, k], l1=[k, base]))
+        pics.append(dict(poc=base + 1, type="B", idr=False, l0=[base, base + 2], l1=[base + 2, k], col_l0=0))
+        pics.append(dict(poc=base + 3, type="B", idr=False, l0=[base + 2, base], l1=[k]))
+        base = k
+    return pics[:num_pictures]
+
+
 def write_stream(c, num_pictures, seed, tables, renorm):
     rng = random.Random(seed)
     out = bytearray()
     out += nal(NAL_SPS, write_sps(c), long_start=True)
     out += nal(NAL_PPS, write_pps(c), long_start=True)
     stats = []
-    for k in range(num_pictures):
+    for pic in gop_plan(num_pictures, c.inter):
         b = Bits()
-        write_slice_header(c, b, 0, k == 0)
-        cab = Cabac(tables, renorm, 2, c.qp)
-        pw = PictureWriter(c, cab, rng)
+        write_slice_header(c, b, pic)
+        cab = Cabac(tables, renorm, {"B": 0, "P": 1, "I": 2}[pic["type"]], c.qp)
+        pw = PictureWriter(c, cab, rng, pic)
         pw.picture()
         b.b += cab.finish()
         b.trailing()
-        out += nal(NAL_IDR_N_LP, b.bytes(), long_start=True)
+        out += nal(NAL_IDR_N_LP if pic["idr"] else NAL_TRAIL, b.bytes(), long_start=True)
         stats.append(pw.stats)
     return bytes(out), stats
 
@@ -600,6 +882,11 @@ FIXTURES = [
     ("mini_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, qp=27, p_split=0.7), 2, 3),
     ("mini_ctu64_tb32_192x128_8bit", dict(width=192, height=128, log2_ctu=6, qp=35, bit_depth=8, max_tb64=False, p_cbf=0.8, p_cbf_chroma=0.6), 2, 4),
     ("mini_ctu128_nodeblock_384x256", dict(width=384, height=256, log2_ctu=7, qp=24, deblock=False, p_split=0.8), 2, 5),
+    # inter pictures: skip / merge / AMVP CUs, temporal MV prediction, BDOF and DMVR (decoder-side tools: no syntax of their own)
+    ("mini_inter_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, inter=True), 9, 11),
+    ("mini_inter_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, qp=28, inter=True, p_split=0.7), 9, 12),
+    ("mini_inter_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, qp=32, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True, p_split=0.65), 9, 13),
+    ("mini_inter_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, qp=34, bit_depth=8, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True, p_skip=0.2), 13, 14),
 ]
 
 
@@ -623,6 +910,8 @@ def main():
         assert nbytes == n * frame_bytes, "the reference decoder put out %d bytes, %d pictures of %d expected\n%s" % (nbytes, n, frame_bytes, log[-1500:])
         open(os.path.join(d, name + ".yuv.md5"), "w").write("%s  %s.yuv\n" % (md5, name))
         print("%-40s %6d bytes, %d pictures, %s  CUs %s" % (name, len(data), n, md5, [s["cus"] for s in stats]))
+        if c.inter:
+            print("     " + ", ".join("%s %d" % (k, sum(s[k] for s in stats)) for k in ("skip", "merge", "amvp", "intra", "cbf", "coefs")))
 
 
 if __name__ == "__main__":
