@@ -250,7 +250,8 @@ class Cabac:
 # ---------------------------------------------------------------------------------------------------------------------
 class Cfg:
     def __init__(self, width, height, log2_ctu=6, log2_min_qt=3, bit_depth=10, qp=30, max_tb64=True, p_split=0.6, p_cbf=0.5, p_cbf_chroma=0.3, deblock=True,
-                 inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24):
+                 inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
+                 sao=False, lmcs=False, jccr=False, dep_quant=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -306,15 +307,15 @@ def write_sps(c):
     b.flag(0)                                        # sps_transform_skip_enabled_flag
     b.flag(0)                                        # sps_mts_enabled_flag
     b.flag(0)                                        # sps_lfnst_enabled_flag
-    b.flag(0)                                        # sps_joint_cbcr_enabled_flag
+    b.flag(c.jccr)                                   # sps_joint_cbcr_enabled_flag
     b.flag(1)                                        # sps_same_qp_table_for_chroma_flag
     b.se(0)                                          # sps_qp_table_start_minus26[0]
     b.ue(0)                                          # sps_num_points_in_qp_table_minus1[0]
     b.ue(0)                                          # sps_delta_qp_in_val_minus1[0][0]
     b.ue(1)                                          # sps_delta_qp_diff_val[0][0]: the identity table
-    b.flag(0)                                        # sps_sao_enabled_flag
+    b.flag(c.sao)                                    # sps_sao_enabled_flag
     b.flag(0)                                        # sps_alf_enabled_flag
-    b.flag(0)                                        # sps_lmcs_enable_flag
+    b.flag(c.lmcs)                                   # sps_lmcs_enable_flag
     b.flag(0)                                        # sps_weighted_pred_flag
     b.flag(0)                                        # sps_weighted_bipred_flag
     b.flag(0)                                        # sps_long_term_ref_pics_flag
@@ -360,7 +361,7 @@ def write_sps(c):
     b.flag(0)                                        # sps_ibc_enabled_flag
     b.flag(0)                                        # sps_ladf_enabled_flag
     b.flag(0)                                        # sps_explicit_scaling_list_enabled_flag
-    b.flag(0)                                        # sps_dep_quant_enabled_flag
+    b.flag(c.dep_quant)                              # sps_dep_quant_enabled_flag
     b.flag(0)                                        # sps_sign_data_hiding_enabled_flag
     b.flag(0)                                        # sps_virtual_boundaries_enabled_flag
     b.flag(0)                                        # sps_timing_hrd_params_present_flag
@@ -406,6 +407,34 @@ def write_pps(c):
     return b.bytes()
 
 
+NAL_PREFIX_APS = 17
+
+
+def write_lmcs_aps(c, rng, aps_id):
+    """adaptation_parameter_set_rbsp with lmcs_data (parseAPS / parseLmcsAps): bins 1..14, code words around the default one, their sum below the range"""
+    b = Bits()
+    b.u(3, 1)                                        # aps_params_type: LMCS_APS
+    b.u(5, aps_id)                                   # aps_adaptation_parameter_set_id
+    b.flag(1)                                        # aps_chroma_present_flag
+    b.ue(1)                                          # lmcs_min_bin_idx
+    b.ue(1)                                          # lmcs_delta_max_bin_idx: LmcsMaxBinIdx = 14
+    org = (1 << c.bit_depth) // 16
+    prec = max(1, (org // 4).bit_length())
+    b.ue(prec - 1)                                   # lmcs_delta_cw_prec_minus1
+    for i in range(1, 15):
+        d = rng.randrange(-(org // 4) + 1, org // 4)
+        b.u(prec, abs(d))                            # lmcs_delta_abs_cw[i]
+        if d:
+            b.flag(d < 0)                            # lmcs_delta_sign_cw_flag[i]
+    crs = rng.randrange(-3, 4)
+    b.u(3, abs(crs))                                 # lmcs_delta_abs_crs
+    if crs:
+        b.flag(crs < 0)                              # lmcs_delta_sign_crs_flag
+    b.flag(0)                                        # aps_extension_flag
+    b.trailing()
+    return b.bytes()
+
+
 def write_rpl(b, cur_poc, ref_pocs):
     """ref_pic_list_struct (parseRefPicList): short-term entries only, deltas relative to the previous entry"""
     b.ue(len(ref_pocs))                              # num_ref_entries
@@ -433,12 +462,18 @@ def write_slice_header(c, b, pic):
         b.flag(1)                                    # ph_intra_slice_allowed_flag
     b.ue(0)                                          # ph_pic_parameter_set_id
     b.u(8, pic["poc"] & 255)                         # ph_pic_order_cnt_lsb
-    # (no ALF, LMCS, scaling lists, virtual boundaries, output flag, RPL in the PH, partition overrides, delta QP / chroma QP offset subdivisions)
+    if c.lmcs:
+        b.flag(1)                                    # ph_lmcs_enabled_flag
+        b.u(2, 0)                                    # ph_lmcs_aps_id
+        b.flag(pic.get("cscale", 1))                 # ph_chroma_residual_scale_flag
+    # (no ALF, scaling lists, virtual boundaries, output flag, RPL in the PH, partition overrides, delta QP / chroma QP offset subdivisions)
     if inter_allowed:
         if c.tmvp:
             b.flag(1)                                # ph_temporal_mvp_enabled_flag
         b.flag(0)                                    # ph_mvd_l1_zero_flag
-    # (no QP delta, joint Cb-Cr sign, SAO, deblocking info in the PH)
+    if c.jccr:
+        b.flag(pic.get("jccr_sign", 0))              # ph_joint_cbcr_sign_flag
+    # (no QP delta, SAO, deblocking info in the PH)
     # slice header proper: one slice per picture
     if inter_allowed:
         b.ue({"B": 0, "P": 1, "I": 2}[st])           # sh_slice_type
@@ -462,6 +497,11 @@ def write_slice_header(c, b, pic):
             if (col_l0 and n0 > 1) or (not col_l0 and n1 > 1):
                 b.ue(0)                              # sh_collocated_ref_idx
     b.se(c.qp - 26)                                  # sh_qp_delta
+    if c.sao:
+        b.flag(1)                                    # sh_sao_luma_used_flag
+        b.flag(1)                                    # sh_sao_chroma_used_flag
+    if c.dep_quant:
+        b.flag(1)                                    # sh_dep_quant_used_flag
     b.trailing()                                     # byte_alignment()
 
 
@@ -487,8 +527,48 @@ class PictureWriter:
         S = 1 << self.c.log2_ctu
         for y in range(0, self.c.height, S):
             for x in range(0, self.c.width, S):
+                if self.c.sao:
+                    self.sao(x, y)
                 self.coding_tree(x, y, S)
         self.cab.trm(1)                              # end_of_slice_one_bit
+
+    # -- sao( rx, ry ) (CABACReader::sao): merge left / above, else type, four offsets, band position or edge class per component
+    def sao(self, x, y):
+        cab, rng = self.cab, self.rng
+        if x > 0:
+            m = rng.random() < 0.25
+            cab.bin(1 if m else 0, "SaoMergeFlag", 0)                          # sao_merge_left_flag
+            if m:
+                return
+        if y > 0:
+            m = rng.random() < 0.25
+            cab.bin(1 if m else 0, "SaoMergeFlag", 0)                          # sao_merge_up_flag
+            if m:
+                return
+        mx = (1 << (min(self.c.bit_depth, 10) - 5)) - 1
+        mode_cb = 0
+        for comp in range(3):
+            if comp != 2:
+                mode = rng.choice([0, 1, 2])                                   # off, band offset, edge offset
+                cab.bin(1 if mode else 0, "SaoTypeIdx", 0)                     # sao_type_idx_luma / chroma
+                if mode:
+                    cab.ep(1 if mode == 2 else 0)
+                if comp == 1:
+                    mode_cb = mode
+            else:
+                mode = mode_cb
+            if not mode:
+                continue
+            offs = [rng.randrange(0, min(mx, 6) + 1) for _ in range(4)]
+            for o in offs:
+                self.unary_eq(o, mx)                                           # sao_offset_abs
+            if mode == 1:
+                for o in offs:
+                    if o:
+                        cab.ep(rng.randrange(0, 2))                            # sao_offset_sign_flag
+                cab.eps(rng.randrange(0, 32), 5)                               # sao_band_position
+            elif comp != 2:
+                cab.eps(rng.randrange(0, 4), 2)                                # sao_eo_class_luma / chroma
 
     # -- coding_tree (quad-tree only): split_cu_flag where both choices exist (CABACReader::split_cu_mode)
     def coding_tree(self, x, y, size):
@@ -756,11 +836,15 @@ class PictureWriter:
             yy = True                                                          # (inferred: the CU has a residual and chroma has none)
         else:
             cab.bin(1 if yy else 0, "QtCbf", 0, sub=0)                         # tu_y_coded_flag
+        joint = False
+        if self.c.jccr and ((intra and (cb or cr)) or (cb and cr)):
+            joint = rng.random() < 0.4
+            cab.bin(1 if joint else 0, "JointCbCrFlag", 2 * cb + cr - 1)       # tu_joint_cbcr_residual_flag
         if yy:
             self.residual(size, size, 0)
         if cb:
             self.residual(size >> 1, size >> 1, 1)
-        if cr:
+        if cr and not (joint and cb):
             self.residual(size >> 1, size >> 1, 1)
 
     # -- residual_coding: coefficients of the first 4x4 coefficient group only, levels 1..3, at most three of them (well inside the budget of
@@ -790,6 +874,7 @@ class PictureWriter:
         first = True
         tmpl_diag, tmpl_sum1 = -1, -1
         signs = []
+        state, trans = 0, (32040 if self.c.dep_quant else 0)                   # dependent quantisation: the quantiser state picks the context set of sig_coeff_flag
         for sp in range(last, -1, -1):
             x, y = SCAN4[sp]
             lv = levels.get(sp, 0)
@@ -800,7 +885,7 @@ class PictureWriter:
                 if ch == 0:
                     ofs += 4 if diag < 5 else 0
                 tmpl_diag, tmpl_sum1 = diag, s - n
-                cab.bin(1 if lv else 0, "SigFlag", ofs, sub=ch)                # sig_coeff_flag (state 0: SigFlag[chType])
+                cab.bin(1 if lv else 0, "SigFlag", ofs, sub=ch + 2 * max(0, state - 1))      # sig_coeff_flag')
             if lv:
                 off = 0
                 if tmpl_diag != -1:
@@ -818,6 +903,7 @@ class PictureWriter:
                     if px >= 0 and py >= 0:
                         s, n = tpl.get((px, py), (0, 0))
                         tpl[(px, py)] = (s + lv, n + 1)
+            state = (trans >> ((state << 2) + ((lv & 1) << 1))) & 3
             first = False
         for s in signs:
             cab.ep(s)                                                          # coeff_sign_flag, in coding order
@@ -850,6 +936,8 @@ def write_stream(c, num_pictures, seed, tables, renorm):
     out = bytearray()
     out += nal(NAL_SPS, write_sps(c), long_start=True)
     out += nal(NAL_PPS, write_pps(c), long_start=True)
+    if c.lmcs:
+        out += nal(NAL_PREFIX_APS, write_lmcs_aps(c, rng, 0), long_start=True)
     stats = []
     for pic in gop_plan(num_pictures, c.inter):
         b = Bits()
@@ -887,6 +975,10 @@ FIXTURES = [
     ("mini_inter_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, qp=28, inter=True, p_split=0.7), 9, 12),
     ("mini_inter_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, qp=32, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True, p_split=0.65), 9, 13),
     ("mini_inter_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, qp=34, bit_depth=8, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True, p_skip=0.2), 13, 14),
+    # SAO, LMCS (luma mapping + chroma residual scaling), joint Cb-Cr residuals, dependent quantisation - intra pictures, then with every inter tool
+    ("mini_filters_ctu64_256x192", dict(width=256, height=192, log2_ctu=6, qp=30, sao=True, lmcs=True, jccr=True, dep_quant=True, p_cbf=0.7, p_cbf_chroma=0.5), 3, 21),
+    ("mini_filters_inter_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, qp=29, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True,
+                                               sao=True, lmcs=True, jccr=True, dep_quant=True, p_cbf=0.6, p_cbf_chroma=0.4), 9, 22),
 ]
 
 
