@@ -2244,10 +2244,283 @@ __global__ __launch_bounds__( 256 ) void k_deblock( PicDev pic, DevPlanes r, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_deblock4 - the same edge filters with FOUR LANES PER EDGE SEGMENT (round 4).  k_deblock gave a thread a whole 4-sample segment: ~70 dependent
+// memory operations per wavefront on 2-byte accesses, one round of wavefronts on the device - latency, not bandwidth, not arithmetic (DESIGN.md
+// section 6, profiles/round3_deblock_counters.json).  Here a lane owns ONE LINE of the segment: it fetches the line's 16 samples across the edge at
+// once (four 8-byte loads along a row for vertical edges; 16 two-byte loads down a column for horizontal edges, 128 bytes per row over the
+// wavefront), parks them in LDS next to the other three lines of its quad, takes the segment's decisions from lines 0 and 3 there (every lane for
+// itself: the arithmetic is cheap, nothing is exchanged), filters its own line in LDS and writes back exactly the samples the chosen filter touched.
+// Memory round trips per lane: the edge parameters, the line, the stores.  Chroma: the two lines of a unit's Cb and Cr edge are the four lanes.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DB_LS 20          // samples per staged line in LDS (16 used: p7 .. p0 q0 .. q7; 40 bytes keep 8-byte alignment)
+
+// long luma filter of one line (filter_long, one of its four lines)
+__device__ __forceinline__ void filter_long_line( pel_t* q0, int nP, int nQ, int tc )
+{
+  const int iP = ( nP - 3 ) >> 1, iQ = ( nQ - 3 ) >> 1;
+  pel_t* p0 = q0 - 1;
+  int mid = 8;
+  for( int k = 0; k < 7; k++ ) mid += c_dbLongMidW[iP][iQ][k] * p0[-k] + c_dbLongMidW[iQ][iP][k] * q0[k];
+  mid >>= 4;
+  const int farP = ( p0[-( nP - 1 )] + p0[-nP] + 1 ) >> 1, farQ = ( q0[nQ - 1] + q0[nQ] + 1 ) >> 1;
+  for( int side = 0; side < 2; side++ )
+  {
+    pel_t* s = side ? q0 : p0; const int d = side ? 1 : -1, n = side ? nQ : nP, far = side ? farQ : farP;
+    for( int k = 0; k < n; k++ )
+    {
+      const int cf = c_dbLongCf[( n - 3 ) >> 1][k], lim = ( tc * c_dbLongTc[n > 3][k] ) >> 1, v = s[d * k];
+      s[d * k] = (pel_t) clip3( v - lim, v + lim, ( mid * cf + far * ( 64 - cf ) + 32 ) >> 6 );
+    }
+  }
+}
+
+// One line (`li`) of the luma edge segment at sample position (x, y) whose four lines are staged at `seg` (line stride DB_LS, q0 of a line at index 8):
+// deblock_luma_segment with the lines in LDS.  Returns the samples this line's filter modified: P side | Q side << 4.
+__device__ __forceinline__ int deblock_luma_line( const PicDev& pic, pel_t* seg, int li, int x, int y, int dir, const vvr_lfp& l )
+{
+  const vvr_pic_header& H = pic.hdr;
+  const int bd = H.bit_depth;
+  const int bsY = BS_GET( l.bs, 0 );
+  pel_t* src = seg + 8;
+  const int o = 1, step = DB_LS;
+  int qp = l.qp[0];
+  if( H.ladf_num_intervals )
+  {
+    const int level = ( src[0] + src[3 * step] + src[-o] + src[3 * step - o] ) >> 2;
+    int shift = H.ladf_qp_offset[0];
+    for( int k = 1; k < H.ladf_num_intervals; k++ ) { if( level > H.ladf_lower_bound[k] ) shift = H.ladf_qp_offset[k]; else break; }
+    qp += shift;
+  }
+  const int lenP = ( l.side_max_filt_length >> 4 ) & 7, lenQ = l.side_max_filt_length & 7;
+  bool pLarge = lenP > 3, qLarge = lenQ > 3;
+  if( dir == 1 && ( y & ( ( 1 << H.log2_ctu ) - 1 ) ) == 0 ) pLarge = false;
+  const int offs = deblock_offsets_at( pic, x, y, 0 );
+  const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * ( ( offs >> 8 ) - 64 ) );
+  const int idxB  = clip3( 0, 63, qp + 2 * ( ( offs & 255 ) - 64 ) );
+  const int tc = tc_value( idxTC, bd ), beta = d_db_beta_table[idxB] << ( bd - 8 );
+  const int sideThr = ( beta + ( beta >> 1 ) ) >> 3, thrCut = tc * 10;
+  const pel_t* s0 = src; const pel_t* s3 = src + 3 * step;
+  const int dp0 = calc_dp( s0, o ), dq0 = calc_dq( s0, o ), dp3 = calc_dp( s3, o ), dq3 = calc_dq( s3, o );
+  const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+  if( pLarge || qLarge )
+  {
+    const int o3 = 3 * o;
+    const int dp0L = pLarge ? ( dp0 + calc_dp( s0 - o3, o ) + 1 ) >> 1 : dp0;
+    const int dq0L = qLarge ? ( dq0 + calc_dq( s0 + o3, o ) + 1 ) >> 1 : dq0;
+    const int dp3L = pLarge ? ( dp3 + calc_dp( s3 - o3, o ) + 1 ) >> 1 : dp3;
+    const int dq3L = qLarge ? ( dq3 + calc_dq( s3 + o3, o ) + 1 ) >> 1 : dq3;
+    const int d0L = dp0L + dq0L, d3L = dp3L + dq3L, dL = d0L + d3L;
+    if( dL < beta )
+    {
+      const bool swL = use_strong( s0, o, 2 * d0L, beta, tc, pLarge, qLarge, lenP, lenQ, false ) && use_strong( s3, o, 2 * d3L, beta, tc, pLarge, qLarge, lenP, lenQ, false );
+      if( swL )
+      {
+        const int nP = pLarge ? lenP : 3, nQ = qLarge ? lenQ : 3;
+        // (the other lines are read by the other lanes' decisions: lines 0 and 3 only - which their own lanes change.  Every lane has taken its decisions
+        // from the UNFILTERED lines before any lane writes: the caller puts the quad's LDS reads in front of its writes)
+        filter_long_line( src + step * li, nP, nQ, tc );
+        return nP | ( nQ << 4 );
+      }
+    }
+  }
+  const int dp = dp0 + dp3, dq = dq0 + dq3, d = d0 + d3;
+  if( d < beta )
+  {
+    bool fP = false, fQ = false, sw = false;
+    if( lenP > 1 && lenQ > 1 ) { fP = dp < sideThr; fQ = dq < sideThr; }
+    if( lenP > 2 && lenQ > 2 ) sw = use_strong( s0, o, 2 * d0, beta, tc, false, false, 7, 7, false ) && use_strong( s3, o, 2 * d3, beta, tc, false, false, 7, 7, false );
+    pel_t* s = src + step * li;
+    if( sw ) { filter_luma_pel( s, o, tc, true, thrCut, fP, fQ, bd ); return 3 | ( 3 << 4 ); }
+    const int m2 = s[-2], m3 = s[-1], m4 = s[0], m5 = s[1];
+    const int delta = ( 9 * ( m4 - m3 ) - 3 * ( m5 - m2 ) + 8 ) >> 4;
+    if( iabs( delta ) >= thrCut ) return 0;
+    filter_luma_pel( s, o, tc, false, thrCut, fP, fQ, bd );
+    return ( fP ? 2 : 1 ) | ( ( fQ ? 2 : 1 ) << 4 );
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__( 256 ) void k_deblock4( PicDev pic, DevPlanes r, int dir )
+{
+  __shared__ pel_t lines[256 * DB_LS];
+  const int tid = threadIdx.x, quad = tid >> 2, li = tid & 3;
+  // a wavefront = 16 neighbouring units of a unit row: rows of 128 bytes over the wavefront for horizontal edges, neighbouring 32-byte windows of four
+  // rows for vertical edges; a workgroup = 16 x 4 units
+  const int x4 = blockIdx.x * 16 + ( quad & 15 ), y4 = blockIdx.y * 4 + ( quad >> 4 );
+  if( x4 >= pic.w4 || y4 >= pic.h4 ) return;
+  const vvr_lfp* lp = pic.lfp[dir] + (size_t) y4 * pic.w4 + x4;
+  const vvr_lfp l = *lp;
+  const vvr_pic_header& H = pic.hdr;
+  const int bd = H.bit_depth;
+  pel_t* const seg = &lines[( tid & ~3 ) * DB_LS];           // the quad's four lines
+  pel_t* const mine = seg + li * DB_LS;
+  const int nStep = dir == 0 ? 2 : 2 * pic.w4;                      // table distance of the unit 8 samples across the edge
+  const bool hasNext = dir == 0 ? x4 + 2 < pic.w4 : y4 + 2 < pic.h4, hasPrev = dir == 0 ? x4 >= 2 : y4 >= 2;
+  // (the LDS accesses of a wavefront execute in order; the quad's lanes sit in one wavefront: what the compiler must not do is move them across)
+#define DB_SYNC() asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" )
+  if( BS_GET( l.bs, 0 ) && !( hasNext && db_luma_p7( lp[nStep] ) ) )
+  {
+    pel_t* __restrict__ P = r.p[0];
+    const int stride = r.stride[0], W = r.w[0], Hh = r.h[0];
+    // sample k of this lane's line (k = 0: 8 samples before the edge): where it lies in the plane
+    const int x = x4 * 4, y = y4 * 4;
+    auto loadLine = [&]( int ex, int ey, int k0, int k1 )            // samples k0 .. k1 - 1 of the line of the segment at (ex, ey) into `mine`
+    {
+      if( dir == 0 )
+      {
+        const pel_t* row = P + (size_t) ( ey + li ) * stride;
+#pragma unroll
+        for( int c = 0; c < 4; c++ )
+        {
+          if( 4 * c < k0 || 4 * c >= k1 ) continue;
+          const int cx = ex - 8 + 4 * c;
+          uint2 v = make_uint2( 0, 0 );
+          if( cx >= 0 && cx < W ) v = *reinterpret_cast<const uint2*>( row + cx );
+          *reinterpret_cast<uint2*>( mine + 4 * c ) = v;
+        }
+      }
+      else
+      {
+        const pel_t* col = P + ex + li;
+        int v[16];
+#pragma unroll
+        for( int k = 0; k < 16; k++ ) { const int ry = ey - 8 + k; v[k] = ( k >= k0 && k < k1 && ry >= 0 && ry < Hh ) ? (int) col[(size_t) ry * stride] : 0; }
+#pragma unroll
+        for( int k = 0; k < 16; k++ ) if( k >= k0 && k < k1 ) mine[k] = (pel_t) v[k];
+      }
+    };
+    auto storeLine = [&]( int ex, int ey, int mod )                   // the samples the filter modified: mod & 15 before the edge, mod >> 4 behind it
+    {
+      const int nP = mod & 15, nQ = mod >> 4;
+      if( dir == 0 )
+      {
+        pel_t* row = P + (size_t) ( ey + li ) * stride + ex;
+        for( int k = 1; k <= nP; k++ ) row[-k] = mine[8 - k];
+        for( int k = 0; k < nQ; k++ ) row[k] = mine[8 + k];
+      }
+      else
+      {
+        pel_t* col = P + (size_t) ey * stride + ex + li;
+        for( int k = 1; k <= nP; k++ ) col[-(ptrdiff_t) k * stride] = mine[8 - k];
+        for( int k = 0; k < nQ; k++ ) col[(size_t) k * stride] = mine[8 + k];
+      }
+    };
+    bool havePside = false;
+    if( db_luma_p7( l ) && hasPrev )
+    {
+      // the one overlapping pair: a coding-sub-block edge 8 samples before an edge whose P side is filtered over 7 samples - that edge first, by the
+      // same four lanes (the reference's raster order), and its Q side is what this edge finds on its P side
+      const vvr_lfp lPrev = lp[-nStep];
+      if( BS_GET( lPrev.bs, 0 ) )
+      {
+        const int px = dir == 0 ? x - 8 : x, py = dir == 0 ? y : y - 8;
+        loadLine( px, py, 0, 16 );
+        DB_SYNC();
+        const int mod = deblock_luma_line( pic, seg, li, px, py, dir, lPrev );
+        DB_SYNC();
+        storeLine( px, py, mod );
+        // its Q side (samples 8 .. 15 of the staged line) becomes this edge's P side (samples 0 .. 7)
+        uint2 a = *reinterpret_cast<const uint2*>( mine + 8 ), b = *reinterpret_cast<const uint2*>( mine + 12 );
+        DB_SYNC();
+        *reinterpret_cast<uint2*>( mine ) = a; *reinterpret_cast<uint2*>( mine + 4 ) = b;
+        havePside = true;
+      }
+    }
+    loadLine( x, y, havePside ? 8 : 0, 16 );
+    DB_SYNC();
+    const int mod = deblock_luma_line( pic, seg, li, x, y, dir, l );
+    DB_SYNC();
+    storeLine( x, y, mod );
+  }
+  if( !l.bs ) return;
+  // ---- chroma (4:2:0): edges on the 8-chroma-sample grid, two chroma lines per 4x4 luma unit: lanes 0, 1 = the lines of Cb, lanes 2, 3 = the lines of Cr
+  if( !H.chroma_format ) return;
+  if( dir == 0 ? ( x4 & 3 ) : ( y4 & 3 ) ) return;
+  const int bS[2] = { BS_GET( l.bs, 1 ), BS_GET( l.bs, 2 ) };
+  if( !bS[0] && !bS[1] ) return;
+  const int c = li >> 1, cl = li & 1;
+  const bool large = ( l.flags >> 5 ) & 1;
+  const int bSc = c ? bS[1] : bS[0];
+  const bool active = bSc == 2 || ( large && bSc == 1 );
+  const int stride = r.stride[1], cx = x4 * 2, cy = y4 * 2, CW = r.w[1], CH = r.h[1];
+  pel_t* __restrict__ Pc = c ? r.p[2] : r.p[1];
+  const bool ctb = dir == 1 && ( cy & ( ( ( 1 << H.log2_ctu ) - 1 ) >> 1 ) ) == 0;
+  // this lane's line: samples 4 .. 11 of the staged line = 4 before and 4 behind the edge (q0 at index 8, like luma); both lines of a component are needed
+  // for the decision, so both of its lanes stage theirs first
+  DB_SYNC();
+  if( active )
+  {
+    if( dir == 0 )
+    {
+      const pel_t* row = Pc + (size_t) ( cy + cl ) * stride;
+#pragma unroll
+      for( int k = 0; k < 2; k++ )
+      {
+        const int sx = cx - 4 + 4 * k;
+        uint2 v = make_uint2( 0, 0 );
+        if( sx >= 0 && sx < CW ) v = *reinterpret_cast<const uint2*>( row + sx );
+        *reinterpret_cast<uint2*>( mine + 4 + 4 * k ) = v;
+      }
+    }
+    else
+    {
+      const pel_t* col = Pc + cx + cl;
+      int v[8];
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) { const int ry = cy - 4 + k; v[k] = ( ry >= 0 && ry < CH ) ? (int) col[(size_t) ry * stride] : 0; }
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) mine[4 + k] = (pel_t) v[k];
+    }
+  }
+  DB_SYNC();
+  if( !active ) return;
+  {
+    pel_t* src = seg + ( c * 2 ) * DB_LS + 8;                     // q0 of the component's first line; its second line is DB_LS further
+    const int o = 1, step = DB_LS;
+    const int qp = c ? l.qp[2] : l.qp[1];
+    const int offs = deblock_offsets_at( pic, x4 * 4, y4 * 4, 1 + c );      // offsets of the deblocked CTU's slice (LoopFilter.cpp:1637-1638)
+    const int idxTC = clip3( 0, 65, qp + 2 * ( bSc - 1 ) + 2 * ( ( offs >> 8 ) - 64 ) );
+    const int tc = tc_value( idxTC, bd );
+    bool sw = false;
+    if( large )
+    {
+      const int idxB = clip3( 0, 63, qp + 2 * ( ( offs & 255 ) - 64 ) );
+      const int beta = d_db_beta_table[idxB] * ( 1 << ( bd - 8 ) );
+      const int dp0 = ctb ? calc_dp_ctb( src, o ) : calc_dp( src, o ), dq0 = calc_dq( src, o );
+      const int dp3 = ctb ? calc_dp_ctb( src + step, o ) : calc_dp( src + step, o ), dq3 = calc_dq( src + step, o );
+      const int d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
+      if( d < beta ) sw = use_strong( src, o, 2 * d0, beta, tc, false, false, 7, 7, ctb ) && use_strong( src + step, o, 2 * d3, beta, tc, false, false, 7, 7, ctb );
+    }
+    DB_SYNC();                                                      // (both lanes of the component have read both lines)
+    pel_t* s = src + step * cl;
+    filter_chroma_pel( s, o, tc, sw, bd, ctb );
+    DB_SYNC();
+    const int nP = sw ? ( ctb ? 1 : 3 ) : 1, nQ = sw ? 3 : 1;
+    if( dir == 0 )
+    {
+      pel_t* row = Pc + (size_t) ( cy + cl ) * stride + cx;
+      for( int k = 1; k <= nP; k++ ) row[-k] = s[-k];
+      for( int k = 0; k < nQ; k++ ) row[k] = s[k];
+    }
+    else
+    {
+      pel_t* col = Pc + (size_t) cy * stride + cx + cl;
+      for( int k = 1; k <= nP; k++ ) col[-(ptrdiff_t) k * stride] = s[-k];
+      for( int k = 0; k < nQ; k++ ) col[(size_t) k * stride] = s[k];
+    }
+  }
+#undef DB_SYNC
+}
+
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )
 {
   if( pic.hdr.tool_flags & VVR_TOOL_DEBLOCK_OFF ) return;
-  hipLaunchKernelGGL( k_deblock, dim3( ( pic.w4 + 15 ) / 16, ( pic.h4 + 15 ) / 16 ), dim3( 256 ), 0, s, pic, reco, dir );
+#ifdef VVR_DEV_ENV
+  static const bool one = getenv( "VVR_DEBLOCK_ONE_LANE" ) != nullptr;      // developer build: the kernel of rounds 1 - 3 (a thread per segment), for comparison
+  if( one ) { hipLaunchKernelGGL( k_deblock, dim3( ( pic.w4 + 15 ) / 16, ( pic.h4 + 15 ) / 16 ), dim3( 256 ), 0, s, pic, reco, dir ); return; }
+#endif
+  hipLaunchKernelGGL( k_deblock4, dim3( ( pic.w4 + 15 ) / 16, ( pic.h4 + 3 ) / 4 ), dim3( 256 ), 0, s, pic, reco, dir );
 }
 
 // =====================================================================================================================
