@@ -86,6 +86,7 @@ static void stamp_picture( const PicDev& pic, DevPlanes reco )
 // SAO + ALF pass, every other picture is deblocked in its slot)
 static bool reaches_slot_with_sao_alf( const PicDev& pic ) { return ( pic.hdr.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA | VVR_TOOL_ALF ) ) != 0; }
 void launch_deblock( hipStream_t, const PicDev& pic, DevPlanes reco, int dir ) { if( dir == 0 && !reaches_slot_with_sao_alf( pic ) ) stamp_picture( pic, reco ); }
+void launch_deblock_tile( hipStream_t, const PicDev&, DevPlanes, DevPlanes, int, bool ) {}
 bool sao_alf_fused( const PicDev& ) { return true; }
 void launch_sao_alf( hipStream_t, const PicDev& pic, DevPlanes, DevPlanes dst, bool, bool ) { if( g_delayUs ) usleep( 2 * g_delayUs ); stamp_picture( pic, dst ); }
 void launch_sao( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) { if( g_delayUs ) usleep( 2 * g_delayUs ); }

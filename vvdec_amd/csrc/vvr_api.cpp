@@ -355,7 +355,12 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   const bool sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) != 0 && stopAfter != 1 && stopAfter != 2;
   const bool alf = ( h.tool_flags & VVR_TOOL_ALF ) != 0 && stopAfter == 0;
   const bool fused = ( sao || alf ) && sao_alf_fused( q->pic );
-  const DevPlanes P = fused ? B : A;
+  // With the fused SAO + ALF pass (scratch -> slot) behind them the two deblocking passes run out of place, a tile per workgroup: vertical edges slot -> scratch
+  // picture (the inverse luma mapping in the load), horizontal edges scratch picture -> the residual planes (free once the picture is reconstructed), SAO + ALF from
+  // there into the slot.  Without deblocking: reconstructed in the scratch picture.
+  const bool dbOn = !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF ) && stopAfter != 1;
+  const bool hop = fused && dbOn;
+  const DevPlanes P = ( fused && !hop ) ? B : A;
   auto timedOn = [&]( int k, hipStream_t st, double algoBytes, auto&& fn )
   {
 #ifdef VVR_WATCHDOG
@@ -416,14 +421,19 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   }
   else if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
-  if( lmcsOn ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, P, 1 ); } );
+  if( lmcsOn && !hop ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, P, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
-  if( !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF ) && stopAfter != 1 )
+  if( hop )
+  {
+    timed( K_DEBLOCK_V, [&]{ launch_deblock_tile( s, q->pic, A, B, 0, lmcsOn ); } );
+    timed( K_DEBLOCK_H, [&]{ launch_deblock_tile( s, q->pic, B, R, 1, false ); } );
+  }
+  else if( dbOn )
   {
     timed( K_DEBLOCK_V, [&]{ launch_deblock( s, q->pic, P, 0 ); } );
     timed( K_DEBLOCK_H, [&]{ launch_deblock( s, q->pic, P, 1 ); } );
   }
-  if( fused ) timed( K_ALF, [&]{ launch_sao_alf( s, q->pic, B, A, sao, alf ); } );
+  if( fused ) timed( K_ALF, [&]{ launch_sao_alf( s, q->pic, hop ? R : B, A, sao, alf ); } );
   else if( sao && alf ) { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
   else if( sao )   { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_COPY, [&]{ launch_copy_planes( s, B, A ); } ); }
   else if( alf )   { timed( K_COPY, [&]{ launch_copy_planes( s, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }

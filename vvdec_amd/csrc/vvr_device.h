@@ -130,6 +130,7 @@ void launch_mc     ( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPl
 void launch_expand_mc( hipStream_t s, const PicDev& pic, const McCuRef* cus, int numCus, McItem* plain, McItem* bdof, McItem* dmvr );
 void launch_itrans ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const TbItem* items, int numItems, int sizeClass );
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir );
+void launch_deblock_tile( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst, int dir, bool lmcs );      // one direction out of place (tiles); vertical edges: inverse LMCS in the load
 void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 void launch_alf    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );
 bool sao_alf_fused ( const PicDev& pic );      // SAO + ALF in one pass (launch_sao_alf) apply to this picture; else launch_sao, launch_alf

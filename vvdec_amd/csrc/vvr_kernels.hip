@@ -2255,38 +2255,18 @@ __global__ __launch_bounds__( 256 ) void k_deblock( PicDev pic, DevPlanes r, int
 // ---------------------------------------------------------------------------------------------------------------------
 #define DB_LS 20          // samples per staged line in LDS (16 used: p7 .. p0 q0 .. q7; 40 bytes keep 8-byte alignment)
 
-// long luma filter of one line (filter_long, one of its four lines)
-__device__ __forceinline__ void filter_long_line( pel_t* q0, int nP, int nQ, int tc )
-{
-  const int iP = ( nP - 3 ) >> 1, iQ = ( nQ - 3 ) >> 1;
-  pel_t* p0 = q0 - 1;
-  int mid = 8;
-  for( int k = 0; k < 7; k++ ) mid += c_dbLongMidW[iP][iQ][k] * p0[-k] + c_dbLongMidW[iQ][iP][k] * q0[k];
-  mid >>= 4;
-  const int farP = ( p0[-( nP - 1 )] + p0[-nP] + 1 ) >> 1, farQ = ( q0[nQ - 1] + q0[nQ] + 1 ) >> 1;
-  for( int side = 0; side < 2; side++ )
-  {
-    pel_t* s = side ? q0 : p0; const int d = side ? 1 : -1, n = side ? nQ : nP, far = side ? farQ : farP;
-    for( int k = 0; k < n; k++ )
-    {
-      const int cf = c_dbLongCf[( n - 3 ) >> 1][k], lim = ( tc * c_dbLongTc[n > 3][k] ) >> 1, v = s[d * k];
-      s[d * k] = (pel_t) clip3( v - lim, v + lim, ( mid * cf + far * ( 64 - cf ) + 32 ) >> 6 );
-    }
-  }
-}
-
-// One line (`li`) of the luma edge segment at sample position (x, y) whose four lines are staged at `seg` (line stride DB_LS, q0 of a line at index 8):
-// deblock_luma_segment with the lines in LDS.  Returns the samples this line's filter modified: P side | Q side << 4.
-__device__ __forceinline__ int deblock_luma_line( const PicDev& pic, pel_t* seg, int li, int x, int y, int dir, const vvr_lfp& l )
+// The DECISIONS of a luma edge segment, taken from its lines 0 and 3 (VVC 8.8.3.6.2, xEdgeFilterLuma LoopFilter.cpp:1389-1570): `src` = q0 of line 0, `o` = distance
+// of neighbouring samples across the edge, `step` = distance of the segment's lines.  -> code: bits 0-1 the filter (0 none, 1 long, 2 strong, 3 weak), bits 2-4
+// the P-side length of the long filter (weak: bit 2 = the second P sample too), bits 5-7 the same for Q, bits 8.. tc
+__device__ __forceinline__ uint32_t deblock_luma_decide( const PicDev& pic, const pel_t* src, int o, int step, int x, int y, int dir, const vvr_lfp& l )
 {
   const vvr_pic_header& H = pic.hdr;
   const int bd = H.bit_depth;
   const int bsY = BS_GET( l.bs, 0 );
-  pel_t* src = seg + 8;
-  const int o = 1, step = DB_LS;
   int qp = l.qp[0];
   if( H.ladf_num_intervals )
   {
+    // luma-adaptive deblocking: QP offset chosen by the mean of four samples at the corners of the segment (deriveLADFShift, LoopFilter.cpp:1363-1386)
     const int level = ( src[0] + src[3 * step] + src[-o] + src[3 * step - o] ) >> 2;
     int shift = H.ladf_qp_offset[0];
     for( int k = 1; k < H.ladf_num_intervals; k++ ) { if( level > H.ladf_lower_bound[k] ) shift = H.ladf_qp_offset[k]; else break; }
@@ -2295,11 +2275,12 @@ __device__ __forceinline__ int deblock_luma_line( const PicDev& pic, pel_t* seg,
   const int lenP = ( l.side_max_filt_length >> 4 ) & 7, lenQ = l.side_max_filt_length & 7;
   bool pLarge = lenP > 3, qLarge = lenQ > 3;
   if( dir == 1 && ( y & ( ( 1 << H.log2_ctu ) - 1 ) ) == 0 ) pLarge = false;
+  // the offsets of the slice the deblocked CTU belongs to - the CTU that holds the segment, its Q side (LoopFilter.cpp:421,1473)
   const int offs = deblock_offsets_at( pic, x, y, 0 );
   const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * ( ( offs >> 8 ) - 64 ) );
   const int idxB  = clip3( 0, 63, qp + 2 * ( ( offs & 255 ) - 64 ) );
   const int tc = tc_value( idxTC, bd ), beta = d_db_beta_table[idxB] << ( bd - 8 );
-  const int sideThr = ( beta + ( beta >> 1 ) ) >> 3, thrCut = tc * 10;
+  const int sideThr = ( beta + ( beta >> 1 ) ) >> 3;
   const pel_t* s0 = src; const pel_t* s3 = src + 3 * step;
   const int dp0 = calc_dp( s0, o ), dq0 = calc_dq( s0, o ), dp3 = calc_dp( s3, o ), dq3 = calc_dq( s3, o );
   const int d0 = dp0 + dq0, d3 = dp3 + dq3;
@@ -2314,14 +2295,7 @@ __device__ __forceinline__ int deblock_luma_line( const PicDev& pic, pel_t* seg,
     if( dL < beta )
     {
       const bool swL = use_strong( s0, o, 2 * d0L, beta, tc, pLarge, qLarge, lenP, lenQ, false ) && use_strong( s3, o, 2 * d3L, beta, tc, pLarge, qLarge, lenP, lenQ, false );
-      if( swL )
-      {
-        const int nP = pLarge ? lenP : 3, nQ = qLarge ? lenQ : 3;
-        // (the other lines are read by the other lanes' decisions: lines 0 and 3 only - which their own lanes change.  Every lane has taken its decisions
-        // from the UNFILTERED lines before any lane writes: the caller puts the quad's LDS reads in front of its writes)
-        filter_long_line( src + step * li, nP, nQ, tc );
-        return nP | ( nQ << 4 );
-      }
+      if( swL ) return 1u | ( ( pLarge ? lenP : 3 ) << 2 ) | ( ( qLarge ? lenQ : 3 ) << 5 ) | ( (uint32_t) tc << 8 );
     }
   }
   const int dp = dp0 + dp3, dq = dq0 + dq3, d = d0 + d3;
@@ -2330,15 +2304,58 @@ __device__ __forceinline__ int deblock_luma_line( const PicDev& pic, pel_t* seg,
     bool fP = false, fQ = false, sw = false;
     if( lenP > 1 && lenQ > 1 ) { fP = dp < sideThr; fQ = dq < sideThr; }
     if( lenP > 2 && lenQ > 2 ) sw = use_strong( s0, o, 2 * d0, beta, tc, false, false, 7, 7, false ) && use_strong( s3, o, 2 * d3, beta, tc, false, false, 7, 7, false );
-    pel_t* s = src + step * li;
-    if( sw ) { filter_luma_pel( s, o, tc, true, thrCut, fP, fQ, bd ); return 3 | ( 3 << 4 ); }
-    const int m2 = s[-2], m3 = s[-1], m4 = s[0], m5 = s[1];
-    const int delta = ( 9 * ( m4 - m3 ) - 3 * ( m5 - m2 ) + 8 ) >> 4;
-    if( iabs( delta ) >= thrCut ) return 0;
-    filter_luma_pel( s, o, tc, false, thrCut, fP, fQ, bd );
-    return ( fP ? 2 : 1 ) | ( ( fQ ? 2 : 1 ) << 4 );
+    if( sw ) return 2u | ( (uint32_t) tc << 8 );
+    return 3u | ( fP ? 4u : 0u ) | ( fQ ? 32u : 0u ) | ( (uint32_t) tc << 8 );
   }
   return 0;
+}
+
+// long luma filter of one line (filter_long, one of its four lines)
+__device__ __forceinline__ void filter_long_line( pel_t* q0, int o, int nP, int nQ, int tc )
+{
+  const int iP = ( nP - 3 ) >> 1, iQ = ( nQ - 3 ) >> 1;
+  pel_t* p0 = q0 - o;
+  int mid = 8;
+  for( int k = 0; k < 7; k++ ) mid += c_dbLongMidW[iP][iQ][k] * p0[-k * o] + c_dbLongMidW[iQ][iP][k] * q0[k * o];
+  mid >>= 4;
+  const int farP = ( p0[-( nP - 1 ) * o] + p0[-nP * o] + 1 ) >> 1, farQ = ( q0[( nQ - 1 ) * o] + q0[nQ * o] + 1 ) >> 1;
+  for( int side = 0; side < 2; side++ )
+  {
+    pel_t* s = side ? q0 : p0; const int d = side ? o : -o, n = side ? nQ : nP, far = side ? farQ : farP;
+    for( int k = 0; k < n; k++ )
+    {
+      const int cf = c_dbLongCf[( n - 3 ) >> 1][k], lim = ( tc * c_dbLongTc[n > 3][k] ) >> 1, v = s[d * k];
+      s[d * k] = (pel_t) clip3( v - lim, v + lim, ( mid * cf + far * ( 64 - cf ) + 32 ) >> 6 );
+    }
+  }
+}
+
+// the filter a segment's decisions chose, on ONE of its lines (`q0` = the line's first sample behind the edge)
+__device__ __forceinline__ void deblock_luma_apply( pel_t* q0, int o, uint32_t code, int bd )
+{
+  const int kind = code & 3, tc = code >> 8;
+  if( kind == 1 ) filter_long_line( q0, o, ( code >> 2 ) & 7, ( code >> 5 ) & 7, tc );
+  else if( kind == 2 ) filter_luma_pel( q0, o, tc, true, 0, false, false, bd );
+  else if( kind == 3 ) filter_luma_pel( q0, o, tc, false, tc * 10, ( code & 4 ) != 0, ( code & 32 ) != 0, bd );
+}
+
+// One line (`li`) of the luma edge segment at sample position (x, y) whose four lines are staged at `seg` (line stride `step`, q0 of a line at index 8): decisions
+// by every lane for itself, then the lane's own line.  Returns the samples this line's filter modified: P side | Q side << 4.
+__device__ __forceinline__ int deblock_luma_line( const PicDev& pic, pel_t* seg, int li, int x, int y, int dir, const vvr_lfp& l, const int step = DB_LS )
+{
+  const uint32_t code = deblock_luma_decide( pic, seg + 8, 1, step, x, y, dir, l );
+  // (the other lanes take their decisions from lines 0 and 3 too - which their own lanes change: every lane has read them before any lane writes)
+  asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
+  pel_t* s = seg + 8 + step * li;
+  const int kind = code & 3;
+  if( !kind ) return 0;
+  if( kind == 1 ) { deblock_luma_apply( s, 1, code, pic.hdr.bit_depth ); return ( ( code >> 2 ) & 7 ) | ( ( ( code >> 5 ) & 7 ) << 4 ); }
+  if( kind == 2 ) { deblock_luma_apply( s, 1, code, pic.hdr.bit_depth ); return 3 | ( 3 << 4 ); }
+  const int tc = code >> 8, m2 = s[-2], m3 = s[-1], m4 = s[0], m5 = s[1];
+  const int delta = ( 9 * ( m4 - m3 ) - 3 * ( m5 - m2 ) + 8 ) >> 4;
+  if( iabs( delta ) >= tc * 10 ) return 0;
+  deblock_luma_apply( s, 1, code, pic.hdr.bit_depth );
+  return ( ( code & 4 ) ? 2 : 1 ) | ( ( ( code & 32 ) ? 2 : 1 ) << 4 );
 }
 
 __global__ __launch_bounds__( 256 ) void k_deblock4( PicDev pic, DevPlanes r, int dir )
@@ -2511,6 +2528,292 @@ __global__ __launch_bounds__( 256 ) void k_deblock4( PicDev pic, DevPlanes r, in
     }
   }
 #undef DB_SYNC
+}
+
+
+// One line (`cl` = 0 / 1) of the chroma edge segment of a 4x4 luma unit, the two lines staged at `src` (q0 of the first line; line stride `step`): decision from both
+// lines (`o` = distance of neighbouring samples across the edge), filter of the own line.  Returns the samples modified: P side | Q side << 4.  The caller keeps the pair's reads in front of its writes (DB_SYNC).
+__device__ __forceinline__ int deblock_chroma_line( const PicDev& pic, pel_t* src, int o, int step, int cl, int c, int x4, int y4, int dir, const vvr_lfp& l, int bSc, bool large )
+{
+  const vvr_pic_header& H = pic.hdr;
+  const int bd = H.bit_depth, cy = y4 * 2;
+  const bool ctb = dir == 1 && ( cy & ( ( ( 1 << H.log2_ctu ) - 1 ) >> 1 ) ) == 0;
+  const int qp = c ? l.qp[2] : l.qp[1];
+  const int offs = deblock_offsets_at( pic, x4 * 4, y4 * 4, 1 + c );      // offsets of the deblocked CTU's slice (LoopFilter.cpp:1637-1638)
+  const int idxTC = clip3( 0, 65, qp + 2 * ( bSc - 1 ) + 2 * ( ( offs >> 8 ) - 64 ) );
+  const int tc = tc_value( idxTC, bd );
+  bool sw = false;
+  if( large )
+  {
+    const int idxB = clip3( 0, 63, qp + 2 * ( ( offs & 255 ) - 64 ) );
+    const int beta = d_db_beta_table[idxB] * ( 1 << ( bd - 8 ) );
+    const int dp0 = ctb ? calc_dp_ctb( src, o ) : calc_dp( src, o ), dq0 = calc_dq( src, o );
+    const int dp3 = ctb ? calc_dp_ctb( src + step, o ) : calc_dp( src + step, o ), dq3 = calc_dq( src + step, o );
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
+    if( d < beta ) sw = use_strong( src, o, 2 * d0, beta, tc, false, false, 7, 7, ctb ) && use_strong( src + step, o, 2 * d3, beta, tc, false, false, 7, 7, ctb );
+  }
+  asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );                // (both lanes of the component have read both lines)
+  filter_chroma_pel( src + step * cl, o, tc, sw, bd, ctb );
+  return ( sw ? ( ctb ? 1 : 3 ) : 1 ) | ( ( sw ? 3 : 1 ) << 4 );
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_deblock_tile<LMCS, DIR> - the edges of one direction, a TILE per workgroup, OUT OF PLACE (round 4); vertical edges: 128 x 16 luma samples (and the 64 x 8 of
+// Cb and Cr) with the inverse luma mapping in the load (k_lmcs is not launched), horizontal edges: 64 x 64.
+// With a lane per line (k_deblock4) the vertical pass still took 46 us: its lines run along rows, so every store instruction of a wavefront put 2 bytes into each
+// of 64 different cache lines, 14 such instructions per edge; and in both passes the four lanes of a segment each took the segment's decisions - three quarters
+// of the instructions the device issued.  Here the workgroup OWNS a tile.  It loads it with the halo its edges read - 16 samples before the tile: the P side of
+// the first edge and the sub-block edge 8 samples before that, the one overlapping pair; 8 behind it: the Q side of the edge on the tile's far border, whose P
+// side changes the tile's last samples - with wide loads, all issued before the first barrier; lists the segments that have an edge at all (an eighth at a mean
+// block size of 32); takes the decisions ONE LANE PER SEGMENT; applies the filters four lanes per segment, a line each; and writes the whole tile with 16-byte
+// stores into ANOTHER picture buffer (a neighbour's halo must see unfiltered samples).  The edge on the far border is filtered by two workgroups, each keeping
+// its side.  Chroma: two lines per segment and component, a lane per line.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DT_HL 16                                    // halo before the tile (across the edges)
+#define DT_HR 8                                     // halo behind it
+template<int DIR> struct DbTile;
+template<> struct DbTile<0> { static constexpr int N = 128, T = 16; };      // N: owned samples across the edges, T: along them
+template<> struct DbTile<1> { static constexpr int N = 64, T = 64; };
+template<bool LMCS, int DIR>
+__global__ __launch_bounds__( 256 ) void k_deblock_tile( PicDev pic, DevPlanes s, DevPlanes d, int dbg )
+{
+  constexpr int NT = 256;
+  constexpr int N = DbTile<DIR>::N, T = DbTile<DIR>::T, NN = DT_HL + N + DT_HR, NNC = 4 + N / 2 + 4;
+  constexpr int TS = ( DIR == 0 ? NN : T ) + 4, CS = ( DIR == 0 ? NNC : T / 2 ) + 4;          // LDS row strides (rows stay 8-byte aligned)
+  constexpr int YO = DIR == 0 ? 1 : TS, YSTEP = DIR == 0 ? TS : 1;                            // luma: across the edge / from line to line
+  constexpr int CO = DIR == 0 ? 1 : CS, CSTEP = DIR == 0 ? CS : 1;
+  constexpr int EC = N / 4 + 1, EA = T / 4, NE = EC * EA;                                      // edge positions across (the far border's included) x units along
+  __shared__ pel_t ty[( DIR == 0 ? T : NN ) * TS];
+  __shared__ pel_t tc[2][( DIR == 0 ? T / 2 : NNC ) * CS];
+  __shared__ int16_t lut[LMCS ? 1024 : 2];
+  __shared__ vvr_lfp edge[NE];
+  __shared__ uint16_t list[NE];
+  __shared__ uint32_t codes[NE];
+  __shared__ int cnt;
+  const int tid = threadIdx.x;
+  const int X0 = blockIdx.x * ( DIR == 0 ? N : T ), Y0 = blockIdx.y * ( DIR == 0 ? T : N ), X4 = X0 >> 2, Y4 = Y0 >> 2;
+  const vvr_pic_header& H = pic.hdr;
+  const int W = s.w[0], Hh = s.h[0], bd = H.bit_depth;
+  const bool chroma = H.chroma_format != 0;
+  // ---- every global load of the workgroup first, into registers: the table, the edge parameters, the samples (one memory latency, not three)
+  constexpr int NLF = ( NE + NT - 1 ) / NT;
+  constexpr int NLU = 512 / NT;
+  if( tid == 0 ) cnt = 0;
+  uint32_t lutv[NLU];
+  if( LMCS )
+  {
+    const uint32_t* lp32 = reinterpret_cast<const uint32_t*>( pic.lmcs->inv_lut ); const int n2 = ( 1 << bd ) >> 1;
+#pragma unroll
+    for( int k = 0; k < NLU; k++ ) { lutv[k] = 0; if( tid + NT * k < n2 ) lutv[k] = lp32[tid + NT * k]; }
+  }
+  const int lfAcross = DIR == 0 ? 2 : 2 * pic.w4;                    // table distance of the unit 8 samples across the edge
+  vvr_lfp lf[NLF]; uint32_t lfMine = 0;
+#pragma unroll
+  for( int k = 0; k < NLF; k++ )
+  {
+    vvr_lfp& l = lf[k];
+    l.qp[0] = l.qp[1] = l.qp[2] = 0; l.bs = 0; l.side_max_filt_length = 0; l.flags = 0; l.pad[0] = l.pad[1] = 0;
+    const int t = tid + NT * k, e = t % EC, a = t / EC, x4 = X4 + ( DIR == 0 ? e : a ), y4 = Y4 + ( DIR == 0 ? a : e );
+    if( t < NE && x4 < pic.w4 && y4 < pic.h4 )
+    {
+      const vvr_lfp* lp = pic.lfp[DIR] + (size_t) y4 * pic.w4 + x4;
+      l = *lp;
+      bool nextP7 = false;
+      if( DIR == 0 ? x4 + 2 < pic.w4 : y4 + 2 < pic.h4 ) nextP7 = db_luma_p7( lp[lfAcross] );
+      // a luma edge that is this segment's to filter (not the first of an overlapping pair: its partner takes both)
+      if( BS_GET( l.bs, 0 ) && !nextP7 ) lfMine |= 1u << k;
+    }
+  }
+  // luma chunks: vertical edges 4 samples (8 bytes) of a row, horizontal edges 8 samples (16 bytes) of a row; chroma the same
+  constexpr int LCPR = DIR == 0 ? NN / 4 : T / 8, LROWS = DIR == 0 ? T : NN, NLC = ( LROWS * LCPR + NT - 1 ) / NT;
+  constexpr int CCPR = DIR == 0 ? NNC / 4 : T / 16, CROWS = DIR == 0 ? T / 2 : NNC, NCC = ( 2 * CROWS * CCPR + NT - 1 ) / NT;
+  uint4 yv[NLC], cv[NCC];
+  uint32_t ymap = 0;
+  {
+    const pel_t* __restrict__ P = s.p[0];
+    const int stride = s.stride[0];
+#pragma unroll
+    for( int k = 0; k < NLC; k++ )
+    {
+      const int i = tid + NT * k, r = i / LCPR, c = i - r * LCPR;
+      const int x = DIR == 0 ? X0 - DT_HL + 4 * c : X0 + 8 * c, y = DIR == 0 ? Y0 + r : Y0 - DT_HL + r;
+      yv[k] = make_uint4( 0, 0, 0, 0 );
+      if( i < LROWS * LCPR && y >= 0 && y < Hh && x >= 0 && x < W && !( dbg & 2 ) )
+      {
+        if( DIR == 0 ) { const uint2 v = *reinterpret_cast<const uint2*>( P + (size_t) y * stride + x ); yv[k].x = v.x; yv[k].y = v.y; }
+        else yv[k] = *reinterpret_cast<const uint4*>( P + (size_t) y * stride + x );
+        if( LMCS && ( !pic.slices || ( flags_at( pic, x, y ) & VVR_TOOL_LMCS ) ) ) ymap |= 1u << k;        // the CTU's slice uses LMCS (Reshape.cpp:385)
+      }
+    }
+    if( chroma )
+    {
+      const int CW = s.w[1], CH = s.h[1], cstride = s.stride[1];
+#pragma unroll
+      for( int k = 0; k < NCC; k++ )
+      {
+        const int i = tid + NT * k, pl = i / ( CROWS * CCPR ), j = i - pl * CROWS * CCPR, r = j / CCPR, c = j - r * CCPR;
+        const int x = DIR == 0 ? X0 / 2 - 4 + 4 * c : X0 / 2 + 8 * c, y = DIR == 0 ? Y0 / 2 + r : Y0 / 2 - 4 + r;
+        cv[k] = make_uint4( 0, 0, 0, 0 );
+        if( i < 2 * CROWS * CCPR && y >= 0 && y < CH && x >= 0 && x < CW )
+        {
+          const pel_t* p = s.p[1 + pl] + (size_t) y * cstride + x;
+          if( DIR == 0 ) { const uint2 v = *reinterpret_cast<const uint2*>( p ); cv[k].x = v.x; cv[k].y = v.y; }
+          else cv[k] = *reinterpret_cast<const uint4*>( p );
+        }
+      }
+    }
+  }
+  if( LMCS )
+  {
+    uint32_t* l32 = reinterpret_cast<uint32_t*>( lut ); const int n2 = ( 1 << bd ) >> 1;
+#pragma unroll
+    for( int k = 0; k < NLU; k++ ) if( tid + NT * k < n2 ) l32[tid + NT * k] = lutv[k];
+  }
+  __syncthreads();
+  // ---- the tile's edge parameters and the list of the segments to filter
+#pragma unroll
+  for( int k = 0; k < NLF; k++ )
+  {
+    const int t = tid + NT * k;
+    if( t < NE ) { edge[t] = lf[k]; if( ( lfMine >> k ) & 1 ) list[atomicAdd( &cnt, 1 )] = (uint16_t) t; }
+  }
+  // ---- the samples into the tile, luma through the inverse table of the slice
+  {
+    const int n1 = ( 1 << bd ) - 1;
+#pragma unroll
+    for( int k = 0; k < NLC; k++ )
+    {
+      const int i = tid + NT * k, r = i / LCPR, c = i - r * LCPR;
+      uint4 v = yv[k];
+      if( LMCS && ( ( ymap >> k ) & 1 ) )
+      {
+        v.x = (uint32_t) (uint16_t) lut[v.x & 0xffff & n1] | ( (uint32_t) (uint16_t) lut[( v.x >> 16 ) & n1] << 16 );
+        v.y = (uint32_t) (uint16_t) lut[v.y & 0xffff & n1] | ( (uint32_t) (uint16_t) lut[( v.y >> 16 ) & n1] << 16 );
+        if( DIR == 1 )
+        {
+          v.z = (uint32_t) (uint16_t) lut[v.z & 0xffff & n1] | ( (uint32_t) (uint16_t) lut[( v.z >> 16 ) & n1] << 16 );
+          v.w = (uint32_t) (uint16_t) lut[v.w & 0xffff & n1] | ( (uint32_t) (uint16_t) lut[( v.w >> 16 ) & n1] << 16 );
+        }
+      }
+      if( i < LROWS * LCPR )
+      {
+        pel_t* q = &ty[r * TS + ( DIR == 0 ? 4 : 8 ) * c];
+        *reinterpret_cast<uint2*>( q ) = make_uint2( v.x, v.y );
+        if( DIR == 1 ) *reinterpret_cast<uint2*>( q + 4 ) = make_uint2( v.z, v.w );
+      }
+    }
+    if( chroma )
+    {
+#pragma unroll
+      for( int k = 0; k < NCC; k++ )
+      {
+        const int i = tid + NT * k, pl = i / ( CROWS * CCPR ), j = i - pl * CROWS * CCPR, r = j / CCPR, c = j - r * CCPR;
+        if( i < 2 * CROWS * CCPR )
+        {
+          pel_t* q = &tc[pl][r * CS + ( DIR == 0 ? 4 : 8 ) * c];
+          *reinterpret_cast<uint2*>( q ) = make_uint2( cv[k].x, cv[k].y );
+          if( DIR == 1 ) *reinterpret_cast<uint2*>( q + 4 ) = make_uint2( cv[k].z, cv[k].w );
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- luma decisions: a lane per listed segment.  q0 of line 0 of segment (e, a): DT_HL + 4 e across, 4 a along
+  // (a tile has some 25 of them: one wavefront's work, and a different wavefront - SIMD - of the workgroup from tile to tile, or the first SIMD of every compute
+  // unit would take the decisions of all its workgroups)
+  const int nEdges = ( dbg & 1 ) ? 0 : cnt;
+  const int rot = ( dbg & 16 ) ? 0 : ( ( blockIdx.x + blockIdx.y ) & 3 ) * 64;
+  for( int i = ( tid + rot ) & ( NT - 1 ); i < nEdges; i += NT )
+  {
+    const int t = list[i], e = t % EC, a = t / EC, x4 = X4 + ( DIR == 0 ? e : a ), y4 = Y4 + ( DIR == 0 ? a : e ), x = x4 * 4, y = y4 * 4;
+    const vvr_lfp le = edge[t];
+    pel_t* q0 = &ty[( DT_HL + 4 * e ) * YO + ( 4 * a ) * YSTEP];
+    if( db_luma_p7( le ) && ( DIR == 0 ? x4 >= 2 : y4 >= 2 ) )
+    {
+      // the one overlapping pair: a coding-sub-block edge 8 samples before an edge whose P side is filtered over 7 samples - that edge first, decisions and all four
+      // lines by this lane (the reference's raster order); its Q side is what this edge finds on its P side
+      const vvr_lfp lPrev = e >= 2 ? edge[t - 2] : pic.lfp[DIR][(size_t) y4 * pic.w4 + x4 - lfAcross];
+      if( BS_GET( lPrev.bs, 0 ) )
+      {
+        const uint32_t cp = deblock_luma_decide( pic, q0 - 8 * YO, YO, YSTEP, DIR == 0 ? x - 8 : x, DIR == 0 ? y : y - 8, DIR, lPrev );
+        for( int li = 0; li < 4; li++ ) deblock_luma_apply( q0 - 8 * YO + li * YSTEP, YO, cp, bd );
+      }
+    }
+    codes[i] = ( dbg & 64 ) ? ( 2u | ( 5u << 8 ) ) : deblock_luma_decide( pic, q0, YO, YSTEP, x, y, DIR, le );
+  }
+  __syncthreads();
+  // ---- luma filters: four lanes per listed segment, a line each
+  for( int i = ( tid + rot + 64 ) & ( NT - 1 ); i < 4 * nEdges; i += NT )
+  {
+    const uint32_t code = codes[i >> 2];
+    if( !( code & 3 ) || ( dbg & 32 ) ) continue;
+    const int t = list[i >> 2], e = t % EC, a = t / EC;
+    deblock_luma_apply( &ty[( DT_HL + 4 * e ) * YO + ( 4 * a + ( i & 3 ) ) * YSTEP], YO, code, bd );
+  }
+  // ---- chroma: edges on the 8-chroma-sample grid (every 4th edge position), two lines per unit and component, a lane per line
+  if( chroma && !( dbg & 8 ) )
+  {
+    constexpr int CE = N / 16 + 1, PER = CE * ( T / 2 );             // lines of a component
+    for( int t = tid; t < 2 * PER; t += NT )
+    {
+      const int c = t / PER, rem = t - c * PER, ce = rem / ( T / 2 ), line = rem % ( T / 2 ), a = line >> 1, cl = line & 1;
+      const vvr_lfp lc = edge[a * EC + 4 * ce];
+      const int bSc = BS_GET( lc.bs, 1 + c );
+      const bool large = ( lc.flags >> 5 ) & 1;
+      if( bSc == 2 || ( large && bSc == 1 ) )
+        deblock_chroma_line( pic, &tc[c][( 4 + 8 * ce ) * CO + ( 2 * a ) * CSTEP], CO, CSTEP, cl, c, X4 + ( DIR == 0 ? 4 * ce : a ), Y4 + ( DIR == 0 ? a : 4 * ce ), DIR, lc, bSc, large );
+    }
+  }
+  __syncthreads();
+  // ---- the tile, 16 bytes per lane and store
+  {
+    constexpr int OW = DIR == 0 ? N : T, OH = DIR == 0 ? T : N, OX = DIR == 0 ? DT_HL : 0, OY = DIR == 0 ? 0 : DT_HL;
+    for( int i = tid; i < OH * ( OW / 8 ); i += NT )
+    {
+      const int r = i / ( OW / 8 ), c = i % ( OW / 8 ), x = X0 + 8 * c, y = Y0 + r;
+      if( y < Hh && x < W && !( dbg & 4 ) )
+      {
+        const pel_t* q = &ty[( OY + r ) * TS + OX + 8 * c];
+        const uint2 a = *reinterpret_cast<const uint2*>( q ), b = *reinterpret_cast<const uint2*>( q + 4 );
+        *reinterpret_cast<uint4*>( d.p[0] + (size_t) y * d.stride[0] + x ) = make_uint4( a.x, a.y, b.x, b.y );
+      }
+    }
+    if( chroma )
+    {
+      constexpr int CWo = OW / 2, CHo = OH / 2, CX = DIR == 0 ? 4 : 0, CY = DIR == 0 ? 0 : 4;
+      for( int i = tid; i < 2 * CHo * ( CWo / 8 ); i += NT )
+      {
+        const int pl = i / ( CHo * ( CWo / 8 ) ), j = i % ( CHo * ( CWo / 8 ) ), r = j / ( CWo / 8 ), c = j % ( CWo / 8 ), x = X0 / 2 + 8 * c, y = Y0 / 2 + r;
+        if( y < s.h[1] && x < s.w[1] )
+        {
+          const pel_t* q = &tc[pl][( CY + r ) * CS + CX + 8 * c];
+          const uint2 a = *reinterpret_cast<const uint2*>( q ), b = *reinterpret_cast<const uint2*>( q + 4 );
+          *reinterpret_cast<uint4*>( d.p[1 + pl] + (size_t) y * d.stride[1] + x ) = make_uint4( a.x, a.y, b.x, b.y );
+        }
+      }
+    }
+  }
+}
+
+// one pass out of place (src -> dst); vertical edges: the inverse luma mapping folded in when `lmcs`
+void launch_deblock_tile( hipStream_t st, const PicDev& pic, DevPlanes src, DevPlanes dst, int dir, bool lmcs )
+{
+  int dbg = 0;
+#ifdef VVR_DEV_ENV
+  static const int dbgEnv = getenv( "VVR_DBV_DBG" ) ? atoi( getenv( "VVR_DBV_DBG" ) ) : 0;      // developer build: 1 no edges, 2 no luma loads, 4 no luma stores, 8 no chroma edges (timing only)
+  dbg = dbgEnv;
+#endif
+  if( dir == 0 )
+  {
+    const dim3 grid( ( src.w[0] + DbTile<0>::N - 1 ) / DbTile<0>::N, ( src.h[0] + DbTile<0>::T - 1 ) / DbTile<0>::T );
+    if( lmcs ) hipLaunchKernelGGL( ( k_deblock_tile<true, 0> ), grid, dim3( 256 ), 0, st, pic, src, dst, dbg );
+    else       hipLaunchKernelGGL( ( k_deblock_tile<false, 0> ), grid, dim3( 256 ), 0, st, pic, src, dst, dbg );
+  }
+  else
+  {
+    const dim3 grid( ( src.w[0] + DbTile<1>::T - 1 ) / DbTile<1>::T, ( src.h[0] + DbTile<1>::N - 1 ) / DbTile<1>::N );
+    hipLaunchKernelGGL( ( k_deblock_tile<false, 1> ), grid, dim3( 256 ), 0, st, pic, src, dst, dbg );
+  }
 }
 
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )
