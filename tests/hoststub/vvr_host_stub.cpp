@@ -177,6 +177,7 @@ __attribute__(( visibility( "default" ) )) void vvt_set_delay( int us ) { g_dela
 __attribute__(( visibility( "default" ) )) void vvt_slow_i_pictures( int us ) { g_vvtSlowIUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_slow_b_pictures( int us ) { g_vvtSlowBUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_events_pending( int on ) { g_eventsPending = on; }
+__attribute__(( visibility( "default" ) )) int vvt_band_pictures( void ) { return vvr_host_band_pictures(); }      // pictures with inter CUs whose work lists were built in bands by the workers together
 __attribute__(( visibility( "default" ) )) int vvt_dead_event_uses( void ) { return g_deadEventUses; }      // uses of an event after hipEventDestroy since the library was loaded
 __attribute__(( visibility( "default" ) )) unsigned long long vvt_overtakes( vvr_context* c ) { return c->overtakes; }
 __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { return which == 0 ? sizeof( IntraUnit ) : which == 1 ? sizeof( IntraItem ) : 0; }

@@ -839,8 +839,9 @@ def test_worker_threads_commit_in_submission_order(stub):
 
 
 def test_i_pictures_are_prepared_by_the_workers_together(stub):
-    """the work lists of a picture whose CUs are all intra CUs are built in parts (bands of CTU rows) by the worker threads together and appended in band
-    order: everything that is uploaded for a stream - I pictures of several sizes among B pictures - is byte for byte what one thread uploads"""
+    """the work lists of a picture are built in parts (bands of CTU rows) by the worker threads together and appended in band order - an I picture always, a
+    picture with inter CUs while the device is short of work: everything that is uploaded for a stream - I pictures of several sizes among B pictures - is
+    byte for byte what one thread uploads"""
     stub.vvt_take_h2d_hash.restype = C.c_ulonglong
     stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
     stub.vvr_wait.argtypes = [C.c_void_p, C.c_int]
@@ -869,7 +870,11 @@ def test_i_pictures_are_prepared_by_the_workers_together(stub):
         one = run(0, W, H, l2, 9, 4, 4, T, **kw)
         assert len(set(one)) == len(one)
         for threads in (2, 3, 8):
+            before = stub.vvt_band_pictures()
             assert run(threads, W, H, l2, 9, 4, 4, T, **kw) == one, (W, H, threads)
+            # (submitted one at a time the device is always short of work: the B pictures go the same way, what a band reads of the band above looked up when
+            # the bands are joined)
+            assert stub.vvt_band_pictures() - before >= (5 if W >= 832 else 0), (W, H, threads)        # (the smallest size has too few CUs to be split)
     # records that are wrong in a part other than the first are reported like by one thread
     plans, nslots = stream.ra_plan(1, gop=1, seed_poc0_is_external=False)
     d = synth.picture_for_plan(plans[0], 1920, 1080, seed=531, tool_flags=TOOLS)

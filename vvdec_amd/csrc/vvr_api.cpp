@@ -126,7 +126,7 @@ struct Job {
   std::vector<vvr_motion> col;      // collocated motion (VVR_TOOL_COL_MOTION), likewise
   bool handled = false;             // committed (or failed) ahead of its turn: its bySeq entry stays until the commit front passes it
 #ifdef VVR_WATCHDOG
-  double tSubmit = 0, tPrep = 0, tBuilt = 0, tRing = 0, tReady = 0, tCommit0 = 0, tCommit1 = 0;      // developer build: where a picture spends its time on the host
+  double tSubmit = 0, tPrep = 0, tBuilt = 0, tRing = 0, tReady = 0, tCommit0 = 0, tCommit1 = 0; hipEvent_t tlA = nullptr, tlB = nullptr; int tlPoc = 0, tlType = 0; unsigned long long tlSeq = 0;      // developer build: where a picture spends its time on the host
 #endif
 };
 
@@ -180,6 +180,10 @@ struct vvr_context {
   PrepScratch* inlineScratch = nullptr; // host_threads == 0, and vvr_prepare
   PinnedRanges pinned;                  // vvr_host_alloc
   bool       statsOn = false;
+  int        partsPolicy = 2;              // pictures with inter CUs built in bands by the workers together: 0 never, 1 always, 2 while the device is short of work (VVR_PARTS)
+#ifdef VVR_WATCHDOG
+  hipEvent_t tlBase = nullptr; double tlBaseHost = 0, tl0 = 0;      // developer build, VVR_TIMELINE: device times of a picture relative to the first commit of a burst
+#endif
   Stat       stats[K_NUM];
   void setError( const std::string& e ) { err = e; }
 };
@@ -228,6 +232,14 @@ static hipEvent_t takeEvent( vvr_context* c )
 static void completeLocked( vvr_context* c, Job& j )
 {
   if( j.completed ) return;
+#ifdef VVR_WATCHDOG
+  if( j.tlA && j.tlB && c->tlBase )
+  {
+    float a = 0, b = 0; hipEventElapsedTime( &a, c->tlBase, j.tlA ); hipEventElapsedTime( &b, c->tlBase, j.tlB );
+    fprintf( stderr, "[vvr timeline] device seq %3llu poc %4d type %d lane %d: %6.2f .. %6.2f  (base event recorded at host %6.2f)\n", j.tlSeq, j.tlPoc, j.tlType, j.lane, a, b, c->tlBaseHost - c->tl0 );
+  }
+  if( j.tlA ) { hipEventDestroy( j.tlA ); j.tlA = nullptr; } if( j.tlB ) { hipEventDestroy( j.tlB ); j.tlB = nullptr; }
+#endif
   for( auto& t : j.timings )
   {
     float ms = 0; hipEventElapsedTime( &ms, t.a, t.b );
@@ -344,6 +356,19 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
 #endif
 #ifdef VVR_WATCHDOG
   const double wdC = wdNow(); g_wdPart[1] += wdC - wdB; g_wdPartMax[1] = std::max( g_wdPartMax[1], wdC - wdB );
+  // VVR_TIMELINE: when the picture's kernels start and end on the device, relative to an event recorded with the first commit of a burst
+  static const bool tlOn = getenv( "VVR_TIMELINE" ) != nullptr;
+  if( tlOn && job.ring )
+  {
+    if( job.tSubmit - c->tl0 > 50 )
+    {
+      static hipStream_t tlStream = nullptr; if( !tlStream ) hipStreamCreate( &tlStream );      // (an idle stream: the event completes when it is recorded)
+      c->tl0 = job.tSubmit; hipEventCreate( &c->tlBase ); hipEventRecord( c->tlBase, tlStream ); c->tlBaseHost = wdNow();
+      fprintf( stderr, "[vvr timeline] ---- (host: ms since the first submit of the burst; device: ms since the base event)\n" );
+    }
+    hipEventCreate( &job.tlA ); hipEventCreate( &job.tlB ); job.tlPoc = h.poc; job.tlType = h.slice_type; job.tlSeq = job.seq;
+    hipEventRecord( job.tlA, s );
+  }
 #endif
   const RefSet& refs = plan.refs;
   DevPlanes A = c->slots[h.out_slot], B = c->scratchB[lane], R = c->scratchR[lane];
@@ -440,6 +465,9 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
 #ifdef VVR_WATCHDOG
   const double wdD = wdNow(); g_wdPart[2] += wdD - wdC; g_wdPartMax[2] = std::max( g_wdPartMax[2], wdD - wdC );
 #endif
+#ifdef VVR_WATCHDOG
+  if( job.tlB ) hipEventRecord( job.tlB, s );
+#endif
   hipError_t le = hipGetLastError();
   if( le == hipSuccess ) le = hipEventRecord( job.done, s );
   if( le == hipSuccess ) le = hipEventRecord( job.doneHost, s );
@@ -520,8 +548,8 @@ static void commitReady( vvr_context* c )
     { const double ms = std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - wdT0 ).count(); g_wdEnqMs = g_wdEnqMs + ms; g_wdEnqMax = std::max( g_wdEnqMax, ms ); g_wdEnqN++; WD_STAMP( *j, tCommit1 );
       if( j->ring ) { g_wdSum[0] += j->tPrep - j->tSubmit; g_wdSum[1] += j->tBuilt - j->tPrep; g_wdSum[2] += j->tRing - j->tBuilt; g_wdSum[3] += j->tReady - j->tRing; g_wdSum[4] += j->tCommit0 - j->tReady; g_wdSum[5] += j->tCommit1 - j->tCommit0; g_wdJobs++; }
       // developer build: one line per picture with the times of its host stages (VVR_TIMELINE)
-      static const bool tl = getenv( "VVR_TIMELINE" ) != nullptr; static double tl0 = 0;
-      if( tl && j->ring ) { if( j->tSubmit - tl0 > 50 ) { tl0 = j->tSubmit; fprintf( stderr, "[vvr timeline] ---- (ms since the first submit of the burst)\n" ); }
+      static const bool tl = getenv( "VVR_TIMELINE" ) != nullptr; const double tl0 = c->tl0;
+      if( tl && j->ring ) {
         fprintf( stderr, "[vvr timeline] seq %3llu poc %4d type %d: submit %6.2f prepare %6.2f built %6.2f ring %6.2f ready %6.2f commit %6.2f..%6.2f\n", (unsigned long long) j->seq, j->pic.hdr.poc, j->pic.hdr.slice_type,
                  j->tSubmit - tl0, j->tPrep - tl0, j->tBuilt - tl0, j->tRing - tl0, j->tReady - tl0, j->tCommit0 - tl0, j->tCommit1 - tl0 ); } }
 #endif
@@ -587,6 +615,22 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S, HostHelpers* h
   if( g_vvtSlowBUs && job.pic.hdr.slice_type != 2 ) std::this_thread::sleep_for( std::chrono::microseconds( g_vvtSlowBUs ) );
 #endif
   size_t total = 0; std::string err;
+  // A picture with inter CUs is normally one worker's job (pictures side by side: no joining, no waiting for the slowest band).  While the device has
+  // next to nothing to do - the first pictures of a burst, a stream that is submitted picture by picture - the workers build it together, in bands
+  // (vvr_host_build): what counts then is when the picture reaches the device, 4.5 ms for a 4K B picture on one thread.
+  if( helpers )
+  {
+    int policy = c->partsPolicy;
+    bool parts = policy == 1;
+    if( policy == 2 )
+    {
+      std::lock_guard<std::mutex> lk( c->mu );
+      int ahead = 0;        // pictures the device has or is about to get
+      for( auto& kv : c->jobs ) { const Job& j = *kv.second; if( !j.completed && j.seq < job.seq && ( j.state == J_COMMITTED || j.state == J_READY ) ) ahead++; }
+      parts = ahead < c->numLanesRR;
+    }
+    vvr_scratch_parts_for_all( &S, parts );
+  }
   WD_STAMP( job, tPrep );
   // (the CU / TU records are checked here - on the way, by whoever builds the part - unless there are no workers: then vvr_submit has checked them)
   int rc = vvr_host_build( &job.pic, S, &total, err, &c->pinned, helpers, !c->workers.empty() );
@@ -876,6 +920,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   // (also without worker threads: vvr_submit_prepared and inline submission order pictures the same way)
   const int nl = ns + ( ns >= 2 ? 1 : 0 );
   c->numLanesRR = ns; c->prioLane = nl > ns ? ns : -1;
+  if( const char* e = getenv( "VVR_PARTS" ) ) c->partsPolicy = atoi( e );      // 0 / 1 / 2: see partsPolicy
   c->streams.resize( nl, nullptr );
   bool ok = true;
   for( int i = 0; i < ns && ok; i++ ) ok = hipStreamCreateWithFlags( &c->streams[i], hipStreamNonBlocking ) == hipSuccess;

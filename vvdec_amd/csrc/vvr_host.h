@@ -54,6 +54,8 @@ struct DirectCopy { const void* src; size_t n, off; };
 // Reusable scratch of one preparing thread: the lists are built here (no allocation in the steady state), then packed into pinned memory.
 struct PrepScratch;
 PrepScratch* vvr_scratch_create();
+int          vvr_host_band_pictures();
+void         vvr_scratch_parts_for_all( PrepScratch*, bool on );      // the next pictures built with this scratch: in bands of CTU rows over the helpers whatever their kind (else: I pictures only)
 void         vvr_scratch_destroy( PrepScratch* );
 void         vvr_scratch_warm( PrepScratch*, const vvr_config& cfg );      // allocate and touch room for an ordinary picture of this size (call from the thread that will use it)
 

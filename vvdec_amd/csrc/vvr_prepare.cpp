@@ -7,6 +7,7 @@
 // staging memory of the upload ring.  No device call happens here.
 #include "vvr_host.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -162,6 +163,12 @@ struct PrepScratch
     const uint32_t start = (uint32_t) csProdPool.size();
     auto look = [&]( int lx, int ly )
     {
+      if( ly < partTopY )
+      {
+        if( ( ly >> 2 ) != ( partTopY >> 2 ) - 1 ) { partBad = true; return; }
+        csProdPool.push_back( 0x80000000u | (uint32_t) pending.size() ); pending.push_back( (uint32_t) ( lx >> 2 ) );      // (component 0)
+        return;
+      }
       const int32_t id = itemAtGet( 0, cellIdx( lx >> 2, ly >> 2 ) );
       if( id >= 0 && std::find( csProdPool.begin() + start, csProdPool.end(), (uint32_t) id ) == csProdPool.end() ) csProdPool.push_back( (uint32_t) id );
     };
@@ -178,6 +185,14 @@ struct PrepScratch
   int mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string& err );
   bool anyIntra = false; uint32_t curCtuIdx = 0;
   uint32_t partCtu0 = 0, partCtu1 = 0xffffffffu;      // (buildInParts) the CTUs the CUs of the range being built have to lie in
+  // (buildInParts, pictures with producer analysis) A band of CTU rows is analysed without the band above it: what a block reads of the last cell row of that
+  // band (reference lines, CCLM templates, the luma of a chroma scaling factor) is entered as a PENDING producer - ( 1 << 31 | index into `pending` ), the entry
+  // = component << 16 | cell column - and looked up when the bands are joined, in `edgeRow` (owner: per component and cell column the block, in picture-wide
+  // numbering, that reconstructs the cell of the last cell row of the band joined before)
+  int partTopY = 0; bool partBad = false;
+  bool partsForAll = false;                // (set by whoever owns the scratch) pictures with inter CUs are built in bands too
+  std::vector<uint32_t> pending;
+  std::vector<int32_t> edgeRow[3];
   bool allIntraCus = false;                // every CU of the picture is an intra CU: every CTU takes the fast path, nobody ever looks a producer up
   int buildWorkLists( std::string& err, uint32_t cu0 = 0, uint32_t cu1 = 0xffffffffu );
   int buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool validate, std::string& err );
@@ -190,6 +205,9 @@ struct PrepScratch
 };
 
 PrepScratch* vvr_scratch_create() { return new PrepScratch(); }
+void vvr_scratch_parts_for_all( PrepScratch* S, bool on ) { S->partsForAll = on; }
+static std::atomic<int> g_bandPictures{ 0 };
+int vvr_host_band_pictures() { return g_bandPictures.load(); }      // (tests) pictures with producer analysis that were built in bands so far
 
 // Room for the lists of an ordinary picture of the context's size, allocated AND written once, by the thread that is going to use the scratch
 // (first touch decides where the pages live).  A vector that has to grow in the middle of a picture is a new mapping, a copy and a page fault
@@ -751,6 +769,15 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
             {
               const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
               if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
+              if( ly < partTopY )
+              {
+                // a cell of the band above (its last cell row: nothing else is ever read across a CTU row): looked up when the bands are joined
+                if( ( ly >> 2 ) != ( partTopY >> 2 ) - 1 ) { partBad = true; return; }
+                const uint32_t pe = ( (uint32_t) k << 16 ) | (uint32_t) ( lx >> 2 );
+                if( !pending.empty() && pending.back() == pe && pool.size() > IH.p0 && pool.back() == ( 0x80000000u | (uint32_t) ( pending.size() - 1 ) ) ) return;
+                pool.push_back( 0x80000000u | (uint32_t) pending.size() ); pending.push_back( pe ); lastKey = 0xffffffffu;
+                return;
+              }
               const int32_t d = itemAtGet( k, cellIdx( lx >> 2, ly >> 2 ) );
               if( d < 0 ) return;
               const uint32_t key = ( (uint32_t) k << 28 ) | (uint32_t) d;
@@ -1466,6 +1493,8 @@ int PrepScratch::buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool
   struct Shared { std::mutex mu; std::condition_variable cv; int turn = 0; int rc = VVR_OK; std::string err; uint64_t area[2] = { 0, 0 }; } sh;
   const vvr_picture* pic = p;
   PrepScratch* owner = this;
+  const bool analysed = !allIntraCus;            // blocks name their producers: what a band reads of the band above is resolved when the bands are joined
+  if( analysed ) { g_bandPictures++; for( int k = 0; k < ncomp; k++ ) edgeRow[k].assign( (size_t) w4, -1 ); }
   helpers.run( n, *this, [&]( int part, PrepScratch& R )
   {
     const int row0 = (int) ( (int64_t) owner->ctusY * part / n ), row1 = (int) ( (int64_t) owner->ctusY * ( part + 1 ) / n );
@@ -1477,8 +1506,10 @@ int PrepScratch::buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool
     {
       if( &R != owner ) { R.begin( pic ); rc = R.beginMaps( owner ); }
       R.partCtu0 = (uint32_t) row0 * owner->ctusX; R.partCtu1 = (uint32_t) row1 * owner->ctusX;
+      R.partTopY = analysed ? row0 << owner->h.log2_ctu : 0; R.partBad = false; R.pending.clear();
       if( rc == VVR_OK ) rc = R.buildWorkLists( e, cu0, cu1 );
-      R.partCtu0 = 0; R.partCtu1 = 0xffffffffu;
+      if( rc == VVR_OK && R.partBad ) { rc = VVR_ERR_UNSUPPORTED; e = "a block reads further up than the CTU row above it"; }
+      R.partCtu0 = 0; R.partCtu1 = 0xffffffffu; R.partTopY = 0;
     }
     // append in band order (the owner's own part is the first and already in place)
     std::unique_lock<std::mutex> lk( sh.mu );
@@ -1487,23 +1518,71 @@ int PrepScratch::buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool
     if( rc == VVR_OK && sh.rc == VVR_OK )
     {
       sh.area[0] += area[0]; sh.area[1] += area[1];
+      PrepScratch& O = *owner;
+      uint32_t off[3] = { 0, 0, 0 };
       if( &R != owner )
       {
-        for( int k = 0; k < owner->ncomp; k++ )
+        for( int k = 0; k < O.ncomp; k++ ) off[k] = (uint32_t) O.intra[k].size();
+        for( int k = 0; k < O.ncomp; k++ )
         {
-          owner->intra[k].insert( owner->intra[k].end(), R.intra[k].begin(), R.intra[k].end() );
-          owner->itemH[k].insert( owner->itemH[k].end(), R.itemH[k].begin(), R.itemH[k].end() );        // (no producer lists in all-intra CTUs: p0 / pn stay 0)
+          O.intra[k].insert( O.intra[k].end(), R.intra[k].begin(), R.intra[k].end() );
+          if( !analysed ) O.itemH[k].insert( O.itemH[k].end(), R.itemH[k].begin(), R.itemH[k].end() );        // (no producer lists in all-intra CTUs: p0 / pn stay 0)
+          else
+          {
+            // the producer lists in picture-wide numbering; pending producers from the edge row the band above left behind; no producer twice
+            std::vector<uint32_t>& pool = O.prodPool[k];
+            for( ItemH IH : R.itemH[k] )
+            {
+              const uint32_t p0 = (uint32_t) pool.size();
+              for( uint32_t q = IH.p0; q < IH.p0 + IH.pn; q++ )
+              {
+                uint32_t key = R.prodPool[k][q];
+                if( key & 0x80000000u )
+                {
+                  const uint32_t pe = R.pending[key & 0x7fffffffu], kk = pe >> 16;
+                  const int32_t id = O.edgeRow[kk][pe & 0xffff];
+                  if( id < 0 ) continue;
+                  key = ( kk << 28 ) | (uint32_t) id;
+                }
+                else key = ( key & 0xf0000000u ) | ( ( key & 0x0fffffffu ) + off[key >> 28] );
+                if( std::find( pool.begin() + p0, pool.end(), key ) == pool.end() ) pool.push_back( key );
+              }
+              IH.p0 = p0; IH.pn = (uint32_t) pool.size() - p0;
+              O.itemH[k].push_back( IH );
+            }
+          }
         }
-        for( int k = 0; k < 3; k++ ) owner->tb[k].insert( owner->tb[k].end(), R.tb[k].begin(), R.tb[k].end() );
-        for( int k = 0; k < K_NUM; k++ ) owner->bytes[k] += R.bytes[k];
-        owner->bytesIntraLuma += R.bytesIntraLuma; for( int k = 0; k < 3; k++ ) owner->bytesTb[k] += R.bytesTb[k];
-        for( uint32_t c = (uint32_t) row0 * owner->ctusX; c < (uint32_t) row1 * owner->ctusX; c++ ) owner->fastCtu[c] = R.fastCtu[c];
-        if( owner->cscale )
+        for( int k = 0; k < 3; k++ ) O.tb[k].insert( O.tb[k].end(), R.tb[k].begin(), R.tb[k].end() );
+        for( int k = 0; k < K_NUM; k++ ) O.bytes[k] += R.bytes[k];
+        O.bytesIntraLuma += R.bytesIntraLuma; O.bytesBdof += R.bytesBdof; for( int k = 0; k < 3; k++ ) O.bytesTb[k] += R.bytesTb[k];
+        for( uint32_t c = (uint32_t) row0 * O.ctusX; c < (uint32_t) row1 * O.ctusX; c++ ) O.fastCtu[c] = R.fastCtu[c];
+        if( O.cscale )
         {
-          const int nv = 1 << ( owner->h.log2_ctu - owner->vpduLog2 );
-          const size_t v0 = (size_t) row0 * nv * owner->vpdusX, v1 = std::min( (size_t) row1 * nv, (size_t) owner->vpdusY ) * owner->vpdusX;
-          if( v1 > v0 ) memcpy( &owner->csVpduV[v0], &R.csVpduV[v0], sizeof( uint32_t ) * ( v1 - v0 ) );
+          const int nv = 1 << ( O.h.log2_ctu - O.vpduLog2 );
+          const size_t v0 = (size_t) row0 * nv * O.vpdusX, v1 = std::min( (size_t) row1 * nv, (size_t) O.vpdusY ) * O.vpdusX;
+          if( v1 > v0 ) memcpy( &O.csVpduV[v0], &R.csVpduV[v0], sizeof( uint32_t ) * ( v1 - v0 ) );
         }
+        // the inter stage: tiles the host writes (the sub-block motion of affine tiles sits behind what is there already), CUs whose tiles the device writes
+        {
+          const int32_t affOff = (int32_t) O.affMv.size();
+          const size_t a0 = O.mcAff.size();
+          O.mc.insert( O.mc.end(), R.mc.begin(), R.mc.end() );
+          O.mcBdof.insert( O.mcBdof.end(), R.mcBdof.begin(), R.mcBdof.end() );
+          O.mcDmvr.insert( O.mcDmvr.end(), R.mcDmvr.begin(), R.mcDmvr.end() );
+          O.mcAff.insert( O.mcAff.end(), R.mcAff.begin(), R.mcAff.end() );
+          if( !( O.h.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) ) for( size_t i = a0; i < O.mcAff.size(); i++ ) O.mcAff[i].mv[0][0] += affOff;
+          O.affMv.insert( O.affMv.end(), R.affMv.begin(), R.affMv.end() );
+          for( McCuRef m : R.mcCus ) { m.first += O.devTiles[m.first >> 30]; O.mcCus.push_back( m ); }
+          for( int k = 0; k < 3; k++ ) O.devTiles[k] += R.devTiles[k];
+          O.numDmvr = std::max( O.numDmvr, R.numDmvr );
+          O.resiAdd.insert( O.resiAdd.end(), R.resiAdd.begin(), R.resiAdd.end() );
+        }
+      }
+      if( analysed && part + 1 < n )
+      {
+        // what the next band reads of this one: the blocks of its last cell row
+        const int cy = ( std::min( row1 << O.h.log2_ctu, (int) O.h.height ) - 1 ) >> 2;
+        for( int k = 0; k < O.ncomp; k++ ) for( int cx = 0; cx < O.w4; cx++ ) { const int32_t d = R.itemAtGet( k, R.cellIdx( cx, cy ) ); O.edgeRow[k][cx] = d < 0 ? -1 : d + (int32_t) off[k]; }
       }
     }
     sh.turn = part + 1;
@@ -1519,10 +1598,13 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
   S.begin( p );
   int rc;
   // an I picture without intra block copy whose CUs are all intra CUs (beginMaps looks): in parts, when there is somebody to share the work with
-  if( helpers && helpers->width() > 1 && p->hdr.slice_type == 2 && !( p->hdr.tool_flags & VVR_TOOL_IBC ) && p->ctu_first_cu && p->num_cu >= 512 && S.ctusY >= 2 )
+  // ... and, when the owner of the scratch asks for it (partsForAll: the device is waiting for work), any other picture: bands of CTU rows, what a band reads of
+  // the band above resolved when the bands are joined (buildInParts)
+  const bool anyInParts = S.partsForAll && !p->rpr;
+  if( helpers && helpers->width() > 1 && !( p->hdr.tool_flags & VVR_TOOL_IBC ) && p->ctu_first_cu && p->num_cu >= 512 && S.ctusY >= 2 && ( p->hdr.slice_type == 2 || anyInParts ) )
   {
     if( ( rc = S.beginMaps() ) != VVR_OK ) return rc;
-    if( S.allIntraCus )
+    if( S.allIntraCus || anyInParts )
     {
       if( ( rc = S.buildInParts( vvr_config(), *helpers, validateRecords, err ) ) != VVR_OK || ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK
        || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
