@@ -446,7 +446,7 @@ def main():
         # HBM-side traffic of that kernel from the separate PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over this command,
         # gfx950 correction applied, profiles/*_pmc_traffic.json); counters cannot be collected inside this run
         # (keyed by configuration AND kernel: the 8K and all-intra lines must not carry the 4K figure)
-        for name in ("round3_pmc_traffic.json",):
+        for name in ("round4_pmc_traffic.json", "round3_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["configs"][a.config]["kernels"]
                 ent = next(v for k, v in pmc.items() if k.split("<")[0] == dom["name"])

@@ -1,4 +1,4 @@
-"""developer helper: copies what tools/gpu_round3.sh left in gpurun_out/<tag>/ into profiles/ under the names the documents cite
+"""developer helper: copies what tools/gpu_round3.sh / gpu_round4.sh left in gpurun_out/<tag>/ into profiles/ under the names the documents cite
    (kernel statistics of the driver's command, PMC traffic per configuration, counters of the streaming kernels, the bench lines).
    usage: python tools/collect_profiles.py gpurun_out/r3ev2 round3"""
 import glob, json, os, shutil, sys
@@ -18,7 +18,8 @@ if configs:
               open(os.path.join(P, rnd + "_pmc_traffic.json"), "w"), indent=1)
 for a, b in (("deblock_counters.json", "_deblock_counters.json"), ("host.txt", "_gpu_box_host.txt"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
              ("bench_4k_steps20_warmup5.json", "_bench_steps20_warmup5.json"), ("bench_4k_steps64_warmup16.json", "_bench_steps64_warmup16.json"),
-             ("bench_allintra.json", "_bench_allintra.json"), ("bench_8k.json", "_bench_8k.json")):
+             ("bench_allintra.json", "_bench_allintra.json"), ("bench_8k.json", "_bench_8k.json"), ("gpu_parity_suite.log", "_gpu_parity_suite.log"),
+             ("kernels_alone.txt", "_kernels_alone.txt"), ("intra_block_phases.txt", "_intra_block_phases.txt"), ("dropin_decode.json", "_dropin_decode.json")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(P, rnd + b))
 print(sorted(f for f in os.listdir(P) if f.startswith(rnd)))

@@ -437,14 +437,15 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
       c->syncBuf[lane] = p; c->syncCap[lane] = need * 2;
     }
   }
+  const int wideIntra = h.slice_type == 2 && ( lane == c->prioLane || c->numLanesRR == 1 );      // an I picture the pictures behind it wait for (launch_intra)
   // A picture whose inter blocks carry scaled chroma residuals (LMCS): luma units, the residual-add blocks, chroma units
   if( q->numResi )
   {
-    if( q->numLumaUnits ) timedOn( K_INTRA, s, q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numLumaUnits, q->intraWorkgroups, c->syncBuf[lane] ); } );
+    if( q->numLumaUnits ) timedOn( K_INTRA, s, q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numLumaUnits, q->intraWorkgroups, c->syncBuf[lane], wideIntra ); } );
     timed( K_RESI_ADD, [&]{ launch_resi_add( s, q->pic, P, R, q->resiItems, q->numResi ); } );
-    if( q->numActive > q->numLumaUnits ) timedOn( K_INTRA, s, q->bytes[K_INTRA] - q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, q->numLumaUnits, q->numActive, q->intraWorkgroupsChroma, c->syncBuf[lane] ); } );
+    if( q->numActive > q->numLumaUnits ) timedOn( K_INTRA, s, q->bytes[K_INTRA] - q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, q->numLumaUnits, q->numActive, q->intraWorkgroupsChroma, c->syncBuf[lane], wideIntra ); } );
   }
-  else if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane] ); } );
+  else if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane], wideIntra ); } );
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
   if( lmcsOn && !hop ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, P, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)

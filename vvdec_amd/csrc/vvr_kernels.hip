@@ -5283,7 +5283,7 @@ void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlane
 // The units [ticket0, ticket1) of the table.  A picture whose inter blocks carry scaled chroma residuals runs the stage in two launches - the luma
 // units, then (behind k_resi_add) the chroma units: the flags of the first launch stay set, so a chroma unit that names a luma producer finds it done.
 void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numActive, int ticket0, int ticket1,
-                   int numWorkgroups, int* sync )
+                   int numWorkgroups, int* sync, int wide )
 {
   if( !numActive || ticket1 <= ticket0 ) return;
   numWorkgroups = std::max( 1, std::min( numWorkgroups, ticket1 - ticket0 ) );
@@ -5297,8 +5297,12 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   }
   else hipMemsetD32Async( (hipDeviceptr_t) sync, ticket0, 1, s );      // the ticket counter of the second launch starts where the first ended
   numActive = ticket1;
-  // a picture of intra CTUs: workgroups of eight wavefronts; the scattered intra blocks of an inter picture: four
-  int waves = pic.hdr.slice_type == 2 ? 8 : 4;
+  // an I picture the stream waits for (`wide`: it has the priority lane, or the context has one lane): workgroups of eight wavefronts - the bands of a block side by
+  // side - and as many workgroups as the host stage counted; I pictures among I pictures (all-intra: a dozen in flight fill the device, what counts is how many
+  // units are resident) and the scattered intra blocks of an inter picture: four wavefronts, and half the workgroups for the I picture (all-intra at 4K, 12
+  // pictures in flight: 1065 against 810 pictures/s, profiles/round4_lanes_and_host_threads.txt)
+  int waves = wide ? 8 : 4;
+  if( pic.hdr.slice_type == 2 && !wide ) numWorkgroups = std::max( 1, numWorkgroups / 2 );
 #ifndef VVR_INTRA_DEV
   if( waves == 8 ) hipLaunchKernelGGL( k_intra<8>, dim3( numWorkgroups ), dim3( 512 ), 0, s, ip, items, ctx, units, numActive, sync );
   else             hipLaunchKernelGGL( k_intra<4>, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync );
