@@ -158,9 +158,9 @@ def dropin_host_cost(cfg_name, seed, gop, threads=8):
         if not ms:
             return None
         first, m = ms[0], ms[-1]
-        return {"lf_init": float(m[1]), "flatten": float(m[2]), "planes_back": float(m[4]), "pool_threads": threads,
-                "first_picture_of_the_process": {"lf_init": float(first[1]), "flatten": float(first[2]), "planes_back": float(first[4])},
-                "what": "ms per picture (one B picture of this stream) the reference-side half of the drop-in spends on the host: the reference's own edge-parameter derivation over its thread pool, "
+        return {"lf_init": round(float(m[1]) / threads, 2), "lf_init_cpu_ms_summed_over_the_ctu_row_tasks": float(m[1]), "flatten": float(m[2]), "planes_back": float(m[4]), "pool_threads": threads,
+                "first_picture_of_the_process": {"lf_init": round(float(first[1]) / threads, 2), "flatten": float(first[2]), "planes_back": float(first[4])},
+                "what": "ms per picture (one B picture of this stream) the reference-side half of the drop-in spends on the host: the reference's own edge-parameter derivation (one task per CTU row on the decoder's pool: lf_init = the tasks' summed time / pool threads), "
                         "the walk over the reference's CU / TU lists into the records of include/vvr.h, the finished planes copied back into the Picture's buffers.  The picture runs three times, "
                         "each through a decoder instance of its own; the figures are those of the third run (the process's memory is warm, as in a decoder that has been running), "
                         "first_picture_of_the_process those of the first (every buffer touched for the first time)"}
