@@ -40,13 +40,17 @@
 #include <cmath>
 // The extractor reads two things that are not public in the reference (the LMCS tables of Reshape, TrQuant::getTrTypes); a maintainer who compiles
 // this file into the reference tree adds two friend declarations instead of the next two lines (the layout of the classes does not change).
+#ifndef VVDEC_AMD_FRIEND_PATCH      // (with the one-line friend declaration in CommonLib/Reshape.h nothing is redefined)
 #define private public
 #define protected public
+#endif
 #include "DecLibRecon.h"
 #include "CommonLib/UnitTools.h"
 #include "CommonLib/TrQuant_EMT.h"
+#ifndef VVDEC_AMD_FRIEND_PATCH
 #undef private
 #undef protected
+#endif
 #include "../include/vvr.h"
 #include "vvr_extract.h"
 

@@ -22,7 +22,29 @@
 
 namespace vvr_glue
 {
+
 using namespace vvdec;
+
+// The ONE place that reads non-public members of a reference class: the LMCS tables of Reshape.  A maintainer adds to CommonLib/Reshape.h
+//   namespace vvr_glue { struct LmcsTables; }      (before namespace vvdec)      and      friend struct ::vvr_glue::LmcsTables;      (inside class Reshape)
+// and compiles the glue with -DVVDEC_AMD_FRIEND_PATCH; without the patch DecLibReconDropIn.cpp / DecLibReconAmd.h open the class the blunt way.
+struct LmcsTables
+{
+  static void read( const Reshape& r, int bd, vvr_lmcs_params& L )
+  {
+    const int lutSize = 1 << bd, orgCW = lutSize / PIC_CODE_CW_BINS, l2cw = getLog2( orgCW );
+    const SliceReshapeInfo& ri = const_cast<Reshape&>( r ).getSliceReshaperInfo();
+    for( int v = 0; v < lutSize; v++ )
+    {
+      L.inv_lut[v] = r.m_invLUT[v];
+      const int i = v >> l2cw;
+      L.fwd_lut[v] = (int16_t) Clip3( 0, lutSize - 1, (int) r.m_reshapePivot[i] + ( ( (int) r.m_fwdScaleCoef[i] * ( v - (int) r.m_inputPivot[i] ) + ( 1 << ( FP_PREC - 1 ) ) ) >> FP_PREC ) );
+    }
+    for( int i = 0; i < 16; i++ ) { L.chroma_scale[i] = (int16_t) r.m_chromaAdjHelpLUT[i]; L.model_delta_cw[i] = (int16_t) ri.reshaperModelBinCWDelta[i]; }
+    for( int i = 0; i < 17; i++ ) L.pivot[i] = r.m_reshapePivot[i];
+    L.min_bin = (int16_t) ri.reshaperModelMinBinIdx; L.max_bin = (int16_t) ri.reshaperModelMaxBinIdx; L.model_delta_crs = (int16_t) ri.chrResScalingOffset;
+  }
+};
 
 // [0, n) over up to `threads` threads (contiguous chunks); the first exception is rethrown.  The per-picture host steps of an integration (LF_INIT,
 // the 4x4 tables of the flat description) are independent per CTU / row; a decoder that keeps its own pool busy with other pictures passes 1.
@@ -623,20 +645,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
 
   // ---- LMCS: the tables Reshape::constructReshaper built (Reshape.cpp:318-374); the forward map is tabulated with rspFwdCore's formula
   memset( &E.lmcs, 0, sizeof( E.lmcs ) );
-  if( ( h.tool_flags & VVR_TOOL_LMCS ) && reshaper )
-  {
-    const int lutSize = 1 << bd, orgCW = lutSize / PIC_CODE_CW_BINS, l2cw = getLog2( orgCW );
-    const SliceReshapeInfo& ri = reshaper->getSliceReshaperInfo();
-    for( int v = 0; v < lutSize; v++ )
-    {
-      E.lmcs.inv_lut[v] = reshaper->m_invLUT[v];
-      const int i = v >> l2cw;
-      E.lmcs.fwd_lut[v] = (int16_t) Clip3( 0, lutSize - 1, (int) reshaper->m_reshapePivot[i] + ( ( (int) reshaper->m_fwdScaleCoef[i] * ( v - (int) reshaper->m_inputPivot[i] ) + ( 1 << ( FP_PREC - 1 ) ) ) >> FP_PREC ) );
-    }
-    for( int i = 0; i < 16; i++ ) { E.lmcs.chroma_scale[i] = (int16_t) reshaper->m_chromaAdjHelpLUT[i]; E.lmcs.model_delta_cw[i] = (int16_t) ri.reshaperModelBinCWDelta[i]; }
-    for( int i = 0; i < 17; i++ ) E.lmcs.pivot[i] = reshaper->m_reshapePivot[i];
-    E.lmcs.min_bin = (int16_t) ri.reshaperModelMinBinIdx; E.lmcs.max_bin = (int16_t) ri.reshaperModelMaxBinIdx; E.lmcs.model_delta_crs = (int16_t) ri.chrResScalingOffset;
-  }
+  if( ( h.tool_flags & VVR_TOOL_LMCS ) && reshaper ) LmcsTables::read( *reshaper, bd, E.lmcs );
 
   // ---- explicit weighted prediction (the slices' tables re-indexed to the union of the reference lists), scaling lists
   E.wpSets.clear();
