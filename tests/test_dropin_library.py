@@ -141,6 +141,25 @@ def test_decodes_conformance_bitstreams():
     assert not bad, bad
 
 
+@pytest.mark.gpu
+def test_a_wrong_picture_hash_is_noticed(tmp_path):
+    """the streams of tests/bitstreams carry a decoded-picture-hash SEI behind every picture (the reference decoder's own hashes, tools/mini_vvenc.py): with
+    one byte of the last SEI changed the decode through the drop-in library reports the mismatch - the per-picture check is live, not vacuous"""
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import dropin_decode as dd
+    src = os.path.join(HERE, "bitstreams", "mini_all_tools_ctu128_384x256", "mini_all_tools_ctu128_384x256.bit")
+    if not os.path.exists(dd.APP_DROPIN) or not os.path.exists(src):
+        pytest.skip("oracle/_ref/vvdecapp_dropin or the stream missing")
+    d = bytearray(open(src, "rb").read())
+    i = d.rfind(bytes([0, 0, 1, 0, (24 << 3) | 1]))          # the last suffix SEI NAL unit
+    assert i > 0
+    d[i + 12] ^= 0xFF                                        # a byte of the luma MD5
+    bad = tmp_path / "bad.bit"
+    bad.write_bytes(bytes(d))
+    r = dd.decode_stream(str(bad), threads=4, with_reference=False)
+    assert r["dropin"]["rc"] == 0 and (r["dropin_dph"]["mismatch"] or r["dropin_dph"]["rc"] != 0) and not r["ok"], r
+
+
 def test_conformance_harness_on_the_stand_in_runtime(tmp_path):
     """tools/dropin_decode.py end to end without a GPU: the reference's application (oracle/_ref/vvdecapp_dropin) starts on the drop-in library with
     the stand-in back-end bound the way the tool binds the real one, refuses a stream that is noise without crashing, and the tool reports the

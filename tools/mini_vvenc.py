@@ -251,11 +251,13 @@ class Cabac:
 class Cfg:
     def __init__(self, width, height, log2_ctu=6, log2_min_qt=3, bit_depth=10, qp=30, max_tb64=True, p_split=0.6, p_cbf=0.5, p_cbf_chroma=0.3, deblock=True,
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
-                 sao=False, lmcs=False, jccr=False, dep_quant=False):
+                 sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
+                 mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
         self.log2_max_tb = 6 if (max_tb64 and log2_ctu > 5) else 5
+        self.log2_max_btt = min(6, log2_ctu)           # largest block a binary / ternary split applies to (sps_log2_diff_max_bt / tt_min_qt)
         if not inter:
             self.tmvp = self.sbtmvp = self.bdof = self.dmvr = self.mmvd = self.affine = self.ciip = self.gpm = False
         self.max_aff_merge = 5 if self.affine else (1 if (self.sbtmvp and self.tmvp) else 0)
@@ -298,15 +300,24 @@ def write_sps(c):
     b.ue(c.log2_min_cb - 2)                          # sps_log2_min_luma_coding_block_size_minus2
     b.flag(0)                                        # sps_partition_constraints_override_enabled_flag
     b.ue(c.log2_min_qt - c.log2_min_cb)              # sps_log2_diff_min_qt_min_cb_intra_slice_luma
-    b.ue(0)                                          # sps_max_mtt_hierarchy_depth_intra_slice_luma
+    b.ue(c.mtt_depth)                                # sps_max_mtt_hierarchy_depth_intra_slice_luma
+    if c.mtt_depth:
+        b.ue(c.log2_max_btt - c.log2_min_qt)         # sps_log2_diff_max_bt_min_qt_intra_slice_luma
+        b.ue(c.log2_max_btt - c.log2_min_qt)         # sps_log2_diff_max_tt_min_qt_intra_slice_luma
     b.flag(0)                                        # sps_qtbtt_dual_tree_intra_flag
     b.ue(c.log2_min_qt - c.log2_min_cb)              # sps_log2_diff_min_qt_min_cb_inter_slice
-    b.ue(0)                                          # sps_max_mtt_hierarchy_depth_inter_slice
+    b.ue(c.mtt_depth)                                # sps_max_mtt_hierarchy_depth_inter_slice
+    if c.mtt_depth:
+        b.ue(c.log2_max_btt - c.log2_min_qt)         # sps_log2_diff_max_bt_min_qt_inter_slice
+        b.ue(c.log2_max_btt - c.log2_min_qt)         # sps_log2_diff_max_tt_min_qt_inter_slice
     if c.log2_ctu > 5:
         b.flag(c.log2_max_tb == 6)                   # sps_max_luma_transform_size_64_flag
     b.flag(0)                                        # sps_transform_skip_enabled_flag
-    b.flag(0)                                        # sps_mts_enabled_flag
-    b.flag(0)                                        # sps_lfnst_enabled_flag
+    b.flag(c.mts)                                    # sps_mts_enabled_flag
+    if c.mts:
+        b.flag(1)                                    # sps_explicit_mts_intra_enabled_flag
+        b.flag(1)                                    # sps_explicit_mts_inter_enabled_flag
+    b.flag(c.lfnst)                                  # sps_lfnst_enabled_flag
     b.flag(c.jccr)                                   # sps_joint_cbcr_enabled_flag
     b.flag(1)                                        # sps_same_qp_table_for_chroma_flag
     b.se(0)                                          # sps_qp_table_start_minus26[0]
@@ -314,7 +325,9 @@ def write_sps(c):
     b.ue(0)                                          # sps_delta_qp_in_val_minus1[0][0]
     b.ue(1)                                          # sps_delta_qp_diff_val[0][0]: the identity table
     b.flag(c.sao)                                    # sps_sao_enabled_flag
-    b.flag(0)                                        # sps_alf_enabled_flag
+    b.flag(c.alf)                                    # sps_alf_enabled_flag
+    if c.alf:
+        b.flag(c.ccalf)                              # sps_ccalf_enabled_flag
     b.flag(c.lmcs)                                   # sps_lmcs_enable_flag
     b.flag(0)                                        # sps_weighted_pred_flag
     b.flag(0)                                        # sps_weighted_bipred_flag
@@ -351,10 +364,10 @@ def write_sps(c):
     if c.gpm:
         b.ue(0)                                      # sps_max_num_merge_cand_minus_max_num_gpm_cand
     b.ue(0)                                          # sps_log2_parallel_merge_level_minus2
-    b.flag(0)                                        # sps_isp_enabled_flag
-    b.flag(0)                                        # sps_mrl_enabled_flag
-    b.flag(0)                                        # sps_mip_enabled_flag
-    b.flag(0)                                        # sps_cclm_enabled_flag
+    b.flag(c.isp)                                    # sps_isp_enabled_flag
+    b.flag(c.mrl)                                    # sps_mrl_enabled_flag
+    b.flag(c.mip)                                    # sps_mip_enabled_flag
+    b.flag(c.cclm)                                   # sps_cclm_enabled_flag
     b.flag(0)                                        # sps_chroma_horizontal_collocated_flag
     b.flag(0)                                        # sps_chroma_vertical_collocated_flag
     b.flag(0)                                        # sps_palette_enabled_flag
@@ -408,6 +421,7 @@ def write_pps(c):
 
 
 NAL_PREFIX_APS = 17
+NAL_SUFFIX_SEI = 24
 
 
 def write_lmcs_aps(c, rng, aps_id):
@@ -433,6 +447,60 @@ def write_lmcs_aps(c, rng, aps_id):
     b.flag(0)                                        # aps_extension_flag
     b.trailing()
     return b.bytes()
+
+
+def write_alf_aps(c, rng, aps_id):
+    """adaptation_parameter_set_rbsp with alf_data (parseAlfAps / alfFilterCoeffs): luma filters with a class map, chroma alternatives, CC-ALF filters, clipping indices.
+    -> (bytes, number of chroma alternatives, CC-ALF filter counts)"""
+    b = Bits()
+    b.u(3, 0)                                        # aps_params_type: ALF_APS
+    b.u(5, aps_id)                                   # aps_adaptation_parameter_set_id
+    b.flag(1)                                        # aps_chroma_present_flag
+    b.flag(1)                                        # alf_luma_filter_signal_flag
+    b.flag(1)                                        # alf_chroma_filter_signal_flag
+    b.flag(c.ccalf)                                  # alf_cc_cb_filter_signal_flag
+    b.flag(c.ccalf)                                  # alf_cc_cr_filter_signal_flag
+
+    def coeffs(n, m):
+        for _ in range(n):
+            v = rng.choice([0, 0, 1, 1, 2, 3, 5, 8, 13, m])
+            b.ue(v)                                  # alf_luma_coeff_abs / alf_chroma_coeff_abs
+            if v:
+                b.flag(rng.randrange(0, 2))          # ..._sign
+    clip = rng.random() < 0.7
+    b.flag(clip)                                     # alf_luma_clip_flag
+    nf = rng.choice([1, 2, 5, 25])
+    b.ue(nf - 1)                                     # alf_luma_num_filters_signalled_minus1
+    if nf > 1:
+        length = (nf - 1).bit_length()
+        for _ in range(25):
+            b.u(length, rng.randrange(0, nf))        # alf_luma_coeff_delta_idx
+    coeffs(nf * 12, 20)
+    if clip:
+        for _ in range(nf * 12):
+            b.u(2, rng.randrange(0, 4))              # alf_luma_clip_idx
+    cclip = rng.random() < 0.7
+    b.flag(cclip)                                    # alf_chroma_clip_flag
+    nalt = rng.randrange(1, 5)
+    b.ue(nalt - 1)                                   # alf_chroma_num_alt_filters_minus1
+    for _ in range(nalt):
+        coeffs(6, 20)
+        if cclip:
+            for _ in range(6):
+                b.u(2, rng.randrange(0, 4))          # alf_chroma_clip_idx
+    ncc = [0, 0]
+    if c.ccalf:
+        for k in range(2):
+            ncc[k] = rng.randrange(1, 5)
+            b.ue(ncc[k] - 1)                         # alf_cc_cb / cr_filters_signalled_minus1
+            for _ in range(ncc[k] * 7):
+                v = rng.choice([0, 0, 1, 2, 3, 4])
+                b.u(3, v)                            # alf_cc_cb / cr_mapped_coeff_abs
+                if v:
+                    b.flag(rng.randrange(0, 2))      # alf_cc_cb / cr_coeff_sign
+    b.flag(0)                                        # aps_extension_flag
+    b.trailing()
+    return b.bytes(), nalt, ncc
 
 
 def write_rpl(b, cur_poc, ref_pocs):
@@ -479,7 +547,25 @@ def write_slice_header(c, b, pic):
         b.ue({"B": 0, "P": 1, "I": 2}[st])           # sh_slice_type
     if idr:
         b.flag(0)                                    # sh_no_output_of_prior_pics_flag
-    else:
+    if c.alf:
+        a = pic["alf"]
+        b.flag(a["on"])                              # sh_alf_enabled_flag
+        if a["on"]:
+            b.u(3, len(a["luma_aps"]))               # sh_num_alf_aps_ids_luma
+            for i in a["luma_aps"]:
+                b.u(3, i)                            # sh_alf_aps_id_luma
+            b.flag(a["cb"])                          # sh_alf_cb_enabled_flag
+            b.flag(a["cr"])                          # sh_alf_cr_enabled_flag
+            if a["cb"] or a["cr"]:
+                b.u(3, a["chroma_aps"])              # sh_alf_aps_id_chroma
+            if c.ccalf:
+                b.flag(a["cc_cb"] is not None)       # sh_alf_cc_cb_enabled_flag
+                if a["cc_cb"] is not None:
+                    b.u(3, a["cc_cb"])               # sh_alf_cc_cb_aps_id
+                b.flag(a["cc_cr"] is not None)       # sh_alf_cc_cr_enabled_flag
+                if a["cc_cr"] is not None:
+                    b.u(3, a["cc_cr"])
+    if not idr:
         write_rpl(b, pic["poc"], pic["l0"])          # ref_pic_lists(): both lists, whatever the slice type
         write_rpl(b, pic["poc"], pic["l1"])
         n0, n1 = len(pic["l0"]), len(pic["l1"])
@@ -521,6 +607,7 @@ class PictureWriter:
         self.cu_w = [[0] * w4 for _ in range(h4)]      # luma width / height of the CU that covers a 4x4 cell (0: not coded yet)
         self.cu_h = [[0] * w4 for _ in range(h4)]
         self.cu_f = [[0] * w4 for _ in range(h4)]      # per cell: 1 skip, 2 intra, 4 affine (context of the flags of later CUs)
+        self.cu_q = [[0] * w4 for _ in range(h4)]      # quad-tree depth of the CU
         self.stats = dict(cus=0, split=0, cbf=0, coefs=0, skip=0, merge=0, amvp=0, intra=0)
 
     def picture(self):
@@ -529,8 +616,56 @@ class PictureWriter:
             for x in range(0, self.c.width, S):
                 if self.c.sao:
                     self.sao(x, y)
-                self.coding_tree(x, y, S)
+                if self.c.alf and self.pic["alf"]["on"]:
+                    self.alf(x >> self.c.log2_ctu, y >> self.c.log2_ctu)
+                self.coding_tree(x, y, S, S)
         self.cab.trm(1)                              # end_of_slice_one_bit
+
+    # -- ALF controls of a CTU (CABACReader::readAlf :391-467): on / off per component, filter set, chroma alternative, CC-ALF filter
+    def alf(self, rx, ry):
+        cab, rng, a = self.cab, self.rng, self.pic["alf"]
+        if not hasattr(self, "alf_ctu"):
+            self.alf_ctu = {}
+        left, above = self.alf_ctu.get((rx - 1, ry), [0] * 5), self.alf_ctu.get((rx, ry - 1), [0] * 5)
+        cur = [0] * 5
+        for comp in range(3):
+            if comp and not a["cb" if comp == 1 else "cr"]:
+                continue
+            on = rng.random() < 0.7
+            cab.bin(1 if on else 0, "ctbAlfFlag", comp * 3 + left[comp] + above[comp])      # alf_ctb_flag
+            cur[comp] = 1 if on else 0
+            if comp == 0 and on:
+                n = len(a["luma_aps"])
+                use_aps = n > 0 and rng.random() < 0.6
+                if n > 0:
+                    cab.bin(1 if use_aps else 0, "AlfUseTemporalFilt", 0)      # alf_use_aps_flag
+                if use_aps:
+                    if n > 1:
+                        self.trunc_bin(rng.randrange(0, n), n)                 # alf_luma_prev_filter_idx
+                else:
+                    self.trunc_bin(rng.randrange(0, 16), 16)                   # alf_luma_fixed_filter_idx
+            if comp and on:
+                alt = rng.randrange(0, a["nalt"])
+                for k in range(a["nalt"] - 1):                                 # alf_ctb_filter_alt_idx: unary, context coded
+                    cab.bin(1 if alt > k else 0, "ctbAlfAlternative", comp - 1)
+                    if alt <= k:
+                        break
+        for comp in (1, 2):
+            key = "cc_cb" if comp == 1 else "cc_cr"
+            if self.c.ccalf and a[key] is not None:
+                cnt = a["ncc"][comp - 1]
+                idc = rng.randrange(0, cnt + 1)
+                ctx = (1 if left[2 + comp] else 0) + (1 if above[2 + comp] else 0) + (3 if comp == 2 else 0)
+                cab.bin(1 if idc else 0, "CcAlfFilterControlFlag", ctx)        # alf_ctb_cc_cb_idc / cr_idc
+                if idc:
+                    v = 1
+                    while v != cnt:
+                        cab.ep(1 if idc > v else 0)
+                        if idc <= v:
+                            break
+                        v += 1
+                cur[2 + comp] = idc
+        self.alf_ctu[(rx, ry)] = cur
 
     # -- sao( rx, ry ) (CABACReader::sao): merge left / above, else type, four offsets, band position or edge class per component
     def sao(self, x, y):
@@ -570,38 +705,127 @@ class PictureWriter:
             elif comp != 2:
                 cab.eps(rng.randrange(0, 4), 2)                                # sao_eo_class_luma / chroma
 
-    # -- coding_tree (quad-tree only): split_cu_flag where both choices exist (CABACReader::split_cu_mode)
-    def coding_tree(self, x, y, size):
-        can_split = size > (1 << self.c.log2_min_qt)
-        split = False
-        if can_split:
-            split = self.rng.random() < self.c.p_split
-            left = self.cu_h[y >> 2][(x >> 2) - 1] if x > 0 else 0
-            above = self.cu_w[(y >> 2) - 1][x >> 2] if y > 0 else 0
-            ctx = (1 if (left and left < size) else 0) + (1 if (above and above < size) else 0)      # (+ ctxOffset[numSplit = 2] = 0)
-            self.cab.bin(1 if split else 0, "SplitFlag", ctx)
-        if split:
+    # -- which splits a block may take (Partitioner::canSplit, UnitPartitioner.cpp:281-385, for a single tree inside the picture; the smallest coding block is
+    # 8x8, so none of the mode-type conditions - local dual tree - ever holds)
+    def can_split(self, w, h, mt_depth, last, idx):
+        c = self.c
+        min_qt, min_bt, max_btt = 1 << c.log2_min_qt, 1 << c.log2_min_cb, 1 << c.log2_max_btt
+        can_qt = last in ("ctu", "qt") and w > min_qt
+        bh = bv = th = tv = False
+        if mt_depth < c.mtt_depth and (w > min_bt or h > min_bt) and w <= max_btt and h <= max_btt:
+            bh = bv = True
+            if last in ("th", "tv") and idx == 1:                              # the middle part of a ternary split is not halved in the same direction
+                if last == "th":
+                    bh = False
+                else:
+                    bv = False
+            bh = bh and h > min_bt and (w <= 64 or h > 64)
+            bv = bv and w > min_bt and (w > 64 or h <= 64)
+            if w <= 64 and h <= 64:
+                th, tv = h > 2 * min_bt, w > 2 * min_bt
+        return can_qt, bh, bv, th, tv
+
+    # -- coding_tree: split_cu_flag, split_qt_flag, mtt_split_cu_vertical_flag, mtt_split_cu_binary_flag where more than one choice exists
+    # (CABACReader::split_cu_mode :679-830)
+    def coding_tree(self, x, y, w, h, qt_depth=0, mt_depth=0, last="ctu", idx=0):
+        cab, rng = self.cab, self.rng
+        can_qt, bh, bv, th, tv = self.can_split(w, h, mt_depth, last, idx)
+        num_hor, num_ver = bh + th, bv + tv
+        num_split = 2 * can_qt + num_hor + num_ver
+        mode = None
+        if num_split:
+            left_h = self.cu_h[y >> 2][(x >> 2) - 1] if x > 0 else 0
+            above_w = self.cu_w[(y >> 2) - 1][x >> 2] if y > 0 else 0
+            p = self.c.p_split if can_qt else self.c.p_mtt
+            split = rng.random() < p
+            ctx = (1 if (left_h and left_h < h) else 0) + (1 if (above_w and above_w < w) else 0) + (0, 0, 0, 3, 3, 6, 6)[num_split]
+            cab.bin(1 if split else 0, "SplitFlag", ctx)                       # split_cu_flag
+            if split:
+                can_btt = num_hor or num_ver
+                is_qt = can_qt
+                if can_qt and can_btt:
+                    is_qt = rng.random() < 0.5
+                    lq = self.cu_q[y >> 2][(x >> 2) - 1] if x > 0 else -1
+                    aq = self.cu_q[(y >> 2) - 1][x >> 2] if y > 0 else -1
+                    cab.bin(1 if is_qt else 0, "SplitQtFlag", (1 if lq > qt_depth else 0) + (1 if aq > qt_depth else 0) + (0 if qt_depth < 2 else 3))      # split_qt_flag
+                if is_qt:
+                    mode = "qt"
+                else:
+                    ver = bool(num_ver)
+                    if num_ver and num_hor:
+                        ver = rng.random() < 0.5
+                        chv = 0
+                        if num_ver == num_hor:
+                            if left_h and above_w:
+                                dep_a, dep_l = w >> (above_w.bit_length() - 1), h >> (left_h.bit_length() - 1)
+                                chv = 0 if dep_a == dep_l else (1 if dep_a < dep_l else 2)
+                        else:
+                            chv = 3 if num_ver < num_hor else 4
+                        cab.bin(1 if ver else 0, "SplitHvFlag", chv)           # mtt_split_cu_vertical_flag
+                    can14, is12 = (tv, bv) if ver else (th, bh)
+                    if is12 and can14:
+                        is12 = rng.random() < 0.5
+                        cab.bin(1 if is12 else 0, "Split12Flag", (1 if mt_depth <= 1 else 0) + (2 if ver else 0))      # mtt_split_cu_binary_flag
+                    mode = ("bv" if is12 else "tv") if ver else ("bh" if is12 else "th")
+        if mode:
             self.stats["split"] += 1
-            h = size >> 1
-            for (dx, dy) in ((0, 0), (h, 0), (0, h), (h, h)):
-                self.coding_tree(x + dx, y + dy, h)
+            if mode == "qt":
+                parts = [(x, y, w >> 1, h >> 1), (x + (w >> 1), y, w >> 1, h >> 1), (x, y + (h >> 1), w >> 1, h >> 1), (x + (w >> 1), y + (h >> 1), w >> 1, h >> 1)]
+            elif mode == "bh":
+                parts = [(x, y, w, h >> 1), (x, y + (h >> 1), w, h >> 1)]
+            elif mode == "bv":
+                parts = [(x, y, w >> 1, h), (x + (w >> 1), y, w >> 1, h)]
+            elif mode == "th":
+                parts = [(x, y, w, h >> 2), (x, y + (h >> 2), w, h >> 1), (x, y + 3 * (h >> 2), w, h >> 2)]
+            else:
+                parts = [(x, y, w >> 2, h), (x + (w >> 2), y, w >> 1, h), (x + 3 * (w >> 2), y, w >> 2, h)]
+            for i, (px, py, pw, ph) in enumerate(parts):
+                if mode == "qt":
+                    self.coding_tree(px, py, pw, ph, qt_depth + 1, 0, "qt", i)
+                else:
+                    self.coding_tree(px, py, pw, ph, qt_depth, mt_depth + 1, mode, i)
             return
-        f = self.coding_unit(x, y, size)
-        for yy in range(y >> 2, (y + size) >> 2):
-            for xx in range(x >> 2, (x + size) >> 2):
-                self.cu_w[yy][xx] = size
-                self.cu_h[yy][xx] = size
+        f = self.coding_unit(x, y, w, h)
+        for yy in range(y >> 2, (y + h) >> 2):
+            for xx in range(x >> 2, (x + w) >> 2):
+                self.cu_w[yy][xx] = w
+                self.cu_h[yy][xx] = h
                 self.cu_f[yy][xx] = f
+                self.cu_q[yy][xx] = qt_depth
 
     # -- coding_unit of an I slice, single tree: intra luma mode, intra chroma mode, transform tree
-    def coding_unit(self, x, y, size):
+    def coding_unit(self, x, y, w, h):
         cab, rng = self.cab, self.rng
         self.stats["cus"] += 1
         if self.st != "I":
-            return self.coding_unit_inter(x, y, size)
-        self.intra_modes()
-        self.transform_tree(size, intra=True, root=True)
-        return 2
+            return self.coding_unit_inter(x, y, w, h)
+        return self.intra_cu(x, y, w, h)
+
+    # -- an intra CU: modes, transform tree, lfnst_idx, mts_idx (CABACReader::cu_pred_data, cu_residual :1404-1456)
+    def intra_cu(self, x, y, w, h):
+        info = self.intra_modes(x, y, w, h)
+        self.cu = dict(intra=True, w=w, h=h, isp=info["isp"], mip=info["mip"], viol=False, lfnst_last=False, mts_last=False)
+        self.transform_tree(w, h, intra=True, root=True)
+        self.lfnst_and_mts()
+        return 2 | (8 if info["mip"] else 0)
+
+    def lfnst_and_mts(self):
+        cab, rng, c, cu = self.cab, self.rng, self.c, self.cu
+        mx = 1 << c.log2_max_tb
+        lfnst = 0
+        if c.lfnst and cu["intra"] and not (cu["mip"] and not (cu["w"] >= 16 and cu["h"] >= 16)) and cu["w"] <= mx and cu["h"] <= mx \
+                and not cu["viol"] and (cu["lfnst_last"] or cu["isp"]):
+            lfnst = rng.choice([0, 1, 2])
+            cab.bin(1 if lfnst else 0, "LFNSTIdx", 0)                          # lfnst_idx (single tree)
+            if lfnst:
+                cab.bin(lfnst - 1, "LFNSTIdx", 2)
+        if c.mts and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and cu["mts_last"] and lfnst == 0:
+            m = rng.choice([0, 0, 1, 2, 3, 4])
+            cab.bin(1 if m else 0, "MTSIndex", 0)                                # mts_idx
+            for k in range(1, 4):
+                if m < k:
+                    break
+                cab.bin(1 if m > k else 0, "MTSIndex", k)
 
     def neigh(self, x, y):
         left = self.cu_f[y >> 2][(x >> 2) - 1] if x > 0 else 0
@@ -609,36 +833,36 @@ class PictureWriter:
         return left, above
 
     # -- coding_unit of a P / B slice (CABACReader::coding_unit, prediction_unit, merge_data)
-    def coding_unit_inter(self, x, y, size):
+    def coding_unit_inter(self, x, y, w, h):
         cab, rng, c = self.cab, self.rng, self.c
         left, above = self.neigh(x, y)
         skip = rng.random() < c.p_skip
         cab.bin(1 if skip else 0, "SkipFlag", (left & 1) + (above & 1))        # cu_skip_flag
         if skip:
             self.stats["skip"] += 1
-            aff = self.merge_data(x, y, size, True, left, above)
+            aff = self.merge_data(x, y, w, h, True, left, above)
             return 1 | (4 if aff else 0)
         intra = rng.random() < c.p_intra
         cab.bin(1 if intra else 0, "PredMode", 1 if ((left & 2) or (above & 2)) else 0)      # pred_mode_flag
         if intra:
             self.stats["intra"] += 1
-            self.intra_modes()
-            self.transform_tree(size, intra=True, root=True)
-            return 2
+            return self.intra_cu(x, y, w, h)
         merge = rng.random() < c.p_merge
         cab.bin(1 if merge else 0, "MergeFlag", 0)                             # general_merge_flag
         aff = False
         if merge:
             self.stats["merge"] += 1
-            aff = self.merge_data(x, y, size, False, left, above)
+            aff = self.merge_data(x, y, w, h, False, left, above)
             root = True                                                        # (a merge CU that is not skipped has a residual)
         else:
             self.stats["amvp"] += 1
-            aff = self.amvp(size, left, above)
+            aff = self.amvp(w, h, left, above)
             root = rng.random() < 0.7
             cab.bin(1 if root else 0, "QtRootCbf", 0)                          # cu_coded_flag
         if root:
-            self.transform_tree(size, intra=False, root=True)
+            self.cu = dict(intra=False, w=w, h=h, isp=0, mip=False, viol=False, lfnst_last=False, mts_last=False)
+            self.transform_tree(w, h, intra=False, root=True)
+            self.lfnst_and_mts()
         return 4 if aff else 0
 
     def merge_idx(self, name, num_minus1):
@@ -657,16 +881,16 @@ class PictureWriter:
         if v < mx:
             self.cab.ep(0)
 
-    def merge_data(self, x, y, size, skip, left, above):
+    def merge_data(self, x, y, w, h, skip, left, above):
         cab, rng, c = self.cab, self.rng, self.c
-        if c.max_aff_merge > 0 and size >= 8:
+        if c.max_aff_merge > 0 and w >= 8 and h >= 8:
             aff = rng.random() < 0.25
             cab.bin(1 if aff else 0, "SubblockMergeFlag", (1 if left & 4 else 0) + (1 if above & 4 else 0))      # merge_subblock_flag
             if aff:
                 self.merge_idx("AffMergeIdx", c.max_aff_merge - 1)             # merge_subblock_idx
                 return True
-        ciip_av = c.ciip and not skip and size < 128 and size * size >= 64
-        geo_av = c.gpm and self.st == "B" and 8 <= size <= 64
+        ciip_av = c.ciip and not skip and w < 128 and h < 128 and w * h >= 64
+        geo_av = c.gpm and self.st == "B" and 8 <= w <= 64 and 8 <= h <= 64 and w < 8 * h and h < 8 * w
         regular = True
         if geo_av or ciip_av:
             regular = rng.random() < 0.6
@@ -762,18 +986,17 @@ class PictureWriter:
                     if not b:
                         break
 
-    def amvp(self, size, left, above):
+    def amvp(self, w, h, left, above):
         cab, rng, c = self.cab, self.rng, self.c
         n0, n1 = len(self.pic["l0"]), len(self.pic["l1"])
-        log2 = size.bit_length() - 1
         dirn = 1
         if self.st == "B":
             dirn = rng.choice([1, 2, 3, 3])
-            cab.bin(1 if dirn == 3 else 0, "InterDir", 7 - ((2 * log2 + 1) >> 1))      # inter_pred_idc (no 4x8 / 8x4 blocks here)
+            cab.bin(1 if dirn == 3 else 0, "InterDir", 7 - ((w.bit_length() + h.bit_length() - 2 + 1) >> 1))      # inter_pred_idc (no 4x8 / 8x4 blocks here)
             if dirn != 3:
                 cab.bin(1 if dirn == 2 else 0, "InterDir", 5)
         aff, six = False, False
-        if c.affine and size >= 16:
+        if c.affine and w >= 16 and h >= 16:
             aff = rng.random() < 0.3
             cab.bin(1 if aff else 0, "AffineFlag", (1 if left & 4 else 0) + (1 if above & 4 else 0))      # inter_affine_flag
             if aff:
@@ -787,26 +1010,70 @@ class PictureWriter:
                 cab.bin(rng.randrange(0, 2), "MVPIdx", 0)                      # mvp_l0_flag / mvp_l1_flag
         return aff
 
-    def intra_modes(self):
-        cab, rng = self.cab, self.rng
-        mpm = rng.random() < 0.6
-        cab.bin(1 if mpm else 0, "IPredMode", 0, sub=0)                       # intra_luma_mpm_flag
-        if mpm:
-            not_planar = rng.random() < 0.7
-            cab.bin(1 if not_planar else 0, "IntraLumaPlanarFlag", 1)          # intra_luma_not_planar_flag (ctx 1: no ISP)
-            if not_planar:
-                idx = rng.randrange(0, 5)                                      # intra_luma_mpm_idx: truncated unary, bypass, cMax 4
-                for k in range(idx):
-                    cab.ep(1)
-                if idx < 4:
-                    cab.ep(0)
-        else:
-            self.trunc_bin(rng.randrange(0, 61), 61)                           # intra_luma_mpm_remainder
+    # -- intra_luma_pred_mode / intra_chroma_pred_mode (CABACReader :1242-1400, :2541-2576, :3125-3149)
+    def intra_modes(self, x, y, w, h):
+        cab, rng, c = self.cab, self.rng, self.c
+        info = dict(isp=0, mip=False)
+        done = False
+        if c.mip:
+            left, above = self.neigh(x, y)
+            mip = rng.random() < 0.25
+            ctx = 3 if (w > 2 * h or h > 2 * w) else (1 if left & 8 else 0) + (1 if above & 8 else 0)
+            cab.bin(1 if mip else 0, "MipFlag", ctx)                           # intra_mip_flag
+            if mip:
+                cab.ep(rng.randrange(0, 2))                                    # intra_mip_transposed_flag
+                n = 16 if (w == 4 and h == 4) else (8 if (w == 4 or h == 4 or (w == 8 and h == 8)) else 6)
+                self.trunc_bin(rng.randrange(0, n), n)                         # intra_mip_mode
+                info["mip"] = True
+                done = True
+        if not done:
+            mrl = 0
+            if c.mrl and (y & ((1 << c.log2_ctu) - 1)):
+                mrl = rng.choice([0, 0, 0, 1, 2])
+                cab.bin(1 if mrl else 0, "MultiRefLineIdx", 0)                 # intra_luma_ref_idx
+                if mrl:
+                    cab.bin(mrl - 1, "MultiRefLineIdx", 1)
+            mx = 1 << c.log2_max_tb
+            if c.isp and not mrl and w <= mx and h <= mx and w * h > 16:
+                # (only where the partitions stay at least 4 wide / high: the residual writer codes 4x4 coefficient groups)
+                cands = [d for d in (1, 2) if (h if d == 1 else w) >= 16]
+                isp = rng.choice(cands) if (cands and rng.random() < 0.3) else 0
+                cab.bin(1 if isp else 0, "ISPMode", 0)                         # intra_subpartitions_mode_flag
+                if isp:
+                    cab.bin(isp - 1, "ISPMode", 1)                             # intra_subpartitions_split_flag: 0 horizontal, 1 vertical
+                info["isp"] = isp
+            mpm = True
+            if not mrl:
+                mpm = rng.random() < 0.6
+                cab.bin(1 if mpm else 0, "IPredMode", 0, sub=0)               # intra_luma_mpm_flag
+            if mpm:
+                not_planar = True
+                if not mrl:
+                    not_planar = rng.random() < 0.7
+                    cab.bin(1 if not_planar else 0, "IntraLumaPlanarFlag", 0 if info["isp"] else 1)      # intra_luma_not_planar_flag
+                if not_planar:
+                    idx = rng.randrange(0, 5)                                  # intra_luma_mpm_idx: truncated unary, bypass, cMax 4
+                    for k in range(idx):
+                        cab.ep(1)
+                    if idx < 4:
+                        cab.ep(0)
+            else:
+                self.trunc_bin(rng.randrange(0, 61), 61)                       # intra_luma_mpm_remainder
+        if c.cclm:
+            lm = rng.random() < 0.3
+            cab.bin(1 if lm else 0, "CclmModeFlag", 0)                         # cclm_mode_flag
+            if lm:
+                k = rng.randrange(0, 3)
+                cab.bin(1 if k else 0, "CclmModeIdx", 0)                       # cclm_mode_idx: LM, MDLM_L, MDLM_T
+                if k:
+                    cab.ep(k - 1)
+                return info
         if rng.random() < 0.5:
             cab.bin(0, "IPredMode", 0, sub=1)                                  # intra_chroma_pred_mode: derived mode
         else:
             cab.bin(1, "IPredMode", 0, sub=1)
             cab.eps(rng.randrange(0, 4), 2)
+        return info
 
     def trunc_bin(self, v, n):                                                 # xReadTruncBinCode
         thresh = n.bit_length() - 1
@@ -817,35 +1084,59 @@ class PictureWriter:
         else:
             self.cab.eps(v + val - b, thresh + 1)
 
-    def transform_tree(self, size, intra, root):
+    def transform_tree(self, w, h, intra, root):
         mx = 1 << self.c.log2_max_tb
-        if size > mx:
-            for _ in range(4):                                                 # TU_MAX_TR_SPLIT: four transform units in z order
-                self.transform_tree(size >> 1, intra, False)
+        if w > mx or h > mx:                                                   # TU_MAX_TR_SPLIT: halved in every direction that is too long, z order
+            nw, nh = (w >> 1 if w > mx else w), (h >> 1 if h > mx else h)
+            for _ in range((w // nw) * (h // nh)):
+                self.transform_tree(nw, nh, intra, False)
             return
-        self.transform_unit(size, intra, root)
+        isp = self.cu["isp"] if (intra and root) else 0
+        if isp:
+            # intra sub-partitions: four transform units of a quarter of the height (1) / width (2) - CUs whose partitions would be thinner than 4 do not take ISP
+            # here -, luma coded flags with the previous partition's flag as context, the last one inferred when none before it is set; chroma with the last
+            n, pw, ph = 4, (w if isp == 1 else w >> 2), (h >> 2 if isp == 1 else h)
+            prev, any_cbf = False, False
+            for i in range(n):
+                last = i == n - 1
+                prev = self.transform_unit(pw, ph, True, False, isp=(i, last, prev, any_cbf), cw=w >> 1, ch=h >> 1)
+                any_cbf = any_cbf or prev
+            return
+        self.transform_unit(w, h, intra, root)
 
-    def transform_unit(self, size, intra, depth0):
+    def transform_unit(self, w, h, intra, depth0, isp=None, cw=None, ch=None):
         cab, rng, c = self.cab, self.rng, self.c
-        cb = rng.random() < c.p_cbf_chroma
-        cr = rng.random() < c.p_cbf_chroma
+        chroma = isp is None or isp[1]                                         # (ISP: the unsplit chroma blocks come with the last partition)
+        cb = cr = False
+        if chroma:
+            cb = rng.random() < c.p_cbf_chroma
+            cr = rng.random() < c.p_cbf_chroma
+            cab.bin(1 if cb else 0, "QtCbf", 0, sub=1)                         # tu_cb_coded_flag
+            cab.bin(1 if cr else 0, "QtCbf", 1 if cb else 0, sub=2)            # tu_cr_coded_flag
         yy = rng.random() < c.p_cbf
-        cab.bin(1 if cb else 0, "QtCbf", 0, sub=1)                             # tu_cb_coded_flag
-        cab.bin(1 if cr else 0, "QtCbf", 1 if cb else 0, sub=2)                # tu_cr_coded_flag
-        if not intra and depth0 and not (cb or cr):
+        if isp is not None:
+            i, last, prev, any_cbf = isp
+            if last and not any_cbf:
+                yy = True                                                      # (inferred)
+            else:
+                cab.bin(1 if yy else 0, "QtCbf", 2 + (1 if prev else 0), sub=0)
+        elif not intra and depth0 and not (cb or cr):
             yy = True                                                          # (inferred: the CU has a residual and chroma has none)
         else:
             cab.bin(1 if yy else 0, "QtCbf", 0, sub=0)                         # tu_y_coded_flag
         joint = False
-        if self.c.jccr and ((intra and (cb or cr)) or (cb and cr)):
+        if chroma and self.c.jccr and ((intra and (cb or cr)) or (cb and cr)):
             joint = rng.random() < 0.4
             cab.bin(1 if joint else 0, "JointCbCrFlag", 2 * cb + cr - 1)       # tu_joint_cbcr_residual_flag
+        if cw is None:
+            cw, ch = w >> 1, h >> 1
         if yy:
-            self.residual(size, size, 0)
+            self.residual(w, h, 0)
         if cb:
-            self.residual(size >> 1, size >> 1, 1)
+            self.residual(cw, ch, 1)
         if cr and not (joint and cb):
-            self.residual(size >> 1, size >> 1, 1)
+            self.residual(cw, ch, 1)
+        return yy
 
     # -- residual_coding: coefficients of the first 4x4 coefficient group only, levels 1..3, at most three of them (well inside the budget of
     # context-coded bins, CoeffCodingContext::m_regBinLimit)
@@ -858,6 +1149,12 @@ class PictureWriter:
             levels[p] = rng.choice([1, 1, 2, 3])
         self.stats["coefs"] += len(levels)
         log2w, log2h = w.bit_length() - 1, h.bit_length() - 1
+        cu = getattr(self, "cu", None)
+        if cu is not None:                                                     # what lfnst_idx / mts_idx depend on (CABACReader::residual_coding :2385-2399)
+            cu["viol"] = cu["viol"] or last > (7 if ((w == 4 and h == 4) or (w == 8 and h == 8)) else 15)
+            cu["lfnst_last"] = cu["lfnst_last"] or last >= 1
+            if ch == 0:
+                cu["mts_last"] = cu["mts_last"] or last >= 1
         lx, ly = SCAN4[last]
         # last_sig_coeff_x_prefix / y_prefix (positions 0..3: no suffix)
         for (pos, log2s, size, name) in ((lx, log2w, w, "LastX"), (ly, log2h, h, "LastY")):
@@ -931,15 +1228,45 @@ def gop_plan(num_pictures, inter):
     return pics[:num_pictures]
 
 
-def write_stream(c, num_pictures, seed, tables, renorm):
+def write_hash_sei(md5s):
+    """sei_rbsp with one decoded picture hash message (payload type 132): MD5 of every colour component of the decoded picture"""
+    b = Bits()
+    b.u(8, 132)                                      # payload_type
+    b.u(8, 2 + 16 * len(md5s))                       # payload_size
+    b.u(8, 0)                                        # dph_sei_hash_type: MD5
+    b.flag(0)                                        # dph_sei_single_component_flag
+    b.u(7, 0)                                        # dph_sei_reserved_zero_7bits
+    for m in md5s:
+        for byte in m:
+            b.u(8, byte)                             # dph_sei_picture_md5
+    b.trailing()
+    return b.bytes()
+
+
+def write_stream(c, num_pictures, seed, tables, renorm, hashes=None):
+    """hashes: [per picture in decoding order: MD5 digest per component] -> a decoded-picture-hash SEI behind every picture (what the decoder checks with verifyPictureHash / -dph)"""
     rng = random.Random(seed)
     out = bytearray()
     out += nal(NAL_SPS, write_sps(c), long_start=True)
     out += nal(NAL_PPS, write_pps(c), long_start=True)
     if c.lmcs:
         out += nal(NAL_PREFIX_APS, write_lmcs_aps(c, rng, 0), long_start=True)
+    alf_aps = []
+    if c.alf:
+        for i in range(c.alf_aps):
+            data, nalt, ncc = write_alf_aps(c, rng, i)
+            out += nal(NAL_PREFIX_APS, data, long_start=True)
+            alf_aps.append((nalt, ncc))
     stats = []
-    for pic in gop_plan(num_pictures, c.inter):
+    for pic_idx, pic in enumerate(gop_plan(num_pictures, c.inter)):
+        if c.alf:
+            # the slice's ALF choice: which APSs the luma filter sets come from, the APS of the chroma filters (its alternatives), the APSs of the CC-ALF filters
+            ids = list(range(c.alf_aps))
+            rng.shuffle(ids)
+            ch = rng.randrange(0, c.alf_aps)
+            cc = [rng.randrange(0, c.alf_aps) if (c.ccalf and rng.random() < 0.8) else None for _ in range(2)]
+            pic["alf"] = dict(on=rng.random() < 0.9, luma_aps=ids[:rng.randrange(0, c.alf_aps + 1)], cb=rng.random() < 0.8, cr=rng.random() < 0.8, chroma_aps=ch,
+                              nalt=alf_aps[ch][0], cc_cb=cc[0], cc_cr=cc[1], ncc=[alf_aps[cc[0]][1][0] if cc[0] is not None else 0, alf_aps[cc[1]][1][1] if cc[1] is not None else 0])
         b = Bits()
         write_slice_header(c, b, pic)
         cab = Cabac(tables, renorm, {"B": 0, "P": 1, "I": 2}[pic["type"]], c.qp)
@@ -948,19 +1275,42 @@ def write_stream(c, num_pictures, seed, tables, renorm):
         b.b += cab.finish()
         b.trailing()
         out += nal(NAL_IDR_N_LP if pic["idr"] else NAL_TRAIL, b.bytes(), long_start=True)
+        if hashes is not None:
+            out += nal(NAL_SUFFIX_SEI, write_hash_sei(hashes[pic_idx]))
         stats.append(pw.stats)
     return bytes(out), stats
 
 
-def reference_md5(path, frames_expected=None):
+def reference_md5(path, frames_expected=None, keep=False, extra=()):
     """decode with the reference's own decoder and application -> MD5 over the output frames (16-bit little endian for more than 8 bits, planar)"""
     yuv = path + ".ref.yuv"
-    r = subprocess.run([APP_REF, "-b", path, "-o", yuv, "-t", "2", "-v", "3"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([APP_REF, "-b", path, "-o", yuv, "-t", "2", "-v", "3"] + list(extra), capture_output=True, text=True, timeout=300)
     if r.returncode != 0 or not os.path.exists(yuv):
         raise RuntimeError("the reference decoder refused %s:\n%s" % (path, (r.stdout + r.stderr)[-2000:]))
     data = open(yuv, "rb").read()
     os.remove(yuv)
+    if keep:
+        return hashlib.md5(data).hexdigest(), data, r.stdout + r.stderr
     return hashlib.md5(data).hexdigest(), len(data), r.stdout + r.stderr
+
+
+def picture_hashes(c, num_pictures, yuv):
+    """[per picture in decoding order: MD5 digests of Y, Cb, Cr] from the reference decoder's output file (pictures in output order = ascending POC; samples of more than 8 bits as two bytes,
+    little endian - the byte order the hash of the standard is defined over)"""
+    bps = 2 if c.bit_depth > 8 else 1
+    ysz, csz = c.width * c.height * bps, (c.width // 2) * (c.height // 2) * bps
+    plan = gop_plan(num_pictures, c.inter)
+    # (an intra stream is a sequence of IDR pictures, all of POC 0, put out in decoding order; an inter stream is one coded video sequence put out by POC)
+    order = sorted(range(len(plan)), key=lambda i: (plan[i]["poc"], i)) if c.inter else list(range(len(plan)))
+    out, off = [None] * len(plan), 0
+    for i in order:
+        planes = []
+        for sz in (ysz, csz, csz):
+            planes.append(hashlib.md5(yuv[off:off + sz]).digest())
+            off += sz
+        out[i] = planes
+    assert off == len(yuv)
+    return out
 
 
 FIXTURES = [
@@ -979,6 +1329,24 @@ FIXTURES = [
     ("mini_filters_ctu64_256x192", dict(width=256, height=192, log2_ctu=6, qp=30, sao=True, lmcs=True, jccr=True, dep_quant=True, p_cbf=0.7, p_cbf_chroma=0.5), 3, 21),
     ("mini_filters_inter_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, qp=29, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True,
                                                sao=True, lmcs=True, jccr=True, dep_quant=True, p_cbf=0.6, p_cbf_chroma=0.4), 9, 22),
+    # binary and ternary splits (rectangular CUs from 8x16 to 64x32: wide-angle intra modes, rectangular transforms, GPM / CIIP / affine size rules)
+    ("mini_mtt_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, log2_min_qt=4, qp=30, mtt_depth=2), 2, 31),
+    ("mini_mtt_inter_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=5, qp=30, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True,
+                                                 gpm=True, sao=True, lmcs=True, jccr=True, dep_quant=True, p_split=0.7), 9, 34),
+    # the intra tools with syntax of their own: multiple reference lines, intra sub-partitions, matrix-based prediction, cross-component linear model; LFNST and explicit MTS
+    ("mini_intra_tools_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, mrl=True, isp=True, mip=True, cclm=True, lfnst=True, mts=True, p_cbf=0.7), 2, 41),
+    ("mini_intra_tools_mtt_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=28, mtt_depth=2, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True,
+                                                 sao=True, lmcs=True, jccr=True, dep_quant=True), 3, 47),
+    # ALF and CC-ALF: several APSs (luma filter sets with class maps, chroma alternatives, cross-component filters, clipping), per-slice choice, per-CTU controls
+    ("mini_alf_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, alf=True), 3, 51),
+    ("mini_alf_ccalf_sao_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, qp=28, alf=True, ccalf=True, sao=True), 3, 52),
+    # everything at once, random access
+    ("mini_all_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True,
+                                           mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True, alf=True, ccalf=True,
+                                           alf_aps=3, p_intra=0.25), 9, 53),
+    ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
+                                               ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
+                                               alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
 ]
 
 
@@ -997,9 +1365,14 @@ def main():
         os.makedirs(d, exist_ok=True)
         bit = os.path.join(d, name + ".bit")
         open(bit, "wb").write(data)
-        md5, nbytes, log = reference_md5(bit)
+        md5, yuv, log = reference_md5(bit, keep=True)
         frame_bytes = c.width * c.height * 3 // 2 * (2 if c.bit_depth > 8 else 1)
-        assert nbytes == n * frame_bytes, "the reference decoder put out %d bytes, %d pictures of %d expected\n%s" % (nbytes, n, frame_bytes, log[-1500:])
+        assert len(yuv) == n * frame_bytes, "the reference decoder put out %d bytes, %d pictures of %d expected\n%s" % (len(yuv), n, frame_bytes, log[-1500:])
+        # second pass: the same stream with a decoded-picture-hash SEI behind every picture (the hashes are the reference decoder's), checked by the reference decoder itself
+        data, stats = write_stream(c, n, seed, tables, renorm, hashes=picture_hashes(c, n, yuv))
+        open(bit, "wb").write(data)
+        md5b, _, log = reference_md5(bit, extra=["-dph"])
+        assert md5b == md5 and not re.search(r"mismatch|\*\*\*ERROR", log), log[-1500:]
         open(os.path.join(d, name + ".yuv.md5"), "w").write("%s  %s.yuv\n" % (md5, name))
         print("%-40s %6d bytes, %d pictures, %s  CUs %s" % (name, len(data), n, md5, [s["cus"] for s in stats]))
         if c.inter:
