@@ -252,7 +252,7 @@ class Cfg:
     def __init__(self, width, height, log2_ctu=6, log2_min_qt=3, bit_depth=10, qp=30, max_tb64=True, p_split=0.6, p_cbf=0.5, p_cbf_chroma=0.3, deblock=True,
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
-                 mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2):
+                 mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -819,7 +819,7 @@ class PictureWriter:
             cab.bin(1 if lfnst else 0, "LFNSTIdx", 0)                          # lfnst_idx (single tree)
             if lfnst:
                 cab.bin(lfnst - 1, "LFNSTIdx", 2)
-        if c.mts and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and cu["mts_last"] and lfnst == 0:
+        if c.mts and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and cu["mts_last"] and lfnst == 0 and not cu.get("mts_viol"):
             m = rng.choice([0, 0, 1, 2, 3, 4])
             cab.bin(1 if m else 0, "MTSIndex", 0)                                # mts_idx
             for k in range(1, 4):
@@ -1141,6 +1141,8 @@ class PictureWriter:
     # -- residual_coding: coefficients of the first 4x4 coefficient group only, levels 1..3, at most three of them (well inside the budget of
     # context-coded bins, CoeffCodingContext::m_regBinLimit)
     def residual(self, w, h, ch):
+        if self.c.big_resi:
+            return self.residual_full(w, h, ch)
         cab, rng = self.cab, self.rng
         self.stats["cbf"] += 1
         last = rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 7, 9, 12, 15])
@@ -1204,6 +1206,170 @@ class PictureWriter:
             first = False
         for s in signs:
             cab.ep(s)                                                          # coeff_sign_flag, in coding order
+
+
+    # -- residual_coding in full (CABACReader::residual_coding :2361-2460, residual_coding_subblock :2704-2861, CoeffCodingContext): any last position inside the
+    # 32x32 zero-out region, coded_sub_block_flag per 4x4 coefficient group, the context-coded pass with its bin budget, Golomb-Rice remainders with the
+    # template-derived parameter, the bypass pass for what the budget no longer covers, levels up to a few dozen, dependent quantisation states
+    def residual_full(self, w, h, ch):
+        cab, rng = self.cab, self.rng
+        self.stats["cbf"] += 1
+        wz, hz = min(32, w), min(32, h)
+        wg, hg = wz >> 2, hz >> 2
+        cgs = []                                                               # coefficient groups in scan order (ScanGenerator, Rom.cpp:130-172)
+        for d in range(wg + hg - 1):
+            for y in range(min(d, hg - 1), -1, -1):
+                if d - y < wg:
+                    cgs.append((d - y, y))
+        def pos_of(sp):
+            cx, cy = cgs[sp >> 4]
+            ix, iy = SCAN4[sp & 15]
+            return cx * 4 + ix, cy * 4 + iy
+        # -- what is coded: the last group (mostly the first few), which groups hold anything, the levels
+        ncg = len(cgs)
+        last_cg = 0 if rng.random() < 0.45 else min(ncg - 1, int(rng.expovariate(0.5)))
+        last = (last_cg << 4) + rng.choice([0, 0, 1, 2, 3, 5, 8, 11, 15])
+        dense = rng.random() < 0.15                                            # (some blocks full enough to run out of context-coded bins)
+        def level():
+            r = rng.random()
+            return 1 if r < 0.5 else 2 if r < 0.7 else 3 if r < 0.8 else rng.randrange(4, 8) if r < 0.93 else rng.randrange(8, 60)
+        levels = {last: level()}
+        sig_cg = {last_cg: True, 0: True}
+        for g in range(last_cg - 1, -1, -1):
+            if g == 0 or rng.random() < (0.8 if dense else 0.4):
+                sig_cg[g] = True
+                for sp in range((g << 4) + 15, (g << 4) - 1, -1):
+                    if rng.random() < (0.7 if dense else 0.2):
+                        levels[sp] = level()
+        for sp in range(last - 1, (last_cg << 4) - 1, -1):
+            if rng.random() < (0.7 if dense else 0.25):
+                levels[sp] = level()
+        self.stats["coefs"] += len(levels)
+        cu = getattr(self, "cu", None)
+        if cu is not None:                                                     # what lfnst_idx / mts_idx depend on (CABACReader::residual_coding :2385-2399, :2437-2440)
+            cu["viol"] = cu["viol"] or last > (7 if ((w == 4 and h == 4) or (w == 8 and h == 8)) else 15)
+            cu["lfnst_last"] = cu["lfnst_last"] or last >= 1
+            if ch == 0:
+                cu["mts_last"] = cu["mts_last"] or last >= 1
+        # -- last_sig_coeff_{x,y}_prefix, then the suffixes (CABACReader::last_sig_coeff :2636-2700)
+        log2w, log2h = w.bit_length() - 1, h.bit_length() - 1
+        lx, ly = pos_of(last)
+        GROUP_IDX = [0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9]
+        MIN_IN_GROUP = [0, 1, 2, 3, 4, 6, 8, 12, 16, 24]
+        grp = []
+        for (pos, log2s, size, name) in ((lx, log2w, w, "LastX"), (ly, log2h, h, "LastY")):
+            off = PREFIX_CTX[log2s] if ch == 0 else 0
+            shift = ((log2s + 1) >> 2) if ch == 0 else min(2, max(0, size >> 3))
+            g, gmax = GROUP_IDX[pos], GROUP_IDX[min(32, size) - 1]
+            for k in range(g):
+                cab.bin(1, name, off + (k >> shift), sub=ch)
+            if g < gmax:
+                cab.bin(0, name, off + (g >> shift), sub=ch)
+            grp.append((pos, g))
+        for pos, g in grp:
+            if g > 3:
+                cab.eps(pos - MIN_IN_GROUP[g], (g - 2) >> 1)
+        # -- the groups from the last one down
+        tpl, coeff = {}, {}                                                    # per position: (sum of first-pass values, number) of its template; current absolute values
+        tmpl_diag, tmpl_sum1 = -1, -1
+        state, trans = 0, (32040 if self.c.dep_quant else 0)
+        area = wz * hz
+        rem_bins = (area * 28) >> 4
+        flagged = set()
+        RICE = [0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3]
+        def tsum(x, y, base):
+            sm = 0
+            if x + 2 < w:
+                sm += coeff.get((x + 1, y), 0) + coeff.get((x + 2, y), 0)
+                if y + 1 < h:
+                    sm += coeff.get((x + 1, y + 1), 0)
+            elif x + 1 < w:
+                sm += coeff.get((x + 1, y), 0)
+                if y + 1 < h:
+                    sm += coeff.get((x + 1, y + 1), 0)
+            if y + 2 < h:
+                sm += coeff.get((x, y + 1), 0) + coeff.get((x, y + 2), 0)
+            elif y + 1 < h:
+                sm += coeff.get((x, y + 1), 0)
+            return max(min(sm - 5 * base, 31), 0)
+        for g in range(last_cg, -1, -1):
+            cx, cy = cgs[g]
+            min_sub = g << 4
+            is_last = g == last_cg
+            sig = bool(sig_cg.get(g))
+            if not (is_last or g == 0):
+                right = (cx + 1, cy) in flagged if cx != wg - 1 else False
+                lower = (cx, cy + 1) in flagged if cy != hg - 1 else False
+                cab.bin(1 if sig else 0, "SigCoeffGroup", 1 if (right or lower) else 0, sub=ch)      # coded_sub_block_flag
+            if not sig:
+                continue
+            flagged.add((cx, cy))
+            if ch == 0 and (cx > 3 or cy > 3) and cu is not None:
+                cu["mts_viol"] = True
+            nxt = last if is_last else min_sub + 15
+            infer = nxt if is_last else (min_sub if g else -1)
+            if not is_last and g and not any(levels.get(sp, 0) for sp in range(min_sub + 1, min_sub + 16)):
+                levels.setdefault(min_sub, level())                            # (a flagged group holds something: its first position when nothing else)
+                if not levels[min_sub]:
+                    levels[min_sub] = 1
+            num_nz, gt2pos, nsigns = 0, [], 0
+            while nxt >= min_sub and rem_bins >= 4:
+                x, y = pos_of(nxt)
+                lv = levels.get(nxt, 0)
+                inferred = (num_nz == 0 and nxt == infer)
+                if inferred:
+                    assert lv
+                else:
+                    sm, n = tpl.get((x, y), (0, 0))
+                    diag = x + y
+                    ofs = min((sm + 1) >> 1, 3) + (4 if diag < 2 else 0)
+                    if ch == 0:
+                        ofs += 4 if diag < 5 else 0
+                    tmpl_diag, tmpl_sum1 = diag, sm - n
+                    cab.bin(1 if lv else 0, "SigFlag", ofs, sub=ch + 2 * max(0, state - 1))      # sig_coeff_flag
+                    rem_bins -= 1
+                if lv:
+                    off = 0
+                    if tmpl_diag != -1:
+                        off = min(tmpl_sum1, 4) + 1
+                        off += (15 if ch == 0 else 5) if tmpl_diag == 0 else ((10 if tmpl_diag < 3 else 5 if tmpl_diag < 10 else 0) if ch == 0 else 0)
+                    num_nz += 1
+                    gt1 = lv >= 2
+                    cab.bin(1 if gt1 else 0, "GtxFlag", off, sub=ch + 2)       # abs_level_gtx_flag[0]
+                    rem_bins -= 1
+                    v1 = 1
+                    if gt1:
+                        par, gt2 = lv & 1, lv >= 4
+                        cab.bin(par, "ParFlag", off, sub=ch)                   # par_level_flag
+                        cab.bin(1 if gt2 else 0, "GtxFlag", off, sub=ch)       # abs_level_gtx_flag[1]
+                        rem_bins -= 2
+                        v1 = 2 + par + (2 if gt2 else 0)
+                        if gt2:
+                            gt2pos.append((x, y, (lv - v1) >> 1))
+                    coeff[(x, y)] = v1
+                    for (dx, dy) in ((0, 2), (1, 1), (0, 1), (2, 0), (1, 0)):  # absVal1stPass: the positions whose template holds this one
+                        px, py = x - dx, y - dy
+                        if px >= 0 and py >= 0:
+                            sm, n = tpl.get((px, py), (0, 0))
+                            tpl[(px, py)] = (sm + v1, n + 1)
+                state = (trans >> ((state << 2) + ((lv & 1) << 1))) & 3
+                nxt -= 1
+            for (x, y, rem) in gt2pos:                                         # abs_remainder
+                self.rem_abs_ep(rem, RICE[tsum(x, y, 4)], 5)
+                coeff[(x, y)] += rem << 1
+            while nxt >= min_sub:                                              # dec_abs_level: what the budget of context-coded bins no longer covers
+                x, y = pos_of(nxt)
+                lv = levels.get(nxt, 0)
+                rice = RICE[tsum(x, y, 0)]
+                pos0 = (1 if state < 2 else 2) << rice
+                self.rem_abs_ep(pos0 if lv == 0 else (lv - 1 if lv <= pos0 else lv), rice, 5)
+                state = (trans >> ((state << 2) + ((lv & 1) << 1))) & 3
+                if lv:
+                    coeff[(x, y)] = lv
+                    num_nz += 1
+                nxt -= 1
+            for _ in range(num_nz):
+                cab.ep(rng.randrange(0, 2))                                    # coeff_sign_flag
 
 
 NAL_TRAIL = 0
@@ -1344,6 +1510,14 @@ FIXTURES = [
     ("mini_all_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True,
                                            mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True, alf=True, ccalf=True,
                                            alf_aps=3, p_intra=0.25), 9, 53),
+    # residual coding in full: last positions anywhere in the 32x32 region, many coefficient groups, levels up to 59 with Golomb-Rice remainders, blocks dense
+    # enough to exhaust the context-coded bins (bypass pass); what the extractor's packed coefficient corners and the transforms see from a real parser
+    ("mini_resi_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, big_resi=True, p_cbf=0.8, p_cbf_chroma=0.6), 2, 61),
+    ("mini_resi_tb32_8bit_ctu64_192x128", dict(width=192, height=128, log2_ctu=6, qp=36, bit_depth=8, max_tb64=False, big_resi=True, p_cbf=0.8, p_cbf_chroma=0.6, lfnst=True, mts=True), 2, 64),
+    ("mini_resi_dq_jccr_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, qp=34, big_resi=True, dep_quant=True, jccr=True, p_cbf=0.8, p_cbf_chroma=0.6, p_split=0.5), 2, 62),
+    ("mini_resi_all_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=32, mtt_depth=2, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True,
+                                                gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True, alf=True,
+                                                ccalf=True, big_resi=True, p_intra=0.25), 9, 63),
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
