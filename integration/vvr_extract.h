@@ -408,6 +408,10 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
         const int se = st.entryOf( *cu.slice );
         c.inter_dir = (uint8_t) cu.interDir(); c.ref_idx[0] = uniIdx( se, 0, cu.refIdx[0] ); c.ref_idx[1] = uniIdx( se, 1, cu.refIdx[1] );
         for( int k = 0; k < 5; k++ ) if( g_BcwInternFwd[k] == cu.BcwIdx() ) c.bcw_idx = (uint8_t) k;      // description: index into the weight table
+        // A CIIP or GPM CU keeps the BCW index of the merge candidate it took its motion from, but its two predictions are averaged with equal weights
+        // (xWeightedAverage, InterPrediction.cpp:1356: `BcwIdx != BCW_DEFAULT && !ciipFlag`; GPM blends by position): the description says what is APPLIED.
+        // Found with the first parser-fed stream that had BCW (tools/mini_vvenc.py, round 4).
+        if( cu.ciipFlag() || cu.geoFlag() ) c.bcw_idx = 2;
         c.imv = (uint8_t) cu.imv(); c.sbt_info = (uint8_t) cu.sbtInfo(); c.lfnst_idx = 0;
         // control-point MVs only for affine CUs (a GPM CU keeps its two MVs in mv[0][1] / mv[1][1], InterPrediction.cpp:1478,1489: they go to geo_mv)
         for( int l = 0; l < 2; l++ ) for( int k = 0; k < ( isAffine( cu ) ? 3 : 1 ); k++ ) { c.mv[l][k][0] = cu.mv[l][k].getHor(); c.mv[l][k][1] = cu.mv[l][k].getVer(); }

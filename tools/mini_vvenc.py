@@ -103,7 +103,7 @@ def load_context_tables():
     for m in re.finditer(r"ContextSetCfg::(\w+)(\[\])?\s*=\s*(\{)?\s*((?:ContextSetCfg::addCtxSet\s*\(\{.*?\}\)\s*,?\s*)+)\}?;", src, re.S):
         name, sets = m.group(1), []
         for s in re.finditer(r"addCtxSet\s*\(\{(.*?)\}\)", m.group(4), re.S):
-            rows = [[int(v) for v in re.findall(r"\d+", r)] for r in re.findall(r"\{([^{}]*)\}", s.group(1))]
+            rows = [[int(v) for v in re.findall(r"\d+", r.replace("CNU", "35").replace("DWS", "8"))] for r in re.findall(r"\{([^{}]*)\}", s.group(1))]      # (CNU 35, DWS 8: Contexts.cpp)
             sets.append(rows)
         tables[name] = sets if m.group(2) else sets[0]
     rn = re.search(r"m_RenormTable_32\s*\[\s*32\s*\]\s*=\s*\{(.*?)\}", src, re.S)
@@ -252,7 +252,8 @@ class Cfg:
     def __init__(self, width, height, log2_ctu=6, log2_min_qt=3, bit_depth=10, qp=30, max_tb64=True, p_split=0.6, p_cbf=0.5, p_cbf_chroma=0.3, deblock=True,
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
-                 mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False):
+                 mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False,
+                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -260,7 +261,9 @@ class Cfg:
         self.log2_max_btt = min(6, log2_ctu)           # largest block a binary / ternary split applies to (sps_log2_diff_max_bt / tt_min_qt)
         if not inter:
             self.tmvp = self.sbtmvp = self.bdof = self.dmvr = self.mmvd = self.affine = self.ciip = self.gpm = False
+            self.amvr = self.bcw = self.smvd = self.sbt = self.wrap = self.wp = False
         self.max_aff_merge = 5 if self.affine else (1 if (self.sbtmvp and self.tmvp) else 0)
+        self.wrap_minus = 0 if width % 64 else 2       # wrap-around period: the picture's width, or two minimum coding blocks less
 
 
 def write_sps(c):
@@ -329,21 +332,21 @@ def write_sps(c):
     if c.alf:
         b.flag(c.ccalf)                              # sps_ccalf_enabled_flag
     b.flag(c.lmcs)                                   # sps_lmcs_enable_flag
-    b.flag(0)                                        # sps_weighted_pred_flag
-    b.flag(0)                                        # sps_weighted_bipred_flag
+    b.flag(c.wp)                                     # sps_weighted_pred_flag
+    b.flag(c.wp)                                     # sps_weighted_bipred_flag
     b.flag(0)                                        # sps_long_term_ref_pics_flag
     b.flag(0)                                        # sps_idr_rpl_present_flag
     b.flag(1)                                        # sps_rpl1_same_as_rpl0_flag
     b.ue(0)                                          # sps_num_ref_pic_lists[0]
-    b.flag(0)                                        # sps_ref_wraparound_enabled_flag
+    b.flag(c.wrap)                                   # sps_ref_wraparound_enabled_flag
     b.flag(c.tmvp)                                   # sps_temporal_mvp_enabled_flag
     if c.tmvp:
         b.flag(c.sbtmvp)                             # sps_sbtmvp_enabled_flag
-    b.flag(0)                                        # sps_amvr_enabled_flag
+    b.flag(c.amvr)                                   # sps_amvr_enabled_flag
     b.flag(c.bdof)                                   # sps_bdof_enabled_flag
     if c.bdof:
         b.flag(0)                                    # sps_bdof_control_present_in_ph_flag
-    b.flag(0)                                        # sps_smvd_enabled_flag
+    b.flag(c.smvd)                                   # sps_smvd_enabled_flag
     b.flag(c.dmvr)                                   # sps_dmvr_enabled_flag
     if c.dmvr:
         b.flag(0)                                    # sps_dmvr_control_present_in_ph_flag
@@ -351,14 +354,16 @@ def write_sps(c):
     if c.mmvd:
         b.flag(0)                                    # sps_mmvd_fullpel_only_flag
     b.ue(0)                                          # sps_six_minus_max_num_merge_cand: MaxNumMergeCand = 6
-    b.flag(0)                                        # sps_sbt_enabled_flag
+    b.flag(c.sbt)                                    # sps_sbt_enabled_flag
     b.flag(c.affine)                                 # sps_affine_enabled_flag
     if c.affine:
         b.ue(0)                                      # sps_five_minus_max_num_subblock_merge_cand
         b.flag(1)                                    # sps_6param_affine_enabled_flag
+        if c.amvr:
+            b.flag(1)                                # sps_affine_amvr_enabled_flag
         b.flag(1)                                    # sps_affine_prof_enabled_flag
         b.flag(0)                                    # sps_prof_control_present_in_ph_flag
-    b.flag(0)                                        # sps_bcw_enabled_flag
+    b.flag(c.bcw)                                    # sps_bcw_enabled_flag
     b.flag(c.ciip)                                   # sps_ciip_enabled_flag
     b.flag(c.gpm)                                    # sps_gpm_enabled_flag (MaxNumMergeCand = 6)
     if c.gpm:
@@ -372,11 +377,28 @@ def write_sps(c):
     b.flag(0)                                        # sps_chroma_vertical_collocated_flag
     b.flag(0)                                        # sps_palette_enabled_flag
     b.flag(0)                                        # sps_ibc_enabled_flag
-    b.flag(0)                                        # sps_ladf_enabled_flag
+    b.flag(c.ladf)                                   # sps_ladf_enabled_flag
+    if c.ladf:
+        b.u(2, 2)                                    # sps_num_ladf_intervals_minus2: four intervals
+        b.se(2)                                      # sps_ladf_lowest_interval_qp_offset
+        for off, thr in ((-3, 150), (1, 250), (4, 300)):
+            b.se(off)                                # sps_ladf_qp_offset[i]
+            b.ue((thr >> (10 - c.bit_depth)) - 1)    # sps_ladf_delta_threshold_minus1[i]
     b.flag(0)                                        # sps_explicit_scaling_list_enabled_flag
     b.flag(c.dep_quant)                              # sps_dep_quant_enabled_flag
     b.flag(0)                                        # sps_sign_data_hiding_enabled_flag
-    b.flag(0)                                        # sps_virtual_boundaries_enabled_flag
+    b.flag(c.vb)                                     # sps_virtual_boundaries_enabled_flag
+    if c.vb:
+        b.flag(1)                                    # sps_virtual_boundaries_present_flag
+        S = 1 << c.log2_ctu
+        xs = [p for p in (S + 24, 2 * S + S // 2) if p < c.width][:2] if c.width > S + 24 else []
+        ys = [p for p in (S // 2 + 8,) if p < c.height]
+        b.ue(len(xs))                                # sps_num_ver_virtual_boundaries
+        for p in xs:
+            b.ue(p // 8 - 1)                         # sps_virtual_boundary_pos_x_minus1
+        b.ue(len(ys))                                # sps_num_hor_virtual_boundaries
+        for p in ys:
+            b.ue(p // 8 - 1)                         # sps_virtual_boundary_pos_y_minus1
     b.flag(0)                                        # sps_timing_hrd_params_present_flag
     b.flag(0)                                        # sps_field_seq_flag
     b.flag(0)                                        # sps_vui_parameters_present_flag
@@ -401,18 +423,32 @@ def write_pps(c):
     b.ue(0)                                          # pps_num_ref_idx_default_active_minus1[0]
     b.ue(0)                                          # pps_num_ref_idx_default_active_minus1[1]
     b.flag(0)                                        # pps_rpl1_idx_present_flag
-    b.flag(0)                                        # pps_weighted_pred_flag
-    b.flag(0)                                        # pps_weighted_bipred_flag
-    b.flag(0)                                        # pps_ref_wraparound_enabled_flag
+    b.flag(c.wp)                                     # pps_weighted_pred_flag
+    b.flag(c.wp)                                     # pps_weighted_bipred_flag
+    b.flag(c.wrap)                                   # pps_ref_wraparound_enabled_flag
+    if c.wrap:
+        b.ue(c.wrap_minus)                           # pps_pic_width_minus_wraparound_offset (in minimum coding blocks)
     b.se(0)                                          # pps_init_qp_minus26
-    b.flag(0)                                        # pps_cu_qp_delta_enabled_flag
-    b.flag(0)                                        # pps_chroma_tool_offsets_present_flag
+    b.flag(c.dqp)                                    # pps_cu_qp_delta_enabled_flag
+    b.flag(c.chroma_qp)                              # pps_chroma_tool_offsets_present_flag
+    if c.chroma_qp:
+        b.se(3)                                      # pps_cb_qp_offset
+        b.se(-4)                                     # pps_cr_qp_offset
+        b.flag(1)                                    # pps_joint_cbcr_qp_offset_present_flag
+        b.se(2)                                      # pps_joint_cbcr_qp_offset_value
+        b.flag(1)                                    # pps_slice_chroma_qp_offsets_present_flag
+        b.flag(0)                                    # pps_cu_chroma_qp_offset_list_enabled_flag
     b.flag(1)                                        # pps_deblocking_filter_control_present_flag
     b.flag(0)                                        # pps_deblocking_filter_override_enabled_flag
     b.flag(0 if c.deblock else 1)                    # pps_deblocking_filter_disabled_flag
     if c.deblock:
-        b.se(0)                                      # pps_luma_beta_offset_div2
-        b.se(0)                                      # pps_luma_tc_offset_div2
+        b.se(3 if c.db_offsets else 0)               # pps_luma_beta_offset_div2
+        b.se(-2 if c.db_offsets else 0)              # pps_luma_tc_offset_div2
+        if c.chroma_qp:
+            b.se(-3 if c.db_offsets else 0)          # pps_cb_beta_offset_div2
+            b.se(4 if c.db_offsets else 0)           # pps_cb_tc_offset_div2
+            b.se(5 if c.db_offsets else 0)           # pps_cr_beta_offset_div2
+            b.se(-1 if c.db_offsets else 0)          # pps_cr_tc_offset_div2
     b.flag(0)                                        # pps_picture_header_extension_present_flag
     b.flag(0)                                        # pps_slice_header_extension_present_flag
     b.flag(0)                                        # pps_extension_flag
@@ -503,15 +539,20 @@ def write_alf_aps(c, rng, aps_id):
     return b.bytes(), nalt, ncc
 
 
-def write_rpl(b, cur_poc, ref_pocs):
+def write_rpl(b, cur_poc, ref_pocs, wp=False):
     """ref_pic_list_struct (parseRefPicList): short-term entries only, deltas relative to the previous entry"""
     b.ue(len(ref_pocs))                              # num_ref_entries
     prev = 0
-    for r in ref_pocs:
+    for i, r in enumerate(ref_pocs):
         d = (cur_poc - r) - prev
-        assert d != 0
-        b.ue(abs(d) - 1)                             # abs_delta_poc_st (no weighted prediction: + 1)
-        b.flag(d > 0)                                # strp_entry_sign_flag: 1 = a picture that precedes the current one in output order
+        if wp and i > 0:
+            b.ue(abs(d))                             # abs_delta_poc_st (with weighted prediction an entry may repeat the picture before it)
+            if d:
+                b.flag(d > 0)
+        else:
+            assert d != 0
+            b.ue(abs(d) - 1)                         # abs_delta_poc_st (+ 1)
+            b.flag(d > 0)                            # strp_entry_sign_flag: 1 = a picture that precedes the current one in output order
         prev = cur_poc - r
 
 
@@ -534,8 +575,12 @@ def write_slice_header(c, b, pic):
         b.flag(1)                                    # ph_lmcs_enabled_flag
         b.u(2, 0)                                    # ph_lmcs_aps_id
         b.flag(pic.get("cscale", 1))                 # ph_chroma_residual_scale_flag
-    # (no ALF, scaling lists, virtual boundaries, output flag, RPL in the PH, partition overrides, delta QP / chroma QP offset subdivisions)
+    # (no ALF, scaling lists, virtual boundaries, output flag, RPL in the PH, partition overrides, chroma QP offset lists)
+    if c.dqp:
+        b.ue(0)                                      # ph_cu_qp_delta_subdiv_intra_slice: one quantisation group per CTU
     if inter_allowed:
+        if c.dqp:
+            b.ue(0)                                  # ph_cu_qp_delta_subdiv_inter_slice
         if c.tmvp:
             b.flag(1)                                # ph_temporal_mvp_enabled_flag
         b.flag(0)                                    # ph_mvd_l1_zero_flag
@@ -566,8 +611,8 @@ def write_slice_header(c, b, pic):
                 if a["cc_cr"] is not None:
                     b.u(3, a["cc_cr"])
     if not idr:
-        write_rpl(b, pic["poc"], pic["l0"])          # ref_pic_lists(): both lists, whatever the slice type
-        write_rpl(b, pic["poc"], pic["l1"])
+        write_rpl(b, pic["poc"], pic["l0"], c.wp)    # ref_pic_lists(): both lists, whatever the slice type
+        write_rpl(b, pic["poc"], pic["l1"], c.wp)
         n0, n1 = len(pic["l0"]), len(pic["l1"])
         if (st != "I" and n0 > 1) or (st == "B" and n1 > 1):
             b.flag(1)                                # sh_num_ref_idx_active_override_flag
@@ -582,7 +627,31 @@ def write_slice_header(c, b, pic):
                 b.flag(col_l0)                       # sh_collocated_from_l0_flag
             if (col_l0 and n0 > 1) or (not col_l0 and n1 > 1):
                 b.ue(0)                              # sh_collocated_ref_idx
+        if st != "I" and c.wp:
+            # pred_weight_table() (parsePredWeightTable): a denominator, flags per entry, weights and offsets
+            wt = pic["wp"]
+            b.ue(wt["denom"])                        # luma_log2_weight_denom
+            b.se(wt["dchroma"])                      # delta_chroma_log2_weight_denom
+            for lst, n in ((0, n0), (1, n1 if st == "B" else 0)):
+                ent = wt["l%d" % lst][:n]
+                for e in ent:
+                    b.flag(e["luma"] is not None)    # luma_weight_lX_flag
+                for e in ent:
+                    b.flag(e["chroma"] is not None)  # chroma_weight_lX_flag
+                for e in ent:
+                    if e["luma"] is not None:
+                        b.se(e["luma"][0])           # delta_luma_weight_lX
+                        b.se(e["luma"][1])           # luma_offset_lX
+                    if e["chroma"] is not None:
+                        for j in range(2):
+                            b.se(e["chroma"][j][0])  # delta_chroma_weight_lX
+                            b.se(e["chroma"][j][1])  # delta_chroma_offset_lX
     b.se(c.qp - 26)                                  # sh_qp_delta
+    if c.chroma_qp:
+        b.se(pic.get("cb_off", -2))                  # sh_cb_qp_offset
+        b.se(pic.get("cr_off", 3))                   # sh_cr_qp_offset
+        if c.jccr:
+            b.se(-1)                                 # sh_joint_cbcr_qp_offset
     if c.sao:
         b.flag(1)                                    # sh_sao_luma_used_flag
         b.flag(1)                                    # sh_sao_chroma_used_flag
@@ -609,6 +678,7 @@ class PictureWriter:
         self.cu_f = [[0] * w4 for _ in range(h4)]      # per cell: 1 skip, 2 intra, 4 affine (context of the flags of later CUs)
         self.cu_q = [[0] * w4 for _ in range(h4)]      # quad-tree depth of the CU
         self.stats = dict(cus=0, split=0, cbf=0, coefs=0, skip=0, merge=0, amvp=0, intra=0)
+        self.dqp_coded, self.cu_ciip, self.cu = False, False, dict(w=0, h=0, sbt=None, isp=0)
 
     def picture(self):
         S = 1 << self.c.log2_ctu
@@ -618,6 +688,7 @@ class PictureWriter:
                     self.sao(x, y)
                 if self.c.alf and self.pic["alf"]["on"]:
                     self.alf(x >> self.c.log2_ctu, y >> self.c.log2_ctu)
+                self.dqp_coded = False                                         # (quantisation group = CTU)
                 self.coding_tree(x, y, S, S)
         self.cab.trm(1)                              # end_of_slice_one_bit
 
@@ -804,7 +875,7 @@ class PictureWriter:
     # -- an intra CU: modes, transform tree, lfnst_idx, mts_idx (CABACReader::cu_pred_data, cu_residual :1404-1456)
     def intra_cu(self, x, y, w, h):
         info = self.intra_modes(x, y, w, h)
-        self.cu = dict(intra=True, w=w, h=h, isp=info["isp"], mip=info["mip"], viol=False, lfnst_last=False, mts_last=False)
+        self.cu = dict(intra=True, w=w, h=h, isp=info["isp"], mip=info["mip"], viol=False, lfnst_last=False, mts_last=False, sbt=None)
         self.transform_tree(w, h, intra=True, root=True)
         self.lfnst_and_mts()
         return 2 | (8 if info["mip"] else 0)
@@ -819,7 +890,7 @@ class PictureWriter:
             cab.bin(1 if lfnst else 0, "LFNSTIdx", 0)                          # lfnst_idx (single tree)
             if lfnst:
                 cab.bin(lfnst - 1, "LFNSTIdx", 2)
-        if c.mts and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and cu["mts_last"] and lfnst == 0 and not cu.get("mts_viol"):
+        if c.mts and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and not cu["sbt"] and cu["mts_last"] and lfnst == 0 and not cu.get("mts_viol"):
             m = rng.choice([0, 0, 1, 2, 3, 4])
             cab.bin(1 if m else 0, "MTSIndex", 0)                                # mts_idx
             for k in range(1, 4):
@@ -836,6 +907,7 @@ class PictureWriter:
     def coding_unit_inter(self, x, y, w, h):
         cab, rng, c = self.cab, self.rng, self.c
         left, above = self.neigh(x, y)
+        self.cu_ciip = False
         skip = rng.random() < c.p_skip
         cab.bin(1 if skip else 0, "SkipFlag", (left & 1) + (above & 1))        # cu_skip_flag
         if skip:
@@ -860,7 +932,27 @@ class PictureWriter:
             root = rng.random() < 0.7
             cab.bin(1 if root else 0, "QtRootCbf", 0)                          # cu_coded_flag
         if root:
-            self.cu = dict(intra=False, w=w, h=h, isp=0, mip=False, viol=False, lfnst_last=False, mts_last=False)
+            self.cu = dict(intra=False, w=w, h=h, isp=0, mip=False, viol=False, lfnst_last=False, mts_last=False, sbt=None)
+            mx = 1 << c.log2_max_tb
+            if c.sbt and not self.cu_ciip and w <= mx and h <= mx:
+                # cu_sbt_flag, cu_sbt_quad_flag, cu_sbt_horizontal_flag, cu_sbt_pos_flag (CABACReader::sbt_mode :1476)
+                vh, hh, vq, hq = w >= 8, h >= 8, w >= 16, h >= 16
+                if vh or hh:
+                    # (this writer's residual coding knows 4x4 coefficient groups: only splits whose residual part stays 8 luma samples wide and high, chroma 4)
+                    opts = [(q, hz) for q in (False, True) for hz in (False, True) if ((hq if hz else vq) if q else (hh if hz else vh))
+                            and (w if hz else w // (4 if q else 2)) >= 8 and (h // (4 if q else 2) if hz else h) >= 8]
+                    use = bool(opts) and rng.random() < 0.35
+                    cab.bin(1 if use else 0, "SbtFlag", 1 if w * h <= 256 else 0)
+                    if use:
+                        quad, hor = rng.choice(opts)
+                        if (vh or hh) and (vq or hq):
+                            cab.bin(1 if quad else 0, "SbtQuadFlag", 0)
+                        av, ah = (vq, hq) if quad else (vh, hh)
+                        if av and ah:
+                            cab.bin(1 if hor else 0, "SbtHorFlag", 0 if w == h else (1 if w < h else 2))
+                        pos1 = rng.random() < 0.5
+                        cab.bin(1 if pos1 else 0, "SbtPosFlag", 0)
+                        self.cu["sbt"] = (quad, hor, pos1)
             self.transform_tree(w, h, intra=False, root=True)
             self.lfnst_and_mts()
         return 4 if aff else 0
@@ -920,6 +1012,7 @@ class PictureWriter:
         elif ciip_av:
             ciip = True
         if ciip:
+            self.cu_ciip = True
             self.merge_idx("MergeIdx", 5)
             return False
         # geometric partitioning: split direction, two different candidates out of MaxNumGpmMergeCand = 6
@@ -952,6 +1045,7 @@ class PictureWriter:
                 if abs(a) > 1:
                     self.rem_abs_ep(abs(a) - 2, 1, 0)                          # abs_mvd_minus2: EG1
                 cab.ep(1 if a < 0 else 0)                                      # mvd_sign_flag
+        return bool(h or v)
 
     def rem_abs_ep(self, v, rice, cutoff):
         """inverse of BinDecoder::decodeRemAbsEP for values far below the escape length"""
@@ -1002,12 +1096,43 @@ class PictureWriter:
             if aff:
                 six = rng.random() < 0.5
                 cab.bin(1 if six else 0, "AffineType", 0)                      # cu_affine_type_flag
+        smvd = False
+        if c.smvd and dirn == 3 and not aff and self.pic.get("bidir"):
+            smvd = rng.random() < 0.4
+            cab.bin(1 if smvd else 0, "SmvdFlag", 0)                           # sym_mvd_flag
+        nonzero = False
         for lst, n in ((1, n0), (2, n1)):
             if dirn & lst:
-                self.ref_idx(n)                                                # ref_idx_l0 / l1
-                for _ in range(1 + (aff and 1) + (six and 1)):
-                    self.mvd()
+                if not (smvd and lst == 2):
+                    if not smvd:
+                        self.ref_idx(n)                                        # ref_idx_l0 / l1 (symmetric MVD: the nearest pictures on either side)
+                    for _ in range(1 + (aff and 1) + (six and 1)):
+                        nonzero = self.mvd() or nonzero
                 cab.bin(rng.randrange(0, 2), "MVPIdx", 0)                      # mvp_l0_flag / mvp_l1_flag
+        # amvr_flag / amvr_precision_idx (CABACReader::amvr_mode :991, affine_amvr_mode :1031): only with a non-zero MVD
+        if c.amvr and nonzero:
+            if aff:
+                v = rng.choice([0, 0, 1, 2])
+                cab.bin(1 if v else 0, "ImvFlag", 2)
+                if v:
+                    cab.bin(v - 1, "ImvFlag", 3)
+            else:
+                v = rng.choice([0, 0, 1, 2, 3])                                # quarter, (1) integer, (2) four samples, (3) half sample
+                cab.bin(1 if v else 0, "ImvFlag", 0)
+                if v:
+                    cab.bin(0 if v == 3 else 1, "ImvFlag", 4)
+                    if v != 3:
+                        cab.bin(v - 1, "ImvFlag", 1)
+        # bcw_idx (CABACReader::cu_bcw_flag :1180): bi-prediction of at least 256 samples, no explicit weights on the two pictures (this writer: none in the slice)
+        if c.bcw and self.st == "B" and dirn == 3 and w * h >= 256 and not c.wp:
+            num = 5 if self.pic.get("ldc") else 3
+            idx = rng.randrange(0, num)
+            cab.bin(1 if idx else 0, "BcwIdx", 0)
+            if idx:
+                for k in range(1, num - 1):
+                    cab.ep(1 if idx > k else 0)
+                    if idx <= k:
+                        break
         return aff
 
     # -- intra_luma_pred_mode / intra_chroma_pred_mode (CABACReader :1242-1400, :2541-2576, :3125-3149)
@@ -1091,6 +1216,16 @@ class PictureWriter:
             for _ in range((w // nw) * (h // nh)):
                 self.transform_tree(nw, nh, intra, False)
             return
+        sbt = self.cu.get("sbt") if (root and not intra) else None
+        if sbt:
+            # sub-block transform: the CU in two transform units, a half or a quarter of it carries the residual, the other one nothing at all
+            quad, hor, pos1 = sbt
+            frac = 4 if quad else 2
+            rw, rh = (w, h // frac) if hor else (w // frac, h)
+            for i in range(2):
+                if i == (1 if pos1 else 0):
+                    self.transform_unit(rw, rh, False, False, sbt=True)
+            return
         isp = self.cu["isp"] if (intra and root) else 0
         if isp:
             # intra sub-partitions: four transform units of a quarter of the height (1) / width (2) - CUs whose partitions would be thinner than 4 do not take ISP
@@ -1104,7 +1239,7 @@ class PictureWriter:
             return
         self.transform_unit(w, h, intra, root)
 
-    def transform_unit(self, w, h, intra, depth0, isp=None, cw=None, ch=None):
+    def transform_unit(self, w, h, intra, depth0, isp=None, cw=None, ch=None, sbt=False):
         cab, rng, c = self.cab, self.rng, self.c
         chroma = isp is None or isp[1]                                         # (ISP: the unsplit chroma blocks come with the last partition)
         cb = cr = False
@@ -1120,10 +1255,30 @@ class PictureWriter:
                 yy = True                                                      # (inferred)
             else:
                 cab.bin(1 if yy else 0, "QtCbf", 2 + (1 if prev else 0), sub=0)
-        elif not intra and depth0 and not (cb or cr):
+        elif (sbt or (not intra and depth0)) and not (cb or cr):
             yy = True                                                          # (inferred: the CU has a residual and chroma has none)
         else:
             cab.bin(1 if yy else 0, "QtCbf", 0, sub=0)                         # tu_y_coded_flag
+        if c.dqp and not self.dqp_coded and (self.cu["w"] > 64 or self.cu["h"] > 64 or yy or cb or cr):
+            # cu_qp_delta_abs / cu_qp_delta_sign_flag (CABACReader::cu_qp_delta :2293): once per quantisation group - here a CTU
+            dq = rng.choice([0, 0, 1, -1, 2, -2, 3, -4, 5, -6, 7])
+            a = abs(dq)
+            for k in range(min(a, 5)):
+                cab.bin(1, "DeltaQP", 0 if k == 0 else 1)
+            if a < 5:
+                cab.bin(0, "DeltaQP", 0 if a == 0 else 1)
+            else:
+                v, k = a - 5, 0                                                # exp_golomb_eqprob, order 0
+                while v >= (1 << k):
+                    cab.ep(1)
+                    v -= 1 << k
+                    k += 1
+                cab.ep(0)
+                if k:
+                    cab.eps(v, k)
+            if a:
+                cab.ep(1 if dq < 0 else 0)
+            self.dqp_coded = True
         joint = False
         if chroma and self.c.jccr and ((intra and (cb or cr)) or (cb and cr)):
             joint = rng.random() < 0.4
@@ -1226,8 +1381,14 @@ class PictureWriter:
             ix, iy = SCAN4[sp & 15]
             return cx * 4 + ix, cy * 4 + iy
         # -- what is coded: the last group (mostly the first few), which groups hold anything, the levels
-        ncg = len(cgs)
-        last_cg = 0 if rng.random() < 0.45 else min(ncg - 1, int(rng.expovariate(0.5)))
+        # a luma block of an SBT CU in a sequence with MTS keeps coefficients in its first 16 columns / rows only (implicit DST-7 / DCT-8): shorter last-position
+        # prefix, coefficient groups beyond are not even flagged (CABACReader::last_sig_coeff :2641, residual_coding :2416-2424)
+        cu0 = getattr(self, "cu", None) or {}
+        zo = ch == 0 and self.c.mts and bool(cu0.get("sbt")) and w <= 32 and h <= 32
+        lim_x, lim_y = (4 if (zo and w == 32) else wg), (4 if (zo and h == 32) else hg)
+        ok_cg = [i for i, (cx, cy) in enumerate(cgs) if cx < lim_x and cy < lim_y]
+        ncg = len(ok_cg)
+        last_cg = ok_cg[0 if rng.random() < 0.45 else min(ncg - 1, int(rng.expovariate(0.5)))]
         last = (last_cg << 4) + rng.choice([0, 0, 1, 2, 3, 5, 8, 11, 15])
         dense = rng.random() < 0.15                                            # (some blocks full enough to run out of context-coded bins)
         def level():
@@ -1236,6 +1397,8 @@ class PictureWriter:
         levels = {last: level()}
         sig_cg = {last_cg: True, 0: True}
         for g in range(last_cg - 1, -1, -1):
+            if g not in ok_cg:
+                continue
             if g == 0 or rng.random() < (0.8 if dense else 0.4):
                 sig_cg[g] = True
                 for sp in range((g << 4) + 15, (g << 4) - 1, -1):
@@ -1260,7 +1423,7 @@ class PictureWriter:
         for (pos, log2s, size, name) in ((lx, log2w, w, "LastX"), (ly, log2h, h, "LastY")):
             off = PREFIX_CTX[log2s] if ch == 0 else 0
             shift = ((log2s + 1) >> 2) if ch == 0 else min(2, max(0, size >> 3))
-            g, gmax = GROUP_IDX[pos], GROUP_IDX[min(32, size) - 1]
+            g, gmax = GROUP_IDX[pos], GROUP_IDX[(16 if (zo and size == 32) else min(32, size)) - 1]
             for k in range(g):
                 cab.bin(1, name, off + (k >> shift), sub=ch)
             if g < gmax:
@@ -1273,7 +1436,7 @@ class PictureWriter:
         tpl, coeff = {}, {}                                                    # per position: (sum of first-pass values, number) of its template; current absolute values
         tmpl_diag, tmpl_sum1 = -1, -1
         state, trans = 0, (32040 if self.c.dep_quant else 0)
-        area = wz * hz
+        area = (16 if (zo and w == 32) else wz) * (16 if (zo and h == 32) else hz)
         rem_bins = (area * 28) >> 4
         flagged = set()
         RICE = [0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3]
@@ -1293,6 +1456,8 @@ class PictureWriter:
                 sm += coeff.get((x, y + 1), 0)
             return max(min(sm - 5 * base, 31), 0)
         for g in range(last_cg, -1, -1):
+            if g not in ok_cg:
+                continue
             cx, cy = cgs[g]
             min_sub = g << 4
             is_last = g == last_cg
@@ -1425,6 +1590,16 @@ def write_stream(c, num_pictures, seed, tables, renorm, hashes=None):
             alf_aps.append((nalt, ncc))
     stats = []
     for pic_idx, pic in enumerate(gop_plan(num_pictures, c.inter)):
+        if pic["type"] != "I":
+            cur, l0, l1 = pic["poc"], pic["l0"], pic["l1"]
+            pic["ldc"] = all(r < cur for r in l0 + l1)                         # Slice::getCheckLDC: no reference picture follows in output order
+            # symmetric MVD: the nearest picture before in one list and after in the other (DecLibParser.cpp:850-925)
+            pic["bidir"] = (not pic["ldc"]) and ((any(r < cur for r in l0) and any(r > cur for r in l1)) or (any(r > cur for r in l0) and any(r < cur for r in l1)))
+            if c.wp:
+                def entry():
+                    return dict(luma=(rng.randrange(-20, 21), rng.randrange(-10, 11)) if rng.random() < 0.6 else None,
+                                chroma=[(rng.randrange(-20, 21), rng.randrange(-20, 21)) for _ in range(2)] if rng.random() < 0.5 else None)
+                pic["wp"] = dict(denom=rng.randrange(2, 7), dchroma=rng.randrange(-1, 2), l0=[entry() for _ in l0], l1=[entry() for _ in l1])
         if c.alf:
             # the slice's ALF choice: which APSs the luma filter sets come from, the APS of the chroma filters (its alternatives), the APSs of the CC-ALF filters
             ids = list(range(c.alf_aps))
@@ -1518,6 +1693,22 @@ FIXTURES = [
     ("mini_resi_all_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=32, mtt_depth=2, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True,
                                                 gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True, alf=True,
                                                 ccalf=True, big_resi=True, p_intra=0.25), 9, 63),
+    # more inter tools with syntax of their own: adaptive MV resolution (also affine), BCW weights, symmetric MVD, sub-block transforms (with the implicit
+    # DST-7 / DCT-8 zero-out when MTS is on)
+    ("mini_amvr_bcw_smvd_sbt_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=31, mtt_depth=2, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True,
+                                                   gpm=True, amvr=True, bcw=True, smvd=True, sbt=True, mts=True, big_resi=True, p_intra=0.1, p_skip=0.15, p_merge=0.35), 13, 75),
+    # QP that changes from CTU to CTU (cu_qp_delta), chroma QP offsets in the PPS and the slice header, deblocking offsets per component, luma-adaptive deblocking
+    ("mini_dqp_chroma_qp_ladf_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, sbtmvp=True, affine=True, dqp=True,
+                                                    chroma_qp=True, db_offsets=True, ladf=True, jccr=True, sao=True, big_resi=True, p_intra=0.2), 9, 76),
+    # horizontal reference wrap-around with motion vectors that leave the picture by up to 75 samples
+    ("mini_wraparound_ctu64_384x256", dict(width=384, height=256, log2_ctu=6, log2_min_qt=4, qp=30, mtt_depth=1, inter=True, sbtmvp=True, affine=True, mmvd=True, gpm=True, ciip=True,
+                                           wrap=True, max_mvd=300, p_intra=0.1), 9, 79),
+    # virtual boundaries of the in-loop filters (sequence level): deblocking, SAO, ALF and CC-ALF stop there (the back-end's unfused filter passes)
+    ("mini_virtual_boundaries_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, vb=True, sao=True, alf=True, ccalf=True,
+                                                    big_resi=True, p_intra=0.2), 5, 80),
+    # explicit weighted prediction: weights and offsets per reference entry, uni- and bi-prediction
+    ("mini_weighted_pred_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=32, bit_depth=8, mtt_depth=2, inter=True, sbtmvp=True, affine=True, mmvd=True,
+                                                   gpm=True, ciip=True, wp=True, p_intra=0.1), 9, 81),
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
