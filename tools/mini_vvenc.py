@@ -253,7 +253,7 @@ class Cfg:
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
                  mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False,
-                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
+                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -307,7 +307,13 @@ def write_sps(c):
     if c.mtt_depth:
         b.ue(c.log2_max_btt - c.log2_min_qt)         # sps_log2_diff_max_bt_min_qt_intra_slice_luma
         b.ue(c.log2_max_btt - c.log2_min_qt)         # sps_log2_diff_max_tt_min_qt_intra_slice_luma
-    b.flag(0)                                        # sps_qtbtt_dual_tree_intra_flag
+    b.flag(c.dual_tree)                              # sps_qtbtt_dual_tree_intra_flag
+    if c.dual_tree:
+        b.ue(c.log2_min_qt_c - c.log2_min_cb)        # sps_log2_diff_min_qt_min_cb_intra_slice_chroma
+        b.ue(c.mtt_depth)                            # sps_max_mtt_hierarchy_depth_intra_slice_chroma
+        if c.mtt_depth:
+            b.ue(c.log2_max_btt - c.log2_min_qt_c)   # sps_log2_diff_max_bt_min_qt_intra_slice_chroma
+            b.ue(c.log2_max_btt - c.log2_min_qt_c)   # sps_log2_diff_max_tt_min_qt_intra_slice_chroma
     b.ue(c.log2_min_qt - c.log2_min_cb)              # sps_log2_diff_min_qt_min_cb_inter_slice
     b.ue(c.mtt_depth)                                # sps_max_mtt_hierarchy_depth_inter_slice
     if c.mtt_depth:
@@ -677,6 +683,11 @@ class PictureWriter:
         self.cu_h = [[0] * w4 for _ in range(h4)]
         self.cu_f = [[0] * w4 for _ in range(h4)]      # per cell: 1 skip, 2 intra, 4 affine (context of the flags of later CUs)
         self.cu_q = [[0] * w4 for _ in range(h4)]      # quad-tree depth of the CU
+        # dual tree (I slices of a sequence with sps_qtbtt_dual_tree_intra_flag): the chroma tree has neighbours of its own
+        self.dual = bool(c.dual_tree) and self.st == "I"
+        self.maps = {"single": (self.cu_w, self.cu_h, self.cu_q), "luma": (self.cu_w, self.cu_h, self.cu_q),
+                     "chroma": ([[0] * w4 for _ in range(h4)], [[0] * w4 for _ in range(h4)], [[0] * w4 for _ in range(h4)])}
+        self.tree = "single"
         self.stats = dict(cus=0, split=0, cbf=0, coefs=0, skip=0, merge=0, amvp=0, intra=0)
         self.dqp_coded, self.cu_ciip, self.cu = False, False, dict(w=0, h=0, sbt=None, isp=0)
 
@@ -689,7 +700,10 @@ class PictureWriter:
                 if self.c.alf and self.pic["alf"]["on"]:
                     self.alf(x >> self.c.log2_ctu, y >> self.c.log2_ctu)
                 self.dqp_coded = False                                         # (quantisation group = CTU)
-                self.coding_tree(x, y, S, S)
+                if self.dual:
+                    self.dual_ctu(x, y, S, 0, 0)
+                else:
+                    self.coding_tree(x, y, S, S)
         self.cab.trm(1)                              # end_of_slice_one_bit
 
     # -- ALF controls of a CTU (CABACReader::readAlf :391-467): on / off per component, filter set, chroma alternative, CC-ALF filter
@@ -780,8 +794,9 @@ class PictureWriter:
     # 8x8, so none of the mode-type conditions - local dual tree - ever holds)
     def can_split(self, w, h, mt_depth, last, idx):
         c = self.c
-        min_qt, min_bt, max_btt = 1 << c.log2_min_qt, 1 << c.log2_min_cb, 1 << c.log2_max_btt
-        can_qt = last in ("ctu", "qt") and w > min_qt
+        chroma = self.tree == "chroma"
+        min_qt, min_bt, max_btt = 1 << (c.log2_min_qt_c if chroma else c.log2_min_qt), 1 << c.log2_min_cb, 1 << c.log2_max_btt
+        can_qt = last in ("ctu", "qt") and w > min_qt and not (chroma and (w >> 1) <= 4)
         bh = bv = th = tv = False
         if mt_depth < c.mtt_depth and (w > min_bt or h > min_bt) and w <= max_btt and h <= max_btt:
             bh = bv = True
@@ -794,7 +809,27 @@ class PictureWriter:
             bv = bv and w > min_bt and (w > 64 or h <= 64)
             if w <= 64 and h <= 64:
                 th, tv = h > 2 * min_bt, w > 2 * min_bt
+            if chroma:                                                         # (sizes of the chroma block: no chroma block below 16 samples, none 2 wide)
+                cw, ch = w >> 1, h >> 1
+                bh = bh and cw * ch > 16
+                th = th and cw * ch > 32
+                bv = bv and cw * ch > 16 and cw > 4
+                tv = tv and cw * ch > 32 and cw > 8
         return can_qt, bh, bv, th, tv
+
+    # -- a CTU of a dual-tree I slice (CABACReader::dt_implicit_qt_split :172): blocks above 64x64 are quartered without any syntax, then a luma tree and a chroma
+    # tree per 64x64 (or per CTU)
+    def dual_ctu(self, x, y, size, qt_depth, idx):
+        if size > 64:
+            hs = size >> 1
+            for i, (dx, dy) in enumerate(((0, 0), (hs, 0), (0, hs), (hs, hs))):
+                self.dual_ctu(x + dx, y + dy, hs, qt_depth + 1, i)
+            return
+        last = "qt" if qt_depth else "ctu"
+        for tree in ("luma", "chroma"):
+            self.tree = tree
+            self.coding_tree(x, y, size, size, qt_depth, 0, last, idx)
+        self.tree = "single"
 
     # -- coding_tree: split_cu_flag, split_qt_flag, mtt_split_cu_vertical_flag, mtt_split_cu_binary_flag where more than one choice exists
     # (CABACReader::split_cu_mode :679-830)
@@ -804,9 +839,10 @@ class PictureWriter:
         num_hor, num_ver = bh + th, bv + tv
         num_split = 2 * can_qt + num_hor + num_ver
         mode = None
+        m_w, m_h, m_q = self.maps[self.tree]
         if num_split:
-            left_h = self.cu_h[y >> 2][(x >> 2) - 1] if x > 0 else 0
-            above_w = self.cu_w[(y >> 2) - 1][x >> 2] if y > 0 else 0
+            left_h = m_h[y >> 2][(x >> 2) - 1] if x > 0 else 0
+            above_w = m_w[(y >> 2) - 1][x >> 2] if y > 0 else 0
             p = self.c.p_split if can_qt else self.c.p_mtt
             split = rng.random() < p
             ctx = (1 if (left_h and left_h < h) else 0) + (1 if (above_w and above_w < w) else 0) + (0, 0, 0, 3, 3, 6, 6)[num_split]
@@ -816,8 +852,8 @@ class PictureWriter:
                 is_qt = can_qt
                 if can_qt and can_btt:
                     is_qt = rng.random() < 0.5
-                    lq = self.cu_q[y >> 2][(x >> 2) - 1] if x > 0 else -1
-                    aq = self.cu_q[(y >> 2) - 1][x >> 2] if y > 0 else -1
+                    lq = m_q[y >> 2][(x >> 2) - 1] if x > 0 else -1
+                    aq = m_q[(y >> 2) - 1][x >> 2] if y > 0 else -1
                     cab.bin(1 if is_qt else 0, "SplitQtFlag", (1 if lq > qt_depth else 0) + (1 if aq > qt_depth else 0) + (0 if qt_depth < 2 else 3))      # split_qt_flag
                 if is_qt:
                     mode = "qt"
@@ -859,10 +895,11 @@ class PictureWriter:
         f = self.coding_unit(x, y, w, h)
         for yy in range(y >> 2, (y + h) >> 2):
             for xx in range(x >> 2, (x + w) >> 2):
-                self.cu_w[yy][xx] = w
-                self.cu_h[yy][xx] = h
-                self.cu_f[yy][xx] = f
-                self.cu_q[yy][xx] = qt_depth
+                m_w[yy][xx] = w
+                m_h[yy][xx] = h
+                m_q[yy][xx] = qt_depth
+                if self.tree != "chroma":
+                    self.cu_f[yy][xx] = f
 
     # -- coding_unit of an I slice, single tree: intra luma mode, intra chroma mode, transform tree
     def coding_unit(self, x, y, w, h):
@@ -874,6 +911,12 @@ class PictureWriter:
 
     # -- an intra CU: modes, transform tree, lfnst_idx, mts_idx (CABACReader::cu_pred_data, cu_residual :1404-1456)
     def intra_cu(self, x, y, w, h):
+        if self.tree == "chroma":                                              # the chroma CU of a dual tree: a chroma mode, chroma transform units, an LFNST index of its own
+            self.chroma_mode()
+            self.cu = dict(intra=True, w=w, h=h, isp=0, mip=False, viol=False, lfnst_last=False, mts_last=False, sbt=None)
+            self.transform_tree(w, h, intra=True, root=True)
+            self.lfnst_and_mts()
+            return 2
         info = self.intra_modes(x, y, w, h)
         self.cu = dict(intra=True, w=w, h=h, isp=info["isp"], mip=info["mip"], viol=False, lfnst_last=False, mts_last=False, sbt=None)
         self.transform_tree(w, h, intra=True, root=True)
@@ -887,10 +930,10 @@ class PictureWriter:
         if c.lfnst and cu["intra"] and not (cu["mip"] and not (cu["w"] >= 16 and cu["h"] >= 16)) and cu["w"] <= mx and cu["h"] <= mx \
                 and not cu["viol"] and (cu["lfnst_last"] or cu["isp"]):
             lfnst = rng.choice([0, 1, 2])
-            cab.bin(1 if lfnst else 0, "LFNSTIdx", 0)                          # lfnst_idx (single tree)
+            cab.bin(1 if lfnst else 0, "LFNSTIdx", 0 if self.tree == "single" else 1)      # lfnst_idx (context: single or separate tree)
             if lfnst:
                 cab.bin(lfnst - 1, "LFNSTIdx", 2)
-        if c.mts and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and not cu["sbt"] and cu["mts_last"] and lfnst == 0 and not cu.get("mts_viol"):
+        if c.mts and self.tree != "chroma" and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and not cu["sbt"] and cu["mts_last"] and lfnst == 0 and not cu.get("mts_viol"):
             m = rng.choice([0, 0, 1, 2, 3, 4])
             cab.bin(1 if m else 0, "MTSIndex", 0)                                # mts_idx
             for k in range(1, 4):
@@ -1184,7 +1227,13 @@ class PictureWriter:
                         cab.ep(0)
             else:
                 self.trunc_bin(rng.randrange(0, 61), 61)                       # intra_luma_mpm_remainder
-        if c.cclm:
+        if self.tree == "single":
+            self.chroma_mode()
+        return info
+
+    def chroma_mode(self):
+        cab, rng, c = self.cab, self.rng, self.c
+        if c.cclm and self.tree == "single":                                   # (dual tree: whether CCLM is allowed depends on how the luma tree split its 64x64 - not written here)
             lm = rng.random() < 0.3
             cab.bin(1 if lm else 0, "CclmModeFlag", 0)                         # cclm_mode_flag
             if lm:
@@ -1192,13 +1241,12 @@ class PictureWriter:
                 cab.bin(1 if k else 0, "CclmModeIdx", 0)                       # cclm_mode_idx: LM, MDLM_L, MDLM_T
                 if k:
                     cab.ep(k - 1)
-                return info
+                return
         if rng.random() < 0.5:
             cab.bin(0, "IPredMode", 0, sub=1)                                  # intra_chroma_pred_mode: derived mode
         else:
             cab.bin(1, "IPredMode", 0, sub=1)
             cab.eps(rng.randrange(0, 4), 2)
-        return info
 
     def trunc_bin(self, v, n):                                                 # xReadTruncBinCode
         thresh = n.bit_length() - 1
@@ -1241,7 +1289,7 @@ class PictureWriter:
 
     def transform_unit(self, w, h, intra, depth0, isp=None, cw=None, ch=None, sbt=False):
         cab, rng, c = self.cab, self.rng, self.c
-        chroma = isp is None or isp[1]                                         # (ISP: the unsplit chroma blocks come with the last partition)
+        chroma = (isp is None or isp[1]) and self.tree != "luma"               # (ISP: the unsplit chroma blocks come with the last partition; dual tree: none in the luma tree)
         cb = cr = False
         if chroma:
             cb = rng.random() < c.p_cbf_chroma
@@ -1249,7 +1297,9 @@ class PictureWriter:
             cab.bin(1 if cb else 0, "QtCbf", 0, sub=1)                         # tu_cb_coded_flag
             cab.bin(1 if cr else 0, "QtCbf", 1 if cb else 0, sub=2)            # tu_cr_coded_flag
         yy = rng.random() < c.p_cbf
-        if isp is not None:
+        if self.tree == "chroma":
+            yy = False                                                         # (no luma in the chroma tree)
+        elif isp is not None:
             i, last, prev, any_cbf = isp
             if last and not any_cbf:
                 yy = True                                                      # (inferred)
@@ -1259,7 +1309,7 @@ class PictureWriter:
             yy = True                                                          # (inferred: the CU has a residual and chroma has none)
         else:
             cab.bin(1 if yy else 0, "QtCbf", 0, sub=0)                         # tu_y_coded_flag
-        if c.dqp and not self.dqp_coded and (self.cu["w"] > 64 or self.cu["h"] > 64 or yy or cb or cr):
+        if c.dqp and not self.dqp_coded and self.tree != "chroma" and (self.cu["w"] > 64 or self.cu["h"] > 64 or yy or cb or cr):
             # cu_qp_delta_abs / cu_qp_delta_sign_flag (CABACReader::cu_qp_delta :2293): once per quantisation group - here a CTU
             dq = rng.choice([0, 0, 1, -1, 2, -2, 3, -4, 5, -6, 7])
             a = abs(dq)
@@ -1709,6 +1759,15 @@ FIXTURES = [
     # explicit weighted prediction: weights and offsets per reference entry, uni- and bi-prediction
     ("mini_weighted_pred_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=32, bit_depth=8, mtt_depth=2, inter=True, sbtmvp=True, affine=True, mmvd=True,
                                                    gpm=True, ciip=True, wp=True, p_intra=0.1), 9, 81),
+    # dual tree: I slices with a luma tree and a chroma tree per 64x64 (blocks above quartered without syntax), chroma CUs with modes, transform units and LFNST of
+    # their own; single-tree inter pictures behind a dual-tree IRAP
+    ("mini_dual_tree_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, dual_tree=True), 2, 91),
+    ("mini_dual_tree_mtt_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=28, mtt_depth=2, dual_tree=True, big_resi=True, jccr=True), 2, 92),
+    ("mini_dual_tree_ctu32_128x64", dict(width=128, height=64, log2_ctu=5, qp=30, dual_tree=True, log2_min_qt_c=3, big_resi=True), 2, 93),
+    ("mini_dual_tree_tools_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, dual_tree=True, mrl=True, isp=True, mip=True, lfnst=True, mts=True,
+                                                 big_resi=True, jccr=True, dep_quant=True, sao=True, lmcs=True, alf=True, ccalf=True, dqp=True), 3, 94),
+    ("mini_dual_tree_inter_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, dual_tree=True, inter=True, sbtmvp=True, affine=True, mip=True,
+                                                 lfnst=True, big_resi=True, lmcs=True), 5, 95),
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
