@@ -253,7 +253,7 @@ class Cfg:
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
                  mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False,
-                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
+                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -390,7 +390,9 @@ def write_sps(c):
         for off, thr in ((-3, 150), (1, 250), (4, 300)):
             b.se(off)                                # sps_ladf_qp_offset[i]
             b.ue((thr >> (10 - c.bit_depth)) - 1)    # sps_ladf_delta_threshold_minus1[i]
-    b.flag(0)                                        # sps_explicit_scaling_list_enabled_flag
+    b.flag(c.scaling)                                # sps_explicit_scaling_list_enabled_flag
+    if c.scaling and c.lfnst:
+        b.flag(rseed_bit(c))                         # sps_scaling_matrix_for_lfnst_disabled_flag
     b.flag(c.dep_quant)                              # sps_dep_quant_enabled_flag
     b.flag(0)                                        # sps_sign_data_hiding_enabled_flag
     b.flag(c.vb)                                     # sps_virtual_boundaries_enabled_flag
@@ -491,6 +493,83 @@ def write_lmcs_aps(c, rng, aps_id):
     return b.bytes()
 
 
+def rseed_bit(c):
+    return (c.width // 8 + c.qp) & 1                 # (a configuration-dependent constant: both values of the flag appear among the fixtures)
+
+
+def diag_scan(n):
+    """positions (x, y) of an n x n block in the diagonal scan (ScanGenerator, Rom.cpp:130-172)"""
+    out = []
+    for d in range(2 * n - 1):
+        for y in range(min(d, n - 1), -1, -1):
+            if d - y < n:
+                out.append((d - y, y))
+    return out
+
+
+def write_scaling_aps(c, rng, aps_id):
+    """adaptation_parameter_set_rbsp with scaling_list_data (parseScalingList / decodeScalingList): the 28 matrices - flat, copied or predicted from an earlier one of their
+    size, or coded afresh -, DC entries from 16x16 on, no coefficients for the zeroed-out quadrant of the 64x64 matrices"""
+    b = Bits()
+    b.u(3, 2)                                        # aps_params_type: SCALING_APS
+    b.u(5, aps_id)                                   # aps_adaptation_parameter_set_id
+    b.flag(1)                                        # aps_chroma_present_flag
+    rec, dc = {}, {}
+    for sid in range(28):
+        n = 2 if sid < 2 else (4 if sid < 8 else 8)
+        first = sid in (0, 2, 8)
+        max_delta = sid if sid < 2 else (sid - 2 if sid < 8 else sid - 8)
+        mode = rng.choice(["copy", "pred", "new", "new"])
+        delta = 0
+        if mode != "new" and not first:
+            delta = rng.randrange(0, max_delta + 1)
+            if sid > 25 and mode == "pred":
+                delta = 0                            # (the uncoded quadrant takes prediction + last sum: stays positive with a flat prediction)
+        b.flag(mode == "copy")                       # scaling_list_copy_mode_flag
+        if mode != "copy":
+            b.flag(mode == "pred")                   # scaling_list_pred_mode_flag
+        if mode != "new" and not first:
+            b.ue(delta)                              # scaling_list_pred_id_delta
+        if mode == "new":
+            pred, dc_pred = [8] * (n * n), 8
+        elif delta == 0:
+            pred, dc_pred = [16] * (n * n), 16
+        else:
+            ref = sid - delta
+            pred, dc_pred = list(rec[ref]), (dc[ref] if ref > 13 else rec[ref][0])
+        if mode == "copy":
+            rec[sid] = pred
+            if sid >= 14:
+                dc[sid] = dc_pred
+            continue
+        nxt = 0
+        def wrap(v):
+            return ((v + 128) & 255) - 128
+        if sid > 13:
+            t = rng.randrange(4, 60)
+            d = wrap(t - dc_pred)
+            b.se(d)                                  # scaling_list_dc_coef
+            nxt += d
+            dc[sid] = (dc_pred + d) & 255
+        cur = list(pred)
+        scan8, scann = diag_scan(8), diag_scan(n)
+        for i in range(n * n):
+            x, y = scan8[i][0], scan8[i][1]          # (the zero-out test looks at the 8x8 scan whatever the size: only 8x8 matrices reach id 26)
+            px, py = scann[i]
+            pos = py * n + px
+            if not (sid > 25 and x >= 4 and y >= 4):
+                t = max(1, min(255, 16 + int(rng.gauss(0, 1) * 10) + 2 * (px + py)))
+                d = wrap(t - pred[pos] - nxt)
+                b.se(d)                              # scaling_list_delta_coef
+                nxt += d
+            cur[pos] = (pred[pos] + nxt) & 255
+            assert cur[pos] > 0
+        rec[sid] = cur
+    b.flag(0)                                        # aps_extension_flag
+    b.trailing()
+    return b.bytes()
+
+
 def write_alf_aps(c, rng, aps_id):
     """adaptation_parameter_set_rbsp with alf_data (parseAlfAps / alfFilterCoeffs): luma filters with a class map, chroma alternatives, CC-ALF filters, clipping indices.
     -> (bytes, number of chroma alternatives, CC-ALF filter counts)"""
@@ -581,6 +660,10 @@ def write_slice_header(c, b, pic):
         b.flag(1)                                    # ph_lmcs_enabled_flag
         b.u(2, 0)                                    # ph_lmcs_aps_id
         b.flag(pic.get("cscale", 1))                 # ph_chroma_residual_scale_flag
+    if c.scaling:
+        b.flag(pic.get("scaling", 1))                # ph_explicit_scaling_list_enabled_flag
+        if pic.get("scaling", 1):
+            b.u(3, pic.get("scaling_aps", 0))        # ph_scaling_list_aps_id
     # (no ALF, scaling lists, virtual boundaries, output flag, RPL in the PH, partition overrides, chroma QP offset lists)
     if c.dqp:
         b.ue(0)                                      # ph_cu_qp_delta_subdiv_intra_slice: one quantisation group per CTU
@@ -1632,6 +1715,9 @@ def write_stream(c, num_pictures, seed, tables, renorm, hashes=None):
     out += nal(NAL_PPS, write_pps(c), long_start=True)
     if c.lmcs:
         out += nal(NAL_PREFIX_APS, write_lmcs_aps(c, rng, 0), long_start=True)
+    if c.scaling:
+        for i in range(2):
+            out += nal(NAL_PREFIX_APS, write_scaling_aps(c, rng, i), long_start=True)
     alf_aps = []
     if c.alf:
         for i in range(c.alf_aps):
@@ -1640,6 +1726,8 @@ def write_stream(c, num_pictures, seed, tables, renorm, hashes=None):
             alf_aps.append((nalt, ncc))
     stats = []
     for pic_idx, pic in enumerate(gop_plan(num_pictures, c.inter)):
+        if c.scaling:
+            pic["scaling"], pic["scaling_aps"] = (1 if rng.random() < 0.85 else 0), rng.randrange(0, 2)
         if pic["type"] != "I":
             cur, l0, l1 = pic["poc"], pic["l0"], pic["l1"]
             pic["ldc"] = all(r < cur for r in l0 + l1)                         # Slice::getCheckLDC: no reference picture follows in output order
@@ -1768,6 +1856,11 @@ FIXTURES = [
                                                  big_resi=True, jccr=True, dep_quant=True, sao=True, lmcs=True, alf=True, ccalf=True, dqp=True), 3, 94),
     ("mini_dual_tree_inter_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, dual_tree=True, inter=True, sbtmvp=True, affine=True, mip=True,
                                                  lfnst=True, big_resi=True, lmcs=True), 5, 95),
+    # explicit scaling lists: two APSs of 28 matrices (flat, copied, predicted, coded; DC entries; the 64x64 zero-out), chosen per picture; with and without LFNST blocks exempt
+    ("mini_scaling_lists_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, scaling=True, big_resi=True), 3, 101),
+    ("mini_scaling_lists_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, sbtmvp=True, affine=True, scaling=True, lfnst=True,
+                                                     mts=True, isp=True, mip=True, jccr=True, dep_quant=True, big_resi=True, sbt=True, p_intra=0.25), 9, 102),
+    ("mini_scaling_lists_dual_tree_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=27, mtt_depth=2, dual_tree=True, scaling=True, lfnst=True, big_resi=True), 2, 103),
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
