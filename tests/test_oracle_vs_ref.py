@@ -152,7 +152,7 @@ def test_oracle_equals_reference_small_cus(built, W, H, l2, idx, seed, tools, kw
 
 
 @pytest.mark.parametrize("W,H,l2,idx,seed,lmcs,kw", [
-    (256, 128, 7, 0, 301, 0, dict(p_ibc=0.4, p_coded=0.5)),
+    (256, 128, 7, 0, 321, 0, dict(p_ibc=0.4, p_coded=0.5)),
     (384, 256, 6, 0, 302, 1, dict(p_ibc=0.5, p_split_scale=1.4, p_cclm=0.3, p_jccr=0.3, p_coded_chroma=0.5)),
     (200, 136, 5, 0, 303, 0, dict(p_ibc=0.7, p_coded=0.3)),
     (384, 256, 7, 2, 304, 1, dict(p_ibc=0.6, p_intra=0.5, p_ciip=0.1, p_affine=0.1)),

@@ -253,7 +253,7 @@ class Cfg:
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
                  mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False,
-                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
+                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -321,7 +321,10 @@ def write_sps(c):
         b.ue(c.log2_max_btt - c.log2_min_qt)         # sps_log2_diff_max_tt_min_qt_inter_slice
     if c.log2_ctu > 5:
         b.flag(c.log2_max_tb == 6)                   # sps_max_luma_transform_size_64_flag
-    b.flag(0)                                        # sps_transform_skip_enabled_flag
+    b.flag(c.ts)                                     # sps_transform_skip_enabled_flag
+    if c.ts:
+        b.ue(3)                                      # sps_log2_transform_skip_max_size_minus2: 32
+        b.flag(c.bdpcm)                              # sps_bdpcm_enabled_flag
     b.flag(c.mts)                                    # sps_mts_enabled_flag
     if c.mts:
         b.flag(1)                                    # sps_explicit_mts_intra_enabled_flag
@@ -382,6 +385,8 @@ def write_sps(c):
     b.flag(0)                                        # sps_chroma_horizontal_collocated_flag
     b.flag(0)                                        # sps_chroma_vertical_collocated_flag
     b.flag(0)                                        # sps_palette_enabled_flag
+    if c.ts:
+        b.ue(2 if c.bit_depth > 8 else 0)            # sps_internal_bit_depth_minus_input_bit_depth (the QP floor of transform-skip blocks)
     b.flag(0)                                        # sps_ibc_enabled_flag
     b.flag(c.ladf)                                   # sps_ladf_enabled_flag
     if c.ladf:
@@ -746,6 +751,8 @@ def write_slice_header(c, b, pic):
         b.flag(1)                                    # sh_sao_chroma_used_flag
     if c.dep_quant:
         b.flag(1)                                    # sh_dep_quant_used_flag
+    if c.ts and not c.dep_quant:
+        b.flag(c.ts_regular)                         # sh_ts_residual_coding_disabled_flag
     b.trailing()                                     # byte_alignment()
 
 
@@ -995,13 +1002,14 @@ class PictureWriter:
     # -- an intra CU: modes, transform tree, lfnst_idx, mts_idx (CABACReader::cu_pred_data, cu_residual :1404-1456)
     def intra_cu(self, x, y, w, h):
         if self.tree == "chroma":                                              # the chroma CU of a dual tree: a chroma mode, chroma transform units, an LFNST index of its own
-            self.chroma_mode()
-            self.cu = dict(intra=True, w=w, h=h, isp=0, mip=False, viol=False, lfnst_last=False, mts_last=False, sbt=None)
+            self.chroma_mode(w, h)
+            self.cu = dict(intra=True, w=w, h=h, isp=0, mip=False, viol=False, lfnst_last=False, mts_last=False, sbt=None, bdpcm=0, bdpcm_c=self.bdpcm_c)
             self.transform_tree(w, h, intra=True, root=True)
             self.lfnst_and_mts()
             return 2
+        self.bdpcm_c = 0
         info = self.intra_modes(x, y, w, h)
-        self.cu = dict(intra=True, w=w, h=h, isp=info["isp"], mip=info["mip"], viol=False, lfnst_last=False, mts_last=False, sbt=None)
+        self.cu = dict(intra=True, w=w, h=h, isp=info["isp"], mip=info["mip"], viol=False, lfnst_last=False, mts_last=False, sbt=None, bdpcm=info["bdpcm"], bdpcm_c=self.bdpcm_c)
         self.transform_tree(w, h, intra=True, root=True)
         self.lfnst_and_mts()
         return 2 | (8 if info["mip"] else 0)
@@ -1011,12 +1019,12 @@ class PictureWriter:
         mx = 1 << c.log2_max_tb
         lfnst = 0
         if c.lfnst and cu["intra"] and not (cu["mip"] and not (cu["w"] >= 16 and cu["h"] >= 16)) and cu["w"] <= mx and cu["h"] <= mx \
-                and not cu["viol"] and (cu["lfnst_last"] or cu["isp"]):
+                and not cu["viol"] and (cu["lfnst_last"] or cu["isp"]) and not cu.get("ts_any"):
             lfnst = rng.choice([0, 1, 2])
             cab.bin(1 if lfnst else 0, "LFNSTIdx", 0 if self.tree == "single" else 1)      # lfnst_idx (context: single or separate tree)
             if lfnst:
                 cab.bin(lfnst - 1, "LFNSTIdx", 2)
-        if c.mts and self.tree != "chroma" and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and not cu["sbt"] and cu["mts_last"] and lfnst == 0 and not cu.get("mts_viol"):
+        if c.mts and self.tree != "chroma" and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and not cu["sbt"] and not cu.get("ts_first") and not cu.get("bdpcm") and cu["mts_last"] and lfnst == 0 and not cu.get("mts_viol"):
             m = rng.choice([0, 0, 1, 2, 3, 4])
             cab.bin(1 if m else 0, "MTSIndex", 0)                                # mts_idx
             for k in range(1, 4):
@@ -1264,8 +1272,17 @@ class PictureWriter:
     # -- intra_luma_pred_mode / intra_chroma_pred_mode (CABACReader :1242-1400, :2541-2576, :3125-3149)
     def intra_modes(self, x, y, w, h):
         cab, rng, c = self.cab, self.rng, self.c
-        info = dict(isp=0, mip=False)
+        info = dict(isp=0, mip=False, bdpcm=0)
         done = False
+        if c.ts and c.bdpcm and w <= 32 and h <= 32:
+            bd = rng.choice([0, 0, 0, 1, 2])
+            cab.bin(1 if bd else 0, "BDPCMMode", 0)                            # intra_bdpcm_luma_flag
+            if bd:
+                cab.bin(bd - 1, "BDPCMMode", 1)                                # intra_bdpcm_luma_dir_flag
+                info["bdpcm"] = bd
+                if self.tree == "single":
+                    self.chroma_mode(w, h)
+                return info
         if c.mip:
             left, above = self.neigh(x, y)
             mip = rng.random() < 0.25
@@ -1311,11 +1328,19 @@ class PictureWriter:
             else:
                 self.trunc_bin(rng.randrange(0, 61), 61)                       # intra_luma_mpm_remainder
         if self.tree == "single":
-            self.chroma_mode()
+            self.chroma_mode(w, h)
         return info
 
-    def chroma_mode(self):
+    def chroma_mode(self, w, h):
         cab, rng, c = self.cab, self.rng, self.c
+        self.bdpcm_c = 0
+        if c.ts and c.bdpcm and (w >> 1) <= 32 and (h >> 1) <= 32:
+            bd = rng.choice([0, 0, 0, 1, 2])
+            cab.bin(1 if bd else 0, "BDPCMMode", 2)                            # intra_bdpcm_chroma_flag
+            if bd:
+                cab.bin(bd - 1, "BDPCMMode", 3)                                # intra_bdpcm_chroma_dir_flag
+                self.bdpcm_c = bd
+                return
         if c.cclm and self.tree == "single":                                   # (dual tree: whether CCLM is allowed depends on how the luma tree split its 64x64 - not written here)
             lm = rng.random() < 0.3
             cab.bin(1 if lm else 0, "CclmModeFlag", 0)                         # cclm_mode_flag
@@ -1377,8 +1402,9 @@ class PictureWriter:
         if chroma:
             cb = rng.random() < c.p_cbf_chroma
             cr = rng.random() < c.p_cbf_chroma
-            cab.bin(1 if cb else 0, "QtCbf", 0, sub=1)                         # tu_cb_coded_flag
-            cab.bin(1 if cr else 0, "QtCbf", 1 if cb else 0, sub=2)            # tu_cr_coded_flag
+            bdc = self.cu.get("bdpcm_c")
+            cab.bin(1 if cb else 0, "QtCbf", 1 if bdc else 0, sub=1)           # tu_cb_coded_flag (BDPCM blocks: contexts of their own, CABACReader::cbf_comp :2066)
+            cab.bin(1 if cr else 0, "QtCbf", 2 if bdc else (1 if cb else 0), sub=2)      # tu_cr_coded_flag
         yy = rng.random() < c.p_cbf
         if self.tree == "chroma":
             yy = False                                                         # (no luma in the chroma tree)
@@ -1391,7 +1417,7 @@ class PictureWriter:
         elif (sbt or (not intra and depth0)) and not (cb or cr):
             yy = True                                                          # (inferred: the CU has a residual and chroma has none)
         else:
-            cab.bin(1 if yy else 0, "QtCbf", 0, sub=0)                         # tu_y_coded_flag
+            cab.bin(1 if yy else 0, "QtCbf", 1 if self.cu.get("bdpcm") else 0, sub=0)      # tu_y_coded_flag
         if c.dqp and not self.dqp_coded and self.tree != "chroma" and (self.cu["w"] > 64 or self.cu["h"] > 64 or yy or cb or cr):
             # cu_qp_delta_abs / cu_qp_delta_sign_flag (CABACReader::cu_qp_delta :2293): once per quantisation group - here a CTU
             dq = rng.choice([0, 0, 1, -1, 2, -2, 3, -4, 5, -6, 7])
@@ -1429,8 +1455,33 @@ class PictureWriter:
     # -- residual_coding: coefficients of the first 4x4 coefficient group only, levels 1..3, at most three of them (well inside the budget of
     # context-coded bins, CoeffCodingContext::m_regBinLimit)
     def residual(self, w, h, ch):
+        c, cu = self.c, self.cu
+        if c.ts:
+            # transform_skip_flag (CABACReader::ts_flag :2493): inferred for BDPCM blocks; then the transform-skip residual coding unless the slice switches it off
+            bd = cu.get("bdpcm_c") if ch else cu.get("bdpcm")
+            ts = bool(bd)
+            if not bd and not (cu.get("isp") and ch == 0) and w <= 32 and h <= 32 and not cu.get("sbt"):
+                ts = self.rng.random() < 0.3
+                self.cab.bin(1 if ts else 0, "MTSIndex", 4 if ch == 0 else 5)
+            if ts:
+                cu["ts_any"] = True
+                if ch == 0 and not cu.get("luma_tus"):
+                    cu["ts_first"] = True
+                if ch == 0:
+                    cu["luma_tus"] = cu.get("luma_tus", 0) + 1
+                if not c.ts_regular:
+                    return self.residual_ts(w, h, ch, bool(bd))
+                saved = {k: cu.get(k) for k in ("viol", "lfnst_last", "mts_last", "mts_viol")}      # (regular residual coding of a transform-skip block: nothing of it counts for lfnst_idx / mts_idx)
+                r = self.residual_full(w, h, ch) if c.big_resi else self.residual_small(w, h, ch)
+                cu.update(saved)
+                return r
+            if ch == 0:
+                cu["luma_tus"] = cu.get("luma_tus", 0) + 1
         if self.c.big_resi:
             return self.residual_full(w, h, ch)
+        return self.residual_small(w, h, ch)
+
+    def residual_small(self, w, h, ch):
         cab, rng = self.cab, self.rng
         self.stats["cbf"] += 1
         last = rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 7, 9, 12, 15])
@@ -1495,6 +1546,92 @@ class PictureWriter:
         for s in signs:
             cab.ep(s)                                                          # coeff_sign_flag, in coding order
 
+
+    # -- residual_ts_coding (CABACReader::residual_codingTS :2863, residual_coding_subblockTS :2890): coefficient groups first to last, three passes per group; the
+    # contexts look at the left and upper neighbour's value as the decoder holds it at that moment, so this writer RUNS the decoder's procedure with bins of its choice
+    def residual_ts(self, w, h, ch, bdpcm):
+        cab, rng = self.cab, self.rng
+        self.stats["cbf"] += 1
+        wg, hg = w >> 2, h >> 2
+        cgs = []
+        for d in range(wg + hg - 1):
+            for y in range(min(d, hg - 1), -1, -1):
+                if d - y < wg:
+                    cgs.append((d - y, y))
+        coeff, flagged = {}, set()
+        bins = (w * h * 7) >> 2
+        dense = rng.random() < 0.3
+        for g, (cx, cy) in enumerate(cgs):
+            if g == len(cgs) - 1 and not flagged:
+                sig = True
+            else:
+                sig = rng.random() < (0.7 if (dense or g == 0) else 0.25)
+                cab.bin(1 if sig else 0, "TsSigCoeffGroup", (1 if (cx - 1, cy) in flagged else 0) + (1 if (cx, cy - 1) in flagged else 0))
+            if not sig:
+                continue
+            flagged.add((cx, cy))
+            pos = [(cx * 4 + SCAN4[i][0], cy * 4 + SCAN4[i][1]) for i in range(16)]
+            nz, last1, last2 = [], -1, -1
+            i = 0
+            while i < 16 and bins >= 4:                                        # pass 1: sig, sign, gt1, parity
+                x, y = pos[i]
+                l, a = coeff.get((x - 1, y), 0), coeff.get((x, y - 1), 0)
+                if not nz and i == 15:
+                    s1 = 1
+                else:
+                    s1 = 1 if rng.random() < (0.6 if dense else 0.3) else 0
+                    cab.bin(s1, "TsSigFlag", (1 if l else 0) + (1 if a else 0))
+                    bins -= 1
+                if s1:
+                    sc = 0 if ((l == 0 and a == 0) or l * a < 0) else (1 if (l >= 0 and a >= 0) else 2)
+                    sign = rng.randrange(0, 2)
+                    cab.bin(sign, "TsResidualSign", sc + (3 if bdpcm else 0))
+                    gt1 = rng.randrange(0, 2)
+                    cab.bin(gt1, "TsLrg1Flag", 3 if bdpcm else (1 if l else 0) + (1 if a else 0))
+                    bins -= 2
+                    par = 0
+                    if gt1:
+                        par = rng.randrange(0, 2)
+                        cab.bin(par, "TsParFlag", 0)
+                        bins -= 1
+                    coeff[(x, y)] = (-1 if sign else 1) * (1 + par + gt1)
+                    nz.append(((x, y), sign))
+                last1 = i
+                i += 1
+            j = 0
+            while j < 16 and bins >= 4:                                        # pass 2: up to four greater-than flags
+                x, y = pos[j]
+                t = abs(coeff.get((x, y), 0))
+                cutoff = 2
+                for _ in range(4):
+                    if t >= cutoff:
+                        g2 = 1 if rng.random() < 0.4 else 0
+                        cab.bin(g2, "TsGtxFlag", cutoff >> 1)
+                        bins -= 1
+                        t += g2 << 1
+                    cutoff += 2
+                coeff[(x, y)] = t
+                last2 = j
+                j += 1
+            for k in range(16):                                                # pass 3: remainders, and whole values for what the budget did not reach
+                x, y = pos[k]
+                t = abs(coeff.get((x, y), 0))
+                cutoff = 10 if k <= last2 else (2 if k <= last1 else 0)
+                if t >= cutoff:
+                    rem = rng.choice([0, 0, 0, 1, 1, 2, 3, 5, 9])
+                    self.rem_abs_ep(rem, 1, 5)
+                    t += (rem << 1) if k <= last1 else rem
+                    if t and k > last1:
+                        sign = rng.randrange(0, 2)
+                        cab.ep(sign)
+                        nz.append(((x, y), sign))
+                if not bdpcm and cutoff and t > 0:
+                    pred = max(abs(coeff.get((x - 1, y), 0)), abs(coeff.get((x, y - 1), 0)))
+                    t = pred if (t == 1 and pred > 0) else t - (1 if t <= pred else 0)
+                coeff[(x, y)] = t
+            for (xy, sign) in nz:
+                coeff[xy] = -coeff[xy] if sign else coeff[xy]
+            self.stats["coefs"] += len(nz)
 
     # -- residual_coding in full (CABACReader::residual_coding :2361-2460, residual_coding_subblock :2704-2861, CoeffCodingContext): any last position inside the
     # 32x32 zero-out region, coded_sub_block_flag per 4x4 coefficient group, the context-coded pass with its bin budget, Golomb-Rice remainders with the
@@ -1861,6 +1998,16 @@ FIXTURES = [
     ("mini_scaling_lists_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, sbtmvp=True, affine=True, scaling=True, lfnst=True,
                                                      mts=True, isp=True, mip=True, jccr=True, dep_quant=True, big_resi=True, sbt=True, p_intra=0.25), 9, 102),
     ("mini_scaling_lists_dual_tree_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=27, mtt_depth=2, dual_tree=True, scaling=True, lfnst=True, big_resi=True), 2, 103),
+    # transform skip and BDPCM (luma and chroma): the transform-skip residual coding with its neighbour-dependent contexts and level mapping; the regular residual coding
+    # for transform-skip blocks (sh_ts_residual_coding_disabled_flag); with dependent quantisation; in a dual tree with scaling lists
+    ("mini_ts_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, ts=True, big_resi=True, p_cbf=0.8, p_cbf_chroma=0.6), 2, 111),
+    ("mini_ts_bdpcm_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, ts=True, bdpcm=True, big_resi=True, p_cbf=0.8, p_cbf_chroma=0.6), 2, 112),
+    ("mini_ts_regular_resi_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, ts=True, bdpcm=True, ts_regular=True, big_resi=True, p_cbf=0.8, p_cbf_chroma=0.6), 2, 113),
+    ("mini_ts_bdpcm_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, sbtmvp=True, affine=True, ts=True, bdpcm=True, lfnst=True,
+                                                mts=True, isp=True, mip=True, mrl=True, jccr=True, big_resi=True, sbt=True, sao=True, lmcs=True, dqp=True, p_intra=0.3), 9, 114),
+    ("mini_ts_bdpcm_dual_tree_scaling_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=28, mtt_depth=2, dual_tree=True, ts=True, bdpcm=True, lfnst=True,
+                                                            big_resi=True, scaling=True), 2, 115),
+    ("mini_ts_bdpcm_dep_quant_8bit_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, bit_depth=8, ts=True, bdpcm=True, dep_quant=True, big_resi=True), 2, 116),
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),

@@ -421,6 +421,12 @@ struct Gen {
       if( !treeC && ( y & ( ctu - 1 ) ) != 0 && cu.intra_dir[0] != 0 && rng.p( P.p_mrl ) ) cu.multi_ref_idx = (uint8_t) ( 1 + rng.u( 2 ) );
       // BDPCM (implies transform skip of the luma block)
       if( !treeC && w <= 32 && h <= 32 && !cu.multi_ref_idx && rng.p( P.p_bdpcm ) ) { cu.bdpcm[0] = (uint8_t) ( 1 + rng.u( 2 ) ); cu.intra_dir[0] = cu.bdpcm[0] == 1 ? 18 : 50; cu.lfnst_intra_mode = cu.intra_dir[0]; }
+      // chroma BDPCM (intra_bdpcm_chroma_flag: chroma blocks of at most 32x32; implies transform skip of both chroma blocks, horizontal or vertical prediction; no LFNST
+      // on a CU that has a transform-skip block)
+      if( P.chroma_format && !treeL && ( w >> 1 ) <= 32 && ( h >> 1 ) <= 32 && ( w >> 1 ) >= 4 && ( h >> 1 ) >= 4 && rng.p( P.p_bdpcm ) )
+      {
+        cu.bdpcm[1] = (uint8_t) ( 1 + rng.u( 2 ) ); cu.intra_dir[1] = cu.bdpcm[1] == 1 ? 18 : 50; cu.lfnst_idx = 0;
+      }
       // MIP: luma mode index into the matrix set of the block size class (16 / 8 / 6 modes), optional transposition; the chroma
       // derived mode of a MIP CU is planar; no MRL / BDPCM; LFNST only for blocks of at least 16x16 (allowLfnstWithMip)
       if( !treeC && !cu.bdpcm[0] && !cu.multi_ref_idx && w <= 64 && h <= 64 && rng.p( P.p_mip ) )
@@ -428,7 +434,7 @@ struct Gen {
         const int sizeId = ( w == 4 && h == 4 ) ? 0 : ( w == 4 || h == 4 || ( w == 8 && h == 8 ) ) ? 1 : 2;
         cu.flags |= VVR_CU_MIP | ( rng.p( 0.5 ) ? VVR_CU_MIP_TRANSP : 0 );
         cu.intra_dir[0] = (uint8_t) rng.u( sizeId == 0 ? 16 : sizeId == 1 ? 8 : 6 );
-        if( cu.intra_dir[1] < 67 ) cu.intra_dir[1] = 0;
+        if( cu.intra_dir[1] < 67 && !cu.bdpcm[1] ) cu.intra_dir[1] = 0;
         cu.lfnst_intra_mode = 0;
       }
       // intra sub-partitions: horizontal (1) or vertical (2) split of the luma block in four (CU::canUseISP: more than 16 samples,
@@ -437,7 +443,7 @@ struct Gen {
       const int ispParts = ( ( w == 4 && h == 8 ) || ( w == 8 && h == 4 ) ) ? 2 : 4;      // 4x8 / 8x4 CUs are split in two
       const bool ispNoLfnst = cu.isp_mode && ( cu.isp_mode == 1 ? h / ispParts < 4 : w / ispParts < 4 );
       // LFNST index (luma of single-tree CUs): needs DCT2 and a residual confined to the first 8/16 scan positions, see genLevels
-      if( !treeC && ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && ( !( cu.flags & VVR_CU_MIP ) || ( w >= 16 && h >= 16 ) ) && !ispNoLfnst && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
+      if( !treeC && ( P.tool_flags & VVR_TOOL_LFNST ) && !cu.bdpcm[0] && !cu.bdpcm[1] && ( !( cu.flags & VVR_CU_MIP ) || ( w >= 16 && h >= 16 ) ) && !ispNoLfnst && rng.p( P.p_lfnst ) ) cu.lfnst_idx = (uint8_t) ( 1 + rng.u( 2 ) );
     }
     else
     {
@@ -599,6 +605,7 @@ struct Gen {
         if( c == 0 && cu.isp_mode ) ispAnyLuma = true;
         bool ts = bw <= 32 && bh <= 32 && !sbtIdx && !( c == 0 && cu.isp_mode ) && rng.p( P.p_ts );
         if( c == 0 && intra && cu.bdpcm[0] ) ts = true;
+        if( c > 0 && intra && cu.bdpcm[1] ) ts = true;
         if( ( c == 0 || treeC ) && intra && cu.lfnst_idx ) ts = false;
         tu.mts_idx[c] = ts ? VVR_MTS_SKIP : VVR_MTS_DCT2;
         const bool implicitMts = intra && ( P.tool_flags & VVR_TOOL_IMPLICIT_MTS );
@@ -620,7 +627,7 @@ struct Gen {
           else                             { if( bw > 32 ) hor = ver = 0; else { hor = 2; ver = sbtPos == 0 ? 1 : 2; } }
         }
         tu.tr_type[c] = (uint8_t) ( ( ver << 2 ) | hor );
-        genLevels( tu, c, bw, bh, ts, c == 0 && intra && cu.bdpcm[0], ( c == 0 || treeC ) && intra && cu.lfnst_idx );
+        genLevels( tu, c, bw, bh, ts, intra && ( c == 0 ? cu.bdpcm[0] : cu.bdpcm[1] ), ( c == 0 || treeC ) && intra && cu.lfnst_idx );
         rootCbf = true;
       }
       tu_done:
@@ -827,7 +834,7 @@ struct Gen {
         {
           const vvr_tu& TQ = B.tu[tuOf4C[iq]]; const vvr_tu& TP = B.tu[tuOf4C[ip]];
           const int sizeQ = ( d == 0 ? TQ.w : TQ.h ) >> 1, sizeP = ( d == 0 ? TP.w : TP.h ) >> 1;
-          L.flags |= 2 | ( ( sizeP >= 8 && sizeQ >= 8 ) ? 0x20 : 0 ); bsC = 2;
+          L.flags |= 2 | ( ( sizeP >= 8 && sizeQ >= 8 ) ? 0x20 : 0 ); bsC = ( B.cu[TQ.cu].bdpcm[1] && B.cu[TP.cu].bdpcm[1] ) ? 0 : 2;      // no chroma filtering between two chroma BDPCM blocks (LoopFilter.cpp:1132)
           L.qp[1] = (int8_t) ( ( TQ.qp[1] + TP.qp[1] - 2 * qpBd + 1 ) >> 1 );
           L.qp[2] = (int8_t) ( ( TQ.qp[2] + TP.qp[2] - 2 * qpBd + 1 ) >> 1 );
         }
@@ -904,7 +911,7 @@ struct Gen {
         if( chromaEdge )
         {
           const bool jointChr = TQc.joint_cbcr || TPc.joint_cbcr;     // (LoopFilter.cpp:1180-1184)
-          if( intraC ) bsCb = bsCr = 2;
+          if( intraC ) bsCb = bsCr = ( CQc.pred_mode == VVR_PRED_INTRA && CQc.bdpcm[1] && CPc.pred_mode == VVR_PRED_INTRA && CPc.bdpcm[1] ) ? 0 : 2;      // (LoopFilter.cpp:1132)
           else { if( ( TQc.cbf & 2 ) || ( TPc.cbf & 2 ) || jointChr ) bsCb = 1; if( ( TQc.cbf & 4 ) || ( TPc.cbf & 4 ) || jointChr ) bsCr = 1; }
         }
         if( intra ) bsY = ( CQ.bdpcm[0] && CP.bdpcm[0] ) ? 0 : 2;      // no luma filtering between two BDPCM blocks (LoopFilter.cpp:1146)

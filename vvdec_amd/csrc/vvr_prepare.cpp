@@ -482,7 +482,11 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
         for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ ) if( p->tu[t].comp_mask != want ) FAIL( VVR_ERR_PARAMETER, "separate-tree CU: TU component mask" );
         if( cu.tree == VVR_TREE_CHROMA && ( cu.isp_mode || cu.multi_ref_idx || cu.bdpcm[0] || ( cu.flags & VVR_CU_MIP ) ) ) FAIL( VVR_ERR_PARAMETER, "chroma-tree CU with luma tools" );
       }
-      if( cu.intra_dir[0] > 66 || cu.multi_ref_idx > 2 || cu.bdpcm[1] ) FAIL( VVR_ERR_UNSUPPORTED, "bad intra mode / chroma BDPCM not implemented" );
+      if( cu.intra_dir[0] > 66 || cu.multi_ref_idx > 2 ) FAIL( VVR_ERR_UNSUPPORTED, "bad intra mode" );
+      if( cu.bdpcm[0] > 2 || cu.bdpcm[1] > 2 ) FAIL( VVR_ERR_PARAMETER, "bad BDPCM direction" );
+      // (chroma BDPCM, round 4: the chroma blocks of the CU are predicted horizontally / vertically from the unfiltered neighbours and their transform-skip
+      // levels accumulate along that direction - the same code paths as luma BDPCM, selected by bdpcm[1])
+      if( cu.bdpcm[1] && ( ( cu.w >> 1 ) > 32 || ( cu.h >> 1 ) > 32 || cu.intra_dir[1] != ( cu.bdpcm[1] == 1 ? 18 : 50 ) ) ) FAIL( VVR_ERR_PARAMETER, "chroma BDPCM: block size / mode" );
     }
     else if( cu.pred_mode == VVR_PRED_IBC )
     {
