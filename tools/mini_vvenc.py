@@ -253,7 +253,7 @@ class Cfg:
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
                  mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False,
-                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
+                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, part=None, lf_across=True, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -264,6 +264,50 @@ class Cfg:
             self.amvr = self.bcw = self.smvd = self.sbt = self.wrap = self.wp = False
         self.max_aff_merge = 5 if self.affine else (1 if (self.sbtmvp and self.tmvp) else 0)
         self.wrap_minus = 0 if width % 64 else 2       # wrap-around period: the picture's width, or two minimum coding blocks less
+        self.partition = partition_of(self)
+
+
+def partition_of(c):
+    """part = None: one slice, one tile.  ("rows", [explicit slice heights in CTU rows]): one tile, rectangular slices that are bands of CTU rows (the rest of the tile in
+    slices of the last explicit height, pps_exp_slice_height_in_ctus_minus1).  ("tiles", explicit column width, explicit row height): a grid of tiles (the rest of the
+    picture in tiles of that size), one rectangular slice per tile.  -> dict(slices=[[(rx, ry) in coding order]], ctu=(slice, tile) per CTU) or None"""
+    if not c.part:
+        return None
+    S = 1 << c.log2_ctu
+    W, H = c.width // S, c.height // S
+    slices, ctu = [], {}
+    if c.part[0] == "rows":
+        hs, rem = list(c.part[1]), H - sum(c.part[1])
+        assert rem >= 0 and hs
+        while rem >= hs[-1]:
+            hs.append(hs[-1]); rem -= hs[-1]
+        if rem > 0:
+            hs.append(rem)
+        y = 0
+        for k, hh in enumerate(hs):
+            cur = [(rx, ry) for ry in range(y, y + hh) for rx in range(W)]
+            for xy in cur:
+                ctu[xy] = (k, 0)
+            slices.append(cur)
+            y += hh
+    else:
+        cw, rh = c.part[1], c.part[2]
+        cols, rows = [], []
+        x = 0
+        while x < W:
+            cols.append((x, min(cw, W - x))); x += cw
+        y = 0
+        while y < H:
+            rows.append((y, min(rh, H - y))); y += rh
+        k = 0
+        for (y0, hh) in rows:
+            for (x0, ww) in cols:
+                cur = [(rx, ry) for ry in range(y0, y0 + hh) for rx in range(x0, x0 + ww)]
+                for xy in cur:
+                    ctu[xy] = (k, k)
+                slices.append(cur)
+                k += 1
+    return dict(slices=slices, ctu=ctu, W=W, H=H)
 
 
 def write_sps(c):
@@ -430,8 +474,44 @@ def write_pps(c):
     b.flag(0)                                        # pps_conformance_window_flag
     b.flag(0)                                        # pps_scaling_window_explicit_signalling_flag
     b.flag(0)                                        # pps_output_flag_present_flag
-    b.flag(1)                                        # pps_no_pic_partition_flag
+    P = c.partition
+    b.flag(0 if P else 1)                            # pps_no_pic_partition_flag
     b.flag(0)                                        # pps_subpic_id_mapping_present_flag
+    if P:
+        n = len(P["slices"])
+        b.u(2, c.log2_ctu - 5)                       # pps_log2_ctu_size_minus5
+        b.ue(0)                                      # pps_num_exp_tile_columns_minus1
+        b.ue(0)                                      # pps_num_exp_tile_rows_minus1
+        if c.part[0] == "rows":
+            b.ue(P["W"] - 1)                         # pps_tile_column_width_minus1[0]: one tile
+            b.ue(P["H"] - 1)                         # pps_tile_row_height_minus1[0]
+            b.flag(0)                                # pps_single_slice_per_subpic_flag  (one tile: rectangular slices)
+            b.ue(n - 1)                              # pps_num_slices_in_pic_minus1
+            if n - 1 > 1:
+                b.flag(0)                            # pps_tile_idx_delta_present_flag
+            b.ue(len(c.part[1]))                     # pps_num_exp_slices_in_tile[0]  (slice 0: neither a width nor a height in tiles is read in a 1 x 1 grid)
+            for hh in c.part[1]:
+                b.ue(hh - 1)                         # pps_exp_slice_height_in_ctus_minus1
+        else:
+            ncol, nrow = -(-P["W"] // c.part[1]), -(-P["H"] // c.part[2])
+            b.ue(c.part[1] - 1)                      # pps_tile_column_width_minus1[0] (the other columns: the same width, the last one what is left)
+            b.ue(c.part[2] - 1)                      # pps_tile_row_height_minus1[0]
+            b.flag(c.lf_across)                      # pps_loop_filter_across_tiles_enabled_flag
+            b.flag(1)                                # pps_rect_slice_flag
+            b.flag(0)                                # pps_single_slice_per_subpic_flag
+            b.ue(n - 1)                              # pps_num_slices_in_pic_minus1
+            if n - 1 > 1:
+                b.flag(0)                            # pps_tile_idx_delta_present_flag
+            heights = [min(c.part[2], P["H"] - r * c.part[2]) for r in range(nrow)]
+            for i in range(n - 1):                   # (the last slice takes what is left)
+                tx, ty = i % ncol, i // ncol
+                if tx != ncol - 1:
+                    b.ue(0)                          # pps_slice_width_in_tiles_minus1
+                if ty != nrow - 1 and tx == 0:
+                    b.ue(0)                          # pps_slice_height_in_tiles_minus1
+                if heights[ty] > 1:
+                    b.ue(0)                          # pps_num_exp_slices_in_tile: the tile is one slice
+        b.flag(c.lf_across)                          # pps_loop_filter_across_slices_enabled_flag
     b.flag(0)                                        # pps_cabac_init_present_flag
     b.ue(0)                                          # pps_num_ref_idx_default_active_minus1[0]
     b.ue(0)                                          # pps_num_ref_idx_default_active_minus1[1]
@@ -462,6 +542,11 @@ def write_pps(c):
             b.se(4 if c.db_offsets else 0)           # pps_cb_tc_offset_div2
             b.se(5 if c.db_offsets else 0)           # pps_cr_beta_offset_div2
             b.se(-1 if c.db_offsets else 0)          # pps_cr_tc_offset_div2
+    if P:
+        b.flag(0)                                    # pps_rpl_info_in_ph_flag: reference picture lists, SAO, ALF and the QP stay in the slice headers
+        b.flag(0)                                    # pps_sao_info_in_ph_flag
+        b.flag(0)                                    # pps_alf_info_in_ph_flag
+        b.flag(0)                                    # pps_qp_delta_info_in_ph_flag
     b.flag(0)                                        # pps_picture_header_extension_present_flag
     b.flag(0)                                        # pps_slice_header_extension_present_flag
     b.flag(0)                                        # pps_extension_flag
@@ -470,6 +555,7 @@ def write_pps(c):
 
 
 NAL_PREFIX_APS = 17
+NAL_PH = 19
 NAL_SUFFIX_SEI = 24
 
 
@@ -646,11 +732,28 @@ def write_rpl(b, cur_poc, ref_pocs, wp=False):
         prev = cur_poc - r
 
 
-def write_slice_header(c, b, pic):
-    """pic: dict(poc, type 'I' / 'P' / 'B', idr, l0, l1 (POCs))"""
+def write_slice_header(c, b, pic, sl=None):
+    """pic: dict(poc, type 'I' / 'P' / 'B', idr, l0, l1 (POCs)).  sl: None = the picture's only slice, the picture header inside its header; "ph" = the picture header
+    alone (a PH NAL unit in front of the slices of a picture that has several); dict(idx, n, type, qp, ...) = one of several slices"""
     idr, st = pic["idr"], pic["type"]
-    b.flag(1)                                        # sh_picture_header_in_slice_header_flag
-    # picture_header_structure()
+    multi = sl is not None
+    if not multi:
+        b.flag(1)                                    # sh_picture_header_in_slice_header_flag
+    if not multi or sl == "ph":
+        write_picture_header(c, b, pic)
+        if sl == "ph":
+            b.trailing()
+            return
+    else:
+        b.flag(0)                                    # sh_picture_header_in_slice_header_flag
+        if sl["n"] > 1:
+            b.u((sl["n"] - 1).bit_length(), sl["idx"])      # sh_slice_address: index of the rectangular slice
+        st = sl["type"]
+    write_slice_header_rest(c, b, pic, st, sl if multi else None)
+
+
+def write_picture_header(c, b, pic):
+    idr, st = pic["idr"], pic["type"]
     b.flag(1 if idr else 0)                          # ph_gdr_or_irap_pic_flag
     b.flag(0)                                        # ph_non_ref_pic_flag
     if idr:
@@ -681,13 +784,18 @@ def write_slice_header(c, b, pic):
     if c.jccr:
         b.flag(pic.get("jccr_sign", 0))              # ph_joint_cbcr_sign_flag
     # (no QP delta, SAO, deblocking info in the PH)
+
+
+def write_slice_header_rest(c, b, pic, st, sl):
+    idr = pic["idr"]
+    inter_allowed = not idr
     # slice header proper: one slice per picture
     if inter_allowed:
         b.ue({"B": 0, "P": 1, "I": 2}[st])           # sh_slice_type
     if idr:
         b.flag(0)                                    # sh_no_output_of_prior_pics_flag
     if c.alf:
-        a = pic["alf"]
+        a = sl["alf"] if sl else pic["alf"]
         b.flag(a["on"])                              # sh_alf_enabled_flag
         if a["on"]:
             b.u(3, len(a["luma_aps"]))               # sh_num_alf_aps_ids_luma
@@ -704,6 +812,11 @@ def write_slice_header(c, b, pic):
                 b.flag(a["cc_cr"] is not None)       # sh_alf_cc_cr_enabled_flag
                 if a["cc_cr"] is not None:
                     b.u(3, a["cc_cr"])
+    if sl:                                           # (with the picture header in a NAL unit of its own the slices say whether they use the picture's LMCS / scaling lists)
+        if c.lmcs:
+            b.flag(sl["lmcs"])                       # sh_lmcs_used_flag
+        if c.scaling and pic.get("scaling", 1):
+            b.flag(sl["scaling"])                    # sh_explicit_scaling_list_used_flag
     if not idr:
         write_rpl(b, pic["poc"], pic["l0"], c.wp)    # ref_pic_lists(): both lists, whatever the slice type
         write_rpl(b, pic["poc"], pic["l1"], c.wp)
@@ -740,18 +853,19 @@ def write_slice_header(c, b, pic):
                         for j in range(2):
                             b.se(e["chroma"][j][0])  # delta_chroma_weight_lX
                             b.se(e["chroma"][j][1])  # delta_chroma_offset_lX
-    b.se(c.qp - 26)                                  # sh_qp_delta
+    b.se((sl["qp"] if sl else c.qp) - 26)            # sh_qp_delta
     if c.chroma_qp:
         b.se(pic.get("cb_off", -2))                  # sh_cb_qp_offset
         b.se(pic.get("cr_off", 3))                   # sh_cr_qp_offset
         if c.jccr:
             b.se(-1)                                 # sh_joint_cbcr_qp_offset
     if c.sao:
-        b.flag(1)                                    # sh_sao_luma_used_flag
-        b.flag(1)                                    # sh_sao_chroma_used_flag
+        b.flag(sl["sao"][0] if sl else 1)            # sh_sao_luma_used_flag
+        b.flag(sl["sao"][1] if sl else 1)            # sh_sao_chroma_used_flag
+    dq = c.dep_quant and (sl["dq"] if sl else True)
     if c.dep_quant:
-        b.flag(1)                                    # sh_dep_quant_used_flag
-    if c.ts and not c.dep_quant:
+        b.flag(dq)                                   # sh_dep_quant_used_flag
+    if c.ts and not dq:
         b.flag(c.ts_regular)                         # sh_ts_residual_coding_disabled_flag
     b.trailing()                                     # byte_alignment()
 
@@ -778,16 +892,38 @@ class PictureWriter:
         self.maps = {"single": (self.cu_w, self.cu_h, self.cu_q), "luma": (self.cu_w, self.cu_h, self.cu_q),
                      "chroma": ([[0] * w4 for _ in range(h4)], [[0] * w4 for _ in range(h4)], [[0] * w4 for _ in range(h4)])}
         self.tree = "single"
+        self.sl = None                                 # the slice being written (pictures of several slices): dict(idx, type, qp, sao, alf, dq, lmcs)
+        self.P = c.partition
         self.stats = dict(cus=0, split=0, cbf=0, coefs=0, skip=0, merge=0, amvp=0, intra=0)
         self.dqp_coded, self.cu_ciip, self.cu = False, False, dict(w=0, h=0, sbt=None, isp=0)
 
-    def picture(self):
+    # is the 4x4 cell at luma position (nx, ny) a neighbour the block at (x, y) may look at?  (same slice and tile: CodingStructure::getCURestricted)
+    def dq_on(self):
+        return self.c.dep_quant and (self.sl is None or self.sl["dq"])
+
+    def avail(self, x, y, nx, ny):
+        if nx < 0 or ny < 0:
+            return False
+        if not self.P:
+            return True
+        l2 = self.c.log2_ctu
+        return self.P["ctu"][(x >> l2, y >> l2)] == self.P["ctu"][(nx >> l2, ny >> l2)]
+
+    def picture(self, ctus=None, cab=None, sl=None):
         S = 1 << self.c.log2_ctu
-        for y in range(0, self.c.height, S):
-            for x in range(0, self.c.width, S):
-                if self.c.sao:
+        if cab is not None:                                                    # one of several slices: its own arithmetic codeword, type and switches
+            self.cab, self.sl, self.st = cab, sl, sl["type"]
+            self.dual = bool(self.c.dual_tree) and self.st == "I"
+        if ctus is None:
+            ctus = [(rx, ry) for ry in range(self.c.height // S) for rx in range(self.c.width // S)]
+        for (rx, ry) in ctus:
+            x, y = rx * S, ry * S
+            if True:
+                sao_on = self.c.sao and (self.sl is None or any(self.sl["sao"]))
+                if sao_on:
                     self.sao(x, y)
-                if self.c.alf and self.pic["alf"]["on"]:
+                alf = self.sl.get("alf") if self.sl else self.pic.get("alf")
+                if self.c.alf and alf["on"]:
                     self.alf(x >> self.c.log2_ctu, y >> self.c.log2_ctu)
                 self.dqp_coded = False                                         # (quantisation group = CTU)
                 if self.dual:
@@ -798,10 +934,12 @@ class PictureWriter:
 
     # -- ALF controls of a CTU (CABACReader::readAlf :391-467): on / off per component, filter set, chroma alternative, CC-ALF filter
     def alf(self, rx, ry):
-        cab, rng, a = self.cab, self.rng, self.pic["alf"]
+        cab, rng, a = self.cab, self.rng, (self.sl["alf"] if self.sl else self.pic["alf"])
         if not hasattr(self, "alf_ctu"):
             self.alf_ctu = {}
-        left, above = self.alf_ctu.get((rx - 1, ry), [0] * 5), self.alf_ctu.get((rx, ry - 1), [0] * 5)
+        S = 1 << self.c.log2_ctu
+        left = self.alf_ctu.get((rx - 1, ry), [0] * 5) if self.avail(rx * S, ry * S, rx * S - 1, ry * S) else [0] * 5
+        above = self.alf_ctu.get((rx, ry - 1), [0] * 5) if self.avail(rx * S, ry * S, rx * S, ry * S - 1) else [0] * 5
         cur = [0] * 5
         for comp in range(3):
             if comp and not a["cb" if comp == 1 else "cr"]:
@@ -845,12 +983,12 @@ class PictureWriter:
     # -- sao( rx, ry ) (CABACReader::sao): merge left / above, else type, four offsets, band position or edge class per component
     def sao(self, x, y):
         cab, rng = self.cab, self.rng
-        if x > 0:
+        if self.avail(x, y, x - 1, y):
             m = rng.random() < 0.25
             cab.bin(1 if m else 0, "SaoMergeFlag", 0)                          # sao_merge_left_flag
             if m:
                 return
-        if y > 0:
+        if self.avail(x, y, x, y - 1):
             m = rng.random() < 0.25
             cab.bin(1 if m else 0, "SaoMergeFlag", 0)                          # sao_merge_up_flag
             if m:
@@ -858,6 +996,8 @@ class PictureWriter:
         mx = (1 << (min(self.c.bit_depth, 10) - 5)) - 1
         mode_cb = 0
         for comp in range(3):
+            if self.sl is not None and not self.sl["sao"][1 if comp else 0]:
+                continue                                                       # (the slice uses SAO for the other channel type only)
             if comp != 2:
                 mode = rng.choice([0, 1, 2])                                   # off, band offset, edge offset
                 cab.bin(1 if mode else 0, "SaoTypeIdx", 0)                     # sao_type_idx_luma / chroma
@@ -931,8 +1071,8 @@ class PictureWriter:
         mode = None
         m_w, m_h, m_q = self.maps[self.tree]
         if num_split:
-            left_h = m_h[y >> 2][(x >> 2) - 1] if x > 0 else 0
-            above_w = m_w[(y >> 2) - 1][x >> 2] if y > 0 else 0
+            left_h = m_h[y >> 2][(x >> 2) - 1] if self.avail(x, y, x - 1, y) else 0
+            above_w = m_w[(y >> 2) - 1][x >> 2] if self.avail(x, y, x, y - 1) else 0
             p = self.c.p_split if can_qt else self.c.p_mtt
             split = rng.random() < p
             ctx = (1 if (left_h and left_h < h) else 0) + (1 if (above_w and above_w < w) else 0) + (0, 0, 0, 3, 3, 6, 6)[num_split]
@@ -942,8 +1082,8 @@ class PictureWriter:
                 is_qt = can_qt
                 if can_qt and can_btt:
                     is_qt = rng.random() < 0.5
-                    lq = m_q[y >> 2][(x >> 2) - 1] if x > 0 else -1
-                    aq = m_q[(y >> 2) - 1][x >> 2] if y > 0 else -1
+                    lq = m_q[y >> 2][(x >> 2) - 1] if self.avail(x, y, x - 1, y) else -1
+                    aq = m_q[(y >> 2) - 1][x >> 2] if self.avail(x, y, x, y - 1) else -1
                     cab.bin(1 if is_qt else 0, "SplitQtFlag", (1 if lq > qt_depth else 0) + (1 if aq > qt_depth else 0) + (0 if qt_depth < 2 else 3))      # split_qt_flag
                 if is_qt:
                     mode = "qt"
@@ -1033,8 +1173,8 @@ class PictureWriter:
                 cab.bin(1 if m > k else 0, "MTSIndex", k)
 
     def neigh(self, x, y):
-        left = self.cu_f[y >> 2][(x >> 2) - 1] if x > 0 else 0
-        above = self.cu_f[(y >> 2) - 1][x >> 2] if y > 0 else 0
+        left = self.cu_f[y >> 2][(x >> 2) - 1] if self.avail(x, y, x - 1, y) else 0
+        above = self.cu_f[(y >> 2) - 1][x >> 2] if self.avail(x, y, x, y - 1) else 0
         return left, above
 
     # -- coding_unit of a P / B slice (CABACReader::coding_unit, prediction_unit, merge_data)
@@ -1512,7 +1652,7 @@ class PictureWriter:
         first = True
         tmpl_diag, tmpl_sum1 = -1, -1
         signs = []
-        state, trans = 0, (32040 if self.c.dep_quant else 0)                   # dependent quantisation: the quantiser state picks the context set of sig_coeff_flag
+        state, trans = 0, (32040 if self.dq_on() else 0)                   # dependent quantisation: the quantiser state picks the context set of sig_coeff_flag
         for sp in range(last, -1, -1):
             x, y = SCAN4[sp]
             lv = levels.get(sp, 0)
@@ -1705,7 +1845,7 @@ class PictureWriter:
         # -- the groups from the last one down
         tpl, coeff = {}, {}                                                    # per position: (sum of first-pass values, number) of its template; current absolute values
         tmpl_diag, tmpl_sum1 = -1, -1
-        state, trans = 0, (32040 if self.c.dep_quant else 0)
+        state, trans = 0, (32040 if self.dq_on() else 0)
         area = (16 if (zo and w == 32) else wz) * (16 if (zo and h == 32) else hz)
         rem_bins = (area * 28) >> 4
         flagged = set()
@@ -1875,22 +2015,47 @@ def write_stream(c, num_pictures, seed, tables, renorm, hashes=None):
                     return dict(luma=(rng.randrange(-20, 21), rng.randrange(-10, 11)) if rng.random() < 0.6 else None,
                                 chroma=[(rng.randrange(-20, 21), rng.randrange(-20, 21)) for _ in range(2)] if rng.random() < 0.5 else None)
                 pic["wp"] = dict(denom=rng.randrange(2, 7), dchroma=rng.randrange(-1, 2), l0=[entry() for _ in l0], l1=[entry() for _ in l1])
-        if c.alf:
+        def alf_choice():
             # the slice's ALF choice: which APSs the luma filter sets come from, the APS of the chroma filters (its alternatives), the APSs of the CC-ALF filters
             ids = list(range(c.alf_aps))
             rng.shuffle(ids)
             ch = rng.randrange(0, c.alf_aps)
             cc = [rng.randrange(0, c.alf_aps) if (c.ccalf and rng.random() < 0.8) else None for _ in range(2)]
-            pic["alf"] = dict(on=rng.random() < 0.9, luma_aps=ids[:rng.randrange(0, c.alf_aps + 1)], cb=rng.random() < 0.8, cr=rng.random() < 0.8, chroma_aps=ch,
-                              nalt=alf_aps[ch][0], cc_cb=cc[0], cc_cr=cc[1], ncc=[alf_aps[cc[0]][1][0] if cc[0] is not None else 0, alf_aps[cc[1]][1][1] if cc[1] is not None else 0])
-        b = Bits()
-        write_slice_header(c, b, pic)
-        cab = Cabac(tables, renorm, {"B": 0, "P": 1, "I": 2}[pic["type"]], c.qp)
-        pw = PictureWriter(c, cab, rng, pic)
-        pw.picture()
-        b.b += cab.finish()
-        b.trailing()
-        out += nal(NAL_IDR_N_LP if pic["idr"] else NAL_TRAIL, b.bytes(), long_start=True)
+            return dict(on=rng.random() < 0.9, luma_aps=ids[:rng.randrange(0, c.alf_aps + 1)], cb=rng.random() < 0.8, cr=rng.random() < 0.8, chroma_aps=ch,
+                        nalt=alf_aps[ch][0], cc_cb=cc[0], cc_cr=cc[1], ncc=[alf_aps[cc[0]][1][0] if cc[0] is not None else 0, alf_aps[cc[1]][1][1] if cc[1] is not None else 0])
+        if c.alf:
+            pic["alf"] = alf_choice()
+        if c.partition:
+            # a picture header NAL unit, then the slices: each with a type, a QP, SAO / ALF / dependent quantisation / LMCS switches of its own
+            b = Bits()
+            write_slice_header(c, b, pic, "ph")
+            out += nal(NAL_PH, b.bytes(), long_start=True)
+            pw = PictureWriter(c, None, rng, pic)
+            nsl = len(c.partition["slices"])
+            for k, ctus in enumerate(c.partition["slices"]):
+                st = pic["type"]
+                if st != "I" and rng.random() < 0.3:
+                    st = rng.choice(["I", "P"])
+                sl = dict(idx=k, n=nsl, type=st, qp=max(12, min(45, c.qp + rng.randrange(-6, 7))), sao=(rng.random() < 0.8, rng.random() < 0.8), dq=rng.random() < 0.7,
+                          lmcs=1 if rng.random() < 0.75 else 0, scaling=1 if rng.random() < 0.75 else 0)
+                if c.alf:
+                    sl["alf"] = alf_choice()
+                b = Bits()
+                write_slice_header(c, b, pic, sl)
+                cab = Cabac(tables, renorm, {"B": 0, "P": 1, "I": 2}[st], sl["qp"])
+                pw.picture(ctus, cab, sl)
+                b.b += cab.finish()
+                b.trailing()
+                out += nal(NAL_IDR_N_LP if pic["idr"] else NAL_TRAIL, b.bytes(), long_start=(k == 0))
+        else:
+            b = Bits()
+            write_slice_header(c, b, pic)
+            cab = Cabac(tables, renorm, {"B": 0, "P": 1, "I": 2}[pic["type"]], c.qp)
+            pw = PictureWriter(c, cab, rng, pic)
+            pw.picture()
+            b.b += cab.finish()
+            b.trailing()
+            out += nal(NAL_IDR_N_LP if pic["idr"] else NAL_TRAIL, b.bytes(), long_start=True)
         if hashes is not None:
             out += nal(NAL_SUFFIX_SEI, write_hash_sei(hashes[pic_idx]))
         stats.append(pw.stats)
@@ -2008,6 +2173,15 @@ FIXTURES = [
     ("mini_ts_bdpcm_dual_tree_scaling_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=28, mtt_depth=2, dual_tree=True, ts=True, bdpcm=True, lfnst=True,
                                                             big_resi=True, scaling=True), 2, 115),
     ("mini_ts_bdpcm_dep_quant_8bit_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, bit_depth=8, ts=True, bdpcm=True, dep_quant=True, big_resi=True), 2, 116),
+    # several slices per picture (a picture header NAL unit, then slices with a type, QP, SAO / ALF / LMCS / dependent-quantisation switches of their own: I and P slices
+    # inside B pictures): bands of CTU rows inside one tile; a grid of tiles with one slice each, with and without in-loop filtering across the boundaries
+    ("mini_slices_rows_ctu64_256x256", dict(width=256, height=256, log2_ctu=6, qp=30, part=("rows", [1, 2]), sao=True, big_resi=True), 2, 121),
+    ("mini_slices_tiles_ctu64_384x256", dict(width=384, height=256, log2_ctu=6, qp=30, part=("tiles", 3, 2), sao=True, alf=True, ccalf=True, big_resi=True), 2, 122),
+    ("mini_slices_rows_inter_ctu64_384x256", dict(width=384, height=256, log2_ctu=6, log2_min_qt=4, qp=30, mtt_depth=2, part=("rows", [1]), inter=True, sbtmvp=True, affine=True, mmvd=True,
+                                                  gpm=True, ciip=True, sao=True, alf=True, ccalf=True, lmcs=True, dep_quant=True, jccr=True, big_resi=True, dqp=True, p_intra=0.2), 9, 123),
+    ("mini_tiles_no_filter_across_ctu64_384x256", dict(width=384, height=256, log2_ctu=6, log2_min_qt=4, qp=31, mtt_depth=2, part=("tiles", 2, 2), lf_across=False, inter=True, sbtmvp=True,
+                                                       affine=True, sao=True, alf=True, ccalf=True, lmcs=True, scaling=True, dual_tree=True, big_resi=True, mip=True, isp=True, mrl=True,
+                                                       p_intra=0.25), 9, 124),
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
