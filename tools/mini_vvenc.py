@@ -253,7 +253,7 @@ class Cfg:
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
                  mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False,
-                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, part=None, lf_across=True, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
+                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, part=None, lf_across=True, rpr=None, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -265,6 +265,11 @@ class Cfg:
         self.max_aff_merge = 5 if self.affine else (1 if (self.sbtmvp and self.tmvp) else 0)
         self.wrap_minus = 0 if width % 64 else 2       # wrap-around period: the picture's width, or two minimum coding blocks less
         self.partition = partition_of(self)
+        # reference picture resampling: rpr = [(width, height, scaling window offsets or None), ...], one PPS each; a picture takes the sizes in turn every `rpr_every`
+        # pictures (the first size is the sequence's maximum)
+        self.sizes = [(width, height, None)] + list(rpr or [])
+        for (ww, hh, _) in self.sizes:
+            assert ww % (1 << log2_ctu) == 0 and hh % (1 << log2_ctu) == 0 and ww <= width and hh <= height
 
 
 def partition_of(c):
@@ -329,7 +334,9 @@ def write_sps(c):
     b.align_zero()                                   # ptl_reserved_zero_bit
     b.u(8, 0)                                        # ptl_num_sub_profiles
     b.flag(0)                                        # sps_gdr_enabled_flag
-    b.flag(0)                                        # sps_ref_pic_resampling_enabled_flag
+    b.flag(len(c.sizes) > 1)                         # sps_ref_pic_resampling_enabled_flag
+    if len(c.sizes) > 1:
+        b.flag(1)                                    # sps_res_change_in_clvs_allowed_flag
     b.ue(c.width)                                    # sps_pic_width_max_in_luma_samples
     b.ue(c.height)
     b.flag(0)                                        # sps_conformance_window_flag
@@ -464,15 +471,18 @@ def write_sps(c):
     return b.bytes()
 
 
-def write_pps(c):
+def write_pps(c, pps_id=0, win=None):
     b = Bits()
-    b.u(6, 0)                                        # pps_pic_parameter_set_id
+    b.u(6, pps_id)                                   # pps_pic_parameter_set_id
     b.u(4, 0)                                        # pps_seq_parameter_set_id
     b.flag(0)                                        # pps_mixed_nalu_types_in_pic_flag
     b.ue(c.width)
     b.ue(c.height)
     b.flag(0)                                        # pps_conformance_window_flag
-    b.flag(0)                                        # pps_scaling_window_explicit_signalling_flag
+    b.flag(win is not None)                          # pps_scaling_window_explicit_signalling_flag
+    if win is not None:
+        for v in win:
+            b.se(v)                                  # pps_scaling_win_left / right / top / bottom_offset (chroma samples)
     b.flag(0)                                        # pps_output_flag_present_flag
     P = c.partition
     b.flag(0 if P else 1)                            # pps_no_pic_partition_flag
@@ -762,7 +772,7 @@ def write_picture_header(c, b, pic):
     b.flag(inter_allowed)                            # ph_inter_slice_allowed_flag
     if inter_allowed:
         b.flag(1)                                    # ph_intra_slice_allowed_flag
-    b.ue(0)                                          # ph_pic_parameter_set_id
+    b.ue(pic.get("pps", 0))                          # ph_pic_parameter_set_id
     b.u(8, pic["poc"] & 255)                         # ph_pic_order_cnt_lsb
     if c.lmcs:
         b.flag(1)                                    # ph_lmcs_enabled_flag
@@ -779,7 +789,7 @@ def write_picture_header(c, b, pic):
         if c.dqp:
             b.ue(0)                                  # ph_cu_qp_delta_subdiv_inter_slice
         if c.tmvp:
-            b.flag(1)                                # ph_temporal_mvp_enabled_flag
+            b.flag(pic.get("tmvp", 1))               # ph_temporal_mvp_enabled_flag (off when no reference picture has this picture's size: the collocated picture may not be scaled)
         b.flag(0)                                    # ph_mvd_l1_zero_flag
     if c.jccr:
         b.flag(pic.get("jccr_sign", 0))              # ph_joint_cbcr_sign_flag
@@ -827,13 +837,13 @@ def write_slice_header_rest(c, b, pic, st, sl):
                 b.ue(n0 - 1)                         # sh_num_ref_idx_active_minus1[0]
             if st == "B" and n1 > 1:
                 b.ue(n1 - 1)
-        if st != "I" and c.tmvp:
+        if st != "I" and c.tmvp and pic.get("tmvp", 1):
             col_l0 = 1
             if st == "B":
                 col_l0 = pic.get("col_l0", 1)
                 b.flag(col_l0)                       # sh_collocated_from_l0_flag
             if (col_l0 and n0 > 1) or (not col_l0 and n1 > 1):
-                b.ue(0)                              # sh_collocated_ref_idx
+                b.ue(pic.get("col_idx", 0) if (st == "B" or pic.get("col_l0", 1)) else 0)      # sh_collocated_ref_idx
         if st != "I" and c.wp:
             # pred_weight_table() (parsePredWeightTable): a denominator, flags per entry, weights and offsets
             wt = pic["wp"]
@@ -1989,7 +1999,15 @@ def write_stream(c, num_pictures, seed, tables, renorm, hashes=None):
     rng = random.Random(seed)
     out = bytearray()
     out += nal(NAL_SPS, write_sps(c), long_start=True)
-    out += nal(NAL_PPS, write_pps(c), long_start=True)
+    import copy
+    cfgs = []
+    for k, (ww, hh, win) in enumerate(c.sizes):
+        ck = copy.copy(c)
+        ck.width, ck.height = ww, hh
+        ck.partition = partition_of(ck)
+        cfgs.append(ck)
+        out += nal(NAL_PPS, write_pps(ck, k, win), long_start=True)
+    size_of_poc = {}
     if c.lmcs:
         out += nal(NAL_PREFIX_APS, write_lmcs_aps(c, rng, 0), long_start=True)
     if c.scaling:
@@ -2002,7 +2020,27 @@ def write_stream(c, num_pictures, seed, tables, renorm, hashes=None):
             out += nal(NAL_PREFIX_APS, data, long_start=True)
             alf_aps.append((nalt, ncc))
     stats = []
+    c_seq = c
     for pic_idx, pic in enumerate(gop_plan(num_pictures, c.inter)):
+        # the picture's size (reference picture resampling: the sizes in turn); temporal MV prediction only from a picture of the same size and window
+        pic["pps"] = (pic_idx // 2) % len(c_seq.sizes) if len(c_seq.sizes) > 1 else 0
+        c = cfgs[pic["pps"]]
+        size_of_poc[pic["poc"]] = pic["pps"]
+        if len(c_seq.sizes) > 1 and pic["type"] != "I":
+            same0 = [i for i, r in enumerate(pic["l0"]) if size_of_poc[r] == pic["pps"]]
+            same1 = [i for i, r in enumerate(pic["l1"]) if size_of_poc[r] == pic["pps"]]
+            pic["tmvp"] = 1 if (same0 or (same1 and pic["type"] == "B")) else 0
+            if pic["tmvp"]:
+                want_l0 = pic.get("col_l0", 1)
+                if (want_l0 and same0) or not same1 or pic["type"] != "B":
+                    pic["col_l0"], pic["col_idx"] = 1, same0[0] if same0 else 0
+                    if not same0:
+                        pic["tmvp"] = 0
+                else:
+                    pic["col_l0"], pic["col_idx"] = 0, same1[0]
+            if c.sbtmvp and not c.affine:
+                c = copy.copy(c)
+                c.max_aff_merge = 1 if pic["tmvp"] else 0
         if c.scaling:
             pic["scaling"], pic["scaling_aps"] = (1 if rng.random() < 0.85 else 0), rng.randrange(0, 2)
         if pic["type"] != "I":
@@ -2059,6 +2097,7 @@ def write_stream(c, num_pictures, seed, tables, renorm, hashes=None):
         if hashes is not None:
             out += nal(NAL_SUFFIX_SEI, write_hash_sei(hashes[pic_idx]))
         stats.append(pw.stats)
+        c = c_seq
     return bytes(out), stats
 
 
@@ -2079,13 +2118,14 @@ def picture_hashes(c, num_pictures, yuv):
     """[per picture in decoding order: MD5 digests of Y, Cb, Cr] from the reference decoder's output file (pictures in output order = ascending POC; samples of more than 8 bits as two bytes,
     little endian - the byte order the hash of the standard is defined over)"""
     bps = 2 if c.bit_depth > 8 else 1
-    ysz, csz = c.width * c.height * bps, (c.width // 2) * (c.height // 2) * bps
     plan = gop_plan(num_pictures, c.inter)
+    dims = [c.sizes[(i // 2) % len(c.sizes) if len(c.sizes) > 1 else 0][:2] for i in range(len(plan))]
     # (an intra stream is a sequence of IDR pictures, all of POC 0, put out in decoding order; an inter stream is one coded video sequence put out by POC)
     order = sorted(range(len(plan)), key=lambda i: (plan[i]["poc"], i)) if c.inter else list(range(len(plan)))
     out, off = [None] * len(plan), 0
     for i in order:
         planes = []
+        ysz, csz = dims[i][0] * dims[i][1] * bps, (dims[i][0] // 2) * (dims[i][1] // 2) * bps
         for sz in (ysz, csz, csz):
             planes.append(hashlib.md5(yuv[off:off + sz]).digest())
             off += sz
@@ -2182,6 +2222,13 @@ FIXTURES = [
     ("mini_tiles_no_filter_across_ctu64_384x256", dict(width=384, height=256, log2_ctu=6, log2_min_qt=4, qp=31, mtt_depth=2, part=("tiles", 2, 2), lf_across=False, inter=True, sbtmvp=True,
                                                        affine=True, sao=True, alf=True, ccalf=True, lmcs=True, scaling=True, dual_tree=True, big_resi=True, mip=True, isp=True, mrl=True,
                                                        p_intra=0.25), 9, 124),
+    # reference picture resampling: several PPSs of different picture size (and scaling windows with offsets) in one coded video sequence, the size changing every
+    # two pictures - prediction from pictures 2x, 1.5x, 1.2x, 0.5x .. the size, per direction; temporal MV prediction only from a picture of the same size
+    ("mini_rpr_half_ctu64_384x256", dict(width=384, height=256, log2_ctu=6, log2_min_qt=4, qp=30, mtt_depth=1, inter=True, rpr=[(192, 128, None)], p_intra=0.1), 9, 131),
+    ("mini_rpr_four_sizes_ctu64_384x256", dict(width=384, height=256, log2_ctu=6, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, sbtmvp=True, affine=True, mmvd=True, gpm=True, ciip=True,
+                                               rpr=[(256, 192, (2, 2, 0, 4)), (320, 256, (-4, 0, 2, 2)), (192, 128, None)], sao=True, alf=True, lmcs=True, big_resi=True, p_intra=0.1), 13, 132),
+    ("mini_rpr_8bit_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=32, bit_depth=8, mtt_depth=1, inter=True, sbtmvp=True, affine=True, amvr=True, bcw=True,
+                                          rpr=[(128, 128, None)], dep_quant=True, p_intra=0.1), 9, 133),
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
@@ -2204,8 +2251,8 @@ def main():
         bit = os.path.join(d, name + ".bit")
         open(bit, "wb").write(data)
         md5, yuv, log = reference_md5(bit, keep=True)
-        frame_bytes = c.width * c.height * 3 // 2 * (2 if c.bit_depth > 8 else 1)
-        assert len(yuv) == n * frame_bytes, "the reference decoder put out %d bytes, %d pictures of %d expected\n%s" % (len(yuv), n, frame_bytes, log[-1500:])
+        total = sum(c.sizes[(i // 2) % len(c.sizes) if len(c.sizes) > 1 else 0][0] * c.sizes[(i // 2) % len(c.sizes) if len(c.sizes) > 1 else 0][1] * 3 // 2 * (2 if c.bit_depth > 8 else 1) for i in range(n))
+        assert len(yuv) == total, "the reference decoder put out %d bytes, %d pictures of %d bytes in all expected\n%s" % (len(yuv), n, total, log[-1500:])
         # second pass: the same stream with a decoded-picture-hash SEI behind every picture (the hashes are the reference decoder's), checked by the reference decoder itself
         data, stats = write_stream(c, n, seed, tables, renorm, hashes=picture_hashes(c, n, yuv))
         open(bit, "wb").write(data)
