@@ -253,12 +253,14 @@ class Cfg:
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
                  mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False,
-                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, part=None, lf_across=True, rpr=None, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
+                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, part=None, lf_across=True, rpr=None, mono=False, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
         self.log2_max_tb = 6 if (max_tb64 and log2_ctu > 5) else 5
         self.log2_max_btt = min(6, log2_ctu)           # largest block a binary / ternary split applies to (sps_log2_diff_max_bt / tt_min_qt)
+        if mono:                                       # 4:0:0: nothing that only exists with chroma
+            self.jccr = self.ccalf = self.cclm = self.chroma_qp = self.dual_tree = False
         if not inter:
             self.tmvp = self.sbtmvp = self.bdof = self.dmvr = self.mmvd = self.affine = self.ciip = self.gpm = False
             self.amvr = self.bcw = self.smvd = self.sbt = self.wrap = self.wp = False
@@ -320,7 +322,7 @@ def write_sps(c):
     b.u(4, 0)                                        # sps_seq_parameter_set_id
     b.u(4, 0)                                        # sps_video_parameter_set_id
     b.u(3, 0)                                        # sps_max_sublayers_minus1
-    b.u(2, 1)                                        # sps_chroma_format_idc: 4:2:0
+    b.u(2, 0 if c.mono else 1)                       # sps_chroma_format_idc: 4:0:0 / 4:2:0
     b.u(2, c.log2_ctu - 5)                           # sps_log2_ctu_size_minus5
     b.flag(1)                                        # sps_ptl_dpb_hrd_params_present_flag
     # profile_tier_level( 1, 0 )
@@ -358,7 +360,8 @@ def write_sps(c):
     if c.mtt_depth:
         b.ue(c.log2_max_btt - c.log2_min_qt)         # sps_log2_diff_max_bt_min_qt_intra_slice_luma
         b.ue(c.log2_max_btt - c.log2_min_qt)         # sps_log2_diff_max_tt_min_qt_intra_slice_luma
-    b.flag(c.dual_tree)                              # sps_qtbtt_dual_tree_intra_flag
+    if not c.mono:
+        b.flag(c.dual_tree)                          # sps_qtbtt_dual_tree_intra_flag
     if c.dual_tree:
         b.ue(c.log2_min_qt_c - c.log2_min_cb)        # sps_log2_diff_min_qt_min_cb_intra_slice_chroma
         b.ue(c.mtt_depth)                            # sps_max_mtt_hierarchy_depth_intra_slice_chroma
@@ -381,15 +384,16 @@ def write_sps(c):
         b.flag(1)                                    # sps_explicit_mts_intra_enabled_flag
         b.flag(1)                                    # sps_explicit_mts_inter_enabled_flag
     b.flag(c.lfnst)                                  # sps_lfnst_enabled_flag
-    b.flag(c.jccr)                                   # sps_joint_cbcr_enabled_flag
-    b.flag(1)                                        # sps_same_qp_table_for_chroma_flag
-    b.se(0)                                          # sps_qp_table_start_minus26[0]
-    b.ue(0)                                          # sps_num_points_in_qp_table_minus1[0]
-    b.ue(0)                                          # sps_delta_qp_in_val_minus1[0][0]
-    b.ue(1)                                          # sps_delta_qp_diff_val[0][0]: the identity table
+    if not c.mono:
+        b.flag(c.jccr)                               # sps_joint_cbcr_enabled_flag
+        b.flag(1)                                    # sps_same_qp_table_for_chroma_flag
+        b.se(0)                                      # sps_qp_table_start_minus26[0]
+        b.ue(0)                                      # sps_num_points_in_qp_table_minus1[0]
+        b.ue(0)                                      # sps_delta_qp_in_val_minus1[0][0]
+        b.ue(1)                                      # sps_delta_qp_diff_val[0][0]: the identity table
     b.flag(c.sao)                                    # sps_sao_enabled_flag
     b.flag(c.alf)                                    # sps_alf_enabled_flag
-    if c.alf:
+    if c.alf and not c.mono:
         b.flag(c.ccalf)                              # sps_ccalf_enabled_flag
     b.flag(c.lmcs)                                   # sps_lmcs_enable_flag
     b.flag(c.wp)                                     # sps_weighted_pred_flag
@@ -432,9 +436,10 @@ def write_sps(c):
     b.flag(c.isp)                                    # sps_isp_enabled_flag
     b.flag(c.mrl)                                    # sps_mrl_enabled_flag
     b.flag(c.mip)                                    # sps_mip_enabled_flag
-    b.flag(c.cclm)                                   # sps_cclm_enabled_flag
-    b.flag(0)                                        # sps_chroma_horizontal_collocated_flag
-    b.flag(0)                                        # sps_chroma_vertical_collocated_flag
+    if not c.mono:
+        b.flag(c.cclm)                               # sps_cclm_enabled_flag
+        b.flag(0)                                    # sps_chroma_horizontal_collocated_flag
+        b.flag(0)                                    # sps_chroma_vertical_collocated_flag
     b.flag(0)                                        # sps_palette_enabled_flag
     if c.ts:
         b.ue(2 if c.bit_depth > 8 else 0)            # sps_internal_bit_depth_minus_input_bit_depth (the QP floor of transform-skip blocks)
@@ -574,7 +579,7 @@ def write_lmcs_aps(c, rng, aps_id):
     b = Bits()
     b.u(3, 1)                                        # aps_params_type: LMCS_APS
     b.u(5, aps_id)                                   # aps_adaptation_parameter_set_id
-    b.flag(1)                                        # aps_chroma_present_flag
+    b.flag(not c.mono)                               # aps_chroma_present_flag
     b.ue(1)                                          # lmcs_min_bin_idx
     b.ue(1)                                          # lmcs_delta_max_bin_idx: LmcsMaxBinIdx = 14
     org = (1 << c.bit_depth) // 16
@@ -586,9 +591,10 @@ def write_lmcs_aps(c, rng, aps_id):
         if d:
             b.flag(d < 0)                            # lmcs_delta_sign_cw_flag[i]
     crs = rng.randrange(-3, 4)
-    b.u(3, abs(crs))                                 # lmcs_delta_abs_crs
-    if crs:
-        b.flag(crs < 0)                              # lmcs_delta_sign_crs_flag
+    if not c.mono:
+        b.u(3, abs(crs))                             # lmcs_delta_abs_crs
+        if crs:
+            b.flag(crs < 0)                          # lmcs_delta_sign_crs_flag
     b.flag(0)                                        # aps_extension_flag
     b.trailing()
     return b.bytes()
@@ -614,9 +620,13 @@ def write_scaling_aps(c, rng, aps_id):
     b = Bits()
     b.u(3, 2)                                        # aps_params_type: SCALING_APS
     b.u(5, aps_id)                                   # aps_adaptation_parameter_set_id
-    b.flag(1)                                        # aps_chroma_present_flag
+    b.flag(not c.mono)                               # aps_chroma_present_flag
     rec, dc = {}, {}
     for sid in range(28):
+        if c.mono and not (sid % 3 == 2 or sid == 27):                         # (without chroma only the luma matrices: ScalingList::isLumaScalingList)
+            n0 = 2 if sid < 2 else (4 if sid < 8 else 8)
+            rec[sid], dc[sid] = [16] * (n0 * n0), 16
+            continue
         n = 2 if sid < 2 else (4 if sid < 8 else 8)
         first = sid in (0, 2, 8)
         max_delta = sid if sid < 2 else (sid - 2 if sid < 8 else sid - 8)
@@ -626,6 +636,8 @@ def write_scaling_aps(c, rng, aps_id):
             delta = rng.randrange(0, max_delta + 1)
             if sid > 25 and mode == "pred":
                 delta = 0                            # (the uncoded quadrant takes prediction + last sum: stays positive with a flat prediction)
+            if c.mono:
+                delta = 0                            # (4:0:0: the matrices in between are not sent; this decoder predicts from whatever they hold)
         b.flag(mode == "copy")                       # scaling_list_copy_mode_flag
         if mode != "copy":
             b.flag(mode == "pred")                   # scaling_list_pred_mode_flag
@@ -677,11 +689,12 @@ def write_alf_aps(c, rng, aps_id):
     b = Bits()
     b.u(3, 0)                                        # aps_params_type: ALF_APS
     b.u(5, aps_id)                                   # aps_adaptation_parameter_set_id
-    b.flag(1)                                        # aps_chroma_present_flag
+    b.flag(not c.mono)                               # aps_chroma_present_flag
     b.flag(1)                                        # alf_luma_filter_signal_flag
-    b.flag(1)                                        # alf_chroma_filter_signal_flag
-    b.flag(c.ccalf)                                  # alf_cc_cb_filter_signal_flag
-    b.flag(c.ccalf)                                  # alf_cc_cr_filter_signal_flag
+    if not c.mono:
+        b.flag(1)                                    # alf_chroma_filter_signal_flag
+        b.flag(c.ccalf)                              # alf_cc_cb_filter_signal_flag
+        b.flag(c.ccalf)                              # alf_cc_cr_filter_signal_flag
 
     def coeffs(n, m):
         for _ in range(n):
@@ -702,10 +715,11 @@ def write_alf_aps(c, rng, aps_id):
         for _ in range(nf * 12):
             b.u(2, rng.randrange(0, 4))              # alf_luma_clip_idx
     cclip = rng.random() < 0.7
-    b.flag(cclip)                                    # alf_chroma_clip_flag
     nalt = rng.randrange(1, 5)
-    b.ue(nalt - 1)                                   # alf_chroma_num_alt_filters_minus1
-    for _ in range(nalt):
+    if not c.mono:
+        b.flag(cclip)                                # alf_chroma_clip_flag
+        b.ue(nalt - 1)                               # alf_chroma_num_alt_filters_minus1
+    for _ in range(0 if c.mono else nalt):
         coeffs(6, 20)
         if cclip:
             for _ in range(6):
@@ -777,7 +791,8 @@ def write_picture_header(c, b, pic):
     if c.lmcs:
         b.flag(1)                                    # ph_lmcs_enabled_flag
         b.u(2, 0)                                    # ph_lmcs_aps_id
-        b.flag(pic.get("cscale", 1))                 # ph_chroma_residual_scale_flag
+        if not c.mono:
+            b.flag(pic.get("cscale", 1))             # ph_chroma_residual_scale_flag
     if c.scaling:
         b.flag(pic.get("scaling", 1))                # ph_explicit_scaling_list_enabled_flag
         if pic.get("scaling", 1):
@@ -811,9 +826,10 @@ def write_slice_header_rest(c, b, pic, st, sl):
             b.u(3, len(a["luma_aps"]))               # sh_num_alf_aps_ids_luma
             for i in a["luma_aps"]:
                 b.u(3, i)                            # sh_alf_aps_id_luma
-            b.flag(a["cb"])                          # sh_alf_cb_enabled_flag
-            b.flag(a["cr"])                          # sh_alf_cr_enabled_flag
-            if a["cb"] or a["cr"]:
+            if not c.mono:
+                b.flag(a["cb"])                      # sh_alf_cb_enabled_flag
+                b.flag(a["cr"])                      # sh_alf_cr_enabled_flag
+            if (a["cb"] or a["cr"]) and not c.mono:
                 b.u(3, a["chroma_aps"])              # sh_alf_aps_id_chroma
             if c.ccalf:
                 b.flag(a["cc_cb"] is not None)       # sh_alf_cc_cb_enabled_flag
@@ -871,7 +887,8 @@ def write_slice_header_rest(c, b, pic, st, sl):
             b.se(-1)                                 # sh_joint_cbcr_qp_offset
     if c.sao:
         b.flag(sl["sao"][0] if sl else 1)            # sh_sao_luma_used_flag
-        b.flag(sl["sao"][1] if sl else 1)            # sh_sao_chroma_used_flag
+        if not c.mono:
+            b.flag(sl["sao"][1] if sl else 1)        # sh_sao_chroma_used_flag
     dq = c.dep_quant and (sl["dq"] if sl else True)
     if c.dep_quant:
         b.flag(dq)                                   # sh_dep_quant_used_flag
@@ -951,7 +968,7 @@ class PictureWriter:
         left = self.alf_ctu.get((rx - 1, ry), [0] * 5) if self.avail(rx * S, ry * S, rx * S - 1, ry * S) else [0] * 5
         above = self.alf_ctu.get((rx, ry - 1), [0] * 5) if self.avail(rx * S, ry * S, rx * S, ry * S - 1) else [0] * 5
         cur = [0] * 5
-        for comp in range(3):
+        for comp in range(1 if self.c.mono else 3):
             if comp and not a["cb" if comp == 1 else "cr"]:
                 continue
             on = rng.random() < 0.7
@@ -1005,7 +1022,7 @@ class PictureWriter:
                 return
         mx = (1 << (min(self.c.bit_depth, 10) - 5)) - 1
         mode_cb = 0
-        for comp in range(3):
+        for comp in range(1 if self.c.mono else 3):
             if self.sl is not None and not self.sl["sao"][1 if comp else 0]:
                 continue                                                       # (the slice uses SAO for the other channel type only)
             if comp != 2:
@@ -1484,6 +1501,8 @@ class PictureWriter:
     def chroma_mode(self, w, h):
         cab, rng, c = self.cab, self.rng, self.c
         self.bdpcm_c = 0
+        if c.mono:
+            return
         if c.ts and c.bdpcm and (w >> 1) <= 32 and (h >> 1) <= 32:
             bd = rng.choice([0, 0, 0, 1, 2])
             cab.bin(1 if bd else 0, "BDPCMMode", 2)                            # intra_bdpcm_chroma_flag
@@ -1547,7 +1566,7 @@ class PictureWriter:
 
     def transform_unit(self, w, h, intra, depth0, isp=None, cw=None, ch=None, sbt=False):
         cab, rng, c = self.cab, self.rng, self.c
-        chroma = (isp is None or isp[1]) and self.tree != "luma"               # (ISP: the unsplit chroma blocks come with the last partition; dual tree: none in the luma tree)
+        chroma = (isp is None or isp[1]) and self.tree != "luma" and not c.mono               # (ISP: the unsplit chroma blocks come with the last partition; dual tree: none in the luma tree)
         cb = cr = False
         if chroma:
             cb = rng.random() < c.p_cbf_chroma
@@ -1985,7 +2004,7 @@ def write_hash_sei(md5s):
     b.u(8, 132)                                      # payload_type
     b.u(8, 2 + 16 * len(md5s))                       # payload_size
     b.u(8, 0)                                        # dph_sei_hash_type: MD5
-    b.flag(0)                                        # dph_sei_single_component_flag
+    b.flag(len(md5s) == 1)                           # dph_sei_single_component_flag
     b.u(7, 0)                                        # dph_sei_reserved_zero_7bits
     for m in md5s:
         for byte in m:
@@ -2126,6 +2145,11 @@ def picture_hashes(c, num_pictures, yuv):
     for i in order:
         planes = []
         ysz, csz = dims[i][0] * dims[i][1] * bps, (dims[i][0] // 2) * (dims[i][1] // 2) * bps
+        if c.mono:                                                             # (the application writes the luma plane of a 4:0:0 picture only)
+            planes.append(hashlib.md5(yuv[off:off + ysz]).digest())
+            off += ysz
+            out[i] = planes
+            continue
         for sz in (ysz, csz, csz):
             planes.append(hashlib.md5(yuv[off:off + sz]).digest())
             off += sz
@@ -2229,6 +2253,11 @@ FIXTURES = [
                                                rpr=[(256, 192, (2, 2, 0, 4)), (320, 256, (-4, 0, 2, 2)), (192, 128, None)], sao=True, alf=True, lmcs=True, big_resi=True, p_intra=0.1), 13, 132),
     ("mini_rpr_8bit_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=32, bit_depth=8, mtt_depth=1, inter=True, sbtmvp=True, affine=True, amvr=True, bcw=True,
                                           rpr=[(128, 128, None)], dep_quant=True, p_intra=0.1), 9, 133),
+    # 4:0:0: no chroma anywhere - parameter sets, APSs without chroma parts, slice data without chroma modes and coded flags, a single-component picture hash
+    ("mini_400_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, mono=True, big_resi=True, sao=True, alf=True, lmcs=True), 3, 141),
+    ("mini_400_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, mono=True, inter=True, sbtmvp=True, affine=True, mmvd=True, gpm=True,
+                                           ciip=True, mrl=True, isp=True, mip=True, lfnst=True, mts=True, ts=True, bdpcm=True, sbt=True, sao=True, alf=True, lmcs=True, scaling=True,
+                                           dqp=True, big_resi=True, p_intra=0.25), 9, 142),
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
@@ -2251,7 +2280,7 @@ def main():
         bit = os.path.join(d, name + ".bit")
         open(bit, "wb").write(data)
         md5, yuv, log = reference_md5(bit, keep=True)
-        total = sum(c.sizes[(i // 2) % len(c.sizes) if len(c.sizes) > 1 else 0][0] * c.sizes[(i // 2) % len(c.sizes) if len(c.sizes) > 1 else 0][1] * 3 // 2 * (2 if c.bit_depth > 8 else 1) for i in range(n))
+        total = sum(c.sizes[(i // 2) % len(c.sizes) if len(c.sizes) > 1 else 0][0] * c.sizes[(i // 2) % len(c.sizes) if len(c.sizes) > 1 else 0][1] * (2 if c.mono else 3) // 2 * (2 if c.bit_depth > 8 else 1) for i in range(n))
         assert len(yuv) == total, "the reference decoder put out %d bytes, %d pictures of %d bytes in all expected\n%s" % (len(yuv), n, total, log[-1500:])
         # second pass: the same stream with a decoded-picture-hash SEI behind every picture (the hashes are the reference decoder's), checked by the reference decoder itself
         data, stats = write_stream(c, n, seed, tables, renorm, hashes=picture_hashes(c, n, yuv))

@@ -313,7 +313,13 @@ int vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::
 
   if( ( h.tool_flags & VVR_TOOL_SCALING_LIST ) && !p->scaling ) FAIL( VVR_ERR_PARAMETER, "explicit scaling lists enabled without the lists" );
   if( h.tool_flags & VVR_TOOL_SCALING_LIST )
-    for( int id = 0; id < 28; id++ ) for( int k = 0; k < ( id < 2 ? 4 : id < 8 ? 16 : 64 ); k++ ) if( !p->scaling->coef[id][k] ) FAIL( VVR_ERR_PARAMETER, "scaling list entry 0" );
+    for( int id = 0; id < 28; id++ )
+    {
+      // (a 4:0:0 sequence sends the luma matrices only - ids 2, 5, 8, .. and 27, ScalingList::isLumaScalingList -, the others are never looked at and may hold anything:
+      // found with the first parser-fed 4:0:0 stream that had scaling lists, round 4)
+      if( !h.chroma_format && !( id % 3 == 2 || id == 27 ) ) continue;
+      for( int k = 0; k < ( id < 2 ? 4 : id < 8 ? 16 : 64 ); k++ ) if( !p->scaling->coef[id][k] ) FAIL( VVR_ERR_PARAMETER, "scaling list entry 0" );
+    }
   if( !p->cu || !p->tu || !p->coef || !p->lfp[0] || !p->lfp[1] ) FAIL( VVR_ERR_PARAMETER, "missing arrays" );
   if( ( h.tool_flags & VVR_TOOL_ALF ) && ( !p->alf || !p->alf_params ) ) FAIL( VVR_ERR_PARAMETER, "ALF enabled without parameters" );
   if( ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) && !p->sao ) FAIL( VVR_ERR_PARAMETER, "SAO enabled without parameters" );
