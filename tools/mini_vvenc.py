@@ -253,7 +253,7 @@ class Cfg:
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
                  mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False,
-                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, part=None, lf_across=True, rpr=None, mono=False, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
+                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, part=None, lf_across=True, rpr=None, mono=False, subpic=None, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -342,7 +342,31 @@ def write_sps(c):
     b.ue(c.width)                                    # sps_pic_width_max_in_luma_samples
     b.ue(c.height)
     b.flag(0)                                        # sps_conformance_window_flag
-    b.flag(0)                                        # sps_subpic_info_present_flag
+    b.flag(bool(c.subpic))                           # sps_subpic_info_present_flag
+    if c.subpic:
+        # one sub-picture per slice of the partition (a band of CTU rows or a tile); c.subpic = per sub-picture (treated as picture, loop filter across)
+        P, S = c.partition, 1 << c.log2_ctu
+        n = len(P["slices"])
+        assert n > 1 and len(c.subpic) == n
+        b.ue(n - 1)                                  # sps_num_subpics_minus1
+        b.flag(0)                                    # sps_independent_subpics_flag
+        b.flag(0)                                    # sps_subpic_same_size_flag
+        bw, bh = max(0, (P["W"] - 1).bit_length()), max(0, (P["H"] - 1).bit_length())
+        for i, ctus in enumerate(P["slices"]):
+            x0, y0 = min(x for x, _ in ctus), min(y for _, y in ctus)
+            x1, y1 = max(x for x, _ in ctus), max(y for _, y in ctus)
+            if i > 0 and c.width > S:
+                b.u(bw, x0)                          # sps_subpic_ctu_top_left_x
+            if i > 0 and c.height > S:
+                b.u(bh, y0)                          # sps_subpic_ctu_top_left_y
+            if i < n - 1 and c.width > S:
+                b.u(bw, x1 - x0)                     # sps_subpic_width_minus1
+            if i < n - 1 and c.height > S:
+                b.u(bh, y1 - y0)                     # sps_subpic_height_minus1
+            b.flag(c.subpic[i][0])                   # sps_subpic_treated_as_pic_flag
+            b.flag(c.subpic[i][1])                   # sps_loop_filter_across_subpic_enabled_flag
+        b.ue(max(1, (n - 1).bit_length()) - 1)       # sps_subpic_id_len_minus1
+        b.flag(0)                                    # sps_subpic_id_mapping_explicitly_signalled_flag
     b.ue(c.bit_depth - 8)                            # sps_bitdepth_minus8
     b.flag(0)                                        # sps_entropy_coding_sync_enabled_flag
     b.flag(0)                                        # sps_entry_point_offsets_present_flag
@@ -500,25 +524,27 @@ def write_pps(c, pps_id=0, win=None):
         if c.part[0] == "rows":
             b.ue(P["W"] - 1)                         # pps_tile_column_width_minus1[0]: one tile
             b.ue(P["H"] - 1)                         # pps_tile_row_height_minus1[0]
-            b.flag(0)                                # pps_single_slice_per_subpic_flag  (one tile: rectangular slices)
-            b.ue(n - 1)                              # pps_num_slices_in_pic_minus1
-            if n - 1 > 1:
-                b.flag(0)                            # pps_tile_idx_delta_present_flag
-            b.ue(len(c.part[1]))                     # pps_num_exp_slices_in_tile[0]  (slice 0: neither a width nor a height in tiles is read in a 1 x 1 grid)
-            for hh in c.part[1]:
-                b.ue(hh - 1)                         # pps_exp_slice_height_in_ctus_minus1
+            b.flag(bool(c.subpic))                   # pps_single_slice_per_subpic_flag  (one tile: rectangular slices)
+            if not c.subpic:
+                b.ue(n - 1)                          # pps_num_slices_in_pic_minus1
+                if n - 1 > 1:
+                    b.flag(0)                        # pps_tile_idx_delta_present_flag
+                b.ue(len(c.part[1]))                 # pps_num_exp_slices_in_tile[0]  (slice 0: neither a width nor a height in tiles is read in a 1 x 1 grid)
+                for hh in c.part[1]:
+                    b.ue(hh - 1)                     # pps_exp_slice_height_in_ctus_minus1
         else:
             ncol, nrow = -(-P["W"] // c.part[1]), -(-P["H"] // c.part[2])
             b.ue(c.part[1] - 1)                      # pps_tile_column_width_minus1[0] (the other columns: the same width, the last one what is left)
             b.ue(c.part[2] - 1)                      # pps_tile_row_height_minus1[0]
             b.flag(c.lf_across)                      # pps_loop_filter_across_tiles_enabled_flag
             b.flag(1)                                # pps_rect_slice_flag
-            b.flag(0)                                # pps_single_slice_per_subpic_flag
-            b.ue(n - 1)                              # pps_num_slices_in_pic_minus1
-            if n - 1 > 1:
-                b.flag(0)                            # pps_tile_idx_delta_present_flag
+            b.flag(bool(c.subpic))                   # pps_single_slice_per_subpic_flag
+            if not c.subpic:
+                b.ue(n - 1)                          # pps_num_slices_in_pic_minus1
+                if n - 1 > 1:
+                    b.flag(0)                        # pps_tile_idx_delta_present_flag
             heights = [min(c.part[2], P["H"] - r * c.part[2]) for r in range(nrow)]
-            for i in range(n - 1):                   # (the last slice takes what is left)
+            for i in range(0 if c.subpic else n - 1):      # (the last slice takes what is left)
                 tx, ty = i % ncol, i // ncol
                 if tx != ncol - 1:
                     b.ue(0)                          # pps_slice_width_in_tiles_minus1
@@ -770,7 +796,9 @@ def write_slice_header(c, b, pic, sl=None):
             return
     else:
         b.flag(0)                                    # sh_picture_header_in_slice_header_flag
-        if sl["n"] > 1:
+        if c.subpic:
+            b.u(max(1, (sl["n"] - 1).bit_length()), sl["idx"])      # sh_subpic_id (the sub-picture's only slice: no address)
+        elif sl["n"] > 1:
             b.u((sl["n"] - 1).bit_length(), sl["idx"])      # sh_slice_address: index of the rectangular slice
         st = sl["type"]
     write_slice_header_rest(c, b, pic, st, sl if multi else None)
@@ -2258,6 +2286,13 @@ FIXTURES = [
     ("mini_400_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, mono=True, inter=True, sbtmvp=True, affine=True, mmvd=True, gpm=True,
                                            ciip=True, mrl=True, isp=True, mip=True, lfnst=True, mts=True, ts=True, bdpcm=True, sbt=True, sao=True, alf=True, lmcs=True, scaling=True,
                                            dqp=True, big_resi=True, p_intra=0.25), 9, 142),
+    # sub-pictures (one slice each): bands of CTU rows / tiles; treated as pictures or not (motion vectors clipped and references clamped at the sub-picture's
+    # rectangle), in-loop filtering across their boundaries on or off - per sub-picture; motion vectors up to 50 samples
+    ("mini_subpics_rows_ctu64_384x256", dict(width=384, height=256, log2_ctu=6, log2_min_qt=4, qp=30, mtt_depth=1, part=("rows", [2]), subpic=[(1, 0), (1, 1)], inter=True, sbtmvp=True,
+                                             affine=True, mmvd=True, sao=True, alf=True, max_mvd=200, p_intra=0.1), 9, 151),
+    ("mini_subpics_tiles_ctu64_384x256", dict(width=384, height=256, log2_ctu=6, log2_min_qt=4, qp=30, mtt_depth=2, part=("tiles", 3, 2), subpic=[(1, 0), (0, 1), (1, 1), (0, 0)],
+                                              inter=True, sbtmvp=True, affine=True, mmvd=True, gpm=True, ciip=True, sao=True, alf=True, ccalf=True, lmcs=True, big_resi=True,
+                                              max_mvd=200, p_intra=0.1), 9, 152),
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
