@@ -103,6 +103,11 @@ enum {
                                         second 4x4 unit in both directions, with the MVs of DMVR CUs replaced by the refined ones as soon as the DMVR
                                         kernel has them (DecCu::TaskFinishMotionInfo, DecCu.cpp:161-253).  vvr_read_col_motion() hands it out; the host
                                         neither reads the delta MVs nor patches / subsamples its motion field                                      */
+  VVR_TOOL_LFP_ON_DEVICE = 1u << 26, /* the back-end derives the deblocking edge parameters itself (the reference's LF_INIT task, LoopFilter::
+                                        calcFilterStrengthsCTU, LoopFilter.cpp:495-1360) from the CU / TU records: vvr_picture.lfp is not read and may be NULL.
+                                        vvr_picture.motion then has to hold the cells of SbTMVP and GPM CUs - and of affine CUs unless
+                                        VVR_TOOL_AFFINE_MV_ON_DEVICE is set - (the motion of every other CU is in its record); a slice that switches
+                                        deblocking off in a picture that deblocks says so with VVR_TOOL_DEBLOCK_OFF in its vvr_slice_header.tool_flags       */
 };
 
 typedef struct vvr_alf_params {     /* final filters, AdaptiveLoopFilter::reconstructCoeff (AdaptiveLoopFilter.cpp:888) stays on the host */
@@ -375,7 +380,7 @@ typedef struct vvr_picture {
   const int16_t*        coef;          /* packed quantised levels                                               */
   uint64_t              num_coef;
   const vvr_motion*     motion;        /* [h4][w4], may be NULL for intra pictures                               */
-  const vvr_lfp*        lfp[2];        /* [EDGE_VER, EDGE_HOR][h4][w4]                                           */
+  const vvr_lfp*        lfp[2];        /* [EDGE_VER, EDGE_HOR][h4][w4]; not read with VVR_TOOL_LFP_ON_DEVICE        */
   const vvr_sao_ctu*    sao;           /* [num_ctu] or NULL                                                      */
   const vvr_alf_ctu*    alf;           /* [num_ctu] or NULL                                                      */
   const vvr_alf_params* alf_params;    /* NULL when ALF is off; [num_alf_sets] tables when slices refer to different APSs */

@@ -87,6 +87,23 @@ static void stamp_picture( const PicDev& pic, DevPlanes reco )
 static bool reaches_slot_with_sao_alf( const PicDev& pic ) { return ( pic.hdr.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA | VVR_TOOL_ALF ) ) != 0; }
 void launch_deblock( hipStream_t, const PicDev& pic, DevPlanes reco, int dir ) { if( dir == 0 && !reaches_slot_with_sao_alf( pic ) ) stamp_picture( pic, reco ); }
 void launch_deblock_tile( hipStream_t, const PicDev&, DevPlanes, DevPlanes, int, bool ) {}
+// LF_INIT has a functional stand-in: the kernels are thin loops around vvr_lf_init.h, which compiles for the host as it is - so the whole path (the
+// host's list of sub-block motion, the layout of the device-written parts, the derivation itself) is checked against the reference's tables without a GPU
+static vvr_lfp* g_lastLfp[2] = { nullptr, nullptr }; static int g_lastLfpCells = 0;
+static LfInitView lf_view( const PicDev& pic, uint32_t numCu, uint32_t numTu, const int32_t* tuOf4, const int32_t* tuOf4C, const vvr_motion* sbMotion )
+{
+  LfInitView V; V.hdr = &pic.hdr; V.cu = pic.cu; V.tu = pic.tu; V.tuOf4 = tuOf4; V.tuOf4C = tuOf4C; V.sbMotion = sbMotion; V.ctuSlice = pic.ctuSlice; V.ctuTile = pic.ctuTile;
+  V.ctuSubpic = pic.ctuSubpic; V.subpics = pic.subpics; V.slices = pic.slices; V.w4 = pic.w4; V.h4 = pic.h4; V.ctusX = pic.ctus_x; V.numTu = (int) numTu; V.numCu = (int) numCu;
+  return V;
+}
+void launch_lf_init( hipStream_t, const PicDev& pic, uint32_t numCu, uint32_t numTu, int32_t* tuOf4, int32_t* tuOf4C, vvr_motion* sbMotion, const LfSbCell* sb, int numSb, vvr_lfp* out0, vvr_lfp* out1 )
+{
+  for( uint32_t t = 0; t < numTu; t++ ) lfi_map_tu( pic.tu[t], (int) t, pic.cu[lfi_idx( (int) pic.tu[t].cu, (int) numCu )], tuOf4, tuOf4C, pic.w4, pic.h4 );
+  for( int i = 0; i < numSb; i++ ) if( sb[i].cell < (uint32_t) ( pic.w4 * pic.h4 ) ) sbMotion[sb[i].cell] = sb[i].m;
+  const LfInitView V = lf_view( pic, numCu, numTu, tuOf4, tuOf4C, sbMotion );
+  for( int y = 0; y < pic.h4; y++ ) for( int x = 0; x < pic.w4; x++ ) { out0[(size_t) y * pic.w4 + x] = lf_init_cell( V, 0, x, y ); out1[(size_t) y * pic.w4 + x] = lf_init_cell( V, 1, x, y ); }
+  g_lastLfp[0] = out0; g_lastLfp[1] = out1; g_lastLfpCells = pic.w4 * pic.h4;
+}
 bool sao_alf_fused( const PicDev& ) { return true; }
 void launch_sao_alf( hipStream_t, const PicDev& pic, DevPlanes, DevPlanes dst, bool, bool ) { if( g_delayUs ) usleep( 2 * g_delayUs ); stamp_picture( pic, dst ); }
 void launch_sao( hipStream_t, const PicDev&, DevPlanes, DevPlanes ) { if( g_delayUs ) usleep( 2 * g_delayUs ); }
@@ -174,6 +191,8 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
 __attribute__(( visibility( "default" ) )) unsigned long long vvt_take_h2d_hash( void ) { const uint64_t v = g_h2dHash; g_h2dHash = 1469598103934665603ull; return v; }
 __attribute__(( visibility( "default" ) )) void vvt_take_h2d( size_t* copies, size_t* bytes ) { *copies = g_h2dCopies; *bytes = g_h2dBytes; g_h2dCopies = g_h2dBytes = 0; }
 __attribute__(( visibility( "default" ) )) void vvt_set_delay( int us ) { g_delayUs = us; }
+// the edge-parameter tables the last launch_lf_init derived ("device" memory of the picture's image: valid until the ring entry is reused)
+__attribute__(( visibility( "default" ) )) int vvt_last_lfp( const vvr_lfp** d0, const vvr_lfp** d1 ) { *d0 = g_lastLfp[0]; *d1 = g_lastLfp[1]; return g_lastLfpCells; }
 __attribute__(( visibility( "default" ) )) void vvt_slow_i_pictures( int us ) { g_vvtSlowIUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_slow_b_pictures( int us ) { g_vvtSlowBUs = us; }
 __attribute__(( visibility( "default" ) )) void vvt_events_pending( int on ) { g_eventsPending = on; }

@@ -36,7 +36,7 @@ TOOLS = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF
 
 def build_stub():
     """(re)build the product's host code against the stand-in runtime when a source is newer -> path of the library"""
-    deps = [SRC, API] + [os.path.join(os.path.dirname(API), f) for f in ("vvr_device.h", "vvr_host.h", "vvr_prepare.cpp", "vvr_output.inc")] + [os.path.join(os.path.dirname(HERE), "include", "vvr.h")]
+    deps = [SRC, API] + [os.path.join(os.path.dirname(API), f) for f in ("vvr_device.h", "vvr_host.h", "vvr_prepare.cpp", "vvr_output.inc", "vvr_lf_init.h")] + [os.path.join(os.path.dirname(HERE), "include", "vvr.h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in deps):
         # (several test processes may get here at once - pytest -n: build under a private name, then rename into place)
         tmp = "%s.%d.tmp" % (LIB, os.getpid())

@@ -22,7 +22,7 @@ VVR_NOT_READY = 1          # non-blocking stream-order queries: ask again
 # tool flags
 TOOL_SAO_LUMA, TOOL_SAO_CHROMA, TOOL_ALF, TOOL_CCALF, TOOL_LMCS, TOOL_LMCS_CSCALE, TOOL_DEBLOCK_OFF, TOOL_DEP_QUANT, \
     TOOL_BDOF, TOOL_DMVR, TOOL_PROF, TOOL_JCCR_SIGN, TOOL_STILL_REF, TOOL_LFNST, TOOL_MTS, TOOL_CCLM_COLLOC, \
-    TOOL_WP, TOOL_SCALING_LIST, TOOL_SCALING_LIST_NO_LFNST, TOOL_IMPLICIT_MTS, TOOL_IBC, TOOL_LADF, TOOL_NO_LF_ACROSS_SLICES, TOOL_NO_LF_ACROSS_TILES, TOOL_AFFINE_MV_ON_DEVICE, TOOL_COL_MOTION = [1 << i for i in range(26)]
+    TOOL_WP, TOOL_SCALING_LIST, TOOL_SCALING_LIST_NO_LFNST, TOOL_IMPLICIT_MTS, TOOL_IBC, TOOL_LADF, TOOL_NO_LF_ACROSS_SLICES, TOOL_NO_LF_ACROSS_TILES, TOOL_AFFINE_MV_ON_DEVICE, TOOL_COL_MOTION, TOOL_LFP_ON_DEVICE = [1 << i for i in range(27)]
 SLICE_TOOL_MASK = TOOL_DEP_QUANT | TOOL_LMCS | TOOL_LMCS_CSCALE | TOOL_SCALING_LIST | TOOL_WP       # VVR_SLICE_TOOL_MASK: the switches a vvr_slice_header carries
 
 PRED_INTER, PRED_INTRA, PRED_IBC = 0, 1, 2

@@ -89,7 +89,7 @@ static double g_wdSum[6]; static uint64_t g_wdJobs; static double g_wdPart[4], g
 
 struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
-const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_resi_add", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy", "k_output" };
+const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_resi_add", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy", "k_output", "k_lf_init" };
 
 // One slot of the upload ring: pinned staging memory and its image in HBM (grown on demand, never freed while the context lives), the device
 // pointers of the picture that currently sits in it, and the pinned landing area of its DMVR delta MVs.
@@ -168,6 +168,7 @@ struct vvr_context {
   std::vector<std::vector<hipEvent_t>> slotExt;   // events of external work on a slot (vvr_slot_external_event): pictures that use the slot wait for them
   std::vector<RingEntry> ring;
   size_t     ringLargest = 0;           // bytes of the largest picture image seen (+ 25 %): what a ring entry grows to
+  size_t     ringLargestHost = 0;       // ... and of its uploaded part (the pinned half of an entry)
   std::vector<char*> retiredHost, retiredDev;   // outgrown ring buffers, freed with the context
   std::vector<hipEvent_t> eventPool;
   std::vector<int> nodeCpus;            // CPUs of the NUMA node the device is attached to (empty: unknown / pinning off)
@@ -407,6 +408,8 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   // device-only throughput fell from 1870 to 1240 pictures/s with 4 lanes, to 970 with 8 - the cross-stream waits cost more than the overlap gives)
   // (the tiles of plain, BDOF and DMVR CUs are written on the device from the CU records: the host only counted them)
   if( q->numMcCus ) launch_expand_mc( s, q->pic, q->mcCus, q->numMcCus, q->mcDev, q->bdofItems, q->dmvrItems );
+  // LF_INIT (DecLibRecon.cpp:807-829): the edge parameters of the deblocking passes from the CU / TU records, where the caller leaves them to the back-end
+  if( q->lfpOnDevice && dbOn ) timed( K_LF_INIT, [&]{ launch_lf_init( s, q->pic, q->numCu, q->numTu, q->lfTuOf4, q->lfTuOf4C, q->lfMotion, q->lfSb, q->numLfSb, q->lfpDev[0], q->lfpDev[1] ); } );
   if( q->numMc + q->numMcDev ) timedOn( K_MC, s, q->bytes[K_MC] - q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, P, q->mcItems, q->numMc, q->mcDev, q->numMcDev, 0 ); } );
   if( q->numBdofItems ) timedOn( K_MC, s, q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, P, nullptr, 0, q->bdofItems, q->numBdofItems, 1 ); } );
   if( q->numDmvrItems )
@@ -668,13 +671,18 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S, HostHelpers* h
     // Buffers only ever grow, and an entry that has to grow takes the size of the largest picture seen so far (an intra picture needs several
     // times the bytes of a B picture: after the first one has come by, no entry is reallocated when the next one lands on it).  The old
     // buffers are kept until the context goes: hipFree would wait for the device, i.e. for every picture in flight.
-    size_t want;
-    { std::lock_guard<std::mutex> lk( c->mu ); c->ringLargest = std::max( c->ringLargest, alignUp( total + total / 4, 1 << 16 ) ); want = c->ringLargest; }
-    if( total > e.hostCap )
+    size_t want, wantHost;
+    const size_t staged = vvr_host_staged_bytes( S );      // (what the device writes itself - MC tiles, the edge-parameter tables - has no pinned side)
+    {
+      std::lock_guard<std::mutex> lk( c->mu );
+      c->ringLargest = std::max( c->ringLargest, alignUp( total + total / 4, 1 << 16 ) ); want = c->ringLargest;
+      c->ringLargestHost = std::max( c->ringLargestHost, alignUp( staged + staged / 4, 1 << 16 ) ); wantHost = c->ringLargestHost;
+    }
+    if( staged > e.hostCap )
     {
       if( e.host ) { std::lock_guard<std::mutex> lk( c->mu ); c->retiredHost.push_back( e.host ); }
       e.host = nullptr; e.hostCap = 0;
-      if( hipHostMalloc( (void**) &e.host, want, hipHostMallocDefault ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipHostMalloc failed"; } else e.hostCap = want;
+      if( hipHostMalloc( (void**) &e.host, wantHost, hipHostMallocDefault ) != hipSuccess ) { rc = VVR_ERR_DEVICE; err = "hipHostMalloc failed"; } else e.hostCap = wantHost;
     }
     if( rc == VVR_OK && total > e.devCap )
     {
@@ -969,15 +977,17 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
     const size_t w4 = ( cfg->max_width + 3 ) >> 2, h4 = ( cfg->max_height + 3 ) >> 2;
     const size_t estimate = alignUp( w4 * h4 * ( 2 * sizeof( vvr_lfp ) + 14 ) + ( 1u << 20 ), 1 << 16 );
     const size_t dmvrInts = 2 * ( (size_t) cfg->max_width * cfg->max_height / 128 + 1 );
-    c->ringLargest = estimate;
+    // (device side: room for the cell maps and the motion of sub-block CUs as well, should the pictures leave the edge parameters to the back-end)
+    const size_t estimateDev = estimate + alignUp( w4 * h4 * ( 2 * sizeof( int32_t ) + sizeof( vvr_motion ) ), 1 << 16 );
+    c->ringLargest = estimateDev; c->ringLargestHost = estimate;
     for( size_t i = 0; i < c->ring.size() && ok; i++ )
     {
       RingEntry& e = c->ring[i];
       e.turn = i;
       ok = hipEventCreateWithFlags( &e.copied, hipEventDisableTiming ) == hipSuccess
-        && hipHostMalloc( (void**) &e.host, estimate, hipHostMallocDefault ) == hipSuccess && hipMalloc( (void**) &e.dev, estimate ) == hipSuccess
+        && hipHostMalloc( (void**) &e.host, estimate, hipHostMallocDefault ) == hipSuccess && hipMalloc( (void**) &e.dev, estimateDev ) == hipSuccess
         && hipHostMalloc( (void**) &e.dmvrHost, sizeof( int32_t ) * dmvrInts, hipHostMallocDefault ) == hipSuccess;
-      if( ok ) { e.hostCap = e.devCap = estimate; e.dmvrCap = dmvrInts; }
+      if( ok ) { e.hostCap = estimate; e.devCap = estimateDev; e.dmvrCap = dmvrInts; }
     }
   }
   if( !ok ) { vvr_destroy( c ); return VVR_ERR_DEVICE; }

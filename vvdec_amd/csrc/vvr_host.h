@@ -8,7 +8,7 @@
 
 static inline size_t alignUp( size_t v, size_t a ) { return ( v + a - 1 ) / a * a; }
 
-enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_RESI_ADD, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_OUTPUT, K_NUM };
+enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_RESI_ADD, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_OUTPUT, K_LF_INIT, K_NUM };
 
 // A picture description resident in HBM together with its device work lists: every pointer is a device address inside one blob.
 // Streaming submissions (vvr_submit) use the blob of a ring entry owned by the context; vvr_prepare gives the handle a blob of its own.
@@ -28,6 +28,13 @@ struct vvr_prepared {
   int      intraWorkgroups = 0;                            // workgroups the intra stage is launched with (the dependency front they can keep busy)
   IntraItem* resiItems = nullptr; int numResi = 0;         // scaled chroma residuals of inter blocks (k_resi_add); with them the stage runs as luma units, k_resi_add, chroma units
   int      numLumaUnits = 0, intraWorkgroupsChroma = 0;    // (the first numLumaUnits entries of `units` are the luma units then)
+  // deblocking edge parameters derived on the device (VVR_TOOL_LFP_ON_DEVICE): room behind the uploaded image for the cell -> transform unit maps of both
+  // trees, the motion of the cells of sub-block CUs (scattered from lfSb) and the two tables; pic.lfp points at the tables
+  bool     lfpOnDevice = false;
+  int32_t* lfTuOf4 = nullptr; int32_t* lfTuOf4C = nullptr; vvr_motion* lfMotion = nullptr;
+  const struct LfSbCell* lfSb = nullptr; int numLfSb = 0;
+  vvr_lfp* lfpDev[2] = { nullptr, nullptr };
+  uint32_t numCu = 0, numTu = 0;
   double   bytes[K_NUM] = { 0 };                           // algorithmic bytes per kernel
   double   bytesBdof = 0, bytesIntraLuma = 0, bytesTb[3] = { 0, 0, 0 };      // shares of bytes[K_MC] (the BDOF launch), bytes[K_INTRA] (the luma launch), bytes[K_ITRANS] (per size class)
   // ownership (vvr_prepare handles only)
@@ -81,6 +88,7 @@ int    vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes,
 // the H2D image: every staged part at its offset (256-byte aligned) into `host` (pinned memory of at least totalBytes); the parts that are
 // copied straight from the caller's pinned arrays, and the byte range [begin, end) of the image that is staged
 void   vvr_host_pack( const PrepScratch& S, char* host );
+size_t vvr_host_staged_bytes( const PrepScratch& S );      // bytes of the image that have a host side (the rest is written by the device)
 // collocated motion before refinement: every second 4x4 unit of the picture's motion field in both directions (DecCu.cpp:232-253); dst holds vvr_host_num_col() records
 size_t vvr_host_num_col( const vvr_picture* p );
 void   vvr_host_gather_col( const vvr_picture* p, vvr_motion* dst );

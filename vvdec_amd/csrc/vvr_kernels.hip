@@ -9,6 +9,7 @@
 // bit-exactness is checked against the CPU restatement in oracle/ and the reference-driven golden fixtures.
 #include <type_traits>
 #include "vvr_device.h"
+#include "vvr_lf_init.h"
 
 namespace tbl {
 #include "../../tables/vvc_tables.inc"
@@ -2814,6 +2815,51 @@ void launch_deblock_tile( hipStream_t st, const PicDev& pic, DevPlanes src, DevP
     const dim3 grid( ( src.w[0] + DbTile<1>::T - 1 ) / DbTile<1>::T, ( src.h[0] + DbTile<1>::N - 1 ) / DbTile<1>::N );
     hipLaunchKernelGGL( ( k_deblock_tile<false, 1> ), grid, dim3( 256 ), 0, st, pic, src, dst, dbg );
   }
+}
+
+// =====================================================================================================================
+// k_lf_* — the reference's LF_INIT task (LoopFilter::calcFilterStrengthsCTU, LoopFilter.cpp:495-1360; DecLibRecon.cpp:807-829) for pictures that leave the
+// deblocking edge parameters to the back-end (VVR_TOOL_LFP_ON_DEVICE).  The derivation itself is vvr_lf_init.h (one function per 4x4 cell and direction, also
+// compiled for the host by the tests); here: the cell -> transform unit maps of both trees (one thread per transform unit), the motion of the cells of CUs
+// whose motion varies inside the CU (one thread per cell the host listed), the two tables (one thread per cell, 8-byte stores).  HBM-bound and small: 12 MB
+// written and 4-8 MB read back per 4K picture against 8.3 MB of tables that no longer cross PCIe.
+// =====================================================================================================================
+__global__ __launch_bounds__( 256 ) void k_lf_maps( const vvr_cu* __restrict__ cu, const vvr_tu* __restrict__ tu, int numCu, int numTu, int32_t* __restrict__ tuOf4, int32_t* __restrict__ tuOf4C, int w4, int h4 )
+{
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if( t >= numTu ) return;
+  const vvr_tu T = tu[t];
+  const vvr_cu& C = cu[lfi_idx( (int) T.cu, numCu )];
+  if( C.tree == VVR_TREE_CHROMA && !tuOf4C ) return;
+  lfi_map_tu( T, t, C, tuOf4, tuOf4C, w4, h4 );
+}
+__global__ __launch_bounds__( 256 ) void k_lf_scatter( const LfSbCell* __restrict__ sb, int n, vvr_motion* __restrict__ sbMotion, int cells )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= n ) return;
+  const LfSbCell e = sb[i];
+  if( e.cell < (uint32_t) cells ) sbMotion[e.cell] = e.m;
+}
+__global__ __launch_bounds__( 256 ) void k_lf_init( PicDev pic, int numCu, int numTu, const int32_t* __restrict__ tuOf4, const int32_t* __restrict__ tuOf4C, const vvr_motion* __restrict__ sbMotion,
+                                                   vvr_lfp* __restrict__ out0, vvr_lfp* __restrict__ out1 )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= pic.w4 * pic.h4 ) return;
+  const int y4 = i / pic.w4, x4 = i - y4 * pic.w4;
+  LfInitView V; V.hdr = &pic.hdr; V.cu = pic.cu; V.tu = pic.tu; V.tuOf4 = tuOf4; V.tuOf4C = tuOf4C; V.sbMotion = sbMotion; V.ctuSlice = pic.ctuSlice; V.ctuTile = pic.ctuTile;
+  V.ctuSubpic = pic.ctuSubpic; V.subpics = pic.subpics; V.slices = pic.slices; V.w4 = pic.w4; V.h4 = pic.h4; V.ctusX = pic.ctus_x; V.numTu = numTu; V.numCu = numCu;
+  static_assert( sizeof( vvr_lfp ) == 8, "one 8-byte store per table entry" );
+  const vvr_lfp a = lf_init_cell( V, 0, x4, y4 ), b = lf_init_cell( V, 1, x4, y4 );
+  *reinterpret_cast<uint2*>( &out0[i] ) = *reinterpret_cast<const uint2*>( &a );
+  *reinterpret_cast<uint2*>( &out1[i] ) = *reinterpret_cast<const uint2*>( &b );
+}
+void launch_lf_init( hipStream_t s, const PicDev& pic, uint32_t numCu, uint32_t numTu, int32_t* tuOf4, int32_t* tuOf4C, vvr_motion* sbMotion, const LfSbCell* sbCells, int numSbCells, vvr_lfp* out0, vvr_lfp* out1 )
+{
+  if( !numTu || !numCu ) return;
+  const int cells = pic.w4 * pic.h4;
+  hipLaunchKernelGGL( k_lf_maps, dim3( ( numTu + 255 ) / 256 ), dim3( 256 ), 0, s, pic.cu, pic.tu, (int) numCu, (int) numTu, tuOf4, tuOf4C, pic.w4, pic.h4 );
+  if( numSbCells && sbMotion ) hipLaunchKernelGGL( k_lf_scatter, dim3( ( numSbCells + 255 ) / 256 ), dim3( 256 ), 0, s, sbCells, numSbCells, sbMotion, cells );
+  hipLaunchKernelGGL( k_lf_init, dim3( ( cells + 255 ) / 256 ), dim3( 256 ), 0, s, pic, (int) numCu, (int) numTu, (const int32_t*) tuOf4, (const int32_t*) tuOf4C, (const vvr_motion*) sbMotion, out0, out1 );
 }
 
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )

@@ -6,6 +6,7 @@
 // (no allocation in the steady state), per-block producer lists sit in one flat pool, and the result is packed straight into the pinned
 // staging memory of the upload ring.  No device call happens here.
 #include "vvr_host.h"
+#include "vvr_lf_init.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -63,6 +64,8 @@ struct PrepScratch
   uint32_t devTiles[3] = { 0, 0, 0 };      // tiles the device writes per list (plain, BDOF, DMVR)
   std::vector<uint16_t> ctuSubpicV;        // sub-picture of every CTU, built from the rectangles (layout)
   std::vector<vvr_motion> affMv;           // motion of the 4x4 sub-blocks of the affine tiles, 16 entries per tile (the only part of the motion field a kernel reads)
+  bool lfpOnDevice = false;                // VVR_TOOL_LFP_ON_DEVICE on a picture that deblocks: the edge parameters are derived on the device (k_lf_init)
+  std::vector<LfSbCell> lfSb;              // ... which reads the motion of the cells of SbTMVP and GPM CUs (affine: unless the device spans it) from this list
   uint32_t numDmvr = 0;
   std::vector<TbItem> tb[3];
   std::vector<IntraItem> intra[3], intraTmp[3], intraAll;
@@ -106,6 +109,7 @@ struct PrepScratch
   // ---- layout of the H2D image
   std::vector<Part> parts;
   size_t total = 0, numDirect = 0;          // parts [0, numDirect) are copied from the caller's pinned arrays
+  int iLfSb, iLfTu, iLfTuC, iLfMotion;
   int iCu, iTu, iCoef, iAffMv, iL0, iL1, iSao, iAlf, iAlfP, iSlices, iLmcs, iSl, iCtuSlice, iCtuTile, iSubpics, iCtuSubpic, iWp, iCsVpdu, iMc, iMcB, iMcD, iMcA, iTb[3], iIntra, iResi, iUnits, iMcCus, iMcDev[3], iRpr, iMcR;
   size_t stagedEndOff = 0;                  // end of the uploaded part of the image
 
@@ -132,6 +136,7 @@ struct PrepScratch
     cscale = lmcs && ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) && ncomp == 3;
     vpduLog2 = std::min<int>( 6, h.log2_ctu ); vpdusX = ( h.width + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2; vpdusY = ( h.height + ( 1 << vpduLog2 ) - 1 ) >> vpduLog2;
     mc.clear(); mcBdof.clear(); mcDmvr.clear(); mcAff.clear(); mcRpr.clear(); affMv.clear(); numDmvr = 0;
+    lfSb.clear(); lfpOnDevice = ( h.tool_flags & VVR_TOOL_LFP_ON_DEVICE ) && !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF );
     mcCus.clear(); devTiles[0] = devTiles[1] = devTiles[2] = 0;
     for( int k = 0; k < 3; k++ ) { tb[k].clear(); intra[k].clear(); itemH[k].clear(); prodPool[k].clear(); }
     resiAdd.clear(); intraAll.clear(); units.clear(); unitsDev.clear(); csVpduV.clear();
@@ -320,7 +325,7 @@ int vvr_host_validate_header( const vvr_config& cfg, const vvr_picture* p, std::
       if( !h.chroma_format && !( id % 3 == 2 || id == 27 ) ) continue;
       for( int k = 0; k < ( id < 2 ? 4 : id < 8 ? 16 : 64 ); k++ ) if( !p->scaling->coef[id][k] ) FAIL( VVR_ERR_PARAMETER, "scaling list entry 0" );
     }
-  if( !p->cu || !p->tu || !p->coef || !p->lfp[0] || !p->lfp[1] ) FAIL( VVR_ERR_PARAMETER, "missing arrays" );
+  if( !p->cu || !p->tu || !p->coef || ( !( h.tool_flags & VVR_TOOL_LFP_ON_DEVICE ) && ( !p->lfp[0] || !p->lfp[1] ) ) ) FAIL( VVR_ERR_PARAMETER, "missing arrays" );
   if( ( h.tool_flags & VVR_TOOL_ALF ) && ( !p->alf || !p->alf_params ) ) FAIL( VVR_ERR_PARAMETER, "ALF enabled without parameters" );
   if( ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) && !p->sao ) FAIL( VVR_ERR_PARAMETER, "SAO enabled without parameters" );
   if( h.slice_type != 2 )
@@ -414,6 +419,16 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
           if( ( m.ref_idx[0] < 0 && m.ref_idx[1] < 0 ) || m.ref_idx[0] >= h.num_ref[0] || m.ref_idx[1] >= h.num_ref[1] ) FAIL( VVR_ERR_PARAMETER, "SbTMVP CU: bad sub-block motion" );
         }
       if( isGeo != ( ( cu.flags & VVR_CU_GEO ) != 0 ) ) FAIL( VVR_ERR_PARAMETER, "GPM CU: mc_mode / flag mismatch" );
+      if( isGeo && ( h.tool_flags & VVR_TOOL_LFP_ON_DEVICE ) && !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF ) )
+      {
+        // the edge parameters are derived by the back-end: it needs the motion the CU left in the motion field (which of its two predictions a cell keeps)
+        if( !p->motion ) FAIL( VVR_ERR_PARAMETER, "GPM CU: missing motion field (VVR_TOOL_LFP_ON_DEVICE)" );
+        for( int y = 0; y < cu.h; y += 4 ) for( int x = 0; x < cu.w; x += 4 )
+        {
+          const vvr_motion& m = p->motion[(size_t) ( ( cu.y + y ) >> 2 ) * ( ( h.width + 3 ) >> 2 ) + ( ( cu.x + x ) >> 2 )];
+          if( m.ref_idx[0] >= h.num_ref[0] || m.ref_idx[1] >= h.num_ref[1] ) FAIL( VVR_ERR_PARAMETER, "GPM CU: bad motion" );
+        }
+      }
       if( isGeo )
       {
         if( cu.w < 8 || cu.h < 8 || cu.w > 64 || cu.h > 64 || cu.w >= 8 * cu.h || cu.h >= 8 * cu.w || cu.geo_split_dir >= 64 ) FAIL( VVR_ERR_PARAMETER, "GPM CU: size / split direction out of range" );
@@ -907,6 +922,12 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
       {
         if( cu.mc_mode == VVR_MC_GEO ) for( int k = 0; k < 2; k++ ) rprCu |= p->rpr->ref[( cu.geo_dir_ref[k] >> 4 ) - 1][cu.geo_dir_ref[k] & 15].scaled != 0;
         else for( int l = 0; l < 2; l++ ) rprCu |= cu.ref_idx[l] >= 0 && p->rpr->ref[l][cu.ref_idx[l]].scaled;
+      }
+      if( lfpOnDevice && ( sbt || cu.mc_mode == VVR_MC_GEO || ( af && !( h.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) ) ) )
+      {
+        // the edge parameters are derived on the device: the motion of a CU whose motion varies inside it is not in its record
+        const int cx0 = cu.x >> 2, cy0 = cu.y >> 2, cx1 = std::min( ( cu.x + cu.w + 3 ) >> 2, w4 ), cy1 = std::min( ( cu.y + cu.h + 3 ) >> 2, h4 );
+        for( int cy = cy0; cy < cy1; cy++ ) for( int cx = cx0; cx < cx1; cx++ ) { const uint32_t cell = (uint32_t) ( cy * w4 + cx ); lfSb.push_back( LfSbCell{ cell, p->motion[cell] } ); }
       }
       std::vector<McItem>& list = rprCu ? mcRpr : dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc;
       const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
@@ -1448,8 +1469,12 @@ void PrepScratch::layout( PinnedRanges* pinned )
   // where they are, everything behind them is staged (one contiguous range of the image)
   auto addCaller = [&]( const void* src, size_t n ) { const int i = add( src, n ); parts[i].direct = pinned && n >= 65536 && (size_t) i == numDirect && pinned->contains( src, n ); if( parts[i].direct ) numDirect++; return i; };
   numDirect = 0;
-  iL0 = addCaller( p->lfp[0], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
-  iL1 = addCaller( p->lfp[1], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+  iL0 = iL1 = -1;
+  if( !( h.tool_flags & VVR_TOOL_LFP_ON_DEVICE ) )
+  {
+    iL0 = addCaller( p->lfp[0], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+    iL1 = addCaller( p->lfp[1], sizeof( vvr_lfp ) * (size_t) w4 * h4 );
+  }
   iCu = addCaller( p->cu, sizeof( vvr_cu ) * p->num_cu );
   iCoef = addCaller( p->coef, sizeof( int16_t ) * (size_t) p->num_coef );
   iTu = addCaller( p->tu, sizeof( vvr_tu ) * p->num_tu );
@@ -1488,9 +1513,20 @@ void PrepScratch::layout( PinnedRanges* pinned )
   iIntra = add( intraAll.data(), sizeof( IntraItem ) * intraAll.size() );
   iResi = add( resiAdd.data(), sizeof( IntraItem ) * resiAdd.size() );
   iUnits = add( unitsDev.data(), sizeof( IntraUnit ) * unitsDev.size() );
-  // behind everything that is uploaded: room for what the device writes itself (k_expand_mc)
+  iLfSb = lfpOnDevice ? add( lfSb.data(), sizeof( LfSbCell ) * lfSb.size() ) : -1;
+  // behind everything that is uploaded: room for what the device writes itself (k_expand_mc, k_lf_init)
   stagedEndOff = total;
   for( int k = 0; k < 3; k++ ) iMcDev[k] = add( nullptr, sizeof( McItem ) * devTiles[k] );
+  iLfTu = iLfTuC = iLfMotion = -1;
+  if( lfpOnDevice )
+  {
+    const size_t cells = (size_t) w4 * h4;
+    iL0 = add( nullptr, sizeof( vvr_lfp ) * cells ); iL1 = add( nullptr, sizeof( vvr_lfp ) * cells );
+    iLfTu = add( nullptr, sizeof( int32_t ) * cells ); iLfTuC = ncomp == 3 ? add( nullptr, sizeof( int32_t ) * cells ) : -1;
+    iLfMotion = lfSb.empty() ? -1 : add( nullptr, sizeof( vvr_motion ) * cells );
+    // the maps written and read, the two tables written, the records read once
+    bytes[K_LF_INIT] = (double) cells * ( ( ncomp == 3 ? 16 : 8 ) + 2 * sizeof( vvr_lfp ) ) + (double) sizeof( vvr_cu ) * p->num_cu + (double) sizeof( vvr_tu ) * p->num_tu + (double) lfSb.size() * ( sizeof( LfSbCell ) + sizeof( vvr_motion ) );
+  }
 }
 
 // The work lists of a picture whose CUs are all intra CUs, built in parts (bands of CTU rows) by several threads: such CTUs are analysed without looking
@@ -1582,6 +1618,7 @@ int PrepScratch::buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool
           O.mcAff.insert( O.mcAff.end(), R.mcAff.begin(), R.mcAff.end() );
           if( !( O.h.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) ) for( size_t i = a0; i < O.mcAff.size(); i++ ) O.mcAff[i].mv[0][0] += affOff;
           O.affMv.insert( O.affMv.end(), R.affMv.begin(), R.affMv.end() );
+          O.lfSb.insert( O.lfSb.end(), R.lfSb.begin(), R.lfSb.end() );
           for( McCuRef m : R.mcCus ) { m.first += O.devTiles[m.first >> 30]; O.mcCus.push_back( m ); }
           for( int k = 0; k < 3; k++ ) O.devTiles[k] += R.devTiles[k];
           O.numDmvr = std::max( O.numDmvr, R.numDmvr );
@@ -1666,12 +1703,15 @@ void vvr_host_gather_col( const vvr_picture* p, vvr_motion* dst )
   }
 }
 
+size_t vvr_host_staged_bytes( const PrepScratch& S ) { return S.stagedEndOff; }
+
 void vvr_host_pack( const PrepScratch& S, char* host )
 {
   // (the alignment gap behind a part is cleared: what goes to the device is a function of the picture alone, not of what the ring entry held before)
   for( size_t i = S.numDirect; i < S.parts.size(); i++ )
   {
     const Part& pt = S.parts[i];
+    if( pt.off >= S.stagedEndOff ) break;        // (what the device writes itself has no host image)
     if( pt.n && pt.src ) memcpy( host + pt.off, pt.src, pt.n );
     const size_t end = pt.off + ( pt.src ? pt.n : 0 ), next = i + 1 < S.parts.size() ? S.parts[i + 1].off : S.total;
     if( next > end && next - end < 4096 ) memset( host + end, 0, next - end );
@@ -1697,6 +1737,9 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   d.cu = (const vvr_cu*) at( S.iCu ); d.tu = (const vvr_tu*) at( S.iTu ); d.coef = (const int16_t*) at( S.iCoef );
   d.affMotion = (const vvr_motion*) at( S.iAffMv );
   d.lfp[0] = (const vvr_lfp*) at( S.iL0 ); d.lfp[1] = (const vvr_lfp*) at( S.iL1 );
+  q.lfpOnDevice = S.lfpOnDevice; q.lfpDev[0] = (vvr_lfp*) at( S.iL0 ); q.lfpDev[1] = (vvr_lfp*) at( S.iL1 );
+  q.lfTuOf4 = (int32_t*) at( S.iLfTu ); q.lfTuOf4C = (int32_t*) at( S.iLfTuC ); q.lfMotion = (vvr_motion*) at( S.iLfMotion );
+  q.lfSb = (const LfSbCell*) at( S.iLfSb ); q.numLfSb = (int) S.lfSb.size(); q.numCu = p->num_cu; q.numTu = p->num_tu;
   d.sao = (const vvr_sao_ctu*) at( S.iSao ); d.alf = (const vvr_alf_ctu*) at( S.iAlf ); d.alf_params = (const vvr_alf_params*) at( S.iAlfP );
   d.lmcs = (const vvr_lmcs_params*) at( S.iLmcs ); d.scaling = (const vvr_scaling_list*) at( S.iSl ); d.wp = (const vvr_wp_params*) at( S.iWp ); d.rpr = (const vvr_rpr_params*) at( S.iRpr );
   d.ctuSlice = (const uint16_t*) at( S.iCtuSlice ); d.ctuTile = (const uint16_t*) at( S.iCtuTile );

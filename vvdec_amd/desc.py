@@ -77,8 +77,9 @@ class PictureDesc:
         p.num_coef = len(self.coef)
         if self.motion is not None:
             p.motion = self.motion.ctypes.data_as(C.POINTER(abi.Motion))
-        for d in range(2):
-            p.lfp[d] = self.lfp[d].ctypes.data_as(C.POINTER(abi.Lfp))
+        if not (self.hdr.tool_flags & abi.TOOL_LFP_ON_DEVICE):       # (with the flag the back-end derives the edge parameters itself: the tables stay at home)
+            for d in range(2):
+                p.lfp[d] = self.lfp[d].ctypes.data_as(C.POINTER(abi.Lfp))
         if self.sao is not None:
             p.sao = self.sao.ctypes.data_as(C.POINTER(abi.SaoCtu))
         if self.alf is not None:
