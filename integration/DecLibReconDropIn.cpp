@@ -52,6 +52,7 @@
 #undef protected
 #endif
 #include "../include/vvr.h"
+#include "../vvdec_amd/csrc/vvr_lf_init.h"      // (self-check only, VVDEC_AMD_LF_INIT=2: the back-end's derivation of the edge parameters, compiled for the host)
 #include "vvr_extract.h"
 
 namespace vvdec
@@ -112,6 +113,48 @@ std::map<const DecLibRecon*, std::unique_ptr<AmdInst>> g_inst;
 AmdInst& instOf( const DecLibRecon* d ) { std::lock_guard<std::mutex> lk( g_mu ); return *g_inst.at( d ); }
 double nowMs() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
 int envInt( const char* name, int def ) { const char* e = getenv( name ); return e ? atoi( e ) : def; }
+// LF_INIT: 0 (default) = left to the back-end (VVR_TOOL_LFP_ON_DEVICE: no calcFilterStrengthsCTU here, no table copied or uploaded); 1 = the reference's own
+// (the round-3 path); 2 = self-check: the reference's own runs, the back-end's derivation (vvdec_amd/csrc/vvr_lf_init.h, the source k_lf_init is compiled
+// from) runs on the host beside it and every difference the deblocking filter would see is reported
+int lfInitMode() { static const int m = envInt( "VVDEC_AMD_LF_INIT", 0 ); return m; }
+std::atomic<long> g_lfpCheckedCells{ 0 }, g_lfpDifferentCells{ 0 };
+
+// self-check (VVDEC_AMD_LF_INIT=2): the description's tables (the reference's LF_INIT) against the back-end's derivation from the same description
+void checkEdgeParameters( const vvr_glue::Extracted& E )
+{
+  const vvr_picture& p = E.pic;
+  if( p.hdr.tool_flags & VVR_TOOL_DEBLOCK_OFF ) return;
+  const int w4 = ( p.hdr.width + 3 ) >> 2, h4 = ( p.hdr.height + 3 ) >> 2, ctu = 1 << p.hdr.log2_ctu, ctusX = ( p.hdr.width + ctu - 1 ) / ctu, ctusY = ( p.hdr.height + ctu - 1 ) / ctu;
+  std::vector<int32_t> tuOf4( (size_t) w4 * h4, -1 ), tuOf4C( (size_t) w4 * h4, -1 );
+  for( uint32_t t = 0; t < p.num_tu; t++ ) lfi_map_tu( p.tu[t], (int) t, p.cu[p.tu[t].cu], tuOf4.data(), tuOf4C.data(), w4, h4 );
+  std::vector<uint16_t> ctuSubpic;
+  if( p.subpics && p.num_subpics > 1 )
+  {
+    ctuSubpic.assign( (size_t) ctusX * ctusY, 0 );
+    for( uint32_t k = 0; k < p.num_subpics; k++ ) for( int y = p.subpics[k].y0 >> p.hdr.log2_ctu; y <= p.subpics[k].y1 >> p.hdr.log2_ctu; y++ ) for( int x = p.subpics[k].x0 >> p.hdr.log2_ctu; x <= p.subpics[k].x1 >> p.hdr.log2_ctu; x++ ) ctuSubpic[(size_t) y * ctusX + x] = (uint16_t) k;
+  }
+  LfInitView V; V.hdr = &p.hdr; V.cu = p.cu; V.tu = p.tu; V.tuOf4 = tuOf4.data(); V.tuOf4C = tuOf4C.data(); V.sbMotion = p.motion; V.ctuSlice = p.ctu_slice; V.ctuTile = p.ctu_tile;
+  V.ctuSubpic = ctuSubpic.empty() ? nullptr : ctuSubpic.data(); V.subpics = p.subpics; V.slices = p.slices; V.w4 = w4; V.h4 = h4; V.ctusX = ctusX; V.numTu = (int) p.num_tu; V.numCu = (int) p.num_cu;
+  long bad = 0;
+  for( int d = 0; d < 2; d++ ) for( int y = 0; y < h4; y++ ) for( int x = 0; x < w4; x++ )
+  {
+    const vvr_lfp a = p.lfp[d][(size_t) y * w4 + x], b = lf_init_cell( V, d, x, y );
+    const bool grid = p.hdr.chroma_format && ( ( ( d == 0 ? x : y ) << 2 ) & 15 ) == 0;
+    bool differ = ( a.bs & 3 ) != ( b.bs & 3 );
+    if( a.bs & 3 ) differ |= a.qp[0] != b.qp[0] || ( a.side_max_filt_length & 0x77 ) != ( b.side_max_filt_length & 0x77 );
+    if( grid )
+    {
+      differ |= ( a.bs & 0x3c ) != ( b.bs & 0x3c );
+      if( a.bs & 0x0c ) differ |= a.qp[1] != b.qp[1];
+      if( a.bs & 0x30 ) differ |= a.qp[2] != b.qp[2];
+      if( a.bs & 0x3c ) differ |= ( a.flags & 0x20 ) != ( b.flags & 0x20 );
+    }
+    if( differ && bad++ < 4 )
+      fprintf( stderr, "[vvdec_amd] edge parameters differ: POC %d dir %d cell (%d, %d): LF_INIT bs %02x len %02x qp %d %d %d flags %02x, derived bs %02x len %02x qp %d %d %d flags %02x\n", p.hdr.poc, d, x, y,
+               a.bs, a.side_max_filt_length, a.qp[0], a.qp[1], a.qp[2], a.flags, b.bs, b.side_max_filt_length, b.qp[0], b.qp[1], b.qp[2], b.flags );
+  }
+  g_lfpCheckedCells += 2L * w4 * h4; g_lfpDifferentCells += bad;
+}
 }   // namespace
 
 DecLibRecon::DecLibRecon()
@@ -162,6 +205,8 @@ void DecLibRecon::destroy()
       fprintf( stderr, "[vvdec_amd] %d pictures, host ms per picture: MIDER %.2f, LF_INIT %.2f, flatten %.2f, submit+device %.2f, planes back %.2f\n", it->second->pictures,
                it->second->msMider / it->second->pictures, it->second->msLfInit / it->second->pictures, it->second->msFlatten / it->second->pictures,
                ( it->second->msSubmit + it->second->msDevice ) / it->second->pictures, it->second->msReadBack / it->second->pictures );
+    if( lfInitMode() == 2 && it->second->pictures )
+      fprintf( stderr, "[vvdec_amd] edge parameters: %ld entries checked against the reference's LF_INIT, %ld differ\n", g_lfpCheckedCells.exchange( 0 ), g_lfpDifferentCells.exchange( 0 ) );
     g_inst.erase( it );        // (the last instance of a decoder takes the context, hence the DPB in HBM, with it)
   }
 }
@@ -288,10 +333,13 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
         else memset( NO_WARNING_class_memaccess( cd.motion ), MI_NOT_VALID, sizeof( MotionInfo ) * pcv.num4x4CtuBlks );
       }
       const double t1 = nowMs();
-      cd.lfParam[0] = &d.m_loopFilterParam[pcv.num4x4CtuBlks * ( 2 * a + 0 )];
-      cd.lfParam[1] = &d.m_loopFilterParam[pcv.num4x4CtuBlks * ( 2 * a + 1 )];
-      memset( cd.lfParam[0], 0, sizeof( LoopFilterParam ) * 2 * pcv.num4x4CtuBlks );
-      d.m_cLoopFilter.calcFilterStrengthsCTU( cs, a );
+      if( lfInitMode() )
+      {
+        cd.lfParam[0] = &d.m_loopFilterParam[pcv.num4x4CtuBlks * ( 2 * a + 0 )];
+        cd.lfParam[1] = &d.m_loopFilterParam[pcv.num4x4CtuBlks * ( 2 * a + 1 )];
+        memset( cd.lfParam[0], 0, sizeof( LoopFilterParam ) * 2 * pcv.num4x4CtuBlks );
+        d.m_cLoopFilter.calcFilterStrengthsCTU( cs, a );
+      }
       const double t2 = nowMs();
       I.usMider += (int64_t) ( 1e3 * ( t1 - t0 ) ); I.usLfInit += (int64_t) ( 1e3 * ( t2 - t1 ) );
       mine.store( c + 1, std::memory_order_release );
@@ -384,7 +432,8 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
       }
       { AmdCtx::Slot& sl = X.slots[I.slot]; sl.poc = pic->poc; sl.ours = true; }
       const double t2b = nowMs();
-      vvr_glue::extractPicture( cs, slice, *pic, rsp, R.m_cTrQuant, [&X]( const Picture* p ) { auto q = X.slotOf.find( p ); return q == X.slotOf.end() ? -1 : q->second; }, I.slot, I.desc, hostThreads, /* the motion field only where the back-end reads it */ true );
+      vvr_glue::extractPicture( cs, slice, *pic, rsp, R.m_cTrQuant, [&X]( const Picture* p ) { auto q = X.slotOf.find( p ); return q == X.slotOf.end() ? -1 : q->second; }, I.slot, I.desc, hostThreads, /* the motion field only where the back-end reads it */ lfInitMode() != 2, /* edge parameters: the back-end's */ lfInitMode() == 0 );
+      if( lfInitMode() == 2 ) checkEdgeParameters( I.desc );
       const double t3 = nowMs(); I.msFlatten += t3 - t2b;
       const int job = vvr_submit( X.ctx, &I.desc.pic );
       if( job < 0 ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( X.ctx ) );

@@ -266,7 +266,8 @@ static inline int checkExpressible( const CodingStructure& cs, const Picture& pi
 
 // slotOf: DPB slot of a reference picture (the caller owns the mapping picture <-> slot); outSlot: slot of the picture itself
 static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& pic, Reshape* reshaper, TrQuant& trQuant,
-                                   const std::function<int( const Picture* )>& slotOf, int outSlot, Extracted& E, int threads = 1, bool subBlockMotionOnly = false )
+                                   const std::function<int( const Picture* )>& slotOf, int outSlot, Extracted& E, int threads = 1, bool subBlockMotionOnly = false,
+                                   bool lfpOnDevice = false /* VVR_TOOL_LFP_ON_DEVICE: the back-end derives the edge parameters itself - LF_INIT need not have run, no table is copied */ )
 {
   const SPS& sps = *cs.sps; const PPS& pps = *cs.pps; const PreCalcValues& pcv = *cs.pcv;
   const int W = pps.getPicWidthInLumaSamples(), H = pps.getPicHeightInLumaSamples();
@@ -520,7 +521,8 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
 
   const auto tX1 = std::chrono::steady_clock::now();
   // ---- per-4x4 tables: motion (after MIDER), edge parameters (after LF_INIT)
-  E.lfp[0].resize( (size_t) w4 * h4 ); E.lfp[1].resize( (size_t) w4 * h4 );
+  if( !lfpOnDevice ) { E.lfp[0].resize( (size_t) w4 * h4 ); E.lfp[1].resize( (size_t) w4 * h4 ); }
+  else h.tool_flags |= VVR_TOOL_LFP_ON_DEVICE;
   if( !subBlockMotionOnly ) E.motion.resize( (size_t) w4 * h4 );
   else if( E.motionSparseCells < (size_t) w4 * h4 ) { E.motionSparse.reset( new vvr_motion[(size_t) w4 * h4] ); E.motionSparseCells = (size_t) w4 * h4; }
   vvr_motion* const motionOut = subBlockMotionOnly ? E.motionSparse.get() : E.motion.data();
@@ -550,7 +552,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
       // a slice with deblocking switched off in a picture that deblocks: LF_INIT leaves the edge parameters of its CTUs untouched and the
       // filter skips them (LoopFilter.cpp:366,423) - here they carry no edge
       const bool noEdges = !allDbkOff && cd.slice && cd.slice->getDeblockingFilterDisable();
-      for( int d = 0; d < 2; d++ )
+      for( int d = 0; d < 2 && !lfpOnDevice; d++ )
       {
         vvr_lfp* o = &E.lfp[d][(size_t) y * w4 + x0];
         memset( o, 0, sizeof( vvr_lfp ) * n );
@@ -568,7 +570,8 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
       for( size_t k = E.cu.size() * r / threads; k < E.cu.size() * ( r + 1 ) / threads; k++ )
       {
         const vvr_cu& c = E.cu[k];
-        if( c.pred_mode == VVR_PRED_INTER && ( c.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP ) ) )
+        // (with the edge parameters left to the back-end it reads the motion of GPM CUs as well: which of its two predictions a cell kept)
+        if( c.pred_mode == VVR_PRED_INTER && ( c.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP | ( lfpOnDevice ? VVR_CU_GEO : 0 ) ) ) )
           for( int y = c.y >> 2; y < ( c.y + c.h + 3 ) >> 2; y++ ) for( int x = c.x >> 2; x < ( c.x + c.w + 3 ) >> 2; x++ ) motionCell( x, y );
       }
     } );
@@ -688,7 +691,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   // ---- the picture
   E.pic.num_cu = (uint32_t) E.cu.size(); E.pic.num_tu = (uint32_t) E.tu.size();
   E.pic.cu = E.cu.data(); E.pic.tu = E.tu.data(); E.pic.ctu_first_cu = E.ctuFirstCu.data(); E.pic.coef = E.coef.data(); E.pic.num_coef = E.coef.size();
-  E.pic.motion = subBlockMotionOnly ? E.motionSparse.get() : E.motion.data(); E.pic.lfp[0] = E.lfp[0].data(); E.pic.lfp[1] = E.lfp[1].data();
+  E.pic.motion = subBlockMotionOnly ? E.motionSparse.get() : E.motion.data(); E.pic.lfp[0] = lfpOnDevice ? nullptr : E.lfp[0].data(); E.pic.lfp[1] = lfpOnDevice ? nullptr : E.lfp[1].data();
   E.pic.sao = ( h.tool_flags & ( VVR_TOOL_SAO_LUMA | VVR_TOOL_SAO_CHROMA ) ) ? E.sao.data() : nullptr;
   E.pic.alf = ( h.tool_flags & VVR_TOOL_ALF ) ? E.alf.data() : nullptr;
   E.pic.alf_params = ( h.tool_flags & VVR_TOOL_ALF ) ? E.alfSets.data() : nullptr; E.pic.num_alf_sets = (uint32_t) E.alfSets.size();
@@ -717,7 +720,7 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
     {
       const Slice& sl = *st.first[k];
       vvr_slice_header& o = E.slices[k];
-      o.tool_flags = toolFlags( cs, sl, pic ) & VVR_SLICE_TOOL_MASK;
+      o.tool_flags = toolFlags( cs, sl, pic ) & ( VVR_SLICE_TOOL_MASK | VVR_TOOL_DEBLOCK_OFF );      // (deblocking switched off by a slice of a picture that deblocks: read with VVR_TOOL_LFP_ON_DEVICE)
       if( !( o.tool_flags & VVR_TOOL_LMCS ) ) o.tool_flags &= ~(uint32_t) VVR_TOOL_LMCS_CSCALE;       // (the picture's flag and sh_lmcs_used_flag)
       sliceDbk( sl, o.deblock_beta_offset_div2, o.deblock_tc_offset_div2 );
       o.slice_type = (uint8_t) sl.getSliceType();

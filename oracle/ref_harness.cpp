@@ -775,7 +775,9 @@ int vvref_reconstruct( const vvr_picture* vp, const uint16_t* const* ref_planes,
       cu.setRootCbf( !!( c.flags & VVR_CU_ROOT_CBF ) );
       cu.setSkip( !!( c.flags & VVR_CU_SKIP ) );
       cu.setMergeFlag( !!( c.flags & VVR_CU_MERGE ) );
-      cu.setAffineFlag( !!( c.flags & VVR_CU_AFFINE ) );
+      // (a CU in sub-block merge mode carries the affine flag whether its candidate was an affine one or the SbTMVP one: CABACReader::subblock_merge_flag sets it,
+      // DecCu.cpp:746-767 only changes the merge type - and LoopFilter.cpp:920 reads the flag of the CU on the P side.  Found with the parser-fed streams, round 4)
+      cu.setAffineFlag( !!( c.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP ) ) );
       cu.setAffineType( ( c.flags & VVR_CU_AFFINE_6P ) ? AFFINEMODEL_6PARAM : AFFINEMODEL_4PARAM );
       cu.setCiipFlag( !!( c.flags & VVR_CU_CIIP ) );
       cu.setGeoFlag( !!( c.flags & VVR_CU_GEO ) );

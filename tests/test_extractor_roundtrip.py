@@ -197,7 +197,9 @@ def test_edge_tables_of_the_reference_drive_the_oracle(built, name, W, H, l2, id
 
 def test_reference_edge_tables_are_safe_for_one_launch_per_direction(built):
     """k_deblock filters all edges of a direction in one launch: on the tables the reference derives itself, neighbouring luma edges touch
-    disjoint samples, except the pair the kernel orders itself (7-sample P side 8 samples after a coding-sub-block edge)"""
+    disjoint samples.  (Until round 4 the harness built SbTMVP CUs without the affine flag the parser leaves on every sub-block merge CU; the
+    reference then allowed a 7-sample P side 8 samples behind a sub-block edge of such a CU, LoopFilter.cpp:920 - a pair the kernels still order
+    themselves, and one that no parsed stream produces.)"""
     from test_host_logic import _edge_reach
     plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
     ordered = 0
@@ -217,10 +219,9 @@ def test_reference_edge_tables_are_safe_for_one_launch_per_direction(built):
             for line in (lf if dr == 0 else lf.T):
                 edges = [(b * 4, _edge_reach(l, dr, b * 4, ctu), l) for b, l in enumerate(line) if int(l["bs"]) & 3]
                 for (e0, r0, l0), (e1, r1, l1) in zip(edges, edges[1:]):
-                    if e0 + r0[1] - 1 >= e1 - r1[2] or e1 - r1[0] <= e0 + r0[3] - 1:
-                        assert e1 - e0 == 8 and (int(l1["side_max_filt_length"]) >> 4) & 7 == 7, (name, dr, e0, e1)
-                        ordered += 1
-    assert ordered > 0
+                    assert not (e0 + r0[1] - 1 >= e1 - r1[2] or e1 - r1[0] <= e0 + r0[3] - 1), (name, dr, e0, e1)
+                    ordered += 1
+    assert ordered > 1000          # (pairs of neighbouring edges looked at)
 
 
 def _sets_differ(want, got, what, used, cmp):

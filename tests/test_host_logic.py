@@ -131,9 +131,9 @@ def _edge_reach(l, dr, pos, ctu):
 
 
 def test_luma_edges_of_one_direction_are_independent(built):
-    """k_deblock filters all edges of one direction in one launch.  That needs the sample sets of neighbouring edges to be disjoint,
-    except for the one pair the kernel orders itself: a 7-sample P side right after a coding-sub-block edge (SbTMVP CU on the
-    P side, LoopFilter.cpp:920).  Checked on generated edge tables with affine / SbTMVP / SBT / small-CU content."""
+    """k_deblock filters all edges of one direction in one launch.  That needs the sample sets of neighbouring edges to be disjoint.
+    Checked on generated edge tables with affine / SbTMVP / SBT / small-CU content.  (A 7-sample P side right behind a sub-block edge of an
+    SbTMVP CU, which the kernels order themselves, was an artefact of tables derived without the affine flag of sub-block merge CUs.)"""
     plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
     tools = abi.TOOL_SAO_LUMA | abi.TOOL_ALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS
     ordered = 0
@@ -146,7 +146,6 @@ def test_luma_edges_of_one_direction_are_independent(built):
             for line in lines:
                 edges = [(b * 4, _edge_reach(l, dr, b * 4, ctu), l) for b, l in enumerate(line) if int(l["bs"]) & 3]
                 for (e0, r0, l0), (e1, r1, l1) in zip(edges, edges[1:]):
-                    if e0 + r0[1] - 1 >= e1 - r1[2] or e1 - r1[0] <= e0 + r0[3] - 1:
-                        assert e1 - e0 == 8 and (int(l1["side_max_filt_length"]) >> 4) & 7 == 7, (pl.poc, dr, e0, e1)
-                        ordered += 1
-    assert ordered > 0          # the stream does contain the ordered pair
+                    assert not (e0 + r0[1] - 1 >= e1 - r1[2] or e1 - r1[0] <= e0 + r0[3] - 1), (pl.poc, dr, e0, e1)
+                    ordered += 1
+    assert ordered > 1000       # (pairs of neighbouring edges looked at)

@@ -891,7 +891,7 @@ struct Gen {
         const int sizeQ = d == 0 ? TQ.w : TQ.h, sizeP = d == 0 ? TP.w : TP.h;
         int lenP, lenQ;
         if( sizeP <= 4 || sizeQ <= 4 ) lenP = lenQ = 1;
-        else { lenP = sizeP >= 32 ? ( ( CP.flags & VVR_CU_AFFINE ) ? 5 : 7 ) : 3; lenQ = sizeQ >= 32 ? 7 : 3; }      // (:911 cuP->affineFlag())
+        else { lenP = sizeP >= 32 ? ( ( CP.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP ) ) ? 5 : 7 ) : 3; lenQ = sizeQ >= 32 ? 7 : 3; }      // (:911 cuP->affineFlag(): set for every sub-block merge CU, the SbTMVP ones too)
         L.side_max_filt_length = (uint8_t) ( 0x80 | ( lenP << 4 ) | lenQ );
         L.flags = 1;                                           // filterEdge luma
         // chroma edges live on the 8x8 chroma-sample grid = 16 luma samples

@@ -206,7 +206,8 @@ VVR_HD vvr_lfp lf_init_cell( const LfInitView& V, int d, int x4, int y4 )
     te = true;
     const int sizeQ = d == 0 ? TQ.w : TQ.h, sizeP = d == 0 ? TP.w : TP.h;
     if( sizeP <= 4 || sizeQ <= 4 ) lenP = lenQ = 1;
-    else { lenP = sizeP >= 32 ? ( ( CP.flags & VVR_CU_AFFINE ) && CP.pred_mode == VVR_PRED_INTER ? 5 : 7 ) : 3; lenQ = sizeQ >= 32 ? 7 : 3; }
+    // (:920 cuP->affineFlag(): a CU in sub-block merge mode carries that flag whether its candidate was an affine one or the SbTMVP one, DecCu.cpp:746-767)
+    else { lenP = sizeP >= 32 ? ( ( CP.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP ) ) && CP.pred_mode == VVR_PRED_INTER ? 5 : 7 ) : 3; lenQ = sizeQ >= 32 ? 7 : 3; }
     // boundary strength (:1094-1360): 2 next to an intra (or CIIP) block, 1 next to a coded residual, else by prediction mode and motion
     const bool ciip = ( ( CQ.pred_mode == VVR_PRED_INTER && ( CQ.flags & VVR_CU_CIIP ) ) || ( CP.pred_mode == VVR_PRED_INTER && ( CP.flags & VVR_CU_CIIP ) ) );
     if( CQ.pred_mode == VVR_PRED_INTRA || CP.pred_mode == VVR_PRED_INTRA || ciip ) bsY = ( CQ.bdpcm[0] && CP.bdpcm[0] && CQ.pred_mode == VVR_PRED_INTRA && CP.pred_mode == VVR_PRED_INTRA ) ? 0 : 2;
@@ -226,9 +227,11 @@ VVR_HD vvr_lfp lf_init_cell( const LfInitView& V, int d, int x4, int y4 )
     const int tqc = CQ.tree == VVR_TREE_LUMA ? lfi_idx( V.tuOf4C[iq], V.numTu ) : tq, tpc = CP.tree == VVR_TREE_LUMA ? lfi_idx( V.tuOf4C[ip], V.numTu ) : tp;
     if( tqc != tpc )
     {
-      const vvr_tu& TQc = V.tu[tqc]; const vvr_tu& TPc = V.tu[tpc];
-      const vvr_cu& CQc = V.cu[lfi_idx( (int) TQc.cu, V.numCu )]; const vvr_cu& CPc = V.cu[lfi_idx( (int) TPc.cu, V.numCu )];
-      if( !( TQc.cu == TPc.cu && CQc.isp_mode ) )              // (the chroma block of an ISP CU is not split)
+      const vvr_cu& CQc = V.cu[lfi_idx( (int) V.tu[tqc].cu, V.numCu )]; const vvr_cu& CPc = V.cu[lfi_idx( (int) V.tu[tpc].cu, V.numCu )];
+      // (the unsplit chroma blocks of an ISP CU - their coded block flags, their QPs - belong to its last transform unit, :1121-1123)
+      const vvr_tu& TQc = V.tu[CQc.isp_mode ? lfi_idx( (int) ( CQc.first_tu + CQc.num_tu ) - 1, V.numTu ) : tqc];
+      const vvr_tu& TPc = V.tu[CPc.isp_mode ? lfi_idx( (int) ( CPc.first_tu + CPc.num_tu ) - 1, V.numTu ) : tpc];
+      if( !( V.tu[tqc].cu == V.tu[tpc].cu && CQc.isp_mode ) )              // (the chroma block of an ISP CU is not split)
       {
         const int sizeQc = ( CQc.isp_mode ? ( d == 0 ? CQc.w : CQc.h ) : ( d == 0 ? TQc.w : TQc.h ) ) >> 1, sizePc = ( CPc.isp_mode ? ( d == 0 ? CPc.w : CPc.h ) : ( d == 0 ? TPc.w : TPc.h ) ) >> 1;
         large = sizePc >= 8 && sizeQc >= 8;
