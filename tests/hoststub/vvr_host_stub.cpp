@@ -98,6 +98,9 @@ static LfInitView lf_view( const PicDev& pic, uint32_t numCu, uint32_t numTu, co
 }
 void launch_lf_init( hipStream_t, const PicDev& pic, uint32_t numCu, uint32_t numTu, int32_t* tuOf4, int32_t* tuOf4C, vvr_motion* sbMotion, const LfSbCell* sb, int numSb, vvr_lfp* out0, vvr_lfp* out1 )
 {
+#ifdef VVT_NO_LF_STANDIN      // (tools/host_path_probe.py: time of the host stage alone)
+  return;
+#endif
   for( uint32_t t = 0; t < numTu; t++ ) lfi_map_tu( pic.tu[t], (int) t, pic.cu[lfi_idx( (int) pic.tu[t].cu, (int) numCu )], tuOf4, tuOf4C, pic.w4, pic.h4 );
   for( int i = 0; i < numSb; i++ ) if( sb[i].cell < (uint32_t) ( pic.w4 * pic.h4 ) ) sbMotion[sb[i].cell] = sb[i].m;
   const LfInitView V = lf_view( pic, numCu, numTu, tuOf4, tuOf4C, sbMotion );

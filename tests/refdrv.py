@@ -29,7 +29,7 @@ def lib():
 def reconstruct(desc, refs=None, flags=0, want_lfp=False, want_dmvr=0):
     """desc: PictureDesc; refs: {slot: [Y, Cb, Cr] uint16 arrays}. Returns dict(planes=[...], ms=..., lfp=..., dmvr=...)."""
     L = lib()
-    p = desc.c()
+    p = desc.c(keep_lfp=True)
     nslots = (max(refs.keys()) + 1) if refs else 0
     ref_ptrs = (C.POINTER(C.c_uint16) * max(1, nslots * 3))()
     keep = []
@@ -63,7 +63,7 @@ def reconstruct_threaded(desc, refs=None, threads=4):
     ThreadPool with `threads` threads (0: the calling thread), the tasks starting at LF_INIT (the harness hands over final motion).
     -> dict(planes, ms = wall clock of decompressPicture + waitForPrevDecompressedPic)"""
     L = lib()
-    p = desc.c()
+    p = desc.c(keep_lfp=True)
     ref_ptrs, keep, _ = _ref_ptrs(refs or {})
     ncomp = 3 if desc.hdr.chroma_format else 1
     outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
@@ -93,7 +93,7 @@ def _ref_ptrs(refs):
 def reconstruct_with_motion(desc, refs=None, flags=0):
     """the reference's own stages -> (planes, motion field after DecCu::TaskFinishMotionInfo as an array of abi.Motion, picture raster 4x4 grid)"""
     L = lib()
-    p = desc.c()
+    p = desc.c(keep_lfp=True)
     ref_ptrs, keep, _ = _ref_ptrs(refs)
     ncomp = 3 if desc.hdr.chroma_format else 1
     outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
@@ -125,7 +125,7 @@ def run_binding(desc, refs, backend_path, num_slots=8, flags=0):
         _bind = C.CDLL(_BIND)
         _bind.vvref_run_binding.restype = C.c_int
         _bind.vvref_last_error.restype = C.c_char_p
-    p = desc.c()
+    p = desc.c(keep_lfp=True)
     ref_ptrs, keep, nslots = _ref_ptrs(refs)
     ncomp = 3 if desc.hdr.chroma_format else 1
     outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
@@ -162,7 +162,7 @@ def run_dropin(desc, refs, backend_path, threads=2, flags=0):
         _dropin = C.CDLL(_DROPIN_HARNESS)
         _dropin.vvref_run_dropin.restype = C.c_int
         _dropin.vvref_last_error.restype = C.c_char_p
-    p = desc.c()
+    p = desc.c(keep_lfp=True)
     ref_ptrs, keep, nslots = _ref_ptrs(refs)
     ncomp = 3 if desc.hdr.chroma_format else 1
     outs = [np.zeros(desc.plane_shape(c), np.uint16) for c in range(ncomp)]
@@ -185,7 +185,7 @@ def extract(desc, refs=None, flags=0):
     Returns a dict of numpy copies of every array of the extracted vvr_picture (and its header)."""
     L = lib()
     L.vvref_extract.restype = C.POINTER(abi.Picture)
-    p = desc.c()
+    p = desc.c(keep_lfp=True)
     nslots = (max(refs.keys()) + 1) if refs else 0
     ref_ptrs = (C.POINTER(C.c_uint16) * max(1, nslots * 3))()
     keep = []
@@ -261,7 +261,7 @@ def oracle_lib():
 
 def oracle_reconstruct(desc, refs=None, flags=0):
     L = oracle_lib()
-    p = desc.c()
+    p = desc.c(keep_lfp=True)
     nslots = (max(refs.keys()) + 1) if refs else 0
     ref_ptrs = (C.POINTER(C.c_uint16) * max(1, nslots * 3))()
     keep = []

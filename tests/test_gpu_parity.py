@@ -472,6 +472,26 @@ def test_subpictures(built, sp, extra, kw):
     _run_stream(1920, 1080, 3, 2, 323, TOOLS_A | extra, intra=True, streams=3, subpics=sp, **kw)
 
 
+@pytest.mark.parametrize("name,W,H,frames,gop,seed,extra,kw", [
+    ("inter_tools", 416, 240, 9, 4, 801, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE, dict(p_intra=0.15, p_affine=0.25, p_sbtmvp=0.2, p_geo=0.15, p_ciip=0.1, p_sbt=0.2, p_coded=0.4)),
+    ("affine_spanned_on_the_device", 512, 384, 5, 4, 802, abi.TOOL_AFFINE_MV_ON_DEVICE, dict(p_intra=0.05, p_affine=0.5, p_sbtmvp=0.2, p_coded=0.3, log2_ctu=6)),
+    ("intra_tools_dual_tree", 384, 256, 5, 4, 803, abi.TOOL_LMCS, dict(p_intra=0.3, dual_tree=2.0, p_isp=0.3, p_bdpcm=0.2, p_cclm=0.3, p_mip=0.2, log2_ctu=6)),
+    ("small_cus_local_dual_tree_ibc", 264, 200, 5, 4, 804, abi.TOOL_IBC, dict(p_intra=0.3, p_ibc=0.3, min_cu_log2=2, p_split_scale=1.7, p_isp=0.2, p_sbt=0.2)),
+    ("slices_tiles_virtual_boundaries", 512, 384, 5, 4, 805, abi.TOOL_NO_LF_ACROSS_SLICES | abi.TOOL_NO_LF_ACROSS_TILES | abi.TOOL_LADF, dict(p_intra=0.2, p_affine=0.2, num_slices=3, tile_cols=2, tile_rows=2, virtual_boundaries=2 | (2 << 2) | 16, log2_ctu=6)),
+    ("subpictures", 512, 384, 5, 4, 806, 0, dict(p_intra=0.15, p_sbtmvp=0.2, tile_cols=2, tile_rows=2, subpics=1 | (2 << 1) | (1 << 3), mv_sigma=24.0, log2_ctu=6)),
+    ("monochrome_8bit", 256, 128, 5, 4, 807, 0, dict(p_intra=0.25, p_affine=0.2, chroma_format=0, bit_depth=8, log2_ctu=6)),
+    ("1080p", 1920, 1080, 3, 2, 808, abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_AFFINE_MV_ON_DEVICE, dict(p_intra=0.15, p_affine=0.2, p_sbtmvp=0.1, p_geo=0.1, streams=3)),
+])
+def test_edge_parameters_derived_on_the_device(built, name, W, H, frames, gop, seed, extra, kw):
+    """VVR_TOOL_LFP_ON_DEVICE (SURVEY 8(a) a22 on the GPU: the reference's LF_INIT task, LoopFilter::calcFilterStrengthsCTU): the description travels WITHOUT its
+    edge-parameter tables (vvdec_amd/desc.py leaves the pointers NULL under the flag), k_lf_maps / k_lf_scatter / k_lf_init derive them from the CU / TU
+    records, and the pictures are the ones the oracle reconstructs with the description's own tables (pinned to the reference's by
+    tests/test_extractor_roundtrip.py).  The same derivation on the CPU, entry by entry: tests/test_lf_init.py"""
+    kw = dict(kw)
+    geo = {k: kw.pop(k) for k in ("log2_ctu", "bit_depth", "chroma_format", "streams") if k in kw}
+    _run_stream(W, H, frames, gop, seed, TOOLS_A | abi.TOOL_LFP_ON_DEVICE | extra, intra=True, **geo, **kw)
+
+
 def test_affine_motion_spanned_on_the_device(built):
     """VVR_TOOL_AFFINE_MV_ON_DEVICE (SURVEY 8(f)-4): the back-end spans the sub-block MVs of affine CUs from the control-point MVs (PU::setAllAffineMv)
     instead of reading them from the motion field - with the motion of the affine CUs wiped from the description the pictures are the ones the oracle

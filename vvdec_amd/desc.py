@@ -61,7 +61,9 @@ class PictureDesc:
                 self.hdr.ref_slot[l][i] = slot
                 self.hdr.ref_poc[l][i] = poc
 
-    def c(self):
+    def c(self, keep_lfp=False):
+        """the C view.  keep_lfp: hand the edge-parameter tables over even when the header says the back-end derives them itself (VVR_TOOL_LFP_ON_DEVICE):
+        the checkers - oracle, reference classes - always take the tables"""
         p = abi.Picture()
         p.hdr = self.hdr
         p.num_cu, p.num_tu = len(self.cu), len(self.tu)
@@ -77,7 +79,7 @@ class PictureDesc:
         p.num_coef = len(self.coef)
         if self.motion is not None:
             p.motion = self.motion.ctypes.data_as(C.POINTER(abi.Motion))
-        if not (self.hdr.tool_flags & abi.TOOL_LFP_ON_DEVICE):       # (with the flag the back-end derives the edge parameters itself: the tables stay at home)
+        if keep_lfp or not (self.hdr.tool_flags & abi.TOOL_LFP_ON_DEVICE):       # (with the flag the back-end derives the edge parameters itself: the tables stay at home)
             for d in range(2):
                 p.lfp[d] = self.lfp[d].ctypes.data_as(C.POINTER(abi.Lfp))
         if self.sao is not None:
