@@ -125,20 +125,28 @@ void checkEdgeParameters( const vvr_glue::Extracted& E )
   const vvr_picture& p = E.pic;
   if( p.hdr.tool_flags & VVR_TOOL_DEBLOCK_OFF ) return;
   const int w4 = ( p.hdr.width + 3 ) >> 2, h4 = ( p.hdr.height + 3 ) >> 2, ctu = 1 << p.hdr.log2_ctu, ctusX = ( p.hdr.width + ctu - 1 ) / ctu, ctusY = ( p.hdr.height + ctu - 1 ) / ctu;
-  std::vector<int32_t> tuOf4( (size_t) w4 * h4, -1 ), tuOf4C( (size_t) w4 * h4, -1 );
-  for( uint32_t t = 0; t < p.num_tu; t++ ) lfi_map_tu( p.tu[t], (int) t, p.cu[p.tu[t].cu], tuOf4.data(), tuOf4C.data(), w4, h4 );
+  std::vector<LfCell> cell( (size_t) w4 * h4 ), cellC( (size_t) w4 * h4 );
+  std::vector<LfMv> mv( (size_t) w4 * h4 ); std::vector<uint32_t> ref( (size_t) w4 * h4 );
+  lf_init_maps_host( p.hdr, p.cu, p.num_cu, p.tu, p.num_tu, cell.data(), cellC.data(), mv.data(), ref.data(), w4, h4 );
+  // (the cells of CUs whose motion varies inside the CU: what the back-end's host stage lists for the device, from the description's motion field)
+  for( uint32_t k = 0; k < p.num_cu; k++ )
+  {
+    const vvr_cu& c = p.cu[k]; vvr_motion m;
+    if( lfi_cell_motion( p.hdr, c, c.x >> 2, c.y >> 2, m ) != 2 ) continue;
+    for( int y = c.y >> 2; y < std::min( ( c.y + c.h + 3 ) >> 2, h4 ); y++ ) for( int x = c.x >> 2; x < std::min( ( c.x + c.w + 3 ) >> 2, w4 ); x++ ) { mv[(size_t) y * w4 + x] = lfi_pack_mv( p.motion[(size_t) y * w4 + x] ); ref[(size_t) y * w4 + x] = lfi_pack_refs( p.motion[(size_t) y * w4 + x] ); }
+  }
   std::vector<uint16_t> ctuSubpic;
   if( p.subpics && p.num_subpics > 1 )
   {
     ctuSubpic.assign( (size_t) ctusX * ctusY, 0 );
     for( uint32_t k = 0; k < p.num_subpics; k++ ) for( int y = p.subpics[k].y0 >> p.hdr.log2_ctu; y <= p.subpics[k].y1 >> p.hdr.log2_ctu; y++ ) for( int x = p.subpics[k].x0 >> p.hdr.log2_ctu; x <= p.subpics[k].x1 >> p.hdr.log2_ctu; x++ ) ctuSubpic[(size_t) y * ctusX + x] = (uint16_t) k;
   }
-  LfInitView V; V.hdr = &p.hdr; V.cu = p.cu; V.tu = p.tu; V.tuOf4 = tuOf4.data(); V.tuOf4C = tuOf4C.data(); V.sbMotion = p.motion; V.ctuSlice = p.ctu_slice; V.ctuTile = p.ctu_tile;
-  V.ctuSubpic = ctuSubpic.empty() ? nullptr : ctuSubpic.data(); V.subpics = p.subpics; V.slices = p.slices; V.w4 = w4; V.h4 = h4; V.ctusX = ctusX; V.numTu = (int) p.num_tu; V.numCu = (int) p.num_cu;
+  LfInitView V; V.hdr = &p.hdr; V.cell = cell.data(); V.cellC = cellC.data(); V.mv = mv.data(); V.ref = ref.data(); V.ctuSlice = p.ctu_slice; V.ctuTile = p.ctu_tile;
+  V.ctuSubpic = ctuSubpic.empty() ? nullptr : ctuSubpic.data(); V.subpics = p.subpics; V.slices = p.slices; V.w4 = w4; V.h4 = h4; V.ctusX = ctusX;
   long bad = 0;
   for( int d = 0; d < 2; d++ ) for( int y = 0; y < h4; y++ ) for( int x = 0; x < w4; x++ )
   {
-    const vvr_lfp a = p.lfp[d][(size_t) y * w4 + x], b = lf_init_cell( V, d, x, y );
+    const vvr_lfp a = p.lfp[d][(size_t) y * w4 + x], b = lf_init_cell( V, d, x, y, cell[(size_t) y * w4 + x] );
     const bool grid = p.hdr.chroma_format && ( ( ( d == 0 ? x : y ) << 2 ) & 15 ) == 0;
     bool differ = ( a.bs & 3 ) != ( b.bs & 3 );
     if( a.bs & 3 ) differ |= a.qp[0] != b.qp[0] || ( a.side_max_filt_length & 0x77 ) != ( b.side_max_filt_length & 0x77 );

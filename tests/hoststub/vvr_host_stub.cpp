@@ -90,21 +90,16 @@ void launch_deblock_tile( hipStream_t, const PicDev&, DevPlanes, DevPlanes, int,
 // LF_INIT has a functional stand-in: the kernels are thin loops around vvr_lf_init.h, which compiles for the host as it is - so the whole path (the
 // host's list of sub-block motion, the layout of the device-written parts, the derivation itself) is checked against the reference's tables without a GPU
 static vvr_lfp* g_lastLfp[2] = { nullptr, nullptr }; static int g_lastLfpCells = 0;
-static LfInitView lf_view( const PicDev& pic, uint32_t numCu, uint32_t numTu, const int32_t* tuOf4, const int32_t* tuOf4C, const vvr_motion* sbMotion )
-{
-  LfInitView V; V.hdr = &pic.hdr; V.cu = pic.cu; V.tu = pic.tu; V.tuOf4 = tuOf4; V.tuOf4C = tuOf4C; V.sbMotion = sbMotion; V.ctuSlice = pic.ctuSlice; V.ctuTile = pic.ctuTile;
-  V.ctuSubpic = pic.ctuSubpic; V.subpics = pic.subpics; V.slices = pic.slices; V.w4 = pic.w4; V.h4 = pic.h4; V.ctusX = pic.ctus_x; V.numTu = (int) numTu; V.numCu = (int) numCu;
-  return V;
-}
-void launch_lf_init( hipStream_t, const PicDev& pic, uint32_t numCu, uint32_t numTu, int32_t* tuOf4, int32_t* tuOf4C, vvr_motion* sbMotion, const LfSbCell* sb, int numSb, vvr_lfp* out0, vvr_lfp* out1 )
+void launch_lf_init( hipStream_t, const PicDev& pic, uint32_t numCu, uint32_t numTu, LfCell* cell, LfCell* cellC, LfMv* mv, uint32_t* ref, const LfSbCell* sb, int numSb, vvr_lfp* out0, vvr_lfp* out1 )
 {
 #ifdef VVT_NO_LF_STANDIN      // (tools/host_path_probe.py: time of the host stage alone)
   return;
 #endif
-  for( uint32_t t = 0; t < numTu; t++ ) lfi_map_tu( pic.tu[t], (int) t, pic.cu[lfi_idx( (int) pic.tu[t].cu, (int) numCu )], tuOf4, tuOf4C, pic.w4, pic.h4 );
-  for( int i = 0; i < numSb; i++ ) if( sb[i].cell < (uint32_t) ( pic.w4 * pic.h4 ) ) sbMotion[sb[i].cell] = sb[i].m;
-  const LfInitView V = lf_view( pic, numCu, numTu, tuOf4, tuOf4C, sbMotion );
-  for( int y = 0; y < pic.h4; y++ ) for( int x = 0; x < pic.w4; x++ ) { out0[(size_t) y * pic.w4 + x] = lf_init_cell( V, 0, x, y ); out1[(size_t) y * pic.w4 + x] = lf_init_cell( V, 1, x, y ); }
+  lf_init_maps_host( pic.hdr, pic.cu, numCu, pic.tu, numTu, cell, cellC, mv, ref, pic.w4, pic.h4 );
+  for( int i = 0; i < numSb; i++ ) if( sb[i].cell < (uint32_t) ( pic.w4 * pic.h4 ) ) { mv[sb[i].cell] = lfi_pack_mv( sb[i].m ); ref[sb[i].cell] = lfi_pack_refs( sb[i].m ); }
+  LfInitView V; V.hdr = &pic.hdr; V.cell = cell; V.cellC = cellC; V.mv = mv; V.ref = ref; V.ctuSlice = pic.ctuSlice; V.ctuTile = pic.ctuTile;
+  V.ctuSubpic = pic.ctuSubpic; V.subpics = pic.subpics; V.slices = pic.slices; V.w4 = pic.w4; V.h4 = pic.h4; V.ctusX = pic.ctus_x;
+  lf_init_tables_host( V, out0, out1 );
   g_lastLfp[0] = out0; g_lastLfp[1] = out1; g_lastLfpCells = pic.w4 * pic.h4;
 }
 bool sao_alf_fused( const PicDev& ) { return true; }

@@ -409,7 +409,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   // (the tiles of plain, BDOF and DMVR CUs are written on the device from the CU records: the host only counted them)
   if( q->numMcCus ) launch_expand_mc( s, q->pic, q->mcCus, q->numMcCus, q->mcDev, q->bdofItems, q->dmvrItems );
   // LF_INIT (DecLibRecon.cpp:807-829): the edge parameters of the deblocking passes from the CU / TU records, where the caller leaves them to the back-end
-  if( q->lfpOnDevice && dbOn ) timed( K_LF_INIT, [&]{ launch_lf_init( s, q->pic, q->numCu, q->numTu, q->lfTuOf4, q->lfTuOf4C, q->lfMotion, q->lfSb, q->numLfSb, q->lfpDev[0], q->lfpDev[1] ); } );
+  if( q->lfpOnDevice && dbOn ) timed( K_LF_INIT, [&]{ launch_lf_init( s, q->pic, q->numCu, q->numTu, q->lfCell, q->lfCellC, q->lfMv, q->lfRef, q->lfSb, q->numLfSb, q->lfpDev[0], q->lfpDev[1] ); } );
   if( q->numMc + q->numMcDev ) timedOn( K_MC, s, q->bytes[K_MC] - q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, P, q->mcItems, q->numMc, q->mcDev, q->numMcDev, 0 ); } );
   if( q->numBdofItems ) timedOn( K_MC, s, q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, P, nullptr, 0, q->bdofItems, q->numBdofItems, 1 ); } );
   if( q->numDmvrItems )
@@ -978,7 +978,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
     const size_t estimate = alignUp( w4 * h4 * ( 2 * sizeof( vvr_lfp ) + 14 ) + ( 1u << 20 ), 1 << 16 );
     const size_t dmvrInts = 2 * ( (size_t) cfg->max_width * cfg->max_height / 128 + 1 );
     // (device side: room for the cell maps and the motion of sub-block CUs as well, should the pictures leave the edge parameters to the back-end)
-    const size_t estimateDev = estimate + alignUp( w4 * h4 * ( 2 * sizeof( int32_t ) + sizeof( vvr_motion ) ), 1 << 16 );
+    const size_t estimateDev = estimate + alignUp( w4 * h4 * ( 2 * 16 + sizeof( vvr_motion ) ), 1 << 16 );
     c->ringLargest = estimateDev; c->ringLargestHost = estimate;
     for( size_t i = 0; i < c->ring.size() && ok; i++ )
     {

@@ -130,7 +130,7 @@ void launch_mc     ( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPl
 void launch_expand_mc( hipStream_t s, const PicDev& pic, const McCuRef* cus, int numCus, McItem* plain, McItem* bdof, McItem* dmvr );
 void launch_itrans ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const TbItem* items, int numItems, int sizeClass );
 // the deblocking edge parameters of the picture from its CU / TU records (vvr_lf_init.h): cell maps, motion of sub-block CUs, one thread per cell and direction
-void launch_lf_init( hipStream_t s, const PicDev& pic, uint32_t numCu, uint32_t numTu, int32_t* tuOf4, int32_t* tuOf4C, vvr_motion* sbMotion, const struct LfSbCell* sbCells, int numSbCells, vvr_lfp* out0, vvr_lfp* out1 );
+void launch_lf_init( hipStream_t s, const PicDev& pic, uint32_t numCu, uint32_t numTu, struct LfCell* cell, struct LfCell* cellC, struct LfMv* mv, uint32_t* ref, const struct LfSbCell* sbCells, int numSbCells, vvr_lfp* out0, vvr_lfp* out1 );
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir );
 void launch_deblock_tile( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst, int dir, bool lmcs );      // one direction out of place (tiles); vertical edges: inverse LMCS in the load
 void launch_sao    ( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst );

@@ -28,10 +28,10 @@ struct vvr_prepared {
   int      intraWorkgroups = 0;                            // workgroups the intra stage is launched with (the dependency front they can keep busy)
   IntraItem* resiItems = nullptr; int numResi = 0;         // scaled chroma residuals of inter blocks (k_resi_add); with them the stage runs as luma units, k_resi_add, chroma units
   int      numLumaUnits = 0, intraWorkgroupsChroma = 0;    // (the first numLumaUnits entries of `units` are the luma units then)
-  // deblocking edge parameters derived on the device (VVR_TOOL_LFP_ON_DEVICE): room behind the uploaded image for the cell -> transform unit maps of both
-  // trees, the motion of the cells of sub-block CUs (scattered from lfSb) and the two tables; pic.lfp points at the tables
+  // deblocking edge parameters derived on the device (VVR_TOOL_LFP_ON_DEVICE): room behind the uploaded image for the per-cell records of both
+  // trees, the motion field as the filter sees it (from the CU records; sub-block CUs: scattered from lfSb) and the two tables; pic.lfp points at the tables
   bool     lfpOnDevice = false;
-  int32_t* lfTuOf4 = nullptr; int32_t* lfTuOf4C = nullptr; vvr_motion* lfMotion = nullptr;
+  struct LfCell* lfCell = nullptr; struct LfCell* lfCellC = nullptr; struct LfMv* lfMv = nullptr; uint32_t* lfRef = nullptr;
   const struct LfSbCell* lfSb = nullptr; int numLfSb = 0;
   vvr_lfp* lfpDev[2] = { nullptr, nullptr };
   uint32_t numCu = 0, numTu = 0;

@@ -2820,46 +2820,95 @@ void launch_deblock_tile( hipStream_t st, const PicDev& pic, DevPlanes src, DevP
 // =====================================================================================================================
 // k_lf_* — the reference's LF_INIT task (LoopFilter::calcFilterStrengthsCTU, LoopFilter.cpp:495-1360; DecLibRecon.cpp:807-829) for pictures that leave the
 // deblocking edge parameters to the back-end (VVR_TOOL_LFP_ON_DEVICE).  The derivation itself is vvr_lf_init.h (one function per 4x4 cell and direction, also
-// compiled for the host by the tests); here: the cell -> transform unit maps of both trees (one thread per transform unit), the motion of the cells of CUs
-// whose motion varies inside the CU (one thread per cell the host listed), the two tables (one thread per cell, 8-byte stores).  HBM-bound and small: 12 MB
-// written and 4-8 MB read back per 4K picture against 8.3 MB of tables that no longer cross PCIe.
+// compiled for the host by the tests); here: the per-cell records of both trees and the motion field as the filter sees it (one thread per transform unit; one per
+// cell of the host's list for CUs whose motion varies inside the CU) in one launch, the two tables (one thread per cell) in another.  HBM-bound and small: about
+// 27 MB written and 10 MB read back per 4K B picture against 8.3 MB of tables that no longer cross PCIe.
 // =====================================================================================================================
-__global__ __launch_bounds__( 256 ) void k_lf_maps( const vvr_cu* __restrict__ cu, const vvr_tu* __restrict__ tu, int numCu, int numTu, int32_t* __restrict__ tuOf4, int32_t* __restrict__ tuOf4C, int w4, int h4 )
+// eight lanes per transform unit: its record into the cells it covers, the motion of those cells where the CU's record holds it (three stores per cell: 16-byte
+// record, 16 bytes of vectors, the reference indices).  A transform unit of up to eight cells is written by its own lanes, a cell each; the larger ones of a
+// wavefront - eight at most - are written by all 64 lanes together, one after the other (a 64x64 unit has 256 cells), from values broadcast out of the owner's
+// registers: nothing is loaded in those loops.  (One lane per unit left 64 such rounds per wavefront on a fifth of the chip's SIMDs: 34 us instead of 9.)
+// Behind the transform units: one thread per cell of the host's list of sub-block motion.
+__global__ __launch_bounds__( 256 ) void k_lf_maps( PicDev pic, int numCu, int numTu, LfCell* __restrict__ cell, LfCell* __restrict__ cellC, LfMv* __restrict__ mvs, uint32_t* __restrict__ refs,
+                                                   const LfSbCell* __restrict__ sb, int numSb )
 {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if( t >= numTu ) return;
-  const vvr_tu T = tu[t];
-  const vvr_cu& C = cu[lfi_idx( (int) T.cu, numCu )];
-  if( C.tree == VVR_TREE_CHROMA && !tuOf4C ) return;
-  lfi_map_tu( T, t, C, tuOf4, tuOf4C, w4, h4 );
+  const int gt = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, t = gt >> 3, sub = gt & 7;
+  const int w4 = pic.w4, h4 = pic.h4;
+  if( t >= numTu )
+  {
+    const int i = gt - 8 * numTu;
+    if( i < numSb ) { const LfSbCell e = sb[i]; if( e.cell < (uint32_t) ( w4 * h4 ) ) { const LfMv v = lfi_pack_mv( e.m ); *reinterpret_cast<uint4*>( &mvs[e.cell] ) = make_uint4( v.v[0][0], v.v[0][1], v.v[1][0], v.v[1][1] ); refs[e.cell] = lfi_pack_refs( e.m ); } }
+  }
+  LfCell rec; rec.a = rec.b = rec.c = rec.d = 0;
+  int x0 = 0, y0 = 0, nx = 0, ny = 0, cuIdx = 0, cuX4 = 0, cuY4 = 0;
+  int kind = 0;               // bit 0..1: motion of the cells (0 none, 1 the same for all of them: mo, 2 from the host's list, 3 spanned per cell from the control points); bit 2: chroma tree
+  uint32_t mo[5] = { 0, 0, 0, 0, 0 };
+  if( t < numTu )
+  {
+    const vvr_tu T = pic.tu[t];
+    cuIdx = lfi_idx( (int) T.cu, numCu );
+    const vvr_cu& C = pic.cu[cuIdx];
+    if( lfi_tu_owns_cells( T ) && !( C.tree == VVR_TREE_CHROMA && !cellC ) )
+    {
+      rec = lfi_pack_cell( T, t, C, pic.tu[lfi_idx( (int) ( C.first_tu + C.num_tu ) - 1, numTu )] );
+      x0 = T.x >> 2; y0 = T.y >> 2; nx = min( ( T.x + T.w + 3 ) >> 2, w4 ) - x0; ny = min( ( T.y + T.h + 3 ) >> 2, h4 ) - y0;
+      if( nx <= 0 || ny <= 0 ) nx = ny = 0;
+      cuX4 = C.x >> 2; cuY4 = C.y >> 2;
+      vvr_motion m;
+      kind = lfi_cell_motion( pic.hdr, C, x0, y0, m );
+      if( kind == 1 && C.pred_mode == VVR_PRED_INTER && ( C.flags & VVR_CU_AFFINE ) ) kind = 3;
+      if( kind == 1 ) { mo[0] = (uint32_t) m.mv[0][0]; mo[1] = (uint32_t) m.mv[0][1]; mo[2] = (uint32_t) m.mv[1][0]; mo[3] = (uint32_t) m.mv[1][1]; mo[4] = lfi_pack_refs( m ); }
+      if( C.tree == VVR_TREE_CHROMA ) kind |= 4;
+    }
+  }
+  auto put = [&]( const LfCell& r, int cu, int cx4, int cy4, int k, const uint32_t* mv, int x, int y )
+  {
+    const LfCell q = lfi_cell_at( r, cx4, cy4, x, y );
+    const size_t at = (size_t) y * w4 + x;
+    *reinterpret_cast<uint4*>( &( ( k & 4 ) ? cellC : cell )[at] ) = make_uint4( q.a, q.b, q.c, q.d );
+    if( ( k & 3 ) == 1 ) { *reinterpret_cast<uint4*>( &mvs[at] ) = make_uint4( mv[0], mv[1], mv[2], mv[3] ); refs[at] = mv[4]; }
+    else if( ( k & 3 ) == 3 )
+    {   // (affine CU, VVR_TOOL_AFFINE_MV_ON_DEVICE: per cell from the control points)
+      vvr_motion m; lfi_cell_motion( pic.hdr, pic.cu[cu], x, y, m );
+      *reinterpret_cast<uint4*>( &mvs[at] ) = make_uint4( (uint32_t) m.mv[0][0], (uint32_t) m.mv[0][1], (uint32_t) m.mv[1][0], (uint32_t) m.mv[1][1] ); refs[at] = lfi_pack_refs( m );
+    }
+  };
+  const int n = nx * ny;
+  if( sub < n && n <= 8 ) put( rec, cuIdx, cuX4, cuY4, kind, mo, x0 + sub % nx, y0 + sub / nx );
+  unsigned long long big = __ballot( n > 8 && sub == 0 );
+  while( big )
+  {
+    const int L = __builtin_amdgcn_readfirstlane( __ffsll( (long long) big ) - 1 ); big &= big - 1;
+#define BC( V ) ( (int) __builtin_amdgcn_readlane( (int) ( V ), L ) )
+    LfCell r; r.a = (uint32_t) BC( rec.a ); r.b = (uint32_t) BC( rec.b ); r.c = (uint32_t) BC( rec.c ); r.d = (uint32_t) BC( rec.d );
+    const int bx0 = BC( x0 ), by0 = BC( y0 ), bnx = BC( nx ), bn = BC( n ), bcu = BC( cuIdx ), bcx = BC( cuX4 ), bcy = BC( cuY4 ), bk = BC( kind );
+    uint32_t bm[5]; for( int e = 0; e < 5; e++ ) bm[e] = (uint32_t) BC( mo[e] );
+#undef BC
+    for( int i = lane; i < bn; i += 64 ) put( r, bcu, bcx, bcy, bk, bm, bx0 + i % bnx, by0 + i / bnx );
+  }
 }
-__global__ __launch_bounds__( 256 ) void k_lf_scatter( const LfSbCell* __restrict__ sb, int n, vvr_motion* __restrict__ sbMotion, int cells )
-{
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if( i >= n ) return;
-  const LfSbCell e = sb[i];
-  if( e.cell < (uint32_t) cells ) sbMotion[e.cell] = e.m;
-}
-__global__ __launch_bounds__( 256 ) void k_lf_init( PicDev pic, int numCu, int numTu, const int32_t* __restrict__ tuOf4, const int32_t* __restrict__ tuOf4C, const vvr_motion* __restrict__ sbMotion,
+// one thread per cell: both directions (the cell's record is read once, as one 16-byte load)
+__global__ __launch_bounds__( 256 ) void k_lf_init( PicDev pic, const LfCell* __restrict__ cell, const LfCell* __restrict__ cellC, const LfMv* __restrict__ mvs, const uint32_t* __restrict__ refs,
                                                    vvr_lfp* __restrict__ out0, vvr_lfp* __restrict__ out1 )
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if( i >= pic.w4 * pic.h4 ) return;
   const int y4 = i / pic.w4, x4 = i - y4 * pic.w4;
-  LfInitView V; V.hdr = &pic.hdr; V.cu = pic.cu; V.tu = pic.tu; V.tuOf4 = tuOf4; V.tuOf4C = tuOf4C; V.sbMotion = sbMotion; V.ctuSlice = pic.ctuSlice; V.ctuTile = pic.ctuTile;
-  V.ctuSubpic = pic.ctuSubpic; V.subpics = pic.subpics; V.slices = pic.slices; V.w4 = pic.w4; V.h4 = pic.h4; V.ctusX = pic.ctus_x; V.numTu = numTu; V.numCu = numCu;
-  static_assert( sizeof( vvr_lfp ) == 8, "one 8-byte store per table entry" );
-  const vvr_lfp a = lf_init_cell( V, 0, x4, y4 ), b = lf_init_cell( V, 1, x4, y4 );
+  LfInitView V; V.hdr = &pic.hdr; V.cell = cell; V.cellC = cellC; V.mv = mvs; V.ref = refs; V.ctuSlice = pic.ctuSlice; V.ctuTile = pic.ctuTile;
+  V.ctuSubpic = pic.ctuSubpic; V.subpics = pic.subpics; V.slices = pic.slices; V.w4 = pic.w4; V.h4 = pic.h4; V.ctusX = pic.ctus_x;
+  static_assert( sizeof( vvr_lfp ) == 8 && sizeof( LfCell ) == 16, "one 8-byte store per table entry, one 16-byte load per cell record" );
+  const uint4 qv = *reinterpret_cast<const uint4*>( &cell[i] );
+  LfCell Q; Q.a = qv.x; Q.b = qv.y; Q.c = qv.z; Q.d = qv.w;
+  const vvr_lfp a = lf_init_cell( V, 0, x4, y4, Q ), b = lf_init_cell( V, 1, x4, y4, Q );
   *reinterpret_cast<uint2*>( &out0[i] ) = *reinterpret_cast<const uint2*>( &a );
   *reinterpret_cast<uint2*>( &out1[i] ) = *reinterpret_cast<const uint2*>( &b );
 }
-void launch_lf_init( hipStream_t s, const PicDev& pic, uint32_t numCu, uint32_t numTu, int32_t* tuOf4, int32_t* tuOf4C, vvr_motion* sbMotion, const LfSbCell* sbCells, int numSbCells, vvr_lfp* out0, vvr_lfp* out1 )
+void launch_lf_init( hipStream_t s, const PicDev& pic, uint32_t numCu, uint32_t numTu, LfCell* cell, LfCell* cellC, LfMv* mv, uint32_t* ref, const LfSbCell* sbCells, int numSbCells, vvr_lfp* out0, vvr_lfp* out1 )
 {
   if( !numTu || !numCu ) return;
   const int cells = pic.w4 * pic.h4;
-  hipLaunchKernelGGL( k_lf_maps, dim3( ( numTu + 255 ) / 256 ), dim3( 256 ), 0, s, pic.cu, pic.tu, (int) numCu, (int) numTu, tuOf4, tuOf4C, pic.w4, pic.h4 );
-  if( numSbCells && sbMotion ) hipLaunchKernelGGL( k_lf_scatter, dim3( ( numSbCells + 255 ) / 256 ), dim3( 256 ), 0, s, sbCells, numSbCells, sbMotion, cells );
-  hipLaunchKernelGGL( k_lf_init, dim3( ( cells + 255 ) / 256 ), dim3( 256 ), 0, s, pic, (int) numCu, (int) numTu, (const int32_t*) tuOf4, (const int32_t*) tuOf4C, (const vvr_motion*) sbMotion, out0, out1 );
+  hipLaunchKernelGGL( k_lf_maps, dim3( ( 8 * numTu + numSbCells + 255 ) / 256 ), dim3( 256 ), 0, s, pic, (int) numCu, (int) numTu, cell, cellC, mv, ref, sbCells, numSbCells );
+  hipLaunchKernelGGL( k_lf_init, dim3( ( cells + 255 ) / 256 ), dim3( 256 ), 0, s, pic, (const LfCell*) cell, (const LfCell*) cellC, (const LfMv*) mv, (const uint32_t*) ref, out0, out1 );
 }
 
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )

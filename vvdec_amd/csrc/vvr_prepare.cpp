@@ -1522,10 +1522,11 @@ void PrepScratch::layout( PinnedRanges* pinned )
   {
     const size_t cells = (size_t) w4 * h4;
     iL0 = add( nullptr, sizeof( vvr_lfp ) * cells ); iL1 = add( nullptr, sizeof( vvr_lfp ) * cells );
-    iLfTu = add( nullptr, sizeof( int32_t ) * cells ); iLfTuC = ncomp == 3 ? add( nullptr, sizeof( int32_t ) * cells ) : -1;
-    iLfMotion = lfSb.empty() ? -1 : add( nullptr, sizeof( vvr_motion ) * cells );
-    // the maps written and read, the two tables written, the records read once
-    bytes[K_LF_INIT] = (double) cells * ( ( ncomp == 3 ? 16 : 8 ) + 2 * sizeof( vvr_lfp ) ) + (double) sizeof( vvr_cu ) * p->num_cu + (double) sizeof( vvr_tu ) * p->num_tu + (double) lfSb.size() * ( sizeof( LfSbCell ) + sizeof( vvr_motion ) );
+    iLfTu = add( nullptr, sizeof( LfCell ) * cells ); iLfTuC = ncomp == 3 ? add( nullptr, sizeof( LfCell ) * cells ) : -1;
+    iLfMotion = add( nullptr, ( sizeof( LfMv ) + sizeof( uint32_t ) ) * cells );
+    // the per-cell records written and read (chroma tree: as far as there is one - not counted), the motion of inter cells written (read at edges the motion decides:
+    // not counted), the two tables written, the CU / TU records read once
+    bytes[K_LF_INIT] = (double) cells * ( 2 * sizeof( LfCell ) + ( h.slice_type != 2 ? sizeof( vvr_motion ) : 0 ) + 2 * sizeof( vvr_lfp ) ) + (double) sizeof( vvr_cu ) * p->num_cu + (double) sizeof( vvr_tu ) * p->num_tu + (double) lfSb.size() * sizeof( LfSbCell );
   }
 }
 
@@ -1738,7 +1739,7 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   d.affMotion = (const vvr_motion*) at( S.iAffMv );
   d.lfp[0] = (const vvr_lfp*) at( S.iL0 ); d.lfp[1] = (const vvr_lfp*) at( S.iL1 );
   q.lfpOnDevice = S.lfpOnDevice; q.lfpDev[0] = (vvr_lfp*) at( S.iL0 ); q.lfpDev[1] = (vvr_lfp*) at( S.iL1 );
-  q.lfTuOf4 = (int32_t*) at( S.iLfTu ); q.lfTuOf4C = (int32_t*) at( S.iLfTuC ); q.lfMotion = (vvr_motion*) at( S.iLfMotion );
+  q.lfCell = (LfCell*) at( S.iLfTu ); q.lfCellC = (LfCell*) at( S.iLfTuC ); q.lfMv = (LfMv*) at( S.iLfMotion ); q.lfRef = q.lfMv ? (uint32_t*) ( q.lfMv + (size_t) S.w4 * S.h4 ) : nullptr;      // (vectors, then reference indices)
   q.lfSb = (const LfSbCell*) at( S.iLfSb ); q.numLfSb = (int) S.lfSb.size(); q.numCu = p->num_cu; q.numTu = p->num_tu;
   d.sao = (const vvr_sao_ctu*) at( S.iSao ); d.alf = (const vvr_alf_ctu*) at( S.iAlf ); d.alf_params = (const vvr_alf_params*) at( S.iAlfP );
   d.lmcs = (const vvr_lmcs_params*) at( S.iLmcs ); d.scaling = (const vvr_scaling_list*) at( S.iSl ); d.wp = (const vvr_wp_params*) at( S.iWp ); d.rpr = (const vvr_rpr_params*) at( S.iRpr );
