@@ -153,12 +153,17 @@ def dropin_host_cost(cfg_name, seed, gop, threads=8):
         "    refdrv.run_dropin(d, refs, vvdec_amd._LIBPATH, threads=%d)\n"
     ) % (ROOT, ROOT, cfg_name, gop, gop, seed, seed, threads)
     try:
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
-        ms = re.findall(r"host ms per picture: MIDER ([0-9.]+), LF_INIT ([0-9.]+), flatten ([0-9.]+), submit\+device ([0-9.]+), planes back ([0-9.]+)", r.stderr)
+        pat = r"host ms per picture: MIDER ([0-9.]+), LF_INIT ([0-9.]+), flatten ([0-9.]+), submit\+device ([0-9.]+), planes back ([0-9.]+)"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)            # the drop-in as shipped: LF_INIT left to the back-end
+        ms = re.findall(pat, r.stderr)
         if not ms:
             return None
         first, m = ms[0], ms[-1]
+        r1 = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180, env=dict(os.environ, VVDEC_AMD_LF_INIT="1"))      # ... and with the reference's own LF_INIT (round 3)
+        m1 = (re.findall(pat, r1.stderr) or [None])[-1]
         return {"lf_init": round(float(m[1]) / threads, 2), "lf_init_cpu_ms_summed_over_the_ctu_row_tasks": float(m[1]), "flatten": float(m[2]), "planes_back": float(m[4]), "pool_threads": threads,
+                "lf_init_where": "on the device (VVR_TOOL_LFP_ON_DEVICE, k_lf_init): the drop-in neither runs LoopFilter::calcFilterStrengthsCTU nor copies its tables",
+                "with_the_reference_lf_init_instead": None if not m1 else {"lf_init": round(float(m1[1]) / threads, 2), "lf_init_cpu_ms_summed_over_the_ctu_row_tasks": float(m1[1]), "flatten": float(m1[2]), "how": "VVDEC_AMD_LF_INIT=1"},
                 "first_picture_of_the_process": {"lf_init": round(float(first[1]) / threads, 2), "flatten": float(first[2]), "planes_back": float(first[4])},
                 "what": "ms per picture (one B picture of this stream) the reference-side half of the drop-in spends on the host: the reference's own edge-parameter derivation (one task per CTU row on the decoder's pool: lf_init = the tasks' summed time / pool threads), "
                         "the walk over the reference's CU / TU lists into the records of include/vvr.h, the finished planes copied back into the Picture's buffers.  The picture runs three times, "

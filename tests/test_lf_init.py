@@ -108,3 +108,38 @@ def test_tables_are_not_uploaded(stub):
         ctx.close()
     saved = sizes[0] - sizes[1]
     assert 0.8 * 16 * d.w4 * d.h4 < saved <= 16 * d.w4 * d.h4 + 512, sizes
+
+
+def test_parser_fed_pictures_against_the_reference_lf_init():
+    """every picture of the bitstreams in tests/bitstreams (written by tools/mini_vvenc.py, parsed by the reference's own parser): the drop-in decoder library in
+    its self-check mode (VVDEC_AMD_LF_INIT=2, integration/DecLibReconDropIn.cpp) runs the reference's LF_INIT task AND the back-end's derivation (the source
+    k_lf_init is compiled from) on the flattened picture and counts the table entries the deblocking filter would see differently - none.  This is where the
+    generated pictures of the tests above cannot reach: what the real parser leaves in CodingStructure (found this way in round 4: SbTMVP CUs carry the
+    affine flag, LoopFilter.cpp:920; the chroma QPs of an ISP CU live in its last transform unit, :1121-1123).  No GPU: the back-end is the stand-in runtime."""
+    import os, re, sys
+    import refdrv
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import dropin_decode as dd
+    streams = dd.find_streams(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bitstreams"))
+    if not refdrv.dropin_available() or not os.path.exists(dd.APP_DROPIN) or not streams:
+        pytest.skip("oracle/_ref/vvdecapp_dropin not built (needs /root/reference) or no bitstreams")
+    stub_lib = T.build_stub()
+    env0 = os.environ.get("VVDEC_AMD_LF_INIT")
+    os.environ["VVDEC_AMD_LF_INIT"] = "2"
+    try:
+        checked = differ = 0
+        bad = []
+        for b in streams:
+            r, _ = dd.run_app(dd.APP_DROPIN, ["-b", b, "-t", "4", "-v", "0"], preload=stub_lib)
+            m = re.findall(r"edge parameters: (\d+) entries checked against the reference's LF_INIT, (\d+) differ", r.stdout + r.stderr)
+            c, d = sum(int(a) for a, _ in m), sum(int(x) for _, x in m)
+            checked += c
+            differ += d
+            if d or (not c and "nodeblock" not in b):            # (a stream that switches deblocking off has no table)
+                bad.append((os.path.basename(b), c, d))
+    finally:
+        if env0 is None:
+            del os.environ["VVDEC_AMD_LF_INIT"]
+        else:
+            os.environ["VVDEC_AMD_LF_INIT"] = env0
+    assert not bad and differ == 0 and checked > 2_000_000, (checked, differ, bad[:5])

@@ -17,7 +17,7 @@ if configs:
                         "gfx950 correction of the MI355X guide applied (tools/pmc_summary.py); keyed by bench configuration and kernel", "configs": configs},
               open(os.path.join(P, rnd + "_pmc_traffic.json"), "w"), indent=1)
 for a, b in (("deblock_counters.json", "_deblock_counters.json"), ("host.txt", "_gpu_box_host.txt"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
-             ("bench_4k_steps20_warmup5.json", "_bench_steps20_warmup5.json"), ("bench_4k_steps64_warmup16.json", "_bench_steps64_warmup16.json"),
+             ("bench_4k_steps20_warmup5.json", "_bench_steps20_warmup5.json"), ("bench_4k_steps64_warmup16.json", "_bench_steps64_warmup16.json"), ("bench_4k_lf_init_host.json", "_bench_steps20_lf_init_host.json"),
              ("bench_allintra.json", "_bench_allintra.json"), ("bench_8k.json", "_bench_8k.json"), ("gpu_parity_suite.log", "_gpu_parity_suite.log"),
              ("kernels_alone.txt", "_kernels_alone.txt"), ("intra_block_phases.txt", "_intra_block_phases.txt"), ("dropin_decode.json", "_dropin_decode.json")):
     if os.path.exists(os.path.join(src, a)):

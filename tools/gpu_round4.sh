@@ -11,7 +11,7 @@ for cfg in 4k allintra 8k; do
     echo "== pmc $cfg $ctr"; (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $R/$out/pmc_${cfg}_$ctr -o pmc -- python $R/bench.py --config $cfg $PMCARGS > $R/$out/bench_pmc_${cfg}_$ctr.json 2> $R/$out/pmc_${cfg}_$ctr.err)
   done
   f=$(find $out/pmc_${cfg}_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_${cfg}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-  python tools/pmc_summary.py "$f" "$w" $out/pmc_traffic_$cfg.json "python bench.py --config $cfg $PMCARGS" | grep -E "k_intra|k_mc |k_alf|k_deblock|k_sao|k_itrans" | head -12
+  python tools/pmc_summary.py "$f" "$w" $out/pmc_traffic_$cfg.json "python bench.py --config $cfg $PMCARGS" | grep -E "k_intra|k_mc |k_alf|k_deblock|k_sao|k_itrans|k_lf" | head -14
 done
 echo "== GPU suite"; timeout 900 python -m pytest tests -m gpu -q > $out/gpu_parity_suite.log 2>&1; tail -3 $out/gpu_parity_suite.log
 echo "== kernels alone"; PROBE_PICTURES=3 timeout 300 python tools/intra_probe.py > $out/kernels_alone.txt 2>&1; cat $out/kernels_alone.txt
@@ -23,9 +23,10 @@ echo "== drop-in libvvdec.so on the parser-fed bitstreams"; timeout 600 python t
 echo "== bench lines"
 timeout 400 python bench.py --steps 20 --warmup 5 > $out/bench_4k_steps20_warmup5.json 2> $out/bench_4k.err; tail -c 300 $out/bench_4k_steps20_warmup5.json
 timeout 400 python bench.py > $out/bench_4k_steps64_warmup16.json 2> $out/bench_4k_64.err
+timeout 400 python bench.py --steps 20 --warmup 5 --lf-init host --no-cpu-baseline > $out/bench_4k_lf_init_host.json 2> $out/bench_4k_lfhost.err
 timeout 500 python bench.py --config allintra --verify 2 > $out/bench_allintra.json 2> $out/bench_allintra.err
 timeout 600 python bench.py --config 8k --steps 32 --warmup 8 --verify 1 > $out/bench_8k.json 2> $out/bench_8k.err
-for f in $out/bench_4k_steps20_warmup5.json $out/bench_4k_steps64_warmup16.json $out/bench_allintra.json $out/bench_8k.json; do python - "$f" <<'PY'
+for f in $out/bench_4k_steps20_warmup5.json $out/bench_4k_steps64_warmup16.json $out/bench_4k_lf_init_host.json $out/bench_allintra.json $out/bench_8k.json; do python - "$f" <<'PY'
 import json,sys
 try:
     d=json.load(open(sys.argv[1])); c=d['config']; r=d['roofline']

@@ -7,7 +7,7 @@ from vvdec_amd import abi, synth, stream
 import bench
 W, H = 3840, 2160
 tools = (abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS | abi.TOOL_LFNST |
-         abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE)
+         abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | abi.TOOL_LFP_ON_DEVICE)
 if os.environ.get("PROBE_NO_CS"):
     tools &= ~abi.TOOL_LMCS_CSCALE
 plans, nslots = stream.ra_plan(17, gop=16, seed_poc0_is_external=False)
