@@ -305,6 +305,7 @@ def main():
     ap.add_argument("--intra-period", type=int, default=-1, help="an IRAP picture every N pictures (multiple of --gop); default: the configuration's")
     ap.add_argument("--irap-lookahead", type=int, default=8, help="IRAP pictures are submitted N pictures ahead of their decoding-order position (they depend on nothing)")
     ap.add_argument("--lf-init", choices=["device", "host"], default="device", help="device: the back-end derives the deblocking edge parameters itself (VVR_TOOL_LFP_ON_DEVICE, the reference's LF_INIT task on the GPU; the description's tables stay on the host); host: the generator's tables are uploaded (rounds 1-3)")
+    ap.add_argument("--affine-mv", choices=["device", "host"], default="device", help="device: VVR_TOOL_AFFINE_MV_ON_DEVICE - the back-end spans the sub-block vectors of affine CUs from the control points itself (k_mc_affine, k_lf_maps); host: they travel with the picture (the motion field's cells under affine CUs)")
     ap.add_argument("--pageable-records", action="store_true", help="keep the host records in ordinary (pageable) memory: the library stages them through its pinned ring")
     ap.add_argument("--no-picture-sharding", action="store_true", help="N > 1: skip the additional pass that shards ONE stream by picture over the ranks")
     ap.add_argument("--picture-sharding-timeout", type=int, default=150, help="N > 1: seconds after which the picture-sharding pass is given up and the line is printed without it")
@@ -340,7 +341,7 @@ def main():
     W, H, mix, ip_default, cfg_text = CONFIGS[a.config]
     if a.width:
         W, H = a.width, a.height
-    tools = _tools(abi) | (abi.TOOL_LFP_ON_DEVICE if a.lf_init == "device" else 0)
+    tools = _tools(abi) | (abi.TOOL_LFP_ON_DEVICE if a.lf_init == "device" else 0) | (abi.TOOL_AFFINE_MV_ON_DEVICE if a.affine_mv == "device" else 0)
     K, Wm = a.steps, a.warmup
     intra_period = ip_default if a.intra_period < 0 else a.intra_period
     plans, nslots, orders = stream_plan(a.config, a.gop, intra_period, a.irap_lookahead, a.slots, K, Wm)
@@ -495,7 +496,7 @@ def main():
                "config": {"workload": "%s, %dx%d, CTU 128%s; timed: K pictures through vvr_submit from host records (validation, work lists on %d library threads, H2D of %.1f MB per picture, all kernels); %d pre-roll + W warm-up pictures untimed; %d IRAP picture(s) in the timed window"
                                       % (cfg_text, W, H, "" if a.config == "allintra" else ", hierarchical-B GOP %d, IRAP every %d pictures, submitted %d pictures ahead of its decoding-order position" % (a.gop, intra_period, a.irap_lookahead),
                                          a.host_threads, upload_mb, first - Wm, n_irap),
-                          "timed_path": "vvr_submit(host records)", "lf_init": "k_lf_init (VVR_TOOL_LFP_ON_DEVICE: edge parameters derived on the device, no table uploaded)" if a.lf_init == "device" else "tables supplied by the host", "host_records_in": "pageable memory (staged by the library)" if a.pageable_records else "pinned host memory of the context (vvr_host_alloc): cu / tu / coef / lfp arrays are copied to HBM from where the generator wrote them", "host_threads": a.host_threads, "host_cores": os.cpu_count(),
+                          "timed_path": "vvr_submit(host records)", "affine_sub_block_mvs": "spanned on the device from the control points (VVR_TOOL_AFFINE_MV_ON_DEVICE)" if a.affine_mv == "device" else "supplied by the host (motion field)", "lf_init": "k_lf_init (VVR_TOOL_LFP_ON_DEVICE: edge parameters derived on the device, no table uploaded)" if a.lf_init == "device" else "tables supplied by the host", "host_records_in": "pageable memory (staged by the library)" if a.pageable_records else "pinned host memory of the context (vvr_host_alloc): cu / tu / coef / lfp arrays are copied to HBM from where the generator wrote them", "host_threads": a.host_threads, "host_cores": os.cpu_count(),
                           "value_is": "median of %d runs of the K-picture window, each from the first picture of the stream (pre-roll and warm-up untimed)" % len(dts),
                           "value_samples_fps": [round(world * K / x, 1) for x in dts], "value_min_fps": round(world * K / max(dts), 2), "value_max_fps": round(world * K / min(dts), 2),
                           "value_irap_lookahead_0": round(world * K / float(np.median(dts0)), 2) if dts0 else None,
