@@ -614,6 +614,14 @@ int PrepScratch::mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string&
     for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
     {
       const vvr_tu& tu = p->tu[t];
+      if( ( tu.comp_mask & 1 ) && ( tu.comp_mask & 6 ) && !cu.isp_mode )
+      {
+        // (the usual unit: both channels cover the same cells - one walk over its rows, the channel maps lie half the array apart)
+        const int x0 = tu.x >> 2, x1 = std::min( ( tu.x + tu.w + 3 ) >> 2, w4 ), y1 = std::min( ( tu.y + tu.h + 3 ) >> 2, h4 );
+        const size_t chroma = orderIdx( 1, 0, 0 ) - orderIdx( 0, 0, 0 );
+        for( int y = tu.y >> 2; y < y1; y++ ) { int32_t* row = &order[orderIdx( 0, x0 << 2, y << 2 )]; std::fill( row, row + ( x1 - x0 ), (int32_t) t ); std::fill( row + chroma, row + chroma + ( x1 - x0 ), (int32_t) t ); }
+        continue;
+      }
       for( int chn = 0; chn < 2; chn++ )
       {
         if( chn == 0 && !( tu.comp_mask & 1 ) ) continue;
@@ -790,25 +798,45 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
             const int ctuX = cu.x >> h.log2_ctu, ctuY = cu.y >> h.log2_ctu;
             const int mrl = ( comp || isIbcCu ) ? 0 : cu.multi_ref_idx;
             uint32_t lastKey = 0xffffffffu;
-            auto touch = [&]( int k, int xc, int yc )   // component k, component coordinates of a sample that is read
+            // (returns the block found at the sample when it belongs to this band's map, else -1: the walks along a reference line skip the rest of that block)
+            auto touch = [&]( int k, int xc, int yc ) -> int32_t   // component k, component coordinates of a sample that is read
             {
               const int sh = k ? 1 : 0, lx = xc << sh, ly = yc << sh;
-              if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return;
+              if( lx < 0 || ly < 0 || lx >= h.width || ly >= h.height ) return -1;
               if( ly < partTopY )
               {
                 // a cell of the band above (its last cell row: nothing else is ever read across a CTU row): looked up when the bands are joined
-                if( ( ly >> 2 ) != ( partTopY >> 2 ) - 1 ) { partBad = true; return; }
+                if( ( ly >> 2 ) != ( partTopY >> 2 ) - 1 ) { partBad = true; return -1; }
                 const uint32_t pe = ( (uint32_t) k << 16 ) | (uint32_t) ( lx >> 2 );
-                if( !pending.empty() && pending.back() == pe && pool.size() > IH.p0 && pool.back() == ( 0x80000000u | (uint32_t) ( pending.size() - 1 ) ) ) return;
+                if( !pending.empty() && pending.back() == pe && pool.size() > IH.p0 && pool.back() == ( 0x80000000u | (uint32_t) ( pending.size() - 1 ) ) ) return -1;
                 pool.push_back( 0x80000000u | (uint32_t) pending.size() ); pending.push_back( pe ); lastKey = 0xffffffffu;
-                return;
+                return -1;
               }
               const int32_t d = itemAtGet( k, cellIdx( lx >> 2, ly >> 2 ) );
-              if( d < 0 ) return;
+              if( d < 0 ) return -1;
               const uint32_t key = ( (uint32_t) k << 28 ) | (uint32_t) d;
-              if( key == lastKey || ( k == comp && (uint32_t) d == myId ) ) return;      // (neighbouring cells mostly belong to the same block)
+              if( key == lastKey || ( k == comp && (uint32_t) d == myId ) ) return d;      // (neighbouring cells mostly belong to the same block)
               lastKey = key;
               if( std::find( pool.begin() + IH.p0, pool.end(), key ) == pool.end() ) pool.push_back( key );
+              return d;
+            };
+            // a reference line, cell by cell - but a block found on the line is known with its extent: the cells it covers further along the line name it again
+            // and are passed over (blocks whose edges lie on the cell grid; the narrow ones of ISP CUs and 2-wide chroma blocks share cells and are walked)
+            auto walk = [&]( int n, bool alongX, int xc, int yc )
+            {
+              for( int k = 0; k < n; )
+              {
+                const int32_t d = touch( comp, alongX ? xc + k : xc, alongX ? yc : yc + k );
+                int nk = k + unit;
+                if( d >= 0 )
+                {
+                  const IntraItem& pb = intra[comp][d];
+                  const int b0 = alongX ? pb.x : pb.y, bs = 1 << ( alongX ? pb.lw : pb.lh );
+                  const bool ispBlock = !comp && ( pb.flags & ~IT_F_RESI ) == IT_F_ISP;
+                  if( !( ( b0 << cs ) & 3 ) && !( ( bs << cs ) & 3 ) && !ispBlock ) nk = std::max( nk, b0 + bs - ( alongX ? xc : yc ) );
+                }
+                k = nk;
+              }
             };
             {
               // bounding box of everything the kernel's reference fill may read for this block (whole top / left lines incl. padding sources)
@@ -823,8 +851,8 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
             if( !fastCtu[ctuOfCu] )
             {
             if( it.nTL ) touch( comp, rx0 - 1 - mrl, ry0 - 1 - mrl );
-            for( int k = 0; k < it.nA * unit; k += unit ) touch( comp, rx0 + k, ry0 - 1 - mrl );
-            for( int k = 0; k < it.nL * unit; k += unit ) touch( comp, rx0 - 1 - mrl, ry0 + k );
+            walk( it.nA * unit, true, rx0, ry0 - 1 - mrl );
+            walk( it.nL * unit, false, rx0 - 1 - mrl, ry0 );
             if( ispL && ( x0 != rx0 || y0 != ry0 ) ) touch( 0, cu.isp_mode == 2 ? x0 - 1 : x0, cu.isp_mode == 2 ? y0 : y0 - 1 );   // ISP: the previous partition
             if( isIbcCu )
             {
