@@ -865,8 +865,11 @@ def test_i_pictures_are_prepared_by_the_workers_together(stub):
             hashes.append(stub.vvt_take_h2d_hash())
         stub.vvr_destroy(ctx)
         return hashes
-    T = TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE
-    for (W, H, l2, kw) in ((1920, 1080, 7, dict(p_cclm=0.3, p_isp=0.2, p_mip=0.2)), (832, 480, 6, dict(dual_tree=1.0, p_cclm=0.3)), (416, 240, 5, dict())):
+    # (the last case: edge parameters left to the back-end - the list of sub-block motion the bands build for k_lf_maps is appended in band order too)
+    for (W, H, l2, kw) in ((1920, 1080, 7, dict(p_cclm=0.3, p_isp=0.2, p_mip=0.2)), (832, 480, 6, dict(dual_tree=1.0, p_cclm=0.3)), (416, 240, 5, dict()),
+                           (1280, 720, 7, dict(extra=abi.TOOL_LFP_ON_DEVICE, p_intra=0.1, p_sbtmvp=0.2, p_geo=0.15, p_affine=0.2))):
+        kw = dict(kw)
+        T = TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE | kw.pop("extra", 0)
         one = run(0, W, H, l2, 9, 4, 4, T, **kw)
         assert len(set(one)) == len(one)
         for threads in (2, 3, 8):
