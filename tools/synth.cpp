@@ -943,7 +943,14 @@ struct Gen {
         if( cu.pred_mode != VVR_PRED_INTER || !( cu.flags & ( VVR_CU_AFFINE | VVR_CU_SBTMVP ) ) || cu.tree == VVR_TREE_CHROMA ) continue;
         const int perp = d == 0 ? cu.w : cu.h, parl = d == 0 ? cu.h : cu.w;
         auto cell = [&]( int pp, int pl ) { const int x = d == 0 ? cu.x + pp : cu.x + pl, y = d == 0 ? cu.y + pl : cu.y + pp; return ( y >> 2 ) * w4 + ( x >> 2 ); };
-        auto isTe = [&]( int pp, int pl ) { return pp >= 0 && pp < perp && ( B.lfp[d][cell( pp, pl )].side_max_filt_length & 0x80 ) != 0; };
+        // (in a CU with sub-block edges the marker of a transform edge is only written where that edge may be filtered, LoopFilter.cpp:960-981 under bValue)
+        auto isTe = [&]( int pp, int pl )
+        {
+          if( pp < 0 || pp >= perp || !( B.lfp[d][cell( pp, pl )].side_max_filt_length & 0x80 ) ) return false;
+          const int cx = ( d == 0 ? cu.x + pp : cu.x + pl ) >> 2, cy = ( d == 0 ? cu.y + pl : cu.y + pp ) >> 2;
+          if( onVirtualBoundary( d, cx, cy ) ) return false;
+          return pp > 0 || lfMayCross( ctuOfPos( cx << 2, cy << 2 ), ctuOfPos( ( d == 0 ? cx - 1 : cx ) << 2, ( d == 0 ? cy : cy - 1 ) << 2 ) );
+        };
         for( int pl = 0; pl < parl; pl += 4 ) for( int pp = 0; pp < perp; pp += 8 )
         {
           if( ( d == 0 ? cu.x : cu.y ) + pp == 0 ) continue;                       // picture boundary

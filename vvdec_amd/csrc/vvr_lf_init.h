@@ -268,12 +268,19 @@ VVR_HD vvr_lfp lf_init_cell( const LfInitView& V, int d, int x4, int y4, const L
     const int perp = lfc_cu_size( Q, d ), pp = lfc_off( Q, d ) << 2;
     if( ( pp & 7 ) == 0 )
     {
-      // is the cell k cells further along the perpendicular direction (inside this CU) at a transform edge?
+      // is the cell k cells further along the perpendicular direction (inside this CU) MARKED as a transform edge?  In a CU with sub-block edges the reference
+      // writes marker and lengths of a transform edge only where that edge may be filtered (LoopFilter.cpp:960-981 under bValue): not on a virtual boundary, not on
+      // a slice / tile / sub-picture boundary the filter may not cross (the CU's own border).  Found by tools/fuzz_lf_init.py.
       auto isTe = [&]( int k ) -> bool
       {
         const int q = pp + 4 * k;
         if( q < 0 || q >= perp || posPerp + 4 * k == 0 ) return false;
-        return ( V.cell[iq + k * step].a >> 4 ) != ( V.cell[iq + ( k - 1 ) * step].a >> 4 );
+        if( ( V.cell[iq + k * step].a >> 4 ) == ( V.cell[iq + ( k - 1 ) * step].a >> 4 ) ) return false;
+        const int cx = d == 0 ? x4 + k : x4, cy = d == 0 ? y4 : y4 + k;
+        if( lfi_on_virtual_boundary( h, d, cx, cy ) ) return false;
+        if( q > 0 ) return true;
+        const int l2 = h.log2_ctu - 2, qx = d == 0 ? cx - 1 : cx, qy = d == 0 ? cy : cy - 1;
+        return lfi_may_cross( V, ( cy >> l2 ) * V.ctusX + ( cx >> l2 ), ( qy >> l2 ) * V.ctusX + ( qx >> l2 ) );
       };
       if( te )
       {
