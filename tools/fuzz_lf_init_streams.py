@@ -35,6 +35,12 @@ def main():
             m = re.findall(r"edge parameters: (\d+) entries checked against the reference's LF_INIT, (\d+) differ", out)
             c, d = sum(int(a) for a, _ in m), sum(int(x) for _, x in m)
             streams += 1
+            # (anything the back-end's host stage says about a stream the reference parsed: a refusal of something valid would show here)
+            said = [l for l in out.splitlines() if "vvdec_amd" in l and "edge parameters" not in l]
+            if said:
+                keep = os.path.join(tmp, "said_%s_seed%d.bit" % (name, seed))
+                open(keep, "wb").write(data)
+                print("SAID", name, "seed", seed, "rc", r.returncode, said[:2], keep, flush=True)
             if not c:
                 undecodable += 1
                 continue
