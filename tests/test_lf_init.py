@@ -143,3 +143,28 @@ def test_parser_fed_pictures_against_the_reference_lf_init():
         else:
             os.environ["VVDEC_AMD_LF_INIT"] = env0
     assert not bad and differ == 0 and checked > 2_000_000, (checked, differ, bad[:5])
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_dropin_lf_init_modes_on_the_stand_in_runtime(mode):
+    """the drop-in decodes a stream end to end on the stand-in runtime with LF_INIT left to the back-end (the default: no edge-parameter table exists on the host) and
+    with the reference's own LF_INIT (VVDEC_AMD_LF_INIT=1: its tables are copied and handed over): both ways every picture passes the back-end's checks and comes back"""
+    import os, re, sys
+    import refdrv
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import dropin_decode as dd
+    bit = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bitstreams", "mini_all_tools_ctu128_384x256", "mini_all_tools_ctu128_384x256.bit")
+    if not refdrv.dropin_available() or not os.path.exists(dd.APP_DROPIN) or not os.path.exists(bit):
+        pytest.skip("oracle/_ref/vvdecapp_dropin not built (needs /root/reference) or the stream missing")
+    env0 = os.environ.get("VVDEC_AMD_LF_INIT")
+    os.environ["VVDEC_AMD_LF_INIT"] = mode
+    try:
+        r, _ = dd.run_app(dd.APP_DROPIN, ["-b", bit, "-t", "4", "-v", "3"], preload=T.build_stub())
+    finally:
+        if env0 is None:
+            del os.environ["VVDEC_AMD_LF_INIT"]
+        else:
+            os.environ["VVDEC_AMD_LF_INIT"] = env0
+    out = r.stdout + r.stderr
+    frames, _ = dd.frames_and_fps(out)
+    assert r.returncode == 0 and frames and frames >= 5 and "vvdec_amd:" not in out, (r.returncode, out[-600:])
