@@ -612,24 +612,29 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
   {
     memset( &A, 0, sizeof( A ) );
     const APS* const* apss = sl.getAlfAPSs();
+    // (an APS id the slice header did not carry - chroma ALF or CC-ALF of a component switched off - is -1: never an index.  Found by tools/fuzz_dropin_on_the_oracle.py,
+    // round 4: a single-slice picture with CC-ALF on for one chroma component only read apss[-1])
+    auto apsAt = [&]( int id ) -> const APS* { return id >= 0 && id < ALF_CTB_MAX_NUM_APS ? apss[id] : nullptr; };
     A.num_luma_aps = (uint8_t) sl.getNumAlfAps();
     for( int i = 0; i < sl.getNumAlfAps() && i < VVR_MAX_ALF_APS; i++ )
     {
-      const AlfSliceParam& p = apss[sl.getAlfApsIdsLuma()[i]]->getAlfAPSParam();
+      const APS* la = apsAt( sl.getAlfApsIdsLuma()[i] );
+      if( !la ) continue;
+      const AlfSliceParam& p = la->getAlfAPSParam();
       for( int cl = 0; cl < VVR_ALF_CLASSES; cl++ ) for( int k = 0; k < MAX_NUM_ALF_LUMA_COEFF - 1; k++ )      // (the centre tap is implied)
       { A.luma_coeff[i][cl][k] = p.lumaCoeffFinal[cl * MAX_NUM_ALF_LUMA_COEFF + k]; A.luma_clip[i][cl][k] = p.lumaClippFinal[cl * MAX_NUM_ALF_LUMA_COEFF + k]; }
     }
-    if( chroma && ( sl.getAlfEnabledFlag( COMPONENT_Cb ) || sl.getAlfEnabledFlag( COMPONENT_Cr ) || !multi ) && apss[sl.getAlfApsIdChroma()] )
+    if( chroma && ( sl.getAlfEnabledFlag( COMPONENT_Cb ) || sl.getAlfEnabledFlag( COMPONENT_Cr ) || !multi ) && apsAt( sl.getAlfApsIdChroma() ) )
     {
-      const AlfSliceParam& p = apss[sl.getAlfApsIdChroma()]->getAlfAPSParam();
+      const AlfSliceParam& p = apsAt( sl.getAlfApsIdChroma() )->getAlfAPSParam();
       for( int alt = 0; alt < VVR_ALF_MAX_CHR_ALT && alt < p.numAlternativesChroma; alt++ ) for( int k = 0; k < MAX_NUM_ALF_CHROMA_COEFF - 1; k++ )
       { A.chroma_coeff[alt][k] = p.chromaCoeff[alt * MAX_NUM_ALF_CHROMA_COEFF + k]; A.chroma_clip[alt][k] = p.chrmClippFinal[alt * MAX_NUM_ALF_CHROMA_COEFF + k]; }
     }
     if( chroma && ( h.tool_flags & VVR_TOOL_CCALF ) )
       for( int k = 0; k < 2; k++ )
       {
-        if( multi && !sl.getCcAlfEnabledFlag( k + 1 ) ) continue;
-        const APS* aps = apss[k == 0 ? sl.getCcAlfCbApsId() : sl.getCcAlfCrApsId()];
+        if( !sl.getCcAlfEnabledFlag( k + 1 ) ) continue;
+        const APS* aps = apsAt( k == 0 ? sl.getCcAlfCbApsId() : sl.getCcAlfCrApsId() );
         if( !aps ) continue;
         const CcAlfFilterParam& cc = aps->getCcAlfAPSParam();
         for( int fI = 0; fI < VVR_CCALF_FILTERS; fI++ ) for( int j = 0; j < VVR_CCALF_TAPS + 1 && j < MAX_NUM_CC_ALF_CHROMA_COEFF; j++ ) A.ccalf_coeff[k][fI][j] = cc.ccAlfCoeff[k][fI][j];

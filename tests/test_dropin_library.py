@@ -207,3 +207,39 @@ def test_pictures_with_scaled_reference_pictures_through_the_dropin_class():
         assert [p.shape for p in planes] == [d.plane_shape(c) for c in range(len(planes))]
         inter = d.motion["ref_idx"].max(axis=1) >= 0
         assert inter.any() and np.array_equal(motion["ref_idx"][inter], d.motion["ref_idx"][inter])
+
+
+def _oracle_backend():
+    """tests/oraclestub: the ten vvr_* entry points the drop-in calls, served by the CPU oracle (test infrastructure) -> path of the built library"""
+    src = os.path.join(HERE, "oraclestub", "vvr_oracle_backend.cpp")
+    lib = os.path.join(HERE, "oraclestub", "libvvr_oracle_backend.so")
+    odir = os.path.join(HERE, "..", "oracle")
+    refdrv.oracle_lib()
+    deps = [src, os.path.join(HERE, "..", "include", "vvr.h"), os.path.join(HERE, "..", "vvdec_amd", "csrc", "vvr_lf_init.h"), os.path.join(odir, "libvvoracle.so")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(p) for p in deps):
+        tmp = "%s.%d.tmp" % (lib, os.getpid())
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-w", src, "-L" + odir, "-lvvoracle", "-Wl,-rpath," + os.path.abspath(odir), "-o", tmp])
+        os.replace(tmp, lib)
+    return lib
+
+
+def test_parser_fed_streams_end_to_end_on_the_cpu_oracle():
+    """every stream of tests/bitstreams decoded by the reference's application on the DROP-IN library with the CPU ORACLE behind vvdec::DecLibRecon
+    (tests/oraclestub binds the oracle to the C ABI; no GPU, no product kernel): output MD5 and the hash SEI of every picture equal the reference decoder's.
+    What this pins without a GPU: the flattening of what the real parser leaves in CodingStructure (integration/vvr_extract.h, DecLibReconDropIn.cpp) and the
+    back-end's derivation of the deblocking edge parameters (vvr_lf_init.h, the source of k_lf_init - the drop-in does not run the reference's LF_INIT) on parsed
+    pictures; the HIP kernels are pinned to the same oracle by tests/test_gpu_parity.py, and the same streams go through them in test_decodes_conformance_bitstreams"""
+    dd, d = _conformance_streams()
+    if d is None or not os.path.exists(dd.APP_DROPIN):
+        pytest.skip("no bitstreams or oracle/_ref/vvdecapp_dropin not built (needs /root/reference)")
+    keep = dd.BACKEND
+    dd.BACKEND = _oracle_backend()
+    try:
+        bad = []
+        for b in dd.find_streams(d):
+            r = dd.decode_stream(b, threads=4, with_reference=False)
+            if not r["ok"]:
+                bad.append((r["stream"], r["dropin"].get("tail") or r["dropin_dph"].get("tail")))
+    finally:
+        dd.BACKEND = keep
+    assert not bad, bad
