@@ -515,8 +515,11 @@ Picture* DecLibRecon::waitForPrevDecompressedPic()
       // milliseconds goes to sleep until a task is added (ThreadPool.cpp:241-256), and nothing tells it that the device is done.  The thread that
       // asks for the picture is the one that may wait: for the hand-over, then for the device (vvr_wait), then it wakes the pool with an empty task.
       {
+        // (the hand-over is announced on jobCv; a picture whose PARSING failed never gets that far - the pool drops its row, submit and finish tasks as their
+        // barriers carry the parser's exception, which ends up on reconDone with nobody to announce it: looked for every few milliseconds, isBlocked() rethrows it.
+        // Found by tools/fuzz_dropin_on_the_oracle.py: a stream with a broken first picture, which the reference decoder skips, left this thread waiting for ever)
         std::unique_lock<std::mutex> jl( I.jobMu );
-        I.jobCv.wait( jl, [&]{ return I.job.load( std::memory_order_acquire ) != -1 || !m_currDecompPic->reconDone.isBlocked(); } );
+        while( !( I.job.load( std::memory_order_acquire ) != -1 || !m_currDecompPic->reconDone.isBlocked() ) ) I.jobCv.wait_for( jl, std::chrono::milliseconds( 2 ) );
       }
       const int job = I.job.load( std::memory_order_acquire );
       if( job >= 0 ) vvr_wait( I.ctx->ctx, job );
