@@ -6,6 +6,9 @@
 // on as many streams as one likes and without a GPU (tests/test_dropin_library.py, tools/fuzz_dropin_on_the_oracle.py).  No sample is computed by product code here.
 #include <cstdint>
 #include <cstring>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -69,6 +72,31 @@ API int vvr_submit( vvr_context* c, const vvr_picture* pic )
   const vvr_pic_header& h = pic->hdr;
   if( h.out_slot < 0 || h.out_slot >= (int) c->slots.size() ) { c->err = "bad output slot"; return VVR_ERR_PARAMETER; }
   vvr_picture P = *pic;
+  std::vector<vvr_cu> cuCopy;
+  if( const char* e = getenv( "VVR_ORACLE_NO_DMVR" ) )      // developer aid: 1 = every DMVR CU predicted without the refinement; 2 = only those whose MVs leave the picture by more than a CTU
+  {
+    cuCopy.assign( pic->cu, pic->cu + pic->num_cu );
+    for( auto& u : cuCopy )
+    {
+      if( u.mc_mode != VVR_MC_DMVR && u.mc_mode != VVR_MC_DMVR_BDOF ) continue;
+      bool far = false;
+      for( int l = 0; l < 2; l++ ) { const int x = u.x + ( u.mv[l][0][0] >> 4 ); far |= x < -64 - 8 || x + u.w > h.width + 64 + 8; }
+      if( atoi( e ) == 1 || far ) u.mc_mode = u.mc_mode == VVR_MC_DMVR_BDOF ? VVR_MC_BDOF : VVR_MC_BI;
+    }
+    P.cu = cuCopy.data();
+  }
+  if( const char* e = getenv( "VVR_ORACLE_DUMP_AT" ) )      // developer aid: "poc,x,y" -> the CU that covers the luma sample
+  {
+    int poc = 0, x = 0, y = 0;
+    if( sscanf( e, "%d,%d,%d", &poc, &x, &y ) == 3 && poc == h.poc )
+      for( uint32_t k = 0; k < pic->num_cu; k++ )
+      {
+        const vvr_cu& u = pic->cu[k];
+        if( u.tree == VVR_TREE_CHROMA || x < u.x || y < u.y || x >= u.x + u.w || y >= u.y + u.h ) continue;
+        fprintf( stderr, "[oracle back-end] POC %d CU %u at (%d,%d) %dx%d pred %d flags %04x mc_mode %d inter_dir %d ref %d %d mv0 (%d,%d) mv1 (%d,%d) bcw %d imv %d qp %d tool_flags %08x wrap %d\n", h.poc, k, u.x, u.y, u.w, u.h,
+                 u.pred_mode, u.flags, u.mc_mode, u.inter_dir, u.ref_idx[0], u.ref_idx[1], u.mv[0][0][0], u.mv[0][0][1], u.mv[1][0][0], u.mv[1][0][1], u.bcw_idx, u.imv, u.qp, h.tool_flags, h.wrap_offset );
+      }
+  }
   // the edge parameters left to the back-end: derived with the source the device kernel is compiled from
   std::vector<vvr_lfp> lf[2];
   if( ( h.tool_flags & VVR_TOOL_LFP_ON_DEVICE ) && !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF ) )
@@ -120,11 +148,31 @@ API int vvr_submit( vvr_context* c, const vvr_picture* pic )
   const int job = c->nextJob++;
   {
     std::lock_guard<std::mutex> ol( g_oracle );
-    if( vvo_reconstruct( &P, refs.data(), outp, 0 ) != 0 ) { c->err = std::string( "oracle: " ) + vvo_last_error(); c->status[job] = VVR_ERR_PARAMETER; return job; }
+    // developer aid (VVR_ORACLE_USE_REF=<path of oracle/_ref/libvvref.so>): the reference's own classes, rebuilt from the description by oracle/ref_harness.cpp, instead
+    // of the oracle - tells a flaw of the flattening (both differ from the decoder) from one of the oracle's arithmetic (only the oracle differs)
+    typedef int ( *RefFn )( const vvr_picture*, const uint16_t* const*, uint16_t* const*, vvr_lfp* const*, int32_t*, int, double* );
+    static RefFn refFn = []() -> RefFn { const char* e = getenv( "VVR_ORACLE_USE_REF" ); void* hnd = e ? dlopen( e, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND ) : nullptr; return hnd ? (RefFn) dlsym( hnd, "vvref_reconstruct" ) : nullptr; }();
+    if( refFn ) { if( refFn( &P, refs.data(), outp, nullptr, nullptr, 1 /* SIMD */, nullptr ) != 0 ) { typedef const char* ( *ErrFn )(); static ErrFn ef = (ErrFn) dlsym( dlopen( getenv( "VVR_ORACLE_USE_REF" ), RTLD_NOW | RTLD_NOLOAD ), "vvref_last_error" ); c->err = std::string( "reference harness: " ) + ( ef ? ef() : "?" ); c->status[job] = VVR_ERR_PARAMETER; return job; } }
+    else if( vvo_reconstruct( &P, refs.data(), outp, 0 ) != 0 ) { c->err = std::string( "oracle: " ) + vvo_last_error(); c->status[job] = VVR_ERR_PARAMETER; return job; }
     std::vector<int32_t>& d = c->dmvr[job];
     d.assign( 2 * (size_t) ( ( h.width / 16 + 1 ) * ( h.height / 16 + 1 ) * 4 ), 0 );
     const uint32_t n = vvo_get_dmvr( d.data(), (uint32_t) ( d.size() / 2 ) );
     d.resize( 2 * (size_t) n );
+  }
+  if( const char* dir = getenv( "VVR_ORACLE_DUMP_DIR" ) )
+  {
+    // developer aid: the picture as the back-end got it (arrays as raw files, the layout of tests/golden_io.py), its reference pictures and what came out -
+    // tools/replay_oracle_dump.py runs the reference's classes (oracle/_ref harness) and the oracle on it in a process of their own
+    const int w4 = ( h.width + 3 ) >> 2, h4 = ( h.height + 3 ) >> 2, ctu = 1 << h.log2_ctu, numCtu = ( ( h.width + ctu - 1 ) / ctu ) * ( ( h.height + ctu - 1 ) / ctu );
+    auto put = [&]( const char* name, const void* p, size_t n ) { if( !p || !n ) return; char f[512]; snprintf( f, sizeof( f ), "%s/poc%d_%s.bin", dir, h.poc, name ); FILE* o = fopen( f, "wb" ); if( o ) { fwrite( p, 1, n, o ); fclose( o ); } };
+    put( "hdr", &P.hdr, sizeof( P.hdr ) ); put( "cu", P.cu, sizeof( vvr_cu ) * P.num_cu ); put( "tu", P.tu, sizeof( vvr_tu ) * P.num_tu ); put( "ctu_first_cu", P.ctu_first_cu, sizeof( uint32_t ) * ( numCtu + 1 ) );
+    put( "coef", P.coef, sizeof( int16_t ) * P.num_coef ); put( "lfp0", P.lfp[0], sizeof( vvr_lfp ) * w4 * h4 ); put( "lfp1", P.lfp[1], sizeof( vvr_lfp ) * w4 * h4 );
+    put( "motion", P.motion, sizeof( vvr_motion ) * w4 * h4 ); put( "sao", P.sao, sizeof( vvr_sao_ctu ) * numCtu ); put( "alf", P.alf, sizeof( vvr_alf_ctu ) * numCtu );
+    put( "alf_sets", P.alf_params, sizeof( vvr_alf_params ) * ( P.num_alf_sets ? P.num_alf_sets : 1 ) ); put( "lmcs", P.lmcs, sizeof( vvr_lmcs_params ) );
+    put( "wp_sets", P.wp, sizeof( vvr_wp_params ) * ( P.num_wp_sets ? P.num_wp_sets : 1 ) ); put( "scaling", P.scaling, sizeof( vvr_scaling_list ) );
+    for( int l = 0; l < 2 && h.slice_type != 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ ) for( int k = 0; k < 3; k++ )
+    { const int sl = h.ref_slot[l][i]; char nm[64]; snprintf( nm, sizeof( nm ), "ref_%d_%d", sl, k ); put( nm, c->slots[sl].p[k].data(), sizeof( uint16_t ) * c->slots[sl].p[k].size() ); }
+    for( int k = 0; k < 3; k++ ) { char nm[64]; snprintf( nm, sizeof( nm ), "out_%d", k ); put( nm, out.p[k].data(), sizeof( uint16_t ) * out.p[k].size() ); }
   }
   c->slots[h.out_slot] = std::move( out );
   c->status[job] = VVR_OK;
