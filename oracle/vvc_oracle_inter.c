@@ -459,7 +459,7 @@ static int dmvr_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* 
   for( int l = 0; l < 2; l++ )
   {
     int mv[2] = { mergeMv[l][0], mergeMv[l][1] };
-    clip_mv_w( mv, cu->x, cu->y, cu->w, W, Hh, ctu );     /* (with wrap-around the start MVs are clipped per sub-block, below: the period shift depends on the block) */
+    clip_mv_w( mv, cu->x, cu->y, cu->w, W, Hh, ctu );
     mv[0] -= 2 << 4; mv[1] -= 2 << 4;
     bilinear_block( ref[l], cu->x + ( mv[0] >> 4 ), cu->y + ( mv[1] >> 4 ), mv[0] & 15, mv[1] & 15, ew, eh, bd, bil[l], ew );
   }
@@ -469,19 +469,9 @@ static int dmvr_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* 
   {
     const int sx = cu->x + xs, sy = cu->y + ys;
     const pel* c0 = bil[0] + ( 2 + ys ) * ew + 2 + xs; const pel* c1 = bil[1] + ( 2 + ys ) * ew + 2 + xs;
-    int bst = ew;
-    pel lbil[2][20 * 20];
-    if( g_wrapOff )
-    {   /* xinitMC runs per sub-CU (:1804-1845): start MVs clipped against the sub-block, bilinear prediction of the sub-block extended by 2 samples */
-      for( int l = 0; l < 2; l++ )
-      {
-        int smv[2] = { mergeMv[l][0], mergeMv[l][1] };
-        clip_mv_w( smv, sx, sy, dx, W, Hh, ctu );
-        smv[0] -= 2 << 4; smv[1] -= 2 << 4;
-        bilinear_block( ref[l], sx + ( smv[0] >> 4 ), sy + ( smv[1] >> 4 ), smv[0] & 15, smv[1] & 15, dx + 4, dy + 4, bd, lbil[l], dx + 4 );
-      }
-      bst = dx + 4; c0 = lbil[0] + 2 * bst + 2; c1 = lbil[1] + 2 * bst + 2;
-    }
+    const int bst = ew;      /* (xinitMC runs ONCE per CU, InterPrediction.cpp:1859 - also with wrap-around: the start MVs are clipped against the CU, not the sub-block.  Until round 4
+                               * this was done per sub-block under wrap-around, which gives the same samples as long as no clamp is involved - every generated picture - and other
+                               * ones for vectors beyond a wrap period: found with parsed streams, tools/fuzz_dropin_on_the_oracle.py) */
     uint64_t minCost = dmvr_sad( c0, c1, bst, dx, dy );
     minCost >>= 1; minCost -= minCost >> 2;
     int mv[2][2] = { { mergeMv[0][0], mergeMv[0][1] }, { mergeMv[1][0], mergeMv[1][1] } };

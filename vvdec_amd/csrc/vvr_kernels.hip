@@ -706,10 +706,10 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
   {
     const int l = tid;
     int mvx = cu.mv[l][0][0], mvy = cu.mv[l][0][1];
-    // (xinitMC runs per sub-CU, :1804-1815: with wrap-around the period shift depends on the sub-block's position and width; without it the clamp against
-    // the CU gives the same samples)
+    // (xinitMC runs once per CU, InterPrediction.cpp:1859: the start MVs are clipped against the CU - its position and, with wrap-around, its width.  Until round 4 the
+    // wrap-around case clipped against the sub-block: the same samples unless a clamp is involved, i.e. for vectors beyond a wrap period - tests/bitstreams_open)
     const McBounds B = mc_bounds( pic, cu.x, cu.y );
-    const int wrapOff = pic.hdr.wrap_offset ? mc_clip_mv_w( pic, B, it.x, it.y, w, mvx, mvy ) : mc_clip_mv_w( pic, B, cu.x, cu.y, 0, mvx, mvy );
+    const int wrapOff = mc_clip_mv_w( pic, B, cu.x, cu.y, pic.hdr.wrap_offset ? (int) cu.w : 0, mvx, mvy );
     mvx -= 32; mvy -= 32;
     McSeg g; g.wrapOff = wrapOff; g.bx0 = B.x0; g.by0 = B.y0; g.bx1 = B.x1; g.by1 = B.y1;
     g.w = w + 4; g.h = h + 4; g.xFrac = mvx & 15; g.yFrac = mvy & 15;
