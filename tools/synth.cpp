@@ -82,6 +82,8 @@ typedef struct vvs_params {
                                 // of each direction lies on a CTU boundary
   uint16_t scaled_refs[2];      // reference picture resampling: bit i of [l] = reference picture i of list l is a scaled one (vvr_rpr_ref.scaled; the caller attaches
                                 // the table): CUs predicting from it take no BDOF / DMVR (InterPrediction.cpp:1431-1435) and their MVs are left as drawn
+  uint16_t mv_window;           // with wrap_offset: how many luma samples an MV may point beyond the window clipMv leaves it in (0: two CTUs + 64, within one wrap period of
+                                // the margins); a parsed stream may carry vectors several periods out - e.g. 2000 to generate those
 } vvs_params;
 
 typedef struct vvs_buffers {     // caller-allocated, sized with vvs_bounds()
@@ -322,7 +324,8 @@ struct Gen {
   void clipMv( int32_t mv[2], int x, int y ) const   // clipMvInPic, Mv.cpp:64 (with wrap-around the stream may carry MVs beyond it: kept inside a wider window)
   {
     const int off = 8;
-    const int horMax = ( W + off - x - 1 + ( P.wrap_offset ? 2 * ctu + 64 : 0 ) ) * 16, horMin = ( -ctu - off - x + 1 - ( P.wrap_offset ? 2 * ctu + 64 : 0 ) ) * 16;
+    const int beyond = P.wrap_offset ? ( P.mv_window ? P.mv_window : 2 * ctu + 64 ) : 0;
+    const int horMax = ( W + off - x - 1 + beyond ) * 16, horMin = ( -ctu - off - x + 1 - beyond ) * 16;
     const int verMax = ( H + off - y - 1 ) * 16, verMin = ( -ctu - off - y + 1 ) * 16;
     mv[0] = std::min( horMax, std::max( horMin, mv[0] ) );
     mv[1] = std::min( verMax, std::max( verMin, mv[1] ) );

@@ -34,7 +34,7 @@ class Params(C.Structure):
                 ("p_sao", C.c_float), ("p_alf_luma", C.c_float), ("p_alf_chroma", C.c_float), ("p_ccalf", C.c_float),
                 ("p_imv_hpel", C.c_float), ("p_jccr", C.c_float), ("p_mrl", C.c_float), ("p_bdpcm", C.c_float),
                 ("p_affine", C.c_float), ("p_geo", C.c_float), ("p_ciip", C.c_float), ("p_sbtmvp", C.c_float), ("p_bcw", C.c_float), ("p_cclm", C.c_float), ("p_mip", C.c_float), ("p_sbt", C.c_float), ("p_isp", C.c_float), ("dual_tree", C.c_float), ("p_ibc", C.c_float),
-                ("num_slices", C.c_uint8), ("tile_cols", C.c_uint8), ("tile_rows", C.c_uint8), ("wrap_offset", C.c_uint16), ("subpics", C.c_uint8), ("intra_slices", C.c_uint8), ("virtual_boundaries", C.c_uint8), ("scaled_refs", C.c_uint16 * 2)]
+                ("num_slices", C.c_uint8), ("tile_cols", C.c_uint8), ("tile_rows", C.c_uint8), ("wrap_offset", C.c_uint16), ("subpics", C.c_uint8), ("intra_slices", C.c_uint8), ("virtual_boundaries", C.c_uint8), ("scaled_refs", C.c_uint16 * 2), ("mv_window", C.c_uint16)]
 
 
 class Buffers(C.Structure):
