@@ -782,7 +782,11 @@ static int geo_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes* r
 /* ---------------------------------------------------------------------------------------------------------------------
  * Sub-block temporal MV prediction: InterPrediction::xSubPuMC (InterPrediction.cpp:438-549): 8x8 sub-blocks, each with the motion
  * stored in the motion field, predicted by the regular uni/bi path (no BDOF, no DMVR: m_subPuMC).  The reference joins sub-blocks
- * with equal motion before predicting; that changes nothing in the samples (the MV clip only acts outside the padded picture). */
+ * with equal motion along the CU's longer side (:466-512), cuts a joined run of more than 16 samples that is not a multiple of 16
+ * into its multiple-of-16 part and the rest (:514-538), and predicts each piece as one block: motionCompensation makes the piece
+ * m_currCuArea (:1375), so the MV clip refers to the PIECE.  Without wrap-around that changes nothing in the samples (the clamp
+ * only acts outside the padded picture); wrapClipMv (Mv.cpp:117) however moves an MV by a period depending on the piece's
+ * position and WIDTH, so sbtmvp_cu below forms the same pieces and hands each sub-block the area of its piece. */
 static void plain_block( const vvr_picture* pic, const vvo_planes* refs, const vvr_cu* cu /* m_currCuArea: what the MVs are clipped against */, int x, int y, int w, int h, const int mv[2][2], const int ref_idx[2], int bcw_idx, int altHpel, vvo_planes* reco )
 {
   const vvr_pic_header* H = &pic->hdr;
@@ -836,14 +840,40 @@ static int sbtmvp_cu( const vvr_picture* pic, const vvr_cu* cu, const vvo_planes
   const vvr_pic_header* H = &pic->hdr;
   const int w4 = ( H->width + 3 ) >> 2;
   if( !pic->motion ) { vvo_set_error( "SbTMVP CU without a motion field" ); return -1; }
-  for( int y = 0; y < cu->h; y += 8 ) for( int x = 0; x < cu->w; x += 8 )
-  {
-    const vvr_motion* m = &pic->motion[(size_t) ( ( cu->y + y ) >> 2 ) * w4 + ( ( cu->x + x ) >> 2 )];
-    const int mv[2][2] = { { m->mv[0][0], m->mv[0][1] }, { m->mv[1][0], m->mv[1][1] } };
-    const int ri[2] = { m->ref_idx[0], m->ref_idx[1] };
-    if( ( ri[0] < 0 && ri[1] < 0 ) || ri[0] >= H->num_ref[0] || ri[1] >= H->num_ref[1] ) { vvo_set_error( "SbTMVP: bad sub-block motion" ); return -1; }
-    plain_block( pic, refs, cu, cu->x + x, cu->y + y, 8, 8, mv, ri, cu->bcw_idx, cu->imv == 3, reco );
-  }
+  /* the pieces xSubPuMC predicts (see above): runs of equal motion along the longer side, cut at the largest multiple of 16 */
+  const int verMC = cu->h > cu->w;
+  const int nFst = ( verMC ? cu->w : cu->h ) >> 3, nSec = ( verMC ? cu->h : cu->w ) >> 3;
+  const int scaled = rpr_of( 0, 0 ) || ( H->num_ref[1] > 0 && rpr_of( 1, 0 ) );      /* :478 RPR_FIX: no joining when the first reference picture of a list is scaled */
+  for( int f = 0; f < nFst; f++ )
+    for( int s0 = 0; s0 < nSec; )
+    {
+#define SB_AT( f_, s_ ) ( &pic->motion[(size_t) ( ( cu->y + 8 * ( verMC ? (s_) : (f_) ) ) >> 2 ) * w4 + ( ( cu->x + 8 * ( verMC ? (f_) : (s_) ) ) >> 2 )] )
+      const vvr_motion* m = SB_AT( f, s0 );
+      const int ri[2] = { m->ref_idx[0], m->ref_idx[1] };
+      if( ( ri[0] < 0 && ri[1] < 0 ) || ri[0] >= H->num_ref[0] || ri[1] >= H->num_ref[1] ) { vvo_set_error( "SbTMVP: bad sub-block motion" ); return -1; }
+      const int mv[2][2] = { { m->mv[0][0], m->mv[0][1] }, { m->mv[1][0], m->mv[1][1] } };
+      int s1 = s0 + 1;
+      for( ; s1 < nSec && !scaled; s1++ )      /* MotionInfo::operator== (MotionInfo.h:127): the MV of an unused list does not count */
+      {
+        const vvr_motion* n = SB_AT( f, s1 );
+        if( n->ref_idx[0] != ri[0] || n->ref_idx[1] != ri[1] ) break;
+        if( ri[0] >= 0 && ( n->mv[0][0] != mv[0][0] || n->mv[0][1] != mv[0][1] ) ) break;
+        if( ri[1] >= 0 && ( n->mv[1][0] != mv[1][0] || n->mv[1][1] != mv[1][1] ) ) break;
+      }
+#undef SB_AT
+      const int len = 8 * ( s1 - s0 );
+      const int cut = ( len > 16 && ( len & 15 ) ) ? ( len & ~15 ) : len;          /* first piece; the rest (8 samples) is the second */
+      for( int s = s0; s < s1; s++ )
+      {
+        const int inFirst = 8 * ( s - s0 ) < cut;
+        const int p0 = 8 * s0 + ( inFirst ? 0 : cut ), pl = inFirst ? cut : len - cut;
+        vvr_cu piece = *cu;
+        if( verMC ) { piece.x = (uint16_t) ( cu->x + 8 * f ); piece.w = 8; piece.y = (uint16_t) ( cu->y + p0 ); piece.h = (uint8_t) pl; }
+        else        { piece.y = (uint16_t) ( cu->y + 8 * f ); piece.h = 8; piece.x = (uint16_t) ( cu->x + p0 ); piece.w = (uint8_t) pl; }
+        plain_block( pic, refs, &piece, cu->x + 8 * ( verMC ? f : s ), cu->y + 8 * ( verMC ? s : f ), 8, 8, mv, ri, cu->bcw_idx, cu->imv == 3, reco );
+      }
+      s0 = s1;
+    }
   return 0;
 }
 

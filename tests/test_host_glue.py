@@ -1137,7 +1137,7 @@ def test_i_pictures_take_the_priority_lane_when_it_is_free(stub):
     assert len(set(busy[1:])) == 3                          # ... the others go round the three ordinary lanes
 
 
-MC_ITEM_DT = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("flags", "<u2"), ("cu", "<u4"), ("mv", "<i4", (2, 2)), ("ref", "i1", (2,)), ("bcw", "u1"), ("pad", "u1"), ("clipX", "<u2"), ("clipY", "<u2")])
+MC_ITEM_DT = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("flags", "<u2"), ("cu", "<u4"), ("mv", "<i4", (2, 2)), ("ref", "i1", (2,)), ("bcw", "u1"), ("clipW4", "u1"), ("clipX", "<u2"), ("clipY", "<u2")])
 
 
 def _mc_table(ctx, h, which, dt=MC_ITEM_DT):
@@ -1145,6 +1145,67 @@ def _mc_table(ctx, h, which, dt=MC_ITEM_DT):
     ctx.L.vvt_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     assert ctx.L.vvt_table(h, which, C.byref(p), C.byref(n)) == 0
     return np.frombuffer(C.string_at(p.value, n.value), dt).copy() if n.value else np.zeros(0, dt)
+
+
+def _sbtmvp_pieces(cu, motion, w4):
+    """the blocks xSubPuMC predicts (InterPrediction.cpp:466-543), written down independently of the host glue: {(x, y) of a sub-block: (x, y, w) of its piece}"""
+    ver = cu["h"] > cu["w"]
+    n_f, n_s = ((cu["w"], cu["h"]) if ver else (cu["h"], cu["w"]))
+    n_f, n_s = int(n_f) // 8, int(n_s) // 8
+    pos = lambda f, s: (int(cu["x"]) + 8 * (f if ver else s), int(cu["y"]) + 8 * (s if ver else f))
+    def mi(f, s):
+        x, y = pos(f, s)
+        m = motion[(y >> 2) * w4 + (x >> 2)]
+        return tuple((int(m["ref_idx"][l]), tuple(int(v) for v in m["mv"][l]) if m["ref_idx"][l] >= 0 else None) for l in range(2))
+    out = {}
+    for f in range(n_f):
+        s0 = 0
+        while s0 < n_s:
+            s1 = s0 + 1
+            while s1 < n_s and mi(f, s1) == mi(f, s0):
+                s1 += 1
+            length = 8 * (s1 - s0)
+            parts = [(0, length & ~15), (length & ~15, length & 15)] if (length > 16 and length & 15) else [(0, length)]
+            for (o, l) in parts:
+                for s in range(s0 + o // 8, s0 + (o + l) // 8):
+                    px, py = pos(f, s0)
+                    out[pos(f, s)] = (px, py + o, 8) if ver else (px + o, py, l)
+            s0 = s1
+    return out
+
+
+def test_sbtmvp_tiles_carry_their_piece_under_wrap_around(stub):
+    """reference wrap-around: wrapClipMv depends on position and WIDTH of the predicted block, which for SbTMVP is the run of equal sub-blocks xSubPuMC
+    joins (cut at the largest multiple of 16) - every 8x8 tile of an SbTMVP CU names that piece (clipX, clipY, clipW4), tiles of other CUs and of pictures
+    without wrap-around leave the width to the CU"""
+    from test_oracle_vs_ref import ALL
+    seen = {"joined": 0, "cut": 0, "vertical": 0, "single": 0}
+    for (W, H, l2, seed, off) in [(384, 256, 6, 801, 368), (512, 256, 7, 802, 512), (384, 256, 5, 803, 320), (384, 256, 6, 804, 0)]:
+        plans, _ = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+        d = synth.picture_for_plan(plans[2], W, H, seed=seed, tool_flags=ALL, log2_ctu=l2, wrap_offset=off, p_intra=0.05, p_sbtmvp=0.6, mv_sigma=6.0)
+        ctx = Ctx(stub, W, H, 8, log2_ctu=l2)
+        hnd = ctx.prepare(d)
+        tiles = _mc_table(ctx, hnd, 0)
+        n_sbt = 0
+        for k, cu in enumerate(d.cu):
+            if cu["pred_mode"] != abi.PRED_INTER or cu["mc_mode"] != abi.MC_SBTMVP:
+                continue
+            mine = tiles[tiles["cu"] == k]
+            assert len(mine) == (cu["w"] // 8) * (cu["h"] // 8)
+            pieces = _sbtmvp_pieces(cu, d.motion, d.w4)
+            for t in mine:
+                n_sbt += 1
+                if not off:
+                    assert (t["clipX"], t["clipY"], t["clipW4"]) == (t["x"], t["y"], 0)
+                    continue
+                px, py, pw = pieces[(int(t["x"]), int(t["y"]))]
+                assert (int(t["clipX"]), int(t["clipY"]), 4 * int(t["clipW4"])) == (px, py, pw), (k, t, (px, py, pw))
+                seen["vertical" if cu["h"] > cu["w"] else "joined" if pw > 8 else "single"] += 1
+                seen["cut"] += pw not in (8, 16, 32, 64, 128) or (px - int(cu["x"])) % 16 != 0
+        assert n_sbt > 50
+        assert np.all(tiles["clipW4"][~np.isin(tiles["cu"], np.nonzero(d.cu["mc_mode"] == abi.MC_SBTMVP)[0])] == 0)
+        ctx.close()
+    assert all(v > 0 for v in seen.values()), seen
 
 
 def test_scaled_reference_pictures_in_the_host_glue(stub):

@@ -413,7 +413,10 @@ WRAP_CASES = [
     # vectors several wrap periods out (a parsed stream with AMVR carries them; mv_window lets the generator keep them): every clip path is taken with a move by a
     # period AND a clamp - the case in which the DMVR start vectors must be clipped against the CU, not the sub-block (round 4, tests/bitstreams_open)
     (384, 256, 6, 2, 296, 368, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.05, p_bi=0.9, mv_sigma=1500.0, mv_window=2000)),
-    (384, 256, 6, 3, 297, 368, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS, dict(p_intra=0.1, p_bi=0.8, p_affine=0.2, p_geo=0.2, p_ciip=0.1, mv_sigma=3000.0, mv_window=4000)),      # (SbTMVP with such vectors: open, tests/bitstreams_open/README.md)
+    (384, 256, 6, 3, 297, 368, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS, dict(p_intra=0.1, p_bi=0.8, p_affine=0.2, p_geo=0.2, p_ciip=0.1, mv_sigma=3000.0, mv_window=4000)),
+    # SbTMVP with such vectors: the pieces xSubPuMC joins decide the wrap clip (wide, tall and square CUs; cut runs)
+    (384, 256, 6, 2, 298, 368, 0, dict(p_intra=0.05, p_sbtmvp=0.5, p_bi=0.5, mv_sigma=1500.0, mv_window=2000)),
+    (512, 256, 7, 1, 299, 512, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.05, p_sbtmvp=0.4, p_affine=0.2, p_bi=0.7, mv_sigma=2500.0, mv_window=4000)),
 ]
 
 

@@ -31,8 +31,8 @@ struct McItem {
   int32_t  mv[2][2];   // motion vectors of the two lists (1/16 sample), unclipped
   int8_t   ref[2];     // reference indices (-1: list not used)
   uint8_t  bcw;        // BCW weight index (2 = equal weights)
-  uint8_t  pad;
-  uint16_t clipX, clipY;   // position the MV clipping refers to (the CU, or the sub-block itself for SbTMVP)
+  uint8_t  clipW4;     // 0: the MV clipping refers to the CU's width; else the width / 4 of the block it refers to (SbTMVP under reference wrap-around: the joined piece)
+  uint16_t clipX, clipY;   // position the MV clipping refers to (the CU; for SbTMVP the sub-block itself or, under reference wrap-around, the joined piece it belongs to)
 };
 // An inter CU whose tiles the DEVICE writes (k_expand_mc): the host only counts the tiles of such a CU - plain, BDOF and DMVR tiles are a function of
 // the CU record alone (SbTMVP and affine tiles carry motion of the motion field, which stays on the host: those the host writes itself)

@@ -617,7 +617,8 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : ( l ? mRef[1] : mRef[0] );
       int mvx = geo ? cu.geo_mv[k][0] : ( l ? it.mv[1][0] : it.mv[0][0] ), mvy = geo ? cu.geo_mv[k][1] : ( l ? it.mv[1][1] : it.mv[0][1] );
       const McBounds B = mc_bounds( pic, clipX, clipY );
-      const int wrapOff = mc_clip_mv_w( pic, B, clipX, clipY, pic.hdr.wrap_offset ? (int) cu.w : 0, mvx, mvy );         // clipped with the CU position and size (InterPrediction.cpp:651-656 uses m_currCuArea)
+      // clipped with the position and size of m_currCuArea (InterPrediction.cpp:651-656): the CU, or the piece of an SbTMVP CU that xSubPuMC predicts as one block (:514-543)
+      const int wrapOff = mc_clip_mv_w( pic, B, clipX, clipY, pic.hdr.wrap_offset ? ( it.clipW4 ? 4 * (int) it.clipW4 : (int) cu.w ) : 0, mvx, mvy );
       McSeg g;
       const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
       g.wrapOff = wrapOff >> cs; g.bx0 = B.x0 >> cs; g.by0 = B.y0 >> cs; g.bx1 = B.x1 >> cs; g.by1 = B.y1 >> cs;
@@ -1570,7 +1571,7 @@ __global__ __launch_bounds__( 256 ) void k_expand_mc( const vvr_cu* __restrict__
   const int cls = (int) ( r.first >> 30 );
   McItem it;
   it.flags = 0; it.cu = r.cu;
-  it.mv[0][0] = it.mv[0][1] = it.mv[1][0] = it.mv[1][1] = 0; it.ref[0] = it.ref[1] = 0; it.bcw = 0; it.pad = 0; it.clipX = it.clipY = 0;
+  it.mv[0][0] = it.mv[0][1] = it.mv[1][0] = it.mv[1][1] = 0; it.ref[0] = it.ref[1] = 0; it.bcw = 0; it.clipW4 = 0; it.clipX = it.clipY = 0;
   if( cls != 2 )
   {
     // everything k_mc needs about the motion of the tile

@@ -1016,6 +1016,43 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
           it.flags = (uint16_t) ( ( it.flags & ~MC_ITEM_UNI ) | ( uni ? MC_ITEM_UNI : 0 ) );
         }
       }
+      if( sbt && h.wrap_offset )
+      {
+        // reference wrap-around: wrapClipMv (Mv.cpp:112) depends on the position AND the width of the block that is predicted - for SbTMVP the pieces
+        // xSubPuMC forms (InterPrediction.cpp:466-543): sub-blocks of equal motion (MotionInfo::operator==: the MV of an unused list does not count) joined
+        // along the CU's longer side - not when the first reference picture of a list is scaled -, a joined run of more than 16 samples that is no multiple
+        // of 16 cut into its multiple-of-16 part and the rest.  Every sub-block tile carries the area of its piece.
+        const int nx = cu.w >> 3, ny = cu.h >> 3;
+        const bool verMC = cu.h > cu.w;
+        const int nFst = verMC ? nx : ny, nSec = verMC ? ny : nx;
+        const bool scaled = p->rpr && ( p->rpr->ref[0][0].scaled || ( h.num_ref[1] > 0 && p->rpr->ref[1][0].scaled ) );
+        McItem* sb = &list[first];
+        auto at = [&]( int f, int s ) -> McItem& { return verMC ? sb[s * nx + f] : sb[f * nx + s]; };
+        for( int f = 0; f < nFst; f++ )
+          for( int s0 = 0; s0 < nSec; )
+          {
+            const McItem& a = at( f, s0 );
+            int s1 = s0 + 1;
+            for( ; s1 < nSec && !scaled; s1++ )
+            {
+              const McItem& b = at( f, s1 );
+              if( b.ref[0] != a.ref[0] || b.ref[1] != a.ref[1] ) break;
+              if( a.ref[0] >= 0 && ( b.mv[0][0] != a.mv[0][0] || b.mv[0][1] != a.mv[0][1] ) ) break;
+              if( a.ref[1] >= 0 && ( b.mv[1][0] != a.mv[1][0] || b.mv[1][1] != a.mv[1][1] ) ) break;
+            }
+            const int len = 8 * ( s1 - s0 ), cut = ( len > 16 && ( len & 15 ) ) ? ( len & ~15 ) : len;
+            for( int s = s0; s < s1; s++ )
+            {
+              McItem& t = at( f, s );
+              if( p->rpr && ( ( t.ref[0] >= 0 && p->rpr->ref[0][t.ref[0]].scaled ) || ( t.ref[1] >= 0 && p->rpr->ref[1][t.ref[1]].scaled ) ) ) continue;      // (k_mc_rpr: the tile is its own block)
+              const bool inFirst = 8 * ( s - s0 ) < cut;
+              const int p0 = 8 * s0 + ( inFirst ? 0 : cut ), pl = inFirst ? cut : len - cut;
+              if( verMC ) { t.clipX = t.x; t.clipW4 = 2; t.clipY = (uint16_t) ( cu.y + p0 ); }
+              else        { t.clipY = t.y; t.clipX = (uint16_t) ( cu.x + p0 ); t.clipW4 = (uint8_t) ( pl >> 2 ); }
+            }
+            s0 = s1;
+          }
+      }
       if( p->rpr && sbt )
       {   // the sub-blocks that read a scaled picture: to k_mc_rpr
         size_t keep = first;
