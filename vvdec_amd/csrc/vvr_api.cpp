@@ -637,7 +637,16 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S, HostHelpers* h
   }
   WD_STAMP( job, tPrep );
   // (the CU / TU records are checked here - on the way, by whoever builds the part - unless there are no workers: then vvr_submit has checked them)
+#ifdef VVR_DEV_ENV
+  // developer build: where the host stage of a picture spends its time (VVR_PHASES; vvr_host_build prints its own phases)
+  auto devNow = []{ return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); };
+  const bool devPhases = getenv( "VVR_PHASES" ) != nullptr;
+  double devT[4] = { devNow(), 0, 0, 0 };
+#endif
   int rc = vvr_host_build( &job.pic, S, &total, err, &c->pinned, helpers, !c->workers.empty() );
+#ifdef VVR_DEV_ENV
+  devT[1] = devNow();
+#endif
   WD_STAMP( job, tBuilt );
   RingEntry& e = c->ring[job.ringSeq % c->ring.size()];
   {
@@ -693,7 +702,14 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S, HostHelpers* h
   }
   if( rc == VVR_OK )
   {
+#ifdef VVR_DEV_ENV
+    devT[2] = devNow();
+#endif
     vvr_host_pack( S, e.host );
+#ifdef VVR_DEV_ENV
+    devT[3] = devNow();
+    if( devPhases ) fprintf( stderr, "[vvr] host stage (ms): build %.2f, ring %.2f, pack %.2f (%.2f MB staged)\n", devT[1] - devT[0], devT[2] - devT[1], devT[3] - devT[2], vvr_host_staged_bytes( S ) / 1e6 );
+#endif
     vvr_host_bind( S, e.q, e.dev );
     vvr_host_upload_plan( S, e.direct, &e.stagedBegin, &e.stagedEnd );
     e.q.colHost = nullptr; e.q.numCol = 0; e.q.pic.colMotion = nullptr; e.q.pic.colStride = 0;
@@ -730,7 +746,13 @@ static void prepareJob( vvr_context* c, Job& job, PrepScratch& S, HostHelpers* h
     else { job.rc = rc; job.err = err; job.state = J_FAILED; }
     c->cv.notify_all();                                 // (the launcher, if there is one)
   }
+#ifdef VVR_DEV_ENV
+  const double devC0 = devNow();
+#endif
   if( c->workers.empty() ) commitReady( c );            // no worker threads: the submitting thread commits
+#ifdef VVR_DEV_ENV
+  if( devPhases && c->workers.empty() ) fprintf( stderr, "[vvr] host stage (ms): commit %.2f, after pack %.2f\n", devNow() - devC0, devC0 - devT[3] );
+#endif
 }
 
 #ifdef VVR_WATCHDOG

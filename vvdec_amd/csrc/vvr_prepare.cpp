@@ -955,7 +955,9 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
       {
         // the edge parameters are derived on the device: the motion of a CU whose motion varies inside it is not in its record
         const int cx0 = cu.x >> 2, cy0 = cu.y >> 2, cx1 = std::min( ( cu.x + cu.w + 3 ) >> 2, w4 ), cy1 = std::min( ( cu.y + cu.h + 3 ) >> 2, h4 );
-        for( int cy = cy0; cy < cy1; cy++ ) for( int cx = cx0; cx < cx1; cx++ ) { const uint32_t cell = (uint32_t) ( cy * w4 + cx ); lfSb.push_back( LfSbCell{ cell, p->motion[cell] } ); }
+        size_t at = lfSb.size();
+        lfSb.resize( at + (size_t) ( cy1 - cy0 ) * ( cx1 - cx0 ) );           // (one growth per CU, not one per cell)
+        for( int cy = cy0; cy < cy1; cy++ ) for( int cx = cx0; cx < cx1; cx++, at++ ) { const uint32_t cell = (uint32_t) ( cy * w4 + cx ); lfSb[at].cell = cell; lfSb[at].m = p->motion[cell]; }
       }
       std::vector<McItem>& list = rprCu ? mcRpr : dm ? mcDmvr : af ? mcAff : cu.mc_mode == VVR_MC_BDOF ? mcBdof : mc;
       const int nla = af ? ( ( cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 ) ? 2 : 1 ) : nl;
