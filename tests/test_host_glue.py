@@ -514,6 +514,8 @@ def test_malformed_descriptions_are_rejected(stub):
     _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "CU outside")
     d = mk(plans[1], p_intra=0.0); d.cu["ref_idx"][0] = (5, 5)
     _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "ref_idx")
+    d = mk(plans[1], p_intra=0.0); k = int(np.nonzero(d.cu["ref_idx"][:, 0] >= 0)[0][0]); d.cu["mv"][k][0][0] = (1 << 17, 0)
+    _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "18-bit range")
     d = mk(plans[1], p_intra=0.0); d.cu["mc_mode"][0] = 77
     _expect_error(ctx, d, abi.VVR_ERR_PARAMETER, "mc_mode")
     d = mk(plans[1], p_intra=0.0); d.cu["w"][0] = 4; d.cu["h"][0] = 4

@@ -1,6 +1,7 @@
 """developer helper: randomised sweep of the generator's parameter space (tools, sizes, CTU sizes, sample formats, stage) comparing the
-plain-C oracle with the reference decoder's own classes (oracle/_ref).  Usage: tools/fuzz_oracle_vs_ref.py <seed> <seconds>.
-Round 1: 4 x 200 s = 33 800 pictures, no mismatch."""
+plain-C oracle with the reference decoder's own classes (oracle/_ref).  Usage: tools/fuzz_oracle_vs_ref.py <seed> <seconds> [far]   (far: motion vectors up to thousands of samples, reference wrap-around in 6 pictures of 10).
+Round 1: 4 x 200 s = 33 800 pictures, no mismatch.  Round 4 (after the two wrap-around findings): 2 x 600 s `far` = 54 811 pictures and 600 s without = 26 173
+pictures, no mismatch (2 pictures refused by the reference: an 8-bit LMCS model of the generator that breaks the LmcsPivot constraint, Reshape.cpp:363)."""
 import sys, random, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,6 +31,12 @@ def sweep(seed, seconds=None, cases=None):
                 p_imv_hpel=rnd.choice([0, 0.3]), p_small_corner=rnd.choice([0.2, 0.8]))
       if rnd.random() < 0.3: kw["min_cu_log2"] = 2
       if rnd.random() < 0.3: kw["dual_tree"] = rnd.choice([1.0, 2.0, 3.0])
+      if FAR:
+          # vectors far outside the picture (what AMVR in a parsed stream carries; the generator's default window keeps them near it): every MV clamp is taken,
+          # and with reference wrap-around the moves by a period (round 4: the DMVR start clip and the SbTMVP pieces only showed with these)
+          kw["mv_sigma"] = rnd.choice([300.0, 1500.0, 6000.0]); kw["mv_window"] = rnd.choice([500, 2000, 7000])          # ((W + window) * 16 stays inside the 18-bit MV range)
+          off = W - 8 * rnd.randrange(5)
+          if rnd.random() < 0.6 and off >= (1 << l2) + 16 and not (tools & abi.TOOL_IBC): kw["wrap_offset"] = off
       bd = rnd.choice([8, 10, 10]); cf = rnd.choice([1, 1, 1, 0])
       if not cf: tools &= ~abi.TOOL_LMCS_CSCALE
       if (tools & abi.TOOL_LMCS_CSCALE) and not (tools & abi.TOOL_LMCS): tools |= abi.TOOL_LMCS
@@ -53,6 +60,7 @@ def sweep(seed, seconds=None, cases=None):
   return n, bad
 
 
+FAR = len(sys.argv) > 3 and sys.argv[3] == "far"
 if __name__ == "__main__":
     n, bad = sweep(int(sys.argv[1]), seconds=float(sys.argv[2]))
     print("cases", n, "bad", bad)

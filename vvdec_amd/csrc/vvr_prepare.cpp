@@ -448,6 +448,10 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
       if( cu.bcw_idx > 4 ) FAIL( VVR_ERR_PARAMETER, "BCW index out of range" );
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) FAIL( VVR_ERR_PARAMETER, "ref_idx out of range" );
       if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo && !isSbt ) FAIL( VVR_ERR_PARAMETER, "inter CU without reference" );
+      // motion vectors are 18-bit quantities (Mv::clipToStorageBitDepth, Mv.h; the refined vectors of DMVR are clamped to that range and the padded local
+      // copy holds +-2 samples around the START vector: beyond the range the reference itself stops, InterPrediction.cpp:1768)
+      for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= 0 && !isGeo && !isSbt ) for( int k = 0; k < 2; k++ )
+        if( cu.mv[l][0][k] < -( 1 << 17 ) || cu.mv[l][0][k] > ( 1 << 17 ) - 1 ) FAIL( VVR_ERR_PARAMETER, "motion vector outside the 18-bit range" );
       // (the switch and the table are those of the CU's slice)
       const vvr_slice_header* sh = p->slices ? &p->slices[p->ctu_slice[( cu.y >> h.log2_ctu ) * ( ( h.width + ( 1 << h.log2_ctu ) - 1 ) >> h.log2_ctu ) + ( cu.x >> h.log2_ctu )]] : nullptr;
       if( ( sh ? ( sh->tool_flags & VVR_TOOL_WP ) != 0 : wpOn ) && cu.ref_idx[0] >= 0 && cu.ref_idx[1] >= 0 )
