@@ -116,6 +116,9 @@ static int g_lastIntraWg = 0;
 size_t intra_sync_ints( int numUnits, int numItems ) { return ( ( (size_t) 1 + (size_t) numUnits + 63 ) & ~(size_t) 63 ) + (size_t) numItems * 64; }
 void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int, const IntraUnit*, int numUnits, int ticket0, int ticket1, int numWg, int* sync, int ) { (void) ticket1; if( ticket0 ) return; g_lastIntraWg = numWg; g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the launcher's memset touches */ }
 void launch_resi_add( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int ) {}
+static int g_lastLeafItems = -1;
+size_t intra_leaf_map_ints( int w4, int h4, int vpdus ) { return (size_t) 3 * w4 * h4 + 2 * (size_t) vpdus + 64; }
+void launch_intra_leaf( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int numItems, uint32_t*, size_t, int, int ) { g_lastLeafItems = numItems; }
 // the two output-stage kernels have functional stand-ins (a few plain loops with the kernels' contract: packed window; per row the checksum
 // share or the CRC register reached from 0), so that the host half of vvr_read_output / vvr_picture_hash - window geometry, chaining the rows'
 // CRC pieces - is checked against the reference's own functions without a GPU
@@ -201,6 +204,8 @@ __attribute__(( visibility( "default" ) )) size_t vvt_sizeof( int which ) { retu
 // the stage's launches of a prepared picture: number of luma units that go first when the picture has residual-add blocks (else 0), workgroups of both launches
 __attribute__(( visibility( "default" ) )) void vvt_intra_launches( const vvr_prepared* q, int* numLumaUnits, int* wg0, int* wg1 ) { *numLumaUnits = q->numLumaUnits; *wg0 = q->intraWorkgroups; *wg1 = q->intraWorkgroupsChroma; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_launch( void ) { return g_lastIntraUnits; }
+__attribute__(( visibility( "default" ) )) int vvt_last_leaf_items( void ) { return g_lastLeafItems; }      // items of the last k_intra_leaf launch
+__attribute__(( visibility( "default" ) )) int vvt_is_leaf( const vvr_prepared* q ) { return q && q->intraLeaf ? 1 : 0; }
 __attribute__(( visibility( "default" ) )) int vvt_last_intra_wg( void ) { return g_lastIntraWg; }
 // pretend the lane's flag buffer is small (the product sizes it for ordinary pictures; the growth path needs a picture with more units than that)
 __attribute__(( visibility( "default" ) )) void vvt_shrink_sync( vvr_context* c, int lane, size_t cap ) { if( c && lane < (int) c->syncCap.size() && cap < c->syncCap[lane] ) c->syncCap[lane] = cap; }

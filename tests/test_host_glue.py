@@ -64,8 +64,11 @@ def stub():
 
 
 class Ctx:
-    def __init__(self, L, W, H, nslots, log2_ctu=7, bit_depth=10, chroma_format=1, streams=1):
+    def __init__(self, L, W, H, nslots, log2_ctu=7, bit_depth=10, chroma_format=1, streams=1, leaf=False):
+        """leaf: pictures with scattered intra blocks take the one-wavefront-per-block path (the product's default); False: the CTU-tile path with
+        units for every picture, what most tests of this file are about (the library reads VVR_INTRA_LEAF when the context is created)"""
         self.L = L
+        os.environ["VVR_INTRA_LEAF"] = "1" if leaf else "0"
         cfg = abi.Config()
         cfg.abi_version = abi.VVR_ABI_VERSION
         cfg.device, cfg.max_width, cfg.max_height = 0, W, H
@@ -73,6 +76,7 @@ class Ctx:
         cfg.num_slots, cfg.num_streams = nslots, streams
         self.ctx = C.c_void_p()
         assert L.vvr_create(C.byref(cfg), C.byref(self.ctx)) == abi.VVR_OK
+        del os.environ["VVR_INTRA_LEAF"]
 
     def prepare(self, d):
         p = d.c()
@@ -311,6 +315,155 @@ def test_intra_stage_tables(stub, name, W, H, frames, gop, seed, tools, kw):
         stub.vvr_free_prepared(ctx.ctx, hnd)
     ctx.close()
     assert checked > 0 and (resi_blocks > 0) == bool((tools & abi.TOOL_LMCS_CSCALE) and frames > 1)
+
+
+MODE_CSFAC = 253
+
+
+def _check_leaf_items(d, items):
+    """the item list of k_intra_leaf (vvr_intra_leaf.inc): luma blocks, the chroma-scaling factors of the VPDUs, Cb blocks, Cr blocks, each list in decoding
+    order, so that everything an item reads of another item's output comes from an item BEFORE it (the kernel hands items out by ticket, in list order:
+    whoever waits, waits for a wavefront that is running or done).  Checked: the order of the parts, bands consecutive, ISP partitions consecutive, every
+    cell of an intra / CIIP CU produced exactly once, the residual-add blocks complete, and for every sample an item reads (reference lines, the
+    previous ISP partition, co-located luma and templates of CCLM, the luma a scaling factor is averaged over, the factor of a block's VPDU) that its
+    producer - if the stage has one - precedes the item."""
+    h = d.hdr
+    W, H, l2 = h.width, h.height, h.log2_ctu
+    w4, h4 = (W + 3) >> 2, (H + 3) >> 2
+    ncomp = 3 if h.chroma_format else 1
+    nI = len(items)
+    comp = items["comp"] & 3
+    mode = items["mode"]
+    assert ((items["comp"] >> 2) == 0).all()
+    # ---- parts in order: luma, factors, Cb, Cr
+    kind = np.where(mode == MODE_CSFAC, 1, np.where(comp == 0, 0, comp + 1))
+    assert (np.diff(kind.astype(np.int64)) >= 0).all(), "items are not in the order luma, factors, Cb, Cr"
+    vl = min(6, l2)
+    vpdusX = (W + (1 << vl) - 1) >> vl
+    fac_at = {int(items["tu"][i]): i for i in range(nI) if mode[i] == MODE_CSFAC}
+    assert len(fac_at) == int((mode == MODE_CSFAC).sum()), "a VPDU's factor twice"
+    prod = np.full((ncomp, h4, w4), -1, np.int64)
+    isp_first = {}
+    for i in range(nI):
+        it = items[i]
+        if mode[i] == MODE_CSFAC:
+            continue
+        k = int(comp[i]); cs = 1 if k else 0
+        x0, y0, ww, hh = int(it["x"]) << cs, int(it["y"]) << cs, (1 << int(it["lw"])) << cs, (1 << int(it["lh"])) << cs
+        part, lparts = (int(it["nTL"]) >> 1) & 7, (int(it["nTL"]) >> 4) & 3
+        samples = (ww * hh) >> (2 * cs)
+        is_isp = k == 0 and mode[i] <= 66 and (int(it["flags"]) & 6) == 6 and not (int(it["flags"]) & 8)
+        ordinary = int(mode[i]) <= 66 and (k or ((int(it["flags"]) & 8) == 0 and not is_isp))
+        assert part < (1 << lparts) and (lparts == 0 or ordinary)
+        assert lparts or samples <= 256 or not ordinary, "an ordinary block of more than 256 samples that is not split"
+        assert (samples >> lparts) <= 1024 or (k == 0 and (int(it["flags"]) & 8) and int(mode[i]) < MODE_CSFAC), "an item of more than 1024 samples that is no MIP block (the wavefront's LDS block holds 1024)"
+        if lparts:
+            assert i - part >= 0 and all(int(items[i - part + e]["x"]) == int(it["x"]) and int(items[i - part + e]["y"]) == int(it["y"]) and ((int(items[i - part + e]["nTL"]) >> 1) & 7) == e for e in range(1 << lparts)), "the bands of a block are consecutive items"
+            y0 += part * (hh >> lparts); hh >>= lparts
+        if is_isp:
+            tu = int(it["tu"])
+            if tu & 0xfff:
+                # a later partition: predicted by the wavefront of the first one, which reaches it by walking the list
+                assert i > 0 and (i - 1) in isp_first, "an ISP partition that does not follow a partition of its coding unit"
+                isp_first[i] = isp_first[i - 1]
+            else:
+                isp_first[i] = i
+        sub = prod[k, y0 >> 2:(y0 + hh + 3) >> 2, x0 >> 2:(x0 + ww + 3) >> 2]
+        assert (is_isp and min(ww, hh) < 4) or (sub == -1).all(), "two items produce one cell"
+        sub[...] = isp_first.get(i, i)      # (the cells of an ISP coding unit are cleared by its first partition's wavefront, after the last partition)
+    nchk = 0
+    for i in range(nI):
+        it = items[i]
+        m, k = int(mode[i]), int(comp[i])
+        cs = 1 if k else 0
+        unit = 4 >> cs
+        x0, y0, ww, hh = int(it["x"]), int(it["y"]), 1 << int(it["lw"]), 1 << int(it["lh"])
+        reads = []          # (component, x, y) in component samples
+        flags = int(it["flags"])
+        if m == MODE_CSFAC:
+            vp = int(it["tu"])
+            # (Reshape::calculateChromaAdjVpduNei: the column left of / the row above the CU at the VPDU's origin; here a superset: around the VPDU AND around every
+            # CU origin up to a CTU further up / left is not known to the test - it checks the VPDU's own border, which the CU's border contains or precedes)
+            vx, vy = (vp % vpdusX) << vl, (vp // vpdusX) << vl
+            continue
+        if m == MODE_RESI_ADD or (k and (flags & 8)):
+            vp = ((y0 << 1) >> vl) * vpdusX + ((x0 << 1) >> vl)
+            assert vp in fac_at and fac_at[vp] < i, "a block scales its residual with a factor no item before it computes"
+        if m == MODE_RESI_ADD:
+            continue
+        is_isp = k == 0 and m <= 66 and (flags & 6) == 6 and not (flags & 8)
+        mrl = 0 if (k or (flags & 8) or is_isp) else (flags >> 4) & 3
+        rx0, ry0 = x0, y0
+        if is_isp:
+            tu = int(it["tu"])
+            rx0, ry0 = x0 - (tu & 63), y0 - ((tu >> 6) & 63)
+        for kk in range(0, int(it["nA"]) * unit, unit):
+            reads.append((k, rx0 + kk, ry0 - 1 - mrl))
+        for kk in range(0, int(it["nL"]) * unit, unit):
+            reads.append((k, rx0 - 1 - mrl, ry0 + kk))
+        if int(it["nTL"]) & 1:
+            reads.append((k, rx0 - 1 - mrl, ry0 - 1 - mrl))
+        if k and 67 <= m <= 69:
+            lm = int(it["tu"])
+            top, left = lm & 0xff, (lm >> 8) & 0xff
+            for yy in range(-4, 2 * max(hh, left), 4):
+                for xx in range(-4, 2 * max(ww, top), 4):
+                    if yy < 2 * hh or xx < 0:
+                        if xx < 2 * ww or yy < 0:
+                            reads.append((0, 2 * x0 + xx, 2 * y0 + yy))
+        me = isp_first.get(i, i)
+        for (kc, xc, yc) in reads:
+            sh = 1 if kc else 0
+            if xc < 0 or yc < 0 or (xc << sh) >= W or (yc << sh) >= H:
+                continue
+            j = int(prod[kc, (yc << sh) >> 2, (xc << sh) >> 2])
+            if kc == k and j == me:
+                continue            # (CCLM templates and reference lines never lie in the block itself; a later ISP partition reads its own coding unit)
+            assert j < me, "item %d reads a cell item %d produces" % (i, j)
+            nchk += j >= 0
+    # ---- coverage
+    for cu in d.cu:
+        if not (cu["pred_mode"] == abi.PRED_INTRA or (int(cu["flags"]) & abi.CU_CIIP)):
+            continue
+        x0, y0, ww, hh = (int(cu[kx]) for kx in "xywh")
+        comps = [0] if cu["tree"] == abi.TREE_LUMA else [1, 2] if cu["tree"] == abi.TREE_CHROMA else list(range(ncomp))
+        for kc in comps:
+            if kc and (int(cu["flags"]) & abi.CU_CIIP) and ww == 4:
+                continue
+            assert (prod[kc, y0 >> 2:(y0 + hh) >> 2, x0 >> 2:(x0 + ww) >> 2] >= 0).all(), "CU cells without an item"
+    return nchk
+
+
+@pytest.mark.parametrize("name,W,H,frames,gop,seed,tools,kw", STREAMS, ids=[s[0] for s in STREAMS])
+def test_intra_leaf_items(stub, name, W, H, frames, gop, seed, tools, kw):
+    """pictures with scattered intra blocks (every picture that is not all intra CUs and holds no IBC CU): one wavefront per block, no units"""
+    kw = dict(kw)
+    l2 = kw.pop("log2_ctu", 7)
+    plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=False)
+    ctx = Ctx(stub, W, H, nslots, log2_ctu=l2, leaf=True)
+    stub.vvt_is_leaf.argtypes = [C.c_void_p]
+    checked = leaf_pictures = 0
+    for pl in plans:
+        d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
+        hnd = ctx.prepare(d)
+        units, items = ctx.tables(hnd)
+        all_intra = all(cu["pred_mode"] == abi.PRED_INTRA for cu in d.cu) and d.hdr.slice_type == abi.SLICE_I
+        any_ibc = any(cu["pred_mode"] == abi.PRED_IBC for cu in d.cu)
+        want_leaf = not all_intra and not any_ibc and len(items) > 0
+        assert bool(stub.vvt_is_leaf(hnd)) == want_leaf or len(items) == 0
+        if stub.vvt_is_leaf(hnd):
+            assert len(units) == 0
+            resi = items[items["mode"] == MODE_RESI_ADD]
+            _check_resi_add(d, np.zeros(0, UNIT_DT), resi, 0, 0, 0)
+            checked += _check_leaf_items(d, items)
+            leaf_pictures += 1
+            assert stub.vvr_submit_prepared(ctx.ctx, hnd) >= 0 and stub.vvr_sync(ctx.ctx) == 0
+            assert stub.vvt_last_leaf_items() == len(items)
+        else:
+            _check_tables(d, units, items)
+            stub.vvr_free_prepared(ctx.ctx, hnd)
+    ctx.close()
+    assert (leaf_pictures > 0 and checked > 0) or name.startswith("ibc") or name in ("dual_tree_ibc", "small_cus")
 
 
 def test_sync_buffer_grows_with_the_number_of_units(stub):

@@ -292,6 +292,6 @@ class Reconstructor:
         self._check(self.L.vvr_enable_stats(self.ctx, 1 if on else 0))
 
     def stats(self):
-        arr = (abi.KernelStat * 16)()
-        n = self._check(self.L.vvr_get_stats(self.ctx, arr, 16))
+        arr = (abi.KernelStat * 24)()
+        n = self._check(self.L.vvr_get_stats(self.ctx, arr, 24))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, algo_bytes=arr[i].algo_bytes) for i in range(n)]

@@ -89,7 +89,7 @@ static double g_wdSum[6]; static uint64_t g_wdJobs; static double g_wdPart[4], g
 
 struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
-const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_resi_add", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy", "k_output", "k_lf_init" };
+const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_resi_add", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy", "k_output", "k_lf_init", "k_intra_leaf" };
 
 // One slot of the upload ring: pinned staging memory and its image in HBM (grown on demand, never freed while the context lives), the device
 // pointers of the picture that currently sits in it, and the pinned landing area of its DMVR delta MVs.
@@ -145,6 +145,9 @@ struct vvr_context {
   std::deque<std::function<void( PrepScratch& )>> subtasks;      // parts of a picture's host stage that any worker may run (an I picture is prepared by all of them together); guarded by mu, served before `queue`
   std::vector<int*> syncBuf;            // per stream: ticket + one flag per unit of the intra stage
   std::vector<size_t> syncCap;          // ints allocated in syncBuf[lane]; grown when a picture has more units
+  std::vector<uint32_t*> leafMaps;      // per stream: the cell maps, VPDU flags and factors of k_intra_leaf (all zero between launches), ticket + error word at the end
+  size_t     leafMapInts = 0; int leafW4 = 0, leafH4 = 0;
+  bool       intraLeaf = true;          // pictures with scattered intra blocks take the one-wavefront-per-block path (VVR_INTRA_LEAF=0: the CTU-tile path for everything)
   size_t     planeBytes[3] = { 0, 0, 0 }, slotBytes = 0;
   int        stride[3] = { 0, 0, 0 };
   // output stage scratch (device + pinned), grown on demand
@@ -430,7 +433,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   {
     // ticket + one flag per unit: a picture with more units than the lane's buffer holds gets a larger one; work queued on the lane may
     // still use the old buffer, so the lane is drained first (rare: see vvr_create)
-    const size_t need = intra_sync_ints( q->numActive, q->numIntra );
+    const size_t need = q->intraLeaf ? 0 : intra_sync_ints( q->numActive, q->numIntra );
     if( need > c->syncCap[lane] )
     {
       HIPCHK( c, hipStreamSynchronize( s ) );
@@ -441,8 +444,10 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
     }
   }
   const int wideIntra = h.slice_type == 2 && ( lane == c->prioLane || c->numLanesRR == 1 );      // an I picture the pictures behind it wait for (launch_intra)
+  // A picture with scattered intra blocks: one wavefront per block, luma, the scaled residuals of inter chroma blocks and chroma in ONE launch (vvr_intra_leaf.inc)
+  if( q->intraLeaf ) { if( q->numIntra ) timed( K_INTRA_LEAF, [&]{ launch_intra_leaf( s, q->pic, P, R, q->intraItems, q->numIntra, c->leafMaps[lane], c->leafMapInts, c->leafW4, c->leafH4 ); } ); }
   // A picture whose inter blocks carry scaled chroma residuals (LMCS): luma units, the residual-add blocks, chroma units
-  if( q->numResi )
+  else if( q->numResi )
   {
     if( q->numLumaUnits ) timedOn( K_INTRA, s, q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numLumaUnits, q->intraWorkgroups, c->syncBuf[lane], wideIntra ); } );
     timed( K_RESI_ADD, [&]{ launch_resi_add( s, q->pic, P, R, q->resiItems, q->numResi ); } );
@@ -804,7 +809,7 @@ struct WorkerHelpers : HostHelpers
       std::function<void( PrepScratch& )> task;
       { std::lock_guard<std::mutex> lk( c->mu ); if( !c->subtasks.empty() ) { task = std::move( c->subtasks.front() ); c->subtasks.pop_front(); } }
       if( !task ) break;
-      if( !spare ) { spare = vvr_scratch_create(); vvr_scratch_warm( spare, c->cfg ); }
+      if( !spare ) { spare = vvr_scratch_create(); vvr_scratch_intra_leaf( spare, c->intraLeaf ); vvr_scratch_warm( spare, c->cfg ); }
       task( *spare );
     }
     std::unique_lock<std::mutex> lk( st.mu );
@@ -817,10 +822,11 @@ static void workerMain( vvr_context* c )
   hipSetDevice( c->device );
   pinToCpus( c->nodeCpus );
   PrepScratch* S = vvr_scratch_create();
+  vvr_scratch_intra_leaf( S, c->intraLeaf );
   vvr_scratch_warm( S, c->cfg );
   // (a second scratch for the parts of its own I picture that nobody else takes, see WorkerHelpers::run: allocated and touched now, not inside a picture)
   PrepScratch* spare = nullptr;
-  if( c->cfg.host_threads > 1 ) { spare = vvr_scratch_create(); vvr_scratch_warm( spare, c->cfg ); }
+  if( c->cfg.host_threads > 1 ) { spare = vvr_scratch_create(); vvr_scratch_intra_leaf( spare, c->intraLeaf ); vvr_scratch_warm( spare, c->cfg ); }
   WorkerHelpers helpers( c, spare );
   for( ;; )
   {
@@ -952,6 +958,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   const int nl = ns + ( ns >= 2 ? 1 : 0 );
   c->numLanesRR = ns; c->prioLane = nl > ns ? ns : -1;
   if( const char* e = getenv( "VVR_PARTS" ) ) c->partsPolicy = atoi( e );      // 0 / 1 / 2: see partsPolicy
+  if( const char* e = getenv( "VVR_INTRA_LEAF" ) ) c->intraLeaf = atoi( e ) != 0;
   c->streams.resize( nl, nullptr );
   bool ok = true;
   for( int i = 0; i < ns && ok; i++ ) ok = hipStreamCreateWithFlags( &c->streams[i], hipStreamNonBlocking ) == hipSuccess;
@@ -985,6 +992,13 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
     // with a 256-byte parameter record each: 13 MB per lane at 4K); pictures with more units or blocks than that (many isolated small intra
     // CUs) make the lane's buffer grow when they are submitted
     for( int s = 0; s < nl && ok; s++ ) { int* p = nullptr; const size_t cap = intra_sync_ints( (int) ( 24 * numCtu ), (int) ( 100 * numCtu ) ); ok = hipMalloc( (void**) &p, sizeof( int ) * cap ) == hipSuccess; if( ok ) { c->syncBuf.push_back( p ); c->syncCap.push_back( cap ); } }
+    // the per-cell words of k_intra_leaf: three maps of the largest picture, a flag and a factor per VPDU; zero from here on (every launch leaves them so)
+    {
+      c->leafW4 = ( cfg->max_width + 3 ) >> 2; c->leafH4 = ( cfg->max_height + 3 ) >> 2;
+      const int vl = std::min<int>( 6, cfg->log2_ctu ), vpdus = ( ( cfg->max_width + ( 1 << vl ) - 1 ) >> vl ) * ( ( cfg->max_height + ( 1 << vl ) - 1 ) >> vl );
+      c->leafMapInts = intra_leaf_map_ints( c->leafW4, c->leafH4, vpdus );
+      for( int s = 0; s < nl && ok; s++ ) { uint32_t* p = nullptr; ok = hipMalloc( (void**) &p, sizeof( uint32_t ) * c->leafMapInts ) == hipSuccess && hipMemset( p, 0, sizeof( uint32_t ) * c->leafMapInts ) == hipSuccess; if( p ) c->leafMaps.push_back( p ); }
+    }
   }
   if( ok )
   {
@@ -1015,6 +1029,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   if( !ok ) { vvr_destroy( c ); return VVR_ERR_DEVICE; }
   c->slotUsers.resize( cfg->num_slots ); c->slotExt.resize( cfg->num_slots );
   c->inlineScratch = vvr_scratch_create();
+  vvr_scratch_intra_leaf( c->inlineScratch, c->intraLeaf );
   if( cfg->host_threads <= 0 ) vvr_scratch_warm( c->inlineScratch, c->cfg );
   if( cfg->host_threads ) c->nodeCpus = gpuNodeCpus( c->device );
   for( int t = 0; t < cfg->host_threads; t++ ) c->workers.emplace_back( workerMain, c );
@@ -1060,6 +1075,7 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( c->prepStage ) hipHostFree( c->prepStage );
   if( c->outStream ) hipStreamDestroy( c->outStream );
   for( auto p : c->syncBuf ) hipFree( p );
+  for( auto p : c->leafMaps ) hipFree( p );
   if( c->inlineScratch ) vvr_scratch_destroy( c->inlineScratch );
   for( auto& e : c->pinned.r ) hipHostFree( (void*) e.first );
   delete c;
@@ -1312,6 +1328,13 @@ VVR_API int vvr_sync( vvr_context* c )
   for( int id : ids ) { const int r = finishJob( c, id ); if( r != VVR_OK && rc == VVR_OK ) rc = r; }
   if( rc != VVR_OK ) return rc;
   for( auto s : c->streams ) HIPCHK( c, hipStreamSynchronize( s ) );
+  // k_intra_leaf bounds every wait for a neighbouring block: a wavefront that gave up has said so in the lane's error word
+  for( size_t lane = 0; lane < c->leafMaps.size(); lane++ )
+  {
+    int word = 0;
+    HIPCHK( c, hipMemcpy( &word, c->leafMaps[lane] + c->leafMapInts - 63, sizeof( int ), hipMemcpyDeviceToHost ) );
+    if( word ) { hipMemset( c->leafMaps[lane], 0, sizeof( uint32_t ) * c->leafMapInts ); c->setError( "intra stage: a block waited for its neighbours beyond the bound (dependency that never completed)" ); return VVR_ERR_DEVICE; }
+  }
   // external events that are complete are forgotten here (the caller may destroy them after this call, vvr.h)
   { std::lock_guard<std::mutex> lk( c->mu ); for( int slot = 0; slot < (int) c->slotExt.size(); slot++ ) pruneExternalEventsLocked( c, slot ); }
   return VVR_OK;

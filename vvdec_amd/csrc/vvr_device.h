@@ -148,4 +148,9 @@ void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPl
 void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numUnits, int ticket0, int ticket1, int numWorkgroups, int* sync, int wide );      // the units [ticket0, ticket1); wide: an I picture the stream waits for (eight wavefronts per workgroup)
 void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems );      // scaled chroma residuals of inter blocks (between the luma and the chroma units)
 size_t intra_sync_ints( int numUnits, int numItems );      // ints `sync` has to hold: ticket, unit flags, the blocks' parameter records
+// the intra stage of a picture with scattered intra blocks (vvr_intra_leaf.inc): one wavefront per block of `items` (decoding order per component), ordered through
+// per-cell words in `maps` (intra_leaf_map_ints words for the largest picture of the context: all zero between launches)
+#define IT_MODE_CSFAC 253      /* mode value: the LMCS chroma scaling factor of VPDU IntraItem::tu (no samples) */
+size_t intra_leaf_map_ints( int w4, int h4, int vpdus );
+void launch_intra_leaf( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, uint32_t* maps, size_t mapInts, int mapW4, int mapH4 );
 

@@ -8,7 +8,7 @@
 
 static inline size_t alignUp( size_t v, size_t a ) { return ( v + a - 1 ) / a * a; }
 
-enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_RESI_ADD, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_OUTPUT, K_LF_INIT, K_NUM };
+enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_RESI_ADD, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_OUTPUT, K_LF_INIT, K_INTRA_LEAF, K_NUM };
 
 // A picture description resident in HBM together with its device work lists: every pointer is a device address inside one blob.
 // Streaming submissions (vvr_submit) use the blob of a ring entry owned by the context; vvr_prepare gives the handle a blob of its own.
@@ -25,6 +25,7 @@ struct vvr_prepared {
   uint32_t numDmvr = 0;                                    // delta-MV entries the DMVR kernel writes (pairs of ints)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64
   IntraItem* intraItems = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
+  bool     intraLeaf = false;                              // the items are those of k_intra_leaf (one wavefront per block, no units): a picture with scattered intra blocks
   int      intraWorkgroups = 0;                            // workgroups the intra stage is launched with (the dependency front they can keep busy)
   IntraItem* resiItems = nullptr; int numResi = 0;         // scaled chroma residuals of inter blocks (k_resi_add); with them the stage runs as luma units, k_resi_add, chroma units
   int      numLumaUnits = 0, intraWorkgroupsChroma = 0;    // (the first numLumaUnits entries of `units` are the luma units then)
@@ -62,6 +63,7 @@ struct DirectCopy { const void* src; size_t n, off; };
 struct PrepScratch;
 PrepScratch* vvr_scratch_create();
 int          vvr_host_band_pictures();
+void         vvr_scratch_intra_leaf( PrepScratch*, bool on );         // pictures with scattered intra blocks take the one-wavefront-per-block path (default on)
 void         vvr_scratch_parts_for_all( PrepScratch*, bool on );      // the next pictures built with this scratch: in bands of CTU rows over the helpers whatever their kind (else: I pictures only)
 void         vvr_scratch_destroy( PrepScratch* );
 void         vvr_scratch_warm( PrepScratch*, const vvr_config& cfg );      // allocate and touch room for an ordinary picture of this size (call from the thread that will use it)

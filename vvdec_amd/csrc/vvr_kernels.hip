@@ -1648,6 +1648,20 @@ struct IntraPic {
   const vvr_lmcs_params* lmcs;
   int vpdusX, vpduLog2, ctusX, log2Ctu, bitDepth, width, height, colloc;
 };
+// Loads of samples that another workgroup of the SAME launch may have written (k_intra_leaf): device scope (sc1) - they are served by L2 / memory, never
+// by this CU's vector L1, which another CU's stores do not refresh; the writer stores with sc1 (write-through) as well (MI355X_MICROARCH.md, inter-workgroup
+// visibility: "sc1 stores AND sc1 loads").  SC1 = false: the plain load every other kernel uses.
+template<bool SC1> __device__ __forceinline__ int ld_pel( const pel_t* p )
+{
+  if constexpr( SC1 ) return (int) (int16_t) __hip_atomic_load( reinterpret_cast<uint16_t*>( const_cast<pel_t*>( p ) ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  else return (int) *p;
+}
+template<bool SC1> __device__ __forceinline__ uint32_t ld_pel2( const pel_t* p )      // two neighbouring samples (4-byte aligned)
+{
+  if constexpr( SC1 ) return __hip_atomic_load( reinterpret_cast<uint32_t*>( const_cast<pel_t*>( p ) ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  else return *reinterpret_cast<const uint32_t*>( p );
+}
+template<bool SC1 = false>
 __device__ __forceinline__ int lmcs_cscale_factor_wave( const IntraPic& pic, int lumaX, int lumaY, int lane )
 {
   // called by one whole wavefront; every lane returns the factor.  All table reads are issued up front, one entry per lane, so the
@@ -1664,8 +1678,8 @@ __device__ __forceinline__ int lmcs_cscale_factor_wave( const IntraPic& pic, int
   for( int t = lane; t < 2 * n; t += 64 )
   {
     const int side = t >= n, i = t - side * n;
-    if( !side && hasLeft )  part += Y[(size_t) ( yPos + min( i, pic.height - yPos - 1 ) ) * st + xPos - 1];
-    if( side && hasAbove )  part += Y[(size_t) ( yPos - 1 ) * st + xPos + min( i, pic.width - xPos - 1 )];
+    if( !side && hasLeft )  part += ld_pel<SC1>( &Y[(size_t) ( yPos + min( i, pic.height - yPos - 1 ) ) * st + xPos - 1] );
+    if( side && hasAbove )  part += ld_pel<SC1>( &Y[(size_t) ( yPos - 1 ) * st + xPos + min( i, pic.width - xPos - 1 )] );
   }
 #pragma unroll
   for( int off = 32; off >= 1; off >>= 1 ) part += __shfl_xor( part, off, 64 );
@@ -4285,26 +4299,28 @@ __device__ __forceinline__ void intra_stash_resi( const IntraResiRegs& R, const 
 #define IT_CCLM_REGS 256    /* samples of a CCLM block whose luma is fetched ahead (4 per lane); larger blocks fetch it when they are predicted */
 struct IntraLumaRegs { uint32_t v[IT_CCLM_REGS / 128]; int tpl; };
 // luma of chroma sample (x, y) of the block whose co-located luma block starts at (lx0, ly0); the pairs (2x, 2x + 1) are dword loads
+template<bool SC1 = false>
 __device__ __forceinline__ int intra_cclm_luma_at( const pel_t* __restrict__ Yp, int ys, int lx0, int ly0, int x, int y, bool bLeft, bool bAbove, bool colloc )
 {
   const int xl = ( x == 0 && !bLeft ) ? 0 : 2 * x - 1;
   const pel_t* r0 = Yp + (size_t) ( ly0 + 2 * y ) * ys + lx0;
-  const uint32_t m0 = *reinterpret_cast<const uint32_t*>( r0 + 2 * x ), m1 = *reinterpret_cast<const uint32_t*>( r0 + ys + 2 * x );
+  const uint32_t m0 = ld_pel2<SC1>( r0 + 2 * x ), m1 = ld_pel2<SC1>( r0 + ys + 2 * x );
   const int a0 = m0 & 0xffff, b0 = m0 >> 16, a1 = m1 & 0xffff, b1 = m1 >> 16;
   if( colloc )
   {
     const int yu = ( y == 0 && !bAbove ) ? 0 : 2 * y - 1;
-    return ( (int) Yp[(size_t) ( ly0 + yu ) * ys + lx0 + 2 * x] + a0 * 4 + (int) r0[xl] + b0 + a1 + 4 ) >> 3;
+    return ( ld_pel<SC1>( &Yp[(size_t) ( ly0 + yu ) * ys + lx0 + 2 * x] ) + a0 * 4 + ld_pel<SC1>( &r0[xl] ) + b0 + a1 + 4 ) >> 3;
   }
-  return ( a0 * 2 + b0 + (int) r0[xl] + a1 * 2 + b1 + (int) r0[ys + xl] + 4 ) >> 3;
+  return ( a0 * 2 + b0 + ld_pel<SC1>( &r0[xl] ) + a1 * 2 + b1 + ld_pel<SC1>( &r0[ys + xl] ) + 4 ) >> 3;
 }
+template<bool SC1 = false>
 __device__ __forceinline__ void intra_load_cclm_luma( IntraLumaRegs& R, const IntraItem& it, const IntraPic& pic, int lane )
 {
   if( it.mode < 67 || it.mode > 69 ) return;
   const pel_t* __restrict__ Yp = pic.plane[0]; const int ys = pic.stride[0];
   const int lw = it.lw, w = 1 << lw, wh = 1 << ( it.lw + it.lh );
   const int lx0 = (int) it.x << 1, ly0 = (int) it.y << 1;
-#define LU( xx, yy ) ( (int) Yp[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
+#define LU( xx, yy ) ld_pel<SC1>( &Yp[(size_t) ( ly0 + ( yy ) ) * ys + lx0 + ( xx )] )
   const uint32_t lm = it.tu;
   const int actualTop = lm & 0xff, actualLeft = ( lm >> 8 ) & 0xff;
   const bool aboveAvail = ( lm >> 16 ) & 1, leftAvail = ( lm >> 17 ) & 1, bLeft = ( lm >> 18 ) & 1, firstRow = ( lm >> 19 ) & 1, bAbove = ( lm >> 20 ) & 1;
@@ -4339,7 +4355,7 @@ __device__ __forceinline__ void intra_load_cclm_luma( IntraLumaRegs& R, const In
     if( e * 64 < wh )
     {
       const int i = min( e * 64 + lane, wh - 1 );
-      const uint32_t t = (uint16_t) intra_cclm_luma_at( Yp, ys, lx0, ly0, i & ( w - 1 ), i >> lw, bLeft, bAbove, colloc );
+      const uint32_t t = (uint16_t) intra_cclm_luma_at<SC1>( Yp, ys, lx0, ly0, i & ( w - 1 ), i >> lw, bLeft, bAbove, colloc );
       if( e & 1 ) R.v[e >> 1] = ( R.v[e >> 1] & 0xffffu ) | ( t << 16 ); else R.v[e >> 1] = t;
     }
   }
@@ -5369,6 +5385,8 @@ static IntraPic intra_pic( const PicDev& pic, const DevPlanes& reco, const DevPl
   ip.bitDepth = pic.hdr.bit_depth; ip.width = pic.hdr.width; ip.height = pic.hdr.height; ip.colloc = ( pic.hdr.tool_flags & VVR_TOOL_CCLM_COLLOC ) ? 1 : 0;
   return ip;
 }
+
+#include "vvr_intra_leaf.inc"
 
 void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems )
 {

@@ -199,6 +199,12 @@ struct PrepScratch
   std::vector<uint32_t> pending;
   std::vector<int32_t> edgeRow[3];
   bool allIntraCus = false;                // every CU of the picture is an intra CU: every CTU takes the fast path, nobody ever looks a producer up
+  // The intra stage of a picture with SCATTERED intra blocks (any picture that is not all intra CUs and has no IBC CU) runs one wavefront per block, ordered on the
+  // device through per-cell words (k_intra_leaf, vvr_intra_leaf.inc): the host only lists the blocks in decoding order - no producer analysis, no block map, no
+  // units.  `leafOn`: the owner of the scratch allows it (vvr_scratch_intra_leaf); `leaf`: this picture takes that path.
+  bool leafOn = true, leaf = false;
+  std::vector<uint8_t> csNeeded;            // (leaf) per VPDU: a chroma block of the stage scales its residual with the VPDU's factor (an IT_MODE_CSFAC item computes it)
+  int emitLeafItems( std::string& err );
   int buildWorkLists( std::string& err, uint32_t cu0 = 0, uint32_t cu1 = 0xffffffffu );
   int buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool validate, std::string& err );
   int formUnits();
@@ -211,6 +217,7 @@ struct PrepScratch
 
 PrepScratch* vvr_scratch_create() { return new PrepScratch(); }
 void vvr_scratch_parts_for_all( PrepScratch* S, bool on ) { S->partsForAll = on; }
+void vvr_scratch_intra_leaf( PrepScratch* S, bool on ) { S->leafOn = on; }
 static std::atomic<int> g_bandPictures{ 0 };
 int vvr_host_band_pictures() { return g_bandPictures.load(); }      // (tests) pictures with producer analysis that were built in bands so far
 
@@ -573,28 +580,35 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
 // later CTUs are known to be "not decoded yet" from their position, the block map carries the picture's epoch.
 int PrepScratch::beginMaps( const PrepScratch* like /* the same picture in another thread's scratch: what it found out about the picture as a whole */ )
 {
-  if( like ) { anyIntra = like->anyIntra; allIntraCus = like->allIntraCus; }
+  if( like ) { anyIntra = like->anyIntra; allIntraCus = like->allIntraCus; leaf = like->leaf; }
   else
   {
   anyIntra = ( h.tool_flags & VVR_TOOL_LMCS_CSCALE ) != 0;      // (inter blocks with scaled chroma residuals are intra-stage items)
   for( uint32_t i = 0; i < p->num_cu && !anyIntra; i++ ) anyIntra = p->cu[i].pred_mode == VVR_PRED_INTRA || p->cu[i].pred_mode == VVR_PRED_IBC || ( p->cu[i].flags & VVR_CU_CIIP );
   allIntraCus = h.slice_type == 2;
   for( uint32_t i = 0; i < p->num_cu && allIntraCus; i++ ) allIntraCus = p->cu[i].pred_mode == VVR_PRED_INTRA;
+  // scattered intra blocks: one wavefront per block (an IBC block copies samples from anywhere in its CTU row: such pictures keep the CTU-tile path)
+  leaf = leafOn && anyIntra && !allIntraCus;
+  if( leaf && ( h.tool_flags & VVR_TOOL_IBC ) ) for( uint32_t i = 0; i < p->num_cu && leaf; i++ ) leaf = p->cu[i].pred_mode != VVR_PRED_IBC;
   }
   fastCtu.assign( (size_t) numCtu, 0 );
   if( anyIntra )
   {
     const size_t cells = (size_t) w4 * h4;
     order.assign( (size_t) 2 << ( 2 * ( h.log2_ctu - 2 ) ), 0x7fffffff );
-    epoch = ( epoch + 1 ) & 0x3ff;
-    const size_t blocked = (size_t) numCtu << ( 2 * ( h.log2_ctu - 2 ) );
-    for( int k = 0; k < ncomp; k++ ) if( itemAtE[k].size() != blocked || epoch == 0 ) itemAtE[k].assign( blocked, 0xffffffffu );
-    if( epoch == 0 ) epoch = 1;
+    if( !leaf )
+    {
+      epoch = ( epoch + 1 ) & 0x3ff;
+      const size_t blocked = (size_t) numCtu << ( 2 * ( h.log2_ctu - 2 ) );
+      for( int k = 0; k < ncomp; k++ ) if( itemAtE[k].size() != blocked || epoch == 0 ) itemAtE[k].assign( blocked, 0xffffffffu );
+      if( epoch == 0 ) epoch = 1;
+    }
   }
   if( cscale )
   {
     csVpduV.assign( (size_t) vpdusX * vpdusY, 0 );
-    csProdRange.assign( (size_t) vpdusX * vpdusY, std::make_pair( 0xffffffffu, 0u ) ); csProdPool.clear();
+    if( leaf ) csNeeded.assign( (size_t) vpdusX * vpdusY, 0 );
+    else { csProdRange.assign( (size_t) vpdusX * vpdusY, std::make_pair( 0xffffffffu, 0u ) ); csProdPool.clear(); }
   }
   return VVR_OK;
 }
@@ -608,6 +622,7 @@ int PrepScratch::mapCtu( uint32_t i0, uint32_t i1, uint32_t ctuIdx, std::string&
   {
     bool fast = true;
     for( uint32_t i = i0; i < i1 && fast; i++ ) fast = p->cu[i].pred_mode == VVR_PRED_INTRA;
+    if( leaf ) fast = false;        // (the CTU-tile path's shortcut for CTUs of intra CUs)
     fastCtu[ctuIdx] = fast;
     if( fast ) { memset( fastCell, 0xff, sizeof( fastCell ) ); for( int k = 0; k < 3; k++ ) fastFirst[k] = (uint32_t) intra[k].size(); }
   }
@@ -712,6 +727,14 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
             IntraItem it; memset( &it, 0, sizeof( it ) );
             it.tu = t; it.comp = (uint8_t) comp; it.x = (uint16_t) ( tu.x >> 1 ); it.y = (uint16_t) ( tu.y >> 1 ); it.lw = (uint8_t) ilog2i( tu.w >> 1 ); it.lh = (uint8_t) ilog2i( tu.h >> 1 );
             it.mode = IT_MODE_RESI_ADD; it.flags = IT_F_RESI | IT_F_CSCALE;
+            if( leaf )
+            {
+              // one wavefront per block: the block rides in its component's list, in decoding order (the chroma blocks that read its samples come behind it)
+              intra[comp].push_back( it );
+              csNeeded[(size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 )] = 1;
+              bytes[K_INTRA_LEAF] += (double) ( tu.w >> 1 ) * ( tu.h >> 1 ) * 6 + sizeof( IntraItem );
+              continue;
+            }
             resiAdd.push_back( it );
             bytes[K_RESI_ADD] += (double) ( tu.w >> 1 ) * ( tu.h >> 1 ) * 6 + sizeof( IntraItem );      // prediction read, residual read, sample written
             continue;
@@ -796,6 +819,13 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
           const uint32_t myId = (uint32_t) intra[comp].size();
           if( myId >= 0x3fffffu ) FAIL( VVR_ERR_UNSUPPORTED, "too many intra-stage blocks" );
           intra[comp].push_back( it );
+          if( leaf )
+          {
+            // one wavefront per block, ordered on the device: the list in decoding order is all there is to do
+            if( csItem ) csNeeded[(size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 )] = 1;
+            bytes[K_INTRA_LEAF] += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
+            continue;
+          }
           std::vector<uint32_t>& pool = prodPool[comp];
           ItemH IH; IH.ctu = ctuOfCu; IH.p0 = (uint32_t) pool.size(); IH.pn = 0;
           {
@@ -1527,6 +1557,39 @@ int PrepScratch::emitUnitTable( std::string& err )
   return VVR_OK;
 }
 
+// (leaf) the item list of k_intra_leaf: luma blocks, the chroma-scaling factors of the VPDUs that need one, Cb blocks, Cr blocks - each list in decoding order; a
+// block of more than IT_SPLIT_SAMPLES samples (ordinary prediction modes and CIIP) as 2, 4 or 8 bands of rows, like the other path's
+int PrepScratch::emitLeafItems( std::string& err )
+{
+  (void) err;
+  for( int k = 0; k < 3; k++ )
+  {
+    for( const IntraItem& src : intra[k] )
+    {
+      const int samples = 1 << ( src.lw + src.lh );
+      const bool split = samples > IT_SPLIT_SAMPLES && src.mode <= 66 && ( k || ( !( src.flags & IT_F_MIP ) && ( src.flags & IT_F_ISP ) != IT_F_ISP ) );
+      int lp = 0;
+      if( split ) while( lp < IT_MAX_LPARTS && ( samples >> lp ) > IT_SPLIT_SAMPLES ) lp++;
+      for( int part = 0; part < ( 1 << lp ); part++ )
+      {
+        IntraItem it = src;
+        it.nTL = (uint8_t) ( ( src.nTL & 1 ) | ( part << 1 ) | ( lp << 4 ) );
+        it.comp = (uint8_t) k;
+        intraAll.push_back( it );
+      }
+    }
+    if( k == 0 && cscale )
+      for( size_t vp = 0; vp < csNeeded.size(); vp++ ) if( csNeeded[vp] )
+      {
+        IntraItem it; memset( &it, 0, sizeof( it ) );
+        it.mode = IT_MODE_CSFAC; it.tu = (uint32_t) vp; it.comp = 1;
+        intraAll.push_back( it );
+      }
+  }
+  numLumaUnits = 0; intraWorkgroups = intraWorkgroupsChroma = 0;
+  return VVR_OK;
+}
+
 void PrepScratch::layout( PinnedRanges* pinned )
 {
   const double samples = (double) h.width * h.height * ( ncomp == 3 ? 1.5 : 1.0 );
@@ -1611,7 +1674,7 @@ int PrepScratch::buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool
   struct Shared { std::mutex mu; std::condition_variable cv; int turn = 0; int rc = VVR_OK; std::string err; uint64_t area[2] = { 0, 0 }; } sh;
   const vvr_picture* pic = p;
   PrepScratch* owner = this;
-  const bool analysed = !allIntraCus;            // blocks name their producers: what a band reads of the band above is resolved when the bands are joined
+  const bool analysed = !allIntraCus && !leaf;   // blocks name their producers: what a band reads of the band above is resolved when the bands are joined
   if( analysed ) { g_bandPictures++; for( int k = 0; k < ncomp; k++ ) edgeRow[k].assign( (size_t) w4, -1 ); }
   helpers.run( n, *this, [&]( int part, PrepScratch& R )
   {
@@ -1644,6 +1707,7 @@ int PrepScratch::buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool
         for( int k = 0; k < O.ncomp; k++ )
         {
           O.intra[k].insert( O.intra[k].end(), R.intra[k].begin(), R.intra[k].end() );
+          if( O.leaf ) continue;                                                                               // (a list of blocks in decoding order is all there is)
           if( !analysed ) O.itemH[k].insert( O.itemH[k].end(), R.itemH[k].begin(), R.itemH[k].end() );        // (no producer lists in all-intra CTUs: p0 / pn stay 0)
           else
           {
@@ -1679,6 +1743,7 @@ int PrepScratch::buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool
           const int nv = 1 << ( O.h.log2_ctu - O.vpduLog2 );
           const size_t v0 = (size_t) row0 * nv * O.vpdusX, v1 = std::min( (size_t) row1 * nv, (size_t) O.vpdusY ) * O.vpdusX;
           if( v1 > v0 ) memcpy( &O.csVpduV[v0], &R.csVpduV[v0], sizeof( uint32_t ) * ( v1 - v0 ) );
+          if( v1 > v0 && O.leaf ) memcpy( &O.csNeeded[v0], &R.csNeeded[v0], v1 - v0 );
         }
         // the inter stage: tiles the host writes (the sub-block motion of affine tiles sits behind what is there already), CUs whose tiles the device writes
         {
@@ -1725,8 +1790,9 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
     if( ( rc = S.beginMaps() ) != VVR_OK ) return rc;
     if( S.allIntraCus || anyInParts )
     {
-      if( ( rc = S.buildInParts( vvr_config(), *helpers, validateRecords, err ) ) != VVR_OK || ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK
-       || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
+      if( ( rc = S.buildInParts( vvr_config(), *helpers, validateRecords, err ) ) != VVR_OK ) return rc;
+      if( S.leaf ) { if( ( rc = S.emitLeafItems( err ) ) != VVR_OK ) return rc; }
+      else if( ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
       S.layout( pinned );
       *totalBytes = S.total;
       return VVR_OK;
@@ -1741,9 +1807,9 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
     double t[7]; t[0] = now();
     rc = S.beginMaps(); t[1] = now();
     if( rc == VVR_OK ) rc = S.buildWorkLists( err ); t[2] = now();
-    if( rc == VVR_OK ) rc = S.formUnits(); t[3] = now();
-    if( rc == VVR_OK ) rc = S.groupUnits(); t[4] = now();
-    if( rc == VVR_OK ) rc = S.emitUnitTable( err ); t[5] = now();
+    if( rc == VVR_OK && !S.leaf ) rc = S.formUnits(); t[3] = now();
+    if( rc == VVR_OK && !S.leaf ) rc = S.groupUnits(); t[4] = now();
+    if( rc == VVR_OK ) rc = S.leaf ? S.emitLeafItems( err ) : S.emitUnitTable( err ); t[5] = now();
     if( rc != VVR_OK ) return rc;
     S.layout( pinned ); t[6] = now();
     fprintf( stderr, "[vvr] phases (ms): maps %.2f, work lists %.2f, units %.2f, groups %.2f, unit table %.2f, layout %.2f\n", t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5] );
@@ -1751,8 +1817,9 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
     return VVR_OK;
   }
 #endif
-  if( ( rc = S.beginMaps() ) != VVR_OK || ( rc = S.buildWorkLists( err ) ) != VVR_OK || ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK
-   || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
+  if( ( rc = S.beginMaps() ) != VVR_OK || ( rc = S.buildWorkLists( err ) ) != VVR_OK ) return rc;
+  if( S.leaf ) { if( ( rc = S.emitLeafItems( err ) ) != VVR_OK ) return rc; }
+  else if( ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
   S.layout( pinned );
   *totalBytes = S.total;
   return VVR_OK;
@@ -1827,7 +1894,7 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   q.rprItems = (McItem*) at( S.iMcR ); q.numRprItems = (int) S.mcRpr.size();
   q.numDmvr = S.numDmvr;
   for( int k = 0; k < 3; k++ ) { q.tbItems[k] = (TbItem*) at( S.iTb[k] ); q.numTb[k] = (int) S.tb[k].size(); }
-  q.intraItems = (IntraItem*) at( S.iIntra ); q.numIntra = (int) S.intraAll.size();
+  q.intraItems = (IntraItem*) at( S.iIntra ); q.numIntra = (int) S.intraAll.size(); q.intraLeaf = S.leaf;
   q.units = (IntraUnit*) at( S.iUnits ); q.numActive = (int) S.unitsDev.size(); q.intraWorkgroups = S.intraWorkgroups;
   q.resiItems = (IntraItem*) at( S.iResi ); q.numResi = (int) S.resiAdd.size(); q.numLumaUnits = S.numLumaUnits; q.intraWorkgroupsChroma = S.intraWorkgroupsChroma;
   memcpy( q.bytes, S.bytes, sizeof( q.bytes ) );
