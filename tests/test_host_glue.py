@@ -320,7 +320,7 @@ def test_intra_stage_tables(stub, name, W, H, frames, gop, seed, tools, kw):
 MODE_CSFAC = 253
 
 
-def _check_leaf_items(d, items):
+def _check_leaf_items(d, items, resi=None):
     """the item list of k_intra_leaf (vvr_intra_leaf.inc): luma blocks, the chroma-scaling factors of the VPDUs, Cb blocks, Cr blocks, each list in decoding
     order, so that everything an item reads of another item's output comes from an item BEFORE it (the kernel hands items out by ticket, in list order:
     whoever waits, waits for a wavefront that is running or done).  Checked: the order of the parts, bands consecutive, ISP partitions consecutive, every
@@ -344,6 +344,22 @@ def _check_leaf_items(d, items):
     assert len(fac_at) == int((mode == MODE_CSFAC).sum()), "a VPDU's factor twice"
     prod = np.full((ncomp, h4, w4), -1, np.int64)
     isp_first = {}
+    # the residual-add blocks are grouped by VPDU; the VPDU's factor item adds them (x | y << 16 = first, lw | lh << 8 = count): every block once, in its VPDU
+    assert not (mode == MODE_RESI_ADD).any(), "residual-add blocks are no items of their own"
+    if resi is not None:
+        seen = np.zeros(len(resi), np.int64)
+        for vp, i in fac_at.items():
+            f, n = int(items["x"][i]) | (int(items["y"][i]) << 16), int(items["lw"][i]) | (int(items["lh"][i]) << 8)
+            assert f + n <= len(resi)
+            seen[f:f + n] += 1
+            for r in resi[f:f + n]:
+                k = int(r["comp"]) & 3
+                x0, y0, ww, hh = int(r["x"]) << 1, int(r["y"]) << 1, (1 << int(r["lw"])) << 1, (1 << int(r["lh"])) << 1
+                assert (y0 >> vl) * vpdusX + (x0 >> vl) == vp, "a residual-add block in another VPDU's group"
+                sub = prod[k, y0 >> 2:(y0 + hh + 3) >> 2, x0 >> 2:(x0 + ww + 3) >> 2]
+                assert (sub == -1).all()
+                sub[...] = i
+        assert (seen == 1).all(), "a residual-add block that no factor item (or more than one) adds"
     for i in range(nI):
         it = items[i]
         if mode[i] == MODE_CSFAC:
@@ -386,11 +402,9 @@ def _check_leaf_items(d, items):
             # CU origin up to a CTU further up / left is not known to the test - it checks the VPDU's own border, which the CU's border contains or precedes)
             vx, vy = (vp % vpdusX) << vl, (vp // vpdusX) << vl
             continue
-        if m == MODE_RESI_ADD or (k and (flags & 8)):
+        if k and (flags & 8):
             vp = ((y0 << 1) >> vl) * vpdusX + ((x0 << 1) >> vl)
             assert vp in fac_at and fac_at[vp] < i, "a block scales its residual with a factor no item before it computes"
-        if m == MODE_RESI_ADD:
-            continue
         is_isp = k == 0 and m <= 66 and (flags & 6) == 6 and not (flags & 8)
         mrl = 0 if (k or (flags & 8) or is_isp) else (flags >> 4) & 3
         rx0, ry0 = x0, y0
@@ -453,9 +467,9 @@ def test_intra_leaf_items(stub, name, W, H, frames, gop, seed, tools, kw):
         assert bool(stub.vvt_is_leaf(hnd)) == want_leaf or len(items) == 0
         if stub.vvt_is_leaf(hnd):
             assert len(units) == 0
-            resi = items[items["mode"] == MODE_RESI_ADD]
+            resi = ctx.resi_tables(hnd)[0]
             _check_resi_add(d, np.zeros(0, UNIT_DT), resi, 0, 0, 0)
-            checked += _check_leaf_items(d, items)
+            checked += _check_leaf_items(d, items, resi)
             leaf_pictures += 1
             assert stub.vvr_submit_prepared(ctx.ctx, hnd) >= 0 and stub.vvr_sync(ctx.ctx) == 0
             assert stub.vvt_last_leaf_items() == len(items)

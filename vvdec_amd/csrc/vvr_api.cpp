@@ -445,7 +445,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   }
   const int wideIntra = h.slice_type == 2 && ( lane == c->prioLane || c->numLanesRR == 1 );      // an I picture the pictures behind it wait for (launch_intra)
   // A picture with scattered intra blocks: one wavefront per block, luma, the scaled residuals of inter chroma blocks and chroma in ONE launch (vvr_intra_leaf.inc)
-  if( q->intraLeaf ) { if( q->numIntra ) timed( K_INTRA_LEAF, [&]{ launch_intra_leaf( s, q->pic, P, R, q->intraItems, q->numIntra, c->leafMaps[lane], c->leafMapInts, c->leafW4, c->leafH4 ); } ); }
+  if( q->intraLeaf ) { if( q->numIntra ) timed( K_INTRA_LEAF, [&]{ launch_intra_leaf( s, q->pic, P, R, q->intraItems, q->numIntra, q->resiItems, q->numResi, c->leafMaps[lane], c->leafMapInts, c->leafW4, c->leafH4 ); } ); }
   // A picture whose inter blocks carry scaled chroma residuals (LMCS): luma units, the residual-add blocks, chroma units
   else if( q->numResi )
   {

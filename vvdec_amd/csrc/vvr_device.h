@@ -152,5 +152,6 @@ size_t intra_sync_ints( int numUnits, int numItems );      // ints `sync` has to
 // per-cell words in `maps` (intra_leaf_map_ints words for the largest picture of the context: all zero between launches)
 #define IT_MODE_CSFAC 253      /* mode value: the LMCS chroma scaling factor of VPDU IntraItem::tu (no samples) */
 size_t intra_leaf_map_ints( int w4, int h4, int vpdus );
-void launch_intra_leaf( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, uint32_t* maps, size_t mapInts, int mapW4, int mapH4 );
+void launch_intra_leaf( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraItem* resiItems, int numResi /* residual-add blocks grouped by VPDU: done by the VPDU's IT_MODE_CSFAC item */,
+                        uint32_t* maps, size_t mapInts, int mapW4, int mapH4 );
 

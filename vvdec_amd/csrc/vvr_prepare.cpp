@@ -729,9 +729,11 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
             it.mode = IT_MODE_RESI_ADD; it.flags = IT_F_RESI | IT_F_CSCALE;
             if( leaf )
             {
-              // one wavefront per block: the block rides in its component's list, in decoding order (the chroma blocks that read its samples come behind it)
-              intra[comp].push_back( it );
-              csNeeded[(size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 )] = 1;
+              // one wavefront per block - but these blocks are many and small, and all they wait for is the factor of their VPDU: the wavefront that computes
+              // the factor (IT_MODE_CSFAC item) adds the residuals of the VPDU's blocks as well (emitLeafItems groups them); `tu` carries the VPDU
+              it.tu = (uint32_t) ( ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 ) );
+              resiAdd.push_back( it );
+              csNeeded[it.tu] = 1;
               bytes[K_INTRA_LEAF] += (double) ( tu.w >> 1 ) * ( tu.h >> 1 ) * 6 + sizeof( IntraItem );
               continue;
             }
@@ -1579,12 +1581,24 @@ int PrepScratch::emitLeafItems( std::string& err )
       }
     }
     if( k == 0 && cscale )
+    {
+      // the residual-add blocks grouped by VPDU (decoding order inside a VPDU), one IT_MODE_CSFAC item per VPDU whose factor somebody needs: x | y << 16 = its
+      // first block in the list, lw | lh << 8 = how many
+      std::vector<uint32_t>& first = unitCount; first.assign( csNeeded.size() + 1, 0 );
+      for( const IntraItem& r : resiAdd ) first[r.tu + 1]++;
+      for( size_t vp = 0; vp < csNeeded.size(); vp++ ) first[vp + 1] += first[vp];
+      std::vector<IntraItem>& sorted = intraTmp[0]; sorted.resize( resiAdd.size() );
+      { std::vector<uint32_t>& fill = perm; fill.assign( first.begin(), first.end() - 1 ); for( const IntraItem& r : resiAdd ) sorted[fill[r.tu]++] = r; }
+      resiAdd.swap( sorted );
       for( size_t vp = 0; vp < csNeeded.size(); vp++ ) if( csNeeded[vp] )
       {
+        const uint32_t f = first[vp], n = first[vp + 1] - first[vp];
         IntraItem it; memset( &it, 0, sizeof( it ) );
         it.mode = IT_MODE_CSFAC; it.tu = (uint32_t) vp; it.comp = 1;
+        it.x = (uint16_t) ( f & 0xffff ); it.y = (uint16_t) ( f >> 16 ); it.lw = (uint8_t) ( n & 0xff ); it.lh = (uint8_t) ( n >> 8 );
         intraAll.push_back( it );
       }
+    }
   }
   numLumaUnits = 0; intraWorkgroups = intraWorkgroupsChroma = 0;
   return VVR_OK;
