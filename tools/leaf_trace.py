@@ -47,3 +47,10 @@ while hops < 40 and t[cur, 2] - t[cur, 1] > 50:
         prv, kinds[prv], items["mode"][prv], 1 << items["lw"][prv], 1 << items["lh"][prv], items["x"][prv], items["y"][prv], us(t[prv, 1]), us(t[prv, 2]), us(end[prv]), (t[cur, 2] - end[prv]) / 100, (end[cur] - t[cur, 2]) / 100))
     cur = prv; hops += 1
 print("chain length", hops)
+# ---- occupancy of the device over time and how long a wavefront lives
+alive_from, alive_to = t[ran, 0], np.maximum(t[ran, 7], t[ran, 6:8].max(1))
+life = (alive_to - alive_from) / 100.0
+print("wavefront life (entry -> last stamp): median %.1f p90 %.1f max %.1f us; sum %.0f wave-us = %.0f waves alive on average over the span" % (np.median(life), np.percentile(life, 90), life.max(), life.sum(), life.sum() / ((t[ran].max() - t0) / 100.0)))
+grid = np.arange(0, (t[ran].max() - t0) / 100.0, 5.0)
+print("waves alive at t =", " ".join("%d:%d" % (g, ((us(alive_from) <= g) & (us(alive_to) > g)).sum()) for g in grid))
+print("entries per 5 us   ", " ".join("%d:%d" % (g, ((us(alive_from) >= g) & (us(alive_from) < g + 5)).sum()) for g in grid))
