@@ -142,6 +142,7 @@ struct vvr_context {
   std::vector<DevPlanes>   scratchR;    // per stream: residual planes (intra)
   void*      planeMem = nullptr; bool planeMemOwned = false;
   void*      scratchMem = nullptr;
+  int        partsComing = 0;           // workers that have taken an I picture and are about to publish its parts in `subtasks`: the others wait for the parts instead of starting on another picture (guarded by mu)
   std::deque<std::function<void( PrepScratch& )>> subtasks;      // parts of a picture's host stage that any worker may run (an I picture is prepared by all of them together); guarded by mu, served before `queue`
   std::vector<int*> syncBuf;            // per stream: ticket + one flag per unit of the intra stage
   std::vector<size_t> syncCap;          // ints allocated in syncBuf[lane]; grown when a picture has more units
@@ -792,6 +793,7 @@ static void watchdogMain( vvr_context* c )
 struct WorkerHelpers : HostHelpers
 {
   vvr_context* c; PrepScratch*& spare;
+  bool announced = false;               // this worker counts in c->partsComing (it took an I picture and has not published the parts yet)
   WorkerHelpers( vvr_context* c_, PrepScratch*& spare_ ) : c( c_ ), spare( spare_ ) {}
   int width() const override { return c->cfg.host_threads; }
   void run( int n, PrepScratch& own, const std::function<void( int, PrepScratch& )>& fn ) override
@@ -801,6 +803,7 @@ struct WorkerHelpers : HostHelpers
       std::lock_guard<std::mutex> lk( c->mu );
       for( int part = 1; part < n; part++ )
         c->subtasks.push_back( [&st, &fn, part]( PrepScratch& R ) { fn( part, R ); std::lock_guard<std::mutex> l2( st.mu ); st.remaining--; st.cv.notify_all(); } );      // (notified under the lock: `st` lives on the caller's stack and is gone once the caller has seen remaining == 0)
+      if( announced ) { c->partsComing--; announced = false; }
       c->cv.notify_all();
     }
     fn( 0, own );
@@ -833,7 +836,11 @@ static void workerMain( vvr_context* c )
     Job* job = nullptr;
     {
       std::unique_lock<std::mutex> lk( c->mu );
-      c->cv.wait( lk, [&]{ return c->stop || !c->queue.empty() || !c->subtasks.empty(); } );
+      // (while a worker is about to publish the parts of an I picture - a fraction of a millisecond, the scan of its CUs - the others do not start on
+      // another picture: the I picture's chain on the device is the longest thing in the stream, and a worker that has just taken a B picture would be
+      // busy with it for the 2 ms in which the I picture needs everybody.  Measured on the driver's 20-picture window: the IRAP built 2.3 ms after it was
+      // taken, by its own worker alone, because the other seven had each taken a B picture 0.05 ms before its parts appeared)
+      c->cv.wait( lk, [&]{ return c->stop || !c->subtasks.empty() || ( !c->queue.empty() && c->partsComing == 0 ); } );
       if( !c->subtasks.empty() )
       {
         // a part of a picture another worker is preparing: before anything else (that picture is an I picture: the next GOP waits for it)
@@ -857,9 +864,11 @@ static void workerMain( vvr_context* c )
       }
       job = c->queue[pick]; c->queue.erase( c->queue.begin() + pick );
       job->state = J_PREPARING;
+      if( job->pic.hdr.slice_type == 2 && c->cfg.host_threads > 1 ) { c->partsComing++; helpers.announced = true; }
       c->cv.notify_all();                 // (a submitter may be waiting for room in the queue)
     }
     prepareJob( c, *job, *S, c->cfg.host_threads > 1 ? &helpers : nullptr );
+    if( helpers.announced ) { std::lock_guard<std::mutex> lk( c->mu ); c->partsComing--; helpers.announced = false; c->cv.notify_all(); }      // (the picture was not built in parts after all)
   }
   vvr_scratch_destroy( S );
   if( spare ) vvr_scratch_destroy( spare );

@@ -219,7 +219,7 @@ PrepScratch* vvr_scratch_create() { return new PrepScratch(); }
 void vvr_scratch_parts_for_all( PrepScratch* S, bool on ) { S->partsForAll = on; }
 void vvr_scratch_intra_leaf( PrepScratch* S, bool on ) { S->leafOn = on; }
 static std::atomic<int> g_bandPictures{ 0 };
-int vvr_host_band_pictures() { return g_bandPictures.load(); }      // (tests) pictures with producer analysis that were built in bands so far
+int vvr_host_band_pictures() { return g_bandPictures.load(); }      // (tests) pictures with inter CUs that were built in bands so far
 
 // Room for the lists of an ordinary picture of the context's size, allocated AND written once, by the thread that is going to use the scratch
 // (first touch decides where the pages live).  A vector that has to grow in the middle of a picture is a new mapping, a copy and a page fault
@@ -1689,7 +1689,8 @@ int PrepScratch::buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool
   const vvr_picture* pic = p;
   PrepScratch* owner = this;
   const bool analysed = !allIntraCus && !leaf;   // blocks name their producers: what a band reads of the band above is resolved when the bands are joined
-  if( analysed ) { g_bandPictures++; for( int k = 0; k < ncomp; k++ ) edgeRow[k].assign( (size_t) w4, -1 ); }
+  if( !allIntraCus ) g_bandPictures++;
+  if( analysed ) for( int k = 0; k < ncomp; k++ ) edgeRow[k].assign( (size_t) w4, -1 );
   helpers.run( n, *this, [&]( int part, PrepScratch& R )
   {
     const int row0 = (int) ( (int64_t) owner->ctusY * part / n ), row1 = (int) ( (int64_t) owner->ctusY * ( part + 1 ) / n );
