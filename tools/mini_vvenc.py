@@ -96,9 +96,18 @@ NAL_IDR_N_LP, NAL_SPS, NAL_PPS = 8, 15, 16
 # ---------------------------------------------------------------------------------------------------------------------
 # CABAC
 # ---------------------------------------------------------------------------------------------------------------------
+CTX_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mini_vvenc_contexts.json")
+
+
 def load_context_tables():
-    """{set name: [rows B, P, I, rate]} and the renormalisation table, from the reference's CommonLib/Contexts.cpp"""
-    src = open(os.path.join(REF, "source", "Lib", "CommonLib", "Contexts.cpp")).read()
+    """{set name: [rows B, P, I, rate]} and the renormalisation table, from the reference's CommonLib/Contexts.cpp - or, where /root/reference does not
+    exist (the GPU box), from tools/mini_vvenc_contexts.json: the same values (the CABAC initialisation tables of the standard), dumped by this function"""
+    path = os.path.join(REF, "source", "Lib", "CommonLib", "Contexts.cpp")
+    if not os.path.exists(path):
+        import json
+        c = json.load(open(CTX_CACHE))
+        return c["tables"], c["renorm"]
+    src = open(path).read()
     tables = {}
     for m in re.finditer(r"ContextSetCfg::(\w+)(\[\])?\s*=\s*(\{)?\s*((?:ContextSetCfg::addCtxSet\s*\(\{.*?\}\)\s*,?\s*)+)\}?;", src, re.S):
         name, sets = m.group(1), []
@@ -109,6 +118,12 @@ def load_context_tables():
     rn = re.search(r"m_RenormTable_32\s*\[\s*32\s*\]\s*=\s*\{(.*?)\}", src, re.S)
     renorm = [int(v) for v in re.findall(r"\d+", rn.group(1))]
     assert len(renorm) == 32 and "SplitFlag" in tables and len(tables["SplitFlag"][0]) == 9
+    try:
+        import json
+        if not os.path.exists(CTX_CACHE) or json.load(open(CTX_CACHE)) != {"tables": tables, "renorm": renorm}:
+            json.dump({"tables": tables, "renorm": renorm}, open(CTX_CACHE, "w"))
+    except Exception:
+        pass
     return tables, renorm
 
 

@@ -498,10 +498,12 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
       if( h.chroma_format && cu.tree != VVR_TREE_LUMA && cu.intra_dir[1] > 69 ) FAIL( VVR_ERR_PARAMETER, "chroma intra mode out of range" );
       {
         // luma-tree CUs go down to 4x4; CUs with chroma need 8 luma samples of width (no 2-wide intra chroma blocks) and 4 of height
-        const int minW = cu.tree == VVR_TREE_LUMA ? 4 : 8;
+        // (4:0:0: no CU carries chroma - found by the randomised GPU leg, tests/test_gpu_fuzz.py: a monochrome picture with 4-wide intra CUs was refused)
+        const bool lumaOnly = cu.tree == VVR_TREE_LUMA || !h.chroma_format;
+        const int minW = lumaOnly ? 4 : 8;
         // (a 128-wide or -high CU of a single tree is four or two transform units of 64: prediction and reconstruction go transform unit by transform unit,
         // DecCu::xIntraRecQT, so nothing here is larger than 64; found with the first parser-fed stream that left a CTU of 128 unsplit)
-        if( cu.w > 128 || cu.h > 128 || cu.w < minW || cu.h < 4 || ( cu.tree != VVR_TREE_LUMA && cu.w * cu.h < 64 ) ) FAIL( VVR_ERR_PARAMETER, "intra CU size out of range (4..128, with chroma at least 8 wide and 16 chroma samples)" );
+        if( cu.w > 128 || cu.h > 128 || cu.w < minW || cu.h < 4 || ( !lumaOnly && cu.w * cu.h < 64 ) ) FAIL( VVR_ERR_PARAMETER, "intra CU size out of range (4..128, with chroma at least 8 wide and 16 chroma samples)" );
         if( cu.w > 64 || cu.h > 64 )
           for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ ) if( p->tu[t].w > 64 || p->tu[t].h > 64 ) FAIL( VVR_ERR_PARAMETER, "intra CU of more than 64 samples: transform units of at most 64 expected" );
       }
@@ -526,8 +528,9 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
       // (IBC_MAX_CU_SIZE), one TU, no intra / inter tools; sizes as for intra CUs.  That the reference block precedes the CU in decoding order
       // is checked where the work lists are built.
       if( !( h.tool_flags & VVR_TOOL_IBC ) ) FAIL( VVR_ERR_PARAMETER, "IBC CU in a picture without VVR_TOOL_IBC" );
-      const int minW = cu.tree == VVR_TREE_LUMA ? 4 : 8;
-      if( cu.tree == VVR_TREE_CHROMA || cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( cu.tree != VVR_TREE_LUMA && cu.w * cu.h < 64 ) || cu.num_tu != 1 )
+      const bool lumaOnly = cu.tree == VVR_TREE_LUMA || !h.chroma_format;      // (4:0:0: no CU carries chroma)
+      const int minW = lumaOnly ? 4 : 8;
+      if( cu.tree == VVR_TREE_CHROMA || cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( !lumaOnly && cu.w * cu.h < 64 ) || cu.num_tu != 1 )
         FAIL( VVR_ERR_PARAMETER, "IBC CU: chroma tree, size out of range or more than one TU" );
       if( ( cu.mv[0][0][0] | cu.mv[0][0][1] ) & 15 ) FAIL( VVR_ERR_PARAMETER, "IBC CU: fractional block vector" );
       if( cu.isp_mode || cu.bdpcm[0] || cu.bdpcm[1] || cu.lfnst_idx || cu.sbt_info || ( cu.flags & ( VVR_CU_MIP | VVR_CU_CIIP | VVR_CU_AFFINE | VVR_CU_GEO | VVR_CU_SBTMVP ) ) )
