@@ -526,7 +526,9 @@ VVR_API void*        vvr_job_stream(vvr_context* ctx, int job);
  *                         vvr_stream_wait_slot), 0: it only reads it (a sender: later pictures must not overwrite the slot under it).  The
  *                         back-end keeps the handle until the slot is next written or until it finds the event complete (it looks when a
  *                         picture that uses the slot is handed to the device, in vvr_stream_wait_slot and in vvr_sync): the caller keeps the
- *                         event alive until it is complete AND a vvr_sync has returned since (or the slot has been overwritten).
+ *                         event alive until it is complete AND a vvr_sync has returned since (or the slot has been overwritten).  The event
+ *                         MUST be recorded before it is registered: an event that was created but never recorded reads as complete
+ *                         (hipEventQuery) and would be forgotten at once.
  * A picture can only be waited for once it has been handed to the device (its work lists are built by worker threads): blocking = 0 returns
  * VVR_NOT_READY instead of waiting for that on the host.                                                                                      */
 VVR_API int          vvr_stream_wait_job(vvr_context* ctx, int job, void* stream, int blocking);

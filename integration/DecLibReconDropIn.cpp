@@ -476,7 +476,9 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
     if( pic->stillReferenced && I.desc.numDmvr )
     {
       I.dmvrOut.resize( 2 * (size_t) I.desc.numDmvr );
-      vvr_read_dmvr( I.ctx->ctx, job, I.dmvrOut.data(), I.desc.numDmvr );
+      // (a short or failed read would leave zeros / stale vectors in the cache that feeds the temporal MV prediction of later pictures: stop here instead)
+      const int got = vvr_read_dmvr( I.ctx->ctx, job, I.dmvrOut.data(), I.desc.numDmvr );
+      if( got < (int) I.desc.numDmvr ) THROW_RECOVERABLE( "vvdec_amd: vvr_read_dmvr returned " << got << " of " << I.desc.numDmvr << " refined motion vectors: " << vvr_last_error( I.ctx->ctx ) );
       for( auto& e : I.desc.dmvrCus )
       {
         CodingUnit& cu = *e.first;

@@ -187,7 +187,7 @@ API int vvr_read_dmvr( vvr_context* c, int job, int32_t* dst, size_t n )
   auto it = c->dmvr.find( job );
   if( it == c->dmvr.end() ) return VVR_ERR_PARAMETER;
   for( size_t i = 0; i < 2 * n; i++ ) dst[i] = i < it->second.size() ? it->second[i] : 0;
-  return VVR_OK;
+  return (int) ( it->second.size() / 2 );      // (as the product: the number of entries the picture has)
 }
 API int vvr_read_picture( vvr_context* c, int slot, uint16_t* const* dst, const size_t* stride, int )
 {

@@ -377,6 +377,8 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
   const bool wpOn = ( h.tool_flags & VVR_TOOL_WP ) && h.slice_type != 2;
   const int ncomp = h.chroma_format ? 3 : 1;
   uint64_t areaLuma = 0, areaChroma = 0;
+  const bool lfpOnDev = ( h.tool_flags & VVR_TOOL_LFP_ON_DEVICE ) && !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF );
+  if( lfpOnDev && p->num_cu >= ( 1u << 22 ) ) FAIL( VVR_ERR_UNSUPPORTED, "more than 4M coding units (the per-cell records of k_lf_maps hold the CU index in 22 bits)" );
   for( uint32_t i = cu0; i < cu1; i++ )
   {
     const vvr_cu& cu = p->cu[i];
@@ -388,6 +390,8 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
     for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
     {
       const vvr_tu& tu = p->tu[t];
+      // (edge parameters derived on the device: the per-cell records of k_lf_maps hold the transform unit's size in 7 bits - units are at most 64 wide and high)
+      if( lfpOnDev && ( tu.w > 64 || tu.h > 64 ) ) FAIL( VVR_ERR_PARAMETER, "transform unit larger than 64 samples (VVR_TOOL_LFP_ON_DEVICE)" );
       if( tu.comp_mask & 1 ) tuAreaL += (uint32_t) tu.w * tu.h;
       if( tu.comp_mask & 6 ) tuAreaC += cu.isp_mode ? (uint32_t) cu.w * cu.h : (uint32_t) tu.w * tu.h;      // ISP: the unsplit chroma blocks sit in the last TU
       if( tu.cu != i ) FAIL( VVR_ERR_PARAMETER, "TU does not name its CU" );
