@@ -4150,6 +4150,8 @@ void launch_plane_hash_rows( hipStream_t s, const pel_t* plane, int stride, int 
   hipLaunchKernelGGL( k_plane_hash_rows, dim3( h ), dim3( 64 ), 0, s, plane, stride, w, two, crcMode, out );
 }
 
+#include "vvr_intra_cells.inc"
+
 // =====================================================================================================================
 // k_intra — intra prediction + reconstruction, one workgroup per (CTU, colour component).
 //   DecCu::predAndReco intra branch (DecCu.cpp:271-401), IntraPrediction::xFillReferenceSamples (IntraPrediction.cpp:1072),
