@@ -148,6 +148,10 @@ struct vvr_context {
   std::vector<size_t> syncCap;          // ints allocated in syncBuf[lane]; grown when a picture has more units
   std::vector<uint32_t*> leafMaps;      // per stream: the cell maps, VPDU flags and factors of k_intra_leaf (all zero between launches), ticket + error word at the end
   size_t     leafMapInts = 0; int leafW4 = 0, leafH4 = 0;
+  bool       intraFine = false;         // VVR_INTRA_FINE=1: pictures of intra CTUs resolve their CTU wavefront block by block (k_intra<.., FINE>).  Measured in round 5 and left off:
+                                        // an I picture alone 4.23 - 4.46 ms against 4.56 (its blocks read far down the left CTU's last column, the chain of 1442 blocks stays), and
+                                        // with other pictures in flight the 256 polling workgroups of nine wavefronts cost more than they gain (4K RA 1555 against 1801 frames/s,
+                                        // all-intra 547 against 944)
   bool       intraLeaf = true;          // pictures with scattered intra blocks take the one-wavefront-per-block path (VVR_INTRA_LEAF=0: the CTU-tile path for everything)
   size_t     planeBytes[3] = { 0, 0, 0 }, slotBytes = 0;
   int        stride[3] = { 0, 0, 0 };
@@ -454,7 +458,11 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
     timed( K_RESI_ADD, [&]{ launch_resi_add( s, q->pic, P, R, q->resiItems, q->numResi ); } );
     if( q->numActive > q->numLumaUnits ) timedOn( K_INTRA, s, q->bytes[K_INTRA] - q->bytesIntraLuma, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, q->numLumaUnits, q->numActive, q->intraWorkgroupsChroma, c->syncBuf[lane], wideIntra ); } );
   }
-  else if( q->numActive ) timed( K_INTRA, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane], wideIntra ); } );
+  else if( q->numActive )
+  {
+    const bool fine = q->intraFine && c->intraFine;
+    timed( K_INTRA, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane], wideIntra, fine ? c->leafMaps[lane] : nullptr, c->leafMapInts, c->leafW4, c->leafH4 ); } );
+  }
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
   if( lmcsOn && !hop ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, P, 1 ); } );
   // in-loop filters: LF_V, LF_H, SAO, ALF (DecLibRecon.cpp:943-1100)
@@ -968,6 +976,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   c->numLanesRR = ns; c->prioLane = nl > ns ? ns : -1;
   if( const char* e = getenv( "VVR_PARTS" ) ) c->partsPolicy = atoi( e );      // 0 / 1 / 2: see partsPolicy
   if( const char* e = getenv( "VVR_INTRA_LEAF" ) ) c->intraLeaf = atoi( e ) != 0;
+  if( const char* e = getenv( "VVR_INTRA_FINE" ) ) c->intraFine = atoi( e ) != 0;
   c->streams.resize( nl, nullptr );
   bool ok = true;
   for( int i = 0; i < ns && ok; i++ ) ok = hipStreamCreateWithFlags( &c->streams[i], hipStreamNonBlocking ) == hipSuccess;

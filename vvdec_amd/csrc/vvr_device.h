@@ -145,7 +145,8 @@ void launch_plane_hash_rows( hipStream_t s, const pel_t* plane, int stride, int 
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );
 void launch_mc_rpr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );      // tiles of CUs with a scaled reference picture
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );
-void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numUnits, int ticket0, int ticket1, int numWorkgroups, int* sync, int wide );      // the units [ticket0, ticket1); wide: an I picture the stream waits for (eight wavefronts per workgroup)
+void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numUnits, int ticket0, int ticket1, int numWorkgroups, int* sync, int wide,
+                     uint32_t* maps = nullptr, size_t mapInts = 0, int mapW4 = 0, int mapH4 = 0 );      // maps (a picture whose units are all whole CTUs of intra CUs): the per-cell words - the CTU wavefront is resolved block by block (k_intra<.., FINE>)      // the units [ticket0, ticket1); wide: an I picture the stream waits for (eight wavefronts per workgroup)
 void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems );      // scaled chroma residuals of inter blocks (between the luma and the chroma units)
 size_t intra_sync_ints( int numUnits, int numItems );      // ints `sync` has to hold: ticket, unit flags, the blocks' parameter records
 // the intra stage of a picture with scattered intra blocks (vvr_intra_leaf.inc): one wavefront per block of `items` (decoding order per component), ordered through

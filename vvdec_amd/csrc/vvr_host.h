@@ -25,6 +25,7 @@ struct vvr_prepared {
   uint32_t numDmvr = 0;                                    // delta-MV entries the DMVR kernel writes (pairs of ints)
   TbItem*  tbItems[3] = { nullptr, nullptr, nullptr }; int numTb[3] = { 0, 0, 0 };   // size classes 16 / 32 / 64
   IntraItem* intraItems = nullptr; IntraUnit* units = nullptr; int numActive = 0, numIntra = 0;
+  bool     intraFine = false;                              // (tile path) every unit is a whole CTU of intra CUs: the CTU wavefront may be resolved block by block (k_intra<.., FINE>)
   bool     intraLeaf = false;                              // the items are those of k_intra_leaf (one wavefront per block, no units): a picture with scattered intra blocks
   int      intraWorkgroups = 0;                            // workgroups the intra stage is launched with (the dependency front they can keep busy)
   IntraItem* resiItems = nullptr; int numResi = 0;         // scaled chroma residuals of inter blocks (k_resi_add); with them the stage runs as luma units, k_resi_add, chroma units

@@ -4177,6 +4177,7 @@ __device__ __forceinline__ int tile_idx( int dx, int dy )
   return dy < 0 ? ( dy + IT_PAD ) * IT_TS + dx + IT_PADX : IT_PAD * IT_TS + dy * IT_TSB + dx + IT_PADX;
 }
 #define IT_MAXREF ( 2 * 64 + 8 )
+#define LEAF_PUBLISH_BATCH 1
 
 #define IT_BATCH ( IT_WAVES * 16 )   // IntraItems staged in LDS at a time (16 B each: one dword per thread)
 // wavefronts of a workgroup (template parameter of k_intra): each predicts one item (a block of up to 256 samples, or a band of rows of a larger one) at a time.
@@ -4530,10 +4531,16 @@ __global__ __launch_bounds__( 256 ) void k_intra_setup( IntraPic pic, const Intr
   c[C_ORIGIN] = (uint32_t) ox | ( (uint32_t) oy << 16 );
 }
 
-template<int IT_WAVES>
-__global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraItem* __restrict__ items, const uint32_t* __restrict__ ctx /* k_intra_setup */,
+// FINE (round 5; a picture whose CUs are all intra CUs): the CTU-to-CTU dependency is resolved per BLOCK instead of per unit.  A unit waits for nobody when it
+// starts; a block whose reference lines leave the CTU polls the per-cell words of exactly the cells it reads (vvr_intra_cells.inc), fetches those samples from
+// the picture into the border of the tile and goes on as before; an extra wavefront of the workgroup (the publisher) follows the blocks in order, stores every
+// finished block from the tile to the picture (device scope) and clears its cells.  The CTU wavefront of an I picture - 62 steps of a whole CTU at 4K - becomes
+// the dependency chain of the blocks themselves: a CTU starts when the few blocks it reads first are done, not when its neighbours are.  Chroma blocks poll the
+// luma they read (CCLM, the chroma scaling factor) the same way.
+template<int IT_WAVES, bool FINE>
+__global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic pic, const IntraItem* __restrict__ items, const uint32_t* __restrict__ ctx /* k_intra_setup */,
                                                   const IntraUnit* __restrict__ units, int numActive,
-                                                  int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */
+                                                  int* __restrict__ sync /* [0]: ticket, [1 + unit]: done flags */, LeafMaps M /* FINE: the per-cell words */, int* __restrict__ lsync /* FINE: [1] error word */
 #ifdef VVR_INTRA_DEV
                                                   , int dbg, unsigned long long* __restrict__ trace /* developer timeline (VVR_INTRA_TRACE) or nullptr */,
                                                   unsigned long long* __restrict__ btrace /* per block: ready / go / filled / done (shader clock) */
@@ -4569,7 +4576,7 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
   const uint32_t ent = un->ent;
   const int comp = ( ent >> 24 ) & 3, ctu = ent & 0xffffff;
   const bool borderOnly = ( ent >> 31 ) != 0;          // whole CTU, every sample intra: the interior is produced here, never read first
-  const bool publish = ( ( ent >> 30 ) & 1 ) != 0 && !( dbg & 0x100 );     // another unit waits for this one
+  const bool publish = !FINE && ( ( ent >> 30 ) & 1 ) != 0 && !( dbg & 0x100 );     // another unit waits for this one
   const int cxI = ctu % pic.ctusX, cyI = ctu / pic.ctusX;
   const int cs = comp ? 1 : 0;
   const int S = ( 1 << pic.log2Ctu ) >> cs;
@@ -4586,10 +4593,10 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
   const int nb0 = (int) min( (uint32_t) IT_BATCH, i1 - i0 );
   const uint32_t itemPre = tid < nb0 * 4 ? reinterpret_cast<const uint32_t*>( items + i0 )[tid] : 0u;
   uint4 recN = make_uint4( 0, 0, 0, 0 ), recNN = make_uint4( 0, 0, 0, 0 );
-  if( iA + wv < i1 ) recN = intra_load_item( items, iA + wv );
-  if( iA + wv + IT_WAVES < i1 ) recNN = intra_load_item( items, iA + wv + IT_WAVES );
+  if( wv < IT_WAVES && iA + wv < i1 ) recN = intra_load_item( items, iA + wv );
+  if( wv < IT_WAVES && iA + wv + IT_WAVES < i1 ) recNN = intra_load_item( items, iA + wv + IT_WAVES );
   uint32_t ctxPre = 0;
-  if( iA + wv < i1 ) ctxPre = ctx[(size_t) ( iA + wv ) * IT_CTX + lane];
+  if( wv < IT_WAVES && iA + wv < i1 ) ctxPre = ctx[(size_t) ( iA + wv ) * IT_CTX + lane];
 #define TILE( x, y ) sh.tile[tile_idx( ( x ) - ox, ( y ) - oy )]
   // block record q of this unit into scalar registers (uniform per wavefront)
 #define IT_FETCH( IT, Q ) { const uint32_t* ip_ = ( Q ) - i0 < (uint32_t) IT_BATCH ? reinterpret_cast<const uint32_t*>( &sh.items[( Q ) - i0] ) : reinterpret_cast<const uint32_t*>( &items[Q] ); \
@@ -4597,7 +4604,7 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
   // ---- wait for the units that produce intra samples this one reads (same component: reference lines; luma: CCLM)
   {
     // one lane per producer (at most VVR_INTRA_MAX_DEPS of them): the polls overlap instead of queueing behind each other
-    const uint32_t nd = ( dbg & 1 ) ? 0 : un->ndeps;
+    const uint32_t nd = ( FINE || ( dbg & 1 ) ) ? 0 : un->ndeps;      // (FINE: every block waits for exactly the cells it reads)
     if( (uint32_t) tid < nd )
     {
       int* flag = &sync[1 + un->deps[tid]];
@@ -4685,6 +4692,8 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
   // of the (possibly transposed) block from seven reference samples with one filter.
   // The loop is software-pipelined without a copy of its loads in front of it: its first round has no block, it only starts the fetches of
   // the wavefront's first block - and stages the unit's part of the tile behind them.
+  const int w4c = M.w4, h4c = M.h4, cu_ = comp ? 1 : 2;      // (FINE) the cell maps: row stride, rows, log2 samples per cell side of this component
+  if( !FINE || wv < IT_WAVES )
   {
     IntraWave& W = sh.wave[wv];
     pel_t* const T = W.topB + IT_NEG;
@@ -4705,9 +4714,9 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
       if( cur && q >= qEnd ) break;
       const IntraItem it = intra_item_of( recC );
       if( cur ) intra_stash_resi( RR, it, W.resi, lane );
-      const IntraLumaRegs LC = LR;                                             // (CCLM) co-located luma of this block, fetched while the block before was predicted
+      IntraLumaRegs LC = LR;                                                   // (CCLM) co-located luma of this block, fetched while the block before was predicted (FINE: when its turn comes, below)
       // the residual (and the luma of a CCLM block) of the wavefront's next block starts, the records move up
-      if( q + IT_WAVES < qEnd ) { const IntraItem itN = intra_item_of( recN ); intra_load_resi( RR, itN, rs, rstride, lane ); if( comp ) intra_load_cclm_luma( LR, itN, pic, lane ); }
+      if( q + IT_WAVES < qEnd ) { const IntraItem itN = intra_item_of( recN ); intra_load_resi( RR, itN, rs, rstride, lane ); if( comp && !FINE ) intra_load_cclm_luma( LR, itN, pic, lane ); }
       recC = recN; recN = recNN;
       if( q + 3 * IT_WAVES < qEnd ) recNN = intra_load_item( items, (uint32_t) ( q + 3 * IT_WAVES ) );
       const uint32_t ctxC = ctxCur;                                           // the block's parameter record (lane k: value k), fetched two blocks ahead
@@ -4730,7 +4739,7 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
         const int nTop = nch * max( 0, min( by1, oy ) - by0 );                   // chunks in the rows above the CTU
         const int rowsIn = max( 0, by1 - max( by0, oy ) );
         const bool perBlock = !borderOnly;
-        const int total = ( ( dbg & 2 ) || perBlock ) ? 0 : nTop + ( bc0 < 0 ? rowsIn : 0 );
+        const int total = ( FINE || ( dbg & 2 ) || perBlock ) ? 0 : nTop + ( bc0 < 0 ? rowsIn : 0 );      // (FINE: the blocks fetch what they read of the border themselves)
         if( perBlock && !( dbg & 2 ) )
         {
           // a unit that is not a whole intra CTU: only the reference lines its blocks read (one row above, one column left of every
@@ -4821,7 +4830,17 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
       const int lx = ( cxI << pic.log2Ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.log2Ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
       if( wv < 4 && lx < pic.width && ly < pic.height && ( wv == 0 || csNv1 ) )
       {
-        const int f = lmcs_cscale_factor_wave( pic, lx, ly, lane );
+        if( FINE )
+        {
+          // the luma the factor is averaged over: left of / above the CU at the VPDU's origin (calculateChromaAdjVpduNei)
+          const uint32_t d = pic.csVpdu[( ly >> pic.vpduLog2 ) * pic.vpdusX + ( lx >> pic.vpduLog2 )];
+          const int xPos = d & 0x1fff, yPos = ( d >> 13 ) & 0x1fff, n = 1 << pic.vpduLog2;
+          LeafSeg seg[2];
+          seg[0] = ( ( d >> 26 ) & 1 ) ? leaf_seg( M.cell[0], w4c, h4c, ( xPos - 1 ) >> 2, yPos >> 2, ( xPos - 1 ) >> 2, min( yPos + n - 1, pic.height - 1 ) >> 2 ) : leaf_seg( M.cell[0], w4c, h4c, 0, 0, -1, -1 );
+          seg[1] = ( ( d >> 27 ) & 1 ) ? leaf_seg( M.cell[0], w4c, h4c, xPos >> 2, ( yPos - 1 ) >> 2, min( xPos + n - 1, pic.width - 1 ) >> 2, ( yPos - 1 ) >> 2 ) : leaf_seg( M.cell[0], w4c, h4c, 0, 0, -1, -1 );
+          leaf_wait( seg, w4c, lane, lsync );
+        }
+        const int f = lmcs_cscale_factor_wave<FINE>( pic, lx, ly, lane );
         if( lane == 0 ) sh.csFac[wv] = f;
       }
     }
@@ -4880,6 +4899,56 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
         }
         IT_DONE()
         continue;
+      }
+      if( FINE )
+      {
+        // ---- what the block reads outside its CTU: wait for exactly those cells, then bring the samples into the border of the tile (the fill below reads them
+        // there as ever).  A block at the CTU's top edge reads its whole top line (corner, above, above-right) outside, one at the left edge its left line.
+        const bool ispB = ( F & CF_ISP ) != 0;
+        if( ( F & CF_ANY ) && !( ispB && ( it.tu & 0xfff ) ) )      // (later ISP partitions: the coding unit's lines are in the tile since the first one)
+        {
+          const uint32_t ispw = ispB ? it.tu : 0;
+          const int bx0 = it.x, by0 = it.y;
+          const int fx0 = bx0 - (int) ( ispw & 63 ), fy0 = by0 - (int) ( ( ispw >> 6 ) & 63 );
+          const int fTopLen = ispB ? 2 << ( ( ispw >> 12 ) & 7 ) : 2 * w, fLeftLen = ispB ? 2 << ( ( ispw >> 15 ) & 7 ) : 2 * h;
+          const int unitS = 4 >> cs, nTL = it.nTL & 1, nA = it.nA, nL = it.nL;
+          const int szA = min( nA * unitS, fTopLen ), szL = min( nL * unitS, fLeftLen );
+          const int cxx = fx0 - 1 - mrl, cyy = fy0 - 1 - mrl;
+          const bool topOut = fy0 == oy && ( nA || nTL ), leftOut = fx0 == ox && ( nL || nTL );
+          // top rectangle: rows cyy .. oy - 1, columns tc0 .. tc1; left rectangle: columns cxx .. ox - 1, rows lr0 .. lr1
+          const int tc0 = nTL ? cxx : fx0, tc1 = nA ? fx0 + szA - 1 : fx0 - 1, tn = topOut ? max( 0, tc1 - tc0 + 1 ) : 0;
+          const int lr0 = nTL ? cyy : fy0, lr1 = nL ? fy0 + szL - 1 : fy0 - 1, ln = leftOut ? max( 0, lr1 - lr0 + 1 ) : 0;
+          if( tn | ln )
+          {
+            LeafSeg seg[2];
+            seg[0] = tn ? leaf_seg( M.cell[comp], w4c, h4c, tc0 >> cu_, cyy >> cu_, tc1 >> cu_, ( oy - 1 ) >> cu_ ) : leaf_seg( M.cell[comp], w4c, h4c, 0, 0, -1, -1 );
+            seg[1] = ln ? leaf_seg( M.cell[comp], w4c, h4c, cxx >> cu_, lr0 >> cu_, ( ox - 1 ) >> cu_, lr1 >> cu_ ) : leaf_seg( M.cell[comp], w4c, h4c, 0, 0, -1, -1 );
+            leaf_wait( seg, w4c, lane, lsync );
+            const int rowsT = mrl + 1, total = rowsT * ( tn + ln );
+#pragma unroll 1
+            for( int k = lane; k < total; k += 64 )
+            {
+              int x, y;
+              if( k < rowsT * tn ) { const int r = k / tn; x = tc0 + ( k - r * tn ); y = cyy + r; }
+              else { const int k2 = k - rowsT * tn, c = k2 / ln; x = cxx + c; y = lr0 + ( k2 - c * ln ); }
+              sh.tile[tile_idx( x - ox, y - oy )] = (pel_t) ld_pel<true>( &plane[(size_t) y * pstride + x] );
+            }
+            IT_CSYNC();
+          }
+        }
+        if( F & CF_CCLM )
+        {
+          // the co-located luma and its template rows / columns (luma blocks of this and of the neighbouring CTUs: all in units with lower tickets)
+          const uint32_t lm = it.tu;
+          const int actualTop = lm & 0xff, actualLeft = ( lm >> 8 ) & 0xff;
+          const int lx0 = (int) it.x << 1, ly0 = (int) it.y << 1;
+          LeafSeg seg[3];
+          seg[0] = leaf_seg( M.cell[0], w4c, h4c, lx0 >> 2, ly0 >> 2, ( lx0 + 2 * w - 1 ) >> 2, ( ly0 + 2 * h - 1 ) >> 2 );
+          seg[1] = ly0 > 0 ? leaf_seg( M.cell[0], w4c, h4c, ( lx0 - 4 ) >> 2, ( ly0 - 4 ) >> 2, ( lx0 + 2 * max( w, actualTop ) - 1 ) >> 2, ( ly0 - 4 ) >> 2 ) : leaf_seg( M.cell[0], w4c, h4c, 0, 0, -1, -1 );
+          seg[2] = lx0 > 0 ? leaf_seg( M.cell[0], w4c, h4c, ( lx0 - 4 ) >> 2, ly0 >> 2, ( lx0 - 4 ) >> 2, ( ly0 + 2 * max( h, actualLeft ) - 1 ) >> 2 ) : leaf_seg( M.cell[0], w4c, h4c, 0, 0, -1, -1 );
+          leaf_wait( seg, w4c, lane, lsync );
+          intra_load_cclm_luma<true>( LC, it, pic, lane );
+        }
       }
       // ---- xFillReferenceSamples (:1072-1250): one lane per reference position, ONE read per line and lane - the substitution of samples that
       // are not available (the nearest available one along the line, the first left sample for an unavailable corner, mid grey if nothing is)
@@ -5112,7 +5181,7 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
           for( int i = lane; i < wh; i += 64 )
           {
             const int x = i & ( w - 1 ), y = i >> lw;
-            const int t = (int16_t) intra_cclm_luma_at( pic.plane[0], pic.stride[0], x0 << 1, y0 << 1, x, y, bLeft, bAbove, colloc );
+            const int t = (int16_t) intra_cclm_luma_at<FINE>( pic.plane[0], pic.stride[0], x0 << 1, y0 << 1, x, y, bLeft, bAbove, colloc );
             int v = clip_pel( ( ( a * t ) >> shift ) + b, bd );
             if( hasResi ) { const int r = W.resi[i]; v = clip_pel( v + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); }
             sh.tile[tileBase + y * IT_TSB + x] = (pel_t) v;
@@ -5271,10 +5340,73 @@ __global__ __launch_bounds__( IT_NT ) void k_intra( IntraPic pic, const IntraIte
 #undef IT_CSYNC
 #undef CP
   }
+  else
+  {
+    // ---- FINE: the publisher.  It follows the unit's items in order: when item q is in the tile (progress counter of the wavefront that predicts it), its
+    // samples go to the picture with device-scope stores, and behind them (s_waitcnt vmcnt(0)) its cells are cleared - that is what the blocks of the CTUs
+    // to the right and below (and the chroma blocks of this CTU: CCLM, the chroma scaling factor) wait for.  The cells of an ISP coding unit are cleared with
+    // its last partition (partitions share cells).
+    lds_barrier();                    // (the barrier behind the compute wavefronts' first round)
+    const uint32_t qEndP = ( dbg & 4 ) ? i0 : i1;
+    auto itemDone = [&]( uint32_t q ) { const int k = (int) ( q - iA ); return __hip_atomic_load( &sh.prog[k & ( IT_WAVES - 1 )], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) >= k / IT_WAVES + 1; };
+#pragma unroll 1
+    for( uint32_t q = iA; q < qEndP; )
+    {
+      // the items that are in the tile by now, in order, at most LEAF_PUBLISH_BATCH at a time: their stores go out together, one wait for all of them, then
+      // their cells.  Measured at 4K (I picture alone): batches of 1 - 4231 us, of up to 8 - 4531 us: what a neighbouring CTU waits for is the FIRST item of a
+      // batch, and it is held back by the stores of the others
+      while( !itemDone( q ) ) __builtin_amdgcn_s_sleep( 1 );
+      uint32_t n = 1;
+      while( n < LEAF_PUBLISH_BATCH && q + n < qEndP && itemDone( q + n ) ) n++;
+      asm volatile( "" ::: "memory" );
+#pragma unroll 1
+      for( uint32_t j = 0; j < n; j++ )
+      {
+        IntraItem it;
+        IT_FETCH( it, q + j )
+        const int lw = it.lw, rows = intra_part_rows( it ), wh = rows << lw, yb = IT_PART( it ) * rows;
+        if( lw >= 2 && !( it.x & 3 ) )
+        {
+          for( int i = lane; i < ( wh >> 2 ); i += 64 )
+          {
+            const int x = it.x + ( ( i << 2 ) & ( ( 1 << lw ) - 1 ) ), y = it.y + yb + ( ( i << 2 ) >> lw );
+            st_pel4_sc1( &plane[(size_t) y * pstride + x], *reinterpret_cast<const uint2*>( &TILE( x, y ) ) );
+          }
+        }
+        else
+          for( int i = lane; i < wh; i += 64 )
+          {
+            const int x = it.x + ( i & ( ( 1 << lw ) - 1 ) ), y = it.y + yb + ( i >> lw );
+            st_pel_sc1( &plane[(size_t) y * pstride + x], TILE( x, y ) );
+          }
+      }
+      asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+#pragma unroll 1
+      for( uint32_t j = 0; j < n; j++ )
+      {
+        IntraItem it;
+        IT_FETCH( it, q + j )
+        const int rows = intra_part_rows( it ), yb = IT_PART( it ) * rows;
+        const bool ispIt = !comp && it.mode <= 66 && ( it.flags & IT_F_ISP ) == IT_F_ISP && !( it.flags & IT_F_MIP );
+        int cx0 = it.x, cy0 = it.y + yb, cw = 1 << it.lw, ch = rows;
+        if( ispIt )
+        {
+          // the last partition of its coding unit? (the partitions follow each other in the list; they share cells: cleared with the last one)
+          bool more = false;
+          if( q + j + 1 < i1 ) { IntraItem nx; IT_FETCH( nx, q + j + 1 ) more = ( nx.flags & IT_F_ISP ) == IT_F_ISP && !( nx.flags & IT_F_MIP ) && nx.mode <= 66 && ( nx.tu & 0xfff ) != 0; }
+          if( more ) continue;
+          cx0 = it.x - (int) ( it.tu & 63 ); cy0 = it.y - (int) ( ( it.tu >> 6 ) & 63 ); cw = 1 << ( ( it.tu >> 12 ) & 7 ); ch = 1 << ( ( it.tu >> 15 ) & 7 );
+        }
+        leaf_set_cells( M.cell[comp], w4c, cu_, cx0, cy0, cw, ch, 0u, lane );
+      }
+      q += n;
+    }
+  }
   __syncthreads();                    // every block of the unit is in the tile
   IT_TRACE( 3 );
   // ---- write the reconstructed intra samples back to HBM (deferred so that the block loop never waits for a store)
-  if( borderOnly )
+  if( FINE ) { /* the publisher has stored every block */ }
+  else if( borderOnly )
   {
     const int rows = min( PH, oy + S ) - oy, nch = ( min( PW, ox + S ) - ox + 7 ) >> 3;     // a chunk past the picture edge lands in the row padding
     for( int i = tid; i < rows * nch; i += IT_NT )
@@ -5399,7 +5531,7 @@ void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlane
 // The units [ticket0, ticket1) of the table.  A picture whose inter blocks carry scaled chroma residuals runs the stage in two launches - the luma
 // units, then (behind k_resi_add) the chroma units: the flags of the first launch stay set, so a chroma unit that names a luma producer finds it done.
 void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numActive, int ticket0, int ticket1,
-                   int numWorkgroups, int* sync, int wide )
+                   int numWorkgroups, int* sync, int wide, uint32_t* maps, size_t mapInts, int mapW4, int mapH4 )
 {
   if( !numActive || ticket1 <= ticket0 ) return;
   numWorkgroups = std::max( 1, std::min( numWorkgroups, ticket1 - ticket0 ) );
@@ -5419,9 +5551,30 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   // pictures in flight: 1065 against 810 pictures/s, profiles/round4_lanes_and_host_threads.txt)
   int waves = wide ? 8 : 4;
   if( pic.hdr.slice_type == 2 && !wide ) numWorkgroups = std::max( 1, numWorkgroups / 2 );
+  // FINE (maps != nullptr: a picture whose units are all whole CTUs of intra CUs, launched in one go): every cell of the picture is pending until the publisher of
+  // its CTU has stored it; with the units waiting for nobody more of them are worth having resident (the front of the block-level dependency chain spans
+  // several CTU diagonals)
+  LeafMaps M = {};
+  int* lsync = nullptr;
+  const bool fine = maps != nullptr && ticket0 == 0 && ticket1 == numActive;
+  if( fine )
+  {
+    const size_t cellsPerMap = (size_t) mapW4 * mapH4;
+    for( int k = 0; k < 3; k++ ) M.cell[k] = maps + (size_t) k * cellsPerMap;
+    M.w4 = pic.w4; M.h4 = pic.h4;
+    lsync = reinterpret_cast<int*>( maps + mapInts - 64 );
+    for( int k = 0; k < ( pic.hdr.chroma_format ? 3 : 1 ); k++ ) hipMemsetD32Async( (hipDeviceptr_t) M.cell[k], 1, (size_t) pic.w4 * pic.h4, s );
+    static const int fineWg = getenv( "VVR_INTRA_FINE_WG" ) ? atoi( getenv( "VVR_INTRA_FINE_WG" ) ) : 0;
+    numWorkgroups = std::max( 1, std::min( ticket1 - ticket0, fineWg > 0 ? fineWg : ( wide ? 256 : 4 * numWorkgroups ) ) );
+  }
 #ifndef VVR_INTRA_DEV
-  if( waves == 8 ) hipLaunchKernelGGL( k_intra<8>, dim3( numWorkgroups ), dim3( 512 ), 0, s, ip, items, ctx, units, numActive, sync );
-  else             hipLaunchKernelGGL( k_intra<4>, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync );
+  if( fine )
+  {
+    if( waves == 8 ) hipLaunchKernelGGL( ( k_intra<8, true> ), dim3( numWorkgroups ), dim3( 576 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync );
+    else             hipLaunchKernelGGL( ( k_intra<4, true> ), dim3( numWorkgroups ), dim3( 320 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync );
+  }
+  else if( waves == 8 ) hipLaunchKernelGGL( ( k_intra<8, false> ), dim3( numWorkgroups ), dim3( 512 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync );
+  else                  hipLaunchKernelGGL( ( k_intra<4, false> ), dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync );
 #else
   if( const char* e = getenv( "VVR_INTRA_WAVES" ) ) waves = atoi( e ) == 8 ? 8 : 4;
   static const int dbg = getenv( "VVR_INTRA_DBG" ) ? atoi( getenv( "VVR_INTRA_DBG" ) ) : 0;     // timing experiments only (results are wrong with any bit set)
@@ -5430,8 +5583,13 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   const size_t nItems = 1 << 20;      // (block timeline: sized generously, indexed by item)
   if( tr ) { hipMalloc( (void**) &trace, sizeof( unsigned long long ) * 8 * (size_t) numActive ); hipMemsetAsync( trace, 0, sizeof( unsigned long long ) * 8 * (size_t) numActive, s );
              hipMalloc( (void**) &btrace, sizeof( unsigned long long ) * 8 * nItems ); hipMemsetAsync( btrace, 0, sizeof( unsigned long long ) * 8 * nItems, s ); }
-  if( waves == 8 ) hipLaunchKernelGGL( k_intra<8>, dim3( numWorkgroups ), dim3( 512 ), 0, s, ip, items, ctx, units, numActive, sync, dbg, trace, btrace );
-  else             hipLaunchKernelGGL( k_intra<4>, dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync, dbg, trace, btrace );
+  if( fine )
+  {
+    if( waves == 8 ) hipLaunchKernelGGL( ( k_intra<8, true> ), dim3( numWorkgroups ), dim3( 576 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync, dbg, trace, btrace );
+    else             hipLaunchKernelGGL( ( k_intra<4, true> ), dim3( numWorkgroups ), dim3( 320 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync, dbg, trace, btrace );
+  }
+  else if( waves == 8 ) hipLaunchKernelGGL( ( k_intra<8, false> ), dim3( numWorkgroups ), dim3( 512 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync, dbg, trace, btrace );
+  else                  hipLaunchKernelGGL( ( k_intra<4, false> ), dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync, dbg, trace, btrace );
   if( tr )
   {
     // developer timeline: ticket, phase time stamps (100 MHz), block count / unit word, number of producers; per block four shader-clock stamps

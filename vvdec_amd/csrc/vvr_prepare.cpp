@@ -139,7 +139,7 @@ struct PrepScratch
     lfSb.clear(); lfpOnDevice = ( h.tool_flags & VVR_TOOL_LFP_ON_DEVICE ) && !( h.tool_flags & VVR_TOOL_DEBLOCK_OFF );
     mcCus.clear(); devTiles[0] = devTiles[1] = devTiles[2] = 0;
     for( int k = 0; k < 3; k++ ) { tb[k].clear(); intra[k].clear(); itemH[k].clear(); prodPool[k].clear(); }
-    resiAdd.clear(); intraAll.clear(); units.clear(); unitsDev.clear(); csVpduV.clear();
+    resiAdd.clear(); intraAll.clear(); units.clear(); unitsDev.clear(); csVpduV.clear(); intraFine = false;
     ctuStartV.assign( 3 * (size_t) ( numCtu + 1 ), 0 );
     for( double& b : bytes ) b = 0;
     bytesBdof = bytesIntraLuma = 0; bytesTb[0] = bytesTb[1] = bytesTb[2] = 0;
@@ -203,6 +203,7 @@ struct PrepScratch
   // device through per-cell words (k_intra_leaf, vvr_intra_leaf.inc): the host only lists the blocks in decoding order - no producer analysis, no block map, no
   // units.  `leafOn`: the owner of the scratch allows it (vvr_scratch_intra_leaf); `leaf`: this picture takes that path.
   bool leafOn = true, leaf = false;
+  bool intraFine = false;                   // (tile path) every unit is a whole CTU of intra CUs: the launch may order the CTUs block by block
   std::vector<uint8_t> csNeeded;            // (leaf) per VPDU: a chroma block of the stage scales its residual with the VPDU's factor (an IT_MODE_CSFAC item computes it)
   int emitLeafItems( std::string& err );
   int buildWorkLists( std::string& err, uint32_t cu0 = 0, uint32_t cu1 = 0xffffffffu );
@@ -1548,6 +1549,8 @@ int PrepScratch::emitUnitTable( std::string& err )
     unitCount.assign( 3 * (size_t) numCtu, 0 );
     for( auto& u : units ) unitCount[(size_t) u.comp * numCtu + u.ctu]++;
     unitsDev.resize( units.size() );
+    // a picture whose units are all whole CTUs of intra CUs (an I picture without IBC): its CTU wavefront can be resolved block by block (k_intra<.., FINE>)
+    intraFine = allIntraCus && !twoLaunches && !( h.tool_flags & VVR_TOOL_IBC );
     for( size_t t = 0; t < perm.size(); t++ )
     {
       const UnitH& u = units[perm[t]];
@@ -1556,6 +1559,7 @@ int PrepScratch::emitUnitTable( std::string& err )
       // border and writes the CTU back with 16-byte stores
       const bool all = unitCount[(size_t) u.comp * numCtu + u.ctu] == 1 && fastCtu[u.ctu];      // (fastCtu: every CU of the CTU is an intra CU)
       d.ent = ( u.comp << 24 ) | u.ctu | ( u.hasCs ? 0x20000000u : 0 ) | ( u.waited ? 0x40000000u : 0 ) | ( all ? 0x80000000u : 0 );
+      if( !all && u.i1 > u.i0 ) intraFine = false;
       d.i0 = itemMap[u.comp][u.i0]; d.i1 = itemMap[u.comp][u.i1]; d.iA = itemMap[u.comp][u.iA];
       d.bbox = (uint32_t) u.bb.y0 | ( (uint32_t) u.bb.y1 << 8 ) | ( (uint32_t) u.bb.c0 << 16 ) | ( (uint32_t) u.bb.c1 << 24 );
       d.ndeps = (uint32_t) std::min<size_t>( u.deps.size(), VVR_INTRA_MAX_DEPS );
@@ -1916,7 +1920,7 @@ void vvr_host_bind( const PrepScratch& S, vvr_prepared& q, char* base )
   q.rprItems = (McItem*) at( S.iMcR ); q.numRprItems = (int) S.mcRpr.size();
   q.numDmvr = S.numDmvr;
   for( int k = 0; k < 3; k++ ) { q.tbItems[k] = (TbItem*) at( S.iTb[k] ); q.numTb[k] = (int) S.tb[k].size(); }
-  q.intraItems = (IntraItem*) at( S.iIntra ); q.numIntra = (int) S.intraAll.size(); q.intraLeaf = S.leaf;
+  q.intraItems = (IntraItem*) at( S.iIntra ); q.numIntra = (int) S.intraAll.size(); q.intraLeaf = S.leaf; q.intraFine = !S.leaf && S.intraFine && !S.unitsDev.empty();
   q.units = (IntraUnit*) at( S.iUnits ); q.numActive = (int) S.unitsDev.size(); q.intraWorkgroups = S.intraWorkgroups;
   q.resiItems = (IntraItem*) at( S.iResi ); q.numResi = (int) S.resiAdd.size(); q.numLumaUnits = S.numLumaUnits; q.intraWorkgroupsChroma = S.intraWorkgroupsChroma;
   memcpy( q.bytes, S.bytes, sizeof( q.bytes ) );
