@@ -5,8 +5,7 @@ never produced.  Two rules of the reference only show with such vectors (DESIGN.
   * an SbTMVP CU is predicted in the pieces xSubPuMC joins, and wrapClipMv depends on the piece's position and width.
 
 The CPU side (oracle == reference classes, host glue, drop-in on the CPU oracle == reference decoder) is in test_oracle_vs_ref.py, test_host_glue.py and
-test_dropin_library.py.  This file is the GPU side.  It sorts last in the suite on purpose: the SbTMVP rule reached k_mc after round 4's GPU budget was
-spent, so these cases had not run on a device when they were committed."""
+test_dropin_library.py.  This file is the GPU side (green on the device since the end of round 4: GPUTEST_r04.json)."""
 import glob
 import os
 import sys
@@ -31,13 +30,13 @@ def test_vectors_beyond_a_wrap_period(built, W, H, off, kw):
 
 
 def test_parsed_streams_with_vectors_beyond_a_wrap_period():
-    """tests/bitstreams_open: the four streams of the random sweep (tools/fuzz_dropin_on_the_oracle.py) that showed the two rules - decoded by the
+    """tests/bitstreams/wraparound_*: the four streams of the random sweep (tools/fuzz_dropin_on_the_oracle.py) that showed the two rules - decoded by the
     reference's application on the drop-in library with the GPU back-end: output MD5 == the reference decoder's, every decoded picture hash checks"""
     sys.path.insert(0, os.path.join(HERE, "..", "tools"))
     import dropin_decode as dd
     if not os.path.exists(dd.APP_DROPIN):
         pytest.skip("oracle/_ref/vvdecapp_dropin not built")
-    streams = sorted(glob.glob(os.path.join(HERE, "bitstreams_open", "*.bit")))
+    streams = sorted(glob.glob(os.path.join(HERE, "bitstreams", "wraparound_ctu64_384x256_seed*", "*.bit")))
     assert len(streams) == 4
     bad = []
     for b in streams:
