@@ -2314,13 +2314,20 @@ FIXTURES = [
 ]
 
 
+# A stream at a BASELINE size (round 5): 3840x2176 - whole CTUs of 128, the writer makes no implicit splits at the picture boundary -, one GOP of 16 behind the
+# I picture, the tool mix of mini_all_tools_ctu128_384x256.  Kept out of FIXTURES: the random sweeps (tools/fuzz_*.py, tests/test_gpu_fuzz.py) draw from that
+# list, and 8 000 CUs per picture take the writer a second per picture.  `--big` (or --only mini_4k) writes it.
+BIG_FIXTURES = [("mini_4k_all_tools_ctu128_3840x2176", dict(dict([f for f in FIXTURES if f[0] == "mini_all_tools_ctu128_384x256"][0][1]), width=3840, height=2176), 17, 4242)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "bitstreams"))
     ap.add_argument("--only", default=None)
+    ap.add_argument("--big", action="store_true", help="also the stream(s) at a BASELINE picture size (BIG_FIXTURES)")
     a = ap.parse_args()
     tables, renorm = load_context_tables()
-    for name, kw, n, seed in FIXTURES:
+    for name, kw, n, seed in FIXTURES + (BIG_FIXTURES if a.big or (a.only and any(a.only in f[0] for f in BIG_FIXTURES)) else []):
         if a.only and a.only not in name:
             continue
         c = Cfg(**kw)
