@@ -236,8 +236,10 @@ def test_parser_fed_streams_end_to_end_on_the_cpu_oracle():
     dd.BACKEND = _oracle_backend()
     try:
         bad = []
-        # (+ the streams with vectors beyond a wrap period that the sweep on this back-end found, tests/bitstreams_open: bit-exact on the oracle, not yet on the GPU)
-        for b in dd.find_streams(d) + sorted(glob.glob(os.path.join(HERE, "bitstreams_open", "*.bit"))):
+        # (incl. the four streams with vectors beyond a wrap period that the sweep on this back-end found in round 4: tests/bitstreams/wraparound_*)
+        for b in dd.find_streams(d):
+            if "mini_4k_" in b and not os.environ.get("VVDEC_BIG_STREAMS"):
+                continue            # (17 pictures of 3840x2176 take the oracle 47 s - bit-exact, MD5 and picture hashes, when the stream was committed; the GPU suite decodes it every time)
             r = dd.decode_stream(b, threads=4, with_reference=False)
             if not r["ok"]:
                 bad.append((r["stream"], r["dropin"].get("tail") or r["dropin_dph"].get("tail")))
