@@ -549,6 +549,16 @@ def main():
                 cost = dropin_host_cost(a.config, seed, a.gop)
                 if cost:
                     out["cpu_baseline"]["dropin_host_ms_per_picture"] = cost
+            if a.config == "4k":
+                # the DROP-IN as a decoder: the reference's application on the drop-in libvvdec.so decoding the parser-fed 4K stream (tests/bitstreams/mini_4k_*:
+                # 3840x2176, 17 pictures, every tool; output MD5 and picture hashes checked by the GPU suite), next to the reference decoder itself on the same stream
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import dropin_4k_rate
+                    out["cpu_baseline"]["dropin_decoder_on_the_parser_fed_4k_stream"] = {"dropin": dropin_4k_rate.rate(16), "reference_decoder_on_the_cpu": dropin_4k_rate.reference_rate(16),
+                        "what": "vvdecapp --loops 4 -t 16, best loop after the first; a 17-picture stream is mostly pipeline fill and drain (the GOP's chain of five temporal layers: parse, motion derivation, flattening, the back-end's work lists, the device, the planes back, per layer)"}
+                except Exception as e:            # noqa: BLE001
+                    out["cpu_baseline"]["dropin_decoder_on_the_parser_fed_4k_stream"] = {"error": repr(e)[:200]}
     for h in prepared.values():
         rec.free_prepared(h)
     rec.close()

@@ -38,19 +38,11 @@
 #include <iostream>
 #include <cstring>
 #include <cmath>
-// The extractor reads two things that are not public in the reference (the LMCS tables of Reshape, TrQuant::getTrTypes); a maintainer who compiles
-// this file into the reference tree adds two friend declarations instead of the next two lines (the layout of the classes does not change).
-#ifndef VVDEC_AMD_FRIEND_PATCH      // (with the one-line friend declaration in CommonLib/Reshape.h nothing is redefined)
-#define private public
-#define protected public
-#endif
+// (nothing of the reference is redefined or patched: the one thing the extractor reads that is not public - the LMCS tables of Reshape, protected members - is
+// read through pointers to members formed in a derived class, integration/vvr_extract.h::LmcsTables)
 #include "DecLibRecon.h"
 #include "CommonLib/UnitTools.h"
 #include "CommonLib/TrQuant_EMT.h"
-#ifndef VVDEC_AMD_FRIEND_PATCH
-#undef private
-#undef protected
-#endif
 #include "../include/vvr.h"
 #include "../vvdec_amd/csrc/vvr_lf_init.h"      // (self-check only, VVDEC_AMD_LF_INIT=2: the back-end's derivation of the edge parameters, compiled for the host)
 #include "vvr_extract.h"

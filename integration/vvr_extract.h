@@ -25,23 +25,29 @@ namespace vvr_glue
 
 using namespace vvdec;
 
-// The ONE place that reads non-public members of a reference class: the LMCS tables of Reshape.  A maintainer adds to CommonLib/Reshape.h
-//   namespace vvr_glue { struct LmcsTables; }      (before namespace vvdec)      and      friend struct ::vvr_glue::LmcsTables;      (inside class Reshape)
-// and compiles the glue with -DVVDEC_AMD_FRIEND_PATCH; without the patch DecLibReconDropIn.cpp / DecLibReconAmd.h open the class the blunt way.
-struct LmcsTables
+// The ONE place that reads non-public members of a reference class: the LMCS tables of Reshape, which are PROTECTED there.  No patch of the reference and no
+// `#define private public`: a class derived from Reshape may name the protected members, and a pointer to member formed through the derived class
+// ( &LmcsTables::m_invLUT has the type  Pel* Reshape::* ) applies to any Reshape object - plain C++ ([class.protected]); LmcsTables is never instantiated.
+struct LmcsTables : Reshape
 {
+  template<class T> static const T& get( const Reshape& r, T Reshape::* m ) { return r.*m; }
   static void read( const Reshape& r, int bd, vvr_lmcs_params& L )
   {
     const int lutSize = 1 << bd, orgCW = lutSize / PIC_CODE_CW_BINS, l2cw = getLog2( orgCW );
     const SliceReshapeInfo& ri = const_cast<Reshape&>( r ).getSliceReshaperInfo();
+    const Pel* invLUT = get( r, &LmcsTables::m_invLUT );
+    const auto& reshapePivot = get( r, &LmcsTables::m_reshapePivot );
+    const auto& fwdScaleCoef = get( r, &LmcsTables::m_fwdScaleCoef );
+    const auto& inputPivot = get( r, &LmcsTables::m_inputPivot );
+    const auto& chromaAdjHelpLUT = get( r, &LmcsTables::m_chromaAdjHelpLUT );
     for( int v = 0; v < lutSize; v++ )
     {
-      L.inv_lut[v] = r.m_invLUT[v];
+      L.inv_lut[v] = invLUT[v];
       const int i = v >> l2cw;
-      L.fwd_lut[v] = (int16_t) Clip3( 0, lutSize - 1, (int) r.m_reshapePivot[i] + ( ( (int) r.m_fwdScaleCoef[i] * ( v - (int) r.m_inputPivot[i] ) + ( 1 << ( FP_PREC - 1 ) ) ) >> FP_PREC ) );
+      L.fwd_lut[v] = (int16_t) Clip3( 0, lutSize - 1, (int) reshapePivot[i] + ( ( (int) fwdScaleCoef[i] * ( v - (int) inputPivot[i] ) + ( 1 << ( FP_PREC - 1 ) ) ) >> FP_PREC ) );
     }
-    for( int i = 0; i < 16; i++ ) { L.chroma_scale[i] = (int16_t) r.m_chromaAdjHelpLUT[i]; L.model_delta_cw[i] = (int16_t) ri.reshaperModelBinCWDelta[i]; }
-    for( int i = 0; i < 17; i++ ) L.pivot[i] = r.m_reshapePivot[i];
+    for( int i = 0; i < 16; i++ ) { L.chroma_scale[i] = (int16_t) chromaAdjHelpLUT[i]; L.model_delta_cw[i] = (int16_t) ri.reshaperModelBinCWDelta[i]; }
+    for( int i = 0; i < 17; i++ ) L.pivot[i] = reshapePivot[i];
     L.min_bin = (int16_t) ri.reshaperModelMinBinIdx; L.max_bin = (int16_t) ri.reshaperModelMaxBinIdx; L.model_delta_crs = (int16_t) ri.chrResScalingOffset;
   }
 };
