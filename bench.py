@@ -555,8 +555,9 @@ def main():
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
                     import dropin_4k_rate
-                    out["cpu_baseline"]["dropin_decoder_on_the_parser_fed_4k_stream"] = {"dropin": dropin_4k_rate.rate(16), "reference_decoder_on_the_cpu": dropin_4k_rate.reference_rate(16),
-                        "what": "vvdecapp --loops 4 -t 16, best loop after the first; a 17-picture stream is mostly pipeline fill and drain (the GOP's chain of five temporal layers: parse, motion derivation, flattening, the back-end's work lists, the device, the planes back, per layer)"}
+                    out["cpu_baseline"]["dropin_decoder_on_the_parser_fed_4k_stream"] = {"dropin": dropin_4k_rate.rate(16, loops=2, copies=6), "reference_decoder_on_the_cpu": dropin_4k_rate.reference_rate(16, loops=2, copies=6),
+                        "dropin_17_pictures": dropin_4k_rate.rate(16), "reference_decoder_17_pictures": dropin_4k_rate.reference_rate(16),
+                        "what": "vvdecapp -t 16 on the stream six times behind itself (102 pictures, six coded video sequences: the decoder pipelines across them), second of two loops; and on the 17 pictures alone (mostly pipeline fill and drain: the GOP's chain of five temporal layers)"}
                 except Exception as e:            # noqa: BLE001
                     out["cpu_baseline"]["dropin_decoder_on_the_parser_fed_4k_stream"] = {"error": repr(e)[:200]}
     for h in prepared.values():
