@@ -5,12 +5,14 @@
 // DecLib::reconPicture (DecLib.cpp:612-636) calls create( ThreadPool*, unsigned, bool ) / decompressPicture / waitForPrevDecompressedPic exactly
 // as before.
 //
-// What stays on the host, on the reference's own thread pool (one barrier task per picture, ordered behind parseDone and the pictures it references):
+// What stays on the host, on the reference's own thread pool (row tasks, a submit task and a finish task per picture, ordered behind parseDone and the pictures
+// it references; nobody sleeps in vvr_wait):
 //   MIDER   DecCu::TaskDeriveCtuMotionInfo for every CTU (merge / AMVP / affine / HMVP derivation needs the finished motion of collocated pictures)
-//   LF_INIT LoopFilter::calcFilterStrengthsCTU (the edge-parameter tables are an input of the back-end)
 //   flatten vvr_extract.h: CodingStructure -> vvr_picture
-// then vvr_submit / vvr_wait, the planes back into the Picture's buffers (the application, the hash SEI check and film grain read them there),
-// the DMVR-refined motion through DecCu::TaskFinishMotionInfo, reconDone.
+// then vvr_submit, the planes back into the Picture's buffers (the application, the hash SEI check and film grain read them there), the DMVR-refined motion
+// through DecCu::TaskFinishMotionInfo, reconDone.  LF_INIT (LoopFilter::calcFilterStrengthsCTU) does NOT run here since round 4: the description
+// goes out with VVR_TOOL_LFP_ON_DEVICE and the back-end derives the edge parameters from the CU / TU records on the device (VVDEC_AMD_LF_INIT=1 runs the
+// reference's own derivation instead, =2 runs both and compares them entry by entry).
 // The context (DPB in HBM) is shared by the DecLibRecon instances of one decoder: they are keyed by the decoder's thread pool.
 // A Picture object keeps the DPB slot it got when it was first reconstructed (PicListManager recycles Picture objects, so the number of slots is
 // the number of Picture objects the decoder ever allocates: its DPB size + pictures in flight).
