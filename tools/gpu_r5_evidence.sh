@@ -11,7 +11,7 @@ for cfg in 4k allintra 8k; do
     echo "== pmc $cfg $ctr"; (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $R/$out/pmc_${cfg}_$ctr -o pmc -- python $R/bench.py --config $cfg $PMCARGS > $R/$out/bench_pmc_${cfg}_$ctr.json 2> $R/$out/pmc_${cfg}_$ctr.err)
   done
   f=$(find $out/pmc_${cfg}_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_${cfg}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-  python tools/pmc_summary.py "$f" "$w" $out/pmc_traffic_$cfg.json "python bench.py --config $cfg $PMCARGS" | grep -E "k_intra|k_mc |k_alf|k_deblock|k_sao|k_itrans|k_lf|k_resi" | head -16
+  python tools/pmc_summary.py "$f" "$w" $out/pmc_traffic_$cfg.json "python bench.py --config $cfg $PMCARGS" | grep -E "k_intra|k_mc|k_alf|k_deblock|k_sao|k_itrans|k_lf|k_resi" | head -20
 done
 echo "== kernels alone"; PROBE_PICTURES=3 timeout 300 python tools/intra_probe.py > $out/kernels_alone.txt 2>&1; cat $out/kernels_alone.txt
 bash tools/gpu_kstat_alone.sh $(basename $out)/alone > $out/kernels_alone_rocprof.txt 2>&1; head -22 $out/kernels_alone_rocprof.txt
