@@ -809,8 +809,13 @@ struct WorkerHelpers : HostHelpers
     struct State { std::mutex mu; std::condition_variable cv; int remaining; } st; st.remaining = n - 1;
     {
       std::lock_guard<std::mutex> lk( c->mu );
-      for( int part = 1; part < n; part++ )
-        c->subtasks.push_back( [&st, &fn, part]( PrepScratch& R ) { fn( part, R ); std::lock_guard<std::mutex> l2( st.mu ); st.remaining--; st.cv.notify_all(); } );      // (notified under the lock: `st` lives on the caller's stack and is gone once the caller has seen remaining == 0)
+      // (the parts of an I picture go IN FRONT of the parts of B pictures that are waiting there: everything of the next GOP hangs on the I picture's chain on the device)
+      const bool first = announced;
+      for( int part = first ? n - 1 : 1; first ? part >= 1 : part < n; part += first ? -1 : 1 )
+      {
+        auto task = [&st, &fn, part]( PrepScratch& R ) { fn( part, R ); std::lock_guard<std::mutex> l2( st.mu ); st.remaining--; st.cv.notify_all(); };      // (notified under the lock: `st` lives on the caller's stack and is gone once the caller has seen remaining == 0)
+        if( first ) c->subtasks.push_front( task ); else c->subtasks.push_back( task );
+      }
       if( announced ) { c->partsComing--; announced = false; }
       c->cv.notify_all();
     }
