@@ -64,11 +64,12 @@ def stub():
 
 
 class Ctx:
-    def __init__(self, L, W, H, nslots, log2_ctu=7, bit_depth=10, chroma_format=1, streams=1, leaf=False):
+    def __init__(self, L, W, H, nslots, log2_ctu=7, bit_depth=10, chroma_format=1, streams=1, leaf=False, by_level=True):
         """leaf: pictures with scattered intra blocks take the one-wavefront-per-block path (the product's default); False: the CTU-tile path with
         units for every picture, what most tests of this file are about (the library reads VVR_INTRA_LEAF when the context is created)"""
         self.L = L
         os.environ["VVR_INTRA_LEAF"] = "1" if leaf else "0"
+        os.environ["VVR_LEAF_BY_LEVEL"] = "1" if by_level else "0"
         cfg = abi.Config()
         cfg.abi_version = abi.VVR_ABI_VERSION
         cfg.device, cfg.max_width, cfg.max_height = 0, W, H
@@ -76,7 +77,7 @@ class Ctx:
         cfg.num_slots, cfg.num_streams = nslots, streams
         self.ctx = C.c_void_p()
         assert L.vvr_create(C.byref(cfg), C.byref(self.ctx)) == abi.VVR_OK
-        del os.environ["VVR_INTRA_LEAF"]
+        del os.environ["VVR_INTRA_LEAF"], os.environ["VVR_LEAF_BY_LEVEL"]
 
     def prepare(self, d):
         p = d.c()
@@ -320,10 +321,11 @@ def test_intra_stage_tables(stub, name, W, H, frames, gop, seed, tools, kw):
 MODE_CSFAC = 253
 
 
-def _check_leaf_items(d, items, resi=None):
-    """the item list of k_intra_leaf (vvr_intra_leaf.inc): luma blocks, the chroma-scaling factors of the VPDUs, Cb blocks, Cr blocks, each list in decoding
-    order, so that everything an item reads of another item's output comes from an item BEFORE it (the kernel hands items out by ticket, in list order:
-    whoever waits, waits for a wavefront that is running or done).  Checked: the order of the parts, bands consecutive, ISP partitions consecutive, every
+def _check_leaf_items(d, items, resi=None, by_level=True):
+    """the item list of k_intra_leaf (vvr_intra_leaf.inc): luma blocks, the chroma-scaling factors of the VPDUs, Cb blocks, Cr blocks - sorted by level (1 + the
+    highest level among the items whose cells the item polls; decoding order within a level), or, by_level False, each list in decoding order - either way
+    everything an item reads of another item's output comes from an item BEFORE it (the kernel hands items out by ticket, in list order: whoever waits,
+    waits for a wavefront that is running or done).  Checked: the order of the parts (decoding order), bands consecutive, ISP partitions consecutive, every
     cell of an intra / CIIP CU produced exactly once, the residual-add blocks complete, and for every sample an item reads (reference lines, the
     previous ISP partition, co-located luma and templates of CCLM, the luma a scaling factor is averaged over, the factor of a block's VPDU) that its
     producer - if the stage has one - precedes the item."""
@@ -337,7 +339,7 @@ def _check_leaf_items(d, items, resi=None):
     assert ((items["comp"] >> 2) == 0).all()
     # ---- parts in order: luma, factors, Cb, Cr
     kind = np.where(mode == MODE_CSFAC, 1, np.where(comp == 0, 0, comp + 1))
-    assert (np.diff(kind.astype(np.int64)) >= 0).all(), "items are not in the order luma, factors, Cb, Cr"
+    assert by_level or (np.diff(kind.astype(np.int64)) >= 0).all(), "items are not in the order luma, factors, Cb, Cr"
     vl = min(6, l2)
     vpdusX = (W + (1 << vl) - 1) >> vl
     fac_at = {int(items["tu"][i]): i for i in range(nI) if mode[i] == MODE_CSFAC}
@@ -388,6 +390,14 @@ def _check_leaf_items(d, items, resi=None):
         assert (is_isp and min(ww, hh) < 4) or (sub == -1).all(), "two items produce one cell"
         sub[...] = isp_first.get(i, i)      # (the cells of an ISP coding unit are cleared by its first partition's wavefront, after the last partition)
     nchk = 0
+    cu_at = np.full((h4, w4), -1, np.int64)
+    for ci, cu in enumerate(d.cu):
+        if cu["tree"] != abi.TREE_CHROMA:
+            cu_at[int(cu["y"]) >> 2:(int(cu["y"]) + int(cu["h"]) + 3) >> 2, int(cu["x"]) >> 2:(int(cu["x"]) + int(cu["w"]) + 3) >> 2] = ci
+
+    def luma_cu_origin(x, y):
+        cu = d.cu[int(cu_at[y >> 2, x >> 2])]
+        return int(cu["x"]), int(cu["y"])
     for i in range(nI):
         it = items[i]
         m, k = int(mode[i]), int(comp[i])
@@ -401,6 +411,13 @@ def _check_leaf_items(d, items, resi=None):
             # (Reshape::calculateChromaAdjVpduNei: the column left of / the row above the CU at the VPDU's origin; here a superset: around the VPDU AND around every
             # CU origin up to a CTU further up / left is not known to the test - it checks the VPDU's own border, which the CU's border contains or precedes)
             vx, vy = (vp % vpdusX) << vl, (vp // vpdusX) << vl
+            cux, cuy = luma_cu_origin(vx, vy)
+            reads += [(0, cux - 1, yy) for yy in range(cuy, min(cuy + (1 << vl), H), 4)] if cux > 0 else []
+            reads += [(0, xx, cuy - 1) for xx in range(cux, min(cux + (1 << vl), W), 4)] if cuy > 0 else []
+            for (kc, xc, yc) in reads:
+                j = int(prod[kc, yc >> 2, xc >> 2])
+                assert j < i, "the factor item %d reads luma that item %d produces" % (i, j)
+                nchk += j >= 0
             continue
         if k and (flags & 8):
             vp = ((y0 << 1) >> vl) * vpdusX + ((x0 << 1) >> vl)
@@ -448,15 +465,16 @@ def _check_leaf_items(d, items, resi=None):
     return nchk
 
 
+@pytest.mark.parametrize("by_level", [True, False], ids=["by_level", "decoding_order"])
 @pytest.mark.parametrize("name,W,H,frames,gop,seed,tools,kw", STREAMS, ids=[s[0] for s in STREAMS])
-def test_intra_leaf_items(stub, name, W, H, frames, gop, seed, tools, kw):
+def test_intra_leaf_items(stub, name, W, H, frames, gop, seed, tools, kw, by_level):
     """pictures with scattered intra blocks (every picture that is not all intra CUs and holds no IBC CU): one wavefront per block, no units"""
     kw = dict(kw)
     l2 = kw.pop("log2_ctu", 7)
     plans, nslots = stream.ra_plan(frames, gop=gop, seed_poc0_is_external=False)
-    ctx = Ctx(stub, W, H, nslots, log2_ctu=l2, leaf=True)
+    ctx = Ctx(stub, W, H, nslots, log2_ctu=l2, leaf=True, by_level=by_level)
     stub.vvt_is_leaf.argtypes = [C.c_void_p]
-    checked = leaf_pictures = 0
+    checked = leaf_pictures = reordered = 0
     for pl in plans:
         d = synth.picture_for_plan(pl, W, H, seed=seed, tool_flags=tools, log2_ctu=l2, **kw)
         hnd = ctx.prepare(d)
@@ -469,7 +487,9 @@ def test_intra_leaf_items(stub, name, W, H, frames, gop, seed, tools, kw):
             assert len(units) == 0
             resi = ctx.resi_tables(hnd)[0]
             _check_resi_add(d, np.zeros(0, UNIT_DT), resi, 0, 0, 0)
-            checked += _check_leaf_items(d, items, resi)
+            checked += _check_leaf_items(d, items, resi, by_level)
+            kind = np.where(items["mode"] == MODE_CSFAC, 1, np.where((items["comp"] & 3) == 0, 0, (items["comp"] & 3) + 1)).astype(np.int64)
+            reordered += bool((np.diff(kind) < 0).any())
             leaf_pictures += 1
             assert stub.vvr_submit_prepared(ctx.ctx, hnd) >= 0 and stub.vvr_sync(ctx.ctx) == 0
             assert stub.vvt_last_leaf_items() == len(items)
@@ -478,6 +498,7 @@ def test_intra_leaf_items(stub, name, W, H, frames, gop, seed, tools, kw):
             stub.vvr_free_prepared(ctx.ctx, hnd)
     ctx.close()
     assert (leaf_pictures > 0 and checked > 0) or name.startswith("ibc") or name in ("dual_tree_ibc", "small_cus")
+    assert reordered == (leaf_pictures if by_level else 0), "the list by level interleaves luma and chroma items (every picture here has blocks that wait)"
 
 
 def test_sync_buffer_grows_with_the_number_of_units(stub):

@@ -152,6 +152,7 @@ struct vvr_context {
                                         // an I picture alone 4.23 - 4.46 ms against 4.56 (its blocks read far down the left CTU's last column, the chain of 1442 blocks stays), and
                                         // with other pictures in flight the 256 polling workgroups of nine wavefronts cost more than they gain (4K RA 1555 against 1801 frames/s,
                                         // all-intra 547 against 944)
+  bool       leafByLevel = true;        // ... their blocks listed by level instead of decoding order (VVR_LEAF_BY_LEVEL=0; vvr_prepare.cpp, `leafSort`)
   bool       intraLeaf = true;          // pictures with scattered intra blocks take the one-wavefront-per-block path (VVR_INTRA_LEAF=0: the CTU-tile path for everything)
   size_t     planeBytes[3] = { 0, 0, 0 }, slotBytes = 0;
   int        stride[3] = { 0, 0, 0 };
@@ -825,7 +826,7 @@ struct WorkerHelpers : HostHelpers
       std::function<void( PrepScratch& )> task;
       { std::lock_guard<std::mutex> lk( c->mu ); if( !c->subtasks.empty() ) { task = std::move( c->subtasks.front() ); c->subtasks.pop_front(); } }
       if( !task ) break;
-      if( !spare ) { spare = vvr_scratch_create(); vvr_scratch_intra_leaf( spare, c->intraLeaf ); vvr_scratch_warm( spare, c->cfg ); }
+      if( !spare ) { spare = vvr_scratch_create(); vvr_scratch_intra_leaf( spare, c->intraLeaf, c->leafByLevel ); vvr_scratch_warm( spare, c->cfg ); }
       task( *spare );
     }
     std::unique_lock<std::mutex> lk( st.mu );
@@ -838,11 +839,11 @@ static void workerMain( vvr_context* c )
   hipSetDevice( c->device );
   pinToCpus( c->nodeCpus );
   PrepScratch* S = vvr_scratch_create();
-  vvr_scratch_intra_leaf( S, c->intraLeaf );
+  vvr_scratch_intra_leaf( S, c->intraLeaf, c->leafByLevel );
   vvr_scratch_warm( S, c->cfg );
   // (a second scratch for the parts of its own I picture that nobody else takes, see WorkerHelpers::run: allocated and touched now, not inside a picture)
   PrepScratch* spare = nullptr;
-  if( c->cfg.host_threads > 1 ) { spare = vvr_scratch_create(); vvr_scratch_intra_leaf( spare, c->intraLeaf ); vvr_scratch_warm( spare, c->cfg ); }
+  if( c->cfg.host_threads > 1 ) { spare = vvr_scratch_create(); vvr_scratch_intra_leaf( spare, c->intraLeaf, c->leafByLevel ); vvr_scratch_warm( spare, c->cfg ); }
   WorkerHelpers helpers( c, spare );
   for( ;; )
   {
@@ -981,6 +982,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   c->numLanesRR = ns; c->prioLane = nl > ns ? ns : -1;
   if( const char* e = getenv( "VVR_PARTS" ) ) c->partsPolicy = atoi( e );      // 0 / 1 / 2: see partsPolicy
   if( const char* e = getenv( "VVR_INTRA_LEAF" ) ) c->intraLeaf = atoi( e ) != 0;
+  if( const char* e = getenv( "VVR_LEAF_BY_LEVEL" ) ) c->leafByLevel = atoi( e ) != 0;
   if( const char* e = getenv( "VVR_INTRA_FINE" ) ) c->intraFine = atoi( e ) != 0;
   c->streams.resize( nl, nullptr );
   bool ok = true;
@@ -1052,7 +1054,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   if( !ok ) { vvr_destroy( c ); return VVR_ERR_DEVICE; }
   c->slotUsers.resize( cfg->num_slots ); c->slotExt.resize( cfg->num_slots );
   c->inlineScratch = vvr_scratch_create();
-  vvr_scratch_intra_leaf( c->inlineScratch, c->intraLeaf );
+  vvr_scratch_intra_leaf( c->inlineScratch, c->intraLeaf, c->leafByLevel );
   if( cfg->host_threads <= 0 ) vvr_scratch_warm( c->inlineScratch, c->cfg );
   if( cfg->host_threads ) c->nodeCpus = gpuNodeCpus( c->device );
   for( int t = 0; t < cfg->host_threads; t++ ) c->workers.emplace_back( workerMain, c );

@@ -205,6 +205,29 @@ struct PrepScratch
   bool leafOn = true, leaf = false;
   bool intraFine = false;                   // (tile path) every unit is a whole CTU of intra CUs: the launch may order the CTUs block by block
   std::vector<uint8_t> csNeeded;            // (leaf) per VPDU: a chroma block of the stage scales its residual with the VPDU's factor (an IT_MODE_CSFAC item computes it)
+  // (leaf) The device orders the blocks by itself, but a wavefront that waits holds its slot: in decoding order the list front-loads the device with blocks deep in
+  // a chain of neighbours.  `level` of a block: 1 + the highest level among the blocks that own the cells its wavefront polls (1: polls nothing of this stage); the
+  // list sorted by level (stable: decoding order within a level) is still producers-first, and wavefronts find their cells cleared or about to be.  Needs the
+  // blocks above in the map: pictures built in bands by several threads keep decoding order.
+  bool leafSortOn = true, leafSort = false;
+  std::vector<uint16_t> levMap;             // per component and cell: level of the intra-stage block that owns it in this picture, 0: none
+  std::vector<uint16_t> lev[3], csLev;      // per block of intra[k]; per VPDU (0: not looked up yet)
+  std::vector<uint16_t> levAllV;            // per item of the list
+  uint16_t ispLev = 0;
+  void beginLevels();
+  uint16_t csLevelOf( size_t vp );
+  inline void levLook( int k, int cx0, int cy0, int cx1, int cy1, uint32_t& d ) const
+  {
+    cx0 = std::max( cx0, 0 ); cy0 = std::max( cy0, 0 ); cx1 = std::min( cx1, w4 - 1 ); cy1 = std::min( cy1, h4 - 1 );
+    const uint16_t* m = &levMap[(size_t) k * w4 * h4];
+    for( int y = cy0; y <= cy1; y++ ) for( int x = cx0; x <= cx1; x++ ) d = std::max<uint32_t>( d, m[(size_t) y * w4 + x] );
+  }
+  inline void levOwn( int k, int cx0, int cy0, int cx1, int cy1, uint16_t v )
+  {
+    cx1 = std::min( cx1, w4 - 1 ); cy1 = std::min( cy1, h4 - 1 );
+    uint16_t* m = &levMap[(size_t) k * w4 * h4];
+    for( int y = cy0; y <= cy1; y++ ) std::fill( m + (size_t) y * w4 + cx0, m + (size_t) y * w4 + cx1 + 1, v );
+  }
   int emitLeafItems( std::string& err );
   int buildWorkLists( std::string& err, uint32_t cu0 = 0, uint32_t cu1 = 0xffffffffu );
   int buildInParts( const vvr_config& cfg, HostHelpers& helpers, bool validate, std::string& err );
@@ -218,7 +241,7 @@ struct PrepScratch
 
 PrepScratch* vvr_scratch_create() { return new PrepScratch(); }
 void vvr_scratch_parts_for_all( PrepScratch* S, bool on ) { S->partsForAll = on; }
-void vvr_scratch_intra_leaf( PrepScratch* S, bool on ) { S->leafOn = on; }
+void vvr_scratch_intra_leaf( PrepScratch* S, bool on, bool byLevel ) { S->leafOn = on; S->leafSortOn = byLevel; }
 static std::atomic<int> g_bandPictures{ 0 };
 int vvr_host_band_pictures() { return g_bandPictures.load(); }      // (tests) pictures with inter CUs that were built in bands so far
 
@@ -588,6 +611,7 @@ int vvr_host_validate( const vvr_config& cfg, const vvr_picture* p, std::string&
 // later CTUs are known to be "not decoded yet" from their position, the block map carries the picture's epoch.
 int PrepScratch::beginMaps( const PrepScratch* like /* the same picture in another thread's scratch: what it found out about the picture as a whole */ )
 {
+  leafSort = false;
   if( like ) { anyIntra = like->anyIntra; allIntraCus = like->allIntraCus; leaf = like->leaf; }
   else
   {
@@ -619,6 +643,27 @@ int PrepScratch::beginMaps( const PrepScratch* like /* the same picture in anoth
     else { csProdRange.assign( (size_t) vpdusX * vpdusY, std::make_pair( 0xffffffffu, 0u ) ); csProdPool.clear(); }
   }
   return VVR_OK;
+}
+
+// (leaf, one thread builds the whole picture) levels of the blocks: see `leafSort`
+void PrepScratch::beginLevels()
+{
+  if( !leaf || !leafSortOn ) return;
+  leafSort = true;
+  levMap.assign( (size_t) 3 * w4 * h4, 0 );
+  csLev.assign( cscale ? (size_t) vpdusX * vpdusY : 0, 0 );
+  for( int k = 0; k < 3; k++ ) lev[k].clear();
+}
+// level of the item that computes the chroma scaling factor of VPDU `vp`: the luma column left of / row above the VPDU's first CU (what its wavefront polls)
+uint16_t PrepScratch::csLevelOf( size_t vp )
+{
+  if( csLev[vp] ) return csLev[vp];
+  const uint32_t v = csVpduV[vp];
+  const int xPos = v & 0x1fff, yPos = ( v >> 13 ) & 0x1fff, n = 1 << vpduLog2;
+  uint32_t d = 0;
+  if( ( v >> 26 ) & 1 ) levLook( 0, ( xPos - 1 ) >> 2, yPos >> 2, ( xPos - 1 ) >> 2, std::min( yPos + n - 1, (int) h.height - 1 ) >> 2, d );
+  if( ( v >> 27 ) & 1 ) levLook( 0, xPos >> 2, ( yPos - 1 ) >> 2, std::min( xPos + n - 1, (int) h.width - 1 ) >> 2, ( yPos - 1 ) >> 2, d );
+  return csLev[vp] = (uint16_t) std::min<uint32_t>( d + 1, 0xfffe );
 }
 
 // decoding order of the transform blocks of CTU `ctuIdx` (CUs [i0, i1)), its cells covered by intra CUs, the luma neighbourhood of the chroma
@@ -742,6 +787,7 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
               it.tu = (uint32_t) ( ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 ) );
               resiAdd.push_back( it );
               csNeeded[it.tu] = 1;
+              if( leafSort ) levOwn( comp, it.x >> 1, it.y >> 1, ( it.x + ( tu.w >> 1 ) - 1 ) >> 1, ( it.y + ( tu.h >> 1 ) - 1 ) >> 1, csLevelOf( it.tu ) );      // (the factor's wavefront clears them)
               bytes[K_INTRA_LEAF] += (double) ( tu.w >> 1 ) * ( tu.h >> 1 ) * 6 + sizeof( IntraItem );
               continue;
             }
@@ -793,7 +839,7 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
           if( !noRef ) it.nTL = (uint8_t) unitAvail( chn, rx0 - 1, ry0 - 1, rcur );
           if( !noRef && unitAvail( chn, rx0, ry0 - 1, rcur ) ) { int n = rw / unit; for( int k = 0; k < totalAbove - rw / unit; k++ ) { if( !unitAvail( chn, rx0 + rw + k * unit, ry0 - 1, rcur ) ) break; n++; } it.nA = (uint8_t) n; }
           if( !noRef && unitAvail( chn, rx0 - 1, ry0, rcur ) ) { int n = rh / unit; for( int k = 0; k < totalLeft - rh / unit; k++ ) { if( !unitAvail( chn, rx0 - 1, ry0 + rh + k * unit, rcur ) ) break; n++; } it.nL = (uint8_t) n; }
-          int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0; bool isCclm = false;
+          int cclmTop = 0, cclmLeft = 0, cclmBLeft = 0, lmTop = 0, lmLeft = 0; bool isCclm = false;
           const bool csItem = cscaleCtu( ctuOfCu ) && comp && hasResi && w * hh > 4;             // DecCu.cpp:383-388 / :500-505
           if( csItem ) it.flags |= IT_F_CSCALE;
           if( comp && !isCiip && !isCsInter && !isIbcCu && cu.intra_dir[1] >= 67 )
@@ -823,7 +869,7 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
             const int bLeft = leftCu ? 1 : 0;                                                          // availlableLeftUnit >= iTUHeightInUnits
             const int firstRow = ( ( y0 << 1 ) & ( ( 1 << h.log2_ctu ) - 1 ) ) == 0;
             it.tu = (uint32_t) actualTop | ( (uint32_t) actualLeft << 8 ) | ( (uint32_t) aboveAvail << 16 ) | ( (uint32_t) leftAvail << 17 ) | ( (uint32_t) bLeft << 18 ) | ( (uint32_t) firstRow << 19 ) | ( (uint32_t) ( aboveCu ? 1 : 0 ) << 20 );
-            cclmTop = aboveAvail ? actualTop : 0; cclmLeft = leftAvail ? actualLeft : 0; cclmBLeft = bLeft; isCclm = true;
+            cclmTop = aboveAvail ? actualTop : 0; cclmLeft = leftAvail ? actualLeft : 0; cclmBLeft = bLeft; isCclm = true; lmTop = actualTop; lmLeft = actualLeft;
           }
           // ---- the blocks this one reads from, its part of the CTU tile
           const uint32_t myId = (uint32_t) intra[comp].size();
@@ -834,6 +880,33 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
             // one wavefront per block, ordered on the device: the list in decoding order is all there is to do
             if( csItem ) csNeeded[(size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 )] = 1;
             bytes[K_INTRA_LEAF] += (double) w * hh * ( hasResi ? 4 : 2 ) + sizeof( IntraItem );
+            if( leafSort )
+            {
+              // the cells the block's wavefront polls (k_intra_leaf, "wait for the blocks that produce what this one reads"): corner, above and left reference
+              // lines, the VPDU's factor, the luma a cross-component prediction reads; the later partitions of an ISP coding unit ride with the first
+              const int u = comp ? 1 : 2;
+              if( ispL && ( x0 != rx0 || y0 != ry0 ) ) lev[comp].push_back( ispLev );
+              else
+              {
+                uint32_t d = 0;
+                const int mrl = ( comp || ( it.flags & IT_F_MIP ) ) ? 0 : ( it.flags >> 4 ) & 3;
+                const int qx = rx0 - 1 - mrl, qy = ry0 - 1 - mrl, szA = std::min( it.nA * unit, 2 * rw ), szL = std::min( it.nL * unit, 2 * rh );
+                if( it.nTL ) levLook( comp, qx >> u, qy >> u, qx >> u, qy >> u, d );
+                if( it.nA ) levLook( comp, rx0 >> u, qy >> u, ( rx0 + szA - 1 ) >> u, qy >> u, d );
+                if( it.nL ) levLook( comp, qx >> u, ry0 >> u, qx >> u, ( ry0 + szL - 1 ) >> u, d );
+                if( csItem ) d = std::max<uint32_t>( d, csLevelOf( (size_t) ( tu.y >> vpduLog2 ) * vpdusX + ( tu.x >> vpduLog2 ) ) );
+                if( isCclm )
+                {
+                  const int lx0 = x0 << 1, ly0 = y0 << 1;
+                  levLook( 0, lx0 >> 2, ly0 >> 2, ( lx0 + 2 * w - 1 ) >> 2, ( ly0 + 2 * hh - 1 ) >> 2, d );
+                  if( ly0 > 0 ) levLook( 0, ( lx0 - 4 ) >> 2, ( ly0 - 4 ) >> 2, ( lx0 + 2 * std::max( w, lmTop ) - 1 ) >> 2, ( ly0 - 4 ) >> 2, d );
+                  if( lx0 > 0 ) levLook( 0, ( lx0 - 4 ) >> 2, ly0 >> 2, ( lx0 - 4 ) >> 2, ( ly0 + 2 * std::max( hh, lmLeft ) - 1 ) >> 2, d );
+                }
+                const uint16_t lv = (uint16_t) std::min<uint32_t>( d + 1, 0xfffe );
+                lev[comp].push_back( lv ); ispLev = lv;
+                levOwn( comp, rx0 >> u, ry0 >> u, ( rx0 + rw - 1 ) >> u, ( ry0 + rh - 1 ) >> u, lv );
+              }
+            }
             continue;
           }
           std::vector<uint32_t>& pool = prodPool[comp];
@@ -1575,6 +1648,7 @@ int PrepScratch::emitUnitTable( std::string& err )
 int PrepScratch::emitLeafItems( std::string& err )
 {
   (void) err;
+  std::vector<uint16_t>& levAll = levAllV; levAll.clear();
   for( int k = 0; k < 3; k++ )
   {
     for( const IntraItem& src : intra[k] )
@@ -1589,6 +1663,7 @@ int PrepScratch::emitLeafItems( std::string& err )
         it.nTL = (uint8_t) ( ( src.nTL & 1 ) | ( part << 1 ) | ( lp << 4 ) );
         it.comp = (uint8_t) k;
         intraAll.push_back( it );
+        if( leafSort ) levAll.push_back( lev[k][&src - intra[k].data()] );
       }
     }
     if( k == 0 && cscale )
@@ -1608,8 +1683,21 @@ int PrepScratch::emitLeafItems( std::string& err )
         it.mode = IT_MODE_CSFAC; it.tu = (uint32_t) vp; it.comp = 1;
         it.x = (uint16_t) ( f & 0xffff ); it.y = (uint16_t) ( f >> 16 ); it.lw = (uint8_t) ( n & 0xff ); it.lh = (uint8_t) ( n >> 8 );
         intraAll.push_back( it );
+        if( leafSort ) levAll.push_back( csLevelOf( vp ) );
       }
     }
+  }
+  if( leafSort && !intraAll.empty() )
+  {
+    // by level, decoding order within a level (counting sort; the bands of a block and the partitions of an ISP coding unit stay together: same level, neighbours)
+    uint32_t top = 0;
+    for( uint16_t l : levAll ) top = std::max<uint32_t>( top, l );
+    std::vector<uint32_t>& at = unitCount; at.assign( (size_t) top + 2, 0 );
+    for( uint16_t l : levAll ) at[(size_t) l + 1]++;
+    for( uint32_t l = 0; l <= top; l++ ) at[l + 1] += at[l];
+    std::vector<IntraItem>& sorted = intraTmp[1]; sorted.resize( intraAll.size() );
+    for( size_t i = 0; i < intraAll.size(); i++ ) sorted[at[levAll[i]]++] = intraAll[i];
+    intraAll.swap( sorted );
   }
   numLumaUnits = 0; intraWorkgroups = intraWorkgroupsChroma = 0;
   return VVR_OK;
@@ -1831,7 +1919,7 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
     // developer build: time per phase of the work-list builder
     auto now = []{ return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); };
     double t[7]; t[0] = now();
-    rc = S.beginMaps(); t[1] = now();
+    rc = S.beginMaps(); S.beginLevels(); t[1] = now();
     if( rc == VVR_OK ) rc = S.buildWorkLists( err ); t[2] = now();
     if( rc == VVR_OK && !S.leaf ) rc = S.formUnits(); t[3] = now();
     if( rc == VVR_OK && !S.leaf ) rc = S.groupUnits(); t[4] = now();
@@ -1843,7 +1931,9 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
     return VVR_OK;
   }
 #endif
-  if( ( rc = S.beginMaps() ) != VVR_OK || ( rc = S.buildWorkLists( err ) ) != VVR_OK ) return rc;
+  if( ( rc = S.beginMaps() ) != VVR_OK ) return rc;
+  S.beginLevels();
+  if( ( rc = S.buildWorkLists( err ) ) != VVR_OK ) return rc;
   if( S.leaf ) { if( ( rc = S.emitLeafItems( err ) ) != VVR_OK ) return rc; }
   else if( ( rc = S.formUnits() ) != VVR_OK || ( rc = S.groupUnits() ) != VVR_OK || ( rc = S.emitUnitTable( err ) ) != VVR_OK ) return rc;
   S.layout( pinned );
