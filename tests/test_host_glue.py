@@ -1264,7 +1264,9 @@ def test_pictures_pass_pictures_that_are_still_being_prepared(stub):
     results = {}
     stub.vvt_overtakes.restype = C.c_ulonglong
     stub.vvt_overtakes.argtypes = [C.c_void_p]
-    for threads, slow in ((0, "I"), (4, "I"), (4, "B")):
+    for threads, slow, attempt in [(0, "I", 0)] + [(4, sl, a) for sl in ("I", "B") for a in range(3)]:
+        if (threads, slow) in results:
+            continue
         cfg = abi.Config()
         cfg.abi_version = abi.VVR_ABI_VERSION
         cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, 7
@@ -1283,6 +1285,9 @@ def test_pictures_pass_pictures_that_are_still_being_prepared(stub):
         stub.vvt_slow_i_pictures(0)
         stub.vvt_slow_b_pictures(0)
         overtakes = stub.vvt_overtakes(ctx)
+        if threads and not overtakes and attempt < 2:
+            stub.vvr_destroy(ctx)           # (a busy machine: the "slow" pictures were not the slowest this time - once more)
+            continue
         assert (overtakes > 0) == (threads > 0), overtakes          # pictures did pass others - and never without worker threads
         n = stub.vvt_take_trace(buf, len(buf))
         ops = [tuple(buf[i:i + 3]) for i in range(0, n, 3)]

@@ -45,6 +45,7 @@ while hops < 40 and t[cur, 2] - t[cur, 1] > 50:
     prv = max(same, key=lambda c: end[c])
     print("   <- #%d (%s mode %d %dx%d at %d,%d) ticket %.1f waited until %.1f done %.1f  [hop: producer done -> consumer go %.2f us; consumer go -> done %.2f us]" % (
         prv, kinds[prv], items["mode"][prv], 1 << items["lw"][prv], 1 << items["lh"][prv], items["x"][prv], items["y"][prv], us(t[prv, 1]), us(t[prv, 2]), us(end[prv]), (t[cur, 2] - end[prv]) / 100, (end[cur] - t[cur, 2]) / 100))
+    print("        stages of #%d: fill %.2f predict %.2f store %.2f drain %.2f cells %.2f us" % ((cur,) + tuple((t[cur, i + 1] - t[cur, i]) / 100 for i in range(2, 7))))
     cur = prv; hops += 1
 print("chain length", hops)
 # ---- occupancy of the device over time and how long a wavefront lives

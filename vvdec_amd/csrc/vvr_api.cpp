@@ -152,7 +152,7 @@ struct vvr_context {
                                         // an I picture alone 4.23 - 4.46 ms against 4.56 (its blocks read far down the left CTU's last column, the chain of 1442 blocks stays), and
                                         // with other pictures in flight the 256 polling workgroups of nine wavefronts cost more than they gain (4K RA 1555 against 1801 frames/s,
                                         // all-intra 547 against 944)
-  bool       leafByLevel = true;        // ... their blocks listed by level instead of decoding order (VVR_LEAF_BY_LEVEL=0; vvr_prepare.cpp, `leafSort`)
+  bool       leafByLevel = false;       // ... their blocks listed by level instead of decoding order (VVR_LEAF_BY_LEVEL=1; vvr_prepare.cpp, `leafSort`): measured, no gain
   bool       intraLeaf = true;          // pictures with scattered intra blocks take the one-wavefront-per-block path (VVR_INTRA_LEAF=0: the CTU-tile path for everything)
   size_t     planeBytes[3] = { 0, 0, 0 }, slotBytes = 0;
   int        stride[3] = { 0, 0, 0 };

@@ -64,7 +64,7 @@ struct DirectCopy { const void* src; size_t n, off; };
 struct PrepScratch;
 PrepScratch* vvr_scratch_create();
 int          vvr_host_band_pictures();
-void         vvr_scratch_intra_leaf( PrepScratch*, bool on, bool byLevel = true );         // pictures with scattered intra blocks take the one-wavefront-per-block path (default on)
+void         vvr_scratch_intra_leaf( PrepScratch*, bool on, bool byLevel = false );         // pictures with scattered intra blocks take the one-wavefront-per-block path (default on)
 void         vvr_scratch_parts_for_all( PrepScratch*, bool on );      // the next pictures built with this scratch: in bands of CTU rows over the helpers whatever their kind (else: I pictures only)
 void         vvr_scratch_destroy( PrepScratch* );
 void         vvr_scratch_warm( PrepScratch*, const vvr_config& cfg );      // allocate and touch room for an ordinary picture of this size (call from the thread that will use it)

@@ -208,8 +208,10 @@ struct PrepScratch
   // (leaf) The device orders the blocks by itself, but a wavefront that waits holds its slot: in decoding order the list front-loads the device with blocks deep in
   // a chain of neighbours.  `level` of a block: 1 + the highest level among the blocks that own the cells its wavefront polls (1: polls nothing of this stage); the
   // list sorted by level (stable: decoding order within a level) is still producers-first, and wavefronts find their cells cleared or about to be.  Needs the
-  // blocks above in the map: pictures built in bands by several threads keep decoding order.
-  bool leafSortOn = true, leafSort = false;
+  // blocks above in the map: pictures built in bands by several threads keep decoding order.  MEASURED (round 5, 4K B picture alone): 83 us against 84 us in
+  // decoding order - the launch is as long as its longest chain of blocks (17 hops of 4..5 us each: the latency of one wavefront filling, predicting, storing and
+  // publishing one block), not as the wavefronts that wait make it; off unless the owner of the scratch asks (VVR_LEAF_BY_LEVEL=1), kept with its test.
+  bool leafSortOn = false, leafSort = false;
   std::vector<uint16_t> levMap;             // per component and cell: level of the intra-stage block that owns it in this picture, 0: none
   std::vector<uint16_t> lev[3], csLev;      // per block of intra[k]; per VPDU (0: not looked up yet)
   std::vector<uint16_t> levAllV;            // per item of the list
