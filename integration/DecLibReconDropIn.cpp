@@ -63,9 +63,13 @@ struct AmdCtx
   int numSlots = 0;
   // a Picture object keeps its slot (PicListManager recycles the objects); what the slot holds is a LIFE of the object: the POC it carried when the
   // back-end last wrote the slot, and whether the back-end reconstructed it itself or it was uploaded from the Picture's buffers
-  struct Slot { const Picture* pic = nullptr; int poc = 0; bool ours = false; uint64_t lastUse = 0; };
+  // `held`: the picture in the slot is being reconstructed or its planes are still to be copied into the Picture's buffers (the slot is not given up);
+  struct Slot { const Picture* pic = nullptr; int poc = 0; bool ours = false; bool held = false; uint64_t lastUse = 0; };
   std::vector<Slot> slots;
   std::map<const Picture*, int> slotOf;
+  // pictures this back-end reconstructed whose slot was given up while the Picture's own buffers did NOT hold the samples (VVDEC_AMD_NO_READBACK): object -> POC
+  std::map<const Picture*, int> lostWithoutHostCopy;
+  int slotsGivenUp = 0, uploads = 0;
   uint64_t useCounter = 0;
   uint16_t maxW = 0, maxH = 0; uint8_t chroma = 0, bitDepth = 0, log2Ctu = 0;
   ~AmdCtx() { if( ctx ) vvr_destroy( ctx ); }
@@ -111,6 +115,7 @@ int envInt( const char* name, int def ) { const char* e = getenv( name ); return
 // (the round-3 path); 2 = self-check: the reference's own runs, the back-end's derivation (vvdec_amd/csrc/vvr_lf_init.h, the source k_lf_init is compiled
 // from) runs on the host beside it and every difference the deblocking filter would see is reported
 int lfInitMode() { static const int m = envInt( "VVDEC_AMD_LF_INIT", 0 ); return m; }
+bool noReadBack() { static const bool n = getenv( "VVDEC_AMD_NO_READBACK" ) != nullptr; return n; }
 std::atomic<long> g_lfpCheckedCells{ 0 }, g_lfpDifferentCells{ 0 };
 
 // self-check (VVDEC_AMD_LF_INIT=2): the description's tables (the reference's LF_INIT) against the back-end's derivation from the same description
@@ -207,6 +212,8 @@ void DecLibRecon::destroy()
       fprintf( stderr, "[vvdec_amd] %d pictures, host ms per picture: MIDER %.2f, LF_INIT %.2f, flatten %.2f, submit+device %.2f, planes back %.2f\n", it->second->pictures,
                it->second->msMider / it->second->pictures, it->second->msLfInit / it->second->pictures, it->second->msFlatten / it->second->pictures,
                ( it->second->msSubmit + it->second->msDevice ) / it->second->pictures, it->second->msReadBack / it->second->pictures );
+    if( getenv( "VVDEC_AMD_TIMES" ) && it->second->pictures && it->second->ctx )
+      fprintf( stderr, "[vvdec_amd] slots given up: %d, reference pictures uploaded from host memory: %d\n", it->second->ctx->slotsGivenUp, it->second->ctx->uploads );
     if( lfInitMode() == 2 && it->second->pictures )
       fprintf( stderr, "[vvdec_amd] edge parameters: %ld entries checked against the reference's LF_INIT, %ld differ\n", g_lfpCheckedCells.exchange( 0 ), g_lfpDifferentCells.exchange( 0 ) );
     g_inst.erase( it );        // (the last instance of a decoder takes the context, hence the DPB in HBM, with it)
@@ -404,9 +411,10 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
           if( s < 0 )
           {
             for( int k = 0; k < X.numSlots; k++ )
-              if( std::find( needed.begin(), needed.end(), X.slots[k].pic ) == needed.end() && ( s < 0 || X.slots[k].lastUse < X.slots[s].lastUse ) ) s = k;
-            CHECK( s < 0, "vvdec_amd: a picture and its reference pictures need more DPB slots than the back-end has (VVDEC_AMD_SLOTS)" );
-            X.slotOf.erase( X.slots[s].pic );
+              if( !X.slots[k].held && std::find( needed.begin(), needed.end(), X.slots[k].pic ) == needed.end() && ( s < 0 || X.slots[k].lastUse < X.slots[s].lastUse ) ) s = k;
+            CHECK( s < 0, "vvdec_amd: a picture, its reference pictures and the pictures still in flight need more DPB slots than the back-end has (VVDEC_AMD_SLOTS)" );
+            if( X.slots[s].ours && noReadBack() ) X.lostWithoutHostCopy[X.slots[s].pic] = X.slots[s].poc;
+            X.slotOf.erase( X.slots[s].pic ); X.slotsGivenUp++;
           }
           X.slots[s] = AmdCtx::Slot(); X.slots[s].pic = p;
           it = X.slotOf.emplace( p, s ).first;
@@ -426,13 +434,22 @@ bool DecLibRecon::ctuTask( int tid, void* task_param )
         const bool madeUp = ref->slices.empty() || ref->slices[0]->getPicHeader() == nullptr;
         const bool current = !isNew && sl.poc == ref->poc && ( sl.ours ? !madeUp : true );
         if( current ) continue;
+        {
+          // (what is uploaded must be what the decoder reconstructed: a picture of ours that lost its slot before its samples reached the Picture's buffers is gone.
+          // A conforming stream does not get here: a slot is only given up for a picture that is in no reference picture list of the current picture, and such a
+          // picture is never referenced again)
+          auto lost = X.lostWithoutHostCopy.find( ref );
+          if( lost != X.lostWithoutHostCopy.end() && lost->second == ref->poc && !madeUp )
+            THROW_RECOVERABLE( "vvdec_amd: reference picture POC " << ref->poc << " lost its slot without a copy in host memory (VVDEC_AMD_NO_READBACK with too few VVDEC_AMD_SLOTS)" );
+          if( lost != X.lostWithoutHostCopy.end() ) X.lostWithoutHostCopy.erase( lost );
+        }
         vvr_slot_picture_size( X.ctx, rs, (int) ref->lwidth(), (int) ref->lheight() );      // (a coded video sequence may change its picture size)
         CPelUnitBuf rb = const_cast<const Picture*>( ref )->getRecoBuf();
         for( size_t c = 0; c < rb.bufs.size(); c++ )
           if( vvr_write_plane( X.ctx, rs, (int) c, reinterpret_cast<const uint16_t*>( rb.bufs[c].buf ), (size_t) rb.bufs[c].stride ) != VVR_OK ) THROW_RECOVERABLE( "vvdec_amd: " << vvr_last_error( X.ctx ) );
-        sl.poc = ref->poc; sl.ours = false;
+        sl.poc = ref->poc; sl.ours = false; X.uploads++;
       }
-      { AmdCtx::Slot& sl = X.slots[I.slot]; sl.poc = pic->poc; sl.ours = true; }
+      { AmdCtx::Slot& sl = X.slots[I.slot]; sl.poc = pic->poc; sl.ours = true; sl.held = true; X.lostWithoutHostCopy.erase( pic ); }
       const double t2b = nowMs();
       vvr_glue::extractPicture( cs, slice, *pic, rsp, R.m_cTrQuant, [&X]( const Picture* p ) { auto q = X.slotOf.find( p ); return q == X.slotOf.end() ? -1 : q->second; }, I.slot, I.desc, hostThreads, /* the motion field only where the back-end reads it */ lfInitMode() != 2, /* edge parameters: the back-end's */ lfInitMode() == 0 );
       if( lfInitMode() == 2 ) checkEdgeParameters( I.desc );
@@ -494,6 +511,8 @@ Picture* DecLibRecon::waitForPrevDecompressedPic()
 {
   if( !m_currDecompPic ) return nullptr;
   AmdInst& I = instOf( this );
+  // (the slot may be given up again once this picture has left the back-end, with or without an error)
+  auto release = [&]{ if( I.ctx && I.slot >= 0 ) { std::lock_guard<std::mutex> lk( I.sh->mu ); if( I.slot < (int) I.ctx->slots.size() && I.ctx->slots[I.slot].pic == m_currDecompPic ) I.ctx->slots[I.slot].held = false; } };
   try
   {
     if( m_decodeThreadPool->numThreads() == 0 )
@@ -526,7 +545,7 @@ Picture* DecLibRecon::waitForPrevDecompressedPic()
     // ---- the picture as the rest of the decoder expects it: planes in the Picture's own buffers (output, hash SEI, film grain) - this picture only, the
     // others in flight are not waited for; through pinned staging, rows laid out by a few threads of this call.  VVDEC_AMD_NO_READBACK=1 (throughput
     // experiments only: output and hash checks then see stale buffers) leaves it out.
-    if( I.planesPending && !getenv( "VVDEC_AMD_NO_READBACK" ) )
+    if( I.planesPending && !noReadBack() )
     {
       const double t4 = nowMs();
       PelUnitBuf reco = m_currDecompPic->getRecoBuf();
@@ -537,12 +556,14 @@ Picture* DecLibRecon::waitForPrevDecompressedPic()
       I.msReadBack += nowMs() - t4;
     }
     I.planesPending = false;
+    release();
     m_currDecompPic->cs->deallocTempInternals();
   }
   catch( ... )
   {
     m_currDecompPic->error = true;
     m_currDecompPic->reconDone.setException( std::current_exception() );
+    release();
   }
   if( m_currDecompPic->error || m_currDecompPic->reconDone.hasException() ) cleanupOnException();
   return std::exchange( m_currDecompPic, nullptr );

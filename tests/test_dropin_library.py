@@ -246,3 +246,32 @@ def test_parser_fed_streams_end_to_end_on_the_cpu_oracle():
     finally:
         dd.BACKEND = keep
     assert not bad, bad
+
+
+def test_few_slots_are_enough():
+    """the back-end's DPB smaller than the decoder's pool of Picture objects (VVDEC_AMD_SLOTS): the least recently used slot that is neither needed by the
+    picture (itself and every picture of its reference picture lists) nor still in flight is given up - bit-exact all the same; when even that does not
+    leave a slot the picture is refused with a message that names the setting (a slot of a picture in flight is never taken).  On the CPU oracle behind the drop-in"""
+    import re
+    dd, d = _conformance_streams()
+    if d is None or not os.path.exists(dd.APP_DROPIN):
+        pytest.skip("no bitstreams or oracle/_ref/vvdecapp_dropin not built (needs /root/reference)")
+    bit = [b for b in dd.find_streams(d) if "mini_inter_tools_ctu128_384x256" in b][0]
+    keep, env_keep = dd.BACKEND, dict(os.environ)
+    dd.BACKEND = _oracle_backend()
+
+    def run(threads, **env):
+        os.environ.update({k: str(v) for k, v in env.items()})
+        r, _ = dd.run_app(dd.APP_DROPIN, ["-b", bit, "-t", str(threads), "-v", "3", "-md5", dd.expected_md5(bit)], preload=dd.BACKEND)
+        out = r.stdout + r.stderr
+        m = re.search(r"slots given up: (\d+), reference pictures uploaded from host memory: (\d+)", out)
+        return r.returncode, int(m.group(1)) if m else 0, out
+    try:
+        for threads in (0, 1, 4):
+            rc, given_up, out = run(threads, VVDEC_AMD_TIMES=1, VVDEC_AMD_SLOTS=5)
+            assert rc == 0 and given_up > 0, out[-800:]
+        rc, _, out = run(1, VVDEC_AMD_SLOTS=2)
+        assert rc != 0 and "need more DPB slots" in out, out[-800:]
+    finally:
+        dd.BACKEND = keep
+        os.environ.clear(); os.environ.update(env_keep)
