@@ -5,10 +5,10 @@
 out=gpurun_out/${2:-r5final}; mkdir -p $out
 R=$GRAFT_REPO_ROOT
 if [ "$1" = a ]; then
-  echo "== gpu suite"; timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee $out/gpu_parity_suite.log
-  echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-  echo "== bench, driver arguments"; /usr/bin/time -f "%e s wall" timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench_4k_steps20_warmup5.json 2> $out/bench_4k_steps20_warmup5.err; tail -1 $out/bench_4k_steps20_warmup5.err; cut -c1-600 $out/bench_4k_steps20_warmup5.json
-  echo "== bench, default arguments"; /usr/bin/time -f "%e s wall" timeout 900 python bench.py > $out/bench_4k_default.json 2> $out/bench_4k_default.err; tail -1 $out/bench_4k_default.err; cut -c1-300 $out/bench_4k_default.json
+  [ -n "$SKIP_SUITE" ] || { echo "== gpu suite"; timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee $out/gpu_parity_suite.log
+  echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2; }
+  echo "== bench, driver arguments"; t0=$SECONDS; timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench_4k_steps20_warmup5.json 2> $out/bench_4k_steps20_warmup5.err; echo "$((SECONDS-t0)) s wall"; cut -c1-600 $out/bench_4k_steps20_warmup5.json
+  echo "== bench, default arguments"; t0=$SECONDS; timeout 900 python bench.py > $out/bench_4k_default.json 2> $out/bench_4k_default.err; echo "$((SECONDS-t0)) s wall"; cut -c1-300 $out/bench_4k_default.json
   nproc > $out/host.txt; lscpu | head -20 >> $out/host.txt
 else
   bash tools/gpu_r5_evidence.sh $(basename $out) 2>&1 | tail -60
