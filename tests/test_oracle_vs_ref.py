@@ -411,7 +411,7 @@ WRAP_CASES = [
     (384, 256, 5, 2, 294, 320, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS, dict(p_intra=0.1, p_affine=0.3, p_bi=0.8, mv_sigma=20.0)),
     (416, 240, 6, 3, 295, 416, abi.TOOL_WP, dict(p_intra=0.1, p_bi=0.7)),
     # vectors several wrap periods out (a parsed stream with AMVR carries them; mv_window lets the generator keep them): every clip path is taken with a move by a
-    # period AND a clamp - the case in which the DMVR start vectors must be clipped against the CU, not the sub-block (round 4, tests/bitstreams_open)
+    # period AND a clamp - the case in which the DMVR start vectors must be clipped against the CU, not the sub-block (round 4, tests/bitstreams/wraparound_*)
     (384, 256, 6, 2, 296, 368, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF, dict(p_intra=0.05, p_bi=0.9, mv_sigma=1500.0, mv_window=2000)),
     (384, 256, 6, 3, 297, 368, abi.TOOL_BDOF | abi.TOOL_DMVR | abi.TOOL_PROF | abi.TOOL_LMCS, dict(p_intra=0.1, p_bi=0.8, p_affine=0.2, p_geo=0.2, p_ciip=0.1, mv_sigma=3000.0, mv_window=4000)),
     # SbTMVP with such vectors: the pieces xSubPuMC joins decide the wrap clip (wide, tall and square CUs; cut runs)
