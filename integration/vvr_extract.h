@@ -443,7 +443,9 @@ static inline void extractPicture( CodingStructure& cs, Slice& slice, Picture& p
       for( auto& tu : TUTraverser( &cu.firstTU, cu.lastTU->next ) )
       {
         vvr_tu t; memset( &t, 0, sizeof( t ) );
-        const bool hasL = tu.blocks[0].valid(), hasC = chroma && tu.blocks.size() > 1 && tu.blocks[1].valid();
+        // (a CU of a separate tree carries the blocks of its tree only - but the EMPTY transform unit the parser gives a skipped or residual-free IBC CU of the luma
+        // tree spans all components, CodingStructure::addEmptyTUs: found with the first parser-fed IBC streams in dual-tree pictures, round 5)
+        const bool hasL = tu.blocks[0].valid() && !treeC, hasC = chroma && !treeL && tu.blocks.size() > 1 && tu.blocks[1].valid();
         const Area ta = hasL ? Area( tu.blocks[0] ) : Area( tu.blocks[1].x << 1, tu.blocks[1].y << 1, tu.blocks[1].width << 1, tu.blocks[1].height << 1 );
         t.x = (uint16_t) ta.x; t.y = (uint16_t) ta.y; t.w = (uint8_t) ta.width; t.h = (uint8_t) ta.height;
         t.comp_mask = (uint8_t) ( ( hasL ? 1 : 0 ) | ( hasC ? 6 : 0 ) );

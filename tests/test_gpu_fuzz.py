@@ -122,7 +122,7 @@ def test_gpu_fuzz_slice(built):
     print("fuzz seed %d: %d pictures bit-exact, %d parameter sets refused by generator / oracle, %.0f s" % (seed0, n, refused, time.time() - t0))
 
 
-INTRA_SWITCHES = ["sao", "lmcs", "jccr", "dep_quant", "mrl", "isp", "mip", "cclm", "lfnst", "mts", "alf", "ccalf", "dqp", "ts", "bdpcm", "big_resi"]
+INTRA_SWITCHES = ["sao", "lmcs", "jccr", "dep_quant", "mrl", "isp", "mip", "cclm", "lfnst", "mts", "alf", "ccalf", "dqp", "ts", "bdpcm", "big_resi", "ibc"]
 INTER_SWITCHES = ["tmvp", "sbtmvp", "bdof", "dmvr", "mmvd", "affine", "ciip", "gpm", "amvr", "bcw", "smvd", "sbt"]
 
 

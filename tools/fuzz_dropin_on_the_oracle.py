@@ -11,7 +11,7 @@ import dropin_decode as dd
 import test_dropin_library as TD
 
 
-INTRA_SWITCHES = ["sao", "lmcs", "jccr", "dep_quant", "mrl", "isp", "mip", "cclm", "lfnst", "mts", "alf", "ccalf", "dqp", "ts", "bdpcm", "big_resi"]
+INTRA_SWITCHES = ["sao", "lmcs", "jccr", "dep_quant", "mrl", "isp", "mip", "cclm", "lfnst", "mts", "alf", "ccalf", "dqp", "ts", "bdpcm", "big_resi", "ibc"]
 INTER_SWITCHES = ["tmvp", "sbtmvp", "bdof", "dmvr", "mmvd", "affine", "ciip", "gpm", "amvr", "bcw", "smvd", "sbt"]
 MUTATE = len(sys.argv) > 3 and sys.argv[3] == "mutate"
 

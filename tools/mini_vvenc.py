@@ -268,7 +268,7 @@ class Cfg:
                  inter=False, tmvp=True, sbtmvp=False, bdof=True, dmvr=True, mmvd=False, affine=False, ciip=False, gpm=False, p_skip=0.3, p_intra=0.15, p_merge=0.5, max_mvd=24,
                  sao=False, lmcs=False, jccr=False, dep_quant=False, mtt_depth=0, p_mtt=0.5,
                  mrl=False, isp=False, mip=False, cclm=False, lfnst=False, mts=False, alf=False, ccalf=False, alf_aps=2, big_resi=False,
-                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, part=None, lf_across=True, rpr=None, mono=False, subpic=None, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False):
+                 amvr=False, bcw=False, smvd=False, sbt=False, dqp=False, dual_tree=False, log2_min_qt_c=4, scaling=False, ts=False, bdpcm=False, ts_regular=False, part=None, lf_across=True, rpr=None, mono=False, subpic=None, chroma_qp=False, db_offsets=False, ladf=False, wrap=False, vb=False, wp=False, ibc=False, p_ibc=0.3):
         assert width % (1 << log2_ctu) == 0 and height % (1 << log2_ctu) == 0, "pictures of whole CTUs only (no implicit splits at the picture boundary)"
         self.__dict__.update(locals())
         self.log2_min_cb = 3                       # 8x8 luma / 4x4 chroma: no block below 4x4, no local dual tree
@@ -482,7 +482,9 @@ def write_sps(c):
     b.flag(0)                                        # sps_palette_enabled_flag
     if c.ts:
         b.ue(2 if c.bit_depth > 8 else 0)            # sps_internal_bit_depth_minus_input_bit_depth (the QP floor of transform-skip blocks)
-    b.flag(0)                                        # sps_ibc_enabled_flag
+    b.flag(1 if c.ibc else 0)                        # sps_ibc_enabled_flag
+    if c.ibc:
+        b.ue(5)                                      # sps_six_minus_max_num_ibc_merge_cand: one candidate - no merge index, no predictor flag (the writer models candidate 0)
     b.flag(c.ladf)                                   # sps_ladf_enabled_flag
     if c.ladf:
         b.u(2, 2)                                    # sps_num_ladf_intervals_minus2: four intervals
@@ -966,6 +968,10 @@ class PictureWriter:
         self.P = c.partition
         self.stats = dict(cus=0, split=0, cbf=0, coefs=0, skip=0, merge=0, amvp=0, intra=0)
         self.dqp_coded, self.cu_ciip, self.cu = False, False, dict(w=0, h=0, sbt=None, isp=0)
+        # intra block copy: the block vector (whole luma samples) of the IBC CU that covers a cell, the history of block vectors of the CTU row
+        # (MotionHist::motionLutIbc, emptied at the first CTU of a row: DecCu::TaskDeriveCtuMotionInfo :66-74)
+        self.ibc_bv, self.ibc_lut = {}, []
+        assert not (c.ibc and self.P), "this writer's IBC knows one slice, one tile"
 
     # is the 4x4 cell at luma position (nx, ny) a neighbour the block at (x, y) may look at?  (same slice and tile: CodingStructure::getCURestricted)
     def dq_on(self):
@@ -988,6 +994,8 @@ class PictureWriter:
             ctus = [(rx, ry) for ry in range(self.c.height // S) for rx in range(self.c.width // S)]
         for (rx, ry) in ctus:
             x, y = rx * S, ry * S
+            if rx == 0:
+                self.ibc_lut = []
             if True:
                 sao_on = self.c.sao and (self.sl is None or any(self.sl["sao"]))
                 if sao_on:
@@ -1207,7 +1215,106 @@ class PictureWriter:
         self.stats["cus"] += 1
         if self.st != "I":
             return self.coding_unit_inter(x, y, w, h)
+        if self.c.ibc and self.tree != "chroma":
+            return self.coding_unit_ibc(x, y, w, h)
         return self.intra_cu(x, y, w, h)
+
+    # ---- intra block copy (I slices; sps_ibc_enabled_flag with ONE merge candidate).  Unlike every other syntax element of this writer the block vector cannot be
+    # random: the reference block has to be reconstructed already, so the writer follows the decoder's derivation of candidate 0 - the IBC CU left of the bottom-left
+    # sample, else the one above the top-right sample, else the newest entry of the row's history, else zero (PU::getIBCMergeCandidates, UnitTools.cpp:728-830;
+    # history: DecCu.cpp:884-900, MotionInfo.h:242) - and codes the difference to a vector it has checked: reference block inside the current CTU, every 4x4 cell
+    # of it coded before this CU, even components (chroma blocks of 4:2:0 then start on a chroma sample)
+    def ibc_candidate(self, x, y, w, h):
+        for (nx, ny) in ((x - 1, y + h - 1), (x + w - 1, y - 1)):
+            if nx >= 0 and ny >= 0 and self.avail(x, y, nx, ny) and self.cu_w[ny >> 2][nx >> 2] and (self.cu_f[ny >> 2][nx >> 2] & 16):
+                return self.ibc_bv[(nx >> 2, ny >> 2)]
+        return self.ibc_lut[-1] if self.ibc_lut else None
+
+    def ibc_valid(self, x, y, w, h, bv):
+        S = 1 << self.c.log2_ctu
+        rx, ry = x + bv[0], y + bv[1]
+        if (bv[0] | bv[1]) & 1 or rx < (x & -S) or ry < (y & -S) or rx + w > (x & -S) + S or ry + h > (y & -S) + S:
+            return False
+        return all(self.cu_w[cy][cx] for cy in range(ry >> 2, (ry + h + 3) >> 2) for cx in range(rx >> 2, (rx + w + 3) >> 2))
+
+    def ibc_pick(self, x, y, w, h):
+        S, rng = 1 << self.c.log2_ctu, self.rng
+        x0, y0 = x & -S, y & -S
+        for _ in range(24):
+            rx, ry = x0 + 2 * rng.randrange(0, (S - w) // 2 + 1), y0 + 2 * rng.randrange(0, (S - h) // 2 + 1)
+            if self.ibc_valid(x, y, w, h, (rx - x, ry - y)):
+                return (rx - x, ry - y)
+        return None
+
+    def mvd_write(self, hv, vv):                                               # mvd_coding with given components (CABACReader::mvd_coding)
+        cab = self.cab
+        cab.bin(1 if hv else 0, "Mvd", 0)
+        cab.bin(1 if vv else 0, "Mvd", 0)
+        if hv:
+            cab.bin(1 if abs(hv) > 1 else 0, "Mvd", 1)
+        if vv:
+            cab.bin(1 if abs(vv) > 1 else 0, "Mvd", 1)
+        for a in (hv, vv):
+            if a:
+                if abs(a) > 1:
+                    self.rem_abs_ep(abs(a) - 2, 1, 0)
+                cab.ep(1 if a < 0 else 0)
+
+    def ibc_decide(self, x, y, w, h, p):
+        rng = self.rng
+        mode, bv, pred = None, None, None
+        if w <= 64 and h <= 64 and rng.random() < p:
+            pred = self.ibc_candidate(x, y, w, h)
+            pred_ok = pred is not None and self.ibc_valid(x, y, w, h, pred)
+            r = rng.random()
+            if pred_ok and r < 0.45:
+                mode, bv = ("skip" if r < 0.2 else "merge"), pred
+            else:
+                bv = self.ibc_pick(x, y, w, h)
+                mode = "amvp" if bv else None
+        return mode, bv, pred
+
+    # everything of an IBC CU behind pred_mode_ibc_flag (general_merge_flag .. the transform tree), then its vector into the cell map and the history
+    def ibc_rest(self, x, y, w, h, mode, bv, pred):
+        cab, rng, c = self.cab, self.rng, self.c
+        if mode != "skip":
+            cab.bin(1 if mode == "merge" else 0, "MergeFlag", 0)               # general_merge_flag (merge_idx: one candidate)
+            root = True
+            if mode == "amvp":
+                p = pred if pred is not None else (0, 0)
+                dh, dv = bv[0] - p[0], bv[1] - p[1]
+                self.mvd_write(dh, dv)                                         # (mvp_l0_flag: one candidate)
+                if c.amvr and (dh or dv):
+                    cab.bin(0, "ImvFlag", 1)                                   # amvr_precision_idx: whole samples (CABACReader::amvr_mode :1001-1025)
+                root = rng.random() < 0.7
+                cab.bin(1 if root else 0, "QtRootCbf", 0)                      # cu_coded_flag
+            if root:
+                self.cu = dict(intra=False, ibc=True, w=w, h=h, isp=0, mip=False, viol=False, lfnst_last=False, mts_last=False, sbt=None)
+                self.transform_tree(w, h, intra=False, root=True)
+                self.lfnst_and_mts()
+        self.stats["ibc"] = self.stats.get("ibc", 0) + 1
+        for cy in range(y >> 2, (y + h) >> 2):
+            for cx in range(x >> 2, (x + w) >> 2):
+                self.ibc_bv[(cx, cy)] = bv
+        if w * h > 16:
+            if bv in self.ibc_lut:
+                self.ibc_lut.remove(bv)
+            elif len(self.ibc_lut) == 5:
+                self.ibc_lut.pop(0)
+            self.ibc_lut.append(bv)
+        return 16 | (1 if mode == "skip" else 0)
+
+    def coding_unit_ibc(self, x, y, w, h):
+        cab, c = self.cab, self.c
+        left, above = self.neigh(x, y)
+        mode, bv, pred = self.ibc_decide(x, y, w, h, c.p_ibc)
+        cab.bin(1 if mode == "skip" else 0, "SkipFlag", (left & 1) + (above & 1))      # cu_skip_flag (every luma CU of an I slice once IBC is enabled; a skipped one is an IBC merge CU)
+        if mode != "skip":
+            if w <= 64 and h <= 64:
+                cab.bin(1 if mode else 0, "IBCFlag", (1 if left & 16 else 0) + (1 if above & 16 else 0))      # pred_mode_ibc_flag
+            if not mode:
+                return self.intra_cu(x, y, w, h)
+        return self.ibc_rest(x, y, w, h, mode, bv, pred)
 
     # -- an intra CU: modes, transform tree, lfnst_idx, mts_idx (CABACReader::cu_pred_data, cu_residual :1404-1456)
     def intra_cu(self, x, y, w, h):
@@ -1234,7 +1341,7 @@ class PictureWriter:
             cab.bin(1 if lfnst else 0, "LFNSTIdx", 0 if self.tree == "single" else 1)      # lfnst_idx (context: single or separate tree)
             if lfnst:
                 cab.bin(lfnst - 1, "LFNSTIdx", 2)
-        if c.mts and self.tree != "chroma" and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and not cu["sbt"] and not cu.get("ts_first") and not cu.get("bdpcm") and cu["mts_last"] and lfnst == 0 and not cu.get("mts_viol"):
+        if c.mts and not cu.get("ibc") and self.tree != "chroma" and cu["w"] <= 32 and cu["h"] <= 32 and not cu["isp"] and not cu["sbt"] and not cu.get("ts_first") and not cu.get("bdpcm") and cu["mts_last"] and lfnst == 0 and not cu.get("mts_viol"):
             m = rng.choice([0, 0, 1, 2, 3, 4])
             cab.bin(1 if m else 0, "MTSIndex", 0)                                # mts_idx
             for k in range(1, 4):
@@ -1252,17 +1359,28 @@ class PictureWriter:
         cab, rng, c = self.cab, self.rng, self.c
         left, above = self.neigh(x, y)
         self.cu_ciip = False
-        skip = rng.random() < c.p_skip
+        ibc_ctx = (1 if left & 16 else 0) + (1 if above & 16 else 0)
+        ibc_asked = c.ibc and w <= 64 and h <= 64                              # (P / B slices of a sequence with IBC: the flag follows a skip flag of 1 and a pred_mode_flag of 0)
+        imode, ibv, ipred = self.ibc_decide(x, y, w, h, 0.5 * c.p_ibc) if ibc_asked else (None, None, None)
+        skip = imode == "skip" or (imode is None and rng.random() < c.p_skip)
         cab.bin(1 if skip else 0, "SkipFlag", (left & 1) + (above & 1))        # cu_skip_flag
         if skip:
+            if ibc_asked:
+                cab.bin(1 if imode else 0, "IBCFlag", ibc_ctx)                 # pred_mode_ibc_flag of a skipped CU (CABACReader::cu_skip_flag :945-975)
+            if imode:
+                return self.ibc_rest(x, y, w, h, imode, ibv, ipred)
             self.stats["skip"] += 1
             aff = self.merge_data(x, y, w, h, True, left, above)
             return 1 | (4 if aff else 0)
-        intra = rng.random() < c.p_intra
+        intra = imode is None and rng.random() < c.p_intra
         cab.bin(1 if intra else 0, "PredMode", 1 if ((left & 2) or (above & 2)) else 0)      # pred_mode_flag
         if intra:
             self.stats["intra"] += 1
             return self.intra_cu(x, y, w, h)
+        if ibc_asked:
+            cab.bin(1 if imode else 0, "IBCFlag", ibc_ctx)                     # pred_mode_ibc_flag (CABACReader::pred_mode :1082-1093)
+        if imode:
+            return self.ibc_rest(x, y, w, h, imode, ibv, ipred)
         merge = rng.random() < c.p_merge
         cab.bin(1 if merge else 0, "MergeFlag", 0)                             # general_merge_flag
         aff = False
@@ -2311,6 +2429,15 @@ FIXTURES = [
     ("mini_all_tools_ctu64_8bit_320x192", dict(width=320, height=192, log2_ctu=6, log2_min_qt=4, qp=33, bit_depth=8, mtt_depth=3, inter=True, sbtmvp=True, mmvd=True, affine=True,
                                                ciip=True, gpm=True, mrl=True, mip=True, cclm=True, isp=True, lfnst=True, mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True,
                                                alf=True, ccalf=True, p_intra=0.2, p_skip=0.2), 13, 54),
+    # intra block copy through the real parser (round 5): block vectors the writer has checked against its model of the decoder's candidate 0 (see coding_unit_ibc) - I pictures,
+    # with the intra tools and the filters, in the luma tree of dual-tree pictures, and in the I, P and B pictures of a random-access stream with every inter tool
+    ("mini_ibc_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, ibc=True, p_ibc=0.4), 2, 201),
+    ("mini_ibc_tools_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=28, mtt_depth=2, mrl=True, isp=True, mip=True, cclm=True, lfnst=True, mts=True, sao=True, lmcs=True,
+                                           jccr=True, dep_quant=True, alf=True, ccalf=True, ts=True, bdpcm=True, ibc=True, p_ibc=0.4), 2, 202),
+    ("mini_ibc_dual_tree_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, dual_tree=True, mrl=True, isp=True, mip=True, lfnst=True, mts=True,
+                                               ibc=True, p_ibc=0.5), 2, 203),
+    ("mini_ibc_inter_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True, amvr=True,
+                                                 bcw=True, smvd=True, sbt=True, sao=True, lmcs=True, jccr=True, dep_quant=True, alf=True, p_intra=0.2, ibc=True, p_ibc=0.4), 9, 204),
 ]
 
 

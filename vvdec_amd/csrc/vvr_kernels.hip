@@ -2845,7 +2845,7 @@ void launch_deblock_tile( hipStream_t st, const PicDev& pic, DevPlanes src, DevP
 // registers: nothing is loaded in those loops.  (One lane per unit left 64 such rounds per wavefront on a fifth of the chip's SIMDs: 34 us instead of 9.)
 // Behind the transform units: one thread per cell of the host's list of sub-block motion.
 __global__ __launch_bounds__( 256 ) void k_lf_maps( PicDev pic, int numCu, int numTu, LfCell* __restrict__ cell, LfCell* __restrict__ cellC, LfMv* __restrict__ mvs, uint32_t* __restrict__ refs,
-                                                   const LfSbCell* __restrict__ sb, int numSb )
+                                                   const LfSbCell* __restrict__ sb, int numSb, int dbg )
 {
   const int gt = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, t = gt >> 3, sub = gt & 7;
   const int w4 = pic.w4, h4 = pic.h4;
@@ -2874,9 +2874,11 @@ __global__ __launch_bounds__( 256 ) void k_lf_maps( PicDev pic, int numCu, int n
       if( kind == 1 && C.pred_mode == VVR_PRED_INTER && ( C.flags & VVR_CU_AFFINE ) ) kind = 3;
       if( kind == 1 ) { mo[0] = (uint32_t) m.mv[0][0]; mo[1] = (uint32_t) m.mv[0][1]; mo[2] = (uint32_t) m.mv[1][0]; mo[3] = (uint32_t) m.mv[1][1]; mo[4] = lfi_pack_refs( m ); }
       if( C.tree == VVR_TREE_CHROMA ) kind |= 4;
+      if( ( dbg & 1 ) && ( kind & 3 ) == 3 ) kind = ( kind & 4 ) | 1;      // (timing: affine cells like plain ones)
+      if( dbg & 2 ) kind &= 4;                                            // (timing: no motion stores)
     }
   }
-  auto put = [&]( const LfCell& r, int cu, int cx4, int cy4, int k, const uint32_t* mv, int x, int y )
+  auto put = [&]( const LfCell& r, const vvr_cu& cuRec, int cx4, int cy4, int k, const uint32_t* mv, int x, int y )
   {
     const LfCell q = lfi_cell_at( r, cx4, cy4, x, y );
     const size_t at = (size_t) y * w4 + x;
@@ -2884,12 +2886,12 @@ __global__ __launch_bounds__( 256 ) void k_lf_maps( PicDev pic, int numCu, int n
     if( ( k & 3 ) == 1 ) { *reinterpret_cast<uint4*>( &mvs[at] ) = make_uint4( mv[0], mv[1], mv[2], mv[3] ); refs[at] = mv[4]; }
     else if( ( k & 3 ) == 3 )
     {   // (affine CU, VVR_TOOL_AFFINE_MV_ON_DEVICE: per cell from the control points)
-      vvr_motion m; lfi_cell_motion( pic.hdr, pic.cu[cu], x, y, m );
+      vvr_motion m; lfi_cell_motion( pic.hdr, cuRec, x, y, m );
       *reinterpret_cast<uint4*>( &mvs[at] ) = make_uint4( (uint32_t) m.mv[0][0], (uint32_t) m.mv[0][1], (uint32_t) m.mv[1][0], (uint32_t) m.mv[1][1] ); refs[at] = lfi_pack_refs( m );
     }
   };
-  const int n = nx * ny;
-  if( sub < n && n <= 8 ) put( rec, cuIdx, cuX4, cuY4, kind, mo, x0 + sub % nx, y0 + sub / nx );
+  const int n = ( dbg & 4 ) ? 0 : nx * ny;                                // (timing: no cell stores at all: the loads and the packing)
+  if( sub < n && n <= 8 ) put( rec, pic.cu[cuIdx], cuX4, cuY4, kind, mo, x0 + sub % nx, y0 + sub / nx );
   unsigned long long big = __ballot( n > 8 && sub == 0 );
   while( big )
   {
@@ -2899,7 +2901,10 @@ __global__ __launch_bounds__( 256 ) void k_lf_maps( PicDev pic, int numCu, int n
     const int bx0 = BC( x0 ), by0 = BC( y0 ), bnx = BC( nx ), bn = BC( n ), bcu = BC( cuIdx ), bcx = BC( cuX4 ), bcy = BC( cuY4 ), bk = BC( kind );
     uint32_t bm[5]; for( int e = 0; e < 5; e++ ) bm[e] = (uint32_t) BC( mo[e] );
 #undef BC
-    for( int i = lane; i < bn; i += 64 ) put( r, bcu, bcx, bcy, bk, bm, bx0 + i % bnx, by0 + i / bnx );
+    // (an affine CU: its record into registers ONCE - read per cell through the pointer it came back after every store, a chain of loads per round of 64 cells:
+    // 8 such units in a wavefront were the launch's 30 us)
+    vvr_cu bC; if( ( bk & 3 ) == 3 ) bC = pic.cu[bcu];
+    for( int i = lane; i < bn; i += 64 ) put( r, bC, bcx, bcy, bk, bm, bx0 + i % bnx, by0 + i / bnx );
   }
 }
 // one thread per cell: both directions (the cell's record is read once, as one 16-byte load)
@@ -2922,7 +2927,12 @@ void launch_lf_init( hipStream_t s, const PicDev& pic, uint32_t numCu, uint32_t 
 {
   if( !numTu || !numCu ) return;
   const int cells = pic.w4 * pic.h4;
-  hipLaunchKernelGGL( k_lf_maps, dim3( ( 8 * numTu + numSbCells + 255 ) / 256 ), dim3( 256 ), 0, s, pic, (int) numCu, (int) numTu, cell, cellC, mv, ref, sbCells, numSbCells );
+  int dbg = 0;
+#ifdef VVR_DEV_ENV
+  static const int dbgEnv = getenv( "VVR_LFM_DBG" ) ? atoi( getenv( "VVR_LFM_DBG" ) ) : 0;      // developer build: 1 affine cells like plain ones, 2 no motion stores, 4 no stores (timing only)
+  dbg = dbgEnv;
+#endif
+  hipLaunchKernelGGL( k_lf_maps, dim3( ( 8 * numTu + numSbCells + 255 ) / 256 ), dim3( 256 ), 0, s, pic, (int) numCu, (int) numTu, cell, cellC, mv, ref, sbCells, numSbCells, dbg );
   hipLaunchKernelGGL( k_lf_init, dim3( ( cells + 255 ) / 256 ), dim3( 256 ), 0, s, pic, (const LfCell*) cell, (const LfCell*) cellC, (const LfMv*) mv, (const uint32_t*) ref, out0, out1 );
 }
 
