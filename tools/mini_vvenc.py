@@ -1222,8 +1222,8 @@ class PictureWriter:
     # ---- intra block copy (I slices; sps_ibc_enabled_flag with ONE merge candidate).  Unlike every other syntax element of this writer the block vector cannot be
     # random: the reference block has to be reconstructed already, so the writer follows the decoder's derivation of candidate 0 - the IBC CU left of the bottom-left
     # sample, else the one above the top-right sample, else the newest entry of the row's history, else zero (PU::getIBCMergeCandidates, UnitTools.cpp:728-830;
-    # history: DecCu.cpp:884-900, MotionInfo.h:242) - and codes the difference to a vector it has checked: reference block inside the current CTU, every 4x4 cell
-    # of it coded before this CU, even components (chroma blocks of 4:2:0 then start on a chroma sample)
+    # history: DecCu.cpp:884-900, MotionInfo.h:242) - and codes the difference to a vector it has checked: reference block inside the current CTU or the one / two
+    # CTUs left of it, every 4x4 cell of it coded before this CU, even components (chroma blocks of 4:2:0 then start on a chroma sample)
     def ibc_candidate(self, x, y, w, h):
         for (nx, ny) in ((x - 1, y + h - 1), (x + w - 1, y - 1)):
             if nx >= 0 and ny >= 0 and self.avail(x, y, nx, ny) and self.cu_w[ny >> 2][nx >> 2] and (self.cu_f[ny >> 2][nx >> 2] & 16):
@@ -1233,15 +1233,22 @@ class PictureWriter:
     def ibc_valid(self, x, y, w, h, bv):
         S = 1 << self.c.log2_ctu
         rx, ry = x + bv[0], y + bv[1]
-        if (bv[0] | bv[1]) & 1 or rx < (x & -S) or ry < (y & -S) or rx + w > (x & -S) + S or ry + h > (y & -S) + S:
+        # the CTU row of the CU; the CU's CTU and the one (CTU 128) or two CTUs left of it: all of that is still in the decoder's buffer of reconstructed samples
+        # (256 x 128 luma samples for CTU 128, CodingStructure.cpp:543 - twice what the standard's virtual buffer holds, so the left CTU is there whole)
+        left = self.ibc_left_ctus()
+        if (bv[0] | bv[1]) & 1 or rx < max(0, (x & -S) - left * S) or ry < (y & -S) or rx + w > (x & -S) + S or ry + h > (y & -S) + S:
             return False
         return all(self.cu_w[cy][cx] for cy in range(ry >> 2, (ry + h + 3) >> 2) for cx in range(rx >> 2, (rx + w + 3) >> 2))
+
+    def ibc_left_ctus(self):
+        return 1 if self.c.log2_ctu == 7 else 2
 
     def ibc_pick(self, x, y, w, h):
         S, rng = 1 << self.c.log2_ctu, self.rng
         x0, y0 = x & -S, y & -S
+        xl = max(0, x0 - self.ibc_left_ctus() * S)
         for _ in range(24):
-            rx, ry = x0 + 2 * rng.randrange(0, (S - w) // 2 + 1), y0 + 2 * rng.randrange(0, (S - h) // 2 + 1)
+            rx, ry = xl + 2 * rng.randrange(0, (x0 + S - w - xl) // 2 + 1), y0 + 2 * rng.randrange(0, (S - h) // 2 + 1)
             if self.ibc_valid(x, y, w, h, (rx - x, ry - y)):
                 return (rx - x, ry - y)
         return None
