@@ -524,11 +524,11 @@ VVR_API void*        vvr_job_stream(vvr_context* ctx, int job);
  *   vvr_slot_external_event  pictures submitted from now on that use `slot` wait for `event` (hipEvent_t, recorded by the caller behind its
  *                         collective) first; writes != 0: the external work wrote the slot (earlier users were ordered before it by
  *                         vvr_stream_wait_slot), 0: it only reads it (a sender: later pictures must not overwrite the slot under it).  The
- *                         back-end keeps the handle until the slot is next written or until it finds the event complete (it looks when a
- *                         picture that uses the slot is handed to the device, in vvr_stream_wait_slot and in vvr_sync): the caller keeps the
- *                         event alive until it is complete AND a vvr_sync has returned since (or the slot has been overwritten).  The event
- *                         MUST be recorded before it is registered: an event that was created but never recorded reads as complete
- *                         (hipEventQuery) and would be forgotten at once.
+ *                         back-end keeps the handle until the slot is next written (by a picture or by an external writer) or until
+ *                         vvr_sync finds the event complete - nowhere else does it look: the caller keeps the event alive until it is
+ *                         complete AND a vvr_sync has returned since (or the slot has been overwritten).  The event should be recorded
+ *                         before it is registered: one that is recorded later is still waited for by every picture handed to the device
+ *                         after the record, but a vvr_sync in between forgets it (an event that was never recorded reads as complete).
  * A picture can only be waited for once it has been handed to the device (its work lists are built by worker threads): blocking = 0 returns
  * VVR_NOT_READY instead of waiting for that on the host.                                                                                      */
 VVR_API int          vvr_stream_wait_job(vvr_context* ctx, int job, void* stream, int blocking);

@@ -628,6 +628,44 @@ def test_external_slot_users_are_ordered_on_the_device(stub):
     stub.vvr_destroy(ctx)
 
 
+def test_an_external_event_is_waited_for_whatever_a_query_says(stub):
+    """hipEventQuery cannot tell an event that is complete from one that has not been recorded yet: between two vvr_sync calls the back-end therefore
+    waits for every registered event of a slot it uses and forgets none (round-4 advice: an event registered a moment before its record was dropped
+    at the next hand-over and the picture read the slot under the collective).  The stand-in says "complete" for every event here"""
+    W, H = 256, 128
+    plans, nslots = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    ctx = Ctx(stub, W, H, nslots, streams=3)
+    stub.vvr_stream_wait_slot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    stub.vvr_slot_external_event.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    ext = C.c_void_p()
+    stub.hipStreamCreateWithFlags(C.byref(ext), 0)
+    descs = [synth.picture_for_plan(pl, W, H, seed=612, tool_flags=TOOLS) for pl in plans[:3]]
+    pics = [d.c() for d in descs]
+    assert stub.vvr_submit(ctx.ctx, C.byref(pics[0])) >= 0 and stub.vvr_sync(ctx.ctx) == abi.VVR_OK
+    slot = plans[1].slot
+    assert slot in [s for lst in plans[2].ref_slots for (s, _) in lst]
+    scratch = (C.c_int * 30000)()
+    stub.vvt_take_trace(scratch, len(scratch))
+    stub.vvt_events_pending(0)                              # hipEventQuery: hipSuccess, as for an event nobody has recorded yet
+    assert stub.vvr_stream_wait_slot(ctx.ctx, slot, ext, 1) == abi.VVR_OK
+    ev = C.c_void_p()
+    stub.hipEventCreate(C.byref(ev))
+    assert stub.vvr_slot_external_event(ctx.ctx, slot, ev, 1) == abi.VVR_OK
+    stub.hipEventRecord(ev, ext)                            # (recorded AFTER the registration)
+    assert stub.vvr_submit(ctx.ctx, C.byref(pics[2])) >= 0
+    n_before_sync = None
+    assert stub.vvr_sync(ctx.ctx) == abi.VVR_OK
+    n = stub.vvt_take_trace(scratch, len(scratch))
+    ops = [(scratch[3 * k], scratch[3 * k + 1], scratch[3 * k + 2]) for k in range(n // 3)]
+    records = [(s_, e) for (op, s_, e) in ops if op == 1]
+    waits = [(s_, e) for (op, s_, e) in ops if op == 0]
+    ext_stream = max(s_ for (s_, _) in records + waits)
+    mine = [e for (s_, e) in records if s_ == ext_stream]
+    assert mine and any(e == mine[-1] and s_ != ext_stream for (s_, e) in waits), "the picture that reads the slot did not wait for the external event"
+    ctx.close()
+
+
 def test_job_status_without_waiting(stub):
     """vvr_test: the ready check of a completion task (no thread sleeps in vvr_wait) - not ready while the device works, VVR_OK afterwards, and the job
     can still be waited for"""

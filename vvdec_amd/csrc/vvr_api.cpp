@@ -279,7 +279,10 @@ static void completeLocked( vvr_context* c, Job& j )
 struct CommitPlan { int lane; std::vector<hipEvent_t> waits; RefSet refs; std::vector<int> waitInfo; };
 
 // External events of a slot (vvr_slot_external_event) that the device has passed are dropped: nothing has to wait for them any more, and the caller
-// may destroy an event once it is complete and the back-end has been through vvr_sync (vvr.h).  Called with mu held.
+// may destroy an event once it is complete and the back-end has been through vvr_sync (vvr.h).  Called with mu held - by vvr_sync ONLY: hipEventQuery says
+// hipSuccess for an event that has not been recorded yet as well, so between two vvr_sync calls every registered event is waited for by whoever uses the slot
+// (a wait for a complete event costs nothing on the device); the events of a slot are dropped unasked when a picture overwrites the slot (it has waited for them,
+// and everybody after it waits for the picture) or an external writer registers (vvr_slot_external_event, writes).
 static void pruneExternalEventsLocked( vvr_context* c, int slot )
 {
   auto& v = c->slotExt[slot];
@@ -311,9 +314,9 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
   // ---- dependencies: every job that read or wrote one of our slots
   auto waitFor = [&]( int id ) { auto it = c->jobs.find( id ); if( it != c->jobs.end() ) { Job& j = *it->second; if( !j.completed && j.state == J_COMMITTED && j.lane != lane ) { plan.waits.push_back( j.done ); plan.waitInfo.push_back( j.q ? ( j.id * 16 + j.q->hdr.slice_type * 4 ) : -1 ); plan.waitInfo.push_back( j.lane ); } } };
   for( int id : c->slotUsers[h.out_slot] ) waitFor( id );
-  pruneExternalEventsLocked( c, h.out_slot );
   // external work on our slots (a collective that wrote a reference slot, or still reads the slot we overwrite)
   for( hipEvent_t ev : c->slotExt[h.out_slot] ) { plan.waits.push_back( ev ); plan.waitInfo.push_back( -2 ); plan.waitInfo.push_back( -1 ); }
+  c->slotExt[h.out_slot].clear();       // (this picture waits for them; whoever uses the slot afterwards waits for this picture)
   memset( &plan.refs, 0, sizeof( plan.refs ) );
   if( h.slice_type != 2 )
     for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
@@ -321,7 +324,6 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
       const int slot = h.ref_slot[l][i];
       // wait for the writer of the reference (it is the first entry since the slot was last written)
       if( !c->slotUsers[slot].empty() ) waitFor( c->slotUsers[slot][0] );
-      pruneExternalEventsLocked( c, slot );
       for( hipEvent_t ev : c->slotExt[slot] ) if( std::find( plan.waits.begin(), plan.waits.end(), ev ) == plan.waits.end() ) { plan.waits.push_back( ev ); plan.waitInfo.push_back( -2 ); plan.waitInfo.push_back( -1 ); }
       for( int k = 0; k < 3; k++ ) plan.refs.p[l * VVR_MAX_REFS + i][k] = c->slots[slot].p[k];
     }
@@ -1403,7 +1405,6 @@ VVR_API int vvr_stream_wait_slot( vvr_context* c, int slot, void* stream, int bl
     Job& j = *it->second;
     if( !j.completed && j.state == J_COMMITTED && j.done ) HIPCHK( c, hipStreamWaitEvent( (hipStream_t) stream, j.done, 0 ) );
   }
-  pruneExternalEventsLocked( c, slot );
   for( hipEvent_t ev : c->slotExt[slot] ) HIPCHK( c, hipStreamWaitEvent( (hipStream_t) stream, ev, 0 ) );
   return VVR_OK;
 }
