@@ -1395,19 +1395,20 @@ __global__ __launch_bounds__( 256 ) void k_mc_rpr( PicDev pic, RefSet refs, DevP
   const bool aff = ( it.flags & MC_ITEM_AFFINE ) != 0, geo = ( it.flags & MC_ITEM_GEO ) != 0;
   const bool altHpel = ( it.flags & MC_ITEM_HPEL ) != 0;
   const vvr_wp_params* __restrict__ wpT = wp_at( pic, it.x, it.y );
-  int mRef[2] = { aff ? cu.ref_idx[0] : it.ref[0], aff ? cu.ref_idx[1] : it.ref[1] };
+  // (two scalars and selects, not an array indexed with the list: a dynamically indexed local array - and the McItem record with it - lives in scratch memory)
+  const int mRef0 = aff ? cu.ref_idx[0] : it.ref[0], mRef1 = aff ? cu.ref_idx[1] : it.ref[1];
   bool uni;
   if( aff )
   {
-    bool biPred = mRef[0] >= 0 && mRef[1] >= 0;
+    bool biPred = mRef0 >= 0 && mRef1 >= 0;
     // xCheckIdenticalMotion (:404-436)
-    if( biPred && pic.hdr.ref_poc[0][mRef[0]] == pic.hdr.ref_poc[1][mRef[1]]
+    if( biPred && pic.hdr.ref_poc[0][mRef0] == pic.hdr.ref_poc[1][mRef1]
         && cu.mv[0][0][0] == cu.mv[1][0][0] && cu.mv[0][0][1] == cu.mv[1][0][1] && cu.mv[0][1][0] == cu.mv[1][1][0] && cu.mv[0][1][1] == cu.mv[1][1][1]
         && ( !( cu.flags & VVR_CU_AFFINE_6P ) || ( cu.mv[0][2][0] == cu.mv[1][2][0] && cu.mv[0][2][1] == cu.mv[1][2][1] ) ) && !pic.wp ) biPred = false;
     uni = !biPred;
   }
   else uni = ( it.flags & MC_ITEM_UNI ) != 0;
-  const int l0 = uni ? ( mRef[0] >= 0 ? 0 : 1 ) : 0, nl = uni ? 1 : 2;
+  const int l0 = uni ? ( mRef0 >= 0 ? 0 : 1 ) : 0, nl = uni ? 1 : 2;
   const int bcw = aff ? cu.bcw_idx : it.bcw;
   const bool wpOn = wpT && !geo && bcw == 2;
   const bool hi = !uni || wpOn;
@@ -1423,10 +1424,10 @@ __global__ __launch_bounds__( 256 ) void k_mc_rpr( PicDev pic, RefSet refs, DevP
     for( int k = 0; k < nl; k++ )
     {
       const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
-      const int ri = geo ? ( cu.geo_dir_ref[k] & 15 ) : mRef[l];
+      const int ri = geo ? ( cu.geo_dir_ref[k] & 15 ) : ( l ? mRef1 : mRef0 );
       const vvr_rpr_ref& rr = R.ref[l][ri];
       const bool bi = hi || geo;
-      int mvx = geo ? cu.geo_mv[k][0] : it.mv[l][0], mvy = geo ? cu.geo_mv[k][1] : it.mv[l][1];
+      int mvx = geo ? cu.geo_mv[k][0] : ( l ? it.mv[1][0] : it.mv[0][0] ), mvy = geo ? cu.geo_mv[k][1] : ( l ? it.mv[1][1] : it.mv[0][1] );
       if( !rr.scaled ) { const McBounds B = { 0, 0, (int) pic.hdr.width - 1, (int) pic.hdr.height - 1 }; mc_clip_mv( pic, B, it.clipX, it.clipY, mvx, mvy ); }
       for( int c = 0; c < ncomp; c++ )
       {
@@ -1449,7 +1450,7 @@ __global__ __launch_bounds__( 256 ) void k_mc_rpr( PicDev pic, RefSet refs, DevP
     for( int k = 0; k < nl; k++ )
     {
       const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
-      const int ri = geo ? ( cu.geo_dir_ref[k] & 15 ) : mRef[l];
+      const int ri = geo ? ( cu.geo_dir_ref[k] & 15 ) : ( l ? mRef1 : mRef0 );
       const vvr_rpr_ref& rr = R.ref[l][ri];
       const pel_t* __restrict__ plane = refs.p[l * VVR_MAX_REFS + ri][c];
       const bool bi = hi || geo;
@@ -1522,7 +1523,7 @@ __global__ __launch_bounds__( 256 ) void k_mc_rpr( PicDev pic, RefSet refs, DevP
       const int shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
       out = clip_pel( ( wt * p[0] + ( 8 - wt ) * p[1] + offset ) >> shift, bd );
     }
-    else if( wpOn ) out = uni ? wp_uni( wpT, l0, mRef[l0], c, p[0], bd, headroom ) : wp_bi( wpT, mRef[0], mRef[1], c, p[0], p[1], bd, headroom );
+    else if( wpOn ) out = uni ? wp_uni( wpT, l0, l0 ? mRef1 : mRef0, c, p[0], bd, headroom ) : wp_bi( wpT, mRef0, mRef1, c, p[0], p[1], bd, headroom );
     else if( !uni )
     {
       if( bcw != 2 )
