@@ -275,6 +275,9 @@ def picture_sharding_pass(a, W, H, mix, tools, plans, nslots, first, K, Wm, rank
     import vvdec_amd
     from vvdec_amd import synth, parallel
     dev = "cuda" if backend == "nccl" else "cpu"
+    if backend != "nccl" and "hoststub" not in os.path.basename(vvdec_amd._LIBPATH or ""):
+        # (the DPB of this mode lives in host memory then, and streams / events are the stand-in's: with the product library the kernels would be handed host pointers)
+        raise RuntimeError("VVR_BENCH_BACKEND=%s is the control-flow test of this pass on the stand-in runtime (tools/bench_host_side.py); with the product library use the nccl backend" % backend)
     dpb = vvdec_amd.Reconstructor.new_dpb_tensor(W, H, nslots, device=dev)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads, ext_planes=dpb.data_ptr())
     # (gloo: the control-flow test of this path on the stand-in runtime, whose streams and events are the stub library's)
