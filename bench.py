@@ -300,6 +300,28 @@ def picture_sharding_pass(a, W, H, mix, tools, plans, nslots, first, K, Wm, rank
             "what": "ONE stream over all ranks, pictures round-robin within their temporal layer; a reference picture goes from its owner to the ranks that predict from it (point-to-point over xGMI, RCCL), ordered on the device: the collective's stream waits for the picture's event, dependants wait for the event behind the receive; K pictures / max-over-ranks time"}
 
 
+def picture_pass_in_children(rank, timeout):
+    """N > 1: every rank starts this script once more (same arguments, VVR_BENCH_CHILD=picture) and the children - a process group of their own on the next
+    port - run picture_sharding_pass; rank 0's child prints the result.  The pass has never run on more than one device (no such node was at hand): a fault
+    in it must not take the segment-mode result of the line with it."""
+    import subprocess
+    entry = os.path.abspath(getattr(sys.modules.get("__main__"), "__file__", __file__))
+    env = dict(os.environ, VVR_BENCH_CHILD="picture", MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23), TORCHELASTIC_USE_AGENT_STORE="False")
+    try:
+        r = subprocess.run([sys.executable, entry] + sys.argv[1:], env=env, capture_output=True, text=True, timeout=max(1, timeout))
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within %d s" % timeout, "timeout": True}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if rank != 0:
+        return {}
+    if r.returncode == 0 and lines:
+        try:
+            return json.loads(lines[-1])
+        except ValueError:
+            pass
+    return {"error": "the picture-sharding processes ended with %d: %s" % (r.returncode, (r.stderr or "")[-300:].replace("\n", " | "))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -360,6 +382,18 @@ def main():
     plans, nslots, orders = stream_plan(a.config, a.gop, intra_period, a.irap_lookahead, a.slots, K, Wm)
     order, first = orders[a.irap_lookahead]           # submission order of the headline figure (indices into plans) and its first timed picture
     n_irap = sum(1 for i in order[first:first + K] if plans[i].slice_type == abi.SLICE_I)
+    if os.environ.get("VVR_BENCH_CHILD") == "picture" and world > 1:
+        # the picture-sharding pass in processes of its own (one child per rank, a process group of their own: see picture_pass_in_children): whatever happens to
+        # it - an exception, a collective that never completes, a fault on the device - the parents live to print the line with the segment-mode result
+        try:
+            res = picture_sharding_pass(a, W, H, mix, tools, [plans[i] for i in order], nslots, first, K, Wm, rank, world, local_rank, backend)
+        except Exception as e:            # noqa: BLE001
+            res = {"error": repr(e)[:300]}
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     seed = parallel.segment_seed(1234, rank)          # every rank reconstructs its own closed-GOP segment (no data-path collective)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads, ring_entries=a.ring, stop_after=a.stop_after)
     # the records are written where a parser integrated with the back-end would write them: host memory the device reads directly (vvr_host_alloc)
@@ -605,11 +639,11 @@ def main():
                 time.sleep(3)
             os._exit(3)          # (ranks may hang in a collective: the process ends here, NOT with success - the line carries the segment-mode result and "timeout": true)
 
-        timer = threading.Timer(a.picture_sharding_timeout, give_up)
+        timer = threading.Timer(a.picture_sharding_timeout + 30, give_up)     # (the children are given up after the timeout by picture_pass_in_children; this is for a parent that hangs)
         timer.daemon = True
         timer.start()
         try:
-            pic_mode = picture_sharding_pass(a, W, H, mix, tools, [plans[i] for i in order], nslots, first, K, Wm, rank, world, local_rank, backend)
+            pic_mode = picture_pass_in_children(rank, a.picture_sharding_timeout)
         except Exception as e:            # noqa: BLE001 - the segment-mode line must survive
             pic_mode = {"error": repr(e)[:300]}
         with line_lock:
@@ -618,6 +652,8 @@ def main():
                 return
             if rank == 0:
                 out["config"]["picture_sharding"] = pic_mode
+                if pic_mode.get("timeout"):
+                    out["timeout"] = True
                 # `value` stays the segment mode (frames sharded over the GPUs by closed-GOP segment, no inter-GPU reference, no data-path collective:
                 # weak scaling, what north_star's "near-linear" is claimed for).  The picture-level split of ONE stream is reported beside it with the
                 # ceiling its dependency graph allows: a hierarchical-B window is a chain of temporal layers behind its IRAP.
@@ -639,6 +675,8 @@ def main():
                 print(json.dumps(out), flush=True)
         dist.barrier()
         dist.destroy_process_group()
+        if pic_mode.get("timeout"):
+            sys.exit(3)          # (a pass that was given up is not a success: the line carries the segment-mode result and "timeout": true)
         return
     if world > 1:
         dist.barrier()
