@@ -971,6 +971,9 @@ class PictureWriter:
         # intra block copy: the block vector (whole luma samples) of the IBC CU that covers a cell, the history of block vectors of the CTU row
         # (MotionHist::motionLutIbc, emptied at the first CTU of a row: DecCu::TaskDeriveCtuMotionInfo :66-74)
         self.ibc_bv, self.ibc_lut = {}, []
+        # dual tree: what CU::checkCCLMAllowed (UnitTools.cpp:3439-3492) asks about - the splits from the tree's 64x64 node down to the CU being written, and per luma cell
+        # the depth, quad-tree depth and ISP mode of the luma CU that covers it
+        self.path, self.luma_info, self.cur_xy, self.last_isp = [], {}, (0, 0), 0
         assert not (c.ibc and self.P), "this writer's IBC knows one slice, one tile"
 
     # is the 4x4 cell at luma position (nx, ny) a neighbour the block at (x, y) may look at?  (same slice and tile: CodingStructure::getCURestricted)
@@ -1136,6 +1139,7 @@ class PictureWriter:
         last = "qt" if qt_depth else "ctu"
         for tree in ("luma", "chroma"):
             self.tree = tree
+            self.path = []
             self.coding_tree(x, y, size, size, qt_depth, 0, last, idx)
         self.tree = "single"
 
@@ -1194,13 +1198,20 @@ class PictureWriter:
                 parts = [(x, y, w, h >> 2), (x, y + (h >> 2), w, h >> 1), (x, y + 3 * (h >> 2), w, h >> 2)]
             else:
                 parts = [(x, y, w >> 2, h), (x + (w >> 2), y, w >> 1, h), (x + 3 * (w >> 2), y, w >> 2, h)]
+            self.path.append(mode)
             for i, (px, py, pw, ph) in enumerate(parts):
                 if mode == "qt":
                     self.coding_tree(px, py, pw, ph, qt_depth + 1, 0, "qt", i)
                 else:
                     self.coding_tree(px, py, pw, ph, qt_depth, mt_depth + 1, mode, i)
+            self.path.pop()
             return
+        self.cur_xy, self.last_isp = (x, y), 0
         f = self.coding_unit(x, y, w, h)
+        if self.tree != "chroma":
+            for yy in range(y >> 2, (y + h) >> 2):
+                for xx in range(x >> 2, (x + w) >> 2):
+                    self.luma_info[(xx, yy)] = (qt_depth + mt_depth, qt_depth, self.last_isp)
         for yy in range(y >> 2, (y + h) >> 2):
             for xx in range(x >> 2, (x + w) >> 2):
                 m_w[yy][xx] = w
@@ -1333,6 +1344,7 @@ class PictureWriter:
             return 2
         self.bdpcm_c = 0
         info = self.intra_modes(x, y, w, h)
+        self.last_isp = info["isp"]
         self.cu = dict(intra=True, w=w, h=h, isp=info["isp"], mip=info["mip"], viol=False, lfnst_last=False, mts_last=False, sbt=None, bdpcm=info["bdpcm"], bdpcm_c=self.bdpcm_c)
         self.transform_tree(w, h, intra=True, root=True)
         self.lfnst_and_mts()
@@ -1678,7 +1690,22 @@ class PictureWriter:
                 cab.bin(bd - 1, "BDPCMMode", 3)                                # intra_bdpcm_chroma_dir_flag
                 self.bdpcm_c = bd
                 return
-        if c.cclm and self.tree == "single":                                   # (dual tree: whether CCLM is allowed depends on how the luma tree split its 64x64 - not written here)
+        cclm_ok = self.tree == "single"
+        if c.cclm and self.tree == "chroma":
+            # CU::checkCCLMAllowed: CTUs of 32 always; else the chroma tree's 64x64 node must be split by a quad split, not at all, or horizontally in two with the
+            # halves split vertically in two or not at all - and the luma tree's 64x64 node must not start with a binary / ternary split nor be one CU with ISP
+            if c.log2_ctu <= 5:
+                cclm_ok = True
+            else:
+                s1 = self.path[0] if self.path else None
+                s2 = self.path[1] if len(self.path) > 1 else None
+                cclm_ok = s1 == "qt" or s1 is None or (s1 == "bh" and s2 in ("bv", None))
+                if cclm_ok:
+                    d64 = 1 if c.log2_ctu == 7 else 0
+                    d, q, isp = self.luma_info[(self.cur_xy[0] >> 2, self.cur_xy[1] >> 2)]
+                    if (d > d64 and q == d64) or (d == d64 and isp):
+                        cclm_ok = False
+        if c.cclm and cclm_ok:
             lm = rng.random() < 0.3
             cab.bin(1 if lm else 0, "CclmModeFlag", 0)                         # cclm_mode_flag
             if lm:
@@ -2443,6 +2470,10 @@ FIXTURES = [
                                            jccr=True, dep_quant=True, alf=True, ccalf=True, ts=True, bdpcm=True, ibc=True, p_ibc=0.4), 2, 202),
     ("mini_ibc_dual_tree_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, dual_tree=True, mrl=True, isp=True, mip=True, lfnst=True, mts=True,
                                                ibc=True, p_ibc=0.5), 2, 203),
+    # CCLM in the chroma tree of dual-tree pictures (round 5: the writer follows CU::checkCCLMAllowed), with IBC in the luma tree and the filters
+    ("mini_dual_tree_cclm_ibc_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=28, mtt_depth=2, dual_tree=True, cclm=True, mrl=True, isp=True, mip=True, lfnst=True,
+                                                    mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True, alf=True, ccalf=True, ibc=True, p_ibc=0.3), 2, 205),
+    ("mini_dual_tree_cclm_ctu64_256x128", dict(width=256, height=128, log2_ctu=6, qp=30, dual_tree=True, cclm=True, isp=True, mtt_depth=1), 2, 206),
     ("mini_ibc_inter_tools_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, inter=True, sbtmvp=True, mmvd=True, affine=True, ciip=True, gpm=True, amvr=True,
                                                  bcw=True, smvd=True, sbt=True, sao=True, lmcs=True, jccr=True, dep_quant=True, alf=True, p_intra=0.2, ibc=True, p_ibc=0.4), 9, 204),
 ]
