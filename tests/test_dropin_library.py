@@ -275,3 +275,22 @@ def test_few_slots_are_enough():
     finally:
         dd.BACKEND = keep
         os.environ.clear(); os.environ.update(env_keep)
+
+
+def test_every_stream_passes_the_products_record_checks_on_the_stand_in_runtime():
+    """every stream of tests/bitstreams decoded by the reference's application on the drop-in library with the PRODUCT's host code behind it (tests/hoststub: the
+    stand-in HIP runtime, no kernel runs, the output is not looked at): the record checks and the work-list builder of vvr_prepare.cpp accept every picture the real
+    parser produces.  The CPU-oracle run above cannot see this - the oracle back-end does not run those checks - and the GPU suite saw it late: the randomised GPU
+    leg of round 5 found IBC CUs of 64x64 refused in a sequence whose largest transform is 32 (four transform units), which no CPU test would have caught"""
+    dd, d = _conformance_streams()
+    if d is None or not os.path.exists(dd.APP_DROPIN):
+        pytest.skip("no bitstreams or oracle/_ref/vvdecapp_dropin not built (needs /root/reference)")
+    bad = []
+    for b in dd.find_streams(d):
+        if "mini_4k_" in b and not os.environ.get("VVDEC_BIG_STREAMS"):
+            continue
+        r, _ = dd.run_app(dd.APP_DROPIN, ["-b", b, "-t", "2", "-v", "3"], preload=_stub_path())
+        out = r.stdout + r.stderr
+        if r.returncode != 0 or re.search(r"vvdec_amd|exception|ERROR", out):
+            bad.append((os.path.basename(b), out[-400:]))
+    assert not bad, bad

@@ -21,6 +21,7 @@ def main():
     seed0, seconds = int(sys.argv[1]), float(sys.argv[2])
     rnd = random.Random(seed0)
     dd.BACKEND = TD._oracle_backend()
+    stub = TD._stub_path()           # the PRODUCT's host code on the stand-in HIP runtime: its record checks and work-list builder see every picture too (round 5, finding 13)
     tables, renorm = mv.load_context_tables()
     t_end = time.time() + seconds
     streams = refused = differ = 0
@@ -58,7 +59,12 @@ def main():
             r, _ = dd.run_app(dd.APP_DROPIN, ["-b", bit, "-t", "4", "-v", "3", "-md5", md5], preload=dd.BACKEND, timeout=60)
             streams += 1
             out = r.stdout + r.stderr
-            if r.returncode != 0 or re.search(r"WARNING:|runtime error|MD5 mismatch|vvdec_amd:", out):
+            r2, _ = dd.run_app(dd.APP_DROPIN, ["-b", bit, "-t", "2", "-v", "3"], preload=stub, timeout=60)
+            out2 = r2.stdout + r2.stderr
+            if r2.returncode != 0 or re.search(r"vvdec_amd|exception", out2):
+                out += " || the product's host code: " + out2[-300:]
+                r = r2
+            if r.returncode != 0 or re.search(r"WARNING:|runtime error|MD5 mismatch|vvdec_amd:|the product's host code", out):
                 differ += 1
                 keep = os.path.join(tmp, "differ_%s_seed%d.bit" % (name, seed))
                 os.replace(bit, keep)

@@ -2470,6 +2470,9 @@ FIXTURES = [
                                            jccr=True, dep_quant=True, alf=True, ccalf=True, ts=True, bdpcm=True, ibc=True, p_ibc=0.4), 2, 202),
     ("mini_ibc_dual_tree_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=30, mtt_depth=2, dual_tree=True, mrl=True, isp=True, mip=True, lfnst=True, mts=True,
                                                ibc=True, p_ibc=0.5), 2, 203),
+    # IBC CUs of 64x64 / 64x32 in a sequence whose largest transform is 32: four / two transform units per IBC CU (round 5, finding 13 of DESIGN.md section 3: the randomised
+    # GPU leg found such CUs refused by the back-end's record checks)
+    ("mini_ibc_tb32_8bit_ctu64_192x128", dict(width=192, height=128, log2_ctu=6, qp=35, bit_depth=8, max_tb64=False, p_cbf=0.8, p_cbf_chroma=0.6, p_split=0.3, ibc=True, p_ibc=0.6), 3, 207),
     # CCLM in the chroma tree of dual-tree pictures (round 5: the writer follows CU::checkCCLMAllowed), with IBC in the luma tree and the filters
     ("mini_dual_tree_cclm_ibc_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=28, mtt_depth=2, dual_tree=True, cclm=True, mrl=True, isp=True, mip=True, lfnst=True,
                                                     mts=True, sao=True, lmcs=True, jccr=True, dep_quant=True, alf=True, ccalf=True, ibc=True, p_ibc=0.3), 2, 205),

@@ -555,17 +555,22 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
     else if( cu.pred_mode == VVR_PRED_IBC )
     {
       // intra block copy (InterPrediction::xIntraBlockCopy, InterPrediction.cpp:1995): integer block vector in mv[0][0], luma at most 64x64
-      // (IBC_MAX_CU_SIZE), one TU, no intra / inter tools; sizes as for intra CUs.  That the reference block precedes the CU in decoding order
-      // is checked where the work lists are built.
+      // (IBC_MAX_CU_SIZE), no intra / inter tools; sizes as for intra CUs.  One transform unit - or, in a sequence whose largest transform is 32, the four (two) of a
+      // CU that is 64 wide and / or high (round 5, finding 13: such a CU was refused; the stage copies and reconstructs transform unit by transform unit anyway).
+      // That the reference block precedes the CU in decoding order is checked where the work lists are built.
       if( !( h.tool_flags & VVR_TOOL_IBC ) ) FAIL( VVR_ERR_PARAMETER, "IBC CU in a picture without VVR_TOOL_IBC" );
       const bool lumaOnly = cu.tree == VVR_TREE_LUMA || !h.chroma_format;      // (4:0:0: no CU carries chroma)
       const int minW = lumaOnly ? 4 : 8;
-      if( cu.tree == VVR_TREE_CHROMA || cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( !lumaOnly && cu.w * cu.h < 64 ) || cu.num_tu != 1 )
-        FAIL( VVR_ERR_PARAMETER, "IBC CU: chroma tree, size out of range or more than one TU" );
+      if( cu.tree == VVR_TREE_CHROMA || cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( !lumaOnly && cu.w * cu.h < 64 ) || cu.num_tu < 1 || cu.num_tu > 4 )
+        FAIL( VVR_ERR_PARAMETER, "IBC CU: chroma tree, size out of range or a bad number of TUs" );
+      if( cu.num_tu > 1 )
+        for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
+          if( p->tu[t].w > 32 || p->tu[t].h > 32 || (uint32_t) p->tu[t].w * p->tu[t].h * cu.num_tu != (uint32_t) cu.w * cu.h ) FAIL( VVR_ERR_PARAMETER, "IBC CU: several TUs that are not the split at the largest transform size" );
       if( ( cu.mv[0][0][0] | cu.mv[0][0][1] ) & 15 ) FAIL( VVR_ERR_PARAMETER, "IBC CU: fractional block vector" );
       if( cu.isp_mode || cu.bdpcm[0] || cu.bdpcm[1] || cu.lfnst_idx || cu.sbt_info || ( cu.flags & ( VVR_CU_MIP | VVR_CU_CIIP | VVR_CU_AFFINE | VVR_CU_GEO | VVR_CU_SBTMVP ) ) )
         FAIL( VVR_ERR_PARAMETER, "IBC CU combined with an intra / inter tool" );
-      if( cu.tree == VVR_TREE_LUMA && h.chroma_format && p->tu[cu.first_tu].comp_mask != 1 ) FAIL( VVR_ERR_PARAMETER, "separate-tree CU: TU component mask" );
+      if( cu.tree == VVR_TREE_LUMA && h.chroma_format )
+        for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ ) if( p->tu[t].comp_mask != 1 ) FAIL( VVR_ERR_PARAMETER, "separate-tree CU: TU component mask" );
       const int bvx = cu.mv[0][0][0] >> 4, bvy = cu.mv[0][0][1] >> 4, ctuS = 1 << h.log2_ctu, rowTop = cu.y & ~( ctuS - 1 );
       const int bufW = 256 * 128 / ctuS;                              // width of the IBC virtual buffer (Rom.h:210, CodingStructure.cpp:543)
       bool ok = cu.x + bvx >= 0 && cu.x + bvx + cu.w <= h.width && cu.y + bvy >= rowTop && cu.y + bvy + cu.h <= std::min<int>( h.height, rowTop + ctuS )
