@@ -150,6 +150,10 @@ def test_gpu_fuzz_streams(tmp_path):
                 kw[k] = not kw.get(k, False)
             if kw.get("ccalf") and not kw.get("alf"):
                 kw["alf"] = True
+            if rnd.random() < 0.15:
+                kw["max_tb64"] = not kw.get("max_tb64", True)      # (the largest transform 32 instead of 64 or back: CUs of 64 then come in several transform units - finding 13)
+            if not kw.get("max_tb64", True):
+                kw["ciip"] = False                                 # (a CIIP CU of several transform units is refused by the back-end: DESIGN.md section 8)
             kw["qp"] = rnd.choice([22, 27, 32, 37, 42]); kw["p_split"] = rnd.choice([0.3, 0.6, 0.8]); kw["p_cbf"] = rnd.choice([0.2, 0.5, 0.9]); kw["p_cbf_chroma"] = rnd.choice([0.1, 0.4, 0.8])
             if "mtt_depth" not in kw or rnd.random() < 0.3:
                 kw["mtt_depth"] = rnd.choice([0, 1, 2])
