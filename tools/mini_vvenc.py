@@ -19,6 +19,12 @@ Syntax written (everything else is switched off in the parameter sets):
   * CABAC: the arithmetic encoder of the standard (9.3.4) with the two-rate probability model of Contexts.h; initial values of the context sets are
     read from the reference's table (CommonLib/Contexts.cpp) when this tool runs.
 
+That was the first version.  What has been added since is listed where it is used, in the comments of FIXTURES below: inter slices (skip / merge / AMVP, MMVD, affine, CIIP, GPM,
+SbTMVP, AMVR, BCW, SMVD, SBT, weighted prediction), binary / ternary splits, dual trees, the intra tools with syntax of their own (MRL, ISP, MIP, CCLM - also in the chroma tree of
+dual-tree pictures -, BDPCM), LFNST / MTS, transform skip and the regular residual beyond the first coefficient group, dependent quantisation, joint Cb-Cr, delta QPs and chroma QP
+offsets, SAO / ALF / CC-ALF / LMCS / scaling-list APSs, slices / tiles / sub-pictures, virtual boundaries, LADF, reference picture resampling, wrap-around, 4:0:0, and - round 5 -
+intra block copy, the one tool whose syntax values cannot be random (coding_unit_ibc).
+
   python tools/mini_vvenc.py --out tests/bitstreams [--seed N]     writes the fixture set (needs /root/reference for the context tables and
                                                                     oracle/_ref/vvdecapp_ref for the MD5s)
 """
