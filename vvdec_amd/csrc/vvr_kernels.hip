@@ -46,6 +46,7 @@ __device__ uint8_t d_db_beta_table[64];
 __device__ int16_t d_alf_fixed_coeff[64][13];
 __device__ uint8_t d_alf_class_to_filter[16][25];
 
+static int vvr_upload_mc_taps();
 #define UPLOAD( name ) do { hipError_t e = hipMemcpyToSymbol( HIP_SYMBOL( d_##name ), tbl::vvc_##name, sizeof( tbl::vvc_##name ) ); if( e != hipSuccess ) return (int) e; } while( 0 )
 int vvr_upload_tables()
 {
@@ -58,7 +59,7 @@ int vvr_upload_tables()
   UPLOAD( mip_matrix_4x4 ); UPLOAD( mip_matrix_8x8 ); UPLOAD( mip_matrix_16x16 );
   UPLOAD( luma_filter_rpr1 ); UPLOAD( luma_filter_rpr2 ); UPLOAD( affine_luma_filter_rpr1 ); UPLOAD( affine_luma_filter_rpr2 ); UPLOAD( chroma_filter_rpr1 ); UPLOAD( chroma_filter_rpr2 );
   UPLOAD( geo_params ); UPLOAD( geo_weight_offset ); UPLOAD( geo_weights ); UPLOAD( geo_angle2mask ); UPLOAD( geo_angle2mirror );
-  return 0;
+  return vvr_upload_mc_taps();
 }
 
 // =====================================================================================================================
@@ -193,16 +194,6 @@ __device__ __forceinline__ int mc_ref_col( int x, int lo, int hi, int pw, int of
 {
   if( off ) { if( x < 0 ) return -x <= off ? x + off : 0; if( x >= pw ) return x - pw < off ? x - off : pw - 1; return x; }
   return clip3( lo, hi, x );
-}
-
-// filter taps of one segment (InterpolationFilter.cpp:1078-1085 / 669-676: luma 4x4 blocks use the 6-tap table; :105 alternative half-pel filter)
-__device__ __forceinline__ void mc_taps( const McSeg& g, int c, bool altHpel, int16_t* coefH, int16_t* coefV )
-{
-  const int ntaps = c ? 4 : 8;
-  const bool f4 = g.w == 4 && g.h == 4;
-  const int16_t* ch = c ? d_chroma_filter[g.xFrac] : ( g.xFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[g.xFrac] : d_luma_filter[g.xFrac];
-  const int16_t* cv = c ? d_chroma_filter[g.yFrac] : ( g.yFrac == 8 && altHpel ) ? d_luma_alt_hpel : f4 ? d_luma_filter_4x4[g.yFrac] : d_luma_filter[g.yFrac];
-  for( int t = 0; t < ntaps; t++ ) { coefH[t] = ch[t]; coefV[t] = cv[t]; }
 }
 
 // window of one segment into LDS: clamped coordinates = border-extended reference (Picture::extendPicBorder)
@@ -383,16 +374,27 @@ __device__ __forceinline__ void mc_bdof_luma( BdofShared& bs, const pel_t* win0,
   }
 }
 
-// NT threads per tile.  With NT = 64 a tile is one wavefront: 32 tiles resident per CU, barriers are free, and the
-// single exposure to global-memory latency (phase A) is hidden by the other resident tiles.
+// NT threads per tile.  With NT = 64 a tile is one wavefront: barriers are free, and the single exposure to global-memory
+// latency (phase A) is hidden by the other resident tiles.
 // ---------------------------------------------------------------------------------------------------------------------
-// Register-blocked separable interpolation used by k_mc.  Every segment goes through the same two stages — horizontal filter to
-// 14-bit intermediates, vertical filter to the result — with the identity filter (64 at the centre tap) where the MV has no
-// fractional part in that direction.  That is bit-exact with the reference's four code paths (copy / horizontal only /
-// vertical only / separable, InterpolationFilter.cpp:556-651): the intermediate rounding of a pass with the identity filter
-// is exact (64 * s = s << 6), see DESIGN.md §5.
-// One work item = 8 neighbouring outputs of one row (stage 1) or one column (stage 2): 16 input samples are read with two
-// 16-byte LDS loads and each output costs four v_dot2_i32_i16 (two for the 4-tap chroma filter).
+// Register-blocked separable interpolation used by k_mc and k_mc_dmvr (round 6: the instruction diet).  Every segment goes through the same
+// two stages - horizontal filter to 14-bit intermediates, vertical filter to the result - with the identity filter (64 at the centre
+// tap) where the MV has no fractional part in that direction.  That is bit-exact with the reference's four code paths (copy /
+// horizontal only / vertical only / separable, InterpolationFilter.cpp:556-651): the intermediate rounding of a pass with the identity
+// filter is exact (64 * s = s << 6), see DESIGN.md §5.
+//   * window rows lie row-major in LDS (two samples per dword); a tile whose windows lie inside the picture loads them as DWORDS, 16 lanes
+//     per row, and realigns an odd start with one DPP move + v_alignbit (mc3_load_*): a quarter of the load / store instructions of the
+//     per-sample loader, which stays for windows that need clamping, wrap-around or the padded copies of DMVR (mc_load_window);
+//   * a stage-1 work item filters 8 columns of TWO window rows (four 16-byte LDS reads, 64 v_dot2_i32_i16) and writes the eight
+//     results as eight dwords { row 2r, row 2r + 1 } into the column-major intermediate [column][row pair]: half the LDS stores of
+//     a row per item, no per-column predicate, the rounding offset folded into the accumulator's start value;
+//   * a stage-2 work item filters 8 rows of one column for both lists from two 16-byte reads per list; chroma columns run through the
+//     SAME eight-tap code (their taps padded with zeros) so luma and chroma lanes of the wavefront do not diverge; the way the two
+//     predictions are combined (average / BCW / GPM / weighted prediction / BDOF input) is decided once per tile, not per sample.
+// The taps come from ONE table of packed pairs (d_mcTaps) indexed per lane: a lane of list 1 reads list 1's row.
+// Range: the 14-bit intermediates and the second-stage sums >> 6 stay inside int16 for samples of up to 10 bits (positive taps sum to at
+// most 88, negative ones to -24: |stage 1| <= 14330, |stage 2 >> 6| <= 25072), so the reference's stores to int16 never wrap and no
+// sign-extension is spent on them.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int mc_dot2( uint32_t a, uint32_t b, int c )
 {
@@ -400,30 +402,52 @@ __device__ __forceinline__ int mc_dot2( uint32_t a, uint32_t b, int c )
   return __builtin_amdgcn_sdot2( __builtin_bit_cast( s2v, a ), __builtin_bit_cast( s2v, b ), c, false );
 }
 
-// 8 outputs out[j] = sum_t s[j + t] * c[t], s = the 16 samples in D (two per dword), NTAPS = 8 or 4
+// rows of d_mcTaps: luma (frac 0..15) regular / for 4x4 blocks / with the alternative half-sample filter at frac 8 / both; chroma (frac 0..31), taps 4..7 zero
+#define MCT_REG    0
+#define MCT_4X4    16
+#define MCT_ALT    32
+#define MCT_CHROMA 64
+__device__ uint4 d_mcTaps[96];
+static int vvr_upload_mc_taps()
+{
+  uint32_t t[96][4];
+  auto pack = []( const int16_t* c, int n, uint32_t* o ) { for( int i = 0; i < 4; i++ ) o[i] = 2 * i < n ? (uint32_t) (uint16_t) c[2 * i] | (uint32_t) (uint16_t) c[2 * i + 1] << 16 : 0u; };
+  for( int f = 0; f < 16; f++ )
+  {
+    pack( tbl::vvc_luma_filter[f], 8, t[MCT_REG + f] ); pack( tbl::vvc_luma_filter_4x4[f], 8, t[MCT_4X4 + f] );
+    pack( f == 8 ? tbl::vvc_luma_alt_hpel : tbl::vvc_luma_filter[f], 8, t[MCT_ALT + f] ); pack( f == 8 ? tbl::vvc_luma_alt_hpel : tbl::vvc_luma_filter_4x4[f], 8, t[MCT_ALT + MCT_4X4 + f] );
+  }
+  for( int f = 0; f < 32; f++ ) pack( tbl::vvc_chroma_filter[f], 4, t[MCT_CHROMA + f] );
+  return (int) hipMemcpyToSymbol( HIP_SYMBOL( d_mcTaps ), t, sizeof( t ) );
+}
+// (InterpolationFilter.cpp:1078-1085 / 669-676: luma 4x4 blocks use the 6-tap table; :105 alternative half-pel filter - it wins at frac 8)
+__device__ __forceinline__ int mc_tap_row( int c, int frac, bool f4, bool altHpel ) { return c ? MCT_CHROMA + frac : ( altHpel ? MCT_ALT : 0 ) + ( f4 ? MCT_4X4 : 0 ) + frac; }
+
+// 8 outputs out[j] = init + sum_t s[j + t] * c[t], s = the 16 samples in lo / hi (two per dword), NTAPS = 8 or 4
 template<int NTAPS>
-__device__ __forceinline__ void mc_fir8( const uint4 lo, const uint4 hi, const uint32_t* __restrict__ C /* NTAPS / 2 packed pairs */, int ( &out )[8] )
+__device__ __forceinline__ void mc_fir8( const uint4 lo, const uint4 hi, const uint4 Cv, int init, int ( &out )[8] )
 {
   const uint32_t D[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+  const uint32_t C[4] = { Cv.x, Cv.y, Cv.z, Cv.w };
   uint32_t S[7];
 #pragma unroll
   for( int i = 0; i < 7; i++ ) S[i] = __builtin_amdgcn_alignbit( D[i + 1], D[i], 16 );
 #pragma unroll
-  for( int m = 0; m < 4; m++ )
-  {
-    int e = 0, o = 0;
+  for( int j = 0; j < 8; j++ ) out[j] = init;
 #pragma unroll
-    for( int t = 0; t < NTAPS / 2; t++ ) { e = mc_dot2( D[m + t], C[t], e ); o = mc_dot2( S[m + t], C[t], o ); }
-    out[2 * m] = e; out[2 * m + 1] = o;
+  for( int t = 0; t < NTAPS / 2; t++ )
+  {
+#pragma unroll
+    for( int m = 0; m < 4; m++ ) { out[2 * m] = mc_dot2( D[m + t], C[t], out[2 * m] ); out[2 * m + 1] = mc_dot2( S[m + t], C[t], out[2 * m + 1] ); }
   }
 }
 
 #define MC2_WST_L 24        // luma window: 23 x 23 samples, row stride 24 (48 bytes: every row and every 8-sample group is 16-byte aligned)
 #define MC2_WST_C 16        // chroma window: 11 x 11 samples, row stride 16
-#define MC2_TST_L 24        // transposed intermediates: per column 23 values (+1 pad)
-#define MC2_TST_C 16
+#define MC3_TPL   12        // intermediates: dwords per luma column (24 rows as 12 pairs; 48 bytes: 16-byte reads at rows 0 and 8)
+#define MC3_TPC   8         // dwords per chroma column (12 rows as 6 pairs, padded to 8)
+#define MC3_TBC   72        // dwords per chroma (list, component) block: 8 columns + 8 dwords that spread the blocks over the banks
 
-// LDS working set of the two filter stages (one tile = one wavefront)
 // Explicit weighted prediction (WeightPrediction::getWpScaling / addWeightUni / addWeightBi, WeightPrediction.cpp:66-157,238-338,164-236):
 // final stage of plain, SbTMVP, CIIP and affine predictions of a picture with VVR_TOOL_WP (unless BCW weights or GPM are in use);
 // p, p0, p1 are the 14-bit intermediate predictions, headroom = max( 2, 14 - bitDepth )
@@ -441,142 +465,229 @@ __device__ __forceinline__ int wp_bi( const vvr_wp_params* __restrict__ wp, int 
   return clip_pel( ( e0.weight * ( p0 + IF_INTERNAL_OFFS ) + e1.weight * ( p1 + IF_INTERNAL_OFFS ) + ( ( 1 << shift ) >> 1 ) + offset * ( 1 << ( shift - 1 ) ) ) >> shift, bd );
 }
 
+// LDS working set of the two filter stages (one tile)
 struct Mc2Shared {
-  __attribute__( ( aligned( 16 ) ) ) pel_t winL[2][23 * MC2_WST_L];
-  __attribute__( ( aligned( 16 ) ) ) pel_t winC[2][2][11 * MC2_WST_C];
-  __attribute__( ( aligned( 16 ) ) ) pel_t tmpL[2][16 * MC2_TST_L];       // [column][row]
-  __attribute__( ( aligned( 16 ) ) ) pel_t tmpC[2][2][8 * MC2_TST_C];
-  __attribute__( ( aligned( 16 ) ) ) int16_t coefH[2][3][8], coefV[2][3][8];
-  McSeg seg[2][3];
+  __attribute__( ( aligned( 16 ) ) ) pel_t winL[2][24 * MC2_WST_L];          // (row 23 is scratch: the second row of the last row pair)
+  __attribute__( ( aligned( 16 ) ) ) pel_t winC[2][2][12 * MC2_WST_C];
+  __attribute__( ( aligned( 16 ) ) ) uint32_t tmpL[2][16 * MC3_TPL];         // [column][row pair]
+  __attribute__( ( aligned( 16 ) ) ) uint32_t tmpC[4][MC3_TBC];              // [list * 2 + Cb / Cr][column][row pair]
+  McSeg seg[2][3];                                                           // (only tiles that take the per-sample loader)
   const pel_t* refp[2][3];
 };
+// what the stages need to know about the filters of a tile: rows of d_mcTaps per list, [luma, chroma]
+struct McTapRows { int h[2][2], v[2][2]; };
+
+// ---- windows of a tile that lies inside the picture: dword loads, 16 (luma) / 8 (chroma) lanes per window row --------------------
+__device__ __forceinline__ uint32_t mc_dpp_next_lane( uint32_t v ) { return (uint32_t) __builtin_amdgcn_update_dpp( 0, (int) v, 0x101 /* row_shl:1 */, 0xf, 0xf, true ); }
 
 template<int NT>
-__device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int tw, int th, int headroom, int tid )
+__device__ __forceinline__ void mc3_load_luma( pel_t* __restrict__ win, const pel_t* __restrict__ ref, int stride, int x0, int y0, int ww, int wh, int tid )
 {
-  struct { int w, h; } it = { tw, th };
-  auto& winL = m.winL; auto& winC = m.winC; auto& tmpL = m.tmpL; auto& tmpC = m.tmpC; auto& coefH = m.coefH;
-  // stage 1: horizontal filter of every window row, 8 outputs per work item, written transposed ([column][row])
+  const int q = tid & 15, r0 = tid >> 4;
+  const int odd = x0 & 1, sh = odd << 4;
+  const int ndw = ( ww + 1 + odd ) >> 1;              // dwords read per row: samples x0 - odd .. x0 - odd + 2 ndw - 1
+  const int nst = ( ww + 1 ) >> 1;                    // dwords kept per row
+  const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>( ref + (size_t) y0 * stride + ( x0 - odd ) ) + q;
+  uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( win ) + q;
+  const int sd = stride >> 1;
+  constexpr int RP = NT / 16;                         // rows per pass
+  const int np = ( wh + RP - 1 ) / RP;                // (uniform)
+  uint32_t v[6]; int rr[6];
+#pragma unroll
+  for( int i = 0; i < 6; i++ )
   {
-    const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
-    const int wL = it.w, hL = it.h, wC = it.w >> 1, hC = it.h >> 1;
-    const int rowsL = hL + 7, grpL = ( wL + 7 ) >> 3, rowsC = hC + 3, pairsC = ( rowsC + 1 ) >> 1;
-    // (a chroma work item filters two rows - as many multiply-adds as the eight luma outputs of an item: the 136 items of a bi-predicted 16x16
-    // tile would need a third, nearly empty pass of the wavefront)
-    const int perList = rowsL * grpL + ( ncomp == 3 ? 2 * pairsC : 0 );
+    rr[i] = min( r0 + i * RP, wh - 1 );               // (the tail repeats the last row: same value to the same place)
+    v[i] = 0;
+    if( i * RP < wh && q < ndw ) v[i] = base[rr[i] * sd];
+  }
+#pragma unroll
+  for( int i = 0; i < 6; i++ )
+  {
+    if( i * RP < wh )
+    {
+      const uint32_t w = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v[i] ), v[i], sh );
+      if( q < nst ) wdw[rr[i] * ( MC2_WST_L / 2 )] = w;
+    }
+  }
+}
+// Cb and Cr windows of a list (same geometry): 8 lanes per row, the rows of Cb, then those of Cr
+template<int NT>
+__device__ __forceinline__ void mc3_load_chroma( pel_t* __restrict__ winCb /* Cr follows: 12 rows further */, const pel_t* __restrict__ refCb, const pel_t* __restrict__ refCr, int stride, int x0, int y0, int ww, int wh, int tid )
+{
+  const int q = tid & 7, r0 = tid >> 3;
+  const int odd = x0 & 1, sh = odd << 4;
+  const int ndw = ( ww + 1 + odd ) >> 1, nst = ( ww + 1 ) >> 1;
+  const size_t off = (size_t) y0 * stride + ( x0 - odd );
+  const int sd = stride >> 1;
+  constexpr int RP = NT / 8;
+  uint32_t v[3]; int wo[3];
+#pragma unroll
+  for( int i = 0; i < 3; i++ )
+  {
+    const int r2 = min( r0 + i * RP, 2 * wh - 1 ), cc = r2 >= wh, r = r2 - ( cc ? wh : 0 );
+    const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>( ( cc ? refCr : refCb ) + off ) + q;
+    wo[i] = ( cc ? 12 * ( MC2_WST_C / 2 ) : 0 ) + r * ( MC2_WST_C / 2 );
+    v[i] = 0;
+    if( i * RP < 2 * wh && q < ndw ) v[i] = base[r * sd];
+  }
+  uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( winCb ) + q;
+#pragma unroll
+  for( int i = 0; i < 3; i++ )
+  {
+    if( i * RP < 2 * wh )
+    {
+      const uint32_t w = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v[i] ), v[i], sh );
+      if( q < nst ) wdw[wo[i]] = w;
+    }
+  }
+}
+
+// ---- stage 1: horizontal filter of every window row to 14-bit intermediates, two rows x eight columns per work item --------------
+template<int NT>
+__device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int tw, int th, int headroom, int tid, const McTapRows& T )
+{
+  const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+  {
+    const int lg = tw > 8 ? 1 : 0;                    // a 16-wide tile has two groups of eight columns
+    const int perList = ( ( th + 8 ) >> 1 ) << lg;    // th + 7 window rows in pairs
     for( int idx = tid; idx < nl * perList; idx += NT )
     {
-      const int k = idx >= perList, r0 = idx - k * perList;
-      int out[8];
-      if( r0 < rowsL * grpL )
-      {
-        const int r = r0 / grpL, g8 = r0 - r * grpL;
-        const pel_t* src = &winL[k][r * MC2_WST_L + 8 * g8];
-        mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), reinterpret_cast<const uint32_t*>( coefH[k][0] ), out );
-        pel_t* dst = &tmpL[k][( 8 * g8 ) * MC2_TST_L + r];
+      const int k = idx >= perList, r0 = idx - ( k ? perList : 0 ), rp = r0 >> lg, g = r0 & lg;
+      const uint4 C = d_mcTaps[k ? T.h[1][0] : T.h[0][0]];
+      const pel_t* src = &m.winL[k][2 * rp * MC2_WST_L + 8 * g];
+      int a[8], b[8];
+      mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), C, offset1, a );
+      mc_fir8<8>( *reinterpret_cast<const uint4*>( src + MC2_WST_L ), *reinterpret_cast<const uint4*>( src + MC2_WST_L + 8 ), C, offset1, b );
+      uint32_t* dst = &m.tmpL[k][8 * g * MC3_TPL + rp];
 #pragma unroll
-        for( int j = 0; j < 8; j++ ) if( 8 * g8 + j < wL ) dst[j * MC2_TST_L] = (pel_t) ( ( out[j] + offset1 ) >> shift1 );
-      }
-      else
-      {
-        const int q = r0 - rowsL * grpL, cc = q >= pairsC, rp = q - cc * pairsC;
+      for( int j = 0; j < 8; j++ ) dst[j * MC3_TPL] = __builtin_amdgcn_perm( (uint32_t) ( b[j] >> shift1 ), (uint32_t) ( a[j] >> shift1 ), 0x05040100u );
+    }
+  }
+  if( ncomp == 3 )
+  {
+    const int rpC = ( ( th >> 1 ) + 4 ) >> 1, perList = 2 * rpC;      // th / 2 + 3 window rows in pairs, Cb and Cr
+    for( int idx = tid; idx < nl * perList; idx += NT )
+    {
+      const int k = idx >= perList, q = idx - ( k ? perList : 0 ), cc = q >= rpC, rp = q - ( cc ? rpC : 0 );
+      const uint4 C = d_mcTaps[k ? T.h[1][1] : T.h[0][1]];
+      const pel_t* src = &m.winC[k][cc][2 * rp * MC2_WST_C];
+      int a[8], b[8];
+      mc_fir8<4>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), C, offset1, a );
+      mc_fir8<4>( *reinterpret_cast<const uint4*>( src + MC2_WST_C ), *reinterpret_cast<const uint4*>( src + MC2_WST_C + 8 ), C, offset1, b );
+      uint32_t* dst = &m.tmpC[2 * k + cc][rp];
 #pragma unroll
-        for( int half = 0; half < 2; half++ )
-        {
-          const int r = rp + half * pairsC;
-          if( r >= rowsC ) break;
-          const pel_t* src = &winC[k][cc][r * MC2_WST_C];
-          mc_fir8<4>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), reinterpret_cast<const uint32_t*>( coefH[k][1 + cc] ), out );
-          pel_t* dst = &tmpC[k][cc][r];
-#pragma unroll
-          for( int j = 0; j < 8; j++ ) if( j < wC ) dst[j * MC2_TST_C] = (pel_t) ( ( out[j] + offset1 ) >> shift1 );
-        }
-      }
+      for( int j = 0; j < 8; j++ ) dst[j * MC3_TPC] = __builtin_amdgcn_perm( (uint32_t) ( b[j] >> shift1 ), (uint32_t) ( a[j] >> shift1 ), 0x05040100u );
     }
   }
   __syncthreads();
 }
 
-// bs: BDOF buffers (the 14-bit luma predictions go there instead of being averaged) or nullptr
+// how the predictions of a tile become samples (decided once per tile)
+enum { MCM_UNI = 0, MCM_AVG, MCM_BCW, MCM_GEO, MCM_WP_UNI, MCM_WP_BI };
+
+// ---- stage 2: vertical filter, 8 rows of one column per work item, both lists in the same lane, then the combination
+//      (AreaBuf::addAvg / addWeightedAvg, Buffer.cpp:441,372; GPM weights, InterpolationFilter.cpp:1217) or the BDOF input.
+// bsp: BDOF buffers (the 14-bit luma predictions go there instead of being averaged) or nullptr
 template<int NT>
-__device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int nl, int ncomp, bool uni, const vvr_cu& cu, bool geo, int bcwIdx, int bd, int headroom,
+__device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int nl, int ncomp, int mode, const vvr_cu& cu, int bcwIdx, int bd, int headroom,
                                             const DevPlanes& reco, int tx, int ty, int tw, int th, int tid, const int16_t* __restrict__ fwdLut /* LMCS forward map or nullptr */,
-                                            const vvr_wp_params* __restrict__ wp = nullptr /* non-null: explicit weighted prediction */, int wpL = 0, int wpR0 = 0, int wpR1 = 0 )
+                                            const McTapRows& T, const vvr_wp_params* __restrict__ wp = nullptr /* MCM_WP_*: explicit weighted prediction */, int wpL = 0, int wpR0 = 0, int wpR1 = 0 )
 {
-  struct { int x, y, w, h; } it = { tx, ty, tw, th };
-  auto& tmpL = m.tmpL; auto& tmpC = m.tmpC; auto& coefV = m.coefV;
-  // stage 2: vertical filter, 8 rows of one column per work item, both lists in the same lane, then the combination
-  //      (AreaBuf::addAvg / addWeightedAvg, Buffer.cpp:441,372; GPM weights, InterpolationFilter.cpp:1217) or the BDOF input
+  const int wL = tw, hL = th, wC = tw >> 1, hC = th >> 1;
+  const int lwL = wL == 16 ? 4 : wL == 8 ? 3 : 2;
+  const int itemsL = wL * ( ( hL + 7 ) >> 3 ), itemsC = ncomp == 3 ? 2 * wC : 0;            // chroma: at most 8 rows = one group
+  const bool full = hL == 16;                          // every work item has eight rows (luma 2 x 8, chroma 8)
+  const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
+  for( int idx = tid; idx < itemsL + itemsC; idx += NT )
   {
-    const int wL = it.w, hL = it.h, wC = it.w >> 1, hC = it.h >> 1;
-    const int grpL = ( hL + 7 ) >> 3;
-    const int itemsL = wL * grpL, itemsC = ncomp == 3 ? 2 * wC : 0;            // chroma: at most 8 rows = one group
-    for( int idx = tid; idx < itemsL + itemsC; idx += NT )
+    int c, x, g8;
+    if( idx < itemsL ) { c = 0; g8 = idx >> lwL; x = idx & ( wL - 1 ); } else { const int q = idx - itemsL; c = 1 + ( q >= wC ); x = q - ( c - 1 ) * wC; g8 = 0; }
+    const int cs = c ? 1 : 0, hh = c ? hC : hL, nrows = min( 8, hh - 8 * g8 );
+    int p[2][8];
+#pragma unroll
+    for( int k = 0; k < 2; k++ )
     {
-      int c, x, g8;
-      if( idx < itemsL ) { c = 0; g8 = idx / wL; x = idx - g8 * wL; } else { const int q = idx - itemsL; c = 1 + ( q >= wC ); x = q - ( c - 1 ) * wC; g8 = 0; }
-      const int cs = c ? 1 : 0, hh = c ? hC : hL;
-      int p[2][8];
-      for( int k = 0; k < nl; k++ )
+      if( k < nl )
       {
-        const pel_t* src = c ? &tmpC[k][c - 1][x * MC2_TST_C] : &tmpL[k][x * MC2_TST_L + 8 * g8];
-        const uint4 lo = *reinterpret_cast<const uint4*>( src ), hi = *reinterpret_cast<const uint4*>( src + 8 );
-        if( c ) mc_fir8<4>( lo, hi, reinterpret_cast<const uint32_t*>( coefV[k][c] ), p[k] );
-        else    mc_fir8<8>( lo, hi, reinterpret_cast<const uint32_t*>( coefV[k][0] ), p[k] );
+        const uint32_t* src = c ? &m.tmpC[2 * k + c - 1][x * MC3_TPC] : &m.tmpL[k][x * MC3_TPL + 4 * g8];
+        const uint4 C = d_mcTaps[c ? T.v[k][1] : T.v[k][0]];         // (chroma: taps 4..7 are zero)
+        mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 4 ), C, mode == MCM_UNI ? offset2 : 0, p[k] );
       }
+    }
+    if( bsp && c == 0 )
+    {
+#pragma unroll
+      for( int i = 0; i < 8; i++ )
+        if( i < nrows ) { bsp->blk[0][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) ( p[0][i] >> 6 ); bsp->blk[1][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) ( p[1][i] >> 6 ); }
+      continue;
+    }
+    int out[8];
+    if( mode == MCM_UNI )
+    {
+#pragma unroll
+      for( int i = 0; i < 8; i++ ) out[i] = clip_pel( p[0][i] >> shift2, bd );
+    }
+    else if( mode == MCM_AVG )
+    {
+      const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
+#pragma unroll
+      for( int i = 0; i < 8; i++ ) out[i] = clip_pel( ( ( p[0][i] >> 6 ) + ( p[1][i] >> 6 ) + offset ) >> shift, bd );
+    }
+    else if( mode == MCM_BCW )
+    {
+      const int w1 = d_bcw_weights[bcwIdx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
+#pragma unroll
+      for( int i = 0; i < 8; i++ ) out[i] = clip_pel( ( ( p[0][i] >> 6 ) * w0 + ( p[1][i] >> 6 ) * w1 + offset ) >> shift, bd );
+    }
+    else if( mode == MCM_GEO )
+    {
       // GPM: weight of partition 0 from the mask tables, addressed in luma units relative to the CU with the mirroring of the split angle
-      const int8_t* gW = nullptr; int gBase = 0, gSY = 0;
-      if( geo )
-      {
-        const int MS = 112;
-        const int angle = d_geo_params[cu.geo_split_dir][0];
-        const int wIdx = ilog2( cu.w ) - 3, hIdx = ilog2( cu.h ) - 3;
-        const int ox = d_geo_weight_offset[cu.geo_split_dir][hIdx][wIdx][0], oy = d_geo_weight_offset[cu.geo_split_dir][hIdx][wIdx][1];
-        gW = d_geo_weights[d_geo_angle2mask[angle]];
-        const int mir = d_geo_angle2mirror[angle];
-        const int lx = ( ( ( it.x >> cs ) + x ) << cs ) - cu.x, ly0 = ( ( ( it.y >> cs ) + 8 * g8 ) << cs ) - cu.y;
-        if( mir == 2 )      { gBase = ( MS - 1 - oy - ly0 ) * MS + ox + lx; gSY = -( MS << cs ); }
-        else if( mir == 1 ) { gBase = ( oy + ly0 ) * MS + ( MS - 1 - ox ) - lx; gSY = MS << cs; }
-        else                { gBase = ( oy + ly0 ) * MS + ox + lx; gSY = MS << cs; }
-      }
-      pel_t* dstp = reco.p[c] + (size_t) ( ( it.y >> cs ) + 8 * g8 ) * reco.stride[c] + ( it.x >> cs ) + x;
+      const int MS = 112;
+      const int angle = d_geo_params[cu.geo_split_dir][0];
+      const int wIdx = ilog2( cu.w ) - 3, hIdx = ilog2( cu.h ) - 3;
+      const int ox = d_geo_weight_offset[cu.geo_split_dir][hIdx][wIdx][0], oy = d_geo_weight_offset[cu.geo_split_dir][hIdx][wIdx][1];
+      const int8_t* gW = d_geo_weights[d_geo_angle2mask[angle]];
+      const int mir = d_geo_angle2mirror[angle];
+      const int lx = ( ( ( tx >> cs ) + x ) << cs ) - cu.x, ly0 = ( ( ( ty >> cs ) + 8 * g8 ) << cs ) - cu.y;
+      int gBase, gSY;
+      if( mir == 2 )      { gBase = ( MS - 1 - oy - ly0 ) * MS + ox + lx; gSY = -( MS << cs ); }
+      else if( mir == 1 ) { gBase = ( oy + ly0 ) * MS + ( MS - 1 - ox ) - lx; gSY = MS << cs; }
+      else                { gBase = ( oy + ly0 ) * MS + ox + lx; gSY = MS << cs; }
+      const int shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
 #pragma unroll
       for( int i = 0; i < 8; i++ )
       {
-        if( 8 * g8 + i >= hh ) break;
-        int out;
-        if( wp )
-        {
-          if( uni ) out = wp_uni( wp, wpL, wpL ? wpR1 : wpR0, c, (int16_t) ( p[0][i] >> 6 ), bd, headroom );
-          else      out = wp_bi( wp, wpR0, wpR1, c, (int16_t) ( p[0][i] >> 6 ), (int16_t) ( p[1][i] >> 6 ), bd, headroom );
-        }
-        else if( uni )
-        {
-          const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
-          out = clip_pel( (int16_t) ( ( p[0][i] + offset2 ) >> shift2 ), bd );
-        }
-        else
-        {
-          const int p0 = (int16_t) ( p[0][i] >> 6 ), p1 = (int16_t) ( p[1][i] >> 6 );
-          if( bsp && c == 0 ) { bsp->blk[0][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) p0; bsp->blk[1][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) p1; continue; }
-          if( gW )
-          {
-            const int wt = gW[gBase + i * gSY], shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
-            out = clip_pel( ( wt * p0 + ( 8 - wt ) * p1 + offset ) >> shift, bd );
-          }
-          else if( bcwIdx != 2 )
-          {
-            const int w1 = d_bcw_weights[bcwIdx], w0 = 8 - w1, shift = headroom + 3, offset = ( 1 << ( shift - 1 ) ) + ( IF_INTERNAL_OFFS << 3 );
-            out = clip_pel( ( p0 * w0 + p1 * w1 + offset ) >> shift, bd );
-          }
-          else
-          {
-            const int shift = headroom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS;
-            out = clip_pel( ( p0 + p1 + offset ) >> shift, bd );
-          }
-        }
-        dstp[(size_t) i * reco.stride[c]] = (pel_t) lmcs_fwd_luma( fwdLut, c, out );
+        const int wt = gW[gBase + min( i, nrows - 1 ) * gSY];
+        out[i] = clip_pel( ( wt * ( p[0][i] >> 6 ) + ( 8 - wt ) * ( p[1][i] >> 6 ) + offset ) >> shift, bd );
       }
+    }
+    else if( mode == MCM_WP_UNI )
+    {
+#pragma unroll
+      for( int i = 0; i < 8; i++ ) out[i] = wp_uni( wp, wpL, wpL ? wpR1 : wpR0, c, p[0][i] >> 6, bd, headroom );
+    }
+    else
+    {
+#pragma unroll
+      for( int i = 0; i < 8; i++ ) out[i] = wp_bi( wp, wpR0, wpR1, c, p[0][i] >> 6, p[1][i] >> 6, bd, headroom );
+    }
+    if( fwdLut )
+    {
+      // LMCS: luma predictions are stored forward-mapped (chroma lanes look their - valid - values up as well and keep them: no divergence)
+#pragma unroll
+      for( int i = 0; i < 8; i++ ) { const int v = fwdLut[out[i]]; out[i] = c ? out[i] : v; }
+    }
+    const int st = c ? reco.stride[1] : reco.stride[0];
+    pel_t* dstp = ( c == 0 ? reco.p[0] : c == 1 ? reco.p[1] : reco.p[2] ) + (size_t) ( ( ty >> cs ) + 8 * g8 ) * st + ( tx >> cs ) + x;
+    if( full )
+    {
+#pragma unroll
+      for( int i = 0; i < 8; i++ ) dstp[(size_t) i * st] = (pel_t) out[i];
+    }
+    else
+    {
+#pragma unroll
+      for( int i = 0; i < 8; i++ ) if( i < nrows ) dstp[(size_t) i * st] = (pel_t) out[i];
     }
   }
 }
@@ -591,67 +702,124 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   const int item = mc_item_index();
   if( item >= numItems + numItems2 ) return;
   const McItem it = item < numItems ? items[item] : items2[item - numItems];       // (tiles the host wrote - SbTMVP -, then the tiles k_expand_mc wrote)
-  const int16_t* __restrict__ fwdLut = lmcs_fwd_at( pic, it.x, it.y );      // LMCS (where the tile's slice uses it): luma predictions are stored forward-mapped (lmcs_fwd_luma)
-  const int bd = pic.hdr.bit_depth;
   const int tid = threadIdx.x;
   // the tile record is self-contained (motion of the CU, or of the 8x8 sub-block for SbTMVP, with the identical-motion shortcut already
-  // decided, xCheckIdenticalMotion :404); only GPM tiles read their CU (split direction, the two uni-directional motions)
-  const bool geo = ( it.flags & MC_ITEM_GEO ) != 0;       // motionCompensationGeo (:1461): two uni-predictions kept at 14 bit, blended with the GPM masks
-  const vvr_cu& cu = pic.cu[it.cu];                      // (dereferenced for GPM tiles only)
-  const int mRef[2] = { it.ref[0], it.ref[1] };
-  const bool uni = ( it.flags & MC_ITEM_UNI ) != 0;
-  const int clipX = it.clipX, clipY = it.clipY;
+  // decided, xCheckIdenticalMotion :404); only GPM tiles read their CU (split direction, the two uni-directional motions).  The record is the same
+  // for every lane: its fields go to scalar registers, and so does everything derived from them
+#define MC_U( v ) __builtin_amdgcn_readfirstlane( (int) ( v ) )
+  const int ix = MC_U( it.x ), iy = MC_U( it.y ), iw = MC_U( it.w ), ih = MC_U( it.h ), iflags = MC_U( it.flags ), bcwIdx = MC_U( it.bcw );
+  const int mRef[2] = { MC_U( it.ref[0] ), MC_U( it.ref[1] ) };
+  const int clipX = MC_U( it.clipX ), clipY = MC_U( it.clipY ), clipW4 = MC_U( it.clipW4 );
+  const vvr_cu& cu = pic.cu[MC_U( it.cu )];               // (dereferenced for GPM tiles only)
+  const int16_t* __restrict__ fwdLut = lmcs_fwd_at( pic, ix, iy );      // LMCS (where the tile's slice uses it): luma predictions are stored forward-mapped
+  const int bd = pic.hdr.bit_depth;
+  const bool geo = ( iflags & MC_ITEM_GEO ) != 0;         // motionCompensationGeo (:1461): two uni-predictions kept at 14 bit, blended with the GPM masks
+  const bool uni = ( iflags & MC_ITEM_UNI ) != 0;
+  const bool altHpel = ( iflags & MC_ITEM_HPEL ) != 0;
   const bool biPred = mRef[0] >= 0 && mRef[1] >= 0;
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
   const int l0 = uni ? ( ( biPred || mRef[0] >= 0 ) ? 0 : 1 ) : 0;
   const int nl = uni ? 1 : 2;
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  // ---- segment geometry + filter taps: computed once by six lanes, shared through LDS.  The window always spans the full filter
-  // support (the block's integer origin sits at (half, half)), whatever the fractional part of the MV
-  if( tid < 6 )
+  const bool f4 = iw == 4 && ih == 4;
+  McTapRows T = {};
+  // ---- a tile whose windows lie inside the picture (no wrap-around, no sub-picture of its own): geometry in scalar registers, dword loads.
+  // The window always spans the full filter support (the block's integer origin sits at (half, half)), whatever the fractional part of the MV
+  bool fast = !pic.hdr.wrap_offset && !pic.subpics;
+  int wx[2], wy[2], cx[2], cy[2], li[2], ri[2];
+  if( fast )
   {
-    const int k = tid / 3, c = tid - 3 * k;
-    if( k < nl && c < ncomp )
+#pragma unroll
+    for( int k = 0; k < 2; k++ )
     {
-      const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
-      const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : ( l ? mRef[1] : mRef[0] );
-      int mvx = geo ? cu.geo_mv[k][0] : ( l ? it.mv[1][0] : it.mv[0][0] ), mvy = geo ? cu.geo_mv[k][1] : ( l ? it.mv[1][1] : it.mv[0][1] );
-      const McBounds B = mc_bounds( pic, clipX, clipY );
-      // clipped with the position and size of m_currCuArea (InterPrediction.cpp:651-656): the CU, or the piece of an SbTMVP CU that xSubPuMC predicts as one block (:514-543)
-      const int wrapOff = mc_clip_mv_w( pic, B, clipX, clipY, pic.hdr.wrap_offset ? ( it.clipW4 ? 4 * (int) it.clipW4 : (int) cu.w ) : 0, mvx, mvy );
-      McSeg g;
-      const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
-      g.wrapOff = wrapOff >> cs; g.bx0 = B.x0 >> cs; g.by0 = B.y0 >> cs; g.bx1 = B.x1 >> cs; g.by1 = B.y1 >> cs;
-      g.w = it.w >> cs; g.h = it.h >> cs;
-      g.xFrac = mvx & ( ( 1 << shf ) - 1 ); g.yFrac = mvy & ( ( 1 << shf ) - 1 );
-      g.ox = half; g.oy = half;
-      g.ww = g.w + ntaps - 1; g.wh = g.h + ntaps - 1;
-      g.x0 = ( it.x >> cs ) + ( mvx >> shf ) - half;
-      g.y0 = ( it.y >> cs ) + ( mvy >> shf ) - half;
-      g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
-      m.seg[k][c] = g;
-      m.refp[k][c] = refs.p[l * VVR_MAX_REFS + refIdx][c];
-      mc_taps( g, c, ( it.flags & MC_ITEM_HPEL ) != 0, m.coefH[k][c], m.coefV[k][c] );      // frac 0 selects the identity filter { .., 64, .. }
+      if( k < nl )
+      {
+        const int l = geo ? ( MC_U( cu.geo_dir_ref[k] ) >> 4 ) - 1 : uni ? l0 : k;
+        const int refIdx = geo ? ( MC_U( cu.geo_dir_ref[k] ) & 15 ) : ( l ? mRef[1] : mRef[0] );
+        int mvx = geo ? MC_U( cu.geo_mv[k][0] ) : MC_U( l ? it.mv[1][0] : it.mv[0][0] ), mvy = geo ? MC_U( cu.geo_mv[k][1] ) : MC_U( l ? it.mv[1][1] : it.mv[0][1] );
+        const McBounds B = { 0, 0, (int) pic.hdr.width - 1, (int) pic.hdr.height - 1 };
+        mc_clip_mv( pic, B, clipX, clipY, mvx, mvy );       // clipped with the position of m_currCuArea (InterPrediction.cpp:651-656)
+        li[k] = l; ri[k] = refIdx;
+        wx[k] = ix + ( mvx >> 4 ) - 3; wy[k] = iy + ( mvy >> 4 ) - 3;
+        cx[k] = ( ix >> 1 ) + ( mvx >> 5 ) - 1; cy[k] = ( iy >> 1 ) + ( mvy >> 5 ) - 1;
+        T.h[k][0] = mc_tap_row( 0, mvx & 15, f4, altHpel ); T.v[k][0] = mc_tap_row( 0, mvy & 15, f4, altHpel );
+        T.h[k][1] = mc_tap_row( 1, mvx & 31, false, false ); T.v[k][1] = mc_tap_row( 1, mvy & 31, false, false );
+        // (the dword loads read up to one sample beyond the window's last column: that one must lie in the row's padded stride)
+        const int oddL = wx[k] & 1, oddC = cx[k] & 1;
+        fast = fast && wx[k] >= 0 && wy[k] >= 0 && wx[k] + iw + 7 <= reco.w[0] && wy[k] + ih + 7 <= reco.h[0] && wx[k] - oddL + 2 * ( ( iw + 8 + oddL ) >> 1 ) <= reco.stride[0];
+        if( ncomp == 3 )
+          fast = fast && cx[k] >= 0 && cy[k] >= 0 && cx[k] + ( iw >> 1 ) + 3 <= reco.w[1] && cy[k] + ( ih >> 1 ) + 3 <= reco.h[1] && cx[k] - oddC + 2 * ( ( ( iw >> 1 ) + 4 + oddC ) >> 1 ) <= reco.stride[1];
+      }
+    }
+  }
+  if( fast )
+  {
+#pragma unroll
+    for( int k = 0; k < 2; k++ )
+    {
+      if( k < nl )
+      {
+        const int ridx = li[k] * VVR_MAX_REFS + ri[k];
+        mc3_load_luma<NT>( m.winL[k], refs.p[ridx][0], reco.stride[0], wx[k], wy[k], iw + 7, ih + 7, tid );
+        if( ncomp == 3 ) mc3_load_chroma<NT>( m.winC[k][0], refs.p[ridx][1], refs.p[ridx][2], reco.stride[1], cx[k], cy[k], ( iw >> 1 ) + 3, ( ih >> 1 ) + 3, tid );
+      }
+    }
+    if constexpr( BDOF )
+    {
+      // (the BDOF border reads the fractional parts of the luma segments)
+      if( tid < 2 ) { m.seg[tid][0].xFrac = ( tid ? T.h[1][0] : T.h[0][0] ) & 15; m.seg[tid][0].yFrac = ( tid ? T.v[1][0] : T.v[0][0] ) & 15; m.seg[tid][0].ox = m.seg[tid][0].oy = 3; }
+    }
+  }
+  else
+  {
+    // ---- any other tile: segment geometry by six lanes, shared through LDS; windows sample by sample with clamped / wrapped coordinates
+    if( tid < 6 )
+    {
+      const int k = tid / 3, c = tid - 3 * k;
+      if( k < nl && c < ncomp )
+      {
+        const int l = geo ? ( cu.geo_dir_ref[k] >> 4 ) - 1 : uni ? l0 : k;
+        const int refIdx = geo ? ( cu.geo_dir_ref[k] & 15 ) : ( l ? mRef[1] : mRef[0] );
+        int mvx = geo ? cu.geo_mv[k][0] : ( l ? it.mv[1][0] : it.mv[0][0] ), mvy = geo ? cu.geo_mv[k][1] : ( l ? it.mv[1][1] : it.mv[0][1] );
+        const McBounds B = mc_bounds( pic, clipX, clipY );
+        // clipped with the position and size of m_currCuArea (InterPrediction.cpp:651-656): the CU, or the piece of an SbTMVP CU that xSubPuMC predicts as one block (:514-543)
+        const int wrapOff = mc_clip_mv_w( pic, B, clipX, clipY, pic.hdr.wrap_offset ? ( clipW4 ? 4 * clipW4 : (int) cu.w ) : 0, mvx, mvy );
+        McSeg g;
+        const int cs = c ? 1 : 0, shf = 4 + cs, ntaps = c ? 4 : 8, half = ntaps / 2 - 1;
+        g.wrapOff = wrapOff >> cs; g.bx0 = B.x0 >> cs; g.by0 = B.y0 >> cs; g.bx1 = B.x1 >> cs; g.by1 = B.y1 >> cs;
+        g.w = iw >> cs; g.h = ih >> cs;
+        g.xFrac = mvx & ( ( 1 << shf ) - 1 ); g.yFrac = mvy & ( ( 1 << shf ) - 1 );
+        g.ox = half; g.oy = half;
+        g.ww = g.w + ntaps - 1; g.wh = g.h + ntaps - 1;
+        g.x0 = ( ix >> cs ) + ( mvx >> shf ) - half;
+        g.y0 = ( iy >> cs ) + ( mvy >> shf ) - half;
+        g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
+        m.seg[k][c] = g;
+        m.refp[k][c] = refs.p[l * VVR_MAX_REFS + refIdx][c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for( int k = 0; k < 2; k++ )
+    {
+      if( k >= nl ) break;
+      mc_load_window<NT>( m.winL[k], MC2_WST_L, m.seg[k][0], m.refp[k][0], reco.stride[0], reco.w[0], reco.h[0], tid );
+      if( ncomp == 3 ) mc_load_window_c2<NT>( m.winC[k][0], m.winC[k][1], MC2_WST_C, m.seg[k][1], m.seg[k][2], m.refp[k][1], m.refp[k][2], reco.stride[1], reco.w[1], reco.h[1], tid );
+      T.h[k][0] = mc_tap_row( 0, MC_U( m.seg[k][0].xFrac ), f4, altHpel ); T.v[k][0] = mc_tap_row( 0, MC_U( m.seg[k][0].yFrac ), f4, altHpel );
+      if( ncomp == 3 ) { T.h[k][1] = mc_tap_row( 1, MC_U( m.seg[k][1].xFrac ), false, false ); T.v[k][1] = mc_tap_row( 1, MC_U( m.seg[k][1].yFrac ), false, false ); }
     }
   }
   __syncthreads();
-  // ---- phase A: all reference windows of the tile into LDS, one exposure to HBM/L2 latency
-  for( int k = 0; k < nl; k++ )
-  {
-    mc_load_window<NT>( m.winL[k], MC2_WST_L, m.seg[k][0], m.refp[k][0], reco.stride[0], reco.w[0], reco.h[0], tid );
-    if( ncomp == 3 ) mc_load_window_c2<NT>( m.winC[k][0], m.winC[k][1], MC2_WST_C, m.seg[k][1], m.seg[k][2], m.refp[k][1], m.refp[k][2], reco.stride[1], reco.w[1], reco.h[1], tid );
-  }
-  __syncthreads();
-  mc2_stage1<NT>( m, nl, ncomp, it.w, it.h, headroom, tid );
-  __syncthreads();
-  const vvr_wp_params* __restrict__ wpT = wp_at( pic, it.x, it.y );      // the weight table of the tile's slice
-  const bool wpOn = !BDOF && wpT && !geo && it.bcw == 2;          // xPredInterBi (:707,735-742)
-  mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, uni, cu, geo, it.bcw, bd, headroom, reco, it.x, it.y, it.w, it.h, tid, fwdLut,
+  mc2_stage1<NT>( m, nl, ncomp, iw, ih, headroom, tid, T );
+  const vvr_wp_params* __restrict__ wpT = wp_at( pic, ix, iy );      // the weight table of the tile's slice
+  const bool wpOn = !BDOF && wpT && !geo && bcwIdx == 2;          // xPredInterBi (:707,735-742)
+  const int mode = wpOn ? ( uni ? MCM_WP_UNI : MCM_WP_BI ) : uni ? MCM_UNI : geo ? MCM_GEO : bcwIdx != 2 ? MCM_BCW : MCM_AVG;
+  mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, mode, cu, bcwIdx, bd, headroom, reco, ix, iy, iw, ih, tid, fwdLut, T,
                   wpOn ? wpT : nullptr, l0, mRef[0], mRef[1] );
   if constexpr( BDOF )
   {
     __syncthreads();
-    mc_bdof_luma<NT>( bs, m.winL[0], m.winL[1], MC2_WST_L, &m.seg[0][0], 3, bd, reco, it.x, it.y, it.w, it.h, tid, fwdLut );
+    mc_bdof_luma<NT>( bs, m.winL[0], m.winL[1], MC2_WST_L, &m.seg[0][0], 3, bd, reco, ix, iy, iw, ih, tid, fwdLut );
   }
 }
 
@@ -861,16 +1029,22 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
       }
       sh.m.seg[l][c] = g;
       sh.m.refp[l][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
-      mc_taps( g, c, cu.imv == 3, sh.m.coefH[l][c], sh.m.coefV[l][c] );
     }
   }
   __syncthreads();
   for( int k = 0; k < 2; k++ ) for( int c = 0; c < ncomp; c++ )
     mc_load_window<NT>( c ? sh.m.winC[k][c - 1] : sh.m.winL[k], c ? MC2_WST_C : MC2_WST_L, sh.m.seg[k][c], sh.m.refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
   __syncthreads();
-  mc2_stage1<NT>( sh.m, 2, ncomp, w, h, headroom, tid );
-  __syncthreads();
-  mc2_stage2<NT>( sh.m, bioSub ? &sh.bs : nullptr, 2, ncomp, false, cu, false, 2, bd, headroom, reco, it.x, it.y, w, h, tid, fwdLut );
+  McTapRows T;
+#pragma unroll
+  for( int k = 0; k < 2; k++ )
+  {
+    const bool f4 = w == 4 && h == 4, altHpel = cu.imv == 3;
+    T.h[k][0] = mc_tap_row( 0, sh.m.seg[k][0].xFrac, f4, altHpel ); T.v[k][0] = mc_tap_row( 0, sh.m.seg[k][0].yFrac, f4, altHpel );
+    T.h[k][1] = ncomp == 3 ? mc_tap_row( 1, sh.m.seg[k][1].xFrac, false, false ) : 0; T.v[k][1] = ncomp == 3 ? mc_tap_row( 1, sh.m.seg[k][1].yFrac, false, false ) : 0;
+  }
+  mc2_stage1<NT>( sh.m, 2, ncomp, w, h, headroom, tid, T );
+  mc2_stage2<NT>( sh.m, bioSub ? &sh.bs : nullptr, 2, ncomp, MCM_AVG, cu, 2, bd, headroom, reco, it.x, it.y, w, h, tid, fwdLut, T );
   if( bioSub )
   {
     __syncthreads();
