@@ -114,11 +114,11 @@ void launch_mc_rpr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const 
 void launch_mc_dmvr( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, int32_t* ) {}
 static int g_lastIntraWg = 0;
 size_t intra_sync_ints( int numUnits, int numItems ) { return ( ( (size_t) 1 + (size_t) numUnits + 63 ) & ~(size_t) 63 ) + (size_t) numItems * 64; }
-void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int, const IntraUnit*, int numUnits, int ticket0, int ticket1, int numWg, int* sync, int, uint32_t*, size_t, int, int ) { (void) ticket1; if( ticket0 ) return; g_lastIntraWg = numWg; g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the launcher's memset touches */ }
+void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int, const IntraUnit*, int numUnits, int ticket0, int ticket1, int numWg, int* sync, int, uint32_t*, size_t, int, int, int* ) { (void) ticket1; if( ticket0 ) return; g_lastIntraWg = numWg; g_lastIntraUnits = numUnits; g_lastSync = sync; for( int i = 0; i <= numUnits; i++ ) sync[i] = 0; /* what the launcher's memset touches */ }
 void launch_resi_add( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int ) {}
 static int g_lastLeafItems = -1;
 size_t intra_leaf_map_ints( int w4, int h4, int vpdus ) { return (size_t) 3 * w4 * h4 + 2 * (size_t) vpdus + 64; }
-void launch_intra_leaf( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int numItems, const IntraItem*, int, uint32_t*, size_t, int, int ) { g_lastLeafItems = numItems; }
+void launch_intra_leaf( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int numItems, const IntraItem*, int, uint32_t*, size_t, int, int, int* ) { g_lastLeafItems = numItems; }
 // the two output-stage kernels have functional stand-ins (a few plain loops with the kernels' contract: packed window; per row the checksum
 // share or the CRC register reached from 0), so that the host half of vvr_read_output / vvr_picture_hash - window geometry, chaining the rows'
 // CRC pieces - is checked against the reference's own functions without a GPU

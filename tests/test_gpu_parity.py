@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 TOOLS = abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS
 
 
-def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=True, intra=False, bit_depth=10, chroma_format=1, post=None, **kw):
+def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=True, intra=False, bit_depth=10, chroma_format=1, post=None, kernels=None, **kw):
     """intra=False: POC 0 is an uploaded picture and all CUs are inter; intra=True: POC 0 is an I picture reconstructed by the
     back-end and the B pictures contain intra CUs (p_intra)."""
     import vvdec_amd
@@ -38,6 +38,8 @@ def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=Tru
     # verify in decode order; the CPU oracle consumes its own previous outputs as references.  A slot is overwritten
     # later in the stream, so pictures are read back in a second, serial pass.
     rec2 = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=1, **geo)
+    if kernels is not None:
+        rec2.enable_stats()         # which kernels the pictures take (HIP events around every launch)
     if not intra:
         rec2.write_picture(0, seed_pic)
     for pl, d in zip(plans, descs):
@@ -62,6 +64,9 @@ def _run_stream(W, H, frames, gop, seed, tools, streams=2, log2_ctu=7, check=Tru
         b = rec2.read_picture(slot)
         for c in range(ncomp):
             assert np.array_equal(a[c], b[c]), "pipelined vs serial differ in slot %d" % slot
+    if kernels is not None:
+        for e in rec2.stats():
+            kernels[e["name"]] = kernels.get(e["name"], 0) + e["launches"]
     rec.close()
     rec2.close()
     return hashes
@@ -86,6 +91,33 @@ def test_stage_subsets(built):
     _run_stream(256, 128, 5, 4, 22, abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA)                # SAO without ALF
     _run_stream(256, 128, 5, 4, 23, abi.TOOL_ALF | abi.TOOL_DEBLOCK_OFF)                    # ALF without SAO / deblock
     _run_stream(256, 128, 5, 4, 24, TOOLS, p_coded=0.9, p_coded_chroma=0.8, p_small_corner=0.2, p_mts=0.5, p_ts=0.2)   # residual heavy
+
+
+def test_the_kernels_beside_the_fused_passes_are_exercised(built):
+    """Pictures the fused passes do not cover - CTUs of 32, picture-header virtual boundaries, a picture with only one of SAO / ALF, one without deblocking
+    but with LMCS, the stage-wise `stop_after` runs - take k_lmcs, k_deblock4 (in place), k_sao, k_alf_luma + k_alf_chroma(_tile) and k_copy; an inter picture
+    that takes the CTU-tile path of the intra stage (IBC) with LMCS chroma scaling takes k_resi_add.  Every one of them is run here, bit-exact against the
+    oracle, and the back-end's statistics say that it was THAT kernel (round-5 verdict: a GPU test per such branch, or the kernels go)"""
+    T = TOOLS | abi.TOOL_LMCS | abi.TOOL_LMCS_CSCALE
+    k = {}
+    _run_stream(256, 192, 5, 4, 71, T, intra=True, log2_ctu=5, p_intra=0.2, kernels=k)                      # CTU 32: no fused pass covers it
+    assert all(k.get(n, 0) > 0 for n in ("k_lmcs", "k_deblock4", "k_sao", "k_alf_planes")), k
+    assert not k.get("k_alf") and not k.get("k_deblock_v"), k
+    k = {}
+    _run_stream(512, 384, 3, 2, 72, T, intra=True, log2_ctu=6, p_intra=0.2, virtual_boundaries=1 | (1 << 2), kernels=k)      # picture-header virtual boundaries
+    assert all(k.get(n, 0) > 0 for n in ("k_lmcs", "k_deblock4", "k_sao", "k_alf_planes")), k
+    k = {}
+    _run_stream(256, 128, 3, 2, 73, abi.TOOL_SAO_LUMA | abi.TOOL_SAO_CHROMA | abi.TOOL_DEP_QUANT, log2_ctu=5, kernels=k)     # SAO without ALF, CTU 32: SAO into the scratch picture, copied back
+    assert k.get("k_sao", 0) > 0 and k.get("k_copy", 0) > 0 and not k.get("k_alf_planes"), k
+    k = {}
+    _run_stream(256, 128, 3, 2, 74, abi.TOOL_ALF | abi.TOOL_CCALF | abi.TOOL_DEBLOCK_OFF | abi.TOOL_LMCS, log2_ctu=5, kernels=k)      # ALF alone, no deblocking: the inverse luma map as a pass of its own
+    assert k.get("k_alf_planes", 0) > 0 and k.get("k_copy", 0) > 0 and k.get("k_lmcs", 0) > 0 and not k.get("k_deblock4") and not k.get("k_sao"), k
+    k = {}
+    _run_stream(256, 128, 3, 2, 75, TOOLS | abi.TOOL_LMCS | abi.TOOL_DEBLOCK_OFF, kernels=k)                 # CTU 128 without deblocking: fused SAO + ALF behind k_lmcs
+    assert k.get("k_lmcs", 0) > 0 and k.get("k_alf", 0) > 0 and not k.get("k_deblock_v") and not k.get("k_deblock4"), k
+    k = {}
+    _run_stream(256, 128, 5, 4, 76, T | abi.TOOL_IBC, intra=True, p_intra=0.2, p_ibc=0.2, p_coded=0.8, p_coded_chroma=0.7, kernels=k)      # IBC in B pictures: CTU tiles, scaled inter chroma residuals between the launches
+    assert k.get("k_resi_add", 0) > 0 and k.get("k_intra", 0) > 0, k
 
 
 def test_1080p_frame(built):

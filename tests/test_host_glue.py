@@ -40,7 +40,7 @@ def build_stub():
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in deps):
         # (several test processes may get here at once - pytest -n: build under a private name, then rename into place)
         tmp = "%s.%d.tmp" % (LIB, os.getpid())
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I" + HIP_INC, "-D__HIP_PLATFORM_AMD__", "-w", SRC, "-o", tmp])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I" + HIP_INC, "-D__HIP_PLATFORM_AMD__", "-DVVR_DEV_ENV", "-w", SRC, "-o", tmp])
         os.replace(tmp, LIB)
     return LIB
 

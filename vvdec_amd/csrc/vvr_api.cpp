@@ -89,7 +89,7 @@ static double g_wdSum[6]; static uint64_t g_wdJobs; static double g_wdPart[4], g
 
 struct Stat { uint64_t launches = 0; double ms = 0, bytes = 0; };
 struct PendingTiming { hipEvent_t a, b; int kernel; double bytes; };
-const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_resi_add", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy", "k_output", "k_lf_init", "k_intra_leaf" };
+const char* const kKernelNames[K_NUM] = { "k_mc", "k_mc_dmvr", "k_mc_affine", "k_lmcs", "k_itrans", "k_intra", "k_resi_add", "k_deblock_v", "k_deblock_h", "k_sao", "k_alf", "k_copy", "k_output", "k_lf_init", "k_intra_leaf", "k_deblock4", "k_alf_planes" };
 
 // One slot of the upload ring: pinned staging memory and its image in HBM (grown on demand, never freed while the context lives), the device
 // pointers of the picture that currently sits in it, and the pinned landing area of its DMVR delta MVs.
@@ -108,6 +108,7 @@ struct RingEntry {
 
 enum { J_QUEUED, J_PREPARING, J_READY, J_FAILED, J_COMMITTED };
 
+#define VVR_ERR_WORDS 1024
 struct Job {
   int id = 0; uint64_t seq = 0;
   uint64_t ringSeq = 0;             // streaming jobs: position in the sequence of ring users (entry = ringSeq % ring size)
@@ -122,6 +123,7 @@ struct Job {
                                       // hipStreamWaitEvent on the same event (the launcher ordering a later picture) would block behind it
   bool completed = false, waited = false;
   std::vector<PendingTiming> timings;
+  int* errWord = nullptr;           // a word of pinned host memory the intra stage writes when one of its bounded waits gave up: the job fails when it completes
   std::vector<int32_t> dmvr;        // delta MVs, copied out of pinned memory when the job completes
   std::vector<vvr_motion> col;      // collocated motion (VVR_TOOL_COL_MOTION), likewise
   bool handled = false;             // committed (or failed) ahead of its turn: its bySeq entry stays until the commit front passes it
@@ -146,7 +148,8 @@ struct vvr_context {
   std::deque<std::function<void( PrepScratch& )>> subtasks;      // parts of a picture's host stage that any worker may run (an I picture is prepared by all of them together); guarded by mu, served before `queue`
   std::vector<int*> syncBuf;            // per stream: ticket + one flag per unit of the intra stage
   std::vector<size_t> syncCap;          // ints allocated in syncBuf[lane]; grown when a picture has more units
-  std::vector<uint32_t*> leafMaps;      // per stream: the cell maps, VPDU flags and factors of k_intra_leaf (all zero between launches), ticket + error word at the end
+  std::vector<uint32_t*> leafMaps;      // per stream: the cell maps, VPDU flags and factors of k_intra_leaf (all zero between launches), the ticket at the end
+  int*       errHost = nullptr;         // VVR_ERR_WORDS words of pinned host memory: the error word of job j is errHost[j % VVR_ERR_WORDS] (far more than pictures in flight)
   size_t     leafMapInts = 0; int leafW4 = 0, leafH4 = 0;
   bool       intraFine = false;         // VVR_INTRA_FINE=1: pictures of intra CTUs resolve their CTU wavefront block by block (k_intra<.., FINE>).  Measured in round 5 and left off:
                                         // an I picture alone 4.23 - 4.46 ms against 4.56 (its blocks read far down the left CTU's last column, the chain of 1442 blocks stays), and
@@ -257,6 +260,12 @@ static void completeLocked( vvr_context* c, Job& j )
     hipEventDestroy( t.a ); hipEventDestroy( t.b );
   }
   j.timings.clear();
+  if( j.errWord && *j.errWord )
+  {
+    // k_intra_leaf bounds every wait for a neighbouring block: a wavefront that gave up has reconstructed from whatever was there - the picture is wrong
+    *j.errWord = 0;
+    if( j.state == J_COMMITTED ) { j.state = J_FAILED; j.rc = VVR_ERR_DEVICE; j.err = "intra stage: a block waited for its neighbours beyond the bound (dependency that never completed)"; }
+  }
   if( j.q && j.q->numDmvr && j.state == J_COMMITTED )
   {
     // refined MVs feed the temporal MV prediction of later pictures on the host (DecCu::TaskFinishMotionInfo, DecCu.cpp:161)
@@ -382,6 +391,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
     hipEventRecord( job.tlA, s );
   }
 #endif
+  job.errWord = c->errHost + ( (unsigned) job.id % VVR_ERR_WORDS ); *job.errWord = 0;
   const RefSet& refs = plan.refs;
   DevPlanes A = c->slots[h.out_slot], B = c->scratchB[lane], R = c->scratchR[lane];
   // the picture's own size (it may be smaller than the context's pictures: it lies in the top left corner of its slot and of the scratch planes)
@@ -453,7 +463,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   }
   const int wideIntra = h.slice_type == 2 && ( lane == c->prioLane || c->numLanesRR == 1 );      // an I picture the pictures behind it wait for (launch_intra)
   // A picture with scattered intra blocks: one wavefront per block, luma, the scaled residuals of inter chroma blocks and chroma in ONE launch (vvr_intra_leaf.inc)
-  if( q->intraLeaf ) { if( q->numIntra ) timed( K_INTRA_LEAF, [&]{ launch_intra_leaf( s, q->pic, P, R, q->intraItems, q->numIntra, q->resiItems, q->numResi, c->leafMaps[lane], c->leafMapInts, c->leafW4, c->leafH4 ); } ); }
+  if( q->intraLeaf ) { if( q->numIntra ) timed( K_INTRA_LEAF, [&]{ launch_intra_leaf( s, q->pic, P, R, q->intraItems, q->numIntra, q->resiItems, q->numResi, c->leafMaps[lane], c->leafMapInts, c->leafW4, c->leafH4, job.errWord ); } ); }
   // A picture whose inter blocks carry scaled chroma residuals (LMCS): luma units, the residual-add blocks, chroma units
   else if( q->numResi )
   {
@@ -464,7 +474,7 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   else if( q->numActive )
   {
     const bool fine = q->intraFine && c->intraFine;
-    timed( K_INTRA, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane], wideIntra, fine ? c->leafMaps[lane] : nullptr, c->leafMapInts, c->leafW4, c->leafH4 ); } );
+    timed( K_INTRA, [&]{ launch_intra( s, q->pic, P, R, q->intraItems, q->numIntra, q->units, q->numActive, 0, q->numActive, q->intraWorkgroups, c->syncBuf[lane], wideIntra, fine ? c->leafMaps[lane] : nullptr, c->leafMapInts, c->leafW4, c->leafH4, job.errWord ); } );
   }
   // LMCS: inverse luma mapping of the reconstructed picture (RSP state, DecLibRecon.cpp:935)
   if( lmcsOn && !hop ) timed( K_LMCS, [&]{ launch_lmcs( s, q->pic, P, 1 ); } );
@@ -476,13 +486,13 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   }
   else if( dbOn )
   {
-    timed( K_DEBLOCK_V, [&]{ launch_deblock( s, q->pic, P, 0 ); } );
-    timed( K_DEBLOCK_H, [&]{ launch_deblock( s, q->pic, P, 1 ); } );
+    timedOn( K_DEBLOCK4, s, q->bytes[K_DEBLOCK_V], [&]{ launch_deblock( s, q->pic, P, 0 ); } );
+    timedOn( K_DEBLOCK4, s, q->bytes[K_DEBLOCK_H], [&]{ launch_deblock( s, q->pic, P, 1 ); } );
   }
   if( fused ) timed( K_ALF, [&]{ launch_sao_alf( s, q->pic, hop ? R : B, A, sao, alf ); } );
-  else if( sao && alf ) { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
+  else if( sao && alf ) { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timedOn( K_ALF_PLANES, s, q->bytes[K_ALF], [&]{ launch_alf( s, q->pic, B, A ); } ); }
   else if( sao )   { timed( K_SAO, [&]{ launch_sao( s, q->pic, A, B ); } ); timed( K_COPY, [&]{ launch_copy_planes( s, B, A ); } ); }
-  else if( alf )   { timed( K_COPY, [&]{ launch_copy_planes( s, A, B ); } ); timed( K_ALF, [&]{ launch_alf( s, q->pic, B, A ); } ); }
+  else if( alf )   { timed( K_COPY, [&]{ launch_copy_planes( s, A, B ); } ); timedOn( K_ALF_PLANES, s, q->bytes[K_ALF], [&]{ launch_alf( s, q->pic, B, A ); } ); }
 #ifdef VVR_WATCHDOG
   const double wdD = wdNow(); g_wdPart[2] += wdD - wdC; g_wdPartMax[2] = std::max( g_wdPartMax[2], wdD - wdC );
 #endif
@@ -984,8 +994,11 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
   c->numLanesRR = ns; c->prioLane = nl > ns ? ns : -1;
   if( const char* e = getenv( "VVR_PARTS" ) ) c->partsPolicy = atoi( e );      // 0 / 1 / 2: see partsPolicy
   if( const char* e = getenv( "VVR_INTRA_LEAF" ) ) c->intraLeaf = atoi( e ) != 0;
+#ifdef VVR_DEV_ENV
+  // two experiments of round 5, measured and left off: switchable in the developer build only
   if( const char* e = getenv( "VVR_LEAF_BY_LEVEL" ) ) c->leafByLevel = atoi( e ) != 0;
   if( const char* e = getenv( "VVR_INTRA_FINE" ) ) c->intraFine = atoi( e ) != 0;
+#endif
   c->streams.resize( nl, nullptr );
   bool ok = true;
   for( int i = 0; i < ns && ok; i++ ) ok = hipStreamCreateWithFlags( &c->streams[i], hipStreamNonBlocking ) == hipSuccess;
@@ -1025,6 +1038,7 @@ VVR_API int vvr_create( const vvr_config* cfg, vvr_context** out )
       const int vl = std::min<int>( 6, cfg->log2_ctu ), vpdus = ( ( cfg->max_width + ( 1 << vl ) - 1 ) >> vl ) * ( ( cfg->max_height + ( 1 << vl ) - 1 ) >> vl );
       c->leafMapInts = intra_leaf_map_ints( c->leafW4, c->leafH4, vpdus );
       for( int s = 0; s < nl && ok; s++ ) { uint32_t* p = nullptr; ok = hipMalloc( (void**) &p, sizeof( uint32_t ) * c->leafMapInts ) == hipSuccess && hipMemset( p, 0, sizeof( uint32_t ) * c->leafMapInts ) == hipSuccess; if( p ) c->leafMaps.push_back( p ); }
+      if( ok ) { ok = hipHostMalloc( (void**) &c->errHost, sizeof( int ) * VVR_ERR_WORDS, hipHostMallocDefault ) == hipSuccess; if( ok ) memset( c->errHost, 0, sizeof( int ) * VVR_ERR_WORDS ); }
     }
   }
   if( ok )
@@ -1103,6 +1117,7 @@ VVR_API void vvr_destroy( vvr_context* c )
   if( c->outStream ) hipStreamDestroy( c->outStream );
   for( auto p : c->syncBuf ) hipFree( p );
   for( auto p : c->leafMaps ) hipFree( p );
+  if( c->errHost ) hipHostFree( c->errHost );
   if( c->inlineScratch ) vvr_scratch_destroy( c->inlineScratch );
   for( auto& e : c->pinned.r ) hipHostFree( (void*) e.first );
   delete c;
@@ -1355,13 +1370,7 @@ VVR_API int vvr_sync( vvr_context* c )
   for( int id : ids ) { const int r = finishJob( c, id ); if( r != VVR_OK && rc == VVR_OK ) rc = r; }
   if( rc != VVR_OK ) return rc;
   for( auto s : c->streams ) HIPCHK( c, hipStreamSynchronize( s ) );
-  // k_intra_leaf bounds every wait for a neighbouring block: a wavefront that gave up has said so in the lane's error word
-  for( size_t lane = 0; lane < c->leafMaps.size(); lane++ )
-  {
-    int word = 0;
-    HIPCHK( c, hipMemcpy( &word, c->leafMaps[lane] + c->leafMapInts - 63, sizeof( int ), hipMemcpyDeviceToHost ) );
-    if( word ) { hipMemset( c->leafMaps[lane], 0, sizeof( uint32_t ) * c->leafMapInts ); c->setError( "intra stage: a block waited for its neighbours beyond the bound (dependency that never completed)" ); return VVR_ERR_DEVICE; }
-  }
+  // (a wait of the intra stage that gave up fails the picture's own job: completeLocked reads the job's error word - vvr_wait, vvr_test, vvr_read_* and this call all see it)
   // external events that are complete are forgotten here (the caller may destroy them after this call, vvr.h)
   { std::lock_guard<std::mutex> lk( c->mu ); for( int slot = 0; slot < (int) c->slotExt.size(); slot++ ) pruneExternalEventsLocked( c, slot ); }
   return VVR_OK;

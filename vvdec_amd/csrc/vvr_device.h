@@ -146,7 +146,7 @@ void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, Dev
 void launch_mc_rpr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems );      // tiles of CUs with a scaled reference picture
 void launch_mc_dmvr( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, int32_t* dmvrOut );
 void launch_intra  ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numUnits, int ticket0, int ticket1, int numWorkgroups, int* sync, int wide,
-                     uint32_t* maps = nullptr, size_t mapInts = 0, int mapW4 = 0, int mapH4 = 0 );      // maps (a picture whose units are all whole CTUs of intra CUs): the per-cell words - the CTU wavefront is resolved block by block (k_intra<.., FINE>)      // the units [ticket0, ticket1); wide: an I picture the stream waits for (eight wavefronts per workgroup)
+                     uint32_t* maps = nullptr, size_t mapInts = 0, int mapW4 = 0, int mapH4 = 0, int* errWord = nullptr );      // maps (a picture whose units are all whole CTUs of intra CUs): the per-cell words - the CTU wavefront is resolved block by block (k_intra<.., FINE>)      // the units [ticket0, ticket1); wide: an I picture the stream waits for (eight wavefronts per workgroup)
 void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems );      // scaled chroma residuals of inter blocks (between the luma and the chroma units)
 size_t intra_sync_ints( int numUnits, int numItems );      // ints `sync` has to hold: ticket, unit flags, the blocks' parameter records
 // the intra stage of a picture with scattered intra blocks (vvr_intra_leaf.inc): one wavefront per block of `items` (decoding order per component), ordered through
@@ -154,5 +154,5 @@ size_t intra_sync_ints( int numUnits, int numItems );      // ints `sync` has to
 #define IT_MODE_CSFAC 253      /* mode value: the LMCS chroma scaling factor of VPDU IntraItem::tu (no samples) */
 size_t intra_leaf_map_ints( int w4, int h4, int vpdus );
 void launch_intra_leaf( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraItem* resiItems, int numResi /* residual-add blocks grouped by VPDU: done by the VPDU's IT_MODE_CSFAC item */,
-                        uint32_t* maps, size_t mapInts, int mapW4, int mapH4 );
+                        uint32_t* maps, size_t mapInts, int mapW4, int mapH4, int* errWord /* the job's error word: pinned host memory the device writes when a bounded wait gave up */ );
 

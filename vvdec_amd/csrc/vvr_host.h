@@ -8,7 +8,8 @@
 
 static inline size_t alignUp( size_t v, size_t a ) { return ( v + a - 1 ) / a * a; }
 
-enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_RESI_ADD, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_OUTPUT, K_LF_INIT, K_INTRA_LEAF, K_NUM };
+enum { K_MC, K_MC_DMVR, K_MC_AFFINE, K_LMCS, K_ITRANS, K_INTRA, K_RESI_ADD, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_ALF, K_COPY, K_OUTPUT, K_LF_INIT, K_INTRA_LEAF,
+       K_DEBLOCK4, K_ALF_PLANES /* the chain of the pictures the fused passes do not cover: k_deblock4 in place, k_alf_luma + k_alf_chroma(_tile) */, K_NUM };
 
 // A picture description resident in HBM together with its device work lists: every pointer is a device address inside one blob.
 // Streaming submissions (vvr_submit) use the blob of a ring entry owned by the context; vvr_prepare gives the handle a blob of its own.

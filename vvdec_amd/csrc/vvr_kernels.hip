@@ -18,7 +18,8 @@ namespace tbl {
 namespace {
 
 __device__ __forceinline__ int clip3( int lo, int hi, int v ) { return v < lo ? lo : ( v > hi ? hi : v ); }
-__device__ __forceinline__ int clip_pel( int v, int bd ) { return clip3( 0, ( 1 << bd ) - 1, v ); }
+// clip to the sample range: ONE v_med3_i32 (the compiler cannot prove 0 <= 2^bd - 1 for a run-time bit depth and emits min / compare / select)
+__device__ __forceinline__ int clip_pel( int v, int bd ) { const int hi = ( 1 << bd ) - 1; int r; asm( "v_med3_i32 %0, %1, 0, %2" : "=v"( r ) : "v"( v ), "v"( hi ) ); return r; }
 __device__ __forceinline__ int iabs( int v ) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int ilog2( int v ) { return 31 - __clz( v ); }
 __device__ __forceinline__ int sgn( int v ) { return ( v > 0 ) - ( v < 0 ); }
@@ -248,40 +249,6 @@ __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg
   }
 }
 
-// the two chroma windows of a list (same geometry, at most 16 columns): Cb in the lower, Cr in the upper half of every 32 lanes when the window lies
-// inside the picture; else one after the other
-template<int NT>
-__device__ __forceinline__ void mc_load_window_c2( pel_t* winCb, pel_t* winCr, int wst, const McSeg& gCb, const McSeg& gCr, const pel_t* __restrict__ refCb, const pel_t* __restrict__ refCr,
-                                                   int stride, int pw, int ph, int tid )
-{
-  const McSeg& g = gCb;
-  const int ux0 = __builtin_amdgcn_readfirstlane( g.x0 ), uy0 = __builtin_amdgcn_readfirstlane( g.y0 ), uww = __builtin_amdgcn_readfirstlane( g.ww ), uwh = __builtin_amdgcn_readfirstlane( g.wh );
-  const int plain = __builtin_amdgcn_readfirstlane( uww <= 16 && ( g.wrapOff | g.padOff | g.shX | g.shY ) == 0 && g.cw == g.ww && g.chh == g.wh
-                                                    && g.x0 >= g.bx0 && g.x0 + g.ww - 1 <= g.bx1 && g.y0 >= g.by0 && g.y0 + g.wh - 1 <= g.by1 );
-  if( !plain )
-  {
-    mc_load_window<NT>( winCb, wst, gCb, refCb, stride, pw, ph, tid );
-    mc_load_window<NT>( winCr, wst, gCr, refCr, stride, pw, ph, tid );
-    return;
-  }
-  const int col = tid & 15, cr = ( tid >> 4 ) & 1, row0 = tid >> 5;
-  if( col < uww )
-  {
-    constexpr int RS = NT / 32;
-    const pel_t* __restrict__ rp = ( cr ? refCr : refCb ) + (size_t) uy0 * stride + ux0 + col;
-    pel_t* wp = ( cr ? winCr : winCb ) + col;
-    const int last = uwh - 1 - ( ( uwh - 1 - row0 ) % RS );
-    for( int yb = row0; yb < uwh; yb += 4 * RS )
-    {
-      int yy[4]; pel_t v[4];
-#pragma unroll
-      for( int u = 0; u < 4; u++ ) { yy[u] = min( yb + u * RS, last ); v[u] = rp[yy[u] * stride]; }
-#pragma unroll
-      for( int u = 0; u < 4; u++ ) wp[yy[u] * wst] = v[u];
-    }
-  }
-}
-
 // BDOF of one <= 16x16 luma tile (applyBiOptFlow :1290, gradFilterCore :213, BiOptFlowCore :162, calcBIOSums :134, addBIOAvg4 :108);
 // the windows must hold the integer samples around the block (ox, oy >= 1 beyond the filter support)
 struct BdofShared {
@@ -402,6 +369,10 @@ __device__ __forceinline__ int mc_dot2( uint32_t a, uint32_t b, int c )
   return __builtin_amdgcn_sdot2( __builtin_bit_cast( s2v, a ), __builtin_bit_cast( s2v, b ), c, false );
 }
 
+__device__ __forceinline__ int mc_dot2_init( uint32_t a, uint32_t b, int initUniform )
+{
+  int r; asm( "v_dot2_i32_i16 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( b ), "s"( initUniform ) ); return r;
+}
 // rows of d_mcTaps: luma (frac 0..15) regular / for 4x4 blocks / with the alternative half-sample filter at frac 8 / both; chroma (frac 0..31), taps 4..7 zero
 #define MCT_REG    0
 #define MCT_4X4    16
@@ -432,10 +403,11 @@ __device__ __forceinline__ void mc_fir8( const uint4 lo, const uint4 hi, const u
   uint32_t S[7];
 #pragma unroll
   for( int i = 0; i < 7; i++ ) S[i] = __builtin_amdgcn_alignbit( D[i + 1], D[i], 16 );
+  // the first tap takes the start value as the third operand of the three-address form (a uniform value in a scalar register): no register to initialise per output
 #pragma unroll
-  for( int j = 0; j < 8; j++ ) out[j] = init;
+  for( int m = 0; m < 4; m++ ) { out[2 * m] = mc_dot2_init( D[m], C[0], init ); out[2 * m + 1] = mc_dot2_init( S[m], C[0], init ); }
 #pragma unroll
-  for( int t = 0; t < NTAPS / 2; t++ )
+  for( int t = 1; t < NTAPS / 2; t++ )
   {
 #pragma unroll
     for( int m = 0; m < 4; m++ ) { out[2 * m] = mc_dot2( D[m + t], C[t], out[2 * m] ); out[2 * m + 1] = mc_dot2( S[m + t], C[t], out[2 * m + 1] ); }
@@ -477,6 +449,12 @@ struct Mc2Shared {
 // what the stages need to know about the filters of a tile: rows of d_mcTaps per list, [luma, chroma]
 struct McTapRows { int h[2][2], v[2][2]; };
 
+// a pointer that is the same for every lane, moved to scalar registers
+template<class P> __device__ __forceinline__ P* mc_uniform_ptr( P* p )
+{
+  const uint64_t a = (uint64_t) p;
+  return (P*) ( (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane( (int) (uint32_t) a ) | ( (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane( (int) ( a >> 32 ) ) << 32 ) );
+}
 // ---- windows of a tile that lies inside the picture: dword loads, 16 (luma) / 8 (chroma) lanes per window row --------------------
 __device__ __forceinline__ uint32_t mc_dpp_next_lane( uint32_t v ) { return (uint32_t) __builtin_amdgcn_update_dpp( 0, (int) v, 0x101 /* row_shl:1 */, 0xf, 0xf, true ); }
 
@@ -487,27 +465,27 @@ __device__ __forceinline__ void mc3_load_luma( pel_t* __restrict__ win, const pe
   const int odd = x0 & 1, sh = odd << 4;
   const int ndw = ( ww + 1 + odd ) >> 1;              // dwords read per row: samples x0 - odd .. x0 - odd + 2 ndw - 1
   const int nst = ( ww + 1 ) >> 1;                    // dwords kept per row
-  const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>( ref + (size_t) y0 * stride + ( x0 - odd ) ) + q;
-  uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( win ) + q;
-  const int sd = stride >> 1;
-  constexpr int RP = NT / 16;                         // rows per pass
-  const int np = ( wh + RP - 1 ) / RP;                // (uniform)
-  uint32_t v[6]; int rr[6];
+  const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>( ref + (size_t) y0 * stride + ( x0 - odd ) );
+  uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( win );
+  const uint32_t sd = (uint32_t) stride >> 1;
+  constexpr int RP = NT / 16, NP = ( 23 + RP - 1 ) / RP;      // rows per pass; passes of a 23-row window
+  const int last = wh - 1 - ( max( wh - 1 - r0, 0 ) % RP );    // the last row of this lane's residue class: the tail repeats it (same value to the same place), no branch
+  const bool tall = wh > 4 * RP;                               // (uniform: a tile of 4 or 8 rows needs at most 15 window rows)
+  uint32_t v[NP]; int rr[NP];
 #pragma unroll
-  for( int i = 0; i < 6; i++ )
+  for( int i = 0; i < NP; i++ )
   {
-    rr[i] = min( r0 + i * RP, wh - 1 );               // (the tail repeats the last row: same value to the same place)
+    rr[i] = min( r0 + i * RP, last );
     v[i] = 0;
-    if( i * RP < wh && q < ndw ) v[i] = base[rr[i] * sd];
+    if( ( i < 4 || tall ) && q < ndw ) v[i] = base[__umul24( (uint32_t) rr[i], sd ) + (uint32_t) q];
   }
+  uint32_t w[NP];
 #pragma unroll
-  for( int i = 0; i < 6; i++ )
+  for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v[i] ), v[i], sh );
+  if( q < nst )
   {
-    if( i * RP < wh )
-    {
-      const uint32_t w = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v[i] ), v[i], sh );
-      if( q < nst ) wdw[rr[i] * ( MC2_WST_L / 2 )] = w;
-    }
+#pragma unroll
+    for( int i = 0; i < NP; i++ ) if( i < 4 || tall ) wdw[__umul24( (uint32_t) rr[i], MC2_WST_L / 2 ) + (uint32_t) q] = w[i];
   }
 }
 // Cb and Cr windows of a list (same geometry): 8 lanes per row, the rows of Cb, then those of Cr
@@ -518,35 +496,85 @@ __device__ __forceinline__ void mc3_load_chroma( pel_t* __restrict__ winCb /* Cr
   const int odd = x0 & 1, sh = odd << 4;
   const int ndw = ( ww + 1 + odd ) >> 1, nst = ( ww + 1 ) >> 1;
   const size_t off = (size_t) y0 * stride + ( x0 - odd );
-  const int sd = stride >> 1;
-  constexpr int RP = NT / 8;
-  uint32_t v[3]; int wo[3];
+  const uint32_t sd = (uint32_t) stride >> 1;
+  constexpr int RP = NT / 8, NP = ( 22 + RP - 1 ) / RP;        // 2 x 11 rows at most
+  const int last = 2 * wh - 1 - ( max( 2 * wh - 1 - r0, 0 ) % RP );
+  uint32_t v[NP]; uint32_t wo[NP];
 #pragma unroll
-  for( int i = 0; i < 3; i++ )
+  for( int i = 0; i < NP; i++ )
   {
-    const int r2 = min( r0 + i * RP, 2 * wh - 1 ), cc = r2 >= wh, r = r2 - ( cc ? wh : 0 );
-    const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>( ( cc ? refCr : refCb ) + off ) + q;
-    wo[i] = ( cc ? 12 * ( MC2_WST_C / 2 ) : 0 ) + r * ( MC2_WST_C / 2 );
+    const int r2 = min( r0 + i * RP, last ), cc = r2 >= wh, r = r2 - ( cc ? wh : 0 );
+    const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>( ( cc ? refCr : refCb ) + off );
+    wo[i] = ( cc ? 12 * ( MC2_WST_C / 2 ) : 0 ) + r * ( MC2_WST_C / 2 ) + q;
     v[i] = 0;
-    if( i * RP < 2 * wh && q < ndw ) v[i] = base[r * sd];
+    if( q < ndw ) v[i] = base[__umul24( (uint32_t) r, sd ) + (uint32_t) q];
   }
-  uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( winCb ) + q;
+  uint32_t w[NP];
 #pragma unroll
-  for( int i = 0; i < 3; i++ )
+  for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v[i] ), v[i], sh );
+  uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( winCb );
+  if( q < nst )
   {
-    if( i * RP < 2 * wh )
-    {
-      const uint32_t w = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v[i] ), v[i], sh );
-      if( q < nst ) wdw[wo[i]] = w;
-    }
+#pragma unroll
+    for( int i = 0; i < NP; i++ ) wdw[wo[i]] = w[i];
   }
 }
 
+// the windows of a segment record (k_mc's other tiles, k_mc_dmvr): the dword loader where the window lies inside what may be read and is no displaced copy, else sample by sample
+__device__ __forceinline__ bool mc_seg_plain( const McSeg& g, int stride )
+{
+  const int odd = g.x0 & 1;
+  const bool pl = ( g.wrapOff | g.padOff | g.shX | g.shY ) == 0 && g.cw == g.ww && g.chh == g.wh && g.x0 >= g.bx0 && g.y0 >= g.by0 && g.x0 + g.ww - 1 <= g.bx1 && g.y0 + g.wh - 1 <= g.by1
+                  && g.x0 - odd + 2 * ( ( g.ww + 1 + odd ) >> 1 ) <= stride;
+  return __builtin_amdgcn_readfirstlane( pl ) != 0;
+}
+template<int NT>
+__device__ __forceinline__ void mc_load_seg_luma( pel_t* win, const McSeg& g, const pel_t* ref, int stride, int pw, int ph, int tid )
+{
+  if( mc_seg_plain( g, stride ) )
+    mc3_load_luma<NT>( win, mc_uniform_ptr( ref ), stride, __builtin_amdgcn_readfirstlane( g.x0 ), __builtin_amdgcn_readfirstlane( g.y0 ), __builtin_amdgcn_readfirstlane( g.ww ), __builtin_amdgcn_readfirstlane( g.wh ), tid );
+  else mc_load_window<NT>( win, MC2_WST_L, g, ref, stride, pw, ph, tid );
+}
+template<int NT>
+__device__ __forceinline__ void mc_load_seg_chroma( pel_t* winCb, pel_t* winCr, const McSeg& gCb, const McSeg& gCr, const pel_t* refCb, const pel_t* refCr, int stride, int pw, int ph, int tid )
+{
+  if( mc_seg_plain( gCb, stride ) )
+    mc3_load_chroma<NT>( winCb, mc_uniform_ptr( refCb ), mc_uniform_ptr( refCr ), stride, __builtin_amdgcn_readfirstlane( gCb.x0 ), __builtin_amdgcn_readfirstlane( gCb.y0 ), __builtin_amdgcn_readfirstlane( gCb.ww ),
+                           __builtin_amdgcn_readfirstlane( gCb.wh ), tid );
+  else { mc_load_window<NT>( winCb, MC2_WST_C, gCb, refCb, stride, pw, ph, tid ); mc_load_window<NT>( winCr, MC2_WST_C, gCr, refCr, stride, pw, ph, tid ); }
+}
 // ---- stage 1: horizontal filter of every window row to 14-bit intermediates, two rows x eight columns per work item --------------
 template<int NT>
 __device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int tw, int th, int headroom, int tid, const McTapRows& T )
 {
-  const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
+  const int shift1 = 6 - headroom, offset1 = __builtin_amdgcn_readfirstlane( -IF_INTERNAL_OFFS * ( 1 << shift1 ) );
+  {
+    // When the luma and the chroma work items of the tile fit into one pass of the workgroup (one prediction list, small tiles, two wavefronts per tile), the
+    // chroma row pairs go through the eight-tap code beside the luma ones (taps 4..7 of a chroma row of d_mcTaps are zero, a chroma window row holds 16 samples)
+    const int lgU = tw > 8 ? 1 : 0, perL = ( ( th + 8 ) >> 1 ) << lgU, nA = nl * perL;
+    const int rpCU = ( ( th >> 1 ) + 4 ) >> 1, perC = 2 * rpCU, nB = ncomp == 3 ? nl * perC : 0;
+    if( nA + nB <= NT )
+    {
+      if( tid < nA + nB )
+      {
+        const bool isC = tid >= nA;
+        const int h0L = T.h[0][0], h1L = T.h[1][0], h0C = T.h[0][1], h1C = T.h[1][1];      // (values first: a per-lane choice between struct members would put the struct into scratch)
+        int k; const pel_t* src; uint32_t* dst;
+        if( !isC ) { k = tid >= perL; const int r0 = tid - ( k ? perL : 0 ), rp = r0 >> lgU, g = r0 & lgU; src = &m.winL[k][2 * rp * MC2_WST_L + 8 * g]; dst = &m.tmpL[k][8 * g * MC3_TPL + rp]; }
+        else { int q = tid - nA; k = q >= perC; q -= k ? perC : 0; const int cc = q >= rpCU, rp = q - ( cc ? rpCU : 0 ); src = &m.winC[k][cc][2 * rp * MC2_WST_C]; dst = &m.tmpC[2 * k + cc][rp]; }
+        const int tapRow = isC ? ( k ? h1C : h0C ) : ( k ? h1L : h0L );
+        const int ws = isC ? MC2_WST_C : MC2_WST_L, cs = isC ? MC3_TPC : MC3_TPL;
+        const uint4 C = d_mcTaps[tapRow];
+        int a[8], b[8];
+        mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), C, offset1, a );
+        mc_fir8<8>( *reinterpret_cast<const uint4*>( src + ws ), *reinterpret_cast<const uint4*>( src + ws + 8 ), C, offset1, b );
+#pragma unroll
+        for( int j = 0; j < 8; j++ ) dst[j * cs] = __builtin_amdgcn_perm( (uint32_t) ( b[j] >> shift1 ), (uint32_t) ( a[j] >> shift1 ), 0x05040100u );
+      }
+      __syncthreads();
+      return;
+    }
+  }
   {
     const int lg = tw > 8 ? 1 : 0;                    // a 16-wide tile has two groups of eight columns
     const int perList = ( ( th + 8 ) >> 1 ) << lg;    // th + 7 window rows in pairs
@@ -597,7 +625,12 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
   const int lwL = wL == 16 ? 4 : wL == 8 ? 3 : 2;
   const int itemsL = wL * ( ( hL + 7 ) >> 3 ), itemsC = ncomp == 3 ? 2 * wC : 0;            // chroma: at most 8 rows = one group
   const bool full = hL == 16;                          // every work item has eight rows (luma 2 x 8, chroma 8)
+  // (uniform values in scalar registers: a per-lane choice between kernel arguments would become a load from the argument segment)
+  const uint32_t st0 = (uint32_t) __builtin_amdgcn_readfirstlane( reco.stride[0] ), st1 = (uint32_t) __builtin_amdgcn_readfirstlane( reco.stride[1] );
+  pel_t* const p0 = mc_uniform_ptr( reco.p[0] ); pel_t* const p1 = mc_uniform_ptr( reco.p[1] ); pel_t* const p2 = mc_uniform_ptr( reco.p[2] );
+  const int16_t* __restrict__ const fwdU = mc_uniform_ptr( fwdLut );
   const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
+  const int init2 = __builtin_amdgcn_readfirstlane( mode == MCM_UNI ? offset2 : 0 );
   for( int idx = tid; idx < itemsL + itemsC; idx += NT )
   {
     int c, x, g8;
@@ -611,7 +644,7 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
       {
         const uint32_t* src = c ? &m.tmpC[2 * k + c - 1][x * MC3_TPC] : &m.tmpL[k][x * MC3_TPL + 4 * g8];
         const uint4 C = d_mcTaps[c ? T.v[k][1] : T.v[k][0]];         // (chroma: taps 4..7 are zero)
-        mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 4 ), C, mode == MCM_UNI ? offset2 : 0, p[k] );
+        mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 4 ), C, init2, p[k] );
       }
     }
     if( bsp && c == 0 )
@@ -671,23 +704,24 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
 #pragma unroll
       for( int i = 0; i < 8; i++ ) out[i] = wp_bi( wp, wpR0, wpR1, c, p[0][i] >> 6, p[1][i] >> 6, bd, headroom );
     }
-    if( fwdLut )
+    if( fwdU && c == 0 )
     {
-      // LMCS: luma predictions are stored forward-mapped (chroma lanes look their - valid - values up as well and keep them: no divergence)
+      // LMCS: luma predictions are stored forward-mapped
 #pragma unroll
-      for( int i = 0; i < 8; i++ ) { const int v = fwdLut[out[i]]; out[i] = c ? out[i] : v; }
+      for( int i = 0; i < 8; i++ ) out[i] = fwdU[(uint32_t) out[i] & 0xfffu];
     }
-    const int st = c ? reco.stride[1] : reco.stride[0];
-    pel_t* dstp = ( c == 0 ? reco.p[0] : c == 1 ? reco.p[1] : reco.p[2] ) + (size_t) ( ( ty >> cs ) + 8 * g8 ) * st + ( tx >> cs ) + x;
+    const uint32_t st = c ? st1 : st0;
+    pel_t* const dstp = c == 0 ? p0 : c == 1 ? p1 : p2;
+    const uint32_t o0 = __umul24( (uint32_t) ( ( ty >> cs ) + 8 * g8 ), st ) + (uint32_t) ( ( tx >> cs ) + x );      // (a plane has fewer than 2^24 rows and columns; the product needs 32 bits: mul24 keeps the low 32)
     if( full )
     {
 #pragma unroll
-      for( int i = 0; i < 8; i++ ) dstp[(size_t) i * st] = (pel_t) out[i];
+      for( int i = 0; i < 8; i++ ) dstp[o0 + (uint32_t) i * st] = (pel_t) out[i];
     }
     else
     {
 #pragma unroll
-      for( int i = 0; i < 8; i++ ) if( i < nrows ) dstp[(size_t) i * st] = (pel_t) out[i];
+      for( int i = 0; i < 8; i++ ) if( i < nrows ) dstp[o0 + (uint32_t) i * st] = (pel_t) out[i];
     }
   }
 }
@@ -803,8 +837,8 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
     for( int k = 0; k < 2; k++ )
     {
       if( k >= nl ) break;
-      mc_load_window<NT>( m.winL[k], MC2_WST_L, m.seg[k][0], m.refp[k][0], reco.stride[0], reco.w[0], reco.h[0], tid );
-      if( ncomp == 3 ) mc_load_window_c2<NT>( m.winC[k][0], m.winC[k][1], MC2_WST_C, m.seg[k][1], m.seg[k][2], m.refp[k][1], m.refp[k][2], reco.stride[1], reco.w[1], reco.h[1], tid );
+      mc_load_seg_luma<NT>( m.winL[k], m.seg[k][0], m.refp[k][0], reco.stride[0], reco.w[0], reco.h[0], tid );
+      if( ncomp == 3 ) mc_load_seg_chroma<NT>( m.winC[k][0], m.winC[k][1], m.seg[k][1], m.seg[k][2], m.refp[k][1], m.refp[k][2], reco.stride[1], reco.w[1], reco.h[1], tid );
       T.h[k][0] = mc_tap_row( 0, MC_U( m.seg[k][0].xFrac ), f4, altHpel ); T.v[k][0] = mc_tap_row( 0, MC_U( m.seg[k][0].yFrac ), f4, altHpel );
       if( ncomp == 3 ) { T.h[k][1] = mc_tap_row( 1, MC_U( m.seg[k][1].xFrac ), false, false ); T.v[k][1] = mc_tap_row( 1, MC_U( m.seg[k][1].yFrac ), false, false ); }
     }
@@ -887,7 +921,7 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
     sh.m.refp[l][0] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][0];
   }
   __syncthreads();
-  for( int l = 0; l < 2; l++ ) mc_load_window<NT>( sh.m.winL[l], DM_WST_L, sh.m.seg[l][0], sh.m.refp[l][0], reco.stride[0], reco.w[0], reco.h[0], tid );
+  for( int l = 0; l < 2; l++ ) mc_load_seg_luma<NT>( sh.m.winL[l], sh.m.seg[l][0], sh.m.refp[l][0], reco.stride[0], reco.w[0], reco.h[0], tid );
   __syncthreads();
   {
     // InterpolationFilter::filter<2> (:589-600) / filterCopy biMCForDMVR (:445-477) at IF_INTERNAL_PREC_BILINEAR = 10
@@ -1032,8 +1066,11 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
     }
   }
   __syncthreads();
-  for( int k = 0; k < 2; k++ ) for( int c = 0; c < ncomp; c++ )
-    mc_load_window<NT>( c ? sh.m.winC[k][c - 1] : sh.m.winL[k], c ? MC2_WST_C : MC2_WST_L, sh.m.seg[k][c], sh.m.refp[k][c], reco.stride[c], reco.w[c], reco.h[c], tid );
+  for( int k = 0; k < 2; k++ )
+  {
+    mc_load_seg_luma<NT>( sh.m.winL[k], sh.m.seg[k][0], sh.m.refp[k][0], reco.stride[0], reco.w[0], reco.h[0], tid );
+    if( ncomp == 3 ) mc_load_seg_chroma<NT>( sh.m.winC[k][0], sh.m.winC[k][1], sh.m.seg[k][1], sh.m.seg[k][2], sh.m.refp[k][1], sh.m.refp[k][2], reco.stride[1], reco.w[1], reco.h[1], tid );
+  }
   __syncthreads();
   McTapRows T;
 #pragma unroll
@@ -2186,7 +2223,7 @@ void launch_itrans( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes 
 }
 
 // =====================================================================================================================
-// k_deblock — one thread per 4x4 luma unit (= one 4-sample edge segment) and direction.
+// deblocking: the edge decisions and filters shared by k_deblock_tile (a tile per workgroup, out of place) and k_deblock4 (in place).
 //   LoopFilter::xDeblockCtuArea (LoopFilter.cpp:419), xEdgeFilterLuma (:1464), xEdgeFilterChroma (:1620) and the
 //   filters :106-335.  All edges of one direction are independent for a valid edge-parameter table (maximum filter
 //   lengths never overlap, :910-922), so the whole picture is one launch per direction.
@@ -2321,122 +2358,14 @@ __device__ __forceinline__ void filter_chroma_pel( pel_t* s, int o, int tc, bool
 
 __device__ __forceinline__ int tc_value( int idx, int bd ) { const int t = d_db_tc_table[idx]; return bd < 10 ? ( t + ( 1 << ( 9 - bd ) ) ) >> ( 10 - bd ) : t << ( bd - 10 ); }
 
-// luma filtering of the 4-sample edge segment at 4x4 unit (x4, y4)
-__device__ __forceinline__ void deblock_luma_segment( const PicDev& pic, const DevPlanes& r, int dir, int x4, int y4, const vvr_lfp& l )
-{
-  const vvr_pic_header& H = pic.hdr;
-  const int bd = H.bit_depth;
-  const int bsY = BS_GET( l.bs, 0 );
-  const int stride = r.stride[0], x = x4 * 4, y = y4 * 4;
-  pel_t* src = r.p[0] + (size_t) y * stride + x;
-  const int o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
-  int qp = l.qp[0];
-  if( H.ladf_num_intervals )
-  {
-    // luma-adaptive deblocking: QP offset chosen by the mean of four samples at the corners of the segment (deriveLADFShift, LoopFilter.cpp:1363-1386)
-    const int level = ( src[0] + src[3 * step] + src[-o] + src[3 * step - o] ) >> 2;
-    int shift = H.ladf_qp_offset[0];
-    for( int k = 1; k < H.ladf_num_intervals; k++ ) { if( level > H.ladf_lower_bound[k] ) shift = H.ladf_qp_offset[k]; else break; }
-    qp += shift;
-  }
-  const int lenP = ( l.side_max_filt_length >> 4 ) & 7, lenQ = l.side_max_filt_length & 7;
-  bool pLarge = lenP > 3, qLarge = lenQ > 3;
-  if( dir == 1 && ( y & ( ( 1 << H.log2_ctu ) - 1 ) ) == 0 ) pLarge = false;
-  // the offsets of the slice the deblocked CTU belongs to - the CTU that holds the segment, its Q side (LoopFilter.cpp:421,1473)
-  const int offs = deblock_offsets_at( pic, x, y, 0 );
-  const int idxTC = clip3( 0, 65, qp + 2 * ( bsY - 1 ) + 2 * ( ( offs >> 8 ) - 64 ) );
-  const int idxB  = clip3( 0, 63, qp + 2 * ( ( offs & 255 ) - 64 ) );
-  const int tc = tc_value( idxTC, bd ), beta = d_db_beta_table[idxB] << ( bd - 8 );
-  const int sideThr = ( beta + ( beta >> 1 ) ) >> 3, thrCut = tc * 10;
-  const pel_t* s0 = src; const pel_t* s3 = src + 3 * step;
-  const int dp0 = calc_dp( s0, o ), dq0 = calc_dq( s0, o ), dp3 = calc_dp( s3, o ), dq3 = calc_dq( s3, o );
-  const int d0 = dp0 + dq0, d3 = dp3 + dq3;
-  if( pLarge || qLarge )
-  {
-    const int o3 = 3 * o;
-    const int dp0L = pLarge ? ( dp0 + calc_dp( s0 - o3, o ) + 1 ) >> 1 : dp0;
-    const int dq0L = qLarge ? ( dq0 + calc_dq( s0 + o3, o ) + 1 ) >> 1 : dq0;
-    const int dp3L = pLarge ? ( dp3 + calc_dp( s3 - o3, o ) + 1 ) >> 1 : dp3;
-    const int dq3L = qLarge ? ( dq3 + calc_dq( s3 + o3, o ) + 1 ) >> 1 : dq3;
-    const int d0L = dp0L + dq0L, d3L = dp3L + dq3L, dL = d0L + d3L;
-    if( dL < beta )
-    {
-      const bool swL = use_strong( s0, o, 2 * d0L, beta, tc, pLarge, qLarge, lenP, lenQ, false ) && use_strong( s3, o, 2 * d3L, beta, tc, pLarge, qLarge, lenP, lenQ, false );
-      if( swL ) { filter_long( src, step, o, pLarge ? lenP : 3, qLarge ? lenQ : 3, tc ); return; }
-    }
-  }
-  const int dp = dp0 + dp3, dq = dq0 + dq3, d = d0 + d3;
-  if( d < beta )
-  {
-    bool fP = false, fQ = false, sw = false;
-    if( lenP > 1 && lenQ > 1 ) { fP = dp < sideThr; fQ = dq < sideThr; }
-    if( lenP > 2 && lenQ > 2 ) sw = use_strong( s0, o, 2 * d0, beta, tc, false, false, 7, 7, false ) && use_strong( s3, o, 2 * d3, beta, tc, false, false, 7, 7, false );
-    for( int i = 0; i < 4; i++ ) filter_luma_pel( src + step * i, o, tc, sw, thrCut, fP, fQ, bd );
-  }
-}
-
 // An edge whose P side may be filtered over 7 samples reaches the samples of a coding-sub-block edge 8 samples before it
 // (SbTMVP CU on the P side: the reference keeps 7 there, LoopFilter.cpp:920, and filters the edges of a CTU in raster
 // order, :447-462, so the sub-block edge comes first).  Such a pair is handled by ONE thread, in that order; every other
 // pair of edges of one direction touches disjoint samples.
 __device__ __forceinline__ bool db_luma_p7( const vvr_lfp& l ) { return BS_GET( l.bs, 0 ) && ( ( l.side_max_filt_length >> 4 ) & 7 ) == 7; }
 
-__global__ __launch_bounds__( 256 ) void k_deblock( PicDev pic, DevPlanes r, int dir )
-{
-  // thread -> 4x4 unit; along the edge direction neighbouring threads handle neighbouring segments of the same edge line
-  const int x4 = blockIdx.x * 16 + ( dir == 0 ? threadIdx.x / 16 : threadIdx.x % 16 );
-  const int y4 = blockIdx.y * 16 + ( dir == 0 ? threadIdx.x % 16 : threadIdx.x / 16 );
-  if( x4 >= pic.w4 || y4 >= pic.h4 ) return;
-  const vvr_lfp* lp = pic.lfp[dir] + (size_t) y4 * pic.w4 + x4;
-  const vvr_lfp l = *lp;
-  const int nStep = dir == 0 ? 2 : 2 * pic.w4;                      // table distance of the unit 8 samples across the edge
-  const bool hasNext = dir == 0 ? x4 + 2 < pic.w4 : y4 + 2 < pic.h4, hasPrev = dir == 0 ? x4 >= 2 : y4 >= 2;
-  if( BS_GET( l.bs, 0 ) && !( hasNext && db_luma_p7( lp[nStep] ) ) )
-  {
-    if( db_luma_p7( l ) && hasPrev )
-    {
-      const vvr_lfp lPrev = lp[-nStep];
-      if( BS_GET( lPrev.bs, 0 ) ) deblock_luma_segment( pic, r, dir, dir == 0 ? x4 - 2 : x4, dir == 0 ? y4 : y4 - 2, lPrev );
-    }
-    deblock_luma_segment( pic, r, dir, x4, y4, l );
-  }
-  if( !l.bs ) return;
-  const vvr_pic_header& H = pic.hdr;
-  const int bd = H.bit_depth;
-  // ---- chroma (4:2:0): edges on the 8-chroma-sample grid, two chroma lines per 4x4 luma unit
-  if( !H.chroma_format ) return;
-  if( dir == 0 ? ( x4 & 3 ) : ( y4 & 3 ) ) return;
-  const int bS[2] = { BS_GET( l.bs, 1 ), BS_GET( l.bs, 2 ) };
-  if( !bS[0] && !bS[1] ) return;
-  const int stride = r.stride[1], cx = x4 * 2, cy = y4 * 2;
-  const int o = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
-  const bool large = ( l.flags >> 5 ) & 1;
-  const bool ctb = dir == 1 && ( cy & ( ( ( 1 << H.log2_ctu ) - 1 ) >> 1 ) ) == 0;
-  const int offsC[2] = { deblock_offsets_at( pic, x4 * 4, y4 * 4, 1 ), deblock_offsets_at( pic, x4 * 4, y4 * 4, 2 ) };      // offsets of the deblocked CTU's slice (LoopFilter.cpp:1637-1638)
-  for( int c = 0; c < 2; c++ )
-  {
-    if( !( bS[c] == 2 || ( large && bS[c] == 1 ) ) ) continue;
-    pel_t* src = r.p[c + 1] + (size_t) cy * stride + cx;
-    const int qp = l.qp[c + 1];
-    const int offs = c ? offsC[1] : offsC[0];
-    const int idxTC = clip3( 0, 65, qp + 2 * ( bS[c] - 1 ) + 2 * ( ( offs >> 8 ) - 64 ) );
-    const int tc = tc_value( idxTC, bd );
-    bool sw = false;
-    if( large )
-    {
-      const int idxB = clip3( 0, 63, qp + 2 * ( ( offs & 255 ) - 64 ) );
-      const int beta = d_db_beta_table[idxB] * ( 1 << ( bd - 8 ) );
-      const int dp0 = ctb ? calc_dp_ctb( src, o ) : calc_dp( src, o ), dq0 = calc_dq( src, o );
-      const int dp3 = ctb ? calc_dp_ctb( src + step, o ) : calc_dp( src + step, o ), dq3 = calc_dq( src + step, o );
-      const int d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
-      if( d < beta ) sw = use_strong( src, o, 2 * d0, beta, tc, false, false, 7, 7, ctb ) && use_strong( src + step, o, 2 * d3, beta, tc, false, false, 7, 7, ctb );
-    }
-    for( int i = 0; i < 2; i++ ) filter_chroma_pel( src + step * i, o, tc, sw, bd, ctb );
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// k_deblock4 - the same edge filters with FOUR LANES PER EDGE SEGMENT (round 4).  k_deblock gave a thread a whole 4-sample segment: ~70 dependent
+// k_deblock4 - the edge filters with FOUR LANES PER EDGE SEGMENT (round 4).  k_deblock (rounds 1 - 3, removed in round 6) gave a thread a whole 4-sample segment: ~70 dependent
 // memory operations per wavefront on 2-byte accesses, one round of wavefronts on the device - latency, not bandwidth, not arithmetic (DESIGN.md
 // section 6, profiles/round3_deblock_counters.json).  Here a lane owns ONE LINE of the segment: it fetches the line's 16 samples across the edge at
 // once (four 8-byte loads along a row for vertical edges; 16 two-byte loads down a column for horizontal edges, 128 bytes per row over the
@@ -3114,10 +3043,6 @@ void launch_lf_init( hipStream_t s, const PicDev& pic, uint32_t numCu, uint32_t 
 void launch_deblock( hipStream_t s, const PicDev& pic, DevPlanes reco, int dir )
 {
   if( pic.hdr.tool_flags & VVR_TOOL_DEBLOCK_OFF ) return;
-#ifdef VVR_DEV_ENV
-  static const bool one = getenv( "VVR_DEBLOCK_ONE_LANE" ) != nullptr;      // developer build: the kernel of rounds 1 - 3 (a thread per segment), for comparison
-  if( one ) { hipLaunchKernelGGL( k_deblock, dim3( ( pic.w4 + 15 ) / 16, ( pic.h4 + 15 ) / 16 ), dim3( 256 ), 0, s, pic, reco, dir ); return; }
-#endif
   hipLaunchKernelGGL( k_deblock4, dim3( ( pic.w4 + 15 ) / 16, ( pic.h4 + 3 ) / 4 ), dim3( 256 ), 0, s, pic, reco, dir );
 }
 
@@ -3725,8 +3650,8 @@ struct SaoAlfShared {
   pel_t al[SA_ALH * SA_ALW];
   pel_t dc[2][SA_DCH * SA_DCW];
   pel_t ac[2][SA_ACH * SA_ACW];
-  int16_t fCoef[25 * 12], fClip[25 * 12];      // the CTU's luma filter set: per class, un-transposed
-  uint8_t cls[256], trp[256];
+  __attribute__( ( aligned( 16 ) ) ) uint32_t fPack[4 * 25 * 12];      // the CTU's luma filter set, per transpose and class the 12 taps in the order the filter reads them: coefficient | clip value << 16
+  uint8_t cls[256];                            // per 4x4 block: transpose * 25 + class (row of fPack)
   uint32_t sao[9][3][2];                       // SAO parameters of the 3 x 3 CTUs around the region's, per component: mode | type << 8 | band << 16; the four offsets
 };
 
@@ -3805,6 +3730,10 @@ __device__ __forceinline__ uint32_t sao_pair( const SaoAlfShared& sh, const uint
   return (uint32_t) clip_pel( v0 + o0, bd ) | ( (uint32_t) clip_pel( v1 + o1, bd ) << 16 );
 }
 
+// acc + ( low / high half of d ) * ( low half of pk ): v_mad_i32_i16 with its operand-select bits
+__device__ __forceinline__ int alf_mad_lo( alf_s2 d, uint32_t pk, int acc ) { int r; asm( "v_mad_i32_i16 %0, %1, %2, %3" : "=v"( r ) : "v"( __builtin_bit_cast( uint32_t, d ) ), "v"( pk ), "v"( acc ) ); return r; }
+__device__ __forceinline__ int alf_mad_hi( alf_s2 d, uint32_t pk, int acc ) { int r; asm( "v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"( r ) : "v"( __builtin_bit_cast( uint32_t, d ) ), "v"( pk ), "v"( acc ) ); return r; }
+
 template<bool SAO, bool ALF>
 __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, DevPlanes dst )
 {
@@ -3857,18 +3786,22 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
   }
   vvr_alf_ctu f; f.enable[0] = f.enable[1] = f.enable[2] = 0; f.cc_idc[0] = f.cc_idc[1] = 0; f.alt[0] = f.alt[1] = 0; f.luma_filter_idx = 0;
   const vvr_alf_params* __restrict__ A = nullptr;
+  int lumaClips = 0;                                     // some tap of the CTU's luma filter set clips its differences (else the clipping is left out: a fixed set, or an APS whose clip indices are 0)
   if( ALF )
   {
     f = pic.alf[ctuY * pic.ctus_x + ctuX];
     A = alf_set_at( pic, tx0, ty0 );                     // the filters of the APSs the CTU's slice refers to (AdaptiveLoopFilter.cpp:515)
     if( f.enable[0] )
     {
-      const int clipDef = 1 << bd;                       // m_alfClippVls[bd-8][0] = 256 << (bd - 8)
-      for( int i = tid; i < 25 * 12; i += 256 )
+      const int clipDef = 1 << bd;                       // m_alfClippVls[bd-8][0] = 256 << (bd - 8): such a tap is never clipped
+      for( int i = tid; i < 4 * 25 * 12; i += 256 )
       {
-        const int cl = i / 12, k = i - cl * 12;
-        if( f.luma_filter_idx < 16 ) { sh.fCoef[i] = d_alf_fixed_coeff[d_alf_class_to_filter[f.luma_filter_idx][cl]][k]; sh.fClip[i] = (int16_t) clipDef; }
-        else { sh.fCoef[i] = A->luma_coeff[f.luma_filter_idx - 16][cl][k]; sh.fClip[i] = A->luma_clip[f.luma_filter_idx - 16][cl][k]; }
+        const int tr = i / 300, r = i - tr * 300, cl = r / 12, k = c_alf_perm[tr][r - cl * 12];
+        int cf, cp;
+        if( f.luma_filter_idx < 16 ) { cf = d_alf_fixed_coeff[d_alf_class_to_filter[f.luma_filter_idx][cl]][k]; cp = clipDef; }
+        else { cf = A->luma_coeff[f.luma_filter_idx - 16][cl][k]; cp = A->luma_clip[f.luma_filter_idx - 16][cl][k]; }
+        sh.fPack[i] = (uint32_t) (uint16_t) cf | ( (uint32_t) (uint16_t) cp << 16 );
+        lumaClips |= cp < clipDef;
       }
     }
   }
@@ -3876,7 +3809,7 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
   const bool cc[2] = { ccOn && f.cc_idc[0], ccOn && f.cc_idc[1] };
   const bool restricted = lf_restricted( pic );
   const AlfClip kl = alf_clip_of_ctu( pic, ctuX, ctuY, 0 ), kc = alf_clip_of_ctu( pic, ctuX, ctuY, 1 );
-  __syncthreads();
+  const bool lumaClip = __syncthreads_or( lumaClips ) != 0;
   // ---- SAO where the windows are copied into the tiles the ALF reads: entry (x, y) of a tile is the SAO output of the sample the CTU's ALF reads there
   // A region whose windows lie inside the picture, in a CTU whose filters may read everything around it (nearly all): no clamp, no boundary case -
   // two neighbouring samples per step; else sample by sample with every rule
@@ -3926,16 +3859,22 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
   const int vbPos = ctu - 4;
   if( !( SA_SKIP & 2 ) && ALF && f.enable[0] )
   {
-    // ---- classification: 4 lanes per 4x4 block, one Laplacian cell-row pair each, reduced with lane shuffles; 256 blocks in four rounds
-#pragma unroll 1
-    for( int q = 0; q < 4; q++ )
+    // ---- classification: ONE LANE per 4x4 block (round 6; before: four lanes per block, a cell-row pair each, lane shuffles, the decision by all four - 256
+    // blocks in four rounds of the workgroup): the four cell-row pairs one after the other, Laplacians of two cells per packed operation, sums in the two
+    // halves of a register (16 cells of at most 2 * 1023 per half), no cross-lane traffic
     {
-      const int blk = q * 64 + ( tid >> 2 ), i = ( tid & 3 ) * 2;
+      const int blk = tid;
       const int bx = ( blk & 15 ) * 4, by = ( blk >> 4 ) * 4;
       const int yInCtu = ( ty0 + by ) & ( ctu - 1 );
-      int sumV = 0, sumH = 0, sumD0 = 0, sumD1 = 0;
-      if( !( ( yInCtu == vbPos - 4 && i == 6 ) || ( yInCtu == vbPos && i == 0 ) ) )
+      alf_s2 aV = alf_s2{ 0, 0 }, aH = aV, aD0 = aV, aD1 = aV;
+      const alf_s2 zero = alf_s2{ 0, 0 };
+#define LOHI( L, Hh ) __builtin_bit_cast( alf_s2, __builtin_amdgcn_perm( Hh, L, 0x07060100u ) )
+#define ALN( Hh, L )  __builtin_bit_cast( alf_s2, __builtin_amdgcn_alignbit( Hh, L, 16 ) )
+#define LAPL( ACC, B, C ) { const alf_s2 t_ = a2 - ( B ) - ( C ); ACC += __builtin_elementwise_max( t_, zero - t_ ); }
+#pragma unroll
+      for( int i = 0; i < 8; i += 2 )
       {
+        if( ( yInCtu == vbPos - 4 && i == 6 ) || ( yInCtu == vbPos && i == 0 ) ) continue;
         const int r = by - 2 + i, rel = yInCtu - 2 + i;
         int rm1 = r - 1, rp2 = r + 2;
         if( rel > 0 && ( rel % ctu ) == vbPos - 2 ) rp2 = r + 1;
@@ -3953,11 +3892,6 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
             wr[k][0] = u0.x; wr[k][1] = u0.y; wr[k][2] = u1.x; wr[k][3] = u1.y; wr[k][4] = u2.x; wr[k][5] = u2.y;
           }
         }
-        alf_s2 aV = alf_s2{ 0, 0 }, aH = aV, aD0 = aV, aD1 = aV;
-        const alf_s2 zero = alf_s2{ 0, 0 };
-#define LOHI( L, Hh ) __builtin_bit_cast( alf_s2, ( ( L ) & 0xffffu ) | ( ( Hh ) & 0xffff0000u ) )
-#define ALN( Hh, L )  __builtin_bit_cast( alf_s2, __builtin_amdgcn_alignbit( Hh, L, 16 ) )
-#define LAPL( ACC, B, C ) { const alf_s2 t_ = a2 - ( B ) - ( C ); ACC += __builtin_elementwise_max( t_, zero - t_ ); }
 #pragma unroll
         for( int d = 1; d <= 4; d++ )          // cX = bx - 2 + 2 ( d - 1 ): register d of a row holds columns ( cX, cX + 1 )
         {
@@ -3967,16 +3901,13 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
           LAPL( aD0, ALN( wr[1][d], wr[0][d - 1] ), ALN( wr[3][d + 1], wr[2][d] ) )
           LAPL( aD1, ALN( wr[3][d], wr[2][d - 1] ), ALN( wr[1][d + 1], wr[0][d] ) )
         }
+      }
 #undef LAPL
 #undef ALN
 #undef LOHI
-        sumV = (int) aV.x + (int) aV.y; sumH = (int) aH.x + (int) aH.y; sumD0 = (int) aD0.x + (int) aD0.y; sumD1 = (int) aD1.x + (int) aD1.y;
-      }
-      sumV  += __shfl_xor( sumV, 1 );  sumV  += __shfl_xor( sumV, 2 );
-      sumH  += __shfl_xor( sumH, 1 );  sumH  += __shfl_xor( sumH, 2 );
-      sumD0 += __shfl_xor( sumD0, 1 ); sumD0 += __shfl_xor( sumD0, 2 );
-      sumD1 += __shfl_xor( sumD1, 1 ); sumD1 += __shfl_xor( sumD1, 2 );
-      if( ( tid & 3 ) == 0 )
+#define HSUM( A ) ( (int) ( __builtin_bit_cast( uint32_t, A ) & 0xffffu ) + (int) ( __builtin_bit_cast( uint32_t, A ) >> 16 ) )
+      const int sumV = HSUM( aV ), sumH = HSUM( aH ), sumD0 = HSUM( aD0 ), sumD1 = HSUM( aD1 );
+#undef HSUM
       {
         const int act = clip3( 0, 15, ( ( sumV + sumH ) * ( ( yInCtu == vbPos - 4 || yInCtu == vbPos ) ? 96 : 64 ) ) >> ( bd + 4 ) );
         int cl = (int) ( ( 0x4333333332222210ull >> ( 4 * act ) ) & 15 );          // { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 }
@@ -3989,7 +3920,8 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
         if( hvd1 > 2 * hvd0 ) strength = 1;
         if( hvd1 * 2 > 9 * hvd0 ) strength = 2;
         if( strength ) cl += ( ( ( mainDir & 1 ) << 1 ) + strength ) * 5;
-        sh.cls[blk] = (uint8_t) cl; sh.trp[blk] = (uint8_t) ( ( 0x31322010u >> ( 4 * ( mainDir * 2 + ( secDir >> 1 ) ) ) ) & 15 );      // { 0, 1, 0, 2, 2, 3, 1, 3 }
+        const int tr = (int) ( ( 0x31322010u >> ( 4 * ( mainDir * 2 + ( secDir >> 1 ) ) ) ) & 15 );      // { 0, 1, 0, 2, 2, 3, 1, 3 }
+        sh.cls[blk] = (uint8_t) ( tr * 25 + cl );
       }
     }
     __syncthreads();
@@ -4008,10 +3940,13 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
       if( !( SA_SKIP & 4 ) && ALF && f.enable[0] )
       {
         const int b = ( y >> 2 ) * 16 + ( x4 >> 2 );
-        const int cl = sh.cls[b], tr = sh.trp[b];
-        int cf[12], cp[12];
-#pragma unroll
-        for( int k = 0; k < 12; k++ ) { const int sk = c_alf_perm[tr][k]; cf[k] = sh.fCoef[cl * 12 + sk]; cp[k] = sh.fClip[cl * 12 + sk]; }
+        // the 12 taps of the block's class, in the order of its transpose: coefficient | clip value << 16 (three 16-byte LDS reads)
+        uint32_t pk[12];
+        {
+          const uint4* tp = reinterpret_cast<const uint4*>( &sh.fPack[(int) sh.cls[b] * 12] );
+          const uint4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+          pk[0] = t0.x; pk[1] = t0.y; pk[2] = t0.z; pk[3] = t0.w; pk[4] = t1.x; pk[5] = t1.y; pk[6] = t1.z; pk[7] = t1.w; pk[8] = t2.x; pk[9] = t2.y; pk[10] = t2.z; pk[11] = t2.w;
+        }
         const int yVb = gy & ( ctu - 1 );
         int r1 = y + 1, r2 = y - 1, r3 = y + 2, r4 = y - 2, r5 = y + 3, r6 = y - 3;
         if( yVb < vbPos && yVb >= vbPos - 4 )
@@ -4041,35 +3976,50 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
         }
         // pair of samples at columns ( x4 - 4 + OFF, + 1 ) of row K
 #define AP( K, OFF ) ( ( ( OFF ) & 1 ) ? __builtin_amdgcn_alignbit( wv[K][( ( OFF ) + 1 ) >> 1], wv[K][( ( OFF ) - 1 ) >> 1], 16 ) : wv[K][( OFF ) >> 1] )
-        uint32_t ck[12]; alf_s2 cpP[12], cpN[12];
-#pragma unroll
-        for( int k = 0; k < 12; k++ ) { ck[k] = (uint16_t) cf[k]; const short c = (short) cp[k]; cpP[k] = alf_s2{ c, c }; cpN[k] = alf_s2{ (short) -c, (short) -c }; }
-#pragma unroll
-        for( int p = 0; p < 2; p++ )
+        // s0 / s1: the sums of the two samples of a pair; a tap adds coefficient * ( two differences to the centre, clipped to the tap's clip value where the CTU's
+        // filter set clips at all ): v_mad_i32_i16 takes the coefficient out of the low half of the packed tap and the difference out of either half
+#define ALF_MADS( D, PK ) { s0 = alf_mad_lo( D, PK, s0 ); s1 = alf_mad_hi( D, PK, s1 ); }
+        // rows: 0 = r6, 1 = r4, 2 = r2, 3 = y, 4 = r1, 5 = r3, 6 = r5; OFF = 2 p + dx + 4
+#define ALF_TAPS \
+          TAP( 0, 6, 0, 0, 0 ) TAP( 1, 5, 1, 1, -1 ) TAP( 2, 5, 0, 1, 0 ) TAP( 3, 5, -1, 1, 1 ) TAP( 4, 4, 2, 2, -2 ) TAP( 5, 4, 1, 2, -1 ) \
+          TAP( 6, 4, 0, 2, 0 ) TAP( 7, 4, -1, 2, 1 ) TAP( 8, 4, -2, 2, 2 ) TAP( 9, 3, 3, 3, -3 ) TAP( 10, 3, 2, 3, -2 ) TAP( 11, 3, 1, 3, -1 )
+        if( lumaClip )
         {
-          const alf_s2 cur = __builtin_bit_cast( alf_s2, wv[3][2 + p] );
-          int s0 = 0, s1 = 0;
-          // rows: 0 = r6, 1 = r4, 2 = r2, 3 = y, 4 = r1, 5 = r3, 6 = r5; OFF = 2 p + dx + 4
+          alf_s2 cpP[12], cpN[12];
+#pragma unroll
+          for( int k = 0; k < 12; k++ ) { cpP[k] = __builtin_bit_cast( alf_s2, __builtin_amdgcn_perm( pk[k], pk[k], 0x07060706u ) ); cpN[k] = alf_s2{ 0, 0 } - cpP[k]; }
+#pragma unroll
+          for( int p = 0; p < 2; p++ )
+          {
+            const alf_s2 cur = __builtin_bit_cast( alf_s2, wv[3][2 + p] );
+            int s0 = 0, s1 = 0;
 #define TAP( K, KA, DXA, KB, DXB ) { const alf_s2 a = __builtin_bit_cast( alf_s2, AP( KA, 2 * p + ( DXA ) + 4 ) ), b = __builtin_bit_cast( alf_s2, AP( KB, 2 * p + ( DXB ) + 4 ) ); \
-            const alf_s2 d = __builtin_elementwise_min( __builtin_elementwise_max( a - cur, cpN[K] ), cpP[K] ) + __builtin_elementwise_min( __builtin_elementwise_max( b - cur, cpN[K] ), cpP[K] ); \
-            s0 = __builtin_amdgcn_sdot2( d, __builtin_bit_cast( alf_s2, ck[K] ), s0, false ); s1 = __builtin_amdgcn_sdot2( d, __builtin_bit_cast( alf_s2, ck[K] << 16 ), s1, false ); }
-          TAP( 0, 6, 0, 0, 0 )
-          TAP( 1, 5, 1, 1, -1 )
-          TAP( 2, 5, 0, 1, 0 )
-          TAP( 3, 5, -1, 1, 1 )
-          TAP( 4, 4, 2, 2, -2 )
-          TAP( 5, 4, 1, 2, -1 )
-          TAP( 6, 4, 0, 2, 0 )
-          TAP( 7, 4, -1, 2, 1 )
-          TAP( 8, 4, -2, 2, 2 )
-          TAP( 9, 3, 3, 3, -3 )
-          TAP( 10, 3, 2, 3, -2 )
-          TAP( 11, 3, 1, 3, -1 )
+              const alf_s2 d = __builtin_elementwise_min( __builtin_elementwise_max( a - cur, cpN[K] ), cpP[K] ) + __builtin_elementwise_min( __builtin_elementwise_max( b - cur, cpN[K] ), cpP[K] ); \
+              ALF_MADS( d, pk[K] ) }
+            ALF_TAPS
 #undef TAP
-          s0 = nearVb ? ( s0 + 512 ) >> 10 : ( s0 + 64 ) >> 7;
-          s1 = nearVb ? ( s1 + 512 ) >> 10 : ( s1 + 64 ) >> 7;
-          o[2 * p] = clip_pel( s0 + (int) cur.x, bd ); o[2 * p + 1] = clip_pel( s1 + (int) cur.y, bd );
+            s0 = nearVb ? ( s0 + 512 ) >> 10 : ( s0 + 64 ) >> 7;
+            s1 = nearVb ? ( s1 + 512 ) >> 10 : ( s1 + 64 ) >> 7;
+            o[2 * p] = clip_pel( s0 + (int) cur.x, bd ); o[2 * p + 1] = clip_pel( s1 + (int) cur.y, bd );
+          }
         }
+        else
+        {
+#pragma unroll
+          for( int p = 0; p < 2; p++ )
+          {
+            const alf_s2 cur = __builtin_bit_cast( alf_s2, wv[3][2 + p] ), cur2 = cur + cur;
+            int s0 = 0, s1 = 0;
+#define TAP( K, KA, DXA, KB, DXB ) { const alf_s2 d = __builtin_bit_cast( alf_s2, AP( KA, 2 * p + ( DXA ) + 4 ) ) + __builtin_bit_cast( alf_s2, AP( KB, 2 * p + ( DXB ) + 4 ) ) - cur2; ALF_MADS( d, pk[K] ) }
+            ALF_TAPS
+#undef TAP
+            s0 = nearVb ? ( s0 + 512 ) >> 10 : ( s0 + 64 ) >> 7;
+            s1 = nearVb ? ( s1 + 512 ) >> 10 : ( s1 + 64 ) >> 7;
+            o[2 * p] = clip_pel( s0 + (int) cur.x, bd ); o[2 * p + 1] = clip_pel( s1 + (int) cur.y, bd );
+          }
+        }
+#undef ALF_TAPS
+#undef ALF_MADS
 #undef AP
       }
       else
@@ -5716,7 +5666,7 @@ void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlane
 // The units [ticket0, ticket1) of the table.  A picture whose inter blocks carry scaled chroma residuals runs the stage in two launches - the luma
 // units, then (behind k_resi_add) the chroma units: the flags of the first launch stay set, so a chroma unit that names a luma producer finds it done.
 void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraUnit* units, int numActive, int ticket0, int ticket1,
-                   int numWorkgroups, int* sync, int wide, uint32_t* maps, size_t mapInts, int mapW4, int mapH4 )
+                   int numWorkgroups, int* sync, int wide, uint32_t* maps, size_t mapInts, int mapW4, int mapH4, int* errWord )
 {
   if( !numActive || ticket1 <= ticket0 ) return;
   numWorkgroups = std::max( 1, std::min( numWorkgroups, ticket1 - ticket0 ) );
@@ -5741,24 +5691,24 @@ void launch_intra( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes r
   // several CTU diagonals)
   LeafMaps M = {};
   int* lsync = nullptr;
+#ifdef VVR_INTRA_DEV
   const bool fine = maps != nullptr && ticket0 == 0 && ticket1 == numActive;
+#else
+  const bool fine = false;
+#endif
   if( fine )
   {
     const size_t cellsPerMap = (size_t) mapW4 * mapH4;
     for( int k = 0; k < 3; k++ ) M.cell[k] = maps + (size_t) k * cellsPerMap;
     M.w4 = pic.w4; M.h4 = pic.h4;
-    lsync = reinterpret_cast<int*>( maps + mapInts - 64 );
+    lsync = errWord;
     for( int k = 0; k < ( pic.hdr.chroma_format ? 3 : 1 ); k++ ) hipMemsetD32Async( (hipDeviceptr_t) M.cell[k], 1, (size_t) pic.w4 * pic.h4, s );
     static const int fineWg = getenv( "VVR_INTRA_FINE_WG" ) ? atoi( getenv( "VVR_INTRA_FINE_WG" ) ) : 0;
     numWorkgroups = std::max( 1, std::min( ticket1 - ticket0, fineWg > 0 ? fineWg : ( wide ? 256 : 4 * numWorkgroups ) ) );
   }
 #ifndef VVR_INTRA_DEV
-  if( fine )
-  {
-    if( waves == 8 ) hipLaunchKernelGGL( ( k_intra<8, true> ), dim3( numWorkgroups ), dim3( 576 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync );
-    else             hipLaunchKernelGGL( ( k_intra<4, true> ), dim3( numWorkgroups ), dim3( 320 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync );
-  }
-  else if( waves == 8 ) hipLaunchKernelGGL( ( k_intra<8, false> ), dim3( numWorkgroups ), dim3( 512 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync );
+  // (the block-by-block variant k_intra<.., FINE> - measured in round 5, slower under load - exists in the developer build only: `maps` is never set here)
+  if( waves == 8 )      hipLaunchKernelGGL( ( k_intra<8, false> ), dim3( numWorkgroups ), dim3( 512 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync );
   else                  hipLaunchKernelGGL( ( k_intra<4, false> ), dim3( numWorkgroups ), dim3( 256 ), 0, s, ip, items, ctx, units, numActive, sync, M, lsync );
 #else
   if( const char* e = getenv( "VVR_INTRA_WAVES" ) ) waves = atoi( e ) == 8 ? 8 : 4;
