@@ -19,8 +19,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: l
   * a K-picture window is 10-20 ms of a pipeline with host threads in it, so the whole sequence - stream from its first picture, pre-roll,
     warm-up, K timed pictures - is run --repeats times (default 5) and `value` is the MEDIAN of the K-picture times (all samples, minimum and
     maximum are in `config`); `config.value_irap_lookahead_0` is the same stream submitted in plain decoding order (no look-ahead);
-  * N > 1: the stream shards by closed-GOP segment (each rank reconstructs its own independently decodable segment with its
-    own DPB): no data-path collective, "scaling": "weak"; value = pictures of all ranks / max-over-ranks time;
+  * N > 1: `value` = ONE stream sharded by PICTURE over the GPUs (north_star's split: pictures round-robin within their temporal layer, reference
+    pictures over RCCL / xGMI to the ranks that predict from them); a step is one picture per GPU, the timed window holds K x N pictures of the stream,
+    "scaling": "weak"; value = those pictures / max-over-ranks time.  The closed-GOP segment mode (each rank its own independently decodable segment
+    and DPB, no data-path collective) is measured in the same run and reported as `value_segment_mode`;
   * verification (rank 0, after the timed passes): the last timed run's last pictures and the IRAP of its window == a one-picture-at-a-time
     run, and the IRAP + --verify of those last pictures == the CPU oracle fed with the same reference pictures (checker only, never timed or shipped);
   * roofline: per-kernel durations from HIP events recorded on the launch streams in a further pass over the K timed pictures only
@@ -30,10 +32,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: l
     set-up and its CTU task state machine on its ThreadPool, 64 threads and all hardware threads, wall clock per picture (cpu_reference_threaded) -,
     with the frame-parallel figure beside it (one picture per process, no scheduler: pictures / (summed stage time / processes)); without that
     build the plain-C restatement (oracle/), one picture per process;
-  * N > 1: besides the segment mode the line carries config.picture_sharding (ONE stream sharded by picture, reference pictures sent point to point
-    over RCCL; strong scaling, with the ceiling the window's reference graph allows), and both modes as first-class fields `value_segment_mode` /
-    `value_picture_mode` (fps, scaling, ceiling, MB sent per picture, ranks); if that pass does not come back the line says "timeout": true
-    and the process ends with a non-zero status;
+  * N > 1: the picture-mode pass runs in child processes (it has never run on two devices: a fault in it must not sink the line); both modes are
+    first-class fields `value_picture_mode` / `value_segment_mode` (fps, pictures, ceiling of the reference graph for the window and for the open
+    stream, MB sent per picture, ranks); if the pass does not come back `value` is the segment mode, config.value_is says so, the line carries
+    "timeout": true and the process ends with a non-zero status;
   * N = 1, --config 4k (the driver's command): behind the headline configuration the 8K (configs[2]) and all-intra (configs[4]) configurations run in short
     windows, each in a process of its own, and land in config.other_configs (fps, device only, pictures verified against the oracle); roofline carries the
     dominant kernel, the dominant kernel of the B pictures and the I picture's intra kernel apart, and the VALU-issue utilisation from the counter pass.
@@ -253,18 +255,27 @@ def cpu_baseline(cfg_name, seed, gop, budget_s=20.0):
         t64 = cpu_reference_threaded(cfg_name, seed, gop, min(64, os.cpu_count() or 1))
         tall = cpu_reference_threaded(cfg_name, seed, gop, os.cpu_count() or 1) if (os.cpu_count() or 1) > 64 else None
         if t64:
-            best = max([t for t in (t64, tall) if t], key=lambda t: t["fps"])
-            if per_process["value"] > best["fps"]:
-                # the stronger of the two CPU figures is the baseline: frame-parallel reconstruction by the reference's classes (one picture per process) beats the
-                # reference's picture-internal scheduler on this host; the threaded figures stay beside it
-                return {"value": per_process["value"], "unit": "frames/s", "cores": per_process["cores"], "kind": "reference", "host_cores": os.cpu_count(), "sample": per_process["what"],
-                        "which": "one picture per process (the higher of the two CPU figures)", "threaded_64": t64, "threaded_all_hardware_threads": tall, "one_picture_per_process": per_process}
-            return {"value": best["fps"], "unit": "frames/s", "cores": best["threads"], "kind": "reference", "host_cores": os.cpu_count(), "which": "the reference's own threaded path (the higher of the two CPU figures)",
+            # the headline is a WALL-CLOCK rate of the reference's own threaded path (round-5 verdict: the per-process figure is an extrapolation - stage time summed over
+            # one-picture processes, divided by the cores - and stands beside it, as does the run on every hardware thread)
+            best = t64
+            return {"value": best["fps"], "unit": "frames/s", "cores": best["threads"], "kind": "reference", "host_cores": os.cpu_count(), "which": "the reference's own threaded path on 64 threads, wall clock (one_picture_per_process: the frame-parallel extrapolation; threaded_all_hardware_threads: the same path on every hardware thread)",
                     "sample": "the IRAP and %d B pictures of the same %dx%d stream, one after the other through the reference's own scheduler (DecLibRecon's set-up + ctuTask state machine on its ThreadPool, "
                               "started at LF_INIT: the pictures arrive with their motion derived) on %d threads, wall clock of decompressPicture + waitForPrevDecompressedPic per picture, weighted one IRAP per "
                               "intra period (%.1f ms per I picture, %.1f ms per B picture); reference classes with SIMD" % (best["pictures"] - 1, W, H, best["threads"], best["ms_per_I_picture"], best["ms_per_B_picture"]),
                     "threaded_64": t64, "threaded_all_hardware_threads": tall, "one_picture_per_process": per_process}
     return {"value": per_process["value"], "unit": "frames/s", "cores": cores, "kind": kind, "host_cores": os.cpu_count(), "sample": per_process["what"]}
+
+
+def kernel_source_hash():
+    """MD5 over the kernel and host sources of the library (the files the Makefile lists): the counter / traffic summaries under profiles/ carry the hash of
+    the sources they were measured with (tools/collect_profiles.py, tools/gpu_r6_counters.sh), and the line says "stale" when it differs"""
+    import hashlib
+    h = hashlib.md5()
+    d = os.path.join(ROOT, "vvdec_amd", "csrc")
+    for f in ("vvr_api.cpp", "vvr_prepare.cpp", "vvr_kernels.hip", "vvr_device.h", "vvr_host.h", "vvr_lf_init.h", "vvr_output.inc", "vvr_intra_leaf.inc", "vvr_intra_cells.inc"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def picture_sharding_pass(a, W, H, mix, tools, plans, nslots, first, K, Wm, rank, world, local_rank, backend):
@@ -281,23 +292,36 @@ def picture_sharding_pass(a, W, H, mix, tools, plans, nslots, first, K, Wm, rank
     dpb = vvdec_amd.Reconstructor.new_dpb_tensor(W, H, nslots, device=dev)
     rec = vvdec_amd.Reconstructor(W, H, num_slots=nslots, num_streams=a.streams, device=local_rank, host_threads=a.host_threads, ext_planes=dpb.data_ptr())
     # (gloo: the control-flow test of this path on the stand-in runtime, whose streams and events are the stub library's)
-    pp = parallel.PictureParallel(rec, dpb, plans, rank, world, runtime=None if backend == "nccl" else parallel.HostStubRuntime(vvdec_amd.lib()))
+    mk_rt = (lambda: None) if backend == "nccl" else (lambda: parallel.HostStubRuntime(vvdec_amd.lib()))
+    transfer = os.environ.get("VVR_BENCH_TRANSFER", "p2p")        # "broadcast": the rank-wide RCCL broadcast instead of sends to the dependants
+    pp = parallel.PictureParallel(rec, dpb, plans, rank, world, runtime=mk_rt(), transfer=transfer)
     descs = [synth.picture_for_plan(pl, W, H, seed=1234, tool_flags=tools, alloc=rec.host_array, **mix) if pp.owners[i] == rank else None for i, pl in enumerate(plans)]
-    pp.run(descs, 0, first)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pp.run(descs, first, first + K)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    samples = []
+    for rep in range(max(1, min(3, a.repeats))):
+        # every window from the first picture of the stream (pre-roll and warm-up untimed), as the one-GPU line does
+        if rep:
+            pp = parallel.PictureParallel(rec, dpb, plans, rank, world, runtime=mk_rt(), transfer=transfer)
+        pp.run(descs, 0, first)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pp.run(descs, first, first + K)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        samples.append(float(t.item()))
+    med = sorted(samples)[len(samples) // 2]
     nb = sum(1 for i in range(first, first + K) if pp.need[i])
     sends = sum(len(pp.deps[i]) for i in range(first, first + K))
     host_waits = sum(1 for (op, _) in pp.trace if op == "host_wait")
+    n_irap = sum(1 for pl in plans[first:first + K] if pl.slice_type == 2)
     rec.close()
-    return {"fps": round(K / float(t.item()), 2), "seconds": float(t.item()), "scaling": "strong", "pictures": K, "replicated_pictures_in_window": nb, "point_to_point_sends_in_window": sends,
+    return {"fps": round(K / med, 2), "seconds": med, "samples_fps": [round(K / x, 1) for x in samples], "scaling": "weak", "pictures": K, "pictures_per_rank": K // world, "irap_pictures_in_window": n_irap,
+            "replicated_pictures_in_window": nb, "point_to_point_sends_in_window": sends, "transfer": transfer,
             "slot_MB": round(dpb.numel() / nslots / 1e6, 1), "host_waits_for_hand_over": host_waits,
-            "what": "ONE stream over all ranks, pictures round-robin within their temporal layer; a reference picture goes from its owner to the ranks that predict from it (point-to-point over xGMI, RCCL), ordered on the device: the collective's stream waits for the picture's event, dependants wait for the event behind the receive; K pictures / max-over-ranks time"}
+            "what": "ONE stream over all ranks, pictures round-robin within their temporal layer; a reference picture goes from its owner to the ranks that predict from it (point-to-point over xGMI, RCCL; "
+                    "VVR_BENCH_TRANSFER=broadcast: to every rank), ordered on the device: the collective's stream waits for the picture's event, dependants wait for the event behind the receive; "
+                    "a step is one picture per GPU: the window holds steps x ranks pictures of the stream, value = those pictures / max-over-ranks time"}
 
 
 def picture_pass_in_children(rank, timeout):
@@ -386,7 +410,11 @@ def main():
         # the picture-sharding pass in processes of its own (one child per rank, a process group of their own: see picture_pass_in_children): whatever happens to
         # it - an exception, a collective that never completes, a fault on the device - the parents live to print the line with the segment-mode result
         try:
-            res = picture_sharding_pass(a, W, H, mix, tools, [plans[i] for i in order], nslots, first, K, Wm, rank, world, local_rank, backend)
+            # a step = one picture per GPU: the window of this mode holds K x world pictures of the ONE stream (at the driver's K = 20: 40 / 80 / 160 pictures at
+            # 2 / 4 / 8 GPUs - five GOPs of 32 in flight at N = 8; IRAP pictures in stream proportion)
+            plans_p, nslots_p, orders_p = stream_plan(a.config, a.gop, intra_period, a.irap_lookahead, a.slots, K * world, Wm)
+            order_p, first_p = orders_p[a.irap_lookahead]
+            res = picture_sharding_pass(a, W, H, mix, tools, [plans_p[i] for i in order_p], nslots_p, first_p, K * world, Wm, rank, world, local_rank, backend)
         except Exception as e:            # noqa: BLE001
             res = {"error": repr(e)[:300]}
         if rank == 0:
@@ -509,8 +537,14 @@ def main():
         roof["b_picture_kernel"] = _entry(bk[0]) if bk and a.config != "allintra" else None
         roof["i_picture_kernel"] = _entry(ik[0]) if ik else None
         # VALU-issue utilisation of the kernels alone on the device (a separate rocprofv3 --pmc pass: tools/gpu_r5_counters.sh -> profiles/round5_sq_counters.json)
+        src_hash = kernel_source_hash()
+        roof["kernel_source_hash"] = src_hash
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "round5_sq_counters.json")))["kernels"]
+            sqf = next(f for f in ("round6_sq_counters.json", "round5_sq_counters.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            sqd = json.load(open(os.path.join(ROOT, "profiles", sqf)))
+            sq = sqd["kernels"]
+            roof["valu_frac_source"] = "profiles/" + sqf
+            roof["valu_frac_stale"] = sqd.get("kernel_source_hash") != src_hash          # the counter pass was made with other kernel sources than this library
             def _valu(name):
                 v = [e["valu_issue_utilisation"] for k, e in sq.items() if k.split("<")[0] == name or (name == "k_alf" and k.startswith("k_sao_alf")) or (name in ("k_deblock_v", "k_deblock_h") and k.startswith("k_deblock_tile"))]
                 return round(max(v), 3) if v else None
@@ -522,9 +556,11 @@ def main():
         # HBM-side traffic of that kernel from the separate PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over this command,
         # gfx950 correction applied, profiles/*_pmc_traffic.json); counters cannot be collected inside this run
         # (keyed by configuration AND kernel: the 8K and all-intra lines must not carry the 4K figure)
-        for name in ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json"):
+        for name in ("round6_pmc_traffic.json", "round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json"):
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["configs"][a.config]["kernels"]
+                pmcd = json.load(open(os.path.join(ROOT, "profiles", name)))
+                pmc = pmcd["configs"][a.config]["kernels"]
+                roof["traffic_stale"] = pmcd.get("kernel_source_hash") != src_hash
                 ent = next(v for k, v in pmc.items() if k.split("<")[0] == dom["name"])
                 roof["traffic"] = ent["hbm_side_bytes_per_launch_corrected"]
                 roof["traffic_source"] = "profiles/%s, configuration %s (separate rocprofv3 --pmc passes, bytes per launch)" % (name, a.config)
@@ -565,6 +601,7 @@ def main():
                "config": {"workload": "%s, %dx%d, CTU 128%s; timed: K pictures through vvr_submit from host records (validation, work lists on %d library threads, H2D of %.1f MB per picture, all kernels); %d pre-roll + W warm-up pictures untimed; %d IRAP picture(s) in the timed window"
                                       % (cfg_text, W, H, "" if a.config == "allintra" else ", hierarchical-B GOP %d, IRAP every %d pictures, submitted %d pictures ahead of its decoding-order position" % (a.gop, intra_period, a.irap_lookahead),
                                          a.host_threads, upload_mb, first - Wm, n_irap),
+                          "conformance": "JVET set unpinned: no JVET bitstream exists offline; parser-fed parity is pinned on the streams tools/mini_vvenc.py writes (tests/bitstreams, reference decoder's MD5 / picture hashes)",
                           "timed_path": "vvr_submit(host records)", "affine_sub_block_mvs": "spanned on the device from the control points (VVR_TOOL_AFFINE_MV_ON_DEVICE)" if a.affine_mv == "device" else "supplied by the host (motion field)", "lf_init": "k_lf_init (VVR_TOOL_LFP_ON_DEVICE: edge parameters derived on the device, no table uploaded)" if a.lf_init == "device" else "tables supplied by the host", "host_records_in": "pageable memory (staged by the library)" if a.pageable_records else "pinned host memory of the context (vvr_host_alloc): cu / tu / coef / lfp arrays are copied to HBM from where the generator wrote them", "host_threads": a.host_threads, "host_cores": os.cpu_count(),
                           "value_is": "median of %d runs of the K-picture window, each from the first picture of the stream (pre-roll and warm-up untimed)" % len(dts),
                           "value_samples_fps": [round(world * K / x, 1) for x in dts], "value_min_fps": round(world * K / max(dts), 2), "value_max_fps": round(world * K / min(dts), 2),
@@ -618,6 +655,16 @@ def main():
             except Exception as e:            # noqa: BLE001 - the headline line must survive
                 others[name] = {"error": repr(e)[:300]}
         out["config"]["other_configs"] = others
+        # the same 4K stream through vvr_submit with K = 64 (the default arguments of this script): the pipeline's steady state next to the driver's short window,
+        # whose IRAP chain and fill weigh 3.2 times their share of the stream (round-5 verdict: a first-class field of the line, not only a file under profiles/)
+        if K < 64:
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "64", "--warmup", "16", "--repeats", "3", "--verify", "0", "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=300)
+                o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["value_k64"] = {"fps": o["value"], "steps": 64, "warmup": 16, "ms_per_step": o["ms_per_step"], "samples_fps": o["config"]["value_samples_fps"], "device_only_fps": o["config"]["device_only_fps"],
+                                    "what": "the same stream and path (vvr_submit from host records) over a 64-picture window with one IRAP: python bench.py --steps 64 --warmup 16"}
+            except Exception as e:            # noqa: BLE001
+                out["value_k64"] = {"error": repr(e)[:300]}
     # ---- N > 1: the same stream sharded by PICTURE over the ranks (BASELINE north_star / SURVEY 8(e): pictures round-robin within their temporal layer,
     # reference pictures broadcast slot to slot over RCCL), next to the segment mode above.  Reported under config.picture_sharding.  It runs last and
     # under a watchdog: whatever happens to it (an exception, a collective that never completes), the line with the segment-mode result is printed.
@@ -657,19 +704,45 @@ def main():
                 # `value` stays the segment mode (frames sharded over the GPUs by closed-GOP segment, no inter-GPU reference, no data-path collective:
                 # weak scaling, what north_star's "near-linear" is claimed for).  The picture-level split of ONE stream is reported beside it with the
                 # ceiling its dependency graph allows: a hierarchical-B window is a chain of temporal layers behind its IRAP.
-                if "fps" in pic_mode:
-                    from vvdec_amd import parallel as _par
-                    dev_ms = 1e3 * dt_dev / K
-                    ceil_, tot_, crit_ = _par.strong_scaling_ceiling([plans[i] for i in order][first:first + K], lambda pl: 10.0 * dev_ms if pl.slice_type == 2 else dev_ms)
-                    pic_mode["strong_scaling_ceiling"] = {"speedup_at_most": round(ceil_, 2), "what": "total work / critical path of the window's reference graph, an I picture counted as 10 B pictures (its intra wavefront)"}
-                # both modes as first-class fields of the line: the split north_star names (frames one-per-GPU of ONE stream, reference pictures over xGMI) and the
-                # closed-GOP segment mode that `value` is
-                out["value_segment_mode"] = {"fps": out["value"], "scaling": "weak", "collective_on_the_data_path": None, "what": "every rank its own closed-GOP segment and DPB; RCCL carries the barrier and the max-over-ranks time"}
-                out["value_picture_mode"] = {"fps": pic_mode.get("fps"), "scaling": "strong", "ceiling_speedup": (pic_mode.get("strong_scaling_ceiling") or {}).get("speedup_at_most"),
-                                             "MB_sent_per_picture": round(pic_mode.get("slot_MB", 0.0) * pic_mode.get("point_to_point_sends_in_window", 0) / max(1, K), 1) if "fps" in pic_mode else None,
+                # both modes as first-class fields of the line.  `value` is the PICTURE mode - the split north_star names: frames one-per-GPU of ONE stream, reference
+                # pictures over xGMI; a step is one picture per GPU, so the window holds steps x ranks pictures ("scaling": "weak": the work per GPU is fixed as N
+                # grows).  The closed-GOP segment mode measured above (no data-path collective) stands beside it; it becomes `value` only when the picture-mode pass
+                # did not come back, and the line then says so.
+                seg = {"fps": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak", "collective_on_the_data_path": None, "pictures": K * world,
+                       "what": "every rank its own closed-GOP segment and DPB, steps pictures each; RCCL carries the barrier and the max-over-ranks time"}
+                out["value_segment_mode"] = seg
+                from vvdec_amd import parallel as _par, stream as _stream
+                dev_ms = 1e3 * dt_dev / K
+                cost = lambda pl: 10.0 * dev_ms if pl.slice_type == 2 else dev_ms      # (an I picture counted as 10 B pictures: its intra wavefront)
+                plans_p, _, orders_p = stream_plan(a.config, a.gop, intra_period, a.irap_lookahead, a.slots, K * world, Wm)
+                order_p, first_p = orders_p[a.irap_lookahead]
+                win = [plans_p[i] for i in order_p][first_p:first_p + K * world]
+                long_ = _stream.ra_plan(intra_period * 8 + 1, gop=a.gop, seed_poc0_is_external=False, pool=a.slots, intra_period=intra_period)[0]
+                xfer = pic_mode.get("slot_MB", 25.0) / 100.0        # ms: a slot over one xGMI link pair at ~100 GB/s
+                sp_w, _, _ = _par.predicted_speedup(win, world, cost, xfer)
+                sp_s, _, _ = _par.predicted_speedup(long_, world, cost, xfer)
+                ceil_w, _, _ = _par.strong_scaling_ceiling(win, cost)
+                ceil_s, _, _ = _par.strong_scaling_ceiling(long_, cost)
+                ceilings = {"speedup_over_one_gpu_at_least": {"this_window": round(sp_w, 2), "open_stream": round(sp_s, 2)}, "speedup_over_one_gpu_at_most": {"this_window": round(min(world, ceil_w), 2), "open_stream": round(min(world, ceil_s), 2)},
+                            "what": "bounds from the reference graph (DecLibRecon's whole-picture gating), an I picture counted as 10 B pictures at the measured device-only time per picture. At most: total work / "
+                                    "critical path (capped at the number of GPUs). At least: a list schedule in which every rank takes its pictures strictly in order, ONE at a time, a reference from another rank "
+                                    "%.2f ms later (parallel.predicted_speedup) - a back-end keeps several pictures in flight per GPU, so a picture that waits does not hold up the next. Open stream = 8 intra "
+                                    "periods of the same hierarchy. None of this is a measurement" % xfer}
+                out["value_picture_mode"] = {"fps": pic_mode.get("fps"), "scaling": "weak", "pictures": pic_mode.get("pictures"), "samples_fps": pic_mode.get("samples_fps"), "ceiling": ceilings,
+                                             "MB_sent_per_picture": round(pic_mode.get("slot_MB", 0.0) * pic_mode.get("point_to_point_sends_in_window", 0) / max(1, pic_mode.get("pictures", 1)), 1) if "fps" in pic_mode else None,
                                              "ranks": dist.get_world_size(), "backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
-                                             "transfer": "point-to-point sends of a reconstructed picture to exactly the ranks that predict from it (batch_isend_irecv), not a broadcast: most pictures have one or two dependants",
+                                             "transfer": "point-to-point sends of a reconstructed picture to exactly the ranks that predict from it (batch_isend_irecv): most pictures of a GOP-32 have one or two "
+                                                         "dependants among eight ranks - a refinement of north_star's broadcast, which VVR_BENCH_TRANSFER=broadcast runs instead" if pic_mode.get("transfer", "p2p") == "p2p" else "RCCL broadcast of every replicated picture to every rank",
                                              "error": pic_mode.get("error")}
+                out["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
+                if "fps" in pic_mode:
+                    out["value"] = pic_mode["fps"]
+                    out["ms_per_step"] = round(1e3 * pic_mode["seconds"] / K, 4)
+                    out["scaling"] = "weak"
+                    out["config"]["sharding"] = "ONE stream sharded by picture over the GPUs (round-robin within the temporal layer), reference pictures point to point over RCCL / xGMI; steps x GPUs pictures in the timed window"
+                    out["config"]["value_is"] = "picture mode (value_picture_mode); the closed-GOP segment mode is value_segment_mode"
+                else:
+                    out["config"]["value_is"] = "SEGMENT mode: the picture-mode pass did not come back (%s)" % (pic_mode.get("error") or "no result")
             state["printed"] = True
             if rank == 0:
                 print(json.dumps(out), flush=True)

@@ -999,15 +999,20 @@ def test_bench_control_flow(stub, ranks):
     if ranks == 1:
         assert out["scaling"] is None and out["config"]["sharding"] is None          # (one GPU: nothing is sharded)
     else:
-        # N > 1: the headline is the segment mode (a closed-GOP segment per GPU, no data-path collective: weak scaling); ONE stream sharded by
-        # picture (strong scaling) sits next to it with the ceiling its reference graph allows
-        assert out["scaling"] == "weak" and "segment" in out["config"]["sharding"]
-        assert out["config"]["picture_sharding"]["strong_scaling_ceiling"]["speedup_at_most"] >= 1.0
+        # N > 1 (round 6): `value` IS the picture mode - ONE stream sharded by picture over the ranks, a step = one picture per GPU (steps x ranks pictures in the
+        # window, weak scaling) - and the closed-GOP segment mode stands beside it
+        assert out["scaling"] == "weak" and "ONE stream sharded by picture" in out["config"]["sharding"] and "picture mode" in out["config"]["value_is"]
+        pm, sm = out["value_picture_mode"], out["value_segment_mode"]
+        assert out["value"] == pm["fps"] > 0 and pm["pictures"] == out["steps"] * ranks and pm["ranks"] == ranks and sm["fps"] > 0 and sm["pictures"] == out["steps"] * ranks
+        assert abs(out["ms_per_step"] - 1e3 * out["steps"] * ranks / out["value"] / out["steps"]) < 0.05 * out["ms_per_step"]
+        c = pm["ceiling"]
+        assert 1.0 <= c["speedup_over_one_gpu_at_least"]["open_stream"] <= c["speedup_over_one_gpu_at_most"]["open_stream"] <= ranks
+        assert "rccl_ranks" in out
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in out["roofline"]
     if ranks > 1:
-        ps = out["config"]["picture_sharding"]           # the second mode: ONE stream, pictures sharded over the ranks, reference slots broadcast
-        assert "error" not in ps and ps["fps"] > 0 and ps["scaling"] == "strong" and ps["point_to_point_sends_in_window"] > 0, ps
+        ps = out["config"]["picture_sharding"]           # the pass itself: ONE stream, pictures sharded over the ranks, reference slots to their dependants
+        assert "error" not in ps and ps["fps"] > 0 and ps["scaling"] == "weak" and ps["point_to_point_sends_in_window"] > 0, ps
 
 
 def test_bench_line_survives_the_picture_sharding_pass(stub):

@@ -105,6 +105,7 @@ from vvdec_amd import abi, synth, stream, parallel
 # reference slots when it was submitted (see launch_deblock in the stub).
 vvdec_amd._LIBPATH = T.LIB
 W, H, GOP, FRAMES = 128, 64, {gop}, {frames}
+TRANSFER = {transfer!r}
 TOOLS = abi.TOOL_SAO_LUMA | abi.TOOL_ALF | abi.TOOL_DEP_QUANT | abi.TOOL_MTS
 replicate = {replicate}
 rank, world, _ = parallel.init(backend="gloo")
@@ -112,7 +113,7 @@ plans, nslots = stream.ra_plan(FRAMES, gop=GOP, seed_poc0_is_external=False, poo
 nslots = max(nslots, {pool})
 dpb = vvdec_amd.Reconstructor.new_dpb_tensor(W, H, nslots, device="cpu")
 rec = vvdec_amd.Reconstructor(W, H, log2_ctu=6, num_slots=nslots, num_streams=3, host_threads=2, ext_planes=dpb.data_ptr())
-pp = parallel.PictureParallel(rec, dpb, plans, rank, world, replicate=replicate, runtime=parallel.HostStubRuntime(vvdec_amd.lib()))
+pp = parallel.PictureParallel(rec, dpb, plans, rank, world, replicate=replicate, runtime=parallel.HostStubRuntime(vvdec_amd.lib()), transfer=TRANSFER)
 descs = [synth.picture_for_plan(pl, W, H, seed=77, tool_flags=TOOLS, log2_ctu=6, p_intra=0.1) if pp.owners[i] == rank else None for i, pl in enumerate(plans)]
 # the stamp of a picture has to be read before its slot is reused: run the plan in pieces that end where a slot is about to be overwritten
 stamps = {{}}
@@ -139,9 +140,9 @@ if dist.is_initialized():
 '''
 
 
-def _run_pic(world, tmp_path, replicate=True, gop=8, frames=17, pool=10, split=9):
-    script = tmp_path / ("pic_worker_%d_%d_%d.py" % (world, int(replicate), gop))
-    script.write_text(PIC_WORKER.format(root=ROOT, replicate=replicate, gop=gop, frames=frames, pool=pool, split=split))
+def _run_pic(world, tmp_path, replicate=True, gop=8, frames=17, pool=10, split=9, transfer="p2p"):
+    script = tmp_path / ("pic_worker_%d_%d_%d_%s.py" % (world, int(replicate), gop, transfer))
+    script.write_text(PIC_WORKER.format(root=ROOT, replicate=replicate, gop=gop, frames=frames, pool=pool, split=split, transfer=transfer))
     port = _free_port()
     procs = []
     for r in range(world):
@@ -262,3 +263,66 @@ def test_picture_parallel_four_ranks_gop32(built, tmp_path):
     assert recv_total == sum(len(x) for x in readers)
     # most pictures have one or two dependants: a broadcast to all four ranks would move at least twice the bytes
     assert sum(len(x) for x in readers) * 2 <= 3 * sum(1 for x in readers if x) + 3 * len([x for x in readers if x])
+
+
+def test_picture_parallel_eight_ranks_three_gops(built, tmp_path):
+    """the driver's widest launch: eight ranks, three GOPs of 32 in ONE call (97 pictures - the window `bench.py --gpus 8` times holds 160): the pictures equal the
+    one-rank run, every picture goes to exactly the ranks that read its slot, no rank waits for the device, all eight ranks own pictures of every GOP"""
+    import test_host_glue as T
+    if not os.path.exists(os.path.join(T.HIP_INC, "hip", "hip_runtime_api.h")):
+        pytest.skip("HIP headers not installed")
+    T.build_stub()
+    kw = dict(gop=32, frames=97, pool=48, split=97)
+    one = _run_pic(1, tmp_path, **kw)[0]
+    try:
+        eight = _run_pic(8, tmp_path, **kw)
+    except AssertionError as e:            # (gloo's TCP rendezvous between eight processes on a loaded build container: once more)
+        if "all_gather_object" not in str(e) and "Connection" not in str(e) and "gloo" not in str(e):
+            raise
+        eight = _run_pic(8, tmp_path, **kw)
+    owners, slots, refs, pocs = eight[0]["owners"], eight[0]["slots"], eight[0]["refs"], eight[0]["pocs"]
+    assert set(owners) == set(range(8))
+    for g in range(3):
+        assert {owners[i] for i in range(len(pocs)) if 32 * g < pocs[i] <= 32 * (g + 1)} == set(range(8)), "a GOP keeps every rank busy"
+    readers = []
+    for i in range(len(slots)):
+        rd = set()
+        for j in range(i + 1, len(slots)):
+            if slots[i] in refs[j]:
+                rd.add(owners[j])
+            if slots[j] == slots[i]:
+                break
+        readers.append(sorted(rd - {owners[i]}))
+    recv_total = 0
+    for r in eight:
+        assert r["stamps"] == one["stamps"], "pictures reconstructed from other reference content than in the one-rank run"
+        assert r["dead_event_uses"] == 0
+        tr = [tuple(t) for t in r["trace"]]
+        assert not any(op == "wait" for (op, _) in tr), "a rank waited for the device: the pipeline drains there"
+        for k, (op, i) in enumerate(tr):
+            if op == "send":
+                assert r["owners"][i] == r["rank"] and sorted(r["deps"][i]) == readers[i] and ("submit", i) in tr[:k]
+            if op == "recv":
+                assert r["rank"] in readers[i]
+                recv_total += 1
+    assert recv_total == sum(len(x) for x in readers)
+    # point to point moves a fraction of what a broadcast to all eight ranks would: most pictures have one or two dependants
+    assert sum(len(x) for x in readers) * 2 <= 7 * sum(1 for x in readers if x)      # (less than half of a broadcast's receivers: 2.8 per replicated picture here)
+
+
+def test_picture_parallel_broadcast_transfer(built, tmp_path):
+    """north_star's literal wording - the DPB replicated by a BROADCAST - behind the switch: every replicated picture goes from its owner to every rank (one
+    rank-wide collective per picture, issued in plan order on all ranks); the pictures equal the one-rank run and the point-to-point run"""
+    import test_host_glue as T
+    if not os.path.exists(os.path.join(T.HIP_INC, "hip", "hip_runtime_api.h")):
+        pytest.skip("HIP headers not installed")
+    T.build_stub()
+    one = _run_pic(1, tmp_path)[0]
+    three = _run_pic(3, tmp_path, transfer="broadcast")
+    for r in three:
+        assert r["stamps"] == one["stamps"]
+        assert r["dead_event_uses"] == 0
+        # every rank takes part in the transfer of every replicated picture
+        assert r["n_bcast"] == sum(r["need"]) > 0
+        for i, d in enumerate(r["deps"]):
+            assert d == ([x for x in range(3) if x != r["owners"][i]] if r["need"][i] else [])

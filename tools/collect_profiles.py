@@ -12,14 +12,24 @@ for cfg in ("4k", "allintra", "8k"):
     f = os.path.join(src, "pmc_traffic_%s.json" % cfg)
     if os.path.exists(f):
         configs[cfg] = json.load(open(f))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    SRC_HASH = bench.kernel_source_hash()          # the summaries say which kernel sources they were measured with (bench.py: "stale" when the library's differ)
+except Exception:
+    SRC_HASH = None
+sq = os.path.join(src, "sq_counters_4k.json")
+if os.path.exists(sq):
+    d = json.load(open(sq)); d["kernel_source_hash"] = SRC_HASH
+    json.dump(d, open(os.path.join(P, rnd + "_sq_counters.json"), "w"), indent=1)
 if configs:
-    json.dump({"_note": "HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over bench.py (one picture in flight), "
+    json.dump({"kernel_source_hash": SRC_HASH, "_note": "HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over bench.py (one picture in flight), "
                         "gfx950 correction of the MI355X guide applied (tools/pmc_summary.py); keyed by bench configuration and kernel", "configs": configs},
               open(os.path.join(P, rnd + "_pmc_traffic.json"), "w"), indent=1)
 for a, b in (("deblock_counters.json", "_deblock_counters.json"), ("host.txt", "_gpu_box_host.txt"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"),
              ("bench_4k_steps20_warmup5.json", "_bench_steps20_warmup5.json"), ("bench_4k_steps64_warmup16.json", "_bench_steps64_warmup16.json"), ("bench_4k_lf_init_host.json", "_bench_steps20_lf_init_host.json"),
              ("bench_allintra.json", "_bench_allintra.json"), ("bench_8k.json", "_bench_8k.json"), ("gpu_parity_suite.log", "_gpu_parity_suite.log"),
-             ("kernels_alone.txt", "_kernels_alone.txt"), ("intra_block_phases.txt", "_intra_block_phases.txt"), ("dropin_decode.json", "_dropin_decode.json")):
+             ("kernels_alone.txt", "_kernels_alone.txt"), ("kernels_alone_rocprof.txt", "_kernels_alone_rocprof.txt"), ("bench_4k_default.json", "_bench_default_steps64.json"), ("intra_block_phases.txt", "_intra_block_phases.txt"), ("dropin_decode.json", "_dropin_decode.json")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(P, rnd + b))
 print(sorted(f for f in os.listdir(P) if f.startswith(rnd)))

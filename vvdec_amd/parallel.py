@@ -1,17 +1,19 @@
-"""Multi-GPU sharding of the reconstruction path: one process per GPU, one closed-GOP segment per process.
+"""Multi-GPU sharding of the reconstruction path: one process per GPU.
 
-The path shards by independently decodable SEGMENT (an IRAP picture and everything that predicts from it, directly or
-transitively, up to the next IRAP — in the reference that is the unit `DecLib` can start decoding at,
-source/Lib/DecoderLib/DecLib.cpp:182-312).  Pictures inside a segment depend on each other through their reference lists
-(whole-picture dependencies, DecLibRecon.cpp:460-489), so a segment stays on one GPU with its own DPB; segments never read
-each other's pictures, hence there is NO data-path collective.  torch.distributed (RCCL on GPUs, gloo in the CPU tests) is
-used only for the control plane: the barrier around the timed region, the max-over-ranks time and gathering per-picture
-MD5s for verification.
+PICTURE mode (`PictureParallel`; SURVEY.md §8(e), BASELINE north_star: "frames shard one-per-GPU, DPB replicated via RCCL ... only for
+inter-GPU references"; what `bench.py --gpus N` reports as `value`): ONE stream over all ranks, pictures round-robin within their
+temporal layer, every rank keeps a DPB of its own in one torch tensor (`vvr_config.ext_planes`), and a reconstructed picture that a
+picture on ANOTHER rank predicts from goes, slot to slot, from the rank that reconstructed it to the ranks that need it.  The transfer
+is point to point by default (`transfer="p2p"`: exactly the ranks that own a dependant take part - one or two of eight for most
+pictures of a hierarchical-B GOP; xGMI is a point-to-point fabric, a ring broadcast would move the 25 MB of a 4K picture over every
+link) and a rank-wide RCCL broadcast on request (`transfer="broadcast"`: the literal reading of north_star; every rank receives every
+replicated picture).  Both are ordered on the device against the back-end's pictures (vvr_stream_wait_job / vvr_stream_wait_slot /
+vvr_slot_external_event); the reference's DPB book-keeping this mirrors is CommonLib/PicListManager.cpp:234-283.
 
-Picture-level sharding of ONE stream (BASELINE north_star: "frames shard one-per-GPU, DPB replicated via RCCL
-broadcast only for inter-GPU references") is `PictureParallel` below: pictures go to the ranks round-robin within their temporal
-layer, every rank keeps a DPB of its own in one torch tensor (`vvr_config.ext_planes`), and a reference picture that a picture
-on another rank predicts from is broadcast once, slot to slot, from the rank that reconstructed it.
+SEGMENT mode (`reconstruct_segments`; reported beside it as `value_segment_mode`): the stream shards by independently decodable
+segment (an IRAP picture and everything that predicts from it up to the next IRAP - the unit `DecLib` can start decoding at,
+source/Lib/DecoderLib/DecLib.cpp:182-312); a segment stays on one GPU with its own DPB, segments never read each other's pictures:
+no data-path collective, torch.distributed carries the barrier, the max-over-ranks time and the per-picture MD5s only.
 """
 import hashlib
 import os
@@ -151,6 +153,30 @@ def strong_scaling_ceiling(plans, cost):
     return (total / critical if critical else 1.0), total, critical
 
 
+def predicted_speedup(plans, world, cost, transfer_cost=0.0):
+    """What the picture split of `plans` (submission order) over `world` ranks should reach against one rank, by a plain list schedule of the reference graph:
+    every rank takes its pictures (assign_owners) in order, one after the other (a device's throughput: cost(plan) per picture), a picture starts when its
+    rank is free and its reference pictures are done - plus transfer_cost when a reference was reconstructed on another rank.  Returns (speedup, makespan of
+    one rank, makespan of `world` ranks).  For the driver's window sizes (20 pictures per GPU) the first IRAP's chain and the fill of the hierarchy are part
+    of the window; over an open stream the IRAPs, which depend on nothing, leave the critical path and the speedup approaches `world`."""
+    def makespan(n):
+        owners = assign_owners(plans, n)
+        free = [0.0] * n
+        done = {}
+        for pl, r in zip(plans, owners):
+            start = free[r]
+            for poc in list(pl.l0 or []) + list(pl.l1 or []):
+                if poc in done:
+                    t, o = done[poc]
+                    start = max(start, t + (transfer_cost if o != r else 0.0))
+            end = start + float(cost(pl))
+            done[pl.poc] = (end, r)
+            free[r] = end
+        return max(free)
+    t1, tn = makespan(1), makespan(world)
+    return (t1 / tn if tn else 1.0), t1, tn
+
+
 class TorchDeviceRuntime:
     """streams and events of the collective on a GPU: one torch stream the RCCL operations are ordered on"""
 
@@ -170,6 +196,12 @@ class TorchDeviceRuntime:
         with self.torch.cuda.stream(self.stream):
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+
+    def broadcast(self, view, src):
+        """rank-wide RCCL broadcast of a slot, ordered like transfer()"""
+        import torch.distributed as dist
+        with self.torch.cuda.stream(self.stream):
+            dist.broadcast(view, src)
 
     def event_ptr(self):
         ev = self.torch.cuda.Event()
@@ -206,6 +238,10 @@ class HostStubRuntime:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 
+    def broadcast(self, view, src):
+        import torch.distributed as dist
+        dist.broadcast(view, src)
+
     def event_ptr(self):
         e = self.C.c_void_p()
         self.L.hipEventCreate(self.C.byref(e))
@@ -241,10 +277,14 @@ class PictureParallel:
     `rec` is this rank's Reconstructor created with ext_planes = dpb.data_ptr(); `dpb` a uint8 tensor of num_slots * rec.slot_bytes();
     `runtime`: TorchDeviceRuntime() on GPUs (default when dpb is a CUDA tensor), HostStubRuntime(stub library) in the CPU tests."""
 
-    def __init__(self, rec, dpb, plans, rank, world, replicate=True, runtime=None):
+    def __init__(self, rec, dpb, plans, rank, world, replicate=True, runtime=None, transfer="p2p"):
+        assert transfer in ("p2p", "broadcast")
         self.rec, self.dpb, self.plans, self.rank, self.world = rec, dpb, plans, rank, world
+        self.transfer = transfer
         self.owners = assign_owners(plans, world)
         self.deps = dependants(plans, self.owners) if replicate else [[] for _ in plans]
+        if transfer == "broadcast":       # every rank receives every replicated picture
+            self.deps = [[r for r in range(world) if r != self.owners[i]] if d else [] for i, d in enumerate(self.deps)]
         self.need = [bool(d) for d in self.deps]
         self.slot_bytes = rec.slot_bytes()
         self.rt = runtime if runtime is not None else (TorchDeviceRuntime() if getattr(dpb, "is_cuda", False) else None)
@@ -264,14 +304,20 @@ class PictureParallel:
         if owner == self.rank:
             if not self.rec.stream_wait_job(job, self.rt.stream_ptr(), blocking):
                 return False
-            self.rt.transfer([dist.P2POp(dist.isend, view, r) for r in self.deps[i]])
+            if self.transfer == "broadcast":
+                self.rt.broadcast(view, owner)
+            else:
+                self.rt.transfer([dist.P2POp(dist.isend, view, r) for r in self.deps[i]])
             self.rec.slot_external_event(pl.slot, self.rt.event_ptr(), writes=False)
             self.trace.append(("send", i))
             self.bytes_sent += self.slot_bytes * len(self.deps[i])
         else:
             if not self.rec.stream_wait_slot(pl.slot, self.rt.stream_ptr(), blocking):
                 return False
-            self.rt.transfer([dist.P2POp(dist.irecv, view, owner)])
+            if self.transfer == "broadcast":
+                self.rt.broadcast(view, owner)
+            else:
+                self.rt.transfer([dist.P2POp(dist.irecv, view, owner)])
             self.rec.slot_external_event(pl.slot, self.rt.event_ptr(), writes=True)
             self.trace.append(("recv", i))
         self.n_bcast += 1
