@@ -250,93 +250,108 @@ __device__ __forceinline__ void mc_load_window( pel_t* win, int wst, const McSeg
 }
 
 // BDOF of one <= 16x16 luma tile (applyBiOptFlow :1290, gradFilterCore :213, BiOptFlowCore :162, calcBIOSums :134, addBIOAvg4 :108);
-// the windows must hold the integer samples around the block (ox, oy >= 1 beyond the filter support)
+// the windows must hold the integer samples around the block (ox, oy >= 1 beyond the filter support).
+// Round 6: no gradient arrays, no lane shuffles through LDS.  A lane owns ONE COLUMN of one row of 4x4 units (64 lanes = 4 unit rows x 16 columns): it forms the
+// gradients and the five products of the unit row's six window rows from the predictions themselves (the block is stored with two rows of slack above and below its
+// one-sample border, so that the eight rows the six positions read are plain offsets; the two positions a block edge replicates are copied from their neighbours
+// afterwards), sums them down its column, and the six-column sums of a unit come together with DPP moves inside the 16-lane row - the column before / behind the unit
+// from the neighbouring quad, or the lane's own value where the window is clamped at the block's edge.  Every lane then refines and writes the four samples of its column.
+#define BDOF_PR 2           /* slack rows above the border row of the padded prediction block */
 struct BdofShared {
-  pel_t blk[2][( 16 + 2 ) * BDOF_S];       // 14-bit luma predictions with a one-sample border, stride BDOF_S
-  pel_t gx[2][16 * 16], gy[2][16 * 16];    // gradients of the interior
+  pel_t blk[2][( 16 + 2 + 2 * BDOF_PR ) * BDOF_S];       // 14-bit luma predictions with a one-sample border, stride BDOF_S; sample (x, y) at [( BDOF_PR + 1 + y ) * BDOF_S + 1 + x]
 };
+#define BDOF_AT( x, y ) ( ( BDOF_PR + 1 + ( y ) ) * BDOF_S + 1 + ( x ) )
 template<int NT>
 __device__ __forceinline__ void mc_bdof_luma( BdofShared& bs, const pel_t* win0, const pel_t* win1, int wst, const McSeg* seg /* luma segment of list 0 */, int segStride,
                                               int bd, const DevPlanes& reco, int x0, int y0, int w, int h, int tid, const int16_t* __restrict__ fwdLut /* LMCS forward map or nullptr */ )
 {
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  const int lw = w == 16 ? 4 : 3;
   const McSeg& g0 = seg[0]; const McSeg& g1 = seg[segStride];
   // (1) bs.blk holds the 14-bit predictions of both lists (written by the vertical filter stage); add the border of nearest
-  //     integer samples around them (xPredInterBlk :863-890)
+  //     integer samples around them (xPredInterBlk :863-890): lanes 0 .. w + 1 the rows above and below, the next h lanes the columns left and right, both lists
+  if( tid < w + 2 + h )
   {
-    const int ring = 2 * ( w + 2 ) + 2 * h;
-    for( int i = tid; i < 2 * ring; i += NT )
-    {
-      const int l = i >= ring, r = i - l * ring;
-      int bi_, bj;                                       // padded coordinates: (0,0) = corner above-left of the block
-      if( r < w + 2 ) { bi_ = r; bj = 0; } else if( r < 2 * ( w + 2 ) ) { bi_ = r - ( w + 2 ); bj = h + 1; }
-      else { const int q = r - 2 * ( w + 2 ); bi_ = ( q & 1 ) ? w + 1 : 0; bj = 1 + ( q >> 1 ); }
-      const McSeg& g = l ? g1 : g0;
-      const int xOff = g.xFrac < 8 ? 1 : 0, yOff = g.yFrac < 8 ? 1 : 0;
-      const int sref = ( l ? win1 : win0 )[( g.oy - yOff + bj ) * wst + g.ox - xOff + bi_];
-      bs.blk[l][bj * BDOF_S + bi_] = (pel_t) ( (int16_t) ( sref << headroom ) - (int16_t) IF_INTERNAL_OFFS );
-    }
-  }
-  __syncthreads();
-  // (2) gradients of the interior; everything outside is a replica of the nearest interior value (the padding of :236-264),
-  //     which is what the clamped indices below read
-  for( int i = tid; i < w * h; i += NT )
-  {
-    const int px = i & ( w - 1 ), py = i >> lw;
+    const bool row = tid < w + 2;
+    const int q = row ? tid : tid - ( w + 2 );
+#pragma unroll
     for( int l = 0; l < 2; l++ )
     {
-      const pel_t* P = bs.blk[l];
-      bs.gy[l][py * 16 + px] = (pel_t) ( ( P[( 2 + py ) * BDOF_S + 1 + px] >> 6 ) - ( P[py * BDOF_S + 1 + px] >> 6 ) );
-      bs.gx[l][py * 16 + px] = (pel_t) ( ( P[( 1 + py ) * BDOF_S + 2 + px] >> 6 ) - ( P[( 1 + py ) * BDOF_S + px] >> 6 ) );
+      const McSeg& g = l ? g1 : g0;
+      const pel_t* wn = l ? win1 : win0;
+      const int xOff = g.xFrac < 8 ? 1 : 0, yOff = g.yFrac < 8 ? 1 : 0;
+      // padded coordinates (bi, bj): (0, 0) = the corner above-left of the block
+      const int biA = row ? q : 0, bjA = row ? 0 : 1 + q, biB = row ? q : w + 1, bjB = row ? h + 1 : 1 + q;
+      const int sA = wn[( g.oy - yOff + bjA ) * wst + g.ox - xOff + biA], sB = wn[( g.oy - yOff + bjB ) * wst + g.ox - xOff + biB];
+      bs.blk[l][BDOF_AT( biA - 1, bjA - 1 )] = (pel_t) ( ( sA << headroom ) - IF_INTERNAL_OFFS );
+      bs.blk[l][BDOF_AT( biB - 1, bjB - 1 )] = (pel_t) ( ( sB << headroom ) - IF_INTERNAL_OFFS );
     }
   }
   __syncthreads();
-  // (3) per 4x4 unit: 6x6 window sums by four lanes, motion refinement, output
+  if( tid >= 64 ) return;
+  const int X = tid & 15, yu = tid >> 4;                 // column, row of units
+  const bool act = X < w && 4 * yu < h;
   const int shiftNum = 15 - bd, offset = ( 1 << ( shiftNum - 1 ) ) + 2 * IF_INTERNAL_OFFS;
-  const int unitsX = w >> 2, units = unitsX * ( h >> 2 );
-  for( int u0 = 0; u0 < units; u0 += NT / 4 )
+  int sAGX = 0, sAGY = 0, sDIX = 0, sDIY = 0, sSG = 0;
+  int dgx[4], dgy[4], psum[4];                           // per output row of the column: gx0 - gx1, gy0 - gy1, p0 + p1
   {
-    const int u = u0 + ( tid >> 2 ), q = tid & 3;
-    const bool act = u < units;
-    const int xu = act ? u % unitsX : 0, yu = act ? u / unitsX : 0;
-    int sAGX = 0, sAGY = 0, sDIX = 0, sDIY = 0, sSG = 0;
-    if( act )
+    const int xc = act ? X : 0, yb = act ? 4 * yu : 0;
+    const pel_t* c0 = &bs.blk[0][BDOF_AT( xc, yb - 2 )];
+    const pel_t* c1 = &bs.blk[1][BDOF_AT( xc, yb - 2 )];
+    // rows yb - 2 .. yb + 5 of the column (row -2 / h + 1 of a unit row at the block's edge is slack: only the positions replaced below read it)
+    int P0[8], P1[8];
+#pragma unroll
+    for( int j = 0; j < 8; j++ ) { P0[j] = c0[j * BDOF_S]; P1[j] = c1[j * BDOF_S]; }
+    int aGX[6], aGY[6], dIX[6], dIY[6], sG[6];
+#pragma unroll
+    for( int k = 0; k < 6; k++ )                         // window row yb - 1 + k = register row k + 1
     {
-      for( int p = q; p < 36; p += 4 )
-      {
-        const int wy = p / 6, wx = p - wy * 6;
-        const int ix = min( w - 1, max( 0, ( xu << 2 ) + wx - 1 ) ), iy = min( h - 1, max( 0, ( yu << 2 ) + wy - 1 ) );    // interior coordinates, clamped
-        const int o = iy * 16 + ix, ob = ( 1 + iy ) * BDOF_S + 1 + ix;
-        const int tGX = ( bs.gx[0][o] + bs.gx[1][o] ) >> 1, tGY = ( bs.gy[0][o] + bs.gy[1][o] ) >> 1;
-        const int tDI = ( bs.blk[1][ob] >> 4 ) - ( bs.blk[0][ob] >> 4 );
-        sAGX += iabs( tGX ); sAGY += iabs( tGY );
-        sDIX += tGX < 0 ? -tDI : tGX == 0 ? 0 : tDI;
-        sDIY += tGY < 0 ? -tDI : tGY == 0 ? 0 : tDI;
-        sSG  += tGY < 0 ? -tGX : tGY == 0 ? 0 : tGX;
-      }
+      const int l0m = c0[( k + 1 ) * BDOF_S - 1], l0p = c0[( k + 1 ) * BDOF_S + 1], l1m = c1[( k + 1 ) * BDOF_S - 1], l1p = c1[( k + 1 ) * BDOF_S + 1];
+      const int gx0 = ( l0p >> 6 ) - ( l0m >> 6 ), gx1 = ( l1p >> 6 ) - ( l1m >> 6 );
+      const int gy0 = ( P0[k + 2] >> 6 ) - ( P0[k] >> 6 ), gy1 = ( P1[k + 2] >> 6 ) - ( P1[k] >> 6 );
+      const int tGX = ( gx0 + gx1 ) >> 1, tGY = ( gy0 + gy1 ) >> 1;
+      const int tDI = ( P1[k + 1] >> 4 ) - ( P0[k + 1] >> 4 );
+      const int sgX = clip3( -1, 1, tGX ), sgY = clip3( -1, 1, tGY );
+      aGX[k] = iabs( tGX ); aGY[k] = iabs( tGY );
+      dIX[k] = __mul24( sgX, tDI ); dIY[k] = __mul24( sgY, tDI ); sG[k] = __mul24( sgY, tGX );
+      if( k >= 1 && k <= 4 ) { dgx[k - 1] = gx0 - gx1; dgy[k - 1] = gy0 - gy1; psum[k - 1] = P0[k + 1] + P1[k + 1]; }
     }
-    for( int o = 1; o < 4; o <<= 1 )
+    // the window rows outside the block repeat the block's first / last row (the padding of :236-264)
+    const bool top = yb == 0, bot = yb + 4 >= h;
+    if( top ) { aGX[0] = aGX[1]; aGY[0] = aGY[1]; dIX[0] = dIX[1]; dIY[0] = dIY[1]; sG[0] = sG[1]; }
+    if( bot ) { aGX[5] = aGX[4]; aGY[5] = aGY[4]; dIX[5] = dIX[4]; dIY[5] = dIY[4]; sG[5] = sG[4]; }
+#pragma unroll
+    for( int k = 0; k < 6; k++ ) { sAGX += aGX[k]; sAGY += aGY[k]; sDIX += dIX[k]; sDIY += dIY[k]; sSG += sG[k]; }
+  }
+  // the six columns of the unit's window: the quad's four + the column before and behind it (the quad's own first / last column where the window leaves the block)
+  const bool lastCol = X == w - 1;
+  auto win6 = [&]( int v ) -> int
+  {
+    int q4 = v + __builtin_amdgcn_update_dpp( 0, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true );
+    q4 += __builtin_amdgcn_update_dpp( 0, q4, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true );
+    int before = __builtin_amdgcn_update_dpp( v, v, 0x111 /* row_shr:1: the column before; lane 0 of the row keeps its own */, 0xf, 0xf, false );
+    before = __builtin_amdgcn_update_dpp( 0, before, 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, true );
+    int behind = __builtin_amdgcn_update_dpp( v, v, 0x101 /* row_shl:1: the column behind; lane 15 keeps its own */, 0xf, 0xf, false );
+    behind = lastCol ? v : behind;
+    behind = __builtin_amdgcn_update_dpp( 0, behind, 0xFF /* quad_perm [3,3,3,3] */, 0xf, 0xf, true );
+    return q4 + before + behind;
+  };
+  sAGX = win6( sAGX ); sAGY = win6( sAGY ); sDIX = win6( sDIX ); sDIY = win6( sDIY ); sSG = win6( sSG );
+  if( act )
+  {
+    int tmpx = sAGX == 0 ? 0 : ( ( sDIX * 4 ) >> ( 31 - __clz( sAGX ) ) );        // rightShiftMSB (:92): shift by floor(log2(denominator))
+    tmpx = clip3( -15, 15, tmpx );
+    const int mains = sSG >> 12, secs = sSG & 4095;
+    int tmpData = tmpx * mains;
+    tmpData = ( ( tmpData * ( 1 << 12 ) ) + tmpx * secs ) >> 1;
+    int tmpy = sAGY == 0 ? 0 : ( ( ( sDIY * 4 ) - tmpData ) >> ( 31 - __clz( sAGY ) ) );
+    tmpy = clip3( -15, 15, tmpy );
+    pel_t* dst = reco.p[0] + (size_t) ( y0 + 4 * yu ) * reco.stride[0] + x0 + X;
+#pragma unroll
+    for( int r = 0; r < 4; r++ )
     {
-      sAGX += __shfl_xor( sAGX, o ); sAGY += __shfl_xor( sAGY, o ); sDIX += __shfl_xor( sDIX, o ); sDIY += __shfl_xor( sDIY, o ); sSG += __shfl_xor( sSG, o );
-    }
-    if( act )
-    {
-      int tmpx = sAGX == 0 ? 0 : ( ( sDIX * 4 ) >> ( 31 - __clz( sAGX ) ) );        // rightShiftMSB (:92): shift by floor(log2(denominator))
-      tmpx = clip3( -15, 15, tmpx );
-      const int mains = sSG >> 12, secs = sSG & 4095;
-      int tmpData = tmpx * mains;
-      tmpData = ( ( tmpData * ( 1 << 12 ) ) + tmpx * secs ) >> 1;
-      int tmpy = sAGY == 0 ? 0 : ( ( ( sDIY * 4 ) - tmpData ) >> ( 31 - __clz( sAGY ) ) );
-      tmpy = clip3( -15, 15, tmpy );
-      const int py = ( yu << 2 ) + q;
-      for( int x = 0; x < 4; x++ )
-      {
-        const int px = ( xu << 2 ) + x, o = py * 16 + px, ob = ( 1 + py ) * BDOF_S + 1 + px;
-        const int b = tmpx * ( bs.gx[0][o] - bs.gx[1][o] ) + tmpy * ( bs.gy[0][o] - bs.gy[1][o] );
-        const int v = clip_pel( (int16_t) ( ( bs.blk[0][ob] + bs.blk[1][ob] + b + offset ) >> shiftNum ), bd );
-        reco.p[0][(size_t) ( y0 + py ) * reco.stride[0] + x0 + px] = (pel_t) lmcs_fwd_luma( fwdLut, 0, v );
-      }
+      const int b = tmpx * dgx[r] + tmpy * dgy[r];
+      const int v = clip_pel( ( psum[r] + b + offset ) >> shiftNum, bd );
+      dst[(size_t) r * reco.stride[0]] = (pel_t) lmcs_fwd_luma( fwdLut, 0, v );
     }
   }
 }
@@ -651,7 +666,7 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
     {
 #pragma unroll
       for( int i = 0; i < 8; i++ )
-        if( i < nrows ) { bsp->blk[0][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) ( p[0][i] >> 6 ); bsp->blk[1][( 1 + 8 * g8 + i ) * BDOF_S + 1 + x] = (pel_t) ( p[1][i] >> 6 ); }
+        if( i < nrows ) { bsp->blk[0][BDOF_AT( x, 8 * g8 + i )] = (pel_t) ( p[0][i] >> 6 ); bsp->blk[1][BDOF_AT( x, 8 * g8 + i )] = (pel_t) ( p[1][i] >> 6 ); }
       continue;
     }
     int out[8];
@@ -1100,10 +1115,10 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
 #define AF_WC 8             // row stride of a chroma sub-block window (7 x 7)
 struct AffSeg { int x0, y0, xFrac, yFrac, wrapOff; };     // window origin (block origin - 3 / - 1) in the reference plane, fractional MV, wrap-around period (0: clamped reads)
 struct AffShared {
-  pel_t  winL[2][16][11 * AF_WL];
-  pel_t  winC[2][2][4][7 * AF_WC];
-  pel_t  tmpL[2][16][11 * 4];
-  pel_t  tmpC[2][2][4][7 * 4];
+  __attribute__( ( aligned( 16 ) ) ) pel_t winL[2][16][12 * AF_WL];        // (row 11 is scratch: the second row of the last row pair of the horizontal stage)
+  __attribute__( ( aligned( 16 ) ) ) pel_t winC[2][2][4][8 * AF_WC];
+  __attribute__( ( aligned( 16 ) ) ) uint32_t tmpL[2][16][4][6];           // horizontal stage, 14 bit: [column][row pair]
+  __attribute__( ( aligned( 16 ) ) ) uint32_t tmpC[2][2][4][4][4];
   pel_t  ext[2][16][36];          // PROF: 6x6 block of 14-bit luma samples (interior = prediction, ring = integer reference samples)
   pel_t  predL[2][16 * 16];       // per list: final (uni) or 14-bit (bi) luma after PROF
   AffSeg segL[2][16], segC[2][4];
@@ -1149,35 +1164,19 @@ __device__ __forceinline__ void aff_span_mv( const vvr_cu& cu, int l, int wx, in
   mx = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mx ); my = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, my );
 }
 
-// one 4x4 sub-block sample: the four (xFrac, yFrac) cases of xPredAffineBlk (:1224-1236) = xPredInterBlk's arithmetic
-__device__ __forceinline__ int aff_sample( const pel_t* win, int wst, const pel_t* tmp, const AffSeg& g, int comp, bool bi, int bd, int px, int py )
+// one chroma sample of a 4x4 sub-block from its column of horizontally filtered row pairs (vertical 4-tap stage; the identity filter for a whole-sample vector:
+// the four (xFrac, yFrac) cases of xPredAffineBlk :1224-1236 = xPredInterBlk's arithmetic)
+__device__ __forceinline__ int aff_chroma_sample( const uint32_t* col /* 4 row pairs */, int yFrac, int py, bool bi, int bd, int headroom )
 {
-  const int ntaps = comp ? 4 : 8, half = ntaps / 2 - 1;
-  const int headroom = 14 - bd > 2 ? 14 - bd : 2;
-  const int16_t* ch = comp ? d_chroma_filter[g.xFrac] : d_luma_filter_4x4[g.xFrac];
-  const int16_t* cv = comp ? d_chroma_filter[g.yFrac] : d_luma_filter_4x4[g.yFrac];
-  const bool doH = g.xFrac != 0, doV = g.yFrac != 0;
-  if( !doH && !doV )
-  {
-    const int s = win[( py + half ) * wst + px + half];
-    return bi ? (int16_t) ( (int16_t) ( s << headroom ) - (int16_t) IF_INTERNAL_OFFS ) : s;
-  }
-  if( doH != doV )
-  {
-    int shift, offset;
-    if( !bi ) { shift = 6; offset = 32; } else { shift = 6 - headroom; offset = -IF_INTERNAL_OFFS * ( 1 << shift ); }
-    int sum = 0;
-    if( doH ) { for( int t = 0; t < ntaps; t++ ) sum += win[( py + half ) * wst + px + t] * ch[t]; }
-    else      { for( int t = 0; t < ntaps; t++ ) sum += win[( py + t ) * wst + px + half] * cv[t]; }
-    const int val = (int16_t) ( ( sum + offset ) >> shift );
-    return bi ? val : clip_pel( val, bd );
-  }
-  int shift2, offset2;
-  if( !bi ) { shift2 = 6 + headroom; offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 ); } else { shift2 = 6; offset2 = 0; }
-  int sum = 0;
-  for( int t = 0; t < ntaps; t++ ) sum += tmp[( py + t ) * 4 + px] * cv[t];
-  const int val = (int16_t) ( ( sum + offset2 ) >> shift2 );
-  return bi ? val : clip_pel( val, bd );
+  const uint4 u = *reinterpret_cast<const uint4*>( col );
+  const uint4 C = d_mcTaps[MCT_CHROMA + yFrac];
+  const uint32_t D[4] = { u.x, u.y, u.z, u.w };
+  const int m = py >> 1;
+  uint32_t a = m ? D[1] : D[0], b = m ? D[2] : D[1];
+  if( py & 1 ) { const uint32_t c = m ? D[3] : D[2]; a = __builtin_amdgcn_alignbit( b, a, 16 ); b = __builtin_amdgcn_alignbit( c, b, 16 ); }
+  const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
+  const int sum = mc_dot2( b, C.y, mc_dot2( a, C.x, bi ? 0 : offset2 ) );
+  return bi ? sum >> 6 : clip_pel( sum >> shift2, bd );
 }
 
 template<int NT>
@@ -1206,6 +1205,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   const bool hi = biPred || wpOn;
   const int headroom = 14 - bd > 2 ? 14 - bd : 2;
   const McBounds AB = mc_bounds( pic, cu.x, cu.y );
+  bool inside = true;                 // every window of the tile this lane laid out lies inside the picture (sub-picture): the windows can be loaded as dwords
   // ---- sub-block geometry
   {
     // (picture bounds, or the CU's sub-picture when that is treated as a picture: clipMvInSubpic against the CU, :1188-1193)
@@ -1229,6 +1229,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
         g.xFrac = mx & 15; g.yFrac = my & 15;
         g.x0 = it.x + 4 * sx + ( mx >> 4 ) - 3; g.y0 = it.y + 4 * sy + ( my >> 4 ) - 3;
         sh.segL[k][r] = g;
+        inside = inside && !g.wrapOff && g.x0 >= AB.x0 && g.y0 >= AB.y0 && g.x0 + 10 <= AB.x1 && g.y0 + 10 <= AB.y1 && g.x0 - ( g.x0 & 1 ) + 12 <= reco.stride[0];
       }
       else
       {
@@ -1253,6 +1254,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
         g.xFrac = mx & 31; g.yFrac = my & 31;
         g.x0 = ( it.x >> 1 ) + 4 * sx + ( mx >> 5 ) - 1; g.y0 = ( it.y >> 1 ) + 4 * sy + ( my >> 5 ) - 1;
         sh.segC[k][q] = g;
+        inside = inside && !g.wrapOff && g.x0 >= ( AB.x0 >> 1 ) && g.y0 >= ( AB.y0 >> 1 ) && g.x0 + 6 <= ( AB.x1 >> 1 ) && g.y0 + 6 <= ( AB.y1 >> 1 ) && g.x0 - ( g.x0 & 1 ) + 8 <= reco.stride[1];
       }
     }
     if( tid < nl )
@@ -1284,9 +1286,37 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       }
     }
   }
-  __syncthreads();
-  // ---- windows: 11x11 per luma sub-block, 7x7 per chroma sub-block, clamped coordinates
+  const bool fastWin = __syncthreads_and( inside ) != 0;
+  // ---- windows: 11x11 per luma sub-block, 7x7 per chroma sub-block
+  if( fastWin )
   {
+    // every window inside: dword loads, 8 (luma) / 4 (chroma) lanes per window row, an odd first column realigned with one DPP move + v_alignbit (as mc3_load_*)
+    const int q = tid & 7, rowsL = nl * nsb * 11;
+    for( int R = tid >> 3; R < rowsL; R += NT / 8 )
+    {
+      const int blk = R / 11, yy = R - blk * 11, k = blk / nsb, sb = blk - k * nsb;
+      const int x0 = sh.segL[k][sb].x0, y0 = sh.segL[k][sb].y0, odd = x0 & 1;
+      uint32_t v = 0;
+      if( q < 6 ) v = reinterpret_cast<const uint32_t*>( sh.refp[k][0] + (size_t) ( y0 + yy ) * reco.stride[0] + ( x0 - odd ) )[q];
+      const uint32_t w = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v ), v, odd << 4 );
+      if( q < 6 ) reinterpret_cast<uint32_t*>( &sh.winL[k][sb][yy * AF_WL] )[q] = w;
+    }
+    if( ncomp == 3 )
+    {
+      const int q4 = tid & 3, rowsC = nl * 2 * ncb * 7;
+      for( int R = tid >> 2; R < rowsC; R += NT / 4 )
+      {
+        const int blk = R / 7, yy = R - blk * 7, k = blk / ( 2 * ncb ), qq = blk - k * 2 * ncb, c = qq / ncb, sb = qq - c * ncb;
+        const int x0 = sh.segC[k][sb].x0, y0 = sh.segC[k][sb].y0, odd = x0 & 1;
+        const uint32_t v = reinterpret_cast<const uint32_t*>( sh.refp[k][1 + c] + (size_t) ( y0 + yy ) * reco.stride[1] + ( x0 - odd ) )[q4];
+        const uint32_t w = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v ), v, odd << 4 );      // (lane 3 takes its upper half from another row: column 7 of the window is never read)
+        reinterpret_cast<uint32_t*>( &sh.winC[k][c][sb][yy * AF_WC] )[q4] = w;
+      }
+    }
+  }
+  else
+  {
+    // clamped / wrapped coordinates, sample by sample
     const int nL = nl * nsb * 11 * AF_WL;
     for( int i = tid; i < nL; i += NT )
     {
@@ -1312,40 +1342,94 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
     }
   }
   __syncthreads();
-  // ---- horizontal pass of the sub-blocks with a 2-D fractional MV
+  // ---- the two filter stages of every sub-block, in the form of k_mc (round 6): horizontal filter of two window rows x four columns per work item to 14-bit
+  // intermediates [column][row pair], vertical filter of a column of four rows per work item and list - v_dot2_i32_i16 on sample pairs, the identity filter where
+  // the vector has no fractional part in a direction (exact: 64 s >> 6; xPredAffineBlk :1224-1236 = xPredInterBlk's four cases), taps from d_mcTaps per lane
+  // (every sub-block has its own fraction; luma: the table of 4x4 blocks)
   {
-    const int shift1 = 6 - headroom, offset1 = -IF_INTERNAL_OFFS * ( 1 << shift1 );
-    for( int i = tid; i < nl * nsb * 44; i += NT )
+    const int shift1 = 6 - headroom, offset1 = __builtin_amdgcn_readfirstlane( -IF_INTERNAL_OFFS * ( 1 << shift1 ) );
+    const int itemsL = nl * nsb * 6;
+    for( int idx = tid; idx < itemsL; idx += NT )
     {
-      const int blk = i / 44, r = i - blk * 44, yy = r >> 2, xx = r & 3, k = blk / nsb, sb = blk - k * nsb;
-      const AffSeg g = sh.segL[k][sb];
-      if( !( g.xFrac && g.yFrac ) ) continue;
-      const int16_t* cf = d_luma_filter_4x4[g.xFrac];
-      int sum = 0;
-      for( int t = 0; t < 8; t++ ) sum += sh.winL[k][sb][yy * AF_WL + xx + t] * cf[t];
-      sh.tmpL[k][sb][r] = (int16_t) ( ( sum + offset1 ) >> shift1 );
+      const int blk = idx / 6, rp = idx - blk * 6, k = blk / nsb, sb = blk - k * nsb;
+      const uint4 C = d_mcTaps[MCT_4X4 + sh.segL[k][sb].xFrac];
+      const uint2* s0 = reinterpret_cast<const uint2*>( &sh.winL[k][sb][2 * rp * AF_WL] );
+      int a[4], b[4];
+#pragma unroll
+      for( int rr = 0; rr < 2; rr++ )
+      {
+        const uint2 u0 = s0[3 * rr], u1 = s0[3 * rr + 1], u2 = s0[3 * rr + 2];
+        const uint32_t D[6] = { u0.x, u0.y, u1.x, u1.y, u2.x, u2.y };
+        uint32_t S[5];
+#pragma unroll
+        for( int e = 0; e < 5; e++ ) S[e] = __builtin_amdgcn_alignbit( D[e + 1], D[e], 16 );
+        int o[4];
+        o[0] = mc_dot2_init( D[0], C.x, offset1 ); o[1] = mc_dot2_init( S[0], C.x, offset1 ); o[2] = mc_dot2_init( D[1], C.x, offset1 ); o[3] = mc_dot2_init( S[1], C.x, offset1 );
+        o[0] = mc_dot2( D[1], C.y, o[0] ); o[1] = mc_dot2( S[1], C.y, o[1] ); o[2] = mc_dot2( D[2], C.y, o[2] ); o[3] = mc_dot2( S[2], C.y, o[3] );
+        o[0] = mc_dot2( D[2], C.z, o[0] ); o[1] = mc_dot2( S[2], C.z, o[1] ); o[2] = mc_dot2( D[3], C.z, o[2] ); o[3] = mc_dot2( S[3], C.z, o[3] );
+        o[0] = mc_dot2( D[3], C.w, o[0] ); o[1] = mc_dot2( S[3], C.w, o[1] ); o[2] = mc_dot2( D[4], C.w, o[2] ); o[3] = mc_dot2( S[4], C.w, o[3] );
+#pragma unroll
+        for( int e = 0; e < 4; e++ ) { if( rr ) b[e] = o[e] >> shift1; else a[e] = o[e] >> shift1; }
+      }
+#pragma unroll
+      for( int e = 0; e < 4; e++ ) sh.tmpL[k][sb][e][rp] = __builtin_amdgcn_perm( (uint32_t) b[e], (uint32_t) a[e], 0x05040100u );
     }
     if( ncomp == 3 )
-      for( int i = tid; i < nl * 2 * ncb * 28; i += NT )
+    {
+      const int itemsC = nl * 2 * ncb * 4;
+      for( int idx = tid; idx < itemsC; idx += NT )
       {
-        const int blk = i / 28, r = i - blk * 28, yy = r >> 2, xx = r & 3, k = blk / ( 2 * ncb ), q = blk - k * 2 * ncb, c = q / ncb, sb = q - c * ncb;
-        const AffSeg g = sh.segC[k][sb];
-        if( !( g.xFrac && g.yFrac ) ) continue;
-        const int16_t* cf = d_chroma_filter[g.xFrac];
-        int sum = 0;
-        for( int t = 0; t < 4; t++ ) sum += sh.winC[k][c][sb][yy * AF_WC + xx + t] * cf[t];
-        sh.tmpC[k][c][sb][r] = (int16_t) ( ( sum + offset1 ) >> shift1 );
+        const int blk = idx >> 2, rp = idx & 3, k = blk / ( 2 * ncb ), qq = blk - k * 2 * ncb, c = qq / ncb, sb = qq - c * ncb;
+        const uint4 C = d_mcTaps[MCT_CHROMA + sh.segC[k][sb].xFrac];
+        int a[4], b[4];
+#pragma unroll
+        for( int rr = 0; rr < 2; rr++ )
+        {
+          const uint4 u = *reinterpret_cast<const uint4*>( &sh.winC[k][c][sb][( 2 * rp + rr ) * AF_WC] );
+          const uint32_t D[4] = { u.x, u.y, u.z, u.w };
+          uint32_t S[3];
+#pragma unroll
+          for( int e = 0; e < 3; e++ ) S[e] = __builtin_amdgcn_alignbit( D[e + 1], D[e], 16 );
+          int o[4];
+          o[0] = mc_dot2_init( D[0], C.x, offset1 ); o[1] = mc_dot2_init( S[0], C.x, offset1 ); o[2] = mc_dot2_init( D[1], C.x, offset1 ); o[3] = mc_dot2_init( S[1], C.x, offset1 );
+          o[0] = mc_dot2( D[1], C.y, o[0] ); o[1] = mc_dot2( S[1], C.y, o[1] ); o[2] = mc_dot2( D[2], C.y, o[2] ); o[3] = mc_dot2( S[2], C.y, o[3] );
+#pragma unroll
+          for( int e = 0; e < 4; e++ ) { if( rr ) b[e] = o[e] >> shift1; else a[e] = o[e] >> shift1; }
+        }
+#pragma unroll
+        for( int e = 0; e < 4; e++ ) sh.tmpC[k][c][sb][e][rp] = __builtin_amdgcn_perm( (uint32_t) b[e], (uint32_t) a[e], 0x05040100u );
       }
+    }
   }
   __syncthreads();
-  // ---- luma: prediction (14-bit when bi-predicted or refined by PROF), PROF border from the integer reference samples
-  for( int i = tid; i < nl * w * h; i += NT )
+  // ---- luma: vertical stage = the prediction (14-bit when bi-predicted or refined by PROF; else the final sample), a column of a sub-block per work item and list
   {
-    const int k = i / ( w * h ), r = i - k * w * h, sb = r >> 4, px = r & 3, py = ( r >> 2 ) & 3;
-    const bool prof = sh.prof[k] != 0;
-    const int v = aff_sample( sh.winL[k][sb], AF_WL, sh.tmpL[k][sb], sh.segL[k][sb], 0, hi || prof, bd, px, py );
-    if( prof ) sh.ext[k][sb][( 1 + py ) * 6 + 1 + px] = (pel_t) v;
-    else sh.predL[k][sb * 16 + py * 4 + px] = (pel_t) v;
+    const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
+    for( int idx = tid; idx < nl * nsb * 4; idx += NT )
+    {
+      const int k = idx / ( nsb * 4 ), r = idx - k * nsb * 4, sb = r >> 2, x = r & 3;
+      const bool prof = sh.prof[k] != 0, fin = !( hi || prof );
+      const uint4 C = d_mcTaps[MCT_4X4 + sh.segL[k][sb].yFrac];
+      const uint2* tp = reinterpret_cast<const uint2*>( sh.tmpL[k][sb][x] );
+      const uint2 u0 = tp[0], u1 = tp[1], u2 = tp[2];
+      const uint32_t D[6] = { u0.x, u0.y, u1.x, u1.y, u2.x, u2.y };
+      uint32_t S[5];
+#pragma unroll
+      for( int e = 0; e < 5; e++ ) S[e] = __builtin_amdgcn_alignbit( D[e + 1], D[e], 16 );
+      const int init = fin ? offset2 : 0;
+      int o[4] = { init, init, init, init };
+      o[0] = mc_dot2( D[0], C.x, o[0] ); o[1] = mc_dot2( S[0], C.x, o[1] ); o[2] = mc_dot2( D[1], C.x, o[2] ); o[3] = mc_dot2( S[1], C.x, o[3] );
+      o[0] = mc_dot2( D[1], C.y, o[0] ); o[1] = mc_dot2( S[1], C.y, o[1] ); o[2] = mc_dot2( D[2], C.y, o[2] ); o[3] = mc_dot2( S[2], C.y, o[3] );
+      o[0] = mc_dot2( D[2], C.z, o[0] ); o[1] = mc_dot2( S[2], C.z, o[1] ); o[2] = mc_dot2( D[3], C.z, o[2] ); o[3] = mc_dot2( S[3], C.z, o[3] );
+      o[0] = mc_dot2( D[3], C.w, o[0] ); o[1] = mc_dot2( S[3], C.w, o[1] ); o[2] = mc_dot2( D[4], C.w, o[2] ); o[3] = mc_dot2( S[4], C.w, o[3] );
+#pragma unroll
+      for( int y = 0; y < 4; y++ )
+      {
+        const int v = fin ? clip_pel( o[y] >> shift2, bd ) : o[y] >> 6;
+        if( prof ) sh.ext[k][sb][( 1 + y ) * 6 + 1 + x] = (pel_t) v;
+        else sh.predL[k][sb * 16 + y * 4 + x] = (pel_t) v;
+      }
+    }
   }
   for( int i = tid; i < nl * nsb * 20; i += NT )
   {
@@ -1383,8 +1467,8 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
       if( c == 0 ) { p0 = sh.predL[0][sb * 16 + py * 4 + px]; if( biPred ) p1 = sh.predL[1][sb * 16 + py * 4 + px]; }
       else
       {
-        p0 = aff_sample( sh.winC[0][c - 1][sb], AF_WC, sh.tmpC[0][c - 1][sb], sh.segC[0][sb], c, hi, bd, px, py );
-        if( biPred ) p1 = aff_sample( sh.winC[1][c - 1][sb], AF_WC, sh.tmpC[1][c - 1][sb], sh.segC[1][sb], c, true, bd, px, py );
+        p0 = aff_chroma_sample( sh.tmpC[0][c - 1][sb][px], sh.segC[0][sb].yFrac, py, hi, bd, headroom );
+        if( biPred ) p1 = aff_chroma_sample( sh.tmpC[1][c - 1][sb][px], sh.segC[1][sb].yFrac, py, true, bd, headroom );
       }
       int out = p0;
       if( wpOn ) out = biPred ? wp_bi( wpT, cu.ref_idx[0], cu.ref_idx[1], c, p0, p1, bd, headroom ) : wp_uni( wpT, l0, cu.ref_idx[l0], c, p0, bd, headroom );
