@@ -212,7 +212,36 @@ int vvo_reconstruct( const vvr_picture* pic, const uint16_t* const* ref_planes, 
         vvr_cu icu = *cu;
         icu.intra_dir[0] = icu.intra_dir[1] = 0; icu.multi_ref_idx = 0; icu.bdpcm[0] = icu.bdpcm[1] = 0; icu.isp_mode = 0; icu.flags &= (uint16_t) ~VVR_CU_MIP;
         const int wIntra = 1 + ( cu->ciip_neigh_intra & 1 ) + ( ( cu->ciip_neigh_intra >> 1 ) & 1 );
-        if( cu->num_tu != 1 ) { vvo_set_error( "CIIP: CU with several TUs not restated" ); goto done; }
+        if( cu->num_tu != 1 )
+        {
+          /* a CU of several transform units (the split at a largest transform size of 32): predicted and blended as a whole, the residuals are added unit by
+           * unit (finishLMCSAndReco, DecCu.cpp:483-520) - here: collected in a residual of the CU's size (zero where a unit has none: pred + 0, already in range) */
+          const int nc = H->chroma_format ? 3 : 1;
+          int16_t* cuResi[3] = { NULL, NULL, NULL };
+          int any[3] = { 0, 0, 0 }, fail = 0;
+          for( int c = 0; c < nc; c++ ) cuResi[c] = (int16_t*) calloc( (size_t) ( cu->w >> ( c ? 1 : 0 ) ) * ( cu->h >> ( c ? 1 : 0 ) ), sizeof( int16_t ) );
+          for( uint32_t t = cu->first_tu; t < cu->first_tu + cu->num_tu && !fail; t++ )
+          {
+            const vvr_tu* tu = &pic->tu[t];
+            int bw[3], bh[3];
+            const int mask = ( cu->flags & VVR_CU_ROOT_CBF ) ? tu_residuals( pic, cu, tu, resi, bw, bh ) : 0;
+            if( mask < 0 ) { fail = 1; break; }
+            CSCALE_TU( tu, mask )
+            for( int c = 0; c < nc; c++ )
+            {
+              if( !( mask & ( 1 << c ) ) ) continue;
+              const int cs = c ? 1 : 0, ox = ( tu->x - cu->x ) >> cs, oy = ( tu->y - cu->y ) >> cs, cw = cu->w >> cs;
+              for( int y = 0; y < bh[c]; y++ ) for( int x = 0; x < bw[c]; x++ ) cuResi[c][(size_t) ( oy + y ) * cw + ox + x] = resi[c][y * bw[c] + x];
+              any[c] = 1;
+            }
+          }
+          vvr_tu whole = pic->tu[cu->first_tu];
+          whole.x = cu->x; whole.y = cu->y; whole.w = cu->w; whole.h = cu->h;
+          for( int c = 0; c < nc && !fail; c++ ) if( vvo_intra_tu( pic, &icu, &whole, cu->first_tu, c, &reco, order, cuResi[c], any[c], wIntra ) ) fail = 1;
+          for( int c = 0; c < nc; c++ ) free( cuResi[c] );
+          if( fail ) goto done;
+          continue;
+        }
         const vvr_tu* tu = &pic->tu[cu->first_tu];
         int bw[3], bh[3];
         const int mask = ( cu->flags & VVR_CU_ROOT_CBF ) ? tu_residuals( pic, cu, tu, resi, bw, bh ) : 0;

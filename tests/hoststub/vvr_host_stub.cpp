@@ -41,6 +41,7 @@ hipError_t hipEventCreate( hipEvent_t* e ) { StubEvent* p = (StubEvent*) calloc(
 hipError_t hipEventCreateWithFlags( hipEvent_t* e, unsigned ) { return hipEventCreate( e ); }
 hipError_t hipEventDestroy( hipEvent_t e ) { live( e )->dead = 1; return hipSuccess; }
 hipError_t hipEventRecord( hipEvent_t e, hipStream_t s ) { g_trace.push_back( 1 ); g_trace.push_back( ( (StubStream*) s )->id ); g_trace.push_back( live( e )->id ); return hipSuccess; }
+static int g_failLeafWaits = 0;      // vvt_fail_leaf_waits: the next n launches of the intra stage of inter pictures report a wait that gave up (the job's error word)
 static int g_delayUs = 0;      // vvt_set_delay: calls that block on a real device take this long here (stress tests of the host pipeline)
 hipError_t hipEventSynchronize( hipEvent_t e ) { live( e ); if( g_delayUs ) usleep( g_delayUs ); return hipSuccess; }
 hipError_t hipEventElapsedTime( float* ms, hipEvent_t, hipEvent_t ) { *ms = 0.f; return hipSuccess; }
@@ -118,7 +119,7 @@ void launch_intra( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const Intra
 void launch_resi_add( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int ) {}
 static int g_lastLeafItems = -1;
 size_t intra_leaf_map_ints( int w4, int h4, int vpdus ) { return (size_t) 3 * w4 * h4 + 2 * (size_t) vpdus + 64; }
-void launch_intra_leaf( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int numItems, const IntraItem*, int, uint32_t*, size_t, int, int, int* ) { g_lastLeafItems = numItems; }
+void launch_intra_leaf( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const IntraItem*, int numItems, const IntraItem*, int, uint32_t*, size_t, int, int, int* errWord ) { g_lastLeafItems = numItems; if( g_failLeafWaits > 0 && errWord ) { g_failLeafWaits--; *errWord = 1; } /* what a wavefront of k_intra_leaf does when a bounded wait gives up */ }
 // the two output-stage kernels have functional stand-ins (a few plain loops with the kernels' contract: packed window; per row the checksum
 // share or the CRC register reached from 0), so that the host half of vvr_read_output / vvr_picture_hash - window geometry, chaining the rows'
 // CRC pieces - is checked against the reference's own functions without a GPU
@@ -192,6 +193,7 @@ __attribute__(( visibility( "default" ) )) int vvt_table( const vvr_prepared* q,
 __attribute__(( visibility( "default" ) )) unsigned long long vvt_take_h2d_hash( void ) { const uint64_t v = g_h2dHash; g_h2dHash = 1469598103934665603ull; return v; }
 __attribute__(( visibility( "default" ) )) void vvt_take_h2d( size_t* copies, size_t* bytes ) { *copies = g_h2dCopies; *bytes = g_h2dBytes; g_h2dCopies = g_h2dBytes = 0; }
 __attribute__(( visibility( "default" ) )) void vvt_set_delay( int us ) { g_delayUs = us; }
+__attribute__(( visibility( "default" ) )) void vvt_fail_leaf_waits( int n ) { g_failLeafWaits = n; }
 // the edge-parameter tables the last launch_lf_init derived ("device" memory of the picture's image: valid until the ring entry is reused)
 __attribute__(( visibility( "default" ) )) int vvt_last_lfp( const vvr_lfp** d0, const vvr_lfp** d1 ) { *d0 = g_lastLfp[0]; *d1 = g_lastLfp[1]; return g_lastLfpCells; }
 __attribute__(( visibility( "default" ) )) void vvt_slow_i_pictures( int us ) { g_vvtSlowIUs = us; }

@@ -1166,6 +1166,43 @@ def test_errors_of_queued_pictures_come_back_from_wait(stub):
     stub.vvr_destroy(ctx)
 
 
+def test_a_wait_of_the_intra_stage_that_gave_up_fails_its_own_picture(stub):
+    """k_intra_leaf bounds every wait for a neighbouring block; a wavefront that gives up writes the error word of the picture's JOB (pinned host memory) and
+    reconstructs from whatever is there.  That picture - and no other - fails with VVR_ERR_DEVICE wherever the decoder asks about it: vvr_wait, vvr_test, vvr_sync;
+    the pictures around it are fine (round-5 advisor: only vvr_sync looked at a per-lane word, and the drop-in only calls vvr_wait)"""
+    W, H = 256, 128
+    plans, nslots = stream.ra_plan(5, gop=4, seed_poc0_is_external=False)
+    cfg = abi.Config()
+    cfg.abi_version = abi.VVR_ABI_VERSION
+    cfg.device, cfg.max_width, cfg.max_height, cfg.chroma_format, cfg.bit_depth, cfg.log2_ctu = 0, W, H, 1, 10, 7
+    cfg.num_slots, cfg.num_streams, cfg.host_threads = nslots, 2, 2
+    ctx = C.c_void_p()
+    assert stub.vvr_create(C.byref(cfg), C.byref(ctx)) == abi.VVR_OK
+    stub.vvr_submit.argtypes = [C.c_void_p, C.c_void_p]
+    stub.vvr_wait.argtypes = [C.c_void_p, C.c_int]
+    stub.vvr_test.argtypes = [C.c_void_p, C.c_int]
+    stub.vvr_sync.argtypes = [C.c_void_p]
+    descs = [synth.picture_for_plan(pl, W, H, seed=611, tool_flags=TOOLS, p_intra=0.3) for pl in plans]        # (kept alive: the C structs point into their arrays)
+    pics = [d.c() for d in descs]
+    j0 = stub.vvr_submit(ctx, C.byref(pics[0]))                       # the I picture: the CTU-tile kernel, no such wait
+    assert j0 >= 0 and stub.vvr_wait(ctx, j0) == abi.VVR_OK
+    stub.vvt_fail_leaf_waits(1)
+    j1 = stub.vvr_submit(ctx, C.byref(pics[1]))                       # its intra stage gives up a wait
+    assert j1 >= 0 and stub.vvr_wait(ctx, j1) == abi.VVR_ERR_DEVICE
+    assert "waited for its neighbours beyond the bound" in stub.vvr_last_error(ctx).decode()
+    assert stub.vvr_test(ctx, j1) == abi.VVR_ERR_DEVICE               # (asked again: the same answer)
+    j2 = stub.vvr_submit(ctx, C.byref(pics[2]))
+    assert j2 >= 0 and stub.vvr_wait(ctx, j2) == abi.VVR_OK           # the next picture is not tainted
+    stub.vvt_fail_leaf_waits(1)
+    j3 = stub.vvr_submit(ctx, C.byref(pics[3]))
+    j4 = stub.vvr_submit(ctx, C.byref(pics[4]))
+    assert j3 >= 0 and j4 >= 0
+    assert stub.vvr_sync(ctx) == abi.VVR_ERR_DEVICE                   # vvr_sync reports the failed job ...
+    assert stub.vvr_wait(ctx, j4) == abi.VVR_OK                       # ... and the other one of the pair is fine
+    stub.vvt_fail_leaf_waits(0)
+    stub.vvr_destroy(ctx)
+
+
 def test_records_in_pinned_memory_are_not_staged(stub):
     """arrays of a description that lie in memory of vvr_host_alloc go to the device from where they are: per picture one copy of the staged
     rest plus one per pinned array, the same bytes in total (up to alignment padding)"""

@@ -2478,6 +2478,10 @@ FIXTURES = [
                                                ibc=True, p_ibc=0.5), 2, 203),
     # IBC CUs of 64x64 / 64x32 in a sequence whose largest transform is 32: four / two transform units per IBC CU (round 5, finding 13 of DESIGN.md section 3: the randomised
     # GPU leg found such CUs refused by the back-end's record checks)
+    # CIIP coding units of several transform units: a largest transform size of 32 splits a 64-wide / 64-high CIIP CU into two or four units - the CU is predicted and
+    # blended as a whole, the residuals are added unit by unit (DecCu.cpp:449-470); refused by the back-end until round 6
+    ("mini_ciip_tb32_ctu128_384x256", dict(width=384, height=256, log2_ctu=7, log2_min_qt=4, qp=32, max_tb64=False, mtt_depth=1, inter=True, mmvd=True, ciip=True, lmcs=True, jccr=True,
+                                           p_split=0.35, p_merge=0.6, p_cbf=0.8, p_cbf_chroma=0.6, p_intra=0.15), 9, 301),
     ("mini_ibc_tb32_8bit_ctu64_192x128", dict(width=192, height=128, log2_ctu=6, qp=35, bit_depth=8, max_tb64=False, p_cbf=0.8, p_cbf_chroma=0.6, p_split=0.3, ibc=True, p_ibc=0.6), 3, 207),
     # CCLM in the chroma tree of dual-tree pictures (round 5: the writer follows CU::checkCCLMAllowed), with IBC in the luma tree and the filters
     ("mini_dual_tree_cclm_ibc_ctu128_256x256", dict(width=256, height=256, log2_ctu=7, log2_min_qt=4, qp=28, mtt_depth=2, dual_tree=True, cclm=True, mrl=True, isp=True, mip=True, lfnst=True,

@@ -884,7 +884,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
 #define DM_WST_L MC2_WST_L
 struct DmvrShared {
   Mc2Shared m;                   // windows / intermediates / taps of the final prediction (stage 1 reuses winL for the bilinear windows)
-  pel_t bil[2][20 * 20];
+  __attribute__( ( aligned( 16 ) ) ) pel_t bil[2][20 * 20];      // bilinear predictions of the extended sub-block, 10 bit (two per dword in the search)
   unsigned sad[25];
   int dmv[2], bioSub, minCost;
   BdofShared bs;
@@ -940,24 +940,22 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
   __syncthreads();
   {
     // InterpolationFilter::filter<2> (:589-600) / filterCopy biMCForDMVR (:445-477) at IF_INTERNAL_PREC_BILINEAR = 10
+    // One form for the four cases of the reference (copy / horizontal / vertical / both): the horizontal stage to 10 bit, the vertical one on its results.
+    // A whole-sample direction is the weights ( 16, 0 ), which leaves the other stage's value as it is: ( 16 t + 8 ) >> 4 = t, and for fewer than 10 bits
+    // ( 16 p + offF ) >> shiftF = p << ( 10 - bd ) with ( ( A << ( 10 - bd ) ) + 8 ) >> 4 = ( A + offF ) >> shiftF for the vertical-only case.
     const int shiftF = 4 - ( 10 - bd ), offF = shiftF > 0 ? 1 << ( shiftF - 1 ) : 0;
-    const int ew = w + 4, eh = h + 4;
-    for( int i = tid; i < 2 * ew * eh; i += NT )
+    const int ew = w + 4, eh = h + 4, n1 = ew * eh;
+    const int inv = ( 65536 + ew - 1 ) / ew;          // r / ew = ( r * inv ) >> 16 for r < 400 (ew = 12: 5462, ew = 20: 3277)
+    const int fx0 = __builtin_amdgcn_readfirstlane( sh.m.seg[0][0].xFrac ), fy0 = __builtin_amdgcn_readfirstlane( sh.m.seg[0][0].yFrac );
+    const int fx1 = __builtin_amdgcn_readfirstlane( sh.m.seg[1][0].xFrac ), fy1 = __builtin_amdgcn_readfirstlane( sh.m.seg[1][0].yFrac );
+    for( int i = tid; i < 2 * n1; i += NT )
     {
-      const int l = i >= ew * eh, r = i - l * ew * eh, y = r / ew, x = r - y * ew;
-      const McSeg& g = sh.m.seg[l][0];
+      const int l = i >= n1, r = i - ( l ? n1 : 0 ), y = ( r * inv ) >> 16, x = r - y * ew;
+      const int fx = l ? fx1 : fx0, fy = l ? fy1 : fy0;
       const pel_t* p = &sh.m.winL[l][y * DM_WST_L + x];
-      int v;
-      if( !g.xFrac && !g.yFrac ) v = p[0] * ( 1 << ( 10 - bd ) );
-      else if( !g.yFrac ) v = ( p[0] * ( 16 - g.xFrac ) + p[1] * g.xFrac + offF ) >> shiftF;
-      else if( !g.xFrac ) v = ( p[0] * ( 16 - g.yFrac ) + p[DM_WST_L] * g.yFrac + offF ) >> shiftF;
-      else
-      {
-        const int t0 = (int16_t) ( ( p[0] * ( 16 - g.xFrac ) + p[1] * g.xFrac + offF ) >> shiftF );
-        const int t1 = (int16_t) ( ( p[DM_WST_L] * ( 16 - g.xFrac ) + p[DM_WST_L + 1] * g.xFrac + offF ) >> shiftF );
-        v = ( t0 * ( 16 - g.yFrac ) + t1 * g.yFrac + 8 ) >> 4;
-      }
-      sh.bil[l][y * 20 + x] = (pel_t) v;
+      const int t0 = ( p[0] * ( 16 - fx ) + p[1] * fx + offF ) >> shiftF;
+      const int t1 = ( p[DM_WST_L] * ( 16 - fx ) + p[DM_WST_L + 1] * fx + offF ) >> shiftF;
+      sh.bil[l][y * 20 + x] = (pel_t) ( ( t0 * ( 16 - fy ) + t1 * fy + 8 ) >> 4 );
     }
   }
   __syncthreads();
@@ -990,10 +988,24 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
       unsigned sad = 0;
       if( cand < 25 && cand != 12 )
       {
+        // two samples per v_sad_u16 (the 10-bit bilinear predictions are not negative); the two blocks start at columns 2 + hor and 2 - hor: both even or
+        // both odd - an odd start is realigned from the dwords around it
         const int ver = cand / 5 - 2, hor = cand - ( cand / 5 ) * 5 - 2;
-        const pel_t* a = &sh.bil[0][( 2 + ver ) * 20 + 2 + hor];
-        const pel_t* b = &sh.bil[1][( 2 - ver ) * 20 + 2 - hor];
-        for( int y = half * 2; y < h; y += 2 * LPC ) for( int x = 0; x < w; x++ ) sad += (unsigned) iabs( a[y * 20 + x] - b[y * 20 + x] );
+        const int oa = ( 2 + ver ) * 20 + 2 + hor, ob = ( 2 - ver ) * 20 + 2 - hor, odd = oa & 1, nd = w >> 1;
+        const uint32_t* a = reinterpret_cast<const uint32_t*>( sh.bil[0] ) + ( ( oa - odd ) >> 1 );
+        const uint32_t* b = reinterpret_cast<const uint32_t*>( sh.bil[1] ) + ( ( ob - odd ) >> 1 );
+        const int sh = odd << 4;
+        for( int y = half * 2; y < h; y += 2 * LPC )
+        {
+          // the row's nine dwords of both blocks first (one wait for the LDS), then the sums; columns beyond the block are read (they lie inside the 20-sample row) and left out
+          const uint32_t* ar = a + y * 10; const uint32_t* br = b + y * 10;
+          uint32_t ra[9], rb[9];
+#pragma unroll
+          for( int d = 0; d < 9; d++ ) { ra[d] = ar[d]; rb[d] = br[d]; }
+#pragma unroll
+          for( int d = 0; d < 8; d++ )
+            if( d < nd ) sad = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( ra[d + 1], ra[d], sh ), __builtin_amdgcn_alignbit( rb[d + 1], rb[d], sh ), sad );
+        }
       }
       for( int o = 1; o < LPC; o <<= 1 ) sad += __shfl_xor( sad, o );
       if( cand < 25 && !half ) sh.sad[cand] = cand == 12 ? minCost : ( ( sad << 1 ) >> 1 );      // X5: ( SAD << subShift ) >> 1
@@ -1947,6 +1959,14 @@ struct IntraPic {
 // Loads of samples that another workgroup of the SAME launch may have written (k_intra_leaf): device scope (sc1) - they are served by L2 / memory, never
 // by this CU's vector L1, which another CU's stores do not refresh; the writer stores with sc1 (write-through) as well (MI355X_MICROARCH.md, inter-workgroup
 // visibility: "sc1 stores AND sc1 loads").  SC1 = false: the plain load every other kernel uses.
+// eight samples (16 bytes, 8-byte aligned), device scope when SC1: two 8-byte loads that bypass the vector L1 (what another workgroup of the launch stored write-through)
+template<bool SC1> __device__ __forceinline__ uint4 ld_pel8( const pel_t* p )
+{
+  if( !SC1 ) return *reinterpret_cast<const uint4*>( p );
+  const unsigned long long a = __hip_atomic_load( reinterpret_cast<const unsigned long long*>( p ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  const unsigned long long b = __hip_atomic_load( reinterpret_cast<const unsigned long long*>( p ) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  return make_uint4( (uint32_t) a, (uint32_t) ( a >> 32 ), (uint32_t) b, (uint32_t) ( b >> 32 ) );
+}
 template<bool SC1> __device__ __forceinline__ int ld_pel( const pel_t* p )
 {
   if constexpr( SC1 ) return (int) (int16_t) __hip_atomic_load( reinterpret_cast<uint16_t*>( const_cast<pel_t*>( p ) ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
@@ -4480,11 +4500,20 @@ __device__ __forceinline__ void intra_load_resi( IntraResiRegs& R, const IntraIt
   if( wh > IT_PART_SAMPLES ) return;                 // (a block that is not split: read where it is added)
   if( intra_resi_vec4( it ) )
   {
+    // a CIIP coding unit of several transform units (IntraItem::tu: bit 31; the split at a largest transform size of 32): the residual plane holds something only
+    // where a unit was coded - bit k of the word: unit k in raster order, bit 4: two units per row; the others contribute nothing (DecCu.cpp:449-470)
+    const bool perUnit = ( it.flags >> 6 ) != 0 && ( it.flags & IT_F_ISP ) != IT_F_ISP && ( it.tu >> 31 ) != 0;
+    const int thr = IT_COMP( it ) ? 16 : 32, yBand = IT_PART( it ) * rows;
 #pragma unroll
     for( int e = 0; e < 4; e++ )
     {
       const int i = ( e * 64 + lane ) << 2;
-      if( e * 256 < wh ) { const int ii = min( i, wh - 4 ); R.v[e] = *reinterpret_cast<const uint2*>( &rs[(size_t) ( y0 + ( ii >> lw ) ) * rstride + it.x + ( ii & ( ( 1 << lw ) - 1 ) )] ); }
+      if( e * 256 < wh )
+      {
+        const int ii = min( i, wh - 4 ), yy = ii >> lw, xx = ii & ( ( 1 << lw ) - 1 );
+        R.v[e] = *reinterpret_cast<const uint2*>( &rs[(size_t) ( y0 + yy ) * rstride + it.x + xx] );
+        if( perUnit && !( ( it.tu >> ( ( yBand + yy >= thr ? 1 + ( ( it.tu >> 4 ) & 1 ) : 0 ) + ( xx >= thr ? 1 : 0 ) ) ) & 1 ) ) R.v[e] = make_uint2( 0, 0 );
+      }
     }
   }
   else
@@ -4770,6 +4799,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
   constexpr int dbg = 0; constexpr unsigned long long* trace = nullptr, * btrace = nullptr;      // (the timing experiments and the in-kernel timeline are developer builds only)
 #endif
   __shared__ IntraShared<IT_WAVES> sh;
+  constexpr bool WT = true;            // samples that cross workgroups of the launch: written through (sc1), read device scope - no agent-scope fences (round 6)
 #define IT_TRACE( K ) if( trace && threadIdx.x == 0 ) trace[(size_t) 8 * tr_ticket + ( K )] = wall_clock64()
   int tr_ticket = 0;
   const int tid = threadIdx.x;
@@ -4832,7 +4862,10 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
     if( nd )
     {
       __syncthreads();
-      __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );      // nothing produced by another workgroup is read otherwise
+      // (round 6: no agent-scope acquire here - 1.7 us per unit on the CTU wavefront, and a release fence of 6 - 10 us on the producer's side with a CTU of 32 KB
+      // freshly written.  Every sample another workgroup of the launch produces is stored write-through (sc1) and read device scope (sc1 loads: ld_pel / ld_pel8),
+      // the flag follows the stores behind s_waitcnt vmcnt(0): MI355X_MICROARCH.md, inter-workgroup visibility, "sc1 stores AND sc1 loads")
+      if( !WT ) __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );
     }
   }
   if( tid < nb0 * 4 ) reinterpret_cast<uint32_t*>( sh.items )[tid] = itemPre;
@@ -4848,7 +4881,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
       const int lx = ( cxI << pic.log2Ctu ) + ( ( wv & csNv1 ) << pic.vpduLog2 ), ly = ( cyI << pic.log2Ctu ) + ( ( ( wv >> 1 ) & csNv1 ) << pic.vpduLog2 );
       if( wv < 4 && lx < pic.width && ly < pic.height && ( wv == 0 || csNv1 ) )
       {
-        const int f = lmcs_cscale_factor_wave( pic, lx, ly, lane );
+        const int f = lmcs_cscale_factor_wave<WT>( pic, lx, ly, lane );
         if( lane == 0 ) sh.csFac[wv] = f;
       }
     }
@@ -4874,7 +4907,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
           const int pr[4] = { (int) ( pv.x & 0xffff ), (int) ( pv.x >> 16 ), (int) ( pv.y & 0xffff ), (int) ( pv.y >> 16 ) };
           int o[4];
           for( int e = 0; e < 4; e++ ) o[e] = clip_pel( pr[e] + ( cs ? lmcs_scale_resi( r[e], f, bd ) : r[e] ), bd );
-          *pp = make_uint2( (uint32_t) o[0] | ( (uint32_t) o[1] << 16 ), (uint32_t) o[2] | ( (uint32_t) o[3] << 16 ) );
+          st_pel4_sc1( &plane[(size_t) y * pstride + x], make_uint2( (uint32_t) o[0] | ( (uint32_t) o[1] << 16 ), (uint32_t) o[2] | ( (uint32_t) o[3] << 16 ) ) );
         }
       }
       else
@@ -4882,7 +4915,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
         {
           const int x = x0 + ( i & ( ( 1 << lw ) - 1 ) ), y = y0 + ( i >> lw );
           const int r = (int16_t) rs[(size_t) y * rstride + x];
-          plane[(size_t) y * pstride + x] = (pel_t) clip_pel( plane[(size_t) y * pstride + x] + ( cs ? lmcs_scale_resi( r, f, bd ) : r ), bd );
+          st_pel_sc1( &plane[(size_t) y * pstride + x], clip_pel( plane[(size_t) y * pstride + x] + ( cs ? lmcs_scale_resi( r, f, bd ) : r ), bd ) );
         }
     }
     IT_TRACE( 4 );
@@ -4892,7 +4925,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
     __syncthreads();
     if( tid == 0 )
     {
-      __builtin_amdgcn_fence( __ATOMIC_RELEASE, "agent" );
+      if( !WT ) __builtin_amdgcn_fence( __ATOMIC_RELEASE, "agent" );      // (WT: the samples went out write-through, every wavefront has drained its stores in front of the barrier)
       asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
       __hip_atomic_store( &sync[1 + ticket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     }
@@ -4935,7 +4968,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
       if( cur ) intra_stash_resi( RR, it, W.resi, lane );
       IntraLumaRegs LC = LR;                                                   // (CCLM) co-located luma of this block, fetched while the block before was predicted (FINE: when its turn comes, below)
       // the residual (and the luma of a CCLM block) of the wavefront's next block starts, the records move up
-      if( q + IT_WAVES < qEnd ) { const IntraItem itN = intra_item_of( recN ); intra_load_resi( RR, itN, rs, rstride, lane ); if( comp && !FINE ) intra_load_cclm_luma( LR, itN, pic, lane ); }
+      if( q + IT_WAVES < qEnd ) { const IntraItem itN = intra_item_of( recN ); intra_load_resi( RR, itN, rs, rstride, lane ); if( comp && !FINE ) intra_load_cclm_luma<WT>( LR, itN, pic, lane ); }
       recC = recN; recN = recNN;
       if( q + 3 * IT_WAVES < qEnd ) recNN = intra_load_item( items, (uint32_t) ( q + 3 * IT_WAVES ) );
       const uint32_t ctxC = ctxCur;                                           // the block's parameter record (lane k: value k), fetched two blocks ahead
@@ -4980,7 +5013,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
               for( int i = lane; i < cch * bh; i += 64 )
               {
                 const int y = ry + i / cch, x = cx0 + 8 * ( i % cch );
-                const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
+                const uint4 v = ld_pel8<WT>( &plane[(size_t) y * pstride + x] );
                 *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
               }
               return;
@@ -5009,13 +5042,13 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
             if( lane < nT + nL + nC )
             {
               int x, y; chunkAt( lane, x, y );
-              sv = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
+              sv = ld_pel8<WT>( &plane[(size_t) y * pstride + x] );
               so = tile_idx( x - ox, y - oy );
             }
             for( int i = lane + 64; i < nT + nL + nC; i += 64 )
             {
               int x, y; chunkAt( i, x, y );
-              const uint4 v = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] );
+              const uint4 v = ld_pel8<WT>( &plane[(size_t) y * pstride + x] );
               *reinterpret_cast<uint4*>( &sh.tile[tile_idx( x - ox, y - oy )] ) = v;
             }
           };
@@ -5034,7 +5067,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
           uint4 v0, v1, v2, v3; int o0, o1, o2, o3;
 #define IT_LD( V, O, U ) { const int i = min( base + U * IT_NT + tid, total - 1 ); int r, cidx; \
             if( i < nTop ) { r = i / nch; cidx = bc0 + ( i - r * nch ); } else { r = ( max( by0, oy ) - by0 ) + ( i - nTop ); cidx = -1; } \
-            const int y = by0 + r, x = ox + cidx * 8; V = *reinterpret_cast<const uint4*>( &plane[(size_t) y * pstride + x] ); O = tile_idx( x - ox, y - oy ); }
+            const int y = by0 + r, x = ox + cidx * 8; V = ld_pel8<WT>( &plane[(size_t) y * pstride + x] ); O = tile_idx( x - ox, y - oy ); }
           IT_LD( v0, o0, 0 ) IT_LD( v1, o1, 1 ) IT_LD( v2, o2, 2 ) IT_LD( v3, o3, 3 )
 #undef IT_LD
           *reinterpret_cast<uint4*>( &sh.tile[o0] ) = v0; *reinterpret_cast<uint4*>( &sh.tile[o1] ) = v1;
@@ -5059,7 +5092,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
           seg[1] = ( ( d >> 27 ) & 1 ) ? leaf_seg( M.cell[0], w4c, h4c, xPos >> 2, ( yPos - 1 ) >> 2, min( xPos + n - 1, pic.width - 1 ) >> 2, ( yPos - 1 ) >> 2 ) : leaf_seg( M.cell[0], w4c, h4c, 0, 0, -1, -1 );
           leaf_wait( seg, w4c, lane, lsync );
         }
-        const int f = lmcs_cscale_factor_wave<FINE>( pic, lx, ly, lane );
+        const int f = lmcs_cscale_factor_wave<FINE || WT>( pic, lx, ly, lane );
         if( lane == 0 ) sh.csFac[wv] = f;
       }
     }
@@ -5112,7 +5145,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
         {
           const int x = i & ( w - 1 ), y = yb + ( i >> lw );
           const int sx = qx + x, sy = qy + y;
-          int v = sx >= ox ? (int) TILE( sx, sy ) : (int) plane[(size_t) sy * pstride + sx];
+          int v = sx >= ox ? (int) TILE( sx, sy ) : ld_pel<WT>( &plane[(size_t) sy * pstride + sx] );
           if( hasResi ) { const int r = RES( i ); v = clip_pel( v + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); }
           sh.tile[tileBase + y * IT_TSB + x] = (pel_t) v;
         }
@@ -5400,7 +5433,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
           for( int i = lane; i < wh; i += 64 )
           {
             const int x = i & ( w - 1 ), y = i >> lw;
-            const int t = (int16_t) intra_cclm_luma_at<FINE>( pic.plane[0], pic.stride[0], x0 << 1, y0 << 1, x, y, bLeft, bAbove, colloc );
+            const int t = (int16_t) intra_cclm_luma_at<FINE || WT>( pic.plane[0], pic.stride[0], x0 << 1, y0 << 1, x, y, bLeft, bAbove, colloc );
             int v = clip_pel( ( ( a * t ) >> shift ) + b, bd );
             if( hasResi ) { const int r = W.resi[i]; v = clip_pel( v + ( csOn ? lmcs_scale_resi( r, csScale, bd ) : r ), bd ); }
             sh.tile[tileBase + y * IT_TSB + x] = (pel_t) v;
@@ -5631,7 +5664,11 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
     for( int i = tid; i < rows * nch; i += IT_NT )
     {
       const int r = i / nch, c = i - r * nch;
-      *reinterpret_cast<uint4*>( &plane[(size_t) ( oy + r ) * pstride + ox + c * 8] ) = *reinterpret_cast<const uint4*>( &TILE( ox + c * 8, oy + r ) );
+      {
+        const uint4 v = *reinterpret_cast<const uint4*>( &TILE( ox + c * 8, oy + r ) );
+        pel_t* d = &plane[(size_t) ( oy + r ) * pstride + ox + c * 8];
+        if( WT ) { st_pel4_sc1( d, make_uint2( v.x, v.y ) ); st_pel4_sc1( d + 4, make_uint2( v.z, v.w ) ); } else *reinterpret_cast<uint4*>( d ) = v;
+      }
     }
   }
   else
@@ -5648,14 +5685,14 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
         for( int i = lane; i < ( wh >> 2 ); i += 64 )
         {
           const int x = it.x + ( ( i << 2 ) & ( ( 1 << lw ) - 1 ) ), y = it.y + yb + ( ( i << 2 ) >> lw );
-          *reinterpret_cast<uint2*>( &plane[(size_t) y * pstride + x] ) = *reinterpret_cast<const uint2*>( &TILE( x, y ) );
+          st_pel4_sc1( &plane[(size_t) y * pstride + x], *reinterpret_cast<const uint2*>( &TILE( x, y ) ) );
         }
       }
       else
         for( int i = lane; i < wh; i += 64 )
         {
           const int x = it.x + ( i & ( ( 1 << lw ) - 1 ) ), y = it.y + yb + ( i >> lw );
-          plane[(size_t) y * pstride + x] = TILE( x, y );
+          st_pel_sc1( &plane[(size_t) y * pstride + x], TILE( x, y ) );
         }
     }
   }
@@ -5669,7 +5706,7 @@ __global__ __launch_bounds__( IT_NT + ( FINE ? 64 : 0 ) ) void k_intra( IntraPic
   __syncthreads();
   if( tid == 0 )
   {
-    __builtin_amdgcn_fence( __ATOMIC_RELEASE, "agent" );
+    if( !WT ) __builtin_amdgcn_fence( __ATOMIC_RELEASE, "agent" );
     asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
     __hip_atomic_store( &sync[1 + ticket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
   }

@@ -244,6 +244,19 @@ struct PrepScratch
 PrepScratch* vvr_scratch_create() { return new PrepScratch(); }
 void vvr_scratch_parts_for_all( PrepScratch* S, bool on ) { S->partsForAll = on; }
 void vvr_scratch_intra_leaf( PrepScratch* S, bool on, bool byLevel ) { S->leafOn = on; S->leafSortOn = byLevel; }
+// the transform units of a CU 64 wide and / or high in a sequence whose largest transform is 32: min( w, 32 ) x min( h, 32 ) each, in raster order over the CU
+static bool tusAreTheSplitAt32( const vvr_picture* p, const vvr_cu& cu )
+{
+  const int tw = cu.w < 32 ? cu.w : 32, th = cu.h < 32 ? cu.h : 32, nx = cu.w / tw, ny = cu.h / th;
+  if( (int) cu.num_tu != nx * ny || cu.num_tu < 2 ) return false;
+  for( int k = 0; k < nx * ny; k++ )
+  {
+    const vvr_tu& tu = p->tu[cu.first_tu + k];
+    if( tu.w != tw || tu.h != th || tu.x != cu.x + ( k % nx ) * tw || tu.y != cu.y + ( k / nx ) * th ) return false;
+  }
+  return true;
+}
+
 static std::atomic<int> g_bandPictures{ 0 };
 int vvr_host_band_pictures() { return g_bandPictures.load(); }      // (tests) pictures with inter CUs that were built in bands so far
 
@@ -480,8 +493,10 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
         FAIL( VVR_ERR_PARAMETER, "mc_mode DMVR on a CU that cannot use DMVR (UnitTools.cpp:1277)" );
       if( cu.mc_mode == VVR_MC_BDOF && ( !( h.tool_flags & VVR_TOOL_BDOF ) || cu.ref_idx[0] < 0 || cu.ref_idx[1] < 0 || cu.w < 8 || cu.h < 8 || cu.w * cu.h < 128 || cu.bcw_idx != 2 ) )
         FAIL( VVR_ERR_PARAMETER, "mc_mode BDOF on a CU that cannot use BDOF (InterPrediction.cpp:1407-1427)" );
-      if( ( cu.flags & VVR_CU_CIIP ) && ( ( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI ) || cu.w * cu.h < 64 || cu.w > 64 || cu.h > 64 || cu.num_tu != 1 ) )
-        FAIL( VVR_ERR_PARAMETER, "CIIP CU: needs plain uni/bi prediction, at least 64 luma samples, sides of at most 64 and one TU" );
+      // CIIP: one transform unit - or, in a sequence whose largest transform is 32, the four (two) of a CU that is 64 wide and / or high (round 6: the CU is
+      // predicted and blended as a whole, the residuals are added transform unit by transform unit, DecCu.cpp:449-470)
+      if( ( cu.flags & VVR_CU_CIIP ) && ( ( cu.mc_mode != VVR_MC_UNI && cu.mc_mode != VVR_MC_BI ) || cu.w * cu.h < 64 || cu.w > 64 || cu.h > 64 || ( cu.num_tu != 1 && !tusAreTheSplitAt32( p, cu ) ) ) )
+        FAIL( VVR_ERR_PARAMETER, "CIIP CU: needs plain uni/bi prediction, at least 64 luma samples, sides of at most 64 and one TU (or the split at the largest transform size)" );
       if( cu.bcw_idx > 4 ) FAIL( VVR_ERR_PARAMETER, "BCW index out of range" );
       for( int l = 0; l < 2; l++ ) if( cu.ref_idx[l] >= h.num_ref[l] ) FAIL( VVR_ERR_PARAMETER, "ref_idx out of range" );
       if( cu.ref_idx[0] < 0 && cu.ref_idx[1] < 0 && !isGeo && !isSbt ) FAIL( VVR_ERR_PARAMETER, "inter CU without reference" );
@@ -563,9 +578,7 @@ static int validate_records_range( const vvr_picture* p, uint32_t cu0, uint32_t 
       const int minW = lumaOnly ? 4 : 8;
       if( cu.tree == VVR_TREE_CHROMA || cu.w > 64 || cu.h > 64 || cu.w < minW || cu.h < 4 || ( !lumaOnly && cu.w * cu.h < 64 ) || cu.num_tu < 1 || cu.num_tu > 4 )
         FAIL( VVR_ERR_PARAMETER, "IBC CU: chroma tree, size out of range or a bad number of TUs" );
-      if( cu.num_tu > 1 )
-        for( uint32_t t = cu.first_tu; t < cu.first_tu + cu.num_tu; t++ )
-          if( p->tu[t].w > 32 || p->tu[t].h > 32 || (uint32_t) p->tu[t].w * p->tu[t].h * cu.num_tu != (uint32_t) cu.w * cu.h ) FAIL( VVR_ERR_PARAMETER, "IBC CU: several TUs that are not the split at the largest transform size" );
+      if( cu.num_tu > 1 && !tusAreTheSplitAt32( p, cu ) ) FAIL( VVR_ERR_PARAMETER, "IBC CU: several TUs that are not the split at the largest transform size" );
       if( ( cu.mv[0][0][0] | cu.mv[0][0][1] ) & 15 ) FAIL( VVR_ERR_PARAMETER, "IBC CU: fractional block vector" );
       if( cu.isp_mode || cu.bdpcm[0] || cu.bdpcm[1] || cu.lfnst_idx || cu.sbt_info || ( cu.flags & ( VVR_CU_MIP | VVR_CU_CIIP | VVR_CU_AFFINE | VVR_CU_GEO | VVR_CU_SBTMVP ) ) )
         FAIL( VVR_ERR_PARAMETER, "IBC CU combined with an intra / inter tool" );
@@ -776,6 +789,10 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
           if( !( tu.comp_mask & ( 1 << comp ) ) ) continue;
           // the 2-wide chroma blocks of a 4-wide CIIP CU are not blended (predBlendIntraCiip, IntraPrediction.cpp:891): plain inter blocks
           const bool isCiip = isCiipCu && !( comp && cu.w == 4 );
+          // a CIIP CU of several transform units (the split at a largest transform size of 32): ONE block per component, the CU - it is predicted from the CU's
+          // neighbours and blended as a whole (DecCu.cpp:449-470) -, carried by the first unit; which units bring a residual rides in the item's `tu` word
+          const bool ciipCu = isCiip && cu.num_tu > 1;
+          if( ciipCu && t != cu.first_tu ) continue;
           const bool isCsInter = cscaleCtu( ctuOfCu ) && cu.pred_mode == VVR_PRED_INTER && !isCiip && ( cu.flags & VVR_CU_ROOT_CBF );
           if( cu.pred_mode != VVR_PRED_INTRA && !isCiip && !isCsInter && !isIbcCu ) continue;
           if( isCsInter && ( !comp || !( ( ( tu.cbf >> comp ) & 1 ) || tu.joint_cbcr ) || ( tu.w >> 1 ) * ( tu.h >> 1 ) <= 4 ) ) continue;
@@ -809,7 +826,8 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
           const bool ispL = cu.isp_mode && !comp, ispC = cu.isp_mode && comp;
           const bool ispPair = ispL && cu.isp_mode == 2 && tu.w < 4;                              // group of 4 / tu.w partitions
           if( ispPair && ( ( tu.x - cu.x ) & 3 ) ) continue;                                      // not the first of its group: part of the group's item
-          const int x0 = ( ispC ? cu.x : tu.x ) >> cs, y0 = ( ispC ? cu.y : tu.y ) >> cs, w = ispPair ? 4 : ( ispC ? cu.w : tu.w ) >> cs, hh = ( ispC ? cu.h : tu.h ) >> cs;
+          const bool wholeCu = ispC || ciipCu;
+          const int x0 = ( wholeCu ? cu.x : tu.x ) >> cs, y0 = ( wholeCu ? cu.y : tu.y ) >> cs, w = ispPair ? 4 : ( wholeCu ? cu.w : tu.w ) >> cs, hh = ( wholeCu ? cu.h : tu.h ) >> cs;
           // block whose neighbourhood decides the availability of the reference samples
           const int rx0 = ispL ? cu.x : x0, ry0 = ispL ? cu.y : y0, rw = ispL ? cu.w : w, rh = ispL ? cu.h : hh;
           const int32_t rcur = ispL ? (int32_t) cu.first_tu : (int32_t) t;
@@ -823,6 +841,14 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
           const int ibcDx = isIbcCu ? ( cu.mv[0][0][0] >> 4 ) >> cs : 0, ibcDy = isIbcCu ? ( cu.mv[0][0][1] >> 4 ) >> cs : 0;
           if( isIbcCu ) it.tu = ( (uint32_t) ibcDx & 0xffff ) | ( (uint32_t) ibcDy << 16 );
           bool hasResi = ( ( tu.cbf >> comp ) & 1 ) || ( comp && tu.joint_cbcr );
+          if( ciipCu )
+          {
+            // bit k: transform unit k of the CU (raster order) has a residual for this component; bits 4-5: units per row - 1; bit 31: the marker
+            uint32_t mask = 0;
+            for( uint32_t k = 0; k < cu.num_tu; k++ ) { const vvr_tu& tk = p->tu[cu.first_tu + k]; if( ( ( tk.cbf >> comp ) & 1 ) || ( comp && tk.joint_cbcr ) ) mask |= 1u << k; }
+            it.tu = 0x80000000u | mask | ( (uint32_t) ( cu.w > 32 ? 1 : 0 ) << 4 );
+            hasResi = mask != 0;
+          }
           if( ispL )
           {
             // residual flags of the partitions of a group (2 of width 2, or 4 of width 1), geometry of the partition inside its CU
