@@ -643,7 +643,7 @@ def main():
         import subprocess
         del descs, cpics
         others = {}
-        for name, extra in (("8k", ["--steps", "16", "--warmup", "4", "--repeats", "3", "--verify", "1", "--intra-period", "32"]), ("allintra", ["--steps", "32", "--warmup", "8", "--repeats", "3", "--verify", "2"])):
+        for name, extra in (("8k", ["--steps", "16", "--warmup", "4", "--repeats", "3", "--verify", "1", "--intra-period", "32"]), ("allintra", ["--steps", "64", "--warmup", "16", "--repeats", "5", "--verify", "2"])):
             t0 = time.perf_counter()
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--no-cpu-baseline", "--no-other-configs"] + extra, capture_output=True, text=True, timeout=400)
