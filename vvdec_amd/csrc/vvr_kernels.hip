@@ -3749,13 +3749,17 @@ void launch_alf( hipStream_t s, const PicDev& pic, DevPlanes src, DevPlanes dst 
 #define SA_DCH  38
 #define SA_ACW  40      // SAO-filtered chroma tiles: rows cy0 - 2 .. cy0 + 33, column index = x - ( cx0 - 4 )
 #define SA_ACH  36
-struct SaoAlfShared {
-  pel_t dl[SA_DLH * SA_DLW];
-  pel_t al[SA_ALH * SA_ALW];
-  pel_t dc[2][SA_DCH * SA_DCW];
-  pel_t ac[2][SA_ACH * SA_ACW];
-  __attribute__( ( aligned( 16 ) ) ) uint32_t fPack[4 * 25 * 12];      // the CTU's luma filter set, per transpose and class the 12 taps in the order the filter reads them: coefficient | clip value << 16
+struct SaoAlfTables {
+  uint32_t fPack[4 * 25 * 12];                 // the CTU's luma filter set, per transpose and class the 12 taps in the order the filter reads them: coefficient | clip value << 16
   uint8_t cls[256];                            // per 4x4 block: transpose * 25 + class (row of fPack)
+};
+// 27.7 KB (round 6; 39 KB before): five workgroups per compute unit instead of four.  The luma window `dl` is dead once SAO has copied it into `al` - the filter
+// tables live in its place from then on; Cb and Cr go through ONE pair of chroma buffers, one after the other.
+struct SaoAlfShared {
+  union { __attribute__( ( aligned( 16 ) ) ) pel_t dl[SA_DLH * SA_DLW]; SaoAlfTables t; };
+  __attribute__( ( aligned( 16 ) ) ) pel_t al[SA_ALH * SA_ALW];
+  __attribute__( ( aligned( 16 ) ) ) pel_t dc[SA_DCH * SA_DCW];
+  __attribute__( ( aligned( 16 ) ) ) pel_t ac[SA_ACH * SA_ACW];
   uint32_t sao[9][3][2];                       // SAO parameters of the 3 x 3 CTUs around the region's, per component: mode | type << 8 | band << 16; the four offsets
 };
 
@@ -3855,6 +3859,20 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
 #define SA_SKIP 0          /* developer builds: phases left out for timing (1 SAO, 2 classification, 4 luma filter, 8 chroma filters, 16 CC-ALF); results are wrong */
 #endif
   const bool saoL = !( SA_SKIP & 1 ) && SAO && pic.sao && ( pic.hdr.tool_flags & VVR_TOOL_SAO_LUMA ), saoC = !( SA_SKIP & 1 ) && SAO && pic.sao && ( pic.hdr.tool_flags & VVR_TOOL_SAO_CHROMA );
+  // the window of deblocked samples of one chroma component
+  auto loadChroma = [&]( int k )
+  {
+    const pel_t* __restrict__ C = k ? src.p[2] : src.p[1];
+    for( int j = tid; j < SA_DCH * ( SA_DCW / 4 ); j += 256 )
+    {
+      const int r = j / ( SA_DCW / 4 ), cch = j - r * ( SA_DCW / 4 );
+      const int y = clip3( 0, CH - 1, cy0 - 3 + r ), x = cx0 - 4 + 4 * cch;
+      uint2 v;
+      if( x >= 0 && x < CW ) v = *reinterpret_cast<const uint2*>( &C[(size_t) y * cst + x] );   // (the chroma width is a multiple of 4)
+      else { const uint32_t e = (uint16_t) C[(size_t) y * cst + ( x < 0 ? 0 : CW - 1 )]; v.x = v.y = e | ( e << 16 ); }
+      *reinterpret_cast<uint2*>( &sh.dc[r * SA_DCW + 4 * cch] ) = v;
+    }
+  };
   // ---- the windows of deblocked samples; coordinates outside the picture repeat its border (the ALF's clamp; SAO never uses such a neighbour)
   {
     const pel_t* __restrict__ S = src.p[0];
@@ -3867,17 +3885,7 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
       else { const uint32_t e = (uint16_t) S[(size_t) y * st + ( x < 0 ? 0 : W - 1 )]; v.x = v.y = v.z = v.w = e | ( e << 16 ); }
       *reinterpret_cast<uint4*>( &sh.dl[r * SA_DLW + 8 * cch] ) = v;
     }
-    if( chroma )
-      for( int i = tid; i < 2 * SA_DCH * ( SA_DCW / 4 ); i += 256 )
-      {
-        const int k = i / ( SA_DCH * ( SA_DCW / 4 ) ), j = i - k * ( SA_DCH * ( SA_DCW / 4 ) ), r = j / ( SA_DCW / 4 ), cch = j - r * ( SA_DCW / 4 );
-        const pel_t* __restrict__ C = k ? src.p[2] : src.p[1];
-        const int y = clip3( 0, CH - 1, cy0 - 3 + r ), x = cx0 - 4 + 4 * cch;
-        uint2 v;
-        if( x >= 0 && x < CW ) v = *reinterpret_cast<const uint2*>( &C[(size_t) y * cst + x] );   // (the chroma width is a multiple of 4)
-        else { const uint32_t e = (uint16_t) C[(size_t) y * cst + ( x < 0 ? 0 : CW - 1 )]; v.x = v.y = e | ( e << 16 ); }
-        *reinterpret_cast<uint2*>( &sh.dc[k][r * SA_DCW + 4 * cch] ) = v;
-      }
+    if( chroma ) loadChroma( 0 );
     if( SAO && pic.sao && tid < 27 )
     {
       const int q = tid / 3, c = tid - q * 3;
@@ -3890,34 +3898,45 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
   }
   vvr_alf_ctu f; f.enable[0] = f.enable[1] = f.enable[2] = 0; f.cc_idc[0] = f.cc_idc[1] = 0; f.alt[0] = f.alt[1] = 0; f.luma_filter_idx = 0;
   const vvr_alf_params* __restrict__ A = nullptr;
-  int lumaClips = 0;                                     // some tap of the CTU's luma filter set clips its differences (else the clipping is left out: a fixed set, or an APS whose clip indices are 0)
   if( ALF )
   {
     f = pic.alf[ctuY * pic.ctus_x + ctuX];
     A = alf_set_at( pic, tx0, ty0 );                     // the filters of the APSs the CTU's slice refers to (AdaptiveLoopFilter.cpp:515)
-    if( f.enable[0] )
-    {
-      const int clipDef = 1 << bd;                       // m_alfClippVls[bd-8][0] = 256 << (bd - 8): such a tap is never clipped
-      for( int i = tid; i < 4 * 25 * 12; i += 256 )
-      {
-        const int tr = i / 300, r = i - tr * 300, cl = r / 12, k = c_alf_perm[tr][r - cl * 12];
-        int cf, cp;
-        if( f.luma_filter_idx < 16 ) { cf = d_alf_fixed_coeff[d_alf_class_to_filter[f.luma_filter_idx][cl]][k]; cp = clipDef; }
-        else { cf = A->luma_coeff[f.luma_filter_idx - 16][cl][k]; cp = A->luma_clip[f.luma_filter_idx - 16][cl][k]; }
-        sh.fPack[i] = (uint32_t) (uint16_t) cf | ( (uint32_t) (uint16_t) cp << 16 );
-        lumaClips |= cp < clipDef;
-      }
-    }
   }
   const bool ccOn = ALF && ( pic.hdr.tool_flags & VVR_TOOL_CCALF ) != 0;
   const bool cc[2] = { ccOn && f.cc_idc[0], ccOn && f.cc_idc[1] };
   const bool restricted = lf_restricted( pic );
   const AlfClip kl = alf_clip_of_ctu( pic, ctuX, ctuY, 0 ), kc = alf_clip_of_ctu( pic, ctuX, ctuY, 1 );
-  const bool lumaClip = __syncthreads_or( lumaClips ) != 0;
+  __syncthreads();
   // ---- SAO where the windows are copied into the tiles the ALF reads: entry (x, y) of a tile is the SAO output of the sample the CTU's ALF reads there
   // A region whose windows lie inside the picture, in a CTU whose filters may read everything around it (nearly all): no clamp, no boundary case -
   // two neighbouring samples per step; else sample by sample with every rule
   const bool plain = !kl.f && !kc.f && !restricted && tx0 >= 8 && ty0 >= 8 && tx0 + SA_T + 4 <= W && ty0 + SA_T + 4 <= H;
+  // SAO of chroma component k: its window `dc` into the tile `ac`
+  auto saoChroma = [&]( int k )
+  {
+    if( plain )
+    {
+      for( int r = tid; r < SA_ACH * 18; r += 256 )
+      {
+        const int ay = r / 18, j = 1 + ( r - ay * 18 );
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>( sh.dc ) + ( ay + 1 ) * ( SA_DCW / 2 ) + j;
+        reinterpret_cast<uint32_t*>( sh.ac )[ay * ( SA_ACW / 2 ) + j] = saoC ? sao_pair( sh, wp, SA_DCW / 2, 1 + k, l2 - 1, bd, cx0 - 4 + 2 * j, cy0 - 2 + ay, ctuX, ctuY ) : wp[0];
+      }
+    }
+    else
+    {
+      for( int j = tid; j < SA_ACH * 36; j += 256 )
+      {
+        const int ay = j / 36, ax = j - ay * 36;
+        int sx = cx0 - 2 + ax, sy = cy0 - 2 + ay;
+        alf_clip_coord( kc, sx, sy );
+        sx = clip3( 0, CW - 1, sx ); sy = clip3( 0, CH - 1, sy );
+        sh.ac[ay * SA_ACW + ax + 2] = (pel_t) ( saoC ? sao_at<true>( pic, sh, sh.dc, SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted )
+                                                     : sao_at<false>( pic, sh, sh.dc, SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted ) );
+      }
+    }
+  };
   if( plain )
   {
     const uint32_t* dlw = reinterpret_cast<const uint32_t*>( sh.dl );
@@ -3928,13 +3947,7 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
       const uint32_t* wp = dlw + ( ay + 1 ) * ( SA_DLW / 2 ) + j + 2;
       alw[ay * ( SA_ALW / 2 ) + j] = saoL ? sao_pair( sh, wp, SA_DLW / 2, 0, l2, bd, tx0 - 4 + 2 * j, ty0 - 3 + ay, ctuX, ctuY ) : wp[0];
     }
-    if( chroma )
-      for( int i = tid; i < 2 * SA_ACH * 18; i += 256 )
-      {
-        const int k = i / ( SA_ACH * 18 ), r = i - k * ( SA_ACH * 18 ), ay = r / 18, j = 1 + ( r - ay * 18 );
-        const uint32_t* wp = reinterpret_cast<const uint32_t*>( sh.dc[k] ) + ( ay + 1 ) * ( SA_DCW / 2 ) + j;
-        reinterpret_cast<uint32_t*>( sh.ac[k] )[ay * ( SA_ACW / 2 ) + j] = saoC ? sao_pair( sh, wp, SA_DCW / 2, 1 + k, l2 - 1, bd, cx0 - 4 + 2 * j, cy0 - 2 + ay, ctuX, ctuY ) : wp[0];
-      }
+    if( chroma ) saoChroma( 0 );
   }
   else
   {
@@ -3947,18 +3960,25 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
       sh.al[ay * SA_ALW + ax + 1] = (pel_t) ( saoL ? sao_at<true>( pic, sh, sh.dl, SA_DLW, tx0 - 8, ty0 - 4, 0, 0, sx, sy, W, H, ctuX, ctuY, restricted )
                                                    : sao_at<false>( pic, sh, sh.dl, SA_DLW, tx0 - 8, ty0 - 4, 0, 0, sx, sy, W, H, ctuX, ctuY, restricted ) );
     }
-    if( chroma )
-      for( int i = tid; i < 2 * SA_ACH * 36; i += 256 )
-      {
-        const int k = i / ( SA_ACH * 36 ), j = i - k * ( SA_ACH * 36 ), ay = j / 36, ax = j - ay * 36;
-        int sx = cx0 - 2 + ax, sy = cy0 - 2 + ay;
-        alf_clip_coord( kc, sx, sy );
-        sx = clip3( 0, CW - 1, sx ); sy = clip3( 0, CH - 1, sy );
-        sh.ac[k][ay * SA_ACW + ax + 2] = (pel_t) ( saoC ? sao_at<true>( pic, sh, sh.dc[k], SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted )
-                                                        : sao_at<false>( pic, sh, sh.dc[k], SA_DCW, cx0 - 4, cy0 - 3, 1 + k, 1, sx, sy, CW, CH, ctuX, ctuY, restricted ) );
-      }
+    if( chroma ) saoChroma( 0 );
   }
   __syncthreads();
+  // ---- the CTU's luma filter set (where the luma window was: SAO is through with it)
+  int lumaClips = 0;                                     // some tap of the CTU's luma filter set clips its differences (else the clipping is left out: a fixed set, or an APS whose clip indices are 0)
+  if( ALF && f.enable[0] )
+  {
+    const int clipDef = 1 << bd;                       // m_alfClippVls[bd-8][0] = 256 << (bd - 8): such a tap is never clipped
+    for( int i = tid; i < 4 * 25 * 12; i += 256 )
+    {
+      const int tr = i / 300, r = i - tr * 300, cl = r / 12, k = c_alf_perm[tr][r - cl * 12];
+      int cf, cp;
+      if( f.luma_filter_idx < 16 ) { cf = d_alf_fixed_coeff[d_alf_class_to_filter[f.luma_filter_idx][cl]][k]; cp = clipDef; }
+      else { cf = A->luma_coeff[f.luma_filter_idx - 16][cl][k]; cp = A->luma_clip[f.luma_filter_idx - 16][cl][k]; }
+      sh.t.fPack[i] = (uint32_t) (uint16_t) cf | ( (uint32_t) (uint16_t) cp << 16 );
+      lumaClips |= cp < clipDef;
+    }
+  }
+  const bool lumaClip = __syncthreads_or( lumaClips ) != 0;
 #define T( x, y ) sh.al[( ( y ) + 3 ) * SA_ALW + ( x ) + 4]      // region-relative luma sample
   const int vbPos = ctu - 4;
   if( !( SA_SKIP & 2 ) && ALF && f.enable[0] )
@@ -4025,7 +4045,7 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
         if( hvd1 * 2 > 9 * hvd0 ) strength = 2;
         if( strength ) cl += ( ( ( mainDir & 1 ) << 1 ) + strength ) * 5;
         const int tr = (int) ( ( 0x31322010u >> ( 4 * ( mainDir * 2 + ( secDir >> 1 ) ) ) ) & 15 );      // { 0, 1, 0, 2, 2, 3, 1, 3 }
-        sh.cls[blk] = (uint8_t) ( tr * 25 + cl );
+        sh.t.cls[blk] = (uint8_t) ( tr * 25 + cl );
       }
     }
     __syncthreads();
@@ -4047,7 +4067,7 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
         // the 12 taps of the block's class, in the order of its transpose: coefficient | clip value << 16 (three 16-byte LDS reads)
         uint32_t pk[12];
         {
-          const uint4* tp = reinterpret_cast<const uint4*>( &sh.fPack[(int) sh.cls[b] * 12] );
+          const uint4* tp = reinterpret_cast<const uint4*>( &sh.t.fPack[(int) sh.t.cls[b] * 12] );
           const uint4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
           pk[0] = t0.x; pk[1] = t0.y; pk[2] = t0.z; pk[3] = t0.w; pk[4] = t1.x; pk[5] = t1.y; pk[6] = t1.z; pk[7] = t1.w; pk[8] = t2.x; pk[9] = t2.y; pk[10] = t2.z; pk[11] = t2.w;
         }
@@ -4135,11 +4155,11 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
     }
   }
   if( !chroma ) return;
-  // ---- chroma: thread -> (row, 4 consecutive columns) of the 32x32 region, both planes: 5x5 diamond + the CC-ALF cross over the luma tile
+  // ---- chroma: thread -> (row, 4 consecutive columns) of the 32x32 region, Cb then Cr through the one pair of buffers: 5x5 diamond + the CC-ALF cross over the luma tile
   {
     const int ly = tid >> 3, lx4 = ( tid & 7 ) * 4;
     const int y = cy0 + ly;
-    if( y >= CH || cx0 + lx4 >= CW ) return;
+    const bool inPic = y < CH && cx0 + lx4 < CW;
     // rows of the 5x5 diamond at the ALF line-buffer boundary of the CTU row (chroma: 2 rows above the CTU's last 2)
     const int vbC = ctuC - 2, yVb = y & ( ctuC - 1 );
     int r1 = ly + 1, r2 = ly - 1, r3 = ly + 2, r4 = ly - 2;
@@ -4162,6 +4182,15 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
 #pragma unroll
     for( int k = 0; k < 2; k++ )
     {
+      if( k )
+      {
+        __syncthreads();          // Cb is through with the buffers
+        loadChroma( 1 );
+        __syncthreads();
+        saoChroma( 1 );
+        __syncthreads();
+      }
+      if( !inPic ) continue;
       pel_t* __restrict__ D = k ? dst.p[2] : dst.p[1];
       const bool en = !( SA_SKIP & 8 ) && ALF && f.enable[1 + k] != 0;
       const int16_t* cf = nullptr; const int16_t* cp = nullptr; const int16_t* ccf = nullptr;
@@ -4175,7 +4204,7 @@ __global__ __launch_bounds__( 256 ) void k_sao_alf( PicDev pic, DevPlanes src, D
 #pragma unroll
         for( int j = 0; j < 5; j++ )
         {
-          const uint2* rp = reinterpret_cast<const uint2*>( &sh.ac[k][( rr[j] + 2 ) * SA_ACW + lx4] );
+          const uint2* rp = reinterpret_cast<const uint2*>( &sh.ac[( rr[j] + 2 ) * SA_ACW + lx4] );
           const uint2 u0 = rp[0], u1 = rp[1], u2 = rp[2];
           wv[j][0] = u0.x; wv[j][1] = u0.y; wv[j][2] = u1.x; wv[j][3] = u1.y; wv[j][4] = u2.x; wv[j][5] = u2.y;
         }
