@@ -60,7 +60,7 @@ hipError_t hipMemsetAsync( void* d, int v, size_t n, hipStream_t ) { memset( d, 
 // kernel launches: nothing to run on the host; the launch of the intra stage records what it was handed
 static int g_lastIntraUnits = -1; static const int* g_lastSync = nullptr;
 int  vvr_upload_tables() { return 0; }
-void launch_expand_mc( hipStream_t, const PicDev&, const McCuRef*, int, McItem*, McItem*, McItem* ) {}
+void launch_prep( hipStream_t, const PicDev&, const PrepWork& ) {}
 void launch_mc( hipStream_t, const PicDev&, const RefSet&, DevPlanes, const McItem*, int, const McItem*, int, int ) { if( g_delayUs ) usleep( g_delayUs ); }
 void launch_itrans( hipStream_t, const PicDev&, DevPlanes, DevPlanes, const TbItem*, int, int ) {}
 // The one launch that leaves a trace in the "picture": the vertical deblocking pass stamps the first four luma samples of the output slot with

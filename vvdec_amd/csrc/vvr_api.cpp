@@ -428,7 +428,13 @@ static int enqueuePicture( vvr_context* c, Job& job, const CommitPlan& plan, std
   // (the four launches write disjoint tiles.  Running them side by side on extra streams of the lane, forked and joined with events, was measured:
   // device-only throughput fell from 1870 to 1240 pictures/s with 4 lanes, to 970 with 8 - the cross-stream waits cost more than the overlap gives)
   // (the tiles of plain, BDOF and DMVR CUs are written on the device from the CU records: the host only counted them)
-  if( q->numMcCus ) launch_expand_mc( s, q->pic, q->mcCus, q->numMcCus, q->mcDev, q->bdofItems, q->dmvrItems );
+  {
+    PrepWork w;
+    if( q->numMcCus ) { w.mcCus = q->mcCus; w.numMcCus = q->numMcCus; w.plain = q->mcDev; w.bdof = q->bdofItems; w.dmvr = q->dmvrItems; }
+    if( q->lfpOnDevice && dbOn ) { w.lfMaps = true; w.numCu = q->numCu; w.numTu = q->numTu; w.cell = q->lfCell; w.cellC = q->lfCellC; w.mv = q->lfMv; w.ref = q->lfRef; w.sb = q->lfSb; w.numSb = q->numLfSb; }
+    if( q->intraLeaf && q->numIntra ) { w.items = q->intraItems; w.numItems = q->numIntra; w.resi = q->resiItems; w.numResi = q->numResi; w.maps = c->leafMaps[lane]; w.mapInts = c->leafMapInts; w.mapW4 = c->leafW4; w.mapH4 = c->leafH4; }
+    launch_prep( s, q->pic, w );
+  }
   // LF_INIT (DecLibRecon.cpp:807-829): the edge parameters of the deblocking passes from the CU / TU records, where the caller leaves them to the back-end
   if( q->lfpOnDevice && dbOn ) timed( K_LF_INIT, [&]{ launch_lf_init( s, q->pic, q->numCu, q->numTu, q->lfCell, q->lfCellC, q->lfMv, q->lfRef, q->lfSb, q->numLfSb, q->lfpDev[0], q->lfpDev[1] ); } );
   if( q->numMc + q->numMcDev ) timedOn( K_MC, s, q->bytes[K_MC] - q->bytesBdof, [&]{ launch_mc( s, q->pic, refs, P, q->mcItems, q->numMc, q->mcDev, q->numMcDev, 0 ); } );

@@ -127,7 +127,6 @@ struct RefSet { const pel_t* p[2 * VVR_MAX_REFS][3]; };   // reference planes in
 
 // kernel launchers (vvr_kernels.hip) ----------------------------------------------------------------------------------
 void launch_mc     ( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems, const McItem* items2, int numItems2, int bdof );      // tiles of two arrays (host-written, device-written) in one launch
-void launch_expand_mc( hipStream_t s, const PicDev& pic, const McCuRef* cus, int numCus, McItem* plain, McItem* bdof, McItem* dmvr );
 void launch_itrans ( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const TbItem* items, int numItems, int sizeClass );
 // the deblocking edge parameters of the picture from its CU / TU records (vvr_lf_init.h): cell maps, motion of sub-block CUs, one thread per cell and direction
 void launch_lf_init( hipStream_t s, const PicDev& pic, uint32_t numCu, uint32_t numTu, struct LfCell* cell, struct LfCell* cellC, struct LfMv* mv, uint32_t* ref, const struct LfSbCell* sbCells, int numSbCells, vvr_lfp* out0, vvr_lfp* out1 );
@@ -153,6 +152,15 @@ size_t intra_sync_ints( int numUnits, int numItems );      // ints `sync` has to
 // per-cell words in `maps` (intra_leaf_map_ints words for the largest picture of the context: all zero between launches)
 #define IT_MODE_CSFAC 253      /* mode value: the LMCS chroma scaling factor of VPDU IntraItem::tu (no samples) */
 size_t intra_leaf_map_ints( int w4, int h4, int vpdus );
+// The picture's first launch (k_prep): the passes over its records that depend on nothing but the uploaded image - the motion-compensation tiles of the CUs
+// the host only counted, the cell maps of the deblocking edge derivation (lfMaps), the cells and the ticket of the scattered intra blocks (numItems)
+struct PrepWork
+{
+  const McCuRef* mcCus = nullptr; int numMcCus = 0; McItem *plain = nullptr, *bdof = nullptr, *dmvr = nullptr;
+  bool lfMaps = false; uint32_t numCu = 0, numTu = 0; struct LfCell *cell = nullptr, *cellC = nullptr; struct LfMv* mv = nullptr; uint32_t* ref = nullptr; const struct LfSbCell* sb = nullptr; int numSb = 0;
+  const IntraItem *items = nullptr, *resi = nullptr; int numItems = 0, numResi = 0; uint32_t* maps = nullptr; size_t mapInts = 0; int mapW4 = 0, mapH4 = 0;
+};
+void launch_prep( hipStream_t s, const PicDev& pic, const PrepWork& w );
 void launch_intra_leaf( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems, const IntraItem* resiItems, int numResi /* residual-add blocks grouped by VPDU: done by the VPDU's IT_MODE_CSFAC item */,
                         uint32_t* maps, size_t mapInts, int mapW4, int mapH4, int* errWord /* the job's error word: pinned host memory the device writes when a bounded wait gave up */ );
 

@@ -750,7 +750,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   __shared__ typename std::conditional<BDOF, BdofShared, int>::type bs;
   const int item = mc_item_index();
   if( item >= numItems + numItems2 ) return;
-  const McItem it = item < numItems ? items[item] : items2[item - numItems];       // (tiles the host wrote - SbTMVP -, then the tiles k_expand_mc wrote)
+  const McItem it = item < numItems ? items[item] : items2[item - numItems];       // (tiles the host wrote - SbTMVP -, then the tiles k_prep wrote)
   const int tid = threadIdx.x;
   // the tile record is self-contained (motion of the CU, or of the 8x8 sub-block for SbTMVP, with the identical-motion shortcut already
   // decided, xCheckIdenticalMotion :404); only GPM tiles read their CU (split direction, the two uni-directional motions).  The record is the same
@@ -1863,14 +1863,14 @@ void launch_mc( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes 
 }
 
 // =====================================================================================================================
-// k_expand_mc - the motion-compensation tiles of the CUs whose tiles are a function of the CU record alone (plain, BDOF, DMVR): the records of a
+// prep_expand_mc (a section of k_prep) - the motion-compensation tiles of the CUs whose tiles are a function of the CU record alone (plain, BDOF, DMVR): the records of a
 // CU's <= 16x16 tiles, written where the host reserved room for them (the host only counted them).  Same records as
 // PrepScratch::buildWorkLists writes for the tiles it still writes itself.
 // =====================================================================================================================
-__global__ __launch_bounds__( 256 ) void k_expand_mc( const vvr_cu* __restrict__ cus, const McCuRef* __restrict__ refs, int numRefs, McItem* __restrict__ plain, McItem* __restrict__ bdof, McItem* __restrict__ dmvr )
+__device__ __forceinline__ void prep_expand_mc( int bid, const vvr_cu* __restrict__ cus, const McCuRef* __restrict__ refs, int numRefs, McItem* __restrict__ plain, McItem* __restrict__ bdof, McItem* __restrict__ dmvr )
 {
   // one wavefront per CU, one lane per tile (a 128x128 CU has 64 of them)
-  const int i = blockIdx.x * 4 + ( threadIdx.x >> 6 ), t = threadIdx.x & 63;
+  const int i = bid * 4 + ( threadIdx.x >> 6 ), t = threadIdx.x & 63;
   if( i >= numRefs ) return;
   const McCuRef r = refs[i];
   const vvr_cu& cu = cus[r.cu];
@@ -1892,11 +1892,6 @@ __global__ __launch_bounds__( 256 ) void k_expand_mc( const vvr_cu* __restrict__
   const int ty = t / tilesX, tx = t - ty * tilesX, x = tx << 4, y = ty << 4;          // (rows of tiles, as the host writes them)
   it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) min( 16, cw - x ); it.h = (uint8_t) min( 16, ch - y );
   ( cls == 0 ? plain : cls == 1 ? bdof : dmvr )[( r.first & 0x3fffffffu ) + t] = it;
-}
-void launch_expand_mc( hipStream_t s, const PicDev& pic, const McCuRef* cus, int numCus, McItem* plain, McItem* bdof, McItem* dmvr )
-{
-  if( !numCus ) return;
-  hipLaunchKernelGGL( k_expand_mc, dim3( ( numCus + 3 ) / 4 ), dim3( 256 ), 0, s, pic.cu, cus, numCus, plain, bdof, dmvr );
 }
 
 void launch_mc_affine( hipStream_t s, const PicDev& pic, const RefSet& refs, DevPlanes reco, const McItem* items, int numItems )
@@ -3052,10 +3047,10 @@ void launch_deblock_tile( hipStream_t st, const PicDev& pic, DevPlanes src, DevP
 // wavefront - eight at most - are written by all 64 lanes together, one after the other (a 64x64 unit has 256 cells), from values broadcast out of the owner's
 // registers: nothing is loaded in those loops.  (One lane per unit left 64 such rounds per wavefront on a fifth of the chip's SIMDs: 34 us instead of 9.)
 // Behind the transform units: one thread per cell of the host's list of sub-block motion.
-__global__ __launch_bounds__( 256 ) void k_lf_maps( PicDev pic, int numCu, int numTu, LfCell* __restrict__ cell, LfCell* __restrict__ cellC, LfMv* __restrict__ mvs, uint32_t* __restrict__ refs,
-                                                   const LfSbCell* __restrict__ sb, int numSb, int dbg )
+__device__ __forceinline__ void prep_lf_maps( int bid, const PicDev& pic, int numCu, int numTu, LfCell* __restrict__ cell, LfCell* __restrict__ cellC, LfMv* __restrict__ mvs, uint32_t* __restrict__ refs,
+                                              const LfSbCell* __restrict__ sb, int numSb, int dbg )
 {
-  const int gt = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, t = gt >> 3, sub = gt & 7;
+  const int gt = bid * 256 + threadIdx.x, lane = threadIdx.x & 63, t = gt >> 3, sub = gt & 7;
   const int w4 = pic.w4, h4 = pic.h4;
   if( t >= numTu )
   {
@@ -3133,14 +3128,9 @@ __global__ __launch_bounds__( 256 ) void k_lf_init( PicDev pic, const LfCell* __
 }
 void launch_lf_init( hipStream_t s, const PicDev& pic, uint32_t numCu, uint32_t numTu, LfCell* cell, LfCell* cellC, LfMv* mv, uint32_t* ref, const LfSbCell* sbCells, int numSbCells, vvr_lfp* out0, vvr_lfp* out1 )
 {
+  // (the cell maps were written by launch_prep at the head of the picture)
   if( !numTu || !numCu ) return;
   const int cells = pic.w4 * pic.h4;
-  int dbg = 0;
-#ifdef VVR_DEV_ENV
-  static const int dbgEnv = getenv( "VVR_LFM_DBG" ) ? atoi( getenv( "VVR_LFM_DBG" ) ) : 0;      // developer build: 1 affine cells like plain ones, 2 no motion stores, 4 no stores (timing only)
-  dbg = dbgEnv;
-#endif
-  hipLaunchKernelGGL( k_lf_maps, dim3( ( 8 * numTu + numSbCells + 255 ) / 256 ), dim3( 256 ), 0, s, pic, (int) numCu, (int) numTu, cell, cellC, mv, ref, sbCells, numSbCells, dbg );
   hipLaunchKernelGGL( k_lf_init, dim3( ( cells + 255 ) / 256 ), dim3( 256 ), 0, s, pic, (const LfCell*) cell, (const LfCell*) cellC, (const LfMv*) mv, (const uint32_t*) ref, out0, out1 );
 }
 
@@ -5806,6 +5796,55 @@ static IntraPic intra_pic( const PicDev& pic, const DevPlanes& reco, const DevPl
 }
 
 #include "vvr_intra_leaf.inc"
+
+// =====================================================================================================================
+// k_prep - the picture's first launch: three passes over its records that depend on nothing but the uploaded image and on each other not at all,
+// as sections of one grid (each was a launch of 6 to 22 us that could not fill the device):
+//   * prep_expand_mc   the motion-compensation tiles of plain, BDOF and DMVR CUs from the CU records
+//   * prep_lf_maps     the per-cell records and motion of the deblocking edge derivation (k_lf_init, the next launch of that stage, reads them)
+//   * prep_intra_mark  the cells the scattered intra blocks of the picture are going to produce, and their ticket (k_intra_leaf)
+// =====================================================================================================================
+struct PrepArgs
+{
+  const McCuRef* mcCus; int numMcCus; McItem *plain, *bdof, *dmvr;
+  int numCu, numTu, numSb, dbg; LfCell *cell, *cellC; LfMv* mv; uint32_t* ref; const LfSbCell* sb;
+  const IntraItem *items, *resi; int numItems, numResi; LeafMaps M; int* sync;
+  int blocksExpand, blocksMaps;
+};
+__global__ __launch_bounds__( 256 ) void k_prep( PicDev pic, PrepArgs a )
+{
+  int bid = blockIdx.x;
+  // (the longest section first: the maps' waves walk lists, the other two are a handful of stores)
+  if( bid < a.blocksMaps ) { prep_lf_maps( bid, pic, a.numCu, a.numTu, a.cell, a.cellC, a.mv, a.ref, a.sb, a.numSb, a.dbg ); return; }
+  bid -= a.blocksMaps;
+  if( bid < a.blocksExpand ) { prep_expand_mc( bid, pic.cu, a.mcCus, a.numMcCus, a.plain, a.bdof, a.dmvr ); return; }
+  bid -= a.blocksExpand;
+  prep_intra_mark( bid, a.items, a.numItems, a.resi, a.numResi, a.M, a.sync );
+}
+
+void launch_prep( hipStream_t s, const PicDev& pic, const PrepWork& w )
+{
+  PrepArgs a = {};
+  if( w.numMcCus ) { a.mcCus = w.mcCus; a.numMcCus = w.numMcCus; a.plain = w.plain; a.bdof = w.bdof; a.dmvr = w.dmvr; a.blocksExpand = ( w.numMcCus + 3 ) / 4; }
+  if( w.lfMaps && w.numCu && w.numTu )
+  {
+    a.numCu = (int) w.numCu; a.numTu = (int) w.numTu; a.cell = w.cell; a.cellC = w.cellC; a.mv = w.mv; a.ref = w.ref; a.sb = w.sb; a.numSb = w.numSb;
+#ifdef VVR_DEV_ENV
+    static const int dbgEnv = getenv( "VVR_LFM_DBG" ) ? atoi( getenv( "VVR_LFM_DBG" ) ) : 0;      // developer build: 1 affine cells like plain ones, 2 no motion stores, 4 no stores (timing only)
+    a.dbg = dbgEnv;
+#endif
+    a.blocksMaps = (int) ( ( 8 * w.numTu + w.numSb + 255 ) / 256 );
+  }
+  int blocksMark = 0;
+  if( w.numItems )
+  {
+    a.items = w.items; a.numItems = w.numItems; a.resi = w.resi; a.numResi = w.numResi;
+    a.M = leaf_maps_of( pic, w.maps, w.mapW4, w.mapH4 ); a.sync = reinterpret_cast<int*>( w.maps + w.mapInts - 64 );
+    blocksMark = ( w.numItems + w.numResi + 15 ) / 16;
+  }
+  const int blocks = a.blocksMaps + a.blocksExpand + blocksMark;
+  if( blocks ) hipLaunchKernelGGL( k_prep, dim3( blocks ), dim3( 256 ), 0, s, pic, a );
+}
 
 void launch_resi_add( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes resi, const IntraItem* items, int numItems )
 {
