@@ -473,66 +473,103 @@ template<class P> __device__ __forceinline__ P* mc_uniform_ptr( P* p )
 // ---- windows of a tile that lies inside the picture: dword loads, 16 (luma) / 8 (chroma) lanes per window row --------------------
 __device__ __forceinline__ uint32_t mc_dpp_next_lane( uint32_t v ) { return (uint32_t) __builtin_amdgcn_update_dpp( 0, (int) v, 0x101 /* row_shl:1 */, 0xf, 0xf, true ); }
 
+// The loads of a window and what becomes of them are two steps (issue / commit): a tile issues the loads of all its windows, then waits once
+// (four windows loaded one after the other were four memory round trips of a wavefront that lives for ten)
+template<int NT> struct Mc3Luma   { static constexpr int RP = NT / 16, NP = ( 23 + RP - 1 ) / RP; uint32_t v[NP]; };      // rows per pass; passes of a 23-row window
+template<int NT> struct Mc3Chroma { static constexpr int RP = NT / 8,  NP = ( 22 + RP - 1 ) / RP; uint32_t v[NP]; };      // 2 x 11 rows at most
 template<int NT>
-__device__ __forceinline__ void mc3_load_luma( pel_t* __restrict__ win, const pel_t* __restrict__ ref, int stride, int x0, int y0, int ww, int wh, int tid )
+__device__ __forceinline__ void mc3_issue_luma( Mc3Luma<NT>& R, const pel_t* __restrict__ ref, int stride, int x0, int y0, int ww, int wh, int tid )
 {
+  constexpr int RP = Mc3Luma<NT>::RP, NP = Mc3Luma<NT>::NP;
   const int q = tid & 15, r0 = tid >> 4;
-  const int odd = x0 & 1, sh = odd << 4;
+  const int odd = x0 & 1;
   const int ndw = ( ww + 1 + odd ) >> 1;              // dwords read per row: samples x0 - odd .. x0 - odd + 2 ndw - 1
-  const int nst = ( ww + 1 ) >> 1;                    // dwords kept per row
   const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>( ref + (size_t) y0 * stride + ( x0 - odd ) );
-  uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( win );
   const uint32_t sd = (uint32_t) stride >> 1;
-  constexpr int RP = NT / 16, NP = ( 23 + RP - 1 ) / RP;      // rows per pass; passes of a 23-row window
   const int last = wh - 1 - ( max( wh - 1 - r0, 0 ) % RP );    // the last row of this lane's residue class: the tail repeats it (same value to the same place), no branch
   const bool tall = wh > 4 * RP;                               // (uniform: a tile of 4 or 8 rows needs at most 15 window rows)
-  uint32_t v[NP]; int rr[NP];
 #pragma unroll
   for( int i = 0; i < NP; i++ )
   {
-    rr[i] = min( r0 + i * RP, last );
-    v[i] = 0;
-    if( ( i < 4 || tall ) && q < ndw ) v[i] = base[__umul24( (uint32_t) rr[i], sd ) + (uint32_t) q];
+    const int rr = min( r0 + i * RP, last );
+    R.v[i] = 0;
+    if( ( i < 4 || tall ) && q < ndw ) R.v[i] = base[__umul24( (uint32_t) rr, sd ) + (uint32_t) q];
   }
+}
+template<int NT>
+__device__ __forceinline__ void mc3_commit_luma( const Mc3Luma<NT>& R, pel_t* __restrict__ win, int x0, int ww, int wh, int tid )
+{
+  constexpr int RP = Mc3Luma<NT>::RP, NP = Mc3Luma<NT>::NP;
+  const int q = tid & 15, r0 = tid >> 4;
+  const int sh = ( x0 & 1 ) << 4;
+  const int nst = ( ww + 1 ) >> 1;                    // dwords kept per row
+  uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( win );
+  const int last = wh - 1 - ( max( wh - 1 - r0, 0 ) % RP );
+  const bool tall = wh > 4 * RP;
   uint32_t w[NP];
 #pragma unroll
-  for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v[i] ), v[i], sh );
+  for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( R.v[i] ), R.v[i], sh );
   if( q < nst )
   {
 #pragma unroll
-    for( int i = 0; i < NP; i++ ) if( i < 4 || tall ) wdw[__umul24( (uint32_t) rr[i], MC2_WST_L / 2 ) + (uint32_t) q] = w[i];
+    for( int i = 0; i < NP; i++ ) if( i < 4 || tall ) wdw[__umul24( (uint32_t) min( r0 + i * RP, last ), MC2_WST_L / 2 ) + (uint32_t) q] = w[i];
   }
+}
+template<int NT>
+__device__ __forceinline__ void mc3_load_luma( pel_t* __restrict__ win, const pel_t* __restrict__ ref, int stride, int x0, int y0, int ww, int wh, int tid )
+{
+  Mc3Luma<NT> R;
+  mc3_issue_luma<NT>( R, ref, stride, x0, y0, ww, wh, tid );
+  mc3_commit_luma<NT>( R, win, x0, ww, wh, tid );
 }
 // Cb and Cr windows of a list (same geometry): 8 lanes per row, the rows of Cb, then those of Cr
 template<int NT>
-__device__ __forceinline__ void mc3_load_chroma( pel_t* __restrict__ winCb /* Cr follows: 12 rows further */, const pel_t* __restrict__ refCb, const pel_t* __restrict__ refCr, int stride, int x0, int y0, int ww, int wh, int tid )
+__device__ __forceinline__ void mc3_issue_chroma( Mc3Chroma<NT>& R, const pel_t* __restrict__ refCb, const pel_t* __restrict__ refCr, int stride, int x0, int y0, int ww, int wh, int tid )
 {
+  constexpr int RP = Mc3Chroma<NT>::RP, NP = Mc3Chroma<NT>::NP;
   const int q = tid & 7, r0 = tid >> 3;
-  const int odd = x0 & 1, sh = odd << 4;
-  const int ndw = ( ww + 1 + odd ) >> 1, nst = ( ww + 1 ) >> 1;
+  const int odd = x0 & 1;
+  const int ndw = ( ww + 1 + odd ) >> 1;
   const size_t off = (size_t) y0 * stride + ( x0 - odd );
   const uint32_t sd = (uint32_t) stride >> 1;
-  constexpr int RP = NT / 8, NP = ( 22 + RP - 1 ) / RP;        // 2 x 11 rows at most
   const int last = 2 * wh - 1 - ( max( 2 * wh - 1 - r0, 0 ) % RP );
-  uint32_t v[NP]; uint32_t wo[NP];
 #pragma unroll
   for( int i = 0; i < NP; i++ )
   {
     const int r2 = min( r0 + i * RP, last ), cc = r2 >= wh, r = r2 - ( cc ? wh : 0 );
     const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>( ( cc ? refCr : refCb ) + off );
-    wo[i] = ( cc ? 12 * ( MC2_WST_C / 2 ) : 0 ) + r * ( MC2_WST_C / 2 ) + q;
-    v[i] = 0;
-    if( q < ndw ) v[i] = base[__umul24( (uint32_t) r, sd ) + (uint32_t) q];
+    R.v[i] = 0;
+    if( q < ndw ) R.v[i] = base[__umul24( (uint32_t) r, sd ) + (uint32_t) q];
   }
+}
+template<int NT>
+__device__ __forceinline__ void mc3_commit_chroma( const Mc3Chroma<NT>& R, pel_t* __restrict__ winCb /* Cr follows: 12 rows further */, int x0, int ww, int wh, int tid )
+{
+  constexpr int RP = Mc3Chroma<NT>::RP, NP = Mc3Chroma<NT>::NP;
+  const int q = tid & 7, r0 = tid >> 3;
+  const int sh = ( x0 & 1 ) << 4;
+  const int nst = ( ww + 1 ) >> 1;
+  const int last = 2 * wh - 1 - ( max( 2 * wh - 1 - r0, 0 ) % RP );
   uint32_t w[NP];
 #pragma unroll
-  for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v[i] ), v[i], sh );
+  for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( R.v[i] ), R.v[i], sh );
   uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( winCb );
   if( q < nst )
   {
 #pragma unroll
-    for( int i = 0; i < NP; i++ ) wdw[wo[i]] = w[i];
+    for( int i = 0; i < NP; i++ )
+    {
+      const int r2 = min( r0 + i * RP, last ), cc = r2 >= wh, r = r2 - ( cc ? wh : 0 );
+      wdw[( cc ? 12 * ( MC2_WST_C / 2 ) : 0 ) + r * ( MC2_WST_C / 2 ) + q] = w[i];
+    }
   }
+}
+template<int NT>
+__device__ __forceinline__ void mc3_load_chroma( pel_t* __restrict__ winCb, const pel_t* __restrict__ refCb, const pel_t* __restrict__ refCr, int stride, int x0, int y0, int ww, int wh, int tid )
+{
+  Mc3Chroma<NT> R;
+  mc3_issue_chroma<NT>( R, refCb, refCr, stride, x0, y0, ww, wh, tid );
+  mc3_commit_chroma<NT>( R, winCb, x0, ww, wh, tid );
 }
 
 // the windows of a segment record (k_mc's other tiles, k_mc_dmvr): the dword loader where the window lies inside what may be read and is no displaced copy, else sample by sample
@@ -558,69 +595,199 @@ __device__ __forceinline__ void mc_load_seg_chroma( pel_t* winCb, pel_t* winCr, 
                            __builtin_amdgcn_readfirstlane( gCb.wh ), tid );
   else { mc_load_window<NT>( winCb, MC2_WST_C, gCb, refCb, stride, pw, ph, tid ); mc_load_window<NT>( winCr, MC2_WST_C, gCr, refCr, stride, pw, ph, tid ); }
 }
-// ---- stage 1: horizontal filter of every window row to 14-bit intermediates, two rows x eight columns per work item --------------
-template<int NT>
-__device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int tw, int th, int headroom, int tid, const McTapRows& T )
+// ---- any window sample by sample (clamped / wrapped / displaced copies), in two steps like the dword loaders: 32 lanes per row
+template<int NT, int ROWS> struct McWinS { static constexpr int RS = NT / 32, NP = ( ROWS + RS - 1 ) / RS; int v[NP]; };
+template<int NT, int ROWS>
+__device__ __forceinline__ void mcs_issue( McWinS<NT, ROWS>& R, const McSeg& g, const pel_t* __restrict__ ref, int stride, int pw, int tid )
 {
-  const int shift1 = 6 - headroom, offset1 = __builtin_amdgcn_readfirstlane( -IF_INTERNAL_OFFS * ( 1 << shift1 ) );
-  {
-    // When the luma and the chroma work items of the tile fit into one pass of the workgroup (one prediction list, small tiles, two wavefronts per tile), the
-    // chroma row pairs go through the eight-tap code beside the luma ones (taps 4..7 of a chroma row of d_mcTaps are zero, a chroma window row holds 16 samples)
-    const int lgU = tw > 8 ? 1 : 0, perL = ( ( th + 8 ) >> 1 ) << lgU, nA = nl * perL;
-    const int rpCU = ( ( th >> 1 ) + 4 ) >> 1, perC = 2 * rpCU, nB = ncomp == 3 ? nl * perC : 0;
-    if( nA + nB <= NT )
-    {
-      if( tid < nA + nB )
-      {
-        const bool isC = tid >= nA;
-        const int h0L = T.h[0][0], h1L = T.h[1][0], h0C = T.h[0][1], h1C = T.h[1][1];      // (values first: a per-lane choice between struct members would put the struct into scratch)
-        int k; const pel_t* src; uint32_t* dst;
-        if( !isC ) { k = tid >= perL; const int r0 = tid - ( k ? perL : 0 ), rp = r0 >> lgU, g = r0 & lgU; src = &m.winL[k][2 * rp * MC2_WST_L + 8 * g]; dst = &m.tmpL[k][8 * g * MC3_TPL + rp]; }
-        else { int q = tid - nA; k = q >= perC; q -= k ? perC : 0; const int cc = q >= rpCU, rp = q - ( cc ? rpCU : 0 ); src = &m.winC[k][cc][2 * rp * MC2_WST_C]; dst = &m.tmpC[2 * k + cc][rp]; }
-        const int tapRow = isC ? ( k ? h1C : h0C ) : ( k ? h1L : h0L );
-        const int ws = isC ? MC2_WST_C : MC2_WST_L, cs = isC ? MC3_TPC : MC3_TPL;
-        const uint4 C = d_mcTaps[tapRow];
-        int a[8], b[8];
-        mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), C, offset1, a );
-        mc_fir8<8>( *reinterpret_cast<const uint4*>( src + ws ), *reinterpret_cast<const uint4*>( src + ws + 8 ), C, offset1, b );
+  constexpr int RS = McWinS<NT, ROWS>::RS, NP = McWinS<NT, ROWS>::NP;
+  const int col = min( tid & 31, g.ww - 1 ), row0 = tid >> 5;      // (lanes beyond the window read its last column and store nothing)
+  const int sx = mc_ref_col( g.x0 + clip3( 0, g.cw - 1, col + g.shX - g.padOff ), g.bx0, g.bx1, pw, g.wrapOff );
+  const int last = g.wh - 1 - ( max( g.wh - 1 - row0, 0 ) % RS );   // last row of this lane's residue class (the tail repeats it: same value to the same place)
 #pragma unroll
-        for( int j = 0; j < 8; j++ ) dst[j * cs] = __builtin_amdgcn_perm( (uint32_t) ( b[j] >> shift1 ), (uint32_t) ( a[j] >> shift1 ), 0x05040100u );
-      }
-      __syncthreads();
-      return;
+  for( int i = 0; i < NP; i++ )
+  {
+    const int yy = min( row0 + i * RS, last );
+    const int sy = clip3( g.by0, g.by1, g.y0 + clip3( 0, g.chh - 1, yy + g.shY - g.padOff ) );
+    R.v[i] = ref[__umul24( (uint32_t) sy, (uint32_t) stride ) + (uint32_t) sx];      // (clamped coordinates: inside the plane, whose rows and columns number fewer than 2^24)
+  }
+}
+template<int NT, int ROWS>
+__device__ __forceinline__ void mcs_commit( const McWinS<NT, ROWS>& R, pel_t* win, int wst, const McSeg& g, int tid )
+{
+  constexpr int RS = McWinS<NT, ROWS>::RS, NP = McWinS<NT, ROWS>::NP;
+  const int col = tid & 31, row0 = tid >> 5;
+  const int last = g.wh - 1 - ( max( g.wh - 1 - row0, 0 ) % RS );
+  if( col < g.ww )
+  {
+#pragma unroll
+    for( int i = 0; i < NP; i++ ) win[min( row0 + i * RS, last ) * wst + col] = (pel_t) R.v[i];
+  }
+}
+// the luma windows of both lists with one wait (k_mc_dmvr: the bilinear windows)
+template<int NT, int ROWS>
+__device__ __forceinline__ void mc_load_seg_luma_pair( Mc2Shared& m, int stride, int pw, int tid )
+{
+  const bool plain = mc_seg_plain( m.seg[0][0], stride ) && mc_seg_plain( m.seg[1][0], stride );
+  if( plain )
+  {
+    Mc3Luma<NT> R[2];
+#pragma unroll
+    for( int l = 0; l < 2; l++ )
+    {
+      const McSeg& g = m.seg[l][0];
+      mc3_issue_luma<NT>( R[l], mc_uniform_ptr( m.refp[l][0] ), stride, __builtin_amdgcn_readfirstlane( g.x0 ), __builtin_amdgcn_readfirstlane( g.y0 ), __builtin_amdgcn_readfirstlane( g.ww ), __builtin_amdgcn_readfirstlane( g.wh ), tid );
+    }
+#pragma unroll
+    for( int l = 0; l < 2; l++ )
+    {
+      const McSeg& g = m.seg[l][0];
+      mc3_commit_luma<NT>( R[l], m.winL[l], __builtin_amdgcn_readfirstlane( g.x0 ), __builtin_amdgcn_readfirstlane( g.ww ), __builtin_amdgcn_readfirstlane( g.wh ), tid );
     }
   }
+  else
   {
-    const int lg = tw > 8 ? 1 : 0;                    // a 16-wide tile has two groups of eight columns
-    const int perList = ( ( th + 8 ) >> 1 ) << lg;    // th + 7 window rows in pairs
-    for( int idx = tid; idx < nl * perList; idx += NT )
+    McWinS<NT, ROWS> R[2];
+#pragma unroll
+    for( int l = 0; l < 2; l++ ) mcs_issue<NT, ROWS>( R[l], m.seg[l][0], m.refp[l][0], stride, pw, tid );
+#pragma unroll
+    for( int l = 0; l < 2; l++ ) mcs_commit<NT, ROWS>( R[l], m.winL[l], MC2_WST_L, m.seg[l][0], tid );
+  }
+}
+// all windows of a bi-predicted tile with one wait (k_mc_dmvr: the final prediction)
+template<int NT>
+__device__ __forceinline__ void mc_load_seg_all( Mc2Shared& m, int ncomp, int strideL, int strideC, int pwL, int pwC, int tid )
+{
+  bool plain = mc_seg_plain( m.seg[0][0], strideL ) && mc_seg_plain( m.seg[1][0], strideL );
+  if( ncomp == 3 ) plain = plain && mc_seg_plain( m.seg[0][1], strideC ) && mc_seg_plain( m.seg[1][1], strideC );
+  if( plain )
+  {
+    Mc3Luma<NT> RL[2]; Mc3Chroma<NT> RC[2];
+#pragma unroll
+    for( int l = 0; l < 2; l++ )
     {
-      const int k = idx >= perList, r0 = idx - ( k ? perList : 0 ), rp = r0 >> lg, g = r0 & lg;
-      const uint4 C = d_mcTaps[k ? T.h[1][0] : T.h[0][0]];
-      const pel_t* src = &m.winL[k][2 * rp * MC2_WST_L + 8 * g];
+      const McSeg& g = m.seg[l][0];
+      mc3_issue_luma<NT>( RL[l], mc_uniform_ptr( m.refp[l][0] ), strideL, __builtin_amdgcn_readfirstlane( g.x0 ), __builtin_amdgcn_readfirstlane( g.y0 ), __builtin_amdgcn_readfirstlane( g.ww ), __builtin_amdgcn_readfirstlane( g.wh ), tid );
+      if( ncomp == 3 )
+      {
+        const McSeg& c = m.seg[l][1];
+        mc3_issue_chroma<NT>( RC[l], mc_uniform_ptr( m.refp[l][1] ), mc_uniform_ptr( m.refp[l][2] ), strideC, __builtin_amdgcn_readfirstlane( c.x0 ), __builtin_amdgcn_readfirstlane( c.y0 ), __builtin_amdgcn_readfirstlane( c.ww ), __builtin_amdgcn_readfirstlane( c.wh ), tid );
+      }
+    }
+#pragma unroll
+    for( int l = 0; l < 2; l++ )
+    {
+      const McSeg& g = m.seg[l][0];
+      mc3_commit_luma<NT>( RL[l], m.winL[l], __builtin_amdgcn_readfirstlane( g.x0 ), __builtin_amdgcn_readfirstlane( g.ww ), __builtin_amdgcn_readfirstlane( g.wh ), tid );
+      if( ncomp == 3 )
+      {
+        const McSeg& c = m.seg[l][1];
+        mc3_commit_chroma<NT>( RC[l], m.winC[l][0], __builtin_amdgcn_readfirstlane( c.x0 ), __builtin_amdgcn_readfirstlane( c.ww ), __builtin_amdgcn_readfirstlane( c.wh ), tid );
+      }
+    }
+  }
+  else
+  {
+    // (two waits - luma, chroma: all six windows in flight at once cost the registers of one resident sub-block in sixteen)
+    {
+      McWinS<NT, 23> RL[2];
+#pragma unroll
+      for( int l = 0; l < 2; l++ ) mcs_issue<NT, 23>( RL[l], m.seg[l][0], m.refp[l][0], strideL, pwL, tid );
+#pragma unroll
+      for( int l = 0; l < 2; l++ ) mcs_commit<NT, 23>( RL[l], m.winL[l], MC2_WST_L, m.seg[l][0], tid );
+    }
+    if( ncomp == 3 )
+    {
+      McWinS<NT, 11> RC[2][2];
+#pragma unroll
+      for( int l = 0; l < 2; l++ ) { mcs_issue<NT, 11>( RC[l][0], m.seg[l][1], m.refp[l][1], strideC, pwC, tid ); mcs_issue<NT, 11>( RC[l][1], m.seg[l][2], m.refp[l][2], strideC, pwC, tid ); }
+#pragma unroll
+      for( int l = 0; l < 2; l++ ) { mcs_commit<NT, 11>( RC[l][0], m.winC[l][0], MC2_WST_C, m.seg[l][1], tid ); mcs_commit<NT, 11>( RC[l][1], m.winC[l][1], MC2_WST_C, m.seg[l][2], tid ); }
+    }
+  }
+}
+
+// The tap rows of the two stages, read before the windows are waited for (one memory round trip for everything a tile reads before it computes): what lane
+// `tid` needs in stage 1 (s1[0]: the merged pass or the luma pass, s1[1]: the chroma pass) and in stage 2 (s2[list]).  Same lane -> work item mapping as the stages.
+struct McTapsPre { uint4 s1[2], s2[2]; };
+template<int NT, int PARTS = 3 /* 1: stage 1, 2: stage 2 */>
+__device__ __forceinline__ void mc2_prefetch_taps( McTapsPre& P, int nl, int ncomp, int tw, int th, int tid, const McTapRows& T )
+{
+  const int h0L = T.h[0][0], h1L = T.h[1][0], h0C = T.h[0][1], h1C = T.h[1][1], v0L = T.v[0][0], v1L = T.v[1][0], v0C = T.v[0][1], v1C = T.v[1][1];
+  const int lgU = tw > 8 ? 1 : 0, perL = ( ( th + 8 ) >> 1 ) << lgU, nA = nl * perL;
+  const int rpCU = ( ( th >> 1 ) + 4 ) >> 1, perC = 2 * rpCU, nB = ncomp == 3 ? nl * perC : 0;
+  const bool merged = nA + nB <= NT;
+  const int rowL = tid >= perL ? h1L : h0L;
+  const int rowA = ( merged && tid >= nA ) ? ( tid - nA >= perC ? h1C : h0C ) : rowL;
+  // (no branches: a load that may not happen would have to be waited for where the paths meet; rows nobody uses are row 0)
+  if constexpr( PARTS & 1 )
+  {
+    P.s1[0] = d_mcTaps[rowA];
+    P.s1[1] = d_mcTaps[tid >= perC ? h1C : h0C];
+  }
+  if constexpr( PARTS & 2 )
+  {
+    const bool isC = tid >= tw * ( ( th + 7 ) >> 3 );
+    P.s2[0] = d_mcTaps[isC ? v0C : v0L];
+    P.s2[1] = d_mcTaps[isC ? v1C : v1L];
+  }
+}
+
+// ---- stage 1: horizontal filter of every window row to 14-bit intermediates, two rows x eight columns per work item --------------
+// (a tile is at most 16x16: every pass is one work item per lane at most - 48 luma items, 24 chroma items)
+template<int NT>
+__device__ __forceinline__ void mc2_stage1( Mc2Shared& m, int nl, int ncomp, int tw, int th, int headroom, int tid, const McTapRows& T, const McTapsPre& pre )
+{
+  static_assert( NT >= 64, "one work item per lane and pass" );
+  const int shift1 = 6 - headroom, offset1 = __builtin_amdgcn_readfirstlane( -IF_INTERNAL_OFFS * ( 1 << shift1 ) );
+  const int h0L = T.h[0][0], h1L = T.h[1][0], h0C = T.h[0][1], h1C = T.h[1][1];      // (values first: a per-lane choice between struct members would put the struct into scratch)
+  // When the luma and the chroma work items of the tile fit into one pass of the workgroup (one prediction list, small tiles, two wavefronts per tile), the
+  // chroma row pairs go through the eight-tap code beside the luma ones (taps 4..7 of a chroma row of d_mcTaps are zero, a chroma window row holds 16 samples)
+  const int lgU = tw > 8 ? 1 : 0, perL = ( ( th + 8 ) >> 1 ) << lgU, nA = nl * perL;      // a 16-wide tile has two groups of eight columns; th + 7 window rows in pairs
+  const int rpCU = ( ( th >> 1 ) + 4 ) >> 1, perC = 2 * rpCU, nB = ncomp == 3 ? nl * perC : 0;      // th / 2 + 3 window rows in pairs, Cb and Cr
+  if( nA + nB <= NT )
+  {
+    if( tid < nA + nB )
+    {
+      const bool isC = tid >= nA;
+      int k; const pel_t* src; uint32_t* dst;
+      if( !isC ) { k = tid >= perL; const int r0 = tid - ( k ? perL : 0 ), rp = r0 >> lgU, g = r0 & lgU; src = &m.winL[k][2 * rp * MC2_WST_L + 8 * g]; dst = &m.tmpL[k][8 * g * MC3_TPL + rp]; }
+      else { int q = tid - nA; k = q >= perC; q -= k ? perC : 0; const int cc = q >= rpCU, rp = q - ( cc ? rpCU : 0 ); src = &m.winC[k][cc][2 * rp * MC2_WST_C]; dst = &m.tmpC[2 * k + cc][rp]; }
+      const int tapRow = isC ? ( k ? h1C : h0C ) : ( k ? h1L : h0L );
+      const int ws = isC ? MC2_WST_C : MC2_WST_L, cs = isC ? MC3_TPC : MC3_TPL;
+      const uint4 C = pre.s1[0];
       int a[8], b[8];
       mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), C, offset1, a );
-      mc_fir8<8>( *reinterpret_cast<const uint4*>( src + MC2_WST_L ), *reinterpret_cast<const uint4*>( src + MC2_WST_L + 8 ), C, offset1, b );
-      uint32_t* dst = &m.tmpL[k][8 * g * MC3_TPL + rp];
+      mc_fir8<8>( *reinterpret_cast<const uint4*>( src + ws ), *reinterpret_cast<const uint4*>( src + ws + 8 ), C, offset1, b );
 #pragma unroll
-      for( int j = 0; j < 8; j++ ) dst[j * MC3_TPL] = __builtin_amdgcn_perm( (uint32_t) ( b[j] >> shift1 ), (uint32_t) ( a[j] >> shift1 ), 0x05040100u );
+      for( int j = 0; j < 8; j++ ) dst[j * cs] = __builtin_amdgcn_perm( (uint32_t) ( b[j] >> shift1 ), (uint32_t) ( a[j] >> shift1 ), 0x05040100u );
     }
+    __syncthreads();
+    return;
   }
-  if( ncomp == 3 )
+  if( tid < nA )
   {
-    const int rpC = ( ( th >> 1 ) + 4 ) >> 1, perList = 2 * rpC;      // th / 2 + 3 window rows in pairs, Cb and Cr
-    for( int idx = tid; idx < nl * perList; idx += NT )
-    {
-      const int k = idx >= perList, q = idx - ( k ? perList : 0 ), cc = q >= rpC, rp = q - ( cc ? rpC : 0 );
-      const uint4 C = d_mcTaps[k ? T.h[1][1] : T.h[0][1]];
-      const pel_t* src = &m.winC[k][cc][2 * rp * MC2_WST_C];
-      int a[8], b[8];
-      mc_fir8<4>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), C, offset1, a );
-      mc_fir8<4>( *reinterpret_cast<const uint4*>( src + MC2_WST_C ), *reinterpret_cast<const uint4*>( src + MC2_WST_C + 8 ), C, offset1, b );
-      uint32_t* dst = &m.tmpC[2 * k + cc][rp];
+    const int k = tid >= perL, r0 = tid - ( k ? perL : 0 ), rp = r0 >> lgU, g = r0 & lgU;
+    const uint4 C = pre.s1[0];
+    const pel_t* src = &m.winL[k][2 * rp * MC2_WST_L + 8 * g];
+    int a[8], b[8];
+    mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), C, offset1, a );
+    mc_fir8<8>( *reinterpret_cast<const uint4*>( src + MC2_WST_L ), *reinterpret_cast<const uint4*>( src + MC2_WST_L + 8 ), C, offset1, b );
+    uint32_t* dst = &m.tmpL[k][8 * g * MC3_TPL + rp];
 #pragma unroll
-      for( int j = 0; j < 8; j++ ) dst[j * MC3_TPC] = __builtin_amdgcn_perm( (uint32_t) ( b[j] >> shift1 ), (uint32_t) ( a[j] >> shift1 ), 0x05040100u );
-    }
+    for( int j = 0; j < 8; j++ ) dst[j * MC3_TPL] = __builtin_amdgcn_perm( (uint32_t) ( b[j] >> shift1 ), (uint32_t) ( a[j] >> shift1 ), 0x05040100u );
+  }
+  if( tid < nB )
+  {
+    const int k = tid >= perC, q = tid - ( k ? perC : 0 ), cc = q >= rpCU, rp = q - ( cc ? rpCU : 0 );
+    const uint4 C = pre.s1[1];
+    const pel_t* src = &m.winC[k][cc][2 * rp * MC2_WST_C];
+    int a[8], b[8];
+    mc_fir8<4>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 8 ), C, offset1, a );
+    mc_fir8<4>( *reinterpret_cast<const uint4*>( src + MC2_WST_C ), *reinterpret_cast<const uint4*>( src + MC2_WST_C + 8 ), C, offset1, b );
+    uint32_t* dst = &m.tmpC[2 * k + cc][rp];
+#pragma unroll
+    for( int j = 0; j < 8; j++ ) dst[j * MC3_TPC] = __builtin_amdgcn_perm( (uint32_t) ( b[j] >> shift1 ), (uint32_t) ( a[j] >> shift1 ), 0x05040100u );
   }
   __syncthreads();
 }
@@ -634,8 +801,9 @@ enum { MCM_UNI = 0, MCM_AVG, MCM_BCW, MCM_GEO, MCM_WP_UNI, MCM_WP_BI };
 template<int NT>
 __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int nl, int ncomp, int mode, const vvr_cu& cu, int bcwIdx, int bd, int headroom,
                                             const DevPlanes& reco, int tx, int ty, int tw, int th, int tid, const int16_t* __restrict__ fwdLut /* LMCS forward map or nullptr */,
-                                            const McTapRows& T, const vvr_wp_params* __restrict__ wp = nullptr /* MCM_WP_*: explicit weighted prediction */, int wpL = 0, int wpR0 = 0, int wpR1 = 0 )
+                                            const McTapRows& T, const vvr_wp_params* __restrict__ wp /* MCM_WP_*: explicit weighted prediction */, int wpL, int wpR0, int wpR1, const McTapsPre& pre )
 {
+  static_assert( NT >= 64, "one work item per lane" );
   const int wL = tw, hL = th, wC = tw >> 1, hC = th >> 1;
   const int lwL = wL == 16 ? 4 : wL == 8 ? 3 : 2;
   const int itemsL = wL * ( ( hL + 7 ) >> 3 ), itemsC = ncomp == 3 ? 2 * wC : 0;            // chroma: at most 8 rows = one group
@@ -646,7 +814,8 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
   const int16_t* __restrict__ const fwdU = mc_uniform_ptr( fwdLut );
   const int shift2 = 6 + headroom, offset2 = ( 1 << ( shift2 - 1 ) ) + ( IF_INTERNAL_OFFS << 6 );
   const int init2 = __builtin_amdgcn_readfirstlane( mode == MCM_UNI ? offset2 : 0 );
-  for( int idx = tid; idx < itemsL + itemsC; idx += NT )
+  const int idx = tid;                                 // (32 luma + 16 chroma work items at most)
+  if( idx < itemsL + itemsC )
   {
     int c, x, g8;
     if( idx < itemsL ) { c = 0; g8 = idx >> lwL; x = idx & ( wL - 1 ); } else { const int q = idx - itemsL; c = 1 + ( q >= wC ); x = q - ( c - 1 ) * wC; g8 = 0; }
@@ -658,7 +827,7 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
       if( k < nl )
       {
         const uint32_t* src = c ? &m.tmpC[2 * k + c - 1][x * MC3_TPC] : &m.tmpL[k][x * MC3_TPL + 4 * g8];
-        const uint4 C = d_mcTaps[c ? T.v[k][1] : T.v[k][0]];         // (chroma: taps 4..7 are zero)
+        const uint4 C = pre.s2[k];         // (chroma: taps 4..7 are zero)
         mc_fir8<8>( *reinterpret_cast<const uint4*>( src ), *reinterpret_cast<const uint4*>( src + 4 ), C, init2, p[k] );
       }
     }
@@ -667,7 +836,7 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
 #pragma unroll
       for( int i = 0; i < 8; i++ )
         if( i < nrows ) { bsp->blk[0][BDOF_AT( x, 8 * g8 + i )] = (pel_t) ( p[0][i] >> 6 ); bsp->blk[1][BDOF_AT( x, 8 * g8 + i )] = (pel_t) ( p[1][i] >> 6 ); }
-      continue;
+      return;
     }
     int out[8];
     if( mode == MCM_UNI )
@@ -776,6 +945,7 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   // The window always spans the full filter support (the block's integer origin sits at (half, half)), whatever the fractional part of the MV
   bool fast = !pic.hdr.wrap_offset && !pic.subpics;
   int wx[2], wy[2], cx[2], cy[2], li[2], ri[2];
+  McTapsPre pre;
   if( fast )
   {
 #pragma unroll
@@ -803,14 +973,26 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
   }
   if( fast )
   {
+    // every load of the tile's windows is in flight before the first of them is waited for, and so are the tap rows of both stages
+    Mc3Luma<NT> RL[2]; Mc3Chroma<NT> RC[2];
+    mc2_prefetch_taps<NT>( pre, nl, ncomp, iw, ih, tid, T );
 #pragma unroll
     for( int k = 0; k < 2; k++ )
     {
       if( k < nl )
       {
         const int ridx = li[k] * VVR_MAX_REFS + ri[k];
-        mc3_load_luma<NT>( m.winL[k], refs.p[ridx][0], reco.stride[0], wx[k], wy[k], iw + 7, ih + 7, tid );
-        if( ncomp == 3 ) mc3_load_chroma<NT>( m.winC[k][0], refs.p[ridx][1], refs.p[ridx][2], reco.stride[1], cx[k], cy[k], ( iw >> 1 ) + 3, ( ih >> 1 ) + 3, tid );
+        mc3_issue_luma<NT>( RL[k], refs.p[ridx][0], reco.stride[0], wx[k], wy[k], iw + 7, ih + 7, tid );
+        if( ncomp == 3 ) mc3_issue_chroma<NT>( RC[k], refs.p[ridx][1], refs.p[ridx][2], reco.stride[1], cx[k], cy[k], ( iw >> 1 ) + 3, ( ih >> 1 ) + 3, tid );
+      }
+    }
+#pragma unroll
+    for( int k = 0; k < 2; k++ )
+    {
+      if( k < nl )
+      {
+        mc3_commit_luma<NT>( RL[k], m.winL[k], wx[k], iw + 7, ih + 7, tid );
+        if( ncomp == 3 ) mc3_commit_chroma<NT>( RC[k], m.winC[k][0], cx[k], ( iw >> 1 ) + 3, ( ih >> 1 ) + 3, tid );
       }
     }
     if constexpr( BDOF )
@@ -857,14 +1039,15 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
       T.h[k][0] = mc_tap_row( 0, MC_U( m.seg[k][0].xFrac ), f4, altHpel ); T.v[k][0] = mc_tap_row( 0, MC_U( m.seg[k][0].yFrac ), f4, altHpel );
       if( ncomp == 3 ) { T.h[k][1] = mc_tap_row( 1, MC_U( m.seg[k][1].xFrac ), false, false ); T.v[k][1] = mc_tap_row( 1, MC_U( m.seg[k][1].yFrac ), false, false ); }
     }
+    mc2_prefetch_taps<NT>( pre, nl, ncomp, iw, ih, tid, T );
   }
   __syncthreads();
-  mc2_stage1<NT>( m, nl, ncomp, iw, ih, headroom, tid, T );
+  mc2_stage1<NT>( m, nl, ncomp, iw, ih, headroom, tid, T, pre );
   const vvr_wp_params* __restrict__ wpT = wp_at( pic, ix, iy );      // the weight table of the tile's slice
   const bool wpOn = !BDOF && wpT && !geo && bcwIdx == 2;          // xPredInterBi (:707,735-742)
   const int mode = wpOn ? ( uni ? MCM_WP_UNI : MCM_WP_BI ) : uni ? MCM_UNI : geo ? MCM_GEO : bcwIdx != 2 ? MCM_BCW : MCM_AVG;
   mc2_stage2<NT>( m, BDOF ? reinterpret_cast<BdofShared*>( &bs ) : nullptr, nl, ncomp, mode, cu, bcwIdx, bd, headroom, reco, ix, iy, iw, ih, tid, fwdLut, T,
-                  wpOn ? wpT : nullptr, l0, mRef[0], mRef[1] );
+                  wpOn ? wpT : nullptr, l0, mRef[0], mRef[1], pre );
   if constexpr( BDOF )
   {
     __syncthreads();
@@ -883,8 +1066,8 @@ __global__ __launch_bounds__( NT ) void k_mc( PicDev pic, RefSet refs, DevPlanes
 // =====================================================================================================================
 #define DM_WST_L MC2_WST_L
 struct DmvrShared {
-  Mc2Shared m;                   // windows / intermediates / taps of the final prediction (stage 1 reuses winL for the bilinear windows)
-  __attribute__( ( aligned( 16 ) ) ) pel_t bil[2][20 * 20];      // bilinear predictions of the extended sub-block, 10 bit (two per dword in the search)
+  Mc2Shared m;                   // windows / intermediates / taps of the final prediction (stage 1 reuses winL for the bilinear windows, and the intermediates' place -
+                                 // tmpL + tmpC, 2688 bytes - for the bilinear predictions of the extended sub-block: 2 x 20 x 20 samples at 10 bit, two per dword in the search)
   unsigned sad[25];
   int dmv[2], bioSub, minCost;
   BdofShared bs;
@@ -905,8 +1088,9 @@ __device__ __forceinline__ int dmvr_div_for_maxq7( long long N, long long D )
   return neg ? -q : q;
 }
 
+// (16 sub-blocks per compute unit: 64 vector registers and 10 KB of LDS at most - a 4K B picture's 3700 sub-blocks are resident at once)
 template<int NT>
-__global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems, int32_t* __restrict__ dmvrOut )
+__global__ __launch_bounds__( NT ) __attribute__( ( amdgpu_waves_per_eu( 8, 8 ) ) ) void k_mc_dmvr( PicDev pic, RefSet refs, DevPlanes reco, const McItem* __restrict__ items, int numItems, int32_t* __restrict__ dmvrOut )
 {
   __shared__ DmvrShared sh;
   const int item = mc_item_index();
@@ -919,24 +1103,28 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
   const int w = it.w, h = it.h;
   const bool bio = cu.mc_mode == VVR_MC_DMVR_BDOF;
+  pel_t ( * const bil )[20 * 20] = reinterpret_cast<pel_t( * )[20 * 20]>( &sh.m.tmpL[0][0] );
+  static_assert( sizeof( sh.m.tmpL ) + sizeof( sh.m.tmpC ) >= 2 * 20 * 20 * sizeof( pel_t ) && offsetof( Mc2Shared, tmpC ) == offsetof( Mc2Shared, tmpL ) + sizeof( sh.m.tmpL ), "the bilinear predictions lie where the intermediates will" );
   // ---- stage 1: bilinear predictions of the sub-block extended by 2 samples (start MVs clipped against the CU, then moved by -2)
+  // (the start vectors, the reference indices and the CU's position and width come with the tile record: the CU record is first needed by the search's last step)
   if( tid < 2 )
   {
     const int l = tid;
-    int mvx = cu.mv[l][0][0], mvy = cu.mv[l][0][1];
+    const int cuX = it.clipX, cuY = it.clipY, cuW = 4 * it.clipW4;
+    int mvx = l ? it.mv[1][0] : it.mv[0][0], mvy = l ? it.mv[1][1] : it.mv[0][1];      // (values, never a per-lane index into the record: that would put it into scratch)
     // (xinitMC runs once per CU, InterPrediction.cpp:1859: the start MVs are clipped against the CU - its position and, with wrap-around, its width.  Until round 4 the
     // wrap-around case clipped against the sub-block: the same samples unless a clamp is involved, i.e. for vectors beyond a wrap period - tests/bitstreams_open)
-    const McBounds B = mc_bounds( pic, cu.x, cu.y );
-    const int wrapOff = mc_clip_mv_w( pic, B, cu.x, cu.y, pic.hdr.wrap_offset ? (int) cu.w : 0, mvx, mvy );
+    const McBounds B = mc_bounds( pic, cuX, cuY );
+    const int wrapOff = mc_clip_mv_w( pic, B, cuX, cuY, pic.hdr.wrap_offset ? cuW : 0, mvx, mvy );
     mvx -= 32; mvy -= 32;
     McSeg g; g.wrapOff = wrapOff; g.bx0 = B.x0; g.by0 = B.y0; g.bx1 = B.x1; g.by1 = B.y1;
     g.w = w + 4; g.h = h + 4; g.xFrac = mvx & 15; g.yFrac = mvy & 15;
     g.x0 = it.x + ( mvx >> 4 ); g.y0 = it.y + ( mvy >> 4 ); g.ww = g.w + 1; g.wh = g.h + 1; g.ox = g.oy = 0; g.padOff = 0; g.cw = g.ww; g.chh = g.wh; g.shX = g.shY = 0;
     sh.m.seg[l][0] = g;
-    sh.m.refp[l][0] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][0];
+    sh.m.refp[l][0] = refs.p[l * VVR_MAX_REFS + ( l ? it.ref[1] : it.ref[0] )][0];
   }
   __syncthreads();
-  for( int l = 0; l < 2; l++ ) mc_load_seg_luma<NT>( sh.m.winL[l], sh.m.seg[l][0], sh.m.refp[l][0], reco.stride[0], reco.w[0], reco.h[0], tid );
+  mc_load_seg_luma_pair<NT, 21>( sh.m, reco.stride[0], reco.w[0], tid );
   __syncthreads();
   {
     // InterpolationFilter::filter<2> (:589-600) / filterCopy biMCForDMVR (:445-477) at IF_INTERNAL_PREC_BILINEAR = 10
@@ -955,7 +1143,7 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
       const pel_t* p = &sh.m.winL[l][y * DM_WST_L + x];
       const int t0 = ( p[0] * ( 16 - fx ) + p[1] * fx + offF ) >> shiftF;
       const int t1 = ( p[DM_WST_L] * ( 16 - fx ) + p[DM_WST_L + 1] * fx + offF ) >> shiftF;
-      sh.bil[l][y * 20 + x] = (pel_t) ( ( t0 * ( 16 - fy ) + t1 * fy + 8 ) >> 4 );
+      bil[l][y * 20 + x] = (pel_t) ( ( t0 * ( 16 - fy ) + t1 * fy + 8 ) >> 4 );
     }
   }
   __syncthreads();
@@ -966,7 +1154,7 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
     for( int i = tid; i < w * ( h >> 1 ); i += NT )
     {
       const int x = i & ( w - 1 ), y = ( i >> lw ) << 1;
-      part += iabs( sh.bil[0][( 2 + y ) * 20 + 2 + x] - sh.bil[1][( 2 + y ) * 20 + 2 + x] );
+      part += iabs( bil[0][( 2 + y ) * 20 + 2 + x] - bil[1][( 2 + y ) * 20 + 2 + x] );
     }
     for( int o = 32; o; o >>= 1 ) part += __shfl_xor( part, o );
     if constexpr( NT > 64 )
@@ -992,8 +1180,8 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
         // both odd - an odd start is realigned from the dwords around it
         const int ver = cand / 5 - 2, hor = cand - ( cand / 5 ) * 5 - 2;
         const int oa = ( 2 + ver ) * 20 + 2 + hor, ob = ( 2 - ver ) * 20 + 2 - hor, odd = oa & 1, nd = w >> 1;
-        const uint32_t* a = reinterpret_cast<const uint32_t*>( sh.bil[0] ) + ( ( oa - odd ) >> 1 );
-        const uint32_t* b = reinterpret_cast<const uint32_t*>( sh.bil[1] ) + ( ( ob - odd ) >> 1 );
+        const uint32_t* a = reinterpret_cast<const uint32_t*>( bil[0] ) + ( ( oa - odd ) >> 1 );
+        const uint32_t* b = reinterpret_cast<const uint32_t*>( bil[1] ) + ( ( ob - odd ) >> 1 );
         const int sh = odd << 4;
         for( int y = half * 2; y < h; y += 2 * LPC )
         {
@@ -1093,22 +1281,22 @@ __global__ __launch_bounds__( NT ) void k_mc_dmvr( PicDev pic, RefSet refs, DevP
     }
   }
   __syncthreads();
-  for( int k = 0; k < 2; k++ )
-  {
-    mc_load_seg_luma<NT>( sh.m.winL[k], sh.m.seg[k][0], sh.m.refp[k][0], reco.stride[0], reco.w[0], reco.h[0], tid );
-    if( ncomp == 3 ) mc_load_seg_chroma<NT>( sh.m.winC[k][0], sh.m.winC[k][1], sh.m.seg[k][1], sh.m.seg[k][2], sh.m.refp[k][1], sh.m.refp[k][2], reco.stride[1], reco.w[1], reco.h[1], tid );
-  }
-  __syncthreads();
+  // the tap rows of both stages and every window of the sub-block: one wait
   McTapRows T;
 #pragma unroll
   for( int k = 0; k < 2; k++ )
   {
-    const bool f4 = w == 4 && h == 4, altHpel = cu.imv == 3;
+    const bool f4 = w == 4 && h == 4, altHpel = ( it.flags & MC_ITEM_HPEL ) != 0;
     T.h[k][0] = mc_tap_row( 0, sh.m.seg[k][0].xFrac, f4, altHpel ); T.v[k][0] = mc_tap_row( 0, sh.m.seg[k][0].yFrac, f4, altHpel );
     T.h[k][1] = ncomp == 3 ? mc_tap_row( 1, sh.m.seg[k][1].xFrac, false, false ) : 0; T.v[k][1] = ncomp == 3 ? mc_tap_row( 1, sh.m.seg[k][1].yFrac, false, false ) : 0;
   }
-  mc2_stage1<NT>( sh.m, 2, ncomp, w, h, headroom, tid, T );
-  mc2_stage2<NT>( sh.m, bioSub ? &sh.bs : nullptr, 2, ncomp, MCM_AVG, cu, 2, bd, headroom, reco, it.x, it.y, w, h, tid, fwdLut, T );
+  McTapsPre pre;
+  mc2_prefetch_taps<NT, 1>( pre, 2, ncomp, w, h, tid, T );
+  mc_load_seg_all<NT>( sh.m, ncomp, reco.stride[0], reco.stride[1], reco.w[0], reco.w[1], tid );
+  mc2_prefetch_taps<NT, 2>( pre, 2, ncomp, w, h, tid, T );      // (these arrive while stage 1 computes; held across the window loads they would cost the 16th sub-block per compute unit)
+  __syncthreads();
+  mc2_stage1<NT>( sh.m, 2, ncomp, w, h, headroom, tid, T, pre );
+  mc2_stage2<NT>( sh.m, bioSub ? &sh.bs : nullptr, 2, ncomp, MCM_AVG, cu, 2, bd, headroom, reco, it.x, it.y, w, h, tid, fwdLut, T, nullptr, 0, 0, 0, pre );
   if( bioSub )
   {
     __syncthreads();
@@ -1162,18 +1350,29 @@ __device__ __forceinline__ bool aff_spread_over_limit( int a, int b, int c, int 
 // host (PU::setAllAffineMv, UnitTools.cpp:2689-2810): the affine model evaluated at the sub-block's centre in 1/16 sample with 7 fractional bits
 // more, rounded away from zero at .5, clipped to the 18-bit MV storage range; ONE vector for the whole CU (the model at the CU's centre) when the
 // sub-block vectors would spread too far (isSubblockVectorSpreadOverLimit, InterPrediction.cpp:892).  VVR_TOOL_AFFINE_MV_ON_DEVICE.
-__device__ __forceinline__ void aff_span_mv( const vvr_cu& cu, int l, int wx, int wy, int& mx, int& my )
+// (the CU's fields as values: the control points of ONE list, already chosen - the record itself is read once per tile, see AffCu)
+struct AffCpmv { int m[3][2]; };
+__device__ __forceinline__ void aff_span_mv( const AffCpmv& P, int cuW, int cuH, bool sixP, int interDir, int wx, int wy, int& mx, int& my )
 {
-  const int lw = ilog2( cu.w ), lh = ilog2( cu.h );
-  const int dHX = ( cu.mv[l][1][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lw ) ), dHY = ( cu.mv[l][1][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lw ) );
+  const int lw = ilog2( cuW ), lh = ilog2( cuH );
+  const int dHX = ( P.m[1][0] - P.m[0][0] ) * ( 1 << ( 7 - lw ) ), dHY = ( P.m[1][1] - P.m[0][1] ) * ( 1 << ( 7 - lw ) );
   int dVX, dVY;
-  if( cu.flags & VVR_CU_AFFINE_6P ) { dVX = ( cu.mv[l][2][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lh ) ); dVY = ( cu.mv[l][2][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lh ) ); }
+  if( sixP ) { dVX = ( P.m[2][0] - P.m[0][0] ) * ( 1 << ( 7 - lh ) ); dVY = ( P.m[2][1] - P.m[0][1] ) * ( 1 << ( 7 - lh ) ); }
   else { dVX = -dHY; dVY = dHX; }
-  const bool over = aff_spread_over_limit( dHX, dHY, dVX, dVY, cu.inter_dir );
-  const int px = over ? cu.w >> 1 : 2 + 4 * wx, py = over ? cu.h >> 1 : 2 + 4 * wy;
-  mx = cu.mv[l][0][0] * 128 + dHX * px + dVX * py; my = cu.mv[l][0][1] * 128 + dHY * px + dVY * py;
+  const bool over = aff_spread_over_limit( dHX, dHY, dVX, dVY, interDir );
+  const int px = over ? cuW >> 1 : 2 + 4 * wx, py = over ? cuH >> 1 : 2 + 4 * wy;
+  mx = P.m[0][0] * 128 + dHX * px + dVX * py; my = P.m[0][1] * 128 + dHY * px + dVY * py;
   aff_round_mv( mx, my, 7 );
   mx = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mx ); my = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, my );
+}
+
+// (from the record in global memory: k_mc_rpr)
+__device__ __forceinline__ void aff_span_mv( const vvr_cu& cu, int l, int wx, int wy, int& mx, int& my )
+{
+  AffCpmv P;
+#pragma unroll
+  for( int a = 0; a < 3; a++ ) { P.m[a][0] = cu.mv[l][a][0]; P.m[a][1] = cu.mv[l][a][1]; }
+  aff_span_mv( P, cu.w, cu.h, ( cu.flags & VVR_CU_AFFINE_6P ) != 0, cu.inter_dir, wx, wy, mx, my );
 }
 
 // one chroma sample of a 4x4 sub-block from its column of horizontally filtered row pairs (vertical 4-tap stage; the identity filter for a whole-sample vector:
@@ -1199,7 +1398,24 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   if( item >= numItems ) return;
   const McItem it = items[item];
   const int16_t* __restrict__ fwdLut = lmcs_fwd_at( pic, it.x, it.y );      // LMCS (where the tile's slice uses it): luma predictions are stored forward-mapped (lmcs_fwd_luma)
-  const vvr_cu& cu = pic.cu[it.cu];
+  // The CU record is read ONCE, as dwords all in flight together: the geometry below evaluates the affine model per lane and list, and
+  // every field it touched through a reference into global memory was a load of its own with a wait of its own (twenty of them before the first window sample)
+  struct { int x, y, w, h, flags, inter_dir, ref_idx[2], bcw_idx; int mv[2][3][2]; } cu;
+  {
+    static_assert( offsetof( vvr_cu, w ) == 4 && offsetof( vvr_cu, flags ) == 8 && offsetof( vvr_cu, inter_dir ) == 20 && offsetof( vvr_cu, ref_idx ) == 21 && offsetof( vvr_cu, bcw_idx ) == 23
+                   && offsetof( vvr_cu, mv ) == 32 && sizeof( vvr_cu ) % 4 == 0, "the dwords of vvr_cu read below" );
+    const uint32_t* __restrict__ cw = reinterpret_cast<const uint32_t*>( &pic.cu[__builtin_amdgcn_readfirstlane( it.cu )] );
+    uint32_t hd[4]; int mvv[12];
+    hd[0] = cw[0]; hd[1] = cw[1]; hd[2] = cw[2]; hd[3] = cw[5];
+#pragma unroll
+    for( int i = 0; i < 12; i++ ) mvv[i] = (int) cw[8 + i];
+#pragma unroll
+    for( int i = 0; i < 4; i++ ) hd[i] = (uint32_t) __builtin_amdgcn_readfirstlane( (int) hd[i] );
+    cu.x = hd[0] & 0xffff; cu.y = hd[0] >> 16; cu.w = hd[1] & 0xff; cu.h = ( hd[1] >> 8 ) & 0xff; cu.flags = hd[2] & 0xffff;
+    cu.inter_dir = hd[3] & 0xff; cu.ref_idx[0] = (int) (int8_t) ( hd[3] >> 8 ); cu.ref_idx[1] = (int) (int8_t) ( hd[3] >> 16 ); cu.bcw_idx = hd[3] >> 24;
+#pragma unroll
+    for( int i = 0; i < 12; i++ ) cu.mv[i / 6][( i / 2 ) % 3][i & 1] = mvv[i];      // (the same in every lane, but in vector registers: twelve more scalar ones cost the eighth resident tile)
+  }
   const int bd = pic.hdr.bit_depth, ctu = 1 << pic.hdr.log2_ctu;
   const int tid = threadIdx.x;
   const int ncomp = pic.hdr.chroma_format ? 3 : 1;
@@ -1224,15 +1440,19 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
     const int horMax = ( AB.x1 + 1 + 8 - cu.x - 1 ) * 16, horMin = ( -ctu - 8 - ( cu.x - AB.x0 ) + 1 ) * 16;
     const int verMax = ( AB.y1 + 1 + 8 - cu.y - 1 ) * 16, verMin = ( -ctu - 8 - ( cu.y - AB.y0 ) + 1 ) * 16;
     const bool onDev = ( pic.hdr.tool_flags & VVR_TOOL_AFFINE_MV_ON_DEVICE ) != 0;
+    const bool sixP = ( cu.flags & VVR_CU_AFFINE_6P ) != 0;
     for( int i = tid; i < nl * ( nsb + ncb ); i += NT )
     {
       const int k = i / ( nsb + ncb ), r = i - k * ( nsb + ncb ), l = biPred ? k : l0;
+      AffCpmv P;        // the control points of this lane's list (values chosen per lane, never an index into the record)
+#pragma unroll
+      for( int a = 0; a < 3; a++ ) { P.m[a][0] = l ? cu.mv[1][a][0] : cu.mv[0][a][0]; P.m[a][1] = l ? cu.mv[1][a][1] : cu.mv[0][a][1]; }
       AffSeg g;
       if( r < nsb )
       {
         const int sx = r % sbx, sy = r / sbx;
         int smx, smy;
-        if( onDev ) aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + sx, ( ( it.y - cu.y ) >> 2 ) + sy, smx, smy );
+        if( onDev ) aff_span_mv( P, cu.w, cu.h, sixP, cu.inter_dir, ( ( it.x - cu.x ) >> 2 ) + sx, ( ( it.y - cu.y ) >> 2 ) + sy, smx, smy );
         else { const vvr_motion& m = pic.affMotion[it.mv[0][0] + 4 * sy + sx]; smx = m.mv[l][0]; smy = m.mv[l][1]; }
         int mx = smx, my = smy;
         // wrap-around: ONE wrapClipMv per sub-block, against the sub-block (:1177-1186)
@@ -1250,8 +1470,8 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
         if( onDev )
         {
           int ax, ay, bx, by;
-          aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + 2 * sx, ( ( it.y - cu.y ) >> 2 ) + 2 * sy, ax, ay );
-          aff_span_mv( cu, l, ( ( it.x - cu.x ) >> 2 ) + 2 * sx + 1, ( ( it.y - cu.y ) >> 2 ) + 2 * sy + 1, bx, by );
+          aff_span_mv( P, cu.w, cu.h, sixP, cu.inter_dir, ( ( it.x - cu.x ) >> 2 ) + 2 * sx, ( ( it.y - cu.y ) >> 2 ) + 2 * sy, ax, ay );
+          aff_span_mv( P, cu.w, cu.h, sixP, cu.inter_dir, ( ( it.x - cu.x ) >> 2 ) + 2 * sx + 1, ( ( it.y - cu.y ) >> 2 ) + 2 * sy + 1, bx, by );
           mx = ax + bx; my = ay + by;
         }
         else
@@ -1272,16 +1492,18 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
     if( tid < nl )
     {
       const int k = tid, l = biPred ? k : l0;
-      for( int c = 0; c < ncomp; c++ ) sh.refp[k][c] = refs.p[l * VVR_MAX_REFS + cu.ref_idx[l]][c];
+      for( int c = 0; c < ncomp; c++ ) sh.refp[k][c] = refs.p[l * VVR_MAX_REFS + ( l ? cu.ref_idx[1] : cu.ref_idx[0] )][c];
       // PROF switch and the per-position MV offsets of a 4x4 sub-block (:1015-1090)
+      AffCpmv P;
+#pragma unroll
+      for( int a = 0; a < 3; a++ ) { P.m[a][0] = l ? cu.mv[1][a][0] : cu.mv[0][a][0]; P.m[a][1] = l ? cu.mv[1][a][1] : cu.mv[0][a][1]; }
       const int lw = ilog2( cu.w ), lh = ilog2( cu.h );
-      const int dHX = ( cu.mv[l][1][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lw ) ), dHY = ( cu.mv[l][1][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lw ) );
+      const int dHX = ( P.m[1][0] - P.m[0][0] ) * ( 1 << ( 7 - lw ) ), dHY = ( P.m[1][1] - P.m[0][1] ) * ( 1 << ( 7 - lw ) );
       int dVX, dVY;
-      const bool sixP = ( cu.flags & VVR_CU_AFFINE_6P ) != 0;
-      if( sixP ) { dVX = ( cu.mv[l][2][0] - cu.mv[l][0][0] ) * ( 1 << ( 7 - lh ) ); dVY = ( cu.mv[l][2][1] - cu.mv[l][0][1] ) * ( 1 << ( 7 - lh ) ); }
+      if( sixP ) { dVX = ( P.m[2][0] - P.m[0][0] ) * ( 1 << ( 7 - lh ) ); dVY = ( P.m[2][1] - P.m[0][1] ) * ( 1 << ( 7 - lh ) ); }
       else { dVX = -dHY; dVY = dHX; }
-      const bool eqRT = cu.mv[l][0][0] == cu.mv[l][1][0] && cu.mv[l][0][1] == cu.mv[l][1][1];
-      const bool eqLB = cu.mv[l][0][0] == cu.mv[l][2][0] && cu.mv[l][0][1] == cu.mv[l][2][1];
+      const bool eqRT = P.m[0][0] == P.m[1][0] && P.m[0][1] == P.m[1][1];
+      const bool eqLB = P.m[0][0] == P.m[2][0] && P.m[0][1] == P.m[2][1];
       bool prof = ( pic.hdr.tool_flags & VVR_TOOL_PROF ) != 0;
       prof = prof && !( ( sixP && eqRT && eqLB ) || ( !sixP && eqRT ) ) && !aff_spread_over_limit( dHX, dHY, dVX, dVY, cu.inter_dir );
       sh.prof[k] = prof;
@@ -1302,27 +1524,61 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
   // ---- windows: 11x11 per luma sub-block, 7x7 per chroma sub-block
   if( fastWin )
   {
-    // every window inside: dword loads, 8 (luma) / 4 (chroma) lanes per window row, an odd first column realigned with one DPP move + v_alignbit (as mc3_load_*)
-    const int q = tid & 7, rowsL = nl * nsb * 11;
-    for( int R = tid >> 3; R < rowsL; R += NT / 8 )
+    // every window inside: dword loads, 8 (luma) / 4 (chroma) lanes per window row, an odd first column realigned with one DPP move + v_alignbit (as mc3_load_*).
+    // A bi-predicted 16x16 tile has 352 luma rows (11 passes of the workgroup) and 112 chroma rows (2 passes): the loads of six passes are issued before the first
+    // of them is waited for - two memory round trips instead of thirteen (all at once would cost the eighth resident tile of a compute unit its registers)
+    constexpr int ITL = ( 2 * 16 * 11 + NT / 8 - 1 ) / ( NT / 8 ), ITC = ( 2 * 2 * 4 * 7 + NT / 4 - 1 ) / ( NT / 4 ), HL = ( ITL + 1 ) / 2;
+    const int q = tid & 7, rowsL = nl * nsb * 11, lgN = ilog2( nsb );            // (nsb is a power of two)
+    const int q4 = tid & 3, rowsC = ncomp == 3 ? nl * 2 * ncb * 7 : 0, lgC = ilog2( max( ncb, 1 ) );
+    uint32_t* const winLdw = reinterpret_cast<uint32_t*>( &sh.winL[0][0][0] );
+    uint32_t* const winCdw = reinterpret_cast<uint32_t*>( &sh.winC[0][0][0][0] );
+#pragma unroll
+    for( int half = 0; half < 2; half++ )
     {
-      const int blk = R / 11, yy = R - blk * 11, k = blk / nsb, sb = blk - k * nsb;
-      const int x0 = sh.segL[k][sb].x0, y0 = sh.segL[k][sb].y0, odd = x0 & 1;
-      uint32_t v = 0;
-      if( q < 6 ) v = reinterpret_cast<const uint32_t*>( sh.refp[k][0] + (size_t) ( y0 + yy ) * reco.stride[0] + ( x0 - odd ) )[q];
-      const uint32_t w = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v ), v, odd << 4 );
-      if( q < 6 ) reinterpret_cast<uint32_t*>( &sh.winL[k][sb][yy * AF_WL] )[q] = w;
-    }
-    if( ncomp == 3 )
-    {
-      const int q4 = tid & 3, rowsC = nl * 2 * ncb * 7;
-      for( int R = tid >> 2; R < rowsC; R += NT / 4 )
+      uint32_t v[HL], vc[ITC]; int dw[HL], dc[ITC];
+#pragma unroll
+      for( int j = 0; j < HL; j++ )
       {
-        const int blk = R / 7, yy = R - blk * 7, k = blk / ( 2 * ncb ), qq = blk - k * 2 * ncb, c = qq / ncb, sb = qq - c * ncb;
-        const int x0 = sh.segC[k][sb].x0, y0 = sh.segC[k][sb].y0, odd = x0 & 1;
-        const uint32_t v = reinterpret_cast<const uint32_t*>( sh.refp[k][1 + c] + (size_t) ( y0 + yy ) * reco.stride[1] + ( x0 - odd ) )[q4];
-        const uint32_t w = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v ), v, odd << 4 );      // (lane 3 takes its upper half from another row: column 7 of the window is never read)
-        reinterpret_cast<uint32_t*>( &sh.winC[k][c][sb][yy * AF_WC] )[q4] = w;
+        v[j] = 0; dw[j] = -1;
+        const int itn = half * HL + j, R = ( tid >> 3 ) + itn * ( NT / 8 );
+        if( itn < ITL && R < rowsL )
+        {
+          const int blk = R / 11, yy = R - blk * 11, k = blk >> lgN, sb = blk & ( nsb - 1 );
+          const int x0 = sh.segL[k][sb].x0, y0 = sh.segL[k][sb].y0, odd = x0 & 1;
+          if( q < 6 ) v[j] = reinterpret_cast<const uint32_t*>( sh.refp[k][0] + (size_t) ( y0 + yy ) * reco.stride[0] + ( x0 - odd ) )[q];
+          dw[j] = ( ( ( ( k * 16 + sb ) * 12 + yy ) * AF_WL ) >> 1 ) + q + ( odd << 30 );
+        }
+      }
+      if( half == 1 )
+      {
+#pragma unroll
+        for( int j = 0; j < ITC; j++ )
+        {
+          vc[j] = 0; dc[j] = -1;
+          const int R = ( tid >> 2 ) + j * ( NT / 4 );
+          if( R < rowsC )
+          {
+            const int blk = R / 7, yy = R - blk * 7, k = blk >> ( lgC + 1 ), qq = blk & ( 2 * ncb - 1 ), c = qq >> lgC, sb = qq & ( ncb - 1 );
+            const int x0 = sh.segC[k][sb].x0, y0 = sh.segC[k][sb].y0, odd = x0 & 1;
+            vc[j] = reinterpret_cast<const uint32_t*>( sh.refp[k][1 + c] + (size_t) ( y0 + yy ) * reco.stride[1] + ( x0 - odd ) )[q4];
+            dc[j] = ( ( ( ( ( k * 2 + c ) * 4 + sb ) * 8 + yy ) * AF_WC ) >> 1 ) + q4 + ( odd << 30 );
+          }
+        }
+      }
+#pragma unroll
+      for( int j = 0; j < HL; j++ )
+      {
+        const uint32_t wv = __builtin_amdgcn_alignbit( mc_dpp_next_lane( v[j] ), v[j], ( dw[j] >> 30 ) << 4 );      // (a pass that has no row: dw = -1, the shift does not matter)
+        if( dw[j] >= 0 && q < 6 ) winLdw[dw[j] & 0x3fffffff] = wv;
+      }
+      if( half == 1 )
+      {
+#pragma unroll
+        for( int j = 0; j < ITC; j++ )
+        {
+          const uint32_t wv = __builtin_amdgcn_alignbit( mc_dpp_next_lane( vc[j] ), vc[j], ( dc[j] >> 30 ) << 4 );      // (lane 3 takes its upper half from another row: column 7 of the window is never read)
+          if( dc[j] >= 0 ) winCdw[dc[j] & 0x3fffffff] = wv;
+        }
       }
     }
   }
@@ -1483,7 +1739,7 @@ __global__ __launch_bounds__( NT ) void k_mc_affine( PicDev pic, RefSet refs, De
         if( biPred ) p1 = aff_chroma_sample( sh.tmpC[1][c - 1][sb][px], sh.segC[1][sb].yFrac, py, true, bd, headroom );
       }
       int out = p0;
-      if( wpOn ) out = biPred ? wp_bi( wpT, cu.ref_idx[0], cu.ref_idx[1], c, p0, p1, bd, headroom ) : wp_uni( wpT, l0, cu.ref_idx[l0], c, p0, bd, headroom );
+      if( wpOn ) out = biPred ? wp_bi( wpT, cu.ref_idx[0], cu.ref_idx[1], c, p0, p1, bd, headroom ) : wp_uni( wpT, l0, l0 ? cu.ref_idx[1] : cu.ref_idx[0], c, p0, bd, headroom );
       else if( biPred )
       {
         if( cu.bcw_idx != 2 )
@@ -1880,14 +2136,14 @@ __device__ __forceinline__ void prep_expand_mc( int bid, const vvr_cu* __restric
   McItem it;
   it.flags = 0; it.cu = r.cu;
   it.mv[0][0] = it.mv[0][1] = it.mv[1][0] = it.mv[1][1] = 0; it.ref[0] = it.ref[1] = 0; it.bcw = 0; it.clipW4 = 0; it.clipX = it.clipY = 0;
-  if( cls != 2 )
   {
-    // everything k_mc needs about the motion of the tile
+    // everything k_mc needs about the motion of the tile (k_mc_dmvr: the start vectors and what they are clipped against)
     it.ref[0] = cu.ref_idx[0]; it.ref[1] = cu.ref_idx[1];
     it.mv[0][0] = cu.mv[0][0][0]; it.mv[0][1] = cu.mv[0][0][1]; it.mv[1][0] = cu.mv[1][0][0]; it.mv[1][1] = cu.mv[1][0][1];
     it.clipX = cu.x; it.clipY = cu.y;
     it.bcw = cu.bcw_idx;
     it.flags = (uint16_t) ( ( cu.mc_mode == VVR_MC_UNI ? MC_ITEM_UNI : 0 ) | ( cu.imv == 3 ? MC_ITEM_HPEL : 0 ) | ( cu.mc_mode == VVR_MC_GEO ? MC_ITEM_GEO : 0 ) );
+    if( cls == 2 ) it.clipW4 = (uint8_t) ( cw >> 2 );       // (the start vectors of a DMVR CU are clipped against the CU: its width under reference wrap-around)
   }
   const int ty = t / tilesX, tx = t - ty * tilesX, x = tx << 4, y = ty << 4;          // (rows of tiles, as the host writes them)
   it.x = (uint16_t) ( cu.x + x ); it.y = (uint16_t) ( cu.y + y ); it.w = (uint8_t) min( 16, cw - x ); it.h = (uint8_t) min( 16, ch - y );
