@@ -3050,11 +3050,14 @@ template<int DIR> struct DbTile;
 template<> struct DbTile<0> { static constexpr int N = 128, T = 16; };      // N: owned samples across the edges, T: along them
 template<> struct DbTile<1> { static constexpr int N = 64, T = 64; };
 template<bool LMCS, int DIR>
-__global__ __launch_bounds__( 256 ) void k_deblock_tile( PicDev pic, DevPlanes s, DevPlanes d, int dbg )
+__global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( 8, 8 ) ) ) void k_deblock_tile( PicDev pic, DevPlanes s, DevPlanes d, int dbg )
 {
   constexpr int NT = 256;
   constexpr int N = DbTile<DIR>::N, T = DbTile<DIR>::T, NN = DT_HL + N + DT_HR, NNC = 4 + N / 2 + 4;
-  constexpr int TS = ( DIR == 0 ? NN : T ) + 4, CS = ( DIR == 0 ? NNC : T / 2 ) + 4;          // LDS row strides (rows stay 8-byte aligned)
+  // LDS row strides (rows stay 8-byte aligned).  Vertical edges: lines run along rows, the lanes of a segment are a row stride apart - 4 samples of padding spread them
+  // over the banks; horizontal edges: the lanes of a segment are neighbours in a row whatever the stride, and without the padding the tile's 20.2 KB let EIGHT
+  // workgroups share a compute unit - a 4K picture's 2040 tiles are resident at once (with 21.5 KB: seven, and a second round for 248 of them)
+  constexpr int TS = DIR == 0 ? NN + 4 : T, CS = DIR == 0 ? NNC + 4 : T / 2;
   constexpr int YO = DIR == 0 ? 1 : TS, YSTEP = DIR == 0 ? TS : 1;                            // luma: across the edge / from line to line
   constexpr int CO = DIR == 0 ? 1 : CS, CSTEP = DIR == 0 ? CS : 1;
   constexpr int EC = N / 4 + 1, EA = T / 4, NE = EC * EA;                                      // edge positions across (the far border's included) x units along
