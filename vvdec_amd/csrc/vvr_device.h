@@ -48,9 +48,11 @@ struct TbItem {
   uint8_t  comp;       // component the coded levels belong to
   uint8_t  mode;       // TB_ADD: reco += residual (inter CU, prediction already in the picture); TB_STORE: write residual plane
   uint8_t  ict;        // 0, or 4 + ICT mode (-3..3 -> 1..7): joint Cb-Cr, the item writes both chroma blocks
-  uint8_t  pad;
+  uint8_t  pad;        // TB_P_*: what k_itrans must know of the CU before it has the CU record (it asks for the record, the levels and the basis rows at once)
 };
 enum { TB_ADD = 0, TB_STORE = 1 };
+enum { TB_P_CUGEOM = 1 /* chroma block of an ISP CU: position and size are the CU's */, TB_P_BDPCM = 2 /* BDPCM: every level of the block is coded */,
+       TB_P_LFNST = 4 /* the CU applies LFNST to this component: cu.lfnst_idx > 0 && ( cu.tree != VVR_TREE_JOINT || comp == 0 ) */ };
 
 // One intra-predicted transform block (decode order inside its CTU).  The reference-sample availability counts are the
 // m_neighborSize[] values IntraPrediction::xFillReferenceSamples derives by walking the CU/TU tree (IntraPrediction.cpp:1104-1139);

@@ -30,9 +30,10 @@ __device__ __forceinline__ int lmcs_fwd_luma( const int16_t* __restrict__ fwdLut
 } // namespace
 
 // ---- device copies of the constant tables (initialised from the generated include at load time) ----------------------
-__device__ int16_t d_dct2_2[4], d_dct2_4[16], d_dct2_8[64], d_dct2_16[256], d_dct2_32[1024], d_dct2_64[4096];
-__device__ int16_t d_dct8_4[16], d_dct8_8[64], d_dct8_16[256], d_dct8_32[1024];
-__device__ int16_t d_dst7_4[16], d_dst7_8[64], d_dst7_16[256], d_dst7_32[1024];
+#define TR_ALIGN __attribute__( ( aligned( 16 ) ) )      /* (k_itrans stages the basis rows with dword loads) */
+__device__ TR_ALIGN int16_t d_dct2_2[4], d_dct2_4[16], d_dct2_8[64], d_dct2_16[256], d_dct2_32[1024], d_dct2_64[4096];
+__device__ TR_ALIGN int16_t d_dct8_4[16], d_dct8_8[64], d_dct8_16[256], d_dct8_32[1024];
+__device__ TR_ALIGN int16_t d_dst7_4[16], d_dst7_8[64], d_dst7_16[256], d_dst7_32[1024];
 __device__ int8_t  d_lfnst8x8[4][2][48][16], d_lfnst4x4[4][2][16][16];
 __device__ uint8_t d_lfnst_lut[97], d_lfnst_scan8x8_xy[16][2], d_lfnst_scan4x4_xy[16][2];
 __device__ int32_t d_inv_quant_scales[2][6];
@@ -2293,54 +2294,127 @@ __device__ __forceinline__ int scaling_entry( const vvr_scaling_list* __restrict
 }
 
 // NT threads per transform block: 64 for the <= 16x16 class (one wavefront per block: four times as many blocks resident, no
-// cross-wave barrier), 256 for the larger classes
+// cross-wave barrier), 256 for the larger classes.
+// Round 6: three memory round trips per block - the item; its TU record; then EVERYTHING else at once: the CU record, the coded levels, the basis rows of both
+// passes and, for a block that is added onto the prediction, the prediction samples its lanes are going to change - instead of seven one after the other (item, TU,
+// CU, levels, basis rows, and at the very end a read of the prediction for every group of stores).  What the loads depend on of the CU - a chroma block that takes
+// its geometry from an ISP CU, BDPCM, LFNST - the host says in the item (TbItem::pad), so that only such a block waits for the CU record before it asks for the rest.
 template<int MAXN, int NT>
-__global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, DevPlanes resi, const TbItem* __restrict__ items, int numItems )
+__global__ __launch_bounds__( NT ) __attribute__( ( amdgpu_waves_per_eu( MAXN > 32 ? 3 : 8, 8 ) ) ) void k_itrans( PicDev pic, DevPlanes reco, DevPlanes resi, const TbItem* __restrict__ items, int numItems )
 {
   __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t dq[MAXN * MAXN];      // (16-byte reads in the two passes)
   __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t tmp[MAXN * MAXN];
-  __shared__ int16_t mvS[MAXN * MAXN], mhS[MAXN * MAXN];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t mvS[MAXN * MAXN], mhS[MAXN * MAXN];
   __shared__ int32_t lf_in[16], lf_out[48];
   const int item = blockIdx.x;
   if( item >= numItems ) return;
   const TbItem it = items[item];
   const vvr_tu& tu = pic.tu[it.tu];
-  const vvr_cu& cu = pic.cu[tu.cu];
   const int comp = it.comp, bd = pic.hdr.bit_depth, tid = threadIdx.x;
   const int csh = comp ? 1 : 0;
-  int bw = tu.w >> csh, bh = tu.h >> csh, bx = tu.x >> csh, by = tu.y >> csh;
-  if( comp && cu.isp_mode ) { bw = cu.w >> 1; bh = cu.h >> 1; bx = cu.x >> 1; by = cu.y >> 1; }
-  const int lw = ilog2( bw ), lh = ilog2( bh );
-  const bool isTS = tu.mts_idx[comp] == VVR_MTS_SKIP;
-  const int bdpcm = comp ? cu.bdpcm[1] : cu.bdpcm[0];
-  int maxX = tu.max_scan_x[comp], maxY = tu.max_scan_y[comp];
+  // ---- the TU record: every field the block needs, asked for together
+  const int tuX = tu.x, tuY = tu.y, tuW = tu.w, tuH = tu.h, mts = tu.mts_idx[comp], trt = tu.tr_type[comp];
+  const int scanX = tu.max_scan_x[comp], scanY = tu.max_scan_y[comp], tuQp = tu.qp[comp];
   const int16_t* __restrict__ lev = pic.coef + tu.coef_off[comp];
-
-  const int n = bw * bh;
-  for( int i = tid; i < n; i += NT ) dq[i] = 0;
-  __syncthreads();
+  const vvr_cu& cu = pic.cu[tu.cu];
+  int bw = tuW >> csh, bh = tuH >> csh, bx = tuX >> csh, by = tuY >> csh;
+  if( it.pad & TB_P_CUGEOM ) { bw = cu.w >> 1; bh = cu.h >> 1; bx = cu.x >> 1; by = cu.y >> 1; }      // (chroma of an ISP CU)
+  const int lw = ilog2( bw ), lh = ilog2( bh ), n = bw * bh;
+  const bool isTS = mts == VVR_MTS_SKIP;
+  const bool bdpcmOn = ( it.pad & TB_P_BDPCM ) != 0;
+  const bool lfnstBit = ( it.pad & TB_P_LFNST ) != 0;                // cu.lfnst_idx > 0 && ( cu.tree != VVR_TREE_JOINT || comp == 0 )
+  const bool lfnstOn = ( pic.hdr.tool_flags & VVR_TOOL_LFNST ) && lfnstBit && !isTS;
+  // the corner that carries coefficients when the passes start: the coded one, the whole block under BDPCM, at least the LFNST output region
+  const int cw = scanX + 1, codedRows = scanY + 1;
+  int maxX = scanX, maxY = scanY;
+  if( bdpcmOn ) { maxX = bw - 1; maxY = bh - 1; }
+  if( lfnstOn ) { maxX = max( maxX, min( bw - 1, 7 ) ); maxY = max( maxY, min( bh - 1, 7 ) ); }
+  const int trHor = trt & 3, trVer = trt >> 2;
+  const int shift1 = 7, shift2 = 20 - bd;
+  const bool dcOnly = !isTS && maxX == 0 && maxY == 0 && trHor == 0 && trVer == 0;
+  const bool oneD = !isTS && ( bw == 1 || bh == 1 );        // ISP partitions of 4xN / Nx4 CUs: one pass, shift_2nd + 1 (TrQuant.cpp:466-482)
+  const bool twoD = !isTS && !dcOnly && !oneD;
+  const bool fourRows = bh >= 4 && !oneD;                   // four neighbouring rows of a column per work item in the output stage
+  // basis rows the passes touch (zero-out of the high frequencies: TrQuant_EMT.cpp:389)
+  int redW = 0, cutH = 0, cntV = 0, cntH = 0;
+  const int16_t* __restrict__ Mv = nullptr; const int16_t* __restrict__ Mh = nullptr;
+  if( oneD )
+  {
+    const int n1 = bw == 1 ? bh : bw, tr = bw == 1 ? trVer : trHor, maxPos = bw == 1 ? maxY : maxX;
+    const int skip = max( ( tr != 0 && n1 == 32 ) ? 16 : n1 > 32 ? n1 - 32 : 0, n1 - maxPos - 1 );
+    redW = n1 - skip;                                        // rows of the basis that take part
+    Mh = tr_matrix( tr, n1 ); cntH = redW * n1;
+  }
+  else if( twoD )
+  {
+    const int skipW = max( ( trHor != 0 && bw == 32 ) ? 16 : bw > 32 ? bw - 32 : 0, bw - maxX - 1 );
+    const int skipH = max( ( trVer != 0 && bh == 32 ) ? 16 : bh > 32 ? bh - 32 : 0, bh - maxY - 1 );
+    cutH = bh - skipH; redW = bw - skipW;
+    Mv = tr_matrix( trVer, bh ); Mh = tr_matrix( trHor, bw ); cntV = cutH * bh; cntH = redW * bw;
+  }
+  // ---- the loads: levels (one per lane and step over the whole block: zero outside the coded corner), basis rows as dwords, prediction samples
+  constexpr int ITER_C = MAXN * MAXN / NT, ITER_M = ( MAXN > 32 ? 32 : MAXN ) * MAXN / 2 / NT, ITER_E = MAXN * MAXN / 4 / NT;
+  int lv[ITER_C];
+  if( !bdpcmOn )
+  {
+#pragma unroll
+    for( int k = 0; k < ITER_C; k++ )
+    {
+      const int i = tid + k * NT, y = i >> lw, x = i & ( bw - 1 );
+      lv[k] = 0;
+      if( i < n && x < cw && y < codedRows ) lv[k] = lev[y * cw + x];
+    }
+  }
+  uint32_t mvR[ITER_M], mhR[ITER_M];
+#pragma unroll
+  for( int k = 0; k < ITER_M; k++ )
+  {
+    const int j = tid + k * NT;
+    mvR[k] = 0; mhR[k] = 0;
+    if( 2 * j < cntV ) mvR[k] = reinterpret_cast<const uint32_t*>( Mv )[j];
+    if( 2 * j < cntH ) mhR[k] = reinterpret_cast<const uint32_t*>( Mh )[j];
+  }
+  const int ict = it.ict ? (int) it.ict - 4 : 0;
+  const bool havePred = it.mode == TB_ADD && !ict && fourRows;
+  int predv[ITER_E][4];
+  {
+    const pel_t* __restrict__ P = reco.p[comp]; const int stride = reco.stride[comp];
+#pragma unroll
+    for( int e = 0; e < ITER_E; e++ )
+    {
+      const int i = tid + e * NT, x = i & ( bw - 1 ), y0 = ( i >> lw ) << 2;
+#pragma unroll
+      for( int r = 0; r < 4; r++ ) { predv[e][r] = 0; if( havePred && i < ( bh >> 2 ) * bw ) predv[e][r] = P[(size_t) ( by + y0 + r ) * stride + bx + x]; }
+    }
+  }
+  // ---- basis rows into LDS
+#pragma unroll
+  for( int k = 0; k < ITER_M; k++ )
+  {
+    const int j = tid + k * NT;
+    if( 2 * j < cntV ) reinterpret_cast<uint32_t*>( mvS )[j] = mvR[k];
+    if( 2 * j < cntH ) reinterpret_cast<uint32_t*>( mhS )[j] = mhR[k];
+  }
   // ---- dequantisation
   {
-    const uint32_t sliceFlags = flags_at( pic, tu.x, tu.y );      // dependent quantisation and the scaling lists are switches of the block's slice (Quant.cpp:306,336)
+    const uint32_t sliceFlags = flags_at( pic, tuX, tuY );      // dependent quantisation and the scaling lists are switches of the block's slice (Quant.cpp:306,336)
     const bool depQuant = ( sliceFlags & VVR_TOOL_DEP_QUANT ) && !isTS;
-    int qp = tu.qp[comp];
+    int qp = tuQp;
     if( isTS ) qp = max( qp, (int) pic.hdr.min_qp_ts );
     const int per = depQuant ? ( qp + 1 ) / 6 : qp / 6;
     const int rem = depQuant ? ( qp + 1 - 6 * per ) : qp - 6 * per;
     const bool needSqrt = !isTS && ( ( lw + lh ) & 1 );
     const int trShift = 15 - bd - ( ( lw + lh ) >> 1 ) - ( needSqrt ? 1 : 0 );
     // explicit scaling list (getUseScalingList, Quant.h:103): not for transform skip, optionally not for LFNST blocks
-    const bool lfnstApplied = cu.lfnst_idx > 0 && ( cu.tree != VVR_TREE_JOINT || comp == 0 );
-    const bool useSL = pic.scaling && ( sliceFlags & VVR_TOOL_SCALING_LIST ) && !isTS && !( lfnstApplied && ( pic.hdr.tool_flags & VVR_TOOL_SCALING_LIST_NO_LFNST ) );
-    const int listType = ( cu.pred_mode == VVR_PRED_INTRA ? 0 : 3 ) + comp;
+    const bool useSL = pic.scaling && ( sliceFlags & VVR_TOOL_SCALING_LIST ) && !isTS && !( lfnstBit && ( pic.hdr.tool_flags & VVR_TOOL_SCALING_LIST_NO_LFNST ) );
     const int rightShift = 6 + ( depQuant ? 1 : 0 ) - ( ( isTS ? 0 : trShift ) + per ) + ( useSL ? 4 : 0 );
     const int scaleQP = d_inv_quant_scales[needSqrt ? 1 : 0][rem];
-    const int scale = scaleQP;
     int targetBits = 32 + rightShift - 7; if( targetBits > 16 ) targetBits = 16;
     const int inMax = ( 1 << ( targetBits - 1 ) ) - 1, inMin = -inMax - 1;
-    if( bdpcm )
+    if( bdpcmOn )
     {
       // invResDPCM (Quant.cpp:239): running sums along rows (mode 1) / columns (mode 2); one thread per line
+      const int bdpcm = comp ? cu.bdpcm[1] : cu.bdpcm[0];
       const int lines = bdpcm == 1 ? bh : bw, len = bdpcm == 1 ? bw : bh;
       for( int l = tid; l < lines; l += NT )
       {
@@ -2354,38 +2428,43 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
         }
       }
       __syncthreads();
-      maxX = bw - 1; maxY = bh - 1;
       for( int i = tid; i < n; i += NT )
       {
         const int level = dq[i];
         if( level )
         {
           const long long c = clip3( inMin, inMax, level );
-          const long long v = rightShift > 0 ? ( c * scale + ( 1ll << ( rightShift - 1 ) ) ) >> rightShift : ( c * scale ) * ( 1ll << -rightShift );
+          const long long v = rightShift > 0 ? ( c * scaleQP + ( 1ll << ( rightShift - 1 ) ) ) >> rightShift : ( c * scaleQP ) * ( 1ll << -rightShift );
           dq[i] = clip3( -32768, 32767, (int) v );
         }
       }
     }
     else
     {
-      const int cw = maxX + 1, cn = cw * ( maxY + 1 );
-      for( int i = tid; i < cn; i += NT )
+      const int listType = useSL ? ( cu.pred_mode == VVR_PRED_INTRA ? 0 : 3 ) + comp : 0;
+#pragma unroll
+      for( int k = 0; k < ITER_C; k++ )
       {
-        const int y = i / cw, x = i - y * cw;
-        const int level = lev[i];
-        if( level )
+        const int i = tid + k * NT;
+        if( i < n )
         {
-          const long long c = clip3( inMin, inMax, level );
-          const int scale = useSL ? scaling_entry( pic.scaling, listType, lw, lh, x, y ) * scaleQP : scaleQP;
-          const long long v = rightShift > 0 ? ( c * scale + ( 1ll << ( rightShift - 1 ) ) ) >> rightShift : ( c * scale ) * ( 1ll << -rightShift );
-          dq[y * bw + x] = clip3( -32768, 32767, (int) v );
+          const int level = lv[k];
+          int out = 0;
+          if( level )
+          {
+            const long long c = clip3( inMin, inMax, level );
+            const int scale = useSL ? scaling_entry( pic.scaling, listType, lw, lh, i & ( bw - 1 ), i >> lw ) * scaleQP : scaleQP;
+            const long long v = rightShift > 0 ? ( c * scale + ( 1ll << ( rightShift - 1 ) ) ) >> rightShift : ( c * scale ) * ( 1ll << -rightShift );
+            out = clip3( -32768, 32767, (int) v );
+          }
+          dq[i] = out;
         }
       }
     }
   }
   __syncthreads();
   // ---- LFNST
-  if( ( pic.hdr.tool_flags & VVR_TOOL_LFNST ) && cu.lfnst_idx && !isTS && ( cu.tree != VVR_TREE_JOINT || comp == 0 ) )
+  if( lfnstOn )
   {
     const bool whge3 = bw >= 8 && bh >= 8;
     int mode;
@@ -2422,16 +2501,9 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
         else if( x < 4 ) dq[y * bw + x] = lf_out[32 + ( y - 4 ) * 4 + x];
       }
     }
-    maxX = max( maxX, min( bw - 1, 7 ) );
-    maxY = max( maxY, min( bh - 1, 7 ) );
     __syncthreads();
   }
   // ---- inverse transform; every thread produces the final residual of its samples and emits it right away
-  const int trHor = tu.tr_type[comp] & 3, trVer = tu.tr_type[comp] >> 2;
-  const int shift1 = 7, shift2 = 20 - bd;
-  const bool dcOnly = !isTS && maxX == 0 && maxY == 0 && trHor == 0 && trVer == 0;
-  const bool oneD = !isTS && ( bw == 1 || bh == 1 );        // ISP partitions of 4xN / Nx4 CUs: one pass, shift_2nd + 1 (TrQuant.cpp:466-482)
-  int redW = 0;
   int dcVal = 0;
   if( dcOnly )
   {
@@ -2442,27 +2514,8 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
       dcVal = (int16_t) ( ( dcVal * 64 + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
     }
   }
-  else if( oneD )
+  else if( twoD )
   {
-    const int n1 = bw == 1 ? bh : bw, tr = bw == 1 ? trVer : trHor, maxPos = bw == 1 ? maxY : maxX;
-    const int skip = max( ( tr != 0 && n1 == 32 ) ? 16 : n1 > 32 ? n1 - 32 : 0, n1 - maxPos - 1 );
-    redW = n1 - skip;                                        // rows of the basis that take part
-    const int16_t* __restrict__ M1 = tr_matrix( tr, n1 );
-    for( int i = tid; i < redW * n1; i += NT ) mhS[i] = M1[i];
-    __syncthreads();
-  }
-  else if( !isTS )
-  {
-    const int skipW = max( ( trHor != 0 && bw == 32 ) ? 16 : bw > 32 ? bw - 32 : 0, bw - maxX - 1 );
-    const int skipH = max( ( trVer != 0 && bh == 32 ) ? 16 : bh > 32 ? bh - 32 : 0, bh - maxY - 1 );
-    const int cutH = bh - skipH;
-    redW = bw - skipW;
-    // the basis rows both passes touch, staged in LDS (the tables themselves stay L2-resident)
-    const int16_t* __restrict__ Mv = tr_matrix( trVer, bh );
-    const int16_t* __restrict__ Mh = tr_matrix( trHor, bw );
-    for( int i = tid; i < cutH * bh; i += NT ) mvS[i] = Mv[i];
-    for( int i = tid; i < redW * bw; i += NT ) mhS[i] = Mh[i];
-    __syncthreads();
     // pass 1 (vertical): tmp[x*bh + y] = clip16( ( sum_k dq[k*bw + x] * Mv[k*bh + y] + 64 ) >> 7 ), x < redW
     // Four neighbouring columns per work item: one 16-byte read of dq and one basis value per step instead of a read of each per multiply-add
     // (the kernel lives on the LDS pipe: 512 + 1024 scalar reads per thread for a 64x64 block with a 32x32 corner before this)
@@ -2471,7 +2524,7 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
       const int grpX = ( redW + 3 ) >> 2;
       for( int i = tid; i < grpX * bh; i += NT )
       {
-        const int xg = i / bh, y = i - xg * bh, x0 = xg << 2;
+        const int xg = i >> lh, y = i & ( bh - 1 ), x0 = xg << 2;
         int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         for( int k = 0; k < cutH; k++ )
         {
@@ -2487,7 +2540,7 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
     else
     for( int i = tid; i < redW * bh; i += NT )
     {
-      const int x = i / bh, y = i - x * bh;
+      const int x = i >> lh, y = i & ( bh - 1 );
       int sum = 0;
       for( int k = 0; k < cutH; k++ ) sum += dq[k * bw + x] * mvS[k * bh + y];
       tmp[x * bh + y] = clip3( -32768, 32767, ( sum + ( 1 << ( shift1 - 1 ) ) ) >> shift1 );
@@ -2495,7 +2548,6 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
     __syncthreads();
   }
   // ---- pass 2 (horizontal) + output
-  const int ict = it.ict ? (int) it.ict - 4 : 0;
   // the residual r of sample (x, y) goes where it belongs: onto the prediction (inter blocks) or into the residual plane; joint Cb-Cr derives the second one
   auto emit = [&]( int x, int y, int r )
   {
@@ -2524,30 +2576,56 @@ __global__ __launch_bounds__( NT ) void k_itrans( PicDev pic, DevPlanes reco, De
       if( ict ) resi.p[cOther][(size_t) ( by + y ) * resi.stride[cOther] + bx + x] = (pel_t) rOther;
     }
   };
-  if( !isTS && !dcOnly && !oneD && bh >= 4 )
+  if( fourRows )
   {
     // out[y*bw + x] = clip16( ( sum_{k<redW} tmp[k*bh + y] * Mh[k*bw + x] + rnd ) >> shift2 ): four neighbouring rows per work item (one 16-byte read of
-    // tmp and one basis value per step); neighbouring lanes hold neighbouring columns, so the stores of a row stay contiguous
-    const int grpY = bh >> 2;
-    for( int i = tid; i < grpY * bw; i += NT )
-    {
-      const int yg = i / bw, x = i - yg * bw, y0 = yg << 2;
-      int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-      for( int k = 0; k < redW; k++ )
-      {
-        const int m = mhS[k * bw + x];
-        const int4 t = *reinterpret_cast<const int4*>( &tmp[k * bh + y0] );
-        s0 += t.x * m; s1 += t.y * m; s2 += t.z * m; s3 += t.w * m;
-      }
-      const int sv[4] = { s0, s1, s2, s3 };
+    // tmp and one basis value per step); neighbouring lanes hold neighbouring columns, so the stores of a row stay contiguous.  Transform-skipped and
+    // DC-only blocks take the same form (their residual is there already).
+    const int nItems = ( bh >> 2 ) * bw;
 #pragma unroll
-      for( int r = 0; r < 4; r++ ) emit( x, y0 + r, clip3( -32768, 32767, ( sv[r] + ( 1 << ( shift2 - 1 ) ) ) >> shift2 ) );
+    for( int e = 0; e < ITER_E; e++ )
+    {
+      const int i = tid + e * NT;
+      if( i < nItems )
+      {
+        const int yg = i >> lw, x = i & ( bw - 1 ), y0 = yg << 2;
+        int rv[4];
+        if( twoD )
+        {
+          int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+          for( int k = 0; k < redW; k++ )
+          {
+            const int m = mhS[k * bw + x];
+            const int4 t = *reinterpret_cast<const int4*>( &tmp[k * bh + y0] );
+            s0 += t.x * m; s1 += t.y * m; s2 += t.z * m; s3 += t.w * m;
+          }
+          const int sv[4] = { s0, s1, s2, s3 };
+#pragma unroll
+          for( int r = 0; r < 4; r++ ) rv[r] = clip3( -32768, 32767, ( sv[r] + ( 1 << ( shift2 - 1 ) ) ) >> shift2 );
+        }
+        else
+        {
+#pragma unroll
+          for( int r = 0; r < 4; r++ ) rv[r] = isTS ? (int) (int16_t) dq[( y0 + r ) * bw + x] : dcVal;
+        }
+        if( havePred )
+        {
+          pel_t* d = &reco.p[comp][(size_t) ( by + y0 ) * reco.stride[comp] + bx + x];
+#pragma unroll
+          for( int r = 0; r < 4; r++ ) d[(size_t) r * reco.stride[comp]] = (pel_t) clip_pel( predv[e][r] + rv[r], bd );
+        }
+        else
+        {
+#pragma unroll
+          for( int r = 0; r < 4; r++ ) emit( x, y0 + r, rv[r] );
+        }
+      }
     }
     return;
   }
   for( int i = tid; i < n; i += NT )
   {
-    const int y = i / bw, x = i - y * bw;
+    const int y = i >> lw, x = i & ( bw - 1 );
     int r;
     if( isTS ) r = (int16_t) dq[i];
     else if( dcOnly ) r = dcVal;
@@ -3379,9 +3457,17 @@ __global__ __launch_bounds__( 256 ) void k_lf_init( PicDev pic, const LfCell* __
   LfInitView V; V.hdr = &pic.hdr; V.cell = cell; V.cellC = cellC; V.mv = mvs; V.ref = refs; V.ctuSlice = pic.ctuSlice; V.ctuTile = pic.ctuTile;
   V.ctuSubpic = pic.ctuSubpic; V.subpics = pic.subpics; V.slices = pic.slices; V.w4 = pic.w4; V.h4 = pic.h4; V.ctusX = pic.ctus_x;
   static_assert( sizeof( vvr_lfp ) == 8 && sizeof( LfCell ) == 16, "one 8-byte store per table entry, one 16-byte load per cell record" );
-  const uint4 qv = *reinterpret_cast<const uint4*>( &cell[i] );
-  LfCell Q; Q.a = qv.x; Q.b = qv.y; Q.c = qv.z; Q.d = qv.w;
-  const vvr_lfp a = lf_init_cell( V, 0, x4, y4, Q ), b = lf_init_cell( V, 1, x4, y4, Q );
+  // the cell and the cells before it in both directions: three loads in flight together (nine cells in ten need nothing else)
+  // (as one asm statement: written as three loads the compiler moved the third behind the first direction's decisions - where its value is first used)
+  typedef uint32_t u32x4 __attribute__( ( ext_vector_type( 4 ) ) );
+  u32x4 qv, pv0, pv1;
+  {
+    const LfCell* aq = &cell[i]; const LfCell* a0 = &cell[x4 > 0 ? i - 1 : i]; const LfCell* a1 = &cell[y4 > 0 ? i - pic.w4 : i];
+    asm volatile( "global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_dwordx4 %2, %5, off\n\ts_waitcnt vmcnt(0)"
+                  : "=&v"( qv ), "=&v"( pv0 ), "=&v"( pv1 ) : "v"( aq ), "v"( a0 ), "v"( a1 ) : "memory" );
+  }
+  LfCell Q, P0, P1; Q.a = qv.x; Q.b = qv.y; Q.c = qv.z; Q.d = qv.w; P0.a = pv0.x; P0.b = pv0.y; P0.c = pv0.z; P0.d = pv0.w; P1.a = pv1.x; P1.b = pv1.y; P1.c = pv1.z; P1.d = pv1.w;
+  const vvr_lfp a = lf_init_cell( V, 0, x4, y4, Q, P0 ), b = lf_init_cell( V, 1, x4, y4, Q, P1 );
   *reinterpret_cast<uint2*>( &out0[i] ) = *reinterpret_cast<const uint2*>( &a );
   *reinterpret_cast<uint2*>( &out1[i] ) = *reinterpret_cast<const uint2*>( &b );
 }

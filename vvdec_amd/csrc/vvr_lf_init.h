@@ -197,7 +197,9 @@ VVR_HD bool lfi_on_virtual_boundary( const vvr_pic_header& h, int d, int x4, int
 }
 
 // the table entry of cell (x4, y4) for the edges of direction d (0: the cell's left edge, vertical edges; 1: its top edge); Q = the cell's record
-VVR_HD vvr_lfp lf_init_cell( const LfInitView& V, int d, int x4, int y4, const LfCell& Q )
+// (P: the record of the cell on the other side of the edge - the cell before this one in direction d; the device kernel reads it together with Q and the
+// other direction's, before anything is decided: one memory round trip for the three of them.  Not looked at on the picture boundary.)
+VVR_HD vvr_lfp lf_init_cell( const LfInitView& V, int d, int x4, int y4, const LfCell& Q, const LfCell& P )
 {
   vvr_lfp L; L.qp[0] = L.qp[1] = L.qp[2] = 0; L.bs = 0; L.side_max_filt_length = 0; L.flags = 0; L.pad[0] = L.pad[1] = 0;
   const int px4 = d == 0 ? x4 - 1 : x4, py4 = d == 0 ? y4 : y4 - 1;
@@ -205,7 +207,6 @@ VVR_HD vvr_lfp lf_init_cell( const LfInitView& V, int d, int x4, int y4, const L
   const vvr_pic_header& h = *V.hdr;
   const int step = d == 0 ? 1 : V.w4;
   const int iq = y4 * V.w4 + x4, ip = iq - step;
-  const LfCell P = V.cell[ip];
   const int posPerp = ( d == 0 ? x4 : y4 ) << 2;
   // nothing to derive where both cells lie in one transform unit of a CU without sub-block edges and without a chroma tree of its own (a chroma edge inside a luma
   // transform unit needs one): nine cells in ten
@@ -306,6 +307,13 @@ VVR_HD vvr_lfp lf_init_cell( const LfInitView& V, int d, int x4, int y4, const L
   if( te ) L.side_max_filt_length |= 0x80;
   if( bsCb | bsCr ) { L.qp[1] = (int8_t) qpCb; L.qp[2] = (int8_t) qpCr; L.flags |= (uint8_t) ( 2 | ( large ? 0x20 : 0 ) ); }
   return L;
+}
+
+VVR_HD vvr_lfp lf_init_cell( const LfInitView& V, int d, int x4, int y4, const LfCell& Q )
+{
+  const int px4 = d == 0 ? x4 - 1 : x4, py4 = d == 0 ? y4 : y4 - 1;
+  const LfCell P = ( px4 < 0 || py4 < 0 ) ? Q : V.cell[(size_t) py4 * V.w4 + px4];
+  return lf_init_cell( V, d, x4, y4, Q, P );
 }
 
 // ---- the two passes as plain loops (the tests' stand-in runtime, the drop-in's self-check): what k_lf_maps and k_lf_init do with one thread per transform unit / cell

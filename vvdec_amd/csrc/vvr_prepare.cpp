@@ -1244,6 +1244,8 @@ int PrepScratch::buildWorkLists( std::string& err, uint32_t cu0, uint32_t cu1 )
         else if( !( tu.cbf & ( 1 << comp ) ) ) continue;
         const int bw = ( ( it.comp && cu.isp_mode ) ? cu.w : tu.w ) >> ( it.comp ? 1 : 0 ), bh = ( ( it.comp && cu.isp_mode ) ? cu.h : tu.h ) >> ( it.comp ? 1 : 0 );
         if( ( bw < 2 || bh < 2 ) && !( cu.isp_mode && !it.comp && bw * bh >= 16 ) ) FAIL( VVR_ERR_PARAMETER, "1-D transform block outside an ISP CU" );
+        it.pad = (uint8_t) ( ( ( it.comp && cu.isp_mode ) ? TB_P_CUGEOM : 0 ) | ( ( it.comp ? cu.bdpcm[1] : cu.bdpcm[0] ) ? TB_P_BDPCM : 0 )
+                             | ( ( cu.lfnst_idx && ( cu.tree != VVR_TREE_JOINT || it.comp == 0 ) ) ? TB_P_LFNST : 0 ) );
         const int cls = std::max( bw, bh ) <= 16 ? 0 : std::max( bw, bh ) <= 32 ? 1 : 2;
         // LMCS chroma residual scaling of an inter block: the factor needs the reconstructed luma around the VPDU, which the intra stage
         // may still have to produce, so the block's residual is stored and added (scaled) by a residual-add item of the intra stage
