@@ -2651,7 +2651,7 @@ void launch_itrans( hipStream_t s, const PicDev& pic, DevPlanes reco, DevPlanes 
 {
   if( !numItems ) return;
   if( sizeClass <= 16 )      hipLaunchKernelGGL( ( k_itrans<16, 64> ),  dim3( numItems ), dim3( 64 ),  0, s, pic, reco, resi, items, numItems );
-  else if( sizeClass <= 32 ) hipLaunchKernelGGL( ( k_itrans<32, 256> ), dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
+  else if( sizeClass <= 32 ) hipLaunchKernelGGL( ( k_itrans<32, 128> ), dim3( numItems ), dim3( 128 ), 0, s, pic, reco, resi, items, numItems );
   else                       hipLaunchKernelGGL( ( k_itrans<64, 256> ), dim3( numItems ), dim3( 256 ), 0, s, pic, reco, resi, items, numItems );
 }
 
