@@ -285,7 +285,7 @@ static void completeLocked( vvr_context* c, Job& j )
 // What the committer decides about a picture while it holds mu: its lane, the events of the pictures it has to be ordered behind, its
 // reference planes.  The HIP calls themselves (enqueuePicture) run WITHOUT mu: a launch blocks when the device's queues are full, and the
 // worker threads must be able to go on preparing pictures meanwhile.
-struct CommitPlan { int lane; std::vector<hipEvent_t> waits; RefSet refs; std::vector<int> waitInfo; };
+struct CommitPlan { int lane; std::vector<hipEvent_t> waits; RefSet refs; std::vector<int> waitInfo; std::vector<hipEvent_t> outExt /* external events of the output slot this picture waits for */; };
 
 // External events of a slot (vvr_slot_external_event) that the device has passed are dropped: nothing has to wait for them any more, and the caller
 // may destroy an event once it is complete and the back-end has been through vvr_sync (vvr.h).  Called with mu held - by vvr_sync ONLY: hipEventQuery says
@@ -324,8 +324,10 @@ static void planCommitLocked( vvr_context* c, Job& job, CommitPlan& plan )
   auto waitFor = [&]( int id ) { auto it = c->jobs.find( id ); if( it != c->jobs.end() ) { Job& j = *it->second; if( !j.completed && j.state == J_COMMITTED && j.lane != lane ) { plan.waits.push_back( j.done ); plan.waitInfo.push_back( j.q ? ( j.id * 16 + j.q->hdr.slice_type * 4 ) : -1 ); plan.waitInfo.push_back( j.lane ); } } };
   for( int id : c->slotUsers[h.out_slot] ) waitFor( id );
   // external work on our slots (a collective that wrote a reference slot, or still reads the slot we overwrite)
-  for( hipEvent_t ev : c->slotExt[h.out_slot] ) { plan.waits.push_back( ev ); plan.waitInfo.push_back( -2 ); plan.waitInfo.push_back( -1 ); }
-  c->slotExt[h.out_slot].clear();       // (this picture waits for them; whoever uses the slot afterwards waits for this picture)
+  // (this picture waits for them, and whoever uses the slot afterwards waits for this picture: they are dropped when the picture HAS been enqueued - exactly these
+  // handles, the lock is released in between and another may have been registered; a picture that could not be enqueued leaves them where they are)
+  plan.outExt.clear();
+  for( hipEvent_t ev : c->slotExt[h.out_slot] ) { plan.waits.push_back( ev ); plan.waitInfo.push_back( -2 ); plan.waitInfo.push_back( -1 ); plan.outExt.push_back( ev ); }
   memset( &plan.refs, 0, sizeof( plan.refs ) );
   if( h.slice_type != 2 )
     for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ )
@@ -598,7 +600,7 @@ static void commitReady( vvr_context* c )
         {
           const vvr_pic_header& h = j->q->hdr;
           c->slotUsers[h.out_slot].clear(); c->slotUsers[h.out_slot].push_back( j->id );
-          c->slotExt[h.out_slot].clear();          // (whatever happened to the slot outside is ordered before this writer now)
+          { auto& v = c->slotExt[h.out_slot]; for( hipEvent_t ev : plan.outExt ) v.erase( std::remove( v.begin(), v.end(), ev ), v.end() ); }      // (what this writer waited for is ordered before it now)
           if( h.slice_type != 2 ) for( int l = 0; l < 2; l++ ) for( int i = 0; i < h.num_ref[l]; i++ ) c->slotUsers[h.ref_slot[l][i]].push_back( j->id );
           j->state = J_COMMITTED;
         }
@@ -823,6 +825,7 @@ struct WorkerHelpers : HostHelpers
   bool announced = false;               // this worker counts in c->partsComing (it took an I picture and has not published the parts yet)
   WorkerHelpers( vvr_context* c_, PrepScratch*& spare_ ) : c( c_ ), spare( spare_ ) {}
   int width() const override { return c->cfg.host_threads; }
+  void notInParts() override { if( announced ) { std::lock_guard<std::mutex> lk( c->mu ); c->partsComing--; announced = false; c->cv.notify_all(); } }
   void run( int n, PrepScratch& own, const std::function<void( int, PrepScratch& )>& fn ) override
   {
     struct State { std::mutex mu; std::condition_variable cv; int remaining; } st; st.remaining = n - 1;

@@ -85,6 +85,7 @@ struct HostHelpers
   virtual ~HostHelpers() {}
   virtual int  width() const = 0;       // threads that may run parts at the same time (incl. the caller)
   virtual void run( int n, PrepScratch& own, const std::function<void( int, PrepScratch& )>& fn ) = 0;
+  virtual void notInParts() {}          // vvr_host_build has decided to build this picture alone (whoever held others back for its parts lets them go)
 };
 // validateRecords: the CU / TU records are checked on the way (vvr_host_validate_records has not been called); helpers: a picture whose work lists can be
 // built in independent parts (every CU an intra CU: no analysis across CTUs) is - an I picture is what everything of the next GOP waits for

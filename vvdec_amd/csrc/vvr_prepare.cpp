@@ -1947,6 +1947,7 @@ int vvr_host_build( const vvr_picture* p, PrepScratch& S, size_t* totalBytes, st
       return VVR_OK;
     }
   }
+  if( helpers ) helpers->notInParts();      // (e.g. an I picture with intra block copy: the other workers need not wait for parts that will not come)
   if( validateRecords && ( rc = vvr_host_validate_records( vvr_config(), p, err ) ) != VVR_OK ) return rc;
 #ifdef VVR_DEV_ENV
   if( getenv( "VVR_PHASES" ) )
