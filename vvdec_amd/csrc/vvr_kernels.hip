@@ -489,24 +489,12 @@ __device__ __forceinline__ void mc3_issue_luma( Mc3Luma<NT>& R, const pel_t* __r
   const uint32_t sd = (uint32_t) stride >> 1;
   const int last = wh - 1 - ( max( wh - 1 - r0, 0 ) % RP );    // the last row of this lane's residue class: the tail repeats it (same value to the same place), no branch
   const bool tall = wh > 4 * RP;                               // (uniform: a tile of 4 or 8 rows needs at most 15 window rows)
-  // (rows r0 + i RP, i < 4, exist in every window the loader is used for - 11 rows at least - unless the tile has 4 rows and NT is 128: then `last` clamps them;
-  // in a tall window the first four passes need no clamp at all: their offsets are the first one plus multiples of RP rows)
-  const uint32_t oRP = (uint32_t) RP * sd;
 #pragma unroll
-  for( int i = 0; i < NP; i++ ) R.v[i] = 0;
-  if( tall )
+  for( int i = 0; i < NP; i++ )
   {
-    const uint32_t o0 = __umul24( (uint32_t) r0, sd ) + (uint32_t) q;
-    if( q < ndw )
-    {
-#pragma unroll
-      for( int i = 0; i < NP; i++ ) R.v[i] = base[i < 4 ? o0 + (uint32_t) i * oRP : __umul24( (uint32_t) min( r0 + i * RP, last ), sd ) + (uint32_t) q];
-    }
-  }
-  else if( q < ndw )
-  {
-#pragma unroll
-    for( int i = 0; i < 4 && i < NP; i++ ) R.v[i] = base[__umul24( (uint32_t) min( r0 + i * RP, last ), sd ) + (uint32_t) q];
+    const int rr = min( r0 + i * RP, last );
+    R.v[i] = 0;
+    if( ( i < 4 || tall ) && q < ndw ) R.v[i] = base[__umul24( (uint32_t) rr, sd ) + (uint32_t) q];
   }
 }
 template<int NT>
@@ -524,17 +512,8 @@ __device__ __forceinline__ void mc3_commit_luma( const Mc3Luma<NT>& R, pel_t* __
   for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( R.v[i] ), R.v[i], sh );
   if( q < nst )
   {
-    if( tall )
-    {
-      const uint32_t o0 = (uint32_t) r0 * ( MC2_WST_L / 2 ) + (uint32_t) q;
 #pragma unroll
-      for( int i = 0; i < NP; i++ ) wdw[i < 4 ? o0 + (uint32_t) ( i * RP * ( MC2_WST_L / 2 ) ) : __umul24( (uint32_t) min( r0 + i * RP, last ), MC2_WST_L / 2 ) + (uint32_t) q] = w[i];
-    }
-    else
-    {
-#pragma unroll
-      for( int i = 0; i < 4 && i < NP; i++ ) wdw[__umul24( (uint32_t) min( r0 + i * RP, last ), MC2_WST_L / 2 ) + (uint32_t) q] = w[i];
-    }
+    for( int i = 0; i < NP; i++ ) if( i < 4 || tall ) wdw[__umul24( (uint32_t) min( r0 + i * RP, last ), MC2_WST_L / 2 ) + (uint32_t) q] = w[i];
   }
 }
 template<int NT>
@@ -914,7 +893,7 @@ __device__ __forceinline__ void mc2_stage2( Mc2Shared& m, BdofShared* bsp, int n
     {
       // LMCS: luma predictions are stored forward-mapped
 #pragma unroll
-      for( int i = 0; i < 8; i++ ) out[i] = fwdU[(uint32_t) out[i]];      // (a clipped sample: 0 .. 2^bd - 1, inside the table)
+      for( int i = 0; i < 8; i++ ) out[i] = fwdU[(uint32_t) out[i] & 0xfffu];
     }
     const uint32_t st = c ? st1 : st0;
     pel_t* const dstp = c == 0 ? p0 : c == 1 ? p1 : p2;
