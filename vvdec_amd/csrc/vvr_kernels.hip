@@ -509,7 +509,12 @@ __device__ __forceinline__ void mc3_commit_luma( const Mc3Luma<NT>& R, pel_t* __
   const bool tall = wh > 4 * RP;
   uint32_t w[NP];
 #pragma unroll
-  for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( R.v[i] ), R.v[i], sh );
+  for( int i = 0; i < NP; i++ ) w[i] = R.v[i];
+  if( sh )        // (uniform: a window that starts at an even column is stored as it was loaded)
+  {
+#pragma unroll
+    for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( R.v[i] ), R.v[i], 16 );
+  }
   if( q < nst )
   {
 #pragma unroll
@@ -553,7 +558,12 @@ __device__ __forceinline__ void mc3_commit_chroma( const Mc3Chroma<NT>& R, pel_t
   const int last = 2 * wh - 1 - ( max( 2 * wh - 1 - r0, 0 ) % RP );
   uint32_t w[NP];
 #pragma unroll
-  for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( R.v[i] ), R.v[i], sh );
+  for( int i = 0; i < NP; i++ ) w[i] = R.v[i];
+  if( sh )
+  {
+#pragma unroll
+    for( int i = 0; i < NP; i++ ) w[i] = __builtin_amdgcn_alignbit( mc_dpp_next_lane( R.v[i] ), R.v[i], 16 );
+  }
   uint32_t* __restrict__ wdw = reinterpret_cast<uint32_t*>( winCb );
   if( q < nst )
   {

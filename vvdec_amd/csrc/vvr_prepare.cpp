@@ -104,6 +104,7 @@ struct PrepScratch
   size_t intraChunk = (size_t) 1 << 30;      // blocks per unit of a long intra cluster (formUnits); off: measured, no gain
   // union-find / grouping scratch
   std::vector<uint32_t> parent, newIdx, firstOf, perm, inv, unitCount, unitOfItem[3];
+  std::vector<uint64_t> sortKey;
   std::vector<int32_t> unitOfRoot, target;
   std::vector<std::vector<uint32_t>> members, groups;
   // ---- layout of the H2D image
@@ -1300,21 +1301,24 @@ int PrepScratch::formUnits()
     {
       // a picture whose CUs are all intra CUs: the blocks of a (component, CTU) are one unit and already lie together, in coding order - the units
       // are the runs of equal CTU (what the general way below arrives at through union-find, member lists and a sorted copy of the blocks)
-      for( size_t i = 0; i < n; )
-      {
-        UnitH u; u.comp = (uint32_t) k; u.ctu = itemH[k][i].ctu; u.i0 = (uint32_t) i;
-        for( ; i < n && itemH[k][i].ctu == u.ctu; i++ )
-        {
-          const BBox& b = itemH[k][i].bb;
-          u.bb.y0 = std::min( u.bb.y0, b.y0 ); u.bb.y1 = std::max( u.bb.y1, b.y1 ); u.bb.c0 = std::min( u.bb.c0, b.c0 ); u.bb.c1 = std::max( u.bb.c1, b.c1 );
-          if( k && ( intra[k][i].flags & IT_F_CSCALE ) ) u.hasCs = true;
-        }
-        u.i1 = (uint32_t) i; u.iA = u.i0;
-        units.push_back( std::move( u ) );
-      }
+      // (one pass over the blocks: the runs, their bounding boxes and the per-CTU counts - this is the serial tail behind an I picture's parts, on the path the
+      // next GOP waits for)
       uint32_t* cnt = &ctuStartV[(size_t) k * ( numCtu + 1 )];
       std::fill( cnt, cnt + numCtu + 1, 0u );
-      for( auto& ih : itemH[k] ) cnt[ih.ctu + 1]++;
+      const ItemH* IH = itemH[k].data(); const IntraItem* IT = intra[k].data();
+      for( size_t i = 0; i < n; )
+      {
+        UnitH u; u.comp = (uint32_t) k; u.ctu = IH[i].ctu; u.i0 = (uint32_t) i;
+        for( ; i < n && IH[i].ctu == u.ctu; i++ )
+        {
+          const BBox& b = IH[i].bb;
+          u.bb.y0 = std::min( u.bb.y0, b.y0 ); u.bb.y1 = std::max( u.bb.y1, b.y1 ); u.bb.c0 = std::min( u.bb.c0, b.c0 ); u.bb.c1 = std::max( u.bb.c1, b.c1 );
+          if( k && ( IT[i].flags & IT_F_CSCALE ) ) u.hasCs = true;
+        }
+        u.i1 = (uint32_t) i; u.iA = u.i0;
+        cnt[u.ctu + 1] += u.i1 - u.i0;
+        units.push_back( std::move( u ) );
+      }
       for( int a = 0; a < numCtu; a++ ) cnt[a + 1] += cnt[a];
       continue;
     }
@@ -1396,9 +1400,13 @@ int PrepScratch::formUnits()
   }
   // dependencies between units
   {
+    // (a picture whose CUs are all intra CUs collected no producers per block - every CTU is a "fast" one, below: nothing to map, nothing to walk)
+    if( !allIntraCus )
+    {
     for( int k = 0; k < ncomp; k++ ) unitOfItem[k].assign( intra[k].size(), 0 );
     for( size_t u = 0; u < units.size(); u++ ) for( uint32_t i = units[u].i0; i < units[u].i1; i++ ) unitOfItem[units[u].comp][i] = (uint32_t) u;
-    for( size_t u = 0; u < units.size(); u++ )
+    }
+    for( size_t u = 0; !allIntraCus && u < units.size(); u++ )
     {
       UnitH& U = units[u];
       const std::vector<uint32_t>& pool = prodPool[U.comp];
@@ -1574,30 +1582,46 @@ int PrepScratch::emitUnitTable( std::string& err )
   // (ordinary prediction modes and CIIP, luma and chroma) becomes 2, 4 or 8 items, one band of rows each: the kernel predicts an item
   // with one wavefront, the bands of a block with several at once (they read the same reference samples and write disjoint rows, so
   // band p is independent of the p items before it) - a band of 256 samples is one round of four samples per lane
-  itemMap[0].clear(); itemMap[1].clear(); itemMap[2].clear();
+  // (two passes: where every block's items start, then the items - written in place, no growing vector on the serial tail of an I picture's host stage)
+  auto bandsLog2 = [&]( const IntraItem& src, int k )
+  {
+    const int samples = 1 << ( src.lw + src.lh );
+    const bool split = samples > IT_SPLIT_SAMPLES && src.mode <= 66 && ( k || ( !( src.flags & IT_F_MIP ) && ( src.flags & IT_F_ISP ) != IT_F_ISP ) );
+    int lp = 0;
+    if( split ) while( lp < IT_MAX_LPARTS && ( samples >> lp ) > IT_SPLIT_SAMPLES ) lp++;
+    return lp;
+  };
+  {
+    uint32_t at = (uint32_t) intraAll.size();
+    for( int k = 0; k < 3; k++ )
+    {
+      const size_t n = intra[k].size();
+      itemMap[k].resize( n + 1 );
+      uint32_t* im = itemMap[k].data(); const IntraItem* src = intra[k].data();
+      for( size_t bi = 0; bi < n; bi++ ) { im[bi] = at; at += 1u << bandsLog2( src[bi], k ); }
+      im[n] = at;
+    }
+    intraAll.resize( at );
+  }
   for( int k = 0; k < 3; k++ )
   {
-    itemMap[k].reserve( intra[k].size() + 1 );
-    for( size_t bi = 0; bi < intra[k].size(); bi++ )
+    const size_t n = intra[k].size();
+    const uint32_t* im = itemMap[k].data(); const IntraItem* srcs = intra[k].data(); IntraItem* out = intraAll.data();
+    for( size_t bi = 0; bi < n; bi++ )
     {
-      const IntraItem& src = intra[k][bi];
-      itemMap[k].push_back( (uint32_t) intraAll.size() );
+      const IntraItem& src = srcs[bi];
       // the blocks before this one that it does not read from (groupUnits), counted in items
       const uint32_t indepBlocks = std::min<uint32_t>( src.comp >> 2, (uint32_t) bi );
-      const uint32_t indepItems = itemMap[k][bi] - itemMap[k][bi - indepBlocks];
-      const int samples = 1 << ( src.lw + src.lh );
-      const bool split = samples > IT_SPLIT_SAMPLES && src.mode <= 66 && ( k || ( !( src.flags & IT_F_MIP ) && ( src.flags & IT_F_ISP ) != IT_F_ISP ) );
-      int lp = 0;
-      if( split ) while( lp < IT_MAX_LPARTS && ( samples >> lp ) > IT_SPLIT_SAMPLES ) lp++;
+      const uint32_t indepItems = im[bi] - im[bi - indepBlocks];
+      const int lp = ilog2i( (int) ( im[bi + 1] - im[bi] ) );
       for( int part = 0; part < ( 1 << lp ); part++ )
       {
         IntraItem it = src;
         it.nTL = (uint8_t) ( ( src.nTL & 1 ) | ( part << 1 ) | ( lp << 4 ) );
         it.comp = (uint8_t) ( k | ( std::min<uint32_t>( 63, indepItems + part ) << 2 ) );
-        intraAll.push_back( it );
+        out[im[bi] + part] = it;
       }
     }
-    itemMap[k].push_back( (uint32_t) intraAll.size() );
   }
   // device unit table: units that wait for nothing first (they can never block a resident workgroup slot), then the others by depth of the
   // dependency graph and along the CTU wavefront; a unit only ever waits for units that hold a lower ticket
@@ -1611,11 +1635,10 @@ int PrepScratch::emitUnitTable( std::string& err )
       // pictures where depth and wavefront coincide.
       const size_t first = perm.size();
       for( size_t t = 0; t < units.size(); t++ ) if( !units[t].deps.empty() ) perm.push_back( (uint32_t) t );
-      std::stable_sort( perm.begin() + first, perm.end(), [&]( uint32_t a, uint32_t b )
-      {
-        const int ka = (int) ( units[a].ctu % ctusX ) + 2 * (int) ( units[a].ctu / ctusX ), kb = (int) ( units[b].ctu % ctusX ) + 2 * (int) ( units[b].ctu / ctusX );
-        return units[a].rank != units[b].rank ? units[a].rank < units[b].rank : ka < kb;
-      } );
+      // (the key of a unit once, not two divisions per comparison: the sort was the largest single piece of an I picture's serial tail)
+      std::vector<uint64_t>& key = sortKey; key.resize( units.size() );
+      for( size_t t = 0; t < units.size(); t++ ) key[t] = ( (uint64_t) (uint32_t) units[t].rank << 32 ) | (uint32_t) ( (int) ( units[t].ctu % ctusX ) + 2 * (int) ( units[t].ctu / ctusX ) );
+      std::stable_sort( perm.begin() + first, perm.end(), [&]( uint32_t a, uint32_t b ) { return key[a] < key[b]; } );
     }
     // with residual-add blocks in the picture the stage runs in two launches, luma units then chroma units (k_resi_add between them): the luma
     // units take the first tickets; the order inside both parts stays (luma units never wait for chroma units)
