@@ -1569,3 +1569,43 @@ def test_read_picture_lays_the_rows_out_at_the_callers_strides(stub, threads):
         assert stub.vvr_read_picture(ctx, 1, dst, short, threads) == abi.VVR_ERR_PARAMETER
         assert stub.vvr_slot_picture_size(ctx, 1, W + 8, H) == abi.VVR_ERR_PARAMETER
         stub.vvr_destroy(ctx)
+
+
+def test_transform_block_items_say_what_the_kernel_must_know_of_the_cu(stub):
+    """k_itrans asks for the CU record, the coded levels, the basis rows and the prediction samples in ONE memory round trip; what those loads depend on of the CU
+    it reads from the item (TbItem::pad, vvr_device.h): bit 0 - a chroma block of an ISP coding unit takes position and size from the CU; bit 1 - BDPCM (every level of
+    the block is coded); bit 2 - the CU applies LFNST to this component (lfnst_idx > 0, and not the chroma of a single-tree CU).  Every item of an I picture with
+    these tools on, against the records"""
+    TB_DT = np.dtype([("tu", "<u4"), ("comp", "u1"), ("mode", "u1"), ("ict", "u1"), ("pad", "u1")])
+    W, H = 416, 240
+    plans, nslots = stream.ra_plan(1, gop=1, seed_poc0_is_external=False)
+    seen = {1: 0, 2: 0, 4: 0}
+    for seed, kw in ((91, dict(p_isp=0.5, p_lfnst=0.6, p_coded=0.9, p_coded_chroma=0.8)), (92, dict(p_bdpcm=0.5, p_lfnst=0.5, p_coded=0.9, p_coded_chroma=0.8, dual_tree=1.0)), (93, dict(p_isp=0.3, p_bdpcm=0.3, p_lfnst=0.5, p_coded=0.9, p_coded_chroma=0.9))):
+        d = synth.picture_for_plan(plans[0], W, H, seed=seed, tool_flags=TOOLS, log2_ctu=6, **kw)
+        ctx = Ctx(stub, W, H, max(nslots, 2), log2_ctu=6)
+        h = ctx.prepare(d)
+        stub.vvt_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        n_items = 0
+        for which in (4, 5, 6):
+            p, n = C.c_void_p(), C.c_size_t()
+            assert stub.vvt_table(h, which, C.byref(p), C.byref(n)) == 0
+            items = np.frombuffer(C.string_at(p.value, n.value), TB_DT) if n.value else np.zeros(0, TB_DT)
+            for it in items:
+                tu = d.tu[int(it["tu"])]
+                cu = d.cu[int(tu["cu"])]
+                comp = int(it["comp"])
+                want = 0
+                if comp and int(cu["isp_mode"]):
+                    want |= 1
+                if int(cu["bdpcm"][1 if comp else 0]):
+                    want |= 2
+                if int(cu["lfnst_idx"]) and (int(cu["tree"]) != abi.TREE_JOINT or comp == 0):
+                    want |= 4
+                assert int(it["pad"]) == want, (seed, which, int(it["tu"]), comp, int(it["pad"]), want)
+                for b in (1, 2, 4):
+                    seen[b] += 1 if want & b else 0
+                n_items += 1
+        assert n_items > 100
+        stub.vvr_free_prepared(ctx.ctx, h)
+        ctx.close()
+    assert seen[1] and seen[2] and seen[4], seen        # (chroma blocks of ISP coding units, BDPCM blocks and LFNST blocks were among them)
