@@ -149,3 +149,40 @@ def test_luma_edges_of_one_direction_are_independent(built):
                     assert not (e0 + r0[1] - 1 >= e1 - r1[2] or e1 - r1[0] <= e0 + r0[3] - 1), (pl.poc, dr, e0, e1)
                     ordered += 1
     assert ordered > 1000       # (pairs of neighbouring edges looked at)
+
+
+def test_no_kernel_spills_and_the_resident_tile_counts_hold():
+    """what round 6 relies on, read off the compiler (no GPU): no kernel of the library uses scratch memory (a spilled register or a record indexed per lane is a memory
+    round trip on the critical path of every wavefront), and the kernels whose launches are meant to be resident at once keep the registers and the LDS for it -
+    eight wavefronts per SIMD for the deblocking tiles, the DMVR sub-blocks, the affine tiles, the <= 32 transform classes and the edge-parameter cells; 20.5 KB of LDS
+    at most for the horizontal deblocking tile and the affine tile (eight workgroups of four wavefronts per compute unit), 10 KB for a DMVR sub-block (sixteen)"""
+    import os, re, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vvdec_amd", "csrc")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-scalarize-global-loads=false", "-w", "-c", "--cuda-device-only", "-x", "hip",
+                          "vvr_kernels.hip", "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], cwd=src, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, name = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1); kernels[name] = {}
+        for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occ", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and name:
+                kernels[name][key] = int(m.group(1))
+    assert len(kernels) >= 25, sorted(kernels)
+    spilled = {k: v["scratch"] for k, v in kernels.items() if v.get("scratch")}
+    assert not spilled, spilled
+
+    def one(prefix):
+        ks = [k for k in kernels if prefix in k]
+        assert ks, prefix
+        return [kernels[k] for k in ks]
+    for prefix in ("k_deblock_tile", "k_mc_dmvr", "k_mc_affine", "k_itransILi16", "k_lf_init"):
+        for r in one(prefix):
+            assert r["occ"] == 8 and r["vgpr"] <= 64, (prefix, r)
+    assert one("k_itransILi32")[0]["vgpr"] <= 64
+    assert one("k_deblock_tileILb0ELi1")[0]["lds"] <= 20480 and one("k_mc_affine")[0]["lds"] <= 20480 and one("k_mc_dmvr")[0]["lds"] <= 10240
